@@ -1,0 +1,233 @@
+/*
+ * sgv3d_hip.h — C ABI of libsgv3d_hip.so, the MI355X (gfx950) kernels behind the SGV3D / BEVHeight
+ * camera->BEV forward path.
+ *
+ * Plain C: pointers are DEVICE pointers unless marked "host"; sizes are ints / size_t; `stream` is a
+ * hipStream_t passed as void* (NULL = the null stream).  No torch types.  Every entry point only
+ * ENQUEUES work on `stream` (no allocation, no synchronisation, graph-capturable) and returns
+ * 0 on success or a negative SGV3D_E* code; sgv3d_last_error() gives the message for the calling
+ * thread.  Nothing is retained between calls: all buffers, including workspaces, are owned by the
+ * caller.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the reference repo).
+ */
+#ifndef SGV3D_HIP_H
+#define SGV3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGV3D_OK 0
+#define SGV3D_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported shape) */
+#define SGV3D_ELAUNCH (-2)  /* hipLaunchKernel / hipMemsetAsync reported an error                 */
+#define SGV3D_ENOSPACE (-3) /* workspace too small                                               */
+
+const char *sgv3d_last_error(void);
+/* ABI version, bumped on any signature change. */
+int sgv3d_abi_version(void);
+
+/* ================================================================================================
+ * Voxel pooling ("splat")
+ * ================================================================================================ */
+
+/* Drop-in for voxel_pooling_forward_wrapper + voxel_pooling_forward_kernel_launcher
+ *   ops/voxel_pooling/src/voxel_pooling_forward.cpp:26-39, ops/voxel_pooling/src/voxel_pooling_forward_cuda.cu:9-56
+ * Same argument order and meaning:
+ *   geom_xyz        int32 [B, N, 3]   voxel index (x, y, z) per frustum point
+ *   input_features  f32   [B, N, C]
+ *   output_features f32   [B, Y, X, C] pre-zeroed by the caller, accumulated in place (float atomics,
+ *                                      order-nondeterministic like the reference)
+ *   pos_memo        int32 [B, N, 3]   pre-filled with -1 by the caller; (b, y, x) written for kept
+ *                                      points; may be NULL (inference)
+ * A launch failure is reported through the return code instead of exit(-1) (..cuda.cu:51-55). */
+int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
+                                int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                const int32_t *geom_xyz, const float *input_features,
+                                float *output_features, int32_t *pos_memo, void *stream);
+
+/* Deterministic, atomic-free formulation of the same operator: a CSR "plan" (voxel -> ascending list
+ * of point ids) is built from geom_xyz, then every output row is gathered, reduced in registers and
+ * written exactly once (empty voxels are written as zeros: no pre-zeroing needed).  The plan only
+ * depends on geom_xyz (i.e. on the camera calibration) and can be reused across calls.
+ *
+ * Plan workspace layout (bytes from sgv3d_voxel_plan_bytes, 256-B aligned by the caller):
+ *   int32 seg_start[B*Y*X + 1] | int32 cursor[B*Y*X] | int32 order[B*N] | int32 scan scratch      */
+size_t sgv3d_voxel_plan_bytes(int batch_size, int num_points, int num_voxel_x, int num_voxel_y);
+
+/* Build the plan.  pos_memo as above (may be NULL).  sort_segments != 0 makes every voxel's point
+ * list ascending (bitwise-reproducible sums); 0 leaves the arrival order of the fill pass. */
+int sgv3d_voxel_plan_build(int batch_size, int num_points,
+                           int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                           const int32_t *geom_xyz, int32_t *pos_memo,
+                           void *plan, size_t plan_bytes, int sort_segments, void *stream);
+
+/* output_features f32 [B, Y, X, C], fully overwritten.  Replaces the same reference kernel
+ * (voxel_pooling_forward_cuda.cu:9-36) when the caller holds a plan. */
+int sgv3d_voxel_pooling_forward_planned(int batch_size, int num_points, int num_channels,
+                                        int num_voxel_x, int num_voxel_y,
+                                        const void *plan, const float *input_features,
+                                        float *output_features, void *stream);
+
+/* Fused lift-splat (optional fast path beyond the operator boundary):
+ *   out[b, y, x, :] = sum over plan points p=(d, pixel) of prob[b, d, pixel] * context[b, pixel, :]
+ * without materialising the [B, N, C] lifted tensor of layers/backbones/lss_fpn.py:462-466,486.
+ *   prob    f32 [B, D, P]  (softmax over D already applied), P = fH*fW, N = D*P, p = d*P + pixel
+ *   context f32 [B, P, C]  channel-last */
+int sgv3d_lift_splat_planned(int batch_size, int num_depth, int num_pixels, int num_channels,
+                             int num_voxel_x, int num_voxel_y, const void *plan,
+                             const float *prob, const float *context,
+                             float *output_features, void *stream);
+
+/* VoxelPooling.backward  ops/voxel_pooling/voxel_pooling.py:58-69
+ *   grad_output f32 [B, C, Y, X] with element strides (sb, sc, sy, sx)  (the autograd grad is a
+ *   permuted view in the reference; strides let both NCHW-contiguous and NHWC-backed grads in)
+ *   grad_input  f32 [B, N, C] fully written: grad_output[b, :, y, x] for kept points, 0 otherwise. */
+int sgv3d_voxel_pooling_backward(int batch_size, int num_points, int num_channels,
+                                 const int32_t *pos_memo, const float *grad_output,
+                                 long long sb, long long sc, long long sy, long long sx,
+                                 float *grad_input, void *stream);
+
+/* ================================================================================================
+ * Geometry (frustum -> voxel indices)
+ * ================================================================================================ */
+
+/* Per-camera 4x4 preparation of LSSFPN.get_geometry / height2localtion
+ *   layers/backbones/lss_fpn.py:361 (sensor2virtual @ inverse(intrin)), :367 (sensor2ego @
+ *   inverse(sensor2virtual)), :390 (inverse(ida)).
+ * Inputs f32 [num_cams, 4, 4] each; prep f32 [num_cams, 3, 4, 4] = (ida_inv, combine_virtual,
+ * combine_ego).  Fixed-order float32 arithmetic (see oracle/geometry_ref.py::inv4 / mm4). */
+int sgv3d_calib_prep(int num_cams, const float *sensor2ego, const float *sensor2virtual,
+                     const float *intrin, const float *ida, float *prep, void *stream);
+
+/* Per-point pass of get_geometry + the quantise expression
+ *   layers/backbones/lss_fpn.py:350-401 and :487-488.
+ *   frustum   f32 [D, fH, fW, 4]            (the registered buffer, lss_fpn.py:293)
+ *   prep      f32 [num_cams, 3, 4, 4]       from sgv3d_calib_prep (or the caller's own 4x4 products)
+ *   ref_h     f32 [num_cams]                mats_dict['reference_heights']
+ *   bda       f32 [num_cams / cams_per_batch, 4, 4] or NULL (lss_fpn.py:394-400)
+ *   voxel_coord, voxel_size  host float[3]  (buffers lss_fpn.py:281-288)
+ *   geom_xyz  int32 [num_cams, D, fH, fW, 3]   float->int32: truncate, saturate, NaN -> 0
+ *   geom_f    f32   [num_cams, D, fH, fW, 3] or NULL (the un-quantised ego-frame points) */
+int sgv3d_geometry_voxel_index(int num_cams, int cams_per_batch, int num_depth, int feat_h, int feat_w,
+                               const float *frustum, const float *prep, const float *ref_h,
+                               const float *bda, const float *voxel_coord /*host*/,
+                               const float *voxel_size /*host*/, int32_t *geom_xyz, float *geom_f,
+                               void *stream);
+
+/* ================================================================================================
+ * Lift (softmax over height bins  (x)  context)
+ * ================================================================================================ */
+
+/* layers/backbones/lss_fpn.py:462-466 + the permute/contiguous of :486,:490.
+ *   height_context f32 [B, P, D + C] channel-last HeightNet output (height logits first)
+ *   prob    f32 [B, D, P] or NULL   softmax(height logits) (kept for the fused path / training)
+ *   lifted  f32 [B, D, P, C] or NULL  = prob[b,d,p] * context[b,p,c]  (== [B,1,D,fH,fW,C] contiguous) */
+int sgv3d_lift(int batch_size, int num_pixels, int num_depth, int num_channels,
+               const float *height_context, float *prob, float *lifted, void *stream);
+
+/* ================================================================================================
+ * Convolution family (MFMA implicit GEMM, fp32 in / fp32 accumulate, NHWC activations)
+ * ================================================================================================ */
+
+/* Replaces the cuDNN/cuBLAS convolutions PyTorch dispatches for every nn.Conv2d /
+ * nn.ConvTranspose2d of the path (mmdet ResNet, mmdet3d SECONDFPN, HeightNet, CenterHead:
+ * layers/backbones/lss_fpn.py:18-250,296-301, layers/heads/bev_height_head.py:75-110).
+ *
+ * y[n, oh, ow, co_off + co] = act( scale[co] * sum_{kh,kw,ci} x[n, ih, iw, ci_off + ci] * w[co, kh, kw, ci]
+ *                                  + bias[co] + residual[n, oh, ow, co] ) * gate[n, co]
+ * with ih = oh*stride - pad + kh*dil (zero outside).  Weights are pre-packed by
+ * sgv3d_conv_pack_weight into [cout_pad][k_pad] rows, k = (kh*KW + kw)*cin + ci.
+ *
+ * mode SGV3D_CONV_DECONV: ConvTranspose2d with kernel == stride (SECONDFPN deblocks): the GEMM has
+ * cout*ks*ks columns ordered (dy, dx, co) and column (dy,dx,co) of input pixel (ih,iw) is stored at
+ * output pixel (ih*ks+dy, iw*ks+dx), channel co. */
+typedef struct sgv3d_conv_desc {
+    int batch, in_h, in_w, cin;      /* input  [batch, in_h, in_w, x_ld] (x_ld >= cin_off + cin)        */
+    int out_h, out_w, cout;          /* output [batch, out_h, out_w, y_ld]                              */
+    int kh, kw, stride, pad, dil;
+    int x_ld, x_coff;                /* input channel stride per pixel and first channel                */
+    int y_ld, y_coff;                /* output channel stride per pixel and first channel (concat)      */
+    int res_ld;                      /* residual channel stride per pixel (0 if no residual)            */
+    int relu;                        /* 1: max(.,0) after bias/residual                                 */
+    int mode;                        /* SGV3D_CONV_NORMAL / _DECONV / _NCHW_OUT                         */
+    int deconv_ks;                   /* kernel == stride of the transposed conv (mode DECONV)           */
+    int k_pad, cout_pad;             /* packed-weight geometry (from sgv3d_conv_pack_geometry)          */
+    int tile;                        /* 0 = heuristic, else SGV3D_TILE_*                                */
+    int x_nchw;                      /* 1: x is NCHW [batch, cin, in_h, in_w] (image stem only)         */
+} sgv3d_conv_desc;
+
+#define SGV3D_CONV_NORMAL 0
+#define SGV3D_CONV_DECONV 1
+#define SGV3D_CONV_NCHW_OUT 2   /* y is [batch, y_ld, out_h, out_w] planes (final head maps)        */
+
+#define SGV3D_TILE_128x128 1
+#define SGV3D_TILE_128x64 2
+#define SGV3D_TILE_64x128 3
+#define SGV3D_TILE_64x64 4
+
+/* Packed weight geometry for a GEMM with `k` reduction elements and `n` output columns. */
+void sgv3d_conv_pack_geometry(int k, int n, int *k_pad, int *n_pad);
+
+/* Repack an OIHW (nn.Conv2d.weight, [cout, cin, kh, kw]) tensor into the kernel's [cout_pad][k_pad]
+ * layout (k = (kh*KW+kw)*cin_pad + ci).  `transposed` != 0: the source is an nn.ConvTranspose2d.weight
+ * [cin, cout, ks, ks] and the packed rows are (dy, dx, co). cin_pad >= cin pads channels with zeros. */
+int sgv3d_conv_pack_weight(const float *w_src, int cout, int cin, int kh, int kw, int cin_pad,
+                           int transposed, float *w_packed, int k_pad, int cout_pad, void *stream);
+
+/* scale/bias f32 [cout] (NULL = 1 / 0), residual NHWC f32 or NULL, gate f32 [batch, cout] or NULL. */
+int sgv3d_conv2d_forward(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *w_packed,
+                         const float *scale, const float *bias, const float *residual,
+                         const float *gate, float *y, void *stream);
+
+/* ================================================================================================
+ * Small layers around the convolutions (all NHWC f32)
+ * ================================================================================================ */
+
+/* nn.MaxPool2d(kernel 3, stride 2, pad 1) of the mmdet ResNet stem (lss_fpn.py:296). */
+int sgv3d_maxpool3x3s2(int batch, int in_h, int in_w, int channels, const float *x, float *y,
+                       void *stream);
+
+/* NCHW f32 [B, C, H, W] -> NHWC [B, H, W, c_pad] with zero-padded channels (image ingest). */
+int sgv3d_nchw_to_nhwc(int batch, int channels, int h, int w, int c_pad, const float *x, float *y,
+                       void *stream);
+/* NHWC [B, H, W, ld] channels [coff, coff+C) -> NCHW [B, C, H, W] (outputs handed back to torch). */
+int sgv3d_nhwc_to_nchw(int batch, int channels, int h, int w, int ld, int coff, const float *x,
+                       float *y, void *stream);
+
+/* nn.AdaptiveAvgPool2d((1,1)) : NHWC [B, H*W, C] -> [B, C]  (ASPP.global_avg_pool, lss_fpn.py:81-86). */
+int sgv3d_global_avgpool(int batch, int pixels, int channels, int x_ld, const float *x, float *y,
+                         void *stream);
+
+/* y[b, :] = act(scale * (W @ x[b, :]) + bias): small dense layer on [B, K] vectors (Mlp fc1/fc2,
+ * SELayer 1x1 convs on [B,C,1,1], ASPP pooled branch; lss_fpn.py:122-159).  W f32 [N, K] row-major.
+ * act: 0 none, 1 relu, 2 sigmoid. */
+int sgv3d_dense(int batch, int k, int n, const float *x, const float *w, const float *scale,
+                const float *bias, int act, float *y, void *stream);
+
+/* y[b, p, coff + c] = v[b, c] for every pixel p (F.interpolate of a 1x1 map, lss_fpn.py:101-104). */
+int sgv3d_broadcast_channels(int batch, int pixels, int channels, int y_ld, int y_coff,
+                             const float *v, float *y, void *stream);
+
+/* Deformable 3x3 sampling of mmcv DeformConv2dPack (DCNv1, deform_groups=1, stride 1, pad 1, dil 1;
+ * lss_fpn.py:190-198): col[b, p, g, tap, cg] = bilinear(x[b, :, :, g*cpg + cg], p + tap + offset).
+ *   x      f32 [B, H, W, C] NHWC;  offset f32 [B, H, W, off_ld] with (dy, dx) of tap t at 2t, 2t+1
+ *   col    f32 [B, H*W, groups, 9, C/groups] */
+int sgv3d_deform_im2col3x3(int batch, int h, int w, int channels, int groups, const float *x,
+                           const float *offset, int off_ld, float *col, void *stream);
+
+/* CenterHead second-layer convs fused over all branches (mmdet3d SeparateHead final conv, 3x3,
+ * 64 -> c_k, bias; bev_height_head.py:110): hidden f32 NHWC [B, H, W, nb*hc] (branch-major), weights
+ * f32 [sum_c][3][3][hc], bias f32 [sum_c]; branch_of_out int32 [sum_c] maps an output channel to
+ * its branch.  out f32 NCHW [B, sum_c, H, W]. */
+int sgv3d_head_final_conv(int batch, int h, int w, int num_branches, int hidden_ch, int total_out,
+                          const float *hidden, const float *weight, const float *bias,
+                          const int32_t *branch_of_out, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGV3D_HIP_H */

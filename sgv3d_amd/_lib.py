@@ -1,0 +1,94 @@
+"""ctypes binding of libsgv3d_hip.so (the C ABI declared in include/sgv3d_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails this module
+raises.  PyTorch is only used by callers for device memory and streams; every compute call here
+takes raw device pointers (``tensor.data_ptr()``) and the current HIP stream handle.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsgv3d_hip.so")
+
+c_int, c_void_p, c_size_t, c_ll = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_longlong
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``sgv3d_conv_desc`` (include/sgv3d_hip.h)."""
+    _fields_ = [(n, c_int) for n in (
+        "batch", "in_h", "in_w", "cin", "out_h", "out_w", "cout", "kh", "kw", "stride", "pad", "dil",
+        "x_ld", "x_coff", "y_ld", "y_coff", "res_ld", "relu", "mode", "deconv_ks", "k_pad", "cout_pad",
+        "tile", "x_nchw")]
+
+
+CONV_NORMAL, CONV_DECONV, CONV_NCHW_OUT = 0, 1, 2
+TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64 = 0, 1, 2, 3, 4
+
+# name -> (restype, argtypes); must list every symbol include/sgv3d_hip.h declares
+_PROTOS = {
+    "sgv3d_last_error": (ctypes.c_char_p, []),
+    "sgv3d_abi_version": (c_int, []),
+    "sgv3d_voxel_pooling_forward": (c_int, [c_int] * 6 + [c_void_p] * 5),
+    "sgv3d_voxel_plan_bytes": (c_size_t, [c_int] * 4),
+    "sgv3d_voxel_plan_build": (c_int, [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "sgv3d_voxel_pooling_forward_planned": (c_int, [c_int] * 5 + [c_void_p] * 4),
+    "sgv3d_lift_splat_planned": (c_int, [c_int] * 6 + [c_void_p] * 5),
+    "sgv3d_voxel_pooling_backward": (c_int, [c_int] * 3 + [c_void_p, c_void_p, c_ll, c_ll, c_ll, c_ll, c_void_p, c_void_p]),
+    "sgv3d_calib_prep": (c_int, [c_int] + [c_void_p] * 6),
+    "sgv3d_geometry_voxel_index": (c_int, [c_int] * 5 + [c_void_p] * 4 + [ctypes.POINTER(ctypes.c_float)] * 2 + [c_void_p] * 3),
+    "sgv3d_lift": (c_int, [c_int] * 4 + [c_void_p] * 4),
+    "sgv3d_conv_pack_geometry": (None, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "sgv3d_conv_pack_weight": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_int, c_int, c_void_p]),
+    "sgv3d_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8),
+    "sgv3d_maxpool3x3s2": (c_int, [c_int] * 4 + [c_void_p] * 3),
+    "sgv3d_nchw_to_nhwc": (c_int, [c_int] * 5 + [c_void_p] * 3),
+    "sgv3d_nhwc_to_nchw": (c_int, [c_int] * 6 + [c_void_p] * 3),
+    "sgv3d_global_avgpool": (c_int, [c_int] * 4 + [c_void_p] * 3),
+    "sgv3d_dense": (c_int, [c_int] * 3 + [c_void_p] * 4 + [c_int, c_void_p, c_void_p]),
+    "sgv3d_broadcast_channels": (c_int, [c_int] * 5 + [c_void_p] * 3),
+    "sgv3d_deform_im2col3x3": (c_int, [c_int] * 5 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "sgv3d_head_final_conv": (c_int, [c_int] * 6 + [c_void_p] * 6),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+class SGV3DError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SGV3DError(
+                f"{LIB_PATH} is missing: build it with `make -C sgv3d_amd/csrc` (or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().sgv3d_last_error()
+        raise SGV3DError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def stream_handle(device=None):
+    """Current HIP stream of torch as an integer handle (0 = null stream)."""
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor or None."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,330 @@
+// Small layers around the convolutions (all NHWC fp32, all HBM/latency-bound, no MFMA).
+// Reference call sites are cited per kernel; paths relative to the reference repo.
+#include "common.hpp"
+
+using namespace sgv3d;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// nn.MaxPool2d(3, stride 2, pad 1) of the mmdet ResNet stem (built at layers/backbones/lss_fpn.py:296)
+__global__ __launch_bounds__(kBlock) void maxpool3x3s2_kernel(int B, int H, int W, int C4, int OH, int OW,
+                                                              const float4 *__restrict__ x, float4 *__restrict__ y) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long total = (long long)B * OH * OW * C4;
+    if (i >= total) return;
+    const int c = (int)(i % C4);
+    long long t = i / C4;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int ih = oh * 2 - 1 + dy;
+        if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int iw = ow * 2 - 1 + dx;
+            if ((unsigned)iw >= (unsigned)W) continue;
+            const float4 v = x[((long long)(b * H + ih) * W + iw) * C4 + c];
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    y[i] = m;
+}
+
+// image ingest: NCHW -> NHWC with zero-padded channels (the harness hands [B,1,1,3,H,W], exps/...:246)
+__global__ __launch_bounds__(kBlock) void nchw_to_nhwc_kernel(int B, int C, long long HW, int Cp,
+                                                              const float *__restrict__ x, float *__restrict__ y) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;  // one pixel per thread
+    if (i >= (long long)B * HW) return;
+    const long long b = i / HW, p = i - b * HW;
+    const float *src = x + b * C * HW + p;
+    float *dst = y + i * Cp;
+    for (int c = 0; c < Cp; ++c) dst[c] = c < C ? src[(long long)c * HW] : 0.f;
+}
+
+// NHWC channel slice -> NCHW through a 32x32 LDS transpose (coalesced on both sides)
+__global__ __launch_bounds__(kBlock) void nhwc_to_nchw_kernel(int C, long long HW, int ld, int coff,
+                                                              const float *__restrict__ x, float *__restrict__ y) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const long long p0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const long long p = p0 + r;
+        const int c = c0 + tx;
+        tile[r][tx] = (p < HW && c < C) ? x[((long long)b * HW + p) * ld + coff + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r;
+        const long long p = p0 + tx;
+        if (c < C && p < HW) y[((long long)b * C + c) * HW + p] = tile[tx][r];
+    }
+}
+
+// nn.AdaptiveAvgPool2d((1,1))  (ASPP.global_avg_pool, layers/backbones/lss_fpn.py:81-86)
+__global__ __launch_bounds__(kBlock) void global_avgpool_kernel(int P, int C, int ld, const float *__restrict__ x,
+                                                                float *__restrict__ y) {
+    __shared__ float part[4][64];
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (int p = g; p < P; p += 4) s += x[((long long)b * P + p) * ld + c];
+    part[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && c < C) y[(long long)b * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / (float)P;
+}
+
+// y[b,n] = act(scale[n] * dot(W[n,:], x[b,:]) + bias[n]) : one wave per output
+// (Mlp fc1/fc2, SELayer conv_reduce/conv_expand on [B,C,1,1], ASPP pooled 1x1; lss_fpn.py:122-159,81-86)
+__global__ __launch_bounds__(kBlock) void dense_kernel(int B, int K, int N, const float *__restrict__ x,
+                                                       const float *__restrict__ w, const float *__restrict__ scale,
+                                                       const float *__restrict__ bias, int act, float *__restrict__ y) {
+    const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave >= B * N) return;
+    const int b = wave / N, n = wave - b * N;
+    const float *xr = x + (long long)b * K;
+    const float *wr = w + (long long)n * K;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += wr[k] * xr[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+        float v = s * (scale ? scale[n] : 1.f) + (bias ? bias[n] : 0.f);
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = 1.f / (1.f + expf(-v));
+        y[(long long)b * N + n] = v;
+    }
+}
+
+// F.interpolate of a 1x1 map to HxW (bilinear, align_corners) == broadcast  (lss_fpn.py:101-104)
+__global__ __launch_bounds__(kBlock) void broadcast_channels_kernel(long long total, int P, int C, int ld, int coff,
+                                                                    const float *__restrict__ v, float *__restrict__ y) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const long long bp = i / C;
+    const long long b = bp / P;
+    y[bp * ld + coff + c] = v[b * C + c];
+}
+
+// mmcv DeformConv2dPack sampling (DCNv1: deformable_im2col + bilinear with zero padding;
+// configured at lss_fpn.py:190-198: 3x3, pad 1, stride 1, dil 1, deform_groups 1)
+__global__ __launch_bounds__(kBlock) void deform_im2col3x3_kernel(int B, int H, int W, int C, int groups,
+                                                                  const float *__restrict__ x,
+                                                                  const float *__restrict__ off, int off_ld,
+                                                                  float *__restrict__ col) {
+    const int C4 = C >> 2;
+    const long long total = (long long)B * H * W * 9 * C4;
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int tap = (int)(t % 9);
+    t /= 9;  // pixel index b*H*W + h*W + w
+    const int w_ = (int)(t % W);
+    const long long t2 = t / W;
+    const int h_ = (int)(t2 % H);
+    const int b = (int)(t2 / H);
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const float oy = off[t * off_ld + 2 * tap], ox = off[t * off_ld + 2 * tap + 1];
+    const float hf = (float)(h_ - 1 + ky) + oy;
+    const float wf = (float)(w_ - 1 + kx) + ox;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hf > -1.f && wf > -1.f && hf < (float)H && wf < (float)W) {
+        const int h_low = (int)floorf(hf), w_low = (int)floorf(wf);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = hf - (float)h_low, lw = wf - (float)w_low;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float *base = x + (long long)b * H * W * C + c4 * 4;
+        const float4 v1 = (h_low >= 0 && w_low >= 0) ? *reinterpret_cast<const float4 *>(base + ((long long)h_low * W + w_low) * C) : z;
+        const float4 v2 = (h_low >= 0 && w_high <= W - 1) ? *reinterpret_cast<const float4 *>(base + ((long long)h_low * W + w_high) * C) : z;
+        const float4 v3 = (h_high <= H - 1 && w_low >= 0) ? *reinterpret_cast<const float4 *>(base + ((long long)h_high * W + w_low) * C) : z;
+        const float4 v4 = (h_high <= H - 1 && w_high <= W - 1) ? *reinterpret_cast<const float4 *>(base + ((long long)h_high * W + w_high) * C) : z;
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        val.x = w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+        val.y = w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+        val.z = w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+        val.w = w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+    }
+    const int cpg = C / groups;
+    const int c = c4 * 4;
+    const int g = c / cpg, cg = c - g * cpg;
+    *reinterpret_cast<float4 *>(col + ((t * groups + g) * 9 + tap) * cpg + cg) = val;
+}
+
+// CenterHead second-layer 3x3 convs of all branches in one launch (mmdet3d SeparateHead final conv,
+// reached through layers/heads/bev_height_head.py:110).  Output widths are 1..3 channels per branch,
+// far below an MFMA tile, and fp32 MFMA runs at the fp32 VALU rate anyway => VALU kernel.
+// Workgroup = 16x16 output pixels of one branch; the (18x18) halo patch of the branch's hidden
+// channels is staged in LDS 32 channels at a time (rows padded to 36 floats: conflict-free b128
+// reads), the branch's weights sit in LDS and are read as broadcasts.
+constexpr int kHfTile = 16;
+constexpr int kHfPatch = kHfTile + 2;
+constexpr int kHfLd = 36;
+constexpr int kHfMaxOut = 4;
+
+__global__ __launch_bounds__(kBlock) void head_final_conv_kernel(int H, int W, int nb, int hc, int total_out,
+                                                                 const float *__restrict__ hidden,
+                                                                 const float *__restrict__ weight,
+                                                                 const float *__restrict__ bias,
+                                                                 const int32_t *__restrict__ branch_of_out,
+                                                                 float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *patch = smem;                                    // [18*18][36]
+    float *wts = smem + kHfPatch * kHfPatch * kHfLd;        // [ck][9][hc]
+    // branch bookkeeping lives in the dynamic region too (a static __shared__ in front of it would
+    // shift its base off 16-B alignment)
+    int *meta = reinterpret_cast<int *>(wts + kHfMaxOut * 9 * hc);
+    const int br = blockIdx.z % nb, b = blockIdx.z / nb;
+    const int tiles_x = (W + kHfTile - 1) / kHfTile;
+    const int ty0 = (blockIdx.x / tiles_x) * kHfTile, tx0 = (blockIdx.x % tiles_x) * kHfTile;
+    if (threadIdx.x == 0) {
+        int first = -1, ck = 0;
+        for (int o = 0; o < total_out; ++o)
+            if (branch_of_out[o] == br) { if (first < 0) first = o; ++ck; }
+        meta[0] = first;
+        meta[1] = ck < kHfMaxOut ? ck : kHfMaxOut;
+    }
+    __syncthreads();
+    const int first = meta[0], ck = meta[1];
+    if (ck == 0) return;
+    for (int i = threadIdx.x; i < ck * 9 * hc; i += kBlock) wts[i] = weight[(long long)first * 9 * hc + i];
+    const int px = threadIdx.x & 15, py = threadIdx.x >> 4;
+    const int ld = nb * hc;
+    float acc[kHfMaxOut] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < hc; c0 += 32) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < kHfPatch * kHfPatch * 8; i += kBlock) {
+            const int pp = i >> 3, q = i & 7;
+            const int yy = ty0 - 1 + pp / kHfPatch, xx = tx0 - 1 + pp % kHfPatch;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                v = *reinterpret_cast<const float4 *>(hidden + ((long long)(b * H + yy) * W + xx) * ld + br * hc + c0 + q * 4);
+            *reinterpret_cast<float4 *>(patch + pp * kHfLd + q * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float *pr = patch + ((py + tap / 3) * kHfPatch + px + tap % 3) * kHfLd;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(pr + q * 4);
+#pragma unroll
+                for (int o = 0; o < kHfMaxOut; ++o) {
+                    if (o < ck) {
+                        const float4 wv = *reinterpret_cast<const float4 *>(wts + (o * 9 + tap) * hc + c0 + q * 4);
+                        acc[o] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+                    }
+                }
+            }
+        }
+    }
+    const int y = ty0 + py, x = tx0 + px;
+    if (y < H && x < W) {
+        for (int o = 0; o < kHfMaxOut; ++o)
+            if (o < ck) out[((long long)(b * total_out + first + o) * H + y) * W + x] = acc[o] + bias[first + o];
+    }
+}
+
+}  // namespace
+
+extern "C" int sgv3d_maxpool3x3s2(int batch, int in_h, int in_w, int channels, const float *x, float *y, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && in_h > 0 && in_w > 0 && channels > 0 && (channels & 3) == 0, "maxpool3x3s2: bad shape");
+    SGV3D_REQUIRE(x && y, "maxpool3x3s2: null pointer");
+    const int oh = (in_h - 1) / 2 + 1, ow = (in_w - 1) / 2 + 1;
+    const long long total = (long long)batch * oh * ow * (channels / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, as_stream(stream), batch, in_h,
+                       in_w, channels / 4, oh, ow, reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y));
+    return check_launch("maxpool3x3s2_kernel");
+}
+
+extern "C" int sgv3d_nchw_to_nhwc(int batch, int channels, int h, int w, int c_pad, const float *x, float *y, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && channels > 0 && h > 0 && w > 0 && c_pad >= channels, "nchw_to_nhwc: bad shape");
+    SGV3D_REQUIRE(x && y, "nchw_to_nhwc: null pointer");
+    const long long hw = (long long)h * w;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(batch * hw, kBlock)), dim3(kBlock), 0, as_stream(stream), batch,
+                       channels, hw, c_pad, x, y);
+    return check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int sgv3d_nhwc_to_nchw(int batch, int channels, int h, int w, int ld, int coff, const float *x, float *y,
+                                  void *stream) {
+    SGV3D_REQUIRE(batch > 0 && channels > 0 && h > 0 && w > 0 && ld >= coff + channels && coff >= 0, "nhwc_to_nchw: bad shape");
+    SGV3D_REQUIRE(x && y, "nhwc_to_nchw: null pointer");
+    const long long hw = (long long)h * w;
+    dim3 grid(cdiv(hw, 32), cdiv(channels, 32), batch);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(kBlock), 0, as_stream(stream), channels, hw, ld, coff, x, y);
+    return check_launch("nhwc_to_nchw_kernel");
+}
+
+extern "C" int sgv3d_global_avgpool(int batch, int pixels, int channels, int x_ld, const float *x, float *y, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && pixels > 0 && channels > 0 && x_ld >= channels, "global_avgpool: bad shape");
+    SGV3D_REQUIRE(x && y, "global_avgpool: null pointer");
+    hipLaunchKernelGGL(global_avgpool_kernel, dim3(cdiv(channels, 64), batch), dim3(kBlock), 0, as_stream(stream), pixels,
+                       channels, x_ld, x, y);
+    return check_launch("global_avgpool_kernel");
+}
+
+extern "C" int sgv3d_dense(int batch, int k, int n, const float *x, const float *w, const float *scale,
+                           const float *bias, int act, float *y, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && k > 0 && n > 0 && act >= 0 && act <= 2, "dense: bad shape/act");
+    SGV3D_REQUIRE(x && w && y, "dense: null pointer");
+    hipLaunchKernelGGL(dense_kernel, dim3(cdiv((long long)batch * n, kBlock / 64)), dim3(kBlock), 0, as_stream(stream),
+                       batch, k, n, x, w, scale, bias, act, y);
+    return check_launch("dense_kernel");
+}
+
+extern "C" int sgv3d_broadcast_channels(int batch, int pixels, int channels, int y_ld, int y_coff, const float *v,
+                                        float *y, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && pixels > 0 && channels > 0 && y_ld >= y_coff + channels && y_coff >= 0, "broadcast_channels: bad shape");
+    SGV3D_REQUIRE(v && y, "broadcast_channels: null pointer");
+    const long long total = (long long)batch * pixels * channels;
+    hipLaunchKernelGGL(broadcast_channels_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, as_stream(stream), total,
+                       pixels, channels, y_ld, y_coff, v, y);
+    return check_launch("broadcast_channels_kernel");
+}
+
+extern "C" int sgv3d_deform_im2col3x3(int batch, int h, int w, int channels, int groups, const float *x,
+                                      const float *offset, int off_ld, float *col, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && h > 0 && w > 0 && channels > 0 && groups > 0 && channels % groups == 0 &&
+                      ((channels / groups) & 3) == 0 && off_ld >= 18,
+                  "deform_im2col3x3: bad shape");
+    SGV3D_REQUIRE(x && offset && col, "deform_im2col3x3: null pointer");
+    const long long total = (long long)batch * h * w * 9 * (channels / 4);
+    hipLaunchKernelGGL(deform_im2col3x3_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, as_stream(stream), batch, h, w,
+                       channels, groups, x, offset, off_ld, col);
+    return check_launch("deform_im2col3x3_kernel");
+}
+
+extern "C" int sgv3d_head_final_conv(int batch, int h, int w, int num_branches, int hidden_ch, int total_out,
+                                     const float *hidden, const float *weight, const float *bias,
+                                     const int32_t *branch_of_out, float *out, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && h > 0 && w > 0 && num_branches > 0 && hidden_ch > 0 && hidden_ch % 32 == 0 && total_out > 0,
+                  "head_final_conv: bad shape");
+    SGV3D_REQUIRE(hidden && weight && bias && branch_of_out && out, "head_final_conv: null pointer");
+    const size_t lds = sizeof(float) * ((size_t)kHfPatch * kHfPatch * kHfLd + (size_t)kHfMaxOut * 9 * hidden_ch + 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&head_final_conv_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+            return fail(SGV3D_ELAUNCH, "head_final_conv: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    SGV3D_REQUIRE(lds <= 96 * 1024, "head_final_conv: hidden_ch too large");
+    const int tiles = cdiv(h, kHfTile) * cdiv(w, kHfTile);
+    dim3 grid(tiles, 1, batch * num_branches);
+    hipLaunchKernelGGL(head_final_conv_kernel, grid, dim3(kBlock), lds, as_stream(stream), h, w, num_branches, hidden_ch,
+                       total_out, hidden, weight, bias, branch_of_out, out);
+    return check_launch("head_final_conv_kernel");
+}

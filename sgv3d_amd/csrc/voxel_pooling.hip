@@ -1,0 +1,500 @@
+// Voxel pooling ("splat") for gfx950 — the operator of ops/voxel_pooling (reference:
+// ops/voxel_pooling/src/voxel_pooling_forward_cuda.cu:9-36, ops/voxel_pooling/voxel_pooling.py:10-69).
+//
+// Three formulations, all HBM-bound indexing work (no contraction => no MFMA):
+//   1. vp_atomic_kernel      reference-faithful scatter with float atomics.  One lane per (point,
+//                            channel) so every atomic wave-instruction covers contiguous 256-B row
+//                            segments (the shape the memory-side atomic units run at full rate);
+//                            rows of dropped points are never read.
+//   2. plan build + vp_gather_kernel   deterministic CSR formulation: count -> scan -> fill ->
+//                            per-segment sort, then every output row is gathered with 16-B loads,
+//                            reduced in registers by 64/LPR row groups per wave and written once.
+//   3. vp_lift_splat_kernel  the same gather with rows formed on the fly as prob * context
+//                            (never materialises the [B,N,C] lifted tensor).
+#include "common.hpp"
+
+using namespace sgv3d;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------------
+// shared index helper: (x, y, z) -> flat voxel id or -1   (bounds test of ..cuda.cu:24)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int voxel_of_point(const int32_t *__restrict__ geom, long long pt, int b,
+                                              int X, int Y, int Z, int &x, int &y) {
+    x = geom[pt * 3 + 0];
+    y = geom[pt * 3 + 1];
+    const int z = geom[pt * 3 + 2];
+    if (x < 0 || x >= X || y < 0 || y >= Y || z < 0 || z >= Z) return -1;
+    return (b * Y + y) * X + x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. atomic scatter
+// ------------------------------------------------------------------------------------------------
+constexpr int kAtomicPts = 64;  // points per workgroup
+
+__global__ __launch_bounds__(kBlock) void vp_atomic_kernel(
+    long long total_pts, int N, int C, int X, int Y, int Z, const int32_t *__restrict__ geom,
+    const float *__restrict__ feats, float *__restrict__ out, int32_t *__restrict__ pos_memo) {
+    __shared__ int vid_s[kAtomicPts];
+    const int tid = threadIdx.x;
+    const long long p0 = (long long)blockIdx.x * kAtomicPts;
+    if (tid < kAtomicPts) {
+        const long long pt = p0 + tid;
+        int v = -1;
+        if (pt < total_pts) {
+            const int b = (int)(pt / N);
+            int x, y;
+            v = voxel_of_point(geom, pt, b, X, Y, Z, x, y);
+            if (v >= 0 && pos_memo) {
+                pos_memo[pt * 3 + 0] = b;
+                pos_memo[pt * 3 + 1] = y;
+                pos_memo[pt * 3 + 2] = x;
+            }
+        }
+        vid_s[tid] = v;
+    }
+    __syncthreads();
+    const int nelem = kAtomicPts * C;
+    const float *f = feats + (size_t)p0 * C;
+    for (int e = tid; e < nelem; e += kBlock) {
+        const int pl = e / C;
+        const int c = e - pl * C;
+        const int v = vid_s[pl];
+        if (v >= 0) {
+            // no-return hardware float atomic (global_atomic_add_f32), agent scope
+            __hip_atomic_fetch_add(out + (size_t)v * C + c, f[e], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. plan (CSR) build
+// ------------------------------------------------------------------------------------------------
+constexpr int kScanPerThread = 8;
+constexpr int kScanElems = kBlock * kScanPerThread;  // 2048 counters per workgroup
+
+struct PlanLayout {
+    long long V;        // B*Y*X
+    long long total;    // B*N
+    int nblk;           // scan workgroups
+    size_t off_seg, off_cur, off_order, off_blk, bytes;
+};
+
+PlanLayout plan_layout(int B, int N, int X, int Y) {
+    PlanLayout L;
+    L.V = (long long)B * Y * X;
+    L.total = (long long)B * N;
+    L.nblk = cdiv(L.V, kScanElems);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    L.off_seg = 0;
+    L.off_cur = al(L.off_seg + sizeof(int) * (size_t)(L.V + 1));
+    L.off_order = al(L.off_cur + sizeof(int) * (size_t)(L.V + 1));
+    L.off_blk = al(L.off_order + sizeof(int) * (size_t)L.total);
+    L.bytes = al(L.off_blk + sizeof(int) * (size_t)(L.nblk + 2));
+    return L;
+}
+
+__global__ __launch_bounds__(kBlock) void vp_count_kernel(long long total_pts, int N, int X, int Y, int Z,
+                                                          const int32_t *__restrict__ geom,
+                                                          int32_t *__restrict__ pos_memo,
+                                                          int *__restrict__ count) {
+    const long long pt = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (pt >= total_pts) return;
+    const int b = (int)(pt / N);
+    int x, y;
+    const int v = voxel_of_point(geom, pt, b, X, Y, Z, x, y);
+    if (v < 0) return;
+    if (pos_memo) {
+        pos_memo[pt * 3 + 0] = b;
+        pos_memo[pt * 3 + 1] = y;
+        pos_memo[pt * 3 + 2] = x;
+    }
+    atomicAdd(count + v, 1);
+}
+
+// exclusive scan of one int per thread across a 256-thread workgroup; returns the exclusive prefix
+// and leaves the workgroup total in *total_out (same value for every thread).
+__device__ __forceinline__ int block_exclusive_scan(int v, int *wave_tot /*LDS[4]*/, int &total_out) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) wave_tot[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        const int t = wave_tot[w];
+        if (w < wid) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    total_out = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kBlock) void vp_scan_local_kernel(long long V, const int *__restrict__ count,
+                                                               int *__restrict__ seg_start,
+                                                               int *__restrict__ blk_sum) {
+    __shared__ int wave_tot[kBlock / 64];
+    const long long base = (long long)blockIdx.x * kScanElems + (long long)threadIdx.x * kScanPerThread;
+    int v[kScanPerThread];
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) {
+        v[i] = (base + i < V) ? count[base + i] : 0;
+        sum += v[i];
+    }
+    int tot;
+    int run = block_exclusive_scan(sum, wave_tot, tot);
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) {
+        if (base + i < V) seg_start[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == 0) blk_sum[blockIdx.x] = tot;
+}
+
+// one workgroup: exclusive scan of blk_sum[0..nblk) in place; blk_sum[nblk] = grand total
+__global__ __launch_bounds__(kBlock) void vp_scan_top_kernel(int nblk, int *__restrict__ blk_sum) {
+    __shared__ int wave_tot[kBlock / 64];
+    int carry = 0;
+    for (int c0 = 0; c0 < nblk; c0 += kBlock) {
+        const int i = c0 + threadIdx.x;
+        const int v = (i < nblk) ? blk_sum[i] : 0;
+        int tot;
+        const int ex = block_exclusive_scan(v, wave_tot, tot);
+        if (i < nblk) blk_sum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) blk_sum[nblk] = carry;
+}
+
+__global__ __launch_bounds__(kBlock) void vp_scan_add_kernel(long long V, int nblk,
+                                                             const int *__restrict__ blk_sum,
+                                                             int *__restrict__ seg_start,
+                                                             int *__restrict__ cursor) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i < V) {
+        const int s = seg_start[i] + blk_sum[i / kScanElems];
+        seg_start[i] = s;
+        cursor[i] = s;
+    } else if (i == V) {
+        seg_start[V] = blk_sum[nblk];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void vp_fill_kernel(long long total_pts, int N, int X, int Y, int Z,
+                                                         const int32_t *__restrict__ geom,
+                                                         int *__restrict__ cursor,
+                                                         int *__restrict__ order) {
+    const long long pt = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (pt >= total_pts) return;
+    const int b = (int)(pt / N);
+    int x, y;
+    const int v = voxel_of_point(geom, pt, b, X, Y, Z, x, y);
+    if (v < 0) return;
+    const int slot = atomicAdd(cursor + v, 1);
+    order[slot] = (int)pt;
+}
+
+// Ascending sort of every segment whose length is in (lo, hi]: normalised bitonic network (all
+// comparators ascending, virtual +inf padding => works for any length), data staged in LDS when it
+// fits, otherwise sorted in place in global memory by the one workgroup that owns the segment.
+template <int T, int LDS_CAP>
+__global__ __launch_bounds__(T) void vp_sort_segments_kernel(long long V, const int *__restrict__ seg_start,
+                                                             int *__restrict__ order, int lo, int hi) {
+    __shared__ int buf[LDS_CAP];
+    const int tid = threadIdx.x;
+    for (long long v = blockIdx.x; v < V; v += gridDim.x) {
+        const int s = seg_start[v];
+        const int n = seg_start[v + 1] - s;
+        if (n <= lo || n > hi) continue;  // uniform per workgroup
+        int *data = order + s;
+        const bool in_lds = n <= LDS_CAP;
+        if (in_lds) {
+            for (int i = tid; i < n; i += T) buf[i] = data[i];
+        }
+        __syncthreads();
+        int *d = in_lds ? buf : data;
+        int half = 1;  // npow2 / 2
+        while (half * 2 < n) half <<= 1;
+        for (int k = 2; (k >> 1) < n; k <<= 1) {
+            const int hk = k >> 1;
+            for (int i = tid; i < half; i += T) {  // flip stage: i <-> k-1-i inside each k block
+                const int blk = i / hk, off = i - blk * hk;
+                const int a = blk * k + off, b = blk * k + k - 1 - off;
+                if (b < n) {
+                    const int va = d[a], vb = d[b];
+                    if (va > vb) { d[a] = vb; d[b] = va; }
+                }
+            }
+            __syncthreads();
+            for (int j = k >> 2; j > 0; j >>= 1) {  // half cleaners
+                for (int i = tid; i < half; i += T) {
+                    const int a = 2 * j * (i / j) + (i % j), b = a + j;
+                    if (b < n) {
+                        const int va = d[a], vb = d[b];
+                        if (va > vb) { d[a] = vb; d[b] = va; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (in_lds) {
+            for (int i = tid; i < n; i += T) data[i] = buf[i];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2b/3. gather + register reduce.  One wave owns kVoxPerWave consecutive output rows; its 64 lanes
+// form G = 64/LPR row groups of LPR lanes (LPR = lanes per row: C/4 float4 lanes, or C scalar lanes
+// when C % 4 != 0); group g reduces points s+g, s+g+G, ... of the voxel's segment, four rows in
+// flight per group, then the groups are summed through the cross-lane network in fixed order.
+// ------------------------------------------------------------------------------------------------
+constexpr int kVoxPerWave = 4;
+constexpr int kRowsInFlight = 4;
+
+template <int VEC> struct VecT;
+template <> struct VecT<4> { using type = float4; };
+template <> struct VecT<1> { using type = float; };
+
+__device__ __forceinline__ float4 vzero(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float vzero(float) { return 0.f; }
+__device__ __forceinline__ void vacc(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ __forceinline__ void vacc(float &a, const float &b) { a += b; }
+__device__ __forceinline__ void vfma(float4 &a, float s, const float4 &b) {
+    a.x += s * b.x; a.y += s * b.y; a.z += s * b.z; a.w += s * b.w;
+}
+__device__ __forceinline__ void vfma(float &a, float s, const float &b) { a += s * b; }
+__device__ __forceinline__ float4 vshfl(const float4 &a, int src) {
+    return make_float4(__shfl(a.x, src, 64), __shfl(a.y, src, 64), __shfl(a.z, src, 64), __shfl(a.w, src, 64));
+}
+__device__ __forceinline__ float vshfl(const float &a, int src) { return __shfl(a, src, 64); }
+
+template <int VEC, bool FUSED>
+__global__ __launch_bounds__(kBlock) void vp_gather_kernel(
+    long long V, int C, int lpr, int groups, const int *__restrict__ seg_start,
+    const int *__restrict__ order, const float *__restrict__ feats /* !FUSED: [B*N, C] */,
+    const float *__restrict__ prob /* FUSED: [B*N] */, const float *__restrict__ ctx /* FUSED: [B*P, C] */,
+    int N, int P, float *__restrict__ out) {
+    using vec = typename VecT<VEC>::type;
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int g = lane / lpr;
+    const int cl = lane - g * lpr;
+    const bool active = g < groups;
+    const int ncols = C / VEC;
+    const long long v0 = wave * kVoxPerWave;
+    for (int vi = 0; vi < kVoxPerWave; ++vi) {
+        const long long v = v0 + vi;
+        if (v >= V) return;  // wave-uniform
+        const int s = __builtin_amdgcn_readfirstlane(seg_start[v]);
+        const int e = __builtin_amdgcn_readfirstlane(seg_start[v + 1]);
+        for (int cb = 0; cb < ncols; cb += lpr) {  // one pass unless the row is wider than a wave
+            const int col = cb + cl;
+            const bool col_ok = active && col < ncols;
+            vec acc = vzero(vec{});
+            for (int i = s + g; i < e; i += groups * kRowsInFlight) {
+                int idx[kRowsInFlight];
+#pragma unroll
+                for (int u = 0; u < kRowsInFlight; ++u) {
+                    const int ii = i + u * groups;
+                    idx[u] = (col_ok && ii < e) ? order[ii] : -1;
+                }
+                vec val[kRowsInFlight];
+                float pr[kRowsInFlight];
+#pragma unroll
+                for (int u = 0; u < kRowsInFlight; ++u) {
+                    val[u] = vzero(vec{});
+                    pr[u] = 0.f;
+                    if (idx[u] >= 0) {
+                        if constexpr (FUSED) {
+                            const int b = idx[u] / N;
+                            const int pix = (idx[u] - b * N) % P;
+                            pr[u] = prob[idx[u]];
+                            val[u] = *reinterpret_cast<const vec *>(ctx + ((size_t)b * P + pix) * C + (size_t)col * VEC);
+                        } else {
+                            val[u] = *reinterpret_cast<const vec *>(feats + (size_t)idx[u] * C + (size_t)col * VEC);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kRowsInFlight; ++u) {
+                    if constexpr (FUSED) vfma(acc, pr[u], val[u]);
+                    else vacc(acc, val[u]);
+                }
+            }
+            vec tot = acc;
+            for (int gg = 1; gg < groups; ++gg) {  // fixed order: group 0 + group 1 + ...
+                const vec o = vshfl(acc, lane + gg * lpr);
+                vacc(tot, o);
+            }
+            if (g == 0 && col < ncols) *reinterpret_cast<vec *>(out + (size_t)v * C + (size_t)col * VEC) = tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward gather  (voxel_pooling.py:58-69)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void vp_backward_kernel(long long total_elems, int C,
+                                                             const int32_t *__restrict__ pos_memo,
+                                                             const float *__restrict__ grad_out,
+                                                             long long sb, long long sc, long long sy, long long sx,
+                                                             float *__restrict__ grad_in) {
+    const long long idx = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= total_elems) return;
+    const long long pt = idx / C;
+    const int c = (int)(idx - pt * C);
+    const int b = pos_memo[pt * 3 + 0];
+    float g = 0.f;
+    if (b != -1) {
+        const int y = pos_memo[pt * 3 + 1], x = pos_memo[pt * 3 + 2];
+        g = grad_out[b * sb + c * sc + y * sy + x * sx];
+    }
+    grad_in[idx] = g;
+}
+
+int check_common(int B, int N, int C, int X, int Y, int Z) {
+    SGV3D_REQUIRE(B > 0 && N > 0 && C > 0 && X > 0 && Y > 0 && Z > 0,
+                  "voxel_pooling: non-positive size (B=%d N=%d C=%d X=%d Y=%d Z=%d)", B, N, C, X, Y, Z);
+    SGV3D_REQUIRE((long long)B * N < 0x7fffffffLL, "voxel_pooling: B*N=%lld does not fit int32 point ids",
+                  (long long)B * N);
+    SGV3D_REQUIRE((long long)B * Y * X < 0x7fffffffLL, "voxel_pooling: B*Y*X too large");
+    return SGV3D_OK;
+}
+
+template <bool FUSED>
+int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const float *feats,
+                  const float *prob, const float *ctx, int P, float *out, hipStream_t st) {
+    const PlanLayout L = plan_layout(B, N, X, Y);
+    const char *base = static_cast<const char *>(plan);
+    const int *seg = reinterpret_cast<const int *>(base + L.off_seg);
+    const int *order = reinterpret_cast<const int *>(base + L.off_order);
+    const long long waves = (L.V + kVoxPerWave - 1) / kVoxPerWave;
+    const int grid = cdiv(waves, kBlock / 64);
+    if (C % 4 == 0) {
+        const int ncols = C / 4;
+        const int lpr = ncols < 64 ? ncols : 64;
+        const int groups = 64 / lpr;
+        hipLaunchKernelGGL((vp_gather_kernel<4, FUSED>), dim3(grid), dim3(kBlock), 0, st, L.V, C, lpr, groups,
+                           seg, order, feats, prob, ctx, N, P, out);
+    } else {
+        const int lpr = C < 64 ? C : 64;
+        const int groups = 64 / lpr;
+        hipLaunchKernelGGL((vp_gather_kernel<1, FUSED>), dim3(grid), dim3(kBlock), 0, st, L.V, C, lpr, groups,
+                           seg, order, feats, prob, ctx, N, P, out);
+    }
+    return check_launch(FUSED ? "vp_lift_splat_kernel" : "vp_gather_kernel");
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
+                                           int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                           const int32_t *geom_xyz, const float *input_features,
+                                           float *output_features, int32_t *pos_memo, void *stream) {
+    if (int rc = check_common(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, num_voxel_z)) return rc;
+    SGV3D_REQUIRE(geom_xyz && input_features && output_features, "voxel_pooling_forward: null pointer");
+    const long long total = (long long)batch_size * num_points;
+    const int grid = cdiv(total, kAtomicPts);
+    hipLaunchKernelGGL(vp_atomic_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), total, num_points,
+                       num_channels, num_voxel_x, num_voxel_y, num_voxel_z, geom_xyz, input_features,
+                       output_features, pos_memo);
+    return check_launch("vp_atomic_kernel");
+}
+
+extern "C" size_t sgv3d_voxel_plan_bytes(int batch_size, int num_points, int num_voxel_x, int num_voxel_y) {
+    if (batch_size <= 0 || num_points <= 0 || num_voxel_x <= 0 || num_voxel_y <= 0) return 0;
+    return plan_layout(batch_size, num_points, num_voxel_x, num_voxel_y).bytes;
+}
+
+extern "C" int sgv3d_voxel_plan_build(int batch_size, int num_points, int num_voxel_x, int num_voxel_y,
+                                      int num_voxel_z, const int32_t *geom_xyz, int32_t *pos_memo,
+                                      void *plan, size_t plan_bytes, int sort_segments, void *stream) {
+    if (int rc = check_common(batch_size, num_points, 1, num_voxel_x, num_voxel_y, num_voxel_z)) return rc;
+    SGV3D_REQUIRE(geom_xyz && plan, "voxel_plan_build: null pointer");
+    SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0, "voxel_plan_build: plan must be 16-B aligned");
+    const PlanLayout L = plan_layout(batch_size, num_points, num_voxel_x, num_voxel_y);
+    if (plan_bytes < L.bytes)
+        return fail(SGV3D_ENOSPACE, "voxel_plan_build: plan has %zu bytes, needs %zu", plan_bytes, L.bytes);
+    hipStream_t st = as_stream(stream);
+    char *base = static_cast<char *>(plan);
+    int *seg = reinterpret_cast<int *>(base + L.off_seg);
+    int *cur = reinterpret_cast<int *>(base + L.off_cur);
+    int *order = reinterpret_cast<int *>(base + L.off_order);
+    int *blk = reinterpret_cast<int *>(base + L.off_blk);
+    if (hipMemsetAsync(cur, 0, sizeof(int) * (size_t)(L.V + 1), st) != hipSuccess)
+        return fail(SGV3D_ELAUNCH, "voxel_plan_build: hipMemsetAsync failed");
+    const int pgrid = cdiv(L.total, kBlock);
+    hipLaunchKernelGGL(vp_count_kernel, dim3(pgrid), dim3(kBlock), 0, st, L.total, num_points, num_voxel_x,
+                       num_voxel_y, num_voxel_z, geom_xyz, pos_memo, cur);
+    hipLaunchKernelGGL(vp_scan_local_kernel, dim3(L.nblk), dim3(kBlock), 0, st, L.V, cur, seg, blk);
+    hipLaunchKernelGGL(vp_scan_top_kernel, dim3(1), dim3(kBlock), 0, st, L.nblk, blk);
+    hipLaunchKernelGGL(vp_scan_add_kernel, dim3(cdiv(L.V + 1, kBlock)), dim3(kBlock), 0, st, L.V, L.nblk, blk,
+                       seg, cur);
+    hipLaunchKernelGGL(vp_fill_kernel, dim3(pgrid), dim3(kBlock), 0, st, L.total, num_points, num_voxel_x,
+                       num_voxel_y, num_voxel_z, geom_xyz, cur, order);
+    if (sort_segments) {
+        const int g_small = (int)(L.V < 8192 ? L.V : 8192);
+        hipLaunchKernelGGL((vp_sort_segments_kernel<64, 256>), dim3(g_small), dim3(64), 0, st, L.V, seg, order, 1, 256);
+        const int g_large = (int)(L.V < 1024 ? L.V : 1024);
+        hipLaunchKernelGGL((vp_sort_segments_kernel<256, 8192>), dim3(g_large), dim3(256), 0, st, L.V, seg, order,
+                           256, 0x7fffffff);
+    }
+    return check_launch("voxel_plan_build");
+}
+
+extern "C" int sgv3d_voxel_pooling_forward_planned(int batch_size, int num_points, int num_channels,
+                                                   int num_voxel_x, int num_voxel_y, const void *plan,
+                                                   const float *input_features, float *output_features,
+                                                   void *stream) {
+    if (int rc = check_common(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, 1)) return rc;
+    SGV3D_REQUIRE(plan && input_features && output_features, "voxel_pooling_forward_planned: null pointer");
+    SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(input_features) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(output_features) & 15) == 0,
+                  "voxel_pooling_forward_planned: feature buffers must be 16-B aligned");
+    return launch_gather<false>(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, plan,
+                                input_features, nullptr, nullptr, 1, output_features, as_stream(stream));
+}
+
+extern "C" int sgv3d_lift_splat_planned(int batch_size, int num_depth, int num_pixels, int num_channels,
+                                        int num_voxel_x, int num_voxel_y, const void *plan, const float *prob,
+                                        const float *context, float *output_features, void *stream) {
+    SGV3D_REQUIRE(num_depth > 0 && num_pixels > 0, "lift_splat_planned: non-positive size");
+    const long long N = (long long)num_depth * num_pixels;
+    SGV3D_REQUIRE(N < 0x7fffffffLL, "lift_splat_planned: D*P too large");
+    if (int rc = check_common(batch_size, (int)N, num_channels, num_voxel_x, num_voxel_y, 1)) return rc;
+    SGV3D_REQUIRE(plan && prob && context && output_features, "lift_splat_planned: null pointer");
+    SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(context) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(output_features) & 15) == 0,
+                  "lift_splat_planned: context/output must be 16-B aligned");
+    return launch_gather<true>(batch_size, (int)N, num_channels, num_voxel_x, num_voxel_y, plan, nullptr, prob,
+                               context, num_pixels, output_features, as_stream(stream));
+}
+
+extern "C" int sgv3d_voxel_pooling_backward(int batch_size, int num_points, int num_channels,
+                                            const int32_t *pos_memo, const float *grad_output, long long sb,
+                                            long long sc, long long sy, long long sx, float *grad_input,
+                                            void *stream) {
+    SGV3D_REQUIRE(batch_size > 0 && num_points > 0 && num_channels > 0, "voxel_pooling_backward: non-positive size");
+    SGV3D_REQUIRE(pos_memo && grad_output && grad_input, "voxel_pooling_backward: null pointer");
+    const long long total = (long long)batch_size * num_points * num_channels;
+    hipLaunchKernelGGL(vp_backward_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, as_stream(stream), total,
+                       num_channels, pos_memo, grad_output, sb, sc, sy, sx, grad_input);
+    return check_launch("vp_backward_kernel");
+}

@@ -1,0 +1,184 @@
+"""``voxel_pooling(geom_xyz, input_features, voxel_num) -> Tensor[B, C, Y, X]``
+
+Mirror of the reference's autograd operator (ops/voxel_pooling/voxel_pooling.py:10-72): same
+callable, argument meaning, asserts, non-differentiable ``geom_xyz``, permuted-view return and
+``(None, grad_features, None)`` backward.  What is different underneath:
+
+* the kernel is hand-written HIP for gfx950 behind the C ABI (``include/sgv3d_hip.h``);
+* two modes (``set_mode``): ``"planned"`` (default) — deterministic sort-by-voxel + segmented
+  gather-reduce, every output row written once with 16-B stores; ``"atomic"`` — the reference's
+  float-atomic scatter (order-nondeterministic, voxel_pooling_forward_cuda.cu:30-33);
+* the 149 MB ``grad_input_features`` memset and ``pos_memo`` are only produced when a gradient is
+  actually required (the reference allocates both unconditionally, voxel_pooling.py:29,40);
+* ``voxel_num`` is read back from the device at most once per distinct tensor version (the
+  reference indexes a CUDA tensor five times per call, each a device->host sync);
+* backward is one gather kernel (no boolean-mask indexing / nonzero sync, voxel_pooling.py:58-69).
+"""
+import torch
+from torch.autograd import Function
+
+from ... import _lib
+
+_MODE = "planned"
+
+
+def set_mode(mode):
+    """'planned' (deterministic, default) or 'atomic' (reference-faithful float atomics)."""
+    global _MODE
+    if mode not in ("planned", "atomic"):
+        raise ValueError("mode must be 'planned' or 'atomic'")
+    _MODE = mode
+
+
+def get_mode():
+    return _MODE
+
+
+_VOXEL_NUM_CACHE = {}
+
+
+def _voxel_num_ints(voxel_num):
+    """(X, Y, Z) as python ints; a device tensor costs one sync per (storage, version)."""
+    if isinstance(voxel_num, torch.Tensor):
+        if voxel_num.numel() != 3:
+            raise RuntimeError("voxel_num must have 3 elements")
+        if voxel_num.is_cuda:
+            key = (voxel_num.data_ptr(), voxel_num._version, voxel_num.device.index)
+            hit = _VOXEL_NUM_CACHE.get(key)
+            if hit is None:
+                if len(_VOXEL_NUM_CACHE) > 64:
+                    _VOXEL_NUM_CACHE.clear()
+                hit = tuple(int(v) for v in voxel_num.tolist())
+                _VOXEL_NUM_CACHE[key] = hit
+            return hit
+        return tuple(int(v) for v in voxel_num.tolist())
+    x, y, z = voxel_num
+    return int(x), int(y), int(z)
+
+
+def _check_cuda(t, name, dtype):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDAtensor ")          # voxel_pooling_forward.cpp:12-13
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")  # data_ptr<T>() :30-33
+
+
+class VoxelPlan:
+    """CSR plan (voxel -> ascending point ids) for one ``geom_xyz``; reusable while the camera
+    calibration (hence ``geom_xyz``) is unchanged."""
+
+    def __init__(self, geom_xyz, voxel_num, pos_memo=None, sort_segments=True):
+        _check_cuda(geom_xyz, "geom_xyz", torch.int32)
+        assert geom_xyz.is_contiguous()
+        self.X, self.Y, self.Z = _voxel_num_ints(voxel_num)
+        self.B = int(geom_xyz.shape[0])
+        self.N = int(geom_xyz.numel() // (3 * self.B))
+        lib = _lib.load()
+        nbytes = lib.sgv3d_voxel_plan_bytes(self.B, self.N, self.X, self.Y)
+        if nbytes == 0:
+            raise RuntimeError("voxel plan: bad sizes")
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=geom_xyz.device)
+        with torch.cuda.device(geom_xyz.device):
+            rc = lib.sgv3d_voxel_plan_build(self.B, self.N, self.X, self.Y, self.Z, geom_xyz.data_ptr(),
+                                            _lib.ptr(pos_memo), self.buf.data_ptr(), nbytes,
+                                            1 if sort_segments else 0, _lib.stream_handle(geom_xyz.device))
+        _lib.check(rc, "sgv3d_voxel_plan_build")
+
+    def pool(self, input_features, out=None):
+        """input_features f32 [B, N, C] -> [B, Y, X, C] (fully written)."""
+        _check_cuda(input_features, "input_features", torch.float32)
+        assert input_features.is_contiguous()
+        C = int(input_features.shape[-1])
+        assert input_features.numel() == self.B * self.N * C
+        if out is None:
+            out = input_features.new_empty(self.B, self.Y, self.X, C)
+        with torch.cuda.device(input_features.device):
+            rc = _lib.load().sgv3d_voxel_pooling_forward_planned(
+                self.B, self.N, C, self.X, self.Y, self.buf.data_ptr(), input_features.data_ptr(),
+                out.data_ptr(), _lib.stream_handle(input_features.device))
+        _lib.check(rc, "sgv3d_voxel_pooling_forward_planned")
+        return out
+
+    def lift_splat(self, prob, context, out=None):
+        """Fused path: prob f32 [B, D, P], context f32 [B, P, C] -> [B, Y, X, C]."""
+        B, D, P = (int(s) for s in prob.shape)
+        C = int(context.shape[-1])
+        assert B == self.B and D * P == self.N and context.shape[:2] == (B, P)
+        assert prob.is_contiguous() and context.is_contiguous()
+        if out is None:
+            out = context.new_empty(B, self.Y, self.X, C)
+        with torch.cuda.device(context.device):
+            rc = _lib.load().sgv3d_lift_splat_planned(B, D, P, C, self.X, self.Y, self.buf.data_ptr(),
+                                                     prob.data_ptr(), context.data_ptr(), out.data_ptr(),
+                                                     _lib.stream_handle(context.device))
+        _lib.check(rc, "sgv3d_lift_splat_planned")
+        return out
+
+
+class VoxelPooling(Function):
+    @staticmethod
+    def forward(ctx, geom_xyz: torch.Tensor, input_features: torch.Tensor,
+                voxel_num) -> torch.Tensor:
+        """Forward function for `voxel pooling.
+
+        Args:
+            geom_xyz (Tensor): int32 voxel coord of each frustum point, shape [B, ..., 3].
+            input_features (Tensor): float32 feature of each point, shape [B, ..., C].
+            voxel_num (Tensor | sequence): number of voxels per dim (X, Y, Z).
+
+        Returns:
+            Tensor: (B, C, Y, X) bev feature map (a permuted view of an NHWC buffer).
+        """
+        assert geom_xyz.is_contiguous()                      # voxel_pooling.py:25
+        assert input_features.is_contiguous()                # voxel_pooling.py:26
+        _check_cuda(geom_xyz, "geom_xyz", torch.int32)
+        _check_cuda(input_features, "input_features", torch.float32)
+        ctx.mark_non_differentiable(geom_xyz)                # voxel_pooling.py:28
+        features_shape = input_features.shape
+        geom_xyz = geom_xyz.reshape(geom_xyz.shape[0], -1, geom_xyz.shape[-1])
+        input_features = input_features.reshape(geom_xyz.shape[0], -1, input_features.shape[-1])
+        assert geom_xyz.shape[1] == input_features.shape[1]  # voxel_pooling.py:33
+        batch_size, num_points, num_channels = (int(s) for s in input_features.shape)
+        X, Y, Z = _voxel_num_ints(voxel_num)
+        needs_grad = ctx.needs_input_grad[1]
+        pos_memo = None
+        if needs_grad:
+            pos_memo = torch.full((batch_size, num_points, 3), -1, dtype=torch.int32,
+                                  device=geom_xyz.device)   # voxel_pooling.py:40
+        lib = _lib.load()
+        if _MODE == "atomic":
+            output_features = input_features.new_zeros(batch_size, Y, X, num_channels)  # :37-38
+            with torch.cuda.device(input_features.device):
+                rc = lib.sgv3d_voxel_pooling_forward(batch_size, num_points, num_channels, X, Y, Z,
+                                                     geom_xyz.data_ptr(), input_features.data_ptr(),
+                                                     output_features.data_ptr(), _lib.ptr(pos_memo),
+                                                     _lib.stream_handle(input_features.device))
+            _lib.check(rc, "sgv3d_voxel_pooling_forward")
+        else:
+            plan = VoxelPlan(geom_xyz, (X, Y, Z), pos_memo=pos_memo)
+            output_features = plan.pool(input_features)
+        if needs_grad:
+            ctx.save_for_backward(pos_memo)
+            ctx.features_shape = features_shape
+        return output_features.permute(0, 3, 1, 2)           # voxel_pooling.py:55
+
+    @staticmethod
+    def backward(ctx, grad_output_features):
+        (pos_memo,) = ctx.saved_tensors
+        shape = ctx.features_shape
+        B, N = int(pos_memo.shape[0]), int(pos_memo.shape[1])
+        C = int(shape[-1])
+        g = grad_output_features
+        if g.dtype != torch.float32:
+            g = g.float()
+        grad_input = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
+        sb, sc, sy, sx = (int(s) for s in g.stride())
+        with torch.cuda.device(g.device):
+            rc = _lib.load().sgv3d_voxel_pooling_backward(B, N, C, pos_memo.data_ptr(), g.data_ptr(),
+                                                         sb, sc, sy, sx, grad_input.data_ptr(),
+                                                         _lib.stream_handle(g.device))
+        _lib.check(rc, "sgv3d_voxel_pooling_backward")
+        return None, grad_input.reshape(shape), None         # voxel_pooling.py:69
+
+
+voxel_pooling = VoxelPooling.apply

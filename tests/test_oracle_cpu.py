@@ -1,0 +1,122 @@
+"""CPU: the oracle against the golden vectors captured from the reference (tests/golden/*.npz)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import geometry_ref as G
+from oracle import lift_ref, voxel_pooling_ref as VP
+
+FR_CFGS = ["r50_864x1536_s16_d90", "bsm_864x1536_s8_d180", "rope_864x1536_s16_d90",
+           "cfg3_1088x1920_s16_d90", "small_80x112_s16_d6"]
+CALIBS = ["dair_p11_h5.5", "p5_h8_yaw3", "p20_h4_roll2", "p14_h6.3_yaw-7_roll-1"]
+BOUNDS256 = ([0, 102.4, 0.4], [-51.2, 51.2, 0.4], [-5, 3, 8])
+BOUNDS128 = ([0, 102.4, 0.8], [-51.2, 51.2, 0.8], [-5, 3, 8])
+
+
+def _frustum_from_cfg(cfg):
+    return G.create_frustum((int(cfg[0]), int(cfg[1])), int(cfg[2]), [cfg[3], cfg[4], int(cfg[5])])
+
+
+@pytest.mark.parametrize("name", FR_CFGS)
+def test_frustum_bit_exact(golden, name):
+    fr = golden["frustum"]
+    f = _frustum_from_cfg(fr[name + "/cfg"])
+    assert list(f.shape) == list(fr[name + "/shape"])
+    assert np.array_equal(f[0, 0, :, 0], fr[name + "/xs"])
+    assert np.array_equal(f[0, :, 0, 1], fr[name + "/ys"])
+    assert np.array_equal(f[:, 0, 0, 2], fr[name + "/ds"])
+    assert hashlib.sha256(f.tobytes()).digest() == fr[name + "/sha256"].tobytes()
+
+
+def test_voxel_params():
+    for bounds, n in ((BOUNDS256, 256), (BOUNDS128, 128)):
+        vs, vc, vn = G.voxel_params(*bounds)
+        assert list(vn) == [n, n, 1]
+    vs, vc, vn = G.voxel_params([0, 140.8, 0.4], [-51.2, 51.2, 0.4], [-5, 3, 8])
+    assert list(vn) == [352, 256, 1]
+
+
+def _calib(geo, n):
+    return {k: geo[f"{n}/{k}"] for k in ("sensor2ego", "sensor2virtual", "intrin", "ida", "bda")}, geo[f"{n}/reference_height"]
+
+
+@pytest.mark.parametrize("name", CALIBS + ["nan_ray_small"])
+def test_geometry_small_bit_exact_with_reference_prep(golden, name):
+    """Per-point pass fed with the reference's own 4x4 products: float bits and indices identical."""
+    geo = golden["geometry"]
+    c, rh = _calib(geo, name)
+    vs, vc, _ = G.voxel_params(*BOUNDS256)
+    small = G.create_frustum((80, 112), 16, [-2.0, 0.0, 6])
+    pts = G.geometry_points(small, geo[f"{name}/ref_ida_inv"], geo[f"{name}/ref_combine_virtual"],
+                            geo[f"{name}/ref_combine_ego"], rh, c["bda"])
+    ref = geo[f"{name}/small/geom"]
+    same = (pts.view(np.int32) == ref.view(np.int32)) | (np.isnan(pts) & np.isnan(ref))
+    assert same.all()
+    assert np.array_equal(G.quantise(pts, vc, vs), geo[f"{name}/small/geom_xyz"])
+
+
+def test_nan_ray_goes_to_voxel_zero(golden):
+    """GPU cast semantics: NaN -> 0, +-inf saturate."""
+    geo = golden["geometry"]
+    g = geo["nan_ray_small/small/geom"]
+    gi = geo["nan_ray_small/small/geom_xyz"]
+    assert np.isnan(g).any()
+    assert (gi[np.isnan(g)] == 0).all()
+    inf = np.isinf(g)
+    if inf.any():
+        assert set(np.unique(gi[inf])) <= {np.int32(2147483647), np.int32(-2147483648)}
+    assert np.array_equal(G.cvt_i32_gpu(np.array([np.nan, np.inf, -np.inf, 3e9, -3e9, -0.7, 0.7, 5.9], np.float32)),
+                          np.array([0, 2147483647, -2147483648, 2147483647, -2147483648, 0, 0, 5], np.int32))
+
+
+@pytest.mark.parametrize("name", CALIBS)
+@pytest.mark.parametrize("tag,bounds", [("full256", BOUNDS256), ("full128", BOUNDS128)])
+def test_geometry_full_size_hash(golden, name, tag, bounds):
+    """Whole pipeline incl. the build's own 4x4 inverse at cfg-2 size (466 560 points): the int32
+    index tensor hashes to the reference's."""
+    geo = golden["geometry"]
+    c, rh = _calib(geo, name)
+    vs, vc, vn = G.voxel_params(*bounds)
+    full = G.create_frustum((864, 1536), 16, [-2.0, 0.0, 90])
+    gi, _ = G.geom_xyz_for_camera(full, c["sensor2ego"], c["sensor2virtual"], c["intrin"], c["ida"], rh,
+                                  c["bda"], vc, vs)
+    assert np.array_equal(gi[::7, ::5, ::9], geo[f"{name}/{tag}/geom_xyz_sample"])
+    assert hashlib.sha256(gi.tobytes()).digest() == geo[f"{name}/{tag}/geom_xyz_sha256"].tobytes()
+    inr = ((gi[..., 0] >= 0) & (gi[..., 0] < vn[0]) & (gi[..., 1] >= 0) & (gi[..., 1] < vn[1]) &
+           (gi[..., 2] >= 0) & (gi[..., 2] < vn[2]))
+    stats = geo[f"{name}/{tag}/stats"]
+    assert abs(inr.mean() - stats[0]) < 1e-12
+
+
+def test_cfg2_multiplicity_invariant(golden):
+    """74.3 % in range, 21 672 voxels hit, mean 16.0, max 246."""
+    s = golden["geometry"]["dair_p11_h5.5/full256/stats"]
+    assert abs(s[0] - 0.7432) < 1e-3 and int(s[1]) == 21672 and abs(s[2] - 16.0) < 0.01 and int(s[3]) == 246
+
+
+VP_CASES = ["tiny", "b2_c80", "z2", "dups", "all_out"]
+
+
+@pytest.mark.parametrize("name", VP_CASES)
+@pytest.mark.parametrize("threads", [1, 3])
+def test_voxel_pooling_oracle_matches_reference(golden, name, threads):
+    vp = golden["voxel_pooling"]
+    out, pm = VP.forward(vp[f"{name}/geom_xyz"], vp[f"{name}/feats"], vp[f"{name}/voxel_num"], threads=threads)
+    assert np.array_equal(out, vp[f"{name}/out"])
+    gi = VP.backward(pm, vp[f"{name}/grad_out"], vp[f"{name}/feats"].shape[-1])
+    assert np.array_equal(gi.reshape(vp[f"{name}/grad_feats"].shape), vp[f"{name}/grad_feats"])
+
+
+def test_voxel_pooling_oracle_randn(golden):
+    vp = golden["voxel_pooling"]
+    out, _ = VP.forward(vp["b2_c80_randn/geom_xyz"], vp["b2_c80_randn/feats"], vp["b2_c80_randn/voxel_num"])
+    np.testing.assert_allclose(out, vp["b2_c80_randn/out"], rtol=1e-6, atol=1e-6)
+
+
+def test_lift_oracle(golden):
+    lf = golden["lift"]
+    B, D, C, fH, fW = lf["dims"]
+    prob, lifted = lift_ref.lift(lf["height_feature"], D, C)
+    np.testing.assert_allclose(lifted, lf["lifted"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(prob.sum(1), 1.0, atol=1e-6)
