@@ -1,0 +1,224 @@
+"""Thin host-side wrappers over the C ABI for the convolution family and the small layers.
+
+Tensors here are torch CUDA tensors used purely as device buffers: activations are NHWC float32
+``[B, H, W, C]`` (channel-last, the layout the gfx950 kernels want), every call enqueues on torch's
+current stream.  No arithmetic happens in PyTorch on this path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, CONV_NORMAL, CONV_DECONV, CONV_NCHW_OUT  # noqa: F401
+
+
+def _st(t):
+    return _lib.stream_handle(t.device)
+
+
+def pack_geometry(k, n):
+    kp, np_ = ctypes.c_int(), ctypes.c_int()
+    _lib.load().sgv3d_conv_pack_geometry(int(k), int(n), ctypes.byref(kp), ctypes.byref(np_))
+    return kp.value, np_.value
+
+
+def fold_bn(bn, conv_bias=None):
+    """Eval-mode BatchNorm folded to per-channel (scale, shift):  y = scale * conv + shift."""
+    with torch.no_grad():
+        inv = torch.rsqrt(bn.running_var.float() + bn.eps)
+        gamma = bn.weight.float() if bn.weight is not None else torch.ones_like(inv)
+        beta = bn.bias.float() if bn.bias is not None else torch.zeros_like(inv)
+        scale = gamma * inv
+        shift = beta - bn.running_mean.float() * scale
+        if conv_bias is not None:
+            shift = shift + conv_bias.float() * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+class PackedConv:
+    """One convolution (or kernel==stride transposed convolution) with its weights repacked for the
+    MFMA implicit-GEMM kernel and BN / bias folded into a per-channel scale & shift."""
+
+    def __init__(self, weight, *, stride=1, pad=0, dil=1, scale=None, shift=None, relu=False,
+                 transposed=False, cin_pad=None, device=None, tile=0):
+        w = weight.detach()
+        device = device or w.device
+        w = w.to(device=device, dtype=torch.float32).contiguous()
+        if transposed:
+            cin, cout, kh, kw = (int(s) for s in w.shape)
+            assert kh == kw == stride, "only kernel == stride transposed convs (SECONDFPN deblocks)"
+            self.ks = kh
+            self.kh = self.kw = 1
+            self.stride, self.pad, self.dil = 1, 0, 1
+            gemm_n = cout * kh * kw
+        else:
+            cout, cin, kh, kw = (int(s) for s in w.shape)
+            self.ks = 0
+            self.kh, self.kw = kh, kw
+            self.stride, self.pad, self.dil = int(stride), int(pad), int(dil)
+            gemm_n = cout
+        self.transposed = bool(transposed)
+        self.cin = int(cin_pad) if cin_pad else cin
+        assert self.cin >= cin and self.cin % 4 == 0, f"cin={cin} must be padded to a multiple of 4"
+        self.cout = cout
+        self.relu = bool(relu)
+        self.tile = int(tile)
+        k = self.cin if transposed else kh * kw * self.cin
+        self.k_pad, self.cout_pad = pack_geometry(k, gemm_n)
+        self.w = torch.empty(self.cout_pad, self.k_pad, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            rc = _lib.load().sgv3d_conv_pack_weight(w.data_ptr(), cout, cin, kh, kw, self.cin,
+                                                   1 if transposed else 0, self.w.data_ptr(), self.k_pad,
+                                                   self.cout_pad, _st(w))
+        _lib.check(rc, "sgv3d_conv_pack_weight")
+        self.scale = None if scale is None else scale.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.shift = None if shift is None else shift.detach().to(device=device, dtype=torch.float32).contiguous()
+        self._keep = w  # the pack kernel reads it asynchronously
+
+    def out_hw(self, h, w):
+        if self.transposed:
+            return h * self.ks, w * self.ks
+        oh = (h + 2 * self.pad - self.dil * (self.kh - 1) - 1) // self.stride + 1
+        ow = (w + 2 * self.pad - self.dil * (self.kw - 1) - 1) // self.stride + 1
+        return oh, ow
+
+    def __call__(self, x, out=None, *, x_coff=0, y_coff=0, residual=None, gate=None, nchw_out=False, tile=None):
+        """x NHWC [B,H,W,x_ld]; reads channels [x_coff, x_coff+cin).  out NHWC [B,OH,OW,y_ld] written
+        at channels [y_coff, y_coff+cout) (allocated [B,OH,OW,cout] if None)."""
+        B, H, W, x_ld = (int(s) for s in x.shape)
+        assert x.is_contiguous() and x.dtype == torch.float32
+        oh, ow = self.out_hw(H, W)
+        if out is None:
+            shape = (B, self.cout, oh, ow) if nchw_out else (B, oh, ow, self.cout)
+            out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        y_ld = int(out.shape[1] if nchw_out else out.shape[-1])
+        d = ConvDesc()
+        d.batch, d.in_h, d.in_w, d.cin = B, H, W, self.cin
+        d.out_h, d.out_w, d.cout = oh, ow, self.cout
+        d.kh, d.kw, d.stride, d.pad, d.dil = self.kh, self.kw, self.stride, self.pad, self.dil
+        d.x_ld, d.x_coff, d.y_ld, d.y_coff = x_ld, int(x_coff), y_ld, int(y_coff)
+        d.res_ld = int(residual.shape[-1]) if residual is not None else 0
+        d.relu = 1 if self.relu else 0
+        d.mode = CONV_DECONV if self.transposed else (CONV_NCHW_OUT if nchw_out else CONV_NORMAL)
+        d.deconv_ks = self.ks
+        d.k_pad, d.cout_pad = self.k_pad, self.cout_pad
+        d.tile = int(self.tile if tile is None else tile)
+        d.x_nchw = 0
+        with torch.cuda.device(x.device):
+            rc = _lib.load().sgv3d_conv2d_forward(ctypes.byref(d), x.data_ptr(), self.w.data_ptr(),
+                                                 _lib.ptr(self.scale), _lib.ptr(self.shift),
+                                                 _lib.ptr(residual), _lib.ptr(gate), out.data_ptr(), _st(x))
+        _lib.check(rc, "sgv3d_conv2d_forward")
+        return out
+
+
+def maxpool3x3s2(x, out=None):
+    B, H, W, C = (int(s) for s in x.shape)
+    oh, ow = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty(B, oh, ow, C, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().sgv3d_maxpool3x3s2(B, H, W, C, x.data_ptr(), out.data_ptr(), _st(x))
+    _lib.check(rc, "sgv3d_maxpool3x3s2")
+    return out
+
+
+def nchw_to_nhwc(x, c_pad=None, out=None):
+    B, C, H, W = (int(s) for s in x.shape)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    c_pad = int(c_pad or C)
+    if out is None:
+        out = torch.empty(B, H, W, c_pad, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().sgv3d_nchw_to_nhwc(B, C, H, W, c_pad, x.data_ptr(), out.data_ptr(), _st(x))
+    _lib.check(rc, "sgv3d_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, channels=None, coff=0, out=None):
+    B, H, W, ld = (int(s) for s in x.shape)
+    C = int(channels or ld)
+    if out is None:
+        out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().sgv3d_nhwc_to_nchw(B, C, H, W, ld, int(coff), x.data_ptr(), out.data_ptr(), _st(x))
+    _lib.check(rc, "sgv3d_nhwc_to_nchw")
+    return out
+
+
+def global_avgpool(x, out=None):
+    B, H, W, C = (int(s) for s in x.shape)
+    if out is None:
+        out = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().sgv3d_global_avgpool(B, H * W, C, C, x.data_ptr(), out.data_ptr(), _st(x))
+    _lib.check(rc, "sgv3d_global_avgpool")
+    return out
+
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+def dense(x, w, scale=None, bias=None, act=ACT_NONE, out=None):
+    """x [B,K], w [N,K] -> act(scale*(x @ w.T) + bias) [B,N]."""
+    B, K = (int(s) for s in x.shape)
+    N = int(w.shape[0])
+    assert int(w.shape[1]) == K and x.is_contiguous() and w.is_contiguous()
+    if out is None:
+        out = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().sgv3d_dense(B, K, N, x.data_ptr(), w.data_ptr(), _lib.ptr(scale), _lib.ptr(bias),
+                                    int(act), out.data_ptr(), _st(x))
+    _lib.check(rc, "sgv3d_dense")
+    return out
+
+
+def broadcast_channels(v, out, y_coff=0):
+    """v [B,C] written to out[b, :, :, y_coff:y_coff+C] for every pixel (out NHWC)."""
+    B, H, W, ld = (int(s) for s in out.shape)
+    C = int(v.shape[1])
+    with torch.cuda.device(out.device):
+        rc = _lib.load().sgv3d_broadcast_channels(B, H * W, C, ld, int(y_coff), v.data_ptr(), out.data_ptr(), _st(out))
+    _lib.check(rc, "sgv3d_broadcast_channels")
+    return out
+
+
+def deform_im2col3x3(x, offset, groups, out=None):
+    """x NHWC [B,H,W,C], offset NHWC [B,H,W,>=18] -> col [B,H,W,groups*9*(C/groups)]."""
+    B, H, W, C = (int(s) for s in x.shape)
+    if out is None:
+        out = torch.empty(B, H, W, 9 * C, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().sgv3d_deform_im2col3x3(B, H, W, C, int(groups), x.data_ptr(), offset.data_ptr(),
+                                               int(offset.shape[-1]), out.data_ptr(), _st(x))
+    _lib.check(rc, "sgv3d_deform_im2col3x3")
+    return out
+
+
+def head_final_conv(hidden, weight, bias, branch_of_out, num_branches, hidden_ch, out=None):
+    """hidden NHWC [B,H,W,nb*hc]; weight [sum_c,3,3,hc]; -> NCHW [B,sum_c,H,W]."""
+    B, H, W, ld = (int(s) for s in hidden.shape)
+    assert ld == num_branches * hidden_ch
+    total = int(weight.shape[0])
+    if out is None:
+        out = torch.empty(B, total, H, W, dtype=torch.float32, device=hidden.device)
+    with torch.cuda.device(hidden.device):
+        rc = _lib.load().sgv3d_head_final_conv(B, H, W, int(num_branches), int(hidden_ch), total,
+                                              hidden.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                              branch_of_out.data_ptr(), out.data_ptr(), _st(hidden))
+    _lib.check(rc, "sgv3d_head_final_conv")
+    return out
+
+
+def lift(height_context, D, C, want_prob=False, want_lifted=True):
+    """height_context NHWC [B,fH,fW,D+C] -> (prob [B,D,P] | None, lifted [B,D,P,C] | None)."""
+    B, fH, fW, ld = (int(s) for s in height_context.shape)
+    assert ld == D + C
+    P = fH * fW
+    prob = torch.empty(B, D, P, dtype=torch.float32, device=height_context.device) if want_prob else None
+    lifted = torch.empty(B, D, P, C, dtype=torch.float32, device=height_context.device) if want_lifted else None
+    with torch.cuda.device(height_context.device):
+        rc = _lib.load().sgv3d_lift(B, P, D, C, height_context.data_ptr(), _lib.ptr(prob), _lib.ptr(lifted),
+                                   _st(height_context))
+    _lib.check(rc, "sgv3d_lift")
+    return prob, lifted

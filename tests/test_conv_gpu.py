@@ -1,0 +1,249 @@
+"""GPU: MFMA implicit-GEMM convolution family and the small layers against plain PyTorch fp32 on CPU
+(F.conv2d / F.conv_transpose2d / F.max_pool2d ...: the fp32 reference of a floating-point kernel).
+Tolerance: 1e-3 (BASELINE north_star, fp32)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = dict(rtol=1e-3, atol=1e-3)
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def _conv_case(B, cin, H, W, cout, k, stride, pad, dil, seed, **kw):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    return x, w
+
+
+CASES = [
+    # (B, cin, H, W, cout, k, stride, pad, dil)
+    (1, 64, 20, 24, 64, 1, 1, 0, 1),
+    (2, 64, 17, 19, 128, 3, 1, 1, 1),      # ragged M, 3x3
+    (1, 128, 16, 16, 256, 3, 2, 1, 1),     # stride 2
+    (1, 256, 14, 18, 96, 3, 1, 6, 6),      # dilated (ASPP), cout not a tile multiple
+    (1, 80, 32, 32, 160, 7, 2, 3, 1),      # BEV trunk stem, cin % 32 != 0
+    (1, 4, 40, 56, 64, 7, 2, 3, 1),        # image stem with cin padded 3 -> 4
+    (1, 256, 12, 12, 128, 4, 4, 0, 1),     # SECONDFPN patchify conv (k == stride)
+    (1, 512, 9, 11, 18, 3, 1, 1, 1),       # conv_offset: tiny cout
+    (1, 2560, 6, 8, 512, 1, 1, 0, 1),      # ASPP conv1: long K
+    (3, 32, 5, 7, 40, 1, 2, 0, 1),         # 1x1 stride 2 (downsample)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_conv_matches_torch(hip, case, tile):
+    from sgv3d_amd.hip_ops import PackedConv
+    B, cin, H, W, cout, k, stride, pad, dil = case
+    x, w = _conv_case(*case, seed=sum(case))
+    ref = F.conv2d(x, w, None, stride, pad, dil)
+    conv = PackedConv(w.to(DEV), stride=stride, pad=pad, dil=dil, tile=tile)
+    y = conv(nhwc(x).to(DEV))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(nchw(y.cpu()), ref, **TOL)
+
+
+def test_conv_exact_on_integers(hip):
+    """fp32 MFMA is an exact fp32 FMA chain: small-integer data must come out bit-exact."""
+    from sgv3d_amd.hip_ops import PackedConv
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(-3, 4, (1, 64, 13, 15), generator=g).float()
+    w = torch.randint(-2, 3, (96, 64, 3, 3), generator=g).float()
+    ref = F.conv2d(x, w, None, 1, 1)
+    y = PackedConv(w.to(DEV), pad=1)(nhwc(x).to(DEV))
+    assert torch.equal(nchw(y.cpu()), ref)
+
+
+def test_conv_epilogue_bn_residual_relu_gate_offsets(hip):
+    from sgv3d_amd.hip_ops import PackedConv, fold_bn
+    g = torch.Generator().manual_seed(7)
+    B, cin, H, W, cout = 2, 64, 10, 12, 96
+    xfull = torch.randn(B, cin + 32, H, W, generator=g)              # read a channel slice
+    w = torch.randn(cout, cin, 3, 3, generator=g) / 24
+    bias = torch.randn(cout, generator=g)
+    bn = torch.nn.BatchNorm2d(cout, eps=1e-3)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(cout, generator=g))
+        bn.running_mean.copy_(torch.randn(cout, generator=g))
+        bn.running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+    bn.eval()
+    res = torch.randn(B, cout, H, W, generator=g)
+    gate = torch.rand(B, cout, generator=g)
+    with torch.no_grad():
+        ref = F.relu(bn(F.conv2d(xfull[:, 16:16 + cin], w, bias, 1, 1)) + res) * gate[:, :, None, None]
+    scale, shift = fold_bn(bn, bias)
+    conv = PackedConv(w.to(DEV), pad=1, scale=scale, shift=shift, relu=True)
+    out = torch.full((B, H, W, cout + 40), 7.0, device=DEV)           # write into a concat slice
+    conv(nhwc(xfull).to(DEV), out, x_coff=16, y_coff=8, residual=nhwc(res).to(DEV), gate=gate.to(DEV))
+    torch.cuda.synchronize()
+    o = out.cpu()
+    torch.testing.assert_close(nchw(o[..., 8:8 + cout]), ref, **TOL)
+    assert (o[..., :8] == 7).all() and (o[..., 8 + cout:] == 7).all()
+
+
+@pytest.mark.parametrize("ks,cin,cout", [(1, 128, 1024 // 8), (2, 160, 64), (4, 320, 64), (8, 640, 64)])
+def test_deconv_kernel_eq_stride(hip, ks, cin, cout):
+    """SECONDFPN deblocks: ConvTranspose2d(k = stride) + BN + ReLU, written into a concat slice."""
+    from sgv3d_amd.hip_ops import PackedConv
+    g = torch.Generator().manual_seed(ks)
+    x = torch.randn(2, cin, 5, 6, generator=g)
+    w = torch.randn(cin, cout, ks, ks, generator=g) / cin ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv_transpose2d(x, w, None, stride=ks) * scale[None, :, None, None] + shift[None, :, None, None])
+    conv = PackedConv(w.to(DEV), stride=ks, transposed=True, scale=scale, shift=shift, relu=True)
+    out = torch.zeros(2, 5 * ks, 6 * ks, 256, device=DEV)
+    conv(nhwc(x).to(DEV), out, y_coff=64)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(nchw(out.cpu()[..., 64:64 + cout]), ref, **TOL)
+
+
+def test_nchw_out_mode(hip):
+    from sgv3d_amd.hip_ops import PackedConv
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 9, 10, generator=g)
+    w = torch.randn(70, 64, 3, 3, generator=g) / 24
+    b = torch.randn(70, generator=g)
+    ref = F.conv2d(x, w, b, 1, 1)
+    y = PackedConv(w.to(DEV), pad=1, shift=b)(nhwc(x).to(DEV), nchw_out=True)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.cpu(), ref, **TOL)
+
+
+def test_layer_sized_conv_heightnet(hip):
+    """The hottest shape of the model: 512->512 3x3 @54x96 (HeightNet, 12.2 GMAC)."""
+    from sgv3d_amd.hip_ops import PackedConv
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 512, 54, 96, generator=g)
+    w = torch.randn(512, 512, 3, 3, generator=g) / (512 * 9) ** 0.5
+    ref = F.conv2d(x, w, None, 1, 1)
+    y = PackedConv(w.to(DEV), pad=1)(nhwc(x).to(DEV))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(nchw(y.cpu()), ref, **TOL)
+
+
+def test_conv_rejects_bad_args(hip):
+    from sgv3d_amd.hip_ops import PackedConv
+    from sgv3d_amd._lib import SGV3DError
+    w = torch.randn(8, 6, 1, 1)
+    with pytest.raises(AssertionError):
+        PackedConv(w.to(DEV))                                          # cin not a multiple of 4
+    conv = PackedConv(torch.randn(8, 8, 3, 3).to(DEV), pad=1)
+    with pytest.raises(SGV3DError):
+        conv(torch.zeros(1, 4, 4, 8, device=DEV), torch.zeros(1, 5, 4, 8, device=DEV))   # wrong out size
+
+
+# ------------------------------------------------------------------------------------------ small layers
+def test_maxpool(hip):
+    from sgv3d_amd.hip_ops import maxpool3x3s2
+    x = torch.randn(2, 64, 11, 14)
+    y = maxpool3x3s2(nhwc(x).to(DEV))
+    assert torch.equal(nchw(y.cpu()), F.max_pool2d(x, 3, 2, 1))
+
+
+def test_layout_kernels(hip):
+    from sgv3d_amd.hip_ops import nchw_to_nhwc, nhwc_to_nchw
+    x = torch.randn(2, 3, 37, 41)
+    y = nchw_to_nhwc(x.to(DEV), c_pad=4).cpu()
+    assert torch.equal(y[..., :3], nhwc(x)) and (y[..., 3] == 0).all()
+    z = torch.randn(2, 9, 13, 70)
+    assert torch.equal(nhwc_to_nchw(z.to(DEV), channels=33, coff=5).cpu(), nchw(z[..., 5:38]))
+
+
+def test_avgpool_dense_broadcast(hip):
+    from sgv3d_amd.hip_ops import global_avgpool, dense, broadcast_channels, ACT_RELU, ACT_SIGMOID
+    x = torch.randn(2, 512, 9, 7)
+    p = global_avgpool(nhwc(x).to(DEV))
+    torch.testing.assert_close(p.cpu(), x.mean((2, 3)), rtol=1e-5, atol=1e-5)
+    w, b, s = torch.randn(100, 512) / 22, torch.randn(100), torch.rand(100) + 0.5
+    torch.testing.assert_close(dense(p, w.to(DEV), s.to(DEV), b.to(DEV), ACT_RELU).cpu(),
+                               F.relu((p.cpu() @ w.T) * s + b), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dense(p, w.to(DEV), None, b.to(DEV), ACT_SIGMOID).cpu(),
+                               torch.sigmoid(p.cpu() @ w.T + b), rtol=1e-4, atol=1e-4)
+    v = torch.randn(2, 48)
+    out = torch.zeros(2, 5, 6, 100, device=DEV)
+    broadcast_channels(v.to(DEV), out, y_coff=20)
+    o = out.cpu()
+    assert torch.equal(o[..., 20:68], v[:, None, None, :].expand(2, 5, 6, 48)) and (o[..., :20] == 0).all()
+
+
+def _deform_conv_ref(x, offset, weight, groups):
+    """DCNv1 (mmcv DeformConv2dPack semantics: 3x3, pad 1, zero padding bilinear) in plain torch fp64."""
+    B, C, H, W = x.shape
+    x = x.double()
+    cols = []
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    for t in range(9):
+        ky, kx = t // 3, t % 3
+        hf = ys[None] - 1 + ky + offset[:, 2 * t].double()
+        wf = xs[None] - 1 + kx + offset[:, 2 * t + 1].double()
+        valid = (hf > -1) & (wf > -1) & (hf < H) & (wf < W)
+        h0, w0 = torch.floor(hf), torch.floor(wf)
+        lh, lw = hf - h0, wf - w0
+        val = torch.zeros(B, C, H, W, dtype=torch.float64)
+        for dh, dw, wt in ((0, 0, (1 - lh) * (1 - lw)), (0, 1, (1 - lh) * lw), (1, 0, lh * (1 - lw)), (1, 1, lh * lw)):
+            hh, ww = (h0 + dh).long(), (w0 + dw).long()
+            ok = valid & (hh >= 0) & (hh <= H - 1) & (ww >= 0) & (ww <= W - 1)
+            idx = (hh.clamp(0, H - 1) * W + ww.clamp(0, W - 1))[:, None].expand(B, C, H, W).reshape(B, C, -1)
+            g = torch.gather(x.reshape(B, C, -1), 2, idx).reshape(B, C, H, W)
+            val = val + g * (wt * ok)[:, None]
+        cols.append(val)
+    col = torch.stack(cols, 2)                                   # [B, C, 9, H, W]
+    cout = weight.shape[0]
+    cpg, opg = C // groups, cout // groups
+    out = torch.zeros(B, cout, H, W, dtype=torch.float64)
+    for g_ in range(groups):
+        wg = weight[g_ * opg:(g_ + 1) * opg].double().reshape(opg, cpg * 9)
+        cg = col[:, g_ * cpg:(g_ + 1) * cpg].reshape(B, cpg * 9, H * W)
+        out[:, g_ * opg:(g_ + 1) * opg] = (wg @ cg).reshape(B, opg, H, W)
+    return out.float()
+
+
+def test_deform_conv(hip):
+    """deform_im2col + grouped GEMM == DCNv1; zero offsets == plain grouped conv (known answer)."""
+    from sgv3d_amd.hip_ops import PackedConv, deform_im2col3x3
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W, groups = 2, 64, 9, 11, 4
+    x = torch.randn(B, C, H, W, generator=g)
+    weight = torch.randn(C, C // groups, 3, 3, generator=g) / 12
+    for offs in (torch.zeros(B, 18, H, W), torch.randn(B, 18, H, W, generator=g) * 2.5):
+        col = deform_im2col3x3(nhwc(x).to(DEV), nhwc(offs).to(DEV), groups)
+        out = torch.empty(B, H, W, C, device=DEV)
+        cpg = C // groups
+        for gi in range(groups):
+            wg = weight[gi * cpg:(gi + 1) * cpg].permute(0, 2, 3, 1).reshape(cpg, 9 * cpg, 1, 1)   # [o, (tap, c)]
+            PackedConv(wg.contiguous().to(DEV))(col, out, x_coff=gi * 9 * cpg, y_coff=gi * cpg)
+        torch.cuda.synchronize()
+        ref = _deform_conv_ref(x, offs, weight, groups)
+        torch.testing.assert_close(nchw(out.cpu()), ref, **TOL)
+        if offs.abs().sum() == 0:
+            torch.testing.assert_close(ref, F.conv2d(x, weight, None, 1, 1, 1, groups), **TOL)
+
+
+def test_head_final_conv(hip):
+    from sgv3d_amd.hip_ops import head_final_conv
+    g = torch.Generator().manual_seed(9)
+    B, H, W, hc = 2, 21, 37, 64
+    widths = [2, 1, 3, 2, 2, 1]                                    # reg, height, dim, rot, vel, heatmap
+    nb = len(widths)
+    hidden = torch.randn(B, nb * hc, H, W, generator=g)
+    ws = [torch.randn(c, hc, 3, 3, generator=g) / 24 for c in widths]
+    bs = [torch.randn(c, generator=g) for c in widths]
+    ref = torch.cat([F.conv2d(hidden[:, i * hc:(i + 1) * hc], ws[i], bs[i], 1, 1) for i in range(nb)], 1)
+    wcat = torch.cat([w.permute(0, 2, 3, 1) for w in ws], 0).contiguous()       # [sum_c, 3, 3, hc]
+    branch = torch.tensor(sum([[i] * c for i, c in enumerate(widths)], []), dtype=torch.int32)
+    out = head_final_conv(nhwc(hidden).to(DEV), wcat.to(DEV), torch.cat(bs).to(DEV), branch.to(DEV), nb, hc)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu(), ref, **TOL)

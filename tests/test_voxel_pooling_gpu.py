@@ -1,0 +1,207 @@
+"""GPU: HIP voxel pooling (C ABI + python op mirror) against the oracle and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import geometry_ref as G
+from oracle import voxel_pooling_ref as VPO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+VP_CASES = ["tiny", "b2_c80", "z2", "dups", "all_out"]
+
+
+def _run_abi(hip, geom, feats, voxel_num, mode, sort=True):
+    """Call straight through the C ABI. Returns NCHW out (numpy), pos_memo (numpy)."""
+    lib = hip.load()
+    B = geom.shape[0]
+    C = feats.shape[-1]
+    g = torch.from_numpy(np.ascontiguousarray(geom, np.int32).reshape(B, -1, 3)).to(DEV)
+    f = torch.from_numpy(np.ascontiguousarray(feats, np.float32).reshape(B, -1, C)).to(DEV)
+    N = g.shape[1]
+    X, Y, Z = (int(v) for v in voxel_num)
+    pm = torch.full((B, N, 3), -1, dtype=torch.int32, device=DEV)
+    st = hip.stream_handle()
+    if mode == "atomic":
+        out = torch.zeros(B, Y, X, C, device=DEV)
+        hip.check(lib.sgv3d_voxel_pooling_forward(B, N, C, X, Y, Z, g.data_ptr(), f.data_ptr(), out.data_ptr(),
+                                                  pm.data_ptr(), st), "atomic")
+    else:
+        nbytes = lib.sgv3d_voxel_plan_bytes(B, N, X, Y)
+        plan = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        out = torch.full((B, Y, X, C), float("nan"), device=DEV)   # must be fully overwritten
+        hip.check(lib.sgv3d_voxel_plan_build(B, N, X, Y, Z, g.data_ptr(), pm.data_ptr(), plan.data_ptr(), nbytes,
+                                             1 if sort else 0, st), "plan")
+        hip.check(lib.sgv3d_voxel_pooling_forward_planned(B, N, C, X, Y, plan.data_ptr(), f.data_ptr(),
+                                                          out.data_ptr(), st), "planned")
+    torch.cuda.synchronize()
+    return out.permute(0, 3, 1, 2).contiguous().cpu().numpy(), pm.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", VP_CASES)
+@pytest.mark.parametrize("mode", ["atomic", "planned"])
+def test_golden_exact(hip, golden, name, mode):
+    vp = golden["voxel_pooling"]
+    out, pm = _run_abi(hip, vp[f"{name}/geom_xyz"], vp[f"{name}/feats"], vp[f"{name}/voxel_num"], mode)
+    assert np.array_equal(out, vp[f"{name}/out"])            # integer-valued floats: bit-exact
+    _, pm_ref = VPO.forward(vp[f"{name}/geom_xyz"], vp[f"{name}/feats"], vp[f"{name}/voxel_num"])
+    assert np.array_equal(pm, pm_ref)
+
+
+@pytest.mark.parametrize("mode", ["atomic", "planned"])
+def test_golden_randn_tolerance(hip, golden, mode):
+    vp = golden["voxel_pooling"]
+    out, _ = _run_abi(hip, vp["b2_c80_randn/geom_xyz"], vp["b2_c80_randn/feats"], vp["b2_c80_randn/voxel_num"], mode)
+    np.testing.assert_allclose(out, vp["b2_c80_randn/out"], rtol=1e-3, atol=1e-3)   # north_star: 1e-3 fp32
+
+
+@pytest.mark.parametrize("C", [80, 87, 4, 1, 260])
+@pytest.mark.parametrize("mode", ["atomic", "planned"])
+def test_random_vs_oracle_exact(hip, C, mode):
+    """Ragged / colliding / out-of-range indices, channel counts incl. C%4!=0 and rows wider than a wave."""
+    rng = np.random.default_rng(C)
+    B, N, X, Y, Z = 2, 3001, 13, 9, 2
+    geom = rng.integers(-3, 16, size=(B, N, 3)).astype(np.int32)
+    geom[0, :50] = [5, 5, 0]                                   # a 50-fold collision
+    feats = rng.integers(-8, 9, size=(B, N, C)).astype(np.float32)
+    out, pm = _run_abi(hip, geom, feats, (X, Y, Z), mode)
+    ref, pm_ref = VPO.forward(geom, feats, (X, Y, Z))
+    assert np.array_equal(out, ref) and np.array_equal(pm, pm_ref)
+
+
+def test_long_segments_sorted(hip):
+    """Segments of 1, 64, 65, 300 and 9000 points: the plan's per-voxel lists come out ascending
+    (covers the in-register-size, LDS and global-memory bitonic paths)."""
+    lib = hip.load()
+    lens = [1, 64, 65, 300, 9000, 2, 3, 257]
+    X, Y, Z = len(lens), 1, 1
+    vox = np.concatenate([np.full(n, i) for i, n in enumerate(lens)])
+    rng = np.random.default_rng(0)
+    rng.shuffle(vox)
+    N = len(vox)
+    geom = np.zeros((1, N, 3), np.int32)
+    geom[0, :, 0] = vox
+    g = torch.from_numpy(geom).to(DEV)
+    nbytes = lib.sgv3d_voxel_plan_bytes(1, N, X, Y)
+    plan = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    hip.check(lib.sgv3d_voxel_plan_build(1, N, X, Y, Z, g.data_ptr(), None, plan.data_ptr(), nbytes, 1,
+                                         hip.stream_handle()), "plan")
+    torch.cuda.synchronize()
+    ints = plan.cpu().numpy().view(np.int32)
+    V = X * Y
+    al = lambda b: (b + 255) & ~255
+    off_cur = al(4 * (V + 1))
+    off_order = al(off_cur + 4 * (V + 1))
+    seg = ints[:V + 1]
+    order = ints[off_order // 4: off_order // 4 + N]
+    assert list(np.diff(seg)) == lens
+    for v in range(V):
+        s = order[seg[v]:seg[v + 1]]
+        assert np.array_equal(s, np.nonzero(vox == v)[0]), f"segment {v} (len {lens[v]}) not ascending"
+
+
+def test_planned_is_bitwise_reproducible(hip):
+    rng = np.random.default_rng(5)
+    B, N, C, X, Y = 1, 20000, 80, 16, 16
+    geom = rng.integers(-1, 17, size=(B, N, 3)).astype(np.int32)
+    geom[..., 2] = 0
+    feats = rng.standard_normal((B, N, C)).astype(np.float32)
+    a, _ = _run_abi(hip, geom, feats, (X, Y, 1), "planned")
+    b, _ = _run_abi(hip, geom, feats, (X, Y, 1), "planned")
+    assert np.array_equal(a, b)
+    ref, _ = VPO.forward(geom, feats, (X, Y, 1))
+    np.testing.assert_allclose(a, ref, rtol=1e-3, atol=1e-3)
+
+
+def _cfg2_geom(golden):
+    geo = golden["geometry"]
+    n = "dair_p11_h5.5"
+    vs, vc, vn = G.voxel_params([0, 102.4, 0.4], [-51.2, 51.2, 0.4], [-5, 3, 8])
+    fr = G.create_frustum((864, 1536), 16, [-2.0, 0.0, 90])
+    gi, _ = G.geom_xyz_for_camera(fr, geo[f"{n}/sensor2ego"], geo[f"{n}/sensor2virtual"], geo[f"{n}/intrin"],
+                                  geo[f"{n}/ida"], geo[f"{n}/reference_height"], geo[f"{n}/bda"], vc, vs)
+    return gi[None], vn
+
+
+@pytest.mark.parametrize("mode", ["atomic", "planned"])
+def test_cfg2_full_size_properties(hip, golden, mode):
+    """BASELINE cfg-2 size (N=466 560, C=80, 256x256): exact vs the oracle on integer-valued features,
+    plus size-independent properties: linearity and conservation of mass."""
+    geom, vn = _cfg2_geom(golden)
+    rng = np.random.default_rng(1)
+    N = geom.shape[1] * geom.shape[2] * geom.shape[3]
+    f1 = rng.integers(-4, 5, size=(1, N, 80)).astype(np.float32)
+    f2 = rng.integers(-4, 5, size=(1, N, 80)).astype(np.float32)
+    o1, pm = _run_abi(hip, geom, f1, vn, mode)
+    ref, pm_ref = VPO.forward(geom, f1, vn)
+    assert np.array_equal(o1, ref) and np.array_equal(pm, pm_ref)
+    o2, _ = _run_abi(hip, geom, f2, vn, mode)
+    o12, _ = _run_abi(hip, geom, f1 + 2 * f2, vn, mode)
+    assert np.array_equal(o12, o1 + 2 * o2)                                   # linearity
+    kept = pm.reshape(-1, 3)[:, 0] != -1
+    assert np.array_equal(o1.sum(axis=(0, 2, 3)), f1.reshape(-1, 80)[kept].sum(0))  # mass conservation
+    assert abs(kept.mean() - 0.7432) < 1e-3
+
+
+@pytest.mark.parametrize("mode", ["atomic", "planned"])
+def test_python_op_forward_backward(hip, golden, mode):
+    """The reference-shaped operator: permuted-view output, (None, grad, None) backward."""
+    from sgv3d_amd.ops.voxel_pooling import voxel_pooling, set_mode
+    vp = golden["voxel_pooling"]
+    set_mode(mode)
+    try:
+        for name in ["b2_c80", "z2", "dups", "all_out"]:
+            geom = torch.from_numpy(vp[f"{name}/geom_xyz"]).to(DEV)
+            feats = torch.from_numpy(vp[f"{name}/feats"]).to(DEV).requires_grad_(True)
+            vnum = torch.from_numpy(vp[f"{name}/voxel_num"]).to(DEV)       # CUDA LongTensor like lss_fpn.py:491
+            out = voxel_pooling(geom, feats, vnum)
+            assert tuple(out.shape) == vp[f"{name}/out"].shape
+            assert np.array_equal(out.detach().cpu().numpy(), vp[f"{name}/out"])
+            out.backward(torch.from_numpy(vp[f"{name}/grad_out"]).to(DEV))
+            assert np.array_equal(feats.grad.cpu().numpy(), vp[f"{name}/grad_feats"])
+            with torch.no_grad():
+                out2 = voxel_pooling(geom, feats.detach(), vnum)
+            assert torch.equal(out2, out.detach())
+    finally:
+        set_mode("planned")
+
+
+def test_python_op_errors(hip):
+    from sgv3d_amd.ops.voxel_pooling import voxel_pooling
+    g = torch.zeros(1, 4, 3, dtype=torch.int32, device=DEV)
+    f = torch.zeros(1, 4, 8, device=DEV)
+    with pytest.raises(RuntimeError):
+        voxel_pooling(g.cpu(), f, (2, 2, 1))                   # not a CUDA tensor
+    with pytest.raises(AssertionError):
+        voxel_pooling(g, f.transpose(1, 2).contiguous().transpose(1, 2), (2, 2, 1))   # non-contiguous
+    with pytest.raises(RuntimeError):
+        voxel_pooling(g.long(), f, (2, 2, 1))                  # wrong dtype
+
+
+def test_ext_shim_runs_reference_wrapper_protocol(hip, golden):
+    """voxel_pooling_ext.voxel_pooling_forward_wrapper: same 10-argument call the reference makes."""
+    from sgv3d_amd.ops.voxel_pooling import voxel_pooling_ext as ext
+    vp = golden["voxel_pooling"]
+    name = "b2_c80"
+    geom = torch.from_numpy(vp[f"{name}/geom_xyz"]).to(DEV).reshape(2, -1, 3)
+    feats = torch.from_numpy(vp[f"{name}/feats"]).to(DEV).reshape(2, -1, 80)
+    X, Y, Z = (int(v) for v in vp[f"{name}/voxel_num"])
+    out = feats.new_zeros(2, Y, X, 80)
+    pm = geom.new_ones(2, geom.shape[1], 3) * -1
+    assert ext.voxel_pooling_forward_wrapper(2, geom.shape[1], 80, X, Y, Z, geom, feats, out, pm) == 1
+    assert np.array_equal(out.permute(0, 3, 1, 2).cpu().numpy(), vp[f"{name}/out"])
+    with pytest.raises(RuntimeError):
+        ext.voxel_pooling_forward_wrapper(2, geom.shape[1], 80, X, Y, Z, geom.cpu(), feats, out, pm)
+
+
+def test_fused_lift_splat_matches_materialised(hip, golden):
+    from sgv3d_amd.ops.voxel_pooling import VoxelPlan
+    rng = np.random.default_rng(3)
+    B, D, P, C, X, Y = 2, 6, 35, 80, 8, 7
+    geom = torch.from_numpy(rng.integers(-2, 10, size=(B, D * P, 3)).astype(np.int32)).to(DEV)
+    geom[..., 2] = 0
+    prob = torch.from_numpy(rng.integers(0, 4, size=(B, D, P)).astype(np.float32)).to(DEV)
+    ctx = torch.from_numpy(rng.integers(-4, 5, size=(B, P, C)).astype(np.float32)).to(DEV)
+    lifted = (prob[..., None] * ctx[:, None]).reshape(B, D * P, C).contiguous()
+    plan = VoxelPlan(geom, (X, Y, 1))
+    assert torch.equal(plan.lift_splat(prob, ctx), plan.pool(lifted))
