@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: camera frames/s of the BEVHeight camera->BEV forward on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "cfg-2"): ResNet-50, 864x1536 image -> 256x256 BEV, batch 1 per
+GPU, fp32, synthetic images / DAIR-like calibration / random-init weights (no dataset or checkpoint
+is reachable), inputs resident in HBM before the timed region.  One "step" = one full forward
+(image backbone + neck + HeightNet + lift + geometry + voxel pooling + BEV head) of the per-GPU batch;
+frames shard over GPUs as independent replicas (no collective on the data path), so
+``value`` = N * batch * K / max-over-ranks(time) and ``scaling`` is weak.
+
+Printed by rank 0 as ONE JSON line, with
+* ``roofline``: the dominant kernel (MFMA implicit-GEMM conv) — algorithmic FLOPs of its launches /
+  their summed durations, measured live with HIP events on the launch stream in an instrumented
+  pass over the same K steps (events around every launch would perturb the throughput loop, so the
+  two loops are separate; both run in this process on the same inputs);
+* ``cpu_baseline``: the torch-CPU oracle restatement of the same forward (oracle/torch_model.py)
+  timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+HBM_PEAK_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (cfg-2: 1)")
+    ap.add_argument("--no-graph", action="store_true", help="eager stream launches instead of a hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--fuse-lift-splat", action="store_true", help="skip the materialised [B,N,C] lifted tensor")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
+
+    from sgv3d_amd import hip_ops, synthetic as S
+    from sgv3d_amd.models.bev_height import BEVHeight
+
+    bc, hc = S.r50_256_conf()
+    torch.manual_seed(0)
+    model = BEVHeight(bc, hc).eval()
+    S.randomize_norm_stats_(model, 0)
+    model = model.to(dev)
+    model.backbone.fuse_lift_splat = bool(args.fuse_lift_splat)
+    B = args.batch
+    imgs = S.make_images(B, bc['final_dim'], device=dev, seed=rank)
+    mats = S.make_mats(B, device=dev)
+
+    def step():
+        with torch.no_grad():
+            return model(imgs, mats)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up: packs weights, tunes tiles, fills the caching allocator ---------------------
+    for _ in range(max(1, args.warmup)):
+        out = step()
+    torch.cuda.synchronize()
+
+    # ---- optional hipGraph capture of one step ---------------------------------------------------
+    use_graph = not args.no_graph
+    graph = None
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph, stream=s):
+                    out = step()
+            torch.cuda.current_stream().wait_stream(s)
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:  # capture unsupported -> eager launches of the same kernels
+            if rank == 0:
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            graph = None
+            use_graph = False
+            torch.cuda.synchronize()
+    run = (lambda: graph.replay()) if graph is not None else step
+    for _ in range(args.warmup):
+        run()
+
+    # ---- timed region: exactly K steps ------------------------------------------------------------
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames = world * B * args.steps
+    value = frames / elapsed
+
+    # ---- roofline: instrumented pass, HIP events around every conv launch -------------------------
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        hip_ops.PROFILE = []
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        recs = hip_ops.PROFILE
+        hip_ops.PROFILE = None
+        by_kernel = {}
+        for name, flops, e0, e1 in recs:
+            d = by_kernel.setdefault(name, [0.0, 0.0, 0])
+            d[0] += flops
+            d[1] += e0.elapsed_time(e1) * 1e-3
+            d[2] += 1
+        conv = {k: v for k, v in by_kernel.items() if k.startswith("conv_igemm")}
+        top = max(conv, key=lambda k: conv[k][1])
+        fl, sec, n = conv[top]
+        fam_fl = sum(v[0] for v in conv.values())
+        fam_sec = sum(v[1] for v in conv.values())
+        all_sec = sum(v[1] for v in by_kernel.values())
+        roofline = {
+            "bound": "mfma", "kernel": top, "achieved": fl / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+            "launches": n, "avg_launch_us": sec / n * 1e6, "flop_per_launch": fl / n,
+            "conv_family": {"achieved": fam_fl / fam_sec / 1e12, "frac": fam_fl / fam_sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                            "gflop_per_frame": fam_fl / (args.steps * B) / 1e9,
+                            "ms_per_step": fam_sec / args.steps * 1e3,
+                            "share_of_instrumented_time": fam_sec / all_sec},
+            "other_kernels_ms_per_step": {k: v[1] / args.steps * 1e3 for k, v in by_kernel.items()
+                                          if not k.startswith("conv_igemm")},
+            "method": "HIP events on the launch stream around every launch, separate instrumented pass",
+        }
+
+    # ---- CPU baseline (oracle port), rank 0 at N=1 only -------------------------------------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_model as TM
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        cimgs, cmats = imgs[:1].cpu(), {k: v[:1].cpu() for k, v in mats.items()}
+        cores = torch.get_num_threads()
+        t1 = time.perf_counter()
+        n_cpu = 0
+        while True:
+            TM.bevheight_forward(sd, bc, hc, cimgs, cmats)
+            n_cpu += 1
+            dt = time.perf_counter() - t1
+            if dt > 12.0 or n_cpu >= 4:
+                break
+        cpu_baseline = {"value": n_cpu / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+                        "sample": f"{n_cpu} full cfg-2 frame(s) through oracle/torch_model.py (torch-CPU fp32 "
+                                  f"eager + numpy geometry + C voxel pooling), {dt:.1f} s"}
+
+    if rank == 0:
+        line = {
+            "metric": "camera frames/sec at 864x1536->BEV",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg-2: ResNet-50 864x1536 -> 256x256 BEV, fp32, full BEVHeight forward "
+                                   "(backbone+neck+HeightNet+lift+geometry+voxel_pooling+head)",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world}",
+                       "hip_graph": bool(use_graph), "fuse_lift_splat": bool(args.fuse_lift_splat),
+                       "voxel_pooling_mode": "planned", "weights": "random-init, BN stats perturbed (seed 0)"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

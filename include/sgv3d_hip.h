@@ -212,6 +212,16 @@ int sgv3d_dense(int batch, int k, int n, const float *x, const float *w, const f
 int sgv3d_broadcast_channels(int batch, int pixels, int channels, int y_ld, int y_coff,
                              const float *v, float *y, void *stream);
 
+/* SELayer gating x * sigmoid(...)  (layers/backbones/lss_fpn.py:155-159): y[b,p,c] = x[b,p,c] * gate[b,c].
+ * x, y NHWC f32 [B, P, C] (may alias). */
+int sgv3d_scale_channels(int batch, int pixels, int channels, const float *x, const float *gate,
+                         float *y, void *stream);
+
+/* Channel-slice copy: y[b,p,0:C] = x[b,p,coff:coff+C], x row stride x_ld, y contiguous [B,P,C]
+ * (the context slice of HeightNet's output, lss_fpn.py:464-465). */
+int sgv3d_copy_channels(int batch, int pixels, int channels, int x_ld, int x_coff, const float *x,
+                        float *y, void *stream);
+
 /* Deformable 3x3 sampling of mmcv DeformConv2dPack (DCNv1, deform_groups=1, stride 1, pad 1, dil 1;
  * lss_fpn.py:190-198): col[b, p, g, tap, cg] = bilinear(x[b, :, :, g*cpg + cg], p + tap + offset).
  *   x      f32 [B, H, W, C] NHWC;  offset f32 [B, H, W, off_ld] with (dy, dx) of tap t at 2t, 2t+1

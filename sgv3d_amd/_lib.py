@@ -46,6 +46,8 @@ _PROTOS = {
     "sgv3d_global_avgpool": (c_int, [c_int] * 4 + [c_void_p] * 3),
     "sgv3d_dense": (c_int, [c_int] * 3 + [c_void_p] * 4 + [c_int, c_void_p, c_void_p]),
     "sgv3d_broadcast_channels": (c_int, [c_int] * 5 + [c_void_p] * 3),
+    "sgv3d_scale_channels": (c_int, [c_int] * 3 + [c_void_p] * 4),
+    "sgv3d_copy_channels": (c_int, [c_int] * 5 + [c_void_p] * 3),
     "sgv3d_deform_im2col3x3": (c_int, [c_int] * 5 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "sgv3d_head_final_conv": (c_int, [c_int] * 6 + [c_void_p] * 6),
 }

@@ -117,6 +117,28 @@ __global__ __launch_bounds__(kBlock) void broadcast_channels_kernel(long long to
     y[bp * ld + coff + c] = v[b * C + c];
 }
 
+// SELayer gate (lss_fpn.py:155-159): y = x * gate[b, c]
+__global__ __launch_bounds__(kBlock) void scale_channels_kernel(long long total4, int P, int C4,
+                                                                const float4 *__restrict__ x,
+                                                                const float4 *__restrict__ gate,
+                                                                float4 *__restrict__ y) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total4) return;
+    const int c = (int)(i % C4);
+    const long long b = i / ((long long)P * C4);
+    const float4 v = x[i], g = gate[b * C4 + c];
+    y[i] = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
+}
+
+__global__ __launch_bounds__(kBlock) void copy_channels_kernel(long long total, int C, int ld, int coff,
+                                                               const float *__restrict__ x, float *__restrict__ y) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    const long long bp = i / C;
+    const int c = (int)(i - bp * C);
+    y[i] = x[bp * ld + coff + c];
+}
+
 // mmcv DeformConv2dPack sampling (DCNv1: deformable_im2col + bilinear with zero padding;
 // configured at lss_fpn.py:190-198: 3x3, pad 1, stride 1, dil 1, deform_groups 1)
 __global__ __launch_bounds__(kBlock) void deform_im2col3x3_kernel(int B, int H, int W, int C, int groups,
@@ -293,6 +315,27 @@ extern "C" int sgv3d_broadcast_channels(int batch, int pixels, int channels, int
     hipLaunchKernelGGL(broadcast_channels_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, as_stream(stream), total,
                        pixels, channels, y_ld, y_coff, v, y);
     return check_launch("broadcast_channels_kernel");
+}
+
+extern "C" int sgv3d_scale_channels(int batch, int pixels, int channels, const float *x, const float *gate, float *y,
+                                    void *stream) {
+    SGV3D_REQUIRE(batch > 0 && pixels > 0 && channels > 0 && (channels & 3) == 0, "scale_channels: bad shape");
+    SGV3D_REQUIRE(x && gate && y, "scale_channels: null pointer");
+    const long long total4 = (long long)batch * pixels * (channels / 4);
+    hipLaunchKernelGGL(scale_channels_kernel, dim3(cdiv(total4, kBlock)), dim3(kBlock), 0, as_stream(stream), total4,
+                       pixels, channels / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(gate),
+                       reinterpret_cast<float4 *>(y));
+    return check_launch("scale_channels_kernel");
+}
+
+extern "C" int sgv3d_copy_channels(int batch, int pixels, int channels, int x_ld, int x_coff, const float *x, float *y,
+                                   void *stream) {
+    SGV3D_REQUIRE(batch > 0 && pixels > 0 && channels > 0 && x_coff >= 0 && x_ld >= x_coff + channels, "copy_channels: bad shape");
+    SGV3D_REQUIRE(x && y, "copy_channels: null pointer");
+    const long long total = (long long)batch * pixels * channels;
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, as_stream(stream), total, channels,
+                       x_ld, x_coff, x, y);
+    return check_launch("copy_channels_kernel");
 }
 
 extern "C" int sgv3d_deform_im2col3x3(int batch, int h, int w, int channels, int groups, const float *x,

@@ -16,6 +16,47 @@ def _st(t):
     return _lib.stream_handle(t.device)
 
 
+# When a list, every wrapper appends (kernel name, algorithmic flops, start event, end event) recorded
+# on the launch stream (bench.py's roofline pass).  None = no instrumentation.
+PROFILE = None
+# Pick the conv tile per (layer, input shape) by timing the four variants once, outside graph capture.
+AUTOTUNE = True
+TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64"}
+
+
+class prof:
+    """``with prof("kernel", flops):`` brackets a launch with HIP events when PROFILE is active."""
+    __slots__ = ("name", "flops", "e0")
+
+    def __init__(self, name, flops=0.0):
+        self.name, self.flops, self.e0 = name, flops, None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE.append((self.name, self.flops, self.e0, e1))
+            self.e0 = None
+        return False
+
+
+def heuristic_tile(M, N):
+    """Same cost model as pick_tile() in csrc/conv_igemm.hip."""
+    best, best_cost = 1, None
+    for t, (bm, bn, pen) in enumerate(((128, 128, 1.0), (128, 64, 1.06), (64, 128, 1.06), (64, 64, 1.18)), 1):
+        tiles = -(-M // bm) * -(-N // bn)
+        cost = -(-tiles // 256) * bm * bn * pen
+        if best_cost is None or cost < best_cost:
+            best, best_cost = t, cost
+    return best
+
+
 def pack_geometry(k, n):
     kp, np_ = ctypes.c_int(), ctypes.c_int()
     _lib.load().sgv3d_conv_pack_geometry(int(k), int(n), ctypes.byref(kp), ctypes.byref(np_))
@@ -74,6 +115,7 @@ class PackedConv:
         self.scale = None if scale is None else scale.detach().to(device=device, dtype=torch.float32).contiguous()
         self.shift = None if shift is None else shift.detach().to(device=device, dtype=torch.float32).contiguous()
         self._keep = w  # the pack kernel reads it asynchronously
+        self._tile_cache = {}
 
     def out_hw(self, h, w):
         if self.transposed:
@@ -91,6 +133,11 @@ class PackedConv:
         if out is None:
             shape = (B, self.cout, oh, ow) if nchw_out else (B, oh, ow, self.cout)
             out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        else:
+            want = (B, None, oh, ow) if nchw_out else (B, oh, ow, None)
+            got = tuple(int(v) for v in out.shape)
+            if len(got) != 4 or any(w is not None and w != g for w, g in zip(want, got)) or not out.is_contiguous():
+                raise _lib.SGV3DError(f"conv output buffer {got} does not match {want}")
         y_ld = int(out.shape[1] if nchw_out else out.shape[-1])
         d = ConvDesc()
         d.batch, d.in_h, d.in_w, d.cin = B, H, W, self.cin
@@ -102,14 +149,47 @@ class PackedConv:
         d.mode = CONV_DECONV if self.transposed else (CONV_NCHW_OUT if nchw_out else CONV_NORMAL)
         d.deconv_ks = self.ks
         d.k_pad, d.cout_pad = self.k_pad, self.cout_pad
-        d.tile = int(self.tile if tile is None else tile)
         d.x_nchw = 0
-        with torch.cuda.device(x.device):
-            rc = _lib.load().sgv3d_conv2d_forward(ctypes.byref(d), x.data_ptr(), self.w.data_ptr(),
-                                                 _lib.ptr(self.scale), _lib.ptr(self.shift),
-                                                 _lib.ptr(residual), _lib.ptr(gate), out.data_ptr(), _st(x))
+        lib = _lib.load()
+        args = (x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
+                _lib.ptr(gate), out.data_ptr(), _st(x))
+        gemm_m = B * (H * W if self.transposed else oh * ow)
+        gemm_n = self.cout * (self.ks * self.ks if self.transposed else 1)
+        t = int(self.tile if tile is None else tile)
+        if t == 0:
+            key = (B, H, W)
+            t = self._tile_cache.get(key, 0)
+            if t == 0:
+                if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+                    t = self._autotune(lib, d, args, x.device)
+                    self._tile_cache[key] = t
+                else:
+                    t = heuristic_tile(gemm_m, gemm_n)
+        d.tile = t
+        flops = 2.0 * gemm_m * gemm_n * (self.cin * self.kh * self.kw)
+        with torch.cuda.device(x.device), prof("conv_igemm_" + TILE_NAMES[t], flops):
+            rc = lib.sgv3d_conv2d_forward(ctypes.byref(d), *args)
         _lib.check(rc, "sgv3d_conv2d_forward")
         return out
+
+    def _autotune(self, lib, d, args, device):
+        """Time the four tile shapes on the real buffers (results are bitwise identical across tiles:
+        every output element sums k in the same order) and keep the fastest."""
+        best, best_t = 1, None
+        with torch.cuda.device(device):
+            for t in (1, 2, 3, 4):
+                d.tile = t
+                _lib.check(lib.sgv3d_conv2d_forward(ctypes.byref(d), *args), "sgv3d_conv2d_forward")   # warm
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(2):
+                    lib.sgv3d_conv2d_forward(ctypes.byref(d), *args)
+                e1.record()
+                e1.synchronize()
+                dt = e0.elapsed_time(e1)
+                if best_t is None or dt < best_t:
+                    best, best_t = t, dt
+        return best
 
 
 def maxpool3x3s2(x, out=None):
@@ -117,7 +197,7 @@ def maxpool3x3s2(x, out=None):
     oh, ow = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if out is None:
         out = torch.empty(B, oh, ow, C, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), prof("maxpool3x3s2"):
         rc = _lib.load().sgv3d_maxpool3x3s2(B, H, W, C, x.data_ptr(), out.data_ptr(), _st(x))
     _lib.check(rc, "sgv3d_maxpool3x3s2")
     return out
@@ -129,7 +209,7 @@ def nchw_to_nhwc(x, c_pad=None, out=None):
     c_pad = int(c_pad or C)
     if out is None:
         out = torch.empty(B, H, W, c_pad, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), prof("nchw_to_nhwc"):
         rc = _lib.load().sgv3d_nchw_to_nhwc(B, C, H, W, c_pad, x.data_ptr(), out.data_ptr(), _st(x))
     _lib.check(rc, "sgv3d_nchw_to_nhwc")
     return out
@@ -140,7 +220,7 @@ def nhwc_to_nchw(x, channels=None, coff=0, out=None):
     C = int(channels or ld)
     if out is None:
         out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), prof("nhwc_to_nchw"):
         rc = _lib.load().sgv3d_nhwc_to_nchw(B, C, H, W, ld, int(coff), x.data_ptr(), out.data_ptr(), _st(x))
     _lib.check(rc, "sgv3d_nhwc_to_nchw")
     return out
@@ -150,7 +230,7 @@ def global_avgpool(x, out=None):
     B, H, W, C = (int(s) for s in x.shape)
     if out is None:
         out = torch.empty(B, C, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), prof("global_avgpool"):
         rc = _lib.load().sgv3d_global_avgpool(B, H * W, C, C, x.data_ptr(), out.data_ptr(), _st(x))
     _lib.check(rc, "sgv3d_global_avgpool")
     return out
@@ -166,7 +246,7 @@ def dense(x, w, scale=None, bias=None, act=ACT_NONE, out=None):
     assert int(w.shape[1]) == K and x.is_contiguous() and w.is_contiguous()
     if out is None:
         out = torch.empty(B, N, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), prof("dense"):
         rc = _lib.load().sgv3d_dense(B, K, N, x.data_ptr(), w.data_ptr(), _lib.ptr(scale), _lib.ptr(bias),
                                     int(act), out.data_ptr(), _st(x))
     _lib.check(rc, "sgv3d_dense")
@@ -177,9 +257,32 @@ def broadcast_channels(v, out, y_coff=0):
     """v [B,C] written to out[b, :, :, y_coff:y_coff+C] for every pixel (out NHWC)."""
     B, H, W, ld = (int(s) for s in out.shape)
     C = int(v.shape[1])
-    with torch.cuda.device(out.device):
+    with torch.cuda.device(out.device), prof("broadcast_channels"):
         rc = _lib.load().sgv3d_broadcast_channels(B, H * W, C, ld, int(y_coff), v.data_ptr(), out.data_ptr(), _st(out))
     _lib.check(rc, "sgv3d_broadcast_channels")
+    return out
+
+
+def scale_channels(x, gate, out=None):
+    """x NHWC [B,H,W,C] * gate [B,C] (SELayer gating)."""
+    B, H, W, C = (int(s) for s in x.shape)
+    assert tuple(gate.shape) == (B, C) and x.is_contiguous() and gate.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    with torch.cuda.device(x.device), prof("scale_channels"):
+        rc = _lib.load().sgv3d_scale_channels(B, H * W, C, x.data_ptr(), gate.data_ptr(), out.data_ptr(), _st(x))
+    _lib.check(rc, "sgv3d_scale_channels")
+    return out
+
+
+def copy_channels(x, out, coff=0):
+    """out[B,H,W,C] (contiguous) = x[B,H,W,coff:coff+C]."""
+    B, H, W, ld = (int(s) for s in x.shape)
+    C = int(out.shape[-1])
+    assert out.is_contiguous() and out.numel() == B * H * W * C
+    with torch.cuda.device(x.device), prof("copy_channels"):
+        rc = _lib.load().sgv3d_copy_channels(B, H * W, C, ld, int(coff), x.data_ptr(), out.data_ptr(), _st(x))
+    _lib.check(rc, "sgv3d_copy_channels")
     return out
 
 
@@ -188,7 +291,7 @@ def deform_im2col3x3(x, offset, groups, out=None):
     B, H, W, C = (int(s) for s in x.shape)
     if out is None:
         out = torch.empty(B, H, W, 9 * C, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), prof("deform_im2col3x3"):
         rc = _lib.load().sgv3d_deform_im2col3x3(B, H, W, C, int(groups), x.data_ptr(), offset.data_ptr(),
                                                int(offset.shape[-1]), out.data_ptr(), _st(x))
     _lib.check(rc, "sgv3d_deform_im2col3x3")
@@ -202,7 +305,7 @@ def head_final_conv(hidden, weight, bias, branch_of_out, num_branches, hidden_ch
     total = int(weight.shape[0])
     if out is None:
         out = torch.empty(B, total, H, W, dtype=torch.float32, device=hidden.device)
-    with torch.cuda.device(hidden.device):
+    with torch.cuda.device(hidden.device), prof("head_final_conv", 2.0 * B * H * W * total * 9 * hidden_ch):
         rc = _lib.load().sgv3d_head_final_conv(B, H, W, int(num_branches), int(hidden_ch), total,
                                               hidden.data_ptr(), weight.data_ptr(), bias.data_ptr(),
                                               branch_of_out.data_ptr(), out.data_ptr(), _st(hidden))
@@ -217,7 +320,7 @@ def lift(height_context, D, C, want_prob=False, want_lifted=True):
     P = fH * fW
     prob = torch.empty(B, D, P, dtype=torch.float32, device=height_context.device) if want_prob else None
     lifted = torch.empty(B, D, P, C, dtype=torch.float32, device=height_context.device) if want_lifted else None
-    with torch.cuda.device(height_context.device):
+    with torch.cuda.device(height_context.device), prof("lift"):
         rc = _lib.load().sgv3d_lift(B, P, D, C, height_context.data_ptr(), _lib.ptr(prob), _lib.ptr(lifted),
                                    _st(height_context))
     _lib.check(rc, "sgv3d_lift")

@@ -1,0 +1,413 @@
+"""``LSSFPN`` — BEVHeight view transform (image backbone + neck, HeightNet, lift, geometry, voxel
+pooling) on MI355X.
+
+Mirror of the reference module surface, layers/backbones/lss_fpn.py:
+``LSSFPN(x_bound, y_bound, z_bound, d_bound, final_dim, output_channels, downsample_factor,
+img_backbone_conf, img_neck_conf, height_net_conf, is_train_height, is_bsm=False)`` (:254-256),
+``.forward(sweep_imgs, mats_dict, timestamps=None)`` (:497-550), buffers ``voxel_size / voxel_coord /
+voxel_num / frustum`` (:281-293) and the sub-module / parameter names of SURVEY.md Appendix C, so
+Lightning checkpoints of the reference load by name.
+
+The modules hold parameters; the forward runs hand-written gfx950 kernels through the C ABI:
+  image [B,1,1,3,H,W] -> NHWC ingest -> ResNet + SECONDFPN (MFMA implicit-GEMM convs, BN/ReLU/residual
+  in the epilogue, concat by channel-slice writes) -> HeightNet (camera-aware SE gates, BasicBlocks,
+  ASPP, DCNv1, 1x1 heads) -> lift (softmax (x) context) -> geometry (bit-exact voxel indices) ->
+  voxel pooling -> BEV NHWC.
+There is no CPU / eager fallback: a CPU tensor or training mode raises.
+"""
+import ctypes
+
+import numpy as np
+import torch
+from torch import nn
+
+from ... import _lib, hip_ops
+from ...hip_ops import PackedConv, fold_bn
+from ...ops.voxel_pooling import VoxelPlan, voxel_pooling
+from ..blocks import BasicBlock, HipModule, build_backbone, build_neck, conv_bn
+
+__all__ = ['LSSFPN']
+
+
+class _ASPPModule(HipModule):
+    """lss_fpn.py:18-46"""
+
+    def __init__(self, inplanes, planes, kernel_size, padding, dilation, BatchNorm):
+        super().__init__()
+        self.atrous_conv = nn.Conv2d(inplanes, planes, kernel_size=kernel_size, stride=1, padding=padding,
+                                     dilation=dilation, bias=False)
+        self.bn = BatchNorm(planes)
+        self.relu = nn.ReLU()
+        torch.nn.init.kaiming_normal_(self.atrous_conv.weight)
+
+    def hip_compile(self, device):
+        return conv_bn(self.atrous_conv, self.bn, True, device)
+
+
+class ASPP(HipModule):
+    """lss_fpn.py:49-119.  The five branches write straight into their channel slice of one
+    [B,H,W,5*mid] buffer; the pooled branch is a per-image vector broadcast (bilinear upsampling of a
+    1x1 map with align_corners=True is a constant, :101-104)."""
+
+    def __init__(self, inplanes, mid_channels=256, BatchNorm=nn.BatchNorm2d):
+        super().__init__()
+        dilations = [1, 6, 12, 18]
+        self.aspp1 = _ASPPModule(inplanes, mid_channels, 1, padding=0, dilation=dilations[0], BatchNorm=BatchNorm)
+        self.aspp2 = _ASPPModule(inplanes, mid_channels, 3, padding=dilations[1], dilation=dilations[1], BatchNorm=BatchNorm)
+        self.aspp3 = _ASPPModule(inplanes, mid_channels, 3, padding=dilations[2], dilation=dilations[2], BatchNorm=BatchNorm)
+        self.aspp4 = _ASPPModule(inplanes, mid_channels, 3, padding=dilations[3], dilation=dilations[3], BatchNorm=BatchNorm)
+        self.global_avg_pool = nn.Sequential(
+            nn.AdaptiveAvgPool2d((1, 1)),
+            nn.Conv2d(inplanes, mid_channels, 1, stride=1, bias=False),
+            BatchNorm(mid_channels),
+            nn.ReLU(),
+        )
+        self.conv1 = nn.Conv2d(int(mid_channels * 5), mid_channels, 1, bias=False)
+        self.bn1 = BatchNorm(mid_channels)
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout(0.5)
+        self.mid_channels = mid_channels
+        for m in (self.global_avg_pool[1], self.conv1):
+            torch.nn.init.kaiming_normal_(m.weight)
+
+    def hip_compile(self, device):
+        gscale, gshift = fold_bn(self.global_avg_pool[2])
+        return dict(
+            gap_w=self.global_avg_pool[1].weight.detach().reshape(self.mid_channels, -1).to(device).float().contiguous(),
+            gap_scale=gscale.to(device), gap_shift=gshift.to(device),
+            conv1=conv_bn(self.conv1, self.bn1, True, device))
+
+    def hip_forward(self, x):
+        s = self.hip_state(x.device)
+        B, H, W, _ = x.shape
+        mid = self.mid_channels
+        cat = torch.empty(B, H, W, 5 * mid, dtype=torch.float32, device=x.device)
+        for i, m in enumerate((self.aspp1, self.aspp2, self.aspp3, self.aspp4)):
+            m.hip_state(x.device)(x, cat, y_coff=i * mid)
+        pooled = hip_ops.global_avgpool(x)
+        x5 = hip_ops.dense(pooled, s['gap_w'], s['gap_scale'], s['gap_shift'], hip_ops.ACT_RELU)
+        hip_ops.broadcast_channels(x5, cat, y_coff=4 * mid)
+        return s['conv1'](cat)          # Dropout(0.5) is the identity in eval mode (:111)
+
+
+class Mlp(nn.Module):
+    """lss_fpn.py:122-144 (parameter holder; evaluated with the dense kernel)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.ReLU, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.drop1 = nn.Dropout(drop)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop2 = nn.Dropout(drop)
+
+
+class SELayer(nn.Module):
+    """lss_fpn.py:147-159 (parameter holder)."""
+
+    def __init__(self, channels, act_layer=nn.ReLU, gate_layer=nn.Sigmoid):
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(channels, channels, 1, bias=True)
+        self.act1 = act_layer()
+        self.conv_expand = nn.Conv2d(channels, channels, 1, bias=True)
+        self.gate = gate_layer()
+
+
+class DCN(HipModule):
+    """mmcv 1.4.0 ``DeformConv2dPack`` as configured at lss_fpn.py:190-198 (3x3, pad 1, groups 4,
+    deform_groups 1, no bias): ``conv_offset`` (zero-initialised 3x3 conv, 18 channels) predicts the
+    sampling offsets, then a deformable bilinear im2col feeds one grouped GEMM per group."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, padding=1, groups=1, deform_groups=1,
+                 stride=1, dilation=1, im2col_step=32, **unused):
+        super().__init__()
+        assert kernel_size == 3 and padding == 1 and stride == 1 and dilation == 1 and deform_groups == 1
+        assert in_channels % groups == 0 and out_channels % groups == 0
+        self.in_channels, self.out_channels, self.groups = in_channels, out_channels, groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, 3, 3))
+        nn.init.kaiming_uniform_(self.weight, nonlinearity='relu')
+        self.conv_offset = nn.Conv2d(in_channels, deform_groups * 2 * 9, kernel_size=3, stride=1, padding=1, bias=True)
+        nn.init.zeros_(self.conv_offset.weight)
+        nn.init.zeros_(self.conv_offset.bias)
+
+    def hip_compile(self, device):
+        g = self.groups
+        opg, cpg = self.out_channels // g, self.in_channels // g
+        convs = []
+        for gi in range(g):
+            wg = self.weight.detach()[gi * opg:(gi + 1) * opg]                   # [opg, cpg, 3, 3]
+            wg = wg.permute(0, 2, 3, 1).reshape(opg, 9 * cpg, 1, 1).contiguous()   # k = (tap, c)
+            convs.append(PackedConv(wg, device=device))
+        return dict(offset=conv_bn(self.conv_offset, None, False, device), convs=convs, opg=opg, cpg=cpg)
+
+    def hip_forward(self, x):
+        s = self.hip_state(x.device)
+        B, H, W, C = x.shape
+        offset = s['offset'](x)                                     # [B,H,W,18]
+        col = hip_ops.deform_im2col3x3(x, offset, self.groups)      # [B,H,W,g*9*cpg]
+        out = torch.empty(B, H, W, self.out_channels, dtype=torch.float32, device=x.device)
+        for gi, conv in enumerate(s['convs']):
+            conv(col, out, x_coff=gi * 9 * s['cpg'], y_coff=gi * s['opg'])
+        return out
+
+
+class HeightNet(HipModule):
+    """lss_fpn.py:162-250"""
+
+    def __init__(self, in_channels, mid_channels, context_channels, height_channels):
+        super().__init__()
+        self.reduce_conv = nn.Sequential(
+            nn.Conv2d(in_channels, mid_channels, kernel_size=3, stride=1, padding=1),
+            nn.BatchNorm2d(mid_channels),
+            nn.ReLU(inplace=True),
+        )
+        self.context_conv = nn.Conv2d(mid_channels, context_channels, kernel_size=1, stride=1, padding=0)
+        self.bn = nn.BatchNorm1d(27)
+        self.height_mlp = Mlp(27, mid_channels, mid_channels)
+        self.height_se = SELayer(mid_channels)  # NOTE: add camera-aware
+        self.context_mlp = Mlp(27, mid_channels, mid_channels)
+        self.context_se = SELayer(mid_channels)  # NOTE: add camera-aware
+        self.height_conv = nn.Sequential(
+            BasicBlock(mid_channels, mid_channels),
+            BasicBlock(mid_channels, mid_channels),
+            BasicBlock(mid_channels, mid_channels),
+            ASPP(mid_channels, mid_channels),
+            DCN(in_channels=mid_channels, out_channels=mid_channels, kernel_size=3, padding=1, groups=4,
+                im2col_step=128),
+        )
+        self.height_layer = nn.Conv2d(mid_channels, height_channels, kernel_size=1, stride=1, padding=0)
+        self.mid_channels = mid_channels
+        self.context_channels = context_channels
+        self.height_channels = height_channels
+
+    def hip_compile(self, device):
+        f = lambda t: t.detach().to(device).float().contiguous()
+        bn = self.bn
+        inv = torch.rsqrt(bn.running_var.float() + bn.eps)
+        bn_scale = (bn.weight.float() * inv).detach()
+        bn_shift = (bn.bias.float() - bn.running_mean.float() * bn.weight.float() * inv).detach()
+        s = dict(reduce=conv_bn(self.reduce_conv[0], self.reduce_conv[1], True, device),
+                 context=conv_bn(self.context_conv, None, False, device),
+                 height=conv_bn(self.height_layer, None, False, device),
+                 bn_scale=f(bn_scale), bn_shift=f(bn_shift))
+        for name in ('height', 'context'):
+            mlp, se = getattr(self, name + '_mlp'), getattr(self, name + '_se')
+            s[name + '_gate'] = [
+                (f(mlp.fc1.weight), f(mlp.fc1.bias), hip_ops.ACT_RELU),
+                (f(mlp.fc2.weight), f(mlp.fc2.bias), hip_ops.ACT_NONE),
+                (f(se.conv_reduce.weight.reshape(self.mid_channels, -1)), f(se.conv_reduce.bias), hip_ops.ACT_RELU),
+                (f(se.conv_expand.weight.reshape(self.mid_channels, -1)), f(se.conv_expand.bias), hip_ops.ACT_SIGMOID),
+            ]
+        return s
+
+    @staticmethod
+    def mlp_input(mats_dict):
+        """The 27-vector per camera, lss_fpn.py:208-240 (pure indexing: torch views on the device)."""
+        intrins = mats_dict['intrin_mats'][:, 0:1, ..., :3, :3]
+        batch_size = intrins.shape[0]
+        num_cams = intrins.shape[2]
+        ida = mats_dict['ida_mats'][:, 0:1, ...]
+        sensor2ego = mats_dict['sensor2ego_mats'][:, 0:1, ..., :3, :]
+        bda = mats_dict['bda_mat'].view(batch_size, 1, 1, 4, 4).repeat(1, 1, num_cams, 1, 1)
+        mlp_input = torch.cat(
+            [
+                torch.stack(
+                    [
+                        intrins[:, 0:1, ..., 0, 0], intrins[:, 0:1, ..., 1, 1],
+                        intrins[:, 0:1, ..., 0, 2], intrins[:, 0:1, ..., 1, 2],
+                        ida[:, 0:1, ..., 0, 0], ida[:, 0:1, ..., 0, 1], ida[:, 0:1, ..., 0, 3],
+                        ida[:, 0:1, ..., 1, 0], ida[:, 0:1, ..., 1, 1], ida[:, 0:1, ..., 1, 3],
+                        bda[:, 0:1, ..., 0, 0], bda[:, 0:1, ..., 0, 1], bda[:, 0:1, ..., 1, 0],
+                        bda[:, 0:1, ..., 1, 1], bda[:, 0:1, ..., 2, 2],
+                    ],
+                    dim=-1,
+                ),
+                sensor2ego.view(batch_size, 1, num_cams, -1),
+            ],
+            -1,
+        )
+        return mlp_input.reshape(-1, mlp_input.shape[-1]).float().contiguous()
+
+    def hip_forward(self, x, mats_dict):
+        """x NHWC [B*N,fH,fW,in] -> NHWC [B*N,fH,fW,D+C] = cat(height logits, context)  (:250)."""
+        s = self.hip_state(x.device)
+        B, H, W, _ = x.shape
+        v = self.mlp_input(mats_dict)                                                   # [B*N, 27]
+        # BatchNorm1d(27) in eval mode is a per-feature affine: folded once into fc1
+        # (W' = W * scale, b' = b + W @ shift).
+        gates = {}
+        for name in ('context', 'height'):
+            fc1_w, fc1_b, _ = s[name + '_gate'][0]
+            key = name + '_fc1_folded'
+            if key not in s:
+                s[key] = ((fc1_w * s['bn_scale'][None, :]).contiguous(),
+                          (fc1_b + fc1_w @ s['bn_shift']).contiguous())
+            h = hip_ops.dense(v, s[key][0], None, s[key][1], hip_ops.ACT_RELU)
+            for w, b, act in s[name + '_gate'][1:]:
+                h = hip_ops.dense(h, w, None, b, act)
+            gates[name] = h                                                             # sigmoid gate [B*N, mid]
+        x = s['reduce'](x)                                                              # :241
+        out = torch.empty(B, H, W, self.height_channels + self.context_channels, dtype=torch.float32, device=x.device)
+        ctx_in = hip_ops.scale_channels(x, gates['context'])                           # SELayer, :155-159
+        s['context'](ctx_in, out, y_coff=self.height_channels)                         # :242-244
+        h = hip_ops.scale_channels(x, gates['height'])                                  # :245-246
+        for blk in self.height_conv:
+            h = blk.hip_forward(h)                                                      # :247
+        s['height'](h, out, y_coff=0)                                                   # :248
+        return out
+
+
+class LSSFPN(HipModule):
+    def __init__(self, x_bound, y_bound, z_bound, d_bound, final_dim, output_channels, downsample_factor,
+                 img_backbone_conf, img_neck_conf, height_net_conf, is_train_height, is_bsm=False):
+        """Same arguments as the reference (lss_fpn.py:254-273)."""
+        super().__init__()
+        self.downsample_factor = downsample_factor
+        self.d_bound = d_bound
+        self.final_dim = final_dim
+        self.output_channels = output_channels
+        self.is_train_height = is_train_height
+
+        self.register_buffer('voxel_size', torch.Tensor([row[2] for row in [x_bound, y_bound, z_bound]]))
+        self.register_buffer('voxel_coord',
+                             torch.Tensor([row[0] + row[2] / 2.0 for row in [x_bound, y_bound, z_bound]]))
+        # the reference truncates a python-float quotient (lss_fpn.py:289-292); every shipped bound
+        # divides exactly, a quotient landing at k - eps would silently lose a row => round and assert
+        nums = [(row[1] - row[0]) / row[2] for row in [x_bound, y_bound, z_bound]]
+        for q in nums:
+            assert abs(q - round(q)) < 1e-6, f"voxel bound does not divide evenly: {q}"
+        self.register_buffer('voxel_num', torch.LongTensor([int(round(q)) for q in nums]))
+        self.register_buffer('frustum', self.create_frustum())
+        self.height_channels, _, _, _ = self.frustum.shape
+
+        self.img_backbone = build_backbone(img_backbone_conf)
+        self.img_neck = build_neck(img_neck_conf)
+        self.img_neck.init_weights()
+        self.img_backbone.init_weights()
+        self.height_net = self._configure_height_net(height_net_conf)
+        self.assist_layer = nn.Conv2d(512, 256, kernel_size=1, stride=1, padding=0)
+        # host copies of the (static) voxel grid for the kernel launches: no device->host sync per call
+        self._voxel_num_host = tuple(int(round(q)) for q in nums)
+        self._voxel_coord_host = [float(np.float32(row[0] + row[2] / 2.0)) for row in [x_bound, y_bound, z_bound]]
+        self._voxel_size_host = [float(np.float32(row[2])) for row in [x_bound, y_bound, z_bound]]
+        self.fuse_lift_splat = False    # True: skip the [B,N,C] lifted tensor
+
+    def _configure_height_net(self, height_net_conf):
+        return HeightNet(height_net_conf['in_channels'], height_net_conf['mid_channels'], self.output_channels,
+                         self.height_channels)
+
+    def create_frustum(self):
+        """lss_fpn.py:325-348 (init-time, host)."""
+        ogfH, ogfW = self.final_dim
+        fH, fW = ogfH // self.downsample_factor, ogfW // self.downsample_factor
+        alpha = 1.5
+        d_coords = np.arange(self.d_bound[2]) / self.d_bound[2]
+        d_coords = np.power(d_coords, alpha)
+        d_coords = self.d_bound[0] + d_coords * (self.d_bound[1] - self.d_bound[0])
+        d_coords = torch.tensor(d_coords, dtype=torch.float).view(-1, 1, 1).expand(-1, fH, fW)
+        D, _, _ = d_coords.shape
+        x_coords = torch.linspace(0, ogfW - 1, fW, dtype=torch.float).view(1, 1, fW).expand(D, fH, fW)
+        y_coords = torch.linspace(0, ogfH - 1, fH, dtype=torch.float).view(1, fH, 1).expand(D, fH, fW)
+        paddings = torch.ones_like(d_coords)
+        return torch.stack((x_coords, y_coords, d_coords, paddings), -1)
+
+    # -------------------------------------------------------------------------------- geometry
+    def get_geometry_voxel_index(self, sensor2ego_mat, sensor2virtual_mat, intrin_mat, ida_mat,
+                                 reference_heights, bda_mat, want_float=False):
+        """get_geometry (lss_fpn.py:372-401) fused with the quantise of :487-488.
+        Inputs [B, num_cams, 4, 4] / [B, num_cams] / [B, 4, 4] on the device.
+        Returns int32 [B, num_cams, D, fH, fW, 3] (and the float points when asked)."""
+        lib = _lib.load()
+        B, num_cams = int(sensor2ego_mat.shape[0]), int(sensor2ego_mat.shape[1])
+        n = B * num_cams
+        dev = sensor2ego_mat.device
+        c = lambda t: t.reshape(n, 4, 4).float().contiguous()
+        s2e, s2v, K, ida = c(sensor2ego_mat), c(sensor2virtual_mat), c(intrin_mat), c(ida_mat)
+        refh = reference_heights.reshape(n).float().contiguous()
+        bda = bda_mat.reshape(B, 4, 4).float().contiguous() if bda_mat is not None else None
+        D, fH, fW, _ = (int(v) for v in self.frustum.shape)
+        prep = torch.empty(n, 3, 4, 4, dtype=torch.float32, device=dev)
+        geom = torch.empty(B, num_cams, D, fH, fW, 3, dtype=torch.int32, device=dev)
+        geom_f = torch.empty(B, num_cams, D, fH, fW, 3, dtype=torch.float32, device=dev) if want_float else None
+        frustum = self.frustum if self.frustum.is_contiguous() else self.frustum.contiguous()
+        vc = (ctypes.c_float * 3)(*self._voxel_coord_host)
+        vs = (ctypes.c_float * 3)(*self._voxel_size_host)
+        with torch.cuda.device(dev), hip_ops.prof("geometry"):
+            st = _lib.stream_handle(dev)
+            _lib.check(lib.sgv3d_calib_prep(n, s2e.data_ptr(), s2v.data_ptr(), K.data_ptr(), ida.data_ptr(),
+                                            prep.data_ptr(), st), "sgv3d_calib_prep")
+            _lib.check(lib.sgv3d_geometry_voxel_index(n, num_cams, D, fH, fW, frustum.data_ptr(), prep.data_ptr(),
+                                                      refh.data_ptr(), _lib.ptr(bda), vc, vs, geom.data_ptr(),
+                                                      _lib.ptr(geom_f), st), "sgv3d_geometry_voxel_index")
+        return (geom, geom_f) if want_float else geom
+
+    # -------------------------------------------------------------------------------- features
+    def get_cam_feats_nhwc(self, imgs):
+        """get_cam_feats (lss_fpn.py:403-414): [B,S,N,3,H,W] -> NHWC [B*S*N, fH, fW, 512]."""
+        batch_size, num_sweeps, num_cams, num_channels, imH, imW = imgs.shape
+        imgs = imgs.reshape(batch_size * num_sweeps * num_cams, num_channels, imH, imW).float().contiguous()
+        cin_pad = self.img_backbone.hip_state(imgs.device)['cin_pad']
+        x = hip_ops.nchw_to_nhwc(imgs, c_pad=cin_pad)
+        feats = self.img_backbone.hip_forward(x)
+        return self.img_neck.hip_forward(feats)
+
+    def _forward_single_sweep(self, sweep_index, sweep_imgs, mats_dict, nhwc_out=False):
+        """lss_fpn.py:422-495.  Returns the BEV map [B, C, Y, X] (NHWC buffer [B,Y,X,C] when
+        ``nhwc_out``: the hand-off BEVHeight uses towards the head)."""
+        batch_size, num_sweeps, num_cams, num_channels, img_height, img_width = sweep_imgs.shape
+        source_features = self.get_cam_feats_nhwc(sweep_imgs)                 # [B*N, fH, fW, 512]
+        # assist_layer (:459) only feeds the is_train_height branch (:493-494); in eval its result is
+        # discarded by the reference, so it is not computed here.
+        height_feature = self.height_net.hip_forward(source_features, mats_dict)   # [B*N,fH,fW,D+C]
+        D, C = self.height_channels, self.output_channels
+        geom_xyz = self.get_geometry_voxel_index(
+            mats_dict['sensor2ego_mats'][:, sweep_index, ...],
+            mats_dict['sensor2virtual_mats'][:, sweep_index, ...],
+            mats_dict['intrin_mats'][:, sweep_index, ...],
+            mats_dict['ida_mats'][:, sweep_index, ...],
+            mats_dict['reference_heights'][:, sweep_index, ...],
+            mats_dict.get('bda_mat', None),
+        )                                                                      # int32 [B,N,D,fH,fW,3]
+        fH, fW = int(height_feature.shape[1]), int(height_feature.shape[2])
+        if self.fuse_lift_splat:
+            prob, _ = hip_ops.lift(height_feature, D, C, want_prob=True, want_lifted=False)
+            assert num_cams == 1, "fused lift-splat is implemented for one camera per sample"
+            ctx = torch.empty(batch_size, fH * fW, C, dtype=torch.float32, device=height_feature.device)
+            hip_ops.copy_channels(height_feature, ctx.view(batch_size, fH, fW, C), coff=D)
+            plan = VoxelPlan(geom_xyz.reshape(batch_size, -1, 3), self._voxel_num_host)
+            bev = plan.lift_splat(prob, ctx)                                   # [B,Y,X,C]
+            feature_map = bev.permute(0, 3, 1, 2)
+        else:
+            _, lifted = hip_ops.lift(height_feature, D, C)                     # [B*N, D, fH*fW, C]
+            img_feat_with_height = lifted.view(batch_size, num_cams, D, fH, fW, C)   # == :486 permute + contiguous
+            feature_map = voxel_pooling(geom_xyz, img_feat_with_height, self._voxel_num_host)   # :490-491
+        if nhwc_out:
+            return feature_map.permute(0, 2, 3, 1)                             # the NHWC buffer itself
+        return hip_ops.nhwc_to_nchw(feature_map.permute(0, 2, 3, 1))           # .contiguous() of :495
+
+    def forward(self, sweep_imgs, mats_dict, timestamps=None, nhwc_out=False):
+        """lss_fpn.py:497-550 (inference)."""
+        _require_hip_inference(self, sweep_imgs)
+        batch_size, num_sweeps, num_cams, num_channels, img_height, img_width = sweep_imgs.shape
+        key_frame_res = self._forward_single_sweep(0, sweep_imgs[:, 0:1, ...], mats_dict, nhwc_out=nhwc_out)
+        if num_sweeps == 1:
+            return key_frame_res
+        ret_feature_list = [key_frame_res]
+        for sweep_index in range(1, num_sweeps):
+            ret_feature_list.append(self._forward_single_sweep(
+                sweep_index, sweep_imgs[:, sweep_index:sweep_index + 1, ...], mats_dict, nhwc_out=nhwc_out))
+        return torch.cat(ret_feature_list, 3 if nhwc_out else 1)
+
+    def hip_compile(self, device):
+        return {}
+
+
+def _require_hip_inference(module, x):
+    if not x.is_cuda:
+        raise RuntimeError("sgv3d_amd runs on the MI355X only: got a CPU tensor and there is no CPU fallback "
+                           "(the CPU restatement lives in oracle/ and is test infrastructure)")
+    if module.training:
+        raise NotImplementedError("the HIP path implements the inference forward (call model.eval()); the "
+                                  "training step is SURVEY.md §8(f) rank 2 and is not built yet")

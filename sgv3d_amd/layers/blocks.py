@@ -1,0 +1,289 @@
+"""Building blocks the reference pulls from third-party packages, re-created here as parameter
+containers with the SAME constructor configs and state_dict names, plus a HIP forward.
+
+Reference call sites: ``build_backbone(img_backbone_conf)`` / ``build_neck(img_neck_conf)``
+(layers/backbones/lss_fpn.py:296-297), ``BasicBlock`` (lss_fpn.py:186-188), ``build_backbone(
+bev_backbone_conf)`` / ``build_neck(bev_neck_conf)`` (layers/heads/bev_height_head.py:75-78).
+Upstream definitions followed: mmdet 2.19.0 ``ResNet`` / ``BasicBlock`` / ``Bottleneck``
+(style='pytorch'), mmdet3d 0.18.1 ``SECONDFPN``.
+
+The ``torch.nn`` leaf modules (Conv2d, BatchNorm2d, ...) are used only as parameter/buffer holders so
+that Lightning checkpoints load by name; arithmetic runs in ``hip_forward`` through the C ABI on
+NHWC float32 buffers.  BatchNorm is the eval-mode affine (running statistics) folded into the
+convolution epilogue.
+"""
+import torch
+from torch import nn
+
+from .. import hip_ops
+from ..hip_ops import PackedConv, fold_bn
+
+
+def _kaiming_(m):
+    if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+        nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+    elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+        nn.init.ones_(m.weight)
+        nn.init.zeros_(m.bias)
+
+
+class HipModule(nn.Module):
+    """nn.Module whose packed HIP state (repacked weights, folded BN) is built lazily per device."""
+
+    def __init__(self):
+        super().__init__()
+        self._hip = None
+
+    def hip_state(self, device):
+        if self._hip is None or self._hip[0] != device:
+            self._hip = (device, self.hip_compile(device))
+        return self._hip[1]
+
+    def hip_invalidate(self):
+        self._hip = None
+        for m in self.children():
+            if isinstance(m, HipModule):
+                m.hip_invalidate()
+            else:
+                for sub in m.modules():
+                    if isinstance(sub, HipModule):
+                        sub.hip_invalidate()
+
+    def hip_compile(self, device):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+
+def conv_bn(conv, bn=None, relu=False, device=None, cin_pad=None):
+    """PackedConv of an nn.Conv2d (+ optional eval BatchNorm2d folded, + ReLU)."""
+    assert conv.groups == 1
+    k = conv.kernel_size[0]
+    assert conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1]
+    if bn is not None:
+        scale, shift = fold_bn(bn, conv.bias)
+    else:
+        scale, shift = None, (conv.bias.detach() if conv.bias is not None else None)
+    return PackedConv(conv.weight, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0],
+                      scale=scale, shift=shift, relu=relu, device=device, cin_pad=cin_pad)
+
+
+# ------------------------------------------------------------------------------------------------
+# mmdet ResNet family
+# ------------------------------------------------------------------------------------------------
+class BasicBlock(HipModule):
+    """mmdet.models.backbones.resnet.BasicBlock: conv3x3-BN-ReLU-conv3x3-BN, + identity, ReLU."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def hip_compile(self, device):
+        s = dict(c1=conv_bn(self.conv1, self.bn1, True, device), c2=conv_bn(self.conv2, self.bn2, True, device))
+        if self.downsample is not None:
+            s['ds'] = conv_bn(self.downsample[0], self.downsample[1], False, device)
+        return s
+
+    def hip_forward(self, x):
+        s = self.hip_state(x.device)
+        identity = s['ds'](x) if 'ds' in s else x
+        out = s['c1'](x)
+        return s['c2'](out, residual=identity)      # relu(bn2(conv2) + identity)
+
+
+class Bottleneck(HipModule):
+    """mmdet Bottleneck, style='pytorch' (the stride sits on the 3x3)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def hip_compile(self, device):
+        s = dict(c1=conv_bn(self.conv1, self.bn1, True, device), c2=conv_bn(self.conv2, self.bn2, True, device),
+                 c3=conv_bn(self.conv3, self.bn3, True, device))
+        if self.downsample is not None:
+            s['ds'] = conv_bn(self.downsample[0], self.downsample[1], False, device)
+        return s
+
+    def hip_forward(self, x):
+        s = self.hip_state(x.device)
+        identity = s['ds'](x) if 'ds' in s else x
+        out = s['c2'](s['c1'](x))
+        return s['c3'](out, residual=identity)
+
+
+class ResNet(HipModule):
+    """mmdet 2.19.0 ``ResNet`` (deep_stem=False, avg_down=False, style='pytorch', no DCN/plugins).
+
+    Accepts the config dicts of the reference verbatim, e.g.
+    ``dict(type='ResNet', depth=50, frozen_stages=0, out_indices=[0,1,2,3], norm_eval=False,
+    init_cfg=...)`` (exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:44-52) and
+    ``dict(type='ResNet', in_channels=80, depth=18, num_stages=3, strides=(1,2,2), dilations=(1,1,1),
+    out_indices=[0,1,2], norm_eval=False, base_channels=160)`` (:77-87).
+    """
+    arch_settings = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)),
+                     50: (Bottleneck, (3, 4, 6, 3)), 101: (Bottleneck, (3, 4, 23, 3)),
+                     152: (Bottleneck, (3, 8, 36, 3))}
+
+    def __init__(self, depth, in_channels=3, stem_channels=None, base_channels=64, num_stages=4,
+                 strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), style='pytorch',
+                 deep_stem=False, avg_down=False, frozen_stages=-1, norm_eval=True, init_cfg=None,
+                 pretrained=None, **unused):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError(f'invalid depth {depth} for resnet')
+        assert style == 'pytorch' and not deep_stem and not avg_down
+        assert all(d == 1 for d in dilations[:num_stages])
+        block, stage_blocks = self.arch_settings[depth]
+        self.depth = depth
+        self.deep_stem = deep_stem
+        self.out_indices = list(out_indices)
+        self.frozen_stages = frozen_stages
+        self.norm_eval = norm_eval
+        stem_channels = stem_channels or base_channels
+        self.in_channels = in_channels
+        self.conv1 = nn.Conv2d(in_channels, stem_channels, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(stem_channels)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.res_layers = []
+        inplanes = stem_channels
+        for i in range(num_stages):
+            planes = base_channels * 2 ** i
+            layers = []
+            for j in range(stage_blocks[i]):
+                stride = strides[i] if j == 0 else 1
+                downsample = None
+                if j == 0 and (stride != 1 or inplanes != planes * block.expansion):
+                    downsample = nn.Sequential(
+                        nn.Conv2d(inplanes, planes * block.expansion, 1, stride=stride, bias=False),
+                        nn.BatchNorm2d(planes * block.expansion))
+                layers.append(block(inplanes, planes, stride, downsample))
+                inplanes = planes * block.expansion
+            name = f'layer{i + 1}'
+            self.add_module(name, nn.Sequential(*layers))
+            self.res_layers.append(name)
+        self.feat_dim = inplanes
+
+    @property
+    def norm1(self):
+        return self.bn1
+
+    def init_weights(self):
+        """Kaiming / constant init (mmdet's fallback when no checkpoint is given; the reference asks
+        for torchvision weights, lss_fpn.py:299, which need network access and load by name)."""
+        for m in self.modules():
+            _kaiming_(m)
+        for m in self.modules():
+            if isinstance(m, Bottleneck):
+                nn.init.zeros_(m.bn3.weight)
+            elif isinstance(m, BasicBlock):
+                nn.init.zeros_(m.bn2.weight)
+
+    def hip_compile(self, device):
+        cin_pad = (self.in_channels + 3) // 4 * 4
+        return dict(stem=conv_bn(self.conv1, self.bn1, True, device, cin_pad=cin_pad), cin_pad=cin_pad)
+
+    def hip_stem(self, x_nhwc):
+        """conv1 + bn1 + relu on an NHWC input whose channels are already padded to a multiple of 4."""
+        return self.hip_state(x_nhwc.device)['stem'](x_nhwc)
+
+    def hip_forward(self, x_nhwc, use_maxpool=True):
+        x = self.hip_stem(x_nhwc)
+        if use_maxpool:
+            x = hip_ops.maxpool3x3s2(x)
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            for blk in getattr(self, name):
+                x = blk.hip_forward(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return outs
+
+
+class SECONDFPN(HipModule):
+    """mmdet3d 0.18.1 ``SECONDFPN``: per level ConvTranspose2d(k = s, stride s) for s >= 1, or
+    Conv2d(k = 1/s, stride 1/s) for s < 1; BN(eps=1e-3, momentum=0.01); ReLU; concat on channels.
+    Configs: exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:53-59 and :89-92."""
+
+    def __init__(self, in_channels=(128, 128, 256), out_channels=(256, 256, 256), upsample_strides=(1, 2, 4),
+                 norm_cfg=None, upsample_cfg=None, conv_cfg=None, use_conv_for_no_stride=False, init_cfg=None,
+                 **unused):
+        super().__init__()
+        assert len(out_channels) == len(upsample_strides) == len(in_channels)
+        norm_cfg = norm_cfg or dict(type='BN', eps=1e-3, momentum=0.01)
+        self.in_channels = list(in_channels)
+        self.out_channels = list(out_channels)
+        self.upsample_strides = list(upsample_strides)
+        deblocks = []
+        for i, oc in enumerate(out_channels):
+            stride = upsample_strides[i]
+            if stride > 1 or (stride == 1 and not use_conv_for_no_stride):
+                s = int(stride)
+                layer = nn.ConvTranspose2d(in_channels[i], oc, kernel_size=s, stride=s, bias=False)
+            else:
+                s = int(round(1 / stride))
+                layer = nn.Conv2d(in_channels[i], oc, kernel_size=s, stride=s, bias=False)
+            bn = nn.BatchNorm2d(oc, eps=norm_cfg.get('eps', 1e-3), momentum=norm_cfg.get('momentum', 0.01))
+            deblocks.append(nn.Sequential(layer, bn, nn.ReLU(inplace=True)))
+        self.deblocks = nn.ModuleList(deblocks)
+
+    def init_weights(self):
+        for m in self.modules():
+            _kaiming_(m)
+
+    def hip_compile(self, device):
+        convs = []
+        for blk in self.deblocks:
+            layer, bn = blk[0], blk[1]
+            scale, shift = fold_bn(bn)
+            if isinstance(layer, nn.ConvTranspose2d):
+                convs.append(PackedConv(layer.weight, stride=layer.stride[0], transposed=True, scale=scale,
+                                        shift=shift, relu=True, device=device))
+            else:
+                convs.append(PackedConv(layer.weight, stride=layer.stride[0], scale=scale, shift=shift, relu=True,
+                                        device=device))
+        return convs
+
+    def hip_forward(self, feats, out=None):
+        """feats: list of NHWC maps -> one NHWC map [B, H, W, sum(out_channels)] (levels written
+        straight into their channel slice: no torch.cat)."""
+        convs = self.hip_state(feats[0].device)
+        B, h0, w0, _ = feats[0].shape
+        oh, ow = convs[0].out_hw(int(h0), int(w0))
+        total = sum(self.out_channels)
+        if out is None:
+            out = torch.empty(B, oh, ow, total, dtype=torch.float32, device=feats[0].device)
+        off = 0
+        for conv, f, oc in zip(convs, feats, self.out_channels):
+            assert conv.out_hw(int(f.shape[1]), int(f.shape[2])) == (oh, ow), \
+                "SECONDFPN levels do not align (the reference's torch.cat would fail too)"
+            conv(f, out, y_coff=off)
+            off += oc
+        return out
+
+
+_BACKBONES = {'ResNet': ResNet}
+_NECKS = {'SECONDFPN': SECONDFPN}
+
+
+def build_backbone(cfg):
+    cfg = dict(cfg)
+    return _BACKBONES[cfg.pop('type')](**cfg)
+
+
+def build_neck(cfg):
+    cfg = dict(cfg)
+    return _NECKS[cfg.pop('type')](**cfg)

@@ -1,0 +1,204 @@
+"""``BEVHeightHead`` — CenterPoint head on the BEV map, MI355X forward.
+
+Mirror of layers/heads/bev_height_head.py:31-111 (constructor keywords and defaults :13-64, forward
+:85-111) on top of what the reference inherits from mmdet3d 0.18.1 ``CenterHead`` / ``SeparateHead``
+(SURVEY.md §2.2): ``shared_conv`` = Conv3x3(in_channels -> 64, no bias) + BN + ReLU, then per task a
+``SeparateHead`` whose branches ``reg, height, dim, rot, vel, heatmap`` are each
+Conv3x3(64 -> 64, no bias) + BN + ReLU followed by Conv3x3(64 -> c, bias) (heatmap bias -2.19).
+Parameter names: ``trunk.*``, ``neck.deblocks.*``, ``shared_conv.{conv,bn}``,
+``task_heads.{t}.{branch}.0.{conv,bn}``, ``task_heads.{t}.{branch}.1``.
+
+HIP forward ("CenterHead convs fused per scale"):
+  trunk (7x7 stem without max-pool, 3 BasicBlock stages) -> SECONDFPN into one 256-ch map ->
+  shared conv -> ONE 3x3 conv producing the 64-channel hidden maps of all 36 branches
+  (64 -> 36*64, the 36 first-layer convs share their input) -> ONE kernel for the 36 final 3x3
+  convs, writing a single NCHW [B, 70, H, W] buffer whose channel slices are the returned maps.
+Return structure is the reference's: ``tuple(task -> [dict(branch -> Tensor[B, c, H, W])])``.
+
+get_targets / loss / get_bboxes belong to the training and decode rows of SURVEY.md §8(f) and are
+not implemented in this round (they raise).
+"""
+import torch
+from torch import nn
+
+from ... import hip_ops
+from ...hip_ops import PackedConv, fold_bn
+from ..blocks import HipModule, build_backbone, build_neck, conv_bn
+
+__all__ = ['BEVHeightHead']
+
+bev_backbone_conf = dict(
+    type='ResNet',
+    in_channels=80,
+    depth=18,
+    num_stages=3,
+    strides=(1, 2, 2),
+    dilations=(1, 1, 1),
+    out_indices=[0, 1, 2],
+    norm_eval=False,
+    base_channels=160,
+)
+
+bev_neck_conf = dict(type='SECONDFPN',
+                     in_channels=[160, 320, 640],
+                     upsample_strides=[2, 4, 8],
+                     out_channels=[64, 64, 128])
+
+
+class ConvModule(nn.Module):
+    """mmcv ConvModule(conv -> bn -> relu) parameter holder with mmcv's attribute names."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, padding=0, bias=False):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, padding=padding, bias=bias)
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.activate = nn.ReLU(inplace=True)
+        nn.init.kaiming_normal_(self.conv.weight, mode='fan_out', nonlinearity='relu')
+
+
+class SeparateHead(nn.Module):
+    """mmdet3d 0.18.1 SeparateHead (parameter holder): one Sequential per branch."""
+
+    def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, init_bias=-2.19, **unused):
+        super().__init__()
+        self.heads = heads
+        self.init_bias = init_bias
+        for head in self.heads:
+            classes, num_conv = self.heads[head]
+            conv_layers = []
+            c_in = in_channels
+            for _ in range(num_conv - 1):
+                conv_layers.append(ConvModule(c_in, head_conv, final_kernel, padding=final_kernel // 2))
+                c_in = head_conv
+            conv_layers.append(nn.Conv2d(head_conv, classes, final_kernel, stride=1, padding=final_kernel // 2, bias=True))
+            self.__setattr__(head, nn.Sequential(*conv_layers))
+        self.init_weights()
+
+    def init_weights(self):
+        for head in self.heads:
+            if head == 'heatmap':
+                self.__getattr__(head)[-1].bias.data.fill_(self.init_bias)
+
+
+class BEVHeightHead(HipModule):
+    """Head for BEVHeight (see module docstring).  Keyword arguments as the reference,
+    layers/heads/bev_height_head.py:46-64."""
+
+    def __init__(
+        self,
+        in_channels=256,
+        tasks=None,
+        bbox_coder=None,
+        common_heads=dict(),
+        loss_cls=dict(type='GaussianFocalLoss', reduction='mean'),
+        loss_bbox=dict(type='L1Loss', reduction='mean', loss_weight=0.25),
+        gaussian_overlap=0.1,
+        min_radius=2,
+        train_cfg=None,
+        test_cfg=None,
+        bev_backbone_conf=bev_backbone_conf,
+        bev_neck_conf=bev_neck_conf,
+        separate_head=dict(type='SeparateHead', init_bias=-2.19, final_kernel=3),
+        share_conv_channel=64,
+        num_heatmap_convs=2,
+    ):
+        super().__init__()
+        num_classes = [len(t['class_names']) for t in tasks]
+        self.class_names = [t['class_names'] for t in tasks]
+        self.num_classes = num_classes
+        self.in_channels = in_channels
+        self.bbox_coder_cfg = bbox_coder
+        self.loss_cls_cfg, self.loss_bbox_cfg = loss_cls, loss_bbox
+        self.norm_bbox = True
+        self.shared_conv = ConvModule(in_channels, share_conv_channel, 3, padding=1)
+        self.task_heads = nn.ModuleList()
+        for num_cls in num_classes:
+            heads = dict(common_heads)
+            heads.update(dict(heatmap=(num_cls, num_heatmap_convs)))
+            sh = dict(separate_head)
+            sh.pop('type', None)
+            self.task_heads.append(SeparateHead(in_channels=share_conv_channel, heads=heads, head_conv=64, **sh))
+        self.trunk = build_backbone(bev_backbone_conf)
+        self.trunk.init_weights()
+        self.neck = build_neck(bev_neck_conf)
+        self.neck.init_weights()
+        del self.trunk.maxpool                                   # bev_height_head.py:79
+        self.gaussian_overlap = gaussian_overlap
+        self.min_radius = min_radius
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        self.share_conv_channel = share_conv_channel
+
+    # ---------------------------------------------------------------------------------------------
+    def _branches(self):
+        """[(task index, branch name, Sequential)] in the reference's dict order."""
+        out = []
+        for t, th in enumerate(self.task_heads):
+            for name in th.heads:
+                out.append((t, name, getattr(th, name)))
+        return out
+
+    def hip_compile(self, device):
+        br = self._branches()
+        hc = 64
+        for _, name, seq in br:
+            assert len(seq) == 2 and seq[0].conv.out_channels == hc, "fused head expects (ConvModule, Conv2d) branches"
+            assert seq[1].out_channels <= 4
+        # first layers: one conv 64 -> nb*64 with per-channel folded BN
+        w1 = torch.cat([seq[0].conv.weight.detach() for _, _, seq in br], 0)
+        sc, sh = zip(*[fold_bn(seq[0].bn, seq[0].conv.bias) for _, _, seq in br])
+        first = PackedConv(w1, pad=1, scale=torch.cat(sc), shift=torch.cat(sh), relu=True, device=device)
+        # final layers: [sum_c, 3, 3, 64] + bias + branch map
+        w2 = torch.cat([seq[1].weight.detach().permute(0, 2, 3, 1) for _, _, seq in br], 0)
+        b2 = torch.cat([seq[1].bias.detach() for _, _, seq in br], 0)
+        branch_of_out, slices, off = [], [], 0
+        for i, (t, name, seq) in enumerate(br):
+            c = seq[1].out_channels
+            branch_of_out += [i] * c
+            slices.append((t, name, off, c))
+            off += c
+        f = lambda t_: t_.to(device).float().contiguous()
+        return dict(shared=conv_bn(self.shared_conv.conv, self.shared_conv.bn, True, device), first=first,
+                    w2=f(w2), b2=f(b2), branch_of_out=torch.tensor(branch_of_out, dtype=torch.int32, device=device),
+                    slices=slices, nb=len(br), hc=hc, total=off)
+
+    def hip_forward(self, x):
+        """x: BEV map NHWC [B, Y, X, C] -> the reference's nested prediction structure."""
+        s = self.hip_state(x.device)
+        trunk_outs = [x]                                               # bev_height_head.py:97
+        h = self.trunk.hip_stem(x)                                     # conv1 + norm1 + relu, no maxpool (:101-103)
+        for i, layer_name in enumerate(self.trunk.res_layers):         # :104-108
+            for blk in getattr(self.trunk, layer_name):
+                h = blk.hip_forward(h)
+            if i in self.trunk.out_indices:
+                trunk_outs.append(h)
+        fpn_output = self.neck.hip_forward(trunk_outs)                 # :109
+        shared = s['shared'](fpn_output)                               # CenterHead.forward_single
+        hidden = s['first'](shared)                                    # all branch first layers: [B,H,W,nb*64]
+        out = hip_ops.head_final_conv(hidden, s['w2'], s['b2'], s['branch_of_out'], s['nb'], s['hc'])
+        ret = [dict() for _ in self.task_heads]
+        for t, name, off, c in s['slices']:
+            ret[t][name] = out[:, off:off + c]                         # [B, c, H, W] views of one buffer
+        return tuple([d] for d in ret)                                 # multi_apply over one level
+
+    def forward(self, x, nhwc=False):
+        """x: [B, C, Y, X] (reference layout) or, with ``nhwc``, the NHWC buffer [B, Y, X, C]."""
+        if not x.is_cuda:
+            raise RuntimeError("sgv3d_amd runs on the MI355X only (no CPU fallback)")
+        if self.training:
+            raise NotImplementedError("HIP path = inference forward; call model.eval()")
+        if not nhwc:
+            x = hip_ops.nchw_to_nhwc(x.float().contiguous())
+        elif not x.is_contiguous():
+            x = x.contiguous()
+        return self.hip_forward(x)
+
+    # --------------------------------------------------------------- later rounds
+    def get_targets(self, gt_bboxes_3d, gt_labels_3d):
+        raise NotImplementedError("target assignment (bev_height_head.py:113-253) is SURVEY §8(f) rank 2")
+
+    def loss(self, targets, preds_dicts, **kwargs):
+        raise NotImplementedError("loss (bev_height_head.py:255-311) is SURVEY §8(f) rank 2")
+
+    def get_bboxes(self, preds_dicts, img_metas=None, img=None, rescale=False):
+        raise NotImplementedError("box decode + circle NMS (models/bev_height.py:116-126) is SURVEY §8(f) rank 1")

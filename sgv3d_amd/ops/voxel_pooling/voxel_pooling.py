@@ -17,7 +17,7 @@ callable, argument meaning, asserts, non-differentiable ``geom_xyz``, permuted-v
 import torch
 from torch.autograd import Function
 
-from ... import _lib
+from ... import _lib, hip_ops
 
 _MODE = "planned"
 
@@ -78,7 +78,7 @@ class VoxelPlan:
         if nbytes == 0:
             raise RuntimeError("voxel plan: bad sizes")
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=geom_xyz.device)
-        with torch.cuda.device(geom_xyz.device):
+        with torch.cuda.device(geom_xyz.device), hip_ops.prof("voxel_plan_build"):
             rc = lib.sgv3d_voxel_plan_build(self.B, self.N, self.X, self.Y, self.Z, geom_xyz.data_ptr(),
                                             _lib.ptr(pos_memo), self.buf.data_ptr(), nbytes,
                                             1 if sort_segments else 0, _lib.stream_handle(geom_xyz.device))
@@ -92,7 +92,7 @@ class VoxelPlan:
         assert input_features.numel() == self.B * self.N * C
         if out is None:
             out = input_features.new_empty(self.B, self.Y, self.X, C)
-        with torch.cuda.device(input_features.device):
+        with torch.cuda.device(input_features.device), hip_ops.prof("voxel_pooling_planned"):
             rc = _lib.load().sgv3d_voxel_pooling_forward_planned(
                 self.B, self.N, C, self.X, self.Y, self.buf.data_ptr(), input_features.data_ptr(),
                 out.data_ptr(), _lib.stream_handle(input_features.device))
@@ -107,7 +107,7 @@ class VoxelPlan:
         assert prob.is_contiguous() and context.is_contiguous()
         if out is None:
             out = context.new_empty(B, self.Y, self.X, C)
-        with torch.cuda.device(context.device):
+        with torch.cuda.device(context.device), hip_ops.prof("lift_splat_planned"):
             rc = _lib.load().sgv3d_lift_splat_planned(B, D, P, C, self.X, self.Y, self.buf.data_ptr(),
                                                      prob.data_ptr(), context.data_ptr(), out.data_ptr(),
                                                      _lib.stream_handle(context.device))
@@ -148,7 +148,7 @@ class VoxelPooling(Function):
         lib = _lib.load()
         if _MODE == "atomic":
             output_features = input_features.new_zeros(batch_size, Y, X, num_channels)  # :37-38
-            with torch.cuda.device(input_features.device):
+            with torch.cuda.device(input_features.device), hip_ops.prof("voxel_pooling_atomic"):
                 rc = lib.sgv3d_voxel_pooling_forward(batch_size, num_points, num_channels, X, Y, Z,
                                                      geom_xyz.data_ptr(), input_features.data_ptr(),
                                                      output_features.data_ptr(), _lib.ptr(pos_memo),

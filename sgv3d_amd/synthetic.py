@@ -1,0 +1,216 @@
+"""Configs and synthetic inputs for benchmarks, smoke runs and tests (no dataset, no checkpoint).
+
+* ``r50_256_conf()`` etc. reproduce the config dicts of the reference's experiment files verbatim
+  (exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:33-172) so the same dicts drive
+  this build and, in the reference harness, the reference model.
+* ``make_mats`` builds a DAIR-V2X-like ``mats_dict`` with the dataset's formulas
+  (dataset/nusc_mv_det_dataset.py:63-86 get_denorm / get_sensor2virtual / get_reference_height,
+  :433-446 sample_ida_augmentation, :864-871 collate layout) — SURVEY.md §8(d) "Synthetic inputs".
+* ``randomize_norm_stats_`` perturbs BatchNorm affine/running statistics so BN folding is exercised
+  (fresh BN layers are the identity, and mmdet zero-initialises the last BN of every residual block).
+"""
+import copy
+import math
+
+import numpy as np
+import torch
+
+H, W = 1080, 1920
+final_dim = (864, 1536)
+
+_backbone_conf = {
+    'x_bound': [0, 102.4, 0.4],
+    'y_bound': [-51.2, 51.2, 0.4],
+    'z_bound': [-5, 3, 8],
+    'd_bound': [-2.0, 0.0, 90],
+    'final_dim': final_dim,
+    'output_channels': 80,
+    'downsample_factor': 16,
+    'img_backbone_conf': dict(
+        type='ResNet',
+        depth=50,
+        frozen_stages=0,
+        out_indices=[0, 1, 2, 3],
+        norm_eval=False,
+        init_cfg=dict(type='Pretrained', checkpoint='torchvision://resnet50'),
+    ),
+    'img_neck_conf': dict(
+        type='SECONDFPN',
+        in_channels=[256, 512, 1024, 2048],
+        upsample_strides=[0.25, 0.5, 1, 2],
+        out_channels=[128, 128, 128, 128],
+    ),
+    'height_net_conf': dict(in_channels=512, mid_channels=512),
+    'is_train_height': False,
+    'is_bsm': False,
+}
+
+_bev_backbone = dict(type='ResNet', in_channels=80, depth=18, num_stages=3, strides=(1, 2, 2), dilations=(1, 1, 1),
+                     out_indices=[0, 1, 2], norm_eval=False, base_channels=160)
+_bev_neck = dict(type='SECONDFPN', in_channels=[80, 160, 320, 640], upsample_strides=[1, 2, 4, 8],
+                 out_channels=[64, 64, 64, 64])
+
+CLASSES = ['car', 'truck', 'construction_vehicle', 'bus', 'trailer', 'barrier', 'motorcycle', 'bicycle',
+           'pedestrian', 'traffic_cone']
+TASKS = [
+    dict(num_class=1, class_names=['car']),
+    dict(num_class=2, class_names=['truck', 'construction_vehicle']),
+    dict(num_class=2, class_names=['bus', 'trailer']),
+    dict(num_class=1, class_names=['barrier']),
+    dict(num_class=2, class_names=['motorcycle', 'bicycle']),
+    dict(num_class=2, class_names=['pedestrian', 'traffic_cone']),
+]
+common_heads = dict(reg=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2))
+bbox_coder = dict(type='CenterPointBBoxCoder', post_center_range=[0.0, -61.2, -10.0, 122.4, 61.2, 10.0], max_num=500,
+                  score_threshold=0.1, out_size_factor=4, voxel_size=[0.1, 0.1, 8], pc_range=[0, -51.2, -5, 104.4, 51.2, 3],
+                  code_size=9)
+train_cfg = dict(point_cloud_range=[0, -51.2, -5, 102.4, 51.2, 3], grid_size=[1024, 1024, 1], voxel_size=[0.1, 0.1, 8],
+                 out_size_factor=4, dense_reg=1, gaussian_overlap=0.1, max_objs=500, min_radius=2,
+                 code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.5, 0.5])
+test_cfg = dict(post_center_limit_range=[0.0, -61.2, -10.0, 122.4, 61.2, 10.0], max_per_img=500, max_pool_nms=False,
+                min_radius=[4, 12, 10, 1, 0.85, 0.175], score_threshold=0.1, out_size_factor=4, voxel_size=[0.1, 0.1, 8],
+                nms_type='circle', pre_max_size=1000, post_max_size=83, nms_thr=0.2)
+_head_conf = {
+    'bev_backbone_conf': _bev_backbone,
+    'bev_neck_conf': _bev_neck,
+    'tasks': TASKS,
+    'common_heads': common_heads,
+    'bbox_coder': bbox_coder,
+    'train_cfg': train_cfg,
+    'test_cfg': test_cfg,
+    'in_channels': 256,  # Equal to bev_neck output_channels.
+    'loss_cls': dict(type='GaussianFocalLoss', reduction='mean'),
+    'loss_bbox': dict(type='L1Loss', reduction='mean', loss_weight=0.25),
+    'gaussian_overlap': 0.1,
+    'min_radius': 2,
+}
+
+
+def r50_256_conf():
+    """BASELINE cfg-2: R50, 864x1536 -> 256x256 BEV (the reference's DAIR-V2X experiment file)."""
+    return copy.deepcopy(_backbone_conf), copy.deepcopy(_head_conf)
+
+
+def r101_256_conf():
+    b, h = r50_256_conf()
+    b['img_backbone_conf']['depth'] = 101
+    return b, h
+
+
+def small_conf(final=(128, 192), bev=64, depth=18):
+    """Reduced geometry with the same layer structure (tests: the CPU oracle finishes in seconds)."""
+    b, h = r50_256_conf()
+    b['final_dim'] = final
+    b['d_bound'] = [-2.0, 0.0, 12]
+    half = bev * 0.4 / 2
+    b['x_bound'] = [0, bev * 0.4, 0.4]
+    b['y_bound'] = [-half, half, 0.4]
+    if depth != 50:
+        b['img_backbone_conf']['depth'] = depth
+        if depth in (18, 34):
+            b['img_neck_conf']['in_channels'] = [64, 128, 256, 512]
+    return b, h
+
+
+# -------------------------------------------------------------------------------------------------
+def _rodrigues(rvec):
+    th = float(np.linalg.norm(rvec))
+    if th < 1e-12:
+        return np.eye(3)
+    k = rvec / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + math.sin(th) * Kx + (1 - math.cos(th)) * (Kx @ Kx)
+
+
+def _equation_plane(p):
+    (x1, y1, z1), (x2, y2, z2), (x3, y3, z3) = p
+    a1, b1, c1 = x2 - x1, y2 - y1, z2 - z1
+    a2, b2, c2 = x3 - x1, y3 - y1, z3 - z1
+    a = b1 * c2 - b2 * c1
+    b = a2 * c1 - a1 * c2
+    c = a1 * b2 - b1 * a2
+    return np.array([a, b, c, -a * x1 - b * y1 - c * z1])
+
+
+def make_calib(pitch_deg=11.0, cam_h=5.5, yaw_deg=0.0, roll_deg=0.0, fx=2183.375, fy=2329.2976, cx=940.59,
+               cy=567.568, resize=0.8, crop=(0.0, 0.0)):
+    """One roadside camera: (x right, y down, z forward) looking along ego +x, pitched down."""
+    f32 = np.float32
+    p, yw, rl = (math.radians(a) for a in (pitch_deg, yaw_deg, roll_deg))
+    fwd = np.array([math.cos(p), 0.0, -math.sin(p)])
+    right = np.array([0.0, -1.0, 0.0])
+    down = np.cross(fwd, right)
+    R = np.stack([right, down, fwd], axis=1)
+    Rroll = _rodrigues(np.array([0.0, 0.0, 1.0]) * rl)
+    Rz = np.array([[math.cos(yw), -math.sin(yw), 0], [math.sin(yw), math.cos(yw), 0], [0, 0, 1]])
+    s2e = np.eye(4)
+    s2e[:3, :3] = Rz @ R @ Rroll
+    s2e[:3, 3] = [0.0, 0.0, cam_h]
+    e2s = np.linalg.inv(s2e)
+    gp = np.array([[0, 0, 0, 1.0], [0, 1, 0, 1], [1, 1, 0, 1]])
+    denorm = -1 * _equation_plane((e2s @ gp.T).T[:, :3])                    # get_denorm
+    origin = np.array([0.0, 1.0, 0.0])
+    target = -1 * denorm[:3]
+    tn = target / np.linalg.norm(target)
+    sita = math.acos(float(np.clip(np.inner(tn, origin), -1, 1)))
+    nv = np.cross(tn, origin)
+    s2v = np.eye(4)
+    if np.linalg.norm(nv) > 1e-12:                                           # get_sensor2virtual
+        nv = (nv / np.linalg.norm(nv)).astype(f32).astype(np.float64)
+        s2v[:3, :3] = _rodrigues(nv * sita).astype(f32)
+    refh = f32(abs(denorm[3]) / np.linalg.norm(denorm[:3]))                  # get_reference_height
+    K = np.eye(4)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = fx, fy, cx, cy
+    ida = np.eye(4)
+    ida[0, 0] = ida[1, 1] = resize
+    ida[0, 3], ida[1, 3] = -crop[0], -crop[1]
+    return dict(sensor2ego=s2e.astype(f32), sensor2virtual=s2v.astype(f32), intrin=K.astype(f32),
+                ida=ida.astype(f32), bda=np.eye(4, dtype=f32), reference_height=refh)
+
+
+def make_mats(batch, device='cpu', scale=1.0, vary=True):
+    """mats_dict for ``batch`` samples x 1 sweep x 1 camera (collate layout dataset/...:864-871).
+    ``scale`` shrinks the intrinsics for reduced-resolution test configs."""
+    cams = []
+    for b in range(batch):
+        kw = dict(fx=2183.375 * scale, fy=2329.2976 * scale, cx=940.59 * scale, cy=567.568 * scale)
+        if vary and b > 0:
+            kw.update(pitch_deg=11.0 + 1.5 * b, cam_h=5.5 + 0.4 * b, yaw_deg=1.0 * b, roll_deg=0.3 * b)
+        cams.append(make_calib(**kw))
+    t = lambda k: torch.from_numpy(np.stack([c[k] for c in cams])).view(batch, 1, 1, 4, 4).to(device)
+    return {
+        'sensor2ego_mats': t('sensor2ego'),
+        'intrin_mats': t('intrin'),
+        'ida_mats': t('ida'),
+        'sensor2sensor_mats': torch.eye(4).view(1, 1, 1, 4, 4).repeat(batch, 1, 1, 1, 1).to(device),
+        'sensor2virtual_mats': t('sensor2virtual'),
+        'reference_heights': torch.tensor([float(c['reference_height']) for c in cams]).view(batch, 1, 1).to(device),
+        'bda_mat': torch.from_numpy(np.stack([c['bda'] for c in cams])).to(device),
+    }
+
+
+def make_images(batch, final=final_dim, device='cpu', seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(batch, 1, 1, 3, final[0], final[1], generator=g).to(device)
+
+
+def randomize_norm_stats_(model, seed=0, dcn_offsets=True):
+    """Seeded perturbation of every BatchNorm (weight, bias, running stats) and of the DCN offset
+    conv (zero-initialised => plain conv), so folded-BN and deformable sampling are really tested."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, m in model.named_modules():
+            if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+                n = m.num_features
+                m.weight.copy_(1.0 + 0.1 * torch.randn(n, generator=g))
+                m.bias.copy_(0.1 * torch.randn(n, generator=g))
+                m.running_mean.copy_(0.1 * torch.randn(n, generator=g))
+                m.running_var.copy_(1.0 + 0.1 * torch.rand(n, generator=g))
+            if dcn_offsets and name.endswith('conv_offset'):
+                m.weight.copy_(0.02 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.5 * torch.randn(m.bias.shape, generator=g))
+            # default-initialised 1x1 heads give near-zero logits / context: scale them to O(1) so the
+            # softmax, the BEV map and the head see realistic dynamic range
+            if name.endswith(('height_layer', 'context_conv')):
+                m.weight.mul_(8.0)
+    return model

@@ -25,11 +25,11 @@ def _run(hip, frustum, cams, bounds, prep_override=None, want_float=True):
     n = len(cams)
     D, fH, fW, _ = frustum.shape
     vs, vc, vn = G.voxel_params(*bounds)
-    stack = lambda k: _t(np.stack([c[k] for c in cams]))
+    mats = {k: _t(np.stack([c[k] for c in cams])) for k in ("sensor2ego", "sensor2virtual", "intrin", "ida")}
     prep = torch.empty(n, 3, 4, 4, device=DEV)
     st = hip.stream_handle()
-    hip.check(lib.sgv3d_calib_prep(n, stack("sensor2ego").data_ptr(), stack("sensor2virtual").data_ptr(),
-                                   stack("intrin").data_ptr(), stack("ida").data_ptr(), prep.data_ptr(), st), "prep")
+    hip.check(lib.sgv3d_calib_prep(n, mats["sensor2ego"].data_ptr(), mats["sensor2virtual"].data_ptr(),
+                                   mats["intrin"].data_ptr(), mats["ida"].data_ptr(), prep.data_ptr(), st), "prep")
     if prep_override is not None:
         prep = _t(prep_override)
     fr = _t(frustum)

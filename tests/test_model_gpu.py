@@ -1,0 +1,126 @@
+"""GPU: the assembled BEVHeight forward (HIP) against the torch-CPU oracle on identical weights and
+synthetic DAIR-like inputs.  Tolerances are the north_star's: voxel indices bit-exact, BEV features
+and head outputs within 1e-3 (fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_model as TM
+from sgv3d_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = dict(rtol=1e-3, atol=1e-3)
+
+
+def _build(bc, hc, seed=1):
+    from sgv3d_amd.models.bev_height import BEVHeight
+    torch.manual_seed(0)
+    m = BEVHeight(bc, hc).eval()
+    S.randomize_norm_stats_(m, seed)
+    return m
+
+
+def _to_dev(mats):
+    return {k: v.to(DEV) for k, v in mats.items()}
+
+
+@pytest.fixture(scope="module")
+def small():
+    bc, hc = S.small_conf(depth=18)
+    m = _build(bc, hc)
+    imgs = S.make_images(2, bc['final_dim'], seed=3)
+    mats = S.make_mats(2, scale=128 / 864)
+    keep = {}
+    ref = TM.bevheight_forward(m.state_dict(), bc, hc, imgs, mats, keep)
+    m = m.to(DEV)
+    return dict(m=m, bc=bc, hc=hc, imgs=imgs, mats=mats, ref=ref, keep=keep)
+
+
+def test_voxel_indices_bit_exact(small):
+    m, mats = small['m'], _to_dev(small['mats'])
+    geom = m.backbone.get_geometry_voxel_index(mats['sensor2ego_mats'][:, 0], mats['sensor2virtual_mats'][:, 0],
+                                               mats['intrin_mats'][:, 0], mats['ida_mats'][:, 0],
+                                               mats['reference_heights'][:, 0], mats['bda_mat'])
+    assert geom.dtype == torch.int32
+    assert np.array_equal(geom.cpu().numpy(), small['keep']['geom_xyz'])
+
+
+def test_image_features_and_heightnet(small):
+    m = small['m']
+    imgs = small['imgs'].to(DEV)
+    with torch.no_grad():
+        src = m.backbone.get_cam_feats_nhwc(imgs)
+        hf = m.backbone.height_net.hip_forward(src, _to_dev(small['mats']))
+    torch.testing.assert_close(src.permute(0, 3, 1, 2).cpu(), small['keep']['img_feats'], **TOL)
+    torch.testing.assert_close(hf.permute(0, 3, 1, 2).cpu(), small['keep']['height_feature'], **TOL)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_bev_features(small, fused):
+    m = small['m']
+    m.backbone.fuse_lift_splat = fused
+    try:
+        with torch.no_grad():
+            bev = m.backbone(small['imgs'].to(DEV), _to_dev(small['mats']))
+    finally:
+        m.backbone.fuse_lift_splat = False
+    assert bev.shape == small['keep']['bev'].shape and bev.is_contiguous()      # [B, C, Y, X] like lss_fpn.py:495
+    torch.testing.assert_close(bev.cpu(), small['keep']['bev'], **TOL)
+    assert (bev != 0).any()
+
+
+def test_full_forward_structure_and_values(small):
+    m = small['m']
+    with torch.no_grad():
+        preds = m(small['imgs'].to(DEV), _to_dev(small['mats']))
+    ref = small['ref']
+    assert isinstance(preds, tuple) and len(preds) == 6
+    for t in range(6):
+        assert isinstance(preds[t], list) and len(preds[t]) == 1
+        assert list(preds[t][0].keys()) == ['reg', 'height', 'dim', 'rot', 'vel', 'heatmap']
+        for k, v in preds[t][0].items():
+            assert v.shape == ref[t][0][k].shape
+            torch.testing.assert_close(v.cpu(), ref[t][0][k], **TOL)
+    assert preds[1][0]['heatmap'].shape[1] == 2 and preds[0][0]['dim'].shape[1] == 3
+
+
+def test_weights_repacked_after_load_state_dict(small):
+    from sgv3d_amd.models.bev_height import BEVHeight
+    m = small['m']
+    imgs, mats = small['imgs'].to(DEV), _to_dev(small['mats'])
+    with torch.no_grad():
+        a = m(imgs, mats)[0][0]['heatmap'].clone()
+        m2 = _build(small['bc'], small['hc'], seed=77).to(DEV)
+        b = m2(imgs, mats)[0][0]['heatmap'].clone()
+        assert not torch.allclose(a, b)
+        m2.load_state_dict(m.state_dict())            # Lightning checkpoints restore this way
+        c = m2(imgs, mats)[0][0]['heatmap']
+    assert torch.equal(a, c)
+
+
+def test_rejects_cpu_and_training(small):
+    m = small['m']
+    with pytest.raises(RuntimeError):
+        m(small['imgs'], small['mats'])
+    m.train()
+    try:
+        with pytest.raises(NotImplementedError):
+            m(small['imgs'].to(DEV), _to_dev(small['mats']))
+    finally:
+        m.eval()
+
+
+def test_r50_bottleneck_path():
+    """ResNet-50 image backbone (Bottleneck blocks) at reduced resolution, batch 1."""
+    bc, hc = S.small_conf(depth=50)
+    m = _build(bc, hc, seed=5)
+    imgs = S.make_images(1, bc['final_dim'], seed=9)
+    mats = S.make_mats(1, scale=128 / 864)
+    ref = TM.bevheight_forward(m.state_dict(), bc, hc, imgs, mats)
+    m = m.to(DEV)
+    with torch.no_grad():
+        preds = m(imgs.to(DEV), _to_dev(mats))
+    for t in range(6):
+        for k, v in preds[t][0].items():
+            torch.testing.assert_close(v.cpu(), ref[t][0][k], **TOL)
