@@ -70,6 +70,10 @@ def load():
             raise SGV3DError(
                 f"{LIB_PATH} is missing: build it with `make -C sgv3d_amd/csrc` (or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        # torch must be imported first: it bundles its own libamdhip64 (SONAME libamdhip64.so.7) and this
+        # library has to bind to that same runtime instance, otherwise the process ends up with two HIP
+        # runtimes and pointers / streams from one are unknown to the other ("no ROCm-capable device").
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(lib, name)
