@@ -157,7 +157,9 @@ typedef struct sgv3d_conv_desc {
     int deconv_ks;                   /* kernel == stride of the transposed conv (mode DECONV)           */
     int k_pad, cout_pad;             /* packed-weight geometry (from sgv3d_conv_pack_geometry)          */
     int tile;                        /* 0 = heuristic, else SGV3D_TILE_*                                */
-    int x_nchw;                      /* 1: x is NCHW [batch, cin, in_h, in_w] (image stem only)         */
+    int x_nchw;                      /* reserved, must be 0 (NCHW images go through sgv3d_nchw_to_nhwc) */
+    int k_order;                     /* packed-weight k order, must match sgv3d_conv_pack_weight:       */
+                                     /* 0: k = tap*cin + ci;  1: k = ((ci/32)*taps + tap)*32 + ci%32    */
 } sgv3d_conv_desc;
 
 #define SGV3D_CONV_NORMAL 0
@@ -173,10 +175,14 @@ typedef struct sgv3d_conv_desc {
 void sgv3d_conv_pack_geometry(int k, int n, int *k_pad, int *n_pad);
 
 /* Repack an OIHW (nn.Conv2d.weight, [cout, cin, kh, kw]) tensor into the kernel's [cout_pad][k_pad]
- * layout (k = (kh*KW+kw)*cin_pad + ci).  `transposed` != 0: the source is an nn.ConvTranspose2d.weight
- * [cin, cout, ks, ks] and the packed rows are (dy, dx, co). cin_pad >= cin pads channels with zeros. */
+ * layout.  k_order 0: k = (kh*KW+kw)*cin_pad + ci (any cin_pad % 4 == 0).  k_order 1 (cin_pad % 32 == 0):
+ * k = ((ci/32)*KH*KW + kh*KW+kw)*32 + ci%32, i.e. the taps of one 32-channel chunk are adjacent so their
+ * overlapping input pixels are fetched back to back (L1/L2 hits).  `transposed` != 0: the source is an
+ * nn.ConvTranspose2d.weight [cin, cout, ks, ks] and the packed rows are (dy, dx, co).  cin_pad >= cin
+ * pads channels with zeros. */
 int sgv3d_conv_pack_weight(const float *w_src, int cout, int cin, int kh, int kw, int cin_pad,
-                           int transposed, float *w_packed, int k_pad, int cout_pad, void *stream);
+                           int transposed, int k_order, float *w_packed, int k_pad, int cout_pad,
+                           void *stream);
 
 /* scale/bias f32 [cout] (NULL = 1 / 0), residual NHWC f32 or NULL, gate f32 [batch, cout] or NULL. */
 int sgv3d_conv2d_forward(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *w_packed,
@@ -198,9 +204,11 @@ int sgv3d_nchw_to_nhwc(int batch, int channels, int h, int w, int c_pad, const f
 int sgv3d_nhwc_to_nchw(int batch, int channels, int h, int w, int ld, int coff, const float *x,
                        float *y, void *stream);
 
-/* nn.AdaptiveAvgPool2d((1,1)) : NHWC [B, H*W, C] -> [B, C]  (ASPP.global_avg_pool, lss_fpn.py:81-86). */
+/* nn.AdaptiveAvgPool2d((1,1)) : NHWC [B, H*W, C] -> [B, C]  (ASPP.global_avg_pool, lss_fpn.py:81-86).
+ * Deterministic two-stage sum through a caller-owned workspace. */
+size_t sgv3d_global_avgpool_workspace_bytes(int batch, int channels);
 int sgv3d_global_avgpool(int batch, int pixels, int channels, int x_ld, const float *x, float *y,
-                         void *stream);
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* y[b, :] = act(scale * (W @ x[b, :]) + bias): small dense layer on [B, K] vectors (Mlp fc1/fc2,
  * SELayer 1x1 convs on [B,C,1,1], ASPP pooled branch; lss_fpn.py:122-159).  W f32 [N, K] row-major.

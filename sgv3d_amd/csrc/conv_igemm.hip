@@ -45,9 +45,10 @@ struct ConvArgs {
     int kh, kw, stride, pad, dil;
     int x_ld, x_coff, y_ld, y_coff, res_ld, relu, mode, ks;
     int tiles_m, tiles_n;
+    int korder;  // 0: k = tap*cin + ci   1: k = (ci/32 * taps + tap)*32 + ci%32  (cin % 32 == 0)
 };
 
-template <int WTM, int WTN>
+template <int WTM, int WTN, bool FAST>
 __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     constexpr int A_CH = BM / 32, B_CH = BN / 32;  // 16-B chunks per thread per k-tile
@@ -85,25 +86,44 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
         const int oh = t - n * a.m_h;
         a_ih0[i] = oh * a.stride - a.pad;
         a_iw0[i] = ow * a.stride - a.pad;
-        a_ptr[i] = a.x + ((long long)(n * a.in_h + a_ih0[i]) * a.in_w + a_iw0[i]) * a.x_ld + a.x_coff;
+        a_ptr[i] = a.x + ((long long)(n * a.in_h + a_ih0[i]) * a.in_w + a_iw0[i]) * a.x_ld + a.x_coff + cc * 4;
     }
     const float *b_ptr = a.w + (size_t)(n0 + r0) * a.k_pad + cc * 4;
-
-    float4 ra[A_CH], rb[B_CH];
     const float *__restrict__ zeros = a.zeros;
-    // Global -> register stage of k-tile `kt`.  Loads are unconditional: lanes whose tap falls outside
-    // the image (or whose row/k is padding) read a 16-byte block of zeros instead, so the stage is
-    // straight-line global_load_dwordx4 with no exec-mask branches and no post-load selects; the
-    // values are first touched by the ds_write at the top of the next iteration.
-#define SGV3D_LOAD_TILE(kt_)                                                                          \
+
+    // Two register stages: tile t+2 is fetched while tile t is multiplied and tile t+1 is written to
+    // the other LDS buffer between the two MFMA halves.
+    float4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
+    // k state of the NEXT tile to fetch.  FAST (cin % 32 == 0, weights packed channel-chunk-major):
+    // a k-tile is (32-channel chunk c0, tap (kh, kw)) -- wave-uniform, advanced incrementally, and the
+    // nine taps of one chunk are fetched back to back so their overlapping input pixels hit in L1/L2.
+    // General path: k = tap * cin + ci, decoded per thread with integer division.
+    int ld_kt = 0, ld_kh = 0, ld_kw = 0, ld_c0 = 0;
+    const int nkt = a.k_pad / BK;
+
+    // Loads are unconditional: lanes whose tap falls outside the image (or whose row / k is padding)
+    // read a 16-byte block of zeros, so the stage is straight-line global_load_dwordx4 with no
+    // exec-mask branches and no post-load selects.
+#define SGV3D_LOAD_TILE(RA, RB)                                                                       \
     do {                                                                                              \
-        const int k_ = (kt_) * BK + cc * 4;                                                           \
-        const bool kvalid_ = k_ < a.K;                                                                \
-        const int tap_ = k_ / a.cin;                                                                  \
-        const int ci_ = k_ - tap_ * a.cin;                                                            \
-        const int kh_ = tap_ / a.kw;                                                                  \
-        const int kw_ = tap_ - kh_ * a.kw;                                                            \
-        const int dy_ = kh_ * a.dil, dx_ = kw_ * a.dil;                                               \
+        int dy_, dx_, ci_;                                                                            \
+        /* past the last tile (pipeline drain) nothing is fetched for A and the last B tile is */     \
+        /* re-read: keeps the stage branch-free so the compiler can count vmcnt exactly        */     \
+        bool kvalid_ = ld_kt < nkt;                                                                   \
+        const int ktb_ = ld_kt < nkt ? ld_kt : nkt - 1;                                               \
+        if constexpr (FAST) {                                                                         \
+            dy_ = ld_kh * a.dil;                                                                      \
+            dx_ = ld_kw * a.dil;                                                                      \
+            ci_ = ld_c0;                                                                              \
+        } else {                                                                                      \
+            const int k_ = ktb_ * BK + cc * 4;                                                        \
+            kvalid_ = kvalid_ & (k_ < a.K);                                                           \
+            const int tap_ = k_ / a.cin;                                                              \
+            ci_ = k_ - tap_ * a.cin - cc * 4;                                                         \
+            const int kh_ = tap_ / a.kw;                                                              \
+            dy_ = kh_ * a.dil;                                                                        \
+            dx_ = (tap_ - kh_ * a.kw) * a.dil;                                                        \
+        }                                                                                             \
         const int koff_ = (dy_ * a.in_w + dx_) * a.x_ld + ci_;                                        \
         _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                            \
             const int ih_ = a_ih0[i] + dy_, iw_ = a_iw0[i] + dx_;                                     \
@@ -111,12 +131,28 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
                             ((unsigned)iw_ < (unsigned)a.in_w);                                       \
             const float *p_ = v_ ? a_ptr[i] + koff_ : zeros;                                          \
             const float4 t_ = *reinterpret_cast<const float4 *>(p_);                                  \
-            ra[i].x = t_.x; ra[i].y = t_.y; ra[i].z = t_.z; ra[i].w = t_.w;                           \
+            RA[i].x = t_.x; RA[i].y = t_.y; RA[i].z = t_.z; RA[i].w = t_.w;                           \
         }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < B_CH; ++i) {                                            \
-            const float4 t_ = *reinterpret_cast<const float4 *>(b_ptr + (size_t)(32 * i) * a.k_pad + (kt_) * BK); \
-            rb[i].x = t_.x; rb[i].y = t_.y; rb[i].z = t_.z; rb[i].w = t_.w;                           \
+            const float4 t_ = *reinterpret_cast<const float4 *>(b_ptr + (size_t)(32 * i) * a.k_pad + ktb_ * BK); \
+            RB[i].x = t_.x; RB[i].y = t_.y; RB[i].z = t_.z; RB[i].w = t_.w;                           \
         }                                                                                             \
+        ++ld_kt;                                                                                      \
+        if constexpr (FAST) {                                                                         \
+            if (++ld_kw == a.kw) {                                                                    \
+                ld_kw = 0;                                                                            \
+                if (++ld_kh == a.kh) { ld_kh = 0; ld_c0 += BK; }                                      \
+            }                                                                                         \
+        }                                                                                             \
+    } while (0)
+
+#define SGV3D_STORE_TILE(RA, RB, BUF)                                                                 \
+    do {                                                                                              \
+        float *As_ = As0 + (BUF) * kBufStride, *Bs_ = Bs0 + (BUF) * kBufStride;                       \
+        _Pragma("unroll") for (int i = 0; i < A_CH; ++i)                                              \
+            *reinterpret_cast<float4 *>(As_ + (r0 + 32 * i) * LDK + cc * 4) = RA[i];                  \
+        _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                              \
+            *reinterpret_cast<float4 *>(Bs_ + (r0 + 32 * i) * LDK + cc * 4) = RB[i];                  \
     } while (0)
 
     // ---- MFMA fragments ------------------------------------------------------------------------
@@ -134,49 +170,57 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
 
-    const int nkt = a.k_pad / BK;
-    SGV3D_LOAD_TILE(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        {   // registers -> LDS[buf]; the previous reader of this buffer (tile kt-2) finished before
-            // the barrier of iteration kt-1
-            float *As = As0 + buf * kBufStride, *Bs = Bs0 + buf * kBufStride;
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) *reinterpret_cast<float4 *>(As + (r0 + 32 * i) * LDK + cc * 4) = ra[i];
-#pragma unroll
-            for (int j = 0; j < B_CH; ++j) *reinterpret_cast<float4 *>(Bs + (r0 + 32 * j) * LDK + cc * 4) = rb[j];
-        }
+    // two k-groups (16 of the tile's 32 k) from LDS buffer BUF
+#define SGV3D_MFMA_HALF(BUF, KQ0)                                                                     \
+    do {                                                                                              \
+        const float *Aw_ = As0 + (BUF) * kBufStride + a_frag_off;                                     \
+        const float *Bw_ = Bs0 + (BUF) * kBufStride + b_frag_off;                                     \
+        _Pragma("unroll") for (int kq = (KQ0); kq < (KQ0) + 2; ++kq) {                                \
+            float4 af[WTM], bf[WTN];                                                                  \
+            _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                        \
+                af[mt] = *reinterpret_cast<const float4 *>(Aw_ + mt * 32 * LDK + kq * 8);             \
+            _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt)                                        \
+                bf[nt] = *reinterpret_cast<const float4 *>(Bw_ + nt * 32 * LDK + kq * 8);             \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+                _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt) {                                  \
+                    const float av = j == 0 ? af[mt].x : j == 1 ? af[mt].y : j == 2 ? af[mt].z : af[mt].w; \
+                    _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt) {                              \
+                        const float bv = j == 0 ? bf[nt].x : j == 1 ? bf[nt].y : j == 2 ? bf[nt].z : bf[nt].w; \
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][nt], 0, 0, 0); \
+                    }                                                                                 \
+                }                                                                                     \
+            }                                                                                         \
+        }                                                                                             \
+    } while (0)
+
+    SGV3D_LOAD_TILE(ra0, rb0);                       // tile 0
+    SGV3D_LOAD_TILE(ra1, rb1);                       // tile 1
+    SGV3D_STORE_TILE(ra0, rb0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        // ---- tile kt sits in LDS buffer 0 ---------------------------------------------------------
+        SGV3D_LOAD_TILE(ra0, rb0);                   // tile kt+2 (branch-free, see the macro)
+        __builtin_amdgcn_sched_barrier(0);
+        SGV3D_MFMA_HALF(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nkt) SGV3D_STORE_TILE(ra1, rb1, 1);   // buffer 1 was last read before the previous barrier
+        __builtin_amdgcn_sched_barrier(0);
+        SGV3D_MFMA_HALF(0, 2);
         __syncthreads();
-        {   // next tile's global loads stay in flight while the MFMAs below run (the last iteration
-            // re-reads its own tile: branch-free, and the values are never stored)
-            const int ktn = kt + 1 < nkt ? kt + 1 : kt;
-            SGV3D_LOAD_TILE(ktn);
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMA block
-        const float *Aw = As0 + buf * kBufStride + a_frag_off;
-        const float *Bw = Bs0 + buf * kBufStride + b_frag_off;
-#pragma unroll
-        for (int kq = 0; kq < BK / 8; ++kq) {
-            float4 af[WTM], bf[WTN];
-#pragma unroll
-            for (int mt = 0; mt < WTM; ++mt) af[mt] = *reinterpret_cast<const float4 *>(Aw + mt * 32 * LDK + kq * 8);
-#pragma unroll
-            for (int nt = 0; nt < WTN; ++nt) bf[nt] = *reinterpret_cast<const float4 *>(Bw + nt * 32 * LDK + kq * 8);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int mt = 0; mt < WTM; ++mt) {
-                    const float av = j == 0 ? af[mt].x : j == 1 ? af[mt].y : j == 2 ? af[mt].z : af[mt].w;
-#pragma unroll
-                    for (int nt = 0; nt < WTN; ++nt) {
-                        const float bv = j == 0 ? bf[nt].x : j == 1 ? bf[nt].y : j == 2 ? bf[nt].z : bf[nt].w;
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][nt], 0, 0, 0);
-                    }
-                }
-            }
-        }
+        if (kt + 1 >= nkt) break;
+        // ---- tile kt+1 sits in LDS buffer 1 -------------------------------------------------------
+        SGV3D_LOAD_TILE(ra1, rb1);                   // tile kt+3
+        __builtin_amdgcn_sched_barrier(0);
+        SGV3D_MFMA_HALF(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nkt) SGV3D_STORE_TILE(ra0, rb0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        SGV3D_MFMA_HALF(1, 2);
+        __syncthreads();
     }
 #undef SGV3D_LOAD_TILE
+#undef SGV3D_STORE_TILE
+#undef SGV3D_MFMA_HALF
 
     // ---- epilogue: scale/bias (folded BN or conv bias), residual, ReLU, gate, store ---------------
     const int hw = a.m_h * a.m_w;
@@ -228,15 +272,24 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
 // weight packing
 // ------------------------------------------------------------------------------------------------
 __global__ void pack_weight_kernel(const float *__restrict__ src, int cout, int cin, int kh, int kw, int cin_pad,
-                                   int transposed, float *__restrict__ dst, int k_pad, int cout_pad) {
+                                   int transposed, int korder, float *__restrict__ dst, int k_pad, int cout_pad) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)k_pad * cout_pad) return;
     const int n = (int)(i / k_pad), k = (int)(i - (long long)n * k_pad);
     float v = 0.f;
     if (!transposed) {
-        const int K = kh * kw * cin_pad;
+        const int taps = kh * kw;
+        const int K = taps * cin_pad;
         if (n < cout && k < K) {
-            const int tap = k / cin_pad, ci = k - tap * cin_pad;
+            int tap, ci;
+            if (korder == 1) {                       // channel-chunk-major: (chunk, tap, ci % 32)
+                const int chunk = k / (taps * 32), rem = k - chunk * taps * 32;
+                tap = rem >> 5;
+                ci = chunk * 32 + (rem & 31);
+            } else {
+                tap = k / cin_pad;
+                ci = k - tap * cin_pad;
+            }
             const int y = tap / kw, x = tap - y * kw;
             if (ci < cin) v = src[(((size_t)n * cin + ci) * kh + y) * kw + x];
         }
@@ -252,13 +305,13 @@ __global__ void pack_weight_kernel(const float *__restrict__ src, int cout, int 
     dst[i] = v;
 }
 
-template <int WTM, int WTN>
-int launch(const ConvArgs &a, hipStream_t st) {
+template <int WTM, int WTN, bool FAST>
+int launch_t(const ConvArgs &a, hipStream_t st) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * LDK;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_kernel<WTM, WTN>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_kernel<WTM, WTN, FAST>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot raise the dynamic LDS limit to %zu", lds);
         attr_set = true;
@@ -274,8 +327,13 @@ int launch(const ConvArgs &a, hipStream_t st) {
     b.zeros = zero_block;
     b.tiles_m = cdiv(a.M, BM);
     b.tiles_n = cdiv(a.N, BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<WTM, WTN>), dim3(b.tiles_m * b.tiles_n), dim3(kThreads), lds, st, b);
+    hipLaunchKernelGGL((conv_igemm_kernel<WTM, WTN, FAST>), dim3(b.tiles_m * b.tiles_n), dim3(kThreads), lds, st, b);
     return check_launch("conv_igemm_kernel");
+}
+
+template <int WTM, int WTN>
+int launch(const ConvArgs &a, hipStream_t st) {
+    return a.korder == 1 ? launch_t<WTM, WTN, true>(a, st) : launch_t<WTM, WTN, false>(a, st);
 }
 
 int pick_tile(long long M, int N) {
@@ -301,17 +359,19 @@ extern "C" void sgv3d_conv_pack_geometry(int k, int n, int *k_pad, int *n_pad) {
 }
 
 extern "C" int sgv3d_conv_pack_weight(const float *w_src, int cout, int cin, int kh, int kw, int cin_pad,
-                                      int transposed, float *w_packed, int k_pad, int cout_pad, void *stream) {
+                                      int transposed, int k_order, float *w_packed, int k_pad, int cout_pad,
+                                      void *stream) {
     SGV3D_REQUIRE(w_src && w_packed, "conv_pack_weight: null pointer");
     SGV3D_REQUIRE(cout > 0 && cin > 0 && kh > 0 && kw > 0 && cin_pad >= cin, "conv_pack_weight: bad shape");
     const int K = transposed ? cin_pad : kh * kw * cin_pad;
     const int Nn = transposed ? cout * kh * kw : cout;
     SGV3D_REQUIRE(!transposed || kh == kw, "conv_pack_weight: transposed needs a square kernel");
+    SGV3D_REQUIRE(k_order == 0 || (k_order == 1 && cin_pad % BK == 0), "conv_pack_weight: k_order 1 needs cin %% 32 == 0");
     SGV3D_REQUIRE(k_pad >= K && k_pad % BK == 0 && cout_pad >= Nn && cout_pad % 128 == 0,
                   "conv_pack_weight: k_pad=%d / cout_pad=%d do not cover K=%d, N=%d", k_pad, cout_pad, K, Nn);
     const long long total = (long long)k_pad * cout_pad;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w_src, cout, cin,
-                       kh, kw, cin_pad, transposed, w_packed, k_pad, cout_pad);
+                       kh, kw, cin_pad, transposed, k_order, w_packed, k_pad, cout_pad);
     return check_launch("pack_weight_kernel");
 }
 
@@ -337,6 +397,8 @@ extern "C" int sgv3d_conv2d_forward(const sgv3d_conv_desc *d, const float *x, co
     a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff; a.res_ld = d->res_ld;
     a.relu = d->relu; a.mode = d->mode; a.ks = d->deconv_ks; a.k_pad = d->k_pad;
     a.tiles_m = a.tiles_n = 0;
+    a.korder = d->k_order;
+    SGV3D_REQUIRE(d->k_order == 0 || (d->k_order == 1 && d->cin % BK == 0), "conv2d_forward: k_order 1 needs cin %% 32 == 0");
     if (d->mode == SGV3D_CONV_DECONV) {
         SGV3D_REQUIRE(d->deconv_ks >= 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0,
                       "conv2d_forward: DECONV runs as a 1x1 GEMM with deconv_ks = kernel = stride");

@@ -69,18 +69,38 @@ __global__ __launch_bounds__(kBlock) void nhwc_to_nchw_kernel(int C, long long H
 }
 
 // nn.AdaptiveAvgPool2d((1,1))  (ASPP.global_avg_pool, layers/backbones/lss_fpn.py:81-86)
-__global__ __launch_bounds__(kBlock) void global_avgpool_kernel(int P, int C, int ld, const float *__restrict__ x,
-                                                                float *__restrict__ y) {
-    __shared__ float part[4][64];
-    const int b = blockIdx.y;
+// Two deterministic stages: kAvgChunks workgroups per (image, 64-channel group) sum a pixel range each
+// into the caller's workspace, then one wave per output adds the partials in fixed order.
+constexpr int kAvgChunks = 32;
+
+__global__ __launch_bounds__(kBlock) void global_avgpool_partial_kernel(int P, int C, int ld,
+                                                                        const float *__restrict__ x,
+                                                                        float *__restrict__ part) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.z, chunk = blockIdx.y;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int g = threadIdx.x >> 6;
+    const int per = (P + kAvgChunks - 1) / kAvgChunks;
+    const int p0 = chunk * per, p1 = min(P, p0 + per);
     float s = 0.f;
     if (c < C)
-        for (int p = g; p < P; p += 4) s += x[((long long)b * P + p) * ld + c];
-    part[g][threadIdx.x & 63] = s;
+        for (int p = p0 + g; p < p1; p += 4) s += x[((long long)b * P + p) * ld + c];
+    red[g][threadIdx.x & 63] = s;
     __syncthreads();
-    if (g == 0 && c < C) y[(long long)b * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / (float)P;
+    if (g == 0 && c < C)
+        part[((long long)b * kAvgChunks + chunk) * C + c] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(kBlock) void global_avgpool_final_kernel(int B, int P, int C,
+                                                                      const float *__restrict__ part,
+                                                                      float *__restrict__ y) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;   // b*C + c
+    if (i >= (long long)B * C) return;
+    const int b = (int)(i / C), c = (int)(i - (long long)b * C);
+    float s = 0.f;
+    for (int k = 0; k < kAvgChunks; ++k) s += part[((long long)b * kAvgChunks + k) * C + c];
+    y[i] = s / (float)P;
 }
 
 // y[b,n] = act(scale[n] * dot(W[n,:], x[b,:]) + bias[n]) : one wave per output
@@ -290,11 +310,22 @@ extern "C" int sgv3d_nhwc_to_nchw(int batch, int channels, int h, int w, int ld,
     return check_launch("nhwc_to_nchw_kernel");
 }
 
-extern "C" int sgv3d_global_avgpool(int batch, int pixels, int channels, int x_ld, const float *x, float *y, void *stream) {
+extern "C" size_t sgv3d_global_avgpool_workspace_bytes(int batch, int channels) {
+    if (batch <= 0 || channels <= 0) return 0;
+    return sizeof(float) * (size_t)batch * kAvgChunks * channels;
+}
+
+extern "C" int sgv3d_global_avgpool(int batch, int pixels, int channels, int x_ld, const float *x, float *y,
+                                    void *workspace, size_t workspace_bytes, void *stream) {
     SGV3D_REQUIRE(batch > 0 && pixels > 0 && channels > 0 && x_ld >= channels, "global_avgpool: bad shape");
-    SGV3D_REQUIRE(x && y, "global_avgpool: null pointer");
-    hipLaunchKernelGGL(global_avgpool_kernel, dim3(cdiv(channels, 64), batch), dim3(kBlock), 0, as_stream(stream), pixels,
-                       channels, x_ld, x, y);
+    SGV3D_REQUIRE(x && y && workspace, "global_avgpool: null pointer");
+    if (workspace_bytes < sgv3d_global_avgpool_workspace_bytes(batch, channels))
+        return fail(SGV3D_ENOSPACE, "global_avgpool: workspace too small");
+    float *part = static_cast<float *>(workspace);
+    hipLaunchKernelGGL(global_avgpool_partial_kernel, dim3(cdiv(channels, 64), kAvgChunks, batch), dim3(kBlock), 0,
+                       as_stream(stream), pixels, channels, x_ld, x, part);
+    hipLaunchKernelGGL(global_avgpool_final_kernel, dim3(cdiv((long long)batch * channels, kBlock)), dim3(kBlock), 0,
+                       as_stream(stream), batch, pixels, channels, part, y);
     return check_launch("global_avgpool_kernel");
 }
 

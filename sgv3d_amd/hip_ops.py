@@ -106,11 +106,12 @@ class PackedConv:
         self.tile = int(tile)
         k = self.cin if transposed else kh * kw * self.cin
         self.k_pad, self.cout_pad = pack_geometry(k, gemm_n)
+        self.k_order = 1 if self.cin % 32 == 0 else 0      # channel-chunk-major k when possible
         self.w = torch.empty(self.cout_pad, self.k_pad, dtype=torch.float32, device=device)
         with torch.cuda.device(device):
             rc = _lib.load().sgv3d_conv_pack_weight(w.data_ptr(), cout, cin, kh, kw, self.cin,
-                                                   1 if transposed else 0, self.w.data_ptr(), self.k_pad,
-                                                   self.cout_pad, _st(w))
+                                                   1 if transposed else 0, self.k_order, self.w.data_ptr(),
+                                                   self.k_pad, self.cout_pad, _st(w))
         _lib.check(rc, "sgv3d_conv_pack_weight")
         self.scale = None if scale is None else scale.detach().to(device=device, dtype=torch.float32).contiguous()
         self.shift = None if shift is None else shift.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -150,6 +151,7 @@ class PackedConv:
         d.deconv_ks = self.ks
         d.k_pad, d.cout_pad = self.k_pad, self.cout_pad
         d.x_nchw = 0
+        d.k_order = self.k_order
         lib = _lib.load()
         args = (x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
                 _lib.ptr(gate), out.data_ptr(), _st(x))
@@ -230,8 +232,11 @@ def global_avgpool(x, out=None):
     B, H, W, C = (int(s) for s in x.shape)
     if out is None:
         out = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.sgv3d_global_avgpool_workspace_bytes(B, C)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device), prof("global_avgpool"):
-        rc = _lib.load().sgv3d_global_avgpool(B, H * W, C, C, x.data_ptr(), out.data_ptr(), _st(x))
+        rc = lib.sgv3d_global_avgpool(B, H * W, C, C, x.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes, _st(x))
     _lib.check(rc, "sgv3d_global_avgpool")
     return out
 
