@@ -170,57 +170,77 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
 
-    // two k-groups (16 of the tile's 32 k) from LDS buffer BUF
-#define SGV3D_MFMA_HALF(BUF, KQ0)                                                                     \
+    // Fragment double buffering at k-group granularity: the ds_read_b128 of k-group q+1 are issued
+    // before the MFMAs of k-group q, and the first k-group of the NEXT tile is fetched right after the
+    // barrier that publishes it, under the last MFMAs of the current tile -> no exposed LDS latency.
+    float4 fa0[WTM], fb0[WTN], fa1[WTM], fb1[WTN];
+#define SGV3D_READ_FRAG(FA, FB, BUF, KQ)                                                              \
     do {                                                                                              \
-        const float *Aw_ = As0 + (BUF) * kBufStride + a_frag_off;                                     \
-        const float *Bw_ = Bs0 + (BUF) * kBufStride + b_frag_off;                                     \
-        _Pragma("unroll") for (int kq = (KQ0); kq < (KQ0) + 2; ++kq) {                                \
-            float4 af[WTM], bf[WTN];                                                                  \
-            _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                        \
-                af[mt] = *reinterpret_cast<const float4 *>(Aw_ + mt * 32 * LDK + kq * 8);             \
-            _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt)                                        \
-                bf[nt] = *reinterpret_cast<const float4 *>(Bw_ + nt * 32 * LDK + kq * 8);             \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
-                _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt) {                                  \
-                    const float av = j == 0 ? af[mt].x : j == 1 ? af[mt].y : j == 2 ? af[mt].z : af[mt].w; \
-                    _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt) {                              \
-                        const float bv = j == 0 ? bf[nt].x : j == 1 ? bf[nt].y : j == 2 ? bf[nt].z : bf[nt].w; \
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][nt], 0, 0, 0); \
-                    }                                                                                 \
+        const float *Aw_ = As0 + (BUF) * kBufStride + a_frag_off + (KQ) * 8;                          \
+        const float *Bw_ = Bs0 + (BUF) * kBufStride + b_frag_off + (KQ) * 8;                          \
+        _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt) {                                          \
+            const float4 t_ = *reinterpret_cast<const float4 *>(Aw_ + mt * 32 * LDK);                 \
+            FA[mt].x = t_.x; FA[mt].y = t_.y; FA[mt].z = t_.z; FA[mt].w = t_.w;                       \
+        }                                                                                             \
+        _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt) {                                          \
+            const float4 t_ = *reinterpret_cast<const float4 *>(Bw_ + nt * 32 * LDK);                 \
+            FB[nt].x = t_.x; FB[nt].y = t_.y; FB[nt].z = t_.z; FB[nt].w = t_.w;                       \
+        }                                                                                             \
+    } while (0)
+#define SGV3D_MFMA_KQ(FA, FB)                                                                         \
+    do {                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+            _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt) {                                      \
+                const float av = j == 0 ? FA[mt].x : j == 1 ? FA[mt].y : j == 2 ? FA[mt].z : FA[mt].w; \
+                _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt) {                                  \
+                    const float bv = j == 0 ? FB[nt].x : j == 1 ? FB[nt].y : j == 2 ? FB[nt].z : FB[nt].w; \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][nt], 0, 0, 0); \
                 }                                                                                     \
             }                                                                                         \
         }                                                                                             \
+    } while (0)
+#define SGV3D_SB() __builtin_amdgcn_sched_barrier(0)
+
+    // One k-tile held in LDS buffer BUF: fetch tile +2 into (RA, RB), publish tile +1 from (SA, SB).
+#define SGV3D_PHASE(BUF, RA, RB, SA, SB, HAVE_NEXT)                                                   \
+    do {                                                                                              \
+        SGV3D_LOAD_TILE(RA, RB);                                                                      \
+        SGV3D_READ_FRAG(fa1, fb1, BUF, 1);                                                            \
+        SGV3D_SB();                                                                                   \
+        SGV3D_MFMA_KQ(fa0, fb0);                                                                      \
+        SGV3D_SB();                                                                                   \
+        SGV3D_READ_FRAG(fa0, fb0, BUF, 2);                                                            \
+        SGV3D_SB();                                                                                   \
+        SGV3D_MFMA_KQ(fa1, fb1);                                                                      \
+        SGV3D_SB();                                                                                   \
+        if (HAVE_NEXT) SGV3D_STORE_TILE(SA, SB, (BUF) ^ 1);                                           \
+        SGV3D_READ_FRAG(fa1, fb1, BUF, 3);                                                            \
+        SGV3D_SB();                                                                                   \
+        SGV3D_MFMA_KQ(fa0, fb0);                                                                      \
+        SGV3D_SB();                                                                                   \
+        __syncthreads();                                                                              \
+        if (HAVE_NEXT) SGV3D_READ_FRAG(fa0, fb0, (BUF) ^ 1, 0);                                       \
+        SGV3D_SB();                                                                                   \
+        SGV3D_MFMA_KQ(fa1, fb1);                                                                      \
+        SGV3D_SB();                                                                                   \
     } while (0)
 
     SGV3D_LOAD_TILE(ra0, rb0);                       // tile 0
     SGV3D_LOAD_TILE(ra1, rb1);                       // tile 1
     SGV3D_STORE_TILE(ra0, rb0, 0);
     __syncthreads();
+    SGV3D_READ_FRAG(fa0, fb0, 0, 0);
     for (int kt = 0; kt < nkt; kt += 2) {
-        // ---- tile kt sits in LDS buffer 0 ---------------------------------------------------------
-        SGV3D_LOAD_TILE(ra0, rb0);                   // tile kt+2 (branch-free, see the macro)
-        __builtin_amdgcn_sched_barrier(0);
-        SGV3D_MFMA_HALF(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nkt) SGV3D_STORE_TILE(ra1, rb1, 1);   // buffer 1 was last read before the previous barrier
-        __builtin_amdgcn_sched_barrier(0);
-        SGV3D_MFMA_HALF(0, 2);
-        __syncthreads();
+        SGV3D_PHASE(0, ra0, rb0, ra1, rb1, kt + 1 < nkt);      // tile kt in buffer 0
         if (kt + 1 >= nkt) break;
-        // ---- tile kt+1 sits in LDS buffer 1 -------------------------------------------------------
-        SGV3D_LOAD_TILE(ra1, rb1);                   // tile kt+3
-        __builtin_amdgcn_sched_barrier(0);
-        SGV3D_MFMA_HALF(1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nkt) SGV3D_STORE_TILE(ra0, rb0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        SGV3D_MFMA_HALF(1, 2);
-        __syncthreads();
+        SGV3D_PHASE(1, ra1, rb1, ra0, rb0, kt + 2 < nkt);      // tile kt+1 in buffer 1
     }
 #undef SGV3D_LOAD_TILE
 #undef SGV3D_STORE_TILE
-#undef SGV3D_MFMA_HALF
+#undef SGV3D_READ_FRAG
+#undef SGV3D_MFMA_KQ
+#undef SGV3D_PHASE
+#undef SGV3D_SB
 
     // ---- epilogue: scale/bias (folded BN or conv bias), residual, ReLU, gate, store ---------------
     const int hw = a.m_h * a.m_w;
