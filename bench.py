@@ -59,13 +59,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
-
     from sgv3d_amd import hip_ops, synthetic as S
+    from sgv3d_amd.replicas import ReplicaGroup
+    group = ReplicaGroup(backend="nccl" if world > 1 else None, device=dev)   # nccl == RCCL on ROCm
     from sgv3d_amd.models.bev_height import BEVHeight
 
     bc, hc = S.r50_256_conf()
@@ -81,11 +77,6 @@ def main():
     def step():
         with torch.no_grad():
             return model(imgs, mats)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     # ---- warm-up: packs weights, tunes tiles, fills the caching allocator ---------------------
     for _ in range(max(1, args.warmup)):
@@ -119,18 +110,8 @@ def main():
         run()
 
     # ---- timed region: exactly K steps ------------------------------------------------------------
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    frames = world * B * args.steps
-    value = frames / elapsed
+    elapsed = group.timed(run, args.steps)          # barrier+sync | K steps | barrier+sync, MAX over ranks
+    value = group.aggregate_throughput(B, args.steps, elapsed)
 
     # ---- roofline: instrumented pass, HIP events around every conv launch -------------------------
     roofline = None
@@ -199,8 +180,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":
