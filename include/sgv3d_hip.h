@@ -54,8 +54,9 @@ int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int num_channels
  * written exactly once (empty voxels are written as zeros: no pre-zeroing needed).  The plan only
  * depends on geom_xyz (i.e. on the camera calibration) and can be reused across calls.
  *
- * Plan workspace layout (bytes from sgv3d_voxel_plan_bytes, 256-B aligned by the caller):
- *   int32 seg_start[B*Y*X + 1] | int32 cursor[B*Y*X] | int32 order[B*N] | int32 scan scratch      */
+ * Plan layout (bytes from sgv3d_voxel_plan_bytes, 16-B aligned by the caller):
+ *   int32 seg_start[B*Y*X + 1] | int32 cursor[B*Y*X + 1] | int32 order[B*N] | int32 slot_voxel[B*N + 1]
+ *   | int32 scan scratch                                                                            */
 size_t sgv3d_voxel_plan_bytes(int batch_size, int num_points, int num_voxel_x, int num_voxel_y);
 
 /* Build the plan.  pos_memo as above (may be NULL).  sort_segments != 0 makes every voxel's point
@@ -66,21 +67,26 @@ int sgv3d_voxel_plan_build(int batch_size, int num_points,
                            void *plan, size_t plan_bytes, int sort_segments, void *stream);
 
 /* output_features f32 [B, Y, X, C], fully overwritten.  Replaces the same reference kernel
- * (voxel_pooling_forward_cuda.cu:9-36) when the caller holds a plan. */
+ * (voxel_pooling_forward_cuda.cu:9-36) when the caller holds a plan.  `workspace` (bytes from
+ * sgv3d_voxel_pooling_workspace_bytes, 16-B aligned) holds the partial rows of voxels whose point
+ * list is cut by a work-chunk border; it is scratch, its content is meaningless after the call. */
+size_t sgv3d_voxel_pooling_workspace_bytes(int batch_size, int num_points, int num_channels);
 int sgv3d_voxel_pooling_forward_planned(int batch_size, int num_points, int num_channels,
                                         int num_voxel_x, int num_voxel_y,
                                         const void *plan, const float *input_features,
-                                        float *output_features, void *stream);
+                                        float *output_features, void *workspace, size_t workspace_bytes,
+                                        void *stream);
 
 /* Fused lift-splat (optional fast path beyond the operator boundary):
  *   out[b, y, x, :] = sum over plan points p=(d, pixel) of prob[b, d, pixel] * context[b, pixel, :]
  * without materialising the [B, N, C] lifted tensor of layers/backbones/lss_fpn.py:462-466,486.
  *   prob    f32 [B, D, P]  (softmax over D already applied), P = fH*fW, N = D*P, p = d*P + pixel
- *   context f32 [B, P, C]  channel-last */
+ *   context f32 [B, P, C]  channel-last;  workspace as for sgv3d_voxel_pooling_forward_planned */
 int sgv3d_lift_splat_planned(int batch_size, int num_depth, int num_pixels, int num_channels,
                              int num_voxel_x, int num_voxel_y, const void *plan,
                              const float *prob, const float *context,
-                             float *output_features, void *stream);
+                             float *output_features, void *workspace, size_t workspace_bytes,
+                             void *stream);
 
 /* VoxelPooling.backward  ops/voxel_pooling/voxel_pooling.py:58-69
  *   grad_output f32 [B, C, Y, X] with element strides (sb, sc, sy, sx)  (the autograd grad is a

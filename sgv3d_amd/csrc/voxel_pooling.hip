@@ -82,7 +82,7 @@ struct PlanLayout {
     long long V;        // B*Y*X
     long long total;    // B*N
     int nblk;           // scan workgroups
-    size_t off_seg, off_cur, off_order, off_blk, bytes;
+    size_t off_seg, off_cur, off_order, off_slotvox, off_blk, bytes;
 };
 
 PlanLayout plan_layout(int B, int N, int X, int Y) {
@@ -94,9 +94,24 @@ PlanLayout plan_layout(int B, int N, int X, int Y) {
     L.off_seg = 0;
     L.off_cur = al(L.off_seg + sizeof(int) * (size_t)(L.V + 1));
     L.off_order = al(L.off_cur + sizeof(int) * (size_t)(L.V + 1));
-    L.off_blk = al(L.off_order + sizeof(int) * (size_t)L.total);
+    L.off_slotvox = al(L.off_order + sizeof(int) * (size_t)L.total);
+    L.off_blk = al(L.off_slotvox + sizeof(int) * (size_t)(L.total + 1));
     L.bytes = al(L.off_blk + sizeof(int) * (size_t)(L.nblk + 2));
     return L;
+}
+
+// Runs of equal voxel id inside one wave (consecutive frustum points along the image row mostly land
+// in the same voxel): the head lane of a run issues ONE atomic for the whole run, which cuts the
+// atomic count ~5-10x on real geometry and removes most of the same-address contention.
+__device__ __forceinline__ void wave_runs(int v, int lane, int &head_lane, int &run_len, bool &is_head) {
+    const int vp = __shfl_up(v, 1, 64);
+    is_head = (lane == 0) || (vp != v);
+    const unsigned long long heads = __ballot(is_head);
+    const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1);
+    head_lane = 63 - __clzll((long long)(heads & upto));
+    const unsigned long long after = head_lane == 63 ? 0ull : heads & ~((1ull << (head_lane + 1)) - 1);
+    const int next = after ? __ffsll((long long)after) - 1 : 64;
+    run_len = next - head_lane;
 }
 
 __global__ __launch_bounds__(kBlock) void vp_count_kernel(long long total_pts, int N, int X, int Y, int Z,
@@ -104,17 +119,22 @@ __global__ __launch_bounds__(kBlock) void vp_count_kernel(long long total_pts, i
                                                           int32_t *__restrict__ pos_memo,
                                                           int *__restrict__ count) {
     const long long pt = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (pt >= total_pts) return;
-    const int b = (int)(pt / N);
-    int x, y;
-    const int v = voxel_of_point(geom, pt, b, X, Y, Z, x, y);
-    if (v < 0) return;
-    if (pos_memo) {
-        pos_memo[pt * 3 + 0] = b;
-        pos_memo[pt * 3 + 1] = y;
-        pos_memo[pt * 3 + 2] = x;
+    const int lane = threadIdx.x & 63;
+    int v = -1;
+    if (pt < total_pts) {
+        const int b = (int)(pt / N);
+        int x, y;
+        v = voxel_of_point(geom, pt, b, X, Y, Z, x, y);
+        if (v >= 0 && pos_memo) {
+            pos_memo[pt * 3 + 0] = b;
+            pos_memo[pt * 3 + 1] = y;
+            pos_memo[pt * 3 + 2] = x;
+        }
     }
-    atomicAdd(count + v, 1);
+    int head_lane, run_len;
+    bool is_head;
+    wave_runs(v, lane, head_lane, run_len, is_head);
+    if (is_head && v >= 0) atomicAdd(count + v, run_len);
 }
 
 // exclusive scan of one int per thread across a 256-thread workgroup; returns the exclusive prefix
@@ -195,15 +215,78 @@ __global__ __launch_bounds__(kBlock) void vp_scan_add_kernel(long long V, int nb
 __global__ __launch_bounds__(kBlock) void vp_fill_kernel(long long total_pts, int N, int X, int Y, int Z,
                                                          const int32_t *__restrict__ geom,
                                                          int *__restrict__ cursor,
-                                                         int *__restrict__ order) {
+                                                         int *__restrict__ order,
+                                                         int *__restrict__ slot_voxel) {
     const long long pt = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (pt >= total_pts) return;
-    const int b = (int)(pt / N);
-    int x, y;
-    const int v = voxel_of_point(geom, pt, b, X, Y, Z, x, y);
-    if (v < 0) return;
-    const int slot = atomicAdd(cursor + v, 1);
-    order[slot] = (int)pt;
+    const int lane = threadIdx.x & 63;
+    int v = -1;
+    if (pt < total_pts) {
+        const int b = (int)(pt / N);
+        int x, y;
+        v = voxel_of_point(geom, pt, b, X, Y, Z, x, y);
+    }
+    int head_lane, run_len;
+    bool is_head;
+    wave_runs(v, lane, head_lane, run_len, is_head);
+    int base = 0;
+    if (is_head && v >= 0) base = atomicAdd(cursor + v, run_len);
+    base = __shfl(base, head_lane, 64);
+    if (v >= 0) {
+        const int slot = base + (lane - head_lane);
+        order[slot] = (int)pt;
+        slot_voxel[slot] = v;
+    }
+}
+
+// Segments of lo+1 .. 64*R points: one wave per voxel, the list lives in R registers per lane
+// (element e = r*64 + lane) and is sorted by a bitonic network whose steps run over the cross-lane
+// network (distance < 64) or between registers of one lane (distance >= 64): no LDS, no barrier, and
+// every long voxel gets its own wave, so the per-voxel multiplicity skew costs no serialisation.
+template <int R>
+__global__ __launch_bounds__(kBlock) void vp_sort_wave_kernel(long long V, const int *__restrict__ seg_start,
+                                                              int *__restrict__ order, int lo) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (kBlock / 64);
+    for (long long v = wave0; v < V; v += nwaves) {
+        const int s = seg_start[v];
+        const int n = seg_start[v + 1] - s;
+        if (n <= lo || n > 64 * R) continue;   // wave-uniform
+        int val[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) val[r] = (r * 64 + lane) < n ? order[s + r * 64 + lane] : 0x7fffffff;
+#pragma unroll
+        for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j >= 64) {
+                    const int rj = j >> 6;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if ((r & rj) == 0) {
+                            const bool up = (((r * 64 + lane) & k) == 0);
+                            const int a = val[r], b = val[r | rj];
+                            const int mn = min(a, b), mx = max(a, b);
+                            val[r] = up ? mn : mx;
+                            val[r | rj] = up ? mx : mn;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int other = __shfl_xor(val[r], j, 64);
+                        const bool up = (((r * 64 + lane) & k) == 0);
+                        const bool lower = (lane & j) == 0;
+                        const int mn = min(val[r], other), mx = max(val[r], other);
+                        val[r] = (lower == up) ? mn : mx;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((r * 64 + lane) < n) order[s + r * 64 + lane] = val[r];
+    }
 }
 
 // Ascending sort of every segment whose length is in (lo, hi]: normalised bitonic network (all
@@ -213,44 +296,62 @@ template <int T, int LDS_CAP>
 __global__ __launch_bounds__(T) void vp_sort_segments_kernel(long long V, const int *__restrict__ seg_start,
                                                              int *__restrict__ order, int lo, int hi) {
     __shared__ int buf[LDS_CAP];
+    __shared__ int todo[T];
+    __shared__ int ntodo;
     const int tid = threadIdx.x;
-    for (long long v = blockIdx.x; v < V; v += gridDim.x) {
-        const int s = seg_start[v];
-        const int n = seg_start[v + 1] - s;
-        if (n <= lo || n > hi) continue;  // uniform per workgroup
-        int *data = order + s;
-        const bool in_lds = n <= LDS_CAP;
-        if (in_lds) {
-            for (int i = tid; i < n; i += T) buf[i] = data[i];
+    // The workgroup inspects T voxels at a time and queues the ones it has to sort.  Voxel ids are
+    // dealt round-robin over the workgroups (v = slot * gridDim + block): long segments cluster in
+    // neighbouring voxels (near the camera), a contiguous assignment would serialise them on one CU.
+    const long long G = gridDim.x;
+    for (long long sb = 0; sb * G < V; sb += T) {
+        if (tid == 0) ntodo = 0;
+        __syncthreads();
+        {
+            const long long v = (sb + tid) * G + blockIdx.x;
+            const int n = v < V ? seg_start[v + 1] - seg_start[v] : 0;
+            if (n > lo && n <= hi) todo[atomicAdd(&ntodo, 1)] = tid;   // queue order does not matter
         }
         __syncthreads();
-        int *d = in_lds ? buf : data;
-        int half = 1;  // npow2 / 2
-        while (half * 2 < n) half <<= 1;
-        for (int k = 2; (k >> 1) < n; k <<= 1) {
-            const int hk = k >> 1;
-            for (int i = tid; i < half; i += T) {  // flip stage: i <-> k-1-i inside each k block
-                const int blk = i / hk, off = i - blk * hk;
-                const int a = blk * k + off, b = blk * k + k - 1 - off;
-                if (b < n) {
-                    const int va = d[a], vb = d[b];
-                    if (va > vb) { d[a] = vb; d[b] = va; }
-                }
+        const int nq = ntodo;
+        for (int qi = 0; qi < nq; ++qi) {
+            const long long v = (sb + todo[qi]) * G + blockIdx.x;
+            const int s = seg_start[v];
+            const int n = seg_start[v + 1] - s;
+            int *data = order + s;
+            const bool in_lds = n <= LDS_CAP;
+            if (in_lds) {
+                for (int i = tid; i < n; i += T) buf[i] = data[i];
             }
             __syncthreads();
-            for (int j = k >> 2; j > 0; j >>= 1) {  // half cleaners
-                for (int i = tid; i < half; i += T) {
-                    const int a = 2 * j * (i / j) + (i % j), b = a + j;
+            int *d = in_lds ? buf : data;
+            int half = 1;  // npow2 / 2
+            while (half * 2 < n) half <<= 1;
+            for (int k = 2; (k >> 1) < n; k <<= 1) {
+                const int hk = k >> 1;
+                for (int i = tid; i < half; i += T) {  // flip stage: i <-> k-1-i inside each k block
+                    const int blk = i / hk, off = i - blk * hk;
+                    const int a = blk * k + off, b = blk * k + k - 1 - off;
                     if (b < n) {
                         const int va = d[a], vb = d[b];
                         if (va > vb) { d[a] = vb; d[b] = va; }
                     }
                 }
                 __syncthreads();
+                for (int j = k >> 2; j > 0; j >>= 1) {  // half cleaners
+                    for (int i = tid; i < half; i += T) {
+                        const int a = 2 * j * (i / j) + (i % j), b = a + j;
+                        if (b < n) {
+                            const int va = d[a], vb = d[b];
+                            if (va > vb) { d[a] = vb; d[b] = va; }
+                        }
+                    }
+                    __syncthreads();
+                }
             }
-        }
-        if (in_lds) {
-            for (int i = tid; i < n; i += T) data[i] = buf[i];
+            if (in_lds) {
+                for (int i = tid; i < n; i += T) data[i] = buf[i];
+            }
+            __syncthreads();
         }
         __syncthreads();
     }
@@ -346,6 +447,139 @@ __global__ __launch_bounds__(kBlock) void vp_gather_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// 2c. balanced gather ("v2").  Work is cut over the SORTED SLOTS, not over voxels: each LPR-lane row
+// group owns `ch` consecutive slots of the plan's order[] (ch = min(16, LPR-2)), fetches all of
+// their rows at once (ch x 16 B in flight per lane), and runs a segmented sum over them.  A run that
+// covers a whole voxel is stored directly; a run cut by a chunk border goes to partial[chunk][0]
+// (it started in an earlier chunk) or partial[chunk][1] (it starts here and continues), and
+// vp_fixup_kernel adds the pieces of each cut voxel in ascending chunk order.  Every group does the
+// same amount of work whatever the per-voxel multiplicity (mean 16, max 246 at cfg-2; max 775 on the
+// 128^2 grid), which the one-wave-per-voxel kernel above cannot offer.  Deterministic.
+// ------------------------------------------------------------------------------------------------
+constexpr int kChunkMax = 16;
+
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) void vp_gather2_kernel(
+    long long V, int C, int lpr, int groups, int ch, const int *__restrict__ seg_start,
+    const int *__restrict__ order, const int *__restrict__ slot_voxel, const float *__restrict__ feats,
+    const float *__restrict__ prob, const float *__restrict__ ctx, int N, int P, float *__restrict__ out,
+    float *__restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane / lpr;
+    const int cl = lane - g * lpr;
+    const int glane0 = g * lpr;
+    const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const long long chunk = wave * groups + g;
+    const int T = seg_start[V];
+    const long long base = chunk * ch;
+    const bool active = g < groups && base < T;
+    const int ncols = C >> 2;
+    // lanes 0..ch+1 of the group fetch slot base-1+cl: voxel id (all) and point id (the ch inner ones)
+    int my_vox = -1, my_idx = -1;
+    if (active && cl < ch + 2) {
+        const long long sl = base - 1 + cl;
+        if (sl >= 0 && sl < T) {
+            my_vox = slot_voxel[sl];
+            if (cl >= 1 && cl <= ch) my_idx = order[sl];
+        }
+    }
+    const int prev_vox = __shfl(my_vox, glane0, 64);
+    const int next_vox = __shfl(my_vox, glane0 + ch + 1, 64);
+    const int cnt = active ? (int)min((long long)ch, (long long)T - base) : 0;
+    int vox[kChunkMax];
+    float4 val[kChunkMax];
+    float pr[kChunkMax];
+#pragma unroll
+    for (int k = 0; k < kChunkMax; ++k) {
+        const int src = glane0 + 1 + (k < ch ? k : 0);
+        const int idx = __shfl(my_idx, src, 64);
+        vox[k] = __shfl(my_vox, src, 64);
+        val[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pr[k] = 0.f;
+        if (k < cnt && cl < ncols) {
+            if constexpr (FUSED) {
+                const int b = idx / N;
+                const int pix = (idx - b * N) % P;
+                pr[k] = prob[idx];
+                val[k] = *reinterpret_cast<const float4 *>(ctx + ((size_t)b * P + pix) * C + (size_t)cl * 4);
+            } else {
+                val[k] = *reinterpret_cast<const float4 *>(feats + (size_t)idx * C + (size_t)cl * 4);
+            }
+        }
+    }
+    // rows of empty voxels: every group of the launch clears its share (disjoint from every row the
+    // gather / fix-up write, so no ordering is needed and no memset pass either)
+    if (g < groups && cl < ncols) {
+        const long long ngroups = (long long)gridDim.x * (kBlock / 64) * groups;
+        const long long per = (V + ngroups - 1) / ngroups;
+        const long long v0 = chunk * per, v1 = min(V, v0 + per);
+        for (long long v = v0; v < v1; ++v)
+            if (seg_start[v] == seg_start[v + 1])
+                *reinterpret_cast<float4 *>(out + (size_t)v * C + (size_t)cl * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (!active || cl >= ncols) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cur = vox[0];
+    bool before = prev_vox == cur;       // the first run started in an earlier chunk
+#pragma unroll
+    for (int k = 0; k < kChunkMax; ++k) {
+        if (k < cnt) {
+            if (vox[k] != cur) {             // run of `cur` ended inside the chunk
+                float *dst = before ? partial + ((size_t)chunk * 2 + 0) * C : out + (size_t)cur * C;
+                *reinterpret_cast<float4 *>(dst + (size_t)cl * 4) = acc;
+                acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                cur = vox[k];
+                before = false;
+            }
+            if constexpr (FUSED) vfma(acc, pr[k], val[k]);
+            else vacc(acc, val[k]);
+        }
+    }
+    const bool after = cnt == ch && next_vox == cur;   // the last run continues in the next chunk
+    float *dst = before ? partial + ((size_t)chunk * 2 + 0) * C
+                        : after ? partial + ((size_t)chunk * 2 + 1) * C : out + (size_t)cur * C;
+    *reinterpret_cast<float4 *>(dst + (size_t)cl * 4) = acc;
+}
+
+// One row group per chunk: if the chunk's last run starts here and continues, it leads that voxel:
+// out[v] = partial[j][1] + partial[j+1][0] + ... in ascending chunk order.  The leader test reads its
+// four slot ids up front (independent loads) and the piece count comes from the voxel's segment
+// bounds, so the partial rows are fetched as independent loads, not as a dependent chain.
+__global__ __launch_bounds__(kBlock) void vp_fixup_kernel(long long V, int C, int lpr, int groups, int ch,
+                                                          const int *__restrict__ seg_start,
+                                                          const int *__restrict__ slot_voxel,
+                                                          const float *__restrict__ partial, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane / lpr;
+    const int cl = lane - g * lpr;
+    const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const long long j = wave * groups + g;
+    const int T = seg_start[V];
+    const long long base = j * ch;
+    if (g >= groups || base + ch >= T || cl >= (C >> 2)) return;   // the last chunk cannot continue
+    const int v_last = slot_voxel[base + ch - 1];
+    const int v_next = slot_voxel[base + ch];
+    const int v_first = slot_voxel[base];
+    const int v_prev = base > 0 ? slot_voxel[base - 1] : -1;
+    if (v_next != v_last) return;                                   // last run ends with this chunk
+    if (v_first == v_last && v_prev == v_last) return;              // middle piece, not the leader
+    const int v = v_last;
+    const long long jl = ((long long)seg_start[v + 1] - 1) / ch;    // chunk holding the voxel's last point
+    float4 sum = *reinterpret_cast<const float4 *>(partial + ((size_t)j * 2 + 1) * C + (size_t)cl * 4);
+    for (long long jj = j + 1; jj <= jl; jj += 4) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            p[u] = (jj + u <= jl) ? *reinterpret_cast<const float4 *>(partial + ((size_t)(jj + u) * 2 + 0) * C + (size_t)cl * 4)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (jj + u <= jl) vacc(sum, p[u]);
+    }
+    *reinterpret_cast<float4 *>(out + (size_t)v * C + (size_t)cl * 4) = sum;
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward gather  (voxel_pooling.py:58-69)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void vp_backward_kernel(long long total_elems, int C,
@@ -375,13 +609,48 @@ int check_common(int B, int N, int C, int X, int Y, int Z) {
     return SGV3D_OK;
 }
 
+struct GatherGeom {
+    bool v2;
+    int lpr, groups, ch;
+    long long nchunks;
+};
+
+GatherGeom gather_geom(long long total_pts, int C) {
+    GatherGeom G;
+    G.v2 = false; G.lpr = G.groups = G.ch = 0; G.nchunks = 0;
+    if (C % 4 == 0 && C / 4 <= 64 && C / 4 >= 6) {
+        G.v2 = true;
+        G.lpr = C / 4;
+        G.groups = 64 / G.lpr;
+        G.ch = G.lpr - 2 < kChunkMax ? G.lpr - 2 : kChunkMax;
+        G.nchunks = (total_pts + G.ch - 1) / G.ch;
+    }
+    return G;
+}
+
 template <bool FUSED>
 int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const float *feats,
-                  const float *prob, const float *ctx, int P, float *out, hipStream_t st) {
+                  const float *prob, const float *ctx, int P, float *out, void *workspace, size_t ws_bytes,
+                  hipStream_t st) {
     const PlanLayout L = plan_layout(B, N, X, Y);
     const char *base = static_cast<const char *>(plan);
     const int *seg = reinterpret_cast<const int *>(base + L.off_seg);
     const int *order = reinterpret_cast<const int *>(base + L.off_order);
+    const int *slotvox = reinterpret_cast<const int *>(base + L.off_slotvox);
+    const GatherGeom G = gather_geom(L.total, C);
+    if (G.v2) {
+        const size_t need = sizeof(float) * (size_t)G.nchunks * 2 * C;
+        if (!workspace || ws_bytes < need)
+            return fail(SGV3D_ENOSPACE, "voxel pooling: workspace has %zu bytes, needs %zu", ws_bytes, need);
+        const long long waves = (G.nchunks + G.groups - 1) / G.groups;
+        const int grid = cdiv(waves, kBlock / 64);
+        float *partial = static_cast<float *>(workspace);
+        hipLaunchKernelGGL((vp_gather2_kernel<FUSED>), dim3(grid), dim3(kBlock), 0, st, L.V, C, G.lpr, G.groups, G.ch,
+                           seg, order, slotvox, feats, prob, ctx, N, P, out, partial);
+        hipLaunchKernelGGL(vp_fixup_kernel, dim3(grid), dim3(kBlock), 0, st, L.V, C, G.lpr, G.groups, G.ch, seg, slotvox,
+                           partial, out);
+        return check_launch(FUSED ? "vp_lift_splat(v2)" : "vp_gather2_kernel");
+    }
     const long long waves = (L.V + kVoxPerWave - 1) / kVoxPerWave;
     const int grid = cdiv(waves, kBlock / 64);
     if (C % 4 == 0) {
@@ -448,33 +717,43 @@ extern "C" int sgv3d_voxel_plan_build(int batch_size, int num_points, int num_vo
     hipLaunchKernelGGL(vp_scan_add_kernel, dim3(cdiv(L.V + 1, kBlock)), dim3(kBlock), 0, st, L.V, L.nblk, blk,
                        seg, cur);
     hipLaunchKernelGGL(vp_fill_kernel, dim3(pgrid), dim3(kBlock), 0, st, L.total, num_points, num_voxel_x,
-                       num_voxel_y, num_voxel_z, geom_xyz, cur, order);
+                       num_voxel_y, num_voxel_z, geom_xyz, cur, order, reinterpret_cast<int *>(base + L.off_slotvox));
     if (sort_segments) {
-        const int g_small = (int)(L.V < 8192 ? L.V : 8192);
-        hipLaunchKernelGGL((vp_sort_segments_kernel<64, 256>), dim3(g_small), dim3(64), 0, st, L.V, seg, order, 1, 256);
-        const int g_large = (int)(L.V < 1024 ? L.V : 1024);
+        const int g_wave = (int)(L.V / 4 < 4096 ? (L.V + 3) / 4 : 4096);
+        hipLaunchKernelGGL((vp_sort_wave_kernel<1>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 1);
+        hipLaunchKernelGGL((vp_sort_wave_kernel<4>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 64);
+        hipLaunchKernelGGL((vp_sort_wave_kernel<16>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 256);
+        const int g_large = (int)((L.V + 255) / 256 < 1024 ? (L.V + 255) / 256 : 1024);
         hipLaunchKernelGGL((vp_sort_segments_kernel<256, 8192>), dim3(g_large), dim3(256), 0, st, L.V, seg, order,
-                           256, 0x7fffffff);
+                           1024, 0x7fffffff);
     }
     return check_launch("voxel_plan_build");
+}
+
+extern "C" size_t sgv3d_voxel_pooling_workspace_bytes(int batch_size, int num_points, int num_channels) {
+    if (batch_size <= 0 || num_points <= 0 || num_channels <= 0) return 0;
+    const GatherGeom G = gather_geom((long long)batch_size * num_points, num_channels);
+    return G.v2 ? sizeof(float) * (size_t)G.nchunks * 2 * num_channels : 16;
 }
 
 extern "C" int sgv3d_voxel_pooling_forward_planned(int batch_size, int num_points, int num_channels,
                                                    int num_voxel_x, int num_voxel_y, const void *plan,
                                                    const float *input_features, float *output_features,
-                                                   void *stream) {
+                                                   void *workspace, size_t workspace_bytes, void *stream) {
     if (int rc = check_common(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, 1)) return rc;
     SGV3D_REQUIRE(plan && input_features && output_features, "voxel_pooling_forward_planned: null pointer");
     SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(input_features) & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(output_features) & 15) == 0,
                   "voxel_pooling_forward_planned: feature buffers must be 16-B aligned");
     return launch_gather<false>(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, plan,
-                                input_features, nullptr, nullptr, 1, output_features, as_stream(stream));
+                                input_features, nullptr, nullptr, 1, output_features, workspace, workspace_bytes,
+                                as_stream(stream));
 }
 
 extern "C" int sgv3d_lift_splat_planned(int batch_size, int num_depth, int num_pixels, int num_channels,
                                         int num_voxel_x, int num_voxel_y, const void *plan, const float *prob,
-                                        const float *context, float *output_features, void *stream) {
+                                        const float *context, float *output_features, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
     SGV3D_REQUIRE(num_depth > 0 && num_pixels > 0, "lift_splat_planned: non-positive size");
     const long long N = (long long)num_depth * num_pixels;
     SGV3D_REQUIRE(N < 0x7fffffffLL, "lift_splat_planned: D*P too large");
@@ -484,7 +763,7 @@ extern "C" int sgv3d_lift_splat_planned(int batch_size, int num_depth, int num_p
                       (reinterpret_cast<uintptr_t>(output_features) & 15) == 0,
                   "lift_splat_planned: context/output must be 16-B aligned");
     return launch_gather<true>(batch_size, (int)N, num_channels, num_voxel_x, num_voxel_y, plan, nullptr, prob,
-                               context, num_pixels, output_features, as_stream(stream));
+                               context, num_pixels, output_features, workspace, workspace_bytes, as_stream(stream));
 }
 
 extern "C" int sgv3d_voxel_pooling_backward(int batch_size, int num_points, int num_channels,

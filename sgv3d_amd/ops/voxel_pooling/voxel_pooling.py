@@ -84,6 +84,10 @@ class VoxelPlan:
                                             1 if sort_segments else 0, _lib.stream_handle(geom_xyz.device))
         _lib.check(rc, "sgv3d_voxel_plan_build")
 
+    def _workspace(self, C):
+        nws = _lib.load().sgv3d_voxel_pooling_workspace_bytes(self.B, self.N, int(C))
+        return torch.empty(nws, dtype=torch.uint8, device=self.buf.device), nws
+
     def pool(self, input_features, out=None):
         """input_features f32 [B, N, C] -> [B, Y, X, C] (fully written)."""
         _check_cuda(input_features, "input_features", torch.float32)
@@ -92,10 +96,11 @@ class VoxelPlan:
         assert input_features.numel() == self.B * self.N * C
         if out is None:
             out = input_features.new_empty(self.B, self.Y, self.X, C)
+        ws, nws = self._workspace(C)
         with torch.cuda.device(input_features.device), hip_ops.prof("voxel_pooling_planned"):
             rc = _lib.load().sgv3d_voxel_pooling_forward_planned(
                 self.B, self.N, C, self.X, self.Y, self.buf.data_ptr(), input_features.data_ptr(),
-                out.data_ptr(), _lib.stream_handle(input_features.device))
+                out.data_ptr(), ws.data_ptr(), nws, _lib.stream_handle(input_features.device))
         _lib.check(rc, "sgv3d_voxel_pooling_forward_planned")
         return out
 
@@ -107,10 +112,11 @@ class VoxelPlan:
         assert prob.is_contiguous() and context.is_contiguous()
         if out is None:
             out = context.new_empty(B, self.Y, self.X, C)
+        ws, nws = self._workspace(C)
         with torch.cuda.device(context.device), hip_ops.prof("lift_splat_planned"):
             rc = _lib.load().sgv3d_lift_splat_planned(B, D, P, C, self.X, self.Y, self.buf.data_ptr(),
                                                      prob.data_ptr(), context.data_ptr(), out.data_ptr(),
-                                                     _lib.stream_handle(context.device))
+                                                     ws.data_ptr(), nws, _lib.stream_handle(context.device))
         _lib.check(rc, "sgv3d_lift_splat_planned")
         return out
 

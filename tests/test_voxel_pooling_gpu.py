@@ -32,8 +32,10 @@ def _run_abi(hip, geom, feats, voxel_num, mode, sort=True):
         out = torch.full((B, Y, X, C), float("nan"), device=DEV)   # must be fully overwritten
         hip.check(lib.sgv3d_voxel_plan_build(B, N, X, Y, Z, g.data_ptr(), pm.data_ptr(), plan.data_ptr(), nbytes,
                                              1 if sort else 0, st), "plan")
+        nws = lib.sgv3d_voxel_pooling_workspace_bytes(B, N, C)
+        ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
         hip.check(lib.sgv3d_voxel_pooling_forward_planned(B, N, C, X, Y, plan.data_ptr(), f.data_ptr(),
-                                                          out.data_ptr(), st), "planned")
+                                                          out.data_ptr(), ws.data_ptr(), nws, st), "planned")
     torch.cuda.synchronize()
     return out.permute(0, 3, 1, 2).contiguous().cpu().numpy(), pm.cpu().numpy()
 
