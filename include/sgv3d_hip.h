@@ -171,6 +171,8 @@ typedef struct sgv3d_conv_desc {
 #define SGV3D_CONV_NORMAL 0
 #define SGV3D_CONV_DECONV 1
 #define SGV3D_CONV_NCHW_OUT 2   /* y is [batch, y_ld, out_h, out_w] planes (final head maps)        */
+#define SGV3D_CONV_GROUP_PLANES 3 /* y is [cout/g][batch*out_h*out_w][g], g = deconv_ks: one NHWC map per
+                                    group of g output channels (the per-branch hidden maps of the head) */
 
 #define SGV3D_TILE_128x128 1
 #define SGV3D_TILE_128x64 2
@@ -244,9 +246,10 @@ int sgv3d_deform_im2col3x3(int batch, int h, int w, int channels, int groups, co
                            const float *offset, int off_ld, float *col, void *stream);
 
 /* CenterHead second-layer convs fused over all branches (mmdet3d SeparateHead final conv, 3x3,
- * 64 -> c_k, bias; bev_height_head.py:110): hidden f32 NHWC [B, H, W, nb*hc] (branch-major), weights
- * f32 [sum_c][3][3][hc], bias f32 [sum_c]; branch_of_out int32 [sum_c] maps an output channel to
- * its branch.  out f32 NCHW [B, sum_c, H, W]. */
+ * 64 -> c_k, bias; bev_height_head.py:110): hidden f32 [nb][B][H][W][hc] (one NHWC map per branch, as
+ * written by sgv3d_conv2d_forward in mode SGV3D_CONV_GROUP_PLANES), weights f32 [sum_c][3][3][hc], bias
+ * f32 [sum_c]; branch_of_out int32 [sum_c] maps an output channel to its branch (<= 4 per branch).
+ * out f32 NCHW [B, sum_c, H, W]. */
 int sgv3d_head_final_conv(int batch, int h, int w, int num_branches, int hidden_ch, int total_out,
                           const float *hidden, const float *weight, const float *bias,
                           const int32_t *branch_of_out, float *out, void *stream);

@@ -21,7 +21,7 @@ class ConvDesc(ctypes.Structure):
         "tile", "x_nchw", "k_order")]
 
 
-CONV_NORMAL, CONV_DECONV, CONV_NCHW_OUT = 0, 1, 2
+CONV_NORMAL, CONV_DECONV, CONV_NCHW_OUT, CONV_GROUP_PLANES = 0, 1, 2, 3
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64 = 0, 1, 2, 3, 4
 
 # name -> (restype, argtypes); must list every symbol include/sgv3d_hip.h declares

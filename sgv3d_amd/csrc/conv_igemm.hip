@@ -275,8 +275,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
                     if (a.mode == SGV3D_CONV_DECONV) {
                         const int ih = pix / a.m_w, iw = pix - ih * a.m_w;
                         yi = ((size_t)(img * a.out_h + ih * a.ks + dy) * a.out_w + (iw * a.ks + dx)) * a.y_ld + a.y_coff + co;
-                    } else {  // NCHW_OUT
+                    } else if (a.mode == SGV3D_CONV_NCHW_OUT) {
                         yi = ((size_t)img * a.y_ld + a.y_coff + co) * hw + pix;
+                    } else {  // GROUP_PLANES: [cout/g][M][g], g = a.ks
+                        const int grp = co / a.ks;
+                        yi = ((size_t)grp * a.M + row) * a.ks + (co - grp * a.ks);
                     }
                 }
                 if (a.res) v += a.res[(size_t)row * a.res_ld + co];
@@ -428,7 +431,10 @@ extern "C" int sgv3d_conv2d_forward(const sgv3d_conv_desc *d, const float *x, co
         a.m_h = d->in_h; a.m_w = d->in_w;
         a.N = d->cout * d->deconv_ks * d->deconv_ks;
     } else {
-        SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL || d->mode == SGV3D_CONV_NCHW_OUT, "conv2d_forward: bad mode %d", d->mode);
+        SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL || d->mode == SGV3D_CONV_NCHW_OUT || d->mode == SGV3D_CONV_GROUP_PLANES,
+                      "conv2d_forward: bad mode %d", d->mode);
+        SGV3D_REQUIRE(d->mode != SGV3D_CONV_GROUP_PLANES || (d->deconv_ks > 0 && d->cout % d->deconv_ks == 0 && !residual),
+                      "conv2d_forward: GROUP_PLANES needs deconv_ks = group width dividing cout, no residual");
         const int eh = (d->in_h + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
         const int ew = (d->in_w + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
         SGV3D_REQUIRE(eh == d->out_h && ew == d->out_w, "conv2d_forward: output %dx%d does not match conv arithmetic %dx%d",
@@ -437,7 +443,8 @@ extern "C" int sgv3d_conv2d_forward(const sgv3d_conv_desc *d, const float *x, co
         a.m_h = d->out_h; a.m_w = d->out_w;
         a.N = d->cout;
     }
-    SGV3D_REQUIRE(d->mode == SGV3D_CONV_NCHW_OUT || d->y_ld >= d->y_coff + d->cout, "conv2d_forward: y_ld too small");
+    SGV3D_REQUIRE(d->mode == SGV3D_CONV_NCHW_OUT || d->mode == SGV3D_CONV_GROUP_PLANES || d->y_ld >= d->y_coff + d->cout,
+                  "conv2d_forward: y_ld too small");
     const long long M = (long long)d->batch * a.m_h * a.m_w;
     SGV3D_REQUIRE(M < 0x7fffffffLL, "conv2d_forward: too many output pixels");
     SGV3D_REQUIRE((long long)d->batch * d->in_h * d->in_w * d->x_ld < (1LL << 40), "conv2d_forward: input too large");

@@ -207,75 +207,117 @@ __global__ __launch_bounds__(kBlock) void deform_im2col3x3_kernel(int B, int H, 
 
 // CenterHead second-layer 3x3 convs of all branches in one launch (mmdet3d SeparateHead final conv,
 // reached through layers/heads/bev_height_head.py:110).  Output widths are 1..3 channels per branch,
-// far below an MFMA tile, and fp32 MFMA runs at the fp32 VALU rate anyway => VALU kernel.
-// Workgroup = 16x16 output pixels of one branch; the (18x18) halo patch of the branch's hidden
-// channels is staged in LDS 32 channels at a time (rows padded to 36 floats: conflict-free b128
-// reads), the branch's weights sit in LDS and are read as broadcasts.
-constexpr int kHfTile = 16;
-constexpr int kHfPatch = kHfTile + 2;
-constexpr int kHfLd = 36;
+// far below an MFMA tile, and fp32 MFMA runs at the fp32 VALU rate anyway => VALU kernel, register
+// blocked: a thread owns 4 vertically adjacent pixels x all (<= 4) outputs of its branch, so one
+// ds_read_b128 of the patch feeds up to 3 taps x 4 outputs and every broadcast weight read feeds 4
+// pixels (8 FMA per LDS read instead of 2.7).  Workgroup = 128 threads = 32 columns x 16 rows of one
+// branch; the (18 x 34) halo patch is staged 16 hidden channels at a time, pixel stride 20 floats
+// (80 B: 5*lane mod 16 is a bijection => conflict-free ds_read_b128).
+constexpr int kHfTx = 32, kHfTy = 16, kHfRpt = 4, kHfCp = 16, kHfLd = 20;
+constexpr int kHfPr = kHfTy + 2, kHfPc = kHfTx + 2;
 constexpr int kHfMaxOut = 4;
+constexpr int kHfThreads = kHfTx * (kHfTy / kHfRpt);   // 128
 
-__global__ __launch_bounds__(kBlock) void head_final_conv_kernel(int H, int W, int nb, int hc, int total_out,
-                                                                 const float *__restrict__ hidden,
-                                                                 const float *__restrict__ weight,
-                                                                 const float *__restrict__ bias,
-                                                                 const int32_t *__restrict__ branch_of_out,
-                                                                 float *__restrict__ out) {
+__global__ __launch_bounds__(kHfThreads) void head_final_conv_kernel(int H, int W, int nb, int hc, int total_out,
+                                                                     const float *__restrict__ hidden,
+                                                                     const float *__restrict__ weight,
+                                                                     const float *__restrict__ bias,
+                                                                     const int32_t *__restrict__ branch_of_out,
+                                                                     float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *patch = smem;                                    // [18*18][36]
-    float *wts = smem + kHfPatch * kHfPatch * kHfLd;        // [ck][9][hc]
-    // branch bookkeeping lives in the dynamic region too (a static __shared__ in front of it would
-    // shift its base off 16-B alignment)
+    float *patch = smem;                                   // [18*34][20]
+    float *wts = smem + kHfPr * kHfPc * kHfLd;             // [ck][9][hc]
     int *meta = reinterpret_cast<int *>(wts + kHfMaxOut * 9 * hc);
     const int br = blockIdx.z % nb, b = blockIdx.z / nb;
-    const int tiles_x = (W + kHfTile - 1) / kHfTile;
-    const int ty0 = (blockIdx.x / tiles_x) * kHfTile, tx0 = (blockIdx.x % tiles_x) * kHfTile;
-    if (threadIdx.x == 0) {
-        int first = -1, ck = 0;
-        for (int o = 0; o < total_out; ++o)
-            if (branch_of_out[o] == br) { if (first < 0) first = o; ++ck; }
-        meta[0] = first;
-        meta[1] = ck < kHfMaxOut ? ck : kHfMaxOut;
-    }
+    const int tiles_x = (W + kHfTx - 1) / kHfTx;
+    const int ty0 = (blockIdx.x / tiles_x) * kHfTy, tx0 = (blockIdx.x % tiles_x) * kHfTx;
+    // which output channels belong to this branch: all threads look in parallel (a serial scan by one
+    // thread is ~total_out dependent L2 round trips per workgroup and dominated the first version)
+    if (threadIdx.x == 0) { meta[0] = 0x7fffffff; meta[1] = 0; }
     __syncthreads();
-    const int first = meta[0], ck = meta[1];
+    for (int o = threadIdx.x; o < total_out; o += kHfThreads)
+        if (branch_of_out[o] == br) { atomicMin(&meta[0], o); atomicAdd(&meta[1], 1); }
+    __syncthreads();
+    const int first = meta[0];
+    const int ck = meta[1] < kHfMaxOut ? meta[1] : kHfMaxOut;
     if (ck == 0) return;
-    for (int i = threadIdx.x; i < ck * 9 * hc; i += kBlock) wts[i] = weight[(long long)first * 9 * hc + i];
-    const int px = threadIdx.x & 15, py = threadIdx.x >> 4;
-    const int ld = nb * hc;
-    float acc[kHfMaxOut] = {0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < hc; c0 += 32) {
+    for (int i = threadIdx.x; i < ck * 9 * hc; i += kHfThreads) wts[i] = weight[(long long)first * 9 * hc + i];
+    const int tx = threadIdx.x & (kHfTx - 1), tq = threadIdx.x / kHfTx;   // rows tq*4 .. tq*4+3
+    // hidden is [nb][B][H][W][hc]: one NHWC map per branch (pixel stride hc floats, rows contiguous)
+    const float *hmap = hidden + ((long long)br * (gridDim.z / nb) + b) * H * W * hc;
+    float acc[kHfMaxOut][kHfRpt];
+#pragma unroll
+    for (int o = 0; o < kHfMaxOut; ++o)
+#pragma unroll
+        for (int r = 0; r < kHfRpt; ++r) acc[o][r] = 0.f;
+    // patch staging is software-pipelined through registers: all of a pass's global loads are issued
+    // back to back (one load in flight per thread made the first version latency-bound: 20 dependent
+    // HBM round trips per pass) and the NEXT pass is fetched while the current one is multiplied.
+    constexpr int kLd = (kHfPr * kHfPc * (kHfCp / 4) + kHfThreads - 1) / kHfThreads;   // float4 per thread per pass
+    float4 stage[kLd];
+    const float *src[kLd];
+#pragma unroll
+    for (int it = 0; it < kLd; ++it) {
+        const int i = threadIdx.x + it * kHfThreads;
+        const int pp = i >> 2, q = i & 3;
+        const int yy = ty0 - 1 + pp / kHfPc, xx = tx0 - 1 + pp % kHfPc;
+        const bool ok = i < kHfPr * kHfPc * (kHfCp / 4) && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        src[it] = ok ? hmap + ((long long)yy * W + xx) * hc + q * 4 : nullptr;
+    }
+#define SGV3D_HF_LOAD(C0)                                                                              \
+    _Pragma("unroll") for (int it = 0; it < kLd; ++it) {                                               \
+        float4 t_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+        if (src[it]) t_ = *reinterpret_cast<const float4 *>(src[it] + (C0));                          \
+        stage[it].x = t_.x; stage[it].y = t_.y; stage[it].z = t_.z; stage[it].w = t_.w;                \
+    }
+    SGV3D_HF_LOAD(0);
+    for (int c0 = 0; c0 < hc; c0 += kHfCp) {
         __syncthreads();
-        for (int i = threadIdx.x; i < kHfPatch * kHfPatch * 8; i += kBlock) {
-            const int pp = i >> 3, q = i & 7;
-            const int yy = ty0 - 1 + pp / kHfPatch, xx = tx0 - 1 + pp % kHfPatch;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                v = *reinterpret_cast<const float4 *>(hidden + ((long long)(b * H + yy) * W + xx) * ld + br * hc + c0 + q * 4);
-            *reinterpret_cast<float4 *>(patch + pp * kHfLd + q * 4) = v;
+#pragma unroll
+        for (int it = 0; it < kLd; ++it) {
+            const int i = threadIdx.x + it * kHfThreads;
+            if (i < kHfPr * kHfPc * (kHfCp / 4))
+                *reinterpret_cast<float4 *>(patch + (i >> 2) * kHfLd + (i & 3) * 4) = stage[it];
         }
         __syncthreads();
+        if (c0 + kHfCp < hc) { SGV3D_HF_LOAD(c0 + kHfCp); }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const float *pr = patch + ((py + tap / 3) * kHfPatch + px + tap % 3) * kHfLd;
+        for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 v = *reinterpret_cast<const float4 *>(pr + q * 4);
+            for (int q = 0; q < kHfCp / 4; ++q) {
+                float4 p[kHfRpt + 2];
+#pragma unroll
+                for (int r = 0; r < kHfRpt + 2; ++r)
+                    p[r] = *reinterpret_cast<const float4 *>(patch + ((tq * kHfRpt + r) * kHfPc + tx + kx) * kHfLd + q * 4);
 #pragma unroll
                 for (int o = 0; o < kHfMaxOut; ++o) {
                     if (o < ck) {
-                        const float4 wv = *reinterpret_cast<const float4 *>(wts + (o * 9 + tap) * hc + c0 + q * 4);
-                        acc[o] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky) {
+                            const float4 wv = *reinterpret_cast<const float4 *>(wts + (o * 9 + ky * 3 + kx) * hc + c0 + q * 4);
+#pragma unroll
+                            for (int r = 0; r < kHfRpt; ++r)
+                                acc[o][r] += p[r + ky].x * wv.x + p[r + ky].y * wv.y + p[r + ky].z * wv.z + p[r + ky].w * wv.w;
+                        }
                     }
                 }
             }
         }
     }
-    const int y = ty0 + py, x = tx0 + px;
-    if (y < H && x < W) {
-        for (int o = 0; o < kHfMaxOut; ++o)
-            if (o < ck) out[((long long)(b * total_out + first + o) * H + y) * W + x] = acc[o] + bias[first + o];
+#undef SGV3D_HF_LOAD
+    const int x = tx0 + tx;
+    if (x < W) {
+#pragma unroll
+        for (int o = 0; o < kHfMaxOut; ++o) {
+            if (o < ck) {
+                const float bv = bias[first + o];
+#pragma unroll
+                for (int r = 0; r < kHfRpt; ++r) {
+                    const int y = ty0 + tq * kHfRpt + r;
+                    if (y < H) out[((long long)(b * total_out + first + o) * H + y) * W + x] = acc[o][r] + bv;
+                }
+            }
+        }
     }
 }
 
@@ -384,10 +426,11 @@ extern "C" int sgv3d_deform_im2col3x3(int batch, int h, int w, int channels, int
 extern "C" int sgv3d_head_final_conv(int batch, int h, int w, int num_branches, int hidden_ch, int total_out,
                                      const float *hidden, const float *weight, const float *bias,
                                      const int32_t *branch_of_out, float *out, void *stream) {
-    SGV3D_REQUIRE(batch > 0 && h > 0 && w > 0 && num_branches > 0 && hidden_ch > 0 && hidden_ch % 32 == 0 && total_out > 0,
+    SGV3D_REQUIRE(batch > 0 && h > 0 && w > 0 && num_branches > 0 && hidden_ch > 0 && hidden_ch % kHfCp == 0 && total_out > 0,
                   "head_final_conv: bad shape");
     SGV3D_REQUIRE(hidden && weight && bias && branch_of_out && out, "head_final_conv: null pointer");
-    const size_t lds = sizeof(float) * ((size_t)kHfPatch * kHfPatch * kHfLd + (size_t)kHfMaxOut * 9 * hidden_ch + 4);
+    SGV3D_REQUIRE((long long)batch * num_branches <= 65535, "head_final_conv: batch*branches exceeds grid.z");
+    const size_t lds = sizeof(float) * ((size_t)kHfPr * kHfPc * kHfLd + (size_t)kHfMaxOut * 9 * hidden_ch + 4);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&head_final_conv_kernel),
@@ -396,9 +439,9 @@ extern "C" int sgv3d_head_final_conv(int batch, int h, int w, int num_branches, 
         attr_set = true;
     }
     SGV3D_REQUIRE(lds <= 96 * 1024, "head_final_conv: hidden_ch too large");
-    const int tiles = cdiv(h, kHfTile) * cdiv(w, kHfTile);
+    const int tiles = cdiv(h, kHfTy) * cdiv(w, kHfTx);
     dim3 grid(tiles, 1, batch * num_branches);
-    hipLaunchKernelGGL(head_final_conv_kernel, grid, dim3(kBlock), lds, as_stream(stream), h, w, num_branches, hidden_ch,
+    hipLaunchKernelGGL(head_final_conv_kernel, grid, dim3(kHfThreads), lds, as_stream(stream), h, w, num_branches, hidden_ch,
                        total_out, hidden, weight, bias, branch_of_out, out);
     return check_launch("head_final_conv_kernel");
 }

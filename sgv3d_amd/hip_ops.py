@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, CONV_NORMAL, CONV_DECONV, CONV_NCHW_OUT  # noqa: F401
+from ._lib import ConvDesc, CONV_NORMAL, CONV_DECONV, CONV_NCHW_OUT, CONV_GROUP_PLANES  # noqa: F401
 
 
 def _st(t):
@@ -125,13 +125,20 @@ class PackedConv:
         ow = (w + 2 * self.pad - self.dil * (self.kw - 1) - 1) // self.stride + 1
         return oh, ow
 
-    def __call__(self, x, out=None, *, x_coff=0, y_coff=0, residual=None, gate=None, nchw_out=False, tile=None):
+    def __call__(self, x, out=None, *, x_coff=0, y_coff=0, residual=None, gate=None, nchw_out=False, tile=None,
+                 group_planes=0):
         """x NHWC [B,H,W,x_ld]; reads channels [x_coff, x_coff+cin).  out NHWC [B,OH,OW,y_ld] written
         at channels [y_coff, y_coff+cout) (allocated [B,OH,OW,cout] if None)."""
         B, H, W, x_ld = (int(s) for s in x.shape)
         assert x.is_contiguous() and x.dtype == torch.float32
         oh, ow = self.out_hw(H, W)
-        if out is None:
+        if group_planes:
+            # [cout/g, B, OH, OW, g]: one NHWC map per group of g output channels
+            assert self.cout % group_planes == 0 and not self.transposed and residual is None
+            if out is None:
+                out = torch.empty(self.cout // group_planes, B, oh, ow, group_planes, dtype=torch.float32, device=x.device)
+            assert out.is_contiguous() and out.numel() == B * oh * ow * self.cout
+        elif out is None:
             shape = (B, self.cout, oh, ow) if nchw_out else (B, oh, ow, self.cout)
             out = torch.empty(shape, dtype=torch.float32, device=x.device)
         else:
@@ -140,6 +147,8 @@ class PackedConv:
             if len(got) != 4 or any(w is not None and w != g for w, g in zip(want, got)) or not out.is_contiguous():
                 raise _lib.SGV3DError(f"conv output buffer {got} does not match {want}")
         y_ld = int(out.shape[1] if nchw_out else out.shape[-1])
+        if group_planes:
+            y_ld, y_coff = self.cout, 0
         d = ConvDesc()
         d.batch, d.in_h, d.in_w, d.cin = B, H, W, self.cin
         d.out_h, d.out_w, d.cout = oh, ow, self.cout
@@ -149,6 +158,8 @@ class PackedConv:
         d.relu = 1 if self.relu else 0
         d.mode = CONV_DECONV if self.transposed else (CONV_NCHW_OUT if nchw_out else CONV_NORMAL)
         d.deconv_ks = self.ks
+        if group_planes:
+            d.mode, d.deconv_ks = CONV_GROUP_PLANES, int(group_planes)
         d.k_pad, d.cout_pad = self.k_pad, self.cout_pad
         d.x_nchw = 0
         d.k_order = self.k_order
@@ -304,9 +315,9 @@ def deform_im2col3x3(x, offset, groups, out=None):
 
 
 def head_final_conv(hidden, weight, bias, branch_of_out, num_branches, hidden_ch, out=None):
-    """hidden NHWC [B,H,W,nb*hc]; weight [sum_c,3,3,hc]; -> NCHW [B,sum_c,H,W]."""
-    B, H, W, ld = (int(s) for s in hidden.shape)
-    assert ld == num_branches * hidden_ch
+    """hidden [nb, B, H, W, hc] (one NHWC map per branch); weight [sum_c,3,3,hc]; -> NCHW [B,sum_c,H,W]."""
+    nb, B, H, W, hc = (int(s) for s in hidden.shape)
+    assert nb == num_branches and hc == hidden_ch and hidden.is_contiguous()
     total = int(weight.shape[0])
     if out is None:
         out = torch.empty(B, total, H, W, dtype=torch.float32, device=hidden.device)

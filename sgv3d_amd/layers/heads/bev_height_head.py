@@ -174,7 +174,7 @@ class BEVHeightHead(HipModule):
                 trunk_outs.append(h)
         fpn_output = self.neck.hip_forward(trunk_outs)                 # :109
         shared = s['shared'](fpn_output)                               # CenterHead.forward_single
-        hidden = s['first'](shared)                                    # all branch first layers: [B,H,W,nb*64]
+        hidden = s['first'](shared, group_planes=s['hc'])              # all branch first layers: [nb,B,H,W,64]
         out = hip_ops.head_final_conv(hidden, s['w2'], s['b2'], s['branch_of_out'], s['nb'], s['hc'])
         ret = [dict() for _ in self.task_heads]
         for t, name, off, c in s['slices']:

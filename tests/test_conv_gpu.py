@@ -110,6 +110,18 @@ def test_deconv_kernel_eq_stride(hip, ks, cin, cout):
     torch.testing.assert_close(nchw(out.cpu()[..., 64:64 + cout]), ref, **TOL)
 
 
+def test_group_planes_mode(hip):
+    from sgv3d_amd.hip_ops import PackedConv
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 64, 9, 10, generator=g)
+    w = torch.randn(192, 64, 3, 3, generator=g) / 24
+    ref = F.relu(F.conv2d(x, w, None, 1, 1))
+    y = PackedConv(w.to(DEV), pad=1, relu=True)(nhwc(x).to(DEV), group_planes=64)     # [3, B, H, W, 64]
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (3, 2, 9, 10, 64)
+    torch.testing.assert_close(y.cpu().permute(1, 0, 4, 2, 3).reshape(2, 192, 9, 10), ref, **TOL)
+
+
 def test_nchw_out_mode(hip):
     from sgv3d_amd.hip_ops import PackedConv
     g = torch.Generator().manual_seed(3)
@@ -244,6 +256,7 @@ def test_head_final_conv(hip):
     ref = torch.cat([F.conv2d(hidden[:, i * hc:(i + 1) * hc], ws[i], bs[i], 1, 1) for i in range(nb)], 1)
     wcat = torch.cat([w.permute(0, 2, 3, 1) for w in ws], 0).contiguous()       # [sum_c, 3, 3, hc]
     branch = torch.tensor(sum([[i] * c for i, c in enumerate(widths)], []), dtype=torch.int32)
-    out = head_final_conv(nhwc(hidden).to(DEV), wcat.to(DEV), torch.cat(bs).to(DEV), branch.to(DEV), nb, hc)
+    planes = hidden.reshape(B, nb, hc, H, W).permute(1, 0, 3, 4, 2).contiguous()      # [nb, B, H, W, hc]
+    out = head_final_conv(planes.to(DEV), wcat.to(DEV), torch.cat(bs).to(DEV), branch.to(DEV), nb, hc)
     torch.cuda.synchronize()
     torch.testing.assert_close(out.cpu(), ref, **TOL)
