@@ -166,6 +166,8 @@ typedef struct sgv3d_conv_desc {
     int x_nchw;                      /* reserved, must be 0 (NCHW images go through sgv3d_nchw_to_nhwc) */
     int k_order;                     /* packed-weight k order, must match sgv3d_conv_pack_weight:       */
                                      /* 0: k = tap*cin + ci;  1: k = ((ci/32)*taps + tap)*32 + ci%32    */
+    int split_k;                     /* <= 1: one workgroup per tile sums all of K.  s > 1: s workgroups */
+                                     /* per tile, partial sums in the workspace, fixed-order reduce      */
 } sgv3d_conv_desc;
 
 #define SGV3D_CONV_NORMAL 0
@@ -192,10 +194,13 @@ int sgv3d_conv_pack_weight(const float *w_src, int cout, int cin, int kh, int kw
                            int transposed, int k_order, float *w_packed, int k_pad, int cout_pad,
                            void *stream);
 
-/* scale/bias f32 [cout] (NULL = 1 / 0), residual NHWC f32 or NULL, gate f32 [batch, cout] or NULL. */
+/* scale/bias f32 [cout] (NULL = 1 / 0), residual NHWC f32 or NULL, gate f32 [batch, cout] or NULL.
+ * workspace: sgv3d_conv2d_workspace_bytes(desc) bytes (0 / NULL when split_k <= 1), scratch. */
+size_t sgv3d_conv2d_workspace_bytes(const sgv3d_conv_desc *desc /*host*/);
 int sgv3d_conv2d_forward(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *w_packed,
                          const float *scale, const float *bias, const float *residual,
-                         const float *gate, float *y, void *stream);
+                         const float *gate, float *y, void *workspace, size_t workspace_bytes,
+                         void *stream);
 
 /* ================================================================================================
  * Small layers around the convolutions (all NHWC f32)

@@ -18,7 +18,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in (
         "batch", "in_h", "in_w", "cin", "out_h", "out_w", "cout", "kh", "kw", "stride", "pad", "dil",
         "x_ld", "x_coff", "y_ld", "y_coff", "res_ld", "relu", "mode", "deconv_ks", "k_pad", "cout_pad",
-        "tile", "x_nchw", "k_order")]
+        "tile", "x_nchw", "k_order", "split_k")]
 
 
 CONV_NORMAL, CONV_DECONV, CONV_NCHW_OUT, CONV_GROUP_PLANES = 0, 1, 2, 3
@@ -40,7 +40,8 @@ _PROTOS = {
     "sgv3d_lift": (c_int, [c_int] * 4 + [c_void_p] * 4),
     "sgv3d_conv_pack_geometry": (None, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "sgv3d_conv_pack_weight": (c_int, [c_void_p] + [c_int] * 7 + [c_void_p, c_int, c_int, c_void_p]),
-    "sgv3d_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8),
+    "sgv3d_conv2d_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "sgv3d_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "sgv3d_maxpool3x3s2": (c_int, [c_int] * 4 + [c_void_p] * 3),
     "sgv3d_nchw_to_nhwc": (c_int, [c_int] * 5 + [c_void_p] * 3),
     "sgv3d_nhwc_to_nchw": (c_int, [c_int] * 6 + [c_void_p] * 3),

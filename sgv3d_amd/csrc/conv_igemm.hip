@@ -46,10 +46,61 @@ struct ConvArgs {
     int x_ld, x_coff, y_ld, y_coff, res_ld, relu, mode, ks;
     int tiles_m, tiles_n;
     int korder;  // 0: k = tap*cin + ci   1: k = (ci/32 * taps + tap)*32 + ci%32  (cin % 32 == 0)
+    int split_k; // > 1: blockIdx.y owns a slice of the k-tiles and stores raw partial sums to ws
+    float *ws;   // [split_k][M][N] partial sums (split_k > 1)
 };
 
+// Shared by the conv kernel (split_k == 1) and the split-K reduce kernel: scale/shift (folded BN or
+// bias), residual, ReLU, SE gate and the store in the mode's layout.
+__device__ __forceinline__ void conv_epilogue_store(const ConvArgs &a, int row, int col, float accv) {
+    const int hw = a.m_h * a.m_w;
+    int co = col, dy = 0, dx = 0;
+    if (a.mode == SGV3D_CONV_DECONV) {
+        const int tap = col / a.cout;
+        co = col - tap * a.cout;
+        dy = tap / a.ks;
+        dx = tap - dy * a.ks;
+    }
+    float v = accv * (a.scale ? a.scale[co] : 1.f) + (a.bias ? a.bias[co] : 0.f);
+    size_t yi;
+    int img = 0;
+    if (a.mode == SGV3D_CONV_NORMAL) {
+        yi = (size_t)row * a.y_ld + a.y_coff + co;
+        if (a.gate) img = row / hw;
+    } else {
+        img = row / hw;
+        const int pix = row - img * hw;
+        if (a.mode == SGV3D_CONV_DECONV) {
+            const int ih = pix / a.m_w, iw = pix - ih * a.m_w;
+            yi = ((size_t)(img * a.out_h + ih * a.ks + dy) * a.out_w + (iw * a.ks + dx)) * a.y_ld + a.y_coff + co;
+        } else if (a.mode == SGV3D_CONV_NCHW_OUT) {
+            yi = ((size_t)img * a.y_ld + a.y_coff + co) * hw + pix;
+        } else {  // GROUP_PLANES: [cout/g][M][g], g = a.ks
+            const int grp = co / a.ks;
+            yi = ((size_t)grp * a.M + row) * a.ks + (co - grp * a.ks);
+        }
+    }
+    if (a.res) v += a.res[(size_t)row * a.res_ld + co];
+    if (a.relu) v = fmaxf(v, 0.f);
+    if (a.gate) v *= a.gate[(size_t)img * a.cout + co];
+    a.y[yi] = v;
+}
+
+// Split-K second stage: sums the split partials in fixed order and runs the common epilogue.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)a.M * a.N;
+    if (i >= total) return;
+    const int row = (int)(i / a.N), col = (int)(i - (long long)row * a.N);
+    float v = 0.f;
+    for (int s = 0; s < a.split_k; ++s) v += a.ws[(size_t)s * total + i];
+    conv_epilogue_store(a, row, col, v);
+}
+
+// 128x128 needs ~280 VGPRs with the two register stages: it runs one workgroup per CU (1 wave/SIMD,
+// the pipeline covers its own latency); the smaller tiles keep >= 2 waves/SIMD.
 template <int WTM, int WTN, bool FAST>
-__global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     constexpr int A_CH = BM / 32, B_CH = BN / 32;  // 16-B chunks per thread per k-tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -98,8 +149,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
     // a k-tile is (32-channel chunk c0, tap (kh, kw)) -- wave-uniform, advanced incrementally, and the
     // nine taps of one chunk are fetched back to back so their overlapping input pixels hit in L1/L2.
     // General path: k = tap * cin + ci, decoded per thread with integer division.
-    int ld_kt = 0, ld_kh = 0, ld_kw = 0, ld_c0 = 0;
-    const int nkt = a.k_pad / BK;
+    // split-K: blockIdx.y owns k-tiles [kt_begin, nkt) of a balanced partition
+    const int nkt_all = a.k_pad / BK;
+    const int kt_begin = (int)((long long)nkt_all * blockIdx.y / a.split_k);
+    const int nkt = (int)((long long)nkt_all * (blockIdx.y + 1) / a.split_k);   // exclusive end ("nkt" below)
+    int ld_kt = kt_begin, ld_kh = 0, ld_kw = 0, ld_c0 = 0;
+    if constexpr (FAST) {
+        const int taps = a.kh * a.kw;
+        const int chunk = kt_begin / taps, tap = kt_begin - chunk * taps;
+        ld_c0 = chunk * BK;
+        ld_kh = tap / a.kw;
+        ld_kw = tap - ld_kh * a.kw;
+    }
 
     // Loads are unconditional: lanes whose tap falls outside the image (or whose row / k is padding)
     // read a 16-byte block of zeros, so the stage is straight-line global_load_dwordx4 with no
@@ -230,7 +291,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
     SGV3D_STORE_TILE(ra0, rb0, 0);
     __syncthreads();
     SGV3D_READ_FRAG(fa0, fb0, 0, 0);
-    for (int kt = 0; kt < nkt; kt += 2) {
+    for (int kt = kt_begin; kt < nkt; kt += 2) {
         SGV3D_PHASE(0, ra0, rb0, ra1, rb1, kt + 1 < nkt);      // tile kt in buffer 0
         if (kt + 1 >= nkt) break;
         SGV3D_PHASE(1, ra1, rb1, ra0, rb0, kt + 2 < nkt);      // tile kt+1 in buffer 1
@@ -242,53 +303,32 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
 #undef SGV3D_PHASE
 #undef SGV3D_SB
 
-    // ---- epilogue: scale/bias (folded BN or conv bias), residual, ReLU, gate, store ---------------
-    const int hw = a.m_h * a.m_w;
-#pragma unroll
-    for (int nt = 0; nt < WTN; ++nt) {
-        const int col = n0 + wn * (BN / 2) + nt * 32 + lr;
-        if (col >= a.N) continue;
-        int co = col, dy = 0, dx = 0;
-        if (a.mode == SGV3D_CONV_DECONV) {
-            const int tap = col / a.cout;
-            co = col - tap * a.cout;
-            dy = tap / a.ks;
-            dx = tap - dy * a.ks;
-        }
-        const float sc = a.scale ? a.scale[co] : 1.f;
-        const float bi = a.bias ? a.bias[co] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < WTM; ++mt) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (BM / 2) + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (row >= a.M) continue;
-                float v = acc[mt][nt][e] * sc + bi;
-                size_t yi;
-                int img = 0;
-                if (a.mode == SGV3D_CONV_NORMAL) {
-                    yi = (size_t)row * a.y_ld + a.y_coff + co;
-                    if (a.gate) img = row / hw;
-                } else {
-                    img = row / hw;
-                    const int pix = row - img * hw;
-                    if (a.mode == SGV3D_CONV_DECONV) {
-                        const int ih = pix / a.m_w, iw = pix - ih * a.m_w;
-                        yi = ((size_t)(img * a.out_h + ih * a.ks + dy) * a.out_w + (iw * a.ks + dx)) * a.y_ld + a.y_coff + co;
-                    } else if (a.mode == SGV3D_CONV_NCHW_OUT) {
-                        yi = ((size_t)img * a.y_ld + a.y_coff + co) * hw + pix;
-                    } else {  // GROUP_PLANES: [cout/g][M][g], g = a.ks
-                        const int grp = co / a.ks;
-                        yi = ((size_t)grp * a.M + row) * a.ks + (co - grp * a.ks);
-                    }
-                }
-                if (a.res) v += a.res[(size_t)row * a.res_ld + co];
-                if (a.relu) v = fmaxf(v, 0.f);
-                if (a.gate) v *= a.gate[(size_t)img * a.cout + co];
-                a.y[yi] = v;
-            }
-        }
+    // ---- epilogue (expanded by hand: the accumulators must keep compile-time register indices) ----
+    float *ws = a.split_k > 1 ? a.ws + (size_t)blockIdx.y * a.M * a.N : nullptr;
+    const int row_base = m0 + wm * (BM / 2) + 4 * lh;
+    const int col_base = n0 + wn * (BN / 2) + lr;
+#define SGV3D_EPI_E(MT, NT, E)                                                                        \
+    {                                                                                                 \
+        const int col_ = col_base + (NT) * 32;                                                        \
+        const int row_ = row_base + (MT) * 32 + ((E) & 3) + 8 * ((E) >> 2);                           \
+        if (col_ < a.N && row_ < a.M) {                                                               \
+            if (ws) ws[(size_t)row_ * a.N + col_] = acc[MT][NT][E];                                   \
+            else conv_epilogue_store(a, row_, col_, acc[MT][NT][E]);                                  \
+        }                                                                                             \
     }
+#define SGV3D_EPI_TILE(MT, NT)                                                                        \
+    SGV3D_EPI_E(MT, NT, 0) SGV3D_EPI_E(MT, NT, 1) SGV3D_EPI_E(MT, NT, 2) SGV3D_EPI_E(MT, NT, 3)       \
+    SGV3D_EPI_E(MT, NT, 4) SGV3D_EPI_E(MT, NT, 5) SGV3D_EPI_E(MT, NT, 6) SGV3D_EPI_E(MT, NT, 7)       \
+    SGV3D_EPI_E(MT, NT, 8) SGV3D_EPI_E(MT, NT, 9) SGV3D_EPI_E(MT, NT, 10) SGV3D_EPI_E(MT, NT, 11)     \
+    SGV3D_EPI_E(MT, NT, 12) SGV3D_EPI_E(MT, NT, 13) SGV3D_EPI_E(MT, NT, 14) SGV3D_EPI_E(MT, NT, 15)
+    SGV3D_EPI_TILE(0, 0)
+    if constexpr (WTN > 1) { SGV3D_EPI_TILE(0, 1) }
+    if constexpr (WTM > 1) {
+        SGV3D_EPI_TILE(1, 0)
+        if constexpr (WTN > 1) { SGV3D_EPI_TILE(1, 1) }
+    }
+#undef SGV3D_EPI_TILE
+#undef SGV3D_EPI_E
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -350,7 +390,12 @@ int launch_t(const ConvArgs &a, hipStream_t st) {
     b.zeros = zero_block;
     b.tiles_m = cdiv(a.M, BM);
     b.tiles_n = cdiv(a.N, BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<WTM, WTN, FAST>), dim3(b.tiles_m * b.tiles_n), dim3(kThreads), lds, st, b);
+    hipLaunchKernelGGL((conv_igemm_kernel<WTM, WTN, FAST>), dim3(b.tiles_m * b.tiles_n, b.split_k), dim3(kThreads), lds,
+                       st, b);
+    if (b.split_k > 1) {
+        const long long total = (long long)b.M * b.N;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, b);
+    }
     return check_launch("conv_igemm_kernel");
 }
 
@@ -398,9 +443,18 @@ extern "C" int sgv3d_conv_pack_weight(const float *w_src, int cout, int cin, int
     return check_launch("pack_weight_kernel");
 }
 
+extern "C" size_t sgv3d_conv2d_workspace_bytes(const sgv3d_conv_desc *d) {
+    if (!d || d->split_k <= 1) return 0;
+    const long long mh = d->mode == SGV3D_CONV_DECONV ? d->in_h : d->out_h;
+    const long long mw = d->mode == SGV3D_CONV_DECONV ? d->in_w : d->out_w;
+    const long long n = d->mode == SGV3D_CONV_DECONV ? (long long)d->cout * d->deconv_ks * d->deconv_ks : d->cout;
+    return sizeof(float) * (size_t)d->split_k * d->batch * mh * mw * n;
+}
+
 extern "C" int sgv3d_conv2d_forward(const sgv3d_conv_desc *d, const float *x, const float *w_packed,
                                     const float *scale, const float *bias, const float *residual,
-                                    const float *gate, float *y, void *stream) {
+                                    const float *gate, float *y, void *workspace, size_t workspace_bytes,
+                                    void *stream) {
     SGV3D_REQUIRE(d && x && w_packed && y, "conv2d_forward: null pointer");
     SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->out_h > 0 && d->out_w > 0 &&
                       d->cout > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0,
@@ -453,6 +507,15 @@ extern "C" int sgv3d_conv2d_forward(const sgv3d_conv_desc *d, const float *x, co
     SGV3D_REQUIRE(d->k_pad >= a.K && d->k_pad % BK == 0, "conv2d_forward: k_pad=%d does not cover K=%d", d->k_pad, a.K);
     SGV3D_REQUIRE(d->cout_pad >= a.N && d->cout_pad % 128 == 0, "conv2d_forward: cout_pad=%d does not cover N=%d",
                   d->cout_pad, a.N);
+    a.split_k = d->split_k > 1 ? d->split_k : 1;
+    a.ws = static_cast<float *>(workspace);
+    SGV3D_REQUIRE(a.split_k <= d->k_pad / BK && a.split_k <= 64, "conv2d_forward: split_k=%d too large for %d k-tiles",
+                  a.split_k, d->k_pad / BK);
+    if (a.split_k > 1) {
+        const size_t need = sizeof(float) * (size_t)a.split_k * a.M * a.N;
+        if (!workspace || workspace_bytes < need)
+            return fail(SGV3D_ENOSPACE, "conv2d_forward: split-K workspace has %zu bytes, needs %zu", workspace_bytes, need);
+    }
     const int tile = d->tile ? d->tile : pick_tile(M, a.N);
     hipStream_t st = as_stream(stream);
     switch (tile) {

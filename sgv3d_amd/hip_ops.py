@@ -21,6 +21,8 @@ def _st(t):
 PROFILE = None
 # Pick the conv tile per (layer, input shape) by timing the four variants once, outside graph capture.
 AUTOTUNE = True
+# True: conv records carry the layer shape in their name (tools/layer_report.py)
+PROFILE_DETAIL = False
 TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64"}
 
 
@@ -126,7 +128,7 @@ class PackedConv:
         return oh, ow
 
     def __call__(self, x, out=None, *, x_coff=0, y_coff=0, residual=None, gate=None, nchw_out=False, tile=None,
-                 group_planes=0):
+                 group_planes=0, split_k=None):
         """x NHWC [B,H,W,x_ld]; reads channels [x_coff, x_coff+cin).  out NHWC [B,OH,OW,y_ld] written
         at channels [y_coff, y_coff+cout) (allocated [B,OH,OW,cout] if None)."""
         B, H, W, x_ld = (int(s) for s in x.shape)
@@ -164,44 +166,68 @@ class PackedConv:
         d.x_nchw = 0
         d.k_order = self.k_order
         lib = _lib.load()
-        args = (x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
-                _lib.ptr(gate), out.data_ptr(), _st(x))
         gemm_m = B * (H * W if self.transposed else oh * ow)
         gemm_n = self.cout * (self.ks * self.ks if self.transposed else 1)
+        nkt = self.k_pad // 32
         t = int(self.tile if tile is None else tile)
-        if t == 0:
-            key = (B, H, W)
-            t = self._tile_cache.get(key, 0)
-            if t == 0:
+        sk = int(split_k) if split_k else 0
+        if t == 0 or sk == 0:
+            key = (B, H, W, t, sk)
+            choice = self._tile_cache.get(key)
+            if choice is None:
                 if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
-                    t = self._autotune(lib, d, args, x.device)
-                    self._tile_cache[key] = t
+                    choice = self._autotune(lib, d, x, residual, gate, out, gemm_m, gemm_n, nkt, t, sk)
+                    self._tile_cache[key] = choice
                 else:
-                    t = heuristic_tile(gemm_m, gemm_n)
-        d.tile = t
+                    choice = (t or heuristic_tile(gemm_m, gemm_n), sk or 1)
+            t, sk = choice
+        d.tile, d.split_k = t, sk
         flops = 2.0 * gemm_m * gemm_n * (self.cin * self.kh * self.kw)
-        with torch.cuda.device(x.device), prof("conv_igemm_" + TILE_NAMES[t], flops):
-            rc = lib.sgv3d_conv2d_forward(ctypes.byref(d), *args)
+        name = "conv_igemm_" + TILE_NAMES[t]
+        if PROFILE_DETAIL:
+            name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
+                     f"s{self.stride} d{self.dil} splitk{sk}")
+        with torch.cuda.device(x.device), prof(name, flops):
+            rc = self._launch(lib, d, x, residual, gate, out)
         _lib.check(rc, "sgv3d_conv2d_forward")
         return out
 
-    def _autotune(self, lib, d, args, device):
-        """Time the four tile shapes on the real buffers (results are bitwise identical across tiles:
-        every output element sums k in the same order) and keep the fastest."""
-        best, best_t = 1, None
-        with torch.cuda.device(device):
-            for t in (1, 2, 3, 4):
-                d.tile = t
-                _lib.check(lib.sgv3d_conv2d_forward(ctypes.byref(d), *args), "sgv3d_conv2d_forward")   # warm
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(2):
-                    lib.sgv3d_conv2d_forward(ctypes.byref(d), *args)
-                e1.record()
-                e1.synchronize()
-                dt = e0.elapsed_time(e1)
-                if best_t is None or dt < best_t:
-                    best, best_t = t, dt
+    def _launch(self, lib, d, x, residual, gate, out):
+        ws, nws = None, 0
+        if d.split_k > 1:
+            nws = lib.sgv3d_conv2d_workspace_bytes(ctypes.byref(d))
+            ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+        return lib.sgv3d_conv2d_forward(ctypes.byref(d), x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.scale),
+                                        _lib.ptr(self.shift), _lib.ptr(residual), _lib.ptr(gate), out.data_ptr(),
+                                        _lib.ptr(ws), nws, _st(x))
+
+    def _autotune(self, lib, d, x, residual, gate, out, gemm_m, gemm_n, nkt, fixed_tile, fixed_split):
+        """Time the candidate (tile, split-K) pairs on the real buffers and keep the fastest.  Results do
+        not depend on the tile shape (every output element sums k in the same order); split-K changes
+        the association of the k sum (partials added in fixed order), still deterministic."""
+        tiles = (fixed_tile,) if fixed_tile else (1, 2, 3, 4)
+        dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64)}
+        best, best_t = (tiles[0], fixed_split or 1), None
+        with torch.cuda.device(x.device):
+            for t in tiles:
+                bm, bn = dims[t]
+                wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
+                if fixed_split:
+                    splits = (fixed_split,)
+                else:
+                    splits = [1] + [s for s in (2, 3, 4, 6, 8) if nkt // s >= 8 and wgs < 1024 and wgs * s <= 4096]
+                for sk in splits:
+                    d.tile, d.split_k = t, sk
+                    _lib.check(self._launch(lib, d, x, residual, gate, out), "sgv3d_conv2d_forward")   # warm
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        self._launch(lib, d, x, residual, gate, out)
+                    e1.record()
+                    e1.synchronize()
+                    dt = e0.elapsed_time(e1)
+                    if best_t is None or dt < best_t:
+                        best, best_t = (t, sk), dt
         return best
 
 

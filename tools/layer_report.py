@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-launch time / TFLOP/s table of one cfg-2 forward (HIP events around every launch)."""
+import json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sgv3d_amd import hip_ops, synthetic as S
+from sgv3d_amd.models.bev_height import BEVHeight
+
+bc, hc = S.r50_256_conf()
+torch.manual_seed(0)
+m = BEVHeight(bc, hc).eval()
+S.randomize_norm_stats_(m, 0)
+m = m.cuda()
+imgs = S.make_images(1, bc['final_dim'], device='cuda')
+mats = S.make_mats(1, device='cuda')
+with torch.no_grad():
+    for _ in range(3):
+        m(imgs, mats)
+    torch.cuda.synchronize()
+    hip_ops.PROFILE_DETAIL = True
+    reps = 5
+    hip_ops.PROFILE = []
+    for _ in range(reps):
+        m(imgs, mats)
+    torch.cuda.synchronize()
+recs = hip_ops.PROFILE
+hip_ops.PROFILE = None
+n = len(recs) // reps
+rows = []
+for i in range(n):
+    name, flops = recs[i][0], recs[i][1]
+    us = sorted(recs[i + r * n][2].elapsed_time(recs[i + r * n][3]) * 1e3 for r in range(reps))[reps // 2]
+    rows.append((i, name, flops, us))
+tot = sum(r[3] for r in rows)
+print(f"{'#':>3} {'us':>8} {'TF':>6} {'%pk':>5}  kernel")
+for i, name, flops, us in rows:
+    tf = flops / us / 1e6 if flops else 0
+    print(f"{i:3d} {us:8.1f} {tf:6.1f} {tf / 157.3 * 100:5.1f}  {name}")
+print("total us", tot)
+json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "layers.json"), "w"))
