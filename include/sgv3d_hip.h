@@ -259,6 +259,30 @@ int sgv3d_head_final_conv(int batch, int h, int w, int num_branches, int hidden_
                           const float *hidden, const float *weight, const float *bias,
                           const int32_t *branch_of_out, float *out, void *stream);
 
+/* ================================================================================================
+ * Box decode + circle NMS  
+ * ================================================================================================ */
+
+/* One CenterHead task: BEVHeight.get_bboxes (models/bev_height.py:116-126) -> mmdet3d 0.18.1
+ * CenterHead.get_bboxes, CenterPointBBoxCoder.decode and circle_nms, all on the device.
+ *   heatmap f32 logits [B, num_class, H, W]; reg [B,2,H,W]; height [B,1,H,W]; dim [B,3,H,W];
+ *   rot [B,2,H,W] (sin, cos); vel [B,2,H,W] or NULL.  Every map is addressed as
+ *   base + b*batch_stride + c*H*W + pixel, so channel slices of one [B,70,H,W] buffer can be passed.
+ *   post_center_range host float[6] or NULL.
+ * Outputs (candidates in descending score order, ties by lower flat index):
+ *   boxes f32 [B, max_num, 9] = (x, y, z, dim0, dim1, dim2, rot, vx, vy); scores f32 [B, max_num];
+ *   labels int32 [B, max_num] (class inside the task); valid u8 [B, max_num] (score/range mask);
+ *   keep u8 [B, max_num] (survives circle NMS, at most post_max_size per sample). */
+size_t sgv3d_centerpoint_decode_workspace_bytes(int batch, int num_class, int max_num);
+int sgv3d_centerpoint_decode(int batch, int num_class, int h, int w, int max_num, const float *heatmap,
+                             const float *reg, const float *height, const float *dim, const float *rot,
+                             const float *vel, long long batch_stride, float out_size_factor,
+                             float voxel_x, float voxel_y, float pc_x, float pc_y, float score_threshold,
+                             const float *post_center_range /*host*/, int norm_bbox, float nms_thresh,
+                             int post_max_size, void *workspace, size_t workspace_bytes, float *boxes,
+                             float *scores, int32_t *labels, unsigned char *valid, unsigned char *keep,
+                             void *stream);
+
 #ifdef __cplusplus
 }
 #endif

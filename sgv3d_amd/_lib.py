@@ -53,6 +53,10 @@ _PROTOS = {
     "sgv3d_copy_channels": (c_int, [c_int] * 5 + [c_void_p] * 3),
     "sgv3d_deform_im2col3x3": (c_int, [c_int] * 5 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "sgv3d_head_final_conv": (c_int, [c_int] * 6 + [c_void_p] * 6),
+    "sgv3d_centerpoint_decode_workspace_bytes": (c_size_t, [c_int] * 3),
+    "sgv3d_centerpoint_decode": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_ll] + [ctypes.c_float] * 6 +
+                                 [ctypes.POINTER(ctypes.c_float), c_int, ctypes.c_float, c_int, c_void_p, c_size_t] +
+                                 [c_void_p] * 6),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

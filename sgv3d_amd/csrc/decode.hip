@@ -1,0 +1,276 @@
+// CenterPoint box decode + circle NMS on the device.
+// Reference: BEVHeight.get_bboxes (models/bev_height.py:116-126) -> mmdet3d 0.18.1
+// CenterHead.get_bboxes / CenterPointBBoxCoder.decode / circle_nms (source not in the reference
+// repository: restated from the published algorithm; the reference runs the NMS
+// on the CPU through numba with a device->host copy per task).
+//
+// Per task (one C-ABI call, three launches, no host synchronisation):
+//   1. topk_per_class   sigmoid + exact top-K per (sample, class) over H*W: 4-pass MSB radix select on
+//                       order-preserving float keys, deterministic compaction in index order, bitonic
+//                       sort by (score desc, index asc) in LDS
+//   2. merge_decode     top-K over classes x K, gather of the regression maps, box assembly
+//                       (x = (col + reg_x) * out_size_factor * voxel + pc_range, dim = exp, rot = atan2),
+//                       score / centre-range mask
+//   3. circle_nms       greedy suppression by squared centre distance in score order, one workgroup
+//                       per sample, the inner "suppress everything after i" loop in parallel
+// Ties (equal scores) are broken by the lower flat index; the reference leaves them to torch.topk /
+// numpy argsort, i.e. unspecified.
+#include "common.hpp"
+
+using namespace sgv3d;
+
+namespace {
+
+constexpr int kTk = 1024;     // threads of the top-k workgroup
+constexpr int kMaxK = 1024;   // K padded to a power of two must fit the LDS sort buffers
+
+__device__ __forceinline__ unsigned fkey(float f) {   // ascending order-preserving key
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// (score desc, index asc): a goes before b
+__device__ __forceinline__ bool before(float sa, int ia, float sb, int ib) { return sa > sb || (sa == sb && ia < ib); }
+
+// In-LDS bitonic sort of n (power of two) (score, index) pairs into "before" order by T threads.
+template <int T>
+__device__ void bitonic_pairs(float *sc, int *ix, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += T) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool up = (i & k) == 0;
+                    const float sa = sc[i], sb = sc[p];
+                    const int ia = ix[i], ib = ix[p];
+                    const bool ok = before(sa, ia, sb, ib);      // already in "before" order
+                    if (up ? !ok : ok) { sc[i] = sb; sc[p] = sa; ix[i] = ib; ix[p] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kTk) void topk_per_class_kernel(int cat, long long hw, int K, int Kp,
+                                                             const float *__restrict__ heat, long long batch_stride,
+                                                             float *__restrict__ out_score, int *__restrict__ out_ind) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_krem;
+    __shared__ int s_cnt[kTk / 64][2];
+    __shared__ float ssc[kMaxK];
+    __shared__ int six[kMaxK];
+    const int b = blockIdx.x / cat, c = blockIdx.x - b * cat;
+    const float *src = heat + (long long)b * batch_stride + (long long)c * hw;
+    const int tid = threadIdx.x;
+    const long long per = (hw + kTk - 1) / kTk;            // contiguous slice per thread (index order)
+    const long long i0 = tid * per, i1 = min(hw, i0 + per);
+    auto score = [&](long long i) { return 1.f / (1.f + expf(-src[i])); };
+    // ---- radix select of the K-th largest key ------------------------------------------------
+    if (tid == 0) { s_prefix = 0; s_krem = (unsigned)K; }
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+        for (long long i = i0; i < i1; ++i) {
+            const unsigned k = fkey(score(i));
+            if ((k & himask) == (prefix & himask)) atomicAdd(&hist[(k >> shift) & 255], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned cum = 0, krem = s_krem;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (cum + hist[d] >= krem) break;
+                cum += hist[d];
+            }
+            s_prefix = prefix | ((unsigned)d << shift);
+            s_krem = krem - cum;       // how many are still needed among keys with this digit
+        }
+        __syncthreads();
+    }
+    const unsigned kth = s_prefix;
+    const int need_eq = (int)s_krem;                        // ties at the K-th key to take (lowest index first)
+    // ---- deterministic compaction in index order ---------------------------------------------
+    int n_gt = 0, n_eq = 0;
+    for (long long i = i0; i < i1; ++i) {
+        const unsigned k = fkey(score(i));
+        n_gt += k > kth;
+        n_eq += k == kth;
+    }
+    // block exclusive scans of (n_gt, n_eq)
+    int inc_gt = n_gt, inc_eq = n_eq;
+    const int lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int a = __shfl_up(inc_gt, d, 64), e = __shfl_up(inc_eq, d, 64);
+        if (lane >= d) { inc_gt += a; inc_eq += e; }
+    }
+    if (lane == 63) { s_cnt[wid][0] = inc_gt; s_cnt[wid][1] = inc_eq; }
+    __syncthreads();
+    int base_gt = 0, base_eq = 0, tot_gt = 0;
+    for (int w = 0; w < kTk / 64; ++w) {
+        if (w < wid) { base_gt += s_cnt[w][0]; base_eq += s_cnt[w][1]; }
+        tot_gt += s_cnt[w][0];
+    }
+    int pos_gt = base_gt + inc_gt - n_gt, pos_eq = base_eq + inc_eq - n_eq;
+    for (int i = tid; i < Kp; i += kTk) { ssc[i] = -INFINITY; six[i] = 0x7fffffff; }
+    __syncthreads();
+    for (long long i = i0; i < i1; ++i) {
+        const float s = score(i);
+        const unsigned k = fkey(s);
+        if (k > kth) { ssc[pos_gt] = s; six[pos_gt] = (int)i; ++pos_gt; }
+        else if (k == kth) { if (pos_eq < need_eq) { ssc[tot_gt + pos_eq] = s; six[tot_gt + pos_eq] = (int)i; } ++pos_eq; }
+    }
+    __syncthreads();
+    bitonic_pairs<kTk>(ssc, six, Kp);
+    for (int i = tid; i < K; i += kTk) {
+        out_score[((long long)b * cat + c) * K + i] = ssc[i];
+        out_ind[((long long)b * cat + c) * K + i] = six[i];
+    }
+}
+
+struct DecodeCfg {
+    float out_size_factor, vx, vy, pcx, pcy, score_thr;
+    float range[6];
+    int norm_bbox, has_range, has_vel;
+};
+
+__global__ __launch_bounds__(kTk) void merge_decode_kernel(int cat, int h, int w, int K, int Kp2,
+                                                           const float *__restrict__ cls_score, const int *__restrict__ cls_ind,
+                                                           const float *__restrict__ reg, const float *__restrict__ hei,
+                                                           const float *__restrict__ dim, const float *__restrict__ rot,
+                                                           const float *__restrict__ vel, long long batch_stride,
+                                                           DecodeCfg cfg, float *__restrict__ boxes, float *__restrict__ scores,
+                                                           int *__restrict__ labels, unsigned char *__restrict__ valid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    float *ssc = reinterpret_cast<float *>(dsm);
+    int *six = reinterpret_cast<int *>(dsm + sizeof(float) * Kp2);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long long hw = (long long)h * w;
+    const int n = cat * K;
+    for (int i = tid; i < Kp2; i += kTk) {
+        if (i < n) { ssc[i] = cls_score[(long long)b * n + i]; six[i] = i; }   // flat index = class*K + rank
+        else { ssc[i] = -INFINITY; six[i] = 0x7fffffff; }
+    }
+    __syncthreads();
+    bitonic_pairs<kTk>(ssc, six, Kp2);
+    for (int t = tid; t < K; t += kTk) {
+        const float s = ssc[t];
+        const int flat = six[t];
+        const long long o = (long long)b * K + t;
+        if (flat >= n || s == -INFINITY) {                       // fewer than K candidates
+            for (int q = 0; q < 9; ++q) boxes[o * 9 + q] = 0.f;
+            scores[o] = 0.f; labels[o] = 0; valid[o] = 0;
+            continue;
+        }
+        const int cls = flat / K;
+        const int ind = cls_ind[(long long)b * n + flat];
+        const int yq = (int)((float)ind / (float)w);            // topk_ys: (ind.float() / width).int()
+        const int xq = ind % w;
+        const long long bo = (long long)b * batch_stride + ind;
+        const float xs = ((float)xq + reg[bo]) * cfg.out_size_factor * cfg.vx + cfg.pcx;
+        const float ys = ((float)yq + reg[bo + hw]) * cfg.out_size_factor * cfg.vy + cfg.pcy;
+        const float z = hei[bo];
+        float d0 = dim[bo], d1 = dim[bo + hw], d2 = dim[bo + 2 * hw];
+        if (cfg.norm_bbox) { d0 = expf(d0); d1 = expf(d1); d2 = expf(d2); }
+        const float r = atan2f(rot[bo], rot[bo + hw]);          // atan2(sin, cos)
+        float *bx = boxes + o * 9;
+        bx[0] = xs; bx[1] = ys; bx[2] = z; bx[3] = d0; bx[4] = d1; bx[5] = d2; bx[6] = r;
+        bx[7] = cfg.has_vel ? vel[bo] : 0.f;
+        bx[8] = cfg.has_vel ? vel[bo + hw] : 0.f;
+        bool ok = s > cfg.score_thr;
+        if (cfg.has_range)
+            ok = ok && xs >= cfg.range[0] && ys >= cfg.range[1] && z >= cfg.range[2] && xs <= cfg.range[3] &&
+                 ys <= cfg.range[4] && z <= cfg.range[5];
+        scores[o] = s;
+        labels[o] = cls;
+        valid[o] = ok ? 1 : 0;
+    }
+}
+
+// greedy circle NMS over the valid candidates of one sample, in score order (they are sorted already)
+__global__ __launch_bounds__(512) void circle_nms_kernel(int K, const float *__restrict__ boxes,
+                                                         const unsigned char *__restrict__ valid, float thresh,
+                                                         int post_max_size, unsigned char *__restrict__ keep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    float *cx = reinterpret_cast<float *>(dsm);
+    float *cy = cx + K;
+    int *cid = reinterpret_cast<int *>(cy + K);
+    unsigned char *sup = reinterpret_cast<unsigned char *>(cid + K);
+    __shared__ int s_n, s_kept;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {                                   // ordered compaction (K <= 1024: a serial pass is fine)
+        int n = 0;
+        for (int i = 0; i < K; ++i)
+            if (valid[(long long)b * K + i]) { cid[n] = i; ++n; }
+        s_n = n;
+        s_kept = 0;
+    }
+    for (int i = tid; i < K; i += blockDim.x) keep[(long long)b * K + i] = 0;
+    __syncthreads();
+    const int n = s_n;
+    for (int i = tid; i < n; i += blockDim.x) {
+        const float *bx = boxes + ((long long)b * K + cid[i]) * 9;
+        cx[i] = bx[0]; cy[i] = bx[1]; sup[i] = 0;
+    }
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        if (sup[i]) continue;                           // uniform: read after the barrier below
+        if (s_kept >= post_max_size) break;             // keep[:post_max_size]
+        const float xi = cx[i], yi = cy[i];
+        for (int j = i + 1 + tid; j < n; j += blockDim.x) {
+            const float dx = xi - cx[j], dy = yi - cy[j];
+            if (dx * dx + dy * dy <= thresh) sup[j] = 1;
+        }
+        if (tid == 0) { keep[(long long)b * K + cid[i]] = 1; s_kept = s_kept + 1; }
+        __syncthreads();
+    }
+}
+
+int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+}  // namespace
+
+extern "C" size_t sgv3d_centerpoint_decode_workspace_bytes(int batch, int num_class, int max_num) {
+    if (batch <= 0 || num_class <= 0 || max_num <= 0) return 0;
+    return (sizeof(float) + sizeof(int)) * (size_t)batch * num_class * max_num + 256;
+}
+
+extern "C" int sgv3d_centerpoint_decode(int batch, int num_class, int h, int w, int max_num, const float *heatmap,
+                                        const float *reg, const float *height, const float *dim, const float *rot,
+                                        const float *vel, long long batch_stride, float out_size_factor,
+                                        float voxel_x, float voxel_y, float pc_x, float pc_y, float score_threshold,
+                                        const float *post_center_range, int norm_bbox, float nms_thresh,
+                                        int post_max_size, void *workspace, size_t workspace_bytes, float *boxes,
+                                        float *scores, int32_t *labels, unsigned char *valid, unsigned char *keep,
+                                        void *stream) {
+    SGV3D_REQUIRE(batch > 0 && num_class > 0 && h > 0 && w > 0 && max_num > 0, "centerpoint_decode: non-positive size");
+    SGV3D_REQUIRE(heatmap && reg && height && dim && rot && boxes && scores && labels && valid && keep && workspace,
+                  "centerpoint_decode: null pointer");
+    const int Kp = pow2_ge(max_num), Kp2 = pow2_ge(num_class * max_num);
+    SGV3D_REQUIRE(Kp <= kMaxK && Kp2 <= 8192, "centerpoint_decode: max_num=%d x %d classes exceeds the LDS sort buffers", max_num, num_class);
+    SGV3D_REQUIRE((long long)h * w >= max_num, "centerpoint_decode: max_num exceeds H*W");
+    const size_t need = sgv3d_centerpoint_decode_workspace_bytes(batch, num_class, max_num);
+    if (workspace_bytes < need) return fail(SGV3D_ENOSPACE, "centerpoint_decode: workspace has %zu bytes, needs %zu", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    float *cls_score = static_cast<float *>(workspace);
+    int *cls_ind = reinterpret_cast<int *>(cls_score + (size_t)batch * num_class * max_num);
+    const long long hw = (long long)h * w;
+    hipLaunchKernelGGL(topk_per_class_kernel, dim3(batch * num_class), dim3(kTk), 0, st, num_class, hw, max_num, Kp, heatmap,
+                       batch_stride, cls_score, cls_ind);
+    DecodeCfg cfg;
+    cfg.out_size_factor = out_size_factor; cfg.vx = voxel_x; cfg.vy = voxel_y; cfg.pcx = pc_x; cfg.pcy = pc_y;
+    cfg.score_thr = score_threshold; cfg.norm_bbox = norm_bbox; cfg.has_vel = vel != nullptr;
+    cfg.has_range = post_center_range != nullptr;
+    for (int i = 0; i < 6; ++i) cfg.range[i] = post_center_range ? post_center_range[i] : 0.f;
+    hipLaunchKernelGGL(merge_decode_kernel, dim3(batch), dim3(kTk), (sizeof(float) + sizeof(int)) * (size_t)Kp2, st, num_class,
+                       h, w, max_num, Kp2, cls_score, cls_ind, reg, height, dim, rot, vel, batch_stride, cfg, boxes, scores,
+                       labels, valid);
+    const size_t nms_lds = (size_t)max_num * (2 * sizeof(float) + sizeof(int) + 1) + 16;
+    hipLaunchKernelGGL(circle_nms_kernel, dim3(batch), dim3(512), nms_lds, st, max_num, boxes, valid, nms_thresh, post_max_size,
+                       keep);
+    return check_launch("centerpoint_decode");
+}

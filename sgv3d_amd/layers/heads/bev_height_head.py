@@ -15,8 +15,8 @@ HIP forward ("CenterHead convs fused per scale"):
   convs, writing a single NCHW [B, 70, H, W] buffer whose channel slices are the returned maps.
 Return structure is the reference's: ``tuple(task -> [dict(branch -> Tensor[B, c, H, W])])``.
 
-get_targets / loss / get_bboxes belong to the training and decode rows of SURVEY.md §8(f) and are
-not implemented in this round (they raise).
+get_bboxes (decode + circle NMS) runs on the device (csrc/decode.hip).  get_targets / loss belong to
+the training row of SURVEY.md §8(f) and are not implemented in this round (they raise).
 """
 import torch
 from torch import nn
@@ -201,4 +201,78 @@ class BEVHeightHead(HipModule):
         raise NotImplementedError("loss (bev_height_head.py:255-311) is SURVEY §8(f) rank 2")
 
     def get_bboxes(self, preds_dicts, img_metas=None, img=None, rescale=False):
-        raise NotImplementedError("box decode + circle NMS (models/bev_height.py:116-126) is SURVEY §8(f) rank 1")
+        """mmdet3d ``CenterHead.get_bboxes`` (reached via models/bev_height.py:116-126) on the device:
+        sigmoid + top-K + box assembly + circle NMS per task run as HIP kernels (the reference does the
+        NMS on the CPU through numba); only the final variable-length gather uses torch indexing.
+
+        Returns ``[[bboxes, scores, labels], ...]`` per sample; ``bboxes`` is
+        ``img_metas[i]['box_type_3d'](tensor, code_size)`` when the harness passes mmdet3d's box class,
+        else a ``Boxes3D`` stand-in with the same ``.tensor`` attribute (exps/...:254)."""
+        import ctypes
+        from ... import _lib
+        coder, tcfg = self.bbox_coder_cfg, self.test_cfg
+        assert tcfg.get('nms_type', 'circle') == 'circle', "only nms_type='circle' (every shipped config) is built"
+        lib = _lib.load()
+        K = int(coder['max_num'])
+        rng = coder.get('post_center_range')
+        rng_c = (ctypes.c_float * 6)(*[float(v) for v in rng]) if rng is not None else None
+        thr = coder.get('score_threshold')
+        per_task = []
+        for task_id, preds in enumerate(preds_dicts):
+            p = preds[0]
+            heat = p['heatmap']
+            B, cat, H, W = (int(v) for v in heat.shape)
+            dev = heat.device
+            bs = int(heat.stride(0))
+            for k in ('reg', 'height', 'dim', 'rot'):
+                assert p[k].stride(0) == bs and p[k].stride(1) == H * W and p[k].stride(3) == 1
+            assert heat.stride(1) == H * W and heat.dtype == torch.float32
+            vel = p.get('vel')
+            nws = lib.sgv3d_centerpoint_decode_workspace_bytes(B, cat, K)
+            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+            boxes = torch.empty(B, K, 9, dtype=torch.float32, device=dev)
+            scores = torch.empty(B, K, dtype=torch.float32, device=dev)
+            labels = torch.empty(B, K, dtype=torch.int32, device=dev)
+            valid = torch.empty(B, K, dtype=torch.uint8, device=dev)
+            keep = torch.empty(B, K, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev), hip_ops.prof("centerpoint_decode"):
+                rc = lib.sgv3d_centerpoint_decode(
+                    B, cat, H, W, K, heat.data_ptr(), p['reg'].data_ptr(), p['height'].data_ptr(), p['dim'].data_ptr(),
+                    p['rot'].data_ptr(), _lib.ptr(vel), bs, float(coder['out_size_factor']),
+                    float(coder['voxel_size'][0]), float(coder['voxel_size'][1]), float(coder['pc_range'][0]),
+                    float(coder['pc_range'][1]), float(thr) if thr is not None else float('-inf'), rng_c,
+                    1 if self.norm_bbox else 0, float(tcfg['min_radius'][task_id]), int(tcfg['post_max_size']),
+                    ws.data_ptr(), nws, boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(), valid.data_ptr(),
+                    keep.data_ptr(), _lib.stream_handle(dev))
+            _lib.check(rc, "sgv3d_centerpoint_decode")
+            per_task.append((boxes, scores, labels, keep.bool()))
+        # merge tasks (CenterHead.get_bboxes tail): concat, label offsets, z -= h/2
+        B = per_task[0][0].shape[0]
+        ret_list = []
+        for i in range(B):
+            bl, sl, ll, flag = [], [], [], 0
+            for (boxes, scores, labels, keep), nc in zip(per_task, self.num_classes):
+                k = keep[i]
+                bl.append(boxes[i][k])
+                sl.append(scores[i][k])
+                ll.append(labels[i][k] + flag)
+                flag += nc
+            bboxes = torch.cat(bl)
+            bboxes[:, 2] = bboxes[:, 2] - bboxes[:, 5] * 0.5
+            box_type = img_metas[i].get('box_type_3d') if img_metas is not None and i < len(img_metas) else None
+            code_size = int(coder.get('code_size', 9))
+            bboxes = box_type(bboxes, code_size) if callable(box_type) else Boxes3D(bboxes, code_size)
+            ret_list.append([bboxes, torch.cat(sl), torch.cat(ll).int()])
+        return ret_list
+
+
+class Boxes3D:
+    """Minimal stand-in for mmdet3d ``LiDARInstance3DBoxes`` (absent in this image): the harness only
+    reads ``.tensor`` (exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:254)."""
+
+    def __init__(self, tensor, box_dim=9):
+        self.tensor = tensor
+        self.box_dim = box_dim
+
+    def __len__(self):
+        return self.tensor.shape[0]
