@@ -82,6 +82,7 @@ def main():
     for _ in range(max(1, args.warmup)):
         out = step()
     torch.cuda.synchronize()
+    hip_ops.save_tune_db()          # no-op unless SGV3D_TUNE_CACHE is set (tools/profile_round.sh)
 
     # ---- optional hipGraph capture of one step ---------------------------------------------------
     use_graph = not args.no_graph

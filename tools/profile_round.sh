@@ -1,0 +1,26 @@
+#!/bin/bash
+# Produce the round's profile artefacts on the GPU box (run from the repo root through gpurun):
+#   bash tools/profile_round.sh r01
+# Outputs land in gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/.
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+# tile / split-K choices are made once (first run) and replayed by the profiled runs
+export SGV3D_TUNE_CACHE=$OUT/${TAG}_tune_cache.json
+# 1. the bench line itself (with the CPU baseline)
+python3 $R/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+# 2. kernel trace + stats of the same command (no CPU baseline: it is host work)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err
+# 3. HBM traffic counters, separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/pmc_write.err
+# 4. voxel pooling micro-benchmark (the HBM-bound headline kernel) + its trace and traffic
+python3 $R/tools/microbench.py --what vp,lift --out $OUT/${TAG}_voxel_pooling_microbench.json > $OUT/microbench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_vp -- python3 $R/tools/vp_probe.py > /dev/null 2> $OUT/vp.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_vp_pmc_fetch -- python3 $R/tools/vp_probe.py > /dev/null 2>> $OUT/vp.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_vp_pmc_write -- python3 $R/tools/vp_probe.py > /dev/null 2>> $OUT/vp.err
+ls -la $OUT | head -40
