@@ -243,6 +243,22 @@ int sgv3d_scale_channels(int batch, int pixels, int channels, const float *x, co
 int sgv3d_copy_channels(int batch, int pixels, int channels, int x_ld, int x_coff, const float *x,
                         float *y, void *stream);
 
+/* F.interpolate(x, scale_factor=2, mode='bilinear') (align_corners=False), NHWC f32
+ * [B,H,W,C] -> [B,2H,2W,C]  (TaskFPN.forward, layers/backbones/bsm_lss_fpn.py:209-212). */
+int sgv3d_upsample_bilinear2x(int batch, int h, int w, int channels, const float *x, float *y, void *stream);
+
+/* y = a + b * sigmoid(c), n f32 elements: SABlock product plus the TaskFPN residual
+ * (layers/backbones/bsm_lss_fpn.py:151-160, 211). */
+int sgv3d_add_mul_sigmoid(long long n, const float *a, const float *b, const float *c, float *y, void *stream);
+
+/* Background suppression of BSMLSSFPN._forward_single_sweep (layers/backbones/bsm_lss_fpn.py:524-529),
+ * in place on height_context f32 [B, P, ld] that holds depth logits at [0,D) and context at [D,D+ctx):
+ * context *= keep, semantic softmax * keep is written at [D+ctx, D+ctx+sem), remaining channels up to ld
+ * are zeroed; keep = 0 where softmax(semantic_logits)[0] > background_threshold, else 1. */
+int sgv3d_bsm_compose(int batch, int pixels, int num_depth, int context_channels, int semantic_channels,
+                      int ld, const float *semantic_logits, int semantic_ld, float background_threshold,
+                      float *height_context, void *stream);
+
 /* Deformable 3x3 sampling of mmcv DeformConv2dPack (DCNv1, deform_groups=1, stride 1, pad 1, dil 1;
  * lss_fpn.py:190-198): col[b, p, g, tap, cg] = bilinear(x[b, :, :, g*cpg + cg], p + tap + offset).
  *   x      f32 [B, H, W, C] NHWC;  offset f32 [B, H, W, off_ld] with (dy, dx) of tap t at 2t, 2t+1

@@ -218,6 +218,77 @@ def lss_fpn_forward(sd, conf, imgs, mats, keep=None):
     return bev
 
 
+# ------------------------------------------------------------------------------------------------
+# SGV3D BSM variant (layers/backbones/bsm_lss_fpn.py)
+# ------------------------------------------------------------------------------------------------
+def _sablock(sd, p, x, y):
+    """bsm_lss_fpn.py:151-160"""
+    return conv(sd, p + '.conv', x, 1, 1) * torch.sigmoid(conv(sd, p + '.attention.0', y, 1, 1))
+
+
+def _task_decoder(sd, p, x):
+    """TaskHead.decoder, bsm_lss_fpn.py:184-190"""
+    x = basic_block(sd, p + '.decoder.0', x, 1)
+    x = basic_block(sd, p + '.decoder.1', x, 1)
+    return F.relu(bn(sd, p + '.decoder.3', conv(sd, p + '.decoder.2', x, 1, 1)))
+
+
+def _task_fpn(sd, p, feat0, feat1):
+    """bsm_lss_fpn.py:209-212"""
+    feat0 = conv(sd, p + '.reduce_conv', F.interpolate(feat0, scale_factor=2, mode='bilinear'), 1, 1)
+    return feat0 + _sablock(sd, p + '.self_attention', feat1, feat0)
+
+
+def msct_head(sd, p, feats, mats):
+    """MSCThead.forward, bsm_lss_fpn.py:259-320 -> (depth1, semantic1, context1, semantic0)"""
+    v = mlp_input(mats)
+    v = F.batch_norm(v, sd[p + '.bn.running_mean'], sd[p + '.bn.running_var'], sd[p + '.bn.weight'], sd[p + '.bn.bias'],
+                     False, 0.0, 1e-5)
+    s0 = F.relu(bn(sd, p + '.reduce_conv0.1', conv(sd, p + '.reduce_conv0.0', feats[0], 1, 1)))
+    s1 = F.relu(bn(sd, p + '.reduce_conv1.1', conv(sd, p + '.reduce_conv1.0', feats[1], 1, 1)))
+    s0 = _se(sd, p + '.scale0_se', s0, _mlp(sd, p + '.scale0_mlp', v)[..., None, None])
+    s1 = _se(sd, p + '.scale1_se', s1, _mlp(sd, p + '.scale1_mlp', v)[..., None, None])
+    s0 = aspp(sd, p + '.aspp', s0)
+    depth_feat = s0                                               # TaskHead(with_head=False) returns its input
+    semantic_feat = _task_decoder(sd, p + '.semantic_head0', s0)
+    semantic0 = conv(sd, p + '.semantic_head0.head', semantic_feat)
+    context_feat = F.relu(bn(sd, p + '.context_conv0.1', conv(sd, p + '.context_conv0.0', s0, 1, 1)))
+    depth_feat = _task_fpn(sd, p + '.depth_fpn', depth_feat, s1)
+    semantic_feat = _task_fpn(sd, p + '.semantic_fpn', semantic_feat, s1)
+    context_feat = _task_fpn(sd, p + '.context_fpn', context_feat, s1)
+    depth1 = conv(sd, p + '.depth_head1.head', _task_decoder(sd, p + '.depth_head1', depth_feat))
+    semantic1 = conv(sd, p + '.semantic_head1.head', _task_decoder(sd, p + '.semantic_head1', semantic_feat))
+    c = F.relu(bn(sd, p + '.context_conv1.1', conv(sd, p + '.context_conv1.0', context_feat, 1, 1)))
+    context1 = conv(sd, p + '.context_conv1.3', c)
+    return depth1, semantic1, context1, semantic0
+
+
+def bsm_lss_fpn_forward(sd, conf, imgs, mats, keep=None):
+    """BSMLSSFPN._forward_single_sweep (bsm_lss_fpn.py:485-559) -> BEV [B, 87, Y, X]."""
+    B, S, N, Cin, H, W = imgs.shape
+    x = imgs[:, 0].reshape(B * N, Cin, H, W)
+    feats = resnet(sd, 'backbone.img_backbone', x, conf['img_backbone_conf'])
+    n16 = secondfpn(sd, 'backbone.img_neck_16', feats, conf['img_neck_conf'])
+    cfg8 = dict(conf['img_neck_conf'], upsample_strides=[0.5, 1, 2, 4])            # :368
+    n8 = secondfpn(sd, 'backbone.img_neck_8', feats, cfg8)
+    depth1, semantic1, context1, semantic0 = msct_head(sd, 'backbone.height_net', [n16, n8], mats)
+    height = depth1.softmax(dim=1)                                                    # :521
+    semantic = semantic1.softmax(dim=1)
+    tran = torch.cat((context1, semantic), dim=1)                                     # :524
+    mask = semantic[:, 0, :, :].unsqueeze(1) > 0.45                                   # :526 background
+    tran = tran * (1 - mask.int())
+    lifted = height.unsqueeze(1) * tran.unsqueeze(2)                                  # :530
+    C, D, fH, fW = lifted.shape[1:]
+    lifted = lifted.reshape(B, N, C, D, fH, fW).permute(0, 1, 3, 4, 5, 2).contiguous()
+    geom = geometry_indices(sd, mats)
+    vn = [int(v) for v in sd['backbone.voxel_num']]
+    bev, _ = VP.forward(geom, lifted.numpy(), vn, want_pos_memo=False)
+    bev = torch.from_numpy(bev)
+    if keep is not None:
+        keep.update(neck16=n16, neck8=n8, depth1=depth1, semantic1=semantic1, context1=context1, geom_xyz=geom, bev=bev)
+    return bev
+
+
 def head_forward(sd, conf, x, keep=None):
     """BEVHeightHead.forward (bev_height_head.py:85-111) + mmdet3d CenterHead.forward."""
     bcfg = conf.get('bev_backbone_conf')
@@ -244,5 +315,6 @@ def bevheight_forward(sd, backbone_conf, head_conf, imgs, mats, keep=None):
     with torch.no_grad():
         sd = {k: v.detach().cpu() for k, v in sd.items()}
         mats = {k: v.detach().cpu() for k, v in mats.items()}
-        bev = lss_fpn_forward(sd, backbone_conf, imgs.detach().cpu().float(), mats, keep)
+        fwd = bsm_lss_fpn_forward if backbone_conf.get('is_bsm') else lss_fpn_forward
+        bev = fwd(sd, backbone_conf, imgs.detach().cpu().float(), mats, keep)
         return head_forward(sd, head_conf, bev, keep)

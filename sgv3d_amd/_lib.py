@@ -51,6 +51,9 @@ _PROTOS = {
     "sgv3d_broadcast_channels": (c_int, [c_int] * 5 + [c_void_p] * 3),
     "sgv3d_scale_channels": (c_int, [c_int] * 3 + [c_void_p] * 4),
     "sgv3d_copy_channels": (c_int, [c_int] * 5 + [c_void_p] * 3),
+    "sgv3d_upsample_bilinear2x": (c_int, [c_int] * 4 + [c_void_p] * 3),
+    "sgv3d_add_mul_sigmoid": (c_int, [c_ll] + [c_void_p] * 5),
+    "sgv3d_bsm_compose": (c_int, [c_int] * 6 + [c_void_p, c_int, ctypes.c_float, c_void_p, c_void_p]),
     "sgv3d_deform_im2col3x3": (c_int, [c_int] * 5 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "sgv3d_head_final_conv": (c_int, [c_int] * 6 + [c_void_p] * 6),
     "sgv3d_centerpoint_decode_workspace_bytes": (c_size_t, [c_int] * 3),

@@ -159,6 +159,71 @@ __global__ __launch_bounds__(kBlock) void copy_channels_kernel(long long total, 
     y[i] = x[bp * ld + coff + c];
 }
 
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=False)  (TaskFPN, bsm_lss_fpn.py:210)
+__global__ __launch_bounds__(kBlock) void upsample_bilinear2x_kernel(int B, int H, int W, int C4,
+                                                                     const float4 *__restrict__ x, float4 *__restrict__ y) {
+    const long long total = (long long)B * 2 * H * 2 * W * C4;
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C4);
+    long long t = i / C4;
+    const int ow = (int)(t % (2 * W));
+    t /= (2 * W);
+    const int oh = (int)(t % (2 * H));
+    const int b = (int)(t / (2 * H));
+    // area_pixel_compute_source_index(scale = 0.5, align_corners = false): max(0.5*(dst+0.5)-0.5, 0)
+    const float sh = fmaxf(0.5f * ((float)oh + 0.5f) - 0.5f, 0.f), sw = fmaxf(0.5f * ((float)ow + 0.5f) - 0.5f, 0.f);
+    const int h1 = (int)sh, w1 = (int)sw;
+    const int h1p = h1 < H - 1 ? 1 : 0, w1p = w1 < W - 1 ? 1 : 0;
+    const float lh1 = sh - (float)h1, lw1 = sw - (float)w1;
+    const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+    const float4 *p = x + ((long long)b * H * W) * C4 + c;
+    const float4 a = p[((long long)h1 * W + w1) * C4], bq = p[((long long)h1 * W + w1 + w1p) * C4];
+    const float4 cq = p[((long long)(h1 + h1p) * W + w1) * C4], d = p[((long long)(h1 + h1p) * W + w1 + w1p) * C4];
+    float4 o;
+    o.x = lh0 * (lw0 * a.x + lw1 * bq.x) + lh1 * (lw0 * cq.x + lw1 * d.x);
+    o.y = lh0 * (lw0 * a.y + lw1 * bq.y) + lh1 * (lw0 * cq.y + lw1 * d.y);
+    o.z = lh0 * (lw0 * a.z + lw1 * bq.z) + lh1 * (lw0 * cq.z + lw1 * d.z);
+    o.w = lh0 * (lw0 * a.w + lw1 * bq.w) + lh1 * (lw0 * cq.w + lw1 * d.w);
+    y[i] = o;
+}
+
+// SABlock + residual (bsm_lss_fpn.py:151-160, 211): y = a + b * sigmoid(c)
+__global__ __launch_bounds__(kBlock) void add_mul_sigmoid_kernel(long long n4, const float4 *__restrict__ a,
+                                                                 const float4 *__restrict__ b, const float4 *__restrict__ c,
+                                                                 float4 *__restrict__ y) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n4) return;
+    const float4 av = a[i], bv = b[i], cv = c[i];
+    float4 o;
+    o.x = av.x + bv.x * (1.f / (1.f + expf(-cv.x)));
+    o.y = av.y + bv.y * (1.f / (1.f + expf(-cv.y)));
+    o.z = av.z + bv.z * (1.f / (1.f + expf(-cv.z)));
+    o.w = av.w + bv.w * (1.f / (1.f + expf(-cv.w)));
+    y[i] = o;
+}
+
+// Background suppression of BSMLSSFPN (bsm_lss_fpn.py:524-529), in place on the [B,P,ld] buffer that
+// already holds depth logits [0,D) and context [D,D+ctx): semantic = softmax(sem_logits); the
+// transferred feature is cat(context, semantic) zeroed where semantic[0] (background) > thr.
+__global__ __launch_bounds__(kBlock) void bsm_compose_kernel(long long pixels, int D, int ctx, int sem, int ld,
+                                                             const float *__restrict__ sem_logits, int sem_ld, float thr,
+                                                             float *__restrict__ buf) {
+    const long long p = (long long)blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5);   // 32 lanes per pixel
+    const int l = threadIdx.x & 31;
+    if (p >= pixels) return;
+    const float *sl = sem_logits + p * sem_ld;
+    float m = -INFINITY;
+    for (int k = 0; k < sem; ++k) m = fmaxf(m, sl[k]);
+    float den = 0.f;
+    for (int k = 0; k < sem; ++k) den += expf(sl[k] - m);
+    const float p0 = expf(sl[0] - m) / den;
+    const float keep = p0 > thr ? 0.f : 1.f;          // tran_feat * (1 - mask.int())
+    float *row = buf + p * ld + D;
+    for (int c = l; c < ctx; c += 32) row[c] = row[c] * keep;
+    for (int k = l; k < ld - D - ctx; k += 32) row[ctx + k] = k < sem ? expf(sl[k] - m) / den * keep : 0.f;
+}
+
 // mmcv DeformConv2dPack sampling (DCNv1: deformable_im2col + bilinear with zero padding;
 // configured at lss_fpn.py:190-198: 3x3, pad 1, stride 1, dil 1, deform_groups 1)
 __global__ __launch_bounds__(kBlock) void deform_im2col3x3_kernel(int B, int H, int W, int C, int groups,
@@ -409,6 +474,38 @@ extern "C" int sgv3d_copy_channels(int batch, int pixels, int channels, int x_ld
     hipLaunchKernelGGL(copy_channels_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, as_stream(stream), total, channels,
                        x_ld, x_coff, x, y);
     return check_launch("copy_channels_kernel");
+}
+
+extern "C" int sgv3d_upsample_bilinear2x(int batch, int h, int w, int channels, const float *x, float *y, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && h > 0 && w > 0 && channels > 0 && (channels & 3) == 0, "upsample_bilinear2x: bad shape");
+    SGV3D_REQUIRE(x && y, "upsample_bilinear2x: null pointer");
+    const long long total = (long long)batch * 4 * h * w * (channels / 4);
+    hipLaunchKernelGGL(upsample_bilinear2x_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, as_stream(stream), batch, h, w,
+                       channels / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y));
+    return check_launch("upsample_bilinear2x_kernel");
+}
+
+extern "C" int sgv3d_add_mul_sigmoid(long long n, const float *a, const float *b, const float *c, float *y, void *stream) {
+    SGV3D_REQUIRE(n > 0 && (n & 3) == 0, "add_mul_sigmoid: n must be a positive multiple of 4");
+    SGV3D_REQUIRE(a && b && c && y, "add_mul_sigmoid: null pointer");
+    hipLaunchKernelGGL(add_mul_sigmoid_kernel, dim3(cdiv(n / 4, kBlock)), dim3(kBlock), 0, as_stream(stream), n / 4,
+                       reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b),
+                       reinterpret_cast<const float4 *>(c), reinterpret_cast<float4 *>(y));
+    return check_launch("add_mul_sigmoid_kernel");
+}
+
+extern "C" int sgv3d_bsm_compose(int batch, int pixels, int num_depth, int context_channels, int semantic_channels,
+                                 int ld, const float *semantic_logits, int semantic_ld, float background_threshold,
+                                 float *height_context, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && pixels > 0 && num_depth > 0 && context_channels > 0 && semantic_channels > 0 &&
+                      ld >= num_depth + context_channels + semantic_channels && semantic_ld >= semantic_channels,
+                  "bsm_compose: bad shape");
+    SGV3D_REQUIRE(semantic_logits && height_context, "bsm_compose: null pointer");
+    const long long px = (long long)batch * pixels;
+    hipLaunchKernelGGL(bsm_compose_kernel, dim3(cdiv(px, kBlock / 32)), dim3(kBlock), 0, as_stream(stream), px, num_depth,
+                       context_channels, semantic_channels, ld, semantic_logits, semantic_ld, background_threshold,
+                       height_context);
+    return check_launch("bsm_compose_kernel");
 }
 
 extern "C" int sgv3d_deform_im2col3x3(int batch, int h, int w, int channels, int groups, const float *x,

@@ -113,10 +113,28 @@ class PackedConv:
     MFMA implicit-GEMM kernel and BN / bias folded into a per-channel scale & shift."""
 
     def __init__(self, weight, *, stride=1, pad=0, dil=1, scale=None, shift=None, relu=False,
-                 transposed=False, cin_pad=None, device=None, tile=0):
+                 transposed=False, cin_pad=None, device=None, tile=0, pad_out=False):
         w = weight.detach()
         device = device or w.device
         w = w.to(device=device, dtype=torch.float32).contiguous()
+        # Channel counts that are not multiples of 4 (SGV3D's 87 / 174-channel BEV trunk) are padded:
+        # inputs with zero weight columns (always), outputs with zero rows when the caller owns the
+        # activation buffer (pad_out): the extra output channels come out exactly 0 and feed zero
+        # weights downstream, so every pixel row stays 16-byte aligned for the kernels.
+        odim = 1 if transposed else 0
+        self.cout_real = int(w.shape[odim])
+        if pad_out and self.cout_real % 4:
+            extra = 4 - self.cout_real % 4
+            shape = list(w.shape)
+            shape[odim] = extra
+            w = torch.cat([w, w.new_zeros(shape)], odim).contiguous()
+            if scale is not None:
+                scale = torch.cat([scale.detach().float().to(device), torch.ones(extra, device=device)])
+            if shift is not None:
+                shift = torch.cat([shift.detach().float().to(device), torch.zeros(extra, device=device)])
+        if cin_pad is None:
+            cin_real = int(w.shape[0] if transposed else w.shape[1])
+            cin_pad = (cin_real + 3) // 4 * 4
         if transposed:
             cin, cout, kh, kw = (int(s) for s in w.shape)
             assert kh == kw == stride, "only kernel == stride transposed convs (SECONDFPN deblocks)"
@@ -362,6 +380,39 @@ def copy_channels(x, out, coff=0):
         rc = _lib.load().sgv3d_copy_channels(B, H * W, C, ld, int(coff), x.data_ptr(), out.data_ptr(), _st(x))
     _lib.check(rc, "sgv3d_copy_channels")
     return out
+
+
+def upsample_bilinear2x(x, out=None):
+    B, H, W, C = (int(s) for s in x.shape)
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty(B, 2 * H, 2 * W, C, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), prof("upsample_bilinear2x"):
+        rc = _lib.load().sgv3d_upsample_bilinear2x(B, H, W, C, x.data_ptr(), out.data_ptr(), _st(x))
+    _lib.check(rc, "sgv3d_upsample_bilinear2x")
+    return out
+
+
+def add_mul_sigmoid(a, b, c, out=None):
+    """a + b * sigmoid(c), same-shape contiguous tensors."""
+    assert a.shape == b.shape == c.shape and a.is_contiguous() and b.is_contiguous() and c.is_contiguous()
+    if out is None:
+        out = torch.empty_like(a)
+    with torch.cuda.device(a.device), prof("add_mul_sigmoid"):
+        rc = _lib.load().sgv3d_add_mul_sigmoid(a.numel(), a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr(), _st(a))
+    _lib.check(rc, "sgv3d_add_mul_sigmoid")
+    return out
+
+
+def bsm_compose(height_context, semantic_logits, D, ctx, sem, thr):
+    """In place on height_context [B,H,W,ld]; semantic_logits [B,H,W,>=sem]."""
+    B, H, W, ld = (int(s) for s in height_context.shape)
+    with torch.cuda.device(height_context.device), prof("bsm_compose"):
+        rc = _lib.load().sgv3d_bsm_compose(B, H * W, int(D), int(ctx), int(sem), ld, semantic_logits.data_ptr(),
+                                          int(semantic_logits.shape[-1]), float(thr), height_context.data_ptr(),
+                                          _st(height_context))
+    _lib.check(rc, "sgv3d_bsm_compose")
+    return height_context
 
 
 def deform_im2col3x3(x, offset, groups, out=None):

@@ -55,7 +55,7 @@ class HipModule(nn.Module):
         raise NotImplementedError
 
 
-def conv_bn(conv, bn=None, relu=False, device=None, cin_pad=None):
+def conv_bn(conv, bn=None, relu=False, device=None, cin_pad=None, pad_out=False):
     """PackedConv of an nn.Conv2d (+ optional eval BatchNorm2d folded, + ReLU)."""
     assert conv.groups == 1
     k = conv.kernel_size[0]
@@ -65,7 +65,7 @@ def conv_bn(conv, bn=None, relu=False, device=None, cin_pad=None):
     else:
         scale, shift = None, (conv.bias.detach() if conv.bias is not None else None)
     return PackedConv(conv.weight, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0],
-                      scale=scale, shift=shift, relu=relu, device=device, cin_pad=cin_pad)
+                      scale=scale, shift=shift, relu=relu, device=device, cin_pad=cin_pad, pad_out=pad_out)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -84,9 +84,10 @@ class BasicBlock(HipModule):
         self.downsample = downsample
 
     def hip_compile(self, device):
-        s = dict(c1=conv_bn(self.conv1, self.bn1, True, device), c2=conv_bn(self.conv2, self.bn2, True, device))
+        s = dict(c1=conv_bn(self.conv1, self.bn1, True, device, pad_out=True),
+                 c2=conv_bn(self.conv2, self.bn2, True, device, pad_out=True))
         if self.downsample is not None:
-            s['ds'] = conv_bn(self.downsample[0], self.downsample[1], False, device)
+            s['ds'] = conv_bn(self.downsample[0], self.downsample[1], False, device, pad_out=True)
         return s
 
     def hip_forward(self, x):
@@ -194,7 +195,7 @@ class ResNet(HipModule):
 
     def hip_compile(self, device):
         cin_pad = (self.in_channels + 3) // 4 * 4
-        return dict(stem=conv_bn(self.conv1, self.bn1, True, device, cin_pad=cin_pad), cin_pad=cin_pad)
+        return dict(stem=conv_bn(self.conv1, self.bn1, True, device, cin_pad=cin_pad, pad_out=True), cin_pad=cin_pad)
 
     def hip_stem(self, x_nhwc):
         """conv1 + bn1 + relu on an NHWC input whose channels are already padded to a multiple of 4."""

@@ -188,7 +188,7 @@ class BEVHeightHead(HipModule):
         if self.training:
             raise NotImplementedError("HIP path = inference forward; call model.eval()")
         if not nhwc:
-            x = hip_ops.nchw_to_nhwc(x.float().contiguous())
+            x = hip_ops.nchw_to_nhwc(x.float().contiguous(), c_pad=(int(x.shape[1]) + 3) // 4 * 4)
         elif not x.is_contiguous():
             x = x.contiguous()
         return self.hip_forward(x)

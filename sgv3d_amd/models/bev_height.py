@@ -13,6 +13,7 @@ contiguous, layers/backbones/lss_fpn.py:495, only for cuDNN's benefit).
 import torch
 from torch import nn
 
+from ..layers.backbones.bsm_lss_fpn import BSMLSSFPN
 from ..layers.backbones.lss_fpn import LSSFPN
 from ..layers.blocks import HipModule
 from ..layers.heads.bev_height_head import BEVHeightHead
@@ -32,9 +33,9 @@ class BEVHeight(nn.Module):
     def __init__(self, backbone_conf, head_conf, is_train_height=False, checkpoint=None):
         super(BEVHeight, self).__init__()
         if backbone_conf['is_bsm']:
-            raise NotImplementedError("BSMLSSFPN (SGV3D background-suppressed variant, "
-                                      "layers/backbones/bsm_lss_fpn.py) is SURVEY §8(f) rank 3")
-        self.backbone = LSSFPN(**backbone_conf)
+            self.backbone = BSMLSSFPN(**backbone_conf)
+        else:
+            self.backbone = LSSFPN(**backbone_conf)
         self.head = BEVHeightHead(**head_conf)
         self.is_train_height = is_train_height
         self._param_stamp = None

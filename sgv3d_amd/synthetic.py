@@ -97,6 +97,35 @@ def r101_256_conf():
     return b, h
 
 
+def bsm_r101_256_conf():
+    """BASELINE cfg-5 model: SGV3D BSM, R101, 864x1536 -> 256x256 BEV
+    (exps/sgv3d/bsm_bev_height_lss_r101_864_1536_256x256.py:42-101)."""
+    b, h = r50_256_conf()
+    b['d_bound'] = [-2.0, 3.5, 180]
+    b['img_backbone_conf']['depth'] = 101
+    b['img_backbone_conf']['init_cfg'] = dict(type='Pretrained', checkpoint='torchvision://resnet101')
+    b['height_net_conf'] = dict(in_channels=[512, 512], mid_channels=[512, 256], semantic_channels=7)
+    b['is_bsm'] = True
+    h['bev_backbone_conf'] = dict(type='ResNet', in_channels=87, depth=18, num_stages=3, strides=(1, 2, 2),
+                                  dilations=(1, 1, 1), out_indices=[0, 1, 2], norm_eval=False, base_channels=174)
+    h['bev_neck_conf'] = dict(type='SECONDFPN', in_channels=[87, 174, 348, 696], upsample_strides=[1, 2, 4, 8],
+                              out_channels=[64, 64, 64, 64])
+    return b, h
+
+
+def small_bsm_conf(final=(128, 192), bev=64, depth=18):
+    """Reduced-size BSM config with the cfg-5 layer structure (tests)."""
+    b, h = bsm_r101_256_conf()
+    sb, _ = small_conf(final, bev, depth)
+    for k in ('final_dim', 'x_bound', 'y_bound'):
+        b[k] = sb[k]
+    b['d_bound'] = [-2.0, 3.5, 12]
+    b['img_backbone_conf']['depth'] = depth
+    if depth in (18, 34):
+        b['img_neck_conf']['in_channels'] = [64, 128, 256, 512]
+    return b, h
+
+
 def small_conf(final=(128, 192), bev=64, depth=18):
     """Reduced geometry with the same layer structure (tests: the CPU oracle finishes in seconds)."""
     b, h = r50_256_conf()
@@ -211,6 +240,10 @@ def randomize_norm_stats_(model, seed=0, dcn_offsets=True):
                 m.bias.copy_(0.5 * torch.randn(m.bias.shape, generator=g))
             # default-initialised 1x1 heads give near-zero logits / context: scale them to O(1) so the
             # softmax, the BEV map and the head see realistic dynamic range
-            if name.endswith(('height_layer', 'context_conv')):
+            if name.endswith(('height_layer', 'context_conv', 'depth_head1.head', 'context_conv1.3')):
                 m.weight.mul_(8.0)
+            # BSM: make the background class win on part of the image so the 0.45 mask is exercised
+            if name.endswith('semantic_head1.head'):
+                m.weight.mul_(20.0)
+                m.bias[0] += 0.5
     return model

@@ -146,12 +146,26 @@ def test_layer_sized_conv_heightnet(hip):
     torch.testing.assert_close(nchw(y.cpu()), ref, **TOL)
 
 
+def test_channel_padding(hip):
+    """cin / cout that are not multiples of 4 (SGV3D's 87 / 174 channels): zero-padded weights."""
+    from sgv3d_amd.hip_ops import PackedConv
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 87, 9, 11, generator=g)
+    w = torch.randn(174, 87, 3, 3, generator=g) / 28
+    ref = F.relu(F.conv2d(x, w, None, 1, 1))
+    xp = torch.cat([nhwc(x), torch.full((1, 9, 11, 1), 3.0)], -1)        # 88-channel buffer, junk in the pad channel
+    conv = PackedConv(w.to(DEV), pad=1, relu=True, pad_out=True)
+    assert conv.cin == 88 and conv.cout == 176 and conv.cout_real == 174
+    y = conv(xp.to(DEV)).cpu()
+    torch.testing.assert_close(nchw(y[..., :174]), ref, **TOL)
+    assert (y[..., 174:] == 0).all()
+
+
 def test_conv_rejects_bad_args(hip):
     from sgv3d_amd.hip_ops import PackedConv
     from sgv3d_amd._lib import SGV3DError
-    w = torch.randn(8, 6, 1, 1)
-    with pytest.raises(AssertionError):
-        PackedConv(w.to(DEV))                                          # cin not a multiple of 4
+    with pytest.raises(SGV3DError):
+        PackedConv(torch.randn(8, 6, 1, 1).to(DEV))(torch.zeros(1, 4, 4, 6, device=DEV))   # buffer narrower than cin_pad
     conv = PackedConv(torch.randn(8, 8, 3, 3).to(DEV), pad=1)
     with pytest.raises(SGV3DError):
         conv(torch.zeros(1, 4, 4, 8, device=DEV), torch.zeros(1, 5, 4, 8, device=DEV))   # wrong out size
@@ -189,6 +203,27 @@ def test_avgpool_dense_broadcast(hip):
     broadcast_channels(v.to(DEV), out, y_coff=20)
     o = out.cpu()
     assert torch.equal(o[..., 20:68], v[:, None, None, :].expand(2, 5, 6, 48)) and (o[..., :20] == 0).all()
+
+
+def test_bsm_kernels(hip):
+    from sgv3d_amd.hip_ops import upsample_bilinear2x, add_mul_sigmoid, bsm_compose
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 64, 7, 9, generator=g)
+    up = upsample_bilinear2x(nhwc(x).to(DEV))
+    torch.testing.assert_close(nchw(up.cpu()), F.interpolate(x, scale_factor=2, mode='bilinear'), rtol=1e-5, atol=1e-5)
+    a, b, c = (torch.randn(2, 5, 6, 32, generator=g) for _ in range(3))
+    torch.testing.assert_close(add_mul_sigmoid(a.to(DEV), b.to(DEV), c.to(DEV)).cpu(), a + b * torch.sigmoid(c),
+                               rtol=1e-5, atol=1e-5)
+    D, ctx, sem, ld = 12, 80, 7, 12 + 88
+    buf = torch.randn(2, 4, 5, ld, generator=g)
+    logits = torch.randn(2, 4, 5, sem, generator=g) * 3
+    out = bsm_compose(buf.clone().to(DEV), logits.to(DEV), D, ctx, sem, 0.45).cpu()
+    p = logits.softmax(-1)
+    keep = (1 - (p[..., :1] > 0.45).int()).float()
+    assert torch.equal(out[..., :D], buf[..., :D])
+    torch.testing.assert_close(out[..., D:D + ctx], buf[..., D:D + ctx] * keep, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out[..., D + ctx:D + ctx + sem], p * keep, rtol=1e-5, atol=1e-6)
+    assert (out[..., D + ctx + sem:] == 0).all() and (keep == 0).any() and (keep == 1).any()
 
 
 def _deform_conv_ref(x, offset, weight, groups):

@@ -143,3 +143,53 @@ def test_r50_bottleneck_path():
     for t in range(6):
         for k, v in preds[t][0].items():
             torch.testing.assert_close(v.cpu(), ref[t][0][k], **TOL)
+
+
+def test_bsm_variant_sgv3d():
+    """SGV3D background-suppressed model (BASELINE cfg-5 structure) at reduced resolution: BEV map
+    (87 channels, incl. the semantic probabilities and the 0.45 background mask) and head outputs."""
+    bc, hc = S.small_bsm_conf(depth=18)
+    m = _build(bc, hc, seed=3)
+    imgs = S.make_images(2, bc['final_dim'], seed=11)
+    mats = S.make_mats(2, scale=128 / 864)
+    keep = {}
+    ref = TM.bevheight_forward(m.state_dict(), bc, hc, imgs, mats, keep)
+    sem = keep['semantic1'].softmax(1)
+    assert 0.02 < (sem[:, 0] > 0.45).float().mean() < 0.98, "fixture must exercise the background mask"
+    m = m.to(DEV)
+    dmats = _to_dev(mats)
+    with torch.no_grad():
+        bev = m.backbone(imgs.to(DEV), dmats)
+        preds = m(imgs.to(DEV), dmats)
+        m.backbone.fuse_lift_splat = True
+        bev_fused = m.backbone(imgs.to(DEV), dmats)
+        m.backbone.fuse_lift_splat = False
+    assert bev.shape == keep['bev'].shape == (2, 87, 64, 64)
+    torch.testing.assert_close(bev.cpu(), keep['bev'], **TOL)
+    torch.testing.assert_close(bev_fused.cpu(), keep['bev'], **TOL)
+    for t in range(6):
+        for k, v in preds[t][0].items():
+            torch.testing.assert_close(v.cpu(), ref[t][0][k], **TOL)
+
+
+def test_bsm_state_dict_names():
+    from sgv3d_amd.models.bev_height import BEVHeight
+    bc, hc = S.bsm_r101_256_conf()
+    sd = BEVHeight(bc, hc).state_dict()
+    for k, shp in {
+        'backbone.frustum': (180, 108, 192, 4),
+        'backbone.img_neck_16.deblocks.0.0.weight': (128, 256, 4, 4),
+        'backbone.img_neck_8.deblocks.0.0.weight': (128, 256, 2, 2),
+        'backbone.img_neck_8.deblocks.3.0.weight': (2048, 128, 4, 4),
+        'backbone.height_net.reduce_conv1.0.weight': (256, 512, 3, 3),
+        'backbone.height_net.scale1_mlp.fc1.weight': (256, 27),
+        'backbone.height_net.depth_head0.decoder.0.conv1.weight': (512, 512, 3, 3),
+        'backbone.height_net.semantic_head0.head.weight': (7, 512, 1, 1),
+        'backbone.height_net.depth_fpn.reduce_conv.weight': (256, 512, 3, 3),
+        'backbone.height_net.depth_fpn.self_attention.attention.0.weight': (256, 256, 3, 3),
+        'backbone.height_net.depth_head1.head.weight': (180, 256, 1, 1),
+        'backbone.height_net.context_conv1.3.weight': (80, 256, 1, 1),
+        'head.trunk.conv1.weight': (174, 87, 7, 7),
+        'head.neck.deblocks.3.0.weight': (696, 64, 8, 8),
+    }.items():
+        assert tuple(sd[k].shape) == shp, k
