@@ -45,7 +45,29 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fuse-lift-splat", action="store_true", help="skip the materialised [B,N,C] lifted tensor")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "r101", "cfg5"],
+                    help="cfg2 (default, the judged workload): R50 BEVHeight; r101: R101 BEVHeight; "
+                         "cfg5: SGV3D BSM R101 (model of BASELINE configs[4], fp32, batch 1)")
     return ap.parse_args()
+
+
+def load_traffic(tile_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes of this same command, tools/profile_round.sh; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md §HBM prescribes for gfx950).  bench.py cannot read PMC counters itself."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None, None
+    bm, bn = tile_name.replace("conv_igemm_", "").split("x")
+    sym = f"conv_igemm_kernel<{int(bm) // 64}, {int(bn) // 64}, true>"
+    try:
+        rec = json.load(open(files[-1]))["bench"].get(sym)
+    except Exception:
+        rec = None
+    if not rec:
+        return None, None
+    return rec["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT) + ":" + sym
 
 
 def main():
@@ -64,7 +86,12 @@ def main():
     group = ReplicaGroup(backend="nccl" if world > 1 else None, device=dev)   # nccl == RCCL on ROCm
     from sgv3d_amd.models.bev_height import BEVHeight
 
-    bc, hc = S.r50_256_conf()
+    bc, hc = {"cfg2": S.r50_256_conf, "r101": S.r101_256_conf, "cfg5": S.bsm_r101_256_conf}[args.config]()
+    workload = {"cfg2": "BASELINE cfg-2: ResNet-50 864x1536 -> 256x256 BEV, fp32, full BEVHeight forward "
+                        "(backbone+neck+HeightNet+lift+geometry+voxel_pooling+head)",
+                "r101": "ResNet-101 864x1536 -> 256x256 BEV, fp32, full BEVHeight forward",
+                "cfg5": "SGV3D BSM ResNet-101 864x1536 -> 256x256 BEV (stride-8 frustum, D=180, 87-ch BEV), fp32, "
+                        "full forward"}[args.config]
     torch.manual_seed(0)
     model = BEVHeight(bc, hc).eval()
     S.randomize_norm_stats_(model, 0)
@@ -135,9 +162,11 @@ def main():
         fam_fl = sum(v[0] for v in conv.values())
         fam_sec = sum(v[1] for v in conv.values())
         all_sec = sum(v[1] for v in by_kernel.values())
+        traffic, traffic_src = load_traffic(top)
         roofline = {
             "bound": "mfma", "kernel": top, "achieved": fl / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_source": traffic_src,
             "launches": n, "avg_launch_us": sec / n * 1e6, "flop_per_launch": fl / n,
             "conv_family": {"achieved": fam_fl / fam_sec / 1e12, "frac": fam_fl / fam_sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
                             "gflop_per_frame": fam_fl / (args.steps * B) / 1e9,
@@ -173,8 +202,7 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg-2: ResNet-50 864x1536 -> 256x256 BEV, fp32, full BEVHeight forward "
-                                   "(backbone+neck+HeightNet+lift+geometry+voxel_pooling+head)",
+            "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world}",
                        "hip_graph": bool(use_graph), "fuse_lift_splat": bool(args.fuse_lift_splat),
                        "voxel_pooling_mode": "planned", "weights": "random-init, BN stats perturbed (seed 0)"},

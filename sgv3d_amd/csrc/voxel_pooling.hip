@@ -248,7 +248,11 @@ __global__ __launch_bounds__(kBlock) void vp_sort_wave_kernel(long long V, const
     const int lane = threadIdx.x & 63;
     const long long wave0 = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * (kBlock / 64);
-    for (long long v = wave0; v < V; v += nwaves) {
+    // voxels are dealt to waves with a per-round rotation (97 is coprime to any power-of-two wave
+    // count): long lists cluster in a few BEV columns and a plain stride would pile them on few waves
+    for (long long it = 0; it * nwaves < V; ++it) {
+        const long long v = it * nwaves + (wave0 + 97 * it) % nwaves;
+        if (v >= V) continue;
         const int s = seg_start[v];
         const int n = seg_start[v + 1] - s;
         if (n <= lo || n > 64 * R) continue;   // wave-uniform
@@ -307,14 +311,16 @@ __global__ __launch_bounds__(T) void vp_sort_segments_kernel(long long V, const 
         if (tid == 0) ntodo = 0;
         __syncthreads();
         {
-            const long long v = (sb + tid) * G + blockIdx.x;
+            // rotate the column by 37 per row: a plain v = slot*G + block would hand one BEV column
+            // (all rows of one x when G == X) to one workgroup, and the hot voxels sit in few columns
+            const long long v = (sb + tid) * G + (blockIdx.x + 37 * (sb + tid)) % G;
             const int n = v < V ? seg_start[v + 1] - seg_start[v] : 0;
             if (n > lo && n <= hi) todo[atomicAdd(&ntodo, 1)] = tid;   // queue order does not matter
         }
         __syncthreads();
         const int nq = ntodo;
         for (int qi = 0; qi < nq; ++qi) {
-            const long long v = (sb + todo[qi]) * G + blockIdx.x;
+            const long long v = (sb + todo[qi]) * G + (blockIdx.x + 37 * (sb + todo[qi])) % G;
             const int s = seg_start[v];
             const int n = seg_start[v + 1] - s;
             int *data = order + s;
@@ -723,9 +729,10 @@ extern "C" int sgv3d_voxel_plan_build(int batch_size, int num_points, int num_vo
         hipLaunchKernelGGL((vp_sort_wave_kernel<1>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 1);
         hipLaunchKernelGGL((vp_sort_wave_kernel<4>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 64);
         hipLaunchKernelGGL((vp_sort_wave_kernel<16>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 256);
+        hipLaunchKernelGGL((vp_sort_wave_kernel<32>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 1024);
         const int g_large = (int)((L.V + 255) / 256 < 1024 ? (L.V + 255) / 256 : 1024);
         hipLaunchKernelGGL((vp_sort_segments_kernel<256, 8192>), dim3(g_large), dim3(256), 0, st, L.V, seg, order,
-                           1024, 0x7fffffff);
+                           2048, 0x7fffffff);
     }
     return check_launch("voxel_plan_build");
 }
