@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fuse-lift-splat", action="store_true", help="skip the materialised [B,N,C] lifted tensor")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="frames in flight: consecutive steps are replayed round-robin on this many HIP streams "
+                         "(each with its own graph and activation buffers), so kernels of frame i+1 fill the CUs that "
+                         "the batch-1 layers of frame i leave idle")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "r101", "cfg5"],
                     help="cfg2 (default, the judged workload): R50 BEVHeight; r101: R101 BEVHeight; "
                          "cfg5: SGV3D BSM R101 (model of BASELINE configs[4], fp32, batch 1)")
@@ -111,35 +115,29 @@ def main():
     torch.cuda.synchronize()
     hip_ops.save_tune_db()          # no-op unless SGV3D_TUNE_CACHE is set (tools/profile_round.sh)
 
-    # ---- optional hipGraph capture of one step ---------------------------------------------------
-    use_graph = not args.no_graph
-    graph = None
-    if use_graph:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                step()
-                torch.cuda.synchronize()
-                with torch.cuda.graph(graph, stream=s):
-                    out = step()
-            torch.cuda.current_stream().wait_stream(s)
-            graph.replay()
-            torch.cuda.synchronize()
-        except Exception as e:  # capture unsupported -> eager launches of the same kernels
-            if rank == 0:
-                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            graph = None
-            use_graph = False
-            torch.cuda.synchronize()
-    run = (lambda: graph.replay()) if graph is not None else step
-    for _ in range(args.warmup):
+    # ---- hipGraph capture: one graph + activation pool per frame in flight (sgv3d_amd/pipeline.py) ----
+    from sgv3d_amd.pipeline import FramePipeline
+    nstreams = max(1, args.streams)
+    pipe = FramePipeline(model, imgs, mats, slots=nstreams, use_graph=not args.no_graph)
+    use_graph = pipe.use_graph
+    if not use_graph and not args.no_graph and rank == 0:
+        print("[bench] hipGraph capture failed; running eager launches on the slot streams", file=sys.stderr)
+    run = pipe.replay
+    for _ in range(args.warmup * nstreams):
         run()
+    torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps ------------------------------------------------------------
     elapsed = group.timed(run, args.steps)          # barrier+sync | K steps | barrier+sync, MAX over ranks
     value = group.aggregate_throughput(B, args.steps, elapsed)
+    single = None
+    if nstreams > 1 and rank == 0 and world == 1:   # same K steps with one frame in flight, for reference
+        one = FramePipeline(model, imgs, mats, slots=1, use_graph=use_graph)
+        for _ in range(args.warmup):
+            one.replay()
+        t1 = group.timed(one.replay, args.steps)
+        single = {"value": B * args.steps / t1, "ms_per_step": t1 / args.steps * 1e3}
+        del one
 
     # ---- roofline: instrumented pass, HIP events around every conv launch -------------------------
     roofline = None
@@ -204,7 +202,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world}",
-                       "hip_graph": bool(use_graph), "fuse_lift_splat": bool(args.fuse_lift_splat),
+                       "hip_graph": bool(use_graph), "frames_in_flight": nstreams, "one_frame_in_flight": single, "fuse_lift_splat": bool(args.fuse_lift_splat),
                        "voxel_pooling_mode": "planned", "weights": "random-init, BN stats perturbed (seed 0)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -23,6 +23,9 @@ PROFILE = None
 AUTOTUNE = True
 # True: conv records carry the layer shape in their name (tools/layer_report.py)
 PROFILE_DETAIL = False
+# False: the autotuner never proposes split-K (experiments; SGV3D_NO_SPLITK=1)
+import os as _os
+SPLIT_K = not _os.environ.get("SGV3D_NO_SPLITK")
 # (tile, split-K) decisions by layer signature.  SGV3D_TUNE_CACHE=<file> loads them at import and
 # save_tune_db() writes them back, so that a profiled run replays the choices of an earlier run
 # instead of timing candidates again (keeps rocprofv3 per-kernel averages free of tuning launches).
@@ -268,6 +271,8 @@ class PackedConv:
                 wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
                 if fixed_split:
                     splits = (fixed_split,)
+                elif not SPLIT_K:
+                    splits = (1,)
                 else:
                     splits = [1] + [s for s in (2, 3, 4, 6, 8) if nkt // s >= 8 and wgs < 1024 and wgs * s <= 4096]
                 for sk in splits:

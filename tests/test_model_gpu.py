@@ -193,3 +193,24 @@ def test_bsm_state_dict_names():
         'head.neck.deblocks.3.0.weight': (696, 64, 8, 8),
     }.items():
         assert tuple(sd[k].shape) == shp, k
+
+
+def test_frame_pipeline_matches_direct_forward(small):
+    """FramePipeline (hipGraph per slot, several frames in flight) returns what the direct forward does."""
+    from sgv3d_amd.pipeline import FramePipeline
+    m = small['m']
+    imgs, mats = small['imgs'].to(DEV), _to_dev(small['mats'])
+    with torch.no_grad():
+        direct = m(imgs, mats)
+        want = {k: v.clone() for k, v in direct[3][0].items()}
+        imgs2 = S.make_images(2, small['bc']['final_dim'], seed=21).to(DEV)
+        want2 = {k: v.clone() for k, v in m(imgs2, mats)[3][0].items()}
+    pipe = FramePipeline(m, imgs, mats, slots=2)
+    s0 = pipe.submit(imgs, mats)
+    s1 = pipe.submit(imgs2, mats)
+    r0 = {k: v.clone() for k, v in pipe.result(s0)[3][0].items()}
+    r1 = {k: v.clone() for k, v in pipe.result(s1)[3][0].items()}
+    for k in want:
+        torch.testing.assert_close(r0[k], want[k], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(r1[k], want2[k], rtol=1e-5, atol=1e-5)
+    assert s0 != s1
