@@ -1,0 +1,64 @@
+// Shared by the convolution kernels (conv_igemm.hip, conv_wino.hip): launch arguments, the common
+// epilogue (folded BN / bias, residual, ReLU, SE gate, store in the mode's layout) and the split-K tail.
+#pragma once
+#include "common.hpp"
+
+namespace sgv3d {
+
+struct ConvArgs {
+    const float *x, *w, *scale, *bias, *res, *gate, *zeros;
+    float *y;
+    int M, N, K, k_pad;
+    int in_h, in_w, cin, out_h, out_w, cout;
+    int m_h, m_w;  // spatial dims used to decode m (output dims; input dims for the deconv GEMM)
+    int kh, kw, stride, pad, dil;
+    int x_ld, x_coff, y_ld, y_coff, res_ld, relu, mode, ks;
+    int tiles_m, tiles_n;
+    int wb_y, wb_x;  // Winograd kernel: 16x16-pixel output blocks per image
+    int korder;  // 0: k = tap*cin + ci   1: k = (ci/32 * taps + tap)*32 + ci%32  (cin % 32 == 0)
+    int split_k; // > 1: blockIdx.y owns a slice of the k-tiles and stores raw partial sums to ws
+    float *ws;   // [split_k][M][N] partial sums (split_k > 1)
+};
+
+// Shared by the conv kernel (split_k == 1) and the split-K reduce kernel: scale/shift (folded BN or
+// bias), residual, ReLU, SE gate and the store in the mode's layout.
+static __device__ __forceinline__ void conv_epilogue_store(const ConvArgs &a, int row, int col, float accv) {
+    const int hw = a.m_h * a.m_w;
+    int co = col, dy = 0, dx = 0;
+    if (a.mode == SGV3D_CONV_DECONV) {
+        const int tap = col / a.cout;
+        co = col - tap * a.cout;
+        dy = tap / a.ks;
+        dx = tap - dy * a.ks;
+    }
+    float v = accv * (a.scale ? a.scale[co] : 1.f) + (a.bias ? a.bias[co] : 0.f);
+    size_t yi;
+    int img = 0;
+    if (a.mode == SGV3D_CONV_NORMAL) {
+        yi = (size_t)row * a.y_ld + a.y_coff + co;
+        if (a.gate) img = row / hw;
+    } else {
+        img = row / hw;
+        const int pix = row - img * hw;
+        if (a.mode == SGV3D_CONV_DECONV) {
+            const int ih = pix / a.m_w, iw = pix - ih * a.m_w;
+            yi = ((size_t)(img * a.out_h + ih * a.ks + dy) * a.out_w + (iw * a.ks + dx)) * a.y_ld + a.y_coff + co;
+        } else if (a.mode == SGV3D_CONV_NCHW_OUT) {
+            yi = ((size_t)img * a.y_ld + a.y_coff + co) * hw + pix;
+        } else {  // GROUP_PLANES: [cout/g][M][g], g = a.ks
+            const int grp = co / a.ks;
+            yi = ((size_t)grp * a.M + row) * a.ks + (co - grp * a.ks);
+        }
+    }
+    if (a.res) v += a.res[(size_t)row * a.res_ld + co];
+    if (a.relu) v = fmaxf(v, 0.f);
+    if (a.gate) v *= a.gate[(size_t)img * a.cout + co];
+    a.y[yi] = v;
+}
+
+// Split-K second stage (conv_igemm.hip): sums a.ws[split][M][N] in fixed order and runs the epilogue.
+int launch_splitk_reduce(const ConvArgs &a, hipStream_t st);
+// 16 zero bytes in device memory that padded / out-of-image lanes load from (conv_igemm.hip).
+const float *conv_zero_block();
+
+}  // namespace sgv3d

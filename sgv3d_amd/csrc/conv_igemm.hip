@@ -21,7 +21,7 @@
 // buffer afterwards (one barrier per k-tile); 2 workgroups/CU cover each other's barrier stalls.
 // Block ids are remapped so that the workgroups sharing an XCD (private 4 MiB L2) work on
 // consecutive m-tiles of the same n-tile, i.e. share one packed-weight panel.
-#include "common.hpp"
+#include "conv_common.hpp"
 
 using namespace sgv3d;
 
@@ -35,56 +35,6 @@ constexpr int kThreads = 256;
 
 // 16 zero bytes that padded / out-of-image lanes load from
 __device__ __attribute__((aligned(16))) float4 g_zero16 = {0.f, 0.f, 0.f, 0.f};
-
-struct ConvArgs {
-    const float *x, *w, *scale, *bias, *res, *gate, *zeros;
-    float *y;
-    int M, N, K, k_pad;
-    int in_h, in_w, cin, out_h, out_w, cout;
-    int m_h, m_w;  // spatial dims used to decode m (output dims; input dims for the deconv GEMM)
-    int kh, kw, stride, pad, dil;
-    int x_ld, x_coff, y_ld, y_coff, res_ld, relu, mode, ks;
-    int tiles_m, tiles_n;
-    int korder;  // 0: k = tap*cin + ci   1: k = (ci/32 * taps + tap)*32 + ci%32  (cin % 32 == 0)
-    int split_k; // > 1: blockIdx.y owns a slice of the k-tiles and stores raw partial sums to ws
-    float *ws;   // [split_k][M][N] partial sums (split_k > 1)
-};
-
-// Shared by the conv kernel (split_k == 1) and the split-K reduce kernel: scale/shift (folded BN or
-// bias), residual, ReLU, SE gate and the store in the mode's layout.
-__device__ __forceinline__ void conv_epilogue_store(const ConvArgs &a, int row, int col, float accv) {
-    const int hw = a.m_h * a.m_w;
-    int co = col, dy = 0, dx = 0;
-    if (a.mode == SGV3D_CONV_DECONV) {
-        const int tap = col / a.cout;
-        co = col - tap * a.cout;
-        dy = tap / a.ks;
-        dx = tap - dy * a.ks;
-    }
-    float v = accv * (a.scale ? a.scale[co] : 1.f) + (a.bias ? a.bias[co] : 0.f);
-    size_t yi;
-    int img = 0;
-    if (a.mode == SGV3D_CONV_NORMAL) {
-        yi = (size_t)row * a.y_ld + a.y_coff + co;
-        if (a.gate) img = row / hw;
-    } else {
-        img = row / hw;
-        const int pix = row - img * hw;
-        if (a.mode == SGV3D_CONV_DECONV) {
-            const int ih = pix / a.m_w, iw = pix - ih * a.m_w;
-            yi = ((size_t)(img * a.out_h + ih * a.ks + dy) * a.out_w + (iw * a.ks + dx)) * a.y_ld + a.y_coff + co;
-        } else if (a.mode == SGV3D_CONV_NCHW_OUT) {
-            yi = ((size_t)img * a.y_ld + a.y_coff + co) * hw + pix;
-        } else {  // GROUP_PLANES: [cout/g][M][g], g = a.ks
-            const int grp = co / a.ks;
-            yi = ((size_t)grp * a.M + row) * a.ks + (co - grp * a.ks);
-        }
-    }
-    if (a.res) v += a.res[(size_t)row * a.res_ld + co];
-    if (a.relu) v = fmaxf(v, 0.f);
-    if (a.gate) v *= a.gate[(size_t)img * a.cout + co];
-    a.y[yi] = v;
-}
 
 // Split-K second stage: sums the split partials in fixed order and runs the common epilogue.
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs a) {
@@ -379,23 +329,14 @@ int launch_t(const ConvArgs &a, hipStream_t st) {
             return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot raise the dynamic LDS limit to %zu", lds);
         attr_set = true;
     }
-    static const float *zero_block = nullptr;
-    if (!zero_block) {
-        void *p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero16)) != hipSuccess || !p)
-            return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot resolve the zero block");
-        zero_block = static_cast<const float *>(p);
-    }
     ConvArgs b = a;
-    b.zeros = zero_block;
+    b.zeros = conv_zero_block();
+    if (!b.zeros) return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot resolve the zero block");
     b.tiles_m = cdiv(a.M, BM);
     b.tiles_n = cdiv(a.N, BN);
     hipLaunchKernelGGL((conv_igemm_kernel<WTM, WTN, FAST>), dim3(b.tiles_m * b.tiles_n, b.split_k), dim3(kThreads), lds,
                        st, b);
-    if (b.split_k > 1) {
-        const long long total = (long long)b.M * b.N;
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, b);
-    }
+    if (b.split_k > 1) return launch_splitk_reduce(b, st);
     return check_launch("conv_igemm_kernel");
 }
 
@@ -420,6 +361,23 @@ int pick_tile(long long M, int N) {
 }
 
 }  // namespace
+
+namespace sgv3d {
+int launch_splitk_reduce(const ConvArgs &a, hipStream_t st) {
+    const long long total = (long long)a.M * a.N;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, a);
+    return check_launch("conv_splitk_reduce_kernel");
+}
+const float *conv_zero_block() {
+    static const float *zero_block = nullptr;
+    if (!zero_block) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero16)) != hipSuccess) return nullptr;
+        zero_block = static_cast<const float *>(p);
+    }
+    return zero_block;
+}
+}  // namespace sgv3d
 
 extern "C" void sgv3d_conv_pack_geometry(int k, int n, int *k_pad, int *n_pad) {
     if (k_pad) *k_pad = ((k + BK - 1) / BK) * BK;

@@ -26,6 +26,8 @@ PROFILE_DETAIL = False
 # False: the autotuner never proposes split-K (experiments; SGV3D_NO_SPLITK=1)
 import os as _os
 SPLIT_K = not _os.environ.get("SGV3D_NO_SPLITK")
+# False: 3x3 / stride-1 layers never use the Winograd F(2x2,3x3) kernel (SGV3D_NO_WINOGRAD=1)
+WINOGRAD = not _os.environ.get("SGV3D_NO_WINOGRAD")
 # (tile, split-K) decisions by layer signature.  SGV3D_TUNE_CACHE=<file> loads them at import and
 # save_tune_db() writes them back, so that a profiled run replays the choices of an earlier run
 # instead of timing candidates again (keeps rocprofv3 per-kernel averages free of tuning launches).
@@ -56,7 +58,8 @@ def save_tune_db(path=None):
 
 
 load_tune_db()
-TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64"}
+TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino"}
+TILE_WINO = 5   # host-side algorithm id: sgv3d_conv2d_winograd_forward instead of the implicit GEMM
 
 
 class prof:
@@ -168,7 +171,17 @@ class PackedConv:
         _lib.check(rc, "sgv3d_conv_pack_weight")
         self.scale = None if scale is None else scale.detach().to(device=device, dtype=torch.float32).contiguous()
         self.shift = None if shift is None else shift.detach().to(device=device, dtype=torch.float32).contiguous()
-        self._keep = w  # the pack kernel reads it asynchronously
+        # Winograd F(2x2,3x3) weights for the layers the second kernel covers
+        self.w_wino = None
+        if (WINOGRAD and not transposed and kh == 3 and kw == 3 and self.stride == 1 and self.dil == 1
+                and self.pad == 1 and self.cin % 8 == 0):
+            lib = _lib.load()
+            self.w_wino = torch.empty(lib.sgv3d_conv_winograd_weight_floats(cout, self.cin), dtype=torch.float32,
+                                      device=device)
+            with torch.cuda.device(device):
+                rc = lib.sgv3d_conv_winograd_pack_weight(w.data_ptr(), cout, cin, self.cin, self.w_wino.data_ptr(), _st(w))
+            _lib.check(rc, "sgv3d_conv_winograd_pack_weight")
+        self._keep = w  # the pack kernels read it asynchronously
         self._tile_cache = {}
 
     def out_hw(self, h, w):
@@ -240,7 +253,7 @@ class PackedConv:
             t, sk = choice
         d.tile, d.split_k = t, sk
         flops = 2.0 * gemm_m * gemm_n * (self.cin * self.kh * self.kw)
-        name = "conv_igemm_" + TILE_NAMES[t]
+        name = ("conv_" if t == TILE_WINO else "conv_igemm_") + TILE_NAMES[t]
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
                      f"s{self.stride} d{self.dil} splitk{sk}")
@@ -254,6 +267,12 @@ class PackedConv:
         if d.split_k > 1:
             nws = lib.sgv3d_conv2d_workspace_bytes(ctypes.byref(d))
             ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+        if d.tile == TILE_WINO:
+            if self.w_wino is None:
+                raise _lib.SGV3DError("this layer has no Winograd weights (needs 3x3 / stride 1 / pad 1 / cin % 8 == 0)")
+            return lib.sgv3d_conv2d_winograd_forward(ctypes.byref(d), x.data_ptr(), self.w_wino.data_ptr(),
+                                                     _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
+                                                     _lib.ptr(gate), out.data_ptr(), _lib.ptr(ws), nws, _st(x))
         return lib.sgv3d_conv2d_forward(ctypes.byref(d), x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.scale),
                                         _lib.ptr(self.shift), _lib.ptr(residual), _lib.ptr(gate), out.data_ptr(),
                                         _lib.ptr(ws), nws, _st(x))
@@ -262,19 +281,23 @@ class PackedConv:
         """Time the candidate (tile, split-K) pairs on the real buffers and keep the fastest.  Results do
         not depend on the tile shape (every output element sums k in the same order); split-K changes
         the association of the k sum (partials added in fixed order), still deterministic."""
-        tiles = (fixed_tile,) if fixed_tile else (1, 2, 3, 4)
-        dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64)}
+        tiles = (fixed_tile,) if fixed_tile else ((1, 2, 3, 4, 5) if self.w_wino is not None and WINOGRAD else (1, 2, 3, 4))
+        dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 64)}
         best, best_t = (tiles[0], fixed_split or 1), None
         with torch.cuda.device(x.device):
             for t in tiles:
                 bm, bn = dims[t]
                 wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
+                nk = nkt
+                if t == TILE_WINO:
+                    nk = self.cin // 4      # k-steps of 8 channels; nk // s >= 8 keeps >= 4 steps per split
+                    wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 16) * -(-gemm_n // 64)
                 if fixed_split:
                     splits = (fixed_split,)
                 elif not SPLIT_K:
                     splits = (1,)
                 else:
-                    splits = [1] + [s for s in (2, 3, 4, 6, 8) if nkt // s >= 8 and wgs < 1024 and wgs * s <= 4096]
+                    splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 8 and wgs < 1024 and wgs * s <= 4096]
                 for sk in splits:
                     d.tile, d.split_k = t, sk
                     _lib.check(self._launch(lib, d, x, residual, gate, out), "sgv3d_conv2d_forward")   # warm
