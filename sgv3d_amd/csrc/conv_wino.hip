@@ -28,150 +28,173 @@ using namespace sgv3d;
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void gl_void;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WK = 8;                           // input channels per k-step
 constexpr int A_ROWS = 18, A_HALF = 10;         // patch rows; 16-B slots per (row, column parity), 9 used
 constexpr int A_PLANE = A_ROWS * 2 * A_HALF;    // 360 slots per 4-channel plane
 constexpr int A_USED = 2 * A_PLANE;             // 720
-constexpr int A_SLOTS = 768;                    // 12 wave-instructions of 64 slots
-constexpr int W_SLOTS = 16 * 2 * 64;            // 2048 slots = 32 KB per step
-constexpr int BUF_SLOTS = A_SLOTS + W_SLOTS;    // 45 056 B per buffer
-constexpr int kWinoLds = 3 * BUF_SLOTS * 16;           // 135 168 B: three buffers
+constexpr int A_SLOTS = 768;                    // 3 slots per thread
+constexpr int W_STEP = 16 * 2 * 64 * 4;         // floats of one k-step of one 64-channel tile (32 KB)
+constexpr int W_POS = 2 * 64 * 4;               // floats per Winograd position inside a step
+constexpr int kWinoLds = 2 * A_SLOTS * 16;      // two patch buffers (24 KB)
 
-// Asynchronous 16-byte-per-lane global -> LDS copy (lane i lands at dst_wave_base + 16*i).  Issued as
-// inline asm: the compiler would otherwise drain it (vmcnt(0)) before the next ds_read.  The copies of
-// step s+2 are issued right after the barrier in the middle of step s and retired by the
-// "s_waitcnt vmcnt(0); s_barrier" in the middle of step s+1 (SGV3D_WINO_PUBLISH), one full step later.
-__device__ __forceinline__ void glds16(const float *src, float4 *dst_wave_base) {
-    unsigned keep;
-    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void *)dst_wave_base);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src), "s"(lds_dst)
-                 : "memory");
-}
-#define SGV3D_WINO_PUBLISH() asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
 #define SGV3D_SB() __builtin_amdgcn_sched_barrier(0)
-
-// The 11 copies (3 patch pieces + 8 weight pieces of 1 KiB) a wave issues per k-step.  An LDS-DMA piece
-// costs the issuing wave ~60-180 cycles of vector issue, so the pieces are not issued in a burst after the
-// barrier but one per MFMA gap in the second half of the step (wino_pair).
-struct WinoLoader {
-    const float *asrc[3];
-    int ainc[3];
-    const float *wsrc;
-    float4 *dst;      // destination buffer (LDS) of the step being fetched
-    int wave;
-    bool on;          // false in the last two steps: nothing left to fetch
-    template <int K>
-    __device__ __forceinline__ void piece() {
-        if (!on) return;
-        if constexpr (K < 3) {
-            glds16(asrc[K], dst + (wave * 3 + K) * 64);
-            asrc[K] += ainc[K];
-        } else {
-            glds16(wsrc + (K - 3) * 256, dst + A_SLOTS + (wave * 8 + (K - 3)) * 64);
-            if constexpr (K == 10) wsrc += W_SLOTS * 4;
-        }
-    }
-    __device__ __forceinline__ void all() {
-        piece<0>(); piece<1>(); piece<2>(); piece<3>(); piece<4>(); piece<5>();
-        piece<6>(); piece<7>(); piece<8>(); piece<9>(); piece<10>();
-    }
-};
+// every wave's patch writes have landed (lgkmcnt) -> barrier.  Outstanding global loads (weight
+// fragments, the next patch) stay in flight: unlike __syncthreads() this does not wait on vmcnt.
+#define SGV3D_WINO_PUBLISH() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // B^T rows of F(2x2,3x3): (x0 - x2, x1 + x2, x2 - x1, x1 - x3)
 template <int R>
-__device__ __forceinline__ float4 wino_bt(const float4 &x0, const float4 &x1, const float4 &x2, const float4 &x3) {
+__device__ __forceinline__ f32x4 wino_bt(const f32x4 &x0, const f32x4 &x1, const f32x4 &x2, const f32x4 &x3) {
     if constexpr (R == 0) return x0 - x2;
     else if constexpr (R == 1) return x1 + x2;
     else if constexpr (R == 2) return x2 - x1;
     else return x1 - x3;
 }
 
-// Two Winograd positions P, P+1 of the current step: 2 x 4 MFMAs (k = 4h + 0..3), interleaved so that
-// every MFMA is followed by one on the other accumulator, with the rest of the pipeline in their shadows
-// (the wave is alone on its SIMD, so whatever is issued between two MFMAs is free while the issue costs
-// fit the 64-cycle gap):
-//   the weight fragments of the next pair (ring of 4; positions 16, 17 = 0, 1 of the next step),
-//   the row pass (V = T B) of the next pair,
-//   the next step's patch -- raw reads in pair 8 (after the mid-step barrier that publishes it), then
-//   its column pass T = B^T d row by row into tc as soon as the row of the current step is dead
-//   (rows 0, 1 in pair 10, row 2 in pair 12, row 3 in pair 14),
-//   and, in pairs 8..14, three of the 11 LDS-DMA pieces of the step after next.
+// Per-wave state of the two operand streams.  Both are read with buffer loads: the resource and the
+// step / position part of the address live in scalar registers, the lane part is one constant VGPR, so
+// a fragment load costs no vector ALU work (on this chip VALU instructions and fp32 MFMAs of one wave do
+// not overlap), and out-of-image patch lanes simply carry an out-of-range offset (buffer loads return 0).
+struct WinoStreams {
+    __amdgpu_buffer_rsrc_t w_rsrc, x_rsrc;
+    unsigned w_cur, w_next;        // byte offset of the current / next k-step of this cout tile (uniform)
+    unsigned w_lane;               // this lane's byte offset inside a position: (h*64 + wn*32 + t) * 16
+    unsigned x_step;               // byte offset of the k-step whose patch is fetched next (uniform)
+    unsigned x0, x1, x2;           // this thread's three patch slots: byte offset of the pixel (or out of range)
+    f32x4 stage0, stage1, stage2;  // patch of the next step on its way global -> registers -> LDS
+    f32x4 *a_wr;                   // LDS slot 0 of this thread in the buffer the next patch is written to
+};
+
+__device__ __forceinline__ f32x4 wino_buffer_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+// Two Winograd positions P, P+1 of the current step: 2 x 4 MFMAs (k = 4h + 0..3) alternating between the
+// two accumulators.  Everything else the wave has to issue is gathered into two of the eight MFMA gaps
+// (measured on gfx950, one wave per SIMD: a gap that carries other instructions costs ~10 cycles plus ~3
+// per VALU instruction, because fp32 MFMAs and VALU share the SIMD's fp32 lanes -- so fewer, fuller gaps):
+//   gap 1 (memory): the weight fragments three pairs ahead (P+6, P+7; positions >= 16 are the next
+//     step's) -- buffer_load_dwordx4 straight into the fragment registers: the packed layout IS the
+//     fragment layout, each half-wave reads 512 contiguous bytes, the two waves sharing a channel half
+//     hit in L1; ring of 8 fragments, ~1500 cycles of prefetch distance.  Plus the patch pipeline's
+//     memory operations: pairs 0..4 write the staged patch of step s+1 to LDS (published by the barrier in
+//     the middle of the step), pair 8 reads it back as 4x4 tiles, pairs 10..14 fetch the patch of step s+2.
+//   gap 2 (VALU): the row pass (V = T B) of the next pair, and in pairs 10..14 the column pass
+//     T = B^T d of the next step's patch, row by row into tc as soon as the current step's row is dead
+//     (rows 0, 1 in pair 10, row 2 in pair 12, row 3 in pair 14).
 #define SGV3D_WINO_MFMA(P, C, V, BF) acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(V.C, BF.C, acc[P], 0, 0, 0)
 template <int P>
-__device__ __forceinline__ void wino_pair(f32x16 (&acc)[16], float4 (&tc)[4][4], float4 (&raw)[4][4], float4 &vc0,
-                                          float4 &vc1, float4 &vn0, float4 &vn1, float4 (&bf)[4], const float4 *Bc,
-                                          const float4 *Bn, const float4 *An, WinoLoader &ld) {
+__device__ __forceinline__ void wino_pair(f32x16 (&acc)[16], f32x4 (&tc)[4][4], f32x4 (&raw)[4][4], f32x4 &vc0,
+                                          f32x4 &vc1, f32x4 &vn0, f32x4 &vn1, f32x4 (&wf)[8], WinoStreams &st,
+                                          const f32x4 *An) {
     static_assert((P & 1) == 0, "pairs start at even positions");
-    constexpr int G = P >= 8 ? 3 * ((P - 8) / 2) : 100;   // first piece of this pair (none before the barrier)
-    const float4 b0 = bf[P & 3], b1 = bf[(P + 1) & 3];
+    constexpr int R0 = P & 7, R1 = (P + 1) & 7;          // ring slots of this pair
+    constexpr int L0 = (P + 6) & 7, L1 = (P + 7) & 7;    // ring slots (= those of pair P-2) refilled now
+    const f32x4 b0 = wf[R0], b1 = wf[R1];
     SGV3D_WINO_MFMA(P, x, vc0, b0);
     SGV3D_SB();
-    if constexpr (P + 2 < 16) bf[(P + 2) & 3] = Bc[(P + 2) * 128];
-    else bf[(P + 2) & 3] = Bn[(P + 2 - 16) * 128];
+    // ---- gap 1: memory ----
+    if constexpr (P + 6 < 16) wf[L0] = wino_buffer_load(st.w_rsrc, st.w_lane, st.w_cur + (P + 6) * (W_POS * 4));
+    else wf[L0] = wino_buffer_load(st.w_rsrc, st.w_lane, st.w_next + (P + 6 - 16) * (W_POS * 4));
+    if constexpr (P + 7 < 16) wf[L1] = wino_buffer_load(st.w_rsrc, st.w_lane, st.w_cur + (P + 7) * (W_POS * 4));
+    else wf[L1] = wino_buffer_load(st.w_rsrc, st.w_lane, st.w_next + (P + 7 - 16) * (W_POS * 4));
+    if constexpr (P == 0 || P == 2 || P == 4) {
+        st.a_wr[(P / 2) * 256] = P == 0 ? st.stage0 : P == 2 ? st.stage1 : st.stage2;   // slot (P/2)*256 + tid
+    } else if constexpr (P == 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) raw[i][j] = An[i * (2 * A_HALF) + (j & 1) * A_HALF + (j >> 1)];
+    } else if constexpr (P == 10) {
+        st.stage0 = wino_buffer_load(st.x_rsrc, st.x0, st.x_step);
+    } else if constexpr (P == 12) {
+        st.stage1 = wino_buffer_load(st.x_rsrc, st.x1, st.x_step);
+    } else if constexpr (P == 14) {
+        st.stage2 = wino_buffer_load(st.x_rsrc, st.x2, st.x_step);
+    }
     SGV3D_SB();
     SGV3D_WINO_MFMA(P + 1, x, vc1, b1);
     SGV3D_SB();
-    if constexpr (P + 3 < 16) bf[(P + 3) & 3] = Bc[(P + 3) * 128];
-    else bf[(P + 3) & 3] = Bn[(P + 3 - 16) * 128];
-    if constexpr (G < 11) ld.template piece<(G < 11 ? G : 0)>();
-    SGV3D_SB();
     SGV3D_WINO_MFMA(P, y, vc0, b0);
-    SGV3D_SB();
-    {
-        constexpr int Q = (P + 2) & 15;
-        vn0 = wino_bt<(Q & 3)>(tc[Q >> 2][0], tc[Q >> 2][1], tc[Q >> 2][2], tc[Q >> 2][3]);
-    }
     SGV3D_SB();
     SGV3D_WINO_MFMA(P + 1, y, vc1, b1);
     SGV3D_SB();
-    {
-        constexpr int Q = (P + 3) & 15;
-        vn1 = wino_bt<(Q & 3)>(tc[Q >> 2][0], tc[Q >> 2][1], tc[Q >> 2][2], tc[Q >> 2][3]);
-    }
-    SGV3D_SB();
     SGV3D_WINO_MFMA(P, z, vc0, b0);
     SGV3D_SB();
-    if constexpr (P == 8) {
+    // ---- gap 2: vector ALU ----
+    {
+        constexpr int Q0 = (P + 2) & 15, Q1 = (P + 3) & 15;
+        vn0 = wino_bt<(Q0 & 3)>(tc[Q0 >> 2][0], tc[Q0 >> 2][1], tc[Q0 >> 2][2], tc[Q0 >> 2][3]);
+        vn1 = wino_bt<(Q1 & 3)>(tc[Q1 >> 2][0], tc[Q1 >> 2][1], tc[Q1 >> 2][2], tc[Q1 >> 2][3]);
+    }
+    if constexpr (P == 10) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) {
+            tc[0][j] = wino_bt<0>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
+            tc[1][j] = wino_bt<1>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
+        }
+    } else if constexpr (P == 12) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) raw[i][j] = An[i * (2 * A_HALF) + (j & 1) * A_HALF + (j >> 1)];
-    } else if constexpr (P == 10 || P == 12) {
-        constexpr int R = P == 10 ? 0 : 2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tc[R][j] = wino_bt<R>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
+        for (int j = 0; j < 4; ++j) tc[2][j] = wino_bt<2>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
     }
     SGV3D_SB();
     SGV3D_WINO_MFMA(P + 1, z, vc1, b1);
     SGV3D_SB();
-    if constexpr (P == 8) {
-#pragma unroll
-        for (int i = 2; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) raw[i][j] = An[i * (2 * A_HALF) + (j & 1) * A_HALF + (j >> 1)];
-    } else if constexpr (P == 10 || P == 14) {
-        constexpr int R = P == 10 ? 1 : 3;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tc[R][j] = wino_bt<R>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
-    }
-    SGV3D_SB();
     SGV3D_WINO_MFMA(P, w, vc0, b0);
-    SGV3D_SB();
-    if constexpr (G + 1 < 11) ld.template piece<(G + 1 < 11 ? G + 1 : 0)>();
     SGV3D_SB();
     SGV3D_WINO_MFMA(P + 1, w, vc1, b1);
     SGV3D_SB();
-    if constexpr (G + 2 < 11) ld.template piece<(G + 2 < 11 ? G + 2 : 0)>();
-    SGV3D_SB();
+    if constexpr (P == 14) {   // row 3 of the current step died with vn1 (position 15) above
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tc[3][j] = wino_bt<3>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
+        SGV3D_SB();
+    }
+}
+
+// Output transform Y = A^T M A of the 16 tiles a lane holds (one output channel each) and their stores;
+// see the epilogue comment in the kernel for the addressing.  PARTIAL: raw split-K partials.
+template <bool PARTIAL, bool HAS_RES>
+__device__ __forceinline__ void wino_store(f32x16 (&acc)[16], __amdgpu_buffer_rsrc_t y_rsrc, __amdgpu_buffer_rsrc_t r_rsrc,
+                                           const unsigned (&voff)[4][2], const unsigned (&roff)[4][2], unsigned rowpitch,
+                                           unsigned rpitch, int oy_wave, int out_h, float sc, float sh, float gt,
+                                           float floor_) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        // tile (ty, tx) of accumulator element e:  ty = wm*4 + (e >> 2),  tx = 4h + (e & 3)
+        float r0[4], r1[4];   // rows of A^T M:  r0 = m0 + m1 + m2,  r1 = m1 - m2 - m3   (per Winograd column j)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m0 = acc[j][e], m1 = acc[4 + j][e], m2 = acc[8 + j][e], m3 = acc[12 + j][e];
+            r0[j] = m0 + m1 + m2;
+            r1[j] = m1 - m2 - m3;
+        }
+        const float yv[2][2] = {{r0[0] + r0[1] + r0[2], r0[1] - r0[2] - r0[3]},
+                                {r1[0] + r1[1] + r1[2], r1[1] - r1[2] - r1[3]}};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int yy = 2 * (e >> 2) + dy;
+            if (oy_wave + yy < out_h) {   // wave-uniform
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float v = yv[dy][dx];
+                    if constexpr (!PARTIAL) {
+                        v = v * sc + sh;
+                        if constexpr (HAS_RES)
+                            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, roff[e & 3][dx], yy * rpitch, 0));
+                        v = fmaxf(v, floor_) * gt;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, voff[e & 3][dx], yy * rowpitch, 0);
+                }
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
 
     // ---- XCD-aware tile mapping (same bijection as the implicit-GEMM kernel) ----------------------
     const int ntiles = a.tiles_m * a.tiles_n;
@@ -197,22 +220,35 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     const int kb = (int)((long long)nsteps_all * blockIdx.y / a.split_k);
     const int ke = (int)((long long)nsteps_all * (blockIdx.y + 1) / a.split_k);
 
-    // ---- global sources of this lane's three patch slots and of the weight stream ----------------
-    WinoLoader ld;
-    ld.wave = wave;
+    // ---- the two operand streams -------------------------------------------------------------------
+    // Patch: thread tid owns LDS slots tid, tid + 256, tid + 512 of each buffer; slot -> (channel half,
+    // row, column parity, column / 2) -> one input pixel, or an out-of-range offset (reads as zeros) for
+    // the conv padding, ragged image edges and the layout's pad slots.
+    WinoStreams st;
+    const unsigned x_bytes = (unsigned)((size_t)a.M * a.x_ld * sizeof(float));   // in == out size (host checks < 4 GiB)
+    st.x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)x_bytes, 0x00020000);
+    unsigned xoff[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int s = (wave * 3 + i) * 64 + lane;
+        const int s = i * 256 + tid;
         const int hh = s / A_PLANE, rem = s - hh * A_PLANE;
         const int row = rem / (2 * A_HALF), r2 = rem - row * (2 * A_HALF);
         const int par = r2 / A_HALF, ch = r2 - par * A_HALF;
         const int iy = oy0 - 1 + row, ix = ox0 - 1 + 2 * ch + par;
         const bool ok = (s < A_USED) & (ch < 9) & (iy >= 0) & (iy < a.in_h) & (ix >= 0) & (ix < a.in_w);
-        ld.asrc[i] = ok ? a.x + ((long long)(img * a.in_h + iy) * a.in_w + ix) * a.x_ld + a.x_coff + hh * 4 + kb * WK
-                        : a.zeros;
-        ld.ainc[i] = ok ? WK : 0;
+        xoff[i] = ok ? (unsigned)((((size_t)(img * a.in_h + iy) * a.in_w + ix) * a.x_ld + a.x_coff + hh * 4) * sizeof(float))
+                     : 0xfffffff0u - (unsigned)(a.cin * sizeof(float));   // stays out of range for every k-step
     }
-    ld.wsrc = a.w + ((size_t)tn * nsteps_all + kb) * (W_SLOTS * 4) + (wave * 8 * 64 + lane) * 4;
+    st.x0 = xoff[0];
+    st.x1 = xoff[1];
+    st.x2 = xoff[2];
+    st.x_step = (unsigned)(kb * WK * sizeof(float));
+    // Weights: packed [cout tile][k-step][pos][channel half][64 n][4] = exactly the MFMA B fragments.
+    const unsigned w_bytes = (unsigned)((size_t)a.tiles_n * nsteps_all * W_STEP * sizeof(float));
+    st.w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)w_bytes, 0x00020000);
+    st.w_cur = (unsigned)(((size_t)tn * nsteps_all + kb) * W_STEP * sizeof(float));
+    st.w_next = kb + 1 < ke ? st.w_cur + W_STEP * 4 : st.w_cur;
+    st.w_lane = (unsigned)(h * 64 + wn * 32 + t) * 16u;
 
     f32x16 acc[16];
 #pragma unroll
@@ -221,25 +257,29 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
         for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
 
     const int abase = (h * A_ROWS + 2 * (wm * 4 + (t >> 3))) * (2 * A_HALF) + (t & 7);
-    const int bbase = A_SLOTS + h * 64 + wn * 32 + t;
 
-    // ---- prologue: steps kb (buffer 0) and kb+1 (buffer 1) in flight, first patch transformed ------
-    ld.on = true;
-    ld.dst = smem;
-    ld.all();
+    // ---- prologue: patch of step kb through LDS, transformed; fragments of positions 0..5; patch of
+    //      step kb+1 on its way ------------------------------------------------------------------------
+    f32x4 tc[4][4], raw[4][4], wf[8], va0, va1, vb0, vb1;
+    st.stage0 = wino_buffer_load(st.x_rsrc, st.x0, st.x_step);
+    st.stage1 = wino_buffer_load(st.x_rsrc, st.x1, st.x_step);
+    st.stage2 = wino_buffer_load(st.x_rsrc, st.x2, st.x_step);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) wf[p] = wino_buffer_load(st.w_rsrc, st.w_lane, st.w_cur + p * (W_POS * 4));
+    smem[tid] = st.stage0;
+    smem[256 + tid] = st.stage1;
+    smem[512 + tid] = st.stage2;
+    if (kb + 1 < ke) st.x_step += WK * sizeof(float);
+    st.stage0 = wino_buffer_load(st.x_rsrc, st.x0, st.x_step);
+    st.stage1 = wino_buffer_load(st.x_rsrc, st.x1, st.x_step);
+    st.stage2 = wino_buffer_load(st.x_rsrc, st.x2, st.x_step);
     SGV3D_WINO_PUBLISH();
-    ld.on = kb + 1 < ke;
-    ld.dst = smem + BUF_SLOTS;
-    ld.all();
-    float4 tc[4][4], raw[4][4], bf[4], va0, va1, vb0, vb1;
     {
-        const float4 *const A = smem + abase;
+        const f32x4 *const A = smem + abase;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) raw[i][j] = A[i * (2 * A_HALF) + (j & 1) * A_HALF + (j >> 1)];
-        bf[0] = smem[bbase];
-        bf[1] = smem[bbase + 128];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             tc[0][j] = wino_bt<0>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
@@ -251,64 +291,93 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
         va1 = wino_bt<1>(tc[0][0], tc[0][1], tc[0][2], tc[0][3]);
     }
 
-    // ---- main loop: three LDS buffers, one barrier per step (in its middle) ------------------------
-    // Step s reads buffer s%3.  In the middle of step s: every wave retires its copies of step s+1
-    // (vmcnt), the barrier publishes buffer (s+1)%3 and proves that buffer (s+2)%3 (last read in step
-    // s-1) is free, and the copies of step s+2 start.  The second half of step s already reads the
-    // next step's patch and runs its column pass, so MFMAs never wait at a step boundary.  (In the last
-    // step those reads hit a stale but valid buffer and their results are dropped.)
-    int slot = 0;
+    // ---- main loop: one barrier per step, in its middle ---------------------------------------------
+    // Patch buffers alternate: step s+1's patch is written to buffer (s+1)&1 in the first half of step
+    // s (its previous content, patch s-1, was last read in the second half of step s-2, and every wave
+    // has passed the barrier of step s-1 since), published by the barrier of step s, read back in the
+    // second half of step s.  In the last step the patch / fragment prefetches re-read the last valid
+    // step (offsets stop advancing) and their results are dropped.
     for (int s = kb; s < ke; ++s) {
-        const int nslot = slot == 2 ? 0 : slot + 1;
-        const float4 *const Bc = smem + slot * BUF_SLOTS + bbase;
-        const float4 *const Bn = smem + nslot * BUF_SLOTS + bbase;
-        const float4 *const An = smem + nslot * BUF_SLOTS + abase;
-        wino_pair<0>(acc, tc, raw, va0, va1, vb0, vb1, bf, Bc, Bn, An, ld);
-        wino_pair<2>(acc, tc, raw, vb0, vb1, va0, va1, bf, Bc, Bn, An, ld);
-        wino_pair<4>(acc, tc, raw, va0, va1, vb0, vb1, bf, Bc, Bn, An, ld);
-        wino_pair<6>(acc, tc, raw, vb0, vb1, va0, va1, bf, Bc, Bn, An, ld);
-        if (s + 1 < ke) SGV3D_WINO_PUBLISH();
-        ld.on = s + 2 < ke;
-        ld.dst = smem + (nslot == 2 ? 0 : nslot + 1) * BUF_SLOTS;
+        const int nb = (s + 1 - kb) & 1;
+        st.a_wr = smem + nb * A_SLOTS + tid;
+        const f32x4 *const An = smem + nb * A_SLOTS + abase;
+        wino_pair<0>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+        wino_pair<2>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+        wino_pair<4>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+        wino_pair<6>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+        SGV3D_WINO_PUBLISH();
+        if (s + 2 < ke) st.x_step += WK * sizeof(float);   // the patch fetched in the second half is step s+2's
         SGV3D_SB();
-        wino_pair<8>(acc, tc, raw, va0, va1, vb0, vb1, bf, Bc, Bn, An, ld);
-        wino_pair<10>(acc, tc, raw, vb0, vb1, va0, va1, bf, Bc, Bn, An, ld);
-        wino_pair<12>(acc, tc, raw, va0, va1, vb0, vb1, bf, Bc, Bn, An, ld);
-        wino_pair<14>(acc, tc, raw, vb0, vb1, va0, va1, bf, Bc, Bn, An, ld);
-        slot = nslot;
+        wino_pair<8>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+        wino_pair<10>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+        wino_pair<12>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+        wino_pair<14>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+        st.w_cur = st.w_next;
+        if (s + 2 < ke) st.w_next += W_STEP * 4;
     }
 
     // ---- output transform + epilogue ---------------------------------------------------------------
-    float *ws = a.split_k > 1 ? a.ws + (size_t)blockIdx.y * a.M * a.N : nullptr;
+    // At one wave per SIMD nothing hides the epilogue, so it is kept to a few instructions per output:
+    // a lane holds ONE output channel (col) of 16 tiles x 2x2 pixels, every channel-only term (scale,
+    // shift, gate, channel part of the address) is hoisted, and the stores are buffer stores whose
+    // address is  [uniform base in the resource]  +  [one of 8 per-lane VGPR offsets: lane's channel, its
+    // wave's tile rows, column 2c+dx -- or out of range, which drops the store, when that column is
+    // outside the image]  +  [scalar offset of tile row / dy].  Same arithmetic as conv_epilogue_store.
     const int col = tn * 64 + wn * 32 + t;
-    if (col >= a.N) return;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int tw = 8 * (e >> 2) + 4 * h + (e & 3);
-        const int ty = wm * 4 + (tw >> 3), tx = tw & 7;
-        const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
-        // rows of A^T M:  r0 = m0 + m1 + m2,  r1 = m1 - m2 - m3   (per Winograd column j)
-        float r0[4], r1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float m0 = acc[j][e], m1 = acc[4 + j][e], m2 = acc[8 + j][e], m3 = acc[12 + j][e];
-            r0[j] = m0 + m1 + m2;
-            r1[j] = m1 - m2 - m3;
+    const bool partial = a.split_k > 1;
+    const long long row0 = ((long long)img * a.out_h + oy0) * a.out_w + ox0;   // first pixel of the block
+    const char *ybase;         // uniform
+    unsigned pixstride;        // bytes between horizontally adjacent output pixels
+    unsigned lane_off;         // this lane's channel
+    float sc = 1.f, sh = 0.f, gt = 1.f, floor_ = -__builtin_inff();
+    if (partial) {
+        ybase = reinterpret_cast<const char *>(a.ws + ((size_t)blockIdx.y * a.M + row0) * a.N + tn * 64);
+        pixstride = a.N * 4u;
+        lane_off = (wn * 32 + t) * 4u;
+    } else {
+        if (col < a.N) {
+            if (a.scale) sc = a.scale[col];
+            if (a.bias) sh = a.bias[col];
+            if (a.gate) gt = a.gate[(size_t)img * a.cout + col];
         }
-        const float y00 = r0[0] + r0[1] + r0[2], y01 = r0[1] - r0[2] - r0[3];
-        const float y10 = r1[0] + r1[1] + r1[2], y11 = r1[1] - r1[2] - r1[3];
-        const float yv[2][2] = {{y00, y01}, {y10, y11}};
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                if (oy + dy < a.out_h && ox + dx < a.out_w) {
-                    const int row = (img * a.out_h + oy + dy) * a.out_w + ox + dx;
-                    if (ws) ws[(size_t)row * a.N + col] = yv[dy][dx];
-                    else conv_epilogue_store(a, row, col, yv[dy][dx]);
-                }
-            }
+        if (a.relu) floor_ = 0.f;
+        if (a.mode == SGV3D_CONV_NORMAL) {
+            ybase = reinterpret_cast<const char *>(a.y + row0 * a.y_ld + a.y_coff + tn * 64);
+            pixstride = a.y_ld * 4u;
+            lane_off = (wn * 32 + t) * 4u;
+        } else if (a.mode == SGV3D_CONV_NCHW_OUT) {
+            const long long hw = (long long)a.out_h * a.out_w;
+            ybase = reinterpret_cast<const char *>(a.y + ((size_t)img * a.y_ld + a.y_coff + tn * 64) * hw +
+                                                   (long long)oy0 * a.out_w + ox0);
+            pixstride = 4u;
+            lane_off = (unsigned)((wn * 32 + t) * hw * 4);
+        } else {  // GROUP_PLANES: [cout/g][M][g], g = a.ks
+            const int grp0 = (tn * 64) / a.ks, grp = col / a.ks;
+            ybase = reinterpret_cast<const char *>(a.y + ((size_t)grp0 * a.M + row0) * a.ks);
+            pixstride = a.ks * 4u;
+            lane_off = (unsigned)((((size_t)(grp - grp0) * a.M) * a.ks + (col - grp * a.ks)) * 4);
+        }
     }
+    const unsigned rowpitch = a.out_w * pixstride;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ybase, 0, (int)0xffffff00u, 0x00020000);
+    const bool has_res = !partial && a.res != nullptr;
+    const unsigned rpix = a.res_ld * 4u, rpitch = a.out_w * rpix;
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_res ? a.res + row0 * a.res_ld + tn * 64 : a.zeros), 0, has_res ? (int)0xffffff00u : 0, 0x00020000);
+    unsigned voff[4][2], roff[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int xx = 8 * h + 2 * c + dx;
+            const bool ok = (col < a.N) & (ox0 + xx < a.out_w);
+            voff[c][dx] = ok ? lane_off + (wm * 8) * rowpitch + xx * pixstride : 0xffffffffu;
+            roff[c][dx] = ok ? (wn * 32 + t) * 4u + (wm * 8) * rpitch + xx * rpix : 0xffffffffu;
+        }
+    const int oy_wave = oy0 + wm * 8;
+    if (partial) wino_store<true, false>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
+    else if (has_res) wino_store<false, true>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
+    else wino_store<false, false>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
 }
 
 // U = G g G^T per (cout, cin), written in the order the kernel streams it:
@@ -342,7 +411,7 @@ __global__ void wino_pack_weight_kernel(const float *__restrict__ src, int cout,
 
 extern "C" size_t sgv3d_conv_winograd_weight_floats(int cout, int cin_pad) {
     if (cout <= 0 || cin_pad <= 0 || cin_pad % WK) return 0;
-    return (size_t)((cout + 63) / 64) * (cin_pad / WK) * (W_SLOTS * 4);
+    return (size_t)((cout + 63) / 64) * (cin_pad / WK) * W_STEP;
 }
 
 extern "C" int sgv3d_conv_winograd_pack_weight(const float *w_src, int cout, int cin, int cin_pad, float *w_packed,
@@ -380,7 +449,10 @@ extern "C" int sgv3d_conv2d_winograd_forward(const sgv3d_conv_desc *d, const flo
     SGV3D_REQUIRE(residual == nullptr || d->res_ld >= d->cout, "conv2d_winograd_forward: res_ld too small");
     const long long M = (long long)d->batch * d->out_h * d->out_w;
     SGV3D_REQUIRE(M < 0x7fffffffLL, "conv2d_winograd_forward: too many output pixels");
-    SGV3D_REQUIRE((long long)d->batch * d->in_h * d->in_w * d->x_ld < (1LL << 40), "conv2d_winograd_forward: input too large");
+    SGV3D_REQUIRE((long long)d->batch * d->in_h * d->in_w * d->x_ld * 4 < 0xf0000000LL,
+                  "conv2d_winograd_forward: input larger than 3.75 GiB (32-bit buffer offsets)");
+    SGV3D_REQUIRE((long long)sgv3d_conv_winograd_weight_floats(d->cout, d->cin) * 4 < 0xf0000000LL,
+                  "conv2d_winograd_forward: packed weights larger than 3.75 GiB");
     ConvArgs a;
     a.x = x; a.w = w_wino; a.scale = scale; a.bias = bias; a.res = residual; a.gate = gate; a.y = y;
     a.zeros = conv_zero_block();
