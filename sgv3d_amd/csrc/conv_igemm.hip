@@ -253,7 +253,65 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
 #undef SGV3D_PHASE
 #undef SGV3D_SB
 
-    // ---- epilogue (expanded by hand: the accumulators must keep compile-time register indices) ----
+    // ---- epilogue ------------------------------------------------------------------------------------
+    // Fast path (row-linear layouts: NHWC output with channel offset, or the split-K partials; whole
+    // m-tile inside M; no SE gate): the small-K layers (ResNet 1x1 convolutions) are bound by the
+    // instructions of this epilogue, so it is a handful per output -- every channel-only term hoisted,
+    // buffer stores addressed as [uniform tile base in the resource] + [per-lane VGPR: channel and the
+    // lane half's 4 rows, or out of range for padded channels] + [scalar: row inside the wave's tile].
+    if ((a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr)) && m0 + BM <= a.M) {
+        const bool partial = a.split_k > 1;
+        const int wmu = __builtin_amdgcn_readfirstlane(wm);
+        const unsigned ld = partial ? (unsigned)a.N : (unsigned)a.y_ld;
+        const long long tile_row = m0 + wmu * (BM / 2);
+        const float *const ybase = partial ? a.ws + ((size_t)blockIdx.y * a.M + tile_row) * a.N
+                                           : a.y + tile_row * a.y_ld + a.y_coff;
+        const __amdgpu_buffer_rsrc_t y_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)ybase, 0, (int)0xffffff00u, 0x00020000);
+        const bool has_res = !partial && a.res != nullptr;
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(has_res ? a.res + tile_row * a.res_ld : a.zeros), 0, has_res ? (int)0xffffff00u : 0, 0x00020000);
+        const float floor_ = (!partial && a.relu) ? 0.f : -__builtin_inff();
+        unsigned voff[WTN], roff[WTN];
+        float sc[WTN], sh[WTN];
+#pragma unroll
+        for (int nt = 0; nt < WTN; ++nt) {
+            const int col = n0 + wn * (BN / 2) + nt * 32 + lr;
+            const bool ok = col < a.N;
+            voff[nt] = ok ? (4u * lh * ld + col) * 4u : 0xffffffffu;
+            roff[nt] = ok ? (4u * lh * (unsigned)a.res_ld + col) * 4u : 0xffffffffu;
+            sc[nt] = (!partial && ok && a.scale) ? a.scale[col] : 1.f;
+            sh[nt] = (!partial && ok && a.bias) ? a.bias[col] : 0.f;
+        }
+#define SGV3D_EPI_F(MT, NT, E)                                                                        \
+    {                                                                                                 \
+        const unsigned r_ = (MT) * 32 + ((E) & 3) + 8 * ((E) >> 2);                                   \
+        float v_ = acc[MT][NT][E];                                                                    \
+        if (!partial) {                                                                               \
+            v_ = v_ * sc[NT] + sh[NT];                                                                \
+            if (has_res)                                                                              \
+                v_ += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, roff[NT], r_ * a.res_ld * 4u, 0)); \
+            v_ = fmaxf(v_, floor_);                                                                   \
+        }                                                                                             \
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v_), y_rsrc, voff[NT], r_ * ld * 4u, 0); \
+    }
+#define SGV3D_EPI_FT(MT, NT)                                                                          \
+    SGV3D_EPI_F(MT, NT, 0) SGV3D_EPI_F(MT, NT, 1) SGV3D_EPI_F(MT, NT, 2) SGV3D_EPI_F(MT, NT, 3)       \
+    SGV3D_EPI_F(MT, NT, 4) SGV3D_EPI_F(MT, NT, 5) SGV3D_EPI_F(MT, NT, 6) SGV3D_EPI_F(MT, NT, 7)       \
+    SGV3D_EPI_F(MT, NT, 8) SGV3D_EPI_F(MT, NT, 9) SGV3D_EPI_F(MT, NT, 10) SGV3D_EPI_F(MT, NT, 11)     \
+    SGV3D_EPI_F(MT, NT, 12) SGV3D_EPI_F(MT, NT, 13) SGV3D_EPI_F(MT, NT, 14) SGV3D_EPI_F(MT, NT, 15)
+        SGV3D_EPI_FT(0, 0)
+        if constexpr (WTN > 1) { SGV3D_EPI_FT(0, 1) }
+        if constexpr (WTM > 1) {
+            SGV3D_EPI_FT(1, 0)
+            if constexpr (WTN > 1) { SGV3D_EPI_FT(1, 1) }
+        }
+#undef SGV3D_EPI_FT
+#undef SGV3D_EPI_F
+        return;
+    }
+    // General path (pixel-shuffle / NCHW / grouped-plane layouts, SE gate, ragged last m-tile); expanded by
+    // hand: the accumulators must keep compile-time register indices.
     float *ws = a.split_k > 1 ? a.ws + (size_t)blockIdx.y * a.M * a.N : nullptr;
     const int row_base = m0 + wm * (BM / 2) + 4 * lh;
     const int col_base = n0 + wn * (BN / 2) + lr;
