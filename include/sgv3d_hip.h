@@ -180,6 +180,10 @@ typedef struct sgv3d_conv_desc {
 #define SGV3D_TILE_128x64 2
 #define SGV3D_TILE_64x128 3
 #define SGV3D_TILE_64x64 4
+/* sgv3d_conv2d_winograd_forward only: desc.tile == SGV3D_WINOGRAD_RESIDENT selects the variant that keeps
+ * the input patch of all channels in LDS and walks over the cout tiles (cin <= 96, split_k <= 1: the
+ * fused CenterHead branch layer); any other value selects the streaming variant. */
+#define SGV3D_WINOGRAD_RESIDENT 6
 
 /* Packed weight geometry for a GEMM with `k` reduction elements and `n` output columns. */
 void sgv3d_conv_pack_geometry(int k, int n, int *k_pad, int *n_pad);
@@ -206,7 +210,7 @@ int sgv3d_conv2d_forward(const sgv3d_conv_desc *desc /*host*/, const float *x, c
  * cin % 8 == 0 (2.25x fewer multiplies; cuDNN, which the reference's nn.Conv2d dispatches to, uses the
  * same algorithm family for these layers).  Same descriptor, epilogue, modes (NORMAL / NCHW_OUT /
  * GROUP_PLANES), workspace and split_k semantics (split over input-channel steps of 8) as
- * sgv3d_conv2d_forward; desc.tile / k_pad / cout_pad / k_order are ignored.  Results agree with the direct
+ * sgv3d_conv2d_forward; desc.k_pad / cout_pad / k_order are ignored, desc.tile selects the variant (below).  Results agree with the direct
  * form to fp32 rounding (different summation order), bit-exact on small-integer data.
  * Weights: sgv3d_conv_winograd_pack_weight transforms an OIHW [cout, cin, 3, 3] tensor (U = G g G^T,
  * computed in double, rounded once) into sgv3d_conv_winograd_weight_floats(cout, cin_pad) floats ordered

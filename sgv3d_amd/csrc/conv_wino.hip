@@ -86,7 +86,7 @@ __device__ __forceinline__ f32x4 wino_buffer_load(__amdgpu_buffer_rsrc_t rsrc, u
 //     T = B^T d of the next step's patch, row by row into tc as soon as the current step's row is dead
 //     (rows 0, 1 in pair 10, row 2 in pair 12, row 3 in pair 14).
 #define SGV3D_WINO_MFMA(P, C, V, BF) acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(V.C, BF.C, acc[P], 0, 0, 0)
-template <int P>
+template <int P, bool RESIDENT = false>
 __device__ __forceinline__ void wino_pair(f32x16 (&acc)[16], f32x4 (&tc)[4][4], f32x4 (&raw)[4][4], f32x4 &vc0,
                                           f32x4 &vc1, f32x4 &vn0, f32x4 &vn1, f32x4 (&wf)[8], WinoStreams &st,
                                           const f32x4 *An) {
@@ -101,18 +101,18 @@ __device__ __forceinline__ void wino_pair(f32x16 (&acc)[16], f32x4 (&tc)[4][4], 
     else wf[L0] = wino_buffer_load(st.w_rsrc, st.w_lane, st.w_next + (P + 6 - 16) * (W_POS * 4));
     if constexpr (P + 7 < 16) wf[L1] = wino_buffer_load(st.w_rsrc, st.w_lane, st.w_cur + (P + 7) * (W_POS * 4));
     else wf[L1] = wino_buffer_load(st.w_rsrc, st.w_lane, st.w_next + (P + 7 - 16) * (W_POS * 4));
-    if constexpr (P == 0 || P == 2 || P == 4) {
+    if constexpr (!RESIDENT && (P == 0 || P == 2 || P == 4)) {
         st.a_wr[(P / 2) * 256] = P == 0 ? st.stage0 : P == 2 ? st.stage1 : st.stage2;   // slot (P/2)*256 + tid
     } else if constexpr (P == 8) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) raw[i][j] = An[i * (2 * A_HALF) + (j & 1) * A_HALF + (j >> 1)];
-    } else if constexpr (P == 10) {
+    } else if constexpr (!RESIDENT && P == 10) {
         st.stage0 = wino_buffer_load(st.x_rsrc, st.x0, st.x_step);
-    } else if constexpr (P == 12) {
+    } else if constexpr (!RESIDENT && P == 12) {
         st.stage1 = wino_buffer_load(st.x_rsrc, st.x1, st.x_step);
-    } else if constexpr (P == 14) {
+    } else if constexpr (!RESIDENT && P == 14) {
         st.stage2 = wino_buffer_load(st.x_rsrc, st.x2, st.x_step);
     }
     SGV3D_SB();
@@ -191,6 +191,79 @@ __device__ __forceinline__ void wino_store(f32x16 (&acc)[16], __amdgpu_buffer_rs
             }
         }
     }
+}
+
+// Epilogue of one (block, cout tile): output transform, folded BN / bias, residual, ReLU, SE gate, store.
+// At one wave per SIMD nothing hides it, so it is kept to a few instructions per output: a lane holds ONE
+// output channel (col) of 16 tiles x 2x2 pixels, every channel-only term (scale, shift, gate, channel
+// part of the address) is hoisted, and the stores are buffer stores whose address is
+//   [uniform base in the resource] + [one of 8 per-lane VGPR offsets: lane's channel, its wave's tile
+//   rows, column 2c+dx -- or out of range, which drops the store, when that column is outside the image]
+//   + [scalar offset of tile row / dy].
+// Same arithmetic as conv_epilogue_store (conv_common.hpp).
+__device__ __forceinline__ void wino_epilogue(const ConvArgs &a, f32x16 (&acc)[16], int tn, int img, int oy0, int ox0,
+                                              int wm, int wn, int h, int t) {
+    // At one wave per SIMD nothing hides the epilogue, so it is kept to a few instructions per output:
+    // a lane holds ONE output channel (col) of 16 tiles x 2x2 pixels, every channel-only term (scale,
+    // shift, gate, channel part of the address) is hoisted, and the stores are buffer stores whose
+    // address is  [uniform base in the resource]  +  [one of 8 per-lane VGPR offsets: lane's channel, its
+    // wave's tile rows, column 2c+dx -- or out of range, which drops the store, when that column is
+    // outside the image]  +  [scalar offset of tile row / dy].  Same arithmetic as conv_epilogue_store.
+    const int col = tn * 64 + wn * 32 + t;
+    const bool partial = a.split_k > 1;
+    const long long row0 = ((long long)img * a.out_h + oy0) * a.out_w + ox0;   // first pixel of the block
+    const char *ybase;         // uniform
+    unsigned pixstride;        // bytes between horizontally adjacent output pixels
+    unsigned lane_off;         // this lane's channel
+    float sc = 1.f, sh = 0.f, gt = 1.f, floor_ = -__builtin_inff();
+    if (partial) {
+        ybase = reinterpret_cast<const char *>(a.ws + ((size_t)blockIdx.y * a.M + row0) * a.N + tn * 64);
+        pixstride = a.N * 4u;
+        lane_off = (wn * 32 + t) * 4u;
+    } else {
+        if (col < a.N) {
+            if (a.scale) sc = a.scale[col];
+            if (a.bias) sh = a.bias[col];
+            if (a.gate) gt = a.gate[(size_t)img * a.cout + col];
+        }
+        if (a.relu) floor_ = 0.f;
+        if (a.mode == SGV3D_CONV_NORMAL) {
+            ybase = reinterpret_cast<const char *>(a.y + row0 * a.y_ld + a.y_coff + tn * 64);
+            pixstride = a.y_ld * 4u;
+            lane_off = (wn * 32 + t) * 4u;
+        } else if (a.mode == SGV3D_CONV_NCHW_OUT) {
+            const long long hw = (long long)a.out_h * a.out_w;
+            ybase = reinterpret_cast<const char *>(a.y + ((size_t)img * a.y_ld + a.y_coff + tn * 64) * hw +
+                                                   (long long)oy0 * a.out_w + ox0);
+            pixstride = 4u;
+            lane_off = (unsigned)((wn * 32 + t) * hw * 4);
+        } else {  // GROUP_PLANES: [cout/g][M][g], g = a.ks
+            const int grp0 = (tn * 64) / a.ks, grp = col / a.ks;
+            ybase = reinterpret_cast<const char *>(a.y + ((size_t)grp0 * a.M + row0) * a.ks);
+            pixstride = a.ks * 4u;
+            lane_off = (unsigned)((((size_t)(grp - grp0) * a.M) * a.ks + (col - grp * a.ks)) * 4);
+        }
+    }
+    const unsigned rowpitch = a.out_w * pixstride;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ybase, 0, (int)0xffffff00u, 0x00020000);
+    const bool has_res = !partial && a.res != nullptr;
+    const unsigned rpix = a.res_ld * 4u, rpitch = a.out_w * rpix;
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_res ? a.res + row0 * a.res_ld + tn * 64 : a.zeros), 0, has_res ? (int)0xffffff00u : 0, 0x00020000);
+    unsigned voff[4][2], roff[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int xx = 8 * h + 2 * c + dx;
+            const bool ok = (col < a.N) & (ox0 + xx < a.out_w);
+            voff[c][dx] = ok ? lane_off + (wm * 8) * rowpitch + xx * pixstride : 0xffffffffu;
+            roff[c][dx] = ok ? (wn * 32 + t) * 4u + (wm * 8) * rpitch + xx * rpix : 0xffffffffu;
+        }
+    const int oy_wave = oy0 + wm * 8;
+    if (partial) wino_store<true, false>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
+    else if (has_res) wino_store<false, true>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
+    else wino_store<false, false>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
 }
 
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
@@ -316,68 +389,104 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
         if (s + 2 < ke) st.w_next += W_STEP * 4;
     }
 
-    // ---- output transform + epilogue ---------------------------------------------------------------
-    // At one wave per SIMD nothing hides the epilogue, so it is kept to a few instructions per output:
-    // a lane holds ONE output channel (col) of 16 tiles x 2x2 pixels, every channel-only term (scale,
-    // shift, gate, channel part of the address) is hoisted, and the stores are buffer stores whose
-    // address is  [uniform base in the resource]  +  [one of 8 per-lane VGPR offsets: lane's channel, its
-    // wave's tile rows, column 2c+dx -- or out of range, which drops the store, when that column is
-    // outside the image]  +  [scalar offset of tile row / dy].  Same arithmetic as conv_epilogue_store.
-    const int col = tn * 64 + wn * 32 + t;
-    const bool partial = a.split_k > 1;
-    const long long row0 = ((long long)img * a.out_h + oy0) * a.out_w + ox0;   // first pixel of the block
-    const char *ybase;         // uniform
-    unsigned pixstride;        // bytes between horizontally adjacent output pixels
-    unsigned lane_off;         // this lane's channel
-    float sc = 1.f, sh = 0.f, gt = 1.f, floor_ = -__builtin_inff();
-    if (partial) {
-        ybase = reinterpret_cast<const char *>(a.ws + ((size_t)blockIdx.y * a.M + row0) * a.N + tn * 64);
-        pixstride = a.N * 4u;
-        lane_off = (wn * 32 + t) * 4u;
-    } else {
-        if (col < a.N) {
-            if (a.scale) sc = a.scale[col];
-            if (a.bias) sh = a.bias[col];
-            if (a.gate) gt = a.gate[(size_t)img * a.cout + col];
-        }
-        if (a.relu) floor_ = 0.f;
-        if (a.mode == SGV3D_CONV_NORMAL) {
-            ybase = reinterpret_cast<const char *>(a.y + row0 * a.y_ld + a.y_coff + tn * 64);
-            pixstride = a.y_ld * 4u;
-            lane_off = (wn * 32 + t) * 4u;
-        } else if (a.mode == SGV3D_CONV_NCHW_OUT) {
-            const long long hw = (long long)a.out_h * a.out_w;
-            ybase = reinterpret_cast<const char *>(a.y + ((size_t)img * a.y_ld + a.y_coff + tn * 64) * hw +
-                                                   (long long)oy0 * a.out_w + ox0);
-            pixstride = 4u;
-            lane_off = (unsigned)((wn * 32 + t) * hw * 4);
-        } else {  // GROUP_PLANES: [cout/g][M][g], g = a.ks
-            const int grp0 = (tn * 64) / a.ks, grp = col / a.ks;
-            ybase = reinterpret_cast<const char *>(a.y + ((size_t)grp0 * a.M + row0) * a.ks);
-            pixstride = a.ks * 4u;
-            lane_off = (unsigned)((((size_t)(grp - grp0) * a.M) * a.ks + (col - grp * a.ks)) * 4);
-        }
+    wino_epilogue(a, acc, tn, img, oy0, ox0, wm, wn, h, t);
+}
+
+// Patch-resident variant for layers with few input channels and many output channels (the fused first
+// layer of the 36 CenterHead branches: 64 -> 2304 at 256x256): a workgroup keeps the raw patch of ALL
+// k-steps of its 16x16 block in LDS (18x18 x cin floats, 83 KB at cin = 64) and walks over a range of
+// cout tiles.  Per cout tile there is no patch traffic and no barrier at all; the weight-fragment ring
+// keeps prefetching across cout-tile boundaries (the packed weights of consecutive (tile, step) pairs are
+// contiguous), so the only per-tile cost besides the MFMAs is the epilogue.  All workgroups walk the cout
+// tiles in the same order, so the weight panel of the moment is shared through L2.
+__global__ __launch_bounds__(256, 1) void conv_wino_resident_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    const int ngroups = gridDim.x / a.tiles_m;
+    const int tm = blockIdx.x % a.tiles_m, grp = blockIdx.x / a.tiles_m;
+    const int tn_begin = (int)((long long)a.tiles_n * grp / ngroups);
+    const int tn_end = (int)((long long)a.tiles_n * (grp + 1) / ngroups);
+    const int bpi = a.wb_y * a.wb_x;
+    const int img = tm / bpi;
+    const int rb = tm - img * bpi;
+    const int by = rb / a.wb_x, bx = rb - by * a.wb_x;
+    const int oy0 = by * 16, ox0 = bx * 16;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, t = lane & 31;
+    const int nsteps = a.cin / WK;
+
+    WinoStreams st;
+    const unsigned x_bytes = (unsigned)((size_t)a.M * a.x_ld * sizeof(float));
+    st.x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)x_bytes, 0x00020000);
+    // ---- the whole patch, once ----------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int s = i * 256 + tid;
+        const int hh = s / A_PLANE, rem = s - hh * A_PLANE;
+        const int row = rem / (2 * A_HALF), r2 = rem - row * (2 * A_HALF);
+        const int par = r2 / A_HALF, ch = r2 - par * A_HALF;
+        const int iy = oy0 - 1 + row, ix = ox0 - 1 + 2 * ch + par;
+        const bool ok = (s < A_USED) & (ch < 9) & (iy >= 0) & (iy < a.in_h) & (ix >= 0) & (ix < a.in_w);
+        const unsigned xo = ok ? (unsigned)((((size_t)(img * a.in_h + iy) * a.in_w + ix) * a.x_ld + a.x_coff + hh * 4) * sizeof(float))
+                               : 0xfffffff0u - (unsigned)(a.cin * sizeof(float));
+        for (int ks = 0; ks < nsteps; ++ks)
+            smem[ks * A_SLOTS + s] = wino_buffer_load(st.x_rsrc, xo, (unsigned)(ks * WK * sizeof(float)));
     }
-    const unsigned rowpitch = a.out_w * pixstride;
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ybase, 0, (int)0xffffff00u, 0x00020000);
-    const bool has_res = !partial && a.res != nullptr;
-    const unsigned rpix = a.res_ld * 4u, rpitch = a.out_w * rpix;
-    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(has_res ? a.res + row0 * a.res_ld + tn * 64 : a.zeros), 0, has_res ? (int)0xffffff00u : 0, 0x00020000);
-    unsigned voff[4][2], roff[4][2];
+    const unsigned w_bytes = (unsigned)((size_t)a.tiles_n * nsteps * W_STEP * sizeof(float));
+    st.w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)w_bytes, 0x00020000);
+    st.w_cur = (unsigned)((size_t)tn_begin * nsteps * W_STEP * sizeof(float));
+    st.w_next = st.w_cur + W_STEP * 4;       // reads past the last tile are out of range and return 0
+    st.w_lane = (unsigned)(h * 64 + wn * 32 + t) * 16u;
+    st.x0 = st.x1 = st.x2 = st.x_step = 0;
+    st.a_wr = smem;
+
+    const int abase = (h * A_ROWS + 2 * (wm * 4 + (t >> 3))) * (2 * A_HALF) + (t & 7);
+    f32x4 tc[4][4], raw[4][4], wf[8], va0, va1, vb0, vb1;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int p = 0; p < 6; ++p) wf[p] = wino_buffer_load(st.w_rsrc, st.w_lane, st.w_cur + p * (W_POS * 4));
+    __syncthreads();
+    {
+        const f32x4 *const A = smem + abase;
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            const int xx = 8 * h + 2 * c + dx;
-            const bool ok = (col < a.N) & (ox0 + xx < a.out_w);
-            voff[c][dx] = ok ? lane_off + (wm * 8) * rowpitch + xx * pixstride : 0xffffffffu;
-            roff[c][dx] = ok ? (wn * 32 + t) * 4u + (wm * 8) * rpitch + xx * rpix : 0xffffffffu;
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) raw[i][j] = A[i * (2 * A_HALF) + (j & 1) * A_HALF + (j >> 1)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tc[0][j] = wino_bt<0>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
+            tc[1][j] = wino_bt<1>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
+            tc[2][j] = wino_bt<2>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
+            tc[3][j] = wino_bt<3>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
         }
-    const int oy_wave = oy0 + wm * 8;
-    if (partial) wino_store<true, false>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
-    else if (has_res) wino_store<false, true>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
-    else wino_store<false, false>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
+        va0 = wino_bt<0>(tc[0][0], tc[0][1], tc[0][2], tc[0][3]);
+        va1 = wino_bt<1>(tc[0][0], tc[0][1], tc[0][2], tc[0][3]);
+    }
+
+    for (int tn = tn_begin; tn < tn_end; ++tn) {
+        f32x16 acc[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+        for (int s = 0; s < nsteps; ++s) {
+            // the second half of the step reads the patch of the next step (step 0 again after the last)
+            const f32x4 *const An = smem + (s + 1 < nsteps ? s + 1 : 0) * A_SLOTS + abase;
+            wino_pair<0, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<2, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            wino_pair<4, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<6, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            wino_pair<8, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<10, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            wino_pair<12, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<14, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            st.w_cur = st.w_next;
+            st.w_next += W_STEP * 4;
+        }
+        wino_epilogue(a, acc, tn, img, oy0, ox0, wm, wn, h, t);
+    }
 }
 
 // U = G g G^T per (cout, cin), written in the order the kernel streams it:
@@ -477,6 +586,26 @@ extern "C" int sgv3d_conv2d_winograd_forward(const sgv3d_conv_desc *d, const flo
         if (!workspace || workspace_bytes < need)
             return fail(SGV3D_ENOSPACE, "conv2d_winograd_forward: split-K workspace has %zu bytes, needs %zu", workspace_bytes, need);
     }
+    hipStream_t st = as_stream(stream);
+    if (d->tile == SGV3D_WINOGRAD_RESIDENT) {
+        // whole patch in LDS: cin/8 steps x 12 KB
+        const int lds = (d->cin / WK) * A_SLOTS * 16;
+        SGV3D_REQUIRE(lds <= 160 * 1024 - 4096, "conv2d_winograd_forward: patch-resident variant needs cin <= 96 (got %d)", d->cin);
+        SGV3D_REQUIRE(a.split_k == 1, "conv2d_winograd_forward: patch-resident variant has no split-K");
+        static int lds_set = 0;
+        if (lds > lds_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_resident_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                return fail(SGV3D_ELAUNCH, "conv2d_winograd_forward: cannot raise the dynamic LDS limit to %d", lds);
+            lds_set = lds;
+        }
+        // cout tiles are dealt to `groups` workgroups per block so that the grid is about one wave of CUs
+        int groups = 256 / a.tiles_m;
+        if (groups < 1) groups = 1;
+        if (groups > a.tiles_n) groups = a.tiles_n;
+        hipLaunchKernelGGL(conv_wino_resident_kernel, dim3(a.tiles_m * groups), dim3(256), lds, st, a);
+        return check_launch("conv_wino_resident_kernel");
+    }
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -484,7 +613,6 @@ extern "C" int sgv3d_conv2d_winograd_forward(const sgv3d_conv_desc *d, const flo
             return fail(SGV3D_ELAUNCH, "conv2d_winograd_forward: cannot raise the dynamic LDS limit to %d", kWinoLds);
         attr_set = true;
     }
-    hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(conv_wino_kernel, dim3(a.tiles_m * a.tiles_n, a.split_k), dim3(256), kWinoLds, st, a);
     if (a.split_k > 1) return launch_splitk_reduce(a, st);
     return check_launch("conv_wino_kernel");

@@ -58,8 +58,9 @@ def save_tune_db(path=None):
 
 
 load_tune_db()
-TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino"}
-TILE_WINO = 5   # host-side algorithm id: sgv3d_conv2d_winograd_forward instead of the implicit GEMM
+TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: "wino_resident"}
+TILE_WINO = 5       # host-side algorithm id: sgv3d_conv2d_winograd_forward instead of the implicit GEMM
+TILE_WINO_RES = 6   # = SGV3D_WINOGRAD_RESIDENT: its patch-resident variant (cin <= 96, many cout tiles)
 
 
 class prof:
@@ -253,7 +254,7 @@ class PackedConv:
             t, sk = choice
         d.tile, d.split_k = t, sk
         flops = 2.0 * gemm_m * gemm_n * (self.cin * self.kh * self.kw)
-        name = ("conv_" if t == TILE_WINO else "conv_igemm_") + TILE_NAMES[t]
+        name = ("conv_" if t >= TILE_WINO else "conv_igemm_") + TILE_NAMES[t]
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
                      f"s{self.stride} d{self.dil} splitk{sk}")
@@ -267,7 +268,7 @@ class PackedConv:
         if d.split_k > 1:
             nws = lib.sgv3d_conv2d_workspace_bytes(ctypes.byref(d))
             ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
-        if d.tile == TILE_WINO:
+        if d.tile in (TILE_WINO, TILE_WINO_RES):
             if self.w_wino is None:
                 raise _lib.SGV3DError("this layer has no Winograd weights (needs 3x3 / stride 1 / pad 1 / cin % 8 == 0)")
             return lib.sgv3d_conv2d_winograd_forward(ctypes.byref(d), x.data_ptr(), self.w_wino.data_ptr(),
@@ -281,8 +282,14 @@ class PackedConv:
         """Time the candidate (tile, split-K) pairs on the real buffers and keep the fastest.  Results do
         not depend on the tile shape (every output element sums k in the same order); split-K changes
         the association of the k sum (partials added in fixed order), still deterministic."""
-        tiles = (fixed_tile,) if fixed_tile else ((1, 2, 3, 4, 5) if self.w_wino is not None and WINOGRAD else (1, 2, 3, 4))
-        dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 64)}
+        tiles = (1, 2, 3, 4)
+        if self.w_wino is not None and WINOGRAD:
+            tiles += (TILE_WINO,)
+            if self.cin <= 96 and self.cout >= 128:
+                tiles += (TILE_WINO_RES,)
+        if fixed_tile:
+            tiles = (fixed_tile,)
+        dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 64), 6: (256, 64)}
         best, best_t = (tiles[0], fixed_split or 1), None
         with torch.cuda.device(x.device):
             for t in tiles:
@@ -292,7 +299,9 @@ class PackedConv:
                 if t == TILE_WINO:
                     nk = self.cin // 4      # k-steps of 8 channels; nk // s >= 8 keeps >= 4 steps per split
                     wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 16) * -(-gemm_n // 64)
-                if fixed_split:
+                if t == TILE_WINO_RES:
+                    splits = (1,)
+                elif fixed_split:
                     splits = (fixed_split,)
                 elif not SPLIT_K:
                     splits = (1,)

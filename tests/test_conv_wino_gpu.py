@@ -117,3 +117,32 @@ def test_winograd_deterministic():
     a = conv(xc, tile=TILE_WINO, split_k=3).clone()
     for _ in range(5):
         assert torch.equal(a, conv(xc, tile=TILE_WINO, split_k=3))
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 40, 56, 256), (2, 32, 17, 33, 200), (1, 96, 16, 16, 128), (1, 8, 70, 20, 64)])
+def test_winograd_patch_resident_variant(shape):
+    """cin <= 96: the whole patch stays in LDS and one workgroup walks over the cout tiles."""
+    from sgv3d_amd.hip_ops import PackedConv, TILE_WINO, TILE_WINO_RES
+    B, cin, H, W, cout = shape
+    x, w = _mk(B, cin, H, W, cout, seed=11)
+    g = torch.Generator().manual_seed(12)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    conv = PackedConv(w.cuda(), pad=1, scale=scale.cuda(), shift=shift.cuda(), relu=True)
+    xc = x.cuda()
+    y = conv(xc, tile=TILE_WINO_RES, split_k=1)
+    ref = _ref(x, w, scale, shift, relu=True)
+    assert (y.cpu().double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    assert torch.equal(y, conv(xc, tile=TILE_WINO, split_k=1))        # same arithmetic, same order
+    if cout % 64 == 0:
+        a = conv(xc, group_planes=64, tile=TILE_WINO_RES, split_k=1)
+        b = conv(xc, group_planes=64, tile=TILE_WINO, split_k=1)
+        assert torch.equal(a, b)
+
+
+def test_winograd_patch_resident_rejects_wide_inputs():
+    from sgv3d_amd import _lib
+    from sgv3d_amd.hip_ops import PackedConv, TILE_WINO_RES
+    x, w = _mk(1, 128, 16, 16, 128)
+    conv = PackedConv(w.cuda(), pad=1)
+    with pytest.raises(_lib.SGV3DError):
+        conv(x.cuda(), tile=TILE_WINO_RES, split_k=1)
