@@ -18,6 +18,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- 
 # 3. HBM traffic counters, separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/pmc_write.err
+# 3b. MFMA utilisation counters (own pass; SQ counters fit one pass)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_mfma -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --streams 1 > /dev/null 2> $OUT/pmc_mfma.err
 # 4. voxel pooling micro-benchmark (the HBM-bound headline kernel) + its trace and traffic
 python3 $R/tools/microbench.py --what vp,lift --out $OUT/${TAG}_voxel_pooling_microbench.json > $OUT/microbench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_vp -- python3 $R/tools/vp_probe.py > /dev/null 2> $OUT/vp.err

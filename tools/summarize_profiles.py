@@ -52,6 +52,38 @@ for prefix, key in ((f"{tag}_pmc", "bench"), (f"{tag}_vp_pmc", "vp_probe")):
                   "raw_FETCH_SIZE_KB": f_kb, "raw_WRITE_SIZE_KB": w_kb}
     traffic[key] = out
 json.dump(traffic, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+
+# MFMA utilisation per kernel (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... of `bench.py --streams 1`):
+#   MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs)   (busy cycles of the matrix
+#   pipes over the kernel's own cycles; rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs)
+#   executed TFLOP/s = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 / kernel duration; clock = GRBM_GUI_ACTIVE/8/duration
+mfma_csv = os.path.join(src, f"{tag}_pmc_mfma_counter_collection.csv")
+if os.path.exists(mfma_csv):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    seen = collections.defaultdict(set)
+    for r in csv.DictReader(open(mfma_csv)):
+        k = short(r["Kernel_Name"])
+        if not k.startswith("conv_"):
+            continue
+        per[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in seen[k]:
+            seen[k].add(r["Dispatch_Id"])
+            per[k]["_ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    out = {}
+    for k, c in per.items():
+        if not c.get("GRBM_GUI_ACTIVE") or not c["_ns"]:
+            continue
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+        out[k] = {"launches": len(seen[k]), "time_ms": c["_ns"] / 1e6,
+                  "mfma_util": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cyc * 1024),
+                  "executed_tflops": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512 / (c["_ns"] * 1e-9) / 1e12,
+                  "clock_ghz": cyc / c["_ns"],
+                  "executed_frac_of_157.3": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512 / (c["_ns"] * 1e-9) / 1e12 / 157.3}
+    json.dump(out, open(os.path.join(dst, f"{tag}_mfma_util.json"), "w"), indent=1)
+    print("wrote", os.path.join(dst, f"{tag}_mfma_util.json"))
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["time_ms"]):
+        print(f"mfma      {k[:50]:50s} util {v['mfma_util'] * 100:5.1f} %  {v['executed_tflops']:6.1f} TF executed  "
+              f"clock {v['clock_ghz']:.2f} GHz  ({v['time_ms']:.2f} ms over {v['launches']} launches)")
 print("wrote", os.path.join(dst, f"{tag}_hbm_traffic.json"))
 for key in traffic:
     for k, v in sorted(traffic[key].items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
