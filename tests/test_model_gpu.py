@@ -214,3 +214,36 @@ def test_frame_pipeline_matches_direct_forward(small):
         torch.testing.assert_close(r0[k], want[k], rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(r1[k], want2[k], rtol=1e-5, atol=1e-5)
     assert s0 != s1
+
+
+# the harness passes other geometries than cfg-2 -- rope3d's 180 height bins over
+# [-2, 3.5], the 140.8 m range (352 cells), the 128-cell grids with 0.8 m voxels, a wider d_bound.
+# Reduced image / grid sizes, same code paths; voxel indices must stay bit-exact, maps within 1e-3.
+@pytest.mark.parametrize("name,over", [
+    ("rope3d_180bins", dict(d_bound=[-2.0, 3.5, 30], x_bound=[0, 25.6, 0.4], y_bound=[-12.8, 12.8, 0.4])),
+    ("rope3d_140.8m", dict(d_bound=[-0.5, 2.5, 12], x_bound=[0, 35.2, 0.4], y_bound=[-12.8, 12.8, 0.4])),
+    ("grid128_0.8m", dict(d_bound=[-2.0, 0.0, 12], x_bound=[0, 51.2, 0.8], y_bound=[-25.6, 25.6, 0.8])),
+    ("odd_image", dict(final=(96, 160), d_bound=[-2.0, 0.0, 10], x_bound=[0, 19.2, 0.4], y_bound=[-9.6, 9.6, 0.4])),
+])
+def test_config_matrix_matches_oracle(name, over):
+    bc, hc = S.small_conf(depth=18)
+    over = dict(over)
+    if "final" in over:
+        bc["final_dim"] = over.pop("final")
+    bc.update(over)
+    m = _build(bc, hc, seed=5)
+    imgs = S.make_images(1, bc["final_dim"], seed=6)
+    mats = S.make_mats(1, scale=bc["final_dim"][0] / 864)
+    keep = {}
+    ref = TM.bevheight_forward(m.state_dict(), bc, hc, imgs, mats, keep)
+    m = m.to(DEV)
+    dm = _to_dev(mats)
+    geom = m.backbone.get_geometry_voxel_index(dm['sensor2ego_mats'][:, 0], dm['sensor2virtual_mats'][:, 0],
+                                               dm['intrin_mats'][:, 0], dm['ida_mats'][:, 0],
+                                               dm['reference_heights'][:, 0], dm['bda_mat'])
+    assert np.array_equal(geom.cpu().numpy(), keep['geom_xyz']), name
+    with torch.no_grad():
+        out = m(imgs.to(DEV), dm)
+    for task_out, task_ref in zip(out, ref):
+        for k, v in task_ref[0].items():
+            torch.testing.assert_close(task_out[0][k].cpu(), v, **TOL)
