@@ -32,9 +32,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WK = 8;                           // input channels per k-step
-constexpr int A_ROWS = 18, A_HALF = 10;         // patch rows; 16-B slots per (row, column parity), 9 used
-constexpr int A_PLANE = A_ROWS * 2 * A_HALF;    // 360 slots per 4-channel plane
-constexpr int A_USED = 2 * A_PLANE;             // 720
+// Shape of the 64 tiles of a workgroup: TR x TC tiles (8 x 8 = 16x16 output pixels, or 4 x 16 = 8x32 pixels
+// for feature maps like 54x96 whose height is far from a multiple of 16).  Patch = (2TR+2) x (2TC+2) pixels,
+// stored [channel half][row][column parity][column / 2 (TC+1 used, padded to HALF)]; HALF makes the 16
+// lanes of a ds_read_b128 group (8 tiles x 2 tile rows, or 16 tiles of one row) hit 16 distinct 16-B slots.
+template <int TC>
+struct WinoGeom {
+    static constexpr int TR = 64 / TC;
+    static constexpr int RW = 32 / TC;                 // tile rows per wave
+    static constexpr int ROWS = 2 * TR + 2;            // 18 | 10
+    static constexpr int HALF = TC == 8 ? 10 : 18;     // 9 | 17 used
+    static constexpr int PLANE = ROWS * 2 * HALF;      // 360 slots per 4-channel plane (both shapes)
+    static constexpr int USED = 2 * PLANE;             // 720
+    static_assert(PLANE == 360, "the patch must fit 3 slots per thread");
+};
 constexpr int A_SLOTS = 768;                    // 3 slots per thread
 constexpr int W_STEP = 16 * 2 * 64 * 4;         // floats of one k-step of one 64-channel tile (32 KB)
 constexpr int W_POS = 2 * 64 * 4;               // floats per Winograd position inside a step
@@ -86,7 +97,7 @@ __device__ __forceinline__ f32x4 wino_buffer_load(__amdgpu_buffer_rsrc_t rsrc, u
 //     T = B^T d of the next step's patch, row by row into tc as soon as the current step's row is dead
 //     (rows 0, 1 in pair 10, row 2 in pair 12, row 3 in pair 14).
 #define SGV3D_WINO_MFMA(P, C, V, BF) acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(V.C, BF.C, acc[P], 0, 0, 0)
-template <int P, bool RESIDENT = false>
+template <int P, int TC, bool RESIDENT = false>
 __device__ __forceinline__ void wino_pair(f32x16 (&acc)[16], f32x4 (&tc)[4][4], f32x4 (&raw)[4][4], f32x4 &vc0,
                                           f32x4 &vc1, f32x4 &vn0, f32x4 &vn1, f32x4 (&wf)[8], WinoStreams &st,
                                           const f32x4 *An) {
@@ -107,7 +118,8 @@ __device__ __forceinline__ void wino_pair(f32x16 (&acc)[16], f32x4 (&tc)[4][4], 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) raw[i][j] = An[i * (2 * A_HALF) + (j & 1) * A_HALF + (j >> 1)];
+            for (int j = 0; j < 4; ++j)
+                raw[i][j] = An[i * (2 * WinoGeom<TC>::HALF) + (j & 1) * WinoGeom<TC>::HALF + (j >> 1)];
     } else if constexpr (!RESIDENT && P == 10) {
         st.stage0 = wino_buffer_load(st.x_rsrc, st.x0, st.x_step);
     } else if constexpr (!RESIDENT && P == 12) {
@@ -156,14 +168,14 @@ __device__ __forceinline__ void wino_pair(f32x16 (&acc)[16], f32x4 (&tc)[4][4], 
 
 // Output transform Y = A^T M A of the 16 tiles a lane holds (one output channel each) and their stores;
 // see the epilogue comment in the kernel for the addressing.  PARTIAL: raw split-K partials.
-template <bool PARTIAL, bool HAS_RES>
+template <int TC, bool PARTIAL, bool HAS_RES>
 __device__ __forceinline__ void wino_store(f32x16 (&acc)[16], __amdgpu_buffer_rsrc_t y_rsrc, __amdgpu_buffer_rsrc_t r_rsrc,
-                                           const unsigned (&voff)[4][2], const unsigned (&roff)[4][2], unsigned rowpitch,
+                                           const unsigned (&voff)[TC / 2][2], const unsigned (&roff)[TC / 2][2], unsigned rowpitch,
                                            unsigned rpitch, int oy_wave, int out_h, float sc, float sh, float gt,
                                            float floor_) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        // tile (ty, tx) of accumulator element e:  ty = wm*4 + (e >> 2),  tx = 4h + (e & 3)
+        // accumulator element e is tile tw = 8*(e>>2) + 4h + (e&3) of the wave: row tw / TC, column tw % TC
         float r0[4], r1[4];   // rows of A^T M:  r0 = m0 + m1 + m2,  r1 = m1 - m2 - m3   (per Winograd column j)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -175,7 +187,8 @@ __device__ __forceinline__ void wino_store(f32x16 (&acc)[16], __amdgpu_buffer_rs
                                 {r1[0] + r1[1] + r1[2], r1[1] - r1[2] - r1[3]}};
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
-            const int yy = 2 * (e >> 2) + dy;
+            const int yy = 2 * ((8 * (e >> 2)) / TC) + dy;
+            const int xi = ((e >> 2) % (TC / 8)) * 4 + (e & 3);
             if (oy_wave + yy < out_h) {   // wave-uniform
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
@@ -183,10 +196,10 @@ __device__ __forceinline__ void wino_store(f32x16 (&acc)[16], __amdgpu_buffer_rs
                     if constexpr (!PARTIAL) {
                         v = v * sc + sh;
                         if constexpr (HAS_RES)
-                            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, roff[e & 3][dx], yy * rpitch, 0));
+                            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, roff[xi][dx], yy * rpitch, 0));
                         v = fmaxf(v, floor_) * gt;
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, voff[e & 3][dx], yy * rowpitch, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, voff[xi][dx], yy * rowpitch, 0);
                 }
             }
         }
@@ -201,6 +214,7 @@ __device__ __forceinline__ void wino_store(f32x16 (&acc)[16], __amdgpu_buffer_rs
 //   rows, column 2c+dx -- or out of range, which drops the store, when that column is outside the image]
 //   + [scalar offset of tile row / dy].
 // Same arithmetic as conv_epilogue_store (conv_common.hpp).
+template <int TC>
 __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, f32x16 (&acc)[16], int tn, int img, int oy0, int ox0,
                                               int wm, int wn, int h, int t) {
     // At one wave per SIMD nothing hides the epilogue, so it is kept to a few instructions per output:
@@ -250,23 +264,26 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, f32x16 (&acc)[1
     const unsigned rpix = a.res_ld * 4u, rpitch = a.out_w * rpix;
     const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(has_res ? a.res + row0 * a.res_ld + tn * 64 : a.zeros), 0, has_res ? (int)0xffffff00u : 0, 0x00020000);
-    unsigned voff[4][2], roff[4][2];
+    constexpr int RW2 = 2 * WinoGeom<TC>::RW;      // output rows per wave
+    unsigned voff[TC / 2][2], roff[TC / 2][2];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < TC / 2; ++c)
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-            const int xx = 8 * h + 2 * c + dx;
+            const int xx = 8 * h + 2 * ((c >> 2) * 8 + (c & 3)) + dx;   // column of tile 8*(c>>2) + 4h + (c&3)
             const bool ok = (col < a.N) & (ox0 + xx < a.out_w);
-            voff[c][dx] = ok ? lane_off + (wm * 8) * rowpitch + xx * pixstride : 0xffffffffu;
-            roff[c][dx] = ok ? (wn * 32 + t) * 4u + (wm * 8) * rpitch + xx * rpix : 0xffffffffu;
+            voff[c][dx] = ok ? lane_off + (wm * RW2) * rowpitch + xx * pixstride : 0xffffffffu;
+            roff[c][dx] = ok ? (wn * 32 + t) * 4u + (wm * RW2) * rpitch + xx * rpix : 0xffffffffu;
         }
-    const int oy_wave = oy0 + wm * 8;
-    if (partial) wino_store<true, false>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
-    else if (has_res) wino_store<false, true>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
-    else wino_store<false, false>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
+    const int oy_wave = oy0 + wm * RW2;
+    if (partial) wino_store<TC, true, false>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
+    else if (has_res) wino_store<TC, false, true>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
+    else wino_store<TC, false, false>(acc, y_rsrc, r_rsrc, voff, roff, rowpitch, rpitch, oy_wave, a.out_h, sc, sh, gt, floor_);
 }
 
+template <int TC>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
+    using G = WinoGeom<TC>;
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
 
     // ---- XCD-aware tile mapping (same bijection as the implicit-GEMM kernel) ----------------------
@@ -281,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     const int img = tm / bpi;
     const int rb = tm - img * bpi;
     const int by = rb / a.wb_x, bx = rb - by * a.wb_x;
-    const int oy0 = by * 16, ox0 = bx * 16;
+    const int oy0 = by * (2 * G::TR), ox0 = bx * (2 * TC);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -304,11 +321,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int s = i * 256 + tid;
-        const int hh = s / A_PLANE, rem = s - hh * A_PLANE;
-        const int row = rem / (2 * A_HALF), r2 = rem - row * (2 * A_HALF);
-        const int par = r2 / A_HALF, ch = r2 - par * A_HALF;
+        const int hh = s / G::PLANE, rem = s - hh * G::PLANE;
+        const int row = rem / (2 * G::HALF), r2 = rem - row * (2 * G::HALF);
+        const int par = r2 / G::HALF, ch = r2 - par * G::HALF;
         const int iy = oy0 - 1 + row, ix = ox0 - 1 + 2 * ch + par;
-        const bool ok = (s < A_USED) & (ch < 9) & (iy >= 0) & (iy < a.in_h) & (ix >= 0) & (ix < a.in_w);
+        const bool ok = (s < G::USED) & (ch < TC + 1) & (iy >= 0) & (iy < a.in_h) & (ix >= 0) & (ix < a.in_w);
         xoff[i] = ok ? (unsigned)((((size_t)(img * a.in_h + iy) * a.in_w + ix) * a.x_ld + a.x_coff + hh * 4) * sizeof(float))
                      : 0xfffffff0u - (unsigned)(a.cin * sizeof(float));   // stays out of range for every k-step
     }
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
 
-    const int abase = (h * A_ROWS + 2 * (wm * 4 + (t >> 3))) * (2 * A_HALF) + (t & 7);
+    const int abase = (h * G::ROWS + 2 * (wm * G::RW + t / TC)) * (2 * G::HALF) + t % TC;
 
     // ---- prologue: patch of step kb through LDS, transformed; fragments of positions 0..5; patch of
     //      step kb+1 on its way ------------------------------------------------------------------------
@@ -352,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) raw[i][j] = A[i * (2 * A_HALF) + (j & 1) * A_HALF + (j >> 1)];
+            for (int j = 0; j < 4; ++j) raw[i][j] = A[i * (2 * G::HALF) + (j & 1) * G::HALF + (j >> 1)];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             tc[0][j] = wino_bt<0>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
@@ -374,22 +391,22 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
         const int nb = (s + 1 - kb) & 1;
         st.a_wr = smem + nb * A_SLOTS + tid;
         const f32x4 *const An = smem + nb * A_SLOTS + abase;
-        wino_pair<0>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
-        wino_pair<2>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
-        wino_pair<4>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
-        wino_pair<6>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+        wino_pair<0, TC>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+        wino_pair<2, TC>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+        wino_pair<4, TC>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+        wino_pair<6, TC>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
         SGV3D_WINO_PUBLISH();
         if (s + 2 < ke) st.x_step += WK * sizeof(float);   // the patch fetched in the second half is step s+2's
         SGV3D_SB();
-        wino_pair<8>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
-        wino_pair<10>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
-        wino_pair<12>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
-        wino_pair<14>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+        wino_pair<8, TC>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+        wino_pair<10, TC>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+        wino_pair<12, TC>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+        wino_pair<14, TC>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
         st.w_cur = st.w_next;
         if (s + 2 < ke) st.w_next += W_STEP * 4;
     }
 
-    wino_epilogue(a, acc, tn, img, oy0, ox0, wm, wn, h, t);
+    wino_epilogue<TC>(a, acc, tn, img, oy0, ox0, wm, wn, h, t);
 }
 
 // Patch-resident variant for layers with few input channels and many output channels (the fused first
@@ -400,6 +417,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
 // contiguous), so the only per-tile cost besides the MFMAs is the epilogue.  All workgroups walk the cout
 // tiles in the same order, so the weight panel of the moment is shared through L2.
 __global__ __launch_bounds__(256, 1) void conv_wino_resident_kernel(const ConvArgs a) {
+    constexpr int TC = 8;
+    using G = WinoGeom<TC>;
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     const int ngroups = gridDim.x / a.tiles_m;
     const int tm = blockIdx.x % a.tiles_m, grp = blockIdx.x / a.tiles_m;
@@ -425,11 +444,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_resident_kernel(const ConvAr
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int s = i * 256 + tid;
-        const int hh = s / A_PLANE, rem = s - hh * A_PLANE;
-        const int row = rem / (2 * A_HALF), r2 = rem - row * (2 * A_HALF);
-        const int par = r2 / A_HALF, ch = r2 - par * A_HALF;
+        const int hh = s / G::PLANE, rem = s - hh * G::PLANE;
+        const int row = rem / (2 * G::HALF), r2 = rem - row * (2 * G::HALF);
+        const int par = r2 / G::HALF, ch = r2 - par * G::HALF;
         const int iy = oy0 - 1 + row, ix = ox0 - 1 + 2 * ch + par;
-        const bool ok = (s < A_USED) & (ch < 9) & (iy >= 0) & (iy < a.in_h) & (ix >= 0) & (ix < a.in_w);
+        const bool ok = (s < G::USED) & (ch < TC + 1) & (iy >= 0) & (iy < a.in_h) & (ix >= 0) & (ix < a.in_w);
         const unsigned xo = ok ? (unsigned)((((size_t)(img * a.in_h + iy) * a.in_w + ix) * a.x_ld + a.x_coff + hh * 4) * sizeof(float))
                                : 0xfffffff0u - (unsigned)(a.cin * sizeof(float));
         for (int ks = 0; ks < nsteps; ++ks)
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_resident_kernel(const ConvAr
     st.x0 = st.x1 = st.x2 = st.x_step = 0;
     st.a_wr = smem;
 
-    const int abase = (h * A_ROWS + 2 * (wm * 4 + (t >> 3))) * (2 * A_HALF) + (t & 7);
+    const int abase = (h * G::ROWS + 2 * (wm * G::RW + t / TC)) * (2 * G::HALF) + t % TC;
     f32x4 tc[4][4], raw[4][4], wf[8], va0, va1, vb0, vb1;
 #pragma unroll
     for (int p = 0; p < 6; ++p) wf[p] = wino_buffer_load(st.w_rsrc, st.w_lane, st.w_cur + p * (W_POS * 4));
@@ -453,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_resident_kernel(const ConvAr
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) raw[i][j] = A[i * (2 * A_HALF) + (j & 1) * A_HALF + (j >> 1)];
+            for (int j = 0; j < 4; ++j) raw[i][j] = A[i * (2 * G::HALF) + (j & 1) * G::HALF + (j >> 1)];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             tc[0][j] = wino_bt<0>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
@@ -474,18 +493,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_resident_kernel(const ConvAr
         for (int s = 0; s < nsteps; ++s) {
             // the second half of the step reads the patch of the next step (step 0 again after the last)
             const f32x4 *const An = smem + (s + 1 < nsteps ? s + 1 : 0) * A_SLOTS + abase;
-            wino_pair<0, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
-            wino_pair<2, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
-            wino_pair<4, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
-            wino_pair<6, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
-            wino_pair<8, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
-            wino_pair<10, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
-            wino_pair<12, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
-            wino_pair<14, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            wino_pair<0, TC, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<2, TC, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            wino_pair<4, TC, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<6, TC, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            wino_pair<8, TC, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<10, TC, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            wino_pair<12, TC, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<14, TC, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
             st.w_cur = st.w_next;
             st.w_next += W_STEP * 4;
         }
-        wino_epilogue(a, acc, tn, img, oy0, ox0, wm, wn, h, t);
+        wino_epilogue<TC>(a, acc, tn, img, oy0, ox0, wm, wn, h, t);
     }
 }
 
@@ -573,8 +592,12 @@ extern "C" int sgv3d_conv2d_winograd_forward(const sgv3d_conv_desc *d, const flo
     a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff; a.res_ld = d->res_ld;
     a.relu = d->relu; a.mode = d->mode; a.ks = d->deconv_ks;
     a.korder = 0;
-    a.wb_y = cdiv(d->out_h, 16);
-    a.wb_x = cdiv(d->out_w, 16);
+    // tile-block shape: 8x8 tiles (16x16 pixels) or 4x16 tiles (8x32 pixels), whichever covers the image
+    // with fewer blocks (54x96: 21 instead of 24); the patch-resident variant is built for 8x8 only
+    const int blocks8 = cdiv(d->out_h, 16) * cdiv(d->out_w, 16), blocks16 = cdiv(d->out_h, 8) * cdiv(d->out_w, 32);
+    const bool wide = blocks16 < blocks8 && d->tile != SGV3D_WINOGRAD_RESIDENT;
+    a.wb_y = wide ? cdiv(d->out_h, 8) : cdiv(d->out_h, 16);
+    a.wb_x = wide ? cdiv(d->out_w, 32) : cdiv(d->out_w, 16);
     a.tiles_m = d->batch * a.wb_y * a.wb_x;
     a.tiles_n = cdiv(d->cout, 64);
     a.split_k = d->split_k > 1 ? d->split_k : 1;
@@ -606,14 +629,8 @@ extern "C" int sgv3d_conv2d_winograd_forward(const sgv3d_conv_desc *d, const flo
         hipLaunchKernelGGL(conv_wino_resident_kernel, dim3(a.tiles_m * groups), dim3(256), lds, st, a);
         return check_launch("conv_wino_resident_kernel");
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kWinoLds) != hipSuccess)
-            return fail(SGV3D_ELAUNCH, "conv2d_winograd_forward: cannot raise the dynamic LDS limit to %d", kWinoLds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(conv_wino_kernel, dim3(a.tiles_m * a.tiles_n, a.split_k), dim3(256), kWinoLds, st, a);
+    if (wide) hipLaunchKernelGGL(conv_wino_kernel<16>, dim3(a.tiles_m * a.tiles_n, a.split_k), dim3(256), kWinoLds, st, a);
+    else hipLaunchKernelGGL(conv_wino_kernel<8>, dim3(a.tiles_m * a.tiles_n, a.split_k), dim3(256), kWinoLds, st, a);
     if (a.split_k > 1) return launch_splitk_reduce(a, st);
     return check_launch("conv_wino_kernel");
 }

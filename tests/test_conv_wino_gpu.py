@@ -35,6 +35,8 @@ SHAPES = [
     (1, 160, 32, 32, 160),   # cout = 2.5 tiles
     (1, 512, 27, 48, 512),
     (1, 64, 37, 21, 20),     # tiny cout
+    (1, 16, 8, 32, 64),      # exactly one 8x32-pixel block (4 x 16 tiles)
+    (2, 32, 20, 70, 96),     # 4 x 16-tile blocks with ragged right / bottom edges, batch 2
 ]
 
 
