@@ -67,6 +67,8 @@ def load_traffic(tile_name):
         sym = "conv_wino_kernel"
     elif tile_name == "conv_wino_resident":
         sym = "conv_wino_resident_kernel"
+    elif tile_name == "conv_wino_head":
+        sym = "conv_wino_head_kernel"
     else:
         bm, bn = tile_name.replace("conv_igemm_", "").split("x")
         sym = f"conv_igemm_kernel<{int(bm) // 64}, {int(bn) // 64}, true>"
