@@ -142,23 +142,7 @@ def small_conf(final=(128, 192), bev=64, depth=18):
 
 
 # -------------------------------------------------------------------------------------------------
-def _rodrigues(rvec):
-    th = float(np.linalg.norm(rvec))
-    if th < 1e-12:
-        return np.eye(3)
-    k = rvec / th
-    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
-    return np.eye(3) + math.sin(th) * Kx + (1 - math.cos(th)) * (Kx @ Kx)
-
-
-def _equation_plane(p):
-    (x1, y1, z1), (x2, y2, z2), (x3, y3, z3) = p
-    a1, b1, c1 = x2 - x1, y2 - y1, z2 - z1
-    a2, b2, c2 = x3 - x1, y3 - y1, z3 - z1
-    a = b1 * c2 - b2 * c1
-    b = a2 * c1 - a1 * c2
-    c = a1 * b2 - b1 * a2
-    return np.array([a, b, c, -a * x1 - b * y1 - c * z1])
+from .input_contract import get_denorm, get_reference_height, get_sensor2virtual, rodrigues as _rodrigues
 
 
 def make_calib(pitch_deg=11.0, cam_h=5.5, yaw_deg=0.0, roll_deg=0.0, fx=2183.375, fy=2329.2976, cx=940.59,
@@ -176,18 +160,9 @@ def make_calib(pitch_deg=11.0, cam_h=5.5, yaw_deg=0.0, roll_deg=0.0, fx=2183.375
     s2e[:3, :3] = Rz @ R @ Rroll
     s2e[:3, 3] = [0.0, 0.0, cam_h]
     e2s = np.linalg.inv(s2e)
-    gp = np.array([[0, 0, 0, 1.0], [0, 1, 0, 1], [1, 1, 0, 1]])
-    denorm = -1 * _equation_plane((e2s @ gp.T).T[:, :3])                    # get_denorm
-    origin = np.array([0.0, 1.0, 0.0])
-    target = -1 * denorm[:3]
-    tn = target / np.linalg.norm(target)
-    sita = math.acos(float(np.clip(np.inner(tn, origin), -1, 1)))
-    nv = np.cross(tn, origin)
-    s2v = np.eye(4)
-    if np.linalg.norm(nv) > 1e-12:                                           # get_sensor2virtual
-        nv = (nv / np.linalg.norm(nv)).astype(f32).astype(np.float64)
-        s2v[:3, :3] = _rodrigues(nv * sita).astype(f32)
-    refh = f32(abs(denorm[3]) / np.linalg.norm(denorm[:3]))                  # get_reference_height
+    denorm = get_denorm(e2s)                                                 # dataset/nusc_mv_det_dataset.py:63-86
+    s2v = get_sensor2virtual(denorm)
+    refh = get_reference_height(denorm)
     K = np.eye(4)
     K[0, 0], K[1, 1], K[0, 2], K[1, 2] = fx, fy, cx, cy
     ida = np.eye(4)

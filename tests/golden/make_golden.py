@@ -13,6 +13,9 @@ unmodified from the reference:
   ``voxel_pooling_ext`` that follows voxel_pooling_forward_cuda.cu:9-36 literally (the CUDA
   extension itself cannot be built or loaded here).
 
+* the dataset-side geometry helpers (get_denorm, get_sensor2virtual, get_reference_height, the ida /
+  bda matrices)   dataset/nusc_mv_det_dataset.py:41-179,433-446   -> input_contract.npz
+
 Outputs are DATA ONLY (inputs and expected outputs); no reference source text is stored.
 
     python tests/golden/make_golden.py
@@ -330,5 +333,68 @@ def main():
         print(fn, os.path.getsize(os.path.join(HERE, fn)), "bytes")
 
 
+# ------------------------------------------------------------------ input contract (dataset helpers)
+def make_input_contract():
+    """Outputs of the reference's dataset-side geometry helpers (dataset/nusc_mv_det_dataset.py:41-86,
+    130-161 img_transform's matrix, 164-179 bev_transform's matrix, 433-446 sample_ida_augmentation)."""
+    from scipy.spatial.transform import Rotation
+
+    class _Img:                                   # the only PIL.Image methods img_transform touches
+        def resize(self, *_a, **_k): return self
+        def crop(self, *_a, **_k): return self
+        def transpose(self, *_a, **_k): return self
+        def rotate(self, *_a, **_k): return self
+
+    _stub('cv2', Rodrigues=lambda v: (Rotation.from_rotvec(np.asarray(v, np.float64)).as_matrix(), None))
+    for name in ('mmcv', 'mmdet3d', 'mmdet3d.core', 'imageio', 'skimage', 'nuscenes', 'nuscenes.utils', 'pyquaternion', 'PIL', 'mmdet3d.core.bbox',
+                 'mmdet3d.core.bbox.structures', 'dataset.transforms'):
+        _stub(name)
+    _stub('skimage.transform', rotate=_raise, warp=_raise, resize=_raise)
+    _stub('mmdet3d.core.bbox.structures.lidar_box3d', LiDARInstance3DBoxes=object)
+    _stub('nuscenes.utils.data_classes', Box=object)
+    sys.modules['PIL'].Image = types.SimpleNamespace(ANTIALIAS=0, BICUBIC=0, FLIP_LEFT_RIGHT=0)
+    sys.modules['pyquaternion'].Quaternion = object
+    sys.modules['dataset.transforms'].ResizeLongestSide = object
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import importlib
+    ds = importlib.import_module('dataset.nusc_mv_det_dataset')
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from sgv3d_amd import synthetic as S
+    out = {}
+    poses = [(11.0, 5.5, 0.0, 0.0), (5.0, 4.0, 2.0, 0.5), (20.0, 8.0, -3.0, -1.0), (14.5, 6.3, 7.0, 2.0)]
+    s2e = np.stack([S.make_calib(pitch_deg=p, cam_h=hh, yaw_deg=y, roll_deg=r)['sensor2ego'] for p, hh, y, r in poses])
+    out['sensor2ego'] = s2e
+    den, s2v, ref = [], [], []
+    for m in s2e:
+        e2s = np.linalg.inv(m.astype(np.float64))
+        d = ds.get_denorm(e2s)
+        den.append(d)
+        s2v.append(ds.get_sensor2virtual(d))
+        ref.append(ds.get_reference_height(d))
+    out['denorm'], out['sensor2virtual'], out['reference_height'] = np.stack(den), np.stack(s2v), np.stack(ref)
+    pts = np.array([[0.3, -1.2, 4.0], [2.0, 0.5, 3.5], [-1.0, 0.7, 6.0]])
+    out['plane_points'], out['plane'] = pts, ds.equation_plane(pts)
+    # ida: eval-mode sampling for the DAIR (1080x1920 -> 864x1536) and a letterboxed case, + its matrix
+    fake = types.SimpleNamespace(ida_aug_conf={'H': 1080, 'W': 1920, 'final_dim': (864, 1536), 'bot_pct_lim': (0.0, 0.0)})
+    r = ds.NuscMVDetDataset.sample_ida_augmentation(fake)
+    out['ida_dair_sample'] = np.array([r[0], *r[1], *r[2], float(r[3]), float(r[4])], dtype=np.float64)
+    out['ida_dair_mat'] = ds.img_transform(_Img(), *r)[1].numpy()
+    fake.ida_aug_conf = {'H': 900, 'W': 1600, 'final_dim': (256, 704), 'bot_pct_lim': (0.0, 0.22)}
+    r = ds.NuscMVDetDataset.sample_ida_augmentation(fake)
+    out['ida_nusc_sample'] = np.array([r[0], *r[1], *r[2], float(r[3]), float(r[4])], dtype=np.float64)
+    out['ida_nusc_mat'] = ds.img_transform(_Img(), *r)[1].numpy()
+    out['ida_aug_args'] = np.array([0.47, 12.0, 30.0, 12.0 + 704, 30.0 + 256, 1.0, 5.4])
+    out['ida_aug_mat'] = ds.img_transform(_Img(), 0.47, (752, 423), (12, 30, 12 + 704, 30 + 256), True, 5.4)[1].numpy()
+    # bda
+    out['bda_identity'] = ds.bev_transform(torch.zeros(0, 9), 0, 1.0, False, False)[1].numpy()
+    out['bda_aug_args'] = np.array([22.5, 1.05, 1.0, 0.0])
+    out['bda_aug'] = ds.bev_transform(torch.zeros(0, 9), 22.5, 1.05, True, False)[1].numpy()
+    np.savez_compressed(os.path.join(HERE, "input_contract.npz"), **out)
+    print("input_contract.npz:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if "--input-contract" not in sys.argv:      # `--input-contract`: only (re)generate input_contract.npz
+        main()
+    make_input_contract()
