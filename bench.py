@@ -49,8 +49,9 @@ def parse():
                     help="frames in flight: consecutive steps are replayed round-robin on this many HIP streams "
                          "(each with its own graph and activation buffers), so kernels of frame i+1 fill the CUs that "
                          "the batch-1 layers of frame i leave idle")
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "r101", "cfg5"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "r101", "cfg3", "cfg5"],
                     help="cfg2 (default, the judged workload): R50 BEVHeight; r101: R101 BEVHeight; "
+                         "cfg3: R101 1088x1920 -> 512x512 BEV (geometry of BASELINE configs[2]; fp32 here, use --batch 4); "
                          "cfg5: SGV3D BSM R101 (model of BASELINE configs[4], fp32, batch 1)")
     return ap.parse_args()
 
@@ -97,10 +98,13 @@ def main():
     group = ReplicaGroup(backend="nccl" if world > 1 else None, device=dev)   # nccl == RCCL on ROCm
     from sgv3d_amd.models.bev_height import BEVHeight
 
-    bc, hc = {"cfg2": S.r50_256_conf, "r101": S.r101_256_conf, "cfg5": S.bsm_r101_256_conf}[args.config]()
+    bc, hc = {"cfg2": S.r50_256_conf, "r101": S.r101_256_conf, "cfg3": S.r101_512_conf,
+              "cfg5": S.bsm_r101_256_conf}[args.config]()
     workload = {"cfg2": "BASELINE cfg-2: ResNet-50 864x1536 -> 256x256 BEV, fp32, full BEVHeight forward "
                         "(backbone+neck+HeightNet+lift+geometry+voxel_pooling+head)",
                 "r101": "ResNet-101 864x1536 -> 256x256 BEV, fp32, full BEVHeight forward",
+                "cfg3": "ResNet-101 1088x1920 (1080 padded) -> 512x512 BEV, fp32 (BASELINE configs[2] asks bf16), "
+                        "full BEVHeight forward",
                 "cfg5": "SGV3D BSM ResNet-101 864x1536 -> 256x256 BEV (stride-8 frustum, D=180, 87-ch BEV), fp32, "
                         "full forward"}[args.config]
     torch.manual_seed(0)

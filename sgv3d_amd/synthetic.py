@@ -97,6 +97,19 @@ def r101_256_conf():
     return b, h
 
 
+def r101_512_conf():
+    """BASELINE cfg-3 geometry: R101, 1080x1920 images padded to 1088x1920 (a multiple of the stride-16
+    feature grid), 512x512 BEV grid (0.2 m cells).  This build computes it in fp32."""
+    b, h = r101_256_conf()
+    b['final_dim'] = (1088, 1920)
+    b['x_bound'] = [0, 102.4, 0.2]
+    b['y_bound'] = [-51.2, 51.2, 0.2]
+    h['bbox_coder'] = dict(h['bbox_coder'], out_size_factor=4, voxel_size=[0.05, 0.05, 8])
+    h['test_cfg'] = dict(h['test_cfg'], voxel_size=[0.05, 0.05, 8])
+    h['train_cfg'] = dict(h['train_cfg'], grid_size=[2048, 2048, 1], voxel_size=[0.05, 0.05, 8])
+    return b, h
+
+
 def bsm_r101_256_conf():
     """BASELINE cfg-5 model: SGV3D BSM, R101, 864x1536 -> 256x256 BEV
     (exps/sgv3d/bsm_bev_height_lss_r101_864_1536_256x256.py:42-101)."""
