@@ -296,6 +296,25 @@ int sgv3d_head_final_conv(int batch, int h, int w, int num_branches, int hidden_
                           const float *hidden, const float *weight, const float *bias,
                           const int32_t *branch_of_out, float *out, void *stream);
 
+/* Both layers of all CenterHead branches in one kernel (mmdet3d SeparateHead = [3x3 cin -> 64 + BN + ReLU,
+ * 3x3 64 -> c_k + bias] per branch; bev_height_head.py:110): the 64-channel hidden maps stay in LDS and are
+ * never written to HBM.  Same results as sgv3d_conv2d_winograd_forward (GROUP_PLANES) followed by
+ * sgv3d_head_final_conv up to fp32 summation order (the 9 taps of a border pixel are added block by block in
+ * a fixed order: deterministic).
+ *   x         f32 NHWC [batch, h, w, x_ld], channels [x_coff, x_coff + cin), cin % 8 == 0, cin <= 64
+ *   w1_wino   first-layer weights of all branches, [num_branches*64, cin, 3, 3] packed by
+ *             sgv3d_conv_winograd_pack_weight; scale1 / bias1 f32 [num_branches*64] folded BN (NULL = 1 / 0)
+ *   w2        f32 [total_out][3][3][64], bias2 f32 [total_out]; out_begin int32 [num_branches + 1] (device):
+ *             branch k owns output channels [out_begin[k], out_begin[k+1]), at most 4
+ *   out       f32 NCHW [batch, total_out, h, w]
+ *   workspace sgv3d_centerhead_branches_workspace_bytes(...) bytes of scratch (ring partial sums) */
+size_t sgv3d_centerhead_branches_workspace_bytes(int batch, int h, int w, int total_out);
+int sgv3d_centerhead_branches_forward(int batch, int h, int w, int cin, int x_ld, int x_coff, const float *x,
+                                      int num_branches, const float *w1_wino, const float *scale1,
+                                      const float *bias1, int total_out, const float *w2, const float *bias2,
+                                      const int32_t *out_begin, float *out, void *workspace,
+                                      size_t workspace_bytes, void *stream);
+
 /* ================================================================================================
  * Box decode + circle NMS  
  * ================================================================================================ */

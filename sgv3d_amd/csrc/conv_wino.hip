@@ -29,6 +29,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WK = 8;                           // input channels per k-step
@@ -97,12 +98,13 @@ __device__ __forceinline__ f32x4 wino_buffer_load(__amdgpu_buffer_rsrc_t rsrc, u
 //     T = B^T d of the next step's patch, row by row into tc as soon as the current step's row is dead
 //     (rows 0, 1 in pair 10, row 2 in pair 12, row 3 in pair 14).
 #define SGV3D_WINO_MFMA(P, C, V, BF) acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(V.C, BF.C, acc[P], 0, 0, 0)
-template <int P, int TC, bool RESIDENT = false>
+template <int P, int TC, bool RESIDENT = false, int DIST = 3, int HALF = WinoGeom<TC>::HALF>
 __device__ __forceinline__ void wino_pair(f32x16 (&acc)[16], f32x4 (&tc)[4][4], f32x4 (&raw)[4][4], f32x4 &vc0,
                                           f32x4 &vc1, f32x4 &vn0, f32x4 &vn1, f32x4 (&wf)[8], WinoStreams &st,
                                           const f32x4 *An) {
     static_assert((P & 1) == 0, "pairs start at even positions");
     constexpr int R0 = P & 7, R1 = (P + 1) & 7;          // ring slots of this pair
+    static_assert(DIST == 3, "fragment ring: three pairs ahead");
     constexpr int L0 = (P + 6) & 7, L1 = (P + 7) & 7;    // ring slots (= those of pair P-2) refilled now
     const f32x4 b0 = wf[R0], b1 = wf[R1];
     SGV3D_WINO_MFMA(P, x, vc0, b0);
@@ -119,7 +121,7 @@ __device__ __forceinline__ void wino_pair(f32x16 (&acc)[16], f32x4 (&tc)[4][4], 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                raw[i][j] = An[i * (2 * WinoGeom<TC>::HALF) + (j & 1) * WinoGeom<TC>::HALF + (j >> 1)];
+                raw[i][j] = An[i * (2 * HALF) + (j & 1) * HALF + (j >> 1)];
     } else if constexpr (!RESIDENT && P == 10) {
         st.stage0 = wino_buffer_load(st.x_rsrc, st.x0, st.x_step);
     } else if constexpr (!RESIDENT && P == 12) {
@@ -217,6 +219,10 @@ __device__ __forceinline__ void wino_store(f32x16 (&acc)[16], __amdgpu_buffer_rs
 template <int TC>
 __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, f32x16 (&acc)[16], int tn, int img, int oy0, int ox0,
                                               int wm, int wn, int h, int t) {
+    // Opaque copies: everything derived from the lane / block coordinates below (address tables, bounds) is
+    // computed HERE, after the main loop, instead of being hoisted in front of it and kept -- or spilled --
+    // across a loop that has no registers to spare.
+    asm volatile("" : "+v"(h), "+v"(t), "+s"(wm), "+s"(wn), "+s"(oy0), "+s"(ox0), "+s"(tn), "+s"(img));
     // At one wave per SIMD nothing hides the epilogue, so it is kept to a few instructions per output:
     // a lane holds ONE output channel (col) of 16 tiles x 2x2 pixels, every channel-only term (scale,
     // shift, gate, channel part of the address) is hoisted, and the stores are buffer stores whose
@@ -508,6 +514,343 @@ __global__ __launch_bounds__(256, 1) void conv_wino_resident_kernel(const ConvAr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// CenterHead branches fused: [3x3 64 -> 64 + BN + ReLU] and [3x3 64 -> c_k + bias] of all branches
+// (mmdet3d SeparateHead, reached through layers/heads/bev_height_head.py:110) in one kernel, so the 64-
+// channel hidden maps (604 MB per frame at cfg-2: the largest tensor of the model) never reach HBM.
+//
+// Patch-resident Winograd kernel as above; one cout tile = one branch (hidden_ch == 64).  Instead of
+// storing the tile, the epilogue puts the block's 16x16 x 64 hidden values (BN + ReLU applied, zero
+// outside the image) and the branch's final weights into LDS and runs the final 3x3 convolution from
+// there: thread = output pixel, weights are broadcast LDS reads.  A block can only add the taps that fall
+// inside its own 16x16 hidden pixels: it writes those partial sums (+ bias) for its own pixels to the
+// output, and the partial sums it owes to the one-pixel ring AROUND the block (owned by the 8 neighbours)
+// to a small workspace; head_ring_fixup_kernel then adds each border pixel's <= 3 ring contributions in a
+// fixed order (N, S, W, E, NW, NE, SW, SE) -- deterministic, no atomics.
+//
+// LDS (160 KB): patch of all k-steps without pad slots (8 x 648 x 16 B = 81 KB; costs a 2-way conflict on a
+// quarter of the patch reads), hidden tile [256 px + 1 zero px][68 floats] (17 16-B slots per pixel:
+// conflict-free for thread = pixel), final weights of the branch [c][9 taps][64] (<= 9 KB).
+constexpr int HID_LD = 68;
+constexpr int HEAD_HALF = 9;                        // patch slots per (row, column parity): no padding
+constexpr int HEAD_PLANE = 18 * 2 * HEAD_HALF;      // 324
+constexpr int HEAD_PATCH_SLOTS = 2 * HEAD_PLANE;    // 648 per k-step
+constexpr int HEAD_RING = 68;                       // ring pixels around a 16x16 block
+constexpr int HEAD_MAX_OUT = 4;                     // output channels per branch
+
+struct HeadArgs {
+    const float *w2, *bias2;      // [total_out][3][3][64], [total_out]
+    const int *out_begin;         // [tiles_n + 1] first output channel of each branch
+    float *out;                   // NCHW [batch][total_out][H][W]
+    float *ring;                  // [tiles_m][total_out][68]
+    int total_out;
+};
+
+// Partial final-conv sums of local output pixel (oy, ox) in [-1, 16]^2 over the taps ky in [KY0, KY1],
+// kx in [KX0, KX1] from the hidden pixels inside the block; a tap whose source pixel lies outside the block
+// reads the zero pixel kept behind the tile (no divergence).  wts: the branch's weights in LDS.
+template <int CB, int KY0, int KY1, int KX0, int KX1>
+__device__ __forceinline__ void head_taps(const float *hid, const float *wts, int oy, int ox, float (&accf)[HEAD_MAX_OUT]) {
+    // two partial sums per output (even / odd channel pairs): the products are natural register pairs of
+    // the 16-byte LDS reads, so they map onto packed FMAs (2 per instruction) without operand shuffles
+    f32x2 acc2[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc2[c] = f32x2{0.f, 0.f};
+#pragma unroll 1
+    for (int ky = KY0; ky <= KY1; ++ky)
+#pragma unroll 1
+        for (int kx = KX0; kx <= KX1; ++kx) {
+            const int sy = oy + ky - 1, sx = ox + kx - 1;
+            const bool in = ((unsigned)sy < 16u) & ((unsigned)sx < 16u);
+            const f32x4 *hp = reinterpret_cast<const f32x4 *>(hid + (in ? sy * 16 + sx : 256) * HID_LD);
+            const f32x4 *wp = reinterpret_cast<const f32x4 *>(wts + (ky * 3 + kx) * 64);
+#pragma unroll
+            for (int qd = 0; qd < 16; ++qd) {
+                const f32x4 hv = hp[qd];
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    const f32x4 wv = wp[c * (9 * 16) + qd];
+                    acc2[c] = hv.xy * wv.xy + acc2[c];
+                    acc2[c] = hv.zw * wv.zw + acc2[c];
+                }
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < HEAD_MAX_OUT; ++c) accf[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) accf[c] = acc2[c].x + acc2[c].y;
+}
+
+template <int KY0, int KY1, int KX0, int KX1>
+__device__ __forceinline__ void head_taps_n(int cb, const float *hid, const float *wts, int oy, int ox,
+                                            float (&accf)[HEAD_MAX_OUT]) {
+    if (cb == 1) head_taps<1, KY0, KY1, KX0, KX1>(hid, wts, oy, ox, accf);
+    else if (cb == 2) head_taps<2, KY0, KY1, KX0, KX1>(hid, wts, oy, ox, accf);
+    else if (cb == 3) head_taps<3, KY0, KY1, KX0, KX1>(hid, wts, oy, ox, accf);
+    else head_taps<4, KY0, KY1, KX0, KX1>(hid, wts, oy, ox, accf);
+}
+
+// Own pixels of the block, channel-split: wave w takes hidden channels [16w, 16w + 16) of all 256 pixels,
+// a lane a vertical strip of 4 pixels (x = lane & 15, y = 4 (lane >> 4) .. +3).  The strip's 6 x 3 hidden
+// neighbourhood is read once per 4 channels (consecutive lanes = consecutive pixels: conflict-free) and
+// every broadcast weight read feeds 4 pixels -- a third of the LDS traffic of thread = pixel, which is what
+// bounds this phase.  Partial sums of the 4 waves are added afterwards in fixed order (head kernel).
+template <int CB>
+__device__ __forceinline__ void head_own_ksplit(const float *hid, const float *wts, int wave, int lane,
+                                                float (&part)[4][HEAD_MAX_OUT]) {
+    f32x2 acc2[4][CB];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) acc2[r][c] = f32x2{0.f, 0.f};
+    const int x = lane & 15, y0 = 4 * (lane >> 4);
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const int qd = wave * 4 + q;
+        f32x4 hv[6][3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int sy = y0 - 1 + i, sx = x - 1 + j;
+                const bool in = ((unsigned)sy < 16u) & ((unsigned)sx < 16u);
+                hv[i][j] = reinterpret_cast<const f32x4 *>(hid + (in ? sy * 16 + sx : 256) * HID_LD)[qd];
+            }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    const f32x4 wv = reinterpret_cast<const f32x4 *>(wts + (c * 9 + ky * 3 + kx) * 64)[qd];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc2[r][c] = hv[r + ky][kx].xy * wv.xy + acc2[r][c];
+                        acc2[r][c] = hv[r + ky][kx].zw * wv.zw + acc2[r][c];
+                    }
+                }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < HEAD_MAX_OUT; ++c) part[r][c] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) part[r][c] = acc2[r][c].x + acc2[r][c].y;
+}
+
+__global__ __launch_bounds__(256, 1) void conv_wino_head_kernel(const ConvArgs a, const HeadArgs ha) {
+    constexpr int TC = 8;
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    const int nsteps = a.cin / WK;
+    float *const hid = reinterpret_cast<float *>(smem + nsteps * HEAD_PATCH_SLOTS);
+    float *const wts = hid + 257 * HID_LD;
+    const int tm = blockIdx.x;
+    const int bpi = a.wb_y * a.wb_x;
+    const int img = tm / bpi;
+    const int rb = tm - img * bpi;
+    const int by = rb / a.wb_x, bx = rb - by * a.wb_x;
+    const int oy0 = by * 16, ox0 = bx * 16;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, t = lane & 31;
+
+    WinoStreams st;
+    const unsigned x_bytes = (unsigned)((size_t)a.M * a.x_ld * sizeof(float));
+    st.x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)x_bytes, 0x00020000);
+    // ---- the whole patch, once: slot -> (channel half, row, column parity, column / 2) ------------------
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int s = i * 256 + tid;
+        const int hh = s / HEAD_PLANE, rem = s - hh * HEAD_PLANE;
+        const int row = rem / (2 * HEAD_HALF), r2 = rem - row * (2 * HEAD_HALF);
+        const int par = r2 / HEAD_HALF, ch = r2 - par * HEAD_HALF;
+        const int iy = oy0 - 1 + row, ix = ox0 - 1 + 2 * ch + par;
+        const bool ok = (iy >= 0) & (iy < a.in_h) & (ix >= 0) & (ix < a.in_w);
+        const unsigned xo = ok ? (unsigned)((((size_t)(img * a.in_h + iy) * a.in_w + ix) * a.x_ld + a.x_coff + hh * 4) * sizeof(float))
+                               : 0xfffffff0u - (unsigned)(a.cin * sizeof(float));
+        if (s < HEAD_PATCH_SLOTS)
+            for (int ks = 0; ks < nsteps; ++ks)
+                smem[ks * HEAD_PATCH_SLOTS + s] = wino_buffer_load(st.x_rsrc, xo, (unsigned)(ks * WK * sizeof(float)));
+    }
+    const unsigned w_bytes = (unsigned)((size_t)a.tiles_n * nsteps * W_STEP * sizeof(float));
+    st.w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)w_bytes, 0x00020000);
+    st.w_cur = st.w_next = 0;
+    st.w_lane = (unsigned)(h * 64 + wn * 32 + t) * 16u;
+    st.x0 = st.x1 = st.x2 = st.x_step = 0;
+    st.a_wr = smem;
+    if (tid < HID_LD) hid[256 * HID_LD + tid] = 0.f;   // the zero pixel out-of-block taps read
+
+    const int abase = (h * 18 + 2 * (wm * 4 + (t >> 3))) * (2 * HEAD_HALF) + (t & 7);
+    __syncthreads();
+
+    const size_t plane = (size_t)a.out_h * a.out_w;
+    for (int tn = 0; tn < a.tiles_n; ++tn) {
+        // Nothing of the main loop's register state lives across the epilogue: fragment ring, transformed
+        // patch of step 0 and accumulators are set up per branch.
+        f32x4 tc[4][4], raw[4][4], wf[8], va0, va1, vb0, vb1;
+        st.w_cur = (unsigned)((size_t)tn * nsteps * W_STEP * sizeof(float));
+        st.w_next = st.w_cur + W_STEP * 4;       // reads past the last tile are out of range and return 0
+#pragma unroll
+        for (int p = 0; p < 6; ++p) wf[p] = wino_buffer_load(st.w_rsrc, st.w_lane, st.w_cur + p * (W_POS * 4));
+        {
+            const f32x4 *const A = smem + abase;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) raw[i][j] = A[i * (2 * HEAD_HALF) + (j & 1) * HEAD_HALF + (j >> 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tc[0][j] = wino_bt<0>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
+                tc[1][j] = wino_bt<1>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
+                tc[2][j] = wino_bt<2>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
+                tc[3][j] = wino_bt<3>(raw[0][j], raw[1][j], raw[2][j], raw[3][j]);
+            }
+            va0 = wino_bt<0>(tc[0][0], tc[0][1], tc[0][2], tc[0][3]);
+            va1 = wino_bt<1>(tc[0][0], tc[0][1], tc[0][2], tc[0][3]);
+        }
+        f32x16 acc[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+        for (int s = 0; s < nsteps; ++s) {
+            const f32x4 *const An = smem + (s + 1 < nsteps ? s + 1 : 0) * HEAD_PATCH_SLOTS + abase;
+            wino_pair<0, TC, true, 3, HEAD_HALF>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<2, TC, true, 3, HEAD_HALF>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            wino_pair<4, TC, true, 3, HEAD_HALF>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<6, TC, true, 3, HEAD_HALF>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            wino_pair<8, TC, true, 3, HEAD_HALF>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<10, TC, true, 3, HEAD_HALF>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            wino_pair<12, TC, true, 3, HEAD_HALF>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<14, TC, true, 3, HEAD_HALF>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            st.w_cur = st.w_next;
+            st.w_next += W_STEP * 4;
+        }
+        // ---- hidden tile + the branch's final weights -> LDS ------------------------------------------------
+        SGV3D_WINO_PUBLISH();          // every wave is done reading the previous branch's hidden tile / weights
+        // Opaque copies of the thread / block coordinates: what the epilogue derives from them (bounds masks,
+        // LDS addresses, output pointers) is recomputed per branch instead of being hoisted out of the branch
+        // loop and kept -- or spilled -- across the main loop, which has no registers to spare.
+        int tid_ = tid, oy0_ = oy0, ox0_ = ox0;
+        asm volatile("" : "+v"(tid_), "+s"(oy0_), "+s"(ox0_));
+        const int lane_ = tid_ & 63, wave_ = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+        const int wm_ = wave_ >> 1, wn_ = wave_ & 1, h_ = lane_ >> 5, t_ = lane_ & 31;
+        const int o0 = __builtin_amdgcn_readfirstlane(ha.out_begin[tn]);
+        const int cb = __builtin_amdgcn_readfirstlane(min(ha.out_begin[tn + 1] - o0, HEAD_MAX_OUT));
+        if (tid_ < cb * 144)            // cb x 9 x 64 floats, contiguous in w2
+            reinterpret_cast<f32x4 *>(wts)[tid_] = reinterpret_cast<const f32x4 *>(ha.w2 + (size_t)o0 * 576)[tid_];
+        if (tid_ + 256 < cb * 144)
+            reinterpret_cast<f32x4 *>(wts)[tid_ + 256] = reinterpret_cast<const f32x4 *>(ha.w2 + (size_t)o0 * 576)[tid_ + 256];
+        if (tid_ + 512 < cb * 144)
+            reinterpret_cast<f32x4 *>(wts)[tid_ + 512] = reinterpret_cast<const f32x4 *>(ha.w2 + (size_t)o0 * 576)[tid_ + 512];
+        {
+            const int col = tn * 64 + wn_ * 32 + t_;
+            const float sc = a.scale ? a.scale[col] : 1.f, sh = a.bias ? a.bias[col] : 0.f;
+            float *const hl = hid + (wn_ * 32 + t_);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float r0[4], r1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float m0 = acc[j][e], m1 = acc[4 + j][e], m2 = acc[8 + j][e], m3 = acc[12 + j][e];
+                    r0[j] = m0 + m1 + m2;
+                    r1[j] = m1 - m2 - m3;
+                }
+                const float yv[2][2] = {{r0[0] + r0[1] + r0[2], r0[1] - r0[2] - r0[3]},
+                                        {r1[0] + r1[1] + r1[2], r1[1] - r1[2] - r1[3]}};
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int ly = 2 * (wm_ * 4 + (e >> 2)) + dy, lx = 2 * (4 * h_ + (e & 3)) + dx;
+                        const bool in = (oy0_ + ly < a.out_h) & (ox0_ + lx < a.out_w);
+                        hl[(ly * 16 + lx) * HID_LD] = in ? fmaxf(yv[dy][dx] * sc + sh, 0.f) : 0.f;
+                    }
+            }
+        }
+        __syncthreads();               // (also waits for the weight loads above)
+        // ---- final 3x3 conv of this branch from LDS -------------------------------------------------------
+        float accf[HEAD_MAX_OUT];
+        {   // the ring owed to the neighbours: one side per wave, only the three taps that can reach the block
+            int ridx;
+            if (wave_ == 0) { ridx = lane_; head_taps_n<2, 2, 0, 2>(cb, hid, wts, -1, lane_ - 1, accf); }
+            else if (wave_ == 1) { ridx = 18 + lane_; head_taps_n<0, 0, 0, 2>(cb, hid, wts, 16, lane_ - 1, accf); }
+            else if (wave_ == 2) { ridx = 36 + lane_; head_taps_n<0, 2, 2, 2>(cb, hid, wts, lane_, -1, accf); }
+            else { ridx = 52 + lane_; head_taps_n<0, 2, 0, 0>(cb, hid, wts, lane_, 16, accf); }
+            if (lane_ < (wave_ < 2 ? 18 : 16)) {
+                float *rp = ha.ring + ((size_t)tm * ha.total_out + o0) * HEAD_RING + ridx;
+#pragma unroll
+                for (int c = 0; c < HEAD_MAX_OUT; ++c)
+                    if (c < cb) rp[c * HEAD_RING] = accf[c];
+            }
+        }
+        {   // own pixels, channel-split over the waves; partial sums meet in LDS (over the hidden tile)
+            float part[4][HEAD_MAX_OUT];
+            if (cb == 1) head_own_ksplit<1>(hid, wts, wave_, lane_, part);
+            else if (cb == 2) head_own_ksplit<2>(hid, wts, wave_, lane_, part);
+            else if (cb == 3) head_own_ksplit<3>(hid, wts, wave_, lane_, part);
+            else head_own_ksplit<4>(hid, wts, wave_, lane_, part);
+            SGV3D_WINO_PUBLISH();      // every wave is done reading the hidden tile
+            f32x4 *const pl = reinterpret_cast<f32x4 *>(hid);           // [wave][pixel] x 4 outputs
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                pl[wave_ * 256 + (4 * (lane_ >> 4) + r) * 16 + (lane_ & 15)] = f32x4{part[r][0], part[r][1], part[r][2], part[r][3]};
+            SGV3D_WINO_PUBLISH();
+            const int py = tid_ >> 4, px = tid_ & 15;
+            const f32x4 s4 = ((pl[tid_] + pl[256 + tid_]) + pl[512 + tid_]) + pl[768 + tid_];
+            if (oy0_ + py < a.out_h && ox0_ + px < a.out_w) {
+                float *op = ha.out + ((size_t)img * ha.total_out + o0) * plane + (size_t)(oy0_ + py) * a.out_w + ox0_ + px;
+                const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                for (int c = 0; c < HEAD_MAX_OUT; ++c)
+                    if (c < cb) op[c * plane] = sv[c] + ha.bias2[o0 + c];
+            }
+        }
+    }
+}
+
+// out[b][oc][y][x] += ring contributions of the up-to-3 neighbouring blocks, fixed order N S W E NW NE SW SE
+__global__ void head_ring_fixup_kernel(int batch, int H, int W, int nby, int nbx, int total_out,
+                                       const float *__restrict__ ring, float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)batch * nby * nbx * total_out * 60;
+    if (i >= total) return;
+    const int bi = (int)(i % 60);
+    long long r = i / 60;
+    const int oc = (int)(r % total_out);
+    r /= total_out;
+    const int bx = (int)(r % nbx);
+    r /= nbx;
+    const int by = (int)(r % nby), img = (int)(r / nby);
+    int py, px;   // the 60 border pixels of a 16x16 block
+    if (bi < 16) { py = 0; px = bi; }
+    else if (bi < 32) { py = 15; px = bi - 16; }
+    else if (bi < 46) { py = bi - 32 + 1; px = 0; }
+    else { py = bi - 46 + 1; px = 15; }
+    const int y = by * 16 + py, x = bx * 16 + px;
+    if (y >= H || x >= W) return;
+    auto R = [&](int nby_, int nbx_, int ridx) -> float {
+        if (nby_ < 0 || nby_ >= nby || nbx_ < 0 || nbx_ >= nbx) return 0.f;
+        const size_t blk = ((size_t)img * nby + nby_) * nbx + nbx_;
+        return ring[(blk * total_out + oc) * HEAD_RING + ridx];
+    };
+    float v = out[((size_t)img * total_out + oc) * H * W + (size_t)y * W + x];
+    if (py == 0) v += R(by - 1, bx, 18 + px + 1);
+    if (py == 15) v += R(by + 1, bx, px + 1);
+    if (px == 0) v += R(by, bx - 1, 52 + py);
+    if (px == 15) v += R(by, bx + 1, 36 + py);
+    if (py == 0 && px == 0) v += R(by - 1, bx - 1, 35);
+    if (py == 0 && px == 15) v += R(by - 1, bx + 1, 18);
+    if (py == 15 && px == 0) v += R(by + 1, bx - 1, 17);
+    if (py == 15 && px == 15) v += R(by + 1, bx + 1, 0);
+    out[((size_t)img * total_out + oc) * H * W + (size_t)y * W + x] = v;
+}
+
 // U = G g G^T per (cout, cin), written in the order the kernel streams it:
 // [cout tile of 64][k-step of 8 channels][pos 16][channel half 2][n 64][4 channels]
 __global__ void wino_pack_weight_kernel(const float *__restrict__ src, int cout, int cin, int cin_pad,
@@ -633,4 +976,53 @@ extern "C" int sgv3d_conv2d_winograd_forward(const sgv3d_conv_desc *d, const flo
     else hipLaunchKernelGGL(conv_wino_kernel<8>, dim3(a.tiles_m * a.tiles_n, a.split_k), dim3(256), kWinoLds, st, a);
     if (a.split_k > 1) return launch_splitk_reduce(a, st);
     return check_launch("conv_wino_kernel");
+}
+
+extern "C" size_t sgv3d_centerhead_branches_workspace_bytes(int batch, int h, int w, int total_out) {
+    if (batch <= 0 || h <= 0 || w <= 0 || total_out <= 0) return 0;
+    return sizeof(float) * (size_t)batch * cdiv(h, 16) * cdiv(w, 16) * total_out * HEAD_RING;
+}
+
+extern "C" int sgv3d_centerhead_branches_forward(int batch, int h, int w, int cin, int x_ld, int x_coff, const float *x,
+                                                 int num_branches, const float *w1_wino, const float *scale1,
+                                                 const float *bias1, int total_out, const float *w2,
+                                                 const float *bias2, const int32_t *out_begin, float *out,
+                                                 void *workspace, size_t workspace_bytes, void *stream) {
+    SGV3D_REQUIRE(x && w1_wino && w2 && bias2 && out_begin && out, "centerhead_branches_forward: null pointer");
+    SGV3D_REQUIRE(batch > 0 && h > 0 && w > 0 && num_branches > 0 && total_out > 0, "centerhead_branches_forward: non-positive dimension");
+    SGV3D_REQUIRE(cin % WK == 0 && (x_ld & 3) == 0 && (x_coff & 3) == 0 && x_ld >= x_coff + cin,
+                  "centerhead_branches_forward: cin must be a multiple of 8, x_ld/x_coff of 4");
+    const int lds = (cin / WK) * HEAD_PATCH_SLOTS * 16 + 257 * HID_LD * 4 + HEAD_MAX_OUT * 576 * 4;
+    SGV3D_REQUIRE(lds <= 160 * 1024, "centerhead_branches_forward: cin=%d too large for the patch-resident kernel (<= 64)", cin);
+    SGV3D_REQUIRE((long long)batch * h * w * x_ld * 4 < 0xf0000000LL, "centerhead_branches_forward: input larger than 3.75 GiB");
+    const size_t need = sgv3d_centerhead_branches_workspace_bytes(batch, h, w, total_out);
+    if (!workspace || workspace_bytes < need)
+        return fail(SGV3D_ENOSPACE, "centerhead_branches_forward: workspace has %zu bytes, needs %zu", workspace_bytes, need);
+    ConvArgs a;
+    a.x = x; a.w = w1_wino; a.scale = scale1; a.bias = bias1; a.res = nullptr; a.gate = nullptr; a.y = nullptr;
+    a.zeros = nullptr; a.ws = nullptr;
+    a.M = batch * h * w; a.N = num_branches * 64; a.K = 9 * cin; a.k_pad = a.K;
+    a.in_h = h; a.in_w = w; a.cin = cin; a.out_h = h; a.out_w = w; a.cout = a.N;
+    a.m_h = h; a.m_w = w; a.kh = 3; a.kw = 3; a.stride = 1; a.pad = 1; a.dil = 1;
+    a.x_ld = x_ld; a.x_coff = x_coff; a.y_ld = 0; a.y_coff = 0; a.res_ld = 0; a.relu = 1; a.mode = 0; a.ks = 0;
+    a.korder = 0; a.split_k = 1;
+    a.wb_y = cdiv(h, 16); a.wb_x = cdiv(w, 16);
+    a.tiles_m = batch * a.wb_y * a.wb_x;
+    a.tiles_n = num_branches;
+    HeadArgs ha;
+    ha.w2 = w2; ha.bias2 = bias2; ha.out_begin = out_begin; ha.out = out; ha.ring = static_cast<float *>(workspace);
+    ha.total_out = total_out;
+    static int lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds) != hipSuccess)
+            return fail(SGV3D_ELAUNCH, "centerhead_branches_forward: cannot raise the dynamic LDS limit to %d", lds);
+        lds_set = lds;
+    }
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(conv_wino_head_kernel, dim3(a.tiles_m), dim3(256), lds, st, a, ha);
+    const long long total = (long long)a.tiles_m * total_out * 60;
+    hipLaunchKernelGGL(head_ring_fixup_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, batch, h, w, a.wb_y, a.wb_x,
+                       total_out, ha.ring, out);
+    return check_launch("conv_wino_head_kernel");
 }

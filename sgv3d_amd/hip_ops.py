@@ -28,6 +28,8 @@ import os as _os
 SPLIT_K = not _os.environ.get("SGV3D_NO_SPLITK")
 # False: 3x3 / stride-1 layers never use the Winograd F(2x2,3x3) kernel (SGV3D_NO_WINOGRAD=1)
 WINOGRAD = not _os.environ.get("SGV3D_NO_WINOGRAD")
+# False: CenterHead branches run as two kernels with the hidden maps in HBM (SGV3D_NO_FUSED_HEAD=1)
+FUSED_HEAD = not _os.environ.get("SGV3D_NO_FUSED_HEAD")
 # (tile, split-K) decisions by layer signature.  SGV3D_TUNE_CACHE=<file> loads them at import and
 # save_tune_db() writes them back, so that a profiled run replays the choices of an earlier run
 # instead of timing candidates again (keeps rocprofv3 per-kernel averages free of tuning launches).
@@ -476,6 +478,28 @@ def head_final_conv(hidden, weight, bias, branch_of_out, num_branches, hidden_ch
                                               hidden.data_ptr(), weight.data_ptr(), bias.data_ptr(),
                                               branch_of_out.data_ptr(), out.data_ptr(), _st(hidden))
     _lib.check(rc, "sgv3d_head_final_conv")
+    return out
+
+
+def centerhead_branches(x, first, w2, b2, out_begin, num_branches, out=None):
+    """Both layers of all CenterHead branches in one kernel (hidden maps never leave the chip).
+    x NHWC [B,H,W,ld]; first: PackedConv of the concatenated first layers (needs Winograd weights, hidden 64);
+    w2 [sum_c,3,3,64]; b2 [sum_c]; out_begin int32 [nb+1] (device).  -> NCHW [B,sum_c,H,W]."""
+    B, H, W, ld = (int(s) for s in x.shape)
+    assert x.is_contiguous() and first.w_wino is not None and first.cout == num_branches * 64
+    total = int(w2.shape[0])
+    if out is None:
+        out = torch.empty(B, total, H, W, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nws = lib.sgv3d_centerhead_branches_workspace_bytes(B, H, W, total)
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+    flops = 2.0 * B * H * W * (first.cout * first.cin * 9 + total * 9 * 64)
+    with torch.cuda.device(x.device), prof("conv_wino_head", flops):
+        rc = lib.sgv3d_centerhead_branches_forward(B, H, W, first.cin, ld, 0, x.data_ptr(), int(num_branches),
+                                                   first.w_wino.data_ptr(), _lib.ptr(first.scale), _lib.ptr(first.shift),
+                                                   total, w2.data_ptr(), b2.data_ptr(), out_begin.data_ptr(), out.data_ptr(),
+                                                   ws.data_ptr(), nws, _st(x))
+    _lib.check(rc, "sgv3d_centerhead_branches_forward")
     return out
 
 

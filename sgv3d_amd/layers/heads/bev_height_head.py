@@ -151,15 +151,17 @@ class BEVHeightHead(HipModule):
         # final layers: [sum_c, 3, 3, 64] + bias + branch map
         w2 = torch.cat([seq[1].weight.detach().permute(0, 2, 3, 1) for _, _, seq in br], 0)
         b2 = torch.cat([seq[1].bias.detach() for _, _, seq in br], 0)
-        branch_of_out, slices, off = [], [], 0
+        branch_of_out, out_begin, slices, off = [], [0], [], 0
         for i, (t, name, seq) in enumerate(br):
             c = seq[1].out_channels
             branch_of_out += [i] * c
             slices.append((t, name, off, c))
             off += c
+            out_begin.append(off)
         f = lambda t_: t_.to(device).float().contiguous()
         return dict(shared=conv_bn(self.shared_conv.conv, self.shared_conv.bn, True, device), first=first,
                     w2=f(w2), b2=f(b2), branch_of_out=torch.tensor(branch_of_out, dtype=torch.int32, device=device),
+                    out_begin=torch.tensor(out_begin, dtype=torch.int32, device=device),
                     slices=slices, nb=len(br), hc=hc, total=off)
 
     def hip_forward(self, x):
@@ -174,8 +176,12 @@ class BEVHeightHead(HipModule):
                 trunk_outs.append(h)
         fpn_output = self.neck.hip_forward(trunk_outs)                 # :109
         shared = s['shared'](fpn_output)                               # CenterHead.forward_single
-        hidden = s['first'](shared, group_planes=s['hc'])              # all branch first layers: [nb,B,H,W,64]
-        out = hip_ops.head_final_conv(hidden, s['w2'], s['b2'], s['branch_of_out'], s['nb'], s['hc'])
+        if hip_ops.FUSED_HEAD and s['first'].w_wino is not None and s['first'].cin <= 64 and s['hc'] == 64:
+            # both branch layers in one kernel: the [nb,B,H,W,64] hidden maps stay on the chip
+            out = hip_ops.centerhead_branches(shared, s['first'], s['w2'], s['b2'], s['out_begin'], s['nb'])
+        else:
+            hidden = s['first'](shared, group_planes=s['hc'])          # all branch first layers: [nb,B,H,W,64]
+            out = hip_ops.head_final_conv(hidden, s['w2'], s['b2'], s['branch_of_out'], s['nb'], s['hc'])
         ret = [dict() for _ in self.task_heads]
         for t, name, off, c in s['slices']:
             ret[t][name] = out[:, off:off + c]                         # [B, c, H, W] views of one buffer

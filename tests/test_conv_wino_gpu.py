@@ -148,3 +148,34 @@ def test_winograd_patch_resident_rejects_wide_inputs():
     conv = PackedConv(w.cuda(), pad=1)
     with pytest.raises(_lib.SGV3DError):
         conv(x.cuda(), tile=TILE_WINO_RES, split_k=1)
+
+
+@pytest.mark.parametrize("B,H,W,cin,counts", [(1, 32, 48, 64, (2, 1, 3, 2)), (2, 20, 37, 32, (1, 3)), (1, 16, 16, 64, (4,)),
+                                             (1, 50, 33, 64, (2, 1, 3, 2, 2, 1, 1, 3))])
+def test_fused_centerhead_branches(B, H, W, cin, counts):
+    """sgv3d_centerhead_branches_forward == [3x3 cin->64 + BN + ReLU] then [3x3 64->c + bias] per branch."""
+    from sgv3d_amd import hip_ops
+    from sgv3d_amd.hip_ops import PackedConv
+    g = torch.Generator().manual_seed(21)
+    nb = len(counts)
+    x = torch.randn(B, H, W, cin, generator=g)
+    w1 = torch.randn(nb * 64, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    sc, sh = torch.rand(nb * 64, generator=g) + 0.5, torch.randn(nb * 64, generator=g) * 0.2
+    total = sum(counts)
+    w2 = torch.randn(total, 64, 3, 3, generator=g) / 24.0
+    b2 = torch.randn(total, generator=g)
+    hid = (F.conv2d(x.permute(0, 3, 1, 2).double(), w1.double(), padding=1) * sc.double()[None, :, None, None]
+           + sh.double()[None, :, None, None]).clamp_min(0)
+    ref, off = [], 0
+    for k, c in enumerate(counts):
+        ref.append(F.conv2d(hid[:, k * 64:(k + 1) * 64], w2[off:off + c].double(), b2[off:off + c].double(), padding=1))
+        off += c
+    ref = torch.cat(ref, 1)
+    first = PackedConv(w1.cuda(), pad=1, scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    ob = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).cuda()
+    out = hip_ops.centerhead_branches(x.cuda(), first, w2.permute(0, 2, 3, 1).contiguous().cuda(), b2.cuda(), ob, nb)
+    assert out.shape == ref.shape
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
+    again = hip_ops.centerhead_branches(x.cuda(), first, w2.permute(0, 2, 3, 1).contiguous().cuda(), b2.cuda(), ob, nb)
+    assert torch.equal(out, again)          # fixed summation order: bit-reproducible
