@@ -247,3 +247,37 @@ def test_config_matrix_matches_oracle(name, over):
     for task_out, task_ref in zip(out, ref):
         for k, v in task_ref[0].items():
             torch.testing.assert_close(task_out[0][k].cpu(), v, **TOL)
+
+
+def test_two_cameras_per_sample_matches_oracle():
+    """The reference's nuScenes-style inputs carry several cameras per sample (num_cams > 1): their frustum
+    points pool into the same BEV grid (lss_fpn.py:469-491).  Two differently posed cameras, batch 2."""
+    bc, hc = S.small_conf(depth=18)
+    m = _build(bc, hc, seed=7)
+    B, N = 2, 2
+    scale = bc["final_dim"][0] / 864
+    poses = [[dict(), dict(pitch_deg=13.0, cam_h=6.0, yaw_deg=6.0)],
+             [dict(pitch_deg=9.5, cam_h=5.0, yaw_deg=-4.0, roll_deg=0.5), dict(pitch_deg=15.0, cam_h=7.0, yaw_deg=2.0)]]
+    K = dict(fx=2183.375 * scale, fy=2329.2976 * scale, cx=940.59 * scale, cy=567.568 * scale)
+    cams = [[S.make_calib(**K, **p) for p in row] for row in poses]
+    stack = lambda k: torch.from_numpy(np.stack([np.stack([c[k] for c in row]) for row in cams])).view(B, 1, N, 4, 4)
+    mats = {'sensor2ego_mats': stack('sensor2ego'), 'intrin_mats': stack('intrin'), 'ida_mats': stack('ida'),
+            'sensor2sensor_mats': torch.eye(4).view(1, 1, 1, 4, 4).repeat(B, 1, N, 1, 1),
+            'sensor2virtual_mats': stack('sensor2virtual'),
+            'reference_heights': torch.tensor([[float(c['reference_height']) for c in row] for row in cams]).view(B, 1, N),
+            'bda_mat': torch.eye(4).repeat(B, 1, 1)}
+    g = torch.Generator().manual_seed(8)
+    imgs = torch.randn(B, 1, N, 3, *bc["final_dim"], generator=g)
+    keep = {}
+    ref = TM.bevheight_forward(m.state_dict(), bc, hc, imgs, mats, keep)
+    m = m.to(DEV)
+    dm = _to_dev(mats)
+    geom = m.backbone.get_geometry_voxel_index(dm['sensor2ego_mats'][:, 0], dm['sensor2virtual_mats'][:, 0],
+                                               dm['intrin_mats'][:, 0], dm['ida_mats'][:, 0],
+                                               dm['reference_heights'][:, 0], dm['bda_mat'])
+    assert np.array_equal(geom.cpu().numpy(), keep['geom_xyz'])
+    with torch.no_grad():
+        out = m(imgs.to(DEV), dm)
+    for task_out, task_ref in zip(out, ref):
+        for k, v in task_ref[0].items():
+            torch.testing.assert_close(task_out[0][k].cpu(), v, **TOL)
