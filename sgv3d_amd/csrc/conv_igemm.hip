@@ -100,16 +100,42 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     // nine taps of one chunk are fetched back to back so their overlapping input pixels hit in L1/L2.
     // General path: k = tap * cin + ci, decoded per thread with integer division.
     // split-K: blockIdx.y owns k-tiles [kt_begin, nkt) of a balanced partition
-    const int nkt_all = a.k_pad / BK;
+    // FAST path only: kernel rows whose input row lies outside the image for EVERY output row of this m-tile
+    // are skipped altogether (the dilated ASPP convolutions at 54x96 with dilation 12 / 18 lose up to a third
+    // of their taps this way; the zero-block loads they would have made feed MFMAs with zeros).  The valid
+    // rows form a contiguous range [kh_lo, kh_hi]; k-tiles are counted over the valid list.
+    int kh_lo = 0, kh_hi = a.kh - 1;
+    if constexpr (FAST) {
+        if (a.mode != SGV3D_CONV_DECONV && a.kh > 1) {
+            const int hw = a.m_h * a.m_w;
+            const int m_last = (m0 + BM < a.M ? m0 + BM : a.M) - 1;
+            const int img0 = m0 / hw, img1 = m_last / hw;
+            if (img0 == img1) {
+                const int r_first = (m0 - img0 * hw) / a.m_w, r_last = (m_last - img0 * hw) / a.m_w;
+                const int lo_num = a.pad - r_last * a.stride;                 // kh * dil >= lo_num
+                const int hi_num = a.in_h - 1 + a.pad - r_first * a.stride;   // kh * dil <= hi_num
+                const int lo = lo_num <= 0 ? 0 : (lo_num + a.dil - 1) / a.dil;
+                const int hi = hi_num < 0 ? -1 : hi_num / a.dil;
+                if (lo <= hi && lo < a.kh) {
+                    kh_lo = lo;
+                    kh_hi = hi < a.kh - 1 ? hi : a.kh - 1;
+                }
+            }
+        }
+    }
+    const int nkh = kh_hi - kh_lo + 1;
+    const int nkt_all = FAST ? (a.cin / BK) * nkh * a.kw : a.k_pad / BK;
     const int kt_begin = (int)((long long)nkt_all * blockIdx.y / a.split_k);
     const int nkt = (int)((long long)nkt_all * (blockIdx.y + 1) / a.split_k);   // exclusive end ("nkt" below)
-    int ld_kt = kt_begin, ld_kh = 0, ld_kw = 0, ld_c0 = 0;
+    int ld_kt = kt_begin, ld_kh = 0, ld_kw = 0, ld_c0 = 0, ld_kp = 0;
     if constexpr (FAST) {
-        const int taps = a.kh * a.kw;
-        const int chunk = kt_begin / taps, tap = kt_begin - chunk * taps;
+        const int per_chunk = nkh * a.kw;
+        const int kt0 = kt_begin < nkt_all ? kt_begin : nkt_all - 1;     // (an empty split slice reads the last tile)
+        const int chunk = kt0 / per_chunk, rem = kt0 - chunk * per_chunk;
         ld_c0 = chunk * BK;
-        ld_kh = tap / a.kw;
-        ld_kw = tap - ld_kh * a.kw;
+        ld_kh = kh_lo + rem / a.kw;
+        ld_kw = rem - (rem / a.kw) * a.kw;
+        ld_kp = chunk * a.kh * a.kw + ld_kh * a.kw + ld_kw;     // k-tile index in the packed weight order
     }
 
     // Loads are unconditional: lanes whose tap falls outside the image (or whose row / k is padding)
@@ -121,7 +147,7 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
         /* past the last tile (pipeline drain) nothing is fetched for A and the last B tile is */     \
         /* re-read: keeps the stage branch-free so the compiler can count vmcnt exactly        */     \
         bool kvalid_ = ld_kt < nkt;                                                                   \
-        const int ktb_ = ld_kt < nkt ? ld_kt : nkt - 1;                                               \
+        const int ktb_ = FAST ? ld_kp : (ld_kt < nkt ? ld_kt : nkt - 1);                              \
         if constexpr (FAST) {                                                                         \
             dy_ = ld_kh * a.dil;                                                                      \
             dx_ = ld_kw * a.dil;                                                                      \
@@ -150,9 +176,12 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
         }                                                                                             \
         ++ld_kt;                                                                                      \
         if constexpr (FAST) {                                                                         \
-            if (++ld_kw == a.kw) {                                                                    \
-                ld_kw = 0;                                                                            \
-                if (++ld_kh == a.kh) { ld_kh = 0; ld_c0 += BK; }                                      \
+            if (ld_kt < nkt) { /* past the end the state stays on the last valid tile (drain re-reads it) */ \
+                if (++ld_kw == a.kw) {                                                                \
+                    ld_kw = 0;                                                                        \
+                    if (++ld_kh > kh_hi) { ld_kh = kh_lo; ld_c0 += BK; }                              \
+                }                                                                                     \
+                ld_kp = (ld_c0 / BK) * a.kh * a.kw + ld_kh * a.kw + ld_kw;                            \
             }                                                                                         \
         }                                                                                             \
     } while (0)
