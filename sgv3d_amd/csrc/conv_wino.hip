@@ -7,20 +7,28 @@
 //   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A        per 2x2 output tile, 4x4 input tile d
 //
 // One kernel, nothing spilled to HBM in the Winograd domain:
-//   * workgroup = 4 waves (2 x 2) = 64 tiles (an 8x8 block = 16x16 output pixels) x 64 output channels
-//     x all 16 Winograd positions; each wave owns 32 tiles x 32 channels x 16 positions = 16 MFMA
-//     accumulator tiles (256 accumulator registers: one wave per SIMD, the whole 512-register file).
-//   * k-step = 8 input channels.  Per step the 18x18 raw input patch (11.5 KB) and the pre-transformed
-//     weights of the step ([16 pos][2][64 n][4], 32 KB, one linear stream thanks to the packing) are
-//     copied global -> LDS by global_load_lds_dwordx4 (no staging registers), double-buffered.
+//   * workgroup = 4 waves (2 x 2) = 64 tiles (8x8 tiles = 16x16 output pixels, or 4x16 tiles = 8x32 pixels)
+//     x 64 output channels x all 16 Winograd positions; each wave owns 32 tiles x 32 channels x 16
+//     positions = 16 MFMA accumulator tiles (256 accumulator registers: one wave per SIMD, the whole
+//     512-register file).
+//   * k-step = 8 input channels = 64 MFMAs per wave.  The raw input patch of the step (11.5 KB) goes
+//     global -> registers -> LDS (two buffers, one barrier per step, in its middle); the pre-transformed
+//     weights never touch LDS: packed [cout tile][k-step][16 pos][2][64 n][4] they ARE the MFMA B
+//     fragments and are read by buffer_load_dwordx4 straight into a ring of fragment registers, three
+//     position pairs ahead.  (An LDS-DMA version, global_load_lds_dwordx4 for both operands, was slower:
+//     a piece costs the issuing wave 60-180 cycles.)
 //   * the input transform B^T d B runs in registers on the fly (each lane reads the 16 raw float4 of its
 //     tile once per step: 64 add/sub per component), feeding 16 x 4 MFMAs per step and wave.
-//   * LDS images are conflict-free: the patch is stored [k/4][row][column parity][column/2 (pad 10)] so
-//     the 16 lanes of a ds_read_b128 group (8 tiles x 2 tile rows) hit 16 distinct 16-B slots.
+//   * the patch image in LDS is conflict-free: [k/4][row][column parity][column/2 (padded)] so the 16
+//     lanes of a ds_read_b128 group (8 tiles x 2 tile rows, or 16 tiles of a row) hit 16 distinct slots.
+//   * at one wave per SIMD VALU instructions and fp32 MFMAs do not overlap (tools/ubench/mfma_rate.hip):
+//     the MFMAs of two positions alternate and everything else is gathered into two MFMA gaps per pair.
 //   * the output transform A^T M A is lane-local (the 16 positions of one (tile, channel) element sit in
-//     the same lane / register index of the 16 accumulator tiles), followed by the common epilogue.
+//     the same lane / register index of the 16 accumulator tiles), followed by a slim epilogue.
 //   * split-K over input-channel steps (grid.y) for layers with too few tiles to fill 256 CUs; partial
 //     OUTPUT tiles (the transform is linear) go to the workspace and the igemm reduce kernel finishes.
+// Variants: conv_wino_resident_kernel (patch of all k-steps resident in LDS, walks over the cout tiles) and
+// conv_wino_head_kernel (both CenterHead branch layers, hidden maps never leave LDS).
 #include "conv_common.hpp"
 
 using namespace sgv3d;
