@@ -71,8 +71,9 @@ def load_traffic(tile_name):
     elif tile_name == "conv_wino_head":
         sym = "conv_wino_head_kernel"
     else:
-        bm, bn = tile_name.replace("conv_igemm_", "").split("x")
-        sym = f"conv_igemm_kernel<{int(bm) // 64}, {int(bn) // 64}, true>"
+        fast = not tile_name.endswith("_tapmajor")
+        bm, bn = tile_name.replace("conv_igemm_", "").replace("_tapmajor", "").split("x")
+        sym = f"conv_igemm_kernel<{int(bm) // 64}, {int(bn) // 64}, {'true' if fast else 'false'}>"
     try:
         rec = json.load(open(files[-1]))["bench"].get(sym)
     except Exception:

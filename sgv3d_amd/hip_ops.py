@@ -257,6 +257,8 @@ class PackedConv:
         d.tile, d.split_k = t, sk
         flops = 2.0 * gemm_m * gemm_n * (self.cin * self.kh * self.kw)
         name = ("conv_" if t >= TILE_WINO else "conv_igemm_") + TILE_NAMES[t]
+        if t < TILE_WINO and self.k_order == 0:
+            name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
                      f"s{self.stride} d{self.dil} splitk{sk}")
@@ -308,7 +310,7 @@ class PackedConv:
                 elif not SPLIT_K:
                     splits = (1,)
                 else:
-                    splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 8 and wgs < 1024 and wgs * s <= 4096]
+                    splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 4 and wgs < 2048 and wgs * s <= 6144]
                 for sk in splits:
                     d.tile, d.split_k = t, sk
                     _lib.check(self._launch(lib, d, x, residual, gate, out), "sgv3d_conv2d_forward")   # warm
