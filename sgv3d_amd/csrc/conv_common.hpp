@@ -15,6 +15,7 @@ struct ConvArgs {
     int x_ld, x_coff, y_ld, y_coff, res_ld, relu, mode, ks;
     int tiles_m, tiles_n;
     int wb_y, wb_x;  // Winograd kernel: 16x16-pixel output blocks per image
+    unsigned x_bytes, w_bytes;   // implicit GEMM: sizes of the input / packed-weight buffers (buffer resources)
     int korder;  // 0: k = tap*cin + ci   1: k = (ci/32 * taps + tap)*32 + ci%32  (cin % 32 == 0)
     int split_k; // > 1: blockIdx.y owns a slice of the k-tiles and stores raw partial sums to ws
     float *ws;   // [split_k][M][N] partial sums (split_k > 1)

@@ -28,6 +28,7 @@ using namespace sgv3d;
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4n __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
@@ -73,7 +74,13 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     const int r0 = tid >> 3;   // first row handled by this thread (then +32, +64, ...)
 
     // ---- per-thread A rows -----------------------------------------------------------------
-    const float *a_ptr[A_CH];
+    // Operands are read with buffer loads: resource (base, size) and the uniform part of the address in
+    // scalar registers, a 32-bit byte offset per lane -- out-of-image / padding lanes carry an out-of-range
+    // offset and read zeros.  fp32 MFMAs and VALU instructions share the SIMD's lanes on this chip, so
+    // every vector instruction saved in the loop (64-bit pointer arithmetic, selects) is MFMA time.
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.w_bytes, 0x00020000);
+    unsigned a_off[A_CH];
     int a_ih0[A_CH], a_iw0[A_CH];
     bool a_ok[A_CH];
 #pragma unroll
@@ -87,10 +94,12 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
         const int oh = t - n * a.m_h;
         a_ih0[i] = oh * a.stride - a.pad;
         a_iw0[i] = ow * a.stride - a.pad;
-        a_ptr[i] = a.x + ((long long)(n * a.in_h + a_ih0[i]) * a.in_w + a_iw0[i]) * a.x_ld + a.x_coff + cc * 4;
+        // (wraps for rows / columns in the padding; only used when the tap is inside the image)
+        a_off[i] = (unsigned)((((long long)(n * a.in_h + a_ih0[i]) * a.in_w + a_iw0[i]) * a.x_ld + a.x_coff + cc * 4) * 4);
     }
-    const float *b_ptr = a.w + (size_t)(n0 + r0) * a.k_pad + cc * 4;
-    const float *__restrict__ zeros = a.zeros;
+    unsigned b_off[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) b_off[i] = (unsigned)(((size_t)(n0 + r0 + 32 * i) * a.k_pad + cc * 4) * 4);
 
     // Two register stages: tile t+2 is fetched while tile t is multiplied and tile t+1 is written to
     // the other LDS buffer between the two MFMA halves.
@@ -166,12 +175,12 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
             const int ih_ = a_ih0[i] + dy_, iw_ = a_iw0[i] + dx_;                                     \
             const bool v_ = a_ok[i] & kvalid_ & ((unsigned)ih_ < (unsigned)a.in_h) &                  \
                             ((unsigned)iw_ < (unsigned)a.in_w);                                       \
-            const float *p_ = v_ ? a_ptr[i] + koff_ : zeros;                                          \
-            const float4 t_ = *reinterpret_cast<const float4 *>(p_);                                  \
+            const unsigned vo_ = v_ ? a_off[i] + (unsigned)(koff_ * 4) : 0xffffffffu;                 \
+            const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo_, 0, 0)); \
             RA[i].x = t_.x; RA[i].y = t_.y; RA[i].z = t_.z; RA[i].w = t_.w;                           \
         }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < B_CH; ++i) {                                            \
-            const float4 t_ = *reinterpret_cast<const float4 *>(b_ptr + (size_t)(32 * i) * a.k_pad + ktb_ * BK); \
+            const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_off[i], ktb_ * (BK * 4), 0)); \
             RB[i].x = t_.x; RB[i].y = t_.y; RB[i].z = t_.z; RB[i].w = t_.w;                           \
         }                                                                                             \
         ++ld_kt;                                                                                      \
@@ -520,6 +529,12 @@ extern "C" int sgv3d_conv2d_forward(const sgv3d_conv_desc *d, const float *x, co
     a.relu = d->relu; a.mode = d->mode; a.ks = d->deconv_ks; a.k_pad = d->k_pad;
     a.tiles_m = a.tiles_n = 0;
     a.korder = d->k_order;
+    {
+        const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * 4, wb = (long long)d->cout_pad * d->k_pad * 4;
+        SGV3D_REQUIRE(xb < 0xf0000000LL && wb < 0xf0000000LL, "conv2d_forward: input / packed weights larger than 3.75 GiB (32-bit buffer offsets)");
+        a.x_bytes = (unsigned)xb;
+        a.w_bytes = (unsigned)wb;
+    }
     SGV3D_REQUIRE(d->k_order == 0 || (d->k_order == 1 && d->cin % BK == 0), "conv2d_forward: k_order 1 needs cin %% 32 == 0");
     if (d->mode == SGV3D_CONV_DECONV) {
         SGV3D_REQUIRE(d->deconv_ks >= 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0,
