@@ -199,7 +199,9 @@ int sgv3d_conv_pack_weight(const float *w_src, int cout, int cin, int kh, int kw
                            void *stream);
 
 /* scale/bias f32 [cout] (NULL = 1 / 0), residual NHWC f32 or NULL, gate f32 [batch, cout] or NULL.
- * workspace: sgv3d_conv2d_workspace_bytes(desc) bytes (0 / NULL when split_k <= 1), scratch. */
+ * workspace: sgv3d_conv2d_workspace_bytes(desc) bytes (0 / NULL when split_k <= 1), scratch.
+ * The input tensor and the packed weights must each be smaller than 3.75 GiB (the kernels address them
+ * with 32-bit buffer offsets); outputs are not limited. */
 size_t sgv3d_conv2d_workspace_bytes(const sgv3d_conv_desc *desc /*host*/);
 int sgv3d_conv2d_forward(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *w_packed,
                          const float *scale, const float *bias, const float *residual,
