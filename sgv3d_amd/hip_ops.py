@@ -19,8 +19,11 @@ def _st(t):
 # When a list, every wrapper appends (kernel name, algorithmic flops, start event, end event) recorded
 # on the launch stream (bench.py's roofline pass).  None = no instrumentation.
 PROFILE = None
-# Pick the conv tile per (layer, input shape) by timing the four variants once, outside graph capture.
-AUTOTUNE = True
+# Pick algorithm / tile / split-K per (layer, input shape) by timing the candidates once, outside graph capture.
+# False (SGV3D_NO_AUTOTUNE=1): a fixed rule instead -- the same choices on every run and every rank, hence
+# bitwise reproducible results (measured choices can differ between runs with timing noise, which moves the
+# results by fp32 rounding since the algorithms sum in different orders); ~10 % slower.
+AUTOTUNE = not __import__("os").environ.get("SGV3D_NO_AUTOTUNE")
 # True: conv records carry the layer shape in their name (tools/layer_report.py)
 PROFILE_DETAIL = False
 # False: the autotuner never proposes split-K (experiments; SGV3D_NO_SPLITK=1)
@@ -252,7 +255,7 @@ class PackedConv:
                     self._tile_cache[key] = choice
                     TUNE_DB[sig] = choice
                 else:
-                    choice = (t or heuristic_tile(gemm_m, gemm_n), sk or 1)
+                    choice = self._rule(t, sk, d, gemm_m, gemm_n)
             t, sk = choice
         d.tile, d.split_k = t, sk
         flops = 2.0 * gemm_m * gemm_n * (self.cin * self.kh * self.kw)
@@ -266,6 +269,20 @@ class PackedConv:
             rc = self._launch(lib, d, x, residual, gate, out)
         _lib.check(rc, "sgv3d_conv2d_forward")
         return out
+
+    def _rule(self, t, sk, d, gemm_m, gemm_n):
+        """Deterministic choice without measurement: Winograd for the layers it covers once the map has
+        enough tiles to occupy the chip (split over channel steps to reach ~2 workgroups per CU), else the
+        implicit-GEMM tile of the cost model; explicit tile / split arguments win."""
+        if t == 0 and self.w_wino is not None and WINOGRAD and d.out_h * d.out_w * d.batch >= 1024:
+            wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 16) * -(-gemm_n // 64)
+            split = 1
+            if not sk and SPLIT_K:
+                for cand in (2, 3, 4, 6, 8):
+                    if wgs * cand <= 512 and self.cin // 8 // cand >= 4:
+                        split = cand
+            return TILE_WINO, sk or split
+        return (t or heuristic_tile(gemm_m, gemm_n)), (sk or 1)
 
     def _launch(self, lib, d, x, residual, gate, out):
         ws, nws = None, 0
