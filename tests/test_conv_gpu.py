@@ -295,3 +295,14 @@ def test_head_final_conv(hip):
     out = head_final_conv(planes.to(DEV), wcat.to(DEV), torch.cat(bs).to(DEV), branch.to(DEV), nb, hc)
     torch.cuda.synchronize()
     torch.testing.assert_close(out.cpu(), ref, **TOL)
+
+
+def test_random_shape_fuzz_all_algorithms():
+    """tools/fuzz_conv.py in small: random conv shapes through every algorithm / tile / split-K variant."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_conv.py"), "60", "3"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
