@@ -22,13 +22,12 @@ __all__ = ['BEVHeight']
 
 
 class BEVHeight(nn.Module):
-    """
-    Args:
-        backbone_conf (dict): Config of backbone.
-        head_conf (dict): Config of head.
-        is_train_height (bool): Whether to return height.
-            Default: False.
-    """
+    """Detector = camera backbone (``LSSFPN`` or, with ``backbone_conf['is_bsm']``, ``BSMLSSFPN``) + BEV head.
+
+    ``backbone_conf`` / ``head_conf`` are the experiment files' dicts, taken verbatim; ``is_train_height`` is
+    accepted for signature compatibility (the height-supervision branch belongs to the training step);
+    ``checkpoint`` optionally names a Lightning checkpoint whose ``model.backbone.*`` entries initialise the
+    backbone."""
 
     def __init__(self, backbone_conf, head_conf, is_train_height=False, checkpoint=None):
         super(BEVHeight, self).__init__()
@@ -65,18 +64,14 @@ class BEVHeight(nn.Module):
         self._param_stamp = None
 
     def forward(self, x, mats_dict, timestamps=None):
-        """Forward function for BEVHeight (models/bev_height.py:42-80).
+        """Images -> per-task prediction maps, as models/bev_height.py:42-80 does.
 
-        Args:
-            x (Tensor): images [B, num_sweeps, num_cams, 3, H, W] on the GPU.
-            mats_dict (dict): sensor2ego_mats, intrin_mats, ida_mats, sensor2sensor_mats,
-                sensor2virtual_mats [B, num_sweeps, num_cams, 4, 4], reference_heights
-                [B, num_sweeps, num_cams], bda_mat [B, 4, 4].
-            timestamps: unused (as in the reference).
-
-        Returns:
-            tuple(list[dict]): Output results for tasks.
-        """
+        ``x``: float32 [B, num_sweeps, num_cams, 3, H, W] on the GPU.  ``mats_dict``: the seven calibration
+        tensors of the reference's collate function -- 'sensor2ego_mats', 'intrin_mats', 'ida_mats',
+        'sensor2sensor_mats', 'sensor2virtual_mats' as [B, num_sweeps, num_cams, 4, 4], 'reference_heights' as
+        [B, num_sweeps, num_cams], 'bda_mat' as [B, 4, 4].  ``timestamps`` is ignored here as it is there.
+        Result: one single-element list per task holding a dict of NCHW maps (reg, height, dim, rot, vel,
+        heatmap) -- the nesting mmdet3d's CenterHead produces."""
         if self.is_train_height and self.training:
             raise NotImplementedError("training forward (height_pred branch) is SURVEY §8(f) rank 2")
         stamp = self._stamp()
