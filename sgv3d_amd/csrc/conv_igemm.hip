@@ -58,6 +58,24 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     float *const As0 = smem;
     float *const Bs0 = smem + BM * LDK;
     constexpr int kBufStride = (BM + BN) * LDK;
+    // Tap-major K (cin % 32 != 0: the 7x7 stems): decoding k -> (tap, channel) takes two integer divisions
+    // per thread and k-tile -- vector instructions that cost MFMA time on this chip.  They are done once per
+    // workgroup instead: a table in LDS behind the tiles, one entry per 16-byte k-chunk:
+    // {input offset of the chunk relative to the pixel, dy << 16 | dx}, dy = -1 for chunks past K.
+    int2 *const klut = reinterpret_cast<int2 *>(smem + 2 * kBufStride);
+    if constexpr (!FAST) {
+        for (int kc = threadIdx.x; kc < a.k_pad / 4; kc += kThreads) {
+            const int k = kc * 4;
+            int2 e = make_int2(0, -1);
+            if (k < a.K) {
+                const int tap = k / a.cin, ci = k - tap * a.cin;
+                const int kh = tap / a.kw, dy = kh * a.dil, dx = (tap - kh * a.kw) * a.dil;
+                e = make_int2((dy * a.in_w + dx) * a.x_ld + ci, (dy << 16) | dx);
+            }
+            klut[kc] = e;
+        }
+        __syncthreads();
+    }
 
     // ---- XCD-aware tile mapping (bijective for any tile count) --------------------------------
     const int ntiles = a.tiles_m * a.tiles_n;
@@ -152,7 +170,7 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     // exec-mask branches and no post-load selects.
 #define SGV3D_LOAD_TILE(RA, RB)                                                                       \
     do {                                                                                              \
-        int dy_, dx_, ci_;                                                                            \
+        int dy_, dx_, koff_;                                                                          \
         /* past the last tile (pipeline drain) nothing is fetched for A and the last B tile is */     \
         /* re-read: keeps the stage branch-free so the compiler can count vmcnt exactly        */     \
         bool kvalid_ = ld_kt < nkt;                                                                   \
@@ -160,17 +178,14 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
         if constexpr (FAST) {                                                                         \
             dy_ = ld_kh * a.dil;                                                                      \
             dx_ = ld_kw * a.dil;                                                                      \
-            ci_ = ld_c0;                                                                              \
+            koff_ = (dy_ * a.in_w + dx_) * a.x_ld + ld_c0;                                            \
         } else {                                                                                      \
-            const int k_ = ktb_ * BK + cc * 4;                                                        \
-            kvalid_ = kvalid_ & (k_ < a.K);                                                           \
-            const int tap_ = k_ / a.cin;                                                              \
-            ci_ = k_ - tap_ * a.cin - cc * 4;                                                         \
-            const int kh_ = tap_ / a.kw;                                                              \
-            dy_ = kh_ * a.dil;                                                                        \
-            dx_ = (tap_ - kh_ * a.kw) * a.dil;                                                        \
+            const int2 e_ = klut[ktb_ * (BK / 4) + cc];                                               \
+            kvalid_ = kvalid_ & (e_.y >= 0);                                                          \
+            dy_ = e_.y >> 16;                                                                         \
+            dx_ = e_.y & 0xffff;                                                                      \
+            koff_ = e_.x - cc * 4;       /* a_off already holds this thread's chunk column */          \
         }                                                                                             \
-        const int koff_ = (dy_ * a.in_w + dx_) * a.x_ld + ci_;                                        \
         _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                            \
             const int ih_ = a_ih0[i] + dy_, iw_ = a_iw0[i] + dx_;                                     \
             const bool v_ = a_ok[i] & kvalid_ & ((unsigned)ih_ < (unsigned)a.in_h) &                  \
@@ -417,13 +432,16 @@ __global__ void pack_weight_kernel(const float *__restrict__ src, int cout, int 
 template <int WTM, int WTN, bool FAST>
 int launch_t(const ConvArgs &a, hipStream_t st) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
-    constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * LDK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    constexpr size_t tiles_lds = sizeof(float) * 2 * (BM + BN) * LDK;
+    // tap-major K: + the k-chunk decode table (8 bytes per 16-byte chunk of K)
+    const size_t lds = tiles_lds + (FAST ? 0 : (size_t)a.k_pad / 4 * 8);
+    SGV3D_REQUIRE(lds <= 160 * 1024, "conv2d_forward: K = %d too long for the tap-major kernel's decode table", a.K);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_kernel<WTM, WTN, FAST>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot raise the dynamic LDS limit to %zu", lds);
-        attr_set = true;
+        lds_set = lds;
     }
     ConvArgs b = a;
     b.zeros = conv_zero_block();
