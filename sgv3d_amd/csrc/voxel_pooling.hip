@@ -114,6 +114,11 @@ __device__ __forceinline__ void wave_runs(int v, int lane, int &head_lane, int &
     run_len = next - head_lane;
 }
 
+__global__ __launch_bounds__(kBlock) void vp_zero_kernel(long long n, int *__restrict__ p) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
 __global__ __launch_bounds__(kBlock) void vp_count_kernel(long long total_pts, int N, int X, int Y, int Z,
                                                           const int32_t *__restrict__ geom,
                                                           int32_t *__restrict__ pos_memo,
@@ -713,8 +718,9 @@ extern "C" int sgv3d_voxel_plan_build(int batch_size, int num_points, int num_vo
     int *cur = reinterpret_cast<int *>(base + L.off_cur);
     int *order = reinterpret_cast<int *>(base + L.off_order);
     int *blk = reinterpret_cast<int *>(base + L.off_blk);
-    if (hipMemsetAsync(cur, 0, sizeof(int) * (size_t)(L.V + 1), st) != hipSuccess)
-        return fail(SGV3D_ELAUNCH, "voxel_plan_build: hipMemsetAsync failed");
+    // (a plain kernel, not hipMemsetAsync: a memset node inside a captured hipGraph faulted on replay
+    // -- "write access to a read-only page" -- once the host had made small allocations after the capture)
+    hipLaunchKernelGGL(vp_zero_kernel, dim3(cdiv(L.V + 1, kBlock)), dim3(kBlock), 0, st, L.V + 1, cur);
     const int pgrid = cdiv(L.total, kBlock);
     hipLaunchKernelGGL(vp_count_kernel, dim3(pgrid), dim3(kBlock), 0, st, L.total, num_points, num_voxel_x,
                        num_voxel_y, num_voxel_z, geom_xyz, pos_memo, cur);
