@@ -153,7 +153,9 @@ class VoxelPooling(Function):
                                   device=geom_xyz.device)   # voxel_pooling.py:40
         lib = _lib.load()
         if _MODE == "atomic":
-            output_features = input_features.new_zeros(batch_size, Y, X, num_channels)  # :37-38
+            # :37-38; filled by a kernel (new_full), not zero_(): inside a captured hipGraph zero_() becomes a memset
+            # node, which faults on replay on this ROCm once the host allocates between replays
+            output_features = input_features.new_full((batch_size, Y, X, num_channels), 0.0)
             with torch.cuda.device(input_features.device), hip_ops.prof("voxel_pooling_atomic"):
                 rc = lib.sgv3d_voxel_pooling_forward(batch_size, num_points, num_channels, X, Y, Z,
                                                      geom_xyz.data_ptr(), input_features.data_ptr(),
