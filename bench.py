@@ -85,6 +85,12 @@ def load_traffic(tile_name):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON record of rank 0.  Libraries write there too (RCCL prints a
+    # version banner through C stdio, which would surface after our line at exit), so file descriptor 1 points
+    # to stderr for the whole run and is restored only for the final print.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,7 +102,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     from sgv3d_amd import hip_ops, synthetic as S
     from sgv3d_amd.replicas import ReplicaGroup
-    group = ReplicaGroup(backend="nccl" if world > 1 else None, device=dev)   # nccl == RCCL on ROCm
+    group = ReplicaGroup(backend="nccl" if (world > 1 or os.environ.get("SGV3D_FORCE_DIST")) else None, device=dev)   # nccl == RCCL on ROCm
     from sgv3d_amd.models.bev_height import BEVHeight
 
     bc, hc = {"cfg2": S.r50_256_conf, "r101": S.r101_256_conf, "cfg3": S.r101_512_conf,
@@ -233,8 +239,13 @@ def main():
                        "voxel_pooling_mode": "planned", "weights": "random-init, BN stats perturbed (seed 0)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(line), flush=True)
     group.close()
+    if rank == 0:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)        # C stdio buffers (the RCCL banner) go to stderr, not after our line
+        os.dup2(real_stdout, 1)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

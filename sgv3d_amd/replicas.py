@@ -28,7 +28,9 @@ class ReplicaGroup:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.device = device
         self.dist = None
-        if self.world > 1:
+        # SGV3D_FORCE_DIST=1 forms the (1-rank) process group anyway: exercises the RCCL barrier / MAX-reduce of
+        # the measurement protocol on a single-GPU box
+        if self.world > 1 or os.environ.get("SGV3D_FORCE_DIST"):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
