@@ -26,6 +26,10 @@ import os
 import sys
 import time
 
+# RCCL / cross-process device-memory sharing on this pool needs the dmabuf IPC path (see the image notes);
+# exported by the environment normally -- set here as well, before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

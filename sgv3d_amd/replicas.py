@@ -33,6 +33,8 @@ class ReplicaGroup:
         if self.world > 1 or os.environ.get("SGV3D_FORCE_DIST"):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
             kw = {}
             if backend == "nccl" and device is not None:
