@@ -207,3 +207,43 @@ def test_fused_lift_splat_matches_materialised(hip, golden):
     lifted = (prob[..., None] * ctx[:, None]).reshape(B, D * P, C).contiguous()
     plan = VoxelPlan(geom, (X, Y, 1))
     assert torch.equal(plan.lift_splat(prob, ctx), plan.pool(lifted))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_geometry_fuzz_vs_oracle(hip, seed):
+    """Random sizes / channel counts / grids and point clouds from benign to pathological (everything in one
+    voxel, everything out of range, long runs of equal voxels, interleaved duplicates): both kernels exact on
+    integer-valued features, pos_memo exact, planned output fully written."""
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 4))
+    N = int(rng.choice([1, 7, 64, 500, 4097, 30000]))
+    C = int(rng.choice([1, 3, 4, 20, 80, 87, 132]))
+    X, Y, Z = int(rng.integers(1, 70)), int(rng.integers(1, 70)), int(rng.integers(1, 3))
+    kind = seed % 6
+    if kind == 0:      # uniform with a halo of out-of-range points
+        geom = rng.integers(-3, max(X, Y) + 3, size=(B, N, 3))
+        geom[..., 2] = rng.integers(-1, Z + 1, size=(B, N))
+    elif kind == 1:    # everything in one voxel
+        geom = np.zeros((B, N, 3), np.int64)
+        geom[..., 0], geom[..., 1] = X - 1, Y // 2
+    elif kind == 2:    # everything out of range
+        geom = np.full((B, N, 3), -5, np.int64)
+    elif kind == 3:    # long runs of equal voxels (frustum rows)
+        base = rng.integers(0, X * Y, size=(B, max(1, N // 37) + 1))
+        v = np.repeat(base, 37, axis=1)[:, :N]
+        geom = np.stack([v % X, v // X, np.zeros_like(v)], -1)
+    elif kind == 4:    # two hot voxels interleaved with noise
+        geom = rng.integers(0, max(X, Y), size=(B, N, 3))
+        geom[..., 2] = 0
+        geom[:, ::2, 0], geom[:, ::2, 1] = 0, 0
+        geom[:, 1::4, 0], geom[:, 1::4, 1] = X - 1, Y - 1
+    else:              # sorted by voxel (best case for the run aggregation)
+        v = np.sort(rng.integers(0, X * Y, size=(B, N)), axis=1)
+        geom = np.stack([v % X, v // X, np.zeros_like(v)], -1)
+    geom = geom.astype(np.int32)
+    feats = rng.integers(-4, 5, size=(B, N, C)).astype(np.float32)
+    ref_out, ref_pm = VPO.forward(geom, feats, (X, Y, Z))
+    for mode in ("atomic", "planned"):
+        out, pm = _run_abi(hip, geom, feats, (X, Y, Z), mode)
+        assert np.array_equal(out, ref_out), (seed, mode, B, N, C, X, Y, Z)
+        assert np.array_equal(pm.reshape(ref_pm.shape), ref_pm), (seed, mode)
