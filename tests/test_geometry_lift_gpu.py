@@ -125,3 +125,30 @@ def test_lift_vs_oracle(hip, D, C, P):
     np.testing.assert_allclose(prob.cpu().numpy(), p_ref.reshape(B, D, P), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(lifted.cpu().numpy(), l_ref.reshape(B, D, P, C), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(prob.sum(1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_calibration_fuzz_bit_exact(hip, seed):
+    """Random roadside poses (pitch 2..35 deg, height 3..12 m, yaw, roll), intrinsics, resize / crop and BEV
+    grids: voxel indices of the HIP kernels == the oracle restatement, every point, every bit."""
+    from sgv3d_amd import synthetic as S
+    rng = np.random.default_rng(500 + seed)
+    cams = []
+    for _ in range(3):
+        c = S.make_calib(pitch_deg=float(rng.uniform(2, 35)), cam_h=float(rng.uniform(3, 12)),
+                         yaw_deg=float(rng.uniform(-15, 15)), roll_deg=float(rng.uniform(-3, 3)),
+                         fx=float(rng.uniform(900, 2600)), fy=float(rng.uniform(900, 2600)),
+                         cx=float(rng.uniform(700, 1200)), cy=float(rng.uniform(400, 700)),
+                         resize=float(rng.uniform(0.4, 1.0)), crop=(float(rng.integers(0, 40)), float(rng.integers(0, 40))))
+        cams.append({k: c[k] for k in ("sensor2ego", "sensor2virtual", "intrin", "ida", "bda")} | {"reference_height": float(c["reference_height"])})
+    step = float(rng.choice([0.2, 0.4, 0.8]))
+    half = float(rng.choice([25.6, 51.2]))
+    bounds = ([0, 2 * half, step], [-half, half, step], [-5, 3, 8])
+    D = int(rng.choice([6, 12, 20]))
+    frustum = G.create_frustum((96, 160), 16, [float(rng.uniform(-3, -0.5)), float(rng.uniform(0, 3.5)), D])
+    gi, _, prep = _run(hip, frustum, cams, bounds, want_float=False)
+    vs, vc, vn = G.voxel_params(*bounds)
+    for i, c in enumerate(cams):
+        ref, _ = G.geom_xyz_for_camera(frustum, c["sensor2ego"], c["sensor2virtual"], c["intrin"], c["ida"],
+                                       c["reference_height"], c["bda"], vc, vs)
+        assert np.array_equal(gi[i], ref), (seed, i, int((gi[i] != ref).sum()))
