@@ -341,6 +341,51 @@ int sgv3d_centerpoint_decode(int batch, int num_class, int h, int w, int max_num
                              float *scores, int32_t *labels, unsigned char *valid, unsigned char *keep,
                              void *stream);
 
+/* ================================================================================================
+ * Training-side head functions  
+ * ================================================================================================ */
+
+/* Target assignment for every sample and task in one call: BEVHeightHead.get_targets_single
+ * (layers/heads/bev_height_head.py:113-253) under mmdet3d 0.18.1 CenterHead.get_targets, gaussian_radius and
+ * draw_heatmap_gaussian.
+ *   boxes   f32 [batch, n_max, 9] (x, y, z, w, l, h, yaw, vx, vy), padded; labels int32 [batch, n_max], < 0 = padding
+ *   classes_per_task  host int32[num_tasks]; label ids run task after task (task 0 owns 0..classes_per_task[0]-1, ...)
+ *   h, w    feature map = grid_size // out_size_factor; gaussian_overlap / min_radius / max_objs from train_cfg
+ * Outputs (all cleared by the call):
+ *   heatmap f32 [batch, total_classes, h, w]  (task t = channels of its classes)
+ *   anno_box f32 [num_tasks, batch, max_objs, 10]; ind int64 [num_tasks, batch, max_objs];
+ *   mask u8 [num_tasks, batch, max_objs]; slot k of a task = k-th box of the task in the reference's order
+ *   (class after class, input order inside a class); boxes past max_objs are dropped as there. */
+int sgv3d_centerhead_targets(int batch, int n_max, const float *boxes, const int32_t *labels, int num_tasks,
+                             const int32_t *classes_per_task /*host*/, int max_objs, int h, int w, float pc_x,
+                             float pc_y, float voxel_x, float voxel_y, float out_size_factor,
+                             double gaussian_overlap, int min_radius, int norm_bbox, float *heatmap,
+                             float *anno_box, long long *ind, unsigned char *mask, void *stream);
+
+/* Detection loss of ONE task and its gradient with respect to the six prediction maps: BEVHeightHead.loss
+ * (layers/heads/bev_height_head.py:255-311) = GaussianFocalLoss(clip_sigmoid(heatmap)) / max(num_pos, 1)
+ * + loss_bbox_weight * L1(gathered 10-channel box code, anno_box; mask * code_weights) / max(num, 1e-4).
+ *   _stats  stats[0] = count(target_heatmap == 1), stats[1] = sum(mask); the caller averages stats over the
+ *           data-parallel ranks (reduce_mean) before passing them on, without a host synchronisation.
+ *   maps are addressed as base + b*batch_stride + c*h*w + cell (channel slices of one buffer are fine);
+ *   g_* receive d(loss)/d(map) * grad_scale, addressed the same way with grad_batch_stride, or pass all six NULL
+ *   for the value only;
+ *   loss_out f32[2] = (loss_heatmap, loss_bbox); code_weights host float[10];
+ *   workspace sgv3d_centerhead_loss_workspace_bytes(batch) bytes. */
+size_t sgv3d_centerhead_loss_workspace_bytes(int batch);
+int sgv3d_centerhead_loss_stats(int batch, int num_class, int h, int w, int max_objs, const float *target_heatmap,
+                                long long target_batch_stride, const unsigned char *mask, float *stats,
+                                void *workspace, size_t workspace_bytes, void *stream);
+int sgv3d_centerhead_loss(int batch, int num_class, int h, int w, int max_objs, const float *heatmap,
+                          const float *reg, const float *height, const float *dim, const float *rot,
+                          const float *vel, long long pred_batch_stride, const float *target_heatmap,
+                          long long target_batch_stride, const float *anno_box, const long long *ind,
+                          const unsigned char *mask, const float *stats, const float *code_weights /*host*/,
+                          float loss_bbox_weight, float grad_scale, float *g_heatmap, float *g_reg,
+                          float *g_height, float *g_dim, float *g_rot, float *g_vel, long long grad_batch_stride,
+                          float *loss_out,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

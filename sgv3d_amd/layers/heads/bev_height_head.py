@@ -199,12 +199,65 @@ class BEVHeightHead(HipModule):
             x = x.contiguous()
         return self.hip_forward(x)
 
-    # --------------------------------------------------------------- later rounds
+    # --------------------------------------------------------------- training side
     def get_targets(self, gt_bboxes_3d, gt_labels_3d):
-        raise NotImplementedError("target assignment (bev_height_head.py:113-253) is SURVEY §8(f) rank 2")
+        """mmdet3d ``CenterHead.get_targets`` over ``get_targets_single`` (bev_height_head.py:113-253) as one
+        device launch for the whole batch (the reference loops over boxes in Python with device scalars).
+
+        ``gt_bboxes_3d``: list (per sample) of [N_i, 9] float tensors (x, y, z, w, l, h, yaw, vx, vy) or objects
+        with a ``.tensor``; ``gt_labels_3d``: list of [N_i] integer tensors.  Returns the reference's tuple
+        ``(heatmaps, anno_boxes, inds, masks)``, each a list over tasks of [B, ...] tensors (heatmaps are channel
+        slices of one [B, total_classes, H, W] buffer)."""
+        import ctypes
+        from ... import _lib
+        cfg = self.train_cfg
+        lib = _lib.load()
+        boxes = [getattr(b, 'tensor', b) for b in gt_bboxes_3d]
+        dev = next((b.device for b in boxes if b.is_cuda), None) or next(self.parameters()).device
+        assert dev.type == 'cuda', "target assignment runs on the GPU (no CPU fallback)"
+        B = len(boxes)
+        n_max = max([int(b.shape[0]) for b in boxes] + [1])
+        bx = torch.zeros(B, n_max, 9, dtype=torch.float32, device=dev)
+        lb = torch.full((B, n_max), -1, dtype=torch.int32, device=dev)
+        for i, (b, l) in enumerate(zip(boxes, gt_labels_3d)):
+            n = int(b.shape[0])
+            if n:
+                bx[i, :n] = b.to(dev, torch.float32).reshape(n, -1)[:, :9]
+                lb[i, :n] = l.to(dev, torch.int32).reshape(n)
+        osf = int(cfg['out_size_factor'])
+        W, H = int(cfg['grid_size'][0]) // osf, int(cfg['grid_size'][1]) // osf
+        max_objs = int(cfg['max_objs']) * int(cfg['dense_reg'])
+        T, total = len(self.num_classes), sum(self.num_classes)
+        heat = torch.empty(B, total, H, W, dtype=torch.float32, device=dev)
+        anno = torch.empty(T, B, max_objs, 10, dtype=torch.float32, device=dev)
+        ind = torch.empty(T, B, max_objs, dtype=torch.int64, device=dev)
+        mask = torch.empty(T, B, max_objs, dtype=torch.uint8, device=dev)
+        cpt = (ctypes.c_int32 * T)(*self.num_classes)
+        with torch.cuda.device(dev), hip_ops.prof("centerhead_targets"):
+            rc = lib.sgv3d_centerhead_targets(
+                B, n_max, bx.data_ptr(), lb.data_ptr(), T, cpt, max_objs, H, W,
+                float(cfg['point_cloud_range'][0]), float(cfg['point_cloud_range'][1]), float(cfg['voxel_size'][0]),
+                float(cfg['voxel_size'][1]), float(osf), float(cfg['gaussian_overlap']), int(cfg['min_radius']),
+                1 if self.norm_bbox else 0, heat.data_ptr(), anno.data_ptr(), ind.data_ptr(), mask.data_ptr(),
+                _lib.stream_handle(dev))
+        _lib.check(rc, "sgv3d_centerhead_targets")
+        heatmaps, c0 = [], 0
+        for nc in self.num_classes:
+            heatmaps.append(heat[:, c0:c0 + nc])
+            c0 += nc
+        return heatmaps, [anno[t] for t in range(T)], [ind[t] for t in range(T)], [mask[t] for t in range(T)]
 
     def loss(self, targets, preds_dicts, **kwargs):
-        raise NotImplementedError("loss (bev_height_head.py:255-311) is SURVEY §8(f) rank 2")
+        """Detection loss of bev_height_head.py:255-311 (Gaussian focal loss on the clipped sigmoid heatmap + weighted
+        L1 on the gathered box code, summed over tasks) as HIP kernels.  The two averaging factors per task stay on
+        the device; with an initialised process group they are averaged over the ranks by ONE all-reduce for all
+        tasks (the reference's ``reduce_mean`` per factor, with an ``.item()`` each).
+
+        Returns a scalar tensor.  Gradients with respect to the prediction maps are computed in the same launches;
+        they flow to ``preds_dicts`` tensors that require grad, and are kept in ``self.last_pred_grads`` (list over
+        tasks of dicts) for the hand-written backward path.  Unlike the reference this does not overwrite
+        ``preds_dict[0]['heatmap']`` with its sigmoid nor add an ``'anno_box'`` entry."""
+        return _CenterHeadLoss.run(self, targets, preds_dicts)
 
     def get_bboxes(self, preds_dicts, img_metas=None, img=None, rescale=False):
         """mmdet3d ``CenterHead.get_bboxes`` (reached via models/bev_height.py:116-126) on the device:
@@ -270,6 +323,94 @@ class BEVHeightHead(HipModule):
             bboxes = box_type(bboxes, code_size) if callable(box_type) else Boxes3D(bboxes, code_size)
             ret_list.append([bboxes, torch.cat(sl), torch.cat(ll).int()])
         return ret_list
+
+
+_MAP_KEYS = ('heatmap', 'reg', 'height', 'dim', 'rot', 'vel')
+
+
+class _CenterHeadLoss(torch.autograd.Function):
+    """Loss value + gradients of all tasks; autograd only routes the precomputed gradients."""
+
+    @staticmethod
+    def run(head, targets, preds_dicts):
+        maps = [preds[0][k] for preds in preds_dicts for k in _MAP_KEYS]
+        return _CenterHeadLoss.apply(head, targets, *maps)
+
+    @staticmethod
+    def forward(ctx, head, targets, *maps):
+        import ctypes
+        import torch.distributed as dist
+        from ... import _lib
+        lib = _lib.load()
+        heatmaps, anno_boxes, inds, masks = targets
+        T = len(heatmaps)
+        dev = maps[0].device
+        assert dev.type == 'cuda', "the loss runs on the GPU (no CPU fallback)"
+        cw = (ctypes.c_float * 10)(*[float(v) for v in head.train_cfg['code_weights']])
+        box_w = float(head.loss_bbox_cfg.get('loss_weight', 1.0)) if head.loss_bbox_cfg else 1.0
+        cls_w = float(head.loss_cls_cfg.get('loss_weight', 1.0)) if head.loss_cls_cfg else 1.0
+        assert cls_w == 1.0, "GaussianFocalLoss loss_weight != 1 is not used by any shipped config"
+        stats = torch.empty(T, 2, dtype=torch.float32, device=dev)
+        out = torch.empty(T, 2, dtype=torch.float32, device=dev)
+        B = int(maps[0].shape[0])
+        nws = lib.sgv3d_centerhead_loss_workspace_bytes(B)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        stream = _lib.stream_handle(dev)
+        per_task = []
+        with torch.cuda.device(dev):
+            for t in range(T):
+                p = [m if (m.dtype == torch.float32 and m.stride(3) == 1 and m.stride(2) == m.shape[3]
+                           and m.stride(1) == m.shape[2] * m.shape[3]) else m.float().contiguous()
+                     for m in maps[t * 6:t * 6 + 6]]
+                bs = int(p[0].stride(0))
+                if any(int(m.stride(0)) != bs for m in p):        # separate tensors: give them a common batch stride
+                    buf = torch.cat(p, 1)
+                    c0, q = 0, []
+                    for m in p:
+                        q.append(buf[:, c0:c0 + m.shape[1]])
+                        c0 += m.shape[1]
+                    p, bs = q, int(buf.stride(0))
+                tgt = heatmaps[t]
+                assert tgt.dtype == torch.float32 and tgt.stride(3) == 1 and tgt.stride(1) == tgt.shape[2] * tgt.shape[3]
+                _, cat, H, W = (int(v) for v in tgt.shape)
+                mo = int(inds[t].shape[1])
+                m8, i64, an = masks[t].contiguous(), inds[t].contiguous(), anno_boxes[t].contiguous()
+                assert m8.dtype == torch.uint8 and i64.dtype == torch.int64 and an.dtype == torch.float32
+                with hip_ops.prof("centerhead_loss_stats"):
+                    rc = lib.sgv3d_centerhead_loss_stats(B, cat, H, W, mo, tgt.data_ptr(), int(tgt.stride(0)), m8.data_ptr(),
+                                                         stats[t].data_ptr(), ws.data_ptr(), nws, stream)
+                _lib.check(rc, "sgv3d_centerhead_loss_stats")
+                per_task.append((p, bs, tgt, cat, H, W, mo, m8, i64, an))
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(stats)                              # reduce_mean of every factor in one collective
+                stats /= dist.get_world_size()
+            grads = []
+            for t, (p, bs, tgt, cat, H, W, mo, m8, i64, an) in enumerate(per_task):
+                gbuf = torch.empty(B, cat + 10, H, W, dtype=torch.float32, device=dev)   # heatmap, reg, height, dim, rot, vel
+                g, c0 = [], 0
+                for m in p:
+                    g.append(gbuf[:, c0:c0 + m.shape[1]])
+                    c0 += int(m.shape[1])
+                with hip_ops.prof("centerhead_loss"):
+                    rc = lib.sgv3d_centerhead_loss(
+                        B, cat, H, W, mo, *[m.data_ptr() for m in p], bs, tgt.data_ptr(), int(tgt.stride(0)), an.data_ptr(),
+                        i64.data_ptr(), m8.data_ptr(), stats[t].data_ptr(), cw, box_w, 1.0, *[m.data_ptr() for m in g],
+                        int(gbuf.stride(0)), out[t].data_ptr(), ws.data_ptr(), nws, stream)
+                _lib.check(rc, "sgv3d_centerhead_loss")
+                grads.append(g)
+        head.last_pred_grads = [dict(zip(_MAP_KEYS, g)) for g in grads]
+        head.last_loss_parts = out
+        ctx.grads = grads
+        ctx.shapes = [m.shape for m in maps]
+        return out.sum()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        res = [None, None]
+        for g in ctx.grads:
+            for m in g:
+                res.append(m * grad_out)
+        return tuple(res)
 
 
 class Boxes3D:

@@ -235,3 +235,33 @@ def randomize_norm_stats_(model, seed=0, dcn_offsets=True):
                 m.weight.mul_(20.0)
                 m.bias[0] += 0.5
     return model
+
+
+def make_gt(batch, seed=0, n_range=(0, 40), num_labels=10, pc_range=(0, -51.2, 102.4, 51.2), stress=True):
+    """Seeded ground-truth boxes [N, 9] (x, y, z, w, l, h, yaw, vx, vy) and labels [N] per sample, CPU tensors.
+    With ``stress`` a few boxes are placed outside the range, just below the lower edges (cell truncation) and
+    with a non-positive size, which the target assignment has to skip without losing their slot."""
+    rng = np.random.default_rng(seed)
+    boxes, labels = [], []
+    for b in range(batch):
+        n = int(rng.integers(n_range[0], n_range[1] + 1))
+        bx = np.zeros((n, 9), np.float32)
+        bx[:, 0] = rng.uniform(pc_range[0] - (8 if stress else 0), pc_range[2] + (8 if stress else 0), n)
+        bx[:, 1] = rng.uniform(pc_range[1] - (8 if stress else 0), pc_range[3] + (8 if stress else 0), n)
+        bx[:, 2] = rng.uniform(-3, 1, n)
+        bx[:, 3] = rng.uniform(0.4, 3.0, n)
+        bx[:, 4] = rng.uniform(0.4, 12.0, n)
+        bx[:, 5] = rng.uniform(0.5, 4.0, n)
+        bx[:, 6] = rng.uniform(-np.pi, np.pi, n)
+        bx[:, 7:9] = rng.normal(0, 2, (n, 2))
+        if stress and n >= 4:
+            bx[0, 0] = pc_range[0] - 0.2          # cell coordinate in (-1, 0): truncates to cell 0
+            bx[1, 1] = pc_range[1] - 0.3
+            bx[2, 3] = 0.0                        # non-positive width
+            bx[3, 0:2] = bx[n - 1, 0:2]           # two boxes on one cell
+        lb = rng.integers(0, num_labels, n).astype(np.int64)
+        if stress and n >= 4:
+            lb[3] = lb[n - 1]                     # ... of the same class, so they share a cell of one task
+        boxes.append(torch.from_numpy(bx))
+        labels.append(torch.from_numpy(lb))
+    return boxes, labels
