@@ -386,6 +386,24 @@ int sgv3d_centerhead_loss(int batch, int num_class, int h, int w, int max_objs, 
                           float *loss_out,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* Weight gradient of sgv3d_conv2d_forward's convolution (mode NORMAL geometry; what nn.Conv2d's backward asks
+ * cuDNN for on the training step, exps/...:224-240): dw f32 OIHW [cout, cin, kh, kw] = sum over pixels of
+ * dy (NHWC, channel stride y_ld, first channel y_coff) x shifted x (NHWC, x_ld / x_coff).  desc is the FORWARD
+ * descriptor; only its geometry and channel strides are read.  split = number of pixel ranges reduced
+ * independently (0 = chosen by the library); partial sums are added in a fixed order (deterministic).
+ * For an nn.ConvTranspose2d with kernel == stride pass the roles swapped (x := upstream gradient at the fine
+ * resolution, dy := the layer's input, desc of the equivalent stride-k convolution): the OIHW result then is
+ * the [cin, cout, k, k] layout of ConvTranspose2d.weight. */
+size_t sgv3d_conv2d_backward_weight_workspace_bytes(const sgv3d_conv_desc *desc /*host*/, int split);
+int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *dy, float *dw,
+                                 int split, void *workspace, size_t workspace_bytes, void *stream);
+
+/* y[b, oy, ox, :] = x[b, oy/stride, ox/stride, :] where both divide evenly (and stay inside x), else 0.
+ * NHWC f32, channels % 4 == 0, out >= (in - 1) * stride + 1.  The data gradient of a strided convolution is a
+ * stride-1 convolution of this map with the flipped, transposed weights (sgv3d_amd/conv_grad.py). */
+int sgv3d_zero_insert(int batch, int in_h, int in_w, int channels, int stride, int out_h, int out_w,
+                      const float *x, float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,109 @@
+"""Backward of the NHWC convolutions (the training step of
+exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:224-240 asks cuDNN for these through autograd).
+
+* weight gradient: ``conv_wgrad_kernel`` (csrc/conv_wgrad.hip), fp32 MFMA, pixel-split with a fixed-order reduce;
+* data gradient: a stride-1 convolution of the upstream gradient with the flipped, transposed weights through the
+  forward kernels (implicit GEMM or Winograd, autotuned like every other layer); strided layers first spread the
+  gradient over a zero-filled map (1x1 layers convolve at the coarse resolution and spread afterwards);
+* ``conv2d`` is the autograd function tying the three together for NHWC tensors.
+
+There is no CPU fallback: every function raises if the HIP library is missing.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .hip_ops import ConvDesc, PackedConv, prof, _st
+
+__all__ = ['conv2d_backward_weight', 'conv2d_backward_data', 'zero_insert', 'conv2d']
+
+
+def _out_hw(h, w, k, stride, pad, dil):
+    return ((h + 2 * pad - dil * (k[0] - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k[1] - 1) - 1) // stride + 1)
+
+
+def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, cout=None, x_coff=0, y_coff=0, split=0):
+    """dW (OIHW [cout, cin, kh, kw]) of ``y = conv2d(x, W)`` for NHWC ``x`` [B, H, W, x_ld] and ``dy`` [B, OH, OW, y_ld];
+    channel windows [x_coff, x_coff + cin) / [y_coff, y_coff + cout) default to the whole tensors."""
+    kh, kw = (kernel, kernel) if isinstance(kernel, int) else kernel
+    B, H, W, x_ld = (int(v) for v in x.shape)
+    _, OH, OW, y_ld = (int(v) for v in dy.shape)
+    cin = x_ld - x_coff if cin is None else int(cin)
+    cout = y_ld - y_coff if cout is None else int(cout)
+    assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype == torch.float32 and x.is_cuda
+    assert (OH, OW) == _out_hw(H, W, (kh, kw), stride, pad, dil) and int(dy.shape[0]) == B
+    d = ConvDesc()
+    d.batch, d.in_h, d.in_w, d.cin, d.out_h, d.out_w, d.cout = B, H, W, cin, OH, OW, cout
+    d.kh, d.kw, d.stride, d.pad, d.dil = kh, kw, int(stride), int(pad), int(dil)
+    d.x_ld, d.x_coff, d.y_ld, d.y_coff = x_ld, int(x_coff), y_ld, int(y_coff)
+    lib = _lib.load()
+    nws = lib.sgv3d_conv2d_backward_weight_workspace_bytes(ctypes.byref(d), int(split))
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
+    dw = torch.empty(cout, cin, kh, kw, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), prof("conv_wgrad", 2.0 * B * OH * OW * cout * cin * kh * kw):
+        rc = lib.sgv3d_conv2d_backward_weight(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(split),
+                                              ws.data_ptr(), nws, _st(x))
+    _lib.check(rc, "sgv3d_conv2d_backward_weight")
+    return dw
+
+
+def zero_insert(x, stride, out_hw):
+    """NHWC map with ``x`` on every ``stride``-th pixel and zeros elsewhere."""
+    B, H, W, C = (int(v) for v in x.shape)
+    assert x.is_contiguous() and x.dtype == torch.float32 and C % 4 == 0
+    y = torch.empty(B, out_hw[0], out_hw[1], C, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), prof("zero_insert"):
+        rc = _lib.load().sgv3d_zero_insert(B, H, W, C, int(stride), int(out_hw[0]), int(out_hw[1]), x.data_ptr(),
+                                           y.data_ptr(), _st(x))
+    _lib.check(rc, "sgv3d_zero_insert")
+    return y
+
+
+def conv2d_backward_data(dy, weight, in_hw, stride=1, pad=0, dil=1):
+    """dX (NHWC [B, H, W, cin]) of ``y = conv2d(x, weight)``; ``weight`` OIHW, ``dy`` NHWC [B, OH, OW, cout(+padding to 4)]."""
+    cout, cin, kh, kw = (int(v) for v in weight.shape)
+    H, W = in_hw
+    assert kh == kw, "square kernels only (every layer of the model)"
+    if int(dy.shape[-1]) % 4:
+        dy = torch.nn.functional.pad(dy, (0, 4 - int(dy.shape[-1]) % 4))
+    wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()          # [cin, cout, kh, kw], rotated by 180 degrees
+    conv = PackedConv(wt, stride=1, pad=dil * (kh - 1) - pad, dil=dil, cin_pad=int(dy.shape[-1]), pad_out=True)
+    if stride == 1:
+        return conv(dy)
+    if kh == 1 and pad == 0:
+        return zero_insert(conv(dy), stride, (H, W))                      # 1x1: convolve at the coarse resolution
+    hz, wz = H + 2 * pad - dil * (kh - 1), W + 2 * pad - dil * (kw - 1)
+    return conv(zero_insert(dy, stride, (hz, wz)))
+
+
+class _Conv2dNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil):
+        conv = PackedConv(weight, stride=stride, pad=pad, dil=dil, shift=bias, cin_pad=int(x.shape[-1]))
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (stride, pad, dil, bias is not None)
+        return conv(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad, dil, has_bias = ctx.geom
+        dy = dy.contiguous()
+        cout, cin, kh, kw = (int(v) for v in weight.shape)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_backward_data(dy, weight, (int(x.shape[1]), int(x.shape[2])), stride, pad, dil)
+            if int(dx.shape[-1]) != int(x.shape[-1]):
+                dx = torch.nn.functional.pad(dx, (0, int(x.shape[-1]) - int(dx.shape[-1])))
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_backward_weight(x, dy, (kh, kw), stride, pad, dil, cin=cin, cout=cout)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 1, 2))
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1):
+    """``F.conv2d`` on NHWC float32 CUDA tensors through the HIP kernels, differentiable in ``x``, ``weight``, ``bias``.
+    ``x`` may carry zero padding channels beyond ``weight.shape[1]`` (a multiple of 4 is required)."""
+    return _Conv2dNHWC.apply(x, weight, bias, int(stride), int(pad), int(dil))

@@ -1,0 +1,223 @@
+// Weight gradient of the NHWC convolution on the fp32 MFMA pipe (the training step's
+// replacement for the cuDNN backward-filter call behind nn.Conv2d / nn.ConvTranspose2d), plus the
+// zero-insertion helper the data gradient of strided convolutions uses.
+//
+//   dW[co][ci][kh][kw] = sum over (image, oy, ox) of dY[image, oy, ox, co] * X[image, oy*s - p + kh*d, ox*s - p + kw*d, ci]
+//
+// GEMM view per kernel tap: C[co][ci] = sum_k A[k][co] * B[k][ci] with k = output pixel -- both operands are
+// pixel-major in NHWC, which is exactly the operand shape of v_mfma_f32_32x32x2_f32 (lane l supplies
+// A[k = l/32][m = l%32]), so tiles go global -> registers -> LDS [pixel][channel] without a transpose and the
+// fragment reads are conflict-free ds_read_b32 of 32 consecutive floats per lane half.
+//
+// Workgroup = 256 threads = 2 x 2 waves, tile 64 co x 64 ci of ONE tap, 64 pixels per stage (32 MFMAs per wave),
+// register-staged double buffering with one barrier per stage.  The pixel range is split over blockIdx.y
+// (the reduction is the long axis here: 5 000 - 83 000 pixels against 64 x 64 outputs); with more than one split
+// the partial tiles go to the workspace and wgrad_reduce_kernel adds them in split order (deterministic) while
+// transposing to the OIHW layout of nn.Conv2d.weight.grad.
+#include "common.hpp"
+
+using namespace sgv3d;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kStagePix = 64;
+
+struct WgradArgs {
+    const float *x, *dy;
+    float *dw, *ws;
+    int batch, in_h, in_w, cin, out_h, out_w, cout, kh, kw, stride, pad, dil;
+    int x_ld, x_coff, y_ld, y_coff;
+    int tiles_co, tiles_ci, taps, split, pix_total, pix_per_split;
+    int vec_x, vec_y;   // 1: 16-byte loads are aligned and inside the channel range
+};
+
+__device__ __forceinline__ float4 load4_guard(const float *p, int c, int cmax, bool vec, bool ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!ok) return v;
+    if (vec && c + 3 < cmax) return *reinterpret_cast<const float4 *>(p);
+    if (c < cmax) v.x = p[0];
+    if (c + 1 < cmax) v.y = p[1];
+    if (c + 2 < cmax) v.z = p[2];
+    if (c + 3 < cmax) v.w = p[3];
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float sA[2][kStagePix][64];
+    __shared__ __attribute__((aligned(16))) float sB[2][kStagePix][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
+    int bid = blockIdx.x;
+    const int tci = bid % a.tiles_ci; bid /= a.tiles_ci;
+    const int tco = bid % a.tiles_co; bid /= a.tiles_co;
+    const int tap = bid;
+    const int th = tap / a.kw, tw = tap - th * a.kw;
+    const int co0 = tco * 64, ci0 = tci * 64;
+    const int pix_begin = blockIdx.y * a.pix_per_split;
+    const int pix_end = min(pix_begin + a.pix_per_split, a.pix_total);
+    const int c4 = (tid & 15) * 4, prow = tid >> 4;   // this thread stages pixels prow + 16 i, channels c4 .. c4 + 3
+    const int hw = a.out_h * a.out_w;
+
+    float4 ra[4], rb[4];
+    auto load_stage = [&](int p0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pix = p0 + prow + 16 * i;
+            const bool inside = pix < pix_end;
+            const int img = pix / hw, rem = pix - img * hw;
+            const int oy = rem / a.out_w, ox = rem - oy * a.out_w;
+            ra[i] = load4_guard(a.dy + (size_t)pix * a.y_ld + a.y_coff + co0 + c4, co0 + c4, a.cout, a.vec_y, inside);
+            const int iy = oy * a.stride - a.pad + th * a.dil, ix = ox * a.stride - a.pad + tw * a.dil;
+            const bool in_img = inside && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
+            rb[i] = load4_guard(a.x + ((size_t)(img * a.in_h + iy) * a.in_w + ix) * a.x_ld + a.x_coff + ci0 + c4,
+                                ci0 + c4, a.cin, a.vec_x, in_img);
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4 *>(&sA[buf][prow + 16 * i][c4]) = ra[i];
+            *reinterpret_cast<float4 *>(&sB[buf][prow + 16 * i][c4]) = rb[i];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    load_stage(pix_begin);
+    store_stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int p0 = pix_begin; p0 < pix_end; p0 += kStagePix) {
+        const bool more = p0 + kStagePix < pix_end;
+        if (more) load_stage(p0 + kStagePix);
+        const float *pa = &sA[buf][half][wm * 32 + l32];
+        const float *pb = &sB[buf][half][wn * 32 + l32];
+#pragma unroll
+        for (int j = 0; j < kStagePix / 2; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j * 128], pb[j * 128], acc, 0, 0, 0);
+        if (more) store_stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    const int ci = ci0 + wn * 32 + l32;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wm * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
+        if (co >= a.cout || ci >= a.cin) continue;
+        if (a.split > 1)
+            a.ws[(((size_t)blockIdx.y * a.taps + tap) * a.cout + co) * a.cin + ci] = acc[e];
+        else
+            a.dw[((size_t)co * a.cin + ci) * a.taps + tap] = acc[e];
+    }
+}
+
+// i = (tap, co, ci) with ci fastest: coalesced partial reads, split order fixed.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
+    const long long total = (long long)a.taps * a.cout * a.cin;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float v = 0.f;
+    for (int s = 0; s < a.split; ++s) v += a.ws[(size_t)s * total + i];
+    const int ci = (int)(i % a.cin);
+    const long long r = i / a.cin;
+    const int co = (int)(r % a.cout), tap = (int)(r / a.cout);
+    a.dw[((size_t)co * a.cin + ci) * a.taps + tap] = v;
+}
+
+__global__ __launch_bounds__(256) void zero_insert_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int batch,
+                                                           int in_h, int in_w, int c4, int stride, int out_h, int out_w) {
+    const long long total = (long long)batch * out_h * out_w * c4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % c4);
+        long long r = i / c4;
+        const int ox = (int)(r % out_w); r /= out_w;
+        const int oy = (int)(r % out_h);
+        const int img = (int)(r / out_h);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (oy % stride == 0 && ox % stride == 0 && oy / stride < in_h && ox / stride < in_w)
+            v = x[((size_t)(img * in_h + oy / stride) * in_w + ox / stride) * c4 + c];
+        y[i] = v;
+    }
+}
+
+int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a) {
+    SGV3D_REQUIRE(d, "conv2d_backward_weight: null descriptor");
+    SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->out_h > 0 && d->out_w > 0,
+                  "conv2d_backward_weight: bad sizes");
+    SGV3D_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0, "conv2d_backward_weight: bad kernel geometry");
+    SGV3D_REQUIRE(d->x_ld >= d->x_coff + d->cin && d->y_ld >= d->y_coff + d->cout, "conv2d_backward_weight: channel strides too small");
+    SGV3D_REQUIRE(d->out_h == (d->in_h + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1 &&
+                  d->out_w == (d->in_w + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1,
+                  "conv2d_backward_weight: output size does not belong to this input size");
+    const long long pix = (long long)d->batch * d->out_h * d->out_w;
+    SGV3D_REQUIRE(pix < (1ll << 31) && (long long)d->batch * d->in_h * d->in_w < (1ll << 31), "conv2d_backward_weight: too many pixels");
+    a = WgradArgs{};
+    a.batch = d->batch; a.in_h = d->in_h; a.in_w = d->in_w; a.cin = d->cin; a.out_h = d->out_h; a.out_w = d->out_w;
+    a.cout = d->cout; a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+    a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff;
+    a.tiles_co = cdiv(d->cout, 64); a.tiles_ci = cdiv(d->cin, 64); a.taps = d->kh * d->kw;
+    a.pix_total = (int)pix;
+    const long long tiles = (long long)a.tiles_co * a.tiles_ci * a.taps;
+    SGV3D_REQUIRE(tiles < (1ll << 31), "conv2d_backward_weight: too many tiles");
+    const int stages = cdiv(pix, kStagePix);
+    if (split <= 0) {   // aim at ~6 workgroups per CU, at least 4 stages each
+        split = (int)((1536 + tiles - 1) / tiles);
+        split = split < 1 ? 1 : split;
+        const int cap = stages / 4 > 0 ? stages / 4 : 1;
+        split = split > cap ? cap : split;
+    }
+    split = split > stages ? stages : split;
+    split = split > 65535 ? 65535 : split;
+    a.pix_per_split = cdiv(stages, split) * kStagePix;
+    a.split = cdiv(pix, a.pix_per_split);
+    a.vec_x = (d->x_ld % 4 == 0 && d->x_coff % 4 == 0) ? 1 : 0;
+    a.vec_y = (d->y_ld % 4 == 0 && d->y_coff % 4 == 0) ? 1 : 0;
+    return SGV3D_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sgv3d_conv2d_backward_weight_workspace_bytes(const sgv3d_conv_desc *d, int split) {
+    WgradArgs a;
+    if (fill_args(d, split, a) != SGV3D_OK) return 0;
+    return a.split > 1 ? (size_t)a.split * a.taps * a.cout * a.cin * sizeof(float) : 0;
+}
+
+extern "C" int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *d, const float *x, const float *dy, float *dw,
+                                            int split, void *workspace, size_t workspace_bytes, void *stream) {
+    WgradArgs a;
+    if (int rc = fill_args(d, split, a)) return rc;
+    SGV3D_REQUIRE(x && dy && dw, "conv2d_backward_weight: null pointer");
+    SGV3D_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv2d_backward_weight: x / dy must be 16-byte aligned");
+    const size_t need = a.split > 1 ? (size_t)a.split * a.taps * a.cout * a.cin * sizeof(float) : 0;
+    SGV3D_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "conv2d_backward_weight: workspace too small (%zu < %zu)",
+                  workspace_bytes, need);
+    a.x = x; a.dy = dy; a.dw = dw; a.ws = static_cast<float *>(workspace);
+    hipStream_t st = as_stream(stream);
+    conv_wgrad_kernel<<<dim3(a.tiles_co * a.tiles_ci * a.taps, a.split), 256, 0, st>>>(a);
+    if (int rc = check_launch("conv_wgrad_kernel")) return rc;
+    if (a.split > 1) {
+        const long long total = (long long)a.taps * a.cout * a.cin;
+        wgrad_reduce_kernel<<<cdiv(total, 256), 256, 0, st>>>(a);
+        return check_launch("wgrad_reduce_kernel");
+    }
+    return SGV3D_OK;
+}
+
+extern "C" int sgv3d_zero_insert(int batch, int in_h, int in_w, int channels, int stride, int out_h, int out_w,
+                                 const float *x, float *y, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && in_h > 0 && in_w > 0 && channels > 0 && stride > 0, "zero_insert: bad sizes");
+    SGV3D_REQUIRE(channels % 4 == 0, "zero_insert: channels must be a multiple of 4");
+    SGV3D_REQUIRE(out_h >= (in_h - 1) * stride + 1 && out_w >= (in_w - 1) * stride + 1, "zero_insert: output too small");
+    SGV3D_REQUIRE(x && y, "zero_insert: null pointer");
+    const long long total = (long long)batch * out_h * out_w * (channels / 4);
+    const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
+    zero_insert_kernel<<<blocks, 256, 0, as_stream(stream)>>>(reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y),
+                                                             batch, in_h, in_w, channels / 4, stride, out_h, out_w);
+    return check_launch("zero_insert_kernel");
+}

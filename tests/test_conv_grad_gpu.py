@@ -1,0 +1,106 @@
+"""Convolution backward on the MI355X against torch autograd in float64 on the CPU:
+weight gradient kernel, data gradient through the forward kernels, and the autograd function."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from sgv3d_amd import conv_grad
+
+pytestmark = pytest.mark.gpu
+
+# (batch, cin, H, W, cout, k, stride, pad, dil)
+SHAPES = [
+    (2, 64, 20, 28, 64, 3, 1, 1, 1),        # ResNet layer1 3x3
+    (1, 64, 24, 40, 256, 1, 1, 0, 1),       # bottleneck expand
+    (2, 128, 21, 27, 128, 3, 2, 1, 1),      # strided 3x3, odd sizes
+    (1, 256, 18, 26, 512, 1, 2, 0, 1),      # downsample branch
+    (1, 4, 38, 50, 64, 7, 2, 3, 1),         # stem (3 channels padded to 4)
+    (1, 128, 20, 24, 128, 3, 1, 6, 6),      # ASPP dilated
+    (2, 80, 16, 16, 160, 3, 1, 1, 1),       # BEV trunk widths (not multiples of 64)
+    (1, 96, 12, 20, 18, 3, 1, 1, 1),        # DCN offset conv: cout % 4 != 0
+    (1, 64, 16, 16, 32, 4, 4, 0, 1),        # neck patchify conv (kernel == stride)
+    (3, 32, 9, 11, 48, 3, 1, 1, 1),         # tiny, several images
+]
+
+
+def _reference(x, w, dy, stride, pad, dil):
+    xr = x.double().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wr = w.double().clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, stride, pad, dil)
+    y.backward(dy.double().permute(0, 3, 1, 2))
+    return y.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1), wr.grad
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv_backward_matches_autograd(shape):
+    B, cin, H, W, cout, k, s, p, d = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, H, W, cin, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    oh = (H + 2 * p - d * (k - 1) - 1) // s + 1
+    ow = (W + 2 * p - d * (k - 1) - 1) // s + 1
+    dy = torch.randn(B, oh, ow, cout, generator=g)
+    y_ref, dx_ref, dw_ref = _reference(x, w, dy, s, p, d)
+    xg = x.cuda().requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    y = conv_grad.conv2d(xg, wg, None, s, p, d)
+    assert float((y.detach().cpu().double() - y_ref).abs().max()) <= 1e-5 * float(y_ref.abs().max())
+    y.backward(dy.cuda())
+    for name, got, want in (("dx", xg.grad, dx_ref), ("dw", wg.grad, dw_ref)):
+        err = float((got.cpu().double() - want).abs().max())
+        assert err <= 2e-5 * float(want.abs().max()), (name, err, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("split", [1, 2, 5, 0])
+def test_wgrad_split_variants_and_channel_windows(split):
+    g = torch.Generator().manual_seed(split)
+    B, H, W = 2, 19, 23
+    x_full = torch.randn(B, H, W, 96, generator=g)
+    dy_full = torch.randn(B, H, W, 80, generator=g)
+    x, dy = x_full[..., 16:80], dy_full[..., 8:72]          # 64-channel windows of wider buffers
+    w = torch.zeros(64, 64, 3, 3)
+    _, _, dw_ref = _reference(x, w, dy, 1, 1, 1)
+    dw = conv_grad.conv2d_backward_weight(x_full.cuda(), dy_full.cuda(), 3, 1, 1, 1, cin=64, cout=64, x_coff=16, y_coff=8, split=split)
+    assert float((dw.cpu().double() - dw_ref).abs().max()) <= 2e-5 * float(dw_ref.abs().max())
+    again = conv_grad.conv2d_backward_weight(x_full.cuda(), dy_full.cuda(), 3, 1, 1, 1, cin=64, cout=64, x_coff=16, y_coff=8, split=split)
+    assert torch.equal(dw, again)                            # fixed-order reduction
+
+
+def test_wgrad_is_exact_on_small_integers():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-3, 4, (2, 30, 34, 64), generator=g).float()
+    dy = torch.randint(-2, 3, (2, 30, 34, 128), generator=g).float()
+    _, _, dw_ref = _reference(x, torch.zeros(128, 64, 3, 3), dy, 1, 1, 1)
+    dw = conv_grad.conv2d_backward_weight(x.cuda(), dy.cuda(), 3, 1, 1, 1)
+    assert torch.equal(dw.cpu().double(), dw_ref)
+
+
+def test_transposed_conv_weight_gradient_by_role_swap():
+    """ConvTranspose2d(kernel == stride): dW[ci][co][ky][kx] = wgrad of the equivalent strided conv with x and dy swapped."""
+    g = torch.Generator().manual_seed(2)
+    B, cin, cout, H, W, k = 1, 64, 32, 10, 12, 2
+    x = torch.randn(B, H, W, cin, generator=g)
+    w = torch.randn(cin, cout, k, k, generator=g)
+    dy = torch.randn(B, H * k, W * k, cout, generator=g)
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    F.conv_transpose2d(xr, wr, stride=k).backward(dy.double().permute(0, 3, 1, 2))
+    dw = conv_grad.conv2d_backward_weight(dy.cuda(), x.cuda(), k, k, 0, 1)       # roles swapped
+    assert float((dw.cpu().double() - wr.grad).abs().max()) <= 2e-5 * float(wr.grad.abs().max())
+
+
+def test_bias_gradient_and_chain():
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 14, 18, 32, generator=g)
+    w1 = torch.randn(64, 32, 3, 3, generator=g) * 0.1
+    b1 = torch.randn(64, generator=g)
+    w2 = torch.randn(16, 64, 1, 1, generator=g) * 0.1
+    params = [t.cuda().requires_grad_(True) for t in (x, w1, b1, w2)]
+    out = conv_grad.conv2d(torch.relu(conv_grad.conv2d(params[0], params[1], params[2], 1, 1, 1)), params[3])
+    out.square().sum().backward()
+    ref = [t.double().requires_grad_(True) for t in (x, w1, b1, w2)]
+    r = F.conv2d(torch.relu(F.conv2d(ref[0].permute(0, 3, 1, 2), ref[1], ref[2], 1, 1)), ref[3])
+    r.square().sum().backward()
+    for got, want in zip(params, ref):
+        wg = want.grad
+        assert float((got.grad.cpu().double() - wg).abs().max()) <= 5e-5 * float(wg.abs().max())
