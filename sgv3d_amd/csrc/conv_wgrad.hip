@@ -30,19 +30,10 @@ struct WgradArgs {
     int batch, in_h, in_w, cin, out_h, out_w, cout, kh, kw, stride, pad, dil;
     int x_ld, x_coff, y_ld, y_coff;
     int tiles_co, tiles_ci, taps, split, pix_total, pix_per_split;
-    int vec_x, vec_y;   // 1: 16-byte loads are aligned and inside the channel range
+    unsigned x_bytes, y_bytes;   // extents of x / dy from their base pointers (buffer resources)
 };
 
-__device__ __forceinline__ float4 load4_guard(const float *p, int c, int cmax, bool vec, bool ok) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!ok) return v;
-    if (vec && c + 3 < cmax) return *reinterpret_cast<const float4 *>(p);
-    if (c < cmax) v.x = p[0];
-    if (c + 1 < cmax) v.y = p[1];
-    if (c + 2 < cmax) v.z = p[2];
-    if (c + 3 < cmax) v.w = p[3];
-    return v;
-}
+typedef float f32x4n __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float sA[2][kStagePix][64];
@@ -60,26 +51,45 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     const int c4 = (tid & 15) * 4, prow = tid >> 4;   // this thread stages pixels prow + 16 i, channels c4 .. c4 + 3
     const int hw = a.out_h * a.out_w;
 
-    float4 ra[4], rb[4];
+    // Branch-free staging: buffer loads return zeros for the offset 0xffffffff (pixels past the range, taps that
+    // fall outside the image).  Channel tails are loaded as they come: they only reach discarded rows / columns.
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)a.y_bytes, 0x00020000);
+    const unsigned x_c = (unsigned)(a.x_coff + ci0 + c4) * 4u, y_c = (unsigned)(a.y_coff + co0 + c4) * 4u;
+    // (image, oy, ox) of the first pixel of the stage being loaded, advanced by 64 pixels per stage
+    int s_img = pix_begin / hw;
+    int s_oy = (pix_begin - s_img * hw) / a.out_w;
+    int s_ox = pix_begin - s_img * hw - s_oy * a.out_w;
+
+    f32x4n ra[4], rb[4];
     auto load_stage = [&](int p0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int pix = p0 + prow + 16 * i;
-            const bool inside = pix < pix_end;
-            const int img = pix / hw, rem = pix - img * hw;
-            const int oy = rem / a.out_w, ox = rem - oy * a.out_w;
-            ra[i] = load4_guard(a.dy + (size_t)pix * a.y_ld + a.y_coff + co0 + c4, co0 + c4, a.cout, a.vec_y, inside);
+            const int off = prow + 16 * i;
+            int img = s_img, oy = s_oy, ox = s_ox + off;
+            while (ox >= a.out_w) {
+                ox -= a.out_w;
+                if (++oy == a.out_h) { oy = 0; ++img; }
+            }
+            const bool inside = p0 + off < pix_end;
+            const unsigned yo = inside ? (unsigned)(p0 + off) * (unsigned)(a.y_ld * 4) + y_c : 0xffffffffu;
+            ra[i] = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, yo, 0, 0));
             const int iy = oy * a.stride - a.pad + th * a.dil, ix = ox * a.stride - a.pad + tw * a.dil;
             const bool in_img = inside && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
-            rb[i] = load4_guard(a.x + ((size_t)(img * a.in_h + iy) * a.in_w + ix) * a.x_ld + a.x_coff + ci0 + c4,
-                                ci0 + c4, a.cin, a.vec_x, in_img);
+            const unsigned xo = in_img ? (unsigned)((img * a.in_h + iy) * a.in_w + ix) * (unsigned)(a.x_ld * 4) + x_c : 0xffffffffu;
+            rb[i] = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xo, 0, 0));
+        }
+        s_ox += kStagePix;
+        while (s_ox >= a.out_w) {
+            s_ox -= a.out_w;
+            if (++s_oy == a.out_h) { s_oy = 0; ++s_img; }
         }
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4 *>(&sA[buf][prow + 16 * i][c4]) = ra[i];
-            *reinterpret_cast<float4 *>(&sB[buf][prow + 16 * i][c4]) = rb[i];
+            *reinterpret_cast<f32x4n *>(&sA[buf][prow + 16 * i][c4]) = ra[i];
+            *reinterpret_cast<f32x4n *>(&sB[buf][prow + 16 * i][c4]) = rb[i];
         }
     };
 
@@ -96,9 +106,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
         if (more) load_stage(p0 + kStagePix);
         const float *pa = &sA[buf][half][wm * 32 + l32];
         const float *pb = &sB[buf][half][wn * 32 + l32];
+        // fragments of 16 k-steps at a time in registers, the second batch in flight under the first MFMAs
+        float fa0[16], fb0[16], fa1[16], fb1[16];
 #pragma unroll
-        for (int j = 0; j < kStagePix / 2; ++j)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j * 128], pb[j * 128], acc, 0, 0, 0);
+        for (int j = 0; j < 16; ++j) { fa0[j] = pa[j * 128]; fb0[j] = pb[j * 128]; }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { fa1[j] = pa[(16 + j) * 128]; fb1[j] = pb[(16 + j) * 128]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j], fb0[j], acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[j], fb1[j], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (more) store_stage(buf ^ 1);
         __syncthreads();
         buf ^= 1;
@@ -165,8 +184,10 @@ int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a) {
     const long long tiles = (long long)a.tiles_co * a.tiles_ci * a.taps;
     SGV3D_REQUIRE(tiles < (1ll << 31), "conv2d_backward_weight: too many tiles");
     const int stages = cdiv(pix, kStagePix);
-    if (split <= 0) {   // aim at ~6 workgroups per CU, at least 4 stages each
-        split = (int)((1536 + tiles - 1) / tiles);
+    if (split <= 0) {   // measured on cfg-2 layers: ~64 pixel ranges per tile, between 1 and 6 workgroups per CU in total
+        long long target = tiles * 64;
+        target = target < 256 ? 256 : (target > 1536 ? 1536 : target);
+        split = (int)((target + tiles - 1) / tiles);
         split = split < 1 ? 1 : split;
         const int cap = stages / 4 > 0 ? stages / 4 : 1;
         split = split > cap ? cap : split;
@@ -175,8 +196,10 @@ int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a) {
     split = split > 65535 ? 65535 : split;
     a.pix_per_split = cdiv(stages, split) * kStagePix;
     a.split = cdiv(pix, a.pix_per_split);
-    a.vec_x = (d->x_ld % 4 == 0 && d->x_coff % 4 == 0) ? 1 : 0;
-    a.vec_y = (d->y_ld % 4 == 0 && d->y_coff % 4 == 0) ? 1 : 0;
+    const unsigned long long xb = (unsigned long long)d->batch * d->in_h * d->in_w * d->x_ld * 4ull;
+    const unsigned long long yb = (unsigned long long)pix * d->y_ld * 4ull;
+    SGV3D_REQUIRE(xb < 0xf0000000ull && yb < 0xf0000000ull, "conv2d_backward_weight: x / dy must be smaller than 3.75 GiB");
+    a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
     return SGV3D_OK;
 }
 
@@ -193,7 +216,7 @@ extern "C" int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *d, const floa
     WgradArgs a;
     if (int rc = fill_args(d, split, a)) return rc;
     SGV3D_REQUIRE(x && dy && dw, "conv2d_backward_weight: null pointer");
-    SGV3D_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv2d_backward_weight: x / dy must be 16-byte aligned");
+    SGV3D_REQUIRE(((uintptr_t)x & 3) == 0 && ((uintptr_t)dy & 3) == 0, "conv2d_backward_weight: x / dy must be 4-byte aligned");
     const size_t need = a.split > 1 ? (size_t)a.split * a.taps * a.cout * a.cin * sizeof(float) : 0;
     SGV3D_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "conv2d_backward_weight: workspace too small (%zu < %zu)",
                   workspace_bytes, need);
