@@ -404,6 +404,14 @@ int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *desc /*host*/, const flo
 int sgv3d_zero_insert(int batch, int in_h, int in_w, int channels, int stride, int out_h, int out_w,
                       const float *x, float *y, void *stream);
 
+/* One fused AdamW step (torch.optim.AdamW semantics, amsgrad off) over a flat fp32 bucket of n parameters:
+ * the optimiser of the reference's configure_optimizers (exps/...:298-305).  grad is multiplied by grad_scale
+ * first (1 / world size after a sum all-reduce).  step >= 1 is the step count after this update.  All four
+ * buffers 16-byte aligned. */
+int sgv3d_adamw_step(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int step,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,65 @@
+// Fused AdamW update over a flat fp32 parameter bucket (the optimiser step of
+// exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:298-305, torch.optim.AdamW(lr, weight_decay=1e-7)).
+// One pass over HBM: reads p, g, m, v (16 B per parameter), writes p, m, v (12 B); the gradient average over the
+// data-parallel ranks (1 / world size) is folded in as grad_scale, so the all-reduced sum needs no pass of its own.
+// Arithmetic follows torch's single-tensor AdamW step operation by operation (decoupled decay first, bias
+// corrections as step_size = lr / (1 - beta1^t) and denom = sqrt(v) / sqrt(1 - beta2^t) + eps).
+#include "common.hpp"
+
+using namespace sgv3d;
+
+namespace {
+
+struct AdamArgs {
+    float *p, *m, *v;
+    const float *g;
+    long long n;
+    float lr, beta1, beta2, eps, wd, grad_scale, step_size, inv_sqrt_bc2;
+};
+
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, const AdamArgs &a) {
+    g *= a.grad_scale;
+    p *= 1.f - a.lr * a.wd;
+    m = m * a.beta1 + g * (1.f - a.beta1);          // lerp(m, g, 1 - beta1)
+    v = v * a.beta2 + (g * g) * (1.f - a.beta2);
+    const float denom = sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
+    p -= a.step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
+    const long long n4 = a.n / 4;
+    float4 *p4 = reinterpret_cast<float4 *>(a.p), *m4 = reinterpret_cast<float4 *>(a.m), *v4 = reinterpret_cast<float4 *>(a.v);
+    const float4 *g4 = reinterpret_cast<const float4 *>(a.g);
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += gridDim.x * 256ll) {
+        float4 p = p4[i], m = m4[i], v = v4[i];
+        const float4 g = g4[i];
+        adam_one(p.x, g.x, m.x, v.x, a);
+        adam_one(p.y, g.y, m.y, v.y, a);
+        adam_one(p.z, g.z, m.z, v.z, a);
+        adam_one(p.w, g.w, m.w, v.w, a);
+        p4[i] = p; m4[i] = m; v4[i] = v;
+    }
+    for (long long i = n4 * 4 + blockIdx.x * 256ll + threadIdx.x; i < a.n; i += gridDim.x * 256ll)
+        adam_one(a.p[i], a.g[i], a.m[i], a.v[i], a);
+}
+
+}  // namespace
+
+extern "C" int sgv3d_adamw_step(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                                int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                float grad_scale, void *stream) {
+    SGV3D_REQUIRE(n >= 0 && step >= 1, "adamw_step: bad n / step");
+    if (n == 0) return SGV3D_OK;
+    SGV3D_REQUIRE(param && grad && exp_avg && exp_avg_sq, "adamw_step: null pointer");
+    SGV3D_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                  "adamw_step: buffers must be 16-byte aligned");
+    AdamArgs a{};
+    a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.grad_scale = grad_scale;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    a.step_size = (float)((double)lr / bc1);
+    a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const long long blocks = (n / 4 + 255) / 256 + 1;
+    adamw_kernel<<<(int)(blocks < 4096 ? blocks : 4096), 256, 0, as_stream(stream)>>>(a);
+    return check_launch("adamw_kernel");
+}

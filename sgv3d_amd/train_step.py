@@ -1,0 +1,129 @@
+"""Data-parallel optimiser step (BASELINE config 4: global batch 32 over 8 MI355X).
+
+The reference wraps the model in Lightning's DDP (exps/base_cli.py:57-58 ``accelerator='ddp'``) and steps
+``torch.optim.AdamW(lr = 2e-4 / 64 * batch * gpus, weight_decay=1e-7)`` under ``MultiStepLR([19, 23])``
+(exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:197,298-305).  Here:
+
+* ``FlatParams`` re-homes every parameter and its gradient as views of a few large flat fp32 buffers (buckets) in
+  reverse registration order -- the order backward produces gradients in -- so a bucket is ONE contiguous RCCL
+  all-reduce and ONE fused AdamW launch.  Buckets default to 256 MiB: xGMI is point-to-point (7 links, ~153 GB/s each),
+  a ring all-reduce is bound by one link, and the 288 GB of HBM make large buckets free; the ~0.4 GB of BEVHeight-R50
+  gradients are two collectives per step.
+* ``all_reduce_grads`` launches the sum all-reduces asynchronously on torch's RCCL stream (``async_op=True``) as soon
+  as it is called per bucket; the 1 / world factor is folded into the AdamW kernel (no averaging pass over HBM).
+* ``step`` waits for each bucket's collective and runs ``sgv3d_adamw_step`` on it.
+
+With the "gloo" backend and CPU tensors (the world-size-2 tests) the collectives run through gloo; the fused update
+itself needs the GPU library and raises without it.
+"""
+import torch
+
+from . import _lib
+
+__all__ = ['FlatParams', 'DataParallelAdamW', 'reference_lr', 'multistep_lr']
+
+
+def reference_lr(batch_size_per_device, gpus, basic_lr_per_img=2e-4 / 64):
+    """exps/...:197,299: lr = basic_lr_per_img * batch_size_per_device * gpus."""
+    return basic_lr_per_img * batch_size_per_device * gpus
+
+
+def multistep_lr(base_lr, epoch, milestones=(19, 23), gamma=0.1):
+    """torch.optim.lr_scheduler.MultiStepLR as a function of the epoch (exps/...:303)."""
+    return base_lr * gamma ** sum(1 for m in milestones if epoch >= m)
+
+
+class FlatParams:
+    def __init__(self, params, bucket_bytes=256 << 20):
+        params = [p for p in params if p.requires_grad]
+        assert params, "no trainable parameters"
+        assert all(p.dtype == torch.float32 for p in params), "fp32 parameters only"
+        self.params = params
+        dev = params[0].device
+        order = list(reversed(params))                 # backward reaches the last layers first
+        self.buckets = []                              # (flat_param, flat_grad, [(param, offset, numel)])
+        cur, cur_n = [], 0
+        limit = max(1, bucket_bytes // 4)
+        for p in order:
+            n = (p.numel() + 3) // 4 * 4               # keep every view 16-byte aligned
+            if cur and cur_n + n > limit:
+                self._close(cur, cur_n, dev)
+                cur, cur_n = [], 0
+            cur.append((p, cur_n, p.numel()))
+            cur_n += n
+        self._close(cur, cur_n, dev)
+
+    def _close(self, entries, n, dev):
+        flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, off, cnt in entries:
+            flat_p[off:off + cnt].copy_(p.data.reshape(-1))
+            p.data = flat_p[off:off + cnt].view(p.shape)
+            p.grad = flat_g[off:off + cnt].view(p.shape)
+        self.buckets.append((flat_p, flat_g, entries))
+
+    def zero_grad(self):
+        for _, g, _ in self.buckets:
+            g.zero_()
+
+    def check_views(self):
+        """Gradients must still live in the flat buffers (an optimiser / autograd that replaced ``p.grad`` would
+        silently cut the bucket out of the all-reduce)."""
+        for flat_p, flat_g, entries in self.buckets:
+            for p, off, cnt in entries:
+                if p.grad is None or p.grad.data_ptr() != flat_g.data_ptr() + off * 4:
+                    raise _lib.SGV3DError("a parameter's .grad no longer aliases its bucket; use zero_grad() of FlatParams")
+                if p.data_ptr() != flat_p.data_ptr() + off * 4:
+                    raise _lib.SGV3DError("a parameter no longer aliases its bucket")
+
+
+class DataParallelAdamW:
+    """AdamW over ``FlatParams`` with the gradient all-reduce of the data-parallel step."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7, bucket_bytes=256 << 20, group=None):
+        self.flat = params if isinstance(params, FlatParams) else FlatParams(params, bucket_bytes)
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
+        self.group = group
+        self.state = [(torch.zeros_like(p), torch.zeros_like(p)) for p, _, _ in self.flat.buckets]
+        self.steps = 0
+        self._pending = []
+
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group)
+        return 1
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    def all_reduce_grads(self):
+        """Start the sum all-reduce of every bucket (asynchronous; ``step`` waits per bucket)."""
+        import torch.distributed as dist
+        self._pending = []
+        if self._world() == 1:
+            return
+        for _, g, _ in self.flat.buckets:
+            self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def step(self, lr=None):
+        """One AdamW update of every bucket with the averaged gradients (call ``all_reduce_grads`` first when the
+        process group has more than one rank)."""
+        lr = self.lr if lr is None else float(lr)
+        world = self._world()
+        if world > 1 and not self._pending:
+            self.all_reduce_grads()
+        self.flat.check_views()
+        self.steps += 1
+        lib = _lib.load()
+        for i, ((p, g, _), (m, v)) in enumerate(zip(self.flat.buckets, self.state)):
+            if self._pending:
+                self._pending[i].wait()
+            if not p.is_cuda:
+                raise _lib.SGV3DError("the fused AdamW update runs on the GPU (no CPU fallback)")
+            with torch.cuda.device(p.device):
+                rc = lib.sgv3d_adamw_step(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), self.steps, lr,
+                                          self.betas[0], self.betas[1], self.eps, self.weight_decay, 1.0 / world,
+                                          _lib.stream_handle(p.device))
+            _lib.check(rc, "sgv3d_adamw_step")
+        self._pending = []

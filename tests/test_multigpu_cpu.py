@@ -57,3 +57,63 @@ def test_shard_frames_single_process():
     assert shard_frames(list(range(5)), 0, 1) == [0, 1, 2, 3, 4]
     parts = [shard_frames(list(range(10)), r, 4) for r in range(4)]
     assert sorted(sum(parts, [])) == list(range(10)) and max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+TRAIN_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from sgv3d_amd.train_step import FlatParams, DataParallelAdamW
+    from sgv3d_amd._lib import SGV3DError
+
+    rank = int(os.environ["RANK"])
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    torch.manual_seed(0)                                     # same initial weights on both ranks
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 5, 1))
+    before = [p.detach().clone() for p in net.parameters()]
+    opt = DataParallelAdamW(net.parameters(), lr=1e-3, bucket_bytes=1024)     # tiny buckets: several collectives
+    assert len(opt.flat.buckets) >= 2
+    assert all(torch.equal(a, b) for a, b in zip(before, net.parameters()))   # re-homing keeps the values
+    torch.manual_seed(100 + rank)                            # different data per rank
+    x = torch.randn(4, 3, 10, 10)
+    opt.zero_grad()
+    net(x).square().mean().backward()                        # autograd accumulates into the bucket views
+    opt.flat.check_views()
+    local = [p.grad.detach().clone() for p in net.parameters()]
+    opt.all_reduce_grads()
+    for w in opt._pending:
+        w.wait()
+    gathered = [None, None]
+    dist.all_gather_object(gathered, [g.tolist() for g in local])
+    for i, p in enumerate(net.parameters()):
+        want = torch.tensor(gathered[0][i]) + torch.tensor(gathered[1][i])
+        assert torch.allclose(p.grad, want, rtol=1e-6, atol=1e-7), i
+    try:
+        opt.step()
+        raise AssertionError("the CPU must not have an optimiser path")
+    except SGV3DError as e:
+        assert "GPU" in str(e) or "missing" in str(e)
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"ok": True}))
+""") % ROOT
+
+
+def test_two_process_gloo_gradient_buckets(tmp_path):
+    script = tmp_path / "train_worker.py"
+    script.write_text(TRAIN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-2000:]
+    assert b'"ok": true' in outs[0][0]
+
+
+def test_learning_rate_rules():
+    from sgv3d_amd.train_step import reference_lr, multistep_lr
+    assert abs(reference_lr(4, 8) - 2e-4 / 64 * 32) < 1e-15          # config 4: global batch 32
+    assert multistep_lr(1.0, 0) == 1.0 and abs(multistep_lr(1.0, 19) - 0.1) < 1e-12 and abs(multistep_lr(1.0, 23) - 0.01) < 1e-12
