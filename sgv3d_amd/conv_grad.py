@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from .hip_ops import ConvDesc, PackedConv, prof, _st
 
-__all__ = ['conv2d_backward_weight', 'conv2d_backward_data', 'zero_insert', 'conv2d']
+__all__ = ['conv2d_backward_weight', 'conv2d_backward_data', 'zero_insert', 'conv2d', 'conv_transpose2d']
 
 
 def _out_hw(h, w, k, stride, pad, dil):
@@ -107,3 +107,37 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1):
     """``F.conv2d`` on NHWC float32 CUDA tensors through the HIP kernels, differentiable in ``x``, ``weight``, ``bias``.
     ``x`` may carry zero padding channels beyond ``weight.shape[1]`` (a multiple of 4 is required)."""
     return _Conv2dNHWC.apply(x, weight, bias, int(stride), int(pad), int(dil))
+
+
+class _ConvTranspose2dNHWC(torch.autograd.Function):
+    """nn.ConvTranspose2d with kernel == stride (the SECONDFPN deblocks): every input pixel owns a k x k output patch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride):
+        assert int(weight.shape[2]) == int(weight.shape[3]) == stride
+        ctx.save_for_backward(x, weight)
+        ctx.stride = stride
+        return PackedConv(weight, stride=stride, transposed=True, cin_pad=int(x.shape[-1]))(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        k = ctx.stride
+        dy = dy.contiguous()
+        cin, cout = int(weight.shape[0]), int(weight.shape[1])
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # dX[i, j, ci] = sum_{dy, dx, co} dY[i k + dy, j k + dx, co] W[ci, co, dy, dx]: a stride-k convolution of dY
+            # whose OIHW weight is W as stored
+            dyp = dy if int(dy.shape[-1]) % 4 == 0 else torch.nn.functional.pad(dy, (0, 4 - int(dy.shape[-1]) % 4))
+            dx = PackedConv(weight, stride=k, cin_pad=int(dyp.shape[-1]), pad_out=True)(dyp)
+            if int(dx.shape[-1]) != int(x.shape[-1]):
+                dx = torch.nn.functional.pad(dx, (0, int(x.shape[-1]) - int(dx.shape[-1])))
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_backward_weight(dy, x, k, k, 0, 1, cin=cout, cout=cin)      # roles swapped: OIHW = [cin, cout, k, k]
+        return dx, dw, None
+
+
+def conv_transpose2d(x, weight, stride):
+    """``F.conv_transpose2d`` (kernel == stride, no bias) on NHWC float32 CUDA tensors, differentiable."""
+    return _ConvTranspose2dNHWC.apply(x, weight, int(stride))

@@ -63,6 +63,13 @@ class BEVHeight(nn.Module):
                 m._hip = None
         self._param_stamp = None
 
+    def train(self, mode=True):
+        """Switching between training and inference drops the packed inference weights: the fused optimiser step
+        (train_step.DataParallelAdamW) writes parameters through raw pointers, which no version counter records."""
+        super().train(mode)
+        self.refresh()
+        return self
+
     def forward(self, x, mats_dict, timestamps=None):
         """Images -> per-task prediction maps, as models/bev_height.py:42-80 does.
 
@@ -72,8 +79,11 @@ class BEVHeight(nn.Module):
         [B, num_sweeps, num_cams], 'bda_mat' as [B, 4, 4].  ``timestamps`` is ignored here as it is there.
         Result: one single-element list per task holding a dict of NCHW maps (reg, height, dim, rot, vel,
         heatmap) -- the nesting mmdet3d's CenterHead produces."""
-        if self.is_train_height and self.training:
-            raise NotImplementedError("training forward (height_pred branch) is SURVEY §8(f) rank 2")
+        if self.training:
+            if self.is_train_height:
+                raise NotImplementedError("the height_pred output of is_train_height (models/bev_height.py:62-70) is not built")
+            from ..train_forward import bevheight_train_forward
+            return bevheight_train_forward(self, x, mats_dict)          # differentiable (SURVEY §8(f) rank 2)
         stamp = self._stamp()
         if stamp != self._param_stamp:
             self.refresh()

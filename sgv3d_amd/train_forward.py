@@ -1,0 +1,215 @@
+"""Training-mode forward of ``BEVHeight``, differentiable end to end.
+
+The reference trains the same modules through autograd with cuDNN behind every convolution
+(exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:224-240).  Here the layers that carry the flops and
+the HBM traffic run on the hand-written kernels, forward and backward:
+
+* every nn.Conv2d / nn.ConvTranspose2d -> ``conv_grad.conv2d`` / ``conv_transpose2d`` (MFMA implicit GEMM / Winograd
+  forward, data gradient through the same kernels, MFMA weight-gradient kernel);
+* the frustum geometry -> ``sgv3d_geometry_voxel_index`` (integer indices, no gradient);
+* the splat -> the ``voxel_pooling`` autograd operator (planned gather forward, gather backward);
+* targets / loss / optimiser -> ``BEVHeightHead.get_targets`` / ``.loss`` / ``train_step.DataParallelAdamW``.
+
+The layers in between -- BatchNorm with batch statistics, ReLU, max / average pooling, the 27-feature MLPs, the softmax
+over height bins, the bilinear sampling of the deformable convolution -- are HBM-bound glue and use torch operators on
+the same NHWC buffers in this round; they are next in line for fused HIP versions.  Activations are NHWC float32
+throughout (an NCHW view with channels-last strides is handed to the torch operators, no layout copies).
+
+Layer semantics follow the eval-mode HIP path module by module (layers/blocks.py, layers/backbones/lss_fpn.py,
+layers/heads/bev_height_head.py); the only differences are the ones training mode implies in the reference:
+BatchNorm uses and updates batch statistics, Dropout(0.5) in the ASPP is active.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import conv_grad, hip_ops
+from .layers import blocks
+from .layers.backbones import lss_fpn
+from .ops.voxel_pooling import voxel_pooling
+
+__all__ = ['bevheight_train_forward']
+
+
+def _nchw(x):            # NHWC tensor -> NCHW view (channels-last strides)
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x):            # NCHW tensor (any strides) -> contiguous NHWC
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def conv(m, x):
+    return conv_grad.conv2d(x, m.weight, m.bias, m.stride[0], m.padding[0], m.dilation[0])
+
+
+def bn(m, x):
+    y = F.batch_norm(_nchw(x), m.running_mean, m.running_var, m.weight, m.bias, m.training, m.momentum, m.eps)
+    return _nhwc(y)
+
+
+def basic_block(b, x):
+    identity = x if b.downsample is None else bn(b.downsample[1], conv(b.downsample[0], x))
+    out = F.relu(bn(b.bn1, conv(b.conv1, x)))
+    out = bn(b.bn2, conv(b.conv2, out))
+    return F.relu(out + identity)
+
+
+def bottleneck(b, x):
+    identity = x if b.downsample is None else bn(b.downsample[1], conv(b.downsample[0], x))
+    out = F.relu(bn(b.bn1, conv(b.conv1, x)))
+    out = F.relu(bn(b.bn2, conv(b.conv2, out)))
+    out = bn(b.bn3, conv(b.conv3, out))
+    return F.relu(out + identity)
+
+
+def block(b, x):
+    return bottleneck(b, x) if isinstance(b, blocks.Bottleneck) else basic_block(b, x)
+
+
+def resnet(r, x, use_maxpool=True):
+    x = F.relu(bn(r.bn1, conv(r.conv1, x)))
+    if use_maxpool:
+        x = _nhwc(F.max_pool2d(_nchw(x), 3, 2, 1))
+    outs = []
+    for i, name in enumerate(r.res_layers):
+        for b in getattr(r, name):
+            x = block(b, x)
+        if i in r.out_indices:
+            outs.append(x)
+    return outs
+
+
+def secondfpn(n, feats):
+    ups = []
+    for blk, f in zip(n.deblocks, feats):
+        layer = blk[0]
+        if isinstance(layer, nn.ConvTranspose2d):
+            y = conv_grad.conv_transpose2d(f, layer.weight, layer.stride[0])
+        else:
+            y = conv(layer, f)
+        ups.append(F.relu(bn(blk[1], y)))
+    return torch.cat(ups, -1)
+
+
+def aspp(a, x):
+    branches = [F.relu(bn(m.bn, conv(m.atrous_conv, x))) for m in (a.aspp1, a.aspp2, a.aspp3, a.aspp4)]
+    pooled = x.mean((1, 2), keepdim=True)                                  # AdaptiveAvgPool2d((1, 1))
+    g = a.global_avg_pool
+    x5 = F.relu(bn(g[2], F.conv2d(_nchw(pooled), g[1].weight).permute(0, 2, 3, 1)))
+    branches.append(x5.expand(-1, x.shape[1], x.shape[2], -1))             # bilinear upsampling of a 1x1 map = broadcast
+    y = F.relu(bn(a.bn1, conv(a.conv1, torch.cat(branches, -1).contiguous())))
+    return F.dropout(y, a.dropout.p, a.dropout.training)
+
+
+def deform_conv(d, x):
+    """mmcv DeformConv2dPack (3x3, pad 1, deform_groups 1): bilinear taps gathered with torch indexing (differentiable
+    in the input and the offsets), then one 1x1 HIP convolution per group over the (tap, channel) columns."""
+    B, H, W, C = (int(v) for v in x.shape)
+    offset = conv(d.conv_offset, x)                                        # [B, H, W, 18]: (dy, dx) per tap
+    ys = torch.arange(H, device=x.device, dtype=x.dtype).view(1, H, 1)
+    xs = torch.arange(W, device=x.device, dtype=x.dtype).view(1, 1, W)
+    flat = x.reshape(B, H * W, C)
+    cols = []
+    for t in range(9):
+        hf = ys - 1 + t // 3 + offset[..., 2 * t]
+        wf = xs - 1 + t % 3 + offset[..., 2 * t + 1]
+        valid = (hf > -1) & (wf > -1) & (hf < H) & (wf < W)
+        h0, w0 = torch.floor(hf), torch.floor(wf)
+        lh, lw = hf - h0, wf - w0
+        val = 0
+        for dh, dw, wt in ((0, 0, (1 - lh) * (1 - lw)), (0, 1, (1 - lh) * lw), (1, 0, lh * (1 - lw)), (1, 1, lh * lw)):
+            hh, ww = (h0 + dh).long(), (w0 + dw).long()
+            ok = valid & (hh >= 0) & (hh <= H - 1) & (ww >= 0) & (ww <= W - 1)
+            idx = (hh.clamp(0, H - 1) * W + ww.clamp(0, W - 1)).reshape(B, H * W, 1).expand(-1, -1, C)
+            val = val + torch.gather(flat, 1, idx).reshape(B, H, W, C) * (wt * ok).unsqueeze(-1)
+        cols.append(val)
+    col = torch.stack(cols, 3)                                             # [B, H, W, 9, C]
+    g = d.groups
+    cpg, opg = d.in_channels // g, d.out_channels // g
+    outs = []
+    for gi in range(g):
+        wg = d.weight[gi * opg:(gi + 1) * opg].permute(0, 2, 3, 1).reshape(opg, 9 * cpg, 1, 1)
+        cg = col[..., gi * cpg:(gi + 1) * cpg].reshape(B, H, W, 9 * cpg).contiguous()
+        outs.append(conv_grad.conv2d(cg, wg))
+    return torch.cat(outs, -1)
+
+
+def _gate(mlp, se, v):
+    h = mlp.drop2(mlp.fc2(mlp.drop1(mlp.act(mlp.fc1(v)))))
+    w_r = se.conv_reduce.weight.reshape(se.conv_reduce.out_channels, -1)
+    w_e = se.conv_expand.weight.reshape(se.conv_expand.out_channels, -1)
+    h = F.relu(F.linear(h, w_r, se.conv_reduce.bias))
+    return torch.sigmoid(F.linear(h, w_e, se.conv_expand.bias))            # [B*N, mid]
+
+
+def heightnet(hn, x, mats_dict):
+    """lss_fpn.py:207-250 -> (height logits [BN, H, W, D], context [BN, H, W, C])."""
+    v = hn.bn(lss_fpn.HeightNet.mlp_input(mats_dict))
+    x = F.relu(bn(hn.reduce_conv[1], conv(hn.reduce_conv[0], x)))
+    context = conv(hn.context_conv, x * _gate(hn.context_mlp, hn.context_se, v)[:, None, None, :])
+    h = x * _gate(hn.height_mlp, hn.height_se, v)[:, None, None, :]
+    for m in hn.height_conv:
+        if isinstance(m, lss_fpn.ASPP):
+            h = aspp(m, h)
+        elif isinstance(m, lss_fpn.DCN):
+            h = deform_conv(m, h)
+        else:
+            h = basic_block(m, h)
+    return conv(hn.height_layer, h), context
+
+
+def lss_fpn_forward(bb, imgs, mats_dict):
+    """LSSFPN._forward_single_sweep for the key frame (lss_fpn.py:422-495) -> BEV map NHWC [B, Y, X, C]."""
+    B, S, N, _, imH, imW = imgs.shape
+    assert S == 1, "one sweep (every shipped config)"
+    x = hip_ops.nchw_to_nhwc(imgs.reshape(B * N, 3, imH, imW).float().contiguous(), c_pad=4)
+    feats = secondfpn(bb.img_neck, resnet(bb.img_backbone, x))
+    height, context = heightnet(bb.height_net, feats, mats_dict)
+    prob = height.softmax(-1)                                              # over the D height bins (:483)
+    lifted = prob.permute(0, 3, 1, 2).unsqueeze(-1) * context.unsqueeze(1)  # [BN, D, fH, fW, C] (:484-486)
+    with torch.no_grad():
+        geom = bb.get_geometry_voxel_index(
+            mats_dict['sensor2ego_mats'][:, 0], mats_dict['sensor2virtual_mats'][:, 0], mats_dict['intrin_mats'][:, 0],
+            mats_dict['ida_mats'][:, 0], mats_dict['reference_heights'][:, 0], mats_dict.get('bda_mat', None))
+    D, fH, fW, C = (int(v) for v in lifted.shape[1:])
+    bev = voxel_pooling(geom, lifted.reshape(B, N, D, fH, fW, C).contiguous(), bb._voxel_num_host)   # [B, C, Y, X] view
+    return bev.permute(0, 2, 3, 1)
+
+
+def head_forward(head, bev):
+    """BEVHeightHead.forward (bev_height_head.py:85-111) + CenterHead.forward_single."""
+    t = head.trunk
+    if bev.shape[-1] % 4:
+        bev = F.pad(bev, (0, 4 - bev.shape[-1] % 4))
+    outs = [bev]
+    h = F.relu(bn(t.bn1, conv(t.conv1, bev.contiguous())))
+    for i, name in enumerate(t.res_layers):
+        for b in getattr(t, name):
+            h = block(b, h)
+        if i in t.out_indices:
+            outs.append(h)
+    fpn = secondfpn(head.neck, outs)
+    sc = head.shared_conv
+    shared = F.relu(bn(sc.bn, conv(sc.conv, fpn)))
+    ret = []
+    for th in head.task_heads:
+        d = {}
+        for name in th.heads:
+            seq = getattr(th, name)
+            y = shared
+            for layer in seq[:-1]:
+                y = F.relu(bn(layer.bn, conv(layer.conv, y)))
+            d[name] = _nchw(conv(seq[-1], y))                              # [B, c, H, W] like the reference
+        ret.append([d])
+    return tuple(ret)
+
+
+def bevheight_train_forward(model, imgs, mats_dict):
+    """``BEVHeight.forward`` in training mode: images -> per-task prediction maps with an autograd graph."""
+    if not imgs.is_cuda:
+        raise RuntimeError("sgv3d_amd runs on the MI355X only (no CPU fallback)")
+    if isinstance(model.backbone, lss_fpn.LSSFPN) and type(model.backbone) is not lss_fpn.LSSFPN:
+        raise NotImplementedError("training forward of the BSM variant is not built yet")
+    bev = lss_fpn_forward(model.backbone, imgs, mats_dict)
+    return head_forward(model.head, bev)
