@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Training step of BASELINE config 4's per-GPU share on synthetic data: forward (train mode) + targets + loss +
+backward + gradient all-reduce + fused AdamW.  `python tools/train_bench.py [--batch 4] [--steps 5] [--config cfg2]`
+or under torch.distributed.run for several ranks (RCCL).  Prints one JSON line (samples/s over all ranks); this is
+NOT the headline metric of bench.py (inference frames/s), it tracks SURVEY §8(f) rank 2."""
+import argparse, json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sgv3d_amd import hip_ops, synthetic
+from sgv3d_amd.models.bev_height import BEVHeight
+from sgv3d_amd.replicas import ReplicaGroup
+from sgv3d_amd.train_step import DataParallelAdamW, reference_lr
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=4)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--config", default="cfg2", choices=["cfg2", "small"])
+ap.add_argument("--profile", action="store_true", help="per-kernel-family times of one step (HIP events, eager)")
+args = ap.parse_args()
+
+local = int(os.environ.get("LOCAL_RANK", "0"))
+dev = torch.device("cuda", local)
+torch.cuda.set_device(dev)
+group = ReplicaGroup(device=dev)
+bconf, hconf = synthetic.r50_256_conf() if args.config == "cfg2" else synthetic.small_conf()
+torch.manual_seed(0)
+model = BEVHeight(bconf, hconf).to(dev).train()
+for m in model.modules():
+    if isinstance(m, torch.nn.Dropout):
+        m.p = 0.5
+if args.config == "small":
+    model.head.train_cfg = dict(model.head.train_cfg, grid_size=[256, 256, 1], point_cloud_range=[0, -12.8, -5, 25.6, 12.8, 3])
+imgs = synthetic.make_images(args.batch, final=bconf['final_dim'], device=dev, seed=group.rank)
+mats = synthetic.make_mats(args.batch, device=dev)
+boxes, labels = synthetic.make_gt(args.batch, seed=group.rank, n_range=(10, 40), stress=False)
+boxes, labels = [b.to(dev) for b in boxes], [l.to(dev) for l in labels]
+opt = DataParallelAdamW(model.parameters(), lr=reference_lr(args.batch, group.world))
+nparam = sum(p.numel() for p in model.parameters())
+
+
+def step():
+    opt.zero_grad()
+    preds = model(imgs, mats)
+    targets = model.get_targets(boxes, labels)
+    loss = model.loss(targets, preds)
+    loss.backward()
+    opt.all_reduce_grads()
+    opt.step()
+    return loss
+
+
+for _ in range(args.warmup):
+    loss = step()
+torch.cuda.synchronize()
+elapsed = group.timed(step, args.steps)
+out = {"metric": "training samples/s (forward + loss + backward + all-reduce + AdamW)", "value": group.world * args.batch * args.steps / elapsed,
+       "unit": "samples/s", "n_gpus": group.world, "steps": args.steps, "ms_per_step": 1e3 * elapsed / args.steps,
+       "batch_per_gpu": args.batch, "parameters": nparam, "loss": float(loss.detach()), "config": args.config,
+       "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2**30, "data": "synthetic"}
+if args.profile and group.rank == 0:
+    hip_ops.PROFILE = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    fam = {}
+    for name, flops, e0, e1 in hip_ops.PROFILE:
+        d = fam.setdefault(name.split('|')[0], [0.0, 0.0, 0])
+        d[0] += e0.elapsed_time(e1)
+        d[1] += flops
+        d[2] += 1
+    hip_ops.PROFILE = None
+    out["profiled_step_ms"] = 1e3 * wall
+    out["hip_kernels_ms"] = {k: {"ms": round(v[0], 2), "launches": v[2], "tflops": round(v[1] / v[0] / 1e9, 1) if v[0] > 0 and v[1] > 0 else None}
+                             for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
+group.close()
+if group.rank == 0:
+    print(json.dumps(out))
