@@ -61,8 +61,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     int s_oy = (pix_begin - s_img * hw) / a.out_w;
     int s_ox = pix_begin - s_img * hw - s_oy * a.out_w;
 
-    f32x4n ra[4], rb[4];
-    auto load_stage = [&](int p0) {
+    // Two register sets: the loads of stage s + 2 are issued before the MFMAs of stage s and land in LDS one stage
+    // later, so a load has two stages of MFMA work (>= 4096 cycles per SIMD) to cover its HBM / L2 latency.
+    f32x4n ra0[4], rb0[4], ra1[4], rb1[4];
+    auto load_stage = [&](int p0, f32x4n (&ra)[4], f32x4n (&rb)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int off = prow + 16 * i;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
             if (++s_oy == a.out_h) { s_oy = 0; ++s_img; }
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, const f32x4n (&ra)[4], const f32x4n (&rb)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<f32x4n *>(&sA[buf][prow + 16 * i][c4]) = ra[i];
@@ -97,30 +99,48 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 
-    load_stage(pix_begin);
-    store_stage(0);
-    __syncthreads();
-    int buf = 0;
-    for (int p0 = pix_begin; p0 < pix_end; p0 += kStagePix) {
-        const bool more = p0 + kStagePix < pix_end;
-        if (more) load_stage(p0 + kStagePix);
+    // 32 k-steps of the stage in LDS buffer `buf`: fragments in batches of 8 k-steps, the next batch in flight under
+    // the MFMAs of the current one
+    auto compute = [&](int buf) {
         const float *pa = &sA[buf][half][wm * 32 + l32];
         const float *pb = &sB[buf][half][wn * 32 + l32];
-        // fragments of 16 k-steps at a time in registers, the second batch in flight under the first MFMAs
-        float fa0[16], fb0[16], fa1[16], fb1[16];
+        float fa0[8], fb0[8], fa1[8], fb1[8];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { fa0[j] = pa[j * 128]; fb0[j] = pb[j * 128]; }
+        for (int j = 0; j < 8; ++j) { fa0[j] = pa[j * 128]; fb0[j] = pb[j * 128]; }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { fa1[j] = pa[(16 + j) * 128]; fb1[j] = pb[(16 + j) * 128]; }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < 4; q += 2) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j], fb0[j], acc, 0, 0, 0);
+            for (int j = 0; j < 8; ++j) { fa1[j] = pa[((q + 1) * 8 + j) * 128]; fb1[j] = pb[((q + 1) * 8 + j) * 128]; }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[j], fb1[j], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) store_stage(buf ^ 1);
+            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j], fb0[j], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { fa0[j] = pa[((q + 2) * 8 + j) * 128]; fb0[j] = pb[((q + 2) * 8 + j) * 128]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[j], fb1[j], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int nst = (pix_end - pix_begin + kStagePix - 1) / kStagePix;
+    load_stage(pix_begin, ra0, rb0);
+    if (nst > 1) load_stage(pix_begin + kStagePix, ra1, rb1);
+    store_stage(0, ra0, rb0);
+    __syncthreads();
+    for (int st = 0; st < nst; st += 2) {
+        if (st + 2 < nst) load_stage(pix_begin + (st + 2) * kStagePix, ra0, rb0);
+        compute(0);
+        if (st + 1 < nst) store_stage(1, ra1, rb1);
         __syncthreads();
-        buf ^= 1;
+        if (st + 1 >= nst) break;
+        if (st + 3 < nst) load_stage(pix_begin + (st + 3) * kStagePix, ra1, rb1);
+        compute(1);
+        if (st + 2 < nst) store_stage(0, ra0, rb0);
+        __syncthreads();
     }
 
     const int ci = ci0 + wn * 32 + l32;

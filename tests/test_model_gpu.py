@@ -118,15 +118,19 @@ def test_bitwise_reproducible_without_autotune(small):
         hip_ops.AUTOTUNE = old
 
 
-def test_rejects_cpu_and_training(small):
+def test_rejects_cpu_and_unbuilt_training_output(small):
     m = small['m']
     with pytest.raises(RuntimeError):
         m(small['imgs'], small['mats'])
     m.train()
     try:
+        with pytest.raises(RuntimeError):
+            m(small['imgs'], small['mats'])                       # the training forward has no CPU path either
+        m.is_train_height = True
         with pytest.raises(NotImplementedError):
-            m(small['imgs'].to(DEV), _to_dev(small['mats']))
+            m(small['imgs'].to(DEV), _to_dev(small['mats']))       # the height_pred output is not built
     finally:
+        m.is_train_height = False
         m.eval()
 
 
