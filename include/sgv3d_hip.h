@@ -389,7 +389,8 @@ int sgv3d_centerhead_loss(int batch, int num_class, int h, int w, int max_objs, 
 /* Weight gradient of sgv3d_conv2d_forward's convolution (mode NORMAL geometry; what nn.Conv2d's backward asks
  * cuDNN for on the training step, exps/...:224-240): dw f32 OIHW [cout, cin, kh, kw] = sum over pixels of
  * dy (NHWC, channel stride y_ld, first channel y_coff) x shifted x (NHWC, x_ld / x_coff).  desc is the FORWARD
- * descriptor; only its geometry and channel strides are read.  split = number of pixel ranges reduced
+ * descriptor; only its geometry and channel strides are read (and desc.tile: 0 = workgroup tile chosen by the
+ * library, 1..4 = 64x64, 64x128, 128x64, 128x128 output channels x input channels, for experiments).  split = number of pixel ranges reduced
  * independently (0 = chosen by the library); partial sums are added in a fixed order (deterministic).
  * For an nn.ConvTranspose2d with kernel == stride pass the roles swapped (x := upstream gradient at the fine
  * resolution, dy := the layer's input, desc of the equivalent stride-k convolution): the OIHW result then is

@@ -23,7 +23,7 @@ def _out_hw(h, w, k, stride, pad, dil):
     return ((h + 2 * pad - dil * (k[0] - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k[1] - 1) - 1) // stride + 1)
 
 
-def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, cout=None, x_coff=0, y_coff=0, split=0):
+def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, cout=None, x_coff=0, y_coff=0, split=0, tile=0):
     """dW (OIHW [cout, cin, kh, kw]) of ``y = conv2d(x, W)`` for NHWC ``x`` [B, H, W, x_ld] and ``dy`` [B, OH, OW, y_ld];
     channel windows [x_coff, x_coff + cin) / [y_coff, y_coff + cout) default to the whole tensors."""
     kh, kw = (kernel, kernel) if isinstance(kernel, int) else kernel
@@ -37,6 +37,7 @@ def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, c
     d.batch, d.in_h, d.in_w, d.cin, d.out_h, d.out_w, d.cout = B, H, W, cin, OH, OW, cout
     d.kh, d.kw, d.stride, d.pad, d.dil = kh, kw, int(stride), int(pad), int(dil)
     d.x_ld, d.x_coff, d.y_ld, d.y_coff = x_ld, int(x_coff), y_ld, int(y_coff)
+    d.tile = int(tile)
     lib = _lib.load()
     nws = lib.sgv3d_conv2d_backward_weight_workspace_bytes(ctypes.byref(d), int(split))
     ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)

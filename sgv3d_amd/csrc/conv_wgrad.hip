@@ -9,8 +9,9 @@
 // A[k = l/32][m = l%32]), so tiles go global -> registers -> LDS [pixel][channel] without a transpose and the
 // fragment reads are conflict-free ds_read_b32 of 32 consecutive floats per lane half.
 //
-// Workgroup = 256 threads = 2 x 2 waves, tile 64 co x 64 ci of ONE tap, 64 pixels per stage (32 MFMAs per wave),
-// register-staged double buffering with one barrier per stage.  The pixel range is split over blockIdx.y
+// Workgroup = 256 threads = 2 x 2 waves, tile (64 WM) co x (64 WN) ci of ONE tap with WM, WN in {1, 2} (chosen per
+// layer from its channel counts), 32 or 64 pixels per stage, loads issued two stages ahead into registers, LDS
+// double-buffered with one barrier per stage.  The pixel range is split over blockIdx.y
 // (the reduction is the long axis here: 5 000 - 83 000 pixels against 64 x 64 outputs); with more than one split
 // the partial tiles go to the workspace and wgrad_reduce_kernel adds them in split order (deterministic) while
 // transposing to the OIHW layout of nn.Conv2d.weight.grad.
@@ -22,7 +23,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kStagePix = 64;
 
 struct WgradArgs {
     const float *x, *dy;
@@ -30,14 +30,24 @@ struct WgradArgs {
     int batch, in_h, in_w, cin, out_h, out_w, cout, kh, kw, stride, pad, dil;
     int x_ld, x_coff, y_ld, y_coff;
     int tiles_co, tiles_ci, taps, split, pix_total, pix_per_split;
+    int wm, wn;   // wave tiles of the chosen instantiation
     unsigned x_bytes, y_bytes;   // extents of x / dy from their base pointers (buffer resources)
 };
 
 typedef float f32x4n __attribute__((ext_vector_type(4)));
 
+// WM x WN = 32x32 MFMA tiles per wave (2 x 2 waves: workgroup tile 64*WM co x 64*WN ci); STAGE = pixels per stage, chosen
+// so that both LDS buffers of both operands take 64 KB (two workgroups per CU).  On this chip VALU instructions do not
+// overlap with fp32 MFMAs (they share the lanes), so the staging arithmetic is pure overhead: the larger tiles halve the
+// address / load / LDS-store instructions per MFMA.
+template <int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float sA[2][kStagePix][64];
-    __shared__ __attribute__((aligned(16))) float sB[2][kStagePix][64];
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int STAGE = 8192 / (BM + BN) >= 64 ? 64 : 32;
+    constexpr int A_ROWS = 1024 / BM, B_ROWS = 1024 / BN;       // pixels staged per pass of the 256 threads
+    constexpr int A_PASS = STAGE / A_ROWS, B_PASS = STAGE / B_ROWS;
+    __shared__ __attribute__((aligned(16))) float sA[2][STAGE][BM];
+    __shared__ __attribute__((aligned(16))) float sB[2][STAGE][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
     int bid = blockIdx.x;
@@ -45,114 +55,131 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     const int tco = bid % a.tiles_co; bid /= a.tiles_co;
     const int tap = bid;
     const int th = tap / a.kw, tw = tap - th * a.kw;
-    const int co0 = tco * 64, ci0 = tci * 64;
+    const int co0 = tco * BM, ci0 = tci * BN;
     const int pix_begin = blockIdx.y * a.pix_per_split;
     const int pix_end = min(pix_begin + a.pix_per_split, a.pix_total);
-    const int c4 = (tid & 15) * 4, prow = tid >> 4;   // this thread stages pixels prow + 16 i, channels c4 .. c4 + 3
+    const int ac4 = (tid % (BM / 4)) * 4, arow = tid / (BM / 4);   // A: pixels arow + A_ROWS i, channels ac4 .. ac4 + 3
+    const int bc4 = (tid % (BN / 4)) * 4, brow = tid / (BN / 4);
     const int hw = a.out_h * a.out_w;
 
     // Branch-free staging: buffer loads return zeros for the offset 0xffffffff (pixels past the range, taps that
     // fall outside the image).  Channel tails are loaded as they come: they only reach discarded rows / columns.
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)a.y_bytes, 0x00020000);
-    const unsigned x_c = (unsigned)(a.x_coff + ci0 + c4) * 4u, y_c = (unsigned)(a.y_coff + co0 + c4) * 4u;
-    // (image, oy, ox) of the first pixel of the stage being loaded, advanced by 64 pixels per stage
+    const unsigned x_c = (unsigned)(a.x_coff + ci0 + bc4) * 4u, y_c = (unsigned)(a.y_coff + co0 + ac4) * 4u;
+    // (image, oy, ox) of the first pixel of the stage being loaded, advanced by STAGE pixels per stage
     int s_img = pix_begin / hw;
     int s_oy = (pix_begin - s_img * hw) / a.out_w;
     int s_ox = pix_begin - s_img * hw - s_oy * a.out_w;
 
-    // Two register sets: the loads of stage s + 2 are issued before the MFMAs of stage s and land in LDS one stage
-    // later, so a load has two stages of MFMA work (>= 4096 cycles per SIMD) to cover its HBM / L2 latency.
-    f32x4n ra0[4], rb0[4], ra1[4], rb1[4];
-    auto load_stage = [&](int p0, f32x4n (&ra)[4], f32x4n (&rb)[4]) {
+    // Two register sets: the loads of stage s + 2 are issued before the MFMAs of stage s and land in LDS one stage later.
+    f32x4n ra0[A_PASS], rb0[B_PASS], ra1[A_PASS], rb1[B_PASS];
+    auto load_stage = [&](int p0, f32x4n (&ra)[A_PASS], f32x4n (&rb)[B_PASS]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = prow + 16 * i;
+        for (int i = 0; i < A_PASS; ++i) {
+            const int pix = p0 + arow + A_ROWS * i;
+            const unsigned yo = pix < pix_end ? (unsigned)pix * (unsigned)(a.y_ld * 4) + y_c : 0xffffffffu;
+            ra[i] = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, yo, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {
+            const int off = brow + B_ROWS * i;
             int img = s_img, oy = s_oy, ox = s_ox + off;
             while (ox >= a.out_w) {
                 ox -= a.out_w;
                 if (++oy == a.out_h) { oy = 0; ++img; }
             }
-            const bool inside = p0 + off < pix_end;
-            const unsigned yo = inside ? (unsigned)(p0 + off) * (unsigned)(a.y_ld * 4) + y_c : 0xffffffffu;
-            ra[i] = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, yo, 0, 0));
             const int iy = oy * a.stride - a.pad + th * a.dil, ix = ox * a.stride - a.pad + tw * a.dil;
-            const bool in_img = inside && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
+            const bool in_img = p0 + off < pix_end && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
             const unsigned xo = in_img ? (unsigned)((img * a.in_h + iy) * a.in_w + ix) * (unsigned)(a.x_ld * 4) + x_c : 0xffffffffu;
             rb[i] = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xo, 0, 0));
         }
-        s_ox += kStagePix;
+        s_ox += STAGE;
         while (s_ox >= a.out_w) {
             s_ox -= a.out_w;
             if (++s_oy == a.out_h) { s_oy = 0; ++s_img; }
         }
     };
-    auto store_stage = [&](int buf, const f32x4n (&ra)[4], const f32x4n (&rb)[4]) {
+    auto store_stage = [&](int buf, const f32x4n (&ra)[A_PASS], const f32x4n (&rb)[B_PASS]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4n *>(&sA[buf][prow + 16 * i][c4]) = ra[i];
-            *reinterpret_cast<f32x4n *>(&sB[buf][prow + 16 * i][c4]) = rb[i];
-        }
+        for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<f32x4n *>(&sA[buf][arow + A_ROWS * i][ac4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) *reinterpret_cast<f32x4n *>(&sB[buf][brow + B_ROWS * i][bc4]) = rb[i];
     };
 
-    f32x16 acc;
+    f32x16 acc[WM][WN];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
-    // 32 k-steps of the stage in LDS buffer `buf`: fragments in batches of 8 k-steps, the next batch in flight under
-    // the MFMAs of the current one
+    // The STAGE / 2 k-steps of the stage in LDS buffer `buf`: fragments in batches of KB k-steps, the next batch in
+    // flight under the MFMAs of the current one.
+    constexpr int KB = WM * WN == 4 ? 4 : 8;     // k-steps per fragment batch (register budget of the 128 x 128 tile)
+    constexpr int NB = STAGE / 2 / KB;
     auto compute = [&](int buf) {
-        const float *pa = &sA[buf][half][wm * 32 + l32];
-        const float *pb = &sB[buf][half][wn * 32 + l32];
-        float fa0[8], fb0[8], fa1[8], fb1[8];
+        const float *pa = &sA[buf][half][wm * (BM / 2) + l32];
+        const float *pb = &sB[buf][half][wn * (BN / 2) + l32];
+        float fa[2][KB][WM], fb[2][KB][WN];
+        auto read_batch = [&](int q, int set) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { fa0[j] = pa[j * 128]; fb0[j] = pb[j * 128]; }
+            for (int j = 0; j < KB; ++j) {
 #pragma unroll
-        for (int q = 0; q < 4; q += 2) {
+                for (int m = 0; m < WM; ++m) fa[set][j][m] = pa[(q * KB + j) * 2 * BM + m * 32];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { fa1[j] = pa[((q + 1) * 8 + j) * 128]; fb1[j] = pb[((q + 1) * 8 + j) * 128]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[j], fb0[j], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (q + 2 < 4) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { fa0[j] = pa[((q + 2) * 8 + j) * 128]; fb0[j] = pb[((q + 2) * 8 + j) * 128]; }
+                for (int n = 0; n < WN; ++n) fb[set][j][n] = pb[(q * KB + j) * 2 * BN + n * 32];
             }
+        };
+        read_batch(0, 0);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            if (q + 1 < NB) read_batch(q + 1, (q + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[j], fb1[j], acc, 0, 0, 0);
+            for (int j = 0; j < KB; ++j)
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int n = 0; n < WN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][j][m], fb[q & 1][j][n], acc[m][n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    const int nst = (pix_end - pix_begin + kStagePix - 1) / kStagePix;
+    const int nst = (pix_end - pix_begin + STAGE - 1) / STAGE;
     load_stage(pix_begin, ra0, rb0);
-    if (nst > 1) load_stage(pix_begin + kStagePix, ra1, rb1);
+    if (nst > 1) load_stage(pix_begin + STAGE, ra1, rb1);
     store_stage(0, ra0, rb0);
     __syncthreads();
     for (int st = 0; st < nst; st += 2) {
-        if (st + 2 < nst) load_stage(pix_begin + (st + 2) * kStagePix, ra0, rb0);
+        if (st + 2 < nst) load_stage(pix_begin + (st + 2) * STAGE, ra0, rb0);
         compute(0);
         if (st + 1 < nst) store_stage(1, ra1, rb1);
         __syncthreads();
         if (st + 1 >= nst) break;
-        if (st + 3 < nst) load_stage(pix_begin + (st + 3) * kStagePix, ra1, rb1);
+        if (st + 3 < nst) load_stage(pix_begin + (st + 3) * STAGE, ra1, rb1);
         compute(1);
         if (st + 2 < nst) store_stage(0, ra0, rb0);
         __syncthreads();
     }
 
-    const int ci = ci0 + wn * 32 + l32;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int co = co0 + wm * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
-        if (co >= a.cout || ci >= a.cin) continue;
-        if (a.split > 1)
-            a.ws[(((size_t)blockIdx.y * a.taps + tap) * a.cout + co) * a.cin + ci] = acc[e];
-        else
-            a.dw[((size_t)co * a.cin + ci) * a.taps + tap] = acc[e];
-    }
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int ci = ci0 + wn * (BN / 2) + n * 32 + l32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wm * (BM / 2) + m * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
+                if (co >= a.cout || ci >= a.cin) continue;
+                if (a.split > 1)
+                    a.ws[(((size_t)blockIdx.y * a.taps + tap) * a.cout + co) * a.cin + ci] = acc[m][n][e];
+                else
+                    a.dw[((size_t)co * a.cin + ci) * a.taps + tap] = acc[m][n][e];
+            }
+        }
 }
 
 // i = (tap, co, ci) with ci fastest: coalesced partial reads, split order fixed.
@@ -184,7 +211,7 @@ __global__ __launch_bounds__(256) void zero_insert_kernel(const float4 *__restri
     }
 }
 
-int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a) {
+int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a, int tile_override = 0) {
     SGV3D_REQUIRE(d, "conv2d_backward_weight: null descriptor");
     SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->out_h > 0 && d->out_w > 0,
                   "conv2d_backward_weight: bad sizes");
@@ -199,11 +226,23 @@ int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a) {
     a.batch = d->batch; a.in_h = d->in_h; a.in_w = d->in_w; a.cin = d->cin; a.out_h = d->out_h; a.out_w = d->out_w;
     a.cout = d->cout; a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
     a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff;
-    a.tiles_co = cdiv(d->cout, 64); a.tiles_ci = cdiv(d->cin, 64); a.taps = d->kh * d->kw;
+    // tile: the padded MFMA work divided by the measured relative efficiency of the instantiation.  On the cfg-2 layers
+    // the 64 x 64 tile wins almost everywhere (more workgroups per round outweigh the fewer staging instructions per
+    // MFMA of the larger tiles), so the larger ones are only chosen when they pad less.
+    double best = 0;
+    for (int wm = 1; wm <= 2; ++wm)
+        for (int wn = 1; wn <= 2; ++wn) {
+            const double eff = wm * wn == 1 ? 1.0 : 0.85;
+            const double cost = (double)cdiv(d->cout, 64 * wm) * (64 * wm) * cdiv(d->cin, 64 * wn) * (64 * wn) / eff;
+            if (best == 0 || cost < best) { best = cost; a.wm = wm; a.wn = wn; }
+        }
+    if (tile_override > 0) { a.wm = ((tile_override - 1) >> 1) ? 2 : 1; a.wn = ((tile_override - 1) & 1) ? 2 : 1; }
+    const int stage_pix = 8192 / (64 * a.wm + 64 * a.wn) >= 64 ? 64 : 32;
+    a.tiles_co = cdiv(d->cout, 64 * a.wm); a.tiles_ci = cdiv(d->cin, 64 * a.wn); a.taps = d->kh * d->kw;
     a.pix_total = (int)pix;
     const long long tiles = (long long)a.tiles_co * a.tiles_ci * a.taps;
     SGV3D_REQUIRE(tiles < (1ll << 31), "conv2d_backward_weight: too many tiles");
-    const int stages = cdiv(pix, kStagePix);
+    const int stages = cdiv(pix, stage_pix);
     if (split <= 0) {   // measured on cfg-2 layers: ~64 pixel ranges per tile, between 1 and 6 workgroups per CU in total
         long long target = tiles * 64;
         target = target < 256 ? 256 : (target > 1536 ? 1536 : target);
@@ -214,7 +253,7 @@ int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a) {
     }
     split = split > stages ? stages : split;
     split = split > 65535 ? 65535 : split;
-    a.pix_per_split = cdiv(stages, split) * kStagePix;
+    a.pix_per_split = cdiv(stages, split) * stage_pix;
     a.split = cdiv(pix, a.pix_per_split);
     const unsigned long long xb = (unsigned long long)d->batch * d->in_h * d->in_w * d->x_ld * 4ull;
     const unsigned long long yb = (unsigned long long)pix * d->y_ld * 4ull;
@@ -227,14 +266,14 @@ int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a) {
 
 extern "C" size_t sgv3d_conv2d_backward_weight_workspace_bytes(const sgv3d_conv_desc *d, int split) {
     WgradArgs a;
-    if (fill_args(d, split, a) != SGV3D_OK) return 0;
+    if (fill_args(d, split, a, d ? d->tile : 0) != SGV3D_OK) return 0;
     return a.split > 1 ? (size_t)a.split * a.taps * a.cout * a.cin * sizeof(float) : 0;
 }
 
 extern "C" int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *d, const float *x, const float *dy, float *dw,
                                             int split, void *workspace, size_t workspace_bytes, void *stream) {
     WgradArgs a;
-    if (int rc = fill_args(d, split, a)) return rc;
+    if (int rc = fill_args(d, split, a, d ? d->tile : 0)) return rc;
     SGV3D_REQUIRE(x && dy && dw, "conv2d_backward_weight: null pointer");
     SGV3D_REQUIRE(((uintptr_t)x & 3) == 0 && ((uintptr_t)dy & 3) == 0, "conv2d_backward_weight: x / dy must be 4-byte aligned");
     const size_t need = a.split > 1 ? (size_t)a.split * a.taps * a.cout * a.cin * sizeof(float) : 0;
@@ -242,7 +281,11 @@ extern "C" int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *d, const floa
                   workspace_bytes, need);
     a.x = x; a.dy = dy; a.dw = dw; a.ws = static_cast<float *>(workspace);
     hipStream_t st = as_stream(stream);
-    conv_wgrad_kernel<<<dim3(a.tiles_co * a.tiles_ci * a.taps, a.split), 256, 0, st>>>(a);
+    const dim3 grid(a.tiles_co * a.tiles_ci * a.taps, a.split);
+    if (a.wm == 2 && a.wn == 2) conv_wgrad_kernel<2, 2><<<grid, 256, 0, st>>>(a);
+    else if (a.wm == 2) conv_wgrad_kernel<2, 1><<<grid, 256, 0, st>>>(a);
+    else if (a.wn == 2) conv_wgrad_kernel<1, 2><<<grid, 256, 0, st>>>(a);
+    else conv_wgrad_kernel<1, 1><<<grid, 256, 0, st>>>(a);
     if (int rc = check_launch("conv_wgrad_kernel")) return rc;
     if (a.split > 1) {
         const long long total = (long long)a.taps * a.cout * a.cin;

@@ -85,7 +85,7 @@ struct LossArgs {
     int batch, cat, hw, max_objs, heat_blocks;
     float code_w[kCodes];
     float box_weight, grad_scale;
-    double *partial;         // workspace: [heat_blocks + batch]
+    double *partial;         // workspace: [heat_blocks + batch * kBoxSplit]
     float *out;              // [2] = (loss_heatmap, loss_bbox)
 };
 
@@ -125,11 +125,14 @@ __global__ void __launch_bounds__(kT) heat_kernel(LossArgs a) {
     if (threadIdx.x == 0) a.partial[blockIdx.x] = total;
 }
 
-// One workgroup per sample.  Thread = slot (strided).
+// kBoxSplit workgroups per sample, each owning a contiguous range of slots (all of them keep the sample's index
+// list in LDS to find the slots that share a cell).
+constexpr int kBoxSplit = 8;
+
 __global__ void __launch_bounds__(kT) box_kernel(LossArgs a) {
     extern __shared__ long long s_ind[];   // [max_objs], -1 = masked out
     __shared__ double lds[kT / 64];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x / kBoxSplit, part = blockIdx.x % kBoxSplit;
     const float num = fmaxf(a.stats[1], 1e-4f);
     const float gs = a.grad_scale * a.box_weight / num;
     for (int k = threadIdx.x; k < a.max_objs; k += kT) {
@@ -140,35 +143,44 @@ __global__ void __launch_bounds__(kT) box_kernel(LossArgs a) {
     __syncthreads();
     const int ch_map[kCodes] = {0, 0, 1, 2, 2, 2, 3, 3, 4, 4};
     const int ch_off[kCodes] = {0, 1, 0, 0, 1, 2, 0, 1, 0, 1};
+    const int per = (a.max_objs + kBoxSplit - 1) / kBoxSplit;
+    const int k_end = min(a.max_objs, (part + 1) * per);
     double acc = 0.0;
-    for (int k = threadIdx.x; k < a.max_objs; k += kT) {
+    for (int k = part * per + threadIdx.x; k < k_end; k += kT) {
         const long long cell = s_ind[k];
         if (cell < 0) continue;
         const float *tg = a.anno + ((size_t)b * a.max_objs + k) * kCodes;
-        bool first = true;
-        for (int j = 0; j < k; ++j) first = first && s_ind[j] != cell;
+        float pred[kCodes], g[kCodes];
+#pragma unroll
         for (int c = 0; c < kCodes; ++c) {
-            const size_t off = (size_t)b * a.p_stride + (size_t)ch_off[c] * a.hw + cell;
-            const float pred = a.maps[ch_map[c]][off];
+            pred[c] = a.maps[ch_map[c]][(size_t)b * a.p_stride + (size_t)ch_off[c] * a.hw + cell];
             const float t = tg[c];
             const float w = (t == t) ? a.code_w[c] : 0.f;      // isnotnan mask (bev_height_head.py:298-299)
-            acc += (double)(fabsf(pred - t) * w);
-            if (first && a.g_maps[ch_map[c]]) {
-                // gather backward = scatter-add: this slot owns the cell and adds the other slots on it, in order
-                float g = 0.f;
-                for (int j = k; j < a.max_objs; ++j) {
-                    if (s_ind[j] != cell) continue;
-                    const float tj = a.anno[((size_t)b * a.max_objs + j) * kCodes + c];
-                    const float wj = (tj == tj) ? a.code_w[c] : 0.f;
-                    const float dj = pred - tj;
-                    g += (dj > 0.f ? 1.f : (dj < 0.f ? -1.f : 0.f)) * wj;
-                }
-                a.g_maps[ch_map[c]][(size_t)b * a.g_stride + (size_t)ch_off[c] * a.hw + cell] = g * gs;
+            acc += (double)(fabsf(pred[c] - t) * w);
+            g[c] = 0.f;
+        }
+        if (!a.g_maps[0]) continue;
+        bool first = true;
+        for (int j = 0; j < k; ++j) first = first && s_ind[j] != cell;
+        if (!first) continue;
+        // gather backward = scatter-add: the first slot on a cell adds up every slot on it, in slot order
+        for (int j = k; j < a.max_objs; ++j) {
+            if (s_ind[j] != cell) continue;
+            const float *tj = a.anno + ((size_t)b * a.max_objs + j) * kCodes;
+#pragma unroll
+            for (int c = 0; c < kCodes; ++c) {
+                const float t = tj[c];
+                const float w = (t == t) ? a.code_w[c] : 0.f;
+                const float d = pred[c] - t;
+                g[c] += (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w;
             }
         }
+#pragma unroll
+        for (int c = 0; c < kCodes; ++c)
+            a.g_maps[ch_map[c]][(size_t)b * a.g_stride + (size_t)ch_off[c] * a.hw + cell] = g[c] * gs;
     }
     const double total = block_sum<double>(acc, lds);
-    if (threadIdx.x == 0) a.partial[a.heat_blocks + b] = total;
+    if (threadIdx.x == 0) a.partial[a.heat_blocks + blockIdx.x] = total;
 }
 
 __global__ void __launch_bounds__(kT) finish_kernel(LossArgs a) {
@@ -176,7 +188,7 @@ __global__ void __launch_bounds__(kT) finish_kernel(LossArgs a) {
     double h = 0.0, x = 0.0;
     // fixed assignment of partials to threads and fixed tree: the same sum on every run
     for (int i = threadIdx.x; i < a.heat_blocks; i += kT) h += a.partial[i];
-    for (int i = threadIdx.x; i < a.batch; i += kT) x += a.partial[a.heat_blocks + i];
+    for (int i = threadIdx.x; i < a.batch * kBoxSplit; i += kT) x += a.partial[a.heat_blocks + i];
     const double hs = block_sum<double>(h, lds);
     const double xs = block_sum<double>(x, lds);
     if (threadIdx.x == 0) {
@@ -201,7 +213,7 @@ __global__ void __launch_bounds__(kT) zero_maps_kernel(LossArgs a) {
 }  // namespace
 
 extern "C" size_t sgv3d_centerhead_loss_workspace_bytes(int batch) {
-    return 16 + (size_t)kStatsBlocks * 4 + ((size_t)kHeatBlocks + (size_t)(batch > 0 ? batch : 0)) * 8 + 16;
+    return 16 + (size_t)kStatsBlocks * 4 + ((size_t)kHeatBlocks + (size_t)(batch > 0 ? batch : 0) * 8) * 8 + 16;
 }
 
 extern "C" int sgv3d_centerhead_loss_stats(int batch, int num_class, int h, int w, int max_objs,
@@ -260,7 +272,7 @@ extern "C" int sgv3d_centerhead_loss(int batch, int num_class, int h, int w, int
     }
     heat_kernel<<<kHeatBlocks, kT, 0, s>>>(a);
     if (int rc = check_launch("heat_kernel")) return rc;
-    box_kernel<<<batch, kT, (size_t)max_objs * 8, s>>>(a);
+    box_kernel<<<batch * kBoxSplit, kT, (size_t)max_objs * 8, s>>>(a);
     if (int rc = check_launch("box_kernel")) return rc;
     finish_kernel<<<1, kT, 0, s>>>(a);
     return check_launch("finish_kernel");

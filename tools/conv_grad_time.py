@@ -35,7 +35,8 @@ for shape in os.environ.get("SHAPES", DEFAULT).split(";"):
     conv_grad.conv2d_backward_data(dy, w, (H, W), s, p, d)          # packs + autotunes once
     t_d = timed(lambda: conv_grad.conv2d_backward_data(dy, w, (H, W), s, p, d), 5)
     res = [f"{shape:34s} fwd {t_f:7.1f} us {flops / t_f / 1e6:6.1f} TF | dgrad(+pack) {t_d:7.1f} us {flops / t_d / 1e6:6.1f} TF | wgrad"]
-    for split in (0,) + tuple(int(v) for v in os.environ.get("SPLITS", "").split(",") if v):
-        t_w = timed(lambda: conv_grad.conv2d_backward_weight(x, dy, k, s, p, d, split=split))
-        res.append(f"split {split}: {t_w:7.1f} us {flops / t_w / 1e6:6.1f} TF")
+    for tile in (0,) + tuple(int(v) for v in os.environ.get("TILES", "").split(",") if v):
+        for split in (0,) + tuple(int(v) for v in os.environ.get("SPLITS", "").split(",") if v):
+            t_w = timed(lambda: conv_grad.conv2d_backward_weight(x, dy, k, s, p, d, split=split, tile=tile))
+            res.append(f"t{tile} s{split}: {t_w:6.1f} us {flops / t_w / 1e6:5.1f} TF")
     print(" ".join(res), flush=True)

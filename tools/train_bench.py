@@ -75,6 +75,7 @@ if args.profile and group.rank == 0:
     out["profiled_step_ms"] = 1e3 * wall
     out["hip_kernels_ms"] = {k: {"ms": round(v[0], 2), "launches": v[2], "tflops": round(v[1] / v[0] / 1e9, 1) if v[0] > 0 and v[1] > 0 else None}
                              for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
+hip_ops.save_tune_db()          # no-op unless SGV3D_TUNE_CACHE is set (tools/profile_train.sh)
 group.close()
 if group.rank == 0:
     print(json.dumps(out))
