@@ -413,6 +413,24 @@ int sgv3d_adamw_step(long long n, float *param, const float *grad, float *exp_av
                      float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                      void *stream);
 
+/* Training-mode BatchNorm2d over NHWC f32 [pixels, channels] (channels % 4 == 0) fused with the residual add and the
+ * ReLU that follow it in the reference's blocks: y = relu(gamma * (x - mean) / sqrt(var + eps) + beta + residual) with
+ * the statistics of THIS batch (biased variance), running_mean / running_var updated like nn.BatchNorm2d does
+ * (momentum, unbiased variance; NULL = not tracked).  residual NULL = none, relu 0 = none.  save_mean / save_invstd
+ * f32 [channels] are kept for the backward.  Backward: dy is the gradient w.r.t. y; dx w.r.t. x, dresidual (NULL = not
+ * wanted) w.r.t. the residual, dgamma / dbeta w.r.t. the affine parameters; y (the forward output) supplies the ReLU
+ * mask.  Statistics and gradient sums are accumulated in float64 in a fixed order (deterministic).
+ * workspace: sgv3d_batchnorm_workspace_bytes(channels) bytes, 16-byte aligned like every tensor here. */
+size_t sgv3d_batchnorm_workspace_bytes(int channels);
+int sgv3d_batchnorm_train_forward(long long pixels, int channels, const float *x, const float *residual,
+                                  const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                  float momentum, float eps, int relu, float *y, float *save_mean,
+                                  float *save_invstd, void *workspace, size_t workspace_bytes, void *stream);
+int sgv3d_batchnorm_train_backward(long long pixels, int channels, const float *x, const float *y, const float *dy,
+                                   const float *gamma, const float *save_mean, const float *save_invstd, int relu,
+                                   float *dx, float *dresidual, float *dgamma, float *dbeta, void *workspace,
+                                   size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

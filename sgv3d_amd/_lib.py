@@ -71,6 +71,10 @@ _PROTOS = {
     "sgv3d_conv2d_backward_weight_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
     "sgv3d_conv2d_backward_weight": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 3 + [c_int, c_void_p, c_size_t, c_void_p]),
     "sgv3d_zero_insert": (c_int, [c_int] * 7 + [c_void_p] * 3),
+    "sgv3d_batchnorm_workspace_bytes": (c_size_t, [c_int]),
+    "sgv3d_batchnorm_train_forward": (c_int, [c_ll, c_int] + [c_void_p] * 6 + [ctypes.c_float, ctypes.c_float, c_int] +
+                                      [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "sgv3d_batchnorm_train_backward": (c_int, [c_ll, c_int] + [c_void_p] * 6 + [c_int] + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "sgv3d_adamw_step": (c_int, [c_ll] + [c_void_p] * 4 + [c_int] + [ctypes.c_float] * 6 + [c_void_p]),
     "sgv3d_centerhead_loss_workspace_bytes": (c_size_t, [c_int]),
     "sgv3d_centerhead_loss_stats": (c_int, [c_int] * 5 + [c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

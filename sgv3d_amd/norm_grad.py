@@ -1,0 +1,67 @@
+"""Training-mode BatchNorm2d fused with the residual add and ReLU around it, on NHWC float32 CUDA tensors
+(csrc/bn_train.hip).  ``batch_norm_act`` is differentiable in the input, the residual and the
+affine parameters and updates the module's running statistics like ``nn.BatchNorm2d`` in training mode."""
+import torch
+
+from . import _lib
+from .hip_ops import prof
+
+__all__ = ['batch_norm_act']
+
+
+def _ws(channels, device):
+    n = _lib.load().sgv3d_batchnorm_workspace_bytes(int(channels))
+    return torch.empty(n, dtype=torch.uint8, device=device), n
+
+
+class _BatchNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu):
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+        C = int(x.shape[-1])
+        pixels = x.numel() // C
+        if residual is not None:
+            assert residual.shape == x.shape and residual.is_contiguous() and residual.dtype == torch.float32
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws, nws = _ws(C, x.device)
+        with torch.cuda.device(x.device), prof("batchnorm_train_forward"):
+            rc = _lib.load().sgv3d_batchnorm_train_forward(
+                pixels, C, x.data_ptr(), _lib.ptr(residual), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(running_mean),
+                _lib.ptr(running_var), float(momentum), float(eps), 1 if relu else 0, y.data_ptr(), mean.data_ptr(),
+                invstd.data_ptr(), ws.data_ptr(), nws, _lib.stream_handle(x.device))
+        _lib.check(rc, "sgv3d_batchnorm_train_forward")
+        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+        ctx.relu = bool(relu)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = int(x.shape[-1])
+        pixels = x.numel() // C
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws, nws = _ws(C, x.device)
+        with torch.cuda.device(x.device), prof("batchnorm_train_backward"):
+            rc = _lib.load().sgv3d_batchnorm_train_backward(
+                pixels, C, x.data_ptr(), _lib.ptr(y), dy.data_ptr(), _lib.ptr(weight), mean.data_ptr(), invstd.data_ptr(),
+                1 if ctx.relu else 0, dx.data_ptr(), _lib.ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nws,
+                _lib.stream_handle(x.device))
+        _lib.check(rc, "sgv3d_batchnorm_train_backward")
+        return (dx, dres, dgamma if weight is not None else None, dbeta if ctx.needs_input_grad[3] else None,
+                None, None, None, None, None)
+
+
+def batch_norm_act(bn, x, residual=None, relu=False):
+    """``relu(bn(x) + residual)`` for an ``nn.BatchNorm2d`` in training mode; ``x`` / ``residual`` NHWC float32."""
+    assert bn.training and bn.track_running_stats, "training-mode BatchNorm with running statistics"
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BatchNormAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu)

@@ -10,9 +10,12 @@ the HBM traffic run on the hand-written kernels, forward and backward:
 * the splat -> the ``voxel_pooling`` autograd operator (planned gather forward, gather backward);
 * targets / loss / optimiser -> ``BEVHeightHead.get_targets`` / ``.loss`` / ``train_step.DataParallelAdamW``.
 
-The layers in between -- BatchNorm with batch statistics, ReLU, max / average pooling, the 27-feature MLPs, the softmax
-over height bins, the bilinear sampling of the deformable convolution -- are HBM-bound glue and use torch operators on
-the same NHWC buffers in this round; they are next in line for fused HIP versions.  Activations are NHWC float32
+* BatchNorm with batch statistics + residual add + ReLU -> ``norm_grad.batch_norm_act`` (one statistics pass and one
+  apply pass forward, one reduction pass and one apply pass backward; running statistics updated in the kernel).
+
+The small layers in between -- max / average pooling, the 27-feature MLPs with their BatchNorm1d, the softmax over
+height bins, the bilinear sampling of the deformable convolution, concatenations -- use torch operators on the same
+NHWC buffers in this round.  Activations are NHWC float32
 throughout (an NCHW view with channels-last strides is handed to the torch operators, no layout copies).
 
 Layer semantics follow the eval-mode HIP path module by module (layers/blocks.py, layers/backbones/lss_fpn.py,
@@ -24,6 +27,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import conv_grad, hip_ops
+from .norm_grad import batch_norm_act
 from .layers import blocks
 from .layers.backbones import lss_fpn
 from .ops.voxel_pooling import voxel_pooling
@@ -43,24 +47,28 @@ def conv(m, x):
     return conv_grad.conv2d(x, m.weight, m.bias, m.stride[0], m.padding[0], m.dilation[0])
 
 
-def bn(m, x):
-    y = F.batch_norm(_nchw(x), m.running_mean, m.running_var, m.weight, m.bias, m.training, m.momentum, m.eps)
-    return _nhwc(y)
+def bn(m, x, relu=False, residual=None):
+    """``relu(norm(x) + residual)``: one fused pass (csrc/bn_train.hip) for a BatchNorm2d in training mode; a module
+    kept in eval mode (norm_eval) or with an odd channel count goes through torch."""
+    if m.training and m.track_running_stats and x.shape[-1] % 4 == 0:
+        return batch_norm_act(m, x.contiguous(), None if residual is None else residual.contiguous(), relu)
+    y = _nhwc(F.batch_norm(_nchw(x), m.running_mean, m.running_var, m.weight, m.bias, m.training, m.momentum, m.eps))
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
 
 
 def basic_block(b, x):
     identity = x if b.downsample is None else bn(b.downsample[1], conv(b.downsample[0], x))
-    out = F.relu(bn(b.bn1, conv(b.conv1, x)))
-    out = bn(b.bn2, conv(b.conv2, out))
-    return F.relu(out + identity)
+    out = bn(b.bn1, conv(b.conv1, x), relu=True)
+    return bn(b.bn2, conv(b.conv2, out), relu=True, residual=identity)
 
 
 def bottleneck(b, x):
     identity = x if b.downsample is None else bn(b.downsample[1], conv(b.downsample[0], x))
-    out = F.relu(bn(b.bn1, conv(b.conv1, x)))
-    out = F.relu(bn(b.bn2, conv(b.conv2, out)))
-    out = bn(b.bn3, conv(b.conv3, out))
-    return F.relu(out + identity)
+    out = bn(b.bn1, conv(b.conv1, x), relu=True)
+    out = bn(b.bn2, conv(b.conv2, out), relu=True)
+    return bn(b.bn3, conv(b.conv3, out), relu=True, residual=identity)
 
 
 def block(b, x):
@@ -68,7 +76,7 @@ def block(b, x):
 
 
 def resnet(r, x, use_maxpool=True):
-    x = F.relu(bn(r.bn1, conv(r.conv1, x)))
+    x = bn(r.bn1, conv(r.conv1, x), relu=True)
     if use_maxpool:
         x = _nhwc(F.max_pool2d(_nchw(x), 3, 2, 1))
     outs = []
@@ -88,17 +96,17 @@ def secondfpn(n, feats):
             y = conv_grad.conv_transpose2d(f, layer.weight, layer.stride[0])
         else:
             y = conv(layer, f)
-        ups.append(F.relu(bn(blk[1], y)))
+        ups.append(bn(blk[1], y, relu=True))
     return torch.cat(ups, -1)
 
 
 def aspp(a, x):
-    branches = [F.relu(bn(m.bn, conv(m.atrous_conv, x))) for m in (a.aspp1, a.aspp2, a.aspp3, a.aspp4)]
+    branches = [bn(m.bn, conv(m.atrous_conv, x), relu=True) for m in (a.aspp1, a.aspp2, a.aspp3, a.aspp4)]
     pooled = x.mean((1, 2), keepdim=True)                                  # AdaptiveAvgPool2d((1, 1))
     g = a.global_avg_pool
-    x5 = F.relu(bn(g[2], F.conv2d(_nchw(pooled), g[1].weight).permute(0, 2, 3, 1)))
+    x5 = bn(g[2], F.conv2d(_nchw(pooled), g[1].weight).permute(0, 2, 3, 1), relu=True)
     branches.append(x5.expand(-1, x.shape[1], x.shape[2], -1))             # bilinear upsampling of a 1x1 map = broadcast
-    y = F.relu(bn(a.bn1, conv(a.conv1, torch.cat(branches, -1).contiguous())))
+    y = bn(a.bn1, conv(a.conv1, torch.cat(branches, -1).contiguous()), relu=True)
     return F.dropout(y, a.dropout.p, a.dropout.training)
 
 
@@ -146,7 +154,7 @@ def _gate(mlp, se, v):
 def heightnet(hn, x, mats_dict):
     """lss_fpn.py:207-250 -> (height logits [BN, H, W, D], context [BN, H, W, C])."""
     v = hn.bn(lss_fpn.HeightNet.mlp_input(mats_dict))
-    x = F.relu(bn(hn.reduce_conv[1], conv(hn.reduce_conv[0], x)))
+    x = bn(hn.reduce_conv[1], conv(hn.reduce_conv[0], x), relu=True)
     context = conv(hn.context_conv, x * _gate(hn.context_mlp, hn.context_se, v)[:, None, None, :])
     h = x * _gate(hn.height_mlp, hn.height_se, v)[:, None, None, :]
     for m in hn.height_conv:
@@ -183,7 +191,7 @@ def head_forward(head, bev):
     if bev.shape[-1] % 4:
         bev = F.pad(bev, (0, 4 - bev.shape[-1] % 4))
     outs = [bev]
-    h = F.relu(bn(t.bn1, conv(t.conv1, bev.contiguous())))
+    h = bn(t.bn1, conv(t.conv1, bev.contiguous()), relu=True)
     for i, name in enumerate(t.res_layers):
         for b in getattr(t, name):
             h = block(b, h)
@@ -191,7 +199,7 @@ def head_forward(head, bev):
             outs.append(h)
     fpn = secondfpn(head.neck, outs)
     sc = head.shared_conv
-    shared = F.relu(bn(sc.bn, conv(sc.conv, fpn)))
+    shared = bn(sc.bn, conv(sc.conv, fpn), relu=True)
     ret = []
     for th in head.task_heads:
         d = {}
@@ -199,7 +207,7 @@ def head_forward(head, bev):
             seq = getattr(th, name)
             y = shared
             for layer in seq[:-1]:
-                y = F.relu(bn(layer.bn, conv(layer.conv, y)))
+                y = bn(layer.bn, conv(layer.conv, y), relu=True)
             d[name] = _nchw(conv(seq[-1], y))                              # [B, c, H, W] like the reference
         ret.append([d])
     return tuple(ret)

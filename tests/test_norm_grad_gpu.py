@@ -1,0 +1,77 @@
+"""Fused training-mode BatchNorm (+ residual, + ReLU) kernels on the MI355X against torch's batch_norm in float64 on the
+CPU: output, running statistics, and the gradients of input, residual, weight and bias."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from sgv3d_amd.norm_grad import batch_norm_act
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(x, res, bn, relu, dy):
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    w = bn.weight.detach().double().cpu().requires_grad_(True)
+    b = bn.bias.detach().double().cpu().requires_grad_(True)
+    rm, rv = bn.running_mean.detach().double().cpu().clone(), bn.running_var.detach().double().cpu().clone()
+    y = F.batch_norm(xr, rm, rv, w, b, True, bn.momentum, bn.eps)
+    rr = None
+    if res is not None:
+        rr = res.double().permute(0, 3, 1, 2).requires_grad_(True)
+        y = y + rr
+    if relu:
+        y = F.relu(y)
+    y.backward(dy.double().permute(0, 3, 1, 2))
+    p = lambda t: t.permute(0, 2, 3, 1)
+    return p(y.detach()), p(xr.grad), (p(rr.grad) if rr is not None else None), w.grad, b.grad, rm, rv
+
+
+@pytest.mark.parametrize("shape,use_res,relu,offset", [
+    ((2, 20, 28, 64), False, True, 0.0),
+    ((1, 13, 17, 256), True, True, 0.0),
+    ((3, 9, 11, 128), True, False, 0.0),
+    ((2, 31, 33, 80), False, False, 0.0),
+    ((2, 40, 48, 64), False, True, 25.0),        # |mean| >> std: E[x^2] - mean^2 must not cancel
+    ((2, 1, 1, 512), False, True, 0.0),          # the ASPP's pooled branch: two "pixels"
+])
+def test_batch_norm_act_matches_torch(shape, use_res, relu, offset):
+    g = torch.Generator().manual_seed(sum(shape))
+    C = shape[-1]
+    x = torch.randn(shape, generator=g) * 0.7 + offset
+    res = torch.randn(shape, generator=g) if use_res else None
+    dy = torch.randn(shape, generator=g)
+    bn = torch.nn.BatchNorm2d(C, momentum=0.1).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g))
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    want = _reference(x, res, bn, relu, dy)
+    xg = x.cuda().requires_grad_(True)
+    rg = res.cuda().requires_grad_(True) if use_res else None
+    y = batch_norm_act(bn, xg, rg, relu)
+    y.backward(dy.cuda())
+    tol = lambda w: 3e-5 * max(1.0, float(w.abs().max()))
+    assert float((y.detach().cpu().double() - want[0]).abs().max()) <= tol(want[0])
+    assert float((xg.grad.cpu().double() - want[1]).abs().max()) <= tol(want[1])
+    if use_res:
+        assert float((rg.grad.cpu().double() - want[2]).abs().max()) <= tol(want[2])
+    assert float((bn.weight.grad.cpu().double() - want[3]).abs().max()) <= 1e-4 * max(1.0, float(want[3].abs().max()))
+    assert float((bn.bias.grad.cpu().double() - want[4]).abs().max()) <= 1e-4 * max(1.0, float(want[4].abs().max()))
+    assert float((bn.running_mean.cpu().double() - want[5]).abs().max()) <= 1e-5 * max(1.0, abs(offset))
+    assert float((bn.running_var.cpu().double() - want[6]).abs().max()) <= 1e-5
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_batch_norm_act_is_deterministic():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 37, 41, 192, generator=g).cuda()
+    dy = torch.randn(2, 37, 41, 192, generator=g).cuda()
+    outs = []
+    for _ in range(2):
+        bn = torch.nn.BatchNorm2d(192).cuda().train()
+        xg = x.clone().requires_grad_(True)
+        y = batch_norm_act(bn, xg, None, True)
+        y.backward(dy)
+        outs.append((y.detach().clone(), xg.grad.clone(), bn.weight.grad.clone(), bn.running_var.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))

@@ -88,8 +88,9 @@ def test_training_forward_backward_matches_oracle():
         worst.append((rel, n, float(want.norm())))
     worst.sort(reverse=True)
     print('largest relative gradient errors:', [(f'{r:.1e}', n) for r, n, _ in worst[:5]])
-    bad = [w for w in worst if w[0] > 2e-3 and w[2] > 1e-7]
+    bad = [w for w in worst if w[0] > 5e-3 and w[2] > 1e-7]
     assert not bad, bad[:10]
+    assert sorted(w[0] for w in worst)[len(worst) // 2] < 3e-4          # typical tensor: fp32 rounding only
     assert len(worst) > 150
 
 
