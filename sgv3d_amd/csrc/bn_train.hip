@@ -70,25 +70,28 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs a) {
     }
 }
 
-// Sum of the per-range partials of channel c (64 channels per block, 4 threads per channel over the range axis,
-// fixed order): out[0..1] valid in the threads with slice 0.
-__device__ __forceinline__ void sum_partials(const BnArgs &a, int c, int slice, double (*lds)[64][2], double &s0, double &s1) {
+// Sum of the per-range partials of channel c: 16 channels per block, 16 threads per channel over the range axis, the 16
+// slice sums added in slice order (fixed order); s0 / s1 valid in the threads with slice 0.
+__device__ __forceinline__ void sum_partials(const BnArgs &a, int c, int slice, double (*lds)[16][2], double &s0, double &s1) {
     double s = 0, q = 0;
     if (c < a.channels)
-        for (int r = slice; r < a.ranges; r += 4) {
-            s += a.partial[((size_t)r * a.channels + c) * 2];
-            q += a.partial[((size_t)r * a.channels + c) * 2 + 1];
+        for (int r = slice; r < a.ranges; r += 16) {
+            const double2 v = *reinterpret_cast<const double2 *>(a.partial + ((size_t)r * a.channels + c) * 2);
+            s += v.x;
+            q += v.y;
         }
-    lds[slice][threadIdx.x & 63][0] = s;
-    lds[slice][threadIdx.x & 63][1] = q;
+    const int cl = threadIdx.x & 15;
+    lds[slice][cl][0] = s;
+    lds[slice][cl][1] = q;
     __syncthreads();
-    s0 = lds[0][threadIdx.x & 63][0] + lds[1][threadIdx.x & 63][0] + lds[2][threadIdx.x & 63][0] + lds[3][threadIdx.x & 63][0];
-    s1 = lds[0][threadIdx.x & 63][1] + lds[1][threadIdx.x & 63][1] + lds[2][threadIdx.x & 63][1] + lds[3][threadIdx.x & 63][1];
+    s0 = s1 = 0;
+    if (slice == 0)
+        for (int i = 0; i < 16; ++i) { s0 += lds[i][cl][0]; s1 += lds[i][cl][1]; }
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnArgs a) {
-    __shared__ double lds[4][64][2];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    __shared__ double lds[16][16][2];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), slice = threadIdx.x >> 4;
     double s, q;
     sum_partials(a, c, slice, lds, s, q);
     if (slice != 0 || c >= a.channels) return;
@@ -177,8 +180,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnArgs a) {
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnArgs a) {
-    __shared__ double lds[4][64][2];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    __shared__ double lds[16][16][2];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), slice = threadIdx.x >> 4;
     double sb, sg;
     sum_partials(a, c, slice, lds, sb, sg);
     if (slice != 0 || c >= a.channels) return;
@@ -273,7 +276,7 @@ extern "C" int sgv3d_batchnorm_train_forward(long long pixels, int channels, con
     hipStream_t s = as_stream(stream);
     bn_stats_kernel<<<dim3(cdiv(channels, 64), a.ranges), 256, 0, s>>>(a);
     if (int rc = check_launch("bn_stats_kernel")) return rc;
-    bn_finalize_kernel<<<cdiv(channels, 64), 256, 0, s>>>(a);
+    bn_finalize_kernel<<<cdiv(channels, 16), 256, 0, s>>>(a);
     if (int rc = check_launch("bn_finalize_kernel")) return rc;
     bn_apply_kernel<<<stream_blocks(pixels * (channels / 4), channels / 4), 256, 0, s>>>(a);
     return check_launch("bn_apply_kernel");
@@ -298,7 +301,7 @@ extern "C" int sgv3d_batchnorm_train_backward(long long pixels, int channels, co
     hipStream_t s = as_stream(stream);
     bn_bwd_reduce_kernel<<<dim3(cdiv(channels, 64), a.ranges), 256, 0, s>>>(a);
     if (int rc = check_launch("bn_bwd_reduce_kernel")) return rc;
-    bn_bwd_finalize_kernel<<<cdiv(channels, 64), 256, 0, s>>>(a);
+    bn_bwd_finalize_kernel<<<cdiv(channels, 16), 256, 0, s>>>(a);
     if (int rc = check_launch("bn_bwd_finalize_kernel")) return rc;
     bn_bwd_apply_kernel<<<stream_blocks(pixels * (channels / 4), channels / 4), 256, 0, s>>>(a);
     return check_launch("bn_bwd_apply_kernel");
