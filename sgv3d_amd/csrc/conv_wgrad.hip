@@ -31,6 +31,7 @@ struct WgradArgs {
     int x_ld, x_coff, y_ld, y_coff;
     int tiles_co, tiles_ci, taps, split, pix_total, pix_per_split;
     int wm, wn;   // wave tiles of the chosen instantiation
+    int tap_cols; // 1: cin <= 4 (image stem): the ci axis of the tile is (tap, ci) -- 16 taps x 4 channels per 64 columns
     unsigned x_bytes, y_bytes;   // extents of x / dy from their base pointers (buffer resources)
 };
 
@@ -53,9 +54,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     int bid = blockIdx.x;
     const int tci = bid % a.tiles_ci; bid /= a.tiles_ci;
     const int tco = bid % a.tiles_co; bid /= a.tiles_co;
-    const int tap = bid;
+    // tap_cols: blockIdx enumerates groups of BN / 4 taps instead of (ci tile, tap); a thread's float4 of staged columns is
+    // the 4 channels of ONE tap, so its tap (and whether it exists) is fixed for the whole kernel
+    const int tap = a.tap_cols ? tci * (BN / 4) + (int)(threadIdx.x % (BN / 4)) : bid;
+    const bool tap_ok = tap < a.taps;
     const int th = tap / a.kw, tw = tap - th * a.kw;
-    const int co0 = tco * BM, ci0 = tci * BN;
+    const int co0 = tco * BM, ci0 = a.tap_cols ? 0 : tci * BN;
     const int pix_begin = blockIdx.y * a.pix_per_split;
     const int pix_end = min(pix_begin + a.pix_per_split, a.pix_total);
     const int ac4 = (tid % (BM / 4)) * 4, arow = tid / (BM / 4);   // A: pixels arow + A_ROWS i, channels ac4 .. ac4 + 3
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     // fall outside the image).  Channel tails are loaded as they come: they only reach discarded rows / columns.
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)a.y_bytes, 0x00020000);
-    const unsigned x_c = (unsigned)(a.x_coff + ci0 + bc4) * 4u, y_c = (unsigned)(a.y_coff + co0 + ac4) * 4u;
+    const unsigned x_c = (unsigned)(a.x_coff + (a.tap_cols ? 0 : ci0 + bc4)) * 4u, y_c = (unsigned)(a.y_coff + co0 + ac4) * 4u;
     // (image, oy, ox) of the first pixel of the stage being loaded, advanced by STAGE pixels per stage
     int s_img = pix_begin / hw;
     int s_oy = (pix_begin - s_img * hw) / a.out_w;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
                 if (++oy == a.out_h) { oy = 0; ++img; }
             }
             const int iy = oy * a.stride - a.pad + th * a.dil, ix = ox * a.stride - a.pad + tw * a.dil;
-            const bool in_img = p0 + off < pix_end && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
+            const bool in_img = tap_ok && p0 + off < pix_end && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
             const unsigned xo = in_img ? (unsigned)((img * a.in_h + iy) * a.in_w + ix) * (unsigned)(a.x_ld * 4) + x_c : 0xffffffffu;
             rb[i] = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xo, 0, 0));
         }
@@ -169,15 +173,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     for (int m = 0; m < WM; ++m)
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
-            const int ci = ci0 + wn * (BN / 2) + n * 32 + l32;
+            const int col = wn * (BN / 2) + n * 32 + l32;                 // column of the workgroup tile
+            const int ci = a.tap_cols ? (col & 3) : ci0 + col;
+            const int otap = a.tap_cols ? tci * (BN / 4) + (col >> 2) : tap;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = co0 + wm * (BM / 2) + m * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
-                if (co >= a.cout || ci >= a.cin) continue;
+                if (co >= a.cout || ci >= a.cin || otap >= a.taps) continue;
                 if (a.split > 1)
-                    a.ws[(((size_t)blockIdx.y * a.taps + tap) * a.cout + co) * a.cin + ci] = acc[m][n][e];
+                    a.ws[(((size_t)blockIdx.y * a.taps + otap) * a.cout + co) * a.cin + ci] = acc[m][n][e];
                 else
-                    a.dw[((size_t)co * a.cin + ci) * a.taps + tap] = acc[m][n][e];
+                    a.dw[((size_t)co * a.cin + ci) * a.taps + otap] = acc[m][n][e];
             }
         }
 }
@@ -237,10 +243,14 @@ int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a, int tile_overri
             if (best == 0 || cost < best) { best = cost; a.wm = wm; a.wn = wn; }
         }
     if (tile_override > 0) { a.wm = ((tile_override - 1) >> 1) ? 2 : 1; a.wn = ((tile_override - 1) & 1) ? 2 : 1; }
+    a.taps = d->kh * d->kw;
+    a.tap_cols = (d->cin <= 4 && d->x_ld == 4 && d->x_coff == 0 && a.taps > 1) ? 1 : 0;   // the 3-channel image stem
+    if (a.tap_cols) a.wn = 1;
     const int stage_pix = 8192 / (64 * a.wm + 64 * a.wn) >= 64 ? 64 : 32;
-    a.tiles_co = cdiv(d->cout, 64 * a.wm); a.tiles_ci = cdiv(d->cin, 64 * a.wn); a.taps = d->kh * d->kw;
+    a.tiles_co = cdiv(d->cout, 64 * a.wm);
+    a.tiles_ci = a.tap_cols ? cdiv(a.taps, 16 * a.wn) : cdiv(d->cin, 64 * a.wn);
     a.pix_total = (int)pix;
-    const long long tiles = (long long)a.tiles_co * a.tiles_ci * a.taps;
+    const long long tiles = (long long)a.tiles_co * a.tiles_ci * (a.tap_cols ? 1 : a.taps);
     SGV3D_REQUIRE(tiles < (1ll << 31), "conv2d_backward_weight: too many tiles");
     const int stages = cdiv(pix, stage_pix);
     if (split <= 0) {   // measured on cfg-2 layers: ~64 pixel ranges per tile, between 1 and 6 workgroups per CU in total
@@ -281,7 +291,7 @@ extern "C" int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *d, const floa
                   workspace_bytes, need);
     a.x = x; a.dy = dy; a.dw = dw; a.ws = static_cast<float *>(workspace);
     hipStream_t st = as_stream(stream);
-    const dim3 grid(a.tiles_co * a.tiles_ci * a.taps, a.split);
+    const dim3 grid(a.tiles_co * a.tiles_ci * (a.tap_cols ? 1 : a.taps), a.split);
     if (a.wm == 2 && a.wn == 2) conv_wgrad_kernel<2, 2><<<grid, 256, 0, st>>>(a);
     else if (a.wm == 2) conv_wgrad_kernel<2, 1><<<grid, 256, 0, st>>>(a);
     else if (a.wn == 2) conv_wgrad_kernel<1, 2><<<grid, 256, 0, st>>>(a);

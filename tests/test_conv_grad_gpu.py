@@ -89,6 +89,19 @@ def test_transposed_conv_weight_gradient_by_role_swap():
     assert float((dw.cpu().double() - wr.grad).abs().max()) <= 2e-5 * float(wr.grad.abs().max())
 
 
+def test_stem_weight_gradient_with_padded_image_channels():
+    """The image stem: 3 weight channels over a 4-channel (zero-padded) NHWC image, taps packed into the tile columns."""
+    g = torch.Generator().manual_seed(4)
+    x3 = torch.randn(2, 45, 61, 3, generator=g)
+    x4 = torch.cat([x3, torch.zeros(2, 45, 61, 1)], -1).contiguous()
+    dy = torch.randn(2, 23, 31, 64, generator=g)
+    _, _, dw_ref = _reference(x3, torch.zeros(64, 3, 7, 7), dy, 2, 3, 1)
+    for split in (0, 1, 3):
+        dw = conv_grad.conv2d_backward_weight(x4.cuda(), dy.cuda(), 7, 2, 3, 1, cin=3, split=split)
+        assert dw.shape == (64, 3, 7, 7)
+        assert float((dw.cpu().double() - dw_ref).abs().max()) <= 2e-5 * float(dw_ref.abs().max())
+
+
 def test_bias_gradient_and_chain():
     g = torch.Generator().manual_seed(9)
     x = torch.randn(1, 14, 18, 32, generator=g)
