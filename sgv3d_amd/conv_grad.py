@@ -4,7 +4,8 @@ exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:224-240 asks cuDN
 * weight gradient: ``conv_wgrad_kernel`` (csrc/conv_wgrad.hip), fp32 MFMA, pixel-split with a fixed-order reduce;
 * data gradient: a stride-1 convolution of the upstream gradient with the flipped, transposed weights through the
   forward kernels (implicit GEMM or Winograd, autotuned like every other layer); strided layers first spread the
-  gradient over a zero-filled map (1x1 layers convolve at the coarse resolution and spread afterwards);
+  gradient over a zero-filled map (1x1 layers convolve at the coarse resolution and spread afterwards; kernel == stride
+  layers are the transposed-convolution kernel with the same weights);
 * ``conv2d`` is the autograd function tying the three together for NHWC tensors.
 
 There is no CPU fallback: every function raises if the HIP library is missing.
@@ -68,6 +69,12 @@ def conv2d_backward_data(dy, weight, in_hw, stride=1, pad=0, dil=1):
     assert kh == kw, "square kernels only (every layer of the model)"
     if int(dy.shape[-1]) % 4:
         dy = torch.nn.functional.pad(dy, (0, 4 - int(dy.shape[-1]) % 4))
+    if kh == stride and stride > 1 and pad == 0 and dil == 1:
+        # kernel == stride ("patchify" convolutions of the necks): every input pixel belongs to exactly one output pixel,
+        # so the data gradient is the transposed convolution with the same weight tensor read as [in = cout, out = cin, k, k]
+        dx = PackedConv(weight.detach(), stride=stride, transposed=True, cin_pad=int(dy.shape[-1]))(dy)
+        ph, pw = H - int(dx.shape[1]), W - int(dx.shape[2])
+        return dx if ph == 0 and pw == 0 else torch.nn.functional.pad(dx, (0, 0, 0, pw, 0, ph))   # rows the conv never read
     wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()          # [cin, cout, kh, kw], rotated by 180 degrees
     conv = PackedConv(wt, stride=1, pad=dil * (kh - 1) - pad, dil=dil, cin_pad=int(dy.shape[-1]), pad_out=True)
     if stride == 1:

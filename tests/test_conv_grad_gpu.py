@@ -19,6 +19,7 @@ SHAPES = [
     (2, 80, 16, 16, 160, 3, 1, 1, 1),       # BEV trunk widths (not multiples of 64)
     (1, 96, 12, 20, 18, 3, 1, 1, 1),        # DCN offset conv: cout % 4 != 0
     (1, 64, 16, 16, 32, 4, 4, 0, 1),        # neck patchify conv (kernel == stride)
+    (2, 32, 19, 22, 48, 2, 2, 0, 1),        # kernel == stride with rows / columns the conv never reads
     (3, 32, 9, 11, 48, 3, 1, 1, 1),         # tiny, several images
 ]
 
