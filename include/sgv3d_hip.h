@@ -431,6 +431,13 @@ int sgv3d_batchnorm_train_backward(long long pixels, int channels, const float *
                                    float *dx, float *dresidual, float *dgamma, float *dbeta, void *workspace,
                                    size_t workspace_bytes, void *stream);
 
+/* y[b, 2 i + py, 2 j + px, :] = phases[py * 2 + px][b, i + row0, j + col0, :]: interleaves the four sub-pixel phases of a
+ * stride-2 data gradient (each phase is a stride-1 convolution of the upstream gradient with the taps of its parity,
+ * sgv3d_amd/conv_grad.py) into the NHWC result.  phases / phase_h / phase_w / row0 / col0: host arrays of 4; channels % 4 == 0. */
+int sgv3d_interleave_phases2(int batch, int out_h, int out_w, int channels, const float *const *phases /*host*/,
+                             const int32_t *phase_h, const int32_t *phase_w, const int32_t *row0, const int32_t *col0,
+                             float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,6 +217,28 @@ __global__ __launch_bounds__(256) void zero_insert_kernel(const float4 *__restri
     }
 }
 
+struct PhaseArgs {
+    const float4 *src[4];     // phase (py, px) = src[py * 2 + px]: NHWC [batch, h[p], w[p], c4 * 4]
+    int h[4], w[4], r0[4], c0[4];
+    float4 *dst;              // NHWC [batch, out_h, out_w, c4 * 4]
+    int batch, out_h, out_w, c4;
+};
+
+// dst[b, 2 i + py, 2 j + px, :] = src[py][px][b, i + r0, j + c0, :]  (the four sub-pixel phases of a stride-2 data gradient)
+__global__ __launch_bounds__(256) void interleave_phases_kernel(const PhaseArgs a) {
+    const long long total = (long long)a.batch * a.out_h * a.out_w * a.c4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % a.c4);
+        long long r = i / a.c4;
+        const int x = (int)(r % a.out_w); r /= a.out_w;
+        const int y = (int)(r % a.out_h);
+        const int b = (int)(r / a.out_h);
+        const int p = (y & 1) * 2 + (x & 1);
+        const int sy = (y >> 1) + a.r0[p], sx = (x >> 1) + a.c0[p];
+        a.dst[i] = a.src[p][((size_t)(b * a.h[p] + sy) * a.w[p] + sx) * a.c4 + c];
+    }
+}
+
 int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a, int tile_override = 0) {
     SGV3D_REQUIRE(d, "conv2d_backward_weight: null descriptor");
     SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->out_h > 0 && d->out_w > 0,
@@ -316,4 +338,25 @@ extern "C" int sgv3d_zero_insert(int batch, int in_h, int in_w, int channels, in
     zero_insert_kernel<<<blocks, 256, 0, as_stream(stream)>>>(reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y),
                                                              batch, in_h, in_w, channels / 4, stride, out_h, out_w);
     return check_launch("zero_insert_kernel");
+}
+
+extern "C" int sgv3d_interleave_phases2(int batch, int out_h, int out_w, int channels, const float *const *phases,
+                                        const int32_t *phase_h, const int32_t *phase_w, const int32_t *row0,
+                                        const int32_t *col0, float *y, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && out_h > 0 && out_w > 0 && channels > 0 && channels % 4 == 0, "interleave_phases2: bad sizes");
+    SGV3D_REQUIRE(phases && phase_h && phase_w && row0 && col0 && y, "interleave_phases2: null pointer");
+    PhaseArgs a{};
+    for (int p = 0; p < 4; ++p) {
+        const int need_h = (out_h - (p >> 1) + 1) / 2, need_w = (out_w - (p & 1) + 1) / 2;   // pixels of this phase
+        SGV3D_REQUIRE(need_h == 0 || need_w == 0 || phases[p], "interleave_phases2: null phase");
+        SGV3D_REQUIRE(row0[p] >= 0 && col0[p] >= 0 && row0[p] + need_h <= phase_h[p] && col0[p] + need_w <= phase_w[p],
+                      "interleave_phases2: phase %d does not cover its pixels", p);
+        a.src[p] = reinterpret_cast<const float4 *>(phases[p]);
+        a.h[p] = phase_h[p]; a.w[p] = phase_w[p]; a.r0[p] = row0[p]; a.c0[p] = col0[p];
+    }
+    a.dst = reinterpret_cast<float4 *>(y);
+    a.batch = batch; a.out_h = out_h; a.out_w = out_w; a.c4 = channels / 4;
+    const long long total = (long long)batch * out_h * out_w * a.c4;
+    interleave_phases_kernel<<<(int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192), 256, 0, as_stream(stream)>>>(a);
+    return check_launch("interleave_phases_kernel");
 }

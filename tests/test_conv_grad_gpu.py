@@ -21,6 +21,10 @@ SHAPES = [
     (1, 64, 16, 16, 32, 4, 4, 0, 1),        # neck patchify conv (kernel == stride)
     (2, 32, 19, 22, 48, 2, 2, 0, 1),        # kernel == stride with rows / columns the conv never reads
     (3, 32, 9, 11, 48, 3, 1, 1, 1),         # tiny, several images
+    (1, 80, 30, 34, 160, 7, 2, 3, 1),       # BEV trunk stem: 7x7 stride 2 (four-phase data gradient)
+    (2, 64, 17, 23, 64, 3, 2, 0, 1),        # stride 2 without padding, odd sizes
+    (1, 32, 16, 20, 32, 5, 2, 2, 1),        # 5x5 stride 2
+    (1, 32, 15, 19, 64, 3, 3, 1, 1),        # stride 3: zero-insertion path
 ]
 
 
