@@ -267,7 +267,7 @@ int sgv3d_copy_channels(int batch, int pixels, int channels, int x_ld, int x_cof
                         float *y, void *stream);
 
 /* F.interpolate(x, scale_factor=2, mode='bilinear') (align_corners=False), NHWC f32
- * [B,H,W,C] -> [B,2H,2W,C]  (TaskFPN.forward, layers/backbones/bsm_lss_fpn.py:209-212). */
+ * [B,H,W,C] -> [B,2H,2W,C]  (TaskFPN.forward, layers/backbones/bsm_lss_fpn.py:209-212); any C, float4 path when C % 4 == 0. */
 int sgv3d_upsample_bilinear2x(int batch, int h, int w, int channels, const float *x, float *y, void *stream);
 
 /* y = a + b * sigmoid(c), n f32 elements: SABlock product plus the TaskFPN residual
@@ -437,6 +437,38 @@ int sgv3d_batchnorm_train_backward(long long pixels, int channels, const float *
 int sgv3d_interleave_phases2(int batch, int out_h, int out_w, int channels, const float *const *phases /*host*/,
                              const int32_t *phase_h, const int32_t *phase_w, const int32_t *row0, const int32_t *col0,
                              float *y, void *stream);
+
+/* ---- SGV3D BSM branch, training side ------------------------------------------------------- */
+
+/* get_downsampled_gt_semantic (exps/sgv3d/bsm_bev_height_lss_r101_864_1536_256x256.py:258-276): gt u8 [B, H, W] class
+ * ids of the SAM mask image -> labels u8 [B, H/factor, W/factor], the maximum id of each factor x factor block
+ * (H, W multiples of factor). */
+int sgv3d_semantic_labels_downsample(int batch, int h, int w, int factor, const unsigned char *gt,
+                                     unsigned char *labels, void *stream);
+
+/* FocalLoss.forward (losses/focal.py:57-90) over focal_loss_with_logits (losses/_functional.py:37-108; `normalized` and
+ * `reduced_threshold` off as in the shipped configs): value and gradient in one pass.
+ *   logits f32, element (b, c, p) at b*batch_stride + c*class_stride + p*pixel_stride (floats) -- NHWC rows or NCHW
+ *   planes; target_kind 0: u8 labels [B, P], 1: int64 labels [B, P] (multiclass mode: the target of class c is
+ *   label == c; labels equal to ignore_index are left out when use_ignore_index), 2: f32 targets addressed like
+ *   logits (binary / multilabel mode); alpha < 0 = no alpha weighting; reduction_mean 1: every class is averaged over
+ *   the kept pixels and the classes are summed (multiclass) / mean over all elements (target_kind 2), 0: sum.
+ *   grad (NULL = not wanted) receives grad_scale * d loss / d logit, addressed like logits; loss_out f32 [1].
+ *   workspace: sgv3d_focal_loss_workspace_bytes() bytes. */
+size_t sgv3d_focal_loss_workspace_bytes(void);
+int sgv3d_focal_loss_with_logits(int batch, int num_classes, int pixels, const float *logits, long long batch_stride,
+                                 long long class_stride, long long pixel_stride, const void *target, int target_kind,
+                                 float alpha, float gamma, long long ignore_index, int use_ignore_index,
+                                 int reduction_mean, float grad_scale, float *grad, float *loss_out, void *workspace,
+                                 size_t workspace_bytes, void *stream);
+
+/* Adjoint of sgv3d_upsample_bilinear2x: dy f32 [B, 2H, 2W, C] -> dx f32 [B, H, W, C] (any C). */
+int sgv3d_upsample_bilinear2x_backward(int batch, int h, int w, int channels, const float *dy, float *dx, void *stream);
+
+/* Gradients of sgv3d_add_mul_sigmoid (y = a + b * sigmoid(c); da = dy): db = dy * sigmoid(c),
+ * dc = dy * b * sigmoid(c) * (1 - sigmoid(c)); n f32 elements, n % 4 == 0. */
+int sgv3d_add_mul_sigmoid_backward(long long n, const float *dy, const float *b, const float *c, float *db, float *dc,
+                                   void *stream);
 
 #ifdef __cplusplus
 }

@@ -245,8 +245,8 @@ def _task_fpn(sd, p, feat0, feat1):
 def msct_head(sd, p, feats, mats):
     """MSCThead.forward, bsm_lss_fpn.py:259-320 -> (depth1, semantic1, context1, semantic0)"""
     v = mlp_input(mats)
-    v = F.batch_norm(v, sd[p + '.bn.running_mean'], sd[p + '.bn.running_var'], sd[p + '.bn.weight'], sd[p + '.bn.bias'],
-                     False, 0.0, 1e-5)
+    v = F.batch_norm(v.to(feats[0].dtype), sd[p + '.bn.running_mean'], sd[p + '.bn.running_var'], sd[p + '.bn.weight'],
+                     sd[p + '.bn.bias'], BN_TRAINING, 0.0, 1e-5)
     s0 = F.relu(bn(sd, p + '.reduce_conv0.1', conv(sd, p + '.reduce_conv0.0', feats[0], 1, 1)))
     s1 = F.relu(bn(sd, p + '.reduce_conv1.1', conv(sd, p + '.reduce_conv1.0', feats[1], 1, 1)))
     s0 = _se(sd, p + '.scale0_se', s0, _mlp(sd, p + '.scale0_mlp', v)[..., None, None])
@@ -326,28 +326,43 @@ def voxel_pool_torch(geom, lifted, voxel_num):
     return out.reshape(B, Y, X, C).permute(0, 3, 1, 2)
 
 
-def bevheight_train_forward(sd, backbone_conf, head_conf, imgs, mats):
-    """BEVHeight.forward in training mode (BatchNorm on batch statistics, models/bev_height.py:42-80 with
-    is_train_height False) WITH an autograd graph over ``sd``: the checker of sgv3d_amd/train_forward.py.  Dropout is
-    not restated (the tests set p = 0)."""
+def bevheight_train_forward(sd, backbone_conf, head_conf, imgs, mats, is_train_height=False):
+    """BEVHeight.forward in training mode (BatchNorm on batch statistics, models/bev_height.py:42-80) WITH an autograd
+    graph over ``sd``: the checker of sgv3d_amd/train_forward.py, for LSSFPN and the BSM variant.  With
+    ``is_train_height`` returns ``(preds, height_pred)`` (:72-77): (semantic0, semantic1) logits of BSMLSSFPN
+    (bsm_lss_fpn.py:557-558) / (assist, assist) of LSSFPN (lss_fpn.py:459,493-494).  Dropout is not restated (the tests
+    set p = 0)."""
     global BN_TRAINING
-    assert not backbone_conf.get('is_bsm')
     BN_TRAINING = True
     try:
         B, S, N, Cin, H, W = imgs.shape
         dt = next(iter(sd.values())).dtype
         x = imgs[:, 0].reshape(B * N, Cin, H, W).to(dt)
         feats = resnet(sd, 'backbone.img_backbone', x, backbone_conf['img_backbone_conf'])
-        src = secondfpn(sd, 'backbone.img_neck', feats, backbone_conf['img_neck_conf'])
-        hf = heightnet(sd, 'backbone.height_net', src, mats)
-        D, C = sd['backbone.frustum'].shape[0], backbone_conf['output_channels']
-        lifted = hf[:, :D].softmax(1).unsqueeze(1) * hf[:, D:D + C].unsqueeze(2)
-        fH, fW = lifted.shape[3], lifted.shape[4]
+        geo_sd = {k: v.detach().float() for k, v in sd.items() if k.startswith('backbone.frustum') or
+                  k.startswith('backbone.voxel')}
+        if backbone_conf.get('is_bsm'):
+            n16 = secondfpn(sd, 'backbone.img_neck_16', feats, backbone_conf['img_neck_conf'])
+            n8 = secondfpn(sd, 'backbone.img_neck_8', feats, dict(backbone_conf['img_neck_conf'], upsample_strides=[0.5, 1, 2, 4]))
+            depth1, semantic1, context1, semantic0 = msct_head(sd, 'backbone.height_net', [n16, n8], mats)
+            semantic = semantic1.softmax(dim=1)
+            tran = torch.cat((context1, semantic), dim=1)
+            tran = tran * (1 - (semantic[:, 0:1] > 0.45).int())
+            lifted = depth1.softmax(dim=1).unsqueeze(1) * tran.unsqueeze(2)
+            aux = (semantic0, semantic1)
+        else:
+            src = secondfpn(sd, 'backbone.img_neck', feats, backbone_conf['img_neck_conf'])
+            hf = heightnet(sd, 'backbone.height_net', src, mats)
+            D, C = sd['backbone.frustum'].shape[0], backbone_conf['output_channels']
+            lifted = hf[:, :D].softmax(1).unsqueeze(1) * hf[:, D:D + C].unsqueeze(2)
+            assist = conv(sd, 'backbone.assist_layer', src)
+            aux = (assist, assist)
+        C, D, fH, fW = lifted.shape[1:]
         lifted = lifted.reshape(B, N, C, D, fH, fW).permute(0, 1, 3, 4, 5, 2)
-        geom = geometry_indices({k: v.detach().float() for k, v in sd.items() if k.startswith('backbone.frustum') or
-                                 k.startswith('backbone.voxel')}, mats)
+        geom = geometry_indices(geo_sd, mats)
         bev = voxel_pool_torch(geom, lifted, [int(v) for v in sd['backbone.voxel_num']])
-        return head_forward(sd, head_conf, bev)
+        preds = head_forward(sd, head_conf, bev)
+        return (preds, aux) if is_train_height else preds
     finally:
         BN_TRAINING = False
 

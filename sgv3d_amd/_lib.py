@@ -83,6 +83,13 @@ _PROTOS = {
     "sgv3d_centerhead_loss": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_ll, c_void_p, c_ll] + [c_void_p] * 4 +
                               [ctypes.POINTER(ctypes.c_float), ctypes.c_float, ctypes.c_float] + [c_void_p] * 6 +
                               [c_ll, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sgv3d_semantic_labels_downsample": (c_int, [c_int] * 4 + [c_void_p] * 3),
+    "sgv3d_focal_loss_workspace_bytes": (c_size_t, []),
+    "sgv3d_focal_loss_with_logits": (c_int, [c_int] * 3 + [c_void_p, c_ll, c_ll, c_ll, c_void_p, c_int, ctypes.c_float,
+                                             ctypes.c_float, c_ll, c_int, c_int, ctypes.c_float, c_void_p, c_void_p,
+                                             c_void_p, c_size_t, c_void_p]),
+    "sgv3d_upsample_bilinear2x_backward": (c_int, [c_int] * 4 + [c_void_p] * 3),
+    "sgv3d_add_mul_sigmoid_backward": (c_int, [c_ll] + [c_void_p] * 6),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

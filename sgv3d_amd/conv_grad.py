@@ -131,6 +131,11 @@ def _dgrad_stride2(dy, weight, in_hw, pad):
     return dx
 
 
+def _pad4(x):
+    c = int(x.shape[-1])
+    return x if c % 4 == 0 else torch.nn.functional.pad(x, (0, 4 - c % 4))
+
+
 class _Conv2dNHWC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil):
@@ -159,8 +164,9 @@ class _Conv2dNHWC(torch.autograd.Function):
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1):
     """``F.conv2d`` on NHWC float32 CUDA tensors through the HIP kernels, differentiable in ``x``, ``weight``, ``bias``.
-    ``x`` may carry zero padding channels beyond ``weight.shape[1]`` (a multiple of 4 is required)."""
-    return _Conv2dNHWC.apply(x, weight, bias, int(stride), int(pad), int(dil))
+    ``x`` may carry zero padding channels beyond ``weight.shape[1]``; a channel count that is not a multiple of 4 (the
+    174-channel maps of the BSM head) is zero-padded here, because every kernel reads pixels in 16-byte pieces."""
+    return _Conv2dNHWC.apply(_pad4(x), weight, bias, int(stride), int(pad), int(dil))
 
 
 class _ConvTranspose2dNHWC(torch.autograd.Function):
@@ -194,4 +200,4 @@ class _ConvTranspose2dNHWC(torch.autograd.Function):
 
 def conv_transpose2d(x, weight, stride):
     """``F.conv_transpose2d`` (kernel == stride, no bias) on NHWC float32 CUDA tensors, differentiable."""
-    return _ConvTranspose2dNHWC.apply(x, weight, int(stride))
+    return _ConvTranspose2dNHWC.apply(_pad4(x), weight, int(stride))

@@ -188,6 +188,29 @@ __global__ __launch_bounds__(kBlock) void upsample_bilinear2x_kernel(int B, int 
     y[i] = o;
 }
 
+// Scalar-channel forward for maps whose channel count is not a multiple of 4 (the 7-class semantic logits).
+__global__ void __launch_bounds__(kBlock) upsample2x_scalar_kernel(int B, int H, int W, int C, const float *__restrict__ x,
+                                                               float *__restrict__ y) {
+    const long long total = (long long)B * 4 * H * W * C;
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int ow = (int)(t % (2 * W));
+    t /= (2 * W);
+    const int oh = (int)(t % (2 * H));
+    const int b = (int)(t / (2 * H));
+    const float sh = fmaxf(0.5f * ((float)oh + 0.5f) - 0.5f, 0.f), sw = fmaxf(0.5f * ((float)ow + 0.5f) - 0.5f, 0.f);
+    const int h1 = (int)sh, w1 = (int)sw;
+    const int h1p = h1 < H - 1 ? 1 : 0, w1p = w1 < W - 1 ? 1 : 0;
+    const float lh1 = sh - (float)h1, lw1 = sw - (float)w1;
+    const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+    const float *p = x + (long long)b * H * W * C + c;
+    const float a = p[((long long)h1 * W + w1) * C], bq = p[((long long)h1 * W + w1 + w1p) * C];
+    const float cq = p[((long long)(h1 + h1p) * W + w1) * C], d = p[((long long)(h1 + h1p) * W + w1 + w1p) * C];
+    y[i] = lh0 * (lw0 * a + lw1 * bq) + lh1 * (lw0 * cq + lw1 * d);
+}
+
 // SABlock + residual (bsm_lss_fpn.py:151-160, 211): y = a + b * sigmoid(c)
 __global__ __launch_bounds__(kBlock) void add_mul_sigmoid_kernel(long long n4, const float4 *__restrict__ a,
                                                                  const float4 *__restrict__ b, const float4 *__restrict__ c,
@@ -477,8 +500,14 @@ extern "C" int sgv3d_copy_channels(int batch, int pixels, int channels, int x_ld
 }
 
 extern "C" int sgv3d_upsample_bilinear2x(int batch, int h, int w, int channels, const float *x, float *y, void *stream) {
-    SGV3D_REQUIRE(batch > 0 && h > 0 && w > 0 && channels > 0 && (channels & 3) == 0, "upsample_bilinear2x: bad shape");
+    SGV3D_REQUIRE(batch > 0 && h > 0 && w > 0 && channels > 0, "upsample_bilinear2x: bad shape");
     SGV3D_REQUIRE(x && y, "upsample_bilinear2x: null pointer");
+    if (channels & 3) {                                  // e.g. the 7-class semantic logits
+        const long long n = (long long)batch * 4 * h * w * channels;
+        hipLaunchKernelGGL(upsample2x_scalar_kernel, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, as_stream(stream), batch, h, w,
+                           channels, x, y);
+        return check_launch("upsample2x_scalar_kernel");
+    }
     const long long total = (long long)batch * 4 * h * w * (channels / 4);
     hipLaunchKernelGGL(upsample_bilinear2x_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, as_stream(stream), batch, h, w,
                        channels / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y));

@@ -24,8 +24,8 @@ __all__ = ['BEVHeight']
 class BEVHeight(nn.Module):
     """Detector = camera backbone (``LSSFPN`` or, with ``backbone_conf['is_bsm']``, ``BSMLSSFPN``) + BEV head.
 
-    ``backbone_conf`` / ``head_conf`` are the experiment files' dicts, taken verbatim; ``is_train_height`` is
-    accepted for signature compatibility (the height-supervision branch belongs to the training step);
+    ``backbone_conf`` / ``head_conf`` are the experiment files' dicts, taken verbatim; ``is_train_height``
+    makes the training-mode forward return ``(preds, height_pred)`` as models/bev_height.py:72-77 does;
     ``checkpoint`` optionally names a Lightning checkpoint whose ``model.backbone.*`` entries initialise the
     backbone."""
 
@@ -80,8 +80,6 @@ class BEVHeight(nn.Module):
         Result: one single-element list per task holding a dict of NCHW maps (reg, height, dim, rot, vel,
         heatmap) -- the nesting mmdet3d's CenterHead produces."""
         if self.training:
-            if self.is_train_height:
-                raise NotImplementedError("the height_pred output of is_train_height (models/bev_height.py:62-70) is not built")
             from ..train_forward import bevheight_train_forward
             return bevheight_train_forward(self, x, mats_dict)          # differentiable (SURVEY §8(f) rank 2)
         stamp = self._stamp()

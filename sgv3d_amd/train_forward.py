@@ -13,9 +13,12 @@ the HBM traffic run on the hand-written kernels, forward and backward:
 * BatchNorm with batch statistics + residual add + ReLU -> ``norm_grad.batch_norm_act`` (one statistics pass and one
   apply pass forward, one reduction pass and one apply pass backward; running statistics updated in the kernel).
 
+* the BSM variant's x2 bilinear upsampling and spatial-attention gate -> ``bsm_grad`` (forward kernels of the
+  inference path, adjoint kernels in csrc/bsm_train.hip).
+
 The small layers in between -- max / average pooling, the 27-feature MLPs with their BatchNorm1d, the softmax over
-height bins, the bilinear sampling of the deformable convolution, concatenations -- use torch operators on the same
-NHWC buffers in this round.  Activations are NHWC float32
+height bins / semantic classes, the bilinear sampling of the deformable convolution, concatenations -- use torch
+operators on the same NHWC buffers in this round.  Activations are NHWC float32
 throughout (an NCHW view with channels-last strides is handed to the torch operators, no layout copies).
 
 Layer semantics follow the eval-mode HIP path module by module (layers/blocks.py, layers/backbones/lss_fpn.py,
@@ -27,9 +30,10 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import conv_grad, hip_ops
+from .bsm_grad import add_mul_sigmoid, upsample_bilinear2x
 from .norm_grad import batch_norm_act
 from .layers import blocks
-from .layers.backbones import lss_fpn
+from .layers.backbones import bsm_lss_fpn, lss_fpn
 from .ops.voxel_pooling import voxel_pooling
 
 __all__ = ['bevheight_train_forward']
@@ -167,8 +171,9 @@ def heightnet(hn, x, mats_dict):
     return conv(hn.height_layer, h), context
 
 
-def lss_fpn_forward(bb, imgs, mats_dict):
-    """LSSFPN._forward_single_sweep for the key frame (lss_fpn.py:422-495) -> BEV map NHWC [B, Y, X, C]."""
+def lss_fpn_forward(bb, imgs, mats_dict, want_feats=False):
+    """LSSFPN._forward_single_sweep for the key frame (lss_fpn.py:422-495) -> BEV map NHWC [B, Y, X, C]
+    (and, with ``want_feats``, the neck features the assist layer reads, :459)."""
     B, S, N, _, imH, imW = imgs.shape
     assert S == 1, "one sweep (every shipped config)"
     x = hip_ops.nchw_to_nhwc(imgs.reshape(B * N, 3, imH, imW).float().contiguous(), c_pad=4)
@@ -182,7 +187,72 @@ def lss_fpn_forward(bb, imgs, mats_dict):
             mats_dict['ida_mats'][:, 0], mats_dict['reference_heights'][:, 0], mats_dict.get('bda_mat', None))
     D, fH, fW, C = (int(v) for v in lifted.shape[1:])
     bev = voxel_pooling(geom, lifted.reshape(B, N, D, fH, fW, C).contiguous(), bb._voxel_num_host)   # [B, C, Y, X] view
-    return bev.permute(0, 2, 3, 1)
+    return (bev.permute(0, 2, 3, 1), feats) if want_feats else bev.permute(0, 2, 3, 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SGV3D BSM variant (layers/backbones/bsm_lss_fpn.py), SURVEY.md §8(f) rank 3
+# ---------------------------------------------------------------------------------------------------------------
+def task_decoder(th, x):
+    """TaskHead.decoder (bsm_lss_fpn.py:184-190)."""
+    x = basic_block(th.decoder[0], x)
+    x = basic_block(th.decoder[1], x)
+    return bn(th.decoder[3], conv(th.decoder[2], x), relu=True)
+
+
+def task_fpn(f, feat0, feat1):
+    """TaskFPN.forward (bsm_lss_fpn.py:209-212): reduce(upsample(feat0)) + conv(feat1) * sigmoid(attention(that))."""
+    feat0 = conv(f.reduce_conv, upsample_bilinear2x(feat0))
+    sa = f.self_attention
+    return add_mul_sigmoid(feat0, conv(sa.conv, feat1), conv(sa.attention[0], feat0))
+
+
+def msct_head(hn, feats, mats_dict):
+    """MSCThead.forward (bsm_lss_fpn.py:259-320) -> (depth1, semantic1, context1, semantic0), NHWC."""
+    v = hn.bn(lss_fpn.HeightNet.mlp_input(mats_dict))
+    s0 = bn(hn.reduce_conv0[1], conv(hn.reduce_conv0[0], feats[0]), relu=True)
+    s1 = bn(hn.reduce_conv1[1], conv(hn.reduce_conv1[0], feats[1]), relu=True)
+    s0 = s0 * _gate(hn.scale0_mlp, hn.scale0_se, v)[:, None, None, :]
+    s1 = s1 * _gate(hn.scale1_mlp, hn.scale1_se, v)[:, None, None, :]
+    s0 = aspp(hn.aspp, s0)
+    depth_feat = s0                                                         # TaskHead(with_head=False) is the identity (:195-199)
+    semantic_feat = task_decoder(hn.semantic_head0, s0)
+    semantic0 = conv(hn.semantic_head0.head, semantic_feat)
+    context_feat = bn(hn.context_conv0[1], conv(hn.context_conv0[0], s0), relu=True)
+    depth_feat = task_fpn(hn.depth_fpn, depth_feat, s1)
+    semantic_feat = task_fpn(hn.semantic_fpn, semantic_feat, s1)
+    context_feat = task_fpn(hn.context_fpn, context_feat, s1)
+    depth1 = conv(hn.depth_head1.head, task_decoder(hn.depth_head1, depth_feat))
+    semantic1 = conv(hn.semantic_head1.head, task_decoder(hn.semantic_head1, semantic_feat))
+    c = bn(hn.context_conv1[1], conv(hn.context_conv1[0], context_feat), relu=True)
+    return depth1, semantic1, conv(hn.context_conv1[3], c), semantic0
+
+
+def bsm_lss_fpn_forward(bb, imgs, mats_dict):
+    """BSMLSSFPN._forward_single_sweep for the key frame (bsm_lss_fpn.py:485-559) -> (BEV map NHWC [B, Y, X, 88],
+    (semantic0, semantic1) logits as NCHW views -- what the reference returns under is_train_height, :557-558)."""
+    B, S, N, _, imH, imW = imgs.shape
+    assert S == 1, "one sweep (every shipped config)"
+    x = hip_ops.nchw_to_nhwc(imgs.reshape(B * N, 3, imH, imW).float().contiguous(), c_pad=4)
+    feats = resnet(bb.img_backbone, x)
+    n16, n8 = secondfpn(bb.img_neck_16, feats), secondfpn(bb.img_neck_8, feats)
+    depth1, semantic1, context1, semantic0 = msct_head(bb.height_net, [n16, n8], mats_dict)
+    height = depth1.softmax(-1)                                            # :521
+    semantic = semantic1.softmax(-1)                                       # :522
+    tran = torch.cat((context1, semantic), -1)                             # :524
+    keep = 1 - (semantic[..., :1] > bb.background_threshold).int()         # :526-527
+    tran = tran * keep
+    C = int(tran.shape[-1])
+    if C % 4:
+        tran = F.pad(tran, (0, 4 - C % 4))                                 # 87 -> 88, as the inference path carries it
+    lifted = height.permute(0, 3, 1, 2).unsqueeze(-1) * tran.unsqueeze(1)  # [BN, D, fH, fW, 88] (:530)
+    with torch.no_grad():
+        geom = bb.get_geometry_voxel_index(
+            mats_dict['sensor2ego_mats'][:, 0], mats_dict['sensor2virtual_mats'][:, 0], mats_dict['intrin_mats'][:, 0],
+            mats_dict['ida_mats'][:, 0], mats_dict['reference_heights'][:, 0], mats_dict.get('bda_mat', None))
+    D, fH, fW, Cp = (int(v) for v in lifted.shape[1:])
+    bev = voxel_pooling(geom, lifted.reshape(B, N, D, fH, fW, Cp).contiguous(), bb._voxel_num_host)
+    return bev.permute(0, 2, 3, 1), (_nchw(semantic0), _nchw(semantic1))
 
 
 def head_forward(head, bev):
@@ -214,10 +284,25 @@ def head_forward(head, bev):
 
 
 def bevheight_train_forward(model, imgs, mats_dict):
-    """``BEVHeight.forward`` in training mode: images -> per-task prediction maps with an autograd graph."""
+    """``BEVHeight.forward`` in training mode (models/bev_height.py:42-80): images -> per-task prediction maps with an
+    autograd graph; with ``is_train_height`` the tuple ``(preds, height_pred)`` of :72-77, where ``height_pred`` is what
+    the backbone hands out beside the BEV map -- ``(semantic0, semantic1)`` logits for the BSM variant
+    (bsm_lss_fpn.py:557-558), ``(assist_features, assist_features)`` for ``LSSFPN`` (lss_fpn.py:459,493-494)."""
     if not imgs.is_cuda:
         raise RuntimeError("sgv3d_amd runs on the MI355X only (no CPU fallback)")
-    if isinstance(model.backbone, lss_fpn.LSSFPN) and type(model.backbone) is not lss_fpn.LSSFPN:
-        raise NotImplementedError("training forward of the BSM variant is not built yet")
-    bev = lss_fpn_forward(model.backbone, imgs, mats_dict)
-    return head_forward(model.head, bev)
+    bb = model.backbone
+    if isinstance(bb, bsm_lss_fpn.BSMLSSFPN):
+        bev, aux = bsm_lss_fpn_forward(bb, imgs, mats_dict)
+    else:
+        bev, feats = lss_fpn_forward(bb, imgs, mats_dict, want_feats=True)
+        aux = None
+        if bb.is_train_height:
+            assist = _nchw(conv(bb.assist_layer, feats))
+            aux = (assist, assist)
+    preds = head_forward(model.head, bev)
+    if model.is_train_height:
+        if not bb.is_train_height:
+            raise RuntimeError("is_train_height: the backbone was built without it (backbone_conf['is_train_height'], "
+                               "exps/sgv3d/bsm_bev_height_lss_r101_864_1536_256x256.py:236)")
+        return preds, aux
+    return preds

@@ -25,6 +25,8 @@ SHAPES = [
     (2, 64, 17, 23, 64, 3, 2, 0, 1),        # stride 2 without padding, odd sizes
     (1, 32, 16, 20, 32, 5, 2, 2, 1),        # 5x5 stride 2
     (1, 32, 15, 19, 64, 3, 3, 1, 1),        # stride 3: zero-insertion path
+    (1, 174, 12, 14, 174, 3, 1, 1, 1),      # BSM head width 2 x 87: neither side a multiple of 4
+    (1, 174, 12, 14, 348, 3, 2, 1, 1),      # ... and its strided successor
 ]
 
 
