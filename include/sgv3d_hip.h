@@ -470,6 +470,36 @@ int sgv3d_upsample_bilinear2x_backward(int batch, int h, int w, int channels, co
 int sgv3d_add_mul_sigmoid_backward(long long n, const float *dy, const float *b, const float *c, float *db, float *dc,
                                    void *stream);
 
+/* ---- KITTI-AP evaluator ---------------------------------------------------------------------- */
+
+/* Rotated-box overlaps for every same-image (box, query box) pair of a whole validation set in one launch: replaces
+ * rotate_iou_gpu_eval (evaluators/kitti_utils/rotate_iou.py:340-378, the numba.cuda kernel :284-337) and, for
+ * box_dim 7, d3_box_overlap (evaluators/kitti_utils/eval.py:153-160).
+ *   box_offsets / qbox_offsets i32 [num_images + 1] (device): rows of image m are [off[m], off[m+1]);
+ *   tile_offsets i32 [num_images + 1] (device): prefix sum of ceil(N_m/16) * ceil(K_m/16); num_tiles = its last entry;
+ *   out_offsets i64 [num_images] (device): out[out_offsets[m] + i*K_m + j] = overlap(box i, query box j) as f32;
+ *   boxes / qboxes f64 [*, box_dim] (device): box_dim 5 = (x, y, dx, dy, angle) BEV rectangles; box_dim 7 = camera-frame
+ *   boxes (x, y, z, l, h, w, ry), BEV part (x, z, l, w, ry) and height overlap on [y - h, y];
+ *   criterion -1: intersection / union, 0: / area of the query box (box_dim 7: volume of the box), 1: the other one,
+ *   2: the intersection itself.  The clipping runs in float32 in the reference's operation order. */
+int sgv3d_rotate_iou_pairs(int num_images, int num_tiles, const int32_t *box_offsets, const int32_t *qbox_offsets,
+                           const int32_t *tile_offsets, const long long *out_offsets, const double *boxes,
+                           const double *qboxes, int box_dim, int criterion, float *out, void *stream);
+
+/* HOST function (host pointers, no GPU work): precision / recall / orientation-similarity curves of one (class,
+ * difficulty, minimum overlap) cell -- the loop body of eval_class (evaluators/kitti_utils/eval.py:487-556) over
+ * compute_statistics_jit (:157-277), get_thresholds (:7-25) and fused_compute_statistics (:289-335).
+ *   gt_num / dt_num / dc_num i32 [num_images]; overlaps f64, image after image [dt_num[m]][gt_num[m]];
+ *   gt_datas f64 [sum gt][5] (2-D box, alpha); dt_datas f64 [sum dt][6] (2-D box, alpha, score); ignored_gt /
+ *   ignored_det i64 (0 evaluate, 1 ignore, -1 other class) and dontcares f64 [sum dc][4] from clean_data (:28-79);
+ *   metric 0 bbox / 1 bev / 2 3d; num_valid_gt from clean_data; precision / recall / orientation f64 [41];
+ *   num_thresholds (may be NULL) receives the number of recall thresholds found.  Deterministic for any num_threads. */
+int sgv3d_kitti_eval_curves(int num_images, const int32_t *gt_num, const int32_t *dt_num, const int32_t *dc_num,
+                            const double *overlaps, const double *gt_datas, const double *dt_datas,
+                            const int64_t *ignored_gt, const int64_t *ignored_det, const double *dontcares, int metric,
+                            double min_overlap, int compute_aos, long long num_valid_gt, int num_threads,
+                            double *precision, double *recall, double *orientation, int *num_thresholds);
+
 #ifdef __cplusplus
 }
 #endif
