@@ -6,6 +6,7 @@ mkdir -p $OUT
 export SGV3D_TUNE_CACHE=$OUT/train_tune_cache.json   # the profiled run replays the choices of the first run
 python tools/train_bench.py --batch 2 --steps 5 --warmup 2 --profile > $OUT/train_bench.json 2> $OUT/train_bench.err
 python tools/train_bench.py --batch 4 --steps 5 --warmup 2 > $OUT/train_bench_b4.json 2> $OUT/train_bench_b4.err
+python tools/train_bench.py --config cfg5 --batch 2 --steps 3 --warmup 2 --profile > $OUT/train_bench_cfg5_b2.json 2> $OUT/train_bench_cfg5_b2.err || true
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof -o train -- python3 $REPO/tools/train_bench.py --batch 2 --steps 3 --warmup 1 > $OUT/train_under_rocprof.json 2> $OUT/rocprof.err || true

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Training step of BASELINE config 4's per-GPU share on synthetic data: forward (train mode) + targets + loss +
-backward + gradient all-reduce + fused AdamW.  `python tools/train_bench.py [--batch 4] [--steps 5] [--config cfg2]`
+backward + gradient all-reduce + fused AdamW.  `python tools/train_bench.py [--batch 4] [--steps 5] [--config cfg2|cfg5]`
 or under torch.distributed.run for several ranks (RCCL).  Prints one JSON line (samples/s over all ranks); this is
 NOT the headline metric of bench.py (inference frames/s), it tracks SURVEY §8(f) rank 2."""
 import argparse, json, os, sys, time
@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
-ap.add_argument("--config", default="cfg2", choices=["cfg2", "small"])
+ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg5", "small"])
 ap.add_argument("--profile", action="store_true", help="per-kernel-family times of one step (HIP events, eager)")
 args = ap.parse_args()
 
@@ -23,9 +23,12 @@ local = int(os.environ.get("LOCAL_RANK", "0"))
 dev = torch.device("cuda", local)
 torch.cuda.set_device(dev)
 group = ReplicaGroup(device=dev)
-bconf, hconf = synthetic.r50_256_conf() if args.config == "cfg2" else synthetic.small_conf()
+bconf, hconf = {"cfg2": synthetic.r50_256_conf, "cfg5": synthetic.bsm_r101_256_conf, "small": synthetic.small_conf}[args.config]()
+BSM = bool(bconf.get('is_bsm'))                 # cfg5: SGV3D BSM R101 with the semantic (SAM-mask) supervision
+if BSM:
+    bconf = dict(bconf, is_train_height=True)
 torch.manual_seed(0)
-model = BEVHeight(bconf, hconf).to(dev).train()
+model = BEVHeight(bconf, hconf, is_train_height=BSM).to(dev).train()
 for m in model.modules():
     if isinstance(m, torch.nn.Dropout):
         m.p = 0.5
@@ -35,6 +38,11 @@ imgs = synthetic.make_images(args.batch, final=bconf['final_dim'], device=dev, s
 mats = synthetic.make_mats(args.batch, device=dev)
 boxes, labels = synthetic.make_gt(args.batch, seed=group.rank, n_range=(10, 40), stress=False)
 boxes, labels = [b.to(dev) for b in boxes], [l.to(dev) for l in labels]
+if BSM:
+    from sgv3d_amd.losses import SemanticSupervision
+    semantic = SemanticSupervision(8)
+    gt_semantic = torch.randint(0, 7, (args.batch, 1) + tuple(bconf['final_dim']), dtype=torch.uint8,
+                                generator=torch.Generator().manual_seed(group.rank)).to(dev)
 opt = DataParallelAdamW(model.parameters(), lr=reference_lr(args.batch, group.world))
 nparam = sum(p.numel() for p in model.parameters())
 
@@ -42,8 +50,12 @@ nparam = sum(p.numel() for p in model.parameters())
 def step():
     opt.zero_grad()
     preds = model(imgs, mats)
+    if BSM:                                     # exps/sgv3d/bsm_bev_height_lss_r101_864_1536_256x256.py:304-330
+        preds, img_preds = preds
     targets = model.get_targets(boxes, labels)
     loss = model.loss(targets, preds)
+    if BSM:
+        loss = loss + semantic(img_preds, gt_semantic) * 500
     loss.backward()
     opt.all_reduce_grads()
     opt.step()
