@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (--dtype bf16 only)
 HBM_PEAK_GBPS = 8000.0
 
 
@@ -57,6 +58,10 @@ def parse():
                     help="cfg2 (default, the judged workload): R50 BEVHeight; r101: R101 BEVHeight; "
                          "cfg3: R101 1088x1920 -> 512x512 BEV (geometry of BASELINE configs[2]; fp32 here, use --batch 4); "
                          "cfg5: SGV3D BSM R101 (model of BASELINE configs[4], fp32, batch 1)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 (default; what BASELINE cfg-2, the judged line, asks for) or bf16: convolutions multiply on "
+                         "the bf16 matrix cores with f32 accumulation (the compute dtype of BASELINE configs[2] / [4]; "
+                         "use with --config cfg3 --batch 4 or --config cfg5).  Never the default.")
     return ap.parse_args()
 
 
@@ -108,6 +113,8 @@ def main():
     from sgv3d_amd.replicas import ReplicaGroup
     group = ReplicaGroup(backend="nccl" if (world > 1 or os.environ.get("SGV3D_FORCE_DIST")) else None, device=dev)   # nccl == RCCL on ROCm
     from sgv3d_amd.models.bev_height import BEVHeight
+    hip_ops.MFMA_BF16 = args.dtype == "bf16"
+    peak = MFMA_BF16_PEAK_TFLOPS if hip_ops.MFMA_BF16 else MFMA_F32_PEAK_TFLOPS
 
     bc, hc = {"cfg2": S.r50_256_conf, "r101": S.r101_256_conf, "cfg3": S.r101_512_conf,
               "cfg5": S.bsm_r101_256_conf}[args.config]()
@@ -118,6 +125,9 @@ def main():
                         "full BEVHeight forward",
                 "cfg5": "SGV3D BSM ResNet-101 864x1536 -> 256x256 BEV (stride-8 frustum, D=180, 87-ch BEV), fp32, "
                         "full forward"}[args.config]
+    if args.dtype == "bf16":
+        workload = workload.replace("fp32 (BASELINE configs[2] asks bf16)", "fp32").replace(
+            "fp32", "bf16 MFMA operands / f32 accumulation and f32 tensors in HBM")
     torch.manual_seed(0)
     model = BEVHeight(bc, hc).eval()
     S.randomize_norm_stats_(model, 0)
@@ -200,16 +210,16 @@ def main():
         all_sec = sum(v[1] for v in by_kernel.values())
         traffic, traffic_src = load_traffic(top)
         roofline = {
-            "bound": "mfma", "kernel": top, "achieved": fl / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+            "bound": "mfma", "kernel": top, "achieved": fl / sec / 1e12, "peak": peak,
+            "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak, "traffic": traffic,
             "traffic_source": traffic_src,
             "algorithm": "winograd F(2x2,3x3): executes 1/2.25 of the algorithmic flops" if "wino" in top else "implicit GEMM",
             "executed": {"achieved": executed(top, fl) / sec / 1e12,
-                         "frac": executed(top, fl) / sec / 1e12 / MFMA_F32_PEAK_TFLOPS},
+                         "frac": executed(top, fl) / sec / 1e12 / peak},
             "launches": n, "avg_launch_us": sec / n * 1e6, "flop_per_launch": fl / n,
-            "conv_family": {"achieved": fam_fl / fam_sec / 1e12, "frac": fam_fl / fam_sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "conv_family": {"achieved": fam_fl / fam_sec / 1e12, "frac": fam_fl / fam_sec / 1e12 / peak,
                             "executed_achieved": fam_ex / fam_sec / 1e12,
-                            "executed_frac": fam_ex / fam_sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                            "executed_frac": fam_ex / fam_sec / 1e12 / peak,
                             "gflop_per_frame": fam_fl / (args.steps * B) / 1e9,
                             "ms_per_step": fam_sec / args.steps * 1e3,
                             "share_of_instrumented_time": fam_sec / all_sec,
@@ -248,7 +258,7 @@ def main():
             "metric": "camera frames/sec at 864x1536->BEV",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world}",
                        "hip_graph": bool(use_graph), "frames_in_flight": nstreams, "one_frame_in_flight": single, "fuse_lift_splat": bool(args.fuse_lift_splat),

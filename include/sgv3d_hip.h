@@ -208,6 +208,15 @@ int sgv3d_conv2d_forward(const sgv3d_conv_desc *desc /*host*/, const float *x, c
                          const float *gate, float *y, void *workspace, size_t workspace_bytes,
                          void *stream);
 
+/* Same convolution with the multiplications on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 2.5 PFLOP/s dense):
+ * x, w_packed, y and the epilogue operands are the same f32 buffers; both operands are rounded to bf16 (nearest even)
+ * between the load registers and LDS, sums are accumulated in f32.  Equals sgv3d_conv2d_forward on operands that are
+ * bf16-representable, up to the f32 summation order.  The compute dtype of BASELINE configs 3 and 5. */
+int sgv3d_conv2d_forward_bf16(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *w_packed,
+                              const float *scale, const float *bias, const float *residual,
+                              const float *gate, float *y, void *workspace, size_t workspace_bytes,
+                              void *stream);
+
 /* Winograd F(2x2, 3x3) variant of the same operator for 3x3 / stride 1 / dilation 1 / pad 1 layers with
  * cin % 8 == 0 (2.25x fewer multiplies; cuDNN, which the reference's nn.Conv2d dispatches to, uses the
  * same algorithm family for these layers).  Same descriptor, epilogue, modes (NORMAL / NCHW_OUT /

@@ -393,6 +393,213 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 variant (BASELINE cfg-3 / cfg-5 ask for bf16 compute): same GEMM view, same fp32 operands in HBM, same
+// fp32 accumulators and epilogue -- the operands are rounded to bf16 (round to nearest even, v_cvt_pk_bf16_f32)
+// on their way from the load registers into LDS and multiplied by v_mfma_f32_32x32x16_bf16 (dense peak 2.5 PFLOP/s,
+// 16x the fp32 rate), so the loop is bound by the operand traffic, not by MFMA.  LDS rows hold the 32 k of a tile as
+// 64 bytes + 16 bytes of padding (row stride 80 B: the 16 lanes of a ds_read_b128 service group fall on 16 distinct
+// 16-byte slots, 5 r mod 16 being a bijection); one ds_read_b128 per lane and operand feeds one MFMA of 16 k.
+// Lane half h supplies k = 16 s + 8 h + j (j = 0..7) of k-step s for BOTH operands, so whatever k the hardware
+// assigns to a lane's slot, A and W agree on it.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int LDKB = BK + 8;   // row stride in bf16 elements (80 bytes)
+
+template <int WTM, int WTN, bool FAST>
+__global__ __launch_bounds__(kThreads, 2) void conv_igemm_bf16_kernel(const ConvArgs a) {
+    constexpr int BM = 64 * WTM, BN = 64 * WTN;
+    constexpr int A_CH = BM / 32, B_CH = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16 *const As0 = reinterpret_cast<__bf16 *>(smem);
+    __bf16 *const Bs0 = As0 + BM * LDKB;
+    constexpr int kBufStride = (BM + BN) * LDKB;               // bf16 elements
+    int2 *const klut = reinterpret_cast<int2 *>(As0 + 2 * kBufStride);
+    if constexpr (!FAST) {
+        for (int kc = threadIdx.x; kc < a.k_pad / 4; kc += kThreads) {
+            const int k = kc * 4;
+            int2 e = make_int2(0, -1);
+            if (k < a.K) {
+                const int tap = k / a.cin, ci = k - tap * a.cin;
+                const int kh = tap / a.kw, dy = kh * a.dil, dx = (tap - kh * a.kw) * a.dil;
+                e = make_int2((dy * a.in_w + dx) * a.x_ld + ci, (dy << 16) | dx);
+            }
+            klut[kc] = e;
+        }
+        __syncthreads();
+    }
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tn = logical / a.tiles_m;
+    const int tm = logical - tn * a.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x;
+    const int cc = tid & 7;
+    const int r0 = tid >> 3;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.w_bytes, 0x00020000);
+    unsigned a_off[A_CH];
+    int a_ih0[A_CH], a_iw0[A_CH];
+    bool a_ok[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        a_ok[i] = m < a.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int t = mm / a.m_w;
+        const int ow = mm - t * a.m_w;
+        const int n = t / a.m_h;
+        const int oh = t - n * a.m_h;
+        a_ih0[i] = oh * a.stride - a.pad;
+        a_iw0[i] = ow * a.stride - a.pad;
+        a_off[i] = (unsigned)((((long long)(n * a.in_h + a_ih0[i]) * a.in_w + a_iw0[i]) * a.x_ld + a.x_coff + cc * 4) * 4);
+    }
+    unsigned b_off[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) b_off[i] = (unsigned)(((size_t)(n0 + r0 + 32 * i) * a.k_pad + cc * 4) * 4);
+
+    float4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
+    const int nkt_all = FAST ? (a.cin / BK) * a.kh * a.kw : a.k_pad / BK;
+    const int kt_begin = (int)((long long)nkt_all * blockIdx.y / a.split_k);
+    const int nkt = (int)((long long)nkt_all * (blockIdx.y + 1) / a.split_k);
+    int ld_kt = kt_begin, ld_kh = 0, ld_kw = 0, ld_c0 = 0;
+    if constexpr (FAST) {
+        const int per_chunk = a.kh * a.kw;
+        const int kt0 = kt_begin < nkt_all ? kt_begin : nkt_all - 1;
+        const int chunk = kt0 / per_chunk, rem = kt0 - chunk * per_chunk;
+        ld_c0 = chunk * BK;
+        ld_kh = rem / a.kw;
+        ld_kw = rem - ld_kh * a.kw;
+    }
+#define SGV3D_LOAD_TILE(RA, RB)                                                                       \
+    do {                                                                                              \
+        int dy_, dx_, koff_;                                                                          \
+        bool kvalid_ = ld_kt < nkt;                                                                   \
+        const int ktb_ = ld_kt < nkt ? ld_kt : nkt - 1;                                               \
+        if constexpr (FAST) {                                                                         \
+            dy_ = ld_kh * a.dil;                                                                      \
+            dx_ = ld_kw * a.dil;                                                                      \
+            koff_ = (dy_ * a.in_w + dx_) * a.x_ld + ld_c0;                                            \
+        } else {                                                                                      \
+            const int2 e_ = klut[ktb_ * (BK / 4) + cc];                                               \
+            kvalid_ = kvalid_ & (e_.y >= 0);                                                          \
+            dy_ = e_.y >> 16;                                                                         \
+            dx_ = e_.y & 0xffff;                                                                      \
+            koff_ = e_.x - cc * 4;                                                                    \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                            \
+            const int ih_ = a_ih0[i] + dy_, iw_ = a_iw0[i] + dx_;                                     \
+            const bool v_ = a_ok[i] & kvalid_ & ((unsigned)ih_ < (unsigned)a.in_h) &                  \
+                            ((unsigned)iw_ < (unsigned)a.in_w);                                       \
+            const unsigned vo_ = v_ ? a_off[i] + (unsigned)(koff_ * 4) : 0xffffffffu;                 \
+            const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo_, 0, 0)); \
+            RA[i].x = t_.x; RA[i].y = t_.y; RA[i].z = t_.z; RA[i].w = t_.w;                           \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < B_CH; ++i) {                                            \
+            const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_off[i], ktb_ * (BK * 4), 0)); \
+            RB[i].x = t_.x; RB[i].y = t_.y; RB[i].z = t_.z; RB[i].w = t_.w;                           \
+        }                                                                                             \
+        ++ld_kt;                                                                                      \
+        if constexpr (FAST) {                                                                         \
+            if (ld_kt < nkt) {                                                                        \
+                if (++ld_kw == a.kw) {                                                                \
+                    ld_kw = 0;                                                                        \
+                    if (++ld_kh == a.kh) { ld_kh = 0; ld_c0 += BK; }                                  \
+                }                                                                                     \
+            }                                                                                         \
+        }                                                                                             \
+    } while (0)
+#define SGV3D_CVT_STORE(DST, V)                                                                       \
+    do {                                                                                              \
+        const f32x4v f_ = {V.x, V.y, V.z, V.w};                                                       \
+        *reinterpret_cast<bf16x4 *>(DST) = __builtin_convertvector(f_, bf16x4);                       \
+    } while (0)
+#define SGV3D_STORE_TILE(RA, RB, BUF)                                                                 \
+    do {                                                                                              \
+        __bf16 *As_ = As0 + (BUF) * kBufStride, *Bs_ = Bs0 + (BUF) * kBufStride;                      \
+        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) SGV3D_CVT_STORE(As_ + (r0 + 32 * i) * LDKB + cc * 4, RA[i]); \
+        _Pragma("unroll") for (int i = 0; i < B_CH; ++i) SGV3D_CVT_STORE(Bs_ + (r0 + 32 * i) * LDKB + cc * 4, RB[i]); \
+    } while (0)
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int a_frag_off = (wm * (BM / 2) + lr) * LDKB + lh * 8;
+    const int b_frag_off = (wn * (BN / 2) + lr) * LDKB + lh * 8;
+    f32x16 acc[WTM][WTN];
+#pragma unroll
+    for (int mt = 0; mt < WTM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WTN; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+    bf16x8 fa[2][WTM], fb[2][WTN];
+#define SGV3D_PHASE(BUF, RA, RB, SA, SB, HAVE_NEXT)                                                   \
+    do {                                                                                              \
+        SGV3D_LOAD_TILE(RA, RB);                                                                      \
+        _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                            \
+            _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                        \
+                fa[s_][mt] = *reinterpret_cast<const bf16x8 *>(As0 + (BUF) * kBufStride + a_frag_off + mt * 32 * LDKB + s_ * 16); \
+            _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt)                                        \
+                fb[s_][nt] = *reinterpret_cast<const bf16x8 *>(Bs0 + (BUF) * kBufStride + b_frag_off + nt * 32 * LDKB + s_ * 16); \
+        }                                                                                             \
+        _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                            \
+            _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt)                                        \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][mt], fb[0][nt], acc[mt][nt], 0, 0, 0); \
+        if (HAVE_NEXT) SGV3D_STORE_TILE(SA, SB, (BUF) ^ 1);                                           \
+        _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                            \
+            _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt)                                        \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][mt], fb[1][nt], acc[mt][nt], 0, 0, 0); \
+        __syncthreads();                                                                              \
+    } while (0)
+
+    SGV3D_LOAD_TILE(ra0, rb0);
+    SGV3D_LOAD_TILE(ra1, rb1);
+    SGV3D_STORE_TILE(ra0, rb0, 0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < nkt; kt += 2) {
+        SGV3D_PHASE(0, ra0, rb0, ra1, rb1, kt + 1 < nkt);
+        if (kt + 1 >= nkt) break;
+        SGV3D_PHASE(1, ra1, rb1, ra0, rb0, kt + 2 < nkt);
+    }
+#undef SGV3D_LOAD_TILE
+#undef SGV3D_CVT_STORE
+#undef SGV3D_STORE_TILE
+#undef SGV3D_PHASE
+
+    // epilogue: the accumulator layout is that of every 32x32 MFMA (row = (e & 3) + 8 (e >> 2) + 4 h, column = lane & 31)
+    float *ws = a.split_k > 1 ? a.ws + (size_t)blockIdx.y * a.M * a.N : nullptr;
+    const int row_base = m0 + wm * (BM / 2) + 4 * lh;
+    const int col_base = n0 + wn * (BN / 2) + lr;
+#define SGV3D_EPI_E(MT, NT, E)                                                                        \
+    {                                                                                                 \
+        const int col_ = col_base + (NT) * 32;                                                        \
+        const int row_ = row_base + (MT) * 32 + ((E) & 3) + 8 * ((E) >> 2);                           \
+        if (col_ < a.N && row_ < a.M) {                                                               \
+            if (ws) ws[(size_t)row_ * a.N + col_] = acc[MT][NT][E];                                   \
+            else conv_epilogue_store(a, row_, col_, acc[MT][NT][E]);                                  \
+        }                                                                                             \
+    }
+#define SGV3D_EPI_TILE(MT, NT)                                                                        \
+    SGV3D_EPI_E(MT, NT, 0) SGV3D_EPI_E(MT, NT, 1) SGV3D_EPI_E(MT, NT, 2) SGV3D_EPI_E(MT, NT, 3)       \
+    SGV3D_EPI_E(MT, NT, 4) SGV3D_EPI_E(MT, NT, 5) SGV3D_EPI_E(MT, NT, 6) SGV3D_EPI_E(MT, NT, 7)       \
+    SGV3D_EPI_E(MT, NT, 8) SGV3D_EPI_E(MT, NT, 9) SGV3D_EPI_E(MT, NT, 10) SGV3D_EPI_E(MT, NT, 11)     \
+    SGV3D_EPI_E(MT, NT, 12) SGV3D_EPI_E(MT, NT, 13) SGV3D_EPI_E(MT, NT, 14) SGV3D_EPI_E(MT, NT, 15)
+    SGV3D_EPI_TILE(0, 0)
+    if constexpr (WTN > 1) { SGV3D_EPI_TILE(0, 1) }
+    if constexpr (WTM > 1) {
+        SGV3D_EPI_TILE(1, 0)
+        if constexpr (WTN > 1) { SGV3D_EPI_TILE(1, 1) }
+    }
+#undef SGV3D_EPI_TILE
+#undef SGV3D_EPI_E
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
 __global__ void pack_weight_kernel(const float *__restrict__ src, int cout, int cin, int kh, int kw, int cin_pad,
@@ -459,6 +666,35 @@ int launch(const ConvArgs &a, hipStream_t st) {
     return a.korder == 1 ? launch_t<WTM, WTN, true>(a, st) : launch_t<WTM, WTN, false>(a, st);
 }
 
+template <int WTM, int WTN, bool FAST>
+int launch_bf16_t(const ConvArgs &a, hipStream_t st) {
+    constexpr int BM = 64 * WTM, BN = 64 * WTN;
+    constexpr size_t tiles_lds = sizeof(unsigned short) * 2 * (BM + BN) * LDKB;
+    const size_t lds = tiles_lds + (FAST ? 0 : (size_t)a.k_pad / 4 * 8);
+    SGV3D_REQUIRE(lds <= 160 * 1024, "conv2d_forward_bf16: K = %d too long for the tap-major kernel's decode table", a.K);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16_kernel<WTM, WTN, FAST>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(SGV3D_ELAUNCH, "conv2d_forward_bf16: cannot raise the dynamic LDS limit to %zu", lds);
+        lds_set = lds;
+    }
+    ConvArgs b = a;
+    b.zeros = conv_zero_block();
+    if (!b.zeros) return fail(SGV3D_ELAUNCH, "conv2d_forward_bf16: cannot resolve the zero block");
+    b.tiles_m = cdiv(a.M, BM);
+    b.tiles_n = cdiv(a.N, BN);
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<WTM, WTN, FAST>), dim3(b.tiles_m * b.tiles_n, b.split_k), dim3(kThreads), lds,
+                       st, b);
+    if (b.split_k > 1) return launch_splitk_reduce(b, st);
+    return check_launch("conv_igemm_bf16_kernel");
+}
+
+template <int WTM, int WTN>
+int launch_bf16(const ConvArgs &a, hipStream_t st) {
+    return a.korder == 1 ? launch_bf16_t<WTM, WTN, true>(a, st) : launch_bf16_t<WTM, WTN, false>(a, st);
+}
+
 int pick_tile(long long M, int N) {
     // cost = (max workgroups any CU runs) x tile area x a small-tile inefficiency factor
     const int bm[4] = {128, 128, 64, 64}, bn[4] = {128, 64, 128, 64};
@@ -523,10 +759,10 @@ extern "C" size_t sgv3d_conv2d_workspace_bytes(const sgv3d_conv_desc *d) {
     return sizeof(float) * (size_t)d->split_k * d->batch * mh * mw * n;
 }
 
-extern "C" int sgv3d_conv2d_forward(const sgv3d_conv_desc *d, const float *x, const float *w_packed,
-                                    const float *scale, const float *bias, const float *residual,
-                                    const float *gate, float *y, void *workspace, size_t workspace_bytes,
-                                    void *stream) {
+static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const float *w_packed,
+                               const float *scale, const float *bias, const float *residual,
+                               const float *gate, float *y, void *workspace, size_t workspace_bytes,
+                               void *stream, bool bf16) {
     SGV3D_REQUIRE(d && x && w_packed && y, "conv2d_forward: null pointer");
     SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->out_h > 0 && d->out_w > 0 &&
                       d->cout > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0,
@@ -596,6 +832,15 @@ extern "C" int sgv3d_conv2d_forward(const sgv3d_conv_desc *d, const float *x, co
     }
     const int tile = d->tile ? d->tile : pick_tile(M, a.N);
     hipStream_t st = as_stream(stream);
+    if (bf16) {
+        switch (tile) {
+            case SGV3D_TILE_128x128: return launch_bf16<2, 2>(a, st);
+            case SGV3D_TILE_128x64: return launch_bf16<2, 1>(a, st);
+            case SGV3D_TILE_64x128: return launch_bf16<1, 2>(a, st);
+            case SGV3D_TILE_64x64: return launch_bf16<1, 1>(a, st);
+            default: return fail(SGV3D_EINVAL, "conv2d_forward_bf16: unknown tile %d", tile);
+        }
+    }
     switch (tile) {
         case SGV3D_TILE_128x128: return launch<2, 2>(a, st);
         case SGV3D_TILE_128x64: return launch<2, 1>(a, st);
@@ -603,4 +848,18 @@ extern "C" int sgv3d_conv2d_forward(const sgv3d_conv_desc *d, const float *x, co
         case SGV3D_TILE_64x64: return launch<1, 1>(a, st);
         default: return fail(SGV3D_EINVAL, "conv2d_forward: unknown tile %d", tile);
     }
+}
+
+extern "C" int sgv3d_conv2d_forward(const sgv3d_conv_desc *d, const float *x, const float *w_packed,
+                                    const float *scale, const float *bias, const float *residual,
+                                    const float *gate, float *y, void *workspace, size_t workspace_bytes,
+                                    void *stream) {
+    return conv2d_forward_impl(d, x, w_packed, scale, bias, residual, gate, y, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int sgv3d_conv2d_forward_bf16(const sgv3d_conv_desc *d, const float *x, const float *w_packed,
+                                         const float *scale, const float *bias, const float *residual,
+                                         const float *gate, float *y, void *workspace, size_t workspace_bytes,
+                                         void *stream) {
+    return conv2d_forward_impl(d, x, w_packed, scale, bias, residual, gate, y, workspace, workspace_bytes, stream, true);
 }

@@ -28,15 +28,27 @@ AUTOTUNE = not __import__("os").environ.get("SGV3D_NO_AUTOTUNE")
 PROFILE_DETAIL = False
 # False: the autotuner never proposes split-K (experiments; SGV3D_NO_SPLITK=1)
 import os as _os
+# Number of concurrent copies of a candidate the autotuner times (SGV3D_TUNE_STREAMS, default 1 = an isolated launch).
+# With several frames in flight (pipeline.FramePipeline) a layer shares the chip with other frames' kernels: the
+# throughput-optimal tile / split differs from the latency-optimal one an isolated launch finds (a split-K or small-tile
+# choice that fills idle CUs in isolation only adds work when the CUs are busy anyway).  N > 1 launches the candidate on
+# N streams at once and compares the time for all of them to finish.
+TUNE_STREAMS = max(1, int(_os.environ.get("SGV3D_TUNE_STREAMS", "1")))
 SPLIT_K = not _os.environ.get("SGV3D_NO_SPLITK")
 # False: 3x3 / stride-1 layers never use the Winograd F(2x2,3x3) kernel (SGV3D_NO_WINOGRAD=1)
 WINOGRAD = not _os.environ.get("SGV3D_NO_WINOGRAD")
 # False: CenterHead branches run as two kernels with the hidden maps in HBM (SGV3D_NO_FUSED_HEAD=1)
 FUSED_HEAD = not _os.environ.get("SGV3D_NO_FUSED_HEAD")
+# True (SGV3D_BF16=1 or set before the first forward): every convolution multiplies through the bf16 MFMA variant of the
+# implicit-GEMM kernel (operands rounded to bf16 on their way into LDS, fp32 accumulation and epilogue, fp32 tensors in
+# HBM) -- the compute dtype BASELINE cfg-3 / cfg-5 name.  Winograd and the fused head kernel are fp32-only and are not
+# used in this mode (a bf16 direct convolution runs at 16x the fp32 MFMA rate, so the 2.25x saving no longer matters).
+MFMA_BF16 = bool(_os.environ.get("SGV3D_BF16"))
 # (tile, split-K) decisions by layer signature.  SGV3D_TUNE_CACHE=<file> loads them at import and
 # save_tune_db() writes them back, so that a profiled run replays the choices of an earlier run
 # instead of timing candidates again (keeps rocprofv3 per-kernel averages free of tuning launches).
 TUNE_DB = {}
+_TUNE_SIDE_STREAMS = []
 
 
 def _tune_db_path():
@@ -242,11 +254,12 @@ class PackedConv:
         t = int(self.tile if tile is None else tile)
         sk = int(split_k) if split_k else 0
         if t == 0 or sk == 0:
-            key = (B, H, W, t, sk)
+            key = (B, H, W, t, sk, MFMA_BF16)
             choice = self._tile_cache.get(key)
             if choice is None:
                 sig = (f"{self.cout}x{self.cin}k{self.kh}x{self.kw}s{self.stride}p{self.pad}d{self.dil}"
-                       f"ks{self.ks}|{B}x{H}x{W}|m{d.mode}r{int(residual is not None)}g{int(gate is not None)}|{t}.{sk}")
+                       f"ks{self.ks}|{B}x{H}x{W}|m{d.mode}r{int(residual is not None)}g{int(gate is not None)}|{t}.{sk}"
+                       + ("|bf16" if MFMA_BF16 else ""))
                 if sig in TUNE_DB:
                     choice = TUNE_DB[sig]
                     self._tile_cache[key] = choice
@@ -259,7 +272,7 @@ class PackedConv:
             t, sk = choice
         d.tile, d.split_k = t, sk
         flops = 2.0 * gemm_m * gemm_n * (self.cin * self.kh * self.kw)
-        name = ("conv_" if t >= TILE_WINO else "conv_igemm_") + TILE_NAMES[t]
+        name = ("conv_" if t >= TILE_WINO else ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_")) + TILE_NAMES[t]
         if t < TILE_WINO and self.k_order == 0:
             name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
         if PROFILE_DETAIL:
@@ -274,7 +287,7 @@ class PackedConv:
         """Deterministic choice without measurement: Winograd for the layers it covers once the map has
         enough tiles to occupy the chip (split over channel steps to reach ~2 workgroups per CU), else the
         implicit-GEMM tile of the cost model; explicit tile / split arguments win."""
-        if t == 0 and self.w_wino is not None and WINOGRAD and d.out_h * d.out_w * d.batch >= 1024:
+        if t == 0 and self.w_wino is not None and WINOGRAD and not MFMA_BF16 and d.out_h * d.out_w * d.batch >= 1024:
             wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 16) * -(-gemm_n // 64)
             split = 1
             if not sk and SPLIT_K:
@@ -295,16 +308,41 @@ class PackedConv:
             return lib.sgv3d_conv2d_winograd_forward(ctypes.byref(d), x.data_ptr(), self.w_wino.data_ptr(),
                                                      _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
                                                      _lib.ptr(gate), out.data_ptr(), _lib.ptr(ws), nws, _st(x))
-        return lib.sgv3d_conv2d_forward(ctypes.byref(d), x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.scale),
+        fwd = lib.sgv3d_conv2d_forward_bf16 if MFMA_BF16 else lib.sgv3d_conv2d_forward
+        return fwd(ctypes.byref(d), x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.scale),
                                         _lib.ptr(self.shift), _lib.ptr(residual), _lib.ptr(gate), out.data_ptr(),
                                         _lib.ptr(ws), nws, _st(x))
+
+    def _time_under_load(self, lib, d, x, residual, gate, out, rounds=3):
+        """Time for TUNE_STREAMS concurrent copies of the launch, ``rounds`` back to back on every stream (all copies
+        write the same values to ``out``; split-K workspaces are per launch)."""
+        global _TUNE_SIDE_STREAMS
+        cur = torch.cuda.current_stream(x.device)
+        if len(_TUNE_SIDE_STREAMS) < TUNE_STREAMS:
+            _TUNE_SIDE_STREAMS = [torch.cuda.Stream(device=x.device) for _ in range(TUNE_STREAMS)]
+        best = None
+        for _ in range(2):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            for s in _TUNE_SIDE_STREAMS[:TUNE_STREAMS]:
+                s.wait_event(e0)
+                with torch.cuda.stream(s):
+                    for _r in range(rounds):
+                        self._launch(lib, d, x, residual, gate, out)
+                cur.wait_stream(s)
+            e1.record(cur)
+            e1.synchronize()
+            dt = e0.elapsed_time(e1)
+            best = dt if best is None else min(best, dt)
+        return best
 
     def _autotune(self, lib, d, x, residual, gate, out, gemm_m, gemm_n, nkt, fixed_tile, fixed_split):
         """Time the candidate (tile, split-K) pairs on the real buffers and keep the fastest.  Results do
         not depend on the tile shape (every output element sums k in the same order); split-K changes
         the association of the k sum (partials added in fixed order), still deterministic."""
         tiles = (1, 2, 3, 4)
-        if self.w_wino is not None and WINOGRAD:
+        if self.w_wino is not None and WINOGRAD and not MFMA_BF16:
             tiles += (TILE_WINO,)
             if self.cin <= 96 and self.cout >= 128:
                 tiles += (TILE_WINO_RES,)
@@ -331,13 +369,16 @@ class PackedConv:
                 for sk in splits:
                     d.tile, d.split_k = t, sk
                     _lib.check(self._launch(lib, d, x, residual, gate, out), "sgv3d_conv2d_forward")   # warm
-                    evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-                    evs[0].record()
-                    for r in range(4):
-                        self._launch(lib, d, x, residual, gate, out)
-                        evs[r + 1].record()
-                    evs[-1].synchronize()
-                    dt = min(evs[r].elapsed_time(evs[r + 1]) for r in range(4))
+                    if TUNE_STREAMS > 1:
+                        dt = self._time_under_load(lib, d, x, residual, gate, out)
+                    else:
+                        evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                        evs[0].record()
+                        for r in range(4):
+                            self._launch(lib, d, x, residual, gate, out)
+                            evs[r + 1].record()
+                        evs[-1].synchronize()
+                        dt = min(evs[r].elapsed_time(evs[r + 1]) for r in range(4))
                     if best_t is None or dt < best_t:
                         best, best_t = (t, sk), dt
         return best

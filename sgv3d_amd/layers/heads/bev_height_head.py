@@ -176,7 +176,7 @@ class BEVHeightHead(HipModule):
                 trunk_outs.append(h)
         fpn_output = self.neck.hip_forward(trunk_outs)                 # :109
         shared = s['shared'](fpn_output)                               # CenterHead.forward_single
-        if hip_ops.FUSED_HEAD and s['first'].w_wino is not None and s['first'].cin <= 64 and s['hc'] == 64:
+        if hip_ops.FUSED_HEAD and not hip_ops.MFMA_BF16 and s['first'].w_wino is not None and s['first'].cin <= 64 and s['hc'] == 64:
             # both branch layers in one kernel: the [nb,B,H,W,64] hidden maps stay on the chip
             out = hip_ops.centerhead_branches(shared, s['first'], s['w2'], s['b2'], s['out_begin'], s['nb'])
         else:

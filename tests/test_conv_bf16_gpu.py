@@ -1,0 +1,104 @@
+"""bf16-MFMA variant of the implicit-GEMM convolution (the compute dtype BASELINE configs[2] / [4] name) on the MI355X.
+
+The kernel rounds both operands to bf16 (nearest even) and accumulates in float32, so against a float64 convolution of
+the SAME bf16-rounded operands only the summation order differs (bar 2e-5); against the unrounded float32 convolution
+the difference is the operand rounding (2^-9 per operand, bar 2e-2 of the output scale).  Model level: predictions of
+the bf16 forward against the float32 oracle, voxel indices untouched (geometry never goes through MFMA)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from sgv3d_amd import hip_ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CASES = [
+    # (B, cin, H, W, cout, k, stride, pad, dil)
+    (1, 64, 20, 24, 64, 1, 1, 0, 1),
+    (2, 64, 17, 19, 128, 3, 1, 1, 1),      # ragged M
+    (1, 128, 16, 16, 256, 3, 2, 1, 1),     # stride 2
+    (1, 256, 14, 18, 96, 3, 1, 6, 6),      # dilated, cout not a tile multiple
+    (1, 80, 32, 32, 160, 7, 2, 3, 1),      # tap-major K (cin % 32 != 0)
+    (1, 4, 40, 56, 64, 7, 2, 3, 1),        # image stem, cin padded 3 -> 4
+    (1, 512, 9, 11, 18, 3, 1, 1, 1),       # tiny cout
+    (1, 2560, 6, 8, 512, 1, 1, 0, 1),      # long K
+]
+
+
+@pytest.fixture
+def bf16_mode():
+    old = hip_ops.MFMA_BF16
+    hip_ops.MFMA_BF16 = True
+    yield
+    hip_ops.MFMA_BF16 = old
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("tile,split", [(0, 0), (1, 1), (2, 2), (3, 1), (4, 3)])
+def test_bf16_conv_matches_rounded_operands(bf16_mode, case, tile, split):
+    B, cin, H, W, cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g)
+    conv = hip_ops.PackedConv(w.to(DEV), stride=stride, pad=pad, dil=dil, scale=scale.to(DEV), shift=shift.to(DEV), relu=True)
+    nkt = conv.k_pad // 32
+    if split > nkt:
+        split = 1
+    y = conv(x.permute(0, 2, 3, 1).contiguous().to(DEV), tile=tile or None, split_k=split or None)
+    got = y.cpu().double().permute(0, 3, 1, 2)
+    rx, rw = x.bfloat16().double(), w.bfloat16().double()
+    want = F.relu(F.conv2d(rx, rw, None, stride, pad, dil) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None])
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    full = F.relu(F.conv2d(x.double(), w.double(), None, stride, pad, dil) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None])
+    assert float((got - full).abs().max()) <= 2e-2 * max(1.0, float(full.abs().max()))
+
+
+def test_bf16_conv_exact_on_small_integers(bf16_mode):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(-4, 5, (1, 96, 13, 15), generator=g).float()            # bf16-representable operands, exact f32 sums
+    w = torch.randint(-3, 4, (80, 96, 3, 3), generator=g).float()
+    want = F.conv2d(x, w, None, 1, 1)
+    for tile in (1, 2, 3, 4):
+        y = hip_ops.PackedConv(w.to(DEV), stride=1, pad=1)(x.permute(0, 2, 3, 1).contiguous().to(DEV), tile=tile)
+        assert torch.equal(y.cpu().permute(0, 3, 1, 2), want), tile
+
+
+def test_bf16_transposed_conv_and_residual(bf16_mode):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 64, 9, 11, generator=g)
+    w = torch.randn(64, 32, 2, 2, generator=g) / 8
+    y = hip_ops.PackedConv(w.to(DEV), stride=2, transposed=True)(x.permute(0, 2, 3, 1).contiguous().to(DEV))
+    want = F.conv_transpose2d(x.bfloat16().double(), w.bfloat16().double(), None, 2)
+    assert float((y.cpu().double().permute(0, 3, 1, 2) - want).abs().max()) <= 2e-5
+    w2 = torch.randn(64, 64, 1, 1, generator=g) / 8
+    res = torch.randn(1, 9, 11, 64, generator=g)
+    y2 = hip_ops.PackedConv(w2.to(DEV), relu=True)(x.permute(0, 2, 3, 1).contiguous().to(DEV), residual=res.to(DEV))
+    want2 = F.relu(F.conv2d(x.bfloat16().double(), w2.bfloat16().double()) + res.double().permute(0, 3, 1, 2))
+    assert float((y2.cpu().double().permute(0, 3, 1, 2) - want2).abs().max()) <= 2e-5
+
+
+def test_bf16_model_forward_close_to_fp32_oracle(bf16_mode):
+    from oracle import torch_model as TM
+    from sgv3d_amd import synthetic as S
+    from sgv3d_amd.models.bev_height import BEVHeight
+    torch.manual_seed(0)
+    bc, hc = S.small_conf()
+    m = BEVHeight(bc, hc).eval()
+    S.randomize_norm_stats_(m, 0)
+    imgs = S.make_images(2, bc['final_dim'], seed=5)
+    mats = S.make_mats(2, scale=128 / 864)
+    keep = {}
+    ref = TM.bevheight_forward(m.state_dict(), bc, hc, imgs, mats, keep)
+    m = m.to(DEV)
+    with torch.no_grad():
+        preds = m(imgs.to(DEV), {k: v.to(DEV) for k, v in mats.items()})
+    worst = 0.0
+    for t in range(6):
+        for k, v in preds[t][0].items():
+            want = ref[t][0][k]
+            err = float((v.cpu() - want).abs().max()) / max(1.0, float(want.abs().max()))
+            worst = max(worst, err)
+    assert 1e-5 < worst < 5e-2, worst                                        # rounded operands: not the fp32 path, yet close
