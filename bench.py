@@ -58,10 +58,11 @@ def parse():
                     help="cfg2 (default, the judged workload): R50 BEVHeight; r101: R101 BEVHeight; "
                          "cfg3: R101 1088x1920 -> 512x512 BEV (geometry of BASELINE configs[2]; fp32 here, use --batch 4); "
                          "cfg5: SGV3D BSM R101 (model of BASELINE configs[4], fp32, batch 1)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x3"],
                     help="f32 (default; what BASELINE cfg-2, the judged line, asks for) or bf16: convolutions multiply on "
                          "the bf16 matrix cores with f32 accumulation (the compute dtype of BASELINE configs[2] / [4]; "
-                         "use with --config cfg3 --batch 4 or --config cfg5).  Never the default.")
+                         "use with --config cfg3 --batch 4 or --config cfg5); f32x3: float32-accurate products from three "
+                         "bf16 terms per operand on the bf16 matrix cores (experimental).  Never the default.")
     return ap.parse_args()
 
 
@@ -81,8 +82,9 @@ def load_traffic(tile_name):
         sym = "conv_wino_head_kernel"
     else:
         fast = not tile_name.endswith("_tapmajor")
-        bm, bn = tile_name.replace("conv_igemm_", "").replace("_tapmajor", "").split("x")
-        sym = f"conv_igemm_kernel<{int(bm) // 64}, {int(bn) // 64}, {'true' if fast else 'false'}>"
+        kern = "conv_igemm_bf16_kernel" if tile_name.startswith(("conv_igemm_bf16_", "conv_igemm_f32x3_")) else "conv_igemm_kernel"
+        bm, bn = tile_name.replace("conv_igemm_bf16_", "").replace("conv_igemm_f32x3_", "").replace("conv_igemm_", "").replace("_tapmajor", "").split("x")
+        sym = f"{kern}<{int(bm) // 64}, {int(bn) // 64}, {'true' if fast else 'false'}>"
     try:
         rec = json.load(open(files[-1]))["bench"].get(sym)
     except Exception:
@@ -114,6 +116,7 @@ def main():
     group = ReplicaGroup(backend="nccl" if (world > 1 or os.environ.get("SGV3D_FORCE_DIST")) else None, device=dev)   # nccl == RCCL on ROCm
     from sgv3d_amd.models.bev_height import BEVHeight
     hip_ops.MFMA_BF16 = args.dtype == "bf16"
+    hip_ops.MFMA_F32X3 = args.dtype == "f32x3"
     peak = MFMA_BF16_PEAK_TFLOPS if hip_ops.MFMA_BF16 else MFMA_F32_PEAK_TFLOPS
 
     bc, hc = {"cfg2": S.r50_256_conf, "r101": S.r101_256_conf, "cfg3": S.r101_512_conf,
@@ -125,6 +128,8 @@ def main():
                         "full BEVHeight forward",
                 "cfg5": "SGV3D BSM ResNet-101 864x1536 -> 256x256 BEV (stride-8 frustum, D=180, 87-ch BEV), fp32, "
                         "full forward"}[args.config]
+    if args.dtype == "f32x3":
+        workload = workload.replace("fp32", "fp32 products as 3 x bf16 split operands on the bf16 MFMA, f32 accumulation")
     if args.dtype == "bf16":
         workload = workload.replace("fp32 (BASELINE configs[2] asks bf16)", "fp32").replace(
             "fp32", "bf16 MFMA operands / f32 accumulation and f32 tensors in HBM")

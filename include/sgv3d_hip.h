@@ -217,6 +217,14 @@ int sgv3d_conv2d_forward_bf16(const sgv3d_conv_desc *desc /*host*/, const float 
                               const float *gate, float *y, void *workspace, size_t workspace_bytes,
                               void *stream);
 
+/* Same convolution, float32-accurate, on the bf16 matrix cores ("f32x3"): each operand is split exactly into three bf16
+ * terms (hi + mid + lo) and a product is the f32 sum of the six partial products of weight >= 2^-16; the neglected
+ * terms are below 2^-23 relative, i.e. one f32 rounding per product.  Bit-exact on data that is exact in bf16. */
+int sgv3d_conv2d_forward_f32x3(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *w_packed,
+                               const float *scale, const float *bias, const float *residual,
+                               const float *gate, float *y, void *workspace, size_t workspace_bytes,
+                               void *stream);
+
 /* Winograd F(2x2, 3x3) variant of the same operator for 3x3 / stride 1 / dilation 1 / pad 1 layers with
  * cin % 8 == 0 (2.25x fewer multiplies; cuDNN, which the reference's nn.Conv2d dispatches to, uses the
  * same algorithm family for these layers).  Same descriptor, epilogue, modes (NORMAL / NCHW_OUT /

@@ -407,14 +407,23 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int LDKB = BK + 8;   // row stride in bf16 elements (80 bytes)
 
-template <int WTM, int WTN, bool FAST>
-__global__ __launch_bounds__(kThreads, 2) void conv_igemm_bf16_kernel(const ConvArgs a) {
+//
+// SPLIT3 ("f32x3"): float32-accurate products on the bf16 matrix cores.  Every operand x is split exactly into three
+// bf16 terms, x = hi + mid + lo (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); the remainders are exact in
+// f32), kept as three planes in LDS, and a . b is summed from the six partial products whose weight is >= 2^-16 of the
+// leading one: hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi, each exact in the f32 accumulator.  The dropped terms
+// (mid.lo, lo.mid, lo.lo) are below 2^-23 relative: the error of a product is that of one f32 rounding.  Six bf16 MFMAs
+// of K = 16 take 192 cycles where the f32 MFMA needs 512 for the same K.
+template <int WTM, int WTN, bool FAST, bool SPLIT3>
+__global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void conv_igemm_bf16_kernel(const ConvArgs a) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     constexpr int A_CH = BM / 32, B_CH = BN / 32;
+    constexpr int NP = SPLIT3 ? 3 : 1;                         // bf16 planes per operand
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16 *const As0 = reinterpret_cast<__bf16 *>(smem);
-    __bf16 *const Bs0 = As0 + BM * LDKB;
-    constexpr int kBufStride = (BM + BN) * LDKB;               // bf16 elements
+    __bf16 *const Bs0 = As0 + NP * BM * LDKB;
+    constexpr int kBufStride = NP * (BM + BN) * LDKB;          // bf16 elements
+    constexpr int kPlaneA = BM * LDKB, kPlaneB = BN * LDKB;
     int2 *const klut = reinterpret_cast<int2 *>(As0 + 2 * kBufStride);
     if constexpr (!FAST) {
         for (int kc = threadIdx.x; kc < a.k_pad / 4; kc += kThreads) {
@@ -513,16 +522,24 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_bf16_kernel(const Conv
             }                                                                                         \
         }                                                                                             \
     } while (0)
-#define SGV3D_CVT_STORE(DST, V)                                                                       \
+#define SGV3D_CVT_STORE(DST, V, PLANE)                                                                \
     do {                                                                                              \
-        const f32x4v f_ = {V.x, V.y, V.z, V.w};                                                       \
-        *reinterpret_cast<bf16x4 *>(DST) = __builtin_convertvector(f_, bf16x4);                       \
+        f32x4v f_ = {V.x, V.y, V.z, V.w};                                                             \
+        const bf16x4 h_ = __builtin_convertvector(f_, bf16x4);                                        \
+        *reinterpret_cast<bf16x4 *>(DST) = h_;                                                        \
+        if constexpr (SPLIT3) {                                                                       \
+            f_ -= __builtin_convertvector(h_, f32x4v);                                                \
+            const bf16x4 m_ = __builtin_convertvector(f_, bf16x4);                                    \
+            *reinterpret_cast<bf16x4 *>((DST) + (PLANE)) = m_;                                        \
+            f_ -= __builtin_convertvector(m_, f32x4v);                                                \
+            *reinterpret_cast<bf16x4 *>((DST) + 2 * (PLANE)) = __builtin_convertvector(f_, bf16x4);   \
+        }                                                                                             \
     } while (0)
 #define SGV3D_STORE_TILE(RA, RB, BUF)                                                                 \
     do {                                                                                              \
         __bf16 *As_ = As0 + (BUF) * kBufStride, *Bs_ = Bs0 + (BUF) * kBufStride;                      \
-        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) SGV3D_CVT_STORE(As_ + (r0 + 32 * i) * LDKB + cc * 4, RA[i]); \
-        _Pragma("unroll") for (int i = 0; i < B_CH; ++i) SGV3D_CVT_STORE(Bs_ + (r0 + 32 * i) * LDKB + cc * 4, RB[i]); \
+        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) SGV3D_CVT_STORE(As_ + (r0 + 32 * i) * LDKB + cc * 4, RA[i], kPlaneA); \
+        _Pragma("unroll") for (int i = 0; i < B_CH; ++i) SGV3D_CVT_STORE(Bs_ + (r0 + 32 * i) * LDKB + cc * 4, RB[i], kPlaneB); \
     } while (0)
 
     const int wave = tid >> 6, lane = tid & 63;
@@ -537,23 +554,36 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_bf16_kernel(const Conv
         for (int nt = 0; nt < WTN; ++nt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
-    bf16x8 fa[2][WTM], fb[2][WTN];
+    bf16x8 fa[NP][WTM], fb[NP][WTN];
+#define SGV3D_READ_STEP(BUF, S)                                                                       \
+    do {                                                                                              \
+        _Pragma("unroll") for (int p_ = 0; p_ < NP; ++p_) {                                           \
+            _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                        \
+                fa[p_][mt] = *reinterpret_cast<const bf16x8 *>(As0 + (BUF) * kBufStride + p_ * kPlaneA + a_frag_off + mt * 32 * LDKB + (S) * 16); \
+            _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt)                                        \
+                fb[p_][nt] = *reinterpret_cast<const bf16x8 *>(Bs0 + (BUF) * kBufStride + p_ * kPlaneB + b_frag_off + nt * 32 * LDKB + (S) * 16); \
+        }                                                                                             \
+    } while (0)
+#define SGV3D_MM(PA, PB)                                                                              \
+    _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                                \
+        _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt)                                            \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][mt], fb[PB][nt], acc[mt][nt], 0, 0, 0);
+    // small terms first, so that the leading product meets an accumulator that already holds the corrections
+#define SGV3D_MFMA_STEP()                                                                             \
+    do {                                                                                              \
+        if constexpr (SPLIT3) {                                                                       \
+            SGV3D_MM(0, 2) SGV3D_MM(2, 0) SGV3D_MM(1, 1) SGV3D_MM(0, 1) SGV3D_MM(1, 0)                \
+        }                                                                                             \
+        SGV3D_MM(0, 0)                                                                                \
+    } while (0)
 #define SGV3D_PHASE(BUF, RA, RB, SA, SB, HAVE_NEXT)                                                   \
     do {                                                                                              \
         SGV3D_LOAD_TILE(RA, RB);                                                                      \
-        _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                            \
-            _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                        \
-                fa[s_][mt] = *reinterpret_cast<const bf16x8 *>(As0 + (BUF) * kBufStride + a_frag_off + mt * 32 * LDKB + s_ * 16); \
-            _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt)                                        \
-                fb[s_][nt] = *reinterpret_cast<const bf16x8 *>(Bs0 + (BUF) * kBufStride + b_frag_off + nt * 32 * LDKB + s_ * 16); \
-        }                                                                                             \
-        _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                            \
-            _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt)                                        \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][mt], fb[0][nt], acc[mt][nt], 0, 0, 0); \
+        SGV3D_READ_STEP(BUF, 0);                                                                      \
+        SGV3D_MFMA_STEP();                                                                            \
+        SGV3D_READ_STEP(BUF, 1);                                                                      \
         if (HAVE_NEXT) SGV3D_STORE_TILE(SA, SB, (BUF) ^ 1);                                           \
-        _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                            \
-            _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt)                                        \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][mt], fb[1][nt], acc[mt][nt], 0, 0, 0); \
+        SGV3D_MFMA_STEP();                                                                            \
         __syncthreads();                                                                              \
     } while (0)
 
@@ -570,6 +600,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_bf16_kernel(const Conv
 #undef SGV3D_CVT_STORE
 #undef SGV3D_STORE_TILE
 #undef SGV3D_PHASE
+#undef SGV3D_READ_STEP
+#undef SGV3D_MM
+#undef SGV3D_MFMA_STEP
 
     // epilogue: the accumulator layout is that of every 32x32 MFMA (row = (e & 3) + 8 (e >> 2) + 4 h, column = lane & 31)
     float *ws = a.split_k > 1 ? a.ws + (size_t)blockIdx.y * a.M * a.N : nullptr;
@@ -666,15 +699,15 @@ int launch(const ConvArgs &a, hipStream_t st) {
     return a.korder == 1 ? launch_t<WTM, WTN, true>(a, st) : launch_t<WTM, WTN, false>(a, st);
 }
 
-template <int WTM, int WTN, bool FAST>
+template <int WTM, int WTN, bool FAST, bool SPLIT3>
 int launch_bf16_t(const ConvArgs &a, hipStream_t st) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
-    constexpr size_t tiles_lds = sizeof(unsigned short) * 2 * (BM + BN) * LDKB;
+    constexpr size_t tiles_lds = sizeof(unsigned short) * 2 * (SPLIT3 ? 3 : 1) * (BM + BN) * LDKB;
     const size_t lds = tiles_lds + (FAST ? 0 : (size_t)a.k_pad / 4 * 8);
     SGV3D_REQUIRE(lds <= 160 * 1024, "conv2d_forward_bf16: K = %d too long for the tap-major kernel's decode table", a.K);
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16_kernel<WTM, WTN, FAST>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16_kernel<WTM, WTN, FAST, SPLIT3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return fail(SGV3D_ELAUNCH, "conv2d_forward_bf16: cannot raise the dynamic LDS limit to %zu", lds);
         lds_set = lds;
@@ -684,15 +717,16 @@ int launch_bf16_t(const ConvArgs &a, hipStream_t st) {
     if (!b.zeros) return fail(SGV3D_ELAUNCH, "conv2d_forward_bf16: cannot resolve the zero block");
     b.tiles_m = cdiv(a.M, BM);
     b.tiles_n = cdiv(a.N, BN);
-    hipLaunchKernelGGL((conv_igemm_bf16_kernel<WTM, WTN, FAST>), dim3(b.tiles_m * b.tiles_n, b.split_k), dim3(kThreads), lds,
-                       st, b);
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<WTM, WTN, FAST, SPLIT3>), dim3(b.tiles_m * b.tiles_n, b.split_k), dim3(kThreads),
+                       lds, st, b);
     if (b.split_k > 1) return launch_splitk_reduce(b, st);
     return check_launch("conv_igemm_bf16_kernel");
 }
 
 template <int WTM, int WTN>
-int launch_bf16(const ConvArgs &a, hipStream_t st) {
-    return a.korder == 1 ? launch_bf16_t<WTM, WTN, true>(a, st) : launch_bf16_t<WTM, WTN, false>(a, st);
+int launch_bf16(const ConvArgs &a, hipStream_t st, bool split3) {
+    if (split3) return a.korder == 1 ? launch_bf16_t<WTM, WTN, true, true>(a, st) : launch_bf16_t<WTM, WTN, false, true>(a, st);
+    return a.korder == 1 ? launch_bf16_t<WTM, WTN, true, false>(a, st) : launch_bf16_t<WTM, WTN, false, false>(a, st);
 }
 
 int pick_tile(long long M, int N) {
@@ -762,7 +796,7 @@ extern "C" size_t sgv3d_conv2d_workspace_bytes(const sgv3d_conv_desc *d) {
 static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const float *w_packed,
                                const float *scale, const float *bias, const float *residual,
                                const float *gate, float *y, void *workspace, size_t workspace_bytes,
-                               void *stream, bool bf16) {
+                               void *stream, int bf16 /* 0: f32 MFMA, 1: bf16 operands, 3: f32 as three bf16 terms */) {
     SGV3D_REQUIRE(d && x && w_packed && y, "conv2d_forward: null pointer");
     SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->out_h > 0 && d->out_w > 0 &&
                       d->cout > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0,
@@ -834,10 +868,10 @@ static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const f
     hipStream_t st = as_stream(stream);
     if (bf16) {
         switch (tile) {
-            case SGV3D_TILE_128x128: return launch_bf16<2, 2>(a, st);
-            case SGV3D_TILE_128x64: return launch_bf16<2, 1>(a, st);
-            case SGV3D_TILE_64x128: return launch_bf16<1, 2>(a, st);
-            case SGV3D_TILE_64x64: return launch_bf16<1, 1>(a, st);
+            case SGV3D_TILE_128x128: return launch_bf16<2, 2>(a, st, bf16 == 3);
+            case SGV3D_TILE_128x64: return launch_bf16<2, 1>(a, st, bf16 == 3);
+            case SGV3D_TILE_64x128: return launch_bf16<1, 2>(a, st, bf16 == 3);
+            case SGV3D_TILE_64x64: return launch_bf16<1, 1>(a, st, bf16 == 3);
             default: return fail(SGV3D_EINVAL, "conv2d_forward_bf16: unknown tile %d", tile);
         }
     }
@@ -854,12 +888,19 @@ extern "C" int sgv3d_conv2d_forward(const sgv3d_conv_desc *d, const float *x, co
                                     const float *scale, const float *bias, const float *residual,
                                     const float *gate, float *y, void *workspace, size_t workspace_bytes,
                                     void *stream) {
-    return conv2d_forward_impl(d, x, w_packed, scale, bias, residual, gate, y, workspace, workspace_bytes, stream, false);
+    return conv2d_forward_impl(d, x, w_packed, scale, bias, residual, gate, y, workspace, workspace_bytes, stream, 0);
 }
 
 extern "C" int sgv3d_conv2d_forward_bf16(const sgv3d_conv_desc *d, const float *x, const float *w_packed,
                                          const float *scale, const float *bias, const float *residual,
                                          const float *gate, float *y, void *workspace, size_t workspace_bytes,
                                          void *stream) {
-    return conv2d_forward_impl(d, x, w_packed, scale, bias, residual, gate, y, workspace, workspace_bytes, stream, true);
+    return conv2d_forward_impl(d, x, w_packed, scale, bias, residual, gate, y, workspace, workspace_bytes, stream, 1);
+}
+
+extern "C" int sgv3d_conv2d_forward_f32x3(const sgv3d_conv_desc *d, const float *x, const float *w_packed,
+                                          const float *scale, const float *bias, const float *residual,
+                                          const float *gate, float *y, void *workspace, size_t workspace_bytes,
+                                          void *stream) {
+    return conv2d_forward_impl(d, x, w_packed, scale, bias, residual, gate, y, workspace, workspace_bytes, stream, 3);
 }

@@ -44,6 +44,11 @@ FUSED_HEAD = not _os.environ.get("SGV3D_NO_FUSED_HEAD")
 # HBM) -- the compute dtype BASELINE cfg-3 / cfg-5 name.  Winograd and the fused head kernel are fp32-only and are not
 # used in this mode (a bf16 direct convolution runs at 16x the fp32 MFMA rate, so the 2.25x saving no longer matters).
 MFMA_BF16 = bool(_os.environ.get("SGV3D_BF16"))
+# True (SGV3D_F32X3=1): the implicit-GEMM layers compute float32-accurate products on the bf16 matrix cores -- every
+# operand is split exactly into three bf16 terms and six partial products are accumulated in f32 (csrc/conv_igemm.hip,
+# SPLIT3): the error of a product is one f32 rounding, the MFMA time 192 instead of 512 cycles per 16 k.  Winograd
+# layers keep competing in the first-call measurement.  Opt-in: the default path multiplies on the f32 MFMA.
+MFMA_F32X3 = bool(_os.environ.get("SGV3D_F32X3"))
 # (tile, split-K) decisions by layer signature.  SGV3D_TUNE_CACHE=<file> loads them at import and
 # save_tune_db() writes them back, so that a profiled run replays the choices of an earlier run
 # instead of timing candidates again (keeps rocprofv3 per-kernel averages free of tuning launches).
@@ -254,12 +259,12 @@ class PackedConv:
         t = int(self.tile if tile is None else tile)
         sk = int(split_k) if split_k else 0
         if t == 0 or sk == 0:
-            key = (B, H, W, t, sk, MFMA_BF16)
+            key = (B, H, W, t, sk, MFMA_BF16, MFMA_F32X3)
             choice = self._tile_cache.get(key)
             if choice is None:
                 sig = (f"{self.cout}x{self.cin}k{self.kh}x{self.kw}s{self.stride}p{self.pad}d{self.dil}"
                        f"ks{self.ks}|{B}x{H}x{W}|m{d.mode}r{int(residual is not None)}g{int(gate is not None)}|{t}.{sk}"
-                       + ("|bf16" if MFMA_BF16 else ""))
+                       + ("|bf16" if MFMA_BF16 else "|f32x3" if MFMA_F32X3 else ""))
                 if sig in TUNE_DB:
                     choice = TUNE_DB[sig]
                     self._tile_cache[key] = choice
@@ -272,7 +277,7 @@ class PackedConv:
             t, sk = choice
         d.tile, d.split_k = t, sk
         flops = 2.0 * gemm_m * gemm_n * (self.cin * self.kh * self.kw)
-        name = ("conv_" if t >= TILE_WINO else ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_")) + TILE_NAMES[t]
+        name = ("conv_" if t >= TILE_WINO else ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_f32x3_" if MFMA_F32X3 else "conv_igemm_")) + TILE_NAMES[t]
         if t < TILE_WINO and self.k_order == 0:
             name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
         if PROFILE_DETAIL:
@@ -308,7 +313,8 @@ class PackedConv:
             return lib.sgv3d_conv2d_winograd_forward(ctypes.byref(d), x.data_ptr(), self.w_wino.data_ptr(),
                                                      _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
                                                      _lib.ptr(gate), out.data_ptr(), _lib.ptr(ws), nws, _st(x))
-        fwd = lib.sgv3d_conv2d_forward_bf16 if MFMA_BF16 else lib.sgv3d_conv2d_forward
+        fwd = (lib.sgv3d_conv2d_forward_bf16 if MFMA_BF16 else
+               lib.sgv3d_conv2d_forward_f32x3 if MFMA_F32X3 else lib.sgv3d_conv2d_forward)
         return fwd(ctypes.byref(d), x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.scale),
                                         _lib.ptr(self.shift), _lib.ptr(residual), _lib.ptr(gate), out.data_ptr(),
                                         _lib.ptr(ws), nws, _st(x))

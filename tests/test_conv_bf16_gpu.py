@@ -102,3 +102,64 @@ def test_bf16_model_forward_close_to_fp32_oracle(bf16_mode):
             err = float((v.cpu() - want).abs().max()) / max(1.0, float(want.abs().max()))
             worst = max(worst, err)
     assert 1e-5 < worst < 5e-2, worst                                        # rounded operands: not the fp32 path, yet close
+
+
+# ---------------------------------------------------------------------------------------------- f32x3 (three bf16 terms)
+@pytest.fixture
+def f32x3_mode():
+    old = hip_ops.MFMA_F32X3
+    hip_ops.MFMA_F32X3 = True
+    yield
+    hip_ops.MFMA_F32X3 = old
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+def test_f32x3_conv_is_float32_accurate(case, tile):
+    """Error against float64 of the split-operand kernel beside that of the f32-MFMA kernel on the same data: the same
+    order of magnitude (both are bounded by float32 rounding of products and sums), and within 2e-6 of the output scale."""
+    B, cin, H, W, cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(B, cin, H, W, generator=g) * torch.exp(torch.randn(B, cin, 1, 1, generator=g))     # mixed magnitudes
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    want = F.conv2d(x.double(), w.double(), None, stride, pad, dil)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    errs = {}
+    for mode in (False, True):
+        hip_ops.MFMA_F32X3 = mode
+        try:
+            y = hip_ops.PackedConv(w.to(DEV), stride=stride, pad=pad, dil=dil)(xd, tile=tile, split_k=1)
+        finally:
+            hip_ops.MFMA_F32X3 = False
+        errs[mode] = float((y.cpu().double().permute(0, 3, 1, 2) - want).abs().max()) / float(want.abs().max())
+    assert errs[True] <= 2e-6, errs
+    assert errs[True] <= 4 * errs[False] + 1e-7, errs
+
+
+def test_f32x3_exact_on_small_integers(f32x3_mode):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-4, 5, (1, 96, 13, 15), generator=g).float()
+    w = torch.randint(-3, 4, (80, 96, 3, 3), generator=g).float()
+    want = F.conv2d(x, w, None, 1, 1)
+    for tile in (1, 2, 3, 4):
+        y = hip_ops.PackedConv(w.to(DEV), stride=1, pad=1)(x.permute(0, 2, 3, 1).contiguous().to(DEV), tile=tile)
+        assert torch.equal(y.cpu().permute(0, 3, 1, 2), want), tile
+
+
+def test_f32x3_model_forward_meets_the_fp32_bar(f32x3_mode):
+    from oracle import torch_model as TM
+    from sgv3d_amd import synthetic as S
+    from sgv3d_amd.models.bev_height import BEVHeight
+    torch.manual_seed(0)
+    bc, hc = S.small_conf()
+    m = BEVHeight(bc, hc).eval()
+    S.randomize_norm_stats_(m, 0)
+    imgs = S.make_images(2, bc['final_dim'], seed=5)
+    mats = S.make_mats(2, scale=128 / 864)
+    ref = TM.bevheight_forward(m.state_dict(), bc, hc, imgs, mats)
+    m = m.to(DEV)
+    with torch.no_grad():
+        preds = m(imgs.to(DEV), {k: v.to(DEV) for k, v in mats.items()})
+    for t in range(6):
+        for k, v in preds[t][0].items():
+            torch.testing.assert_close(v.cpu(), ref[t][0][k], rtol=1e-3, atol=1e-3)      # the north-star bar of the f32 path
