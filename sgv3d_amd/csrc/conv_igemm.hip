@@ -471,6 +471,26 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) b_off[i] = (unsigned)(((size_t)(n0 + r0 + 32 * i) * a.k_pad + cc * 4) * 4);
 
+    // bf16 MFMAs are 16x faster than f32 ones: the address arithmetic of the operand loads must shrink with them.
+    // FAST path: which taps of a row's pixel fall inside the image is a bit mask computed once (<= 32 taps); a k-tile
+    // then costs one bit test, one add and one select per 16-byte chunk.  1x1 / unpadded single-tap layers (most
+    // launches of a ResNet) need nothing per tile: the lane offset is fixed and the channel chunk goes into the
+    // buffer load's scalar offset.
+    const int taps = a.kh * a.kw;
+    const bool use_mask = FAST && taps <= 32;
+    const bool one_tap = FAST && taps == 1 && a.pad == 0;
+    unsigned a_mask[A_CH], a_fix[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        unsigned mk = 0;
+        if (use_mask)
+            for (int t = 0; t < taps; ++t) {
+                const int ih = a_ih0[i] + (t / a.kw) * a.dil, iw = a_iw0[i] + (t % a.kw) * a.dil;
+                mk |= (a_ok[i] && (unsigned)ih < (unsigned)a.in_h && (unsigned)iw < (unsigned)a.in_w) ? (1u << t) : 0u;
+            }
+        a_mask[i] = mk;
+        a_fix[i] = (mk & 1u) ? a_off[i] : 0xffffffffu;
+    }
     float4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
     const int nkt_all = FAST ? (a.cin / BK) * a.kh * a.kw : a.k_pad / BK;
     const int kt_begin = (int)((long long)nkt_all * blockIdx.y / a.split_k);
@@ -500,13 +520,27 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
             dx_ = e_.y & 0xffff;                                                                      \
             koff_ = e_.x - cc * 4;                                                                    \
         }                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                            \
-            const int ih_ = a_ih0[i] + dy_, iw_ = a_iw0[i] + dx_;                                     \
-            const bool v_ = a_ok[i] & kvalid_ & ((unsigned)ih_ < (unsigned)a.in_h) &                  \
-                            ((unsigned)iw_ < (unsigned)a.in_w);                                       \
-            const unsigned vo_ = v_ ? a_off[i] + (unsigned)(koff_ * 4) : 0xffffffffu;                 \
-            const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo_, 0, 0)); \
-            RA[i].x = t_.x; RA[i].y = t_.y; RA[i].z = t_.z; RA[i].w = t_.w;                           \
+        if (one_tap) {                                                                                \
+            _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                        \
+                const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, a_fix[i], koff_ * 4, 0)); \
+                RA[i].x = t_.x; RA[i].y = t_.y; RA[i].z = t_.z; RA[i].w = t_.w;                       \
+            }                                                                                         \
+        } else if (use_mask) {                                                                        \
+            const unsigned bit_ = kvalid_ ? 1u << (ld_kh * a.kw + ld_kw) : 0u;                        \
+            _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                        \
+                const unsigned vo_ = (a_mask[i] & bit_) ? a_off[i] + (unsigned)(koff_ * 4) : 0xffffffffu; \
+                const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo_, 0, 0)); \
+                RA[i].x = t_.x; RA[i].y = t_.y; RA[i].z = t_.z; RA[i].w = t_.w;                       \
+            }                                                                                         \
+        } else {                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                        \
+                const int ih_ = a_ih0[i] + dy_, iw_ = a_iw0[i] + dx_;                                 \
+                const bool v_ = a_ok[i] & kvalid_ & ((unsigned)ih_ < (unsigned)a.in_h) &              \
+                                ((unsigned)iw_ < (unsigned)a.in_w);                                   \
+                const unsigned vo_ = v_ ? a_off[i] + (unsigned)(koff_ * 4) : 0xffffffffu;             \
+                const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo_, 0, 0)); \
+                RA[i].x = t_.x; RA[i].y = t_.y; RA[i].z = t_.z; RA[i].w = t_.w;                       \
+            }                                                                                         \
         }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < B_CH; ++i) {                                            \
             const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_off[i], ktb_ * (BK * 4), 0)); \
@@ -604,7 +638,59 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
 #undef SGV3D_MM
 #undef SGV3D_MFMA_STEP
 
-    // epilogue: the accumulator layout is that of every 32x32 MFMA (row = (e & 3) + 8 (e >> 2) + 4 h, column = lane & 31)
+    // epilogue: the accumulator layout is that of every 32x32 MFMA (row = (e & 3) + 8 (e >> 2) + 4 h, column = lane & 31),
+    // so the f32 kernel's fast path (hoisted channel terms, buffer stores with scalar row offsets) applies unchanged
+    if ((a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr)) && m0 + BM <= a.M) {
+        const bool partial = a.split_k > 1;
+        const int wmu = __builtin_amdgcn_readfirstlane(wm);
+        const unsigned ld = partial ? (unsigned)a.N : (unsigned)a.y_ld;
+        const long long tile_row = m0 + wmu * (BM / 2);
+        const float *const ybase = partial ? a.ws + ((size_t)blockIdx.y * a.M + tile_row) * a.N
+                                           : a.y + tile_row * a.y_ld + a.y_coff;
+        const __amdgpu_buffer_rsrc_t y_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)ybase, 0, (int)0xffffff00u, 0x00020000);
+        const bool has_res = !partial && a.res != nullptr;
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(has_res ? a.res + tile_row * a.res_ld : a.zeros), 0, has_res ? (int)0xffffff00u : 0, 0x00020000);
+        const float floor_ = (!partial && a.relu) ? 0.f : -__builtin_inff();
+        unsigned voff[WTN], roff[WTN];
+        float sc[WTN], sh[WTN];
+#pragma unroll
+        for (int nt = 0; nt < WTN; ++nt) {
+            const int col = n0 + wn * (BN / 2) + nt * 32 + lr;
+            const bool ok = col < a.N;
+            voff[nt] = ok ? (4u * lh * ld + col) * 4u : 0xffffffffu;
+            roff[nt] = ok ? (4u * lh * (unsigned)a.res_ld + col) * 4u : 0xffffffffu;
+            sc[nt] = (!partial && ok && a.scale) ? a.scale[col] : 1.f;
+            sh[nt] = (!partial && ok && a.bias) ? a.bias[col] : 0.f;
+        }
+#define SGV3D_EPI_F(MT, NT, E)                                                                        \
+    {                                                                                                 \
+        const unsigned r_ = (MT) * 32 + ((E) & 3) + 8 * ((E) >> 2);                                   \
+        float v_ = acc[MT][NT][E];                                                                    \
+        if (!partial) {                                                                               \
+            v_ = v_ * sc[NT] + sh[NT];                                                                \
+            if (has_res)                                                                              \
+                v_ += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, roff[NT], r_ * a.res_ld * 4u, 0)); \
+            v_ = fmaxf(v_, floor_);                                                                   \
+        }                                                                                             \
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v_), y_rsrc, voff[NT], r_ * ld * 4u, 0); \
+    }
+#define SGV3D_EPI_FT(MT, NT)                                                                          \
+    SGV3D_EPI_F(MT, NT, 0) SGV3D_EPI_F(MT, NT, 1) SGV3D_EPI_F(MT, NT, 2) SGV3D_EPI_F(MT, NT, 3)       \
+    SGV3D_EPI_F(MT, NT, 4) SGV3D_EPI_F(MT, NT, 5) SGV3D_EPI_F(MT, NT, 6) SGV3D_EPI_F(MT, NT, 7)       \
+    SGV3D_EPI_F(MT, NT, 8) SGV3D_EPI_F(MT, NT, 9) SGV3D_EPI_F(MT, NT, 10) SGV3D_EPI_F(MT, NT, 11)     \
+    SGV3D_EPI_F(MT, NT, 12) SGV3D_EPI_F(MT, NT, 13) SGV3D_EPI_F(MT, NT, 14) SGV3D_EPI_F(MT, NT, 15)
+        SGV3D_EPI_FT(0, 0)
+        if constexpr (WTN > 1) { SGV3D_EPI_FT(0, 1) }
+        if constexpr (WTM > 1) {
+            SGV3D_EPI_FT(1, 0)
+            if constexpr (WTN > 1) { SGV3D_EPI_FT(1, 1) }
+        }
+#undef SGV3D_EPI_FT
+#undef SGV3D_EPI_F
+        return;
+    }
     float *ws = a.split_k > 1 ? a.ws + (size_t)blockIdx.y * a.M * a.N : nullptr;
     const int row_base = m0 + wm * (BM / 2) + 4 * lh;
     const int col_base = n0 + wn * (BN / 2) + lr;

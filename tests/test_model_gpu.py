@@ -118,7 +118,7 @@ def test_bitwise_reproducible_without_autotune(small):
         hip_ops.AUTOTUNE = old
 
 
-def test_rejects_cpu_and_unbuilt_training_output(small):
+def test_rejects_cpu_and_inconsistent_train_height_flags(small):
     m = small['m']
     with pytest.raises(RuntimeError):
         m(small['imgs'], small['mats'])
@@ -126,9 +126,9 @@ def test_rejects_cpu_and_unbuilt_training_output(small):
     try:
         with pytest.raises(RuntimeError):
             m(small['imgs'], small['mats'])                       # the training forward has no CPU path either
-        m.is_train_height = True
-        with pytest.raises(NotImplementedError):
-            m(small['imgs'].to(DEV), _to_dev(small['mats']))       # the height_pred output is not built
+        m.is_train_height = True                                    # ... while backbone_conf['is_train_height'] was False
+        with pytest.raises(RuntimeError, match="is_train_height"):
+            m(small['imgs'].to(DEV), _to_dev(small['mats']))       # the reference would fail unpacking the backbone's output
     finally:
         m.is_train_height = False
         m.eval()
