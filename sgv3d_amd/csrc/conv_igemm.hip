@@ -292,20 +292,25 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     // Residual prefetch (64x64 tile, fast-path epilogue): the small-K layers that carry a residual (the expanding 1x1
     // convolutions of the bottlenecks) spend a third of a workgroup's life waiting for the residual rows they only
     // ask for after the k loop; asked for here, the 16 values per lane arrive under the loop.
-    constexpr bool kPrefetchRes = WTM * WTN == 1;
+    constexpr bool kPrefetchRes = WTM * WTN <= 2;
     const bool fast_epi = (a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr)) && m0 + BM <= a.M;
-    float resv[16];
+    float resv[WTM][WTN][16];
     if constexpr (kPrefetchRes) {
         const bool want = fast_epi && a.split_k <= 1 && a.res != nullptr;
         const long long tile_row = m0 + __builtin_amdgcn_readfirstlane(wm) * (BM / 2);
         const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(want ? a.res + tile_row * a.res_ld : a.zeros), 0, want ? (int)0xffffff00u : 0, 0x00020000);
-        const int col = n0 + wn * (BN / 2) + lr;
-        const unsigned roff0 = (want && col < a.N) ? (4u * lh * (unsigned)a.res_ld + col) * 4u : 0xffffffffu;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const unsigned r_ = (e & 3) + 8 * (e >> 2);
-            resv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr_rsrc, roff0, r_ * a.res_ld * 4u, 0));
+        for (int nt = 0; nt < WTN; ++nt) {
+            const int col = n0 + wn * (BN / 2) + nt * 32 + lr;
+            const unsigned roff0 = (want && col < a.N) ? (4u * lh * (unsigned)a.res_ld + col) * 4u : 0xffffffffu;
+#pragma unroll
+            for (int mt = 0; mt < WTM; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned r_ = mt * 32 + (e & 3) + 8 * (e >> 2);
+                    resv[mt][nt][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr_rsrc, roff0, r_ * a.res_ld * 4u, 0));
+                }
         }
     }
     SGV3D_LOAD_TILE(ra0, rb0);                       // tile 0
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
         if (!partial) {                                                                               \
             v_ = v_ * sc[NT] + sh[NT];                                                                \
             if constexpr (kPrefetchRes) {                                                             \
-                v_ += resv[E];        /* zeros when there is no residual */                           \
+                v_ += resv[MT][NT][E]; /* zeros when there is no residual */                          \
             } else if (has_res)                                                                       \
                 v_ += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, roff[NT], r_ * a.res_ld * 4u, 0)); \
             v_ = fmaxf(v_, floor_);                                                                   \
@@ -642,6 +647,30 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
         __syncthreads();                                                                              \
     } while (0)
 
+    // Residual prefetch (64x64 tile, fast-path epilogue): the small-K layers that carry a residual (the expanding 1x1
+    // convolutions of the bottlenecks) spend a third of a workgroup's life waiting for the residual rows they only
+    // ask for after the k loop; asked for here, the 16 values per lane arrive under the loop.
+    constexpr bool kPrefetchRes = WTM * WTN <= 2 && !SPLIT3;
+    const bool fast_epi = (a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr)) && m0 + BM <= a.M;
+    float resv[WTM][WTN][16];
+    if constexpr (kPrefetchRes) {
+        const bool want = fast_epi && a.split_k <= 1 && a.res != nullptr;
+        const long long tile_row = m0 + __builtin_amdgcn_readfirstlane(wm) * (BM / 2);
+        const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(want ? a.res + tile_row * a.res_ld : a.zeros), 0, want ? (int)0xffffff00u : 0, 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < WTN; ++nt) {
+            const int col = n0 + wn * (BN / 2) + nt * 32 + lr;
+            const unsigned roff0 = (want && col < a.N) ? (4u * lh * (unsigned)a.res_ld + col) * 4u : 0xffffffffu;
+#pragma unroll
+            for (int mt = 0; mt < WTM; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned r_ = mt * 32 + (e & 3) + 8 * (e >> 2);
+                    resv[mt][nt][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr_rsrc, roff0, r_ * a.res_ld * 4u, 0));
+                }
+        }
+    }
     SGV3D_LOAD_TILE(ra0, rb0);
     SGV3D_LOAD_TILE(ra1, rb1);
     SGV3D_STORE_TILE(ra0, rb0, 0);
@@ -661,7 +690,7 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
 
     // epilogue: the accumulator layout is that of every 32x32 MFMA (row = (e & 3) + 8 (e >> 2) + 4 h, column = lane & 31),
     // so the f32 kernel's fast path (hoisted channel terms, buffer stores with scalar row offsets) applies unchanged
-    if ((a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr)) && m0 + BM <= a.M) {
+    if (fast_epi) {
         const bool partial = a.split_k > 1;
         const int wmu = __builtin_amdgcn_readfirstlane(wm);
         const unsigned ld = partial ? (unsigned)a.N : (unsigned)a.y_ld;
@@ -691,7 +720,9 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
         float v_ = acc[MT][NT][E];                                                                    \
         if (!partial) {                                                                               \
             v_ = v_ * sc[NT] + sh[NT];                                                                \
-            if (has_res)                                                                              \
+            if constexpr (kPrefetchRes) {                                                             \
+                v_ += resv[MT][NT][E]; /* zeros when there is no residual */                          \
+            } else if (has_res)                                                                       \
                 v_ += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, roff[NT], r_ * a.res_ld * 4u, 0)); \
             v_ = fmaxf(v_, floor_);                                                                   \
         }                                                                                             \
