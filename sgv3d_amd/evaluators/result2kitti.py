@@ -1,11 +1,25 @@
-"""``kitti_evaluation`` of evaluators/result2kitti.py:62-72: read the prediction and ground-truth label folders, run the
-KITTI evaluation (R40), write the result text under ``metric_path/R40`` and return the moderate 3-D AP of ``Car``."""
+"""Detections -> KITTI label files -> KITTI AP, as evaluators/result2kitti.py does it.
+
+``result2kitti`` (:212-268): the results JSON written by ``RoadSideEvaluator._format_bbox`` (per image token a list of
+``translation`` / ``size`` / ``box_yaw`` / ``detection_score`` / ``detection_name``) and the KITTI-format calibration
+files of the data root (``training/calib/%06d.txt`` with ``P2:`` and ``Tr_velo_to_cam:`` rows, :200-210) -> one label
+file per image under ``results_path/data``: class through ``category_map_dair`` (:16), detections above score 0.45,
+``alpha`` from the box edge in the camera frame (:99-124), the 2-D box from the projected corners clipped to the image
+(:157-173), location = the box's bottom centre in the camera frame, ``rotation_y = pi/2 - yaw``, every number rounded
+to 4 decimals.  ``kitti_evaluation`` (:62-72): read the two label folders, run the KITTI evaluation (R40), write the
+result text under ``metric_path/R40`` and return the moderate 3-D AP of ``Car``.  Host code (numpy), as in the
+reference; the variants for the raw DAIR-V2X-I / Rope3D roots (:270-393, other calibration file formats) are not
+rebuilt."""
+import json
+import math
 import os
+
+import numpy as np
 
 from .kitti_utils import kitti_common as kitti
 from .kitti_utils.eval import kitti_eval
 
-__all__ = ['kitti_evaluation']
+__all__ = ['kitti_evaluation', 'result2kitti', 'load_calib_dair', 'category_map_dair']
 
 
 def kitti_evaluation(pred_label_path, gt_label_path, current_classes=("Car", "Pedestrian", "Cyclist"), metric_path="metric"):
@@ -19,3 +33,85 @@ def kitti_evaluation(pred_label_path, gt_label_path, current_classes=("Car", "Pe
         f.write(result)
     print(result)
     return mAP_3d_moderate
+
+
+category_map_dair = {"car": "Car", "van": "Car", "truck": "Car", "bus": "Car", "pedestrian": "Pedestrian",
+                     "bicycle": "Cyclist", "trailer": "Cyclist", "motorcycle": "Cyclist"}
+
+
+def load_calib_dair(calib_file):
+    """-> (Tr_velo_to_cam 4x4, camera matrix 3x3) from a KITTI-format calibration file; both rows are parsed in float32
+    like the reference does (:200-210)."""
+    P2 = Tr = None
+    with open(calib_file, 'r') as f:
+        for line in f:
+            row = line.rstrip('\n').split(' ')
+            if row[0] == 'P2:':
+                P2 = np.array([float(v) for v in row[1:]], dtype=np.float32).reshape(3, 4)
+            elif row[0] == 'Tr_velo_to_cam:':
+                Tr = np.array([float(v) for v in row[1:]], dtype=np.float32).reshape(3, 4)
+    Tr = np.concatenate((Tr, np.array([[0, 0, 0, 1]])), axis=0)
+    return Tr, P2[:3, :3]
+
+
+def _yaw_matrix(yaw):
+    c, s = math.cos(yaw), math.sin(yaw)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], np.float64)
+
+
+def _box_corners(size, yaw, bottom_centre):
+    """8 corners [3, 8] of a box given (x extent, y extent, height), yaw about z and its bottom centre (:19-32,:99-110)."""
+    l, w, h = size
+    c = np.array([[l / 2, l / 2, -l / 2, -l / 2, l / 2, l / 2, -l / 2, -l / 2],
+                  [w / 2, -w / 2, -w / 2, w / 2, w / 2, -w / 2, -w / 2, w / 2],
+                  [0, 0, 0, 0, h, h, h, h]], np.float64)
+    return _yaw_matrix(yaw) @ c + np.asarray(bottom_centre, np.float64).reshape(3, 1)
+
+
+def _normalize_angle(angle):
+    a = np.arctan(np.tan(angle))                                    # :92-97
+    return a + math.pi if np.cos(angle) < 0 else a
+
+
+def result2kitti(results_file, results_path, dair_root, gt_label_path, demo=False):
+    with open(results_file, 'r', encoding='utf8') as fp:
+        results = json.load(fp)["results"]
+    os.makedirs(os.path.join(results_path, "data"), exist_ok=True)
+    for sample_token, preds in results.items():
+        sample_id = int(sample_token.split("/")[-1].split(".")[0])
+        Tr, K = load_calib_dair(os.path.join(dair_root, "training/calib", "{:06d}".format(sample_id) + ".txt"))
+        R, t = Tr[:3, :3].astype(np.float64), Tr[:3, 3].astype(np.float64).reshape(3, 1)
+        K34 = np.concatenate([K, np.zeros((3, 1))], axis=1)
+        lines = []
+        for pred in preds:
+            x, y, z = pred["translation"]
+            w, l, h = pred["size"]
+            yaw_lidar = pred["box_yaw"]
+            score, cls = pred["detection_score"], pred["detection_name"]
+            centre_cam = R @ np.array([[x], [y], [z]], np.float64) + t
+            # orientation: direction of the box edge corner 3 -> corner 0 in the camera's x-z plane (:112-124)
+            cam = R @ _box_corners([l, w, h], yaw_lidar, [x, y, z]) + t
+            yaw_cam = math.atan2(-(cam[2, 0] - cam[2, 3]), cam[0, 0] - cam[0, 3])
+            alpha = yaw_cam - math.atan2(centre_cam[0, 0], centre_cam[2, 0])
+            if alpha > math.pi:
+                alpha -= 2.0 * math.pi
+            if alpha <= -math.pi:
+                alpha += 2.0 * math.pi
+            alpha = _normalize_angle(alpha)
+            rot_y = 0.5 * np.pi - yaw_lidar                                                   # :239
+            cam_xyz = (Tr @ np.array([x, y, z, 1]))[:3]
+            # 2-D box: the reference builds these corners with (w, l, h) as extents and the centre raised by h/2, whose
+            # bottom is lowered again inside get_lidar_3d_8points (:241-243, :19-32)
+            corners = _box_corners([w, l, h], yaw_lidar, [x, y, (z + h / 2) - h / 2]).T       # [8, 3]
+            hom = Tr @ np.concatenate([corners, np.ones((8, 1), dtype=np.float32)], axis=1).T
+            uv = K34 @ hom
+            uv = uv[:2] / uv[2]
+            box2d = np.array([max(uv[0].min(), 0.0), max(uv[1].min(), 0.0), min(uv[0].max(), 1920.0), min(uv[1].max(), 1080.0)])
+            if score > 0.45 and cls in category_map_dair:
+                r4 = lambda v: str(round(v, 4))
+                lines.append([category_map_dair[cls], "0", "0", r4(alpha)] + [r4(v) for v in box2d] +
+                             [r4(h), r4(l), r4(w), r4(cam_xyz[0]), r4(cam_xyz[1]), r4(cam_xyz[2]), r4(rot_y), r4(score)])
+        with open(os.path.join(results_path, "data", "{:06d}".format(sample_id) + ".txt"), "w") as f:
+            for line in lines:
+                f.write(" ".join(line) + "\n")
+    return os.path.join(results_path, "data")

@@ -11,6 +11,8 @@ REFERENCE'S OWN PYTHON in the build container (needs /root/reference, which neve
                executed on a synthetic label set.  numba is absent: an identity ``jit`` runs the jitted functions as the
                plain Python they are, and the numba.cuda kernel is run thread by thread (see ``_numba_stub``).
 
+* result2kitti.npz  ``result2kitti`` (evaluators/result2kitti.py:212-268) on synthetic calibration files and a results JSON.
+
 Outputs are DATA ONLY (inputs and expected outputs); no reference source text is stored.
 
     python tests/golden/make_golden_aux.py
@@ -283,9 +285,64 @@ def make_kitti_eval():
     print("kitti_eval.npz:", result[:400])
 
 
+# ------------------------------------------------------------------------------------------------ result2kitti
+def make_result2kitti():
+    """evaluators/result2kitti.py:212-268 (``result2kitti``, the KITTI-format DAIR-V2X-I / Rope3D roots) executed on
+    synthetic calibration files and a synthetic results JSON -> the label files it writes."""
+    import json
+    import tempfile
+    import types
+    _numba_stub()
+    for name in ('cv2', 'mmcv', 'skimage', 'skimage.io'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    pq = types.ModuleType('pyquaternion')
+    pq.Quaternion = object
+    sys.modules.setdefault('pyquaternion', pq)
+    sys.path.insert(0, REF)
+    import importlib
+    r2k = importlib.import_module('evaluators.result2kitti')
+    rng = np.random.default_rng(5)
+    calibs, results = {}, {}
+    for sid in (3, 17, 250):
+        pitch = np.deg2rad(rng.uniform(8, 14))
+        # lidar/ego (x forward, y left, z up) -> camera (x right, y down, z forward), pitched down
+        base = np.array([[0, -1, 0], [0, 0, -1], [1, 0, 0]], np.float64)
+        rx = np.array([[1, 0, 0], [0, np.cos(pitch), -np.sin(pitch)], [0, np.sin(pitch), np.cos(pitch)]])
+        R_ = rx @ base
+        t_ = np.array([rng.uniform(-0.2, 0.2), rng.uniform(5.0, 7.0), rng.uniform(-0.3, 0.3)])
+        tr = np.concatenate([R_, t_[:, None]], 1)
+        P2 = np.array([[2183.4, 0, 940.6, 0], [0, 2329.3, 567.6, 0], [0, 0, 1, 0]])
+        calibs[sid] = "P2: " + " ".join(f"{v:.6f}" for v in P2.reshape(-1)) + "\n" + \
+                      "Tr_velo_to_cam: " + " ".join(f"{v:.8f}" for v in tr.reshape(-1)) + "\n"
+        preds = []
+        for k in range(int(rng.integers(3, 9))):
+            name = ['car', 'van', 'truck', 'bus', 'pedestrian', 'bicycle', 'trailer', 'motorcycle', 'barrier'][int(rng.integers(0, 9))]
+            preds.append(dict(translation=[float(rng.uniform(15, 90)), float(rng.uniform(-20, 20)), float(rng.uniform(-1.5, -0.5))],
+                              size=[float(rng.uniform(0.5, 2.5)), float(rng.uniform(0.5, 10)), float(rng.uniform(1.4, 3.2))],
+                              box_yaw=float(rng.uniform(-np.pi, np.pi)), detection_score=float(rng.uniform(0.2, 1.0)),
+                              detection_name=name))
+        results[f"training/image_2/{sid:06d}.jpg"] = preds
+    out = {'calib_ids': np.array(sorted(calibs)), 'calib_text': np.array([calibs[k] for k in sorted(calibs)]),
+           'results_json': np.array(json.dumps({'meta': {}, 'results': results}))}
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, 'root', 'training', 'calib'))
+        for sid, text in calibs.items():
+            with open(os.path.join(d, 'root', 'training', 'calib', f'{sid:06d}.txt'), 'w') as f:
+                f.write(text)
+        rf = os.path.join(d, 'results_nusc.json')
+        with open(rf, 'w') as f:
+            json.dump({'meta': {}, 'results': results}, f)
+        path = r2k.result2kitti(rf, os.path.join(d, 'out'), os.path.join(d, 'root'), os.path.join(d, 'gt'), demo=False)
+        out['label_text'] = np.array([open(os.path.join(path, f'{sid:06d}.txt')).read() for sid in sorted(calibs)])
+    np.savez_compressed(os.path.join(HERE, "result2kitti.npz"), **out)
+    print("result2kitti.npz:", out['label_text'][0][:300])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["losses", "kitti_eval"]
+    which = sys.argv[1:] or ["losses", "kitti_eval", "result2kitti"]
     if "losses" in which:
         make_losses()
     if "kitti_eval" in which:
         make_kitti_eval()
+    if "result2kitti" in which:
+        make_result2kitti()

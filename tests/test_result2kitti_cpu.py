@@ -1,0 +1,61 @@
+"""Detection -> KITTI label-file conversion (host code): ``result2kitti`` against the label files the
+reference's own function wrote for the same calibration files and results JSON (tests/golden/result2kitti.npz), and the
+``RoadSideEvaluator`` JSON stage feeding it."""
+import json
+import os
+
+import numpy as np
+
+from sgv3d_amd.evaluators.det_evaluators import RoadSideEvaluator
+from sgv3d_amd.evaluators.result2kitti import load_calib_dair, result2kitti
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "result2kitti.npz"))
+
+
+def _root(tmp_path):
+    os.makedirs(tmp_path / 'dair-v2x-i-kitti' / 'training' / 'calib')
+    for sid, text in zip(GOLD['calib_ids'], GOLD['calib_text']):
+        (tmp_path / 'dair-v2x-i-kitti' / 'training' / 'calib' / f'{int(sid):06d}.txt').write_text(str(text))
+    return str(tmp_path / 'dair-v2x-i-kitti')
+
+
+def test_result2kitti_writes_the_reference_label_files(tmp_path):
+    root = _root(tmp_path)
+    rf = tmp_path / 'results_nusc.json'
+    rf.write_text(str(GOLD['results_json']))
+    out = result2kitti(str(rf), str(tmp_path / 'out'), root, str(tmp_path / 'gt'))
+    assert out == str(tmp_path / 'out' / 'data')
+    n_lines = 0
+    for sid, want in zip(GOLD['calib_ids'], GOLD['label_text']):
+        got = open(os.path.join(out, f'{int(sid):06d}.txt')).read()
+        assert got == str(want), int(sid)                     # character by character: classes, rounding, field order
+        n_lines += len(got.splitlines())
+    assert n_lines >= 8                                        # the fixture keeps detections and drops others (score, class)
+
+
+def test_calibration_reader(tmp_path):
+    root = _root(tmp_path)
+    Tr, K = load_calib_dair(os.path.join(root, 'training', 'calib', f"{int(GOLD['calib_ids'][0]):06d}.txt"))
+    assert Tr.shape == (4, 4) and K.shape == (3, 3) and K.dtype == np.float32
+    assert np.allclose(Tr[3], [0, 0, 0, 1]) and abs(np.linalg.det(Tr[:3, :3]) - 1) < 1e-5
+
+
+def test_roadside_evaluator_json_stage(tmp_path):
+    """Identity ego2global (the roadside case): the JSON carries the boxes unchanged in the layout result2kitti reads."""
+    ev = RoadSideEvaluator(class_names=['car', 'truck', 'pedestrian'], current_classes=['Car'], data_root='x-kitti',
+                           gt_label_path='gt', output_dir=None)
+    boxes = np.array([[30.0, -2.0, -1.0, 4.2, 1.9, 1.6, 0.3, 0.0, 0.0], [50.0, 5.0, -1.2, 0.6, 0.7, 1.7, -1.0, 0.5, 0.1]])
+    res = [(boxes, np.array([0.9, 0.6]), np.array([0, 2]))]
+    metas = [dict(token='training/image_2/000003.jpg', ego2global_translation=[0, 0, 0], ego2global_rotation=[1, 0, 0, 0])]
+    files, tmp = ev.format_results(res, metas, jsonfile_prefix=str(tmp_path / 'json'))
+    data = json.load(open(files['img_bbox']))['results']['training/image_2/000003.jpg']
+    assert [d['detection_name'] for d in data] == ['car', 'pedestrian']
+    assert np.allclose(data[0]['translation'], [30, -2, -1]) and np.allclose(data[0]['size'], [1.9, 4.2, 1.6])   # (w, l, h)
+    assert data[0]['box_yaw'] == 0.3 and data[1]['attribute_name'] == 'pedestrian.moving'
+    # a 90 degree ego2global turn about z moves the centre and composes the orientation
+    metas[0]['ego2global_rotation'] = [np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)]
+    metas[0]['ego2global_translation'] = [1.0, 2.0, 3.0]
+    files, _ = ev.format_results(res, metas, jsonfile_prefix=str(tmp_path / 'json2'))
+    d0 = json.load(open(files['img_bbox']))['results']['training/image_2/000003.jpg'][0]
+    assert np.allclose(d0['translation'], [2.0 + 1.0, 30.0 + 2.0, -1.0 + 3.0])
+    assert np.allclose(d0['rotation'], [np.cos(np.pi / 4 + 0.15), 0, 0, np.sin(np.pi / 4 + 0.15)])
