@@ -1,4 +1,2 @@
-"""Loss modes, losses/constants.py:1-18: one foreground channel, mutually exclusive classes, or independent channels."""
-BINARY_MODE = "binary"
-MULTICLASS_MODE = "multiclass"
-MULTILABEL_MODE = "multilabel"
+"""Import location of the loss-mode names in the reference (losses/constants.py); they live in focal.py here."""
+from .focal import BINARY_MODE, MULTICLASS_MODE, MULTILABEL_MODE  # noqa: F401

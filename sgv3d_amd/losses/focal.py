@@ -18,9 +18,12 @@ from torch.nn.modules.loss import _Loss
 
 from .. import _lib
 from ..hip_ops import prof
-from .constants import BINARY_MODE, MULTICLASS_MODE, MULTILABEL_MODE
 
-__all__ = ['FocalLoss', 'focal_loss_with_logits']
+__all__ = ['FocalLoss', 'focal_loss_with_logits', 'BINARY_MODE', 'MULTICLASS_MODE', 'MULTILABEL_MODE']
+
+# the three target layouts FocalLoss understands (the reference keeps them in losses/constants.py): one foreground
+# channel / mutually exclusive class ids / independent per-channel targets
+BINARY_MODE, MULTICLASS_MODE, MULTILABEL_MODE = "binary", "multiclass", "multilabel"
 
 
 class _Focal(torch.autograd.Function):
