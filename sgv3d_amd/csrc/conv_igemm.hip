@@ -293,7 +293,10 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     // convolutions of the bottlenecks) spend a third of a workgroup's life waiting for the residual rows they only
     // ask for after the k loop; asked for here, the 16 values per lane arrive under the loop.
     constexpr bool kPrefetchRes = WTM * WTN <= 2;
-    const bool fast_epi = (a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr)) && m0 + BM <= a.M;
+    // (GROUP_PLANES -- the per-branch hidden maps of the two-kernel head path -- is row-linear too when a wave's columns
+    // stay inside one group: plane base + row * group width)
+    const bool fast_epi = (a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr) ||
+                           (a.mode == SGV3D_CONV_GROUP_PLANES && a.gate == nullptr && a.ks % (BN / 2) == 0)) && m0 + BM <= a.M;
     float resv[WTM][WTN][16];
     if constexpr (kPrefetchRes) {
         const bool want = fast_epi && a.split_k <= 1 && a.res != nullptr;
@@ -339,10 +342,14 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     if (fast_epi) {
         const bool partial = a.split_k > 1;
         const int wmu = __builtin_amdgcn_readfirstlane(wm);
-        const unsigned ld = partial ? (unsigned)a.N : (unsigned)a.y_ld;
+        const bool planes = !partial && a.mode == SGV3D_CONV_GROUP_PLANES;
+        const int grp = planes ? (n0 + __builtin_amdgcn_readfirstlane(wn) * (BN / 2)) / a.ks : 0;
+        const int col_sub = grp * a.ks;                      // columns are counted inside the group's plane
+        const unsigned ld = partial ? (unsigned)a.N : planes ? (unsigned)a.ks : (unsigned)a.y_ld;
         const long long tile_row = m0 + wmu * (BM / 2);
         const float *const ybase = partial ? a.ws + ((size_t)blockIdx.y * a.M + tile_row) * a.N
-                                           : a.y + tile_row * a.y_ld + a.y_coff;
+                                   : planes ? a.y + ((size_t)grp * a.M + tile_row) * a.ks
+                                            : a.y + tile_row * a.y_ld + a.y_coff;
         const __amdgpu_buffer_rsrc_t y_rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void *)ybase, 0, (int)0xffffff00u, 0x00020000);
         const bool has_res = !partial && a.res != nullptr;
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
         for (int nt = 0; nt < WTN; ++nt) {
             const int col = n0 + wn * (BN / 2) + nt * 32 + lr;
             const bool ok = col < a.N;
-            voff[nt] = ok ? (4u * lh * ld + col) * 4u : 0xffffffffu;
+            voff[nt] = ok ? (4u * lh * ld + (col - col_sub)) * 4u : 0xffffffffu;
             roff[nt] = ok ? (4u * lh * (unsigned)a.res_ld + col) * 4u : 0xffffffffu;
             sc[nt] = (!partial && ok && a.scale) ? a.scale[col] : 1.f;
             sh[nt] = (!partial && ok && a.bias) ? a.bias[col] : 0.f;
@@ -651,7 +658,10 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
     // convolutions of the bottlenecks) spend a third of a workgroup's life waiting for the residual rows they only
     // ask for after the k loop; asked for here, the 16 values per lane arrive under the loop.
     constexpr bool kPrefetchRes = WTM * WTN <= 2 && !SPLIT3;
-    const bool fast_epi = (a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr)) && m0 + BM <= a.M;
+    // (GROUP_PLANES -- the per-branch hidden maps of the two-kernel head path -- is row-linear too when a wave's columns
+    // stay inside one group: plane base + row * group width)
+    const bool fast_epi = (a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr) ||
+                           (a.mode == SGV3D_CONV_GROUP_PLANES && a.gate == nullptr && a.ks % (BN / 2) == 0)) && m0 + BM <= a.M;
     float resv[WTM][WTN][16];
     if constexpr (kPrefetchRes) {
         const bool want = fast_epi && a.split_k <= 1 && a.res != nullptr;
@@ -693,10 +703,14 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
     if (fast_epi) {
         const bool partial = a.split_k > 1;
         const int wmu = __builtin_amdgcn_readfirstlane(wm);
-        const unsigned ld = partial ? (unsigned)a.N : (unsigned)a.y_ld;
+        const bool planes = !partial && a.mode == SGV3D_CONV_GROUP_PLANES;
+        const int grp = planes ? (n0 + __builtin_amdgcn_readfirstlane(wn) * (BN / 2)) / a.ks : 0;
+        const int col_sub = grp * a.ks;                      // columns are counted inside the group's plane
+        const unsigned ld = partial ? (unsigned)a.N : planes ? (unsigned)a.ks : (unsigned)a.y_ld;
         const long long tile_row = m0 + wmu * (BM / 2);
         const float *const ybase = partial ? a.ws + ((size_t)blockIdx.y * a.M + tile_row) * a.N
-                                           : a.y + tile_row * a.y_ld + a.y_coff;
+                                   : planes ? a.y + ((size_t)grp * a.M + tile_row) * a.ks
+                                            : a.y + tile_row * a.y_ld + a.y_coff;
         const __amdgpu_buffer_rsrc_t y_rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void *)ybase, 0, (int)0xffffff00u, 0x00020000);
         const bool has_res = !partial && a.res != nullptr;
@@ -709,7 +723,7 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
         for (int nt = 0; nt < WTN; ++nt) {
             const int col = n0 + wn * (BN / 2) + nt * 32 + lr;
             const bool ok = col < a.N;
-            voff[nt] = ok ? (4u * lh * ld + col) * 4u : 0xffffffffu;
+            voff[nt] = ok ? (4u * lh * ld + (col - col_sub)) * 4u : 0xffffffffu;
             roff[nt] = ok ? (4u * lh * (unsigned)a.res_ld + col) * 4u : 0xffffffffu;
             sc[nt] = (!partial && ok && a.scale) ? a.scale[col] : 1.f;
             sh[nt] = (!partial && ok && a.bias) ? a.bias[col] : 0.f;

@@ -122,6 +122,29 @@ def test_group_planes_mode(hip):
     torch.testing.assert_close(y.cpu().permute(1, 0, 4, 2, 3).reshape(2, 192, 9, 10), ref, **TOL)
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_group_planes_fast_epilogue(hip, tile, mode):
+    """Whole m-tiles take the row-linear store path of the GROUP_PLANES layout (a wave's columns inside one 64-wide group),
+    the ragged tail the general one; 192 channels = 3 groups, so a 128-wide n-tile also carries columns past N."""
+    from sgv3d_amd import hip_ops
+    from sgv3d_amd.hip_ops import PackedConv
+    g = torch.Generator().manual_seed(40 + tile)
+    x = torch.randn(2, 64, 17, 24, generator=g)                      # M = 816: six / twelve whole tiles + a tail
+    w = torch.randn(192, 64, 3, 3, generator=g) / 24
+    scale, shift = torch.rand(192, generator=g) + 0.5, torch.randn(192, generator=g)
+    old = hip_ops.MFMA_BF16
+    hip_ops.MFMA_BF16 = mode == "bf16"
+    try:
+        y = PackedConv(w.to(DEV), pad=1, relu=True, scale=scale.to(DEV), shift=shift.to(DEV))(nhwc(x).to(DEV), group_planes=64, tile=tile, split_k=1)
+    finally:
+        hip_ops.MFMA_BF16 = old
+    xr, wr = (x.bfloat16().float(), w.bfloat16().float()) if mode == "bf16" else (x, w)
+    ref = F.relu(F.conv2d(xr, wr, None, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None])
+    assert tuple(y.shape) == (3, 2, 17, 24, 64)
+    torch.testing.assert_close(y.cpu().permute(1, 0, 4, 2, 3).reshape(2, 192, 17, 24), ref, rtol=1e-4, atol=1e-4)
+
+
 def test_nchw_out_mode(hip):
     from sgv3d_amd.hip_ops import PackedConv
     g = torch.Generator().manual_seed(3)
