@@ -95,3 +95,68 @@ def test_average_precision_tables_match_reference():
         for idx, diff in enumerate(('easy', 'moderate', 'hard')):
             assert abs(ap[j, idx, 0] - vals[f'KITTI/{name}_3D_{diff}_strict']) < 1e-9
             assert abs(ap[j, idx, 1] - vals[f'KITTI/{name}_3D_{diff}_loose']) < 1e-9
+
+
+def _oracle_curves(frames, metric, min_overlap, compute_aos, num_valid):
+    """eval_class's inner loop (eval.py:487-556) over precomputed overlaps, with the oracle's frame statistics."""
+    tps = [R.frame_statistics(f['ov'], f['gt'], f['dt'], f['ig'], f['id'], f['dc'], metric, min_overlap)[4] for f in frames]
+    thr = R.recall_thresholds(np.concatenate(tps) if tps else np.zeros(0), num_valid)
+    pr = np.zeros((len(thr), 4))
+    for f in frames:
+        for t, th in enumerate(thr):
+            tp, fp, fn, sim, _ = R.frame_statistics(f['ov'], f['gt'], f['dt'], f['ig'], f['id'], f['dc'], metric, min_overlap, th, True, compute_aos)
+            pr[t, :3] += (tp, fp, fn)
+            if sim != -1:
+                pr[t, 3] += sim
+    p, r, o = np.zeros(41), np.zeros(41), np.zeros(41)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        for t in range(len(thr)):
+            r[t] = pr[t, 0] / (pr[t, 0] + pr[t, 2])
+            p[t] = pr[t, 0] / (pr[t, 0] + pr[t, 1])
+            if compute_aos:
+                o[t] = pr[t, 3] / (pr[t, 0] + pr[t, 1])
+    for t in range(len(thr)):
+        p[t], r[t] = np.max(p[t:]), np.max(r[t:])
+        if compute_aos:
+            o[t] = np.max(o[t:])
+    return p, r, o, len(thr)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_host_curve_function_random_stress(seed):
+    """Random frames -- tied scores and overlaps, empty images, every ignore flag, DontCare regions, detections below the
+    score thresholds -- through the C++ sweep and the Python oracle: identical curves (counts are integers, the
+    orientation sums are formed in the same order)."""
+    from sgv3d_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(100 + seed)
+    metric = int(rng.integers(0, 3))
+    aos = metric == 0 and bool(rng.integers(0, 2))
+    frames = []
+    for _ in range(int(rng.integers(1, 9))):
+        G, D, C = int(rng.integers(0, 7)), int(rng.integers(0, 9)), int(rng.integers(0, 3))
+        ov = np.round(rng.uniform(0, 1, (D, G)), 1) * (rng.uniform(0, 1, (D, G)) < 0.6)         # many zeros, many ties
+        box = lambda n: np.concatenate([rng.uniform(0, 500, (n, 2)), rng.uniform(500, 900, (n, 2))], 1)
+        gt = np.concatenate([box(G), rng.uniform(-3, 3, (G, 1))], 1)
+        dt = np.concatenate([box(D), rng.uniform(-3, 3, (D, 1)), np.round(rng.uniform(0, 1, (D, 1)), 1)], 1)
+        frames.append(dict(ov=ov, gt=gt, dt=dt, ig=rng.integers(-1, 2, G).astype(np.int64), id=rng.integers(-1, 2, D).astype(np.int64),
+                           dc=box(C)))
+    num_valid = max(1, sum(int((f['ig'] == 0).sum()) for f in frames))
+    mo = float(rng.choice([0.25, 0.5, 0.7]))
+    want = _oracle_curves(frames, metric, mo, aos, num_valid)
+    P = lambda a: np.ascontiguousarray(a).ctypes.data_as(ctypes.c_void_p)
+    cat = lambda key, width, dt_: np.ascontiguousarray(np.concatenate([f[key].reshape(-1, width) for f in frames]).astype(dt_))
+    arrs = dict(gn=np.array([len(f['gt']) for f in frames], np.int32), dn=np.array([len(f['dt']) for f in frames], np.int32),
+                cn=np.array([len(f['dc']) for f in frames], np.int32), ov=np.ascontiguousarray(np.concatenate([f['ov'].reshape(-1) for f in frames])),
+                gt=cat('gt', 5, np.float64), dt=cat('dt', 6, np.float64), ig=cat('ig', 1, np.int64), id=cat('id', 1, np.int64),
+                dc=cat('dc', 4, np.float64))
+    for threads in (1, 3):
+        p, r, o = np.zeros(41), np.zeros(41), np.zeros(41)
+        n = ctypes.c_int(0)
+        rc = lib.sgv3d_kitti_eval_curves(len(frames), P(arrs['gn']), P(arrs['dn']), P(arrs['cn']), P(arrs['ov']), P(arrs['gt']), P(arrs['dt']),
+                                         P(arrs['ig']), P(arrs['id']), P(arrs['dc']), metric, mo, 1 if aos else 0, num_valid, threads,
+                                         P(p), P(r), P(o), ctypes.addressof(n))
+        assert rc == 0 and n.value == want[3]
+        np.testing.assert_array_equal(p, want[0])
+        np.testing.assert_array_equal(r, want[1])
+        np.testing.assert_allclose(o, want[2], rtol=0, atol=1e-12, equal_nan=True)
