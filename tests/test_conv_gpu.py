@@ -329,3 +329,25 @@ def test_random_shape_fuzz_all_algorithms():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_conv.py"), "60", "3"], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_autotune_under_load_picks_a_valid_choice(hip):
+    """SGV3D_TUNE_STREAMS > 1: candidates are timed as concurrent copies on side streams; whatever wins, the result is
+    the same convolution."""
+    from sgv3d_amd import hip_ops
+    from sgv3d_amd.hip_ops import PackedConv
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 64, 24, 40, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24
+    old = hip_ops.TUNE_STREAMS
+    hip_ops.TUNE_STREAMS = 3
+    try:
+        conv = PackedConv(w.to(DEV), pad=1, relu=True)
+        y = conv(nhwc(x).to(DEV))
+        assert len(conv._tile_cache) == 1                       # the measurement ran and its choice is cached
+        y2 = conv(nhwc(x).to(DEV))
+    finally:
+        hip_ops.TUNE_STREAMS = old
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    torch.testing.assert_close(nchw(y.cpu()), F.relu(F.conv2d(x, w, None, 1, 1)), **TOL)
