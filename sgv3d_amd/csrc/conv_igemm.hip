@@ -438,7 +438,12 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-constexpr int LDKB = BK + 8;   // row stride in bf16 elements (80 bytes)
+// Row stride in bf16 elements: the 32 k of a tile, 64 bytes, NO padding.  Bank conflicts are avoided by an XOR swizzle of the
+// row's four 16-byte chunks with bits 2..3 of the row index: the 16 lanes of a ds_read_b128 service group (16 consecutive
+// rows, same logical chunk) then touch 16 distinct 16-byte slots of the 256-byte bank row, and a half-wave of the 8-byte
+// stores covers 4 consecutive rows = 256 contiguous bytes.  (An 80-byte padded row made the reads conflict-free but put
+// every fourth row of the stores on the banks of the first: SQ_LDS_BANK_CONFLICT was a third of the LDS cycles.)
+constexpr int LDKB = BK;
 
 //
 // SPLIT3 ("f32x3"): float32-accurate products on the bf16 matrix cores.  Every operand x is split exactly into three
@@ -482,6 +487,7 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
     const int tid = threadIdx.x;
     const int cc = tid & 7;
     const int r0 = tid >> 3;
+    const int st_off = (((cc >> 1) ^ ((r0 >> 2) & 3)) * 8) + (cc & 1) * 4;   // swizzled place of this thread's 4 k in its row
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.w_bytes, 0x00020000);
     unsigned a_off[A_CH];
@@ -605,15 +611,17 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
 #define SGV3D_STORE_TILE(RA, RB, BUF)                                                                 \
     do {                                                                                              \
         __bf16 *As_ = As0 + (BUF) * kBufStride, *Bs_ = Bs0 + (BUF) * kBufStride;                      \
-        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) SGV3D_CVT_STORE(As_ + (r0 + 32 * i) * LDKB + cc * 4, RA[i], kPlaneA); \
-        _Pragma("unroll") for (int i = 0; i < B_CH; ++i) SGV3D_CVT_STORE(Bs_ + (r0 + 32 * i) * LDKB + cc * 4, RB[i], kPlaneB); \
+        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) SGV3D_CVT_STORE(As_ + (r0 + 32 * i) * LDKB + st_off, RA[i], kPlaneA); \
+        _Pragma("unroll") for (int i = 0; i < B_CH; ++i) SGV3D_CVT_STORE(Bs_ + (r0 + 32 * i) * LDKB + st_off, RB[i], kPlaneB); \
     } while (0)
 
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
-    const int a_frag_off = (wm * (BM / 2) + lr) * LDKB + lh * 8;
-    const int b_frag_off = (wn * (BN / 2) + lr) * LDKB + lh * 8;
+    const int a_frag_off = (wm * (BM / 2) + lr) * LDKB;
+    const int b_frag_off = (wn * (BN / 2) + lr) * LDKB;
+    const int rd_swz = (lr >> 2) & 3;                               // rows of a tile start at multiples of 32
+    const int rd_off[2] = {((0 + lh) ^ rd_swz) * 8, ((2 + lh) ^ rd_swz) * 8};   // k-step s: logical 16-byte chunk 2 s + h
     f32x16 acc[WTM][WTN];
 #pragma unroll
     for (int mt = 0; mt < WTM; ++mt)
@@ -626,9 +634,9 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
     do {                                                                                              \
         _Pragma("unroll") for (int p_ = 0; p_ < NP; ++p_) {                                           \
             _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                        \
-                fa[p_][mt] = *reinterpret_cast<const bf16x8 *>(As0 + (BUF) * kBufStride + p_ * kPlaneA + a_frag_off + mt * 32 * LDKB + (S) * 16); \
+                fa[p_][mt] = *reinterpret_cast<const bf16x8 *>(As0 + (BUF) * kBufStride + p_ * kPlaneA + a_frag_off + mt * 32 * LDKB + rd_off[S]); \
             _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt)                                        \
-                fb[p_][nt] = *reinterpret_cast<const bf16x8 *>(Bs0 + (BUF) * kBufStride + p_ * kPlaneB + b_frag_off + nt * 32 * LDKB + (S) * 16); \
+                fb[p_][nt] = *reinterpret_cast<const bf16x8 *>(Bs0 + (BUF) * kBufStride + p_ * kPlaneB + b_frag_off + nt * 32 * LDKB + rd_off[S]); \
         }                                                                                             \
     } while (0)
 #define SGV3D_MM(PA, PB)                                                                              \
