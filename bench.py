@@ -58,7 +58,7 @@ def parse():
                     help="cfg2 (default, the judged workload): R50 BEVHeight; r101: R101 BEVHeight; "
                          "cfg3: R101 1088x1920 -> 512x512 BEV (geometry of BASELINE configs[2]; fp32 here, use --batch 4); "
                          "cfg5: SGV3D BSM R101 (model of BASELINE configs[4], fp32, batch 1)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x3"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x3", "f32x3auto"],
                     help="f32 (default; what BASELINE cfg-2, the judged line, asks for) or bf16: convolutions multiply on "
                          "the bf16 matrix cores with f32 accumulation (the compute dtype of BASELINE configs[2] / [4]; "
                          "use with --config cfg3 --batch 4 or --config cfg5); f32x3: float32-accurate products from three "
@@ -116,7 +116,7 @@ def main():
     group = ReplicaGroup(backend="nccl" if (world > 1 or os.environ.get("SGV3D_FORCE_DIST")) else None, device=dev)   # nccl == RCCL on ROCm
     from sgv3d_amd.models.bev_height import BEVHeight
     hip_ops.MFMA_BF16 = args.dtype == "bf16"
-    hip_ops.MFMA_F32X3 = args.dtype == "f32x3"
+    hip_ops.MFMA_F32X3 = True if args.dtype == "f32x3" else ("auto" if args.dtype == "f32x3auto" else False)
     peak = MFMA_BF16_PEAK_TFLOPS if hip_ops.MFMA_BF16 else MFMA_F32_PEAK_TFLOPS
 
     bc, hc = {"cfg2": S.r50_256_conf, "r101": S.r101_256_conf, "cfg3": S.r101_512_conf,
@@ -128,6 +128,8 @@ def main():
                         "full BEVHeight forward",
                 "cfg5": "SGV3D BSM ResNet-101 864x1536 -> 256x256 BEV (stride-8 frustum, D=180, 87-ch BEV), fp32, "
                         "full forward"}[args.config]
+    if args.dtype == "f32x3auto":
+        workload = workload.replace("fp32", "fp32; per layer the faster of the f32 MFMA and 3 x bf16 split operands on the bf16 MFMA (f32-accurate)")
     if args.dtype == "f32x3":
         workload = workload.replace("fp32", "fp32 products as 3 x bf16 split operands on the bf16 MFMA, f32 accumulation")
     if args.dtype == "bf16":

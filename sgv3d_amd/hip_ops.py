@@ -48,7 +48,9 @@ MFMA_BF16 = bool(_os.environ.get("SGV3D_BF16"))
 # operand is split exactly into three bf16 terms and six partial products are accumulated in f32 (csrc/conv_igemm.hip,
 # SPLIT3): the error of a product is one f32 rounding, the MFMA time 192 instead of 512 cycles per 16 k.  Winograd
 # layers keep competing in the first-call measurement.  Opt-in: the default path multiplies on the f32 MFMA.
-MFMA_F32X3 = bool(_os.environ.get("SGV3D_F32X3"))
+# SGV3D_F32X3=auto ("auto" here): the f32x3 tiles compete with the f32-MFMA tiles and Winograd in the first-call
+# measurement of every layer (host-side tile ids 11..14 = f32x3 of tiles 1..4); long-K layers pick it, small-K ones do not.
+MFMA_F32X3 = {"": False, "0": False, "auto": "auto"}.get(_os.environ.get("SGV3D_F32X3", ""), True)
 # (tile, split-K) decisions by layer signature.  SGV3D_TUNE_CACHE=<file> loads them at import and
 # save_tune_db() writes them back, so that a profiled run replays the choices of an earlier run
 # instead of timing candidates again (keeps rocprofv3 per-kernel averages free of tuning launches).
@@ -80,7 +82,8 @@ def save_tune_db(path=None):
 
 
 load_tune_db()
-TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: "wino_resident"}
+TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: "wino_resident",
+              11: "128x128", 12: "128x64", 13: "64x128", 14: "64x64"}     # 11..14: f32x3 of tiles 1..4 (host-side ids)
 TILE_WINO = 5       # host-side algorithm id: sgv3d_conv2d_winograd_forward instead of the implicit GEMM
 TILE_WINO_RES = 6   # = SGV3D_WINOGRAD_RESIDENT: its patch-resident variant (cin <= 96, many cout tiles)
 
@@ -264,7 +267,7 @@ class PackedConv:
             if choice is None:
                 sig = (f"{self.cout}x{self.cin}k{self.kh}x{self.kw}s{self.stride}p{self.pad}d{self.dil}"
                        f"ks{self.ks}|{B}x{H}x{W}|m{d.mode}r{int(residual is not None)}g{int(gate is not None)}|{t}.{sk}"
-                       + ("|bf16" if MFMA_BF16 else "|f32x3" if MFMA_F32X3 else ""))
+                       + ("|bf16" if MFMA_BF16 else "|f32x3" if MFMA_F32X3 is True else "|x3auto" if MFMA_F32X3 else ""))
                 if sig in TUNE_DB:
                     choice = TUNE_DB[sig]
                     self._tile_cache[key] = choice
@@ -277,8 +280,10 @@ class PackedConv:
             t, sk = choice
         d.tile, d.split_k = t, sk
         flops = 2.0 * gemm_m * gemm_n * (self.cin * self.kh * self.kw)
-        name = ("conv_" if t >= TILE_WINO else ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_f32x3_" if MFMA_F32X3 else "conv_igemm_")) + TILE_NAMES[t]
-        if t < TILE_WINO and self.k_order == 0:
+        x3 = t > 10 or (MFMA_F32X3 is True and t < TILE_WINO)
+        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES) else
+                ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_f32x3_" if x3 else "conv_igemm_")) + TILE_NAMES[t]
+        if t not in (TILE_WINO, TILE_WINO_RES) and self.k_order == 0:
             name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
@@ -313,11 +318,18 @@ class PackedConv:
             return lib.sgv3d_conv2d_winograd_forward(ctypes.byref(d), x.data_ptr(), self.w_wino.data_ptr(),
                                                      _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
                                                      _lib.ptr(gate), out.data_ptr(), _lib.ptr(ws), nws, _st(x))
+        x3 = d.tile > 10 or (MFMA_F32X3 is True)
         fwd = (lib.sgv3d_conv2d_forward_bf16 if MFMA_BF16 else
-               lib.sgv3d_conv2d_forward_f32x3 if MFMA_F32X3 else lib.sgv3d_conv2d_forward)
-        return fwd(ctypes.byref(d), x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.scale),
-                                        _lib.ptr(self.shift), _lib.ptr(residual), _lib.ptr(gate), out.data_ptr(),
-                                        _lib.ptr(ws), nws, _st(x))
+               lib.sgv3d_conv2d_forward_f32x3 if x3 else lib.sgv3d_conv2d_forward)
+        host_tile = d.tile
+        if host_tile > 10:
+            d.tile = host_tile - 10
+        try:
+            return fwd(ctypes.byref(d), x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.scale),
+                       _lib.ptr(self.shift), _lib.ptr(residual), _lib.ptr(gate), out.data_ptr(),
+                       _lib.ptr(ws), nws, _st(x))
+        finally:
+            d.tile = host_tile
 
     def _time_under_load(self, lib, d, x, residual, gate, out, rounds=3):
         """Time for TUNE_STREAMS concurrent copies of the launch, ``rounds`` back to back on every stream (all copies
@@ -348,13 +360,16 @@ class PackedConv:
         not depend on the tile shape (every output element sums k in the same order); split-K changes
         the association of the k sum (partials added in fixed order), still deterministic."""
         tiles = (1, 2, 3, 4)
+        if MFMA_F32X3 == "auto" and not MFMA_BF16:
+            tiles += (11, 12, 13, 14)
         if self.w_wino is not None and WINOGRAD and not MFMA_BF16:
             tiles += (TILE_WINO,)
             if self.cin <= 96 and self.cout >= 128:
                 tiles += (TILE_WINO_RES,)
         if fixed_tile:
             tiles = (fixed_tile,)
-        dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 64), 6: (256, 64)}
+        dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 64), 6: (256, 64),
+                11: (128, 128), 12: (128, 64), 13: (64, 128), 14: (64, 64)}
         best, best_t = (tiles[0], fixed_split or 1), None
         with torch.cuda.device(x.device):
             for t in tiles:
