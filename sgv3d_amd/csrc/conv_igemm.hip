@@ -665,7 +665,7 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
     // Residual prefetch (64x64 tile, fast-path epilogue): the small-K layers that carry a residual (the expanding 1x1
     // convolutions of the bottlenecks) spend a third of a workgroup's life waiting for the residual rows they only
     // ask for after the k loop; asked for here, the 16 values per lane arrive under the loop.
-    constexpr bool kPrefetchRes = WTM * WTN <= 2 && !SPLIT3;
+    constexpr bool kPrefetchRes = WTM * WTN <= 2;
     // (GROUP_PLANES -- the per-branch hidden maps of the two-kernel head path -- is row-linear too when a wave's columns
     // stay inside one group: plane base + row * group width)
     const bool fast_epi = (a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr) ||
