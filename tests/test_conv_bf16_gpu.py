@@ -163,3 +163,33 @@ def test_f32x3_model_forward_meets_the_fp32_bar(f32x3_mode):
     for t in range(6):
         for k, v in preds[t][0].items():
             torch.testing.assert_close(v.cpu(), ref[t][0][k], rtol=1e-3, atol=1e-3)      # the north-star bar of the f32 path
+
+
+def test_f32x3_auto_mode_model_meets_the_fp32_bar():
+    """'auto': f32x3 tiles (host-side ids 11..14) compete with the f32-MFMA tiles and Winograd per layer; whatever mix the
+    measurement picks, the model stays inside the 1e-3 bar and at least one layer took an f32x3 tile."""
+    from oracle import torch_model as TM
+    from sgv3d_amd import synthetic as S
+    from sgv3d_amd.models.bev_height import BEVHeight
+    torch.manual_seed(0)
+    bc, hc = S.small_conf()
+    m = BEVHeight(bc, hc).eval()
+    S.randomize_norm_stats_(m, 0)
+    imgs = S.make_images(2, bc['final_dim'], seed=5)
+    mats = S.make_mats(2, scale=128 / 864)
+    ref = TM.bevheight_forward(m.state_dict(), bc, hc, imgs, mats)
+    m = m.to(DEV)
+    old, old_db = hip_ops.MFMA_F32X3, dict(hip_ops.TUNE_DB)
+    hip_ops.MFMA_F32X3 = "auto"
+    try:
+        with torch.no_grad():
+            preds = m(imgs.to(DEV), {k: v.to(DEV) for k, v in mats.items()})
+        picked = [v for k, v in hip_ops.TUNE_DB.items() if k.endswith("|x3auto")]
+    finally:
+        hip_ops.MFMA_F32X3 = old
+        hip_ops.TUNE_DB.clear()
+        hip_ops.TUNE_DB.update(old_db)
+    assert picked and all(t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14) for t, _ in picked)
+    for t in range(6):
+        for k, v in preds[t][0].items():
+            torch.testing.assert_close(v.cpu(), ref[t][0][k], rtol=1e-3, atol=1e-3)
