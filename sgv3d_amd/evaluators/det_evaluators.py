@@ -13,7 +13,7 @@ import tempfile
 
 import numpy as np
 
-from .result2kitti import kitti_evaluation, result2kitti
+from .result2kitti import kitti_evaluation, result2kitti, result2kitti_dair
 
 __all__ = ['RoadSideEvaluator']
 
@@ -66,12 +66,16 @@ class RoadSideEvaluator():
 
     def evaluate(self, results, img_metas, metric='bbox', logger=None, jsonfile_prefix=None, result_names=['img_bbox'],
                  show=False, out_dir=None, pipeline=None, results_path="outputs", metric_path="outputs/metrics"):
-        """:83-107.  Only the KITTI-format data roots ('dair-v2x-i-kitti', 'rope3d-kitti') are handled by this build."""
+        """:83-107: KITTI-layout roots and the raw DAIR-V2X-I root (the one the dair-v2x experiment files configure)."""
         result_files, tmp_dir = self.format_results(results, img_metas, result_names, jsonfile_prefix)
-        if not ('dair-v2x-i-kitti' in self.data_root or 'rope3d-kitti' in self.data_root):
-            raise NotImplementedError("result2kitti_dair / result2kitti_rope3d (raw data roots, evaluators/result2kitti.py:"
-                                      "270-393) are not rebuilt; convert the data set to the KITTI layout")
-        pred_label_path = result2kitti(result_files["img_bbox"], results_path, self.data_root, self.gt_label_path, demo=False)
+        if 'dair-v2x-i-kitti' in self.data_root or 'rope3d-kitti' in self.data_root:
+            convert = result2kitti
+        elif 'dair-v2x-i' in self.data_root:
+            convert = result2kitti_dair
+        else:
+            raise NotImplementedError("result2kitti_rope3d (raw Rope3D root, evaluators/result2kitti.py:330-393) is not "
+                                      "rebuilt; convert the data set to the KITTI layout")
+        pred_label_path = convert(result_files["img_bbox"], results_path, self.data_root, self.gt_label_path, demo=False)
         return kitti_evaluation(pred_label_path, self.gt_label_path, current_classes=self.current_classes,
                                 metric_path=metric_path)
 

@@ -8,8 +8,8 @@ file per image under ``results_path/data``: class through ``category_map_dair`` 
 (:157-173), location = the box's bottom centre in the camera frame, ``rotation_y = pi/2 - yaw``, every number rounded
 to 4 decimals.  ``kitti_evaluation`` (:62-72): read the two label folders, run the KITTI evaluation (R40), write the
 result text under ``metric_path/R40`` and return the moderate 3-D AP of ``Car``.  Host code (numpy), as in the
-reference; the variants for the raw DAIR-V2X-I / Rope3D roots (:270-393, other calibration file formats) are not
-rebuilt."""
+reference.  ``result2kitti_dair`` (:270-328) is the same conversion for the raw DAIR-V2X-I root (JSON calibration files,
+float64); the Rope3D variant (:330-393: denorm files, a token -> id map at a fixed path) is not rebuilt."""
 import json
 import math
 import os
@@ -19,7 +19,7 @@ import numpy as np
 from .kitti_utils import kitti_common as kitti
 from .kitti_utils.eval import kitti_eval
 
-__all__ = ['kitti_evaluation', 'result2kitti', 'load_calib_dair', 'category_map_dair']
+__all__ = ['kitti_evaluation', 'result2kitti', 'result2kitti_dair', 'load_calib_dair', 'load_calib_dair_json', 'category_map_dair']
 
 
 def kitti_evaluation(pred_label_path, gt_label_path, current_classes=("Car", "Pedestrian", "Cyclist"), metric_path="metric"):
@@ -73,13 +73,42 @@ def _normalize_angle(angle):
     return a + math.pi if np.cos(angle) < 0 else a
 
 
+def load_calib_dair_json(dair_root, sample_id):
+    """Calibration of the raw DAIR-V2X-I layout (:180-198): ``calib/camera_intrinsic/%06d.json`` (``cam_K``) and
+    ``calib/virtuallidar_to_camera/%06d.json`` (``rotation`` + ``translation``, or ``Tr_velo_to_cam``), float64."""
+    with open(os.path.join(dair_root, "calib/camera_intrinsic", "{:06d}".format(sample_id) + ".json")) as f:
+        K = np.array(json.load(f)["cam_K"]).reshape([3, 3], order="C")
+    with open(os.path.join(dair_root, "calib/virtuallidar_to_camera", "{:06d}".format(sample_id) + ".json")) as f:
+        js = json.load(f)
+    if "Tr_velo_to_cam" in js:
+        v2c = np.array(js["Tr_velo_to_cam"]).reshape(3, 4)
+        r, t = v2c[:, :3], v2c[:, 3].reshape(3, 1)
+    else:
+        r, t = np.array(js["rotation"]), np.array(js["translation"])
+    Tr = np.eye(4)
+    Tr[:3, :3] = r
+    Tr[:3, 3] = t.flatten()
+    return Tr, K
+
+
 def result2kitti(results_file, results_path, dair_root, gt_label_path, demo=False):
+    """KITTI-layout data roots ('dair-v2x-i-kitti', 'rope3d-kitti'), :212-268."""
+    return _convert(results_file, results_path,
+                    lambda sid: load_calib_dair(os.path.join(dair_root, "training/calib", "{:06d}".format(sid) + ".txt")))
+
+
+def result2kitti_dair(results_file, results_path, dair_root, gt_label_path, demo=False):
+    """Raw DAIR-V2X-I root (what exps/bevheight/dair-v2x/*.py configure: data_root 'data/dair-v2x-i/'), :270-328."""
+    return _convert(results_file, results_path, lambda sid: load_calib_dair_json(dair_root, sid))
+
+
+def _convert(results_file, results_path, load_calib):
     with open(results_file, 'r', encoding='utf8') as fp:
         results = json.load(fp)["results"]
     os.makedirs(os.path.join(results_path, "data"), exist_ok=True)
     for sample_token, preds in results.items():
         sample_id = int(sample_token.split("/")[-1].split(".")[0])
-        Tr, K = load_calib_dair(os.path.join(dair_root, "training/calib", "{:06d}".format(sample_id) + ".txt"))
+        Tr, K = load_calib(sample_id)
         R, t = Tr[:3, :3].astype(np.float64), Tr[:3, 3].astype(np.float64).reshape(3, 1)
         K34 = np.concatenate([K, np.zeros((3, 1))], axis=1)
         lines = []

@@ -334,6 +334,27 @@ def make_result2kitti():
             json.dump({'meta': {}, 'results': results}, f)
         path = r2k.result2kitti(rf, os.path.join(d, 'out'), os.path.join(d, 'root'), os.path.join(d, 'gt'), demo=False)
         out['label_text'] = np.array([open(os.path.join(path, f'{sid:06d}.txt')).read() for sid in sorted(calibs)])
+    # the same detections through result2kitti_dair (:270-328): raw DAIR-V2X-I root, JSON calibration files
+    dair_cam, dair_v2c = {}, {}
+    for sid in sorted(calibs):
+        rows = calibs[sid].splitlines()
+        P2 = np.array([float(v) for v in rows[0].split(' ')[1:]]).reshape(3, 4)
+        tr = np.array([float(v) for v in rows[1].split(' ')[1:]]).reshape(3, 4)
+        dair_cam[sid] = json.dumps({"cam_D": [0.0] * 5, "cam_K": P2[:, :3].reshape(-1).tolist()})
+        dair_v2c[sid] = json.dumps({"rotation": tr[:, :3].tolist(), "translation": tr[:, 3:].tolist()})
+    out['dair_cam_json'] = np.array([dair_cam[k] for k in sorted(calibs)])
+    out['dair_v2c_json'] = np.array([dair_v2c[k] for k in sorted(calibs)])
+    with tempfile.TemporaryDirectory() as d:
+        for sub_ in ('camera_intrinsic', 'virtuallidar_to_camera'):
+            os.makedirs(os.path.join(d, 'root', 'calib', sub_))
+        for sid in calibs:
+            open(os.path.join(d, 'root', 'calib', 'camera_intrinsic', f'{sid:06d}.json'), 'w').write(dair_cam[sid])
+            open(os.path.join(d, 'root', 'calib', 'virtuallidar_to_camera', f'{sid:06d}.json'), 'w').write(dair_v2c[sid])
+        rf = os.path.join(d, 'results_nusc.json')
+        with open(rf, 'w') as f:
+            json.dump({'meta': {}, 'results': results}, f)
+        path = r2k.result2kitti_dair(rf, os.path.join(d, 'out'), os.path.join(d, 'root'), os.path.join(d, 'gt'), demo=False)
+        out['dair_label_text'] = np.array([open(os.path.join(path, f'{sid:06d}.txt')).read() for sid in sorted(calibs)])
     np.savez_compressed(os.path.join(HERE, "result2kitti.npz"), **out)
     print("result2kitti.npz:", out['label_text'][0][:300])
 

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 from sgv3d_amd.evaluators.det_evaluators import RoadSideEvaluator
-from sgv3d_amd.evaluators.result2kitti import load_calib_dair, result2kitti
+from sgv3d_amd.evaluators.result2kitti import load_calib_dair, result2kitti, result2kitti_dair
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "result2kitti.npz"))
 
@@ -59,3 +59,19 @@ def test_roadside_evaluator_json_stage(tmp_path):
     d0 = json.load(open(files['img_bbox']))['results']['training/image_2/000003.jpg'][0]
     assert np.allclose(d0['translation'], [2.0 + 1.0, 30.0 + 2.0, -1.0 + 3.0])
     assert np.allclose(d0['rotation'], [np.cos(np.pi / 4 + 0.15), 0, 0, np.sin(np.pi / 4 + 0.15)])
+
+
+def test_result2kitti_dair_writes_the_reference_label_files(tmp_path):
+    """Raw DAIR-V2X-I root (JSON calibration, float64): the path the dair-v2x experiment files take."""
+    root = tmp_path / 'dair-v2x-i'
+    for sub in ('camera_intrinsic', 'virtuallidar_to_camera'):
+        os.makedirs(root / 'calib' / sub)
+    for sid, cam, v2c in zip(GOLD['calib_ids'], GOLD['dair_cam_json'], GOLD['dair_v2c_json']):
+        (root / 'calib' / 'camera_intrinsic' / f'{int(sid):06d}.json').write_text(str(cam))
+        (root / 'calib' / 'virtuallidar_to_camera' / f'{int(sid):06d}.json').write_text(str(v2c))
+    rf = tmp_path / 'results_nusc.json'
+    rf.write_text(str(GOLD['results_json']))
+    out = result2kitti_dair(str(rf), str(tmp_path / 'out'), str(root), str(tmp_path / 'gt'))
+    for sid, want in zip(GOLD['calib_ids'], GOLD['dair_label_text']):
+        assert open(os.path.join(out, f'{int(sid):06d}.txt')).read() == str(want), int(sid)
+    assert any(str(a) != str(b) for a, b in zip(GOLD['dair_label_text'], GOLD['label_text']))     # float64 vs float32 calibration
