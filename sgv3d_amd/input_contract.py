@@ -14,7 +14,8 @@ import numpy as np
 import torch
 
 __all__ = ['equation_plane', 'get_denorm', 'get_sensor2virtual', 'get_reference_height', 'rodrigues',
-           'ida_resize_crop', 'ida_matrix', 'bda_matrix', 'collate_mats']
+           'ida_resize_crop', 'ida_matrix', 'bda_matrix', 'collate_mats', 'camera_from_info', 'mats_from_infos',
+           'gt_from_info', 'NAME_TO_DETECTION_CLASS']
 
 
 def rodrigues(rvec):
@@ -131,3 +132,64 @@ def collate_mats(cameras, device='cpu'):
             'sensor2virtual_mats': t(s2v),
             'reference_heights': torch.from_numpy(np.asarray(refh, np.float32)).view(n, 1, 1).to(device),
             'bda_mat': torch.from_numpy(np.stack(bda)).to(device)}
+
+
+# ------------------------------------------------------------------------------------------------ info records (.pkl schema)
+# category_name -> detection class, dataset/nusc_mv_det_dataset.py:18-39 (the roadside infos of scripts/gen_info_dair.py
+# already carry detection names, which map to themselves)
+NAME_TO_DETECTION_CLASS = {n: n for n in ('car', 'truck', 'construction_vehicle', 'bus', 'trailer', 'barrier', 'motorcycle',
+                                          'bicycle', 'pedestrian', 'traffic_cone')}
+
+
+def _quat_to_matrix(q):
+    w, x, y, z = (float(v) for v in q)
+    n = math.sqrt(w * w + x * x + y * y + z * z)
+    w, x, y, z = w / n, x / n, y / n, z / n
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def camera_from_info(cam_info, final_dim, bot_pct_lim=(0.0, 0.0)):
+    """One camera record of an info entry (scripts/gen_info_dair.py:125-147: 'calibrated_sensor' with 'rotation_matrix' or
+    a 'rotation' quaternion, 'translation', 'camera_intrinsic'; 'height' / 'width') -> the dict ``collate_mats`` takes, with
+    the evaluation-time image transform (resize to ``final_dim``, no flip / rotation; dataset/...:433-446, 520-531)."""
+    cs = cam_info['calibrated_sensor']
+    rot = np.asarray(cs['rotation_matrix'], np.float64) if 'rotation_matrix' in cs else _quat_to_matrix(cs['rotation'])
+    s2e = np.eye(4)
+    s2e[:3, :3] = rot
+    s2e[:3, 3] = np.asarray(cs['translation'], np.float64).reshape(3)
+    K = np.eye(4)
+    K[:3, :3] = np.asarray(cs['camera_intrinsic'], np.float64).reshape(3, 3)
+    resize, _, crop, flip, rotate = ida_resize_crop((int(cam_info.get('height', 1080)), int(cam_info.get('width', 1920))),
+                                                    final_dim, bot_pct_lim)
+    return dict(sensor2ego=s2e, intrin=K, ida=ida_matrix(resize, crop, flip, rotate), bda=np.eye(4))
+
+
+def mats_from_infos(infos, final_dim, cam='CAM_FRONT', device='cpu'):
+    """``mats_dict`` of a batch of info entries (one key frame, one camera each: every shipped roadside config)."""
+    return collate_mats([camera_from_info(info['cam_infos'][cam], final_dim) for info in infos], device)
+
+
+def gt_from_info(info, classes, cam='CAM_FRONT'):
+    """``get_gt`` (dataset/...:668-712): annotations -> (boxes float32 [n, 9] = x, y, z, dx (l), dy (w), dz (h), yaw, vx, vy
+    in the ego frame; labels int64 [n]).  'size' is (w, l, h) as nuscenes' Box keeps it; the yaw is the rotation of the
+    box's quaternion (or 'yaw_lidar') composed with the inverse ego pose."""
+    ego = info['cam_infos'][cam]['ego_pose']
+    R = _quat_to_matrix(ego['rotation']).T                       # global -> ego
+    t = -np.asarray(ego['translation'], np.float64)
+    boxes, labels = [], []
+    for ann in info['ann_infos']:
+        name = NAME_TO_DETECTION_CLASS.get(ann['category_name'])
+        if name not in classes or ann['num_lidar_pts'] + ann['num_radar_pts'] <= 0:
+            continue
+        centre = R @ (np.asarray(ann['translation'], np.float64) + t)
+        q = ann['rotation']
+        q = getattr(q, 'elements', q)                            # pyquaternion object or a plain (w, x, y, z)
+        Rb = R @ _quat_to_matrix(q)
+        yaw = math.atan2(Rb[1, 0], Rb[0, 0])
+        w, l, h = (float(v) for v in ann['size'])
+        vel = R @ np.asarray(ann.get('velocity', np.zeros(3)), np.float64).reshape(3)
+        boxes.append([centre[0], centre[1], centre[2], l, w, h, yaw, vel[0], vel[1]])
+        labels.append(classes.index(name))
+    return torch.tensor(boxes, dtype=torch.float32).reshape(-1, 9), torch.tensor(labels, dtype=torch.int64)

@@ -52,3 +52,35 @@ def test_collate_layout_and_synthetic_calibration_agree():
     for i, c in enumerate(cams):
         assert np.allclose(mats["sensor2virtual_mats"][i, 0, 0].numpy(), c["sensor2virtual"], atol=1e-6)
         assert abs(float(mats["reference_heights"][i]) - float(c["reference_height"])) < 1e-5
+
+
+def test_info_record_adapter():
+    """info entry in the layout scripts/gen_info_dair.py:111-196 writes -> mats_dict / ground-truth boxes."""
+    from sgv3d_amd import input_contract as IC
+    from sgv3d_amd import synthetic as S
+    calib = S.make_calib()
+    s2e = calib['sensor2ego'].astype(np.float64)
+    cam_info = dict(height=1080, width=1920, filename='image/000001.jpg',
+                    ego_pose=dict(translation=[0.0, 0.0, 0.0], rotation=[1.0, 0.0, 0.0, 0.0]),
+                    calibrated_sensor=dict(translation=s2e[:3, 3], rotation_matrix=s2e[:3, :3], camera_intrinsic=calib['intrin'][:3, :3]))
+    yaw = 0.7
+    ann = dict(category_name='car', translation=np.array([30.0, -4.0, -1.2]), size=np.array([1.9, 4.4, 1.6]),
+               rotation=[np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)], yaw_lidar=yaw, num_lidar_pts=3, num_radar_pts=0,
+               velocity=np.zeros(3))
+    skipped = dict(ann, category_name='animal')
+    info = dict(sample_token='image/000001.jpg', cam_infos={'CAM_FRONT': cam_info}, ann_infos=[ann, skipped], sweeps=[])
+    mats = IC.mats_from_infos([info], final_dim=(864, 1536))
+    ref = S.make_mats(1)                                          # the same camera through the direct producer
+    for k in ref:
+        assert mats[k].shape == ref[k].shape, k
+        assert torch.allclose(mats[k], ref[k], rtol=1e-5, atol=1e-5), k
+    boxes, labels = IC.gt_from_info(info, ['car', 'truck', 'pedestrian'])
+    assert boxes.shape == (1, 9) and labels.tolist() == [0]
+    assert torch.allclose(boxes[0], torch.tensor([30.0, -4.0, -1.2, 4.4, 1.9, 1.6, yaw, 0.0, 0.0]), atol=1e-6)
+    # a quaternion instead of the rotation matrix, and a moved / turned ego pose
+    q = [np.cos(0.25), 0.0, 0.0, np.sin(0.25)]                    # yaw 0.5
+    cam_q = dict(cam_info, ego_pose=dict(translation=[1.0, 2.0, 0.0], rotation=q))
+    b2, _ = IC.gt_from_info(dict(info, cam_infos={'CAM_FRONT': cam_q}), ['car'])
+    c, s_ = np.cos(-0.5), np.sin(-0.5)
+    want_xy = np.array([[c, -s_], [s_, c]]) @ np.array([30.0 - 1.0, -4.0 - 2.0])
+    assert np.allclose(b2[0, :2].numpy(), want_xy, atol=1e-5) and abs(float(b2[0, 6]) - (yaw - 0.5)) < 1e-6
