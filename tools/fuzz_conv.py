@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """Random-shape parity fuzz of the convolution entry points against torch (CPU, fp64 accumulate):
 implicit GEMM (all tiles, split-K), Winograd (streaming, patch-resident), with BN fold / residual / ReLU /
-gate / channel-slice input and output.  usage: fuzz_conv.py [N=300] [seed=0]"""
+gate / channel-slice input and output.  usage: fuzz_conv.py [N=300] [seed=0] [mode=f32|bf16|f32x3]
+(bf16: the reference convolves the bf16-rounded operands, so only the summation order differs; Winograd is f32-only)"""
 import os, random, sys
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sgv3d_amd import hip_ops
 from sgv3d_amd.hip_ops import PackedConv, TILE_WINO, TILE_WINO_RES
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+MODE = sys.argv[3] if len(sys.argv) > 3 else "f32"
+hip_ops.MFMA_BF16, hip_ops.MFMA_F32X3 = MODE == "bf16", MODE == "f32x3"
 rng = random.Random(seed)
 g = torch.Generator().manual_seed(seed)
 bad = 0
@@ -32,7 +36,8 @@ for it in range(N):
     sh = torch.randn(cout, generator=g) if use_bn else None
     x_coff = x_extra // 2 // 4 * 4
     xin = x[..., x_coff:x_coff + cin]
-    ref = F.conv2d(xin.permute(0, 3, 1, 2).double(), w.double(), stride=stride, padding=pad, dilation=dil).permute(0, 2, 3, 1)
+    rx, rw = (xin.bfloat16().double(), w.bfloat16().double()) if MODE == "bf16" else (xin.double(), w.double())
+    ref = F.conv2d(rx.permute(0, 3, 1, 2), rw, stride=stride, padding=pad, dilation=dil).permute(0, 2, 3, 1)
     OH, OW = ref.shape[1], ref.shape[2]
     if use_bn:
         ref = ref * sc.double() + sh.double()
@@ -47,7 +52,7 @@ for it in range(N):
     conv = PackedConv(w.cuda(), stride=stride, pad=pad, dil=dil, scale=None if sc is None else sc.cuda(),
                       shift=None if sh is None else sh.cuda(), relu=use_relu)
     cands = [(t, s) for t in (1, 2, 3, 4) for s in (1, 2, 3)]
-    if conv.w_wino is not None:
+    if conv.w_wino is not None and MODE != "bf16":
         cands += [(TILE_WINO, 1), (TILE_WINO, 2), (TILE_WINO, 3)]
         if cin <= 96:
             cands.append((TILE_WINO_RES, 1))
@@ -75,5 +80,5 @@ for it in range(N):
             print("FAIL", (B, cin, H, W, cout, k, stride, pad, dil), (t, s), "err", err, "guard", bool(guard_ok),
                   dict(bn=use_bn, res=use_res, relu=use_relu, gate=use_gate, x_coff=x_coff, y_coff=y_coff))
 torch.cuda.synchronize()
-print(f"fuzz done: {N} shapes, failures: {bad}")
+print(f"fuzz done ({MODE}): {N} shapes, failures: {bad}")
 sys.exit(1 if bad else 0)
