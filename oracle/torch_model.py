@@ -199,12 +199,17 @@ def geometry_indices(sd, mats, sweep=0):
     return out
 
 
-def lss_fpn_forward(sd, conf, imgs, mats, keep=None):
-    """LSSFPN._forward_single_sweep (lss_fpn.py:422-495), one sweep -> BEV [B, C, Y, X]."""
+def lss_fpn_forward(sd, conf, imgs, mats, keep=None, cam_feats=None):
+    """LSSFPN._forward_single_sweep (lss_fpn.py:422-495), one sweep -> BEV [B, C, Y, X].
+    ``cam_feats`` [B*N, C, fH, fW]: stands in for get_cam_feats (:403-414) -- the pinned-composition test feeds the
+    same neck features the golden run of the reference was given (tests/golden/make_golden_modules.py)."""
     B, S, N, Cin, H, W = imgs.shape
-    x = imgs[:, 0].reshape(B * N, Cin, H, W)
-    feats = resnet(sd, 'backbone.img_backbone', x, conf['img_backbone_conf'])
-    src = secondfpn(sd, 'backbone.img_neck', feats, conf['img_neck_conf'])
+    if cam_feats is None:
+        x = imgs[:, 0].reshape(B * N, Cin, H, W)
+        feats = resnet(sd, 'backbone.img_backbone', x, conf['img_backbone_conf'])
+        src = secondfpn(sd, 'backbone.img_neck', feats, conf['img_neck_conf'])
+    else:
+        feats, src = None, cam_feats
     hf = heightnet(sd, 'backbone.height_net', src, mats)
     D = sd['backbone.frustum'].shape[0]
     C = conf['output_channels']
@@ -266,14 +271,18 @@ def msct_head(sd, p, feats, mats):
     return depth1, semantic1, context1, semantic0
 
 
-def bsm_lss_fpn_forward(sd, conf, imgs, mats, keep=None):
-    """BSMLSSFPN._forward_single_sweep (bsm_lss_fpn.py:485-559) -> BEV [B, 87, Y, X]."""
+def bsm_lss_fpn_forward(sd, conf, imgs, mats, keep=None, cam_feats=None):
+    """BSMLSSFPN._forward_single_sweep (bsm_lss_fpn.py:485-559) -> BEV [B, 87, Y, X].
+    ``cam_feats`` = (stride-16 features, stride-8 features), each [B*N, C, h, w]: stands in for get_cam_feats."""
     B, S, N, Cin, H, W = imgs.shape
-    x = imgs[:, 0].reshape(B * N, Cin, H, W)
-    feats = resnet(sd, 'backbone.img_backbone', x, conf['img_backbone_conf'])
-    n16 = secondfpn(sd, 'backbone.img_neck_16', feats, conf['img_neck_conf'])
-    cfg8 = dict(conf['img_neck_conf'], upsample_strides=[0.5, 1, 2, 4])            # :368
-    n8 = secondfpn(sd, 'backbone.img_neck_8', feats, cfg8)
+    if cam_feats is None:
+        x = imgs[:, 0].reshape(B * N, Cin, H, W)
+        feats = resnet(sd, 'backbone.img_backbone', x, conf['img_backbone_conf'])
+        n16 = secondfpn(sd, 'backbone.img_neck_16', feats, conf['img_neck_conf'])
+        cfg8 = dict(conf['img_neck_conf'], upsample_strides=[0.5, 1, 2, 4])            # :368
+        n8 = secondfpn(sd, 'backbone.img_neck_8', feats, cfg8)
+    else:
+        n16, n8 = cam_feats
     depth1, semantic1, context1, semantic0 = msct_head(sd, 'backbone.height_net', [n16, n8], mats)
     height = depth1.softmax(dim=1)                                                    # :521
     semantic = semantic1.softmax(dim=1)

@@ -177,6 +177,8 @@ CALIBS = {
     "p20_h4_roll2": dict(pitch_deg=20.0, cam_h=4.0, roll_deg=2.0, crop=(16.0, 8.0)),
     "p14_h6.3_yaw-7_roll-1": dict(pitch_deg=14.0, cam_h=6.3, yaw_deg=-7.0, roll_deg=-1.0,
                                   fx=2100.0, fy=2250.5, cx=955.25, cy=540.75),
+    # full-resolution frame (no resize): what a 1080x1920 image padded to 1088x1920 (BASELINE cfg-3) carries
+    "p11_h5.5_fullres": dict(resize=1.0),
 }
 
 
@@ -251,6 +253,10 @@ def main():
     small = make_lss(L, (80, 112), 16, [-2.0, 0.0, 6], [0, 102.4, 0.4], [-51.2, 51.2, 0.4], [-5, 3, 8])
     full = make_lss(L, (864, 1536), 16, [-2.0, 0.0, 90], [0, 102.4, 0.4], [-51.2, 51.2, 0.4], [-5, 3, 8])
     full128 = make_lss(L, (864, 1536), 16, [-2.0, 0.0, 90], [0, 102.4, 0.8], [-51.2, 51.2, 0.8], [-5, 3, 8])
+    # BASELINE cfg-3 (R101, 1088x1920 padded frame, 0.2 m cells -> 512x512 BEV, N = 734 400 points) and
+    # cfg-5 (SGV3D BSM: stride-8 frustum 108x192, 180 height bins in [-2, 3.5] -> N = 3 732 480 points)
+    cfg3 = make_lss(L, (1088, 1920), 16, [-2.0, 0.0, 90], [0, 102.4, 0.2], [-51.2, 51.2, 0.2], [-5, 3, 8])
+    cfg5 = make_lss(L, (864, 1536), 8, [-2.0, 3.5, 180], [0, 102.4, 0.4], [-51.2, 51.2, 0.4], [-5, 3, 8])
     calibs = {k: make_calib(**kw) for k, kw in CALIBS.items()}
     # a ray exactly parallel to the ground: pitch 0, principal point on a frustum row of the small
     # config (ys[2] = 39.5 -> v' = 39.5/0.8 = 49.375): ratio = h/0 = inf, 0*inf = NaN
@@ -268,7 +274,7 @@ def main():
         if name == "nan_ray_small":
             assert np.isnan(g).any(), "fixture must contain a NaN ray"
             continue
-        for tag, obj in (("full256", full), ("full128", full128)):
+        for tag, obj in (("full256", full), ("full128", full128), ("cfg3_512", cfg3), ("cfg5_s8d180", cfg5)):
             g, gi, *_ = run_geometry(obj, c)
             vn = obj.voxel_num.numpy()
             inr = ((gi[..., 0] >= 0) & (gi[..., 0] < vn[0]) & (gi[..., 1] >= 0) & (gi[..., 1] < vn[1])

@@ -95,6 +95,38 @@ def test_full_size_hash_batch4(hip, golden, tag, bounds):
         assert hashlib.sha256(gi[i].tobytes()).digest() == geo[f"{n}/{tag}/geom_xyz_sha256"].tobytes(), n
 
 
+BIG_CFGS = {"cfg3_512": ((1088, 1920), 16, [-2.0, 0.0, 90], ([0, 102.4, 0.2], [-51.2, 51.2, 0.2], [-5, 3, 8])),
+            "cfg5_s8d180": ((864, 1536), 8, [-2.0, 3.5, 180], BOUNDS256)}
+
+
+@pytest.mark.parametrize("tag", list(BIG_CFGS))
+def test_cfg3_cfg5_full_size_hash(hip, golden, tag):
+    """BASELINE cfg-3 (1088x1920 frame, 0.2 m cells -> 512x512 BEV, 734 400 points per camera) and cfg-5 (SGV3D BSM:
+    stride-8 frustum, 180 height bins, 3 732 480 points per camera) at full size, five calibrations in one launch.
+    Fed with the reference's own 4x4 products, every int32 index tensor hashes to the one the reference's get_geometry +
+    quantise produced; with the device-side 4x4 preparation the kernel equals the oracle bit for bit (which differs from
+    the reference tensor on <= 20 border points of one calibration, tests/test_oracle_cpu.py explains why)."""
+    geo = golden["geometry"]
+    names = CALIBS + ["p11_h5.5_fullres"]
+    cams = [_calib(geo, n) for n in names]
+    fd, ds, db, bounds = BIG_CFGS[tag]
+    fr = G.create_frustum(fd, ds, db)
+    ref_prep = np.stack([np.stack([geo[f"{n}/ref_ida_inv"], geo[f"{n}/ref_combine_virtual"], geo[f"{n}/ref_combine_ego"]])
+                         for n in names])
+    gi, _, _ = _run(hip, fr, cams, bounds, prep_override=ref_prep, want_float=False)
+    for i, n in enumerate(names):
+        assert np.array_equal(gi[i][::7, ::5, ::9], geo[f"{n}/{tag}/geom_xyz_sample"])
+        assert hashlib.sha256(gi[i].tobytes()).digest() == geo[f"{n}/{tag}/geom_xyz_sha256"].tobytes(), n
+    own, _, _ = _run(hip, fr, cams, bounds, want_float=False)
+    vs, vc, vn = G.voxel_params(*bounds)
+    for i, (n, c) in enumerate(zip(names, cams)):
+        ora, _ = G.geom_xyz_for_camera(fr, c["sensor2ego"], c["sensor2virtual"], c["intrin"], c["ida"],
+                                       c["reference_height"], c["bda"], vc, vs)
+        assert np.array_equal(own[i], ora), n
+        moved = (np.abs(own[i].astype(np.int64) - gi[i]).sum(-1) > 0).sum()
+        assert moved <= 20 and (moved == 0 or n == "p14_h6.3_yaw-7_roll-1"), (n, int(moved))
+
+
 def test_lift_golden(hip, golden):
     lib = hip.load()
     lf = golden["lift"]
