@@ -17,8 +17,15 @@ Printed by rank 0 as ONE JSON line, with
   their summed durations, measured live with HIP events on the launch stream in an instrumented
   pass over the same K steps (events around every launch would perturb the throughput loop, so the
   two loops are separate; both run in this process on the same inputs);
+* ``roofline_hbm``: the voxel-pooling operator (vp_gather2 + vp_fixup) against HBM peak -- the 175.9 MB
+  of SURVEY 8(d) / launch duration -- with the plan build reported beside it (it runs once per
+  calibration, never inside the timed region);
 * ``cpu_baseline``: the torch-CPU oracle restatement of the same forward (oracle/torch_model.py)
-  timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+  timed on this box's host cores on a bounded sample (rank 0, N=1 only), plus the C restatement of the
+  voxel-pooling operator single-threaded and with OpenMP (BASELINE.md 3);
+* ``parity``: the outputs of the very model that was timed against that oracle forward on the same
+  frame and weights (max |hip - oracle| over all prediction maps, voxel indices bit-exact); the run
+  exits non-zero if the fp32 line is above 1e-3.
 """
 import argparse
 import json
@@ -64,6 +71,25 @@ def parse():
                          "use with --config cfg3 --batch 4 or --config cfg5); f32x3: float32-accurate products from three "
                          "bf16 terms per operand on the bf16 matrix cores (experimental).  Never the default.")
     return ap.parse_args()
+
+
+def load_vp_traffic():
+    """HBM bytes per launch of the voxel-pooling gather + fix-up from the committed PMC summary."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    for f in reversed(files):
+        try:
+            rec = json.load(open(f))["bench"]
+        except Exception:
+            continue
+        tot, names = 0.0, []
+        for sym, r in rec.items():
+            if sym.startswith(("vp_gather2_kernel", "vp_fixup_kernel")):
+                tot += r["hbm_bytes_per_launch"]
+                names.append(sym)
+        if names:
+            return tot, os.path.relpath(f, ROOT) + ":" + "+".join(sorted(names))
+    return None, None
 
 
 def load_traffic(tile_name):
@@ -137,7 +163,7 @@ def main():
             "fp32", "bf16 MFMA operands / f32 accumulation and f32 tensors in HBM")
     torch.manual_seed(0)
     model = BEVHeight(bc, hc).eval()
-    S.randomize_norm_stats_(model, 0)
+    S.randomize_norm_stats_(model, 0, residual_gamma=0.3)    # small last-BN gamma per residual block, as mmdet initialises
     model = model.to(dev)
     model.backbone.fuse_lift_splat = bool(args.fuse_lift_splat)
     B = args.batch
@@ -161,22 +187,35 @@ def main():
     use_graph = pipe.use_graph
     if not use_graph and not args.no_graph and rank == 0:
         print("[bench] hipGraph capture failed; running eager launches on the slot streams", file=sys.stderr)
-    run = pipe.replay
+    run = lambda: pipe.submit(imgs, mats)       # the product call: resident frame -> slot's static inputs -> graph replay
     for _ in range(args.warmup * nstreams):
         run()
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps ------------------------------------------------------------
-    elapsed = group.timed(run, args.steps)          # barrier+sync | K steps | barrier+sync, MAX over ranks
+    elapsed_local = [0.0]
+    counters0 = (sum(c.hits for c in pipe.caches), sum(c.refreshes for c in pipe.caches),
+                 sum(c.plan.builds() for c in pipe.caches if c.plan is not None))
+
+    def timed_local(fn, n):
+        t = group.timed(fn, n, local_out=elapsed_local)
+        return t
+    elapsed = timed_local(run, args.steps)          # barrier+sync | K steps | barrier+sync, MAX over ranks
     value = group.aggregate_throughput(B, args.steps, elapsed)
     single = None
     if nstreams > 1 and rank == 0 and world == 1:   # same K steps with one frame in flight, for reference
         one = FramePipeline(model, imgs, mats, slots=1, use_graph=use_graph)
         for _ in range(args.warmup):
-            one.replay()
-        t1 = group.timed(one.replay, args.steps)
+            one.submit(imgs, mats)
+        t1 = group.timed(lambda: one.submit(imgs, mats), args.steps)
         single = {"value": B * args.steps / t1, "ms_per_step": t1 / args.steps * 1e3}
         del one
+    # calibration cache counters of the timed slots: geometry / plan kernels launched inside the timed region
+    calib = {"plan_builds_before_timed_region": counters0[2],
+             "plan_builds_in_timed_region": sum(c.plan.builds() for c in pipe.caches if c.plan is not None) - counters0[2],
+             "geometry_launches_in_timed_region": sum(c.refreshes for c in pipe.caches) - counters0[1]}
+    per_rank = group.all_gather_object({"rank": rank, "frames_per_s": B * args.steps / elapsed_local[0],
+                                        "device": torch.cuda.get_device_name(dev)})
 
     # ---- roofline: instrumented pass, HIP events around every conv launch -------------------------
     roofline = None
@@ -241,24 +280,122 @@ def main():
             "event_pair_gap_us": gap_s * 1e6,
         }
 
+    # ---- voxel pooling against the HBM roofline (north_star: >= 60 % of HBM peak) -----------------
+    roofline_hbm = None
+    if rank == 0 and not args.no_roofline:
+        from sgv3d_amd.ops.voxel_pooling import VoxelPlan
+        bb = model.backbone
+        with torch.no_grad():
+            geom, plan = bb.calibration(mats, 0)
+        Bn, Np = plan.B, plan.N
+        Cvp = bb.output_channels if not bc.get('is_bsm') else (bb.bev_channels + 3) // 4 * 4
+        feats = torch.randn(Bn, Np, Cvp, device=dev)
+        X, Y, _ = bb._voxel_num_host
+
+        def time_us(fn, reps=20):
+            fn(); torch.cuda.synchronize()
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+            evs[0].record()
+            for r in range(reps):
+                fn()
+                evs[r + 1].record()
+            torch.cuda.synchronize()
+            return sorted(evs[r].elapsed_time(evs[r + 1]) for r in range(reps))[reps // 2] * 1e3
+        outb = torch.empty(Bn, Y, X, Cvp, device=dev)
+        pool_us = time_us(lambda: plan.pool(feats, out=outb))
+        flat = geom.view(Bn, -1, 3)
+        build_us = time_us(lambda: VoxelPlan(flat, (X, Y, 1), cached=False), reps=10)
+        clean_us = time_us(lambda: plan.rebuild(flat), reps=10)
+        alg = 12.0 * Bn * Np + 4.0 * Bn * Np * Cvp + 4.0 * Bn * Y * X * Cvp           # geom + feats + output
+        vtraffic, vsrc = load_vp_traffic()
+        roofline_hbm = {
+            "bound": "hbm", "kernel": "vp_gather2_kernel + vp_fixup_kernel (sgv3d_voxel_pooling_forward_planned)",
+            "bytes": alg, "us": pool_us, "achieved": alg / pool_us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": alg / pool_us / 1e3 / HBM_PEAK_GBPS, "traffic": vtraffic, "traffic_source": vsrc,
+            "plan_build_us": build_us, "plan_check_us": clean_us,
+            "frac_including_plan": alg / (pool_us + build_us) / 1e3 / HBM_PEAK_GBPS,
+            "frac_including_check": alg / (pool_us + clean_us) / 1e3 / HBM_PEAK_GBPS,
+            "plan_builds_in_timed_region": calib["plan_builds_in_timed_region"],
+            "note": "the plan depends only on the calibration: built once per calibration outside the captured forward "
+                    "(frac_including_plan = if it were rebuilt on every frame, as the reference-style operator call with "
+                    "ever-changing geom_xyz would; frac_including_check = operator call with an unchanged geom_xyz: "
+                    "device-side compare + empty build launches)",
+            "method": "HIP events on the launch stream, median of 20 launches, N(0,1) features on this run's geometry",
+        }
+        del feats, outb
+
     # ---- CPU baseline (oracle port), rank 0 at N=1 only -------------------------------------------
-    cpu_baseline = None
+    cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import torch_model as TM
+        import numpy as np
+        from oracle import torch_model as TM, voxel_pooling_ref as VPR
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         cimgs, cmats = imgs[:1].cpu(), {k: v[:1].cpu() for k, v in mats.items()}
         cores = torch.get_num_threads()
-        t1 = time.perf_counter()
-        n_cpu = 0
-        while True:
+        # BASELINE.md 3 asks warm-up 3 / median of 10; a cfg-2 frame takes ~5 s on these host cores, so the sample is
+        # bounded to 1 warm-up + up to 3 timed frames (<= ~25 s), median reported
+        keep = {}
+        t0 = time.perf_counter()
+        ref = TM.bevheight_forward(sd, bc, hc, cimgs, cmats, keep)          # warm-up frame; also the parity reference
+        warm = time.perf_counter() - t0
+        times = []
+        while len(times) < 3 and sum(times) + warm < 22.0:
+            t1 = time.perf_counter()
             TM.bevheight_forward(sd, bc, hc, cimgs, cmats)
-            n_cpu += 1
-            dt = time.perf_counter() - t1
-            if dt > 12.0 or n_cpu >= 4:
-                break
-        cpu_baseline = {"value": n_cpu / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-                        "sample": f"{n_cpu} full cfg-2 frame(s) through oracle/torch_model.py (torch-CPU fp32 "
-                                  f"eager + numpy geometry + C voxel pooling), {dt:.1f} s"}
+            times.append(time.perf_counter() - t1)
+        med = sorted(times)[len(times) // 2] if times else warm
+        # operator-level baseline: the C restatement of voxel_pooling_forward_kernel on this frame's geometry
+        g = np.ascontiguousarray(keep['geom_xyz'].reshape(1, -1, 3))
+        Cc = int(keep['bev'].shape[1])
+        f = np.random.default_rng(0).standard_normal((1, g.shape[1], Cc)).astype(np.float32)
+        Xc, Yc, Zc = (int(v) for v in sd['backbone.voxel_num'])
+        ob = np.zeros((1, Yc, Xc, Cc), np.float32)
+
+        def cpu_med(threads, reps=5):
+            VPR.forward_nhwc_inplace(g, f, ob, Xc, Yc, Zc, threads)
+            ts = []
+            for _ in range(reps):
+                t = time.perf_counter()
+                VPR.forward_nhwc_inplace(g, f, ob, Xc, Yc, Zc, threads)
+                ts.append(time.perf_counter() - t)
+            return sorted(ts)[reps // 2] * 1e3
+        ncpu = os.cpu_count() or 1
+        cpu_baseline = {"value": 1.0 / med, "unit": "frames/s", "cores": cores, "kind": "port",
+                        "sample": f"1 warm-up + {len(times)} timed full {args.config} frame(s) (batch 1) through "
+                                  f"oracle/torch_model.py (torch-CPU fp32 eager + numpy geometry + C voxel pooling), "
+                                  f"median {med:.2f} s per frame, {warm + sum(times):.1f} s in total",
+                        "voxel_pooling_c_1thread_ms": cpu_med(1), "voxel_pooling_c_openmp_ms": cpu_med(ncpu),
+                        "voxel_pooling_openmp_threads": ncpu,
+                        "voxel_pooling_sample": f"oracle/voxel_pooling_ref.c on this frame's geometry, N={g.shape[1]}, "
+                                                f"C={Cc}, warm-up 1, median of 5"}
+        # ---- parity of the timed model: same frame, same weights, GPU vs oracle ---------------------
+        with torch.no_grad():
+            got = model(imgs[:1], {k: v[:1] for k, v in mats.items()})
+            ggeom, _ = model.backbone.calibration({k: v[:1] for k, v in mats.items()}, 0)
+        torch.cuda.synchronize()
+        worst, worst_name, nmaps, scale = 0.0, None, 0, 0.0
+        for t in range(len(ref)):
+            for k, v in ref[t][0].items():
+                e = float((got[t][0][k].float().cpu() - v).abs().max())
+                scale = max(scale, float(v.abs().max()))
+                nmaps += 1
+                if e > worst:
+                    worst, worst_name = e, f"task{t}.{k}"
+        tol = 1e-3 if args.dtype in ("f32", "f32x3", "f32x3auto") else 1e-1
+        # yardstick: the same forward in float64 (torch on the GPU, a checker): how far is EACH float32 execution from
+        # exact arithmetic?  Two float32 implementations differ by their summed rounding noise; the HIP path has to be
+        # as close to the float64 result as the reference-style torch-CPU float32 execution is.
+        ref64 = TM.bevheight_forward_highprec(sd, bc, hc, cimgs, cmats, device=dev)
+        e_hip = max(float((got[t][0][k].double() - ref64[t][0][k]).abs().max()) for t in range(len(ref)) for k in ref[t][0])
+        e_cpu = max(float((ref[t][0][k].double() - ref64[t][0][k].cpu()).abs().max()) for t in range(len(ref)) for k in ref[t][0])
+        del ref64
+        parity = {"max_abs_err": worst, "worst_map": worst_name, "n_maps": nmaps, "max_abs_ref": scale,
+                  "voxel_indices_equal": bool(np.array_equal(ggeom.cpu().numpy(), keep['geom_xyz'])),
+                  "tolerance": tol, "reference": "oracle/torch_model.py::bevheight_forward on the same frame and weights",
+                  "float64_yardstick": {"hip_max_abs_err": e_hip, "oracle_fp32_max_abs_err": e_cpu,
+                                        "what": "max |x - float64 forward| over the 36 maps for x = HIP output / torch-CPU fp32 oracle"},
+                  "ok": bool(worst <= tol)}
+        parity["ok"] = parity["ok"] and parity["voxel_indices_equal"]
 
     if rank == 0:
         line = {
@@ -268,9 +405,20 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world}",
-                       "hip_graph": bool(use_graph), "frames_in_flight": nstreams, "one_frame_in_flight": single, "fuse_lift_splat": bool(args.fuse_lift_splat),
-                       "voxel_pooling_mode": "planned", "weights": "random-init, BN stats perturbed (seed 0)"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+                       "hip_graph": bool(use_graph), "frames_in_flight": nstreams,
+                       "one_frame_in_flight_value": single["value"] if single else None,
+                       "one_frame_in_flight_ms_per_step": single["ms_per_step"] if single else None,
+                       "fuse_lift_splat": bool(args.fuse_lift_splat),
+                       "voxel_pooling_mode": "planned, plan cached per calibration",
+                       "calibration_cache": calib,
+                       "weights": "random-init (seed 0), BN statistics / affine perturbed, last BN of every residual block scaled by 0.3 "
+                                  "(mmdet zero-initialises it) so that activations stay O(1-10)",
+                       "world_size": group.dist.get_world_size() if group.dist is not None else 1,
+                       "backend": (group.backend or "none") + (" (RCCL)" if group.backend == "nccl" else ""),
+                       "per_rank": per_rank},
+            "one_frame_in_flight_value": single["value"] if single else None,
+            "one_frame_in_flight_ms_per_step": single["ms_per_step"] if single else None,
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "parity": parity,
         }
     group.close()
     if rank == 0:
@@ -279,6 +427,10 @@ def main():
         ctypes.CDLL(None).fflush(None)        # C stdio buffers (the RCCL banner) go to stderr, not after our line
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        if parity is not None and not parity["ok"]:
+            print(f"[bench] PARITY FAILURE: max |hip - oracle| = {parity['max_abs_err']:.3e} on {parity['worst_map']} "
+                  f"(tolerance {parity['tolerance']}), voxel indices equal: {parity['voxel_indices_equal']}", file=sys.stderr)
+            sys.exit(3)
 
 
 if __name__ == "__main__":

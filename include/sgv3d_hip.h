@@ -56,7 +56,7 @@ int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int num_channels
  *
  * Plan layout (bytes from sgv3d_voxel_plan_bytes, 16-B aligned by the caller):
  *   int32 seg_start[B*Y*X + 1] | int32 cursor[B*Y*X + 1] | int32 order[B*N] | int32 slot_voxel[B*N + 1]
- *   | int32 scan scratch                                                                            */
+ *   | int32 scan scratch | cache header (11 x int32) | int32 geom_xyz copy [B*N*3] (cached build only)  */
 size_t sgv3d_voxel_plan_bytes(int batch_size, int num_points, int num_voxel_x, int num_voxel_y);
 
 /* Build the plan.  pos_memo as above (may be NULL).  sort_segments != 0 makes every voxel's point
@@ -65,6 +65,23 @@ int sgv3d_voxel_plan_build(int batch_size, int num_points,
                            int num_voxel_x, int num_voxel_y, int num_voxel_z,
                            const int32_t *geom_xyz, int32_t *pos_memo,
                            void *plan, size_t plan_bytes, int sort_segments, void *stream);
+
+/* Cached build: geom_xyz depends only on the camera calibration, which is static per roadside camera
+ * (SURVEY.md §7.3), so the plan is rebuilt only when geom_xyz is not bytewise the tensor it was built
+ * for (or the grid / sort mode differs).  The decision is taken ON THE DEVICE: one compare kernel
+ * (reads geom_xyz and the plan's copy once, ~12*B*N*2 bytes) sets a flag in the plan's header and the
+ * build kernels return immediately when it is clear -- no host synchronisation, stream-ordered,
+ * capturable in a hipGraph.  The plan must have been passed to sgv3d_voxel_plan_init once after
+ * allocation.  There is no pos_memo here (training uses sgv3d_voxel_plan_build).
+ * sgv3d_voxel_plan_stats_offset: byte offset inside the plan of the header
+ *   { int32 dirty, diff, ticket, params[7], builds } -- `builds` counts the real rebuilds (tests, profiling). */
+int sgv3d_voxel_plan_init(int batch_size, int num_points, int num_voxel_x, int num_voxel_y,
+                          void *plan, size_t plan_bytes, void *stream);
+int sgv3d_voxel_plan_build_cached(int batch_size, int num_points,
+                                  int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                  const int32_t *geom_xyz, void *plan, size_t plan_bytes,
+                                  int sort_segments, void *stream);
+size_t sgv3d_voxel_plan_stats_offset(int batch_size, int num_points, int num_voxel_x, int num_voxel_y);
 
 /* output_features f32 [B, Y, X, C], fully overwritten.  Replaces the same reference kernel
  * (voxel_pooling_forward_cuda.cu:9-36) when the caller holds a plan.  `workspace` (bytes from

@@ -96,7 +96,8 @@ def deform_conv3x3(x, offset, weight, groups):
     offset channel 2t = dy, 2t+1 = dx of tap t (row-major); bilinear sampling with zero padding,
     samples outside (-1, H) x (-1, W) are zero; grouped 3x3 weights, no bias."""
     B, C, H, W = x.shape
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=x.dtype), torch.arange(W, dtype=x.dtype), indexing="ij")
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=x.dtype, device=x.device), torch.arange(W, dtype=x.dtype, device=x.device),
+                            indexing="ij")
     cols = []
     flat = x.reshape(B, C, -1)
     for t in range(9):
@@ -184,8 +185,9 @@ def heightnet(sd, p, x, mats):
 def geometry_indices(sd, mats, sweep=0):
     """get_geometry + quantise for every (batch, camera) via the numpy oracle.
     -> int32 [B, N, D, fH, fW, 3]"""
-    fr = sd['backbone.frustum'].numpy()
-    vc, vs = sd['backbone.voxel_coord'].numpy(), sd['backbone.voxel_size'].numpy()
+    fr = sd['backbone.frustum'].float().cpu().numpy()
+    vc, vs = sd['backbone.voxel_coord'].float().cpu().numpy(), sd['backbone.voxel_size'].float().cpu().numpy()
+    mats = {k: v.float().cpu() for k, v in mats.items()}
     B, N = mats['sensor2ego_mats'].shape[0], mats['sensor2ego_mats'].shape[2]
     out = np.empty((B, N) + fr.shape[:3] + (3,), np.int32)
     for b in range(B):
@@ -327,10 +329,10 @@ def voxel_pool_torch(geom, lifted, voxel_num):
     the others add their feature row to cell (b, y, x).  geom int32 numpy [B, ..., 3], lifted [B, ..., C] -> [B, C, Y, X]."""
     X, Y, Z = voxel_num
     B, C = lifted.shape[0], lifted.shape[-1]
-    g = torch.from_numpy(np.ascontiguousarray(geom)).reshape(B, -1, 3).long()
+    g = torch.from_numpy(np.ascontiguousarray(geom)).reshape(B, -1, 3).long().to(lifted.device)
     f = lifted.reshape(B, -1, C)
     ok = (g[..., 0] >= 0) & (g[..., 0] < X) & (g[..., 1] >= 0) & (g[..., 1] < Y) & (g[..., 2] >= 0) & (g[..., 2] < Z)
-    cell = (torch.arange(B)[:, None] * Y + g[..., 1]) * X + g[..., 0]
+    cell = (torch.arange(B, device=lifted.device)[:, None] * Y + g[..., 1]) * X + g[..., 0]
     out = f.new_zeros(B * Y * X, C).index_add(0, cell[ok], f[ok])
     return out.reshape(B, Y, X, C).permute(0, 3, 1, 2)
 
@@ -384,3 +386,41 @@ def bevheight_forward(sd, backbone_conf, head_conf, imgs, mats, keep=None):
         fwd = bsm_lss_fpn_forward if backbone_conf.get('is_bsm') else lss_fpn_forward
         bev = fwd(sd, backbone_conf, imgs.detach().cpu().float(), mats, keep)
         return head_forward(sd, head_conf, bev, keep)
+
+
+def bevheight_forward_highprec(sd, backbone_conf, head_conf, imgs, mats, device="cpu", dtype=torch.float64, keep=None):
+    """The same eval-mode forward evaluated in ``dtype`` (float64) on ``device``: the yardstick that tells how far BOTH
+    float32 executions -- this oracle on torch-CPU and the HIP path -- are from exact arithmetic (two float32
+    implementations of a 100-layer network differ from each other by their summed rounding noise, so the meaningful
+    question is whether the HIP path is as close to the exact result as the reference-style float32 execution is).
+    Voxel indices come from the float32 geometry oracle (they are integer data, identical by construction); the splat is
+    an index_add in ``dtype``.  A checker like the rest of this file; on a GPU it runs through torch's im2col + dgemm
+    convolution path."""
+    with torch.no_grad():
+        sdd = {k: (v.detach().to(device=device, dtype=dtype) if v.is_floating_point() else v.detach().to(device))
+               for k, v in sd.items()}
+        matsd = {k: v.detach().to(device=device, dtype=dtype) for k, v in mats.items()}
+        B, S, N, Cin, H, W = imgs.shape
+        x = imgs[:, 0].reshape(B * N, Cin, H, W).to(device=device, dtype=dtype)
+        feats = resnet(sdd, 'backbone.img_backbone', x, backbone_conf['img_backbone_conf'])
+        if backbone_conf.get('is_bsm'):
+            n16 = secondfpn(sdd, 'backbone.img_neck_16', feats, backbone_conf['img_neck_conf'])
+            n8 = secondfpn(sdd, 'backbone.img_neck_8', feats, dict(backbone_conf['img_neck_conf'], upsample_strides=[0.5, 1, 2, 4]))
+            depth1, semantic1, context1, _ = msct_head(sdd, 'backbone.height_net', [n16, n8], matsd)
+            semantic = semantic1.softmax(dim=1)
+            tran = torch.cat((context1, semantic), dim=1)
+            tran = tran * (1 - (semantic[:, 0:1] > 0.45).to(dtype))
+            lifted = depth1.softmax(dim=1).unsqueeze(1) * tran.unsqueeze(2)
+            src = hf = None
+        else:
+            src = secondfpn(sdd, 'backbone.img_neck', feats, backbone_conf['img_neck_conf'])
+            hf = heightnet(sdd, 'backbone.height_net', src, matsd)
+            D, C = sdd['backbone.frustum'].shape[0], backbone_conf['output_channels']
+            lifted = hf[:, :D].softmax(1).unsqueeze(1) * hf[:, D:D + C].unsqueeze(2)
+        C, D, fH, fW = lifted.shape[1:]
+        lifted = lifted.reshape(B, N, C, D, fH, fW).permute(0, 1, 3, 4, 5, 2)
+        geom = geometry_indices(sd, mats)
+        bev = voxel_pool_torch(geom, lifted, [int(v) for v in sd['backbone.voxel_num']])
+        if keep is not None:
+            keep.update(img_feats=src, height_feature=hf, bev=bev, geom_xyz=geom)
+        return head_forward(sdd, head_conf, bev)

@@ -31,6 +31,9 @@ _PROTOS = {
     "sgv3d_voxel_pooling_forward": (c_int, [c_int] * 6 + [c_void_p] * 5),
     "sgv3d_voxel_plan_bytes": (c_size_t, [c_int] * 4),
     "sgv3d_voxel_plan_build": (c_int, [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "sgv3d_voxel_plan_init": (c_int, [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
+    "sgv3d_voxel_plan_build_cached": (c_int, [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "sgv3d_voxel_plan_stats_offset": (c_size_t, [c_int] * 4),
     "sgv3d_voxel_pooling_workspace_bytes": (c_size_t, [c_int] * 3),
     "sgv3d_voxel_pooling_forward_planned": (c_int, [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_void_p]),
     "sgv3d_lift_splat_planned": (c_int, [c_int] * 6 + [c_void_p] * 5 + [c_size_t, c_void_p]),

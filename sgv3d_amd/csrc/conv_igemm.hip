@@ -836,13 +836,9 @@ int launch_t(const ConvArgs &a, hipStream_t st) {
     // tap-major K: + the k-chunk decode table (8 bytes per 16-byte chunk of K)
     const size_t lds = tiles_lds + (FAST ? 0 : (size_t)a.k_pad / 4 * 8);
     SGV3D_REQUIRE(lds <= 160 * 1024, "conv2d_forward: K = %d too long for the tap-major kernel's decode table", a.K);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_kernel<WTM, WTN, FAST>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot raise the dynamic LDS limit to %zu", lds);
-        lds_set = lds;
-    }
+    static PerDeviceSize lds_set;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel<WTM, WTN, FAST>), lds, lds_set))
+        return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot raise the dynamic LDS limit to %zu", lds);
     ConvArgs b = a;
     b.zeros = conv_zero_block();
     if (!b.zeros) return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot resolve the zero block");
@@ -865,13 +861,9 @@ int launch_bf16_t(const ConvArgs &a, hipStream_t st) {
     constexpr size_t tiles_lds = sizeof(unsigned short) * 2 * (SPLIT3 ? 3 : 1) * (BM + BN) * LDKB;
     const size_t lds = tiles_lds + (FAST ? 0 : (size_t)a.k_pad / 4 * 8);
     SGV3D_REQUIRE(lds <= 160 * 1024, "conv2d_forward_bf16: K = %d too long for the tap-major kernel's decode table", a.K);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16_kernel<WTM, WTN, FAST, SPLIT3>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(SGV3D_ELAUNCH, "conv2d_forward_bf16: cannot raise the dynamic LDS limit to %zu", lds);
-        lds_set = lds;
-    }
+    static PerDeviceSize lds_set;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_bf16_kernel<WTM, WTN, FAST, SPLIT3>), lds, lds_set))
+        return fail(SGV3D_ELAUNCH, "conv2d_forward_bf16: cannot raise the dynamic LDS limit to %zu", lds);
     ConvArgs b = a;
     b.zeros = conv_zero_block();
     if (!b.zeros) return fail(SGV3D_ELAUNCH, "conv2d_forward_bf16: cannot resolve the zero block");
@@ -913,13 +905,17 @@ int launch_splitk_reduce(const ConvArgs &a, hipStream_t st) {
     return check_launch("conv_splitk_reduce_kernel");
 }
 const float *conv_zero_block() {
-    static const float *zero_block = nullptr;
-    if (!zero_block) {
+    static const float *zero_block[kMaxDevices] = {};      // a device symbol has one address per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    const float *z = __atomic_load_n(&zero_block[dev], __ATOMIC_RELAXED);
+    if (!z) {
         void *p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero16)) != hipSuccess) return nullptr;
-        zero_block = static_cast<const float *>(p);
+        z = static_cast<const float *>(p);
+        __atomic_store_n(&zero_block[dev], z, __ATOMIC_RELAXED);
     }
-    return zero_block;
+    return z;
 }
 }  // namespace sgv3d
 

@@ -966,13 +966,9 @@ extern "C" int sgv3d_conv2d_winograd_forward(const sgv3d_conv_desc *d, const flo
         const int lds = (d->cin / WK) * A_SLOTS * 16;
         SGV3D_REQUIRE(lds <= 160 * 1024 - 4096, "conv2d_winograd_forward: patch-resident variant needs cin <= 96 (got %d)", d->cin);
         SGV3D_REQUIRE(a.split_k == 1, "conv2d_winograd_forward: patch-resident variant has no split-K");
-        static int lds_set = 0;
-        if (lds > lds_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_resident_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-                return fail(SGV3D_ELAUNCH, "conv2d_winograd_forward: cannot raise the dynamic LDS limit to %d", lds);
-            lds_set = lds;
-        }
+        static PerDeviceSize lds_set;
+        if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wino_resident_kernel), (size_t)lds, lds_set))
+            return fail(SGV3D_ELAUNCH, "conv2d_winograd_forward: cannot raise the dynamic LDS limit to %d", lds);
         // cout tiles are dealt to `groups` workgroups per block so that the grid is about one wave of CUs
         int groups = 256 / a.tiles_m;
         if (groups < 1) groups = 1;
@@ -1020,13 +1016,9 @@ extern "C" int sgv3d_centerhead_branches_forward(int batch, int h, int w, int ci
     HeadArgs ha;
     ha.w2 = w2; ha.bias2 = bias2; ha.out_begin = out_begin; ha.out = out; ha.ring = static_cast<float *>(workspace);
     ha.total_out = total_out;
-    static int lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess)
-            return fail(SGV3D_ELAUNCH, "centerhead_branches_forward: cannot raise the dynamic LDS limit to %d", lds);
-        lds_set = lds;
-    }
+    static PerDeviceSize lds_set;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_wino_head_kernel), (size_t)lds, lds_set))
+        return fail(SGV3D_ELAUNCH, "centerhead_branches_forward: cannot raise the dynamic LDS limit to %d", lds);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(conv_wino_head_kernel, dim3(a.tiles_m), dim3(256), lds, st, a, ha);
     const long long total = (long long)a.tiles_m * total_out * 60;

@@ -557,13 +557,9 @@ extern "C" int sgv3d_head_final_conv(int batch, int h, int w, int num_branches, 
     SGV3D_REQUIRE(hidden && weight && bias && branch_of_out && out, "head_final_conv: null pointer");
     SGV3D_REQUIRE((long long)batch * num_branches <= 65535, "head_final_conv: batch*branches exceeds grid.z");
     const size_t lds = sizeof(float) * ((size_t)kHfPr * kHfPc * kHfLd + (size_t)kHfMaxOut * 9 * hidden_ch + 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&head_final_conv_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-            return fail(SGV3D_ELAUNCH, "head_final_conv: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    static PerDeviceSize attr_set;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&head_final_conv_kernel), 96 * 1024, attr_set))
+        return fail(SGV3D_ELAUNCH, "head_final_conv: cannot raise the dynamic LDS limit");
     SGV3D_REQUIRE(lds <= 96 * 1024, "head_final_conv: hidden_ch too large");
     const int tiles = cdiv(h, kHfTy) * cdiv(w, kHfTx);
     dim3 grid(tiles, 1, batch * num_branches);

@@ -82,8 +82,18 @@ struct PlanLayout {
     long long V;        // B*Y*X
     long long total;    // B*N
     int nblk;           // scan workgroups
-    size_t off_seg, off_cur, off_order, off_slotvox, off_blk, bytes;
+    size_t off_seg, off_cur, off_order, off_slotvox, off_blk, off_hdr, off_geom, bytes;
 };
+
+// Cache header of a plan (sgv3d_voxel_plan_build_cached): which geom_xyz / grid the plan was built for.
+struct PlanHeader {
+    int dirty;       // result of the last compare: 1 = the build kernels of this call run, 0 = they return at once
+    int diff;        // accumulator of the compare workgroups
+    int ticket;      // last-workgroup election of the compare kernel
+    int params[7];   // magic, B, N, X, Y, Z, sort_segments of the plan held (all 0 = none)
+    int builds;      // number of real builds so far (statistics / tests)
+};
+constexpr int kPlanMagic = 0x53475633;  // "SGV3"
 
 PlanLayout plan_layout(int B, int N, int X, int Y) {
     PlanLayout L;
@@ -96,7 +106,9 @@ PlanLayout plan_layout(int B, int N, int X, int Y) {
     L.off_order = al(L.off_cur + sizeof(int) * (size_t)(L.V + 1));
     L.off_slotvox = al(L.off_order + sizeof(int) * (size_t)L.total);
     L.off_blk = al(L.off_slotvox + sizeof(int) * (size_t)(L.total + 1));
-    L.bytes = al(L.off_blk + sizeof(int) * (size_t)(L.nblk + 2));
+    L.off_hdr = al(L.off_blk + sizeof(int) * (size_t)(L.nblk + 2));
+    L.off_geom = al(L.off_hdr + sizeof(PlanHeader));
+    L.bytes = al(L.off_geom + sizeof(int) * 3 * (size_t)L.total);
     return L;
 }
 
@@ -114,7 +126,68 @@ __device__ __forceinline__ void wave_runs(int v, int lane, int &head_lane, int &
     run_len = next - head_lane;
 }
 
-__global__ __launch_bounds__(kBlock) void vp_zero_kernel(long long n, int *__restrict__ p) {
+// Every kernel of the plan build takes `dirty` (NULL = always run): the cached build
+// (sgv3d_voxel_plan_build_cached) points it at PlanHeader::dirty, written by vp_geom_compare_kernel
+// earlier on the same stream, and the whole build degenerates to empty launches while geom_xyz is the
+// tensor the plan was built for.  Graph-capturable: the decision is taken on the device.
+#define VP_SKIP_IF_CLEAN(dirty) \
+    if ((dirty) != nullptr && *reinterpret_cast<const volatile int *>(dirty) == 0) return
+
+__global__ __launch_bounds__(kBlock) void vp_plan_init_kernel(PlanHeader *__restrict__ hdr) {
+    if (threadIdx.x == 0) {
+        hdr->dirty = 1; hdr->diff = 0; hdr->ticket = 0; hdr->builds = 0;
+        for (int i = 0; i < 7; ++i) hdr->params[i] = 0;
+    }
+}
+
+// geom_xyz == the copy the plan keeps?  16-byte compares, grid-stride; the last workgroup to finish publishes the
+// verdict (dirty) and re-arms the accumulators for the next call.
+__global__ __launch_bounds__(kBlock) void vp_geom_compare_kernel(long long n_ints, const int32_t *__restrict__ geom,
+                                                                 const int32_t *__restrict__ copy,
+                                                                 PlanHeader *__restrict__ hdr, int p0, int p1, int p2,
+                                                                 int p3, int p4, int p5, int p6) {
+    __shared__ int any_s;
+    if (threadIdx.x == 0) any_s = 0;
+    __syncthreads();
+    const long long n4 = n_ints >> 2;
+    const long long stride = (long long)gridDim.x * kBlock;
+    bool diff = false;
+    const int4 *g4 = reinterpret_cast<const int4 *>(geom);
+    const int4 *c4 = reinterpret_cast<const int4 *>(copy);
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+        const int4 a = g4[i], b = c4[i];
+        diff |= (a.x != b.x) | (a.y != b.y) | (a.z != b.z) | (a.w != b.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n_ints & 3)) diff |= geom[n4 * 4 + threadIdx.x] != copy[n4 * 4 + threadIdx.x];
+    if (diff) any_s = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (any_s) atomicOr(&hdr->diff, 1);
+        __threadfence();
+        const int t = atomicAdd(&hdr->ticket, 1);
+        if (t == (int)gridDim.x - 1) {
+            __threadfence();
+            const int d = atomicOr(&hdr->diff, 0);
+            const int *q = hdr->params;
+            const bool same = q[0] == p0 && q[1] == p1 && q[2] == p2 && q[3] == p3 && q[4] == p4 && q[5] == p5 && q[6] == p6;
+            hdr->dirty = (d != 0 || !same) ? 1 : 0;
+            hdr->diff = 0;
+            hdr->ticket = 0;
+        }
+    }
+}
+
+// closes a (re)build: the header now describes the plan held
+__global__ __launch_bounds__(64) void vp_plan_commit_kernel(PlanHeader *__restrict__ hdr, int p0, int p1, int p2, int p3,
+                                                            int p4, int p5, int p6) {
+    if (threadIdx.x != 0 || hdr->dirty == 0) return;
+    hdr->params[0] = p0; hdr->params[1] = p1; hdr->params[2] = p2; hdr->params[3] = p3;
+    hdr->params[4] = p4; hdr->params[5] = p5; hdr->params[6] = p6;
+    hdr->builds += 1;
+}
+
+__global__ __launch_bounds__(kBlock) void vp_zero_kernel(long long n, int *__restrict__ p, const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) p[i] = 0;
 }
@@ -122,7 +195,9 @@ __global__ __launch_bounds__(kBlock) void vp_zero_kernel(long long n, int *__res
 __global__ __launch_bounds__(kBlock) void vp_count_kernel(long long total_pts, int N, int X, int Y, int Z,
                                                           const int32_t *__restrict__ geom,
                                                           int32_t *__restrict__ pos_memo,
-                                                          int *__restrict__ count) {
+                                                          int *__restrict__ count, const int *__restrict__ dirty,
+                                                          int32_t *__restrict__ geom_copy) {
+    VP_SKIP_IF_CLEAN(dirty);
     const long long pt = (long long)blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int v = -1;
@@ -130,6 +205,11 @@ __global__ __launch_bounds__(kBlock) void vp_count_kernel(long long total_pts, i
         const int b = (int)(pt / N);
         int x, y;
         v = voxel_of_point(geom, pt, b, X, Y, Z, x, y);
+        if (geom_copy) {        // the cached build remembers the tensor it is built for
+            geom_copy[pt * 3 + 0] = x;
+            geom_copy[pt * 3 + 1] = y;
+            geom_copy[pt * 3 + 2] = geom[pt * 3 + 2];
+        }
         if (v >= 0 && pos_memo) {
             pos_memo[pt * 3 + 0] = b;
             pos_memo[pt * 3 + 1] = y;
@@ -168,7 +248,8 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *wave_tot /*LDS[4
 
 __global__ __launch_bounds__(kBlock) void vp_scan_local_kernel(long long V, const int *__restrict__ count,
                                                                int *__restrict__ seg_start,
-                                                               int *__restrict__ blk_sum) {
+                                                               int *__restrict__ blk_sum, const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
     __shared__ int wave_tot[kBlock / 64];
     const long long base = (long long)blockIdx.x * kScanElems + (long long)threadIdx.x * kScanPerThread;
     int v[kScanPerThread];
@@ -189,7 +270,9 @@ __global__ __launch_bounds__(kBlock) void vp_scan_local_kernel(long long V, cons
 }
 
 // one workgroup: exclusive scan of blk_sum[0..nblk) in place; blk_sum[nblk] = grand total
-__global__ __launch_bounds__(kBlock) void vp_scan_top_kernel(int nblk, int *__restrict__ blk_sum) {
+__global__ __launch_bounds__(kBlock) void vp_scan_top_kernel(int nblk, int *__restrict__ blk_sum,
+                                                             const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
     __shared__ int wave_tot[kBlock / 64];
     int carry = 0;
     for (int c0 = 0; c0 < nblk; c0 += kBlock) {
@@ -206,7 +289,8 @@ __global__ __launch_bounds__(kBlock) void vp_scan_top_kernel(int nblk, int *__re
 __global__ __launch_bounds__(kBlock) void vp_scan_add_kernel(long long V, int nblk,
                                                              const int *__restrict__ blk_sum,
                                                              int *__restrict__ seg_start,
-                                                             int *__restrict__ cursor) {
+                                                             int *__restrict__ cursor, const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i < V) {
         const int s = seg_start[i] + blk_sum[i / kScanElems];
@@ -221,7 +305,8 @@ __global__ __launch_bounds__(kBlock) void vp_fill_kernel(long long total_pts, in
                                                          const int32_t *__restrict__ geom,
                                                          int *__restrict__ cursor,
                                                          int *__restrict__ order,
-                                                         int *__restrict__ slot_voxel) {
+                                                         int *__restrict__ slot_voxel, const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
     const long long pt = (long long)blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int v = -1;
@@ -249,7 +334,9 @@ __global__ __launch_bounds__(kBlock) void vp_fill_kernel(long long total_pts, in
 // every long voxel gets its own wave, so the per-voxel multiplicity skew costs no serialisation.
 template <int R>
 __global__ __launch_bounds__(kBlock) void vp_sort_wave_kernel(long long V, const int *__restrict__ seg_start,
-                                                              int *__restrict__ order, int lo) {
+                                                              int *__restrict__ order, int lo,
+                                                              const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
     const int lane = threadIdx.x & 63;
     const long long wave0 = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * (kBlock / 64);
@@ -303,7 +390,9 @@ __global__ __launch_bounds__(kBlock) void vp_sort_wave_kernel(long long V, const
 // fits, otherwise sorted in place in global memory by the one workgroup that owns the segment.
 template <int T, int LDS_CAP>
 __global__ __launch_bounds__(T) void vp_sort_segments_kernel(long long V, const int *__restrict__ seg_start,
-                                                             int *__restrict__ order, int lo, int hi) {
+                                                             int *__restrict__ order, int lo, int hi,
+                                                             const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
     __shared__ int buf[LDS_CAP];
     __shared__ int todo[T];
     __shared__ int ntodo;
@@ -703,44 +792,88 @@ extern "C" size_t sgv3d_voxel_plan_bytes(int batch_size, int num_points, int num
     return plan_layout(batch_size, num_points, num_voxel_x, num_voxel_y).bytes;
 }
 
-extern "C" int sgv3d_voxel_plan_build(int batch_size, int num_points, int num_voxel_x, int num_voxel_y,
-                                      int num_voxel_z, const int32_t *geom_xyz, int32_t *pos_memo,
-                                      void *plan, size_t plan_bytes, int sort_segments, void *stream) {
+namespace {
+
+int plan_build_impl(int batch_size, int num_points, int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                    const int32_t *geom_xyz, int32_t *pos_memo, void *plan, size_t plan_bytes, int sort_segments,
+                    bool cached, hipStream_t st, const char *what) {
     if (int rc = check_common(batch_size, num_points, 1, num_voxel_x, num_voxel_y, num_voxel_z)) return rc;
-    SGV3D_REQUIRE(geom_xyz && plan, "voxel_plan_build: null pointer");
-    SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0, "voxel_plan_build: plan must be 16-B aligned");
+    SGV3D_REQUIRE(geom_xyz && plan, "%s: null pointer", what);
+    SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0, "%s: plan must be 16-B aligned", what);
+    SGV3D_REQUIRE(!cached || (reinterpret_cast<uintptr_t>(geom_xyz) & 15) == 0, "%s: geom_xyz must be 16-B aligned", what);
     const PlanLayout L = plan_layout(batch_size, num_points, num_voxel_x, num_voxel_y);
-    if (plan_bytes < L.bytes)
-        return fail(SGV3D_ENOSPACE, "voxel_plan_build: plan has %zu bytes, needs %zu", plan_bytes, L.bytes);
-    hipStream_t st = as_stream(stream);
+    if (plan_bytes < L.bytes) return fail(SGV3D_ENOSPACE, "%s: plan has %zu bytes, needs %zu", what, plan_bytes, L.bytes);
     char *base = static_cast<char *>(plan);
     int *seg = reinterpret_cast<int *>(base + L.off_seg);
     int *cur = reinterpret_cast<int *>(base + L.off_cur);
     int *order = reinterpret_cast<int *>(base + L.off_order);
     int *blk = reinterpret_cast<int *>(base + L.off_blk);
+    PlanHeader *hdr = reinterpret_cast<PlanHeader *>(base + L.off_hdr);
+    int32_t *gcopy = reinterpret_cast<int32_t *>(base + L.off_geom);
+    const int *dirty = cached ? &hdr->dirty : nullptr;
+    const int p[7] = {kPlanMagic, batch_size, num_points, num_voxel_x, num_voxel_y, num_voxel_z, sort_segments ? 1 : 0};
+    if (cached) {
+        const long long n_ints = L.total * 3;
+        const int cgrid = (int)(cdiv(n_ints / 4 + 1, kBlock) < 1024 ? cdiv(n_ints / 4 + 1, kBlock) : 1024);
+        hipLaunchKernelGGL(vp_geom_compare_kernel, dim3(cgrid), dim3(kBlock), 0, st, n_ints, geom_xyz, gcopy, hdr, p[0],
+                           p[1], p[2], p[3], p[4], p[5], p[6]);
+    }
     // (a plain kernel, not hipMemsetAsync: a memset node inside a captured hipGraph faulted on replay
     // -- "write access to a read-only page" -- once the host had made small allocations after the capture)
-    hipLaunchKernelGGL(vp_zero_kernel, dim3(cdiv(L.V + 1, kBlock)), dim3(kBlock), 0, st, L.V + 1, cur);
+    hipLaunchKernelGGL(vp_zero_kernel, dim3(cdiv(L.V + 1, kBlock)), dim3(kBlock), 0, st, L.V + 1, cur, dirty);
     const int pgrid = cdiv(L.total, kBlock);
     hipLaunchKernelGGL(vp_count_kernel, dim3(pgrid), dim3(kBlock), 0, st, L.total, num_points, num_voxel_x,
-                       num_voxel_y, num_voxel_z, geom_xyz, pos_memo, cur);
-    hipLaunchKernelGGL(vp_scan_local_kernel, dim3(L.nblk), dim3(kBlock), 0, st, L.V, cur, seg, blk);
-    hipLaunchKernelGGL(vp_scan_top_kernel, dim3(1), dim3(kBlock), 0, st, L.nblk, blk);
+                       num_voxel_y, num_voxel_z, geom_xyz, pos_memo, cur, dirty, cached ? gcopy : nullptr);
+    hipLaunchKernelGGL(vp_scan_local_kernel, dim3(L.nblk), dim3(kBlock), 0, st, L.V, cur, seg, blk, dirty);
+    hipLaunchKernelGGL(vp_scan_top_kernel, dim3(1), dim3(kBlock), 0, st, L.nblk, blk, dirty);
     hipLaunchKernelGGL(vp_scan_add_kernel, dim3(cdiv(L.V + 1, kBlock)), dim3(kBlock), 0, st, L.V, L.nblk, blk,
-                       seg, cur);
+                       seg, cur, dirty);
     hipLaunchKernelGGL(vp_fill_kernel, dim3(pgrid), dim3(kBlock), 0, st, L.total, num_points, num_voxel_x,
-                       num_voxel_y, num_voxel_z, geom_xyz, cur, order, reinterpret_cast<int *>(base + L.off_slotvox));
+                       num_voxel_y, num_voxel_z, geom_xyz, cur, order, reinterpret_cast<int *>(base + L.off_slotvox), dirty);
     if (sort_segments) {
         const int g_wave = (int)(L.V / 4 < 4096 ? (L.V + 3) / 4 : 4096);
-        hipLaunchKernelGGL((vp_sort_wave_kernel<1>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 1);
-        hipLaunchKernelGGL((vp_sort_wave_kernel<4>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 64);
-        hipLaunchKernelGGL((vp_sort_wave_kernel<16>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 256);
-        hipLaunchKernelGGL((vp_sort_wave_kernel<32>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 1024);
+        hipLaunchKernelGGL((vp_sort_wave_kernel<1>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 1, dirty);
+        hipLaunchKernelGGL((vp_sort_wave_kernel<4>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 64, dirty);
+        hipLaunchKernelGGL((vp_sort_wave_kernel<16>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 256, dirty);
+        hipLaunchKernelGGL((vp_sort_wave_kernel<32>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 1024, dirty);
         const int g_large = (int)((L.V + 255) / 256 < 1024 ? (L.V + 255) / 256 : 1024);
         hipLaunchKernelGGL((vp_sort_segments_kernel<256, 8192>), dim3(g_large), dim3(256), 0, st, L.V, seg, order,
-                           2048, 0x7fffffff);
+                           2048, 0x7fffffff, dirty);
     }
-    return check_launch("voxel_plan_build");
+    if (cached)
+        hipLaunchKernelGGL(vp_plan_commit_kernel, dim3(1), dim3(64), 0, st, hdr, p[0], p[1], p[2], p[3], p[4], p[5], p[6]);
+    return check_launch(what);
+}
+
+}  // namespace
+
+extern "C" int sgv3d_voxel_plan_build(int batch_size, int num_points, int num_voxel_x, int num_voxel_y,
+                                      int num_voxel_z, const int32_t *geom_xyz, int32_t *pos_memo,
+                                      void *plan, size_t plan_bytes, int sort_segments, void *stream) {
+    return plan_build_impl(batch_size, num_points, num_voxel_x, num_voxel_y, num_voxel_z, geom_xyz, pos_memo, plan,
+                           plan_bytes, sort_segments, false, as_stream(stream), "voxel_plan_build");
+}
+
+extern "C" int sgv3d_voxel_plan_init(int batch_size, int num_points, int num_voxel_x, int num_voxel_y, void *plan,
+                                     size_t plan_bytes, void *stream) {
+    SGV3D_REQUIRE(plan && batch_size > 0 && num_points > 0 && num_voxel_x > 0 && num_voxel_y > 0, "voxel_plan_init: bad argument");
+    const PlanLayout L = plan_layout(batch_size, num_points, num_voxel_x, num_voxel_y);
+    if (plan_bytes < L.bytes) return fail(SGV3D_ENOSPACE, "voxel_plan_init: plan has %zu bytes, needs %zu", plan_bytes, L.bytes);
+    hipLaunchKernelGGL(vp_plan_init_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream),
+                       reinterpret_cast<PlanHeader *>(static_cast<char *>(plan) + L.off_hdr));
+    return check_launch("voxel_plan_init");
+}
+
+extern "C" int sgv3d_voxel_plan_build_cached(int batch_size, int num_points, int num_voxel_x, int num_voxel_y,
+                                             int num_voxel_z, const int32_t *geom_xyz, void *plan, size_t plan_bytes,
+                                             int sort_segments, void *stream) {
+    return plan_build_impl(batch_size, num_points, num_voxel_x, num_voxel_y, num_voxel_z, geom_xyz, nullptr, plan,
+                           plan_bytes, sort_segments, true, as_stream(stream), "voxel_plan_build_cached");
+}
+
+extern "C" size_t sgv3d_voxel_plan_stats_offset(int batch_size, int num_points, int num_voxel_x, int num_voxel_y) {
+    if (batch_size <= 0 || num_points <= 0 || num_voxel_x <= 0 || num_voxel_y <= 0) return 0;
+    return plan_layout(batch_size, num_points, num_voxel_x, num_voxel_y).off_hdr;
 }
 
 extern "C" size_t sgv3d_voxel_pooling_workspace_bytes(int batch_size, int num_points, int num_channels) {

@@ -13,7 +13,7 @@ import tempfile
 
 import numpy as np
 
-from .result2kitti import kitti_evaluation, result2kitti, result2kitti_dair
+from .result2kitti import kitti_evaluation, result2kitti, result2kitti_dair, result2kitti_rope3d
 
 __all__ = ['RoadSideEvaluator']
 
@@ -66,15 +66,15 @@ class RoadSideEvaluator():
 
     def evaluate(self, results, img_metas, metric='bbox', logger=None, jsonfile_prefix=None, result_names=['img_bbox'],
                  show=False, out_dir=None, pipeline=None, results_path="outputs", metric_path="outputs/metrics"):
-        """:83-107: KITTI-layout roots and the raw DAIR-V2X-I root (the one the dair-v2x experiment files configure)."""
+        """:83-107: KITTI-layout roots, the raw DAIR-V2X-I root (the one the dair-v2x experiment files configure) and,
+        for any other root, the raw Rope3D layout (exps/bevheight/rope3d/*.py)."""
         result_files, tmp_dir = self.format_results(results, img_metas, result_names, jsonfile_prefix)
         if 'dair-v2x-i-kitti' in self.data_root or 'rope3d-kitti' in self.data_root:
             convert = result2kitti
         elif 'dair-v2x-i' in self.data_root:
             convert = result2kitti_dair
         else:
-            raise NotImplementedError("result2kitti_rope3d (raw Rope3D root, evaluators/result2kitti.py:330-393) is not "
-                                      "rebuilt; convert the data set to the KITTI layout")
+            convert = result2kitti_rope3d
         pred_label_path = convert(result_files["img_bbox"], results_path, self.data_root, self.gt_label_path, demo=False)
         return kitti_evaluation(pred_label_path, self.gt_label_path, current_classes=self.current_classes,
                                 metric_path=metric_path)

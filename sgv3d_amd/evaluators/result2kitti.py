@@ -9,7 +9,9 @@ file per image under ``results_path/data``: class through ``category_map_dair`` 
 to 4 decimals.  ``kitti_evaluation`` (:62-72): read the two label folders, run the KITTI evaluation (R40), write the
 result text under ``metric_path/R40`` and return the moderate 3-D AP of ``Car``.  Host code (numpy), as in the
 reference.  ``result2kitti_dair`` (:270-328) is the same conversion for the raw DAIR-V2X-I root (JSON calibration files,
-float64); the Rope3D variant (:330-393: denorm files, a token -> id map at a fixed path) is not rebuilt."""
+float64) and ``result2kitti_rope3d`` (:330-393) for the raw Rope3D root: the lidar -> camera transform comes from the
+image's ground-plane ("denorm") file (scripts/gen_info_rope3d.py:50-86), the camera matrix from the ``P2`` row of a calib
+file named by the image token, and the output file name from a token -> sample-id JSON map."""
 import json
 import math
 import os
@@ -19,7 +21,8 @@ import numpy as np
 from .kitti_utils import kitti_common as kitti
 from .kitti_utils.eval import kitti_eval
 
-__all__ = ['kitti_evaluation', 'result2kitti', 'result2kitti_dair', 'load_calib_dair', 'load_calib_dair_json', 'category_map_dair']
+__all__ = ['kitti_evaluation', 'result2kitti', 'result2kitti_dair', 'result2kitti_rope3d', 'load_calib_dair',
+           'load_calib_dair_json', 'load_calib_rope3d', 'category_map_dair', 'category_map_rope3d']
 
 
 def kitti_evaluation(pred_label_path, gt_label_path, current_classes=("Car", "Pedestrian", "Cyclist"), metric_path="metric"):
@@ -37,6 +40,9 @@ def kitti_evaluation(pred_label_path, gt_label_path, current_classes=("Car", "Pe
 
 category_map_dair = {"car": "Car", "van": "Car", "truck": "Car", "bus": "Car", "pedestrian": "Pedestrian",
                      "bicycle": "Cyclist", "trailer": "Cyclist", "motorcycle": "Cyclist"}
+
+
+category_map_rope3d = dict(category_map_dair)          # evaluators/result2kitti.py:17: the same mapping
 
 
 def load_calib_dair(calib_file):
@@ -91,24 +97,75 @@ def load_calib_dair_json(dair_root, sample_id):
     return Tr, K
 
 
+def load_calib_rope3d(rope_root, sample_token):
+    """(Tr_velo_to_cam 4x4 float64, camera matrix 3x3 float32) of one Rope3D image: ``{training,validation}/denorm/
+    <token>.txt`` holds the ground plane (a, b, c, d) in the camera frame, ``.../calib/<token>.txt`` the ``P2`` row
+    (evaluators/result2kitti.py:337-345).  The camera -> lidar rotation turns the plane normal onto the camera's y axis
+    (Rodrigues vector = unit axis in float32 times the angle, matrix rounded to float32 as the reference does), followed
+    by the two axis permutations Rx, Rz; the lidar origin sits on the ground below the camera at distance |d| / |(a,b,c)|
+    (scripts/gen_info_rope3d.py:56-86); Tr_velo_to_cam is its inverse (result2kitti.py:81-86)."""
+    from ..input_contract import rodrigues
+    sub = "training"
+    if not os.path.exists(os.path.join(rope_root, "training/denorm", sample_token + ".txt")):
+        sub = "validation"                                                          # :339-341
+    with open(os.path.join(rope_root, sub, "denorm", sample_token + ".txt")) as f:
+        denorm = np.array([float(v) for v in f.readlines()[0].split(' ')])
+    P2 = None
+    with open(os.path.join(rope_root, sub, "calib", sample_token + ".txt")) as f:
+        for line in f:
+            row = line.rstrip('\n').split(' ')
+            if row[0] == 'P2:':
+                P2 = np.array([float(v) for v in row[1:]], dtype=np.float32).reshape(3, 4)
+    Rx = np.array([[1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [0.0, -1.0, 0.0]])
+    Rz = np.array([[0.0, 1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    origin = np.array([0, 1, 0])
+    target = -1 * denorm[:3]
+    target = target / np.sqrt(target[0] ** 2 + target[1] ** 2 + target[2] ** 2)
+    sita = math.acos(np.inner(target, origin))
+    n = np.cross(target, origin)
+    n = (n / np.sqrt(n[0] ** 2 + n[1] ** 2 + n[2] ** 2)).astype(np.float32)
+    cam2lidar = rodrigues(n * sita).astype(np.float32)
+    cam2lidar = Rz @ (Rx @ cam2lidar)
+    Tr_cam2lidar = np.eye(4)
+    Tr_cam2lidar[:3, :3] = cam2lidar
+    Tr_cam2lidar[:3, 3] = [0, 0, abs(denorm[3]) / np.sqrt(np.sum(np.square(denorm[:3])))]
+    return np.linalg.inv(Tr_cam2lidar), P2[:3, :3]
+
+
+def _numeric_id(sample_token):
+    return int(sample_token.split("/")[-1].split(".")[0])
+
+
 def result2kitti(results_file, results_path, dair_root, gt_label_path, demo=False):
     """KITTI-layout data roots ('dair-v2x-i-kitti', 'rope3d-kitti'), :212-268."""
-    return _convert(results_file, results_path,
-                    lambda sid: load_calib_dair(os.path.join(dair_root, "training/calib", "{:06d}".format(sid) + ".txt")))
+    return _convert(results_file, results_path, _numeric_id,
+                    lambda tok: load_calib_dair(os.path.join(dair_root, "training/calib", "{:06d}".format(_numeric_id(tok)) + ".txt")),
+                    category_map_dair)
 
 
 def result2kitti_dair(results_file, results_path, dair_root, gt_label_path, demo=False):
     """Raw DAIR-V2X-I root (what exps/bevheight/dair-v2x/*.py configure: data_root 'data/dair-v2x-i/'), :270-328."""
-    return _convert(results_file, results_path, lambda sid: load_calib_dair_json(dair_root, sid))
+    return _convert(results_file, results_path, _numeric_id, lambda tok: load_calib_dair_json(dair_root, _numeric_id(tok)),
+                    category_map_dair)
 
 
-def _convert(results_file, results_path, load_calib):
+def result2kitti_rope3d(results_file, results_path, dair_root, gt_label_path, demo=False,
+                        token_map="data/rope3d-kitti/map_token2id.json"):
+    """Raw Rope3D root (exps/bevheight/rope3d/*.py), :330-393.  ``token_map`` is the JSON the reference opens at this
+    fixed relative path (:333-334): image token -> sample id of the KITTI-format copy, which names the label file."""
+    with open(token_map) as fp:
+        token2sample = json.load(fp)
+    return _convert(results_file, results_path, lambda tok: int(token2sample[tok]),
+                    lambda tok: load_calib_rope3d(dair_root, tok), category_map_rope3d)
+
+
+def _convert(results_file, results_path, sample_id_of, load_calib, category_map):
     with open(results_file, 'r', encoding='utf8') as fp:
         results = json.load(fp)["results"]
     os.makedirs(os.path.join(results_path, "data"), exist_ok=True)
     for sample_token, preds in results.items():
-        sample_id = int(sample_token.split("/")[-1].split(".")[0])
-        Tr, K = load_calib(sample_id)
+        sample_id = sample_id_of(sample_token)
+        Tr, K = load_calib(sample_token)
         R, t = Tr[:3, :3].astype(np.float64), Tr[:3, 3].astype(np.float64).reshape(3, 1)
         K34 = np.concatenate([K, np.zeros((3, 1))], axis=1)
         lines = []
@@ -136,9 +193,9 @@ def _convert(results_file, results_path, load_calib):
             uv = K34 @ hom
             uv = uv[:2] / uv[2]
             box2d = np.array([max(uv[0].min(), 0.0), max(uv[1].min(), 0.0), min(uv[0].max(), 1920.0), min(uv[1].max(), 1080.0)])
-            if score > 0.45 and cls in category_map_dair:
+            if score > 0.45 and cls in category_map:
                 r4 = lambda v: str(round(v, 4))
-                lines.append([category_map_dair[cls], "0", "0", r4(alpha)] + [r4(v) for v in box2d] +
+                lines.append([category_map[cls], "0", "0", r4(alpha)] + [r4(v) for v in box2d] +
                              [r4(h), r4(l), r4(w), r4(cam_xyz[0]), r4(cam_xyz[1]), r4(cam_xyz[2]), r4(rot_y), r4(score)])
         with open(os.path.join(results_path, "data", "{:06d}".format(sample_id) + ".txt"), "w") as f:
             for line in lines:

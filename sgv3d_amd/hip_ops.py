@@ -164,9 +164,9 @@ class PackedConv:
                 scale = torch.cat([scale.detach().float().to(device), torch.ones(extra, device=device)])
             if shift is not None:
                 shift = torch.cat([shift.detach().float().to(device), torch.zeros(extra, device=device)])
+        self.cin_real = int(w.shape[0] if transposed else w.shape[1])    # what the algorithmic flop count prices
         if cin_pad is None:
-            cin_real = int(w.shape[0] if transposed else w.shape[1])
-            cin_pad = (cin_real + 3) // 4 * 4
+            cin_pad = (self.cin_real + 3) // 4 * 4
         if transposed:
             cin, cout, kh, kw = (int(s) for s in w.shape)
             assert kh == kw == stride, "only kernel == stride transposed convs (SECONDFPN deblocks)"
@@ -262,7 +262,7 @@ class PackedConv:
         t = int(self.tile if tile is None else tile)
         sk = int(split_k) if split_k else 0
         if t == 0 or sk == 0:
-            key = (B, H, W, t, sk, MFMA_BF16, MFMA_F32X3)
+            key = (B, H, W, t, sk, MFMA_BF16, MFMA_F32X3, d.mode, residual is not None, gate is not None)
             choice = self._tile_cache.get(key)
             if choice is None:
                 sig = (f"{self.cout}x{self.cin}k{self.kh}x{self.kw}s{self.stride}p{self.pad}d{self.dil}"
@@ -279,7 +279,9 @@ class PackedConv:
                     choice = self._rule(t, sk, d, gemm_m, gemm_n)
             t, sk = choice
         d.tile, d.split_k = t, sk
-        flops = 2.0 * gemm_m * gemm_n * (self.cin * self.kh * self.kw)
+        # ALGORITHMIC flops: real channel counts, not the zero-padded ones the kernel multiplies
+        real_n = self.cout_real * (self.ks * self.ks if self.transposed else 1)
+        flops = 2.0 * gemm_m * real_n * (self.cin_real * self.kh * self.kw)
         x3 = t > 10 or (MFMA_F32X3 is True and t < TILE_WINO)
         name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES) else
                 ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_f32x3_" if x3 else "conv_igemm_")) + TILE_NAMES[t]

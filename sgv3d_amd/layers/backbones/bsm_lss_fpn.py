@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from ... import hip_ops
-from ...ops.voxel_pooling import VoxelPlan, voxel_pooling
+from ...calibration import CalibrationCache
 from ..blocks import BasicBlock, HipModule, build_backbone, build_neck, conv_bn
 from .lss_fpn import ASPP, HeightNet, LSSFPN, Mlp, SELayer, _require_hip_inference
 
@@ -227,6 +227,7 @@ class BSMLSSFPN(LSSFPN):
         self.semantic_channels = height_net_conf['semantic_channels']
         self.background_threshold = 0.45                                     # :528
         self.fuse_lift_splat = False
+        self.calib_cache = CalibrationCache()
 
     def _configure_height_net(self, height_net_conf):
         return MSCThead(
@@ -258,25 +259,18 @@ class BSMLSSFPN(LSSFPN):
         hc, semantic1, _semantic0 = self.height_net.hip_forward(img_feats, mats_dict, out_ld=D + Cp)
         hip_ops.bsm_compose(hc, semantic1, D, self.output_channels, self.semantic_channels,
                             self.background_threshold)                        # :521-529
-        geom_xyz = self.get_geometry_voxel_index(
-            mats_dict['sensor2ego_mats'][:, sweep_index, ...],
-            mats_dict['sensor2virtual_mats'][:, sweep_index, ...],
-            mats_dict['intrin_mats'][:, sweep_index, ...],
-            mats_dict['ida_mats'][:, sweep_index, ...],
-            mats_dict['reference_heights'][:, sweep_index, ...],
-            mats_dict.get('bda_mat', None),
-        )
+        geom_xyz, plan = self.calibration(mats_dict, sweep_index)             # :540-553 (cached per calibration)
         fH, fW = int(hc.shape[1]), int(hc.shape[2])
         if self.fuse_lift_splat:
             assert num_cams == 1
             prob, _ = hip_ops.lift(hc, D, Cp, want_prob=True, want_lifted=False)
             ctx = torch.empty(batch_size, fH, fW, Cp, dtype=torch.float32, device=hc.device)
             hip_ops.copy_channels(hc, ctx, coff=D)
-            plan = VoxelPlan(geom_xyz.reshape(batch_size, -1, 3), self._voxel_num_host)
-            feature_map = plan.lift_splat(prob, ctx.view(batch_size, fH * fW, Cp)).permute(0, 3, 1, 2)
+            bev = plan.lift_splat(prob, ctx.view(batch_size, fH * fW, Cp))
         else:
             _, lifted = hip_ops.lift(hc, D, Cp)
-            feature_map = voxel_pooling(geom_xyz, lifted.view(batch_size, num_cams, D, fH, fW, Cp), self._voxel_num_host)
+            bev = plan.pool(lifted.view(batch_size, num_cams * D * fH * fW, Cp))     # voxel_pooling of :554-555
+        feature_map = bev.permute(0, 3, 1, 2)
         nhwc = feature_map.permute(0, 2, 3, 1)                                # [B, Y, X, 88]
         if nhwc_out:
             return nhwc

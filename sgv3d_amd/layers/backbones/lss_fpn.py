@@ -23,7 +23,8 @@ from torch import nn
 
 from ... import _lib, hip_ops
 from ...hip_ops import PackedConv, fold_bn
-from ...ops.voxel_pooling import VoxelPlan, voxel_pooling
+from ...calibration import CalibrationCache
+from ...ops.voxel_pooling import VoxelPlan
 from ..blocks import BasicBlock, HipModule, build_backbone, build_neck, conv_bn
 
 __all__ = ['LSSFPN']
@@ -293,6 +294,9 @@ class LSSFPN(HipModule):
         self._voxel_coord_host = [float(np.float32(row[0] + row[2] / 2.0)) for row in [x_bound, y_bound, z_bound]]
         self._voxel_size_host = [float(np.float32(row[2])) for row in [x_bound, y_bound, z_bound]]
         self.fuse_lift_splat = False    # True: skip the [B,N,C] lifted tensor
+        # voxel indices + voxel-pooling plan of the calibration last seen (sgv3d_amd/calibration.py); a
+        # FramePipeline swaps in one cache per frame slot
+        self.calib_cache = CalibrationCache()
 
     def _configure_height_net(self, height_net_conf):
         return HeightNet(height_net_conf['in_channels'], height_net_conf['mid_channels'], self.output_channels,
@@ -315,10 +319,10 @@ class LSSFPN(HipModule):
 
     # -------------------------------------------------------------------------------- geometry
     def get_geometry_voxel_index(self, sensor2ego_mat, sensor2virtual_mat, intrin_mat, ida_mat,
-                                 reference_heights, bda_mat, want_float=False):
+                                 reference_heights, bda_mat, want_float=False, out=None):
         """get_geometry (lss_fpn.py:372-401) fused with the quantise of :487-488.
         Inputs [B, num_cams, 4, 4] / [B, num_cams] / [B, 4, 4] on the device.
-        Returns int32 [B, num_cams, D, fH, fW, 3] (and the float points when asked)."""
+        Returns int32 [B, num_cams, D, fH, fW, 3] (written into ``out`` when given; and the float points when asked)."""
         lib = _lib.load()
         B, num_cams = int(sensor2ego_mat.shape[0]), int(sensor2ego_mat.shape[1])
         n = B * num_cams
@@ -329,7 +333,8 @@ class LSSFPN(HipModule):
         bda = bda_mat.reshape(B, 4, 4).float().contiguous() if bda_mat is not None else None
         D, fH, fW, _ = (int(v) for v in self.frustum.shape)
         prep = torch.empty(n, 3, 4, 4, dtype=torch.float32, device=dev)
-        geom = torch.empty(B, num_cams, D, fH, fW, 3, dtype=torch.int32, device=dev)
+        geom = out if out is not None else torch.empty(B, num_cams, D, fH, fW, 3, dtype=torch.int32, device=dev)
+        assert tuple(geom.shape) == (B, num_cams, D, fH, fW, 3) and geom.dtype == torch.int32 and geom.is_contiguous()
         geom_f = torch.empty(B, num_cams, D, fH, fW, 3, dtype=torch.float32, device=dev) if want_float else None
         frustum = self.frustum if self.frustum.is_contiguous() else self.frustum.contiguous()
         vc = (ctypes.c_float * 3)(*self._voxel_coord_host)
@@ -342,6 +347,41 @@ class LSSFPN(HipModule):
                                                       refh.data_ptr(), _lib.ptr(bda), vc, vs, geom.data_ptr(),
                                                       _lib.ptr(geom_f), st), "sgv3d_geometry_voxel_index")
         return (geom, geom_f) if want_float else geom
+
+    def calibration(self, mats_dict, sweep_index=0):
+        """(geom_xyz int32 [B, num_cams, D, fH, fW, 3], VoxelPlan) for the calibration in ``mats_dict``, through
+        ``self.calib_cache``: nothing is launched when the calibration tensors are the objects (and versions) the
+        cached pair was computed from; otherwise the geometry kernel rewrites the index tensor in place and the
+        plan is rebuilt only if the indices actually changed (decided on the device, no host sync)."""
+        names = ('sensor2ego_mats', 'sensor2virtual_mats', 'intrin_mats', 'ida_mats', 'reference_heights')
+        srcs = [mats_dict[k] for k in names] + [mats_dict.get('bda_mat', None)]
+        cc = self.calib_cache
+        s2e = mats_dict['sensor2ego_mats']
+        D, fH, fW, _ = (int(v) for v in self.frustum.shape)
+        tag = (int(sweep_index), tuple(s2e.shape), str(s2e.device), self.frustum.data_ptr(), self.frustum._version,
+               self._voxel_num_host)
+        if cc.geom is not None and cc.matches(srcs, tag):
+            cc.hits += 1
+            return cc.geom, cc.plan
+        B, num_cams = int(s2e.shape[0]), int(s2e.shape[2])
+        shape = (B, num_cams, D, fH, fW, 3)
+        reuse = cc.geom is not None and tuple(cc.geom.shape) == shape and cc.geom.device == s2e.device
+        geom = self.get_geometry_voxel_index(
+            mats_dict['sensor2ego_mats'][:, sweep_index, ...],
+            mats_dict['sensor2virtual_mats'][:, sweep_index, ...],
+            mats_dict['intrin_mats'][:, sweep_index, ...],
+            mats_dict['ida_mats'][:, sweep_index, ...],
+            mats_dict['reference_heights'][:, sweep_index, ...],
+            mats_dict.get('bda_mat', None), out=cc.geom if reuse else None)
+        flat = geom.view(B, -1, 3)
+        if reuse and cc.plan is not None:
+            cc.plan.rebuild(flat)
+        else:
+            cc.plan = VoxelPlan(flat, self._voxel_num_host, cached=True)
+        cc.geom = geom
+        cc.remember(srcs, tag)
+        cc.refreshes += 1
+        return geom, cc.plan
 
     # -------------------------------------------------------------------------------- features
     def get_cam_feats_nhwc(self, imgs):
@@ -362,27 +402,19 @@ class LSSFPN(HipModule):
         # discarded by the reference, so it is not computed here.
         height_feature = self.height_net.hip_forward(source_features, mats_dict)   # [B*N,fH,fW,D+C]
         D, C = self.height_channels, self.output_channels
-        geom_xyz = self.get_geometry_voxel_index(
-            mats_dict['sensor2ego_mats'][:, sweep_index, ...],
-            mats_dict['sensor2virtual_mats'][:, sweep_index, ...],
-            mats_dict['intrin_mats'][:, sweep_index, ...],
-            mats_dict['ida_mats'][:, sweep_index, ...],
-            mats_dict['reference_heights'][:, sweep_index, ...],
-            mats_dict.get('bda_mat', None),
-        )                                                                      # int32 [B,N,D,fH,fW,3]
+        geom_xyz, plan = self.calibration(mats_dict, sweep_index)              # :478-488, int32 [B,N,D,fH,fW,3] + CSR plan
         fH, fW = int(height_feature.shape[1]), int(height_feature.shape[2])
         if self.fuse_lift_splat:
             prob, _ = hip_ops.lift(height_feature, D, C, want_prob=True, want_lifted=False)
             assert num_cams == 1, "fused lift-splat is implemented for one camera per sample"
             ctx = torch.empty(batch_size, fH * fW, C, dtype=torch.float32, device=height_feature.device)
             hip_ops.copy_channels(height_feature, ctx.view(batch_size, fH, fW, C), coff=D)
-            plan = VoxelPlan(geom_xyz.reshape(batch_size, -1, 3), self._voxel_num_host)
             bev = plan.lift_splat(prob, ctx)                                   # [B,Y,X,C]
-            feature_map = bev.permute(0, 3, 1, 2)
         else:
-            _, lifted = hip_ops.lift(height_feature, D, C)                     # [B*N, D, fH*fW, C]
-            img_feat_with_height = lifted.view(batch_size, num_cams, D, fH, fW, C)   # == :486 permute + contiguous
-            feature_map = voxel_pooling(geom_xyz, img_feat_with_height, self._voxel_num_host)   # :490-491
+            _, lifted = hip_ops.lift(height_feature, D, C)                     # [B*N, D, fH*fW, C] == :486 permute + contiguous
+            # voxel_pooling(geom_xyz, img_feat_with_height, voxel_num) of :490-491 with the plan of this calibration
+            bev = plan.pool(lifted.view(batch_size, num_cams * D * fH * fW, C))    # [B,Y,X,C]
+        feature_map = bev.permute(0, 3, 1, 2)
         if nhwc_out:
             return feature_map.permute(0, 2, 3, 1)                             # the NHWC buffer itself
         return hip_ops.nhwc_to_nchw(feature_map.permute(0, 2, 3, 1))           # .contiguous() of :495

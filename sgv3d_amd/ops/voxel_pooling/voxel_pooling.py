@@ -20,6 +20,13 @@ from torch.autograd import Function
 from ... import _lib, hip_ops
 
 _MODE = "planned"
+# plans of the operator-level calls without gradient, one per (device, stream, sizes): geom_xyz depends only on the
+# camera calibration, so consecutive frames of a roadside camera hand in the same tensor content and the cached build
+# (VoxelPlan(cached=True)) skips the rebuild on the device.  Keyed by stream as well, so that frames in flight on
+# different streams never share a plan buffer.
+_PLAN_CACHE = {}
+_PLAN_CACHE_MAX = 8
+CACHE_PLANS = True
 
 
 def set_mode(mode):
@@ -65,24 +72,55 @@ def _check_cuda(t, name, dtype):
 
 class VoxelPlan:
     """CSR plan (voxel -> ascending point ids) for one ``geom_xyz``; reusable while the camera
-    calibration (hence ``geom_xyz``) is unchanged."""
+    calibration (hence ``geom_xyz``) is unchanged.
 
-    def __init__(self, geom_xyz, voxel_num, pos_memo=None, sort_segments=True):
+    ``cached=True``: the plan keeps a copy of the ``geom_xyz`` it was built for and ``rebuild(geom_xyz)`` only
+    redoes the work when the new tensor differs -- decided on the device by one compare kernel, so the call never
+    synchronises and can sit inside a captured hipGraph (the build kernels then return at once)."""
+
+    def __init__(self, geom_xyz, voxel_num, pos_memo=None, sort_segments=True, cached=False):
         _check_cuda(geom_xyz, "geom_xyz", torch.int32)
         assert geom_xyz.is_contiguous()
+        assert not (cached and pos_memo is not None), "the cached build writes no pos_memo (training builds a fresh plan)"
         self.X, self.Y, self.Z = _voxel_num_ints(voxel_num)
         self.B = int(geom_xyz.shape[0])
         self.N = int(geom_xyz.numel() // (3 * self.B))
+        self.cached = bool(cached)
+        self.sort_segments = bool(sort_segments)
         lib = _lib.load()
         nbytes = lib.sgv3d_voxel_plan_bytes(self.B, self.N, self.X, self.Y)
         if nbytes == 0:
             raise RuntimeError("voxel plan: bad sizes")
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=geom_xyz.device)
-        with torch.cuda.device(geom_xyz.device), hip_ops.prof("voxel_plan_build"):
-            rc = lib.sgv3d_voxel_plan_build(self.B, self.N, self.X, self.Y, self.Z, geom_xyz.data_ptr(),
-                                            _lib.ptr(pos_memo), self.buf.data_ptr(), nbytes,
-                                            1 if sort_segments else 0, _lib.stream_handle(geom_xyz.device))
+        self.nbytes = nbytes
+        if cached:
+            with torch.cuda.device(geom_xyz.device):
+                _lib.check(lib.sgv3d_voxel_plan_init(self.B, self.N, self.X, self.Y, self.buf.data_ptr(), nbytes,
+                                                     _lib.stream_handle(geom_xyz.device)), "sgv3d_voxel_plan_init")
+        self.rebuild(geom_xyz, pos_memo)
+
+    def rebuild(self, geom_xyz, pos_memo=None):
+        """(Re)build for ``geom_xyz`` [B, N, 3] on the current stream; a cached plan skips the work on the device when
+        the tensor is bytewise the one it holds."""
+        assert geom_xyz.is_contiguous() and geom_xyz.numel() == self.B * self.N * 3 and geom_xyz.dtype == torch.int32
+        lib = _lib.load()
+        with torch.cuda.device(geom_xyz.device), hip_ops.prof("voxel_plan_build_cached" if self.cached else "voxel_plan_build"):
+            st = _lib.stream_handle(geom_xyz.device)
+            if self.cached:
+                rc = lib.sgv3d_voxel_plan_build_cached(self.B, self.N, self.X, self.Y, self.Z, geom_xyz.data_ptr(),
+                                                       self.buf.data_ptr(), self.nbytes, 1 if self.sort_segments else 0, st)
+            else:
+                rc = lib.sgv3d_voxel_plan_build(self.B, self.N, self.X, self.Y, self.Z, geom_xyz.data_ptr(),
+                                                _lib.ptr(pos_memo), self.buf.data_ptr(), self.nbytes,
+                                                1 if self.sort_segments else 0, st)
         _lib.check(rc, "sgv3d_voxel_plan_build")
+        return self
+
+    def builds(self):
+        """Number of real (re)builds of a cached plan so far (reads the plan header: synchronises)."""
+        assert self.cached
+        off = _lib.load().sgv3d_voxel_plan_stats_offset(self.B, self.N, self.X, self.Y)
+        return int(self.buf[off:off + 44].view(torch.int32)[10].item())
 
     def _workspace(self, C):
         nws = _lib.load().sgv3d_voxel_pooling_workspace_bytes(self.B, self.N, int(C))
@@ -162,8 +200,20 @@ class VoxelPooling(Function):
                                                      output_features.data_ptr(), _lib.ptr(pos_memo),
                                                      _lib.stream_handle(input_features.device))
             _lib.check(rc, "sgv3d_voxel_pooling_forward")
-        else:
+        elif needs_grad or not CACHE_PLANS:
             plan = VoxelPlan(geom_xyz, (X, Y, Z), pos_memo=pos_memo)
+            output_features = plan.pool(input_features)
+        else:
+            dev = geom_xyz.device
+            key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, batch_size, num_points, X, Y, Z)
+            plan = _PLAN_CACHE.pop(key, None)
+            if plan is None:
+                while len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+                    _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+                plan = VoxelPlan(geom_xyz, (X, Y, Z), cached=True)
+            else:
+                plan.rebuild(geom_xyz)
+            _PLAN_CACHE[key] = plan                             # most recently used last
             output_features = plan.pool(input_features)
         if needs_grad:
             ctx.save_for_backward(pos_memo)

@@ -5,32 +5,49 @@ A batch-1 forward is a chain of ~130 kernels, many of which cannot fill 256 CUs 
 HeightNet gate kernel).  ``FramePipeline`` captures the whole forward into one hipGraph per slot
 (each slot has its own stream and its own activation pool; weights are shared) and replays
 consecutive frames round-robin over the slots, so the kernels of frame i+1 occupy the CUs that the
-narrow layers of frame i leave idle.  Frames stay independent batch-1 forwards; nothing is batched,
-skipped or cached.  Measured on cfg-2: 1 slot 100 frames/s, 2 slots 112, 3 slots 115.
+narrow layers of frame i leave idle.  Frames stay independent batch-1 forwards; nothing is batched
+or skipped.
+
+Calibration (geometry + voxel-pooling plan) is per slot and lives OUTSIDE the captured graph: the graph
+reads the slot's plan buffer, and ``submit`` refreshes that buffer eagerly on the slot's stream only when it
+is handed calibration tensors other than the ones the slot already holds (sgv3d_amd/calibration.py; the
+refresh itself re-runs the plan build only if the voxel indices really changed, decided on the device).
+A roadside camera's calibration is static, so in steady state a frame costs no geometry or plan kernels.
 
 Usage (static input buffers, as for any graph replay)::
 
-    pipe = FramePipeline(model, imgs, mats, slots=2)
+    pipe = FramePipeline(model, imgs, mats, slots=3)
     for frame in frames:
         slot = pipe.submit(frame_imgs, frame_mats)   # copies into the slot's static inputs, replays its graph
         ...
-        preds = pipe.result(slot)                    # waits for that slot only
+        preds = pipe.result(slot)                    # orders the caller's stream after that slot's frame
+
+Stream contract: ``submit`` orders the slot's stream after everything already enqueued on the caller's current
+stream (producers of ``imgs`` / ``mats``, consumers of the slot's previous outputs); ``result`` makes the caller's
+current stream wait for the frame and returns the slot's static output tensors, valid until that slot is submitted
+again (``slots`` submits later) -- clone what must live longer.
 """
 import torch
+
+from .calibration import CalibrationCache
 
 
 class FramePipeline:
     def __init__(self, model, imgs, mats, slots=2, use_graph=True):
         assert imgs.is_cuda, "FramePipeline runs on the GPU"
         self.model = model
+        self.device = imgs.device
         self.slots = max(1, int(slots))
         self.streams = [torch.cuda.Stream(device=imgs.device) for _ in range(self.slots)]
         self.in_imgs = [imgs.clone() for _ in range(self.slots)]
         self.in_mats = [{k: v.clone() for k, v in mats.items()} for _ in range(self.slots)]
+        self.caches = [CalibrationCache() for _ in range(self.slots)]
+        self._last_mats = [None] * self.slots      # [(tensor, version)] of the mats last copied into the slot
         self.outputs = [None] * self.slots
         self.graphs = []
         self.done = [torch.cuda.Event() for _ in range(self.slots)]
         self._next = 0
+        self._own_cache = model.backbone.calib_cache
         with torch.no_grad():
             model(imgs, mats)                      # packs weights / tunes tiles outside any capture
             torch.cuda.synchronize(imgs.device)
@@ -39,8 +56,8 @@ class FramePipeline:
                     for i, s in enumerate(self.streams):
                         g = torch.cuda.CUDAGraph()
                         s.wait_stream(torch.cuda.current_stream(imgs.device))
-                        with torch.cuda.stream(s):
-                            model(self.in_imgs[i], self.in_mats[i])
+                        with torch.cuda.stream(s), self._slot(i):
+                            model(self.in_imgs[i], self.in_mats[i])      # builds the slot's geometry + plan, eagerly
                             torch.cuda.synchronize(imgs.device)
                             with torch.cuda.graph(g, stream=s):
                                 self.outputs[i] = model(self.in_imgs[i], self.in_mats[i])
@@ -51,6 +68,21 @@ class FramePipeline:
                     torch.cuda.synchronize(imgs.device)
         self.use_graph = bool(self.graphs)
 
+    class _Slot:
+        def __init__(self, pipe, i):
+            self.pipe, self.i = pipe, i
+
+        def __enter__(self):
+            self.pipe.model.backbone.calib_cache = self.pipe.caches[self.i]
+
+        def __exit__(self, *exc):
+            self.pipe.model.backbone.calib_cache = self.pipe._own_cache
+            return False
+
+    def _slot(self, i):
+        """The model's backbone uses slot i's calibration cache inside this context."""
+        return FramePipeline._Slot(self, i)
+
     def replay(self, slot=None):
         """Run one forward on the next (or given) slot with whatever its static inputs hold."""
         i = self._next if slot is None else slot
@@ -59,19 +91,45 @@ class FramePipeline:
             if self.graphs:
                 self.graphs[i].replay()
             else:
-                self.outputs[i] = self.model(self.in_imgs[i], self.in_mats[i])
+                with self._slot(i):
+                    self.outputs[i] = self.model(self.in_imgs[i], self.in_mats[i])
             self.done[i].record()
         return i
+
+    def _same_mats(self, i, mats):
+        last = self._last_mats[i]
+        if last is None or len(last) != len(mats):
+            return False
+        return all(k in last and last[k][0] is v and last[k][1] == v._version for k, v in mats.items())
 
     def submit(self, imgs, mats):
         """Copy a frame into the next slot's static inputs (on that slot's stream) and run it."""
         i = self._next
-        with torch.cuda.stream(self.streams[i]):
+        s = self.streams[i]
+        # the frame may have been produced on the caller's stream (a preprocessing kernel, a non_blocking H2D copy),
+        # and kernels reading this slot's previous outputs may still be queued there
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s), torch.no_grad():
             self.in_imgs[i].copy_(imgs, non_blocking=True)
-            for k, v in mats.items():
-                self.in_mats[i][k].copy_(v, non_blocking=True)
+            if imgs.is_cuda:
+                imgs.record_stream(s)
+            if not self._same_mats(i, mats):
+                for k, v in mats.items():
+                    self.in_mats[i][k].copy_(v, non_blocking=True)
+                    if v.is_cuda:
+                        v.record_stream(s)
+                self._last_mats[i] = {k: (v, v._version) for k, v in mats.items()}
+                if self.graphs:
+                    # the captured graph holds no geometry / plan kernels: bring the slot's plan buffer up to date
+                    # here (a no-op on the device when the new calibration yields the same voxel indices)
+                    with self._slot(i):
+                        self.model.backbone.calibration(self.in_mats[i], 0)
         return self.replay(i)
 
-    def result(self, slot):
-        self.done[slot].synchronize()
+    def result(self, slot, wait_host=False):
+        """Outputs of the frame last submitted to ``slot``.  The caller's current stream is ordered after the frame;
+        ``wait_host=True`` additionally blocks the host until it is done (needed before reading from the CPU)."""
+        torch.cuda.current_stream(self.device).wait_event(self.done[slot])
+        if wait_host:
+            self.done[slot].synchronize()
         return self.outputs[slot]

@@ -57,12 +57,17 @@ class ReplicaGroup:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(self, step, steps):
-        """Exactly ``steps`` calls of ``step`` bracketed by barrier + synchronize; MAX over ranks."""
+    def timed(self, step, steps, local_out=None):
+        """Exactly ``steps`` calls of ``step`` bracketed by barrier + synchronize; MAX over ranks.
+        ``local_out`` (a one-element list) receives this rank's own time: barrier | steps | device synchronise."""
         self.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        if local_out is not None:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            local_out[0] = time.perf_counter() - t0
         self.barrier()
         return self.max_over_ranks(time.perf_counter() - t0)
 

@@ -211,10 +211,24 @@ def make_images(batch, final=final_dim, device='cpu', seed=0):
     return torch.randn(batch, 1, 1, 3, final[0], final[1], generator=g).to(device)
 
 
-def randomize_norm_stats_(model, seed=0, dcn_offsets=True):
+def randomize_norm_stats_(model, seed=0, dcn_offsets=True, residual_gamma=None):
     """Seeded perturbation of every BatchNorm (weight, bias, running stats) and of the DCN offset
-    conv (zero-initialised => plain conv), so folded-BN and deformable sampling are really tested."""
+    conv (zero-initialised => plain conv), so folded-BN and deformable sampling are really tested.
+
+    ``residual_gamma`` (e.g. 0.3): scale of the last BatchNorm of every residual block.  mmdet zero-initialises it
+    (``zero_init_residual``) and training keeps it small; with gamma ~ 1 and untrained running statistics every block
+    doubles the variance of its input (16 bottlenecks: activations ~ 1e2 at the image neck, ~ 2e2 in the BEV map), which
+    turns an absolute 1e-3 parity bar into a 1e-5 relative one -- below the rounding noise of ANY float32 execution
+    (tools/parity_scale_probe.py measures both float32 paths against a float64 evaluation)."""
+    from .layers import blocks as _blocks
     g = torch.Generator().manual_seed(seed)
+    last_bn = set()
+    if residual_gamma is not None:
+        for m in model.modules():
+            if isinstance(m, _blocks.Bottleneck):
+                last_bn.add(m.bn3)
+            elif isinstance(m, _blocks.BasicBlock):
+                last_bn.add(m.bn2)
     with torch.no_grad():
         for name, m in model.named_modules():
             if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
@@ -223,6 +237,8 @@ def randomize_norm_stats_(model, seed=0, dcn_offsets=True):
                 m.bias.copy_(0.1 * torch.randn(n, generator=g))
                 m.running_mean.copy_(0.1 * torch.randn(n, generator=g))
                 m.running_var.copy_(1.0 + 0.1 * torch.rand(n, generator=g))
+                if m in last_bn:
+                    m.weight.mul_(residual_gamma)
             if dcn_offsets and name.endswith('conv_offset'):
                 m.weight.copy_(0.02 * torch.randn(m.weight.shape, generator=g))
                 m.bias.copy_(0.5 * torch.randn(m.bias.shape, generator=g))
@@ -234,6 +250,44 @@ def randomize_norm_stats_(model, seed=0, dcn_offsets=True):
             if name.endswith('semantic_head1.head'):
                 m.weight.mul_(20.0)
                 m.bias[0] += 0.5
+    return model
+
+
+def calibrate_norm_stats_(model, imgs, mats):
+    """Running statistics of the BatchNorm2d layers := the batch statistics of ``imgs`` (one training-mode forward of
+    the HIP path with momentum 1), i.e. what training leaves behind: every normalised activation is O(1), as in a
+    trained network.  Random-initialised weights with running statistics (0, 1) let the activations drift with depth
+    (the BEV map of a near-camera voxel sums ~250 rows, the head trunk adds seven residual stages on top: |outputs| ~
+    1e2), which turns the absolute 1e-3 parity bar into a 1e-5 relative one -- fp32 rounding noise of the reference
+    itself.  Layers whose statistics would come from fewer than 64 values per channel (the 27-feature BatchNorm1d, the
+    ASPP image-pooling branch) keep their statistics.  GPU only (the training forward has no CPU path)."""
+    bns = [(n, m) for n, m in model.named_modules() if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d))]
+    keep = {n: (m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone()) for n, m in bns
+            if isinstance(m, torch.nn.BatchNorm1d) or 'global_avg_pool' in n}
+    mom = {n: m.momentum for n, m in bns}
+    drops = [(m, m.p) for m in model.modules() if isinstance(m, torch.nn.Dropout)]
+    was_training = model.training
+    try:
+        for n, m in bns:
+            m.momentum = 1.0
+        for m, _ in drops:
+            m.p = 0.0
+        model.train()
+        with torch.no_grad():
+            model(imgs, mats)
+        torch.cuda.synchronize()
+    finally:
+        for n, m in bns:
+            m.momentum = mom[n]
+        for m, p in drops:
+            m.p = p
+        model.train(was_training)
+    with torch.no_grad():
+        for n, m in bns:
+            if n in keep:
+                m.running_mean.copy_(keep[n][0]); m.running_var.copy_(keep[n][1]); m.num_batches_tracked.copy_(keep[n][2])
+            else:
+                m.running_var.clamp_(min=1e-3)
     return model
 
 

@@ -355,8 +355,47 @@ def make_result2kitti():
             json.dump({'meta': {}, 'results': results}, f)
         path = r2k.result2kitti_dair(rf, os.path.join(d, 'out'), os.path.join(d, 'root'), os.path.join(d, 'gt'), demo=False)
         out['dair_label_text'] = np.array([open(os.path.join(path, f'{sid:06d}.txt')).read() for sid in sorted(calibs)])
+    # the same detections through result2kitti_rope3d (:330-393): raw Rope3D root -- per-image ground-plane ("denorm")
+    # files, KITTI-style calib files named by token, and a token -> sample-id map read from a path relative to the
+    # working directory.  cv2 is absent: cv2.Rodrigues (scripts/gen_info_rope3d.py:73) is supplied by scipy's
+    # rotation-vector -> matrix conversion (the same Rodrigues formula, float64).
+    from scipy.spatial.transform import Rotation
+    sys.modules['cv2'].Rodrigues = lambda v: (Rotation.from_rotvec(np.asarray(v, np.float64)).as_matrix(), None)
+    r2k.cv2 = sys.modules['cv2']
+    tokens = {3: "1632_fa2sd4a11North151_420_1613710840_1613716786_1_obstacle", 17: "val_cam07_000017", 250: "tok250"}
+    split = {3: "training", 17: "validation", 250: "training"}
+    denorms, rope_calib, rope_results = {}, {}, {}
+    for sid in sorted(calibs):
+        pitch = np.deg2rad(rng.uniform(8, 14))
+        roll = np.deg2rad(rng.uniform(-1.5, 1.5))
+        n = np.array([np.sin(roll), -np.cos(pitch) * np.cos(roll), -np.sin(pitch) * np.cos(roll)])   # ground normal in the camera frame
+        denorms[sid] = " ".join(f"{v:.10f}" for v in list(n) + [float(rng.uniform(5.0, 7.5))]) + "\n"
+        rope_calib[sid] = calibs[sid].splitlines()[0] + "\n"
+        rope_results[tokens[sid]] = results[f"training/image_2/{sid:06d}.jpg"]
+    out['rope_tokens'] = np.array([tokens[k] for k in sorted(calibs)])
+    out['rope_split'] = np.array([split[k] for k in sorted(calibs)])
+    out['rope_denorm_text'] = np.array([denorms[k] for k in sorted(calibs)])
+    out['rope_calib_text'] = np.array([rope_calib[k] for k in sorted(calibs)])
+    out['rope_results_json'] = np.array(json.dumps({'meta': {}, 'results': rope_results}))
+    with tempfile.TemporaryDirectory() as d:
+        for sid in calibs:
+            for sub_, text in (('denorm', denorms[sid]), ('calib', rope_calib[sid])):
+                os.makedirs(os.path.join(d, 'root', split[sid], sub_), exist_ok=True)
+                open(os.path.join(d, 'root', split[sid], sub_, tokens[sid] + '.txt'), 'w').write(text)
+        os.makedirs(os.path.join(d, 'data', 'rope3d-kitti'))
+        json.dump({tokens[k]: f"{k:06d}" for k in calibs}, open(os.path.join(d, 'data', 'rope3d-kitti', 'map_token2id.json'), 'w'))
+        rf = os.path.join(d, 'results_nusc.json')
+        json.dump({'meta': {}, 'results': rope_results}, open(rf, 'w'))
+        cwd = os.getcwd()
+        os.chdir(d)
+        try:
+            path = r2k.result2kitti_rope3d(rf, os.path.join(d, 'out'), os.path.join(d, 'root'), os.path.join(d, 'gt'), demo=False)
+        finally:
+            os.chdir(cwd)
+        out['rope_label_text'] = np.array([open(os.path.join(path, f'{sid:06d}.txt')).read() for sid in sorted(calibs)])
     np.savez_compressed(os.path.join(HERE, "result2kitti.npz"), **out)
     print("result2kitti.npz:", out['label_text'][0][:300])
+    print("rope3d:", out['rope_label_text'][0][:300])
 
 
 if __name__ == "__main__":

@@ -220,6 +220,54 @@ def test_frame_pipeline_matches_direct_forward(small):
     assert s0 != s1
 
 
+def test_calibration_cache_and_pipeline_recalibration(small):
+    """Geometry + voxel plan are computed once per calibration (sgv3d_amd/calibration.py): the same ``mats`` tensors
+    launch nothing, fresh tensors with the same content re-run the geometry kernel but not the plan build (decided on
+    the device), a different calibration rebuilds -- and results always equal a cold model's.  The graph-replay
+    pipeline refreshes a slot's plan when it is handed another calibration."""
+    from sgv3d_amd.calibration import CalibrationCache
+    from sgv3d_amd.pipeline import FramePipeline
+    m = small['m']
+    imgs, mats = small['imgs'].to(DEV), _to_dev(small['mats'])
+    old = m.backbone.calib_cache
+    m.backbone.calib_cache = cc = CalibrationCache()
+    try:
+        with torch.no_grad():
+            a = m(imgs, mats)[0][0]['heatmap'].clone()
+            assert (cc.hits, cc.refreshes, cc.plan.builds()) == (0, 1, 1)
+            b = m(imgs, mats)[0][0]['heatmap'].clone()
+            assert (cc.hits, cc.refreshes, cc.plan.builds()) == (1, 1, 1)
+            mats_copy = {k: v.clone() for k, v in mats.items()}                 # new tensor objects, same calibration
+            c = m(imgs, mats_copy)[0][0]['heatmap'].clone()
+            assert (cc.refreshes, cc.plan.builds()) == (2, 1)
+            mats_copy['reference_heights'] += 0.5                              # in-place edit: version bump, new geometry
+            mats_copy['sensor2ego_mats'][:, :, :, 2, 3] += 0.5
+            d = m(imgs, mats_copy)[0][0]['heatmap'].clone()
+            assert (cc.refreshes, cc.plan.builds()) == (3, 2)
+            m.backbone.calib_cache = CalibrationCache()                         # cold reference for the moved camera
+            d_cold = m(imgs, mats_copy)[0][0]['heatmap'].clone()
+            m.backbone.calib_cache = cc
+            e = m(imgs, mats)[0][0]['heatmap'].clone()                          # and back
+            assert cc.plan.builds() == 3
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, e)
+        assert torch.equal(d, d_cold) and not torch.equal(a, d)
+        # pipeline: slot plans live outside the captured graphs and follow the calibration handed to submit()
+        with torch.no_grad():
+            pipe = FramePipeline(m, imgs, mats, slots=2)
+            assert pipe.use_graph
+            r = []
+            for frame_mats in (mats, mats_copy, mats, mats_copy, mats_copy):
+                slot = pipe.submit(imgs, frame_mats)
+                r.append(pipe.result(slot)[0][0]['heatmap'].clone())
+        for got, want in zip(r, (a, d, a, d, d)):
+            torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+        # slot 0 saw mats, (mats again: skipped on the host), mats_copy; slot 1 saw mats_copy twice: one rebuild each
+        # on top of the build at construction
+        assert [c.plan.builds() for c in pipe.caches] == [2, 2]
+    finally:
+        m.backbone.calib_cache = old
+
+
 # SURVEY Appendix A: the harness passes other geometries than cfg-2 -- rope3d's 180 height bins over
 # [-2, 3.5], the 140.8 m range (352 cells), the 128-cell grids with 0.8 m voxels, a wider d_bound.
 # Reduced image / grid sizes, same code paths; voxel indices must stay bit-exact, maps within 1e-3.

@@ -75,3 +75,27 @@ def test_result2kitti_dair_writes_the_reference_label_files(tmp_path):
     for sid, want in zip(GOLD['calib_ids'], GOLD['dair_label_text']):
         assert open(os.path.join(out, f'{int(sid):06d}.txt')).read() == str(want), int(sid)
     assert any(str(a) != str(b) for a, b in zip(GOLD['dair_label_text'], GOLD['label_text']))     # float64 vs float32 calibration
+
+
+def test_result2kitti_rope3d_writes_the_reference_label_files(tmp_path):
+    """Raw Rope3D root (denorm + calib files named by token, token -> id map): the label files are character-identical
+    to the ones the reference's ``result2kitti_rope3d`` (evaluators/result2kitti.py:330-393) wrote."""
+    from sgv3d_amd.evaluators.result2kitti import load_calib_rope3d, result2kitti_rope3d
+    root = tmp_path / 'rope3d'
+    token_map = {}
+    for sid, tok, split, den, cal in zip(GOLD['calib_ids'], GOLD['rope_tokens'], GOLD['rope_split'],
+                                         GOLD['rope_denorm_text'], GOLD['rope_calib_text']):
+        for sub, text in (('denorm', den), ('calib', cal)):
+            os.makedirs(root / str(split) / sub, exist_ok=True)
+            (root / str(split) / sub / f'{tok}.txt').write_text(str(text))
+        token_map[str(tok)] = f'{int(sid):06d}'
+    assert set(str(s) for s in GOLD['rope_split']) == {'training', 'validation'}          # both lookup branches
+    (tmp_path / 'map_token2id.json').write_text(json.dumps(token_map))
+    rf = tmp_path / 'results_nusc.json'
+    rf.write_text(str(GOLD['rope_results_json']))
+    out = result2kitti_rope3d(str(rf), str(tmp_path / 'out'), str(root), str(tmp_path / 'gt'),
+                              token_map=str(tmp_path / 'map_token2id.json'))
+    for sid, want in zip(GOLD['calib_ids'], GOLD['rope_label_text']):
+        assert open(os.path.join(out, f'{int(sid):06d}.txt')).read() == str(want), int(sid)
+    Tr, K = load_calib_rope3d(str(root), str(GOLD['rope_tokens'][0]))
+    assert abs(np.linalg.det(Tr[:3, :3]) - 1) < 1e-5 and K.dtype == np.float32

@@ -209,6 +209,44 @@ def test_fused_lift_splat_matches_materialised(hip, golden):
     assert torch.equal(plan.lift_splat(prob, ctx), plan.pool(lifted))
 
 
+def test_cached_plan_rebuilds_only_on_change(hip):
+    """VoxelPlan(cached=True): the device-side compare skips the build while geom_xyz is bytewise unchanged (also for a
+    fresh tensor object with the same content), rebuilds after a single changed index, and every result equals the
+    uncached plan's bit for bit.  The operator-level call keeps one such plan per (stream, sizes)."""
+    from sgv3d_amd.ops.voxel_pooling import VoxelPlan, voxel_pooling
+    from sgv3d_amd.ops.voxel_pooling import voxel_pooling as vp_mod
+    import sgv3d_amd.ops.voxel_pooling.voxel_pooling as VPM
+    rng = np.random.default_rng(77)
+    B, N, C, X, Y = 2, 30001, 80, 40, 33           # N*3 not a multiple of 4: exercises the compare tail
+    geom = torch.from_numpy(rng.integers(-2, 42, size=(B, N, 3)).astype(np.int32)).to(DEV)
+    geom[..., 2] = 0
+    feats = torch.from_numpy(rng.integers(-4, 5, size=(B, N, C)).astype(np.float32)).to(DEV)
+    plan = VoxelPlan(geom, (X, Y, 1), cached=True)
+    want = VoxelPlan(geom, (X, Y, 1)).pool(feats)
+    assert plan.builds() == 1 and torch.equal(plan.pool(feats), want)
+    plan.rebuild(geom)
+    plan.rebuild(geom.clone())
+    assert plan.builds() == 1 and torch.equal(plan.pool(feats), want)
+    g2 = geom.clone()
+    g2[1, N - 1, 0] = (g2[1, N - 1, 0] + 1) % X                                   # the very last point moves one cell
+    plan.rebuild(g2)
+    assert plan.builds() == 2
+    assert torch.equal(plan.pool(feats), VoxelPlan(g2, (X, Y, 1)).pool(feats))
+    plan.rebuild(geom)
+    assert plan.builds() == 3 and torch.equal(plan.pool(feats), want)
+    with pytest.raises(AssertionError):
+        VoxelPlan(geom, (X, Y, 1), cached=True, pos_memo=torch.empty(B, N, 3, dtype=torch.int32, device=DEV))
+    # operator level: consecutive frames of one camera
+    VPM._PLAN_CACHE.clear()
+    o1 = voxel_pooling(geom, feats, (X, Y, 1))
+    o2 = voxel_pooling(geom.clone(), feats, (X, Y, 1))
+    o3 = voxel_pooling(g2, feats, (X, Y, 1))
+    (cached_plan,) = VPM._PLAN_CACHE.values()
+    assert cached_plan.builds() == 2
+    assert torch.equal(o1, want.permute(0, 3, 1, 2)) and torch.equal(o2, o1) and not torch.equal(o3, o1)
+    VPM._PLAN_CACHE.clear()
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_geometry_fuzz_vs_oracle(hip, seed):
     """Random sizes / channel counts / grids and point clouds from benign to pathological (everything in one
