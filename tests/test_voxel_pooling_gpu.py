@@ -214,8 +214,8 @@ def test_cached_plan_rebuilds_only_on_change(hip):
     fresh tensor object with the same content), rebuilds after a single changed index, and every result equals the
     uncached plan's bit for bit.  The operator-level call keeps one such plan per (stream, sizes)."""
     from sgv3d_amd.ops.voxel_pooling import VoxelPlan, voxel_pooling
-    from sgv3d_amd.ops.voxel_pooling import voxel_pooling as vp_mod
-    import sgv3d_amd.ops.voxel_pooling.voxel_pooling as VPM
+    import sys
+    VPM = sys.modules['sgv3d_amd.ops.voxel_pooling.voxel_pooling']     # (the package rebinds the name to the function)
     rng = np.random.default_rng(77)
     B, N, C, X, Y = 2, 30001, 80, 40, 33           # N*3 not a multiple of 4: exercises the compare tail
     geom = torch.from_numpy(rng.integers(-2, 42, size=(B, N, 3)).astype(np.int32)).to(DEV)
