@@ -61,7 +61,18 @@ class _BatchNormAct(torch.autograd.Function):
 def batch_norm_act(bn, x, residual=None, relu=False):
     """``relu(bn(x) + residual)`` for an ``nn.BatchNorm2d`` in training mode; ``x`` / ``residual`` NHWC float32."""
     assert bn.training and bn.track_running_stats, "training-mode BatchNorm with running statistics"
-    momentum = 0.1 if bn.momentum is None else bn.momentum
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return _BatchNormAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu)
+    if bn.momentum is None:
+        # torch: cumulative moving average, factor 1 / num_batches_tracked (after the increment)
+        if bn.num_batches_tracked is None:
+            raise NotImplementedError("BatchNorm with momentum=None needs num_batches_tracked")
+        momentum = 1.0 / float(bn.num_batches_tracked)          # one device->host read; momentum=None is not a configuration the reference uses
+    else:
+        momentum = bn.momentum
+    out = _BatchNormAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu)
+    # the kernel wrote the running statistics through raw pointers: bump their version counters so that anything keyed
+    # on tensor versions (BEVHeight._stamp -> repacked inference weights) sees the change
+    bn.running_mean.add_(0)
+    bn.running_var.add_(0)
+    return out

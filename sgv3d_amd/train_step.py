@@ -13,6 +13,15 @@ The reference wraps the model in Lightning's DDP (exps/base_cli.py:57-58 ``accel
   as it is called per bucket; the 1 / world factor is folded into the AdamW kernel (no averaging pass over HBM).
 * ``step`` waits for each bucket's collective and runs ``sgv3d_adamw_step`` on it.
 
+* at construction with more than one rank the flat parameter buckets are broadcast from rank 0 (what Lightning's DDP
+  does when it wraps the model), so replicas start identical whatever each rank's seed was; ``check_replicas`` compares
+  a checksum of the parameters over the ranks and raises on drift.
+
+Deviation from ``torch.optim.AdamW``: gradients live as always-defined, zero-filled views of the buckets, so a parameter
+that received no gradient in a step (``assist_layer`` without ``is_train_height``, lss_fpn.py:459,493-495) still gets
+its moments decayed and its weight decay applied, where torch skips parameters whose ``.grad`` is None.  With the
+reference's weight_decay of 1e-7 the difference is below fp32 resolution per step.
+
 With the "gloo" backend and CPU tensors (the world-size-2 tests) the collectives run through gloo; the fused update
 itself needs the GPU library and raises without it.
 """
@@ -87,6 +96,27 @@ class DataParallelAdamW:
         self.state = [(torch.zeros_like(p), torch.zeros_like(p)) for p, _, _ in self.flat.buckets]
         self.steps = 0
         self._pending = []
+        if self._world() > 1:
+            self.broadcast_parameters()
+
+    def broadcast_parameters(self, src=0):
+        """Every rank takes rank ``src``'s parameters (one broadcast per flat bucket)."""
+        import torch.distributed as dist
+        for p, _, _ in self.flat.buckets:
+            dist.broadcast(p, src=src, group=self.group)
+
+    def check_replicas(self):
+        """Raise if the parameters differ between ranks (sum and sum of squares of every bucket, compared through one
+        MIN and one MAX all-reduce).  Cheap enough to call every few hundred steps."""
+        import torch.distributed as dist
+        if self._world() == 1:
+            return
+        sums = torch.stack([torch.stack([p.double().sum(), (p.double() ** 2).sum()]) for p, _, _ in self.flat.buckets])
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not torch.equal(lo, hi):
+            raise _lib.SGV3DError("data-parallel replicas have drifted apart: parameter checksums differ between ranks")
 
     def _world(self):
         import torch.distributed as dist
@@ -97,14 +127,38 @@ class DataParallelAdamW:
     def zero_grad(self):
         self.flat.zero_grad()
 
+    def overlap_with_backward(self):
+        """Launch a bucket's all-reduce from inside backward, as soon as the last of its parameters has accumulated its
+        gradient (post-accumulate-grad hooks; buckets are filled in backward order, so the first collectives run under
+        the rest of the backward pass like DDP's).  A bucket holding a parameter that receives no gradient in a step
+        never completes; ``all_reduce_grads`` / ``step`` launch whatever is still missing."""
+        self._early = {}
+        self._left = [len(entries) for _, _, entries in self.flat.buckets]
+        self._hooks = []
+        for bi, (_, _, entries) in enumerate(self.flat.buckets):
+            for p, _, _ in entries:
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, bi=bi: self._on_grad(bi)))
+        return self
+
+    def _on_grad(self, bi):
+        import torch.distributed as dist
+        self._left[bi] -= 1
+        if self._left[bi] == 0 and self._world() > 1 and bi not in self._early:
+            self._early[bi] = dist.all_reduce(self.flat.buckets[bi][1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def all_reduce_grads(self):
-        """Start the sum all-reduce of every bucket (asynchronous; ``step`` waits per bucket)."""
+        """Start the sum all-reduce of every bucket that is not already in flight (asynchronous; ``step`` waits per
+        bucket)."""
         import torch.distributed as dist
         self._pending = []
-        if self._world() == 1:
-            return
-        for _, g, _ in self.flat.buckets:
-            self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        early = getattr(self, '_early', {})
+        if self._world() > 1:
+            for bi, (_, g, _) in enumerate(self.flat.buckets):
+                self._pending.append(early[bi] if bi in early else
+                                     dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if hasattr(self, '_left'):
+            self._early = {}
+            self._left = [len(entries) for _, _, entries in self.flat.buckets]
 
     def step(self, lr=None):
         """One AdamW update of every bucket with the averaged gradients (call ``all_reduce_grads`` first when the

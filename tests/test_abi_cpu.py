@@ -54,3 +54,18 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"non-positive" in lib.sgv3d_last_error()
     assert lib.sgv3d_voxel_plan_bytes(1, 466560, 256, 256) > 4 * (466560 + 2 * 65536)
     assert lib.sgv3d_voxel_plan_bytes(0, 1, 1, 1) == 0
+
+
+def test_compiled_pybind_extension_loads_and_checks_inputs():
+    """The compiled drop-in for the reference's pybind11 module (ops/voxel_pooling/src/voxel_pooling_forward.cpp:41-43):
+    loads without a GPU, exports voxel_pooling_forward_wrapper with the reference's ten arguments, and refuses CPU
+    tensors with the reference's message (:12-13) -- no compute call here."""
+    import torch
+    from sgv3d_amd.ops.voxel_pooling import compiled_ext
+    ext = compiled_ext.load()
+    doc = ext.voxel_pooling_forward_wrapper.__doc__
+    assert doc.count("SupportsInt") == 6 and doc.count("torch.Tensor") == 4 and "-> int" in doc
+    import pytest
+    with pytest.raises(RuntimeError, match="must be a CUDAtensor"):
+        ext.voxel_pooling_forward_wrapper(1, 2, 3, 4, 5, 1, torch.zeros(1, 2, 3, dtype=torch.int32), torch.zeros(1, 2, 3),
+                                          torch.zeros(1, 5, 4, 3), torch.zeros(1, 2, 3, dtype=torch.int32))

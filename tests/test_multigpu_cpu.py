@@ -68,12 +68,26 @@ TRAIN_WORKER = textwrap.dedent("""
 
     rank = int(os.environ["RANK"])
     dist.init_process_group("gloo", rank=rank, world_size=2)
-    torch.manual_seed(0)                                     # same initial weights on both ranks
+    torch.manual_seed(7 * rank)                              # DIFFERENT initial weights per rank ...
     net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 5, 1))
-    before = [p.detach().clone() for p in net.parameters()]
+    mine = [p.detach().clone() for p in net.parameters()]
     opt = DataParallelAdamW(net.parameters(), lr=1e-3, bucket_bytes=1024)     # tiny buckets: several collectives
     assert len(opt.flat.buckets) >= 2
-    assert all(torch.equal(a, b) for a, b in zip(before, net.parameters()))   # re-homing keeps the values
+    both = [None, None]
+    dist.all_gather_object(both, [p.tolist() for p in mine])
+    for i, p in enumerate(net.parameters()):                  # ... and the constructor broadcast rank 0's (what DDP does)
+        assert torch.equal(p.detach(), torch.tensor(both[0][i])), i
+    opt.check_replicas()
+    if rank == 1:
+        with torch.no_grad():
+            next(net.parameters()).add_(1e-3)                 # drift on one rank
+    try:
+        opt.check_replicas()
+        raise AssertionError("drift not detected")
+    except SGV3DError as e:
+        assert "drifted" in str(e)
+    opt.broadcast_parameters()
+    opt.check_replicas()
     torch.manual_seed(100 + rank)                            # different data per rank
     x = torch.randn(4, 3, 10, 10)
     opt.zero_grad()
@@ -88,6 +102,18 @@ TRAIN_WORKER = textwrap.dedent("""
     for i, p in enumerate(net.parameters()):
         want = torch.tensor(gathered[0][i]) + torch.tensor(gathered[1][i])
         assert torch.allclose(p.grad, want, rtol=1e-6, atol=1e-7), i
+    # overlap mode: the collectives are launched from inside backward, bucket by bucket
+    opt.overlap_with_backward()
+    opt.zero_grad()
+    net(x).square().mean().backward()
+    assert len(opt._early) == len(opt.flat.buckets)           # every bucket went out during backward
+    opt.all_reduce_grads()
+    for w in opt._pending:
+        w.wait()
+    for i, p in enumerate(net.parameters()):
+        want = torch.tensor(gathered[0][i]) + torch.tensor(gathered[1][i])
+        assert torch.allclose(p.grad, want, rtol=1e-6, atol=1e-7), ("overlap", i)
+    assert opt._early == {} and opt._left == [len(e) for _, _, e in opt.flat.buckets]
     try:
         opt.step()
         raise AssertionError("the CPU must not have an optimiser path")

@@ -196,6 +196,35 @@ def test_ext_shim_runs_reference_wrapper_protocol(hip, golden):
         ext.voxel_pooling_forward_wrapper(2, geom.shape[1], 80, X, Y, Z, geom.cpu(), feats, out, pm)
 
 
+def test_compiled_pybind_ext_runs_reference_wrapper_protocol(hip, golden):
+    """The COMPILED pybind11 module (src/voxel_pooling_ext.cpp): the 10-argument call of the reference's
+    voxel_pooling.py:41-52 on the reference-generated goldens, on the current (non-default) stream; error behaviour of
+    its CHECK_INPUT macros."""
+    from sgv3d_amd.ops.voxel_pooling import compiled_ext
+    ext = compiled_ext.load()
+    vp = golden["voxel_pooling"]
+    for name in ("tiny", "b2_c80", "z2", "dups", "all_out"):
+        geom = torch.from_numpy(vp[f"{name}/geom_xyz"]).to(DEV)
+        B, C = geom.shape[0], vp[f"{name}/feats"].shape[-1]
+        geom = geom.reshape(B, -1, 3)
+        feats = torch.from_numpy(vp[f"{name}/feats"]).to(DEV).reshape(B, -1, C)
+        X, Y, Z = (int(v) for v in vp[f"{name}/voxel_num"])
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            out = feats.new_zeros(B, Y, X, C)
+            pm = geom.new_full((B, geom.shape[1], 3), -1)
+            assert ext.voxel_pooling_forward_wrapper(B, geom.shape[1], C, X, Y, Z, geom, feats, out, pm) == 1
+        s.synchronize()
+        assert np.array_equal(out.permute(0, 3, 1, 2).cpu().numpy(), vp[f"{name}/out"]), name
+    with pytest.raises(RuntimeError, match="CUDAtensor"):
+        ext.voxel_pooling_forward_wrapper(B, geom.shape[1], C, X, Y, Z, geom.cpu(), feats, out, pm)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ext.voxel_pooling_forward_wrapper(B, geom.shape[1], C, X, Y, Z, geom, feats.transpose(1, 2), out, pm)
+    with pytest.raises(RuntimeError):                                   # dtype mismatch: data_ptr<float>() on an int tensor
+        ext.voxel_pooling_forward_wrapper(B, geom.shape[1], C, X, Y, Z, geom, feats.int(), out, pm)
+
+
 def test_fused_lift_splat_matches_materialised(hip, golden):
     from sgv3d_amd.ops.voxel_pooling import VoxelPlan
     rng = np.random.default_rng(3)

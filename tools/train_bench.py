@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Training step of BASELINE config 4's per-GPU share on synthetic data: forward (train mode) + targets + loss +
 backward + gradient all-reduce + fused AdamW.  `python tools/train_bench.py [--batch 4] [--steps 5] [--config cfg2|cfg5]`
-or under torch.distributed.run for several ranks (RCCL).  Prints one JSON line (samples/s over all ranks); this is
+or, BASELINE config 4 (global batch 32 = 4 per GPU over 8 MI355X, 304 MB of fp32 gradients all-reduced over RCCL/xGMI in
+two flat buckets launched from inside backward):
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+        tools/train_bench.py --config cfg4 --steps 10  Prints one JSON line (samples/s over all ranks); this is
 NOT the headline metric of bench.py (inference frames/s), it tracks SURVEY §8(f) rank 2."""
 import argparse, json, os, sys, time
 import torch
@@ -15,7 +18,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
-ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg5", "small"])
+ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg4", "cfg5", "small"],
+                help="cfg4 = the cfg-2 model at BASELINE configs[3]'s per-GPU share (batch 4 per rank, global batch 4 x ranks)")
+ap.add_argument("--no-overlap", action="store_true", help="all-reduce after backward instead of from grad hooks")
 ap.add_argument("--profile", action="store_true", help="per-kernel-family times of one step (HIP events, eager)")
 args = ap.parse_args()
 
@@ -23,7 +28,9 @@ local = int(os.environ.get("LOCAL_RANK", "0"))
 dev = torch.device("cuda", local)
 torch.cuda.set_device(dev)
 group = ReplicaGroup(device=dev)
-bconf, hconf = {"cfg2": synthetic.r50_256_conf, "cfg5": synthetic.bsm_r101_256_conf, "small": synthetic.small_conf}[args.config]()
+if args.config == "cfg4":
+    args.batch = 4
+bconf, hconf = {"cfg2": synthetic.r50_256_conf, "cfg4": synthetic.r50_256_conf, "cfg5": synthetic.bsm_r101_256_conf, "small": synthetic.small_conf}[args.config]()
 BSM = bool(bconf.get('is_bsm'))                 # cfg5: SGV3D BSM R101 with the semantic (SAM-mask) supervision
 if BSM:
     bconf = dict(bconf, is_train_height=True)
@@ -43,7 +50,9 @@ if BSM:
     semantic = SemanticSupervision(8)
     gt_semantic = torch.randint(0, 7, (args.batch, 1) + tuple(bconf['final_dim']), dtype=torch.uint8,
                                 generator=torch.Generator().manual_seed(group.rank)).to(dev)
-opt = DataParallelAdamW(model.parameters(), lr=reference_lr(args.batch, group.world))
+opt = DataParallelAdamW(model.parameters(), lr=reference_lr(args.batch, group.world))   # broadcasts rank 0's parameters
+if not args.no_overlap:
+    opt.overlap_with_backward()
 nparam = sum(p.numel() for p in model.parameters())
 
 
@@ -68,9 +77,13 @@ torch.cuda.synchronize()
 elapsed = group.timed(step, args.steps)
 out = {"metric": "training samples/s (forward + loss + backward + all-reduce + AdamW)", "value": group.world * args.batch * args.steps / elapsed,
        "unit": "samples/s", "n_gpus": group.world, "steps": args.steps, "ms_per_step": 1e3 * elapsed / args.steps,
-       "batch_per_gpu": args.batch, "parameters": nparam, "loss": float(loss.detach()), "config": args.config,
+       "batch_per_gpu": args.batch, "global_batch": args.batch * group.world,
+       "world_size": group.dist.get_world_size() if group.dist is not None else 1, "backend": group.backend,
+       "allreduce_bytes_per_step": 4 * sum(g.numel() for _, g, _ in opt.flat.buckets), "allreduce_buckets": len(opt.flat.buckets),
+       "allreduce_overlapped_with_backward": not args.no_overlap, "parameters": nparam, "loss": float(loss.detach()), "config": args.config,
        "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2**30, "data": "synthetic"}
-if args.profile and group.rank == 0:
+if args.profile:
+    # the profiled step holds collectives (loss-factor and gradient all-reduces): every rank runs it, rank 0 reports
     hip_ops.PROFILE = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
