@@ -351,6 +351,25 @@ int sgv3d_centerhead_branches_forward(int batch, int h, int w, int cin, int x_ld
                                       const int32_t *out_begin, float *out, void *workspace,
                                       size_t workspace_bytes, void *stream);
 
+/* bf16-mode counterpart (BASELINE configs[2] / [4] compute dtype): the same two layers of all branches in one kernel on
+ * the bf16 matrix cores, fp32 accumulation, hidden maps kept in LDS as bf16 (csrc/head_bf16.hip).  cin must be 64.
+ *   w1_packed  sgv3d_centerhead_bf16_weight_bytes(num_branches) bytes, filled by sgv3d_centerhead_bf16_pack_weight from
+ *              the concatenated first-layer weights f32 [num_branches*64, 64, 3, 3] (OIHW)
+ *   w2_packed  sgv3d_centerhead_bf16_weight2_bytes(num_branches) bytes, filled by sgv3d_centerhead_bf16_pack_weight2 from
+ *              the final-layer weights f32 [total_out, 3, 3, 64] and out_begin
+ *   x, scale1, shift1 (folded BN of the first layers; 16-B aligned), bias2, out_begin, out: as for
+ *              sgv3d_centerhead_branches_forward
+ * No workspace: the one-pixel ring of hidden values a tile needs from its neighbours is recomputed, not exchanged. */
+size_t sgv3d_centerhead_bf16_weight_bytes(int num_branches);
+int sgv3d_centerhead_bf16_pack_weight(const float *w1, int num_branches, int cin, void *w1_packed, void *stream);
+size_t sgv3d_centerhead_bf16_weight2_bytes(int num_branches);
+int sgv3d_centerhead_bf16_pack_weight2(const float *w2, const int32_t *out_begin, int num_branches, void *w2_packed,
+                                       void *stream);
+int sgv3d_centerhead_branches_forward_bf16(int batch, int h, int w, int cin, int x_ld, int x_coff, const float *x,
+                                           int num_branches, const void *w1_packed, const float *scale1,
+                                           const float *shift1, int total_out, const void *w2_packed, const float *bias2,
+                                           const int32_t *out_begin, float *out, void *stream);
+
 /* ================================================================================================
  * Box decode + circle NMS  
  * ================================================================================================ */

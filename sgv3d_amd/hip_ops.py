@@ -586,6 +586,44 @@ def centerhead_branches(x, first, w2, b2, out_begin, num_branches, out=None):
     return out
 
 
+def pack_centerhead_bf16(w1, w2, out_begin):
+    """First layers of the CenterHead branches concatenated, f32 [nb*64, 64, 3, 3], and final layers f32 [sum_c, 3, 3, 64]
+    with ``out_begin`` int32 [nb+1] -> the two bf16 buffers sgv3d_centerhead_branches_forward_bf16 streams
+    (fragment-ordered first layers; [branch][tap][4][64] final layers)."""
+    w1 = w1.detach().float().contiguous()
+    w2 = w2.detach().float().contiguous()
+    nb = int(w1.shape[0]) // 64
+    assert int(w1.shape[0]) == nb * 64 and tuple(w1.shape[1:]) == (64, 3, 3), "bf16 fused head: 64 -> 64 3x3 first layers"
+    assert tuple(w2.shape[1:]) == (3, 3, 64) and int(out_begin.numel()) == nb + 1 and out_begin.dtype == torch.int32
+    lib = _lib.load()
+    p1 = torch.empty(lib.sgv3d_centerhead_bf16_weight_bytes(nb), dtype=torch.uint8, device=w1.device)
+    p2 = torch.empty(lib.sgv3d_centerhead_bf16_weight2_bytes(nb), dtype=torch.uint8, device=w1.device)
+    with torch.cuda.device(w1.device):
+        _lib.check(lib.sgv3d_centerhead_bf16_pack_weight(w1.data_ptr(), nb, 64, p1.data_ptr(), _st(w1)),
+                   "sgv3d_centerhead_bf16_pack_weight")
+        _lib.check(lib.sgv3d_centerhead_bf16_pack_weight2(w2.data_ptr(), out_begin.data_ptr(), nb, p2.data_ptr(), _st(w1)),
+                   "sgv3d_centerhead_bf16_pack_weight2")
+    p1._keep = (w1, w2)             # the pack kernels read them asynchronously
+    return p1, p2
+
+
+def centerhead_branches_bf16(x, packed, scale1, shift1, b2, out_begin, num_branches, out=None, x_coff=0):
+    """bf16-MFMA version of ``centerhead_branches``: x NHWC f32 [B,H,W,ld] (channels [x_coff, x_coff+64)), ``packed`` from
+    ``pack_centerhead_bf16``, scale1 / shift1 [nb*64] folded BN, b2 [sum_c] -> NCHW f32 [B,sum_c,H,W]."""
+    B, H, W, ld = (int(s) for s in x.shape)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    total = int(b2.shape[0])
+    if out is None:
+        out = torch.empty(B, total, H, W, dtype=torch.float32, device=x.device)
+    flops = 2.0 * B * H * W * (num_branches * 64 * 64 * 9 + total * 9 * 64)
+    with torch.cuda.device(x.device), prof("conv_head_bf16", flops):
+        rc = _lib.load().sgv3d_centerhead_branches_forward_bf16(
+            B, H, W, 64, ld, int(x_coff), x.data_ptr(), int(num_branches), packed[0].data_ptr(), scale1.data_ptr(),
+            shift1.data_ptr(), total, packed[1].data_ptr(), b2.data_ptr(), out_begin.data_ptr(), out.data_ptr(), _st(x))
+    _lib.check(rc, "sgv3d_centerhead_branches_forward_bf16")
+    return out
+
+
 def lift(height_context, D, C, want_prob=False, want_lifted=True):
     """height_context NHWC [B,fH,fW,D+C] -> (prob [B,D,P] | None, lifted [B,D,P,C] | None)."""
     B, fH, fW, ld = (int(s) for s in height_context.shape)

@@ -159,9 +159,14 @@ class BEVHeightHead(HipModule):
             off += c
             out_begin.append(off)
         f = lambda t_: t_.to(device).float().contiguous()
-        return dict(shared=conv_bn(self.shared_conv.conv, self.shared_conv.bn, True, device), first=first,
+        ob_dev = torch.tensor(out_begin, dtype=torch.int32, device=device)
+        # bf16 mode: fragment-ordered bf16 copies of both branch layers for the fused bf16 head kernel (csrc/head_bf16.hip)
+        w1_bf16 = None
+        if hip_ops.MFMA_BF16 and hip_ops.FUSED_HEAD and tuple(w1.shape[1:]) == (64, 3, 3):
+            w1_bf16 = hip_ops.pack_centerhead_bf16(w1.to(device), w2.to(device), ob_dev)
+        return dict(w1_bf16=w1_bf16, shared=conv_bn(self.shared_conv.conv, self.shared_conv.bn, True, device), first=first,
                     w2=f(w2), b2=f(b2), branch_of_out=torch.tensor(branch_of_out, dtype=torch.int32, device=device),
-                    out_begin=torch.tensor(out_begin, dtype=torch.int32, device=device),
+                    out_begin=ob_dev,
                     slices=slices, nb=len(br), hc=hc, total=off)
 
     def hip_forward(self, x):
@@ -176,7 +181,11 @@ class BEVHeightHead(HipModule):
                 trunk_outs.append(h)
         fpn_output = self.neck.hip_forward(trunk_outs)                 # :109
         shared = s['shared'](fpn_output)                               # CenterHead.forward_single
-        if hip_ops.FUSED_HEAD and not hip_ops.MFMA_BF16 and s['first'].w_wino is not None and s['first'].cin <= 64 and s['hc'] == 64:
+        if hip_ops.MFMA_BF16 and s.get('w1_bf16') is not None:
+            # bf16 matrix cores: both branch layers in one kernel, hidden maps in LDS as bf16
+            out = hip_ops.centerhead_branches_bf16(shared, s['w1_bf16'], s['first'].scale, s['first'].shift, s['b2'],
+                                                   s['out_begin'], s['nb'])
+        elif hip_ops.FUSED_HEAD and not hip_ops.MFMA_BF16 and s['first'].w_wino is not None and s['first'].cin <= 64 and s['hc'] == 64:
             # both branch layers in one kernel: the [nb,B,H,W,64] hidden maps stay on the chip
             out = hip_ops.centerhead_branches(shared, s['first'], s['w2'], s['b2'], s['out_begin'], s['nb'])
         else:

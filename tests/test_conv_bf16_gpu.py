@@ -193,3 +193,101 @@ def test_f32x3_auto_mode_model_meets_the_fp32_bar():
     for t in range(6):
         for k, v in preds[t][0].items():
             torch.testing.assert_close(v.cpu(), ref[t][0][k], rtol=1e-3, atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------- fused bf16 CenterHead
+def _head_case(B, H, W, counts, seed):
+    g = torch.Generator().manual_seed(seed)
+    nb, total = len(counts), sum(counts)
+    x = torch.randn(B, H, W, 64, generator=g)
+    w1 = torch.randn(nb * 64, 64, 3, 3, generator=g) / 24.0
+    sc, sh = torch.rand(nb * 64, generator=g) + 0.5, torch.randn(nb * 64, generator=g) * 0.2
+    w2 = torch.randn(total, 64, 3, 3, generator=g) / 24.0
+    b2 = torch.randn(total, generator=g)
+    return x, w1, sc, sh, w2, b2
+
+
+def _head_reference(x, w1, sc, sh, w2, b2, counts, dev):
+    """float64 evaluation of what the bf16 kernel computes: bf16-rounded x / w1 / w2, exact products and sums, BN + ReLU in
+    high precision, the hidden map rounded to bf16 before the second convolution."""
+    r = lambda t: t.to(dev).bfloat16().double()
+    hid = F.conv2d(r(x).permute(0, 3, 1, 2), r(w1), padding=1) * sc.to(dev).double()[None, :, None, None] + sh.to(dev).double()[None, :, None, None]
+    hid = hid.clamp_min(0).float().bfloat16().double()
+    outs, off = [], 0
+    for k, c in enumerate(counts):
+        outs.append(F.conv2d(hid[:, k * 64:(k + 1) * 64], r(w2[off:off + c]), b2[off:off + c].to(dev).double(), padding=1))
+        off += c
+    return torch.cat(outs, 1)
+
+
+@pytest.mark.parametrize("B,H,W,counts", [(1, 16, 16, (2,)), (2, 20, 37, (1, 3)), (1, 50, 33, (2, 1, 3, 2, 2, 1, 1, 3)),
+                                          (1, 64, 48, (4, 1))])
+def test_fused_centerhead_bf16(B, H, W, counts):
+    """sgv3d_centerhead_branches_forward_bf16 == [3x3 64->64 + BN + ReLU] -> bf16 -> [3x3 64->c + bias] per branch, tiles
+    that cross the image border in both directions, up to 4 output channels per branch."""
+    x, w1, sc, sh, w2, b2 = _head_case(B, H, W, counts, seed=31)
+    nb = len(counts)
+    ob = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).to(DEV)
+    packed = hip_ops.pack_centerhead_bf16(w1.to(DEV), w2.permute(0, 2, 3, 1).contiguous().to(DEV), ob)
+    out = hip_ops.centerhead_branches_bf16(x.to(DEV), packed, sc.to(DEV), sh.to(DEV), b2.to(DEV), ob, nb)
+    ref = _head_reference(x, w1, sc, sh, w2, b2, counts, DEV)
+    assert out.shape == ref.shape
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((out.double() - ref).abs().max())
+    # fp32 accumulation flips the bf16 rounding of a hidden value now and then (one flip moves an output by ~2e-4)
+    assert err < 2e-3 * scale, (err, scale)
+    again = hip_ops.centerhead_branches_bf16(x.to(DEV), packed, sc.to(DEV), sh.to(DEV), b2.to(DEV), ob, nb)
+    assert torch.equal(out, again)
+    # input channels taken as a slice of a wider buffer
+    wide = torch.randn(B, H, W, 96).to(DEV)
+    wide[..., 16:80] = x.to(DEV)
+    sl = hip_ops.centerhead_branches_bf16(wide, packed, sc.to(DEV), sh.to(DEV), b2.to(DEV), ob, nb, x_coff=16)
+    assert torch.equal(out, sl)
+
+
+def test_fused_centerhead_bf16_exact_on_small_integers():
+    """bf16-exact operands and hidden values: every product and sum is exact, the result equals the integer convolution."""
+    g = torch.Generator().manual_seed(5)
+    counts = (2, 1, 3)
+    nb, total = len(counts), sum(counts)
+    x = torch.randint(-2, 3, (1, 23, 19, 64), generator=g).float()
+    w1 = torch.randint(-1, 2, (nb * 64, 64, 3, 3), generator=g).float()
+    w1 = w1 * (torch.rand(w1.shape, generator=g) < 0.05)                    # sparse: hidden values stay below 256 (bf16-exact)
+    sc, sh = torch.ones(nb * 64), torch.zeros(nb * 64)
+    w2 = torch.randint(-1, 2, (total, 64, 3, 3), generator=g).float()
+    b2 = torch.randint(-3, 4, (total,), generator=g).float()
+    ob = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).to(DEV)
+    out = hip_ops.centerhead_branches_bf16(x.to(DEV), hip_ops.pack_centerhead_bf16(w1.to(DEV), w2.permute(0, 2, 3, 1).contiguous().to(DEV), ob),
+                                           sc.to(DEV), sh.to(DEV), b2.to(DEV), ob, nb)
+    hid = F.conv2d(x.permute(0, 3, 1, 2).double(), w1.double(), padding=1).clamp_min(0)
+    assert float(hid.max()) < 256
+    ref, off = [], 0
+    for k, c in enumerate(counts):
+        ref.append(F.conv2d(hid[:, k * 64:(k + 1) * 64], w2[off:off + c].double(), b2[off:off + c].double(), padding=1))
+        off += c
+    assert torch.equal(out.cpu().double(), torch.cat(ref, 1))
+
+
+def test_fused_centerhead_bf16_36_branches_256x256_and_speed():
+    """The cfg-2 head shape; also prints the kernel time next to the fp32 fused head's."""
+    counts = []
+    for nc in (1, 2, 2, 1, 2, 2):
+        counts += [2, 1, 3, 2, 2, nc]
+    x, w1, sc, sh, w2, b2 = _head_case(1, 256, 256, counts, seed=36)
+    nb = len(counts)
+    ob = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).to(DEV)
+    args = (x.to(DEV), hip_ops.pack_centerhead_bf16(w1.to(DEV), w2.permute(0, 2, 3, 1).contiguous().to(DEV), ob), sc.to(DEV), sh.to(DEV),
+            b2.to(DEV), ob, nb)
+    out = hip_ops.centerhead_branches_bf16(*args)
+    ref = _head_reference(x, w1, sc, sh, w2, b2, counts, DEV)
+    err = float((out.double() - ref).abs().max())
+    assert err < 2e-3 * max(1.0, float(ref.abs().max())), err
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    evs[0].record()
+    for i in range(5):
+        hip_ops.centerhead_branches_bf16(*args)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    us = min(evs[i].elapsed_time(evs[i + 1]) for i in range(5)) * 1e3
+    flops = 2.0 * 256 * 256 * (nb * 64 * 576 + sum(counts) * 576)
+    print(f"bf16 fused head 36 x 256x256: {us:.0f} us = {flops / us / 1e6:.0f} TFLOP/s algorithmic")
