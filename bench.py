@@ -106,13 +106,17 @@ def load_traffic(tile_name):
         sym = "conv_wino_resident_kernel"
     elif tile_name == "conv_wino_head":
         sym = "conv_wino_head_kernel"
+    elif tile_name == "conv_head_bf16":
+        sym = "head_bf16_kernel"
     else:
         fast = not tile_name.endswith("_tapmajor")
-        kern = "conv_igemm_bf16_kernel" if tile_name.startswith(("conv_igemm_bf16_", "conv_igemm_f32x3_")) else "conv_igemm_kernel"
-        bm, bn = tile_name.replace("conv_igemm_bf16_", "").replace("conv_igemm_f32x3_", "").replace("conv_igemm_", "").replace("_tapmajor", "").split("x")
-        sym = f"{kern}<{int(bm) // 64}, {int(bn) // 64}, {'true' if fast else 'false'}>"
+        kern = "conv_igemm_bf16_kernel" if tile_name.startswith(("conv_igemm_bf16", "conv_igemm_f32x3_")) else "conv_igemm_kernel"
+        bm, bn = tile_name.replace("conv_igemm_bf16io_", "").replace("conv_igemm_bf16_", "").replace("conv_igemm_f32x3_", "").replace(
+            "conv_igemm_", "").replace("_tapmajor", "").split("x")
+        sym = f"{kern}<{int(bm) // 64}, {int(bn) // 64}, {'true' if fast else 'false'}"      # prefix: the bf16 kernel has more template arguments
     try:
-        rec = json.load(open(files[-1]))["bench"].get(sym)
+        table = json.load(open(files[-1]))["bench"]
+        rec = table.get(sym) or table.get(sym + ">") or next((v for k, v in table.items() if k.startswith(sym)), None)
     except Exception:
         rec = None
     if not rec:

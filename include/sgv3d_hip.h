@@ -234,6 +234,14 @@ int sgv3d_conv2d_forward_bf16(const sgv3d_conv_desc *desc /*host*/, const float 
                               const float *gate, float *y, void *workspace, size_t workspace_bytes,
                               void *stream);
 
+/* bf16 ACTIVATIONS in HBM (bf16 mode, the convolution chains of the image backbone / BEV trunk): the same bf16-MFMA
+ * convolution reading and / or writing bf16 tensors.  io_flags bit 0: x is bf16 [.., x_ld] (element offsets as in the
+ * desc); bit 1: y AND residual are bf16 -- mode NORMAL only, no gate, cout / y_ld / y_coff / res_ld multiples of 8; the
+ * epilogue (folded BN, residual, ReLU) runs in fp32 and rounds once to bf16.  Weights, scale, bias stay f32. */
+int sgv3d_conv2d_forward_bf16io(const sgv3d_conv_desc *desc /*host*/, const void *x, const float *w_packed,
+                                const float *scale, const float *bias, const void *residual, const float *gate,
+                                void *y, void *workspace, size_t workspace_bytes, void *stream, int io_flags);
+
 /* Same convolution, float32-accurate, on the bf16 matrix cores ("f32x3"): each operand is split exactly into three bf16
  * terms (hi + mid + lo) and a product is the f32 sum of the six partial products of weight >= 2^-16; the neglected
  * terms are below 2^-23 relative, i.e. one f32 rounding per product.  Bit-exact on data that is exact in bf16. */
@@ -268,6 +276,8 @@ int sgv3d_maxpool3x3s2(int batch, int in_h, int in_w, int channels, const float 
                        void *stream);
 
 /* NCHW f32 [B, C, H, W] -> NHWC [B, H, W, c_pad] with zero-padded channels (image ingest). */
+/* MaxPool2d(3, 2, 1) on a bf16 NHWC map (channels % 8 == 0). */
+int sgv3d_maxpool3x3s2_bf16(int batch, int in_h, int in_w, int channels, const void *x, void *y, void *stream);
 int sgv3d_nchw_to_nhwc(int batch, int channels, int h, int w, int c_pad, const float *x, float *y,
                        void *stream);
 /* NHWC [B, H, W, ld] channels [coff, coff+C) -> NCHW [B, C, H, W] (outputs handed back to torch). */

@@ -46,6 +46,7 @@ _PROTOS = {
     "sgv3d_conv2d_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "sgv3d_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "sgv3d_conv2d_forward_bf16": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_size_t, c_void_p]),
+    "sgv3d_conv2d_forward_bf16io": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_size_t, c_void_p, c_int]),
     "sgv3d_conv2d_forward_f32x3": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "sgv3d_centerhead_branches_workspace_bytes": (c_size_t, [c_int] * 4),
     "sgv3d_centerhead_branches_forward": (c_int, [c_int] * 6 + [c_void_p, c_int] + [c_void_p] * 3 + [c_int] + [c_void_p] * 5
@@ -59,6 +60,7 @@ _PROTOS = {
     "sgv3d_conv_winograd_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sgv3d_conv2d_winograd_forward": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "sgv3d_maxpool3x3s2": (c_int, [c_int] * 4 + [c_void_p] * 3),
+    "sgv3d_maxpool3x3s2_bf16": (c_int, [c_int] * 4 + [c_void_p] * 3),
     "sgv3d_nchw_to_nhwc": (c_int, [c_int] * 5 + [c_void_p] * 3),
     "sgv3d_nhwc_to_nchw": (c_int, [c_int] * 6 + [c_void_p] * 3),
     "sgv3d_global_avgpool_workspace_bytes": (c_size_t, [c_int] * 2),

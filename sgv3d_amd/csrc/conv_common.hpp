@@ -12,7 +12,7 @@ struct ConvArgs {
     int in_h, in_w, cin, out_h, out_w, cout;
     int m_h, m_w;  // spatial dims used to decode m (output dims; input dims for the deconv GEMM)
     int kh, kw, stride, pad, dil;
-    int x_ld, x_coff, y_ld, y_coff, res_ld, relu, mode, ks;
+    int x_ld, x_coff, y_ld, y_coff, res_ld, relu, mode, ks;   // mode: SGV3D_CONV_* | kConvYBf16 | kConvResBf16
     int tiles_m, tiles_n;
     int wb_y, wb_x;  // Winograd kernel: 16x16-pixel output blocks per image
     unsigned x_bytes, w_bytes;   // implicit GEMM: sizes of the input / packed-weight buffers (buffer resources)
@@ -21,12 +21,17 @@ struct ConvArgs {
     float *ws;   // [split_k][M][N] partial sums (split_k > 1)
 };
 
+// bf16-activation mode (sgv3d_conv2d_forward_bf16io): y / res point to bf16 tensors.  Carried in the high bits of `mode`:
+// two more kernel-argument words pushed the 128x128 bf16 kernel (256 VGPRs at two workgroups per CU) into spilling.
+constexpr int kConvModeMask = 0xff, kConvYBf16 = 0x100, kConvResBf16 = 0x200;
+
 // Shared by the conv kernel (split_k == 1) and the split-K reduce kernel: scale/shift (folded BN or
 // bias), residual, ReLU, SE gate and the store in the mode's layout.
 static __device__ __forceinline__ void conv_epilogue_store(const ConvArgs &a, int row, int col, float accv) {
     const int hw = a.m_h * a.m_w;
+    const int mode = a.mode & kConvModeMask;
     int co = col, dy = 0, dx = 0;
-    if (a.mode == SGV3D_CONV_DECONV) {
+    if (mode == SGV3D_CONV_DECONV) {
         const int tap = col / a.cout;
         co = col - tap * a.cout;
         dy = tap / a.ks;
@@ -35,26 +40,28 @@ static __device__ __forceinline__ void conv_epilogue_store(const ConvArgs &a, in
     float v = accv * (a.scale ? a.scale[co] : 1.f) + (a.bias ? a.bias[co] : 0.f);
     size_t yi;
     int img = 0;
-    if (a.mode == SGV3D_CONV_NORMAL) {
+    if (mode == SGV3D_CONV_NORMAL) {
         yi = (size_t)row * a.y_ld + a.y_coff + co;
         if (a.gate) img = row / hw;
     } else {
         img = row / hw;
         const int pix = row - img * hw;
-        if (a.mode == SGV3D_CONV_DECONV) {
+        if (mode == SGV3D_CONV_DECONV) {
             const int ih = pix / a.m_w, iw = pix - ih * a.m_w;
             yi = ((size_t)(img * a.out_h + ih * a.ks + dy) * a.out_w + (iw * a.ks + dx)) * a.y_ld + a.y_coff + co;
-        } else if (a.mode == SGV3D_CONV_NCHW_OUT) {
+        } else if (mode == SGV3D_CONV_NCHW_OUT) {
             yi = ((size_t)img * a.y_ld + a.y_coff + co) * hw + pix;
         } else {  // GROUP_PLANES: [cout/g][M][g], g = a.ks
             const int grp = co / a.ks;
             yi = ((size_t)grp * a.M + row) * a.ks + (co - grp * a.ks);
         }
     }
-    if (a.res) v += a.res[(size_t)row * a.res_ld + co];
+    if (a.res)
+        v += (a.mode & kConvResBf16) ? (float)reinterpret_cast<const __bf16 *>(a.res)[(size_t)row * a.res_ld + co] : a.res[(size_t)row * a.res_ld + co];
     if (a.relu) v = fmaxf(v, 0.f);
     if (a.gate) v *= a.gate[(size_t)img * a.cout + co];
-    a.y[yi] = v;
+    if (a.mode & kConvYBf16) reinterpret_cast<__bf16 *>(a.y)[yi] = (__bf16)v;
+    else a.y[yi] = v;
 }
 
 // Split-K second stage (conv_igemm.hip): sums a.ws[split][M][N] in fixed order and runs the epilogue.

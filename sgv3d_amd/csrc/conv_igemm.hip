@@ -29,6 +29,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4n __attribute__((ext_vector_type(4)));
+typedef float f32x2n __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
@@ -452,8 +453,17 @@ constexpr int LDKB = BK;
 // leading one: hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi, each exact in the f32 accumulator.  The dropped terms
 // (mid.lo, lo.mid, lo.lo) are below 2^-23 relative: the error of a product is that of one f32 rounding.  Six bf16 MFMAs
 // of K = 16 take 192 cycles where the f32 MFMA needs 512 for the same K.
-template <int WTM, int WTN, bool FAST, bool SPLIT3>
+//
+// XB / YB (sgv3d_conv2d_forward_bf16io): bf16 ACTIVATIONS in HBM.  XB: the input tensor is bf16 -- a thread's 4 k of a tile
+// are one 8-byte buffer load that goes to LDS as it is (no conversion, half the bytes).  YB: output (and residual) are
+// bf16 -- the MFMA operands are swapped (C^T = W . X^T), which puts the PIXEL on the lane and 4 consecutive output
+// channels in registers 4g..4g+3; each wave stages its 32 x 32 tile through LDS in fp32 and leaves it as 16-byte stores
+// of 8 channels per lane (one 64-byte row of a pixel per 4 lanes), after folded BN, residual (bf16, added in fp32) and
+// ReLU.  NORMAL mode only (concat offsets allowed, multiples of 8 channels).
+template <int WTM, int WTN, bool FAST, bool SPLIT3, bool XB = false, bool YB = false>
 __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void conv_igemm_bf16_kernel(const ConvArgs a) {
+    static_assert(!(SPLIT3 && (XB || YB)), "f32x3 works on f32 tensors");
+    constexpr int XES = XB ? 2 : 4;                            // bytes per input element
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     constexpr int A_CH = BM / 32, B_CH = BN / 32;
     constexpr int NP = SPLIT3 ? 3 : 1;                         // bf16 planes per operand
@@ -504,7 +514,7 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
         const int oh = t - n * a.m_h;
         a_ih0[i] = oh * a.stride - a.pad;
         a_iw0[i] = ow * a.stride - a.pad;
-        a_off[i] = (unsigned)((((long long)(n * a.in_h + a_ih0[i]) * a.in_w + a_iw0[i]) * a.x_ld + a.x_coff + cc * 4) * 4);
+        a_off[i] = (unsigned)((((long long)(n * a.in_h + a_ih0[i]) * a.in_w + a_iw0[i]) * a.x_ld + a.x_coff + cc * 4) * XES);
     }
     unsigned b_off[B_CH];
 #pragma unroll
@@ -543,6 +553,17 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
         ld_kh = rem / a.kw;
         ld_kw = rem - ld_kh * a.kw;
     }
+    // one chunk of 4 k of the input: 16 bytes of f32, or (XB) 8 bytes of bf16 parked in .x / .y
+#define SGV3D_LOAD_A(R, VOFF, SOFF)                                                                   \
+    do {                                                                                              \
+        if constexpr (XB) {                                                                           \
+            const f32x2n t_ = __builtin_bit_cast(f32x2n, __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, VOFF, SOFF, 0)); \
+            R.x = t_.x; R.y = t_.y;                                                                   \
+        } else {                                                                                      \
+            const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, VOFF, SOFF, 0)); \
+            R.x = t_.x; R.y = t_.y; R.z = t_.z; R.w = t_.w;                                           \
+        }                                                                                             \
+    } while (0)
 #define SGV3D_LOAD_TILE(RA, RB)                                                                       \
     do {                                                                                              \
         int dy_, dx_, koff_;                                                                          \
@@ -561,24 +582,21 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
         }                                                                                             \
         if (one_tap) {                                                                                \
             _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                        \
-                const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, a_fix[i], koff_ * 4, 0)); \
-                RA[i].x = t_.x; RA[i].y = t_.y; RA[i].z = t_.z; RA[i].w = t_.w;                       \
+                SGV3D_LOAD_A(RA[i], a_fix[i], koff_ * XES);                                           \
             }                                                                                         \
         } else if (use_mask) {                                                                        \
             const unsigned bit_ = kvalid_ ? 1u << (ld_kh * a.kw + ld_kw) : 0u;                        \
             _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                        \
-                const unsigned vo_ = (a_mask[i] & bit_) ? a_off[i] + (unsigned)(koff_ * 4) : 0xffffffffu; \
-                const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo_, 0, 0)); \
-                RA[i].x = t_.x; RA[i].y = t_.y; RA[i].z = t_.z; RA[i].w = t_.w;                       \
+                const unsigned vo_ = (a_mask[i] & bit_) ? a_off[i] + (unsigned)(koff_ * XES) : 0xffffffffu; \
+                SGV3D_LOAD_A(RA[i], vo_, 0);                                                          \
             }                                                                                         \
         } else {                                                                                      \
             _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                        \
                 const int ih_ = a_ih0[i] + dy_, iw_ = a_iw0[i] + dx_;                                 \
                 const bool v_ = a_ok[i] & kvalid_ & ((unsigned)ih_ < (unsigned)a.in_h) &              \
                                 ((unsigned)iw_ < (unsigned)a.in_w);                                   \
-                const unsigned vo_ = v_ ? a_off[i] + (unsigned)(koff_ * 4) : 0xffffffffu;             \
-                const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo_, 0, 0)); \
-                RA[i].x = t_.x; RA[i].y = t_.y; RA[i].z = t_.z; RA[i].w = t_.w;                       \
+                const unsigned vo_ = v_ ? a_off[i] + (unsigned)(koff_ * XES) : 0xffffffffu;           \
+                SGV3D_LOAD_A(RA[i], vo_, 0);                                                          \
             }                                                                                         \
         }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < B_CH; ++i) {                                            \
@@ -611,7 +629,14 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
 #define SGV3D_STORE_TILE(RA, RB, BUF)                                                                 \
     do {                                                                                              \
         __bf16 *As_ = As0 + (BUF) * kBufStride, *Bs_ = Bs0 + (BUF) * kBufStride;                      \
-        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) SGV3D_CVT_STORE(As_ + (r0 + 32 * i) * LDKB + st_off, RA[i], kPlaneA); \
+        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                            \
+            if constexpr (XB) {                                                                       \
+                f32x2n t2_ = {RA[i].x, RA[i].y};                                                      \
+                *reinterpret_cast<f32x2n *>(As_ + (r0 + 32 * i) * LDKB + st_off) = t2_;               \
+            } else {                                                                                  \
+                SGV3D_CVT_STORE(As_ + (r0 + 32 * i) * LDKB + st_off, RA[i], kPlaneA);                 \
+            }                                                                                         \
+        }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < B_CH; ++i) SGV3D_CVT_STORE(Bs_ + (r0 + 32 * i) * LDKB + st_off, RB[i], kPlaneB); \
     } while (0)
 
@@ -642,7 +667,8 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
 #define SGV3D_MM(PA, PB)                                                                              \
     _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                                \
         _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt)                                            \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][mt], fb[PB][nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = YB ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB][nt], fa[PA][mt], acc[mt][nt], 0, 0, 0)     \
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][mt], fb[PB][nt], acc[mt][nt], 0, 0, 0);
     // small terms first, so that the leading product meets an accumulator that already holds the corrections
 #define SGV3D_MFMA_STEP()                                                                             \
     do {                                                                                              \
@@ -665,7 +691,25 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
     // Residual prefetch (64x64 tile, fast-path epilogue): the small-K layers that carry a residual (the expanding 1x1
     // convolutions of the bottlenecks) spend a third of a workgroup's life waiting for the residual rows they only
     // ask for after the k loop; asked for here, the 16 values per lane arrive under the loop.
-    constexpr bool kPrefetchRes = WTM * WTN <= 2;
+    constexpr bool kPrefetchRes = WTM * WTN <= 2 && !YB;
+    // YB: lane -> (pixel p = lane >> 2 (+16 in the second pass), 8-channel chunk c = lane & 3) of a 32 x 32 tile
+    constexpr bool kPrefetchResB = YB && WTM * WTN <= 2;
+    const __bf16 *const resb = reinterpret_cast<const __bf16 *>(a.res);
+    bf16x8 resq[WTM][WTN][2];
+    if constexpr (kPrefetchResB) {
+        if (a.res != nullptr && a.split_k <= 1) {
+#pragma unroll
+            for (int mt = 0; mt < WTM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < WTN; ++nt)
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const int row = m0 + (tid >> 7) * (BM / 2) + mt * 32 + ((tid & 63) >> 2) + 16 * ps;
+                        const int ch = n0 + ((tid >> 6) & 1) * (BN / 2) + nt * 32 + 8 * (tid & 3);
+                        if (row < a.M && ch < a.N) resq[mt][nt][ps] = *reinterpret_cast<const bf16x8 *>(resb + (size_t)row * a.res_ld + ch);
+                    }
+        }
+    }
     // (GROUP_PLANES -- the per-branch hidden maps of the two-kernel head path -- is row-linear too when a wave's columns
     // stay inside one group: plane base + row * group width)
     const bool fast_epi = (a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr) ||
@@ -699,6 +743,7 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
         SGV3D_PHASE(1, ra1, rb1, ra0, rb0, kt + 2 < nkt);
     }
 #undef SGV3D_LOAD_TILE
+#undef SGV3D_LOAD_A
 #undef SGV3D_CVT_STORE
 #undef SGV3D_STORE_TILE
 #undef SGV3D_PHASE
@@ -706,6 +751,75 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
 #undef SGV3D_MM
 #undef SGV3D_MFMA_STEP
 
+    if constexpr (YB) {
+        // transposed accumulators: acc[mt][nt][4 g + i] = C[pixel m0 + wm (BM/2) + 32 mt + lr][channel n0 + wn (BN/2) + 32 nt + 8 g + 4 lh + i]
+        const int prow0 = m0 + wm * (BM / 2), pcol0 = n0 + wn * (BN / 2);
+        if (a.split_k > 1) {            // raw partial sums, [split][M][N] f32: 16-byte stores of 4 channels
+            float *ws = a.ws + (size_t)blockIdx.y * a.M * a.N;
+#pragma unroll
+            for (int mt = 0; mt < WTM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < WTN; ++nt) {
+                    const int row = prow0 + mt * 32 + lr;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ch = pcol0 + nt * 32 + 8 * g + 4 * lh;
+                        if (row < a.M && ch < a.N) {
+                            f32x4n v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                            *reinterpret_cast<f32x4n *>(ws + (size_t)row * a.N + ch) = v;
+                        }
+                    }
+                }
+            return;
+        }
+        constexpr int SLD = 36;                                          // floats per staged pixel row (144 B)
+        float *stage = smem + wave * (32 * SLD);                          // the operand buffers are dead: the loop ended on a barrier
+        __bf16 *const yb = reinterpret_cast<__bf16 *>(a.y);
+        const int pc = lane & 3, pp = lane >> 2;
+#pragma unroll
+        for (int nt = 0; nt < WTN; ++nt) {
+            const int ch = pcol0 + nt * 32 + 8 * pc;
+            const bool ch_ok = ch < a.N;
+            f32x4n sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+            if (ch_ok && a.scale) { sc0 = *reinterpret_cast<const f32x4n *>(a.scale + ch); sc1 = *reinterpret_cast<const f32x4n *>(a.scale + ch + 4); }
+            if (ch_ok && a.bias) { sh0 = *reinterpret_cast<const f32x4n *>(a.bias + ch); sh1 = *reinterpret_cast<const f32x4n *>(a.bias + ch + 4); }
+#pragma unroll
+            for (int mt = 0; mt < WTM; ++mt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4n v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                    *reinterpret_cast<f32x4n *>(stage + lr * SLD + 8 * g + 4 * lh) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int p = pp + 16 * ps;
+                    const int row = prow0 + mt * 32 + p;
+                    f32x4n v0 = *reinterpret_cast<const f32x4n *>(stage + p * SLD + 8 * pc);
+                    f32x4n v1 = *reinterpret_cast<const f32x4n *>(stage + p * SLD + 8 * pc + 4);
+                    if (row < a.M && ch_ok) {
+                        v0 = v0 * sc0 + sh0;
+                        v1 = v1 * sc1 + sh1;
+                        if (a.res != nullptr) {
+                            bf16x8 rq;
+                            if constexpr (kPrefetchResB) rq = resq[mt][nt][ps];
+                            else rq = *reinterpret_cast<const bf16x8 *>(resb + (size_t)row * a.res_ld + ch);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { v0[i] += (float)rq[i]; v1[i] += (float)rq[4 + i]; }
+                        }
+                        if (a.relu) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], 0.f); v1[i] = fmaxf(v1[i], 0.f); }
+                        }
+                        const bf16x4 o0 = __builtin_convertvector(v0, bf16x4), o1 = __builtin_convertvector(v1, bf16x4);
+                        *reinterpret_cast<bf16x8 *>(yb + (size_t)row * a.y_ld + a.y_coff + ch) = __builtin_shufflevector(o0, o1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
     // epilogue: the accumulator layout is that of every 32x32 MFMA (row = (e & 3) + 8 (e >> 2) + 4 h, column = lane & 31),
     // so the f32 kernel's fast path (hoisted channel terms, buffer stores with scalar row offsets) applies unchanged
     if (fast_epi) {
@@ -855,24 +969,38 @@ int launch(const ConvArgs &a, hipStream_t st) {
     return a.korder == 1 ? launch_t<WTM, WTN, true>(a, st) : launch_t<WTM, WTN, false>(a, st);
 }
 
-template <int WTM, int WTN, bool FAST, bool SPLIT3>
+template <int WTM, int WTN, bool FAST, bool SPLIT3, bool XB = false, bool YB = false>
 int launch_bf16_t(const ConvArgs &a, hipStream_t st) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
-    constexpr size_t tiles_lds = sizeof(unsigned short) * 2 * (SPLIT3 ? 3 : 1) * (BM + BN) * LDKB;
+    constexpr size_t tiles_only = sizeof(unsigned short) * 2 * (SPLIT3 ? 3 : 1) * (BM + BN) * LDKB;
+    constexpr size_t stage_lds = YB ? sizeof(float) * 4 * 32 * 36 : 0;       // YB epilogue: a 32 x 36 f32 tile per wave
+    constexpr size_t tiles_lds = tiles_only > stage_lds ? tiles_only : stage_lds;
     const size_t lds = tiles_lds + (FAST ? 0 : (size_t)a.k_pad / 4 * 8);
     SGV3D_REQUIRE(lds <= 160 * 1024, "conv2d_forward_bf16: K = %d too long for the tap-major kernel's decode table", a.K);
     static PerDeviceSize lds_set;
-    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_bf16_kernel<WTM, WTN, FAST, SPLIT3>), lds, lds_set))
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_bf16_kernel<WTM, WTN, FAST, SPLIT3, XB, YB>), lds, lds_set))
         return fail(SGV3D_ELAUNCH, "conv2d_forward_bf16: cannot raise the dynamic LDS limit to %zu", lds);
     ConvArgs b = a;
     b.zeros = conv_zero_block();
     if (!b.zeros) return fail(SGV3D_ELAUNCH, "conv2d_forward_bf16: cannot resolve the zero block");
     b.tiles_m = cdiv(a.M, BM);
     b.tiles_n = cdiv(a.N, BN);
-    hipLaunchKernelGGL((conv_igemm_bf16_kernel<WTM, WTN, FAST, SPLIT3>), dim3(b.tiles_m * b.tiles_n, b.split_k), dim3(kThreads),
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<WTM, WTN, FAST, SPLIT3, XB, YB>), dim3(b.tiles_m * b.tiles_n, b.split_k), dim3(kThreads),
                        lds, st, b);
     if (b.split_k > 1) return launch_splitk_reduce(b, st);
     return check_launch("conv_igemm_bf16_kernel");
+}
+
+// io: bit 0 = the input is bf16, bit 1 = output and residual are bf16
+template <int WTM, int WTN>
+int launch_bf16io(const ConvArgs &a, hipStream_t st, int io) {
+    const bool fast = a.korder == 1;
+    switch (io) {
+        case 1: return fast ? launch_bf16_t<WTM, WTN, true, false, true, false>(a, st) : launch_bf16_t<WTM, WTN, false, false, true, false>(a, st);
+        case 2: return fast ? launch_bf16_t<WTM, WTN, true, false, false, true>(a, st) : launch_bf16_t<WTM, WTN, false, false, false, true>(a, st);
+        case 3: return fast ? launch_bf16_t<WTM, WTN, true, false, true, true>(a, st) : launch_bf16_t<WTM, WTN, false, false, true, true>(a, st);
+        default: return fail(SGV3D_EINVAL, "conv2d_forward_bf16io: io flags %d", io);
+    }
 }
 
 template <int WTM, int WTN>
@@ -952,8 +1080,18 @@ extern "C" size_t sgv3d_conv2d_workspace_bytes(const sgv3d_conv_desc *d) {
 static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const float *w_packed,
                                const float *scale, const float *bias, const float *residual,
                                const float *gate, float *y, void *workspace, size_t workspace_bytes,
-                               void *stream, int bf16 /* 0: f32 MFMA, 1: bf16 operands, 3: f32 as three bf16 terms */) {
+                               void *stream, int bf16 /* 0: f32 MFMA, 1: bf16 operands, 3: f32 as three bf16 terms */,
+                               int io = 0 /* bf16 == 1 only: bit 0 = x is a bf16 tensor, bit 1 = y and residual are */) {
     SGV3D_REQUIRE(d && x && w_packed && y, "conv2d_forward: null pointer");
+    SGV3D_REQUIRE(io == 0 || bf16 == 1, "conv2d_forward: bf16 tensors need the bf16 MFMA entry point");
+    if (io & 2) {
+        SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL && gate == nullptr, "conv2d_forward_bf16io: bf16 output in NORMAL mode without gate only");
+        SGV3D_REQUIRE(d->cout % 8 == 0 && d->y_ld % 8 == 0 && d->y_coff % 8 == 0 && (residual == nullptr || d->res_ld % 8 == 0),
+                      "conv2d_forward_bf16io: cout / y_ld / y_coff / res_ld must be multiples of 8 (16-byte rows of bf16)");
+        SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0 &&
+                          (reinterpret_cast<uintptr_t>(scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0,
+                      "conv2d_forward_bf16io: y, residual, scale and bias must be 16-B aligned");
+    }
     SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->out_h > 0 && d->out_w > 0 &&
                       d->cout > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0,
                   "conv2d_forward: non-positive dimension");
@@ -974,7 +1112,7 @@ static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const f
     a.tiles_m = a.tiles_n = 0;
     a.korder = d->k_order;
     {
-        const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * 4, wb = (long long)d->cout_pad * d->k_pad * 4;
+        const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * ((io & 1) ? 2 : 4), wb = (long long)d->cout_pad * d->k_pad * 4;
         SGV3D_REQUIRE(xb < 0xf0000000LL && wb < 0xf0000000LL, "conv2d_forward: input / packed weights larger than 3.75 GiB (32-bit buffer offsets)");
         a.x_bytes = (unsigned)xb;
         a.w_bytes = (unsigned)wb;
@@ -1022,6 +1160,16 @@ static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const f
     }
     const int tile = d->tile ? d->tile : pick_tile(M, a.N);
     hipStream_t st = as_stream(stream);
+    if (io & 2) a.mode |= kConvYBf16 | kConvResBf16;       // (NORMAL mode, checked above)
+    if (io) {
+        switch (tile) {
+            case SGV3D_TILE_128x128: return launch_bf16io<2, 2>(a, st, io);
+            case SGV3D_TILE_128x64: return launch_bf16io<2, 1>(a, st, io);
+            case SGV3D_TILE_64x128: return launch_bf16io<1, 2>(a, st, io);
+            case SGV3D_TILE_64x64: return launch_bf16io<1, 1>(a, st, io);
+            default: return fail(SGV3D_EINVAL, "conv2d_forward_bf16io: unknown tile %d", tile);
+        }
+    }
     if (bf16) {
         switch (tile) {
             case SGV3D_TILE_128x128: return launch_bf16<2, 2>(a, st, bf16 == 3);
@@ -1052,6 +1200,14 @@ extern "C" int sgv3d_conv2d_forward_bf16(const sgv3d_conv_desc *d, const float *
                                          const float *gate, float *y, void *workspace, size_t workspace_bytes,
                                          void *stream) {
     return conv2d_forward_impl(d, x, w_packed, scale, bias, residual, gate, y, workspace, workspace_bytes, stream, 1);
+}
+
+extern "C" int sgv3d_conv2d_forward_bf16io(const sgv3d_conv_desc *d, const void *x, const float *w_packed, const float *scale,
+                                           const float *bias, const void *residual, const float *gate, void *y,
+                                           void *workspace, size_t workspace_bytes, void *stream, int io_flags) {
+    SGV3D_REQUIRE(io_flags >= 1 && io_flags <= 3, "conv2d_forward_bf16io: io_flags must be 1 (bf16 input), 2 (bf16 output + residual) or 3");
+    return conv2d_forward_impl(d, static_cast<const float *>(x), w_packed, scale, bias, static_cast<const float *>(residual), gate,
+                               static_cast<float *>(y), workspace, workspace_bytes, stream, 1, io_flags);
 }
 
 extern "C" int sgv3d_conv2d_forward_f32x3(const sgv3d_conv_desc *d, const float *x, const float *w_packed,

@@ -36,6 +36,41 @@ __global__ __launch_bounds__(kBlock) void maxpool3x3s2_kernel(int B, int H, int 
     y[i] = m;
 }
 
+// the same pooling on a bf16 map (bf16-activation mode): 8 channels per thread, max is exact in bf16
+typedef __bf16 mp_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(kBlock) void maxpool3x3s2_bf16_kernel(int B, int H, int W, int C8, int OH, int OW,
+                                                                   const mp_bf16x8 *__restrict__ x, mp_bf16x8 *__restrict__ y) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long total = (long long)B * OH * OW * C8;
+    if (i >= total) return;
+    const int c = (int)(i % C8);
+    long long t = i / C8;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int ih = oh * 2 - 1 + dy;
+        if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int iw = ow * 2 - 1 + dx;
+            if ((unsigned)iw >= (unsigned)W) continue;
+            const mp_bf16x8 v = x[((long long)(b * H + ih) * W + iw) * C8 + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)v[j]);
+        }
+    }
+    mp_bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)m[j];
+    y[i] = o;
+}
+
 // image ingest: NCHW -> NHWC with zero-padded channels (the harness hands [B,1,1,3,H,W], exps/...:246)
 __global__ __launch_bounds__(kBlock) void nchw_to_nhwc_kernel(int B, int C, long long HW, int Cp,
                                                               const float *__restrict__ x, float *__restrict__ y) {
@@ -419,6 +454,17 @@ extern "C" int sgv3d_maxpool3x3s2(int batch, int in_h, int in_w, int channels, c
     hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, as_stream(stream), batch, in_h,
                        in_w, channels / 4, oh, ow, reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y));
     return check_launch("maxpool3x3s2_kernel");
+}
+
+extern "C" int sgv3d_maxpool3x3s2_bf16(int batch, int in_h, int in_w, int channels, const void *x, void *y, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && in_h > 0 && in_w > 0 && channels > 0 && channels % 8 == 0, "maxpool3x3s2_bf16: channels must be a multiple of 8");
+    SGV3D_REQUIRE(x && y && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
+                  "maxpool3x3s2_bf16: null or unaligned pointer");
+    const int oh = (in_h - 1) / 2 + 1, ow = (in_w - 1) / 2 + 1;
+    const long long total = (long long)batch * oh * ow * (channels / 8);
+    hipLaunchKernelGGL(maxpool3x3s2_bf16_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, as_stream(stream), batch, in_h,
+                       in_w, channels / 8, oh, ow, static_cast<const mp_bf16x8 *>(x), static_cast<mp_bf16x8 *>(y));
+    return check_launch("maxpool3x3s2_bf16_kernel");
 }
 
 extern "C" int sgv3d_nchw_to_nhwc(int batch, int channels, int h, int w, int c_pad, const float *x, float *y, void *stream) {

@@ -44,6 +44,12 @@ FUSED_HEAD = not _os.environ.get("SGV3D_NO_FUSED_HEAD")
 # HBM) -- the compute dtype BASELINE cfg-3 / cfg-5 name.  Winograd and the fused head kernel are fp32-only and are not
 # used in this mode (a bf16 direct convolution runs at 16x the fp32 MFMA rate, so the 2.25x saving no longer matters).
 MFMA_BF16 = bool(_os.environ.get("SGV3D_BF16"))
+# bf16 mode only: the convolution chains of the ResNets (image backbone, BEV trunk) keep their activations as bf16
+# tensors in HBM -- the 1x1 / strided layers at the large resolutions are HBM-bound, so halving the bytes is worth more
+# than any MFMA tuning there (a 256 -> 1024 1x1 with residual at 68x120x4: 99 -> 55 us).  The stem conv writes bf16, the
+# blocks read and write bf16 (epilogue in fp32, one rounding), the necks read bf16 and write fp32.
+# SGV3D_NO_BF16_ACTIVATIONS=1 keeps fp32 tensors everywhere (round 1 behaviour).
+BF16_ACTIVATIONS = not _os.environ.get("SGV3D_NO_BF16_ACTIVATIONS")
 # True (SGV3D_F32X3=1): the implicit-GEMM layers compute float32-accurate products on the bf16 matrix cores -- every
 # operand is split exactly into three bf16 terms and six partial products are accumulated in f32 (csrc/conv_igemm.hip,
 # SPLIT3): the error of a product is one f32 rounding, the MFMA time 192 instead of 512 cycles per 16 k.  Winograd
@@ -218,11 +224,25 @@ class PackedConv:
         return oh, ow
 
     def __call__(self, x, out=None, *, x_coff=0, y_coff=0, residual=None, gate=None, nchw_out=False, tile=None,
-                 group_planes=0, split_k=None):
+                 group_planes=0, split_k=None, out_dtype=None):
         """x NHWC [B,H,W,x_ld]; reads channels [x_coff, x_coff+cin).  out NHWC [B,OH,OW,y_ld] written
-        at channels [y_coff, y_coff+cout) (allocated [B,OH,OW,cout] if None)."""
+        at channels [y_coff, y_coff+cout) (allocated [B,OH,OW,cout] if None).
+        bf16 mode: ``x`` may be a bf16 tensor, and ``out_dtype=torch.bfloat16`` (or a bf16 ``out``) makes the layer write
+        bf16 (then ``residual`` is bf16 too) -- NORMAL layout only."""
         B, H, W, x_ld = (int(s) for s in x.shape)
-        assert x.is_contiguous() and x.dtype == torch.float32
+        assert x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)
+        if out is not None:
+            out_dtype = out.dtype
+        out_dtype = out_dtype or torch.float32
+        io = (1 if x.dtype == torch.bfloat16 else 0) | (2 if out_dtype == torch.bfloat16 else 0)
+        if io:
+            if not MFMA_BF16 or MFMA_F32X3:
+                raise _lib.SGV3DError("bf16 tensors are only handled in bf16 mode (hip_ops.MFMA_BF16)")
+            if io & 2:
+                assert not (nchw_out or group_planes or self.transposed or gate is not None), "bf16 output: NORMAL layout only"
+                assert residual is None or residual.dtype == torch.bfloat16
+            else:
+                assert residual is None or residual.dtype == torch.float32
         oh, ow = self.out_hw(H, W)
         if group_planes:
             # [cout/g, B, OH, OW, g]: one NHWC map per group of g output channels
@@ -232,7 +252,7 @@ class PackedConv:
             assert out.is_contiguous() and out.numel() == B * oh * ow * self.cout
         elif out is None:
             shape = (B, self.cout, oh, ow) if nchw_out else (B, oh, ow, self.cout)
-            out = torch.empty(shape, dtype=torch.float32, device=x.device)
+            out = torch.empty(shape, dtype=out_dtype, device=x.device)
         else:
             want = (B, None, oh, ow) if nchw_out else (B, oh, ow, None)
             got = tuple(int(v) for v in out.shape)
@@ -262,17 +282,18 @@ class PackedConv:
         t = int(self.tile if tile is None else tile)
         sk = int(split_k) if split_k else 0
         if t == 0 or sk == 0:
-            key = (B, H, W, t, sk, MFMA_BF16, MFMA_F32X3, d.mode, residual is not None, gate is not None)
+            key = (B, H, W, t, sk, MFMA_BF16, MFMA_F32X3, d.mode, residual is not None, gate is not None, io)
             choice = self._tile_cache.get(key)
             if choice is None:
                 sig = (f"{self.cout}x{self.cin}k{self.kh}x{self.kw}s{self.stride}p{self.pad}d{self.dil}"
                        f"ks{self.ks}|{B}x{H}x{W}|m{d.mode}r{int(residual is not None)}g{int(gate is not None)}|{t}.{sk}"
-                       + ("|bf16" if MFMA_BF16 else "|f32x3" if MFMA_F32X3 is True else "|x3auto" if MFMA_F32X3 else ""))
+                       + ("|bf16" if MFMA_BF16 else "|f32x3" if MFMA_F32X3 is True else "|x3auto" if MFMA_F32X3 else "")
+                       + (f"|io{io}" if io else ""))
                 if sig in TUNE_DB:
                     choice = TUNE_DB[sig]
                     self._tile_cache[key] = choice
                 elif AUTOTUNE and not torch.cuda.is_current_stream_capturing():
-                    choice = self._autotune(lib, d, x, residual, gate, out, gemm_m, gemm_n, nkt, t, sk)
+                    choice = self._autotune(lib, d, x, residual, gate, out, gemm_m, gemm_n, nkt, t, sk, io)
                     self._tile_cache[key] = choice
                     TUNE_DB[sig] = choice
                 else:
@@ -290,8 +311,10 @@ class PackedConv:
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
                      f"s{self.stride} d{self.dil} splitk{sk}")
+        if io:
+            name = name.replace("conv_igemm_bf16_", "conv_igemm_bf16io_")
         with torch.cuda.device(x.device), prof(name, flops):
-            rc = self._launch(lib, d, x, residual, gate, out)
+            rc = self._launch(lib, d, x, residual, gate, out, io)
         _lib.check(rc, "sgv3d_conv2d_forward")
         return out
 
@@ -309,7 +332,7 @@ class PackedConv:
             return TILE_WINO, sk or split
         return (t or heuristic_tile(gemm_m, gemm_n)), (sk or 1)
 
-    def _launch(self, lib, d, x, residual, gate, out):
+    def _launch(self, lib, d, x, residual, gate, out, io=0):
         ws, nws = None, 0
         if d.split_k > 1:
             nws = lib.sgv3d_conv2d_workspace_bytes(ctypes.byref(d))
@@ -320,6 +343,10 @@ class PackedConv:
             return lib.sgv3d_conv2d_winograd_forward(ctypes.byref(d), x.data_ptr(), self.w_wino.data_ptr(),
                                                      _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
                                                      _lib.ptr(gate), out.data_ptr(), _lib.ptr(ws), nws, _st(x))
+        if io:
+            return lib.sgv3d_conv2d_forward_bf16io(ctypes.byref(d), x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.scale),
+                                                   _lib.ptr(self.shift), _lib.ptr(residual), _lib.ptr(gate), out.data_ptr(),
+                                                   _lib.ptr(ws), nws, _st(x), int(io))
         x3 = d.tile > 10 or (MFMA_F32X3 is True)
         fwd = (lib.sgv3d_conv2d_forward_bf16 if MFMA_BF16 else
                lib.sgv3d_conv2d_forward_f32x3 if x3 else lib.sgv3d_conv2d_forward)
@@ -333,7 +360,7 @@ class PackedConv:
         finally:
             d.tile = host_tile
 
-    def _time_under_load(self, lib, d, x, residual, gate, out, rounds=3):
+    def _time_under_load(self, lib, d, x, residual, gate, out, rounds=3, io=0):
         """Time for TUNE_STREAMS concurrent copies of the launch, ``rounds`` back to back on every stream (all copies
         write the same values to ``out``; split-K workspaces are per launch)."""
         global _TUNE_SIDE_STREAMS
@@ -349,7 +376,7 @@ class PackedConv:
                 s.wait_event(e0)
                 with torch.cuda.stream(s):
                     for _r in range(rounds):
-                        self._launch(lib, d, x, residual, gate, out)
+                        self._launch(lib, d, x, residual, gate, out, io)
                 cur.wait_stream(s)
             e1.record(cur)
             e1.synchronize()
@@ -357,7 +384,7 @@ class PackedConv:
             best = dt if best is None else min(best, dt)
         return best
 
-    def _autotune(self, lib, d, x, residual, gate, out, gemm_m, gemm_n, nkt, fixed_tile, fixed_split):
+    def _autotune(self, lib, d, x, residual, gate, out, gemm_m, gemm_n, nkt, fixed_tile, fixed_split, io=0):
         """Time the candidate (tile, split-K) pairs on the real buffers and keep the fastest.  Results do
         not depend on the tile shape (every output element sums k in the same order); split-K changes
         the association of the k sum (partials added in fixed order), still deterministic."""
@@ -391,14 +418,14 @@ class PackedConv:
                     splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 4 and wgs < 2048 and wgs * s <= 6144]
                 for sk in splits:
                     d.tile, d.split_k = t, sk
-                    _lib.check(self._launch(lib, d, x, residual, gate, out), "sgv3d_conv2d_forward")   # warm
+                    _lib.check(self._launch(lib, d, x, residual, gate, out, io), "sgv3d_conv2d_forward")   # warm
                     if TUNE_STREAMS > 1:
-                        dt = self._time_under_load(lib, d, x, residual, gate, out)
+                        dt = self._time_under_load(lib, d, x, residual, gate, out, io=io)
                     else:
                         evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
                         evs[0].record()
                         for r in range(4):
-                            self._launch(lib, d, x, residual, gate, out)
+                            self._launch(lib, d, x, residual, gate, out, io)
                             evs[r + 1].record()
                         evs[-1].synchronize()
                         dt = min(evs[r].elapsed_time(evs[r + 1]) for r in range(4))
@@ -411,9 +438,12 @@ def maxpool3x3s2(x, out=None):
     B, H, W, C = (int(s) for s in x.shape)
     oh, ow = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if out is None:
-        out = torch.empty(B, oh, ow, C, dtype=torch.float32, device=x.device)
+        out = torch.empty(B, oh, ow, C, dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device), prof("maxpool3x3s2"):
-        rc = _lib.load().sgv3d_maxpool3x3s2(B, H, W, C, x.data_ptr(), out.data_ptr(), _st(x))
+        if x.dtype == torch.bfloat16:
+            rc = _lib.load().sgv3d_maxpool3x3s2_bf16(B, H, W, C, x.data_ptr(), out.data_ptr(), _st(x))
+        else:
+            rc = _lib.load().sgv3d_maxpool3x3s2(B, H, W, C, x.data_ptr(), out.data_ptr(), _st(x))
     _lib.check(rc, "sgv3d_maxpool3x3s2")
     return out
 

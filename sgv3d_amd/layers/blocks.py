@@ -90,11 +90,11 @@ class BasicBlock(HipModule):
             s['ds'] = conv_bn(self.downsample[0], self.downsample[1], False, device, pad_out=True)
         return s
 
-    def hip_forward(self, x):
+    def hip_forward(self, x, act_dtype=None):
         s = self.hip_state(x.device)
-        identity = s['ds'](x) if 'ds' in s else x
-        out = s['c1'](x)
-        return s['c2'](out, residual=identity)      # relu(bn2(conv2) + identity)
+        identity = s['ds'](x, out_dtype=act_dtype) if 'ds' in s else x
+        out = s['c1'](x, out_dtype=act_dtype)
+        return s['c2'](out, residual=identity, out_dtype=act_dtype)      # relu(bn2(conv2) + identity)
 
 
 class Bottleneck(HipModule):
@@ -118,11 +118,11 @@ class Bottleneck(HipModule):
             s['ds'] = conv_bn(self.downsample[0], self.downsample[1], False, device)
         return s
 
-    def hip_forward(self, x):
+    def hip_forward(self, x, act_dtype=None):
         s = self.hip_state(x.device)
-        identity = s['ds'](x) if 'ds' in s else x
-        out = s['c2'](s['c1'](x))
-        return s['c3'](out, residual=identity)
+        identity = s['ds'](x, out_dtype=act_dtype) if 'ds' in s else x
+        out = s['c2'](s['c1'](x, out_dtype=act_dtype), out_dtype=act_dtype)
+        return s['c3'](out, residual=identity, out_dtype=act_dtype)
 
 
 class ResNet(HipModule):
@@ -201,14 +201,23 @@ class ResNet(HipModule):
         """conv1 + bn1 + relu on an NHWC input whose channels are already padded to a multiple of 4."""
         return self.hip_state(x_nhwc.device)['stem'](x_nhwc)
 
+    def act_dtype(self):
+        """bf16 mode keeps this network's activations as bf16 tensors in HBM (hip_ops.BF16_ACTIVATIONS) when every
+        channel count is a multiple of 8 (16-byte rows); None = fp32 tensors."""
+        if not (hip_ops.MFMA_BF16 and hip_ops.BF16_ACTIVATIONS) or hip_ops.MFMA_F32X3:
+            return None
+        chans = [self.conv1.out_channels] + [m.out_channels for m in self.modules() if isinstance(m, nn.Conv2d)]
+        return torch.bfloat16 if all(c % 8 == 0 for c in chans) else None
+
     def hip_forward(self, x_nhwc, use_maxpool=True):
-        x = self.hip_stem(x_nhwc)
+        dt = self.act_dtype()
+        x = self.hip_state(x_nhwc.device)['stem'](x_nhwc, out_dtype=dt)
         if use_maxpool:
             x = hip_ops.maxpool3x3s2(x)
         outs = []
         for i, name in enumerate(self.res_layers):
             for blk in getattr(self, name):
-                x = blk.hip_forward(x)
+                x = blk.hip_forward(x, dt)
             if i in self.out_indices:
                 outs.append(x)
         return outs

@@ -173,10 +173,11 @@ class BEVHeightHead(HipModule):
         """x: BEV map NHWC [B, Y, X, C] -> the reference's nested prediction structure."""
         s = self.hip_state(x.device)
         trunk_outs = [x]                                               # bev_height_head.py:97
-        h = self.trunk.hip_stem(x)                                     # conv1 + norm1 + relu, no maxpool (:101-103)
+        dt = self.trunk.act_dtype()                                    # bf16 mode: bf16 tensors between the trunk's layers
+        h = self.trunk.hip_state(x.device)['stem'](x, out_dtype=dt)    # conv1 + norm1 + relu, no maxpool (:101-103)
         for i, layer_name in enumerate(self.trunk.res_layers):         # :104-108
             for blk in getattr(self.trunk, layer_name):
-                h = blk.hip_forward(h)
+                h = blk.hip_forward(h, dt)
             if i in self.trunk.out_indices:
                 trunk_outs.append(h)
         fpn_output = self.neck.hip_forward(trunk_outs)                 # :109

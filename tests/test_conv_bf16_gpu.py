@@ -291,3 +291,60 @@ def test_fused_centerhead_bf16_36_branches_256x256_and_speed():
     us = min(evs[i].elapsed_time(evs[i + 1]) for i in range(5)) * 1e3
     flops = 2.0 * 256 * 256 * (nb * 64 * 576 + sum(counts) * 576)
     print(f"bf16 fused head 36 x 256x256: {us:.0f} us = {flops / us / 1e6:.0f} TFLOP/s algorithmic")
+
+
+# ---------------------------------------------------------------------------------------------- bf16 activations in HBM
+@pytest.mark.parametrize("shape", [
+    # B, cin, H, W, cout, k, stride, pad, dil, residual
+    (2, 64, 20, 28, 256, 1, 1, 0, 1, True),        # expanding 1x1 with residual (ResNet conv3)
+    (1, 256, 19, 23, 64, 1, 1, 0, 1, False),       # reducing 1x1, ragged M
+    (1, 64, 17, 21, 64, 3, 1, 1, 1, False),        # 3x3
+    (2, 128, 18, 22, 128, 3, 2, 1, 1, False),      # strided 3x3
+    (1, 256, 16, 16, 512, 1, 2, 0, 1, False),      # strided 1x1 (downsample)
+    (1, 512, 9, 11, 136, 3, 1, 2, 2, True),        # dilated, cout not a multiple of 32
+    (1, 4, 40, 56, 64, 7, 2, 3, 1, False),         # stem (tap-major K), f32 image in -> bf16 out
+])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+def test_bf16_io_conv(bf16_mode, shape, tile):
+    """sgv3d_conv2d_forward_bf16io: bf16 tensors in (io bit 0), out + residual (bit 1), both; every tile shape, split-K.
+    Reference: float64 convolution of the bf16-rounded operands, epilogue in high precision, one rounding to bf16."""
+    B, cin, H, W, cout, k, stride, pad, dil, with_res = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    conv = hip_ops.PackedConv(w.to(DEV), stride=stride, pad=pad, dil=dil, scale=sc.to(DEV), shift=sh.to(DEV), relu=True)
+    oh, ow = conv.out_hw(H, W)
+    res = torch.randn(B, cout, oh, ow, generator=g) if with_res else None
+    x_bf16_ok = cin % 8 == 0
+    xq = x.bfloat16() if x_bf16_ok else x
+    ref = F.conv2d(xq.double() if x_bf16_ok else x.bfloat16().double(), w.bfloat16().double(), None, stride, pad, dil)
+    ref = ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    if res is not None:
+        ref = ref + res.bfloat16().double()
+    ref = ref.clamp_min(0)
+    scale = max(1.0, float(ref.abs().max()))
+    xin = xq.permute(0, 2, 3, 1).contiguous().to(DEV)                       # bf16 NHWC when the channel count allows it
+    rin = res.bfloat16().permute(0, 2, 3, 1).contiguous().to(DEV) if res is not None else None
+    for sk in (1, 2):
+        y = conv(xin, residual=rin, tile=tile, split_k=sk, out_dtype=torch.bfloat16)
+        assert y.dtype == torch.bfloat16 and tuple(y.shape) == (B, oh, ow, cout)
+        err = float((y.float().permute(0, 3, 1, 2).cpu().double() - ref).abs().max())
+        assert err <= 2.0 ** -8 * scale, (sk, err, scale)                  # half an ulp of bf16 at the output scale (+ f32 noise)
+    if x_bf16_ok and res is None:                                           # bf16 in -> f32 out (the necks)
+        y32 = conv(xin, tile=tile, split_k=1)
+        assert y32.dtype == torch.float32
+        assert float((y32.permute(0, 3, 1, 2).cpu().double() - ref).abs().max()) <= 2e-5 * scale
+    # channel-slice output (concat) in bf16
+    wide = torch.zeros(B, oh, ow, cout + 16, dtype=torch.bfloat16, device=DEV)
+    conv(xin, wide, y_coff=8, residual=rin, tile=tile, split_k=1)
+    assert torch.equal(wide[..., 8:8 + cout], conv(xin, residual=rin, tile=tile, split_k=1, out_dtype=torch.bfloat16))
+    assert float(wide[..., :8].abs().max()) == 0 and float(wide[..., 8 + cout:].abs().max()) == 0
+
+
+def test_bf16_maxpool(bf16_mode):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 21, 30, generator=g).bfloat16()
+    y = hip_ops.maxpool3x3s2(x.permute(0, 2, 3, 1).contiguous().to(DEV))
+    want = F.max_pool2d(x.float(), 3, 2, 1)
+    assert y.dtype == torch.bfloat16 and torch.equal(y.float().permute(0, 3, 1, 2).cpu(), want)

@@ -7,13 +7,16 @@ sys.path.insert(0, ROOT)
 from sgv3d_amd import hip_ops, synthetic as S
 from sgv3d_amd.models.bev_height import BEVHeight
 
-bc, hc = S.r50_256_conf()
+cfg = os.environ.get("CONFIG", "cfg2")
+batch = int(os.environ.get("BATCH", "1"))
+hip_ops.MFMA_BF16 = os.environ.get("DTYPE", "f32") == "bf16"
+bc, hc = {"cfg2": S.r50_256_conf, "cfg3": S.r101_512_conf, "cfg5": S.bsm_r101_256_conf}[cfg]()
 torch.manual_seed(0)
 m = BEVHeight(bc, hc).eval()
-S.randomize_norm_stats_(m, 0)
+S.randomize_norm_stats_(m, 0, residual_gamma=0.3)
 m = m.cuda()
-imgs = S.make_images(1, bc['final_dim'], device='cuda')
-mats = S.make_mats(1, device='cuda')
+imgs = S.make_images(batch, bc['final_dim'], device='cuda')
+mats = S.make_mats(batch, device='cuda')
 with torch.no_grad():
     for _ in range(3):
         m(imgs, mats)
@@ -36,6 +39,6 @@ tot = sum(r[3] for r in rows)
 print(f"{'#':>3} {'us':>8} {'TF':>6} {'%pk':>5}  kernel")
 for i, name, flops, us in rows:
     tf = flops / us / 1e6 if flops else 0
-    print(f"{i:3d} {us:8.1f} {tf:6.1f} {tf / 157.3 * 100:5.1f}  {name}")
+    print(f"{i:3d} {us:8.1f} {tf:6.1f} {tf / (2500.0 if hip_ops.MFMA_BF16 else 157.3) * 100:5.1f}  {name}")
 print("total us", tot)
 json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "layers.json"), "w"))
