@@ -236,7 +236,7 @@ int sgv3d_conv2d_forward_bf16(const sgv3d_conv_desc *desc /*host*/, const float 
 
 /* bf16 ACTIVATIONS in HBM (bf16 mode, the convolution chains of the image backbone / BEV trunk): the same bf16-MFMA
  * convolution reading and / or writing bf16 tensors.  io_flags bit 0: x is bf16 [.., x_ld] (element offsets as in the
- * desc); bit 1: y AND residual are bf16 -- mode NORMAL only, no gate, cout / y_ld / y_coff / res_ld multiples of 8; the
+ * desc); bit 1: y AND residual are bf16 -- mode NORMAL or DECONV, no gate, cout / y_ld / y_coff / res_ld multiples of 8; the
  * epilogue (folded BN, residual, ReLU) runs in fp32 and rounds once to bf16.  Weights, scale, bias stay f32. */
 int sgv3d_conv2d_forward_bf16io(const sgv3d_conv_desc *desc /*host*/, const void *x, const float *w_packed,
                                 const float *scale, const float *bias, const void *residual, const float *gate,
@@ -379,6 +379,18 @@ int sgv3d_centerhead_branches_forward_bf16(int batch, int h, int w, int cin, int
                                            int num_branches, const void *w1_packed, const float *scale1,
                                            const float *shift1, int total_out, const void *w2_packed, const float *bias2,
                                            const int32_t *out_begin, float *out, void *stream);
+
+/* The same with the shared map given as a bf16 tensor (bf16-activation mode: x_ld / x_coff multiples of 8). */
+int sgv3d_centerhead_branches_forward_bf16x(int batch, int h, int w, int cin, int x_ld, int x_coff, const void *x_bf16,
+                                            int num_branches, const void *w1_packed, const float *scale1,
+                                            const float *shift1, int total_out, const void *w2_packed, const float *bias2,
+                                            const int32_t *out_begin, float *out, void *stream);
+
+/* Tools / tests: select_plain(1) runs the single-role variant of the bf16 head kernel (4 waves, phases of a branch one after
+ * the other; bitwise the same results) instead of the warp-specialised default; debug_stamps(buf) makes workgroup 0 of the
+ * single-role variant write 4 * num_branches + 2 cycle-counter stamps into the device buffer (NULL switches it off). */
+void sgv3d_centerhead_bf16_select_plain(int plain);
+void sgv3d_centerhead_bf16_debug_stamps(void *buf);
 
 /* ================================================================================================
  * Box decode + circle NMS  

@@ -776,13 +776,23 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
         float *stage = smem + wave * (32 * SLD);                          // the operand buffers are dead: the loop ended on a barrier
         __bf16 *const yb = reinterpret_cast<__bf16 *>(a.y);
         const int pc = lane & 3, pp = lane >> 2;
+        const bool deconv = (a.mode & kConvModeMask) == SGV3D_CONV_DECONV;
 #pragma unroll
         for (int nt = 0; nt < WTN; ++nt) {
-            const int ch = pcol0 + nt * 32 + 8 * pc;
+            const int ch = pcol0 + nt * 32 + 8 * pc;                      // GEMM column of this lane's 8-channel chunk
             const bool ch_ok = ch < a.N;
+            // DECONV (kernel == stride transposed conv as a 1x1 GEMM): column = tap * cout + co, the chunk stays inside one
+            // tap because cout % 8 == 0; input pixel (ih, iw) lands at output pixel (ih ks + dy, iw ks + dx)
+            int co = ch, dy = 0, dx = 0;
+            if (deconv) {
+                const int tap = ch / a.cout;
+                co = ch - tap * a.cout;
+                dy = tap / a.ks;
+                dx = tap - dy * a.ks;
+            }
             f32x4n sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
-            if (ch_ok && a.scale) { sc0 = *reinterpret_cast<const f32x4n *>(a.scale + ch); sc1 = *reinterpret_cast<const f32x4n *>(a.scale + ch + 4); }
-            if (ch_ok && a.bias) { sh0 = *reinterpret_cast<const f32x4n *>(a.bias + ch); sh1 = *reinterpret_cast<const f32x4n *>(a.bias + ch + 4); }
+            if (ch_ok && a.scale) { sc0 = *reinterpret_cast<const f32x4n *>(a.scale + co); sc1 = *reinterpret_cast<const f32x4n *>(a.scale + co + 4); }
+            if (ch_ok && a.bias) { sh0 = *reinterpret_cast<const f32x4n *>(a.bias + co); sh1 = *reinterpret_cast<const f32x4n *>(a.bias + co + 4); }
 #pragma unroll
             for (int mt = 0; mt < WTM; ++mt) {
 #pragma unroll
@@ -811,8 +821,14 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
 #pragma unroll
                             for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], 0.f); v1[i] = fmaxf(v1[i], 0.f); }
                         }
+                        size_t yi = (size_t)row * a.y_ld;
+                        if (deconv) {
+                            const int t = row / a.m_w, iw = row - t * a.m_w;
+                            const int img = t / a.m_h, ih = t - img * a.m_h;
+                            yi = ((size_t)(img * a.out_h + ih * a.ks + dy) * a.out_w + (iw * a.ks + dx)) * a.y_ld;
+                        }
                         const bf16x4 o0 = __builtin_convertvector(v0, bf16x4), o1 = __builtin_convertvector(v1, bf16x4);
-                        *reinterpret_cast<bf16x8 *>(yb + (size_t)row * a.y_ld + a.y_coff + ch) = __builtin_shufflevector(o0, o1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        *reinterpret_cast<bf16x8 *>(yb + yi + a.y_coff + co) = __builtin_shufflevector(o0, o1, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1085,7 +1101,8 @@ static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const f
     SGV3D_REQUIRE(d && x && w_packed && y, "conv2d_forward: null pointer");
     SGV3D_REQUIRE(io == 0 || bf16 == 1, "conv2d_forward: bf16 tensors need the bf16 MFMA entry point");
     if (io & 2) {
-        SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL && gate == nullptr, "conv2d_forward_bf16io: bf16 output in NORMAL mode without gate only");
+        SGV3D_REQUIRE((d->mode == SGV3D_CONV_NORMAL || d->mode == SGV3D_CONV_DECONV) && gate == nullptr,
+                      "conv2d_forward_bf16io: bf16 output in NORMAL / DECONV mode without gate only");
         SGV3D_REQUIRE(d->cout % 8 == 0 && d->y_ld % 8 == 0 && d->y_coff % 8 == 0 && (residual == nullptr || d->res_ld % 8 == 0),
                       "conv2d_forward_bf16io: cout / y_ld / y_coff / res_ld must be multiples of 8 (16-byte rows of bf16)");
         SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0 &&
@@ -1160,7 +1177,7 @@ static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const f
     }
     const int tile = d->tile ? d->tile : pick_tile(M, a.N);
     hipStream_t st = as_stream(stream);
-    if (io & 2) a.mode |= kConvYBf16 | kConvResBf16;       // (NORMAL mode, checked above)
+    if (io & 2) a.mode |= kConvYBf16 | kConvResBf16;       // (NORMAL / DECONV mode, checked above)
     if (io) {
         switch (tile) {
             case SGV3D_TILE_128x128: return launch_bf16io<2, 2>(a, st, io);

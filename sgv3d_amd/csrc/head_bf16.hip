@@ -87,6 +87,7 @@ struct HeadBf16Args {
     float *out;                // NCHW [B, total_out, H, W]
     int H, W, x_ld, x_coff, nb, total_out, tiles_x, tiles_y;
     long long *dbg;            // optional [4 * nb + 2] timestamps of workgroup 0 (tools only), else NULL
+    int x_bf16;                // 1: x is a bf16 tensor (bf16-activation mode)
 };
 
 __global__ __launch_bounds__(256, 1) void head_bf16_kernel(const HeadBf16Args a) {
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(256, 1) void head_bf16_kernel(const HeadBf16Args a)
 
     // ---- input patch: 400 pixels x 8 chunks of 8 channels (fp32 -> bf16); zeros outside the image ---------------------
     {
-        const float *xb = a.x + (size_t)b * a.H * a.W * a.x_ld + a.x_coff;
+        const size_t xoff0 = (size_t)b * a.H * a.W * a.x_ld + a.x_coff;
+        const float *xb = a.x + xoff0;
         for (int e = tid; e < kIP * kIP * 8; e += 256) {        // e = pixel * 8 + chunk: a pixel's 256 B are read by 8 lanes
             const int p = e >> 3, chunk = e & 7;
             const int iy = p / kIP, ix = p - iy * kIP;
@@ -112,10 +114,15 @@ __global__ __launch_bounds__(256, 1) void head_bf16_kernel(const HeadBf16Args a)
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                const float *src = xb + ((size_t)gy * a.W + gx) * a.x_ld + chunk * 8;
-                const f32x4 lo = *reinterpret_cast<const f32x4 *>(src), hi = *reinterpret_cast<const f32x4 *>(src + 4);
-                const bf16x4 l4 = __builtin_convertvector(lo, bf16x4), h4 = __builtin_convertvector(hi, bf16x4);
-                v = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+                const size_t eoff = ((size_t)gy * a.W + gx) * a.x_ld + chunk * 8;
+                if (a.x_bf16) {
+                    v = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const __bf16 *>(a.x) + xoff0 + eoff);
+                } else {
+                    const float *src = xb + eoff;
+                    const f32x4 lo = *reinterpret_cast<const f32x4 *>(src), hi = *reinterpret_cast<const f32x4 *>(src + 4);
+                    const bf16x4 l4 = __builtin_convertvector(lo, bf16x4), h4 = __builtin_convertvector(hi, bf16x4);
+                    v = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
             }
             *reinterpret_cast<bf16x8 *>(in_s + iy * kInRowB + chunk * kInChunkB + ix * 16) = v;
         }
@@ -306,9 +313,241 @@ __global__ __launch_bounds__(256, 1) void head_bf16_kernel(const HeadBf16Args a)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Warp-specialised variant (the default): 8 waves.  Waves 0..3 run layer 1 + its epilogue of branch i while waves 4..7 run
+// layer 2 + the stores of branch i-1 from the other half of a double-buffered hidden image, and stage the folded-BN
+// vectors / final-layer weights of the coming branches.  One workgroup barrier per branch.  The layer-2 phase (LDS
+// bandwidth bound, 4.0 k cycles) and the loads hide behind layer 1 + epilogue (MFMA / VALU bound, 11.3 k cycles).
+// Same arithmetic in the same order as head_bf16_kernel: results are bitwise identical.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kWsHidRows = kHP + 1;                               // 18 real rows + 1 row all padding pixels are parked in
+constexpr int kWsHidBytes = kWsHidRows * kHidRowB;                // 43 776
+constexpr int kWsLds = kInBytes + 2 * kWsHidBytes + 2 * kW2Elems * 2 + 2 * 2 * kCH * 4;   // 51 200 + 87 552 + 9 216 + 1 024
+
+__global__ __launch_bounds__(512, 1) void head_bf16_ws_kernel(const HeadBf16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *in_s = smem;
+    char *hid_s = smem + kInBytes;                                                     // [2][kWsHidBytes]
+    __bf16 *w2_s = reinterpret_cast<__bf16 *>(smem + kInBytes + 2 * kWsHidBytes);      // [2][kW2Elems]
+    float *bn_s = reinterpret_cast<float *>(smem + kInBytes + 2 * kWsHidBytes + 2 * kW2Elems * 2);   // [2][scale 64 | shift 64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool l1 = wave < 4;                                       // wave-uniform role
+    const int gw = wave & 3, gt = tid & 255;                        // wave / thread index inside the role group
+    const int r = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int y0 = ty * kTP, x0 = tx * kTP;
+    {
+        const size_t xoff0 = (size_t)b * a.H * a.W * a.x_ld + a.x_coff;
+        const float *xb = a.x + xoff0;
+        for (int e = tid; e < kIP * kIP * 8; e += 512) {
+            const int p = e >> 3, chunk = e & 7;
+            const int iy = p / kIP, ix = p - iy * kIP;
+            const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const size_t eoff = ((size_t)gy * a.W + gx) * a.x_ld + chunk * 8;
+                if (a.x_bf16) {
+                    v = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const __bf16 *>(a.x) + xoff0 + eoff);
+                } else {
+                    const float *src = xb + eoff;
+                    const f32x4 lo = *reinterpret_cast<const f32x4 *>(src), hi = *reinterpret_cast<const f32x4 *>(src + 4);
+                    const bf16x4 l4 = __builtin_convertvector(lo, bf16x4), h4 = __builtin_convertvector(hi, bf16x4);
+                    v = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+            *reinterpret_cast<bf16x8 *>(in_s + iy * kInRowB + chunk * kInChunkB + ix * 16) = v;
+        }
+        if (tid < 2 * kCH) bn_s[tid] = tid < kCH ? a.scale1[tid] : a.shift1[tid - kCH];           // branch 0
+    }
+    // layer-1 geometry (waves 0..3; computed by everybody, cheap)
+    const char *ain[kMT];
+    int hoff[kMT];                     // byte offset inside one hidden buffer
+    bool hin[kMT];
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) {
+        const int m = gw * (kMT * 32) + mt * 32 + r;
+        const int hy = m / kHP, hx = m - hy * kHP;
+        const int hyc = hy < kHP ? hy : kHP - 1;
+        ain[mt] = in_s + hyc * kInRowB + h * kInChunkB + hx * 16;
+        hoff[mt] = (hy < kHP ? hy : kHP) * kHidRowB + hx * 16 + h * 8;        // padding pixels -> row 18 (never read)
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        hin[mt] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    }
+    const int col = lane & 15, kq = lane >> 4;
+    const int a2off = (gw * 4) * kHidRowB + kq * kHidChunkB + col * 16;
+    const int b2off = (col & 3) * 64 + kq * 8;
+    const bf16x8 *w1l = reinterpret_cast<const bf16x8 *>(a.w1) + lane;
+    bf16x8 bq[2][4][2];
+    if (l1) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bq[0][ks][nt] = w1l[(size_t)ks * 2 * 64 + nt * 64];
+    }
+    __syncthreads();
+
+    for (int it = 0; it <= a.nb; ++it) {
+        if (l1) {
+            if (it < a.nb) {
+                const int br = it;
+                char *hbuf = hid_s + (br & 1) * kWsHidBytes;
+                const float *bnb = bn_s + (br & 1) * 2 * kCH;
+                f32x16 acc[kMT][2];
+#pragma unroll
+                for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+                bf16x8 af[2][kMT];
+#pragma unroll
+                for (int mt = 0; mt < kMT; ++mt) af[0][mt] = *reinterpret_cast<const bf16x8 *>(ain[mt]);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int cur = tap & 1, nxt = cur ^ 1;
+                    {
+                        int nb_ = br, nt_ = tap + 1;
+                        if (nt_ == 9) { nt_ = 0; nb_ = br + 1 < a.nb ? br + 1 : br; }
+                        const size_t base = (size_t)((nb_ * 9 + nt_) * 4) * 2 * 64;
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt) bq[nxt][ks][nt] = w1l[base + (size_t)ks * 2 * 64 + nt * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int ac = (tap * 4 + ks) & 1, an = ac ^ 1;
+                        if (!(tap == 8 && ks == 3)) {
+                            const int t2 = ks == 3 ? tap + 1 : tap, k2 = ks == 3 ? 0 : ks + 1;
+                            const int off2 = (t2 / 3) * kInRowB + (t2 % 3) * 16 + k2 * 2 * kInChunkB;
+#pragma unroll
+                            for (int mt = 0; mt < kMT; ++mt) af[an][mt] = *reinterpret_cast<const bf16x8 *>(ain[mt] + off2);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[cur][ks][nt], af[ac][mt], acc[mt][nt], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) bq[0][ks][nt] = bq[1][ks][nt];
+                // epilogue: BN + ReLU -> hidden buffer (br & 1); its previous reader (layer 2 of branch br - 2) finished
+                // before the barrier that ended iteration br - 1
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ch = nt * 32 + 8 * g + 4 * h;
+                        const f32x4 sc = *reinterpret_cast<const f32x4 *>(bnb + ch);
+                        const f32x4 sh = *reinterpret_cast<const f32x4 *>(bnb + kCH + ch);
+#pragma unroll
+                        for (int mt = 0; mt < kMT; ++mt) {
+                            f32x4 v;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaxf(acc[mt][nt][4 * g + i] * sc[i] + sh[i], 0.f);
+                            union { bf16x4 b; unsigned long long u; } pk;
+                            pk.b = __builtin_convertvector(v, bf16x4);
+                            pk.u = hin[mt] ? pk.u : 0ull;
+                            *reinterpret_cast<unsigned long long *>(hbuf + hoff[mt] + (nt * 4 + g) * kHidChunkB) = pk.u;
+                        }
+                    }
+            }
+        } else {
+            // ---- staging for later iterations: folded BN of branch it + 1 (read by the epilogue of iteration it + 1) and the
+            // final-layer weights of branch it (read by layer 2 in iteration it + 1)
+            if (it + 1 < a.nb && gt < 2 * kCH)
+                bn_s[((it + 1) & 1) * 2 * kCH + gt] = gt < kCH ? a.scale1[(it + 1) * kCH + gt] : a.shift1[(it + 1) * kCH + gt - kCH];
+            bf16x8 w2pre[2];
+            if (it < a.nb) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = gt + u * 256;
+                    if (e < kW2Elems / 8) w2pre[u] = reinterpret_cast<const bf16x8 *>(a.w2 + (size_t)it * kW2Elems)[e];
+                }
+            }
+            if (it >= 1) {
+                const int br = it - 1;
+                const char *hbuf = hid_s + (br & 1) * kWsHidBytes;
+                const __bf16 *w2b = w2_s + (br & 1) * kW2Elems;
+                const int ob = a.out_begin[br], c = a.out_begin[br + 1] - ob;
+                f32x4 acc2[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc2[rr][i] = 0.f;
+                bf16x8 bf[18];
+#pragma unroll
+                for (int st = 0; st < 18; ++st) bf[st] = *reinterpret_cast<const bf16x8 *>(w2b + b2off + (st >> 1) * 256 + (st & 1) * 32);
+                constexpr int kAhead = 3;
+                bf16x8 a2[kAhead + 1][4];
+#define HEAD_A2W(st_, rr_) *reinterpret_cast<const bf16x8 *>(hbuf + a2off + ((rr_) + ((st_) >> 1) / 3) * kHidRowB + (((st_) >> 1) % 3) * 16 + ((st_) & 1) * 4 * kHidChunkB)
+#pragma unroll
+                for (int st = 0; st < kAhead; ++st)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) a2[st][rr] = HEAD_A2W(st, rr);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int st = 0; st < 18; ++st) {
+                    if (st + kAhead < 18) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) a2[(st + kAhead) % (kAhead + 1)][rr] = HEAD_A2W(st + kAhead, rr);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        acc2[rr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[st % (kAhead + 1)][rr], bf[st], acc2[rr], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef HEAD_A2W
+                if (col < c) {
+                    const float bias = a.bias2[ob + col];
+                    float *plane = a.out + ((size_t)b * a.total_out + ob + col) * a.H * a.W;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int gy = y0 + gw * 4 + rr, gx = x0 + kq * 4;
+                        if (gy < a.H) {
+                            float *dst = plane + (size_t)gy * a.W + gx;
+                            if (gx + 3 < a.W && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+                                f32x4 v = acc2[rr];
+                                v += bias;
+                                *reinterpret_cast<f32x4 *>(dst) = v;
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (gx + i < a.W) dst[i] = acc2[rr][i] + bias;
+                            }
+                        }
+                    }
+                }
+            }
+            if (it < a.nb) {                      // w2 of branch `it` -> buffer it & 1 (its previous content, branch it - 2, was consumed in iteration it - 1)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = gt + u * 256;
+                    if (e < kW2Elems / 8) reinterpret_cast<bf16x8 *>(w2_s + (it & 1) * kW2Elems)[e] = w2pre[u];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 static long long *g_head_dbg = nullptr;
+static bool g_head_plain = false;
+// tools / tests only: 1 selects the single-role kernel (4 waves, the phases of a branch run one after the other)
+extern "C" void sgv3d_centerhead_bf16_select_plain(int plain) { g_head_plain = plain != 0; }
 // tools only: device buffer of 4 * nb + 2 int64 that receives cycle-counter stamps of workgroup 0 (NULL switches it off)
 extern "C" void sgv3d_centerhead_bf16_debug_stamps(void *buf) { g_head_dbg = static_cast<long long *>(buf); }
 
@@ -336,13 +575,14 @@ extern "C" int sgv3d_centerhead_bf16_pack_weight2(const float *w2, const int32_t
     return check_launch("head_bf16_pack_w2_kernel");
 }
 
-extern "C" int sgv3d_centerhead_branches_forward_bf16(int batch, int h, int w, int cin, int x_ld, int x_coff, const float *x,
-                                                      int num_branches, const void *w1_packed, const float *scale1,
-                                                      const float *shift1, int total_out, const void *w2_packed,
-                                                      const float *bias2, const int32_t *out_begin, float *out, void *stream) {
+static int head_bf16_launch(int batch, int h, int w, int cin, int x_ld, int x_coff, const float *x, int x_is_bf16,
+                            int num_branches, const void *w1_packed, const float *scale1,
+                            const float *shift1, int total_out, const void *w2_packed,
+                            const float *bias2, const int32_t *out_begin, float *out, void *stream) {
     SGV3D_REQUIRE(batch > 0 && h > 0 && w > 0 && num_branches > 0 && total_out > 0, "centerhead_branches_forward_bf16: bad shape");
     SGV3D_REQUIRE(cin == kCH, "centerhead_branches_forward_bf16: built for %d input channels (got %d)", kCH, cin);
     SGV3D_REQUIRE(x_ld >= x_coff + cin && x_ld % 4 == 0 && x_coff % 4 == 0, "centerhead_branches_forward_bf16: bad channel slice");
+    SGV3D_REQUIRE(!x_is_bf16 || (x_ld % 8 == 0 && x_coff % 8 == 0), "centerhead_branches_forward_bf16: bf16 input needs x_ld / x_coff multiples of 8");
     SGV3D_REQUIRE(x && w1_packed && scale1 && shift1 && w2_packed && bias2 && out_begin && out, "centerhead_branches_forward_bf16: null pointer");
     SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w1_packed) & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(w2_packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(scale1) & 15) == 0 &&
@@ -355,9 +595,33 @@ extern "C" int sgv3d_centerhead_branches_forward_bf16(int batch, int h, int w, i
     a.out_begin = out_begin; a.out = out; a.H = h; a.W = w; a.x_ld = x_ld; a.x_coff = x_coff; a.nb = num_branches;
     a.total_out = total_out; a.tiles_x = cdiv(w, kTP); a.tiles_y = cdiv(h, kTP);
     a.dbg = g_head_dbg;
+    a.x_bf16 = x_is_bf16 ? 1 : 0;
+    if (g_head_dbg == nullptr && !g_head_plain) {      // default: the warp-specialised kernel (layer 2 overlapped with layer 1)
+        static PerDeviceSize lds_ws;
+        if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&head_bf16_ws_kernel), kWsLds, lds_ws))
+            return fail(SGV3D_ELAUNCH, "centerhead_branches_forward_bf16: cannot raise the dynamic LDS limit to %d", kWsLds);
+        hipLaunchKernelGGL(head_bf16_ws_kernel, dim3(a.tiles_x * a.tiles_y, batch), dim3(512), kWsLds, as_stream(stream), a);
+        return check_launch("head_bf16_ws_kernel");
+    }
     static PerDeviceSize lds_set;
     if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&head_bf16_kernel), kHeadLds, lds_set))
         return fail(SGV3D_ELAUNCH, "centerhead_branches_forward_bf16: cannot raise the dynamic LDS limit to %d", kHeadLds);
     hipLaunchKernelGGL(head_bf16_kernel, dim3(a.tiles_x * a.tiles_y, batch), dim3(256), kHeadLds, as_stream(stream), a);
     return check_launch("head_bf16_kernel");
+}
+
+extern "C" int sgv3d_centerhead_branches_forward_bf16(int batch, int h, int w, int cin, int x_ld, int x_coff, const float *x,
+                                                      int num_branches, const void *w1_packed, const float *scale1,
+                                                      const float *shift1, int total_out, const void *w2_packed,
+                                                      const float *bias2, const int32_t *out_begin, float *out, void *stream) {
+    return head_bf16_launch(batch, h, w, cin, x_ld, x_coff, x, 0, num_branches, w1_packed, scale1, shift1, total_out, w2_packed,
+                            bias2, out_begin, out, stream);
+}
+
+extern "C" int sgv3d_centerhead_branches_forward_bf16x(int batch, int h, int w, int cin, int x_ld, int x_coff, const void *x_bf16,
+                                                       int num_branches, const void *w1_packed, const float *scale1,
+                                                       const float *shift1, int total_out, const void *w2_packed,
+                                                       const float *bias2, const int32_t *out_begin, float *out, void *stream) {
+    return head_bf16_launch(batch, h, w, cin, x_ld, x_coff, static_cast<const float *>(x_bf16), 1, num_branches, w1_packed, scale1,
+                            shift1, total_out, w2_packed, bias2, out_begin, out, stream);
 }

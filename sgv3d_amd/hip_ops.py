@@ -239,7 +239,7 @@ class PackedConv:
             if not MFMA_BF16 or MFMA_F32X3:
                 raise _lib.SGV3DError("bf16 tensors are only handled in bf16 mode (hip_ops.MFMA_BF16)")
             if io & 2:
-                assert not (nchw_out or group_planes or self.transposed or gate is not None), "bf16 output: NORMAL layout only"
+                assert not (nchw_out or group_planes or gate is not None), "bf16 output: NORMAL / transposed-conv layouts only"
                 assert residual is None or residual.dtype == torch.bfloat16
             else:
                 assert residual is None or residual.dtype == torch.float32
@@ -641,13 +641,15 @@ def centerhead_branches_bf16(x, packed, scale1, shift1, b2, out_begin, num_branc
     """bf16-MFMA version of ``centerhead_branches``: x NHWC f32 [B,H,W,ld] (channels [x_coff, x_coff+64)), ``packed`` from
     ``pack_centerhead_bf16``, scale1 / shift1 [nb*64] folded BN, b2 [sum_c] -> NCHW f32 [B,sum_c,H,W]."""
     B, H, W, ld = (int(s) for s in x.shape)
-    assert x.is_contiguous() and x.dtype == torch.float32
+    assert x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)
     total = int(b2.shape[0])
     if out is None:
         out = torch.empty(B, total, H, W, dtype=torch.float32, device=x.device)
     flops = 2.0 * B * H * W * (num_branches * 64 * 64 * 9 + total * 9 * 64)
+    lib = _lib.load()
+    fwd = lib.sgv3d_centerhead_branches_forward_bf16x if x.dtype == torch.bfloat16 else lib.sgv3d_centerhead_branches_forward_bf16
     with torch.cuda.device(x.device), prof("conv_head_bf16", flops):
-        rc = _lib.load().sgv3d_centerhead_branches_forward_bf16(
+        rc = fwd(
             B, H, W, 64, ld, int(x_coff), x.data_ptr(), int(num_branches), packed[0].data_ptr(), scale1.data_ptr(),
             shift1.data_ptr(), total, packed[1].data_ptr(), b2.data_ptr(), out_begin.data_ptr(), out.data_ptr(), _st(x))
     _lib.check(rc, "sgv3d_centerhead_branches_forward_bf16")

@@ -267,15 +267,18 @@ class SECONDFPN(HipModule):
                                         device=device))
         return convs
 
-    def hip_forward(self, feats, out=None):
+    def hip_forward(self, feats, out=None, out_dtype=None):
         """feats: list of NHWC maps -> one NHWC map [B, H, W, sum(out_channels)] (levels written
-        straight into their channel slice: no torch.cat)."""
+        straight into their channel slice: no torch.cat).  ``out_dtype=torch.bfloat16`` (bf16-activation mode, every
+        level's channel count a multiple of 8): the concatenated map is a bf16 tensor."""
         convs = self.hip_state(feats[0].device)
         B, h0, w0, _ = feats[0].shape
         oh, ow = convs[0].out_hw(int(h0), int(w0))
         total = sum(self.out_channels)
         if out is None:
-            out = torch.empty(B, oh, ow, total, dtype=torch.float32, device=feats[0].device)
+            if out_dtype == torch.bfloat16 and any(c % 8 for c in self.out_channels):
+                out_dtype = None
+            out = torch.empty(B, oh, ow, total, dtype=out_dtype or torch.float32, device=feats[0].device)
         off = 0
         for conv, f, oc in zip(convs, feats, self.out_channels):
             assert conv.out_hw(int(f.shape[1]), int(f.shape[2])) == (oh, ow), \

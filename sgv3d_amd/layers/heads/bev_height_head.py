@@ -180,8 +180,10 @@ class BEVHeightHead(HipModule):
                 h = blk.hip_forward(h, dt)
             if i in self.trunk.out_indices:
                 trunk_outs.append(h)
-        fpn_output = self.neck.hip_forward(trunk_outs)                 # :109
-        shared = s['shared'](fpn_output)                               # CenterHead.forward_single
+        # bf16-activation mode with the fused bf16 head: neck output and shared map stay bf16 tensors as well
+        nd = dt if (dt is not None and hip_ops.MFMA_BF16 and s.get('w1_bf16') is not None) else None
+        fpn_output = self.neck.hip_forward(trunk_outs, out_dtype=nd)   # :109
+        shared = s['shared'](fpn_output, out_dtype=nd if fpn_output.dtype == torch.bfloat16 else None)   # CenterHead.forward_single
         if hip_ops.MFMA_BF16 and s.get('w1_bf16') is not None:
             # bf16 matrix cores: both branch layers in one kernel, hidden maps in LDS as bf16
             out = hip_ops.centerhead_branches_bf16(shared, s['w1_bf16'], s['first'].scale, s['first'].shift, s['b2'],

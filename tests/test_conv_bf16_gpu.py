@@ -238,6 +238,13 @@ def test_fused_centerhead_bf16(B, H, W, counts):
     assert err < 2e-3 * scale, (err, scale)
     again = hip_ops.centerhead_branches_bf16(x.to(DEV), packed, sc.to(DEV), sh.to(DEV), b2.to(DEV), ob, nb)
     assert torch.equal(out, again)
+    from sgv3d_amd import _lib
+    _lib.load().sgv3d_centerhead_bf16_select_plain(1)           # the single-role variant: same arithmetic, same order
+    try:
+        plain = hip_ops.centerhead_branches_bf16(x.to(DEV), packed, sc.to(DEV), sh.to(DEV), b2.to(DEV), ob, nb)
+    finally:
+        _lib.load().sgv3d_centerhead_bf16_select_plain(0)
+    assert torch.equal(out, plain)
     # input channels taken as a slice of a wider buffer
     wide = torch.randn(B, H, W, 96).to(DEV)
     wide[..., 16:80] = x.to(DEV)
@@ -348,3 +355,27 @@ def test_bf16_maxpool(bf16_mode):
     y = hip_ops.maxpool3x3s2(x.permute(0, 2, 3, 1).contiguous().to(DEV))
     want = F.max_pool2d(x.float(), 3, 2, 1)
     assert y.dtype == torch.bfloat16 and torch.equal(y.float().permute(0, 3, 1, 2).cpu(), want)
+
+
+@pytest.mark.parametrize("cin,cout,ks,H,W,x_bf16", [(64, 32, 2, 9, 11, True), (160, 64, 4, 6, 7, True), (80, 64, 1, 10, 12, False),
+                                                    (640, 64, 8, 4, 5, True)])
+def test_bf16_io_transposed_conv(bf16_mode, cin, cout, ks, H, W, x_bf16):
+    """SECONDFPN deblocks (ConvTranspose2d, kernel == stride) writing a channel slice of a bf16 concat buffer."""
+    g = torch.Generator().manual_seed(cin + ks)
+    B = 2
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cin, cout, ks, ks, generator=g) / cin ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    conv = hip_ops.PackedConv(w.to(DEV), stride=ks, transposed=True, scale=sc.to(DEV), shift=sh.to(DEV), relu=True)
+    ref = F.conv_transpose2d(x.bfloat16().double(), w.bfloat16().double(), None, stride=ks)
+    ref = (ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).clamp_min(0)
+    xin = (x.bfloat16() if x_bf16 else x).permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = torch.zeros(B, H * ks, W * ks, cout + 24, dtype=torch.bfloat16, device=DEV)
+    for tile in (1, 2, 3, 4):
+        out.zero_()
+        conv(xin, out, y_coff=16, tile=tile, split_k=1)
+        got = out[..., 16:16 + cout].float().permute(0, 3, 1, 2).cpu().double()
+        assert float((got - ref).abs().max()) <= 2.0 ** -8 * max(1.0, float(ref.abs().max())), tile
+        assert float(out[..., :16].abs().max()) == 0 and float(out[..., 16 + cout:].abs().max()) == 0
+    conv(xin, out, y_coff=16, tile=4, split_k=2)
+    assert float((out[..., 16:16 + cout].float().permute(0, 3, 1, 2).cpu().double() - ref).abs().max()) <= 2.0 ** -8 * max(1.0, float(ref.abs().max()))

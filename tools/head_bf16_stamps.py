@@ -4,8 +4,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sgv3d_amd import _lib, hip_ops
 lib = _lib.load()
-lib.sgv3d_centerhead_bf16_debug_stamps.argtypes = [ctypes.c_void_p]
-lib.sgv3d_centerhead_bf16_debug_stamps.restype = None
 H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 counts = []
 for nc in (1, 2, 2, 1, 2, 2):
@@ -18,8 +16,20 @@ w2 = (torch.randn(sum(counts), 3, 3, 64, generator=g) / 24).cuda()
 ob = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).cuda()
 packed = hip_ops.pack_centerhead_bf16(w1, w2, ob)
 sc, sh, b2 = torch.ones(nb * 64).cuda(), torch.zeros(nb * 64).cuda(), torch.zeros(sum(counts)).cuda()
-for _ in range(3):
-    hip_ops.centerhead_branches_bf16(x, packed, sc, sh, b2, ob, nb)
+def timed(tag):
+    for _ in range(3):
+        hip_ops.centerhead_branches_bf16(x, packed, sc, sh, b2, ob, nb)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    evs[0].record()
+    for i in range(5):
+        hip_ops.centerhead_branches_bf16(x, packed, sc, sh, b2, ob, nb)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    print(f"{tag}: {min(evs[i].elapsed_time(evs[i + 1]) for i in range(5)) * 1e3:.0f} us")
+timed("warp-specialised kernel (default)")
+lib.sgv3d_centerhead_bf16_select_plain(1)
+timed("single-role kernel")
+lib.sgv3d_centerhead_bf16_select_plain(0)
 dbg = torch.zeros(4 * nb + 2, dtype=torch.int64).cuda()
 lib.sgv3d_centerhead_bf16_debug_stamps(dbg.data_ptr())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
