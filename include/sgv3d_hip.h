@@ -575,6 +575,31 @@ int sgv3d_kitti_eval_curves(int num_images, const int32_t *gt_num, const int32_t
                             double min_overlap, int compute_aos, long long num_valid_gt, int num_threads,
                             double *precision, double *recall, double *orientation, int *num_thresholds);
 
+/* ================================================================================================
+ * Training-mode forms of the small layers (csrc/train_misc.hip)
+ * ================================================================================================ */
+
+/* nn.MaxPool2d(3, 2, 1) of the image ResNet stem with the arg-max tap (0..8, row-major in the window) kept as one byte per
+ * output element, and its adjoint in gather form (deterministic; ties: first maximum in window order, as torch).
+ *   x f32 NHWC [B, H, W, C] (C % 4 == 0) -> y f32 [B, OH, OW, C], argmax u8 [B, OH, OW, C]
+ *   grad_out f32 [B, OH, OW, C] -> grad_in f32 [B, H, W, C] (fully written) */
+int sgv3d_maxpool3x3s2_train_forward(int batch, int in_h, int in_w, int channels, const float *x, float *y,
+                                     unsigned char *argmax, void *stream);
+int sgv3d_maxpool3x3s2_backward(int batch, int in_h, int in_w, int channels, const unsigned char *argmax,
+                                const float *grad_out, float *grad_in, void *stream);
+
+/* Weight gradient of y = x @ w^T (sgv3d_dense): grad_w[n][k] = sum_b grad_out[b][n] * x[b][k]; x [batch, k], grad_out
+ * [batch, n], grad_w [n, k].  (The data gradient is sgv3d_dense with the transposed weight.) */
+int sgv3d_dense_backward_weight(int batch, int k, int n, const float *x, const float *grad_out, float *grad_w, void *stream);
+
+/* Adjoint of sgv3d_deform_im2col3x3 (mmcv DeformConv2dPack sampling, layers/backbones/lss_fpn.py:190-198):
+ *   grad_col f32 in the layout of the forward's `col`  ->  grad_x f32 NHWC [B, H, W, C] (zeroed here, then accumulated
+ *   with float atomics like mmcv's deformable_col2im: order-nondeterministic) and grad_offset f32 [B, H, W, grad_off_ld]
+ *   (channels 2 t = d/dy, 2 t + 1 = d/dx of tap t; channel sums in fixed order). */
+int sgv3d_deform_im2col3x3_backward(int batch, int h, int w, int channels, int groups, const float *x,
+                                    const float *offset, int off_ld, const float *grad_col, float *grad_x,
+                                    float *grad_offset, int grad_off_ld, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,10 @@ _PROTOS = {
                                              c_void_p, c_size_t, c_void_p]),
     "sgv3d_upsample_bilinear2x_backward": (c_int, [c_int] * 4 + [c_void_p] * 3),
     "sgv3d_add_mul_sigmoid_backward": (c_int, [c_ll] + [c_void_p] * 6),
+    "sgv3d_maxpool3x3s2_train_forward": (c_int, [c_int] * 4 + [c_void_p] * 4),
+    "sgv3d_maxpool3x3s2_backward": (c_int, [c_int] * 4 + [c_void_p] * 4),
+    "sgv3d_dense_backward_weight": (c_int, [c_int] * 3 + [c_void_p] * 4),
+    "sgv3d_deform_im2col3x3_backward": (c_int, [c_int] * 5 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "sgv3d_rotate_iou_pairs": (c_int, [c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p]),
     "sgv3d_kitti_eval_curves": (c_int, [c_int] + [c_void_p] * 9 + [c_int, ctypes.c_double, c_int, c_ll, c_int] + [c_void_p] * 4),
 }

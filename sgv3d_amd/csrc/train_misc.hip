@@ -1,0 +1,225 @@
+// Training-mode kernels of the layers that ran as ATen operators in round 1:
+//
+//   sgv3d_maxpool3x3s2_train_forward / _backward   nn.MaxPool2d(3, 2, 1) of the image ResNet stem (mmdet ResNet, built at
+//        layers/backbones/lss_fpn.py:296) with the arg-max tap kept as one byte per output, and its adjoint in GATHER form:
+//        every input element sums the (at most four) windows that selected it -- deterministic, no atomics.  Ties go to the
+//        first maximum in row-major window order, as torch's kernel does.
+//   sgv3d_dense_backward_weight   dW[n][k] = sum_b dY[b][n] X[b][k]: weight gradient of the ASPP image-pooling branch's
+//        1x1 convolution, which acts on a [B, C] vector (lss_fpn.py:80-88,101); its forward and data gradient are the
+//        `dense` kernel.
+//   sgv3d_deform_im2col3x3_backward   adjoint of the deformable bilinear im2col of mmcv's DeformConv2dPack
+//        (lss_fpn.py:190-198): d loss / d offsets (one wave per (pixel, tap), channels reduced in fixed order) and
+//        d loss / d input (scatter to the four corners with float atomics, like mmcv's deformable_col2im).
+//
+// All HBM-bound streaming work: one read of the operands, one write of the results.
+#include "common.hpp"
+
+using namespace sgv3d;
+
+namespace {
+
+constexpr int kT = 256;
+
+// ------------------------------------------------------------------------------------------------ max pooling
+__global__ __launch_bounds__(kT) void maxpool_train_fwd_kernel(int B, int H, int W, int C4, int OH, int OW,
+                                                              const float4 *__restrict__ x, float4 *__restrict__ y,
+                                                              uchar4 *__restrict__ idx) {
+    const long long i = (long long)blockIdx.x * kT + threadIdx.x;
+    const long long total = (long long)B * OH * OW * C4;
+    if (i >= total) return;
+    const int c = (int)(i % C4);
+    long long t = i / C4;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    unsigned char am[4] = {255, 255, 255, 255};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int ih = oh * 2 - 1 + dy;
+        if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int iw = ow * 2 - 1 + dx;
+            if ((unsigned)iw >= (unsigned)W) continue;
+            const float4 v4 = x[((long long)(b * H + ih) * W + iw) * C4 + c];
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (am[j] == 255 || v[j] > m[j] || v[j] != v[j]) {      // first maximum wins; NaN propagates like torch
+                    m[j] = v[j];
+                    am[j] = (unsigned char)(dy * 3 + dx);
+                }
+        }
+    }
+    y[i] = make_float4(m[0], m[1], m[2], m[3]);
+    idx[i] = make_uchar4(am[0], am[1], am[2], am[3]);
+}
+
+__global__ __launch_bounds__(kT) void maxpool_bwd_kernel(int B, int H, int W, int C4, int OH, int OW,
+                                                        const uchar4 *__restrict__ idx, const float4 *__restrict__ dy,
+                                                        float4 *__restrict__ dx) {
+    const long long i = (long long)blockIdx.x * kT + threadIdx.x;
+    const long long total = (long long)B * H * W * C4;
+    if (i >= total) return;
+    const int c = (int)(i % C4);
+    long long t = i / C4;
+    const int iw = (int)(t % W);
+    t /= W;
+    const int ih = (int)(t % H);
+    const int b = (int)(t / H);
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    // windows containing (ih, iw): oh in {ih / 2, (ih + 1) / 2}, ascending -- fixed order of the (<= 4) terms
+    const int oh0 = ih >> 1, oh1 = (ih + 1) >> 1, ow0 = iw >> 1, ow1 = (iw + 1) >> 1;
+    for (int a = 0; a < 2; ++a) {
+        const int oh = a == 0 ? oh0 : oh1;
+        if ((a == 1 && oh1 == oh0) || oh >= OH) continue;
+        const int ty = ih - (oh * 2 - 1);
+        for (int e = 0; e < 2; ++e) {
+            const int ow = e == 0 ? ow0 : ow1;
+            if ((e == 1 && ow1 == ow0) || ow >= OW) continue;
+            const int tap = ty * 3 + (iw - (ow * 2 - 1));
+            const long long o = ((long long)(b * OH + oh) * OW + ow) * C4 + c;
+            const uchar4 k = idx[o];
+            const float4 d = dy[o];
+            g[0] += k.x == tap ? d.x : 0.f;
+            g[1] += k.y == tap ? d.y : 0.f;
+            g[2] += k.z == tap ? d.z : 0.f;
+            g[3] += k.w == tap ? d.w : 0.f;
+        }
+    }
+    dx[i] = make_float4(g[0], g[1], g[2], g[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ dense: weight gradient
+__global__ __launch_bounds__(kT) void dense_bwd_weight_kernel(int B, int K, int N, const float *__restrict__ x,
+                                                             const float *__restrict__ dy, float *__restrict__ dw) {
+    const long long i = (long long)blockIdx.x * kT + threadIdx.x;
+    if (i >= (long long)N * K) return;
+    const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dy[(size_t)b * N + n] * x[(size_t)b * K + k];
+    dw[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ deformable im2col adjoint
+// one wave per (pixel, tap); lanes walk the channels as float4.  dcol uses the layout of sgv3d_deform_im2col3x3:
+// [pixel][group][tap][channels per group].
+__global__ __launch_bounds__(kT) void deform_im2col_bwd_kernel(int B, int H, int W, int C, int groups,
+                                                              const float *__restrict__ x, const float *__restrict__ off,
+                                                              int off_ld, const float *__restrict__ dcol,
+                                                              float *__restrict__ dx, float *__restrict__ doff, int doff_ld) {
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
+    const long long total = (long long)B * H * W * 9;
+    if (item >= total) return;                                   // wave-uniform
+    const int tap = (int)(item % 9);
+    const long long p = item / 9;
+    const int w_ = (int)(p % W);
+    const long long t2 = p / W;
+    const int h_ = (int)(t2 % H);
+    const int b = (int)(t2 / H);
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const float oy = off[p * off_ld + 2 * tap], ox = off[p * off_ld + 2 * tap + 1];
+    const float hf = (float)(h_ - 1 + ky) + oy;
+    const float wf = (float)(w_ - 1 + kx) + ox;
+    float gy = 0.f, gx = 0.f;
+    if (hf > -1.f && wf > -1.f && hf < (float)H && wf < (float)W) {
+        const int h_low = (int)floorf(hf), w_low = (int)floorf(wf);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = hf - (float)h_low, lw = wf - (float)w_low;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const bool ok1 = h_low >= 0 && w_low >= 0, ok2 = h_low >= 0 && w_high <= W - 1;
+        const bool ok3 = h_high <= H - 1 && w_low >= 0, ok4 = h_high <= H - 1 && w_high <= W - 1;
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const long long img = (long long)b * H * W;
+        const long long o1 = (img + (long long)h_low * W + w_low) * C, o2 = (img + (long long)h_low * W + w_high) * C;
+        const long long o3 = (img + (long long)h_high * W + w_low) * C, o4 = (img + (long long)h_high * W + w_high) * C;
+        const int cpg = C / groups;
+        for (int c = lane * 4; c < C; c += 256) {
+            const int g = c / cpg, cg = c - g * cpg;
+            const float4 d = *reinterpret_cast<const float4 *>(dcol + ((p * groups + g) * 9 + tap) * cpg + cg);
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v1 = ok1 ? *reinterpret_cast<const float4 *>(x + o1 + c) : z;
+            const float4 v2 = ok2 ? *reinterpret_cast<const float4 *>(x + o2 + c) : z;
+            const float4 v3 = ok3 ? *reinterpret_cast<const float4 *>(x + o3 + c) : z;
+            const float4 v4 = ok4 ? *reinterpret_cast<const float4 *>(x + o4 + c) : z;
+            // d val / d hf = hw (v3 - v1) + lw (v4 - v2);  d val / d wf = hh (v2 - v1) + lh (v4 - v3)
+            gy += d.x * (hw * (v3.x - v1.x) + lw * (v4.x - v2.x)) + d.y * (hw * (v3.y - v1.y) + lw * (v4.y - v2.y)) +
+                  d.z * (hw * (v3.z - v1.z) + lw * (v4.z - v2.z)) + d.w * (hw * (v3.w - v1.w) + lw * (v4.w - v2.w));
+            gx += d.x * (hh * (v2.x - v1.x) + lh * (v4.x - v3.x)) + d.y * (hh * (v2.y - v1.y) + lh * (v4.y - v3.y)) +
+                  d.z * (hh * (v2.z - v1.z) + lh * (v4.z - v3.z)) + d.w * (hh * (v2.w - v1.w) + lh * (v4.w - v3.w));
+            const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ok1) __hip_atomic_fetch_add(dx + o1 + c + j, w1 * dv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ok2) __hip_atomic_fetch_add(dx + o2 + c + j, w2 * dv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ok3) __hip_atomic_fetch_add(dx + o3 + c + j, w3 * dv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ok4) __hip_atomic_fetch_add(dx + o4 + c + j, w4 * dv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {                            // butterfly: the same order for every lane, every run
+        gy += __shfl_xor(gy, o, 64);
+        gx += __shfl_xor(gx, o, 64);
+    }
+    if (lane == 0) {
+        doff[p * doff_ld + 2 * tap] = gy;
+        doff[p * doff_ld + 2 * tap + 1] = gx;
+    }
+}
+
+__global__ __launch_bounds__(kT) void zero_f32_kernel(long long n4, float4 *__restrict__ p) {
+    const long long i = (long long)blockIdx.x * kT + threadIdx.x;
+    if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+}  // namespace
+
+extern "C" int sgv3d_maxpool3x3s2_train_forward(int batch, int in_h, int in_w, int channels, const float *x, float *y,
+                                                unsigned char *argmax, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && in_h > 0 && in_w > 0 && channels > 0 && channels % 4 == 0, "maxpool3x3s2_train_forward: bad shape");
+    SGV3D_REQUIRE(x && y && argmax, "maxpool3x3s2_train_forward: null pointer");
+    const int oh = (in_h - 1) / 2 + 1, ow = (in_w - 1) / 2 + 1;
+    const long long total = (long long)batch * oh * ow * (channels / 4);
+    hipLaunchKernelGGL(maxpool_train_fwd_kernel, dim3(cdiv(total, kT)), dim3(kT), 0, as_stream(stream), batch, in_h, in_w,
+                       channels / 4, oh, ow, reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y),
+                       reinterpret_cast<uchar4 *>(argmax));
+    return check_launch("maxpool_train_fwd_kernel");
+}
+
+extern "C" int sgv3d_maxpool3x3s2_backward(int batch, int in_h, int in_w, int channels, const unsigned char *argmax,
+                                           const float *grad_out, float *grad_in, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && in_h > 0 && in_w > 0 && channels > 0 && channels % 4 == 0, "maxpool3x3s2_backward: bad shape");
+    SGV3D_REQUIRE(argmax && grad_out && grad_in, "maxpool3x3s2_backward: null pointer");
+    const int oh = (in_h - 1) / 2 + 1, ow = (in_w - 1) / 2 + 1;
+    const long long total = (long long)batch * in_h * in_w * (channels / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(cdiv(total, kT)), dim3(kT), 0, as_stream(stream), batch, in_h, in_w, channels / 4,
+                       oh, ow, reinterpret_cast<const uchar4 *>(argmax), reinterpret_cast<const float4 *>(grad_out),
+                       reinterpret_cast<float4 *>(grad_in));
+    return check_launch("maxpool_bwd_kernel");
+}
+
+extern "C" int sgv3d_dense_backward_weight(int batch, int k, int n, const float *x, const float *grad_out, float *grad_w,
+                                           void *stream) {
+    SGV3D_REQUIRE(batch > 0 && k > 0 && n > 0 && x && grad_out && grad_w, "dense_backward_weight: bad argument");
+    hipLaunchKernelGGL(dense_bwd_weight_kernel, dim3(cdiv((long long)n * k, kT)), dim3(kT), 0, as_stream(stream), batch, k, n, x,
+                       grad_out, grad_w);
+    return check_launch("dense_bwd_weight_kernel");
+}
+
+extern "C" int sgv3d_deform_im2col3x3_backward(int batch, int h, int w, int channels, int groups, const float *x,
+                                               const float *offset, int off_ld, const float *grad_col, float *grad_x,
+                                               float *grad_offset, int grad_off_ld, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && h > 0 && w > 0 && channels > 0 && groups > 0 && channels % (4 * groups) == 0 && off_ld >= 18 &&
+                      grad_off_ld >= 18,
+                  "deform_im2col3x3_backward: bad shape");
+    SGV3D_REQUIRE(x && offset && grad_col && grad_x && grad_offset, "deform_im2col3x3_backward: null pointer");
+    const long long n4 = (long long)batch * h * w * channels / 4;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3(cdiv(n4, kT)), dim3(kT), 0, as_stream(stream), n4, reinterpret_cast<float4 *>(grad_x));
+    const long long items = (long long)batch * h * w * 9;
+    hipLaunchKernelGGL(deform_im2col_bwd_kernel, dim3(cdiv(items, kT / 64)), dim3(kT), 0, as_stream(stream), batch, h, w, channels,
+                       groups, x, offset, off_ld, grad_col, grad_x, grad_offset, grad_off_ld);
+    return check_launch("deform_im2col_bwd_kernel");
+}

@@ -16,9 +16,12 @@ the HBM traffic run on the hand-written kernels, forward and backward:
 * the BSM variant's x2 bilinear upsampling and spatial-attention gate -> ``bsm_grad`` (forward kernels of the
   inference path, adjoint kernels in csrc/bsm_train.hip).
 
-The small layers in between -- max / average pooling, the 27-feature MLPs with their BatchNorm1d, the softmax over
-height bins / semantic classes, the bilinear sampling of the deformable convolution, concatenations -- use torch
-operators on the same NHWC buffers in this round.  Activations are NHWC float32
+* max pooling of the stem, the ASPP image-pooling branch (global average + 1x1 convolution) and the deformable bilinear
+  sampling of the DCN -> ``misc_grad`` (forward kernels of the inference path or their index-keeping variants, adjoint
+  kernels in csrc/train_misc.hip; round 2).
+
+The small layers in between -- the 27-feature MLPs with their BatchNorm1d, the softmax over height bins / semantic
+classes, concatenations, elementwise gates -- use torch operators on the same NHWC buffers.  Activations are NHWC float32
 throughout (an NCHW view with channels-last strides is handed to the torch operators, no layout copies).
 
 Layer semantics follow the eval-mode HIP path module by module (layers/blocks.py, layers/backbones/lss_fpn.py,
@@ -31,6 +34,7 @@ from torch import nn
 
 from . import conv_grad, hip_ops
 from .bsm_grad import add_mul_sigmoid, upsample_bilinear2x
+from . import misc_grad
 from .norm_grad import batch_norm_act
 from .layers import blocks
 from .layers.backbones import bsm_lss_fpn, lss_fpn
@@ -82,7 +86,7 @@ def block(b, x):
 def resnet(r, x, use_maxpool=True):
     x = bn(r.bn1, conv(r.conv1, x), relu=True)
     if use_maxpool:
-        x = _nhwc(F.max_pool2d(_nchw(x), 3, 2, 1))
+        x = misc_grad.maxpool3x3s2(x)
     outs = []
     for i, name in enumerate(r.res_layers):
         for b in getattr(r, name):
@@ -106,43 +110,26 @@ def secondfpn(n, feats):
 
 def aspp(a, x):
     branches = [bn(m.bn, conv(m.atrous_conv, x), relu=True) for m in (a.aspp1, a.aspp2, a.aspp3, a.aspp4)]
-    pooled = x.mean((1, 2), keepdim=True)                                  # AdaptiveAvgPool2d((1, 1))
-    g = a.global_avg_pool
-    x5 = bn(g[2], F.conv2d(_nchw(pooled), g[1].weight).permute(0, 2, 3, 1), relu=True)
+    g = a.global_avg_pool                                                  # AdaptiveAvgPool2d((1, 1)) + 1x1 conv: HIP kernels
+    x5 = bn(g[2], misc_grad.pooled_linear(x, g[1].weight)[:, None, None, :], relu=True)
     branches.append(x5.expand(-1, x.shape[1], x.shape[2], -1))             # bilinear upsampling of a 1x1 map = broadcast
     y = bn(a.bn1, conv(a.conv1, torch.cat(branches, -1).contiguous()), relu=True)
     return F.dropout(y, a.dropout.p, a.dropout.training)
 
 
 def deform_conv(d, x):
-    """mmcv DeformConv2dPack (3x3, pad 1, deform_groups 1): bilinear taps gathered with torch indexing (differentiable
-    in the input and the offsets), then one 1x1 HIP convolution per group over the (tap, channel) columns."""
+    """mmcv DeformConv2dPack (3x3, pad 1, deform_groups 1): deformable bilinear im2col (HIP kernel, differentiable in the
+    input and the offsets through its adjoint kernel), then one 1x1 HIP convolution per group over the (tap, channel)
+    columns."""
     B, H, W, C = (int(v) for v in x.shape)
     offset = conv(d.conv_offset, x)                                        # [B, H, W, 18]: (dy, dx) per tap
-    ys = torch.arange(H, device=x.device, dtype=x.dtype).view(1, H, 1)
-    xs = torch.arange(W, device=x.device, dtype=x.dtype).view(1, 1, W)
-    flat = x.reshape(B, H * W, C)
-    cols = []
-    for t in range(9):
-        hf = ys - 1 + t // 3 + offset[..., 2 * t]
-        wf = xs - 1 + t % 3 + offset[..., 2 * t + 1]
-        valid = (hf > -1) & (wf > -1) & (hf < H) & (wf < W)
-        h0, w0 = torch.floor(hf), torch.floor(wf)
-        lh, lw = hf - h0, wf - w0
-        val = 0
-        for dh, dw, wt in ((0, 0, (1 - lh) * (1 - lw)), (0, 1, (1 - lh) * lw), (1, 0, lh * (1 - lw)), (1, 1, lh * lw)):
-            hh, ww = (h0 + dh).long(), (w0 + dw).long()
-            ok = valid & (hh >= 0) & (hh <= H - 1) & (ww >= 0) & (ww <= W - 1)
-            idx = (hh.clamp(0, H - 1) * W + ww.clamp(0, W - 1)).reshape(B, H * W, 1).expand(-1, -1, C)
-            val = val + torch.gather(flat, 1, idx).reshape(B, H, W, C) * (wt * ok).unsqueeze(-1)
-        cols.append(val)
-    col = torch.stack(cols, 3)                                             # [B, H, W, 9, C]
     g = d.groups
     cpg, opg = d.in_channels // g, d.out_channels // g
+    col = misc_grad.deform_im2col3x3(x, offset, g)                         # [B, H, W, g * 9 * cpg], HIP forward + adjoint
     outs = []
     for gi in range(g):
         wg = d.weight[gi * opg:(gi + 1) * opg].permute(0, 2, 3, 1).reshape(opg, 9 * cpg, 1, 1)
-        cg = col[..., gi * cpg:(gi + 1) * cpg].reshape(B, H, W, 9 * cpg).contiguous()
+        cg = col[..., gi * 9 * cpg:(gi + 1) * 9 * cpg].contiguous()
         outs.append(conv_grad.conv2d(cg, wg))
     return torch.cat(outs, -1)
 

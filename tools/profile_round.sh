@@ -16,7 +16,7 @@ python3 $R/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/bench
 # 2. kernel trace + stats of the same command (no CPU baseline: it is host work).  One frame in flight, so that the
 #    per-kernel durations are those of the kernels alone (with 3 frames in flight concurrent kernels stretch each
 #    other) and compare directly with roofline.avg_launch_us of the bench line, which is measured the same way.
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --streams 1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-plan-timing --streams 1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err
 # 3. HBM traffic counters, separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/pmc_write.err
