@@ -172,12 +172,13 @@ def test_fp32_noise_regime_against_float64():
     assert e_hip <= 1e-3 * scale
 
 
-# bf16 tolerance.  Operands are rounded to bf16 (relative 2^-9 = 2e-3) before every product and accumulated in f32; over
-# the K = 576..4608 terms of a layer the rounding errors average out (relative error of a layer output ~ 2^-9, not
-# K x 2^-9) and compound over the ~60-110 convolutions between image and prediction maps like a random walk:
-# ~2e-3 x sqrt(2 x 110) = 3e-2 of the activation scale is the expected order for the R101 models; the bound asserted is
-# 1e-1 of max(1, |ref|max) (3x head-room over that estimate; measured values are printed and recorded in DESIGN.md).
-BF16_TOL = 1e-1
+# bf16 tolerance.  Operands and (in bf16-activation mode) the tensors between the ResNet layers are rounded to bf16 (relative
+# 2^-9 = 2e-3) and accumulated in f32; over the K = 576..4608 terms of a layer the rounding errors average out (relative
+# error of a layer output ~ 2^-9, not K x 2^-9) and compound over the ~60-110 convolutions between image and prediction maps
+# like a random walk: ~2e-3 x sqrt(110) = 2e-2 of the activation scale is the expected order for the R101 models.  Measured
+# at full size (printed below, recorded in DESIGN.md 3.1d): 6e-3 (cfg-2), 5e-3 (cfg-3), 7e-3 (cfg-5) of max |ref|.  The
+# bound asserted is 2e-2 of max(1, |ref|max): 3x head-room over the measurements, the order of the estimate.
+BF16_TOL = 2e-2
 
 
 def test_full_size_bf16_mode(full):
