@@ -111,6 +111,8 @@ def load_traffic(tile_name):
         sym = "conv_wino_head_kernel"
     elif tile_name == "conv_head_bf16":
         sym = "head_bf16_kernel"
+    elif tile_name == "conv_patch_bf16":
+        sym = "conv_patch_bf16_kernel"
     else:
         fast = not tile_name.endswith("_tapmajor")
         kern = "conv_igemm_bf16_kernel" if tile_name.startswith(("conv_igemm_bf16", "conv_igemm_f32x3_")) else "conv_igemm_kernel"

@@ -392,6 +392,22 @@ int sgv3d_centerhead_branches_forward_bf16x(int batch, int h, int w, int cin, in
 void sgv3d_centerhead_bf16_select_plain(int plain);
 void sgv3d_centerhead_bf16_debug_stamps(void *buf);
 
+/* bf16-mode 3x3 / stride 1 / pad 1 convolution with the input patch resident in LDS (csrc/conv_patch_bf16.hip): the
+ * algorithm the bf16 configs use where the fp32 configs use Winograd -- the BasicBlock / Bottleneck 3x3 layers of
+ * HeightNet (layers/backbones/lss_fpn.py:166-198), MSCThead (bsm_lss_fpn.py:185-257), the BEV trunk
+ * (layers/heads/bev_height_head.py:75-110) and the image ResNet.  y = relu?(conv(x) * scale + bias + residual).
+ *   w_packed  sgv3d_conv3x3_patch_bf16_weight_bytes(cout, cin) bytes, filled by ..._pack_weight from f32 OIHW [cout, cin, 3, 3]
+ *   x         NHWC [batch, h, w, x_ld] (channels x_coff .. x_coff + cin), f32 or bf16 (io_flags bit 0)
+ *   y         NHWC [batch, h, w, y_ld] (channels y_coff .. y_coff + cout), f32 or bf16 (io_flags bit 1)
+ *   residual  NHWC [batch, h, w, res_ld] in the dtype of y, or NULL;  scale / bias  f32 [cout] or NULL (1 / 0)
+ * cin must be a multiple of 32, cout of 8; strides and offsets multiples of 8; pointers 16-B aligned. */
+size_t sgv3d_conv3x3_patch_bf16_weight_bytes(int cout, int cin);
+int sgv3d_conv3x3_patch_bf16_pack_weight(const float *w, int cout, int cin, void *w_packed, void *stream);
+int sgv3d_conv3x3_patch_bf16_forward(int batch, int h, int w, int cin, int cout, int x_ld, int x_coff, int y_ld,
+                                     int y_coff, int res_ld, int relu, const void *x, const void *w_packed,
+                                     const float *scale, const float *bias, const void *residual, void *y,
+                                     int io_flags, void *stream);
+
 /* ================================================================================================
  * Box decode + circle NMS  
  * ================================================================================================ */

@@ -88,10 +88,12 @@ def save_tune_db(path=None):
 
 
 load_tune_db()
-TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: "wino_resident",
+TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: "wino_resident", 7: "patch_bf16",
               11: "128x128", 12: "128x64", 13: "64x128", 14: "64x64"}     # 11..14: f32x3 of tiles 1..4 (host-side ids)
 TILE_WINO = 5       # host-side algorithm id: sgv3d_conv2d_winograd_forward instead of the implicit GEMM
 TILE_WINO_RES = 6   # = SGV3D_WINOGRAD_RESIDENT: its patch-resident variant (cin <= 96, many cout tiles)
+TILE_PATCH = 7      # bf16 mode: the LDS-resident-patch 3x3 kernel (sgv3d_conv3x3_patch_bf16_forward)
+PATCH_BF16 = _os.environ.get("SGV3D_PATCH_BF16", "1") != "0"
 
 
 class prof:
@@ -215,6 +217,21 @@ class PackedConv:
             _lib.check(rc, "sgv3d_conv_winograd_pack_weight")
         self._keep = w  # the pack kernels read it asynchronously
         self._tile_cache = {}
+        # bf16 mode: fragment-ordered bf16 weights for the patch kernel, packed on first use
+        self.w_patch = None
+        self.patch_ok = (not transposed and kh == 3 and kw == 3 and self.stride == 1 and self.dil == 1
+                         and self.pad == 1 and self.cin % 32 == 0 and self.cout % 8 == 0 and self.cin == cin)
+
+    def _patch_weights(self):
+        if self.w_patch is None:
+            lib = _lib.load()
+            w = self._keep
+            self.w_patch = torch.empty(lib.sgv3d_conv3x3_patch_bf16_weight_bytes(self.cout, self.cin), dtype=torch.uint8,
+                                       device=w.device)
+            with torch.cuda.device(w.device):
+                rc = lib.sgv3d_conv3x3_patch_bf16_pack_weight(w.data_ptr(), self.cout, self.cin, self.w_patch.data_ptr(), _st(w))
+            _lib.check(rc, "sgv3d_conv3x3_patch_bf16_pack_weight")
+        return self.w_patch
 
     def out_hw(self, h, w):
         if self.transposed:
@@ -304,9 +321,9 @@ class PackedConv:
         real_n = self.cout_real * (self.ks * self.ks if self.transposed else 1)
         flops = 2.0 * gemm_m * real_n * (self.cin_real * self.kh * self.kw)
         x3 = t > 10 or (MFMA_F32X3 is True and t < TILE_WINO)
-        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES) else
+        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH) else
                 ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_f32x3_" if x3 else "conv_igemm_")) + TILE_NAMES[t]
-        if t not in (TILE_WINO, TILE_WINO_RES) and self.k_order == 0:
+        if t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH) and self.k_order == 0:
             name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
@@ -330,13 +347,27 @@ class PackedConv:
                     if wgs * cand <= 512 and self.cin // 8 // cand >= 4:
                         split = cand
             return TILE_WINO, sk or split
+        if t == 0 and self._patch_eligible(d) and d.out_h * d.out_w * d.batch >= 4096:
+            return TILE_PATCH, 1
         return (t or heuristic_tile(gemm_m, gemm_n)), (sk or 1)
+
+    def _patch_eligible(self, d, gate=None):
+        return (MFMA_BF16 and not MFMA_F32X3 and PATCH_BF16 and self.patch_ok and d.mode == CONV_NORMAL and gate is None
+                and d.x_ld % 8 == 0 and d.x_coff % 8 == 0 and d.y_ld % 8 == 0 and d.y_coff % 8 == 0
+                and (d.res_ld % 8 == 0))
 
     def _launch(self, lib, d, x, residual, gate, out, io=0):
         ws, nws = None, 0
         if d.split_k > 1:
             nws = lib.sgv3d_conv2d_workspace_bytes(ctypes.byref(d))
             ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+        if d.tile == TILE_PATCH:
+            if not self._patch_eligible(d, gate):
+                raise _lib.SGV3DError("the bf16 patch kernel covers 3x3 / stride 1 / pad 1 layers with cin % 32 == 0 in bf16 mode")
+            return lib.sgv3d_conv3x3_patch_bf16_forward(d.batch, d.in_h, d.in_w, self.cin, self.cout, d.x_ld, d.x_coff, d.y_ld,
+                                                        d.y_coff, d.res_ld, d.relu, x.data_ptr(), self._patch_weights().data_ptr(),
+                                                        _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
+                                                        out.data_ptr(), int(io), _st(x))
         if d.tile in (TILE_WINO, TILE_WINO_RES):
             if self.w_wino is None:
                 raise _lib.SGV3DError("this layer has no Winograd weights (needs 3x3 / stride 1 / pad 1 / cin % 8 == 0)")
@@ -395,6 +426,8 @@ class PackedConv:
             tiles += (TILE_WINO,)
             if self.cin <= 96 and self.cout >= 128:
                 tiles += (TILE_WINO_RES,)
+        if self._patch_eligible(d, gate):
+            tiles += (TILE_PATCH,)
         if fixed_tile:
             tiles = (fixed_tile,)
         dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 64), 6: (256, 64),
@@ -402,13 +435,13 @@ class PackedConv:
         best, best_t = (tiles[0], fixed_split or 1), None
         with torch.cuda.device(x.device):
             for t in tiles:
-                bm, bn = dims[t]
+                bm, bn = dims.get(t, (512, 64))
                 wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
                 nk = nkt
                 if t == TILE_WINO:
                     nk = self.cin // 4      # k-steps of 8 channels; nk // s >= 8 keeps >= 4 steps per split
                     wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 16) * -(-gemm_n // 64)
-                if t == TILE_WINO_RES:
+                if t in (TILE_WINO_RES, TILE_PATCH):
                     splits = (1,)
                 elif fixed_split:
                     splits = (fixed_split,)

@@ -379,3 +379,58 @@ def test_bf16_io_transposed_conv(bf16_mode, cin, cout, ks, H, W, x_bf16):
         assert float(out[..., :16].abs().max()) == 0 and float(out[..., 16 + cout:].abs().max()) == 0
     conv(xin, out, y_coff=16, tile=4, split_k=2)
     assert float((out[..., 16:16 + cout].float().permute(0, 3, 1, 2).cpu().double() - ref).abs().max()) <= 2.0 ** -8 * max(1.0, float(ref.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------- LDS-resident-patch 3x3 kernel
+@pytest.mark.parametrize("shape", [
+    # B, cin, H, W, cout, residual
+    (1, 32, 16, 32, 64, False),        # exactly one tile, one chunk
+    (2, 64, 17, 35, 64, True),         # ragged tile edges, two chunks
+    (1, 160, 33, 20, 160, True),       # BEV trunk widths (cout = 2.5 tiles of 64)
+    (1, 512, 9, 11, 40, False),        # long K, cout % 64 = 40
+    (3, 96, 40, 70, 264, True),        # several tiles in x / y / channel, batch
+])
+@pytest.mark.parametrize("io", [0, 1, 2, 3])
+def test_bf16_patch_conv(bf16_mode, shape, io):
+    """sgv3d_conv3x3_patch_bf16_forward (tile id 7) against a float64 convolution of the bf16-rounded operands, for the four
+    combinations of f32 / bf16 input and output; bitwise equal is not expected against the implicit-GEMM kernel (other k order)."""
+    B, cin, H, W, cout, with_res = shape
+    g = torch.Generator().manual_seed(cin * 13 + cout + io)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    conv = hip_ops.PackedConv(w.to(DEV), stride=1, pad=1, scale=sc.to(DEV), shift=sh.to(DEV), relu=True)
+    xb, yb = bool(io & 1), bool(io & 2)
+    res = torch.randn(B, cout, H, W, generator=g) if with_res else None
+    xq = x.bfloat16()
+    ref = F.conv2d(xq.double(), w.bfloat16().double(), None, 1, 1) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    if res is not None:
+        ref = ref + (res.bfloat16() if yb else res).double()
+    ref = ref.clamp_min(0)
+    scale = max(1.0, float(ref.abs().max()))
+    xin = (xq if xb else x).permute(0, 2, 3, 1).contiguous().to(DEV)
+    rin = None if res is None else (res.bfloat16() if yb else res).permute(0, 2, 3, 1).contiguous().to(DEV)
+    odt = torch.bfloat16 if yb else torch.float32
+    y = conv(xin, residual=rin, tile=hip_ops.TILE_PATCH, out_dtype=odt)
+    assert y.dtype == odt and tuple(y.shape) == (B, H, W, cout)
+    err = float((y.float().permute(0, 3, 1, 2).cpu().double() - ref).abs().max())
+    assert err <= (2.0 ** -8 if yb else 2e-5) * scale, (err, scale)
+    # against the implicit-GEMM kernel: same operands, different summation order
+    y2 = conv(xin, residual=rin, tile=4, split_k=1, out_dtype=odt)
+    assert float((y.float() - y2.float()).abs().max()) <= (2.0 ** -7 if yb else 2e-5) * scale
+    # channel-slice input and output
+    wide_in = torch.zeros(B, H, W, cin + 16, dtype=xin.dtype, device=DEV)
+    wide_in[..., 8:8 + cin] = xin
+    wide = torch.zeros(B, H, W, cout + 16, dtype=odt, device=DEV)
+    conv(wide_in, wide, x_coff=8, y_coff=8, residual=rin, tile=hip_ops.TILE_PATCH)
+    assert torch.equal(wide[..., 8:8 + cout], y)
+    assert float(wide[..., :8].abs().max()) == 0 and float(wide[..., 8 + cout:].abs().max()) == 0
+
+
+def test_bf16_patch_conv_exact_on_small_integers(bf16_mode):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-3, 4, (2, 64, 20, 37), generator=g).float()
+    w = torch.randint(-2, 3, (72, 64, 3, 3), generator=g).float()
+    conv = hip_ops.PackedConv(w.to(DEV), stride=1, pad=1)
+    y = conv(x.permute(0, 2, 3, 1).contiguous().to(DEV), tile=hip_ops.TILE_PATCH)
+    assert torch.equal(y.permute(0, 3, 1, 2).cpu(), F.conv2d(x, w, None, 1, 1))
