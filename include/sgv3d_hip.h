@@ -392,6 +392,25 @@ int sgv3d_centerhead_branches_forward_bf16x(int batch, int h, int w, int cin, in
 void sgv3d_centerhead_bf16_select_plain(int plain);
 void sgv3d_centerhead_bf16_debug_stamps(void *buf);
 
+/* bf16-activation twins of the small layers between the convolutions of HeightNet / MSCThead (csrc/act_bf16.hip; bf16
+ * compute mode only).  Tensors marked bf16 are NHWC bf16 with channel counts / strides / offsets multiples of 8; arithmetic is
+ * float32 as in the f32 functions of the same name, rounded once (nearest even) on the store.
+ *   scale_channels_bf16      y[b,p,c] = x[b,p,c] * gate[b,c]                  x, y bf16; gate f32      (lss_fpn.py:155-159)
+ *   global_avgpool_bf16      y[b,c] = mean_p x[b,p,c]                         x bf16; y f32; workspace as the f32 function
+ *   broadcast_channels_bf16  y[b,p,y_coff+c] = v[b,c]                         v f32; y bf16            (lss_fpn.py:101-104)
+ *   upsample_bilinear2x_bf16 F.interpolate(scale_factor=2, bilinear)          x, y bf16                (bsm_lss_fpn.py:210)
+ *   add_mul_sigmoid_bf16     y = a + b * sigmoid(c)                           all bf16, n elements     (bsm_lss_fpn.py:151-160, 211)
+ *   deform_im2col3x3_bf16    DCNv1 sampling as sgv3d_deform_im2col3x3         x, col bf16; offset f32  (lss_fpn.py:190-198) */
+int sgv3d_scale_channels_bf16(int batch, int pixels, int channels, const void *x, const float *gate, void *y, void *stream);
+int sgv3d_global_avgpool_bf16(int batch, int pixels, int channels, int x_ld, const void *x, float *y, void *workspace,
+                              size_t workspace_bytes, void *stream);
+int sgv3d_broadcast_channels_bf16(int batch, int pixels, int channels, int y_ld, int y_coff, const float *v, void *y,
+                                  void *stream);
+int sgv3d_upsample_bilinear2x_bf16(int batch, int h, int w, int channels, const void *x, void *y, void *stream);
+int sgv3d_add_mul_sigmoid_bf16(long long n, const void *a, const void *b, const void *c, void *y, void *stream);
+int sgv3d_deform_im2col3x3_bf16(int batch, int h, int w, int channels, int groups, const void *x, const float *offset,
+                                int off_ld, void *col, void *stream);
+
 /* bf16-mode 3x3 / stride 1 / pad 1 convolution with the input patch resident in LDS (csrc/conv_patch_bf16.hip): the
  * algorithm the bf16 configs use where the fp32 configs use Winograd -- the BasicBlock / Bottleneck 3x3 layers of
  * HeightNet (layers/backbones/lss_fpn.py:166-198), MSCThead (bsm_lss_fpn.py:185-257), the BEV trunk

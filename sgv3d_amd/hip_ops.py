@@ -148,6 +148,14 @@ def fold_bn(bn, conv_bias=None):
     return scale.contiguous(), shift.contiguous()
 
 
+def activation_dtype(*channel_counts):
+    """torch.bfloat16 when bf16 mode keeps activations as bf16 tensors in HBM (MFMA_BF16 and BF16_ACTIVATIONS, not the f32x3
+    split) and every given channel count allows 16-byte bf16 rows (multiple of 8); else None (= float32 tensors)."""
+    if not (MFMA_BF16 and BF16_ACTIVATIONS) or MFMA_F32X3:
+        return None
+    return torch.bfloat16 if all(int(c) % 8 == 0 for c in channel_counts) else None
+
+
 class PackedConv:
     """One convolution (or kernel==stride transposed convolution) with its weights repacked for the
     MFMA implicit-GEMM kernel and BN / bias folded into a per-channel scale & shift."""
@@ -511,8 +519,9 @@ def global_avgpool(x, out=None):
     lib = _lib.load()
     nbytes = lib.sgv3d_global_avgpool_workspace_bytes(B, C)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    fn = lib.sgv3d_global_avgpool_bf16 if x.dtype == torch.bfloat16 else lib.sgv3d_global_avgpool
     with torch.cuda.device(x.device), prof("global_avgpool"):
-        rc = lib.sgv3d_global_avgpool(B, H * W, C, C, x.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes, _st(x))
+        rc = fn(B, H * W, C, C, x.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes, _st(x))
     _lib.check(rc, "sgv3d_global_avgpool")
     return out
 
@@ -538,8 +547,10 @@ def broadcast_channels(v, out, y_coff=0):
     """v [B,C] written to out[b, :, :, y_coff:y_coff+C] for every pixel (out NHWC)."""
     B, H, W, ld = (int(s) for s in out.shape)
     C = int(v.shape[1])
+    lib = _lib.load()
+    fn = lib.sgv3d_broadcast_channels_bf16 if out.dtype == torch.bfloat16 else lib.sgv3d_broadcast_channels
     with torch.cuda.device(out.device), prof("broadcast_channels"):
-        rc = _lib.load().sgv3d_broadcast_channels(B, H * W, C, ld, int(y_coff), v.data_ptr(), out.data_ptr(), _st(out))
+        rc = fn(B, H * W, C, ld, int(y_coff), v.data_ptr(), out.data_ptr(), _st(out))
     _lib.check(rc, "sgv3d_broadcast_channels")
     return out
 
@@ -550,8 +561,10 @@ def scale_channels(x, gate, out=None):
     assert tuple(gate.shape) == (B, C) and x.is_contiguous() and gate.is_contiguous()
     if out is None:
         out = torch.empty_like(x)
+    lib = _lib.load()
+    fn = lib.sgv3d_scale_channels_bf16 if x.dtype == torch.bfloat16 else lib.sgv3d_scale_channels
     with torch.cuda.device(x.device), prof("scale_channels"):
-        rc = _lib.load().sgv3d_scale_channels(B, H * W, C, x.data_ptr(), gate.data_ptr(), out.data_ptr(), _st(x))
+        rc = fn(B, H * W, C, x.data_ptr(), gate.data_ptr(), out.data_ptr(), _st(x))
     _lib.check(rc, "sgv3d_scale_channels")
     return out
 
@@ -571,9 +584,11 @@ def upsample_bilinear2x(x, out=None):
     B, H, W, C = (int(s) for s in x.shape)
     assert x.is_contiguous()
     if out is None:
-        out = torch.empty(B, 2 * H, 2 * W, C, dtype=torch.float32, device=x.device)
+        out = torch.empty(B, 2 * H, 2 * W, C, dtype=x.dtype, device=x.device)
+    lib = _lib.load()
+    fn = lib.sgv3d_upsample_bilinear2x_bf16 if x.dtype == torch.bfloat16 else lib.sgv3d_upsample_bilinear2x
     with torch.cuda.device(x.device), prof("upsample_bilinear2x"):
-        rc = _lib.load().sgv3d_upsample_bilinear2x(B, H, W, C, x.data_ptr(), out.data_ptr(), _st(x))
+        rc = fn(B, H, W, C, x.data_ptr(), out.data_ptr(), _st(x))
     _lib.check(rc, "sgv3d_upsample_bilinear2x")
     return out
 
@@ -581,10 +596,13 @@ def upsample_bilinear2x(x, out=None):
 def add_mul_sigmoid(a, b, c, out=None):
     """a + b * sigmoid(c), same-shape contiguous tensors."""
     assert a.shape == b.shape == c.shape and a.is_contiguous() and b.is_contiguous() and c.is_contiguous()
+    assert a.dtype == b.dtype == c.dtype
     if out is None:
         out = torch.empty_like(a)
+    lib = _lib.load()
+    fn = lib.sgv3d_add_mul_sigmoid_bf16 if a.dtype == torch.bfloat16 else lib.sgv3d_add_mul_sigmoid
     with torch.cuda.device(a.device), prof("add_mul_sigmoid"):
-        rc = _lib.load().sgv3d_add_mul_sigmoid(a.numel(), a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr(), _st(a))
+        rc = fn(a.numel(), a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr(), _st(a))
     _lib.check(rc, "sgv3d_add_mul_sigmoid")
     return out
 
@@ -604,10 +622,12 @@ def deform_im2col3x3(x, offset, groups, out=None):
     """x NHWC [B,H,W,C], offset NHWC [B,H,W,>=18] -> col [B,H,W,groups*9*(C/groups)]."""
     B, H, W, C = (int(s) for s in x.shape)
     if out is None:
-        out = torch.empty(B, H, W, 9 * C, dtype=torch.float32, device=x.device)
+        out = torch.empty(B, H, W, 9 * C, dtype=x.dtype, device=x.device)
+    assert offset.dtype == torch.float32 and out.dtype == x.dtype
+    lib = _lib.load()
+    fn = lib.sgv3d_deform_im2col3x3_bf16 if x.dtype == torch.bfloat16 else lib.sgv3d_deform_im2col3x3
     with torch.cuda.device(x.device), prof("deform_im2col3x3"):
-        rc = _lib.load().sgv3d_deform_im2col3x3(B, H, W, C, int(groups), x.data_ptr(), offset.data_ptr(),
-                                               int(offset.shape[-1]), out.data_ptr(), _st(x))
+        rc = fn(B, H, W, C, int(groups), x.data_ptr(), offset.data_ptr(), int(offset.shape[-1]), out.data_ptr(), _st(x))
     _lib.check(rc, "sgv3d_deform_im2col3x3")
     return out
 

@@ -40,7 +40,8 @@ class SABlock(HipModule):
     def hip_forward_residual(self, x, y, residual):
         """residual + conv(x) * sigmoid(attention(y))  (the form TaskFPN uses, :211)."""
         s = self.hip_state(x.device)
-        return hip_ops.add_mul_sigmoid(residual, s['conv'](x), s['att'](y))
+        dt = residual.dtype
+        return hip_ops.add_mul_sigmoid(residual, s['conv'](x, out_dtype=dt), s['att'](y, out_dtype=dt))
 
 
 class TaskHead(HipModule):
@@ -69,9 +70,10 @@ class TaskHead(HipModule):
 
     def hip_decoder(self, x):
         s = self.hip_state(x.device)
-        x = self.decoder[0].hip_forward(x)
-        x = self.decoder[1].hip_forward(x)
-        return s['conv'](x)
+        dt = x.dtype if x.dtype == torch.bfloat16 else None       # bf16-activation mode: stay in the dtype of the input map
+        x = self.decoder[0].hip_forward(x, dt)
+        x = self.decoder[1].hip_forward(x, dt)
+        return s['conv'](x, out_dtype=dt)
 
     def hip_head(self, feat, out=None, y_coff=0):
         return self.hip_state(feat.device)['head'](feat, out, y_coff=y_coff)
@@ -91,7 +93,7 @@ class TaskFPN(HipModule):
     def hip_forward(self, feat0, feat1):
         s = self.hip_state(feat0.device)
         up = hip_ops.upsample_bilinear2x(feat0)                         # F.interpolate(scale_factor=2, bilinear), :210
-        feat0 = s['reduce'](up)
+        feat0 = s['reduce'](up, out_dtype=up.dtype)
         return self.self_attention.hip_forward_residual(feat1, feat0, feat0)   # feat0 + SA(feat1, feat0), :211
 
 
@@ -173,15 +175,17 @@ class MSCThead(HipModule):
             for w, b, act in s[f'gate{i}']:
                 h = hip_ops.dense(h, w, None, b, act)
             gates.append(h)
-        scale0 = hip_ops.scale_channels(s['reduce0'](feats[0]), gates[0])     # :300-305
-        scale1 = hip_ops.scale_channels(s['reduce1'](feats[1]), gates[1])
+        # bf16 mode: every mid-channel map of this head lives in HBM as bf16; the logits / context it returns are f32
+        dt = hip_ops.activation_dtype(*[c.cout for c in (s['reduce0'], s['reduce1'], s['ctx0'], s['ctx1a'])])
+        scale0 = hip_ops.scale_channels(s['reduce0'](feats[0], out_dtype=dt), gates[0])     # :300-305
+        scale1 = hip_ops.scale_channels(s['reduce1'](feats[1], out_dtype=dt), gates[1])
         scale0 = self.aspp.hip_forward(scale0)                                # :306
         # TaskHead(with_head=False).forward(feat) returns ``feat`` unchanged (:195-199): the decoder of
         # depth_head0 is never run by the reference, its parameters are dead weights.
         depth_feat = scale0                                                   # :308
         semantic_feat = self.semantic_head0.hip_decoder(scale0)               # :309
         semantic0 = self.semantic_head0.hip_head(semantic_feat)
-        context_feat = s['ctx0'](scale0)                                      # :310
+        context_feat = s['ctx0'](scale0, out_dtype=dt)                        # :310
         depth_feat = self.depth_fpn.hip_forward(depth_feat, scale1)           # :313-315
         semantic_feat = self.semantic_fpn.hip_forward(semantic_feat, scale1)
         context_feat = self.context_fpn.hip_forward(context_feat, scale1)
@@ -189,7 +193,7 @@ class MSCThead(HipModule):
         out = torch.empty(B, H, W, out_ld, dtype=torch.float32, device=scale1.device)
         self.depth_head1.hip_head(self.depth_head1.hip_decoder(depth_feat), out, y_coff=0)          # :317
         semantic1 = self.semantic_head1.hip_head(self.semantic_head1.hip_decoder(semantic_feat))    # :318
-        s['ctx1b'](s['ctx1a'](context_feat), out, y_coff=self.depth_channels)                       # :319
+        s['ctx1b'](s['ctx1a'](context_feat, out_dtype=dt), out, y_coff=self.depth_channels)         # :319
         return out, semantic1, semantic0
 
 

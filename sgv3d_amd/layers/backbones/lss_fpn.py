@@ -79,16 +79,17 @@ class ASPP(HipModule):
             conv1=conv_bn(self.conv1, self.bn1, True, device))
 
     def hip_forward(self, x):
+        """The concat buffer and the output take the dtype of ``x`` (bf16 tensors in bf16-activation mode)."""
         s = self.hip_state(x.device)
         B, H, W, _ = x.shape
         mid = self.mid_channels
-        cat = torch.empty(B, H, W, 5 * mid, dtype=torch.float32, device=x.device)
+        cat = torch.empty(B, H, W, 5 * mid, dtype=x.dtype, device=x.device)
         for i, m in enumerate((self.aspp1, self.aspp2, self.aspp3, self.aspp4)):
             m.hip_state(x.device)(x, cat, y_coff=i * mid)
         pooled = hip_ops.global_avgpool(x)
         x5 = hip_ops.dense(pooled, s['gap_w'], s['gap_scale'], s['gap_shift'], hip_ops.ACT_RELU)
         hip_ops.broadcast_channels(x5, cat, y_coff=4 * mid)
-        return s['conv1'](cat)          # Dropout(0.5) is the identity in eval mode (:111)
+        return s['conv1'](cat, out_dtype=x.dtype)          # Dropout(0.5) is the identity in eval mode (:111)
 
 
 class Mlp(nn.Module):
@@ -146,9 +147,9 @@ class DCN(HipModule):
     def hip_forward(self, x):
         s = self.hip_state(x.device)
         B, H, W, C = x.shape
-        offset = s['offset'](x)                                     # [B,H,W,18]
-        col = hip_ops.deform_im2col3x3(x, offset, self.groups)      # [B,H,W,g*9*cpg]
-        out = torch.empty(B, H, W, self.out_channels, dtype=torch.float32, device=x.device)
+        offset = s['offset'](x)                                     # [B,H,W,18], f32 whatever the dtype of x
+        col = hip_ops.deform_im2col3x3(x, offset, self.groups)      # [B,H,W,g*9*cpg], dtype of x
+        out = torch.empty(B, H, W, self.out_channels, dtype=x.dtype, device=x.device)
         for gi, conv in enumerate(s['convs']):
             conv(col, out, x_coff=gi * 9 * s['cpg'], y_coff=gi * s['opg'])
         return out
@@ -249,13 +250,15 @@ class HeightNet(HipModule):
             for w, b, act in s[name + '_gate'][1:]:
                 h = hip_ops.dense(h, w, None, b, act)
             gates[name] = h                                                             # sigmoid gate [B*N, mid]
-        x = s['reduce'](x)                                                              # :241
+        # bf16 mode: the mid-channel maps live in HBM as bf16 (like the ResNet chains); logits + context leave as f32
+        dt = hip_ops.activation_dtype(self.mid_channels, self.mid_channels // 4)
+        x = s['reduce'](x, out_dtype=dt)                                                # :241
         out = torch.empty(B, H, W, self.height_channels + self.context_channels, dtype=torch.float32, device=x.device)
         ctx_in = hip_ops.scale_channels(x, gates['context'])                           # SELayer, :155-159
         s['context'](ctx_in, out, y_coff=self.height_channels)                         # :242-244
         h = hip_ops.scale_channels(x, gates['height'])                                  # :245-246
         for blk in self.height_conv:
-            h = blk.hip_forward(h)                                                      # :247
+            h = blk.hip_forward(h, dt) if isinstance(blk, BasicBlock) else blk.hip_forward(h)   # :247
         s['height'](h, out, y_coff=0)                                                   # :248
         return out
 

@@ -434,3 +434,46 @@ def test_bf16_patch_conv_exact_on_small_integers(bf16_mode):
     conv = hip_ops.PackedConv(w.to(DEV), stride=1, pad=1)
     y = conv(x.permute(0, 2, 3, 1).contiguous().to(DEV), tile=hip_ops.TILE_PATCH)
     assert torch.equal(y.permute(0, 3, 1, 2).cpu(), F.conv2d(x, w, None, 1, 1))
+
+
+# ---------------------------------------------------------------------------------------------- bf16 twins of the small layers
+def _bf(t):
+    return t.bfloat16().to(DEV)
+
+
+def test_bf16_small_layers_match_f32_twins():
+    """act_bf16.hip: each kernel == its float32 twin evaluated on the same (bf16-representable) inputs, rounded once to bf16."""
+    g = torch.Generator().manual_seed(11)
+    B, H, W, C = 2, 9, 13, 64
+    x = torch.randn(B, H, W, C, generator=g).bfloat16()
+    xf = x.float().to(DEV)
+    gate = torch.rand(B, C, generator=g).to(DEV)
+    # SELayer gate
+    assert torch.equal(hip_ops.scale_channels(x.to(DEV), gate), hip_ops.scale_channels(xf, gate).bfloat16())
+    # global average pooling: f32 result, same two-stage summation order
+    assert torch.equal(hip_ops.global_avgpool(x.to(DEV)), hip_ops.global_avgpool(xf))
+    # broadcast into a channel slice
+    v = torch.randn(B, 32, generator=g).to(DEV)
+    wide = torch.zeros(B, H, W, 96, dtype=torch.bfloat16, device=DEV)
+    hip_ops.broadcast_channels(v, wide, y_coff=48)
+    ref = torch.zeros(B, H, W, 96, device=DEV)
+    hip_ops.broadcast_channels(v, ref, y_coff=48)
+    assert torch.equal(wide, ref.bfloat16())
+    # bilinear x2
+    assert torch.equal(hip_ops.upsample_bilinear2x(x.to(DEV)), hip_ops.upsample_bilinear2x(xf).bfloat16())
+    # a + b * sigmoid(c)
+    a, b, c = (torch.randn(B, H, W, C, generator=g).bfloat16() for _ in range(3))
+    assert torch.equal(hip_ops.add_mul_sigmoid(a.to(DEV), b.to(DEV), c.to(DEV)),
+                       hip_ops.add_mul_sigmoid(a.float().to(DEV), b.float().to(DEV), c.float().to(DEV)).bfloat16())
+    # deformable sampling (offsets stay f32), 4 groups
+    off = (torch.randn(B, H, W, 18, generator=g) * 1.5).to(DEV)
+    assert torch.equal(hip_ops.deform_im2col3x3(x.to(DEV), off, 4), hip_ops.deform_im2col3x3(xf, off, 4).bfloat16())
+
+
+def test_bf16_small_layers_reject_odd_channels():
+    from sgv3d_amd._lib import SGV3DError
+    x = torch.zeros(1, 4, 4, 12, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(SGV3DError):
+        hip_ops.scale_channels(x, torch.ones(1, 12, device=DEV))
+    with pytest.raises(SGV3DError):
+        hip_ops.upsample_bilinear2x(x)
