@@ -419,13 +419,16 @@ int sgv3d_deform_im2col3x3_bf16(int batch, int h, int w, int channels, int group
  *   x         NHWC [batch, h, w, x_ld] (channels x_coff .. x_coff + cin), f32 or bf16 (io_flags bit 0)
  *   y         NHWC [batch, h, w, y_ld] (channels y_coff .. y_coff + cout), f32 or bf16 (io_flags bit 1)
  *   residual  NHWC [batch, h, w, res_ld] in the dtype of y, or NULL;  scale / bias  f32 [cout] or NULL (1 / 0)
- * cin must be a multiple of 32, cout of 8; strides and offsets multiples of 8; pointers 16-B aligned. */
+ * cin must be a multiple of 32, cout of 8; strides and offsets multiples of 8; pointers 16-B aligned.
+ * split_k > 1 (small maps): the 32-channel stages of cin are divided over split_k workgroups per tile, raw partial sums go
+ * to workspace (4 * split_k * batch * h * w * cout bytes) and are added in fixed order by the split-K reduce kernel of
+ * sgv3d_conv2d_forward, which applies the epilogue; split_k <= cin / 32. */
 size_t sgv3d_conv3x3_patch_bf16_weight_bytes(int cout, int cin);
 int sgv3d_conv3x3_patch_bf16_pack_weight(const float *w, int cout, int cin, void *w_packed, void *stream);
 int sgv3d_conv3x3_patch_bf16_forward(int batch, int h, int w, int cin, int cout, int x_ld, int x_coff, int y_ld,
                                      int y_coff, int res_ld, int relu, const void *x, const void *w_packed,
                                      const float *scale, const float *bias, const void *residual, void *y,
-                                     int io_flags, void *stream);
+                                     int io_flags, int split_k, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ================================================================================================
  * Box decode + circle NMS  

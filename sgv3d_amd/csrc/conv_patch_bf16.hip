@@ -16,7 +16,7 @@
 //     (C^T = W . X^T), so the epilogue (folded BN, residual, ReLU in fp32) goes through a per-wave LDS stage and leaves as
 //     16-byte stores of 8 channels (bf16 output) or 4 channels (f32 output).
 // Bound: MFMA bf16 (2.5 PFLOP/s dense); algorithmic work 2 * B*H*W * cout * 9 * cin per launch.
-#include "common.hpp"
+#include "conv_common.hpp"
 
 using namespace sgv3d;
 
@@ -63,6 +63,8 @@ struct PatchArgs {
     const void *res;           // residual NHWC [B, H, W, res_ld] in the OUTPUT dtype, or NULL
     void *y;                   // NHWC [B, H, W, y_ld], f32 or bf16
     int H, W, cin, cout, x_ld, x_coff, y_ld, y_coff, res_ld, relu, tiles_x, tiles_y, ctiles;
+    int split;                 // > 1: blockIdx.z owns a range of the 32-channel stages and stores raw partial sums to ws
+    float *ws;                 // [split][B*H*W][cout] (the layout of the implicit-GEMM split-K, reduced by the same kernel)
 };
 
 template <bool XB, bool YB>
@@ -76,6 +78,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_bf16_kernel(const PatchArgs
     const int y0 = ty * kTY, x0 = tx * kTX;
     const int nchunk = a.cin / kCK;
     const size_t img = (size_t)b * a.H * a.W;
+    const int ck0 = a.split > 1 ? (int)((long long)nchunk * blockIdx.z / a.split) : 0;
+    const int ck1 = a.split > 1 ? (int)((long long)nchunk * (blockIdx.z + 1) / a.split) : nchunk;
 
     // ---- staging: this thread's (up to 10) 16-byte slots of a 32-channel patch stage ---------------------------------------
     constexpr int kPer = (kSlots + 255) / 256;      // 10
@@ -131,19 +135,19 @@ __global__ __launch_bounds__(256, 2) void conv_patch_bf16_kernel(const PatchArgs
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-    stage_load(0);
-    stage_store(0);
+    stage_load(ck0);
+    stage_store(ck0 & 1);
     bf16x8 bq[2][2][2];                 // weight fragments of the current / next tap: [buffer][k-step][n-tile]
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) bq[0][ks][nt] = wl[(size_t)(ks * 2 + nt) * 64];
+        for (int nt = 0; nt < 2; ++nt) bq[0][ks][nt] = wl[(size_t)ck0 * 9 * 4 * 64 + (size_t)(ks * 2 + nt) * 64];
     __syncthreads();
 
-    for (int ck = 0; ck < nchunk; ++ck) {
+    for (int ck = ck0; ck < ck1; ++ck) {
         const int buf = ck & 1;
         const char *pa = smem + buf * kBufB + abase;
-        const bool more = ck + 1 < nchunk;
+        const bool more = ck + 1 < ck1;
         if (more) stage_load(ck + 1);                                    // global loads of the next stage fly under the MFMAs
         const size_t wbase = (size_t)ck * 9 * 4 * 64;
 #pragma unroll
@@ -207,7 +211,13 @@ __global__ __launch_bounds__(256, 2) void conv_patch_bf16_kernel(const PatchArgs
                 const int gx = x0 + p;
                 f32x4 v0 = *reinterpret_cast<const f32x4 *>(stage + p * kStageLd + 8 * pc);
                 f32x4 v1 = *reinterpret_cast<const f32x4 *>(stage + p * kStageLd + 8 * pc + 4);
-                if (gy < a.H && gx < a.W && ch_ok) {
+                if (a.split > 1) {
+                    if (gy < a.H && gx < a.W && ch_ok) {
+                        float *wp = a.ws + ((size_t)blockIdx.z * gridDim.y * a.H * a.W + img + (size_t)gy * a.W + gx) * a.cout + ch;
+                        *reinterpret_cast<f32x4 *>(wp) = v0;
+                        *reinterpret_cast<f32x4 *>(wp + 4) = v1;
+                    }
+                } else if (gy < a.H && gx < a.W && ch_ok) {
                     const size_t pix = img + (size_t)gy * a.W + gx;
                     v0 = v0 * sc0 + sh0;
                     v1 = v1 * sc1 + sh1;
@@ -247,7 +257,16 @@ int launch_patch(const PatchArgs &a, int batch, hipStream_t st) {
     static PerDeviceSize lds_set;
     if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_patch_bf16_kernel<XB, YB>), kPatchLds, lds_set))
         return fail(SGV3D_ELAUNCH, "conv3x3_patch_bf16: cannot raise the dynamic LDS limit to %d", kPatchLds);
-    hipLaunchKernelGGL((conv_patch_bf16_kernel<XB, YB>), dim3(a.tiles_x * a.tiles_y * a.ctiles, batch), dim3(256), kPatchLds, st, a);
+    hipLaunchKernelGGL((conv_patch_bf16_kernel<XB, YB>), dim3(a.tiles_x * a.tiles_y * a.ctiles, batch, a.split), dim3(256), kPatchLds, st, a);
+    if (a.split > 1) {                   // second stage shared with the implicit GEMM: fixed-order sum of the partials + epilogue
+        ConvArgs r = {};
+        r.scale = a.scale; r.bias = a.bias; r.res = static_cast<const float *>(a.res); r.y = static_cast<float *>(a.y);
+        r.M = batch * a.H * a.W; r.N = a.cout; r.cout = a.cout; r.m_h = a.H; r.m_w = a.W; r.out_h = a.H; r.out_w = a.W;
+        r.y_ld = a.y_ld; r.y_coff = a.y_coff; r.res_ld = a.res_ld; r.relu = a.relu;
+        r.mode = SGV3D_CONV_NORMAL | (YB ? kConvYBf16 | kConvResBf16 : 0);
+        r.split_k = a.split; r.ws = a.ws;
+        return launch_splitk_reduce(r, st);
+    }
     return check_launch("conv_patch_bf16_kernel");
 }
 
@@ -268,7 +287,7 @@ extern "C" int sgv3d_conv3x3_patch_bf16_pack_weight(const float *w, int cout, in
 extern "C" int sgv3d_conv3x3_patch_bf16_forward(int batch, int h, int w, int cin, int cout, int x_ld, int x_coff, int y_ld,
                                                 int y_coff, int res_ld, int relu, const void *x, const void *w_packed,
                                                 const float *scale, const float *bias, const void *residual, void *y,
-                                                int io_flags, void *stream) {
+                                                int io_flags, int split_k, void *workspace, size_t workspace_bytes, void *stream) {
     SGV3D_REQUIRE(batch > 0 && batch <= 65535 && h > 0 && w > 0 && cin > 0 && cout > 0, "conv3x3_patch_bf16: bad shape");
     SGV3D_REQUIRE(cin % kCK == 0 && cout % 8 == 0, "conv3x3_patch_bf16: cin must be a multiple of 32 and cout of 8 (got %d / %d)", cin, cout);
     SGV3D_REQUIRE(x && w_packed && y, "conv3x3_patch_bf16: null pointer");
@@ -278,7 +297,15 @@ extern "C" int sgv3d_conv3x3_patch_bf16_forward(int batch, int h, int w, int cin
     SGV3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
                     reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
                   "conv3x3_patch_bf16: pointers must be 16-B aligned");
+    if (split_k < 1) split_k = 1;
+    SGV3D_REQUIRE(split_k <= cin / kCK && split_k <= 64, "conv3x3_patch_bf16: split_k = %d exceeds the %d stages of 32 input channels", split_k, cin / kCK);
+    if (split_k > 1) {
+        SGV3D_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "conv3x3_patch_bf16: split_k needs a 16-B aligned workspace");
+        if (workspace_bytes < sizeof(float) * (size_t)split_k * batch * h * w * cout)
+            return fail(SGV3D_ENOSPACE, "conv3x3_patch_bf16: workspace too small for split_k = %d", split_k);
+    }
     PatchArgs a;
+    a.split = split_k; a.ws = static_cast<float *>(workspace);
     a.x = x; a.w = static_cast<const __bf16 *>(w_packed); a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
     a.H = h; a.W = w; a.cin = cin; a.cout = cout; a.x_ld = x_ld; a.x_coff = x_coff; a.y_ld = y_ld; a.y_coff = y_coff;
     a.res_ld = res_ld; a.relu = relu; a.tiles_x = cdiv(w, kTX); a.tiles_y = cdiv(h, kTY); a.ctiles = cdiv(cout, 64);

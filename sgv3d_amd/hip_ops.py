@@ -356,7 +356,13 @@ class PackedConv:
                         split = cand
             return TILE_WINO, sk or split
         if t == 0 and self._patch_eligible(d) and d.out_h * d.out_w * d.batch >= 4096:
-            return TILE_PATCH, 1
+            wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 32) * -(-gemm_n // 64)
+            split = 1
+            if not sk and SPLIT_K:
+                for cand in (2, 3, 4, 6, 8):
+                    if wgs * cand <= 512 and self.cin // 32 // cand >= 2:
+                        split = cand
+            return TILE_PATCH, sk or split
         return (t or heuristic_tile(gemm_m, gemm_n)), (sk or 1)
 
     def _patch_eligible(self, d, gate=None):
@@ -375,7 +381,7 @@ class PackedConv:
             return lib.sgv3d_conv3x3_patch_bf16_forward(d.batch, d.in_h, d.in_w, self.cin, self.cout, d.x_ld, d.x_coff, d.y_ld,
                                                         d.y_coff, d.res_ld, d.relu, x.data_ptr(), self._patch_weights().data_ptr(),
                                                         _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
-                                                        out.data_ptr(), int(io), _st(x))
+                                                        out.data_ptr(), int(io), int(d.split_k), _lib.ptr(ws), nws, _st(x))
         if d.tile in (TILE_WINO, TILE_WINO_RES):
             if self.w_wino is None:
                 raise _lib.SGV3DError("this layer has no Winograd weights (needs 3x3 / stride 1 / pad 1 / cin % 8 == 0)")
@@ -449,8 +455,13 @@ class PackedConv:
                 if t == TILE_WINO:
                     nk = self.cin // 4      # k-steps of 8 channels; nk // s >= 8 keeps >= 4 steps per split
                     wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 16) * -(-gemm_n // 64)
-                if t in (TILE_WINO_RES, TILE_PATCH):
+                if t == TILE_PATCH:
+                    nk = self.cin // 32     # stages of 32 input channels; >= 2 per split
+                    wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 32) * -(-gemm_n // 64)
+                if t == TILE_WINO_RES:
                     splits = (1,)
+                elif t == TILE_PATCH and not fixed_split and SPLIT_K:
+                    splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 2 and wgs * s <= 1024]
                 elif fixed_split:
                     splits = (fixed_split,)
                 elif not SPLIT_K:

@@ -418,6 +418,12 @@ def test_bf16_patch_conv(bf16_mode, shape, io):
     # against the implicit-GEMM kernel: same operands, different summation order
     y2 = conv(xin, residual=rin, tile=4, split_k=1, out_dtype=odt)
     assert float((y.float() - y2.float()).abs().max()) <= (2.0 ** -7 if yb else 2e-5) * scale
+    # split over the 32-channel stages of cin (small maps): partial sums + the shared reduce kernel
+    for sk in (2, 3):
+        if cin // 32 >= sk:
+            y3 = conv(xin, residual=rin, tile=hip_ops.TILE_PATCH, split_k=sk, out_dtype=odt)
+            err3 = float((y3.float().permute(0, 3, 1, 2).cpu().double() - ref).abs().max())
+            assert err3 <= (2.0 ** -8 if yb else 2e-5) * scale, (sk, err3, scale)
     # channel-slice input and output
     wide_in = torch.zeros(B, H, W, cin + 16, dtype=xin.dtype, device=DEV)
     wide_in[..., 8:8 + cin] = xin
