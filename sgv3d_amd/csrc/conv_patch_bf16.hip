@@ -65,6 +65,7 @@ struct PatchArgs {
     int H, W, cin, cout, x_ld, x_coff, y_ld, y_coff, res_ld, relu, tiles_x, tiles_y, ctiles;
     int split;                 // > 1: blockIdx.z owns a range of the 32-channel stages and stores raw partial sums to ws
     float *ws;                 // [split][B*H*W][cout] (the layout of the implicit-GEMM split-K, reduced by the same kernel)
+    long long *dbg;            // tools only: cycle-counter stamps of workgroup 0 (2 + 2 * stages + 1 values), else NULL
 };
 
 template <bool XB, bool YB>
@@ -81,6 +82,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_bf16_kernel(const PatchArgs
     const int ck0 = a.split > 1 ? (int)((long long)nchunk * blockIdx.z / a.split) : 0;
     const int ck1 = a.split > 1 ? (int)((long long)nchunk * (blockIdx.z + 1) / a.split) : nchunk;
 
+#define PATCH_STAMP(slot) do { if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) a.dbg[slot] = (long long)__builtin_readcyclecounter(); } while (0)
+    PATCH_STAMP(0);
     // ---- staging: this thread's (up to 10) 16-byte slots of a 32-channel patch stage ---------------------------------------
     constexpr int kPer = (kSlots + 255) / 256;      // 10
     int s_lds[kPer];
@@ -143,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_bf16_kernel(const PatchArgs
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) bq[0][ks][nt] = wl[(size_t)ck0 * 9 * 4 * 64 + (size_t)(ks * 2 + nt) * 64];
     __syncthreads();
+    PATCH_STAMP(1);
 
     for (int ck = ck0; ck < ck1; ++ck) {
         const int buf = ck & 1;
@@ -181,8 +185,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_bf16_kernel(const PatchArgs
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) bq[0][ks][nt] = bq[1][ks][nt];
+        PATCH_STAMP(2 + 2 * (ck - ck0));
         if (more) stage_store(buf ^ 1);            // its readers (chunk ck - 1) passed the barrier that ended the previous iteration
         __syncthreads();
+        PATCH_STAMP(3 + 2 * (ck - ck0));
     }
 
     // ---- epilogue: transposed accumulators (pixel on the lane, 4 consecutive channels in registers 4 g .. 4 g + 3) -> per-wave
@@ -250,7 +256,11 @@ __global__ __launch_bounds__(256, 2) void conv_patch_bf16_kernel(const PatchArgs
             __builtin_amdgcn_wave_barrier();
         }
     }
+    PATCH_STAMP(2 + 2 * (ck1 - ck0));
+#undef PATCH_STAMP
 }
+
+static long long *g_patch_dbg = nullptr;
 
 template <bool XB, bool YB>
 int launch_patch(const PatchArgs &a, int batch, hipStream_t st) {
@@ -271,6 +281,8 @@ int launch_patch(const PatchArgs &a, int batch, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" void sgv3d_conv3x3_patch_bf16_debug_stamps(void *buf) { g_patch_dbg = static_cast<long long *>(buf); }
 
 extern "C" size_t sgv3d_conv3x3_patch_bf16_weight_bytes(int cout, int cin) {
     if (cout <= 0 || cin <= 0 || cin % kCK) return 0;
@@ -305,6 +317,7 @@ extern "C" int sgv3d_conv3x3_patch_bf16_forward(int batch, int h, int w, int cin
             return fail(SGV3D_ENOSPACE, "conv3x3_patch_bf16: workspace too small for split_k = %d", split_k);
     }
     PatchArgs a;
+    a.dbg = g_patch_dbg;
     a.split = split_k; a.ws = static_cast<float *>(workspace);
     a.x = x; a.w = static_cast<const __bf16 *>(w_packed); a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
     a.H = h; a.W = w; a.cin = cin; a.cout = cout; a.x_ld = x_ld; a.x_coff = x_coff; a.y_ld = y_ld; a.y_coff = y_coff;
