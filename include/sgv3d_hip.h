@@ -237,8 +237,11 @@ int sgv3d_conv2d_forward_bf16(const sgv3d_conv_desc *desc /*host*/, const float 
 /* bf16 ACTIVATIONS in HBM (bf16 mode, the convolution chains of the image backbone / BEV trunk): the same bf16-MFMA
  * convolution reading and / or writing bf16 tensors.  io_flags bit 0: x is bf16 [.., x_ld] (element offsets as in the
  * desc); bit 1: y AND residual are bf16 -- mode NORMAL or DECONV, no gate, cout / y_ld / y_coff / res_ld multiples of 8; the
- * epilogue (folded BN, residual, ReLU) runs in fp32 and rounds once to bf16.  Weights, scale, bias stay f32. */
-int sgv3d_conv2d_forward_bf16io(const sgv3d_conv_desc *desc /*host*/, const void *x, const float *w_packed,
+ * epilogue (folded BN, residual, ReLU) runs in fp32 and rounds once to bf16.  Scale and bias stay f32; w_packed is the
+ * bf16 copy of the packed weights here (same [cout_pad][k_pad] layout, made by sgv3d_conv_weight_to_bf16): the weights are
+ * the operand every workgroup of an output column re-reads from L2, 80 % of the load requests of a 1x1 layer. */
+int sgv3d_conv_weight_to_bf16(const float *w_packed, int k_pad, int cout_pad, void *w_packed_bf16, void *stream);
+int sgv3d_conv2d_forward_bf16io(const sgv3d_conv_desc *desc /*host*/, const void *x, const void *w_packed,
                                 const float *scale, const float *bias, const void *residual, const float *gate,
                                 void *y, void *workspace, size_t workspace_bytes, void *stream, int io_flags);
 

@@ -47,6 +47,7 @@ _PROTOS = {
     "sgv3d_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "sgv3d_conv2d_forward_bf16": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "sgv3d_conv2d_forward_bf16io": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_size_t, c_void_p, c_int]),
+    "sgv3d_conv_weight_to_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "sgv3d_conv2d_forward_f32x3": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "sgv3d_centerhead_branches_workspace_bytes": (c_size_t, [c_int] * 4),
     "sgv3d_centerhead_branches_forward": (c_int, [c_int] * 6 + [c_void_p, c_int] + [c_void_p] * 3 + [c_int] + [c_void_p] * 5

@@ -516,9 +516,13 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
         a_iw0[i] = ow * a.stride - a.pad;
         a_off[i] = (unsigned)((((long long)(n * a.in_h + a_ih0[i]) * a.in_w + a_iw0[i]) * a.x_ld + a.x_coff + cc * 4) * XES);
     }
+    // WB: with bf16 activations the packed weights are the bf16 copy as well (half the L2 -> CU bytes of the operand every
+    // workgroup of a column re-reads: 80 % of the requests of a ResNet 1x1 layer), stored to LDS as loaded
+    constexpr bool WB = XB || YB;
+    constexpr int WES = WB ? 2 : 4;
     unsigned b_off[B_CH];
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i) b_off[i] = (unsigned)(((size_t)(n0 + r0 + 32 * i) * a.k_pad + cc * 4) * 4);
+    for (int i = 0; i < B_CH; ++i) b_off[i] = (unsigned)(((size_t)(n0 + r0 + 32 * i) * a.k_pad + cc * 4) * WES);
 
     // bf16 MFMAs are 16x faster than f32 ones: the address arithmetic of the operand loads must shrink with them.
     // FAST path: which taps of a row's pixel fall inside the image is a bit mask computed once (<= 32 taps); a k-tile
@@ -600,8 +604,13 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
             }                                                                                         \
         }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < B_CH; ++i) {                                            \
-            const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_off[i], ktb_ * (BK * 4), 0)); \
-            RB[i].x = t_.x; RB[i].y = t_.y; RB[i].z = t_.z; RB[i].w = t_.w;                           \
+            if constexpr (WB) {                                                                       \
+                const f32x2n t_ = __builtin_bit_cast(f32x2n, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, b_off[i], ktb_ * (BK * 2), 0)); \
+                RB[i].x = t_.x; RB[i].y = t_.y;                                                       \
+            } else {                                                                                  \
+                const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_off[i], ktb_ * (BK * 4), 0)); \
+                RB[i].x = t_.x; RB[i].y = t_.y; RB[i].z = t_.z; RB[i].w = t_.w;                       \
+            }                                                                                         \
         }                                                                                             \
         ++ld_kt;                                                                                      \
         if constexpr (FAST) {                                                                         \
@@ -637,7 +646,14 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
                 SGV3D_CVT_STORE(As_ + (r0 + 32 * i) * LDKB + st_off, RA[i], kPlaneA);                 \
             }                                                                                         \
         }                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < B_CH; ++i) SGV3D_CVT_STORE(Bs_ + (r0 + 32 * i) * LDKB + st_off, RB[i], kPlaneB); \
+        _Pragma("unroll") for (int i = 0; i < B_CH; ++i) {                                            \
+            if constexpr (WB) {                                                                       \
+                f32x2n t2_ = {RB[i].x, RB[i].y};                                                      \
+                *reinterpret_cast<f32x2n *>(Bs_ + (r0 + 32 * i) * LDKB + st_off) = t2_;               \
+            } else {                                                                                  \
+                SGV3D_CVT_STORE(Bs_ + (r0 + 32 * i) * LDKB + st_off, RB[i], kPlaneB);                 \
+            }                                                                                         \
+        }                                                                                             \
     } while (0)
 
     const int wave = tid >> 6, lane = tid & 63;
@@ -1085,6 +1101,21 @@ extern "C" int sgv3d_conv_pack_weight(const float *w_src, int cout, int cin, int
     return check_launch("pack_weight_kernel");
 }
 
+namespace {
+__global__ __launch_bounds__(256) void weight_to_bf16_kernel(const float *__restrict__ src, long long n, __bf16 *__restrict__ dst) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (__bf16)src[i];
+}
+}  // namespace
+
+extern "C" int sgv3d_conv_weight_to_bf16(const float *w_packed, int k_pad, int cout_pad, void *w_packed_bf16, void *stream) {
+    SGV3D_REQUIRE(w_packed && w_packed_bf16 && k_pad > 0 && cout_pad > 0, "conv_weight_to_bf16: bad arguments");
+    const long long n = (long long)k_pad * cout_pad;
+    hipLaunchKernelGGL(weight_to_bf16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w_packed, n,
+                       static_cast<__bf16 *>(w_packed_bf16));
+    return check_launch("weight_to_bf16_kernel");
+}
+
 extern "C" size_t sgv3d_conv2d_workspace_bytes(const sgv3d_conv_desc *d) {
     if (!d || d->split_k <= 1) return 0;
     const long long mh = d->mode == SGV3D_CONV_DECONV ? d->in_h : d->out_h;
@@ -1129,7 +1160,7 @@ static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const f
     a.tiles_m = a.tiles_n = 0;
     a.korder = d->k_order;
     {
-        const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * ((io & 1) ? 2 : 4), wb = (long long)d->cout_pad * d->k_pad * 4;
+        const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * ((io & 1) ? 2 : 4), wb = (long long)d->cout_pad * d->k_pad * (io ? 2 : 4);
         SGV3D_REQUIRE(xb < 0xf0000000LL && wb < 0xf0000000LL, "conv2d_forward: input / packed weights larger than 3.75 GiB (32-bit buffer offsets)");
         a.x_bytes = (unsigned)xb;
         a.w_bytes = (unsigned)wb;
@@ -1219,12 +1250,13 @@ extern "C" int sgv3d_conv2d_forward_bf16(const sgv3d_conv_desc *d, const float *
     return conv2d_forward_impl(d, x, w_packed, scale, bias, residual, gate, y, workspace, workspace_bytes, stream, 1);
 }
 
-extern "C" int sgv3d_conv2d_forward_bf16io(const sgv3d_conv_desc *d, const void *x, const float *w_packed, const float *scale,
+extern "C" int sgv3d_conv2d_forward_bf16io(const sgv3d_conv_desc *d, const void *x, const void *w_packed, const float *scale,
                                            const float *bias, const void *residual, const float *gate, void *y,
                                            void *workspace, size_t workspace_bytes, void *stream, int io_flags) {
     SGV3D_REQUIRE(io_flags >= 1 && io_flags <= 3, "conv2d_forward_bf16io: io_flags must be 1 (bf16 input), 2 (bf16 output + residual) or 3");
-    return conv2d_forward_impl(d, static_cast<const float *>(x), w_packed, scale, bias, static_cast<const float *>(residual), gate,
-                               static_cast<float *>(y), workspace, workspace_bytes, stream, 1, io_flags);
+    return conv2d_forward_impl(d, static_cast<const float *>(x), static_cast<const float *>(w_packed), scale, bias,
+                               static_cast<const float *>(residual), gate, static_cast<float *>(y), workspace, workspace_bytes, stream,
+                               1, io_flags);
 }
 
 extern "C" int sgv3d_conv2d_forward_f32x3(const sgv3d_conv_desc *d, const float *x, const float *w_packed,

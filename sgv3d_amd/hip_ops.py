@@ -227,8 +227,18 @@ class PackedConv:
         self._tile_cache = {}
         # bf16 mode: fragment-ordered bf16 weights for the patch kernel, packed on first use
         self.w_patch = None
+        self.w_bf16 = None
         self.patch_ok = (not transposed and kh == 3 and kw == 3 and self.stride == 1 and self.dil == 1
                          and self.pad == 1 and self.cin % 32 == 0 and self.cout % 8 == 0 and self.cin == cin)
+
+    def _bf16_weights(self):
+        """bf16 copy of the packed implicit-GEMM weights (bf16-activation launches), made on first use."""
+        if self.w_bf16 is None:
+            self.w_bf16 = torch.empty(self.cout_pad, self.k_pad, dtype=torch.bfloat16, device=self.w.device)
+            with torch.cuda.device(self.w.device):
+                rc = _lib.load().sgv3d_conv_weight_to_bf16(self.w.data_ptr(), self.k_pad, self.cout_pad, self.w_bf16.data_ptr(), _st(self.w))
+            _lib.check(rc, "sgv3d_conv_weight_to_bf16")
+        return self.w_bf16
 
     def _patch_weights(self):
         if self.w_patch is None:
@@ -389,7 +399,7 @@ class PackedConv:
                                                      _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
                                                      _lib.ptr(gate), out.data_ptr(), _lib.ptr(ws), nws, _st(x))
         if io:
-            return lib.sgv3d_conv2d_forward_bf16io(ctypes.byref(d), x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.scale),
+            return lib.sgv3d_conv2d_forward_bf16io(ctypes.byref(d), x.data_ptr(), self._bf16_weights().data_ptr(), _lib.ptr(self.scale),
                                                    _lib.ptr(self.shift), _lib.ptr(residual), _lib.ptr(gate), out.data_ptr(),
                                                    _lib.ptr(ws), nws, _st(x), int(io))
         x3 = d.tile > 10 or (MFMA_F32X3 is True)
