@@ -427,8 +427,9 @@ int sgv3d_deform_im2col3x3_bf16(int batch, int h, int w, int channels, int group
  * to workspace (4 * split_k * batch * h * w * cout bytes) and are added in fixed order by the split-K reduce kernel of
  * sgv3d_conv2d_forward, which applies the epilogue; split_k <= cin / 32. */
 size_t sgv3d_conv3x3_patch_bf16_weight_bytes(int cout, int cin);
-/* Tools: debug_stamps(buf) makes workgroup 0 write 3 + 2 * (cin / 32) cycle-counter stamps (start, prologue done, then per
- * 32-channel stage: MFMAs done / stage handed over, and the end of the epilogue) into the device buffer; NULL switches it off. */
+/* Tools: debug_stamps(buf) makes workgroup 0 write 5 + 2 * (cin / 32) cycle-counter stamps (start, prologue done, then per
+ * 32-channel stage: MFMAs done / stage handed over, the end of the epilogue, and two stamps inside it) into the device
+ * buffer; NULL switches it off. */
 void sgv3d_conv3x3_patch_bf16_debug_stamps(void *buf);
 int sgv3d_conv3x3_patch_bf16_pack_weight(const float *w, int cout, int cin, void *w_packed, void *stream);
 int sgv3d_conv3x3_patch_bf16_forward(int batch, int h, int w, int cin, int cout, int x_ld, int x_coff, int y_ld,

@@ -712,20 +712,19 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
     constexpr bool kPrefetchResB = YB && WTM * WTN <= 2;
     const __bf16 *const resb = reinterpret_cast<const __bf16 *>(a.res);
     bf16x8 resq[WTM][WTN][2];
-    if constexpr (kPrefetchResB) {
-        if (a.res != nullptr && a.split_k <= 1) {
-#pragma unroll
-            for (int mt = 0; mt < WTM; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < WTN; ++nt)
-#pragma unroll
-                    for (int ps = 0; ps < 2; ++ps) {
-                        const int row = m0 + (tid >> 7) * (BM / 2) + mt * 32 + ((tid & 63) >> 2) + 16 * ps;
-                        const int ch = n0 + ((tid >> 6) & 1) * (BN / 2) + nt * 32 + 8 * (tid & 3);
-                        if (row < a.M && ch < a.N) resq[mt][nt][ps] = *reinterpret_cast<const bf16x8 *>(resb + (size_t)row * a.res_ld + ch);
-                    }
-        }
-    }
+#define SGV3D_FETCH_RESB()                                                                            \
+    do {                                                                                              \
+        if (a.res != nullptr && a.split_k <= 1) {                                                     \
+            _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                        \
+                _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt)                                    \
+                    _Pragma("unroll") for (int ps = 0; ps < 2; ++ps) {                                \
+                        const int row = m0 + (tid >> 7) * (BM / 2) + mt * 32 + ((tid & 63) >> 2) + 16 * ps; \
+                        const int ch = n0 + ((tid >> 6) & 1) * (BN / 2) + nt * 32 + 8 * (tid & 3);    \
+                        if (row < a.M && ch < a.N) resq[mt][nt][ps] = *reinterpret_cast<const bf16x8 *>(resb + (size_t)row * a.res_ld + ch); \
+                    }                                                                                 \
+        }                                                                                             \
+    } while (0)
+    if constexpr (kPrefetchResB) SGV3D_FETCH_RESB();
     // (GROUP_PLANES -- the per-branch hidden maps of the two-kernel head path -- is row-linear too when a wave's columns
     // stay inside one group: plane base + row * group width)
     const bool fast_epi = (a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr) ||
@@ -788,27 +787,41 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
                 }
             return;
         }
+        // 128x128 tile: no registers for the residual under the k loop, but the operand stages are dead now -- all residual
+        // rows of the wave's four tiles are asked for at once, not one tile at a time behind the previous tile's stores
+        if constexpr (YB && !kPrefetchResB) SGV3D_FETCH_RESB();
         constexpr int SLD = 36;                                          // floats per staged pixel row (144 B)
         float *stage = smem + wave * (32 * SLD);                          // the operand buffers are dead: the loop ended on a barrier
         __bf16 *const yb = reinterpret_cast<__bf16 *>(a.y);
         const int pc = lane & 3, pp = lane >> 2;
         const bool deconv = (a.mode & kConvModeMask) == SGV3D_CONV_DECONV;
+        // per-channel terms of all the wave's n-tiles first: one memory latency, not one per n-tile
+        int co_[WTN], dy_[WTN], dx_[WTN];
+        f32x4n sc0_[WTN], sc1_[WTN], sh0_[WTN], sh1_[WTN];
 #pragma unroll
         for (int nt = 0; nt < WTN; ++nt) {
             const int ch = pcol0 + nt * 32 + 8 * pc;                      // GEMM column of this lane's 8-channel chunk
-            const bool ch_ok = ch < a.N;
             // DECONV (kernel == stride transposed conv as a 1x1 GEMM): column = tap * cout + co, the chunk stays inside one
             // tap because cout % 8 == 0; input pixel (ih, iw) lands at output pixel (ih ks + dy, iw ks + dx)
-            int co = ch, dy = 0, dx = 0;
+            co_[nt] = ch; dy_[nt] = 0; dx_[nt] = 0;
             if (deconv) {
                 const int tap = ch / a.cout;
-                co = ch - tap * a.cout;
-                dy = tap / a.ks;
-                dx = tap - dy * a.ks;
+                co_[nt] = ch - tap * a.cout;
+                dy_[nt] = tap / a.ks;
+                dx_[nt] = tap - dy_[nt] * a.ks;
             }
-            f32x4n sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
-            if (ch_ok && a.scale) { sc0 = *reinterpret_cast<const f32x4n *>(a.scale + co); sc1 = *reinterpret_cast<const f32x4n *>(a.scale + co + 4); }
-            if (ch_ok && a.bias) { sh0 = *reinterpret_cast<const f32x4n *>(a.bias + co); sh1 = *reinterpret_cast<const f32x4n *>(a.bias + co + 4); }
+            const f32x4n one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+            sc0_[nt] = sc1_[nt] = one;
+            sh0_[nt] = sh1_[nt] = zero;
+            if (ch < a.N && a.scale) { sc0_[nt] = *reinterpret_cast<const f32x4n *>(a.scale + co_[nt]); sc1_[nt] = *reinterpret_cast<const f32x4n *>(a.scale + co_[nt] + 4); }
+            if (ch < a.N && a.bias) { sh0_[nt] = *reinterpret_cast<const f32x4n *>(a.bias + co_[nt]); sh1_[nt] = *reinterpret_cast<const f32x4n *>(a.bias + co_[nt] + 4); }
+        }
+#pragma unroll
+        for (int nt = 0; nt < WTN; ++nt) {
+            const int ch = pcol0 + nt * 32 + 8 * pc;
+            const bool ch_ok = ch < a.N;
+            const int co = co_[nt], dy = dy_[nt], dx = dx_[nt];
+            const f32x4n sc0 = sc0_[nt], sc1 = sc1_[nt], sh0 = sh0_[nt], sh1 = sh1_[nt];
 #pragma unroll
             for (int mt = 0; mt < WTM; ++mt) {
 #pragma unroll
@@ -827,9 +840,7 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
                         v0 = v0 * sc0 + sh0;
                         v1 = v1 * sc1 + sh1;
                         if (a.res != nullptr) {
-                            bf16x8 rq;
-                            if constexpr (kPrefetchResB) rq = resq[mt][nt][ps];
-                            else rq = *reinterpret_cast<const bf16x8 *>(resb + (size_t)row * a.res_ld + ch);
+                            const bf16x8 rq = resq[mt][nt][ps];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) { v0[i] += (float)rq[i]; v1[i] += (float)rq[4 + i]; }
                         }
@@ -852,6 +863,7 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
         }
         return;
     }
+#undef SGV3D_FETCH_RESB
     // epilogue: the accumulator layout is that of every 32x32 MFMA (row = (e & 3) + 8 (e >> 2) + 4 h, column = lane & 31),
     // so the f32 kernel's fast path (hoisted channel terms, buffer stores with scalar row offsets) applies unchanged
     if (fast_epi) {

@@ -195,13 +195,42 @@ __global__ __launch_bounds__(256, 2) void conv_patch_bf16_kernel(const PatchArgs
     // LDS stage -> lane = (pixel lane >> 2 (+16), 8-channel chunk lane & 3) -> folded BN, residual, ReLU -> 16- / 32-byte rows
     float *stage = reinterpret_cast<float *>(smem) + wave * (32 * kStageLd);
     const int pc = lane & 3, pp = lane >> 2;
+    // per-channel terms and (no split) the residual rows of all 8 tiles of the wave first: one memory latency in all,
+    // not one per tile behind the previous tile's stores
+    f32x4 sc0_[2], sc1_[2], sh0_[2], sh1_[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int ch = ct * 64 + nt * 32 + 8 * pc;
+        const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+        sc0_[nt] = sc1_[nt] = one;
+        sh0_[nt] = sh1_[nt] = zero;
+        if (ch < a.cout && a.scale) { sc0_[nt] = *reinterpret_cast<const f32x4 *>(a.scale + ch); sc1_[nt] = *reinterpret_cast<const f32x4 *>(a.scale + ch + 4); }
+        if (ch < a.cout && a.bias) { sh0_[nt] = *reinterpret_cast<const f32x4 *>(a.bias + ch); sh1_[nt] = *reinterpret_cast<const f32x4 *>(a.bias + ch + 4); }
+    }
+    bf16x8 resq[2][4][2];             // bf16 output: the residual of the 8 tiles (an f32 residual is read at its use: 128 registers)
+    const bool has_res = a.res != nullptr && a.split <= 1;
+    if (YB && has_res) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int ch = ct * 64 + nt * 32 + 8 * pc;
+                    const int gy = y0 + wave * 4 + mt, gx = x0 + pp + 16 * ps;
+                    if (gy < a.H && gx < a.W && ch < a.cout) {
+                        const size_t pix = img + (size_t)gy * a.W + gx;
+                        resq[nt][mt][ps] = *reinterpret_cast<const bf16x8 *>(static_cast<const __bf16 *>(a.res) + pix * a.res_ld + ch);
+                    }
+                }
+    }
+    PATCH_STAMP(3 + 2 * (ck1 - ck0));
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        if (nt == 1) PATCH_STAMP(4 + 2 * (ck1 - ck0));
+        const int ch = ct * 64 + nt * 32 + 8 * pc;
         const bool ch_ok = ch < a.cout;
-        f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
-        if (ch_ok && a.scale) { sc0 = *reinterpret_cast<const f32x4 *>(a.scale + ch); sc1 = *reinterpret_cast<const f32x4 *>(a.scale + ch + 4); }
-        if (ch_ok && a.bias) { sh0 = *reinterpret_cast<const f32x4 *>(a.bias + ch); sh1 = *reinterpret_cast<const f32x4 *>(a.bias + ch + 4); }
+        const f32x4 sc0 = sc0_[nt], sc1 = sc1_[nt], sh0 = sh0_[nt], sh1 = sh1_[nt];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -227,9 +256,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_bf16_kernel(const PatchArgs
                     const size_t pix = img + (size_t)gy * a.W + gx;
                     v0 = v0 * sc0 + sh0;
                     v1 = v1 * sc1 + sh1;
-                    if (a.res != nullptr) {
+                    if (has_res) {
                         if constexpr (YB) {
-                            const bf16x8 rq = *reinterpret_cast<const bf16x8 *>(static_cast<const __bf16 *>(a.res) + pix * a.res_ld + ch);
+                            const bf16x8 rq = resq[nt][mt][ps];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) { v0[i] += (float)rq[i]; v1[i] += (float)rq[4 + i]; }
                         } else {
