@@ -156,6 +156,18 @@ def activation_dtype(*channel_counts):
     return torch.bfloat16 if all(int(c) % 8 == 0 for c in channel_counts) else None
 
 
+def channel_align():
+    """Granularity the layers that own their activation buffers pad channel counts to: 4 (16-byte f32 rows); 32 in
+    bf16-activation mode, where a multiple of 32 input channels opens the chunk-major k order, bf16 tensors in HBM and the
+    patch kernel (SGV3D's 87 / 174 / 348 / 696-channel BEV trunk -> 96 / 192 / 352 / 704; the extra channels are exact zeros)."""
+    return 32 if activation_dtype() is not None else 4
+
+
+def pad_channels(c, align=None):
+    align = int(align or channel_align())
+    return (int(c) + align - 1) // align * align
+
+
 class PackedConv:
     """One convolution (or kernel==stride transposed convolution) with its weights repacked for the
     MFMA implicit-GEMM kernel and BN / bias folded into a per-channel scale & shift."""
@@ -171,8 +183,9 @@ class PackedConv:
         # weights downstream, so every pixel row stays 16-byte aligned for the kernels.
         odim = 1 if transposed else 0
         self.cout_real = int(w.shape[odim])
-        if pad_out and self.cout_real % 4:
-            extra = 4 - self.cout_real % 4
+        out_align = 4 if pad_out is True else int(pad_out or 0)       # pad_out: True = 4, or the alignment itself
+        if out_align and self.cout_real % out_align:
+            extra = out_align - self.cout_real % out_align
             shape = list(w.shape)
             shape[odim] = extra
             w = torch.cat([w, w.new_zeros(shape)], odim).contiguous()

@@ -84,10 +84,15 @@ class BasicBlock(HipModule):
         self.downsample = downsample
 
     def hip_compile(self, device):
-        s = dict(c1=conv_bn(self.conv1, self.bn1, True, device, pad_out=True),
-                 c2=conv_bn(self.conv2, self.bn2, True, device, pad_out=True))
+        # channel counts are padded to the owner network's alignment (ResNet.hip_compile hands it down; 4, or 32 in
+        # bf16-activation mode): this block's input was padded the same way by its producer
+        al = getattr(self, '_hip_align', None) or hip_ops.channel_align()
+        pc = lambda c: hip_ops.pad_channels(c, al)
+        s = dict(c1=conv_bn(self.conv1, self.bn1, True, device, cin_pad=pc(self.conv1.in_channels), pad_out=al),
+                 c2=conv_bn(self.conv2, self.bn2, True, device, cin_pad=pc(self.conv2.in_channels), pad_out=al))
         if self.downsample is not None:
-            s['ds'] = conv_bn(self.downsample[0], self.downsample[1], False, device, pad_out=True)
+            s['ds'] = conv_bn(self.downsample[0], self.downsample[1], False, device,
+                              cin_pad=pc(self.downsample[0].in_channels), pad_out=al)
         return s
 
     def hip_forward(self, x, act_dtype=None):
@@ -195,7 +200,11 @@ class ResNet(HipModule):
 
     def hip_compile(self, device):
         cin_pad = (self.in_channels + 3) // 4 * 4
-        return dict(stem=conv_bn(self.conv1, self.bn1, True, device, cin_pad=cin_pad, pad_out=True), cin_pad=cin_pad)
+        align = hip_ops.channel_align()
+        for m in self.modules():
+            if isinstance(m, BasicBlock):
+                m._hip_align = align          # the blocks compile lazily: same padding as the stem, whatever the mode is then
+        return dict(stem=conv_bn(self.conv1, self.bn1, True, device, cin_pad=cin_pad, pad_out=align), cin_pad=cin_pad, align=align)
 
     def hip_stem(self, x_nhwc):
         """conv1 + bn1 + relu on an NHWC input whose channels are already padded to a multiple of 4."""
@@ -206,7 +215,10 @@ class ResNet(HipModule):
         channel count is a multiple of 8 (16-byte rows); None = fp32 tensors."""
         if not (hip_ops.MFMA_BF16 and hip_ops.BF16_ACTIVATIONS) or hip_ops.MFMA_F32X3:
             return None
-        chans = [self.conv1.out_channels] + [m.out_channels for m in self.modules() if isinstance(m, nn.Conv2d)]
+        align = self._hip[1].get('align', 4) if self._hip is not None else hip_ops.channel_align()   # as compiled
+        basic = any(isinstance(m, BasicBlock) for m in self.modules())
+        pad = (lambda c: hip_ops.pad_channels(c, align)) if basic else (lambda c: c)    # as compiled (Bottlenecks are not padded)
+        chans = [pad(self.conv1.out_channels)] + [pad(m.out_channels) for m in self.modules() if isinstance(m, nn.Conv2d)]
         return torch.bfloat16 if all(c % 8 == 0 for c in chans) else None
 
     def hip_forward(self, x_nhwc, use_maxpool=True):
