@@ -169,7 +169,8 @@ def main():
         workload = workload.replace("fp32", "fp32 products as 3 x bf16 split operands on the bf16 MFMA, f32 accumulation")
     if args.dtype == "bf16":
         workload = workload.replace("fp32 (BASELINE configs[2] asks bf16)", "fp32").replace(
-            "fp32", "bf16 MFMA operands / f32 accumulation and f32 tensors in HBM")
+            "fp32", "bf16 MFMA operands / f32 accumulation, bf16 activations in HBM inside the conv chains "
+                    "(height / depth logits, context, lifted features, BEV map and predictions f32)")
     torch.manual_seed(0)
     model = BEVHeight(bc, hc).eval()
     S.randomize_norm_stats_(model, 0, residual_gamma=0.3)    # small last-BN gamma per residual block, as mmdet initialises
