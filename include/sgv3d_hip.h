@@ -93,6 +93,11 @@ int sgv3d_voxel_pooling_forward_planned(int batch_size, int num_points, int num_
                                         const void *plan, const float *input_features,
                                         float *output_features, void *workspace, size_t workspace_bytes,
                                         void *stream);
+/* bf16 compute mode: input_features are bf16 [B, N, C] (24 <= C <= 256, C % 4 == 0); sums and output_features stay f32. */
+int sgv3d_voxel_pooling_forward_planned_bf16(int batch_size, int num_points, int num_channels,
+                                             int num_voxel_x, int num_voxel_y, const void *plan,
+                                             const void *input_features_bf16, float *output_features,
+                                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* Fused lift-splat (optional fast path beyond the operator boundary):
  *   out[b, y, x, :] = sum over plan points p=(d, pixel) of prob[b, d, pixel] * context[b, pixel, :]
@@ -151,6 +156,10 @@ int sgv3d_geometry_voxel_index(int num_cams, int cams_per_batch, int num_depth, 
  *   lifted  f32 [B, D, P, C] or NULL  = prob[b,d,p] * context[b,p,c]  (== [B,1,D,fH,fW,C] contiguous) */
 int sgv3d_lift(int batch_size, int num_pixels, int num_depth, int num_channels,
                const float *height_context, float *prob, float *lifted, void *stream);
+/* bf16 compute mode: the same with the lifted tensor written as bf16 (products formed in f32, rounded once; the largest
+ * HBM stream of the path shrinks 2x).  num_channels % 4 == 0; read back by sgv3d_voxel_pooling_forward_planned_bf16. */
+int sgv3d_lift_bf16(int batch_size, int num_pixels, int num_depth, int num_channels, const float *height_context,
+                    float *prob, void *lifted_bf16, void *stream);
 
 /* ================================================================================================
  * Convolution family (MFMA implicit GEMM, fp32 in / fp32 accumulate, NHWC activations)

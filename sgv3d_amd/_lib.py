@@ -36,11 +36,13 @@ _PROTOS = {
     "sgv3d_voxel_plan_stats_offset": (c_size_t, [c_int] * 4),
     "sgv3d_voxel_pooling_workspace_bytes": (c_size_t, [c_int] * 3),
     "sgv3d_voxel_pooling_forward_planned": (c_int, [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "sgv3d_voxel_pooling_forward_planned_bf16": (c_int, [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_void_p]),
     "sgv3d_lift_splat_planned": (c_int, [c_int] * 6 + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "sgv3d_voxel_pooling_backward": (c_int, [c_int] * 3 + [c_void_p, c_void_p, c_ll, c_ll, c_ll, c_ll, c_void_p, c_void_p]),
     "sgv3d_calib_prep": (c_int, [c_int] + [c_void_p] * 6),
     "sgv3d_geometry_voxel_index": (c_int, [c_int] * 5 + [c_void_p] * 4 + [ctypes.POINTER(ctypes.c_float)] * 2 + [c_void_p] * 3),
     "sgv3d_lift": (c_int, [c_int] * 4 + [c_void_p] * 4),
+    "sgv3d_lift_bf16": (c_int, [c_int] * 4 + [c_void_p] * 4),
     "sgv3d_conv_pack_geometry": (None, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "sgv3d_conv_pack_weight": (c_int, [c_void_p] + [c_int] * 7 + [c_void_p, c_int, c_int, c_void_p]),
     "sgv3d_conv2d_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),

@@ -11,9 +11,15 @@ namespace {
 constexpr int kPixTile = 16;   // pixels per workgroup
 constexpr int kBlock = 256;
 
-// height_context [B, P, D+C]; prob [B, D, P]; lifted [B, D, P, C]
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// height_context [B, P, D+C]; prob [B, D, P]; lifted [B, D, P, C] (f32, or bf16 with LB: bf16 compute mode, C % 4 == 0 --
+// the products are formed in f32 and rounded once; the tensor is the largest HBM stream of the path, 2x smaller this way)
+template <bool LB>
 __global__ __launch_bounds__(kBlock) void lift_kernel(int P, int D, int C, const float *__restrict__ hc,
-                                                      float *__restrict__ prob, float *__restrict__ lifted) {
+                                                      float *__restrict__ prob, void *__restrict__ lifted_) {
+    float *const lifted = static_cast<float *>(lifted_);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *pr = smem;                      // [kPixTile][D]
     float *cx = smem + kPixTile * D;       // [kPixTile][C]   (D*kPixTile is a multiple of 4 floats)
@@ -65,8 +71,13 @@ __global__ __launch_bounds__(kBlock) void lift_kernel(int P, int D, int C, const
                 const int px = r / c4n, c4 = r - px * c4n;
                 const float w = pr[px * D + d];
                 const float4 v = *reinterpret_cast<const float4 *>(cx + px * C + c4 * 4);
-                float4 o = make_float4(w * v.x, w * v.y, w * v.z, w * v.w);
-                *reinterpret_cast<float4 *>(lifted + (((size_t)b * D + d) * P + p0 + px) * C + c4 * 4) = o;
+                const size_t at = (((size_t)b * D + d) * P + p0 + px) * C + c4 * 4;
+                if constexpr (LB) {
+                    const f32x4 o = {w * v.x, w * v.y, w * v.z, w * v.w};
+                    *reinterpret_cast<bf16x4 *>(static_cast<__bf16 *>(lifted_) + at) = __builtin_convertvector(o, bf16x4);
+                } else {
+                    *reinterpret_cast<float4 *>(lifted + at) = make_float4(w * v.x, w * v.y, w * v.z, w * v.w);
+                }
             }
         } else {
             const int per_d = npix * C;
@@ -91,7 +102,21 @@ extern "C" int sgv3d_lift(int batch_size, int num_pixels, int num_depth, int num
     if ((num_channels & 3) == 0)
         SGV3D_REQUIRE(lifted == nullptr || (reinterpret_cast<uintptr_t>(lifted) & 15) == 0, "lift: lifted must be 16-B aligned");
     dim3 grid(cdiv(num_pixels, kPixTile), batch_size);
-    hipLaunchKernelGGL(lift_kernel, grid, dim3(kBlock), lds, as_stream(stream), num_pixels, num_depth, num_channels,
-                       height_context, prob, lifted);
+    hipLaunchKernelGGL(lift_kernel<false>, grid, dim3(kBlock), lds, as_stream(stream), num_pixels, num_depth, num_channels,
+                       height_context, prob, static_cast<void *>(lifted));
     return check_launch("lift_kernel");
+}
+
+extern "C" int sgv3d_lift_bf16(int batch_size, int num_pixels, int num_depth, int num_channels, const float *height_context,
+                               float *prob, void *lifted_bf16, void *stream) {
+    SGV3D_REQUIRE(batch_size > 0 && num_pixels > 0 && num_depth > 0 && num_channels > 0 && (num_channels & 3) == 0,
+                  "lift_bf16: sizes must be positive and the channel count a multiple of 4");
+    SGV3D_REQUIRE(height_context && lifted_bf16, "lift_bf16: null pointer");
+    const size_t lds = sizeof(float) * (size_t)kPixTile * (num_depth + num_channels);
+    SGV3D_REQUIRE(lds <= 64 * 1024, "lift_bf16: D+C=%d too large for the LDS tile", num_depth + num_channels);
+    SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(lifted_bf16) & 7) == 0, "lift_bf16: lifted must be 8-B aligned");
+    dim3 grid(cdiv(num_pixels, kPixTile), batch_size);
+    hipLaunchKernelGGL(lift_kernel<true>, grid, dim3(kBlock), lds, as_stream(stream), num_pixels, num_depth, num_channels,
+                       height_context, prob, lifted_bf16);
+    return check_launch("lift_kernel<bf16>");
 }

@@ -558,7 +558,10 @@ __global__ __launch_bounds__(kBlock) void vp_gather_kernel(
 // ------------------------------------------------------------------------------------------------
 constexpr int kChunkMax = 16;
 
-template <bool FUSED>
+typedef __bf16 vp_bf16x4 __attribute__((ext_vector_type(4)));
+
+// FB: the feature rows are bf16 (bf16 compute mode: sgv3d_lift_bf16 wrote them); sums stay f32
+template <bool FUSED, bool FB = false>
 __global__ __launch_bounds__(kBlock) void vp_gather2_kernel(
     long long V, int C, int lpr, int groups, int ch, const int *__restrict__ seg_start,
     const int *__restrict__ order, const int *__restrict__ slot_voxel, const float *__restrict__ feats,
@@ -602,6 +605,9 @@ __global__ __launch_bounds__(kBlock) void vp_gather2_kernel(
                 const int pix = (idx - b * N) % P;
                 pr[k] = prob[idx];
                 val[k] = *reinterpret_cast<const float4 *>(ctx + ((size_t)b * P + pix) * C + (size_t)cl * 4);
+            } else if constexpr (FB) {
+                const vp_bf16x4 q = *reinterpret_cast<const vp_bf16x4 *>(reinterpret_cast<const __bf16 *>(feats) + (size_t)idx * C + (size_t)cl * 4);
+                val[k] = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
             } else {
                 val[k] = *reinterpret_cast<const float4 *>(feats + (size_t)idx * C + (size_t)cl * 4);
             }
@@ -728,7 +734,7 @@ GatherGeom gather_geom(long long total_pts, int C) {
     return G;
 }
 
-template <bool FUSED>
+template <bool FUSED, bool FB = false>
 int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const float *feats,
                   const float *prob, const float *ctx, int P, float *out, void *workspace, size_t ws_bytes,
                   hipStream_t st) {
@@ -745,12 +751,13 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
         const long long waves = (G.nchunks + G.groups - 1) / G.groups;
         const int grid = cdiv(waves, kBlock / 64);
         float *partial = static_cast<float *>(workspace);
-        hipLaunchKernelGGL((vp_gather2_kernel<FUSED>), dim3(grid), dim3(kBlock), 0, st, L.V, C, G.lpr, G.groups, G.ch,
+        hipLaunchKernelGGL((vp_gather2_kernel<FUSED, FB>), dim3(grid), dim3(kBlock), 0, st, L.V, C, G.lpr, G.groups, G.ch,
                            seg, order, slotvox, feats, prob, ctx, N, P, out, partial);
         hipLaunchKernelGGL(vp_fixup_kernel, dim3(grid), dim3(kBlock), 0, st, L.V, C, G.lpr, G.groups, G.ch, seg, slotvox,
                            partial, out);
         return check_launch(FUSED ? "vp_lift_splat(v2)" : "vp_gather2_kernel");
     }
+    if (FB) return fail(SGV3D_EINVAL, "voxel pooling: bf16 features need 24 <= C <= 256, C %% 4 == 0 (got %d)", C);
     const long long waves = (L.V + kVoxPerWave - 1) / kVoxPerWave;
     const int grid = cdiv(waves, kBlock / 64);
     if (C % 4 == 0) {
@@ -894,6 +901,19 @@ extern "C" int sgv3d_voxel_pooling_forward_planned(int batch_size, int num_point
     return launch_gather<false>(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, plan,
                                 input_features, nullptr, nullptr, 1, output_features, workspace, workspace_bytes,
                                 as_stream(stream));
+}
+
+extern "C" int sgv3d_voxel_pooling_forward_planned_bf16(int batch_size, int num_points, int num_channels, int num_voxel_x,
+                                                        int num_voxel_y, const void *plan, const void *input_features_bf16,
+                                                        float *output_features, void *workspace, size_t workspace_bytes,
+                                                        void *stream) {
+    if (int rc = check_common(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, 1)) return rc;
+    SGV3D_REQUIRE(plan && input_features_bf16 && output_features, "voxel_pooling_forward_planned_bf16: null pointer");
+    SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(input_features_bf16) & 7) == 0 && (reinterpret_cast<uintptr_t>(output_features) & 15) == 0,
+                  "voxel_pooling_forward_planned_bf16: features must be 8-B, output 16-B aligned");
+    return launch_gather<false, true>(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, plan,
+                                      static_cast<const float *>(input_features_bf16), nullptr, nullptr, 1, output_features,
+                                      workspace, workspace_bytes, as_stream(stream));
 }
 
 extern "C" int sgv3d_lift_splat_planned(int batch_size, int num_depth, int num_pixels, int num_channels,

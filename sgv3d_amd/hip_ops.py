@@ -743,15 +743,18 @@ def centerhead_branches_bf16(x, packed, scale1, shift1, b2, out_begin, num_branc
     return out
 
 
-def lift(height_context, D, C, want_prob=False, want_lifted=True):
-    """height_context NHWC [B,fH,fW,D+C] -> (prob [B,D,P] | None, lifted [B,D,P,C] | None)."""
+def lift(height_context, D, C, want_prob=False, want_lifted=True, lifted_dtype=None):
+    """height_context NHWC [B,fH,fW,D+C] -> (prob [B,D,P] | None, lifted [B,D,P,C] | None).
+    ``lifted_dtype=torch.bfloat16`` (bf16 compute mode, C % 4 == 0): the lifted tensor is written as bf16."""
     B, fH, fW, ld = (int(s) for s in height_context.shape)
     assert ld == D + C
     P = fH * fW
+    lifted_dtype = lifted_dtype or torch.float32
     prob = torch.empty(B, D, P, dtype=torch.float32, device=height_context.device) if want_prob else None
-    lifted = torch.empty(B, D, P, C, dtype=torch.float32, device=height_context.device) if want_lifted else None
+    lifted = torch.empty(B, D, P, C, dtype=lifted_dtype, device=height_context.device) if want_lifted else None
+    lib = _lib.load()
+    fn = lib.sgv3d_lift_bf16 if (want_lifted and lifted_dtype == torch.bfloat16) else lib.sgv3d_lift
     with torch.cuda.device(height_context.device), prof("lift"):
-        rc = _lib.load().sgv3d_lift(B, P, D, C, height_context.data_ptr(), _lib.ptr(prob), _lib.ptr(lifted),
-                                   _st(height_context))
+        rc = fn(B, P, D, C, height_context.data_ptr(), _lib.ptr(prob), _lib.ptr(lifted), _st(height_context))
     _lib.check(rc, "sgv3d_lift")
     return prob, lifted

@@ -272,7 +272,7 @@ class BSMLSSFPN(LSSFPN):
             hip_ops.copy_channels(hc, ctx, coff=D)
             bev = plan.lift_splat(prob, ctx.view(batch_size, fH * fW, Cp))
         else:
-            _, lifted = hip_ops.lift(hc, D, Cp)
+            _, lifted = hip_ops.lift(hc, D, Cp, lifted_dtype=hip_ops.activation_dtype(Cp))
             bev = plan.pool(lifted.view(batch_size, num_cams * D * fH * fW, Cp))     # voxel_pooling of :554-555
         feature_map = bev.permute(0, 3, 1, 2)
         nhwc = feature_map.permute(0, 2, 3, 1)                                # [B, Y, X, 88]

@@ -414,7 +414,8 @@ class LSSFPN(HipModule):
             hip_ops.copy_channels(height_feature, ctx.view(batch_size, fH, fW, C), coff=D)
             bev = plan.lift_splat(prob, ctx)                                   # [B,Y,X,C]
         else:
-            _, lifted = hip_ops.lift(height_feature, D, C)                     # [B*N, D, fH*fW, C] == :486 permute + contiguous
+            # (bf16 compute mode: the lifted tensor -- the largest HBM stream of the path -- is bf16, pooled sums stay f32)
+            _, lifted = hip_ops.lift(height_feature, D, C, lifted_dtype=hip_ops.activation_dtype(C))   # [B*N, D, fH*fW, C] == :486 permute + contiguous
             # voxel_pooling(geom_xyz, img_feat_with_height, voxel_num) of :490-491 with the plan of this calibration
             bev = plan.pool(lifted.view(batch_size, num_cams * D * fH * fW, C))    # [B,Y,X,C]
         feature_map = bev.permute(0, 3, 1, 2)

@@ -127,18 +127,20 @@ class VoxelPlan:
         return torch.empty(nws, dtype=torch.uint8, device=self.buf.device), nws
 
     def pool(self, input_features, out=None):
-        """input_features f32 [B, N, C] -> [B, Y, X, C] (fully written)."""
-        _check_cuda(input_features, "input_features", torch.float32)
+        """input_features f32 (or, bf16 compute mode, bf16) [B, N, C] -> f32 [B, Y, X, C] (fully written)."""
+        bf16 = input_features.dtype == torch.bfloat16
+        _check_cuda(input_features, "input_features", torch.bfloat16 if bf16 else torch.float32)
         assert input_features.is_contiguous()
         C = int(input_features.shape[-1])
         assert input_features.numel() == self.B * self.N * C
         if out is None:
-            out = input_features.new_empty(self.B, self.Y, self.X, C)
+            out = torch.empty(self.B, self.Y, self.X, C, dtype=torch.float32, device=input_features.device)
         ws, nws = self._workspace(C)
+        lib = _lib.load()
+        fn = lib.sgv3d_voxel_pooling_forward_planned_bf16 if bf16 else lib.sgv3d_voxel_pooling_forward_planned
         with torch.cuda.device(input_features.device), hip_ops.prof("voxel_pooling_planned"):
-            rc = _lib.load().sgv3d_voxel_pooling_forward_planned(
-                self.B, self.N, C, self.X, self.Y, self.buf.data_ptr(), input_features.data_ptr(),
-                out.data_ptr(), ws.data_ptr(), nws, _lib.stream_handle(input_features.device))
+            rc = fn(self.B, self.N, C, self.X, self.Y, self.buf.data_ptr(), input_features.data_ptr(),
+                    out.data_ptr(), ws.data_ptr(), nws, _lib.stream_handle(input_features.device))
         _lib.check(rc, "sgv3d_voxel_pooling_forward_planned")
         return out
 

@@ -483,3 +483,23 @@ def test_bf16_small_layers_reject_odd_channels():
         hip_ops.scale_channels(x, torch.ones(1, 12, device=DEV))
     with pytest.raises(SGV3DError):
         hip_ops.upsample_bilinear2x(x)
+
+
+def test_bf16_lift_and_pooling_match_f32_twins(bf16_mode):
+    """sgv3d_lift_bf16 == the f32 lift rounded once; sgv3d_voxel_pooling_forward_planned_bf16 == the f32 gather on the same
+    (bf16-representable) feature rows, bit for bit (sums are f32 in the same order)."""
+    from sgv3d_amd.ops.voxel_pooling import VoxelPlan
+    g = torch.Generator().manual_seed(3)
+    B, fH, fW, D, C = 2, 9, 14, 12, 40
+    hc = torch.randn(B, fH, fW, D + C, generator=g).to(DEV)
+    _, lifted32 = hip_ops.lift(hc, D, C)
+    prob, lifted16 = hip_ops.lift(hc, D, C, want_prob=True, lifted_dtype=torch.bfloat16)
+    assert lifted16.dtype == torch.bfloat16 and torch.equal(lifted16, lifted32.bfloat16())
+    assert torch.equal(prob, hip_ops.lift(hc, D, C, want_prob=True, want_lifted=False)[0])
+    N = D * fH * fW
+    geom = torch.stack([torch.randint(-2, 18, (B, N), generator=g), torch.randint(-2, 22, (B, N), generator=g),
+                        torch.randint(-1, 2, (B, N), generator=g)], -1).int().to(DEV)
+    plan = VoxelPlan(geom, (16, 20, 1))
+    out16 = plan.pool(lifted16.view(B, N, C))
+    out32 = plan.pool(lifted16.float().view(B, N, C))
+    assert out16.dtype == torch.float32 and torch.equal(out16, out32)
