@@ -93,10 +93,13 @@ int sgv3d_voxel_pooling_forward_planned(int batch_size, int num_points, int num_
                                         const void *plan, const float *input_features,
                                         float *output_features, void *workspace, size_t workspace_bytes,
                                         void *stream);
-/* bf16 compute mode: input_features are bf16 [B, N, C] (24 <= C <= 256, C % 4 == 0); sums and output_features stay f32. */
+/* bf16 compute mode: input_features are bf16 [B, N, C] (24 <= C <= 256, C % 4 == 0); sums stay f32.  out_bf16_ld == 0:
+ * output_features f32 [B, Y, X, C] as above; out_bf16_ld > 0: output_features bf16 [B, Y, X, out_bf16_ld] (a multiple of 4
+ * in [C, 2C]), channels C .. out_bf16_ld - 1 written as zeros -- the layout the bf16 BEV trunk reads (its first convolution
+ * rounds its input to bf16 anyway and wants a multiple of 32 input channels). */
 int sgv3d_voxel_pooling_forward_planned_bf16(int batch_size, int num_points, int num_channels,
                                              int num_voxel_x, int num_voxel_y, const void *plan,
-                                             const void *input_features_bf16, float *output_features,
+                                             const void *input_features_bf16, void *output_features, int out_bf16_ld,
                                              void *workspace, size_t workspace_bytes, void *stream);
 
 /* Fused lift-splat (optional fast path beyond the operator boundary):

@@ -560,13 +560,31 @@ constexpr int kChunkMax = 16;
 
 typedef __bf16 vp_bf16x4 __attribute__((ext_vector_type(4)));
 
-// FB: the feature rows are bf16 (bf16 compute mode: sgv3d_lift_bf16 wrote them); sums stay f32
-template <bool FUSED, bool FB = false>
+// One output row (voxel v), 4 channels per lane.  OB: the pooled map is written as bf16 with rows of ldo >= C channels, the
+// padding channels zeroed (bf16 compute mode: the BEV trunk's first convolution wants a multiple of 32 input channels and
+// rounds its input to bf16 anyway, so the rounding here changes no result downstream)
+template <bool OB>
+__device__ __forceinline__ void vp_store_row(float *out, long long v, int C, int ldo, int cl, const float4 &val) {
+    if constexpr (OB) {
+        __bf16 *o = reinterpret_cast<__bf16 *>(out) + (size_t)v * ldo;
+        const vp_bf16x4 q = {(__bf16)val.x, (__bf16)val.y, (__bf16)val.z, (__bf16)val.w};
+        *reinterpret_cast<vp_bf16x4 *>(o + (size_t)cl * 4) = q;
+        if (cl < ((ldo - C) >> 2)) {
+            const vp_bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            *reinterpret_cast<vp_bf16x4 *>(o + C + (size_t)cl * 4) = z;
+        }
+    } else {
+        *reinterpret_cast<float4 *>(out + (size_t)v * C + (size_t)cl * 4) = val;
+    }
+}
+
+// FB: the feature rows are bf16 (bf16 compute mode: sgv3d_lift_bf16 wrote them); sums stay f32.  OB: see vp_store_row.
+template <bool FUSED, bool FB = false, bool OB = false>
 __global__ __launch_bounds__(kBlock) void vp_gather2_kernel(
     long long V, int C, int lpr, int groups, int ch, const int *__restrict__ seg_start,
     const int *__restrict__ order, const int *__restrict__ slot_voxel, const float *__restrict__ feats,
     const float *__restrict__ prob, const float *__restrict__ ctx, int N, int P, float *__restrict__ out,
-    float *__restrict__ partial) {
+    float *__restrict__ partial, int ldo) {
     const int lane = threadIdx.x & 63;
     const int g = lane / lpr;
     const int cl = lane - g * lpr;
@@ -620,8 +638,7 @@ __global__ __launch_bounds__(kBlock) void vp_gather2_kernel(
         const long long per = (V + ngroups - 1) / ngroups;
         const long long v0 = chunk * per, v1 = min(V, v0 + per);
         for (long long v = v0; v < v1; ++v)
-            if (seg_start[v] == seg_start[v + 1])
-                *reinterpret_cast<float4 *>(out + (size_t)v * C + (size_t)cl * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (seg_start[v] == seg_start[v + 1]) vp_store_row<OB>(out, v, C, ldo, cl, make_float4(0.f, 0.f, 0.f, 0.f));
     }
     if (!active || cl >= ncols) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -631,8 +648,8 @@ __global__ __launch_bounds__(kBlock) void vp_gather2_kernel(
     for (int k = 0; k < kChunkMax; ++k) {
         if (k < cnt) {
             if (vox[k] != cur) {             // run of `cur` ended inside the chunk
-                float *dst = before ? partial + ((size_t)chunk * 2 + 0) * C : out + (size_t)cur * C;
-                *reinterpret_cast<float4 *>(dst + (size_t)cl * 4) = acc;
+                if (before) *reinterpret_cast<float4 *>(partial + ((size_t)chunk * 2 + 0) * C + (size_t)cl * 4) = acc;
+                else vp_store_row<OB>(out, cur, C, ldo, cl, acc);
                 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 cur = vox[k];
                 before = false;
@@ -642,19 +659,20 @@ __global__ __launch_bounds__(kBlock) void vp_gather2_kernel(
         }
     }
     const bool after = cnt == ch && next_vox == cur;   // the last run continues in the next chunk
-    float *dst = before ? partial + ((size_t)chunk * 2 + 0) * C
-                        : after ? partial + ((size_t)chunk * 2 + 1) * C : out + (size_t)cur * C;
-    *reinterpret_cast<float4 *>(dst + (size_t)cl * 4) = acc;
+    if (before) *reinterpret_cast<float4 *>(partial + ((size_t)chunk * 2 + 0) * C + (size_t)cl * 4) = acc;
+    else if (after) *reinterpret_cast<float4 *>(partial + ((size_t)chunk * 2 + 1) * C + (size_t)cl * 4) = acc;
+    else vp_store_row<OB>(out, cur, C, ldo, cl, acc);
 }
 
 // One row group per chunk: if the chunk's last run starts here and continues, it leads that voxel:
 // out[v] = partial[j][1] + partial[j+1][0] + ... in ascending chunk order.  The leader test reads its
 // four slot ids up front (independent loads) and the piece count comes from the voxel's segment
 // bounds, so the partial rows are fetched as independent loads, not as a dependent chain.
+template <bool OB = false>
 __global__ __launch_bounds__(kBlock) void vp_fixup_kernel(long long V, int C, int lpr, int groups, int ch,
                                                           const int *__restrict__ seg_start,
                                                           const int *__restrict__ slot_voxel,
-                                                          const float *__restrict__ partial, float *__restrict__ out) {
+                                                          const float *__restrict__ partial, float *__restrict__ out, int ldo) {
     const int lane = threadIdx.x & 63;
     const int g = lane / lpr;
     const int cl = lane - g * lpr;
@@ -682,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void vp_fixup_kernel(long long V, int C, in
         for (int u = 0; u < 4; ++u)
             if (jj + u <= jl) vacc(sum, p[u]);
     }
-    *reinterpret_cast<float4 *>(out + (size_t)v * C + (size_t)cl * 4) = sum;
+    vp_store_row<OB>(out, v, C, ldo, cl, sum);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -734,10 +752,10 @@ GatherGeom gather_geom(long long total_pts, int C) {
     return G;
 }
 
-template <bool FUSED, bool FB = false>
+template <bool FUSED, bool FB = false, bool OB = false>
 int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const float *feats,
                   const float *prob, const float *ctx, int P, float *out, void *workspace, size_t ws_bytes,
-                  hipStream_t st) {
+                  hipStream_t st, int ldo = 0) {
     const PlanLayout L = plan_layout(B, N, X, Y);
     const char *base = static_cast<const char *>(plan);
     const int *seg = reinterpret_cast<const int *>(base + L.off_seg);
@@ -751,13 +769,13 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
         const long long waves = (G.nchunks + G.groups - 1) / G.groups;
         const int grid = cdiv(waves, kBlock / 64);
         float *partial = static_cast<float *>(workspace);
-        hipLaunchKernelGGL((vp_gather2_kernel<FUSED, FB>), dim3(grid), dim3(kBlock), 0, st, L.V, C, G.lpr, G.groups, G.ch,
-                           seg, order, slotvox, feats, prob, ctx, N, P, out, partial);
-        hipLaunchKernelGGL(vp_fixup_kernel, dim3(grid), dim3(kBlock), 0, st, L.V, C, G.lpr, G.groups, G.ch, seg, slotvox,
-                           partial, out);
+        hipLaunchKernelGGL((vp_gather2_kernel<FUSED, FB, OB>), dim3(grid), dim3(kBlock), 0, st, L.V, C, G.lpr, G.groups, G.ch,
+                           seg, order, slotvox, feats, prob, ctx, N, P, out, partial, ldo);
+        hipLaunchKernelGGL(vp_fixup_kernel<OB>, dim3(grid), dim3(kBlock), 0, st, L.V, C, G.lpr, G.groups, G.ch, seg, slotvox,
+                           partial, out, ldo);
         return check_launch(FUSED ? "vp_lift_splat(v2)" : "vp_gather2_kernel");
     }
-    if (FB) return fail(SGV3D_EINVAL, "voxel pooling: bf16 features need 24 <= C <= 256, C %% 4 == 0 (got %d)", C);
+    if (FB || OB) return fail(SGV3D_EINVAL, "voxel pooling: bf16 features / output need 24 <= C <= 256, C %% 4 == 0 (got %d)", C);
     const long long waves = (L.V + kVoxPerWave - 1) / kVoxPerWave;
     const int grid = cdiv(waves, kBlock / 64);
     if (C % 4 == 0) {
@@ -905,15 +923,22 @@ extern "C" int sgv3d_voxel_pooling_forward_planned(int batch_size, int num_point
 
 extern "C" int sgv3d_voxel_pooling_forward_planned_bf16(int batch_size, int num_points, int num_channels, int num_voxel_x,
                                                         int num_voxel_y, const void *plan, const void *input_features_bf16,
-                                                        float *output_features, void *workspace, size_t workspace_bytes,
-                                                        void *stream) {
+                                                        void *output_features, int out_bf16_ld, void *workspace,
+                                                        size_t workspace_bytes, void *stream) {
     if (int rc = check_common(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, 1)) return rc;
     SGV3D_REQUIRE(plan && input_features_bf16 && output_features, "voxel_pooling_forward_planned_bf16: null pointer");
     SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(input_features_bf16) & 7) == 0 && (reinterpret_cast<uintptr_t>(output_features) & 15) == 0,
                   "voxel_pooling_forward_planned_bf16: features must be 8-B, output 16-B aligned");
+    SGV3D_REQUIRE(out_bf16_ld == 0 || (out_bf16_ld >= num_channels && out_bf16_ld % 4 == 0 && out_bf16_ld - num_channels <= 4 * (num_channels / 4)),
+                  "voxel_pooling_forward_planned_bf16: out_bf16_ld must be 0 (f32 output) or a multiple of 4 in [C, 2C]");
+    if (out_bf16_ld)
+        return launch_gather<false, true, true>(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, plan,
+                                                static_cast<const float *>(input_features_bf16), nullptr, nullptr, 1,
+                                                static_cast<float *>(output_features), workspace, workspace_bytes, as_stream(stream),
+                                                out_bf16_ld);
     return launch_gather<false, true>(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, plan,
-                                      static_cast<const float *>(input_features_bf16), nullptr, nullptr, 1, output_features,
-                                      workspace, workspace_bytes, as_stream(stream));
+                                      static_cast<const float *>(input_features_bf16), nullptr, nullptr, 1,
+                                      static_cast<float *>(output_features), workspace, workspace_bytes, as_stream(stream));
 }
 
 extern "C" int sgv3d_lift_splat_planned(int batch_size, int num_depth, int num_pixels, int num_channels,

@@ -273,7 +273,8 @@ class BSMLSSFPN(LSSFPN):
             bev = plan.lift_splat(prob, ctx.view(batch_size, fH * fW, Cp))
         else:
             _, lifted = hip_ops.lift(hc, D, Cp, lifted_dtype=hip_ops.activation_dtype(Cp))
-            bev = plan.pool(lifted.view(batch_size, num_cams * D * fH * fW, Cp))     # voxel_pooling of :554-555
+            ldo = hip_ops.pad_channels(Cp) if (nhwc_out and lifted.dtype == torch.bfloat16 and getattr(self, '_single_sweep', True)) else 0    # as in LSSFPN
+            bev = plan.pool(lifted.view(batch_size, num_cams * D * fH * fW, Cp), out_bf16_ld=ldo)     # voxel_pooling of :554-555
         feature_map = bev.permute(0, 3, 1, 2)
         nhwc = feature_map.permute(0, 2, 3, 1)                                # [B, Y, X, 88]
         if nhwc_out:

@@ -417,7 +417,10 @@ class LSSFPN(HipModule):
             # (bf16 compute mode: the lifted tensor -- the largest HBM stream of the path -- is bf16, pooled sums stay f32)
             _, lifted = hip_ops.lift(height_feature, D, C, lifted_dtype=hip_ops.activation_dtype(C))   # [B*N, D, fH*fW, C] == :486 permute + contiguous
             # voxel_pooling(geom_xyz, img_feat_with_height, voxel_num) of :490-491 with the plan of this calibration
-            bev = plan.pool(lifted.view(batch_size, num_cams * D * fH * fW, C))    # [B,Y,X,C]
+            # bf16-activation mode, NHWC hand-off to the head: bf16 rows padded to the trunk's channel alignment (its first
+            # convolution rounds its input to bf16 anyway); the module-boundary output ([B, C, Y, X]) stays f32
+            ldo = hip_ops.pad_channels(C) if (nhwc_out and lifted.dtype == torch.bfloat16 and getattr(self, '_single_sweep', True)) else 0
+            bev = plan.pool(lifted.view(batch_size, num_cams * D * fH * fW, C), out_bf16_ld=ldo)    # [B,Y,X,C]
         feature_map = bev.permute(0, 3, 1, 2)
         if nhwc_out:
             return feature_map.permute(0, 2, 3, 1)                             # the NHWC buffer itself
@@ -427,6 +430,7 @@ class LSSFPN(HipModule):
         """lss_fpn.py:497-550 (inference)."""
         _require_hip_inference(self, sweep_imgs)
         batch_size, num_sweeps, num_cams, num_channels, img_height, img_width = sweep_imgs.shape
+        self._single_sweep = num_sweeps == 1       # channel-padded bf16 hand-off only when nothing is concatenated after it
         key_frame_res = self._forward_single_sweep(0, sweep_imgs[:, 0:1, ...], mats_dict, nhwc_out=nhwc_out)
         if num_sweeps == 1:
             return key_frame_res

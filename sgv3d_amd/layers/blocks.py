@@ -199,8 +199,10 @@ class ResNet(HipModule):
                 nn.init.zeros_(m.bn2.weight)
 
     def hip_compile(self, device):
-        cin_pad = (self.in_channels + 3) // 4 * 4
         align = hip_ops.channel_align()
+        # a wide input (the 80 / 87-channel BEV map of the head's trunk) is padded like the activations: in bf16-activation
+        # mode the producer (voxel pooling) writes rows of pad_channels(C) channels; an image (3 channels) just to 4
+        cin_pad = hip_ops.pad_channels(self.in_channels, align) if self.in_channels >= 64 else (self.in_channels + 3) // 4 * 4
         for m in self.modules():
             if isinstance(m, BasicBlock):
                 m._hip_align = align          # the blocks compile lazily: same padding as the stem, whatever the mode is then

@@ -205,10 +205,13 @@ class BEVHeightHead(HipModule):
             raise RuntimeError("sgv3d_amd runs on the MI355X only (no CPU fallback)")
         if self.training:
             raise NotImplementedError("HIP path = inference forward; call model.eval()")
+        cin_pad = self.trunk.hip_state(x.device)['cin_pad']            # channels the trunk's first convolution reads
         if not nhwc:
-            x = hip_ops.nchw_to_nhwc(x.float().contiguous(), c_pad=(int(x.shape[1]) + 3) // 4 * 4)
+            x = hip_ops.nchw_to_nhwc(x.float().contiguous(), c_pad=max(cin_pad, (int(x.shape[1]) + 3) // 4 * 4))
         elif not x.is_contiguous():
             x = x.contiguous()
+        if int(x.shape[-1]) < cin_pad:                                 # a producer that did not pad (fused lift-splat, external maps)
+            x = torch.nn.functional.pad(x, (0, cin_pad - int(x.shape[-1])))
         return self.hip_forward(x)
 
     # --------------------------------------------------------------- training side

@@ -126,20 +126,28 @@ class VoxelPlan:
         nws = _lib.load().sgv3d_voxel_pooling_workspace_bytes(self.B, self.N, int(C))
         return torch.empty(nws, dtype=torch.uint8, device=self.buf.device), nws
 
-    def pool(self, input_features, out=None):
-        """input_features f32 (or, bf16 compute mode, bf16) [B, N, C] -> f32 [B, Y, X, C] (fully written)."""
+    def pool(self, input_features, out=None, out_bf16_ld=0):
+        """input_features f32 (or, bf16 compute mode, bf16) [B, N, C] -> f32 [B, Y, X, C] (fully written).
+        ``out_bf16_ld`` (bf16 features only): the pooled map is written as bf16 [B, Y, X, out_bf16_ld] with zeroed padding
+        channels -- the layout the bf16 BEV trunk reads."""
         bf16 = input_features.dtype == torch.bfloat16
         _check_cuda(input_features, "input_features", torch.bfloat16 if bf16 else torch.float32)
-        assert input_features.is_contiguous()
+        assert input_features.is_contiguous() and (bf16 or not out_bf16_ld)
         C = int(input_features.shape[-1])
         assert input_features.numel() == self.B * self.N * C
         if out is None:
-            out = torch.empty(self.B, self.Y, self.X, C, dtype=torch.float32, device=input_features.device)
+            out = torch.empty(self.B, self.Y, self.X, int(out_bf16_ld) or C, dtype=torch.bfloat16 if out_bf16_ld else torch.float32,
+                              device=input_features.device)
         ws, nws = self._workspace(C)
         lib = _lib.load()
-        fn = lib.sgv3d_voxel_pooling_forward_planned_bf16 if bf16 else lib.sgv3d_voxel_pooling_forward_planned
         with torch.cuda.device(input_features.device), hip_ops.prof("voxel_pooling_planned"):
-            rc = fn(self.B, self.N, C, self.X, self.Y, self.buf.data_ptr(), input_features.data_ptr(),
+            if bf16:
+                rc = lib.sgv3d_voxel_pooling_forward_planned_bf16(
+                    self.B, self.N, C, self.X, self.Y, self.buf.data_ptr(), input_features.data_ptr(), out.data_ptr(),
+                    int(out_bf16_ld), ws.data_ptr(), nws, _lib.stream_handle(input_features.device))
+            else:
+                rc = lib.sgv3d_voxel_pooling_forward_planned(
+                    self.B, self.N, C, self.X, self.Y, self.buf.data_ptr(), input_features.data_ptr(),
                     out.data_ptr(), ws.data_ptr(), nws, _lib.stream_handle(input_features.device))
         _lib.check(rc, "sgv3d_voxel_pooling_forward_planned")
         return out

@@ -503,3 +503,18 @@ def test_bf16_lift_and_pooling_match_f32_twins(bf16_mode):
     out16 = plan.pool(lifted16.view(B, N, C))
     out32 = plan.pool(lifted16.float().view(B, N, C))
     assert out16.dtype == torch.float32 and torch.equal(out16, out32)
+
+
+def test_bf16_pooling_padded_bf16_output(bf16_mode):
+    """out_bf16_ld: the pooled map as bf16 rows padded with zero channels == the f32 result rounded once."""
+    from sgv3d_amd.ops.voxel_pooling import VoxelPlan
+    g = torch.Generator().manual_seed(4)
+    B, N, C = 2, 5000, 88
+    feats = torch.randn(B, N, C, generator=g).bfloat16().to(DEV)
+    geom = torch.stack([torch.randint(-2, 34, (B, N), generator=g), torch.randint(-2, 30, (B, N), generator=g),
+                        torch.randint(-1, 2, (B, N), generator=g)], -1).int().to(DEV)
+    plan = VoxelPlan(geom, (32, 28, 1))
+    ref = plan.pool(feats)                                   # f32 [B, 28, 32, 88]
+    out = plan.pool(feats, out_bf16_ld=96)
+    assert out.dtype == torch.bfloat16 and tuple(out.shape) == (B, 28, 32, 96)
+    assert torch.equal(out[..., :C], ref.bfloat16()) and float(out[..., C:].abs().max()) == 0
