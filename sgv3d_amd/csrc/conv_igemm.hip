@@ -38,6 +38,15 @@ constexpr int kThreads = 256;
 // 16 zero bytes that padded / out-of-image lanes load from
 __device__ __attribute__((aligned(16))) float4 g_zero16 = {0.f, 0.f, 0.f, 0.f};
 
+// tools/igemm_stamps.py builds a private copy of the library with -DSGV3D_IGEMM_STAMPS: every 97th workgroup of the f32
+// kernel writes 4 cycle-counter stamps (entry, operands of the first k-tile in LDS, k loop done, epilogue issued)
+#ifdef SGV3D_IGEMM_STAMPS
+__device__ long long *g_igemm_dbg = nullptr;
+#define IGEMM_STAMP(i) do { if (g_igemm_dbg && blockIdx.y == 0 && blockIdx.x % 97 == 0 && blockIdx.x / 97 < 64 && threadIdx.x == 0) g_igemm_dbg[(blockIdx.x / 97) * 4 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define IGEMM_STAMP(i) do { } while (0)
+#endif
+
 // Split-K second stage: sums the split partials in fixed order and runs the common epilogue.
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs a) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -56,6 +65,7 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     constexpr int A_CH = BM / 32, B_CH = BN / 32;  // 16-B chunks per thread per k-tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    IGEMM_STAMP(0);
     float *const As0 = smem;
     float *const Bs0 = smem + BM * LDK;
     constexpr int kBufStride = (BM + BN) * LDK;
@@ -84,7 +94,7 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tn = logical / a.tiles_m;
+    const int tn = (int)((unsigned)logical / (unsigned)a.tiles_m);     // (unsigned: half the scalar instructions of a signed division)
     const int tm = logical - tn * a.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -99,6 +109,10 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     // every vector instruction saved in the loop (64-bit pointer arithmetic, selects) is MFMA time.
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.w_bytes, 0x00020000);
+    // The prologue runs in the shadow of the other workgroups' MFMAs: at four waves per SIMD an instruction of this wave issues
+    // every 8-13 cycles, and ~1000 scalar + vector instructions of address set-up were 9-13 k cycles before the first k-tile
+    // reached LDS (tools/igemm_stamps.py) -- as long as the whole k loop of a 256-deep 1x1 layer.  Hence the shortcuts below.
+    const bool pointwise = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.in_h == a.m_h && a.in_w == a.m_w;
     unsigned a_off[A_CH];
     int a_ih0[A_CH], a_iw0[A_CH];
     bool a_ok[A_CH];
@@ -107,9 +121,15 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
         const int m = m0 + r0 + 32 * i;
         a_ok[i] = m < a.M;
         const int mm = a_ok[i] ? m : 0;
-        const int t = mm / a.m_w;
+        if (pointwise) {             // 1x1 / stride 1 / no padding: the input pixel IS the output pixel, no division
+            a_ih0[i] = 0;
+            a_iw0[i] = 0;
+            a_off[i] = (unsigned)(((long long)mm * a.x_ld + a.x_coff + cc * 4) * 4);
+            continue;
+        }
+        const int t = (int)((unsigned)mm / (unsigned)a.m_w);
         const int ow = mm - t * a.m_w;
-        const int n = t / a.m_h;
+        const int n = (int)((unsigned)t / (unsigned)a.m_h);
         const int oh = t - n * a.m_h;
         a_ih0[i] = oh * a.stride - a.pad;
         a_iw0[i] = ow * a.stride - a.pad;
@@ -153,17 +173,23 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     }
     const int nkh = kh_hi - kh_lo + 1;
     const int nkt_all = FAST ? (a.cin / BK) * nkh * a.kw : a.k_pad / BK;
-    const int kt_begin = (int)((long long)nkt_all * blockIdx.y / a.split_k);
-    const int nkt = (int)((long long)nkt_all * (blockIdx.y + 1) / a.split_k);   // exclusive end ("nkt" below)
-    int ld_kt = kt_begin, ld_kh = 0, ld_kw = 0, ld_c0 = 0, ld_kp = 0;
+    // (nkt_all <= 65536 and split_k <= 64: 32-bit unsigned arithmetic; no division at all without split-K)
+    int kt_begin = 0, nkt = nkt_all;                                   // [kt_begin, nkt): this workgroup's k-tiles
+    if (a.split_k > 1) {
+        kt_begin = (int)((unsigned)nkt_all * blockIdx.y / (unsigned)a.split_k);
+        nkt = (int)((unsigned)nkt_all * (blockIdx.y + 1) / (unsigned)a.split_k);
+    }
+    int ld_kt = kt_begin, ld_kh = kh_lo, ld_kw = 0, ld_c0 = 0, ld_kp = kh_lo * a.kw;
     if constexpr (FAST) {
-        const int per_chunk = nkh * a.kw;
-        const int kt0 = kt_begin < nkt_all ? kt_begin : nkt_all - 1;     // (an empty split slice reads the last tile)
-        const int chunk = kt0 / per_chunk, rem = kt0 - chunk * per_chunk;
-        ld_c0 = chunk * BK;
-        ld_kh = kh_lo + rem / a.kw;
-        ld_kw = rem - (rem / a.kw) * a.kw;
-        ld_kp = chunk * a.kh * a.kw + ld_kh * a.kw + ld_kw;     // k-tile index in the packed weight order
+        if (kt_begin != 0) {
+            const unsigned per_chunk = nkh * a.kw;
+            const unsigned kt0 = kt_begin < nkt_all ? kt_begin : nkt_all - 1;     // (an empty split slice reads the last tile)
+            const unsigned chunk = kt0 / per_chunk, rem = kt0 - chunk * per_chunk;
+            ld_c0 = chunk * BK;
+            ld_kh = kh_lo + rem / (unsigned)a.kw;
+            ld_kw = rem - (rem / (unsigned)a.kw) * a.kw;
+            ld_kp = chunk * a.kh * a.kw + ld_kh * a.kw + ld_kw;     // k-tile index in the packed weight order
+        }
     }
 
     // Loads are unconditional: lanes whose tap falls outside the image (or whose row / k is padding)
@@ -298,6 +324,10 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     // stay inside one group: plane base + row * group width)
     const bool fast_epi = (a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr) ||
                            (a.mode == SGV3D_CONV_GROUP_PLANES && a.gate == nullptr && a.ks % (BN / 2) == 0)) && m0 + BM <= a.M;
+    // the first two k-tiles are asked for BEFORE the residual rows: memory returns in order, and the wait for k-tile 0
+    // (the workgroup's prologue: 9-13 k cycles on a loaded chip, tools/igemm_stamps.py) must not queue behind 16 more loads
+    SGV3D_LOAD_TILE(ra0, rb0);                       // tile 0
+    SGV3D_LOAD_TILE(ra1, rb1);                       // tile 1
     float resv[WTM][WTN][16];
     if constexpr (kPrefetchRes) {
         const bool want = fast_epi && a.split_k <= 1 && a.res != nullptr;
@@ -317,16 +347,16 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
                 }
         }
     }
-    SGV3D_LOAD_TILE(ra0, rb0);                       // tile 0
-    SGV3D_LOAD_TILE(ra1, rb1);                       // tile 1
     SGV3D_STORE_TILE(ra0, rb0, 0);
     __syncthreads();
+    IGEMM_STAMP(1);
     SGV3D_READ_FRAG(fa0, fb0, 0, 0);
     for (int kt = kt_begin; kt < nkt; kt += 2) {
         SGV3D_PHASE(0, ra0, rb0, ra1, rb1, kt + 1 < nkt);      // tile kt in buffer 0
         if (kt + 1 >= nkt) break;
         SGV3D_PHASE(1, ra1, rb1, ra0, rb0, kt + 2 < nkt);      // tile kt+1 in buffer 1
     }
+    IGEMM_STAMP(2);
 #undef SGV3D_LOAD_TILE
 #undef SGV3D_STORE_TILE
 #undef SGV3D_READ_FRAG
@@ -395,6 +425,7 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
         }
 #undef SGV3D_EPI_FT
 #undef SGV3D_EPI_F
+        IGEMM_STAMP(3);
         return;
     }
     // General path (pixel-shuffle / NCHW / grouped-plane layouts, SE gate, ragged last m-tile); expanded by
@@ -491,7 +522,7 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tn = logical / a.tiles_m;
+    const int tn = (int)((unsigned)logical / (unsigned)a.tiles_m);     // (unsigned: half the scalar instructions of a signed division)
     const int tm = logical - tn * a.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x;
@@ -500,6 +531,10 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
     const int st_off = (((cc >> 1) ^ ((r0 >> 2) & 3)) * 8) + (cc & 1) * 4;   // swizzled place of this thread's 4 k in its row
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.w_bytes, 0x00020000);
+    // The prologue runs in the shadow of the other workgroups' MFMAs: at four waves per SIMD an instruction of this wave issues
+    // every 8-13 cycles, and ~1000 scalar + vector instructions of address set-up were 9-13 k cycles before the first k-tile
+    // reached LDS (tools/igemm_stamps.py) -- as long as the whole k loop of a 256-deep 1x1 layer.  Hence the shortcuts below.
+    const bool pointwise = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.in_h == a.m_h && a.in_w == a.m_w;
     unsigned a_off[A_CH];
     int a_ih0[A_CH], a_iw0[A_CH];
     bool a_ok[A_CH];
@@ -508,9 +543,15 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
         const int m = m0 + r0 + 32 * i;
         a_ok[i] = m < a.M;
         const int mm = a_ok[i] ? m : 0;
-        const int t = mm / a.m_w;
+        if (pointwise) {             // 1x1 / stride 1 / no padding: the input pixel IS the output pixel, no division
+            a_ih0[i] = 0;
+            a_iw0[i] = 0;
+            a_off[i] = (unsigned)(((long long)mm * a.x_ld + a.x_coff + cc * 4) * XES);
+            continue;
+        }
+        const int t = (int)((unsigned)mm / (unsigned)a.m_w);
         const int ow = mm - t * a.m_w;
-        const int n = t / a.m_h;
+        const int n = (int)((unsigned)t / (unsigned)a.m_h);
         const int oh = t - n * a.m_h;
         a_ih0[i] = oh * a.stride - a.pad;
         a_iw0[i] = ow * a.stride - a.pad;
@@ -536,26 +577,37 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
         unsigned mk = 0;
-        if (use_mask)
-            for (int t = 0; t < taps; ++t) {
-                const int ih = a_ih0[i] + (t / a.kw) * a.dil, iw = a_iw0[i] + (t % a.kw) * a.dil;
-                mk |= (a_ok[i] && (unsigned)ih < (unsigned)a.in_h && (unsigned)iw < (unsigned)a.in_w) ? (1u << t) : 0u;
+        if (use_mask) {
+            int t = 0;                               // (nested counters: no division per tap in the prologue)
+            for (int th = 0; th < a.kh; ++th) {
+                const int ih = a_ih0[i] + th * a.dil;
+                const bool row_in = a_ok[i] && (unsigned)ih < (unsigned)a.in_h;
+                for (int tw = 0; tw < a.kw; ++tw, ++t) {
+                    const int iw = a_iw0[i] + tw * a.dil;
+                    mk |= (row_in && (unsigned)iw < (unsigned)a.in_w) ? (1u << t) : 0u;
+                }
             }
+        }
         a_mask[i] = mk;
         a_fix[i] = (mk & 1u) ? a_off[i] : 0xffffffffu;
     }
     float4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
     const int nkt_all = FAST ? (a.cin / BK) * a.kh * a.kw : a.k_pad / BK;
-    const int kt_begin = (int)((long long)nkt_all * blockIdx.y / a.split_k);
-    const int nkt = (int)((long long)nkt_all * (blockIdx.y + 1) / a.split_k);
+    int kt_begin = 0, nkt = nkt_all;                                   // (no division without split-K: see the f32 kernel)
+    if (a.split_k > 1) {
+        kt_begin = (int)((unsigned)nkt_all * blockIdx.y / (unsigned)a.split_k);
+        nkt = (int)((unsigned)nkt_all * (blockIdx.y + 1) / (unsigned)a.split_k);
+    }
     int ld_kt = kt_begin, ld_kh = 0, ld_kw = 0, ld_c0 = 0;
     if constexpr (FAST) {
-        const int per_chunk = a.kh * a.kw;
-        const int kt0 = kt_begin < nkt_all ? kt_begin : nkt_all - 1;
-        const int chunk = kt0 / per_chunk, rem = kt0 - chunk * per_chunk;
-        ld_c0 = chunk * BK;
-        ld_kh = rem / a.kw;
-        ld_kw = rem - ld_kh * a.kw;
+        if (kt_begin != 0) {
+            const unsigned per_chunk = a.kh * a.kw;
+            const unsigned kt0 = kt_begin < nkt_all ? kt_begin : nkt_all - 1;
+            const unsigned chunk = kt0 / per_chunk, rem = kt0 - chunk * per_chunk;
+            ld_c0 = chunk * BK;
+            ld_kh = rem / (unsigned)a.kw;
+            ld_kw = rem - ld_kh * a.kw;
+        }
     }
     // one chunk of 4 k of the input: 16 bytes of f32, or (XB) 8 bytes of bf16 parked in .x / .y
 #define SGV3D_LOAD_A(R, VOFF, SOFF)                                                                   \
@@ -724,11 +776,12 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
                     }                                                                                 \
         }                                                                                             \
     } while (0)
-    if constexpr (kPrefetchResB) SGV3D_FETCH_RESB();
     // (GROUP_PLANES -- the per-branch hidden maps of the two-kernel head path -- is row-linear too when a wave's columns
     // stay inside one group: plane base + row * group width)
     const bool fast_epi = (a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr) ||
                            (a.mode == SGV3D_CONV_GROUP_PLANES && a.gate == nullptr && a.ks % (BN / 2) == 0)) && m0 + BM <= a.M;
+    SGV3D_LOAD_TILE(ra0, rb0);
+    SGV3D_LOAD_TILE(ra1, rb1);
     float resv[WTM][WTN][16];
     if constexpr (kPrefetchRes) {
         const bool want = fast_epi && a.split_k <= 1 && a.res != nullptr;
@@ -748,8 +801,7 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
                 }
         }
     }
-    SGV3D_LOAD_TILE(ra0, rb0);
-    SGV3D_LOAD_TILE(ra1, rb1);
+    if constexpr (kPrefetchResB) SGV3D_FETCH_RESB();   // after the k-tiles: memory returns in order (see the f32 kernel)
     SGV3D_STORE_TILE(ra0, rb0, 0);
     __syncthreads();
     for (int kt = kt_begin; kt < nkt; kt += 2) {
@@ -1127,6 +1179,13 @@ extern "C" int sgv3d_conv_weight_to_bf16(const float *w_packed, int k_pad, int c
                        static_cast<__bf16 *>(w_packed_bf16));
     return check_launch("weight_to_bf16_kernel");
 }
+
+#ifdef SGV3D_IGEMM_STAMPS
+extern "C" int sgv3d_igemm_debug_stamps(void *buf) {
+    long long *p = static_cast<long long *>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_dbg), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" size_t sgv3d_conv2d_workspace_bytes(const sgv3d_conv_desc *d) {
     if (!d || d->split_k <= 1) return 0;
