@@ -185,6 +185,10 @@ def main():
             return model(imgs, mats)
 
     # ---- warm-up: packs weights, tunes tiles, fills the caching allocator ---------------------
+    # (the per-layer candidates are timed as the pipeline will run them: args.streams concurrent copies -- FramePipeline does
+    # the same when it sees the first forward; here that forward happens before the pipeline exists)
+    if "SGV3D_TUNE_STREAMS" not in os.environ and args.streams > 1:
+        hip_ops.TUNE_STREAMS = max(hip_ops.TUNE_STREAMS, args.streams)
     for _ in range(max(1, args.warmup)):
         out = step()
     torch.cuda.synchronize()

@@ -213,6 +213,9 @@ typedef struct sgv3d_conv_desc {
  * the input patch of all channels in LDS and walks over the cout tiles (cin <= 96, split_k <= 1: the
  * fused CenterHead branch layer); any other value selects the streaming variant. */
 #define SGV3D_WINOGRAD_RESIDENT 6
+/* ... == SGV3D_WINOGRAD_HALF: workgroups of 64 tiles x 32 channels whose waves split the 16 Winograd positions in two halves
+ * (two workgroups per CU; same weights, same results up to the summation order of the output transform) */
+#define SGV3D_WINOGRAD_HALF 8
 
 /* Packed weight geometry for a GEMM with `k` reduction elements and `n` output columns. */
 void sgv3d_conv_pack_geometry(int k, int n, int *k_pad, int *n_pad);

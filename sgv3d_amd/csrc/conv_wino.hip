@@ -29,6 +29,7 @@
 //     OUTPUT tiles (the transform is linear) go to the workspace and the igemm reduce kernel finishes.
 // Variants: conv_wino_resident_kernel (patch of all k-steps resident in LDS, walks over the cout tiles) and
 // conv_wino_head_kernel (both CenterHead branch layers, hidden maps never leave LDS).
+#include <type_traits>
 #include "conv_common.hpp"
 
 using namespace sgv3d;
@@ -421,6 +422,301 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     }
 
     wino_epilogue<TC>(a, acc, tn, img, oy0, ox0, wm, wn, h, t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// "Half-position" variant: two workgroups per CU.
+// conv_wino_kernel owns the whole register file (256 accumulator registers per wave, one wave per SIMD): whenever its
+// wave is not issuing an MFMA -- the input transform, the barrier in the middle of a step, prologue, epilogue -- the
+// SIMD's matrix pipe idles, and no other workgroup can share the CU (MFMA busy 39-48 % over a launch).  Here a workgroup
+// is 64 tiles x 32 output channels and its four waves are (tile half) x (Winograd rows i in {0,1} | {2,3}): a wave holds
+// 8 of the 16 position accumulators (128 registers), needs three of the four raw tile rows (T0 = d0 - d2, T1 = d1 + d2
+// | T2 = d2 - d1, T3 = d1 - d3) and half the weight fragments, so per-MFMA transform work and operand traffic are those of
+// the full kernel -- but at <= 256 registers two workgroups share a CU and fill each other's gaps, there are twice as many
+// (half as long) workgroups to balance, and the split-K the full kernel needs to fill 256 CUs is rarely necessary.
+// The output transform Y = A^T M A is linear in the positions: each wave transforms its two rows of M, keeps the output
+// row it owns (rows {0,1} -> dy = 0, rows {2,3} -> dy = 1), hands the other row's partial sums to its partner wave through
+// LDS (8 KB per wave), adds what it receives and runs the common epilogue on half of the pixels.
+// Weights: the layout of conv_wino_kernel ([cout tile of 64][k-step][16 pos][2][64 n][4]); the workgroup's 32 channels
+// are one half of a tile.  Schedule: plain -- one position at a time (V = row pass on the fly, 4 MFMAs, refill of the
+// position's fragment for the next step); the co-resident workgroup covers the latencies this leaves open.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWinoHalfLds = 2 * A_SLOTS * 16 > 4 * 16 * 64 * 8 ? 2 * A_SLOTS * 16 : 4 * 16 * 64 * 8;   // patch buffers | exchange
+
+template <int TC>
+__global__ __launch_bounds__(256, 2) void conv_wino_half_kernel(const ConvArgs a) {
+    using G = WinoGeom<TC>;
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+
+    // ---- tile mapping: (block of 64 tiles) x (32 output channels); a.tiles_n counts 32-channel tiles here ----
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tn2 = (int)((unsigned)logical / (unsigned)a.tiles_m);
+    const int tm = logical - tn2 * a.tiles_m;
+    const int tn = tn2 >> 1, wn = tn2 & 1;          // 64-channel tile of the packed weights, half inside it
+    const int bpi = a.wb_y * a.wb_x;
+    const int img = tm / bpi;
+    const int rb = tm - img * bpi;
+    const int by = rb / a.wb_x, bx = rb - by * a.wb_x;
+    const int oy0 = by * (2 * G::TR), ox0 = bx * (2 * TC);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, ph = wave & 1;        // tile half, position half (Winograd rows 2 ph, 2 ph + 1)
+    const int h = lane >> 5, t = lane & 31;
+
+    const int nsteps_all = a.cin / WK;
+    int kb = 0, ke = nsteps_all;
+    if (a.split_k > 1) {
+        kb = (int)((unsigned)nsteps_all * blockIdx.y / (unsigned)a.split_k);
+        ke = (int)((unsigned)nsteps_all * (blockIdx.y + 1) / (unsigned)a.split_k);
+    }
+
+    // ---- operand streams (as in conv_wino_kernel) ------------------------------------------------------
+    const unsigned x_bytes = (unsigned)((size_t)a.M * a.x_ld * sizeof(float));
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)x_bytes, 0x00020000);
+    unsigned xoff[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int s = i * 256 + tid;
+        const int hh = s / G::PLANE, rem = s - hh * G::PLANE;
+        const int row = rem / (2 * G::HALF), r2 = rem - row * (2 * G::HALF);
+        const int par = r2 / G::HALF, ch = r2 - par * G::HALF;
+        const int iy = oy0 - 1 + row, ix = ox0 - 1 + 2 * ch + par;
+        const bool ok = (s < G::USED) & (ch < TC + 1) & (iy >= 0) & (iy < a.in_h) & (ix >= 0) & (ix < a.in_w);
+        xoff[i] = ok ? (unsigned)((((size_t)(img * a.in_h + iy) * a.in_w + ix) * a.x_ld + a.x_coff + hh * 4) * sizeof(float))
+                     : 0xfffffff0u - (unsigned)(a.cin * sizeof(float));
+    }
+    unsigned x_step = (unsigned)(kb * WK * sizeof(float));
+    const unsigned w_bytes = (unsigned)((size_t)((a.tiles_n + 1) >> 1) * nsteps_all * W_STEP * sizeof(float));
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)w_bytes, 0x00020000);
+    // this wave's eight positions start at position 8 ph of the step
+    unsigned w_cur = (unsigned)((((size_t)tn * nsteps_all + kb) * W_STEP + (size_t)ph * 8 * W_POS) * sizeof(float));
+    unsigned w_next = kb + 1 < ke ? w_cur + W_STEP * 4 : w_cur;
+    const unsigned w_lane = (unsigned)(h * 64 + wn * 32 + t) * 16u;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+
+    // raw tile row R (0..3) / column j of this lane's tile in a patch buffer
+    const int abase = (h * G::ROWS + 2 * (wm * G::RW + t / TC)) * (2 * G::HALF) + t % TC;
+#define SGV3D_WH_RAW(A, R, J) (A)[(R) * (2 * G::HALF) + ((J) & 1) * G::HALF + ((J) >> 1)]
+    // one transformed row of one column from the patch buffer A:  ROW 0: ph ? d2 - d1 : d0 - d2,  ROW 1: ph ? d1 - d3 : d1 + d2
+#define SGV3D_WH_T(A, ROW, J)                                                                         \
+    ((ROW) == 0 ? (ph ? SGV3D_WH_RAW(A, 2, J) - SGV3D_WH_RAW(A, 1, J) : SGV3D_WH_RAW(A, 0, J) - SGV3D_WH_RAW(A, 2, J)) \
+                : (ph ? SGV3D_WH_RAW(A, 1, J) - SGV3D_WH_RAW(A, 3, J) : SGV3D_WH_RAW(A, 1, J) + SGV3D_WH_RAW(A, 2, J)))
+
+    // ---- prologue -----------------------------------------------------------------------------------
+    f32x4 tc[2][4], wf[8], stage0, stage1, stage2, va0, va1, vb0, vb1;
+    stage0 = wino_buffer_load(x_rsrc, xoff[0], x_step);
+    stage1 = wino_buffer_load(x_rsrc, xoff[1], x_step);
+    stage2 = wino_buffer_load(x_rsrc, xoff[2], x_step);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) wf[p] = wino_buffer_load(w_rsrc, w_lane, w_cur + p * (W_POS * 4));
+    smem[tid] = stage0;
+    smem[256 + tid] = stage1;
+    smem[512 + tid] = stage2;
+    if (kb + 1 < ke) x_step += WK * sizeof(float);
+    stage0 = wino_buffer_load(x_rsrc, xoff[0], x_step);
+    stage1 = wino_buffer_load(x_rsrc, xoff[1], x_step);
+    stage2 = wino_buffer_load(x_rsrc, xoff[2], x_step);
+    SGV3D_WINO_PUBLISH();
+    {
+        const f32x4 *const A = smem + abase;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tc[0][j] = SGV3D_WH_T(A, 0, j);
+            tc[1][j] = SGV3D_WH_T(A, 1, j);
+        }
+        va0 = wino_bt<0>(tc[0][0], tc[0][1], tc[0][2], tc[0][3]);
+        va1 = wino_bt<1>(tc[0][0], tc[0][1], tc[0][2], tc[0][3]);
+    }
+
+    // ---- main loop: one barrier per step, after the second pair --------------------------------------
+    // A step = 8 positions = 4 pairs; the MFMAs of a pair alternate between its two accumulators and everything else is pinned
+    // into two gaps per pair (the scheduler otherwise issues the four MFMAs of an accumulator back to back -- a dependent
+    // chain -- and sinks the loads to their first use):
+    //   gap 1 (memory): refill of the previous pair's two weight fragments with the next step's (a full step of prefetch
+    //     distance); the patch pipeline -- pair 0 writes the staged patch of step s+1 to LDS, the barrier after pair 2 publishes
+    //     it, pair 4 fetches the patch of step s+2; the raw tile columns the row pass of this gap's pair needs.
+    //   gap 2 (VALU): the column pass (V = T B) of the next pair, and the row pass T = B^T d of the next step, row by row as
+    //     soon as the current row is dead: row 0 (positions 0..3, done after pair 2) in pairs 4 / 6 from the buffer just
+    //     published, row 1 (positions 4..7) in pairs 0 / 2 of the next step.
+    // Patch buffers: step s+1's patch goes to buffer (s+1)&1 at pair 0 of step s (its previous content, patch s-1, was last
+    // read in pair 2 of step s-1 and every wave has passed that step's barrier since), and is read from pair 4 of step s to
+    // pair 2 of step s+1.  In the last step the prefetches re-read the last valid step and their results are dropped.
+#define SGV3D_WH_MFMA(P, C, V, BF) acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(V.C, BF.C, acc[P], 0, 0, 0)
+    auto pair = [&](auto Pc, f32x4 &vc0, f32x4 &vc1, f32x4 &vn0, f32x4 &vn1, const f32x4 *Acur, const f32x4 *Anew,
+                    f32x4 *a_wr) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value;
+        constexpr int L0 = (P + 6) & 7, L1 = (P + 7) & 7;        // the previous pair's fragments, dead now
+        const f32x4 b0 = wf[P], b1 = wf[P + 1];
+        SGV3D_WH_MFMA(P, x, vc0, b0);
+        SGV3D_SB();
+        // ---- gap 1: memory ----
+        wf[L0] = wino_buffer_load(w_rsrc, w_lane, (P == 0 ? w_cur : w_next) + L0 * (W_POS * 4));
+        wf[L1] = wino_buffer_load(w_rsrc, w_lane, (P == 0 ? w_cur : w_next) + L1 * (W_POS * 4));
+        if constexpr (P == 0) {
+            a_wr[0] = stage0;
+            a_wr[256] = stage1;
+            a_wr[512] = stage2;
+        } else if constexpr (P == 4) {
+            stage0 = wino_buffer_load(x_rsrc, xoff[0], x_step);
+            stage1 = wino_buffer_load(x_rsrc, xoff[1], x_step);
+            stage2 = wino_buffer_load(x_rsrc, xoff[2], x_step);
+        }
+        f32x4 t0, t1;
+        if constexpr (P == 0) { t0 = SGV3D_WH_T(Acur, 1, 0); t1 = SGV3D_WH_T(Acur, 1, 1); }
+        else if constexpr (P == 2) { t0 = SGV3D_WH_T(Acur, 1, 2); t1 = SGV3D_WH_T(Acur, 1, 3); }
+        else if constexpr (P == 4) { t0 = SGV3D_WH_T(Anew, 0, 0); t1 = SGV3D_WH_T(Anew, 0, 1); }
+        else { t0 = SGV3D_WH_T(Anew, 0, 2); t1 = SGV3D_WH_T(Anew, 0, 3); }
+        SGV3D_SB();
+        SGV3D_WH_MFMA(P + 1, x, vc1, b1);
+        SGV3D_SB();
+        SGV3D_WH_MFMA(P, y, vc0, b0);
+        SGV3D_SB();
+        SGV3D_WH_MFMA(P + 1, y, vc1, b1);
+        SGV3D_SB();
+        SGV3D_WH_MFMA(P, z, vc0, b0);
+        SGV3D_SB();
+        // ---- gap 2: vector ALU ----
+        if constexpr (P == 0) { tc[1][0] = t0; tc[1][1] = t1; }
+        else if constexpr (P == 2) { tc[1][2] = t0; tc[1][3] = t1; }
+        else if constexpr (P == 4) { tc[0][0] = t0; tc[0][1] = t1; }      // (row 0 of this step was last read in gap 2 of pair 0)
+        else { tc[0][2] = t0; tc[0][3] = t1; }
+        {
+            constexpr int Q = (P + 2) & 7;                       // next pair: positions Q, Q + 1 of row Q >> 2
+            vn0 = wino_bt<(Q & 3)>(tc[Q >> 2][0], tc[Q >> 2][1], tc[Q >> 2][2], tc[Q >> 2][3]);
+            vn1 = wino_bt<((Q + 1) & 3)>(tc[Q >> 2][0], tc[Q >> 2][1], tc[Q >> 2][2], tc[Q >> 2][3]);
+        }
+        SGV3D_SB();
+        SGV3D_WH_MFMA(P + 1, z, vc1, b1);
+        SGV3D_SB();
+        SGV3D_WH_MFMA(P, w, vc0, b0);
+        SGV3D_SB();
+        SGV3D_WH_MFMA(P + 1, w, vc1, b1);
+        SGV3D_SB();
+    };
+    for (int s = kb; s < ke; ++s) {
+        const int nb = (s + 1 - kb) & 1;
+        f32x4 *const a_wr = smem + nb * A_SLOTS + tid;
+        const f32x4 *const Acur = smem + (nb ^ 1) * A_SLOTS + abase;
+        const f32x4 *const Anew = smem + nb * A_SLOTS + abase;
+        pair(std::integral_constant<int, 0>{}, va0, va1, vb0, vb1, Acur, Anew, a_wr);
+        pair(std::integral_constant<int, 2>{}, vb0, vb1, va0, va1, Acur, Anew, a_wr);
+        SGV3D_WINO_PUBLISH();
+        if (s + 2 < ke) x_step += WK * sizeof(float);   // the patch fetched in pair 4 is step s+2's
+        SGV3D_SB();
+        pair(std::integral_constant<int, 4>{}, va0, va1, vb0, vb1, Acur, Anew, a_wr);
+        pair(std::integral_constant<int, 6>{}, vb0, vb1, va0, va1, Acur, Anew, a_wr);
+        w_cur = w_next;
+        if (s + 2 < ke) w_next += W_STEP * 4;
+    }
+#undef SGV3D_WH_MFMA
+#undef SGV3D_WH_T
+#undef SGV3D_WH_RAW
+
+    // ---- epilogue: partial output transform, exchange with the partner wave, common epilogue on output row dy = ph ----
+    __syncthreads();                                   // every wave is done with the patch buffers: they become the exchange area
+    f32x2 *const xbuf = reinterpret_cast<f32x2 *>(smem);     // [wave][e][lane]
+    float keep[16][2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        // rows of M this wave holds: (acc[0..3][e]) = row 2 ph, (acc[4..7][e]) = row 2 ph + 1; column transform first
+        const float ra0 = acc[0][e] + acc[1][e] + acc[2][e], ra1 = acc[1][e] - acc[2][e] - acc[3][e];
+        const float rb0 = acc[4][e] + acc[5][e] + acc[6][e], rb1 = acc[5][e] - acc[6][e] - acc[7][e];
+        // A^T = [1 1 1 0; 0 1 -1 -1]:  Y0 = M0 + M1 + M2,  Y1 = M1 - M2 - M3
+        f32x2 send;
+        if (ph == 0) {       // rows 0, 1: all of Y0's share, M1 of Y1
+            keep[e][0] = ra0 + rb0; keep[e][1] = ra1 + rb1;
+            send = f32x2{rb0, rb1};
+        } else {             // rows 2, 3: M2 of Y0, -M2 - M3 of Y1
+            keep[e][0] = -ra0 - rb0; keep[e][1] = -ra1 - rb1;
+            send = f32x2{ra0, ra1};
+        }
+        xbuf[(wave * 16 + e) * 64 + lane] = send;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const f32x2 got = xbuf[((wave ^ 1) * 16 + e) * 64 + lane];
+        keep[e][0] += got[0];
+        keep[e][1] += got[1];
+    }
+
+    // address set-up of wino_epilogue, for 32 channels and one output row (dy = ph) per tile
+    const int col = tn2 * 32 + t;
+    const bool partial = a.split_k > 1;
+    const long long row0 = ((long long)img * a.out_h + oy0) * a.out_w + ox0;
+    const char *ybase;
+    unsigned pixstride, lane_off;
+    float sc = 1.f, sh = 0.f, gt = 1.f, floor_ = -__builtin_inff();
+    if (partial) {
+        ybase = reinterpret_cast<const char *>(a.ws + ((size_t)blockIdx.y * a.M + row0) * a.N + tn2 * 32);
+        pixstride = a.N * 4u;
+        lane_off = t * 4u;
+    } else {
+        if (col < a.N) {
+            if (a.scale) sc = a.scale[col];
+            if (a.bias) sh = a.bias[col];
+            if (a.gate) gt = a.gate[(size_t)img * a.cout + col];
+        }
+        if (a.relu) floor_ = 0.f;
+        if (a.mode == SGV3D_CONV_NORMAL) {
+            ybase = reinterpret_cast<const char *>(a.y + row0 * a.y_ld + a.y_coff + tn2 * 32);
+            pixstride = a.y_ld * 4u;
+            lane_off = t * 4u;
+        } else if (a.mode == SGV3D_CONV_NCHW_OUT) {
+            const long long hw = (long long)a.out_h * a.out_w;
+            ybase = reinterpret_cast<const char *>(a.y + ((size_t)img * a.y_ld + a.y_coff + tn2 * 32) * hw + (long long)oy0 * a.out_w + ox0);
+            pixstride = 4u;
+            lane_off = (unsigned)(t * hw * 4);
+        } else {  // GROUP_PLANES: [cout/g][M][g], g = a.ks
+            const int grp0 = (tn2 * 32) / a.ks, grp = col / a.ks;
+            ybase = reinterpret_cast<const char *>(a.y + ((size_t)grp0 * a.M + row0) * a.ks);
+            pixstride = a.ks * 4u;
+            lane_off = (unsigned)((((size_t)(grp - grp0) * a.M) * a.ks + (col - grp * a.ks)) * 4);
+        }
+    }
+    const unsigned rowpitch = a.out_w * pixstride;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ybase, 0, (int)0xffffff00u, 0x00020000);
+    const bool has_res = !partial && a.res != nullptr;
+    const unsigned rpix = a.res_ld * 4u, rpitch = a.out_w * rpix;
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_res ? a.res + row0 * a.res_ld + tn2 * 32 : a.zeros), 0, has_res ? (int)0xffffff00u : 0, 0x00020000);
+    constexpr int RW2 = 2 * G::RW;                 // output rows per tile half
+    const int oy_wave = oy0 + wm * RW2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        // accumulator element e is tile tw = 8*(e>>2) + 4h + (e&3) of the tile half: row tw / TC, column tw % TC
+        const int yy = 2 * ((8 * (e >> 2)) / TC) + ph;
+        const int c = ((e >> 2) % (TC / 8)) * 4 + (e & 3);
+        if (oy_wave + yy < a.out_h) {              // wave-uniform
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int xx = 8 * h + 2 * ((c >> 2) * 8 + (c & 3)) + dx;
+                const bool ok = (col < a.N) & (ox0 + xx < a.out_w);
+                const unsigned vo = ok ? lane_off + (wm * RW2) * rowpitch + xx * pixstride : 0xffffffffu;
+                float v = keep[e][dx];
+                if (!partial) {
+                    v = v * sc + sh;
+                    if (has_res) {
+                        const unsigned ro = ok ? t * 4u + (wm * RW2) * rpitch + xx * rpix : 0xffffffffu;
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, ro, yy * rpitch, 0));
+                    }
+                    v = fmaxf(v, floor_) * gt;
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, vo, yy * rowpitch, 0);
+            }
+        }
+    }
 }
 
 // Patch-resident variant for layers with few input channels and many output channels (the fused first
@@ -975,6 +1271,13 @@ extern "C" int sgv3d_conv2d_winograd_forward(const sgv3d_conv_desc *d, const flo
         if (groups > a.tiles_n) groups = a.tiles_n;
         hipLaunchKernelGGL(conv_wino_resident_kernel, dim3(a.tiles_m * groups), dim3(256), lds, st, a);
         return check_launch("conv_wino_resident_kernel");
+    }
+    if (d->tile == SGV3D_WINOGRAD_HALF) {           // 64 tiles x 32 channels per workgroup, two workgroups per CU
+        a.tiles_n = cdiv(d->cout, 32);
+        if (wide) hipLaunchKernelGGL(conv_wino_half_kernel<16>, dim3(a.tiles_m * a.tiles_n, a.split_k), dim3(256), kWinoHalfLds, st, a);
+        else hipLaunchKernelGGL(conv_wino_half_kernel<8>, dim3(a.tiles_m * a.tiles_n, a.split_k), dim3(256), kWinoHalfLds, st, a);
+        if (a.split_k > 1) return launch_splitk_reduce(a, st);
+        return check_launch("conv_wino_half_kernel");
     }
     if (wide) hipLaunchKernelGGL(conv_wino_kernel<16>, dim3(a.tiles_m * a.tiles_n, a.split_k), dim3(256), kWinoLds, st, a);
     else hipLaunchKernelGGL(conv_wino_kernel<8>, dim3(a.tiles_m * a.tiles_n, a.split_k), dim3(256), kWinoLds, st, a);

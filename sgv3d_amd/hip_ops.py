@@ -88,11 +88,13 @@ def save_tune_db(path=None):
 
 
 load_tune_db()
-TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: "wino_resident", 7: "patch_bf16",
+TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: "wino_resident", 7: "patch_bf16", 8: "wino_half",
               11: "128x128", 12: "128x64", 13: "64x128", 14: "64x64"}     # 11..14: f32x3 of tiles 1..4 (host-side ids)
 TILE_WINO = 5       # host-side algorithm id: sgv3d_conv2d_winograd_forward instead of the implicit GEMM
 TILE_WINO_RES = 6   # = SGV3D_WINOGRAD_RESIDENT: its patch-resident variant (cin <= 96, many cout tiles)
 TILE_PATCH = 7      # bf16 mode: the LDS-resident-patch 3x3 kernel (sgv3d_conv3x3_patch_bf16_forward)
+TILE_WINO_HALF = 8  # = SGV3D_WINOGRAD_HALF: 64 tiles x 32 channels per workgroup, positions split over wave pairs (2 workgroups / CU)
+WINO_HALF = _os.environ.get("SGV3D_WINO_HALF", "1") != "0"
 PATCH_BF16 = _os.environ.get("SGV3D_PATCH_BF16", "1") != "0"
 
 
@@ -352,9 +354,9 @@ class PackedConv:
         real_n = self.cout_real * (self.ks * self.ks if self.transposed else 1)
         flops = 2.0 * gemm_m * real_n * (self.cin_real * self.kh * self.kw)
         x3 = t > 10 or (MFMA_F32X3 is True and t < TILE_WINO)
-        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH) else
+        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) else
                 ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_f32x3_" if x3 else "conv_igemm_")) + TILE_NAMES[t]
-        if t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH) and self.k_order == 0:
+        if t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) and self.k_order == 0:
             name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
@@ -405,7 +407,7 @@ class PackedConv:
                                                         d.y_coff, d.res_ld, d.relu, x.data_ptr(), self._patch_weights().data_ptr(),
                                                         _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
                                                         out.data_ptr(), int(io), int(d.split_k), _lib.ptr(ws), nws, _st(x))
-        if d.tile in (TILE_WINO, TILE_WINO_RES):
+        if d.tile in (TILE_WINO, TILE_WINO_RES, TILE_WINO_HALF):
             if self.w_wino is None:
                 raise _lib.SGV3DError("this layer has no Winograd weights (needs 3x3 / stride 1 / pad 1 / cin % 8 == 0)")
             return lib.sgv3d_conv2d_winograd_forward(ctypes.byref(d), x.data_ptr(), self.w_wino.data_ptr(),
@@ -461,6 +463,8 @@ class PackedConv:
             tiles += (11, 12, 13, 14)
         if self.w_wino is not None and WINOGRAD and not MFMA_BF16:
             tiles += (TILE_WINO,)
+            if WINO_HALF:
+                tiles += (TILE_WINO_HALF,)
             if self.cin <= 96 and self.cout >= 128:
                 tiles += (TILE_WINO_RES,)
         if self._patch_eligible(d, gate):
@@ -475,9 +479,9 @@ class PackedConv:
                 bm, bn = dims.get(t, (512, 64))
                 wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
                 nk = nkt
-                if t == TILE_WINO:
+                if t in (TILE_WINO, TILE_WINO_HALF):
                     nk = self.cin // 4      # k-steps of 8 channels; nk // s >= 8 keeps >= 4 steps per split
-                    wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 16) * -(-gemm_n // 64)
+                    wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 16) * -(-gemm_n // (64 if t == TILE_WINO else 32))
                 if t == TILE_PATCH:
                     nk = self.cin // 32     # stages of 32 input channels; >= 2 per split
                     wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 32) * -(-gemm_n // 64)

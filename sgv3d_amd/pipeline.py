@@ -27,6 +27,8 @@ stream (producers of ``imgs`` / ``mats``, consumers of the slot's previous outpu
 current stream wait for the frame and returns the slot's static output tensors, valid until that slot is submitted
 again (``slots`` submits later) -- clone what must live longer.
 """
+import os
+
 import torch
 
 from .calibration import CalibrationCache
@@ -48,6 +50,13 @@ class FramePipeline:
         self.done = [torch.cuda.Event() for _ in range(self.slots)]
         self._next = 0
         self._own_cache = model.backbone.calib_cache
+        # The first forward times the per-layer candidates (tile, split-K, Winograd variant).  With several frames in flight a
+        # launch shares the chip with the other slots' kernels, and what wins alone is not what wins then (a Winograd kernel
+        # that owns a whole CU against one that leaves room for a second workgroup): the candidates are timed as `slots`
+        # concurrent copies unless SGV3D_TUNE_STREAMS says otherwise.
+        from . import hip_ops
+        if "SGV3D_TUNE_STREAMS" not in os.environ and self.slots > 1:
+            hip_ops.TUNE_STREAMS = max(hip_ops.TUNE_STREAMS, self.slots)
         with torch.no_grad():
             model(imgs, mats)                      # packs weights / tunes tiles outside any capture
             torch.cuda.synchronize(imgs.device)

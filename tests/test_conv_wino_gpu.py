@@ -40,10 +40,14 @@ SHAPES = [
 ]
 
 
+VARIANTS = [5, 8]       # hip_ops.TILE_WINO (one workgroup per CU), TILE_WINO_HALF (positions split over wave pairs)
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("split", [1, 2])
-def test_winograd_matches_conv2d(shape, split):
-    from sgv3d_amd.hip_ops import PackedConv, TILE_WINO
+@pytest.mark.parametrize("TILE_WINO", VARIANTS)
+def test_winograd_matches_conv2d(shape, split, TILE_WINO):
+    from sgv3d_amd.hip_ops import PackedConv
     B, cin, H, W, cout = shape
     if cin // 8 < split:
         pytest.skip("not enough k-steps")
@@ -56,8 +60,9 @@ def test_winograd_matches_conv2d(shape, split):
     assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
 
 
-def test_winograd_bit_exact_on_integer_data():
-    from sgv3d_amd.hip_ops import PackedConv, TILE_WINO
+@pytest.mark.parametrize("TILE_WINO", VARIANTS)
+def test_winograd_bit_exact_on_integer_data(TILE_WINO):
+    from sgv3d_amd.hip_ops import PackedConv
     x, w = _mk(2, 32, 20, 36, 72, integer=True)
     conv = PackedConv(w.cuda(), pad=1)
     y = conv(x.cuda(), tile=TILE_WINO, split_k=1)
@@ -66,8 +71,9 @@ def test_winograd_bit_exact_on_integer_data():
     assert torch.equal(y2.cpu().double(), _ref(x, w))
 
 
-def test_winograd_epilogue_bn_residual_relu_gate_and_slices():
-    from sgv3d_amd.hip_ops import PackedConv, TILE_WINO
+@pytest.mark.parametrize("TILE_WINO", VARIANTS)
+def test_winograd_epilogue_bn_residual_relu_gate_and_slices(TILE_WINO):
+    from sgv3d_amd.hip_ops import PackedConv
     B, cin, H, W, cout = 2, 32, 19, 23, 48
     x, w = _mk(B, cin, H, W, cout, seed=3)
     g = torch.Generator().manual_seed(4)
@@ -87,8 +93,9 @@ def test_winograd_epilogue_bn_residual_relu_gate_and_slices():
         assert (got[..., :4] == -7).all() and (got[..., 4 + cout:] == -7).all()
 
 
-def test_winograd_modes_match_implicit_gemm():
-    from sgv3d_amd.hip_ops import PackedConv, TILE_WINO
+@pytest.mark.parametrize("TILE_WINO", VARIANTS)
+def test_winograd_modes_match_implicit_gemm(TILE_WINO):
+    from sgv3d_amd.hip_ops import PackedConv
     B, cin, H, W, cout = 1, 64, 40, 24, 128
     x, w = _mk(B, cin, H, W, cout, seed=5)
     conv = PackedConv(w.cuda(), pad=1, relu=True)

@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sgv3d_amd import hip_ops
-from sgv3d_amd.hip_ops import PackedConv, TILE_WINO, TILE_WINO_RES
+from sgv3d_amd.hip_ops import PackedConv, TILE_WINO, TILE_WINO_RES, TILE_WINO_HALF
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -53,12 +53,12 @@ for it in range(N):
                       shift=None if sh is None else sh.cuda(), relu=use_relu)
     cands = [(t, s) for t in (1, 2, 3, 4) for s in (1, 2, 3)]
     if conv.w_wino is not None and MODE != "bf16":
-        cands += [(TILE_WINO, 1), (TILE_WINO, 2), (TILE_WINO, 3)]
+        cands += [(TILE_WINO, 1), (TILE_WINO, 2), (TILE_WINO, 3), (TILE_WINO_HALF, 1), (TILE_WINO_HALF, 2), (TILE_WINO_HALF, 3)]
         if cin <= 96:
             cands.append((TILE_WINO_RES, 1))
     scale_ref = max(1.0, ref.abs().max().item())
     for t, s in cands:
-        nk = conv.k_pad // 32 if t < TILE_WINO else cin // 8
+        nk = conv.k_pad // 32 if t < TILE_WINO else cin // 8      # (Winograd variants: k-steps of 8 channels)
         if s > nk:
             continue
         out = torch.full((B, OH, OW, cout + y_extra), -7.0, device="cuda")
