@@ -624,34 +624,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_half_kernel(const ConvArgs a
 #undef SGV3D_WH_RAW
 
     // ---- epilogue: partial output transform, exchange with the partner wave, common epilogue on output row dy = ph ----
-    __syncthreads();                                   // every wave is done with the patch buffers: they become the exchange area
-    f32x2 *const xbuf = reinterpret_cast<f32x2 *>(smem);     // [wave][e][lane]
-    float keep[16][2];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        // rows of M this wave holds: (acc[0..3][e]) = row 2 ph, (acc[4..7][e]) = row 2 ph + 1; column transform first
-        const float ra0 = acc[0][e] + acc[1][e] + acc[2][e], ra1 = acc[1][e] - acc[2][e] - acc[3][e];
-        const float rb0 = acc[4][e] + acc[5][e] + acc[6][e], rb1 = acc[5][e] - acc[6][e] - acc[7][e];
-        // A^T = [1 1 1 0; 0 1 -1 -1]:  Y0 = M0 + M1 + M2,  Y1 = M1 - M2 - M3
-        f32x2 send;
-        if (ph == 0) {       // rows 0, 1: all of Y0's share, M1 of Y1
-            keep[e][0] = ra0 + rb0; keep[e][1] = ra1 + rb1;
-            send = f32x2{rb0, rb1};
-        } else {             // rows 2, 3: M2 of Y0, -M2 - M3 of Y1
-            keep[e][0] = -ra0 - rb0; keep[e][1] = -ra1 - rb1;
-            send = f32x2{ra0, ra1};
-        }
-        xbuf[(wave * 16 + e) * 64 + lane] = send;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const f32x2 got = xbuf[((wave ^ 1) * 16 + e) * 64 + lane];
-        keep[e][0] += got[0];
-        keep[e][1] += got[1];
-    }
-
-    // address set-up of wino_epilogue, for 32 channels and one output row (dy = ph) per tile
+    // address set-up of wino_epilogue, for 32 channels and one output row (dy = ph) per tile; the residual values are asked
+    // for first, so that they arrive under the exchange
     const int col = tn2 * 32 + t;
     const bool partial = a.split_k > 1;
     const long long row0 = ((long long)img * a.out_h + oy0) * a.out_w + ox0;
@@ -693,27 +667,60 @@ __global__ __launch_bounds__(256, 2) void conv_wino_half_kernel(const ConvArgs a
         (void *)(has_res ? a.res + row0 * a.res_ld + tn2 * 32 : a.zeros), 0, has_res ? (int)0xffffff00u : 0, 0x00020000);
     constexpr int RW2 = 2 * G::RW;                 // output rows per tile half
     const int oy_wave = oy0 + wm * RW2;
+    // accumulator element e is tile tw = 8*(e>>2) + 4h + (e&3) of the tile half: row tw / TC, column tw % TC
+    unsigned voff[TC / 2][2], roff[TC / 2][2];
+#pragma unroll
+    for (int c = 0; c < TC / 2; ++c)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int xx = 8 * h + 2 * ((c >> 2) * 8 + (c & 3)) + dx;
+            const bool ok = (col < a.N) & (ox0 + xx < a.out_w);
+            voff[c][dx] = ok ? lane_off + (wm * RW2) * rowpitch + xx * pixstride : 0xffffffffu;
+            roff[c][dx] = (ok && has_res) ? t * 4u + (wm * RW2) * rpitch + xx * rpix : 0xffffffffu;
+        }
+    float resv[16][2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        // accumulator element e is tile tw = 8*(e>>2) + 4h + (e&3) of the tile half: row tw / TC, column tw % TC
+        const int yy = 2 * ((8 * (e >> 2)) / TC) + ph;
+        const int c = ((e >> 2) % (TC / 8)) * 4 + (e & 3);
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx)      // (no residual: zero-sized resource -> 0; rows below the image are not touched)
+            resv[e][dx] = (oy_wave + yy < a.out_h)
+                              ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, roff[c][dx], yy * rpitch, 0))
+                              : 0.f;
+    }
+
+    __syncthreads();                                   // every wave is done with the patch buffers: they become the exchange area
+    f32x2 *const xbuf = reinterpret_cast<f32x2 *>(smem);     // [wave][e][lane]
+    float keep[16][2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        // rows of M this wave holds: (acc[0..3][e]) = row 2 ph, (acc[4..7][e]) = row 2 ph + 1; column transform first
+        const float ra0 = acc[0][e] + acc[1][e] + acc[2][e], ra1 = acc[1][e] - acc[2][e] - acc[3][e];
+        const float rb0 = acc[4][e] + acc[5][e] + acc[6][e], rb1 = acc[5][e] - acc[6][e] - acc[7][e];
+        // A^T = [1 1 1 0; 0 1 -1 -1]:  Y0 = M0 + M1 + M2,  Y1 = M1 - M2 - M3
+        f32x2 send;
+        if (ph == 0) {       // rows 0, 1: all of their share of Y0 stays, M1 goes to Y1
+            keep[e][0] = ra0 + rb0; keep[e][1] = ra1 + rb1;
+            send = f32x2{rb0, rb1};
+        } else {             // rows 2, 3: -M2 - M3 of Y1 stays, M2 goes to Y0
+            keep[e][0] = -ra0 - rb0; keep[e][1] = -ra1 - rb1;
+            send = f32x2{ra0, ra1};
+        }
+        xbuf[(wave * 16 + e) * 64 + lane] = send;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const f32x2 got = xbuf[((wave ^ 1) * 16 + e) * 64 + lane];
         const int yy = 2 * ((8 * (e >> 2)) / TC) + ph;
         const int c = ((e >> 2) % (TC / 8)) * 4 + (e & 3);
         if (oy_wave + yy < a.out_h) {              // wave-uniform
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
-                const int xx = 8 * h + 2 * ((c >> 2) * 8 + (c & 3)) + dx;
-                const bool ok = (col < a.N) & (ox0 + xx < a.out_w);
-                const unsigned vo = ok ? lane_off + (wm * RW2) * rowpitch + xx * pixstride : 0xffffffffu;
-                float v = keep[e][dx];
-                if (!partial) {
-                    v = v * sc + sh;
-                    if (has_res) {
-                        const unsigned ro = ok ? t * 4u + (wm * RW2) * rpitch + xx * rpix : 0xffffffffu;
-                        v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, ro, yy * rpitch, 0));
-                    }
-                    v = fmaxf(v, floor_) * gt;
-                }
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, vo, yy * rowpitch, 0);
+                float v = keep[e][dx] + got[dx];
+                if (!partial) v = fmaxf(v * sc + sh + resv[e][dx], floor_) * gt;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, voff[c][dx], yy * rowpitch, 0);
             }
         }
     }
