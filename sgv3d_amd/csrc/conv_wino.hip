@@ -27,8 +27,9 @@
 //     the same lane / register index of the 16 accumulator tiles), followed by a slim epilogue.
 //   * split-K over input-channel steps (grid.y) for layers with too few tiles to fill 256 CUs; partial
 //     OUTPUT tiles (the transform is linear) go to the workspace and the igemm reduce kernel finishes.
-// Variants: conv_wino_resident_kernel (patch of all k-steps resident in LDS, walks over the cout tiles) and
-// conv_wino_head_kernel (both CenterHead branch layers, hidden maps never leave LDS).
+// Variants: conv_wino_half_kernel (64 tiles x 32 channels, the 16 positions split over wave pairs: two workgroups per CU --
+// what the pipeline with several frames in flight prefers), conv_wino_resident_kernel (patch of all k-steps resident in
+// LDS, walks over the cout tiles) and conv_wino_head_kernel (both CenterHead branch layers, hidden maps never leave LDS).
 #include <type_traits>
 #include "conv_common.hpp"
 
