@@ -40,6 +40,9 @@ def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, c
     d.x_ld, d.x_coff, d.y_ld, d.y_coff = x_ld, int(x_coff), y_ld, int(y_coff)
     d.tile = int(tile)
     lib = _lib.load()
+    if not tile and not split:
+        tile, split = _wgrad_choice(lib, d, x, dy)       # first-call measurement per layer shape (0, 0 = the library's rule)
+        d.tile = int(tile)
     nws = lib.sgv3d_conv2d_backward_weight_workspace_bytes(ctypes.byref(d), int(split))
     ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
     dw = torch.empty(cout, cin, kh, kw, dtype=torch.float32, device=x.device)
@@ -48,6 +51,55 @@ def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, c
                                               ws.data_ptr(), nws, _st(x))
     _lib.check(rc, "sgv3d_conv2d_backward_weight")
     return dw
+
+
+_WGRAD_DB = {}
+
+
+def _wgrad_choice(lib, d, x, dy):
+    """(tile, split) of the weight-gradient kernel for this layer shape: the library's rule and a handful of alternatives
+    (the four tile shapes; half / twice / four times the rule's pixel split) timed once on the real tensors.  Every choice
+    sums each tile's pixel ranges in a fixed order, so results differ only by the association of that sum."""
+    from . import hip_ops
+    key = (d.batch, d.in_h, d.in_w, d.cin, d.out_h, d.out_w, d.cout, d.kh, d.kw, d.stride, d.pad, d.dil, d.x_ld, d.y_ld)
+    if key in _WGRAD_DB:
+        return _WGRAD_DB[key]
+    if not hip_ops.AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        return 0, 0
+    pixels = d.batch * d.out_h * d.out_w
+    cands = [(0, 0)]
+    for t in (1, 2, 3, 4):
+        tiles = -(-d.cout // (128 if t > 2 else 64)) * -(-d.cin // (128 if t in (2, 4) else 64)) * d.kh * d.kw
+        base = max(1, min(max(256, min(1536, tiles * 64)) // max(tiles, 1), pixels // 256))
+        for f in (0.5, 1, 2, 4):
+            sp = int(max(1, min(base * f, pixels // 128)))
+            if (t, sp) not in cands:
+                cands.append((t, sp))
+    dw = torch.empty(d.cout, d.cin, d.kh, d.kw, dtype=torch.float32, device=x.device)
+    best, best_t = (0, 0), None
+    with torch.cuda.device(x.device):
+        for t, sp in cands:
+            d.tile = t
+            nws = lib.sgv3d_conv2d_backward_weight_workspace_bytes(ctypes.byref(d), sp)
+            if nws > (2 << 30):
+                continue
+            ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
+            run = lambda: lib.sgv3d_conv2d_backward_weight(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), sp,
+                                                           ws.data_ptr(), nws, _st(x))
+            if run() != 0:
+                continue
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            evs[0].record()
+            for r in range(3):
+                run()
+                evs[r + 1].record()
+            evs[-1].synchronize()
+            dt = min(evs[r].elapsed_time(evs[r + 1]) for r in range(3))
+            if best_t is None or dt < best_t:
+                best, best_t = (t, sp), dt
+    d.tile = 0
+    _WGRAD_DB[key] = best
+    return best
 
 
 def zero_insert(x, stride, out_hw):
