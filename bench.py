@@ -415,6 +415,24 @@ def main():
                   "ok": bool(worst <= tol)}
         parity["ok"] = parity["ok"] and parity["voxel_indices_equal"]
 
+    # ---- one frame in flight with the kernels chosen FOR one frame in flight ---------------------------------------
+    # `single` above replays one frame at a time with the tiles / Winograd variants that were picked for `nstreams` frames in
+    # flight.  A caller who runs one frame at a time builds its pipeline with one slot and gets its own choices: measured here,
+    # last (it drops every packed weight and measurement of the model), so both uses of the library are on the record.
+    single_own = None
+    if single is not None and hip_ops.TUNE_STREAMS > 1 and hip_ops.AUTOTUNE and not os.environ.get("SGV3D_TUNE_CACHE"):
+        saved_streams = hip_ops.TUNE_STREAMS
+        hip_ops.TUNE_STREAMS = 1
+        hip_ops.TUNE_DB.clear()
+        model.refresh()                      # drops the packed weights and with them every layer's cached choice
+        one = FramePipeline(model, imgs, mats, slots=1, use_graph=use_graph)     # its first forward re-measures, alone
+        for _ in range(args.warmup):
+            one.submit(imgs, mats)
+        t1 = group.timed(lambda: one.submit(imgs, mats), args.steps)
+        single_own = {"value": B * args.steps / t1, "ms_per_step": t1 / args.steps * 1e3}
+        del one
+        hip_ops.TUNE_STREAMS = saved_streams
+
     if rank == 0:
         line = {
             "metric": "camera frames/sec at 864x1536->BEV",
@@ -436,6 +454,8 @@ def main():
                        "per_rank": per_rank},
             "one_frame_in_flight_value": single["value"] if single else None,
             "one_frame_in_flight_ms_per_step": single["ms_per_step"] if single else None,
+            "one_frame_in_flight_own_tiles_value": single_own["value"] if single_own else None,
+            "one_frame_in_flight_own_tiles_ms_per_step": single_own["ms_per_step"] if single_own else None,
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "parity": parity,
         }
     group.close()
