@@ -42,3 +42,4 @@ for i, name, flops, us in rows:
     print(f"{i:3d} {us:8.1f} {tf:6.1f} {tf / (2500.0 if hip_ops.MFMA_BF16 else 157.3) * 100:5.1f}  {name}")
 print("total us", tot)
 json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "layers.json"), "w"))
+hip_ops.save_tune_db()          # no-op unless SGV3D_TUNE_CACHE is set (tools/layer_traffic.py replays the same choices under rocprofv3)
