@@ -209,6 +209,9 @@ typedef struct sgv3d_conv_desc {
 #define SGV3D_TILE_128x64 2
 #define SGV3D_TILE_64x128 3
 #define SGV3D_TILE_64x64 4
+/* ... | SGV3D_TILE_MFIRST: the workgroups walk the output-channel tiles of one m-tile back to back (input rows fetched once
+ * from HBM) instead of the m-tiles of one channel tile (weight tile shared); same results */
+#define SGV3D_TILE_MFIRST 16
 /* sgv3d_conv2d_winograd_forward only: desc.tile == SGV3D_WINOGRAD_RESIDENT selects the variant that keeps
  * the input patch of all channels in LDS and walks over the cout tiles (cin <= 96, split_k <= 1: the
  * fused CenterHead branch layer); any other value selects the streaming variant. */

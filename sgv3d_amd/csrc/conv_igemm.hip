@@ -94,8 +94,18 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tn = (int)((unsigned)logical / (unsigned)a.tiles_m);     // (unsigned: half the scalar instructions of a signed division)
-    const int tm = logical - tn * a.tiles_m;
+    // Default walk: the output-channel tile changes slowest (consecutive workgroups share a weight tile).  korder bit 1
+    // (desc.tile | SGV3D_TILE_MFIRST): the m-tile changes slowest -- its input rows are fetched from HBM once instead of once
+    // per channel tile (tools/layer_traffic.py); pays on the bandwidth-heavy layers (64->256 at 216x384, 2560->512), costs on
+    // the others, so it is one more candidate of the first-call measurement.
+    int tn, tm;
+    if (a.korder & 2) {
+        tm = (int)((unsigned)logical / (unsigned)a.tiles_n);
+        tn = logical - tm * a.tiles_n;
+    } else {
+        tn = (int)((unsigned)logical / (unsigned)a.tiles_m);     // (unsigned: half the scalar instructions of a signed division)
+        tm = logical - tn * a.tiles_m;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x;
@@ -522,8 +532,18 @@ __global__ __launch_bounds__(kThreads, (SPLIT3 && WTM * WTN >= 2) ? 1 : 2) void 
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tn = (int)((unsigned)logical / (unsigned)a.tiles_m);     // (unsigned: half the scalar instructions of a signed division)
-    const int tm = logical - tn * a.tiles_m;
+    // Default walk: the output-channel tile changes slowest (consecutive workgroups share a weight tile).  korder bit 1
+    // (desc.tile | SGV3D_TILE_MFIRST): the m-tile changes slowest -- its input rows are fetched from HBM once instead of once
+    // per channel tile (tools/layer_traffic.py); pays on the bandwidth-heavy layers (64->256 at 216x384, 2560->512), costs on
+    // the others, so it is one more candidate of the first-call measurement.
+    int tn, tm;
+    if (a.korder & 2) {
+        tm = (int)((unsigned)logical / (unsigned)a.tiles_n);
+        tn = logical - tm * a.tiles_n;
+    } else {
+        tn = (int)((unsigned)logical / (unsigned)a.tiles_m);     // (unsigned: half the scalar instructions of a signed division)
+        tm = logical - tn * a.tiles_m;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x;
     const int cc = tid & 7;
@@ -1062,7 +1082,7 @@ int launch_t(const ConvArgs &a, hipStream_t st) {
 
 template <int WTM, int WTN>
 int launch(const ConvArgs &a, hipStream_t st) {
-    return a.korder == 1 ? launch_t<WTM, WTN, true>(a, st) : launch_t<WTM, WTN, false>(a, st);
+    return (a.korder & 1) ? launch_t<WTM, WTN, true>(a, st) : launch_t<WTM, WTN, false>(a, st);
 }
 
 template <int WTM, int WTN, bool FAST, bool SPLIT3, bool XB = false, bool YB = false>
@@ -1090,7 +1110,7 @@ int launch_bf16_t(const ConvArgs &a, hipStream_t st) {
 // io: bit 0 = the input is bf16, bit 1 = output and residual are bf16
 template <int WTM, int WTN>
 int launch_bf16io(const ConvArgs &a, hipStream_t st, int io) {
-    const bool fast = a.korder == 1;
+    const bool fast = (a.korder & 1) != 0;
     switch (io) {
         case 1: return fast ? launch_bf16_t<WTM, WTN, true, false, true, false>(a, st) : launch_bf16_t<WTM, WTN, false, false, true, false>(a, st);
         case 2: return fast ? launch_bf16_t<WTM, WTN, true, false, false, true>(a, st) : launch_bf16_t<WTM, WTN, false, false, false, true>(a, st);
@@ -1101,8 +1121,8 @@ int launch_bf16io(const ConvArgs &a, hipStream_t st, int io) {
 
 template <int WTM, int WTN>
 int launch_bf16(const ConvArgs &a, hipStream_t st, bool split3) {
-    if (split3) return a.korder == 1 ? launch_bf16_t<WTM, WTN, true, true>(a, st) : launch_bf16_t<WTM, WTN, false, true>(a, st);
-    return a.korder == 1 ? launch_bf16_t<WTM, WTN, true, false>(a, st) : launch_bf16_t<WTM, WTN, false, false>(a, st);
+    if (split3) return (a.korder & 1) ? launch_bf16_t<WTM, WTN, true, true>(a, st) : launch_bf16_t<WTM, WTN, false, true>(a, st);
+    return (a.korder & 1) ? launch_bf16_t<WTM, WTN, true, false>(a, st) : launch_bf16_t<WTM, WTN, false, false>(a, st);
 }
 
 int pick_tile(long long M, int N) {
@@ -1229,7 +1249,7 @@ static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const f
     a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff; a.res_ld = d->res_ld;
     a.relu = d->relu; a.mode = d->mode; a.ks = d->deconv_ks; a.k_pad = d->k_pad;
     a.tiles_m = a.tiles_n = 0;
-    a.korder = d->k_order;
+    a.korder = d->k_order | ((d->tile & SGV3D_TILE_MFIRST) ? 2 : 0);
     {
         const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * ((io & 1) ? 2 : 4), wb = (long long)d->cout_pad * d->k_pad * (io ? 2 : 4);
         SGV3D_REQUIRE(xb < 0xf0000000LL && wb < 0xf0000000LL, "conv2d_forward: input / packed weights larger than 3.75 GiB (32-bit buffer offsets)");
@@ -1277,7 +1297,7 @@ static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const f
         if (!workspace || workspace_bytes < need)
             return fail(SGV3D_ENOSPACE, "conv2d_forward: split-K workspace has %zu bytes, needs %zu", workspace_bytes, need);
     }
-    const int tile = d->tile ? d->tile : pick_tile(M, a.N);
+    const int tile = (d->tile & ~SGV3D_TILE_MFIRST) ? (d->tile & ~SGV3D_TILE_MFIRST) : pick_tile(M, a.N);
     hipStream_t st = as_stream(stream);
     if (io & 2) a.mode |= kConvYBf16 | kConvResBf16;       // (NORMAL / DECONV mode, checked above)
     if (io) {

@@ -89,7 +89,9 @@ def save_tune_db(path=None):
 
 load_tune_db()
 TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: "wino_resident", 7: "patch_bf16", 8: "wino_half",
-              11: "128x128", 12: "128x64", 13: "64x128", 14: "64x64"}     # 11..14: f32x3 of tiles 1..4 (host-side ids)
+              11: "128x128", 12: "128x64", 13: "64x128", 14: "64x64",      # 11..14: f32x3 of tiles 1..4 (host-side ids)
+              21: "128x128", 22: "128x64", 23: "64x128", 24: "64x64"}      # 21..24: tiles 1..4 walked m-tile first (SGV3D_TILE_MFIRST)
+MFIRST = _os.environ.get("SGV3D_MFIRST", "1") != "0"
 TILE_WINO = 5       # host-side algorithm id: sgv3d_conv2d_winograd_forward instead of the implicit GEMM
 TILE_WINO_RES = 6   # = SGV3D_WINOGRAD_RESIDENT: its patch-resident variant (cin <= 96, many cout tiles)
 TILE_PATCH = 7      # bf16 mode: the LDS-resident-patch 3x3 kernel (sgv3d_conv3x3_patch_bf16_forward)
@@ -353,14 +355,14 @@ class PackedConv:
         # ALGORITHMIC flops: real channel counts, not the zero-padded ones the kernel multiplies
         real_n = self.cout_real * (self.ks * self.ks if self.transposed else 1)
         flops = 2.0 * gemm_m * real_n * (self.cin_real * self.kh * self.kw)
-        x3 = t > 10 or (MFMA_F32X3 is True and t < TILE_WINO)
+        x3 = 10 < t < 20 or (MFMA_F32X3 is True and t < TILE_WINO)
         name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) else
                 ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_f32x3_" if x3 else "conv_igemm_")) + TILE_NAMES[t]
         if t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) and self.k_order == 0:
             name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
-                     f"s{self.stride} d{self.dil} splitk{sk}")
+                     f"s{self.stride} d{self.dil} splitk{sk}" + (" mfirst" if 20 < t < 30 else ""))
         if io:
             name = name.replace("conv_igemm_bf16_", "conv_igemm_bf16io_")
         with torch.cuda.device(x.device), prof(name, flops):
@@ -413,16 +415,21 @@ class PackedConv:
             return lib.sgv3d_conv2d_winograd_forward(ctypes.byref(d), x.data_ptr(), self.w_wino.data_ptr(),
                                                      _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
                                                      _lib.ptr(gate), out.data_ptr(), _lib.ptr(ws), nws, _st(x))
+        x3 = 10 < d.tile < 20 or (MFMA_F32X3 is True)
+        host_tile = d.tile
+        if host_tile > 20:
+            d.tile = (host_tile - 20) | 16          # SGV3D_TILE_MFIRST
+        elif host_tile > 10:
+            d.tile = host_tile - 10
         if io:
-            return lib.sgv3d_conv2d_forward_bf16io(ctypes.byref(d), x.data_ptr(), self._bf16_weights().data_ptr(), _lib.ptr(self.scale),
-                                                   _lib.ptr(self.shift), _lib.ptr(residual), _lib.ptr(gate), out.data_ptr(),
-                                                   _lib.ptr(ws), nws, _st(x), int(io))
-        x3 = d.tile > 10 or (MFMA_F32X3 is True)
+            try:
+                return lib.sgv3d_conv2d_forward_bf16io(ctypes.byref(d), x.data_ptr(), self._bf16_weights().data_ptr(), _lib.ptr(self.scale),
+                                                       _lib.ptr(self.shift), _lib.ptr(residual), _lib.ptr(gate), out.data_ptr(),
+                                                       _lib.ptr(ws), nws, _st(x), int(io))
+            finally:
+                d.tile = host_tile
         fwd = (lib.sgv3d_conv2d_forward_bf16 if MFMA_BF16 else
                lib.sgv3d_conv2d_forward_f32x3 if x3 else lib.sgv3d_conv2d_forward)
-        host_tile = d.tile
-        if host_tile > 10:
-            d.tile = host_tile - 10
         try:
             return fwd(ctypes.byref(d), x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.scale),
                        _lib.ptr(self.shift), _lib.ptr(residual), _lib.ptr(gate), out.data_ptr(),
@@ -459,6 +466,8 @@ class PackedConv:
         not depend on the tile shape (every output element sums k in the same order); split-K changes
         the association of the k sum (partials added in fixed order), still deterministic."""
         tiles = (1, 2, 3, 4)
+        if MFIRST and d.mode in (CONV_NORMAL, CONV_NCHW_OUT) and gemm_n > 64:
+            tiles += tuple(t + 20 for t in (1, 2, 3, 4) if gemm_n > (128 if t in (1, 3) else 64))   # more than one channel tile
         if MFMA_F32X3 == "auto" and not MFMA_BF16:
             tiles += (11, 12, 13, 14)
         if self.w_wino is not None and WINOGRAD and not MFMA_BF16:
@@ -472,7 +481,8 @@ class PackedConv:
         if fixed_tile:
             tiles = (fixed_tile,)
         dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 64), 6: (256, 64),
-                11: (128, 128), 12: (128, 64), 13: (64, 128), 14: (64, 64)}
+                11: (128, 128), 12: (128, 64), 13: (64, 128), 14: (64, 64),
+                21: (128, 128), 22: (128, 64), 23: (64, 128), 24: (64, 64)}
         best, best_t = (tiles[0], fixed_split or 1), None
         with torch.cuda.device(x.device):
             for t in tiles:

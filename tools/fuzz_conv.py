@@ -51,14 +51,14 @@ for it in range(N):
         ref = ref * gate.double()[:, None, None, :]
     conv = PackedConv(w.cuda(), stride=stride, pad=pad, dil=dil, scale=None if sc is None else sc.cuda(),
                       shift=None if sh is None else sh.cuda(), relu=use_relu)
-    cands = [(t, s) for t in (1, 2, 3, 4) for s in (1, 2, 3)]
+    cands = [(t, s) for t in (1, 2, 3, 4, 21, 22, 23, 24) for s in (1, 2, 3)]      # 21..24: the same tiles walked m-tile first
     if conv.w_wino is not None and MODE != "bf16":
         cands += [(TILE_WINO, 1), (TILE_WINO, 2), (TILE_WINO, 3), (TILE_WINO_HALF, 1), (TILE_WINO_HALF, 2), (TILE_WINO_HALF, 3)]
         if cin <= 96:
             cands.append((TILE_WINO_RES, 1))
     scale_ref = max(1.0, ref.abs().max().item())
     for t, s in cands:
-        nk = conv.k_pad // 32 if t < TILE_WINO else cin // 8      # (Winograd variants: k-steps of 8 channels)
+        nk = conv.k_pad // 32 if (t < TILE_WINO or t > 20) else cin // 8      # (Winograd variants: k-steps of 8 channels)
         if s > nk:
             continue
         out = torch.full((B, OH, OW, cout + y_extra), -7.0, device="cuda")

@@ -50,7 +50,7 @@ for it in range(N):
         ref = ref.clamp_min(0)
     conv = PackedConv(w.cuda(), stride=stride, pad=pad, dil=dil, scale=None if sc is None else sc.cuda(),
                       shift=None if sh is None else sh.cuda(), relu=use_relu)
-    cands = [(t, s) for t in (1, 2, 3, 4) for s in (1, 2, 3)]
+    cands = [(t, s) for t in (1, 2, 3, 4, 21, 24) for s in (1, 2, 3)]      # 21 / 24: walked m-tile first
     if conv.patch_ok:
         cands += [(TILE_PATCH, s) for s in (1, 2, 3)]
     scale_ref = max(1.0, ref.abs().max().item())
