@@ -420,7 +420,7 @@ def main():
     # flight.  A caller who runs one frame at a time builds its pipeline with one slot and gets its own choices: measured here,
     # last (it drops every packed weight and measurement of the model), so both uses of the library are on the record.
     single_own = None
-    if single is not None and hip_ops.TUNE_STREAMS > 1 and hip_ops.AUTOTUNE and not os.environ.get("SGV3D_TUNE_CACHE"):
+    if single is not None and hip_ops.TUNE_STREAMS > 1 and hip_ops.AUTOTUNE:     # (a tune cache was saved right after the warm-up)
         saved_streams = hip_ops.TUNE_STREAMS
         hip_ops.TUNE_STREAMS = 1
         hip_ops.TUNE_DB.clear()
