@@ -33,6 +33,7 @@ from torch import nn
 
 warnings.filterwarnings("ignore")
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("SGV3D_GOLDEN_OUT", HERE)      # tests/test_golden_regen_cpu.py regenerates into a temp dir
 REF = "/root/reference"
 f32 = np.float32
 
@@ -246,7 +247,7 @@ def main():
         fr_out[name + "/sha256"] = np.frombuffer(bytes.fromhex(sha(fr)), np.uint8)
         fr_out[name + "/cfg"] = np.array([fd[0], fd[1], ds, db[0], db[1], db[2]], np.float64)
         assert np.all(fr[..., 3] == 1)
-    np.savez_compressed(os.path.join(HERE, "frustum.npz"), **fr_out)
+    np.savez_compressed(os.path.join(OUT, "frustum.npz"), **fr_out)
 
     # ---------------- G2/G3: geometry, small exact tensors + full-size hashes -------------------
     geo = {}
@@ -288,7 +289,7 @@ def main():
             geo[f"{name}/{tag}/geom_xyz_sample"] = gi[::7, ::5, ::9].copy()
             print(f"{name:24s} {tag}: in-range {inr.mean():.4f} hit voxels {(cnt > 0).sum()} "
                   f"mean {cnt[cnt > 0].mean():.2f} max {cnt.max()}")
-    np.savez_compressed(os.path.join(HERE, "geometry.npz"), **geo)
+    np.savez_compressed(os.path.join(OUT, "geometry.npz"), **geo)
 
     # ---------------- VP-H/VP-K/VP-B: the reference's autograd wrapper around the literal stub ---
     vp = {}
@@ -322,7 +323,7 @@ def main():
     vp["b2_c80_randn/feats"] = feats.numpy()
     vp["b2_c80_randn/voxel_num"] = vp["b2_c80/voxel_num"]
     vp["b2_c80_randn/out"] = VP.voxel_pooling(geom, feats, torch.tensor([8, 7, 1])).contiguous().numpy()
-    np.savez_compressed(os.path.join(HERE, "voxel_pooling.npz"), **vp)
+    np.savez_compressed(os.path.join(OUT, "voxel_pooling.npz"), **vp)
 
     # ---------------- B3: lift = softmax over D (x) context, lss_fpn.py:462-466,486 --------------
     lift = {}
@@ -334,9 +335,9 @@ def main():
     lift["height_feature"] = height_feature.numpy()
     lift["lifted"] = prod.numpy()
     lift["dims"] = np.array([B, D, C, fH, fW])
-    np.savez_compressed(os.path.join(HERE, "lift.npz"), **lift)
+    np.savez_compressed(os.path.join(OUT, "lift.npz"), **lift)
     for fn in ("frustum.npz", "geometry.npz", "voxel_pooling.npz", "lift.npz"):
-        print(fn, os.path.getsize(os.path.join(HERE, fn)), "bytes")
+        print(fn, os.path.getsize(os.path.join(OUT, fn)), "bytes")
 
 
 # ------------------------------------------------------------------ input contract (dataset helpers)
@@ -396,7 +397,7 @@ def make_input_contract():
     out['bda_identity'] = ds.bev_transform(torch.zeros(0, 9), 0, 1.0, False, False)[1].numpy()
     out['bda_aug_args'] = np.array([22.5, 1.05, 1.0, 0.0])
     out['bda_aug'] = ds.bev_transform(torch.zeros(0, 9), 22.5, 1.05, True, False)[1].numpy()
-    np.savez_compressed(os.path.join(HERE, "input_contract.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "input_contract.npz"), **out)
     print("input_contract.npz:", {k: v.shape for k, v in out.items()})
 
 

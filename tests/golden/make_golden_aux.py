@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("SGV3D_GOLDEN_OUT", HERE)      # tests/test_golden_regen_cpu.py regenerates into a temp dir
 REF = "/root/reference"
 
 
@@ -54,7 +55,7 @@ def make_losses():
         out[name + "_kw"] = np.array(repr(kw))
         # the same inputs in float32 (what the harness feeds), value only
         out[name + "_loss32"] = np.float32(FocalLoss(**kw)(x.detach().float(), y).item())
-    np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
     print("losses.npz:", sorted(k for k in out if k.endswith("_loss")))
 
 
@@ -281,7 +282,7 @@ def make_kitti_eval():
     for k in ('truncated', 'occluded', 'alpha', 'bbox', 'dimensions', 'location', 'rotation_y', 'score'):
         out['reader_' + k] = np.asarray(an[k], np.float64)
     out['reader_name'] = np.array([str(s) for s in an['name']])
-    np.savez_compressed(os.path.join(HERE, "kitti_eval.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "kitti_eval.npz"), **out)
     print("kitti_eval.npz:", result[:400])
 
 
@@ -393,7 +394,7 @@ def make_result2kitti():
         finally:
             os.chdir(cwd)
         out['rope_label_text'] = np.array([open(os.path.join(path, f'{sid:06d}.txt')).read() for sid in sorted(calibs)])
-    np.savez_compressed(os.path.join(HERE, "result2kitti.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "result2kitti.npz"), **out)
     print("result2kitti.npz:", out['label_text'][0][:300])
     print("rope3d:", out['rope_label_text'][0][:300])
 

@@ -196,25 +196,33 @@ def bare_lss(cls, final_dim, downsample, d_bound, xb, yb, zb, out_channels):
     return obj
 
 
-def main():
+def main(out_dir=None):
     L, Bm = import_reference()
     gen = torch.Generator().manual_seed(20261003)
     rn = lambda *s: torch.randn(*s, generator=gen)
     out = {}
+    site = [0]
+
+    def seeded(ctor, *a, **k):
+        """Constructors draw their initial weights from the GLOBAL generator: reseed it per construction site, so the
+        fixture regenerates bit for bit (tests/test_golden_regen_cpu.py)."""
+        site[0] += 1
+        torch.manual_seed(20261007 + 1000 * site[0])
+        return ctor(*a, **k)
     with torch.no_grad():
         # ---------------- ASPP / Mlp / SELayer  (lss_fpn.py:49-159) -------------------------------
-        m = randomize_(L.ASPP(16, 16), gen)
+        m = randomize_(seeded(L.ASPP, 16, 16), gen)
         x = rn(2, 16, 9, 11)
         put(out, "aspp", m, x=x, y=m(x))
-        m = L.Mlp(27, 16, 12).eval()
+        m = seeded(L.Mlp, 27, 16, 12).eval()
         x = rn(3, 27)
         put(out, "mlp", m, x=x, y=m(x))
-        m = L.SELayer(16).eval()
+        m = seeded(L.SELayer, 16).eval()
         x, xs = rn(2, 16, 5, 7), rn(2, 16, 1, 1)
         put(out, "se", m, x=x, x_se=xs, y=m(x, xs))
 
         # ---------------- HeightNet.forward  (lss_fpn.py:207-250), two cameras per sample ----------
-        hn = randomize_(L.HeightNet(24, 16, 8, 6), gen)
+        hn = randomize_(seeded(L.HeightNet, 24, 16, 8, 6), gen)
         mats = make_mats(2, 112 / 1536, num_cams=2)
         seen = {}
         h = hn.bn.register_forward_pre_hook(lambda mod, inp: seen.__setitem__('v', inp[0].clone()))
@@ -228,7 +236,7 @@ def main():
         xb, yb, zb = [0, 25.6, 0.4], [-12.8, 12.8, 0.4], [-5, 3, 8]
         lss = bare_lss(L.LSSFPN, (80, 112), 16, [-2.0, 0.0, 6], xb, yb, zb, 8)
         lss.height_net = hn
-        lss.assist_layer = nn.Conv2d(24, 4, 1)
+        lss.assist_layer = seeded(nn.Conv2d, 24, 4, 1)
         mats = make_mats(2, 112 / 1536)
         feats = rn(2, 1, 1, 24, 5, 7)
         lss.get_cam_feats = lambda imgs: feats
@@ -248,20 +256,20 @@ def main():
         assert 0.3 < inr < 1.0, "fixture must have points inside and outside the grid"
 
         # ---------------- SABlock / TaskHead / TaskFPN  (bsm_lss_fpn.py:151-212) -------------------
-        m = Bm.SABlock(8, 8).eval()
+        m = seeded(Bm.SABlock, 8, 8).eval()
         x, y = rn(2, 8, 6, 5), rn(2, 8, 6, 5)
         put(out, "sablock", m, x=x, y_in=y, y=m(x, y))
-        m = randomize_(Bm.TaskHead(8, 8, 5), gen)
+        m = randomize_(seeded(Bm.TaskHead, 8, 8, 5), gen)
         x = rn(2, 8, 6, 5)
         logits, feat = m(x)
         put(out, "taskhead", m, x=x, logits=logits, feat=feat, logits_only=m(x, return_feat=False))
-        m = Bm.TaskFPN(8, 6).eval()
+        m = seeded(Bm.TaskFPN, 8, 6).eval()
         f0, f1 = rn(2, 8, 5, 7), rn(2, 6, 10, 14)
         put(out, "taskfpn", m, feat0=f0, feat1=f1, y=m(f0, f1))
 
         # ---------------- MSCThead.forward  (bsm_lss_fpn.py:259-320) --------------------------------
-        ms = randomize_(Bm.MSCThead(in_channels=[24, 20], mid_channels=[16, 12], depth_channels=10,
-                                    semantic_channels=7, context_channels=8), gen)
+        ms = randomize_(seeded(Bm.MSCThead, in_channels=[24, 20], mid_channels=[16, 12], depth_channels=10,
+                                   semantic_channels=7, context_channels=8), gen)
         mats = make_mats(2, 112 / 1536)
         x0, x1 = rn(2, 1, 24, 5, 7), rn(2, 1, 20, 10, 14)
         d1, s1, c1, s0 = ms([x0, x1], mats)
@@ -282,10 +290,10 @@ def main():
         assert torch.equal(sem0, s0) and torch.equal(sem1, s1)
         put(out, "bsm_sweep", None, bev=bev, frustum=bsm.frustum, bounds=np.array([xb, yb, zb], np.float64),
             cfg=np.array([80, 112, 8, -2.0, 3.5, 10], np.float64))
-    path = os.path.join(HERE, "modules.npz")
+    path = os.path.join(out_dir or os.environ.get("SGV3D_GOLDEN_OUT", HERE), "modules.npz")
     np.savez_compressed(path, **out)
     print("modules.npz", os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None)
