@@ -25,7 +25,11 @@ Printed by rank 0 as ONE JSON line, with
   voxel-pooling operator single-threaded and with OpenMP (BASELINE.md 3);
 * ``parity``: the outputs of the very model that was timed against that oracle forward on the same
   frame and weights (max |hip - oracle| over all prediction maps, voxel indices bit-exact); the run
-  exits non-zero if the fp32 line is above 1e-3.
+  exits non-zero if the fp32 line is above 1e-3 (bf16 mode: 2e-2 of the output scale);
+* ``fresh_calibration_every_frame``: the same K steps when every frame arrives with NEW calibration tensor
+  objects, as the reference harness does -- geometry kernel + device-side voxel-index compare per frame;
+* ``other_configs`` (default cfg-2 run at N=1 only): BASELINE configs[2] / [4] in bf16 as compact records
+  from child runs of this script (value, conv-family and voxel-pooling fractions, parity).
 """
 import argparse
 import json
@@ -68,6 +72,10 @@ def parse():
                     help="cfg2 (default, the judged workload): R50 BEVHeight; r101: R101 BEVHeight; "
                          "cfg3: R101 1088x1920 -> 512x512 BEV (geometry of BASELINE configs[2]; fp32 here, use --batch 4); "
                          "cfg5: SGV3D BSM R101 (model of BASELINE configs[4], fp32, batch 1)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the compact cfg-3 / cfg-5 bf16 records (other_configs) the default cfg-2 run appends")
+    ap.add_argument("--sub", action="store_true",
+                    help="internal: this is one of the other_configs child runs (prints a compact record)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x3", "f32x3auto"],
                     help="f32 (default; what BASELINE cfg-2, the judged line, asks for) or bf16: convolutions multiply on "
                          "the bf16 matrix cores with f32 accumulation (the compute dtype of BASELINE configs[2] / [4]; "
@@ -126,7 +134,41 @@ def load_traffic(tile_name):
         rec = None
     if not rec:
         return None, None
-    return rec["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT) + ":" + sym
+    full = next((k for k in table if k == sym or k == sym + ">" or k.startswith(sym)), sym)     # the table's own (complete) symbol
+    return rec["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT) + ":" + full
+
+
+def run_other_configs(args, budget_s=120.0):
+    """cfg-3 (R101 1088x1920 -> 512x512 BEV, batch 4) and cfg-5 (SGV3D BSM R101, batch 1) in bf16 -- the dtype BASELINE
+    configs[2] / [4] name -- as child runs of this script: value, ms, conv-family fraction of the bf16 MFMA peak, voxel
+    pooling against HBM peak and the parity of the timed model against the oracle (2e-2 of the output scale).  One GPU
+    process at a time; the children reuse the committed tune DB (tune/), so they spend no time on candidate timing."""
+    import subprocess
+    out, t_start = [], time.perf_counter()
+    for cfg, batch in (("cfg3", 4), ("cfg5", 1)):
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 20.0:
+            out.append({"config": cfg, "skipped": f"other_configs budget of {budget_s:.0f} s spent"})
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--sub", "--config", cfg, "--batch", str(batch), "--dtype", "bf16",
+               "--steps", "10", "--warmup", "2", "--streams", str(args.streams), "--no-plan-timing"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left + 30.0)
+            rec = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:          # a failed child is reported, never silently dropped
+            out.append({"config": cfg, "error": repr(e)[:300]})
+            continue
+        rf, rh, par = rec.get("roofline") or {}, rec.get("roofline_hbm") or {}, rec.get("parity") or {}
+        out.append({"config": cfg, "dtype": "bf16", "batch_per_gpu": batch, "workload": rec["config"]["workload"],
+                    "value": rec["value"], "unit": "frames/s", "ms_per_step": rec["ms_per_step"], "steps": rec["steps"],
+                    "frames_in_flight": rec["config"]["frames_in_flight"],
+                    "conv_family_frac": (rf.get("conv_family") or {}).get("frac"), "dominant_kernel": rf.get("kernel"),
+                    "dominant_kernel_frac": rf.get("frac"), "roofline_hbm_frac": rh.get("frac"),
+                    "parity": {k: par.get(k) for k in ("max_abs_err", "max_abs_ref", "rel_err", "tolerance",
+                                                       "voxel_indices_equal", "ok")},
+                    "exit_code": r.returncode, "wall_s": time.perf_counter() - t0})
+    return out
 
 
 def main():
@@ -157,7 +199,9 @@ def main():
     bc, hc = {"cfg2": S.r50_256_conf, "r101": S.r101_256_conf, "cfg3": S.r101_512_conf,
               "cfg5": S.bsm_r101_256_conf}[args.config]()
     workload = {"cfg2": "BASELINE cfg-2: ResNet-50 864x1536 -> 256x256 BEV, fp32, full BEVHeight forward "
-                        "(backbone+neck+HeightNet+lift+geometry+voxel_pooling+head)",
+                        "(backbone+neck+HeightNet+lift+voxel_pooling+head; geometry + voxel plan cached per calibration: "
+                        "computed once outside the timed region, see fresh_calibration_every_frame_value for the "
+                        "reference harness's call pattern)",
                 "r101": "ResNet-101 864x1536 -> 256x256 BEV, fp32, full BEVHeight forward",
                 "cfg3": "ResNet-101 1088x1920 (1080 padded) -> 512x512 BEV, fp32 (BASELINE configs[2] asks bf16), "
                         "full BEVHeight forward",
@@ -217,7 +261,7 @@ def main():
     elapsed = timed_local(run, args.steps)          # barrier+sync | K steps | barrier+sync, MAX over ranks
     value = group.aggregate_throughput(B, args.steps, elapsed)
     single = None
-    if nstreams > 1 and rank == 0 and world == 1:   # same K steps with one frame in flight, for reference
+    if nstreams > 1 and rank == 0 and world == 1 and not args.sub:   # same K steps with one frame in flight, for reference
         one = FramePipeline(model, imgs, mats, slots=1, use_graph=use_graph)
         for _ in range(args.warmup):
             one.submit(imgs, mats)
@@ -228,6 +272,27 @@ def main():
     calib = {"plan_builds_before_timed_region": counters0[2],
              "plan_builds_in_timed_region": sum(c.plan.builds() for c in pipe.caches if c.plan is not None) - counters0[2],
              "geometry_launches_in_timed_region": sum(c.refreshes for c in pipe.caches) - counters0[1]}
+    # ---- the reference harness's call pattern: FRESH calibration tensors with every frame ------------------------
+    # exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:244-247 makes new `mats[k].cuda()` tensors every step, so
+    # the host fast path of the calibration cache never fires: every submit copies the seven tensors into the slot, re-runs
+    # calib_prep + the geometry kernel and the device-side compare of the voxel indices (the plan itself is rebuilt only when
+    # the indices really changed).  Same K steps, same pipeline; a ring of distinct tensor objects with the same content.
+    fresh = None
+    if rank == 0 and world == 1 and not args.sub:
+        ring = [{k: v.clone() for k, v in mats.items()} for _ in range(2 * nstreams + 1)]
+        ctr = [0]
+
+        def run_fresh():
+            ctr[0] += 1
+            return pipe.submit(imgs, ring[ctr[0] % len(ring)])
+        for _ in range(args.warmup * nstreams):
+            run_fresh()
+        c1 = (sum(c.refreshes for c in pipe.caches), sum(c.plan.builds() for c in pipe.caches if c.plan is not None))
+        tf = group.timed(run_fresh, args.steps)
+        fresh = {"value": B * args.steps / tf, "ms_per_step": tf / args.steps * 1e3,
+                 "geometry_launches_in_timed_region": sum(c.refreshes for c in pipe.caches) - c1[0],
+                 "plan_builds_in_timed_region": sum(c.plan.builds() for c in pipe.caches if c.plan is not None) - c1[1]}
+        del ring
     per_rank = group.all_gather_object({"rank": rank, "frames_per_s": B * args.steps / elapsed_local[0],
                                         "device": torch.cuda.get_device_name(dev)})
 
@@ -355,7 +420,7 @@ def main():
         ref = TM.bevheight_forward(sd, bc, hc, cimgs, cmats, keep)          # warm-up frame; also the parity reference
         warm = time.perf_counter() - t0
         times = []
-        while len(times) < 3 and sum(times) + warm < 22.0:
+        while len(times) < 3 and sum(times) + warm < 22.0 and not args.sub:      # (child runs: the one frame parity needs)
             t1 = time.perf_counter()
             TM.bevheight_forward(sd, bc, hc, cimgs, cmats)
             times.append(time.perf_counter() - t1)
@@ -399,7 +464,9 @@ def main():
                 nmaps += 1
                 if e > worst:
                     worst, worst_name = e, f"task{t}.{k}"
-        tol = 1e-3 if args.dtype in ("f32", "f32x3", "f32x3auto") else 1e-1
+        # fp32: the literal 1e-3 of north_star; bf16 mode: the full-size tests' bar, 2e-2 of the output scale
+        # (tests/test_fullsize_gpu.py BF16_TOL; measured 6e-3..7e-3) -- not an absolute figure a 5x regression would pass
+        tol = 1e-3 if args.dtype in ("f32", "f32x3", "f32x3auto") else 2e-2 * max(1.0, scale)
         # yardstick: the same forward in float64 (torch on the GPU, a checker): how far is EACH float32 execution from
         # exact arithmetic?  Two float32 implementations differ by their summed rounding noise; the HIP path has to be
         # as close to the float64 result as the reference-style torch-CPU float32 execution is.
@@ -414,6 +481,27 @@ def main():
                                         "what": "max |x - float64 forward| over the 36 maps for x = HIP output / torch-CPU fp32 oracle"},
                   "ok": bool(worst <= tol)}
         parity["ok"] = parity["ok"] and parity["voxel_indices_equal"]
+        parity["rel_err"] = worst / max(scale, 1e-30)
+        # The figures above hold for THESE weights (last BatchNorm of every residual block at gamma x 0.3, activations
+        # O(1-10)).  With gamma ~ 1 (untrained statistics, activations ~1e2) two float32 executions of the network differ
+        # by more than 1e-3 ABSOLUTE while their RELATIVE distance stays ~1e-5: reported here so that nobody reads the
+        # absolute figure as a property of arbitrary checkpoints ("float32 noise and the 1e-3 bar").
+        if args.dtype == "f32" and not args.sub:
+            torch.manual_seed(0)
+            m1 = BEVHeight(bc, hc).eval()
+            S.randomize_norm_stats_(m1, 0)                       # residual_gamma = 1
+            sd1 = {k: v.detach().cpu() for k, v in m1.state_dict().items()}
+            ref1 = TM.bevheight_forward(sd1, bc, hc, cimgs, cmats)
+            m1 = m1.to(dev)
+            with torch.no_grad():
+                got1 = m1(imgs[:1], {k: v[:1] for k, v in mats.items()})
+            torch.cuda.synchronize()
+            e1 = max(float((got1[t][0][k].float().cpu() - ref1[t][0][k]).abs().max()) for t in range(len(ref1)) for k in ref1[t][0])
+            s1 = max(float(ref1[t][0][k].abs().max()) for t in range(len(ref1)) for k in ref1[t][0])
+            parity["gamma1_weights"] = {"max_abs_err": e1, "max_abs_ref": s1, "rel_err": e1 / max(s1, 1e-30),
+                                        "what": "same check with the residual-block BatchNorm gamma left at ~1 (activations ~1e2): "
+                                                "not gated, float32 noise of both executions (DESIGN.md section 4)"}
+            del m1, got1, ref1, sd1
 
     # ---- one frame in flight with the kernels chosen FOR one frame in flight ---------------------------------------
     # `single` above replays one frame at a time with the tiles / Winograd variants that were picked for `nstreams` frames in
@@ -432,6 +520,12 @@ def main():
         single_own = {"value": B * args.steps / t1, "ms_per_step": t1 / args.steps * 1e3}
         del one
         hip_ops.TUNE_STREAMS = saved_streams
+
+    # ---- BASELINE configs[2] / [4] in their own dtype, as compact records (child runs of this script) ---------------
+    other_configs = None
+    if rank == 0 and world == 1 and args.config == "cfg2" and args.dtype == "f32" and not args.sub and not args.no_other_configs \
+            and not args.no_cpu_baseline:
+        other_configs = run_other_configs(args)
 
     if rank == 0:
         line = {
@@ -456,8 +550,14 @@ def main():
             "one_frame_in_flight_ms_per_step": single["ms_per_step"] if single else None,
             "one_frame_in_flight_own_tiles_value": single_own["value"] if single_own else None,
             "one_frame_in_flight_own_tiles_ms_per_step": single_own["ms_per_step"] if single_own else None,
+            "fresh_calibration_every_frame_value": fresh["value"] if fresh else None,
+            "fresh_calibration_every_frame": fresh,
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "parity": parity,
+            "other_configs": other_configs,
         }
+    # rank 0 has been busy alone since the last collective (roofline pass, CPU baseline): every rank waits here, so that
+    # no rank tears RCCL down while another one is still inside the job
+    group.barrier()
     group.close()
     if rank == 0:
         import ctypes
@@ -465,6 +565,10 @@ def main():
         ctypes.CDLL(None).fflush(None)        # C stdio buffers (the RCCL banner) go to stderr, not after our line
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        bad = [o for o in (other_configs or []) if o.get("exit_code") or ("parity" in o and o["parity"].get("ok") is False)]
+        if bad:
+            print(f"[bench] PARITY FAILURE in other_configs: {bad}", file=sys.stderr)
+            sys.exit(3)
         if parity is not None and not parity["ok"]:
             print(f"[bench] PARITY FAILURE: max |hip - oracle| = {parity['max_abs_err']:.3e} on {parity['worst_map']} "
                   f"(tolerance {parity['tolerance']}), voxel indices equal: {parity['voxel_indices_equal']}", file=sys.stderr)

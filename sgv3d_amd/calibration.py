@@ -21,25 +21,86 @@ are only ever written by torch ops here (``copy_``), which do.
 
 
 class CalibrationCache:
+    """One entry per sweep index (multi-sweep inputs carry one calibration per sweep; with a single slot consecutive
+    sweeps would evict each other and every sweep would pay the geometry kernel + plan rebuild on every frame).
+    ``geom`` / ``plan`` / ``matches`` / ``remember`` of the cache itself are those of sweep 0, the key frame.
+
+    Stream safety: an entry records the stream it was (re)built on and an event behind the last build kernel.  A host
+    fast-path hit on ANOTHER stream makes that stream wait for the event before it reads ``geom`` / ``plan.buf`` (the
+    caller cannot know that a hidden plan build is still in flight on the first stream).  ``invalidate()`` is for callers
+    that rewrite the calibration tensors out of band (raw pointers, ``.data``): tensor versions do not see such writes."""
+
+    class Entry:
+        __slots__ = ("_src", "_tag", "geom", "plan", "event", "stream")
+
+        def __init__(self):
+            self._src = None          # [(tensor, version)] the cached geometry was computed from
+            self._tag = None          # (sweep index, shapes ...) part of the key that is not a tensor
+            self.geom = None          # int32 [B, num_cams, D, fH, fW, 3]
+            self.plan = None          # VoxelPlan(cached=True) for geom
+            self.event = None         # recorded behind the last (re)build
+            self.stream = None        # cuda_stream handle of that build
+
+        def matches(self, tensors, tag):
+            if self._src is None or self._tag != tag or len(tensors) != len(self._src):
+                return False
+            for t, (old, ver) in zip(tensors, self._src):
+                if t is not old or (t is not None and t._version != ver):
+                    return False
+            return True
+
+        def remember(self, tensors, tag):
+            self._src = [(t, None if t is None else t._version) for t in tensors]
+            self._tag = tag
+
+        def mark_built(self, device):
+            """Call right after enqueueing the geometry / plan kernels on the current stream."""
+            import torch
+            cur = torch.cuda.current_stream(device)
+            if torch.cuda.is_current_stream_capturing():
+                return                # inside a capture the graph's own edges order the kernels
+            if self.event is None:
+                self.event = torch.cuda.Event()
+            self.event.record(cur)
+            self.stream = cur.cuda_stream
+
+        def order_after_build(self, device):
+            """Host-path hit: make the current stream wait for the build if it ran on another stream."""
+            import torch
+            if self.event is None or torch.cuda.is_current_stream_capturing():
+                return
+            cur = torch.cuda.current_stream(device)
+            if cur.cuda_stream != self.stream:
+                cur.wait_event(self.event)
+
     def __init__(self):
-        self._src = None          # [(tensor, version)] the cached geometry was computed from
-        self._tag = None          # (sweep index, shapes ...) part of the key that is not a tensor
-        self.geom = None          # int32 [B, num_cams, D, fH, fW, 3]
-        self.plan = None          # VoxelPlan(cached=True) for geom
+        self._entries = {0: CalibrationCache.Entry()}
         self.hits = 0             # forwards that launched neither geometry nor plan kernels
         self.refreshes = 0        # forwards that re-ran the geometry kernel (+ device-side plan check)
 
+    def entry(self, sweep_index=0):
+        e = self._entries.get(int(sweep_index))
+        if e is None:
+            e = self._entries[int(sweep_index)] = CalibrationCache.Entry()
+        return e
+
+    # sweep 0 (the key frame) through the cache object itself
+    @property
+    def geom(self):
+        return self._entries[0].geom
+
+    @property
+    def plan(self):
+        return self._entries[0].plan
+
     def matches(self, tensors, tag):
-        if self._src is None or self._tag != tag or len(tensors) != len(self._src):
-            return False
-        for t, (old, ver) in zip(tensors, self._src):
-            if t is not old or (t is not None and t._version != ver):
-                return False
-        return True
+        return self._entries[0].matches(tensors, tag)
 
     def remember(self, tensors, tag):
-        self._src = [(t, None if t is None else t._version) for t in tensors]
-        self._tag = tag
+        self._entries[0].remember(tensors, tag)
 
     def invalidate(self):
-        self._src = None
+        """Forget what the cached geometry was computed from (every sweep): the next forward re-runs the geometry kernel
+        and the device-side plan check.  Needed after writing calibration tensors through raw pointers / ``.data``."""
+        for e in self._entries.values():
+            e._src = None

@@ -349,7 +349,7 @@ class PackedConv:
                     self._tile_cache[key] = choice
                     TUNE_DB[sig] = choice
                 else:
-                    choice = self._rule(t, sk, d, gemm_m, gemm_n)
+                    choice = self._rule(t, sk, d, gemm_m, gemm_n, gate)
             t, sk = choice
         d.tile, d.split_k = t, sk
         # ALGORITHMIC flops: real channel counts, not the zero-padded ones the kernel multiplies
@@ -370,7 +370,7 @@ class PackedConv:
         _lib.check(rc, "sgv3d_conv2d_forward")
         return out
 
-    def _rule(self, t, sk, d, gemm_m, gemm_n):
+    def _rule(self, t, sk, d, gemm_m, gemm_n, gate=None):
         """Deterministic choice without measurement: Winograd for the layers it covers once the map has
         enough tiles to occupy the chip (split over channel steps to reach ~2 workgroups per CU), else the
         implicit-GEMM tile of the cost model; explicit tile / split arguments win."""
@@ -382,7 +382,7 @@ class PackedConv:
                     if wgs * cand <= 512 and self.cin // 8 // cand >= 4:
                         split = cand
             return TILE_WINO, sk or split
-        if t == 0 and self._patch_eligible(d) and d.out_h * d.out_w * d.batch >= 4096:
+        if t == 0 and self._patch_eligible(d, gate) and d.out_h * d.out_w * d.batch >= 4096:
             wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 32) * -(-gemm_n // 64)
             split = 1
             if not sk and SPLIT_K:

@@ -358,17 +358,21 @@ class LSSFPN(HipModule):
         plan is rebuilt only if the indices actually changed (decided on the device, no host sync)."""
         names = ('sensor2ego_mats', 'sensor2virtual_mats', 'intrin_mats', 'ida_mats', 'reference_heights')
         srcs = [mats_dict[k] for k in names] + [mats_dict.get('bda_mat', None)]
-        cc = self.calib_cache
+        cache = self.calib_cache
+        cc = cache.entry(sweep_index)
         s2e = mats_dict['sensor2ego_mats']
         D, fH, fW, _ = (int(v) for v in self.frustum.shape)
         tag = (int(sweep_index), tuple(s2e.shape), str(s2e.device), self.frustum.data_ptr(), self.frustum._version,
                self._voxel_num_host)
         if cc.geom is not None and cc.matches(srcs, tag):
-            cc.hits += 1
+            cache.hits += 1
+            cc.order_after_build(s2e.device)       # a hit on another stream than the build's waits for the build
             return cc.geom, cc.plan
         B, num_cams = int(s2e.shape[0]), int(s2e.shape[2])
         shape = (B, num_cams, D, fH, fW, 3)
         reuse = cc.geom is not None and tuple(cc.geom.shape) == shape and cc.geom.device == s2e.device
+        if reuse:
+            cc.order_after_build(s2e.device)       # the buffers are rewritten in place: after their last builder
         geom = self.get_geometry_voxel_index(
             mats_dict['sensor2ego_mats'][:, sweep_index, ...],
             mats_dict['sensor2virtual_mats'][:, sweep_index, ...],
@@ -383,7 +387,8 @@ class LSSFPN(HipModule):
             cc.plan = VoxelPlan(flat, self._voxel_num_host, cached=True)
         cc.geom = geom
         cc.remember(srcs, tag)
-        cc.refreshes += 1
+        cc.mark_built(s2e.device)
+        cache.refreshes += 1
         return geom, cc.plan
 
     # -------------------------------------------------------------------------------- features
@@ -449,5 +454,5 @@ def _require_hip_inference(module, x):
         raise RuntimeError("sgv3d_amd runs on the MI355X only: got a CPU tensor and there is no CPU fallback "
                            "(the CPU restatement lives in oracle/ and is test infrastructure)")
     if module.training:
-        raise NotImplementedError("the HIP path implements the inference forward (call model.eval()); the "
-                                  "training step is SURVEY.md §8(f) rank 2 and is not built yet")
+        raise NotImplementedError("this entry point is the inference forward (call model.eval()); a module in training mode "
+                                  "goes through sgv3d_amd/train_forward.py, which BEVHeight.forward dispatches to")

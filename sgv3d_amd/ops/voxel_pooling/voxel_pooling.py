@@ -210,7 +210,9 @@ class VoxelPooling(Function):
                                                      output_features.data_ptr(), _lib.ptr(pos_memo),
                                                      _lib.stream_handle(input_features.device))
             _lib.check(rc, "sgv3d_voxel_pooling_forward")
-        elif needs_grad or not CACHE_PLANS:
+        elif needs_grad or not CACHE_PLANS or geom_xyz.data_ptr() % 16 != 0:
+            # (the cached build compares geom_xyz with 16-byte loads: a contiguous slice such as geom[1:] whose storage
+            # offset is not a multiple of 16 bytes -- accepted by the reference extension -- takes the uncached build)
             plan = VoxelPlan(geom_xyz, (X, Y, Z), pos_memo=pos_memo)
             output_features = plan.pool(input_features)
         else:

@@ -96,7 +96,7 @@ class DataParallelAdamW:
         self.state = [(torch.zeros_like(p), torch.zeros_like(p)) for p, _, _ in self.flat.buckets]
         self.steps = 0
         self._pending = []
-        if self._world() > 1:
+        if self._collectives():
             self.broadcast_parameters()
 
     def broadcast_parameters(self, src=0):
@@ -109,7 +109,7 @@ class DataParallelAdamW:
         """Raise if the parameters differ between ranks (sum and sum of squares of every bucket, compared through one
         MIN and one MAX all-reduce).  Cheap enough to call every few hundred steps."""
         import torch.distributed as dist
-        if self._world() == 1:
+        if not self._collectives():
             return
         sums = torch.stack([torch.stack([p.double().sum(), (p.double() ** 2).sum()]) for p, _, _ in self.flat.buckets])
         lo, hi = sums.clone(), sums.clone()
@@ -124,27 +124,58 @@ class DataParallelAdamW:
             return dist.get_world_size(self.group)
         return 1
 
+    def _collectives(self):
+        """True when the step talks to the process group: more than one rank, or a 1-rank group with
+        SGV3D_FORCE_DIST=1 (runs broadcast / all-reduce through RCCL on a single-GPU box: the stand-in for BASELINE
+        configs[3], whose 8-GPU node only the driver has)."""
+        import os
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(self.group) > 1 or bool(os.environ.get("SGV3D_FORCE_DIST"))
+
     def zero_grad(self):
         self.flat.zero_grad()
+        if hasattr(self, '_left') and not self._pending:
+            self._arm()
 
     def overlap_with_backward(self):
         """Launch a bucket's all-reduce from inside backward, as soon as the last of its parameters has accumulated its
         gradient (post-accumulate-grad hooks; buckets are filled in backward order, so the first collectives run under
         the rest of the backward pass like DDP's).  A bucket holding a parameter that receives no gradient in a step
-        never completes; ``all_reduce_grads`` / ``step`` launch whatever is still missing."""
-        self._early = {}
-        self._left = [len(entries) for _, _, entries in self.flat.buckets]
+        never completes; ``all_reduce_grads`` / ``step`` launch whatever is still missing.
+
+        Contract: ONE backward per optimiser step.  The per-bucket counters are re-armed by ``zero_grad`` /
+        ``all_reduce_grads`` / ``step``; a second backward before the step (gradient accumulation) would add local
+        gradients on top of an already reduced bucket, so it raises instead.  Early collectives are launched in
+        bucket order only (bucket i after bucket i-1): every rank issues the same sequence of collectives even if the
+        set of parameters that receive a gradient differs between ranks (a bucket that completes out of order waits
+        for ``all_reduce_grads``)."""
         self._hooks = []
+        self._arm()
         for bi, (_, _, entries) in enumerate(self.flat.buckets):
             for p, _, _ in entries:
                 self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, bi=bi: self._on_grad(bi)))
         return self
 
+    def _arm(self):
+        self._early = {}
+        self._left = [len(entries) for _, _, entries in self.flat.buckets]
+        self._next_early = 0
+
     def _on_grad(self, bi):
         import torch.distributed as dist
         self._left[bi] -= 1
-        if self._left[bi] == 0 and self._world() > 1 and bi not in self._early:
-            self._early[bi] = dist.all_reduce(self.flat.buckets[bi][1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self._left[bi] < 0:
+            raise _lib.SGV3DError("overlap_with_backward: a second backward ran before step(); the bucket all-reduces of "
+                                  "the first one are already in flight (accumulate micro-batches without the overlap, or "
+                                  "call step() / zero_grad() between backwards)")
+        if self._collectives():
+            # fixed order: launch every complete bucket from the front of the queue
+            while self._next_early < len(self._left) and self._left[self._next_early] == 0:
+                i = self._next_early
+                self._early[i] = dist.all_reduce(self.flat.buckets[i][1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._next_early += 1
 
     def all_reduce_grads(self):
         """Start the sum all-reduce of every bucket that is not already in flight (asynchronous; ``step`` waits per
@@ -152,20 +183,19 @@ class DataParallelAdamW:
         import torch.distributed as dist
         self._pending = []
         early = getattr(self, '_early', {})
-        if self._world() > 1:
+        if self._collectives():
             for bi, (_, g, _) in enumerate(self.flat.buckets):
                 self._pending.append(early[bi] if bi in early else
                                      dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         if hasattr(self, '_left'):
-            self._early = {}
-            self._left = [len(entries) for _, _, entries in self.flat.buckets]
+            self._arm()
 
     def step(self, lr=None):
         """One AdamW update of every bucket with the averaged gradients (call ``all_reduce_grads`` first when the
         process group has more than one rank)."""
         lr = self.lr if lr is None else float(lr)
         world = self._world()
-        if world > 1 and not self._pending:
+        if self._collectives() and not self._pending:
             self.all_reduce_grads()
         self.flat.check_views()
         self.steps += 1
