@@ -184,13 +184,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
+    # SGV3D_BENCH_STUB=1 (tests/test_multigpu_cpu.py only): a CPU rehearsal of THIS script's multi-rank protocol -- process
+    # group, barriers, MAX over ranks, gather of the per-rank records, final barrier, one JSON line from rank 0 -- with the
+    # model replaced by a sleep.  It measures nothing and says so in the line ("data": "stub").
+    stub = bool(os.environ.get("SGV3D_BENCH_STUB"))
+    if stub:
+        args.no_roofline = args.no_cpu_baseline = True
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if not stub:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
     from sgv3d_amd import hip_ops, synthetic as S
     from sgv3d_amd.replicas import ReplicaGroup
-    group = ReplicaGroup(backend="nccl" if (world > 1 or os.environ.get("SGV3D_FORCE_DIST")) else None, device=dev)   # nccl == RCCL on ROCm
+    group = ReplicaGroup(backend=("gloo" if stub else "nccl") if (world > 1 or os.environ.get("SGV3D_FORCE_DIST")) else None,
+                         device=None if stub else dev)                              # nccl == RCCL on ROCm
     from sgv3d_amd.models.bev_height import BEVHeight
     hip_ops.MFMA_BF16 = args.dtype == "bf16"
     hip_ops.MFMA_F32X3 = True if args.dtype == "f32x3" else ("auto" if args.dtype == "f32x3auto" else False)
@@ -215,40 +223,52 @@ def main():
         workload = workload.replace("fp32 (BASELINE configs[2] asks bf16)", "fp32").replace(
             "fp32", "bf16 MFMA operands / f32 accumulation, bf16 activations in HBM inside the conv chains "
                     "(height / depth logits, context, lifted features, BEV map and predictions f32)")
-    torch.manual_seed(0)
-    model = BEVHeight(bc, hc).eval()
-    S.randomize_norm_stats_(model, 0, residual_gamma=0.3)    # small last-BN gamma per residual block, as mmdet initialises
-    model = model.to(dev)
-    model.backbone.fuse_lift_splat = bool(args.fuse_lift_splat)
     B = args.batch
-    imgs = S.make_images(B, bc['final_dim'], device=dev, seed=rank)
-    mats = S.make_mats(B, device=dev)
+    nstreams = max(1, args.streams)
+    if stub:
+        class _StubPipe:
+            caches, use_graph = [], False
+
+            def submit(self, imgs, mats):
+                time.sleep(0.002 * (1 + rank))           # rank-dependent: the MAX over ranks has to pick the slowest rank
+        model = imgs = mats = None
+        pipe, use_graph = _StubPipe(), False
+        workload = "STUB (SGV3D_BENCH_STUB=1): control-flow rehearsal on the CPU, no model -- not a measurement"
+    else:
+        torch.manual_seed(0)
+        model = BEVHeight(bc, hc).eval()
+        S.randomize_norm_stats_(model, 0, residual_gamma=0.3)    # small last-BN gamma per residual block, as mmdet initialises
+        model = model.to(dev)
+        model.backbone.fuse_lift_splat = bool(args.fuse_lift_splat)
+        imgs = S.make_images(B, bc['final_dim'], device=dev, seed=rank)
+        mats = S.make_mats(B, device=dev)
 
     def step():
         with torch.no_grad():
             return model(imgs, mats)
 
-    # ---- warm-up: packs weights, tunes tiles, fills the caching allocator ---------------------
-    # (the per-layer candidates are timed as the pipeline will run them: args.streams concurrent copies -- FramePipeline does
-    # the same when it sees the first forward; here that forward happens before the pipeline exists)
-    if "SGV3D_TUNE_STREAMS" not in os.environ and args.streams > 1:
-        hip_ops.TUNE_STREAMS = max(hip_ops.TUNE_STREAMS, args.streams)
-    for _ in range(max(1, args.warmup)):
-        out = step()
-    torch.cuda.synchronize()
-    hip_ops.save_tune_db()          # no-op unless SGV3D_TUNE_CACHE is set (tools/profile_round.sh)
+    if not stub:
+        # ---- warm-up: packs weights, tunes tiles, fills the caching allocator ---------------------
+        # (the per-layer candidates are timed as the pipeline will run them: args.streams concurrent copies -- FramePipeline
+        # does the same when it sees the first forward; here that forward happens before the pipeline exists)
+        if "SGV3D_TUNE_STREAMS" not in os.environ and args.streams > 1:
+            hip_ops.TUNE_STREAMS = max(hip_ops.TUNE_STREAMS, args.streams)
+        for _ in range(max(1, args.warmup)):
+            out = step()
+        torch.cuda.synchronize()
+        hip_ops.save_tune_db()          # no-op unless SGV3D_TUNE_CACHE is set (tools/profile_round.sh)
 
-    # ---- hipGraph capture: one graph + activation pool per frame in flight (sgv3d_amd/pipeline.py) ----
-    from sgv3d_amd.pipeline import FramePipeline
-    nstreams = max(1, args.streams)
-    pipe = FramePipeline(model, imgs, mats, slots=nstreams, use_graph=not args.no_graph)
-    use_graph = pipe.use_graph
-    if not use_graph and not args.no_graph and rank == 0:
-        print("[bench] hipGraph capture failed; running eager launches on the slot streams", file=sys.stderr)
+        # ---- hipGraph capture: one graph + activation pool per frame in flight (sgv3d_amd/pipeline.py) ----
+        from sgv3d_amd.pipeline import FramePipeline
+        pipe = FramePipeline(model, imgs, mats, slots=nstreams, use_graph=not args.no_graph)
+        use_graph = pipe.use_graph
+        if not use_graph and not args.no_graph and rank == 0:
+            print("[bench] hipGraph capture failed; running eager launches on the slot streams", file=sys.stderr)
     run = lambda: pipe.submit(imgs, mats)       # the product call: resident frame -> slot's static inputs -> graph replay
     for _ in range(args.warmup * nstreams):
         run()
-    torch.cuda.synchronize()
+    if not stub:
+        torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps ------------------------------------------------------------
     elapsed_local = [0.0]
@@ -261,7 +281,7 @@ def main():
     elapsed = timed_local(run, args.steps)          # barrier+sync | K steps | barrier+sync, MAX over ranks
     value = group.aggregate_throughput(B, args.steps, elapsed)
     single = None
-    if nstreams > 1 and rank == 0 and world == 1 and not args.sub:   # same K steps with one frame in flight, for reference
+    if nstreams > 1 and rank == 0 and world == 1 and not args.sub and not stub:   # same K steps with one frame in flight, for reference
         one = FramePipeline(model, imgs, mats, slots=1, use_graph=use_graph)
         for _ in range(args.warmup):
             one.submit(imgs, mats)
@@ -278,7 +298,7 @@ def main():
     # calib_prep + the geometry kernel and the device-side compare of the voxel indices (the plan itself is rebuilt only when
     # the indices really changed).  Same K steps, same pipeline; a ring of distinct tensor objects with the same content.
     fresh = None
-    if rank == 0 and world == 1 and not args.sub:
+    if rank == 0 and world == 1 and not args.sub and not stub:
         ring = [{k: v.clone() for k, v in mats.items()} for _ in range(2 * nstreams + 1)]
         ctr = [0]
 
@@ -294,7 +314,7 @@ def main():
                  "plan_builds_in_timed_region": sum(c.plan.builds() for c in pipe.caches if c.plan is not None) - c1[1]}
         del ring
     per_rank = group.all_gather_object({"rank": rank, "frames_per_s": B * args.steps / elapsed_local[0],
-                                        "device": torch.cuda.get_device_name(dev)})
+                                        "device": "cpu (stub)" if stub else torch.cuda.get_device_name(dev)})
 
     # ---- roofline: instrumented pass, HIP events around every conv launch -------------------------
     roofline = None
@@ -510,8 +530,7 @@ def main():
     single_own = None
     if single is not None and hip_ops.TUNE_STREAMS > 1 and hip_ops.AUTOTUNE:     # (a tune cache was saved right after the warm-up)
         saved_streams = hip_ops.TUNE_STREAMS
-        hip_ops.TUNE_STREAMS = 1
-        hip_ops.TUNE_DB.clear()
+        hip_ops.TUNE_STREAMS = 1             # (layer signatures carry the load they were measured under: "|ts1")
         model.refresh()                      # drops the packed weights and with them every layer's cached choice
         one = FramePipeline(model, imgs, mats, slots=1, use_graph=use_graph)     # its first forward re-measures, alone
         for _ in range(args.warmup):
@@ -520,6 +539,7 @@ def main():
         single_own = {"value": B * args.steps / t1, "ms_per_step": t1 / args.steps * 1e3}
         del one
         hip_ops.TUNE_STREAMS = saved_streams
+        hip_ops.save_tune_db()               # (SGV3D_TUNE_CACHE only) now also holds the one-frame-in-flight choices
 
     # ---- BASELINE configs[2] / [4] in their own dtype, as compact records (child runs of this script) ---------------
     other_configs = None
@@ -532,7 +552,7 @@ def main():
             "metric": "camera frames/sec at 864x1536->BEV",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "stub" if stub else "synthetic",
             "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world}",
                        "hip_graph": bool(use_graph), "frames_in_flight": nstreams,

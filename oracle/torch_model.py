@@ -201,13 +201,20 @@ def geometry_indices(sd, mats, sweep=0):
     return out
 
 
-def lss_fpn_forward(sd, conf, imgs, mats, keep=None, cam_feats=None):
+def lss_fpn_forward_sweeps(sd, conf, imgs, mats):
+    """LSSFPN.forward with num_sweeps > 1 (lss_fpn.py:535-550): every sweep through _forward_single_sweep with its own
+    images and its own geometry (mats[:, sweep_index]); HeightNet reads the KEY frame's intrinsics / ida / sensor2ego for
+    every sweep (its forward indexes ``[:, 0:1]``, lss_fpn.py:208-212); BEV maps concatenated on the channel axis."""
+    return torch.cat([lss_fpn_forward(sd, conf, imgs, mats, sweep=s) for s in range(imgs.shape[1])], 1)
+
+
+def lss_fpn_forward(sd, conf, imgs, mats, keep=None, cam_feats=None, sweep=0):
     """LSSFPN._forward_single_sweep (lss_fpn.py:422-495), one sweep -> BEV [B, C, Y, X].
     ``cam_feats`` [B*N, C, fH, fW]: stands in for get_cam_feats (:403-414) -- the pinned-composition test feeds the
     same neck features the golden run of the reference was given (tests/golden/make_golden_modules.py)."""
     B, S, N, Cin, H, W = imgs.shape
     if cam_feats is None:
-        x = imgs[:, 0].reshape(B * N, Cin, H, W)
+        x = imgs[:, sweep].reshape(B * N, Cin, H, W)
         feats = resnet(sd, 'backbone.img_backbone', x, conf['img_backbone_conf'])
         src = secondfpn(sd, 'backbone.img_neck', feats, conf['img_neck_conf'])
     else:
@@ -219,7 +226,7 @@ def lss_fpn_forward(sd, conf, imgs, mats, keep=None, cam_feats=None):
     lifted = height.unsqueeze(1) * hf[:, D:D + C].unsqueeze(2)                           # :464-466
     fH, fW = lifted.shape[3], lifted.shape[4]
     lifted = lifted.reshape(B, N, C, D, fH, fW).permute(0, 1, 3, 4, 5, 2).contiguous()   # :469-486
-    geom = geometry_indices(sd, mats)                                                    # :478-488
+    geom = geometry_indices(sd, mats, sweep)                                             # :478-488
     vn = [int(v) for v in sd['backbone.voxel_num']]
     bev, _ = VP.forward(geom, lifted.numpy(), vn, want_pos_memo=False)                   # :490-491
     bev = torch.from_numpy(bev)

@@ -87,6 +87,24 @@ def save_tune_db(path=None):
             json.dump({k: list(v) for k, v in TUNE_DB.items()}, f, indent=0, sort_keys=True)
 
 
+def load_default_tune_dbs():
+    """tune/gfx950_*.json at the repository root: the (algorithm, tile, split-K) choices measured on an MI355X for the
+    BASELINE configurations, committed so that a run neither spends its first forward on candidate timing nor moves by
+    near-tie picks from run to run.  A layer signature that is not in there is measured as before (autotune is the
+    fallback).  SGV3D_NO_TUNE_DB=1 ignores the committed files; SGV3D_TUNE_CACHE=<file> is loaded on top and is the file
+    save_tune_db() writes."""
+    import glob
+    import os
+    if os.environ.get("SGV3D_NO_TUNE_DB"):
+        return 0
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tune")
+    n = 0
+    for f in sorted(glob.glob(os.path.join(root, "gfx950_*.json"))):
+        n += load_tune_db(f) and 1
+    return n
+
+
+load_default_tune_dbs()
 load_tune_db()
 TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: "wino_resident", 7: "patch_bf16", 8: "wino_half",
               11: "128x128", 12: "128x64", 13: "64x128", 14: "64x64",      # 11..14: f32x3 of tiles 1..4 (host-side ids)
@@ -340,7 +358,7 @@ class PackedConv:
                 sig = (f"{self.cout}x{self.cin}k{self.kh}x{self.kw}s{self.stride}p{self.pad}d{self.dil}"
                        f"ks{self.ks}|{B}x{H}x{W}|m{d.mode}r{int(residual is not None)}g{int(gate is not None)}|{t}.{sk}"
                        + ("|bf16" if MFMA_BF16 else "|f32x3" if MFMA_F32X3 is True else "|x3auto" if MFMA_F32X3 else "")
-                       + (f"|io{io}" if io else ""))
+                       + (f"|io{io}" if io else "") + f"|ts{TUNE_STREAMS}")    # choices are per frames-in-flight load
                 if sig in TUNE_DB:
                     choice = TUNE_DB[sig]
                     self._tile_cache[key] = choice

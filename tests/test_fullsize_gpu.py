@@ -200,3 +200,71 @@ def test_full_size_bf16_mode(full):
     worst, scale = _errors(preds, full['ref'])
     print(f"{full['name']}: bf16 max |hip - oracle| = {worst:.3e} (max |ref| {scale:.2f})")
     assert 1e-5 < worst < BF16_TOL * max(1.0, scale), (full['name'], worst, scale)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE batch sizes
+# BASELINE configs[2] is batch 4 per GPU (and configs[3] / [4] shard 4 frames per rank): batch 4 changes M of every
+# convolution -- hence every measured (algorithm, tile, split-K) choice and grid size -- and the 4x voxel plan / lifted
+# tensor.  Four DIFFERENT frames and calibrations, each compared with its own oracle forward.
+@pytest.fixture(scope="module", params=["cfg3", "cfg5"])
+def full_b4(request):
+    from sgv3d_amd.models.bev_height import BEVHeight
+    bc, hc = CONFS[request.param]()
+    torch.manual_seed(0)
+    m = BEVHeight(bc, hc).eval()
+    S.randomize_norm_stats_(m, 0, residual_gamma=0.3)
+    imgs = S.make_images(4, bc['final_dim'], seed=11)
+    mats = S.make_mats(4)                                      # vary=True: four different camera poses
+    assert not torch.equal(mats['sensor2ego_mats'][0], mats['sensor2ego_mats'][3])
+    keep = {}
+    ref = TM.bevheight_forward(m.state_dict(), bc, hc, imgs, mats, keep)
+    return dict(name=request.param, m=m.to(DEV), imgs=imgs.to(DEV), mats={k: v.to(DEV) for k, v in mats.items()},
+                ref=ref, geom=keep['geom_xyz'], bc=bc, hc=hc)
+
+
+def _per_sample_errors(preds, ref, batch):
+    """(max |err|, max |ref|) per sample over all prediction maps."""
+    out = []
+    for b in range(batch):
+        worst, scale = 0.0, 0.0
+        for t in range(len(ref)):
+            for k, v in ref[t][0].items():
+                worst = max(worst, float((preds[t][0][k][b].float().cpu() - v[b]).abs().max()))
+                scale = max(scale, float(v[b].abs().max()))
+        out.append((worst, scale))
+    return out
+
+
+def test_batch4_fp32_parity(full_b4):
+    """cfg-3 / cfg-5 at batch 4, fp32: voxel indices bit-exact for all four calibrations, every frame within 1e-3."""
+    m = full_b4['m']
+    with torch.no_grad():
+        preds = m(full_b4['imgs'], full_b4['mats'])
+        geom, _ = m.backbone.calibration(full_b4['mats'], 0)
+    assert np.array_equal(geom.cpu().numpy(), full_b4['geom'])
+    errs = _per_sample_errors(preds, full_b4['ref'], 4)
+    print(f"{full_b4['name']} batch 4 fp32: per-frame max |hip - oracle| = {[f'{e:.2e}' for e, _ in errs]}")
+    assert all(e < 1e-3 for e, _ in errs), (full_b4['name'], errs)
+    # the frames are really different (a batch that silently repeated frame 0 would pass the per-frame check on frame 0 only)
+    assert float((preds[0][0]['heatmap'][0] - preds[0][0]['heatmap'][3]).abs().max()) > 1e-3
+
+
+def test_batch4_bf16_mode(full_b4):
+    """cfg-3 / cfg-5 at batch 4 in the bf16-MFMA mode (the dtype BASELINE configs[2] / [4] name; the launches
+    bench.py's other_configs records time): every frame within BF16_TOL of its fp32 oracle forward."""
+    m = full_b4['m']
+    old = hip_ops.MFMA_BF16
+    hip_ops.MFMA_BF16 = True
+    m.refresh()
+    try:
+        with torch.no_grad():
+            preds = m(full_b4['imgs'], full_b4['mats'])
+            geom, _ = m.backbone.calibration(full_b4['mats'], 0)
+        torch.cuda.synchronize()
+    finally:
+        hip_ops.MFMA_BF16 = old
+        m.refresh()
+    assert np.array_equal(geom.cpu().numpy(), full_b4['geom'])
+    errs = _per_sample_errors(preds, full_b4['ref'], 4)
+    print(f"{full_b4['name']} batch 4 bf16: per-frame max |hip - oracle| / max |ref| = {[f'{e / max(1.0, s):.2e}' for e, s in errs]}")
+    assert all(1e-5 < e < BF16_TOL * max(1.0, s) for e, s in errs), (full_b4['name'], errs)

@@ -351,3 +351,38 @@ def test_graph_replays_survive_host_side_work_between_them(small):
         if first is None:
             first = vals
         assert vals == first and junk == 10.0
+
+
+def test_two_sweeps_match_oracle(small):
+    """num_sweeps = 2 (lss_fpn.py:535-550; no shipped config uses it, the path exists): every sweep through the single-sweep
+    forward with its own images and its own geometry, HeightNet on the key frame's calibration, BEV maps concatenated on
+    the channel axis -- and one calibration-cache entry per sweep, so a second frame launches no geometry kernel."""
+    from sgv3d_amd.calibration import CalibrationCache
+    m, bc = small['m'], small['bc']
+    imgs = torch.cat([S.make_images(2, bc['final_dim'], seed=21), S.make_images(2, bc['final_dim'], seed=22)], 1)
+    a, b = S.make_mats(2, scale=128 / 864), S.make_mats(2, scale=128 / 864)
+    b['sensor2ego_mats'][:, :, :, 2, 3] += 0.35                        # the sweep camera sits elsewhere: other geometry
+    b['reference_heights'] += 0.35
+    mats = {k: (a[k] if k == 'bda_mat' else torch.cat([a[k], b[k]], 1)) for k in a}
+    ref = TM.lss_fpn_forward_sweeps({k: v.detach().cpu() for k, v in m.state_dict().items()}, bc, imgs, mats)
+    C = bc['output_channels']
+    assert ref.shape[1] == 2 * C and not torch.allclose(ref[:, :C], ref[:, C:])
+    old = m.backbone.calib_cache
+    m.backbone.calib_cache = cc = CalibrationCache()
+    try:
+        with torch.no_grad():
+            dm = _to_dev(mats)
+            bev = m.backbone(imgs.to(DEV), dm)
+            assert (cc.hits, cc.refreshes) == (0, 2)
+            bev2 = m.backbone(imgs.to(DEV), dm)
+            assert (cc.hits, cc.refreshes) == (2, 2)                   # both sweeps served from their own entries
+            nhwc = m.backbone(imgs.to(DEV), dm, nhwc_out=True)
+    finally:
+        m.backbone.calib_cache = old
+    torch.testing.assert_close(bev.cpu(), ref, **TOL)
+    assert torch.equal(bev, bev2)
+    torch.testing.assert_close(nhwc.permute(0, 3, 1, 2).cpu(), ref, **TOL)
+    g0 = cc.entry(0).geom.cpu().numpy()
+    assert np.array_equal(g0, TM.geometry_indices({k: v.cpu() for k, v in m.state_dict().items()}, mats, 0))
+    assert np.array_equal(cc.entry(1).geom.cpu().numpy(), TM.geometry_indices({k: v.cpu() for k, v in m.state_dict().items()}, mats, 1))
+    assert not np.array_equal(g0, cc.entry(1).geom.cpu().numpy())

@@ -143,3 +143,55 @@ def test_learning_rate_rules():
     from sgv3d_amd.train_step import reference_lr, multistep_lr
     assert abs(reference_lr(4, 8) - 2e-4 / 64 * 32) < 1e-15          # config 4: global batch 32
     assert multistep_lr(1.0, 0) == 1.0 and abs(multistep_lr(1.0, 19) - 0.1) < 1e-12 and abs(multistep_lr(1.0, 23) - 0.01) < 1e-12
+
+
+def test_overlap_hooks_allow_one_backward_per_step():
+    """overlap_with_backward(): a second backward before step() would add local gradients on top of buckets whose
+    all-reduce is already in flight -- it raises; zero_grad() / all_reduce_grads() re-arm the counters."""
+    import torch
+    from sgv3d_amd.train_step import DataParallelAdamW
+    from sgv3d_amd._lib import SGV3DError
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    opt = DataParallelAdamW(net.parameters(), lr=1e-3, bucket_bytes=64).overlap_with_backward()
+    assert len(opt.flat.buckets) >= 2
+    x = torch.randn(4, 6)
+    opt.zero_grad()
+    net(x).sum().backward()
+    assert opt._left == [0] * len(opt.flat.buckets) and opt._early == {}      # no process group: nothing launched
+    try:
+        net(x).sum().backward()
+        raise AssertionError("second backward not detected")
+    except SGV3DError as e:
+        assert "second backward" in str(e)
+    opt.zero_grad()                                                            # re-arms
+    net(x).sum().backward()
+    opt.all_reduce_grads()
+    assert opt._left == [len(e) for _, _, e in opt.flat.buckets]
+
+
+def test_bench_multi_rank_control_flow_with_stub_model():
+    """bench.py's own N > 1 protocol, launched the way the driver launches it (RANK / WORLD_SIZE / MASTER_* in the
+    environment, --gpus 2), over gloo with the model replaced by a sleep (SGV3D_BENCH_STUB=1): both ranks finish, rank 0
+    prints exactly one JSON line, the elapsed time is the MAX over ranks (rank 1 is made the slower one), every rank's own
+    record is gathered, and nobody leaves the process group while rank 0 is still working."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29523", WORLD_SIZE="2", SGV3D_BENCH_STUB="1")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1"],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-2000:]
+    lines = [l for l in outs[0][0].decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and not outs[1][0].strip()           # ONE line, from rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 6 and rec["data"] == "stub" and rec["scaling"] == "weak"
+    assert rec["config"]["world_size"] == 2 and rec["config"]["backend"].startswith("gloo")
+    per = rec["config"]["per_rank"]
+    assert [r["rank"] for r in per] == [0, 1]
+    # rank 1 sleeps 4 ms per step, rank 0 2 ms: the aggregate is priced with the slower rank's time
+    assert rec["ms_per_step"] >= 4.0 and per[0]["frames_per_s"] > per[1]["frames_per_s"]
+    assert abs(rec["value"] - 2 * 1 * 6 / (rec["ms_per_step"] * 6e-3)) < 1e-6 * rec["value"]

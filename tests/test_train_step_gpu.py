@@ -106,3 +106,52 @@ def test_adamw_bandwidth_smoke():
     us = sorted(ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(5))[2]
     print(f"fused AdamW: {n * 28 / us / 1e6:.2f} TB/s ({us:.0f} us for {n >> 20} Mi parameters)")
     assert n * 28 / us / 1e6 > 2.0
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[3] stand-in
+def _run_json(cmd, env, timeout=900):
+    import json
+    import subprocess
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_cfg4_share_training_step_through_one_rank_rccl():
+    """BASELINE configs[3] (global batch 32 over 8 MI355X) cannot run on one GPU; its per-GPU share can: the cfg-2 model at
+    batch 4, one FULL data-parallel step -- parameter broadcast, bucket all-reduces launched from inside backward, fused
+    AdamW -- through a real RCCL process group of ONE rank (SGV3D_FORCE_DIST=1).  A 1-rank SUM all-reduce is the identity,
+    so the run must land where the same steps without any process group land."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "train_bench.py"), "--config", "cfg4", "--steps", "2", "--warmup", "1"]
+    base = {k: v for k, v in os.environ.items() if k not in ("SGV3D_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    base["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env = dict(base, SGV3D_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    dist = _run_json(cmd, env)
+    assert dist["backend"] == "nccl" and dist["world_size"] == 1 and dist["collectives_active"] is True
+    assert dist["batch_per_gpu"] == 4 and dist["allreduce_buckets"] >= 1 and dist["allreduce_bytes_per_step"] > 250e6
+    assert dist["allreduces_launched_inside_backward"] == dist["allreduce_buckets"]      # overlapped with backward
+    assert dist["loss"] == dist["loss"] and abs(dist["loss"]) < 1e6
+    plain = _run_json(cmd, base)
+    assert plain["collectives_active"] is False and plain["world_size"] == 1
+    # deformable-conv input gradients use float atomics (order-nondeterministic), so not bitwise: 3 AdamW steps of lr 1.25e-5
+    assert abs(dist["loss"] - plain["loss"]) <= 2e-3 * max(1.0, abs(plain["loss"])), (dist["loss"], plain["loss"])
+    assert abs(dist["param_checksum"] - plain["param_checksum"]) <= 1e-5 * plain["param_checksum"]
+    print(f"cfg-4 share through 1-rank RCCL: {dist['ms_per_step']:.1f} ms / step, {dist['allreduce_bytes_per_step'] / 1e6:.0f} MB "
+          f"all-reduced in {dist['allreduce_buckets']} buckets; without a process group {plain['ms_per_step']:.1f} ms")
+
+
+def test_bench_through_one_rank_rccl():
+    """bench.py's N>1 protocol (RCCL barrier, MAX all-reduce of the elapsed time, all_gather_object of the per-rank
+    records, final barrier before teardown) on a 1-rank RCCL group."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(SGV3D_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    rec = _run_json([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+                     "--no-roofline"], env)
+    assert rec["config"]["backend"] == "nccl (RCCL)" and rec["config"]["world_size"] == 1 and rec["n_gpus"] == 1
+    assert rec["value"] > 10.0 and len(rec["config"]["per_rank"]) == 1

@@ -66,9 +66,13 @@ def step():
     if BSM:
         loss = loss + semantic(img_preds, gt_semantic) * 500
     loss.backward()
+    EARLY[0] = len(getattr(opt, '_early', {}))
     opt.all_reduce_grads()
     opt.step()
     return loss
+
+
+EARLY = [0]
 
 
 for _ in range(args.warmup):
@@ -81,7 +85,10 @@ out = {"metric": "training samples/s (forward + loss + backward + all-reduce + A
        "world_size": group.dist.get_world_size() if group.dist is not None else 1, "backend": group.backend,
        "allreduce_bytes_per_step": 4 * sum(g.numel() for _, g, _ in opt.flat.buckets), "allreduce_buckets": len(opt.flat.buckets),
        "allreduce_overlapped_with_backward": not args.no_overlap, "parameters": nparam, "loss": float(loss.detach()), "config": args.config,
-       "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2**30, "data": "synthetic"}
+       "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2**30, "data": "synthetic",
+       # (a 1-rank group with SGV3D_FORCE_DIST=1 still broadcasts / all-reduces through RCCL: the single-GPU stand-in for cfg-4)
+       "collectives_active": bool(opt._collectives()), "allreduces_launched_inside_backward": EARLY[0],
+       "param_checksum": float(sum(p.double().abs().sum() for p, _, _ in opt.flat.buckets))}
 if args.profile:
     # the profiled step holds collectives (loss-factor and gradient all-reduces): every rank runs it, rank 0 reports
     hip_ops.PROFILE = []
