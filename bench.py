@@ -17,7 +17,7 @@ Printed by rank 0 as ONE JSON line, with
   their summed durations, measured live with HIP events on the launch stream in an instrumented
   pass over the same K steps (events around every launch would perturb the throughput loop, so the
   two loops are separate; both run in this process on the same inputs);
-* ``roofline_hbm``: the voxel-pooling operator (vp_gather2 + vp_fixup) against HBM peak -- the 175.9 MB
+* ``roofline_hbm``: the voxel-pooling operator (vp_gather_fast_kernel) against HBM peak -- the 175.9 MB
   of SURVEY 8(d) / launch duration -- with the plan build reported beside it (it runs once per
   calibration, never inside the timed region);
 * ``cpu_baseline``: the torch-CPU oracle restatement of the same forward (oracle/torch_model.py)
@@ -95,7 +95,7 @@ def load_vp_traffic():
             continue
         tot, names = 0.0, []
         for sym, r in rec.items():
-            if sym.startswith(("vp_gather2_kernel", "vp_fixup_kernel")):
+            if sym.startswith(("vp_gather_fast_kernel", "vp_gather3_kernel", "vp_gather2_kernel", "vp_fixup_kernel")):
                 tot += r["hbm_bytes_per_launch"]
                 names.append(sym)
         if names:
@@ -409,18 +409,33 @@ def main():
             clean_us = time_us(lambda: plan.rebuild(flat), reps=10)
         alg = 12.0 * Bn * Np + 4.0 * Bn * Np * Cvp + 4.0 * Bn * Y * X * Cvp           # geom + feats + output
         vtraffic, vsrc = load_vp_traffic()
+        # level 1 of INTEGRATION.md: the symbol the reference's own voxel_pooling.py reaches through voxel_pooling_ext
+        # (sgv3d_voxel_pooling_forward: device-side compare of geom_xyz + pos_memo, gather accumulating into the caller-zeroed
+        # output from the library-owned plan, gated scatter fallback) -- timed on this run's geometry with pos_memo
+        from sgv3d_amd import _lib as _L
+        lib_ = _L.load()
+        outz = torch.zeros(Bn, Y, X, Cvp, device=dev)
+        pmz = torch.full((Bn, Np, 3), -1, dtype=torch.int32, device=dev)
+        Zv = int(bb._voxel_num_host[2])
+        l1 = lambda: lib_.sgv3d_voxel_pooling_forward(Bn, Np, Cvp, X, Y, Zv, flat.data_ptr(), feats.data_ptr(), outz.data_ptr(),
+                                                      pmz.data_ptr(), _L.stream_handle(dev))
+        level1_us = time_us(l1) if Cvp % 4 == 0 and 24 <= Cvp <= 256 else None
+        del outz, pmz
         roofline_hbm = {
-            "bound": "hbm", "kernel": "vp_gather2_kernel + vp_fixup_kernel (sgv3d_voxel_pooling_forward_planned)",
+            "bound": "hbm", "kernel": "vp_gather_fast_kernel (sgv3d_voxel_pooling_forward_planned: one launch, no fix-up pass)",
             "bytes": alg, "us": pool_us, "achieved": alg / pool_us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": alg / pool_us / 1e3 / HBM_PEAK_GBPS, "traffic": vtraffic, "traffic_source": vsrc,
             "plan_build_us": build_us, "plan_check_us": clean_us,
             "frac_including_plan": alg / (pool_us + build_us) / 1e3 / HBM_PEAK_GBPS if build_us else None,
             "frac_including_check": alg / (pool_us + clean_us) / 1e3 / HBM_PEAK_GBPS if clean_us else None,
             "plan_builds_in_timed_region": calib["plan_builds_in_timed_region"],
+            "level1_ext_us": level1_us,
+            "frac_level1_ext": alg / level1_us / 1e3 / HBM_PEAK_GBPS if level1_us else None,
             "note": "the plan depends only on the calibration: built once per calibration outside the captured forward "
                     "(frac_including_plan = if it were rebuilt on every frame, as the reference-style operator call with "
                     "ever-changing geom_xyz would; frac_including_check = operator call with an unchanged geom_xyz: "
-                    "device-side compare + empty build launches)",
+                    "device-side compare + empty build launches; frac_level1_ext = the reference wrapper's own call into "
+                    "voxel_pooling_ext, which keeps a plan per stream inside the library)",
             "method": "HIP events on the launch stream, median of 20 launches, N(0,1) features on this run's geometry",
         }
         del feats, outb

@@ -39,15 +39,35 @@ int sgv3d_abi_version(void);
  * Same argument order and meaning:
  *   geom_xyz        int32 [B, N, 3]   voxel index (x, y, z) per frustum point
  *   input_features  f32   [B, N, C]
- *   output_features f32   [B, Y, X, C] pre-zeroed by the caller, accumulated in place (float atomics,
- *                                      order-nondeterministic like the reference)
+ *   output_features f32   [B, Y, X, C] pre-zeroed by the caller, ACCUMULATED in place (the reference atomicAdds into it)
  *   pos_memo        int32 [B, N, 3]   pre-filled with -1 by the caller; (b, y, x) written for kept
  *                                      points; may be NULL (inference)
- * A launch failure is reported through the return code instead of exit(-1) (..cuda.cu:51-55). */
+ * A launch failure is reported through the return code instead of exit(-1) (..cuda.cu:51-55).
+ *
+ * This is the symbol the reference's own Python wrapper reaches through voxel_pooling_ext (INTEGRATION.md level 1), so it
+ * carries the fast path itself: per (device, stream, sizes) it keeps a voxel plan (below) in memory the library owns.
+ * Every call compares geom_xyz with the tensor the plan was built for ON THE DEVICE (the same pass writes pos_memo); while
+ * it is unchanged -- a roadside camera -- the rows are summed by the deterministic gather (vp_gather3_kernel, added to
+ * output_features, empty voxels untouched); a call whose geom_xyz differs is served by the float-atomic scatter of the
+ * reference (order-nondeterministic, like the reference) and the plan is rebuilt by a later call, once the host has seen
+ * the device's note -- the host never waits for the device.  Inside a stream capture with no plan yet, with channel counts
+ * the gather does not cover (C % 4 != 0, C < 24 or C > 256), with unaligned feature pointers, or with
+ * SGV3D_VP_LEVEL1_CACHE=0 the call is the plain scatter.  At most 8 plans are kept (least recently used evicted);
+ * sgv3d_voxel_pooling_cache_clear() frees them (synchronises the device), sgv3d_voxel_pooling_cache_stats() reports
+ * {calls, calls served through a plan, scatter-only calls, gated plan builds enqueued}. */
 int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
                                 int num_voxel_x, int num_voxel_y, int num_voxel_z,
                                 const int32_t *geom_xyz, const float *input_features,
                                 float *output_features, int32_t *pos_memo, void *stream);
+int sgv3d_voxel_pooling_cache_clear(void);
+int sgv3d_voxel_pooling_cache_stats(unsigned long long *out4);
+
+/* The float-atomic scatter alone (voxel_pooling_forward_cuda.cu:9-36 as written: one atomicAdd per kept (point, channel),
+ * order-nondeterministic), same arguments; owns no memory.  What ops.voxel_pooling.set_mode("atomic") calls. */
+int sgv3d_voxel_pooling_forward_atomic(int batch_size, int num_points, int num_channels,
+                                       int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                       const int32_t *geom_xyz, const float *input_features,
+                                       float *output_features, int32_t *pos_memo, void *stream);
 
 /* Deterministic, atomic-free formulation of the same operator: a CSR "plan" (voxel -> ascending list
  * of point ids) is built from geom_xyz, then every output row is gathered, reduced in registers and

@@ -29,6 +29,9 @@ _PROTOS = {
     "sgv3d_last_error": (ctypes.c_char_p, []),
     "sgv3d_abi_version": (c_int, []),
     "sgv3d_voxel_pooling_forward": (c_int, [c_int] * 6 + [c_void_p] * 5),
+    "sgv3d_voxel_pooling_forward_atomic": (c_int, [c_int] * 6 + [c_void_p] * 5),
+    "sgv3d_voxel_pooling_cache_clear": (c_int, []),
+    "sgv3d_voxel_pooling_cache_stats": (c_int, [ctypes.POINTER(ctypes.c_ulonglong)]),
     "sgv3d_voxel_plan_bytes": (c_size_t, [c_int] * 4),
     "sgv3d_voxel_plan_build": (c_int, [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "sgv3d_voxel_plan_init": (c_int, [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),

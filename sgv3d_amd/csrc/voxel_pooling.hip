@@ -1,17 +1,27 @@
 // Voxel pooling ("splat") for gfx950 — the operator of ops/voxel_pooling (reference:
 // ops/voxel_pooling/src/voxel_pooling_forward_cuda.cu:9-36, ops/voxel_pooling/voxel_pooling.py:10-69).
 //
-// Three formulations, all HBM-bound indexing work (no contraction => no MFMA):
+// Formulations, all HBM-bound indexing work (no contraction => no MFMA):
 //   1. vp_atomic_kernel      reference-faithful scatter with float atomics.  One lane per (point,
 //                            channel) so every atomic wave-instruction covers contiguous 256-B row
 //                            segments (the shape the memory-side atomic units run at full rate);
 //                            rows of dropped points are never read.
-//   2. plan build + vp_gather_kernel   deterministic CSR formulation: count -> scan -> fill ->
-//                            per-segment sort, then every output row is gathered with 16-B loads,
-//                            reduced in registers by 64/LPR row groups per wave and written once.
-//   3. vp_lift_splat_kernel  the same gather with rows formed on the fly as prob * context
-//                            (never materialises the [B,N,C] lifted tensor).
+//   2. plan build + vp_gather3_kernel   deterministic CSR formulation: count -> scan -> fill ->
+//                            per-segment sort once per calibration, then one launch gathers every output
+//                            row with 16-B loads (work cut evenly over the sorted slot list, each voxel
+//                            summed by one wave) and writes it once.  vp_gather_kernel (one wave per 4
+//                            voxels) serves channel counts the slot-balanced kernel does not cover.
+//   3. the same gather with rows formed on the fly as prob * context (FUSED; never materialises the
+//                            [B,N,C] lifted tensor), with bf16 rows / bf16 output (bf16 compute mode), and
+//                            accumulating into a caller-zeroed tensor behind the reference's own entry
+//                            point (sgv3d_voxel_pooling_forward keeps a plan per stream, "level 1").
 #include "common.hpp"
+
+#include <limits.h>
+#include <stdlib.h>
+
+#include <mutex>
+#include <vector>
 
 using namespace sgv3d;
 
@@ -82,8 +92,14 @@ struct PlanLayout {
     long long V;        // B*Y*X
     long long total;    // B*N
     int nblk;           // scan workgroups
-    size_t off_seg, off_cur, off_order, off_slotvox, off_blk, off_hdr, off_geom, bytes;
+    size_t off_seg, off_cur, off_order, off_slotvox, off_blk, off_hdr, off_geom, off_long, bytes;
+    int long_cap;       // capacity of the long-run list (entries after the count)
 };
+
+// Voxels holding more than kLongRun points ("long runs" of the sorted slot list) are listed in the plan and summed by
+// dedicated workgroups of the gather launch; every other voxel is summed by the one wave whose slot range contains its
+// first point (vp_gather3_kernel).  Must be >= the widest wave range (64 lanes / LPR row groups x <= 16 slots each).
+constexpr int kLongRun = 128;
 
 // Cache header of a plan (sgv3d_voxel_plan_build_cached): which geom_xyz / grid the plan was built for.
 struct PlanHeader {
@@ -108,7 +124,9 @@ PlanLayout plan_layout(int B, int N, int X, int Y) {
     L.off_blk = al(L.off_slotvox + sizeof(int) * (size_t)(L.total + 1));
     L.off_hdr = al(L.off_blk + sizeof(int) * (size_t)(L.nblk + 2));
     L.off_geom = al(L.off_hdr + sizeof(PlanHeader));
-    L.bytes = al(L.off_geom + sizeof(int) * 3 * (size_t)L.total);
+    L.off_long = al(L.off_geom + sizeof(int) * 3 * (size_t)L.total);
+    L.long_cap = (int)(L.total / kLongRun) + 1;
+    L.bytes = al(L.off_long + sizeof(int) * (size_t)(L.long_cap + 1));
     return L;
 }
 
@@ -271,9 +289,10 @@ __global__ __launch_bounds__(kBlock) void vp_scan_local_kernel(long long V, cons
 
 // one workgroup: exclusive scan of blk_sum[0..nblk) in place; blk_sum[nblk] = grand total
 __global__ __launch_bounds__(kBlock) void vp_scan_top_kernel(int nblk, int *__restrict__ blk_sum,
-                                                             const int *__restrict__ dirty) {
+                                                             const int *__restrict__ dirty, int *__restrict__ long_list) {
     VP_SKIP_IF_CLEAN(dirty);
     __shared__ int wave_tot[kBlock / 64];
+    if (threadIdx.x == 0) long_list[0] = 0;      // re-armed for vp_long_list_kernel (runs after the scan)
     int carry = 0;
     for (int c0 = 0; c0 < nblk; c0 += kBlock) {
         const int i = c0 + threadIdx.x;
@@ -301,11 +320,26 @@ __global__ __launch_bounds__(kBlock) void vp_scan_add_kernel(long long V, int nb
     }
 }
 
+// voxels with more than kLongRun points -> long_list[1 ..], count in long_list[0] (order irrelevant: each entry is summed in
+// a fixed internal order by whichever workgroup picks it up)
+__global__ __launch_bounds__(kBlock) void vp_long_list_kernel(long long V, const int *__restrict__ seg_start,
+                                                              int *__restrict__ long_list, int cap,
+                                                              const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    const long long v = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (v >= V) return;
+    if (seg_start[v + 1] - seg_start[v] > kLongRun) {
+        const int i = atomicAdd(long_list, 1);
+        if (i < cap) long_list[1 + i] = (int)v;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void vp_fill_kernel(long long total_pts, int N, int X, int Y, int Z,
                                                          const int32_t *__restrict__ geom,
                                                          int *__restrict__ cursor,
                                                          int *__restrict__ order,
-                                                         int *__restrict__ slot_voxel, const int *__restrict__ dirty) {
+                                                         int *__restrict__ slot_voxel, const int *__restrict__ dirty,
+                                                         const int *__restrict__ seg_start) {
     VP_SKIP_IF_CLEAN(dirty);
     const long long pt = (long long)blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -324,7 +358,8 @@ __global__ __launch_bounds__(kBlock) void vp_fill_kernel(long long total_pts, in
     if (v >= 0) {
         const int slot = base + (lane - head_lane);
         order[slot] = (int)pt;
-        slot_voxel[slot] = v;
+        // slots of a long run carry ~voxel: no gather wave owns them, the long-run workgroups sum them (vp_gather3_kernel)
+        slot_voxel[slot] = (seg_start[v + 1] - seg_start[v] > kLongRun) ? ~v : v;
     }
 }
 
@@ -547,14 +582,24 @@ __global__ __launch_bounds__(kBlock) void vp_gather_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// 2c. balanced gather ("v2").  Work is cut over the SORTED SLOTS, not over voxels: each LPR-lane row
-// group owns `ch` consecutive slots of the plan's order[] (ch = min(16, LPR-2)), fetches all of
-// their rows at once (ch x 16 B in flight per lane), and runs a segmented sum over them.  A run that
-// covers a whole voxel is stored directly; a run cut by a chunk border goes to partial[chunk][0]
-// (it started in an earlier chunk) or partial[chunk][1] (it starts here and continues), and
-// vp_fixup_kernel adds the pieces of each cut voxel in ascending chunk order.  Every group does the
-// same amount of work whatever the per-voxel multiplicity (mean 16, max 246 at cfg-2; max 775 on the
-// 128^2 grid), which the one-wave-per-voxel kernel above cannot offer.  Deterministic.
+// 2c. owner-computes gather ("v3", the default for C % 4 == 0, 24 <= C <= 256).  The work is cut over the SORTED SLOTS of the
+// plan, not over voxels, so every wave streams about the same number of 4C-byte rows whatever the per-voxel populations are
+// (camera frustums put 10^2..10^3 points into near voxels and none into most).  A wave looks at a WINDOW of cap = groups x ch
+// consecutive slots -- one chunk of ch <= 16 slots per LPR-lane row group, all rows of a chunk in flight at once -- that
+// starts every W_nom = cap - margin slots, and every voxel is summed by exactly ONE wave: the one whose nominal range
+// [s0, s0 + W_nom) holds the voxel's first slot.  That wave
+//   * ignores the leading slots of its window that belong to a voxel begun earlier (its owner reads on into this window),
+//   * runs a segmented sum per chunk and stitches the runs cut by chunk borders INSIDE the wave through the cross-lane
+//     network (head / tail pieces in ascending chunk order, fixed association => deterministic),
+//   * follows its last voxel past the nominal range: the margin of the window covers that in most cases with the same batch of
+//     loads; beyond the window it loops (at most kLongRun slots).
+// Nothing is cut between waves: no partial rows in HBM (27.6 of the 157.6 MB the round-2 gather + fix-up pair moved at cfg-2), no
+// fix-up launch, no workspace, and no index lookups besides the window's own slot_voxel / order entries (where a run starts
+// and ends is read off the window by ballots).  Voxels with more than kLongRun points would serialise on their owner: the plan
+// marks their slots (~voxel in slot_voxel) so that no wave owns them, lists them, and the extra workgroups at the end of the
+// grid sum each with all four waves.  Empty voxels are zero-filled by the same launch.
+// ACC (the reference-faithful entry sgv3d_voxel_pooling_forward): rows are ADDED to what `out` holds and empty voxels are
+// left alone -- the semantics of the reference's atomicAdd into a caller-zeroed tensor (voxel_pooling_forward_cuda.cu:30-33).
 // ------------------------------------------------------------------------------------------------
 constexpr int kChunkMax = 16;
 
@@ -578,35 +623,164 @@ __device__ __forceinline__ void vp_store_row(float *out, long long v, int C, int
     }
 }
 
-// FB: the feature rows are bf16 (bf16 compute mode: sgv3d_lift_bf16 wrote them); sums stay f32.  OB: see vp_store_row.
-template <bool FUSED, bool FB = false, bool OB = false>
-__global__ __launch_bounds__(kBlock) void vp_gather2_kernel(
-    long long V, int C, int lpr, int groups, int ch, const int *__restrict__ seg_start,
+// FB: the feature rows are bf16 (bf16 compute mode: sgv3d_lift_bf16 wrote them); sums stay f32.  FUSED: rows are formed on
+// the fly as prob * context (never materialises the [B,N,C] lifted tensor).
+template <bool FUSED, bool FB>
+__device__ __forceinline__ float4 vp_load_row(const float *__restrict__ feats, const float *__restrict__ prob,
+                                              const float *__restrict__ ctx, int idx, int cl, int C, int N, int P, float &pr) {
+    if constexpr (FUSED) {
+        const int b = idx / N;
+        const int pix = (idx - b * N) % P;
+        pr = prob[idx];
+        return *reinterpret_cast<const float4 *>(ctx + ((size_t)b * P + pix) * C + (size_t)cl * 4);
+    } else if constexpr (FB) {
+        const vp_bf16x4 q = *reinterpret_cast<const vp_bf16x4 *>(reinterpret_cast<const __bf16 *>(feats) + (size_t)idx * C + (size_t)cl * 4);
+        return make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+    } else {
+        return *reinterpret_cast<const float4 *>(feats + (size_t)idx * C + (size_t)cl * 4);
+    }
+}
+
+template <bool OB, bool ACC>
+__device__ __forceinline__ void vp_emit_row(float *out, long long v, int C, int ldo, int cl, float4 val) {
+    if constexpr (ACC) {
+        float4 *o = reinterpret_cast<float4 *>(out + (size_t)v * C + (size_t)cl * 4);
+        const float4 old = *o;
+        val.x += old.x; val.y += old.y; val.z += old.z; val.w += old.w;
+        *o = val;
+    } else {
+        vp_store_row<OB>(out, v, C, ldo, cl, val);
+    }
+}
+
+// value of `x` held by lane `src` (any lane index per lane): one ds_bpermute per component
+__device__ __forceinline__ float4 vp_from_lane(const float4 &x, int src) {
+    return make_float4(__shfl(x.x, src, 64), __shfl(x.y, src, 64), __shfl(x.z, src, 64), __shfl(x.w, src, 64));
+}
+
+// Rows of the slots [base, base + groups*ch) that still belong to voxel `want` (marked or not): group g sums slots
+// base + g*ch + k (k ascending) into `acc`; the caller adds the groups' sums in ascending group order.  Returns true when the
+// run ended inside this batch (a slot of another voxel, or the end of the list, was seen).  Wave-uniform.
+template <bool FUSED, bool FB>
+__device__ __forceinline__ bool vp_sum_run_batch(float4 &acc, long long base, int T, int want, int g, int cl, int glane0, int ch,
+                                                 bool ingroup, const int *__restrict__ order, const int *__restrict__ slot_voxel,
+                                                 const float *__restrict__ feats, const float *__restrict__ prob,
+                                                 const float *__restrict__ ctx, int C, int N, int P) {
+    const long long cb = base + (long long)g * ch;
+    int my_idx = -1;
+    bool mine = false;
+    if (ingroup && cl < ch && cb + cl < T) {
+        mine = slot_voxel[cb + cl] == want;
+        if (mine) my_idx = order[cb + cl];
+    }
+    // (slots are sorted by voxel: the slots of `want` form a prefix of the batch)
+    const bool ended = __ballot(ingroup && cl < ch && !mine) != 0ull;
+    float4 val[kChunkMax];
+    float pr[kChunkMax];
+#pragma unroll
+    for (int k = 0; k < kChunkMax; ++k) {
+        const int idx = __shfl(my_idx, glane0 + (k < ch ? k : 0), 64);
+        val[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pr[k] = 0.f;
+        if (ingroup && k < ch && idx >= 0) val[k] = vp_load_row<FUSED, FB>(feats, prob, ctx, idx, cl, C, N, P, pr[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kChunkMax; ++k) {
+        if (k < ch) {                                   // (rows that are not `want`'s are zeros: adding them changes nothing)
+            if constexpr (FUSED) vfma(acc, pr[k], val[k]);
+            else vacc(acc, val[k]);
+        }
+    }
+    return ended;
+}
+
+template <bool FUSED, bool FB = false, bool OB = false, bool ACC = false>
+__global__ __launch_bounds__(kBlock) void vp_gather3_kernel(
+    long long V, int C, int lpr, int groups, int ch, int w_nom, const int *__restrict__ seg_start,
     const int *__restrict__ order, const int *__restrict__ slot_voxel, const float *__restrict__ feats,
-    const float *__restrict__ prob, const float *__restrict__ ctx, int N, int P, float *__restrict__ out,
-    float *__restrict__ partial, int ldo) {
+    const float *__restrict__ prob, const float *__restrict__ ctx, int N, int P, float *__restrict__ out, int ldo,
+    const int *__restrict__ long_list, int long_cap, int nblk_regular,
+    const int *__restrict__ gate /* NULL, or: run only while *gate == 0 */) {
+    if (gate != nullptr && *reinterpret_cast<const volatile int *>(gate) != 0) return;
+    __shared__ float4 red[kBlock / 64][64];
     const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
     const int g = lane / lpr;
     const int cl = lane - g * lpr;
     const int glane0 = g * lpr;
-    const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const long long chunk = wave * groups + g;
+    const bool ingroup = g < groups;        // (lpr == C / 4: every lane of a group owns 4 channels)
+    const int src_cl = ingroup ? cl : 0;
+    const int cap = groups * ch;
     const int T = seg_start[V];
-    const long long base = chunk * ch;
-    const bool active = g < groups && base < T;
-    const int ncols = C >> 2;
-    // lanes 0..ch+1 of the group fetch slot base-1+cl: voxel id (all) and point id (the ch inner ones)
-    int my_vox = -1, my_idx = -1;
-    if (active && cl < ch + 2) {
-        const long long sl = base - 1 + cl;
-        if (sl >= 0 && sl < T) {
-            my_vox = slot_voxel[sl];
-            if (cl >= 1 && cl <= ch) my_idx = order[sl];
+
+    // ---------------------------------------------------------------- long runs: one workgroup per voxel at a time
+    if ((int)blockIdx.x >= nblk_regular) {
+        const int n_long = min(long_list[0], long_cap);
+        const int stride = (int)gridDim.x - nblk_regular;
+        for (int i = (int)blockIdx.x - nblk_regular; i < n_long; i += stride) {      // block-uniform trip count
+            const int v = long_list[1 + i];
+            const long long b = seg_start[v], e = seg_start[v + 1];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (long long base = b + (long long)wid * cap; base < e; base += (long long)(kBlock / 64) * cap)
+                vp_sum_run_batch<FUSED, FB>(acc, base, (int)e, ~v, g, cl, glane0, ch, ingroup, order, slot_voxel, feats, prob, ctx, C, N, P);
+            float4 wsum = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g2 = 0; g2 < groups; ++g2) vacc(wsum, vp_from_lane(acc, g2 * lpr + src_cl));
+            if (g == 0) red[wid][cl] = wsum;
+            __syncthreads();
+            if (wid == 0 && g == 0) {
+                float4 tot = red[0][cl];
+#pragma unroll
+                for (int w = 1; w < kBlock / 64; ++w) vacc(tot, red[w][cl]);
+                vp_emit_row<OB, ACC>(out, v, C, ldo, cl, tot);
+            }
+            __syncthreads();
         }
+        return;
+    }
+
+    const long long wave = (long long)blockIdx.x * (kBlock / 64) + wid;
+    // ---------------------------------------------------------------- rows of empty voxels (not in ACC mode)
+    if constexpr (!ACC) {
+        if (ingroup) {
+            const long long ngroups = (long long)nblk_regular * (kBlock / 64) * groups;
+            const long long per = (V + ngroups - 1) / ngroups;
+            const long long v0 = (wave * groups + g) * per, v1 = min(V, v0 + per);
+            for (long long v = v0; v < v1; ++v)
+                if (seg_start[v] == seg_start[v + 1]) vp_store_row<OB>(out, v, C, ldo, cl, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    }
+    const long long s0 = wave * w_nom;
+    if (s0 >= T) return;                                         // wave-uniform
+    const long long cb = s0 + (long long)g * ch;
+    // lanes 0 .. ch+1 of a group hold slot cb - 1 + cl: voxel id (all of them) and point id (the ch inner ones).  Outside the
+    // list: INT_MIN, which no entry equals (entries are v >= 0, or ~v <= -1 for the slots of a long run, v < INT_MAX)
+    int my_vox = INT_MIN, my_idx = -1;
+    const long long my_slot = cb - 1 + cl;
+    if (ingroup && cl < ch + 2 && my_slot >= 0 && my_slot < T) {
+        my_vox = slot_voxel[my_slot];
+        if (cl >= 1 && cl <= ch) my_idx = order[my_slot];
+    }
+    // where runs start inside the window: lanes cl = 1..ch of every group (slots cb .. cb+ch-1), plus the slot right behind the
+    // window (cl = ch+1 of the last group).  Lane order is slot order.
+    const int up_vox = __shfl_up(my_vox, 1, 64);
+    const bool in_window = ingroup && cl >= 1 && (cl <= ch || (cl == ch + 1 && g == groups - 1));
+    const bool starts = in_window && my_vox != up_vox;
+    const unsigned long long nominal_m = __ballot(in_window && my_slot < s0 + w_nom);
+    const unsigned long long start_m = __ballot(starts);
+    const unsigned long long own_m = start_m & nominal_m;        // runs that start in the nominal range: this wave's
+    if (own_m == 0ull) return;                                   // one voxel covers the whole range: its owner sums it
+    const int first_lane = __ffsll((long long)own_m) - 1;
+    const long long first = s0 + (long long)(first_lane / lpr) * ch + (first_lane % lpr) - 1;
+    const unsigned long long tail_start_m = start_m & ~nominal_m;   // the first run start behind the nominal range ends the last owned run
+    long long endw = s0 + cap;                                   // none inside the window: the last run goes on behind it
+    if (tail_start_m != 0ull) {
+        const int end_lane = __ffsll((long long)tail_start_m) - 1;
+        endw = s0 + (long long)(end_lane / lpr) * ch + (end_lane % lpr) - 1;
     }
     const int prev_vox = __shfl(my_vox, glane0, 64);
     const int next_vox = __shfl(my_vox, glane0 + ch + 1, 64);
-    const int cnt = active ? (int)min((long long)ch, (long long)T - base) : 0;
+    const int lo = (int)max(0ll, min((long long)ch, first - cb));
+    const int hi = (int)max(0ll, min((long long)ch, endw - cb));
     int vox[kChunkMax];
     float4 val[kChunkMax];
     float pr[kChunkMax];
@@ -617,90 +791,353 @@ __global__ __launch_bounds__(kBlock) void vp_gather2_kernel(
         vox[k] = __shfl(my_vox, src, 64);
         val[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         pr[k] = 0.f;
-        if (k < cnt && cl < ncols) {
-            if constexpr (FUSED) {
-                const int b = idx / N;
-                const int pix = (idx - b * N) % P;
-                pr[k] = prob[idx];
-                val[k] = *reinterpret_cast<const float4 *>(ctx + ((size_t)b * P + pix) * C + (size_t)cl * 4);
-            } else if constexpr (FB) {
-                const vp_bf16x4 q = *reinterpret_cast<const vp_bf16x4 *>(reinterpret_cast<const __bf16 *>(feats) + (size_t)idx * C + (size_t)cl * 4);
-                val[k] = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
-            } else {
-                val[k] = *reinterpret_cast<const float4 *>(feats + (size_t)idx * C + (size_t)cl * 4);
-            }
-        }
+        if (ingroup && k >= lo && k < hi && vox[k] >= 0)          // (vox < 0: a long run's slot, or behind the end of the list)
+            val[k] = vp_load_row<FUSED, FB>(feats, prob, ctx, idx, cl, C, N, P, pr[k]);
     }
-    // rows of empty voxels: every group of the launch clears its share (disjoint from every row the
-    // gather / fix-up write, so no ordering is needed and no memset pass either)
-    if (g < groups && cl < ncols) {
-        const long long ngroups = (long long)gridDim.x * (kBlock / 64) * groups;
-        const long long per = (V + ngroups - 1) / ngroups;
-        const long long v0 = chunk * per, v1 = min(V, v0 + per);
-        for (long long v = v0; v < v1; ++v)
-            if (seg_start[v] == seg_start[v + 1]) vp_store_row<OB>(out, v, C, ldo, cl, make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-    if (!active || cl >= ncols) return;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int cur = vox[0];
-    bool before = prev_vox == cur;       // the first run started in an earlier chunk
+    // ---------------------------------------------------------------- segmented sum of the chunk
+    float4 head = make_float4(0.f, 0.f, 0.f, 0.f), tail = head, acc = head;
+    bool has_head = false, single = false, has_tail = false;
+    int tail_vox = -1;
+    if (ingroup && lo < hi) {
+        int cur = vox[0];
+        bool first_run = true;
+        // the first run began in an earlier chunk of this wave (and is one this wave sums)
+        const bool before = lo == 0 && cb > first && prev_vox == vox[0] && vox[0] >= 0;
 #pragma unroll
-    for (int k = 0; k < kChunkMax; ++k) {
-        if (k < cnt) {
-            if (vox[k] != cur) {             // run of `cur` ended inside the chunk
-                if (before) *reinterpret_cast<float4 *>(partial + ((size_t)chunk * 2 + 0) * C + (size_t)cl * 4) = acc;
-                else vp_store_row<OB>(out, cur, C, ldo, cl, acc);
-                acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                cur = vox[k];
-                before = false;
+        for (int k = 0; k < kChunkMax; ++k) {
+            if (k >= lo && k < hi) {
+                if (k == lo) cur = vox[k];
+                if (vox[k] != cur) {                                     // the run of `cur` ended inside the chunk
+                    if (cur >= 0) {
+                        if (first_run && before) { head = acc; has_head = true; }
+                        else vp_emit_row<OB, ACC>(out, cur, C, ldo, cl, acc);
+                    }
+                    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    cur = vox[k];
+                    first_run = false;
+                }
+                if constexpr (FUSED) vfma(acc, pr[k], val[k]);
+                else vacc(acc, val[k]);
             }
-            if constexpr (FUSED) vfma(acc, pr[k], val[k]);
-            else vacc(acc, val[k]);
+        }
+        if (cur >= 0) {
+            const bool after = hi == ch && next_vox == cur;                  // continues in the next chunk / behind the window
+            if (first_run && before) { head = acc; has_head = true; single = after; }
+            else if (after) { tail = acc; has_tail = true; tail_vox = cur; }
+            else vp_emit_row<OB, ACC>(out, cur, C, ldo, cl, acc);
         }
     }
-    const bool after = cnt == ch && next_vox == cur;   // the last run continues in the next chunk
-    if (before) *reinterpret_cast<float4 *>(partial + ((size_t)chunk * 2 + 0) * C + (size_t)cl * 4) = acc;
-    else if (after) *reinterpret_cast<float4 *>(partial + ((size_t)chunk * 2 + 1) * C + (size_t)cl * 4) = acc;
-    else vp_store_row<OB>(out, cur, C, ldo, cl, acc);
+    // ---------------------------------------------------------------- stitch the runs cut by chunk borders (ascending chunks)
+    const unsigned long long head_m = __ballot(has_head && cl == 0);
+    const unsigned long long single_m = __ballot(single && cl == 0);
+    const unsigned long long tail_m = __ballot(has_tail && cl == 0);
+    if ((head_m | tail_m) == 0ull) return;                        // wave-uniform
+    float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
+    int carry_vox = -1;
+    for (int g2 = 0; g2 < groups; ++g2) {
+        const int l0 = g2 * lpr;
+        if ((head_m >> l0) & 1ull) {
+            vacc(carry, vp_from_lane(head, l0 + src_cl));
+            if (!((single_m >> l0) & 1ull)) {                     // the run ends in this chunk: its row is complete
+                if (g == 0) vp_emit_row<OB, ACC>(out, carry_vox, C, ldo, cl, carry);
+                carry_vox = -1;
+            }
+        }
+        if ((tail_m >> l0) & 1ull) {
+            carry = vp_from_lane(tail, l0 + src_cl);
+            carry_vox = __builtin_amdgcn_readfirstlane(__shfl(tail_vox, l0, 64));
+        }
+    }
+    if (carry_vox < 0) return;
+    // ---------------------------------------------------------------- the last run goes on behind the window (<= kLongRun slots)
+    float4 eacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long base = s0 + cap; base < T; base += cap)
+        if (vp_sum_run_batch<FUSED, FB>(eacc, base, T, carry_vox, g, cl, glane0, ch, ingroup, order, slot_voxel, feats, prob, ctx, C, N, P))
+            break;
+    for (int g2 = 0; g2 < groups; ++g2) vacc(carry, vp_from_lane(eacc, g2 * lpr + src_cl));
+    if (g == 0) vp_emit_row<OB, ACC>(out, carry_vox, C, ldo, cl, carry);
 }
 
-// One row group per chunk: if the chunk's last run starts here and continues, it leads that voxel:
-// out[v] = partial[j][1] + partial[j+1][0] + ... in ascending chunk order.  The leader test reads its
-// four slot ids up front (independent loads) and the piece count comes from the voxel's segment
-// bounds, so the partial rows are fetched as independent loads, not as a dependent chain.
-template <bool OB = false>
-__global__ __launch_bounds__(kBlock) void vp_fixup_kernel(long long V, int C, int lpr, int groups, int ch,
-                                                          const int *__restrict__ seg_start,
-                                                          const int *__restrict__ slot_voxel,
-                                                          const float *__restrict__ partial, float *__restrict__ out, int ldo) {
+// ------------------------------------------------------------------------------------------------
+// 2d. the same owner-computes gather, written for instruction count.  The generic kernel above runs ~1700 wave-instructions
+// per wave; at 11.4 waves per SIMD and 4 issue cycles per vector instruction that is 77 k cycles = 38 us on its own -- the
+// launch was issue-bound at 4.0 TB/s, not memory-bound.  Here (non-FUSED, tensors below 4 GB):
+//   * every row load / row store is a raw buffer instruction with a 32-bit offset idx * row_bytes + lane_bytes, and a dead
+//     slot (not this wave's, a long run's, outside the list) carries idx = -1 / voxel = -1, whose offset lies beyond
+//     num_records: the load returns zeros and the store is dropped by the hardware -- no predication, no 64-bit address math;
+//   * liveness is decided once, by the lanes that fetched the window's slot_voxel / order entries, and handed to the row
+//     lanes through LDS (9 ds_read_b128 instead of 34 ds_bpermute);
+//   * the segmented sum takes one wave-uniform branch per slot (any row group at a run border?) with a branch-free body.
+// The rare paths (last run longer than the window, long-run workgroups) are out of line.
+// ------------------------------------------------------------------------------------------------
+typedef int vp_i32x4 __attribute__((ext_vector_type(4)));
+typedef float vp_f32x4 __attribute__((ext_vector_type(4)));
+typedef float vp_f32x2 __attribute__((ext_vector_type(2)));
+
+struct VpFastArgs {
+    const int *seg_start, *order, *slot_voxel, *long_list;
+    const void *feats;
+    void *out;
+    const int *gate;
+    unsigned feat_bytes, out_bytes;   // num_records of the two buffers
+    int V, C, lpr, groups, ch, w_nom, ldo, long_cap, nblk_regular, N;
+};
+
+template <bool FB>
+__device__ __forceinline__ float4 vp_buf_load_row(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+    if constexpr (FB) {
+        const vp_f32x2 raw = __builtin_bit_cast(vp_f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+        const vp_bf16x4 q = __builtin_bit_cast(vp_bf16x4, raw);
+        return make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+    } else {
+        const vp_f32x4 v = __builtin_bit_cast(vp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// row of voxel `vox` (-1: dropped by the hardware).  lane_out: byte offset of the lane inside a row.
+template <bool OB, bool ACC>
+__device__ __forceinline__ void vp_buf_emit(__amdgpu_buffer_rsrc_t rsrc, int vox, unsigned row_bytes, unsigned lane_out,
+                                            unsigned pad_off, float4 v) {
+    const unsigned off = (unsigned)vox * row_bytes + lane_out;
+    if constexpr (OB) {
+        const vp_bf16x4 q = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(vp_f32x2, q), rsrc, off, 0, 0);
+        // zeroed padding channels (pad_off = ~0u marks the lanes that own none: their store goes to "voxel -1" and is dropped)
+        const vp_bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        const unsigned poff = pad_off == ~0u ? ~0u - 8u : (unsigned)vox * row_bytes + pad_off;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(vp_f32x2, z), rsrc, poff, 0, 0);
+    } else {
+        if constexpr (ACC) {
+            const vp_f32x4 old = __builtin_bit_cast(vp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+            v.x += old[0]; v.y += old[1]; v.z += old[2]; v.w += old[3];
+        }
+        const vp_f32x4 o = {v.x, v.y, v.z, v.w};
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 0);
+    }
+}
+
+// Rows of the slots [base, base + groups*ch) that still belong to voxel `want` (marked or not), lean form: group g sums slots
+// base + g*ch + k (k ascending) into `acc`; the caller adds the groups' sums in ascending group order.  Returns true when
+// the run ended inside this batch.  `idw`: the wave's LDS index area.  Wave-uniform.
+template <bool FB>
+__device__ __forceinline__ bool vp_fast_run_batch(float4 &acc, int base, int T, int want, int g, int cl, int ch, bool ingroup,
+                                                  int gs, const int *__restrict__ order, const int *__restrict__ slot_voxel,
+                                                  __amdgpu_buffer_rsrc_t f_rsrc, unsigned row_in, unsigned lane_in, int *idw) {
+    const int slot = base + g * ch + cl;
+    const bool index_lane = ingroup && cl < ch;
+    bool mine = false;
+    int my_idx = -1;
+    if (index_lane && slot < T) {
+        mine = slot_voxel[slot] == want;
+        if (mine) my_idx = order[slot];
+    }
+    const bool ended = __ballot(index_lane && !mine) != 0ull;     // (sorted by voxel: `want`'s slots are a prefix of the batch)
+    if (index_lane) idw[g * kChunkMax + cl] = my_idx;
+    const vp_i32x4 *ip = reinterpret_cast<const vp_i32x4 *>(idw + gs * kChunkMax);
+    int idx[kChunkMax];
+#pragma unroll
+    for (int q = 0; q < kChunkMax / 4; ++q) {
+        const vp_i32x4 t = ip[q];
+        idx[4 * q + 0] = t[0]; idx[4 * q + 1] = t[1]; idx[4 * q + 2] = t[2]; idx[4 * q + 3] = t[3];
+    }
+    float4 val[kChunkMax];
+#pragma unroll
+    for (int k = 0; k < kChunkMax; ++k) val[k] = vp_buf_load_row<FB>(f_rsrc, (unsigned)idx[k] * row_in + lane_in);
+#pragma unroll
+    for (int k = 0; k < kChunkMax; ++k)
+        if (k < ch) vacc(acc, val[k]);                            // (rows that are not `want`'s came back as zeros)
+    return ended;
+}
+
+constexpr int kEvStride = 20;    // ints per row group in the LDS image of the window: entries cl = 0 .. ch+1 (<= 18), 16-B rows
+constexpr int kMaxGroups = 10;   // 64 lanes / LPR >= 6
+
+template <bool FB, bool OB, bool ACC>
+__global__ __launch_bounds__(kBlock) void vp_gather_fast_kernel(const VpFastArgs a) {
+    if (a.gate != nullptr && *reinterpret_cast<const volatile int *>(a.gate) != 0) return;
+    // per wave: ev[group][cl] = voxel of slot cb-1+cl if this wave sums it, else -1; idx[group][k] = its point id, else -1;
+    // one more all-dead block for the lanes that belong to no row group
+    __shared__ __attribute__((aligned(16))) int ev_s[kBlock / 64][(kMaxGroups + 1) * kEvStride];
+    __shared__ __attribute__((aligned(16))) int idx_s[kBlock / 64][(kMaxGroups + 1) * kChunkMax];
+    __shared__ float4 red[kBlock / 64][64];
     const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int lpr = a.lpr, groups = a.groups, ch = a.ch;
     const int g = lane / lpr;
     const int cl = lane - g * lpr;
-    const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const long long j = wave * groups + g;
-    const int T = seg_start[V];
-    const long long base = j * ch;
-    if (g >= groups || base + ch >= T || cl >= (C >> 2)) return;   // the last chunk cannot continue
-    const int v_last = slot_voxel[base + ch - 1];
-    const int v_next = slot_voxel[base + ch];
-    const int v_first = slot_voxel[base];
-    const int v_prev = base > 0 ? slot_voxel[base - 1] : -1;
-    if (v_next != v_last) return;                                   // last run ends with this chunk
-    if (v_first == v_last && v_prev == v_last) return;              // middle piece, not the leader
-    const int v = v_last;
-    const long long jl = ((long long)seg_start[v + 1] - 1) / ch;    // chunk holding the voxel's last point
-    float4 sum = *reinterpret_cast<const float4 *>(partial + ((size_t)j * 2 + 1) * C + (size_t)cl * 4);
-    for (long long jj = j + 1; jj <= jl; jj += 4) {
-        float4 p[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            p[u] = (jj + u <= jl) ? *reinterpret_cast<const float4 *>(partial + ((size_t)(jj + u) * 2 + 0) * C + (size_t)cl * 4)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (jj + u <= jl) vacc(sum, p[u]);
+    const bool ingroup = g < groups;
+    const int gs = ingroup ? g : groups;                         // LDS block of the lane: its row group, or the all-dead one
+    const int src_cl = ingroup ? cl : 0;
+    const int cap = groups * ch;
+    const int T = a.seg_start[a.V];
+    int *evw = ev_s[wid], *idw = idx_s[wid];
+    if (lane < kChunkMax) idw[groups * kChunkMax + lane] = -1;   // the all-dead index block
+    const unsigned row_in = (unsigned)a.C * (FB ? 2u : 4u);
+    const unsigned row_out = OB ? (unsigned)a.ldo * 2u : (unsigned)a.C * 4u;
+    const unsigned lane_in = (unsigned)cl * (FB ? 8u : 16u);
+    const unsigned lane_out = (unsigned)cl * (OB ? 8u : 16u);
+    unsigned pad_off = ~0u;
+    if constexpr (OB) {
+        if (cl < ((a.ldo - a.C) >> 2)) pad_off = (unsigned)a.C * 2u + (unsigned)cl * 8u;
     }
-    vp_store_row<OB>(out, v, C, ldo, cl, sum);
+    const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.feats), 0, (int)a.feat_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    // ---------------------------------------------------------------- long runs: one workgroup per voxel at a time
+    if ((int)blockIdx.x >= a.nblk_regular) {
+        const int n_long = min(a.long_list[0], a.long_cap);
+        const int stride = (int)gridDim.x - a.nblk_regular;
+        for (int i = (int)blockIdx.x - a.nblk_regular; i < n_long; i += stride) {      // block-uniform trip count
+            const int v = a.long_list[1 + i];
+            const int b = a.seg_start[v], e = a.seg_start[v + 1];
+            float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int base = b + wid * cap; base < e; base += (kBlock / 64) * cap)
+                vp_fast_run_batch<FB>(racc, base, e, ~v, g, cl, ch, ingroup, gs, a.order, a.slot_voxel, f_rsrc, row_in, lane_in, idw);
+            float4 wsum = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g2 = 0; g2 < groups; ++g2) vacc(wsum, vp_from_lane(racc, g2 * lpr + src_cl));
+            if (g == 0) red[wid][cl] = wsum;
+            __syncthreads();
+            if (wid == 0) {
+                float4 tot = red[0][src_cl];
+#pragma unroll
+                for (int w = 1; w < kBlock / 64; ++w) vacc(tot, red[w][src_cl]);
+                vp_buf_emit<OB, ACC>(o_rsrc, g == 0 ? v : -1, row_out, lane_out, pad_off, tot);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    const int wave = (int)blockIdx.x * (kBlock / 64) + wid;
+
+    // ---------------------------------------------------------------- rows of empty voxels (not in ACC mode)
+    if constexpr (!ACC) {
+        const int ngroups = a.nblk_regular * (kBlock / 64) * groups;
+        const int per = (a.V + ngroups - 1) / ngroups;
+        const int v0 = (wave * groups + (ingroup ? g : 0)) * per;
+        for (int i = 0; i < per; ++i) {                           // uniform trip count
+            const int v = v0 + i;
+            int vz = -1;
+            if (ingroup && v < a.V && a.seg_start[v] == a.seg_start[v + 1]) vz = v;
+            vp_buf_emit<OB, false>(o_rsrc, vz, row_out, lane_out, pad_off, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    }
+    const int s0 = wave * a.w_nom;
+    if (s0 >= T) return;                                         // wave-uniform
+    const int cb = s0 + g * ch;
+    // ---------------------------------------------------------------- the window's entries: lane cl of a group holds slot cb-1+cl
+    const int my_slot = cb - 1 + cl;
+    int my_vox = INT_MIN, my_idx = -1;
+    if (ingroup && cl < ch + 2 && my_slot >= 0 && my_slot < T) {
+        my_vox = a.slot_voxel[my_slot];
+        my_idx = a.order[my_slot];
+    }
+    const int up_vox = __shfl_up(my_vox, 1, 64);
+    const bool in_window = ingroup && cl >= 1 && (cl <= ch || (cl == ch + 1 && g == groups - 1));
+    const unsigned long long start_m = __ballot(in_window && my_vox != up_vox);
+    const unsigned long long nominal_m = __ballot(in_window && my_slot < s0 + a.w_nom);
+    const unsigned long long own_m = start_m & nominal_m;
+    if (own_m == 0ull) return;                                   // one voxel covers the whole range: its owner sums it
+    const int first_lane = __ffsll((long long)own_m) - 1;
+    const int first = s0 + (first_lane / lpr) * ch + (first_lane % lpr) - 1;
+    const unsigned long long tail_start_m = start_m & ~nominal_m;
+    int endw = s0 + cap;
+    if (tail_start_m != 0ull) {
+        const int end_lane = __ffsll((long long)tail_start_m) - 1;
+        endw = s0 + (end_lane / lpr) * ch + (end_lane % lpr) - 1;
+    }
+    // (slots outside the list hold INT_MIN.)  The slot right behind the window counts as live when no run starts in the tail of
+    // the window: the chunk before it then sees its last run continue and hands it to the extension loop below
+    const bool live = my_vox >= 0 && my_slot >= first && (my_slot < endw || (tail_start_m == 0ull && my_slot == s0 + cap));
+    if (ingroup && cl < ch + 2) {
+        evw[g * kEvStride + cl] = live ? my_vox : -1;
+        if (cl >= 1 && cl <= ch) idw[g * kChunkMax + cl - 1] = live ? my_idx : -1;
+    }
+    if (lane < kEvStride) evw[groups * kEvStride + lane] = -1;   // the all-dead block
+    // ---------------------------------------------------------------- all rows of the chunk in flight
+    float4 val[kChunkMax];
+    {
+        const vp_i32x4 *ip = reinterpret_cast<const vp_i32x4 *>(idw + gs * kChunkMax);
+        int idx[kChunkMax];
+#pragma unroll
+        for (int q = 0; q < kChunkMax / 4; ++q) {
+            const vp_i32x4 t = ip[q];
+            idx[4 * q + 0] = t[0]; idx[4 * q + 1] = t[1]; idx[4 * q + 2] = t[2]; idx[4 * q + 3] = t[3];
+        }
+#pragma unroll
+        for (int k = 0; k < kChunkMax; ++k)                       // (entries k >= ch are stale: never added below)
+            val[k] = vp_buf_load_row<FB>(f_rsrc, (unsigned)idx[k] * row_in + lane_in);
+    }
+    int ev[kEvStride];
+    {
+        const vp_i32x4 *ep = reinterpret_cast<const vp_i32x4 *>(evw + gs * kEvStride);
+#pragma unroll
+        for (int q = 0; q < kEvStride / 4; ++q) {
+            const vp_i32x4 t = ep[q];
+            ev[4 * q + 0] = t[0]; ev[4 * q + 1] = t[1]; ev[4 * q + 2] = t[2]; ev[4 * q + 3] = t[3];
+        }
+    }
+    // ---------------------------------------------------------------- segmented sum of the chunk: ev[1 + k] is slot k's voxel
+    float4 head = make_float4(0.f, 0.f, 0.f, 0.f), acc = head;
+    const bool before = ev[0] == ev[1] && ev[1] >= 0;            // the first run began in the previous chunk of this wave
+    bool first_run = true, has_head = false;
+#pragma unroll
+    for (int k = 0; k < kChunkMax; ++k) {
+        if (k < ch) {                                            // uniform
+            if (k > 0) {
+                const bool bnd = ev[k + 1] != ev[k];             // the run of slot k-1 ended
+                if (__ballot(bnd) != 0ull) {                     // wave-uniform branch, branch-free body
+                    const bool to_head = bnd && first_run && before;
+                    head.x = to_head ? acc.x : head.x; head.y = to_head ? acc.y : head.y;
+                    head.z = to_head ? acc.z : head.z; head.w = to_head ? acc.w : head.w;
+                    has_head = has_head || to_head;
+                    vp_buf_emit<OB, ACC>(o_rsrc, (bnd && !to_head) ? ev[k] : -1, row_out, lane_out, pad_off, acc);
+                    acc.x = bnd ? 0.f : acc.x; acc.y = bnd ? 0.f : acc.y; acc.z = bnd ? 0.f : acc.z; acc.w = bnd ? 0.f : acc.w;
+                    first_run = first_run && !bnd;
+                }
+            }
+            vacc(acc, val[k]);
+        }
+    }
+    // the chunk's last run: slot ch-1 is ev[ch]; the slot behind the chunk ev[ch + 1] (ch is uniform but not a constant:
+    // read the two entries back from LDS instead of indexing the register array dynamically)
+    const int last_vox = evw[gs * kEvStride + ch];
+    const int next_vox = evw[gs * kEvStride + ch + 1];
+    const bool after = next_vox == last_vox && last_vox >= 0;    // continues in the next chunk / behind the window
+    const bool last_is_head = first_run && before;
+    bool single = false, has_tail = false;
+    float4 tail = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (last_is_head) { head = acc; has_head = true; single = after; }
+    else if (after) { tail = acc; has_tail = true; }
+    vp_buf_emit<OB, ACC>(o_rsrc, (!last_is_head && !after) ? last_vox : -1, row_out, lane_out, pad_off, acc);
+    // ---------------------------------------------------------------- stitch the runs cut by chunk borders (ascending chunks)
+    const unsigned long long head_m = __ballot(ingroup && has_head && cl == 0);
+    const unsigned long long single_m = __ballot(ingroup && single && cl == 0);
+    const unsigned long long tail_m = __ballot(ingroup && has_tail && cl == 0);
+    if ((head_m | tail_m) == 0ull) return;                        // wave-uniform
+    float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
+    int carry_vox = -1;
+    for (int g2 = 0; g2 < groups; ++g2) {
+        const int l0 = g2 * lpr;
+        if ((head_m >> l0) & 1ull) {
+            vacc(carry, vp_from_lane(head, l0 + src_cl));
+            if (!((single_m >> l0) & 1ull)) {                     // the run ends in this chunk: its row is complete
+                vp_buf_emit<OB, ACC>(o_rsrc, g == 0 ? carry_vox : -1, row_out, lane_out, pad_off, carry);
+                carry_vox = -1;
+            }
+        }
+        if ((tail_m >> l0) & 1ull) {
+            carry = vp_from_lane(tail, l0 + src_cl);
+            carry_vox = evw[g2 * kEvStride + ch];                 // (uniform address: that chunk's last voxel)
+        }
+    }
+    if (carry_vox < 0) return;
+    // ---------------------------------------------------------------- the last run goes on behind the window (<= kLongRun slots)
+    float4 eacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = s0 + cap; base < T; base += cap)
+        if (vp_fast_run_batch<FB>(eacc, base, T, carry_vox, g, cl, ch, ingroup, gs, a.order, a.slot_voxel, f_rsrc, row_in, lane_in, idw))
+            break;
+    for (int g2 = 0; g2 < groups; ++g2) vacc(carry, vp_from_lane(eacc, g2 * lpr + src_cl));
+    vp_buf_emit<OB, ACC>(o_rsrc, g == 0 ? carry_vox : -1, row_out, lane_out, pad_off, carry);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -734,28 +1171,39 @@ int check_common(int B, int N, int C, int X, int Y, int Z) {
 }
 
 struct GatherGeom {
-    bool v2;
-    int lpr, groups, ch;
-    long long nchunks;
+    bool v2;                // the slot-balanced gather covers this channel count
+    int lpr, groups, ch;    // lanes per row, row groups per wave, slots per chunk
+    int w_nom;              // slots between consecutive wave windows (window = groups * ch slots)
 };
 
 GatherGeom gather_geom(long long total_pts, int C) {
     GatherGeom G;
-    G.v2 = false; G.lpr = G.groups = G.ch = 0; G.nchunks = 0;
+    G.v2 = false; G.lpr = G.groups = G.ch = G.w_nom = 0;
     if (C % 4 == 0 && C / 4 <= 64 && C / 4 >= 6) {
         G.v2 = true;
         G.lpr = C / 4;
         G.groups = 64 / G.lpr;
         G.ch = G.lpr - 2 < kChunkMax ? G.lpr - 2 : kChunkMax;
-        G.nchunks = (total_pts + G.ch - 1) / G.ch;
+        static const int ch_env = [] { const char *e = getenv("SGV3D_VP_CH"); return e ? atoi(e) : 0; }();          // (probe knobs)
+        static const int margin_env = [] { const char *e = getenv("SGV3D_VP_MARGIN"); return e ? atoi(e) : -1; }();
+        if (ch_env > 0 && ch_env < G.ch) G.ch = ch_env;
+        const int cap = G.groups * G.ch;
+        // the margin lets the last owned run finish inside the window (same batch of loads) in most waves
+        int margin = cap / 4 < 8 ? cap / 4 : 8;
+        if (margin_env >= 0 && margin_env < cap) margin = margin_env;
+        G.w_nom = cap - margin;
     }
+    (void)total_pts;
     return G;
 }
 
-template <bool FUSED, bool FB = false, bool OB = false>
+// workgroups appended to the gather grid for the plan's long runs (idle ones leave after one load)
+constexpr int kLongBlocks = 1024;
+
+template <bool FUSED, bool FB = false, bool OB = false, bool ACC = false>
 int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const float *feats,
                   const float *prob, const float *ctx, int P, float *out, void *workspace, size_t ws_bytes,
-                  hipStream_t st, int ldo = 0) {
+                  hipStream_t st, int ldo = 0, const int *gate = nullptr) {
     const PlanLayout L = plan_layout(B, N, X, Y);
     const char *base = static_cast<const char *>(plan);
     const int *seg = reinterpret_cast<const int *>(base + L.off_seg);
@@ -763,18 +1211,32 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
     const int *slotvox = reinterpret_cast<const int *>(base + L.off_slotvox);
     const GatherGeom G = gather_geom(L.total, C);
     if (G.v2) {
-        const size_t need = sizeof(float) * (size_t)G.nchunks * 2 * C;
-        if (!workspace || ws_bytes < need)
-            return fail(SGV3D_ENOSPACE, "voxel pooling: workspace has %zu bytes, needs %zu", ws_bytes, need);
-        const long long waves = (G.nchunks + G.groups - 1) / G.groups;
-        const int grid = cdiv(waves, kBlock / 64);
-        float *partial = static_cast<float *>(workspace);
-        hipLaunchKernelGGL((vp_gather2_kernel<FUSED, FB, OB>), dim3(grid), dim3(kBlock), 0, st, L.V, C, G.lpr, G.groups, G.ch,
-                           seg, order, slotvox, feats, prob, ctx, N, P, out, partial, ldo);
-        hipLaunchKernelGGL(vp_fixup_kernel<OB>, dim3(grid), dim3(kBlock), 0, st, L.V, C, G.lpr, G.groups, G.ch, seg, slotvox,
-                           partial, out, ldo);
-        return check_launch(FUSED ? "vp_lift_splat(v2)" : "vp_gather2_kernel");
+        const long long waves = (L.total + G.w_nom - 1) / G.w_nom;
+        const int nblk = cdiv(waves, kBlock / 64);
+        const int nlong = L.long_cap < kLongBlocks ? L.long_cap : kLongBlocks;
+        if constexpr (!FUSED) {
+            // the instruction-lean kernel addresses both tensors with 32-bit byte offsets (dead slots point past the end)
+            const unsigned long long fbytes = (unsigned long long)L.total * C * (FB ? 2 : 4);
+            const unsigned long long obytes = (unsigned long long)L.V * (OB ? ldo * 2 : C * 4);
+            static const bool generic_env = [] { const char *e = getenv("SGV3D_VP_GENERIC"); return e && e[0] == '1'; }();
+            if (fbytes < 0xfff00000ull && obytes < 0xfff00000ull && L.total < 0x7ff00000ll && !generic_env) {
+                VpFastArgs a;
+                a.seg_start = seg; a.order = order; a.slot_voxel = slotvox;
+                a.long_list = reinterpret_cast<const int *>(base + L.off_long);
+                a.feats = feats; a.out = out; a.gate = gate;
+                a.feat_bytes = (unsigned)fbytes; a.out_bytes = (unsigned)obytes;
+                a.V = (int)L.V; a.C = C; a.lpr = G.lpr; a.groups = G.groups; a.ch = G.ch; a.w_nom = G.w_nom; a.ldo = ldo;
+                a.long_cap = L.long_cap; a.nblk_regular = nblk; a.N = N;
+                hipLaunchKernelGGL((vp_gather_fast_kernel<FB, OB, ACC>), dim3(nblk + nlong), dim3(kBlock), 0, st, a);
+                return check_launch("vp_gather_fast_kernel");
+            }
+        }
+        hipLaunchKernelGGL((vp_gather3_kernel<FUSED, FB, OB, ACC>), dim3(nblk + nlong), dim3(kBlock), 0, st, L.V, C, G.lpr,
+                           G.groups, G.ch, G.w_nom, seg, order, slotvox, feats, prob, ctx, N, P, out, ldo,
+                           reinterpret_cast<const int *>(base + L.off_long), L.long_cap, nblk, gate);
+        return check_launch(FUSED ? "vp_lift_splat(v3)" : "vp_gather3_kernel");
     }
+    if constexpr (ACC) return fail(SGV3D_EINVAL, "voxel pooling: the accumulating gather needs 24 <= C <= 256, C %% 4 == 0 (got %d)", C);
     if (FB || OB) return fail(SGV3D_EINVAL, "voxel pooling: bf16 features / output need 24 <= C <= 256, C %% 4 == 0 (got %d)", C);
     const long long waves = (L.V + kVoxPerWave - 1) / kVoxPerWave;
     const int grid = cdiv(waves, kBlock / 64);
@@ -798,20 +1260,6 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
 // ================================================================================================
 // C ABI
 // ================================================================================================
-extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
-                                           int num_voxel_x, int num_voxel_y, int num_voxel_z,
-                                           const int32_t *geom_xyz, const float *input_features,
-                                           float *output_features, int32_t *pos_memo, void *stream) {
-    if (int rc = check_common(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, num_voxel_z)) return rc;
-    SGV3D_REQUIRE(geom_xyz && input_features && output_features, "voxel_pooling_forward: null pointer");
-    const long long total = (long long)batch_size * num_points;
-    const int grid = cdiv(total, kAtomicPts);
-    hipLaunchKernelGGL(vp_atomic_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), total, num_points,
-                       num_channels, num_voxel_x, num_voxel_y, num_voxel_z, geom_xyz, input_features,
-                       output_features, pos_memo);
-    return check_launch("vp_atomic_kernel");
-}
-
 extern "C" size_t sgv3d_voxel_plan_bytes(int batch_size, int num_points, int num_voxel_x, int num_voxel_y) {
     if (batch_size <= 0 || num_points <= 0 || num_voxel_x <= 0 || num_voxel_y <= 0) return 0;
     return plan_layout(batch_size, num_points, num_voxel_x, num_voxel_y).bytes;
@@ -821,11 +1269,11 @@ namespace {
 
 int plan_build_impl(int batch_size, int num_points, int num_voxel_x, int num_voxel_y, int num_voxel_z,
                     const int32_t *geom_xyz, int32_t *pos_memo, void *plan, size_t plan_bytes, int sort_segments,
-                    bool cached, hipStream_t st, const char *what) {
+                    bool cached, hipStream_t st, const char *what, bool compare_done = false) {
     if (int rc = check_common(batch_size, num_points, 1, num_voxel_x, num_voxel_y, num_voxel_z)) return rc;
     SGV3D_REQUIRE(geom_xyz && plan, "%s: null pointer", what);
     SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0, "%s: plan must be 16-B aligned", what);
-    SGV3D_REQUIRE(!cached || (reinterpret_cast<uintptr_t>(geom_xyz) & 15) == 0, "%s: geom_xyz must be 16-B aligned", what);
+    SGV3D_REQUIRE(!cached || compare_done || (reinterpret_cast<uintptr_t>(geom_xyz) & 15) == 0, "%s: geom_xyz must be 16-B aligned", what);
     const PlanLayout L = plan_layout(batch_size, num_points, num_voxel_x, num_voxel_y);
     if (plan_bytes < L.bytes) return fail(SGV3D_ENOSPACE, "%s: plan has %zu bytes, needs %zu", what, plan_bytes, L.bytes);
     char *base = static_cast<char *>(plan);
@@ -837,9 +1285,10 @@ int plan_build_impl(int batch_size, int num_points, int num_voxel_x, int num_vox
     int32_t *gcopy = reinterpret_cast<int32_t *>(base + L.off_geom);
     const int *dirty = cached ? &hdr->dirty : nullptr;
     const int p[7] = {kPlanMagic, batch_size, num_points, num_voxel_x, num_voxel_y, num_voxel_z, sort_segments ? 1 : 0};
-    if (cached) {
+    if (cached && !compare_done) {
         const long long n_ints = L.total * 3;
-        const int cgrid = (int)(cdiv(n_ints / 4 + 1, kBlock) < 1024 ? cdiv(n_ints / 4 + 1, kBlock) : 1024);
+        // (<= 256 workgroups: every workgroup ends with a ticket atomic on one address; 1024 of them took 28 us for 11 MB)
+        const int cgrid = (int)(cdiv(n_ints / 4 + 1, kBlock) < 256 ? cdiv(n_ints / 4 + 1, kBlock) : 256);
         hipLaunchKernelGGL(vp_geom_compare_kernel, dim3(cgrid), dim3(kBlock), 0, st, n_ints, geom_xyz, gcopy, hdr, p[0],
                            p[1], p[2], p[3], p[4], p[5], p[6]);
     }
@@ -850,11 +1299,13 @@ int plan_build_impl(int batch_size, int num_points, int num_voxel_x, int num_vox
     hipLaunchKernelGGL(vp_count_kernel, dim3(pgrid), dim3(kBlock), 0, st, L.total, num_points, num_voxel_x,
                        num_voxel_y, num_voxel_z, geom_xyz, pos_memo, cur, dirty, cached ? gcopy : nullptr);
     hipLaunchKernelGGL(vp_scan_local_kernel, dim3(L.nblk), dim3(kBlock), 0, st, L.V, cur, seg, blk, dirty);
-    hipLaunchKernelGGL(vp_scan_top_kernel, dim3(1), dim3(kBlock), 0, st, L.nblk, blk, dirty);
+    int *long_list = reinterpret_cast<int *>(base + L.off_long);
+    hipLaunchKernelGGL(vp_scan_top_kernel, dim3(1), dim3(kBlock), 0, st, L.nblk, blk, dirty, long_list);
     hipLaunchKernelGGL(vp_scan_add_kernel, dim3(cdiv(L.V + 1, kBlock)), dim3(kBlock), 0, st, L.V, L.nblk, blk,
                        seg, cur, dirty);
+    hipLaunchKernelGGL(vp_long_list_kernel, dim3(cdiv(L.V, kBlock)), dim3(kBlock), 0, st, L.V, seg, long_list, L.long_cap, dirty);
     hipLaunchKernelGGL(vp_fill_kernel, dim3(pgrid), dim3(kBlock), 0, st, L.total, num_points, num_voxel_x,
-                       num_voxel_y, num_voxel_z, geom_xyz, cur, order, reinterpret_cast<int *>(base + L.off_slotvox), dirty);
+                       num_voxel_y, num_voxel_z, geom_xyz, cur, order, reinterpret_cast<int *>(base + L.off_slotvox), dirty, seg);
     if (sort_segments) {
         const int g_wave = (int)(L.V / 4 < 4096 ? (L.V + 3) / 4 : 4096);
         hipLaunchKernelGGL((vp_sort_wave_kernel<1>), dim3(g_wave), dim3(kBlock), 0, st, L.V, seg, order, 1, dirty);
@@ -896,6 +1347,238 @@ extern "C" int sgv3d_voxel_plan_build_cached(int batch_size, int num_points, int
                            plan_bytes, sort_segments, true, as_stream(stream), "voxel_plan_build_cached");
 }
 
+// ================================================================================================
+// Level-1 drop-in: the symbol the reference's pybind wrapper reaches (INTEGRATION.md level 1)
+// ================================================================================================
+namespace {
+
+// compare geom_xyz with the copy the cached plan holds (-> PlanHeader::dirty, as vp_geom_compare_kernel) and write the
+// pos_memo rows of the kept points ((b, y, x), voxel_pooling_forward_cuda.cu:25-28) in the same pass over geom_xyz.
+// One point per thread and iteration; <= 256 workgroups (each ends with one ticket atomic).
+__global__ __launch_bounds__(kBlock) void vp_level1_prologue_kernel(long long total_pts, int N, int X, int Y, int Z,
+                                                                    const int32_t *__restrict__ geom,
+                                                                    const int32_t *__restrict__ copy,
+                                                                    int32_t *__restrict__ pos_memo, PlanHeader *__restrict__ hdr,
+                                                                    int *__restrict__ host_flag, int p0, int p1, int p2, int p3,
+                                                                    int p4, int p5, int p6) {
+    __shared__ int any_s;
+    if (threadIdx.x == 0) any_s = 0;
+    __syncthreads();
+    bool diff = false;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long pt = (long long)blockIdx.x * kBlock + threadIdx.x; pt < total_pts; pt += stride) {
+        const int x = geom[pt * 3 + 0], y = geom[pt * 3 + 1], z = geom[pt * 3 + 2];
+        diff |= (x != copy[pt * 3 + 0]) | (y != copy[pt * 3 + 1]) | (z != copy[pt * 3 + 2]);
+        if (pos_memo != nullptr && x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {
+            pos_memo[pt * 3 + 0] = (int)(pt / N);
+            pos_memo[pt * 3 + 1] = y;
+            pos_memo[pt * 3 + 2] = x;
+        }
+    }
+    if (diff) any_s = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (any_s) atomicOr(&hdr->diff, 1);
+        __threadfence();
+        const int t = atomicAdd(&hdr->ticket, 1);
+        if (t == (int)gridDim.x - 1) {
+            __threadfence();
+            const int d = atomicOr(&hdr->diff, 0);
+            const int *q = hdr->params;
+            const bool same = q[0] == p0 && q[1] == p1 && q[2] == p2 && q[3] == p3 && q[4] == p4 && q[5] == p5 && q[6] == p6;
+            const int dirty = (d != 0 || !same) ? 1 : 0;
+            hdr->dirty = dirty;
+            hdr->diff = 0;
+            hdr->ticket = 0;
+            // sticky note to the host: a later call enqueues the (device-gated) rebuild when it sees it
+            if (dirty && host_flag != nullptr) __hip_atomic_store(host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// the atomic scatter as the fallback of a cached-plan call: runs only while *gate != 0 (geom_xyz is not the plan's)
+__global__ __launch_bounds__(kBlock) void vp_atomic_gated_kernel(
+    long long total_pts, int N, int C, int X, int Y, int Z, const int32_t *__restrict__ geom,
+    const float *__restrict__ feats, float *__restrict__ out, const int *__restrict__ gate) {
+    if (*reinterpret_cast<const volatile int *>(gate) == 0) return;
+    __shared__ int vid_s[kAtomicPts];
+    const int tid = threadIdx.x;
+    const long long p0 = (long long)blockIdx.x * kAtomicPts;
+    if (tid < kAtomicPts) {
+        const long long pt = p0 + tid;
+        int v = -1;
+        if (pt < total_pts) {
+            int x, y;
+            v = voxel_of_point(geom, pt, (int)(pt / N), X, Y, Z, x, y);
+        }
+        vid_s[tid] = v;
+    }
+    __syncthreads();
+    const int nelem = kAtomicPts * C;
+    const float *f = feats + (size_t)p0 * C;
+    for (int e = tid; e < nelem; e += kBlock) {
+        const int pl = e / C;
+        const int v = vid_s[pl];
+        if (v >= 0) __hip_atomic_fetch_add(out + (size_t)v * C + (e - pl * C), f[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Plans of the drop-in entry, one per (device, stream, sizes).  The C ABI otherwise owns no memory; this entry has to (the
+// reference's signature has no room for a plan), so it is bounded (kLevel1Max entries, least recently used evicted),
+// can be emptied (sgv3d_voxel_pooling_cache_clear) and switched off (SGV3D_VP_LEVEL1_CACHE=0: always the atomic scatter).
+struct Level1Entry {
+    int dev; hipStream_t st; int B, N, X, Y, Z;
+    void *plan; size_t plan_bytes;
+    int *host_flag;          // pinned, device-visible: set by the prologue kernel when geom_xyz is not the plan's
+    int *flag_dev;           // the same word as the device addresses it
+    bool need_build;         // host-side: enqueue the (device-gated) build with the next call
+    unsigned long long last_use;
+};
+constexpr int kLevel1Max = 8;
+std::mutex g_l1_mutex;
+std::vector<Level1Entry> g_l1;
+unsigned long long g_l1_clock = 0;
+unsigned long long g_l1_stats[4] = {0, 0, 0, 0};     // calls, planned launches, atomic-only calls, builds enqueued
+
+bool level1_enabled() {
+    static const bool v = [] { const char *e = getenv("SGV3D_VP_LEVEL1_CACHE"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
+void level1_free(Level1Entry &e) {
+    int cur = 0;
+    hipGetDevice(&cur);
+    hipSetDevice(e.dev);
+    if (e.plan) hipFree(e.plan);
+    if (e.host_flag) hipHostFree(e.host_flag);
+    hipSetDevice(cur);
+}
+
+int launch_atomic(int B, int N, int C, int X, int Y, int Z, const int32_t *geom, const float *feats, float *out,
+                  int32_t *pos_memo, hipStream_t st) {
+    const long long total = (long long)B * N;
+    hipLaunchKernelGGL(vp_atomic_kernel, dim3(cdiv(total, kAtomicPts)), dim3(kBlock), 0, st, total, N, C, X, Y, Z, geom, feats,
+                       out, pos_memo);
+    return check_launch("vp_atomic_kernel");
+}
+
+}  // namespace
+
+extern "C" int sgv3d_voxel_pooling_forward_atomic(int batch_size, int num_points, int num_channels,
+                                                  int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                                  const int32_t *geom_xyz, const float *input_features,
+                                                  float *output_features, int32_t *pos_memo, void *stream) {
+    if (int rc = check_common(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, num_voxel_z)) return rc;
+    SGV3D_REQUIRE(geom_xyz && input_features && output_features, "voxel_pooling_forward: null pointer");
+    return launch_atomic(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, num_voxel_z, geom_xyz,
+                         input_features, output_features, pos_memo, as_stream(stream));
+}
+
+extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
+                                           int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                           const int32_t *geom_xyz, const float *input_features,
+                                           float *output_features, int32_t *pos_memo, void *stream) {
+    const int B = batch_size, N = num_points, C = num_channels, X = num_voxel_x, Y = num_voxel_y, Z = num_voxel_z;
+    if (int rc = check_common(B, N, C, X, Y, Z)) return rc;
+    SGV3D_REQUIRE(geom_xyz && input_features && output_features, "voxel_pooling_forward: null pointer");
+    hipStream_t st = as_stream(stream);
+    const GatherGeom G = gather_geom((long long)B * N, C);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(input_features) | reinterpret_cast<uintptr_t>(output_features)) & 15) == 0;
+    std::lock_guard<std::mutex> lock(g_l1_mutex);
+    g_l1_stats[0]++;
+    if (!level1_enabled() || !G.v2 || !aligned) {
+        g_l1_stats[2]++;
+        return launch_atomic(B, N, C, X, Y, Z, geom_xyz, input_features, output_features, pos_memo, st);
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    int dev = 0;
+    hipGetDevice(&dev);
+    Level1Entry *e = nullptr;
+    for (auto &c : g_l1)
+        if (c.dev == dev && c.st == st && c.B == B && c.N == N && c.X == X && c.Y == Y && c.Z == Z) e = &c;
+    const PlanLayout L = plan_layout(B, N, X, Y);
+    if (e == nullptr) {
+        if (capturing) {            // no allocation inside a stream capture: the plain scatter is always right
+            g_l1_stats[2]++;
+            return launch_atomic(B, N, C, X, Y, Z, geom_xyz, input_features, output_features, pos_memo, st);
+        }
+        if ((int)g_l1.size() >= kLevel1Max) {
+            size_t old = 0;
+            for (size_t i = 1; i < g_l1.size(); ++i)
+                if (g_l1[i].last_use < g_l1[old].last_use) old = i;
+            level1_free(g_l1[old]);
+            g_l1.erase(g_l1.begin() + old);
+        }
+        Level1Entry n{};
+        n.dev = dev; n.st = st; n.B = B; n.N = N; n.X = X; n.Y = Y; n.Z = Z;
+        n.plan_bytes = L.bytes;
+        if (hipMalloc(&n.plan, L.bytes) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&n.host_flag), sizeof(int), hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            level1_free(n);
+            g_l1_stats[2]++;
+            return launch_atomic(B, N, C, X, Y, Z, geom_xyz, input_features, output_features, pos_memo, st);
+        }
+        *n.host_flag = 0;
+        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&n.flag_dev), n.host_flag, 0) != hipSuccess) n.flag_dev = nullptr;
+        n.need_build = true;
+        hipLaunchKernelGGL(vp_plan_init_kernel, dim3(1), dim3(kBlock), 0, st,
+                           reinterpret_cast<PlanHeader *>(static_cast<char *>(n.plan) + L.off_hdr));
+        g_l1.push_back(n);
+        e = &g_l1.back();
+    }
+    e->last_use = ++g_l1_clock;
+    char *base = static_cast<char *>(e->plan);
+    PlanHeader *hdr = reinterpret_cast<PlanHeader *>(base + L.off_hdr);
+    const int32_t *gcopy = reinterpret_cast<const int32_t *>(base + L.off_geom);
+    const int p[7] = {kPlanMagic, B, N, X, Y, Z, 1};
+    int *flag_dev = e->flag_dev;
+    const long long total = (long long)B * N;
+    const int pgrid = (int)(cdiv(total, kBlock) < 256 ? cdiv(total, kBlock) : 256);
+    hipLaunchKernelGGL(vp_level1_prologue_kernel, dim3(pgrid), dim3(kBlock), 0, st, total, N, X, Y, Z, geom_xyz, gcopy, pos_memo,
+                       hdr, flag_dev, p[0], p[1], p[2], p[3], p[4], p[5], p[6]);
+    // the host learns about a changed geom_xyz one or more calls late (it never waits for the device); until then such
+    // calls take the gated scatter below, which is correct for any geom_xyz
+    if (__atomic_load_n(e->host_flag, __ATOMIC_RELAXED) != 0) e->need_build = true;
+    if (e->need_build || capturing) {
+        // gated build (its kernels return at once when the prologue found the plan up to date), then the gather on a plan
+        // that is right either way.  Also the form a stream capture records: valid for whatever geom_xyz a replay sees.
+        if (int rc = plan_build_impl(B, N, X, Y, Z, geom_xyz, nullptr, e->plan, e->plan_bytes, 1, true, st,
+                                     "voxel_pooling_forward(level-1 plan)", /*compare_done=*/true)) return rc;
+        if (!capturing) {
+            e->need_build = false;
+            __atomic_store_n(e->host_flag, 0, __ATOMIC_RELAXED);
+        }
+        g_l1_stats[3]++;
+        g_l1_stats[1]++;
+        return launch_gather<false, false, false, true>(B, N, C, X, Y, e->plan, input_features, nullptr, nullptr, 1,
+                                                        output_features, nullptr, 0, st, 0, nullptr);
+    }
+    g_l1_stats[1]++;
+    if (int rc = launch_gather<false, false, false, true>(B, N, C, X, Y, e->plan, input_features, nullptr, nullptr, 1,
+                                                          output_features, nullptr, 0, st, 0, &hdr->dirty)) return rc;
+    hipLaunchKernelGGL(vp_atomic_gated_kernel, dim3(cdiv(total, kAtomicPts)), dim3(kBlock), 0, st, total, N, C, X, Y, Z,
+                       geom_xyz, input_features, output_features, &hdr->dirty);
+    return check_launch("voxel_pooling_forward(level-1)");
+}
+
+extern "C" int sgv3d_voxel_pooling_cache_clear(void) {
+    std::lock_guard<std::mutex> lock(g_l1_mutex);
+    hipDeviceSynchronize();
+    for (auto &e : g_l1) level1_free(e);
+    g_l1.clear();
+    return SGV3D_OK;
+}
+
+extern "C" int sgv3d_voxel_pooling_cache_stats(unsigned long long *out4) {
+    SGV3D_REQUIRE(out4 != nullptr, "voxel_pooling_cache_stats: null pointer");
+    std::lock_guard<std::mutex> lock(g_l1_mutex);
+    for (int i = 0; i < 4; ++i) out4[i] = g_l1_stats[i];
+    return SGV3D_OK;
+}
+
 extern "C" size_t sgv3d_voxel_plan_stats_offset(int batch_size, int num_points, int num_voxel_x, int num_voxel_y) {
     if (batch_size <= 0 || num_points <= 0 || num_voxel_x <= 0 || num_voxel_y <= 0) return 0;
     return plan_layout(batch_size, num_points, num_voxel_x, num_voxel_y).off_hdr;
@@ -903,8 +1586,7 @@ extern "C" size_t sgv3d_voxel_plan_stats_offset(int batch_size, int num_points, 
 
 extern "C" size_t sgv3d_voxel_pooling_workspace_bytes(int batch_size, int num_points, int num_channels) {
     if (batch_size <= 0 || num_points <= 0 || num_channels <= 0) return 0;
-    const GatherGeom G = gather_geom((long long)batch_size * num_points, num_channels);
-    return G.v2 ? sizeof(float) * (size_t)G.nchunks * 2 * num_channels : 16;
+    return 16;      // the owner-computes gather needs none (round 2 staged partial rows here); kept for ABI compatibility
 }
 
 extern "C" int sgv3d_voxel_pooling_forward_planned(int batch_size, int num_points, int num_channels,

@@ -205,11 +205,11 @@ class VoxelPooling(Function):
             # node, which faults on replay on this ROCm once the host allocates between replays
             output_features = input_features.new_full((batch_size, Y, X, num_channels), 0.0)
             with torch.cuda.device(input_features.device), hip_ops.prof("voxel_pooling_atomic"):
-                rc = lib.sgv3d_voxel_pooling_forward(batch_size, num_points, num_channels, X, Y, Z,
-                                                     geom_xyz.data_ptr(), input_features.data_ptr(),
-                                                     output_features.data_ptr(), _lib.ptr(pos_memo),
-                                                     _lib.stream_handle(input_features.device))
-            _lib.check(rc, "sgv3d_voxel_pooling_forward")
+                rc = lib.sgv3d_voxel_pooling_forward_atomic(batch_size, num_points, num_channels, X, Y, Z,
+                                                            geom_xyz.data_ptr(), input_features.data_ptr(),
+                                                            output_features.data_ptr(), _lib.ptr(pos_memo),
+                                                            _lib.stream_handle(input_features.device))
+            _lib.check(rc, "sgv3d_voxel_pooling_forward_atomic")
         elif needs_grad or not CACHE_PLANS or geom_xyz.data_ptr() % 16 != 0:
             # (the cached build compares geom_xyz with 16-byte loads: a contiguous slice such as geom[1:] whose storage
             # offset is not a multiple of 16 bytes -- accepted by the reference extension -- takes the uncached build)

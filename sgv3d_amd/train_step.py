@@ -143,7 +143,9 @@ class DataParallelAdamW:
         """Launch a bucket's all-reduce from inside backward, as soon as the last of its parameters has accumulated its
         gradient (post-accumulate-grad hooks; buckets are filled in backward order, so the first collectives run under
         the rest of the backward pass like DDP's).  A bucket holding a parameter that receives no gradient in a step
-        never completes; ``all_reduce_grads`` / ``step`` launch whatever is still missing.
+        never completes in the first step (``all_reduce_grads`` / ``step`` launch whatever is still missing); the set of such
+        parameters is learned from that step and not waited for afterwards (every rank sees the same set: it follows from
+        the model's flags, not from the data).
 
         Contract: ONE backward per optimiser step.  The per-bucket counters are re-armed by ``zero_grad`` /
         ``all_reduce_grads`` / ``step``; a second backward before the step (gradient accumulation) would add local
@@ -152,19 +154,34 @@ class DataParallelAdamW:
         set of parameters that receive a gradient differs between ranks (a bucket that completes out of order waits
         for ``all_reduce_grads``)."""
         self._hooks = []
+        self._unused = set()          # ids of parameters that got no gradient in the first step (learned once)
+        self._learned = False
+        self._fired = set()
         self._arm()
         for bi, (_, _, entries) in enumerate(self.flat.buckets):
             for p, _, _ in entries:
-                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, bi=bi: self._on_grad(bi)))
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, bi=bi: self._on_grad(bi, id(_p))))
         return self
 
     def _arm(self):
         self._early = {}
-        self._left = [len(entries) for _, _, entries in self.flat.buckets]
+        self._left = [sum(1 for p, _, _ in entries if id(p) not in self._unused) for _, _, entries in self.flat.buckets]
+        self._hold = set()            # buckets kept for all_reduce_grads this step (an "unused" parameter fired after all)
         self._next_early = 0
+        self._fired = set()
 
-    def _on_grad(self, bi):
+    def _on_grad(self, bi, pid):
         import torch.distributed as dist
+        self._fired.add(pid)
+        if pid in self._unused:
+            # not counted in _left: a parameter that had no gradient in the first step (assist_layer without
+            # is_train_height, lss_fpn.py:459,493-495) got one now
+            if bi in self._early:
+                raise _lib.SGV3DError("overlap_with_backward: a parameter that received no gradient in the first step got one "
+                                      "after its bucket's all-reduce was launched; call overlap_with_backward() again after "
+                                      "changing which parameters train")
+            self._hold.add(bi)
+            return
         self._left[bi] -= 1
         if self._left[bi] < 0:
             raise _lib.SGV3DError("overlap_with_backward: a second backward ran before step(); the bucket all-reduces of "
@@ -172,7 +189,8 @@ class DataParallelAdamW:
                                   "call step() / zero_grad() between backwards)")
         if self._collectives():
             # fixed order: launch every complete bucket from the front of the queue
-            while self._next_early < len(self._left) and self._left[self._next_early] == 0:
+            while (self._next_early < len(self._left) and self._left[self._next_early] == 0
+                   and self._next_early not in self._hold):
                 i = self._next_early
                 self._early[i] = dist.all_reduce(self.flat.buckets[i][1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self._next_early += 1
@@ -188,6 +206,11 @@ class DataParallelAdamW:
                 self._pending.append(early[bi] if bi in early else
                                      dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         if hasattr(self, '_left'):
+            if not self._learned and self._fired:
+                # parameters without a gradient in the first step never complete their bucket (DDP's "unused parameters"):
+                # from now on they are not waited for.  Their (zero) gradient views still travel with the bucket.
+                self._unused = {id(p) for _, _, entries in self.flat.buckets for p, _, _ in entries} - self._fired
+                self._learned = True
             self._arm()
 
     def step(self, lr=None):

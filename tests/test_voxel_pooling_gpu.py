@@ -24,8 +24,20 @@ def _run_abi(hip, geom, feats, voxel_num, mode, sort=True):
     st = hip.stream_handle()
     if mode == "atomic":
         out = torch.zeros(B, Y, X, C, device=DEV)
+        hip.check(lib.sgv3d_voxel_pooling_forward_atomic(B, N, C, X, Y, Z, g.data_ptr(), f.data_ptr(), out.data_ptr(),
+                                                         pm.data_ptr(), st), "atomic")
+    elif mode == "level1":
+        # the drop-in symbol the reference's wrapper reaches: the first call builds the library-owned plan, the second
+        # one runs the steady-state form (device-side compare + gated gather); both must give the same answer
+        first = torch.zeros(B, Y, X, C, device=DEV)
+        pm0 = torch.full((B, N, 3), -1, dtype=torch.int32, device=DEV)
+        hip.check(lib.sgv3d_voxel_pooling_forward(B, N, C, X, Y, Z, g.data_ptr(), f.data_ptr(), first.data_ptr(),
+                                                  pm0.data_ptr(), st), "level1 (first call)")
+        out = torch.zeros(B, Y, X, C, device=DEV)
         hip.check(lib.sgv3d_voxel_pooling_forward(B, N, C, X, Y, Z, g.data_ptr(), f.data_ptr(), out.data_ptr(),
-                                                  pm.data_ptr(), st), "atomic")
+                                                  pm.data_ptr(), st), "level1 (steady state)")
+        torch.cuda.synchronize()
+        assert torch.equal(first, out) and torch.equal(pm0, pm)
     else:
         nbytes = lib.sgv3d_voxel_plan_bytes(B, N, X, Y)
         plan = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
@@ -41,7 +53,7 @@ def _run_abi(hip, geom, feats, voxel_num, mode, sort=True):
 
 
 @pytest.mark.parametrize("name", VP_CASES)
-@pytest.mark.parametrize("mode", ["atomic", "planned"])
+@pytest.mark.parametrize("mode", ["atomic", "planned", "level1"])
 def test_golden_exact(hip, golden, name, mode):
     vp = golden["voxel_pooling"]
     out, pm = _run_abi(hip, vp[f"{name}/geom_xyz"], vp[f"{name}/feats"], vp[f"{name}/voxel_num"], mode)
@@ -58,7 +70,7 @@ def test_golden_randn_tolerance(hip, golden, mode):
 
 
 @pytest.mark.parametrize("C", [80, 87, 4, 1, 260])
-@pytest.mark.parametrize("mode", ["atomic", "planned"])
+@pytest.mark.parametrize("mode", ["atomic", "planned", "level1"])
 def test_random_vs_oracle_exact(hip, C, mode):
     """Ragged / colliding / out-of-range indices, channel counts incl. C%4!=0 and rows wider than a wave."""
     rng = np.random.default_rng(C)
@@ -125,7 +137,7 @@ def _cfg2_geom(golden):
     return gi[None], vn
 
 
-@pytest.mark.parametrize("mode", ["atomic", "planned"])
+@pytest.mark.parametrize("mode", ["atomic", "planned", "level1"])
 def test_cfg2_full_size_properties(hip, golden, mode):
     """BASELINE cfg-2 size (N=466 560, C=80, 256x256): exact vs the oracle on integer-valued features,
     plus size-independent properties: linearity and conservation of mass."""
@@ -310,7 +322,127 @@ def test_random_geometry_fuzz_vs_oracle(hip, seed):
     geom = geom.astype(np.int32)
     feats = rng.integers(-4, 5, size=(B, N, C)).astype(np.float32)
     ref_out, ref_pm = VPO.forward(geom, feats, (X, Y, Z))
-    for mode in ("atomic", "planned"):
+    for mode in ("atomic", "planned", "level1"):
         out, pm = _run_abi(hip, geom, feats, (X, Y, Z), mode)
         assert np.array_equal(out, ref_out), (seed, mode, B, N, C, X, Y, Z)
         assert np.array_equal(pm.reshape(ref_pm.shape), ref_pm), (seed, mode)
+
+
+# ------------------------------------------------------------------------------------------------ owner-computes gather
+@pytest.mark.parametrize("C", [80, 64, 24, 88, 256])
+def test_gather_runs_cut_by_chunk_and_wave_borders(hip, C):
+    """vp_gather3_kernel: voxel populations chosen around every border of its decomposition -- one chunk (<= 16 slots), one
+    wave range (groups x ch slots: 48 at C=80, 56 at C=64, 40 at C=24, 32 at C=88, 16 at C=256), kLongRun = 256 (longer runs
+    go to the long-run workgroups), several ranges, and thousands of points -- in shuffled point order, two samples, empty
+    voxels between them.  Integer-valued features: exact against the oracle; output fully written (NaN-prefilled)."""
+    lens = [1, 2, 15, 16, 17, 31, 32, 33, 39, 40, 41, 47, 48, 49, 55, 56, 57, 95, 96, 97, 255, 256, 257, 258, 300, 511, 513,
+            1000, 4999, 1, 1, 3, 64, 128]
+    X, Y, Z = len(lens) + 7, 3, 1
+    rng = np.random.default_rng(C)
+    geoms = []
+    for b in range(2):
+        cells = rng.permutation(X * Y)[:len(lens)]                       # which voxel gets which population
+        vox = np.concatenate([np.full(n, c) for c, n in zip(cells, lens)] + [np.full(200, -1)])
+        rng.shuffle(vox)
+        gx = np.where(vox >= 0, vox % X, -3)
+        geoms.append(np.stack([gx, np.where(vox >= 0, vox // X, 0), np.zeros_like(vox)], -1))
+    geom = np.stack(geoms).astype(np.int32)
+    feats = rng.integers(-4, 5, size=(2, geom.shape[1], C)).astype(np.float32)
+    ref, pm_ref = VPO.forward(geom, feats, (X, Y, Z))
+    for mode in ("planned", "level1"):
+        out, pm = _run_abi(hip, geom, feats, (X, Y, Z), mode)
+        assert np.array_equal(out, ref), (C, mode)
+        assert np.array_equal(pm.reshape(pm_ref.shape), pm_ref)
+
+
+def test_gather_variants_agree_on_cut_runs(hip):
+    """The fused lift-splat form, the bf16-feature form and the bf16-output form of the gather on the same cut / long runs."""
+    from sgv3d_amd.ops.voxel_pooling import VoxelPlan
+    rng = np.random.default_rng(9)
+    B, D, P, C, X, Y = 1, 40, 700, 80, 9, 5
+    v = rng.choice(X * Y, size=(B, D * P), p=np.r_[[0.45, 0.2, 0.1], np.full(X * Y - 3, 0.25 / (X * Y - 3))])
+    geom = torch.from_numpy(np.stack([v % X, v // X, np.zeros_like(v)], -1).astype(np.int32)).to(DEV)
+    prob = torch.from_numpy(rng.integers(0, 3, size=(B, D, P)).astype(np.float32)).to(DEV)
+    ctx = torch.from_numpy(rng.integers(-4, 5, size=(B, P, C)).astype(np.float32)).to(DEV)
+    lifted = (prob[..., None] * ctx[:, None]).reshape(B, D * P, C).contiguous()
+    plan = VoxelPlan(geom, (X, Y, 1))
+    want = plan.pool(lifted)
+    ref, _ = VPO.forward(geom.cpu().numpy(), lifted.cpu().numpy(), (X, Y, 1))
+    assert np.array_equal(want.permute(0, 3, 1, 2).cpu().numpy(), ref)                # a voxel with ~12 600 points among them
+    assert torch.equal(plan.lift_splat(prob, ctx), want)
+    got_b = plan.pool(lifted.bfloat16())                                               # small integers: exact in bf16
+    assert torch.equal(got_b, want)
+    got_ob = plan.pool(lifted.bfloat16(), out_bf16_ld=96)
+    assert torch.equal(got_ob[..., :C].float(), want.bfloat16().float()) and float(got_ob[..., C:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ level-1 drop-in entry
+def _level1(hip, g, f, out, pm, X, Y, Z):
+    lib = hip.load()
+    B, N, C = f.shape
+    hip.check(lib.sgv3d_voxel_pooling_forward(B, N, C, X, Y, Z, g.data_ptr(), f.data_ptr(), out.data_ptr(),
+                                              None if pm is None else pm.data_ptr(), hip.stream_handle()), "level1")
+
+
+def _l1_stats(hip):
+    import ctypes
+    buf = (ctypes.c_ulonglong * 4)()
+    hip.check(hip.load().sgv3d_voxel_pooling_cache_stats(buf), "stats")
+    return list(buf)
+
+
+def test_level1_entry_accumulates_and_follows_geometry_changes(hip):
+    """sgv3d_voxel_pooling_forward as the reference's wrapper uses it: rows are ADDED to output_features and empty voxels
+    left alone (atomicAdd semantics, voxel_pooling_forward_cuda.cu:30-33); a changed geom_xyz is served correctly at once
+    (gated scatter) and the library-owned plan follows it a call later; pos_memo every time."""
+    hip.check(hip.load().sgv3d_voxel_pooling_cache_clear(), "clear")
+    rng = np.random.default_rng(21)
+    B, N, C, X, Y, Z = 2, 20011, 80, 37, 29, 2
+    mk = lambda: rng.integers(-2, 40, size=(B, N, 3)).astype(np.int32)
+    ga, gb = mk(), mk()
+    ga[..., 2], gb[..., 2] = rng.integers(-1, 3, size=(B, N)), rng.integers(0, 2, size=(B, N))
+    feats = rng.integers(-4, 5, size=(B, N, C)).astype(np.float32)
+    f = torch.from_numpy(feats).to(DEV)
+    refs = {id(g): VPO.forward(g, feats, (X, Y, Z)) for g in (ga, gb)}
+    dev = {id(g): torch.from_numpy(g).to(DEV) for g in (ga, gb)}
+    s0 = _l1_stats(hip)
+    for step, g in enumerate((ga, ga, gb, gb, gb, ga, ga, ga)):
+        out = torch.ones(B, Y, X, C, device=DEV)                          # NOT zero: the entry accumulates
+        pm = torch.full((B, N, 3), -1, dtype=torch.int32, device=DEV)
+        _level1(hip, dev[id(g)], f, out, pm, X, Y, Z)
+        torch.cuda.synchronize()                                          # (lets the host see the device's note)
+        ref_out, ref_pm = refs[id(g)]
+        assert np.array_equal(out.permute(0, 3, 1, 2).cpu().numpy(), ref_out + 1.0), step
+        assert np.array_equal(pm.cpu().numpy().reshape(ref_pm.shape), ref_pm), step
+    s1 = _l1_stats(hip)
+    assert s1[0] - s0[0] == 8 and s1[1] - s0[1] == 8 and s1[2] == s0[2]   # all eight through the plan entry
+    assert 3 <= s1[3] - s0[3] <= 5                                        # first call + one rebuild per geometry change
+    hip.check(hip.load().sgv3d_voxel_pooling_cache_clear(), "clear")
+
+
+def test_level1_entry_inside_a_captured_graph(hip):
+    """A hipGraph that holds the level-1 call keeps working when geom_xyz is rewritten in place between replays."""
+    hip.check(hip.load().sgv3d_voxel_pooling_cache_clear(), "clear")
+    rng = np.random.default_rng(33)
+    B, N, C, X, Y, Z = 1, 9000, 80, 21, 17, 1
+    g0 = rng.integers(-1, 22, size=(B, N, 3)).astype(np.int32); g0[..., 2] = 0
+    g1 = rng.integers(-1, 22, size=(B, N, 3)).astype(np.int32); g1[..., 2] = 0
+    feats = rng.integers(-4, 5, size=(B, N, C)).astype(np.float32)
+    g = torch.from_numpy(g0).to(DEV)
+    f = torch.from_numpy(feats).to(DEV)
+    out = torch.zeros(B, Y, X, C, device=DEV)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        _level1(hip, g, f, out, None, X, Y, Z)                            # eager: creates the plan for this stream
+        s.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            out.mul_(0.0)                                                 # (a kernel, not a memset node)
+            _level1(hip, g, f, out, None, X, Y, Z)
+    for cur in (g0, g1, g1, g0):
+        g.copy_(torch.from_numpy(cur))
+        graph.replay()
+        torch.cuda.synchronize()
+        ref, _ = VPO.forward(cur, feats, (X, Y, Z))
+        assert np.array_equal(out.permute(0, 3, 1, 2).cpu().numpy(), ref)
+    hip.check(hip.load().sgv3d_voxel_pooling_cache_clear(), "clear")

@@ -59,9 +59,17 @@ def bench_vp(res):
 
             def atomic():
                 out.zero_()
-                lib.sgv3d_voxel_pooling_forward(1, N, C, X, Y, Z, g.data_ptr(), f.data_ptr(), out.data_ptr(), None, st)
+                lib.sgv3d_voxel_pooling_forward_atomic(1, N, C, X, Y, Z, g.data_ptr(), f.data_ptr(), out.data_ptr(), None, st)
 
             def atomic_nozero():
+                lib.sgv3d_voxel_pooling_forward_atomic(1, N, C, X, Y, Z, g.data_ptr(), f.data_ptr(), out.data_ptr(), None, st)
+
+            pm = torch.full((1, N, 3), -1, dtype=torch.int32, device="cuda")
+
+            def level1():        # the symbol the reference's wrapper reaches (cached plan: compare + gated gather), with pos_memo
+                lib.sgv3d_voxel_pooling_forward(1, N, C, X, Y, Z, g.data_ptr(), f.data_ptr(), out.data_ptr(), pm.data_ptr(), st)
+
+            def level1_nomemo():
                 lib.sgv3d_voxel_pooling_forward(1, N, C, X, Y, Z, g.data_ptr(), f.data_ptr(), out.data_ptr(), None, st)
 
             plan = VoxelPlan(g, (X, Y, Z))
@@ -76,6 +84,7 @@ def bench_vp(res):
                 VoxelPlan(g, (X, Y, Z), sort_segments=False)
 
             for name, fn in (("atomic+memset", atomic), ("atomic", atomic_nozero), ("planned_gather", planned),
+                             ("level1_ext_entry", level1), ("level1_ext_entry_no_pos_memo", level1_nomemo),
                              ("plan_build", build), ("plan_build_nosort", build_nosort)):
                 med, mn = timeit(fn)
                 r = dict(case=f"{tag}/{kind}", kernel=name, us_median=med * 1e6, us_min=mn * 1e6)
