@@ -23,6 +23,8 @@
 // consecutive m-tiles of the same n-tile, i.e. share one packed-weight panel.
 #include "conv_common.hpp"
 
+#include <stdlib.h>
+
 using namespace sgv3d;
 
 namespace {
@@ -60,8 +62,17 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
 
 // 128x128 needs ~280 VGPRs with the two register stages: it runs one workgroup per CU (1 wave/SIMD,
 // the pipeline covers its own latency); the smaller tiles keep >= 2 waves/SIMD.
-template <int WTM, int WTN, bool FAST>
+//
+// SWAP (64x64 tile, NHWC output, no split-K, no SE gate; chosen by the launcher): the two MFMA operands trade places
+// (C^T = W . X^T), which puts the PIXEL on the lane and 4 consecutive output channels in registers 4q..4q+3 of an
+// accumulator tile.  Every product and the order of the k sum are the same, so results are bitwise those of the unswapped
+// kernel -- but the epilogue moves 16 bytes per instruction: folded-BN terms, residual and output of a lane's 16 values are
+// 4 + 4 + 4 + 4 dwordx4 accesses instead of 16 + 16 dword ones.  For the layers this is for -- the expanding 1x1
+// convolutions of the ResNet bottlenecks, K = 64..512, 2 k-tiles of MFMA work against 32 KB of residual + output per
+// workgroup -- the epilogue's memory instructions are what a workgroup spends its life on.
+template <int WTM, int WTN, bool FAST, bool SWAP = false>
 __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm_kernel(const ConvArgs a) {
+    static_assert(!SWAP || (WTM == 1 && WTN == 1), "the swapped epilogue is written for the 64x64 tile");
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     constexpr int A_CH = BM / 32, B_CH = BN / 32;  // 16-B chunks per thread per k-tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -295,7 +306,8 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
                 const float av = j == 0 ? FA[mt].x : j == 1 ? FA[mt].y : j == 2 ? FA[mt].z : FA[mt].w; \
                 _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt) {                                  \
                     const float bv = j == 0 ? FB[nt].x : j == 1 ? FB[nt].y : j == 2 ? FB[nt].z : FB[nt].w; \
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][nt], 0, 0, 0); \
+                    acc[mt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc[mt][nt], 0, 0, 0)  \
+                                       : __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][nt], 0, 0, 0); \
                 }                                                                                     \
             }                                                                                         \
         }                                                                                             \
@@ -339,7 +351,24 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     SGV3D_LOAD_TILE(ra0, rb0);                       // tile 0
     SGV3D_LOAD_TILE(ra1, rb1);                       // tile 1
     float resv[WTM][WTN][16];
-    if constexpr (kPrefetchRes) {
+    // SWAP: the lane's pixel row (m0 + wm * 32 + lr) and its 4 channel quads (n0 + wn * 32 + 8 q + 4 lh): residual, folded-BN
+    // scale and shift are 4 dwordx4 loads each, asked for here so that they arrive under the k loop
+    f32x4n sw_res[4];
+    if constexpr (SWAP) {
+        const int wmu_ = __builtin_amdgcn_readfirstlane(wm);
+        const long long tile_row = m0 + wmu_ * 32;
+        const bool rok = tile_row + lr < a.M;
+        const bool has_res = a.res != nullptr;
+        const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(has_res ? a.res + tile_row * a.res_ld : a.zeros), 0, has_res ? (int)0xffffff00u : 0, 0x00020000);
+        const int c0 = n0 + wn * 32 + 4 * lh;
+        const unsigned roff = (rok && c0 < a.N) ? ((unsigned)lr * (unsigned)a.res_ld + (unsigned)c0) * 4u : 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)      // (quad q: channels c0 + 8 q; past N the offset runs out of the resource: zeros)
+            sw_res[q] = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(
+                pr_rsrc, (has_res && c0 + 8 * q < a.N) ? roff : 0xffffffffu, 32 * q, 0));
+    }
+    if constexpr (kPrefetchRes && !SWAP) {
         const bool want = fast_epi && a.split_k <= 1 && a.res != nullptr;
         const long long tile_row = m0 + __builtin_amdgcn_readfirstlane(wm) * (BM / 2);
         const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -380,6 +409,38 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     // instructions of this epilogue, so it is a handful per output -- every channel-only term hoisted,
     // buffer stores addressed as [uniform tile base in the resource] + [per-lane VGPR: channel and the
     // lane half's 4 rows, or out of range for padded channels] + [scalar: row inside the wave's tile].
+    if constexpr (SWAP) {
+        const int wmu = __builtin_amdgcn_readfirstlane(wm);
+        const long long tile_row = m0 + wmu * 32;
+        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.y + tile_row * a.y_ld + a.y_coff), 0, (int)0xffffff00u, 0x00020000);
+        const float floor_ = a.relu ? 0.f : -__builtin_inff();
+        const __amdgpu_buffer_rsrc_t sc_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.scale ? a.scale : a.zeros), 0, a.scale ? a.N * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t sh_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.bias ? a.bias : a.zeros), 0, a.bias ? a.N * 4 : 0, 0x00020000);
+        const bool no_scale = a.scale == nullptr;                 // (an absent scale reads zeros: means 1)
+        const int c0 = n0 + wn * 32 + 4 * lh;
+        const bool rok = tile_row + lr < a.M;
+        const unsigned yoff = rok ? ((unsigned)lr * (unsigned)a.y_ld + (unsigned)c0) * 4u : 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // folded-BN terms of the quad: L2 / scalar-cache resident, asked for one quad ahead by the compiler's scheduling
+            const f32x4n sc4 = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(sc_rsrc, (unsigned)c0 * 4u, 32 * q, 0));
+            const f32x4n sh4 = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(sh_rsrc, (unsigned)c0 * 4u, 32 * q, 0));
+            f32x4n o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float sc_ = no_scale ? 1.f : sc4[j];
+                float v_ = acc[0][0][4 * q + j] * sc_ + sh4[j];
+                v_ += sw_res[q][j];
+                o[j] = fmaxf(v_, floor_);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(o, y_rsrc, (c0 + 8 * q < a.N) ? yoff : 0xffffffffu, 32 * q, 0);
+        }
+        IGEMM_STAMP(3);
+        return;
+    }
     if (fast_epi) {
         const bool partial = a.split_k > 1;
         const int wmu = __builtin_amdgcn_readfirstlane(wm);
@@ -1059,6 +1120,12 @@ __global__ void pack_weight_kernel(const float *__restrict__ src, int cout, int 
     dst[i] = v;
 }
 
+// SGV3D_NO_SWAP_EPI=1: never the swapped-operand kernel (A/B measurements; results are bitwise the same either way)
+static bool swap_epilogue_enabled() {
+    const char *e = getenv("SGV3D_NO_SWAP_EPI");     // (read per launch: tests/test_conv_gpu.py flips it inside one process)
+    return !(e && e[0] == '1');
+}
+
 template <int WTM, int WTN, bool FAST>
 int launch_t(const ConvArgs &a, hipStream_t st) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
@@ -1066,14 +1133,27 @@ int launch_t(const ConvArgs &a, hipStream_t st) {
     // tap-major K: + the k-chunk decode table (8 bytes per 16-byte chunk of K)
     const size_t lds = tiles_lds + (FAST ? 0 : (size_t)a.k_pad / 4 * 8);
     SGV3D_REQUIRE(lds <= 160 * 1024, "conv2d_forward: K = %d too long for the tap-major kernel's decode table", a.K);
-    static PerDeviceSize lds_set;
-    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel<WTM, WTN, FAST>), lds, lds_set))
-        return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot raise the dynamic LDS limit to %zu", lds);
     ConvArgs b = a;
     b.zeros = conv_zero_block();
     if (!b.zeros) return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot resolve the zero block");
     b.tiles_m = cdiv(a.M, BM);
     b.tiles_n = cdiv(a.N, BN);
+    if constexpr (WTM == 1 && WTN == 1 && FAST) {
+        // 16-byte epilogue (operands swapped): NHWC output in 16-byte channel quads, everything 16-B aligned
+        const bool quads = a.N % 4 == 0 && a.y_ld % 4 == 0 && a.y_coff % 4 == 0 && (a.res == nullptr || a.res_ld % 4 == 0) &&
+                           ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.res) |
+                             reinterpret_cast<uintptr_t>(a.scale) | reinterpret_cast<uintptr_t>(a.bias)) & 15) == 0;
+        if (quads && a.split_k <= 1 && a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr && swap_epilogue_enabled()) {
+            static PerDeviceSize lds_set_swap;
+            if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel<1, 1, true, true>), lds, lds_set_swap))
+                return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot raise the dynamic LDS limit to %zu", lds);
+            hipLaunchKernelGGL((conv_igemm_kernel<1, 1, true, true>), dim3(b.tiles_m * b.tiles_n, 1), dim3(kThreads), lds, st, b);
+            return check_launch("conv_igemm_kernel(swap)");
+        }
+    }
+    static PerDeviceSize lds_set;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel<WTM, WTN, FAST>), lds, lds_set))
+        return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot raise the dynamic LDS limit to %zu", lds);
     hipLaunchKernelGGL((conv_igemm_kernel<WTM, WTN, FAST>), dim3(b.tiles_m * b.tiles_n, b.split_k), dim3(kThreads), lds,
                        st, b);
     if (b.split_k > 1) return launch_splitk_reduce(b, st);
