@@ -67,9 +67,9 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
 // (C^T = W . X^T), which puts the PIXEL on the lane and 4 consecutive output channels in registers 4q..4q+3 of an
 // accumulator tile.  Every product and the order of the k sum are the same, so results are bitwise those of the unswapped
 // kernel -- but the epilogue moves 16 bytes per instruction: folded-BN terms, residual and output of a lane's 16 values are
-// 4 + 4 + 4 + 4 dwordx4 accesses instead of 16 + 16 dword ones.  For the layers this is for -- the expanding 1x1
-// convolutions of the ResNet bottlenecks, K = 64..512, 2 k-tiles of MFMA work against 32 KB of residual + output per
-// workgroup -- the epilogue's memory instructions are what a workgroup spends its life on.
+// 4 + 4 + 4 + 4 dwordx4 accesses instead of 16 + 16 dword ones.  Meant for the expanding 1x1 convolutions of the ResNet
+// bottlenecks (K = 64..512, 2 k-tiles of MFMA work against 32 KB of residual + output per workgroup); measured, it does
+// not pay (see swap_epilogue_enabled below), so it is opt-in.
 template <int WTM, int WTN, bool FAST, bool SWAP = false>
 __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm_kernel(const ConvArgs a) {
     static_assert(!SWAP || (WTM == 1 && WTN == 1), "the swapped epilogue is written for the 64x64 tile");
@@ -1120,10 +1120,15 @@ __global__ void pack_weight_kernel(const float *__restrict__ src, int cout, int 
     dst[i] = v;
 }
 
-// SGV3D_NO_SWAP_EPI=1: never the swapped-operand kernel (A/B measurements; results are bitwise the same either way)
+// SGV3D_SWAP_EPI=1 selects the swapped-operand kernel where it applies (results are bitwise the same either way).  It is NOT the
+// default: measured on the cfg-2 bottleneck layers (tools/swap_epi_probe.py, us per launch alone / with three launches in
+// flight) it ties or loses -- 64->256 @216x384 + residual 48.3 -> 55.1 alone, 128->512 @108x192 41.2 / 32.5 -> 43.2 / 34.7,
+// 256->1024 @54x96 37.7 / 28.7 -> 38.8 / 29.0, 512->2048 @27x48 37.8 / 28.4 -> 35.1 / 27.4: a dword store instruction of the
+// unswapped layout writes two full 128-byte row segments, a dwordx4 one of the swapped layout 32 bytes to each of 32 rows, and
+// the memory pipeline prefers the former by as much as the four-fold drop in instruction count gains.
 static bool swap_epilogue_enabled() {
-    const char *e = getenv("SGV3D_NO_SWAP_EPI");     // (read per launch: tests/test_conv_gpu.py flips it inside one process)
-    return !(e && e[0] == '1');
+    const char *e = getenv("SGV3D_SWAP_EPI");        // (read per launch: tests/test_conv_gpu.py flips it inside one process)
+    return e && e[0] == '1';
 }
 
 template <int WTM, int WTN, bool FAST>

@@ -357,8 +357,8 @@ def test_autotune_under_load_picks_a_valid_choice(hip):
                                    (1, 64, 24, 24, 64, 3, 1, 1), (1, 256, 20, 20, 128, 1, 2, 0)])
 @pytest.mark.parametrize("with_res", [False, True])
 def test_swapped_operand_epilogue_is_bitwise_the_unswapped_kernel(hip, shape, with_res):
-    """64x64 tile, NHWC output: the launcher takes the operand-swapped kernel (C^T = W . X^T, 16-byte residual loads and
-    stores).  Same products, same k order: bitwise equal to the unswapped kernel (SGV3D_NO_SWAP_EPI=1), with folded BN,
+    """64x64 tile, NHWC output, SGV3D_SWAP_EPI=1: the launcher takes the operand-swapped kernel (C^T = W . X^T, 16-byte
+    residual loads and stores).  Same products, same k order: bitwise equal to the default kernel, with folded BN,
     residual, ReLU, a concat offset, ragged last m-tile and a channel count that is not a multiple of 32."""
     import os
     from sgv3d_amd.hip_ops import PackedConv
@@ -372,18 +372,18 @@ def test_swapped_operand_epilogue_is_bitwise_the_unswapped_kernel(hip, shape, wi
     oh, ow = conv.out_hw(H, W)
     res = torch.randn(B, oh, ow, cout, generator=g).to(DEV) if with_res else None
     outs = []
-    for flag in ("1", None):
+    for flag in (None, "1"):
         if flag is None:
-            os.environ.pop("SGV3D_NO_SWAP_EPI", None)
+            os.environ.pop("SGV3D_SWAP_EPI", None)
         else:
-            os.environ["SGV3D_NO_SWAP_EPI"] = flag
+            os.environ["SGV3D_SWAP_EPI"] = flag
         try:
             out = torch.full((B, oh, ow, cout + 8), -7.0, device=DEV)          # channel-slice write at offset 4
             conv(x, out, y_coff=4, residual=res)
             torch.cuda.synchronize()
             outs.append(out)
         finally:
-            os.environ.pop("SGV3D_NO_SWAP_EPI", None)
+            os.environ.pop("SGV3D_SWAP_EPI", None)
     assert torch.equal(outs[0], outs[1])
     assert float(outs[1][..., :4].min()) == -7.0 and float(outs[1][..., cout + 4:].max()) == -7.0    # neighbours untouched
     ref = F.conv2d(x.permute(0, 3, 1, 2).cpu(), w.cpu(), None, stride, pad) * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None]
