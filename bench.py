@@ -113,6 +113,8 @@ def load_traffic(tile_name):
         return None, None
     if tile_name == "conv_wino":
         sym = "conv_wino_kernel"
+    elif tile_name == "conv_wino4":
+        sym = "conv_igemm_kernel<1, 1, true"          # the grouped GEMM of the F(4x4) path
     elif tile_name == "conv_wino_resident":
         sym = "conv_wino_resident_kernel"
     elif tile_name == "conv_wino_head":
@@ -345,7 +347,7 @@ def main():
         # SURVEY 8d).  The Winograd F(2x2,3x3) kernels execute 1/2.25 of it on the MFMA pipe, so their
         # algorithmic rate can exceed the hardware peak; the executed rate is reported beside it.
         def executed(name, flops):
-            return flops / 2.25 if "wino" in name else flops
+            return flops / 4.0 if "wino4" in name else flops / 2.25 if "wino" in name else flops
         conv = {k: v for k, v in by_kernel.items() if k.startswith("conv_")}
         top = max(conv, key=lambda k: conv[k][1])
         fl, sec, n = conv[top]

@@ -14,7 +14,8 @@ struct ConvArgs {
     int kh, kw, stride, pad, dil;
     int x_ld, x_coff, y_ld, y_coff, res_ld, relu, mode, ks;   // mode: SGV3D_CONV_* | kConvYBf16 | kConvResBf16
     int tiles_m, tiles_n;
-    int wb_y, wb_x;  // Winograd kernel: 16x16-pixel output blocks per image
+    int wb_y, wb_x;  // Winograd kernel: 16x16-pixel output blocks per image.  f32 implicit GEMM: wb_y > 0 = grouped GEMM
+                     // (conv_gemm_grouped): rows [g * wb_y, (g + 1) * wb_y) multiply weight block g (wb_x floats apart)
     unsigned x_bytes, w_bytes;   // implicit GEMM: sizes of the input / packed-weight buffers (buffer resources)
     int korder;  // 0: k = tap*cin + ci   1: k = (ci/32 * taps + tap)*32 + ci%32  (cin % 32 == 0)
     int split_k; // > 1: blockIdx.y owns a slice of the k-tiles and stores raw partial sums to ws
@@ -68,5 +69,11 @@ static __device__ __forceinline__ void conv_epilogue_store(const ConvArgs &a, in
 int launch_splitk_reduce(const ConvArgs &a, hipStream_t st);
 // 16 zero bytes in device memory that padded / out-of-image lanes load from (conv_igemm.hip).
 const float *conv_zero_block();
+// Grouped f32 GEMM on the implicit-GEMM kernel (conv_igemm.hip), used by the F(4x4) Winograd path (conv_wino4.hip):
+// y[g * rows + r][n] = sum_k x[g * rows + r][k] * w_g[n][k] for g < groups, rows % 64 == 0, K % 4 == 0; w: `groups` packed
+// weight blocks [cout_pad][k_pad] (sgv3d_conv_pack_weight of a 1x1 convolution), k_order as packed.  tile: SGV3D_TILE_64x64
+// or SGV3D_TILE_64x128 (the m-tiles must not straddle groups).
+int conv_gemm_grouped(const float *x, const float *w, float *y, int rows, int groups, int K, int N, int k_pad, int cout_pad,
+                      int k_order, int tile, hipStream_t st);
 
 }  // namespace sgv3d

@@ -129,7 +129,9 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     // offset and read zeros.  fp32 MFMAs and VALU instructions share the SIMD's lanes on this chip, so
     // every vector instruction saved in the loop (64-bit pointer arithmetic, selects) is MFMA time.
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.w_bytes, 0x00020000);
+    // (grouped GEMM, conv_gemm_grouped: the m-tile's group picks its weight block; wave-uniform)
+    const float *const w_grp = a.wb_y > 0 ? a.w + (size_t)((unsigned)m0 / (unsigned)a.wb_y) * (size_t)a.wb_x : a.w;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)w_grp, 0, (int)a.w_bytes, 0x00020000);
     // The prologue runs in the shadow of the other workgroups' MFMAs: at four waves per SIMD an instruction of this wave issues
     // every 8-13 cycles, and ~1000 scalar + vector instructions of address set-up were 9-13 k cycles before the first k-tile
     // reached LDS (tools/igemm_stamps.py) -- as long as the whole k loop of a 256-deep 1x1 layer.  Hence the shortcuts below.
@@ -1292,6 +1294,39 @@ extern "C" int sgv3d_igemm_debug_stamps(void *buf) {
 }
 #endif
 
+namespace sgv3d {
+int conv_gemm_grouped(const float *x, const float *w, float *y, int rows, int groups, int K, int N, int k_pad, int cout_pad,
+                      int k_order, int tile, hipStream_t st) {
+    SGV3D_REQUIRE(x && w && y && rows > 0 && groups > 0 && K > 0 && N > 0, "conv_gemm_grouped: bad argument");
+    SGV3D_REQUIRE(rows % 64 == 0 && K % 4 == 0 && k_pad >= K && k_pad % BK == 0 && cout_pad >= N && cout_pad % 128 == 0,
+                  "conv_gemm_grouped: rows %% 64, K %% 4, k_pad / cout_pad as packed (rows=%d K=%d k_pad=%d N=%d cout_pad=%d)", rows, K,
+                  k_pad, N, cout_pad);
+    SGV3D_REQUIRE(k_order == 0 || K % BK == 0, "conv_gemm_grouped: k_order 1 needs K %% 32 == 0");
+    const long long M = (long long)rows * groups;
+    SGV3D_REQUIRE(M < 0x7fffffffLL && M * K * 4 < 0xf0000000LL && (long long)cout_pad * k_pad * 4 < 0xf0000000LL,
+                  "conv_gemm_grouped: operands larger than 3.75 GiB (32-bit buffer offsets)");
+    ConvArgs a;
+    a.zeros = nullptr;
+    a.x = x; a.w = w; a.scale = nullptr; a.bias = nullptr; a.res = nullptr; a.gate = nullptr; a.y = y;
+    a.in_h = 1; a.in_w = (int)M; a.cin = K; a.out_h = 1; a.out_w = (int)M; a.cout = N;
+    a.m_h = 1; a.m_w = (int)M;
+    a.kh = a.kw = 1; a.stride = 1; a.pad = 0; a.dil = 1;
+    a.x_ld = K; a.x_coff = 0; a.y_ld = N; a.y_coff = 0; a.res_ld = 0; a.relu = 0; a.mode = SGV3D_CONV_NORMAL; a.ks = 0;
+    a.k_pad = k_pad; a.tiles_m = a.tiles_n = 0;
+    a.korder = k_order;
+    a.x_bytes = (unsigned)(M * K * 4);
+    a.w_bytes = (unsigned)((long long)cout_pad * k_pad * 4);          // one group's block
+    a.M = (int)M; a.N = N; a.K = K;
+    a.split_k = 1; a.ws = nullptr;
+    a.wb_y = rows; a.wb_x = cout_pad * k_pad;
+    switch (tile) {
+        case SGV3D_TILE_64x128: return launch<1, 2>(a, st);
+        case SGV3D_TILE_64x64: return launch<1, 1>(a, st);
+        default: return fail(SGV3D_EINVAL, "conv_gemm_grouped: tile must be 64x64 or 64x128 (got %d)", tile);
+    }
+}
+}  // namespace sgv3d
+
 extern "C" size_t sgv3d_conv2d_workspace_bytes(const sgv3d_conv_desc *d) {
     if (!d || d->split_k <= 1) return 0;
     const long long mh = d->mode == SGV3D_CONV_DECONV ? d->in_h : d->out_h;
@@ -1328,6 +1363,7 @@ static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const f
     SGV3D_REQUIRE(residual == nullptr || d->res_ld >= d->cout, "conv2d_forward: res_ld too small");
     ConvArgs a;
     a.zeros = nullptr;
+    a.wb_y = a.wb_x = 0;        // (not a grouped GEMM)
     a.x = x; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = residual; a.gate = gate; a.y = y;
     a.in_h = d->in_h; a.in_w = d->in_w; a.cin = d->cin; a.out_h = d->out_h; a.out_w = d->out_w; a.cout = d->cout;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;

@@ -1,0 +1,205 @@
+// Winograd F(4x4, 3x3) for gfx950 in three launches -- the form for layers with MANY channels on SMALL maps (HeightNet's ten
+// 512 -> 512 convolutions at 54x96, ResNet layer 3 / 4, the 640-channel BEV trunk stage): 3x3 / stride 1 / pad 1 convolutions
+// the reference runs through cuDNN (layers/backbones/lss_fpn.py:161-250 and the mmdet ResNet blocks it builds).
+//
+//   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A     per 4x4 output tile (6x6 input tile, 36 positions)
+//
+// executes 36 / 16 / 9 = 1/4 of the direct form's multiplications, against 1/2.25 for the F(2x2) kernels of conv_wino.hip.
+// With 36 positions the accumulators of a fused kernel no longer fit a wave (36 x 16 registers), so the three stages are
+// separate launches and the middle one -- all of the matrix work -- is the f32 MFMA implicit-GEMM kernel itself, run as a
+// GROUPED GEMM over the positions (conv_gemm_grouped, conv_igemm.hip):
+//
+//   1. wino4_input_kernel    x NHWC -> V[36][tiles_pad][cin]          (B^T d B; one thread per tile and 4 channels)
+//   2. conv_gemm_grouped     M[p] = V[p] . U[p]^T, p = 0..35          (U[p][cout][cin] = (G g G^T)[p], packed per position)
+//   3. wino4_output_kernel   M[36][tiles_pad][cout] -> y NHWC         (A^T M A, folded BN / bias, residual, ReLU)
+//
+// V and M (28 MB each for a 512-channel 54x96 layer) are written once and read once; they stay in the 256 MB last-level
+// cache between the launches.  The transforms are HBM / L2-bound streaming kernels (bound: HBM, 4 (1 + 2.25) bytes per input
+// element and 4 (2.25 + 1 [+ 1]) per output element); the GEMM is bound by the f32 MFMA rate.  Pays where cin and cout are
+// large (the transforms cost O(pixels x channels), the GEMM O(pixels x cin x cout)): the first-call measurement of hip_ops
+// decides per layer.  fp32 rounding: the transformed operands are up to 100x the inputs (|B^T| row sums 10), so the error of an
+// output is ~1e-5 of its scale against ~1e-6 for F(2x2); tests/test_conv_wino_gpu.py bounds it against float64.
+#include "conv_common.hpp"
+
+using namespace sgv3d;
+
+namespace {
+
+struct f4 {
+    float x, y, z, w;
+};
+__device__ __forceinline__ f4 ld4(const float *p) {
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    return {v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st4(float *p, const f4 &v) { *reinterpret_cast<float4 *>(p) = make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ f4 fma4(float s, const f4 &a, const f4 &b) {   // s * a + b
+    return {fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w)};
+}
+__device__ __forceinline__ f4 add4(const f4 &a, const f4 &b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+__device__ __forceinline__ f4 sub4(const f4 &a, const f4 &b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+
+// B^T (6 -> 6), 12 operations:
+//   t0 = 4 d0 - 5 d2 + d4          t1 = (d4 - 4 d2) + (d3 - 4 d1)     t2 = (d4 - 4 d2) - (d3 - 4 d1)
+//   t3 = (d4 - d2) + 2 (d3 - d1)   t4 = (d4 - d2) - 2 (d3 - d1)       t5 = 4 d1 - 5 d3 + d5
+__device__ __forceinline__ void wino4_bt(f4 &d0, f4 &d1, f4 &d2, f4 &d3, f4 &d4, f4 &d5) {
+    const f4 a = fma4(-4.f, d2, d4), b = fma4(-4.f, d1, d3);
+    const f4 c = sub4(d4, d2), e = sub4(d3, d1);
+    const f4 t0 = fma4(4.f, d0, fma4(-5.f, d2, d4));
+    const f4 t5 = fma4(4.f, d1, fma4(-5.f, d3, d5));
+    d0 = t0;
+    d1 = add4(a, b);
+    d2 = sub4(a, b);
+    d3 = fma4(2.f, e, c);
+    d4 = fma4(-2.f, e, c);
+    d5 = t5;
+}
+
+// A^T (6 -> 4), 10 operations:
+//   y0 = m0 + (m1 + m2) + (m3 + m4)        y1 = (m1 - m2) + 2 (m3 - m4)
+//   y2 = (m1 + m2) + 4 (m3 + m4)           y3 = (m1 - m2) + 8 (m3 - m4) + m5
+__device__ __forceinline__ void wino4_at(const f4 &m0, const f4 &m1, const f4 &m2, const f4 &m3, const f4 &m4, const f4 &m5,
+                                         f4 &y0, f4 &y1, f4 &y2, f4 &y3) {
+    const f4 p = add4(m1, m2), q = sub4(m1, m2), r = add4(m3, m4), s = sub4(m3, m4);
+    y0 = add4(add4(m0, p), r);
+    y1 = fma4(2.f, s, q);
+    y2 = fma4(4.f, r, p);
+    y3 = add4(fma4(8.f, s, q), m5);
+}
+
+struct Wino4Args {
+    const float *x, *scale, *bias, *res;
+    float *v, *m, *y;
+    int batch, h, w, cin, cout, x_ld, x_coff, y_ld, y_coff, res_ld, relu;
+    int ty, tx;            // tiles per image
+    int rows;              // rows of V / M per position (tiles of all images, padded to a multiple of 64)
+};
+
+// one thread: one tile x 4 input channels.  Consecutive threads = consecutive channel quads: 16-byte accesses, contiguous.
+__global__ __launch_bounds__(256) void wino4_input_kernel(const Wino4Args a) {
+    const int cq = a.cin >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long ntile = (long long)a.batch * a.ty * a.tx;
+    if (i >= ntile * cq) return;
+    const int t = (int)(i / cq), c = (int)(i - (long long)t * cq) * 4;
+    const int b = t / (a.ty * a.tx), r = t - b * (a.ty * a.tx);
+    const int iy = r / a.tx, ix = r - iy * a.tx;
+    const int y0 = 4 * iy - 1, x0 = 4 * ix - 1;
+    const float *xb = a.x + (size_t)b * a.h * a.w * a.x_ld + a.x_coff + c;
+    f4 d[6][6];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+        const int yy = y0 + rr;
+        const bool rok = (unsigned)yy < (unsigned)a.h;
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {
+            const int xx = x0 + cc;
+            d[rr][cc] = (rok && (unsigned)xx < (unsigned)a.w) ? ld4(xb + ((size_t)yy * a.w + xx) * a.x_ld) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) wino4_bt(d[0][cc], d[1][cc], d[2][cc], d[3][cc], d[4][cc], d[5][cc]);     // B^T d
+    float *vb = a.v + (size_t)t * a.cin + c;
+    const size_t plane = (size_t)a.rows * a.cin;
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+        wino4_bt(d[rr][0], d[rr][1], d[rr][2], d[rr][3], d[rr][4], d[rr][5]);                                 // (B^T d) B
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) st4(vb + (size_t)(rr * 6 + cc) * plane, d[rr][cc]);
+    }
+}
+
+// one thread: one tile x 4 output channels
+__global__ __launch_bounds__(256) void wino4_output_kernel(const Wino4Args a) {
+    const int cq = a.cout >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long ntile = (long long)a.batch * a.ty * a.tx;
+    if (i >= ntile * cq) return;
+    const int t = (int)(i / cq), c = (int)(i - (long long)t * cq) * 4;
+    const int b = t / (a.ty * a.tx), r = t - b * (a.ty * a.tx);
+    const int iy = r / a.tx, ix = r - iy * a.tx;
+    const float *mb = a.m + (size_t)t * a.cout + c;
+    const size_t plane = (size_t)a.rows * a.cout;
+    f4 rr_[4][6];                                           // A^T M: 4 x 6
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) {
+        const f4 m0 = ld4(mb + (size_t)(0 * 6 + cc) * plane), m1 = ld4(mb + (size_t)(1 * 6 + cc) * plane),
+                 m2 = ld4(mb + (size_t)(2 * 6 + cc) * plane), m3 = ld4(mb + (size_t)(3 * 6 + cc) * plane),
+                 m4 = ld4(mb + (size_t)(4 * 6 + cc) * plane), m5 = ld4(mb + (size_t)(5 * 6 + cc) * plane);
+        wino4_at(m0, m1, m2, m3, m4, m5, rr_[0][cc], rr_[1][cc], rr_[2][cc], rr_[3][cc]);
+    }
+    const f4 sc = a.scale ? ld4(a.scale + c) : f4{1.f, 1.f, 1.f, 1.f};
+    const f4 sh = a.bias ? ld4(a.bias + c) : f4{0.f, 0.f, 0.f, 0.f};
+    const float floor_ = a.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        f4 o[4];
+        wino4_at(rr_[u][0], rr_[u][1], rr_[u][2], rr_[u][3], rr_[u][4], rr_[u][5], o[0], o[1], o[2], o[3]);   // (A^T M) A
+        const int yy = 4 * iy + u;
+        if (yy >= a.h) continue;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int xx = 4 * ix + v;
+            if (xx >= a.w) continue;
+            const size_t pix = ((size_t)b * a.h + yy) * a.w + xx;
+            f4 q = {fmaf(o[v].x, sc.x, sh.x), fmaf(o[v].y, sc.y, sh.y), fmaf(o[v].z, sc.z, sh.z), fmaf(o[v].w, sc.w, sh.w)};
+            if (a.res) q = add4(q, ld4(a.res + pix * a.res_ld + c));
+            q = {fmaxf(q.x, floor_), fmaxf(q.y, floor_), fmaxf(q.z, floor_), fmaxf(q.w, floor_)};
+            st4(a.y + pix * a.y_ld + a.y_coff + c, q);
+        }
+    }
+}
+
+int wino4_rows(const sgv3d_conv_desc *d) {
+    const long long tiles = (long long)d->batch * cdiv(d->out_h, 4) * cdiv(d->out_w, 4);
+    return (int)((tiles + 63) / 64 * 64);
+}
+
+}  // namespace
+
+// bytes of V + M
+extern "C" size_t sgv3d_conv2d_winograd4_workspace_bytes(const sgv3d_conv_desc *d) {
+    if (!d || d->batch <= 0 || d->out_h <= 0 || d->out_w <= 0 || d->cin <= 0 || d->cout <= 0) return 0;
+    return sizeof(float) * 36 * (size_t)wino4_rows(d) * ((size_t)d->cin + (size_t)d->cout);
+}
+
+// u_packed: 36 blocks [cout_pad][k_pad] (sgv3d_conv_pack_geometry(cin, cout)), block p = i * 6 + j the 1x1 weight
+// (G g G^T)[i][j] packed by sgv3d_conv_pack_weight.  desc: as for sgv3d_conv2d_winograd_forward (NORMAL mode, no gate, no
+// split-K); desc.k_pad / desc.cout_pad describe ONE block; desc.tile: SGV3D_TILE_64x64 (default) or SGV3D_TILE_64x128 for
+// the grouped GEMM.
+extern "C" int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *d, const float *x, const float *u_packed,
+                                              const float *scale, const float *bias, const float *residual, float *y,
+                                              void *workspace, size_t workspace_bytes, void *stream) {
+    SGV3D_REQUIRE(d && x && u_packed && y && workspace, "conv2d_winograd4_forward: null pointer");
+    SGV3D_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1,
+                  "conv2d_winograd4_forward: only 3x3 / stride 1 / dilation 1 / pad 1");
+    SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->out_h == d->in_h && d->out_w == d->in_w,
+                  "conv2d_winograd4_forward: bad sizes");
+    SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL, "conv2d_winograd4_forward: NHWC output only");
+    SGV3D_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && (d->x_ld & 3) == 0 && (d->x_coff & 3) == 0 && (d->y_ld & 3) == 0 &&
+                      (d->y_coff & 3) == 0 && (residual == nullptr || (d->res_ld & 3) == 0),
+                  "conv2d_winograd4_forward: channel counts, leading dimensions and offsets must be multiples of 4");
+    SGV3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
+                    reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(u_packed) |
+                    reinterpret_cast<uintptr_t>(workspace)) & 15) == 0,
+                  "conv2d_winograd4_forward: pointers must be 16-B aligned");
+    SGV3D_REQUIRE(d->x_ld >= d->x_coff + d->cin && d->y_ld >= d->y_coff + d->cout && (residual == nullptr || d->res_ld >= d->cout),
+                  "conv2d_winograd4_forward: leading dimension too small");
+    const size_t need = sgv3d_conv2d_winograd4_workspace_bytes(d);
+    if (workspace_bytes < need) return fail(SGV3D_ENOSPACE, "conv2d_winograd4_forward: workspace has %zu bytes, needs %zu", workspace_bytes, need);
+    Wino4Args a;
+    a.x = x; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
+    a.batch = d->batch; a.h = d->in_h; a.w = d->in_w; a.cin = d->cin; a.cout = d->cout;
+    a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff; a.res_ld = d->res_ld; a.relu = d->relu;
+    a.ty = cdiv(d->out_h, 4); a.tx = cdiv(d->out_w, 4);
+    a.rows = wino4_rows(d);
+    a.v = static_cast<float *>(workspace);
+    a.m = a.v + (size_t)36 * a.rows * d->cin;
+    hipStream_t st = as_stream(stream);
+    const long long tiles = (long long)d->batch * a.ty * a.tx;
+    hipLaunchKernelGGL(wino4_input_kernel, dim3(cdiv(tiles * (d->cin / 4), 256)), dim3(256), 0, st, a);
+    const int tile = (d->tile == SGV3D_TILE_64x128) ? SGV3D_TILE_64x128 : SGV3D_TILE_64x64;
+    if (int rc = conv_gemm_grouped(a.v, u_packed, a.m, a.rows, 36, d->cin, d->cout, d->k_pad, d->cout_pad, d->k_order, tile, st)) return rc;
+    hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(tiles * (d->cout / 4), 256)), dim3(256), 0, st, a);
+    return check_launch("conv2d_winograd4_forward");
+}

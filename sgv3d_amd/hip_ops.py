@@ -107,6 +107,7 @@ def load_default_tune_dbs():
 load_default_tune_dbs()
 load_tune_db()
 TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: "wino_resident", 7: "patch_bf16", 8: "wino_half",
+              9: "wino4", 10: "wino4",                                      # 9 / 10: F(4x4,3x3) with the 64x64 / 64x128 GEMM tile
               11: "128x128", 12: "128x64", 13: "64x128", 14: "64x64",      # 11..14: f32x3 of tiles 1..4 (host-side ids)
               21: "128x128", 22: "128x64", 23: "64x128", 24: "64x64"}      # 21..24: tiles 1..4 walked m-tile first (SGV3D_TILE_MFIRST)
 MFIRST = _os.environ.get("SGV3D_MFIRST", "1") != "0"
@@ -114,6 +115,10 @@ TILE_WINO = 5       # host-side algorithm id: sgv3d_conv2d_winograd_forward inst
 TILE_WINO_RES = 6   # = SGV3D_WINOGRAD_RESIDENT: its patch-resident variant (cin <= 96, many cout tiles)
 TILE_PATCH = 7      # bf16 mode: the LDS-resident-patch 3x3 kernel (sgv3d_conv3x3_patch_bf16_forward)
 TILE_WINO_HALF = 8  # = SGV3D_WINOGRAD_HALF: 64 tiles x 32 channels per workgroup, positions split over wave pairs (2 workgroups / CU)
+TILE_WINO4 = 9      # Winograd F(4x4,3x3) in three launches (sgv3d_conv2d_winograd4_forward), GEMM tile 64x64; 10: 64x128
+TILE_WINO4_WIDE = 10
+WINO4 = _os.environ.get("SGV3D_WINO4", "1") != "0"     # 0: F(4x4) is never a candidate
+WINO4_MIN_CHANNELS = 128                              # candidates only where cin and cout are at least this
 WINO_HALF = _os.environ.get("SGV3D_WINO_HALF", "1") != "0"
 PATCH_BF16 = _os.environ.get("SGV3D_PATCH_BF16", "1") != "0"
 
@@ -275,6 +280,35 @@ class PackedConv:
             _lib.check(rc, "sgv3d_conv_weight_to_bf16")
         return self.w_bf16
 
+    def wino4_ok(self, d=None, gate=None):
+        """F(4x4,3x3) covers this layer (and launch): 3x3 / stride 1 / pad 1, f32, NHWC output, no gate, many channels."""
+        ok = (WINO4 and WINOGRAD and self.w_wino is not None and not MFMA_BF16 and self.cin % 32 == 0 and self.cout % 4 == 0
+              and min(self.cin, self.cout) >= WINO4_MIN_CHANNELS and gate is None)
+        if ok and d is not None:
+            ok = d.mode == CONV_NORMAL and d.y_ld % 4 == 0 and d.y_coff % 4 == 0 and d.x_ld % 4 == 0 and d.x_coff % 4 == 0 and d.res_ld % 4 == 0
+        return ok
+
+    def _wino4_weights(self):
+        """U[p] = (G g G^T)[i][j] for the 36 positions of F(4x4,3x3), each packed as a 1x1 convolution weight of the
+        implicit-GEMM kernel (made on first use: 36 x cout_pad x k_pad floats)."""
+        if getattr(self, 'w_wino4', None) is None:
+            lib = _lib.load()
+            w = self._keep                                           # [cout, cin_real, 3, 3] f32 on the device
+            G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                              [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64, device=w.device)
+            U = torch.einsum('ia,ocab,jb->ijoc', G, w.double(), G).float().contiguous()      # [6, 6, cout, cin_real]
+            k_pad, cout_pad = pack_geometry(self.cin, self.cout)
+            packed = torch.empty(36, cout_pad, k_pad, dtype=torch.float32, device=w.device)
+            with torch.cuda.device(w.device):
+                for p in range(36):
+                    up = U[p // 6, p % 6].reshape(self.cout, -1, 1, 1).contiguous()
+                    rc = lib.sgv3d_conv_pack_weight(up.data_ptr(), self.cout, int(up.shape[1]), 1, 1, self.cin, 0, 1,
+                                                    packed[p].data_ptr(), k_pad, cout_pad, _st(w))
+                    _lib.check(rc, "sgv3d_conv_pack_weight (F(4x4) position)")
+            torch.cuda.current_stream(w.device).synchronize()        # U's slices die with this scope; the pack kernels read them
+            self.w_wino4, self.wino4_geom = packed, (k_pad, cout_pad)
+        return self.w_wino4
+
     def _patch_weights(self):
         if self.w_patch is None:
             lib = _lib.load()
@@ -374,9 +408,9 @@ class PackedConv:
         real_n = self.cout_real * (self.ks * self.ks if self.transposed else 1)
         flops = 2.0 * gemm_m * real_n * (self.cin_real * self.kh * self.kw)
         x3 = 10 < t < 20 or (MFMA_F32X3 is True and t < TILE_WINO)
-        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) else
+        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF, TILE_WINO4, TILE_WINO4_WIDE) else
                 ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_f32x3_" if x3 else "conv_igemm_")) + TILE_NAMES[t]
-        if t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) and self.k_order == 0:
+        if t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF, TILE_WINO4, TILE_WINO4_WIDE) and self.k_order == 0:
             name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
@@ -427,6 +461,22 @@ class PackedConv:
                                                         d.y_coff, d.res_ld, d.relu, x.data_ptr(), self._patch_weights().data_ptr(),
                                                         _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
                                                         out.data_ptr(), int(io), int(d.split_k), _lib.ptr(ws), nws, _st(x))
+        if d.tile in (TILE_WINO4, TILE_WINO4_WIDE):
+            if not self.wino4_ok(d, gate) or d.split_k > 1:
+                raise _lib.SGV3DError("F(4x4) Winograd covers f32 3x3 / stride 1 / pad 1 layers with cin % 32 == 0, cout % 4 == 0, "
+                                      "NHWC output, no gate, no split-K")
+            u = self._wino4_weights()
+            host_tile, kp, cp = d.tile, d.k_pad, d.cout_pad
+            d.tile = 3 if host_tile == TILE_WINO4_WIDE else 4
+            d.k_pad, d.cout_pad = self.wino4_geom
+            try:
+                nws4 = lib.sgv3d_conv2d_winograd4_workspace_bytes(ctypes.byref(d))
+                ws4 = torch.empty(nws4, dtype=torch.uint8, device=x.device)
+                return lib.sgv3d_conv2d_winograd4_forward(ctypes.byref(d), x.data_ptr(), u.data_ptr(), _lib.ptr(self.scale),
+                                                          _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(), ws4.data_ptr(),
+                                                          nws4, _st(x))
+            finally:
+                d.tile, d.k_pad, d.cout_pad = host_tile, kp, cp
         if d.tile in (TILE_WINO, TILE_WINO_RES, TILE_WINO_HALF):
             if self.w_wino is None:
                 raise _lib.SGV3DError("this layer has no Winograd weights (needs 3x3 / stride 1 / pad 1 / cin % 8 == 0)")
@@ -494,6 +544,8 @@ class PackedConv:
                 tiles += (TILE_WINO_HALF,)
             if self.cin <= 96 and self.cout >= 128:
                 tiles += (TILE_WINO_RES,)
+            if self.wino4_ok(d, gate):
+                tiles += (TILE_WINO4, TILE_WINO4_WIDE)
         if self._patch_eligible(d, gate):
             tiles += (TILE_PATCH,)
         if fixed_tile:
@@ -513,7 +565,7 @@ class PackedConv:
                 if t == TILE_PATCH:
                     nk = self.cin // 32     # stages of 32 input channels; >= 2 per split
                     wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 32) * -(-gemm_n // 64)
-                if t == TILE_WINO_RES:
+                if t in (TILE_WINO_RES, TILE_WINO4, TILE_WINO4_WIDE):
                     splits = (1,)
                 elif t == TILE_PATCH and not fixed_split and SPLIT_K:
                     splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 2 and wgs * s <= 1024]

@@ -186,3 +186,56 @@ def test_fused_centerhead_branches(B, H, W, cin, counts):
     assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
     again = hip_ops.centerhead_branches(x.cuda(), first, w2.permute(0, 2, 3, 1).contiguous().cuda(), b2.cuda(), ob, nb)
     assert torch.equal(out, again)          # fixed summation order: bit-reproducible
+
+
+# ------------------------------------------------------------------------------------------------ F(4x4, 3x3)
+WINO4_SHAPES = [
+    (1, 128, 8, 8, 128),       # exactly 2 x 2 tiles
+    (1, 512, 54, 96, 512),     # the HeightNet layer of cfg-2: 14 x 24 tiles (54 = 13 * 4 + 2), 336 -> 384 rows per position
+    (2, 128, 17, 33, 160),     # batch 2, ragged bottom / right tiles, cout = 1.25 GEMM tiles
+    (1, 256, 27, 48, 256),     # ResNet layer 3 at half size
+    (1, 640, 32, 32, 640),     # BEV trunk, last stage
+]
+
+
+@pytest.mark.parametrize("shape", WINO4_SHAPES)
+@pytest.mark.parametrize("tile", [9, 10])          # hip_ops.TILE_WINO4 (64x64 GEMM tile), TILE_WINO4_WIDE (64x128)
+def test_winograd_f4x4_matches_conv2d(shape, tile):
+    """csrc/conv_wino4.hip: input transform -> grouped GEMM over the 36 positions -> output transform, with folded BN,
+    residual, ReLU and a concat offset, against a float64 convolution.  fp32 bound: 1e-4 of the output scale (measured ~1e-5:
+    the transformed operands are up to 100x the inputs)."""
+    from sgv3d_amd.hip_ops import PackedConv
+    B, cin, H, W, cout = shape
+    x, w = _mk(B, cin, H, W, cout, seed=4)
+    g = torch.Generator().manual_seed(44)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    res = torch.randn(B, H, W, cout, generator=g)
+    conv = PackedConv(w.cuda(), pad=1, scale=scale.cuda(), shift=shift.cuda(), relu=True)
+    assert conv.wino4_ok()
+    out = torch.full((B, H, W, cout + 8), -3.0, device="cuda")
+    conv(x.cuda(), out, y_coff=4, residual=res.cuda(), tile=tile, split_k=1)
+    ref = _ref(x, w, scale, shift, res, relu=True)
+    err = (out[..., 4:cout + 4].cpu().double() - ref).abs().max().item()
+    print(f"F(4x4) {shape} tile {tile}: max err {err:.2e} (scale {ref.abs().max().item():.1f})")
+    assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
+    assert float(out[..., :4].max()) == -3.0 and float(out[..., cout + 4:].max()) == -3.0     # neighbours untouched
+    again = torch.full_like(out, -3.0)
+    conv(x.cuda(), again, y_coff=4, residual=res.cuda(), tile=tile, split_k=1)
+    assert torch.equal(out, again)                                                            # deterministic
+    # and against the F(2x2) kernel on the same layer
+    y2 = conv(x.cuda(), residual=res.cuda(), tile=5, split_k=1)
+    assert (y2 - out[..., 4:cout + 4]).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_winograd_f4x4_rejects_what_it_does_not_cover():
+    from sgv3d_amd._lib import SGV3DError
+    from sgv3d_amd.hip_ops import PackedConv
+    x, w = _mk(1, 64, 16, 16, 64)
+    conv = PackedConv(w.cuda(), pad=1)
+    assert not conv.wino4_ok()                                       # fewer channels than the transforms are worth
+    with pytest.raises(SGV3DError):
+        conv(x.cuda(), tile=9, split_k=1)
+    x, w = _mk(1, 128, 16, 16, 128)
+    conv = PackedConv(w.cuda(), pad=1)
+    with pytest.raises(SGV3DError):
+        conv(x.cuda(), tile=9, split_k=2)                            # no split-K
