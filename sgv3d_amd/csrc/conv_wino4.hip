@@ -71,29 +71,44 @@ struct Wino4Args {
     const float *x, *scale, *bias, *res;
     float *v, *m, *y;
     int batch, h, w, cin, cout, x_ld, x_coff, y_ld, y_coff, res_ld, relu;
-    int ty, tx;            // tiles per image
-    int rows;              // rows of V / M per position (tiles of all images, padded to a multiple of 64)
+    int ty, tx;            // tiles per image and phase
+    int dil;               // dilation (pad == dil): the convolution splits into dil x dil independent ones on the sub-grids
+                           // (py + dil * i, px + dil * j); a tile is 4x4 outputs / 6x6 inputs of ONE sub-grid
+    int rows;              // rows of V / M per position (tiles of all images and phases, padded to a multiple of 64)
 };
+
+// tile index -> (image, sub-grid phase, tile position inside the sub-grid)
+__device__ __forceinline__ void wino4_tile(const Wino4Args &a, int t, int &b, int &py, int &px, int &iy, int &ix) {
+    const int per_phase = a.ty * a.tx, per_img = per_phase * a.dil * a.dil;
+    b = t / per_img;
+    int r = t - b * per_img;
+    const int ph = r / per_phase;
+    r -= ph * per_phase;
+    py = ph / a.dil;
+    px = ph - py * a.dil;
+    iy = r / a.tx;
+    ix = r - iy * a.tx;
+}
 
 // one thread: one tile x 4 input channels.  Consecutive threads = consecutive channel quads: 16-byte accesses, contiguous.
 __global__ __launch_bounds__(256) void wino4_input_kernel(const Wino4Args a) {
     const int cq = a.cin >> 2;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long ntile = (long long)a.batch * a.ty * a.tx;
+    const long long ntile = (long long)a.batch * a.ty * a.tx * a.dil * a.dil;
     if (i >= ntile * cq) return;
     const int t = (int)(i / cq), c = (int)(i - (long long)t * cq) * 4;
-    const int b = t / (a.ty * a.tx), r = t - b * (a.ty * a.tx);
-    const int iy = r / a.tx, ix = r - iy * a.tx;
-    const int y0 = 4 * iy - 1, x0 = 4 * ix - 1;
+    int b, py, px, iy, ix;
+    wino4_tile(a, t, b, py, px, iy, ix);
+    const int y0 = py + (4 * iy - 1) * a.dil, x0 = px + (4 * ix - 1) * a.dil;
     const float *xb = a.x + (size_t)b * a.h * a.w * a.x_ld + a.x_coff + c;
     f4 d[6][6];
 #pragma unroll
     for (int rr = 0; rr < 6; ++rr) {
-        const int yy = y0 + rr;
+        const int yy = y0 + rr * a.dil;
         const bool rok = (unsigned)yy < (unsigned)a.h;
 #pragma unroll
         for (int cc = 0; cc < 6; ++cc) {
-            const int xx = x0 + cc;
+            const int xx = x0 + cc * a.dil;
             d[rr][cc] = (rok && (unsigned)xx < (unsigned)a.w) ? ld4(xb + ((size_t)yy * a.w + xx) * a.x_ld) : f4{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -113,11 +128,11 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const Wino4Args a) {
 __global__ __launch_bounds__(256) void wino4_output_kernel(const Wino4Args a) {
     const int cq = a.cout >> 2;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long ntile = (long long)a.batch * a.ty * a.tx;
+    const long long ntile = (long long)a.batch * a.ty * a.tx * a.dil * a.dil;
     if (i >= ntile * cq) return;
     const int t = (int)(i / cq), c = (int)(i - (long long)t * cq) * 4;
-    const int b = t / (a.ty * a.tx), r = t - b * (a.ty * a.tx);
-    const int iy = r / a.tx, ix = r - iy * a.tx;
+    int b, py, px, iy, ix;
+    wino4_tile(a, t, b, py, px, iy, ix);
     const float *mb = a.m + (size_t)t * a.cout + c;
     const size_t plane = (size_t)a.rows * a.cout;
     f4 rr_[4][6];                                           // A^T M: 4 x 6
@@ -135,11 +150,11 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const Wino4Args a) {
     for (int u = 0; u < 4; ++u) {
         f4 o[4];
         wino4_at(rr_[u][0], rr_[u][1], rr_[u][2], rr_[u][3], rr_[u][4], rr_[u][5], o[0], o[1], o[2], o[3]);   // (A^T M) A
-        const int yy = 4 * iy + u;
+        const int yy = py + (4 * iy + u) * a.dil;
         if (yy >= a.h) continue;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int xx = 4 * ix + v;
+            const int xx = px + (4 * ix + v) * a.dil;
             if (xx >= a.w) continue;
             const size_t pix = ((size_t)b * a.h + yy) * a.w + xx;
             f4 q = {fmaf(o[v].x, sc.x, sh.x), fmaf(o[v].y, sc.y, sh.y), fmaf(o[v].z, sc.z, sh.z), fmaf(o[v].w, sc.w, sh.w)};
@@ -150,17 +165,24 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const Wino4Args a) {
     }
 }
 
-int wino4_rows(const sgv3d_conv_desc *d) {
-    const long long tiles = (long long)d->batch * cdiv(d->out_h, 4) * cdiv(d->out_w, 4);
-    return (int)((tiles + 63) / 64 * 64);
+// tiles of one sub-grid (the largest one: phase 0), of all phases and images, and the padded row count per position
+void wino4_geom(const sgv3d_conv_desc *d, int &ty, int &tx, long long &tiles, int &rows) {
+    const int dil = d->dil;
+    ty = cdiv(cdiv(d->out_h, dil), 4);
+    tx = cdiv(cdiv(d->out_w, dil), 4);
+    tiles = (long long)d->batch * dil * dil * ty * tx;
+    rows = (int)((tiles + 63) / 64 * 64);
 }
 
 }  // namespace
 
 // bytes of V + M
 extern "C" size_t sgv3d_conv2d_winograd4_workspace_bytes(const sgv3d_conv_desc *d) {
-    if (!d || d->batch <= 0 || d->out_h <= 0 || d->out_w <= 0 || d->cin <= 0 || d->cout <= 0) return 0;
-    return sizeof(float) * 36 * (size_t)wino4_rows(d) * ((size_t)d->cin + (size_t)d->cout);
+    if (!d || d->batch <= 0 || d->out_h <= 0 || d->out_w <= 0 || d->cin <= 0 || d->cout <= 0 || d->dil <= 0) return 0;
+    int ty, tx, rows;
+    long long tiles;
+    wino4_geom(d, ty, tx, tiles, rows);
+    return sizeof(float) * 36 * (size_t)rows * ((size_t)d->cin + (size_t)d->cout);
 }
 
 // u_packed: 36 blocks [cout_pad][k_pad] (sgv3d_conv_pack_geometry(cin, cout)), block p = i * 6 + j the 1x1 weight
@@ -171,8 +193,8 @@ extern "C" int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *d, const fl
                                               const float *scale, const float *bias, const float *residual, float *y,
                                               void *workspace, size_t workspace_bytes, void *stream) {
     SGV3D_REQUIRE(d && x && u_packed && y && workspace, "conv2d_winograd4_forward: null pointer");
-    SGV3D_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1,
-                  "conv2d_winograd4_forward: only 3x3 / stride 1 / dilation 1 / pad 1");
+    SGV3D_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil >= 1 && d->pad == d->dil,
+                  "conv2d_winograd4_forward: only 3x3 / stride 1 / pad == dilation");
     SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->out_h == d->in_h && d->out_w == d->in_w,
                   "conv2d_winograd4_forward: bad sizes");
     SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL, "conv2d_winograd4_forward: NHWC output only");
@@ -191,12 +213,13 @@ extern "C" int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *d, const fl
     a.x = x; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
     a.batch = d->batch; a.h = d->in_h; a.w = d->in_w; a.cin = d->cin; a.cout = d->cout;
     a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff; a.res_ld = d->res_ld; a.relu = d->relu;
-    a.ty = cdiv(d->out_h, 4); a.tx = cdiv(d->out_w, 4);
-    a.rows = wino4_rows(d);
+    long long tiles;
+    wino4_geom(d, a.ty, a.tx, tiles, a.rows);
+    a.dil = d->dil;
+    SGV3D_REQUIRE(tiles < 0x7fffffffLL / 64, "conv2d_winograd4_forward: too many tiles");
     a.v = static_cast<float *>(workspace);
     a.m = a.v + (size_t)36 * a.rows * d->cin;
     hipStream_t st = as_stream(stream);
-    const long long tiles = (long long)d->batch * a.ty * a.tx;
     hipLaunchKernelGGL(wino4_input_kernel, dim3(cdiv(tiles * (d->cin / 4), 256)), dim3(256), 0, st, a);
     const int tile = (d->tile == SGV3D_TILE_64x128) ? SGV3D_TILE_64x128 : SGV3D_TILE_64x64;
     if (int rc = conv_gemm_grouped(a.v, u_packed, a.m, a.rows, 36, d->cin, d->cout, d->k_pad, d->cout_pad, d->k_order, tile, st)) return rc;

@@ -282,7 +282,8 @@ class PackedConv:
 
     def wino4_ok(self, d=None, gate=None):
         """F(4x4,3x3) covers this layer (and launch): 3x3 / stride 1 / pad 1, f32, NHWC output, no gate, many channels."""
-        ok = (WINO4 and WINOGRAD and self.w_wino is not None and not MFMA_BF16 and self.cin % 32 == 0 and self.cout % 4 == 0
+        is3x3 = (not self.transposed and self.kh == 3 and self.kw == 3 and self.stride == 1 and self.pad == self.dil)   # dilated too
+        ok = (WINO4 and WINOGRAD and is3x3 and not MFMA_BF16 and self.cin % 32 == 0 and self.cout % 4 == 0
               and min(self.cin, self.cout) >= WINO4_MIN_CHANNELS and gate is None)
         if ok and d is not None:
             ok = d.mode == CONV_NORMAL and d.y_ld % 4 == 0 and d.y_coff % 4 == 0 and d.x_ld % 4 == 0 and d.x_coff % 4 == 0 and d.res_ld % 4 == 0
@@ -544,8 +545,9 @@ class PackedConv:
                 tiles += (TILE_WINO_HALF,)
             if self.cin <= 96 and self.cout >= 128:
                 tiles += (TILE_WINO_RES,)
-            if self.wino4_ok(d, gate):
-                tiles += (TILE_WINO4, TILE_WINO4_WIDE)
+
+        if self.wino4_ok(d, gate):            # (also the dilated 3x3 layers, which the F(2x2) kernels do not cover)
+            tiles += (TILE_WINO4, TILE_WINO4_WIDE)
         if self._patch_eligible(d, gate):
             tiles += (TILE_PATCH,)
         if fixed_tile:

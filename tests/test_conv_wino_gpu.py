@@ -239,3 +239,27 @@ def test_winograd_f4x4_rejects_what_it_does_not_cover():
     conv = PackedConv(w.cuda(), pad=1)
     with pytest.raises(SGV3DError):
         conv(x.cuda(), tile=9, split_k=2)                            # no split-K
+
+
+@pytest.mark.parametrize("dil,H,W", [(6, 54, 96), (12, 54, 96), (18, 54, 96), (2, 19, 23), (3, 20, 20)])
+def test_winograd_f4x4_dilated(dil, H, W):
+    """Dilated 3x3 (pad == dilation: the ASPP branches): dil x dil independent sub-grid convolutions through the same three
+    launches, tiles of 4x4 outputs spaced `dil` apart; sub-grids of different sizes (54 = 4 * 12 + 6), ragged tiles."""
+    from sgv3d_amd.hip_ops import PackedConv
+    cin = cout = 128 if H < 54 else 512
+    g = torch.Generator().manual_seed(dil)
+    x = torch.randn(1, H, W, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    conv = PackedConv(w.cuda(), pad=dil, dil=dil, scale=scale.cuda(), shift=shift.cuda(), relu=True)
+    assert conv.wino4_ok() and conv.w_wino is None
+    out = torch.full((1, H, W, cout + 64), -3.0, device="cuda")
+    conv(x.cuda(), out, y_coff=32, tile=9, split_k=1)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=dil, dilation=dil).permute(0, 2, 3, 1)
+    ref = (ref * scale.double() + shift.double()).clamp_min(0)
+    err = (out[..., 32:cout + 32].cpu().double() - ref).abs().max().item()
+    print(f"F(4x4) dilation {dil} @{H}x{W}: max err {err:.2e} (scale {ref.abs().max().item():.1f})")
+    assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
+    assert float(out[..., :32].max()) == -3.0 and float(out[..., cout + 32:].max()) == -3.0
+    direct = conv(x.cuda(), tile=4, split_k=1)
+    assert (direct - out[..., 32:cout + 32]).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())

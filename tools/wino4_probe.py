@@ -38,14 +38,18 @@ def time_loaded(fn, n=8):
     return e0.elapsed_time(e1) * 1e3 / (n * len(streams))
 
 
-for cin, H, W, cout in LAYERS:
+DIL = [(512, 54, 96, 512, 6), (512, 54, 96, 512, 12), (512, 54, 96, 512, 18)]
+for layer in [l + (1,) for l in LAYERS] + DIL:
+    cin, H, W, cout, dil = layer
     x = torch.randn(1, H, W, cin, device="cuda")
     w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
     sc, sh = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda")
-    conv = PackedConv(w, pad=1, scale=sc, shift=sh, relu=True)
+    conv = PackedConv(w, pad=dil, dil=dil, scale=sc, shift=sh, relu=True)
     out = torch.empty(1, H, W, cout, device="cuda")
-    line = f"{cin:4d}->{cout:4d} @{H}x{W}: "
+    line = f"{cin:4d}->{cout:4d} @{H}x{W} d{dil}: "
     for t, sk in CANDS:
+        if t in (5, 8) and conv.w_wino is None:
+            continue
         if t in (9, 10) and not conv.wino4_ok():
             continue
         if t in (5, 8) and cin // 4 // sk < 8 and sk > 1:
