@@ -34,6 +34,10 @@ import os as _os
 # choice that fills idle CUs in isolation only adds work when the CUs are busy anyway).  N > 1 launches the candidate on
 # N streams at once and compares the time for all of them to finish.
 TUNE_STREAMS = max(1, int(_os.environ.get("SGV3D_TUNE_STREAMS", "1")))
+# launches per stream and repetitions of a candidate's timing under load (SGV3D_TUNE_ROUNDS / SGV3D_TUNE_REPEATS; the committed
+# tune DBs are measured with 8 x 4 -- tools/make_tune_db.sh -- so that near-ties are not decided by noise)
+TUNE_ROUNDS = max(1, int(_os.environ.get("SGV3D_TUNE_ROUNDS", "3")))
+TUNE_REPEATS = max(1, int(_os.environ.get("SGV3D_TUNE_REPEATS", "2")))
 SPLIT_K = not _os.environ.get("SGV3D_NO_SPLITK")
 # False: 3x3 / stride-1 layers never use the Winograd F(2x2,3x3) kernel (SGV3D_NO_WINOGRAD=1)
 WINOGRAD = not _os.environ.get("SGV3D_NO_WINOGRAD")
@@ -506,7 +510,7 @@ class PackedConv:
         finally:
             d.tile = host_tile
 
-    def _time_under_load(self, lib, d, x, residual, gate, out, rounds=3, io=0):
+    def _time_under_load(self, lib, d, x, residual, gate, out, rounds=None, io=0):
         """Time for TUNE_STREAMS concurrent copies of the launch, ``rounds`` back to back on every stream (all copies
         write the same values to ``out``; split-K workspaces are per launch)."""
         global _TUNE_SIDE_STREAMS
@@ -514,7 +518,8 @@ class PackedConv:
         if len(_TUNE_SIDE_STREAMS) < TUNE_STREAMS:
             _TUNE_SIDE_STREAMS = [torch.cuda.Stream(device=x.device) for _ in range(TUNE_STREAMS)]
         best = None
-        for _ in range(2):
+        rounds = rounds or TUNE_ROUNDS
+        for _ in range(TUNE_REPEATS):
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(cur)
@@ -583,13 +588,14 @@ class PackedConv:
                     if TUNE_STREAMS > 1:
                         dt = self._time_under_load(lib, d, x, residual, gate, out, io=io)
                     else:
-                        evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                        nrep = max(4, TUNE_ROUNDS * TUNE_REPEATS // 2)
+                        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nrep + 1)]
                         evs[0].record()
-                        for r in range(4):
+                        for r in range(nrep):
                             self._launch(lib, d, x, residual, gate, out, io)
                             evs[r + 1].record()
                         evs[-1].synchronize()
-                        dt = min(evs[r].elapsed_time(evs[r + 1]) for r in range(4))
+                        dt = min(evs[r].elapsed_time(evs[r + 1]) for r in range(nrep))
                     if best_t is None or dt < best_t:
                         best, best_t = (t, sk), dt
         return best

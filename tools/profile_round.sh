@@ -9,19 +9,26 @@ OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-# tile / split-K choices are made once (first run) and replayed by the profiled runs
-export SGV3D_TUNE_CACHE=$OUT/${TAG}_tune_cache.json
+# (tile / split-K choices come from the committed tune DB, tune/gfx950_*.json: every run below makes the same ones)
 # 1. the bench line itself (with the CPU baseline)
 python3 $R/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 # 2. kernel trace + stats of the same command (no CPU baseline: it is host work).  One frame in flight, so that the
 #    per-kernel durations are those of the kernels alone (with 3 frames in flight concurrent kernels stretch each
 #    other) and compare directly with roofline.avg_launch_us of the bench line, which is measured the same way.
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-plan-timing --streams 1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-plan-timing --no-other-configs --streams 1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err
+# 2b. the HEADLINE command itself (three frames in flight) under the kernel trace: concurrent kernels stretch each other,
+#     so these per-kernel durations are "under load" figures, not comparable with roofline.avg_launch_us
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench_3inflight -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-roofline --no-other-configs > $OUT/${TAG}_bench_3inflight_under_rocprof.json 2> $OUT/rocprof3.err
+# 2c. per-layer table (HIP events, one frame at a time) with the tiles chosen for three frames in flight, and for one
+SGV3D_TUNE_STREAMS=3 python3 $R/tools/layer_report.py > $OUT/${TAG}_layers_cfg2_tiles_for_3inflight.txt 2> $OUT/layers3.err
+SGV3D_TUNE_STREAMS=1 python3 $R/tools/layer_report.py > $OUT/${TAG}_layers_cfg2_tiles_for_1inflight.txt 2> $OUT/layers1.err
+# 2d. the three launches of the F(4x4) Winograd path
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_wino4 -- python3 $R/tools/wino4_trace.py > /dev/null 2> $OUT/wino4.err
 # 3. HBM traffic counters, separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs > /dev/null 2> $OUT/pmc_write.err
 # 3b. MFMA utilisation counters (own pass; SQ counters fit one pass)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_mfma -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --streams 1 > /dev/null 2> $OUT/pmc_mfma.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_mfma -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs --streams 1 > /dev/null 2> $OUT/pmc_mfma.err
 # 4. voxel pooling micro-benchmark (the HBM-bound headline kernel) + its trace and traffic
 python3 $R/tools/microbench.py --what vp,lift --out $OUT/${TAG}_voxel_pooling_microbench.json > $OUT/microbench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_vp -- python3 $R/tools/vp_probe.py > /dev/null 2> $OUT/vp.err
