@@ -70,9 +70,17 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
 // 4 + 4 + 4 + 4 dwordx4 accesses instead of 16 + 16 dword ones.  Meant for the expanding 1x1 convolutions of the ResNet
 // bottlenecks (K = 64..512, 2 k-tiles of MFMA work against 32 KB of residual + output per workgroup); measured, it does
 // not pay (see swap_epilogue_enabled below), so it is opt-in.
-template <int WTM, int WTN, bool FAST, bool SWAP = false>
+//
+// PW (pointwise; chosen by the launcher for 1x1 / stride 1 / unpadded layers with cin % 32 == 0 -- the ResNet bottleneck
+// convolutions and the grouped GEMM of the F(4x4) Winograd path): f32 MFMAs and vector-ALU instructions share the SIMD's lanes
+// on this chip EVEN ACROSS WAVES (tools/ubench/mfma_valu_overlap.hip: a pure MFMA wave and a pure v_fma wave on one SIMD take
+// the sum of their times, 933 + 584 -> 1445 us), so every vector instruction of the address arithmetic is MFMA time of the
+// whole SIMD.  Here the A operand needs none inside the loop: the lane offset is fixed (out of range for rows past M), the
+// k-tile offset is a scalar register, and past the last tile the last one is re-read (its data is never stored).
+template <int WTM, int WTN, bool FAST, bool SWAP = false, bool PW = false>
 __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm_kernel(const ConvArgs a) {
     static_assert(!SWAP || (WTM == 1 && WTN == 1), "the swapped epilogue is written for the 64x64 tile");
+    static_assert(!PW || FAST, "the pointwise specialisation is for the channel-chunk-major k order");
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     constexpr int A_CH = BM / 32, B_CH = BN / 32;  // 16-B chunks per thread per k-tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -129,13 +137,14 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     // offset and read zeros.  fp32 MFMAs and VALU instructions share the SIMD's lanes on this chip, so
     // every vector instruction saved in the loop (64-bit pointer arithmetic, selects) is MFMA time.
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_none = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, 0, 0x00020000);   // num_records 0: reads zeros
     // (grouped GEMM, conv_gemm_grouped: the m-tile's group picks its weight block; wave-uniform)
     const float *const w_grp = a.wb_y > 0 ? a.w + (size_t)((unsigned)m0 / (unsigned)a.wb_y) * (size_t)a.wb_x : a.w;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)w_grp, 0, (int)a.w_bytes, 0x00020000);
     // The prologue runs in the shadow of the other workgroups' MFMAs: at four waves per SIMD an instruction of this wave issues
     // every 8-13 cycles, and ~1000 scalar + vector instructions of address set-up were 9-13 k cycles before the first k-tile
     // reached LDS (tools/igemm_stamps.py) -- as long as the whole k loop of a 256-deep 1x1 layer.  Hence the shortcuts below.
-    const bool pointwise = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.in_h == a.m_h && a.in_w == a.m_w;
+    const bool pointwise = PW || (a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.in_h == a.m_h && a.in_w == a.m_w);
     unsigned a_off[A_CH];
     int a_ih0[A_CH], a_iw0[A_CH];
     bool a_ok[A_CH];
@@ -144,6 +153,12 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
         const int m = m0 + r0 + 32 * i;
         a_ok[i] = m < a.M;
         const int mm = a_ok[i] ? m : 0;
+        if constexpr (PW) {          // rows past M carry an out-of-range lane offset for good
+            a_ih0[i] = 0;
+            a_iw0[i] = 0;
+            a_off[i] = a_ok[i] ? (unsigned)(((long long)mm * a.x_ld + a.x_coff + cc * 4) * 4) : 0xffffffffu;
+            continue;
+        }
         if (pointwise) {             // 1x1 / stride 1 / no padding: the input pixel IS the output pixel, no division
             a_ih0[i] = 0;
             a_iw0[i] = 0;
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     // of their taps this way; the zero-block loads they would have made feed MFMAs with zeros).  The valid
     // rows form a contiguous range [kh_lo, kh_hi]; k-tiles are counted over the valid list.
     int kh_lo = 0, kh_hi = a.kh - 1;
-    if constexpr (FAST) {
+    if constexpr (FAST && !PW) {
         if (a.mode != SGV3D_CONV_DECONV && a.kh > 1) {
             const int hw = a.m_h * a.m_w;
             const int m_last = (m0 + BM < a.M ? m0 + BM : a.M) - 1;
@@ -237,19 +252,27 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
             koff_ = e_.x - cc * 4;       /* a_off already holds this thread's chunk column */          \
         }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                            \
-            const int ih_ = a_ih0[i] + dy_, iw_ = a_iw0[i] + dx_;                                     \
-            const bool v_ = a_ok[i] & kvalid_ & ((unsigned)ih_ < (unsigned)a.in_h) &                  \
-                            ((unsigned)iw_ < (unsigned)a.in_w);                                       \
-            const unsigned vo_ = v_ ? a_off[i] + (unsigned)(koff_ * 4) : 0xffffffffu;                 \
-            const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo_, 0, 0)); \
-            RA[i].x = t_.x; RA[i].y = t_.y; RA[i].z = t_.z; RA[i].w = t_.w;                           \
+            if constexpr (PW) {   /* fixed lane offset + scalar channel-chunk offset: no vector instruction; */ \
+                /* past the last tile the EMPTY resource (scalar select): nothing is fetched             */ \
+                const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(kvalid_ ? x_rsrc : x_none, a_off[i], ld_c0 * 4, 0)); \
+                RA[i].x = t_.x; RA[i].y = t_.y; RA[i].z = t_.z; RA[i].w = t_.w;                       \
+            } else {                                                                                  \
+                const int ih_ = a_ih0[i] + dy_, iw_ = a_iw0[i] + dx_;                                 \
+                const bool v_ = a_ok[i] & kvalid_ & ((unsigned)ih_ < (unsigned)a.in_h) &              \
+                                ((unsigned)iw_ < (unsigned)a.in_w);                                   \
+                const unsigned vo_ = v_ ? a_off[i] + (unsigned)(koff_ * 4) : 0xffffffffu;             \
+                const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo_, 0, 0)); \
+                RA[i].x = t_.x; RA[i].y = t_.y; RA[i].z = t_.z; RA[i].w = t_.w;                       \
+            }                                                                                         \
         }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < B_CH; ++i) {                                            \
             const f32x4n t_ = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_off[i], ktb_ * (BK * 4), 0)); \
             RB[i].x = t_.x; RB[i].y = t_.y; RB[i].z = t_.z; RB[i].w = t_.w;                           \
         }                                                                                             \
         ++ld_kt;                                                                                      \
-        if constexpr (FAST) {                                                                         \
+        if constexpr (PW) {                                                                           \
+            if (ld_kt < nkt) { ld_c0 += BK; ld_kp = ld_c0 / BK; }                                     \
+        } else if constexpr (FAST) {                                                                  \
             if (ld_kt < nkt) { /* past the end the state stays on the last valid tile (drain re-reads it) */ \
                 if (++ld_kw == a.kw) {                                                                \
                     ld_kw = 0;                                                                        \
@@ -1133,6 +1156,12 @@ static bool swap_epilogue_enabled() {
     return e && e[0] == '1';
 }
 
+// SGV3D_NO_PW_KERNEL=1: never the pointwise specialisation (A/B measurements; results are bitwise the same)
+static bool pointwise_kernel_enabled() {
+    const char *e = getenv("SGV3D_NO_PW_KERNEL");
+    return !(e && e[0] == '1');
+}
+
 template <int WTM, int WTN, bool FAST>
 int launch_t(const ConvArgs &a, hipStream_t st) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
@@ -1156,6 +1185,23 @@ int launch_t(const ConvArgs &a, hipStream_t st) {
                 return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot raise the dynamic LDS limit to %zu", lds);
             hipLaunchKernelGGL((conv_igemm_kernel<1, 1, true, true>), dim3(b.tiles_m * b.tiles_n, 1), dim3(kThreads), lds, st, b);
             return check_launch("conv_igemm_kernel(swap)");
+        }
+    }
+    if constexpr (WTM == 1 && FAST) {
+        // pointwise specialisation (64x64 and 64x128 tiles): no vector instruction for the A addresses inside the loop
+        const bool pw = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.in_h == a.m_h && a.in_w == a.m_w &&
+                        (a.mode & kConvModeMask) != SGV3D_CONV_DECONV && a.cin >= 128 && pointwise_kernel_enabled();
+        // (cin >= 128: with two k-tiles -- the 64 -> 256 expanders at 216x384, HBM-bound -- the generic kernel's longer
+        //  prologue spreads the residual and output traffic better: 47.8 vs 53.5 us alone, 42.6 vs 43.7 with three in flight;
+        //  everywhere else the specialisation wins 3-6 %: tools/swap_epi_probe.py)
+        if (pw) {
+            static PerDeviceSize lds_set_pw;
+            if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel<WTM, WTN, true, false, true>), lds, lds_set_pw))
+                return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot raise the dynamic LDS limit to %zu", lds);
+            hipLaunchKernelGGL((conv_igemm_kernel<WTM, WTN, true, false, true>), dim3(b.tiles_m * b.tiles_n, b.split_k),
+                               dim3(kThreads), lds, st, b);
+            if (b.split_k > 1) return launch_splitk_reduce(b, st);
+            return check_launch("conv_igemm_kernel(pointwise)");
         }
     }
     static PerDeviceSize lds_set;

@@ -390,3 +390,37 @@ def test_swapped_operand_epilogue_is_bitwise_the_unswapped_kernel(hip, shape, wi
     if res is not None:
         ref = ref + res.permute(0, 3, 1, 2).cpu()
     torch.testing.assert_close(outs[1][..., 4:cout + 4].permute(0, 3, 1, 2).cpu(), ref.clamp_min(0), **TOL)
+
+
+@pytest.mark.parametrize("shape", [(1, 160, 40, 48, 256, 4), (1, 128, 27, 31, 512, 4), (2, 256, 9, 13, 100, 3), (1, 1024, 11, 17, 256, 4),
+                                   (1, 512, 13, 9, 2048, 3)])
+@pytest.mark.parametrize("split", [1, 2])
+def test_pointwise_specialisation_is_bitwise_the_generic_kernel(hip, shape, split):
+    """1x1 / stride 1 / cin % 32 == 0 layers on the 64x64 (4) and 64x128 (3) tiles take the pointwise instantiation (no vector
+    instruction for the A addresses inside the k loop).  Same loads, same order: bitwise equal to the generic kernel
+    (SGV3D_NO_PW_KERNEL=1), with folded BN, residual, ReLU, split-K and a ragged last m-tile."""
+    import os
+    from sgv3d_amd.hip_ops import PackedConv
+    B, cin, H, W, cout, tile = shape
+    if cin // 32 < split:
+        pytest.skip("not enough k-tiles")
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, H, W, cin, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).to(DEV)
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).to(DEV), torch.randn(cout, generator=g).to(DEV)
+    res = torch.randn(B, H, W, cout, generator=g).to(DEV)
+    conv = PackedConv(w, scale=sc, shift=sh, relu=True)
+    outs = []
+    for flag in ("1", None):
+        if flag:
+            os.environ["SGV3D_NO_PW_KERNEL"] = flag
+        else:
+            os.environ.pop("SGV3D_NO_PW_KERNEL", None)
+        try:
+            outs.append(conv(x, residual=res, tile=tile, split_k=split))
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("SGV3D_NO_PW_KERNEL", None)
+    assert torch.equal(outs[0], outs[1])
+    ref = F.conv2d(x.permute(0, 3, 1, 2).cpu(), w.cpu()) * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None] + res.permute(0, 3, 1, 2).cpu()
+    torch.testing.assert_close(outs[1].permute(0, 3, 1, 2).cpu(), ref.clamp_min(0), **TOL)

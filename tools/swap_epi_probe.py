@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev probe: the ResNet-50 1x1 layers of cfg-2 on the 64x64 tile with the swapped-operand (16-byte) epilogue and without
-(SGV3D_SWAP_EPI toggled in-process), residual + ReLU as in the bottlenecks.  Prints us per launch, alone and with three
+(SGV3D_NO_PW_KERNEL / SGV3D_SWAP_EPI toggled in-process), residual + ReLU as in the bottlenecks.  Prints us per launch, alone and with three
 concurrent copies (what the frame pipeline runs)."""
 import os, sys
 import torch
@@ -47,11 +47,14 @@ for cin, H, W, cout, with_res in LAYERS:
     out = torch.empty(1, H, W, cout, device="cuda")
     fn = lambda: conv(x, out, residual=res, tile=4, split_k=1)
     row = []
-    for flag in (None, "1"):
-        if flag:
-            os.environ["SGV3D_SWAP_EPI"] = flag
-        else:
-            os.environ.pop("SGV3D_SWAP_EPI", None)
-        row.append((time_alone(fn), time_loaded(fn)))
-    print(f"{cin:5d}->{cout:5d} @{H}x{W} res={int(with_res)}:  dword epilogue {row[0][0]:6.1f} us alone / {row[0][1]:6.1f} loaded   "
-          f"16-byte epilogue {row[1][0]:6.1f} / {row[1][1]:6.1f}", flush=True)
+    time_loaded(fn)
+    for var, flag in (("SGV3D_NO_PW_KERNEL", "1"), (None, None), ("SGV3D_SWAP_EPI", "1")):
+        if var:
+            os.environ[var] = flag
+        try:
+            row.append((time_alone(fn), time_loaded(fn)))
+        finally:
+            if var:
+                os.environ.pop(var, None)
+    print(f"{cin:5d}->{cout:5d} @{H}x{W} res={int(with_res)}:  generic {row[0][0]:6.1f} us alone / {row[0][1]:6.1f} loaded   "
+          f"pointwise (default) {row[1][0]:6.1f} / {row[1][1]:6.1f}   swapped 16-byte epilogue {row[2][0]:6.1f} / {row[2][1]:6.1f}", flush=True)
