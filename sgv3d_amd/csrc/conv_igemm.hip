@@ -49,6 +49,33 @@ __device__ long long *g_igemm_dbg = nullptr;
 #define IGEMM_STAMP(i) do { } while (0)
 #endif
 
+// Split-K second stage, row-linear outputs (NHWC with channel offset, f32, no SE gate, N % 4 == 0): four channels per
+// thread, 16-byte accesses, 32-bit index arithmetic -- the same sums in the same order as the generic kernel below, at a
+// fifth of its vector instructions (which are MFMA time of the SIMD they run on).
+__global__ __launch_bounds__(256) void conv_splitk_reduce4_kernel(const ConvArgs a) {
+    const unsigned n4 = (unsigned)a.N >> 2;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    const unsigned total4 = (unsigned)a.M * n4;
+    if (i >= total4) return;
+    const unsigned row = i / n4, col = (i - row * n4) * 4u;
+    const size_t stride = (size_t)a.M * a.N;
+    const float *p = a.ws + (size_t)row * a.N + col;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < a.split_k; ++s) {
+        const float4 t = *reinterpret_cast<const float4 *>(p + (size_t)s * stride);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const float4 sc = a.scale ? *reinterpret_cast<const float4 *>(a.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = a.bias ? *reinterpret_cast<const float4 *>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    if (a.res) {
+        const float4 r = *reinterpret_cast<const float4 *>(a.res + (size_t)row * a.res_ld + col);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4 *>(a.y + (size_t)row * a.y_ld + a.y_coff + col) = v;
+}
+
 // Split-K second stage: sums the split partials in fixed order and runs the common epilogue.
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs a) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -483,6 +510,8 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(has_res ? a.res + tile_row * a.res_ld : a.zeros), 0, has_res ? (int)0xffffff00u : 0, 0x00020000);
         const float floor_ = (!partial && a.relu) ? 0.f : -__builtin_inff();
+        // raw: nothing to apply (split-K partials; the grouped GEMM of the F(4x4) path): the accumulators are stored as they are
+        const bool raw = partial || (a.scale == nullptr && a.bias == nullptr && !has_res && !a.relu);
         unsigned voff[WTN], roff[WTN];
         float sc[WTN], sh[WTN];
 #pragma unroll
@@ -498,7 +527,7 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     {                                                                                                 \
         const unsigned r_ = (MT) * 32 + ((E) & 3) + 8 * ((E) >> 2);                                   \
         float v_ = acc[MT][NT][E];                                                                    \
-        if (!partial) {                                                                               \
+        if (!raw) {                                                                                   \
             v_ = v_ * sc[NT] + sh[NT];                                                                \
             if constexpr (kPrefetchRes) {                                                             \
                 v_ += resv[MT][NT][E]; /* zeros when there is no residual */                          \
@@ -1278,6 +1307,14 @@ int pick_tile(long long M, int N) {
 namespace sgv3d {
 int launch_splitk_reduce(const ConvArgs &a, hipStream_t st) {
     const long long total = (long long)a.M * a.N;
+    const bool quads = a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr && a.N % 4 == 0 && a.y_ld % 4 == 0 && a.y_coff % 4 == 0 &&
+                       (a.res == nullptr || a.res_ld % 4 == 0) && total / 4 < 0x7fffffffLL &&
+                       ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.res) | reinterpret_cast<uintptr_t>(a.ws) |
+                         reinterpret_cast<uintptr_t>(a.scale) | reinterpret_cast<uintptr_t>(a.bias)) & 15) == 0;
+    if (quads) {
+        hipLaunchKernelGGL(conv_splitk_reduce4_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, a);
+        return check_launch("conv_splitk_reduce4_kernel");
+    }
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, a);
     return check_launch("conv_splitk_reduce_kernel");
 }

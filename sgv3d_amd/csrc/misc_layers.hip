@@ -284,48 +284,59 @@ __global__ __launch_bounds__(kBlock) void bsm_compose_kernel(long long pixels, i
 
 // mmcv DeformConv2dPack sampling (DCNv1: deformable_im2col + bilinear with zero padding;
 // configured at lss_fpn.py:190-198: 3x3, pad 1, stride 1, dil 1, deform_groups 1)
+// One half-wave (32 lanes) per (pixel, tap): the sampling position, the four corner offsets and the bilinear weights are
+// computed once (32-bit arithmetic) and the lanes walk over the channel quads -- the first version recomputed them, with
+// 64-bit divisions, for every quad (this kernel runs between f32-MFMA convolutions and every vector instruction of it is
+// MFMA time of the SIMD it runs on, tools/valu_tax.py).
 __global__ __launch_bounds__(kBlock) void deform_im2col3x3_kernel(int B, int H, int W, int C, int groups,
                                                                   const float *__restrict__ x,
                                                                   const float *__restrict__ off, int off_ld,
                                                                   float *__restrict__ col) {
     const int C4 = C >> 2;
-    const long long total = (long long)B * H * W * 9 * C4;
-    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= total) return;
-    const int c4 = (int)(i % C4);
-    long long t = i / C4;
-    const int tap = (int)(t % 9);
-    t /= 9;  // pixel index b*H*W + h*W + w
-    const int w_ = (int)(t % W);
-    const long long t2 = t / W;
-    const int h_ = (int)(t2 % H);
-    const int b = (int)(t2 / H);
+    const int lane = threadIdx.x & 31;
+    const unsigned pt = blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5);      // (pixel, tap) pair
+    const unsigned npt = (unsigned)B * H * W * 9;
+    if (pt >= npt) return;
+    const unsigned t = pt / 9u;                 // pixel index b*H*W + h*W + w
+    const int tap = (int)(pt - t * 9u);
+    const unsigned t2 = t / (unsigned)W;
+    const int w_ = (int)(t - t2 * W);
+    const int b = (int)(t2 / (unsigned)H);
+    const int h_ = (int)(t2 - (unsigned)b * H);
     const int ky = tap / 3, kx = tap - ky * 3;
-    const float oy = off[t * off_ld + 2 * tap], ox = off[t * off_ld + 2 * tap + 1];
+    const float oy = off[(size_t)t * off_ld + 2 * tap], ox = off[(size_t)t * off_ld + 2 * tap + 1];
     const float hf = (float)(h_ - 1 + ky) + oy;
     const float wf = (float)(w_ - 1 + kx) + ox;
-    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (hf > -1.f && wf > -1.f && hf < (float)H && wf < (float)W) {
-        const int h_low = (int)floorf(hf), w_low = (int)floorf(wf);
-        const int h_high = h_low + 1, w_high = w_low + 1;
-        const float lh = hf - (float)h_low, lw = wf - (float)w_low;
-        const float hh = 1.f - lh, hw = 1.f - lw;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float *base = x + (long long)b * H * W * C + c4 * 4;
-        const float4 v1 = (h_low >= 0 && w_low >= 0) ? *reinterpret_cast<const float4 *>(base + ((long long)h_low * W + w_low) * C) : z;
-        const float4 v2 = (h_low >= 0 && w_high <= W - 1) ? *reinterpret_cast<const float4 *>(base + ((long long)h_low * W + w_high) * C) : z;
-        const float4 v3 = (h_high <= H - 1 && w_low >= 0) ? *reinterpret_cast<const float4 *>(base + ((long long)h_high * W + w_low) * C) : z;
-        const float4 v4 = (h_high <= H - 1 && w_high <= W - 1) ? *reinterpret_cast<const float4 *>(base + ((long long)h_high * W + w_high) * C) : z;
-        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-        val.x = w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
-        val.y = w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
-        val.z = w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
-        val.w = w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
-    }
+    const bool inside = hf > -1.f && wf > -1.f && hf < (float)H && wf < (float)W;
+    const int h_low = (int)floorf(hf), w_low = (int)floorf(wf);
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const float lh = hf - (float)h_low, lw = wf - (float)w_low;
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    // a corner outside the image contributes zero: weight 0 and a clamped (valid) address
+    const bool ok1 = inside && h_low >= 0 && w_low >= 0, ok2 = inside && h_low >= 0 && w_high <= W - 1;
+    const bool ok3 = inside && h_high <= H - 1 && w_low >= 0, ok4 = inside && h_high <= H - 1 && w_high <= W - 1;
+    const float w1 = ok1 ? hh * hw : 0.f, w2 = ok2 ? hh * lw : 0.f, w3 = ok3 ? lh * hw : 0.f, w4 = ok4 ? lh * lw : 0.f;
+    const float *base = x + (size_t)b * H * W * C;
+    const float *p1 = base + (ok1 ? ((size_t)h_low * W + w_low) * C : 0);
+    const float *p2 = base + (ok2 ? ((size_t)h_low * W + w_high) * C : 0);
+    const float *p3 = base + (ok3 ? ((size_t)h_high * W + w_low) * C : 0);
+    const float *p4 = base + (ok4 ? ((size_t)h_high * W + w_high) * C : 0);
     const int cpg = C / groups;
-    const int c = c4 * 4;
-    const int g = c / cpg, cg = c - g * cpg;
-    *reinterpret_cast<float4 *>(col + ((t * groups + g) * 9 + tap) * cpg + cg) = val;
+    float *cbase = col + (size_t)t * groups * 9 * cpg;
+    for (int c4 = lane; c4 < C4; c4 += 32) {
+        const int c = c4 * 4;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (inside) {                           // (uniform over the half-wave)
+            const float4 v1 = *reinterpret_cast<const float4 *>(p1 + c), v2 = *reinterpret_cast<const float4 *>(p2 + c);
+            const float4 v3 = *reinterpret_cast<const float4 *>(p3 + c), v4 = *reinterpret_cast<const float4 *>(p4 + c);
+            val.x = w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+            val.y = w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+            val.z = w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+            val.w = w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+        }
+        const int g = c / cpg, cg = c - g * cpg;
+        *reinterpret_cast<float4 *>(cbase + ((size_t)g * 9 + tap) * cpg + cg) = val;
+    }
 }
 
 // CenterHead second-layer 3x3 convs of all branches in one launch (mmdet3d SeparateHead final conv,
@@ -589,8 +600,9 @@ extern "C" int sgv3d_deform_im2col3x3(int batch, int h, int w, int channels, int
                       ((channels / groups) & 3) == 0 && off_ld >= 18,
                   "deform_im2col3x3: bad shape");
     SGV3D_REQUIRE(x && offset && col, "deform_im2col3x3: null pointer");
-    const long long total = (long long)batch * h * w * 9 * (channels / 4);
-    hipLaunchKernelGGL(deform_im2col3x3_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, as_stream(stream), batch, h, w,
+    const long long pairs = (long long)batch * h * w * 9;           // one half-wave per (pixel, tap)
+    SGV3D_REQUIRE(pairs < 0x7fffffffLL, "deform_im2col3x3: too many pixels");
+    hipLaunchKernelGGL(deform_im2col3x3_kernel, dim3(cdiv(pairs, kBlock / 32)), dim3(kBlock), 0, as_stream(stream), batch, h, w,
                        channels, groups, x, offset, off_ld, col);
     return check_launch("deform_im2col3x3_kernel");
 }
