@@ -1,9 +1,10 @@
 #!/bin/bash
 # rocprof kernel summary of the cfg-2 training step (tools/train_bench.py), copied to profiles/ afterwards
 set -e
-OUT=$PWD/gpurun_out/profiles_r01_train
+TAG=${1:-r03}
+OUT=$PWD/gpurun_out/profiles_${TAG}_train
 mkdir -p $OUT
-export SGV3D_TUNE_CACHE=$OUT/train_tune_cache.json   # the profiled run replays the choices of the first run
+export SGV3D_TUNE_CACHE=$OUT/train_tune_cache.json   # the profiled run replays the choices of the first run (training shapes are not in tune/)
 python tools/train_bench.py --batch 2 --steps 5 --warmup 2 --profile > $OUT/train_bench.json 2> $OUT/train_bench.err
 python tools/train_bench.py --batch 4 --steps 5 --warmup 2 > $OUT/train_bench_b4.json 2> $OUT/train_bench_b4.err
 python tools/train_bench.py --config cfg5 --batch 2 --steps 3 --warmup 2 --profile > $OUT/train_bench_cfg5_b2.json 2> $OUT/train_bench_cfg5_b2.err || true
