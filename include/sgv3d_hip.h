@@ -76,7 +76,10 @@ int sgv3d_voxel_pooling_forward_atomic(int batch_size, int num_points, int num_c
  *
  * Plan layout (bytes from sgv3d_voxel_plan_bytes, 16-B aligned by the caller):
  *   int32 seg_start[B*Y*X + 1] | int32 cursor[B*Y*X + 1] | int32 order[B*N] | int32 slot_voxel[B*N + 1]
- *   | int32 scan scratch | cache header (11 x int32) | int32 geom_xyz copy [B*N*3] (cached build only)  */
+ *   | int32 scan scratch | cache header (11 x int32) | int32 geom_xyz copy [B*N*3] (cached build only)
+ *   | int32 long-run list [1 + B*N/128 + 1]: count, then the voxels holding more than 128 points (slot_voxel carries
+ *     ~voxel for their slots: the gather's waves leave them to the long-run workgroups of the same launch)
+ * A plan must not be used by two launches at the same time only if one of them rebuilds it; gathers only read it. */
 size_t sgv3d_voxel_plan_bytes(int batch_size, int num_points, int num_voxel_x, int num_voxel_y);
 
 /* Build the plan.  pos_memo as above (may be NULL).  sort_segments != 0 makes every voxel's point
@@ -104,9 +107,9 @@ int sgv3d_voxel_plan_build_cached(int batch_size, int num_points,
 size_t sgv3d_voxel_plan_stats_offset(int batch_size, int num_points, int num_voxel_x, int num_voxel_y);
 
 /* output_features f32 [B, Y, X, C], fully overwritten.  Replaces the same reference kernel
- * (voxel_pooling_forward_cuda.cu:9-36) when the caller holds a plan.  `workspace` (bytes from
- * sgv3d_voxel_pooling_workspace_bytes, 16-B aligned) holds the partial rows of voxels whose point
- * list is cut by a work-chunk border; it is scratch, its content is meaningless after the call. */
+ * (voxel_pooling_forward_cuda.cu:9-36) when the caller holds a plan.  One launch (vp_gather_fast_kernel: every voxel is
+ * summed by one wave, rows written once, empty voxels zero-filled).  `workspace`: unused since round 3 (the round-2 gather
+ * staged partial rows there); sgv3d_voxel_pooling_workspace_bytes returns 16 and the argument may be any pointer or NULL. */
 size_t sgv3d_voxel_pooling_workspace_bytes(int batch_size, int num_points, int num_channels);
 int sgv3d_voxel_pooling_forward_planned(int batch_size, int num_points, int num_channels,
                                         int num_voxel_x, int num_voxel_y,
