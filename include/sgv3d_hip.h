@@ -232,6 +232,8 @@ typedef struct sgv3d_conv_desc {
 #define SGV3D_TILE_128x64 2
 #define SGV3D_TILE_64x128 3
 #define SGV3D_TILE_64x64 4
+/* sgv3d_conv2d_winograd4_forward only: the grouped GEMM on a 32 x 128 tile (rows per position padded to 32 instead of 64) */
+#define SGV3D_TILE_32x128 9
 /* ... | SGV3D_TILE_MFIRST: the workgroups walk the output-channel tiles of one m-tile back to back (input rows fetched once
  * from HBM) instead of the m-tiles of one channel tile (weight tile shared); same results */
 #define SGV3D_TILE_MFIRST 16
@@ -249,7 +251,7 @@ typedef struct sgv3d_conv_desc {
  * u_packed: 36 blocks of [cout_pad][k_pad] floats (sgv3d_conv_pack_geometry(cin, cout)); block p = 6 i + j holds the 1x1
  * weight (G g G^T)[i][j] ([cout, cin], G the 6x3 F(4x4,3x3) matrix) packed by sgv3d_conv_pack_weight with desc.k_order.
  * desc as for sgv3d_conv2d_winograd_forward, NORMAL mode, no gate, no split-K; desc.k_pad / cout_pad describe one block;
- * desc.tile = SGV3D_TILE_64x64 (default) | SGV3D_TILE_64x128 picks the GEMM tile.  workspace: V and M
+ * desc.tile = SGV3D_TILE_64x64 (default) | SGV3D_TILE_64x128 | SGV3D_TILE_32x128 picks the GEMM tile.  workspace: V and M
  * (sgv3d_conv2d_winograd4_workspace_bytes, 16-B aligned).  fp32 error ~1e-5 of the output scale. */
 size_t sgv3d_conv2d_winograd4_workspace_bytes(const sgv3d_conv_desc *desc /*host*/);
 int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *u_packed,

@@ -104,11 +104,17 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
 // the sum of their times, 933 + 584 -> 1445 us), so every vector instruction of the address arithmetic is MFMA time of the
 // whole SIMD.  Here the A operand needs none inside the loop: the lane offset is fixed (out of range for rows past M), the
 // k-tile offset is a scalar register, and past the last tile the last one is re-read (its data is never stored).
-template <int WTM, int WTN, bool FAST, bool SWAP = false, bool PW = false>
+//
+// NARROW (with WTM = WTN = 1): a 32 x 128 tile -- the four waves side by side along N, each one 32 x 32 MFMA tile -- for GEMMs
+// whose row count is a multiple of 32 but not of 64: the grouped GEMM of the F(4x4) path pads the tiles of a position to the
+// m-tile height, and 336 tiles are 352 rows instead of 384, 84 are 96 instead of 128.
+template <int WTM, int WTN, bool FAST, bool SWAP = false, bool PW = false, bool NARROW = false>
 __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm_kernel(const ConvArgs a) {
     static_assert(!SWAP || (WTM == 1 && WTN == 1), "the swapped epilogue is written for the 64x64 tile");
     static_assert(!PW || FAST, "the pointwise specialisation is for the channel-chunk-major k order");
-    constexpr int BM = 64 * WTM, BN = 64 * WTN;
+    static_assert(!NARROW || (WTM == 1 && WTN == 1 && !SWAP), "the narrow tile is one MFMA tile per wave");
+    constexpr int BM = NARROW ? 32 : 64 * WTM, BN = NARROW ? 128 : 64 * WTN;
+    constexpr int WSM = NARROW ? 32 : BM / 2, WSN = NARROW ? 32 : BN / 2;      // rows / columns between neighbouring waves
     constexpr int A_CH = BM / 32, B_CH = BN / 32;  // 16-B chunks per thread per k-tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     IGEMM_STAMP(0);
@@ -321,10 +327,10 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
 
     // ---- MFMA fragments ------------------------------------------------------------------------
     const int wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NARROW ? 0 : wave >> 1, wn = NARROW ? wave : wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
-    const int a_frag_off = (wm * (BM / 2) + lr) * LDK + lh * 4;
-    const int b_frag_off = (wn * (BN / 2) + lr) * LDK + lh * 4;
+    const int a_frag_off = (wm * WSM + lr) * LDK + lh * 4;
+    const int b_frag_off = (wn * WSN + lr) * LDK + lh * 4;
 
     f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     // (GROUP_PLANES -- the per-branch hidden maps of the two-kernel head path -- is row-linear too when a wave's columns
     // stay inside one group: plane base + row * group width)
     const bool fast_epi = (a.split_k > 1 || (a.mode == SGV3D_CONV_NORMAL && a.gate == nullptr) ||
-                           (a.mode == SGV3D_CONV_GROUP_PLANES && a.gate == nullptr && a.ks % (BN / 2) == 0)) && m0 + BM <= a.M;
+                           (a.mode == SGV3D_CONV_GROUP_PLANES && a.gate == nullptr && a.ks % WSN == 0)) && m0 + BM <= a.M;
     // the first two k-tiles are asked for BEFORE the residual rows: memory returns in order, and the wait for k-tile 0
     // (the workgroup's prologue: 9-13 k cycles on a loaded chip, tools/igemm_stamps.py) must not queue behind 16 more loads
     SGV3D_LOAD_TILE(ra0, rb0);                       // tile 0
@@ -422,12 +428,12 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     }
     if constexpr (kPrefetchRes && !SWAP) {
         const bool want = fast_epi && a.split_k <= 1 && a.res != nullptr;
-        const long long tile_row = m0 + __builtin_amdgcn_readfirstlane(wm) * (BM / 2);
+        const long long tile_row = m0 + __builtin_amdgcn_readfirstlane(wm) * WSM;
         const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(want ? a.res + tile_row * a.res_ld : a.zeros), 0, want ? (int)0xffffff00u : 0, 0x00020000);
 #pragma unroll
         for (int nt = 0; nt < WTN; ++nt) {
-            const int col = n0 + wn * (BN / 2) + nt * 32 + lr;
+            const int col = n0 + wn * WSN + nt * 32 + lr;
             const unsigned roff0 = (want && col < a.N) ? (4u * lh * (unsigned)a.res_ld + col) * 4u : 0xffffffffu;
 #pragma unroll
             for (int mt = 0; mt < WTM; ++mt)
@@ -497,10 +503,10 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
         const bool partial = a.split_k > 1;
         const int wmu = __builtin_amdgcn_readfirstlane(wm);
         const bool planes = !partial && a.mode == SGV3D_CONV_GROUP_PLANES;
-        const int grp = planes ? (n0 + __builtin_amdgcn_readfirstlane(wn) * (BN / 2)) / a.ks : 0;
+        const int grp = planes ? (n0 + __builtin_amdgcn_readfirstlane(wn) * WSN) / a.ks : 0;
         const int col_sub = grp * a.ks;                      // columns are counted inside the group's plane
         const unsigned ld = partial ? (unsigned)a.N : planes ? (unsigned)a.ks : (unsigned)a.y_ld;
-        const long long tile_row = m0 + wmu * (BM / 2);
+        const long long tile_row = m0 + wmu * WSM;
         const float *const ybase = partial ? a.ws + ((size_t)blockIdx.y * a.M + tile_row) * a.N
                                    : planes ? a.y + ((size_t)grp * a.M + tile_row) * a.ks
                                             : a.y + tile_row * a.y_ld + a.y_coff;
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
         float sc[WTN], sh[WTN];
 #pragma unroll
         for (int nt = 0; nt < WTN; ++nt) {
-            const int col = n0 + wn * (BN / 2) + nt * 32 + lr;
+            const int col = n0 + wn * WSN + nt * 32 + lr;
             const bool ok = col < a.N;
             voff[nt] = ok ? (4u * lh * ld + (col - col_sub)) * 4u : 0xffffffffu;
             roff[nt] = ok ? (4u * lh * (unsigned)a.res_ld + col) * 4u : 0xffffffffu;
@@ -556,8 +562,8 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     // General path (pixel-shuffle / NCHW / grouped-plane layouts, SE gate, ragged last m-tile); expanded by
     // hand: the accumulators must keep compile-time register indices.
     float *ws = a.split_k > 1 ? a.ws + (size_t)blockIdx.y * a.M * a.N : nullptr;
-    const int row_base = m0 + wm * (BM / 2) + 4 * lh;
-    const int col_base = n0 + wn * (BN / 2) + lr;
+    const int row_base = m0 + wm * WSM + 4 * lh;
+    const int col_base = n0 + wn * WSN + lr;
 #define SGV3D_EPI_E(MT, NT, E)                                                                        \
     {                                                                                                 \
         const int col_ = col_base + (NT) * 32;                                                        \
@@ -1242,6 +1248,21 @@ int launch_t(const ConvArgs &a, hipStream_t st) {
     return check_launch("conv_igemm_kernel");
 }
 
+// 32 x 128 tile, pointwise (conv_gemm_grouped only)
+int launch_narrow_pw(const ConvArgs &a, hipStream_t st) {
+    constexpr size_t lds = sizeof(float) * 2 * (32 + 128) * LDK;
+    ConvArgs b = a;
+    b.zeros = conv_zero_block();
+    if (!b.zeros) return fail(SGV3D_ELAUNCH, "conv_gemm_grouped: cannot resolve the zero block");
+    b.tiles_m = cdiv(a.M, 32);
+    b.tiles_n = cdiv(a.N, 128);
+    static PerDeviceSize lds_set;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel<1, 1, true, false, true, true>), lds, lds_set))
+        return fail(SGV3D_ELAUNCH, "conv_gemm_grouped: cannot raise the dynamic LDS limit to %zu", lds);
+    hipLaunchKernelGGL((conv_igemm_kernel<1, 1, true, false, true, true>), dim3(b.tiles_m * b.tiles_n, 1), dim3(kThreads), lds, st, b);
+    return check_launch("conv_igemm_kernel(narrow)");
+}
+
 template <int WTM, int WTN>
 int launch(const ConvArgs &a, hipStream_t st) {
     return (a.korder & 1) ? launch_t<WTM, WTN, true>(a, st) : launch_t<WTM, WTN, false>(a, st);
@@ -1381,9 +1402,11 @@ namespace sgv3d {
 int conv_gemm_grouped(const float *x, const float *w, float *y, int rows, int groups, int K, int N, int k_pad, int cout_pad,
                       int k_order, int tile, hipStream_t st) {
     SGV3D_REQUIRE(x && w && y && rows > 0 && groups > 0 && K > 0 && N > 0, "conv_gemm_grouped: bad argument");
-    SGV3D_REQUIRE(rows % 64 == 0 && K % 4 == 0 && k_pad >= K && k_pad % BK == 0 && cout_pad >= N && cout_pad % 128 == 0,
-                  "conv_gemm_grouped: rows %% 64, K %% 4, k_pad / cout_pad as packed (rows=%d K=%d k_pad=%d N=%d cout_pad=%d)", rows, K,
-                  k_pad, N, cout_pad);
+    const bool narrow = tile == SGV3D_TILE_32x128;
+    SGV3D_REQUIRE(rows % (narrow ? 32 : 64) == 0 && K % 4 == 0 && k_pad >= K && k_pad % BK == 0 && cout_pad >= N && cout_pad % 128 == 0,
+                  "conv_gemm_grouped: rows %% 64 (32 for the narrow tile), K %% 4, k_pad / cout_pad as packed (rows=%d K=%d k_pad=%d N=%d cout_pad=%d)",
+                  rows, K, k_pad, N, cout_pad);
+    SGV3D_REQUIRE(!narrow || (k_order == 1 && K % BK == 0 && K >= 128), "conv_gemm_grouped: the narrow tile needs K %% 32 == 0, K >= 128");
     SGV3D_REQUIRE(k_order == 0 || K % BK == 0, "conv_gemm_grouped: k_order 1 needs K %% 32 == 0");
     const long long M = (long long)rows * groups;
     SGV3D_REQUIRE(M < 0x7fffffffLL && M * K * 4 < 0xf0000000LL && (long long)cout_pad * k_pad * 4 < 0xf0000000LL,
@@ -1403,9 +1426,10 @@ int conv_gemm_grouped(const float *x, const float *w, float *y, int rows, int gr
     a.split_k = 1; a.ws = nullptr;
     a.wb_y = rows; a.wb_x = cout_pad * k_pad;
     switch (tile) {
+        case SGV3D_TILE_32x128: return launch_narrow_pw(a, st);
         case SGV3D_TILE_64x128: return launch<1, 2>(a, st);
         case SGV3D_TILE_64x64: return launch<1, 1>(a, st);
-        default: return fail(SGV3D_EINVAL, "conv_gemm_grouped: tile must be 64x64 or 64x128 (got %d)", tile);
+        default: return fail(SGV3D_EINVAL, "conv_gemm_grouped: tile must be 64x64, 64x128 or 32x128 (got %d)", tile);
     }
 }
 }  // namespace sgv3d

@@ -171,7 +171,8 @@ void wino4_geom(const sgv3d_conv_desc *d, int &ty, int &tx, long long &tiles, in
     ty = cdiv(cdiv(d->out_h, dil), 4);
     tx = cdiv(cdiv(d->out_w, dil), 4);
     tiles = (long long)d->batch * dil * dil * ty * tx;
-    rows = (int)((tiles + 63) / 64 * 64);
+    const int g = d->tile == SGV3D_TILE_32x128 ? 32 : 64;       // the GEMM's m-tile height
+    rows = (int)((tiles + g - 1) / g * g);
 }
 
 }  // namespace
@@ -221,7 +222,7 @@ extern "C" int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *d, const fl
     a.m = a.v + (size_t)36 * a.rows * d->cin;
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(wino4_input_kernel, dim3(cdiv(tiles * (d->cin / 4), 256)), dim3(256), 0, st, a);
-    const int tile = (d->tile == SGV3D_TILE_64x128) ? SGV3D_TILE_64x128 : SGV3D_TILE_64x64;
+    const int tile = (d->tile == SGV3D_TILE_64x128 || d->tile == SGV3D_TILE_32x128) ? d->tile : SGV3D_TILE_64x64;
     if (int rc = conv_gemm_grouped(a.v, u_packed, a.m, a.rows, 36, d->cin, d->cout, d->k_pad, d->cout_pad, d->k_order, tile, st)) return rc;
     hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(tiles * (d->cout / 4), 256)), dim3(256), 0, st, a);
     return check_launch("conv2d_winograd4_forward");

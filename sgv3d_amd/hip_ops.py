@@ -111,7 +111,7 @@ def load_default_tune_dbs():
 load_default_tune_dbs()
 load_tune_db()
 TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: "wino_resident", 7: "patch_bf16", 8: "wino_half",
-              9: "wino4", 10: "wino4",                                      # 9 / 10: F(4x4,3x3) with the 64x64 / 64x128 GEMM tile
+              9: "wino4", 10: "wino4", 15: "wino4",                         # F(4x4,3x3) with the 64x64 / 64x128 / 32x128 GEMM tile
               11: "128x128", 12: "128x64", 13: "64x128", 14: "64x64",      # 11..14: f32x3 of tiles 1..4 (host-side ids)
               21: "128x128", 22: "128x64", 23: "64x128", 24: "64x64"}      # 21..24: tiles 1..4 walked m-tile first (SGV3D_TILE_MFIRST)
 MFIRST = _os.environ.get("SGV3D_MFIRST", "1") != "0"
@@ -121,6 +121,8 @@ TILE_PATCH = 7      # bf16 mode: the LDS-resident-patch 3x3 kernel (sgv3d_conv3x
 TILE_WINO_HALF = 8  # = SGV3D_WINOGRAD_HALF: 64 tiles x 32 channels per workgroup, positions split over wave pairs (2 workgroups / CU)
 TILE_WINO4 = 9      # Winograd F(4x4,3x3) in three launches (sgv3d_conv2d_winograd4_forward), GEMM tile 64x64; 10: 64x128
 TILE_WINO4_WIDE = 10
+TILE_WINO4_NARROW = 15   # ... with the 32x128 GEMM tile: rows per position padded to 32 instead of 64 (336 tiles -> 352, 84 -> 96)
+WINO4_TILES = (TILE_WINO4, TILE_WINO4_WIDE, TILE_WINO4_NARROW)
 WINO4 = _os.environ.get("SGV3D_WINO4", "1") != "0"     # 0: F(4x4) is never a candidate
 WINO4_MIN_CHANNELS = 128                              # candidates only where cin and cout are at least this
 WINO_HALF = _os.environ.get("SGV3D_WINO_HALF", "1") != "0"
@@ -413,9 +415,9 @@ class PackedConv:
         real_n = self.cout_real * (self.ks * self.ks if self.transposed else 1)
         flops = 2.0 * gemm_m * real_n * (self.cin_real * self.kh * self.kw)
         x3 = 10 < t < 20 or (MFMA_F32X3 is True and t < TILE_WINO)
-        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF, TILE_WINO4, TILE_WINO4_WIDE) else
+        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) + WINO4_TILES else
                 ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_f32x3_" if x3 else "conv_igemm_")) + TILE_NAMES[t]
-        if t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF, TILE_WINO4, TILE_WINO4_WIDE) and self.k_order == 0:
+        if t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) + WINO4_TILES and self.k_order == 0:
             name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
@@ -466,13 +468,13 @@ class PackedConv:
                                                         d.y_coff, d.res_ld, d.relu, x.data_ptr(), self._patch_weights().data_ptr(),
                                                         _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
                                                         out.data_ptr(), int(io), int(d.split_k), _lib.ptr(ws), nws, _st(x))
-        if d.tile in (TILE_WINO4, TILE_WINO4_WIDE):
+        if d.tile in WINO4_TILES:
             if not self.wino4_ok(d, gate) or d.split_k > 1:
                 raise _lib.SGV3DError("F(4x4) Winograd covers f32 3x3 / stride 1 / pad 1 layers with cin % 32 == 0, cout % 4 == 0, "
                                       "NHWC output, no gate, no split-K")
             u = self._wino4_weights()
             host_tile, kp, cp = d.tile, d.k_pad, d.cout_pad
-            d.tile = 3 if host_tile == TILE_WINO4_WIDE else 4
+            d.tile = {TILE_WINO4: 4, TILE_WINO4_WIDE: 3, TILE_WINO4_NARROW: 9}[host_tile]      # SGV3D_TILE_64x64 / 64x128 / 32x128
             d.k_pad, d.cout_pad = self.wino4_geom
             try:
                 nws4 = lib.sgv3d_conv2d_winograd4_workspace_bytes(ctypes.byref(d))
@@ -552,7 +554,7 @@ class PackedConv:
                 tiles += (TILE_WINO_RES,)
 
         if self.wino4_ok(d, gate):            # (also the dilated 3x3 layers, which the F(2x2) kernels do not cover)
-            tiles += (TILE_WINO4, TILE_WINO4_WIDE)
+            tiles += WINO4_TILES if self.cin >= 128 else (TILE_WINO4, TILE_WINO4_WIDE)
         if self._patch_eligible(d, gate):
             tiles += (TILE_PATCH,)
         if fixed_tile:
@@ -572,7 +574,7 @@ class PackedConv:
                 if t == TILE_PATCH:
                     nk = self.cin // 32     # stages of 32 input channels; >= 2 per split
                     wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 32) * -(-gemm_n // 64)
-                if t in (TILE_WINO_RES, TILE_WINO4, TILE_WINO4_WIDE):
+                if t == TILE_WINO_RES or t in WINO4_TILES:
                     splits = (1,)
                 elif t == TILE_PATCH and not fixed_split and SPLIT_K:
                     splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 2 and wgs * s <= 1024]

@@ -19,4 +19,9 @@ SGV3D_TUNE_CACHE=$OUT/gfx950_cfg5_bf16.json python3 bench.py --sub --config cfg5
 echo "cfg5 rc=$?"
 SGV3D_TUNE_CACHE=$OUT/gfx950_cfg5_bf16.json python3 bench.py --sub --config cfg5 --batch 4 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/cfg5b4.json 2> $OUT/cfg5b4.err
 echo "cfg5 b4 rc=$?"
+# one frame in flight for the bf16 configs too ("|ts1": what the --streams 1 profile runs replay)
+SGV3D_TUNE_CACHE=$OUT/gfx950_cfg3_bf16.json python3 bench.py --sub --config cfg3 --batch 4 --dtype bf16 --steps 3 --warmup 2 --streams 1 --no-cpu-baseline --no-roofline > $OUT/cfg3s1.json 2> $OUT/cfg3s1.err
+echo "cfg3 streams 1 rc=$?"
+SGV3D_TUNE_CACHE=$OUT/gfx950_cfg5_bf16.json python3 bench.py --sub --config cfg5 --batch 1 --dtype bf16 --steps 3 --warmup 2 --streams 1 --no-cpu-baseline --no-roofline > $OUT/cfg5s1.json 2> $OUT/cfg5s1.err
+echo "cfg5 streams 1 rc=$?"
 wc -c $OUT/gfx950_*.json

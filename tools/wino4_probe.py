@@ -8,7 +8,7 @@ from sgv3d_amd.hip_ops import PackedConv
 
 LAYERS = [(512, 54, 96, 512), (256, 54, 96, 256), (512, 27, 48, 512), (640, 32, 32, 640), (320, 64, 64, 320), (128, 108, 192, 128),
           (160, 128, 128, 160)]
-CANDS = [(9, 1), (10, 1), (8, 1), (8, 2), (5, 1), (5, 2), (5, 3), (4, 1)]
+CANDS = [(9, 1), (10, 1), (15, 1), (8, 1), (8, 2), (5, 1), (5, 2), (5, 3), (4, 1)]
 streams = [torch.cuda.Stream() for _ in range(3)]
 
 
@@ -50,7 +50,7 @@ for layer in [l + (1,) for l in LAYERS] + DIL:
     for t, sk in CANDS:
         if t in (5, 8) and conv.w_wino is None:
             continue
-        if t in (9, 10) and not conv.wino4_ok():
+        if t in (9, 10, 15) and not conv.wino4_ok():
             continue
         if t in (5, 8) and cin // 4 // sk < 8 and sk > 1:
             continue
