@@ -75,6 +75,8 @@ struct Wino4Args {
     int dil;               // dilation (pad == dil): the convolution splits into dil x dil independent ones on the sub-grids
                            // (py + dil * i, px + dil * j); a tile is 4x4 outputs / 6x6 inputs of ONE sub-grid
     int rows;              // rows of V / M per position (tiles of all images and phases, padded to a multiple of 64)
+    int c0, cn;            // output-channel chunk [c0, c0 + cn) this pass of the GEMM / output transform covers (M holds cn columns)
+    int gw;                // 0: NHWC output; > 0 (GROUP_PLANES): y is [cout / gw][pixels][gw], one NHWC map per group of gw channels
 };
 
 // tile index -> (image, sub-grid phase, tile position inside the sub-grid)
@@ -126,15 +128,16 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const Wino4Args a) {
 
 // one thread: one tile x 4 output channels
 __global__ __launch_bounds__(256) void wino4_output_kernel(const Wino4Args a) {
-    const int cq = a.cout >> 2;
+    const int cq = a.cn >> 2;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long ntile = (long long)a.batch * a.ty * a.tx * a.dil * a.dil;
     if (i >= ntile * cq) return;
-    const int t = (int)(i / cq), c = (int)(i - (long long)t * cq) * 4;
+    const int t = (int)(i / cq), cl = (int)(i - (long long)t * cq) * 4;     // cl: column inside the chunk
+    const int c = a.c0 + cl;                                                // output channel
     int b, py, px, iy, ix;
     wino4_tile(a, t, b, py, px, iy, ix);
-    const float *mb = a.m + (size_t)t * a.cout + c;
-    const size_t plane = (size_t)a.rows * a.cout;
+    const float *mb = a.m + (size_t)t * a.cn + cl;
+    const size_t plane = (size_t)a.rows * a.cn;
     f4 rr_[4][6];                                           // A^T M: 4 x 6
 #pragma unroll
     for (int cc = 0; cc < 6; ++cc) {
@@ -160,7 +163,12 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const Wino4Args a) {
             f4 q = {fmaf(o[v].x, sc.x, sh.x), fmaf(o[v].y, sc.y, sh.y), fmaf(o[v].z, sc.z, sh.z), fmaf(o[v].w, sc.w, sh.w)};
             if (a.res) q = add4(q, ld4(a.res + pix * a.res_ld + c));
             q = {fmaxf(q.x, floor_), fmaxf(q.y, floor_), fmaxf(q.z, floor_), fmaxf(q.w, floor_)};
-            st4(a.y + pix * a.y_ld + a.y_coff + c, q);
+            if (a.gw > 0) {            // plane of the channel's group (gw % 4 == 0: a quad never straddles groups)
+                const int grp = c / a.gw;
+                st4(a.y + ((size_t)grp * a.batch * a.h * a.w + pix) * a.gw + (c - grp * a.gw), q);
+            } else {
+                st4(a.y + pix * a.y_ld + a.y_coff + c, q);
+            }
         }
     }
 }
@@ -175,6 +183,16 @@ void wino4_geom(const sgv3d_conv_desc *d, int &ty, int &tx, long long &tiles, in
     rows = (int)((tiles + g - 1) / g * g);
 }
 
+// Output channels per pass: M of a pass (36 x rows x chunk floats) is kept below ~160 MB so that it is still in the 256 MB
+// last-level cache when the output transform reads it back -- the 64 -> 2304 first layers of the CenterHead branches at
+// 256x256 would otherwise write and re-read 1.36 GB.  Multiples of 128 (the packed weight blocks' row granularity).
+int wino4_chunk(const sgv3d_conv_desc *d, int rows) {
+    const long long per_channel = 36LL * rows * 4;
+    long long cn = (160LL << 20) / per_channel / 128 * 128;
+    if (cn < 128) cn = 128;
+    return cn >= d->cout ? d->cout : (int)cn;
+}
+
 }  // namespace
 
 // bytes of V + M
@@ -183,7 +201,7 @@ extern "C" size_t sgv3d_conv2d_winograd4_workspace_bytes(const sgv3d_conv_desc *
     int ty, tx, rows;
     long long tiles;
     wino4_geom(d, ty, tx, tiles, rows);
-    return sizeof(float) * 36 * (size_t)rows * ((size_t)d->cin + (size_t)d->cout);
+    return sizeof(float) * 36 * (size_t)rows * ((size_t)d->cin + (size_t)wino4_chunk(d, rows));
 }
 
 // u_packed: 36 blocks [cout_pad][k_pad] (sgv3d_conv_pack_geometry(cin, cout)), block p = i * 6 + j the 1x1 weight
@@ -198,15 +216,18 @@ extern "C" int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *d, const fl
                   "conv2d_winograd4_forward: only 3x3 / stride 1 / pad == dilation");
     SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->out_h == d->in_h && d->out_w == d->in_w,
                   "conv2d_winograd4_forward: bad sizes");
-    SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL, "conv2d_winograd4_forward: NHWC output only");
-    SGV3D_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && (d->x_ld & 3) == 0 && (d->x_coff & 3) == 0 && (d->y_ld & 3) == 0 &&
-                      (d->y_coff & 3) == 0 && (residual == nullptr || (d->res_ld & 3) == 0),
+    const bool planes = d->mode == SGV3D_CONV_GROUP_PLANES;
+    SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL || planes, "conv2d_winograd4_forward: NHWC or GROUP_PLANES output only");
+    SGV3D_REQUIRE(!planes || (d->deconv_ks > 0 && d->deconv_ks % 4 == 0 && d->cout % d->deconv_ks == 0 && residual == nullptr),
+                  "conv2d_winograd4_forward: GROUP_PLANES needs deconv_ks = group width (a multiple of 4) dividing cout, no residual");
+    SGV3D_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && (d->x_ld & 3) == 0 && (d->x_coff & 3) == 0 &&
+                      (planes || ((d->y_ld & 3) == 0 && (d->y_coff & 3) == 0)) && (residual == nullptr || (d->res_ld & 3) == 0),
                   "conv2d_winograd4_forward: channel counts, leading dimensions and offsets must be multiples of 4");
     SGV3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
                     reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(u_packed) |
                     reinterpret_cast<uintptr_t>(workspace)) & 15) == 0,
                   "conv2d_winograd4_forward: pointers must be 16-B aligned");
-    SGV3D_REQUIRE(d->x_ld >= d->x_coff + d->cin && d->y_ld >= d->y_coff + d->cout && (residual == nullptr || d->res_ld >= d->cout),
+    SGV3D_REQUIRE(d->x_ld >= d->x_coff + d->cin && (planes || d->y_ld >= d->y_coff + d->cout) && (residual == nullptr || d->res_ld >= d->cout),
                   "conv2d_winograd4_forward: leading dimension too small");
     const size_t need = sgv3d_conv2d_winograd4_workspace_bytes(d);
     if (workspace_bytes < need) return fail(SGV3D_ENOSPACE, "conv2d_winograd4_forward: workspace has %zu bytes, needs %zu", workspace_bytes, need);
@@ -221,9 +242,20 @@ extern "C" int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *d, const fl
     a.v = static_cast<float *>(workspace);
     a.m = a.v + (size_t)36 * a.rows * d->cin;
     hipStream_t st = as_stream(stream);
+    a.gw = planes ? d->deconv_ks : 0;
+    a.c0 = 0; a.cn = d->cout;
     hipLaunchKernelGGL(wino4_input_kernel, dim3(cdiv(tiles * (d->cin / 4), 256)), dim3(256), 0, st, a);
-    const int tile = (d->tile == SGV3D_TILE_64x128 || d->tile == SGV3D_TILE_32x128) ? d->tile : SGV3D_TILE_64x64;
-    if (int rc = conv_gemm_grouped(a.v, u_packed, a.m, a.rows, 36, d->cin, d->cout, d->k_pad, d->cout_pad, d->k_order, tile, st)) return rc;
-    hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(tiles * (d->cout / 4), 256)), dim3(256), 0, st, a);
+    int tile = (d->tile == SGV3D_TILE_64x128 || d->tile == SGV3D_TILE_32x128) ? d->tile : SGV3D_TILE_64x64;
+    if (tile == SGV3D_TILE_32x128 && (d->k_order != 1 || d->cin < 128)) tile = SGV3D_TILE_64x64;    // (what the narrow tile covers)
+    // one pass per chunk of output channels: block p of the chunk's weights is cout_pad x k_pad floats after block p - 1
+    // like the full blocks, shifted by c0 rows
+    const int chunk = wino4_chunk(d, a.rows);
+    for (int c0 = 0; c0 < d->cout; c0 += chunk) {
+        a.c0 = c0;
+        a.cn = d->cout - c0 < chunk ? d->cout - c0 : chunk;
+        if (int rc = conv_gemm_grouped(a.v, u_packed + (size_t)c0 * d->k_pad, a.m, a.rows, 36, d->cin, a.cn, d->k_pad, d->cout_pad,
+                                       d->k_order, tile, st)) return rc;
+        hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(tiles * (a.cn / 4), 256)), dim3(256), 0, st, a);
+    }
     return check_launch("conv2d_winograd4_forward");
 }

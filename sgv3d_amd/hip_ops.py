@@ -43,6 +43,11 @@ SPLIT_K = not _os.environ.get("SGV3D_NO_SPLITK")
 WINOGRAD = not _os.environ.get("SGV3D_NO_WINOGRAD")
 # False: CenterHead branches run as two kernels with the hidden maps in HBM (SGV3D_NO_FUSED_HEAD=1)
 FUSED_HEAD = not _os.environ.get("SGV3D_NO_FUSED_HEAD")
+# fp32 CenterHead branches: 0 (default) = the fused kernel; SGV3D_HEAD_PATH=1: first layers as one convolution (its algorithm
+# measured per load: F(4x4) in channel chunks) + the final-conv kernel; SGV3D_HEAD_PATH=auto (None here): both timed under load at
+# the first call.  Measured (tools/head_path_probe.py, bench): the two-kernel path executes 44 % fewer MFMAs but moves 3.9 GB of
+# M / hidden maps per frame -- 1264 vs 1089 us per call with three in flight, 203.4 vs 203.2 frames/s: no gain, so fused stays.
+HEAD_PATH = {"1": 1, "auto": None}.get(_os.environ.get("SGV3D_HEAD_PATH", ""), 0)
 # True (SGV3D_BF16=1 or set before the first forward): every convolution multiplies through the bf16 MFMA variant of the
 # implicit-GEMM kernel (operands rounded to bf16 on their way into LDS, fp32 accumulation and epilogue, fp32 tensors in
 # HBM) -- the compute dtype BASELINE cfg-3 / cfg-5 name.  Winograd and the fused head kernel are fp32-only and are not
@@ -289,10 +294,13 @@ class PackedConv:
     def wino4_ok(self, d=None, gate=None):
         """F(4x4,3x3) covers this layer (and launch): 3x3 / stride 1 / pad 1, f32, NHWC output, no gate, many channels."""
         is3x3 = (not self.transposed and self.kh == 3 and self.kw == 3 and self.stride == 1 and self.pad == self.dil)   # dilated too
-        ok = (WINO4 and WINOGRAD and is3x3 and not MFMA_BF16 and self.cin % 32 == 0 and self.cout % 4 == 0
-              and min(self.cin, self.cout) >= WINO4_MIN_CHANNELS and gate is None)
+        # enough channels for the transforms to be worth it -- or very many output channels on few input ones (the 64 -> 36 x 64
+        # first layers of the CenterHead branches: the input transform is shared by all of them)
+        wide = min(self.cin, self.cout) >= WINO4_MIN_CHANNELS or (self.cin >= 64 and self.cout >= 1024)
+        ok = (WINO4 and WINOGRAD and is3x3 and not MFMA_BF16 and self.cin % 32 == 0 and self.cout % 4 == 0 and wide and gate is None)
         if ok and d is not None:
-            ok = d.mode == CONV_NORMAL and d.y_ld % 4 == 0 and d.y_coff % 4 == 0 and d.x_ld % 4 == 0 and d.x_coff % 4 == 0 and d.res_ld % 4 == 0
+            ok = ((d.mode == CONV_NORMAL and d.y_ld % 4 == 0 and d.y_coff % 4 == 0) or
+                  (d.mode == CONV_GROUP_PLANES and d.deconv_ks % 4 == 0)) and d.x_ld % 4 == 0 and d.x_coff % 4 == 0 and d.res_ld % 4 == 0
         return ok
 
     def _wino4_weights(self):
@@ -601,6 +609,33 @@ class PackedConv:
                     if best_t is None or dt < best_t:
                         best, best_t = (t, sk), dt
         return best
+
+
+def time_callable(fn, device, rounds=None):
+    """Milliseconds for TUNE_STREAMS concurrent copies of ``fn`` (``rounds`` calls back to back on every stream; one stream =
+    isolated timing), best of TUNE_REPEATS -- how the per-layer candidates are timed, for whole sub-graphs (the CenterHead
+    branch paths).  ``fn`` launches on torch's current stream."""
+    global _TUNE_SIDE_STREAMS
+    rounds = rounds or TUNE_ROUNDS
+    cur = torch.cuda.current_stream(device)
+    n = max(1, TUNE_STREAMS)
+    if len(_TUNE_SIDE_STREAMS) < n:
+        _TUNE_SIDE_STREAMS = [torch.cuda.Stream(device=device) for _ in range(n)]
+    best = None
+    for _ in range(TUNE_REPEATS):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        for s_ in _TUNE_SIDE_STREAMS[:n]:
+            s_.wait_event(e0)
+            with torch.cuda.stream(s_):
+                for _r in range(rounds):
+                    fn()
+            cur.wait_stream(s_)
+        e1.record(cur)
+        e1.synchronize()
+        dt = e0.elapsed_time(e1)
+        best = dt if best is None else min(best, dt)
+    return best
 
 
 def maxpool3x3s2(x, out=None):

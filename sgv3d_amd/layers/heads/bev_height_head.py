@@ -189,15 +189,49 @@ class BEVHeightHead(HipModule):
             out = hip_ops.centerhead_branches_bf16(shared, s['w1_bf16'], s['first'].scale, s['first'].shift, s['b2'],
                                                    s['out_begin'], s['nb'])
         elif hip_ops.FUSED_HEAD and not hip_ops.MFMA_BF16 and s['first'].w_wino is not None and s['first'].cin <= 64 and s['hc'] == 64:
-            # both branch layers in one kernel: the [nb,B,H,W,64] hidden maps stay on the chip
-            out = hip_ops.centerhead_branches(shared, s['first'], s['w2'], s['b2'], s['out_begin'], s['nb'])
+            if self._branch_path(s, shared) == 0:
+                # both branch layers in one kernel: the [nb,B,H,W,64] hidden maps stay on the chip
+                out = hip_ops.centerhead_branches(shared, s['first'], s['w2'], s['b2'], s['out_begin'], s['nb'])
+            else:
+                out = self._two_kernel_branches(s, shared)
         else:
-            hidden = s['first'](shared, group_planes=s['hc'])          # all branch first layers: [nb,B,H,W,64]
-            out = hip_ops.head_final_conv(hidden, s['w2'], s['b2'], s['branch_of_out'], s['nb'], s['hc'])
+            out = self._two_kernel_branches(s, shared)
         ret = [dict() for _ in self.task_heads]
         for t, name, off, c in s['slices']:
             ret[t][name] = out[:, off:off + c]                         # [B, c, H, W] views of one buffer
         return tuple([d] for d in ret)                                 # multi_apply over one level
+
+    @staticmethod
+    def _two_kernel_branches(s, shared):
+        """First layers of all branches as ONE convolution (64 -> nb x 64, hidden maps [nb,B,H,W,64] in HBM; its algorithm is
+        chosen per load like any layer's -- with three frames in flight the three-launch F(4x4) Winograd), then the final
+        3x3 convolutions of all branches in one launch."""
+        hidden = s['first'](shared, group_planes=s['hc'])
+        return hip_ops.head_final_conv(hidden, s['w2'], s['b2'], s['branch_of_out'], s['nb'], s['hc'])
+
+    def _branch_path(self, s, shared):
+        """0: the fused kernel (both branch layers, hidden maps in LDS; 1.08 ms at 256x256, nothing else fits on its CUs);
+        1: the two-kernel path.  Decided like the per-layer choices: by timing both under the load they will run in
+        (hip_ops.TUNE_STREAMS concurrent copies) at the first call outside a graph capture, kept in hip_ops.TUNE_DB.  The fused
+        kernel wins alone (no 1.2 GB of hidden-map traffic); with several frames in flight the chip is bound by MFMA + vector
+        instructions, and the F(4x4) first layer executes 44 % fewer of the former."""
+        B, H, W, _ = (int(v) for v in shared.shape)
+        sig = f"centerhead_branches|{B}x{H}x{W}x{s['nb']}|ts{hip_ops.TUNE_STREAMS}"
+        hit = hip_ops.TUNE_DB.get(sig)
+        if hit is not None:
+            return int(hit[0]) - 100
+        if (not hip_ops.AUTOTUNE or torch.cuda.is_current_stream_capturing() or not s['first'].wino4_ok()
+                or hip_ops.HEAD_PATH in (0, 1)):
+            return hip_ops.HEAD_PATH if hip_ops.HEAD_PATH in (0, 1) else 0
+        fused = lambda: hip_ops.centerhead_branches(shared, s['first'], s['w2'], s['b2'], s['out_begin'], s['nb'])
+        split = lambda: self._two_kernel_branches(s, shared)
+        fused(); split()                                     # warm (the first layer measures its own candidates here)
+        torch.cuda.synchronize(shared.device)
+        t_fused = hip_ops.time_callable(fused, shared.device, rounds=2)
+        t_split = hip_ops.time_callable(split, shared.device, rounds=2)
+        choice = 1 if t_split < t_fused else 0
+        hip_ops.TUNE_DB[sig] = (100 + choice, 1)
+        return choice
 
     def forward(self, x, nhwc=False):
         """x: [B, C, Y, X] (reference layout) or, with ``nhwc``, the NHWC buffer [B, Y, X, C]."""

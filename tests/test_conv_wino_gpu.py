@@ -263,3 +263,25 @@ def test_winograd_f4x4_dilated(dil, H, W):
     assert float(out[..., :32].max()) == -3.0 and float(out[..., cout + 32:].max()) == -3.0
     direct = conv(x.cuda(), tile=4, split_k=1)
     assert (direct - out[..., 32:cout + 32]).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("tile", [9, 10])
+def test_winograd_f4x4_group_planes_in_channel_chunks(tile):
+    """The CenterHead first layers as one convolution (64 -> 36 x 64) with the hidden maps as [branch][B][H][W][64] planes:
+    F(4x4) runs the GEMM + output transform in chunks of output channels (M of a pass stays below ~160 MB), the input
+    transform once.  72 x 80 pixels, batch 2: 360 tiles -> chunks of 1664 + 640 channels."""
+    from sgv3d_amd.hip_ops import PackedConv
+    B, cin, H, W, nb = 2, 64, 72, 80, 36
+    x, w = _mk(B, cin, H, W, nb * 64, seed=9)
+    g = torch.Generator().manual_seed(99)
+    scale, shift = torch.rand(nb * 64, generator=g) + 0.5, torch.randn(nb * 64, generator=g) * 0.2
+    conv = PackedConv(w.cuda(), pad=1, scale=scale.cuda(), shift=shift.cuda(), relu=True)
+    assert conv.wino4_ok()
+    hidden = conv(x.cuda(), group_planes=64, tile=tile, split_k=1)
+    assert tuple(hidden.shape) == (nb, B, H, W, 64)
+    ref = _ref(x, w, scale, shift, None, relu=True)                              # [B, H, W, nb * 64]
+    got = hidden.permute(1, 2, 3, 0, 4).reshape(B, H, W, nb * 64).cpu().double()
+    err = (got - ref).abs().max().item()
+    assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
+    direct = conv(x.cuda(), group_planes=64, tile=4, split_k=1)
+    assert (direct - hidden).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
