@@ -249,10 +249,13 @@ typedef struct sgv3d_conv_desc {
  * positions -> output transform + epilogue.  Executes 1/4 of the direct form's multiplications (F(2x2): 1/2.25); for 3x3 /
  * stride 1 / pad 1 layers with many channels on small maps (it moves 2.25x the activations through the last-level cache).
  * u_packed: 36 blocks of [cout_pad][k_pad] floats (sgv3d_conv_pack_geometry(cin, cout)); block p = 6 i + j holds the 1x1
- * weight (G g G^T)[i][j] ([cout, cin], G the 6x3 F(4x4,3x3) matrix) packed by sgv3d_conv_pack_weight with desc.k_order.
+ * weight (G g G^T)[i][j] ([cout, cin], G the 6x3 F(4x4,3x3) matrix); sgv3d_conv_winograd4_pack_weight makes all 36 in one
+ * launch (k = ci in either k order).
  * desc as for sgv3d_conv2d_winograd_forward, NORMAL mode, no gate, no split-K; desc.k_pad / cout_pad describe one block;
  * desc.tile = SGV3D_TILE_64x64 (default) | SGV3D_TILE_64x128 | SGV3D_TILE_32x128 picks the GEMM tile.  workspace: V and M
  * (sgv3d_conv2d_winograd4_workspace_bytes, 16-B aligned).  fp32 error ~1e-5 of the output scale. */
+int sgv3d_conv_winograd4_pack_weight(const float *w_src /*[cout, cin, 3, 3]*/, int cout, int cin, int k_pad, int cout_pad,
+                                     float *u_packed /*36 x cout_pad x k_pad*/, void *stream);
 size_t sgv3d_conv2d_winograd4_workspace_bytes(const sgv3d_conv_desc *desc /*host*/);
 int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *u_packed,
                                    const float *scale, const float *bias, const float *residual, float *y,

@@ -173,6 +173,46 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const Wino4Args a) {
     }
 }
 
+// U[p][co][ci] = (G g G^T)[i][j], p = 6 i + j, written straight into the 36 packed weight blocks [cout_pad][k_pad] of the
+// grouped GEMM (k = ci: a 1x1 weight in either k order), zero rows / columns in the padding.  One thread per (co, ci).
+//   G = [[1/4, 0, 0], [-1/6, -1/6, -1/6], [-1/6, 1/6, -1/6], [1/24, 1/12, 1/6], [1/24, -1/12, 1/6], [0, 0, 1]]
+__global__ __launch_bounds__(256) void wino4_pack_weight_kernel(const float *__restrict__ w, int cout, int cin, int k_pad,
+                                                                int cout_pad, float *__restrict__ u) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)cout_pad * k_pad) return;
+    const int co = (int)(i / k_pad), ci = (int)(i - (long long)co * k_pad);
+    float g[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (co < cout && ci < cin) {
+        const float *p = w + ((size_t)co * cin + ci) * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = p[a * 3 + b];
+    }
+    // G g: 6 x 3 (rows of G applied to the columns of g), then (G g) G^T: 6 x 6
+    float t[6][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const float s02 = g[0][b] + g[2][b];
+        t[0][b] = 0.25f * g[0][b];
+        t[1][b] = (-1.f / 6.f) * (s02 + g[1][b]);
+        t[2][b] = (-1.f / 6.f) * (s02 - g[1][b]);
+        t[3][b] = (1.f / 24.f) * g[0][b] + (1.f / 12.f) * g[1][b] + (1.f / 6.f) * g[2][b];
+        t[4][b] = (1.f / 24.f) * g[0][b] - (1.f / 12.f) * g[1][b] + (1.f / 6.f) * g[2][b];
+        t[5][b] = g[2][b];
+    }
+    const size_t block = (size_t)cout_pad * k_pad;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const float s02 = t[r][0] + t[r][2];
+        const float o[6] = {0.25f * t[r][0], (-1.f / 6.f) * (s02 + t[r][1]), (-1.f / 6.f) * (s02 - t[r][1]),
+                            (1.f / 24.f) * t[r][0] + (1.f / 12.f) * t[r][1] + (1.f / 6.f) * t[r][2],
+                            (1.f / 24.f) * t[r][0] - (1.f / 12.f) * t[r][1] + (1.f / 6.f) * t[r][2], t[r][2]};
+#pragma unroll
+        for (int c = 0; c < 6; ++c) u[(size_t)(r * 6 + c) * block + i] = o[c];
+    }
+}
+
 // tiles of one sub-grid (the largest one: phase 0), of all phases and images, and the padded row count per position
 void wino4_geom(const sgv3d_conv_desc *d, int &ty, int &tx, long long &tiles, int &rows) {
     const int dil = d->dil;
@@ -194,6 +234,18 @@ int wino4_chunk(const sgv3d_conv_desc *d, int rows) {
 }
 
 }  // namespace
+
+// w_src: OIHW [cout, cin, 3, 3] f32 (cin may be smaller than the layer's padded channel count: the rest is zero) -> u_packed:
+// 36 x cout_pad x k_pad floats, (cout_pad, k_pad) = sgv3d_conv_pack_geometry(cin_pad, cout)
+extern "C" int sgv3d_conv_winograd4_pack_weight(const float *w_src, int cout, int cin, int k_pad, int cout_pad, float *u_packed,
+                                                void *stream) {
+    SGV3D_REQUIRE(w_src && u_packed && cout > 0 && cin > 0 && k_pad >= cin && k_pad % 32 == 0 && cout_pad >= cout,
+                  "conv_winograd4_pack_weight: bad arguments (cout=%d cin=%d k_pad=%d cout_pad=%d)", cout, cin, k_pad, cout_pad);
+    const long long total = (long long)cout_pad * k_pad;
+    hipLaunchKernelGGL(wino4_pack_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w_src, cout, cin, k_pad,
+                       cout_pad, u_packed);
+    return check_launch("wino4_pack_weight_kernel");
+}
 
 // bytes of V + M
 extern "C" size_t sgv3d_conv2d_winograd4_workspace_bytes(const sgv3d_conv_desc *d) {

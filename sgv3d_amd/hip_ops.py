@@ -304,23 +304,17 @@ class PackedConv:
         return ok
 
     def _wino4_weights(self):
-        """U[p] = (G g G^T)[i][j] for the 36 positions of F(4x4,3x3), each packed as a 1x1 convolution weight of the
-        implicit-GEMM kernel (made on first use: 36 x cout_pad x k_pad floats)."""
+        """U[p] = (G g G^T)[i][j] for the 36 positions of F(4x4,3x3), each a packed 1x1 weight block of the implicit-GEMM
+        kernel (36 x cout_pad x k_pad floats), made on first use by one kernel (sgv3d_conv_winograd4_pack_weight)."""
         if getattr(self, 'w_wino4', None) is None:
             lib = _lib.load()
             w = self._keep                                           # [cout, cin_real, 3, 3] f32 on the device
-            G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
-                              [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64, device=w.device)
-            U = torch.einsum('ia,ocab,jb->ijoc', G, w.double(), G).float().contiguous()      # [6, 6, cout, cin_real]
             k_pad, cout_pad = pack_geometry(self.cin, self.cout)
             packed = torch.empty(36, cout_pad, k_pad, dtype=torch.float32, device=w.device)
             with torch.cuda.device(w.device):
-                for p in range(36):
-                    up = U[p // 6, p % 6].reshape(self.cout, -1, 1, 1).contiguous()
-                    rc = lib.sgv3d_conv_pack_weight(up.data_ptr(), self.cout, int(up.shape[1]), 1, 1, self.cin, 0, 1,
-                                                    packed[p].data_ptr(), k_pad, cout_pad, _st(w))
-                    _lib.check(rc, "sgv3d_conv_pack_weight (F(4x4) position)")
-            torch.cuda.current_stream(w.device).synchronize()        # U's slices die with this scope; the pack kernels read them
+                rc = lib.sgv3d_conv_winograd4_pack_weight(w.data_ptr(), self.cout, int(w.shape[1]), k_pad, cout_pad,
+                                                          packed.data_ptr(), _st(w))
+            _lib.check(rc, "sgv3d_conv_winograd4_pack_weight")
             self.w_wino4, self.wino4_geom = packed, (k_pad, cout_pad)
         return self.w_wino4
 
