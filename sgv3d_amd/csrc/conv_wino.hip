@@ -108,7 +108,10 @@ __device__ __forceinline__ f32x4 wino_buffer_load(__amdgpu_buffer_rsrc_t rsrc, u
 //     T = B^T d of the next step's patch, row by row into tc as soon as the current step's row is dead
 //     (rows 0, 1 in pair 10, row 2 in pair 12, row 3 in pair 14).
 #define SGV3D_WINO_MFMA(P, C, V, BF) acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(V.C, BF.C, acc[P], 0, 0, 0)
-template <int P, int TC, bool RESIDENT = false, int DIST = 3, int HALF = WinoGeom<TC>::HALF>
+// ZERO: the pair's accumulators start from zero HERE (first k-step of an output tile): its first MFMA takes the constant 0
+// as C instead of the register, so the 2 x 16 accumulator registers need no clearing (256 v_accvgpr_write per output tile
+// otherwise -- vector instructions that cost MFMA time; the fused head starts 36 tiles per workgroup).
+template <int P, int TC, bool RESIDENT = false, int DIST = 3, int HALF = WinoGeom<TC>::HALF, bool ZERO = false>
 __device__ __forceinline__ void wino_pair(f32x16 (&acc)[16], f32x4 (&tc)[4][4], f32x4 (&raw)[4][4], f32x4 &vc0,
                                           f32x4 &vc1, f32x4 &vn0, f32x4 &vn1, f32x4 (&wf)[8], WinoStreams &st,
                                           const f32x4 *An) {
@@ -117,7 +120,12 @@ __device__ __forceinline__ void wino_pair(f32x16 (&acc)[16], f32x4 (&tc)[4][4], 
     static_assert(DIST == 3, "fragment ring: three pairs ahead");
     constexpr int L0 = (P + 6) & 7, L1 = (P + 7) & 7;    // ring slots (= those of pair P-2) refilled now
     const f32x4 b0 = wf[R0], b1 = wf[R1];
-    SGV3D_WINO_MFMA(P, x, vc0, b0);
+    if constexpr (ZERO) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc0.x, b0.x, z, 0, 0, 0);
+    } else {
+        SGV3D_WINO_MFMA(P, x, vc0, b0);
+    }
     SGV3D_SB();
     // ---- gap 1: memory ----
     if constexpr (P + 6 < 16) wf[L0] = wino_buffer_load(st.w_rsrc, st.w_lane, st.w_cur + (P + 6) * (W_POS * 4));
@@ -140,7 +148,12 @@ __device__ __forceinline__ void wino_pair(f32x16 (&acc)[16], f32x4 (&tc)[4][4], 
         st.stage2 = wino_buffer_load(st.x_rsrc, st.x2, st.x_step);
     }
     SGV3D_SB();
-    SGV3D_WINO_MFMA(P + 1, x, vc1, b1);
+    if constexpr (ZERO) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[P + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc1.x, b1.x, z, 0, 0, 0);
+    } else {
+        SGV3D_WINO_MFMA(P + 1, x, vc1, b1);
+    }
     SGV3D_SB();
     SGV3D_WINO_MFMA(P, y, vc0, b0);
     SGV3D_SB();
@@ -1025,12 +1038,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_head_kernel(const ConvArgs a
             va0 = wino_bt<0>(tc[0][0], tc[0][1], tc[0][2], tc[0][3]);
             va1 = wino_bt<1>(tc[0][0], tc[0][1], tc[0][2], tc[0][3]);
         }
-        f32x16 acc[16];
-#pragma unroll
-        for (int p = 0; p < 16; ++p)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
-        for (int s = 0; s < nsteps; ++s) {
+        f32x16 acc[16];                  // (not cleared: the first k-step's MFMAs start from the constant 0)
+        {
+            const f32x4 *const An = smem + (1 < nsteps ? 1 : 0) * HEAD_PATCH_SLOTS + abase;
+            wino_pair<0, TC, true, 3, HEAD_HALF, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<2, TC, true, 3, HEAD_HALF, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            wino_pair<4, TC, true, 3, HEAD_HALF, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<6, TC, true, 3, HEAD_HALF, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            wino_pair<8, TC, true, 3, HEAD_HALF, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<10, TC, true, 3, HEAD_HALF, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            wino_pair<12, TC, true, 3, HEAD_HALF, true>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
+            wino_pair<14, TC, true, 3, HEAD_HALF, true>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
+            st.w_cur = st.w_next;
+            st.w_next += W_STEP * 4;
+        }
+        for (int s = 1; s < nsteps; ++s) {
             const f32x4 *const An = smem + (s + 1 < nsteps ? s + 1 : 0) * HEAD_PATCH_SLOTS + abase;
             wino_pair<0, TC, true, 3, HEAD_HALF>(acc, tc, raw, va0, va1, vb0, vb1, wf, st, An);
             wino_pair<2, TC, true, 3, HEAD_HALF>(acc, tc, raw, vb0, vb1, va0, va1, wf, st, An);
