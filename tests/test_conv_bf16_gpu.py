@@ -349,6 +349,75 @@ def test_bf16_io_conv(bf16_mode, shape, tile):
     assert float(wide[..., :8].abs().max()) == 0 and float(wide[..., 8 + cout:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("shape", [
+    # B, cin, H, W, cout, stride, residual
+    (2, 64, 20, 28, 256, 1, True),         # expanding 1x1 with residual (ResNet conv3)
+    (1, 256, 19, 23, 64, 1, False),        # reducing 1x1, ragged M
+    (1, 256, 16, 16, 512, 2, False),       # strided 1x1 (downsample)
+    (1, 32, 9, 13, 72, 1, True),           # K = 32: half a chunk; cout not a multiple of 64
+    (1, 96, 11, 10, 136, 1, False),        # K % 64 == 32 with two chunks; waves beyond N
+    (3, 2560, 6, 8, 512, 1, True),         # long K (40 chunks)
+    (1, 1024, 17, 30, 256, 1, False),      # ResNet layer-3 reducing layer
+    (1, 128, 31, 33, 320, 2, True),        # odd strided map, cout = 5 n-chunks of 64
+])
+@pytest.mark.parametrize("tile", [31, 32, 33])
+def test_bf16_pointwise_conv(bf16_mode, shape, tile):
+    """sgv3d_conv_pw_bf16_forward (host tile ids 31-33: 64x256 / 128x128 / 256x64 pixels x channels): bf16 tensors in and out.
+    Reference: float64 convolution of the bf16-rounded operands, epilogue in high precision, one rounding to bf16 -- and the
+    implicit-GEMM bf16io kernel, which multiplies the same bf16 values in the same k order: bitwise equal outputs."""
+    B, cin, H, W, cout, stride, with_res = shape
+    g = torch.Generator().manual_seed(cin * 5 + cout + stride)
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16()
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    conv = hip_ops.PackedConv(w.to(DEV), stride=stride, scale=sc.to(DEV), shift=sh.to(DEV), relu=True)
+    oh, ow = conv.out_hw(H, W)
+    res = torch.randn(B, cout, oh, ow, generator=g).bfloat16() if with_res else None
+    ref = F.conv2d(x.double(), w.bfloat16().double(), None, stride)
+    ref = ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    if res is not None:
+        ref = ref + res.double()
+    ref = ref.clamp_min(0)
+    scale = max(1.0, float(ref.abs().max()))
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rin = res.permute(0, 2, 3, 1).contiguous().to(DEV) if res is not None else None
+    y = conv(xin, residual=rin, tile=tile, split_k=1, out_dtype=torch.bfloat16)
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (B, oh, ow, cout)
+    err = float((y.float().permute(0, 3, 1, 2).cpu().double() - ref).abs().max())
+    assert err <= 2.0 ** -8 * scale, (err, scale)
+    assert torch.equal(y, conv(xin, residual=rin, tile=4, split_k=1, out_dtype=torch.bfloat16))
+    # channel slices on both sides (concat input / output), guard channels untouched
+    xw = torch.randn(B, H, W, cin + 24, generator=g).bfloat16().to(DEV)
+    xw[..., 16:16 + cin] = xin
+    wide = torch.full((B, oh, ow, cout + 16), 7.0, dtype=torch.bfloat16, device=DEV)
+    conv(xw, wide, x_coff=16, y_coff=8, residual=rin, tile=tile, split_k=1)
+    assert torch.equal(wide[..., 8:8 + cout], y)
+    assert float((wide[..., :8] - 7).abs().max()) == 0 and float((wide[..., 8 + cout:] - 7).abs().max()) == 0
+
+
+def test_bf16_pointwise_conv_exact_on_small_integers(bf16_mode):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-3, 4, (2, 192, 12, 21), generator=g).float()
+    w = torch.randint(-2, 3, (200, 192, 1, 1), generator=g).float()
+    conv = hip_ops.PackedConv(w.to(DEV))
+    ref = F.conv2d(x, w)                                                    # |values| < 2^8 * 6: exact in bf16? no -- compare in f32 after rounding
+    xin = x.bfloat16().permute(0, 2, 3, 1).contiguous().to(DEV)
+    for tile in (31, 32, 33):
+        y = conv(xin, tile=tile, split_k=1, out_dtype=torch.bfloat16)
+        assert torch.equal(y.float().permute(0, 3, 1, 2).cpu(), ref.bfloat16().float())
+
+
+def test_bf16_pointwise_conv_rejects_what_it_does_not_cover(bf16_mode):
+    from sgv3d_amd import _lib
+    conv = hip_ops.PackedConv(torch.randn(64, 64, 3, 3, device=DEV), pad=1)
+    x = torch.randn(1, 8, 8, 64, device=DEV).bfloat16()
+    with pytest.raises(_lib.SGV3DError):
+        conv(x, tile=31, split_k=1, out_dtype=torch.bfloat16)               # 3x3
+    conv1 = hip_ops.PackedConv(torch.randn(64, 64, 1, 1, device=DEV))
+    with pytest.raises(_lib.SGV3DError):
+        conv1(x.float(), tile=31, split_k=1)                                # f32 tensors
+
+
 def test_bf16_maxpool(bf16_mode):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 64, 21, 30, generator=g).bfloat16()
