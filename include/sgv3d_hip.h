@@ -496,23 +496,28 @@ int sgv3d_conv3x3_patch_bf16_forward(int batch, int h, int w, int cin, int cout,
                                      const float *scale, const float *bias, const void *residual, void *y,
                                      int io_flags, int split_k, void *workspace, size_t workspace_bytes, void *stream);
 
-/* bf16-mode pointwise (1x1, pad 0, stride >= 1) convolution with bf16 activations in and out (csrc/conv_pw_bf16.hip): the
- * reducing / expanding 1x1 layers and strided shortcuts of the ResNet bottlenecks (mmdet ResNet behind
- * layers/backbones/lss_fpn.py:296-301) and of HeightNet in the bf16 configs.  y = relu?(conv(x) * scale + bias + residual).
- * The weights stream from L2 in MFMA-fragment order and never touch LDS; three workgroups per CU overlap each other's load,
- * MFMA and store phases (most of these layers are bound by HBM).  Uses desc: batch, in_h/in_w, out_h/out_w, cin, cout, kh = kw = 1,
- * stride, pad = 0, dil = 1, x_ld/x_coff, y_ld/y_coff, res_ld, relu, mode = SGV3D_CONV_NORMAL, split_k <= 1 and
- *   desc.tile  SGV3D_TILE_PW_64x256 | SGV3D_TILE_PW_128x128 | SGV3D_TILE_PW_256x64: pixels x channels per workgroup.
- *   w_packed   sgv3d_conv_pw_bf16_weight_bytes(cout, cin) bytes, filled by ..._pack_weight from f32 [cout, cin] (OIHW, 1x1)
+/* bf16-mode implicit-GEMM convolution with bf16 activations in and out whose weights stream from L2 in MFMA-fragment order
+ * (csrc/conv_dw_bf16.hip, "direct-weight kernel"): the 1x1 layers and strided shortcuts of the ResNet bottlenecks (mmdet ResNet
+ * behind layers/backbones/lss_fpn.py:296-301), the 3x3 layers the patch kernel tiles badly, strided / dilated 3x3 layers (ASPP,
+ * lss_fpn.py:58-121) and the 7x7 BEV stem (layers/heads/bev_height_head.py:75-110) in the bf16 configs.
+ * y = relu?(conv(x) * scale + bias + residual).  Only the activation rows pass through LDS; up to four workgroups per CU overlap
+ * each other's load, MFMA and store phases (most 1x1 layers are bound by HBM).  Uses desc: batch, in_h/in_w, out_h/out_w, cin,
+ * cout, kh/kw, stride, pad, dil, x_ld/x_coff, y_ld/y_coff, res_ld, relu, mode = SGV3D_CONV_NORMAL, split_k <= 1 and
+ *   desc.tile  SGV3D_TILE_DW_<pixels>x<channels> per workgroup: 64x256 | 128x128 | 256x64 (64 pixels per wave: the HBM-bound
+ *              layers) | 128x256 | 256x128 (128 pixels per wave: twice the MFMAs per weight fragment, the deep layers)
+ *   w_packed   sgv3d_conv_dw_bf16_weight_bytes(cout, cin, kh, kw) bytes, filled by ..._pack_weight from f32 OIHW
+ *              [cout, cin_w, kh, kw] (cin_w <= cin: the activation's channel count may be padded, the extra columns are zero)
  *   x          NHWC bf16 [batch, in_h, in_w, x_ld];  y  NHWC bf16 [batch, out_h, out_w, y_ld];  residual  bf16 [.., res_ld] or NULL
  * cin must be a multiple of 32, cout of 8; strides and offsets multiples of 8; pointers 16-B aligned.  Results: f32
- * accumulation of bf16 products in ascending k, one rounding on the store -- the same values as sgv3d_conv2d_forward_bf16io. */
-#define SGV3D_TILE_PW_64x256 31
-#define SGV3D_TILE_PW_128x128 32
-#define SGV3D_TILE_PW_256x64 33
-size_t sgv3d_conv_pw_bf16_weight_bytes(int cout, int cin);
-int sgv3d_conv_pw_bf16_pack_weight(const float *w, int cout, int cin, void *w_packed, void *stream);
-int sgv3d_conv_pw_bf16_forward(const sgv3d_conv_desc *desc /*host*/, const void *x, const void *w_packed, const float *scale,
+ * accumulation of bf16 products in ascending (tap, channel) order, one rounding on the store. */
+#define SGV3D_TILE_DW_64x256 31
+#define SGV3D_TILE_DW_128x128 32
+#define SGV3D_TILE_DW_256x64 33
+#define SGV3D_TILE_DW_128x256 34
+#define SGV3D_TILE_DW_256x128 35
+size_t sgv3d_conv_dw_bf16_weight_bytes(int cout, int cin, int kh, int kw);
+int sgv3d_conv_dw_bf16_pack_weight(const float *w, int cout, int cin_w, int cin, int kh, int kw, void *w_packed, void *stream);
+int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *desc /*host*/, const void *x, const void *w_packed, const float *scale,
                                const float *bias, const void *residual, void *y, void *stream);
 
 /* ================================================================================================

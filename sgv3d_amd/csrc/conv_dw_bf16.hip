@@ -1,0 +1,396 @@
+// Implicit-GEMM convolution with bf16 activations in HBM whose WEIGHTS STREAM FROM L2 IN MFMA-FRAGMENT ORDER ("direct-weight
+// kernel"): the bf16-mode algorithm for the 1x1 layers and strided shortcuts of every ResNet bottleneck, the 3x3 layers the
+// patch kernel tiles badly (68 x 120 maps), the strided and dilated 3x3 layers (ASPP) and the 7x7 BEV stem (reference call
+// sites: mmdet ResNet / SECOND behind layers/backbones/lss_fpn.py:296-301, ASPP / HeightNet lss_fpn.py:58-121,200-259, the BEV
+// trunk layers/heads/bev_height_head.py:75-110).  A third of a cfg-3 step is spent in these layers; most of the 1x1 ones are
+// bound by HBM (256 -> 1024 at 4 x 68 x 120 with residual: 150 MB for 17 GFLOP), the others by the matrix pipe.
+// The implicit-GEMM bf16 kernel (conv_igemm.hip) passes BOTH operand tiles through registers and ds_write every 32 k (the LDS
+// store path runs at a third of the read rate), synchronises the workgroup every 8 MFMAs per wave, and at 220 VGPRs only two
+// workgroups share a CU, so a workgroup's residual / store phase has nothing to overlap with.  Here:
+//   * the weights never touch LDS: packed on the host in MFMA-fragment order ([n-tile of 32][k-step of 16][lane][8], k = (tap,
+//     channel) with the channels of a tap padded to 64) they stream from L2 straight into a ring of fragment registers one 64-k
+//     chunk ahead -- 1 KB contiguous per wave load, scalar offset, no vector instruction per load;
+//   * only the activation rows go through LDS: 64 k (128 B) per row and chunk gathered with 16-byte buffer loads (padding /
+//     out-of-image rows: out-of-range offset, zeros) and ds_write_b128, double buffered, ONE barrier per chunk = per 16-32 MFMAs
+//     of a wave; 16-byte slots XOR-swizzled with the row: fragment reads and stores conflict-free without padding;
+//   * a wave owns (32 MT) pixels x 64 channels, MT = 2 (64 accumulator registers, <= 128 VGPRs: four workgroups per CU whose
+//     load, MFMA and store phases overlap -- the HBM-bound layers) or MT = 4 (twice the MFMAs per weight fragment: the
+//     L1-bound deep layers);
+//   * the residual rows are requested during the last chunk into the fragment registers that chunk no longer refills;
+//   * the product is computed transposed (C^T = W . X^T: pixel on the lane, 4 consecutive channels in a register quad); the
+//     epilogue (folded BN, residual, ReLU in f32, one rounding) goes through a per-wave LDS stage and leaves as 16-byte stores
+//     of 8 channels: 4 lanes write one 64-byte row segment.
+// Workgroup = 4 waves as WM x WN, tile (32 MT WM) pixels x (64 WN) channels.  The grid walks the channel tiles of one pixel
+// tile back to back on one XCD, so the input rows come from HBM once.
+// Results: f32 accumulation of bf16 products in ascending (tap, channel) order, one rounding on the store.
+// Bound: HBM for the large maps (2 * (M * K + M * N [+ M * N residual]) bytes), MFMA bf16 (2 * M * N * K flop) for the deep ones.
+#include "conv_common.hpp"
+
+using namespace sgv3d;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kKC = 64;                 // k per chunk: one 128-byte row segment
+constexpr int kRowB = kKC * 2;          // bytes per staged row
+constexpr int kStageLd = 36;            // floats per staged pixel row in the epilogue (144 B: conflict-free b128 rows)
+constexpr int kFragB = 64 * 16;         // bytes of one weight fragment (64 lanes x 8 bf16)
+
+struct DwArgs {
+    const void *x;             // NHWC bf16 [B, in_h, in_w, x_ld]
+    const void *w;             // packed fragments (dw_pack_kernel)
+    const float *scale, *bias; // folded BN / bias per output channel (may be NULL)
+    const void *res;           // bf16 residual [M, res_ld] or NULL
+    void *y;                   // bf16 [M, y_ld]
+    int M, N, cin;
+    int x_ld, x_coff, y_ld, y_coff, res_ld, relu;
+    int in_h, in_w, out_h, out_w, kh, kw, stride, pad, dil;
+    int tiles_m, tiles_n;
+    int cpt, nch, ksteps;      // chunks per tap = ceil(cin / 64), nch = kh kw cpt, ksteps = 4 nch (k-steps of 16 per n-tile)
+    unsigned x_bytes, w_bytes, res_bytes;
+};
+
+// weights: OIHW f32 [cout][cin_w][kh][kw] -> [n-tile of 32][k-step of 16][lane][8] bf16; lane l holds channel 32 nt + (l & 31),
+// k = 16 ks + 8 (l >> 5) .. + 8 (the operand layout of v_mfma_f32_32x32x16_bf16) with k = (tap * cpt + chunk) * 64 + channel in
+// chunk; zero beyond cout / cin_w
+__global__ __launch_bounds__(64) void dw_pack_kernel(const float *__restrict__ w, int cout, int cin_w, int taps, int cpt, __bf16 *__restrict__ out) {
+    const int ksteps = taps * cpt * 4;
+    const int id = blockIdx.x;                     // nt * ksteps + ks
+    const int nt = id / ksteps, ks = id - nt * ksteps;
+    const int chunk = ks >> 2, tap = chunk / cpt, cc = chunk - tap * cpt;
+    const int l = threadIdx.x;
+    const int co = nt * 32 + (l & 31);
+    __bf16 *dst = out + ((size_t)id * 64 + l) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = cc * kKC + (ks & 3) * 16 + 8 * (l >> 5) + j;
+        dst[j] = (co < cout && ci < cin_w) ? (__bf16)w[((size_t)co * cin_w + ci) * taps + tap] : (__bf16)0.f;
+    }
+}
+
+template <int WM, int WN, int MT>
+__global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) void conv_dw_bf16_kernel(const DwArgs a) {
+    static_assert(WM * WN == 4 && (MT == 2 || MT == 4), "four waves, 64 or 128 pixels per wave");
+    constexpr int WROWS = 32 * MT;                           // pixels per wave
+    constexpr int BM = WROWS * WM, BN = 64 * WN;
+    constexpr int A_LD = BM / 32;                            // 16-byte loads per thread and chunk
+    constexpr int kBufB = BM * kRowB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = __builtin_amdgcn_readfirstlane(WN == 1 ? wave : WN == 2 ? wave >> 1 : 0);
+    const int wn = __builtin_amdgcn_readfirstlane(WN == 1 ? 0 : WN == 2 ? wave & 1 : wave);
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // XCD-aware walk: the workgroups that share an XCD's L2 take consecutive logical tiles; the channel tile changes fastest
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tm = (int)((unsigned)logical / (unsigned)a.tiles_n);
+    const int tn = logical - tm * a.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.w_bytes, 0x00020000);
+
+    // activation rows: thread -> (16-byte chunk c8 of the 128-byte row segment, rows r0 + 32 i).  a_base: byte offset of the
+    // row's top-left tap (may lie "before" the tensor: 32-bit wrap-around arithmetic, only used when the tap is inside the image)
+    const int c8 = tid & 7, r0 = tid >> 3;
+    const bool plain = a.kh == 1 && a.kw == 1 && a.pad == 0;          // no tap can fall outside the image
+    unsigned a_base[A_LD];
+    int a_ih0[A_LD], a_iw0[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const int mm = m < a.M ? m : 0;
+        const int t = (int)((unsigned)mm / (unsigned)a.out_w), ow = mm - t * a.out_w;
+        const int img = (int)((unsigned)t / (unsigned)a.out_h), oh = t - img * a.out_h;
+        a_ih0[i] = m < a.M ? oh * a.stride - a.pad : -0x40000000;    // rows beyond M: no tap is ever inside
+        a_iw0[i] = ow * a.stride - a.pad;
+        a_base[i] = (unsigned)((((long long)img * a.in_h + a_ih0[i]) * a.in_w + a_iw0[i]) * a.x_ld + a.x_coff + c8 * 8) * 2u;
+        if (plain) a_base[i] = m < a.M ? a_base[i] : 0xffffffffu;
+    }
+    // cin % 64 == 32: the upper half of a tap's last chunk lies beyond cin -- those lanes read zeros (not the neighbouring channels)
+    const bool tail_dead = (a.cin & 63) != 0 && c8 >= 4;
+    const int st_slot = (c8 ^ ((r0 >> 1) & 7)) * 16;                 // rows r0 + 32 i share (row >> 1) & 7
+    char *const st_ptr = smem + r0 * kRowB + st_slot;
+
+    // fragment reads: row = wm WROWS + mt 32 + lr, logical 16-byte chunk 2 s + lh of k-step s
+    const int swz = (lr >> 1) & 7;
+    int rd_off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rd_off[s] = (wm * WROWS + lr) * kRowB + (((2 * s + lh) ^ swz) * 16);
+
+    // weight fragments of this wave's two n-tiles: byte offset = ((nt * ksteps + ks) * 64 + lane) * 16
+    // (the packed weights hold an even number of n-tiles; a wave whose 64 channels lie beyond N reads zeros)
+    const unsigned w_lane = n0 + wn * 64 < a.N ? lane * 16 : 0xffffffffu;
+    const int nt0 = (n0 + wn * 64) >> 5;
+    const int w_s0 = __builtin_amdgcn_readfirstlane(nt0 * a.ksteps * kFragB);
+    const int w_s1 = __builtin_amdgcn_readfirstlane((nt0 + 1) * a.ksteps * kFragB);
+
+    u32x4 ra[A_LD];
+    bf16x8 wf[4][2];
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+
+    // loader state (uniform): the chunk the next DW_LOAD_A fetches = (tap (ld_kh, ld_kw), 64-channel chunk ld_cc); past the last
+    // chunk every lane's request is out of range and returns zeros without touching memory -- the steady-state loop stays
+    // branch-free, which keeps the compiler's vmcnt counts exact
+    int ld_c = 0, ld_kh = 0, ld_kw = 0, ld_cc = 0;
+#define DW_LOAD_A(R)                                                                                       \
+    do {                                                                                                   \
+        const int dy_ = ld_kh * a.dil, dx_ = ld_kw * a.dil;                                                \
+        const unsigned toff_ = (unsigned)(((dy_ * a.in_w + dx_) * a.x_ld + ld_cc * kKC) * 2);              \
+        const bool dead_ = ld_c >= a.nch || (tail_dead && ld_cc == a.cpt - 1);                             \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                                 \
+            unsigned vo_;                                                                                  \
+            if (plain) vo_ = dead_ ? 0xffffffffu : a_base[i];                                              \
+            else {                                                                                         \
+                const bool in_ = (unsigned)(a_ih0[i] + dy_) < (unsigned)a.in_h && (unsigned)(a_iw0[i] + dx_) < (unsigned)a.in_w; \
+                vo_ = (in_ && !dead_) ? a_base[i] + toff_ : 0xffffffffu;                                   \
+            }                                                                                              \
+            R[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo_, plain ? (int)toff_ : 0, 0)); \
+        }                                                                                                  \
+        ++ld_c;                                                                                            \
+        if (++ld_cc == a.cpt) {                                                                            \
+            ld_cc = 0;                                                                                     \
+            if (++ld_kw == a.kw) { ld_kw = 0; ++ld_kh; }                                                   \
+        }                                                                                                  \
+    } while (0)
+#define DW_STORE_A(BUF)                                                                                    \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                   \
+            *reinterpret_cast<u32x4 *>(st_ptr + (BUF) * kBufB + i * 32 * kRowB) = ra[i];                   \
+    } while (0)
+#define DW_LOAD_W(C, S)                                                                                    \
+    do {                                                                                                   \
+        wf[S][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, w_s0 + ((C) * 4 + (S)) * kFragB, 0)); \
+        wf[S][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, w_s1 + ((C) * 4 + (S)) * kFragB, 0)); \
+    } while (0)
+#define DW_MFMA_STEP(BUF, S)                                                                               \
+    do {                                                                                                   \
+        bf16x8 fa_[MT];                                                                                    \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
+            fa_[mt] = *reinterpret_cast<const bf16x8 *>(smem + (BUF) * kBufB + rd_off[S] + mt * 32 * kRowB); \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                \
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[S][0], fa_[mt], acc[mt][0], 0, 0, 0);  \
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[S][1], fa_[mt], acc[mt][1], 0, 0, 0);  \
+        }                                                                                                  \
+    } while (0)
+
+    // residual rows in the epilogue's layout: lane -> (pixel (lane >> 2) + 16 ps, 8-channel chunk lane & 3) of a 32 x 32 tile;
+    // buffer loads with 32-bit offsets (rows beyond M / chunks beyond N: out of range, zeros)
+    const int pc = lane & 3, pp = lane >> 2;
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.res, 0, a.res ? (int)a.res_bytes : 0, 0x00020000);
+    bf16x8 resq[MT][2][2];
+#define DW_FETCH_RES(MTI, NT, PS)                                                                          \
+    do {                                                                                                   \
+        const int row = m0 + wm * WROWS + (MTI) * 32 + pp + 16 * (PS);                                     \
+        const int ch = n0 + wn * 64 + (NT) * 32 + 8 * pc;                                                  \
+        const unsigned ro = (row < a.M && ch < a.N) ? ((unsigned)row * (unsigned)a.res_ld + ch) * 2u : 0xffffffffu; \
+        resq[MTI][NT][PS] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, ro, 0, 0)); \
+    } while (0)
+
+    // The order of the memory instructions is pinned with sched_barriers: left alone, the compiler sinks every load of an
+    // iteration behind its MFMAs (their destination registers double as LDS fragment registers) and then waits for all of
+    // them at the top of the next one -- a full memory latency per chunk.
+#define DW_SB() __builtin_amdgcn_sched_barrier(0)
+    // Prologue in the loop's order -- activation rows first, then the fragments -- so that the wait in front of the loop's
+    // ds_write counts the same 8 younger fragment loads on the first pass as on every other (chunk 0 in registers of its own).
+    {
+        u32x4 rp[A_LD];
+        DW_LOAD_A(rp);
+        DW_LOAD_A(ra);
+        DW_SB();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) DW_LOAD_W(0, s);
+        DW_SB();
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) *reinterpret_cast<u32x4 *>(st_ptr + i * 32 * kRowB) = rp[i];
+    }
+    DW_SB();
+    __syncthreads();
+    const int last = a.nch - 1;
+    for (int c = 0; c < last; ++c) {
+        const int buf = c & 1;
+        DW_STORE_A(buf ^ 1);                            // chunk c + 1, requested one iteration ago (the 8 fragment loads behind it stay in flight)
+        DW_SB();
+        DW_LOAD_A(ra);                                  // chunk c + 2
+        DW_SB();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            DW_MFMA_STEP(buf, s);
+            DW_SB();
+            DW_LOAD_W(c + 1, s);                        // into the fragment registers this k-step has just used
+            DW_SB();
+        }
+        __syncthreads();
+    }
+    {
+        // last chunk: the residual rows are requested k-step by k-step into the fragment registers it no longer refills
+        // (MT = 4: those of the wave's first n-tile; the second n-tile's follow when the epilogue starts)
+        const int buf = last & 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            DW_MFMA_STEP(buf, s);
+            DW_SB();
+            if constexpr (MT == 2) {
+                DW_FETCH_RES(s >> 1, 0, s & 1);
+                DW_FETCH_RES(s >> 1, 1, s & 1);
+            } else {
+                DW_FETCH_RES(s, 0, 0);
+                DW_FETCH_RES(s, 0, 1);
+            }
+            DW_SB();
+        }
+    }
+    DW_SB();
+    __syncthreads();                                    // the epilogue stage reuses the activation buffers
+    if constexpr (MT == 4) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            DW_FETCH_RES(mt, 1, 0);
+            DW_FETCH_RES(mt, 1, 1);
+        }
+        DW_SB();
+    }
+#undef DW_SB
+#undef DW_LOAD_A
+#undef DW_STORE_A
+#undef DW_LOAD_W
+#undef DW_FETCH_RES
+#undef DW_MFMA_STEP
+
+    // epilogue.  acc[mt][nt][4 g + i] = C[pixel m0 + wm WROWS + 32 mt + lr][channel n0 + wn 64 + 32 nt + 8 g + 4 lh + i].
+    // The loop ended on a barrier: the activation buffers are dead, each wave stages its tiles in its own 32 x 36 f32 slice.
+    float *const stage = reinterpret_cast<float *>(smem) + wave * (32 * kStageLd);
+    __bf16 *const yb = reinterpret_cast<__bf16 *>(a.y);
+    const int prow0 = m0 + wm * WROWS, pcol0 = n0 + wn * 64;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int ch = pcol0 + nt * 32 + 8 * pc;
+        const bool ch_ok = ch < a.N;
+        const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sc0 = one, sc1 = one, sh0 = zero, sh1 = zero;
+        if (ch_ok && a.scale) { sc0 = *reinterpret_cast<const f32x4 *>(a.scale + ch); sc1 = *reinterpret_cast<const f32x4 *>(a.scale + ch + 4); }
+        if (ch_ok && a.bias) { sh0 = *reinterpret_cast<const f32x4 *>(a.bias + ch); sh1 = *reinterpret_cast<const f32x4 *>(a.bias + ch + 4); }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(stage + lr * kStageLd + 8 * g + 4 * lh) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int p = pp + 16 * ps;
+                const int row = prow0 + mt * 32 + p;
+                f32x4 v0 = *reinterpret_cast<const f32x4 *>(stage + p * kStageLd + 8 * pc);
+                f32x4 v1 = *reinterpret_cast<const f32x4 *>(stage + p * kStageLd + 8 * pc + 4);
+                if (row < a.M && ch_ok) {
+                    v0 = v0 * sc0 + sh0;
+                    v1 = v1 * sc1 + sh1;
+                    {                                   // (zeros when there is no residual)
+                        const bf16x8 rq = resq[mt][nt][ps];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { v0[i] += (float)rq[i]; v1[i] += (float)rq[4 + i]; }
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], 0.f); v1[i] = fmaxf(v1[i], 0.f); }
+                    }
+                    const bf16x4 o0 = __builtin_convertvector(v0, bf16x4), o1 = __builtin_convertvector(v1, bf16x4);
+                    *reinterpret_cast<bf16x8 *>(yb + (size_t)row * a.y_ld + a.y_coff + ch) = __builtin_shufflevector(o0, o1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+template <int WM, int WN, int MT>
+int launch_dw(const DwArgs &a0, hipStream_t st) {
+    constexpr int BM = 32 * MT * WM, BN = 64 * WN;
+    DwArgs a = a0;
+    a.tiles_m = cdiv(a.M, BM);
+    a.tiles_n = cdiv(a.N, BN);
+    constexpr size_t tiles = 2 * (size_t)BM * kRowB, stage = sizeof(float) * 4 * 32 * kStageLd;
+    constexpr size_t lds = tiles > stage ? tiles : stage;
+    static PerDeviceSize lds_set;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_dw_bf16_kernel<WM, WN, MT>), lds, lds_set))
+        return fail(SGV3D_ELAUNCH, "conv_dw_bf16: cannot raise the dynamic LDS limit to %zu", lds);
+    hipLaunchKernelGGL((conv_dw_bf16_kernel<WM, WN, MT>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
+    return check_launch("conv_dw_bf16_kernel");
+}
+
+}  // namespace
+
+extern "C" size_t sgv3d_conv_dw_bf16_weight_bytes(int cout, int cin, int kh, int kw) {
+    if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return 0;
+    return (size_t)cdiv(cout, 64) * 2 * ((size_t)kh * kw * cdiv(cin, kKC) * 4) * kFragB;
+}
+
+extern "C" int sgv3d_conv_dw_bf16_pack_weight(const float *w, int cout, int cin_w, int cin, int kh, int kw, void *w_packed, void *stream) {
+    SGV3D_REQUIRE(w && w_packed && cout > 0 && cin_w > 0 && cin >= cin_w && kh > 0 && kw > 0, "conv_dw_bf16_pack_weight: bad argument");
+    const int cpt = cdiv(cin, kKC);
+    hipLaunchKernelGGL(dw_pack_kernel, dim3(cdiv(cout, 64) * 2 * kh * kw * cpt * 4), dim3(64), 0, as_stream(stream), w, cout, cin_w, kh * kw, cpt,
+                       static_cast<__bf16 *>(w_packed));
+    return check_launch("dw_pack_kernel");
+}
+
+extern "C" int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *d, const void *x, const void *w_packed, const float *scale,
+                                          const float *bias, const void *residual, void *y, void *stream) {
+    SGV3D_REQUIRE(d && x && w_packed && y, "conv_dw_bf16: null pointer");
+    SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL && d->split_k <= 1, "conv_dw_bf16: NORMAL mode without split-K only");
+    SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0 &&
+                      d->dil > 0 && d->pad >= 0, "conv_dw_bf16: non-positive dimension");
+    const int eh = (d->in_h + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+    const int ew = (d->in_w + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+    SGV3D_REQUIRE(eh == d->out_h && ew == d->out_w, "conv_dw_bf16: output %dx%d does not match the conv arithmetic %dx%d", d->out_h, d->out_w, eh, ew);
+    SGV3D_REQUIRE(d->cin % 32 == 0 && d->cout % 8 == 0, "conv_dw_bf16: cin must be a multiple of 32 and cout of 8 (got %d / %d)", d->cin, d->cout);
+    SGV3D_REQUIRE(d->x_ld >= d->x_coff + d->cin && d->y_ld >= d->y_coff + d->cout && (residual == nullptr || d->res_ld >= d->cout),
+                  "conv_dw_bf16: channel strides too small");
+    SGV3D_REQUIRE(d->x_ld % 8 == 0 && d->x_coff % 8 == 0 && d->y_ld % 8 == 0 && d->y_coff % 8 == 0 && (residual == nullptr || d->res_ld % 8 == 0),
+                  "conv_dw_bf16: channel strides / offsets must be multiples of 8 (16-byte rows of bf16)");
+    SGV3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
+                    reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+                  "conv_dw_bf16: pointers must be 16-B aligned");
+    const long long M = (long long)d->batch * d->out_h * d->out_w;
+    const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * 2;
+    const size_t wb = sgv3d_conv_dw_bf16_weight_bytes(d->cout, d->cin, d->kh, d->kw);
+    SGV3D_REQUIRE(M < 0x7fffffffLL && xb < 0xf0000000LL && wb < 0xf0000000ULL && (residual == nullptr || M * d->res_ld * 2 < 0xf0000000LL),
+                  "conv_dw_bf16: operands larger than 3.75 GiB (32-bit buffer offsets)");
+    SGV3D_REQUIRE((long long)d->dil * (d->kh - 1) < 0x10000 && d->in_h < 0x10000000 && d->in_w < 0x10000000, "conv_dw_bf16: kernel extent too large");
+    DwArgs a;
+    a.x = x; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
+    a.M = (int)M; a.N = d->cout; a.cin = d->cin;
+    a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff; a.res_ld = d->res_ld; a.relu = d->relu;
+    a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w;
+    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+    a.cpt = cdiv(d->cin, kKC);
+    a.nch = d->kh * d->kw * a.cpt;
+    a.ksteps = a.nch * 4;
+    a.tiles_m = a.tiles_n = 0;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.res_bytes = residual ? (unsigned)(M * d->res_ld * 2) : 0u;
+    hipStream_t st = as_stream(stream);
+    switch (d->tile) {
+        case SGV3D_TILE_DW_64x256: return launch_dw<1, 4, 2>(a, st);
+        case SGV3D_TILE_DW_128x128: return launch_dw<2, 2, 2>(a, st);
+        case SGV3D_TILE_DW_256x64: return launch_dw<4, 1, 2>(a, st);
+        case SGV3D_TILE_DW_128x256: return launch_dw<1, 4, 4>(a, st);
+        case SGV3D_TILE_DW_256x128: return launch_dw<2, 2, 4>(a, st);
+        default: return fail(SGV3D_EINVAL, "conv_dw_bf16: desc.tile must be one of SGV3D_TILE_DW_* (got %d)", d->tile);
+    }
+}

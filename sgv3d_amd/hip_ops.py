@@ -119,7 +119,7 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: 
               9: "wino4", 10: "wino4", 15: "wino4",                         # F(4x4,3x3) with the 64x64 / 64x128 / 32x128 GEMM tile
               11: "128x128", 12: "128x64", 13: "64x128", 14: "64x64",      # 11..14: f32x3 of tiles 1..4 (host-side ids)
               21: "128x128", 22: "128x64", 23: "64x128", 24: "64x64",      # 21..24: tiles 1..4 walked m-tile first (SGV3D_TILE_MFIRST)
-              31: "pw_bf16", 32: "pw_bf16", 33: "pw_bf16"}                  # bf16 pointwise kernel, 64x256 / 128x128 / 256x64 pixels x channels
+              31: "dw_bf16", 32: "dw_bf16", 33: "dw_bf16", 34: "dw_bf16", 35: "dw_bf16"}   # bf16 direct-weight kernel (SGV3D_TILE_DW_*)
 MFIRST = _os.environ.get("SGV3D_MFIRST", "1") != "0"
 TILE_WINO = 5       # host-side algorithm id: sgv3d_conv2d_winograd_forward instead of the implicit GEMM
 TILE_WINO_RES = 6   # = SGV3D_WINOGRAD_RESIDENT: its patch-resident variant (cin <= 96, many cout tiles)
@@ -133,8 +133,10 @@ WINO4 = _os.environ.get("SGV3D_WINO4", "1") != "0"     # 0: F(4x4) is never a ca
 WINO4_MIN_CHANNELS = 128                              # candidates only where cin and cout are at least this
 WINO_HALF = _os.environ.get("SGV3D_WINO_HALF", "1") != "0"
 PATCH_BF16 = _os.environ.get("SGV3D_PATCH_BF16", "1") != "0"
-PW_TILES = (31, 32, 33)  # = SGV3D_TILE_PW_*: bf16 mode, bf16 tensors in and out: the pointwise (1x1) kernel (sgv3d_conv_pw_bf16_forward)
-PW_BF16 = _os.environ.get("SGV3D_PW_BF16", "1") != "0"   # 0: never a candidate
+# = SGV3D_TILE_DW_*: bf16 mode, bf16 tensors in and out: the direct-weight implicit GEMM (sgv3d_conv_dw_bf16_forward), pixels x
+# channels per workgroup 64x256 / 128x128 / 256x64 (64 pixels per wave) and 128x256 / 256x128 (128 pixels per wave)
+DW_TILES = (31, 32, 33, 34, 35)
+DW_BF16 = _os.environ.get("SGV3D_DW_BF16", "1") != "0"   # 0: never a candidate
 
 
 class prof:
@@ -321,27 +323,23 @@ class PackedConv:
             self.w_wino4, self.wino4_geom = packed, (k_pad, cout_pad)
         return self.w_wino4
 
-    def _pw_weights(self):
-        """Fragment-ordered bf16 weights of the pointwise kernel (sgv3d_conv_pw_bf16_pack_weight), made on first use."""
-        if getattr(self, 'w_pw', None) is None:
+    def _dw_weights(self):
+        """Fragment-ordered bf16 weights of the direct-weight kernel (sgv3d_conv_dw_bf16_pack_weight), made on first use."""
+        if getattr(self, 'w_dw', None) is None:
             lib = _lib.load()
-            w = self._keep                                           # [cout, cin_real, 1, 1] f32 on the device
-            wp = w
-            if int(w.shape[1]) != self.cin:                          # input channels padded for the activation layout
-                wp = torch.zeros(self.cout, self.cin, 1, 1, dtype=torch.float32, device=w.device)
-                wp[:, :w.shape[1]] = w
-            self.w_pw = torch.empty(lib.sgv3d_conv_pw_bf16_weight_bytes(self.cout, self.cin), dtype=torch.uint8, device=w.device)
+            w = self._keep                                           # [cout, cin_real, kh, kw] f32 on the device
+            self.w_dw = torch.empty(lib.sgv3d_conv_dw_bf16_weight_bytes(self.cout, self.cin, self.kh, self.kw), dtype=torch.uint8,
+                                    device=w.device)
             with torch.cuda.device(w.device):
-                rc = lib.sgv3d_conv_pw_bf16_pack_weight(wp.data_ptr(), self.cout, self.cin, self.w_pw.data_ptr(), _st(w))
-            _lib.check(rc, "sgv3d_conv_pw_bf16_pack_weight")
-            self._keep_pw = wp
-        return self.w_pw
+                rc = lib.sgv3d_conv_dw_bf16_pack_weight(w.data_ptr(), self.cout, int(w.shape[1]), self.cin, self.kh, self.kw,
+                                                        self.w_dw.data_ptr(), _st(w))
+            _lib.check(rc, "sgv3d_conv_dw_bf16_pack_weight")
+        return self.w_dw
 
-    def _pw_eligible(self, d, gate=None, io=0):
-        return (MFMA_BF16 and not MFMA_F32X3 and PW_BF16 and io == 3 and not self.transposed and self.kh == 1 and self.kw == 1
-                and self.pad == 0 and self.dil == 1 and d.mode == CONV_NORMAL and gate is None and self.cin % 32 == 0
-                and self.cout % 8 == 0 and d.x_ld % 8 == 0 and d.x_coff % 8 == 0 and d.y_ld % 8 == 0 and d.y_coff % 8 == 0
-                and d.res_ld % 8 == 0)
+    def _dw_eligible(self, d, gate=None, io=0):
+        return (MFMA_BF16 and not MFMA_F32X3 and DW_BF16 and io == 3 and not self.transposed and d.mode == CONV_NORMAL
+                and gate is None and self.cin % 32 == 0 and self.cout % 8 == 0 and d.x_ld % 8 == 0 and d.x_coff % 8 == 0
+                and d.y_ld % 8 == 0 and d.y_coff % 8 == 0 and d.res_ld % 8 == 0)
 
     def _patch_weights(self):
         if self.w_patch is None:
@@ -442,9 +440,9 @@ class PackedConv:
         real_n = self.cout_real * (self.ks * self.ks if self.transposed else 1)
         flops = 2.0 * gemm_m * real_n * (self.cin_real * self.kh * self.kw)
         x3 = 10 < t < 20 or (MFMA_F32X3 is True and t < TILE_WINO)
-        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) + WINO4_TILES + PW_TILES else
+        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) + WINO4_TILES + DW_TILES else
                 ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_f32x3_" if x3 else "conv_igemm_")) + TILE_NAMES[t]
-        if t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) + WINO4_TILES + PW_TILES and self.k_order == 0:
+        if t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) + WINO4_TILES + DW_TILES and self.k_order == 0:
             name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
@@ -495,11 +493,11 @@ class PackedConv:
                                                         d.y_coff, d.res_ld, d.relu, x.data_ptr(), self._patch_weights().data_ptr(),
                                                         _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
                                                         out.data_ptr(), int(io), int(d.split_k), _lib.ptr(ws), nws, _st(x))
-        if d.tile in PW_TILES:
-            if not self._pw_eligible(d, gate, io) or d.split_k > 1:
-                raise _lib.SGV3DError("the bf16 pointwise kernel covers 1x1 / pad 0 layers with cin % 32 == 0 and bf16 tensors in and out, "
-                                      "no split-K")
-            return lib.sgv3d_conv_pw_bf16_forward(ctypes.byref(d), x.data_ptr(), self._pw_weights().data_ptr(), _lib.ptr(self.scale),
+        if d.tile in DW_TILES:
+            if not self._dw_eligible(d, gate, io) or d.split_k > 1:
+                raise _lib.SGV3DError("the bf16 direct-weight kernel covers layers with cin % 32 == 0, cout % 8 == 0 and bf16 tensors in "
+                                      "and out (NHWC), no gate, no split-K")
+            return lib.sgv3d_conv_dw_bf16_forward(ctypes.byref(d), x.data_ptr(), self._dw_weights().data_ptr(), _lib.ptr(self.scale),
                                                   _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(), _st(x))
         if d.tile in WINO4_TILES:
             if not self.wino4_ok(d, gate) or d.split_k > 1:
@@ -590,8 +588,9 @@ class PackedConv:
             tiles += WINO4_TILES if self.cin >= 128 else (TILE_WINO4, TILE_WINO4_WIDE)
         if self._patch_eligible(d, gate):
             tiles += (TILE_PATCH,)
-        if self._pw_eligible(d, gate, io):
-            tiles += (31,) if gemm_n > 128 else (32,) if gemm_n > 64 else (32, 33)
+        if self._dw_eligible(d, gate, io):
+            deep = self.kh * self.kw * self.cin >= 512              # enough k for the 128-pixel wave tiles to pay
+            tiles += ((31,) + ((34,) if deep else ()) if gemm_n > 128 else (32,) + ((35,) if deep else ()) if gemm_n > 64 else (32, 33))
         if fixed_tile:
             tiles = (fixed_tile,)
         dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 64), 6: (256, 64),
@@ -609,7 +608,7 @@ class PackedConv:
                 if t == TILE_PATCH:
                     nk = self.cin // 32     # stages of 32 input channels; >= 2 per split
                     wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 32) * -(-gemm_n // 64)
-                if t == TILE_WINO_RES or t in WINO4_TILES or t in PW_TILES:
+                if t == TILE_WINO_RES or t in WINO4_TILES or t in DW_TILES:
                     splits = (1,)
                 elif t == TILE_PATCH and not fixed_split and SPLIT_K:
                     splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 2 and wgs * s <= 1024]

@@ -252,7 +252,7 @@ class BSMLSSFPN(LSSFPN):
         imgs = imgs.reshape(batch_size * num_sweeps * num_cams, num_channels, imH, imW).float().contiguous()
         cin_pad = self.img_backbone.hip_state(imgs.device)['cin_pad']
         feats = self.img_backbone.hip_forward(hip_ops.nchw_to_nhwc(imgs, c_pad=cin_pad))
-        return [self.img_neck_16.hip_forward(feats), self.img_neck_8.hip_forward(feats)]
+        return [n.hip_forward(feats, out_dtype=hip_ops.activation_dtype(*n.out_channels)) for n in (self.img_neck_16, self.img_neck_8)]
 
     def _forward_single_sweep(self, sweep_index, sweep_imgs, mats_dict, nhwc_out=False):
         """bsm_lss_fpn.py:485-559"""

@@ -399,7 +399,9 @@ class LSSFPN(HipModule):
         cin_pad = self.img_backbone.hip_state(imgs.device)['cin_pad']
         x = hip_ops.nchw_to_nhwc(imgs, c_pad=cin_pad)
         feats = self.img_backbone.hip_forward(x)
-        return self.img_neck.hip_forward(feats)
+        # (bf16-activation mode: the concatenated neck map is a bf16 tensor too -- half the bytes, and HeightNet's first 3x3 gets the
+        # bf16-in / bf16-out kernels)
+        return self.img_neck.hip_forward(feats, out_dtype=hip_ops.activation_dtype(*self.img_neck.out_channels))
 
     def _forward_single_sweep(self, sweep_index, sweep_imgs, mats_dict, nhwc_out=False):
         """lss_fpn.py:422-495.  Returns the BEV map [B, C, Y, X] (NHWC buffer [B,Y,X,C] when

@@ -360,9 +360,9 @@ def test_bf16_io_conv(bf16_mode, shape, tile):
     (1, 1024, 17, 30, 256, 1, False),      # ResNet layer-3 reducing layer
     (1, 128, 31, 33, 320, 2, True),        # odd strided map, cout = 5 n-chunks of 64
 ])
-@pytest.mark.parametrize("tile", [31, 32, 33])
-def test_bf16_pointwise_conv(bf16_mode, shape, tile):
-    """sgv3d_conv_pw_bf16_forward (host tile ids 31-33: 64x256 / 128x128 / 256x64 pixels x channels): bf16 tensors in and out.
+@pytest.mark.parametrize("tile", [31, 32, 33, 34, 35])
+def test_bf16_direct_weight_conv_1x1(bf16_mode, shape, tile):
+    """sgv3d_conv_dw_bf16_forward (host tile ids 31-35 = SGV3D_TILE_DW_*) on 1x1 layers: bf16 tensors in and out.
     Reference: float64 convolution of the bf16-rounded operands, epilogue in high precision, one rounding to bf16 -- and the
     implicit-GEMM bf16io kernel, which multiplies the same bf16 values in the same k order: bitwise equal outputs."""
     B, cin, H, W, cout, stride, with_res = shape
@@ -395,27 +395,71 @@ def test_bf16_pointwise_conv(bf16_mode, shape, tile):
     assert float((wide[..., :8] - 7).abs().max()) == 0 and float((wide[..., 8 + cout:] - 7).abs().max()) == 0
 
 
-def test_bf16_pointwise_conv_exact_on_small_integers(bf16_mode):
+@pytest.mark.parametrize("shape", [
+    # B, cin, H, W, cout, k, stride, pad, dil, residual
+    (1, 64, 17, 21, 64, 3, 1, 1, 1, False),        # 3x3
+    (2, 128, 18, 22, 128, 3, 2, 1, 1, False),      # strided 3x3
+    (1, 256, 17, 30, 256, 3, 1, 1, 1, True),       # ResNet layer-3 3x3 with a residual
+    (1, 512, 20, 24, 136, 3, 1, 6, 6, False),      # dilated (ASPP), cout not a multiple of 64
+    (1, 512, 9, 11, 72, 3, 1, 18, 18, True),       # dilation larger than the map: most taps outside
+    (1, 96, 40, 56, 160, 7, 2, 3, 1, False),       # 7x7 stride-2 BEV stem, cin % 64 == 32 (tap chunks half dead)
+    (2, 160, 13, 13, 320, 3, 2, 1, 1, False),      # cin = 2.5 chunks per tap
+    (1, 32, 12, 9, 64, 5, 1, 2, 1, True),          # 5x5, cin = half a chunk
+])
+@pytest.mark.parametrize("tile", [31, 32, 33, 34, 35])
+def test_bf16_direct_weight_conv_kxk(bf16_mode, shape, tile):
+    """The same kernel as an implicit GEMM over taps: padding, stride, dilation, 7x7; against float64 on the bf16-rounded
+    operands (half an ulp of bf16 at the output scale) and against the bf16io implicit-GEMM kernel (other k order: 1 bf16 ulp)."""
+    B, cin, H, W, cout, k, stride, pad, dil, with_res = shape
+    g = torch.Generator().manual_seed(cin * 3 + cout + k)
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16()
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    conv = hip_ops.PackedConv(w.to(DEV), stride=stride, pad=pad, dil=dil, scale=sc.to(DEV), shift=sh.to(DEV), relu=True)
+    oh, ow = conv.out_hw(H, W)
+    res = torch.randn(B, cout, oh, ow, generator=g).bfloat16() if with_res else None
+    ref = F.conv2d(x.double(), w.bfloat16().double(), None, stride, pad, dil)
+    ref = ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    if res is not None:
+        ref = ref + res.double()
+    ref = ref.clamp_min(0)
+    scale = max(1.0, float(ref.abs().max()))
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rin = res.permute(0, 2, 3, 1).contiguous().to(DEV) if res is not None else None
+    y = conv(xin, residual=rin, tile=tile, split_k=1, out_dtype=torch.bfloat16)
+    err = float((y.float().permute(0, 3, 1, 2).cpu().double() - ref).abs().max())
+    assert err <= 2.0 ** -8 * scale, (err, scale)
+    y_ig = conv(xin, residual=rin, tile=4, split_k=1, out_dtype=torch.bfloat16)
+    assert float((y.float() - y_ig.float()).abs().max()) <= 2.0 ** -7 * scale
+    xw = torch.randn(B, H, W, cin + 24, generator=g).bfloat16().to(DEV)
+    xw[..., 16:16 + cin] = xin
+    wide = torch.full((B, oh, ow, cout + 16), 7.0, dtype=torch.bfloat16, device=DEV)
+    conv(xw, wide, x_coff=16, y_coff=8, residual=rin, tile=tile, split_k=1)
+    assert torch.equal(wide[..., 8:8 + cout], y)
+    assert float((wide[..., :8] - 7).abs().max()) == 0 and float((wide[..., 8 + cout:] - 7).abs().max()) == 0
+
+
+def test_bf16_direct_weight_conv_exact_on_small_integers(bf16_mode):
     g = torch.Generator().manual_seed(3)
     x = torch.randint(-3, 4, (2, 192, 12, 21), generator=g).float()
-    w = torch.randint(-2, 3, (200, 192, 1, 1), generator=g).float()
-    conv = hip_ops.PackedConv(w.to(DEV))
-    ref = F.conv2d(x, w)                                                    # |values| < 2^8 * 6: exact in bf16? no -- compare in f32 after rounding
-    xin = x.bfloat16().permute(0, 2, 3, 1).contiguous().to(DEV)
-    for tile in (31, 32, 33):
-        y = conv(xin, tile=tile, split_k=1, out_dtype=torch.bfloat16)
-        assert torch.equal(y.float().permute(0, 3, 1, 2).cpu(), ref.bfloat16().float())
+    for k, pad in ((1, 0), (3, 1)):
+        w = torch.randint(-2, 3, (200, 192, k, k), generator=g).float()
+        conv = hip_ops.PackedConv(w.to(DEV), pad=pad)
+        ref = F.conv2d(x, w, None, 1, pad)                                  # integer sums below 2^24: exact in the f32 accumulators
+        xin = x.bfloat16().permute(0, 2, 3, 1).contiguous().to(DEV)
+        for tile in (31, 32, 33, 34, 35):
+            y = conv(xin, tile=tile, split_k=1, out_dtype=torch.bfloat16)
+            assert torch.equal(y.float().permute(0, 3, 1, 2).cpu(), ref.bfloat16().float())
 
 
-def test_bf16_pointwise_conv_rejects_what_it_does_not_cover(bf16_mode):
+def test_bf16_direct_weight_conv_rejects_what_it_does_not_cover(bf16_mode):
     from sgv3d_amd import _lib
     conv = hip_ops.PackedConv(torch.randn(64, 64, 3, 3, device=DEV), pad=1)
-    x = torch.randn(1, 8, 8, 64, device=DEV).bfloat16()
+    x = torch.randn(1, 8, 8, 64, device=DEV)
     with pytest.raises(_lib.SGV3DError):
-        conv(x, tile=31, split_k=1, out_dtype=torch.bfloat16)               # 3x3
-    conv1 = hip_ops.PackedConv(torch.randn(64, 64, 1, 1, device=DEV))
+        conv(x, tile=31, split_k=1)                                         # f32 tensors
     with pytest.raises(_lib.SGV3DError):
-        conv1(x.float(), tile=31, split_k=1)                                # f32 tensors
+        conv(x.bfloat16(), tile=31, split_k=2, out_dtype=torch.bfloat16)    # split-K
 
 
 def test_bf16_maxpool(bf16_mode):
