@@ -52,7 +52,7 @@ struct DwArgs {
     int in_h, in_w, out_h, out_w, kh, kw, stride, pad, dil;
     int tiles_m, tiles_n;
     int cpt, nch, ksteps;      // chunks per tap = ceil(cin / 64), nch = kh kw cpt, ksteps = 4 nch (k-steps of 16 per n-tile)
-    unsigned x_bytes, w_bytes, res_bytes;
+    unsigned x_bytes, w_bytes, res_bytes, y_bytes;
 };
 
 // weights: OIHW f32 [cout][cin_w][kh][kw] -> [n-tile of 32][k-step of 16][lane][8] bf16; lane l holds channel 32 nt + (l & 31),
@@ -178,16 +178,35 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
         wf[S][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, w_s0 + ((C) * 4 + (S)) * kFragB, 0)); \
         wf[S][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, w_s1 + ((C) * 4 + (S)) * kFragB, 0)); \
     } while (0)
-#define DW_MFMA_STEP(BUF, S)                                                                               \
+#define DW_READ_A(FA, BUF, S)                                                                              \
     do {                                                                                                   \
-        bf16x8 fa_[MT];                                                                                    \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
-            fa_[mt] = *reinterpret_cast<const bf16x8 *>(smem + (BUF) * kBufB + rd_off[S] + mt * 32 * kRowB); \
+            FA[mt] = *reinterpret_cast<const bf16x8 *>(smem + (BUF) * kBufB + rd_off[S] + mt * 32 * kRowB); \
+    } while (0)
+#define DW_MFMA(FA, S)                                                                                     \
+    do {                                                                                                   \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                \
-            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[S][0], fa_[mt], acc[mt][0], 0, 0, 0);  \
-            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[S][1], fa_[mt], acc[mt][1], 0, 0, 0);  \
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[S][0], FA[mt], acc[mt][0], 0, 0, 0);   \
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[S][1], FA[mt], acc[mt][1], 0, 0, 0);   \
         }                                                                                                  \
     } while (0)
+    constexpr bool kPrefetchA = MT == 4 && WM == 1;      // (the 256 x 128 tile has no registers left for it)
+// One k-step.  MT = 4 (two waves per SIMD: the other wave does not always cover an LDS round trip): the fragments of k-step
+// S + 1 are requested before the MFMAs of k-step S (second register set); MT = 2 (four waves per SIMD, 128 registers): read and
+// multiply in place.
+#define DW_MFMA_STEP(BUF, S)                                                                               \
+    do {                                                                                                   \
+        if constexpr (kPrefetchA) {                                                                        \
+            if ((S) == 0) DW_READ_A(fa[0], BUF, 0);                                                        \
+            if ((S) < 3) DW_READ_A(fa[((S) + 1) & 1], BUF, ((S) + 1) & 3);                                 \
+            DW_SB();                                                                                       \
+            DW_MFMA(fa[(S) & 1], S);                                                                       \
+        } else {                                                                                           \
+            DW_READ_A(fa[0], BUF, S);                                                                      \
+            DW_MFMA(fa[0], S);                                                                             \
+        }                                                                                                  \
+    } while (0)
+    bf16x8 fa[kPrefetchA ? 2 : 1][MT];
 
     // residual rows in the epilogue's layout: lane -> (pixel (lane >> 2) + 16 ps, 8-channel chunk lane & 3) of a 32 x 32 tile;
     // buffer loads with 32-bit offsets (rows beyond M / chunks beyond N: out of range, zeros)
@@ -271,12 +290,18 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
 #undef DW_LOAD_W
 #undef DW_FETCH_RES
 #undef DW_MFMA_STEP
+#undef DW_MFMA
+#undef DW_READ_A
 
     // epilogue.  acc[mt][nt][4 g + i] = C[pixel m0 + wm WROWS + 32 mt + lr][channel n0 + wn 64 + 32 nt + 8 g + 4 lh + i].
     // The loop ended on a barrier: the activation buffers are dead, each wave stages its tiles in its own 32 x 36 f32 slice.
     float *const stage = reinterpret_cast<float *>(smem) + wave * (32 * kStageLd);
-    __bf16 *const yb = reinterpret_cast<__bf16 *>(a.y);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, 0x00020000);
     const int prow0 = m0 + wm * WROWS, pcol0 = n0 + wn * 64;
+    // ReLU on the packed bf16 pairs after the rounding (rounding keeps sign and order, so relu(round(v)) == round(relu(v))):
+    // a signed 16-bit max with 0 clears every negative value; without ReLU the floor is the most negative pattern (identity).
+    // 4 instructions per 8 values instead of the 16 of fmaxf on f32 (canonicalise + max).
+    const unsigned floor2 = a.relu ? 0u : 0x80008000u;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int ch = pcol0 + nt * 32 + 8 * pc;
@@ -285,6 +310,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
         f32x4 sc0 = one, sc1 = one, sh0 = zero, sh1 = zero;
         if (ch_ok && a.scale) { sc0 = *reinterpret_cast<const f32x4 *>(a.scale + ch); sc1 = *reinterpret_cast<const f32x4 *>(a.scale + ch + 4); }
         if (ch_ok && a.bias) { sh0 = *reinterpret_cast<const f32x4 *>(a.bias + ch); sh1 = *reinterpret_cast<const f32x4 *>(a.bias + ch + 4); }
+        const unsigned ycol = (unsigned)(a.y_coff + ch) * 2u;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -299,21 +325,22 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
                 const int row = prow0 + mt * 32 + p;
                 f32x4 v0 = *reinterpret_cast<const f32x4 *>(stage + p * kStageLd + 8 * pc);
                 f32x4 v1 = *reinterpret_cast<const f32x4 *>(stage + p * kStageLd + 8 * pc + 4);
-                if (row < a.M && ch_ok) {
-                    v0 = v0 * sc0 + sh0;
-                    v1 = v1 * sc1 + sh1;
-                    {                                   // (zeros when there is no residual)
-                        const bf16x8 rq = resq[mt][nt][ps];
+                v0 = v0 * sc0 + sh0;
+                v1 = v1 * sc1 + sh1;
+                const bf16x8 rq = resq[mt][nt][ps];                       // (zeros when there is no residual)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { v0[i] += (float)rq[i]; v1[i] += (float)rq[4 + i]; }
-                    }
-                    if (a.relu) {
+                for (int i = 0; i < 4; ++i) { v0[i] += (float)rq[i]; v1[i] += (float)rq[4 + i]; }
+                const bf16x4 o0 = __builtin_convertvector(v0, bf16x4), o1 = __builtin_convertvector(v1, bf16x4);
+                u32x4 o = __builtin_bit_cast(u32x4, __builtin_shufflevector(o0, o1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], 0.f); v1[i] = fmaxf(v1[i], 0.f); }
-                    }
-                    const bf16x4 o0 = __builtin_convertvector(v0, bf16x4), o1 = __builtin_convertvector(v1, bf16x4);
-                    *reinterpret_cast<bf16x8 *>(yb + (size_t)row * a.y_ld + a.y_coff + ch) = __builtin_shufflevector(o0, o1, 0, 1, 2, 3, 4, 5, 6, 7);
+                for (int i = 0; i < 4; ++i) {
+                    unsigned d_;
+                    asm("v_pk_max_i16 %0, %1, %2" : "=v"(d_) : "v"(o[i]), "v"(floor2));
+                    o[i] = d_;
                 }
+                // rows beyond M / chunks beyond N: out-of-range offset, the store is dropped (no branch)
+                const unsigned yo = (row < a.M && ch_ok) ? (unsigned)row * (unsigned)(a.y_ld * 2) + ycol : 0xffffffffu;
+                __builtin_amdgcn_raw_buffer_store_b128(o, y_rsrc, yo, 0, 0);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -370,7 +397,8 @@ extern "C" int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *d, const void *
     const long long M = (long long)d->batch * d->out_h * d->out_w;
     const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * 2;
     const size_t wb = sgv3d_conv_dw_bf16_weight_bytes(d->cout, d->cin, d->kh, d->kw);
-    SGV3D_REQUIRE(M < 0x7fffffffLL && xb < 0xf0000000LL && wb < 0xf0000000ULL && (residual == nullptr || M * d->res_ld * 2 < 0xf0000000LL),
+    SGV3D_REQUIRE(M < 0x7fffffffLL && xb < 0xf0000000LL && wb < 0xf0000000ULL && (residual == nullptr || M * d->res_ld * 2 < 0xf0000000LL) &&
+                      M * d->y_ld * 2 < 0xf0000000LL,
                   "conv_dw_bf16: operands larger than 3.75 GiB (32-bit buffer offsets)");
     SGV3D_REQUIRE((long long)d->dil * (d->kh - 1) < 0x10000 && d->in_h < 0x10000000 && d->in_w < 0x10000000, "conv_dw_bf16: kernel extent too large");
     DwArgs a;
@@ -384,6 +412,7 @@ extern "C" int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *d, const void *
     a.ksteps = a.nch * 4;
     a.tiles_m = a.tiles_n = 0;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.res_bytes = residual ? (unsigned)(M * d->res_ld * 2) : 0u;
+    a.y_bytes = (unsigned)(M * d->y_ld * 2);
     hipStream_t st = as_stream(stream);
     switch (d->tile) {
         case SGV3D_TILE_DW_64x256: return launch_dw<1, 4, 2>(a, st);
