@@ -50,6 +50,9 @@ struct DwArgs {
     int M, N, cin;
     int x_ld, x_coff, y_ld, y_coff, res_ld, relu;
     int in_h, in_w, out_h, out_w, kh, kw, stride, pad, dil;
+    int m_h, m_w;              // pixel grid of the GEMM rows (the output map; the input map of a transposed convolution)
+    int ks, cout;              // ks > 0: transposed convolution with kernel == stride == ks as a 1x1 GEMM with N = ks ks cout columns
+                               // ordered (dy, dx, co); column (dy, dx, co) of input pixel (ih, iw) lands at output pixel (ih ks + dy, iw ks + dx)
     int tiles_m, tiles_n;
     int cpt, nch, ksteps;      // chunks per tap = ceil(cin / 64), nch = kh kw cpt, ksteps = 4 nch (k-steps of 16 per n-tile)
     unsigned x_bytes, w_bytes, res_bytes, y_bytes;
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
     for (int i = 0; i < A_LD; ++i) {
         const int m = m0 + r0 + 32 * i;
         const int mm = m < a.M ? m : 0;
-        const int t = (int)((unsigned)mm / (unsigned)a.out_w), ow = mm - t * a.out_w;
-        const int img = (int)((unsigned)t / (unsigned)a.out_h), oh = t - img * a.out_h;
+        const int t = (int)((unsigned)mm / (unsigned)a.m_w), ow = mm - t * a.m_w;
+        const int img = (int)((unsigned)t / (unsigned)a.m_h), oh = t - img * a.m_h;
         a_ih0[i] = m < a.M ? oh * a.stride - a.pad : -0x40000000;    // rows beyond M: no tap is ever inside
         a_iw0[i] = ow * a.stride - a.pad;
         a_base[i] = (unsigned)((((long long)img * a.in_h + a_ih0[i]) * a.in_w + a_iw0[i]) * a.x_ld + a.x_coff + c8 * 8) * 2u;
@@ -302,15 +305,39 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
     // a signed 16-bit max with 0 clears every negative value; without ReLU the floor is the most negative pattern (identity).
     // 4 instructions per 8 values instead of the 16 of fmaxf on f32 (canonicalise + max).
     const unsigned floor2 = a.relu ? 0u : 0x80008000u;
+    // output row offsets of the wave's pixels (bytes, 32-bit).  Transposed convolution: GEMM row = input pixel (img, ih, iw) ->
+    // output pixel (ih ks, iw ks) of the same image; the tap part of the address comes with the column
+    unsigned yrow[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int row = prow0 + mt * 32 + pp + 16 * ps;
+            unsigned pix = (unsigned)row;
+            if (a.ks > 0) {
+                const int rr = row < a.M ? row : 0;
+                const int t = (int)((unsigned)rr / (unsigned)a.in_w), iw = rr - t * a.in_w;
+                const int img = (int)((unsigned)t / (unsigned)a.in_h), ih = t - img * a.in_h;
+                pix = (unsigned)((img * a.out_h + ih * a.ks) * a.out_w + iw * a.ks);
+            }
+            yrow[mt][ps] = row < a.M ? pix * (unsigned)(a.y_ld * 2) : 0xffffffffu;
+        }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int ch = pcol0 + nt * 32 + 8 * pc;
         const bool ch_ok = ch < a.N;
+        int co = ch;                                                       // output channel of the 8-channel chunk
+        unsigned ycol = (unsigned)(a.y_coff + ch) * 2u;
+        if (a.ks > 0) {                                                    // (cout % 8 == 0: a chunk stays inside one tap)
+            const int tap = (int)((unsigned)ch / (unsigned)a.cout);
+            co = ch - tap * a.cout;
+            const int dy = (int)((unsigned)tap / (unsigned)a.ks), dx = tap - dy * a.ks;
+            ycol = (unsigned)((dy * a.out_w + dx) * a.y_ld + a.y_coff + co) * 2u;
+        }
         const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
         f32x4 sc0 = one, sc1 = one, sh0 = zero, sh1 = zero;
-        if (ch_ok && a.scale) { sc0 = *reinterpret_cast<const f32x4 *>(a.scale + ch); sc1 = *reinterpret_cast<const f32x4 *>(a.scale + ch + 4); }
-        if (ch_ok && a.bias) { sh0 = *reinterpret_cast<const f32x4 *>(a.bias + ch); sh1 = *reinterpret_cast<const f32x4 *>(a.bias + ch + 4); }
-        const unsigned ycol = (unsigned)(a.y_coff + ch) * 2u;
+        if (ch_ok && a.scale) { sc0 = *reinterpret_cast<const f32x4 *>(a.scale + co); sc1 = *reinterpret_cast<const f32x4 *>(a.scale + co + 4); }
+        if (ch_ok && a.bias) { sh0 = *reinterpret_cast<const f32x4 *>(a.bias + co); sh1 = *reinterpret_cast<const f32x4 *>(a.bias + co + 4); }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -322,7 +349,6 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
                 const int p = pp + 16 * ps;
-                const int row = prow0 + mt * 32 + p;
                 f32x4 v0 = *reinterpret_cast<const f32x4 *>(stage + p * kStageLd + 8 * pc);
                 f32x4 v1 = *reinterpret_cast<const f32x4 *>(stage + p * kStageLd + 8 * pc + 4);
                 v0 = v0 * sc0 + sh0;
@@ -339,7 +365,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
                     o[i] = d_;
                 }
                 // rows beyond M / chunks beyond N: out-of-range offset, the store is dropped (no branch)
-                const unsigned yo = (row < a.M && ch_ok) ? (unsigned)row * (unsigned)(a.y_ld * 2) + ycol : 0xffffffffu;
+                const unsigned yo = (yrow[mt][ps] != 0xffffffffu && ch_ok) ? yrow[mt][ps] + ycol : 0xffffffffu;
                 __builtin_amdgcn_raw_buffer_store_b128(o, y_rsrc, yo, 0, 0);
             }
             __builtin_amdgcn_wave_barrier();
@@ -380,12 +406,19 @@ extern "C" int sgv3d_conv_dw_bf16_pack_weight(const float *w, int cout, int cin_
 extern "C" int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *d, const void *x, const void *w_packed, const float *scale,
                                           const float *bias, const void *residual, void *y, void *stream) {
     SGV3D_REQUIRE(d && x && w_packed && y, "conv_dw_bf16: null pointer");
-    SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL && d->split_k <= 1, "conv_dw_bf16: NORMAL mode without split-K only");
+    const bool deconv = d->mode == SGV3D_CONV_DECONV;
+    SGV3D_REQUIRE((d->mode == SGV3D_CONV_NORMAL || deconv) && d->split_k <= 1, "conv_dw_bf16: NORMAL / DECONV mode without split-K only");
     SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0 &&
                       d->dil > 0 && d->pad >= 0, "conv_dw_bf16: non-positive dimension");
-    const int eh = (d->in_h + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
-    const int ew = (d->in_w + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
-    SGV3D_REQUIRE(eh == d->out_h && ew == d->out_w, "conv_dw_bf16: output %dx%d does not match the conv arithmetic %dx%d", d->out_h, d->out_w, eh, ew);
+    if (deconv) {
+        SGV3D_REQUIRE(d->deconv_ks >= 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->dil == 1 && residual == nullptr,
+                      "conv_dw_bf16: DECONV runs as a 1x1 GEMM with deconv_ks = kernel = stride, no residual");
+        SGV3D_REQUIRE(d->out_h == d->in_h * d->deconv_ks && d->out_w == d->in_w * d->deconv_ks, "conv_dw_bf16: DECONV output must be input * deconv_ks");
+    } else {
+        const int eh = (d->in_h + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+        const int ew = (d->in_w + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+        SGV3D_REQUIRE(eh == d->out_h && ew == d->out_w, "conv_dw_bf16: output %dx%d does not match the conv arithmetic %dx%d", d->out_h, d->out_w, eh, ew);
+    }
     SGV3D_REQUIRE(d->cin % 32 == 0 && d->cout % 8 == 0, "conv_dw_bf16: cin must be a multiple of 32 and cout of 8 (got %d / %d)", d->cin, d->cout);
     SGV3D_REQUIRE(d->x_ld >= d->x_coff + d->cin && d->y_ld >= d->y_coff + d->cout && (residual == nullptr || d->res_ld >= d->cout),
                   "conv_dw_bf16: channel strides too small");
@@ -394,25 +427,29 @@ extern "C" int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *d, const void *
     SGV3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
                     reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
                   "conv_dw_bf16: pointers must be 16-B aligned");
-    const long long M = (long long)d->batch * d->out_h * d->out_w;
+    const int gemm_n = deconv ? d->cout * d->deconv_ks * d->deconv_ks : d->cout;
+    const long long M = (long long)d->batch * (deconv ? (long long)d->in_h * d->in_w : (long long)d->out_h * d->out_w);
     const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * 2;
-    const size_t wb = sgv3d_conv_dw_bf16_weight_bytes(d->cout, d->cin, d->kh, d->kw);
+    const long long yb = (long long)d->batch * d->out_h * d->out_w * d->y_ld * 2;
+    const size_t wb = sgv3d_conv_dw_bf16_weight_bytes(gemm_n, d->cin, d->kh, d->kw);
     SGV3D_REQUIRE(M < 0x7fffffffLL && xb < 0xf0000000LL && wb < 0xf0000000ULL && (residual == nullptr || M * d->res_ld * 2 < 0xf0000000LL) &&
-                      M * d->y_ld * 2 < 0xf0000000LL,
+                      yb < 0xf0000000LL,
                   "conv_dw_bf16: operands larger than 3.75 GiB (32-bit buffer offsets)");
     SGV3D_REQUIRE((long long)d->dil * (d->kh - 1) < 0x10000 && d->in_h < 0x10000000 && d->in_w < 0x10000000, "conv_dw_bf16: kernel extent too large");
     DwArgs a;
     a.x = x; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
-    a.M = (int)M; a.N = d->cout; a.cin = d->cin;
+    a.M = (int)M; a.N = gemm_n; a.cin = d->cin;
+    a.ks = deconv ? d->deconv_ks : 0; a.cout = d->cout;
     a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff; a.res_ld = d->res_ld; a.relu = d->relu;
     a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w;
+    a.m_h = deconv ? d->in_h : d->out_h; a.m_w = deconv ? d->in_w : d->out_w;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
     a.cpt = cdiv(d->cin, kKC);
     a.nch = d->kh * d->kw * a.cpt;
     a.ksteps = a.nch * 4;
     a.tiles_m = a.tiles_n = 0;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.res_bytes = residual ? (unsigned)(M * d->res_ld * 2) : 0u;
-    a.y_bytes = (unsigned)(M * d->y_ld * 2);
+    a.y_bytes = (unsigned)yb;
     hipStream_t st = as_stream(stream);
     switch (d->tile) {
         case SGV3D_TILE_DW_64x256: return launch_dw<1, 4, 2>(a, st);

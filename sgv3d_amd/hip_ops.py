@@ -324,20 +324,25 @@ class PackedConv:
         return self.w_wino4
 
     def _dw_weights(self):
-        """Fragment-ordered bf16 weights of the direct-weight kernel (sgv3d_conv_dw_bf16_pack_weight), made on first use."""
+        """Fragment-ordered bf16 weights of the direct-weight kernel (sgv3d_conv_dw_bf16_pack_weight), made on first use.
+        Transposed convolution (kernel == stride): a 1x1 layer with ks * ks * cout outputs ordered (dy, dx, co)."""
         if getattr(self, 'w_dw', None) is None:
             lib = _lib.load()
-            w = self._keep                                           # [cout, cin_real, kh, kw] f32 on the device
-            self.w_dw = torch.empty(lib.sgv3d_conv_dw_bf16_weight_bytes(self.cout, self.cin, self.kh, self.kw), dtype=torch.uint8,
-                                    device=w.device)
+            w = self._keep                                           # [cout, cin_real, kh, kw] f32 on the device ([cin_real, cout, ks, ks] transposed)
+            n = self.cout
+            if self.transposed:
+                w = w.permute(2, 3, 1, 0).reshape(self.ks * self.ks * self.cout, int(w.shape[0]), 1, 1).contiguous()
+                n = self.ks * self.ks * self.cout
+            self.w_dw = torch.empty(lib.sgv3d_conv_dw_bf16_weight_bytes(n, self.cin, self.kh, self.kw), dtype=torch.uint8, device=w.device)
             with torch.cuda.device(w.device):
-                rc = lib.sgv3d_conv_dw_bf16_pack_weight(w.data_ptr(), self.cout, int(w.shape[1]), self.cin, self.kh, self.kw,
+                rc = lib.sgv3d_conv_dw_bf16_pack_weight(w.data_ptr(), n, int(w.shape[1]), self.cin, self.kh, self.kw,
                                                         self.w_dw.data_ptr(), _st(w))
             _lib.check(rc, "sgv3d_conv_dw_bf16_pack_weight")
+            self._keep_dw = w
         return self.w_dw
 
     def _dw_eligible(self, d, gate=None, io=0):
-        return (MFMA_BF16 and not MFMA_F32X3 and DW_BF16 and io == 3 and not self.transposed and d.mode == CONV_NORMAL
+        return (MFMA_BF16 and not MFMA_F32X3 and DW_BF16 and io == 3 and d.mode in (CONV_NORMAL, CONV_DECONV)
                 and gate is None and self.cin % 32 == 0 and self.cout % 8 == 0 and d.x_ld % 8 == 0 and d.x_coff % 8 == 0
                 and d.y_ld % 8 == 0 and d.y_coff % 8 == 0 and d.res_ld % 8 == 0)
 

@@ -471,7 +471,7 @@ def test_bf16_maxpool(bf16_mode):
 
 
 @pytest.mark.parametrize("cin,cout,ks,H,W,x_bf16", [(64, 32, 2, 9, 11, True), (160, 64, 4, 6, 7, True), (80, 64, 1, 10, 12, False),
-                                                    (640, 64, 8, 4, 5, True)])
+                                                    (640, 64, 8, 4, 5, True), (1024, 128, 1, 17, 15, True), (256, 128, 4, 19, 13, True)])
 def test_bf16_io_transposed_conv(bf16_mode, cin, cout, ks, H, W, x_bf16):
     """SECONDFPN deblocks (ConvTranspose2d, kernel == stride) writing a channel slice of a bf16 concat buffer."""
     g = torch.Generator().manual_seed(cin + ks)
@@ -492,6 +492,13 @@ def test_bf16_io_transposed_conv(bf16_mode, cin, cout, ks, H, W, x_bf16):
         assert float(out[..., :16].abs().max()) == 0 and float(out[..., 16 + cout:].abs().max()) == 0
     conv(xin, out, y_coff=16, tile=4, split_k=2)
     assert float((out[..., 16:16 + cout].float().permute(0, 3, 1, 2).cpu().double() - ref).abs().max()) <= 2.0 ** -8 * max(1.0, float(ref.abs().max()))
+    if x_bf16 and cin % 32 == 0:           # the direct-weight kernel in DECONV mode: bitwise the implicit-GEMM result
+        conv(xin, out, y_coff=16, tile=4, split_k=1)
+        want = out.clone()
+        for tile in (31, 32, 33, 34, 35):
+            out.zero_()
+            conv(xin, out, y_coff=16, tile=tile, split_k=1)
+            assert torch.equal(out, want), tile
 
 
 # ---------------------------------------------------------------------------------------------- LDS-resident-patch 3x3 kernel
