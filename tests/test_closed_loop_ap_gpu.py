@@ -35,7 +35,19 @@ def _calib_text(c):
            "Tr_velo_to_cam: " + " ".join(f"{v:.8f}" for v in tr.reshape(-1)) + "\n"
 
 
-def test_hip_and_oracle_chains_give_identical_ap_text(tmp_path):
+@pytest.fixture
+def fixed_kernel_choice():
+    """The per-layer first-call measurement picks among kernels whose f32 sums differ in association (split-K, Winograd): with it
+    the HIP outputs move by ~1e-6 from run to run, which can flip one near-threshold 2-D box match and with it a fourth AP
+    digit.  The fixed rule makes the HIP chain the same computation on every run."""
+    from sgv3d_amd import hip_ops
+    old = hip_ops.AUTOTUNE
+    hip_ops.AUTOTUNE = False
+    yield
+    hip_ops.AUTOTUNE = old
+
+
+def test_hip_and_oracle_chains_give_identical_ap_text(tmp_path, fixed_kernel_choice):
     from sgv3d_amd.evaluators import RoadSideEvaluator
     from sgv3d_amd.evaluators.kitti_utils import eval as E, kitti_common as KC
     from sgv3d_amd.models.bev_height import BEVHeight
