@@ -123,6 +123,10 @@ def load_traffic(tile_name):
         sym = "head_bf16_kernel"
     elif tile_name == "conv_patch_bf16":
         sym = "conv_patch_bf16_kernel"
+    elif tile_name == "conv_dw_bf16":
+        sym = "conv_dw_bf16_kernel"
+    elif not tile_name.startswith("conv_igemm"):
+        return None, None                          # a kernel without a PMC summary: traffic stays null
     else:
         fast = not tile_name.endswith("_tapmajor")
         kern = "conv_igemm_bf16_kernel" if tile_name.startswith(("conv_igemm_bf16", "conv_igemm_f32x3_")) else "conv_igemm_kernel"
