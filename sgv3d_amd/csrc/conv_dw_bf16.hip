@@ -8,7 +8,7 @@
 // store path runs at a third of the read rate), synchronises the workgroup every 8 MFMAs per wave, and at 220 VGPRs only two
 // workgroups share a CU, so a workgroup's residual / store phase has nothing to overlap with.  Here:
 //   * the weights never touch LDS: packed on the host in MFMA-fragment order ([n-tile of 32][k-step of 16][lane][8], k = (tap,
-//     channel) with the channels of a tap padded to 64) they stream from L2 straight into a ring of fragment registers one 64-k
+//     32-channel block); a 64-k chunk is two consecutive blocks, which for cin % 64 == 32 may belong to two taps: no padding) they stream from L2 straight into a ring of fragment registers one 64-k
 //     chunk ahead -- 1 KB contiguous per wave load, scalar offset, no vector instruction per load;
 //   * only the activation rows go through LDS: 64 k (128 B) per row and chunk gathered with 16-byte buffer loads (padding /
 //     out-of-image rows: out-of-range offset, zeros) and ds_write_b128, double buffered, ONE barrier per chunk = per 16-32 MFMAs
@@ -54,25 +54,26 @@ struct DwArgs {
     int ks, cout;              // ks > 0: transposed convolution with kernel == stride == ks as a 1x1 GEMM with N = ks ks cout columns
                                // ordered (dy, dx, co); column (dy, dx, co) of input pixel (ih, iw) lands at output pixel (ih ks + dy, iw ks + dx)
     int tiles_m, tiles_n;
-    int cpt, nch, ksteps;      // chunks per tap = ceil(cin / 64), nch = kh kw cpt, ksteps = 4 nch (k-steps of 16 per n-tile)
+    int bpt, nblk, nch, ksteps;   // 32-channel blocks per tap = cin / 32, nblk = kh kw bpt, nch = ceil(nblk / 2) chunks of 64 k, ksteps = 4 nch
     unsigned x_bytes, w_bytes, res_bytes, y_bytes;
 };
 
 // weights: OIHW f32 [cout][cin_w][kh][kw] -> [n-tile of 32][k-step of 16][lane][8] bf16; lane l holds channel 32 nt + (l & 31),
-// k = 16 ks + 8 (l >> 5) .. + 8 (the operand layout of v_mfma_f32_32x32x16_bf16) with k = (tap * cpt + chunk) * 64 + channel in
-// chunk; zero beyond cout / cin_w
-__global__ __launch_bounds__(64) void dw_pack_kernel(const float *__restrict__ w, int cout, int cin_w, int taps, int cpt, __bf16 *__restrict__ out) {
-    const int ksteps = taps * cpt * 4;
+// k = 16 ks + 8 (l >> 5) .. + 8 (the operand layout of v_mfma_f32_32x32x16_bf16).  k runs over BLOCKS of 32 input channels,
+// block = tap * bpt + (channel / 32) with bpt = cin / 32 blocks per tap; a 64-k chunk is two consecutive blocks (for
+// cin % 64 == 32 they may belong to two taps: no padding of a tap's channels); zero beyond cout / cin_w / the last block
+__global__ __launch_bounds__(64) void dw_pack_kernel(const float *__restrict__ w, int cout, int cin_w, int taps, int bpt, int ksteps,
+                                                      __bf16 *__restrict__ out) {
     const int id = blockIdx.x;                     // nt * ksteps + ks
     const int nt = id / ksteps, ks = id - nt * ksteps;
-    const int chunk = ks >> 2, tap = chunk / cpt, cc = chunk - tap * cpt;
+    const int blk = ks >> 1, tap = blk / bpt, cb = blk - tap * bpt;
     const int l = threadIdx.x;
     const int co = nt * 32 + (l & 31);
     __bf16 *dst = out + ((size_t)id * 64 + l) * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int ci = cc * kKC + (ks & 3) * 16 + 8 * (l >> 5) + j;
-        dst[j] = (co < cout && ci < cin_w) ? (__bf16)w[((size_t)co * cin_w + ci) * taps + tap] : (__bf16)0.f;
+        const int ci = cb * 32 + (ks & 1) * 16 + 8 * (l >> 5) + j;
+        dst[j] = (co < cout && tap < taps && ci < cin_w) ? (__bf16)w[((size_t)co * cin_w + ci) * taps + tap] : (__bf16)0.f;
     }
 }
 
@@ -119,8 +120,6 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
         a_base[i] = (unsigned)((((long long)img * a.in_h + a_ih0[i]) * a.in_w + a_iw0[i]) * a.x_ld + a.x_coff + c8 * 8) * 2u;
         if (plain) a_base[i] = m < a.M ? a_base[i] : 0xffffffffu;
     }
-    // cin % 64 == 32: the upper half of a tap's last chunk lies beyond cin -- those lanes read zeros (not the neighbouring channels)
-    const bool tail_dead = (a.cin & 63) != 0 && c8 >= 4;
     const int st_slot = (c8 ^ ((r0 >> 1) & 7)) * 16;                 // rows r0 + 32 i share (row >> 1) & 7
     char *const st_ptr = smem + r0 * kRowB + st_slot;
 
@@ -147,29 +146,42 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
 
-    // loader state (uniform): the chunk the next DW_LOAD_A fetches = (tap (ld_kh, ld_kw), 64-channel chunk ld_cc); past the last
-    // chunk every lane's request is out of range and returns zeros without touching memory -- the steady-state loop stays
-    // branch-free, which keeps the compiler's vmcnt counts exact
-    int ld_c = 0, ld_kh = 0, ld_kw = 0, ld_cc = 0;
+    // loader state (uniform): the chunk the next DW_LOAD_A fetches = blocks ld_b, ld_b + 1 of 32 channels, block = (tap (ld_kh,
+    // ld_kw), 32-channel block ld_cb of the tap).  Lanes c8 < 4 gather the first block, lanes c8 >= 4 the second (which may
+    // belong to the next tap when a tap has an odd number of blocks): tap offset, tap coordinates and "past the end" are
+    // per-half values selected per lane.  Past the last chunk every lane's request is out of range and returns zeros without
+    // touching memory -- the steady-state loop stays branch-free, which keeps the compiler's vmcnt counts exact.
+    int ld_b = 0, ld_kh = 0, ld_kw = 0, ld_cb = 0;
+    const bool half1 = c8 >= 4;
 #define DW_LOAD_A(R)                                                                                       \
     do {                                                                                                   \
-        const int dy_ = ld_kh * a.dil, dx_ = ld_kw * a.dil;                                                \
-        const unsigned toff_ = (unsigned)(((dy_ * a.in_w + dx_) * a.x_ld + ld_cc * kKC) * 2);              \
-        const bool dead_ = ld_c >= a.nch || (tail_dead && ld_cc == a.cpt - 1);                             \
-        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                                 \
-            unsigned vo_;                                                                                  \
-            if (plain) vo_ = dead_ ? 0xffffffffu : a_base[i];                                              \
-            else {                                                                                         \
+        /* second block of the chunk */                                                                    \
+        int kh1_ = ld_kh, kw1_ = ld_kw, cb1_ = ld_cb + 1;                                                  \
+        if (cb1_ == a.bpt) { cb1_ = 0; if (++kw1_ == a.kw) { kw1_ = 0; ++kh1_; } }                         \
+        const int dy0_ = ld_kh * a.dil, dx0_ = ld_kw * a.dil, dy1_ = kh1_ * a.dil, dx1_ = kw1_ * a.dil;    \
+        const bool dead0_ = ld_b >= a.nblk, dead1_ = ld_b + 1 >= a.nblk;                                   \
+        if (plain) {                                                                                       \
+            const bool dead_ = half1 ? dead1_ : dead0_;                                                    \
+            const int toff_ = ld_cb * 64;             /* one tap: the two blocks are consecutive channels */ \
+            _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                               \
+                R[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, dead_ ? 0xffffffffu : a_base[i], toff_, 0)); \
+        } else {                                                                                           \
+            /* a_base already holds the lane's channel offset c8 * 8 = 32 (c8 >> 2) + 8 (c8 & 3) */         \
+            const unsigned toff0_ = (unsigned)(((dy0_ * a.in_w + dx0_) * a.x_ld + ld_cb * 32) * 2);        \
+            const unsigned toff1_ = (unsigned)(((dy1_ * a.in_w + dx1_) * a.x_ld + cb1_ * 32 - 32) * 2);    \
+            const unsigned toff_ = half1 ? toff1_ : toff0_;                                                \
+            const int dy_ = half1 ? dy1_ : dy0_, dx_ = half1 ? dx1_ : dx0_;                                \
+            const bool dead_ = half1 ? dead1_ : dead0_;                                                    \
+            _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                             \
                 const bool in_ = (unsigned)(a_ih0[i] + dy_) < (unsigned)a.in_h && (unsigned)(a_iw0[i] + dx_) < (unsigned)a.in_w; \
-                vo_ = (in_ && !dead_) ? a_base[i] + toff_ : 0xffffffffu;                                   \
+                const unsigned vo_ = (in_ && !dead_) ? a_base[i] + toff_ : 0xffffffffu;                    \
+                R[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo_, 0, 0)); \
             }                                                                                              \
-            R[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo_, plain ? (int)toff_ : 0, 0)); \
         }                                                                                                  \
-        ++ld_c;                                                                                            \
-        if (++ld_cc == a.cpt) {                                                                            \
-            ld_cc = 0;                                                                                     \
-            if (++ld_kw == a.kw) { ld_kw = 0; ++ld_kh; }                                                   \
-        }                                                                                                  \
+        /* advance by two blocks */                                                                        \
+        ld_b += 2;                                                                                         \
+        ld_kh = kh1_; ld_kw = kw1_; ld_cb = cb1_ + 1;                                                      \
+        if (ld_cb == a.bpt) { ld_cb = 0; if (++ld_kw == a.kw) { ld_kw = 0; ++ld_kh; } }                    \
     } while (0)
 #define DW_STORE_A(BUF)                                                                                    \
     do {                                                                                                   \
@@ -392,13 +404,13 @@ int launch_dw(const DwArgs &a0, hipStream_t st) {
 
 extern "C" size_t sgv3d_conv_dw_bf16_weight_bytes(int cout, int cin, int kh, int kw) {
     if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return 0;
-    return (size_t)cdiv(cout, 64) * 2 * ((size_t)kh * kw * cdiv(cin, kKC) * 4) * kFragB;
+    return (size_t)cdiv(cout, 64) * 2 * ((size_t)cdiv((long long)kh * kw * cdiv(cin, 32), 2) * 4) * kFragB;
 }
 
 extern "C" int sgv3d_conv_dw_bf16_pack_weight(const float *w, int cout, int cin_w, int cin, int kh, int kw, void *w_packed, void *stream) {
     SGV3D_REQUIRE(w && w_packed && cout > 0 && cin_w > 0 && cin >= cin_w && kh > 0 && kw > 0, "conv_dw_bf16_pack_weight: bad argument");
-    const int cpt = cdiv(cin, kKC);
-    hipLaunchKernelGGL(dw_pack_kernel, dim3(cdiv(cout, 64) * 2 * kh * kw * cpt * 4), dim3(64), 0, as_stream(stream), w, cout, cin_w, kh * kw, cpt,
+    const int bpt = cdiv(cin, 32), ksteps = cdiv((long long)kh * kw * bpt, 2) * 4;
+    hipLaunchKernelGGL(dw_pack_kernel, dim3(cdiv(cout, 64) * 2 * ksteps), dim3(64), 0, as_stream(stream), w, cout, cin_w, kh * kw, bpt, ksteps,
                        static_cast<__bf16 *>(w_packed));
     return check_launch("dw_pack_kernel");
 }
@@ -444,8 +456,9 @@ extern "C" int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *d, const void *
     a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w;
     a.m_h = deconv ? d->in_h : d->out_h; a.m_w = deconv ? d->in_w : d->out_w;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
-    a.cpt = cdiv(d->cin, kKC);
-    a.nch = d->kh * d->kw * a.cpt;
+    a.bpt = d->cin / 32;
+    a.nblk = d->kh * d->kw * a.bpt;
+    a.nch = cdiv(a.nblk, 2);
     a.ksteps = a.nch * 4;
     a.tiles_m = a.tiles_n = 0;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.res_bytes = residual ? (unsigned)(M * d->res_ld * 2) : 0u;
