@@ -75,6 +75,16 @@ def _wgrad_choice(lib, d, x, dy):
             sp = int(max(1, min(base * f, pixels // 128)))
             if (t, sp) not in cands:
                 cands.append((t, sp))
+    if (d.kh == 3 and d.kw == 3 and d.stride == 1 and d.dil == 1 and d.cin % 4 == 0 and d.cout % 4 == 0 and d.x_coff % 4 == 0
+            and d.y_coff % 4 == 0 and d.x_ld % 4 == 0 and d.y_ld % 4 == 0):
+        # the all-taps kernel (tile 5): work units = (image, output row, 32-pixel segment); the rule's split and neighbours
+        units = d.batch * d.out_h * -(-d.out_w // 32)
+        t2 = -(-d.cout // 64) * -(-d.cin // 64)
+        base = max(1, min(-(-512 // t2), units // 4))
+        for f in (0.5, 1, 2, 4):
+            sp = int(max(1, min(base * f, units)))
+            if (5, sp) not in cands:
+                cands.append((5, sp))
     dw = torch.empty(d.cout, d.cin, d.kh, d.kw, dtype=torch.float32, device=x.device)
     best, best_t = (0, 0), None
     with torch.cuda.device(x.device):

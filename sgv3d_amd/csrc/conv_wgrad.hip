@@ -188,6 +188,126 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / dilation 1: ALL NINE TAPS in one workgroup (tile id 5).  The per-tap kernel above makes nine workgroups
+// load the same dY tile and nine shifted copies of the same X rows, and pays its staging address arithmetic (vector
+// instructions = fp32 MFMA time on this chip) once per 32 MFMAs of a wave.  Here a stage is a SEGMENT OF ONE OUTPUT ROW (32
+// pixels): dY [32][64 co] and the three input rows it touches, X [3][34][64 ci], go to LDS once and feed the nine taps'
+// accumulators -- a wave owns a 32 co x 32 ci quadrant of the 64 x 64 tile for all taps (9 x 16 accumulator registers), a
+// k-step is 1 dY fragment + 9 X fragments (the tap is an LDS address offset) + 9 MFMAs, a stage 144 MFMAs per wave against
+// ~40 vector instructions of staging (row / column validity is per stage: two scalars per row, one compare per column).
+// Work units = (image, output row, segment) split over blockIdx.y; partial tiles go to the workspace in the per-tap kernel's
+// layout [split][tap][co][ci] and wgrad_reduce_kernel adds them in split order.
+constexpr int kSeg = 32;                      // output pixels per stage
+constexpr int kXCols = kSeg + 2;              // input columns per stage
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float sY[2][kSeg][64];
+    __shared__ __attribute__((aligned(16))) float sX[2][3][kXCols][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
+    const int tci = blockIdx.x % a.tiles_ci, tco = blockIdx.x / a.tiles_ci;
+    const int co0 = tco * 64, ci0 = tci * 64;
+    const int segs = (a.out_w + kSeg - 1) / kSeg;
+    const int units = a.batch * a.out_h * segs;
+    const int u_begin = (int)((long long)units * blockIdx.y / a.split), u_end = (int)((long long)units * (blockIdx.y + 1) / a.split);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)a.y_bytes, 0x00020000);
+    // staging slots: a thread moves float4s.  dY: 32 pixels x 16 float4 = 2 per thread; X: 3 rows x 34 columns x 16 float4 =
+    // 1632 = 6.4 per thread (7 passes, the last one partly idle).  Row / column / channel of a slot never change.
+    const int c4 = (tid & 15) * 4;
+    constexpr int XP = (3 * kXCols * 16 + 255) / 256;
+    int x_row[XP], x_col[XP];
+    unsigned x_off[XP];                            // byte offset relative to the unit's base pixel (row 0, column 0 of the patch)
+    bool x_any[XP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        const int slot = (tid >> 4) + 16 * i;     // (row, column) index, 0 .. 3 * 34 - 1
+        x_any[i] = slot < 3 * kXCols;
+        x_row[i] = slot / kXCols;
+        x_col[i] = slot - x_row[i] * kXCols;
+        x_off[i] = (unsigned)((x_row[i] * a.in_w + x_col[i]) * a.x_ld * 4 + (a.x_coff + ci0 + c4) * 4);
+    }
+    const bool ci_ok = ci0 + c4 < a.cin, co_ok = co0 + c4 < a.cout;     // (channel tails: whole float4s, cin / cout % 4 == 0)
+    const int y_p0 = tid >> 4;                     // dY pixels y_p0, y_p0 + 16
+    f32x4n rx[XP], ry[2];
+    auto load_unit = [&](int u) {
+        const int seg = u % segs, t = u / segs;
+        const int oy = t % a.out_h, img = t / a.out_h;
+        const int ox0 = seg * kSeg;
+        const int iy0 = oy - a.pad, ix0 = ox0 - a.pad;                     // top-left input pixel of the patch
+        const long long base = ((long long)(img * a.in_h + iy0) * a.in_w + ix0) * a.x_ld * 4;   // may be negative: wraps, only used when valid
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const bool ok = x_any[i] && ci_ok && u < u_end && (unsigned)(iy0 + x_row[i]) < (unsigned)a.in_h &&
+                            (unsigned)(ix0 + x_col[i]) < (unsigned)a.in_w;
+            rx[i] = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? (unsigned)base + x_off[i] : 0xffffffffu, 0, 0));
+        }
+        const unsigned ybase = (unsigned)(((long long)(img * a.out_h + oy) * a.out_w + ox0) * a.y_ld * 4 + (a.y_coff + co0 + c4) * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = y_p0 + 16 * i;
+            const bool ok = co_ok && u < u_end && ox0 + p < a.out_w;
+            ry[i] = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, ok ? ybase + (unsigned)(p * a.y_ld * 4) : 0xffffffffu, 0, 0));
+        }
+    };
+    auto store_unit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XP; ++i)
+            if (x_any[i]) *reinterpret_cast<f32x4n *>(&sX[buf][x_row[i]][x_col[i]][c4]) = rx[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4n *>(&sY[buf][y_p0 + 16 * i][c4]) = ry[i];
+    };
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    auto compute = [&](int buf) {
+        const float *py = &sY[buf][half][wm * 32 + l32];
+        const float *px = &sX[buf][0][half][wn * 32 + l32];
+        float fa[2], fb[2][9];
+        auto read_step = [&](int j, int set) {
+            fa[set] = py[j * 2 * 64];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) fb[set][t] = px[((t / 3) * kXCols + j * 2 + (t % 3)) * 64];
+        };
+        read_step(0, 0);
+#pragma unroll
+        for (int j = 0; j < kSeg / 2; ++j) {
+            if (j + 1 < kSeg / 2) read_step(j + 1, (j + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1], fb[j & 1][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (u_begin < u_end) {
+        load_unit(u_begin);
+        store_unit(0);
+        __syncthreads();
+        for (int u = u_begin; u < u_end; ++u) {
+            const int buf = (u - u_begin) & 1;
+            load_unit(u + 1);                          // (past the end: every request out of range)
+            compute(buf);
+            store_unit(buf ^ 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ci = ci0 + wn * 32 + l32;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + wm * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
+            if (co >= a.cout || ci >= a.cin) continue;
+            if (a.split > 1)
+                a.ws[(((size_t)blockIdx.y * 9 + t) * a.cout + co) * a.cin + ci] = acc[t][e];
+            else
+                a.dw[((size_t)co * a.cin + ci) * 9 + t] = acc[t][e];
+        }
+    }
+}
+
 // i = (tap, co, ci) with ci fastest: coalesced partial reads, split order fixed.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
     const long long total = (long long)a.taps * a.cout * a.cin;
@@ -264,9 +384,15 @@ int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a, int tile_overri
             const double cost = (double)cdiv(d->cout, 64 * wm) * (64 * wm) * cdiv(d->cin, 64 * wn) * (64 * wn) / eff;
             if (best == 0 || cost < best) { best = cost; a.wm = wm; a.wn = wn; }
         }
-    if (tile_override > 0) { a.wm = ((tile_override - 1) >> 1) ? 2 : 1; a.wn = ((tile_override - 1) & 1) ? 2 : 1; }
+    const bool all_taps = tile_override == 5;     // conv_wgrad3x3_kernel: all nine taps of a 64 x 64 tile in one workgroup
+    if (all_taps) {
+        SGV3D_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->cin % 4 == 0 && d->cout % 4 == 0 && d->x_coff % 4 == 0 &&
+                          d->y_coff % 4 == 0 && d->x_ld % 4 == 0 && d->y_ld % 4 == 0,
+                      "conv2d_backward_weight: tile 5 covers 3x3 / stride 1 / dilation 1 layers with channel counts and offsets that are multiples of 4");
+        a.wm = a.wn = 1;
+    } else if (tile_override > 0) { a.wm = ((tile_override - 1) >> 1) ? 2 : 1; a.wn = ((tile_override - 1) & 1) ? 2 : 1; }
     a.taps = d->kh * d->kw;
-    a.tap_cols = (d->cin <= 4 && d->x_ld == 4 && d->x_coff == 0 && a.taps > 1) ? 1 : 0;   // the 3-channel image stem
+    a.tap_cols = (!all_taps && d->cin <= 4 && d->x_ld == 4 && d->x_coff == 0 && a.taps > 1) ? 1 : 0;   // the 3-channel image stem
     if (a.tap_cols) a.wn = 1;
     const int stage_pix = 8192 / (64 * a.wm + 64 * a.wn) >= 64 ? 64 : 32;
     a.tiles_co = cdiv(d->cout, 64 * a.wm);
@@ -283,10 +409,25 @@ int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a, int tile_overri
         const int cap = stages / 4 > 0 ? stages / 4 : 1;
         split = split > cap ? cap : split;
     }
-    split = split > stages ? stages : split;
-    split = split > 65535 ? 65535 : split;
-    a.pix_per_split = cdiv(stages, split) * stage_pix;
-    a.split = cdiv(pix, a.pix_per_split);
+    if (all_taps) {     // work units = (image, output row, 32-pixel segment); a workgroup per (co tile, ci tile, unit range)
+        const long long units = (long long)d->batch * d->out_h * cdiv(d->out_w, 32);
+        const long long t2 = (long long)a.tiles_co * a.tiles_ci;
+        if (split <= 0) {
+            split = (int)((512 + t2 - 1) / t2);         // ~2 workgroups per CU in total
+            const long long cap = units / 4 > 0 ? units / 4 : 1;
+            split = split > cap ? (int)cap : split;
+        }
+        split = split < 1 ? 1 : split;
+        split = split > units ? (int)units : split;
+        split = split > 65535 ? 65535 : split;
+        a.pix_per_split = 0;
+        a.split = split;
+    } else {
+        split = split > stages ? stages : split;
+        split = split > 65535 ? 65535 : split;
+        a.pix_per_split = cdiv(stages, split) * stage_pix;
+        a.split = cdiv(pix, a.pix_per_split);
+    }
     const unsigned long long xb = (unsigned long long)d->batch * d->in_h * d->in_w * d->x_ld * 4ull;
     const unsigned long long yb = (unsigned long long)pix * d->y_ld * 4ull;
     SGV3D_REQUIRE(xb < 0xf0000000ull && yb < 0xf0000000ull, "conv2d_backward_weight: x / dy must be smaller than 3.75 GiB");
@@ -314,7 +455,8 @@ extern "C" int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *d, const floa
     a.x = x; a.dy = dy; a.dw = dw; a.ws = static_cast<float *>(workspace);
     hipStream_t st = as_stream(stream);
     const dim3 grid(a.tiles_co * a.tiles_ci * (a.tap_cols ? 1 : a.taps), a.split);
-    if (a.wm == 2 && a.wn == 2) conv_wgrad_kernel<2, 2><<<grid, 256, 0, st>>>(a);
+    if (d->tile == 5) conv_wgrad3x3_kernel<<<dim3(a.tiles_co * a.tiles_ci, a.split), 256, 0, st>>>(a);
+    else if (a.wm == 2 && a.wn == 2) conv_wgrad_kernel<2, 2><<<grid, 256, 0, st>>>(a);
     else if (a.wm == 2) conv_wgrad_kernel<2, 1><<<grid, 256, 0, st>>>(a);
     else if (a.wn == 2) conv_wgrad_kernel<1, 2><<<grid, 256, 0, st>>>(a);
     else conv_wgrad_kernel<1, 1><<<grid, 256, 0, st>>>(a);

@@ -73,6 +73,42 @@ def test_wgrad_split_variants_and_channel_windows(split):
     assert torch.equal(dw, again)                            # fixed-order reduction
 
 
+@pytest.mark.parametrize("shape", [
+    # B, cin, H, W, cout, pad
+    (2, 64, 20, 28, 64, 1),          # one tile, rows shorter than a 32-pixel segment
+    (1, 128, 9, 70, 192, 1),         # several tiles, rows of two full segments + a 6-pixel tail
+    (3, 80, 16, 33, 160, 1),         # channel counts that are not multiples of 64, a 1-pixel tail segment
+    (1, 64, 12, 40, 64, 0),          # no padding: the output is smaller than the input
+    (2, 32, 7, 96, 36, 2),           # padding 2: two border rows / columns of zeros
+    (1, 512, 6, 8, 512, 1),          # many tiles on a tiny map
+])
+@pytest.mark.parametrize("split", [0, 1, 3])
+def test_wgrad_all_taps_kernel(shape, split):
+    """Tile id 5 (conv_wgrad3x3_kernel: the nine taps of a 64 x 64 tile in one workgroup, stages = row segments) against
+    float64 autograd; bitwise repeatable; exact on small integers."""
+    B, cin, H, W, cout, pad = shape
+    g = torch.Generator().manual_seed(sum(shape) + split)
+    x = torch.randn(B, H, W, cin + 8, generator=g)
+    oh, ow = H + 2 * pad - 2, W + 2 * pad - 2
+    dy = torch.randn(B, oh, ow, cout + 4, generator=g)
+    _, _, dw_ref = _reference(x[..., 4:4 + cin], torch.zeros(cout, cin, 3, 3), dy[..., 4:], 1, pad, 1)
+    dw = conv_grad.conv2d_backward_weight(x.cuda(), dy.cuda(), 3, 1, pad, 1, cin=cin, cout=cout, x_coff=4, y_coff=4, split=split, tile=5)
+    assert float((dw.cpu().double() - dw_ref).abs().max()) <= 2e-5 * float(dw_ref.abs().max())
+    again = conv_grad.conv2d_backward_weight(x.cuda(), dy.cuda(), 3, 1, pad, 1, cin=cin, cout=cout, x_coff=4, y_coff=4, split=split, tile=5)
+    assert torch.equal(dw, again)
+    xi = torch.randint(-3, 4, (B, H, W, cin), generator=g).float()
+    dyi = torch.randint(-2, 3, (B, oh, ow, cout), generator=g).float()
+    _, _, want = _reference(xi, torch.zeros(cout, cin, 3, 3), dyi, 1, pad, 1)
+    assert torch.equal(conv_grad.conv2d_backward_weight(xi.cuda(), dyi.cuda(), 3, 1, pad, 1, split=split, tile=5).cpu().double(), want)
+
+
+def test_wgrad_all_taps_kernel_rejects_other_layers():
+    from sgv3d_amd import _lib
+    x, dy = torch.randn(1, 8, 8, 64).cuda(), torch.randn(1, 4, 4, 64).cuda()
+    with pytest.raises(_lib.SGV3DError):
+        conv_grad.conv2d_backward_weight(x, dy, 3, 2, 1, 1, tile=5, split=1)          # stride 2
+
+
 def test_wgrad_is_exact_on_small_integers():
     g = torch.Generator().manual_seed(5)
     x = torch.randint(-3, 4, (2, 30, 34, 64), generator=g).float()
