@@ -520,6 +520,16 @@ int sgv3d_conv_dw_bf16_pack_weight(const float *w, int cout, int cin_w, int cin,
 int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *desc /*host*/, const void *x, const void *w_packed, const float *scale,
                                const float *bias, const void *residual, void *y, void *stream);
 
+/* Two layers in one launch (conv_dw_bf16_pair_kernel): conv A = desc (k x k, any stride / dilation, cout == 256, folded BN + ReLU per
+ * desc.relu) followed by conv B = 1x1 over those 256 channels with cout2 % 256 == 0 outputs, folded BN, residual and ReLU -- conv2 +
+ * conv3 of a ResNet layer-3 bottleneck (mmdet Bottleneck behind layers/backbones/lss_fpn.py:296-301; 23 of them in ResNet-101).  The
+ * 256-channel map between the layers stays in LDS.  w_packed = ..._pack_weight(w A), w2_packed = ..._pack_weight(w B as [cout2, 256,
+ * 1, 1]); x / y / residual bf16 NHWC; y [batch, out_h, out_w, y_ld] at channel y_coff.  Results: bitwise those of
+ * sgv3d_conv_dw_bf16_forward called twice (the middle map rounded to bf16 once). */
+int sgv3d_conv_dw_bf16_pair_forward(const sgv3d_conv_desc *desc /*host*/, const void *x, const void *w_packed, const float *scale,
+                                    const float *bias, int cout2, const void *w2_packed, const float *scale2, const float *bias2,
+                                    const void *residual, int res_ld, void *y, int y_ld, int y_coff, int relu2, void *stream);
+
 /* ================================================================================================
  * Box decode + circle NMS  
  * ================================================================================================ */

@@ -56,6 +56,11 @@ struct DwArgs {
     int tiles_m, tiles_n;
     int bpt, nblk, nch, ksteps;   // 32-channel blocks per tap = cin / 32, nblk = kh kw bpt, nch = ceil(nblk / 2) chunks of 64 k, ksteps = 4 nch
     unsigned x_bytes, w_bytes, res_bytes, y_bytes;
+    // conv_dw_bf16_pair_kernel only: the 1x1 convolution that follows (K2 = N channels of the first one, N2 outputs)
+    const void *w2;            // packed fragments of the second layer
+    const float *scale2, *bias2;
+    int N2, relu2, ksteps2;
+    unsigned w2_bytes;
 };
 
 // weights: OIHW f32 [cout][cin_w][kh][kw] -> [n-tile of 32][k-step of 16][lane][8] bf16; lane l holds channel 32 nt + (l & 31),
@@ -299,14 +304,6 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
         }
         DW_SB();
     }
-#undef DW_SB
-#undef DW_LOAD_A
-#undef DW_STORE_A
-#undef DW_LOAD_W
-#undef DW_FETCH_RES
-#undef DW_MFMA_STEP
-#undef DW_MFMA
-#undef DW_READ_A
 
     // epilogue.  acc[mt][nt][4 g + i] = C[pixel m0 + wm WROWS + 32 mt + lr][channel n0 + wn 64 + 32 nt + 8 g + 4 lh + i].
     // The loop ended on a barrier: the activation buffers are dead, each wave stages its tiles in its own 32 x 36 f32 slice.
@@ -384,6 +381,257 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// TWO LAYERS IN ONE KERNEL: a k x k convolution with 256 outputs (folded BN, ReLU) followed by a 1x1 convolution over those 256
+// channels with residual and ReLU -- conv2 + conv3 of a ResNet layer-3 bottleneck (23 of them in ResNet-101).  Phase 1 is the
+// 64 x 256 tile of the kernel above; instead of storing its tile it rounds it to bf16 into LDS in the layout the fragment reads
+// expect (the wave that owns channels 64 w .. 64 w + 63 writes k-chunk w of the second GEMM: 64 pixels x 128 B, same swizzle),
+// and after ONE barrier every wave runs the second GEMM on its own: K2 = 256 from that tile, N2 in chunks of 256 columns
+// (64 per wave), the second layer's weights again streamed from L2 in fragment order, the residual rows of a chunk requested
+// during its last k-chunk, the common epilogue per chunk.  The 256-channel map between the two layers never exists in HBM
+// (17 + 17 MB per layer at cfg-3), the second layer has no activation loads, and one launch replaces two.
+// Same arithmetic as the two launches (f32 accumulation in the same k order, the middle map rounded to bf16 once): bitwise the
+// result of sgv3d_conv_dw_bf16_forward twice.
+__global__ __launch_bounds__(256, 3) void conv_dw_bf16_pair_kernel(const DwArgs a) {
+    constexpr int WM = 1, WN = 4, MT = 2;
+    constexpr int WROWS = 32 * MT, BM = WROWS * WM;
+    constexpr int A_LD = BM / 32;
+    constexpr int kBufB = BM * kRowB;
+    constexpr int kRegion0 = 4 * 32 * kStageLd * 4;          // 18 432 B: activation buffers (2 x 8 KB) in phase 1, epilogue stage in phase 2
+    constexpr bool kPrefetchA = false;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const mid = smem + kRegion0;                         // [4 k-chunks][64 pixels][128 B]: the first layer's tile as bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = 0;
+    const int wn = __builtin_amdgcn_readfirstlane(wave);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ntiles = a.tiles_m;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int tm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int m0 = tm * BM, n0 = 0;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.w_bytes, 0x00020000);
+    const int c8 = tid & 7, r0 = tid >> 3;
+    const bool plain = a.kh == 1 && a.kw == 1 && a.pad == 0;
+    unsigned a_base[A_LD];
+    int a_ih0[A_LD], a_iw0[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const int mm = m < a.M ? m : 0;
+        const int t = (int)((unsigned)mm / (unsigned)a.m_w), ow = mm - t * a.m_w;
+        const int img = (int)((unsigned)t / (unsigned)a.m_h), oh = t - img * a.m_h;
+        a_ih0[i] = m < a.M ? oh * a.stride - a.pad : -0x40000000;
+        a_iw0[i] = ow * a.stride - a.pad;
+        a_base[i] = (unsigned)((((long long)img * a.in_h + a_ih0[i]) * a.in_w + a_iw0[i]) * a.x_ld + a.x_coff + c8 * 8) * 2u;
+        if (plain) a_base[i] = m < a.M ? a_base[i] : 0xffffffffu;
+    }
+    const int st_slot = (c8 ^ ((r0 >> 1) & 7)) * 16;
+    char *const st_ptr = smem + r0 * kRowB + st_slot;
+    const int swz = (lr >> 1) & 7;
+    int rd_off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rd_off[s] = lr * kRowB + (((2 * s + lh) ^ swz) * 16);
+    const unsigned w_lane = lane * 16;
+    const int nt0 = wn * 2;
+    const int w_s0 = __builtin_amdgcn_readfirstlane(nt0 * a.ksteps * kFragB);
+    const int w_s1 = __builtin_amdgcn_readfirstlane((nt0 + 1) * a.ksteps * kFragB);
+    u32x4 ra[A_LD];
+    bf16x8 wf[4][2];
+    bf16x8 fa[1][MT];
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+    int ld_b = 0, ld_kh = 0, ld_kw = 0, ld_cb = 0;
+    const bool half1 = c8 >= 4;
+    // ---- phase 1: the k x k layer (the loop of conv_dw_bf16_kernel<1, 4, 2>) -------------------------------------------------
+    {
+        u32x4 rp[A_LD];
+        DW_LOAD_A(rp);
+        DW_LOAD_A(ra);
+        DW_SB();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) DW_LOAD_W(0, s);
+        DW_SB();
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) *reinterpret_cast<u32x4 *>(st_ptr + i * 32 * kRowB) = rp[i];
+    }
+    DW_SB();
+    __syncthreads();
+    const int last = a.nch - 1;
+    for (int c = 0; c < last; ++c) {
+        const int buf = c & 1;
+        DW_STORE_A(buf ^ 1);
+        DW_SB();
+        DW_LOAD_A(ra);
+        DW_SB();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            DW_MFMA_STEP(buf, s);
+            DW_SB();
+            DW_LOAD_W(c + 1, s);
+            DW_SB();
+        }
+        __syncthreads();
+    }
+    // second layer's fragments: n-tiles (n2 * 8 + wn * 2, + 1), k-steps c * 4 + s of ksteps2 = 16
+    const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, (int)a.w2_bytes, 0x00020000);
+    const int nch2 = a.N2 >> 8;                              // chunks of 256 output columns
+#define PAIR_LOAD_W2(N2I, C, S, LIVE)                                                                     \
+    do {                                                                                                   \
+        const int b0_ = (((N2I) * 8 + nt0) * a.ksteps2 + (C) * 4 + (S)) * kFragB;                          \
+        const unsigned vl_ = (LIVE) ? w_lane : 0xffffffffu;                                                \
+        wf[S][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2_rsrc, vl_, b0_, 0)); \
+        wf[S][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2_rsrc, vl_, b0_ + a.ksteps2 * kFragB, 0)); \
+    } while (0)
+    {
+        const int buf = last & 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            DW_MFMA_STEP(buf, s);
+            DW_SB();
+            PAIR_LOAD_W2(0, 0, s, true);                    // the second GEMM's first fragments, under the first one's tail
+            DW_SB();
+        }
+    }
+    // ---- the first layer's tile -> LDS as bf16 (folded BN, ReLU), k-chunk wn of the second GEMM --------------------------------
+    {
+        const unsigned floor1 = a.relu ? 0u : 0x80008000u;
+        char *const mw = mid + wn * (64 * kRowB);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = wn * 64 + nt * 32 + 8 * g + 4 * lh;
+                const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + ch) : one;
+                const f32x4 sh = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + ch) : zero;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                    v = v * sc + sh;
+                    union { bf16x4 b; unsigned u[2]; } pk;
+                    pk.b = __builtin_convertvector(v, bf16x4);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        unsigned d_;
+                        asm("v_pk_max_i16 %0, %1, %2" : "=v"(d_) : "v"(pk.u[i]), "v"(floor1));
+                        pk.u[i] = d_;
+                    }
+                    const int row = mt * 32 + lr;
+                    *reinterpret_cast<unsigned long long *>(mw + row * kRowB + (((nt * 4 + g) ^ swz) * 16) + lh * 8) =
+                        (unsigned long long)pk.u[0] | ((unsigned long long)pk.u[1] << 32);
+                }
+            }
+    }
+    __syncthreads();               // the tile is complete; the activation buffers (= the epilogue stage) are dead
+    // ---- phase 2: the 1x1 layer, every wave on its own ------------------------------------------------------------------------
+    const int pc = lane & 3, pp = lane >> 2;
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.res, 0, a.res ? (int)a.res_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, 0x00020000);
+    float *const stage = reinterpret_cast<float *>(smem) + wave * (32 * kStageLd);
+    const unsigned floor2 = a.relu2 ? 0u : 0x80008000u;
+    const int prow0 = m0;
+    unsigned yrow[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int row = prow0 + mt * 32 + pp + 16 * ps;
+            yrow[mt][ps] = row < a.M ? (unsigned)row * (unsigned)(a.y_ld * 2) : 0xffffffffu;
+        }
+    for (int n2 = 0; n2 < nch2; ++n2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+        const int pcol0 = n2 * 256 + wn * 64;
+        bf16x8 resq[MT][2][2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    fa[0][mt] = *reinterpret_cast<const bf16x8 *>(mid + c * (64 * kRowB) + rd_off[s] + mt * 32 * kRowB);
+                DW_MFMA(fa[0], s);
+                DW_SB();
+                if (c < 3) PAIR_LOAD_W2(n2, c + 1, s, true);
+                else PAIR_LOAD_W2(n2 + 1, 0, s, n2 + 1 < nch2);
+                if (c == 3) {                                  // the residual rows of this chunk, under its last k-chunk
+                    const int row = prow0 + (s >> 1) * 32 + pp + 16 * (s & 1);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int ch = pcol0 + nt * 32 + 8 * pc;
+                        const unsigned ro = (row < a.M && ch < a.N2) ? ((unsigned)row * (unsigned)a.res_ld + ch) * 2u : 0xffffffffu;
+                        resq[s >> 1][nt][s & 1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, ro, 0, 0));
+                    }
+                }
+                DW_SB();
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int ch = pcol0 + nt * 32 + 8 * pc;
+            const bool ch_ok = ch < a.N2;
+            const unsigned ycol = (unsigned)(a.y_coff + ch) * 2u;
+            const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+            f32x4 sc0 = one, sc1 = one, sh0 = zero, sh1 = zero;
+            if (ch_ok && a.scale2) { sc0 = *reinterpret_cast<const f32x4 *>(a.scale2 + ch); sc1 = *reinterpret_cast<const f32x4 *>(a.scale2 + ch + 4); }
+            if (ch_ok && a.bias2) { sh0 = *reinterpret_cast<const f32x4 *>(a.bias2 + ch); sh1 = *reinterpret_cast<const f32x4 *>(a.bias2 + ch + 4); }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                    *reinterpret_cast<f32x4 *>(stage + lr * kStageLd + 8 * g + 4 * lh) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int p = pp + 16 * ps;
+                    f32x4 v0 = *reinterpret_cast<const f32x4 *>(stage + p * kStageLd + 8 * pc);
+                    f32x4 v1 = *reinterpret_cast<const f32x4 *>(stage + p * kStageLd + 8 * pc + 4);
+                    v0 = v0 * sc0 + sh0;
+                    v1 = v1 * sc1 + sh1;
+                    const bf16x8 rq = resq[mt][nt][ps];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v0[i] += (float)rq[i]; v1[i] += (float)rq[4 + i]; }
+                    const bf16x4 o0 = __builtin_convertvector(v0, bf16x4), o1 = __builtin_convertvector(v1, bf16x4);
+                    u32x4 o = __builtin_bit_cast(u32x4, __builtin_shufflevector(o0, o1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        unsigned d_;
+                        asm("v_pk_max_i16 %0, %1, %2" : "=v"(d_) : "v"(o[i]), "v"(floor2));
+                        o[i] = d_;
+                    }
+                    const unsigned yo = (yrow[mt][ps] != 0xffffffffu && ch_ok) ? yrow[mt][ps] + ycol : 0xffffffffu;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, y_rsrc, yo, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+#undef PAIR_LOAD_W2
+}
+
+#undef DW_SB
+#undef DW_LOAD_A
+#undef DW_STORE_A
+#undef DW_LOAD_W
+#undef DW_FETCH_RES
+#undef DW_MFMA_STEP
+#undef DW_MFMA
+#undef DW_READ_A
 
 template <int WM, int WN, int MT>
 int launch_dw(const DwArgs &a0, hipStream_t st) {
@@ -472,4 +720,57 @@ extern "C" int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *d, const void *
         case SGV3D_TILE_DW_256x128: return launch_dw<2, 2, 4>(a, st);
         default: return fail(SGV3D_EINVAL, "conv_dw_bf16: desc.tile must be one of SGV3D_TILE_DW_* (got %d)", d->tile);
     }
+}
+
+// conv A (k x k, 256 outputs, folded BN + ReLU as desc says) followed by conv B (1x1 over those 256 channels, cout2 outputs,
+// folded BN, residual, ReLU) in one launch (conv_dw_bf16_pair_kernel).
+extern "C" int sgv3d_conv_dw_bf16_pair_forward(const sgv3d_conv_desc *d, const void *x, const void *w_packed, const float *scale,
+                                               const float *bias, int cout2, const void *w2_packed, const float *scale2,
+                                               const float *bias2, const void *residual, int res_ld, void *y, int y_ld, int y_coff,
+                                               int relu2, void *stream) {
+    SGV3D_REQUIRE(d && x && w_packed && w2_packed && y, "conv_dw_bf16_pair: null pointer");
+    SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL && d->split_k <= 1, "conv_dw_bf16_pair: NORMAL mode without split-K only");
+    SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0,
+                  "conv_dw_bf16_pair: non-positive dimension");
+    SGV3D_REQUIRE(d->cout == 256 && cout2 > 0 && cout2 % 256 == 0, "conv_dw_bf16_pair: the first layer must have 256 outputs, the second a multiple of 256 (got %d / %d)",
+                  d->cout, cout2);
+    const int eh = (d->in_h + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+    const int ew = (d->in_w + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+    SGV3D_REQUIRE(eh == d->out_h && ew == d->out_w, "conv_dw_bf16_pair: output %dx%d does not match the conv arithmetic %dx%d", d->out_h, d->out_w, eh, ew);
+    SGV3D_REQUIRE(d->cin % 32 == 0 && d->x_ld >= d->x_coff + d->cin && y_ld >= y_coff + cout2 && (residual == nullptr || res_ld >= cout2),
+                  "conv_dw_bf16_pair: cin %% 32, channel strides");
+    SGV3D_REQUIRE(d->x_ld % 8 == 0 && d->x_coff % 8 == 0 && y_ld % 8 == 0 && y_coff % 8 == 0 && (residual == nullptr || res_ld % 8 == 0),
+                  "conv_dw_bf16_pair: channel strides / offsets must be multiples of 8 (16-byte rows of bf16)");
+    SGV3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
+                    reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(w2_packed) | reinterpret_cast<uintptr_t>(scale) |
+                    reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(scale2) | reinterpret_cast<uintptr_t>(bias2)) & 15) == 0,
+                  "conv_dw_bf16_pair: pointers must be 16-B aligned");
+    const long long M = (long long)d->batch * d->out_h * d->out_w;
+    const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * 2, yb = M * y_ld * 2;
+    const size_t wb = sgv3d_conv_dw_bf16_weight_bytes(256, d->cin, d->kh, d->kw), wb2 = sgv3d_conv_dw_bf16_weight_bytes(cout2, 256, 1, 1);
+    SGV3D_REQUIRE(M < 0x7fffffffLL && xb < 0xf0000000LL && yb < 0xf0000000LL && wb < 0xf0000000ULL && wb2 < 0xf0000000ULL &&
+                      (residual == nullptr || M * res_ld * 2 < 0xf0000000LL),
+                  "conv_dw_bf16_pair: operands larger than 3.75 GiB (32-bit buffer offsets)");
+    SGV3D_REQUIRE((long long)d->dil * (d->kh - 1) < 0x10000 && d->in_h < 0x10000000 && d->in_w < 0x10000000, "conv_dw_bf16_pair: kernel extent too large");
+    DwArgs a;
+    a.x = x; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
+    a.M = (int)M; a.N = 256; a.cin = d->cin;
+    a.ks = 0; a.cout = 256;
+    a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = y_ld; a.y_coff = y_coff; a.res_ld = res_ld; a.relu = d->relu;
+    a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w;
+    a.m_h = d->out_h; a.m_w = d->out_w;
+    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+    a.bpt = d->cin / 32;
+    a.nblk = d->kh * d->kw * a.bpt;
+    a.nch = cdiv(a.nblk, 2);
+    a.ksteps = a.nch * 4;
+    a.tiles_m = cdiv(M, 64); a.tiles_n = 1;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.res_bytes = residual ? (unsigned)(M * res_ld * 2) : 0u; a.y_bytes = (unsigned)yb;
+    a.w2 = w2_packed; a.scale2 = scale2; a.bias2 = bias2; a.N2 = cout2; a.relu2 = relu2; a.ksteps2 = 16; a.w2_bytes = (unsigned)wb2;
+    constexpr size_t lds = 4 * 32 * kStageLd * 4 + 4 * 64 * kRowB;
+    static PerDeviceSize lds_set;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_dw_bf16_pair_kernel), lds, lds_set))
+        return fail(SGV3D_ELAUNCH, "conv_dw_bf16_pair: cannot raise the dynamic LDS limit to %zu", lds);
+    hipLaunchKernelGGL(conv_dw_bf16_pair_kernel, dim3(a.tiles_m), dim3(256), lds, as_stream(stream), a);
+    return check_launch("conv_dw_bf16_pair_kernel");
 }

@@ -642,6 +642,63 @@ class PackedConv:
         return best
 
 
+PAIR_BF16 = _os.environ.get("SGV3D_PAIR_BF16", "1") != "0"   # 0: conv2 + conv3 of a bottleneck are always two launches
+
+
+def conv_pair_eligible(a, b, x, residual=None):
+    """conv ``a`` (k x k, 256 outputs, ReLU) followed by the 1x1 conv ``b`` (cout % 256 == 0) between bf16 NHWC tensors: the pair
+    the fused direct-weight kernel (sgv3d_conv_dw_bf16_pair_forward) covers."""
+    return (MFMA_BF16 and not MFMA_F32X3 and DW_BF16 and PAIR_BF16 and x.dtype == torch.bfloat16 and not a.transposed and not b.transposed
+            and a.cout == 256 and a.cin % 32 == 0 and int(x.shape[-1]) % 8 == 0 and b.cin == 256 and b.kh == 1 and b.kw == 1
+            and b.stride == 1 and b.pad == 0 and b.cout % 256 == 0 and (residual is None or residual.dtype == torch.bfloat16))
+
+
+def conv_pair_bf16(a, b, x, residual=None, out=None):
+    """``b(a(x), residual=residual)`` for two PackedConvs in one launch (bf16 tensors); the map between them stays in LDS."""
+    B, H, W, x_ld = (int(v) for v in x.shape)
+    oh, ow = a.out_hw(H, W)
+    if out is None:
+        out = torch.empty(B, oh, ow, b.cout, dtype=torch.bfloat16, device=x.device)
+    d = ConvDesc()
+    d.batch, d.in_h, d.in_w, d.cin = B, H, W, a.cin
+    d.out_h, d.out_w, d.cout = oh, ow, a.cout
+    d.kh, d.kw, d.stride, d.pad, d.dil = a.kh, a.kw, a.stride, a.pad, a.dil
+    d.x_ld, d.x_coff, d.y_ld, d.y_coff = x_ld, 0, a.cout, 0
+    d.relu, d.mode, d.split_k = (1 if a.relu else 0), CONV_NORMAL, 1
+    flops = 2.0 * B * oh * ow * (a.cout_real * a.cin_real * a.kh * a.kw + b.cout_real * b.cin_real)
+    name = "conv_dw_bf16_pair"
+    if PROFILE_DETAIL:
+        name += f"|{B}x{H}x{W}x{a.cin}->{a.cout} k{a.kh} s{a.stride} d{a.dil} ->{b.cout} k1"
+    with torch.cuda.device(x.device), prof(name, flops):
+        rc = _lib.load().sgv3d_conv_dw_bf16_pair_forward(
+            ctypes.byref(d), x.data_ptr(), a._dw_weights().data_ptr(), _lib.ptr(a.scale), _lib.ptr(a.shift), b.cout,
+            b._dw_weights().data_ptr(), _lib.ptr(b.scale), _lib.ptr(b.shift), _lib.ptr(residual),
+            int(residual.shape[-1]) if residual is not None else 0, out.data_ptr(), int(out.shape[-1]), 0, 1 if b.relu else 0, _st(x))
+    _lib.check(rc, "sgv3d_conv_dw_bf16_pair_forward")
+    return out
+
+
+def conv_pair_choice(a, b, x, residual=None):
+    """True when the fused launch is faster than ``b(a(x))`` with the per-layer choices: measured once per pair and input shape
+    under the load the pipeline runs (like the per-layer choices) and kept in the tune DB under a ``pair|`` signature."""
+    if not conv_pair_eligible(a, b, x, residual):
+        return False
+    B, H, W, _ = (int(v) for v in x.shape)
+    sig = (f"pair|{a.cout}x{a.cin}k{a.kh}x{a.kw}s{a.stride}p{a.pad}d{a.dil}->{b.cout}|{B}x{H}x{W}|r{int(residual is not None)}|bf16|ts{TUNE_STREAMS}")
+    if sig in TUNE_DB:
+        return bool(TUNE_DB[sig][0])
+    if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        return True
+    act = torch.bfloat16
+    two = lambda: b(a(x, out_dtype=act), residual=residual, out_dtype=act)
+    one = lambda: conv_pair_bf16(a, b, x, residual)
+    two(); one()
+    t2 = time_callable(two, x.device)
+    t1 = time_callable(one, x.device)
+    TUNE_DB[sig] = [1 if t1 < t2 else 0, 0]
+    return t1 < t2
+
+
 def time_callable(fn, device, rounds=None):
     """Milliseconds for TUNE_STREAMS concurrent copies of ``fn`` (``rounds`` calls back to back on every stream; one stream =
     isolated timing), best of TUNE_REPEATS -- how the per-layer candidates are timed, for whole sub-graphs (the CenterHead

@@ -126,8 +126,11 @@ class Bottleneck(HipModule):
     def hip_forward(self, x, act_dtype=None):
         s = self.hip_state(x.device)
         identity = s['ds'](x, out_dtype=act_dtype) if 'ds' in s else x
-        out = s['c2'](s['c1'](x, out_dtype=act_dtype), out_dtype=act_dtype)
-        return s['c3'](out, residual=identity, out_dtype=act_dtype)
+        out = s['c1'](x, out_dtype=act_dtype)
+        # bf16 configs, 256-channel bottlenecks (ResNet layer 3): conv2 + conv3 in one launch, the map between them in LDS
+        if act_dtype == torch.bfloat16 and hip_ops.conv_pair_choice(s['c2'], s['c3'], out, identity):
+            return hip_ops.conv_pair_bf16(s['c2'], s['c3'], out, identity)
+        return s['c3'](s['c2'](out, out_dtype=act_dtype), residual=identity, out_dtype=act_dtype)
 
 
 class ResNet(HipModule):

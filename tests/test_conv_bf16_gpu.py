@@ -439,6 +439,46 @@ def test_bf16_direct_weight_conv_kxk(bf16_mode, shape, tile):
     assert float((wide[..., :8] - 7).abs().max()) == 0 and float((wide[..., 8 + cout:] - 7).abs().max()) == 0
 
 
+@pytest.mark.parametrize("shape", [
+    # B, cin, H, W, k, stride, pad, dil, cout2, residual
+    (1, 256, 17, 30, 3, 1, 1, 1, 1024, True),       # ResNet layer-3 bottleneck: conv2 + conv3
+    (2, 256, 9, 13, 3, 1, 1, 1, 1024, True),        # ragged M (234 pixels), two images
+    (1, 256, 20, 22, 3, 2, 1, 1, 1024, True),       # the strided first block of the layer
+    (1, 96, 11, 10, 1, 1, 0, 1, 256, False),        # 1x1 first layer (plain gather), K % 64 == 32, a single output chunk
+    (1, 128, 12, 16, 3, 1, 2, 2, 512, False),       # dilated first layer, no residual
+])
+def test_bf16_direct_weight_conv_pair(bf16_mode, shape):
+    """sgv3d_conv_dw_bf16_pair_forward: conv A (k x k -> 256, BN, ReLU) + conv B (1x1 -> cout2, BN, residual, ReLU) in one launch
+    with the 256-channel map in LDS: bitwise the two direct-weight launches, and close to float64 on the bf16-rounded operands
+    (the middle map rounded to bf16 as both paths do)."""
+    B, cin, H, W, k, stride, pad, dil, cout2, with_res = shape
+    g = torch.Generator().manual_seed(cin + cout2 + k + stride)
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16()
+    wa = torch.randn(256, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    wb = torch.randn(cout2, 256, 1, 1, generator=g) / 16.0
+    sa, ha = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.3
+    sb, hb = torch.rand(cout2, generator=g) + 0.5, torch.randn(cout2, generator=g) * 0.3
+    ca = hip_ops.PackedConv(wa.to(DEV), stride=stride, pad=pad, dil=dil, scale=sa.to(DEV), shift=ha.to(DEV), relu=True)
+    cb = hip_ops.PackedConv(wb.to(DEV), scale=sb.to(DEV), shift=hb.to(DEV), relu=True)
+    oh, ow = ca.out_hw(H, W)
+    res = torch.randn(B, cout2, oh, ow, generator=g).bfloat16() if with_res else None
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rin = res.permute(0, 2, 3, 1).contiguous().to(DEV) if res is not None else None
+    assert hip_ops.conv_pair_eligible(ca, cb, xin, rin)
+    y = hip_ops.conv_pair_bf16(ca, cb, xin, rin)
+    mid = ca(xin, tile=31, split_k=1, out_dtype=torch.bfloat16)
+    want = cb(mid, residual=rin, tile=31, split_k=1, out_dtype=torch.bfloat16)
+    assert torch.equal(y, want)
+    m64 = F.conv2d(x.double(), wa.bfloat16().double(), None, stride, pad, dil)
+    m64 = (m64 * sa.double()[None, :, None, None] + ha.double()[None, :, None, None]).clamp_min(0).bfloat16().double()
+    ref = F.conv2d(m64, wb.bfloat16().double()) * sb.double()[None, :, None, None] + hb.double()[None, :, None, None]
+    if res is not None:
+        ref = ref + res.double()
+    ref = ref.clamp_min(0)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((y.float().permute(0, 3, 1, 2).cpu().double() - ref).abs().max()) <= 2.0 ** -6 * scale   # (+ rounding flips of the middle map)
+
+
 def test_bf16_direct_weight_conv_exact_on_small_integers(bf16_mode):
     g = torch.Generator().manual_seed(3)
     x = torch.randint(-3, 4, (2, 192, 12, 21), generator=g).float()
