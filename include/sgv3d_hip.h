@@ -611,6 +611,13 @@ int sgv3d_centerhead_loss(int batch, int num_class, int h, int w, int max_objs, 
 size_t sgv3d_conv2d_backward_weight_workspace_bytes(const sgv3d_conv_desc *desc /*host*/, int split);
 int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *dy, float *dw,
                                  int split, void *workspace, size_t workspace_bytes, void *stream);
+/* ... with 1 .. 4 output channels (3x3 / stride 1 / dilation 1, desc.y_ld <= 4: the final layers of the CenterHead branches,
+ * layers/heads/bev_height_head.py:75-110 through mmdet3d SeparateHead): a vector-ALU kernel (a lane per input channel, sliding 3x3
+ * window in registers, dY broadcast by v_readlane) instead of an MFMA tile that would be 97 % padding; per-wave partial sums in
+ * the workspace, added in wave order (deterministic). */
+size_t sgv3d_conv2d_backward_weight_thin_workspace_bytes(const sgv3d_conv_desc *desc /*host*/);
+int sgv3d_conv2d_backward_weight_thin(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *dy, float *dw, void *workspace,
+                                      size_t workspace_bytes, void *stream);
 
 /* y[b, oy, ox, :] = x[b, oy/stride, ox/stride, :] where both divide evenly (and stay inside x), else 0.
  * NHWC f32, channels % 4 == 0, out >= (in - 1) * stride + 1.  The data gradient of a strided convolution is a

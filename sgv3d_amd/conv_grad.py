@@ -40,13 +40,26 @@ def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, c
     d.x_ld, d.x_coff, d.y_ld, d.y_coff = x_ld, int(x_coff), y_ld, int(y_coff)
     d.tile = int(tile)
     lib = _lib.load()
+    if (not tile and not split and kh == 3 and kw == 3 and stride == 1 and dil == 1 and cout <= 4 and y_ld <= 4):
+        # 1..4 output channels (the final layers of the CenterHead branches): the vector-ALU kernel, not an MFMA tile of padding
+        nws = lib.sgv3d_conv2d_backward_weight_thin_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
+        dw = torch.empty(cout, cin, kh, kw, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device), prof("conv_wgrad_thin", 2.0 * B * OH * OW * cout * cin * kh * kw):
+            rc = lib.sgv3d_conv2d_backward_weight_thin(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nws, _st(x))
+        _lib.check(rc, "sgv3d_conv2d_backward_weight_thin")
+        return dw
     if not tile and not split:
         tile, split = _wgrad_choice(lib, d, x, dy)       # first-call measurement per layer shape (0, 0 = the library's rule)
         d.tile = int(tile)
     nws = lib.sgv3d_conv2d_backward_weight_workspace_bytes(ctypes.byref(d), int(split))
     ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
     dw = torch.empty(cout, cin, kh, kw, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device), prof("conv_wgrad", 2.0 * B * OH * OW * cout * cin * kh * kw):
+    from . import hip_ops
+    name = "conv_wgrad"
+    if hip_ops.PROFILE_DETAIL:
+        name += f"|{B}x{H}x{W}x{cin}->{cout} k{kh} s{stride} d{dil} tile{int(tile)} split{int(split)}"
+    with torch.cuda.device(x.device), prof(name, 2.0 * B * OH * OW * cout * cin * kh * kw):
         rc = lib.sgv3d_conv2d_backward_weight(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(split),
                                               ws.data_ptr(), nws, _st(x))
     _lib.check(rc, "sgv3d_conv2d_backward_weight")

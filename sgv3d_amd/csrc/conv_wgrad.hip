@@ -308,6 +308,123 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const WgradArgs a
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / dilation 1 with 1 .. 4 OUTPUT channels (the 36 final layers of the CenterHead branches: 64 -> 1 / 2 / 3): an
+// MFMA tile would be 97 % padding (the per-tap kernel runs these at 2 TFLOP/s, 160 us each, 5.7 ms of a training step).  Here a
+// lane owns one input channel, a wave walks output-row segments of 32 pixels, 16 at a time: the 3 x 18 input values of its channel
+// in registers (coalesced 256-byte rows, 48 loads in flight), the dY values of 16 pixels come with ONE coalesced load and
+// are broadcast with v_readlane, and the 9 x COUT products per pixel are plain FMAs into 9 x COUT accumulators per lane.
+// The four waves of a workgroup are added in LDS in wave order, partial sums per workgroup go to the workspace
+// [workgroup][tap][c][ci] and wgrad_thin_reduce_kernel adds them in workgroup order (deterministic).
+// Bound: vector ALU (9 COUT FMAs per pixel and channel) / HBM (X is read once per launch: 33.5 MB for a cfg-2 hidden map).
+struct ThinArgs {
+    const float *x, *dy;
+    float *ws, *dw;
+    int batch, in_h, in_w, out_h, out_w, pad, cin, cout, x_ld, x_coff, y_ld, y_coff;
+    int segs, units, waves;        // 128-pixel segments per output row, units = batch * out_h * segs, waves = gridDim.x * 4
+    unsigned x_bytes, y_bytes;
+};
+constexpr int kThinSeg = 32;
+
+template <int COUT>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(const ThinArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 4 + wave;                     // global wave index
+    const int ci = blockIdx.y * 64 + lane;
+    const bool ci_ok = ci < a.cin;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)a.y_bytes, 0x00020000);
+    float acc[9][COUT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[t][c] = 0.f;
+    const unsigned x_c = (unsigned)(a.x_coff + ci) * 4u;
+    for (int u = gw; u < a.units; u += a.waves) {
+        const int seg = u % a.segs, t0 = u / a.segs;
+        const int oy = t0 % a.out_h, img = t0 / a.out_h;
+        const int ox_begin = seg * kThinSeg, ox_end = min(ox_begin + kThinSeg, a.out_w);
+        const int iy0 = oy - a.pad;
+        // byte offsets of the three input rows at column 0 (out of range: the row is outside the image)
+        unsigned rowoff[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = iy0 + r;
+            rowoff[r] = (ci_ok && (unsigned)iy < (unsigned)a.in_h) ? (unsigned)((img * a.in_h + iy) * a.in_w) * (unsigned)(a.x_ld * 4) + x_c : 0xffffffffu;
+        }
+        auto load_x = [&](int r, int ix) -> float {
+            const unsigned off = (rowoff[r] != 0xffffffffu && (unsigned)ix < (unsigned)a.in_w) ? rowoff[r] + (unsigned)ix * (unsigned)(a.x_ld * 4) : 0xffffffffu;
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off, 0, 0));
+        };
+        // 16 pixels at a time: their 3 x 18 input values are requested together (48 loads in flight per lane, two columns carried
+        // over), then 16 x 9 x COUT FMAs
+        float w[3][18];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            w[r][0] = load_x(r, ox_begin - a.pad);
+            w[r][1] = load_x(r, ox_begin - a.pad + 1);
+        }
+        const unsigned ybase = (unsigned)((img * a.out_h + oy) * a.out_w) * (unsigned)(a.y_ld * 4) + (unsigned)a.y_coff * 4u;
+        for (int ox0 = ox_begin; ox0 < ox_end; ox0 += 16) {
+            // dY of 16 pixels: lane l holds element l of the row's flat (pixel, channel) array starting at pixel ox0
+            const int px = lane / a.y_ld;                      // (y_ld <= 4: at least 16 pixels in 64 lanes)
+            const bool yok = ox0 + px < ox_end && px < 16;     // pixels past the row's end multiply dY = 0
+            const float dyv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                y_rsrc, yok ? ybase + (unsigned)(ox0 * a.y_ld + lane) * 4u : 0xffffffffu, 0, 0));
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[r][2 + j] = load_x(r, ox0 - a.pad + 2 + j);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) {
+                    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dyv), j * a.y_ld + c));
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int s2 = 0; s2 < 3; ++s2) acc[r * 3 + s2][c] = __builtin_fmaf(d, w[r][j + s2], acc[r * 3 + s2][c]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { w[r][0] = w[r][16]; w[r][1] = w[r][17]; }
+        }
+    }
+    // the four waves of the workgroup meet in LDS and are added in wave order; one partial set per workgroup
+    __shared__ float red[4][9 * COUT][64];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) red[wave][t * COUT + c][lane] = acc[t][c];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * COUT * 64; e += 256) {
+        const int l = e & 63, tc = e >> 6;
+        const int cc = blockIdx.y * 64 + l;
+        if (cc < a.cin) a.ws[((size_t)blockIdx.x * 9 * COUT + tc) * a.cin + cc] = ((red[0][tc][l] + red[1][tc][l]) + red[2][tc][l]) + red[3][tc][l];
+    }
+}
+
+// dw[c][ci][tap] = sum over workgroups (in order) of ws[workgroup][tap][c][ci]
+__global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const ThinArgs a) {
+    const int total = 9 * a.cout * a.cin;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float v = 0.f;
+    const int parts = a.waves >> 2;                            // one partial set per workgroup
+    int p = 0;
+    for (; p + 8 <= parts; p += 8) {                           // eight independent loads in flight, added in order
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = a.ws[(size_t)(p + j) * total + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += t[j];
+    }
+    for (; p < parts; ++p) v += a.ws[(size_t)p * total + i];
+    const int ci = i % a.cin, r = i / a.cin;
+    const int c = r % a.cout, tap = r / a.cout;
+    a.dw[((size_t)c * a.cin + ci) * 9 + tap] = v;
+}
+
 // i = (tap, co, ci) with ci fastest: coalesced partial reads, split order fixed.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
     const long long total = (long long)a.taps * a.cout * a.cin;
@@ -467,6 +584,57 @@ extern "C" int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *d, const floa
         return check_launch("wgrad_reduce_kernel");
     }
     return SGV3D_OK;
+}
+
+namespace {
+int thin_fill(const sgv3d_conv_desc *d, ThinArgs &a) {
+    SGV3D_REQUIRE(d, "conv2d_backward_weight_thin: null descriptor");
+    SGV3D_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad >= 0 && d->cout >= 1 && d->cout <= 4 && d->y_ld <= 4,
+                  "conv2d_backward_weight_thin: 3x3 / stride 1 / dilation 1 layers with 1..4 output channels and y_ld <= 4");
+    SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->x_ld >= d->x_coff + d->cin && d->y_ld >= d->y_coff + d->cout,
+                  "conv2d_backward_weight_thin: bad sizes");
+    SGV3D_REQUIRE(d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2, "conv2d_backward_weight_thin: output size does not belong to this input size");
+    const unsigned long long xb = (unsigned long long)d->batch * d->in_h * d->in_w * d->x_ld * 4ull;
+    const unsigned long long yb = (unsigned long long)d->batch * d->out_h * d->out_w * d->y_ld * 4ull;
+    SGV3D_REQUIRE(xb < 0xf0000000ull && yb < 0xf0000000ull, "conv2d_backward_weight_thin: x / dy must be smaller than 3.75 GiB");
+    a = ThinArgs{};
+    a.batch = d->batch; a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w; a.pad = d->pad;
+    a.cin = d->cin; a.cout = d->cout; a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff;
+    a.segs = cdiv(d->out_w, kThinSeg);
+    a.units = d->batch * d->out_h * a.segs;
+    int wgs = cdiv(a.units, 4);
+    wgs = wgs > 512 ? 512 : wgs;          // two waves per SIMD; one partial set per workgroup
+    a.waves = wgs * 4;
+    a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
+    return SGV3D_OK;
+}
+}  // namespace
+
+extern "C" size_t sgv3d_conv2d_backward_weight_thin_workspace_bytes(const sgv3d_conv_desc *d) {
+    ThinArgs a;
+    if (thin_fill(d, a) != SGV3D_OK) return 0;
+    return (size_t)(a.waves / 4) * 9 * a.cout * a.cin * sizeof(float);
+}
+
+extern "C" int sgv3d_conv2d_backward_weight_thin(const sgv3d_conv_desc *d, const float *x, const float *dy, float *dw, void *workspace,
+                                                 size_t workspace_bytes, void *stream) {
+    ThinArgs a;
+    if (int rc = thin_fill(d, a)) return rc;
+    SGV3D_REQUIRE(x && dy && dw && workspace, "conv2d_backward_weight_thin: null pointer");
+    const size_t need = (size_t)(a.waves / 4) * 9 * a.cout * a.cin * sizeof(float);
+    SGV3D_REQUIRE(workspace_bytes >= need, "conv2d_backward_weight_thin: workspace too small (%zu < %zu)", workspace_bytes, need);
+    a.x = x; a.dy = dy; a.dw = dw; a.ws = static_cast<float *>(workspace);
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(a.waves / 4, cdiv(a.cin, 64));
+    switch (a.cout) {
+        case 1: wgrad_thin_kernel<1><<<grid, 256, 0, st>>>(a); break;
+        case 2: wgrad_thin_kernel<2><<<grid, 256, 0, st>>>(a); break;
+        case 3: wgrad_thin_kernel<3><<<grid, 256, 0, st>>>(a); break;
+        default: wgrad_thin_kernel<4><<<grid, 256, 0, st>>>(a); break;
+    }
+    if (int rc = check_launch("wgrad_thin_kernel")) return rc;
+    wgrad_thin_reduce_kernel<<<cdiv(9 * a.cout * a.cin, 256), 256, 0, st>>>(a);
+    return check_launch("wgrad_thin_reduce_kernel");
 }
 
 extern "C" int sgv3d_zero_insert(int batch, int in_h, int in_w, int channels, int stride, int out_h, int out_w,

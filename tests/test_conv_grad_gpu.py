@@ -109,6 +109,33 @@ def test_wgrad_all_taps_kernel_rejects_other_layers():
         conv_grad.conv2d_backward_weight(x, dy, 3, 2, 1, 1, tile=5, split=1)          # stride 2
 
 
+@pytest.mark.parametrize("shape", [
+    # B, cin, H, W, cout, pad
+    (2, 64, 20, 28, 3, 1),           # CenterHead final layer: 64 -> 3
+    (1, 64, 9, 300, 1, 1),           # one output channel, rows of three 128-pixel segments (the last one 44 pixels)
+    (3, 80, 7, 17, 2, 0),            # cin not a multiple of 64, no padding
+    (1, 130, 6, 33, 4, 2),           # three channel tiles, padding 2
+])
+def test_wgrad_thin_kernel(shape):
+    """1..4 output channels (sgv3d_conv2d_backward_weight_thin, taken automatically): against float64 autograd, bitwise
+    repeatable, exact on small integers."""
+    B, cin, H, W, cout, pad = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, H, W, cin + 8, generator=g)
+    oh, ow = H + 2 * pad - 2, W + 2 * pad - 2
+    dy = torch.randn(B, oh, ow, cout, generator=g)
+    _, _, dw_ref = _reference(x[..., 4:4 + cin], torch.zeros(cout, cin, 3, 3), dy, 1, pad, 1)
+    dw = conv_grad.conv2d_backward_weight(x.cuda(), dy.cuda(), 3, 1, pad, 1, cin=cin, cout=cout, x_coff=4)
+    assert float((dw.cpu().double() - dw_ref).abs().max()) <= 2e-5 * float(dw_ref.abs().max())
+    assert torch.equal(dw, conv_grad.conv2d_backward_weight(x.cuda(), dy.cuda(), 3, 1, pad, 1, cin=cin, cout=cout, x_coff=4))
+    assert float((dw - conv_grad.conv2d_backward_weight(x.cuda(), dy.cuda(), 3, 1, pad, 1, cin=cin, cout=cout, x_coff=4, tile=1, split=4)).abs().max()) \
+        <= 2e-5 * float(dw_ref.abs().max())                                   # the MFMA kernel agrees
+    xi = torch.randint(-3, 4, (B, H, W, cin), generator=g).float()
+    dyi = torch.randint(-2, 3, (B, oh, ow, cout), generator=g).float()
+    _, _, want = _reference(xi, torch.zeros(cout, cin, 3, 3), dyi, 1, pad, 1)
+    assert torch.equal(conv_grad.conv2d_backward_weight(xi.cuda(), dyi.cuda(), 3, 1, pad, 1).cpu().double(), want)
+
+
 def test_wgrad_is_exact_on_small_integers():
     g = torch.Generator().manual_seed(5)
     x = torch.randint(-3, 4, (2, 30, 34, 64), generator=g).float()
