@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kT) void dense_bwd_weight_kernel(int B, int K, int 
 }
 
 // ------------------------------------------------------------------------------------------------ deformable im2col adjoint
-// one wave per (pixel, tap); lanes walk the channels as float4.  dcol uses the layout of sgv3d_deform_im2col3x3:
+// one wave per (pixel, tap); lanes walk consecutive channels.  dcol uses the layout of sgv3d_deform_im2col3x3:
 // [pixel][group][tap][channels per group].
 __global__ __launch_bounds__(kT) void deform_im2col_bwd_kernel(int B, int H, int W, int C, int groups,
                                                               const float *__restrict__ x, const float *__restrict__ off,
@@ -137,27 +137,21 @@ __global__ __launch_bounds__(kT) void deform_im2col_bwd_kernel(int B, int H, int
         const long long o1 = (img + (long long)h_low * W + w_low) * C, o2 = (img + (long long)h_low * W + w_high) * C;
         const long long o3 = (img + (long long)h_high * W + w_low) * C, o4 = (img + (long long)h_high * W + w_high) * C;
         const int cpg = C / groups;
-        for (int c = lane * 4; c < C; c += 256) {
+        // lanes walk CONSECUTIVE channels: every load and every atomic instruction of the wave covers one contiguous 256-byte
+        // piece of a pixel row (with a float4 per lane the four atomics of a lane were 16 bytes apart from the next lane's:
+        // 2.35 ms for the cfg-2 layer at batch 2; the memory-side atomic units take whole 64-byte requests)
+        for (int c = lane; c < C; c += 64) {
             const int g = c / cpg, cg = c - g * cpg;
-            const float4 d = *reinterpret_cast<const float4 *>(dcol + ((p * groups + g) * 9 + tap) * cpg + cg);
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 v1 = ok1 ? *reinterpret_cast<const float4 *>(x + o1 + c) : z;
-            const float4 v2 = ok2 ? *reinterpret_cast<const float4 *>(x + o2 + c) : z;
-            const float4 v3 = ok3 ? *reinterpret_cast<const float4 *>(x + o3 + c) : z;
-            const float4 v4 = ok4 ? *reinterpret_cast<const float4 *>(x + o4 + c) : z;
+            const float d = dcol[((p * groups + g) * 9 + tap) * cpg + cg];
+            const float v1 = ok1 ? x[o1 + c] : 0.f, v2 = ok2 ? x[o2 + c] : 0.f;
+            const float v3 = ok3 ? x[o3 + c] : 0.f, v4 = ok4 ? x[o4 + c] : 0.f;
             // d val / d hf = hw (v3 - v1) + lw (v4 - v2);  d val / d wf = hh (v2 - v1) + lh (v4 - v3)
-            gy += d.x * (hw * (v3.x - v1.x) + lw * (v4.x - v2.x)) + d.y * (hw * (v3.y - v1.y) + lw * (v4.y - v2.y)) +
-                  d.z * (hw * (v3.z - v1.z) + lw * (v4.z - v2.z)) + d.w * (hw * (v3.w - v1.w) + lw * (v4.w - v2.w));
-            gx += d.x * (hh * (v2.x - v1.x) + lh * (v4.x - v3.x)) + d.y * (hh * (v2.y - v1.y) + lh * (v4.y - v3.y)) +
-                  d.z * (hh * (v2.z - v1.z) + lh * (v4.z - v3.z)) + d.w * (hh * (v2.w - v1.w) + lh * (v4.w - v3.w));
-            const float dv[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (ok1) __hip_atomic_fetch_add(dx + o1 + c + j, w1 * dv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (ok2) __hip_atomic_fetch_add(dx + o2 + c + j, w2 * dv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (ok3) __hip_atomic_fetch_add(dx + o3 + c + j, w3 * dv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (ok4) __hip_atomic_fetch_add(dx + o4 + c + j, w4 * dv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            gy += d * (hw * (v3 - v1) + lw * (v4 - v2));
+            gx += d * (hh * (v2 - v1) + lh * (v4 - v3));
+            if (ok1) __hip_atomic_fetch_add(dx + o1 + c, w1 * d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ok2) __hip_atomic_fetch_add(dx + o2 + c, w2 * d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ok3) __hip_atomic_fetch_add(dx + o3 + c, w3 * d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ok4) __hip_atomic_fetch_add(dx + o4 + c, w4 * d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     for (int o = 32; o > 0; o >>= 1) {                            // butterfly: the same order for every lane, every run

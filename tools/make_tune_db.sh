@@ -25,3 +25,20 @@ echo "cfg3 streams 1 rc=$?"
 SGV3D_TUNE_CACHE=$OUT/gfx950_cfg5_bf16.json python3 bench.py --sub --config cfg5 --batch 1 --dtype bf16 --steps 3 --warmup 2 --streams 1 --no-cpu-baseline --no-roofline > $OUT/cfg5s1.json 2> $OUT/cfg5s1.err
 echo "cfg5 streams 1 rc=$?"
 wc -c $OUT/gfx950_*.json
+# training step (cfg-2 model at batch 2 and at cfg-4's per-GPU batch 4): forward / data-gradient choices and the weight-gradient
+# (tile, split) choices ("wgrad|" signatures) -> gfx950_cfg2_train.json
+SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2_train.json python3 tools/train_bench.py --batch 2 --steps 3 > $OUT/train_b2.json 2> $OUT/train_b2.err
+echo "train b2 rc=$?"
+SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2_train.json python3 tools/train_bench.py --batch 4 --steps 3 > $OUT/train_b4.json 2> $OUT/train_b4.err
+echo "train b4 rc=$?"
+wc -c $OUT/gfx950_*.json
+# (the file written by train_bench.py holds the whole in-memory table: keep only the signatures that are not in the other files)
+python3 - <<PY
+import json, glob
+t = json.load(open("$OUT/gfx950_cfg2_train.json"))
+o = {}
+for f in glob.glob("$OUT/gfx950_*.json"):
+    if "train" not in f:
+        o.update(json.load(open(f)))
+json.dump({k: v for k, v in t.items() if k not in o}, open("$OUT/gfx950_cfg2_train.json", "w"), indent=0, sort_keys=True)
+PY

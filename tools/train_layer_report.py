@@ -46,6 +46,6 @@ for n, f, us in rows:
 print(f"total {tot / 1e3:.2f} ms in {len(rows)} launches")
 for k, (us, f, n) in sorted(agg.items(), key=lambda x: -x[1][0])[:14]:
     print(f"{us / 1e3:8.2f} ms  n={n:4d}  {f / us / 1e6 if f else 0:6.1f} TF  {k}")
-print("--- weight-gradient launches by time")
-for n, f, us in sorted((r for r in rows if r[0].startswith("conv_wgrad")), key=lambda r: -r[2])[:40]:
-    print(f"{us:8.1f} us {f / us / 1e6:6.1f} TF  {n}")
+print("--- launches by time" + (" (" + os.environ["FILTER"] + ")" if os.environ.get("FILTER") else ""))
+for n, f, us in sorted((r for r in rows if r[0].startswith(os.environ.get("FILTER", ""))), key=lambda r: -r[2])[:int(os.environ.get("TOP", "40"))]:
+    print(f"{us:8.1f} us {(f or 0) / us / 1e6:6.1f} TF  {n}")
