@@ -542,12 +542,239 @@ __global__ __launch_bounds__(512, 1) void head_bf16_ws_kernel(const HeadBf16Args
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Ping-pong variant (built, measured, NOT the default: sgv3d_centerhead_bf16_select_plain(3)): 8 waves in two groups of four; group g owns the branches b = g (mod 2) and alternates between
+// "layer 1 of my branch" and "epilogue + layer 2 + stores of my branch", half a period out of phase with the other group.  In the
+// warp-specialised kernel above the layer-1 waves also run the epilogue (3.0 k of their 11.3 k cycles per branch: vector ALU and LDS
+// stores, the matrix pipe idle) while the layer-2 waves are idle two thirds of the time; here every wave does both kinds of work
+// and at any time one group is on the matrix pipe while the other is on the vector ALU / LDS: a half-step is
+// max(4 taps, epilogue) + max(5 taps, layer 2) = 8.3 k cycles per branch.  Each group has its own hidden image, final-layer weights
+// and folded-BN vectors in LDS (the double buffers of the kernel above); two workgroup barriers per half-step.  Same arithmetic in
+// the same order as head_bf16_kernel: bitwise identical results.  MEASURED: 243 us for 36 branches at 256 x 256 -- exactly the
+// warp-specialised kernel's 243 us (single-role 296): with all 256 CUs in a dense bf16 MFMA loop the chip is at its power / clock
+// limit, and putting the epilogue under the other group's MFMAs buys no time.  What would: fewer MFMAs (the 27 % ring recompute and
+// the 324 -> 384 row padding).
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void head_bf16_pp_kernel(const HeadBf16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *in_s = smem;
+    char *hid_s = smem + kInBytes;                                                     // [2][kWsHidBytes]
+    __bf16 *w2_s = reinterpret_cast<__bf16 *>(smem + kInBytes + 2 * kWsHidBytes);      // [2][kW2Elems]
+    float *bn_s = reinterpret_cast<float *>(smem + kInBytes + 2 * kWsHidBytes + 2 * kW2Elems * 2);   // [2][scale 64 | shift 64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);      // two groups of four waves: even / odd branches
+    const int gw = wave & 3, gt = tid & 255;                        // wave / thread index inside the role group
+    const int r = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int y0 = ty * kTP, x0 = tx * kTP;
+    {
+        const size_t xoff0 = (size_t)b * a.H * a.W * a.x_ld + a.x_coff;
+        const float *xb = a.x + xoff0;
+        for (int e = tid; e < kIP * kIP * 8; e += 512) {
+            const int p = e >> 3, chunk = e & 7;
+            const int iy = p / kIP, ix = p - iy * kIP;
+            const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const size_t eoff = ((size_t)gy * a.W + gx) * a.x_ld + chunk * 8;
+                if (a.x_bf16) {
+                    v = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const __bf16 *>(a.x) + xoff0 + eoff);
+                } else {
+                    const float *src = xb + eoff;
+                    const f32x4 lo = *reinterpret_cast<const f32x4 *>(src), hi = *reinterpret_cast<const f32x4 *>(src + 4);
+                    const bf16x4 l4 = __builtin_convertvector(lo, bf16x4), h4 = __builtin_convertvector(hi, bf16x4);
+                    v = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+            *reinterpret_cast<bf16x8 *>(in_s + iy * kInRowB + chunk * kInChunkB + ix * 16) = v;
+        }
+        if (gt < 2 * kCH && grp < a.nb)                                                                 // folded BN of branch `grp`
+            bn_s[grp * 2 * kCH + gt] = gt < kCH ? a.scale1[grp * kCH + gt] : a.shift1[grp * kCH + gt - kCH];
+    }
+    // layer-1 geometry (waves 0..3; computed by everybody, cheap)
+    const char *ain[kMT];
+    int hoff[kMT];                     // byte offset inside one hidden buffer
+    bool hin[kMT];
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) {
+        const int m = gw * (kMT * 32) + mt * 32 + r;
+        const int hy = m / kHP, hx = m - hy * kHP;
+        const int hyc = hy < kHP ? hy : kHP - 1;
+        ain[mt] = in_s + hyc * kInRowB + h * kInChunkB + hx * 16;
+        hoff[mt] = (hy < kHP ? hy : kHP) * kHidRowB + hx * 16 + h * 8;        // padding pixels -> row 18 (never read)
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        hin[mt] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    }
+    const int col = lane & 15, kq = lane >> 4;
+    const int a2off = (gw * 4) * kHidRowB + kq * kHidChunkB + col * 16;
+    const int b2off = (col & 3) * 64 + kq * 8;
+    const bf16x8 *w1l = reinterpret_cast<const bf16x8 *>(a.w1) + lane;
+    char *const hbuf = hid_s + grp * kWsHidBytes;                 // the group's own hidden image
+    float *const bnb = bn_s + grp * 2 * kCH;
+    __bf16 *const w2b = w2_s + grp * kW2Elems;
+    __syncthreads();
+
+    // Group g owns the branches b = g, g + 2, ... and runs, per branch: layer 1 (a barrier in its middle, one at its end), then
+    // epilogue -> barrier -> layer 2 + stores -> barrier.  Group 1 starts half a period (two barriers) late, so between any two
+    // barriers one group is on the matrix pipe and the other on the vector ALU / LDS; trailing barriers equalise the counts.
+    if (grp == 1) { __syncthreads(); __syncthreads(); }
+    for (int br = grp; br < a.nb; br += 2) {
+        f32x16 acc[kMT][2];
+        {
+            // (the fragments of tap 0 are requested here, not at the end of the group's previous layer 1: 32 registers that
+            // would be live across the other role -- with them the kernel spills)
+            bf16x8 bq[2][4][2];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) bq[0][ks][nt] = w1l[(size_t)(br * 9 * 4) * 2 * 64 + (size_t)ks * 2 * 64 + nt * 64];
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+            bf16x8 af[2][kMT];
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt) af[0][mt] = *reinterpret_cast<const bf16x8 *>(ain[mt]);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap == 4) __syncthreads();               // the half-step's middle barrier (the other group: epilogue done)
+                const int cur = tap & 1, nxt = cur ^ 1;
+                if (tap < 8) {
+                    const size_t base = (size_t)((br * 9 + tap + 1) * 4) * 2 * 64;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) bq[nxt][ks][nt] = w1l[base + (size_t)ks * 2 * 64 + nt * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ac = (tap * 4 + ks) & 1, an = ac ^ 1;
+                    if (!(tap == 8 && ks == 3)) {
+                        const int t2 = ks == 3 ? tap + 1 : tap, k2 = ks == 3 ? 0 : ks + 1;
+                        const int off2 = (t2 / 3) * kInRowB + (t2 % 3) * 16 + k2 * 2 * kInChunkB;
+#pragma unroll
+                        for (int mt = 0; mt < kMT; ++mt) af[an][mt] = *reinterpret_cast<const bf16x8 *>(ain[mt] + off2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[cur][ks][nt], af[ac][mt], acc[mt][nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __syncthreads();
+        bf16x8 w2pre[2];
+        float bnpre = 0.f;
+        {
+            // requested now, parked in LDS after the middle barrier: the final-layer weights of this branch and the folded BN of
+            // the group's next branch (br + 2)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = gt + u * 256;
+                if (e < kW2Elems / 8) w2pre[u] = reinterpret_cast<const bf16x8 *>(a.w2 + (size_t)br * kW2Elems)[e];
+            }
+            if (br + 2 < a.nb && gt < 2 * kCH) bnpre = gt < kCH ? a.scale1[(br + 2) * kCH + gt] : a.shift1[(br + 2) * kCH + gt - kCH];
+            // epilogue: BN + ReLU -> the group's hidden image (its previous reader, layer 2 of branch br - 2, finished two
+            // barriers ago)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = nt * 32 + 8 * g + 4 * h;
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(bnb + ch);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(bnb + kCH + ch);
+#pragma unroll
+                    for (int mt = 0; mt < kMT; ++mt) {
+                        f32x4 v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaxf(acc[mt][nt][4 * g + i] * sc[i] + sh[i], 0.f);
+                        union { bf16x4 b; unsigned long long u; } pk;
+                        pk.b = __builtin_convertvector(v, bf16x4);
+                        pk.u = hin[mt] ? pk.u : 0ull;
+                        *reinterpret_cast<unsigned long long *>(hbuf + hoff[mt] + (nt * 4 + g) * kHidChunkB) = pk.u;
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = gt + u * 256;
+                if (e < kW2Elems / 8) reinterpret_cast<bf16x8 *>(w2b)[e] = w2pre[u];
+            }
+        }
+        __syncthreads();                                          // hidden image and final-layer weights complete
+        {
+            if (br + 2 < a.nb && gt < 2 * kCH) bnb[gt] = bnpre;        // (the epilogue of br has read its own)
+            const int ob = a.out_begin[br], c = a.out_begin[br + 1] - ob;
+            f32x4 acc2[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc2[rr][i] = 0.f;
+            bf16x8 bf[18];
+#pragma unroll
+            for (int st = 0; st < 18; ++st) bf[st] = *reinterpret_cast<const bf16x8 *>(w2b + b2off + (st >> 1) * 256 + (st & 1) * 32);
+            constexpr int kAhead = 3;
+            bf16x8 a2[kAhead + 1][4];
+#define HEAD_A2W(st_, rr_) *reinterpret_cast<const bf16x8 *>(hbuf + a2off + ((rr_) + ((st_) >> 1) / 3) * kHidRowB + (((st_) >> 1) % 3) * 16 + ((st_) & 1) * 4 * kHidChunkB)
+#pragma unroll
+            for (int st = 0; st < kAhead; ++st)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) a2[st][rr] = HEAD_A2W(st, rr);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < 18; ++st) {
+                if (st + kAhead < 18) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) a2[(st + kAhead) % (kAhead + 1)][rr] = HEAD_A2W(st + kAhead, rr);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    acc2[rr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[st % (kAhead + 1)][rr], bf[st], acc2[rr], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef HEAD_A2W
+            if (col < c) {
+                const float bias = a.bias2[ob + col];
+                float *plane = a.out + ((size_t)b * a.total_out + ob + col) * a.H * a.W;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int gy = y0 + gw * 4 + rr, gx = x0 + kq * 4;
+                    if (gy < a.H) {
+                        float *dst = plane + (size_t)gy * a.W + gx;
+                        if (gx + 3 < a.W && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+                            f32x4 v = acc2[rr];
+                            v += bias;
+                            *reinterpret_cast<f32x4 *>(dst) = v;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (gx + i < a.W) dst[i] = acc2[rr][i] + bias;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (grp == (a.nb & 1)) { __syncthreads(); __syncthreads(); }
+}
+
 }  // namespace
 
 static long long *g_head_dbg = nullptr;
-static bool g_head_plain = false;
-// tools / tests only: 1 selects the single-role kernel (4 waves, the phases of a branch run one after the other)
-extern "C" void sgv3d_centerhead_bf16_select_plain(int plain) { g_head_plain = plain != 0; }
+static int g_head_plain = 0;       // 0: warp-specialised kernel (default), 1: single-role kernel, 3: ping-pong kernel
+// tools / tests only: 1 selects the single-role kernel (4 waves, the phases of a branch run one after the other), 3 the
+// ping-pong one (two groups of waves half a period apart), 0 the default (warp-specialised: layer-1 waves / layer-2 waves)
+extern "C" void sgv3d_centerhead_bf16_select_plain(int plain) { g_head_plain = plain; }
 // tools only: device buffer of 4 * nb + 2 int64 that receives cycle-counter stamps of workgroup 0 (NULL switches it off)
 extern "C" void sgv3d_centerhead_bf16_debug_stamps(void *buf) { g_head_dbg = static_cast<long long *>(buf); }
 
@@ -596,7 +823,14 @@ static int head_bf16_launch(int batch, int h, int w, int cin, int x_ld, int x_co
     a.total_out = total_out; a.tiles_x = cdiv(w, kTP); a.tiles_y = cdiv(h, kTP);
     a.dbg = g_head_dbg;
     a.x_bf16 = x_is_bf16 ? 1 : 0;
-    if (g_head_dbg == nullptr && !g_head_plain) {      // default: the warp-specialised kernel (layer 2 overlapped with layer 1)
+    if (g_head_dbg == nullptr && g_head_plain == 3) {   // the ping-pong kernel (two groups of waves half a period apart)
+        static PerDeviceSize lds_pp;
+        if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&head_bf16_pp_kernel), kWsLds, lds_pp))
+            return fail(SGV3D_ELAUNCH, "centerhead_branches_forward_bf16: cannot raise the dynamic LDS limit to %d", kWsLds);
+        hipLaunchKernelGGL(head_bf16_pp_kernel, dim3(a.tiles_x * a.tiles_y, batch), dim3(512), kWsLds, as_stream(stream), a);
+        return check_launch("head_bf16_pp_kernel");
+    }
+    if (g_head_dbg == nullptr && g_head_plain == 0) {   // default: the warp-specialised kernel (layer 2 overlapped with layer 1)
         static PerDeviceSize lds_ws;
         if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&head_bf16_ws_kernel), kWsLds, lds_ws))
             return fail(SGV3D_ELAUNCH, "centerhead_branches_forward_bf16: cannot raise the dynamic LDS limit to %d", kWsLds);

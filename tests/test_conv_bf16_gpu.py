@@ -239,12 +239,13 @@ def test_fused_centerhead_bf16(B, H, W, counts):
     again = hip_ops.centerhead_branches_bf16(x.to(DEV), packed, sc.to(DEV), sh.to(DEV), b2.to(DEV), ob, nb)
     assert torch.equal(out, again)
     from sgv3d_amd import _lib
-    _lib.load().sgv3d_centerhead_bf16_select_plain(1)           # the single-role variant: same arithmetic, same order
-    try:
-        plain = hip_ops.centerhead_branches_bf16(x.to(DEV), packed, sc.to(DEV), sh.to(DEV), b2.to(DEV), ob, nb)
-    finally:
-        _lib.load().sgv3d_centerhead_bf16_select_plain(0)
-    assert torch.equal(out, plain)
+    for variant in (1, 3):              # 1: the single-role kernel, 3: the ping-pong one (default 0: warp-specialised): same arithmetic, same order
+        _lib.load().sgv3d_centerhead_bf16_select_plain(variant)
+        try:
+            other = hip_ops.centerhead_branches_bf16(x.to(DEV), packed, sc.to(DEV), sh.to(DEV), b2.to(DEV), ob, nb)
+        finally:
+            _lib.load().sgv3d_centerhead_bf16_select_plain(0)
+        assert torch.equal(out, other), variant
     # input channels taken as a slice of a wider buffer
     wide = torch.randn(B, H, W, 96).to(DEV)
     wide[..., 16:80] = x.to(DEV)
@@ -298,6 +299,20 @@ def test_fused_centerhead_bf16_36_branches_256x256_and_speed():
     us = min(evs[i].elapsed_time(evs[i + 1]) for i in range(5)) * 1e3
     flops = 2.0 * 256 * 256 * (nb * 64 * 576 + sum(counts) * 576)
     print(f"bf16 fused head 36 x 256x256: {us:.0f} us = {flops / us / 1e6:.0f} TFLOP/s algorithmic")
+    from sgv3d_amd import _lib
+    for variant, name in ((1, "single-role"), (3, "ping-pong")):
+        _lib.load().sgv3d_centerhead_bf16_select_plain(variant)
+        try:
+            o2 = hip_ops.centerhead_branches_bf16(*args)
+            evs[0].record()
+            for i in range(5):
+                hip_ops.centerhead_branches_bf16(*args)
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+        finally:
+            _lib.load().sgv3d_centerhead_bf16_select_plain(0)
+        assert torch.equal(out, o2)
+        print(f"  {name} kernel: {min(evs[i].elapsed_time(evs[i + 1]) for i in range(5)) * 1e3:.0f} us")
 
 
 # ---------------------------------------------------------------------------------------------- bf16 activations in HBM
