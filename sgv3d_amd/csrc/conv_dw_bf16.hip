@@ -82,8 +82,9 @@ __global__ __launch_bounds__(64) void dw_pack_kernel(const float *__restrict__ w
     }
 }
 
-template <int WM, int WN, int MT>
-__global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) void conv_dw_bf16_kernel(const DwArgs a) {
+// NTAIL: N is not a multiple of the tile's 64 WN columns -- some waves (or half-waves) of the last column tile own no channel
+template <int WM, int WN, int MT, bool NTAIL>
+__global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM == 2 ? 3 : 2) void conv_dw_bf16_kernel(const DwArgs a) {
     static_assert(WM * WN == 4 && (MT == 2 || MT == 4), "four waves, 64 or 128 pixels per wave");
     constexpr int WROWS = 32 * MT;                           // pixels per wave
     constexpr int BM = WROWS * WM, BN = 64 * WN;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
     // weight fragments of this wave's two n-tiles: byte offset = ((nt * ksteps + ks) * 64 + lane) * 16
     // (the packed weights hold an even number of n-tiles; a wave whose 64 channels lie beyond N reads zeros)
     const unsigned w_lane = n0 + wn * 64 < a.N ? lane * 16 : 0xffffffffu;
+    const bool nt_live0 = !NTAIL || n0 + wn * 64 < a.N, nt_live1 = !NTAIL || n0 + wn * 64 + 32 < a.N;     // (wave-uniform)
     const int nt0 = (n0 + wn * 64) >> 5;
     const int w_s0 = __builtin_amdgcn_readfirstlane(nt0 * a.ksteps * kFragB);
     const int w_s1 = __builtin_amdgcn_readfirstlane((nt0 + 1) * a.ksteps * kFragB);
@@ -203,11 +205,14 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? 4 : WM == 2 ? 3 : 2) v
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
             FA[mt] = *reinterpret_cast<const bf16x8 *>(smem + (BUF) * kBufB + rd_off[S] + mt * 32 * kRowB); \
     } while (0)
+// (n-tiles of the wave that lie beyond N -- N = 160 on a 256-wide tile leaves one wave idle and one half idle -- are not
+// multiplied: their products would be zeros, but a dense bf16 MFMA loop runs at the chip's power limit, and MFMAs on zeros
+// cost the other waves clock)
 #define DW_MFMA(FA, S)                                                                                     \
     do {                                                                                                   \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                \
-            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[S][0], FA[mt], acc[mt][0], 0, 0, 0);   \
-            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[S][1], FA[mt], acc[mt][1], 0, 0, 0);   \
+            if (nt_live0) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[S][0], FA[mt], acc[mt][0], 0, 0, 0); \
+            if (nt_live1) acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[S][1], FA[mt], acc[mt][1], 0, 0, 0); \
         }                                                                                                  \
     } while (0)
     constexpr bool kPrefetchA = MT == 4 && WM == 1;      // (the 256 x 128 tile has no registers left for it)
@@ -436,6 +441,7 @@ __global__ __launch_bounds__(256, 3) void conv_dw_bf16_pair_kernel(const DwArgs 
 #pragma unroll
     for (int s = 0; s < 4; ++s) rd_off[s] = lr * kRowB + (((2 * s + lh) ^ swz) * 16);
     const unsigned w_lane = lane * 16;
+    constexpr bool nt_live0 = true, nt_live1 = true;
     const int nt0 = wn * 2;
     const int w_s0 = __builtin_amdgcn_readfirstlane(nt0 * a.ksteps * kFragB);
     const int w_s1 = __builtin_amdgcn_readfirstlane((nt0 + 1) * a.ksteps * kFragB);
@@ -633,8 +639,8 @@ __global__ __launch_bounds__(256, 3) void conv_dw_bf16_pair_kernel(const DwArgs 
 #undef DW_MFMA
 #undef DW_READ_A
 
-template <int WM, int WN, int MT>
-int launch_dw(const DwArgs &a0, hipStream_t st) {
+template <int WM, int WN, int MT, bool NTAIL>
+int launch_dw_t(const DwArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * MT * WM, BN = 64 * WN;
     DwArgs a = a0;
     a.tiles_m = cdiv(a.M, BM);
@@ -642,10 +648,15 @@ int launch_dw(const DwArgs &a0, hipStream_t st) {
     constexpr size_t tiles = 2 * (size_t)BM * kRowB, stage = sizeof(float) * 4 * 32 * kStageLd;
     constexpr size_t lds = tiles > stage ? tiles : stage;
     static PerDeviceSize lds_set;
-    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_dw_bf16_kernel<WM, WN, MT>), lds, lds_set))
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_dw_bf16_kernel<WM, WN, MT, NTAIL>), lds, lds_set))
         return fail(SGV3D_ELAUNCH, "conv_dw_bf16: cannot raise the dynamic LDS limit to %zu", lds);
-    hipLaunchKernelGGL((conv_dw_bf16_kernel<WM, WN, MT>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_dw_bf16_kernel<WM, WN, MT, NTAIL>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
     return check_launch("conv_dw_bf16_kernel");
+}
+
+template <int WM, int WN, int MT>
+int launch_dw(const DwArgs &a, hipStream_t st) {
+    return a.N % (64 * WN) == 0 ? launch_dw_t<WM, WN, MT, false>(a, st) : launch_dw_t<WM, WN, MT, true>(a, st);
 }
 
 }  // namespace

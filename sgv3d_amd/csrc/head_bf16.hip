@@ -377,6 +377,9 @@ __global__ __launch_bounds__(512, 1) void head_bf16_ws_kernel(const HeadBf16Args
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
         hin[mt] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     }
+    // the 324 hidden pixels are 10.125 m-tiles of 32 rows on 12: the last m-tile of the last layer-1 wave (rows 352 .. 383) is all
+    // padding -- its MFMAs are skipped (the chip is at its power limit in this loop: MFMAs on padding cost the others clock)
+    const bool last_tile_pad = gw * (kMT * 32) + (kMT - 1) * 32 >= kHP * kHP;
     const int col = lane & 15, kq = lane >> 4;
     const int a2off = (gw * 4) * kHidRowB + kq * kHidChunkB + col * 16;
     const int b2off = (col & 3) * 64 + kq * 8;
@@ -430,10 +433,12 @@ __global__ __launch_bounds__(512, 1) void head_bf16_ws_kernel(const HeadBf16Args
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int mt = 0; mt < kMT; ++mt)
+                        for (int mt = 0; mt < kMT; ++mt) {
+                            if (mt == kMT - 1 && last_tile_pad) continue;        // (wave-uniform)
 #pragma unroll
                             for (int nt = 0; nt < 2; ++nt)
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[cur][ks][nt], af[ac][mt], acc[mt][nt], 0, 0, 0);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
