@@ -611,6 +611,15 @@ int sgv3d_centerhead_loss(int batch, int num_class, int h, int w, int max_objs, 
 size_t sgv3d_conv2d_backward_weight_workspace_bytes(const sgv3d_conv_desc *desc /*host*/, int split);
 int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *dy, float *dw,
                                  int split, void *workspace, size_t workspace_bytes, void *stream);
+/* Batched form of the all-taps kernel (desc.tile 5 layers: 3x3 / stride 1 / dilation 1): n <= 48 weight gradients
+ * dw_list[i] = wgrad(x, dy_list[i]) of layers that read the SAME input, in one launch (blockIdx.z = problem).  The 36 first layers of
+ * the CenterHead branches (64 -> 64 at 256 x 256, layers/heads/bev_height_head.py:75-110 through mmdet3d SeparateHead) are one 64 x 64
+ * tile each: alone a launch needs a pixel split of 256 to fill the chip, batched 36 x 14.  dy_list / dw_list: HOST arrays of device
+ * pointers ([batch, out_h, out_w, y_ld] with desc.y_coff / OIHW [cout, cin, 3, 3]).  workspace: ..._batched_workspace_bytes(desc, n, split). */
+size_t sgv3d_conv2d_backward_weight_batched_workspace_bytes(const sgv3d_conv_desc *desc /*host*/, int n, int split);
+int sgv3d_conv2d_backward_weight_batched(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *const *dy_list /*host*/,
+                                         float *const *dw_list /*host*/, int n, int split, void *workspace, size_t workspace_bytes,
+                                         void *stream);
 /* ... with 1 .. 4 output channels (3x3 / stride 1 / dilation 1, desc.y_ld <= 4: the final layers of the CenterHead branches,
  * layers/heads/bev_height_head.py:75-110 through mmdet3d SeparateHead): a vector-ALU kernel (a lane per input channel, sliding 3x3
  * window in registers, dY broadcast by v_readlane) instead of an MFMA tile that would be 97 % padding; per-wave partial sums in

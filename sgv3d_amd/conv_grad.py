@@ -17,7 +17,8 @@ import torch
 from . import _lib
 from .hip_ops import ConvDesc, PackedConv, prof, _st
 
-__all__ = ['conv2d_backward_weight', 'conv2d_backward_data', 'zero_insert', 'conv2d', 'conv_transpose2d']
+__all__ = ['conv2d_backward_weight', 'conv2d_backward_weight_batched', 'conv2d_backward_data', 'zero_insert', 'conv2d', 'conv_transpose2d',
+           'multi_conv2d']
 
 
 def _out_hw(h, w, k, stride, pad, dil):
@@ -64,6 +65,37 @@ def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, c
                                               ws.data_ptr(), nws, _st(x))
     _lib.check(rc, "sgv3d_conv2d_backward_weight")
     return dw
+
+
+def conv2d_backward_weight_batched(x, dys, pad=1, *, cin=None, cout=None, split=0):
+    """[dW_i] of n 3x3 / stride-1 convolutions that read the same NHWC ``x``: one launch of the all-taps kernel
+    (sgv3d_conv2d_backward_weight_batched).  ``dys``: n contiguous NHWC tensors of one shape."""
+    B, H, W, x_ld = (int(v) for v in x.shape)
+    _, OH, OW, y_ld = (int(v) for v in dys[0].shape)
+    cin = x_ld if cin is None else int(cin)
+    cout = y_ld if cout is None else int(cout)
+    n = len(dys)
+    assert x.is_contiguous() and x.dtype == torch.float32 and all(d.is_contiguous() and d.dtype == torch.float32 and d.shape == dys[0].shape for d in dys)
+    assert (OH, OW) == _out_hw(H, W, (3, 3), 1, pad, 1) and 0 < n <= 48
+    d = ConvDesc()
+    d.batch, d.in_h, d.in_w, d.cin, d.out_h, d.out_w, d.cout = B, H, W, cin, OH, OW, cout
+    d.kh, d.kw, d.stride, d.pad, d.dil = 3, 3, 1, int(pad), 1
+    d.x_ld, d.x_coff, d.y_ld, d.y_coff = x_ld, 0, y_ld, 0
+    d.tile = 5
+    if not split:                       # ~3 workgroups per CU over all problems, at least four row segments per workgroup
+        units = B * OH * -(-OW // 32)
+        tiles = -(-cout // 64) * -(-cin // 64) * n
+        split = max(1, min(-(-768 // tiles), units // 4))
+    lib = _lib.load()
+    nws = lib.sgv3d_conv2d_backward_weight_batched_workspace_bytes(ctypes.byref(d), n, int(split))
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
+    dws = [torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device) for _ in range(n)]
+    dyp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dys])
+    dwp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dws])
+    with torch.cuda.device(x.device), prof("conv_wgrad", 2.0 * n * B * OH * OW * cout * cin * 9):
+        rc = lib.sgv3d_conv2d_backward_weight_batched(ctypes.byref(d), x.data_ptr(), dyp, dwp, n, int(split), ws.data_ptr(), nws, _st(x))
+    _lib.check(rc, "sgv3d_conv2d_backward_weight_batched")
+    return dws
 
 
 _WGRAD_DB = {}
@@ -241,6 +273,37 @@ class _Conv2dNHWC(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 1, 2))
         return dx, dw, db, None, None, None
+
+
+class _MultiConv2dNHWC(torch.autograd.Function):
+    """n 3x3 / stride-1 / pad-1 convolutions without bias of ONE input (the first layers of the CenterHead branches): forward and data
+    gradients are the per-layer kernels, the n weight gradients are one batched launch."""
+    @staticmethod
+    def forward(ctx, x, *weights):
+        ctx.save_for_backward(x, *weights)
+        return tuple(PackedConv(w, stride=1, pad=1, cin_pad=int(x.shape[-1]))(x) for w in weights)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, *weights = ctx.saved_tensors
+        cout, cin = int(weights[0].shape[0]), int(weights[0].shape[1])
+        dys = [torch.zeros(x.shape[:3] + (cout,), dtype=x.dtype, device=x.device) if d is None else d.contiguous() for d in dys]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            for d, w in zip(dys, weights):
+                g = conv2d_backward_data(d, w, (int(x.shape[1]), int(x.shape[2])), 1, 1, 1)
+                if int(g.shape[-1]) != int(x.shape[-1]):
+                    g = torch.nn.functional.pad(g, (0, int(x.shape[-1]) - int(g.shape[-1])))
+                dx = g if dx is None else dx.add_(g)
+        dws = [None] * len(weights)
+        if any(ctx.needs_input_grad[1:]):
+            dws = conv2d_backward_weight_batched(x, dys, 1, cin=cin, cout=cout)
+        return (dx, *dws)
+
+
+def multi_conv2d(x, weights):
+    """[conv2d(x, w, stride 1, pad 1) for w in weights] for 3x3 weights of one shape; see _MultiConv2dNHWC."""
+    return _MultiConv2dNHWC.apply(_pad4(x), *weights)
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1):

@@ -33,6 +33,11 @@ struct WgradArgs {
     int wm, wn;   // wave tiles of the chosen instantiation
     int tap_cols; // 1: cin <= 4 (image stem): the ci axis of the tile is (tap, ci) -- 16 taps x 4 channels per 64 columns
     unsigned x_bytes, y_bytes;   // extents of x / dy from their base pointers (buffer resources)
+    // conv_wgrad3x3_kernel, batched form (blockIdx.z = problem): several dY / dW pairs against ONE x (the first layers of the
+    // CenterHead branches all read the shared map); nbatch == 0: the single pair dy / dw
+    int nbatch;
+    const float *dy_list[48];
+    float *dw_list[48];
 };
 
 typedef float f32x4n __attribute__((ext_vector_type(4)));
@@ -211,7 +216,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const WgradArgs a
     const int units = a.batch * a.out_h * segs;
     const int u_begin = (int)((long long)units * blockIdx.y / a.split), u_end = (int)((long long)units * (blockIdx.y + 1) / a.split);
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)a.y_bytes, 0x00020000);
+    const float *const dyp = a.nbatch ? a.dy_list[blockIdx.z] : a.dy;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dyp, 0, (int)a.y_bytes, 0x00020000);
     // staging slots: a thread moves float4s.  dY: 32 pixels x 16 float4 = 2 per thread; X: 3 rows x 34 columns x 16 float4 =
     // 1632 = 6.4 per thread (7 passes, the last one partly idle).  Row / column / channel of a slot never change.
     const int c4 = (tid & 15) * 4;
@@ -301,9 +307,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const WgradArgs a
             const int co = co0 + wm * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
             if (co >= a.cout || ci >= a.cin) continue;
             if (a.split > 1)
-                a.ws[(((size_t)blockIdx.y * 9 + t) * a.cout + co) * a.cin + ci] = acc[t][e];
+                a.ws[((((size_t)blockIdx.z * a.split + blockIdx.y) * 9 + t) * a.cout + co) * a.cin + ci] = acc[t][e];
             else
-                a.dw[((size_t)co * a.cin + ci) * 9 + t] = acc[t][e];
+                (a.nbatch ? a.dw_list[blockIdx.z] : a.dw)[((size_t)co * a.cin + ci) * 9 + t] = acc[t][e];
         }
     }
 }
@@ -431,11 +437,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     float v = 0.f;
-    for (int s = 0; s < a.split; ++s) v += a.ws[(size_t)s * total + i];
+    const float *ws = a.ws + (size_t)blockIdx.y * a.split * total;           // (batched form: one slab of partials per problem)
+    for (int s = 0; s < a.split; ++s) v += ws[(size_t)s * total + i];
     const int ci = (int)(i % a.cin);
     const long long r = i / a.cin;
     const int co = (int)(r % a.cout), tap = (int)(r / a.cout);
-    a.dw[((size_t)co * a.cin + ci) * a.taps + tap] = v;
+    (a.nbatch ? a.dw_list[blockIdx.y] : a.dw)[((size_t)co * a.cin + ci) * a.taps + tap] = v;
 }
 
 __global__ __launch_bounds__(256) void zero_insert_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int batch,
@@ -581,6 +588,42 @@ extern "C" int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *d, const floa
     if (a.split > 1) {
         const long long total = (long long)a.taps * a.cout * a.cin;
         wgrad_reduce_kernel<<<cdiv(total, 256), 256, 0, st>>>(a);
+        return check_launch("wgrad_reduce_kernel");
+    }
+    return SGV3D_OK;
+}
+
+// Batched form of the all-taps kernel: n weight gradients dw_list[i] = wgrad(x, dy_list[i]) of n 3x3 / stride-1 layers that read the
+// SAME input (desc describes one of them) in one launch -- the 36 first layers of the CenterHead branches (64 -> 64 at 256 x 256) are
+// one 64 x 64 tile each: alone a launch needs a split of 256 to fill the chip and writes 256 partial tiles, batched 36 x 14.
+extern "C" size_t sgv3d_conv2d_backward_weight_batched_workspace_bytes(const sgv3d_conv_desc *d, int n, int split) {
+    WgradArgs a;
+    if (!d || n <= 0 || fill_args(d, split, a, 5) != SGV3D_OK) return 0;
+    return a.split > 1 ? (size_t)n * a.split * a.taps * a.cout * a.cin * sizeof(float) : 0;
+}
+
+extern "C" int sgv3d_conv2d_backward_weight_batched(const sgv3d_conv_desc *d, const float *x, const float *const *dy_list,
+                                                    float *const *dw_list, int n, int split, void *workspace, size_t workspace_bytes,
+                                                    void *stream) {
+    SGV3D_REQUIRE(d && x && dy_list && dw_list && n > 0 && n <= 48, "conv2d_backward_weight_batched: 1 .. 48 problems");
+    WgradArgs a;
+    if (int rc = fill_args(d, split, a, 5)) return rc;
+    const size_t need = a.split > 1 ? (size_t)n * a.split * a.taps * a.cout * a.cin * sizeof(float) : 0;
+    SGV3D_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "conv2d_backward_weight_batched: workspace too small (%zu < %zu)",
+                  workspace_bytes, need);
+    a.x = x; a.dy = nullptr; a.dw = nullptr; a.ws = static_cast<float *>(workspace);
+    a.nbatch = n;
+    for (int i = 0; i < n; ++i) {
+        SGV3D_REQUIRE(dy_list[i] && dw_list[i] && ((uintptr_t)dy_list[i] & 15) == 0, "conv2d_backward_weight_batched: null / unaligned pointer %d", i);
+        a.dy_list[i] = dy_list[i];
+        a.dw_list[i] = dw_list[i];
+    }
+    hipStream_t st = as_stream(stream);
+    conv_wgrad3x3_kernel<<<dim3(a.tiles_co * a.tiles_ci, a.split, n), 256, 0, st>>>(a);
+    if (int rc = check_launch("conv_wgrad3x3_kernel")) return rc;
+    if (a.split > 1) {
+        const long long total = (long long)a.taps * a.cout * a.cin;
+        wgrad_reduce_kernel<<<dim3(cdiv(total, 256), n), 256, 0, st>>>(a);
         return check_launch("wgrad_reduce_kernel");
     }
     return SGV3D_OK;

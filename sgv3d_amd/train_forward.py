@@ -257,14 +257,26 @@ def head_forward(head, bev):
     fpn = secondfpn(head.neck, outs)
     sc = head.shared_conv
     shared = bn(sc.bn, conv(sc.conv, fpn), relu=True)
-    ret = []
+    # the first layers of all branches read the same map: when they are plain 3x3 / stride 1 / pad 1 convolutions of one shape, their
+    # weight gradients run as ONE batched launch (conv_grad.multi_conv2d; 36 launches of one 64 x 64 tile each otherwise)
+    seqs = [(th, name, getattr(th, name)) for th in head.task_heads for name in th.heads]
+    firsts = [seq[0].conv for _, _, seq in seqs if len(seq) == 2]
+    batched = (len(firsts) == len(seqs) and 1 < len(firsts) <= 48 and shared.shape[-1] % 4 == 0 and
+               all(c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.bias is None and
+                   c.weight.shape == firsts[0].weight.shape and c.weight.shape[0] % 4 == 0 for c in firsts))
+    first_out = conv_grad.multi_conv2d(shared, [c.weight for c in firsts]) if batched else None
+    ret, k = [], 0
     for th in head.task_heads:
         d = {}
         for name in th.heads:
             seq = getattr(th, name)
-            y = shared
-            for layer in seq[:-1]:
-                y = bn(layer.bn, conv(layer.conv, y), relu=True)
+            if batched:
+                y = bn(seq[0].bn, first_out[k], relu=True)
+                k += 1
+            else:
+                y = shared
+                for layer in seq[:-1]:
+                    y = bn(layer.bn, conv(layer.conv, y), relu=True)
             d[name] = _nchw(conv(seq[-1], y))                              # [B, c, H, W] like the reference
         ret.append([d])
     return tuple(ret)

@@ -136,6 +136,34 @@ def test_wgrad_thin_kernel(shape):
     assert torch.equal(conv_grad.conv2d_backward_weight(xi.cuda(), dyi.cuda(), 3, 1, pad, 1).cpu().double(), want)
 
 
+def test_wgrad_batched_matches_single_launches():
+    """n weight gradients against one input in one launch (sgv3d_conv2d_backward_weight_batched) and the autograd function built
+    on it (conv_grad.multi_conv2d): against the per-layer launches / float64 autograd."""
+    g = torch.Generator().manual_seed(11)
+    B, H, W, cin, cout, n = 2, 21, 45, 64, 64, 5
+    x = torch.randn(B, H, W, cin, generator=g)
+    dys = [torch.randn(B, H, W, cout, generator=g) for _ in range(n)]
+    got = conv_grad.conv2d_backward_weight_batched(x.cuda(), [d.cuda() for d in dys])
+    for d, dw in zip(dys, got):
+        _, _, dw_ref = _reference(x, torch.zeros(cout, cin, 3, 3), d, 1, 1, 1)
+        assert float((dw.cpu().double() - dw_ref).abs().max()) <= 2e-5 * float(dw_ref.abs().max())
+    again = conv_grad.conv2d_backward_weight_batched(x.cuda(), [d.cuda() for d in dys])
+    assert all(torch.equal(a, b) for a, b in zip(got, again))
+    # the autograd function: outputs, dx (sum over the layers) and every dw
+    ws = [(torch.randn(cout, cin, 3, 3, generator=g) / 24).cuda().requires_grad_(True) for _ in range(n)]
+    xg = x.cuda().requires_grad_(True)
+    outs = conv_grad.multi_conv2d(xg, ws)
+    loss = sum((o * d.cuda()).sum() for o, d in zip(outs, dys))
+    loss.backward()
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = [w.detach().cpu().double().requires_grad_(True) for w in ws]
+    lr = sum((F.conv2d(xr, w, None, 1, 1) * d.double().permute(0, 3, 1, 2)).sum() for w, d in zip(wr, dys))
+    lr.backward()
+    assert float((xg.grad.cpu().double().permute(0, 3, 1, 2) - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max())
+    for w, r in zip(ws, wr):
+        assert float((w.grad.cpu().double() - r.grad).abs().max()) <= 2e-5 * float(r.grad.abs().max())
+
+
 def test_wgrad_is_exact_on_small_integers():
     g = torch.Generator().manual_seed(5)
     x = torch.randint(-3, 4, (2, 30, 34, 64), generator=g).float()
