@@ -31,7 +31,8 @@ struct WgradArgs {
     int x_ld, x_coff, y_ld, y_coff;
     int tiles_co, tiles_ci, taps, split, pix_total, pix_per_split;
     int wm, wn;   // wave tiles of the chosen instantiation
-    int tap_cols; // 1: cin <= 4 (image stem): the ci axis of the tile is (tap, ci) -- 16 taps x 4 channels per 64 columns
+    int tap_cols; // > 0: the ci axis of the tiles is the flat (tap, channel) list with tap_cols = cin rounded up to 4 columns per tap
+                  // (the image stem: 16 taps x 4 channels per 64 columns; cin = 80 at 7x7: 62 tiles instead of 49 x 2 half-empty ones)
     unsigned x_bytes, y_bytes;   // extents of x / dy from their base pointers (buffer resources)
     // conv_wgrad3x3_kernel, batched form (blockIdx.z = problem): several dY / dW pairs against ONE x (the first layers of the
     // CenterHead branches all read the shared map); nbatch == 0: the single pair dy / dw
@@ -61,7 +62,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     const int tco = bid % a.tiles_co; bid /= a.tiles_co;
     // tap_cols: blockIdx enumerates groups of BN / 4 taps instead of (ci tile, tap); a thread's float4 of staged columns is
     // the 4 channels of ONE tap, so its tap (and whether it exists) is fixed for the whole kernel
-    const int tap = a.tap_cols ? tci * (BN / 4) + (int)(threadIdx.x % (BN / 4)) : bid;
+    const int gcol4 = tci * BN + (int)(threadIdx.x % (BN / 4)) * 4;          // tap_cols: first of this thread's 4 staged columns
+    const int tap = a.tap_cols ? gcol4 / a.tap_cols : bid;
     const bool tap_ok = tap < a.taps;
     const int th = tap / a.kw, tw = tap - th * a.kw;
     const int co0 = tco * BM, ci0 = a.tap_cols ? 0 : tci * BN;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     // fall outside the image).  Channel tails are loaded as they come: they only reach discarded rows / columns.
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)a.y_bytes, 0x00020000);
-    const unsigned x_c = (unsigned)(a.x_coff + (a.tap_cols ? 0 : ci0 + bc4)) * 4u, y_c = (unsigned)(a.y_coff + co0 + ac4) * 4u;
+    const unsigned x_c = (unsigned)(a.x_coff + (a.tap_cols ? gcol4 - tap * a.tap_cols : ci0 + bc4)) * 4u, y_c = (unsigned)(a.y_coff + co0 + ac4) * 4u;
     // (image, oy, ox) of the first pixel of the stage being loaded, advanced by STAGE pixels per stage
     int s_img = pix_begin / hw;
     int s_oy = (pix_begin - s_img * hw) / a.out_w;
@@ -179,8 +181,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
             const int col = wn * (BN / 2) + n * 32 + l32;                 // column of the workgroup tile
-            const int ci = a.tap_cols ? (col & 3) : ci0 + col;
-            const int otap = a.tap_cols ? tci * (BN / 4) + (col >> 2) : tap;
+            const int gcol = tci * BN + col;
+            const int otap = a.tap_cols ? gcol / a.tap_cols : tap;
+            const int ci = a.tap_cols ? gcol - otap * a.tap_cols : ci0 + col;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = co0 + wm * (BM / 2) + m * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
@@ -516,11 +519,18 @@ int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a, int tile_overri
         a.wm = a.wn = 1;
     } else if (tile_override > 0) { a.wm = ((tile_override - 1) >> 1) ? 2 : 1; a.wn = ((tile_override - 1) & 1) ? 2 : 1; }
     a.taps = d->kh * d->kw;
-    a.tap_cols = (!all_taps && d->cin <= 4 && d->x_ld == 4 && d->x_coff == 0 && a.taps > 1) ? 1 : 0;   // the 3-channel image stem
+    // flat (tap, channel) columns when that needs fewer 64-column tiles than one tile row per tap: the 3-channel image stem (x_ld 4),
+    // cin = 80 / 160 / 320 with 7x7 or strided 3x3 kernels
+    {
+        const int cpt = (d->cin + 3) / 4 * 4;
+        const bool can = !all_taps && a.taps > 1 && d->x_ld % 4 == 0 && d->x_coff % 4 == 0 && d->x_coff + cpt <= d->x_ld;
+        const long long flat = cdiv((long long)a.taps * cpt, 64), per_tap = (long long)a.taps * cdiv(d->cin, 64 * a.wn) * a.wn;
+        a.tap_cols = (can && flat * 10 < per_tap * 9) ? cpt : 0;
+    }
     if (a.tap_cols) a.wn = 1;
     const int stage_pix = 8192 / (64 * a.wm + 64 * a.wn) >= 64 ? 64 : 32;
     a.tiles_co = cdiv(d->cout, 64 * a.wm);
-    a.tiles_ci = a.tap_cols ? cdiv(a.taps, 16 * a.wn) : cdiv(d->cin, 64 * a.wn);
+    a.tiles_ci = a.tap_cols ? cdiv((long long)a.taps * a.tap_cols, 64 * a.wn) : cdiv(d->cin, 64 * a.wn);
     a.pix_total = (int)pix;
     const long long tiles = (long long)a.tiles_co * a.tiles_ci * (a.tap_cols ? 1 : a.taps);
     SGV3D_REQUIRE(tiles < (1ll << 31), "conv2d_backward_weight: too many tiles");
