@@ -449,7 +449,8 @@ int sgv3d_centerhead_branches_forward_bf16x(int batch, int h, int w, int cin, in
                                             const int32_t *out_begin, float *out, void *stream);
 
 /* Tools / tests: select_plain(1) runs the single-role variant of the bf16 head kernel (4 waves, phases of a branch one after
- * the other; bitwise the same results) instead of the warp-specialised default; debug_stamps(buf) makes workgroup 0 of the
+ * the other), select_plain(3) the ping-pong variant (two groups of waves half a period apart) instead of the warp-specialised
+ * default (0); all three give bitwise the same results; debug_stamps(buf) makes workgroup 0 of the
  * single-role variant write 4 * num_branches + 2 cycle-counter stamps into the device buffer (NULL switches it off). */
 void sgv3d_centerhead_bf16_select_plain(int plain);
 void sgv3d_centerhead_bf16_debug_stamps(void *buf);
