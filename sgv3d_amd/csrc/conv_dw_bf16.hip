@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM =
 // Same arithmetic as the two launches (f32 accumulation in the same k order, the middle map rounded to bf16 once): bitwise the
 // result of sgv3d_conv_dw_bf16_forward twice.
 __global__ __launch_bounds__(256, 3) void conv_dw_bf16_pair_kernel(const DwArgs a) {
-    constexpr int WM = 1, WN = 4, MT = 2;
+    constexpr int WM = 1, MT = 2;                             // (four waves side by side along the 256 channels)
     constexpr int WROWS = 32 * MT, BM = WROWS * WM;
     constexpr int A_LD = BM / 32;
     constexpr int kBufB = BM * kRowB;
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, 3) void conv_dw_bf16_pair_kernel(const DwArgs 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *const mid = smem + kRegion0;                         // [4 k-chunks][64 pixels][128 B]: the first layer's tile as bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = 0;
+    [[maybe_unused]] const int wm = 0;
     const int wn = __builtin_amdgcn_readfirstlane(wave);
     const int lr = lane & 31, lh = lane >> 5;
     const int ntiles = a.tiles_m;
@@ -416,7 +416,8 @@ __global__ __launch_bounds__(256, 3) void conv_dw_bf16_pair_kernel(const DwArgs 
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
     const int tm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int m0 = tm * BM, n0 = 0;
+    [[maybe_unused]] const int n0 = 0;
+    const int m0 = tm * BM;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.w_bytes, 0x00020000);
     const int c8 = tid & 7, r0 = tid >> 3;
