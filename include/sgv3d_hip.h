@@ -520,6 +520,14 @@ size_t sgv3d_conv_dw_bf16_weight_bytes(int cout, int cin, int kh, int kw);
 int sgv3d_conv_dw_bf16_pack_weight(const float *w, int cout, int cin_w, int cin, int kh, int kw, void *w_packed, void *stream);
 int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *desc /*host*/, const void *x, const void *w_packed, const float *scale,
                                const float *bias, const void *residual, void *y, void *stream);
+/* The same layer with the k loop split over desc.split_k workgroups per tile (NORMAL mode; split_k <= ceil(kh kw cin / 64)): for maps
+ * whose tiles do not fill 256 CUs.  Partial tiles go to `workspace` (sgv3d_conv_dw_bf16_workspace_bytes(desc) bytes, 16-B aligned, f32
+ * [split_k][M][cout]), a second kernel adds them in split order and runs the epilogue: deterministic, the k sum associated per split
+ * (differs from split_k = 1 by f32 rounding of the partial sums only).  split_k <= 1: identical to sgv3d_conv_dw_bf16_forward. */
+size_t sgv3d_conv_dw_bf16_workspace_bytes(const sgv3d_conv_desc *desc /*host*/);
+int sgv3d_conv_dw_bf16_forward_splitk(const sgv3d_conv_desc *desc /*host*/, const void *x, const void *w_packed, const float *scale,
+                                      const float *bias, const void *residual, void *y, void *workspace, size_t workspace_bytes,
+                                      void *stream);
 
 /* Two layers in one launch (conv_dw_bf16_pair_kernel): conv A = desc (k x k, any stride / dilation, cout == 256, folded BN + ReLU per
  * desc.relu) followed by conv B = 1x1 over those 256 channels with cout2 % 256 == 0 outputs, folded BN, residual and ReLU -- conv2 +

@@ -78,6 +78,8 @@ _PROTOS = {
     "sgv3d_conv_dw_bf16_weight_bytes": (c_size_t, [c_int] * 4),
     "sgv3d_conv_dw_bf16_pack_weight": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p, c_void_p]),
     "sgv3d_conv_dw_bf16_forward": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 7),
+    "sgv3d_conv_dw_bf16_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "sgv3d_conv_dw_bf16_forward_splitk": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 7 + [c_size_t, c_void_p]),
     "sgv3d_conv_dw_bf16_pair_forward": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4 + [c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sgv3d_conv_winograd_weight_floats": (c_size_t, [c_int, c_int]),
     "sgv3d_conv_winograd_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -56,6 +56,8 @@ struct DwArgs {
     int tiles_m, tiles_n;
     int bpt, nblk, nch, ksteps;   // 32-channel blocks per tap = cin / 32, nblk = kh kw bpt, nch = ceil(nblk / 2) chunks of 64 k, ksteps = 4 nch
     unsigned x_bytes, w_bytes, res_bytes, y_bytes;
+    int split;                 // SPLIT instantiation: workgroups per tile along k (gridDim.y)
+    float *ws;                 // [split][M][N] partial sums
     // conv_dw_bf16_pair_kernel only: the 1x1 convolution that follows (K2 = N channels of the first one, N2 outputs)
     const void *w2;            // packed fragments of the second layer
     const float *scale2, *bias2;
@@ -83,7 +85,9 @@ __global__ __launch_bounds__(64) void dw_pack_kernel(const float *__restrict__ w
 }
 
 // NTAIL: N is not a multiple of the tile's 64 WN columns -- some waves (or half-waves) of the last column tile own no channel
-template <int WM, int WN, int MT, bool NTAIL>
+// SPLIT: blockIdx.y owns a range of the 64-k chunks and stores raw f32 partial sums to a.ws [split][M][N] (dw_splitk_reduce_kernel adds
+// them in split order and runs the epilogue) -- for the maps whose tiles do not fill the chip (cfg-5 at batch 1: 82 - 162 workgroups)
+template <int WM, int WN, int MT, bool NTAIL, bool SPLIT = false>
 __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM == 2 ? 3 : 2) void conv_dw_bf16_kernel(const DwArgs a) {
     static_assert(WM * WN == 4 && (MT == 2 || MT == 4), "four waves, 64 or 128 pixels per wave");
     constexpr int WROWS = 32 * MT;                           // pixels per wave
@@ -158,7 +162,20 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM =
     // belong to the next tap when a tap has an odd number of blocks): tap offset, tap coordinates and "past the end" are
     // per-half values selected per lane.  Past the last chunk every lane's request is out of range and returns zeros without
     // touching memory -- the steady-state loop stays branch-free, which keeps the compiler's vmcnt counts exact.
-    int ld_b = 0, ld_kh = 0, ld_kw = 0, ld_cb = 0;
+    // this workgroup's chunks [c_begin, c_end) (all of them without SPLIT)
+    int c_begin = 0, c_end = a.nch;
+    if constexpr (SPLIT) {
+        c_begin = (int)((unsigned)a.nch * blockIdx.y / (unsigned)a.split);
+        c_end = (int)((unsigned)a.nch * (blockIdx.y + 1) / (unsigned)a.split);
+    }
+    const int nblk_end = SPLIT ? min(a.nblk, 2 * c_end) : a.nblk;
+    int ld_b = 2 * c_begin, ld_kh = 0, ld_kw = 0, ld_cb = 0;
+    if constexpr (SPLIT) {
+        const int tap0 = ld_b / a.bpt;
+        ld_cb = ld_b - tap0 * a.bpt;
+        ld_kh = tap0 / a.kw;
+        ld_kw = tap0 - ld_kh * a.kw;
+    }
     const bool half1 = c8 >= 4;
 #define DW_LOAD_A(R)                                                                                       \
     do {                                                                                                   \
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM =
         int kh1_ = ld_kh, kw1_ = ld_kw, cb1_ = ld_cb + 1;                                                  \
         if (cb1_ == a.bpt) { cb1_ = 0; if (++kw1_ == a.kw) { kw1_ = 0; ++kh1_; } }                         \
         const int dy0_ = ld_kh * a.dil, dx0_ = ld_kw * a.dil, dy1_ = kh1_ * a.dil, dx1_ = kw1_ * a.dil;    \
-        const bool dead0_ = ld_b >= a.nblk, dead1_ = ld_b + 1 >= a.nblk;                                   \
+        const bool dead0_ = ld_b >= nblk_end, dead1_ = ld_b + 1 >= nblk_end;                               \
         if (plain) {                                                                                       \
             const bool dead_ = half1 ? dead1_ : dead0_;                                                    \
             const int toff_ = ld_cb * 64;             /* one tap: the two blocks are consecutive channels */ \
@@ -258,14 +275,14 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM =
         DW_LOAD_A(ra);
         DW_SB();
 #pragma unroll
-        for (int s = 0; s < 4; ++s) DW_LOAD_W(0, s);
+        for (int s = 0; s < 4; ++s) DW_LOAD_W(c_begin, s);
         DW_SB();
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) *reinterpret_cast<u32x4 *>(st_ptr + i * 32 * kRowB) = rp[i];
     }
     DW_SB();
     __syncthreads();
-    const int last = a.nch - 1;
+    const int last = c_end - c_begin - 1;
     for (int c = 0; c < last; ++c) {
         const int buf = c & 1;
         DW_STORE_A(buf ^ 1);                            // chunk c + 1, requested one iteration ago (the 8 fragment loads behind it stay in flight)
@@ -276,7 +293,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM =
         for (int s = 0; s < 4; ++s) {
             DW_MFMA_STEP(buf, s);
             DW_SB();
-            DW_LOAD_W(c + 1, s);                        // into the fragment registers this k-step has just used
+            DW_LOAD_W(c_begin + c + 1, s);              // into the fragment registers this k-step has just used
             DW_SB();
         }
         __syncthreads();
@@ -289,7 +306,8 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM =
         for (int s = 0; s < 4; ++s) {
             DW_MFMA_STEP(buf, s);
             DW_SB();
-            if constexpr (MT == 2) {
+            if constexpr (SPLIT) {
+            } else if constexpr (MT == 2) {
                 DW_FETCH_RES(s >> 1, 0, s & 1);
                 DW_FETCH_RES(s >> 1, 1, s & 1);
             } else {
@@ -301,6 +319,25 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM =
     }
     DW_SB();
     __syncthreads();                                    // the epilogue stage reuses the activation buffers
+    if constexpr (SPLIT) {
+        // raw partial sums, [split][M][N] f32: a lane holds 4 consecutive channels of its pixel per register quad -- 16-byte stores
+        float *const ws = a.ws + (size_t)blockIdx.y * a.M * a.N;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int row = m0 + wm * WROWS + mt * 32 + lr;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = n0 + wn * 64 + nt * 32 + 8 * g + 4 * lh;
+                    if (row < a.M && ch < a.N) {
+                        const f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                        *reinterpret_cast<f32x4 *>(ws + (size_t)row * a.N + ch) = v;
+                    }
+                }
+            }
+        return;
+    }
     if constexpr (MT == 4) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -456,6 +493,7 @@ __global__ __launch_bounds__(256, 3) void conv_dw_bf16_pair_kernel(const DwArgs 
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+    const int nblk_end = a.nblk;
     int ld_b = 0, ld_kh = 0, ld_kw = 0, ld_cb = 0;
     const bool half1 = c8 >= 4;
     // ---- phase 1: the k x k layer (the loop of conv_dw_bf16_kernel<1, 4, 2>) -------------------------------------------------
@@ -640,7 +678,41 @@ __global__ __launch_bounds__(256, 3) void conv_dw_bf16_pair_kernel(const DwArgs 
 #undef DW_MFMA
 #undef DW_READ_A
 
-template <int WM, int WN, int MT, bool NTAIL>
+// split-K epilogue: sums the partial tiles in split order, then the epilogue of the main kernel (scale / shift, residual, ReLU on the
+// rounded value, bf16) -- one thread per 8 channels of a pixel
+__global__ __launch_bounds__(256) void dw_splitk_reduce_kernel(const DwArgs a) {
+    const int nq = a.N >> 3;
+    const long long total = (long long)a.M * nq;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int row = (int)(i / nq), ch = (int)(i - (long long)row * nq) * 8;
+    const float *p = a.ws + (size_t)row * a.N + ch;
+    const size_t plane = (size_t)a.M * a.N;
+    f32x4 v0 = *reinterpret_cast<const f32x4 *>(p), v1 = *reinterpret_cast<const f32x4 *>(p + 4);
+    for (int s = 1; s < a.split; ++s) {
+        v0 += *reinterpret_cast<const f32x4 *>(p + s * plane);
+        v1 += *reinterpret_cast<const f32x4 *>(p + s * plane + 4);
+    }
+    if (a.scale) { v0 = v0 * *reinterpret_cast<const f32x4 *>(a.scale + ch); v1 = v1 * *reinterpret_cast<const f32x4 *>(a.scale + ch + 4); }
+    if (a.bias) { v0 += *reinterpret_cast<const f32x4 *>(a.bias + ch); v1 += *reinterpret_cast<const f32x4 *>(a.bias + ch + 4); }
+    if (a.res) {
+        const bf16x8 rq = *reinterpret_cast<const bf16x8 *>(static_cast<const __bf16 *>(a.res) + (size_t)row * a.res_ld + ch);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v0[k] += (float)rq[k]; v1[k] += (float)rq[4 + k]; }
+    }
+    const bf16x4 o0 = __builtin_convertvector(v0, bf16x4), o1 = __builtin_convertvector(v1, bf16x4);
+    u32x4 o = __builtin_bit_cast(u32x4, __builtin_shufflevector(o0, o1, 0, 1, 2, 3, 4, 5, 6, 7));
+    const unsigned floor2 = a.relu ? 0u : 0x80008000u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned d_;
+        asm("v_pk_max_i16 %0, %1, %2" : "=v"(d_) : "v"(o[k]), "v"(floor2));
+        o[k] = d_;
+    }
+    *reinterpret_cast<u32x4 *>(static_cast<__bf16 *>(a.y) + (size_t)row * a.y_ld + a.y_coff + ch) = o;
+}
+
+template <int WM, int WN, int MT, bool NTAIL, bool SPLIT>
 int launch_dw_t(const DwArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * MT * WM, BN = 64 * WN;
     DwArgs a = a0;
@@ -649,15 +721,22 @@ int launch_dw_t(const DwArgs &a0, hipStream_t st) {
     constexpr size_t tiles = 2 * (size_t)BM * kRowB, stage = sizeof(float) * 4 * 32 * kStageLd;
     constexpr size_t lds = tiles > stage ? tiles : stage;
     static PerDeviceSize lds_set;
-    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_dw_bf16_kernel<WM, WN, MT, NTAIL>), lds, lds_set))
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT>), lds, lds_set))
         return fail(SGV3D_ELAUNCH, "conv_dw_bf16: cannot raise the dynamic LDS limit to %zu", lds);
-    hipLaunchKernelGGL((conv_dw_bf16_kernel<WM, WN, MT, NTAIL>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT>), dim3(a.tiles_m * a.tiles_n, SPLIT ? a.split : 1), dim3(256), lds, st, a);
+    if constexpr (SPLIT) {
+        if (int rc = check_launch("conv_dw_bf16_kernel")) return rc;
+        hipLaunchKernelGGL(dw_splitk_reduce_kernel, dim3((unsigned)cdiv((long long)a.M * (a.N >> 3), 256)), dim3(256), 0, st, a);
+        return check_launch("dw_splitk_reduce_kernel");
+    }
     return check_launch("conv_dw_bf16_kernel");
 }
 
 template <int WM, int WN, int MT>
 int launch_dw(const DwArgs &a, hipStream_t st) {
-    return a.N % (64 * WN) == 0 ? launch_dw_t<WM, WN, MT, false>(a, st) : launch_dw_t<WM, WN, MT, true>(a, st);
+    if (a.split > 1)
+        return a.N % (64 * WN) == 0 ? launch_dw_t<WM, WN, MT, false, true>(a, st) : launch_dw_t<WM, WN, MT, true, true>(a, st);
+    return a.N % (64 * WN) == 0 ? launch_dw_t<WM, WN, MT, false, false>(a, st) : launch_dw_t<WM, WN, MT, true, false>(a, st);
 }
 
 }  // namespace
@@ -675,11 +754,27 @@ extern "C" int sgv3d_conv_dw_bf16_pack_weight(const float *w, int cout, int cin_
     return check_launch("dw_pack_kernel");
 }
 
-extern "C" int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *d, const void *x, const void *w_packed, const float *scale,
-                                          const float *bias, const void *residual, void *y, void *stream) {
+// f32 partial tiles of a split-K launch: [split_k][M][cout]
+extern "C" size_t sgv3d_conv_dw_bf16_workspace_bytes(const sgv3d_conv_desc *d) {
+    if (!d || d->split_k <= 1 || d->batch <= 0 || d->out_h <= 0 || d->out_w <= 0 || d->cout <= 0) return 0;
+    return (size_t)d->split_k * d->batch * d->out_h * d->out_w * d->cout * sizeof(float);
+}
+
+extern "C" int sgv3d_conv_dw_bf16_forward_splitk(const sgv3d_conv_desc *d, const void *x, const void *w_packed, const float *scale,
+                                                 const float *bias, const void *residual, void *y, void *workspace,
+                                                 size_t workspace_bytes, void *stream) {
     SGV3D_REQUIRE(d && x && w_packed && y, "conv_dw_bf16: null pointer");
     const bool deconv = d->mode == SGV3D_CONV_DECONV;
-    SGV3D_REQUIRE((d->mode == SGV3D_CONV_NORMAL || deconv) && d->split_k <= 1, "conv_dw_bf16: NORMAL / DECONV mode without split-K only");
+    SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL || deconv, "conv_dw_bf16: NORMAL / DECONV mode only");
+    const int split = d->split_k > 1 ? d->split_k : 1;
+    if (split > 1) {
+        SGV3D_REQUIRE(!deconv, "conv_dw_bf16: split-K covers NORMAL mode only");
+        SGV3D_REQUIRE(d->kh > 0 && d->kw > 0 && d->cin > 0 && split <= cdiv(d->kh * d->kw * (d->cin / 32), 2),
+                      "conv_dw_bf16: split_k %d exceeds the layer's k chunks of 64", split);
+        const size_t need = sgv3d_conv_dw_bf16_workspace_bytes(d);
+        if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
+            return fail(SGV3D_ENOSPACE, "conv_dw_bf16: split-K needs %zu B of 16-B aligned workspace (got %zu)", need, workspace_bytes);
+    }
     SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0 &&
                       d->dil > 0 && d->pad >= 0, "conv_dw_bf16: non-positive dimension");
     if (deconv) {
@@ -723,6 +818,7 @@ extern "C" int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *d, const void *
     a.tiles_m = a.tiles_n = 0;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.res_bytes = residual ? (unsigned)(M * d->res_ld * 2) : 0u;
     a.y_bytes = (unsigned)yb;
+    a.split = split; a.ws = static_cast<float *>(workspace);
     hipStream_t st = as_stream(stream);
     switch (d->tile) {
         case SGV3D_TILE_DW_64x256: return launch_dw<1, 4, 2>(a, st);
@@ -732,6 +828,12 @@ extern "C" int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *d, const void *
         case SGV3D_TILE_DW_256x128: return launch_dw<2, 2, 4>(a, st);
         default: return fail(SGV3D_EINVAL, "conv_dw_bf16: desc.tile must be one of SGV3D_TILE_DW_* (got %d)", d->tile);
     }
+}
+
+extern "C" int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *d, const void *x, const void *w_packed, const float *scale,
+                                          const float *bias, const void *residual, void *y, void *stream) {
+    SGV3D_REQUIRE(d && d->split_k <= 1, "conv_dw_bf16: split-K takes a workspace (sgv3d_conv_dw_bf16_forward_splitk)");
+    return sgv3d_conv_dw_bf16_forward_splitk(d, x, w_packed, scale, bias, residual, y, nullptr, 0, stream);
 }
 
 // conv A (k x k, 256 outputs, folded BN + ReLU as desc says) followed by conv B (1x1 over those 256 channels, cout2 outputs,

@@ -137,6 +137,7 @@ PATCH_BF16 = _os.environ.get("SGV3D_PATCH_BF16", "1") != "0"
 # channels per workgroup 64x256 / 128x128 / 256x64 (64 pixels per wave) and 128x256 / 256x128 (128 pixels per wave)
 DW_TILES = (31, 32, 33, 34, 35)
 DW_BF16 = _os.environ.get("SGV3D_DW_BF16", "1") != "0"   # 0: never a candidate
+DW_SPLIT_K = _os.environ.get("SGV3D_DW_SPLITK", "1") != "0"   # 0: the direct-weight kernel is never split along k
 
 
 class prof:
@@ -488,7 +489,7 @@ class PackedConv:
 
     def _launch(self, lib, d, x, residual, gate, out, io=0):
         ws, nws = None, 0
-        if d.split_k > 1:
+        if d.split_k > 1 and d.tile not in DW_TILES:
             nws = lib.sgv3d_conv2d_workspace_bytes(ctypes.byref(d))
             ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
         if d.tile == TILE_PATCH:
@@ -499,9 +500,15 @@ class PackedConv:
                                                         _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
                                                         out.data_ptr(), int(io), int(d.split_k), _lib.ptr(ws), nws, _st(x))
         if d.tile in DW_TILES:
-            if not self._dw_eligible(d, gate, io) or d.split_k > 1:
+            if not self._dw_eligible(d, gate, io) or (d.split_k > 1 and d.mode != CONV_NORMAL):
                 raise _lib.SGV3DError("the bf16 direct-weight kernel covers layers with cin % 32 == 0, cout % 8 == 0 and bf16 tensors in "
-                                      "and out (NHWC), no gate, no split-K")
+                                      "and out (NHWC), no gate; split-K in NORMAL mode only")
+            if d.split_k > 1:
+                nws = lib.sgv3d_conv_dw_bf16_workspace_bytes(ctypes.byref(d))
+                ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+                return lib.sgv3d_conv_dw_bf16_forward_splitk(ctypes.byref(d), x.data_ptr(), self._dw_weights().data_ptr(),
+                                                             _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(),
+                                                             ws.data_ptr(), nws, _st(x))
             return lib.sgv3d_conv_dw_bf16_forward(ctypes.byref(d), x.data_ptr(), self._dw_weights().data_ptr(), _lib.ptr(self.scale),
                                                   _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(), _st(x))
         if d.tile in WINO4_TILES:
@@ -613,8 +620,15 @@ class PackedConv:
                 if t == TILE_PATCH:
                     nk = self.cin // 32     # stages of 32 input channels; >= 2 per split
                     wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 32) * -(-gemm_n // 64)
-                if t == TILE_WINO_RES or t in WINO4_TILES or t in DW_TILES:
+                if t in DW_TILES:
+                    nk = -(-(self.kh * self.kw * (self.cin // 32)) // 2)      # chunks of 64 k; >= 4 per split
+                    bm, bn = {31: (64, 256), 32: (128, 128), 33: (256, 64), 34: (128, 256), 35: (256, 128)}[t]
+                    wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
+                if t == TILE_WINO_RES or t in WINO4_TILES or (t in DW_TILES and (d.mode != CONV_NORMAL or not DW_SPLIT_K)):
                     splits = (1,)
+                elif t in DW_TILES:
+                    splits = (fixed_split,) if fixed_split else \
+                        [1] + [s for s in (2, 3, 4, 6, 8) if SPLIT_K and nk // s >= 4 and wgs < 384 and wgs * s <= 1024]
                 elif t == TILE_PATCH and not fixed_split and SPLIT_K:
                     splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 2 and wgs * s <= 1024]
                 elif fixed_split:

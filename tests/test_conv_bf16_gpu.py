@@ -494,6 +494,50 @@ def test_bf16_direct_weight_conv_pair(bf16_mode, shape):
     assert float((y.float().permute(0, 3, 1, 2).cpu().double() - ref).abs().max()) <= 2.0 ** -6 * scale   # (+ rounding flips of the middle map)
 
 
+@pytest.mark.parametrize("shape", [
+    # B, cin, H, W, cout, k, stride, pad, dil, residual, split
+    (1, 256, 17, 30, 256, 3, 1, 1, 1, True, 2),       # 36 chunks, two halves
+    (1, 512, 20, 24, 136, 3, 1, 6, 6, False, 5),      # dilated, cout not a multiple of 64, uneven chunk ranges (72 / 5)
+    (1, 96, 40, 56, 160, 7, 2, 3, 1, False, 8),       # 147 blocks -> 74 chunks (the last half dead); ranges start inside a tap
+    (2, 160, 13, 13, 320, 3, 2, 1, 1, False, 3),      # 2.5 chunks per tap: split boundaries in the middle of a tap
+    (1, 2048, 9, 11, 512, 1, 1, 0, 1, True, 8),       # 1x1 (the plain gather), 32 chunks
+    (1, 64, 12, 9, 64, 3, 1, 1, 1, True, 9),          # one chunk per workgroup (split == chunks)
+])
+@pytest.mark.parametrize("tile", [31, 32, 33, 34, 35])
+def test_bf16_direct_weight_conv_split_k(bf16_mode, shape, tile):
+    """sgv3d_conv_dw_bf16_forward_splitk: the k loop over `split` workgroups per tile, partial tiles summed in split order by the
+    reduce kernel which also runs the epilogue.  Against float64 on the bf16-rounded operands, within one bf16 ulp of the unsplit
+    kernel (the f32 partial sums associate differently), bitwise repeatable, strided in / out tensors."""
+    B, cin, H, W, cout, k, stride, pad, dil, with_res, split = shape
+    g = torch.Generator().manual_seed(cin * 5 + cout + k + split)
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16()
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    conv = hip_ops.PackedConv(w.to(DEV), stride=stride, pad=pad, dil=dil, scale=sc.to(DEV), shift=sh.to(DEV), relu=True)
+    oh, ow = conv.out_hw(H, W)
+    res = torch.randn(B, cout, oh, ow, generator=g).bfloat16() if with_res else None
+    ref = F.conv2d(x.double(), w.bfloat16().double(), None, stride, pad, dil)
+    ref = ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    if res is not None:
+        ref = ref + res.double()
+    ref = ref.clamp_min(0)
+    scale = max(1.0, float(ref.abs().max()))
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rin = res.permute(0, 2, 3, 1).contiguous().to(DEV) if res is not None else None
+    y = conv(xin, residual=rin, tile=tile, split_k=split, out_dtype=torch.bfloat16)
+    err = float((y.float().permute(0, 3, 1, 2).cpu().double() - ref).abs().max())
+    assert err <= 2.0 ** -8 * scale, (err, scale)
+    y1 = conv(xin, residual=rin, tile=tile, split_k=1, out_dtype=torch.bfloat16)
+    assert float((y.float() - y1.float()).abs().max()) <= 2.0 ** -7 * scale
+    assert torch.equal(y, conv(xin, residual=rin, tile=tile, split_k=split, out_dtype=torch.bfloat16))
+    xw = torch.randn(B, H, W, cin + 24, generator=g).bfloat16().to(DEV)
+    xw[..., 16:16 + cin] = xin
+    wide = torch.full((B, oh, ow, cout + 16), 7.0, dtype=torch.bfloat16, device=DEV)
+    conv(xw, wide, x_coff=16, y_coff=8, residual=rin, tile=tile, split_k=split)
+    assert torch.equal(wide[..., 8:8 + cout], y)
+    assert float((wide[..., :8] - 7).abs().max()) == 0 and float((wide[..., 8 + cout:] - 7).abs().max()) == 0
+
+
 def test_bf16_direct_weight_conv_exact_on_small_integers(bf16_mode):
     g = torch.Generator().manual_seed(3)
     x = torch.randint(-3, 4, (2, 192, 12, 21), generator=g).float()
@@ -503,8 +547,9 @@ def test_bf16_direct_weight_conv_exact_on_small_integers(bf16_mode):
         ref = F.conv2d(x, w, None, 1, pad)                                  # integer sums below 2^24: exact in the f32 accumulators
         xin = x.bfloat16().permute(0, 2, 3, 1).contiguous().to(DEV)
         for tile in (31, 32, 33, 34, 35):
-            y = conv(xin, tile=tile, split_k=1, out_dtype=torch.bfloat16)
-            assert torch.equal(y.float().permute(0, 3, 1, 2).cpu(), ref.bfloat16().float())
+            for split in (1, 3):                                            # (exact partial sums: any association gives the same bits)
+                y = conv(xin, tile=tile, split_k=split, out_dtype=torch.bfloat16)
+                assert torch.equal(y.float().permute(0, 3, 1, 2).cpu(), ref.bfloat16().float())
 
 
 def test_bf16_direct_weight_conv_rejects_what_it_does_not_cover(bf16_mode):
@@ -514,7 +559,10 @@ def test_bf16_direct_weight_conv_rejects_what_it_does_not_cover(bf16_mode):
     with pytest.raises(_lib.SGV3DError):
         conv(x, tile=31, split_k=1)                                         # f32 tensors
     with pytest.raises(_lib.SGV3DError):
-        conv(x.bfloat16(), tile=31, split_k=2, out_dtype=torch.bfloat16)    # split-K
+        conv(x.bfloat16(), tile=31, split_k=10, out_dtype=torch.bfloat16)   # more splits than the 9 k-chunks of the layer
+    up = hip_ops.PackedConv(torch.randn(64, 32, 2, 2, device=DEV), stride=2, transposed=True)
+    with pytest.raises(_lib.SGV3DError):
+        up(x.bfloat16(), tile=31, split_k=2, out_dtype=torch.bfloat16)      # split-K of a transposed convolution
 
 
 def test_bf16_maxpool(bf16_mode):

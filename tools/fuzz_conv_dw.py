@@ -2,6 +2,7 @@
 """Random-shape parity fuzz of the bf16 direct-weight kernel (sgv3d_conv_dw_bf16_forward, host tiles 31-35, NORMAL and DECONV) and
 of the fused pair (sgv3d_conv_dw_bf16_pair_forward) against torch CPU fp64 on the bf16-rounded operands: kernel sizes 1-7,
 stride, dilation, padding beyond the kernel, channel counts with odd numbers of 32-channel blocks, BN fold / residual / ReLU,
+split-K,
 channel-slice input and output with guard channels (written buffers are checked around the slice).
 usage: fuzz_conv_dw.py [N=200] [seed=0]"""
 import os, random, sys
@@ -84,11 +85,15 @@ for it in range(N):
                 o = hip_ops.conv_pair_bf16(conv, conv2, xd, None if res is None else res.cuda())
                 out[..., y_coff:y_coff + cout] = o
             else:
-                conv(xd, out, x_coff=x_coff, y_coff=y_coff, residual=None if res is None else res.cuda(), tile=t, split_k=1)
+                split = 1
+                if kind == "conv" and rng.random() < 0.5:                   # split-K: any count up to the layer's 64-k chunks
+                    split = rng.randint(2, max(2, min(12, -(-(k * k * (cin // 32)) // 2))))
+                    split = min(split, -(-(k * k * (cin // 32)) // 2))
+                conv(xd, out, x_coff=x_coff, y_coff=y_coff, residual=None if res is None else res.cuda(), tile=t, split_k=split)
             launches += 1
         except Exception as e:
             bad += 1
-            print("EXC", desc, t, str(e)[:160])
+            print("EXC", desc, t, str(e)[:160], flush=True)
             continue
         got = out.float().cpu().double()
         err = (got[..., y_coff:y_coff + cout] - ref).abs().max().item()
@@ -96,6 +101,6 @@ for it in range(N):
         tol = (2.0 ** -6 if kind == "pair" else 2.0 ** -8) * scale_ref
         if err > tol or not guard_ok or not torch.isfinite(got).all():
             bad += 1
-            print("FAIL", desc, t, "err", err, "tol", tol, "guard", bool(guard_ok), dict(bn=use_bn, res=use_res, relu=use_relu, x_coff=x_coff, y_coff=y_coff))
+            print("FAIL", desc, t, "split", split if kind == "conv" else 1, "err", err, "tol", tol, "guard", bool(guard_ok), dict(bn=use_bn, res=use_res, relu=use_relu, x_coff=x_coff, y_coff=y_coff))
 torch.cuda.synchronize()
 print(f"fuzz done (direct-weight kernel): {N} shapes, {launches} launches, failures: {bad}")
