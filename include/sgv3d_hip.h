@@ -643,6 +643,10 @@ int sgv3d_conv2d_backward_weight_thin(const sgv3d_conv_desc *desc /*host*/, cons
 int sgv3d_zero_insert(int batch, int in_h, int in_w, int channels, int stride, int out_h, int out_w,
                       const float *x, float *y, void *stream);
 
+/* out [cin, cout, kh, kw] = w [cout, cin, kh, kw] with the taps rotated by 180 degrees and in / out swapped: the OIHW weights of the
+ * stride-1 convolution that computes a data gradient (one launch for torch's flip + transpose + contiguous). */
+int sgv3d_weight_rot180_transpose(const float *w, int cout, int cin, int kh, int kw, float *out, void *stream);
+
 /* One fused AdamW step (torch.optim.AdamW semantics, amsgrad off) over a flat fp32 bucket of n parameters:
  * the optimiser of the reference's configure_optimizers (exps/...:298-305).  grad is multiplied by grad_scale
  * first (1 / world size after a sum all-reduce).  step >= 1 is the step count after this update.  All four

@@ -14,7 +14,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, grad_slots
 from .hip_ops import ConvDesc, PackedConv, prof, _st
 
 __all__ = ['conv2d_backward_weight', 'conv2d_backward_weight_batched', 'conv2d_backward_data', 'zero_insert', 'conv2d', 'conv_transpose2d',
@@ -25,9 +25,17 @@ def _out_hw(h, w, k, stride, pad, dil):
     return ((h + 2 * pad - dil * (k[0] - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k[1] - 1) - 1) // stride + 1)
 
 
-def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, cout=None, x_coff=0, y_coff=0, split=0, tile=0):
+def _dw_buffer(out, shape, device):
+    if out is None:
+        return torch.empty(*shape, dtype=torch.float32, device=device)
+    assert tuple(out.shape) == tuple(shape) and out.is_contiguous() and out.dtype == torch.float32 and out.device == device
+    return out
+
+
+def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, cout=None, x_coff=0, y_coff=0, split=0, tile=0, out=None):
     """dW (OIHW [cout, cin, kh, kw]) of ``y = conv2d(x, W)`` for NHWC ``x`` [B, H, W, x_ld] and ``dy`` [B, OH, OW, y_ld];
-    channel windows [x_coff, x_coff + cin) / [y_coff, y_coff + cout) default to the whole tensors."""
+    channel windows [x_coff, x_coff + cin) / [y_coff, y_coff + cout) default to the whole tensors.  ``out``: a contiguous
+    f32 [cout, cin, kh, kw] tensor to write (a gradient slot of the flat buckets, grad_slots.claim)."""
     kh, kw = (kernel, kernel) if isinstance(kernel, int) else kernel
     B, H, W, x_ld = (int(v) for v in x.shape)
     _, OH, OW, y_ld = (int(v) for v in dy.shape)
@@ -45,7 +53,7 @@ def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, c
         # 1..4 output channels (the final layers of the CenterHead branches): the vector-ALU kernel, not an MFMA tile of padding
         nws = lib.sgv3d_conv2d_backward_weight_thin_workspace_bytes(ctypes.byref(d))
         ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
-        dw = torch.empty(cout, cin, kh, kw, dtype=torch.float32, device=x.device)
+        dw = _dw_buffer(out, (cout, cin, kh, kw), x.device)
         with torch.cuda.device(x.device), prof("conv_wgrad_thin", 2.0 * B * OH * OW * cout * cin * kh * kw):
             rc = lib.sgv3d_conv2d_backward_weight_thin(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nws, _st(x))
         _lib.check(rc, "sgv3d_conv2d_backward_weight_thin")
@@ -55,7 +63,7 @@ def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, c
         d.tile = int(tile)
     nws = lib.sgv3d_conv2d_backward_weight_workspace_bytes(ctypes.byref(d), int(split))
     ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
-    dw = torch.empty(cout, cin, kh, kw, dtype=torch.float32, device=x.device)
+    dw = _dw_buffer(out, (cout, cin, kh, kw), x.device)
     from . import hip_ops
     name = "conv_wgrad"
     if hip_ops.PROFILE_DETAIL:
@@ -67,7 +75,7 @@ def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, c
     return dw
 
 
-def conv2d_backward_weight_batched(x, dys, pad=1, *, cin=None, cout=None, split=0):
+def conv2d_backward_weight_batched(x, dys, pad=1, *, cin=None, cout=None, split=0, outs=None):
     """[dW_i] of n 3x3 / stride-1 convolutions that read the same NHWC ``x``: one launch of the all-taps kernel
     (sgv3d_conv2d_backward_weight_batched).  ``dys``: n contiguous NHWC tensors of one shape."""
     B, H, W, x_ld = (int(v) for v in x.shape)
@@ -89,7 +97,7 @@ def conv2d_backward_weight_batched(x, dys, pad=1, *, cin=None, cout=None, split=
     lib = _lib.load()
     nws = lib.sgv3d_conv2d_backward_weight_batched_workspace_bytes(ctypes.byref(d), n, int(split))
     ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
-    dws = [torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device) for _ in range(n)]
+    dws = [_dw_buffer(None if outs is None else outs[i], (cout, cin, 3, 3), x.device) for i in range(n)]
     dyp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dys])
     dwp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dws])
     with torch.cuda.device(x.device), prof("conv_wgrad", 2.0 * n * B * OH * OW * cout * cin * 9):
@@ -175,8 +183,21 @@ def zero_insert(x, stride, out_hw):
     return y
 
 
-def conv2d_backward_data(dy, weight, in_hw, stride=1, pad=0, dil=1):
-    """dX (NHWC [B, H, W, cin]) of ``y = conv2d(x, weight)``; ``weight`` OIHW, ``dy`` NHWC [B, OH, OW, cout(+padding to 4)]."""
+def _rot180_transpose(w):
+    """``w.flip(2, 3).transpose(0, 1).contiguous()`` of an OIHW f32 weight tensor in one launch."""
+    w = w.contiguous()
+    cout, cin, kh, kw = (int(v) for v in w.shape)
+    out = torch.empty(cin, cout, kh, kw, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.load().sgv3d_weight_rot180_transpose(w.data_ptr(), cout, cin, kh, kw, out.data_ptr(), _st(w))
+    _lib.check(rc, "sgv3d_weight_rot180_transpose")
+    return out
+
+
+def conv2d_backward_data(dy, weight, in_hw, stride=1, pad=0, dil=1, add_to=None):
+    """dX (NHWC [B, H, W, cin]) of ``y = conv2d(x, weight)``; ``weight`` OIHW, ``dy`` NHWC [B, OH, OW, cout(+padding to 4)].
+    ``add_to`` (stride 1 only): a tensor of dX's shape added in the convolution's epilogue (the sum of the data gradients of
+    several consumers of one map without separate add launches)."""
     cout, cin, kh, kw = (int(v) for v in weight.shape)
     H, W = in_hw
     assert kh == kw, "square kernels only (every layer of the model)"
@@ -188,10 +209,11 @@ def conv2d_backward_data(dy, weight, in_hw, stride=1, pad=0, dil=1):
         dx = PackedConv(weight.detach(), stride=stride, transposed=True, cin_pad=int(dy.shape[-1]))(dy)
         ph, pw = H - int(dx.shape[1]), W - int(dx.shape[2])
         return dx if ph == 0 and pw == 0 else torch.nn.functional.pad(dx, (0, 0, 0, pw, 0, ph))   # rows the conv never read
-    wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()          # [cin, cout, kh, kw], rotated by 180 degrees
+    wt = _rot180_transpose(weight.detach())                               # [cin, cout, kh, kw], rotated by 180 degrees
     conv = PackedConv(wt, stride=1, pad=dil * (kh - 1) - pad, dil=dil, cin_pad=int(dy.shape[-1]), pad_out=True)
     if stride == 1:
-        return conv(dy)
+        return conv(dy, residual=add_to)
+    assert add_to is None, "add_to: stride-1 layers only"
     if kh == 1 and pad == 0:
         return zero_insert(conv(dy), stride, (H, W))                      # 1x1: convolve at the coarse resolution
     if stride == 2 and dil == 1:
@@ -269,7 +291,7 @@ class _Conv2dNHWC(torch.autograd.Function):
             if int(dx.shape[-1]) != int(x.shape[-1]):
                 dx = torch.nn.functional.pad(dx, (0, int(x.shape[-1]) - int(dx.shape[-1])))
         if ctx.needs_input_grad[1]:
-            dw = conv2d_backward_weight(x, dy, (kh, kw), stride, pad, dil, cin=cin, cout=cout)
+            dw = conv2d_backward_weight(x, dy, (kh, kw), stride, pad, dil, cin=cin, cout=cout, out=grad_slots.claim(weight))
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 1, 2))
         return dx, dw, db, None, None, None
@@ -290,14 +312,13 @@ class _MultiConv2dNHWC(torch.autograd.Function):
         dys = [torch.zeros(x.shape[:3] + (cout,), dtype=x.dtype, device=x.device) if d is None else d.contiguous() for d in dys]
         dx = None
         if ctx.needs_input_grad[0]:
-            for d, w in zip(dys, weights):
-                g = conv2d_backward_data(d, w, (int(x.shape[1]), int(x.shape[2])), 1, 1, 1)
-                if int(g.shape[-1]) != int(x.shape[-1]):
-                    g = torch.nn.functional.pad(g, (0, int(x.shape[-1]) - int(g.shape[-1])))
-                dx = g if dx is None else dx.add_(g)
+            for d, w in zip(dys, weights):                # (the running sum rides in each convolution's residual epilogue)
+                dx = conv2d_backward_data(d, w, (int(x.shape[1]), int(x.shape[2])), 1, 1, 1, add_to=dx)
+            if int(dx.shape[-1]) != int(x.shape[-1]):
+                dx = torch.nn.functional.pad(dx, (0, int(x.shape[-1]) - int(dx.shape[-1])))
         dws = [None] * len(weights)
         if any(ctx.needs_input_grad[1:]):
-            dws = conv2d_backward_weight_batched(x, dys, 1, cin=cin, cout=cout)
+            dws = conv2d_backward_weight_batched(x, dys, 1, cin=cin, cout=cout, outs=[grad_slots.claim(w) for w in weights])
         return (dx, *dws)
 
 
@@ -338,7 +359,7 @@ class _ConvTranspose2dNHWC(torch.autograd.Function):
             if int(dx.shape[-1]) != int(x.shape[-1]):
                 dx = torch.nn.functional.pad(dx, (0, int(x.shape[-1]) - int(dx.shape[-1])))
         if ctx.needs_input_grad[1]:
-            dw = conv2d_backward_weight(dy, x, k, k, 0, 1, cin=cout, cout=cin)      # roles swapped: OIHW = [cin, cout, k, k]
+            dw = conv2d_backward_weight(dy, x, k, k, 0, 1, cin=cout, cout=cin, out=grad_slots.claim(weight))      # roles swapped: OIHW = [cin, cout, k, k]
         return dx, dw, None
 
 

@@ -70,28 +70,40 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs a) {
     }
 }
 
-// Sum of the per-range partials of channel c: 16 channels per block, 16 threads per channel over the range axis, the 16
-// slice sums added in slice order (fixed order); s0 / s1 valid in the threads with slice 0.
-__device__ __forceinline__ void sum_partials(const BnArgs &a, int c, int slice, double (*lds)[16][2], double &s0, double &s1) {
+// Sum of the per-range partials of channel c: kFinCh channels per block, 256 / kFinCh threads per channel over the range axis (a
+// 1024-range layer: 16 independent loads per thread, issued together), the slice sums added in slice order (fixed order);
+// s0 / s1 valid in the threads with slice 0.
+constexpr int kFinCh = 4, kFinSlices = 256 / kFinCh;
+
+__device__ __forceinline__ void sum_partials(const BnArgs &a, int c, int slice, double (*lds)[kFinCh][2], double &s0, double &s1) {
     double s = 0, q = 0;
-    if (c < a.channels)
-        for (int r = slice; r < a.ranges; r += 16) {
+    if (c < a.channels) {
+        int r = slice;
+        for (; r + 3 * kFinSlices < a.ranges; r += 4 * kFinSlices) {
+            double2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const double2 *>(a.partial + ((size_t)(r + u * kFinSlices) * a.channels + c) * 2);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += v[u].x; q += v[u].y; }
+        }
+        for (; r < a.ranges; r += kFinSlices) {
             const double2 v = *reinterpret_cast<const double2 *>(a.partial + ((size_t)r * a.channels + c) * 2);
             s += v.x;
             q += v.y;
         }
-    const int cl = threadIdx.x & 15;
+    }
+    const int cl = threadIdx.x % kFinCh;
     lds[slice][cl][0] = s;
     lds[slice][cl][1] = q;
     __syncthreads();
     s0 = s1 = 0;
     if (slice == 0)
-        for (int i = 0; i < 16; ++i) { s0 += lds[i][cl][0]; s1 += lds[i][cl][1]; }
+        for (int i = 0; i < kFinSlices; ++i) { s0 += lds[i][cl][0]; s1 += lds[i][cl][1]; }
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnArgs a) {
-    __shared__ double lds[16][16][2];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), slice = threadIdx.x >> 4;
+    __shared__ double lds[kFinSlices][kFinCh][2];
+    const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, slice = threadIdx.x / kFinCh;
     double s, q;
     sum_partials(a, c, slice, lds, s, q);
     if (slice != 0 || c >= a.channels) return;
@@ -180,8 +192,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnArgs a) {
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnArgs a) {
-    __shared__ double lds[16][16][2];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), slice = threadIdx.x >> 4;
+    __shared__ double lds[kFinSlices][kFinCh][2];
+    const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, slice = threadIdx.x / kFinCh;
     double sb, sg;
     sum_partials(a, c, slice, lds, sb, sg);
     if (slice != 0 || c >= a.channels) return;
@@ -276,7 +288,7 @@ extern "C" int sgv3d_batchnorm_train_forward(long long pixels, int channels, con
     hipStream_t s = as_stream(stream);
     bn_stats_kernel<<<dim3(cdiv(channels, 64), a.ranges), 256, 0, s>>>(a);
     if (int rc = check_launch("bn_stats_kernel")) return rc;
-    bn_finalize_kernel<<<cdiv(channels, 16), 256, 0, s>>>(a);
+    bn_finalize_kernel<<<cdiv(channels, kFinCh), 256, 0, s>>>(a);
     if (int rc = check_launch("bn_finalize_kernel")) return rc;
     bn_apply_kernel<<<stream_blocks(pixels * (channels / 4), channels / 4), 256, 0, s>>>(a);
     return check_launch("bn_apply_kernel");
@@ -301,7 +313,7 @@ extern "C" int sgv3d_batchnorm_train_backward(long long pixels, int channels, co
     hipStream_t s = as_stream(stream);
     bn_bwd_reduce_kernel<<<dim3(cdiv(channels, 64), a.ranges), 256, 0, s>>>(a);
     if (int rc = check_launch("bn_bwd_reduce_kernel")) return rc;
-    bn_bwd_finalize_kernel<<<cdiv(channels, 16), 256, 0, s>>>(a);
+    bn_bwd_finalize_kernel<<<cdiv(channels, kFinCh), 256, 0, s>>>(a);
     if (int rc = check_launch("bn_bwd_finalize_kernel")) return rc;
     bn_bwd_apply_kernel<<<stream_blocks(pixels * (channels / 4), channels / 4), 256, 0, s>>>(a);
     return check_launch("bn_bwd_apply_kernel");

@@ -169,7 +169,25 @@ __global__ __launch_bounds__(kT) void zero_f32_kernel(long long n4, float4 *__re
     if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// out[ci][co][t] = w[co][ci][taps - 1 - t]: the weights of the data-gradient convolution (flipped taps, in / out swapped)
+__global__ __launch_bounds__(kT) void weight_rot180_transpose_kernel(const float *__restrict__ w, int cout, int cin, int taps,
+                                                                     float *__restrict__ out) {
+    const int i = blockIdx.x * kT + threadIdx.x;
+    if (i >= cout * cin * taps) return;
+    const int t = i % taps, r = i / taps;
+    const int co = r % cout, ci = r / cout;
+    out[i] = w[((size_t)co * cin + ci) * taps + (taps - 1 - t)];
+}
+
 }  // namespace
+
+extern "C" int sgv3d_weight_rot180_transpose(const float *w, int cout, int cin, int kh, int kw, float *out, void *stream) {
+    SGV3D_REQUIRE(w && out && cout > 0 && cin > 0 && kh > 0 && kw > 0 && (long long)cout * cin * kh * kw < 0x7fffffffLL,
+                  "weight_rot180_transpose: bad argument");
+    hipLaunchKernelGGL(weight_rot180_transpose_kernel, dim3(cdiv((long long)cout * cin * kh * kw, kT)), dim3(kT), 0, as_stream(stream),
+                       w, cout, cin, kh * kw, out);
+    return check_launch("weight_rot180_transpose_kernel");
+}
 
 extern "C" int sgv3d_maxpool3x3s2_train_forward(int batch, int in_h, int in_w, int channels, const float *x, float *y,
                                                 unsigned char *argmax, void *stream) {

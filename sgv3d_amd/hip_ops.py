@@ -262,24 +262,16 @@ class PackedConv:
         k = self.cin if transposed else kh * kw * self.cin
         self.k_pad, self.cout_pad = pack_geometry(k, gemm_n)
         self.k_order = 1 if self.cin % 32 == 0 else 0      # channel-chunk-major k when possible
-        self.w = torch.empty(self.cout_pad, self.k_pad, dtype=torch.float32, device=device)
-        with torch.cuda.device(device):
-            rc = _lib.load().sgv3d_conv_pack_weight(w.data_ptr(), cout, cin, kh, kw, self.cin,
-                                                   1 if transposed else 0, self.k_order, self.w.data_ptr(),
-                                                   self.k_pad, self.cout_pad, _st(w))
-        _lib.check(rc, "sgv3d_conv_pack_weight")
         self.scale = None if scale is None else scale.detach().to(device=device, dtype=torch.float32).contiguous()
         self.shift = None if shift is None else shift.detach().to(device=device, dtype=torch.float32).contiguous()
-        # Winograd F(2x2,3x3) weights for the layers the second kernel covers
-        self.w_wino = None
-        if (WINOGRAD and not transposed and kh == 3 and kw == 3 and self.stride == 1 and self.dil == 1
-                and self.pad == 1 and self.cin % 8 == 0):
-            lib = _lib.load()
-            self.w_wino = torch.empty(lib.sgv3d_conv_winograd_weight_floats(cout, self.cin), dtype=torch.float32,
-                                      device=device)
-            with torch.cuda.device(device):
-                rc = lib.sgv3d_conv_winograd_pack_weight(w.data_ptr(), cout, cin, self.cin, self.w_wino.data_ptr(), _st(w))
-            _lib.check(rc, "sgv3d_conv_winograd_pack_weight")
+        # Every packed form of the weights (implicit GEMM, F(2x2) / F(4x4) Winograd, bf16 patch / direct-weight) is made on
+        # first use: a training step packs the current weights of every layer twice (forward, data gradient) and only
+        # needs the form its kernel choice reads.
+        self._w = self._w_wino = None
+        self.device = device
+        # Winograd F(2x2,3x3) covers the layer
+        self.wino_ok = bool(WINOGRAD and not transposed and kh == 3 and kw == 3 and self.stride == 1 and self.dil == 1
+                            and self.pad == 1 and self.cin % 8 == 0)
         self._keep = w  # the pack kernels read it asynchronously
         self._tile_cache = {}
         # bf16 mode: fragment-ordered bf16 weights for the patch kernel, packed on first use
@@ -288,11 +280,40 @@ class PackedConv:
         self.patch_ok = (not transposed and kh == 3 and kw == 3 and self.stride == 1 and self.dil == 1
                          and self.pad == 1 and self.cin % 32 == 0 and self.cout % 8 == 0 and self.cin == cin)
 
+    @property
+    def w(self):
+        """Weights packed for the implicit-GEMM kernels (sgv3d_conv_pack_weight), [cout_pad, k_pad] f32."""
+        if self._w is None:
+            src = self._keep
+            odim = 1 if self.transposed else 0
+            cout, cin = int(src.shape[odim]), int(src.shape[1 - odim])
+            self._w = torch.empty(self.cout_pad, self.k_pad, dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = _lib.load().sgv3d_conv_pack_weight(src.data_ptr(), cout, cin, int(src.shape[2]), int(src.shape[3]), self.cin,
+                                                       1 if self.transposed else 0, self.k_order, self._w.data_ptr(),
+                                                       self.k_pad, self.cout_pad, _st(src))
+            _lib.check(rc, "sgv3d_conv_pack_weight")
+        return self._w
+
+    @property
+    def w_wino(self):
+        """Winograd F(2x2,3x3) weights (sgv3d_conv_winograd_pack_weight), None when the layer is not covered."""
+        if self._w_wino is None and self.wino_ok:
+            lib = _lib.load()
+            src = self._keep
+            self._w_wino = torch.empty(lib.sgv3d_conv_winograd_weight_floats(self.cout, self.cin), dtype=torch.float32,
+                                       device=self.device)
+            with torch.cuda.device(self.device):
+                rc = lib.sgv3d_conv_winograd_pack_weight(src.data_ptr(), self.cout, int(src.shape[1]), self.cin,
+                                                         self._w_wino.data_ptr(), _st(src))
+            _lib.check(rc, "sgv3d_conv_winograd_pack_weight")
+        return self._w_wino
+
     def _bf16_weights(self):
         """bf16 copy of the packed implicit-GEMM weights (bf16-activation launches), made on first use."""
         if self.w_bf16 is None:
-            self.w_bf16 = torch.empty(self.cout_pad, self.k_pad, dtype=torch.bfloat16, device=self.w.device)
-            with torch.cuda.device(self.w.device):
+            self.w_bf16 = torch.empty(self.cout_pad, self.k_pad, dtype=torch.bfloat16, device=self.device)
+            with torch.cuda.device(self.device):
                 rc = _lib.load().sgv3d_conv_weight_to_bf16(self.w.data_ptr(), self.k_pad, self.cout_pad, self.w_bf16.data_ptr(), _st(self.w))
             _lib.check(rc, "sgv3d_conv_weight_to_bf16")
         return self.w_bf16
@@ -464,7 +485,7 @@ class PackedConv:
         """Deterministic choice without measurement: Winograd for the layers it covers once the map has
         enough tiles to occupy the chip (split over channel steps to reach ~2 workgroups per CU), else the
         implicit-GEMM tile of the cost model; explicit tile / split arguments win."""
-        if t == 0 and self.w_wino is not None and WINOGRAD and not MFMA_BF16 and d.out_h * d.out_w * d.batch >= 1024:
+        if t == 0 and self.wino_ok and WINOGRAD and not MFMA_BF16 and d.out_h * d.out_w * d.batch >= 1024:
             wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 16) * -(-gemm_n // 64)
             split = 1
             if not sk and SPLIT_K:
@@ -528,7 +549,7 @@ class PackedConv:
             finally:
                 d.tile, d.k_pad, d.cout_pad = host_tile, kp, cp
         if d.tile in (TILE_WINO, TILE_WINO_RES, TILE_WINO_HALF):
-            if self.w_wino is None:
+            if not self.wino_ok:
                 raise _lib.SGV3DError("this layer has no Winograd weights (needs 3x3 / stride 1 / pad 1 / cin % 8 == 0)")
             return lib.sgv3d_conv2d_winograd_forward(ctypes.byref(d), x.data_ptr(), self.w_wino.data_ptr(),
                                                      _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
@@ -589,7 +610,7 @@ class PackedConv:
             tiles += tuple(t + 20 for t in (1, 2, 3, 4) if gemm_n > (128 if t in (1, 3) else 64))   # more than one channel tile
         if MFMA_F32X3 == "auto" and not MFMA_BF16:
             tiles += (11, 12, 13, 14)
-        if self.w_wino is not None and WINOGRAD and not MFMA_BF16:
+        if self.wino_ok and WINOGRAD and not MFMA_BF16:
             tiles += (TILE_WINO,)
             if WINO_HALF:
                 tiles += (TILE_WINO_HALF,)
@@ -917,7 +938,7 @@ def centerhead_branches(x, first, w2, b2, out_begin, num_branches, out=None):
     x NHWC [B,H,W,ld]; first: PackedConv of the concatenated first layers (needs Winograd weights, hidden 64);
     w2 [sum_c,3,3,64]; b2 [sum_c]; out_begin int32 [nb+1] (device).  -> NCHW [B,sum_c,H,W]."""
     B, H, W, ld = (int(s) for s in x.shape)
-    assert x.is_contiguous() and first.w_wino is not None and first.cout == num_branches * 64
+    assert x.is_contiguous() and first.wino_ok and first.cout == num_branches * 64
     total = int(w2.shape[0])
     if out is None:
         out = torch.empty(B, total, H, W, dtype=torch.float32, device=x.device)

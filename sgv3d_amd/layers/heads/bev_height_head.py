@@ -188,7 +188,7 @@ class BEVHeightHead(HipModule):
             # bf16 matrix cores: both branch layers in one kernel, hidden maps in LDS as bf16
             out = hip_ops.centerhead_branches_bf16(shared, s['w1_bf16'], s['first'].scale, s['first'].shift, s['b2'],
                                                    s['out_begin'], s['nb'])
-        elif hip_ops.FUSED_HEAD and not hip_ops.MFMA_BF16 and s['first'].w_wino is not None and s['first'].cin <= 64 and s['hc'] == 64:
+        elif hip_ops.FUSED_HEAD and not hip_ops.MFMA_BF16 and s['first'].wino_ok and s['first'].cin <= 64 and s['hc'] == 64:
             if self._branch_path(s, shared) == 0:
                 # both branch layers in one kernel: the [nb,B,H,W,64] hidden maps stay on the chip
                 out = hip_ops.centerhead_branches(shared, s['first'], s['w2'], s['b2'], s['out_begin'], s['nb'])

@@ -3,10 +3,10 @@
 affine parameters and updates the module's running statistics like ``nn.BatchNorm2d`` in training mode."""
 import torch
 
-from . import _lib
+from . import _lib, grad_slots
 from .hip_ops import prof
 
-__all__ = ['batch_norm_act']
+__all__ = ['batch_norm_act', 'deferred_counters']
 
 
 def _ws(channels, device):
@@ -32,21 +32,26 @@ class _BatchNormAct(torch.autograd.Function):
                 _lib.ptr(running_var), float(momentum), float(eps), 1 if relu else 0, y.data_ptr(), mean.data_ptr(),
                 invstd.data_ptr(), ws.data_ptr(), nws, _lib.stream_handle(x.device))
         _lib.check(rc, "sgv3d_batchnorm_train_forward")
-        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd, bias)
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, mean, invstd = ctx.saved_tensors
+        x, y, weight, mean, invstd, bias = ctx.saved_tensors
         dy = dy.contiguous()
         C = int(x.shape[-1])
         pixels = x.numel() // C
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[1]) else None
-        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        # (the affine parameters' slots in the flat gradient buckets when they are free, grad_slots)
+        dgamma = grad_slots.claim(weight) if ctx.needs_input_grad[2] else None
+        dbeta = grad_slots.claim(bias) if ctx.needs_input_grad[3] else None
+        if dgamma is None or dgamma.data_ptr() % 16:
+            dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        if dbeta is None or dbeta.data_ptr() % 16:
+            dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws, nws = _ws(C, x.device)
         with torch.cuda.device(x.device), prof("batchnorm_train_backward"):
             rc = _lib.load().sgv3d_batchnorm_train_backward(
@@ -58,11 +63,37 @@ class _BatchNormAct(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+class deferred_counters:
+    """``with deferred_counters():`` -- the ``num_batches_tracked += 1`` of every batch_norm_act inside becomes ONE multi-tensor
+    launch at the end of the block (126 one-element launches per forward of the R50 model otherwise)."""
+    _open = None
+
+    def __enter__(self):
+        self._outer = deferred_counters._open
+        deferred_counters._open = self.pending = []
+        return self
+
+    def __exit__(self, *exc):
+        deferred_counters._open = self._outer
+        if self.pending:
+            torch._foreach_add_(self.pending, 1)
+        return False
+
+
+def _bump_version(t):
+    """Mark ``t`` as modified in place (a kernel wrote it through its raw pointer) without launching anything: an in-place op
+    on an empty view shares the version counter of its base."""
+    t[:0].add_(0)
+
+
 def batch_norm_act(bn, x, residual=None, relu=False):
     """``relu(bn(x) + residual)`` for an ``nn.BatchNorm2d`` in training mode; ``x`` / ``residual`` NHWC float32."""
     assert bn.training and bn.track_running_stats, "training-mode BatchNorm with running statistics"
     if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if deferred_counters._open is not None and bn.momentum is not None:
+            deferred_counters._open.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
     if bn.momentum is None:
         # torch: cumulative moving average, factor 1 / num_batches_tracked (after the increment)
         if bn.num_batches_tracked is None:
@@ -73,6 +104,6 @@ def batch_norm_act(bn, x, residual=None, relu=False):
     out = _BatchNormAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu)
     # the kernel wrote the running statistics through raw pointers: bump their version counters so that anything keyed
     # on tensor versions (BEVHeight._stamp -> repacked inference weights) sees the change
-    bn.running_mean.add_(0)
-    bn.running_var.add_(0)
+    _bump_version(bn.running_mean)
+    _bump_version(bn.running_var)
     return out

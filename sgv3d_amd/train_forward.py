@@ -35,7 +35,7 @@ from torch import nn
 from . import conv_grad, hip_ops
 from .bsm_grad import add_mul_sigmoid, upsample_bilinear2x
 from . import misc_grad
-from .norm_grad import batch_norm_act
+from .norm_grad import batch_norm_act, deferred_counters
 from .layers import blocks
 from .layers.backbones import bsm_lss_fpn, lss_fpn
 from .ops.voxel_pooling import voxel_pooling
@@ -290,15 +290,16 @@ def bevheight_train_forward(model, imgs, mats_dict):
     if not imgs.is_cuda:
         raise RuntimeError("sgv3d_amd runs on the MI355X only (no CPU fallback)")
     bb = model.backbone
-    if isinstance(bb, bsm_lss_fpn.BSMLSSFPN):
-        bev, aux = bsm_lss_fpn_forward(bb, imgs, mats_dict)
-    else:
-        bev, feats = lss_fpn_forward(bb, imgs, mats_dict, want_feats=True)
-        aux = None
-        if bb.is_train_height:
-            assist = _nchw(conv(bb.assist_layer, feats))
-            aux = (assist, assist)
-    preds = head_forward(model.head, bev)
+    with deferred_counters():                   # the BatchNorm step counters: one launch for all of them
+        if isinstance(bb, bsm_lss_fpn.BSMLSSFPN):
+            bev, aux = bsm_lss_fpn_forward(bb, imgs, mats_dict)
+        else:
+            bev, feats = lss_fpn_forward(bb, imgs, mats_dict, want_feats=True)
+            aux = None
+            if bb.is_train_height:
+                assist = _nchw(conv(bb.assist_layer, feats))
+                aux = (assist, assist)
+        preds = head_forward(model.head, bev)
     if model.is_train_height:
         if not bb.is_train_height:
             raise RuntimeError("is_train_height: the backbone was built without it (backbone_conf['is_train_height'], "
