@@ -672,6 +672,12 @@ int sgv3d_batchnorm_train_backward(long long pixels, int channels, const float *
                                    const float *gamma, const float *save_mean, const float *save_invstd, int relu,
                                    float *dx, float *dresidual, float *dgamma, float *dbeta, void *workspace,
                                    size_t workspace_bytes, void *stream);
+/* The backward of y = relu(bn(x)) (no residual) without the forward output: the ReLU mask is bn(x) > 0 recomputed from x with the
+ * scale / shift the forward folded from gamma, beta and the saved statistics (the same roundings, so the mask is the forward's):
+ * two fewer passes over the map than sgv3d_batchnorm_train_backward.  gamma / beta must be the forward's values. */
+int sgv3d_batchnorm_relu_train_backward_from_x(long long pixels, int channels, const float *x, const float *dy, const float *gamma,
+                                               const float *beta, const float *save_mean, const float *save_invstd, float *dx,
+                                               float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
 
 /* y[b, 2 i + py, 2 j + px, :] = phases[py * 2 + px][b, i + row0, j + col0, :]: interleaves the four sub-pixel phases of a
  * stride-2 data gradient (each phase is a stride-1 convolution of the upstream gradient with the taps of its parity,

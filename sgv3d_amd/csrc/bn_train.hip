@@ -29,7 +29,7 @@ struct BnArgs {
     float *running_mean, *running_var, *mean, *invstd, *scale, *shift, *dgamma, *dbeta;
     double *partial;                       // [ranges][C][2]
     long long pixels;
-    int channels, ranges, pix_per_range, relu;
+    int channels, ranges, pix_per_range, relu;   // relu 2 (backward): the mask is bn(x) > 0 recomputed from x (no residual in the forward)
     float momentum, eps;
 };
 
@@ -115,8 +115,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnArgs a) {
     a.mean[c] = (float)mean;
     a.invstd[c] = invstd;
     const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
-    a.scale[c] = g * invstd;
-    a.shift[c] = b - (float)mean * g * invstd;
+    // (explicit roundings: the backward recomputes exactly these two numbers when it derives the ReLU mask from x)
+    const float scale = __fmul_rn(g, invstd);
+    a.scale[c] = scale;
+    a.shift[c] = __fmaf_rn(-(float)mean, scale, b);
     if (a.running_mean) a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
     if (a.running_var) {
         const double unbiased = m > 1 ? var * m / (m - 1) : var;
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs a) {
     const float4 sc = sc4[c], sh = sh4[c];
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
         const float4 v = x4[i];
-        float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+        float4 o = make_float4(__fmaf_rn(v.x, sc.x, sh.x), __fmaf_rn(v.y, sc.y, sh.y), __fmaf_rn(v.z, sc.z, sh.z), __fmaf_rn(v.w, sc.w, sh.w));
         if (r4) {
             const float4 r = r4[i];
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
@@ -144,6 +146,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs a) {
         o.x = fmaxf(o.x, floor_); o.y = fmaxf(o.y, floor_); o.z = fmaxf(o.z, floor_); o.w = fmaxf(o.w, floor_);
         y4[i] = o;
     }
+}
+
+// scale / shift of channels c .. c + 3 exactly as bn_finalize_kernel folded them (same roundings)
+__device__ __forceinline__ void fold_affine(const BnArgs &a, int c, const float4 mean, const float4 istd, float4 &sc, float4 &sh) {
+    float4 g = make_float4(1.f, 1.f, 1.f, 1.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.gamma) g = *reinterpret_cast<const float4 *>(a.gamma + c);
+    if (a.beta) b = *reinterpret_cast<const float4 *>(a.beta + c);
+    sc = make_float4(__fmul_rn(g.x, istd.x), __fmul_rn(g.y, istd.y), __fmul_rn(g.z, istd.z), __fmul_rn(g.w, istd.w));
+    sh = make_float4(__fmaf_rn(-mean.x, sc.x, b.x), __fmaf_rn(-mean.y, sc.y, b.y), __fmaf_rn(-mean.z, sc.z, b.z), __fmaf_rn(-mean.w, sc.w, b.w));
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnArgs a) {
@@ -155,7 +166,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnArgs a) {
     if (cg + c4 < a.channels) {
         const float4 mean = *reinterpret_cast<const float4 *>(a.mean + cg + c4);
         const float4 istd = *reinterpret_cast<const float4 *>(a.invstd + cg + c4);
-        auto one = [&](float4 d, const float4 v, const float4 y) {
+        float4 fsc, fsh;
+        const bool from_x = a.relu == 2;
+        if (from_x) fold_affine(a, cg + c4, mean, istd, fsc, fsh);
+        auto one = [&](float4 d, const float4 v, float4 y) {
+            if (from_x) y = make_float4(__fmaf_rn(v.x, fsc.x, fsh.x), __fmaf_rn(v.y, fsc.y, fsh.y), __fmaf_rn(v.z, fsc.z, fsh.z), __fmaf_rn(v.w, fsc.w, fsh.w));
             if (a.relu) {
                 d.x = y.x > 0.f ? d.x : 0.f; d.y = y.y > 0.f ? d.y : 0.f; d.z = y.z > 0.f ? d.z : 0.f; d.w = y.w > 0.f ? d.w : 0.f;
             }
@@ -169,15 +184,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnArgs a) {
             const size_t o0 = p * a.channels + cg + c4, o1 = (p + 16) * a.channels + cg + c4;
             const float4 d0 = *reinterpret_cast<const float4 *>(a.dy + o0), d1 = *reinterpret_cast<const float4 *>(a.dy + o1);
             const float4 v0 = *reinterpret_cast<const float4 *>(a.x + o0), v1 = *reinterpret_cast<const float4 *>(a.x + o1);
-            const float4 y0 = a.relu ? *reinterpret_cast<const float4 *>(a.y_in + o0) : zero;
-            const float4 y1 = a.relu ? *reinterpret_cast<const float4 *>(a.y_in + o1) : zero;
+            const float4 y0 = a.relu == 1 ? *reinterpret_cast<const float4 *>(a.y_in + o0) : zero;
+            const float4 y1 = a.relu == 1 ? *reinterpret_cast<const float4 *>(a.y_in + o1) : zero;
             one(d0, v0, y0);
             one(d1, v1, y1);
         }
         for (; p < p1; p += 16) {
             const size_t o = p * a.channels + cg + c4;
             one(*reinterpret_cast<const float4 *>(a.dy + o), *reinterpret_cast<const float4 *>(a.x + o),
-                a.relu ? *reinterpret_cast<const float4 *>(a.y_in + o) : zero);
+                a.relu == 1 ? *reinterpret_cast<const float4 *>(a.y_in + o) : zero);
         }
     }
 #pragma unroll
@@ -217,11 +232,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a) {
     const float4 k1 = make_float4(g.x * istd.x, g.y * istd.y, g.z * istd.z, g.w * istd.w);
     db.x *= inv_m; db.y *= inv_m; db.z *= inv_m; db.w *= inv_m;
     dg.x *= istd.x * inv_m; dg.y *= istd.y * inv_m; dg.z *= istd.z * inv_m; dg.w *= istd.w * inv_m;
+    float4 fsc, fsh;
+    const bool from_x = a.relu == 2;
+    if (from_x) fold_affine(a, c, mean, istd, fsc, fsh);
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
         float4 d = d4[i];
         const float4 v = x4[i];
         if (a.relu) {
-            const float4 y = y4[i];
+            const float4 y = from_x ? make_float4(__fmaf_rn(v.x, fsc.x, fsh.x), __fmaf_rn(v.y, fsc.y, fsh.y), __fmaf_rn(v.z, fsc.z, fsh.z),
+                                                  __fmaf_rn(v.w, fsc.w, fsh.w))
+                                    : y4[i];
             d.x = y.x > 0.f ? d.x : 0.f; d.y = y.y > 0.f ? d.y : 0.f; d.z = y.z > 0.f ? d.z : 0.f; d.w = y.w > 0.f ? d.w : 0.f;
         }
         if (dr4) dr4[i] = d;
@@ -294,15 +314,39 @@ extern "C" int sgv3d_batchnorm_train_forward(long long pixels, int channels, con
     return check_launch("bn_apply_kernel");
 }
 
+namespace {
+int bn_backward(long long pixels, int channels, const float *x, const float *y, const float *dy, const float *gamma, const float *beta,
+                const float *save_mean, const float *save_invstd, int relu, float *dx, float *dresidual, float *dgamma, float *dbeta,
+                void *workspace, size_t workspace_bytes, void *stream);
+}
+
 extern "C" int sgv3d_batchnorm_train_backward(long long pixels, int channels, const float *x, const float *y,
                                               const float *dy, const float *gamma, const float *save_mean,
                                               const float *save_invstd, int relu, float *dx, float *dresidual,
                                               float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
                                               void *stream) {
+    SGV3D_REQUIRE(!relu || y, "batchnorm_train_backward: the forward output is needed for the ReLU mask");
+    return bn_backward(pixels, channels, x, y, dy, gamma, nullptr, save_mean, save_invstd, relu ? 1 : 0, dx, dresidual, dgamma, dbeta,
+                       workspace, workspace_bytes, stream);
+}
+
+extern "C" int sgv3d_batchnorm_relu_train_backward_from_x(long long pixels, int channels, const float *x, const float *dy,
+                                                          const float *gamma, const float *beta, const float *save_mean,
+                                                          const float *save_invstd, float *dx, float *dgamma, float *dbeta,
+                                                          void *workspace, size_t workspace_bytes, void *stream) {
+    SGV3D_REQUIRE((!gamma || aligned16(gamma)) && (!beta || aligned16(beta)), "batchnorm_relu_train_backward_from_x: gamma / beta must be 16-byte aligned");
+    return bn_backward(pixels, channels, x, nullptr, dy, gamma, beta, save_mean, save_invstd, 2, dx, nullptr, dgamma, dbeta, workspace,
+                       workspace_bytes, stream);
+}
+
+namespace {
+int bn_backward(long long pixels, int channels, const float *x, const float *y, const float *dy, const float *gamma, const float *beta,
+                const float *save_mean, const float *save_invstd, int relu, float *dx, float *dresidual, float *dgamma, float *dbeta,
+                void *workspace, size_t workspace_bytes, void *stream) {
     BnArgs a{};
     if (int rc = plan(pixels, channels, a)) return rc;
     SGV3D_REQUIRE(x && dy && save_mean && save_invstd && dx && dgamma && dbeta && workspace, "batchnorm_train_backward: null pointer");
-    SGV3D_REQUIRE(!relu || y, "batchnorm_train_backward: the forward output is needed for the ReLU mask");
+    a.beta = beta;
     SGV3D_REQUIRE(workspace_bytes >= sgv3d_batchnorm_workspace_bytes(channels), "batchnorm_train_backward: workspace too small");
     SGV3D_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && (!y || aligned16(y)) && (!dresidual || aligned16(dresidual)) &&
                   aligned16(save_mean) && aligned16(save_invstd) && aligned16(dgamma) && aligned16(dbeta) && (!gamma || aligned16(gamma)),
@@ -318,3 +362,4 @@ extern "C" int sgv3d_batchnorm_train_backward(long long pixels, int channels, co
     bn_bwd_apply_kernel<<<stream_blocks(pixels * (channels / 4), channels / 4), 256, 0, s>>>(a);
     return check_launch("bn_bwd_apply_kernel");
 }
+}  // namespace

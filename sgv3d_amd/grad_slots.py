@@ -14,6 +14,7 @@ CAPABLE = set()      # addresses whose producers called claim(): zero_grad arms 
 
 def register(param_ptr, flat_grad, offset, numel, shape):
     _SLOTS[int(param_ptr)] = [flat_grad, int(offset), int(numel), tuple(shape), False]
+    CAPABLE.discard(int(param_ptr))         # (an address reused by a new parameter: its producers have to ask again)
 
 
 def unregister(param_ptr):

@@ -1,12 +1,17 @@
 """Training-mode BatchNorm2d fused with the residual add and ReLU around it, on NHWC float32 CUDA tensors
 (csrc/bn_train.hip).  ``batch_norm_act`` is differentiable in the input, the residual and the
 affine parameters and updates the module's running statistics like ``nn.BatchNorm2d`` in training mode."""
+import os
+
 import torch
 
 from . import _lib, grad_slots
 from .hip_ops import prof
 
 __all__ = ['batch_norm_act', 'deferred_counters']
+
+
+MASK_FROM_X = os.environ.get("SGV3D_BN_MASK_FROM_X", "1") != "0"   # 0: the backward of relu(bn(x)) always reads the forward output
 
 
 def _ws(channels, device):
@@ -32,7 +37,9 @@ class _BatchNormAct(torch.autograd.Function):
                 _lib.ptr(running_var), float(momentum), float(eps), 1 if relu else 0, y.data_ptr(), mean.data_ptr(),
                 invstd.data_ptr(), ws.data_ptr(), nws, _lib.stream_handle(x.device))
         _lib.check(rc, "sgv3d_batchnorm_train_forward")
-        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd, bias)
+        # ReLU without a residual: the backward recomputes the mask from x (sgv3d_batchnorm_relu_train_backward_from_x), y is not kept
+        ctx.from_x = bool(relu) and residual is None and MASK_FROM_X
+        ctx.save_for_backward(x, y if (relu and not ctx.from_x) else None, weight, mean, invstd, bias)
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
         return y
@@ -53,6 +60,14 @@ class _BatchNormAct(torch.autograd.Function):
         if dbeta is None or dbeta.data_ptr() % 16:
             dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws, nws = _ws(C, x.device)
+        if ctx.from_x:
+            with torch.cuda.device(x.device), prof("batchnorm_train_backward"):
+                rc = _lib.load().sgv3d_batchnorm_relu_train_backward_from_x(
+                    pixels, C, x.data_ptr(), dy.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), mean.data_ptr(), invstd.data_ptr(),
+                    dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nws, _lib.stream_handle(x.device))
+            _lib.check(rc, "sgv3d_batchnorm_relu_train_backward_from_x")
+            return (dx, None, dgamma if weight is not None else None, dbeta if ctx.needs_input_grad[3] else None,
+                    None, None, None, None, None)
         with torch.cuda.device(x.device), prof("batchnorm_train_backward"):
             rc = _lib.load().sgv3d_batchnorm_train_backward(
                 pixels, C, x.data_ptr(), _lib.ptr(y), dy.data_ptr(), _lib.ptr(weight), mean.data_ptr(), invstd.data_ptr(),

@@ -75,3 +75,30 @@ def test_batch_norm_act_is_deterministic():
         y.backward(dy)
         outs.append((y.detach().clone(), xg.grad.clone(), bn.weight.grad.clone(), bn.running_var.clone()))
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 41, 192), (1, 64, 80, 64), (2, 1, 1, 512)])
+def test_relu_mask_recomputed_from_x_is_the_forward_mask(shape):
+    """relu(bn(x)) without a residual: the backward derives the mask from x (sgv3d_batchnorm_relu_train_backward_from_x, the
+    forward's scale / shift with the forward's roundings) instead of reading y -- every gradient bitwise what the y-mask path
+    gives, including elements that sit exactly on the threshold (inputs on a coarse grid)."""
+    from sgv3d_amd import norm_grad
+    g = torch.Generator().manual_seed(shape[-1])
+    x = (torch.randn(shape, generator=g) * 4).round() / 4                  # many equal values, some of them mapping to y == 0 exactly
+    dy = torch.randn(shape, generator=g).cuda()
+    outs = []
+    for from_x in (True, False):
+        old = norm_grad.MASK_FROM_X
+        norm_grad.MASK_FROM_X = from_x
+        try:
+            bn = torch.nn.BatchNorm2d(shape[-1]).cuda().train()
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(0.5, 1.5, shape[-1]))
+                bn.bias.copy_(torch.linspace(-0.4, 0.4, shape[-1]))
+            xg = x.cuda().requires_grad_(True)
+            y = batch_norm_act(bn, xg, None, True)
+            y.backward(dy)
+            outs.append((y.detach().clone(), xg.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+        finally:
+            norm_grad.MASK_FROM_X = old
+    assert all(torch.equal(a, b) for a, b in zip(*outs))

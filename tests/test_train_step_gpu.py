@@ -89,6 +89,48 @@ def test_training_slice_reduces_the_loss():
     assert all(abs(a - b) <= 2e-4 * abs(b) for a, b in zip(losses, rlosses)), (losses, rlosses)
 
 
+def test_gradient_slots_write_into_the_buckets():
+    """Weight and BatchNorm gradients land in the flat buckets without an accumulate launch (grad_slots): from the second
+    step on ``p.grad`` is the kernel's own output view of the bucket, with the bits of the accumulate path (0 + g == g), and a
+    second backward before the step still accumulates."""
+    from sgv3d_amd import grad_slots, train_step
+    from sgv3d_amd.norm_grad import batch_norm_act
+
+    def run(direct):
+        old = train_step.DIRECT_GRADS
+        train_step.DIRECT_GRADS = direct
+        try:
+            torch.manual_seed(11)
+            w1 = (torch.randn(32, 8, 3, 3) * 0.2).cuda().requires_grad_(True)
+            w2 = (torch.randn(8, 32, 1, 1) * 0.2).cuda().requires_grad_(True)
+            wt = (torch.randn(8, 4, 2, 2) * 0.2).cuda().requires_grad_(True)          # transposed convolution [cin, cout, k, k]
+            bn = torch.nn.BatchNorm2d(32).cuda().train()
+            params = [w1, w2, wt, bn.weight, bn.bias]
+            opt = DataParallelAdamW(params, lr=1e-2, weight_decay=0.0)
+            x = torch.randn(2, 10, 12, 8, device='cuda')
+            grads, aliased = [], []
+            for it in range(3):
+                opt.zero_grad()
+                for rep in range(2 if it == 2 else 1):                                 # the last step: two backwards, accumulated
+                    h = batch_norm_act(bn, conv_grad.conv2d(x, w1, None, 1, 1, 1), relu=True)
+                    y = conv_grad.conv_transpose2d(conv_grad.conv2d(h, w2), wt, 2)
+                    y.square().mean().backward()
+                opt.flat.check_views()
+                aliased.append([p.grad is not None and int(p.data_ptr()) in grad_slots.CAPABLE for p in params])
+                grads.append([p.grad.detach().clone() for p in params])
+                opt.step()
+            return grads, aliased
+        finally:
+            train_step.DIRECT_GRADS = old
+
+    g1, a1 = run(True)
+    g0, _ = run(False)
+    assert all(a1[1]) and all(a1[2])                                                   # every parameter here has a slot-aware producer
+    for step1, step0 in zip(g1, g0):
+        for a, b in zip(step1, step0):
+            assert torch.equal(a, b)
+
+
 def test_adamw_bandwidth_smoke():
     """64 Mi parameters through the fused update; prints the achieved HBM rate (28 bytes per parameter)."""
     n = 64 << 20
