@@ -6,14 +6,15 @@ the flat bucket): one small ``add`` launch per parameter, ~380 per step of the R
 of the bucket as its output buffer, and AccumulateGrad adopts that tensor as ``p.grad`` without a copy -- the gradient is already
 where the all-reduce and the fused AdamW read it.  A second contribution to the same parameter in one step (shared weights,
 gradient accumulation over micro-batches) finds the slot taken and goes through the ordinary accumulate path."""
-import torch
+import weakref
 
-_SLOTS = {}          # address of the parameter's data -> [flat_grad, offset, numel, shape, armed]
+_SLOTS = {}          # address of the parameter's data -> [weak reference to the flat gradient bucket, offset, numel, shape, armed]
 CAPABLE = set()      # addresses whose producers called claim(): zero_grad arms these
 
 
 def register(param_ptr, flat_grad, offset, numel, shape):
-    _SLOTS[int(param_ptr)] = [flat_grad, int(offset), int(numel), tuple(shape), False]
+    """The registry does not keep the bucket alive: an entry whose bucket is gone (its FlatParams was dropped) is dead."""
+    _SLOTS[int(param_ptr)] = [weakref.ref(flat_grad), int(offset), int(numel), tuple(shape), False]
     CAPABLE.discard(int(param_ptr))         # (an address reused by a new parameter: its producers have to ask again)
 
 
@@ -37,8 +38,12 @@ def claim(param):
     s = _SLOTS.get(key)
     if s is None or tuple(param.shape) != s[3]:
         return None
+    flat_grad = s[0]()
+    if flat_grad is None:
+        unregister(key)
+        return None
     CAPABLE.add(key)
     if not s[4]:
         return None
     s[4] = False
-    return s[0][s[1]:s[1] + s[2]].view(s[3])
+    return flat_grad[s[1]:s[1] + s[2]].view(s[3])

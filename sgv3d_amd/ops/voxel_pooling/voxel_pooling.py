@@ -10,10 +10,12 @@ callable, argument meaning, asserts, non-differentiable ``geom_xyz``, permuted-v
   float-atomic scatter (order-nondeterministic, voxel_pooling_forward_cuda.cu:30-33);
 * the 149 MB ``grad_input_features`` memset and ``pos_memo`` are only produced when a gradient is
   actually required (the reference allocates both unconditionally, voxel_pooling.py:29,40);
-* ``voxel_num`` is read back from the device at most once per distinct tensor version (the
+* ``voxel_num`` is read back from the device at most once per tensor object and version (the
   reference indexes a CUDA tensor five times per call, each a device->host sync);
 * backward is one gather kernel (no boolean-mask indexing / nonzero sync, voxel_pooling.py:58-69).
 """
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -45,18 +47,19 @@ _VOXEL_NUM_CACHE = {}
 
 
 def _voxel_num_ints(voxel_num):
-    """(X, Y, Z) as python ints; a device tensor costs one sync per (storage, version)."""
+    """(X, Y, Z) as python ints; a device tensor costs one sync per (tensor object, version)."""
     if isinstance(voxel_num, torch.Tensor):
         if voxel_num.numel() != 3:
             raise RuntimeError("voxel_num must have 3 elements")
         if voxel_num.is_cuda:
-            key = (voxel_num.data_ptr(), voxel_num._version, voxel_num.device.index)
-            hit = _VOXEL_NUM_CACHE.get(key)
-            if hit is None:
-                if len(_VOXEL_NUM_CACHE) > 64:
-                    _VOXEL_NUM_CACHE.clear()
-                hit = tuple(int(v) for v in voxel_num.tolist())
-                _VOXEL_NUM_CACHE[key] = hit
+            # keyed by the tensor OBJECT (weak reference) and its version: an address alone can be a new tensor in freed memory
+            ent = _VOXEL_NUM_CACHE.get(id(voxel_num))
+            if ent is not None and ent[0]() is voxel_num and ent[1] == voxel_num._version:
+                return ent[2]
+            if len(_VOXEL_NUM_CACHE) > 64:
+                _VOXEL_NUM_CACHE.clear()
+            hit = tuple(int(v) for v in voxel_num.tolist())
+            _VOXEL_NUM_CACHE[id(voxel_num)] = (weakref.ref(voxel_num), voxel_num._version, hit)
             return hit
         return tuple(int(v) for v in voxel_num.tolist())
     x, y, z = voxel_num
