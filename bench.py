@@ -63,7 +63,8 @@ def parse():
     ap.add_argument("--no-plan-timing", action="store_true",
                     help="roofline_hbm without the plan-build / plan-check timings (keeps a rocprof trace of this command free "
                          "of the plan kernels those timing loops launch)")
-    ap.add_argument("--fuse-lift-splat", action="store_true", help="skip the materialised [B,N,C] lifted tensor")
+    ap.add_argument("--fuse-lift-splat", action="store_true", help="(the default since round 3) rows of the lifted tensor formed inside the pooling gather")
+    ap.add_argument("--no-fuse-lift-splat", action="store_true", help="materialise the [B,N,C] lifted tensor: lift kernel + voxel_pooling operator")
     ap.add_argument("--streams", type=int, default=3,
                     help="frames in flight: consecutive steps are replayed round-robin on this many HIP streams "
                          "(each with its own graph and activation buffers), so kernels of frame i+1 fill the CUs that "
@@ -245,7 +246,7 @@ def main():
         model = BEVHeight(bc, hc).eval()
         S.randomize_norm_stats_(model, 0, residual_gamma=0.3)    # small last-BN gamma per residual block, as mmdet initialises
         model = model.to(dev)
-        model.backbone.fuse_lift_splat = bool(args.fuse_lift_splat)
+        model.backbone.fuse_lift_splat = not args.no_fuse_lift_splat
         imgs = S.make_images(B, bc['final_dim'], device=dev, seed=rank)
         mats = S.make_mats(B, device=dev)
 
@@ -438,6 +439,15 @@ def main():
                 torch.cuda.synchronize()
                 return time_us(fn, reps), "HIP events on the launch stream, median of 20 eager launches"
         pool_us, pool_method = time_graph_us(lambda: plan.pool(feats, out=outb))
+        # the form the timed model runs (one camera per sample): no lifted tensor, rows = prob * context inside the same gather
+        lift_splat_us = None
+        Dh = int(bb.height_channels)
+        if getattr(bb, 'fuse_lift_splat', False) and Np % Dh == 0 and int(imgs.shape[2]) == 1:
+            Pp = Np // Dh
+            prob_t = torch.rand(Bn, Dh, Pp, device=dev)
+            ctx_t = torch.randn(Bn, Pp, Cvp, device=dev)
+            lift_splat_us, _ = time_graph_us(lambda: plan.lift_splat(prob_t, ctx_t, out=outb))
+            del prob_t, ctx_t
         flat = geom.view(Bn, -1, 3)
         build_us = clean_us = None
         if not args.no_plan_timing:
@@ -465,13 +475,16 @@ def main():
             "frac_including_plan": alg / (pool_us + build_us) / 1e3 / HBM_PEAK_GBPS if build_us else None,
             "frac_including_check": alg / (pool_us + clean_us) / 1e3 / HBM_PEAK_GBPS if clean_us else None,
             "plan_builds_in_timed_region": calib["plan_builds_in_timed_region"],
+            "model_path_lift_splat_us": lift_splat_us,
             "level1_ext_us": level1_us,
             "frac_level1_ext": alg / level1_us / 1e3 / HBM_PEAK_GBPS if level1_us else None,
             "note": "the plan depends only on the calibration: built once per calibration outside the captured forward "
                     "(frac_including_plan = if it were rebuilt on every frame, as the reference-style operator call with "
                     "ever-changing geom_xyz would; frac_including_check = operator call with an unchanged geom_xyz: "
                     "device-side compare + empty build launches; frac_level1_ext = the reference wrapper's own call into "
-                    "voxel_pooling_ext, which keeps a plan per stream inside the library)",
+                    "voxel_pooling_ext, which keeps a plan per stream inside the library; model_path_lift_splat_us = what the timed "
+                    "model launches instead of lift + this operator: the same gather forming its rows as prob * context, so the "
+                    "[B,N,C] lifted tensor -- most of the operator's bytes -- is neither written nor read)",
             "method": pool_method + ", N(0,1) features on this run's geometry",
         }
         del feats, outb
@@ -609,7 +622,7 @@ def main():
                        "hip_graph": bool(use_graph), "frames_in_flight": nstreams,
                        "one_frame_in_flight_value": single["value"] if single else None,
                        "one_frame_in_flight_ms_per_step": single["ms_per_step"] if single else None,
-                       "fuse_lift_splat": bool(args.fuse_lift_splat),
+                       "fuse_lift_splat": not args.no_fuse_lift_splat,
                        "voxel_pooling_mode": "planned, plan cached per calibration",
                        "calibration_cache": calib,
                        "weights": "random-init (seed 0), BN statistics / affine perturbed, last BN of every residual block scaled by 0.3 "

@@ -136,6 +136,12 @@ int sgv3d_lift_splat_planned(int batch_size, int num_depth, int num_pixels, int 
                              float *output_features, void *workspace, size_t workspace_bytes,
                              void *stream);
 
+/* The same with the pooled map written as bf16 rows of out_bf16_ld >= C channels (padding channels zeroed), the hand-off
+ * sgv3d_voxel_pooling_forward_planned_bf16 offers: sums in f32 (products not rounded to bf16 first), one rounding on the store. */
+int sgv3d_lift_splat_planned_bf16out(int batch_size, int num_depth, int num_pixels, int num_channels, int num_voxel_x,
+                                     int num_voxel_y, const void *plan, const float *prob, const float *context,
+                                     void *output_bf16, int out_bf16_ld, void *workspace, size_t workspace_bytes, void *stream);
+
 /* VoxelPooling.backward  ops/voxel_pooling/voxel_pooling.py:58-69
  *   grad_output f32 [B, C, Y, X] with element strides (sb, sc, sy, sx)  (the autograd grad is a
  *   permuted view in the reference; strides let both NCHW-contiguous and NHWC-backed grads in)

@@ -881,7 +881,37 @@ struct VpFastArgs {
     const int *gate;
     unsigned feat_bytes, out_bytes;   // num_records of the two buffers
     int V, C, lpr, groups, ch, w_nom, ldo, long_cap, nblk_regular, N;
+    // FUSED (lift-splat): feats = context [B, P, C] f32, rows formed on the fly as prob[point] * context[pixel of the point]
+    const float *prob;
+    int P;
 };
+
+// FUSED: a live slot's point id becomes the row of its pixel in the context tensor, `pr` its probability (0 for dead slots).
+// Done once per slot by the lane that fetched the slot's entry (two integer divisions per window, not per row).
+template <bool FUSED>
+__device__ __forceinline__ void vp_fused_index(const VpFastArgs &a, int &idx, float &pr) {
+    if constexpr (FUSED) {
+        pr = 0.f;
+        if (idx >= 0) {
+            pr = a.prob[idx];
+            const int b = (int)((unsigned)idx / (unsigned)a.N);
+            const int rem = idx - b * a.N;
+            idx = b * a.P + (int)((unsigned)rem % (unsigned)a.P);
+        }
+    }
+}
+
+// acc += row (FUSED: the row is pr * context row, the product rounded to f32 first -- the bits of the materialised lifted tensor)
+template <bool FUSED>
+__device__ __forceinline__ void vp_add_row(float4 &acc, const float4 &v, float pr) {
+    if constexpr (FUSED) {
+#pragma clang fp contract(off)      // (a fused multiply-add would skip the product's rounding)
+        const float px = pr * v.x, py = pr * v.y, pz = pr * v.z, pw = pr * v.w;
+        acc.x += px; acc.y += py; acc.z += pz; acc.w += pw;
+    } else {
+        vacc(acc, v);
+    }
+}
 
 template <bool FB>
 __device__ __forceinline__ float4 vp_buf_load_row(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
@@ -920,10 +950,11 @@ __device__ __forceinline__ void vp_buf_emit(__amdgpu_buffer_rsrc_t rsrc, int vox
 // Rows of the slots [base, base + groups*ch) that still belong to voxel `want` (marked or not), lean form: group g sums slots
 // base + g*ch + k (k ascending) into `acc`; the caller adds the groups' sums in ascending group order.  Returns true when
 // the run ended inside this batch.  `idw`: the wave's LDS index area.  Wave-uniform.
-template <bool FB>
+template <bool FB, bool FUSED>
 __device__ __forceinline__ bool vp_fast_run_batch(float4 &acc, int base, int T, int want, int g, int cl, int ch, bool ingroup,
                                                   int gs, const int *__restrict__ order, const int *__restrict__ slot_voxel,
-                                                  __amdgpu_buffer_rsrc_t f_rsrc, unsigned row_in, unsigned lane_in, int *idw) {
+                                                  __amdgpu_buffer_rsrc_t f_rsrc, unsigned row_in, unsigned lane_in, int *idw,
+                                                  const VpFastArgs &a, float *prw) {
     const int slot = base + g * ch + cl;
     const bool index_lane = ingroup && cl < ch;
     bool mine = false;
@@ -933,7 +964,12 @@ __device__ __forceinline__ bool vp_fast_run_batch(float4 &acc, int base, int T, 
         if (mine) my_idx = order[slot];
     }
     const bool ended = __ballot(index_lane && !mine) != 0ull;     // (sorted by voxel: `want`'s slots are a prefix of the batch)
-    if (index_lane) idw[g * kChunkMax + cl] = my_idx;
+    float my_pr = 0.f;
+    vp_fused_index<FUSED>(a, my_idx, my_pr);
+    if (index_lane) {
+        idw[g * kChunkMax + cl] = my_idx;
+        if constexpr (FUSED) prw[g * kChunkMax + cl] = my_pr;
+    }
     const vp_i32x4 *ip = reinterpret_cast<const vp_i32x4 *>(idw + gs * kChunkMax);
     int idx[kChunkMax];
 #pragma unroll
@@ -941,19 +977,28 @@ __device__ __forceinline__ bool vp_fast_run_batch(float4 &acc, int base, int T, 
         const vp_i32x4 t = ip[q];
         idx[4 * q + 0] = t[0]; idx[4 * q + 1] = t[1]; idx[4 * q + 2] = t[2]; idx[4 * q + 3] = t[3];
     }
+    float pr[kChunkMax];
+    if constexpr (FUSED) {
+        const vp_f32x4 *pp = reinterpret_cast<const vp_f32x4 *>(prw + gs * kChunkMax);
+#pragma unroll
+        for (int q = 0; q < kChunkMax / 4; ++q) {
+            const vp_f32x4 t = pp[q];
+            pr[4 * q + 0] = t[0]; pr[4 * q + 1] = t[1]; pr[4 * q + 2] = t[2]; pr[4 * q + 3] = t[3];
+        }
+    }
     float4 val[kChunkMax];
 #pragma unroll
     for (int k = 0; k < kChunkMax; ++k) val[k] = vp_buf_load_row<FB>(f_rsrc, (unsigned)idx[k] * row_in + lane_in);
 #pragma unroll
     for (int k = 0; k < kChunkMax; ++k)
-        if (k < ch) vacc(acc, val[k]);                            // (rows that are not `want`'s came back as zeros)
+        if (k < ch) vp_add_row<FUSED>(acc, val[k], FUSED ? pr[k] : 0.f);   // (rows that are not `want`'s came back as zeros)
     return ended;
 }
 
 constexpr int kEvStride = 20;    // ints per row group in the LDS image of the window: entries cl = 0 .. ch+1 (<= 18), 16-B rows
 constexpr int kMaxGroups = 10;   // 64 lanes / LPR >= 6
 
-template <bool FB, bool OB, bool ACC>
+template <bool FB, bool OB, bool ACC, bool FUSED = false>
 __global__ __launch_bounds__(kBlock) void vp_gather_fast_kernel(const VpFastArgs a) {
     if (a.gate != nullptr && *reinterpret_cast<const volatile int *>(a.gate) != 0) return;
     // per wave: ev[group][cl] = voxel of slot cb-1+cl if this wave sums it, else -1; idx[group][k] = its point id, else -1;
@@ -961,6 +1006,7 @@ __global__ __launch_bounds__(kBlock) void vp_gather_fast_kernel(const VpFastArgs
     __shared__ __attribute__((aligned(16))) int ev_s[kBlock / 64][(kMaxGroups + 1) * kEvStride];
     __shared__ __attribute__((aligned(16))) int idx_s[kBlock / 64][(kMaxGroups + 1) * kChunkMax];
     __shared__ float4 red[kBlock / 64][64];
+    __shared__ __attribute__((aligned(16))) float pr_s[kBlock / 64][FUSED ? (kMaxGroups + 1) * kChunkMax : 4];   // FUSED: idx's probabilities
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
     const int lpr = a.lpr, groups = a.groups, ch = a.ch;
@@ -972,7 +1018,11 @@ __global__ __launch_bounds__(kBlock) void vp_gather_fast_kernel(const VpFastArgs
     const int cap = groups * ch;
     const int T = a.seg_start[a.V];
     int *evw = ev_s[wid], *idw = idx_s[wid];
-    if (lane < kChunkMax) idw[groups * kChunkMax + lane] = -1;   // the all-dead index block
+    float *prw = pr_s[wid];
+    if (lane < kChunkMax) {                                      // the all-dead index block
+        idw[groups * kChunkMax + lane] = -1;
+        if constexpr (FUSED) prw[groups * kChunkMax + lane] = 0.f;
+    }
     const unsigned row_in = (unsigned)a.C * (FB ? 2u : 4u);
     const unsigned row_out = OB ? (unsigned)a.ldo * 2u : (unsigned)a.C * 4u;
     const unsigned lane_in = (unsigned)cl * (FB ? 8u : 16u);
@@ -992,7 +1042,7 @@ __global__ __launch_bounds__(kBlock) void vp_gather_fast_kernel(const VpFastArgs
             const int b = a.seg_start[v], e = a.seg_start[v + 1];
             float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int base = b + wid * cap; base < e; base += (kBlock / 64) * cap)
-                vp_fast_run_batch<FB>(racc, base, e, ~v, g, cl, ch, ingroup, gs, a.order, a.slot_voxel, f_rsrc, row_in, lane_in, idw);
+                vp_fast_run_batch<FB, FUSED>(racc, base, e, ~v, g, cl, ch, ingroup, gs, a.order, a.slot_voxel, f_rsrc, row_in, lane_in, idw, a, prw);
             float4 wsum = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int g2 = 0; g2 < groups; ++g2) vacc(wsum, vp_from_lane(racc, g2 * lpr + src_cl));
             if (g == 0) red[wid][cl] = wsum;
@@ -1048,13 +1098,28 @@ __global__ __launch_bounds__(kBlock) void vp_gather_fast_kernel(const VpFastArgs
     // (slots outside the list hold INT_MIN.)  The slot right behind the window counts as live when no run starts in the tail of
     // the window: the chunk before it then sees its last run continue and hands it to the extension loop below
     const bool live = my_vox >= 0 && my_slot >= first && (my_slot < endw || (tail_start_m == 0ull && my_slot == s0 + cap));
+    int row_idx = live ? my_idx : -1;
+    float my_pr = 0.f;
+    vp_fused_index<FUSED>(a, row_idx, my_pr);
     if (ingroup && cl < ch + 2) {
         evw[g * kEvStride + cl] = live ? my_vox : -1;
-        if (cl >= 1 && cl <= ch) idw[g * kChunkMax + cl - 1] = live ? my_idx : -1;
+        if (cl >= 1 && cl <= ch) {
+            idw[g * kChunkMax + cl - 1] = row_idx;
+            if constexpr (FUSED) prw[g * kChunkMax + cl - 1] = my_pr;
+        }
     }
     if (lane < kEvStride) evw[groups * kEvStride + lane] = -1;   // the all-dead block
     // ---------------------------------------------------------------- all rows of the chunk in flight
     float4 val[kChunkMax];
+    float pr[kChunkMax];
+    if constexpr (FUSED) {
+        const vp_f32x4 *pp = reinterpret_cast<const vp_f32x4 *>(prw + gs * kChunkMax);
+#pragma unroll
+        for (int q = 0; q < kChunkMax / 4; ++q) {
+            const vp_f32x4 t = pp[q];
+            pr[4 * q + 0] = t[0]; pr[4 * q + 1] = t[1]; pr[4 * q + 2] = t[2]; pr[4 * q + 3] = t[3];
+        }
+    }
     {
         const vp_i32x4 *ip = reinterpret_cast<const vp_i32x4 *>(idw + gs * kChunkMax);
         int idx[kChunkMax];
@@ -1095,7 +1160,7 @@ __global__ __launch_bounds__(kBlock) void vp_gather_fast_kernel(const VpFastArgs
                     first_run = first_run && !bnd;
                 }
             }
-            vacc(acc, val[k]);
+            vp_add_row<FUSED>(acc, val[k], FUSED ? pr[k] : 0.f);
         }
     }
     // the chunk's last run: slot ch-1 is ev[ch]; the slot behind the chunk ev[ch + 1] (ch is uniform but not a constant:
@@ -1134,7 +1199,7 @@ __global__ __launch_bounds__(kBlock) void vp_gather_fast_kernel(const VpFastArgs
     // ---------------------------------------------------------------- the last run goes on behind the window (<= kLongRun slots)
     float4 eacc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = s0 + cap; base < T; base += cap)
-        if (vp_fast_run_batch<FB>(eacc, base, T, carry_vox, g, cl, ch, ingroup, gs, a.order, a.slot_voxel, f_rsrc, row_in, lane_in, idw))
+        if (vp_fast_run_batch<FB, FUSED>(eacc, base, T, carry_vox, g, cl, ch, ingroup, gs, a.order, a.slot_voxel, f_rsrc, row_in, lane_in, idw, a, prw))
             break;
     for (int g2 = 0; g2 < groups; ++g2) vacc(carry, vp_from_lane(eacc, g2 * lpr + src_cl));
     vp_buf_emit<OB, ACC>(o_rsrc, g == 0 ? carry_vox : -1, row_out, lane_out, pad_off, carry);
@@ -1214,21 +1279,22 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
         const long long waves = (L.total + G.w_nom - 1) / G.w_nom;
         const int nblk = cdiv(waves, kBlock / 64);
         const int nlong = L.long_cap < kLongBlocks ? L.long_cap : kLongBlocks;
-        if constexpr (!FUSED) {
+        {
             // the instruction-lean kernel addresses both tensors with 32-bit byte offsets (dead slots point past the end)
-            const unsigned long long fbytes = (unsigned long long)L.total * C * (FB ? 2 : 4);
+            const unsigned long long fbytes = FUSED ? (unsigned long long)B * P * C * 4 : (unsigned long long)L.total * C * (FB ? 2 : 4);
             const unsigned long long obytes = (unsigned long long)L.V * (OB ? ldo * 2 : C * 4);
             static const bool generic_env = [] { const char *e = getenv("SGV3D_VP_GENERIC"); return e && e[0] == '1'; }();
             if (fbytes < 0xfff00000ull && obytes < 0xfff00000ull && L.total < 0x7ff00000ll && !generic_env) {
                 VpFastArgs a;
                 a.seg_start = seg; a.order = order; a.slot_voxel = slotvox;
                 a.long_list = reinterpret_cast<const int *>(base + L.off_long);
-                a.feats = feats; a.out = out; a.gate = gate;
+                a.feats = FUSED ? static_cast<const void *>(ctx) : static_cast<const void *>(feats); a.out = out; a.gate = gate;
+                a.prob = prob; a.P = P;
                 a.feat_bytes = (unsigned)fbytes; a.out_bytes = (unsigned)obytes;
                 a.V = (int)L.V; a.C = C; a.lpr = G.lpr; a.groups = G.groups; a.ch = G.ch; a.w_nom = G.w_nom; a.ldo = ldo;
                 a.long_cap = L.long_cap; a.nblk_regular = nblk; a.N = N;
-                hipLaunchKernelGGL((vp_gather_fast_kernel<FB, OB, ACC>), dim3(nblk + nlong), dim3(kBlock), 0, st, a);
-                return check_launch("vp_gather_fast_kernel");
+                hipLaunchKernelGGL((vp_gather_fast_kernel<FB, OB, ACC, FUSED>), dim3(nblk + nlong), dim3(kBlock), 0, st, a);
+                return check_launch(FUSED ? "vp_gather_fast_kernel (lift-splat)" : "vp_gather_fast_kernel");
             }
         }
         hipLaunchKernelGGL((vp_gather3_kernel<FUSED, FB, OB, ACC>), dim3(nblk + nlong), dim3(kBlock), 0, st, L.V, C, G.lpr,
@@ -1637,6 +1703,24 @@ extern "C" int sgv3d_lift_splat_planned(int batch_size, int num_depth, int num_p
                   "lift_splat_planned: context/output must be 16-B aligned");
     return launch_gather<true>(batch_size, (int)N, num_channels, num_voxel_x, num_voxel_y, plan, nullptr, prob,
                                context, num_pixels, output_features, workspace, workspace_bytes, as_stream(stream));
+}
+
+extern "C" int sgv3d_lift_splat_planned_bf16out(int batch_size, int num_depth, int num_pixels, int num_channels, int num_voxel_x,
+                                                int num_voxel_y, const void *plan, const float *prob, const float *context,
+                                                void *output_bf16, int out_bf16_ld, void *workspace, size_t workspace_bytes,
+                                                void *stream) {
+    SGV3D_REQUIRE(num_depth > 0 && num_pixels > 0, "lift_splat_planned_bf16out: non-positive size");
+    const long long N = (long long)num_depth * num_pixels;
+    SGV3D_REQUIRE(N < 0x7fffffffLL, "lift_splat_planned_bf16out: D*P too large");
+    if (int rc = check_common(batch_size, (int)N, num_channels, num_voxel_x, num_voxel_y, 1)) return rc;
+    SGV3D_REQUIRE(plan && prob && context && output_bf16, "lift_splat_planned_bf16out: null pointer");
+    SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(context) & 15) == 0 && (reinterpret_cast<uintptr_t>(output_bf16) & 15) == 0,
+                  "lift_splat_planned_bf16out: context/output must be 16-B aligned");
+    SGV3D_REQUIRE(out_bf16_ld >= num_channels && out_bf16_ld % 4 == 0 && out_bf16_ld - num_channels <= 4 * (num_channels / 4),
+                  "lift_splat_planned_bf16out: out_bf16_ld must be a multiple of 4 in [C, 2C]");
+    return launch_gather<true, false, true>(batch_size, (int)N, num_channels, num_voxel_x, num_voxel_y, plan, nullptr, prob, context,
+                                            num_pixels, static_cast<float *>(output_bf16), workspace, workspace_bytes,
+                                            as_stream(stream), out_bf16_ld);
 }
 
 extern "C" int sgv3d_voxel_pooling_backward(int batch_size, int num_points, int num_channels,

@@ -21,7 +21,7 @@ from torch import nn
 from ... import hip_ops
 from ...calibration import CalibrationCache
 from ..blocks import BasicBlock, HipModule, build_backbone, build_neck, conv_bn
-from .lss_fpn import ASPP, HeightNet, LSSFPN, Mlp, SELayer, _require_hip_inference
+from .lss_fpn import ASPP, FUSE_LIFT_SPLAT, HeightNet, LSSFPN, Mlp, SELayer, _require_hip_inference
 
 __all__ = ['BSMLSSFPN']
 
@@ -230,7 +230,7 @@ class BSMLSSFPN(LSSFPN):
         self._voxel_size_host = [float(np.float32(row[2])) for row in [x_bound, y_bound, z_bound]]
         self.semantic_channels = height_net_conf['semantic_channels']
         self.background_threshold = 0.45                                     # :528
-        self.fuse_lift_splat = False
+        self.fuse_lift_splat = FUSE_LIFT_SPLAT      # as LSSFPN
         self.calib_cache = CalibrationCache()
 
     def _configure_height_net(self, height_net_conf):
@@ -265,12 +265,12 @@ class BSMLSSFPN(LSSFPN):
                             self.background_threshold)                        # :521-529
         geom_xyz, plan = self.calibration(mats_dict, sweep_index)             # :540-553 (cached per calibration)
         fH, fW = int(hc.shape[1]), int(hc.shape[2])
-        if self.fuse_lift_splat:
-            assert num_cams == 1
+        if self.fuse_lift_splat and num_cams == 1:
             prob, _ = hip_ops.lift(hc, D, Cp, want_prob=True, want_lifted=False)
             ctx = torch.empty(batch_size, fH, fW, Cp, dtype=torch.float32, device=hc.device)
             hip_ops.copy_channels(hc, ctx, coff=D)
-            bev = plan.lift_splat(prob, ctx.view(batch_size, fH * fW, Cp))
+            ldo = hip_ops.pad_channels(Cp) if (nhwc_out and hip_ops.activation_dtype(Cp) == torch.bfloat16 and getattr(self, '_single_sweep', True)) else 0
+            bev = plan.lift_splat(prob, ctx.view(batch_size, fH * fW, Cp), out_bf16_ld=ldo)
         else:
             _, lifted = hip_ops.lift(hc, D, Cp, lifted_dtype=hip_ops.activation_dtype(Cp))
             ldo = hip_ops.pad_channels(Cp) if (nhwc_out and lifted.dtype == torch.bfloat16 and getattr(self, '_single_sweep', True)) else 0    # as in LSSFPN

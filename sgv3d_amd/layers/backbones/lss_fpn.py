@@ -27,6 +27,10 @@ from ...calibration import CalibrationCache
 from ...ops.voxel_pooling import VoxelPlan
 from ..blocks import BasicBlock, HipModule, build_backbone, build_neck, conv_bn
 
+import os as _os
+
+FUSE_LIFT_SPLAT = _os.environ.get("SGV3D_FUSE_LIFT_SPLAT", "1") != "0"   # 0: lift kernel + voxel_pooling operator (the reference's two steps)
+
 __all__ = ['LSSFPN']
 
 
@@ -296,7 +300,9 @@ class LSSFPN(HipModule):
         self._voxel_num_host = tuple(int(round(q)) for q in nums)
         self._voxel_coord_host = [float(np.float32(row[0] + row[2] / 2.0)) for row in [x_bound, y_bound, z_bound]]
         self._voxel_size_host = [float(np.float32(row[2])) for row in [x_bound, y_bound, z_bound]]
-        self.fuse_lift_splat = False    # True: skip the [B,N,C] lifted tensor
+        # the [B,N,C] lifted tensor is not materialised: rows are formed as prob * context inside the pooling
+        # gather, bitwise the sums of the two-kernel form in f32.  False: lift kernel + voxel_pooling operator, as the reference
+        self.fuse_lift_splat = FUSE_LIFT_SPLAT
         # voxel indices + voxel-pooling plan of the calibration last seen (sgv3d_amd/calibration.py); a
         # FramePipeline swaps in one cache per frame slot
         self.calib_cache = CalibrationCache()
@@ -414,12 +420,12 @@ class LSSFPN(HipModule):
         D, C = self.height_channels, self.output_channels
         geom_xyz, plan = self.calibration(mats_dict, sweep_index)              # :478-488, int32 [B,N,D,fH,fW,3] + CSR plan
         fH, fW = int(height_feature.shape[1]), int(height_feature.shape[2])
-        if self.fuse_lift_splat:
+        if self.fuse_lift_splat and num_cams == 1:            # (one camera per sample: point id = depth * pixels + pixel)
             prob, _ = hip_ops.lift(height_feature, D, C, want_prob=True, want_lifted=False)
-            assert num_cams == 1, "fused lift-splat is implemented for one camera per sample"
             ctx = torch.empty(batch_size, fH * fW, C, dtype=torch.float32, device=height_feature.device)
             hip_ops.copy_channels(height_feature, ctx.view(batch_size, fH, fW, C), coff=D)
-            bev = plan.lift_splat(prob, ctx)                                   # [B,Y,X,C]
+            ldo = hip_ops.pad_channels(C) if (nhwc_out and hip_ops.activation_dtype(C) == torch.bfloat16 and getattr(self, '_single_sweep', True)) else 0
+            bev = plan.lift_splat(prob, ctx, out_bf16_ld=ldo)                  # [B,Y,X,C] (bf16-activation hand-off: [B,Y,X,ldo] bf16)
         else:
             # (bf16 compute mode: the lifted tensor -- the largest HBM stream of the path -- is bf16, pooled sums stay f32)
             _, lifted = hip_ops.lift(height_feature, D, C, lifted_dtype=hip_ops.activation_dtype(C))   # [B*N, D, fH*fW, C] == :486 permute + contiguous

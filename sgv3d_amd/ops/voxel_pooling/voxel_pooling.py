@@ -155,15 +155,25 @@ class VoxelPlan:
         _lib.check(rc, "sgv3d_voxel_pooling_forward_planned")
         return out
 
-    def lift_splat(self, prob, context, out=None):
-        """Fused path: prob f32 [B, D, P], context f32 [B, P, C] -> [B, Y, X, C]."""
+    def lift_splat(self, prob, context, out=None, out_bf16_ld=0):
+        """Fused path: prob f32 [B, D, P], context f32 [B, P, C] -> [B, Y, X, C] (``out_bf16_ld``: bf16 rows of that many
+        channels, padding zeroed -- the bf16-activation hand-off of ``pool``)."""
         B, D, P = (int(s) for s in prob.shape)
         C = int(context.shape[-1])
         assert B == self.B and D * P == self.N and context.shape[:2] == (B, P)
         assert prob.is_contiguous() and context.is_contiguous()
+        ws, nws = self._workspace(C)
+        if out_bf16_ld:
+            if out is None:
+                out = torch.empty(B, self.Y, self.X, int(out_bf16_ld), dtype=torch.bfloat16, device=context.device)
+            with torch.cuda.device(context.device), hip_ops.prof("lift_splat_planned"):
+                rc = _lib.load().sgv3d_lift_splat_planned_bf16out(B, D, P, C, self.X, self.Y, self.buf.data_ptr(), prob.data_ptr(),
+                                                                 context.data_ptr(), out.data_ptr(), int(out_bf16_ld), ws.data_ptr(),
+                                                                 nws, _lib.stream_handle(context.device))
+            _lib.check(rc, "sgv3d_lift_splat_planned_bf16out")
+            return out
         if out is None:
             out = context.new_empty(B, self.Y, self.X, C)
-        ws, nws = self._workspace(C)
         with torch.cuda.device(context.device), hip_ops.prof("lift_splat_planned"):
             rc = _lib.load().sgv3d_lift_splat_planned(B, D, P, C, self.X, self.Y, self.buf.data_ptr(),
                                                      prob.data_ptr(), context.data_ptr(), out.data_ptr(),

@@ -59,12 +59,13 @@ def test_image_features_and_heightnet(small):
 @pytest.mark.parametrize("fused", [False, True])
 def test_bev_features(small, fused):
     m = small['m']
+    default = m.backbone.fuse_lift_splat
     m.backbone.fuse_lift_splat = fused
     try:
         with torch.no_grad():
             bev = m.backbone(small['imgs'].to(DEV), _to_dev(small['mats']))
     finally:
-        m.backbone.fuse_lift_splat = False
+        m.backbone.fuse_lift_splat = default
     assert bev.shape == small['keep']['bev'].shape and bev.is_contiguous()      # [B, C, Y, X] like lss_fpn.py:495
     torch.testing.assert_close(bev.cpu(), small['keep']['bev'], **TOL)
     assert (bev != 0).any()
@@ -162,12 +163,15 @@ def test_bsm_variant_sgv3d():
     assert 0.02 < (sem[:, 0] > 0.45).float().mean() < 0.98, "fixture must exercise the background mask"
     m = m.to(DEV)
     dmats = _to_dev(mats)
+    default = m.backbone.fuse_lift_splat
     with torch.no_grad():
+        m.backbone.fuse_lift_splat = False                     # lift kernel + voxel_pooling operator
         bev = m.backbone(imgs.to(DEV), dmats)
-        preds = m(imgs.to(DEV), dmats)
-        m.backbone.fuse_lift_splat = True
+        m.backbone.fuse_lift_splat = True                      # rows formed inside the pooling gather
         bev_fused = m.backbone(imgs.to(DEV), dmats)
-        m.backbone.fuse_lift_splat = False
+        m.backbone.fuse_lift_splat = default
+        preds = m(imgs.to(DEV), dmats)
+    assert torch.equal(bev, bev_fused)                         # (f32: the same products summed in the same order)
     assert bev.shape == keep['bev'].shape == (2, 87, 64, 64)
     torch.testing.assert_close(bev.cpu(), keep['bev'], **TOL)
     torch.testing.assert_close(bev_fused.cpu(), keep['bev'], **TOL)
