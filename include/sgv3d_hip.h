@@ -137,9 +137,12 @@ int sgv3d_lift_splat_planned(int batch_size, int num_depth, int num_pixels, int 
                              void *stream);
 
 /* The same with the pooled map written as bf16 rows of out_bf16_ld >= C channels (padding channels zeroed), the hand-off
- * sgv3d_voxel_pooling_forward_planned_bf16 offers: sums in f32 (products not rounded to bf16 first), one rounding on the store. */
+ * sgv3d_voxel_pooling_forward_planned_bf16 offers: sums in f32 (products not rounded to bf16 first), one rounding on the store.
+ * context_bf16 != 0: `context` is bf16 [B, P, C] (8-byte aligned rows: C % 4 == 0); products and sums stay f32.  (Half the
+ * L2 -> CU bytes, but the launch is bound by its vector instructions and the unpacking costs more than the bytes save: the
+ * model passes f32 rows.) */
 int sgv3d_lift_splat_planned_bf16out(int batch_size, int num_depth, int num_pixels, int num_channels, int num_voxel_x,
-                                     int num_voxel_y, const void *plan, const float *prob, const float *context,
+                                     int num_voxel_y, const void *plan, const float *prob, const void *context, int context_bf16,
                                      void *output_bf16, int out_bf16_ld, void *workspace, size_t workspace_bytes, void *stream);
 
 /* VoxelPooling.backward  ops/voxel_pooling/voxel_pooling.py:58-69

@@ -40,7 +40,7 @@ _PROTOS = {
     "sgv3d_voxel_pooling_workspace_bytes": (c_size_t, [c_int] * 3),
     "sgv3d_voxel_pooling_forward_planned": (c_int, [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_void_p]),
     "sgv3d_voxel_pooling_forward_planned_bf16": (c_int, [c_int] * 5 + [c_void_p] * 3 + [c_int, c_void_p, c_size_t, c_void_p]),
-    "sgv3d_lift_splat_planned_bf16out": (c_int, [c_int] * 6 + [c_void_p] * 4 + [c_int, c_void_p, c_size_t, c_void_p]),
+    "sgv3d_lift_splat_planned_bf16out": (c_int, [c_int] * 6 + [c_void_p] * 3 + [c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "sgv3d_lift_splat_planned": (c_int, [c_int] * 6 + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "sgv3d_voxel_pooling_backward": (c_int, [c_int] * 3 + [c_void_p, c_void_p, c_ll, c_ll, c_ll, c_ll, c_void_p, c_void_p]),
     "sgv3d_calib_prep": (c_int, [c_int] + [c_void_p] * 6),

@@ -632,6 +632,10 @@ __device__ __forceinline__ float4 vp_load_row(const float *__restrict__ feats, c
         const int b = idx / N;
         const int pix = (idx - b * N) % P;
         pr = prob[idx];
+        if constexpr (FB) {                  // bf16 context rows
+            const vp_bf16x4 q = *reinterpret_cast<const vp_bf16x4 *>(reinterpret_cast<const __bf16 *>(ctx) + ((size_t)b * P + pix) * C + (size_t)cl * 4);
+            return make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+        }
         return *reinterpret_cast<const float4 *>(ctx + ((size_t)b * P + pix) * C + (size_t)cl * 4);
     } else if constexpr (FB) {
         const vp_bf16x4 q = *reinterpret_cast<const vp_bf16x4 *>(reinterpret_cast<const __bf16 *>(feats) + (size_t)idx * C + (size_t)cl * 4);
@@ -1281,7 +1285,7 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
         const int nlong = L.long_cap < kLongBlocks ? L.long_cap : kLongBlocks;
         {
             // the instruction-lean kernel addresses both tensors with 32-bit byte offsets (dead slots point past the end)
-            const unsigned long long fbytes = FUSED ? (unsigned long long)B * P * C * 4 : (unsigned long long)L.total * C * (FB ? 2 : 4);
+            const unsigned long long fbytes = (FUSED ? (unsigned long long)B * P : (unsigned long long)L.total) * C * (FB ? 2 : 4);
             const unsigned long long obytes = (unsigned long long)L.V * (OB ? ldo * 2 : C * 4);
             static const bool generic_env = [] { const char *e = getenv("SGV3D_VP_GENERIC"); return e && e[0] == '1'; }();
             if (fbytes < 0xfff00000ull && obytes < 0xfff00000ull && L.total < 0x7ff00000ll && !generic_env) {
@@ -1706,9 +1710,9 @@ extern "C" int sgv3d_lift_splat_planned(int batch_size, int num_depth, int num_p
 }
 
 extern "C" int sgv3d_lift_splat_planned_bf16out(int batch_size, int num_depth, int num_pixels, int num_channels, int num_voxel_x,
-                                                int num_voxel_y, const void *plan, const float *prob, const float *context,
-                                                void *output_bf16, int out_bf16_ld, void *workspace, size_t workspace_bytes,
-                                                void *stream) {
+                                                int num_voxel_y, const void *plan, const float *prob, const void *context,
+                                                int context_bf16, void *output_bf16, int out_bf16_ld, void *workspace,
+                                                size_t workspace_bytes, void *stream) {
     SGV3D_REQUIRE(num_depth > 0 && num_pixels > 0, "lift_splat_planned_bf16out: non-positive size");
     const long long N = (long long)num_depth * num_pixels;
     SGV3D_REQUIRE(N < 0x7fffffffLL, "lift_splat_planned_bf16out: D*P too large");
@@ -1718,9 +1722,13 @@ extern "C" int sgv3d_lift_splat_planned_bf16out(int batch_size, int num_depth, i
                   "lift_splat_planned_bf16out: context/output must be 16-B aligned");
     SGV3D_REQUIRE(out_bf16_ld >= num_channels && out_bf16_ld % 4 == 0 && out_bf16_ld - num_channels <= 4 * (num_channels / 4),
                   "lift_splat_planned_bf16out: out_bf16_ld must be a multiple of 4 in [C, 2C]");
-    return launch_gather<true, false, true>(batch_size, (int)N, num_channels, num_voxel_x, num_voxel_y, plan, nullptr, prob, context,
-                                            num_pixels, static_cast<float *>(output_bf16), workspace, workspace_bytes,
-                                            as_stream(stream), out_bf16_ld);
+    if (context_bf16)      // context rows as bf16 (half the L2 -> CU bytes of the launch): products and sums stay f32
+        return launch_gather<true, true, true>(batch_size, (int)N, num_channels, num_voxel_x, num_voxel_y, plan, nullptr, prob,
+                                               static_cast<const float *>(context), num_pixels, static_cast<float *>(output_bf16),
+                                               workspace, workspace_bytes, as_stream(stream), out_bf16_ld);
+    return launch_gather<true, false, true>(batch_size, (int)N, num_channels, num_voxel_x, num_voxel_y, plan, nullptr, prob,
+                                            static_cast<const float *>(context), num_pixels, static_cast<float *>(output_bf16), workspace,
+                                            workspace_bytes, as_stream(stream), out_bf16_ld);
 }
 
 extern "C" int sgv3d_voxel_pooling_backward(int batch_size, int num_points, int num_channels,

@@ -267,9 +267,9 @@ class BSMLSSFPN(LSSFPN):
         fH, fW = int(hc.shape[1]), int(hc.shape[2])
         if self.fuse_lift_splat and num_cams == 1:
             prob, _ = hip_ops.lift(hc, D, Cp, want_prob=True, want_lifted=False)
-            ctx = torch.empty(batch_size, fH, fW, Cp, dtype=torch.float32, device=hc.device)
-            hip_ops.copy_channels(hc, ctx, coff=D)
             ldo = hip_ops.pad_channels(Cp) if (nhwc_out and hip_ops.activation_dtype(Cp) == torch.bfloat16 and getattr(self, '_single_sweep', True)) else 0
+            ctx = torch.empty(batch_size, fH, fW, Cp, dtype=torch.float32, device=hc.device)     # (f32 rows, as LSSFPN)
+            hip_ops.copy_channels(hc, ctx, coff=D)
             bev = plan.lift_splat(prob, ctx.view(batch_size, fH * fW, Cp), out_bf16_ld=ldo)
         else:
             _, lifted = hip_ops.lift(hc, D, Cp, lifted_dtype=hip_ops.activation_dtype(Cp))

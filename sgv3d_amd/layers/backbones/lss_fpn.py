@@ -422,9 +422,11 @@ class LSSFPN(HipModule):
         fH, fW = int(height_feature.shape[1]), int(height_feature.shape[2])
         if self.fuse_lift_splat and num_cams == 1:            # (one camera per sample: point id = depth * pixels + pixel)
             prob, _ = hip_ops.lift(height_feature, D, C, want_prob=True, want_lifted=False)
+            ldo = hip_ops.pad_channels(C) if (nhwc_out and hip_ops.activation_dtype(C) == torch.bfloat16 and getattr(self, '_single_sweep', True)) else 0
+            # (f32 context rows also in bf16-activation mode: the gather is bound by its vector instructions, not by the rows it
+            # pulls from L2 -- with bf16 rows, which the entry point accepts, the unpacking made it 7 % slower)
             ctx = torch.empty(batch_size, fH * fW, C, dtype=torch.float32, device=height_feature.device)
             hip_ops.copy_channels(height_feature, ctx.view(batch_size, fH, fW, C), coff=D)
-            ldo = hip_ops.pad_channels(C) if (nhwc_out and hip_ops.activation_dtype(C) == torch.bfloat16 and getattr(self, '_single_sweep', True)) else 0
             bev = plan.lift_splat(prob, ctx, out_bf16_ld=ldo)                  # [B,Y,X,C] (bf16-activation hand-off: [B,Y,X,ldo] bf16)
         else:
             # (bf16 compute mode: the lifted tensor -- the largest HBM stream of the path -- is bf16, pooled sums stay f32)

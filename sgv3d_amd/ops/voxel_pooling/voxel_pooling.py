@@ -161,17 +161,20 @@ class VoxelPlan:
         B, D, P = (int(s) for s in prob.shape)
         C = int(context.shape[-1])
         assert B == self.B and D * P == self.N and context.shape[:2] == (B, P)
-        assert prob.is_contiguous() and context.is_contiguous()
+        assert prob.is_contiguous() and context.is_contiguous() and prob.dtype == torch.float32
         ws, nws = self._workspace(C)
         if out_bf16_ld:
+            assert context.dtype in (torch.float32, torch.bfloat16)
             if out is None:
                 out = torch.empty(B, self.Y, self.X, int(out_bf16_ld), dtype=torch.bfloat16, device=context.device)
             with torch.cuda.device(context.device), hip_ops.prof("lift_splat_planned"):
                 rc = _lib.load().sgv3d_lift_splat_planned_bf16out(B, D, P, C, self.X, self.Y, self.buf.data_ptr(), prob.data_ptr(),
-                                                                 context.data_ptr(), out.data_ptr(), int(out_bf16_ld), ws.data_ptr(),
+                                                                 context.data_ptr(), 1 if context.dtype == torch.bfloat16 else 0,
+                                                                 out.data_ptr(), int(out_bf16_ld), ws.data_ptr(),
                                                                  nws, _lib.stream_handle(context.device))
             _lib.check(rc, "sgv3d_lift_splat_planned_bf16out")
             return out
+        assert context.dtype == torch.float32, "bf16 context rows come with the bf16 hand-off output (out_bf16_ld)"
         if out is None:
             out = context.new_empty(B, self.Y, self.X, C)
         with torch.cuda.device(context.device), hip_ops.prof("lift_splat_planned"):

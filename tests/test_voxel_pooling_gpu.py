@@ -250,6 +250,33 @@ def test_fused_lift_splat_matches_materialised(hip, golden):
     assert torch.equal(plan.lift_splat(prob, ctx), plan.pool(lifted))
 
 
+@pytest.mark.parametrize("C,ld", [(80, 96), (88, 96), (24, 32)])
+def test_fused_lift_splat_random_data_and_bf16_forms(hip, C, ld):
+    """The fused gather on random (non-integer) data: f32 bitwise the lift + pool result (products rounded before the add, same
+    order); the bf16 hand-off output = the f32 sums rounded once, padding channels zero; bf16 context rows = the f32 kernel on the
+    rounded context."""
+    from sgv3d_amd.ops.voxel_pooling import VoxelPlan
+    rng = np.random.default_rng(C)
+    B, D, P, X, Y = 2, 9, 77, 10, 9
+    geom = torch.from_numpy(rng.integers(-2, 12, size=(B, D * P, 3)).astype(np.int32)).to(DEV)
+    geom[..., 2] = 0
+    geom[0, : D * P // 3, :2] = 3                                   # one long run (more slots than a wave's window)
+    prob = torch.from_numpy(rng.random(size=(B, D, P)).astype(np.float32)).to(DEV)
+    ctx = torch.from_numpy(rng.standard_normal(size=(B, P, C)).astype(np.float32)).to(DEV)
+    lifted = (prob[..., None] * ctx[:, None]).reshape(B, D * P, C).contiguous()
+    plan = VoxelPlan(geom, (X, Y, 1))
+    want = plan.pool(lifted)
+    got = plan.lift_splat(prob, ctx)
+    assert torch.equal(got, want)
+    ob = plan.lift_splat(prob, ctx, out_bf16_ld=ld)
+    assert ob.dtype == torch.bfloat16 and tuple(ob.shape) == (B, Y, X, ld)
+    assert torch.equal(ob[..., :C], want.bfloat16()) and float(ob[..., C:].float().abs().max()) == 0
+    cb = ctx.bfloat16()
+    ob2 = plan.lift_splat(prob, cb, out_bf16_ld=ld)
+    want2 = plan.lift_splat(prob, cb.float())
+    assert torch.equal(ob2[..., :C], want2.bfloat16()) and float(ob2[..., C:].float().abs().max()) == 0
+
+
 def test_cached_plan_rebuilds_only_on_change(hip):
     """VoxelPlan(cached=True): the device-side compare skips the build while geom_xyz is bytewise unchanged (also for a
     fresh tensor object with the same content), rebuilds after a single changed index, and every result equals the
