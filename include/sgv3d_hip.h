@@ -525,6 +525,10 @@ int sgv3d_conv3x3_patch_bf16_forward(int batch, int h, int w, int cin, int cout,
 #define SGV3D_TILE_DW_256x64 33
 #define SGV3D_TILE_DW_128x256 34
 #define SGV3D_TILE_DW_256x128 35
+/* ... with activation rows and weight fragments requested two k-chunks ahead instead of one (two workgroups per CU): for the
+ * launches that leave about one workgroup per CU, where nothing else covers the memory round trips.  Same results bit for bit. */
+#define SGV3D_TILE_DW_64x256_DEEP 36
+#define SGV3D_TILE_DW_128x128_DEEP 37
 size_t sgv3d_conv_dw_bf16_weight_bytes(int cout, int cin, int kh, int kw);
 int sgv3d_conv_dw_bf16_pack_weight(const float *w, int cout, int cin_w, int cin, int kh, int kw, void *w_packed, void *stream);
 int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *desc /*host*/, const void *x, const void *w_packed, const float *scale,

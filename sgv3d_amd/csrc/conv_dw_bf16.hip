@@ -87,9 +87,14 @@ __global__ __launch_bounds__(64) void dw_pack_kernel(const float *__restrict__ w
 // NTAIL: N is not a multiple of the tile's 64 WN columns -- some waves (or half-waves) of the last column tile own no channel
 // SPLIT: blockIdx.y owns a range of the 64-k chunks and stores raw f32 partial sums to a.ws [split][M][N] (dw_splitk_reduce_kernel adds
 // them in split order and runs the epilogue) -- for the maps whose tiles do not fill the chip (cfg-5 at batch 1: 82 - 162 workgroups)
-template <int WM, int WN, int MT, bool NTAIL, bool SPLIT = false>
-__global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM == 2 ? 3 : 2) void conv_dw_bf16_kernel(const DwArgs a) {
+// DEEP: activation rows and weight fragments are requested TWO chunks ahead (two register sets each, the loop unrolled by two) --
+// for the layers whose grid leaves one workgroup per CU (cfg-5 at batch 1: 81 tiles of 64 pixels): with one wave per SIMD nothing
+// else covers the ~1 - 2 k cycles of an L2 / HBM round trip, and a chunk is only 512 cycles of MFMAs.  Costs 40 registers
+// (two workgroups per CU), same arithmetic in the same order: bitwise the plain instantiation.
+template <int WM, int WN, int MT, bool NTAIL, bool SPLIT = false, bool DEEP = false>
+__global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM == 2 ? 3 : 2) void conv_dw_bf16_kernel(const DwArgs a) {
     static_assert(WM * WN == 4 && (MT == 2 || MT == 4), "four waves, 64 or 128 pixels per wave");
+    static_assert(!DEEP || (MT == 2 && !SPLIT), "the two-chunks-ahead form exists for the 64-pixel wave tiles, unsplit");
     constexpr int WROWS = 32 * MT;                           // pixels per wave
     constexpr int BM = WROWS * WM, BN = 64 * WN;
     constexpr int A_LD = BM / 32;                            // 16-byte loads per thread and chunk
@@ -116,7 +121,10 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM =
     // activation rows: thread -> (16-byte chunk c8 of the 128-byte row segment, rows r0 + 32 i).  a_base: byte offset of the
     // row's top-left tap (may lie "before" the tensor: 32-bit wrap-around arithmetic, only used when the tap is inside the image)
     const int c8 = tid & 7, r0 = tid >> 3;
-    const bool plain = a.kh == 1 && a.kw == 1 && a.pad == 0;          // no tap can fall outside the image
+    // no tap can fall outside the image: scalar tap offsets, no bounds checks.  (DEEP takes the general path for every layer: with
+    // both paths in its unrolled loop the compiler joins them with a flag and then waits for ALL outstanding loads before it
+    // reuses the row registers -- the requests that were meant to stay in flight for two chunks.)
+    const bool plain = !DEEP && a.kh == 1 && a.kw == 1 && a.pad == 0;
     unsigned a_base[A_LD];
     int a_ih0[A_LD], a_iw0[A_LD];
 #pragma unroll
@@ -149,6 +157,8 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM =
 
     u32x4 ra[A_LD];
     bf16x8 wf[4][2];
+    [[maybe_unused]] u32x4 rb[A_LD];         // DEEP: second set (ra = rows of the odd chunks, rb = of the even ones)
+    [[maybe_unused]] bf16x8 wg[4][2];        // DEEP: second set (wf = fragments of the even chunks, wg = of the odd ones)
     f32x16 acc[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -207,16 +217,18 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM =
         ld_kh = kh1_; ld_kw = kw1_; ld_cb = cb1_ + 1;                                                      \
         if (ld_cb == a.bpt) { ld_cb = 0; if (++ld_kw == a.kw) { ld_kw = 0; ++ld_kh; } }                    \
     } while (0)
-#define DW_STORE_A(BUF)                                                                                    \
+#define DW_STORE_A_(BUF, R)                                                                                \
     do {                                                                                                   \
         _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                   \
-            *reinterpret_cast<u32x4 *>(st_ptr + (BUF) * kBufB + i * 32 * kRowB) = ra[i];                   \
+            *reinterpret_cast<u32x4 *>(st_ptr + (BUF) * kBufB + i * 32 * kRowB) = R[i];                    \
     } while (0)
-#define DW_LOAD_W(C, S)                                                                                    \
+#define DW_STORE_A(BUF) DW_STORE_A_(BUF, ra)
+#define DW_LOAD_W_(WF, C, S)                                                                               \
     do {                                                                                                   \
-        wf[S][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, w_s0 + ((C) * 4 + (S)) * kFragB, 0)); \
-        wf[S][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, w_s1 + ((C) * 4 + (S)) * kFragB, 0)); \
+        WF[S][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, w_s0 + ((C) * 4 + (S)) * kFragB, 0)); \
+        WF[S][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, w_s1 + ((C) * 4 + (S)) * kFragB, 0)); \
     } while (0)
+#define DW_LOAD_W(C, S) DW_LOAD_W_(wf, C, S)
 #define DW_READ_A(FA, BUF, S)                                                                              \
     do {                                                                                                   \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
@@ -225,13 +237,14 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM =
 // (n-tiles of the wave that lie beyond N -- N = 160 on a 256-wide tile leaves one wave idle and one half idle -- are not
 // multiplied: their products would be zeros, but a dense bf16 MFMA loop runs at the chip's power limit, and MFMAs on zeros
 // cost the other waves clock)
-#define DW_MFMA(FA, S)                                                                                     \
+#define DW_MFMA_(WF, FA, S)                                                                                \
     do {                                                                                                   \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                \
-            if (nt_live0) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[S][0], FA[mt], acc[mt][0], 0, 0, 0); \
-            if (nt_live1) acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[S][1], FA[mt], acc[mt][1], 0, 0, 0); \
+            if (nt_live0) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[S][0], FA[mt], acc[mt][0], 0, 0, 0); \
+            if (nt_live1) acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[S][1], FA[mt], acc[mt][1], 0, 0, 0); \
         }                                                                                                  \
     } while (0)
+#define DW_MFMA(FA, S) DW_MFMA_(wf, FA, S)
     constexpr bool kPrefetchA = MT == 4 && WM == 1;      // (the 256 x 128 tile has no registers left for it)
 // One k-step.  MT = 4 (two waves per SIMD: the other wave does not always cover an LDS round trip): the fragments of k-step
 // S + 1 are requested before the MFMAs of k-step S (second register set); MT = 2 (four waves per SIMD, 128 registers): read and
@@ -267,54 +280,120 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM =
     // iteration behind its MFMAs (their destination registers double as LDS fragment registers) and then waits for all of
     // them at the top of the next one -- a full memory latency per chunk.
 #define DW_SB() __builtin_amdgcn_sched_barrier(0)
-    // Prologue in the loop's order -- activation rows first, then the fragments -- so that the wait in front of the loop's
-    // ds_write counts the same 8 younger fragment loads on the first pass as on every other (chunk 0 in registers of its own).
-    {
-        u32x4 rp[A_LD];
-        DW_LOAD_A(rp);
-        DW_LOAD_A(ra);
-        DW_SB();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) DW_LOAD_W(c_begin, s);
-        DW_SB();
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) *reinterpret_cast<u32x4 *>(st_ptr + i * 32 * kRowB) = rp[i];
-    }
-    DW_SB();
-    __syncthreads();
-    const int last = c_end - c_begin - 1;
-    for (int c = 0; c < last; ++c) {
-        const int buf = c & 1;
-        DW_STORE_A(buf ^ 1);                            // chunk c + 1, requested one iteration ago (the 8 fragment loads behind it stay in flight)
-        DW_SB();
-        DW_LOAD_A(ra);                                  // chunk c + 2
-        DW_SB();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            DW_MFMA_STEP(buf, s);
+    if constexpr (DEEP) {
+        // chunk c: LDS buffer c & 1, fragments in wf (c even) / wg (c odd); its rows were stored one iteration earlier from ra (c odd)
+        // / rb (c even).  Requests run two chunks ahead; past the last chunk the row requests are dead (zeros, no memory access) and
+        // the fragment requests repeat the last chunk's (the fragment offset is a scalar offset, which the hardware does not check).
+        const int last = c_end - c_begin - 1;
+#define DW_WCHUNK(C) (c_begin + ((C) < last ? (C) : last))
+        {
+            u32x4 rp[A_LD];
+            DW_LOAD_A(rp);                                  // chunk 0
+            DW_LOAD_A(ra);                                  // chunk 1
             DW_SB();
-            DW_LOAD_W(c_begin + c + 1, s);              // into the fragment registers this k-step has just used
+#pragma unroll
+            for (int s = 0; s < 4; ++s) DW_LOAD_W_(wf, c_begin, s);
             DW_SB();
+            DW_LOAD_A(rb);                                  // chunk 2
+            DW_SB();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) DW_LOAD_W_(wg, DW_WCHUNK(1), s);
+            DW_SB();
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) *reinterpret_cast<u32x4 *>(st_ptr + i * 32 * kRowB) = rp[i];
         }
+        DW_SB();
         __syncthreads();
-    }
-    {
-        // last chunk: the residual rows are requested k-step by k-step into the fragment registers it no longer refills
-        // (MT = 4: those of the wave's first n-tile; the second n-tile's follow when the epilogue starts)
-        const int buf = last & 1;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            DW_MFMA_STEP(buf, s);
+#define DW_DEEP_ITER(C, BUF, RNEXT, WCUR)                                                                   \
+    do {                                                                                                   \
+        DW_STORE_A_((BUF) ^ 1, RNEXT);                  /* chunk C + 1, requested two iterations ago */      \
+        DW_SB();                                                                                           \
+        DW_LOAD_A(RNEXT);                               /* chunk C + 3 */                                    \
+        DW_SB();                                                                                           \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                    \
+            DW_READ_A(fa[0], BUF, s);                                                                      \
+            DW_MFMA_(WCUR, fa[0], s);                                                                      \
+            DW_SB();                                                                                       \
+            DW_LOAD_W_(WCUR, DW_WCHUNK((C) + 2), s);    /* chunk C + 2 into the registers this k-step has just used */ \
+            DW_SB();                                                                                       \
+        }                                                                                                  \
+        __syncthreads();                                                                                   \
+    } while (0)
+#define DW_DEEP_LAST(BUF, WCUR)                                                                            \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                    \
+            DW_READ_A(fa[0], BUF, s);                                                                      \
+            DW_MFMA_(WCUR, fa[0], s);                                                                      \
+            DW_SB();                                                                                       \
+            DW_FETCH_RES(s >> 1, 0, s & 1);                                                                \
+            DW_FETCH_RES(s >> 1, 1, s & 1);                                                                \
+            DW_SB();                                                                                       \
+        }                                                                                                  \
+    } while (0)
+        int c = 0;
+        for (; c + 1 < last; c += 2) {
+            DW_DEEP_ITER(c, 0, ra, wf);
+            DW_DEEP_ITER(c + 1, 1, rb, wg);
+        }
+        if (c < last) {                                     // (uniform) one more even chunk before the last, which is odd
+            DW_DEEP_ITER(c, 0, ra, wf);
+            DW_DEEP_LAST(1, wg);
+        } else {
+            DW_DEEP_LAST(0, wf);
+        }
+#undef DW_DEEP_ITER
+#undef DW_DEEP_LAST
+#undef DW_WCHUNK
+    } else {
+        // Prologue in the loop's order -- activation rows first, then the fragments -- so that the wait in front of the loop's
+        // ds_write counts the same 8 younger fragment loads on the first pass as on every other (chunk 0 in registers of its own).
+        {
+            u32x4 rp[A_LD];
+            DW_LOAD_A(rp);
+            DW_LOAD_A(ra);
             DW_SB();
-            if constexpr (SPLIT) {
-            } else if constexpr (MT == 2) {
-                DW_FETCH_RES(s >> 1, 0, s & 1);
-                DW_FETCH_RES(s >> 1, 1, s & 1);
-            } else {
-                DW_FETCH_RES(s, 0, 0);
-                DW_FETCH_RES(s, 0, 1);
+    #pragma unroll
+            for (int s = 0; s < 4; ++s) DW_LOAD_W(c_begin, s);
+            DW_SB();
+    #pragma unroll
+            for (int i = 0; i < A_LD; ++i) *reinterpret_cast<u32x4 *>(st_ptr + i * 32 * kRowB) = rp[i];
+        }
+        DW_SB();
+        __syncthreads();
+        const int last = c_end - c_begin - 1;
+        for (int c = 0; c < last; ++c) {
+            const int buf = c & 1;
+            DW_STORE_A(buf ^ 1);                            // chunk c + 1, requested one iteration ago (the 8 fragment loads behind it stay in flight)
+            DW_SB();
+            DW_LOAD_A(ra);                                  // chunk c + 2
+            DW_SB();
+    #pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                DW_MFMA_STEP(buf, s);
+                DW_SB();
+                DW_LOAD_W(c_begin + c + 1, s);              // into the fragment registers this k-step has just used
+                DW_SB();
             }
-            DW_SB();
+            __syncthreads();
+        }
+        {
+            // last chunk: the residual rows are requested k-step by k-step into the fragment registers it no longer refills
+            // (MT = 4: those of the wave's first n-tile; the second n-tile's follow when the epilogue starts)
+            const int buf = last & 1;
+    #pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                DW_MFMA_STEP(buf, s);
+                DW_SB();
+                if constexpr (SPLIT) {
+                } else if constexpr (MT == 2) {
+                    DW_FETCH_RES(s >> 1, 0, s & 1);
+                    DW_FETCH_RES(s >> 1, 1, s & 1);
+                } else {
+                    DW_FETCH_RES(s, 0, 0);
+                    DW_FETCH_RES(s, 0, 1);
+                }
+                DW_SB();
+            }
         }
     }
     DW_SB();
@@ -672,6 +751,9 @@ __global__ __launch_bounds__(256, 3) void conv_dw_bf16_pair_kernel(const DwArgs 
 #undef DW_SB
 #undef DW_LOAD_A
 #undef DW_STORE_A
+#undef DW_STORE_A_
+#undef DW_LOAD_W_
+#undef DW_MFMA_
 #undef DW_LOAD_W
 #undef DW_FETCH_RES
 #undef DW_MFMA_STEP
@@ -712,7 +794,7 @@ __global__ __launch_bounds__(256) void dw_splitk_reduce_kernel(const DwArgs a) {
     *reinterpret_cast<u32x4 *>(static_cast<__bf16 *>(a.y) + (size_t)row * a.y_ld + a.y_coff + ch) = o;
 }
 
-template <int WM, int WN, int MT, bool NTAIL, bool SPLIT>
+template <int WM, int WN, int MT, bool NTAIL, bool SPLIT, bool DEEP = false>
 int launch_dw_t(const DwArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * MT * WM, BN = 64 * WN;
     DwArgs a = a0;
@@ -721,15 +803,21 @@ int launch_dw_t(const DwArgs &a0, hipStream_t st) {
     constexpr size_t tiles = 2 * (size_t)BM * kRowB, stage = sizeof(float) * 4 * 32 * kStageLd;
     constexpr size_t lds = tiles > stage ? tiles : stage;
     static PerDeviceSize lds_set;
-    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT>), lds, lds_set))
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT, DEEP>), lds, lds_set))
         return fail(SGV3D_ELAUNCH, "conv_dw_bf16: cannot raise the dynamic LDS limit to %zu", lds);
-    hipLaunchKernelGGL((conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT>), dim3(a.tiles_m * a.tiles_n, SPLIT ? a.split : 1), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT, DEEP>), dim3(a.tiles_m * a.tiles_n, SPLIT ? a.split : 1), dim3(256), lds, st, a);
     if constexpr (SPLIT) {
         if (int rc = check_launch("conv_dw_bf16_kernel")) return rc;
         hipLaunchKernelGGL(dw_splitk_reduce_kernel, dim3((unsigned)cdiv((long long)a.M * (a.N >> 3), 256)), dim3(256), 0, st, a);
         return check_launch("dw_splitk_reduce_kernel");
     }
     return check_launch("conv_dw_bf16_kernel");
+}
+
+template <int WM, int WN>
+int launch_dw_deep(const DwArgs &a, hipStream_t st) {
+    if (a.split > 1) return fail(SGV3D_EINVAL, "conv_dw_bf16: the *_DEEP tiles do not split along k");
+    return a.N % (64 * WN) == 0 ? launch_dw_t<WM, WN, 2, false, false, true>(a, st) : launch_dw_t<WM, WN, 2, true, false, true>(a, st);
 }
 
 template <int WM, int WN, int MT>
@@ -826,6 +914,8 @@ extern "C" int sgv3d_conv_dw_bf16_forward_splitk(const sgv3d_conv_desc *d, const
         case SGV3D_TILE_DW_256x64: return launch_dw<4, 1, 2>(a, st);
         case SGV3D_TILE_DW_128x256: return launch_dw<1, 4, 4>(a, st);
         case SGV3D_TILE_DW_256x128: return launch_dw<2, 2, 4>(a, st);
+        case SGV3D_TILE_DW_64x256_DEEP: return launch_dw_deep<1, 4>(a, st);
+        case SGV3D_TILE_DW_128x128_DEEP: return launch_dw_deep<2, 2>(a, st);
         default: return fail(SGV3D_EINVAL, "conv_dw_bf16: desc.tile must be one of SGV3D_TILE_DW_* (got %d)", d->tile);
     }
 }

@@ -119,7 +119,8 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: 
               9: "wino4", 10: "wino4", 15: "wino4",                         # F(4x4,3x3) with the 64x64 / 64x128 / 32x128 GEMM tile
               11: "128x128", 12: "128x64", 13: "64x128", 14: "64x64",      # 11..14: f32x3 of tiles 1..4 (host-side ids)
               21: "128x128", 22: "128x64", 23: "64x128", 24: "64x64",      # 21..24: tiles 1..4 walked m-tile first (SGV3D_TILE_MFIRST)
-              31: "dw_bf16", 32: "dw_bf16", 33: "dw_bf16", 34: "dw_bf16", 35: "dw_bf16"}   # bf16 direct-weight kernel (SGV3D_TILE_DW_*)
+              31: "dw_bf16", 32: "dw_bf16", 33: "dw_bf16", 34: "dw_bf16", 35: "dw_bf16",   # bf16 direct-weight kernel (SGV3D_TILE_DW_*)
+              36: "dw_bf16", 37: "dw_bf16"}                                                # ... requests two k-chunks ahead (*_DEEP)
 MFIRST = _os.environ.get("SGV3D_MFIRST", "1") != "0"
 TILE_WINO = 5       # host-side algorithm id: sgv3d_conv2d_winograd_forward instead of the implicit GEMM
 TILE_WINO_RES = 6   # = SGV3D_WINOGRAD_RESIDENT: its patch-resident variant (cin <= 96, many cout tiles)
@@ -135,7 +136,11 @@ WINO_HALF = _os.environ.get("SGV3D_WINO_HALF", "1") != "0"
 PATCH_BF16 = _os.environ.get("SGV3D_PATCH_BF16", "1") != "0"
 # = SGV3D_TILE_DW_*: bf16 mode, bf16 tensors in and out: the direct-weight implicit GEMM (sgv3d_conv_dw_bf16_forward), pixels x
 # channels per workgroup 64x256 / 128x128 / 256x64 (64 pixels per wave) and 128x256 / 256x128 (128 pixels per wave)
-DW_TILES = (31, 32, 33, 34, 35)
+# 36 / 37 = SGV3D_TILE_DW_64x256_DEEP / 128x128_DEEP: rows and fragments requested two k-chunks ahead (launches of about one
+# workgroup per CU, where nothing else hides the memory round trips); no split-K
+DW_TILES = (31, 32, 33, 34, 35, 36, 37)
+DW_DEEP_TILES = (36, 37)
+DW_DEEP = _os.environ.get("SGV3D_DW_DEEP", "1") != "0"   # 0: the *_DEEP tiles are never candidates
 DW_BF16 = _os.environ.get("SGV3D_DW_BF16", "1") != "0"   # 0: never a candidate
 DW_SPLIT_K = _os.environ.get("SGV3D_DW_SPLITK", "1") != "0"   # 0: the direct-weight kernel is never split along k
 
@@ -624,6 +629,11 @@ class PackedConv:
         if self._dw_eligible(d, gate, io):
             deep = self.kh * self.kw * self.cin >= 512              # enough k for the 128-pixel wave tiles to pay
             tiles += ((31,) + ((34,) if deep else ()) if gemm_n > 128 else (32,) + ((35,) if deep else ()) if gemm_n > 64 else (32, 33))
+            if DW_DEEP and self.kh * self.kw * self.cin >= 256:     # few workgroups per CU: the two-chunks-ahead form of the 64-pixel tiles
+                if gemm_n > 128 and -(-gemm_m // 64) * -(-gemm_n // 256) <= 768:
+                    tiles += (36,)
+                elif 64 < gemm_n <= 128 and -(-gemm_m // 128) * -(-gemm_n // 128) <= 768:
+                    tiles += (37,)
         if fixed_tile:
             tiles = (fixed_tile,)
         dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 64), 6: (256, 64),
@@ -643,9 +653,9 @@ class PackedConv:
                     wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 32) * -(-gemm_n // 64)
                 if t in DW_TILES:
                     nk = -(-(self.kh * self.kw * (self.cin // 32)) // 2)      # chunks of 64 k; >= 4 per split
-                    bm, bn = {31: (64, 256), 32: (128, 128), 33: (256, 64), 34: (128, 256), 35: (256, 128)}[t]
+                    bm, bn = {31: (64, 256), 32: (128, 128), 33: (256, 64), 34: (128, 256), 35: (256, 128), 36: (64, 256), 37: (128, 128)}[t]
                     wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
-                if t == TILE_WINO_RES or t in WINO4_TILES or (t in DW_TILES and (d.mode != CONV_NORMAL or not DW_SPLIT_K)):
+                if t == TILE_WINO_RES or t in WINO4_TILES or t in DW_DEEP_TILES or (t in DW_TILES and (d.mode != CONV_NORMAL or not DW_SPLIT_K)):
                     splits = (1,)
                 elif t in DW_TILES:
                     splits = (fixed_split,) if fixed_split else \

@@ -375,7 +375,7 @@ def test_bf16_io_conv(bf16_mode, shape, tile):
     (1, 1024, 17, 30, 256, 1, False),      # ResNet layer-3 reducing layer
     (1, 128, 31, 33, 320, 2, True),        # odd strided map, cout = 5 n-chunks of 64
 ])
-@pytest.mark.parametrize("tile", [31, 32, 33, 34, 35])
+@pytest.mark.parametrize("tile", [31, 32, 33, 34, 35, 36, 37])
 def test_bf16_direct_weight_conv_1x1(bf16_mode, shape, tile):
     """sgv3d_conv_dw_bf16_forward (host tile ids 31-35 = SGV3D_TILE_DW_*) on 1x1 layers: bf16 tensors in and out.
     Reference: float64 convolution of the bf16-rounded operands, epilogue in high precision, one rounding to bf16 -- and the
@@ -421,7 +421,7 @@ def test_bf16_direct_weight_conv_1x1(bf16_mode, shape, tile):
     (2, 160, 13, 13, 320, 3, 2, 1, 1, False),      # cin = 2.5 chunks per tap
     (1, 32, 12, 9, 64, 5, 1, 2, 1, True),          # 5x5, cin = half a chunk
 ])
-@pytest.mark.parametrize("tile", [31, 32, 33, 34, 35])
+@pytest.mark.parametrize("tile", [31, 32, 33, 34, 35, 36, 37])
 def test_bf16_direct_weight_conv_kxk(bf16_mode, shape, tile):
     """The same kernel as an implicit GEMM over taps: padding, stride, dilation, 7x7; against float64 on the bf16-rounded
     operands (half an ulp of bf16 at the output scale) and against the bf16io implicit-GEMM kernel (other k order: 1 bf16 ulp)."""
@@ -538,6 +538,33 @@ def test_bf16_direct_weight_conv_split_k(bf16_mode, shape, tile):
     assert float((wide[..., :8] - 7).abs().max()) == 0 and float((wide[..., 8 + cout:] - 7).abs().max()) == 0
 
 
+@pytest.mark.parametrize("shape", [
+    # B, cin, H, W, cout, k, stride, pad, dil, residual
+    (1, 1024, 27, 48, 256, 1, 1, 0, 1, False),     # 16 chunks, even count
+    (1, 96, 13, 17, 256, 1, 1, 0, 1, True),        # 1.5 chunks -> two, the second half dead
+    (1, 32, 9, 9, 72, 1, 1, 0, 1, False),          # a single (half) chunk: nothing to prefetch
+    (1, 64, 11, 13, 136, 3, 1, 1, 1, True),        # 9 chunks (odd count), taps outside the image
+    (2, 160, 13, 13, 320, 3, 2, 1, 1, False),      # 2.5 chunks per tap, strided
+    (1, 128, 10, 12, 128, 3, 1, 2, 2, True),       # dilated, 18 chunks
+])
+def test_bf16_direct_weight_conv_deep_prefetch_is_bitwise_the_plain_tile(bf16_mode, shape):
+    """SGV3D_TILE_DW_64x256_DEEP / 128x128_DEEP request rows and fragments two k-chunks ahead (two register sets, loop unrolled by
+    two, the last chunk on either set): the same products in the same order as tiles 31 / 32 -- bitwise, for even and odd chunk
+    counts, one and two chunks, dead half chunks."""
+    B, cin, H, W, cout, k, stride, pad, dil, with_res = shape
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x = torch.randn(B, H, W, cin, generator=g).bfloat16().to(DEV)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    conv = hip_ops.PackedConv(w.to(DEV), stride=stride, pad=pad, dil=dil, scale=(torch.rand(cout, generator=g) + 0.5).to(DEV),
+                              shift=torch.randn(cout, generator=g).to(DEV), relu=True)
+    oh, ow = conv.out_hw(H, W)
+    res = torch.randn(B, oh, ow, cout, generator=g).bfloat16().to(DEV) if with_res else None
+    for plain, deep in ((31, 36), (32, 37)):
+        want = conv(x, residual=res, tile=plain, split_k=1, out_dtype=torch.bfloat16)
+        got = conv(x, residual=res, tile=deep, split_k=1, out_dtype=torch.bfloat16)
+        assert torch.equal(got, want), (plain, deep)
+
+
 def test_bf16_direct_weight_conv_exact_on_small_integers(bf16_mode):
     g = torch.Generator().manual_seed(3)
     x = torch.randint(-3, 4, (2, 192, 12, 21), generator=g).float()
@@ -546,8 +573,8 @@ def test_bf16_direct_weight_conv_exact_on_small_integers(bf16_mode):
         conv = hip_ops.PackedConv(w.to(DEV), pad=pad)
         ref = F.conv2d(x, w, None, 1, pad)                                  # integer sums below 2^24: exact in the f32 accumulators
         xin = x.bfloat16().permute(0, 2, 3, 1).contiguous().to(DEV)
-        for tile in (31, 32, 33, 34, 35):
-            for split in (1, 3):                                            # (exact partial sums: any association gives the same bits)
+        for tile in (31, 32, 33, 34, 35, 36, 37):
+            for split in ((1, 3) if tile < 36 else (1,)):                   # (exact partial sums: any association gives the same bits)
                 y = conv(xin, tile=tile, split_k=split, out_dtype=torch.bfloat16)
                 assert torch.equal(y.float().permute(0, 3, 1, 2).cpu(), ref.bfloat16().float())
 
