@@ -91,12 +91,16 @@ __global__ __launch_bounds__(64) void dw_pack_kernel(const float *__restrict__ w
 // for the layers whose grid leaves one workgroup per CU (cfg-5 at batch 1: 81 tiles of 64 pixels): with one wave per SIMD nothing
 // else covers the ~1 - 2 k cycles of an L2 / HBM round trip, and a chunk is only 512 cycles of MFMAs.  Costs 40 registers
 // (two workgroups per CU), same arithmetic in the same order: bitwise the plain instantiation.
-template <int WM, int WN, int MT, bool NTAIL, bool SPLIT = false, bool DEEP = false>
+// NTW = 1: a wave owns ONE 32-channel tile (workgroup = 64 pixels x 128 channels): twice the workgroups on the maps whose 64 x 256
+// tiles number fewer than the CUs -- those launches are bound by what one CU's vector-memory path delivers (32 KB of fragments per
+// chunk and workgroup at 64 B / clk), and half the fragments per workgroup on twice the CUs is the way to more of those paths.
+template <int WM, int WN, int MT, bool NTAIL, bool SPLIT = false, bool DEEP = false, int NTW = 2>
 __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM == 2 ? 3 : 2) void conv_dw_bf16_kernel(const DwArgs a) {
     static_assert(WM * WN == 4 && (MT == 2 || MT == 4), "four waves, 64 or 128 pixels per wave");
     static_assert(!DEEP || (MT == 2 && !SPLIT), "the two-chunks-ahead form exists for the 64-pixel wave tiles, unsplit");
+    static_assert(NTW == 2 || (NTW == 1 && MT == 2 && !DEEP), "one n-tile per wave: the 64-pixel wave tile only");
     constexpr int WROWS = 32 * MT;                           // pixels per wave
-    constexpr int BM = WROWS * WM, BN = 64 * WN;
+    constexpr int BM = WROWS * WM, BN = 32 * NTW * WN;
     constexpr int A_LD = BM / 32;                            // 16-byte loads per thread and chunk
     constexpr int kBufB = BM * kRowB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -149,9 +153,10 @@ __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 :
 
     // weight fragments of this wave's two n-tiles: byte offset = ((nt * ksteps + ks) * 64 + lane) * 16
     // (the packed weights hold an even number of n-tiles; a wave whose 64 channels lie beyond N reads zeros)
-    const unsigned w_lane = n0 + wn * 64 < a.N ? lane * 16 : 0xffffffffu;
-    const bool nt_live0 = !NTAIL || n0 + wn * 64 < a.N, nt_live1 = !NTAIL || n0 + wn * 64 + 32 < a.N;     // (wave-uniform)
-    const int nt0 = (n0 + wn * 64) >> 5;
+    const int wcol = n0 + wn * (32 * NTW);                       // the wave's first channel
+    const unsigned w_lane = wcol < a.N ? lane * 16 : 0xffffffffu;
+    const bool nt_live0 = !NTAIL || wcol < a.N, nt_live1 = NTW == 2 && (!NTAIL || wcol + 32 < a.N);     // (wave-uniform)
+    const int nt0 = wcol >> 5;
     const int w_s0 = __builtin_amdgcn_readfirstlane(nt0 * a.ksteps * kFragB);
     const int w_s1 = __builtin_amdgcn_readfirstlane((nt0 + 1) * a.ksteps * kFragB);
 
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 :
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
 
@@ -226,7 +231,8 @@ __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 :
 #define DW_LOAD_W_(WF, C, S)                                                                               \
     do {                                                                                                   \
         WF[S][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, w_s0 + ((C) * 4 + (S)) * kFragB, 0)); \
-        WF[S][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, w_s1 + ((C) * 4 + (S)) * kFragB, 0)); \
+        if constexpr (NTW == 2)                                                                            \
+            WF[S][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, w_s1 + ((C) * 4 + (S)) * kFragB, 0)); \
     } while (0)
 #define DW_LOAD_W(C, S) DW_LOAD_W_(wf, C, S)
 #define DW_READ_A(FA, BUF, S)                                                                              \
@@ -241,7 +247,8 @@ __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 :
     do {                                                                                                   \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                \
             if (nt_live0) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[S][0], FA[mt], acc[mt][0], 0, 0, 0); \
-            if (nt_live1) acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[S][1], FA[mt], acc[mt][1], 0, 0, 0); \
+            if constexpr (NTW == 2)                                                                        \
+                if (nt_live1) acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[S][1], FA[mt], acc[mt][1], 0, 0, 0); \
         }                                                                                                  \
     } while (0)
 #define DW_MFMA(FA, S) DW_MFMA_(wf, FA, S)
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 :
 #define DW_FETCH_RES(MTI, NT, PS)                                                                          \
     do {                                                                                                   \
         const int row = m0 + wm * WROWS + (MTI) * 32 + pp + 16 * (PS);                                     \
-        const int ch = n0 + wn * 64 + (NT) * 32 + 8 * pc;                                                  \
+        const int ch = wcol + (NT) * 32 + 8 * pc;                                                          \
         const unsigned ro = (row < a.M && ch < a.N) ? ((unsigned)row * (unsigned)a.res_ld + ch) * 2u : 0xffffffffu; \
         resq[MTI][NT][PS] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, ro, 0, 0)); \
     } while (0)
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 :
             DW_MFMA_(WCUR, fa[0], s);                                                                      \
             DW_SB();                                                                                       \
             DW_FETCH_RES(s >> 1, 0, s & 1);                                                                \
-            DW_FETCH_RES(s >> 1, 1, s & 1);                                                                \
+            if constexpr (NTW == 2) DW_FETCH_RES(s >> 1, 1, s & 1);                                        \
             DW_SB();                                                                                       \
         }                                                                                                  \
     } while (0)
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 :
                 if constexpr (SPLIT) {
                 } else if constexpr (MT == 2) {
                     DW_FETCH_RES(s >> 1, 0, s & 1);
-                    DW_FETCH_RES(s >> 1, 1, s & 1);
+                    if constexpr (NTW == 2) DW_FETCH_RES(s >> 1, 1, s & 1);
                 } else {
                     DW_FETCH_RES(s, 0, 0);
                     DW_FETCH_RES(s, 0, 1);
@@ -404,11 +411,11 @@ __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 :
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NTW; ++nt) {
                 const int row = m0 + wm * WROWS + mt * 32 + lr;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int ch = n0 + wn * 64 + nt * 32 + 8 * g + 4 * lh;
+                    const int ch = wcol + nt * 32 + 8 * g + 4 * lh;
                     if (row < a.M && ch < a.N) {
                         const f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
                         *reinterpret_cast<f32x4 *>(ws + (size_t)row * a.N + ch) = v;
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 :
     // The loop ended on a barrier: the activation buffers are dead, each wave stages its tiles in its own 32 x 36 f32 slice.
     float *const stage = reinterpret_cast<float *>(smem) + wave * (32 * kStageLd);
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, 0x00020000);
-    const int prow0 = m0 + wm * WROWS, pcol0 = n0 + wn * 64;
+    const int prow0 = m0 + wm * WROWS, pcol0 = wcol;
     // ReLU on the packed bf16 pairs after the rounding (rounding keeps sign and order, so relu(round(v)) == round(relu(v))):
     // a signed 16-bit max with 0 clears every negative value; without ReLU the floor is the most negative pattern (identity).
     // 4 instructions per 8 values instead of the 16 of fmaxf on f32 (canonicalise + max).
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 :
             yrow[mt][ps] = row < a.M ? pix * (unsigned)(a.y_ld * 2) : 0xffffffffu;
         }
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NTW; ++nt) {
         const int ch = pcol0 + nt * 32 + 8 * pc;
         const bool ch_ok = ch < a.N;
         int co = ch;                                                       // output channel of the 8-channel chunk
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 :
 // Same arithmetic as the two launches (f32 accumulation in the same k order, the middle map rounded to bf16 once): bitwise the
 // result of sgv3d_conv_dw_bf16_forward twice.
 __global__ __launch_bounds__(256, 3) void conv_dw_bf16_pair_kernel(const DwArgs a) {
-    constexpr int WM = 1, MT = 2;                             // (four waves side by side along the 256 channels)
+    constexpr int WM = 1, MT = 2, NTW = 2;                    // (four waves side by side along the 256 channels, two 32-channel tiles each)
     constexpr int WROWS = 32 * MT, BM = WROWS * WM;
     constexpr int A_LD = BM / 32;
     constexpr int kBufB = BM * kRowB;
@@ -794,18 +801,18 @@ __global__ __launch_bounds__(256) void dw_splitk_reduce_kernel(const DwArgs a) {
     *reinterpret_cast<u32x4 *>(static_cast<__bf16 *>(a.y) + (size_t)row * a.y_ld + a.y_coff + ch) = o;
 }
 
-template <int WM, int WN, int MT, bool NTAIL, bool SPLIT, bool DEEP = false>
+template <int WM, int WN, int MT, bool NTAIL, bool SPLIT, bool DEEP = false, int NTW = 2>
 int launch_dw_t(const DwArgs &a0, hipStream_t st) {
-    constexpr int BM = 32 * MT * WM, BN = 64 * WN;
+    constexpr int BM = 32 * MT * WM, BN = 32 * NTW * WN;
     DwArgs a = a0;
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.N, BN);
     constexpr size_t tiles = 2 * (size_t)BM * kRowB, stage = sizeof(float) * 4 * 32 * kStageLd;
     constexpr size_t lds = tiles > stage ? tiles : stage;
     static PerDeviceSize lds_set;
-    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT, DEEP>), lds, lds_set))
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT, DEEP, NTW>), lds, lds_set))
         return fail(SGV3D_ELAUNCH, "conv_dw_bf16: cannot raise the dynamic LDS limit to %zu", lds);
-    hipLaunchKernelGGL((conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT, DEEP>), dim3(a.tiles_m * a.tiles_n, SPLIT ? a.split : 1), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT, DEEP, NTW>), dim3(a.tiles_m * a.tiles_n, SPLIT ? a.split : 1), dim3(256), lds, st, a);
     if constexpr (SPLIT) {
         if (int rc = check_launch("conv_dw_bf16_kernel")) return rc;
         hipLaunchKernelGGL(dw_splitk_reduce_kernel, dim3((unsigned)cdiv((long long)a.M * (a.N >> 3), 256)), dim3(256), 0, st, a);
@@ -818,6 +825,13 @@ template <int WM, int WN>
 int launch_dw_deep(const DwArgs &a, hipStream_t st) {
     if (a.split > 1) return fail(SGV3D_EINVAL, "conv_dw_bf16: the *_DEEP tiles do not split along k");
     return a.N % (64 * WN) == 0 ? launch_dw_t<WM, WN, 2, false, false, true>(a, st) : launch_dw_t<WM, WN, 2, true, false, true>(a, st);
+}
+
+// 64 pixels x 128 channels: one 32-channel tile per wave
+int launch_dw_narrow(const DwArgs &a, hipStream_t st) {
+    if (a.split > 1)
+        return a.N % 128 == 0 ? launch_dw_t<1, 4, 2, false, true, false, 1>(a, st) : launch_dw_t<1, 4, 2, true, true, false, 1>(a, st);
+    return a.N % 128 == 0 ? launch_dw_t<1, 4, 2, false, false, false, 1>(a, st) : launch_dw_t<1, 4, 2, true, false, false, 1>(a, st);
 }
 
 template <int WM, int WN, int MT>
@@ -916,6 +930,7 @@ extern "C" int sgv3d_conv_dw_bf16_forward_splitk(const sgv3d_conv_desc *d, const
         case SGV3D_TILE_DW_256x128: return launch_dw<2, 2, 4>(a, st);
         case SGV3D_TILE_DW_64x256_DEEP: return launch_dw_deep<1, 4>(a, st);
         case SGV3D_TILE_DW_128x128_DEEP: return launch_dw_deep<2, 2>(a, st);
+        case SGV3D_TILE_DW_64x128: return launch_dw_narrow(a, st);
         default: return fail(SGV3D_EINVAL, "conv_dw_bf16: desc.tile must be one of SGV3D_TILE_DW_* (got %d)", d->tile);
     }
 }
