@@ -152,13 +152,15 @@ def run_other_configs(args, budget_s=120.0):
     process at a time; the children reuse the committed tune DB (tune/), so they spend no time on candidate timing."""
     import subprocess
     out, t_start = [], time.perf_counter()
-    for cfg, batch in (("cfg3", 4), ("cfg5", 1)):
+    # (timed steps sized for a ~0.15 s timed region each: ten 3-ms steps of cfg-5 read 8 % low against a longer run -- clocks and
+    # the first graph replays)
+    for cfg, batch, steps, warm in (("cfg3", 4, 12, 3), ("cfg5", 1, 40, 5)):
         left = budget_s - (time.perf_counter() - t_start)
         if left < 20.0:
             out.append({"config": cfg, "skipped": f"other_configs budget of {budget_s:.0f} s spent"})
             continue
         cmd = [sys.executable, os.path.abspath(__file__), "--sub", "--config", cfg, "--batch", str(batch), "--dtype", "bf16",
-               "--steps", "10", "--warmup", "2", "--streams", str(args.streams), "--no-plan-timing"]
+               "--steps", str(steps), "--warmup", str(warm), "--streams", str(args.streams), "--no-plan-timing"]
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=left + 30.0)
