@@ -515,7 +515,7 @@ int sgv3d_conv3x3_patch_bf16_forward(int batch, int h, int w, int cin, int cout,
  * cout, kh/kw, stride, pad, dil, x_ld/x_coff, y_ld/y_coff, res_ld, relu, mode = SGV3D_CONV_NORMAL, split_k <= 1 and
  *   desc.tile  SGV3D_TILE_DW_<pixels>x<channels> per workgroup: 64x256 | 128x128 | 256x64 (64 pixels per wave: the HBM-bound
  *              layers) | 128x256 | 256x128 (128 pixels per wave: twice the MFMAs per weight fragment, the deep layers)
- *              | 64x256_DEEP | 128x128_DEEP | 64x128 (small maps: below)
+ *              | 64x256_DEEP | 128x128_DEEP | 64x128 | 64x128_DEEP (small maps: below)
  *   w_packed   sgv3d_conv_dw_bf16_weight_bytes(cout, cin, kh, kw) bytes, filled by ..._pack_weight from f32 OIHW
  *              [cout, cin_w, kh, kw] (cin_w <= cin: the activation's channel count may be padded, the extra columns are zero)
  *   x          NHWC bf16 [batch, in_h, in_w, x_ld];  y  NHWC bf16 [batch, out_h, out_w, y_ld];  residual  bf16 [.., res_ld] or NULL
@@ -532,6 +532,7 @@ int sgv3d_conv3x3_patch_bf16_forward(int batch, int h, int w, int cin, int cout,
 #define SGV3D_TILE_DW_128x128_DEEP 37
 /* 64 pixels x 128 channels per workgroup (a wave owns one 32-channel tile): twice the workgroups of 64x256 on small maps */
 #define SGV3D_TILE_DW_64x128 38
+#define SGV3D_TILE_DW_64x128_DEEP 39
 size_t sgv3d_conv_dw_bf16_weight_bytes(int cout, int cin, int kh, int kw);
 int sgv3d_conv_dw_bf16_pack_weight(const float *w, int cout, int cin_w, int cin, int kh, int kw, void *w_packed, void *stream);
 int sgv3d_conv_dw_bf16_forward(const sgv3d_conv_desc *desc /*host*/, const void *x, const void *w_packed, const float *scale,

@@ -94,11 +94,11 @@ __global__ __launch_bounds__(64) void dw_pack_kernel(const float *__restrict__ w
 // NTW = 1: a wave owns ONE 32-channel tile (workgroup = 64 pixels x 128 channels): twice the workgroups on the maps whose 64 x 256
 // tiles number fewer than the CUs -- those launches are bound by what one CU's vector-memory path delivers (32 KB of fragments per
 // chunk and workgroup at 64 B / clk), and half the fragments per workgroup on twice the CUs is the way to more of those paths.
-template <int WM, int WN, int MT, bool NTAIL, bool SPLIT = false, bool DEEP = false, int NTW = 2>
+template <int WM, int WN, int MT, bool NTAIL, bool SPLIT = false, bool DEEP = false, int NTW = 2, int PLAINK = -1>
 __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 : 4) : WM == 2 ? 3 : 2) void conv_dw_bf16_kernel(const DwArgs a) {
     static_assert(WM * WN == 4 && (MT == 2 || MT == 4), "four waves, 64 or 128 pixels per wave");
     static_assert(!DEEP || (MT == 2 && !SPLIT), "the two-chunks-ahead form exists for the 64-pixel wave tiles, unsplit");
-    static_assert(NTW == 2 || (NTW == 1 && MT == 2 && !DEEP), "one n-tile per wave: the 64-pixel wave tile only");
+    static_assert(NTW == 2 || (NTW == 1 && MT == 2), "one n-tile per wave: the 64-pixel wave tile only");
     constexpr int WROWS = 32 * MT;                           // pixels per wave
     constexpr int BM = WROWS * WM, BN = 32 * NTW * WN;
     constexpr int A_LD = BM / 32;                            // 16-byte loads per thread and chunk
@@ -125,10 +125,11 @@ __global__ __launch_bounds__(256, (MT == 4 || DEEP) ? 2 : WM == 1 ? (NTAIL ? 3 :
     // activation rows: thread -> (16-byte chunk c8 of the 128-byte row segment, rows r0 + 32 i).  a_base: byte offset of the
     // row's top-left tap (may lie "before" the tensor: 32-bit wrap-around arithmetic, only used when the tap is inside the image)
     const int c8 = tid & 7, r0 = tid >> 3;
-    // no tap can fall outside the image: scalar tap offsets, no bounds checks.  (DEEP takes the general path for every layer: with
-    // both paths in its unrolled loop the compiler joins them with a flag and then waits for ALL outstanding loads before it
-    // reuses the row registers -- the requests that were meant to stay in flight for two chunks.)
-    const bool plain = !DEEP && a.kh == 1 && a.kw == 1 && a.pad == 0;
+    // no tap can fall outside the image: scalar tap offsets, no bounds checks.  (DEEP gets the choice as a template argument,
+    // PLAINK = 0 / 1: with both paths in its unrolled loop the compiler joins them with a flag and then waits for ALL outstanding
+    // loads before it reuses the row registers -- the requests that were meant to stay in flight for two chunks.)
+    static_assert(DEEP == (PLAINK >= 0), "the two-chunks-ahead form takes the gather path at compile time");
+    const bool plain = PLAINK >= 0 ? PLAINK != 0 : (a.kh == 1 && a.kw == 1 && a.pad == 0);
     unsigned a_base[A_LD];
     int a_ih0[A_LD], a_iw0[A_LD];
 #pragma unroll
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(256) void dw_splitk_reduce_kernel(const DwArgs a) {
     *reinterpret_cast<u32x4 *>(static_cast<__bf16 *>(a.y) + (size_t)row * a.y_ld + a.y_coff + ch) = o;
 }
 
-template <int WM, int WN, int MT, bool NTAIL, bool SPLIT, bool DEEP = false, int NTW = 2>
+template <int WM, int WN, int MT, bool NTAIL, bool SPLIT, bool DEEP = false, int NTW = 2, int PLAINK = -1>
 int launch_dw_t(const DwArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * MT * WM, BN = 32 * NTW * WN;
     DwArgs a = a0;
@@ -810,9 +811,9 @@ int launch_dw_t(const DwArgs &a0, hipStream_t st) {
     constexpr size_t tiles = 2 * (size_t)BM * kRowB, stage = sizeof(float) * 4 * 32 * kStageLd;
     constexpr size_t lds = tiles > stage ? tiles : stage;
     static PerDeviceSize lds_set;
-    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT, DEEP, NTW>), lds, lds_set))
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT, DEEP, NTW, PLAINK>), lds, lds_set))
         return fail(SGV3D_ELAUNCH, "conv_dw_bf16: cannot raise the dynamic LDS limit to %zu", lds);
-    hipLaunchKernelGGL((conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT, DEEP, NTW>), dim3(a.tiles_m * a.tiles_n, SPLIT ? a.split : 1), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_dw_bf16_kernel<WM, WN, MT, NTAIL, SPLIT, DEEP, NTW, PLAINK>), dim3(a.tiles_m * a.tiles_n, SPLIT ? a.split : 1), dim3(256), lds, st, a);
     if constexpr (SPLIT) {
         if (int rc = check_launch("conv_dw_bf16_kernel")) return rc;
         hipLaunchKernelGGL(dw_splitk_reduce_kernel, dim3((unsigned)cdiv((long long)a.M * (a.N >> 3), 256)), dim3(256), 0, st, a);
@@ -824,7 +825,9 @@ int launch_dw_t(const DwArgs &a0, hipStream_t st) {
 template <int WM, int WN>
 int launch_dw_deep(const DwArgs &a, hipStream_t st) {
     if (a.split > 1) return fail(SGV3D_EINVAL, "conv_dw_bf16: the *_DEEP tiles do not split along k");
-    return a.N % (64 * WN) == 0 ? launch_dw_t<WM, WN, 2, false, false, true>(a, st) : launch_dw_t<WM, WN, 2, true, false, true>(a, st);
+    const bool plain = a.kh == 1 && a.kw == 1 && a.pad == 0;
+    if (a.N % (64 * WN) == 0) return plain ? launch_dw_t<WM, WN, 2, false, false, true, 2, 1>(a, st) : launch_dw_t<WM, WN, 2, false, false, true, 2, 0>(a, st);
+    return plain ? launch_dw_t<WM, WN, 2, true, false, true, 2, 1>(a, st) : launch_dw_t<WM, WN, 2, true, false, true, 2, 0>(a, st);
 }
 
 // 64 pixels x 128 channels: one 32-channel tile per wave
@@ -832,6 +835,13 @@ int launch_dw_narrow(const DwArgs &a, hipStream_t st) {
     if (a.split > 1)
         return a.N % 128 == 0 ? launch_dw_t<1, 4, 2, false, true, false, 1>(a, st) : launch_dw_t<1, 4, 2, true, true, false, 1>(a, st);
     return a.N % 128 == 0 ? launch_dw_t<1, 4, 2, false, false, false, 1>(a, st) : launch_dw_t<1, 4, 2, true, false, false, 1>(a, st);
+}
+
+int launch_dw_narrow_deep(const DwArgs &a, hipStream_t st) {
+    if (a.split > 1) return fail(SGV3D_EINVAL, "conv_dw_bf16: the *_DEEP tiles do not split along k");
+    const bool plain = a.kh == 1 && a.kw == 1 && a.pad == 0;
+    if (a.N % 128 == 0) return plain ? launch_dw_t<1, 4, 2, false, false, true, 1, 1>(a, st) : launch_dw_t<1, 4, 2, false, false, true, 1, 0>(a, st);
+    return plain ? launch_dw_t<1, 4, 2, true, false, true, 1, 1>(a, st) : launch_dw_t<1, 4, 2, true, false, true, 1, 0>(a, st);
 }
 
 template <int WM, int WN, int MT>
@@ -931,6 +941,7 @@ extern "C" int sgv3d_conv_dw_bf16_forward_splitk(const sgv3d_conv_desc *d, const
         case SGV3D_TILE_DW_64x256_DEEP: return launch_dw_deep<1, 4>(a, st);
         case SGV3D_TILE_DW_128x128_DEEP: return launch_dw_deep<2, 2>(a, st);
         case SGV3D_TILE_DW_64x128: return launch_dw_narrow(a, st);
+        case SGV3D_TILE_DW_64x128_DEEP: return launch_dw_narrow_deep(a, st);
         default: return fail(SGV3D_EINVAL, "conv_dw_bf16: desc.tile must be one of SGV3D_TILE_DW_* (got %d)", d->tile);
     }
 }

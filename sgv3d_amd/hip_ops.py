@@ -121,7 +121,7 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: 
               21: "128x128", 22: "128x64", 23: "64x128", 24: "64x64",      # 21..24: tiles 1..4 walked m-tile first (SGV3D_TILE_MFIRST)
               31: "dw_bf16", 32: "dw_bf16", 33: "dw_bf16", 34: "dw_bf16", 35: "dw_bf16",   # bf16 direct-weight kernel (SGV3D_TILE_DW_*)
               36: "dw_bf16", 37: "dw_bf16",                                                # ... requests two k-chunks ahead (*_DEEP)
-              38: "dw_bf16"}                                                               # ... 64 pixels x 128 channels
+              38: "dw_bf16", 39: "dw_bf16"}                                                # ... 64 pixels x 128 channels (39: two chunks ahead)
 MFIRST = _os.environ.get("SGV3D_MFIRST", "1") != "0"
 TILE_WINO = 5       # host-side algorithm id: sgv3d_conv2d_winograd_forward instead of the implicit GEMM
 TILE_WINO_RES = 6   # = SGV3D_WINOGRAD_RESIDENT: its patch-resident variant (cin <= 96, many cout tiles)
@@ -139,9 +139,9 @@ PATCH_BF16 = _os.environ.get("SGV3D_PATCH_BF16", "1") != "0"
 # channels per workgroup 64x256 / 128x128 / 256x64 (64 pixels per wave) and 128x256 / 256x128 (128 pixels per wave)
 # 36 / 37 = SGV3D_TILE_DW_64x256_DEEP / 128x128_DEEP: rows and fragments requested two k-chunks ahead (launches of about one
 # workgroup per CU, where nothing else hides the memory round trips); no split-K
-# 38 = SGV3D_TILE_DW_64x128: one 32-channel tile per wave -- twice the workgroups of 64x256 on small maps
-DW_TILES = (31, 32, 33, 34, 35, 36, 37, 38)
-DW_DEEP_TILES = (36, 37)
+# 38 = SGV3D_TILE_DW_64x128: one 32-channel tile per wave -- twice the workgroups of 64x256 on small maps; 39: its *_DEEP form
+DW_TILES = (31, 32, 33, 34, 35, 36, 37, 38, 39)
+DW_DEEP_TILES = (36, 37, 39)
 DW_DEEP = _os.environ.get("SGV3D_DW_DEEP", "1") != "0"   # 0: the *_DEEP tiles are never candidates
 DW_NARROW = _os.environ.get("SGV3D_DW_NARROW", "1") != "0"   # 0: the 64x128 tile is never a candidate
 DW_BF16 = _os.environ.get("SGV3D_DW_BF16", "1") != "0"   # 0: never a candidate
@@ -636,7 +636,7 @@ class PackedConv:
                 if gemm_n > 128 and -(-gemm_m // 64) * -(-gemm_n // 256) <= 768:
                     tiles += (36,)
                     if DW_NARROW and -(-gemm_m // 64) * -(-gemm_n // 256) <= 384:
-                        tiles += (38,)
+                        tiles += (38, 39)
                 elif 64 < gemm_n <= 128 and -(-gemm_m // 128) * -(-gemm_n // 128) <= 768:
                     tiles += (37,)
         if fixed_tile:
@@ -658,7 +658,7 @@ class PackedConv:
                     wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 32) * -(-gemm_n // 64)
                 if t in DW_TILES:
                     nk = -(-(self.kh * self.kw * (self.cin // 32)) // 2)      # chunks of 64 k; >= 4 per split
-                    bm, bn = {31: (64, 256), 32: (128, 128), 33: (256, 64), 34: (128, 256), 35: (256, 128), 36: (64, 256), 37: (128, 128), 38: (64, 128)}[t]
+                    bm, bn = {31: (64, 256), 32: (128, 128), 33: (256, 64), 34: (128, 256), 35: (256, 128), 36: (64, 256), 37: (128, 128), 38: (64, 128), 39: (64, 128)}[t]
                     wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
                 if t == TILE_WINO_RES or t in WINO4_TILES or t in DW_DEEP_TILES or (t in DW_TILES and (d.mode != CONV_NORMAL or not DW_SPLIT_K)):
                     splits = (1,)

@@ -375,7 +375,7 @@ def test_bf16_io_conv(bf16_mode, shape, tile):
     (1, 1024, 17, 30, 256, 1, False),      # ResNet layer-3 reducing layer
     (1, 128, 31, 33, 320, 2, True),        # odd strided map, cout = 5 n-chunks of 64
 ])
-@pytest.mark.parametrize("tile", [31, 32, 33, 34, 35, 36, 37, 38])
+@pytest.mark.parametrize("tile", [31, 32, 33, 34, 35, 36, 37, 38, 39])
 def test_bf16_direct_weight_conv_1x1(bf16_mode, shape, tile):
     """sgv3d_conv_dw_bf16_forward (host tile ids 31-35 = SGV3D_TILE_DW_*) on 1x1 layers: bf16 tensors in and out.
     Reference: float64 convolution of the bf16-rounded operands, epilogue in high precision, one rounding to bf16 -- and the
@@ -421,7 +421,7 @@ def test_bf16_direct_weight_conv_1x1(bf16_mode, shape, tile):
     (2, 160, 13, 13, 320, 3, 2, 1, 1, False),      # cin = 2.5 chunks per tap
     (1, 32, 12, 9, 64, 5, 1, 2, 1, True),          # 5x5, cin = half a chunk
 ])
-@pytest.mark.parametrize("tile", [31, 32, 33, 34, 35, 36, 37, 38])
+@pytest.mark.parametrize("tile", [31, 32, 33, 34, 35, 36, 37, 38, 39])
 def test_bf16_direct_weight_conv_kxk(bf16_mode, shape, tile):
     """The same kernel as an implicit GEMM over taps: padding, stride, dilation, 7x7; against float64 on the bf16-rounded
     operands (half an ulp of bf16 at the output scale) and against the bf16io implicit-GEMM kernel (other k order: 1 bf16 ulp)."""
@@ -559,7 +559,7 @@ def test_bf16_direct_weight_conv_deep_prefetch_is_bitwise_the_plain_tile(bf16_mo
                               shift=torch.randn(cout, generator=g).to(DEV), relu=True)
     oh, ow = conv.out_hw(H, W)
     res = torch.randn(B, oh, ow, cout, generator=g).bfloat16().to(DEV) if with_res else None
-    for plain, deep in ((31, 36), (32, 37)):
+    for plain, deep in ((31, 36), (32, 37), (38, 39)):
         want = conv(x, residual=res, tile=plain, split_k=1, out_dtype=torch.bfloat16)
         got = conv(x, residual=res, tile=deep, split_k=1, out_dtype=torch.bfloat16)
         assert torch.equal(got, want), (plain, deep)
@@ -573,8 +573,8 @@ def test_bf16_direct_weight_conv_exact_on_small_integers(bf16_mode):
         conv = hip_ops.PackedConv(w.to(DEV), pad=pad)
         ref = F.conv2d(x, w, None, 1, pad)                                  # integer sums below 2^24: exact in the f32 accumulators
         xin = x.bfloat16().permute(0, 2, 3, 1).contiguous().to(DEV)
-        for tile in (31, 32, 33, 34, 35, 36, 37, 38):
-            for split in ((1,) if tile in (36, 37) else (1, 3)):                   # (exact partial sums: any association gives the same bits)
+        for tile in (31, 32, 33, 34, 35, 36, 37, 38, 39):
+            for split in ((1,) if tile in (36, 37, 39) else (1, 3)):                   # (exact partial sums: any association gives the same bits)
                 y = conv(xin, tile=tile, split_k=split, out_dtype=torch.bfloat16)
                 assert torch.equal(y.float().permute(0, 3, 1, 2).cpu(), ref.bfloat16().float())
 

@@ -14,7 +14,7 @@ if len(sys.argv) > 1:
     i = 0
     for sh in SHAPES:
         line = f"{sh[0]}->{sh[3]} k{sh[4]} @{sh[1]}x{sh[2]}: "
-        for t in (31, 36, 38):
+        for t in (31, 36, 38, 39):
             seg = sorted(d[i + 1:i + 1 + REPS]); i += 1 + REPS          # (first launch = warm-up)
             line += f"tile {t} {seg[len(seg) // 2]:6.1f} us   "
         print(line)
@@ -28,7 +28,7 @@ for cin, H, W, cout, k, stride, pad, dil in SHAPES:
     conv = hip_ops.PackedConv(w, stride=stride, pad=pad, dil=dil, relu=True)
     x = torch.randn(1, H, W, cin, device="cuda").bfloat16()
     out = torch.empty(1, *conv.out_hw(H, W), cout, dtype=torch.bfloat16, device="cuda")
-    for t in (31, 36, 38):
+    for t in (31, 36, 38, 39):
         for _ in range(1 + REPS):
             conv(x, out, tile=t, split_k=1)
         torch.cuda.synchronize()

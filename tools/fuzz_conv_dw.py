@@ -76,7 +76,7 @@ for it in range(N):
     OH, OW = ref.shape[1], ref.shape[2]
     scale_ref = max(1.0, ref.abs().max().item())
     xd = x.cuda()
-    for t in ((0,) if kind == "pair" else (31, 32, 33, 34, 35, 36, 37, 38)):
+    for t in ((0,) if kind == "pair" else (31, 32, 33, 34, 35, 36, 37, 38, 39)):
         out = torch.full((B, OH, OW, cout + y_extra), -7.0, device="cuda", dtype=torch.bfloat16)
         try:
             if kind == "pair":
@@ -86,7 +86,7 @@ for it in range(N):
                 out[..., y_coff:y_coff + cout] = o
             else:
                 split = 1
-                if kind == "conv" and t not in (36, 37) and rng.random() < 0.5:                   # split-K: any count up to the layer's 64-k chunks
+                if kind == "conv" and t not in (36, 37, 39) and rng.random() < 0.5:                   # split-K: any count up to the layer's 64-k chunks
                     split = rng.randint(2, max(2, min(12, -(-(k * k * (cin // 32)) // 2))))
                     split = min(split, -(-(k * k * (cin // 32)) // 2))
                 conv(xd, out, x_coff=x_coff, y_coff=y_coff, residual=None if res is None else res.cuda(), tile=t, split_k=split)
