@@ -144,6 +144,7 @@ DW_TILES = (31, 32, 33, 34, 35, 36, 37, 38, 39)
 DW_DEEP_TILES = (36, 37, 39)
 DW_DEEP = _os.environ.get("SGV3D_DW_DEEP", "1") != "0"   # 0: the *_DEEP tiles are never candidates
 DW_NARROW = _os.environ.get("SGV3D_DW_NARROW", "1") != "0"   # 0: the 64x128 tile is never a candidate
+DW_DEEP_MAX_WGS = int(_os.environ.get("SGV3D_DW_DEEP_MAX_WGS", "768"))   # the *_DEEP tiles are candidates for grids up to this many workgroups
 DW_BF16 = _os.environ.get("SGV3D_DW_BF16", "1") != "0"   # 0: never a candidate
 DW_SPLIT_K = _os.environ.get("SGV3D_DW_SPLITK", "1") != "0"   # 0: the direct-weight kernel is never split along k
 
@@ -633,11 +634,11 @@ class PackedConv:
             deep = self.kh * self.kw * self.cin >= 512              # enough k for the 128-pixel wave tiles to pay
             tiles += ((31,) + ((34,) if deep else ()) if gemm_n > 128 else (32,) + ((35,) if deep else ()) if gemm_n > 64 else (32, 33))
             if DW_DEEP and self.kh * self.kw * self.cin >= 256:     # few workgroups per CU: the two-chunks-ahead form of the 64-pixel tiles
-                if gemm_n > 128 and -(-gemm_m // 64) * -(-gemm_n // 256) <= 768:
+                if gemm_n > 128 and -(-gemm_m // 64) * -(-gemm_n // 256) <= DW_DEEP_MAX_WGS:
                     tiles += (36,)
                     if DW_NARROW and -(-gemm_m // 64) * -(-gemm_n // 256) <= 384:
                         tiles += (38, 39)
-                elif 64 < gemm_n <= 128 and -(-gemm_m // 128) * -(-gemm_n // 128) <= 768:
+                elif 64 < gemm_n <= 128 and -(-gemm_m // 128) * -(-gemm_n // 128) <= DW_DEEP_MAX_WGS:
                     tiles += (37,)
         if fixed_tile:
             tiles = (fixed_tile,)
