@@ -42,6 +42,7 @@ class _BatchNormAct(torch.autograd.Function):
         ctx.save_for_backward(x, y if (relu and not ctx.from_x) else None, weight, mean, invstd, bias)
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
+        ctx.affine_versions = (None if weight is None else weight._version, None if bias is None else bias._version)
         return y
 
     @staticmethod
@@ -61,6 +62,9 @@ class _BatchNormAct(torch.autograd.Function):
             dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws, nws = _ws(C, x.device)
         if ctx.from_x:
+            if ctx.affine_versions != (None if weight is None else weight._version, None if bias is None else bias._version):
+                raise RuntimeError("batch_norm_act: the BatchNorm weight / bias were modified in place between forward and backward; the "
+                                   "ReLU mask is recomputed from them (set SGV3D_BN_MASK_FROM_X=0 to keep the forward output instead)")
             with torch.cuda.device(x.device), prof("batchnorm_train_backward"):
                 rc = _lib.load().sgv3d_batchnorm_relu_train_backward_from_x(
                     pixels, C, x.data_ptr(), dy.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), mean.data_ptr(), invstd.data_ptr(),
