@@ -102,3 +102,24 @@ def test_relu_mask_recomputed_from_x_is_the_forward_mask(shape):
         finally:
             norm_grad.MASK_FROM_X = old
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+def test_deferred_step_counters_and_version_bumps():
+    """``deferred_counters``: the num_batches_tracked increments of every batch_norm_act inside the block happen once, at its end, in
+    one multi-tensor launch; the running statistics the kernel wrote through raw pointers still count as modified (version bump
+    without a launch)."""
+    from sgv3d_amd.norm_grad import deferred_counters
+    bns = [torch.nn.BatchNorm2d(32).cuda().train() for _ in range(3)]
+    x = torch.randn(2, 5, 7, 32, device="cuda")
+    versions = [(b.running_mean._version, b.running_var._version) for b in bns]
+    with deferred_counters():
+        for b in bns:
+            batch_norm_act(b, x, None, True)
+        batch_norm_act(bns[0], x, None, False)                              # the same module twice: counted twice
+        assert all(int(b.num_batches_tracked) == 0 for b in bns)            # nothing yet
+    assert [int(b.num_batches_tracked) for b in bns] == [2, 1, 1]
+    for b, (vm, vv) in zip(bns, versions):
+        assert b.running_mean._version > vm and b.running_var._version > vv
+        assert float(b.running_mean.abs().max()) > 0
+    batch_norm_act(bns[1], x, None, True)                                   # outside a block: immediately
+    assert int(bns[1].num_batches_tracked) == 2
