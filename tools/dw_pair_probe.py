@@ -46,8 +46,8 @@ for B, H, W, stride in ((4, 68, 120, 1), (4, 136, 240, 2), (1, 54, 96, 1), (4, 5
     mid = torch.empty(B, oh, ow, 256, dtype=torch.bfloat16, device=DEV)
     out = torch.empty(B, oh, ow, 1024, dtype=torch.bfloat16, device=DEV)
     best = None
-    for ta in (31, 34, 32, 7, 21):
-        for tb in (31, 34, 32):
+    for ta in (31, 34, 32, 7, 21, 36, 38, 39):
+        for tb in (31, 34, 32, 36, 38, 39):
             try:
                 two = lambda: cb(ca(x, mid, tile=ta, split_k=1), out, residual=res, tile=tb, split_k=1)
                 us = timeit(two)
