@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Race / determinism soak of the bf16 direct-weight kernels: every tile (and the fused pair) on a few shapes, 25 launches each with
+"""Race / determinism soak of the bf16 direct-weight kernels: every tile incl. the *_DEEP / 64x128 ones and two split-K cases (and the fused pair) on a few shapes, 25 launches each with
 other work in flight on a second stream, outputs compared bitwise with the first launch."""
 import os, sys
 import torch
@@ -19,12 +19,13 @@ for B, cin, H, W, cout, k, s, p, d in SHAPES:
     x = torch.randn(B, H, W, cin, device=DEV).bfloat16()
     oh, ow = conv.out_hw(H, W)
     res = torch.randn(B, oh, ow, cout, device=DEV).bfloat16()
-    for t in (31, 32, 33, 34, 35):
-        first = conv(x, residual=res, tile=t, split_k=1, out_dtype=torch.bfloat16).clone()
+    for t, sk in ((31, 1), (32, 1), (33, 1), (34, 1), (35, 1), (36, 1), (37, 1), (38, 1), (39, 1), (31, 3), (38, 2)):   # (tile, split-K)
+        sk = min(sk, -(-(k * k * (cin // 32)) // 2))                # (no more splits than 64-k chunks)
+        first = conv(x, residual=res, tile=t, split_k=sk, out_dtype=torch.bfloat16).clone()
         for it in range(25):
             with torch.cuda.stream(side):
                 noise_a @ noise_a                                  # keeps the chip busy next to the kernel under test
-            y = conv(x, residual=res, tile=t, split_k=1, out_dtype=torch.bfloat16)
+            y = conv(x, residual=res, tile=t, split_k=sk, out_dtype=torch.bfloat16)
             if not torch.equal(y, first):
                 bad += 1
                 print("MISMATCH", (B, cin, H, W, cout, k, s, p, d), t, it, float((y.float() - first.float()).abs().max()))
