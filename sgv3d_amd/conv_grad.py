@@ -118,10 +118,12 @@ def _wgrad_choice(lib, d, x, dy):
     if key in _WGRAD_DB:
         return _WGRAD_DB[key]
     sig = "wgrad|" + "x".join(str(v) for v in key)      # committed choices (tune/gfx950_*train*.json): no first-call timing, same kernels every run
-    if sig in hip_ops.TUNE_DB:
+    if not hip_ops.AUTOTUNE:
+        return 0, 0                                          # the library's own rule, whatever a tune DB holds
+    if sig in hip_ops.TUNE_DB and not (sig in hip_ops._COMMITTED_SIGS and not hip_ops._is_gfx950(x.device)):
         _WGRAD_DB[key] = tuple(hip_ops.TUNE_DB[sig])
         return _WGRAD_DB[key]
-    if not hip_ops.AUTOTUNE or torch.cuda.is_current_stream_capturing():
+    if torch.cuda.is_current_stream_capturing():
         return 0, 0
     pixels = d.batch * d.out_h * d.out_w
     cands = [(0, 0)]

@@ -202,6 +202,9 @@ __global__ __launch_bounds__(64) void vp_plan_commit_kernel(PlanHeader *__restri
     hdr->params[0] = p0; hdr->params[1] = p1; hdr->params[2] = p2; hdr->params[3] = p3;
     hdr->params[4] = p4; hdr->params[5] = p5; hdr->params[6] = p6;
     hdr->builds += 1;
+    // the plan now is the one of the geom_xyz just seen: the level-1 prologue only ever RAISES dirty (no election among its
+    // workgroups), so the build lowers it.  (vp_geom_compare_kernel rewrites it on every call anyway.)
+    hdr->dirty = 0;
 }
 
 __global__ __launch_bounds__(kBlock) void vp_zero_kernel(long long n, int *__restrict__ p, const int *__restrict__ dirty) {
@@ -1422,47 +1425,80 @@ extern "C" int sgv3d_voxel_plan_build_cached(int batch_size, int num_points, int
 // ================================================================================================
 namespace {
 
-// compare geom_xyz with the copy the cached plan holds (-> PlanHeader::dirty, as vp_geom_compare_kernel) and write the
-// pos_memo rows of the kept points ((b, y, x), voxel_pooling_forward_cuda.cu:25-28) in the same pass over geom_xyz.
-// One point per thread and iteration; <= 256 workgroups (each ends with one ticket atomic).
+// compare geom_xyz with the copy the cached plan holds and write the pos_memo rows of the kept points ((b, y, x),
+// voxel_pooling_forward_cuda.cu:25-28) in the same pass over geom_xyz.  A difference RAISES PlanHeader::dirty (and leaves a
+// note for the host); nothing lowers it here -- the rebuild's commit kernel does -- so no workgroup has to know that it is
+// the last one: the round-3 form ended every workgroup with a ticket atomic on one address (~25 ns each, serialised) and
+// walked the tensors 12 bytes per lane and iteration, 12 us for 11 MB read.  Here a thread owns FOUR consecutive points =
+// three 16-byte loads per tensor, all six in flight at once, one pass, no loop; rows of four kept points leave as three
+// 16-byte stores.  VEC = false: tensors that are not 16-byte aligned (one point per thread).
+template <bool VEC>
 __global__ __launch_bounds__(kBlock) void vp_level1_prologue_kernel(long long total_pts, int N, int X, int Y, int Z,
                                                                     const int32_t *__restrict__ geom,
                                                                     const int32_t *__restrict__ copy,
                                                                     int32_t *__restrict__ pos_memo, PlanHeader *__restrict__ hdr,
-                                                                    int *__restrict__ host_flag, int p0, int p1, int p2, int p3,
-                                                                    int p4, int p5, int p6) {
-    __shared__ int any_s;
-    if (threadIdx.x == 0) any_s = 0;
-    __syncthreads();
+                                                                    int *__restrict__ host_flag) {
     bool diff = false;
-    const long long stride = (long long)gridDim.x * kBlock;
-    for (long long pt = (long long)blockIdx.x * kBlock + threadIdx.x; pt < total_pts; pt += stride) {
-        const int x = geom[pt * 3 + 0], y = geom[pt * 3 + 1], z = geom[pt * 3 + 2];
-        diff |= (x != copy[pt * 3 + 0]) | (y != copy[pt * 3 + 1]) | (z != copy[pt * 3 + 2]);
-        if (pos_memo != nullptr && x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {
-            pos_memo[pt * 3 + 0] = (int)(pt / N);
-            pos_memo[pt * 3 + 1] = y;
-            pos_memo[pt * 3 + 2] = x;
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if constexpr (VEC) {
+        const long long pt0 = t * 4;
+        if (pt0 + 3 < total_pts) {
+            const int4 *g4 = reinterpret_cast<const int4 *>(geom) + t * 3;
+            const int4 *c4 = reinterpret_cast<const int4 *>(copy) + t * 3;
+            const int4 g0 = g4[0], g1 = g4[1], g2 = g4[2];
+            const int4 c0 = c4[0], c1 = c4[1], c2 = c4[2];
+            diff = (g0.x != c0.x) | (g0.y != c0.y) | (g0.z != c0.z) | (g0.w != c0.w) | (g1.x != c1.x) | (g1.y != c1.y) |
+                   (g1.z != c1.z) | (g1.w != c1.w) | (g2.x != c2.x) | (g2.y != c2.y) | (g2.z != c2.z) | (g2.w != c2.w);
+            if (pos_memo != nullptr) {
+                const int px[4] = {g0.x, g0.w, g1.z, g2.y}, py[4] = {g0.y, g1.x, g1.w, g2.z}, pz[4] = {g0.z, g1.y, g2.x, g2.w};
+                bool keep[4];
+                int bb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    keep[i] = px[i] >= 0 && px[i] < X && py[i] >= 0 && py[i] < Y && pz[i] >= 0 && pz[i] < Z;
+                    bb[i] = (int)((pt0 + i) / N);
+                }
+                if (keep[0] && keep[1] && keep[2] && keep[3]) {
+                    int4 *m4 = reinterpret_cast<int4 *>(pos_memo) + t * 3;
+                    m4[0] = make_int4(bb[0], py[0], px[0], bb[1]);
+                    m4[1] = make_int4(py[1], px[1], bb[2], py[2]);
+                    m4[2] = make_int4(px[2], bb[3], py[3], px[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (keep[i]) {
+                            pos_memo[(pt0 + i) * 3 + 0] = bb[i];
+                            pos_memo[(pt0 + i) * 3 + 1] = py[i];
+                            pos_memo[(pt0 + i) * 3 + 2] = px[i];
+                        }
+                }
+            }
+        } else {
+            for (long long pt = pt0; pt < total_pts; ++pt) {             // the last, partial quad
+                const int x = geom[pt * 3 + 0], y = geom[pt * 3 + 1], z = geom[pt * 3 + 2];
+                diff |= (x != copy[pt * 3 + 0]) | (y != copy[pt * 3 + 1]) | (z != copy[pt * 3 + 2]);
+                if (pos_memo != nullptr && x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {
+                    pos_memo[pt * 3 + 0] = (int)(pt / N);
+                    pos_memo[pt * 3 + 1] = y;
+                    pos_memo[pt * 3 + 2] = x;
+                }
+            }
+        }
+    } else {
+        if (t < total_pts) {
+            const int x = geom[t * 3 + 0], y = geom[t * 3 + 1], z = geom[t * 3 + 2];
+            diff = (x != copy[t * 3 + 0]) | (y != copy[t * 3 + 1]) | (z != copy[t * 3 + 2]);
+            if (pos_memo != nullptr && x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {
+                pos_memo[t * 3 + 0] = (int)(t / N);
+                pos_memo[t * 3 + 1] = y;
+                pos_memo[t * 3 + 2] = x;
+            }
         }
     }
-    if (diff) any_s = 1;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (any_s) atomicOr(&hdr->diff, 1);
-        __threadfence();
-        const int t = atomicAdd(&hdr->ticket, 1);
-        if (t == (int)gridDim.x - 1) {
-            __threadfence();
-            const int d = atomicOr(&hdr->diff, 0);
-            const int *q = hdr->params;
-            const bool same = q[0] == p0 && q[1] == p1 && q[2] == p2 && q[3] == p3 && q[4] == p4 && q[5] == p5 && q[6] == p6;
-            const int dirty = (d != 0 || !same) ? 1 : 0;
-            hdr->dirty = dirty;
-            hdr->diff = 0;
-            hdr->ticket = 0;
-            // sticky note to the host: a later call enqueues the (device-gated) rebuild when it sees it
-            if (dirty && host_flag != nullptr) __hip_atomic_store(host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+    if (__ballot(diff) != 0ull && (threadIdx.x & 63) == 0) {             // (rare: one store per wave that saw a difference)
+        __hip_atomic_store(&hdr->dirty, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // sticky note to the host: a later call enqueues the (device-gated) rebuild when it sees it
+        if (host_flag != nullptr) __hip_atomic_store(host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1471,25 +1507,32 @@ __global__ __launch_bounds__(kBlock) void vp_atomic_gated_kernel(
     long long total_pts, int N, int C, int X, int Y, int Z, const int32_t *__restrict__ geom,
     const float *__restrict__ feats, float *__restrict__ out, const int *__restrict__ gate) {
     if (*reinterpret_cast<const volatile int *>(gate) == 0) return;
+    // (a bounded grid walking the point blocks: in the common case -- gate clear -- the launch is a few hundred workgroups
+    // that leave after one load, not one per 64 points)
     __shared__ int vid_s[kAtomicPts];
     const int tid = threadIdx.x;
-    const long long p0 = (long long)blockIdx.x * kAtomicPts;
-    if (tid < kAtomicPts) {
-        const long long pt = p0 + tid;
-        int v = -1;
-        if (pt < total_pts) {
-            int x, y;
-            v = voxel_of_point(geom, pt, (int)(pt / N), X, Y, Z, x, y);
+    const long long nblocks = (total_pts + kAtomicPts - 1) / kAtomicPts;
+    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {       // block-uniform trip count
+        const long long p0 = blk * kAtomicPts;
+        if (tid < kAtomicPts) {
+            const long long pt = p0 + tid;
+            int v = -1;
+            if (pt < total_pts) {
+                int x, y;
+                v = voxel_of_point(geom, pt, (int)(pt / N), X, Y, Z, x, y);
+            }
+            vid_s[tid] = v;
         }
-        vid_s[tid] = v;
-    }
-    __syncthreads();
-    const int nelem = kAtomicPts * C;
-    const float *f = feats + (size_t)p0 * C;
-    for (int e = tid; e < nelem; e += kBlock) {
-        const int pl = e / C;
-        const int v = vid_s[pl];
-        if (v >= 0) __hip_atomic_fetch_add(out + (size_t)v * C + (e - pl * C), f[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const long long left = (total_pts - p0) * C;
+        const int nelem = (long long)kAtomicPts * C < left ? kAtomicPts * C : (int)left;
+        const float *f = feats + (size_t)p0 * C;
+        for (int e = tid; e < nelem; e += kBlock) {
+            const int pl = e / C;
+            const int v = vid_s[pl];
+            if (v >= 0) __hip_atomic_fetch_add(out + (size_t)v * C + (e - pl * C), f[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
     }
 }
 
@@ -1502,6 +1545,8 @@ struct Level1Entry {
     int *host_flag;          // pinned, device-visible: set by the prologue kernel when geom_xyz is not the plan's
     int *flag_dev;           // the same word as the device addresses it
     bool need_build;         // host-side: enqueue the (device-gated) build with the next call
+    bool pinned;             // recorded into a stream capture: a replayed graph reads and writes this plan, so it is never
+                             // evicted and survives sgv3d_voxel_pooling_cache_clear (the graph may outlive any call we see)
     unsigned long long last_use;
 };
 constexpr int kLevel1Max = 8;
@@ -1575,9 +1620,13 @@ extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int n
             return launch_atomic(B, N, C, X, Y, Z, geom_xyz, input_features, output_features, pos_memo, st);
         }
         if ((int)g_l1.size() >= kLevel1Max) {
-            size_t old = 0;
-            for (size_t i = 1; i < g_l1.size(); ++i)
-                if (g_l1[i].last_use < g_l1[old].last_use) old = i;
+            size_t old = g_l1.size();
+            for (size_t i = 0; i < g_l1.size(); ++i)
+                if (!g_l1[i].pinned && (old == g_l1.size() || g_l1[i].last_use < g_l1[old].last_use)) old = i;
+            if (old == g_l1.size()) {      // every plan is baked into some captured graph: serve this call without one
+                g_l1_stats[2]++;
+                return launch_atomic(B, N, C, X, Y, Z, geom_xyz, input_features, output_features, pos_memo, st);
+            }
             level1_free(g_l1[old]);
             g_l1.erase(g_l1.begin() + old);
         }
@@ -1600,18 +1649,24 @@ extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int n
         e = &g_l1.back();
     }
     e->last_use = ++g_l1_clock;
+    if (capturing) e->pinned = true;
     char *base = static_cast<char *>(e->plan);
     PlanHeader *hdr = reinterpret_cast<PlanHeader *>(base + L.off_hdr);
     const int32_t *gcopy = reinterpret_cast<const int32_t *>(base + L.off_geom);
-    const int p[7] = {kPlanMagic, B, N, X, Y, Z, 1};
-    int *flag_dev = e->flag_dev;
-    const long long total = (long long)B * N;
-    const int pgrid = (int)(cdiv(total, kBlock) < 256 ? cdiv(total, kBlock) : 256);
-    hipLaunchKernelGGL(vp_level1_prologue_kernel, dim3(pgrid), dim3(kBlock), 0, st, total, N, X, Y, Z, geom_xyz, gcopy, pos_memo,
-                       hdr, flag_dev, p[0], p[1], p[2], p[3], p[4], p[5], p[6]);
     // the host learns about a changed geom_xyz one or more calls late (it never waits for the device); until then such
     // calls take the gated scatter below, which is correct for any geom_xyz
     if (__atomic_load_n(e->host_flag, __ATOMIC_RELAXED) != 0) e->need_build = true;
+    // (a call that enqueues the rebuild anyway needs no note: its prologue finds the stale plan different by construction)
+    int *flag_dev = (e->need_build && !capturing) ? nullptr : e->flag_dev;
+    const long long total = (long long)B * N;
+    // (the plan's own copy of geom_xyz sits at a 256-byte aligned offset of a hipMalloc'ed block)
+    const bool vec = ((reinterpret_cast<uintptr_t>(geom_xyz) | reinterpret_cast<uintptr_t>(pos_memo)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(vp_level1_prologue_kernel<true>, dim3(cdiv(cdiv(total, 4), kBlock)), dim3(kBlock), 0, st, total, N, X, Y,
+                           Z, geom_xyz, gcopy, pos_memo, hdr, flag_dev);
+    else
+        hipLaunchKernelGGL(vp_level1_prologue_kernel<false>, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, st, total, N, X, Y, Z,
+                           geom_xyz, gcopy, pos_memo, hdr, flag_dev);
     if (e->need_build || capturing) {
         // gated build (its kernels return at once when the prologue found the plan up to date), then the gather on a plan
         // that is right either way.  Also the form a stream capture records: valid for whatever geom_xyz a replay sees.
@@ -1629,16 +1684,21 @@ extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int n
     g_l1_stats[1]++;
     if (int rc = launch_gather<false, false, false, true>(B, N, C, X, Y, e->plan, input_features, nullptr, nullptr, 1,
                                                           output_features, nullptr, 0, st, 0, &hdr->dirty)) return rc;
-    hipLaunchKernelGGL(vp_atomic_gated_kernel, dim3(cdiv(total, kAtomicPts)), dim3(kBlock), 0, st, total, N, C, X, Y, Z,
-                       geom_xyz, input_features, output_features, &hdr->dirty);
+    const long long ablocks = cdiv(total, kAtomicPts);
+    hipLaunchKernelGGL(vp_atomic_gated_kernel, dim3((unsigned)(ablocks < 2048 ? ablocks : 2048)), dim3(kBlock), 0, st, total, N, C, X,
+                       Y, Z, geom_xyz, input_features, output_features, &hdr->dirty);
     return check_launch("voxel_pooling_forward(level-1)");
 }
 
 extern "C" int sgv3d_voxel_pooling_cache_clear(void) {
     std::lock_guard<std::mutex> lock(g_l1_mutex);
     hipDeviceSynchronize();
-    for (auto &e : g_l1) level1_free(e);
-    g_l1.clear();
+    std::vector<Level1Entry> kept;
+    for (auto &e : g_l1) {
+        if (e.pinned) kept.push_back(e);        // a captured graph holds its pointers (see Level1Entry::pinned)
+        else level1_free(e);
+    }
+    g_l1.swap(kept);
     return SGV3D_OK;
 }
 

@@ -109,8 +109,21 @@ def load_default_tune_dbs():
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tune")
     n = 0
     for f in sorted(glob.glob(os.path.join(root, "gfx950_*.json"))):
+        before = set(TUNE_DB)
         n += load_tune_db(f) and 1
+        _COMMITTED_SIGS.update(set(TUNE_DB) - before)
     return n
+
+
+_COMMITTED_SIGS = set()      # signatures that came from tune/gfx950_*.json: honoured on gfx950 devices only
+_ARCH_IS_GFX950 = {}
+
+
+def _is_gfx950(device):
+    idx = torch.device(device).index or 0
+    if idx not in _ARCH_IS_GFX950:
+        _ARCH_IS_GFX950[idx] = "gfx950" in str(getattr(torch.cuda.get_device_properties(idx), "gcnArchName", ""))
+    return _ARCH_IS_GFX950[idx]
 
 
 load_default_tune_dbs()
@@ -461,8 +474,8 @@ class PackedConv:
                        f"ks{self.ks}|{B}x{H}x{W}|m{d.mode}r{int(residual is not None)}g{int(gate is not None)}|{t}.{sk}"
                        + ("|bf16" if MFMA_BF16 else "|f32x3" if MFMA_F32X3 is True else "|x3auto" if MFMA_F32X3 else "")
                        + (f"|io{io}" if io else "") + f"|ts{TUNE_STREAMS}")    # choices are per frames-in-flight load
-                if sig in TUNE_DB:
-                    choice = TUNE_DB[sig]
+                choice = self._db_choice(sig, d, x, gate, gemm_m, gemm_n, nkt, t, sk, io)
+                if choice is not None:
                     self._tile_cache[key] = choice
                 elif AUTOTUNE and not torch.cuda.is_current_stream_capturing():
                     choice = self._autotune(lib, d, x, residual, gate, out, gemm_m, gemm_n, nkt, t, sk, io)
@@ -610,10 +623,10 @@ class PackedConv:
             best = dt if best is None else min(best, dt)
         return best
 
-    def _autotune(self, lib, d, x, residual, gate, out, gemm_m, gemm_n, nkt, fixed_tile, fixed_split, io=0):
-        """Time the candidate (tile, split-K) pairs on the real buffers and keep the fastest.  Results do
-        not depend on the tile shape (every output element sums k in the same order); split-K changes
-        the association of the k sum (partials added in fixed order), still deterministic."""
+    def _candidates(self, d, gate, gemm_m, gemm_n, nkt, fixed_tile, fixed_split, io=0):
+        """The (tile, (split-K, ...)) pairs this layer may run with on this input / output layout under the module's current
+        switches (WINOGRAD, WINO4, WINO_HALF, PATCH_BF16, DW_*, SPLIT_K, MFIRST, MFMA_*): what the first-call measurement times,
+        and what a tune-DB entry is checked against before it is trusted (``_db_choice``)."""
         tiles = (1, 2, 3, 4)
         if MFIRST and d.mode in (CONV_NORMAL, CONV_NCHW_OUT) and gemm_n > 64:
             tiles += tuple(t + 20 for t in (1, 2, 3, 4) if gemm_n > (128 if t in (1, 3) else 64))   # more than one channel tile
@@ -645,35 +658,67 @@ class PackedConv:
         dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 64), 6: (256, 64),
                 11: (128, 128), 12: (128, 64), 13: (64, 128), 14: (64, 64),
                 21: (128, 128), 22: (128, 64), 23: (64, 128), 24: (64, 64)}
-        best, best_t = (tiles[0], fixed_split or 1), None
-        with torch.cuda.device(x.device):
-            for t in tiles:
-                bm, bn = dims.get(t, (512, 64))
+        cands = []
+        for t in tiles:
+            bm, bn = dims.get(t, (512, 64))
+            wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
+            nk = nkt
+            if t in (TILE_WINO, TILE_WINO_HALF):
+                nk = self.cin // 4      # k-steps of 8 channels; nk // s >= 8 keeps >= 4 steps per split
+                wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 16) * -(-gemm_n // (64 if t == TILE_WINO else 32))
+            if t == TILE_PATCH:
+                nk = self.cin // 32     # stages of 32 input channels; >= 2 per split
+                wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 32) * -(-gemm_n // 64)
+            if t in DW_TILES:
+                nk = -(-(self.kh * self.kw * (self.cin // 32)) // 2)      # chunks of 64 k; >= 4 per split
+                bm, bn = {31: (64, 256), 32: (128, 128), 33: (256, 64), 34: (128, 256), 35: (256, 128), 36: (64, 256), 37: (128, 128), 38: (64, 128), 39: (64, 128)}[t]
                 wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
-                nk = nkt
-                if t in (TILE_WINO, TILE_WINO_HALF):
-                    nk = self.cin // 4      # k-steps of 8 channels; nk // s >= 8 keeps >= 4 steps per split
-                    wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 16) * -(-gemm_n // (64 if t == TILE_WINO else 32))
-                if t == TILE_PATCH:
-                    nk = self.cin // 32     # stages of 32 input channels; >= 2 per split
-                    wgs = d.batch * -(-d.out_h // 16) * -(-d.out_w // 32) * -(-gemm_n // 64)
-                if t in DW_TILES:
-                    nk = -(-(self.kh * self.kw * (self.cin // 32)) // 2)      # chunks of 64 k; >= 4 per split
-                    bm, bn = {31: (64, 256), 32: (128, 128), 33: (256, 64), 34: (128, 256), 35: (256, 128), 36: (64, 256), 37: (128, 128), 38: (64, 128), 39: (64, 128)}[t]
-                    wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
-                if t == TILE_WINO_RES or t in WINO4_TILES or t in DW_DEEP_TILES or (t in DW_TILES and (d.mode != CONV_NORMAL or not DW_SPLIT_K)):
-                    splits = (1,)
-                elif t in DW_TILES:
-                    splits = (fixed_split,) if fixed_split else \
-                        [1] + [s for s in (2, 3, 4, 6, 8) if SPLIT_K and nk // s >= 4 and wgs < 384 and wgs * s <= 1024]
-                elif t == TILE_PATCH and not fixed_split and SPLIT_K:
-                    splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 2 and wgs * s <= 1024]
-                elif fixed_split:
-                    splits = (fixed_split,)
-                elif not SPLIT_K:
-                    splits = (1,)
-                else:
-                    splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 4 and wgs < 2048 and wgs * s <= 6144]
+            if t == TILE_WINO_RES or t in WINO4_TILES or t in DW_DEEP_TILES or (t in DW_TILES and (d.mode != CONV_NORMAL or not DW_SPLIT_K)):
+                splits = (1,)
+            elif t in DW_TILES:
+                splits = (fixed_split,) if fixed_split else \
+                    [1] + [s for s in (2, 3, 4, 6, 8) if SPLIT_K and nk // s >= 4 and wgs < 384 and wgs * s <= 1024]
+            elif t == TILE_PATCH and not fixed_split and SPLIT_K:
+                splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 2 and wgs * s <= 1024]
+            elif fixed_split:
+                splits = (fixed_split,)
+            elif not SPLIT_K:
+                splits = (1,)
+            else:
+                splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 4 and wgs < 2048 and wgs * s <= 6144]
+            cands.append((t, tuple(splits)))
+        return cands
+
+    def _db_choice(self, sig, d, x, gate, gemm_m, gemm_n, nkt, fixed_tile, fixed_split, io=0):
+        """The tune-DB entry of ``sig`` if it is one of the candidates this layer would be measured with right now, else None
+        (and the stale entry is dropped, so the caller measures or applies the rule).  A DB is a record of measurements, not
+        an override: the kill switches (SGV3D_NO_WINOGRAD, SGV3D_WINO4=0, SGV3D_DW_BF16=0, SGV3D_NO_SPLITK, ...), an
+        input / output layout the recorded kernel does not cover (channel offsets / strides are not part of the
+        signature) and SGV3D_NO_AUTOTUNE (the documented fixed rule) all win over it, and the committed ``tune/gfx950_*``
+        entries only apply on a gfx950 device."""
+        if not AUTOTUNE:
+            return None
+        choice = TUNE_DB.get(sig)
+        if choice is None:
+            return None
+        if sig in _COMMITTED_SIGS and not _is_gfx950(x.device):
+            return None
+        t, sk = int(choice[0]), int(choice[1])
+        for ct, splits in self._candidates(d, gate, gemm_m, gemm_n, nkt, fixed_tile, fixed_split, io):
+            if ct == t and sk in splits:
+                return (t, sk)
+        del TUNE_DB[sig]
+        _COMMITTED_SIGS.discard(sig)
+        return None
+
+    def _autotune(self, lib, d, x, residual, gate, out, gemm_m, gemm_n, nkt, fixed_tile, fixed_split, io=0):
+        """Time the candidate (tile, split-K) pairs on the real buffers and keep the fastest.  Results do
+        not depend on the tile shape (every output element sums k in the same order); split-K changes
+        the association of the k sum (partials added in fixed order), still deterministic."""
+        cands = self._candidates(d, gate, gemm_m, gemm_n, nkt, fixed_tile, fixed_split, io)
+        best, best_t = (cands[0][0], fixed_split or 1), None
+        with torch.cuda.device(x.device):
+            for t, splits in cands:
                 for sk in splits:
                     d.tile, d.split_k = t, sk
                     _lib.check(self._launch(lib, d, x, residual, gate, out, io), "sgv3d_conv2d_forward")   # warm
@@ -694,6 +739,15 @@ class PackedConv:
 
 
 PAIR_BF16 = _os.environ.get("SGV3D_PAIR_BF16", "1") != "0"   # 0: conv2 + conv3 of a bottleneck are always two launches
+
+
+def switch_state():
+    """Every module-level switch that decides WHICH kernels a forward launches, as one hashable value: part of the key of
+    anything that records launches for replay (BEVHeight's per-signature hipGraph)."""
+    g = globals()
+    return tuple(g.get(k) for k in ("AUTOTUNE", "SPLIT_K", "WINOGRAD", "FUSED_HEAD", "HEAD_PATH", "MFMA_BF16", "BF16_ACTIVATIONS",
+                                    "MFMA_F32X3", "MFIRST", "WINO4", "WINO_HALF", "PATCH_BF16", "DW_BF16", "DW_DEEP", "DW_NARROW",
+                                    "DW_SPLIT_K", "DW_DEEP_MAX_WGS", "PAIR_BF16", "TUNE_STREAMS"))
 
 
 def conv_pair_eligible(a, b, x, residual=None):
@@ -736,9 +790,11 @@ def conv_pair_choice(a, b, x, residual=None):
         return False
     B, H, W, _ = (int(v) for v in x.shape)
     sig = (f"pair|{a.cout}x{a.cin}k{a.kh}x{a.kw}s{a.stride}p{a.pad}d{a.dil}->{b.cout}|{B}x{H}x{W}|r{int(residual is not None)}|bf16|ts{TUNE_STREAMS}")
-    if sig in TUNE_DB:
+    if not AUTOTUNE:                                         # the documented fixed rule: no recorded measurement is consulted
+        return True
+    if sig in TUNE_DB and not (sig in _COMMITTED_SIGS and not _is_gfx950(x.device)):
         return bool(TUNE_DB[sig][0])
-    if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+    if torch.cuda.is_current_stream_capturing():
         return True
     act = torch.bfloat16
     two = lambda: b(a(x, out_dtype=act), residual=residual, out_dtype=act)

@@ -217,8 +217,10 @@ class BEVHeightHead(HipModule):
         instructions, and the F(4x4) first layer executes 44 % fewer of the former."""
         B, H, W, _ = (int(v) for v in shared.shape)
         sig = f"centerhead_branches|{B}x{H}x{W}x{s['nb']}|ts{hip_ops.TUNE_STREAMS}"
-        hit = hip_ops.TUNE_DB.get(sig)
-        if hit is not None:
+        if hip_ops.HEAD_PATH in (0, 1):                      # an explicit setting wins over any recorded measurement
+            return hip_ops.HEAD_PATH
+        hit = hip_ops.TUNE_DB.get(sig) if hip_ops.AUTOTUNE else None
+        if hit is not None and (int(hit[0]) - 100 == 0 or s['first'].wino4_ok()):
             return int(hit[0]) - 100
         if (not hip_ops.AUTOTUNE or torch.cuda.is_current_stream_capturing() or not s['first'].wino4_ok()
                 or hip_ops.HEAD_PATH in (0, 1)):

@@ -95,7 +95,18 @@ class deferred_counters:
     def __exit__(self, *exc):
         deferred_counters._open = self._outer
         if self.pending:
-            torch._foreach_add_(self.pending, 1)
+            # a module called twice in the block (shared BatchNorm, several sweeps) is in the list twice; the multi-tensor
+            # kernel reads every operand before it writes any, so a repeated tensor would be incremented once.  One entry per
+            # tensor, with its multiplicity as the per-tensor scalar.
+            counts = {}
+            for t in self.pending:
+                entry = counts.setdefault(id(t), [t, 0])
+                entry[1] += 1
+            tensors = [e[0] for e in counts.values()]
+            if all(e[1] == 1 for e in counts.values()):
+                torch._foreach_add_(tensors, 1)
+            else:
+                torch._foreach_add_(tensors, [e[1] for e in counts.values()])
         return False
 
 

@@ -166,7 +166,7 @@ class DataParallelAdamW:
         the model's flags, not from the data).
 
         Contract: ONE backward per optimiser step.  The per-bucket counters are re-armed by ``zero_grad`` /
-        ``all_reduce_grads`` / ``step``; a second backward before the step (gradient accumulation) would add local
+        ``all_reduce_grads`` / ``step`` (each of them, so any of the usual loop shapes works); a second backward before the step (gradient accumulation) would add local
         gradients on top of an already reduced bucket, so it raises instead.  Early collectives are launched in
         bucket order only (bucket i after bucket i-1): every rank issues the same sequence of collectives even if the
         set of parameters that receive a gradient differs between ranks (a bucket that completes out of order waits
@@ -224,12 +224,15 @@ class DataParallelAdamW:
                 self._pending.append(early[bi] if bi in early else
                                      dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         if hasattr(self, '_left'):
-            if not self._learned and self._fired:
-                # parameters without a gradient in the first step never complete their bucket (DDP's "unused parameters"):
-                # from now on they are not waited for.  Their (zero) gradient views still travel with the bucket.
-                self._unused = {id(p) for _, _, entries in self.flat.buckets for p, _, _ in entries} - self._fired
-                self._learned = True
+            self._learn_unused()
             self._arm()
+
+    def _learn_unused(self):
+        if not self._learned and self._fired:
+            # parameters without a gradient in the first step never complete their bucket (DDP's "unused parameters"):
+            # from now on they are not waited for.  Their (zero) gradient views still travel with the bucket.
+            self._unused = {id(p) for _, _, entries in self.flat.buckets for p, _, _ in entries} - self._fired
+            self._learned = True
 
     def step(self, lr=None):
         """One AdamW update of every bucket with the averaged gradients (call ``all_reduce_grads`` first when the
@@ -252,3 +255,9 @@ class DataParallelAdamW:
                                           _lib.stream_handle(p.device))
             _lib.check(rc, "sgv3d_adamw_step")
         self._pending = []
+        if hasattr(self, '_left') and self._fired:
+            # overlap hooks installed and a backward ran since the counters were last armed (the no-collectives path never
+            # goes through all_reduce_grads, and a loop may zero gradients with model.zero_grad() instead of ours): learn the
+            # unused-parameter set and re-arm here, so that the next backward is this step's successor, not a "second backward"
+            self._learn_unused()
+            self._arm()

@@ -424,3 +424,46 @@ def test_pointwise_specialisation_is_bitwise_the_generic_kernel(hip, shape, spli
     assert torch.equal(outs[0], outs[1])
     ref = F.conv2d(x.permute(0, 3, 1, 2).cpu(), w.cpu()) * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None] + res.permute(0, 3, 1, 2).cpu()
     torch.testing.assert_close(outs[1].permute(0, 3, 1, 2).cpu(), ref.clamp_min(0), **TOL)
+
+
+def test_tune_db_entry_is_checked_against_the_switches_and_the_layout(hip):
+    """A tune-DB entry is a recorded measurement, not an override: with the Winograd kill switches on or with
+    SGV3D_NO_AUTOTUNE's fixed rule the entry is not used (a stale one is dropped and the layer re-measured among the
+    candidates that are allowed now) -- the call neither raises nor runs the disabled kernel."""
+    from sgv3d_amd import hip_ops
+    from sgv3d_amd.hip_ops import PackedConv
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-3, 4, (1, 128, 32, 40), generator=g).float()
+    w = torch.randint(-2, 3, (128, 128, 3, 3), generator=g).float()
+    ref = F.conv2d(x, w, None, 1, 1)
+    xd = nhwc(x).to(DEV)
+    saved = (hip_ops.WINOGRAD, hip_ops.WINO4, hip_ops.AUTOTUNE, dict(hip_ops.TUNE_DB))
+    try:
+        conv = PackedConv(w.to(DEV), pad=1)
+        hip_ops.PROFILE = []
+        conv(xd)                                            # measured: leaves its signature in the DB
+        sig = next(k for k in hip_ops.TUNE_DB if k not in saved[3] and k.startswith("128x128k3x3"))
+        for forced in ((hip_ops.TILE_WINO, 1), (hip_ops.TILE_WINO4, 1)):
+            hip_ops.TUNE_DB[sig] = forced
+            hip_ops.WINOGRAD, hip_ops.WINO4 = False, False
+            c2 = PackedConv(w.to(DEV), pad=1)
+            hip_ops.PROFILE = []
+            y = c2(xd)
+            assert all("wino" not in rec[0] for rec in hip_ops.PROFILE), hip_ops.PROFILE[-1][0]
+            assert torch.equal(nchw(y.cpu()), ref)
+            assert tuple(hip_ops.TUNE_DB[sig]) != forced                    # dropped and re-measured without Winograd
+            hip_ops.WINOGRAD, hip_ops.WINO4 = saved[0], saved[1]
+        # the fixed rule ignores the DB altogether
+        hip_ops.TUNE_DB[sig] = (hip_ops.TILE_WINO4, 1)
+        hip_ops.AUTOTUNE = False
+        c3 = PackedConv(w.to(DEV), pad=1)
+        hip_ops.PROFILE = []
+        y = c3(xd)
+        assert hip_ops.PROFILE[-1][0] == "conv_wino" and tuple(hip_ops.TUNE_DB[sig]) == (hip_ops.TILE_WINO4, 1)
+        assert torch.equal(nchw(y.cpu()), ref)
+        hip_ops.AUTOTUNE = saved[2]
+    finally:
+        hip_ops.PROFILE = None
+        hip_ops.WINOGRAD, hip_ops.WINO4, hip_ops.AUTOTUNE = saved[:3]
+        hip_ops.TUNE_DB.clear()
+        hip_ops.TUNE_DB.update(saved[3])

@@ -1,0 +1,155 @@
+"""The drop-in as the UNCHANGED reference harness uses it: ``self.model(sweep_imgs, mats)`` per frame, nothing else
+(exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:242-258).  ``BEVHeight.forward`` answers repeated calls of
+one signature with a hipGraph replay; these tests hold that replay to the eager forward bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(depth=18, seed=0, bsm=False):
+    from sgv3d_amd import synthetic as S
+    from sgv3d_amd.models.bev_height import BEVHeight
+    bc, hc = (S.small_bsm_conf if bsm else S.small_conf)(depth=depth)
+    torch.manual_seed(seed)
+    m = BEVHeight(bc, hc).eval()
+    S.randomize_norm_stats_(m, 1)
+    return m.cuda(), bc, hc
+
+
+def _flat(preds):
+    return [(t, k, v) for t, task in enumerate(preds) for k, v in sorted(task[0].items())]
+
+
+def _assert_same(a, b):
+    for (t, k, va), (_, _, vb) in zip(_flat(a), _flat(b)):
+        assert torch.equal(va, vb), f"task {t} map {k} differs"
+
+
+@pytest.mark.parametrize("bsm", [False, True])
+def test_graph_backed_forward_is_bitwise_the_eager_one(hip, bsm):
+    from sgv3d_amd import synthetic as S
+    from sgv3d_amd.pipeline import GraphedForward
+    model, bc, _ = _model(bsm=bsm)
+    scale = bc['final_dim'][0] / 864
+    frames = [S.make_images(2, bc['final_dim'], device='cuda', seed=s) for s in range(4)]
+    mats = S.make_mats(2, device='cuda', scale=scale)
+    with torch.no_grad():
+        model.graph_forward = False
+        want = [model(f, mats) for f in frames]
+        assert not model._graphs
+        model.graph_forward = True
+        got = []
+        for f in frames:
+            # fresh calibration tensor objects with every frame, as the harness's `mats[k] = v.cuda()` makes them
+            got.append(model(f, {k: v.clone() for k, v in mats.items()}))
+    torch.cuda.synchronize()
+    (entry,) = model._graphs.values()
+    assert isinstance(entry[1], GraphedForward) and entry[1].replays == 3      # call 1 eager, calls 2-4 replayed
+    for w, g in zip(want, got):
+        _assert_same(w, g)
+    # the caller owns what it gets: frame 2's maps are not the static buffers frame 3 / 4 were replayed into
+    bases = {(v._base if v._base is not None else v).data_ptr() for preds in got for _, _, v in _flat(preds)}
+    assert len(bases) == len(got)
+    # the 36 maps of one call are still channel slices of ONE buffer (what get_bboxes' stride asserts rely on)
+    assert len({(v._base if v._base is not None else v).data_ptr() for _, _, v in _flat(got[2])}) == 1
+
+
+def test_graph_backed_forward_follows_calibration_and_weights(hip):
+    """Another calibration through the same graph (the plan lives outside the graph and is refreshed eagerly), an in-place
+    edit of the calibration tensors, and a weight change (the graph is dropped with the packed weights)."""
+    from sgv3d_amd import synthetic as S
+    model, bc, _ = _model(seed=3)
+    scale = bc['final_dim'][0] / 864
+    img = S.make_images(1, bc['final_dim'], device='cuda', seed=5)
+    m0 = S.make_mats(1, device='cuda', scale=scale)
+    # the second sample of a varied pair is another camera (pitch 12.5 deg, 5.9 m, yaw 1 deg): use it as sample 0's new calibration
+    m1 = {k: v[1:2].clone() for k, v in S.make_mats(2, device='cuda', scale=scale).items()}
+    with torch.no_grad():
+        model.graph_forward = False
+        want0, want1 = model(img, m0), model(img, m1)
+        g0 = model.backbone.calibration(m0, 0)[0].clone()
+        g1 = model.backbone.calibration(m1, 0)[0].clone()
+        assert not torch.equal(g0, g1), "the second calibration must move voxel indices for this test to mean anything"
+        model.graph_forward = True
+        model(img, m0)                                      # eager (first sight)
+        _assert_same(want0, model(img, m0))                 # replay
+        _assert_same(want1, model(img, m1))                 # replay after the plan refresh
+        _assert_same(want0, model(img, m0))                 # and back
+        live = {k: v.clone() for k, v in m0.items()}
+        _assert_same(want0, model(img, live))
+        for k in live:
+            live[k].copy_(m1[k])                            # in place: same objects, bumped versions
+        _assert_same(want1, model(img, live))
+        (entry,) = model._graphs.values()
+        assert entry[1].replays == 5
+        # weights change -> packed weights and graphs are dropped, the next calls are eager + a new capture
+        with torch.no_grad():
+            model.head.shared_conv.conv.weight.mul_(0.5)
+        model.graph_forward = False
+        want2 = model(img, m0)
+        model.graph_forward = True
+        assert not model._graphs
+        model(img, m0)
+        _assert_same(want2, model(img, m0))
+    torch.cuda.synchronize()
+
+
+def test_eager_always_where_a_replay_would_be_wrong(hip):
+    """Inside someone else's capture, under pipeline.eager_forward, with the instrumented pass on, or with the switch off,
+    forward launches its kernels directly; flipping a kernel-selection switch of hip_ops starts a new signature."""
+    from sgv3d_amd import hip_ops, synthetic as S
+    from sgv3d_amd.pipeline import eager_forward
+    model, bc, _ = _model(seed=4)
+    img = S.make_images(1, bc['final_dim'], device='cuda', seed=1)
+    mats = S.make_mats(1, device='cuda', scale=bc['final_dim'][0] / 864)
+    with torch.no_grad():
+        with eager_forward(model):
+            for _ in range(3):
+                model(img, mats)
+        assert not model._graphs
+        hip_ops.PROFILE = []
+        try:
+            for _ in range(3):
+                model(img, mats)
+            assert hip_ops.PROFILE and not model._graphs
+        finally:
+            hip_ops.PROFILE = None
+        model(img, mats); model(img, mats)
+        assert len(model._graphs) == 1
+        saved = hip_ops.SPLIT_K
+        hip_ops.SPLIT_K = not saved
+        try:
+            model(img, mats)
+            assert len(model._graphs) == 2 and list(model._graphs.values())[-1][1] is None      # first sight: eager
+        finally:
+            hip_ops.SPLIT_K = saved
+    model.train()
+    model.eval()                                # train() / eval() drop the packed weights and the graphs with them
+    assert not model._graphs
+    torch.cuda.synchronize()
+
+
+def test_reference_eval_step_through_the_drop_in(hip):
+    """The reference harness's eval_step, restated in sgv3d_amd/harness.py, on host-side calibration tensors: boxes /
+    scores / labels as numpy arrays per sample, identical between the eager forward and the graph replays, and equal to
+    what decode gives on the eager maps directly."""
+    from sgv3d_amd import harness, synthetic as S
+    model, bc, _ = _model(seed=6)
+    scale = bc['final_dim'][0] / 864
+    host = S.make_mats(2, device='cpu', scale=scale)
+    frames = [S.make_images(2, bc['final_dim'], device='cuda', seed=10 + s) for s in range(3)]
+    with torch.no_grad():
+        model.graph_forward = False
+        want = [harness.eval_step(model, harness.make_batch(f, host)) for f in frames]
+        model.graph_forward = True
+        got = [harness.eval_step(model, harness.make_batch(f, host)) for f in frames]
+        got += [harness.eval_step(model, harness.make_batch(frames[0].cpu(), host))]          # images from the host, too
+    want.append(want[0])
+    assert list(model._graphs.values())[0][1].replays == 3
+    for w, g in zip(want, got):
+        assert len(w) == len(g) == 2
+        for (wb, ws, wl, wm), (gb, gs, gl, gm) in zip(w, g):
+            assert isinstance(gb, np.ndarray) and gb.ndim == 2 and gb.shape[1] == 9 and gs.shape == gl.shape == (gb.shape[0],)
+            assert np.array_equal(wb, gb) and np.array_equal(ws, gs) and np.array_equal(wl, gl) and wm == gm

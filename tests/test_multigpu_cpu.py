@@ -195,3 +195,28 @@ def test_bench_multi_rank_control_flow_with_stub_model():
     # rank 1 sleeps 4 ms per step, rank 0 2 ms: the aggregate is priced with the slower rank's time
     assert rec["ms_per_step"] >= 4.0 and per[0]["frames_per_s"] > per[1]["frames_per_s"]
     assert abs(rec["value"] - 2 * 1 * 6 / (rec["ms_per_step"] * 6e-3)) < 1e-6 * rec["value"]
+
+
+def test_bench_gpus_n_without_launcher_spawns_its_own_ranks():
+    """``python bench.py --gpus 2`` with NO rank environment (a user, not torchrun): the script starts its two ranks itself as
+    fresh child processes and prints their one line with n_gpus 2 -- it must never run one rank silently and report n_gpus 1.
+    Without the stub (a real run) and fewer than N visible GPUs it exits non-zero before any GPU call."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                       env=dict(env, SGV3D_BENCH_STUB="1"), capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["world_size"] == 2 and [p["rank"] for p in rec["config"]["per_rank"]] == [0, 1]
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                           env=env, capture_output=True, timeout=300)
+        assert r.returncode != 0 and not r.stdout.strip()
+        assert b"GPU(s) visible" in r.stderr
+    # a launcher whose world size disagrees with --gpus is refused as well (used to pass silently for WORLD_SIZE=1)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                       env=dict(env, SGV3D_BENCH_STUB="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, timeout=300)
+    assert r.returncode != 0 and b"must agree" in r.stderr

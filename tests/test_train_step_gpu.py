@@ -197,3 +197,20 @@ def test_bench_through_one_rank_rccl():
                      "--no-roofline"], env)
     assert rec["config"]["backend"] == "nccl (RCCL)" and rec["config"]["world_size"] == 1 and rec["n_gpus"] == 1
     assert rec["value"] > 10.0 and len(rec["config"]["per_rank"]) == 1
+
+
+def test_overlap_hooks_are_rearmed_by_step_itself():
+    """A loop that zeroes gradients with ``model.zero_grad()`` (not the optimiser's) on the no-collectives path never goes
+    through zero_grad() / all_reduce_grads() of DataParallelAdamW: step() itself re-arms the per-bucket counters, so the
+    next backward is not mistaken for a second backward of the same step."""
+    from sgv3d_amd.train_step import DataParallelAdamW
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3)).cuda()
+    opt = DataParallelAdamW(net.parameters(), lr=1e-3, bucket_bytes=64).overlap_with_backward()
+    x = torch.randn(4, 6, device="cuda")
+    for _ in range(3):
+        net.zero_grad(set_to_none=False)
+        net(x).sum().backward()
+        opt.step()
+    assert opt.steps == 3 and opt._learned and not opt._unused
+    assert opt._left == [len(e) for _, _, e in opt.flat.buckets]
