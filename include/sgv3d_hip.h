@@ -580,6 +580,18 @@ int sgv3d_centerpoint_decode(int batch, int num_class, int h, int w, int max_num
                              float *scores, int32_t *labels, unsigned char *valid, unsigned char *keep,
                              void *stream);
 
+/* Tail of mmdet3d 0.18.1 CenterHead.get_bboxes (reached from layers/heads/bev_height_head.py:334-405 /
+ * models/bev_height.py:116-126): per sample the boxes that survived circle NMS, task after task in candidate order, with
+ * z -= h / 2 and the labels offset by the class counts of the earlier tasks -- one launch instead of 18 masked selections
+ * (each a host synchronisation) per sample.
+ *   boxes f32 [num_tasks, batch, max_num, 9], scores f32 / labels int32 / keep u8 [num_tasks, batch, max_num]: the outputs of
+ *   sgv3d_centerpoint_decode for every task, stacked; classes_per_task host int32[num_tasks] (<= 16 tasks)
+ *   out_boxes f32 [batch, num_tasks*max_num, 9], out_scores f32 / out_labels int32 [batch, num_tasks*max_num]: the first
+ *   counts[b] rows of sample b are valid; counts int32 [batch]. */
+int sgv3d_centerpoint_merge_tasks(int batch, int num_tasks, int max_num, const float *boxes, const float *scores,
+                                  const int32_t *labels, const unsigned char *keep, const int32_t *classes_per_task /*host*/,
+                                  float *out_boxes, float *out_scores, int32_t *out_labels, int32_t *counts, void *stream);
+
 /* ================================================================================================
  * Training-side head functions  
  * ================================================================================================ */

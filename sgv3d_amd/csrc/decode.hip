@@ -232,7 +232,74 @@ __global__ __launch_bounds__(512) void circle_nms_kernel(int K, const float *__r
 
 int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// Tail of CenterHead.get_bboxes (mmdet3d 0.18.1; reached from layers/heads/bev_height_head.py:334-405): per sample the kept
+// boxes of all tasks, task after task in candidate order, z lowered by half the height, labels offset by the classes of the
+// earlier tasks.  One workgroup per sample compacts the T x K candidates in order (block scan per 256 candidates); the
+// per-sample counts are the only thing the host has to read back before it can slice the outputs.
+constexpr int kMergeMaxTasks = 16;
+struct MergeCfg { int label_offset[kMergeMaxTasks]; };
+
+__global__ __launch_bounds__(256) void merge_tasks_kernel(int batch, int tasks, int K, const float *__restrict__ boxes,
+                                                          const float *__restrict__ scores, const int32_t *__restrict__ labels,
+                                                          const unsigned char *__restrict__ keep, MergeCfg cfg,
+                                                          float *__restrict__ out_boxes, float *__restrict__ out_scores,
+                                                          int32_t *__restrict__ out_labels, int32_t *__restrict__ counts) {
+    __shared__ int wave_sum[4];
+    __shared__ int base_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    const long long total = (long long)tasks * K;
+    for (int t = 0; t < tasks; ++t) {
+        const long long src0 = ((long long)t * batch + b) * K;
+        for (int j0 = 0; j0 < K; j0 += 256) {                      // block-uniform trip counts
+            const int j = j0 + tid;
+            const bool k = j < K && keep[src0 + j] != 0;
+            const unsigned long long m = __ballot(k);
+            const int before = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_sum[wid] = __popcll(m);
+            __syncthreads();
+            int off = base_s;
+            for (int w2 = 0; w2 < wid; ++w2) off += wave_sum[w2];
+            if (k) {
+                const long long dst = (long long)b * total + off + before;
+                const float *src = boxes + (src0 + j) * 9;
+                float v[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) v[c] = src[c];
+                v[2] = __fsub_rn(v[2], __fmul_rn(v[5], 0.5f));     // bboxes[:, 2] - bboxes[:, 5] * 0.5, two roundings as in torch
+#pragma unroll
+                for (int c = 0; c < 9; ++c) out_boxes[dst * 9 + c] = v[c];
+                out_scores[dst] = scores[src0 + j];
+                out_labels[dst] = labels[src0 + j] + cfg.label_offset[t];
+            }
+            __syncthreads();
+            if (tid == 0) base_s = base_s + wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+            __syncthreads();
+        }
+    }
+    if (tid == 0) counts[b] = base_s;
+}
+
 }  // namespace
+
+extern "C" int sgv3d_centerpoint_merge_tasks(int batch, int num_tasks, int max_num, const float *boxes, const float *scores,
+                                             const int32_t *labels, const unsigned char *keep,
+                                             const int32_t *classes_per_task, float *out_boxes, float *out_scores,
+                                             int32_t *out_labels, int32_t *counts, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && num_tasks > 0 && num_tasks <= kMergeMaxTasks && max_num > 0, "centerpoint_merge_tasks: bad size");
+    SGV3D_REQUIRE(boxes && scores && labels && keep && classes_per_task && out_boxes && out_scores && out_labels && counts,
+                  "centerpoint_merge_tasks: null pointer");
+    MergeCfg cfg;
+    int off = 0;
+    for (int t = 0; t < kMergeMaxTasks; ++t) {
+        cfg.label_offset[t] = off;
+        if (t < num_tasks) off += classes_per_task[t];
+    }
+    hipLaunchKernelGGL(merge_tasks_kernel, dim3(batch), dim3(256), 0, as_stream(stream), batch, num_tasks, max_num, boxes, scores,
+                       labels, keep, cfg, out_boxes, out_scores, out_labels, counts);
+    return check_launch("centerpoint_merge_tasks");
+}
 
 extern "C" size_t sgv3d_centerpoint_decode_workspace_bytes(int batch, int num_class, int max_num) {
     if (batch <= 0 || num_class <= 0 || max_num <= 0) return 0;

@@ -327,24 +327,29 @@ class BEVHeightHead(HipModule):
         rng = coder.get('post_center_range')
         rng_c = (ctypes.c_float * 6)(*[float(v) for v in rng]) if rng is not None else None
         thr = coder.get('score_threshold')
-        per_task = []
+        T = len(preds_dicts)
+        heat0 = preds_dicts[0][0]['heatmap']
+        B, dev = int(heat0.shape[0]), heat0.device
+        # the outputs of all tasks stacked, so that the merge below is one launch: [T, B, K, ...]
+        boxes = torch.empty(T, B, K, 9, dtype=torch.float32, device=dev)
+        scores = torch.empty(T, B, K, dtype=torch.float32, device=dev)
+        labels = torch.empty(T, B, K, dtype=torch.int32, device=dev)
+        valid = torch.empty(T, B, K, dtype=torch.uint8, device=dev)
+        keep = torch.empty(T, B, K, dtype=torch.uint8, device=dev)
+        ws = None
         for task_id, preds in enumerate(preds_dicts):
             p = preds[0]
             heat = p['heatmap']
-            B, cat, H, W = (int(v) for v in heat.shape)
-            dev = heat.device
+            Bt, cat, H, W = (int(v) for v in heat.shape)
+            assert Bt == B and heat.device == dev
             bs = int(heat.stride(0))
             for k in ('reg', 'height', 'dim', 'rot'):
                 assert p[k].stride(0) == bs and p[k].stride(1) == H * W and p[k].stride(3) == 1
             assert heat.stride(1) == H * W and heat.dtype == torch.float32
             vel = p.get('vel')
             nws = lib.sgv3d_centerpoint_decode_workspace_bytes(B, cat, K)
-            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-            boxes = torch.empty(B, K, 9, dtype=torch.float32, device=dev)
-            scores = torch.empty(B, K, dtype=torch.float32, device=dev)
-            labels = torch.empty(B, K, dtype=torch.int32, device=dev)
-            valid = torch.empty(B, K, dtype=torch.uint8, device=dev)
-            keep = torch.empty(B, K, dtype=torch.uint8, device=dev)
+            if ws is None or ws.numel() < nws:
+                ws = torch.empty(nws, dtype=torch.uint8, device=dev)      # (tasks run back to back on one stream: shared)
             with torch.cuda.device(dev), hip_ops.prof("centerpoint_decode"):
                 rc = lib.sgv3d_centerpoint_decode(
                     B, cat, H, W, K, heat.data_ptr(), p['reg'].data_ptr(), p['height'].data_ptr(), p['dim'].data_ptr(),
@@ -352,27 +357,29 @@ class BEVHeightHead(HipModule):
                     float(coder['voxel_size'][0]), float(coder['voxel_size'][1]), float(coder['pc_range'][0]),
                     float(coder['pc_range'][1]), float(thr) if thr is not None else float('-inf'), rng_c,
                     1 if self.norm_bbox else 0, float(tcfg['min_radius'][task_id]), int(tcfg['post_max_size']),
-                    ws.data_ptr(), nws, boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(), valid.data_ptr(),
-                    keep.data_ptr(), _lib.stream_handle(dev))
+                    ws.data_ptr(), ws.numel(), boxes[task_id].data_ptr(), scores[task_id].data_ptr(), labels[task_id].data_ptr(),
+                    valid[task_id].data_ptr(), keep[task_id].data_ptr(), _lib.stream_handle(dev))
             _lib.check(rc, "sgv3d_centerpoint_decode")
-            per_task.append((boxes, scores, labels, keep.bool()))
-        # merge tasks (CenterHead.get_bboxes tail): concat, label offsets, z -= h/2
-        B = per_task[0][0].shape[0]
+        # merge tasks (CenterHead.get_bboxes tail): per sample the kept boxes task after task, label offsets, z -= h/2 -- one
+        # launch; the per-sample counts are the single device->host read of the whole call
+        out_boxes = torch.empty(B, T * K, 9, dtype=torch.float32, device=dev)
+        out_scores = torch.empty(B, T * K, dtype=torch.float32, device=dev)
+        out_labels = torch.empty(B, T * K, dtype=torch.int32, device=dev)
+        counts = torch.empty(B, dtype=torch.int32, device=dev)
+        ncls = (ctypes.c_int32 * T)(*[int(n) for n in self.num_classes])
+        with torch.cuda.device(dev), hip_ops.prof("centerpoint_merge_tasks"):
+            rc = lib.sgv3d_centerpoint_merge_tasks(B, T, K, boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(), keep.data_ptr(),
+                                                   ncls, out_boxes.data_ptr(), out_scores.data_ptr(), out_labels.data_ptr(),
+                                                   counts.data_ptr(), _lib.stream_handle(dev))
+        _lib.check(rc, "sgv3d_centerpoint_merge_tasks")
+        n_kept = counts.tolist()
         ret_list = []
+        code_size = int(coder.get('code_size', 9))
         for i in range(B):
-            bl, sl, ll, flag = [], [], [], 0
-            for (boxes, scores, labels, keep), nc in zip(per_task, self.num_classes):
-                k = keep[i]
-                bl.append(boxes[i][k])
-                sl.append(scores[i][k])
-                ll.append(labels[i][k] + flag)
-                flag += nc
-            bboxes = torch.cat(bl)
-            bboxes[:, 2] = bboxes[:, 2] - bboxes[:, 5] * 0.5
+            bboxes = out_boxes[i, :n_kept[i]]
             box_type = img_metas[i].get('box_type_3d') if img_metas is not None and i < len(img_metas) else None
-            code_size = int(coder.get('code_size', 9))
             bboxes = box_type(bboxes, code_size) if callable(box_type) else Boxes3D(bboxes, code_size)
-            ret_list.append([bboxes, torch.cat(sl), torch.cat(ll).int()])
+            ret_list.append([bboxes, out_scores[i, :n_kept[i]], out_labels[i, :n_kept[i]]])
         return ret_list
 
 

@@ -230,13 +230,15 @@ def test_calibration_cache_and_pipeline_recalibration(small):
     the device), a different calibration rebuilds -- and results always equal a cold model's.  The graph-replay
     pipeline refreshes a slot's plan when it is handed another calibration."""
     from sgv3d_amd.calibration import CalibrationCache
-    from sgv3d_amd.pipeline import FramePipeline
+    from sgv3d_amd.pipeline import FramePipeline, eager_forward
     m = small['m']
     imgs, mats = small['imgs'].to(DEV), _to_dev(small['mats'])
     old = m.backbone.calib_cache
     m.backbone.calib_cache = cc = CalibrationCache()
     try:
-        with torch.no_grad():
+        # (direct launches: the counters below are those of the model's own cache; the hipGraph that forward() keeps per
+        # signature has a cache of its own -- tests/test_harness_gpu.py covers that path through the same calibrations)
+        with torch.no_grad(), eager_forward(m):
             a = m(imgs, mats)[0][0]['heatmap'].clone()
             assert (cc.hits, cc.refreshes, cc.plan.builds()) == (0, 1, 1)
             b = m(imgs, mats)[0][0]['heatmap'].clone()
