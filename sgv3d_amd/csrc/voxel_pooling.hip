@@ -92,9 +92,15 @@ struct PlanLayout {
     long long V;        // B*Y*X
     long long total;    // B*N
     int nblk;           // scan workgroups
-    size_t off_seg, off_cur, off_order, off_slotvox, off_blk, off_hdr, off_geom, off_long, bytes;
+    size_t off_seg, off_cur, off_order, off_slotvox, off_blk, off_hdr, off_geom, off_long, off_perm, off_bins, bytes;
     int long_cap;       // capacity of the long-run list (entries after the count)
 };
+
+// Voxels ordered by population (vp_gather_vox_kernel, round 4): `perm` lists the voxel ids by DESCENDING point count -- a
+// counting sort over kLenBins keys (key = min(count, kLenBins - 1)), the empty voxels (key 0) last.  bins[0 .. kLenBins) =
+// number of voxels per key, bins[kLenBins .. 2 kLenBins) = bin_start[key] = position of the key's first voxel in perm
+// (= number of voxels with a larger key for key >= 1; bin_start[0] = number of non-empty voxels), then the scatter cursors.
+constexpr int kLenBins = 1024;
 
 // Voxels holding more than kLongRun points ("long runs" of the sorted slot list) are listed in the plan and summed by
 // dedicated workgroups of the gather launch; every other voxel is summed by the one wave whose slot range contains its
@@ -126,7 +132,9 @@ PlanLayout plan_layout(int B, int N, int X, int Y) {
     L.off_geom = al(L.off_hdr + sizeof(PlanHeader));
     L.off_long = al(L.off_geom + sizeof(int) * 3 * (size_t)L.total);
     L.long_cap = (int)(L.total / kLongRun) + 1;
-    L.bytes = al(L.off_long + sizeof(int) * (size_t)(L.long_cap + 1));
+    L.off_perm = al(L.off_long + sizeof(int) * (size_t)(L.long_cap + 1));
+    L.off_bins = al(L.off_perm + sizeof(int) * (size_t)L.V);
+    L.bytes = al(L.off_bins + sizeof(int) * 3 * (size_t)kLenBins);
     return L;
 }
 
@@ -364,6 +372,72 @@ __global__ __launch_bounds__(kBlock) void vp_fill_kernel(long long total_pts, in
         // slots of a long run carry ~voxel: no gather wave owns them, the long-run workgroups sum them (vp_gather3_kernel)
         slot_voxel[slot] = (seg_start[v + 1] - seg_start[v] > kLongRun) ? ~v : v;
     }
+}
+
+// ---- voxels by descending population (perm), for the voxel-owner gather --------------------------------------------------
+__global__ __launch_bounds__(kBlock) void vp_len_hist_kernel(long long V, const int *__restrict__ seg_start,
+                                                             int *__restrict__ bins, const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    __shared__ int h[kLenBins];
+    for (int i = threadIdx.x; i < kLenBins; i += kBlock) h[i] = 0;
+    __syncthreads();
+    for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < V; v += (long long)gridDim.x * kBlock) {
+        const int n = seg_start[v + 1] - seg_start[v];
+        atomicAdd(&h[n < kLenBins - 1 ? n : kLenBins - 1], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kLenBins; i += kBlock)
+        if (h[i] != 0) atomicAdd(bins + i, h[i]);
+}
+
+// one workgroup: bin_start over the keys in the order kLenBins-1, ..., 1, 0; clears the scatter cursors
+__global__ __launch_bounds__(kBlock) void vp_len_scan_kernel(int *__restrict__ bins, const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    __shared__ int wave_tot[kBlock / 64];
+    constexpr int per = kLenBins / kBlock;
+    // position r in scan order holds key (kLenBins - 1 - r) for r < kLenBins - 1, key 0 for the last position
+    int v[per], sum = 0;
+#pragma unroll
+    for (int i = 0; i < per; ++i) {
+        const int r = threadIdx.x * per + i;
+        const int key = r < kLenBins - 1 ? kLenBins - 1 - r : 0;
+        v[i] = bins[key];
+        sum += v[i];
+    }
+    int tot;
+    int run = block_exclusive_scan(sum, wave_tot, tot);
+#pragma unroll
+    for (int i = 0; i < per; ++i) {
+        const int r = threadIdx.x * per + i;
+        const int key = r < kLenBins - 1 ? kLenBins - 1 - r : 0;
+        bins[kLenBins + key] = run;
+        bins[2 * kLenBins + key] = 0;
+        run += v[i];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void vp_len_scatter_kernel(long long V, const int *__restrict__ seg_start,
+                                                                int *__restrict__ bins, int *__restrict__ perm,
+                                                                const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    // per workgroup: local histogram of its voxels -> one global reservation per key present -> local ranks.  The order of
+    // the voxels inside a key is whatever the atomics give: every voxel is summed on its own, so results do not depend on it.
+    __shared__ int h[kLenBins];
+    __shared__ int base[kLenBins];
+    for (int i = threadIdx.x; i < kLenBins; i += kBlock) h[i] = 0;
+    __syncthreads();
+    const long long v = (long long)blockIdx.x * kBlock + threadIdx.x;
+    int key = -1, rank = 0;
+    if (v < V) {
+        const int n = seg_start[v + 1] - seg_start[v];
+        key = n < kLenBins - 1 ? n : kLenBins - 1;
+        rank = atomicAdd(&h[key], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kLenBins; i += kBlock)
+        if (h[i] != 0) base[i] = bins[kLenBins + i] + atomicAdd(bins + 2 * kLenBins + i, h[i]);
+    __syncthreads();
+    if (key >= 0) perm[base[key] + rank] = (int)v;
 }
 
 // Segments of lo+1 .. 64*R points: one wave per voxel, the list lives in R registers per lane
@@ -895,8 +969,8 @@ struct VpFastArgs {
 
 // FUSED: a live slot's point id becomes the row of its pixel in the context tensor, `pr` its probability (0 for dead slots).
 // Done once per slot by the lane that fetched the slot's entry (two integer divisions per window, not per row).
-template <bool FUSED>
-__device__ __forceinline__ void vp_fused_index(const VpFastArgs &a, int &idx, float &pr) {
+template <bool FUSED, class Args>
+__device__ __forceinline__ void vp_fused_index(const Args &a, int &idx, float &pr) {
     if constexpr (FUSED) {
         pr = 0.f;
         if (idx >= 0) {
@@ -1213,6 +1287,185 @@ __global__ __launch_bounds__(kBlock) void vp_gather_fast_kernel(const VpFastArgs
 }
 
 // ------------------------------------------------------------------------------------------------
+// 2e. voxel-owner gather (round 4).  The slot-balanced kernel above spends ~20 wave-instructions per slot on the
+// book-keeping of runs that start and end anywhere inside a wave's window (ballots, per-slot boundary selects, stitching);
+// it is issue-bound -- harmless for the operator, whose rows come from HBM, but the fused lift-splat form reads its rows from
+// the L2-resident context map and ran at 0.15 of its byte roofline.  Here NOTHING is cut at arbitrary places: the plan lists
+// the voxels by descending population (perm, bin_start) and a row group of lanes owns a whole voxel (or a whole, evenly cut
+// piece of one), so the inner loop is "16 rows in flight, 16 adds" and a voxel is emitted exactly once:
+//   * population <= 32                one row group per voxel, `groups` voxels per wave (neighbours in perm have (almost)
+//                                     the same population, so the groups of a wave finish together);
+//   * 32 < population <= 32 * groups  one wave per voxel: `groups` equal pieces, added in piece order;
+//   * larger                          one workgroup per voxel: 4 * groups equal pieces; a wave adds its pieces in order, the
+//                                     four wave sums meet in LDS and are added in wave order.
+// Fixed association per (population, channel count) => bit-reproducible.  Work is dealt with a static stride over a grid that
+// is resident at once (perm is in descending order, so every wave gets the same mix of long and short voxels and the
+// longest start first); rows of empty voxels are written from the tail of perm.  All loops are bounded by counts read from
+// the plan, every wave reaches the end of the kernel.
+// ------------------------------------------------------------------------------------------------
+struct VpVoxArgs {
+    const int *seg_start, *order, *perm, *bin_start;
+    const void *feats;
+    void *out;
+    const int *gate;
+    unsigned feat_bytes, out_bytes;
+    int V, C, lpr, groups, vb, ldo, N;
+    const float *prob;      // FUSED (lift-splat): feats = context [B, P, C], rows formed as prob[point] * context[pixel]
+    int P;
+};
+constexpr int kVoxBatch = 16;    // rows in flight per lane
+constexpr int kVoxShort = 32;    // populations up to this are summed by one row group
+constexpr int kVoxGrid = 1024;   // workgroups: 4 per CU, all resident (<= 128 VGPRs)
+
+// acc += rows of the slots [pb, pe) in slot order, `vb` at a time; `maxlen` >= pe - pb is wave-uniform (the longest piece of
+// the wave), slots past a group's own end are dead (index -1: the load returns zeros).
+template <bool FB, bool FUSED>
+__device__ __forceinline__ void vp_vox_piece(float4 &acc, int pb, int pe, int maxlen, int cl, bool ingroup, int g, int gs, int vb,
+                                             __amdgpu_buffer_rsrc_t f_rsrc, unsigned row_in, unsigned lane_in, int *idw,
+                                             float *prw, const VpVoxArgs &a) {
+    const bool index_lane = ingroup && cl < vb;
+    for (int base = 0; base < maxlen; base += vb) {              // wave-uniform trip count
+        const int slot = pb + base + cl;
+        int my_idx = -1;
+        if (index_lane && slot < pe) my_idx = a.order[slot];
+        float my_pr = 0.f;
+        vp_fused_index<FUSED>(a, my_idx, my_pr);
+        if (index_lane) {
+            idw[g * kVoxBatch + cl] = my_idx;
+            if constexpr (FUSED) prw[g * kVoxBatch + cl] = my_pr;
+        }
+        const vp_i32x4 *ip = reinterpret_cast<const vp_i32x4 *>(idw + gs * kVoxBatch);
+        int idx[kVoxBatch];
+#pragma unroll
+        for (int q = 0; q < kVoxBatch / 4; ++q) {
+            const vp_i32x4 t = ip[q];
+            idx[4 * q + 0] = t[0]; idx[4 * q + 1] = t[1]; idx[4 * q + 2] = t[2]; idx[4 * q + 3] = t[3];
+        }
+        float pr[kVoxBatch];
+        if constexpr (FUSED) {
+            const vp_f32x4 *pp = reinterpret_cast<const vp_f32x4 *>(prw + gs * kVoxBatch);
+#pragma unroll
+            for (int q = 0; q < kVoxBatch / 4; ++q) {
+                const vp_f32x4 t = pp[q];
+                pr[4 * q + 0] = t[0]; pr[4 * q + 1] = t[1]; pr[4 * q + 2] = t[2]; pr[4 * q + 3] = t[3];
+            }
+        }
+        float4 val[kVoxBatch];
+#pragma unroll
+        for (int k = 0; k < kVoxBatch; ++k) val[k] = vp_buf_load_row<FB>(f_rsrc, (unsigned)idx[k] * row_in + lane_in);
+        const int n = min(vb, maxlen - base);                    // (entries k >= vb stay dead: never written, never added)
+#pragma unroll
+        for (int k = 0; k < kVoxBatch; ++k)
+            if (k < n) vp_add_row<FUSED>(acc, val[k], FUSED ? pr[k] : 0.f);
+    }
+}
+
+template <bool FB, bool OB, bool ACC, bool FUSED = false>
+__global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a) {
+    if (a.gate != nullptr && *reinterpret_cast<const volatile int *>(a.gate) != 0) return;
+    __shared__ __attribute__((aligned(16))) int idx_s[kBlock / 64][(kMaxGroups + 1) * kVoxBatch];
+    __shared__ __attribute__((aligned(16))) float pr_s[kBlock / 64][FUSED ? (kMaxGroups + 1) * kVoxBatch : 4];
+    __shared__ float4 red[kBlock / 64][64];
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int lpr = a.lpr, groups = a.groups, vb = a.vb;
+    const int g = lane / lpr;
+    const int cl = lane - g * lpr;
+    const bool ingroup = g < groups;
+    const int gs = ingroup ? g : groups;                         // LDS block of the lane: its row group, or the all-dead one
+    const int src_cl = ingroup ? cl : 0;
+    int *idw = idx_s[wid];
+    float *prw = pr_s[wid];
+    for (int i = lane; i < (groups + 1) * kVoxBatch; i += 64) {  // every index block starts dead
+        idw[i] = -1;
+        if constexpr (FUSED) prw[i] = 0.f;
+    }
+    const unsigned row_in = (unsigned)a.C * (FB ? 2u : 4u);
+    const unsigned row_out = OB ? (unsigned)a.ldo * 2u : (unsigned)a.C * 4u;
+    const unsigned lane_in = (unsigned)cl * (FB ? 8u : 16u);
+    const unsigned lane_out = (unsigned)cl * (OB ? 8u : 16u);
+    unsigned pad_off = ~0u;
+    if constexpr (OB) {
+        if (cl < ((a.ldo - a.C) >> 2)) pad_off = (unsigned)a.C * 2u + (unsigned)cl * 8u;
+    }
+    const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.feats), 0, (int)a.feat_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    const int nwaves = (int)gridDim.x * (kBlock / 64);
+    const int gw = (int)blockIdx.x * (kBlock / 64) + wid;
+    const int nonempty = a.bin_start[0];
+    const int n_mid_end = a.bin_start[kVoxShort];                // perm[0 .. n_mid_end): populations above kVoxShort
+    const int n_long = a.bin_start[kVoxShort * groups];          // perm[0 .. n_long): above kVoxShort * groups (<= 320 < kLenBins)
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // ---------------------------------------------------------------- rows of empty voxels (not in ACC mode)
+    if constexpr (!ACC) {
+        const int n_rows = (a.V - nonempty + groups - 1) / groups;
+        for (int i = gw; i < n_rows; i += nwaves) {               // wave-uniform
+            const int vi = nonempty + i * groups + g;
+            int v = -1;
+            if (ingroup && vi < a.V) v = a.perm[vi];
+            vp_buf_emit<OB, false>(o_rsrc, v, row_out, lane_out, pad_off, zero4);
+        }
+    }
+    // ---------------------------------------------------------------- the largest voxels: one workgroup each
+    for (int i = (int)blockIdx.x; i < n_long; i += (int)gridDim.x) {      // block-uniform
+        const int v = a.perm[i];
+        const int b = a.seg_start[v], e = a.seg_start[v + 1];
+        const int np = (kBlock / 64) * groups;
+        const int psz = (e - b + np - 1) / np;
+        int pb = 0, pe = 0;
+        if (ingroup) {
+            pb = min(b + (wid * groups + g) * psz, e);
+            pe = min(pb + psz, e);
+        }
+        float4 acc = zero4;
+        vp_vox_piece<FB, FUSED>(acc, pb, pe, psz, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
+        float4 wsum = zero4;
+        for (int g2 = 0; g2 < groups; ++g2) vacc(wsum, vp_from_lane(acc, g2 * lpr + src_cl));
+        if (g == 0) red[wid][cl] = wsum;
+        __syncthreads();
+        if (wid == 0) {
+            float4 tot = red[0][src_cl];
+#pragma unroll
+            for (int w = 1; w < kBlock / 64; ++w) vacc(tot, red[w][src_cl]);
+            vp_buf_emit<OB, ACC>(o_rsrc, g == 0 ? v : -1, row_out, lane_out, pad_off, tot);
+        }
+        __syncthreads();
+    }
+    // ---------------------------------------------------------------- middle populations: one wave each, `groups` pieces
+    for (int i = n_long + gw; i < n_mid_end; i += nwaves) {       // wave-uniform (empty when groups == 1)
+        const int v = a.perm[i];
+        const int b = a.seg_start[v], e = a.seg_start[v + 1];
+        const int psz = (e - b + groups - 1) / groups;
+        int pb = 0, pe = 0;
+        if (ingroup) {
+            pb = min(b + g * psz, e);
+            pe = min(pb + psz, e);
+        }
+        float4 acc = zero4;
+        vp_vox_piece<FB, FUSED>(acc, pb, pe, psz, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
+        float4 tot = zero4;
+        for (int g2 = 0; g2 < groups; ++g2) vacc(tot, vp_from_lane(acc, g2 * lpr + src_cl));
+        vp_buf_emit<OB, ACC>(o_rsrc, g == 0 ? v : -1, row_out, lane_out, pad_off, tot);
+    }
+    // ---------------------------------------------------------------- small populations: one row group each
+    const int n_small = (nonempty - n_mid_end + groups - 1) / groups;
+    for (int i = gw; i < n_small; i += nwaves) {                  // wave-uniform
+        const int vi = n_mid_end + i * groups + g;
+        int v = -1, pb = 0, pe = 0;
+        if (ingroup && vi < nonempty) {
+            v = a.perm[vi];
+            pb = a.seg_start[v];
+            pe = a.seg_start[v + 1];
+        }
+        const int maxlen = __shfl(pe - pb, 0, 64);               // group 0 holds the largest (perm: descending population)
+        float4 acc = zero4;
+        vp_vox_piece<FB, FUSED>(acc, pb, pe, maxlen, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
+        vp_buf_emit<OB, ACC>(o_rsrc, v, row_out, lane_out, pad_off, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward gather  (voxel_pooling.py:58-69)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void vp_backward_kernel(long long total_elems, int C,
@@ -1291,6 +1544,21 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
             const unsigned long long fbytes = (FUSED ? (unsigned long long)B * P : (unsigned long long)L.total) * C * (FB ? 2 : 4);
             const unsigned long long obytes = (unsigned long long)L.V * (OB ? ldo * 2 : C * 4);
             static const bool generic_env = [] { const char *e = getenv("SGV3D_VP_GENERIC"); return e && e[0] == '1'; }();
+            // SGV3D_VP_KERNEL=slot: the slot-balanced kernel of round 3 (vp_gather_fast_kernel) instead of the voxel-owner one
+            static const bool slot_env = [] { const char *e = getenv("SGV3D_VP_KERNEL"); return e && e[0] == 's'; }();
+            if (fbytes < 0xfff00000ull && obytes < 0xfff00000ull && L.total < 0x7ff00000ll && !generic_env && !slot_env) {
+                VpVoxArgs a;
+                a.seg_start = seg; a.order = order;
+                a.perm = reinterpret_cast<const int *>(base + L.off_perm);
+                a.bin_start = reinterpret_cast<const int *>(base + L.off_bins) + kLenBins;
+                a.feats = FUSED ? static_cast<const void *>(ctx) : static_cast<const void *>(feats); a.out = out; a.gate = gate;
+                a.prob = prob; a.P = P;
+                a.feat_bytes = (unsigned)fbytes; a.out_bytes = (unsigned)obytes;
+                a.V = (int)L.V; a.C = C; a.lpr = G.lpr; a.groups = G.groups; a.vb = G.lpr < kVoxBatch ? G.lpr : kVoxBatch;
+                a.ldo = ldo; a.N = N;
+                hipLaunchKernelGGL((vp_gather_vox_kernel<FB, OB, ACC, FUSED>), dim3(kVoxGrid), dim3(kBlock), 0, st, a);
+                return check_launch(FUSED ? "vp_gather_vox_kernel (lift-splat)" : "vp_gather_vox_kernel");
+            }
             if (fbytes < 0xfff00000ull && obytes < 0xfff00000ull && L.total < 0x7ff00000ll && !generic_env) {
                 VpFastArgs a;
                 a.seg_start = seg; a.order = order; a.slot_voxel = slotvox;
@@ -1377,6 +1645,15 @@ int plan_build_impl(int batch_size, int num_points, int num_voxel_x, int num_vox
     hipLaunchKernelGGL(vp_scan_add_kernel, dim3(cdiv(L.V + 1, kBlock)), dim3(kBlock), 0, st, L.V, L.nblk, blk,
                        seg, cur, dirty);
     hipLaunchKernelGGL(vp_long_list_kernel, dim3(cdiv(L.V, kBlock)), dim3(kBlock), 0, st, L.V, seg, long_list, L.long_cap, dirty);
+    {   // voxels by descending population (the voxel-owner gather's work list)
+        int *bins = reinterpret_cast<int *>(base + L.off_bins);
+        int *perm = reinterpret_cast<int *>(base + L.off_perm);
+        hipLaunchKernelGGL(vp_zero_kernel, dim3(cdiv(kLenBins, kBlock)), dim3(kBlock), 0, st, (long long)kLenBins, bins, dirty);
+        const int hgrid = cdiv(L.V, kBlock) < 512 ? cdiv(L.V, kBlock) : 512;
+        hipLaunchKernelGGL(vp_len_hist_kernel, dim3(hgrid), dim3(kBlock), 0, st, L.V, seg, bins, dirty);
+        hipLaunchKernelGGL(vp_len_scan_kernel, dim3(1), dim3(kBlock), 0, st, bins, dirty);
+        hipLaunchKernelGGL(vp_len_scatter_kernel, dim3(cdiv(L.V, kBlock)), dim3(kBlock), 0, st, L.V, seg, bins, perm, dirty);
+    }
     hipLaunchKernelGGL(vp_fill_kernel, dim3(pgrid), dim3(kBlock), 0, st, L.total, num_points, num_voxel_x,
                        num_voxel_y, num_voxel_z, geom_xyz, cur, order, reinterpret_cast<int *>(base + L.off_slotvox), dirty, seg);
     if (sort_segments) {
