@@ -96,8 +96,10 @@ struct PlanLayout {
     int long_cap;       // capacity of the long-run list (entries after the count)
 };
 
-// Voxels ordered by population (vp_gather_vox_kernel, round 4): `perm` lists the voxel ids by DESCENDING point count -- a
-// counting sort over kLenBins keys (key = min(count, kLenBins - 1)), the empty voxels (key 0) last.  bins[0 .. kLenBins) =
+// Voxels ordered by population (vp_gather_vox_kernel, round 4): `perm` lists the voxels by DESCENDING point count -- a
+// counting sort over kLenBins keys (key = min(count, kLenBins - 1)), the empty voxels (key 0) last -- as one 16-byte record
+// {voxel id, first slot, end slot, 0} each, so that a gather wave learns its work with ONE load (the kernel is bound by its
+// chain of dependent loads, not by bytes).  bins[0 .. kLenBins) =
 // number of voxels per key, bins[kLenBins .. 2 kLenBins) = bin_start[key] = position of the key's first voxel in perm
 // (= number of voxels with a larger key for key >= 1; bin_start[0] = number of non-empty voxels), then the scatter cursors.
 constexpr int kLenBins = 1024;
@@ -133,7 +135,7 @@ PlanLayout plan_layout(int B, int N, int X, int Y) {
     L.off_long = al(L.off_geom + sizeof(int) * 3 * (size_t)L.total);
     L.long_cap = (int)(L.total / kLongRun) + 1;
     L.off_perm = al(L.off_long + sizeof(int) * (size_t)(L.long_cap + 1));
-    L.off_bins = al(L.off_perm + sizeof(int) * (size_t)L.V);
+    L.off_bins = al(L.off_perm + sizeof(int) * 4 * (size_t)L.V);      // perm: {voxel, first slot, end slot, 0} per voxel
     L.bytes = al(L.off_bins + sizeof(int) * 3 * (size_t)kLenBins);
     return L;
 }
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void vp_len_scatter_kernel(long long V, con
     for (int i = threadIdx.x; i < kLenBins; i += kBlock)
         if (h[i] != 0) base[i] = bins[kLenBins + i] + atomicAdd(bins + 2 * kLenBins + i, h[i]);
     __syncthreads();
-    if (key >= 0) perm[base[key] + rank] = (int)v;
+    if (key >= 0) reinterpret_cast<int4 *>(perm)[base[key] + rank] = make_int4((int)v, seg_start[v], seg_start[v + 1], 0);
 }
 
 // Segments of lo+1 .. 64*R points: one wave per voxel, the list lives in R registers per lane
@@ -1304,7 +1306,8 @@ __global__ __launch_bounds__(kBlock) void vp_gather_fast_kernel(const VpFastArgs
 // the plan, every wave reaches the end of the kernel.
 // ------------------------------------------------------------------------------------------------
 struct VpVoxArgs {
-    const int *seg_start, *order, *perm, *bin_start;
+    const int *order, *bin_start;
+    const int4 *perm;       // {voxel, first slot, end slot, 0} by descending population
     const void *feats;
     void *out;
     const int *gate;
@@ -1312,14 +1315,33 @@ struct VpVoxArgs {
     int V, C, lpr, groups, vb, ldo, N;
     const float *prob;      // FUSED (lift-splat): feats = context [B, P, C], rows formed as prob[point] * context[pixel]
     int P;
+    unsigned magN, magP;    // exact division of a point id (< 2^31) by N / P: umulhi(id, mag) >> sh (vp_magic)
+    int shN, shP;
 };
-constexpr int kVoxBatch = 16;    // rows in flight per lane
-constexpr int kVoxShort = 32;    // populations up to this are summed by one row group
-constexpr int kVoxGrid = 1024;   // workgroups: 4 per CU, all resident (<= 128 VGPRs)
 
-// acc += rows of the slots [pb, pe) in slot order, `vb` at a time; `maxlen` >= pe - pb is wave-uniform (the longest piece of
-// the wave), slots past a group's own end are dead (index -1: the load returns zeros).
-template <bool FB, bool FUSED>
+// floor(n / d) for 0 <= n < 2^31, d >= 2, as umulhi(n, mag) >> sh (a round-up magic number of 32 bits is exact for 31-bit
+// dividends); the fused gather turns every point id into (sample, pixel) with it instead of two hardware-emulated divisions
+struct VpMagic { unsigned mag; int sh; };
+VpMagic vp_magic(int d) {
+    VpMagic m{0u, 0};
+    if (d < 2) return m;                                        // (d == 1 is handled by the caller's select)
+    int l = 0;
+    while ((1ll << l) < d) ++l;
+    m.mag = (unsigned)(((1ull << (31 + l)) / (unsigned long long)d) + 1ull);
+    m.sh = l - 1;
+    return m;
+}
+__device__ __forceinline__ int vp_fast_div(int n, int d, unsigned mag, int sh) {
+    return d == 1 ? n : (int)(__umulhi((unsigned)n, mag) >> sh);
+}
+constexpr int kVoxShort = 32;    // populations up to this are summed by one row group
+constexpr int kVoxGrid = 2048;   // workgroups: 8 per CU (VB = 8: <= 72 VGPRs, 7 waves per SIMD), each wave ~one small item
+
+// acc += rows of the slots [pb, pe) in slot order, `vb` <= VB at a time; `maxlen` >= pe - pb is wave-uniform (the longest piece
+// of the wave), slots past a group's own end are dead (index -1: the load returns zeros).  What bounds this loop is its
+// chain of dependent loads (slot -> point id -> row): the probabilities of the fused form are requested BEFORE the rows and
+// waited for after the rows are in flight, so they add no round trip.
+template <bool FB, bool FUSED, int VB>
 __device__ __forceinline__ void vp_vox_piece(float4 &acc, int pb, int pe, int maxlen, int cl, bool ingroup, int g, int gs, int vb,
                                              __amdgpu_buffer_rsrc_t f_rsrc, unsigned row_in, unsigned lane_in, int *idw,
                                              float *prw, const VpVoxArgs &a) {
@@ -1329,42 +1351,48 @@ __device__ __forceinline__ void vp_vox_piece(float4 &acc, int pb, int pe, int ma
         int my_idx = -1;
         if (index_lane && slot < pe) my_idx = a.order[slot];
         float my_pr = 0.f;
-        vp_fused_index<FUSED>(a, my_idx, my_pr);
-        if (index_lane) {
-            idw[g * kVoxBatch + cl] = my_idx;
-            if constexpr (FUSED) prw[g * kVoxBatch + cl] = my_pr;
+        int my_row = my_idx;
+        if constexpr (FUSED) {
+            if (my_idx >= 0) {
+                my_pr = a.prob[my_idx];                          // (in flight under the row loads below)
+                const int b = vp_fast_div(my_idx, a.N, a.magN, a.shN);
+                const int rem = my_idx - b * a.N;
+                my_row = b * a.P + rem - vp_fast_div(rem, a.P, a.magP, a.shP) * a.P;
+            }
         }
-        const vp_i32x4 *ip = reinterpret_cast<const vp_i32x4 *>(idw + gs * kVoxBatch);
-        int idx[kVoxBatch];
+        if (index_lane) idw[g * VB + cl] = my_row;
+        const vp_i32x4 *ip = reinterpret_cast<const vp_i32x4 *>(idw + gs * VB);
+        int idx[VB];
 #pragma unroll
-        for (int q = 0; q < kVoxBatch / 4; ++q) {
+        for (int q = 0; q < VB / 4; ++q) {
             const vp_i32x4 t = ip[q];
             idx[4 * q + 0] = t[0]; idx[4 * q + 1] = t[1]; idx[4 * q + 2] = t[2]; idx[4 * q + 3] = t[3];
         }
-        float pr[kVoxBatch];
-        if constexpr (FUSED) {
-            const vp_f32x4 *pp = reinterpret_cast<const vp_f32x4 *>(prw + gs * kVoxBatch);
+        float4 val[VB];
 #pragma unroll
-            for (int q = 0; q < kVoxBatch / 4; ++q) {
+        for (int k = 0; k < VB; ++k) val[k] = vp_buf_load_row<FB>(f_rsrc, (unsigned)idx[k] * row_in + lane_in);
+        float pr[VB];
+        if constexpr (FUSED) {
+            if (index_lane) prw[g * VB + cl] = my_pr;
+            const vp_f32x4 *pp = reinterpret_cast<const vp_f32x4 *>(prw + gs * VB);
+#pragma unroll
+            for (int q = 0; q < VB / 4; ++q) {
                 const vp_f32x4 t = pp[q];
                 pr[4 * q + 0] = t[0]; pr[4 * q + 1] = t[1]; pr[4 * q + 2] = t[2]; pr[4 * q + 3] = t[3];
             }
         }
-        float4 val[kVoxBatch];
-#pragma unroll
-        for (int k = 0; k < kVoxBatch; ++k) val[k] = vp_buf_load_row<FB>(f_rsrc, (unsigned)idx[k] * row_in + lane_in);
         const int n = min(vb, maxlen - base);                    // (entries k >= vb stay dead: never written, never added)
 #pragma unroll
-        for (int k = 0; k < kVoxBatch; ++k)
+        for (int k = 0; k < VB; ++k)
             if (k < n) vp_add_row<FUSED>(acc, val[k], FUSED ? pr[k] : 0.f);
     }
 }
 
-template <bool FB, bool OB, bool ACC, bool FUSED = false>
+template <bool FB, bool OB, bool ACC, bool FUSED, int VB>
 __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a) {
     if (a.gate != nullptr && *reinterpret_cast<const volatile int *>(a.gate) != 0) return;
-    __shared__ __attribute__((aligned(16))) int idx_s[kBlock / 64][(kMaxGroups + 1) * kVoxBatch];
-    __shared__ __attribute__((aligned(16))) float pr_s[kBlock / 64][FUSED ? (kMaxGroups + 1) * kVoxBatch : 4];
+    __shared__ __attribute__((aligned(16))) int idx_s[kBlock / 64][(kMaxGroups + 1) * VB];
+    __shared__ __attribute__((aligned(16))) float pr_s[kBlock / 64][FUSED ? (kMaxGroups + 1) * VB : 4];
     __shared__ float4 red[kBlock / 64][64];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
@@ -1376,7 +1404,7 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
     const int src_cl = ingroup ? cl : 0;
     int *idw = idx_s[wid];
     float *prw = pr_s[wid];
-    for (int i = lane; i < (groups + 1) * kVoxBatch; i += 64) {  // every index block starts dead
+    for (int i = lane; i < (groups + 1) * VB; i += 64) {         // every index block starts dead
         idw[i] = -1;
         if constexpr (FUSED) prw[i] = 0.f;
     }
@@ -1397,20 +1425,10 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
     const int n_long = a.bin_start[kVoxShort * groups];          // perm[0 .. n_long): above kVoxShort * groups (<= 320 < kLenBins)
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // ---------------------------------------------------------------- rows of empty voxels (not in ACC mode)
-    if constexpr (!ACC) {
-        const int n_rows = (a.V - nonempty + groups - 1) / groups;
-        for (int i = gw; i < n_rows; i += nwaves) {               // wave-uniform
-            const int vi = nonempty + i * groups + g;
-            int v = -1;
-            if (ingroup && vi < a.V) v = a.perm[vi];
-            vp_buf_emit<OB, false>(o_rsrc, v, row_out, lane_out, pad_off, zero4);
-        }
-    }
     // ---------------------------------------------------------------- the largest voxels: one workgroup each
     for (int i = (int)blockIdx.x; i < n_long; i += (int)gridDim.x) {      // block-uniform
-        const int v = a.perm[i];
-        const int b = a.seg_start[v], e = a.seg_start[v + 1];
+        const int4 rec = a.perm[i];
+        const int v = rec.x, b = rec.y, e = rec.z;
         const int np = (kBlock / 64) * groups;
         const int psz = (e - b + np - 1) / np;
         int pb = 0, pe = 0;
@@ -1419,7 +1437,7 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
             pe = min(pb + psz, e);
         }
         float4 acc = zero4;
-        vp_vox_piece<FB, FUSED>(acc, pb, pe, psz, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
+        vp_vox_piece<FB, FUSED, VB>(acc, pb, pe, psz, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
         float4 wsum = zero4;
         for (int g2 = 0; g2 < groups; ++g2) vacc(wsum, vp_from_lane(acc, g2 * lpr + src_cl));
         if (g == 0) red[wid][cl] = wsum;
@@ -1434,8 +1452,8 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
     }
     // ---------------------------------------------------------------- middle populations: one wave each, `groups` pieces
     for (int i = n_long + gw; i < n_mid_end; i += nwaves) {       // wave-uniform (empty when groups == 1)
-        const int v = a.perm[i];
-        const int b = a.seg_start[v], e = a.seg_start[v + 1];
+        const int4 rec = a.perm[i];
+        const int v = rec.x, b = rec.y, e = rec.z;
         const int psz = (e - b + groups - 1) / groups;
         int pb = 0, pe = 0;
         if (ingroup) {
@@ -1443,7 +1461,7 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
             pe = min(pb + psz, e);
         }
         float4 acc = zero4;
-        vp_vox_piece<FB, FUSED>(acc, pb, pe, psz, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
+        vp_vox_piece<FB, FUSED, VB>(acc, pb, pe, psz, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
         float4 tot = zero4;
         for (int g2 = 0; g2 < groups; ++g2) vacc(tot, vp_from_lane(acc, g2 * lpr + src_cl));
         vp_buf_emit<OB, ACC>(o_rsrc, g == 0 ? v : -1, row_out, lane_out, pad_off, tot);
@@ -1454,14 +1472,23 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
         const int vi = n_mid_end + i * groups + g;
         int v = -1, pb = 0, pe = 0;
         if (ingroup && vi < nonempty) {
-            v = a.perm[vi];
-            pb = a.seg_start[v];
-            pe = a.seg_start[v + 1];
+            const int4 rec = a.perm[vi];
+            v = rec.x; pb = rec.y; pe = rec.z;
         }
         const int maxlen = __shfl(pe - pb, 0, 64);               // group 0 holds the largest (perm: descending population)
         float4 acc = zero4;
-        vp_vox_piece<FB, FUSED>(acc, pb, pe, maxlen, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
+        vp_vox_piece<FB, FUSED, VB>(acc, pb, pe, maxlen, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
         vp_buf_emit<OB, ACC>(o_rsrc, v, row_out, lane_out, pad_off, acc);
+    }
+    // ---------------------------------------------------------------- rows of empty voxels (not in ACC mode)
+    if constexpr (!ACC) {
+        const int n_rows = (a.V - nonempty + groups - 1) / groups;
+        for (int i = gw; i < n_rows; i += nwaves) {               // wave-uniform
+            const int vi = nonempty + i * groups + g;
+            int v = -1;
+            if (ingroup && vi < a.V) v = a.perm[vi].x;
+            vp_buf_emit<OB, false>(o_rsrc, v, row_out, lane_out, pad_off, zero4);
+        }
     }
 }
 
@@ -1548,15 +1575,28 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
             static const bool slot_env = [] { const char *e = getenv("SGV3D_VP_KERNEL"); return e && e[0] == 's'; }();
             if (fbytes < 0xfff00000ull && obytes < 0xfff00000ull && L.total < 0x7ff00000ll && !generic_env && !slot_env) {
                 VpVoxArgs a;
-                a.seg_start = seg; a.order = order;
-                a.perm = reinterpret_cast<const int *>(base + L.off_perm);
+                a.order = order;
+                a.perm = reinterpret_cast<const int4 *>(base + L.off_perm);
                 a.bin_start = reinterpret_cast<const int *>(base + L.off_bins) + kLenBins;
                 a.feats = FUSED ? static_cast<const void *>(ctx) : static_cast<const void *>(feats); a.out = out; a.gate = gate;
                 a.prob = prob; a.P = P;
                 a.feat_bytes = (unsigned)fbytes; a.out_bytes = (unsigned)obytes;
-                a.V = (int)L.V; a.C = C; a.lpr = G.lpr; a.groups = G.groups; a.vb = G.lpr < kVoxBatch ? G.lpr : kVoxBatch;
+                // rows in flight per lane: 16 (4 waves per SIMD) or, SGV3D_VP_VB=8, 8 (<= 76 VGPRs: 6-7 waves per SIMD);
+                // SGV3D_VP_GRID: workgroups of the launch (probe knobs, tools/vp_probe3.py)
+                static const int vb_env = [] { const char *e = getenv("SGV3D_VP_VB"); return e ? atoi(e) : 0; }();
+                static const int grid_env = [] { const char *e = getenv("SGV3D_VP_GRID"); return e ? atoi(e) : 0; }();
+                const int VBsel = vb_env == 16 || vb_env == 8 ? vb_env : 16;
+                const int vgrid = grid_env > 0 ? grid_env : kVoxGrid;
+                if (FUSED) {
+                    const VpMagic mn = vp_magic(N), mp = vp_magic(P);
+                    a.magN = mn.mag; a.shN = mn.sh; a.magP = mp.mag; a.shP = mp.sh;
+                }
+                a.V = (int)L.V; a.C = C; a.lpr = G.lpr; a.groups = G.groups; a.vb = G.lpr < VBsel ? G.lpr : VBsel;
                 a.ldo = ldo; a.N = N;
-                hipLaunchKernelGGL((vp_gather_vox_kernel<FB, OB, ACC, FUSED>), dim3(kVoxGrid), dim3(kBlock), 0, st, a);
+                if (VBsel == 16)
+                    hipLaunchKernelGGL((vp_gather_vox_kernel<FB, OB, ACC, FUSED, 16>), dim3(vgrid), dim3(kBlock), 0, st, a);
+                else
+                    hipLaunchKernelGGL((vp_gather_vox_kernel<FB, OB, ACC, FUSED, 8>), dim3(vgrid), dim3(kBlock), 0, st, a);
                 return check_launch(FUSED ? "vp_gather_vox_kernel (lift-splat)" : "vp_gather_vox_kernel");
             }
             if (fbytes < 0xfff00000ull && obytes < 0xfff00000ull && L.total < 0x7ff00000ll && !generic_env) {
