@@ -580,6 +580,20 @@ int sgv3d_centerpoint_decode(int batch, int num_class, int h, int w, int max_num
                              float *scores, int32_t *labels, unsigned char *valid, unsigned char *keep,
                              void *stream);
 
+/* The same decode for ALL tasks of the head in three launches (grid.y = task) instead of three per task: what
+ * BEVHeightHead.get_bboxes calls.  classes_per_task / nms_thresh: host arrays [num_tasks] (<= 16 tasks); heatmap .. vel: host
+ * arrays of num_tasks device pointers (vel NULL, or entries NULL, for heads without velocity), every map with the same
+ * batch_stride, h, w; outputs stacked [num_tasks, batch, max_num, ...]. */
+size_t sgv3d_centerpoint_decode_tasks_workspace_bytes(int batch, int num_tasks, int max_class, int max_num);
+int sgv3d_centerpoint_decode_tasks(int batch, int num_tasks, const int32_t *classes_per_task /*host*/, int h, int w, int max_num,
+                                   const void *const *heatmap, const void *const *reg, const void *const *height,
+                                   const void *const *dim, const void *const *rot, const void *const *vel,
+                                   long long batch_stride, float out_size_factor, float voxel_x, float voxel_y, float pc_x,
+                                   float pc_y, float score_threshold, const float *post_center_range /*host*/, int norm_bbox,
+                                   const float *nms_thresh /*host*/, int post_max_size, void *workspace, size_t workspace_bytes,
+                                   float *boxes, float *scores, int32_t *labels, unsigned char *valid, unsigned char *keep,
+                                   void *stream);
+
 /* Tail of mmdet3d 0.18.1 CenterHead.get_bboxes (reached from layers/heads/bev_height_head.py:334-405 /
  * models/bev_height.py:116-126): per sample the boxes that survived circle NMS, task after task in candidate order, with
  * z -= h / 2 and the labels offset by the class counts of the earlier tasks -- one launch instead of 18 masked selections

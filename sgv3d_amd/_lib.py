@@ -107,6 +107,11 @@ _PROTOS = {
     "sgv3d_centerpoint_decode": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_ll] + [ctypes.c_float] * 6 +
                                  [ctypes.POINTER(ctypes.c_float), c_int, ctypes.c_float, c_int, c_void_p, c_size_t] +
                                  [c_void_p] * 6),
+    "sgv3d_centerpoint_decode_tasks_workspace_bytes": (c_size_t, [c_int] * 4),
+    "sgv3d_centerpoint_decode_tasks": (c_int, [c_int, c_int, ctypes.POINTER(ctypes.c_int32), c_int, c_int, c_int] +
+                                       [ctypes.POINTER(c_void_p)] * 6 + [c_ll] + [ctypes.c_float] * 6 +
+                                       [ctypes.POINTER(ctypes.c_float), c_int, ctypes.POINTER(ctypes.c_float), c_int, c_void_p,
+                                        c_size_t] + [c_void_p] * 6),
     "sgv3d_centerpoint_merge_tasks": (c_int, [c_int] * 3 + [c_void_p] * 4 + [ctypes.POINTER(ctypes.c_int32)] + [c_void_p] * 5),
     "sgv3d_centerhead_targets": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, ctypes.POINTER(ctypes.c_int32)] +
                                  [c_int] * 3 + [ctypes.c_float] * 5 + [ctypes.c_double, c_int, c_int] + [c_void_p] * 5),

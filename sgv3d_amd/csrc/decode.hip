@@ -61,17 +61,29 @@ __device__ __forceinline__ float fkey_inv(unsigned k) {   // the float a key cam
 // ~90 us per class at 256 x 256 on a grid of one or two workgroups, i.e. pure latency on the harness's critical path).
 constexpr int kKeyCache = 64;
 
+// All tasks of the head in ONE launch per stage (blockIdx.y = task): the six tasks of the shipped configs used to be 18
+// dependent launches of one or two workgroups each -- pure latency on the harness's critical path.
+constexpr int kMaxTasks = 16;
+struct DecodeTasks {
+    const float *heat[kMaxTasks], *reg[kMaxTasks], *hei[kMaxTasks], *dim[kMaxTasks], *rot[kMaxTasks], *vel[kMaxTasks];
+    int cat[kMaxTasks];
+    float nms[kMaxTasks];
+};
+
 template <bool CACHE>
-__global__ __launch_bounds__(kTk) void topk_per_class_kernel(int cat, long long hw, int K, int Kp,
-                                                             const float *__restrict__ heat, long long batch_stride,
+__global__ __launch_bounds__(kTk) void topk_per_class_kernel(int batch, int max_cat, long long hw, int K, int Kp,
+                                                             const DecodeTasks ts, long long batch_stride,
                                                              float *__restrict__ out_score, int *__restrict__ out_ind) {
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_krem;
     __shared__ int s_cnt[kTk / 64][2];
     __shared__ float ssc[kMaxK];
     __shared__ int six[kMaxK];
-    const int b = blockIdx.x / cat, c = blockIdx.x - b * cat;
-    const float *src = heat + (long long)b * batch_stride + (long long)c * hw;
+    const int task = blockIdx.y, cat = ts.cat[task];
+    const int b = blockIdx.x / max_cat, c = blockIdx.x - b * max_cat;
+    if (c >= cat) return;                                   // (block-uniform)
+    const float *src = ts.heat[task] + (long long)b * batch_stride + (long long)c * hw;
+    const long long slot = ((long long)task * batch + b) * max_cat + c;      // this (task, sample, class)'s K outputs
     const int tid = threadIdx.x;
     const long long per = (hw + kTk - 1) / kTk;            // contiguous slice per thread (index order)
     const long long i0 = tid * per, i1 = min(hw, i0 + per);
@@ -93,11 +105,21 @@ __global__ __launch_bounds__(kTk) void topk_per_class_kernel(int cat, long long 
         const unsigned prefix = s_prefix;
         const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
         if constexpr (CACHE) {
+            // Heat maps are smooth: neighbouring cells share the leading digits of their keys, and ALL lanes of a wave would hit
+            // the same histogram bin -- an LDS atomic on one address is serialised, 65 536 of them per pass took ~30 us.  Each
+            // lane therefore counts runs of equal digits along its slice and adds a whole run at once.
+            unsigned cur = 0u, run = 0u;
 #pragma unroll
             for (int q = 0; q < kKeyCache; ++q) {
                 const unsigned k = keys[q];
-                if (q < cnt && (k & himask) == (prefix & himask)) atomicAdd(&hist[(k >> shift) & 255], 1u);
+                if (q < cnt && (k & himask) == (prefix & himask)) {
+                    const unsigned d = (k >> shift) & 255u;
+                    if (run != 0u && d != cur) { atomicAdd(&hist[cur], run); run = 0u; }
+                    cur = d;
+                    ++run;
+                }
             }
+            if (run != 0u) atomicAdd(&hist[cur], run);
         } else {
             for (long long i = i0; i < i1; ++i) {
                 const unsigned k = fkey(score(i));
@@ -174,8 +196,8 @@ __global__ __launch_bounds__(kTk) void topk_per_class_kernel(int cat, long long 
     __syncthreads();
     bitonic_pairs<kTk>(ssc, six, Kp);
     for (int i = tid; i < K; i += kTk) {
-        out_score[((long long)b * cat + c) * K + i] = ssc[i];
-        out_ind[((long long)b * cat + c) * K + i] = six[i];
+        out_score[slot * K + i] = ssc[i];
+        out_ind[slot * K + i] = six[i];
     }
 }
 
@@ -185,21 +207,27 @@ struct DecodeCfg {
     int norm_bbox, has_range, has_vel;
 };
 
-__global__ __launch_bounds__(kTk) void merge_decode_kernel(int cat, int h, int w, int K, int Kp2,
-                                                           const float *__restrict__ cls_score, const int *__restrict__ cls_ind,
-                                                           const float *__restrict__ reg, const float *__restrict__ hei,
-                                                           const float *__restrict__ dim, const float *__restrict__ rot,
-                                                           const float *__restrict__ vel, long long batch_stride,
+__global__ __launch_bounds__(kTk) void merge_decode_kernel(int batch, int max_cat, int h, int w, int K, int Kp2max,
+                                                           const float *__restrict__ cls_score_all, const int *__restrict__ cls_ind_all,
+                                                           const DecodeTasks ts, long long batch_stride,
                                                            DecodeCfg cfg, float *__restrict__ boxes, float *__restrict__ scores,
                                                            int *__restrict__ labels, unsigned char *__restrict__ valid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     float *ssc = reinterpret_cast<float *>(dsm);
-    int *six = reinterpret_cast<int *>(dsm + sizeof(float) * Kp2);
+    int *six = reinterpret_cast<int *>(dsm + sizeof(float) * Kp2max);
+    const int task = blockIdx.y, cat = ts.cat[task];
     const int b = blockIdx.x, tid = threadIdx.x;
     const long long hw = (long long)h * w;
     const int n = cat * K;
+    int Kp2 = 1;
+    while (Kp2 < n) Kp2 <<= 1;                               // this task's sort size (<= Kp2max)
+    // (the top-k stage stored class c of (task, sample) at rows (task * batch + b) * max_cat + c: contiguous over the classes)
+    const float *cls_score = cls_score_all + ((long long)task * batch + b) * max_cat * K;
+    const int *cls_ind = cls_ind_all + ((long long)task * batch + b) * max_cat * K;
+    const float *reg = ts.reg[task], *hei = ts.hei[task], *dim = ts.dim[task], *rot = ts.rot[task], *vel = ts.vel[task];
+    const bool has_vel = vel != nullptr;
     for (int i = tid; i < Kp2; i += kTk) {
-        if (i < n) { ssc[i] = cls_score[(long long)b * n + i]; six[i] = i; }   // flat index = class*K + rank
+        if (i < n) { ssc[i] = cls_score[i]; six[i] = i; }    // flat index = class*K + rank
         else { ssc[i] = -INFINITY; six[i] = 0x7fffffff; }
     }
     __syncthreads();
@@ -207,14 +235,14 @@ __global__ __launch_bounds__(kTk) void merge_decode_kernel(int cat, int h, int w
     for (int t = tid; t < K; t += kTk) {
         const float s = ssc[t];
         const int flat = six[t];
-        const long long o = (long long)b * K + t;
+        const long long o = ((long long)task * batch + b) * K + t;
         if (flat >= n || s == -INFINITY) {                       // fewer than K candidates
             for (int q = 0; q < 9; ++q) boxes[o * 9 + q] = 0.f;
             scores[o] = 0.f; labels[o] = 0; valid[o] = 0;
             continue;
         }
         const int cls = flat / K;
-        const int ind = cls_ind[(long long)b * n + flat];
+        const int ind = cls_ind[flat];
         const int yq = (int)((float)ind / (float)w);            // topk_ys: (ind.float() / width).int()
         const int xq = ind % w;
         const long long bo = (long long)b * batch_stride + ind;
@@ -226,8 +254,8 @@ __global__ __launch_bounds__(kTk) void merge_decode_kernel(int cat, int h, int w
         const float r = atan2f(rot[bo], rot[bo + hw]);          // atan2(sin, cos)
         float *bx = boxes + o * 9;
         bx[0] = xs; bx[1] = ys; bx[2] = z; bx[3] = d0; bx[4] = d1; bx[5] = d2; bx[6] = r;
-        bx[7] = cfg.has_vel ? vel[bo] : 0.f;
-        bx[8] = cfg.has_vel ? vel[bo + hw] : 0.f;
+        bx[7] = has_vel ? vel[bo] : 0.f;
+        bx[8] = has_vel ? vel[bo + hw] : 0.f;
         bool ok = s > cfg.score_thr;
         if (cfg.has_range)
             ok = ok && xs >= cfg.range[0] && ys >= cfg.range[1] && z >= cfg.range[2] && xs <= cfg.range[3] &&
@@ -241,8 +269,12 @@ __global__ __launch_bounds__(kTk) void merge_decode_kernel(int cat, int h, int w
 // greedy circle NMS over the valid candidates of one sample, in score order (they are sorted already): the plain form, two
 // workgroup barriers per candidate (K > kNmsMaskK only; the shipped configs have K = 500)
 __global__ __launch_bounds__(512) void circle_nms_serial_kernel(int K, const float *__restrict__ boxes,
-                                                         const unsigned char *__restrict__ valid, float thresh,
+                                                         const unsigned char *__restrict__ valid, const DecodeTasks ts,
                                                          int post_max_size, unsigned char *__restrict__ keep) {
+    const float thresh = ts.nms[blockIdx.y];
+    boxes += (long long)blockIdx.y * gridDim.x * K * 9;
+    valid += (long long)blockIdx.y * gridDim.x * K;
+    keep += (long long)blockIdx.y * gridDim.x * K;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     float *cx = reinterpret_cast<float *>(dsm);
     float *cy = cx + K;
@@ -278,24 +310,26 @@ __global__ __launch_bounds__(512) void circle_nms_serial_kernel(int K, const flo
     }
 }
 
-// The same greedy suppression for K <= kNmsMaskK, without a barrier per candidate: (1) ordered compaction of the valid
-// candidates by ballots, (2) the whole "i suppresses j" relation (j > i, squared centre distance <= thresh) as a bit matrix in
-// LDS, all pairs tested in parallel, (3) ONE wave walks the candidates in score order with the "suppressed so far" bits in
-// registers (lane l holds bits 32 l .. 32 l + 31): a kept candidate ORs its row into them.  Same decisions in the same
-// order as the plain form (`dx * dx + dy * dy <= thresh` on the same floats), ~20 us instead of ~0.5 ms per task.
+// The same greedy suppression for K <= kNmsMaskK without a barrier per candidate: ordered compaction of the valid candidates
+// by ballots (one candidate per thread), then ONE wave walks them in score order.  Lane l owns the candidates l, l + 64, ...
+// (coordinates and a "suppressed" bit each in registers); whether candidate i is still alive is one v_readlane (i is
+// wave-uniform), and only a candidate that is KEPT (<= post_max_size of them) makes the lanes test their own candidates
+// against it -- O(kept * n / 64) distance tests instead of two workgroup barriers per candidate.  Same decisions in the same
+// order as the plain form (`dx * dx + dy * dy <= thresh` on the same floats): ~15 us instead of ~0.5 ms per task.
 constexpr int kNmsMaskK = 512;
 
 __global__ __launch_bounds__(512) void circle_nms_kernel(int K, const float *__restrict__ boxes,
-                                                         const unsigned char *__restrict__ valid, float thresh,
+                                                         const unsigned char *__restrict__ valid, const DecodeTasks ts,
                                                          int post_max_size, unsigned char *__restrict__ keep) {
     __shared__ float cx[kNmsMaskK], cy[kNmsMaskK];
     __shared__ int cid[kNmsMaskK];
-    __shared__ unsigned mask[kNmsMaskK * (kNmsMaskK / 32)];       // 32 KB
     __shared__ int wave_cnt[8];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    // (1) ordered compaction (K <= 512 = one candidate per thread)
-    const bool v = tid < K && valid[(long long)b * K + tid] != 0;
-    if (tid < K) keep[(long long)b * K + tid] = 0;
+    const float thresh = ts.nms[blockIdx.y];
+    const long long row0 = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * K;          // this (task, sample)'s K candidates
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // (1) ordered compaction
+    const bool v = tid < K && valid[row0 + tid] != 0;
+    if (tid < K) keep[row0 + tid] = 0;
     const unsigned long long m = __ballot(v);
     if (lane == 0) wave_cnt[wid] = __popcll(m);
     __syncthreads();
@@ -305,41 +339,35 @@ __global__ __launch_bounds__(512) void circle_nms_kernel(int K, const float *__r
         n += wave_cnt[w];
     }
     if (v) {
-        const float *bx = boxes + ((long long)b * K + tid) * 9;
+        const float *bx = boxes + (row0 + tid) * 9;
         cid[pos] = tid; cx[pos] = bx[0]; cy[pos] = bx[1];
     }
     __syncthreads();
-    // (2) suppression rows: word (i, w) = candidates j in [32 w, 32 w + 32) that i suppresses
-    const int words = (n + 31) >> 5;
-    for (int e = tid; e < n * words; e += 512) {
-        const int i = e / words, w = e - i * words;
-        unsigned bits = 0u;
-        const float xi = cx[i], yi = cy[i];
-        const int j0 = w * 32;
-        if (j0 + 31 > i) {
-#pragma unroll 8
-            for (int q = 0; q < 32; ++q) {
-                const int j = j0 + q;
-                if (j > i && j < n) {
-                    const float dx = xi - cx[j], dy = yi - cy[j];
-                    if (dx * dx + dy * dy <= thresh) bits |= 1u << q;
-                }
-            }
-        }
-        mask[e] = bits;
-    }
-    __syncthreads();
-    // (3) the walk, one wave
     if (wid != 0) return;
-    unsigned removed = 0u;                   // lane l: candidates 32 l .. 32 l + 31 suppressed so far
+    // (2) the walk
+    constexpr int R = kNmsMaskK / 64;
+    float xj[R], yj[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int j = lane + 64 * t;
+        xj[t] = j < n ? cx[j] : 0.f;
+        yj[t] = j < n ? cy[j] : 0.f;
+    }
+    int rem = 0;                             // bit t: candidate lane + 64 t is suppressed
     int kept = 0;
     for (int i = 0; i < n; ++i) {            // wave-uniform
-        const unsigned word = (unsigned)__shfl((int)removed, i >> 5, 64);
-        if ((word >> (i & 31)) & 1u) continue;
+        const int r = __builtin_amdgcn_readlane(rem, i & 63);
+        if ((r >> (i >> 6)) & 1) continue;
         if (kept >= post_max_size) break;    // keep[:post_max_size]
-        if (lane == 0) keep[(long long)b * K + cid[i]] = 1;
+        if (lane == 0) keep[row0 + cid[i]] = 1;
         ++kept;
-        if (lane < words) removed |= mask[i * words + lane];
+        const float xi = cx[i], yi = cy[i];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const int j = lane + 64 * t;
+            const float dx = xi - xj[t], dy = yi - yj[t];
+            if (j > i && j < n && dx * dx + dy * dy <= thresh) rem |= 1 << t;
+        }
     }
 }
 
@@ -419,6 +447,74 @@ extern "C" size_t sgv3d_centerpoint_decode_workspace_bytes(int batch, int num_cl
     return (sizeof(float) + sizeof(int)) * (size_t)batch * num_class * max_num + 256;
 }
 
+extern "C" size_t sgv3d_centerpoint_decode_tasks_workspace_bytes(int batch, int num_tasks, int max_class, int max_num) {
+    if (batch <= 0 || num_tasks <= 0 || max_class <= 0 || max_num <= 0) return 0;
+    return (sizeof(float) + sizeof(int)) * (size_t)num_tasks * batch * max_class * max_num + 256;
+}
+
+extern "C" int sgv3d_centerpoint_decode_tasks(int batch, int num_tasks, const int32_t *classes_per_task, int h, int w, int max_num,
+                                              const void *const *heatmap, const void *const *reg, const void *const *height,
+                                              const void *const *dim, const void *const *rot, const void *const *vel,
+                                              long long batch_stride, float out_size_factor, float voxel_x, float voxel_y,
+                                              float pc_x, float pc_y, float score_threshold, const float *post_center_range,
+                                              int norm_bbox, const float *nms_thresh, int post_max_size, void *workspace,
+                                              size_t workspace_bytes, float *boxes, float *scores, int32_t *labels,
+                                              unsigned char *valid, unsigned char *keep, void *stream) {
+    SGV3D_REQUIRE(batch > 0 && num_tasks > 0 && num_tasks <= kMaxTasks && h > 0 && w > 0 && max_num > 0,
+                  "centerpoint_decode: non-positive size (or more than %d tasks)", kMaxTasks);
+    SGV3D_REQUIRE(classes_per_task && heatmap && reg && height && dim && rot && nms_thresh && boxes && scores && labels && valid &&
+                  keep && workspace, "centerpoint_decode: null pointer");
+    DecodeTasks ts;
+    int max_cat = 0;
+    for (int t = 0; t < kMaxTasks; ++t) {
+        const bool on = t < num_tasks;
+        ts.heat[t] = on ? static_cast<const float *>(heatmap[t]) : nullptr;
+        ts.reg[t] = on ? static_cast<const float *>(reg[t]) : nullptr;
+        ts.hei[t] = on ? static_cast<const float *>(height[t]) : nullptr;
+        ts.dim[t] = on ? static_cast<const float *>(dim[t]) : nullptr;
+        ts.rot[t] = on ? static_cast<const float *>(rot[t]) : nullptr;
+        ts.vel[t] = (on && vel) ? static_cast<const float *>(vel[t]) : nullptr;
+        ts.cat[t] = on ? classes_per_task[t] : 0;
+        ts.nms[t] = on ? nms_thresh[t] : 0.f;
+        if (on) {
+            SGV3D_REQUIRE(ts.heat[t] && ts.reg[t] && ts.hei[t] && ts.dim[t] && ts.rot[t] && ts.cat[t] > 0,
+                          "centerpoint_decode: task %d has a null map or no class", t);
+            max_cat = ts.cat[t] > max_cat ? ts.cat[t] : max_cat;
+        }
+    }
+    const int Kp = pow2_ge(max_num), Kp2 = pow2_ge(max_cat * max_num);
+    SGV3D_REQUIRE(Kp <= kMaxK && Kp2 <= 8192, "centerpoint_decode: max_num=%d x %d classes exceeds the LDS sort buffers", max_num, max_cat);
+    SGV3D_REQUIRE((long long)h * w >= max_num, "centerpoint_decode: max_num exceeds H*W");
+    const size_t need = sgv3d_centerpoint_decode_tasks_workspace_bytes(batch, num_tasks, max_cat, max_num);
+    if (workspace_bytes < need) return fail(SGV3D_ENOSPACE, "centerpoint_decode: workspace has %zu bytes, needs %zu", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    float *cls_score = static_cast<float *>(workspace);
+    int *cls_ind = reinterpret_cast<int *>(cls_score + (size_t)num_tasks * batch * max_cat * max_num);
+    const long long hw = (long long)h * w;
+    const dim3 tgrid(batch * max_cat, num_tasks);
+    if (hw <= (long long)kKeyCache * kTk)
+        hipLaunchKernelGGL(topk_per_class_kernel<true>, tgrid, dim3(kTk), 0, st, batch, max_cat, hw, max_num, Kp, ts, batch_stride,
+                           cls_score, cls_ind);
+    else
+        hipLaunchKernelGGL(topk_per_class_kernel<false>, tgrid, dim3(kTk), 0, st, batch, max_cat, hw, max_num, Kp, ts, batch_stride,
+                           cls_score, cls_ind);
+    DecodeCfg cfg;
+    cfg.out_size_factor = out_size_factor; cfg.vx = voxel_x; cfg.vy = voxel_y; cfg.pcx = pc_x; cfg.pcy = pc_y;
+    cfg.score_thr = score_threshold; cfg.norm_bbox = norm_bbox; cfg.has_vel = vel != nullptr;
+    cfg.has_range = post_center_range != nullptr;
+    for (int i = 0; i < 6; ++i) cfg.range[i] = post_center_range ? post_center_range[i] : 0.f;
+    hipLaunchKernelGGL(merge_decode_kernel, dim3(batch, num_tasks), dim3(kTk), (sizeof(float) + sizeof(int)) * (size_t)Kp2, st, batch,
+                       max_cat, h, w, max_num, Kp2, cls_score, cls_ind, ts, batch_stride, cfg, boxes, scores, labels, valid);
+    if (max_num <= kNmsMaskK) {
+        hipLaunchKernelGGL(circle_nms_kernel, dim3(batch, num_tasks), dim3(512), 0, st, max_num, boxes, valid, ts, post_max_size, keep);
+    } else {
+        const size_t nms_lds = (size_t)max_num * (2 * sizeof(float) + sizeof(int) + 1) + 16;
+        hipLaunchKernelGGL(circle_nms_serial_kernel, dim3(batch, num_tasks), dim3(512), nms_lds, st, max_num, boxes, valid, ts,
+                           post_max_size, keep);
+    }
+    return check_launch("centerpoint_decode");
+}
+
 extern "C" int sgv3d_centerpoint_decode(int batch, int num_class, int h, int w, int max_num, const float *heatmap,
                                         const float *reg, const float *height, const float *dim, const float *rot,
                                         const float *vel, long long batch_stride, float out_size_factor,
@@ -427,38 +523,11 @@ extern "C" int sgv3d_centerpoint_decode(int batch, int num_class, int h, int w, 
                                         int post_max_size, void *workspace, size_t workspace_bytes, float *boxes,
                                         float *scores, int32_t *labels, unsigned char *valid, unsigned char *keep,
                                         void *stream) {
-    SGV3D_REQUIRE(batch > 0 && num_class > 0 && h > 0 && w > 0 && max_num > 0, "centerpoint_decode: non-positive size");
-    SGV3D_REQUIRE(heatmap && reg && height && dim && rot && boxes && scores && labels && valid && keep && workspace,
-                  "centerpoint_decode: null pointer");
-    const int Kp = pow2_ge(max_num), Kp2 = pow2_ge(num_class * max_num);
-    SGV3D_REQUIRE(Kp <= kMaxK && Kp2 <= 8192, "centerpoint_decode: max_num=%d x %d classes exceeds the LDS sort buffers", max_num, num_class);
-    SGV3D_REQUIRE((long long)h * w >= max_num, "centerpoint_decode: max_num exceeds H*W");
-    const size_t need = sgv3d_centerpoint_decode_workspace_bytes(batch, num_class, max_num);
-    if (workspace_bytes < need) return fail(SGV3D_ENOSPACE, "centerpoint_decode: workspace has %zu bytes, needs %zu", workspace_bytes, need);
-    hipStream_t st = as_stream(stream);
-    float *cls_score = static_cast<float *>(workspace);
-    int *cls_ind = reinterpret_cast<int *>(cls_score + (size_t)batch * num_class * max_num);
-    const long long hw = (long long)h * w;
-    if (hw <= (long long)kKeyCache * kTk)
-        hipLaunchKernelGGL(topk_per_class_kernel<true>, dim3(batch * num_class), dim3(kTk), 0, st, num_class, hw, max_num, Kp,
-                           heatmap, batch_stride, cls_score, cls_ind);
-    else
-        hipLaunchKernelGGL(topk_per_class_kernel<false>, dim3(batch * num_class), dim3(kTk), 0, st, num_class, hw, max_num, Kp,
-                           heatmap, batch_stride, cls_score, cls_ind);
-    DecodeCfg cfg;
-    cfg.out_size_factor = out_size_factor; cfg.vx = voxel_x; cfg.vy = voxel_y; cfg.pcx = pc_x; cfg.pcy = pc_y;
-    cfg.score_thr = score_threshold; cfg.norm_bbox = norm_bbox; cfg.has_vel = vel != nullptr;
-    cfg.has_range = post_center_range != nullptr;
-    for (int i = 0; i < 6; ++i) cfg.range[i] = post_center_range ? post_center_range[i] : 0.f;
-    hipLaunchKernelGGL(merge_decode_kernel, dim3(batch), dim3(kTk), (sizeof(float) + sizeof(int)) * (size_t)Kp2, st, num_class,
-                       h, w, max_num, Kp2, cls_score, cls_ind, reg, height, dim, rot, vel, batch_stride, cfg, boxes, scores,
-                       labels, valid);
-    if (max_num <= kNmsMaskK) {
-        hipLaunchKernelGGL(circle_nms_kernel, dim3(batch), dim3(512), 0, st, max_num, boxes, valid, nms_thresh, post_max_size, keep);
-    } else {
-        const size_t nms_lds = (size_t)max_num * (2 * sizeof(float) + sizeof(int) + 1) + 16;
-        hipLaunchKernelGGL(circle_nms_serial_kernel, dim3(batch), dim3(512), nms_lds, st, max_num, boxes, valid, nms_thresh,
-                           post_max_size, keep);
-    }
-    return check_launch("centerpoint_decode");
+    // one task = the batched entry with a task list of one
+    const int32_t cat[1] = {num_class};
+    const void *hm[1] = {heatmap}, *rg[1] = {reg}, *he[1] = {height}, *dm[1] = {dim}, *ro[1] = {rot}, *ve[1] = {vel};
+    const float nt[1] = {nms_thresh};
+    return sgv3d_centerpoint_decode_tasks(batch, 1, cat, h, w, max_num, hm, rg, he, dm, ro, vel ? ve : nullptr, batch_stride,
+                                          out_size_factor, voxel_x, voxel_y, pc_x, pc_y, score_threshold, post_center_range, norm_bbox,
+                                          nt, post_max_size, workspace, workspace_bytes, boxes, scores, labels, valid, keep, stream);
 }

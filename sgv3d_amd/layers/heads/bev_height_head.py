@@ -336,30 +336,33 @@ class BEVHeightHead(HipModule):
         labels = torch.empty(T, B, K, dtype=torch.int32, device=dev)
         valid = torch.empty(T, B, K, dtype=torch.uint8, device=dev)
         keep = torch.empty(T, B, K, dtype=torch.uint8, device=dev)
-        ws = None
+        H, W, bs = int(heat0.shape[2]), int(heat0.shape[3]), int(heat0.stride(0))
+        ptrs = {k: (ctypes.c_void_p * T)() for k in ('heatmap', 'reg', 'height', 'dim', 'rot', 'vel')}
+        cats = (ctypes.c_int32 * T)()
+        has_vel = all(p[0].get('vel') is not None for p in preds_dicts)
         for task_id, preds in enumerate(preds_dicts):
             p = preds[0]
             heat = p['heatmap']
-            Bt, cat, H, W = (int(v) for v in heat.shape)
-            assert Bt == B and heat.device == dev
-            bs = int(heat.stride(0))
-            for k in ('reg', 'height', 'dim', 'rot'):
-                assert p[k].stride(0) == bs and p[k].stride(1) == H * W and p[k].stride(3) == 1
-            assert heat.stride(1) == H * W and heat.dtype == torch.float32
-            vel = p.get('vel')
-            nws = lib.sgv3d_centerpoint_decode_workspace_bytes(B, cat, K)
-            if ws is None or ws.numel() < nws:
-                ws = torch.empty(nws, dtype=torch.uint8, device=dev)      # (tasks run back to back on one stream: shared)
-            with torch.cuda.device(dev), hip_ops.prof("centerpoint_decode"):
-                rc = lib.sgv3d_centerpoint_decode(
-                    B, cat, H, W, K, heat.data_ptr(), p['reg'].data_ptr(), p['height'].data_ptr(), p['dim'].data_ptr(),
-                    p['rot'].data_ptr(), _lib.ptr(vel), bs, float(coder['out_size_factor']),
-                    float(coder['voxel_size'][0]), float(coder['voxel_size'][1]), float(coder['pc_range'][0]),
-                    float(coder['pc_range'][1]), float(thr) if thr is not None else float('-inf'), rng_c,
-                    1 if self.norm_bbox else 0, float(tcfg['min_radius'][task_id]), int(tcfg['post_max_size']),
-                    ws.data_ptr(), ws.numel(), boxes[task_id].data_ptr(), scores[task_id].data_ptr(), labels[task_id].data_ptr(),
-                    valid[task_id].data_ptr(), keep[task_id].data_ptr(), _lib.stream_handle(dev))
-            _lib.check(rc, "sgv3d_centerpoint_decode")
+            Bt, cat, Ht, Wt = (int(v) for v in heat.shape)
+            assert (Bt, Ht, Wt) == (B, H, W) and heat.device == dev and heat.dtype == torch.float32
+            for k in ('heatmap', 'reg', 'height', 'dim', 'rot') + (('vel',) if has_vel else ()):
+                assert p[k].stride(0) == bs and p[k].stride(1) == H * W and p[k].stride(3) == 1 and p[k].stride(2) == W
+                ptrs[k][task_id] = p[k].data_ptr()
+            cats[task_id] = cat
+        max_cat = max(int(c) for c in cats)
+        nws = lib.sgv3d_centerpoint_decode_tasks_workspace_bytes(B, T, max_cat, K)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        nms = (ctypes.c_float * T)(*[float(tcfg['min_radius'][t]) for t in range(T)])
+        # every task's top-k / box assembly / circle NMS in three launches (grid.y = task)
+        with torch.cuda.device(dev), hip_ops.prof("centerpoint_decode"):
+            rc = lib.sgv3d_centerpoint_decode_tasks(
+                B, T, cats, H, W, K, ptrs['heatmap'], ptrs['reg'], ptrs['height'], ptrs['dim'], ptrs['rot'],
+                ptrs['vel'] if has_vel else None, bs, float(coder['out_size_factor']), float(coder['voxel_size'][0]),
+                float(coder['voxel_size'][1]), float(coder['pc_range'][0]), float(coder['pc_range'][1]),
+                float(thr) if thr is not None else float('-inf'), rng_c, 1 if self.norm_bbox else 0, nms,
+                int(tcfg['post_max_size']), ws.data_ptr(), nws, boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(),
+                valid.data_ptr(), keep.data_ptr(), _lib.stream_handle(dev))
+        _lib.check(rc, "sgv3d_centerpoint_decode_tasks")
         # merge tasks (CenterHead.get_bboxes tail): per sample the kept boxes task after task, label offsets, z -= h/2 -- one
         # launch; the per-sample counts are the single device->host read of the whole call
         out_boxes = torch.empty(B, T * K, 9, dtype=torch.float32, device=dev)

@@ -36,10 +36,12 @@ def _fake_preds(B, H, W, seed, n_obj=40):
     return buf, preds
 
 
-@pytest.mark.parametrize("H,W,B", [(256, 256, 2), (64, 96, 1)])
-def test_get_bboxes_matches_oracle(H, W, B):
+@pytest.mark.parametrize("H,W,B,max_num", [(256, 256, 2, 500), (64, 96, 1, 500), (128, 128, 2, 600), (512, 512, 1, 500)])
+def test_get_bboxes_matches_oracle(H, W, B, max_num):
+    """(max_num 600: the plain circle-NMS kernel, K > 512; 512 x 512: the top-k form without the cached keys)"""
     from sgv3d_amd.layers.heads.bev_height_head import BEVHeightHead
     _, hc = S.r50_256_conf()
+    hc['bbox_coder'] = dict(hc['bbox_coder'], max_num=max_num)
     head = BEVHeightHead(**hc)
     buf, layout = _fake_preds(B, H, W, seed=H)
     dbuf = torch.from_numpy(buf).to(DEV)
@@ -91,3 +93,51 @@ def test_full_model_decode_runs():
         assert res[i][0].tensor.shape == ref[i][0].shape
         np.testing.assert_allclose(res[i][0].tensor.cpu().numpy(), ref[i][0], rtol=1e-3, atol=1e-3)
         assert np.array_equal(res[i][2].cpu().numpy(), ref[i][2])
+
+
+def test_single_task_entry_is_the_batched_one():
+    """sgv3d_centerpoint_decode (one task per call, the round-1 ABI) and sgv3d_centerpoint_decode_tasks (all tasks in three
+    launches, what get_bboxes calls) give the same bytes."""
+    import ctypes
+    from sgv3d_amd import _lib
+    from sgv3d_amd.layers.heads.bev_height_head import BEVHeightHead
+    _, hc = S.r50_256_conf()
+    head = BEVHeightHead(**hc)
+    B, H, W, K = 2, 128, 128, 500
+    buf, layout = _fake_preds(B, H, W, seed=77)
+    dbuf = torch.from_numpy(buf).to(DEV)
+    lib = _lib.load()
+    T = len(layout)
+    coder, tcfg = hc['bbox_coder'], hc['test_cfg']
+    rng_c = (ctypes.c_float * 6)(*[float(v) for v in coder['post_center_range']])
+    outs = []
+    for t, d in enumerate(layout):
+        p = {k: dbuf[:, o:o + c] for k, (o, c) in d.items()}
+        cat = p['heatmap'].shape[1]
+        nws = lib.sgv3d_centerpoint_decode_workspace_bytes(B, cat, K)
+        ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+        o = dict(boxes=torch.empty(B, K, 9, device=DEV), scores=torch.empty(B, K, device=DEV),
+                 labels=torch.empty(B, K, dtype=torch.int32, device=DEV), valid=torch.empty(B, K, dtype=torch.uint8, device=DEV),
+                 keep=torch.empty(B, K, dtype=torch.uint8, device=DEV))
+        rc = lib.sgv3d_centerpoint_decode(B, cat, H, W, K, p['heatmap'].data_ptr(), p['reg'].data_ptr(), p['height'].data_ptr(),
+                                          p['dim'].data_ptr(), p['rot'].data_ptr(), p['vel'].data_ptr(), int(dbuf.stride(0)),
+                                          float(coder['out_size_factor']), float(coder['voxel_size'][0]), float(coder['voxel_size'][1]),
+                                          float(coder['pc_range'][0]), float(coder['pc_range'][1]), float(coder['score_threshold']),
+                                          rng_c, 1, float(tcfg['min_radius'][t]), int(tcfg['post_max_size']), ws.data_ptr(), nws,
+                                          o['boxes'].data_ptr(), o['scores'].data_ptr(), o['labels'].data_ptr(), o['valid'].data_ptr(),
+                                          o['keep'].data_ptr(), _lib.stream_handle(torch.device(DEV)))
+        _lib.check(rc, "sgv3d_centerpoint_decode")
+        outs.append(o)
+    preds = tuple([{k: dbuf[:, o:o + c] for k, (o, c) in d.items()}] for d in layout)
+    res = head.get_bboxes(preds, img_metas=[dict() for _ in range(B)])
+    torch.cuda.synchronize()
+    for i in range(B):
+        want_b, want_s, want_l, off = [], [], [], 0
+        for t, o in enumerate(outs):
+            k = o['keep'][i].bool()
+            bb = o['boxes'][i][k].clone()
+            bb[:, 2] = bb[:, 2] - bb[:, 5] * 0.5
+            want_b.append(bb); want_s.append(o['scores'][i][k]); want_l.append(o['labels'][i][k] + off)
+            off += head.num_classes[t]
+        assert torch.equal(res[i][0].tensor, torch.cat(want_b)) and torch.equal(res[i][1], torch.cat(want_s))
+        assert torch.equal(res[i][2], torch.cat(want_l).int())
