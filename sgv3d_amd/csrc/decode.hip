@@ -93,8 +93,25 @@ __global__ __launch_bounds__(kTk) void topk_per_class_kernel(int batch, int max_
     const int base32 = (int)i0;
     const float *src32 = src + i0;
     if constexpr (CACHE) {
+        // a thread's slice is contiguous (the compaction below keeps index order): 16-byte loads where the slice allows them --
+        // a scalar load of a wave touches 64 cache lines for 256 useful bytes, and there would be 64 of them per thread
+        const bool vec = (per & 3) == 0 && (hw & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;     // block-uniform
+        if (vec) {
+            const float4 *s4 = reinterpret_cast<const float4 *>(src32);
 #pragma unroll
-        for (int q = 0; q < kKeyCache; ++q) keys[q] = (q < cnt) ? fkey(1.f / (1.f + expf(-src32[q]))) : 0u;     // (0 < every sigmoid key)
+            for (int q4 = 0; q4 < kKeyCache / 4; ++q4) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool in = 4 * q4 < cnt;
+                if (in) v = s4[q4];
+                keys[4 * q4 + 0] = in ? fkey(1.f / (1.f + expf(-v.x))) : 0u;          // (0 < every sigmoid key)
+                keys[4 * q4 + 1] = in ? fkey(1.f / (1.f + expf(-v.y))) : 0u;
+                keys[4 * q4 + 2] = in ? fkey(1.f / (1.f + expf(-v.z))) : 0u;
+                keys[4 * q4 + 3] = in ? fkey(1.f / (1.f + expf(-v.w))) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kKeyCache; ++q) keys[q] = (q < cnt) ? fkey(1.f / (1.f + expf(-src32[q]))) : 0u;
+        }
     }
     // ---- radix select of the K-th largest key ------------------------------------------------
     if (tid == 0) { s_prefix = 0; s_krem = (unsigned)K; }

@@ -45,6 +45,7 @@ class BEVHeight(nn.Module):
         self.graph_cache_size = 2
         self._graphs = {}               # signature -> [calls seen, GraphedForward | None | False (capture failed)]
         self._graph_suspended = 0
+        self._flat, self._flat_age, self._flat_gen = None, 0, 0      # cached walk over parameters + buffers (_stamp)
         if checkpoint is not None:
             with open(checkpoint, "rb") as f:
                 state_dict = torch.load(f, map_location='cpu')
@@ -60,7 +61,39 @@ class BEVHeight(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _stamp(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        """Identity of the weights the packed HIP tensors (and captured graphs) were made from.
+
+        The exact form -- (address, version) of every parameter and buffer from a walk over the module tree -- costs 1-3 ms of
+        pure host time for the ~860 tensors of the cfg-2 model: with one frame in flight (the reference harness's eval_step
+        waits for every frame's boxes) the GPU idles through it.  So the walk is done once and then every
+        ``_RESTAMP_EVERY`` forwards; in between the stamp is the sum of the version counters and of the addresses of the
+        tensors of that walk (~0.25 ms): any in-place write (optimiser step, ``load_state_dict``, ``copy_``) moves the first,
+        a ``p.data = ...`` swap the second.  What the short form cannot see is a parameter or buffer OBJECT replaced behind the
+        model's back; the entry points that do that (``_apply`` = ``.to() / .cuda() / .half()`` from here or any parent
+        module, ``load_state_dict``, ``train()``) drop the cached walk themselves."""
+        flat = self._flat
+        if flat is None or self._flat_age >= self._RESTAMP_EVERY:
+            fresh = list(self.parameters()) + list(self.buffers())
+            if flat is None or len(fresh) != len(flat) or any(a is not b for a, b in zip(fresh, flat)):
+                self._flat_gen += 1                 # another set of tensor objects: never equal to an earlier stamp
+            self._flat = flat = fresh
+            self._flat_age = 0
+        self._flat_age += 1
+        ver = ptr = 0
+        for t in flat:
+            ver += t._version
+            ptr += t.data_ptr()
+        return (self._flat_gen, len(flat), ver, ptr)
+
+    _RESTAMP_EVERY = 256
+
+    def _apply(self, fn, *args, **kwargs):
+        self._flat = None                           # buffers (and, with some flags, parameters) become new objects
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._flat = None                           # (assign=True replaces the Parameter objects)
+        return super().load_state_dict(*args, **kwargs)
 
     def refresh(self):
         """Drop the packed HIP weights (they are rebuilt on the next forward).  Called automatically
@@ -69,6 +102,7 @@ class BEVHeight(nn.Module):
             if isinstance(m, HipModule):
                 m._hip = None
         self._param_stamp = None
+        self._flat = None
         self._graphs = {}               # captured graphs read the packed weights that were just dropped
 
     def train(self, mode=True):
