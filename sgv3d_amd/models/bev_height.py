@@ -102,7 +102,6 @@ class BEVHeight(nn.Module):
             if isinstance(m, HipModule):
                 m._hip = None
         self._param_stamp = None
-        self._flat = None
         self._graphs = {}               # captured graphs read the packed weights that were just dropped
 
     def train(self, mode=True):
