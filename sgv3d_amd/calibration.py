@@ -31,7 +31,7 @@ class CalibrationCache:
     that rewrite the calibration tensors out of band (raw pointers, ``.data``): tensor versions do not see such writes."""
 
     class Entry:
-        __slots__ = ("_src", "_tag", "geom", "plan", "event", "stream")
+        __slots__ = ("_src", "_tag", "geom", "plan", "event", "stream", "join_stream")
 
         def __init__(self):
             self._src = None          # [(tensor, version)] the cached geometry was computed from
@@ -40,6 +40,7 @@ class CalibrationCache:
             self.plan = None          # VoxelPlan(cached=True) for geom
             self.event = None         # recorded behind the last (re)build
             self.stream = None        # cuda_stream handle of that build
+            self.join_stream = None   # stream capture only: the side stream the refresh was recorded on (see join_capture)
 
         def matches(self, tensors, tag):
             if self._src is None or self._tag != tag or len(tensors) != len(self._src):
@@ -63,6 +64,16 @@ class CalibrationCache:
                 self.event = torch.cuda.Event()
             self.event.record(cur)
             self.stream = cur.cuda_stream
+
+        def join_capture(self, device):
+            """Inside a stream capture that recorded this entry's refresh on a forked side stream
+            (``pipeline.GraphedForward``: geometry + plan check run as a parallel branch of the graph, under the image
+            backbone): the first reader of ``geom`` / ``plan`` makes the capturing stream wait for that branch -- the edge
+            that orders the gather behind the plan."""
+            if self.join_stream is not None:
+                import torch
+                torch.cuda.current_stream(device).wait_stream(self.join_stream)
+                self.join_stream = None
 
         def order_after_build(self, device):
             """Host-path hit: make the current stream wait for the build if it ran on another stream."""

@@ -372,6 +372,7 @@ class LSSFPN(HipModule):
                self._voxel_num_host)
         if cc.geom is not None and cc.matches(srcs, tag):
             cache.hits += 1
+            cc.join_capture(s2e.device)            # (graph capture with the refresh on a forked branch)
             cc.order_after_build(s2e.device)       # a hit on another stream than the build's waits for the build
             return cc.geom, cc.plan
         B, num_cams = int(s2e.shape[0]), int(s2e.shape[2])

@@ -310,14 +310,14 @@ class BEVHeightHead(HipModule):
         ``preds_dict[0]['heatmap']`` with its sigmoid nor add an ``'anno_box'`` entry."""
         return _CenterHeadLoss.run(self, targets, preds_dicts)
 
-    def get_bboxes(self, preds_dicts, img_metas=None, img=None, rescale=False):
-        """mmdet3d ``CenterHead.get_bboxes`` (reached via models/bev_height.py:116-126) on the device:
-        sigmoid + top-K + box assembly + circle NMS per task run as HIP kernels (the reference does the
-        NMS on the CPU through numba); only the final variable-length gather uses torch indexing.
+    def decode_device(self, preds_dicts):
+        """Device half of ``get_bboxes``: top-K / box assembly / circle NMS of every task (three launches) and the merge of
+        the tasks (one launch).  Only enqueues kernels on the current stream -- graph-capturable; ``BEVHeight``'s
+        per-signature hipGraph runs it right behind the head, so that a harness calling ``get_bboxes`` on the forward's own
+        output finds the boxes already decoded (``models/bev_height.py``).
 
-        Returns ``[[bboxes, scores, labels], ...]`` per sample; ``bboxes`` is
-        ``img_metas[i]['box_type_3d'](tensor, code_size)`` when the harness passes mmdet3d's box class,
-        else a ``Boxes3D`` stand-in with the same ``.tensor`` attribute (exps/...:254)."""
+        Returns one packed buffer ``[boxes f32 [B, T*K, 9] | scores f32 [B, T*K] | labels i32 [B, T*K] | counts i32 [B]]`` as a
+        uint8 tensor; ``decode_views`` carves it.  Rows ``[:counts[b]]`` of sample ``b`` are its detections."""
         import ctypes
         from ... import _lib
         coder, tcfg = self.bbox_coder_cfg, self.test_cfg
@@ -330,12 +330,6 @@ class BEVHeightHead(HipModule):
         T = len(preds_dicts)
         heat0 = preds_dicts[0][0]['heatmap']
         B, dev = int(heat0.shape[0]), heat0.device
-        # the outputs of all tasks stacked, so that the merge below is one launch: [T, B, K, ...]
-        boxes = torch.empty(T, B, K, 9, dtype=torch.float32, device=dev)
-        scores = torch.empty(T, B, K, dtype=torch.float32, device=dev)
-        labels = torch.empty(T, B, K, dtype=torch.int32, device=dev)
-        valid = torch.empty(T, B, K, dtype=torch.uint8, device=dev)
-        keep = torch.empty(T, B, K, dtype=torch.uint8, device=dev)
         H, W, bs = int(heat0.shape[2]), int(heat0.shape[3]), int(heat0.stride(0))
         ptrs = {k: (ctypes.c_void_p * T)() for k in ('heatmap', 'reg', 'height', 'dim', 'rot', 'vel')}
         cats = (ctypes.c_int32 * T)()
@@ -350,34 +344,56 @@ class BEVHeightHead(HipModule):
                 ptrs[k][task_id] = p[k].data_ptr()
             cats[task_id] = cat
         max_cat = max(int(c) for c in cats)
+        # one scratch allocation: [T,B,K] candidates of every task (boxes | scores | labels | valid | keep) + the kernels' workspace
         nws = lib.sgv3d_centerpoint_decode_tasks_workspace_bytes(B, T, max_cat, K)
-        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        n = T * B * K
+        scratch = torch.empty(n * (36 + 4 + 4 + 1 + 1) + 64 + nws, dtype=torch.uint8, device=dev)
+        base = scratch.data_ptr()
+        boxes, scores, labels, valid = base, base + n * 36, base + n * 40, base + n * 44
+        keep = valid + n
+        ws = (keep + n + 63) // 64 * 64
         nms = (ctypes.c_float * T)(*[float(tcfg['min_radius'][t]) for t in range(T)])
-        # every task's top-k / box assembly / circle NMS in three launches (grid.y = task)
         with torch.cuda.device(dev), hip_ops.prof("centerpoint_decode"):
             rc = lib.sgv3d_centerpoint_decode_tasks(
                 B, T, cats, H, W, K, ptrs['heatmap'], ptrs['reg'], ptrs['height'], ptrs['dim'], ptrs['rot'],
                 ptrs['vel'] if has_vel else None, bs, float(coder['out_size_factor']), float(coder['voxel_size'][0]),
                 float(coder['voxel_size'][1]), float(coder['pc_range'][0]), float(coder['pc_range'][1]),
                 float(thr) if thr is not None else float('-inf'), rng_c, 1 if self.norm_bbox else 0, nms,
-                int(tcfg['post_max_size']), ws.data_ptr(), nws, boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(),
-                valid.data_ptr(), keep.data_ptr(), _lib.stream_handle(dev))
+                int(tcfg['post_max_size']), ws, nws, boxes, scores, labels, valid, keep, _lib.stream_handle(dev))
         _lib.check(rc, "sgv3d_centerpoint_decode_tasks")
-        # merge tasks (CenterHead.get_bboxes tail): per sample the kept boxes task after task, label offsets, z -= h/2 -- one
-        # launch; the per-sample counts are the single device->host read of the whole call
-        out_boxes = torch.empty(B, T * K, 9, dtype=torch.float32, device=dev)
-        out_scores = torch.empty(B, T * K, dtype=torch.float32, device=dev)
-        out_labels = torch.empty(B, T * K, dtype=torch.int32, device=dev)
-        counts = torch.empty(B, dtype=torch.int32, device=dev)
-        ncls = (ctypes.c_int32 * T)(*[int(n) for n in self.num_classes])
+        # merge tasks (CenterHead.get_bboxes tail): per sample the kept boxes task after task, label offsets, z -= h/2
+        TK = T * K
+        packed = torch.empty(B * TK * 44 + B * 4, dtype=torch.uint8, device=dev)
+        pb = packed.data_ptr()
+        ncls = (ctypes.c_int32 * T)(*[int(v) for v in self.num_classes])
         with torch.cuda.device(dev), hip_ops.prof("centerpoint_merge_tasks"):
-            rc = lib.sgv3d_centerpoint_merge_tasks(B, T, K, boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(), keep.data_ptr(),
-                                                   ncls, out_boxes.data_ptr(), out_scores.data_ptr(), out_labels.data_ptr(),
-                                                   counts.data_ptr(), _lib.stream_handle(dev))
+            rc = lib.sgv3d_centerpoint_merge_tasks(B, T, K, boxes, scores, labels, keep, ncls, pb, pb + B * TK * 36, pb + B * TK * 40,
+                                                   pb + B * TK * 44, _lib.stream_handle(dev))
         _lib.check(rc, "sgv3d_centerpoint_merge_tasks")
+        return packed
+
+    def decode_views(self, packed, B):
+        """(boxes [B, T*K, 9] f32, scores [B, T*K] f32, labels [B, T*K] i32, counts [B] i32) views of ``decode_device``'s buffer."""
+        TK = (packed.numel() - 4 * B) // (44 * B)
+        f = packed[:B * TK * 40].view(torch.float32)
+        i = packed[B * TK * 40:].view(torch.int32)
+        return f[:B * TK * 9].view(B, TK, 9), f[B * TK * 9:].view(B, TK), i[:B * TK].view(B, TK), i[B * TK:]
+
+    def get_bboxes(self, preds_dicts, img_metas=None, img=None, rescale=False, decoded=None):
+        """mmdet3d ``CenterHead.get_bboxes`` (reached via models/bev_height.py:116-126) on the device:
+        sigmoid + top-K + box assembly + circle NMS of all tasks and their merge run as HIP kernels (the reference does the
+        NMS on the CPU through numba, with a device->host copy per task); the per-sample detection counts are the single
+        device->host read of the call.  ``decoded``: a ``decode_device`` buffer computed earlier for these very maps.
+
+        Returns ``[[bboxes, scores, labels], ...]`` per sample; ``bboxes`` is
+        ``img_metas[i]['box_type_3d'](tensor, code_size)`` when the harness passes mmdet3d's box class,
+        else a ``Boxes3D`` stand-in with the same ``.tensor`` attribute (exps/...:254)."""
+        B = int(preds_dicts[0][0]['heatmap'].shape[0])
+        packed = decoded if decoded is not None else self.decode_device(preds_dicts)
+        out_boxes, out_scores, out_labels, counts = self.decode_views(packed, B)
         n_kept = counts.tolist()
         ret_list = []
-        code_size = int(coder.get('code_size', 9))
+        code_size = int(self.bbox_coder_cfg.get('code_size', 9))
         for i in range(B):
             bboxes = out_boxes[i, :n_kept[i]]
             box_type = img_metas[i].get('box_type_3d') if img_metas is not None and i < len(img_metas) else None

@@ -11,6 +11,7 @@ stays in the NHWC buffer voxel pooling produced (the reference permutes it to NC
 contiguous, layers/backbones/lss_fpn.py:495, only for cuDNN's benefit).
 """
 import os
+import weakref
 
 import torch
 from torch import nn
@@ -46,6 +47,7 @@ class BEVHeight(nn.Module):
         self._graphs = {}               # signature -> [calls seen, GraphedForward | None | False (capture failed)]
         self._graph_suspended = 0
         self._flat, self._flat_age, self._flat_gen = None, 0, 0      # cached walk over parameters + buffers (_stamp)
+        self._decoded = None            # (decode buffer, weak refs to the maps it was computed from, their version): see get_bboxes
         if checkpoint is not None:
             with open(checkpoint, "rb") as f:
                 state_dict = torch.load(f, map_location='cpu')
@@ -129,7 +131,11 @@ class BEVHeight(nn.Module):
             self._param_stamp = stamp
         graphed = self._graphed_forward(x, mats_dict)
         if graphed is not None:
-            return graphed(self, x, mats_dict)
+            preds, decoded = graphed(self, x, mats_dict)
+            # the graph decoded these maps already: remembered for a get_bboxes call on exactly these tensors, unmodified
+            self._decoded = (decoded, [weakref.ref(v) for task in preds for v in task[0].values()], preds[0][0]['heatmap']._version)
+            return preds
+        self._decoded = None
         bev = self.backbone(x, mats_dict, timestamps, nhwc_out=True)   # NHWC buffer [B, Y, X, C]
         return self.head(bev, nhwc=True)
 
@@ -180,4 +186,20 @@ class BEVHeight(nn.Module):
         return self.head.loss(targets, preds_dicts)
 
     def get_bboxes(self, preds_dicts, img_metas=None, img=None, rescale=False):
-        return self.head.get_bboxes(preds_dicts, img_metas, img, rescale)
+        return self.head.get_bboxes(preds_dicts, img_metas, img, rescale, decoded=self._decoded_for(preds_dicts))
+
+    def _decoded_for(self, preds_dicts):
+        """The decode the forward's hipGraph already ran, if ``preds_dicts`` is the very output of the last forward: the same
+        tensor objects in the same order, never written since (the 36 maps are views of one buffer and share its version
+        counter).  Anything else -- another structure, clones, edited maps, the eager path -- decodes now."""
+        spec, self._decoded = self._decoded, None
+        if spec is None:
+            return None
+        decoded, refs, version = spec
+        try:
+            tensors = [v for task in preds_dicts for v in task[0].values()]
+        except (TypeError, AttributeError, IndexError, KeyError):
+            return None
+        if len(tensors) != len(refs) or any(r() is not t for r, t in zip(refs, tensors)) or tensors[0]._version != version:
+            return None
+        return decoded
