@@ -1317,6 +1317,7 @@ struct VpVoxArgs {
     int P;
     unsigned magN, magP;    // exact division of a point id (< 2^31) by N / P: umulhi(id, mag) >> sh (vp_magic)
     int shN, shP;
+    int dbg;                // SGV3D_VP_DEBUG (tools/vp_probe3.py only; WRONG RESULTS): 1 no empty rows, 2 no row stores, 4 no row loads
 };
 
 // floor(n / d) for 0 <= n < 2^31, d >= 2, as umulhi(n, mag) >> sh (a round-up magic number of 32 bits is exact for 31-bit
@@ -1370,7 +1371,7 @@ __device__ __forceinline__ void vp_vox_piece(float4 &acc, int pb, int pe, int ma
         }
         float4 val[VB];
 #pragma unroll
-        for (int k = 0; k < VB; ++k) val[k] = vp_buf_load_row<FB>(f_rsrc, (unsigned)idx[k] * row_in + lane_in);
+        for (int k = 0; k < VB; ++k) val[k] = vp_buf_load_row<FB>(f_rsrc, (a.dbg & 4) ? ~0u - 64u : (unsigned)idx[k] * row_in + lane_in);
         float pr[VB];
         if constexpr (FUSED) {
             if (index_lane) prw[g * VB + cl] = my_pr;
@@ -1391,8 +1392,8 @@ __device__ __forceinline__ void vp_vox_piece(float4 &acc, int pb, int pe, int ma
 template <bool FB, bool OB, bool ACC, bool FUSED, int VB>
 __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a) {
     if (a.gate != nullptr && *reinterpret_cast<const volatile int *>(a.gate) != 0) return;
-    __shared__ __attribute__((aligned(16))) int idx_s[kBlock / 64][(kMaxGroups + 1) * VB];
-    __shared__ __attribute__((aligned(16))) float pr_s[kBlock / 64][FUSED ? (kMaxGroups + 1) * VB : 4];
+    __shared__ __attribute__((aligned(16))) int idx_s[kBlock / 64][kMaxGroups * VB];
+    __shared__ __attribute__((aligned(16))) float pr_s[kBlock / 64][FUSED ? kMaxGroups * VB : 4];
     __shared__ float4 red[kBlock / 64][64];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
@@ -1400,13 +1401,17 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
     const int g = lane / lpr;
     const int cl = lane - g * lpr;
     const bool ingroup = g < groups;
-    const int gs = ingroup ? g : groups;                         // LDS block of the lane: its row group, or the all-dead one
+    // LDS block of the lane: its row group's; the lanes outside the groups (64 - groups * lpr of them) read group 0's block --
+    // their rows are loaded and summed for nothing, never emitted
+    const int gs = ingroup ? g : 0;
     const int src_cl = ingroup ? cl : 0;
     int *idw = idx_s[wid];
     float *prw = pr_s[wid];
-    for (int i = lane; i < (groups + 1) * VB; i += 64) {         // every index block starts dead
-        idw[i] = -1;
-        if constexpr (FUSED) prw[i] = 0.f;
+    if (vb < VB) {                                               // (narrow rows only: entries k >= vb are never rewritten: dead)
+        for (int i = lane; i < groups * VB; i += 64) {
+            idw[i] = -1;
+            if constexpr (FUSED) prw[i] = 0.f;
+        }
     }
     const unsigned row_in = (unsigned)a.C * (FB ? 2u : 4u);
     const unsigned row_out = OB ? (unsigned)a.ldo * 2u : (unsigned)a.C * 4u;
@@ -1424,6 +1429,24 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
     const int n_mid_end = a.bin_start[kVoxShort];                // perm[0 .. n_mid_end): populations above kVoxShort
     const int n_long = a.bin_start[kVoxShort * groups];          // perm[0 .. n_long): above kVoxShort * groups (<= 320 < kLenBins)
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int kill = (a.dbg & 2) ? -1 : 0;                      // (probe: v | kill = -1 drops every row store)
+    const int n_small = (nonempty - n_mid_end + groups - 1) / groups;
+    // the wave's first small-population record is requested now and arrives under the zero rows below
+    int4 rec_s = make_int4(-1, 0, 0, 0);
+    {
+        const int vi = n_mid_end + gw * groups + g;
+        if (gw < n_small && ingroup && vi < nonempty) rec_s = a.perm[vi];
+    }
+    // ---------------------------------------------------------------- rows of empty voxels (not in ACC mode)
+    if (!ACC && !(a.dbg & 1)) {
+        const int n_rows = (a.V - nonempty + groups - 1) / groups;
+        for (int i = gw; i < n_rows; i += nwaves) {               // wave-uniform
+            const int vi = nonempty + i * groups + g;
+            int v = -1;
+            if (ingroup && vi < a.V) v = a.perm[vi].x;
+            vp_buf_emit<OB, false>(o_rsrc, v, row_out, lane_out, pad_off, zero4);
+        }
+    }
 
     // ---------------------------------------------------------------- the largest voxels: one workgroup each
     for (int i = (int)blockIdx.x; i < n_long; i += (int)gridDim.x) {      // block-uniform
@@ -1446,7 +1469,7 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
             float4 tot = red[0][src_cl];
 #pragma unroll
             for (int w = 1; w < kBlock / 64; ++w) vacc(tot, red[w][src_cl]);
-            vp_buf_emit<OB, ACC>(o_rsrc, g == 0 ? v : -1, row_out, lane_out, pad_off, tot);
+            vp_buf_emit<OB, ACC>(o_rsrc, (g == 0 ? v : -1) | kill, row_out, lane_out, pad_off, tot);
         }
         __syncthreads();
     }
@@ -1464,31 +1487,20 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
         vp_vox_piece<FB, FUSED, VB>(acc, pb, pe, psz, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
         float4 tot = zero4;
         for (int g2 = 0; g2 < groups; ++g2) vacc(tot, vp_from_lane(acc, g2 * lpr + src_cl));
-        vp_buf_emit<OB, ACC>(o_rsrc, g == 0 ? v : -1, row_out, lane_out, pad_off, tot);
+        vp_buf_emit<OB, ACC>(o_rsrc, (g == 0 ? v : -1) | kill, row_out, lane_out, pad_off, tot);
     }
     // ---------------------------------------------------------------- small populations: one row group each
-    const int n_small = (nonempty - n_mid_end + groups - 1) / groups;
     for (int i = gw; i < n_small; i += nwaves) {                  // wave-uniform
         const int vi = n_mid_end + i * groups + g;
         int v = -1, pb = 0, pe = 0;
         if (ingroup && vi < nonempty) {
-            const int4 rec = a.perm[vi];
+            const int4 rec = i == gw ? rec_s : a.perm[vi];
             v = rec.x; pb = rec.y; pe = rec.z;
         }
         const int maxlen = __shfl(pe - pb, 0, 64);               // group 0 holds the largest (perm: descending population)
         float4 acc = zero4;
         vp_vox_piece<FB, FUSED, VB>(acc, pb, pe, maxlen, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
-        vp_buf_emit<OB, ACC>(o_rsrc, v, row_out, lane_out, pad_off, acc);
-    }
-    // ---------------------------------------------------------------- rows of empty voxels (not in ACC mode)
-    if constexpr (!ACC) {
-        const int n_rows = (a.V - nonempty + groups - 1) / groups;
-        for (int i = gw; i < n_rows; i += nwaves) {               // wave-uniform
-            const int vi = nonempty + i * groups + g;
-            int v = -1;
-            if (ingroup && vi < a.V) v = a.perm[vi].x;
-            vp_buf_emit<OB, false>(o_rsrc, v, row_out, lane_out, pad_off, zero4);
-        }
+        vp_buf_emit<OB, ACC>(o_rsrc, v | kill, row_out, lane_out, pad_off, acc);
     }
 }
 
@@ -1585,6 +1597,8 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
                 // SGV3D_VP_GRID: workgroups of the launch (probe knobs, tools/vp_probe3.py)
                 static const int vb_env = [] { const char *e = getenv("SGV3D_VP_VB"); return e ? atoi(e) : 0; }();
                 static const int grid_env = [] { const char *e = getenv("SGV3D_VP_GRID"); return e ? atoi(e) : 0; }();
+                static const int dbg_env = [] { const char *e = getenv("SGV3D_VP_DEBUG"); return e ? atoi(e) : 0; }();
+                a.dbg = dbg_env;
                 const int VBsel = vb_env == 16 || vb_env == 8 ? vb_env : 16;
                 const int vgrid = grid_env > 0 ? grid_env : kVoxGrid;
                 if (FUSED) {
