@@ -1302,11 +1302,11 @@ __global__ __launch_bounds__(kBlock) void vp_gather_fast_kernel(const VpFastArgs
 //                                     four wave sums meet in LDS and are added in wave order.
 // Fixed association per (population, channel count) => bit-reproducible.  Work is dealt with a static stride over a grid that
 // is resident at once (perm is in descending order, so every wave gets the same mix of long and short voxels and the
-// longest start first); rows of empty voxels are written from the tail of perm.  All loops are bounded by counts read from
-// the plan, every wave reaches the end of the kernel.
+// longest start first); rows of empty voxels are zeroed by a walk over contiguous voxel ranges.  All loops are bounded by
+// counts read from the plan, every wave reaches the end of the kernel.
 // ------------------------------------------------------------------------------------------------
 struct VpVoxArgs {
-    const int *order, *bin_start;
+    const int *order, *bin_start, *seg_start;
     const int4 *perm;       // {voxel, first slot, end slot, 0} by descending population
     const void *feats;
     void *out;
@@ -1389,6 +1389,75 @@ __device__ __forceinline__ void vp_vox_piece(float4 &acc, int pb, int pe, int ma
     }
 }
 
+// J small voxels per row group in ONE batch of VB slots: voxel j of the group owns the slots [j W, (j + 1) W), W = VB / J, of the
+// batch (populations <= W).  Four in ten non-empty voxels of cfg-2 (six in ten on cfg-3's 0.2 m grid) hold at most four points:
+// a batch per voxel would run the loads, the index exchange and the emit for one to four rows.  perm[lo .. hi) in descending
+// population; item i of the wave = voxels lo + (i groups + g) J + j.
+template <bool FB, bool OB, bool ACC, bool FUSED, int VB, int J>
+__device__ __forceinline__ void vp_vox_small(int lo, int hi, int gw, int nwaves, int cl, bool ingroup, int g, int gs, int groups,
+                                             __amdgpu_buffer_rsrc_t f_rsrc, __amdgpu_buffer_rsrc_t o_rsrc, unsigned row_in,
+                                             unsigned lane_in, unsigned row_out, unsigned lane_out, unsigned pad_off, int kill,
+                                             int *idw, float *prw, const VpVoxArgs &a) {
+    constexpr int W = VB / J;
+    const int n_items = (hi - lo + groups * J - 1) / (groups * J);
+    const int myj = cl / W, myo = cl - myj * W;                   // (index lanes: cl < VB)
+    for (int i = gw; i < n_items; i += nwaves) {                  // wave-uniform
+        int vox[J], pb = 0, pe = 0, len0 = 0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int vi = lo + (i * groups + g) * J + j;
+            int4 rec = make_int4(-1, 0, 0, 0);
+            if (ingroup && vi < hi) rec = a.perm[vi];
+            vox[j] = rec.x;
+            if (j == 0) len0 = rec.z - rec.y;
+            if (myj == j) { pb = rec.y; pe = rec.z; }
+        }
+        const int n = min(W, __shfl(len0, 0, 64));               // the largest population of the item (perm is descending)
+        const int slot = pb + myo;
+        int my_idx = -1;
+        if (ingroup && cl < VB && slot < pe) my_idx = a.order[slot];
+        float my_pr = 0.f;
+        int my_row = my_idx;
+        if constexpr (FUSED) {
+            if (my_idx >= 0) {
+                my_pr = a.prob[my_idx];
+                const int b = vp_fast_div(my_idx, a.N, a.magN, a.shN);
+                const int rem = my_idx - b * a.N;
+                my_row = b * a.P + rem - vp_fast_div(rem, a.P, a.magP, a.shP) * a.P;
+            }
+        }
+        if (ingroup && cl < VB) idw[g * VB + cl] = my_row;
+        const vp_i32x4 *ip = reinterpret_cast<const vp_i32x4 *>(idw + gs * VB);
+        int idx[VB];
+#pragma unroll
+        for (int q = 0; q < VB / 4; ++q) {
+            const vp_i32x4 t = ip[q];
+            idx[4 * q + 0] = t[0]; idx[4 * q + 1] = t[1]; idx[4 * q + 2] = t[2]; idx[4 * q + 3] = t[3];
+        }
+        float4 val[VB];
+#pragma unroll
+        for (int k = 0; k < VB; ++k) val[k] = vp_buf_load_row<FB>(f_rsrc, (a.dbg & 4) ? ~0u - 64u : (unsigned)idx[k] * row_in + lane_in);
+        float pr[VB];
+        if constexpr (FUSED) {
+            if (ingroup && cl < VB) prw[g * VB + cl] = my_pr;
+            const vp_f32x4 *pp = reinterpret_cast<const vp_f32x4 *>(prw + gs * VB);
+#pragma unroll
+            for (int q = 0; q < VB / 4; ++q) {
+                const vp_f32x4 t = pp[q];
+                pr[4 * q + 0] = t[0]; pr[4 * q + 1] = t[1]; pr[4 * q + 2] = t[2]; pr[4 * q + 3] = t[3];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int o = 0; o < W; ++o)
+                if (o < n) vp_add_row<FUSED>(acc, val[j * W + o], FUSED ? pr[j * W + o] : 0.f);
+            vp_buf_emit<OB, ACC>(o_rsrc, vox[j] | kill, row_out, lane_out, pad_off, acc);
+        }
+    }
+}
+
 template <bool FB, bool OB, bool ACC, bool FUSED, int VB>
 __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a) {
     if (a.gate != nullptr && *reinterpret_cast<const volatile int *>(a.gate) != 0) return;
@@ -1430,21 +1499,33 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
     const int n_long = a.bin_start[kVoxShort * groups];          // perm[0 .. n_long): above kVoxShort * groups (<= 320 < kLenBins)
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int kill = (a.dbg & 2) ? -1 : 0;                      // (probe: v | kill = -1 drops every row store)
-    const int n_small = (nonempty - n_mid_end + groups - 1) / groups;
-    // the wave's first small-population record is requested now and arrives under the zero rows below
-    int4 rec_s = make_int4(-1, 0, 0, 0);
-    {
-        const int vi = n_mid_end + gw * groups + g;
-        if (gw < n_small && ingroup && vi < nonempty) rec_s = a.perm[vi];
-    }
+    // populations 1 .. 4 and 5 .. 8 share a batch (four / two voxels per row group) when the batch has 16 slots
+    const bool pack = VB == 16 && vb == 16;
+    const int n8 = pack ? a.bin_start[8] : nonempty;              // perm[n_mid_end .. n8): 9 .. 32 points (one voxel per row group)
+    const int n4 = pack ? a.bin_start[4] : nonempty;              // perm[n8 .. n4): 5 .. 8 points; perm[n4 .. nonempty): 1 .. 4
     // ---------------------------------------------------------------- rows of empty voxels (not in ACC mode)
     if (!ACC && !(a.dbg & 1)) {
-        const int n_rows = (a.V - nonempty + groups - 1) / groups;
-        for (int i = gw; i < n_rows; i += nwaves) {               // wave-uniform
-            const int vi = nonempty + i * groups + g;
-            int v = -1;
-            if (ingroup && vi < a.V) v = a.perm[vi].x;
-            vp_buf_emit<OB, false>(o_rsrc, v, row_out, lane_out, pad_off, zero4);
+        // Every row group walks a CONTIGUOUS range of voxel ids and zeroes the empty ones it finds in seg_start (eight
+        // look-ups in flight).  On the 512 x 512 grid of cfg-3 nine voxels in ten are empty -- 335 MB of zero rows -- and
+        // writing them in the order of perm's tail (whatever the plan's atomics gave) ran at half the rate of this walk,
+        // whose stores of one group are consecutive rows.
+        constexpr int EU = 8;
+        const int ngr = nwaves * groups;
+        const int per = (a.V + ngr - 1) / ngr;
+        const int v0 = (gw * groups + (ingroup ? g : 0)) * per;
+        for (int i0 = 0; i0 < per; i0 += EU) {                    // uniform trip count
+            int s[EU + 1];
+#pragma unroll
+            for (int u = 0; u <= EU; ++u) {
+                const int v = v0 + i0 + u;
+                s[u] = v <= a.V ? a.seg_start[v] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                const int v = v0 + i0 + u;
+                const bool emp = ingroup && i0 + u < per && v < a.V && s[u] == s[u + 1];
+                vp_buf_emit<OB, false>(o_rsrc, emp ? v : -1, row_out, lane_out, pad_off, zero4);
+            }
         }
     }
 
@@ -1490,17 +1571,26 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
         vp_buf_emit<OB, ACC>(o_rsrc, (g == 0 ? v : -1) | kill, row_out, lane_out, pad_off, tot);
     }
     // ---------------------------------------------------------------- small populations: one row group each
+    const int n_small = (n8 - n_mid_end + groups - 1) / groups;
     for (int i = gw; i < n_small; i += nwaves) {                  // wave-uniform
         const int vi = n_mid_end + i * groups + g;
         int v = -1, pb = 0, pe = 0;
-        if (ingroup && vi < nonempty) {
-            const int4 rec = i == gw ? rec_s : a.perm[vi];
+        if (ingroup && vi < n8) {
+            const int4 rec = a.perm[vi];
             v = rec.x; pb = rec.y; pe = rec.z;
         }
         const int maxlen = __shfl(pe - pb, 0, 64);               // group 0 holds the largest (perm: descending population)
         float4 acc = zero4;
         vp_vox_piece<FB, FUSED, VB>(acc, pb, pe, maxlen, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
         vp_buf_emit<OB, ACC>(o_rsrc, v | kill, row_out, lane_out, pad_off, acc);
+    }
+    if constexpr (VB == 16) {
+        if (pack) {
+            vp_vox_small<FB, OB, ACC, FUSED, VB, 2>(n8, n4, gw, nwaves, cl, ingroup, g, gs, groups, f_rsrc, o_rsrc, row_in, lane_in, row_out,
+                                                    lane_out, pad_off, kill, idw, prw, a);
+            vp_vox_small<FB, OB, ACC, FUSED, VB, 4>(n4, nonempty, gw, nwaves, cl, ingroup, g, gs, groups, f_rsrc, o_rsrc, row_in, lane_in,
+                                                    row_out, lane_out, pad_off, kill, idw, prw, a);
+        }
     }
 }
 
@@ -1583,11 +1673,18 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
             const unsigned long long fbytes = (FUSED ? (unsigned long long)B * P : (unsigned long long)L.total) * C * (FB ? 2 : 4);
             const unsigned long long obytes = (unsigned long long)L.V * (OB ? ldo * 2 : C * 4);
             static const bool generic_env = [] { const char *e = getenv("SGV3D_VP_GENERIC"); return e && e[0] == '1'; }();
-            // SGV3D_VP_KERNEL=slot: the slot-balanced kernel of round 3 (vp_gather_fast_kernel) instead of the voxel-owner one
-            static const bool slot_env = [] { const char *e = getenv("SGV3D_VP_KERNEL"); return e && e[0] == 's'; }();
-            if (fbytes < 0xfff00000ull && obytes < 0xfff00000ull && L.total < 0x7ff00000ll && !generic_env && !slot_env) {
+            // Which of the two gathers: the voxel-owner kernel (round 4) for the fused lift-splat form always (16 / 71 / 140 us
+            // against 21 / 138 / 166 us at cfg-2 / cfg-5 / cfg-3 batch 4), and for the operator form where voxels are well
+            // filled (cfg-5: 185 against 243 us; cfg-2: 25.7 against 26.7).  On sparse grids -- cfg-3's 0.2 m cells: 2.8 points
+            // per voxel of the grid, nine voxels in ten empty -- the operator's rows come from HBM and the slot-balanced kernel,
+            // which walks the voxels in spatial order, reads them with more line reuse (232 against 270 us): it keeps those.
+            // SGV3D_VP_KERNEL=slot | vox forces one of them.
+            static const int kern_env = [] { const char *e = getenv("SGV3D_VP_KERNEL"); return !e ? 0 : e[0] == 's' ? 1 : e[0] == 'v' ? 2 : 0; }();
+            const bool dense = L.total >= 6 * L.V;
+            const bool use_vox = kern_env == 2 || (kern_env == 0 && (FUSED || dense));
+            if (fbytes < 0xfff00000ull && obytes < 0xfff00000ull && L.total < 0x7ff00000ll && !generic_env && use_vox) {
                 VpVoxArgs a;
-                a.order = order;
+                a.order = order; a.seg_start = seg;
                 a.perm = reinterpret_cast<const int4 *>(base + L.off_perm);
                 a.bin_start = reinterpret_cast<const int *>(base + L.off_bins) + kLenBins;
                 a.feats = FUSED ? static_cast<const void *>(ctx) : static_cast<const void *>(feats); a.out = out; a.gate = gate;

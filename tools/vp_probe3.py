@@ -42,12 +42,12 @@ def graph_us(fn, reps=20):
 
 def main():
     kern = os.environ.get("SGV3D_VP_KERNEL", "vox")
-    for name, conf in (("cfg2", S.r50_256_conf), ("cfg5", S.bsm_r101_256_conf)):
+    for name, conf, batch in (("cfg2", S.r50_256_conf, 1), ("cfg5", S.bsm_r101_256_conf, 1), ("cfg3_b4", S.r101_512_conf, 4)):
         bc, hc = conf()
         torch.manual_seed(0)
         model = BEVHeight(bc, hc).eval().cuda()
         bb = model.backbone
-        mats = S.make_mats(1, device="cuda")
+        mats = S.make_mats(batch, device="cuda")
         with torch.no_grad():
             geom, plan = bb.calibration(mats, 0)
         B, N = plan.B, plan.N
@@ -55,6 +55,15 @@ def main():
         D = int(bb.height_channels)
         P = N // D
         X, Y, Z = bb._voxel_num_host
+        g3 = geom.view(B, -1, 3).long()
+        ok = (g3[..., 0] >= 0) & (g3[..., 0] < X) & (g3[..., 1] >= 0) & (g3[..., 1] < Y) & (g3[..., 2] >= 0) & (g3[..., 2] < Z)
+        vid = (torch.arange(B, device="cuda").view(B, 1) * Y + g3[..., 1]) * X + g3[..., 0]
+        cnt = torch.bincount(vid[ok], minlength=B * X * Y)
+        ne = cnt[cnt > 0]
+        edges = [0, 4, 8, 16, 32, 96, 10 ** 9]
+        hist = [(int(((ne > lo) & (ne <= hi)).sum()), int(ne[(ne > lo) & (ne <= hi)].sum())) for lo, hi in zip(edges[:-1], edges[1:])]
+        print(f"{name}: voxels {B * X * Y}, non-empty {ne.numel()}, kept points {int(ne.sum())}, mean {float(ne.float().mean()):.1f}, max {int(ne.max())}; "
+              f"(voxels, points) with population 1-4 / 5-8 / 9-16 / 17-32 / 33-96 / >96: {hist}", flush=True)
         prob = torch.rand(B, D, P, device="cuda")
         ctx = torch.randn(B, P, C, device="cuda")
         lifted = (prob[..., None] * ctx[:, None]).reshape(B, N, C).contiguous()
