@@ -59,6 +59,11 @@ int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int num_channels
                                 int num_voxel_x, int num_voxel_y, int num_voxel_z,
                                 const int32_t *geom_xyz, const float *input_features,
                                 float *output_features, int32_t *pos_memo, void *stream);
+/* Which gather kernel the planned / level-1 / fused entries launch: 0 = by rule (default: the voxel-owner kernel for the
+ * fused lift-splat form and for well-filled grids, the slot-balanced kernel for the operator form on sparse grids), 1 = always
+ * the slot-balanced kernel, 2 = always the voxel-owner kernel.  Both give exact sums of the same rows; their fixed summation
+ * orders differ.  Also SGV3D_VP_KERNEL=slot | vox at load time.  (Tests and probes; not part of the reference's interface.) */
+int sgv3d_voxel_pooling_select_kernel(int which);
 int sgv3d_voxel_pooling_cache_clear(void);
 int sgv3d_voxel_pooling_cache_stats(unsigned long long *out4);
 

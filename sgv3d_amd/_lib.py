@@ -28,6 +28,7 @@ TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64 = 0, 1, 2, 3, 4
 _PROTOS = {
     "sgv3d_last_error": (ctypes.c_char_p, []),
     "sgv3d_abi_version": (c_int, []),
+    "sgv3d_voxel_pooling_select_kernel": (c_int, [c_int]),
     "sgv3d_voxel_pooling_forward": (c_int, [c_int] * 6 + [c_void_p] * 5),
     "sgv3d_voxel_pooling_forward_atomic": (c_int, [c_int] * 6 + [c_void_p] * 5),
     "sgv3d_voxel_pooling_cache_clear": (c_int, []),

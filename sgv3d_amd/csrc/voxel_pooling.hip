@@ -15,6 +15,7 @@
 //                            [B,N,C] lifted tensor), with bf16 rows / bf16 output (bf16 compute mode), and
 //                            accumulating into a caller-zeroed tensor behind the reference's own entry
 //                            point (sgv3d_voxel_pooling_forward keeps a plan per stream, "level 1").
+#include <atomic>
 #include "common.hpp"
 
 #include <limits.h>
@@ -1654,6 +1655,10 @@ GatherGeom gather_geom(long long total_pts, int C) {
 // workgroups appended to the gather grid for the plan's long runs (idle ones leave after one load)
 constexpr int kLongBlocks = 1024;
 
+// 0: by the rule in launch_gather, 1: slot-balanced kernel, 2: voxel-owner kernel (SGV3D_VP_KERNEL=slot | vox at load time,
+// sgv3d_voxel_pooling_select_kernel at run time: tests and probes run both on the same data)
+std::atomic<int> g_vp_kernel{[] { const char *e = getenv("SGV3D_VP_KERNEL"); return !e ? 0 : e[0] == 's' ? 1 : e[0] == 'v' ? 2 : 0; }()};
+
 template <bool FUSED, bool FB = false, bool OB = false, bool ACC = false>
 int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const float *feats,
                   const float *prob, const float *ctx, int P, float *out, void *workspace, size_t ws_bytes,
@@ -1679,7 +1684,7 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
             // per voxel of the grid, nine voxels in ten empty -- the operator's rows come from HBM and the slot-balanced kernel,
             // which walks the voxels in spatial order, reads them with more line reuse (232 against 270 us): it keeps those.
             // SGV3D_VP_KERNEL=slot | vox forces one of them.
-            static const int kern_env = [] { const char *e = getenv("SGV3D_VP_KERNEL"); return !e ? 0 : e[0] == 's' ? 1 : e[0] == 'v' ? 2 : 0; }();
+            const int kern_env = g_vp_kernel.load(std::memory_order_relaxed);
             const bool dense = L.total >= 6 * L.V;
             const bool use_vox = kern_env == 2 || (kern_env == 0 && (FUSED || dense));
             if (fbytes < 0xfff00000ull && obytes < 0xfff00000ull && L.total < 0x7ff00000ll && !generic_env && use_vox) {
@@ -2116,6 +2121,12 @@ extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int n
     hipLaunchKernelGGL(vp_atomic_gated_kernel, dim3((unsigned)(ablocks < 2048 ? ablocks : 2048)), dim3(kBlock), 0, st, total, N, C, X,
                        Y, Z, geom_xyz, input_features, output_features, &hdr->dirty);
     return check_launch("voxel_pooling_forward(level-1)");
+}
+
+extern "C" int sgv3d_voxel_pooling_select_kernel(int which) {
+    SGV3D_REQUIRE(which >= 0 && which <= 2, "voxel_pooling_select_kernel: 0 (rule), 1 (slot-balanced) or 2 (voxel-owner)");
+    g_vp_kernel.store(which, std::memory_order_relaxed);
+    return SGV3D_OK;
 }
 
 extern "C" int sgv3d_voxel_pooling_cache_clear(void) {

@@ -11,6 +11,16 @@ DEV = "cuda:0"
 VP_CASES = ["tiny", "b2_c80", "z2", "dups", "all_out"]
 
 
+@pytest.fixture(params=["rule", "slot", "vox"])
+def gather_kernel(request, hip):
+    """Both gather kernels on the same data: the slot-balanced one of round 3 and the voxel-owner one of round 4 (the default
+    picks per form and grid density, csrc/voxel_pooling.hip::launch_gather)."""
+    lib = hip.load()
+    hip.check(lib.sgv3d_voxel_pooling_select_kernel({"rule": 0, "slot": 1, "vox": 2}[request.param]), "select")
+    yield request.param
+    hip.check(lib.sgv3d_voxel_pooling_select_kernel(0), "select")
+
+
 def _run_abi(hip, geom, feats, voxel_num, mode, sort=True):
     """Call straight through the C ABI. Returns NCHW out (numpy), pos_memo (numpy)."""
     lib = hip.load()
@@ -71,7 +81,7 @@ def test_golden_randn_tolerance(hip, golden, mode):
 
 @pytest.mark.parametrize("C", [80, 87, 4, 1, 260])
 @pytest.mark.parametrize("mode", ["atomic", "planned", "level1"])
-def test_random_vs_oracle_exact(hip, C, mode):
+def test_random_vs_oracle_exact(hip, C, mode, gather_kernel):
     """Ragged / colliding / out-of-range indices, channel counts incl. C%4!=0 and rows wider than a wave."""
     rng = np.random.default_rng(C)
     B, N, X, Y, Z = 2, 3001, 13, 9, 2
@@ -83,7 +93,7 @@ def test_random_vs_oracle_exact(hip, C, mode):
     assert np.array_equal(out, ref) and np.array_equal(pm, pm_ref)
 
 
-def test_long_segments_sorted(hip):
+def test_long_segments_sorted(hip, gather_kernel):
     """Segments of 1, 64, 65, 300 and 9000 points: the plan's per-voxel lists come out ascending
     (covers the in-register-size, LDS and global-memory bitonic paths)."""
     lib = hip.load()
@@ -237,7 +247,7 @@ def test_compiled_pybind_ext_runs_reference_wrapper_protocol(hip, golden):
         ext.voxel_pooling_forward_wrapper(B, geom.shape[1], C, X, Y, Z, geom, feats.int(), out, pm)
 
 
-def test_fused_lift_splat_matches_materialised(hip, golden):
+def test_fused_lift_splat_matches_materialised(hip, golden, gather_kernel):
     from sgv3d_amd.ops.voxel_pooling import VoxelPlan
     rng = np.random.default_rng(3)
     B, D, P, C, X, Y = 2, 6, 35, 80, 8, 7
@@ -251,7 +261,7 @@ def test_fused_lift_splat_matches_materialised(hip, golden):
 
 
 @pytest.mark.parametrize("C,ld", [(80, 96), (88, 96), (24, 32)])
-def test_fused_lift_splat_random_data_and_bf16_forms(hip, C, ld):
+def test_fused_lift_splat_random_data_and_bf16_forms(hip, C, ld, gather_kernel):
     """The fused gather on random (non-integer) data: f32 bitwise the lift + pool result (products rounded before the add, same
     order); the bf16 hand-off output = the f32 sums rounded once, padding channels zero; bf16 context rows = the f32 kernel on the
     rounded context."""
@@ -316,7 +326,7 @@ def test_cached_plan_rebuilds_only_on_change(hip):
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_random_geometry_fuzz_vs_oracle(hip, seed):
+def test_random_geometry_fuzz_vs_oracle(hip, seed, gather_kernel):
     """Random sizes / channel counts / grids and point clouds from benign to pathological (everything in one
     voxel, everything out of range, long runs of equal voxels, interleaved duplicates): both kernels exact on
     integer-valued features, pos_memo exact, planned output fully written."""
@@ -357,7 +367,7 @@ def test_random_geometry_fuzz_vs_oracle(hip, seed):
 
 # ------------------------------------------------------------------------------------------------ owner-computes gather
 @pytest.mark.parametrize("C", [80, 64, 24, 88, 256])
-def test_gather_runs_cut_by_chunk_and_wave_borders(hip, C):
+def test_gather_runs_cut_by_chunk_and_wave_borders(hip, C, gather_kernel):
     """vp_gather3_kernel: voxel populations chosen around every border of its decomposition -- one chunk (<= 16 slots), one
     wave range (groups x ch slots: 48 at C=80, 56 at C=64, 40 at C=24, 32 at C=88, 16 at C=256), kLongRun = 256 (longer runs
     go to the long-run workgroups), several ranges, and thousands of points -- in shuffled point order, two samples, empty
@@ -382,7 +392,7 @@ def test_gather_runs_cut_by_chunk_and_wave_borders(hip, C):
         assert np.array_equal(pm.reshape(pm_ref.shape), pm_ref)
 
 
-def test_gather_variants_agree_on_cut_runs(hip):
+def test_gather_variants_agree_on_cut_runs(hip, gather_kernel):
     """The fused lift-splat form, the bf16-feature form and the bf16-output form of the gather on the same cut / long runs."""
     from sgv3d_amd.ops.voxel_pooling import VoxelPlan
     rng = np.random.default_rng(9)
