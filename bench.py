@@ -85,11 +85,21 @@ def parse():
     return ap.parse_args()
 
 
-def load_vp_traffic(fused=False):
-    """HBM bytes per launch of the voxel-pooling gather from the committed PMC summary: the OPERATOR kernel
-    (``vp_gather_fast_kernel<.., false>``, section ``vp_probe`` = tools/vp_probe.py under the counters) or, with ``fused``,
-    the fused lift-splat instantiation the model launches (``<.., true>``, section ``bench``).  Each figure is attached only
-    to the kernel it was counted on."""
+def _vp_symbol_form(sym):
+    """(kernel family, fused?) of a gather kernel symbol of the PMC summaries, or None: vp_gather_fast_kernel<FB, OB, ACC, FUSED>
+    (slot-balanced, round 3) / vp_gather_vox_kernel<FB, OB, ACC, FUSED, VB> (voxel-owner, round 4)."""
+    for fam, pos in (("vp_gather_fast_kernel", 3), ("vp_gather_vox_kernel", 3)):
+        if sym.startswith(fam + "<"):
+            args = [a.strip() for a in sym[len(fam) + 1:].rstrip(">").split(",")]
+            return fam, (len(args) > pos and args[pos] == "true")
+    return None
+
+
+def load_vp_traffic(fused=False, family=None):
+    """HBM bytes per launch of the voxel-pooling gather from the committed PMC summary: the OPERATOR form (section ``vp_probe``
+    = tools/vp_probe.py under the counters) or, with ``fused``, the fused lift-splat form the model launches (section
+    ``bench``), of the kernel family that runs here (``family``).  Each figure is attached only to the kernel it was counted
+    on; no summary for that kernel -> (None, None)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
     for f in reversed(files):
@@ -99,10 +109,8 @@ def load_vp_traffic(fused=False):
             continue
         for section in (("bench",) if fused else ("vp_probe", "bench")):
             for sym, r in (doc.get(section) or {}).items():
-                if not sym.startswith("vp_gather_fast_kernel<"):
-                    continue
-                is_fused = sym.rstrip(">").split(",")[-1].strip() == "true"
-                if is_fused == fused:
+                form = _vp_symbol_form(sym)
+                if form is not None and form[1] == fused and (family is None or form[0] == family):
                     return r["hbm_bytes_per_launch"], os.path.relpath(f, ROOT) + ":" + section + ":" + sym
     return None, None
 
@@ -506,19 +514,24 @@ def main():
             build_us = time_us(lambda: VoxelPlan(flat, (X, Y, 1), cached=False), reps=10)
             clean_us = time_us(lambda: plan.rebuild(flat), reps=10)
         alg = 12.0 * Bn * Np + 4.0 * Bn * Np * Cvp + 4.0 * Bn * Y * X * Cvp           # geom + feats + output
-        vtraffic, vsrc = load_vp_traffic()
+        kname = {1: "vp_gather_fast_kernel", 2: "vp_gather_vox_kernel"}
+        _Lk = __import__("sgv3d_amd._lib", fromlist=["load"]).load()
+        k_op = kname.get(_Lk.sgv3d_voxel_pooling_kernel_for(Bn, Np, Cvp, X, Y, 0), "vp_gather3_kernel")
+        k_fused = kname.get(_Lk.sgv3d_voxel_pooling_kernel_for(Bn, Np, Cvp, X, Y, 1), "vp_gather3_kernel")
+        vtraffic, vsrc = load_vp_traffic(family=k_op)
         # the fused lift-splat launch against ITS algorithmic bytes ("Fused lift-splat"): probabilities +
         # context rows + one linearised index per point + the output written once
         fused_rec = None
         if lift_splat_us:
             alg_f = 4.0 * Bn * Np + 4.0 * Bn * (Np // Dh) * Cvp + 4.0 * Bn * Np + 4.0 * Bn * Y * X * Cvp
-            ftraffic, fsrc = load_vp_traffic(fused=True)
-            fused_rec = {"kernel": "vp_gather_fast_kernel<.., FUSED> (sgv3d_lift_splat_planned: what the timed model launches)",
+            ftraffic, fsrc = load_vp_traffic(fused=True, family=k_fused)
+            fused_rec = {"kernel": k_fused + "<.., FUSED> (sgv3d_lift_splat_planned: what the timed model launches)",
                          "bytes": alg_f, "us": lift_splat_us, "achieved": alg_f / lift_splat_us / 1e3, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": alg_f / lift_splat_us / 1e3 / HBM_PEAK_GBPS, "traffic": ftraffic,
                          "traffic_source": fsrc,
-                         "note": "L2 / vector-instruction bound, not HBM bound: the context map is L2-resident and every point's row "
-                                 "is re-read from there (DESIGN 3.2)"}
+                         "note": "not HBM bound: the context map is L2-resident and every point's row is re-read from there; with no row "
+                                 "loads and no stores at all the launch still takes 11.5 us at cfg-2 (issue + dependent-load chains, "
+                                 "DESIGN 3.2)"}
         # level 1 of INTEGRATION.md: the symbol the reference's own voxel_pooling.py reaches through voxel_pooling_ext
         # (sgv3d_voxel_pooling_forward: device-side compare of geom_xyz + pos_memo, gather accumulating into the caller-zeroed
         # output from the library-owned plan, gated scatter fallback) -- timed on this run's geometry with pos_memo
@@ -532,7 +545,7 @@ def main():
         level1_us = time_us(l1) if Cvp % 4 == 0 and 24 <= Cvp <= 256 else None
         del outz, pmz
         roofline_hbm = {
-            "bound": "hbm", "kernel": "vp_gather_fast_kernel (sgv3d_voxel_pooling_forward_planned: one launch, no fix-up pass)",
+            "bound": "hbm", "kernel": k_op + " (sgv3d_voxel_pooling_forward_planned: one launch, no fix-up pass)",
             "bytes": alg, "us": pool_us, "achieved": alg / pool_us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": alg / pool_us / 1e3 / HBM_PEAK_GBPS, "traffic": vtraffic, "traffic_source": vsrc,
             "plan_build_us": build_us, "plan_check_us": clean_us,

@@ -64,6 +64,9 @@ int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int num_channels
  * the slot-balanced kernel, 2 = always the voxel-owner kernel.  Both give exact sums of the same rows; their fixed summation
  * orders differ.  Also SGV3D_VP_KERNEL=slot | vox at load time.  (Tests and probes; not part of the reference's interface.) */
 int sgv3d_voxel_pooling_select_kernel(int which);
+/* the kernel those entries launch for these sizes (fused = the lift-splat form): 1 slot-balanced, 2 voxel-owner, 0 = neither
+ * (channel counts outside 24 .. 256 / not a multiple of 4 take the generic gather) -- for reports (bench.py) */
+int sgv3d_voxel_pooling_kernel_for(int batch_size, int num_points, int num_channels, int num_voxel_x, int num_voxel_y, int fused);
 int sgv3d_voxel_pooling_cache_clear(void);
 int sgv3d_voxel_pooling_cache_stats(unsigned long long *out4);
 

@@ -29,6 +29,7 @@ _PROTOS = {
     "sgv3d_last_error": (ctypes.c_char_p, []),
     "sgv3d_abi_version": (c_int, []),
     "sgv3d_voxel_pooling_select_kernel": (c_int, [c_int]),
+    "sgv3d_voxel_pooling_kernel_for": (c_int, [c_int] * 6),
     "sgv3d_voxel_pooling_forward": (c_int, [c_int] * 6 + [c_void_p] * 5),
     "sgv3d_voxel_pooling_forward_atomic": (c_int, [c_int] * 6 + [c_void_p] * 5),
     "sgv3d_voxel_pooling_cache_clear": (c_int, []),

@@ -1659,6 +1659,11 @@ constexpr int kLongBlocks = 1024;
 // sgv3d_voxel_pooling_select_kernel at run time: tests and probes run both on the same data)
 std::atomic<int> g_vp_kernel{[] { const char *e = getenv("SGV3D_VP_KERNEL"); return !e ? 0 : e[0] == 's' ? 1 : e[0] == 'v' ? 2 : 0; }()};
 
+bool vp_use_vox(long long total_pts, long long V, bool fused) {
+    const int sel = g_vp_kernel.load(std::memory_order_relaxed);
+    return sel == 2 || (sel == 0 && (fused || total_pts >= 6 * V));
+}
+
 template <bool FUSED, bool FB = false, bool OB = false, bool ACC = false>
 int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const float *feats,
                   const float *prob, const float *ctx, int P, float *out, void *workspace, size_t ws_bytes,
@@ -1684,9 +1689,7 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
             // per voxel of the grid, nine voxels in ten empty -- the operator's rows come from HBM and the slot-balanced kernel,
             // which walks the voxels in spatial order, reads them with more line reuse (232 against 270 us): it keeps those.
             // SGV3D_VP_KERNEL=slot | vox forces one of them.
-            const int kern_env = g_vp_kernel.load(std::memory_order_relaxed);
-            const bool dense = L.total >= 6 * L.V;
-            const bool use_vox = kern_env == 2 || (kern_env == 0 && (FUSED || dense));
+            const bool use_vox = vp_use_vox(L.total, L.V, FUSED);
             if (fbytes < 0xfff00000ull && obytes < 0xfff00000ull && L.total < 0x7ff00000ll && !generic_env && use_vox) {
                 VpVoxArgs a;
                 a.order = order; a.seg_start = seg;
@@ -2121,6 +2124,14 @@ extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int n
     hipLaunchKernelGGL(vp_atomic_gated_kernel, dim3((unsigned)(ablocks < 2048 ? ablocks : 2048)), dim3(kBlock), 0, st, total, N, C, X,
                        Y, Z, geom_xyz, input_features, output_features, &hdr->dirty);
     return check_launch("voxel_pooling_forward(level-1)");
+}
+
+extern "C" int sgv3d_voxel_pooling_kernel_for(int batch_size, int num_points, int num_channels, int num_voxel_x, int num_voxel_y,
+                                              int fused) {
+    if (batch_size <= 0 || num_points <= 0 || num_voxel_x <= 0 || num_voxel_y <= 0) return 0;
+    const GatherGeom G = gather_geom((long long)batch_size * num_points, num_channels);
+    if (!G.v2) return 0;
+    return vp_use_vox((long long)batch_size * num_points, (long long)batch_size * num_voxel_x * num_voxel_y, fused != 0) ? 2 : 1;
 }
 
 extern "C" int sgv3d_voxel_pooling_select_kernel(int which) {

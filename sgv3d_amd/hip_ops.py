@@ -741,13 +741,57 @@ class PackedConv:
 PAIR_BF16 = _os.environ.get("SGV3D_PAIR_BF16", "1") != "0"   # 0: conv2 + conv3 of a bottleneck are always two launches
 
 
+# Independent pieces of ONE forward as parallel branches of the captured hipGraph (SGV3D_PARALLEL_BRANCHES=0: in sequence).
+# A batch-1 frame is a chain of ~130 launches, and the narrow ones -- the strided shortcut of a residual stage, the four
+# SECONDFPN levels, the 27-feature gate MLPs, the pooled ASPP branch -- leave most CUs idle while the next launch waits for
+# them although it does not need their result.  Inside a stream capture ``run_parallel`` puts every piece on a forked stream
+# and joins them: the graph gets parallel branches and the GPU runs them side by side (one frame in flight is latency-bound;
+# with several frames in flight the other frames' kernels fill those holes anyway).  Outside a capture -- the eager forward,
+# the first-call measurements, the instrumented pass -- the pieces run in order on the current stream.  Every piece writes
+# its own buffer or channel slice and each kernel's result does not depend on what runs beside it: results are bitwise the
+# sequential ones.
+PARALLEL_BRANCHES = _os.environ.get("SGV3D_PARALLEL_BRANCHES", "1") != "0"
+_BRANCH_POOL = {}
+_BRANCH_TOP = {}
+
+
+def run_parallel(device, thunks):
+    """``[t() for t in thunks]``; inside a stream capture the thunks are forked branches of the graph (the first one stays on
+    the capturing stream).  Nested calls take further streams of the per-device pool."""
+    thunks = list(thunks)
+    if len(thunks) <= 1 or not PARALLEL_BRANCHES or not torch.cuda.is_current_stream_capturing():
+        return [t() for t in thunks]
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    pool = _BRANCH_POOL.setdefault(key, [])
+    top = _BRANCH_TOP.get(key, 0)
+    need = top + len(thunks) - 1
+    while len(pool) < need:
+        pool.append(torch.cuda.Stream(device=dev))
+    mine = pool[top:need]
+    _BRANCH_TOP[key] = need
+    cur = torch.cuda.current_stream(dev)
+    results = [None] * len(thunks)
+    try:
+        for st, (i, t) in zip(mine, list(enumerate(thunks))[1:]):
+            st.wait_stream(cur)                                   # fork
+            with torch.cuda.stream(st):
+                results[i] = t()
+        results[0] = thunks[0]()
+    finally:
+        for st in mine:
+            cur.wait_stream(st)                                   # join (every forked stream must rejoin the capture)
+        _BRANCH_TOP[key] = top
+    return results
+
+
 def switch_state():
     """Every module-level switch that decides WHICH kernels a forward launches, as one hashable value: part of the key of
     anything that records launches for replay (BEVHeight's per-signature hipGraph)."""
     g = globals()
     return tuple(g.get(k) for k in ("AUTOTUNE", "SPLIT_K", "WINOGRAD", "FUSED_HEAD", "HEAD_PATH", "MFMA_BF16", "BF16_ACTIVATIONS",
                                     "MFMA_F32X3", "MFIRST", "WINO4", "WINO_HALF", "PATCH_BF16", "DW_BF16", "DW_DEEP", "DW_NARROW",
-                                    "DW_SPLIT_K", "DW_DEEP_MAX_WGS", "PAIR_BF16", "TUNE_STREAMS"))
+                                    "DW_SPLIT_K", "DW_DEEP_MAX_WGS", "PAIR_BF16", "TUNE_STREAMS", "PARALLEL_BRANCHES"))
 
 
 def conv_pair_eligible(a, b, x, residual=None):

@@ -169,31 +169,46 @@ class MSCThead(HipModule):
         [D, D+80) (the caller composes the semantic part), semantic logits NHWC [.., 7]."""
         s = self.hip_state(feats[0].device)
         v = HeightNet.mlp_input(mats_dict)                                   # :262-292
-        gates = []
-        for i in (0, 1):
+        def gate(i):
             h = v
             for w, b, act in s[f'gate{i}']:
                 h = hip_ops.dense(h, w, None, b, act)
-            gates.append(h)
+            return h
         # bf16 mode: every mid-channel map of this head lives in HBM as bf16; the logits / context it returns are f32
         dt = hip_ops.activation_dtype(*[c.cout for c in (s['reduce0'], s['reduce1'], s['ctx0'], s['ctx1a'])])
-        scale0 = hip_ops.scale_channels(s['reduce0'](feats[0], out_dtype=dt), gates[0])     # :300-305
-        scale1 = hip_ops.scale_channels(s['reduce1'](feats[1], out_dtype=dt), gates[1])
-        scale0 = self.aspp.hip_forward(scale0)                                # :306
-        # TaskHead(with_head=False).forward(feat) returns ``feat`` unchanged (:195-199): the decoder of
-        # depth_head0 is never run by the reference, its parameters are dead weights.
-        depth_feat = scale0                                                   # :308
-        semantic_feat = self.semantic_head0.hip_decoder(scale0)               # :309
-        semantic0 = self.semantic_head0.hip_head(semantic_feat)
-        context_feat = s['ctx0'](scale0, out_dtype=dt)                        # :310
-        depth_feat = self.depth_fpn.hip_forward(depth_feat, scale1)           # :313-315
-        semantic_feat = self.semantic_fpn.hip_forward(semantic_feat, scale1)
-        context_feat = self.context_fpn.hip_forward(context_feat, scale1)
+        dev = feats[0].device
+        # the two scales are independent up to the FPN stage, and so are the gate MLPs: branches of the captured graph
+        # (hip_ops.run_parallel; in sequence outside a capture)
+
+        def scale0_branch():
+            r, g0 = hip_ops.run_parallel(dev, (lambda: s['reduce0'](feats[0], out_dtype=dt), lambda: gate(0)))
+            return self.aspp.hip_forward(hip_ops.scale_channels(r, g0))       # :300-306
+
+        def scale1_branch():
+            r, g1 = hip_ops.run_parallel(dev, (lambda: s['reduce1'](feats[1], out_dtype=dt), lambda: gate(1)))
+            return hip_ops.scale_channels(r, g1)
+        scale0, scale1 = hip_ops.run_parallel(dev, (scale0_branch, scale1_branch))
         B, H, W, _ = scale1.shape
         out = torch.empty(B, H, W, out_ld, dtype=torch.float32, device=scale1.device)
-        self.depth_head1.hip_head(self.depth_head1.hip_decoder(depth_feat), out, y_coff=0)          # :317
-        semantic1 = self.semantic_head1.hip_head(self.semantic_head1.hip_decoder(semantic_feat))    # :318
-        s['ctx1b'](s['ctx1a'](context_feat, out_dtype=dt), out, y_coff=self.depth_channels)         # :319
+        # TaskHead(with_head=False).forward(feat) returns ``feat`` unchanged (:195-199): the decoder of
+        # depth_head0 is never run by the reference, its parameters are dead weights.
+        # The three tasks (:308-319) share only scale0 / scale1: three branches, two of them writing channel slices of `out`.
+
+        def depth_task():
+            depth_feat = self.depth_fpn.hip_forward(scale0, scale1)           # :308, :313
+            self.depth_head1.hip_head(self.depth_head1.hip_decoder(depth_feat), out, y_coff=0)          # :317
+
+        def semantic_task():
+            semantic_feat = self.semantic_head0.hip_decoder(scale0)           # :309
+            sem0 = self.semantic_head0.hip_head(semantic_feat)
+            semantic_feat = self.semantic_fpn.hip_forward(semantic_feat, scale1)                        # :314
+            return self.semantic_head1.hip_head(self.semantic_head1.hip_decoder(semantic_feat)), sem0   # :318
+
+        def context_task():
+            context_feat = s['ctx0'](scale0, out_dtype=dt)                    # :310
+            context_feat = self.context_fpn.hip_forward(context_feat, scale1)                           # :315
+            s['ctx1b'](s['ctx1a'](context_feat, out_dtype=dt), out, y_coff=self.depth_channels)         # :319
+        _, (semantic1, semantic0), _ = hip_ops.run_parallel(dev, (depth_task, semantic_task, context_task))
         return out, semantic1, semantic0
 
 

@@ -88,11 +88,16 @@ class ASPP(HipModule):
         B, H, W, _ = x.shape
         mid = self.mid_channels
         cat = torch.empty(B, H, W, 5 * mid, dtype=x.dtype, device=x.device)
-        for i, m in enumerate((self.aspp1, self.aspp2, self.aspp3, self.aspp4)):
-            m.hip_state(x.device)(x, cat, y_coff=i * mid)
-        pooled = hip_ops.global_avgpool(x)
-        x5 = hip_ops.dense(pooled, s['gap_w'], s['gap_scale'], s['gap_shift'], hip_ops.ACT_RELU)
-        hip_ops.broadcast_channels(x5, cat, y_coff=4 * mid)
+
+        def pooled_branch():                               # three tiny launches: beside the convolutions, not behind them
+            pooled = hip_ops.global_avgpool(x)
+            x5 = hip_ops.dense(pooled, s['gap_w'], s['gap_scale'], s['gap_shift'], hip_ops.ACT_RELU)
+            hip_ops.broadcast_channels(x5, cat, y_coff=4 * mid)
+
+        def conv_branches():
+            for i, m in enumerate((self.aspp1, self.aspp2, self.aspp3, self.aspp4)):
+                m.hip_state(x.device)(x, cat, y_coff=i * mid)
+        hip_ops.run_parallel(x.device, (conv_branches, pooled_branch))
         return s['conv1'](cat, out_dtype=x.dtype)          # Dropout(0.5) is the identity in eval mode (:111)
 
 
@@ -243,27 +248,36 @@ class HeightNet(HipModule):
         v = self.mlp_input(mats_dict)                                                   # [B*N, 27]
         # BatchNorm1d(27) in eval mode is a per-feature affine: folded once into fc1
         # (W' = W * scale, b' = b + W @ shift).
-        gates = {}
         for name in ('context', 'height'):
-            fc1_w, fc1_b, _ = s[name + '_gate'][0]
             key = name + '_fc1_folded'
             if key not in s:
+                fc1_w, fc1_b, _ = s[name + '_gate'][0]
                 s[key] = ((fc1_w * s['bn_scale'][None, :]).contiguous(),
                           (fc1_b + fc1_w @ s['bn_shift']).contiguous())
-            h = hip_ops.dense(v, s[key][0], None, s[key][1], hip_ops.ACT_RELU)
+
+        def gate(name):                                   # four one-workgroup launches each
+            h = hip_ops.dense(v, s[name + '_fc1_folded'][0], None, s[name + '_fc1_folded'][1], hip_ops.ACT_RELU)
             for w, b, act in s[name + '_gate'][1:]:
                 h = hip_ops.dense(h, w, None, b, act)
-            gates[name] = h                                                             # sigmoid gate [B*N, mid]
+            return h                                                                    # sigmoid gate [B*N, mid]
         # bf16 mode: the mid-channel maps live in HBM as bf16 (like the ResNet chains); logits + context leave as f32
         dt = hip_ops.activation_dtype(self.mid_channels, self.mid_channels // 4)
-        x = s['reduce'](x, out_dtype=dt)                                                # :241
+        x_in = x
+        # the two gate MLPs (27 numbers per camera) beside the 3x3 reduce convolution (:241) -- three graph branches
+        x, g_ctx, g_h = hip_ops.run_parallel(x_in.device, (lambda: s['reduce'](x_in, out_dtype=dt), lambda: gate('context'),
+                                                            lambda: gate('height')))
         out = torch.empty(B, H, W, self.height_channels + self.context_channels, dtype=torch.float32, device=x.device)
-        ctx_in = hip_ops.scale_channels(x, gates['context'])                           # SELayer, :155-159
-        s['context'](ctx_in, out, y_coff=self.height_channels)                         # :242-244
-        h = hip_ops.scale_channels(x, gates['height'])                                  # :245-246
-        for blk in self.height_conv:
-            h = blk.hip_forward(h, dt) if isinstance(blk, BasicBlock) else blk.hip_forward(h)   # :247
-        s['height'](h, out, y_coff=0)                                                   # :248
+
+        def context_branch():
+            ctx_in = hip_ops.scale_channels(x, g_ctx)                                   # SELayer, :155-159
+            s['context'](ctx_in, out, y_coff=self.height_channels)                      # :242-244
+
+        def height_branch():
+            h = hip_ops.scale_channels(x, g_h)                                          # :245-246
+            for blk in self.height_conv:
+                h = blk.hip_forward(h, dt) if isinstance(blk, BasicBlock) else blk.hip_forward(h)   # :247
+            s['height'](h, out, y_coff=0)                                               # :248
+        hip_ops.run_parallel(x.device, (height_branch, context_branch))                 # two channel slices of `out`
         return out
 
 

@@ -97,8 +97,11 @@ class BasicBlock(HipModule):
 
     def hip_forward(self, x, act_dtype=None):
         s = self.hip_state(x.device)
-        identity = s['ds'](x, out_dtype=act_dtype) if 'ds' in s else x
-        out = s['c1'](x, out_dtype=act_dtype)
+        if 'ds' in s:      # the strided shortcut beside conv1 (two branches of the captured graph, hip_ops.run_parallel)
+            out, identity = hip_ops.run_parallel(x.device, (lambda: s['c1'](x, out_dtype=act_dtype),
+                                                            lambda: s['ds'](x, out_dtype=act_dtype)))
+        else:
+            identity, out = x, s['c1'](x, out_dtype=act_dtype)
         return s['c2'](out, residual=identity, out_dtype=act_dtype)      # relu(bn2(conv2) + identity)
 
 
@@ -125,8 +128,18 @@ class Bottleneck(HipModule):
 
     def hip_forward(self, x, act_dtype=None):
         s = self.hip_state(x.device)
-        identity = s['ds'](x, out_dtype=act_dtype) if 'ds' in s else x
-        out = s['c1'](x, out_dtype=act_dtype)
+        if 'ds' in s:
+            # the shortcut convolution of a stage's first block beside conv1 -> conv2 (two branches of the captured graph)
+            def main():
+                o = s['c1'](x, out_dtype=act_dtype)
+                if act_dtype == torch.bfloat16 and hip_ops.conv_pair_eligible(s['c2'], s['c3'], o):
+                    return o, None                               # (the fused pair needs the residual: finished after the join)
+                return o, s['c2'](o, out_dtype=act_dtype)
+            (out, mid), identity = hip_ops.run_parallel(x.device, (main, lambda: s['ds'](x, out_dtype=act_dtype)))
+            if mid is not None:
+                return s['c3'](mid, residual=identity, out_dtype=act_dtype)
+        else:
+            identity, out = x, s['c1'](x, out_dtype=act_dtype)
         # bf16 configs, 256-channel bottlenecks (ResNet layer 3): conv2 + conv3 in one launch, the map between them in LDS
         if act_dtype == torch.bfloat16 and hip_ops.conv_pair_choice(s['c2'], s['c3'], out, identity):
             return hip_ops.conv_pair_bf16(s['c2'], s['c3'], out, identity)
@@ -296,12 +309,15 @@ class SECONDFPN(HipModule):
             if out_dtype == torch.bfloat16 and any(c % 8 for c in self.out_channels):
                 out_dtype = None
             out = torch.empty(B, oh, ow, total, dtype=out_dtype or torch.float32, device=feats[0].device)
-        off = 0
+        off, jobs = 0, []
         for conv, f, oc in zip(convs, feats, self.out_channels):
             assert conv.out_hw(int(f.shape[1]), int(f.shape[2])) == (oh, ow), \
                 "SECONDFPN levels do not align (the reference's torch.cat would fail too)"
-            conv(f, out, y_coff=off)
+            jobs.append(lambda conv=conv, f=f, off=off: conv(f, out, y_coff=off))
             off += oc
+        # the levels are independent (each writes its own channel slice) and none of them fills the chip: side by side in the
+        # captured graph (hip_ops.run_parallel), the largest level first
+        hip_ops.run_parallel(out.device, jobs)
         return out
 
 
