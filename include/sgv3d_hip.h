@@ -59,10 +59,10 @@ int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int num_channels
                                 int num_voxel_x, int num_voxel_y, int num_voxel_z,
                                 const int32_t *geom_xyz, const float *input_features,
                                 float *output_features, int32_t *pos_memo, void *stream);
-/* Which gather kernel the planned / level-1 / fused entries launch: 0 = by rule (default: the voxel-owner kernel for the
- * fused lift-splat form and for well-filled grids, the slot-balanced kernel for the operator form on sparse grids), 1 = always
- * the slot-balanced kernel, 2 = always the voxel-owner kernel.  Both give exact sums of the same rows; their fixed summation
- * orders differ.  Also SGV3D_VP_KERNEL=slot | vox at load time.  (Tests and probes; not part of the reference's interface.) */
+/* Which gather kernel the planned / level-1 / fused entries launch: 0 or 2 = the voxel-owner kernel (round 4, default),
+ * 1 = the slot-balanced kernel of round 3.  Both give exact sums of the same rows; their fixed summation orders differ (the
+ * fused lift-splat entry and the operator always use the same one, so they stay bitwise equal).  Also SGV3D_VP_KERNEL=slot
+ * at load time.  (Tests and probes; not part of the reference's interface.) */
 int sgv3d_voxel_pooling_select_kernel(int which);
 /* the kernel those entries launch for these sizes (fused = the lift-splat form): 1 slot-balanced, 2 voxel-owner, 0 = neither
  * (channel counts outside 24 .. 256 / not a multiple of 4 take the generic gather) -- for reports (bench.py) */

@@ -1660,8 +1660,11 @@ constexpr int kLongBlocks = 1024;
 std::atomic<int> g_vp_kernel{[] { const char *e = getenv("SGV3D_VP_KERNEL"); return !e ? 0 : e[0] == 's' ? 1 : e[0] == 'v' ? 2 : 0; }()};
 
 bool vp_use_vox(long long total_pts, long long V, bool fused) {
-    const int sel = g_vp_kernel.load(std::memory_order_relaxed);
-    return sel == 2 || (sel == 0 && (fused || total_pts >= 6 * V));
+    // One kernel for both forms: the fused lift-splat launch is bitwise lift + operator only if they sum in the same order.
+    // (On sparse grids -- cfg-3 batch 4: 2.8 points per voxel of the grid, nine voxels in ten empty -- the slot-balanced
+    // kernel, which walks the voxels in spatial order, reads the operator's rows with more line reuse: 232 against 270 us.)
+    (void)total_pts; (void)V; (void)fused;
+    return g_vp_kernel.load(std::memory_order_relaxed) != 1;
 }
 
 template <bool FUSED, bool FB = false, bool OB = false, bool ACC = false>
@@ -1683,12 +1686,9 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
             const unsigned long long fbytes = (FUSED ? (unsigned long long)B * P : (unsigned long long)L.total) * C * (FB ? 2 : 4);
             const unsigned long long obytes = (unsigned long long)L.V * (OB ? ldo * 2 : C * 4);
             static const bool generic_env = [] { const char *e = getenv("SGV3D_VP_GENERIC"); return e && e[0] == '1'; }();
-            // Which of the two gathers: the voxel-owner kernel (round 4) for the fused lift-splat form always (16 / 71 / 140 us
-            // against 21 / 138 / 166 us at cfg-2 / cfg-5 / cfg-3 batch 4), and for the operator form where voxels are well
-            // filled (cfg-5: 185 against 243 us; cfg-2: 25.7 against 26.7).  On sparse grids -- cfg-3's 0.2 m cells: 2.8 points
-            // per voxel of the grid, nine voxels in ten empty -- the operator's rows come from HBM and the slot-balanced kernel,
-            // which walks the voxels in spatial order, reads them with more line reuse (232 against 270 us): it keeps those.
-            // SGV3D_VP_KERNEL=slot | vox forces one of them.
+            // The voxel-owner kernel (round 4) unless sgv3d_voxel_pooling_select_kernel / SGV3D_VP_KERNEL=slot asks for the
+            // slot-balanced one of round 3: fused form 16 / 71 / 140 us against 21 / 138 / 166 us at cfg-2 / cfg-5 / cfg-3
+            // batch 4, operator form 25.7 / 185 / 270 against 26.7 / 243 / 232 us.
             const bool use_vox = vp_use_vox(L.total, L.V, FUSED);
             if (fbytes < 0xfff00000ull && obytes < 0xfff00000ull && L.total < 0x7ff00000ll && !generic_env && use_vox) {
                 VpVoxArgs a;

@@ -741,16 +741,17 @@ class PackedConv:
 PAIR_BF16 = _os.environ.get("SGV3D_PAIR_BF16", "1") != "0"   # 0: conv2 + conv3 of a bottleneck are always two launches
 
 
-# Independent pieces of ONE forward as parallel branches of the captured hipGraph (SGV3D_PARALLEL_BRANCHES=0: in sequence).
-# A batch-1 frame is a chain of ~130 launches, and the narrow ones -- the strided shortcut of a residual stage, the four
-# SECONDFPN levels, the 27-feature gate MLPs, the pooled ASPP branch -- leave most CUs idle while the next launch waits for
-# them although it does not need their result.  Inside a stream capture ``run_parallel`` puts every piece on a forked stream
-# and joins them: the graph gets parallel branches and the GPU runs them side by side (one frame in flight is latency-bound;
-# with several frames in flight the other frames' kernels fill those holes anyway).  Outside a capture -- the eager forward,
-# the first-call measurements, the instrumented pass -- the pieces run in order on the current stream.  Every piece writes
-# its own buffer or channel slice and each kernel's result does not depend on what runs beside it: results are bitwise the
-# sequential ones.
-PARALLEL_BRANCHES = _os.environ.get("SGV3D_PARALLEL_BRANCHES", "1") != "0"
+# Independent pieces of ONE forward as parallel branches of the captured hipGraph -- BUILT, MEASURED, OFF BY DEFAULT
+# (SGV3D_PARALLEL_BRANCHES=1 turns it on).  A batch-1 frame is a chain of ~130 launches, and the narrow ones -- the strided
+# shortcut of a residual stage, the four SECONDFPN levels, the 27-feature gate MLPs, the pooled ASPP branch -- leave most CUs
+# idle while the next launch waits for them although it does not need their result.  Inside a stream capture ``run_parallel``
+# puts every piece on a forked stream and joins them, so the graph gets parallel branches; outside a capture the pieces run in
+# order on the current stream.  Every piece writes its own buffer or channel slice: results are bitwise the sequential ones.
+# Measured on cfg-2 (round 4, one call, same box): the ~30 fork / join pairs per frame cost more than the overlap returns --
+# one frame in flight 169.3 -> 160.7 frames/s, three in flight 209.0 -> 163.3, the harness step 153.3 -> 147.8: every
+# cross-stream edge of a hipGraph is a barrier packet plus a semaphore between hardware queues, tens of microseconds each,
+# where the kernels it lets overlap are 10-60 us long.
+PARALLEL_BRANCHES = _os.environ.get("SGV3D_PARALLEL_BRANCHES", "0") == "1"
 _BRANCH_POOL = {}
 _BRANCH_TOP = {}
 
