@@ -34,4 +34,10 @@ python3 $R/tools/microbench.py --what vp,lift --out $OUT/${TAG}_voxel_pooling_mi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_vp -- python3 $R/tools/vp_probe.py > /dev/null 2> $OUT/vp.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_vp_pmc_fetch -- python3 $R/tools/vp_probe.py > /dev/null 2>> $OUT/vp.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_vp_pmc_write -- python3 $R/tools/vp_probe.py > /dev/null 2>> $OUT/vp.err
-ls -la $OUT | head -40
+# 5. the reference harness's eval_step (sgv3d_amd/harness.py): phase timing, and the kernel trace of the same loop
+python3 $R/tools/harness_profile.py > $OUT/${TAG}_harness_phases.txt 2> $OUT/harness.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_harness -- python3 $R/tools/harness_profile.py > /dev/null 2>> $OUT/harness.err
+# 6. the gather kernels side by side (voxel-owner / slot-balanced) on the cfg-2 / cfg-5 / cfg-3 geometries
+python3 $R/tools/vp_probe3.py > $OUT/${TAG}_gather_probe.txt 2> $OUT/gather_probe.err
+SGV3D_VP_KERNEL=slot python3 $R/tools/vp_probe3.py >> $OUT/${TAG}_gather_probe.txt 2>> $OUT/gather_probe.err
+ls -la $OUT | head -60

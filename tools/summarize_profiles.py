@@ -37,7 +37,8 @@ for f in (f"{tag}_bench.json", f"{tag}_bench_kernel_stats.csv", f"{tag}_vp_kerne
           f"{tag}_layers_cfg2_tiles_for_3inflight.txt", f"{tag}_layers_cfg2_tiles_for_1inflight.txt",
           f"{tag}_wino4_kernel_stats.csv", f"{tag}_bench_cfg3_bf16_b4.json", f"{tag}_bench_cfg5_bf16.json",
           f"{tag}_bench_cfg5_bf16_b4.json", f"{tag}_bench_cfg3_fp32_b4.json", f"{tag}_bench_cfg5.json",
-          f"{tag}_bench_cfg3_bf16_kernel_stats.csv"):
+          f"{tag}_bench_cfg3_bf16_kernel_stats.csv", f"{tag}_harness_phases.txt", f"{tag}_harness_kernel_stats.csv",
+          f"{tag}_gather_probe.txt"):
     p = os.path.join(src, f)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f))
