@@ -93,17 +93,33 @@ struct PlanLayout {
     long long V;        // B*Y*X
     long long total;    // B*N
     int nblk;           // scan workgroups
+    int ncw;            // workgroups of the class sort
     size_t off_seg, off_cur, off_order, off_slotvox, off_blk, off_hdr, off_geom, off_long, off_perm, off_bins, bytes;
     int long_cap;       // capacity of the long-run list (entries after the count)
 };
 
-// Voxels ordered by population (vp_gather_vox_kernel, round 4): `perm` lists the voxels by DESCENDING point count -- a
-// counting sort over kLenBins keys (key = min(count, kLenBins - 1)), the empty voxels (key 0) last -- as one 16-byte record
-// {voxel id, first slot, end slot, 0} each, so that a gather wave learns its work with ONE load (the kernel is bound by its
-// chain of dependent loads, not by bytes).  bins[0 .. kLenBins) =
-// number of voxels per key, bins[kLenBins .. 2 kLenBins) = bin_start[key] = position of the key's first voxel in perm
-// (= number of voxels with a larger key for key >= 1; bin_start[0] = number of non-empty voxels), then the scatter cursors.
-constexpr int kLenBins = 1024;
+// Voxels ordered by population CLASS (vp_gather_vox_kernel, round 4): `perm` lists the voxels class after class, the largest
+// populations first and the empty voxels last, IN VOXEL ORDER INSIDE A CLASS (a stable counting sort), as one 16-byte record
+// {voxel id, first slot, end slot, 0} each -- a gather wave learns its work with ONE load (the kernel is bound by its chains of
+// dependent loads, not by bytes), and consecutive records are spatial neighbours: their points are neighbours in the lifted
+// tensor, so the rows the operator form pulls from HBM share cache lines with the rows of the wave next door (a sort by exact
+// population, which the first version used, lost that: 270 against 232 us for the slot-balanced kernel on cfg-3's sparse grid).
+// Classes: 0 = empty | 1-4 | 5-8 | 9-16 | 17-32 | 33-64 | 65-96 | ... | 289-320 (steps of 32: the one-wave / one-workgroup
+// border is 32 x row groups) | 321-640 | 641-1280 | 1281-2560 | more.  cls[c] (kVoxClasses ints after the table) = number of
+// voxels in classes above c = position of class c's first record.
+constexpr int kVoxClasses = 18;
+__host__ __device__ inline int vp_class(int n) {
+    if (n <= 0) return 0;
+    if (n <= 4) return 1;
+    if (n <= 8) return 2;
+    if (n <= 16) return 3;
+    if (n <= 32) return 4;
+    if (n <= 320) return 5 + (n - 33) / 32;
+    if (n <= 640) return 14;
+    if (n <= 1280) return 15;
+    if (n <= 2560) return 16;
+    return 17;
+}
 
 // Voxels holding more than kLongRun points ("long runs" of the sorted slot list) are listed in the plan and summed by
 // dedicated workgroups of the gather launch; every other voxel is summed by the one wave whose slot range contains its
@@ -137,7 +153,8 @@ PlanLayout plan_layout(int B, int N, int X, int Y) {
     L.long_cap = (int)(L.total / kLongRun) + 1;
     L.off_perm = al(L.off_long + sizeof(int) * (size_t)(L.long_cap + 1));
     L.off_bins = al(L.off_perm + sizeof(int) * 4 * (size_t)L.V);      // perm: {voxel, first slot, end slot, 0} per voxel
-    L.bytes = al(L.off_bins + sizeof(int) * 3 * (size_t)kLenBins);
+    L.ncw = cdiv(L.V, kBlock);                                         // workgroups of the class sort (256 voxels each)
+    L.bytes = al(L.off_bins + sizeof(int) * ((size_t)kVoxClasses * L.ncw + kVoxClasses + 2));
     return L;
 }
 
@@ -377,70 +394,81 @@ __global__ __launch_bounds__(kBlock) void vp_fill_kernel(long long total_pts, in
     }
 }
 
-// ---- voxels by descending population (perm), for the voxel-owner gather --------------------------------------------------
-__global__ __launch_bounds__(kBlock) void vp_len_hist_kernel(long long V, const int *__restrict__ seg_start,
-                                                             int *__restrict__ bins, const int *__restrict__ dirty) {
+// ---- voxels by population class, stable in voxel order (perm), for the voxel-owner gather ------------------------------------
+// tbl[c * ncw + b] = number of class-c voxels among the 256 voxels of workgroup b
+__global__ __launch_bounds__(kBlock) void vp_cls_count_kernel(long long V, const int *__restrict__ seg_start, int ncw,
+                                                              int *__restrict__ tbl, const int *__restrict__ dirty) {
     VP_SKIP_IF_CLEAN(dirty);
-    __shared__ int h[kLenBins];
-    for (int i = threadIdx.x; i < kLenBins; i += kBlock) h[i] = 0;
-    __syncthreads();
-    for (long long v = (long long)blockIdx.x * kBlock + threadIdx.x; v < V; v += (long long)gridDim.x * kBlock) {
-        const int n = seg_start[v + 1] - seg_start[v];
-        atomicAdd(&h[n < kLenBins - 1 ? n : kLenBins - 1], 1);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kLenBins; i += kBlock)
-        if (h[i] != 0) atomicAdd(bins + i, h[i]);
-}
-
-// one workgroup: bin_start over the keys in the order kLenBins-1, ..., 1, 0; clears the scatter cursors
-__global__ __launch_bounds__(kBlock) void vp_len_scan_kernel(int *__restrict__ bins, const int *__restrict__ dirty) {
-    VP_SKIP_IF_CLEAN(dirty);
-    __shared__ int wave_tot[kBlock / 64];
-    constexpr int per = kLenBins / kBlock;
-    // position r in scan order holds key (kLenBins - 1 - r) for r < kLenBins - 1, key 0 for the last position
-    int v[per], sum = 0;
-#pragma unroll
-    for (int i = 0; i < per; ++i) {
-        const int r = threadIdx.x * per + i;
-        const int key = r < kLenBins - 1 ? kLenBins - 1 - r : 0;
-        v[i] = bins[key];
-        sum += v[i];
-    }
-    int tot;
-    int run = block_exclusive_scan(sum, wave_tot, tot);
-#pragma unroll
-    for (int i = 0; i < per; ++i) {
-        const int r = threadIdx.x * per + i;
-        const int key = r < kLenBins - 1 ? kLenBins - 1 - r : 0;
-        bins[kLenBins + key] = run;
-        bins[2 * kLenBins + key] = 0;
-        run += v[i];
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void vp_len_scatter_kernel(long long V, const int *__restrict__ seg_start,
-                                                                int *__restrict__ bins, int *__restrict__ perm,
-                                                                const int *__restrict__ dirty) {
-    VP_SKIP_IF_CLEAN(dirty);
-    // per workgroup: local histogram of its voxels -> one global reservation per key present -> local ranks.  The order of
-    // the voxels inside a key is whatever the atomics give: every voxel is summed on its own, so results do not depend on it.
-    __shared__ int h[kLenBins];
-    __shared__ int base[kLenBins];
-    for (int i = threadIdx.x; i < kLenBins; i += kBlock) h[i] = 0;
+    __shared__ int h[kVoxClasses];
+    if (threadIdx.x < kVoxClasses) h[threadIdx.x] = 0;
     __syncthreads();
     const long long v = (long long)blockIdx.x * kBlock + threadIdx.x;
-    int key = -1, rank = 0;
-    if (v < V) {
-        const int n = seg_start[v + 1] - seg_start[v];
-        key = n < kLenBins - 1 ? n : kLenBins - 1;
-        rank = atomicAdd(&h[key], 1);
+    const int c = v < V ? vp_class(seg_start[v + 1] - seg_start[v]) : -1;
+#pragma unroll
+    for (int k = 0; k < kVoxClasses; ++k) {
+        const unsigned long long m = __ballot(c == k);
+        if ((threadIdx.x & 63) == 0 && m != 0ull) atomicAdd(&h[k], __popcll(m));
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kLenBins; i += kBlock)
-        if (h[i] != 0) base[i] = bins[kLenBins + i] + atomicAdd(bins + 2 * kLenBins + i, h[i]);
+    if (threadIdx.x < kVoxClasses) tbl[threadIdx.x * ncw + blockIdx.x] = h[threadIdx.x];
+}
+
+// one workgroup: exclusive scan of the table in perm order (class kVoxClasses-1 first, class 0 last; workgroups ascending
+// inside a class), in place; cls[c] = position of class c's first record
+__global__ __launch_bounds__(kBlock) void vp_cls_scan_kernel(int ncw, int *__restrict__ tbl, int *__restrict__ cls,
+                                                             const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    __shared__ int wave_tot[kBlock / 64];
+    int carry = 0;
+    for (int c = kVoxClasses - 1; c >= 0; --c) {
+        if (threadIdx.x == 0) cls[c] = carry;
+        int *row = tbl + (size_t)c * ncw;
+        for (int b0 = 0; b0 < ncw; b0 += kBlock * kScanPerThread) {
+            int v[kScanPerThread], sum = 0;
+            const int base = b0 + threadIdx.x * kScanPerThread;
+#pragma unroll
+            for (int i = 0; i < kScanPerThread; ++i) {
+                v[i] = base + i < ncw ? row[base + i] : 0;
+                sum += v[i];
+            }
+            int tot;
+            int run = carry + block_exclusive_scan(sum, wave_tot, tot);
+#pragma unroll
+            for (int i = 0; i < kScanPerThread; ++i) {
+                if (base + i < ncw) row[base + i] = run;
+                run += v[i];
+            }
+            carry += tot;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void vp_cls_scatter_kernel(long long V, const int *__restrict__ seg_start, int ncw,
+                                                                const int *__restrict__ tbl, int *__restrict__ perm,
+                                                                const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    __shared__ int wcnt[kBlock / 64][kVoxClasses];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const long long v = (long long)blockIdx.x * kBlock + threadIdx.x;
+    int s0 = 0, s1 = 0, c = -1;
+    if (v < V) {
+        s0 = seg_start[v];
+        s1 = seg_start[v + 1];
+        c = vp_class(s1 - s0);
+    }
+    int rank = 0;
+#pragma unroll
+    for (int k = 0; k < kVoxClasses; ++k) {                       // stable: rank = earlier voxels of the same class
+        const unsigned long long m = __ballot(c == k);
+        if (c == k) rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[wid][k] = __popcll(m);
+    }
     __syncthreads();
-    if (key >= 0) reinterpret_cast<int4 *>(perm)[base[key] + rank] = make_int4((int)v, seg_start[v], seg_start[v + 1], 0);
+    if (c >= 0) {
+        int pos = tbl[c * ncw + blockIdx.x] + rank;
+        for (int w = 0; w < wid; ++w) pos += wcnt[w][c];
+        reinterpret_cast<int4 *>(perm)[pos] = make_int4((int)v, s0, s1, 0);
+    }
 }
 
 // Segments of lo+1 .. 64*R points: one wave per voxel, the list lives in R registers per lane
@@ -1294,20 +1322,21 @@ __global__ __launch_bounds__(kBlock) void vp_gather_fast_kernel(const VpFastArgs
 // book-keeping of runs that start and end anywhere inside a wave's window (ballots, per-slot boundary selects, stitching);
 // it is issue-bound -- harmless for the operator, whose rows come from HBM, but the fused lift-splat form reads its rows from
 // the L2-resident context map and ran at 0.15 of its byte roofline.  Here NOTHING is cut at arbitrary places: the plan lists
-// the voxels by descending population (perm, bin_start) and a row group of lanes owns a whole voxel (or a whole, evenly cut
+// the voxels by population class (perm, cls) and a row group of lanes owns a whole voxel (or a whole, evenly cut
 // piece of one), so the inner loop is "16 rows in flight, 16 adds" and a voxel is emitted exactly once:
-//   * population <= 32                one row group per voxel, `groups` voxels per wave (neighbours in perm have (almost)
-//                                     the same population, so the groups of a wave finish together);
+//   * population <= 32                one row group per voxel, `groups` voxels per wave (neighbours in perm are of one
+//                                     population class, so the groups of a wave finish together); <= 4 / <= 8 points: four /
+//                                     two voxels share a row group's batch;
 //   * 32 < population <= 32 * groups  one wave per voxel: `groups` equal pieces, added in piece order;
 //   * larger                          one workgroup per voxel: 4 * groups equal pieces; a wave adds its pieces in order, the
 //                                     four wave sums meet in LDS and are added in wave order.
 // Fixed association per (population, channel count) => bit-reproducible.  Work is dealt with a static stride over a grid that
-// is resident at once (perm is in descending order, so every wave gets the same mix of long and short voxels and the
-// longest start first); rows of empty voxels are zeroed by a walk over contiguous voxel ranges.  All loops are bounded by
+// is resident at once (perm goes from the largest class to the smallest, so every wave gets the same mix and the largest
+// voxels start first); rows of empty voxels are zeroed by a walk over contiguous voxel ranges.  All loops are bounded by
 // counts read from the plan, every wave reaches the end of the kernel.
 // ------------------------------------------------------------------------------------------------
 struct VpVoxArgs {
-    const int *order, *bin_start, *seg_start;
+    const int *order, *cls, *seg_start;     // cls[c] = number of voxels in population classes above c (vp_class)
     const int4 *perm;       // {voxel, first slot, end slot, 0} by descending population
     const void *feats;
     void *out;
@@ -1323,6 +1352,11 @@ struct VpVoxArgs {
 
 // floor(n / d) for 0 <= n < 2^31, d >= 2, as umulhi(n, mag) >> sh (a round-up magic number of 32 bits is exact for 31-bit
 // dividends); the fused gather turns every point id into (sample, pixel) with it instead of two hardware-emulated divisions
+__device__ __forceinline__ int vp_wave_max(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
 struct VpMagic { unsigned mag; int sh; };
 VpMagic vp_magic(int d) {
     VpMagic m{0u, 0};
@@ -1336,7 +1370,6 @@ VpMagic vp_magic(int d) {
 __device__ __forceinline__ int vp_fast_div(int n, int d, unsigned mag, int sh) {
     return d == 1 ? n : (int)(__umulhi((unsigned)n, mag) >> sh);
 }
-constexpr int kVoxShort = 32;    // populations up to this are summed by one row group
 constexpr int kVoxGrid = 2048;   // workgroups: 8 per CU (VB = 8: <= 72 VGPRs, 7 waves per SIMD), each wave ~one small item
 
 // acc += rows of the slots [pb, pe) in slot order, `vb` <= VB at a time; `maxlen` >= pe - pb is wave-uniform (the longest piece
@@ -1403,17 +1436,17 @@ __device__ __forceinline__ void vp_vox_small(int lo, int hi, int gw, int nwaves,
     const int n_items = (hi - lo + groups * J - 1) / (groups * J);
     const int myj = cl / W, myo = cl - myj * W;                   // (index lanes: cl < VB)
     for (int i = gw; i < n_items; i += nwaves) {                  // wave-uniform
-        int vox[J], pb = 0, pe = 0, len0 = 0;
+        int vox[J], pb = 0, pe = 0, lenmax = 0;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int vi = lo + (i * groups + g) * J + j;
             int4 rec = make_int4(-1, 0, 0, 0);
             if (ingroup && vi < hi) rec = a.perm[vi];
             vox[j] = rec.x;
-            if (j == 0) len0 = rec.z - rec.y;
+            lenmax = max(lenmax, rec.z - rec.y);
             if (myj == j) { pb = rec.y; pe = rec.z; }
         }
-        const int n = min(W, __shfl(len0, 0, 64));               // the largest population of the item (perm is descending)
+        const int n = min(W, vp_wave_max(lenmax));               // the largest population of the item
         const int slot = pb + myo;
         int my_idx = -1;
         if (ingroup && cl < VB && slot < pe) my_idx = a.order[slot];
@@ -1495,15 +1528,15 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
     const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
     const int nwaves = (int)gridDim.x * (kBlock / 64);
     const int gw = (int)blockIdx.x * (kBlock / 64) + wid;
-    const int nonempty = a.bin_start[0];
-    const int n_mid_end = a.bin_start[kVoxShort];                // perm[0 .. n_mid_end): populations above kVoxShort
-    const int n_long = a.bin_start[kVoxShort * groups];          // perm[0 .. n_long): above kVoxShort * groups (<= 320 < kLenBins)
+    const int nonempty = a.cls[0];
+    const int n_mid_end = a.cls[4];                              // perm[0 .. n_mid_end): populations above 32 (up to 32: one row group)
+    const int n_long = a.cls[3 + groups];                        // perm[0 .. n_long): above 32 * groups (classes step by 32 up to 320)
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int kill = (a.dbg & 2) ? -1 : 0;                      // (probe: v | kill = -1 drops every row store)
     // populations 1 .. 4 and 5 .. 8 share a batch (four / two voxels per row group) when the batch has 16 slots
     const bool pack = VB == 16 && vb == 16;
-    const int n8 = pack ? a.bin_start[8] : nonempty;              // perm[n_mid_end .. n8): 9 .. 32 points (one voxel per row group)
-    const int n4 = pack ? a.bin_start[4] : nonempty;              // perm[n8 .. n4): 5 .. 8 points; perm[n4 .. nonempty): 1 .. 4
+    const int n8 = pack ? a.cls[2] : nonempty;                    // perm[n_mid_end .. n8): 9 .. 32 points (one voxel per row group)
+    const int n4 = pack ? a.cls[1] : nonempty;                    // perm[n8 .. n4): 5 .. 8 points; perm[n4 .. nonempty): 1 .. 4
     // ---------------------------------------------------------------- rows of empty voxels (not in ACC mode)
     if (!ACC && !(a.dbg & 1)) {
         // Every row group walks a CONTIGUOUS range of voxel ids and zeroes the empty ones it finds in seg_start (eight
@@ -1580,7 +1613,7 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
             const int4 rec = a.perm[vi];
             v = rec.x; pb = rec.y; pe = rec.z;
         }
-        const int maxlen = __shfl(pe - pb, 0, 64);               // group 0 holds the largest (perm: descending population)
+        const int maxlen = vp_wave_max(pe - pb);                 // (a class spans a factor of two in population)
         float4 acc = zero4;
         vp_vox_piece<FB, FUSED, VB>(acc, pb, pe, maxlen, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
         vp_buf_emit<OB, ACC>(o_rsrc, v | kill, row_out, lane_out, pad_off, acc);
@@ -1694,7 +1727,7 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
                 VpVoxArgs a;
                 a.order = order; a.seg_start = seg;
                 a.perm = reinterpret_cast<const int4 *>(base + L.off_perm);
-                a.bin_start = reinterpret_cast<const int *>(base + L.off_bins) + kLenBins;
+                a.cls = reinterpret_cast<const int *>(base + L.off_bins) + (size_t)kVoxClasses * L.ncw;
                 a.feats = FUSED ? static_cast<const void *>(ctx) : static_cast<const void *>(feats); a.out = out; a.gate = gate;
                 a.prob = prob; a.P = P;
                 a.feat_bytes = (unsigned)fbytes; a.out_bytes = (unsigned)obytes;
@@ -1804,14 +1837,13 @@ int plan_build_impl(int batch_size, int num_points, int num_voxel_x, int num_vox
     hipLaunchKernelGGL(vp_scan_add_kernel, dim3(cdiv(L.V + 1, kBlock)), dim3(kBlock), 0, st, L.V, L.nblk, blk,
                        seg, cur, dirty);
     hipLaunchKernelGGL(vp_long_list_kernel, dim3(cdiv(L.V, kBlock)), dim3(kBlock), 0, st, L.V, seg, long_list, L.long_cap, dirty);
-    {   // voxels by descending population (the voxel-owner gather's work list)
-        int *bins = reinterpret_cast<int *>(base + L.off_bins);
+    {   // voxels by population class, in voxel order inside a class (the voxel-owner gather's work list)
+        int *tbl = reinterpret_cast<int *>(base + L.off_bins);
+        int *cls = tbl + (size_t)kVoxClasses * L.ncw;
         int *perm = reinterpret_cast<int *>(base + L.off_perm);
-        hipLaunchKernelGGL(vp_zero_kernel, dim3(cdiv(kLenBins, kBlock)), dim3(kBlock), 0, st, (long long)kLenBins, bins, dirty);
-        const int hgrid = cdiv(L.V, kBlock) < 512 ? cdiv(L.V, kBlock) : 512;
-        hipLaunchKernelGGL(vp_len_hist_kernel, dim3(hgrid), dim3(kBlock), 0, st, L.V, seg, bins, dirty);
-        hipLaunchKernelGGL(vp_len_scan_kernel, dim3(1), dim3(kBlock), 0, st, bins, dirty);
-        hipLaunchKernelGGL(vp_len_scatter_kernel, dim3(cdiv(L.V, kBlock)), dim3(kBlock), 0, st, L.V, seg, bins, perm, dirty);
+        hipLaunchKernelGGL(vp_cls_count_kernel, dim3(L.ncw), dim3(kBlock), 0, st, L.V, seg, L.ncw, tbl, dirty);
+        hipLaunchKernelGGL(vp_cls_scan_kernel, dim3(1), dim3(kBlock), 0, st, L.ncw, tbl, cls, dirty);
+        hipLaunchKernelGGL(vp_cls_scatter_kernel, dim3(L.ncw), dim3(kBlock), 0, st, L.V, seg, L.ncw, tbl, perm, dirty);
     }
     hipLaunchKernelGGL(vp_fill_kernel, dim3(pgrid), dim3(kBlock), 0, st, L.total, num_points, num_voxel_x,
                        num_voxel_y, num_voxel_z, geom_xyz, cur, order, reinterpret_cast<int *>(base + L.off_slotvox), dirty, seg);
