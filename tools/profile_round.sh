@@ -5,8 +5,11 @@
 set -u
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/profiles_$TAG
-mkdir -p $OUT
+# raw rocprofv3 output (kernel traces, counter collections: > 64 MiB, more than gpurun copies back) stays on the box under /tmp;
+# the small summaries tools/summarize_profiles.py makes of it go to gpurun_out/profiles_<tag>/ and from there, by hand, to profiles/
+OUT=/tmp/sgv3d_profiles_$TAG
+KEEP=$R/gpurun_out/profiles_$TAG
+rm -rf $OUT; mkdir -p $OUT $KEEP
 export TMPDIR=/tmp
 cd /tmp
 # (tile / split-K choices come from the committed tune DB, tune/gfx950_*.json: every run below makes the same ones)
@@ -41,3 +44,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_harness -
 python3 $R/tools/vp_probe3.py > $OUT/${TAG}_gather_probe.txt 2> $OUT/gather_probe.err
 SGV3D_VP_KERNEL=slot python3 $R/tools/vp_probe3.py >> $OUT/${TAG}_gather_probe.txt 2>> $OUT/gather_probe.err
 ls -la $OUT | head -60
+python3 $R/tools/summarize_profiles.py $OUT $TAG $KEEP > $KEEP/summarize.log 2>&1
+cp $OUT/*.err $KEEP/ 2>/dev/null
+ls -la $KEEP

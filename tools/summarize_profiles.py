@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the raw rocprofv3 CSVs of tools/profile_round.sh into the small files kept under profiles/.
 
-    python tools/summarize_profiles.py gpurun_out/profiles_r01 r01
+    python tools/summarize_profiles.py <dir with the raw CSVs> r01 [<destination>, default profiles/]
 """
 import collections
 import csv
@@ -12,7 +12,7 @@ import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dst = os.path.join(ROOT, "profiles")
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
