@@ -153,3 +153,40 @@ def test_reference_eval_step_through_the_drop_in(hip):
         for (wb, ws, wl, wm), (gb, gs, gl, gm) in zip(w, g):
             assert isinstance(gb, np.ndarray) and gb.ndim == 2 and gb.shape[1] == 9 and gs.shape == gl.shape == (gb.shape[0],)
             assert np.array_equal(wb, gb) and np.array_equal(ws, gs) and np.array_equal(wl, gl) and wm == gm
+
+
+def test_graph_backed_forward_with_two_sweeps(hip):
+    """num_sweeps = 2 through the whole model (the BEV head's trunk takes 2 x 80 channels): the graph's calibration branch
+    refreshes one cache entry per sweep, and a replay after BOTH sweeps' cameras moved equals the eager forward."""
+    from sgv3d_amd import synthetic as S
+    from sgv3d_amd.models.bev_height import BEVHeight
+    bc, hc = S.small_conf(depth=18)
+    hc['bev_backbone_conf'] = dict(hc['bev_backbone_conf'], in_channels=2 * bc['output_channels'])
+    hc['bev_neck_conf'] = dict(hc['bev_neck_conf'], in_channels=[2 * bc['output_channels']] + list(hc['bev_neck_conf']['in_channels'][1:]))
+    torch.manual_seed(2)
+    model = BEVHeight(bc, hc).eval()
+    S.randomize_norm_stats_(model, 1)
+    model = model.cuda()
+    scale = bc['final_dim'][0] / 864
+
+    def mats_for(shift):
+        a, b = S.make_mats(1, device='cuda', scale=scale), S.make_mats(1, device='cuda', scale=scale)
+        b['sensor2ego_mats'][:, :, :, 2, 3] += 0.35 + shift
+        b['reference_heights'] += 0.35 + shift
+        a['sensor2ego_mats'][:, :, :, 2, 3] += shift
+        a['reference_heights'] += shift
+        return {k: (a[k] if k == 'bda_mat' else torch.cat([a[k], b[k]], 1)) for k in a}
+    imgs = torch.cat([S.make_images(1, bc['final_dim'], device='cuda', seed=31), S.make_images(1, bc['final_dim'], device='cuda', seed=32)], 1)
+    m0, m1 = mats_for(0.0), mats_for(0.6)
+    with torch.no_grad():
+        model.graph_forward = False
+        want0, want1 = model(imgs, m0), model(imgs, m1)
+        assert not torch.equal(want0[0][0]['heatmap'], want1[0][0]['heatmap'])
+        model.graph_forward = True
+        model(imgs, m0)
+        _assert_same(want0, model(imgs, m0))
+        _assert_same(want1, model(imgs, m1))
+        _assert_same(want0, model(imgs, {k: v.clone() for k, v in m0.items()}))
+    torch.cuda.synchronize()
+    (entry,) = model._graphs.values()
+    assert entry[1].replays == 3
