@@ -544,6 +544,11 @@ def main():
                                                       pmz.data_ptr(), _L.stream_handle(dev))
         level1_us = time_us(l1) if Cvp % 4 == 0 and 24 <= Cvp <= 256 else None
         del outz, pmz
+        # level 2 of INTEGRATION.md: the Python operator with the reference's signature, as a caller that swaps only the import
+        # uses it -- a fresh output tensor per call, geom_xyz handed in every time (no VoxelPlan object in the caller's hands)
+        from sgv3d_amd.ops.voxel_pooling import voxel_pooling as vp_op
+        with torch.no_grad():
+            op_us = time_us(lambda: vp_op(flat, feats, (X, Y, Zv)))
         roofline_hbm = {
             "bound": "hbm", "kernel": k_op + " (sgv3d_voxel_pooling_forward_planned: one launch, no fix-up pass)",
             "bytes": alg, "us": pool_us, "achieved": alg / pool_us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -553,13 +558,15 @@ def main():
             "frac_including_check": alg / (pool_us + clean_us) / 1e3 / HBM_PEAK_GBPS if clean_us else None,
             "plan_builds_in_timed_region": calib["plan_builds_in_timed_region"],
             "model_path_lift_splat_us": lift_splat_us, "fused_lift_splat": fused_rec,
+            "python_op_us": op_us, "frac_python_op": alg / op_us / 1e3 / HBM_PEAK_GBPS,
             "level1_ext_us": level1_us,
             "frac_level1_ext": alg / level1_us / 1e3 / HBM_PEAK_GBPS if level1_us else None,
             "note": "the plan depends only on the calibration: built once per calibration outside the captured forward "
                     "(frac_including_plan = if it were rebuilt on every frame, as the reference-style operator call with "
                     "ever-changing geom_xyz would; frac_including_check = operator call with an unchanged geom_xyz: "
                     "device-side compare + empty build launches; frac_level1_ext = the reference wrapper's own call into "
-                    "voxel_pooling_ext, which keeps a plan per stream inside the library; model_path_lift_splat_us = what the timed "
+                    "voxel_pooling_ext, which keeps a plan per stream inside the library; frac_python_op = the Python operator "
+                    "voxel_pooling(geom_xyz, feats, voxel_num) called eagerly, output allocation and zero fill included; model_path_lift_splat_us = what the timed "
                     "model launches instead of lift + this operator: the same gather forming its rows as prob * context, so the "
                     "[B,N,C] lifted tensor -- most of the operator's bytes -- is neither written nor read)",
             "method": pool_method + ", N(0,1) features on this run's geometry",

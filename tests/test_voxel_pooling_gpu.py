@@ -314,14 +314,29 @@ def test_cached_plan_rebuilds_only_on_change(hip):
     assert plan.builds() == 3 and torch.equal(plan.pool(feats), want)
     with pytest.raises(AssertionError):
         VoxelPlan(geom, (X, Y, 1), cached=True, pos_memo=torch.empty(B, N, 3, dtype=torch.int32, device=DEV))
-    # operator level: consecutive frames of one camera
-    VPM._PLAN_CACHE.clear()
+    # operator level: consecutive frames of one camera.  C = 80 goes through the library's own plan cache (the level-1
+    # entry): three calls, all through a plan entry, the changed geometry served at once (gated scatter) ...
+    hip.check(hip.load().sgv3d_voxel_pooling_cache_clear(), "clear")
+    s0 = _l1_stats(hip)
     o1 = voxel_pooling(geom, feats, (X, Y, 1))
     o2 = voxel_pooling(geom.clone(), feats, (X, Y, 1))
     o3 = voxel_pooling(g2, feats, (X, Y, 1))
+    torch.cuda.synchronize()
+    o4 = voxel_pooling(g2, feats, (X, Y, 1))                   # ... and by the rebuilt plan a call later
+    s1 = _l1_stats(hip)
+    assert s1[0] - s0[0] == 4 and s1[1] - s0[1] == 4 and s1[3] - s0[3] == 2
+    assert torch.equal(o1, want.permute(0, 3, 1, 2)) and torch.equal(o2, o1) and not torch.equal(o3, o1) and torch.equal(o4, o3)
+    assert torch.equal(o3, VoxelPlan(g2, (X, Y, 1)).pool(feats).permute(0, 3, 1, 2))
+    hip.check(hip.load().sgv3d_voxel_pooling_cache_clear(), "clear")
+    # ... a channel count the level-1 gather does not cover keeps the operator's own cached plan
+    VPM._PLAN_CACHE.clear()
+    f6 = feats[..., :6].contiguous()
+    p1 = voxel_pooling(geom, f6, (X, Y, 1))
+    p2 = voxel_pooling(geom.clone(), f6, (X, Y, 1))
+    p3 = voxel_pooling(g2, f6, (X, Y, 1))
     (cached_plan,) = VPM._PLAN_CACHE.values()
     assert cached_plan.builds() == 2
-    assert torch.equal(o1, want.permute(0, 3, 1, 2)) and torch.equal(o2, o1) and not torch.equal(o3, o1)
+    assert torch.equal(p1, want[..., :6].permute(0, 3, 1, 2)) and torch.equal(p2, p1) and not torch.equal(p3, p1)
     VPM._PLAN_CACHE.clear()
 
 
