@@ -104,21 +104,23 @@ struct PlanLayout {
 // dependent loads, not by bytes), and consecutive records are spatial neighbours: their points are neighbours in the lifted
 // tensor, so the rows the operator form pulls from HBM share cache lines with the rows of the wave next door (a sort by exact
 // population, which the first version used, lost that: 270 against 232 us for the slot-balanced kernel on cfg-3's sparse grid).
-// Classes: 0 = empty | 1-4 | 5-8 | 9-16 | 17-32 | 33-64 | 65-96 | ... | 289-320 (steps of 32: the one-wave / one-workgroup
-// border is 32 x row groups) | 321-640 | 641-1280 | 1281-2560 | more.  cls[c] (kVoxClasses ints after the table) = number of
-// voxels in classes above c = position of class c's first record.
-constexpr int kVoxClasses = 18;
+// Classes: 0 = empty | every population 1 .. 32 its own class (the row groups of a wave then run the same number of rows: a
+// coarser split -- 1-4 | 5-8 | 9-16 | 17-32 -- cost cfg-2's fused launch 2.3 us in rows added for nothing) | 33-64 | 65-96 | ... |
+// 289-320 (steps of 32: the one-wave / one-workgroup border is 32 x row groups) | then steps of a factor 1.25 up to 4 655 | more
+// (the workgroup-per-voxel items are dealt with a static stride: near-equal populations side by side keep the workgroups'
+// shares even).  cls[c] (kVoxClasses ints after the table) = number of voxels in classes above c = position of class c's
+// first record.
+constexpr int kVoxClasses = 55;
 __host__ __device__ inline int vp_class(int n) {
     if (n <= 0) return 0;
-    if (n <= 4) return 1;
-    if (n <= 8) return 2;
-    if (n <= 16) return 3;
-    if (n <= 32) return 4;
-    if (n <= 320) return 5 + (n - 33) / 32;
-    if (n <= 640) return 14;
-    if (n <= 1280) return 15;
-    if (n <= 2560) return 16;
-    return 17;
+    if (n <= 32) return n;
+    if (n <= 320) return 33 + (n - 33) / 32;            // 33 .. 41
+    int c = 42, hi = 400;
+    while (c < kVoxClasses - 1 && n > hi) {              // 42 .. 53: (320, 400], (400, 500], ... x 1.25
+        hi += hi >> 2;
+        ++c;
+    }
+    return c;
 }
 
 // Voxels holding more than kLongRun points ("long runs" of the sorted slot list) are listed in the plan and summed by
@@ -1352,10 +1354,12 @@ struct VpVoxArgs {
 
 // floor(n / d) for 0 <= n < 2^31, d >= 2, as umulhi(n, mag) >> sh (a round-up magic number of 32 bits is exact for 31-bit
 // dividends); the fused gather turns every point id into (sample, pixel) with it instead of two hardware-emulated divisions
-__device__ __forceinline__ int vp_wave_max(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-    return v;
+// max over the row groups of a group-uniform value (lane g * lpr speaks for group g): `groups` v_readlane, no LDS crossbar
+// (six dependent ds_bpermute of a butterfly cost ~400 cycles of latency per work item)
+__device__ __forceinline__ int vp_group_max(int v, int lpr, int groups) {
+    int m = __builtin_amdgcn_readlane(v, 0);
+    for (int g2 = 1; g2 < groups; ++g2) m = max(m, __builtin_amdgcn_readlane(v, g2 * lpr));
+    return m;
 }
 struct VpMagic { unsigned mag; int sh; };
 VpMagic vp_magic(int d) {
@@ -1428,7 +1432,7 @@ __device__ __forceinline__ void vp_vox_piece(float4 &acc, int pb, int pe, int ma
 // a batch per voxel would run the loads, the index exchange and the emit for one to four rows.  perm[lo .. hi) in descending
 // population; item i of the wave = voxels lo + (i groups + g) J + j.
 template <bool FB, bool OB, bool ACC, bool FUSED, int VB, int J>
-__device__ __forceinline__ void vp_vox_small(int lo, int hi, int gw, int nwaves, int cl, bool ingroup, int g, int gs, int groups,
+__device__ __forceinline__ void vp_vox_small(int lo, int hi, int gw, int nwaves, int cl, bool ingroup, int g, int gs, int groups, int lpr,
                                              __amdgpu_buffer_rsrc_t f_rsrc, __amdgpu_buffer_rsrc_t o_rsrc, unsigned row_in,
                                              unsigned lane_in, unsigned row_out, unsigned lane_out, unsigned pad_off, int kill,
                                              int *idw, float *prw, const VpVoxArgs &a) {
@@ -1446,7 +1450,7 @@ __device__ __forceinline__ void vp_vox_small(int lo, int hi, int gw, int nwaves,
             lenmax = max(lenmax, rec.z - rec.y);
             if (myj == j) { pb = rec.y; pe = rec.z; }
         }
-        const int n = min(W, vp_wave_max(lenmax));               // the largest population of the item
+        const int n = min(W, vp_group_max(lenmax, lpr, groups)); // the largest population of the item
         const int slot = pb + myo;
         int my_idx = -1;
         if (ingroup && cl < VB && slot < pe) my_idx = a.order[slot];
@@ -1529,24 +1533,37 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
     const int nwaves = (int)gridDim.x * (kBlock / 64);
     const int gw = (int)blockIdx.x * (kBlock / 64) + wid;
     const int nonempty = a.cls[0];
-    const int n_mid_end = a.cls[4];                              // perm[0 .. n_mid_end): populations above 32 (up to 32: one row group)
-    const int n_long = a.cls[3 + groups];                        // perm[0 .. n_long): above 32 * groups (classes step by 32 up to 320)
+    const int n_mid_end = a.cls[32];                             // perm[0 .. n_mid_end): populations above 32 (up to 32: one row group)
+    const int n_long = a.cls[31 + groups];                       // perm[0 .. n_long): above 32 * groups (classes step by 32 up to 320)
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int kill = (a.dbg & 2) ? -1 : 0;                      // (probe: v | kill = -1 drops every row store)
     // populations 1 .. 4 and 5 .. 8 share a batch (four / two voxels per row group) when the batch has 16 slots
-    const bool pack = VB == 16 && vb == 16;
-    const int n8 = pack ? a.cls[2] : nonempty;                    // perm[n_mid_end .. n8): 9 .. 32 points (one voxel per row group)
-    const int n4 = pack ? a.cls[1] : nonempty;                    // perm[n8 .. n4): 5 .. 8 points; perm[n4 .. nonempty): 1 .. 4
+    const bool pack = VB == 16 && vb == 16 && !(a.dbg & 16);
+    const int n8 = pack ? a.cls[8] : nonempty;                    // perm[n_mid_end .. n8): 9 .. 32 points (one voxel per row group)
+    const int n4 = pack ? a.cls[4] : nonempty;                    // perm[n8 .. n4): 5 .. 8 points; perm[n4 .. nonempty): 1 .. 4
     // ---------------------------------------------------------------- rows of empty voxels (not in ACC mode)
     if (!ACC && !(a.dbg & 1)) {
-        // Every row group walks a CONTIGUOUS range of voxel ids and zeroes the empty ones it finds in seg_start (eight
-        // look-ups in flight).  On the 512 x 512 grid of cfg-3 nine voxels in ten are empty -- 335 MB of zero rows -- and
-        // writing them in the order of perm's tail (whatever the plan's atomics gave) ran at half the rate of this walk,
-        // whose stores of one group are consecutive rows.
+        // perm's tail lists the empty voxels (in voxel order): eight records in flight per row group, then eight row stores.
+        // (The alternative -- every row group walks a contiguous range of voxel ids and zeroes the empty ones it finds in
+        // seg_start -- measured equal or slower everywhere but the fused form on cfg-3's grid, by 4 %.)
         constexpr int EU = 8;
         const int ngr = nwaves * groups;
         const int per = (a.V + ngr - 1) / ngr;
         const int v0 = (gw * groups + (ingroup ? g : 0)) * per;
+        if (!(a.dbg & 8)) {                                       // the zero rows from perm's tail (probe bit 8: the walk below)
+            const int n_rows = (a.V - nonempty + groups - 1) / groups;
+            for (int i0 = gw * EU; i0 < n_rows; i0 += nwaves * EU) {
+                int v[EU];
+#pragma unroll
+                for (int u = 0; u < EU; ++u) {
+                    const int vi = nonempty + (i0 + u) * groups + g;
+                    v[u] = -1;
+                    if (ingroup && i0 + u < n_rows && vi < a.V) v[u] = a.perm[vi].x;
+                }
+#pragma unroll
+                for (int u = 0; u < EU; ++u) vp_buf_emit<OB, false>(o_rsrc, v[u], row_out, lane_out, pad_off, zero4);
+            }
+        } else
         for (int i0 = 0; i0 < per; i0 += EU) {                    // uniform trip count
             int s[EU + 1];
 #pragma unroll
@@ -1564,6 +1581,9 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
     }
 
     // ---------------------------------------------------------------- the largest voxels: one workgroup each
+    // Every phase deals its items with a static stride, and every phase continues where the previous one stopped (`woff`, in
+    // waves): started at wave 0 each, the first few hundred workgroups got a large voxel, a middle one AND three small items in
+    // a row while most of the grid only wrote zero rows.
     for (int i = (int)blockIdx.x; i < n_long; i += (int)gridDim.x) {      // block-uniform
         const int4 rec = a.perm[i];
         const int v = rec.x, b = rec.y, e = rec.z;
@@ -1589,7 +1609,8 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
         __syncthreads();
     }
     // ---------------------------------------------------------------- middle populations: one wave each, `groups` pieces
-    for (int i = n_long + gw; i < n_mid_end; i += nwaves) {       // wave-uniform (empty when groups == 1)
+    int woff = (n_long % (int)gridDim.x) * (kBlock / 64);
+    for (int i = n_long + (gw - woff + nwaves) % nwaves; i < n_mid_end; i += nwaves) {       // wave-uniform (empty when groups == 1)
         const int4 rec = a.perm[i];
         const int v = rec.x, b = rec.y, e = rec.z;
         const int psz = (e - b + groups - 1) / groups;
@@ -1606,23 +1627,28 @@ __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a
     }
     // ---------------------------------------------------------------- small populations: one row group each
     const int n_small = (n8 - n_mid_end + groups - 1) / groups;
-    for (int i = gw; i < n_small; i += nwaves) {                  // wave-uniform
+    woff = (woff + n_mid_end - n_long) % nwaves;
+    for (int i = (gw - woff + nwaves) % nwaves; i < n_small; i += nwaves) {                  // wave-uniform
         const int vi = n_mid_end + i * groups + g;
         int v = -1, pb = 0, pe = 0;
         if (ingroup && vi < n8) {
             const int4 rec = a.perm[vi];
             v = rec.x; pb = rec.y; pe = rec.z;
         }
-        const int maxlen = vp_wave_max(pe - pb);                 // (a class spans a factor of two in population)
+        const int maxlen = vp_group_max(pe - pb, lpr, groups);   // (items at a class border mix two populations)
         float4 acc = zero4;
         vp_vox_piece<FB, FUSED, VB>(acc, pb, pe, maxlen, cl, ingroup, g, gs, vb, f_rsrc, row_in, lane_in, idw, prw, a);
         vp_buf_emit<OB, ACC>(o_rsrc, v | kill, row_out, lane_out, pad_off, acc);
     }
     if constexpr (VB == 16) {
         if (pack) {
-            vp_vox_small<FB, OB, ACC, FUSED, VB, 2>(n8, n4, gw, nwaves, cl, ingroup, g, gs, groups, f_rsrc, o_rsrc, row_in, lane_in, row_out,
+            woff = (woff + n_small) % nwaves;
+            const int gw2 = (gw - woff + nwaves) % nwaves;
+            woff = (woff + (n4 - n8 + groups * 2 - 1) / (groups * 2)) % nwaves;
+            const int gw4 = (gw - woff + nwaves) % nwaves;
+            vp_vox_small<FB, OB, ACC, FUSED, VB, 2>(n8, n4, gw2, nwaves, cl, ingroup, g, gs, groups, lpr, f_rsrc, o_rsrc, row_in, lane_in, row_out,
                                                     lane_out, pad_off, kill, idw, prw, a);
-            vp_vox_small<FB, OB, ACC, FUSED, VB, 4>(n4, nonempty, gw, nwaves, cl, ingroup, g, gs, groups, f_rsrc, o_rsrc, row_in, lane_in,
+            vp_vox_small<FB, OB, ACC, FUSED, VB, 4>(n4, nonempty, gw4, nwaves, cl, ingroup, g, gs, groups, lpr, f_rsrc, o_rsrc, row_in, lane_in,
                                                     row_out, lane_out, pad_off, kill, idw, prw, a);
         }
     }
