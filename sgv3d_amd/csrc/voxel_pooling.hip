@@ -1374,7 +1374,7 @@ VpMagic vp_magic(int d) {
 __device__ __forceinline__ int vp_fast_div(int n, int d, unsigned mag, int sh) {
     return d == 1 ? n : (int)(__umulhi((unsigned)n, mag) >> sh);
 }
-constexpr int kVoxGrid = 2048;   // workgroups: 8 per CU (VB = 8: <= 72 VGPRs, 7 waves per SIMD), each wave ~one small item
+constexpr int kVoxGrid = 1024;   // workgroups of the smallest launch (4 per CU); larger problems take 2 x / 4 x (launch_gather)
 
 // acc += rows of the slots [pb, pe) in slot order, `vb` <= VB at a time; `maxlen` >= pe - pb is wave-uniform (the longest piece
 // of the wave), slots past a group's own end are dead (index -1: the load returns zeros).  What bounds this loop is its
@@ -1764,7 +1764,10 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
                 static const int dbg_env = [] { const char *e = getenv("SGV3D_VP_DEBUG"); return e ? atoi(e) : 0; }();
                 a.dbg = dbg_env;
                 const int VBsel = vb_env == 16 || vb_env == 8 ? vb_env : 16;
-                const int vgrid = grid_env > 0 ? grid_env : kVoxGrid;
+                // workgroups: 1 024 (4 per CU) for frames of up to a million points, 4 096 from two million (cfg-2: 15.3 us fused
+                // with 1 024 against 16.7 / 18.5 with 2 048 / 4 096; cfg-3 batch 4: 238 us operator with 4 096 against 251 / 257;
+                // cfg-5: 178 against 181 / 186)
+                const int vgrid = grid_env > 0 ? grid_env : L.total >= 2000000 ? 4 * kVoxGrid : L.total >= 1000000 ? 2 * kVoxGrid : kVoxGrid;
                 if (FUSED) {
                     const VpMagic mn = vp_magic(N), mp = vp_magic(P);
                     a.magN = mn.mag; a.shN = mn.sh; a.magP = mp.mag; a.shP = mp.sh;
