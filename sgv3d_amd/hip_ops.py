@@ -786,6 +786,16 @@ def run_parallel(device, thunks):
     return results
 
 
+# A capture that wants to be cut into several hipGraphs (pipeline.GraphedForward) installs a callback here; the forward calls
+# graph_split_point() where a cut is useful (after the image backbone's first stage).  None: the call does nothing.
+_GRAPH_SPLIT_HOOK = None
+
+
+def graph_split_point(tag):
+    if _GRAPH_SPLIT_HOOK is not None:
+        _GRAPH_SPLIT_HOOK(tag)
+
+
 def switch_state():
     """Every module-level switch that decides WHICH kernels a forward launches, as one hashable value: part of the key of
     anything that records launches for replay (BEVHeight's per-signature hipGraph)."""

@@ -266,7 +266,7 @@ class BSMLSSFPN(LSSFPN):
         batch_size, num_sweeps, num_cams, num_channels, imH, imW = imgs.shape
         imgs = imgs.reshape(batch_size * num_sweeps * num_cams, num_channels, imH, imW).float().contiguous()
         cin_pad = self.img_backbone.hip_state(imgs.device)['cin_pad']
-        feats = self.img_backbone.hip_forward(hip_ops.nchw_to_nhwc(imgs, c_pad=cin_pad))
+        feats = self.img_backbone.hip_forward(hip_ops.nchw_to_nhwc(imgs, c_pad=cin_pad), split_tag="img_backbone.stage1")
         return [n.hip_forward(feats, out_dtype=hip_ops.activation_dtype(*n.out_channels)) for n in (self.img_neck_16, self.img_neck_8)]
 
     def _forward_single_sweep(self, sweep_index, sweep_imgs, mats_dict, nhwc_out=False):

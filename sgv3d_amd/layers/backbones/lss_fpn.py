@@ -419,7 +419,7 @@ class LSSFPN(HipModule):
         imgs = imgs.reshape(batch_size * num_sweeps * num_cams, num_channels, imH, imW).float().contiguous()
         cin_pad = self.img_backbone.hip_state(imgs.device)['cin_pad']
         x = hip_ops.nchw_to_nhwc(imgs, c_pad=cin_pad)
-        feats = self.img_backbone.hip_forward(x)
+        feats = self.img_backbone.hip_forward(x, split_tag="img_backbone.stage1")
         # (bf16-activation mode: the concatenated neck map is a bf16 tensor too -- half the bytes, and HeightNet's first 3x3 gets the
         # bf16-in / bf16-out kernels)
         return self.img_neck.hip_forward(feats, out_dtype=hip_ops.activation_dtype(*self.img_neck.out_channels))

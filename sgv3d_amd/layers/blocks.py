@@ -239,7 +239,10 @@ class ResNet(HipModule):
         chans = [pad(self.conv1.out_channels)] + [pad(m.out_channels) for m in self.modules() if isinstance(m, nn.Conv2d)]
         return torch.bfloat16 if all(c % 8 == 0 for c in chans) else None
 
-    def hip_forward(self, x_nhwc, use_maxpool=True):
+    def hip_forward(self, x_nhwc, use_maxpool=True, split_tag=None):
+        """``split_tag``: the image backbone names a cut point after its first stage (hip_ops.graph_split_point: a capture
+        that replays the frame as two graphs launches the short one first, so the GPU starts while the host is still
+        submitting the long one)."""
         dt = self.act_dtype()
         x = self.hip_state(x_nhwc.device)['stem'](x_nhwc, out_dtype=dt)
         if use_maxpool:
@@ -250,6 +253,8 @@ class ResNet(HipModule):
                 x = blk.hip_forward(x, dt)
             if i in self.out_indices:
                 outs.append(x)
+            if i == 0 and split_tag is not None:
+                hip_ops.graph_split_point(split_tag)
         return outs
 
 

@@ -32,6 +32,7 @@ import warnings
 
 import torch
 
+from . import hip_ops
 from .calibration import CalibrationCache
 
 # what a failed stream capture raises (HIP errors surface as RuntimeError / torch.AcceleratorError, a library call that
@@ -118,18 +119,46 @@ class GraphedForward:
                 model.head.decode_device(preds)            # (first call of the decode kernels outside any capture)
                 del preds
                 side.synchronize()
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph, stream=side):
-                    branch.wait_stream(side)               # fork: the refresh is recorded on its own branch ...
+                # TWO graphs that share one memory pool: a short one (image stem + first backbone stage, ~15 launches, 0.5 ms
+                # of GPU work) and the rest (~160 launches).  Submitting a long hipGraph takes the host a few hundred
+                # microseconds BEFORE its first kernel starts; with one frame in flight -- the harness waits for every
+                # frame's boxes -- the GPU idles through that.  The short graph starts at once and the long one is submitted
+                # under it (SGV3D_GRAPH_SPLIT=0: one graph).
+                self.graphs = [torch.cuda.CUDAGraph()]
+                pool = torch.cuda.graph_pool_handle()
+                split = os.environ.get("SGV3D_GRAPH_SPLIT", "1") != "0"
+
+                def fork_refresh():                        # the refresh is recorded on its own branch ...
+                    branch.wait_stream(side)
                     with torch.cuda.stream(branch):
                         self.cache.invalidate()
                         for sweep in sweeps:
                             model.backbone.calibration(self.in_mats, sweep)
                     for sweep in sweeps:
                         self.cache.entry(sweep).join_stream = branch     # ... and joined by its first reader (calibration.py)
+
+                def cut(tag):                              # (hip_ops.graph_split_point, once: sweep 0's image backbone)
+                    hip_ops._GRAPH_SPLIT_HOOK = None
+                    self.graphs[-1].capture_end()
+                    self.graphs.append(torch.cuda.CUDAGraph())
+                    self.graphs[-1].capture_begin(pool=pool)
+                    fork_refresh()                         # a fork has to rejoin inside the graph it was recorded in: the last one
+                torch.cuda.synchronize(dev)
+                self.graphs[0].capture_begin(pool=pool)
+                try:
+                    if split:
+                        hip_ops._GRAPH_SPLIT_HOOK = cut
+                    else:
+                        fork_refresh()
                     self.outputs = model(self.in_imgs, self.in_mats)
+                    if hip_ops._GRAPH_SPLIT_HOOK is not None:      # (a backbone without the cut point)
+                        hip_ops._GRAPH_SPLIT_HOOK = None
+                        fork_refresh()
                     side.wait_stream(branch)               # (a join of its own if the forward never asked for the plan)
                     self.decoded = model.head.decode_device(self.outputs)
+                finally:
+                    hip_ops._GRAPH_SPLIT_HOOK = None
+                    self.graphs[-1].capture_end()
         finally:
             for sweep in sweeps:
                 self.cache.entry(sweep).join_stream = None
@@ -140,7 +169,8 @@ class GraphedForward:
         with torch.no_grad():
             self.in_imgs.copy_(imgs, non_blocking=True)
             torch._foreach_copy_(self._mat_dst, [mats[k] for k in self._mat_keys], non_blocking=True)
-            self.graph.replay()
+            for g in self.graphs:
+                g.replay()
             self.replays += 1
             out = _clone_aliased(self.outputs, {})
             return out, self.decoded.clone()
