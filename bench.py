@@ -706,26 +706,35 @@ def main():
         host_mats = {k: v.cpu() for k, v in mats.items()}
         hstep = lambda: H.eval_step(model, H.make_batch(imgs, host_mats))
         with torch.no_grad():
+            default_mode = model.graph_forward                  # "auto": the model keeps the replay where it measures faster
             for _ in range(max(3, args.warmup)):
                 res = hstep()
             th = group.timed(hstep, args.steps)
             n_h = max(args.steps, int(1.2 / max(th / args.steps, 1e-4)) + 1)
             th_long = group.timed(hstep, n_h)
+            chosen = next((e for e in model._graphs.values() if len(e) > 2), None)
+            forced = {}
+            for mode in (True, False):                          # and both forms forced, for the record
+                model.graph_forward = mode
+                model._graphs = {}
+                for _ in range(3):
+                    hstep()
+                forced[mode] = group.timed(hstep, args.steps)
             graph_entry = next((e[1] for e in model._graphs.values() if e[1]), None)
-            model.graph_forward = False
-            for _ in range(2):
-                hstep()
-            th_eager = group.timed(hstep, args.steps)
-            model.graph_forward = True
+            model.graph_forward = default_mode
+            model._graphs = {}
         hip_ops.TUNE_STREAMS = saved_streams
         harness_rec = {"value": B * args.steps / th, "ms_per_step": th / args.steps * 1e3,
                        "long_run_value": B * n_h / th_long, "long_run_steps": n_h,
-                       "eager_forward_value": B * args.steps / th_eager, "eager_forward_ms_per_step": th_eager / args.steps * 1e3,
-                       "graph_replays": getattr(graph_entry, "replays", 0), "boxes_last_frame": int(res[0][0].shape[0]),
+                       "forward_mode": str(default_mode), "auto_choice": chosen[2] if chosen else None,
+                       "graph_forward_value": B * args.steps / forced[True], "graph_forward_ms_per_step": forced[True] / args.steps * 1e3,
+                       "eager_forward_value": B * args.steps / forced[False], "eager_forward_ms_per_step": forced[False] / args.steps * 1e3,
+                       "boxes_last_frame": int(res[0][0].shape[0]),
                        "what": "sgv3d_amd/harness.py::eval_step = the reference Lightning module's eval_step (exps/...:242-258): fresh "
                                ".cuda() calibration tensors, model(imgs, mats), get_bboxes, .cpu().numpy() x3 per sample; one frame in "
-                               "flight, host sync per step; forward = BEVHeight's own hipGraph replay (eager_forward_value: the same "
-                               "with SGV3D_GRAPH_FORWARD=0)"}
+                               "flight, host sync per step; forward = BEVHeight's default (graph_forward 'auto': its own hipGraph replay where "
+                               "that measures faster than the eager call on this host, auto_choice); graph_forward_value / "
+                               "eager_forward_value: SGV3D_GRAPH_FORWARD=1 / 0"}
 
     # ---- BASELINE configs[2] / [4] in their own dtype, as compact records (child runs of this script) ---------------
     other_configs = None

@@ -42,7 +42,9 @@ class BEVHeight(nn.Module):
         self.head = BEVHeightHead(**head_conf)
         self.is_train_height = is_train_height
         self._param_stamp = None
-        self.graph_forward = os.environ.get("SGV3D_GRAPH_FORWARD", "1") != "0"
+        # True: replay from the second call of a signature; False: always eager; "auto" (default): build the graph at the
+        # second call, time it against the eager forward on that very input (three synchronous calls each) and keep the faster
+        self.graph_forward = {"0": False, "1": True}.get(os.environ.get("SGV3D_GRAPH_FORWARD", "auto"), "auto")
         self.graph_cache_size = 2
         self._graphs = {}               # signature -> [calls seen, GraphedForward | None | False (capture failed)]
         self._graph_suspended = 0
@@ -149,7 +151,8 @@ class BEVHeight(nn.Module):
         dtypes, stream, compute mode, weights) the forward is therefore one graph replay on static buffers
         (``pipeline.GraphedForward``; the first call runs eagerly and does the per-layer measurements).  Eager always:
         gradients enabled, inside someone else's stream capture, under ``pipeline.eager_forward`` (``FramePipeline``, the
-        instrumented passes), ``self.graph_forward = False`` / ``SGV3D_GRAPH_FORWARD=0``.  At most ``graph_cache_size``
+        instrumented passes), ``self.graph_forward = False`` / ``SGV3D_GRAPH_FORWARD=0``.  ``graph_forward = "auto"`` (the
+        default) keeps the replay only where it measures faster than the eager call (``_replay_pays``).  At most ``graph_cache_size``
         signatures keep a graph (each owns its activation buffers, ~1 GB at cfg-2); the least recently used one is dropped."""
         if (not self.graph_forward or self._graph_suspended or torch.is_grad_enabled() or not x.is_cuda
                 or hip_ops.PROFILE is not None or torch.cuda.is_current_stream_capturing()):
@@ -177,7 +180,37 @@ class BEVHeight(nn.Module):
                 entry[1] = False
                 warnings.warn(f"BEVHeight.forward: hipGraph capture failed ({type(e).__name__}: {e}); this signature keeps "
                               f"launching eagerly", RuntimeWarning, stacklevel=3)
+            if entry[1] and self.graph_forward == "auto":
+                entry.append(self._replay_pays(entry[1], x, mats_dict))
+                if not entry[2]["replay_chosen"]:
+                    entry[1] = False                             # (drops the graph and its activation pool)
         return entry[1] or None
+
+    def _replay_pays(self, graphed, x, mats_dict, reps=3):
+        """One frame at a time -- the pattern this graph exists for -- through the replay (input copies, the graphs, output
+        copies, decode inside) and through the eager forward + decode, ``reps`` synchronous calls each on the caller's input.
+        Whether ~170 launches from Python or one long graph submission reaches the GPU sooner depends on the host: on the
+        development boxes the two are within 2 % of each other, on a slower host the replay wins by the launch overhead."""
+        import time
+        from ..pipeline import eager_forward
+        dev = x.device
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+                torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / reps
+
+        def eager():
+            with eager_forward(self):
+                bev = self.backbone(x, mats_dict, None, nhwc_out=True)
+                self.head.decode_device(self.head(bev, nhwc=True))
+        t_graph = timed(lambda: graphed(self, x, mats_dict))
+        t_eager = timed(eager)
+        return {"replay_ms": t_graph * 1e3, "eager_ms": t_eager * 1e3, "replay_chosen": bool(t_graph < 0.98 * t_eager)}
 
     def get_targets(self, gt_boxes, gt_labels):
         return self.head.get_targets(gt_boxes, gt_labels)

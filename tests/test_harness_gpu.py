@@ -190,3 +190,25 @@ def test_graph_backed_forward_with_two_sweeps(hip):
     torch.cuda.synchronize()
     (entry,) = model._graphs.values()
     assert entry[1].replays == 3
+
+
+def test_auto_mode_keeps_the_faster_of_replay_and_eager(hip):
+    """graph_forward = "auto" (the default): the second call of a signature builds the graph and times it against the eager
+    forward on that input; whichever is kept, the outputs are the eager ones bit for bit and the decision is on record."""
+    from sgv3d_amd import synthetic as S
+    model, bc, _ = _model(seed=8)
+    assert model.graph_forward == "auto"
+    scale = bc['final_dim'][0] / 864
+    frames = [S.make_images(1, bc['final_dim'], device='cuda', seed=40 + s) for s in range(4)]
+    mats = S.make_mats(1, device='cuda', scale=scale)
+    with torch.no_grad():
+        model.graph_forward = False
+        want = [model(f, mats) for f in frames]
+        model.graph_forward = "auto"
+        got = [model(f, {k: v.clone() for k, v in mats.items()}) for f in frames]
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        _assert_same(w, g)
+    (entry,) = model._graphs.values()
+    assert len(entry) == 3 and set(entry[2]) == {"replay_ms", "eager_ms", "replay_chosen"}
+    assert entry[2]["replay_ms"] > 0 and entry[2]["eager_ms"] > 0 and bool(entry[1]) == entry[2]["replay_chosen"]
