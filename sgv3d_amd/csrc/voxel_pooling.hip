@@ -156,7 +156,7 @@ PlanLayout plan_layout(int B, int N, int X, int Y) {
     L.off_perm = al(L.off_long + sizeof(int) * (size_t)(L.long_cap + 1));
     L.off_bins = al(L.off_perm + sizeof(int) * 4 * (size_t)L.V);      // perm: {voxel, first slot, end slot, 0} per voxel
     L.ncw = cdiv(L.V, kBlock);                                         // workgroups of the class sort (256 voxels each)
-    L.bytes = al(L.off_bins + sizeof(int) * ((size_t)kVoxClasses * L.ncw + kVoxClasses + 2));
+    L.bytes = al(L.off_bins + sizeof(int) * ((size_t)kVoxClasses * L.ncw + 2 * kVoxClasses + 2));   // table | cls | class totals
     return L;
 }
 
@@ -415,42 +415,50 @@ __global__ __launch_bounds__(kBlock) void vp_cls_count_kernel(long long V, const
     if (threadIdx.x < kVoxClasses) tbl[threadIdx.x * ncw + blockIdx.x] = h[threadIdx.x];
 }
 
-// one workgroup: exclusive scan of the table in perm order (class kVoxClasses-1 first, class 0 last; workgroups ascending
-// inside a class), in place; cls[c] = position of class c's first record
-__global__ __launch_bounds__(kBlock) void vp_cls_scan_kernel(int ncw, int *__restrict__ tbl, int *__restrict__ cls,
+// one workgroup per class: exclusive scan of the class's row of the table (workgroups ascending), in place; tot[c] = its sum
+__global__ __launch_bounds__(kBlock) void vp_cls_scan_kernel(int ncw, int *__restrict__ tbl, int *__restrict__ tot,
                                                              const int *__restrict__ dirty) {
     VP_SKIP_IF_CLEAN(dirty);
     __shared__ int wave_tot[kBlock / 64];
+    const int c = blockIdx.x;
+    int *row = tbl + (size_t)c * ncw;
     int carry = 0;
-    for (int c = kVoxClasses - 1; c >= 0; --c) {
-        if (threadIdx.x == 0) cls[c] = carry;
-        int *row = tbl + (size_t)c * ncw;
-        for (int b0 = 0; b0 < ncw; b0 += kBlock * kScanPerThread) {
-            int v[kScanPerThread], sum = 0;
-            const int base = b0 + threadIdx.x * kScanPerThread;
+    for (int b0 = 0; b0 < ncw; b0 += kBlock * kScanPerThread) {
+        int v[kScanPerThread], sum = 0;
+        const int base = b0 + threadIdx.x * kScanPerThread;
 #pragma unroll
-            for (int i = 0; i < kScanPerThread; ++i) {
-                v[i] = base + i < ncw ? row[base + i] : 0;
-                sum += v[i];
-            }
-            int tot;
-            int run = carry + block_exclusive_scan(sum, wave_tot, tot);
-#pragma unroll
-            for (int i = 0; i < kScanPerThread; ++i) {
-                if (base + i < ncw) row[base + i] = run;
-                run += v[i];
-            }
-            carry += tot;
+        for (int i = 0; i < kScanPerThread; ++i) {
+            v[i] = base + i < ncw ? row[base + i] : 0;
+            sum += v[i];
         }
+        int t;
+        int run = carry + block_exclusive_scan(sum, wave_tot, t);
+#pragma unroll
+        for (int i = 0; i < kScanPerThread; ++i) {
+            if (base + i < ncw) row[base + i] = run;
+            run += v[i];
+        }
+        carry += t;
     }
+    if (threadIdx.x == 0) tot[c] = carry;
 }
 
+// perm order: class kVoxClasses-1 first, class 0 (the empty voxels) last; inside a class the workgroups ascending and, inside a
+// workgroup, the voxels ascending (ranks by ballots).  cls[c] = position of class c's first record (written by workgroup 0).
 __global__ __launch_bounds__(kBlock) void vp_cls_scatter_kernel(long long V, const int *__restrict__ seg_start, int ncw,
-                                                                const int *__restrict__ tbl, int *__restrict__ perm,
+                                                                const int *__restrict__ tbl, const int *__restrict__ tot,
+                                                                int *__restrict__ cls, int *__restrict__ perm,
                                                                 const int *__restrict__ dirty) {
     VP_SKIP_IF_CLEAN(dirty);
     __shared__ int wcnt[kBlock / 64][kVoxClasses];
+    __shared__ int cbase[kVoxClasses];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x < kVoxClasses) {
+        int bsum = 0;
+        for (int k = kVoxClasses - 1; k > (int)threadIdx.x; --k) bsum += tot[k];
+        cbase[threadIdx.x] = bsum;
+        if (blockIdx.x == 0) cls[threadIdx.x] = bsum;
+    }
     const long long v = (long long)blockIdx.x * kBlock + threadIdx.x;
     int s0 = 0, s1 = 0, c = -1;
     if (v < V) {
@@ -467,7 +475,7 @@ __global__ __launch_bounds__(kBlock) void vp_cls_scatter_kernel(long long V, con
     }
     __syncthreads();
     if (c >= 0) {
-        int pos = tbl[c * ncw + blockIdx.x] + rank;
+        int pos = cbase[c] + tbl[c * ncw + blockIdx.x] + rank;
         for (int w = 0; w < wid; ++w) pos += wcnt[w][c];
         reinterpret_cast<int4 *>(perm)[pos] = make_int4((int)v, s0, s1, 0);
     }
@@ -1871,8 +1879,9 @@ int plan_build_impl(int batch_size, int num_points, int num_voxel_x, int num_vox
         int *cls = tbl + (size_t)kVoxClasses * L.ncw;
         int *perm = reinterpret_cast<int *>(base + L.off_perm);
         hipLaunchKernelGGL(vp_cls_count_kernel, dim3(L.ncw), dim3(kBlock), 0, st, L.V, seg, L.ncw, tbl, dirty);
-        hipLaunchKernelGGL(vp_cls_scan_kernel, dim3(1), dim3(kBlock), 0, st, L.ncw, tbl, cls, dirty);
-        hipLaunchKernelGGL(vp_cls_scatter_kernel, dim3(L.ncw), dim3(kBlock), 0, st, L.V, seg, L.ncw, tbl, perm, dirty);
+        int *tot = cls + kVoxClasses;
+        hipLaunchKernelGGL(vp_cls_scan_kernel, dim3(kVoxClasses), dim3(kBlock), 0, st, L.ncw, tbl, tot, dirty);
+        hipLaunchKernelGGL(vp_cls_scatter_kernel, dim3(L.ncw), dim3(kBlock), 0, st, L.V, seg, L.ncw, tbl, tot, cls, perm, dirty);
     }
     hipLaunchKernelGGL(vp_fill_kernel, dim3(pgrid), dim3(kBlock), 0, st, L.total, num_points, num_voxel_x,
                        num_voxel_y, num_voxel_z, geom_xyz, cur, order, reinterpret_cast<int *>(base + L.off_slotvox), dirty, seg);
