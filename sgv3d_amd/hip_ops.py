@@ -758,7 +758,7 @@ _BRANCH_TOP = {}
 
 def run_parallel(device, thunks):
     """``[t() for t in thunks]``; inside a stream capture the thunks are forked branches of the graph (the first one stays on
-    the capturing stream).  Nested calls take further streams of the per-device pool."""
+    the capturing stream).  A call from inside a forked branch runs its thunks in sequence."""
     thunks = list(thunks)
     if len(thunks) <= 1 or not PARALLEL_BRANCHES or not torch.cuda.is_current_stream_capturing():
         return [t() for t in thunks]
@@ -766,6 +766,10 @@ def run_parallel(device, thunks):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     pool = _BRANCH_POOL.setdefault(key, [])
     top = _BRANCH_TOP.get(key, 0)
+    if top > 0:
+        # already inside a forked branch: in sequence (forks nested three deep -- MSCThead's scales -> ASPP -> pooled branch --
+        # crashed hipStreamEndCapture on ROCm 7.2)
+        return [t() for t in thunks]
     need = top + len(thunks) - 1
     while len(pool) < need:
         pool.append(torch.cuda.Stream(device=dev))

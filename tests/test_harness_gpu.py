@@ -212,3 +212,29 @@ def test_auto_mode_keeps_the_faster_of_replay_and_eager(hip):
     (entry,) = model._graphs.values()
     assert len(entry) == 3 and set(entry[2]) == {"replay_ms", "eager_ms", "replay_chosen"}
     assert entry[2]["replay_ms"] > 0 and entry[2]["eager_ms"] > 0 and bool(entry[1]) == entry[2]["replay_chosen"]
+
+
+@pytest.mark.parametrize("bsm", [False, True])
+def test_parallel_graph_branches_are_bitwise_the_sequential_forward(hip, bsm):
+    """hip_ops.run_parallel (SGV3D_PARALLEL_BRANCHES=1; measured slower, off by default -- DESIGN 3.6): shortcut convolutions,
+    SECONDFPN levels, ASPP pooled branch, gate MLPs / context branch, MSCThead scales and tasks as forked branches of the
+    captured graph give the bytes of the sequential forward."""
+    from sgv3d_amd import hip_ops, synthetic as S
+    model, bc, _ = _model(seed=11, bsm=bsm)
+    scale = bc['final_dim'][0] / 864
+    frames = [S.make_images(1, bc['final_dim'], device='cuda', seed=50 + s) for s in range(3)]
+    mats = S.make_mats(1, device='cuda', scale=scale)
+    saved = hip_ops.PARALLEL_BRANCHES
+    try:
+        with torch.no_grad():
+            model.graph_forward = False
+            want = [model(f, mats) for f in frames]
+            hip_ops.PARALLEL_BRANCHES = True                 # (part of hip_ops.switch_state: a signature of its own)
+            model.graph_forward = True
+            got = [model(f, mats) for f in frames]
+        torch.cuda.synchronize()
+    finally:
+        hip_ops.PARALLEL_BRANCHES = saved
+    assert list(model._graphs.values())[-1][1].replays == 2
+    for w, g in zip(want, got):
+        _assert_same(w, g)
