@@ -751,19 +751,16 @@ PAIR_BF16 = _os.environ.get("SGV3D_PAIR_BF16", "1") != "0"   # 0: conv2 + conv3 
 # one frame in flight 169.3 -> 160.7 frames/s, three in flight 209.0 -> 163.3, the harness step 153.3 -> 147.8: every
 # cross-stream edge of a hipGraph is a barrier packet plus a semaphore between hardware queues, tens of microseconds each,
 # where the kernels it lets overlap are 10-60 us long.
-# (True: every kind; or a set of kinds -- "shortcut", "neck", "aspp", "gates", "msct" -- SGV3D_PARALLEL_BRANCHES=neck,aspp)
-_pb = _os.environ.get("SGV3D_PARALLEL_BRANCHES", "0")
-PARALLEL_BRANCHES = True if _pb == "1" else False if _pb in ("0", "") else frozenset(_pb.split(","))
+PARALLEL_BRANCHES = _os.environ.get("SGV3D_PARALLEL_BRANCHES", "0") == "1"
 _BRANCH_POOL = {}
 _BRANCH_TOP = {}
 
 
-def run_parallel(device, thunks, kind="other"):
+def run_parallel(device, thunks):
     """``[t() for t in thunks]``; inside a stream capture the thunks are forked branches of the graph (the first one stays on
     the capturing stream).  A call from inside a forked branch runs its thunks in sequence."""
     thunks = list(thunks)
-    on = PARALLEL_BRANCHES is True or (PARALLEL_BRANCHES and kind in PARALLEL_BRANCHES)
-    if len(thunks) <= 1 or not on or not torch.cuda.is_current_stream_capturing():
+    if len(thunks) <= 1 or not PARALLEL_BRANCHES or not torch.cuda.is_current_stream_capturing():
         return [t() for t in thunks]
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
