@@ -20,6 +20,21 @@ are only ever written by torch ops here (``copy_``), which do.
 """
 
 
+def tensor_version(t):
+    """``t._version``; None for a tensor made under ``torch.inference_mode()`` (it has no version counter -- Lightning's
+    validation loop runs under inference mode by default in recent releases): such a tensor never matches a remembered one,
+    i.e. it is treated as new content every time (geometry kernel + device-side compare, nothing wrong, nothing cached on the
+    host)."""
+    if t is None:
+        return None
+    try:
+        if t.is_inference():
+            return None
+    except AttributeError:      # (not a tensor)
+        return None
+    return t._version
+
+
 class CalibrationCache:
     """One entry per sweep index (multi-sweep inputs carry one calibration per sweep; with a single slot consecutive
     sweeps would evict each other and every sweep would pay the geometry kernel + plan rebuild on every frame).
@@ -46,12 +61,12 @@ class CalibrationCache:
             if self._src is None or self._tag != tag or len(tensors) != len(self._src):
                 return False
             for t, (old, ver) in zip(tensors, self._src):
-                if t is not old or (t is not None and t._version != ver):
+                if t is not old or (t is not None and (ver is None or tensor_version(t) != ver)):
                     return False
             return True
 
         def remember(self, tensors, tag):
-            self._src = [(t, None if t is None else t._version) for t in tensors]
+            self._src = [(t, tensor_version(t)) for t in tensors]
             self._tag = tag
 
         def mark_built(self, device):

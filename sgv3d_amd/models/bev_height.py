@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from .. import hip_ops
+from ..calibration import tensor_version
 from ..layers.backbones.bsm_lss_fpn import BSMLSSFPN
 from ..layers.backbones.lss_fpn import LSSFPN
 from ..layers.blocks import HipModule
@@ -135,7 +136,7 @@ class BEVHeight(nn.Module):
         if graphed is not None:
             preds, decoded = graphed(self, x, mats_dict)
             # the graph decoded these maps already: remembered for a get_bboxes call on exactly these tensors, unmodified
-            self._decoded = (decoded, [weakref.ref(v) for task in preds for v in task[0].values()], preds[0][0]['heatmap']._version)
+            self._decoded = (decoded, [weakref.ref(v) for task in preds for v in task[0].values()], tensor_version(preds[0][0]['heatmap']))
             return preds
         self._decoded = None
         bev = self.backbone(x, mats_dict, timestamps, nhwc_out=True)   # NHWC buffer [B, Y, X, C]
@@ -233,6 +234,8 @@ class BEVHeight(nn.Module):
             tensors = [v for task in preds_dicts for v in task[0].values()]
         except (TypeError, AttributeError, IndexError, KeyError):
             return None
-        if len(tensors) != len(refs) or any(r() is not t for r, t in zip(refs, tensors)) or tensors[0]._version != version:
+        # (maps made under torch.inference_mode() have no version counter: in-place edits cannot be seen, so no reuse)
+        if (len(tensors) != len(refs) or any(r() is not t for r, t in zip(refs, tensors)) or version is None
+                or tensor_version(tensors[0]) != version):
             return None
         return decoded

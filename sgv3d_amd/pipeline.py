@@ -33,7 +33,7 @@ import warnings
 import torch
 
 from . import hip_ops
-from .calibration import CalibrationCache
+from .calibration import CalibrationCache, tensor_version
 
 # what a failed stream capture raises (HIP errors surface as RuntimeError / torch.AcceleratorError, a library call that
 # refuses to run under capture as SGV3DError); anything else is a bug and propagates
@@ -261,7 +261,7 @@ class FramePipeline:
         last = self._last_mats[i]
         if last is None or len(last) != len(mats):
             return False
-        return all(k in last and last[k][0] is v and last[k][1] == v._version for k, v in mats.items())
+        return all(k in last and last[k][0] is v and last[k][1] is not None and last[k][1] == tensor_version(v) for k, v in mats.items())
 
     def submit(self, imgs, mats):
         """Copy a frame into the next slot's static inputs (on that slot's stream) and run it."""
@@ -279,7 +279,7 @@ class FramePipeline:
                     self.in_mats[i][k].copy_(v, non_blocking=True)
                     if v.is_cuda:
                         v.record_stream(s)
-                self._last_mats[i] = {k: (v, v._version) for k, v in mats.items()}
+                self._last_mats[i] = {k: (v, tensor_version(v)) for k, v in mats.items()}
                 if self.graphs:
                     # the captured graph holds no geometry / plan kernels: bring the slot's plan buffer up to date
                     # here (a no-op on the device when the new calibration yields the same voxel indices)

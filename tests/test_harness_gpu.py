@@ -238,3 +238,24 @@ def test_parallel_graph_branches_are_bitwise_the_sequential_forward(hip, bsm):
     assert list(model._graphs.values())[-1][1].replays == 2
     for w, g in zip(want, got):
         _assert_same(w, g)
+
+
+def test_eval_step_under_inference_mode(hip):
+    """Recent Lightning releases run validation under ``torch.inference_mode()``: tensors made there have no version counter
+    (the calibration cache and the decode reuse key on versions).  Same boxes as under ``no_grad``; nothing is cached on the
+    strength of a version that does not exist."""
+    from sgv3d_amd import harness, synthetic as S
+    model, bc, _ = _model(seed=9)
+    host = S.make_mats(1, device='cpu', scale=bc['final_dim'][0] / 864)
+    frames = [S.make_images(1, bc['final_dim'], device='cuda', seed=60 + s) for s in range(3)]
+    with torch.no_grad():
+        model.graph_forward = False
+        want = [harness.eval_step(model, harness.make_batch(f, host)) for f in frames]
+    for mode in (False, True):
+        model.graph_forward = mode
+        model._graphs = {}
+        with torch.inference_mode():
+            got = [harness.eval_step(model, harness.make_batch(f, host)) for f in frames]
+        for w, g in zip(want, got):
+            for (wb, ws, wl, _), (gb, gs, gl, _) in zip(w, g):
+                assert np.array_equal(wb, gb) and np.array_equal(ws, gs) and np.array_equal(wl, gl)
