@@ -60,15 +60,15 @@ class eager_forward:
 
 
 def _clone_aliased(obj, memo):
-    """Deep copy of a nest of tensors that keeps their aliasing: views of one buffer become views of ONE copy of it."""
+    """Deep copy of a nest of tensors that keeps their aliasing: tensors that share a storage become views of ONE copy of it
+    (keyed by the storage, not by ``_base``: views made under ``torch.inference_mode()`` do not record their base)."""
     if torch.is_tensor(obj):
-        base = obj._base if obj._base is not None else obj
-        c = memo.get(id(base))
+        st = obj.untyped_storage()
+        c = memo.get(st.data_ptr())
         if c is None:
-            c = memo[id(base)] = base.clone(memory_format=torch.preserve_format)
-        if base is obj:
-            return c
-        return c.as_strided(obj.size(), obj.stride(), obj.storage_offset() - base.storage_offset() + c.storage_offset())
+            whole = torch.empty(0, dtype=obj.dtype, device=obj.device).set_(st)      # the storage as one flat tensor
+            c = memo[st.data_ptr()] = whole.clone()
+        return c.as_strided(obj.size(), obj.stride(), obj.storage_offset())
     if isinstance(obj, dict):
         return {k: _clone_aliased(v, memo) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)):
