@@ -73,6 +73,9 @@ def parse():
                     help="cfg2 (default, the judged workload): R50 BEVHeight; r101: R101 BEVHeight; "
                          "cfg3: R101 1088x1920 -> 512x512 BEV (geometry of BASELINE configs[2]; fp32 here, use --batch 4); "
                          "cfg5: SGV3D BSM R101 (model of BASELINE configs[4], fp32, batch 1)")
+    ap.add_argument("--no-harness", action="store_true",
+                    help="skip long_run_value and harness_eval_step (keeps a rocprof trace / PMC pass of this command to the timed "
+                         "loop's kernels)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the compact cfg-3 / cfg-5 bf16 records (other_configs) the default cfg-2 run appends")
     ap.add_argument("--sub", action="store_true",
@@ -376,7 +379,7 @@ def main():
     # ---- a timed region of >= 1 s with the same pipeline (the K-step region above is ~0.1 s at cfg-2: clock ramp and
     # the first replays weigh on it; `value` stays the K-step figure the contract asks for, this one sits beside it)
     long_run = None
-    if rank == 0 and world == 1 and not args.sub and not stub:
+    if rank == 0 and world == 1 and not args.sub and not stub and not args.no_harness:
         n_long = max(args.steps, int(1.2 / max(elapsed / args.steps, 1e-4)) + 1)
         tl = group.timed(run, n_long)
         long_run = {"value": B * n_long / tl, "ms_per_step": tl / n_long * 1e3, "steps": n_long, "seconds": tl}
@@ -697,7 +700,7 @@ def main():
     # Runs last, with the per-layer choices of ONE frame in flight (TUNE_STREAMS = 1, what a process that never builds a
     # FramePipeline has), i.e. the same kernels as one_frame_in_flight_own_tiles_value.
     harness_rec = None
-    if rank == 0 and world == 1 and not args.sub and not stub:
+    if rank == 0 and world == 1 and not args.sub and not stub and not args.no_harness:
         from sgv3d_amd import harness as H
         saved_streams = hip_ops.TUNE_STREAMS
         if hip_ops.TUNE_STREAMS != 1:

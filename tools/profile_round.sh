@@ -14,33 +14,43 @@ export TMPDIR=/tmp
 cd /tmp
 # (tile / split-K choices come from the committed tune DB, tune/gfx950_*.json: every run below makes the same ones)
 # 1. the bench line itself (with the CPU baseline)
+echo "[profile_round] $(date +%H:%M:%S) 1. the bench line itself (with the CPU baseline)" | tee -a $KEEP/progress.log
 python3 $R/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 # 2. kernel trace + stats of the same command (no CPU baseline: it is host work).  One frame in flight, so that the
+echo "[profile_round] $(date +%H:%M:%S) 2. kernel trace + stats of the same command (no CPU baseli" | tee -a $KEEP/progress.log
 #    per-kernel durations are those of the kernels alone (with 3 frames in flight concurrent kernels stretch each
 #    other) and compare directly with roofline.avg_launch_us of the bench line, which is measured the same way.
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-plan-timing --no-other-configs --streams 1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-plan-timing --no-other-configs --no-harness --streams 1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err
 # 2b. the HEADLINE command itself (three frames in flight) under the kernel trace: concurrent kernels stretch each other,
+echo "[profile_round] $(date +%H:%M:%S) 2b. the HEADLINE command itself (three frames in flight) u" | tee -a $KEEP/progress.log
 #     so these per-kernel durations are "under load" figures, not comparable with roofline.avg_launch_us
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench_3inflight -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-roofline --no-other-configs > $OUT/${TAG}_bench_3inflight_under_rocprof.json 2> $OUT/rocprof3.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench_3inflight -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-roofline --no-other-configs --no-harness > $OUT/${TAG}_bench_3inflight_under_rocprof.json 2> $OUT/rocprof3.err
 # 2c. per-layer table (HIP events, one frame at a time) with the tiles chosen for three frames in flight, and for one
+echo "[profile_round] $(date +%H:%M:%S) 2c. per-layer table (HIP events, one frame at a time) with" | tee -a $KEEP/progress.log
 SGV3D_TUNE_STREAMS=3 python3 $R/tools/layer_report.py > $OUT/${TAG}_layers_cfg2_tiles_for_3inflight.txt 2> $OUT/layers3.err
 SGV3D_TUNE_STREAMS=1 python3 $R/tools/layer_report.py > $OUT/${TAG}_layers_cfg2_tiles_for_1inflight.txt 2> $OUT/layers1.err
 # 2d. the three launches of the F(4x4) Winograd path
+echo "[profile_round] $(date +%H:%M:%S) 2d. the three launches of the F(4x4) Winograd path" | tee -a $KEEP/progress.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_wino4 -- python3 $R/tools/wino4_trace.py > /dev/null 2> $OUT/wino4.err
 # 3. HBM traffic counters, separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs > /dev/null 2> $OUT/pmc_write.err
+echo "[profile_round] $(date +%H:%M:%S) 3. HBM traffic counters, separate passes (FETCH_SIZE and W" | tee -a $KEEP/progress.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs --no-harness > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs --no-harness > /dev/null 2> $OUT/pmc_write.err
 # 3b. MFMA utilisation counters (own pass; SQ counters fit one pass)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_mfma -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs --streams 1 > /dev/null 2> $OUT/pmc_mfma.err
+echo "[profile_round] $(date +%H:%M:%S) 3b. MFMA utilisation counters (own pass; SQ counters fit o" | tee -a $KEEP/progress.log
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_mfma -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs --no-harness --streams 1 > /dev/null 2> $OUT/pmc_mfma.err
 # 4. voxel pooling micro-benchmark (the HBM-bound headline kernel) + its trace and traffic
+echo "[profile_round] $(date +%H:%M:%S) 4. voxel pooling micro-benchmark (the HBM-bound headline k" | tee -a $KEEP/progress.log
 python3 $R/tools/microbench.py --what vp,lift --out $OUT/${TAG}_voxel_pooling_microbench.json > $OUT/microbench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_vp -- python3 $R/tools/vp_probe.py > /dev/null 2> $OUT/vp.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_vp_pmc_fetch -- python3 $R/tools/vp_probe.py > /dev/null 2>> $OUT/vp.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_vp_pmc_write -- python3 $R/tools/vp_probe.py > /dev/null 2>> $OUT/vp.err
 # 5. the reference harness's eval_step (sgv3d_amd/harness.py): phase timing, and the kernel trace of the same loop
+echo "[profile_round] $(date +%H:%M:%S) 5. the reference harness's eval_step (sgv3d_amd/harness.py" | tee -a $KEEP/progress.log
 python3 $R/tools/harness_profile.py > $OUT/${TAG}_harness_phases.txt 2> $OUT/harness.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_harness -- python3 $R/tools/harness_profile.py > /dev/null 2>> $OUT/harness.err
 # 6. the gather kernels side by side (voxel-owner / slot-balanced) on the cfg-2 / cfg-5 / cfg-3 geometries
+echo "[profile_round] $(date +%H:%M:%S) 6. the gather kernels side by side (voxel-owner / slot-bal" | tee -a $KEEP/progress.log
 python3 $R/tools/vp_probe3.py > $OUT/${TAG}_gather_probe.txt 2> $OUT/gather_probe.err
 SGV3D_VP_KERNEL=slot python3 $R/tools/vp_probe3.py >> $OUT/${TAG}_gather_probe.txt 2>> $OUT/gather_probe.err
 ls -la $OUT | head -60
