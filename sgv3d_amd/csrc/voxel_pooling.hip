@@ -1357,7 +1357,7 @@ struct VpVoxArgs {
     int P;
     unsigned magN, magP;    // exact division of a point id (< 2^31) by N / P: umulhi(id, mag) >> sh (vp_magic)
     int shN, shP;
-    int dbg;                // SGV3D_VP_DEBUG (tools/vp_probe3.py only; WRONG RESULTS): 1 no empty rows, 2 no row stores, 4 no row loads
+    int dbg;                // SGV3D_VP_DEBUG probe bits (launch_gather)
 };
 
 // floor(n / d) for 0 <= n < 2^31, d >= 2, as umulhi(n, mag) >> sh (a round-up magic number of 32 bits is exact for 31-bit
@@ -1769,7 +1769,14 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
                 // SGV3D_VP_GRID: workgroups of the launch (probe knobs, tools/vp_probe3.py)
                 static const int vb_env = [] { const char *e = getenv("SGV3D_VP_VB"); return e ? atoi(e) : 0; }();
                 static const int grid_env = [] { const char *e = getenv("SGV3D_VP_GRID"); return e ? atoi(e) : 0; }();
-                static const int dbg_env = [] { const char *e = getenv("SGV3D_VP_DEBUG"); return e ? atoi(e) : 0; }();
+                // SGV3D_VP_DEBUG: bits 8 / 16 pick other (equally correct) forms of the zero-row phase / small-voxel packing; bits
+                // 1 / 2 / 4 drop the zero rows / row stores / row loads -- wrong results by design, for tools/vp_probe3.py only, and
+                // honoured only together with SGV3D_VP_DEBUG_WRONG_RESULTS=1
+                static const int dbg_env = [] {
+                    const char *e = getenv("SGV3D_VP_DEBUG"), *w = getenv("SGV3D_VP_DEBUG_WRONG_RESULTS");
+                    const int v = e ? atoi(e) : 0;
+                    return (w && w[0] == '1') ? v : (v & ~7);
+                }();
                 a.dbg = dbg_env;
                 const int VBsel = vb_env == 16 || vb_env == 8 ? vb_env : 16;
                 // workgroups: 1 024 (4 per CU) for frames of up to a million points, 4 096 from two million (cfg-2: 15.3 us fused
