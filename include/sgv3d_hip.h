@@ -440,6 +440,21 @@ int sgv3d_centerhead_branches_forward(int batch, int h, int w, int cin, int x_ld
                                       const int32_t *out_begin, float *out, void *workspace,
                                       size_t workspace_bytes, void *stream);
 
+/* The same contract with the first layers in Winograd F(4x4, 3x3) form (csrc/head_wino4.hip): a quarter of the direct
+ * form's multiplications (F(2x2) above: 1 / 2.25); the transformed input of a 16x16 block stays in LDS for all branches.
+ * fp32 rounding of F(4x4) is ~1e-5 of the output scale (F(2x2): ~1e-6).  cin must be 64.
+ *   u_packed  sgv3d_centerhead_f4_weight_floats(num_branches) floats, filled by sgv3d_centerhead_f4_pack_weight from the
+ *             concatenated first-layer weights f32 [num_branches*64, 64, 3, 3] (OIHW)
+ *   everything else (and the workspace size) as for sgv3d_centerhead_branches_forward; a branch may own any number of
+ *   output channels */
+size_t sgv3d_centerhead_f4_weight_floats(int num_branches);
+int sgv3d_centerhead_f4_pack_weight(const float *w1, int num_branches, float *u_packed, void *stream);
+int sgv3d_centerhead_branches_forward_f4(int batch, int h, int w, int cin, int x_ld, int x_coff, const float *x,
+                                         int num_branches, const float *u_packed, const float *scale1,
+                                         const float *bias1, int total_out, const float *w2, const float *bias2,
+                                         const int32_t *out_begin, float *out, void *workspace,
+                                         size_t workspace_bytes, void *stream);
+
 /* bf16-mode counterpart (BASELINE configs[2] / [4] compute dtype): the same two layers of all branches in one kernel on
  * the bf16 matrix cores, fp32 accumulation, hidden maps kept in LDS as bf16 (csrc/head_bf16.hip).  cin must be 64.
  *   w1_packed  sgv3d_centerhead_bf16_weight_bytes(num_branches) bytes, filled by sgv3d_centerhead_bf16_pack_weight from

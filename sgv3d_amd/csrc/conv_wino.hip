@@ -1315,6 +1315,17 @@ extern "C" int sgv3d_conv2d_winograd_forward(const sgv3d_conv_desc *d, const flo
     return check_launch("conv_wino_kernel");
 }
 
+namespace sgv3d {
+// Second launch of both fused CenterHead kernels (conv_wino_head_kernel here, head_wino4_kernel in head_wino4.hip): adds the
+// ring partial sums [blocks][total_out][68] of the neighbouring 16x16 blocks to the border pixels of `out`.
+int launch_head_ring_fixup(int batch, int h, int w, int total_out, const float *ring, float *out, hipStream_t st) {
+    const int nby = cdiv(h, 16), nbx = cdiv(w, 16);
+    const long long total = (long long)batch * nby * nbx * total_out * 60;
+    hipLaunchKernelGGL(head_ring_fixup_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, batch, h, w, nby, nbx, total_out, ring, out);
+    return check_launch("head_ring_fixup_kernel");
+}
+}  // namespace sgv3d
+
 extern "C" size_t sgv3d_centerhead_branches_workspace_bytes(int batch, int h, int w, int total_out) {
     if (batch <= 0 || h <= 0 || w <= 0 || total_out <= 0) return 0;
     return sizeof(float) * (size_t)batch * cdiv(h, 16) * cdiv(w, 16) * total_out * HEAD_RING;
@@ -1354,8 +1365,7 @@ extern "C" int sgv3d_centerhead_branches_forward(int batch, int h, int w, int ci
         return fail(SGV3D_ELAUNCH, "centerhead_branches_forward: cannot raise the dynamic LDS limit to %d", lds);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(conv_wino_head_kernel, dim3(a.tiles_m), dim3(256), lds, st, a, ha);
-    const long long total = (long long)a.tiles_m * total_out * 60;
-    hipLaunchKernelGGL(head_ring_fixup_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, batch, h, w, a.wb_y, a.wb_x,
-                       total_out, ha.ring, out);
+    const int rc = launch_head_ring_fixup(batch, h, w, total_out, ha.ring, out, st);
+    if (rc != SGV3D_OK) return rc;
     return check_launch("conv_wino_head_kernel");
 }

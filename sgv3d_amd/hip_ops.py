@@ -1086,6 +1086,39 @@ def centerhead_branches(x, first, w2, b2, out_begin, num_branches, out=None):
     return out
 
 
+def pack_centerhead_f4(w1):
+    """First layers of the CenterHead branches concatenated, f32 OIHW [nb*64, 64, 3, 3] (device) -> the F(4x4) fragment
+    stream of sgv3d_centerhead_branches_forward_f4 (csrc/head_wino4.hip)."""
+    assert w1.is_cuda and w1.dtype == torch.float32 and tuple(w1.shape[1:]) == (64, 3, 3) and int(w1.shape[0]) % 64 == 0
+    nb = int(w1.shape[0]) // 64
+    lib = _lib.load()
+    w1 = w1.contiguous()
+    u = torch.empty(int(lib.sgv3d_centerhead_f4_weight_floats(nb)), dtype=torch.float32, device=w1.device)
+    with torch.cuda.device(w1.device):
+        _lib.check(lib.sgv3d_centerhead_f4_pack_weight(w1.data_ptr(), nb, u.data_ptr(), _st(w1)), "sgv3d_centerhead_f4_pack_weight")
+    return u
+
+
+def centerhead_branches_f4(x, u, scale1, shift1, w2, b2, out_begin, num_branches, out=None):
+    """``centerhead_branches`` with the first layers in Winograd F(4x4) form: x NHWC f32 [B,H,W,ld] (channels [0, 64)),
+    ``u`` from ``pack_centerhead_f4``, scale1 / shift1 the folded BN of the first layers [nb*64].  -> NCHW [B,sum_c,H,W]."""
+    B, H, W, ld = (int(s) for s in x.shape)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    total = int(w2.shape[0])
+    if out is None:
+        out = torch.empty(B, total, H, W, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nws = lib.sgv3d_centerhead_branches_workspace_bytes(B, H, W, total)
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+    flops = 2.0 * B * H * W * (num_branches * 64 * 64 * 9 + total * 9 * 64)
+    with torch.cuda.device(x.device), prof("head_wino4", flops):
+        rc = lib.sgv3d_centerhead_branches_forward_f4(B, H, W, 64, ld, 0, x.data_ptr(), int(num_branches), u.data_ptr(),
+                                                      _lib.ptr(scale1), _lib.ptr(shift1), total, w2.data_ptr(), b2.data_ptr(),
+                                                      out_begin.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, _st(x))
+    _lib.check(rc, "sgv3d_centerhead_branches_forward_f4")
+    return out
+
+
 def pack_centerhead_bf16(w1, w2, out_begin):
     """First layers of the CenterHead branches concatenated, f32 [nb*64, 64, 3, 3], and final layers f32 [sum_c, 3, 3, 64]
     with ``out_begin`` int32 [nb+1] -> the two bf16 buffers sgv3d_centerhead_branches_forward_bf16 streams

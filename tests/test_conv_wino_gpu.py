@@ -188,6 +188,68 @@ def test_fused_centerhead_branches(B, H, W, cin, counts):
     assert torch.equal(out, again)          # fixed summation order: bit-reproducible
 
 
+@pytest.mark.parametrize("B,H,W,counts", [(1, 32, 48, (2, 1, 3, 2)), (2, 20, 37, (1, 3)), (1, 16, 16, (4,)),
+                                         (1, 50, 33, (2, 1, 3, 2, 2, 1, 1, 3)), (1, 64, 64, (5, 1, 7))])
+def test_fused_centerhead_branches_f4(B, H, W, counts):
+    """sgv3d_centerhead_branches_forward_f4 (F(4x4) first layers, V resident in LDS, scatter-form final convolution) ==
+    [3x3 64->64 + BN + ReLU] then [3x3 64->c + bias] per branch; ragged blocks, two images, branches wider than 4."""
+    from sgv3d_amd import hip_ops
+    g = torch.Generator().manual_seed(44)
+    nb, cin = len(counts), 64
+    x = torch.randn(B, H, W, cin, generator=g)
+    w1 = torch.randn(nb * 64, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    sc, sh = torch.rand(nb * 64, generator=g) + 0.5, torch.randn(nb * 64, generator=g) * 0.2
+    total = sum(counts)
+    w2 = torch.randn(total, 64, 3, 3, generator=g) / 24.0
+    b2 = torch.randn(total, generator=g)
+    hid = (F.conv2d(x.permute(0, 3, 1, 2).double(), w1.double(), padding=1) * sc.double()[None, :, None, None]
+           + sh.double()[None, :, None, None]).clamp_min(0)
+    ref, off = [], 0
+    for k, c in enumerate(counts):
+        ref.append(F.conv2d(hid[:, k * 64:(k + 1) * 64], w2[off:off + c].double(), b2[off:off + c].double(), padding=1))
+        off += c
+    ref = torch.cat(ref, 1)
+    u = hip_ops.pack_centerhead_f4(w1.cuda())
+    ob = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).cuda()
+    args = (x.cuda(), u, sc.cuda(), sh.cuda(), w2.permute(0, 2, 3, 1).contiguous().cuda(), b2.cuda(), ob, nb)
+    out = hip_ops.centerhead_branches_f4(*args)
+    assert out.shape == ref.shape
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+    assert torch.equal(out, hip_ops.centerhead_branches_f4(*args))          # fixed summation order: bit-reproducible
+    # a wider buffer (the shared map as a channel slice) gives the same bits
+    wide = torch.cat([x, torch.randn(B, H, W, 16, generator=g)], -1).cuda()
+    assert torch.equal(out, hip_ops.centerhead_branches_f4(wide, *args[1:]))
+
+
+def test_fused_centerhead_f4_exact_on_small_integers():
+    """Integer inputs and weights chosen so that every intermediate of the F(4x4) path is exactly representable: the
+    kernel's index arithmetic (tile order, swizzle, DPP overlap-add, lane folds, ring) is then checked bit for bit."""
+    from sgv3d_amd import hip_ops
+    g = torch.Generator().manual_seed(5)
+    B, H, W, counts = 1, 40, 24, (2, 3)
+    nb, total = len(counts), sum(counts)
+    x = torch.randint(-2, 3, (B, H, W, 64), generator=g).float()
+    # G g G^T is exact in binary floating point when the taps are multiples of 576 = 24^2 (G's entries are k / 24)
+    w1 = torch.randint(-1, 2, (nb * 64, 64, 3, 3), generator=g).float() * 576.0
+    w1 = w1 * (torch.rand(nb * 64, 64, 1, 1, generator=g) < 0.08)           # sparse: sums stay far below 2^24
+    sc = torch.full((nb * 64,), 1.0 / 64.0)                                 # a power of two: hidden = 9 k + shift, exactly
+    sh = torch.randint(-2, 3, (nb * 64,), generator=g).float()
+    w2 = torch.randint(-2, 3, (total, 64, 3, 3), generator=g).float()
+    b2 = torch.randint(-3, 4, (total,), generator=g).float()
+    hid = (F.conv2d(x.permute(0, 3, 1, 2).double(), w1.double(), padding=1) * sc.double()[None, :, None, None]
+           + sh.double()[None, :, None, None]).clamp_min(0)
+    ref, off = [], 0
+    for k, c in enumerate(counts):
+        ref.append(F.conv2d(hid[:, k * 64:(k + 1) * 64], w2[off:off + c].double(), b2[off:off + c].double(), padding=1))
+        off += c
+    ref = torch.cat(ref, 1)
+    ob = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).cuda()
+    out = hip_ops.centerhead_branches_f4(x.cuda(), hip_ops.pack_centerhead_f4(w1.cuda()), sc.cuda(), sh.cuda(),
+                                         w2.permute(0, 2, 3, 1).contiguous().cuda(), b2.cuda(), ob, nb)
+    assert torch.equal(out.cpu().double(), ref)
+
+
 # ------------------------------------------------------------------------------------------------ F(4x4, 3x3)
 WINO4_SHAPES = [
     (1, 128, 8, 8, 128),       # exactly 2 x 2 tiles
