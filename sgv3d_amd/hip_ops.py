@@ -43,11 +43,12 @@ SPLIT_K = not _os.environ.get("SGV3D_NO_SPLITK")
 WINOGRAD = not _os.environ.get("SGV3D_NO_WINOGRAD")
 # False: CenterHead branches run as two kernels with the hidden maps in HBM (SGV3D_NO_FUSED_HEAD=1)
 FUSED_HEAD = not _os.environ.get("SGV3D_NO_FUSED_HEAD")
-# fp32 CenterHead branches: 0 (default) = the fused kernel; SGV3D_HEAD_PATH=1: first layers as one convolution (its algorithm
-# measured per load: F(4x4) in channel chunks) + the final-conv kernel; SGV3D_HEAD_PATH=auto (None here): both timed under load at
-# the first call.  Measured (tools/head_path_probe.py, bench): the two-kernel path executes 44 % fewer MFMAs but moves 3.9 GB of
-# M / hidden maps per frame -- 1264 vs 1089 us per call with three in flight, 203.4 vs 203.2 frames/s: no gain, so fused stays.
-HEAD_PATH = {"1": 1, "auto": None}.get(_os.environ.get("SGV3D_HEAD_PATH", ""), 0)
+# fp32 CenterHead branches (SGV3D_HEAD_PATH): 2 (default) = the fused F(4x4) kernel (csrc/head_wino4.hip: 532 us at the cfg-2
+# launch); 0 = the fused F(2x2) kernel (conv_wino.hip: 976 us); 1 = first layers as one convolution (its algorithm measured per
+# load: F(4x4) in channel chunks) + the final-conv kernel (executes as few MFMAs as path 2 but moves 3.9 GB of M / hidden maps per
+# frame: 1264 vs 1089 us per call against path 0 with three in flight); "auto" (None here): all three timed under load at the
+# first call.
+HEAD_PATH = {"0": 0, "1": 1, "2": 2, "auto": None}.get(_os.environ.get("SGV3D_HEAD_PATH", ""), 2)
 # True (SGV3D_BF16=1 or set before the first forward): every convolution multiplies through the bf16 MFMA variant of the
 # implicit-GEMM kernel (operands rounded to bf16 on their way into LDS, fp32 accumulation and epilogue, fp32 tensors in
 # HBM) -- the compute dtype BASELINE cfg-3 / cfg-5 name.  Winograd and the fused head kernel are fp32-only and are not
@@ -1111,7 +1112,7 @@ def centerhead_branches_f4(x, u, scale1, shift1, w2, b2, out_begin, num_branches
     nws = lib.sgv3d_centerhead_branches_workspace_bytes(B, H, W, total)
     ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
     flops = 2.0 * B * H * W * (num_branches * 64 * 64 * 9 + total * 9 * 64)
-    with torch.cuda.device(x.device), prof("head_wino4", flops):
+    with torch.cuda.device(x.device), prof("conv_head_wino4", flops):
         rc = lib.sgv3d_centerhead_branches_forward_f4(B, H, W, 64, ld, 0, x.data_ptr(), int(num_branches), u.data_ptr(),
                                                       _lib.ptr(scale1), _lib.ptr(shift1), total, w2.data_ptr(), b2.data_ptr(),
                                                       out_begin.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, _st(x))

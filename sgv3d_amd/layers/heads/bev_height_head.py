@@ -164,7 +164,11 @@ class BEVHeightHead(HipModule):
         w1_bf16 = None
         if hip_ops.MFMA_BF16 and hip_ops.FUSED_HEAD and tuple(w1.shape[1:]) == (64, 3, 3):
             w1_bf16 = hip_ops.pack_centerhead_bf16(w1.to(device), w2.to(device), ob_dev)
-        return dict(w1_bf16=w1_bf16, shared=conv_bn(self.shared_conv.conv, self.shared_conv.bn, True, device), first=first,
+        # fp32 mode: the first layers as the F(4x4) fragment stream of the fused kernel of csrc/head_wino4.hip
+        u_f4 = None
+        if hip_ops.FUSED_HEAD and not hip_ops.MFMA_BF16 and tuple(w1.shape[1:]) == (64, 3, 3) and hc == 64:
+            u_f4 = hip_ops.pack_centerhead_f4(w1.to(device).float())
+        return dict(w1_bf16=w1_bf16, u_f4=u_f4, shared=conv_bn(self.shared_conv.conv, self.shared_conv.bn, True, device), first=first,
                     w2=f(w2), b2=f(b2), branch_of_out=torch.tensor(branch_of_out, dtype=torch.int32, device=device),
                     out_begin=ob_dev,
                     slices=slices, nb=len(br), hc=hc, total=off)
@@ -189,8 +193,12 @@ class BEVHeightHead(HipModule):
             out = hip_ops.centerhead_branches_bf16(shared, s['w1_bf16'], s['first'].scale, s['first'].shift, s['b2'],
                                                    s['out_begin'], s['nb'])
         elif hip_ops.FUSED_HEAD and not hip_ops.MFMA_BF16 and s['first'].wino_ok and s['first'].cin <= 64 and s['hc'] == 64:
-            if self._branch_path(s, shared) == 0:
-                # both branch layers in one kernel: the [nb,B,H,W,64] hidden maps stay on the chip
+            path = self._branch_path(s, shared)
+            if path == 2:
+                # both branch layers in one kernel, first layers in F(4x4) form: the hidden maps never leave the registers
+                out = self._fused_f4(s, shared)
+            elif path == 0:
+                # the F(2x2) fused kernel: the [nb,B,H,W,64] hidden maps stay in LDS
                 out = hip_ops.centerhead_branches(shared, s['first'], s['w2'], s['b2'], s['out_begin'], s['nb'])
             else:
                 out = self._two_kernel_branches(s, shared)
@@ -209,29 +217,38 @@ class BEVHeightHead(HipModule):
         hidden = s['first'](shared, group_planes=s['hc'])
         return hip_ops.head_final_conv(hidden, s['w2'], s['b2'], s['branch_of_out'], s['nb'], s['hc'])
 
+    @staticmethod
+    def _fused_f4(s, shared):
+        return hip_ops.centerhead_branches_f4(shared, s['u_f4'], s['first'].scale, s['first'].shift, s['w2'], s['b2'],
+                                              s['out_begin'], s['nb'])
+
     def _branch_path(self, s, shared):
-        """0: the fused kernel (both branch layers, hidden maps in LDS; 1.08 ms at 256x256, nothing else fits on its CUs);
-        1: the two-kernel path.  Decided like the per-layer choices: by timing both under the load they will run in
-        (hip_ops.TUNE_STREAMS concurrent copies) at the first call outside a graph capture, kept in hip_ops.TUNE_DB.  The fused
-        kernel wins alone (no 1.2 GB of hidden-map traffic); with several frames in flight the chip is bound by MFMA + vector
-        instructions, and the F(4x4) first layer executes 44 % fewer of the former."""
+        """2: the fused F(4x4) kernel (both branch layers, transformed input resident in LDS, hidden maps in registers; 0.53 ms
+        at 256x256); 0: the fused F(2x2) kernel (hidden maps in LDS; 0.98 ms); 1: the two-kernel path (hidden maps through
+        HBM).  ``hip_ops.HEAD_PATH`` names one; with "auto" all available ones are timed under the load they will run in
+        (hip_ops.TUNE_STREAMS concurrent copies) at the first call outside a graph capture and the choice is kept in
+        hip_ops.TUNE_DB."""
+        f4_ok = (s.get('u_f4') is not None and shared.dtype == torch.float32 and int(shared.shape[-1]) >= 64
+                 and s['first'].cin == 64)
+        want = hip_ops.HEAD_PATH
+        if want in (0, 1, 2):                                # an explicit setting wins over any recorded measurement
+            return want if (want != 2 or f4_ok) else 0
         B, H, W, _ = (int(v) for v in shared.shape)
-        sig = f"centerhead_branches|{B}x{H}x{W}x{s['nb']}|ts{hip_ops.TUNE_STREAMS}"
-        if hip_ops.HEAD_PATH in (0, 1):                      # an explicit setting wins over any recorded measurement
-            return hip_ops.HEAD_PATH
+        sig = f"centerhead_branches3|{B}x{H}x{W}x{s['nb']}|ts{hip_ops.TUNE_STREAMS}"
+        ok = {0: True, 1: s['first'].wino4_ok(), 2: f4_ok}
         hit = hip_ops.TUNE_DB.get(sig) if hip_ops.AUTOTUNE else None
-        if hit is not None and (int(hit[0]) - 100 == 0 or s['first'].wino4_ok()):
+        if hit is not None and ok.get(int(hit[0]) - 100, False):
             return int(hit[0]) - 100
-        if (not hip_ops.AUTOTUNE or torch.cuda.is_current_stream_capturing() or not s['first'].wino4_ok()
-                or hip_ops.HEAD_PATH in (0, 1)):
-            return hip_ops.HEAD_PATH if hip_ops.HEAD_PATH in (0, 1) else 0
-        fused = lambda: hip_ops.centerhead_branches(shared, s['first'], s['w2'], s['b2'], s['out_begin'], s['nb'])
-        split = lambda: self._two_kernel_branches(s, shared)
-        fused(); split()                                     # warm (the first layer measures its own candidates here)
+        if not hip_ops.AUTOTUNE or torch.cuda.is_current_stream_capturing():
+            return 2 if f4_ok else 0
+        cands = {0: lambda: hip_ops.centerhead_branches(shared, s['first'], s['w2'], s['b2'], s['out_begin'], s['nb']),
+                 1: lambda: self._two_kernel_branches(s, shared), 2: lambda: self._fused_f4(s, shared)}
+        cands = {k: f for k, f in cands.items() if ok[k]}
+        for f in cands.values():
+            f()                                              # warm (the first layer measures its own candidates here)
         torch.cuda.synchronize(shared.device)
-        t_fused = hip_ops.time_callable(fused, shared.device, rounds=2)
-        t_split = hip_ops.time_callable(split, shared.device, rounds=2)
-        choice = 1 if t_split < t_fused else 0
+        times = {k: hip_ops.time_callable(f, shared.device, rounds=2) for k, f in cands.items()}
+        choice = min(times, key=times.get)
         hip_ops.TUNE_DB[sig] = (100 + choice, 1)
         return choice
 
