@@ -119,25 +119,34 @@ __device__ __forceinline__ float h4_fold16(float a, float b) {
 template <bool FIRST>
 __device__ __forceinline__ void h4_kquad(f32x4 (&acc)[H4_POS], f32x4 (&wf)[H4_AHEAD], const f32x4 *vb,
                                          __amdgpu_buffer_rsrc_t rsrc, unsigned w_lane, unsigned w_off) {
-    f32x4 bv = vb[0];
+    // two positions per group, their MFMAs alternating: consecutive MFMAs never wait for each other's accumulator
+    f32x4 bv0 = vb[0], bv1 = vb[256];
 #pragma unroll
-    for (int p = 0; p < H4_POS; ++p) {
+    for (int p = 0; p < H4_POS; p += 2) {
         // the scheduler would otherwise sink the weight loads to just in front of their use (two in flight instead of nine)
         H4_SB();
-        const f32x4 bn = vb[(p + 1 < H4_POS ? p + 1 : p) * 256];
-        const f32x4 av = wf[p % H4_AHEAD];
+        const f32x4 bn0 = vb[(p + 2 < H4_POS ? p + 2 : p) * 256], bn1 = vb[(p + 3 < H4_POS ? p + 3 : p + 1) * 256];
+        const f32x4 av0 = wf[p % H4_AHEAD], av1 = wf[(p + 1) % H4_AHEAD];
         wf[p % H4_AHEAD] = h4_wload(rsrc, w_lane, w_off + (unsigned)((p + H4_AHEAD) * H4_FRAG));
+        wf[(p + 1) % H4_AHEAD] = h4_wload(rsrc, w_lane, w_off + (unsigned)((p + 1 + H4_AHEAD) * H4_FRAG));
         H4_SB();
         if constexpr (FIRST) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, z, 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.x, bv0.x, z, 0, 0, 0);
+            acc[p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.x, bv1.x, z, 0, 0, 0);
         } else {
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.x, bv0.x, acc[p], 0, 0, 0);
+            acc[p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.x, bv1.x, acc[p + 1], 0, 0, 0);
         }
-        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[p], 0, 0, 0);
-        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[p], 0, 0, 0);
-        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[p], 0, 0, 0);
-        bv = bn;
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.y, bv0.y, acc[p], 0, 0, 0);
+        acc[p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.y, bv1.y, acc[p + 1], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.z, bv0.z, acc[p], 0, 0, 0);
+        acc[p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.z, bv1.z, acc[p + 1], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.w, bv0.w, acc[p], 0, 0, 0);
+        acc[p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.w, bv1.w, acc[p + 1], 0, 0, 0);
+        H4_SB();
+        bv0 = bn0;
+        bv1 = bn1;
     }
 }
 
