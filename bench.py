@@ -134,6 +134,8 @@ def load_traffic(tile_name):
         sym = "conv_wino_resident_kernel"
     elif tile_name == "conv_wino_head":
         sym = "conv_wino_head_kernel"
+    elif tile_name == "conv_wino4_resident":
+        sym = "conv_f4res_kernel"
     elif tile_name == "conv_head_wino4":
         sym = "head_wino4_kernel"
     elif tile_name == "conv_head_bf16":

@@ -455,6 +455,17 @@ int sgv3d_centerhead_branches_forward_f4(int batch, int h, int w, int cin, int x
                                          const int32_t *out_begin, float *out, void *workspace,
                                          size_t workspace_bytes, void *stream);
 
+/* The main loop of sgv3d_centerhead_branches_forward_f4 as a plain 3x3 / stride 1 / pad 1 convolution (folded BN / bias,
+ * residual, ReLU, NHWC output) for the two shapes that keep the transformed input resident in LDS: cin == 64 with cout a
+ * multiple of 64 (mmdet ResNet layer 1, Bottleneck.conv2), or cout == 64 with cin a multiple of 64 (mmdet3d
+ * CenterHead.shared_conv, 256 -> 64).  desc: SGV3D_CONV_NORMAL, cin = the (padded) channel count the weights were packed for;
+ * tile / split_k are ignored.  u_packed: sgv3d_conv3x3_f4res_weight_floats(cout, cin) floats (0: shape not covered) from
+ * sgv3d_conv3x3_f4res_pack_weight(w OIHW [cout, cin_real, 3, 3], ...). */
+size_t sgv3d_conv3x3_f4res_weight_floats(int cout, int cin);
+int sgv3d_conv3x3_f4res_pack_weight(const float *w, int cout, int cin_real, int cin, float *u_packed, void *stream);
+int sgv3d_conv3x3_f4res_forward(const sgv3d_conv_desc *d, const float *x, const float *u_packed, const float *scale,
+                                const float *bias, const float *residual, float *y, void *stream);
+
 /* bf16-mode counterpart (BASELINE configs[2] / [4] compute dtype): the same two layers of all branches in one kernel on
  * the bf16 matrix cores, fp32 accumulation, hidden maps kept in LDS as bf16 (csrc/head_bf16.hip).  cin must be 64.
  *   w1_packed  sgv3d_centerhead_bf16_weight_bytes(num_branches) bytes, filled by sgv3d_centerhead_bf16_pack_weight from

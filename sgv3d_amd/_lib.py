@@ -68,6 +68,9 @@ _PROTOS = {
     "sgv3d_centerhead_f4_pack_weight": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "sgv3d_centerhead_branches_forward_f4": (c_int, [c_int] * 6 + [c_void_p, c_int] + [c_void_p] * 3 + [c_int] + [c_void_p] * 5
                                              + [c_size_t, c_void_p]),
+    "sgv3d_conv3x3_f4res_weight_floats": (c_size_t, [c_int, c_int]),
+    "sgv3d_conv3x3_f4res_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "sgv3d_conv3x3_f4res_forward": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 7),
     "sgv3d_centerhead_branches_forward_bf16": (c_int, [c_int] * 6 + [c_void_p, c_int] + [c_void_p] * 3 + [c_int] + [c_void_p] * 5),
     "sgv3d_centerhead_branches_forward_bf16x": (c_int, [c_int] * 6 + [c_void_p, c_int] + [c_void_p] * 3 + [c_int] + [c_void_p] * 5),
     "sgv3d_centerhead_bf16_select_plain": (None, [c_int]),

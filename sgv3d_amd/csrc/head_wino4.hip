@@ -150,6 +150,43 @@ __device__ __forceinline__ void h4_kquad(f32x4 (&acc)[H4_POS], f32x4 (&wf)[H4_AH
     }
 }
 
+// V = B^T d B of the 16 tiles of the block at (oy0, ox0) for 64 input channels starting at xb -> LDS, in two halves so that a
+// caller can put work between the loads and their use.  Thread = (tile, channel quad): consecutive threads read consecutive
+// 16-byte pieces of a pixel's channel row.
+__device__ __forceinline__ void h4_load_raw(f32x4 (&d)[6][6], const float *xb, int x_ld, int h, int w, int oy0, int ox0, int tid) {
+    const int jt = tid >> 4, cq = tid & 15;
+    const int iy0 = oy0 + 4 * (jt & 3) - 1, ix0 = ox0 + 4 * (jt >> 2) - 1;
+    xb += cq * 4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int iy = iy0 + i;
+        const bool rok = (unsigned)iy < (unsigned)h;
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {
+            const int ix = ix0 + jj;
+            const bool ok = rok & ((unsigned)ix < (unsigned)w);
+            d[i][jj] = ok ? *reinterpret_cast<const f32x4 *>(xb + ((size_t)iy * w + ix) * x_ld) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+__device__ __forceinline__ void h4_store_v(f32x4 *smem, f32x4 (&d)[6][6], int tid) {
+    const int jt = tid >> 4, cq = tid & 15;
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) h4_bt(d[0][jj], d[1][jj], d[2][jj], d[3][jj], d[4][jj], d[5][jj]);
+    f32x4 *const vw = smem + jt * 16 + (cq ^ jt);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        h4_bt(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) vw[(i * 6 + jj) * 256] = d[i][jj];
+    }
+}
+__device__ __forceinline__ void h4_build_v(f32x4 *smem, const float *xb, int x_ld, int h, int w, int oy0, int ox0, int tid) {
+    f32x4 d[6][6];
+    h4_load_raw(d, xb, x_ld, h, w, oy0, ox0, tid);
+    h4_store_v(smem, d, tid);
+}
+
 __global__ __launch_bounds__(256, 1) void head_wino4_kernel(const Head4Args a) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     float *const red = reinterpret_cast<float *>(smem + H4_V_SLOTS);
@@ -163,33 +200,8 @@ __global__ __launch_bounds__(256, 1) void head_wino4_kernel(const Head4Args a) {
     const int by = rb / a.wb_x, bx = rb - by * a.wb_x;
     const int oy0 = by * 16, ox0 = bx * 16;
 
-    // ---- V = B^T d B of the block's 16 tiles, once: thread = (tile, channel quad) --------------------------------------
-    {
-        const int jt = tid >> 4, cq = tid & 15;
-        const int iy0 = oy0 + 4 * (jt & 3) - 1, ix0 = ox0 + 4 * (jt >> 2) - 1;
-        const float *xb = a.x + (size_t)img * a.h * a.w * a.x_ld + a.x_coff + cq * 4;
-        f32x4 d[6][6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int iy = iy0 + i;
-            const bool rok = (unsigned)iy < (unsigned)a.h;
-#pragma unroll
-            for (int jj = 0; jj < 6; ++jj) {
-                const int ix = ix0 + jj;
-                const bool ok = rok & ((unsigned)ix < (unsigned)a.w);
-                d[i][jj] = ok ? *reinterpret_cast<const f32x4 *>(xb + ((size_t)iy * a.w + ix) * a.x_ld) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-#pragma unroll
-        for (int jj = 0; jj < 6; ++jj) h4_bt(d[0][jj], d[1][jj], d[2][jj], d[3][jj], d[4][jj], d[5][jj]);
-        f32x4 *const vw = smem + jt * 16 + (cq ^ jt);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            h4_bt(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
-#pragma unroll
-            for (int jj = 0; jj < 6; ++jj) vw[(i * 6 + jj) * 256] = d[i][jj];
-        }
-    }
+    // ---- V = B^T d B of the block's 16 tiles, once -------------------------------------------------------------------
+    h4_build_v(smem, a.x + (size_t)img * a.h * a.w * a.x_ld + a.x_coff, a.x_ld, a.h, a.w, oy0, ox0, tid);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.u, 0, (int)a.u_bytes, 0x00020000);
     const unsigned w_lane = (unsigned)lane * 16u;
     unsigned w_off = (unsigned)wave * (unsigned)a.nb * (unsigned)H4_BRANCH;
@@ -345,10 +357,103 @@ __global__ __launch_bounds__(256, 1) void head_wino4_kernel(const Head4Args a) {
     }
 }
 
-// U = G g G^T per (hidden channel, input channel) in the order the kernel streams it:
-// [channel chunk 4][branch][k-quad 4][pos 36][lane 64][4]; lane = 16 g + m: hidden channel 16 chunk + m, input channel
-// 16 q + 4 g + (0..3)
-__global__ void head_wino4_pack_kernel(const float *__restrict__ w1, int nb, float *__restrict__ dst, long long total) {
+// ------------------------------------------------------------------------------------------------------------------------
+// The same main loop as a plain 3x3 / stride 1 / pad 1 convolution (+ folded BN / bias, residual, ReLU, NHWC store) for the
+// two shapes that keep V resident: cin == 64 with any number of 64-channel output tiles (ResNet layer 1: the output tiles take
+// the place of the head's branches), or cout == 64 with cin a multiple of 64 (the CenterHead's shared 256 -> 64 layer: V is
+// rebuilt per 64-channel chunk of the input, the 36 accumulators run through all chunks).  mmdet ResNet Bottleneck.conv2 /
+// mmdet3d CenterHead.shared_conv as built by layers/backbones/lss_fpn.py:296-301 and layers/heads/bev_height_head.py:75-110.
+struct F4ResArgs {
+    const float *x, *u, *scale, *bias, *res;
+    float *y;
+    int x_ld, x_coff, y_ld, y_coff, res_ld, relu, h, w, wb_y, wb_x;
+    int n_ct, n_kc;               // 64-channel output tiles, 64-channel input chunks (one of them is 1)
+    unsigned u_bytes;
+};
+
+__global__ __launch_bounds__(256, 1) void conv_f4res_kernel(const F4ResArgs a) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tm = blockIdx.x;
+    const int bpi = a.wb_y * a.wb_x;
+    const int img = tm / bpi;
+    const int rb = tm - img * bpi;
+    const int by = rb / a.wb_x, bx = rb - by * a.wb_x;
+    const int oy0 = by * 16, ox0 = bx * 16;
+    const float *const ximg = a.x + (size_t)img * a.h * a.w * a.x_ld + a.x_coff;
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.u, 0, (int)a.u_bytes, 0x00020000);
+    const unsigned w_lane = (unsigned)lane * 16u;
+    unsigned w_off = (unsigned)wave * (unsigned)(a.n_ct * a.n_kc) * (unsigned)H4_BRANCH;
+    f32x4 wf[H4_AHEAD];
+#pragma unroll
+    for (int r = 0; r < H4_AHEAD; ++r) wf[r] = h4_wload(rsrc, w_lane, w_off + (unsigned)(r * H4_FRAG));
+    const int g = lane >> 4, j = lane & 15;
+
+    // (Requesting the raw pixels of chunk kc + 1 before the main loop of chunk kc -- 144 registers held across it, or one
+    // "touch" load per pixel -- does not pay: a wave's loads return in order, so the weight fragments behind them would wait
+    // for HBM too, and the 144 registers spill.)
+    for (int ct = 0; ct < a.n_ct; ++ct) {
+        f32x4 acc[H4_POS];
+        for (int kc = 0; kc < a.n_kc; ++kc) {
+            if (ct == 0 || a.n_kc > 1) {       // (n_kc == 1: the one V serves every output tile)
+                if (ct + kc > 0) H4_BARRIER();             // every wave is done with the previous chunk's V
+                int tid_ = tid;
+                asm volatile("" : "+v"(tid_));
+                h4_build_v(smem, ximg + kc * 64, a.x_ld, a.h, a.w, oy0, ox0, tid_);
+                H4_BARRIER();
+            }
+            if (kc == 0) h4_kquad<true>(acc, wf, smem + j * 16 + (g ^ j), rsrc, w_lane, w_off);
+            else h4_kquad<false>(acc, wf, smem + j * 16 + (g ^ j), rsrc, w_lane, w_off);
+#pragma unroll 1
+            for (int q = 1; q < 4; ++q)
+                h4_kquad<false>(acc, wf, smem + j * 16 + ((4 * q + g) ^ j), rsrc, w_lane, w_off + (unsigned)(q * H4_POS * H4_FRAG));
+            w_off += (unsigned)H4_BRANCH;
+        }
+        // ---- epilogue: A^T M A per (tile, channel) inside the lane, then 4 channels x 16 pixels as 16-byte stores
+        int tid_ = tid, oy0_ = oy0, ox0_ = ox0;
+        asm volatile("" : "+v"(tid_), "+s"(oy0_), "+s"(ox0_));
+        const int lane_ = tid_ & 63, g_ = lane_ >> 4, j_ = lane_ & 15;
+        const int py0 = oy0_ + 4 * (j_ & 3), px0 = ox0_ + 4 * (j_ >> 2);
+        const int co0 = ct * 64 + wave * 16 + 4 * g_;
+        const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + co0) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sh = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + co0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        float hd[4][16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t[4][6];
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj)
+                h4_at(acc[jj][r], acc[6 + jj][r], acc[12 + jj][r], acc[18 + jj][r], acc[24 + jj][r], acc[30 + jj][r], t[0][jj],
+                      t[1][jj], t[2][jj], t[3][jj]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                h4_at(t[u][0], t[u][1], t[u][2], t[u][3], t[u][4], t[u][5], hd[r][u * 4], hd[r][u * 4 + 1], hd[r][u * 4 + 2],
+                      hd[r][u * 4 + 3]);
+        }
+        const float floor_ = a.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int Y = py0 + u, X = px0 + v;
+                if (Y < a.h && X < a.w) {
+                    const size_t pix = ((size_t)img * a.h + Y) * a.w + X;
+                    f32x4 o = f32x4{hd[0][u * 4 + v], hd[1][u * 4 + v], hd[2][u * 4 + v], hd[3][u * 4 + v]} * sc + sh;
+                    if (a.res) o += *reinterpret_cast<const f32x4 *>(a.res + pix * a.res_ld + co0);
+                    o = f32x4{fmaxf(o.x, floor_), fmaxf(o.y, floor_), fmaxf(o.z, floor_), fmaxf(o.w, floor_)};
+                    *reinterpret_cast<f32x4 *>(a.y + pix * a.y_ld + a.y_coff + co0) = o;
+                }
+            }
+    }
+}
+
+// U = G g G^T per (output channel, input channel) in the order the kernels stream it:
+// [channel chunk 4][output tile (head: branch)][input chunk][k-quad 4][pos 36][lane 64][4]; lane = 16 g + m: output channel
+// 64 tile + 16 chunk + m, input channel 64 input-chunk + 16 q + 4 g + (0..3); w: OIHW [n_ct * 64][cin_real][3][3]
+__global__ void h4_pack_kernel(const float *__restrict__ w, int n_ct, int n_kc, int cin_real, float *__restrict__ dst, long long total) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int jj = (int)(i & 3), lane = (int)((i >> 2) & 63);
@@ -357,15 +462,19 @@ __global__ void head_wino4_pack_kernel(const float *__restrict__ w1, int nb, flo
     r /= 36;
     const int q = (int)(r & 3);
     r >>= 2;
-    const int br = (int)(r % nb), chunk = (int)(r / nb);
-    const int co = br * 64 + chunk * 16 + (lane & 15), ci = 16 * q + 4 * (lane >> 4) + jj;
-    const float *gsrc = w1 + ((size_t)co * 64 + ci) * 9;
-    const double G[6][3] = {{0.25, 0, 0},           {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
-                            {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0, 0, 1}};
-    const int pi = p / 6, pj = p - pi * 6;
+    const int kc = (int)(r % n_kc);
+    r /= n_kc;
+    const int ct = (int)(r % n_ct), chunk = (int)(r / n_ct);
+    const int co = ct * 64 + chunk * 16 + (lane & 15), ci = kc * 64 + 16 * q + 4 * (lane >> 4) + jj;
     double u = 0.0;
-    for (int y = 0; y < 3; ++y)
-        for (int x = 0; x < 3; ++x) u += G[pi][y] * (double)gsrc[y * 3 + x] * G[pj][x];
+    if (ci < cin_real) {
+        const float *gsrc = w + ((size_t)co * cin_real + ci) * 9;
+        const double G[6][3] = {{0.25, 0, 0},           {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
+                                {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0, 0, 1}};
+        const int pi = p / 6, pj = p - pi * 6;
+        for (int y = 0; y < 3; ++y)
+            for (int x = 0; x < 3; ++x) u += G[pi][y] * (double)gsrc[y * 3 + x] * G[pj][x];
+    }
     dst[i] = (float)u;
 }
 
@@ -380,8 +489,8 @@ extern "C" int sgv3d_centerhead_f4_pack_weight(const float *w1, int num_branches
     SGV3D_REQUIRE(w1 && u_packed && num_branches > 0, "centerhead_f4_pack_weight: bad arguments");
     const long long total = (long long)sgv3d_centerhead_f4_weight_floats(num_branches);
     SGV3D_REQUIRE(total * 4 < 0xf0000000LL, "centerhead_f4_pack_weight: packed weights larger than 3.75 GiB");
-    hipLaunchKernelGGL(head_wino4_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w1, num_branches, u_packed, total);
-    return check_launch("head_wino4_pack_kernel");
+    hipLaunchKernelGGL(h4_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w1, num_branches, 1, 64, u_packed, total);
+    return check_launch("h4_pack_kernel");
 }
 
 extern "C" int sgv3d_centerhead_branches_forward_f4(int batch, int h, int w, int cin, int x_ld, int x_coff, const float *x,
@@ -414,4 +523,49 @@ extern "C" int sgv3d_centerhead_branches_forward_f4(int batch, int h, int w, int
     const int rc = launch_head_ring_fixup(batch, h, w, total_out, a.ring, out, st);
     if (rc != SGV3D_OK) return rc;
     return check_launch("head_wino4_kernel");
+}
+
+// ---- plain convolution form (conv_f4res_kernel) ------------------------------------------------------------------------
+extern "C" size_t sgv3d_conv3x3_f4res_weight_floats(int cout, int cin) {
+    if (cout <= 0 || cin <= 0 || cout % 64 || cin % 64 || (cout != 64 && cin != 64)) return 0;
+    return (size_t)(cout / 64) * (cin / 64) * 4 * (H4_BRANCH / 4);
+}
+
+// w: OIHW [cout, cin_real, 3, 3] f32, cin_real <= cin (the rest of the input channels multiply zeros)
+extern "C" int sgv3d_conv3x3_f4res_pack_weight(const float *w, int cout, int cin_real, int cin, float *u_packed, void *stream) {
+    const long long total = (long long)sgv3d_conv3x3_f4res_weight_floats(cout, cin);
+    SGV3D_REQUIRE(w && u_packed && total > 0 && cin_real > 0 && cin_real <= cin,
+                  "conv3x3_f4res_pack_weight: needs cout and cin multiples of 64, one of them 64 (got %d, %d / %d real)", cout, cin, cin_real);
+    SGV3D_REQUIRE(total * 4 < 0xf0000000LL, "conv3x3_f4res_pack_weight: packed weights larger than 3.75 GiB");
+    hipLaunchKernelGGL(h4_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, cout / 64, cin / 64, cin_real, u_packed, total);
+    return check_launch("h4_pack_kernel");
+}
+
+extern "C" int sgv3d_conv3x3_f4res_forward(const sgv3d_conv_desc *d, const float *x, const float *u_packed, const float *scale,
+                                           const float *bias, const float *residual, float *y, void *stream) {
+    SGV3D_REQUIRE(d && x && u_packed && y, "conv3x3_f4res_forward: null pointer");
+    SGV3D_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->mode == SGV3D_CONV_NORMAL,
+                  "conv3x3_f4res_forward: only 3x3 / stride 1 / dilation 1 / pad 1, NHWC output (got k%dx%d s%d d%d p%d mode %d)", d->kh,
+                  d->kw, d->stride, d->dil, d->pad, d->mode);
+    SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->out_h == d->in_h && d->out_w == d->in_w,
+                  "conv3x3_f4res_forward: bad map size");
+    SGV3D_REQUIRE(sgv3d_conv3x3_f4res_weight_floats(d->cout, d->cin) > 0,
+                  "conv3x3_f4res_forward: needs cin and cout multiples of 64, one of them 64 (got %d -> %d)", d->cin, d->cout);
+    SGV3D_REQUIRE((d->x_ld & 3) == 0 && (d->x_coff & 3) == 0 && d->x_ld >= d->x_coff + d->cin && (d->y_ld & 3) == 0 &&
+                      (d->y_coff & 3) == 0 && d->y_ld >= d->y_coff + d->cout && (!residual || ((d->res_ld & 3) == 0 && d->res_ld >= d->cout)),
+                  "conv3x3_f4res_forward: channel strides / offsets must be multiples of 4 and cover the channels");
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(u_packed) | reinterpret_cast<uintptr_t>(y) |
+                         reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual);
+    SGV3D_REQUIRE((al & 15) == 0, "conv3x3_f4res_forward: pointers must be 16-B aligned");
+    F4ResArgs a;
+    a.x = x; a.u = u_packed; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
+    a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff; a.res_ld = d->res_ld; a.relu = d->relu;
+    a.h = d->in_h; a.w = d->in_w; a.wb_y = cdiv(d->in_h, 16); a.wb_x = cdiv(d->in_w, 16);
+    a.n_ct = d->cout / 64; a.n_kc = d->cin / 64;
+    a.u_bytes = (unsigned)(sgv3d_conv3x3_f4res_weight_floats(d->cout, d->cin) * 4);
+    static PerDeviceSize lds_set;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_f4res_kernel), (size_t)H4_V_BYTES, lds_set))
+        return fail(SGV3D_ELAUNCH, "conv3x3_f4res_forward: cannot raise the dynamic LDS limit to %d", H4_V_BYTES);
+    hipLaunchKernelGGL(conv_f4res_kernel, dim3(d->batch * a.wb_y * a.wb_x), dim3(256), H4_V_BYTES, as_stream(stream), a);
+    return check_launch("conv_f4res_kernel");
 }

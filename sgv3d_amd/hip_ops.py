@@ -135,7 +135,8 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: 
               21: "128x128", 22: "128x64", 23: "64x128", 24: "64x64",      # 21..24: tiles 1..4 walked m-tile first (SGV3D_TILE_MFIRST)
               31: "dw_bf16", 32: "dw_bf16", 33: "dw_bf16", 34: "dw_bf16", 35: "dw_bf16",   # bf16 direct-weight kernel (SGV3D_TILE_DW_*)
               36: "dw_bf16", 37: "dw_bf16",                                                # ... requests two k-chunks ahead (*_DEEP)
-              38: "dw_bf16", 39: "dw_bf16"}                                                # ... 64 pixels x 128 channels (39: two chunks ahead)
+              38: "dw_bf16", 39: "dw_bf16",                                                # ... 64 pixels x 128 channels (39: two chunks ahead)
+              40: "wino4_resident"}    # F(4x4,3x3) with the transformed input resident in LDS (sgv3d_conv3x3_f4res_forward)
 MFIRST = _os.environ.get("SGV3D_MFIRST", "1") != "0"
 TILE_WINO = 5       # host-side algorithm id: sgv3d_conv2d_winograd_forward instead of the implicit GEMM
 TILE_WINO_RES = 6   # = SGV3D_WINOGRAD_RESIDENT: its patch-resident variant (cin <= 96, many cout tiles)
@@ -145,6 +146,10 @@ TILE_WINO4 = 9      # Winograd F(4x4,3x3) in three launches (sgv3d_conv2d_winogr
 TILE_WINO4_WIDE = 10
 TILE_WINO4_NARROW = 15   # ... with the 32x128 GEMM tile: rows per position padded to 32 instead of 64 (336 tiles -> 352, 84 -> 96)
 WINO4_TILES = (TILE_WINO4, TILE_WINO4_WIDE, TILE_WINO4_NARROW)
+# F(4x4,3x3) in ONE launch with V = B^T d B of a 16x16 block resident in LDS (csrc/head_wino4.hip: conv_f4res_kernel): 3x3 /
+# stride 1 / pad 1 layers with 64 input channels (ResNet layer 1) or 64 output channels (the CenterHead's shared layer), f32
+TILE_F4RES = 40
+F4RES = _os.environ.get("SGV3D_F4RES", "1") != "0"     # 0: never a candidate
 WINO4 = _os.environ.get("SGV3D_WINO4", "1") != "0"     # 0: F(4x4) is never a candidate
 WINO4_MIN_CHANNELS = 128                              # candidates only where cin and cout are at least this
 WINO_HALF = _os.environ.get("SGV3D_WINO_HALF", "1") != "0"
@@ -353,6 +358,30 @@ class PackedConv:
                   (d.mode == CONV_GROUP_PLANES and d.deconv_ks % 4 == 0)) and d.x_ld % 4 == 0 and d.x_coff % 4 == 0 and d.res_ld % 4 == 0
         return ok
 
+    def f4res_ok(self, d=None, gate=None, io=0):
+        """The resident F(4x4) kernel covers this layer (and launch): f32, 3x3 / stride 1 / pad 1 / dilation 1, NHWC in and
+        out, no gate, and 64 input channels with 64 n output channels or 64 n input channels with 64 output channels."""
+        ok = (F4RES and WINO4 and WINOGRAD and not MFMA_BF16 and not MFMA_F32X3 and not self.transposed and self.kh == 3
+              and self.kw == 3 and self.stride == 1 and self.pad == 1 and self.dil == 1 and gate is None and io == 0
+              and self.cin % 64 == 0 and self.cout % 64 == 0 and (self.cin == 64 or self.cout == 64))
+        if ok and d is not None:
+            ok = (d.mode == CONV_NORMAL and d.x_ld % 4 == 0 and d.x_coff % 4 == 0 and d.y_ld % 4 == 0 and d.y_coff % 4 == 0
+                  and d.res_ld % 4 == 0)
+        return ok
+
+    def _f4res_weights(self):
+        """U = G g G^T in the fragment order conv_f4res_kernel streams (sgv3d_conv3x3_f4res_pack_weight), made on first use."""
+        if getattr(self, 'w_f4res', None) is None:
+            lib = _lib.load()
+            w = self._keep                                           # [cout, cin_real, 3, 3] f32 on the device
+            self.w_f4res = torch.empty(int(lib.sgv3d_conv3x3_f4res_weight_floats(self.cout, self.cin)), dtype=torch.float32,
+                                       device=w.device)
+            with torch.cuda.device(w.device):
+                rc = lib.sgv3d_conv3x3_f4res_pack_weight(w.data_ptr(), self.cout, int(w.shape[1]), self.cin,
+                                                         self.w_f4res.data_ptr(), _st(w))
+            _lib.check(rc, "sgv3d_conv3x3_f4res_pack_weight")
+        return self.w_f4res
+
     def _wino4_weights(self):
         """U[p] = (G g G^T)[i][j] for the 36 positions of F(4x4,3x3), each a packed 1x1 weight block of the implicit-GEMM
         kernel (36 x cout_pad x k_pad floats), made on first use by one kernel (sgv3d_conv_winograd4_pack_weight)."""
@@ -490,9 +519,9 @@ class PackedConv:
         real_n = self.cout_real * (self.ks * self.ks if self.transposed else 1)
         flops = 2.0 * gemm_m * real_n * (self.cin_real * self.kh * self.kw)
         x3 = 10 < t < 20 or (MFMA_F32X3 is True and t < TILE_WINO)
-        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) + WINO4_TILES + DW_TILES else
+        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF, TILE_F4RES) + WINO4_TILES + DW_TILES else
                 ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_f32x3_" if x3 else "conv_igemm_")) + TILE_NAMES[t]
-        if t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF) + WINO4_TILES + DW_TILES and self.k_order == 0:
+        if t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF, TILE_F4RES) + WINO4_TILES + DW_TILES and self.k_order == 0:
             name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
@@ -555,6 +584,12 @@ class PackedConv:
                                                              ws.data_ptr(), nws, _st(x))
             return lib.sgv3d_conv_dw_bf16_forward(ctypes.byref(d), x.data_ptr(), self._dw_weights().data_ptr(), _lib.ptr(self.scale),
                                                   _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(), _st(x))
+        if d.tile == TILE_F4RES:
+            if not self.f4res_ok(d, gate, io) or d.split_k > 1 or x.dtype != torch.float32:
+                raise _lib.SGV3DError("the resident F(4x4) kernel covers f32 3x3 / stride 1 / pad 1 layers with 64 input channels "
+                                      "(cout % 64 == 0) or 64 output channels (cin % 64 == 0), NHWC output, no gate, no split-K")
+            return lib.sgv3d_conv3x3_f4res_forward(ctypes.byref(d), x.data_ptr(), self._f4res_weights().data_ptr(), _lib.ptr(self.scale),
+                                                   _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(), _st(x))
         if d.tile in WINO4_TILES:
             if not self.wino4_ok(d, gate) or d.split_k > 1:
                 raise _lib.SGV3DError("F(4x4) Winograd covers f32 3x3 / stride 1 / pad 1 layers with cin % 32 == 0, cout % 4 == 0, "
@@ -642,6 +677,8 @@ class PackedConv:
 
         if self.wino4_ok(d, gate):            # (also the dilated 3x3 layers, which the F(2x2) kernels do not cover)
             tiles += WINO4_TILES if self.cin >= 128 else (TILE_WINO4, TILE_WINO4_WIDE)
+        if self.f4res_ok(d, gate, io):
+            tiles += (TILE_F4RES,)
         if self._patch_eligible(d, gate):
             tiles += (TILE_PATCH,)
         if self._dw_eligible(d, gate, io):
@@ -674,7 +711,7 @@ class PackedConv:
                 nk = -(-(self.kh * self.kw * (self.cin // 32)) // 2)      # chunks of 64 k; >= 4 per split
                 bm, bn = {31: (64, 256), 32: (128, 128), 33: (256, 64), 34: (128, 256), 35: (256, 128), 36: (64, 256), 37: (128, 128), 38: (64, 128), 39: (64, 128)}[t]
                 wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
-            if t == TILE_WINO_RES or t in WINO4_TILES or t in DW_DEEP_TILES or (t in DW_TILES and (d.mode != CONV_NORMAL or not DW_SPLIT_K)):
+            if t in (TILE_WINO_RES, TILE_F4RES) or t in WINO4_TILES or t in DW_DEEP_TILES or (t in DW_TILES and (d.mode != CONV_NORMAL or not DW_SPLIT_K)):
                 splits = (1,)
             elif t in DW_TILES:
                 splits = (fixed_split,) if fixed_split else \

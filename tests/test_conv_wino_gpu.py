@@ -250,6 +250,58 @@ def test_fused_centerhead_f4_exact_on_small_integers():
     assert torch.equal(out.cpu().double(), ref)
 
 
+F4RES_SHAPES = [
+    (1, 64, 16, 16, 64, 64),      # one block
+    (1, 64, 54, 96, 64, 64),      # ResNet layer 1 at quarter size: ragged bottom blocks
+    (2, 64, 21, 37, 192, 64),     # batch 2, three output tiles, odd sizes
+    (1, 256, 48, 40, 64, 256),    # the CenterHead's shared layer: four input chunks
+    (1, 128, 20, 20, 64, 120),    # real cin below the padded one (zero weight columns)
+]
+
+
+@pytest.mark.parametrize("shape", F4RES_SHAPES)
+@pytest.mark.parametrize("epi", ["plain", "bn_relu", "residual_relu"])
+def test_winograd4_resident_matches_conv2d(shape, epi):
+    """sgv3d_conv3x3_f4res_forward (conv_f4res_kernel: F(4x4) with V resident in LDS) through PackedConv(tile=TILE_F4RES) vs the
+    float64 definition; output written into a channel slice of a wider buffer, input read from one."""
+    from sgv3d_amd import hip_ops
+    from sgv3d_amd.hip_ops import PackedConv, TILE_F4RES
+    B, cin, H, W, cout, cin_real = shape
+    x, w = _mk(B, cin, H, W, cout, seed=3)
+    w = w[:, :cin_real].contiguous()
+    x[..., cin_real:] = 7.0                                       # must be multiplied by zero weights
+    g = torch.Generator().manual_seed(9)
+    scale = shift = res = None
+    if epi != "plain":
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    if epi == "residual_relu":
+        res = torch.randn(B, H, W, cout, generator=g)
+    conv = PackedConv(w.cuda(), pad=1, cin_pad=cin, scale=None if scale is None else scale.cuda(),
+                      shift=None if shift is None else shift.cuda(), relu=epi != "plain")
+    assert conv.f4res_ok()
+    xin = torch.cat([torch.full((B, H, W, 8), -3.0), x], -1).cuda()            # channels [8, 8 + cin) of a wider map
+    out = torch.full((B, H, W, cout + 12), 5.0, device="cuda")
+    y = conv(xin, out=out, x_coff=8, y_coff=4, residual=None if res is None else res.cuda(), tile=TILE_F4RES, split_k=1)
+    ref = _ref(x[..., :cin_real], w, scale, shift, res, relu=epi != "plain")
+    got = y[..., 4:4 + cout].cpu().double()
+    err = (got - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+    assert bool((y[..., :4] == 5.0).all()) and bool((y[..., 4 + cout:] == 5.0).all())      # neighbours of the slice untouched
+    again = conv(xin, out=torch.full_like(out, 5.0), x_coff=8, y_coff=4, residual=None if res is None else res.cuda(),
+                 tile=TILE_F4RES, split_k=1)
+    assert torch.equal(y, again)
+
+
+def test_winograd4_resident_rejects_other_shapes():
+    from sgv3d_amd import _lib
+    from sgv3d_amd.hip_ops import PackedConv, TILE_F4RES
+    x, w = _mk(1, 128, 16, 16, 128)
+    conv = PackedConv(w.cuda(), pad=1)
+    assert not conv.f4res_ok()
+    with pytest.raises(_lib.SGV3DError):
+        conv(x.cuda(), tile=TILE_F4RES, split_k=1)
+
+
 # ------------------------------------------------------------------------------------------------ F(4x4, 3x3)
 WINO4_SHAPES = [
     (1, 128, 8, 8, 128),       # exactly 2 x 2 tiles
