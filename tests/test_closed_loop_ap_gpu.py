@@ -6,9 +6,10 @@ set, no checkpoint): a synthetic scene set goes through BOTH chains
 
 and then through the same evaluator code (RoadSideEvaluator -> results JSON -> result2kitti label files -> KITTI AP
 R40, the reference's evaluation path, evaluators/det_evaluators.py:83-106), against ground truth derived from the
-oracle's own detections (kept, jittered or dropped boxes), so that the AP values are neither 0 nor 100.  The two result
-texts must be identical character by character, i.e. the ~1e-6 differences between the two forward passes change no
-detection, no match and no AP digit.
+oracle's own detections (kept, jittered or dropped boxes), so that the AP values are neither 0 nor 100.  With the kernels
+whose f32 rounding is closest to the oracle's (fixed per-layer rule, F(2x2) fused head: ~1e-6 from the oracle) the two result
+texts must be identical character by character: no detection, no match and no AP digit changes.  With the kernels as shipped
+(F(4x4) fused head: ~1e-5) every AP value must stay within 0.05 of the oracle chain's -- half the 0.1 the target allows.
 """
 import json
 import os
@@ -81,18 +82,27 @@ def test_hip_and_oracle_chains_give_identical_ap_text(tmp_path, fixed_kernel_cho
     ref_np = tuple([{k: v.numpy() for k, v in task[0].items()}] for task in ref)
     nc = [len(tk['class_names']) for tk in hc['tasks']]
     det_oracle = [(b, s, l) for b, s, l in decode_ref.get_bboxes(ref_np, hc['bbox_coder'], hc['test_cfg'], nc)]
-    # ---- HIP chain ------------------------------------------------------------------------------------------------
+    # ---- HIP chain, twice: F(2x2) fused head (closest rounding) and the shipped default (F(4x4) fused head) ----------------
+    from sgv3d_amd import hip_ops
     m = m.to(DEV)
-    with torch.no_grad():
-        preds = m(imgs.to(DEV), {k: v.to(DEV) for k, v in mats.items()})
-        out = m.get_bboxes(preds)
-    det_hip = [(b.tensor.cpu().numpy(), s.cpu().numpy(), l.cpu().numpy()) for b, s, l in out]
+    det_hips = {}
+    old_path = hip_ops.HEAD_PATH
+    try:
+        for tag, path in (('hip', 0), ('hip_default', old_path)):
+            hip_ops.HEAD_PATH = path
+            with torch.no_grad():
+                preds = m(imgs.to(DEV), {k: v.to(DEV) for k, v in mats.items()})
+                out = m.get_bboxes(preds)
+            det_hips[tag] = [(b.tensor.cpu().numpy(), s.cpu().numpy(), l.cpu().numpy()) for b, s, l in out]
+    finally:
+        hip_ops.HEAD_PATH = old_path
     n_det = sum(len(s) for _, s, _ in det_oracle)
     assert n_det > 10 * N_FRAMES, n_det                       # a scene set with plenty of detections
-    for (bo, so, lo), (bh, sh, lh) in zip(det_oracle, det_hip):
-        assert len(so) == len(sh) and np.array_equal(lo, lh)
-        np.testing.assert_allclose(bh, bo, rtol=1e-4, atol=1e-4)
-        np.testing.assert_allclose(sh, so, rtol=1e-5, atol=1e-5)
+    for tag, det_hip in det_hips.items():
+        for (bo, so, lo), (bh, sh, lh) in zip(det_oracle, det_hip):
+            assert len(so) == len(sh) and np.array_equal(lo, lh), tag
+            np.testing.assert_allclose(bh, bo, rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(sh, so, rtol=1e-5, atol=1e-5)
     # ---- data root + ground truth derived from the oracle's detections ------------------------------------------------
     root = tmp_path / 'dair-v2x-i-kitti'
     os.makedirs(root / 'training' / 'calib')
@@ -124,13 +134,17 @@ def test_hip_and_oracle_chains_give_identical_ap_text(tmp_path, fixed_kernel_cho
     for i in range(N_FRAMES):                                               # ground-truth files: no score column
         lines = open(os.path.join(gt_raw, f'{i:06d}.txt')).read().splitlines()
         (tmp_path / 'gt' / f'{i:06d}.txt').write_text("".join(" ".join(ln.split(' ')[:15]) + "\n" for ln in lines))
-    texts = {}
-    for tag, dets in (('oracle', det_oracle), ('hip', det_hip)):
+    texts, aps = {}, {}
+    for tag, dets in (('oracle', det_oracle), ('hip', det_hips['hip']), ('hip_default', det_hips['hip_default'])):
         path = labels_of(dets, tag)
         dt, ids = KC.get_label_annos(path, return_ids=True)
         gt = KC.get_label_annos(str(tmp_path / 'gt'), image_ids=ids)
         texts[tag], ret = E.kitti_eval(gt, dt, ["Car", "Pedestrian", "Cyclist"], metric="R40")
+        aps[tag] = ret
         if tag == 'oracle':
             vals = np.array(list(ret.values()))
             assert (vals > 1).any() and (vals < 99).any(), vals          # a non-degenerate AP table
     assert texts['hip'] == texts['oracle']
+    assert aps['hip_default'].keys() == aps['oracle'].keys()
+    worst = max(abs(float(aps['hip_default'][k]) - float(aps['oracle'][k])) for k in aps['oracle'])
+    assert worst < 0.05, (worst, texts['hip_default'], texts['oracle'])
