@@ -714,7 +714,9 @@ def main():
         hstep = lambda: H.eval_step(model, H.make_batch(imgs, host_mats))
         with torch.no_grad():
             default_mode = model.graph_forward                  # "auto": the model keeps the replay where it measures faster
-            for _ in range(max(3, args.warmup)):
+            # (warm-up: call 1 runs eagerly and measures, call 2 captures the model's own graph and times replay against eager,
+            # dropping the graph's ~1 GB activation pool if eager wins; a few more settle the caching allocator after that)
+            for _ in range(max(8, args.warmup)):
                 res = hstep()
             th = group.timed(hstep, args.steps)
             n_h = max(args.steps, int(1.2 / max(th / args.steps, 1e-4)) + 1)
