@@ -254,6 +254,9 @@ typedef struct sgv3d_conv_desc {
 /* ... | SGV3D_TILE_MFIRST: the workgroups walk the output-channel tiles of one m-tile back to back (input rows fetched once
  * from HBM) instead of the m-tiles of one channel tile (weight tile shared); same results */
 #define SGV3D_TILE_MFIRST 16
+/* ... | SGV3D_TILE_OCC5 (with SGV3D_TILE_64x64, f32, channel-chunk-major weights): the five-workgroups-per-CU form of the 64x64
+ * tile -- 32 KB of LDS (swizzled rows), one register stage; for small-K layers (csrc/conv_igemm.hip) */
+#define SGV3D_TILE_OCC5 32
 /* sgv3d_conv2d_winograd_forward only: desc.tile == SGV3D_WINOGRAD_RESIDENT selects the variant that keeps
  * the input patch of all channels in LDS and walks over the cout tiles (cin <= 96, split_k <= 1: the
  * fused CenterHead branch layer); any other value selects the streaming variant. */

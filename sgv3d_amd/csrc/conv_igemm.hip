@@ -108,8 +108,18 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
 // NARROW (with WTM = WTN = 1): a 32 x 128 tile -- the four waves side by side along N, each one 32 x 32 MFMA tile -- for GEMMs
 // whose row count is a multiple of 32 but not of 64: the grouped GEMM of the F(4x4) path pads the tiles of a position to the
 // m-tile height, and 336 tiles are 352 rows instead of 384, 84 are 96 instead of 128.
-template <int WTM, int WTN, bool FAST, bool SWAP = false, bool PW = false, bool NARROW = false>
-__global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm_kernel(const ConvArgs a) {
+//
+// OCC (64 x 64 tile, FAST, not SWAP; desc.tile | SGV3D_TILE_OCC5): FIVE workgroups per CU instead of four -- for the small-K
+// layers whose workgroups spend most of their life in the prologue / epilogue (2-4 k MFMA cycles behind 6-13 k cycles of memory
+// latency), a fifth resident workgroup is a quarter more MFMA work to fill those cycles with.  The budget: exactly 32 KB of
+// LDS (the 4-float row padding becomes an XOR swizzle of the 16-byte chunk with (row >> 1) & 7: conflict-free for the 16-lane
+// phases of both the b128 stores and the b128 fragment reads) and <= 96 registers (one register stage instead of two: tile
+// t+1 is requested at the top of tile t's phase and written to the other buffer just before the phase's barrier; the residual
+// is read in the epilogue instead of being prefetched).  One more candidate of the per-layer measurement.
+template <int WTM, int WTN, bool FAST, bool SWAP = false, bool PW = false, bool NARROW = false, bool OCC = false>
+__global__ __launch_bounds__(kThreads, OCC ? 5 : (WTM * WTN == 4) ? 1 : 2) void conv_igemm_kernel(const ConvArgs a) {
+    static_assert(!OCC || (WTM == 1 && WTN == 1 && FAST && !SWAP && !NARROW), "the five-per-CU form is the plain 64x64 FAST tile");
+    constexpr int LDX = OCC ? BK : LDK;            // floats per LDS row
     static_assert(!SWAP || (WTM == 1 && WTN == 1), "the swapped epilogue is written for the 64x64 tile");
     static_assert(!PW || FAST, "the pointwise specialisation is for the channel-chunk-major k order");
     static_assert(!NARROW || (WTM == 1 && WTN == 1 && !SWAP), "the narrow tile is one MFMA tile per wave");
@@ -119,8 +129,8 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     extern __shared__ __attribute__((aligned(16))) float smem[];
     IGEMM_STAMP(0);
     float *const As0 = smem;
-    float *const Bs0 = smem + BM * LDK;
-    constexpr int kBufStride = (BM + BN) * LDK;
+    float *const Bs0 = smem + BM * LDX;
+    constexpr int kBufStride = (BM + BN) * LDX;
     // Tap-major K (cin % 32 != 0: the 7x7 stems): decoding k -> (tap, channel) takes two integer divisions
     // per thread and k-tile -- vector instructions that cost MFMA time on this chip.  They are done once per
     // workgroup instead: a table in LDS behind the tiles, one entry per 16-byte k-chunk:
@@ -163,6 +173,7 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     const int tid = threadIdx.x;
     const int cc = tid & 7;    // 16-B chunk column inside the 32-wide k-tile
     const int r0 = tid >> 3;   // first row handled by this thread (then +32, +64, ...)
+    const int cs = OCC ? (cc ^ ((r0 >> 1) & 7)) : cc;      // chunk slot inside the LDS row (rows +32 i share the key)
 
     // ---- per-thread A rows -----------------------------------------------------------------
     // Operands are read with buffer loads: resource (base, size) and the uniform part of the address in
@@ -320,17 +331,22 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     do {                                                                                              \
         float *As_ = As0 + (BUF) * kBufStride, *Bs_ = Bs0 + (BUF) * kBufStride;                       \
         _Pragma("unroll") for (int i = 0; i < A_CH; ++i)                                              \
-            *reinterpret_cast<float4 *>(As_ + (r0 + 32 * i) * LDK + cc * 4) = RA[i];                  \
+            *reinterpret_cast<float4 *>(As_ + (r0 + 32 * i) * LDX + cs * 4) = RA[i];                  \
         _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                              \
-            *reinterpret_cast<float4 *>(Bs_ + (r0 + 32 * i) * LDK + cc * 4) = RB[i];                  \
+            *reinterpret_cast<float4 *>(Bs_ + (r0 + 32 * i) * LDX + cs * 4) = RB[i];                  \
     } while (0)
 
     // ---- MFMA fragments ------------------------------------------------------------------------
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = NARROW ? 0 : wave >> 1, wn = NARROW ? wave : wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
-    const int a_frag_off = (wm * WSM + lr) * LDK + lh * 4;
-    const int b_frag_off = (wn * WSN + lr) * LDK + lh * 4;
+    const int a_frag_off = (wm * WSM + lr) * LDX + (OCC ? 0 : lh * 4);
+    const int b_frag_off = (wn * WSN + lr) * LDX + (OCC ? 0 : lh * 4);
+    // offset of k-group KQ's 16-byte chunk (2 KQ + lh) inside the lane's row: plain, or swizzled with the row's key
+    // ((row >> 1) & 7 = (lr >> 1) & 7 for every row of the lane: the wave / MFMA-tile offsets are multiples of 32)
+    int fo[4];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) fo[kq] = OCC ? (((2 * kq + lh) ^ ((lr >> 1) & 7)) * 4) : kq * 8;
 
     f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -346,14 +362,14 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     float4 fa0[WTM], fb0[WTN], fa1[WTM], fb1[WTN];
 #define SGV3D_READ_FRAG(FA, FB, BUF, KQ)                                                              \
     do {                                                                                              \
-        const float *Aw_ = As0 + (BUF) * kBufStride + a_frag_off + (KQ) * 8;                          \
-        const float *Bw_ = Bs0 + (BUF) * kBufStride + b_frag_off + (KQ) * 8;                          \
+        const float *Aw_ = As0 + (BUF) * kBufStride + a_frag_off + fo[KQ];                            \
+        const float *Bw_ = Bs0 + (BUF) * kBufStride + b_frag_off + fo[KQ];                            \
         _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt) {                                          \
-            const float4 t_ = *reinterpret_cast<const float4 *>(Aw_ + mt * 32 * LDK);                 \
+            const float4 t_ = *reinterpret_cast<const float4 *>(Aw_ + mt * 32 * LDX);                 \
             FA[mt].x = t_.x; FA[mt].y = t_.y; FA[mt].z = t_.z; FA[mt].w = t_.w;                       \
         }                                                                                             \
         _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt) {                                          \
-            const float4 t_ = *reinterpret_cast<const float4 *>(Bw_ + nt * 32 * LDK);                 \
+            const float4 t_ = *reinterpret_cast<const float4 *>(Bw_ + nt * 32 * LDX);                 \
             FB[nt].x = t_.x; FB[nt].y = t_.y; FB[nt].z = t_.z; FB[nt].w = t_.w;                       \
         }                                                                                             \
     } while (0)
@@ -396,6 +412,33 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
         SGV3D_SB();                                                                                   \
     } while (0)
 
+    // OCC: one register stage.  Tile t+1 is requested at the top of tile t's phase and published just before the barrier.
+#define SGV3D_PHASE_OCC(BUF, HAVE_NEXT)                                                               \
+    do {                                                                                              \
+        if constexpr (HAVE_NEXT) SGV3D_LOAD_TILE(ra0, rb0);                                           \
+        else SGV3D_PREFETCH_RES();                                                                    \
+        SGV3D_READ_FRAG(fa1, fb1, BUF, 1);                                                            \
+        SGV3D_SB();                                                                                   \
+        SGV3D_MFMA_KQ(fa0, fb0);                                                                      \
+        SGV3D_SB();                                                                                   \
+        SGV3D_READ_FRAG(fa0, fb0, BUF, 2);                                                            \
+        SGV3D_SB();                                                                                   \
+        SGV3D_MFMA_KQ(fa1, fb1);                                                                      \
+        SGV3D_SB();                                                                                   \
+        SGV3D_READ_FRAG(fa1, fb1, BUF, 3);                                                            \
+        SGV3D_SB();                                                                                   \
+        SGV3D_MFMA_KQ(fa0, fb0);                                                                      \
+        SGV3D_SB();                                                                                   \
+        if constexpr (HAVE_NEXT) {                                                                    \
+            SGV3D_STORE_TILE(ra0, rb0, (BUF) ^ 1);                                                    \
+            __syncthreads();                                                                          \
+            SGV3D_READ_FRAG(fa0, fb0, (BUF) ^ 1, 0);                                                  \
+        }                                                                                             \
+        SGV3D_SB();                                                                                   \
+        SGV3D_MFMA_KQ(fa1, fb1);                                                                      \
+        SGV3D_SB();                                                                                   \
+    } while (0)
+
     // Residual prefetch (64x64 tile, fast-path epilogue): the small-K layers that carry a residual (the expanding 1x1
     // convolutions of the bottlenecks) spend a third of a workgroup's life waiting for the residual rows they only
     // ask for after the k loop; asked for here, the 16 values per lane arrive under the loop.
@@ -407,7 +450,7 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
     // the first two k-tiles are asked for BEFORE the residual rows: memory returns in order, and the wait for k-tile 0
     // (the workgroup's prologue: 9-13 k cycles on a loaded chip, tools/igemm_stamps.py) must not queue behind 16 more loads
     SGV3D_LOAD_TILE(ra0, rb0);                       // tile 0
-    SGV3D_LOAD_TILE(ra1, rb1);                       // tile 1
+    if constexpr (!OCC) SGV3D_LOAD_TILE(ra1, rb1);   // tile 1
     float resv[WTM][WTN][16];
     // SWAP: the lane's pixel row (m0 + wm * 32 + lr) and its 4 channel quads (n0 + wn * 32 + 8 q + 4 lh): residual, folded-BN
     // scale and shift are 4 dwordx4 loads each, asked for here so that they arrive under the k loop
@@ -426,32 +469,49 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
             sw_res[q] = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(
                 pr_rsrc, (has_res && c0 + 8 * q < a.N) ? roff : 0xffffffffu, 32 * q, 0));
     }
-    if constexpr (kPrefetchRes && !SWAP) {
-        const bool want = fast_epi && a.split_k <= 1 && a.res != nullptr;
-        const long long tile_row = m0 + __builtin_amdgcn_readfirstlane(wm) * WSM;
-        const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(want ? a.res + tile_row * a.res_ld : a.zeros), 0, want ? (int)0xffffff00u : 0, 0x00020000);
-#pragma unroll
-        for (int nt = 0; nt < WTN; ++nt) {
-            const int col = n0 + wn * WSN + nt * 32 + lr;
-            const unsigned roff0 = (want && col < a.N) ? (4u * lh * (unsigned)a.res_ld + col) * 4u : 0xffffffffu;
-#pragma unroll
-            for (int mt = 0; mt < WTM; ++mt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const unsigned r_ = mt * 32 + (e & 3) + 8 * (e >> 2);
-                    resv[mt][nt][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr_rsrc, roff0, r_ * a.res_ld * 4u, 0));
-                }
-        }
-    }
+    // (OCC: the same loads are issued at the top of the LAST k-tile's phase instead -- the staging registers of the k loop are
+    //  free by then, and one k-tile of MFMAs still covers their latency)
+#define SGV3D_PREFETCH_RES()                                                                          \
+    do {                                                                                              \
+        const bool want = fast_epi && a.split_k <= 1 && a.res != nullptr;                             \
+        const long long tile_row = m0 + __builtin_amdgcn_readfirstlane(wm) * WSM;                     \
+        const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(                     \
+            (void *)(want ? a.res + tile_row * a.res_ld : a.zeros), 0, want ? (int)0xffffff00u : 0, 0x00020000); \
+        _Pragma("unroll") for (int nt = 0; nt < WTN; ++nt) {                                          \
+            const int col = n0 + wn * WSN + nt * 32 + lr;                                             \
+            const unsigned roff0 = (want && col < a.N) ? (4u * lh * (unsigned)a.res_ld + col) * 4u : 0xffffffffu; \
+            _Pragma("unroll") for (int mt = 0; mt < WTM; ++mt)                                        \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                      \
+                    const unsigned r_ = mt * 32 + (e & 3) + 8 * (e >> 2);                             \
+                    resv[mt][nt][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr_rsrc, roff0, r_ * a.res_ld * 4u, 0)); \
+                }                                                                                     \
+        }                                                                                             \
+    } while (0)
+    if constexpr (kPrefetchRes && !SWAP && !OCC) SGV3D_PREFETCH_RES();
     SGV3D_STORE_TILE(ra0, rb0, 0);
     __syncthreads();
     IGEMM_STAMP(1);
     SGV3D_READ_FRAG(fa0, fb0, 0, 0);
-    for (int kt = kt_begin; kt < nkt; kt += 2) {
-        SGV3D_PHASE(0, ra0, rb0, ra1, rb1, kt + 1 < nkt);      // tile kt in buffer 0
-        if (kt + 1 >= nkt) break;
-        SGV3D_PHASE(1, ra1, rb1, ra0, rb0, kt + 2 < nkt);      // tile kt+1 in buffer 1
+    if constexpr (OCC) {
+        // every phase but the last in pairs (buffer 0, buffer 1); the last one is peeled: it asks for the residual rows instead
+        // of a next tile, into the registers the staging no longer needs
+        int kt = kt_begin;
+        for (; kt + 2 < nkt; kt += 2) {
+            SGV3D_PHASE_OCC(0, true);
+            SGV3D_PHASE_OCC(1, true);
+        }
+        if (kt + 1 < nkt) {
+            SGV3D_PHASE_OCC(0, true);
+            SGV3D_PHASE_OCC(1, false);
+        } else if (kt < nkt) {
+            SGV3D_PHASE_OCC(0, false);
+        }
+    } else {
+        for (int kt = kt_begin; kt < nkt; kt += 2) {
+            SGV3D_PHASE(0, ra0, rb0, ra1, rb1, kt + 1 < nkt);      // tile kt in buffer 0
+            if (kt + 1 >= nkt) break;
+            SGV3D_PHASE(1, ra1, rb1, ra0, rb0, kt + 2 < nkt);      // tile kt+1 in buffer 1
+        }
     }
     IGEMM_STAMP(2);
 #undef SGV3D_LOAD_TILE
@@ -459,6 +519,8 @@ __global__ __launch_bounds__(kThreads, (WTM * WTN == 4) ? 1 : 2) void conv_igemm
 #undef SGV3D_READ_FRAG
 #undef SGV3D_MFMA_KQ
 #undef SGV3D_PHASE
+#undef SGV3D_PHASE_OCC
+#undef SGV3D_PREFETCH_RES
 #undef SGV3D_SB
 
     // ---- epilogue ------------------------------------------------------------------------------------
@@ -1210,6 +1272,25 @@ int launch_t(const ConvArgs &a, hipStream_t st) {
     b.tiles_m = cdiv(a.M, BM);
     b.tiles_n = cdiv(a.N, BN);
     if constexpr (WTM == 1 && WTN == 1 && FAST) {
+        if (a.korder & 4) {      // five workgroups per CU (desc.tile | SGV3D_TILE_OCC5): 32 KB of LDS, one register stage
+            constexpr size_t lds5 = sizeof(float) * 2 * (BM + BN) * BK;
+            const bool pw5 = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.in_h == a.m_h && a.in_w == a.m_w &&
+                             (a.mode & kConvModeMask) != SGV3D_CONV_DECONV;
+            static PerDeviceSize lds_set_o, lds_set_opw;
+            if (pw5) {
+                if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel<1, 1, true, false, true, false, true>), lds5, lds_set_opw))
+                    return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot raise the dynamic LDS limit to %zu", lds5);
+                hipLaunchKernelGGL((conv_igemm_kernel<1, 1, true, false, true, false, true>), dim3(b.tiles_m * b.tiles_n, b.split_k),
+                                   dim3(kThreads), lds5, st, b);
+            } else {
+                if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel<1, 1, true, false, false, false, true>), lds5, lds_set_o))
+                    return fail(SGV3D_ELAUNCH, "conv2d_forward: cannot raise the dynamic LDS limit to %zu", lds5);
+                hipLaunchKernelGGL((conv_igemm_kernel<1, 1, true, false, false, false, true>), dim3(b.tiles_m * b.tiles_n, b.split_k),
+                                   dim3(kThreads), lds5, st, b);
+            }
+            if (b.split_k > 1) return launch_splitk_reduce(b, st);
+            return check_launch("conv_igemm_kernel(occ5)");
+        }
         // 16-byte epilogue (operands swapped): NHWC output in 16-byte channel quads, everything 16-B aligned
         const bool quads = a.N % 4 == 0 && a.y_ld % 4 == 0 && a.y_coff % 4 == 0 && (a.res == nullptr || a.res_ld % 4 == 0) &&
                            ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.res) |
@@ -1477,7 +1558,10 @@ static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const f
     a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff; a.res_ld = d->res_ld;
     a.relu = d->relu; a.mode = d->mode; a.ks = d->deconv_ks; a.k_pad = d->k_pad;
     a.tiles_m = a.tiles_n = 0;
-    a.korder = d->k_order | ((d->tile & SGV3D_TILE_MFIRST) ? 2 : 0);
+    a.korder = d->k_order | ((d->tile & SGV3D_TILE_MFIRST) ? 2 : 0) | ((d->tile & SGV3D_TILE_OCC5) ? 4 : 0);
+    SGV3D_REQUIRE(!(d->tile & SGV3D_TILE_OCC5) || ((d->tile & ~(SGV3D_TILE_MFIRST | SGV3D_TILE_OCC5)) == SGV3D_TILE_64x64 &&
+                                                    (d->k_order & 1) && !io && !bf16),
+                  "conv2d_forward: SGV3D_TILE_OCC5 goes with the f32 64x64 tile and channel-chunk-major weights (cin %% 32 == 0)");
     {
         const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * ((io & 1) ? 2 : 4), wb = (long long)d->cout_pad * d->k_pad * (io ? 2 : 4);
         SGV3D_REQUIRE(xb < 0xf0000000LL && wb < 0xf0000000LL, "conv2d_forward: input / packed weights larger than 3.75 GiB (32-bit buffer offsets)");
@@ -1525,7 +1609,8 @@ static int conv2d_forward_impl(const sgv3d_conv_desc *d, const float *x, const f
         if (!workspace || workspace_bytes < need)
             return fail(SGV3D_ENOSPACE, "conv2d_forward: split-K workspace has %zu bytes, needs %zu", workspace_bytes, need);
     }
-    const int tile = (d->tile & ~SGV3D_TILE_MFIRST) ? (d->tile & ~SGV3D_TILE_MFIRST) : pick_tile(M, a.N);
+    const int tile_bits = d->tile & ~(SGV3D_TILE_MFIRST | SGV3D_TILE_OCC5);
+    const int tile = tile_bits ? tile_bits : pick_tile(M, a.N);
     hipStream_t st = as_stream(stream);
     if (io & 2) a.mode |= kConvYBf16 | kConvResBf16;       // (NORMAL / DECONV mode, checked above)
     if (io) {

@@ -136,7 +136,8 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: 
               31: "dw_bf16", 32: "dw_bf16", 33: "dw_bf16", 34: "dw_bf16", 35: "dw_bf16",   # bf16 direct-weight kernel (SGV3D_TILE_DW_*)
               36: "dw_bf16", 37: "dw_bf16",                                                # ... requests two k-chunks ahead (*_DEEP)
               38: "dw_bf16", 39: "dw_bf16",                                                # ... 64 pixels x 128 channels (39: two chunks ahead)
-              40: "wino4_resident"}    # F(4x4,3x3) with the transformed input resident in LDS (sgv3d_conv3x3_f4res_forward)
+              40: "wino4_resident",    # F(4x4,3x3) with the transformed input resident in LDS (sgv3d_conv3x3_f4res_forward)
+              44: "64x64", 45: "64x64"}    # the 64x64 tile at five workgroups per CU (SGV3D_TILE_OCC5); 45: walked m-tile first
 MFIRST = _os.environ.get("SGV3D_MFIRST", "1") != "0"
 TILE_WINO = 5       # host-side algorithm id: sgv3d_conv2d_winograd_forward instead of the implicit GEMM
 TILE_WINO_RES = 6   # = SGV3D_WINOGRAD_RESIDENT: its patch-resident variant (cin <= 96, many cout tiles)
@@ -150,6 +151,10 @@ WINO4_TILES = (TILE_WINO4, TILE_WINO4_WIDE, TILE_WINO4_NARROW)
 # stride 1 / pad 1 layers with 64 input channels (ResNet layer 1) or 64 output channels (the CenterHead's shared layer), f32
 TILE_F4RES = 40
 F4RES = _os.environ.get("SGV3D_F4RES", "1") != "0"     # 0: never a candidate
+# f32 implicit GEMM, 64x64 tile with five workgroups per CU (32 KB of swizzled LDS, one register stage; csrc/conv_igemm.hip:
+# OCC): for the small-K layers; host ids 44 / 45 (= m-tile first) -> SGV3D_TILE_64x64 | SGV3D_TILE_OCC5 [| SGV3D_TILE_MFIRST]
+OCC5_TILES = (44, 45)
+OCC5 = _os.environ.get("SGV3D_OCC5", "1") != "0"       # 0: never candidates
 WINO4 = _os.environ.get("SGV3D_WINO4", "1") != "0"     # 0: F(4x4) is never a candidate
 WINO4_MIN_CHANNELS = 128                              # candidates only where cin and cout are at least this
 WINO_HALF = _os.environ.get("SGV3D_WINO_HALF", "1") != "0"
@@ -525,7 +530,7 @@ class PackedConv:
             name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
-                     f"s{self.stride} d{self.dil} splitk{sk}" + (" mfirst" if 20 < t < 30 else ""))
+                     f"s{self.stride} d{self.dil} splitk{sk}" + (" mfirst" if 20 < t < 30 or t == 45 else "") + (" occ5" if t in OCC5_TILES else ""))
         if io:
             name = name.replace("conv_igemm_bf16_", "conv_igemm_bf16io_")
         with torch.cuda.device(x.device), prof(name, flops):
@@ -614,7 +619,11 @@ class PackedConv:
                                                      _lib.ptr(gate), out.data_ptr(), _lib.ptr(ws), nws, _st(x))
         x3 = 10 < d.tile < 20 or (MFMA_F32X3 is True)
         host_tile = d.tile
-        if host_tile > 20:
+        if host_tile in OCC5_TILES:
+            if MFMA_BF16 or x3 or io or self.k_order != 1:
+                raise _lib.SGV3DError("the five-per-CU 64x64 tile is f32 only and needs channel-chunk-major weights (cin % 32 == 0)")
+            d.tile = 4 | 32 | (16 if host_tile == 45 else 0)      # SGV3D_TILE_64x64 | SGV3D_TILE_OCC5 [| SGV3D_TILE_MFIRST]
+        elif host_tile > 20:
             d.tile = (host_tile - 20) | 16          # SGV3D_TILE_MFIRST
         elif host_tile > 10:
             d.tile = host_tile - 10
@@ -666,6 +675,10 @@ class PackedConv:
         tiles = (1, 2, 3, 4)
         if MFIRST and d.mode in (CONV_NORMAL, CONV_NCHW_OUT) and gemm_n > 64:
             tiles += tuple(t + 20 for t in (1, 2, 3, 4) if gemm_n > (128 if t in (1, 3) else 64))   # more than one channel tile
+        if OCC5 and self.k_order == 1 and not MFMA_BF16 and not MFMA_F32X3 and io == 0:
+            tiles += (44,)
+            if MFIRST and d.mode in (CONV_NORMAL, CONV_NCHW_OUT) and gemm_n > 64:
+                tiles += (45,)
         if MFMA_F32X3 == "auto" and not MFMA_BF16:
             tiles += (11, 12, 13, 14)
         if self.wino_ok and WINOGRAD and not MFMA_BF16:
@@ -695,7 +708,7 @@ class PackedConv:
             tiles = (fixed_tile,)
         dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 64), 6: (256, 64),
                 11: (128, 128), 12: (128, 64), 13: (64, 128), 14: (64, 64),
-                21: (128, 128), 22: (128, 64), 23: (64, 128), 24: (64, 64)}
+                21: (128, 128), 22: (128, 64), 23: (64, 128), 24: (64, 64), 44: (64, 64), 45: (64, 64)}
         cands = []
         for t in tiles:
             bm, bn = dims.get(t, (512, 64))

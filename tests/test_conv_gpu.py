@@ -467,3 +467,35 @@ def test_tune_db_entry_is_checked_against_the_switches_and_the_layout(hip):
         hip_ops.WINOGRAD, hip_ops.WINO4, hip_ops.AUTOTUNE = saved[:3]
         hip_ops.TUNE_DB.clear()
         hip_ops.TUNE_DB.update(saved[3])
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 54, 96, 256, 1, 1, 0), (2, 256, 27, 33, 64, 1, 1, 0), (1, 128, 20, 31, 512, 1, 1, 0),
+                                   (1, 64, 33, 47, 96, 3, 1, 1), (1, 160, 32, 32, 320, 3, 2, 1), (1, 512, 14, 18, 100, 1, 1, 0)])
+@pytest.mark.parametrize("split", [1, 2])
+def test_five_per_cu_tile_is_bitwise_the_64x64_tile(hip, shape, split):
+    """SGV3D_TILE_OCC5 (32 KB of swizzled LDS, one register stage, residual read in the epilogue) sums every output's k in the
+    order of the plain 64x64 tile: bitwise the same result, for pointwise and general layers, with residual / BN / ReLU,
+    ragged m- and n-tiles, split-K and the m-tile-first walk."""
+    from sgv3d_amd.hip_ops import PackedConv
+    B, cin, H, W, cout, k, stride, pad = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, H, W, cin, generator=g).cuda()
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).cuda()
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.2).cuda()
+    conv = PackedConv(w, stride=stride, pad=pad, scale=sc, shift=sh, relu=True)
+    oh, ow = conv.out_hw(H, W)
+    res = torch.randn(B, oh, ow, cout, generator=g).cuda()
+    if split > conv.k_pad // 32:
+        pytest.skip("not enough k-tiles")
+    base = conv(x, residual=res, tile=4, split_k=split)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    ref = (ref * sc.double() + sh.double() + res.double()).clamp_min(0)
+    assert float((base.double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    for t in (44, 45):
+        if t == 45 and cout <= 64:
+            continue
+        got = conv(x, residual=res, tile=t, split_k=split)
+        assert torch.equal(got, base), (t, float((got - base).abs().max()))
+    # plain epilogue (no BN / residual / ReLU): the raw-store path
+    plain = PackedConv(w, stride=stride, pad=pad)
+    assert torch.equal(plain(x, tile=44, split_k=split), plain(x, tile=4, split_k=split))

@@ -52,6 +52,8 @@ for it in range(N):
     conv = PackedConv(w.cuda(), stride=stride, pad=pad, dil=dil, scale=None if sc is None else sc.cuda(),
                       shift=None if sh is None else sh.cuda(), relu=use_relu)
     cands = [(t, s) for t in (1, 2, 3, 4, 21, 22, 23, 24) for s in (1, 2, 3)]      # 21..24: the same tiles walked m-tile first
+    if conv.k_order == 1 and MODE not in ("bf16", "f32x3"):
+        cands += [(t, s) for t in (44, 45) for s in (1, 2, 3)]      # the 64x64 tile at five workgroups per CU (44; 45: m-tile first)
     if conv.w_wino is not None and MODE != "bf16":
         cands += [(TILE_WINO, 1), (TILE_WINO, 2), (TILE_WINO, 3), (TILE_WINO_HALF, 1), (TILE_WINO_HALF, 2), (TILE_WINO_HALF, 3)]
         if cin <= 96:
