@@ -294,7 +294,14 @@ class SECONDFPN(HipModule):
         for blk in self.deblocks:
             layer, bn = blk[0], blk[1]
             scale, shift = fold_bn(bn)
-            if isinstance(layer, nn.ConvTranspose2d):
+            if isinstance(layer, nn.ConvTranspose2d) and layer.stride[0] == 1 and not hip_ops.MFMA_BF16:
+                # ConvTranspose2d(k = 1, stride 1) IS a 1x1 convolution with the weight's first two axes swapped: as such it
+                # gets the row-linear epilogue and the pointwise / five-per-CU kernels (the transposed-conv store decodes a tap
+                # per element: 31 -> 15 us for the BEV neck's 80 -> 64 level at 256x256).  (bf16 mode keeps the transposed form
+                # its committed per-layer choices were measured with.)
+                convs.append(PackedConv(layer.weight.detach().permute(1, 0, 2, 3).contiguous(), scale=scale, shift=shift, relu=True,
+                                        device=device))
+            elif isinstance(layer, nn.ConvTranspose2d):
                 convs.append(PackedConv(layer.weight, stride=layer.stride[0], transposed=True, scale=scale,
                                         shift=shift, relu=True, device=device))
             else:
