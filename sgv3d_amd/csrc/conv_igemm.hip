@@ -1483,6 +1483,9 @@ namespace sgv3d {
 int conv_gemm_grouped(const float *x, const float *w, float *y, int rows, int groups, int K, int N, int k_pad, int cout_pad,
                       int k_order, int tile, hipStream_t st) {
     SGV3D_REQUIRE(x && w && y && rows > 0 && groups > 0 && K > 0 && N > 0, "conv_gemm_grouped: bad argument");
+    const bool occ5 = (tile & SGV3D_TILE_OCC5) != 0;      // (with the 64x64 tile: its five-workgroups-per-CU form)
+    tile &= ~SGV3D_TILE_OCC5;
+    SGV3D_REQUIRE(!occ5 || (tile == SGV3D_TILE_64x64 && k_order == 1), "conv_gemm_grouped: SGV3D_TILE_OCC5 goes with the 64x64 tile and k_order 1");
     const bool narrow = tile == SGV3D_TILE_32x128;
     SGV3D_REQUIRE(rows % (narrow ? 32 : 64) == 0 && K % 4 == 0 && k_pad >= K && k_pad % BK == 0 && cout_pad >= N && cout_pad % 128 == 0,
                   "conv_gemm_grouped: rows %% 64 (32 for the narrow tile), K %% 4, k_pad / cout_pad as packed (rows=%d K=%d k_pad=%d N=%d cout_pad=%d)",
@@ -1500,7 +1503,7 @@ int conv_gemm_grouped(const float *x, const float *w, float *y, int rows, int gr
     a.kh = a.kw = 1; a.stride = 1; a.pad = 0; a.dil = 1;
     a.x_ld = K; a.x_coff = 0; a.y_ld = N; a.y_coff = 0; a.res_ld = 0; a.relu = 0; a.mode = SGV3D_CONV_NORMAL; a.ks = 0;
     a.k_pad = k_pad; a.tiles_m = a.tiles_n = 0;
-    a.korder = k_order;
+    a.korder = k_order | (occ5 ? 4 : 0);
     a.x_bytes = (unsigned)(M * K * 4);
     a.w_bytes = (unsigned)((long long)cout_pad * k_pad * 4);          // one group's block
     a.M = (int)M; a.N = N; a.K = K;

@@ -219,7 +219,7 @@ void wino4_geom(const sgv3d_conv_desc *d, int &ty, int &tx, long long &tiles, in
     ty = cdiv(cdiv(d->out_h, dil), 4);
     tx = cdiv(cdiv(d->out_w, dil), 4);
     tiles = (long long)d->batch * dil * dil * ty * tx;
-    const int g = d->tile == SGV3D_TILE_32x128 ? 32 : 64;       // the GEMM's m-tile height
+    const int g = (d->tile & ~SGV3D_TILE_OCC5) == SGV3D_TILE_32x128 ? 32 : 64;       // the GEMM's m-tile height
     rows = (int)((tiles + g - 1) / g * g);
 }
 
@@ -297,7 +297,8 @@ extern "C" int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *d, const fl
     a.gw = planes ? d->deconv_ks : 0;
     a.c0 = 0; a.cn = d->cout;
     hipLaunchKernelGGL(wino4_input_kernel, dim3(cdiv(tiles * (d->cin / 4), 256)), dim3(256), 0, st, a);
-    int tile = (d->tile == SGV3D_TILE_64x128 || d->tile == SGV3D_TILE_32x128) ? d->tile : SGV3D_TILE_64x64;
+    int tile = (d->tile == SGV3D_TILE_64x128 || d->tile == SGV3D_TILE_32x128) ? d->tile
+               : (d->tile & SGV3D_TILE_OCC5) ? (SGV3D_TILE_64x64 | SGV3D_TILE_OCC5) : SGV3D_TILE_64x64;
     if (tile == SGV3D_TILE_32x128 && (d->k_order != 1 || d->cin < 128)) tile = SGV3D_TILE_64x64;    // (what the narrow tile covers)
     // one pass per chunk of output channels: block p of the chunk's weights is cout_pad x k_pad floats after block p - 1
     // like the full blocks, shifted by c0 rows

@@ -137,7 +137,8 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: 
               36: "dw_bf16", 37: "dw_bf16",                                                # ... requests two k-chunks ahead (*_DEEP)
               38: "dw_bf16", 39: "dw_bf16",                                                # ... 64 pixels x 128 channels (39: two chunks ahead)
               40: "wino4_resident",    # F(4x4,3x3) with the transformed input resident in LDS (sgv3d_conv3x3_f4res_forward)
-              44: "64x64", 45: "64x64"}    # the 64x64 tile at five workgroups per CU (SGV3D_TILE_OCC5); 45: walked m-tile first
+              44: "64x64", 45: "64x64",    # the 64x64 tile at five workgroups per CU (SGV3D_TILE_OCC5); 45: walked m-tile first
+              46: "wino4"}                 # F(4x4,3x3) in three launches with the five-per-CU 64x64 GEMM tile
 MFIRST = _os.environ.get("SGV3D_MFIRST", "1") != "0"
 TILE_WINO = 5       # host-side algorithm id: sgv3d_conv2d_winograd_forward instead of the implicit GEMM
 TILE_WINO_RES = 6   # = SGV3D_WINOGRAD_RESIDENT: its patch-resident variant (cin <= 96, many cout tiles)
@@ -146,7 +147,8 @@ TILE_WINO_HALF = 8  # = SGV3D_WINOGRAD_HALF: 64 tiles x 32 channels per workgrou
 TILE_WINO4 = 9      # Winograd F(4x4,3x3) in three launches (sgv3d_conv2d_winograd4_forward), GEMM tile 64x64; 10: 64x128
 TILE_WINO4_WIDE = 10
 TILE_WINO4_NARROW = 15   # ... with the 32x128 GEMM tile: rows per position padded to 32 instead of 64 (336 tiles -> 352, 84 -> 96)
-WINO4_TILES = (TILE_WINO4, TILE_WINO4_WIDE, TILE_WINO4_NARROW)
+TILE_WINO4_OCC = 46      # ... with the five-workgroups-per-CU form of the 64x64 GEMM tile (SGV3D_TILE_64x64 | SGV3D_TILE_OCC5)
+WINO4_TILES = (TILE_WINO4, TILE_WINO4_WIDE, TILE_WINO4_NARROW, TILE_WINO4_OCC)
 # F(4x4,3x3) in ONE launch with V = B^T d B of a 16x16 block resident in LDS (csrc/head_wino4.hip: conv_f4res_kernel): 3x3 /
 # stride 1 / pad 1 layers with 64 input channels (ResNet layer 1) or 64 output channels (the CenterHead's shared layer), f32
 TILE_F4RES = 40
@@ -601,7 +603,7 @@ class PackedConv:
                                       "NHWC output, no gate, no split-K")
             u = self._wino4_weights()
             host_tile, kp, cp = d.tile, d.k_pad, d.cout_pad
-            d.tile = {TILE_WINO4: 4, TILE_WINO4_WIDE: 3, TILE_WINO4_NARROW: 9}[host_tile]      # SGV3D_TILE_64x64 / 64x128 / 32x128
+            d.tile = {TILE_WINO4: 4, TILE_WINO4_WIDE: 3, TILE_WINO4_NARROW: 9, TILE_WINO4_OCC: 4 | 32}[host_tile]      # SGV3D_TILE_64x64 / 64x128 / 32x128 / 64x64 | OCC5
             d.k_pad, d.cout_pad = self.wino4_geom
             try:
                 nws4 = lib.sgv3d_conv2d_winograd4_workspace_bytes(ctypes.byref(d))
@@ -689,7 +691,7 @@ class PackedConv:
                 tiles += (TILE_WINO_RES,)
 
         if self.wino4_ok(d, gate):            # (also the dilated 3x3 layers, which the F(2x2) kernels do not cover)
-            tiles += WINO4_TILES if self.cin >= 128 else (TILE_WINO4, TILE_WINO4_WIDE)
+            tiles += (TILE_WINO4, TILE_WINO4_WIDE) + ((TILE_WINO4_NARROW,) if self.cin >= 128 else ()) + ((TILE_WINO4_OCC,) if OCC5 else ())
         if self.f4res_ok(d, gate, io):
             tiles += (TILE_F4RES,)
         if self._patch_eligible(d, gate):
