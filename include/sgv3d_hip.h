@@ -59,6 +59,14 @@ int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int num_channels
                                 int num_voxel_x, int num_voxel_y, int num_voxel_z,
                                 const int32_t *geom_xyz, const float *input_features,
                                 float *output_features, int32_t *pos_memo, void *stream);
+/* The same call for a caller that owns the output allocation (this build's Python operator, which replaces
+ * ops/voxel_pooling/voxel_pooling.py:37-52): output_features need NOT be zeroed -- every row is written, empty voxels as
+ * zeros (when the call falls back to the scatter, the library zeroes the map itself first).  Saves the 4 Y X C byte fill of
+ * voxel_pooling.py:37-38.  Same plans, same sums, same pos_memo as sgv3d_voxel_pooling_forward. */
+int sgv3d_voxel_pooling_forward_fresh(int batch_size, int num_points, int num_channels,
+                                      int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                      const int32_t *geom_xyz, const float *input_features,
+                                      float *output_features, int32_t *pos_memo, void *stream);
 /* Which gather kernel the planned / level-1 / fused entries launch: 0 or 2 = the voxel-owner kernel (round 4, default),
  * 1 = the slot-balanced kernel of round 3.  Both give exact sums of the same rows; their fixed summation orders differ (the
  * fused lift-splat entry and the operator always use the same one, so they stay bitwise equal).  Also SGV3D_VP_KERNEL=slot

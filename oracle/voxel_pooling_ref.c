@@ -27,6 +27,7 @@
  */
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #ifdef _OPENMP
@@ -62,7 +63,10 @@ void sgv3d_oracle_voxel_pooling_forward(int batch_size, int num_points, int num_
     }
 }
 
-/* Same result bit for bit, voxel rows partitioned over OpenMP threads (cpu_baseline, cores>1). */
+/* Same result bit for bit on all host cores (cpu_baseline, cores > 1).  The points are partitioned ONCE: every thread scans
+ * its own contiguous chunk of geom_xyz, the kept points are bucketed by the thread that owns their voxel row (y mod threads;
+ * a stable counting sort, so every voxel still sees its points in ascending point order = the scalar loop's summation
+ * order), and each thread then sums only its own bucket.  (The round-1 form had every thread scan all points.) */
 void sgv3d_oracle_voxel_pooling_forward_omp(int batch_size, int num_points, int num_channels,
                                             int num_voxel_x, int num_voxel_y, int num_voxel_z,
                                             const int32_t *geom_xyz, const float *input_features,
@@ -72,29 +76,72 @@ void sgv3d_oracle_voxel_pooling_forward_omp(int batch_size, int num_points, int 
 #ifdef _OPENMP
     if (num_threads < 1) num_threads = 1;
     const long total = (long)batch_size * num_points;
-#pragma omp parallel num_threads(num_threads)
+    const int nth = num_threads;
+    long *cnt = (long *)calloc((size_t)nth * nth + 1, sizeof(long));      /* cnt[scanner][owner] -> offsets */
+    int32_t *list = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));
+    long *begin = (long *)calloc((size_t)nth + 1, sizeof(long));
+    if (!cnt || !list || !begin || total > 0x7fffffffL) {                 /* (out of memory / too many points: scalar loop) */
+        free(cnt); free(list); free(begin);
+        sgv3d_oracle_voxel_pooling_forward(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, num_voxel_z,
+                                           geom_xyz, input_features, output_features, pos_memo);
+        return;
+    }
+#pragma omp parallel num_threads(nth)
     {
         const int tid = omp_get_thread_num();
-        const int nth = omp_get_num_threads();
-        for (long pt = 0; pt < total; ++pt) {
-            const int y = geom_xyz[pt * 3 + 1];
-            if (y < 0 || y >= num_voxel_y || (y % nth) != tid) continue;
-            const int x = geom_xyz[pt * 3 + 0];
-            const int z = geom_xyz[pt * 3 + 2];
-            if (x < 0 || x >= num_voxel_x || z < 0 || z >= num_voxel_z) continue;
-            const int batch_idx = (int)(pt / num_points);
-            if (pos_memo) {
-                pos_memo[pt * 3 + 0] = batch_idx;
-                pos_memo[pt * 3 + 1] = y;
-                pos_memo[pt * 3 + 2] = x;
+        const int n = omp_get_num_threads();       /* (may be fewer than asked for: chunks and owners use nth, looped over) */
+        for (int s = tid; s < nth; s += n) {       /* pass 1: count the kept points of chunk s by owner */
+            const long p0 = total * s / nth, p1 = total * (s + 1) / nth;
+            long *c = cnt + (size_t)s * nth;
+            for (long pt = p0; pt < p1; ++pt) {
+                const int x = geom_xyz[pt * 3 + 0], y = geom_xyz[pt * 3 + 1], z = geom_xyz[pt * 3 + 2];
+                if (x < 0 || x >= num_voxel_x || y < 0 || y >= num_voxel_y || z < 0 || z >= num_voxel_z) continue;
+                c[y % nth]++;
             }
-            float *dst = output_features + ((size_t)batch_idx * num_voxel_y * num_voxel_x +
-                                            (size_t)y * num_voxel_x + x) * num_channels;
-            const float *src = input_features + (size_t)pt * num_channels;
-            for (int c = 0; c < num_channels; ++c)
-                dst[c] += src[c];
+        }
+#pragma omp barrier
+#pragma omp single
+        {                                          /* offsets: owner-major, scanner-minor = ascending point order per owner */
+            long run = 0;
+            for (int o = 0; o < nth; ++o) {
+                begin[o] = run;
+                for (int s = 0; s < nth; ++s) {
+                    const long k = cnt[(size_t)s * nth + o];
+                    cnt[(size_t)s * nth + o] = run;
+                    run += k;
+                }
+            }
+            begin[nth] = run;
+        }
+        for (int s = tid; s < nth; s += n) {       /* pass 2: fill the buckets, write pos_memo */
+            const long p0 = total * s / nth, p1 = total * (s + 1) / nth;
+            long *c = cnt + (size_t)s * nth;
+            for (long pt = p0; pt < p1; ++pt) {
+                const int x = geom_xyz[pt * 3 + 0], y = geom_xyz[pt * 3 + 1], z = geom_xyz[pt * 3 + 2];
+                if (x < 0 || x >= num_voxel_x || y < 0 || y >= num_voxel_y || z < 0 || z >= num_voxel_z) continue;
+                list[c[y % nth]++] = (int32_t)pt;
+                if (pos_memo) {
+                    pos_memo[pt * 3 + 0] = (int)(pt / num_points);
+                    pos_memo[pt * 3 + 1] = y;
+                    pos_memo[pt * 3 + 2] = x;
+                }
+            }
+        }
+#pragma omp barrier
+        for (int o = tid; o < nth; o += n) {       /* pass 3: every owner sums its own voxel rows */
+            for (long i = begin[o]; i < begin[o + 1]; ++i) {
+                const long pt = list[i];
+                const int x = geom_xyz[pt * 3 + 0], y = geom_xyz[pt * 3 + 1];
+                const int batch_idx = (int)(pt / num_points);
+                float *dst = output_features + ((size_t)batch_idx * num_voxel_y * num_voxel_x +
+                                                (size_t)y * num_voxel_x + x) * num_channels;
+                const float *src = input_features + (size_t)pt * num_channels;
+                for (int c = 0; c < num_channels; ++c)
+                    dst[c] += src[c];
+            }
         }
     }
+    free(cnt); free(list); free(begin);
 #else
     (void)num_threads;
     sgv3d_oracle_voxel_pooling_forward(batch_size, num_points, num_channels, num_voxel_x,

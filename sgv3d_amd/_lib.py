@@ -31,6 +31,7 @@ _PROTOS = {
     "sgv3d_voxel_pooling_select_kernel": (c_int, [c_int]),
     "sgv3d_voxel_pooling_kernel_for": (c_int, [c_int] * 6),
     "sgv3d_voxel_pooling_forward": (c_int, [c_int] * 6 + [c_void_p] * 5),
+    "sgv3d_voxel_pooling_forward_fresh": (c_int, [c_int] * 6 + [c_void_p] * 5),
     "sgv3d_voxel_pooling_forward_atomic": (c_int, [c_int] * 6 + [c_void_p] * 5),
     "sgv3d_voxel_pooling_cache_clear": (c_int, []),
     "sgv3d_voxel_pooling_cache_stats": (c_int, [ctypes.POINTER(ctypes.c_ulonglong)]),

@@ -170,6 +170,7 @@ def _wgrad_choice(lib, d, x, dy):
     d.tile = 0
     _WGRAD_DB[key] = best
     hip_ops.TUNE_DB[sig] = list(best)
+    hip_ops._COMMITTED_SIGS.discard(sig)
     return best
 
 

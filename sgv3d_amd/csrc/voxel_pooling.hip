@@ -2102,10 +2102,20 @@ extern "C" int sgv3d_voxel_pooling_forward_atomic(int batch_size, int num_points
                          input_features, output_features, pos_memo, as_stream(stream));
 }
 
-extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
-                                           int num_voxel_x, int num_voxel_y, int num_voxel_z,
-                                           const int32_t *geom_xyz, const float *input_features,
-                                           float *output_features, int32_t *pos_memo, void *stream) {
+namespace {
+
+// the atomic scatter ADDS: a FRESH call (output_features holds garbage) zeroes the map first; ``gate`` != nullptr: only while
+// *gate != 0 (the fallback of a cached-plan call, whose gather has written every row otherwise)
+void zero_output(float *out, long long n, const int *gate, hipStream_t st) {
+    hipLaunchKernelGGL(vp_zero_kernel, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, st, n, reinterpret_cast<int *>(out), gate);
+}
+
+// FRESH = false: the reference's contract (output_features pre-zeroed by the caller, sums are added to it,
+// voxel_pooling.py:37-38 / voxel_pooling_forward_cuda.cu:31-34); FRESH = true: output_features is written, whatever it held
+template <bool FRESH>
+int level1_forward(int batch_size, int num_points, int num_channels, int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                   const int32_t *geom_xyz, const float *input_features, float *output_features, int32_t *pos_memo,
+                   void *stream) {
     const int B = batch_size, N = num_points, C = num_channels, X = num_voxel_x, Y = num_voxel_y, Z = num_voxel_z;
     if (int rc = check_common(B, N, C, X, Y, Z)) return rc;
     SGV3D_REQUIRE(geom_xyz && input_features && output_features, "voxel_pooling_forward: null pointer");
@@ -2114,8 +2124,10 @@ extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int n
     const bool aligned = ((reinterpret_cast<uintptr_t>(input_features) | reinterpret_cast<uintptr_t>(output_features)) & 15) == 0;
     std::lock_guard<std::mutex> lock(g_l1_mutex);
     g_l1_stats[0]++;
+    const long long out_elems = (long long)B * Y * X * C;
     if (!level1_enabled() || !G.v2 || !aligned) {
         g_l1_stats[2]++;
+        if (FRESH) zero_output(output_features, out_elems, nullptr, st);
         return launch_atomic(B, N, C, X, Y, Z, geom_xyz, input_features, output_features, pos_memo, st);
     }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -2130,6 +2142,7 @@ extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int n
     if (e == nullptr) {
         if (capturing) {            // no allocation inside a stream capture: the plain scatter is always right
             g_l1_stats[2]++;
+            if (FRESH) zero_output(output_features, out_elems, nullptr, st);
             return launch_atomic(B, N, C, X, Y, Z, geom_xyz, input_features, output_features, pos_memo, st);
         }
         if ((int)g_l1.size() >= kLevel1Max) {
@@ -2138,6 +2151,7 @@ extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int n
                 if (!g_l1[i].pinned && (old == g_l1.size() || g_l1[i].last_use < g_l1[old].last_use)) old = i;
             if (old == g_l1.size()) {      // every plan is baked into some captured graph: serve this call without one
                 g_l1_stats[2]++;
+                if (FRESH) zero_output(output_features, out_elems, nullptr, st);
                 return launch_atomic(B, N, C, X, Y, Z, geom_xyz, input_features, output_features, pos_memo, st);
             }
             level1_free(g_l1[old]);
@@ -2151,6 +2165,7 @@ extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int n
             (void)hipGetLastError();
             level1_free(n);
             g_l1_stats[2]++;
+            if (FRESH) zero_output(output_features, out_elems, nullptr, st);
             return launch_atomic(B, N, C, X, Y, Z, geom_xyz, input_features, output_features, pos_memo, st);
         }
         *n.host_flag = 0;
@@ -2191,16 +2206,39 @@ extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int n
         }
         g_l1_stats[3]++;
         g_l1_stats[1]++;
-        return launch_gather<false, false, false, true>(B, N, C, X, Y, e->plan, input_features, nullptr, nullptr, 1,
-                                                        output_features, nullptr, 0, st, 0, nullptr);
+        return launch_gather<false, false, false, !FRESH>(B, N, C, X, Y, e->plan, input_features, nullptr, nullptr, 1,
+                                                          output_features, nullptr, 0, st, 0, nullptr);
     }
     g_l1_stats[1]++;
-    if (int rc = launch_gather<false, false, false, true>(B, N, C, X, Y, e->plan, input_features, nullptr, nullptr, 1,
-                                                          output_features, nullptr, 0, st, 0, &hdr->dirty)) return rc;
+    if (int rc = launch_gather<false, false, false, !FRESH>(B, N, C, X, Y, e->plan, input_features, nullptr, nullptr, 1,
+                                                            output_features, nullptr, 0, st, 0, &hdr->dirty)) return rc;
+    if (FRESH) zero_output(output_features, out_elems, &hdr->dirty, st);          // (leaves at once while the plan is current)
     const long long ablocks = cdiv(total, kAtomicPts);
     hipLaunchKernelGGL(vp_atomic_gated_kernel, dim3((unsigned)(ablocks < 2048 ? ablocks : 2048)), dim3(kBlock), 0, st, total, N, C, X,
                        Y, Z, geom_xyz, input_features, output_features, &hdr->dirty);
     return check_launch("voxel_pooling_forward(level-1)");
+}
+
+}  // namespace
+
+// The reference wrapper's call (src/voxel_pooling_forward.cpp:26-39): output_features pre-zeroed by the caller, added to.
+extern "C" int sgv3d_voxel_pooling_forward(int batch_size, int num_points, int num_channels,
+                                           int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                           const int32_t *geom_xyz, const float *input_features,
+                                           float *output_features, int32_t *pos_memo, void *stream) {
+    return level1_forward<false>(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, num_voxel_z, geom_xyz,
+                                 input_features, output_features, pos_memo, stream);
+}
+
+// The same call for a caller that OWNS the output allocation (this build's Python operator): output_features is written --
+// every row, empty voxels as zeros -- so the 4 Y X C byte zero fill the reference does first (voxel_pooling.py:37-38) is
+// not needed.  Same plans, same sums, same pos_memo.
+extern "C" int sgv3d_voxel_pooling_forward_fresh(int batch_size, int num_points, int num_channels,
+                                                 int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                                 const int32_t *geom_xyz, const float *input_features,
+                                                 float *output_features, int32_t *pos_memo, void *stream) {
+    return level1_forward<true>(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, num_voxel_z, geom_xyz,
+                                input_features, output_features, pos_memo, stream);
 }
 
 extern "C" int sgv3d_voxel_pooling_kernel_for(int batch_size, int num_points, int num_channels, int num_voxel_x, int num_voxel_y,

@@ -71,6 +71,8 @@ MFMA_F32X3 = {"": False, "0": False, "auto": "auto"}.get(_os.environ.get("SGV3D_
 # save_tune_db() writes them back, so that a profiled run replays the choices of an earlier run
 # instead of timing candidates again (keeps rocprofv3 per-kernel averages free of tuning launches).
 TUNE_DB = {}
+TUNE_STATS = {"measured": 0, "from_db": 0}     # per process: layer signatures timed here / answered from a tune DB
+_COMMITTED_SIGS = set()      # signatures that came from tune/gfx950_*.json: honoured on gfx950 devices only
 _TUNE_SIDE_STREAMS = []
 
 
@@ -85,7 +87,9 @@ def load_tune_db(path=None):
     path = path or _tune_db_path()
     if path and os.path.exists(path):
         with open(path) as f:
-            TUNE_DB.update({k: tuple(v) for k, v in json.load(f).items()})
+            loaded = {k: tuple(v) for k, v in json.load(f).items()}
+        TUNE_DB.update(loaded)
+        _COMMITTED_SIGS.difference_update(loaded)       # (a local measurement overrides a committed one: no longer arch-bound)
     return len(TUNE_DB)
 
 
@@ -110,13 +114,13 @@ def load_default_tune_dbs():
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tune")
     n = 0
     for f in sorted(glob.glob(os.path.join(root, "gfx950_*.json"))):
-        before = set(TUNE_DB)
+        with open(f) as fh:
+            sigs = list(__import__("json").load(fh))
         n += load_tune_db(f) and 1
-        _COMMITTED_SIGS.update(set(TUNE_DB) - before)
+        _COMMITTED_SIGS.update(sigs)
     return n
 
 
-_COMMITTED_SIGS = set()      # signatures that came from tune/gfx950_*.json: honoured on gfx950 devices only
 _ARCH_IS_GFX950 = {}
 
 
@@ -176,11 +180,14 @@ DW_SPLIT_K = _os.environ.get("SGV3D_DW_SPLITK", "1") != "0"   # 0: the direct-we
 
 
 class prof:
-    """``with prof("kernel", flops):`` brackets a launch with HIP events when PROFILE is active."""
-    __slots__ = ("name", "flops", "e0")
+    """``with prof("kernel", flops, nbytes):`` brackets a launch with HIP events when PROFILE is active.  ``flops`` /
+    ``nbytes``: the launch's ALGORITHMIC work -- 2 x MACs of the direct convolution; every tensor the layer's
+    definition touches read or written exactly once.  PROFILE records are ``(name, flops, start, stop, nbytes, extra)``; ``extra``: None or
+    ``{'symbol': the MFMA kernel's exact symbol, 'mfma_flops': the flops that kernel EXECUTES in this launch}``."""
+    __slots__ = ("name", "flops", "nbytes", "extra", "e0")
 
-    def __init__(self, name, flops=0.0):
-        self.name, self.flops, self.e0 = name, flops, None
+    def __init__(self, name, flops=0.0, nbytes=0.0, extra=None):
+        self.name, self.flops, self.nbytes, self.extra, self.e0 = name, flops, nbytes, extra, None
 
     def __enter__(self):
         if PROFILE is not None:
@@ -192,7 +199,7 @@ class prof:
         if self.e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            PROFILE.append((self.name, self.flops, self.e0, e1))
+            PROFILE.append((self.name, self.flops, self.e0, e1, self.nbytes, self.extra))
             self.e0 = None
         return False
 
@@ -514,10 +521,13 @@ class PackedConv:
                 choice = self._db_choice(sig, d, x, gate, gemm_m, gemm_n, nkt, t, sk, io)
                 if choice is not None:
                     self._tile_cache[key] = choice
+                    TUNE_STATS["from_db"] += 1
                 elif AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+                    TUNE_STATS["measured"] += 1
                     choice = self._autotune(lib, d, x, residual, gate, out, gemm_m, gemm_n, nkt, t, sk, io)
                     self._tile_cache[key] = choice
                     TUNE_DB[sig] = choice
+                    _COMMITTED_SIGS.discard(sig)        # measured on THIS device
                 else:
                     choice = self._rule(t, sk, d, gemm_m, gemm_n, gate)
             t, sk = choice
@@ -528,14 +538,46 @@ class PackedConv:
         x3 = 10 < t < 20 or (MFMA_F32X3 is True and t < TILE_WINO)
         name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF, TILE_F4RES) + WINO4_TILES + DW_TILES else
                 ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_f32x3_" if x3 else "conv_igemm_")) + TILE_NAMES[t]
-        if t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF, TILE_F4RES) + WINO4_TILES + DW_TILES and self.k_order == 0:
+        plain = t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF, TILE_F4RES) + WINO4_TILES + DW_TILES
+        if plain and self.k_order == 0:
             name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
+        elif plain and not MFMA_BF16 and not x3:
+            # the label names the INSTANTIATION launch_t (csrc/conv_igemm.hip) picks, so that a per-symbol rocprof / PMC
+            # summary can be attached to exactly this kernel (bench.py load_traffic): pointwise and five-per-CU forms
+            pw = (self.kh == 1 and self.kw == 1 and self.stride == 1 and self.pad == 0 and not self.transposed)
+            occ = t in OCC5_TILES
+            if pw and (occ or self.cin >= 128) and (occ or TILE_NAMES[t] in ("64x64", "64x128")):
+                name += "_pw"
+            if occ:
+                name += "_occ5"
+        # algorithmic bytes: input map (the channels this layer reads), weights, output (+ residual), each once
+        nbytes = 4.0 * (B * H * W * self.cin_real + self.cout_real * self.cin_real * self.kh * self.kw * (self.ks * self.ks if self.transposed else 1)
+                        + gemm_m * real_n * (2 if residual is not None else 1))
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
                      f"s{self.stride} d{self.dil} splitk{sk}" + (" mfirst" if 20 < t < 30 or t == 45 else "") + (" occ5" if t in OCC5_TILES else ""))
         if io:
             name = name.replace("conv_igemm_bf16_", "conv_igemm_bf16io_")
-        with torch.cuda.device(x.device), prof(name, flops):
+        extra = None
+        if PROFILE is not None and not MFMA_BF16 and not x3:
+            b = lambda v: "true" if v else "false"
+            if plain:
+                wtm, wtn = (int(v) // 64 for v in TILE_NAMES[t].split("x"))
+                extra = {"symbol": f"conv_igemm_kernel<{wtm}, {wtn}, {b(self.k_order != 0)}, false, {b(name.endswith(('_pw', '_pw_occ5')))}, "
+                                   f"false, {b(t in OCC5_TILES)}>",
+                         "mfma_flops": 2.0 * gemm_m * self.cout * self.cin * self.kh * self.kw * (self.ks * self.ks if self.transposed else 1)}
+            elif t in WINO4_TILES:
+                # the grouped GEMM of the three-launch F(4x4) path: 36 positions x rows (tiles padded to the GEMM's m-tile)
+                dil = max(1, self.dil)
+                tiles = B * dil * dil * -(-(-(-oh // dil)) // 4) * -(-(-(-ow // dil)) // 4)
+                g = 32 if t == TILE_WINO4_NARROW else 64
+                rows = -(-tiles // g) * g
+                extra = {"symbol": {TILE_WINO4: "conv_igemm_kernel<1, 1, true, false, true, false, false>",
+                                    TILE_WINO4_WIDE: "conv_igemm_kernel<1, 2, true, false, true, false, false>",
+                                    TILE_WINO4_NARROW: "conv_igemm_kernel<1, 1, true, false, true, true, false>",
+                                    TILE_WINO4_OCC: "conv_igemm_kernel<1, 1, true, false, true, false, true>"}[t],
+                         "mfma_flops": 2.0 * 36 * rows * self.cin * self.cout}
+        with torch.cuda.device(x.device), prof(name, flops, nbytes, extra):
             rc = self._launch(lib, d, x, residual, gate, out, io)
         _lib.check(rc, "sgv3d_conv2d_forward")
         return out
@@ -859,7 +901,7 @@ def switch_state():
     g = globals()
     return tuple(g.get(k) for k in ("AUTOTUNE", "SPLIT_K", "WINOGRAD", "FUSED_HEAD", "HEAD_PATH", "MFMA_BF16", "BF16_ACTIVATIONS",
                                     "MFMA_F32X3", "MFIRST", "WINO4", "WINO_HALF", "PATCH_BF16", "DW_BF16", "DW_DEEP", "DW_NARROW",
-                                    "DW_SPLIT_K", "DW_DEEP_MAX_WGS", "PAIR_BF16", "TUNE_STREAMS", "PARALLEL_BRANCHES"))
+                                    "DW_SPLIT_K", "DW_DEEP_MAX_WGS", "PAIR_BF16", "TUNE_STREAMS", "PARALLEL_BRANCHES", "F4RES", "OCC5"))
 
 
 def conv_pair_eligible(a, b, x, residual=None):
@@ -915,6 +957,7 @@ def conv_pair_choice(a, b, x, residual=None):
     t2 = time_callable(two, x.device)
     t1 = time_callable(one, x.device)
     TUNE_DB[sig] = [1 if t1 < t2 else 0, 0]
+    _COMMITTED_SIGS.discard(sig)
     return t1 < t2
 
 

@@ -327,6 +327,19 @@ class BEVHeightHead(HipModule):
         ``preds_dict[0]['heatmap']`` with its sigmoid nor add an ``'anno_box'`` entry."""
         return _CenterHeadLoss.run(self, targets, preds_dicts)
 
+    def decode_digest(self):
+        """Everything ``decode_device`` bakes into kernel arguments, as one hashable value: a recorded decode (BEVHeight's
+        hipGraph) is only valid for the configuration it was captured with."""
+        def freeze(v):
+            if isinstance(v, dict):
+                return tuple(sorted((str(k), freeze(x)) for k, x in v.items()))
+            if isinstance(v, (list, tuple)):
+                return tuple(freeze(x) for x in v)
+            if torch.is_tensor(v):
+                return tuple(v.flatten().tolist())
+            return v if isinstance(v, (int, float, str, bool, type(None))) else repr(v)
+        return (freeze(self.bbox_coder_cfg), freeze(self.test_cfg), bool(self.norm_bbox), tuple(int(v) for v in self.num_classes))
+
     def decode_device(self, preds_dicts):
         """Device half of ``get_bboxes``: top-K / box assembly / circle NMS of every task (three launches) and the merge of
         the tasks (one launch).  Only enqueues kernels on the current stream -- graph-capturable; ``BEVHeight``'s

@@ -25,6 +25,19 @@ from ..layers.heads.bev_height_head import BEVHeightHead
 
 __all__ = ['BEVHeight']
 
+# Bumped whenever ANY nn.Module in the process registers a parameter, a buffer or a sub-module (torch's global registration
+# hooks; they also fire for attribute assignment and for load_state_dict(assign=True)): BEVHeight._stamp redoes its walk.
+_REGISTRATIONS = [0]
+
+
+def _count_registration(module, name, value):
+    _REGISTRATIONS[0] += 1
+
+
+nn.modules.module.register_module_parameter_registration_hook(_count_registration)
+nn.modules.module.register_module_buffer_registration_hook(_count_registration)
+nn.modules.module.register_module_module_registration_hook(_count_registration)
+
 
 class BEVHeight(nn.Module):
     """Detector = camera backbone (``LSSFPN`` or, with ``backbone_conf['is_bsm']``, ``BSMLSSFPN``) + BEV head.
@@ -49,7 +62,7 @@ class BEVHeight(nn.Module):
         self.graph_cache_size = 2
         self._graphs = {}               # signature -> [calls seen, GraphedForward | None | False (capture failed)]
         self._graph_suspended = 0
-        self._flat, self._flat_age, self._flat_gen = None, 0, 0      # cached walk over parameters + buffers (_stamp)
+        self._flat, self._flat_age, self._flat_gen, self._flat_reg, self._flat_dirty = None, 0, 0, -1, True    # cached walk over the module tree (_stamp)
         self._decoded = None            # (decode buffer, weak refs to the maps it was computed from, their version): see get_bboxes
         if checkpoint is not None:
             with open(checkpoint, "rb") as f:
@@ -70,34 +83,43 @@ class BEVHeight(nn.Module):
 
         The exact form -- (address, version) of every parameter and buffer from a walk over the module tree -- costs 1-3 ms of
         pure host time for the ~860 tensors of the cfg-2 model: with one frame in flight (the reference harness's eval_step
-        waits for every frame's boxes) the GPU idles through it.  So the walk is done once and then every
-        ``_RESTAMP_EVERY`` forwards; in between the stamp is the sum of the version counters and of the addresses of the
-        tensors of that walk (~0.25 ms): any in-place write (optimiser step, ``load_state_dict``, ``copy_``) moves the first,
-        a ``p.data = ...`` swap the second.  What the short form cannot see is a parameter or buffer OBJECT replaced behind the
-        model's back; the entry points that do that (``_apply`` = ``.to() / .cuda() / .half()`` from here or any parent
-        module, ``load_state_dict``, ``train()``) drop the cached walk themselves."""
-        flat = self._flat
-        if flat is None or self._flat_age >= self._RESTAMP_EVERY:
-            fresh = list(self.parameters()) + list(self.buffers())
-            if flat is None or len(fresh) != len(flat) or any(a is not b for a, b in zip(fresh, flat)):
-                self._flat_gen += 1                 # another set of tensor objects: never equal to an earlier stamp
-            self._flat = flat = fresh
-            self._flat_age = 0
+        waits for every frame's boxes) the GPU idles through it.  So the walk only collects the ``_parameters`` / ``_buffers``
+        dicts of the sub-modules; every forward sums the version counters and the addresses of what those dicts hold NOW
+        (~0.3 ms): an in-place write (optimiser step, ``load_state_dict``, ``copy_``) moves the first, a ``p.data = ...`` swap
+        or a tensor object replaced inside a dict (a sub-module's own ``.to()`` / ``.half()``, ``_buffers[...] = ...``) the
+        second.  Objects registered through ``nn.Module``'s own entry points -- ``m.weight = nn.Parameter(...)``,
+        ``register_parameter`` / ``register_buffer``, a sub-module assigned, any ``load_state_dict(assign=True)`` from here, a
+        sub-module or a parent (Lightning) -- bump a process-wide registration counter (torch's global registration hooks,
+        ``_REGISTRATIONS``) and the walk is redone on the NEXT forward: no window of stale weights.  ``_apply`` / ``load_state_dict``
+        / ``train()`` of this module drop the walk themselves.  What no hook sees -- a sub-module swapped by writing into a
+        ``_modules`` dict directly -- is caught by the full walk every ``_RESTAMP_EVERY`` forwards."""
+        walk = self._flat
+        if walk is None or self._flat_dirty or self._flat_age >= self._RESTAMP_EVERY or self._flat_reg != _REGISTRATIONS[0]:
+            mods = list(self.modules())
+            dicts = [d for m in mods for d in (m._parameters, m._buffers) if d]     # (an empty one is filled through a hook)
+            if walk is None or len(mods) != len(walk[0]) or any(a is not b for a, b in zip(mods, walk[0])):
+                self._flat_gen += 1                 # another module tree: never equal to an earlier stamp
+            self._flat = walk = (mods, dicts)
+            self._flat_age, self._flat_dirty = 0, False
+            self._flat_reg = _REGISTRATIONS[0]
         self._flat_age += 1
-        ver = ptr = 0
-        for t in flat:
-            ver += t._version
-            ptr += t.data_ptr()
-        return (self._flat_gen, len(flat), ver, ptr)
+        n = ver = ptr = 0
+        for d in walk[1]:
+            for t in d.values():
+                if t is not None:
+                    n += 1
+                    ver += t._version
+                    ptr += t.data_ptr() + (id(t) >> 4)
+        return (self._flat_gen, n, ver, ptr)
 
     _RESTAMP_EVERY = 256
 
     def _apply(self, fn, *args, **kwargs):
-        self._flat = None                           # buffers (and, with some flags, parameters) become new objects
+        self._flat_dirty = True                     # buffers (and, with some flags, parameters) become new objects
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
-        self._flat = None                           # (assign=True replaces the Parameter objects)
+        self._flat_dirty = True                     # (assign=True replaces the Parameter objects)
         return super().load_state_dict(*args, **kwargs)
 
     def refresh(self):
@@ -110,9 +132,10 @@ class BEVHeight(nn.Module):
         self._graphs = {}               # captured graphs read the packed weights that were just dropped
 
     def train(self, mode=True):
-        """Switching between training and inference drops the packed inference weights: the fused optimiser step
-        (train_step.DataParallelAdamW) writes parameters through raw pointers, which no version counter records."""
+        """Switching between training and inference drops the packed inference weights and the cached module walk: the fused
+        optimiser step (train_step.DataParallelAdamW) writes parameters through raw pointers, which no version counter records."""
         super().train(mode)
+        self._flat_dirty = True
         self.refresh()
         return self
 
@@ -160,7 +183,8 @@ class BEVHeight(nn.Module):
             return None
         key = (tuple(x.shape), x.dtype, str(x.device), torch.cuda.current_stream(x.device).cuda_stream,
                tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(mats_dict.items())),
-               hip_ops.switch_state(), bool(getattr(self.backbone, 'fuse_lift_splat', False)))
+               hip_ops.switch_state(), bool(getattr(self.backbone, 'fuse_lift_splat', False)),
+               self.head.decode_digest())             # (the recorded decode bakes test_cfg / bbox_coder into kernel arguments)
         entry = self._graphs.get(key)
         if entry is None:
             self._graphs[key] = entry = [0, None]

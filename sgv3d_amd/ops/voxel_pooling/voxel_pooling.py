@@ -226,19 +226,22 @@ class VoxelPooling(Function):
                                                             output_features.data_ptr(), _lib.ptr(pos_memo),
                                                             _lib.stream_handle(input_features.device))
             _lib.check(rc, "sgv3d_voxel_pooling_forward_atomic")
-        elif (CACHE_PLANS and num_channels % 4 == 0 and 24 <= num_channels <= 256 and input_features.data_ptr() % 16 == 0):
-            # The library's own entry for the reference wrapper (level 1 of INTEGRATION.md) does everything this call needs in
-            # ~3 launches: it keeps a plan per (device, stream, sizes), compares geom_xyz with the tensor that plan was built
-            # for ON THE DEVICE while it writes pos_memo, sums with the deterministic gather while the geometry is unchanged (a
-            # roadside camera) and with the reference's scatter the one call it is not.  33 us at cfg-2 against 26 + 68 us for
-            # plan.rebuild (compare + 19 gated launches) + plan.pool, and against a 120 us uncached build when a gradient is
-            # needed.  It ADDS to output_features, hence the zero fill (a kernel, not a memset node: see the atomic branch).
-            output_features = input_features.new_full((batch_size, Y, X, num_channels), 0.0)
+        elif (CACHE_PLANS and not needs_grad and num_channels % 4 == 0 and 24 <= num_channels <= 256
+              and input_features.data_ptr() % 16 == 0):
+            # The library's own entry for the reference wrapper (level 1 of INTEGRATION.md) does everything an inference call
+            # needs in 2-3 launches: it keeps a plan per (device, stream, sizes), compares geom_xyz with the tensor that plan was
+            # built for ON THE DEVICE, sums with the deterministic gather while the geometry is unchanged (a roadside camera) and
+            # with the reference's scatter the one call it is not.  The ``_fresh`` form writes every row of the map (empty
+            # voxels as zeros), so the 21 MB zero fill of voxel_pooling.py:37-38 is not launched: torch.empty.
+            # Calls that need a gradient (training: ida / bda augmentation moves geom_xyz every step) stay on the VoxelPlan
+            # branch below -- always the deterministic gather, bit-reproducible run to run, which an alternation between
+            # gather and scatter would not be.
+            output_features = input_features.new_empty((batch_size, Y, X, num_channels))
             with torch.cuda.device(input_features.device), hip_ops.prof("voxel_pooling_level1"):
-                rc = lib.sgv3d_voxel_pooling_forward(batch_size, num_points, num_channels, X, Y, Z, geom_xyz.data_ptr(),
-                                                     input_features.data_ptr(), output_features.data_ptr(), _lib.ptr(pos_memo),
-                                                     _lib.stream_handle(input_features.device))
-            _lib.check(rc, "sgv3d_voxel_pooling_forward")
+                rc = lib.sgv3d_voxel_pooling_forward_fresh(batch_size, num_points, num_channels, X, Y, Z, geom_xyz.data_ptr(),
+                                                           input_features.data_ptr(), output_features.data_ptr(), None,
+                                                           _lib.stream_handle(input_features.device))
+            _lib.check(rc, "sgv3d_voxel_pooling_forward_fresh")
         elif needs_grad or not CACHE_PLANS or geom_xyz.data_ptr() % 16 != 0:
             # (the cached build compares geom_xyz with 16-byte loads: a contiguous slice such as geom[1:] whose storage
             # offset is not a multiple of 16 bytes -- accepted by the reference extension -- takes the uncached build)

@@ -59,6 +59,14 @@ class eager_forward:
         return False
 
 
+def static_copy(t):
+    """A clone of ``t`` that is an ordinary tensor whatever mode the caller is in.  Static graph inputs are written in place on
+    every replay; a clone made under ``torch.inference_mode()`` (Lightning's validation loop) would be an inference tensor, and
+    the first replay under plain ``torch.no_grad()`` would raise 'Inplace update to inference tensor outside InferenceMode'."""
+    with torch.inference_mode(False):
+        return t.clone()
+
+
 def _clone_aliased(obj, memo):
     """Deep copy of a nest of tensors that keeps their aliasing: tensors that share a storage become views of ONE copy of it
     (keyed by the storage, not by ``_base``: views made under ``torch.inference_mode()`` do not record their base)."""
@@ -99,8 +107,8 @@ class GraphedForward:
         # (no reference to the model is kept: it owns this object, and a cycle would hold the graph's activation pool
         # until the cycle collector runs)
         dev = imgs.device
-        self.in_imgs = imgs.clone()
-        self.in_mats = {k: v.clone() for k, v in mats.items()}
+        self.in_imgs = static_copy(imgs)
+        self.in_mats = {k: static_copy(v) for k, v in mats.items()}
         self._mat_keys = sorted(self.in_mats)
         self._mat_dst = [self.in_mats[k] for k in self._mat_keys]
         self.cache = CalibrationCache()
@@ -184,8 +192,8 @@ class FramePipeline:
         self.device = imgs.device
         self.slots = max(1, int(slots))
         self.streams = [torch.cuda.Stream(device=imgs.device) for _ in range(self.slots)]
-        self.in_imgs = [imgs.clone() for _ in range(self.slots)]
-        self.in_mats = [{k: v.clone() for k, v in mats.items()} for _ in range(self.slots)]
+        self.in_imgs = [static_copy(imgs) for _ in range(self.slots)]
+        self.in_mats = [{k: static_copy(v) for k, v in mats.items()} for _ in range(self.slots)]
         self.caches = [CalibrationCache() for _ in range(self.slots)]
         self._last_mats = [None] * self.slots      # [(tensor, version)] of the mats last copied into the slot
         self.outputs = [None] * self.slots

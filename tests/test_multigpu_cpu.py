@@ -220,3 +220,24 @@ def test_bench_gpus_n_without_launcher_spawns_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
                        env=dict(env, SGV3D_BENCH_STUB="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, timeout=300)
     assert r.returncode != 0 and b"must agree" in r.stderr
+
+
+def test_bench_world_8_stub_every_rank_reports_its_tune_db():
+    """The driver's 8-GPU launch, rehearsed on the CPU: eight gloo ranks of bench.py with the stub model.  One JSON line, n_gpus 8,
+    eight per-rank records in rank order, each bound to its own local rank, each with the committed tune DB loaded (so no rank
+    would spend its first forward timing candidates under 8-way host contention) and nothing measured."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1"],
+                       env=dict(env, SGV3D_BENCH_STUB="1", OMP_NUM_THREADS="1"), capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    per = rec["config"]["per_rank"]
+    assert rec["n_gpus"] == 8 and rec["config"]["world_size"] == 8 and rec["config"]["global_batch"] == 8
+    assert [p["rank"] for p in per] == list(range(8)) and [p["local_rank"] for p in per] == list(range(8))
+    assert all(p["tune_db_entries"] > 100 and p["layers_measured_here"] == 0 for p in per)
+    # the slowest rank (rank 7 sleeps 16 ms per step) prices the aggregate
+    assert rec["ms_per_step"] >= 16.0
+    assert abs(rec["value"] - 8 * 4 / (rec["ms_per_step"] * 4e-3)) < 1e-6 * rec["value"]

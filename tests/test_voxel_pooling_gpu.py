@@ -480,6 +480,34 @@ def test_level1_entry_accumulates_and_follows_geometry_changes(hip, misalign, N)
     hip.check(hip.load().sgv3d_voxel_pooling_cache_clear(), "clear")
 
 
+@pytest.mark.parametrize("C", [80, 20])
+def test_level1_fresh_entry_overwrites_garbage_and_follows_geometry_changes(hip, C):
+    """sgv3d_voxel_pooling_forward_fresh (what this build's Python operator calls instead of zero fill + level-1 entry): the map
+    is WRITTEN whatever it held -- NaN here -- through the first call's build, the steady-state gather, the gated scatter of
+    a call whose geom_xyz changed and (C = 20: a channel count the gather does not cover) the scatter-only form."""
+    lib = hip.load()
+    hip.check(lib.sgv3d_voxel_pooling_cache_clear(), "clear")
+    rng = np.random.default_rng(5)
+    B, N, X, Y, Z = 2, 15013, 33, 27, 1
+    mk = lambda: rng.integers(-2, 36, size=(B, N, 3)).astype(np.int32)
+    ga, gb = mk(), mk()
+    ga[..., 2], gb[..., 2] = rng.integers(-1, 2, size=(B, N)), 0
+    feats = rng.integers(-4, 5, size=(B, N, C)).astype(np.float32)
+    f = torch.from_numpy(feats).to(DEV)
+    refs = {id(g): VPO.forward(g, feats, (X, Y, Z)) for g in (ga, gb)}
+    dev = {id(g): torch.from_numpy(g).to(DEV) for g in (ga, gb)}
+    for step, g in enumerate((ga, ga, gb, gb, ga, ga)):
+        out = torch.full((B, Y, X, C), float("nan"), device=DEV)
+        pm = torch.full((B, N, 3), -1, dtype=torch.int32, device=DEV)
+        hip.check(lib.sgv3d_voxel_pooling_forward_fresh(B, N, C, X, Y, Z, dev[id(g)].data_ptr(), f.data_ptr(), out.data_ptr(),
+                                                        pm.data_ptr(), hip.stream_handle()), "level1 fresh")
+        torch.cuda.synchronize()
+        ref_out, ref_pm = refs[id(g)]
+        assert np.array_equal(out.permute(0, 3, 1, 2).cpu().numpy(), ref_out), step
+        assert np.array_equal(pm.cpu().numpy().reshape(ref_pm.shape), ref_pm), step
+    hip.check(lib.sgv3d_voxel_pooling_cache_clear(), "clear")
+
+
 def test_level1_entry_inside_a_captured_graph(hip):
     """A hipGraph that holds the level-1 call keeps working when geom_xyz is rewritten in place between replays."""
     hip.check(hip.load().sgv3d_voxel_pooling_cache_clear(), "clear")

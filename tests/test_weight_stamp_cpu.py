@@ -28,7 +28,7 @@ def test_stamp_is_stable_and_sees_every_kind_of_change():
     assert c != b
     m.double()                                              # _apply: buffers become new objects
     d = m._stamp()
-    assert d != c and d[0] == c[0] + 1
+    assert d != c
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     m.load_state_dict(sd, assign=True)                      # Parameter objects replaced
     e = m._stamp()
@@ -37,11 +37,57 @@ def test_stamp_is_stable_and_sees_every_kind_of_change():
     assert m._stamp() != e
 
 
-def test_periodic_walk_catches_objects_replaced_behind_the_models_back():
+def test_objects_replaced_behind_the_models_back_are_seen_on_the_next_forward():
+    """no window of stale weights.  Every way torch offers to swap a tensor OBJECT under the model moves the very
+    next stamp: a parent's load_state_dict(assign=True) (Lightning; it calls the children's _load_from_state_dict, never
+    BEVHeight.load_state_dict), attribute assignment, a sub-module's own load_state_dict(assign=True) / .half(), a write into
+    a sub-module's ``_buffers`` dict."""
+    m = _model()
+
+    class Parent(torch.nn.Module):
+        def __init__(self, model):
+            super().__init__()
+            self.model = model
+    p = Parent(m)
+    a = m._stamp()
+    p.load_state_dict({k: v.clone() for k, v in p.state_dict().items()}, assign=True)
+    b = m._stamp()
+    assert b != a
+    conv = m.head.shared_conv.conv
+    conv.weight = torch.nn.Parameter(conv.weight.data.clone())
+    c = m._stamp()
+    assert c != b
+    hn = m.backbone.height_net
+    hn.load_state_dict({k: v.clone() for k, v in hn.state_dict().items()}, assign=True)
+    d = m._stamp()
+    assert d != c
+    hn.bn._buffers['running_var'] = hn.bn.running_var.clone()     # (what a sub-module's own .to() does; no hook sees it)
+    e = m._stamp()
+    assert e != d
+    m.backbone.double()                                           # _apply of a SUB-module: BEVHeight._apply is not called
+    f = m._stamp()
+    assert f != e
+    hn.bn.register_buffer('extra', torch.zeros(3))                # a tensor the walk did not know
+    g = m._stamp()
+    assert g != f and g[1] == f[1] + 1
+    assert all(m._stamp() == g for _ in range(3))
+
+
+def test_train_drops_the_cached_walk():
+    m = _model()
+    m._stamp()
+    assert not m._flat_dirty
+    m.train()
+    assert m._flat_dirty
+    m.eval()
+
+
+def test_periodic_walk_catches_a_module_swapped_through_the_modules_dict():
     m = _model()
     m._RESTAMP_EVERY = 4
     a = m._stamp()
-    bn = m.backbone.height_net.bn
-    bn._buffers['running_var'] = bn.running_var.clone()     # (what a sub-module's own .to() does; no hook of ours sees it)
+    hn = m.backbone.height_net
+    import copy
+    hn._modules['bn'] = copy.deepcopy(hn.bn)                # (no registration hook fires for a direct dict write)
     seen = [m._stamp() for _ in range(5)]
     assert seen[-1] != a and seen[-1][0] == a[0] + 1        # at the latest after _RESTAMP_EVERY forwards

@@ -98,7 +98,7 @@ if args.profile:
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     fam = {}
-    for name, flops, e0, e1 in hip_ops.PROFILE:
+    for name, flops, e0, e1, *_ in hip_ops.PROFILE:
         d = fam.setdefault(name.split('|')[0], [0.0, 0.0, 0])
         d[0] += e0.elapsed_time(e1)
         d[1] += flops
