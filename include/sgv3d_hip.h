@@ -259,6 +259,9 @@ typedef struct sgv3d_conv_desc {
 #define SGV3D_TILE_64x64 4
 /* sgv3d_conv2d_winograd4_forward only: the grouped GEMM on a 32 x 128 tile (rows per position padded to 32 instead of 64) */
 #define SGV3D_TILE_32x128 9
+/* sgv3d_conv2d_winograd4_forward only: the grouped GEMM on v_mfma_f32_16x16x4_f32 with 48 x 64 workgroup tiles -- rows per
+ * position padded to a multiple of 48 (a 54x96 map: 336 tiles exactly, against 384 / 352 for the 64- / 32-row tiles) */
+#define SGV3D_TILE_48x64 10
 /* ... | SGV3D_TILE_MFIRST: the workgroups walk the output-channel tiles of one m-tile back to back (input rows fetched once
  * from HBM) instead of the m-tiles of one channel tile (weight tile shared); same results */
 #define SGV3D_TILE_MFIRST 16
@@ -280,7 +283,7 @@ typedef struct sgv3d_conv_desc {
  * weight (G g G^T)[i][j] ([cout, cin], G the 6x3 F(4x4,3x3) matrix); sgv3d_conv_winograd4_pack_weight makes all 36 in one
  * launch (k = ci in either k order).
  * desc as for sgv3d_conv2d_winograd_forward, NORMAL mode, no gate, no split-K; desc.k_pad / cout_pad describe one block;
- * desc.tile = SGV3D_TILE_64x64 (default) | SGV3D_TILE_64x128 | SGV3D_TILE_32x128 picks the GEMM tile.  workspace: V and M
+ * desc.tile = SGV3D_TILE_64x64 (default) | SGV3D_TILE_64x128 | SGV3D_TILE_32x128 | SGV3D_TILE_48x64 picks the GEMM tile.  workspace: V and M
  * (sgv3d_conv2d_winograd4_workspace_bytes, 16-B aligned).  fp32 error ~1e-5 of the output scale. */
 int sgv3d_conv_winograd4_pack_weight(const float *w_src /*[cout, cin, 3, 3]*/, int cout, int cin, int k_pad, int cout_pad,
                                      float *u_packed /*36 x cout_pad x k_pad*/, void *stream);

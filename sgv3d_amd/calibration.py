@@ -1,4 +1,4 @@
-"""Per-calibration state of the view transform: voxel indices + voxel-pooling plan.
+"""Per-calibration state of the view transform: voxel indices + voxel-pooling plan (+ the height net's camera-aware gates).
 
 ``geom_xyz`` (layers/backbones/lss_fpn.py:372-401,487-488 of the reference) and everything derived from it
 depend only on the calibration tensors of ``mats_dict`` -- static for a roadside camera -- while the
@@ -46,13 +46,15 @@ class CalibrationCache:
     that rewrite the calibration tensors out of band (raw pointers, ``.data``): tensor versions do not see such writes."""
 
     class Entry:
-        __slots__ = ("_src", "_tag", "geom", "plan", "event", "stream", "join_stream")
+        __slots__ = ("_src", "_tag", "geom", "plan", "gates", "event", "stream", "join_stream")
 
         def __init__(self):
             self._src = None          # [(tensor, version)] the cached geometry was computed from
             self._tag = None          # (sweep index, shapes ...) part of the key that is not a tensor
             self.geom = None          # int32 [B, num_cams, D, fH, fW, 3]
             self.plan = None          # VoxelPlan(cached=True) for geom
+            self.gates = None         # key frame only: the camera-aware SE gate vectors of the height net (a function of the
+                                      # calibration alone, lss_fpn.py:208-246), persistent buffers rewritten in place
             self.event = None         # recorded behind the last (re)build
             self.stream = None        # cuda_stream handle of that build
             self.join_stream = None   # stream capture only: the side stream the refresh was recorded on (see join_capture)

@@ -75,5 +75,8 @@ const float *conv_zero_block();
 // or SGV3D_TILE_64x128 (the m-tiles must not straddle groups).
 int conv_gemm_grouped(const float *x, const float *w, float *y, int rows, int groups, int K, int N, int k_pad, int cout_pad,
                       int k_order, int tile, hipStream_t st);
+// the same product on v_mfma_f32_16x16x4_f32 with 48 x 64 workgroup tiles (gemm16_grouped.hip): rows % 48 == 0, K % 32 == 0
+int conv_gemm_grouped16(const float *x, const float *w, float *y, int rows, int groups, int K, int N, int k_pad, int cout_pad,
+                        hipStream_t st);
 
 }  // namespace sgv3d

@@ -10,7 +10,8 @@
 // GROUPED GEMM over the positions (conv_gemm_grouped, conv_igemm.hip):
 //
 //   1. wino4_input_kernel    x NHWC -> V[36][tiles_pad][cin]          (B^T d B; one thread per tile and 4 channels)
-//   2. conv_gemm_grouped     M[p] = V[p] . U[p]^T, p = 0..35          (U[p][cout][cin] = (G g G^T)[p], packed per position)
+//   2. conv_gemm_grouped     M[p] = V[p] . U[p]^T, p = 0..35          (U[p][cout][cin] = (G g G^T)[p], packed per position;
+//                                                                       SGV3D_TILE_48x64: conv_gemm_grouped16, gemm16_grouped.hip)
 //   3. wino4_output_kernel   M[36][tiles_pad][cout] -> y NHWC         (A^T M A, folded BN / bias, residual, ReLU)
 //
 // V and M (28 MB each for a 512-channel 54x96 layer) are written once and read once; they stay in the 256 MB last-level
@@ -219,7 +220,7 @@ void wino4_geom(const sgv3d_conv_desc *d, int &ty, int &tx, long long &tiles, in
     ty = cdiv(cdiv(d->out_h, dil), 4);
     tx = cdiv(cdiv(d->out_w, dil), 4);
     tiles = (long long)d->batch * dil * dil * ty * tx;
-    const int g = (d->tile & ~SGV3D_TILE_OCC5) == SGV3D_TILE_32x128 ? 32 : 64;       // the GEMM's m-tile height
+    const int g = (d->tile & ~SGV3D_TILE_OCC5) == SGV3D_TILE_32x128 ? 32 : d->tile == SGV3D_TILE_48x64 ? 48 : 64;   // the GEMM's m-tile height
     rows = (int)((tiles + g - 1) / g * g);
 }
 
@@ -297,17 +298,22 @@ extern "C" int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *d, const fl
     a.gw = planes ? d->deconv_ks : 0;
     a.c0 = 0; a.cn = d->cout;
     hipLaunchKernelGGL(wino4_input_kernel, dim3(cdiv(tiles * (d->cin / 4), 256)), dim3(256), 0, st, a);
-    int tile = (d->tile == SGV3D_TILE_64x128 || d->tile == SGV3D_TILE_32x128) ? d->tile
+    int tile = (d->tile == SGV3D_TILE_64x128 || d->tile == SGV3D_TILE_32x128 || d->tile == SGV3D_TILE_48x64) ? d->tile
                : (d->tile & SGV3D_TILE_OCC5) ? (SGV3D_TILE_64x64 | SGV3D_TILE_OCC5) : SGV3D_TILE_64x64;
     if (tile == SGV3D_TILE_32x128 && (d->k_order != 1 || d->cin < 128)) tile = SGV3D_TILE_64x64;    // (what the narrow tile covers)
+    SGV3D_REQUIRE(tile != SGV3D_TILE_48x64 || (d->k_order == 1 && d->cin % 32 == 0),
+                  "conv2d_winograd4_forward: SGV3D_TILE_48x64 needs channel-chunk-major weights (cin %% 32 == 0)");
     // one pass per chunk of output channels: block p of the chunk's weights is cout_pad x k_pad floats after block p - 1
     // like the full blocks, shifted by c0 rows
     const int chunk = wino4_chunk(d, a.rows);
     for (int c0 = 0; c0 < d->cout; c0 += chunk) {
         a.c0 = c0;
         a.cn = d->cout - c0 < chunk ? d->cout - c0 : chunk;
-        if (int rc = conv_gemm_grouped(a.v, u_packed + (size_t)c0 * d->k_pad, a.m, a.rows, 36, d->cin, a.cn, d->k_pad, d->cout_pad,
-                                       d->k_order, tile, st)) return rc;
+        if (tile == SGV3D_TILE_48x64) {
+            if (int rc = conv_gemm_grouped16(a.v, u_packed + (size_t)c0 * d->k_pad, a.m, a.rows, 36, d->cin, a.cn, d->k_pad,
+                                             d->cout_pad, st)) return rc;
+        } else if (int rc = conv_gemm_grouped(a.v, u_packed + (size_t)c0 * d->k_pad, a.m, a.rows, 36, d->cin, a.cn, d->k_pad,
+                                              d->cout_pad, d->k_order, tile, st)) return rc;
         hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(tiles * (a.cn / 4), 256)), dim3(256), 0, st, a);
     }
     return check_launch("conv2d_winograd4_forward");

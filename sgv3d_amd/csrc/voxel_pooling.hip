@@ -816,14 +816,27 @@ __device__ __forceinline__ bool vp_sum_run_batch(float4 &acc, long long base, in
     return ended;
 }
 
+// A gated gather that finds its gate raised normally leaves without a store (the caller's fallback adds into a map the caller
+// zeroed).  ``zero_on_gate``: the caller did NOT zero the map (sgv3d_voxel_pooling_forward_fresh) -- the gather's workgroups
+// zero it on their way out, so the scatter that follows starts from zeros without a launch of its own.
+__device__ __forceinline__ void vp_zero_output(void *out, unsigned long long bytes) {
+    float4 *p = reinterpret_cast<float4 *>(out);
+    const unsigned long long n = bytes >> 4;                   // (rows are multiples of 16 bytes)
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * kBlock)
+        p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 template <bool FUSED, bool FB = false, bool OB = false, bool ACC = false>
 __global__ __launch_bounds__(kBlock) void vp_gather3_kernel(
     long long V, int C, int lpr, int groups, int ch, int w_nom, const int *__restrict__ seg_start,
     const int *__restrict__ order, const int *__restrict__ slot_voxel, const float *__restrict__ feats,
     const float *__restrict__ prob, const float *__restrict__ ctx, int N, int P, float *__restrict__ out, int ldo,
     const int *__restrict__ long_list, int long_cap, int nblk_regular,
-    const int *__restrict__ gate /* NULL, or: run only while *gate == 0 */) {
-    if (gate != nullptr && *reinterpret_cast<const volatile int *>(gate) != 0) return;
+    const int *__restrict__ gate /* NULL, or: run only while *gate == 0 */, int zero_on_gate) {
+    if (gate != nullptr && *reinterpret_cast<const volatile int *>(gate) != 0) {
+        if (zero_on_gate) vp_zero_output(out, (unsigned long long)V * (OB ? (unsigned long long)ldo * 2u : (unsigned long long)C * 4u));
+        return;
+    }
     __shared__ float4 red[kBlock / 64][64];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
@@ -1006,6 +1019,7 @@ struct VpFastArgs {
     // FUSED (lift-splat): feats = context [B, P, C] f32, rows formed on the fly as prob[point] * context[pixel of the point]
     const float *prob;
     int P;
+    int zero_on_gate;       // gate raised: zero the output instead of leaving it alone (vp_zero_output)
 };
 
 // FUSED: a live slot's point id becomes the row of its pixel in the context tensor, `pr` its probability (0 for dead slots).
@@ -1122,7 +1136,10 @@ constexpr int kMaxGroups = 10;   // 64 lanes / LPR >= 6
 
 template <bool FB, bool OB, bool ACC, bool FUSED = false>
 __global__ __launch_bounds__(kBlock) void vp_gather_fast_kernel(const VpFastArgs a) {
-    if (a.gate != nullptr && *reinterpret_cast<const volatile int *>(a.gate) != 0) return;
+    if (a.gate != nullptr && *reinterpret_cast<const volatile int *>(a.gate) != 0) {
+        if (a.zero_on_gate) vp_zero_output(a.out, a.out_bytes);
+        return;
+    }
     // per wave: ev[group][cl] = voxel of slot cb-1+cl if this wave sums it, else -1; idx[group][k] = its point id, else -1;
     // one more all-dead block for the lanes that belong to no row group
     __shared__ __attribute__((aligned(16))) int ev_s[kBlock / 64][(kMaxGroups + 1) * kEvStride];
@@ -1358,6 +1375,7 @@ struct VpVoxArgs {
     unsigned magN, magP;    // exact division of a point id (< 2^31) by N / P: umulhi(id, mag) >> sh (vp_magic)
     int shN, shP;
     int dbg;                // SGV3D_VP_DEBUG probe bits (launch_gather)
+    int zero_on_gate;       // gate raised: zero the output instead of leaving it alone (vp_zero_output)
 };
 
 // floor(n / d) for 0 <= n < 2^31, d >= 2, as umulhi(n, mag) >> sh (a round-up magic number of 32 bits is exact for 31-bit
@@ -1506,7 +1524,10 @@ __device__ __forceinline__ void vp_vox_small(int lo, int hi, int gw, int nwaves,
 
 template <bool FB, bool OB, bool ACC, bool FUSED, int VB>
 __global__ __launch_bounds__(kBlock) void vp_gather_vox_kernel(const VpVoxArgs a) {
-    if (a.gate != nullptr && *reinterpret_cast<const volatile int *>(a.gate) != 0) return;
+    if (a.gate != nullptr && *reinterpret_cast<const volatile int *>(a.gate) != 0) {
+        if (a.zero_on_gate) vp_zero_output(a.out, a.out_bytes);
+        return;
+    }
     __shared__ __attribute__((aligned(16))) int idx_s[kBlock / 64][kMaxGroups * VB];
     __shared__ __attribute__((aligned(16))) float pr_s[kBlock / 64][FUSED ? kMaxGroups * VB : 4];
     __shared__ float4 red[kBlock / 64][64];
@@ -1737,7 +1758,7 @@ bool vp_use_vox(long long total_pts, long long V, bool fused) {
 template <bool FUSED, bool FB = false, bool OB = false, bool ACC = false>
 int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const float *feats,
                   const float *prob, const float *ctx, int P, float *out, void *workspace, size_t ws_bytes,
-                  hipStream_t st, int ldo = 0, const int *gate = nullptr) {
+                  hipStream_t st, int ldo = 0, const int *gate = nullptr, bool zero_on_gate = false) {
     const PlanLayout L = plan_layout(B, N, X, Y);
     const char *base = static_cast<const char *>(plan);
     const int *seg = reinterpret_cast<const int *>(base + L.off_seg);
@@ -1763,6 +1784,7 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
                 a.perm = reinterpret_cast<const int4 *>(base + L.off_perm);
                 a.cls = reinterpret_cast<const int *>(base + L.off_bins) + (size_t)kVoxClasses * L.ncw;
                 a.feats = FUSED ? static_cast<const void *>(ctx) : static_cast<const void *>(feats); a.out = out; a.gate = gate;
+                a.zero_on_gate = zero_on_gate ? 1 : 0;
                 a.prob = prob; a.P = P;
                 a.feat_bytes = (unsigned)fbytes; a.out_bytes = (unsigned)obytes;
                 // rows in flight per lane: 16 (4 waves per SIMD) or, SGV3D_VP_VB=8, 8 (<= 76 VGPRs: 6-7 waves per SIMD);
@@ -1800,6 +1822,7 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
                 a.seg_start = seg; a.order = order; a.slot_voxel = slotvox;
                 a.long_list = reinterpret_cast<const int *>(base + L.off_long);
                 a.feats = FUSED ? static_cast<const void *>(ctx) : static_cast<const void *>(feats); a.out = out; a.gate = gate;
+                a.zero_on_gate = zero_on_gate ? 1 : 0;
                 a.prob = prob; a.P = P;
                 a.feat_bytes = (unsigned)fbytes; a.out_bytes = (unsigned)obytes;
                 a.V = (int)L.V; a.C = C; a.lpr = G.lpr; a.groups = G.groups; a.ch = G.ch; a.w_nom = G.w_nom; a.ldo = ldo;
@@ -1810,7 +1833,7 @@ int launch_gather(int B, int N, int C, int X, int Y, const void *plan, const flo
         }
         hipLaunchKernelGGL((vp_gather3_kernel<FUSED, FB, OB, ACC>), dim3(nblk + nlong), dim3(kBlock), 0, st, L.V, C, G.lpr,
                            G.groups, G.ch, G.w_nom, seg, order, slotvox, feats, prob, ctx, N, P, out, ldo,
-                           reinterpret_cast<const int *>(base + L.off_long), L.long_cap, nblk, gate);
+                           reinterpret_cast<const int *>(base + L.off_long), L.long_cap, nblk, gate, zero_on_gate ? 1 : 0);
         return check_launch(FUSED ? "vp_lift_splat(v3)" : "vp_gather3_kernel");
     }
     if constexpr (ACC) return fail(SGV3D_EINVAL, "voxel pooling: the accumulating gather needs 24 <= C <= 256, C %% 4 == 0 (got %d)", C);
@@ -2210,9 +2233,9 @@ int level1_forward(int batch_size, int num_points, int num_channels, int num_vox
                                                           output_features, nullptr, 0, st, 0, nullptr);
     }
     g_l1_stats[1]++;
+    // (FRESH: a gather that finds the plan stale zeroes the map on its way out -- the gated scatter below adds into zeros)
     if (int rc = launch_gather<false, false, false, !FRESH>(B, N, C, X, Y, e->plan, input_features, nullptr, nullptr, 1,
-                                                            output_features, nullptr, 0, st, 0, &hdr->dirty)) return rc;
-    if (FRESH) zero_output(output_features, out_elems, &hdr->dirty, st);          // (leaves at once while the plan is current)
+                                                            output_features, nullptr, 0, st, 0, &hdr->dirty, FRESH)) return rc;
     const long long ablocks = cdiv(total, kAtomicPts);
     hipLaunchKernelGGL(vp_atomic_gated_kernel, dim3((unsigned)(ablocks < 2048 ? ablocks : 2048)), dim3(kBlock), 0, st, total, N, C, X,
                        Y, Z, geom_xyz, input_features, output_features, &hdr->dirty);

@@ -141,6 +141,7 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: 
               36: "dw_bf16", 37: "dw_bf16",                                                # ... requests two k-chunks ahead (*_DEEP)
               38: "dw_bf16", 39: "dw_bf16",                                                # ... 64 pixels x 128 channels (39: two chunks ahead)
               40: "wino4_resident",    # F(4x4,3x3) with the transformed input resident in LDS (sgv3d_conv3x3_f4res_forward)
+              47: "wino4",
               44: "64x64", 45: "64x64",    # the 64x64 tile at five workgroups per CU (SGV3D_TILE_OCC5); 45: walked m-tile first
               46: "wino4"}                 # F(4x4,3x3) in three launches with the five-per-CU 64x64 GEMM tile
 MFIRST = _os.environ.get("SGV3D_MFIRST", "1") != "0"
@@ -152,7 +153,9 @@ TILE_WINO4 = 9      # Winograd F(4x4,3x3) in three launches (sgv3d_conv2d_winogr
 TILE_WINO4_WIDE = 10
 TILE_WINO4_NARROW = 15   # ... with the 32x128 GEMM tile: rows per position padded to 32 instead of 64 (336 tiles -> 352, 84 -> 96)
 TILE_WINO4_OCC = 46      # ... with the five-workgroups-per-CU form of the 64x64 GEMM tile (SGV3D_TILE_64x64 | SGV3D_TILE_OCC5)
-WINO4_TILES = (TILE_WINO4, TILE_WINO4_WIDE, TILE_WINO4_NARROW, TILE_WINO4_OCC)
+TILE_WINO4_G48 = 47      # ... with the grouped GEMM on v_mfma_f32_16x16x4_f32, 48 x 64 tiles (SGV3D_TILE_48x64): rows padded to 48 (336 -> 336)
+WINO4_TILES = (TILE_WINO4, TILE_WINO4_WIDE, TILE_WINO4_NARROW, TILE_WINO4_OCC, TILE_WINO4_G48)
+WINO4_G48 = _os.environ.get("SGV3D_WINO4_G48", "1") != "0"     # 0: never a candidate
 # F(4x4,3x3) in ONE launch with V = B^T d B of a 16x16 block resident in LDS (csrc/head_wino4.hip: conv_f4res_kernel): 3x3 /
 # stride 1 / pad 1 layers with 64 input channels (ResNet layer 1) or 64 output channels (the CenterHead's shared layer), f32
 TILE_F4RES = 40
@@ -570,12 +573,13 @@ class PackedConv:
                 # the grouped GEMM of the three-launch F(4x4) path: 36 positions x rows (tiles padded to the GEMM's m-tile)
                 dil = max(1, self.dil)
                 tiles = B * dil * dil * -(-(-(-oh // dil)) // 4) * -(-(-(-ow // dil)) // 4)
-                g = 32 if t == TILE_WINO4_NARROW else 64
+                g = 32 if t == TILE_WINO4_NARROW else 48 if t == TILE_WINO4_G48 else 64
                 rows = -(-tiles // g) * g
                 extra = {"symbol": {TILE_WINO4: "conv_igemm_kernel<1, 1, true, false, true, false, false>",
                                     TILE_WINO4_WIDE: "conv_igemm_kernel<1, 2, true, false, true, false, false>",
                                     TILE_WINO4_NARROW: "conv_igemm_kernel<1, 1, true, false, true, true, false>",
-                                    TILE_WINO4_OCC: "conv_igemm_kernel<1, 1, true, false, true, false, true>"}[t],
+                                    TILE_WINO4_OCC: "conv_igemm_kernel<1, 1, true, false, true, false, true>",
+                                    TILE_WINO4_G48: "gemm16_grouped_kernel<3>"}[t],
                          "mfma_flops": 2.0 * 36 * rows * self.cin * self.cout}
         with torch.cuda.device(x.device), prof(name, flops, nbytes, extra):
             rc = self._launch(lib, d, x, residual, gate, out, io)
@@ -645,7 +649,8 @@ class PackedConv:
                                       "NHWC output, no gate, no split-K")
             u = self._wino4_weights()
             host_tile, kp, cp = d.tile, d.k_pad, d.cout_pad
-            d.tile = {TILE_WINO4: 4, TILE_WINO4_WIDE: 3, TILE_WINO4_NARROW: 9, TILE_WINO4_OCC: 4 | 32}[host_tile]      # SGV3D_TILE_64x64 / 64x128 / 32x128 / 64x64 | OCC5
+            d.tile = {TILE_WINO4: 4, TILE_WINO4_WIDE: 3, TILE_WINO4_NARROW: 9, TILE_WINO4_OCC: 4 | 32,
+                      TILE_WINO4_G48: 10}[host_tile]      # SGV3D_TILE_64x64 / 64x128 / 32x128 / 64x64 | OCC5 / 48x64
             d.k_pad, d.cout_pad = self.wino4_geom
             try:
                 nws4 = lib.sgv3d_conv2d_winograd4_workspace_bytes(ctypes.byref(d))
@@ -733,7 +738,8 @@ class PackedConv:
                 tiles += (TILE_WINO_RES,)
 
         if self.wino4_ok(d, gate):            # (also the dilated 3x3 layers, which the F(2x2) kernels do not cover)
-            tiles += (TILE_WINO4, TILE_WINO4_WIDE) + ((TILE_WINO4_NARROW,) if self.cin >= 128 else ()) + ((TILE_WINO4_OCC,) if OCC5 else ())
+            tiles += ((TILE_WINO4, TILE_WINO4_WIDE) + ((TILE_WINO4_NARROW,) if self.cin >= 128 else ()) + ((TILE_WINO4_OCC,) if OCC5 else ())
+                      + ((TILE_WINO4_G48,) if WINO4_G48 and self.k_order == 1 else ()))
         if self.f4res_ok(d, gate, io):
             tiles += (TILE_F4RES,)
         if self._patch_eligible(d, gate):
@@ -901,7 +907,7 @@ def switch_state():
     g = globals()
     return tuple(g.get(k) for k in ("AUTOTUNE", "SPLIT_K", "WINOGRAD", "FUSED_HEAD", "HEAD_PATH", "MFMA_BF16", "BF16_ACTIVATIONS",
                                     "MFMA_F32X3", "MFIRST", "WINO4", "WINO_HALF", "PATCH_BF16", "DW_BF16", "DW_DEEP", "DW_NARROW",
-                                    "DW_SPLIT_K", "DW_DEEP_MAX_WGS", "PAIR_BF16", "TUNE_STREAMS", "PARALLEL_BRANCHES", "F4RES", "OCC5"))
+                                    "DW_SPLIT_K", "DW_DEEP_MAX_WGS", "PAIR_BF16", "TUNE_STREAMS", "PARALLEL_BRANCHES", "F4RES", "OCC5", "WINO4_G48"))
 
 
 def conv_pair_eligible(a, b, x, residual=None):

@@ -21,7 +21,7 @@ from torch import nn
 from ... import hip_ops
 from ...calibration import CalibrationCache
 from ..blocks import BasicBlock, HipModule, build_backbone, build_neck, conv_bn
-from .lss_fpn import ASPP, FUSE_LIFT_SPLAT, HeightNet, LSSFPN, Mlp, SELayer, _require_hip_inference
+from .lss_fpn import ASPP, CACHE_CAMERA_GATES, FUSE_LIFT_SPLAT, HeightNet, LSSFPN, Mlp, SELayer, _require_hip_inference
 
 __all__ = ['BSMLSSFPN']
 
@@ -163,17 +163,28 @@ class MSCThead(HipModule):
             ]
         return s
 
-    def hip_forward(self, feats, mats_dict, out_ld):
-        """feats = [stride-16 map, stride-8 map] NHWC.  Returns (height_context, semantic1, semantic0):
-        height_context NHWC [B*N, H8, W8, out_ld] holds depth logits at [0, D) and the context at
-        [D, D+80) (the caller composes the semantic part), semantic logits NHWC [.., 7]."""
-        s = self.hip_state(feats[0].device)
+    def camera_gates(self, mats_dict, device):
+        """The SE gate vectors of the two scales (:262-299): a function of the calibration and the weights alone, kept per
+        calibration by ``LSSFPN.calibration`` (layers/backbones/lss_fpn.py here)."""
+        s = self.hip_state(device)
         v = HeightNet.mlp_input(mats_dict)                                   # :262-292
-        def gate(i):
+        out = []
+        for i in (0, 1):
             h = v
             for w, b, act in s[f'gate{i}']:
                 h = hip_ops.dense(h, w, None, b, act)
-            return h
+            out.append(h)
+        return out
+
+    def hip_forward(self, feats, mats_dict, out_ld, gates=None):
+        """feats = [stride-16 map, stride-8 map] NHWC.  Returns (height_context, semantic1, semantic0):
+        height_context NHWC [B*N, H8, W8, out_ld] holds depth logits at [0, D) and the context at
+        [D, D+80) (the caller composes the semantic part), semantic logits NHWC [.., 7].  ``gates``: ``camera_gates`` of this
+        calibration when the caller keeps them; None: computed here."""
+        s = self.hip_state(feats[0].device)
+        if gates is None:
+            gates = self.camera_gates(mats_dict, feats[0].device)
+        gate = lambda i: gates[i]
         # bf16 mode: every mid-channel map of this head lives in HBM as bf16; the logits / context it returns are f32
         dt = hip_ops.activation_dtype(*[c.cout for c in (s['reduce0'], s['reduce1'], s['ctx0'], s['ctx1a'])])
         dev = feats[0].device
@@ -181,12 +192,12 @@ class MSCThead(HipModule):
         # (hip_ops.run_parallel; in sequence outside a capture)
 
         def scale0_branch():
-            r, g0 = hip_ops.run_parallel(dev, (lambda: s['reduce0'](feats[0], out_dtype=dt), lambda: gate(0)))
-            return self.aspp.hip_forward(hip_ops.scale_channels(r, g0))       # :300-306
+            r = s['reduce0'](feats[0], out_dtype=dt)
+            return self.aspp.hip_forward(hip_ops.scale_channels(r, gate(0)))  # :300-306
 
         def scale1_branch():
-            r, g1 = hip_ops.run_parallel(dev, (lambda: s['reduce1'](feats[1], out_dtype=dt), lambda: gate(1)))
-            return hip_ops.scale_channels(r, g1)
+            r = s['reduce1'](feats[1], out_dtype=dt)
+            return hip_ops.scale_channels(r, gate(1))
         scale0, scale1 = hip_ops.run_parallel(dev, (scale0_branch, scale1_branch))
         B, H, W, _ = scale1.shape
         out = torch.empty(B, H, W, out_ld, dtype=torch.float32, device=scale1.device)
@@ -275,10 +286,11 @@ class BSMLSSFPN(LSSFPN):
         img_feats = self.get_cam_feats_nhwc(sweep_imgs)
         D, C = self.height_channels, self.bev_channels
         Cp = (C + 3) // 4 * 4                                                 # 87 -> 88 (zero channel)
-        hc, semantic1, _semantic0 = self.height_net.hip_forward(img_feats, mats_dict, out_ld=D + Cp)
+        geom_xyz, plan = self.calibration(mats_dict, sweep_index)             # :540-553 (cached per calibration, with the gates)
+        gates = self.calib_cache.entry(0).gates if CACHE_CAMERA_GATES else None
+        hc, semantic1, _semantic0 = self.height_net.hip_forward(img_feats, mats_dict, out_ld=D + Cp, gates=gates)
         hip_ops.bsm_compose(hc, semantic1, D, self.output_channels, self.semantic_channels,
                             self.background_threshold)                        # :521-529
-        geom_xyz, plan = self.calibration(mats_dict, sweep_index)             # :540-553 (cached per calibration)
         fH, fW = int(hc.shape[1]), int(hc.shape[2])
         if self.fuse_lift_splat and num_cams == 1:
             prob, _ = hip_ops.lift(hc, D, Cp, want_prob=True, want_lifted=False)

@@ -29,6 +29,9 @@ from ..blocks import BasicBlock, HipModule, build_backbone, build_neck, conv_bn
 
 import os as _os
 
+# 0: the height net's camera-aware SE gates (27 calibration numbers -> MLP -> sigmoid; no pixel enters) are recomputed on every
+# forward, as the reference does (lss_fpn.py:208-246); default: kept per calibration beside the voxel indices and the plan
+CACHE_CAMERA_GATES = _os.environ.get("SGV3D_CACHE_CAMERA_GATES", "1") != "0"
 FUSE_LIFT_SPLAT = _os.environ.get("SGV3D_FUSE_LIFT_SPLAT", "1") != "0"   # 0: lift kernel + voxel_pooling operator (the reference's two steps)
 
 __all__ = ['LSSFPN']
@@ -241,10 +244,12 @@ class HeightNet(HipModule):
         )
         return mlp_input.reshape(-1, mlp_input.shape[-1]).float().contiguous()
 
-    def hip_forward(self, x, mats_dict):
-        """x NHWC [B*N,fH,fW,in] -> NHWC [B*N,fH,fW,D+C] = cat(height logits, context)  (:250)."""
-        s = self.hip_state(x.device)
-        B, H, W, _ = x.shape
+    def camera_gates(self, mats_dict, device):
+        """The two SE gate vectors [B*N, mid] (context, height) of lss_fpn.py:208-246: BatchNorm1d(27) -> Mlp -> SELayer's
+        reduce / expand / sigmoid on the 27 calibration numbers per camera.  A function of the calibration (and the weights)
+        alone -- no pixel enters -- so ``LSSFPN.calibration`` keeps them per calibration like the voxel indices; eight
+        one-workgroup launches plus the torch indexing of ``mlp_input`` that a static camera pays once, not per frame."""
+        s = self.hip_state(device)
         v = self.mlp_input(mats_dict)                                                   # [B*N, 27]
         # BatchNorm1d(27) in eval mode is a per-feature affine: folded once into fc1
         # (W' = W * scale, b' = b + W @ shift).
@@ -260,12 +265,20 @@ class HeightNet(HipModule):
             for w, b, act in s[name + '_gate'][1:]:
                 h = hip_ops.dense(h, w, None, b, act)
             return h                                                                    # sigmoid gate [B*N, mid]
+        return [gate('context'), gate('height')]
+
+    def hip_forward(self, x, mats_dict, gates=None):
+        """x NHWC [B*N,fH,fW,in] -> NHWC [B*N,fH,fW,D+C] = cat(height logits, context)  (:250).  ``gates``: the result of
+        ``camera_gates`` for this calibration when the caller keeps it (``LSSFPN.calibration``); None: computed here."""
+        s = self.hip_state(x.device)
+        B, H, W, _ = x.shape
         # bf16 mode: the mid-channel maps live in HBM as bf16 (like the ResNet chains); logits + context leave as f32
         dt = hip_ops.activation_dtype(self.mid_channels, self.mid_channels // 4)
         x_in = x
-        # the two gate MLPs (27 numbers per camera) beside the 3x3 reduce convolution (:241) -- three graph branches
-        x, g_ctx, g_h = hip_ops.run_parallel(x_in.device, (lambda: s['reduce'](x_in, out_dtype=dt), lambda: gate('context'),
-                                                            lambda: gate('height')))
+        if gates is None:
+            gates = self.camera_gates(mats_dict, x.device)
+        g_ctx, g_h = gates
+        x = s['reduce'](x_in, out_dtype=dt)                                             # 3x3 reduce convolution (:241)
         out = torch.empty(B, H, W, self.height_channels + self.context_channels, dtype=torch.float32, device=x.device)
 
         def context_branch():
@@ -382,8 +395,11 @@ class LSSFPN(HipModule):
         cc = cache.entry(sweep_index)
         s2e = mats_dict['sensor2ego_mats']
         D, fH, fW, _ = (int(v) for v in self.frustum.shape)
+        # (the height net's packed weights are part of what the cached gates were computed from: a weight refresh makes
+        #  a new state dict, hence another tag)
+        hn_state = self.height_net.hip_state(s2e.device) if CACHE_CAMERA_GATES else None
         tag = (int(sweep_index), tuple(s2e.shape), str(s2e.device), self.frustum.data_ptr(), self.frustum._version,
-               self._voxel_num_host)
+               self._voxel_num_host, id(hn_state))
         if cc.geom is not None and cc.matches(srcs, tag):
             cache.hits += 1
             cc.join_capture(s2e.device)            # (graph capture with the refresh on a forked branch)
@@ -407,6 +423,15 @@ class LSSFPN(HipModule):
         else:
             cc.plan = VoxelPlan(flat, self._voxel_num_host, cached=True)
         cc.geom = geom
+        if int(sweep_index) == 0 and CACHE_CAMERA_GATES:
+            # the camera-aware SE gates use the key frame's calibration whatever the sweep (lss_fpn.py:208-240 index 0:1);
+            # persistent buffers rewritten in place: a captured graph that reads them sees the refreshed values
+            fresh = self.height_net.camera_gates(mats_dict, s2e.device)
+            if cc.gates is not None and len(cc.gates) == len(fresh) and all(a.shape == b.shape and a.device == b.device
+                                                                              for a, b in zip(cc.gates, fresh)):
+                torch._foreach_copy_(cc.gates, fresh)
+            else:
+                cc.gates = fresh
         cc.remember(srcs, tag)
         cc.mark_built(s2e.device)
         cache.refreshes += 1
@@ -431,9 +456,11 @@ class LSSFPN(HipModule):
         source_features = self.get_cam_feats_nhwc(sweep_imgs)                 # [B*N, fH, fW, 512]
         # assist_layer (:459) only feeds the is_train_height branch (:493-494); in eval its result is
         # discarded by the reference, so it is not computed here.
-        height_feature = self.height_net.hip_forward(source_features, mats_dict)   # [B*N,fH,fW,D+C]
-        D, C = self.height_channels, self.output_channels
+        # voxel indices + plan (+ the height net's gates) of this calibration: nothing launched for a calibration already seen
         geom_xyz, plan = self.calibration(mats_dict, sweep_index)              # :478-488, int32 [B,N,D,fH,fW,3] + CSR plan
+        gates = self.calib_cache.entry(0).gates if CACHE_CAMERA_GATES else None
+        height_feature = self.height_net.hip_forward(source_features, mats_dict, gates=gates)   # [B*N,fH,fW,D+C]
+        D, C = self.height_channels, self.output_channels
         fH, fW = int(height_feature.shape[1]), int(height_feature.shape[2])
         if self.fuse_lift_splat and num_cams == 1:            # (one camera per sample: point id = depth * pixels + pixel)
             prob, _ = hip_ops.lift(height_feature, D, C, want_prob=True, want_lifted=False)

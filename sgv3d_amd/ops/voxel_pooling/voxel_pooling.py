@@ -283,4 +283,46 @@ class VoxelPooling(Function):
         return None, grad_input.reshape(shape), None         # voxel_pooling.py:69
 
 
-voxel_pooling = VoxelPooling.apply
+def _voxel_pooling_inference(geom_xyz, input_features, voxel_num):
+    """The operator for a call that needs no gradient, with the host work cut to what the call needs: the same checks as
+    ``VoxelPooling.forward`` (voxel_pooling.py:25-33), one output allocation, ONE library call
+    (``sgv3d_voxel_pooling_forward_fresh``: plan per (device, stream, sizes) inside the library, every row of the map
+    written).  At cfg-2 the gather is ~26 us of GPU time; the autograd ``Function.apply`` round trip, two context managers
+    and two reshapes around it were 40 us of Python.  None: a case this path does not cover (the caller falls back)."""
+    if not (geom_xyz.is_cuda and input_features.is_cuda and geom_xyz.dtype == torch.int32 and input_features.dtype == torch.float32):
+        return None                                          # (VoxelPooling.forward raises the reference's errors)
+    assert geom_xyz.is_contiguous()                          # voxel_pooling.py:25
+    assert input_features.is_contiguous()                    # voxel_pooling.py:26
+    num_channels = int(input_features.shape[-1])
+    batch_size = int(geom_xyz.shape[0])
+    num_points = geom_xyz.numel() // (3 * batch_size) if batch_size and int(geom_xyz.shape[-1]) == 3 else -1
+    if (num_points <= 0 or input_features.numel() != batch_size * num_points * num_channels or num_channels % 4
+            or not 24 <= num_channels <= 256 or input_features.data_ptr() % 16):
+        return None
+    X, Y, Z = _voxel_num_ints(voxel_num)
+    dev = input_features.device
+    output_features = torch.empty((batch_size, Y, X, num_channels), dtype=torch.float32, device=dev)
+    if hip_ops.PROFILE is not None or dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev), hip_ops.prof("voxel_pooling_level1"):
+            rc = _lib.load().sgv3d_voxel_pooling_forward_fresh(batch_size, num_points, num_channels, X, Y, Z, geom_xyz.data_ptr(),
+                                                               input_features.data_ptr(), output_features.data_ptr(), None,
+                                                               torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        rc = _lib.load().sgv3d_voxel_pooling_forward_fresh(batch_size, num_points, num_channels, X, Y, Z, geom_xyz.data_ptr(),
+                                                           input_features.data_ptr(), output_features.data_ptr(), None,
+                                                           torch.cuda.current_stream(dev).cuda_stream)
+    if rc:
+        _lib.check(rc, "sgv3d_voxel_pooling_forward_fresh")
+    return output_features.permute(0, 3, 1, 2)               # voxel_pooling.py:55
+
+
+def voxel_pooling(geom_xyz, input_features, voxel_num):
+    """``voxel_pooling(geom_xyz, input_features, voxel_num) -> [B, C, Y, X]`` -- the reference's operator
+    (ops/voxel_pooling/voxel_pooling.py:72, there ``VoxelPooling.apply``).  Calls that need a gradient go through
+    ``VoxelPooling`` (autograd contract of voxel_pooling.py:10-69); the others through the lean inference path."""
+    if (_MODE == "planned" and CACHE_PLANS and torch.is_tensor(input_features) and torch.is_tensor(geom_xyz)
+            and not (input_features.requires_grad and torch.is_grad_enabled())):
+        out = _voxel_pooling_inference(geom_xyz, input_features, voxel_num)
+        if out is not None:
+            return out
+    return VoxelPooling.apply(geom_xyz, input_features, voxel_num)

@@ -313,7 +313,7 @@ WINO4_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", WINO4_SHAPES)
-@pytest.mark.parametrize("tile", [9, 10, 15, 46])  # hip_ops.TILE_WINO4 (64x64 GEMM tile), _WIDE (64x128), _NARROW (32x128), _OCC (64x64, five per CU)
+@pytest.mark.parametrize("tile", [9, 10, 15, 46, 47])  # hip_ops.TILE_WINO4 (64x64 GEMM tile), _WIDE (64x128), _NARROW (32x128), _OCC (64x64, five per CU), _G48 (16x16x4 MFMA, 48x64)
 def test_winograd_f4x4_matches_conv2d(shape, tile):
     """csrc/conv_wino4.hip: input transform -> grouped GEMM over the 36 positions -> output transform, with folded BN,
     residual, ReLU and a concat offset, against a float64 convolution.  fp32 bound: 1e-4 of the output scale (measured ~1e-5:

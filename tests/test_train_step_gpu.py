@@ -185,6 +185,30 @@ def test_cfg4_share_training_step_through_one_rank_rccl():
           f"all-reduced in {dist['allreduce_buckets']} buckets; without a process group {plain['ms_per_step']:.1f} ms")
 
 
+def test_cfg5_share_training_step_through_one_rank_rccl():
+    """BASELINE configs[4] (SGV3D full config: BSM R101 with the BEV-segmentation branch and the SAM-mask focal supervision,
+    exps/sgv3d/bsm_bev_height_lss_r101_864_1536_256x256.py:295-335, on 8 MI355X): its per-GPU share at FULL size --
+    864x1536 images, stride-8 frustum with D = 180, 87-channel BEV map, batch 2 per rank -- one whole data-parallel step
+    through a real RCCL group of one rank: detection loss + 500 x semantic focal loss, backward through the fused
+    lift-splat adjoint, bucket all-reduces launched inside backward, fused AdamW.  (this share had never run
+    in the GPU suite.)"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "train_bench.py"), "--config", "cfg5", "--batch", "2", "--steps", "2",
+           "--warmup", "1"]
+    base = {k: v for k, v in os.environ.items() if k not in ("SGV3D_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    base["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dist = _run_json(cmd, dict(base, SGV3D_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29535"), timeout=1200)
+    assert dist["config"] == "cfg5" and dist["backend"] == "nccl" and dist["world_size"] == 1 and dist["collectives_active"] is True
+    assert dist["batch_per_gpu"] == 2 and dist["parameters"] > 90e6                      # ResNet-101 + MSCThead + BEV head
+    assert dist["allreduces_launched_inside_backward"] == dist["allreduce_buckets"] >= 1
+    assert dist["loss"] == dist["loss"] and 0.0 < dist["loss"] < 1e6                     # finite
+    print(f"cfg-5 share through 1-rank RCCL: {dist['ms_per_step']:.1f} ms / step at batch 2, "
+          f"{dist['allreduce_bytes_per_step'] / 1e6:.0f} MB all-reduced in {dist['allreduce_buckets']} buckets, "
+          f"peak memory {dist['peak_mem_gb']:.1f} GB, loss {dist['loss']:.3f}")
+
+
 def test_bench_through_one_rank_rccl():
     """bench.py's N>1 protocol (RCCL barrier, MAX all-reduce of the elapsed time, all_gather_object of the per-rank
     records, final barrier before teardown) on a 1-rank RCCL group."""
