@@ -419,6 +419,19 @@ int sgv3d_bsm_compose(int batch, int pixels, int num_depth, int context_channels
                       int ld, const float *semantic_logits, int semantic_ld, float background_threshold,
                       float *height_context, void *stream);
 
+/* mmcv DeformConv2dPack (DCNv1) forward as configured at layers/backbones/lss_fpn.py:190-198 -- 3x3, stride 1, pad 1,
+ * dilation 1, deform_groups 1, `groups` channel groups, no bias -- in ONE launch: an implicit GEMM whose A operand is the
+ * bilinear sample (zero outside the image) of x at p + tap + offset[p][tap], formed on the way into LDS (csrc/dcn_fused.hip);
+ * the column tensor of sgv3d_deform_im2col3x3 is never materialised.
+ *   x f32 NHWC [B, H, W, C]; offset f32 [B, H, W, off_ld], (dy, dx) of tap t at 2t, 2t+1
+ *   w_packed[g]: the group's [out_per_group, 9 * C/groups] matrix (k = tap * C/groups + ci) packed by sgv3d_conv_pack_weight as a
+ *                1x1 layer: [cout_pad][k_pad] floats (sgv3d_conv_pack_geometry(9 * C/groups, out_per_group))
+ *   y f32 [B, H, W, y_ld]: channels [y_coff, y_coff + groups * out_per_group) written
+ * C/groups % 32 == 0, out_per_group % 4 == 0, groups <= 8, 16-byte aligned pointers. */
+int sgv3d_deform_conv3x3_forward(int batch, int h, int w, int channels, int groups, int out_per_group, const float *x,
+                                 const float *offset, int off_ld, const float *const *w_packed, int k_pad, int cout_pad,
+                                 float *y, int y_ld, int y_coff, void *stream);
+
 /* Deformable 3x3 sampling of mmcv DeformConv2dPack (DCNv1, deform_groups=1, stride 1, pad 1, dil 1;
  * lss_fpn.py:190-198): col[b, p, g, tap, cg] = bilinear(x[b, :, :, g*cpg + cg], p + tap + offset).
  *   x      f32 [B, H, W, C] NHWC;  offset f32 [B, H, W, off_ld] with (dy, dx) of tap t at 2t, 2t+1

@@ -112,6 +112,8 @@ _PROTOS = {
     "sgv3d_add_mul_sigmoid": (c_int, [c_ll] + [c_void_p] * 5),
     "sgv3d_bsm_compose": (c_int, [c_int] * 6 + [c_void_p, c_int, ctypes.c_float, c_void_p, c_void_p]),
     "sgv3d_deform_im2col3x3": (c_int, [c_int] * 5 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "sgv3d_deform_conv3x3_forward": (c_int, [c_int] * 6 + [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                                                          c_void_p]),
     "sgv3d_head_final_conv": (c_int, [c_int] * 6 + [c_void_p] * 6),
     "sgv3d_centerpoint_decode_workspace_bytes": (c_size_t, [c_int] * 3),
     "sgv3d_centerpoint_decode": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_ll] + [ctypes.c_float] * 6 +

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kThreads, 3) void dcn3x3_fused_kernel(const DcnArgs
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
             f32x4 v_;                                                                                     \
             _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                 \
-                v_[e] = sw[i][0] * rx[i][0][e] + sw[i][1] * rx[i][1][e] + sw[i][2] * rx[i][2][e] + sw[i][3] * rx[i][3][e]; \
+                v_[e] = cw[i][0] * rx[i][0][e] + cw[i][1] * rx[i][1][e] + cw[i][2] * rx[i][2][e] + cw[i][3] * rx[i][3][e]; \
             *reinterpret_cast<f32x4 *>(Xs0 + (BUF) * kBuf + (r0 + 32 * i) * BK + cs * 4) = v_;            \
         }                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
@@ -172,41 +172,35 @@ __global__ __launch_bounds__(kThreads, 3) void dcn3x3_fused_kernel(const DcnArgs
         _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                 \
             FX[mb] = *reinterpret_cast<const f32x4 *>(Xs0 + (BUF) * kBuf + x_frag + mb * 16 * BK + (FO)); \
     } while (0)
-#define DCN_MFMA(FW, FX)                                                                                  \
+#define DCN_MFMA(FW, FX, J0, J1)                                                                          \
     do {                                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+        _Pragma("unroll") for (int j = (J0); j < (J1); ++j)                                               \
             _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                             \
                 acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(FW[j], FX[mb][j], acc[mb], 0, 0, 0);       \
     } while (0)
 #define DCN_SB() __builtin_amdgcn_sched_barrier(0)
-    // The weights a request was made with must be the ones its data is combined with: a request for the FIRST chunk of a tap
-    // recomputes cw / co, while the data of the previous tap's last chunk is still in flight -> the weights of the loads in
-    // flight are kept in sw (copied when the request is made).
-    float sw[2][4];
-#define DCN_KEEP_WEIGHTS()                                                                                \
-    do {                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) sw[i][c] = cw[i][c];                            \
-    } while (0)
+    // (one register stage: the tile requested at the top of a phase is combined and stored in the same phase, so the corner
+    //  weights cw computed for that request are still the current ones at the store)
 #define DCN_PHASE(BUF, HAVE_NEXT)                                                                         \
     do {                                                                                                  \
-        if (HAVE_NEXT) { DCN_LOAD(); DCN_KEEP_WEIGHTS(); }                                                \
+        if (HAVE_NEXT) DCN_LOAD();                                                                                       \
         DCN_READ(fw1, fx1, BUF, fo1);                                                                     \
         DCN_SB();                                                                                         \
-        DCN_MFMA(fw0, fx0);                                                                               \
+        DCN_MFMA(fw0, fx0, 0, 4);                                                                         \
         DCN_SB();                                                                                         \
-        if (HAVE_NEXT) {                                                                                  \
+        DCN_MFMA(fw1, fx1, 0, 2);      /* (the tile requested above gets three quarters of the phase to arrive) */ \
+        DCN_SB();                                                                                         \
+        if (HAVE_NEXT) {                                                                                            \
             DCN_STORE((BUF) ^ 1);                                                                         \
             __syncthreads();                                                                              \
             DCN_READ(fw0, fx0, (BUF) ^ 1, fo0);                                                           \
         }                                                                                                 \
         DCN_SB();                                                                                         \
-        DCN_MFMA(fw1, fx1);                                                                               \
+        DCN_MFMA(fw1, fx1, 2, 4);                                                                         \
         DCN_SB();                                                                                         \
     } while (0)
 
     DCN_LOAD();
-    DCN_KEEP_WEIGHTS();
     DCN_STORE(0);
     __syncthreads();
     DCN_READ(fw0, fx0, 0, fo0);
@@ -221,7 +215,6 @@ __global__ __launch_bounds__(kThreads, 3) void dcn3x3_fused_kernel(const DcnArgs
 #undef DCN_READ
 #undef DCN_MFMA
 #undef DCN_SB
-#undef DCN_KEEP_WEIGHTS
 #undef DCN_PHASE
 
     // accumulator tile mb: pixel m0 + 16 mb + l16, output channels (group grp) n0 + 16 wave + 4 g + (0..3)

@@ -21,7 +21,7 @@
 //               fragment read (16 consecutive rows, one chunk) and of a staging store (2 rows x 8 chunks) fall on 16 distinct
 //               16-byte slots.  2 x (48 + 64) x 128 B = 28 KB per workgroup, ~80 registers -> five workgroups per CU.
 //   pipeline    one register stage, two LDS buffers, one barrier per k-tile (the scheme of the five-per-CU 64x64 tile): tile
-//               t+1 is requested at the top of tile t's phase and written to the other buffer behind the first k-group.
+//               t+1 is requested at the top of tile t's phase and written to the other buffer behind three quarters of its MFMAs.
 //   epilogue    raw accumulators (the output transform kernel applies BN / residual / ReLU).
 //
 // Bound: MFMA f32 (157.3 TFLOP/s); executed work 2 x 36 x rows x cin x cout per launch.
@@ -114,27 +114,29 @@ __global__ __launch_bounds__(kThreads, 5) void gemm16_grouped_kernel(const G16Ar
         _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                 \
             FX[mb] = *reinterpret_cast<const f32x4 *>(Xs0 + (BUF) * kBuf + x_frag + mb * 16 * BK + (FO)); \
     } while (0)
-#define G16_MFMA(FW, FX)                                                                                  \
+#define G16_MFMA(FW, FX, J0, J1)                                                                          \
     do {                                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+        _Pragma("unroll") for (int j = (J0); j < (J1); ++j)                                               \
             _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                             \
                 acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(FW[j], FX[mb][j], acc[mb], 0, 0, 0);       \
     } while (0)
 #define G16_SB() __builtin_amdgcn_sched_barrier(0)
 #define G16_PHASE(BUF, HAVE_NEXT)                                                                         \
     do {                                                                                                  \
-        if constexpr (HAVE_NEXT) G16_LOAD();                                                              \
+        if constexpr (HAVE_NEXT) G16_LOAD();                                                                                       \
         G16_READ(fw1, fx1, BUF, fo1);                                                                     \
         G16_SB();                                                                                         \
-        G16_MFMA(fw0, fx0);                                                                               \
+        G16_MFMA(fw0, fx0, 0, 4);                                                                         \
         G16_SB();                                                                                         \
-        if constexpr (HAVE_NEXT) {                                                                        \
+        G16_MFMA(fw1, fx1, 0, 2);      /* (the tile requested above gets three quarters of the phase to arrive) */ \
+        G16_SB();                                                                                         \
+        if constexpr (HAVE_NEXT) {                                                                                            \
             G16_STORE((BUF) ^ 1);                                                                         \
             __syncthreads();                                                                              \
             G16_READ(fw0, fx0, (BUF) ^ 1, fo0);                                                           \
         }                                                                                                 \
         G16_SB();                                                                                         \
-        G16_MFMA(fw1, fx1);                                                                               \
+        G16_MFMA(fw1, fx1, 2, 4);                                                                         \
         G16_SB();                                                                                         \
     } while (0)
 

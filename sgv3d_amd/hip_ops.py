@@ -455,8 +455,20 @@ class PackedConv:
         ow = (w + 2 * self.pad - self.dil * (self.kw - 1) - 1) // self.stride + 1
         return oh, ow
 
-    def __call__(self, x, out=None, *, x_coff=0, y_coff=0, residual=None, gate=None, nchw_out=False, tile=None,
-                 group_planes=0, split_k=None, out_dtype=None):
+    def __call__(self, x, out=None, *, shift=None, **kw):
+        """``shift``: a per-call replacement of the layer's per-channel shift (f32 [cout] on the device) -- for a layer whose
+        bias depends on the input of THIS call (ASPP's pooled branch folded into the 1x1 convolution behind the concat)."""
+        if shift is None:
+            return self._call(x, out, **kw)
+        assert shift.dtype == torch.float32 and shift.numel() == self.cout and shift.is_contiguous() and shift.device == x.device
+        saved, self.shift = self.shift, shift
+        try:
+            return self._call(x, out, **kw)
+        finally:
+            self.shift = saved
+
+    def _call(self, x, out=None, *, x_coff=0, y_coff=0, residual=None, gate=None, nchw_out=False, tile=None,
+              group_planes=0, split_k=None, out_dtype=None):
         """x NHWC [B,H,W,x_ld]; reads channels [x_coff, x_coff+cin).  out NHWC [B,OH,OW,y_ld] written
         at channels [y_coff, y_coff+cout) (allocated [B,OH,OW,cout] if None).
         bf16 mode: ``x`` may be a bf16 tensor, and ``out_dtype=torch.bfloat16`` (or a bf16 ``out``) makes the layer write
@@ -907,7 +919,7 @@ def switch_state():
     g = globals()
     return tuple(g.get(k) for k in ("AUTOTUNE", "SPLIT_K", "WINOGRAD", "FUSED_HEAD", "HEAD_PATH", "MFMA_BF16", "BF16_ACTIVATIONS",
                                     "MFMA_F32X3", "MFIRST", "WINO4", "WINO_HALF", "PATCH_BF16", "DW_BF16", "DW_DEEP", "DW_NARROW",
-                                    "DW_SPLIT_K", "DW_DEEP_MAX_WGS", "PAIR_BF16", "TUNE_STREAMS", "PARALLEL_BRANCHES", "F4RES", "OCC5", "WINO4_G48"))
+                                    "DW_SPLIT_K", "DW_DEEP_MAX_WGS", "PAIR_BF16", "TUNE_STREAMS", "PARALLEL_BRANCHES", "F4RES", "OCC5", "WINO4_G48", "DCN_FUSED"))
 
 
 def conv_pair_eligible(a, b, x, residual=None):
@@ -1135,6 +1147,42 @@ def bsm_compose(height_context, semantic_logits, D, ctx, sem, thr):
                                           _st(height_context))
     _lib.check(rc, "sgv3d_bsm_compose")
     return height_context
+
+
+DCN_FUSED = _os.environ.get("SGV3D_DCN_FUSED", "1") != "0"     # 0: deformable im2col + one GEMM per group (rounds 1-4)
+
+
+def deform_conv3x3_eligible(x, convs):
+    """f32 NHWC input, packed group weights that share one geometry, channels per group a multiple of 32: what
+    sgv3d_deform_conv3x3_forward covers (bf16-activation mode keeps the im2col form)."""
+    cpg9 = convs[0].cin
+    return (DCN_FUSED and not MFMA_BF16 and not MFMA_F32X3 and x.dtype == torch.float32 and len(convs) <= 8 and cpg9 % 9 == 0
+            and (cpg9 // 9) % 32 == 0 and convs[0].cout % 4 == 0 and convs[0].k_order == 1
+            and all(c.cin == cpg9 and c.cout == convs[0].cout and c.k_pad == convs[0].k_pad and c.cout_pad == convs[0].cout_pad
+                    and c.scale is None and c.shift is None and not c.relu for c in convs))
+
+
+def deform_conv3x3(x, offset, convs, out=None, y_coff=0):
+    """DCNv1 forward (lss_fpn.py:190-198) in one launch: x f32 NHWC [B,H,W,C], offset f32 [B,H,W,>=18], ``convs`` the per-group
+    PackedConvs of the [opg, 9 * cpg] matrices (k = tap * cpg + ci).  Writes out[..., y_coff : y_coff + groups * opg]."""
+    import ctypes
+    B, H, W, C = (int(v) for v in x.shape)
+    g, opg = len(convs), convs[0].cout
+    assert x.is_contiguous() and offset.is_contiguous() and offset.dtype == torch.float32 and int(offset.shape[-1]) >= 18
+    if out is None:
+        out = torch.empty(B, H, W, g * opg, dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape[:3]) == (B, H, W)
+    ptrs = (ctypes.c_void_p * g)(*[c.w.data_ptr() for c in convs])
+    flops = 2.0 * B * H * W * g * opg * (convs[0].cin_real)
+    nbytes = 4.0 * (B * H * W * (C + 18 + g * opg) + g * opg * convs[0].cin_real)
+    with torch.cuda.device(x.device), prof("conv_dcn_fused", flops, nbytes,
+                                           {"symbol": "dcn3x3_fused_kernel", "mfma_flops": 2.0 * B * H * W * g * convs[0].cout * convs[0].cin}
+                                           if PROFILE is not None else None):
+        rc = _lib.load().sgv3d_deform_conv3x3_forward(B, H, W, C, g, opg, x.data_ptr(), offset.data_ptr(), int(offset.shape[-1]), ptrs,
+                                                     convs[0].k_pad, convs[0].cout_pad, out.data_ptr(), int(out.shape[-1]), int(y_coff),
+                                                     _st(x))
+    _lib.check(rc, "sgv3d_deform_conv3x3_forward")
+    return out
 
 
 def deform_im2col3x3(x, offset, groups, out=None):

@@ -32,6 +32,9 @@ import os as _os
 # 0: the height net's camera-aware SE gates (27 calibration numbers -> MLP -> sigmoid; no pixel enters) are recomputed on every
 # forward, as the reference does (lss_fpn.py:208-246); default: kept per calibration beside the voxel indices and the plan
 CACHE_CAMERA_GATES = _os.environ.get("SGV3D_CACHE_CAMERA_GATES", "1") != "0"
+# 0: ASPP's pooled branch is broadcast into the concat buffer and multiplied by conv1 like the other four (lss_fpn.py:101-108);
+# default (batch 1, f32): folded into conv1's per-image bias
+FOLD_ASPP_POOL = _os.environ.get("SGV3D_FOLD_ASPP_POOL", "1") != "0"
 FUSE_LIFT_SPLAT = _os.environ.get("SGV3D_FUSE_LIFT_SPLAT", "1") != "0"   # 0: lift kernel + voxel_pooling operator (the reference's two steps)
 
 __all__ = ['LSSFPN']
@@ -80,27 +83,45 @@ class ASPP(HipModule):
 
     def hip_compile(self, device):
         gscale, gshift = fold_bn(self.global_avg_pool[2])
-        return dict(
-            gap_w=self.global_avg_pool[1].weight.detach().reshape(self.mid_channels, -1).to(device).float().contiguous(),
+        mid = self.mid_channels
+        s = dict(
+            gap_w=self.global_avg_pool[1].weight.detach().reshape(mid, -1).to(device).float().contiguous(),
             gap_scale=gscale.to(device), gap_shift=gshift.to(device),
             conv1=conv_bn(self.conv1, self.bn1, True, device))
+        # Batch 1, f32: the pooled branch is ONE vector per image (bilinear upsampling of a 1x1 map is a constant, :101-104),
+        # so its share of conv1 (:106-108) is a per-image bias: conv1(cat)[co] = W[co, :4 mid] . cat4 + W[co, 4 mid:] . x5.
+        # conv1 then multiplies 4 mid input channels instead of 5 mid, and the broadcast of x5 into the concat buffer (10.6 MB at
+        # cfg-2) is not launched.  The bias is bn1_scale * (W[:, 4 mid:] x5) + bn1_shift, one dense launch.
+        w1 = self.conv1.weight.detach()
+        scale1, shift1 = fold_bn(self.bn1)
+        s['conv1_head'] = PackedConv(w1[:, :4 * mid].contiguous(), scale=scale1, shift=shift1, relu=True, device=device)
+        s['conv1_tail_w'] = w1[:, 4 * mid:].reshape(mid, mid).to(device).float().contiguous()
+        s['bn1_scale'], s['bn1_shift'] = scale1.to(device).float().contiguous(), shift1.to(device).float().contiguous()
+        return s
 
     def hip_forward(self, x):
         """The concat buffer and the output take the dtype of ``x`` (bf16 tensors in bf16-activation mode)."""
         s = self.hip_state(x.device)
         B, H, W, _ = x.shape
         mid = self.mid_channels
-        cat = torch.empty(B, H, W, 5 * mid, dtype=x.dtype, device=x.device)
+        fold = FOLD_ASPP_POOL and B == 1 and x.dtype == torch.float32 and not hip_ops.MFMA_BF16
+        cat = torch.empty(B, H, W, (4 if fold else 5) * mid, dtype=x.dtype, device=x.device)
+        folded = [None]
 
         def pooled_branch():                               # three tiny launches: beside the convolutions, not behind them
             pooled = hip_ops.global_avgpool(x)
             x5 = hip_ops.dense(pooled, s['gap_w'], s['gap_scale'], s['gap_shift'], hip_ops.ACT_RELU)
-            hip_ops.broadcast_channels(x5, cat, y_coff=4 * mid)
+            if fold:
+                folded[0] = hip_ops.dense(x5, s['conv1_tail_w'], s['bn1_scale'], s['bn1_shift'], hip_ops.ACT_NONE)
+            else:
+                hip_ops.broadcast_channels(x5, cat, y_coff=4 * mid)
 
         def conv_branches():
             for i, m in enumerate((self.aspp1, self.aspp2, self.aspp3, self.aspp4)):
                 m.hip_state(x.device)(x, cat, y_coff=i * mid)
         hip_ops.run_parallel(x.device, (conv_branches, pooled_branch))
+        if fold:
+            return s['conv1_head'](cat, shift=folded[0].view(-1), out_dtype=x.dtype)
         return s['conv1'](cat, out_dtype=x.dtype)          # Dropout(0.5) is the identity in eval mode (:111)
 
 
@@ -132,7 +153,8 @@ class SELayer(nn.Module):
 class DCN(HipModule):
     """mmcv 1.4.0 ``DeformConv2dPack`` as configured at lss_fpn.py:190-198 (3x3, pad 1, groups 4,
     deform_groups 1, no bias): ``conv_offset`` (zero-initialised 3x3 conv, 18 channels) predicts the
-    sampling offsets, then a deformable bilinear im2col feeds one grouped GEMM per group."""
+    sampling offsets; the deformable convolution itself is one implicit GEMM whose A operand is sampled on the fly
+    (``hip_ops.deform_conv3x3``; bf16-activation mode: a deformable bilinear im2col feeds one GEMM per group)."""
 
     def __init__(self, in_channels, out_channels, kernel_size=3, padding=1, groups=1, deform_groups=1,
                  stride=1, dilation=1, im2col_step=32, **unused):
@@ -160,6 +182,9 @@ class DCN(HipModule):
         s = self.hip_state(x.device)
         B, H, W, C = x.shape
         offset = s['offset'](x)                                     # [B,H,W,18], f32 whatever the dtype of x
+        if hip_ops.deform_conv3x3_eligible(x, s['convs']):
+            # one launch: the bilinear samples go straight into the GEMM's LDS stage (csrc/dcn_fused.hip), no column tensor
+            return hip_ops.deform_conv3x3(x, offset, s['convs'])
         col = hip_ops.deform_im2col3x3(x, offset, self.groups)      # [B,H,W,g*9*cpg], dtype of x
         out = torch.empty(B, H, W, self.out_channels, dtype=x.dtype, device=x.device)
         for gi, conv in enumerate(s['convs']):

@@ -319,3 +319,59 @@ def make_gt(batch, seed=0, n_range=(0, 40), num_labels=10, pc_range=(0, -51.2, 1
         boxes.append(torch.from_numpy(bx))
         labels.append(torch.from_numpy(lb))
     return boxes, labels
+
+
+def checkpoint_like_(model, seed=0):
+    """Weights shaped like a TRAINED checkpoint rather than a fresh initialisation, on top of
+    ``randomize_norm_stats_``:
+
+    * the last BatchNorm of every residual block: gamma drawn from U(0.05, 0.5) per channel -- mmdet zero-initialises it
+      (``zero_init_residual``) and training grows it to a fraction of 1;
+    * every (convolution, BatchNorm) pair: per-channel raw scales spread over FOUR decades -- ``running_var`` log-uniform in
+      [1e-2, 1e2] times its value, with the convolution's output-channel weights (and bias) and ``running_mean`` scaled by the
+      square root, as the statistics of a trained network follow the scale of the channel that produces them.  Mathematically the
+      network function is unchanged (BatchNorm divides the scale out again), so activations stay O(1-10) and an absolute parity bar
+      keeps its meaning; numerically the folded scales 1 / sqrt(var) now range over 0.1 .. 10 and the packed weights over the same
+      two decades, which default-initialised statistics (var ~ 1) never exercise.
+
+    Pairs are found by module order: a BatchNorm2d directly after a Conv2d / ConvTranspose2d with as many output channels."""
+    from .layers import blocks as _blocks
+    randomize_norm_stats_(model, seed)
+    g = torch.Generator().manual_seed(1000 + seed)
+    last_bn = set()
+    for m in model.modules():
+        if isinstance(m, _blocks.Bottleneck):
+            last_bn.add(m.bn3)
+        elif isinstance(m, _blocks.BasicBlock):
+            last_bn.add(m.bn2)
+    prev = None
+    pairs = 0
+    with torch.no_grad():
+        for name, m in model.named_modules():
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                prev = m
+            elif isinstance(m, torch.nn.BatchNorm2d):
+                if m in last_bn:
+                    m.weight.copy_(0.05 + 0.45 * torch.rand(m.num_features, generator=g))
+                    m.weight.mul_(torch.where(torch.rand(m.num_features, generator=g) < 0.5, -1.0, 1.0))
+                conv = prev
+                prev = None
+                if conv is None or conv.groups != 1:
+                    continue
+                transposed = isinstance(conv, torch.nn.ConvTranspose2d)
+                cout = conv.weight.shape[1] if transposed else conv.weight.shape[0]
+                if cout != m.num_features:
+                    continue
+                v = 10.0 ** (4.0 * torch.rand(cout, generator=g) - 2.0)          # log-uniform over [1e-2, 1e2]
+                r = v.sqrt()
+                conv.weight.mul_(r.view(1, -1, 1, 1) if transposed else r.view(-1, 1, 1, 1))
+                if conv.bias is not None:
+                    conv.bias.mul_(r)
+                m.running_mean.mul_(r)
+                m.running_var.mul_(v)
+                pairs += 1
+            elif not isinstance(m, (torch.nn.ReLU, torch.nn.Identity)) and len(list(m.children())) == 0:
+                prev = None          # something else between a convolution and a norm: not a pair
+    assert pairs > 20, pairs
+    return model
+

@@ -302,6 +302,48 @@ def test_deform_conv(hip):
             torch.testing.assert_close(ref, F.conv2d(x, weight, None, 1, 1, 1, groups), **TOL)
 
 
+@pytest.mark.parametrize("shape", [(2, 128, 9, 11, 4, 128), (1, 512, 54, 96, 4, 512), (1, 256, 13, 7, 2, 96), (3, 64, 5, 5, 2, 264)])
+def test_deform_conv_fused(hip, shape):
+    """sgv3d_deform_conv3x3_forward (csrc/dcn_fused.hip): the deformable 3x3 of lss_fpn.py:190-198 as one implicit GEMM with the
+    bilinear samples formed on the way into LDS -- against the float64 DCNv1 restatement and against the im2col + per-group
+    GEMM form it replaces (same samples, another k order: f32 rounding only).  Offsets up to +-2.5 pixels plus a few that throw
+    the sample far outside the image; zero offsets = the plain grouped convolution; pixel counts that are not multiples of the
+    64-row tile; an output written at a channel offset of a wider buffer; out-of-group channel counts above one 64-column tile."""
+    from sgv3d_amd.hip_ops import PackedConv, deform_conv3x3, deform_conv3x3_eligible, deform_im2col3x3
+    B, C, H, W, groups, cout = shape
+    g = torch.Generator().manual_seed(50 + C)
+    x = torch.randn(B, C, H, W, generator=g)
+    weight = torch.randn(cout, C // groups, 3, 3, generator=g) / (9 * C // groups) ** 0.5
+    cpg, opg = C // groups, cout // groups
+    convs = [PackedConv(weight[gi * opg:(gi + 1) * opg].permute(0, 2, 3, 1).reshape(opg, 9 * cpg, 1, 1).contiguous().to(DEV))
+             for gi in range(groups)]
+    xd = nhwc(x).to(DEV)
+    assert deform_conv3x3_eligible(xd, convs)
+    big = torch.randn(B, 18, H, W, generator=g) * 2.5
+    big[:, :, 0, 0] = 40.0                                      # far outside: zeros
+    big[:, :, H - 1, W - 1] = -40.0
+    for offs in (torch.zeros(B, 18, H, W), big):
+        od = nhwc(offs).to(DEV)
+        out = torch.full((B, H, W, cout + 12), 7.0, device=DEV)
+        deform_conv3x3(xd, od, convs, out=out, y_coff=8)
+        torch.cuda.synchronize()
+        assert float(out[..., :8].min()) == 7.0 and float(out[..., cout + 8:].min()) == 7.0          # neighbours untouched
+        got = out[..., 8:cout + 8]
+        ref = _deform_conv_ref(x, offs, weight, groups)
+        torch.testing.assert_close(nchw(got.cpu()), ref, **TOL)
+        if offs.abs().sum() == 0:
+            torch.testing.assert_close(ref, F.conv2d(x, weight, None, 1, 1, 1, groups), **TOL)
+        col = deform_im2col3x3(xd, od, groups)
+        old = torch.empty(B, H, W, cout, device=DEV)
+        for gi, conv in enumerate(convs):
+            conv(col, old, x_coff=gi * 9 * cpg, y_coff=gi * opg)
+        scale = float(ref.abs().max())
+        assert float((old - got).abs().max()) <= 2e-5 * max(1.0, scale)
+        again = torch.full_like(out, 7.0)
+        deform_conv3x3(xd, od, convs, out=again, y_coff=8)
+        assert torch.equal(out, again)                          # deterministic
+
+
 def test_head_final_conv(hip):
     from sgv3d_amd.hip_ops import head_final_conv
     g = torch.Generator().manual_seed(9)

@@ -172,6 +172,40 @@ def test_fp32_noise_regime_against_float64():
     assert e_hip <= 1e-3 * scale
 
 
+def test_checkpoint_like_weights_against_float64():
+    """cfg-2 at full size with weights shaped like a trained checkpoint (``synthetic.checkpoint_like_``:
+    small random last-BN gammas in every residual block, BatchNorm running_var spread over 1e-2 .. 1e2 with the producing
+    convolution's weights scaled along) instead of hand-shaped initial values.  Bars: the HIP outputs are as close to a float64
+    evaluation as the torch-CPU fp32 oracle is (within 2x) -- the relative bar that holds for any checkpoint -- AND, since these
+    activations stay O(1-10), within the north star's absolute 1e-3 of the fp32 oracle; voxel indices bit-exact."""
+    from sgv3d_amd.models.bev_height import BEVHeight
+    bc, hc = S.r50_256_conf()
+    torch.manual_seed(0)
+    m = BEVHeight(bc, hc).eval()
+    S.checkpoint_like_(m, 3)
+    var = torch.cat([b.running_var.flatten() for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d)])
+    assert float(var.min()) < 2e-2 and float(var.max()) > 50.0                     # four decades of channel scales
+    imgs, mats = S.make_images(1, bc['final_dim'], seed=11), S.make_mats(1)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    keep = {}
+    ref32 = TM.bevheight_forward(sd, bc, hc, imgs, mats, keep)
+    ref64 = TM.bevheight_forward_highprec(sd, bc, hc, imgs, mats, device=DEV)
+    m = m.to(DEV)
+    dmats = {k: v.to(DEV) for k, v in mats.items()}
+    with torch.no_grad():
+        preds = m(imgs.to(DEV), dmats)
+        geom, _ = m.backbone.calibration(dmats, 0)
+    assert np.array_equal(geom.cpu().numpy(), keep['geom_xyz'])
+    e_hip = max(float((preds[t][0][k].double() - ref64[t][0][k]).abs().max()) for t in range(6) for k in ref32[t][0])
+    e_cpu = max(float((ref32[t][0][k].double() - ref64[t][0][k].cpu()).abs().max()) for t in range(6) for k in ref32[t][0])
+    scale = max(float(ref64[t][0][k].abs().max()) for t in range(6) for k in ref32[t][0])
+    worst, _ = _errors(preds, ref32)
+    print(f"checkpoint-like weights: |hip - f64| = {e_hip:.3e}, |torch-cpu fp32 - f64| = {e_cpu:.3e}, |hip - oracle| = {worst:.3e}, "
+          f"output scale {scale:.2f}")
+    assert e_hip <= 2.0 * e_cpu + 1e-6 * scale
+    assert worst < 1e-3
+
+
 # bf16 tolerance.  Operands and (in bf16-activation mode) the tensors between the ResNet layers are rounded to bf16 (relative
 # 2^-9 = 2e-3) and accumulated in f32; over the K = 576..4608 terms of a layer the rounding errors average out (relative
 # error of a layer output ~ 2^-9, not K x 2^-9) and compound over the ~60-110 convolutions between image and prediction maps
