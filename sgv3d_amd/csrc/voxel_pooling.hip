@@ -1869,7 +1869,7 @@ namespace {
 
 int plan_build_impl(int batch_size, int num_points, int num_voxel_x, int num_voxel_y, int num_voxel_z,
                     const int32_t *geom_xyz, int32_t *pos_memo, void *plan, size_t plan_bytes, int sort_segments,
-                    bool cached, hipStream_t st, const char *what, bool compare_done = false, bool commit = true) {
+                    bool cached, hipStream_t st, const char *what, bool compare_done = false) {
     if (int rc = check_common(batch_size, num_points, 1, num_voxel_x, num_voxel_y, num_voxel_z)) return rc;
     SGV3D_REQUIRE(geom_xyz && plan, "%s: null pointer", what);
     SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15) == 0, "%s: plan must be 16-B aligned", what);
@@ -1925,7 +1925,7 @@ int plan_build_impl(int batch_size, int num_points, int num_voxel_x, int num_vox
         hipLaunchKernelGGL((vp_sort_segments_kernel<256, 8192>), dim3(g_large), dim3(256), 0, st, L.V, seg, order,
                            2048, 0x7fffffff, dirty);
     }
-    if (cached && commit)
+    if (cached)
         hipLaunchKernelGGL(vp_plan_commit_kernel, dim3(1), dim3(64), 0, st, hdr, p[0], p[1], p[2], p[3], p[4], p[5], p[6]);
     return check_launch(what);
 }
@@ -2084,8 +2084,6 @@ struct Level1Entry {
     bool pinned;             // recorded into a stream capture: a replayed graph reads and writes this plan, so it is never
                              // evicted and survives sgv3d_voxel_pooling_cache_clear (the graph may outlive any call we see)
     unsigned long long last_use;
-    hipStream_t side;        // stream captures only: the (gated) rebuild is recorded on this stream, as a branch of the graph
-    hipEvent_t ev[3];        // beside the gather -- fork, "fallback done", join
 };
 constexpr int kLevel1Max = 8;
 std::mutex g_l1_mutex;
@@ -2104,9 +2102,6 @@ void level1_free(Level1Entry &e) {
     hipSetDevice(e.dev);
     if (e.plan) hipFree(e.plan);
     if (e.host_flag) hipHostFree(e.host_flag);
-    if (e.side) hipStreamDestroy(e.side);
-    for (auto &v : e.ev)
-        if (v) hipEventDestroy(v);
     hipSetDevice(cur);
 }
 
@@ -2198,10 +2193,6 @@ int level1_forward(int batch_size, int num_points, int num_channels, int num_vox
         }
         *n.host_flag = 0;
         if (hipHostGetDevicePointer(reinterpret_cast<void **>(&n.flag_dev), n.host_flag, 0) != hipSuccess) n.flag_dev = nullptr;
-        // (for stream captures; without them a capture records the build in line, as round 4 did)
-        if (hipStreamCreateWithFlags(&n.side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); n.side = nullptr; }
-        for (auto &v : n.ev)
-            if (hipEventCreateWithFlags(&v, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); v = nullptr; }
         n.need_build = true;
         hipLaunchKernelGGL(vp_plan_init_kernel, dim3(1), dim3(kBlock), 0, st,
                            reinterpret_cast<PlanHeader *>(static_cast<char *>(n.plan) + L.off_hdr));
@@ -2227,34 +2218,9 @@ int level1_forward(int batch_size, int num_points, int num_channels, int num_vox
     else
         hipLaunchKernelGGL(vp_level1_prologue_kernel<false>, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, st, total, N, X, Y, Z,
                            geom_xyz, gcopy, pos_memo, hdr, flag_dev);
-    static const bool fork_env = [] { const char *v = getenv("SGV3D_VP_LEVEL1_FORK"); return !(v && v[0] == '0'); }();
-    if (capturing && fork_env && e->side && e->ev[0] && e->ev[1] && e->ev[2]) {
-        // What a stream capture records.  The rebuild is ~16 launches that leave at once while geom_xyz is the plan's -- in line
-        // they were 27 us of empty launches in front of a 26 us gather (59.8 us per replay at cfg-2, profiles/r04_gather_probe.txt).
-        // Here they are a BRANCH of the graph beside the gather: a replay whose geom_xyz is the plan's runs the gather while the
-        // empty launches drain on the other queue; one whose geom_xyz changed is served by the gated scatter (right for any
-        // geom_xyz) while the branch rebuilds the plan for the replays that follow.  The commit kernel lowers the dirty flag the
-        // scatter is gated on, so it waits for the scatter.
-        PlanHeader *h = hdr;
-        const int pm[7] = {kPlanMagic, B, N, X, Y, Z, 1};
-        if (hipEventRecord(e->ev[0], st) != hipSuccess || hipStreamWaitEvent(e->side, e->ev[0], 0) != hipSuccess)
-            return fail(SGV3D_ELAUNCH, "voxel_pooling_forward(level-1): cannot fork the capture");
-        if (int rc = plan_build_impl(B, N, X, Y, Z, geom_xyz, nullptr, e->plan, e->plan_bytes, 1, true, e->side,
-                                     "voxel_pooling_forward(level-1 plan, forked)", /*compare_done=*/true, /*commit=*/false)) return rc;
-        if (int rc = launch_gather<false, false, false, !FRESH>(B, N, C, X, Y, e->plan, input_features, nullptr, nullptr, 1,
-                                                                output_features, nullptr, 0, st, 0, &h->dirty, FRESH)) return rc;
-        const long long ablocks_ = cdiv(total, kAtomicPts);
-        hipLaunchKernelGGL(vp_atomic_gated_kernel, dim3((unsigned)(ablocks_ < 2048 ? ablocks_ : 2048)), dim3(kBlock), 0, st, total, N, C,
-                           X, Y, Z, geom_xyz, input_features, output_features, &h->dirty);
-        if (hipEventRecord(e->ev[1], st) != hipSuccess || hipStreamWaitEvent(e->side, e->ev[1], 0) != hipSuccess)
-            return fail(SGV3D_ELAUNCH, "voxel_pooling_forward(level-1): cannot order the commit behind the scatter");
-        hipLaunchKernelGGL(vp_plan_commit_kernel, dim3(1), dim3(64), 0, e->side, h, pm[0], pm[1], pm[2], pm[3], pm[4], pm[5], pm[6]);
-        if (hipEventRecord(e->ev[2], e->side) != hipSuccess || hipStreamWaitEvent(st, e->ev[2], 0) != hipSuccess)
-            return fail(SGV3D_ELAUNCH, "voxel_pooling_forward(level-1): cannot join the capture");
-        g_l1_stats[3]++;
-        g_l1_stats[1]++;
-        return check_launch("voxel_pooling_forward(level-1, captured)");
-    }
+    // (A stream capture records the gated build IN LINE: ~16 launches that leave at once while geom_xyz is the plan's, 27 us of a
+    //  59.8 us replay at cfg-2.  Recording them as a forked branch of the graph beside the gather -- built and measured in round 5
+    //  -- made a replay 75 us: the two cross-queue edges of a hipGraph cost more than the empty launches they hide.)
     if (e->need_build || capturing) {
         // gated build (its kernels return at once when the prologue found the plan up to date), then the gather on a plan
         // that is right either way.  Also the form a stream capture records: valid for whatever geom_xyz a replay sees.
