@@ -724,6 +724,15 @@ int sgv3d_centerhead_loss(int batch, int num_class, int h, int w, int max_objs, 
 size_t sgv3d_conv2d_backward_weight_workspace_bytes(const sgv3d_conv_desc *desc /*host*/, int split);
 int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *dy, float *dw,
                                  int split, void *workspace, size_t workspace_bytes, void *stream);
+/* The same weight gradient with the products on the bf16 matrix cores -- the mixed-precision training mode (the reference
+ * trains with --amp_backend native, docs/run_and_eval.md:5,16; BASELINE configs[4] names bf16): x, dy and dw stay f32 tensors,
+ * the operands are rounded to bf16 (nearest even) on their way into LDS, accumulation is f32 (v_mfma_f32_32x32x16_bf16), the
+ * pixel split and its fixed-order reduce are those of sgv3d_conv2d_backward_weight.  desc.tile: 0 = rule, 1 = 64 x 64,
+ * 4 = 128 x 128 (co x ci per workgroup).  Channel counts, strides and offsets % 4 == 0; x / dy 16-byte aligned. */
+size_t sgv3d_conv2d_backward_weight_bf16_workspace_bytes(const sgv3d_conv_desc *desc /*host*/, int split);
+int sgv3d_conv2d_backward_weight_bf16(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *dy, float *dw, int split,
+                                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* Batched form of the all-taps kernel (desc.tile 5 layers: 3x3 / stride 1 / dilation 1): n <= 48 weight gradients
  * dw_list[i] = wgrad(x, dy_list[i]) of layers that read the SAME input, in one launch (blockIdx.z = problem).  The 36 first layers of
  * the CenterHead branches (64 -> 64 at 256 x 256, layers/heads/bev_height_head.py:75-110 through mmdet3d SeparateHead) are one 64 x 64

@@ -17,7 +17,7 @@ import torch
 from . import _lib, grad_slots
 from .hip_ops import ConvDesc, PackedConv, prof, _st
 
-__all__ = ['conv2d_backward_weight', 'conv2d_backward_weight_batched', 'conv2d_backward_data', 'zero_insert', 'conv2d', 'conv_transpose2d',
+__all__ = ['conv2d_backward_weight', 'conv2d_backward_weight_bf16', 'conv2d_backward_weight_batched', 'conv2d_backward_data', 'zero_insert', 'conv2d', 'conv_transpose2d',
            'multi_conv2d']
 
 
@@ -58,13 +58,16 @@ def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, c
             rc = lib.sgv3d_conv2d_backward_weight_thin(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nws, _st(x))
         _lib.check(rc, "sgv3d_conv2d_backward_weight_thin")
         return dw
+    from . import hip_ops
+    if (hip_ops.MFMA_BF16 and hip_ops.TRAIN_BF16_WGRAD and not tile and not split and _bf16_wgrad_ok(x, dy, cin, cout, x_coff, y_coff)):
+        # bf16 compute mode (mixed-precision training): products on the bf16 matrix cores, f32 tensors and accumulation
+        return conv2d_backward_weight_bf16(x, dy, (kh, kw), stride, pad, dil, cin=cin, cout=cout, x_coff=x_coff, y_coff=y_coff, out=out)
     if not tile and not split:
         tile, split = _wgrad_choice(lib, d, x, dy)       # first-call measurement per layer shape (0, 0 = the library's rule)
         d.tile = int(tile)
     nws = lib.sgv3d_conv2d_backward_weight_workspace_bytes(ctypes.byref(d), int(split))
     ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
     dw = _dw_buffer(out, (cout, cin, kh, kw), x.device)
-    from . import hip_ops
     name = "conv_wgrad"
     if hip_ops.PROFILE_DETAIL:
         name += f"|{B}x{H}x{W}x{cin}->{cout} k{kh} s{stride} d{dil} tile{int(tile)} split{int(split)}"
@@ -72,6 +75,49 @@ def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, c
         rc = lib.sgv3d_conv2d_backward_weight(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(split),
                                               ws.data_ptr(), nws, _st(x))
     _lib.check(rc, "sgv3d_conv2d_backward_weight")
+    return dw
+
+
+def _bf16_wgrad_ok(x, dy, cin, cout, x_coff, y_coff):
+    x_ld, y_ld = int(x.shape[-1]), int(dy.shape[-1])
+    return (cin % 4 == 0 and cout % 4 == 0 and x_ld % 4 == 0 and y_ld % 4 == 0 and x_coff % 4 == 0 and y_coff % 4 == 0
+            and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and min(cin, cout) >= 16)
+
+
+def conv2d_backward_weight_bf16(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, cout=None, x_coff=0, y_coff=0, split=0, tile=0, out=None):
+    """``conv2d_backward_weight`` with the products on the bf16 matrix cores (sgv3d_conv2d_backward_weight_bf16): f32 tensors in
+    and out, operands rounded to bf16 while staging, f32 accumulation, fixed-order pixel-split reduce.  ``tile``: 0 = measured per
+    layer shape (first call) / the library's rule, 1 = 64 x 64, 4 = 128 x 128."""
+    from . import hip_ops
+    kh, kw = (kernel, kernel) if isinstance(kernel, int) else kernel
+    B, H, W, x_ld = (int(v) for v in x.shape)
+    _, OH, OW, y_ld = (int(v) for v in dy.shape)
+    cin = x_ld - x_coff if cin is None else int(cin)
+    cout = y_ld - y_coff if cout is None else int(cout)
+    assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype == torch.float32 and x.is_cuda
+    assert (OH, OW) == _out_hw(H, W, (kh, kw), stride, pad, dil) and int(dy.shape[0]) == B
+    if not _bf16_wgrad_ok(x, dy, cin, cout, x_coff, y_coff):
+        raise _lib.SGV3DError("the bf16 weight-gradient kernel needs channel counts, strides and offsets that are multiples of 4 "
+                              "(at least 16 channels on both sides) and 16-byte aligned tensors")
+    d = ConvDesc()
+    d.batch, d.in_h, d.in_w, d.cin, d.out_h, d.out_w, d.cout = B, H, W, cin, OH, OW, cout
+    d.kh, d.kw, d.stride, d.pad, d.dil = kh, kw, int(stride), int(pad), int(dil)
+    d.x_ld, d.x_coff, d.y_ld, d.y_coff = x_ld, int(x_coff), y_ld, int(y_coff)
+    d.tile = int(tile)
+    lib = _lib.load()
+    if not tile and not split:
+        tile, split = _wgrad_choice(lib, d, x, dy, bf16=True)
+        d.tile = int(tile)
+    nws = lib.sgv3d_conv2d_backward_weight_bf16_workspace_bytes(ctypes.byref(d), int(split))
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
+    dw = _dw_buffer(out, (cout, cin, kh, kw), x.device)
+    name = "conv_wgrad_bf16"
+    if hip_ops.PROFILE_DETAIL:
+        name += f"|{B}x{H}x{W}x{cin}->{cout} k{kh} s{stride} d{dil} tile{int(tile)} split{int(split)}"
+    with torch.cuda.device(x.device), prof(name, 2.0 * B * OH * OW * cout * cin * kh * kw):
+        rc = lib.sgv3d_conv2d_backward_weight_bf16(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(split),
+                                                   ws.data_ptr(), nws, _st(x))
+    _lib.check(rc, "sgv3d_conv2d_backward_weight_bf16")
     return dw
 
 
@@ -109,15 +155,18 @@ def conv2d_backward_weight_batched(x, dys, pad=1, *, cin=None, cout=None, split=
 _WGRAD_DB = {}
 
 
-def _wgrad_choice(lib, d, x, dy):
+def _wgrad_choice(lib, d, x, dy, bf16=False):
     """(tile, split) of the weight-gradient kernel for this layer shape: the library's rule and a handful of alternatives
     (the four tile shapes; half / twice / four times the rule's pixel split) timed once on the real tensors.  Every choice
-    sums each tile's pixel ranges in a fixed order, so results differ only by the association of that sum."""
+    sums each tile's pixel ranges in a fixed order, so results differ only by the association of that sum.  ``bf16``: the
+    bf16-MFMA kernel (tiles 1 = 64 x 64 and 4 = 128 x 128 only)."""
     from . import hip_ops
-    key = (d.batch, d.in_h, d.in_w, d.cin, d.out_h, d.out_w, d.cout, d.kh, d.kw, d.stride, d.pad, d.dil, d.x_ld, d.y_ld)
+    key = (d.batch, d.in_h, d.in_w, d.cin, d.out_h, d.out_w, d.cout, d.kh, d.kw, d.stride, d.pad, d.dil, d.x_ld, d.y_ld) + (("bf16",) if bf16 else ())
     if key in _WGRAD_DB:
         return _WGRAD_DB[key]
     sig = "wgrad|" + "x".join(str(v) for v in key)      # committed choices (tune/gfx950_*train*.json): no first-call timing, same kernels every run
+    ws_bytes = lib.sgv3d_conv2d_backward_weight_bf16_workspace_bytes if bf16 else lib.sgv3d_conv2d_backward_weight_workspace_bytes
+    launch = lib.sgv3d_conv2d_backward_weight_bf16 if bf16 else lib.sgv3d_conv2d_backward_weight
     if not hip_ops.AUTOTUNE:
         return 0, 0                                          # the library's own rule, whatever a tune DB holds
     if sig in hip_ops.TUNE_DB and not (sig in hip_ops._COMMITTED_SIGS and not hip_ops._is_gfx950(x.device)):
@@ -127,14 +176,14 @@ def _wgrad_choice(lib, d, x, dy):
         return 0, 0
     pixels = d.batch * d.out_h * d.out_w
     cands = [(0, 0)]
-    for t in (1, 2, 3, 4):
+    for t in ((1, 4) if bf16 else (1, 2, 3, 4)):
         tiles = -(-d.cout // (128 if t > 2 else 64)) * -(-d.cin // (128 if t in (2, 4) else 64)) * d.kh * d.kw
         base = max(1, min(max(256, min(1536, tiles * 64)) // max(tiles, 1), pixels // 256))
         for f in (0.5, 1, 2, 4):
             sp = int(max(1, min(base * f, pixels // 128)))
             if (t, sp) not in cands:
                 cands.append((t, sp))
-    if (d.kh == 3 and d.kw == 3 and d.stride == 1 and d.dil == 1 and d.cin % 4 == 0 and d.cout % 4 == 0 and d.x_coff % 4 == 0
+    if (not bf16 and d.kh == 3 and d.kw == 3 and d.stride == 1 and d.dil == 1 and d.cin % 4 == 0 and d.cout % 4 == 0 and d.x_coff % 4 == 0
             and d.y_coff % 4 == 0 and d.x_ld % 4 == 0 and d.y_ld % 4 == 0):
         # the all-taps kernel (tile 5): work units = (image, output row, 32-pixel segment); the rule's split and neighbours
         units = d.batch * d.out_h * -(-d.out_w // 32)
@@ -149,12 +198,11 @@ def _wgrad_choice(lib, d, x, dy):
     with torch.cuda.device(x.device):
         for t, sp in cands:
             d.tile = t
-            nws = lib.sgv3d_conv2d_backward_weight_workspace_bytes(ctypes.byref(d), sp)
+            nws = ws_bytes(ctypes.byref(d), sp)
             if nws > (2 << 30):
                 continue
             ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
-            run = lambda: lib.sgv3d_conv2d_backward_weight(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), sp,
-                                                           ws.data_ptr(), nws, _st(x))
+            run = lambda: launch(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), sp, ws.data_ptr(), nws, _st(x))
             if run() != 0:
                 continue
             nrep = max(3, hip_ops.TUNE_REPEATS + 1)

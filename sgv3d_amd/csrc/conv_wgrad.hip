@@ -486,6 +486,166 @@ __global__ __launch_bounds__(256) void interleave_phases_kernel(const PhaseArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// bf16 matrix cores (mixed-precision training, BASELINE configs[4]: "ResNet-101 bf16"; the reference trains with
+// --amp_backend native, docs/run_and_eval.md:5,16): the per-tap GEMM C[co][ci] = sum_p dY[p][co] X[p + tap][ci] on
+// v_mfma_f32_32x32x16_bf16 -- f32 tensors in HBM (master copies, gradients and activations stay f32), operands rounded to
+// bf16 (nearest even) on their way into LDS, f32 accumulation, the same partial-tile workspace and fixed-order reduce as the
+// f32 kernel.
+//
+// The reduction index (the pixel) is the SLOW axis of both operands in NHWC, and the MFMA wants 8 consecutive k per lane: the
+// transpose happens in registers while staging.  A thread owns a block of 8 pixels x 4 channels (eight 16-byte loads, one
+// pixel each), rounds it and stores it as four 16-byte rows of 8 pixels into an LDS image laid out [channel][64 pixels] -- the
+// operand layout: lane (m = l % 32, h = l / 32) reads pixels 16 ks + 8 h .. + 8 of channel row m with one ds_read_b128.
+// The 16-byte chunk c of row r sits at slot c ^ key(r), key(r) = ((r >> 2) & 7) ^ (((r >> 1) & 1) << 2): the eight lanes of a
+// store group (consecutive channel quads, one pixel group) and the sixteen lanes of a read group ({0-3, 12-15, 20-27} ...
+// of 32 consecutive rows, one chunk) fall on distinct 16-byte slots.
+//
+// Workgroup = 256 threads = 2 x 2 waves, tile (64 TM) co x (64 TN) ci of one tap, 64 pixels per stage (4 k-steps of 16), one
+// register stage + two LDS buffers.  128 x 128: 32 flop per byte loaded -- the f32 loads of 64 pixels x 256 channels per stage
+// are what bounds it (L2), not the MFMA pipe.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef float wf32x8 __attribute__((ext_vector_type(8)));
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradArgs a) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, STAGE = 64;
+    constexpr int NA = 8 * (BM / 4), NB_ = 8 * (BN / 4);                    // (8 pixels x 4 channels) blocks per stage
+    constexpr int B_OFF = (TM == 1 && TN == 1) ? 128 : 0;                   // 64 x 64: threads 0-127 stage dY, 128-255 stage X
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
+    int bid = blockIdx.x;
+    const int tci = bid % a.tiles_ci; bid /= a.tiles_ci;
+    const int tco = bid % a.tiles_co; bid /= a.tiles_co;
+    const int tap = bid;
+    const int th = tap / a.kw, tw = tap - th * a.kw;
+    const int co0 = tco * BM, ci0 = tci * BN;
+    const int pix_begin = blockIdx.y * a.pix_per_split;
+    const int pix_end = min(pix_begin + a.pix_per_split, a.pix_total);
+    const int hw = a.out_h * a.out_w;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)a.y_bytes, 0x00020000);
+
+    // staging blocks of this thread
+    const int ia = tid, ib = tid - B_OFF;
+    const bool has_a = ia < NA, has_b = ib >= 0 && ib < NB_;
+    const int a_pg = ia / (BM / 4), a_cq = ia % (BM / 4);
+    const int b_pg = has_b ? ib / (BN / 4) : 0, b_cq = has_b ? ib % (BN / 4) : 0;
+    // channel tails: whole float4s (cin / cout % 4 == 0 is required by the entry); a quad past the layer's channels reads zeros
+    const bool a_ch_ok = has_a && co0 + 4 * a_cq < a.cout, b_ch_ok = has_b && ci0 + 4 * b_cq < a.cin;
+    const unsigned y_c = (unsigned)(a.y_coff + co0 + 4 * a_cq) * 4u, x_c = (unsigned)(a.x_coff + ci0 + 4 * b_cq) * 4u;
+    // LDS store addresses (bytes inside a buffer): rows 4 cq + e, chunk pg at slot pg ^ key(row)
+    unsigned a_st[4], b_st[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        a_st[e] = (unsigned)((4 * a_cq + e) * 128 + ((a_pg ^ ((a_cq & 7) ^ ((e >> 1) << 2))) << 4));
+        b_st[e] = (unsigned)((4 * b_cq + e) * 128 + ((b_pg ^ ((b_cq & 7) ^ ((e >> 1) << 2))) << 4));
+    }
+    // fragment read offsets: row = wave offset + t * 32 + l32 (key depends on l32 only), chunk 2 ks + half
+    const int rkey = ((l32 >> 2) & 7) ^ (((l32 >> 1) & 1) << 2);
+    unsigned rd[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rd[ks] = (unsigned)(l32 * 128 + (((2 * ks + half) ^ rkey) << 4));
+    const unsigned a_row0 = (unsigned)(wm * (BM / 2) * 128), b_row0 = (unsigned)(wn * (BN / 2) * 128);
+
+    f32x4n ra[8], rb[8];
+    auto load_stage = [&](int p0) {
+        // dY: pixels p0 + 8 a_pg + j
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pix = p0 + 8 * a_pg + j;
+            const unsigned yo = (a_ch_ok && pix < pix_end) ? (unsigned)pix * (unsigned)(a.y_ld * 4) + y_c : 0xffffffffu;
+            ra[j] = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, yo, 0, 0));
+        }
+        // X: the tap's input pixel of output pixels p0 + 8 b_pg + j (one decode per block, then a walk along the row)
+        const int q0 = p0 + 8 * b_pg;
+        int img = q0 / hw;
+        int r = q0 - img * hw;
+        int oy = r / a.out_w;
+        int ox = r - oy * a.out_w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int iy = oy * a.stride - a.pad + th * a.dil, ix = ox * a.stride - a.pad + tw * a.dil;
+            const bool ok = b_ch_ok && q0 + j < pix_end && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
+            const unsigned xo = ok ? (unsigned)((img * a.in_h + iy) * a.in_w + ix) * (unsigned)(a.x_ld * 4) + x_c : 0xffffffffu;
+            rb[j] = __builtin_bit_cast(f32x4n, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xo, 0, 0));
+            if (++ox == a.out_w) { ox = 0; if (++oy == a.out_h) { oy = 0; ++img; } }
+        }
+    };
+    auto store_stage = [&](int buf) {
+        char *pa = reinterpret_cast<char *>(sA[buf]), *pb = reinterpret_cast<char *>(sB[buf]);
+        if (has_a) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const wf32x8 v = {ra[0][e], ra[1][e], ra[2][e], ra[3][e], ra[4][e], ra[5][e], ra[6][e], ra[7][e]};
+                *reinterpret_cast<wbf16x8 *>(pa + a_st[e]) = __builtin_convertvector(v, wbf16x8);
+            }
+        }
+        if (has_b) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const wf32x8 v = {rb[0][e], rb[1][e], rb[2][e], rb[3][e], rb[4][e], rb[5][e], rb[6][e], rb[7][e]};
+                *reinterpret_cast<wbf16x8 *>(pb + b_st[e]) = __builtin_convertvector(v, wbf16x8);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+    auto compute = [&](int buf) {
+        const char *pa = reinterpret_cast<const char *>(sA[buf]) + a_row0, *pb = reinterpret_cast<const char *>(sB[buf]) + b_row0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            wbf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) fa[m] = *reinterpret_cast<const wbf16x8 *>(pa + m * 32 * 128 + rd[ks]);
+#pragma unroll
+            for (int n = 0; n < TN; ++n) fb[n] = *reinterpret_cast<const wbf16x8 *>(pb + n * 32 * 128 + rd[ks]);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+        }
+    };
+
+    const int nst = (pix_end - pix_begin + STAGE - 1) / STAGE;
+    load_stage(pix_begin);
+    store_stage(0);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) load_stage(pix_begin + (st + 1) * STAGE);     // in flight under this stage's MFMAs
+        compute(buf);
+        if (st + 1 < nst) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // (the accumulator layout and the output / workspace layout of conv_wgrad_kernel)
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int ci = ci0 + wn * (BN / 2) + n * 32 + l32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wm * (BM / 2) + m * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
+                if (co >= a.cout || ci >= a.cin) continue;
+                if (a.split > 1)
+                    a.ws[(((size_t)blockIdx.y * a.taps + tap) * a.cout + co) * a.cin + ci] = acc[m][n][e];
+                else
+                    a.dw[((size_t)co * a.cin + ci) * a.taps + tap] = acc[m][n][e];
+            }
+        }
+}
+
 int fill_args(const sgv3d_conv_desc *d, int split, WgradArgs &a, int tile_override = 0) {
     SGV3D_REQUIRE(d, "conv2d_backward_weight: null descriptor");
     SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->out_h > 0 && d->out_w > 0,
@@ -595,6 +755,56 @@ extern "C" int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *d, const floa
     else if (a.wn == 2) conv_wgrad_kernel<1, 2><<<grid, 256, 0, st>>>(a);
     else conv_wgrad_kernel<1, 1><<<grid, 256, 0, st>>>(a);
     if (int rc = check_launch("conv_wgrad_kernel")) return rc;
+    if (a.split > 1) {
+        const long long total = (long long)a.taps * a.cout * a.cin;
+        wgrad_reduce_kernel<<<cdiv(total, 256), 256, 0, st>>>(a);
+        return check_launch("wgrad_reduce_kernel");
+    }
+    return SGV3D_OK;
+}
+
+// The same gradient with the products on the bf16 matrix cores (conv_wgrad_bf16_kernel: f32 tensors, operands rounded to bf16
+// while staging, f32 accumulation).  desc.tile: 0 = 128 x 128 where both channel counts exceed 64, else 64 x 64; 1 = 64 x 64;
+// 4 = 128 x 128.  Needs channel counts, strides and offsets that are multiples of 4 and 16-byte aligned tensors.  Workspace and
+// split as sgv3d_conv2d_backward_weight (sgv3d_conv2d_backward_weight_bf16_workspace_bytes).
+namespace {
+int fill_args_bf16(const sgv3d_conv_desc *d, int split, WgradArgs &a) {
+    SGV3D_REQUIRE(d, "conv2d_backward_weight_bf16: null descriptor");
+    const int t = d->tile == 0 ? ((d->cout > 64 && d->cin > 64) ? 4 : 1) : d->tile;
+    SGV3D_REQUIRE(t == 1 || t == 4, "conv2d_backward_weight_bf16: tile must be 0, 1 (64 x 64) or 4 (128 x 128), got %d", d->tile);
+    SGV3D_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && d->x_coff % 4 == 0 && d->y_coff % 4 == 0 && d->x_ld % 4 == 0 && d->y_ld % 4 == 0,
+                  "conv2d_backward_weight_bf16: channel counts, strides and offsets must be multiples of 4");
+    if (int rc = fill_args(d, split, a, t)) return rc;
+    if (a.tap_cols) {          // (the flat tap-channel columns of the image stem are an f32-kernel layout: per-tap tiles here)
+        a.tap_cols = 0;
+        a.wn = (t == 4) ? 2 : 1;
+        a.tiles_ci = cdiv(d->cin, 64 * a.wn);
+    }
+    return SGV3D_OK;
+}
+}  // namespace
+
+extern "C" size_t sgv3d_conv2d_backward_weight_bf16_workspace_bytes(const sgv3d_conv_desc *d, int split) {
+    WgradArgs a;
+    if (fill_args_bf16(d, split, a) != SGV3D_OK) return 0;
+    return a.split > 1 ? (size_t)a.split * a.taps * a.cout * a.cin * sizeof(float) : 0;
+}
+
+extern "C" int sgv3d_conv2d_backward_weight_bf16(const sgv3d_conv_desc *d, const float *x, const float *dy, float *dw, int split,
+                                                 void *workspace, size_t workspace_bytes, void *stream) {
+    WgradArgs a;
+    if (int rc = fill_args_bf16(d, split, a)) return rc;
+    SGV3D_REQUIRE(x && dy && dw, "conv2d_backward_weight_bf16: null pointer");
+    SGV3D_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv2d_backward_weight_bf16: x / dy must be 16-byte aligned");
+    const size_t need = a.split > 1 ? (size_t)a.split * a.taps * a.cout * a.cin * sizeof(float) : 0;
+    SGV3D_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "conv2d_backward_weight_bf16: workspace too small (%zu < %zu)",
+                  workspace_bytes, need);
+    a.x = x; a.dy = dy; a.dw = dw; a.ws = static_cast<float *>(workspace);
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(a.tiles_co * a.tiles_ci * a.taps, a.split);
+    if (a.wm == 2 && a.wn == 2) conv_wgrad_bf16_kernel<2, 2><<<grid, 256, 0, st>>>(a);
+    else conv_wgrad_bf16_kernel<1, 1><<<grid, 256, 0, st>>>(a);
+    if (int rc = check_launch("conv_wgrad_bf16_kernel")) return rc;
     if (a.split > 1) {
         const long long total = (long long)a.taps * a.cout * a.cin;
         wgrad_reduce_kernel<<<cdiv(total, 256), 256, 0, st>>>(a);

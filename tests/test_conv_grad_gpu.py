@@ -102,6 +102,47 @@ def test_wgrad_all_taps_kernel(shape, split):
     assert torch.equal(conv_grad.conv2d_backward_weight(xi.cuda(), dyi.cuda(), 3, 1, pad, 1, split=split, tile=5).cpu().double(), want)
 
 
+@pytest.mark.parametrize("shape", [
+    # B, cin, H, W, cout, k, stride, pad, dil
+    (2, 64, 20, 28, 64, 3, 1, 1, 1),          # one 64 x 64 tile per tap
+    (1, 256, 18, 26, 512, 1, 2, 0, 1),        # 1x1 stride 2, several 128 x 128 tiles
+    (2, 128, 21, 27, 128, 3, 2, 1, 1),        # strided 3x3, odd sizes
+    (1, 128, 20, 24, 128, 3, 1, 6, 6),        # dilated: taps far outside the image
+    (2, 80, 16, 16, 160, 3, 1, 1, 1),         # channel counts that are not multiples of 64
+    (1, 80, 30, 34, 160, 7, 2, 3, 1),         # 7x7 stride 2 (the f32 kernel's flat tap columns do not exist here)
+    (3, 32, 9, 11, 48, 3, 1, 1, 1),           # tiny, several images, ragged last stage
+    (1, 512, 27, 48, 512, 3, 1, 1, 1),        # HeightNet-like at half size
+])
+@pytest.mark.parametrize("tile,split", [(1, 1), (1, 3), (4, 1), (4, 5), (0, 0)])
+def test_wgrad_bf16_kernel(shape, tile, split):
+    """sgv3d_conv2d_backward_weight_bf16 (mixed-precision training): f32 tensors, products of bf16-rounded operands on
+    v_mfma_f32_32x32x16_bf16, f32 accumulation.  Against the float64 gradient of the ROUNDED operands: 2e-5 (summation order only);
+    against the unrounded gradient: 1e-2 of its scale (two roundings of 2^-9 each, averaged over the pixel sum); exact on small
+    integers; bitwise repeatable; channel windows of wider buffers."""
+    B, cin, H, W, cout, k, s, p, d = shape
+    g = torch.Generator().manual_seed(sum(shape) + 7 * tile + split)
+    x = torch.randn(B, H, W, cin + 8, generator=g)
+    oh = (H + 2 * p - d * (k - 1) - 1) // s + 1
+    ow = (W + 2 * p - d * (k - 1) - 1) // s + 1
+    dy = torch.randn(B, oh, ow, cout + 4, generator=g)
+    xs, dys = x[..., 4:4 + cin], dy[..., 4:]
+    zero_w = torch.zeros(cout, cin, k, k)
+    _, _, dw_exact = _reference(xs, zero_w, dys, s, p, d)
+    _, _, dw_rounded = _reference(xs.bfloat16().float(), zero_w, dys.bfloat16().float(), s, p, d)
+    run = lambda: conv_grad.conv2d_backward_weight_bf16(x.cuda(), dy.cuda(), k, s, p, d, cin=cin, cout=cout, x_coff=4, y_coff=4,
+                                                        split=split, tile=tile)
+    dw = run()
+    scale = float(dw_exact.abs().max())
+    assert float((dw.cpu().double() - dw_rounded).abs().max()) <= 2e-5 * scale
+    assert float((dw.cpu().double() - dw_exact).abs().max()) <= 1e-2 * scale
+    assert torch.equal(dw, run())
+    xi = torch.randint(-3, 4, (B, H, W, cin), generator=g).float()
+    dyi = torch.randint(-2, 3, (B, oh, ow, cout), generator=g).float()
+    _, _, dwi = _reference(xi, zero_w, dyi, s, p, d)
+    got = conv_grad.conv2d_backward_weight_bf16(xi.cuda(), dyi.cuda(), k, s, p, d, split=split, tile=tile)
+    assert torch.equal(got.cpu().double(), dwi)
+
+
 def test_wgrad_all_taps_kernel_rejects_other_layers():
     from sgv3d_amd import _lib
     x, dy = torch.randn(1, 8, 8, 64).cuda(), torch.randn(1, 4, 4, 64).cuda()

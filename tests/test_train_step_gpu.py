@@ -185,6 +185,28 @@ def test_cfg4_share_training_step_through_one_rank_rccl():
           f"all-reduced in {dist['allreduce_buckets']} buckets; without a process group {plain['ms_per_step']:.1f} ms")
 
 
+def test_cfg4_share_mixed_precision_step_through_one_rank_rccl():
+    """The same per-GPU share of BASELINE configs[3] as a MIXED-PRECISION step (``--dtype bf16``: every convolution product --
+    forward, data gradient, weight gradient -- on the bf16 matrix cores, f32 master weights / gradients / AdamW; the reference's
+    documented training command uses --amp_backend native, docs/run_and_eval.md:5,16): through the 1-rank RCCL group, finite,
+    and within 2 % of the f32 step's loss after the same three steps on the same data."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("SGV3D_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    base["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env = dict(base, SGV3D_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29536")
+    cmd = [sys.executable, os.path.join(root, "tools", "train_bench.py"), "--config", "cfg4", "--steps", "2", "--warmup", "1"]
+    mixed = _run_json(cmd + ["--dtype", "bf16"], env)
+    assert mixed["dtype"] == "bf16" and mixed["backend"] == "nccl" and mixed["collectives_active"] is True and mixed["batch_per_gpu"] == 4
+    assert mixed["allreduces_launched_inside_backward"] == mixed["allreduce_buckets"] >= 1
+    plain = _run_json(cmd, env)
+    assert plain["dtype"] == "f32"
+    assert mixed["loss"] == mixed["loss"] and abs(mixed["loss"] - plain["loss"]) <= 2e-2 * abs(plain["loss"]), (mixed["loss"], plain["loss"])
+    print(f"cfg-4 share, mixed precision: {mixed['ms_per_step']:.1f} ms / step against {plain['ms_per_step']:.1f} ms with f32 products "
+          f"(loss {mixed['loss']:.3f} / {plain['loss']:.3f})")
+
+
 def test_cfg5_share_training_step_through_one_rank_rccl():
     """BASELINE configs[4] (SGV3D full config: BSM R101 with the BEV-segmentation branch and the SAM-mask focal supervision,
     exps/sgv3d/bsm_bev_height_lss_r101_864_1536_256x256.py:295-335, on 8 MI355X): its per-GPU share at FULL size --

@@ -20,10 +20,16 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg4", "cfg5", "small"],
                 help="cfg4 = the cfg-2 model at BASELINE configs[3]'s per-GPU share (batch 4 per rank, global batch 4 x ranks)")
+ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                help="bf16 = mixed-precision step: every convolution product (forward, data gradient, weight gradient) on the bf16 matrix "
+                     "cores with f32 accumulation; parameters, gradients, activations, BatchNorm, loss and AdamW stay f32")
 ap.add_argument("--no-overlap", action="store_true", help="all-reduce after backward instead of from grad hooks")
 ap.add_argument("--profile", action="store_true", help="per-kernel-family times of one step (HIP events, eager)")
 args = ap.parse_args()
 
+if args.dtype == "bf16":
+    hip_ops.MFMA_BF16 = True
+    hip_ops.BF16_ACTIVATIONS = False        # f32 tensors between the layers (the training kernels' contract); bf16 operands only
 local = int(os.environ.get("LOCAL_RANK", "0"))
 dev = torch.device("cuda", local)
 torch.cuda.set_device(dev)
@@ -81,7 +87,7 @@ torch.cuda.synchronize()
 elapsed = group.timed(step, args.steps)
 out = {"metric": "training samples/s (forward + loss + backward + all-reduce + AdamW)", "value": group.world * args.batch * args.steps / elapsed,
        "unit": "samples/s", "n_gpus": group.world, "steps": args.steps, "ms_per_step": 1e3 * elapsed / args.steps,
-       "batch_per_gpu": args.batch, "global_batch": args.batch * group.world,
+       "batch_per_gpu": args.batch, "global_batch": args.batch * group.world, "dtype": args.dtype,
        "world_size": group.dist.get_world_size() if group.dist is not None else 1, "backend": group.backend,
        "allreduce_bytes_per_step": 4 * sum(g.numel() for _, g, _ in opt.flat.buckets), "allreduce_buckets": len(opt.flat.buckets),
        "allreduce_overlapped_with_backward": not args.no_overlap, "parameters": nparam, "loss": float(loss.detach()), "config": args.config,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch table of one cfg-2 training step (forward + loss + backward; HIP events around every library launch, eager):
-which layers the weight-gradient / data-gradient / BatchNorm time goes to.  BATCH=2 by default."""
+which layers the weight-gradient / data-gradient / BatchNorm time goes to.  BATCH=2 by default; DTYPE=bf16: the mixed-precision step."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,6 +8,8 @@ from sgv3d_amd import hip_ops, synthetic
 from sgv3d_amd.models.bev_height import BEVHeight
 
 batch = int(os.environ.get("BATCH", "2"))
+if os.environ.get("DTYPE", "f32") == "bf16":          # the mixed-precision step (tools/train_bench.py --dtype bf16)
+    hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS = True, False
 dev = torch.device("cuda", 0)
 bconf, hconf = synthetic.r50_256_conf()
 torch.manual_seed(0)
