@@ -21,6 +21,8 @@ def test_committed_tune_dbs_name_known_tiles():
                 assert t in (100, 101, 102), (f, sig, choice)            # fused F(2x2) / two kernels / fused F(4x4)
             elif sig.startswith("wgrad|"):
                 assert t >= 0 and s >= 0, (f, sig, choice)               # weight-gradient (tile, pixel split); 0 = the kernel's own rule
+                if sig.endswith("xbf16"):
+                    assert t in (0, 1, 4), (f, sig, choice)              # the bf16 weight-gradient kernel has the 64x64 and 128x128 tiles
             elif sig.startswith("pair|"):
                 assert t in (0, 1), (f, sig, choice)                     # fused conv2 + conv3 launch or not
             else:
@@ -28,7 +30,7 @@ def test_committed_tune_dbs_name_known_tiles():
                 if "bf16" not in sig:
                     assert t < 30 or t >= 40, (f, sig, choice)           # 31..39 are bf16-only kernels
                 else:
-                    assert t not in (40, 44, 45, 46) and t not in (5, 6, 8, 9, 10, 15), (f, sig, choice)   # f32-only algorithms
+                    assert t not in (40, 44, 45, 46, 47) and t not in (5, 6, 8, 9, 10, 15), (f, sig, choice)   # f32-only algorithms
 
 
 def test_every_candidate_tile_has_a_name():

@@ -13,6 +13,11 @@ SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2_train.json python3 tools/train_bench.py --batc
 echo "train b2 rc=$?"
 SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2_train.json python3 tools/train_bench.py --batch 4 --steps 3 > $OUT/train_b4.json 2> $OUT/train_b4.err
 echo "train b4 rc=$?"
+# ... and the mixed-precision step (bf16 products: "|bf16" forward / data-gradient signatures, "wgrad|...xbf16" weight gradients)
+SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2_train.json python3 tools/train_bench.py --batch 2 --steps 3 --dtype bf16 > $OUT/train_b2_bf16.json 2> $OUT/train_b2_bf16.err
+echo "train b2 bf16 rc=$?"
+SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2_train.json python3 tools/train_bench.py --batch 4 --steps 3 --dtype bf16 > $OUT/train_b4_bf16.json 2> $OUT/train_b4_bf16.err
+echo "train b4 bf16 rc=$?"
 mv $OUT/hide/gfx950_cfg2_train.json tune/ 2>/dev/null
 python3 - <<PY
 import json, glob
