@@ -332,7 +332,7 @@ def test_camera_gates_are_cached_per_calibration_and_equal_the_per_frame_ones(hi
             again = model(img, m)
             second = [r[0] for r in hip_ops.PROFILE]
             hip_ops.PROFILE = None
-            assert first.count("dense") >= 8 and second.count("dense") <= 1      # the gate MLPs ran once per calibration
+            assert first.count("dense") >= 10 and second.count("dense") <= 2     # the 8 gate launches ran once per calibration (2 left: ASPP pooled branch)
             _assert_same(out, again)
             fresh = bb.height_net.camera_gates(m, img.device)
             for a, b in zip(bb.calib_cache.entry(0).gates, fresh):
