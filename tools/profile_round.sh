@@ -9,7 +9,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 # the small summaries tools/summarize_profiles.py makes of it go to gpurun_out/profiles_<tag>/ and from there, by hand, to profiles/
 OUT=/tmp/sgv3d_profiles_$TAG
 KEEP=$R/gpurun_out/profiles_$TAG
-rm -rf $OUT; mkdir -p $OUT $KEEP
+PARTS=${PARTS:-ab}      # a = bench line, kernel traces, PMC passes (steps 1-3b); b = voxel pooling, harness, gather probe (4-6); the
+                        # summaries are made at the end of every call from whatever raw files are there (gpurun calls are <= 20 min)
+if [[ $PARTS == *a* ]]; then rm -rf $OUT; fi
+mkdir -p $OUT $KEEP
+if [[ $PARTS == *a* ]]; then
 export TMPDIR=/tmp
 cd /tmp
 # (tile / split-K choices come from the committed tune DB, tune/gfx950_*.json: every run below makes the same ones)
@@ -39,6 +43,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_
 # 3b. MFMA utilisation counters (own pass; SQ counters fit one pass)
 echo "[profile_round] $(date +%H:%M:%S) 3b. MFMA utilisation counters (own pass; SQ counters fit o" | tee -a $KEEP/progress.log
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_mfma -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs --no-harness --streams 1 > /dev/null 2> $OUT/pmc_mfma.err
+fi
+if [[ $PARTS == *b* ]]; then
 # 4. voxel pooling micro-benchmark (the HBM-bound headline kernel) + its trace and traffic
 echo "[profile_round] $(date +%H:%M:%S) 4. voxel pooling micro-benchmark (the HBM-bound headline k" | tee -a $KEEP/progress.log
 python3 $R/tools/microbench.py --what vp,lift --out $OUT/${TAG}_voxel_pooling_microbench.json > $OUT/microbench.log 2>&1
@@ -53,6 +59,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_harness -
 echo "[profile_round] $(date +%H:%M:%S) 6. the gather kernels side by side (voxel-owner / slot-bal" | tee -a $KEEP/progress.log
 python3 $R/tools/vp_probe3.py > $OUT/${TAG}_gather_probe.txt 2> $OUT/gather_probe.err
 SGV3D_VP_KERNEL=slot python3 $R/tools/vp_probe3.py >> $OUT/${TAG}_gather_probe.txt 2>> $OUT/gather_probe.err
+fi
 ls -la $OUT | head -60
 python3 $R/tools/summarize_profiles.py $OUT $TAG $KEEP > $KEEP/summarize.log 2>&1
 cp $OUT/*.err $KEEP/ 2>/dev/null

@@ -1,14 +1,28 @@
 #!/bin/bash
-# rocprof kernel summary of the cfg-2 training step (tools/train_bench.py), copied to profiles/ afterwards
-set -e
-TAG=${1:-r03}
-OUT=$PWD/gpurun_out/profiles_${TAG}_train
+# Profiles of the cfg-2 training step (tools/train_bench.py), f32 and mixed precision (--dtype bf16): bench lines with per-kernel-family
+# times, per-layer tables, rocprofv3 kernel summaries.  Run through gpurun; copy what should be judged from
+# gpurun_out/profiles_<tag>_train/ to profiles/.      bash tools/profile_train.sh r05
+set -u
+TAG=${1:-r05}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profiles_${TAG}_train
 mkdir -p $OUT
-export SGV3D_TUNE_CACHE=$OUT/train_tune_cache.json   # the profiled run replays the choices of the first run (training shapes are not in tune/)
-python tools/train_bench.py --batch 2 --steps 5 --warmup 2 --profile > $OUT/train_bench.json 2> $OUT/train_bench.err
-python tools/train_bench.py --batch 4 --steps 5 --warmup 2 > $OUT/train_bench_b4.json 2> $OUT/train_bench_b4.err
-python tools/train_bench.py --config cfg5 --batch 2 --steps 3 --warmup 2 --profile > $OUT/train_bench_cfg5_b2.json 2> $OUT/train_bench_cfg5_b2.err || true
-REPO=$PWD
+cd $R
+# (per-layer choices come from the committed tune/gfx950_cfg2_train.json: every run below makes the same ones)
+for dt in f32 bf16; do
+  for b in 2 4; do
+    python3 tools/train_bench.py --batch $b --steps 5 --warmup 3 --dtype $dt --profile > $OUT/${TAG}_train_bench_b${b}_${dt}.json 2> $OUT/train_b${b}_${dt}.err
+    echo "train b$b $dt rc=$? $(python3 -c "import json; d=json.loads(open('$OUT/${TAG}_train_bench_b${b}_${dt}.json').read().strip().splitlines()[-1]); print(round(d['ms_per_step'],1), 'ms')")"
+  done
+  DTYPE=$dt TOP=60 python3 tools/train_layer_report.py > $OUT/${TAG}_train_layers_b2_${dt}.txt 2> $OUT/layers_${dt}.err
+done
+python3 tools/train_bench.py --config cfg5 --batch 2 --steps 3 --warmup 2 --profile > $OUT/${TAG}_train_bench_cfg5_b2_f32.json 2> $OUT/train_cfg5.err
+echo "cfg5 b2 rc=$?"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof -o train -- python3 $REPO/tools/train_bench.py --batch 2 --steps 3 --warmup 1 > $OUT/train_under_rocprof.json 2> $OUT/rocprof.err || true
-find $OUT -name "*kernel_stats.csv" | head
+for dt in f32 bf16; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_$dt -o train -- python3 $R/tools/train_bench.py --batch 2 --steps 3 --warmup 2 --dtype $dt > $OUT/train_under_rocprof_$dt.json 2> $OUT/rocprof_$dt.err
+  f=$(find $OUT/rocprof_$dt -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $OUT/${TAG}_train_kernel_stats_${dt}.csv
+  rm -rf $OUT/rocprof_$dt
+done
+ls -la $OUT

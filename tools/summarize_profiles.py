@@ -69,7 +69,7 @@ if os.path.exists(mfma_csv):
     seen = collections.defaultdict(set)
     for r in csv.DictReader(open(mfma_csv)):
         k = short(r["Kernel_Name"])
-        if not k.startswith(("conv_", "head_wino4_kernel", "head_bf16")):      # the MFMA kernels
+        if not k.startswith(("conv_", "head_wino4_kernel", "head_bf16", "gemm16_grouped", "dcn3x3")):      # the MFMA kernels
             continue
         per[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Dispatch_Id"] not in seen[k]:
