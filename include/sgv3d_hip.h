@@ -732,6 +732,11 @@ int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *desc /*host*/, const flo
 size_t sgv3d_conv2d_backward_weight_bf16_workspace_bytes(const sgv3d_conv_desc *desc /*host*/, int split);
 int sgv3d_conv2d_backward_weight_bf16(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *dy, float *dw, int split,
                                       void *workspace, size_t workspace_bytes, void *stream);
+/* ... and its batched form (n layers that read the same x, as sgv3d_conv2d_backward_weight_batched). */
+size_t sgv3d_conv2d_backward_weight_bf16_batched_workspace_bytes(const sgv3d_conv_desc *desc /*host*/, int n, int split);
+int sgv3d_conv2d_backward_weight_bf16_batched(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *const *dy_list /*host*/,
+                                              float *const *dw_list /*host*/, int n, int split, void *workspace,
+                                              size_t workspace_bytes, void *stream);
 
 /* Batched form of the all-taps kernel (desc.tile 5 layers: 3x3 / stride 1 / dilation 1): n <= 48 weight gradients
  * dw_list[i] = wgrad(x, dy_list[i]) of layers that read the SAME input, in one launch (blockIdx.z = problem).  The 36 first layers of

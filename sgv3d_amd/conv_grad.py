@@ -135,12 +135,28 @@ def conv2d_backward_weight_batched(x, dys, pad=1, *, cin=None, cout=None, split=
     d.batch, d.in_h, d.in_w, d.cin, d.out_h, d.out_w, d.cout = B, H, W, cin, OH, OW, cout
     d.kh, d.kw, d.stride, d.pad, d.dil = 3, 3, 1, int(pad), 1
     d.x_ld, d.x_coff, d.y_ld, d.y_coff = x_ld, 0, y_ld, 0
+    from . import hip_ops
+    lib = _lib.load()
+    if (hip_ops.MFMA_BF16 and hip_ops.TRAIN_BF16_WGRAD and not split and _bf16_wgrad_ok(x, dys[0], cin, cout, 0, 0)
+            and all(t.data_ptr() % 16 == 0 for t in dys)):
+        # mixed-precision step: the same n gradients on the bf16 matrix cores, one launch (blockIdx.z = problem)
+        d.tile = 0
+        tiles = -(-cout // 64) * -(-cin // 64) * 9 * n
+        sp = max(1, min(-(-1024 // tiles), (B * OH * OW) // 256))
+        nws = lib.sgv3d_conv2d_backward_weight_bf16_batched_workspace_bytes(ctypes.byref(d), n, int(sp))
+        ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
+        dws = [_dw_buffer(None if outs is None else outs[i], (cout, cin, 3, 3), x.device) for i in range(n)]
+        dyp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dys])
+        dwp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dws])
+        with torch.cuda.device(x.device), prof("conv_wgrad_bf16", 2.0 * n * B * OH * OW * cout * cin * 9):
+            rc = lib.sgv3d_conv2d_backward_weight_bf16_batched(ctypes.byref(d), x.data_ptr(), dyp, dwp, n, int(sp), ws.data_ptr(), nws, _st(x))
+        _lib.check(rc, "sgv3d_conv2d_backward_weight_bf16_batched")
+        return dws
     d.tile = 5
     if not split:                       # ~3 workgroups per CU over all problems, at least four row segments per workgroup
         units = B * OH * -(-OW // 32)
         tiles = -(-cout // 64) * -(-cin // 64) * n
         split = max(1, min(-(-768 // tiles), units // 4))
-    lib = _lib.load()
     nws = lib.sgv3d_conv2d_backward_weight_batched_workspace_bytes(ctypes.byref(d), n, int(split))
     ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
     dws = [_dw_buffer(None if outs is None else outs[i], (cout, cin, 3, 3), x.device) for i in range(n)]

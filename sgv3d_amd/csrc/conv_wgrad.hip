@@ -526,7 +526,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradArgs
     const int pix_end = min(pix_begin + a.pix_per_split, a.pix_total);
     const int hw = a.out_h * a.out_w;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)a.y_bytes, 0x00020000);
+    // (batched form, blockIdx.z = problem: several dY / dW pairs against ONE x, as conv_wgrad3x3_kernel)
+    const float *const dyp = a.nbatch ? a.dy_list[blockIdx.z] : a.dy;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dyp, 0, (int)a.y_bytes, 0x00020000);
 
     // staging blocks of this thread
     const int ia = tid, ib = tid - B_OFF;
@@ -639,9 +641,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradArgs
                 const int co = co0 + wm * (BM / 2) + m * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
                 if (co >= a.cout || ci >= a.cin) continue;
                 if (a.split > 1)
-                    a.ws[(((size_t)blockIdx.y * a.taps + tap) * a.cout + co) * a.cin + ci] = acc[m][n][e];
+                    a.ws[((((size_t)blockIdx.z * a.split + blockIdx.y) * a.taps + tap) * a.cout + co) * a.cin + ci] = acc[m][n][e];
                 else
-                    a.dw[((size_t)co * a.cin + ci) * a.taps + tap] = acc[m][n][e];
+                    (a.nbatch ? a.dw_list[blockIdx.z] : a.dw)[((size_t)co * a.cin + ci) * a.taps + tap] = acc[m][n][e];
             }
         }
 }
@@ -808,6 +810,44 @@ extern "C" int sgv3d_conv2d_backward_weight_bf16(const sgv3d_conv_desc *d, const
     if (a.split > 1) {
         const long long total = (long long)a.taps * a.cout * a.cin;
         wgrad_reduce_kernel<<<cdiv(total, 256), 256, 0, st>>>(a);
+        return check_launch("wgrad_reduce_kernel");
+    }
+    return SGV3D_OK;
+}
+
+// Batched form: n weight gradients dw_list[i] = wgrad(x, dy_list[i]) of n layers that read the SAME input (desc describes one of
+// them), one launch (blockIdx.z = problem) -- the 36 first layers of the CenterHead branches in the mixed-precision step.
+extern "C" size_t sgv3d_conv2d_backward_weight_bf16_batched_workspace_bytes(const sgv3d_conv_desc *d, int n, int split) {
+    WgradArgs a;
+    if (!d || n <= 0 || fill_args_bf16(d, split, a) != SGV3D_OK) return 0;
+    return a.split > 1 ? (size_t)n * a.split * a.taps * a.cout * a.cin * sizeof(float) : 0;
+}
+
+extern "C" int sgv3d_conv2d_backward_weight_bf16_batched(const sgv3d_conv_desc *d, const float *x, const float *const *dy_list,
+                                                         float *const *dw_list, int n, int split, void *workspace,
+                                                         size_t workspace_bytes, void *stream) {
+    SGV3D_REQUIRE(d && x && dy_list && dw_list && n > 0 && n <= 48, "conv2d_backward_weight_bf16_batched: 1 .. 48 problems");
+    WgradArgs a;
+    if (int rc = fill_args_bf16(d, split, a)) return rc;
+    SGV3D_REQUIRE(((uintptr_t)x & 15) == 0, "conv2d_backward_weight_bf16_batched: x must be 16-byte aligned");
+    const size_t need = a.split > 1 ? (size_t)n * a.split * a.taps * a.cout * a.cin * sizeof(float) : 0;
+    SGV3D_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "conv2d_backward_weight_bf16_batched: workspace too small (%zu < %zu)",
+                  workspace_bytes, need);
+    a.x = x; a.dy = nullptr; a.dw = nullptr; a.ws = static_cast<float *>(workspace);
+    a.nbatch = n;
+    for (int i = 0; i < n; ++i) {
+        SGV3D_REQUIRE(dy_list[i] && dw_list[i] && ((uintptr_t)dy_list[i] & 15) == 0, "conv2d_backward_weight_bf16_batched: null / unaligned pointer %d", i);
+        a.dy_list[i] = dy_list[i];
+        a.dw_list[i] = dw_list[i];
+    }
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(a.tiles_co * a.tiles_ci * a.taps, a.split, n);
+    if (a.wm == 2 && a.wn == 2) conv_wgrad_bf16_kernel<2, 2><<<grid, 256, 0, st>>>(a);
+    else conv_wgrad_bf16_kernel<1, 1><<<grid, 256, 0, st>>>(a);
+    if (int rc = check_launch("conv_wgrad_bf16_kernel(batched)")) return rc;
+    if (a.split > 1) {
+        const long long total = (long long)a.taps * a.cout * a.cin;
+        wgrad_reduce_kernel<<<dim3(cdiv(total, 256), n), 256, 0, st>>>(a);
         return check_launch("wgrad_reduce_kernel");
     }
     return SGV3D_OK;

@@ -205,6 +205,34 @@ def test_wgrad_batched_matches_single_launches():
         assert float((w.grad.cpu().double() - r.grad).abs().max()) <= 2e-5 * float(r.grad.abs().max())
 
 
+def test_wgrad_bf16_batched_matches_single_launches():
+    """Mixed-precision mode: conv2d_backward_weight_batched runs the n gradients on the bf16 matrix cores in one launch
+    (sgv3d_conv2d_backward_weight_bf16_batched); per problem it equals the single-layer bf16 launch to f32 summation order and the
+    float64 gradient of the rounded operands to 2e-5; repeatable."""
+    from sgv3d_amd import hip_ops
+    g = torch.Generator().manual_seed(12)
+    B, H, W, cin, cout, n = 2, 21, 45, 64, 64, 5
+    x = torch.randn(B, H, W, cin, generator=g)
+    dys = [torch.randn(B, H, W, cout, generator=g) for _ in range(n)]
+    saved = hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS
+    hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS = True, False
+    try:
+        hip_ops.PROFILE = []
+        got = conv_grad.conv2d_backward_weight_batched(x.cuda(), [d.cuda() for d in dys])
+        assert [r[0] for r in hip_ops.PROFILE] == ["conv_wgrad_bf16"]
+        hip_ops.PROFILE = None
+        again = conv_grad.conv2d_backward_weight_batched(x.cuda(), [d.cuda() for d in dys])
+    finally:
+        hip_ops.PROFILE = None
+        hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS = saved
+    assert all(torch.equal(a, b) for a, b in zip(got, again))
+    for d, dw in zip(dys, got):
+        _, _, dw_ref = _reference(x.bfloat16().float(), torch.zeros(cout, cin, 3, 3), d.bfloat16().float(), 1, 1, 1)
+        assert float((dw.cpu().double() - dw_ref).abs().max()) <= 2e-5 * float(dw_ref.abs().max())
+        single = conv_grad.conv2d_backward_weight_bf16(x.cuda(), d.cuda(), 3, 1, 1, 1, tile=1, split=3)
+        assert float((dw - single).abs().max()) <= 2e-5 * float(dw_ref.abs().max())
+
+
 def test_wgrad_is_exact_on_small_integers():
     g = torch.Generator().manual_seed(5)
     x = torch.randint(-3, 4, (2, 30, 34, 64), generator=g).float()
