@@ -135,6 +135,8 @@ struct PlanHeader {
     int ticket;      // last-workgroup election of the compare kernel
     int params[7];   // magic, B, N, X, Y, Z, sort_segments of the plan held (all 0 = none)
     int builds;      // number of real builds so far (statistics / tests)
+    int bar;         // vp_plan_build_one_kernel: arrivals at its grid barriers (zeroed by the compare / prologue kernel before it)
+    int err;         // ... a barrier that gave up (the plan stays dirty: the level-1 entry's gated scatter serves the call)
 };
 constexpr int kPlanMagic = 0x53475633;  // "SGV3"
 
@@ -183,7 +185,7 @@ __device__ __forceinline__ void wave_runs(int v, int lane, int &head_lane, int &
 
 __global__ __launch_bounds__(kBlock) void vp_plan_init_kernel(PlanHeader *__restrict__ hdr) {
     if (threadIdx.x == 0) {
-        hdr->dirty = 1; hdr->diff = 0; hdr->ticket = 0; hdr->builds = 0;
+        hdr->dirty = 1; hdr->diff = 0; hdr->ticket = 0; hdr->builds = 0; hdr->bar = 0; hdr->err = 0;
         for (int i = 0; i < 7; ++i) hdr->params[i] = 0;
     }
 }
@@ -237,19 +239,22 @@ __global__ __launch_bounds__(64) void vp_plan_commit_kernel(PlanHeader *__restri
     hdr->dirty = 0;
 }
 
-__global__ __launch_bounds__(kBlock) void vp_zero_kernel(long long n, int *__restrict__ p, const int *__restrict__ dirty) {
-    VP_SKIP_IF_CLEAN(dirty);
-    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ void vp_zero_body(long long n, int *__restrict__ p, const int *__restrict__ dirty, const int VBID, const int VGRID) {
+    const long long i = (long long)VBID * kBlock + threadIdx.x;
     if (i < n) p[i] = 0;
 }
 
-__global__ __launch_bounds__(kBlock) void vp_count_kernel(long long total_pts, int N, int X, int Y, int Z,
+__global__ __launch_bounds__(kBlock) void vp_zero_kernel(long long n, int *__restrict__ p, const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    vp_zero_body(n, p, dirty, (int)blockIdx.x, (int)gridDim.x);
+}
+
+__device__ __forceinline__ void vp_count_body(long long total_pts, int N, int X, int Y, int Z,
                                                           const int32_t *__restrict__ geom,
                                                           int32_t *__restrict__ pos_memo,
                                                           int *__restrict__ count, const int *__restrict__ dirty,
-                                                          int32_t *__restrict__ geom_copy) {
-    VP_SKIP_IF_CLEAN(dirty);
-    const long long pt = (long long)blockIdx.x * kBlock + threadIdx.x;
+                                                          int32_t *__restrict__ geom_copy, const int VBID, const int VGRID) {
+    const long long pt = (long long)VBID * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int v = -1;
     if (pt < total_pts) {
@@ -271,6 +276,15 @@ __global__ __launch_bounds__(kBlock) void vp_count_kernel(long long total_pts, i
     bool is_head;
     wave_runs(v, lane, head_lane, run_len, is_head);
     if (is_head && v >= 0) atomicAdd(count + v, run_len);
+}
+
+__global__ __launch_bounds__(kBlock) void vp_count_kernel(long long total_pts, int N, int X, int Y, int Z,
+                                                          const int32_t *__restrict__ geom,
+                                                          int32_t *__restrict__ pos_memo,
+                                                          int *__restrict__ count, const int *__restrict__ dirty,
+                                                          int32_t *__restrict__ geom_copy) {
+    VP_SKIP_IF_CLEAN(dirty);
+    vp_count_body(total_pts, N, X, Y, Z, geom, pos_memo, count, dirty, geom_copy, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // exclusive scan of one int per thread across a 256-thread workgroup; returns the exclusive prefix
@@ -297,12 +311,11 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *wave_tot /*LDS[4
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(kBlock) void vp_scan_local_kernel(long long V, const int *__restrict__ count,
+__device__ __forceinline__ void vp_scan_local_body(long long V, const int *__restrict__ count,
                                                                int *__restrict__ seg_start,
-                                                               int *__restrict__ blk_sum, const int *__restrict__ dirty) {
-    VP_SKIP_IF_CLEAN(dirty);
+                                                               int *__restrict__ blk_sum, const int *__restrict__ dirty, const int VBID, const int VGRID) {
     __shared__ int wave_tot[kBlock / 64];
-    const long long base = (long long)blockIdx.x * kScanElems + (long long)threadIdx.x * kScanPerThread;
+    const long long base = (long long)VBID * kScanElems + (long long)threadIdx.x * kScanPerThread;
     int v[kScanPerThread];
     int sum = 0;
 #pragma unroll
@@ -317,13 +330,19 @@ __global__ __launch_bounds__(kBlock) void vp_scan_local_kernel(long long V, cons
         if (base + i < V) seg_start[base + i] = run;
         run += v[i];
     }
-    if (threadIdx.x == 0) blk_sum[blockIdx.x] = tot;
+    if (threadIdx.x == 0) blk_sum[VBID] = tot;
+}
+
+__global__ __launch_bounds__(kBlock) void vp_scan_local_kernel(long long V, const int *__restrict__ count,
+                                                               int *__restrict__ seg_start,
+                                                               int *__restrict__ blk_sum, const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    vp_scan_local_body(V, count, seg_start, blk_sum, dirty, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // one workgroup: exclusive scan of blk_sum[0..nblk) in place; blk_sum[nblk] = grand total
-__global__ __launch_bounds__(kBlock) void vp_scan_top_kernel(int nblk, int *__restrict__ blk_sum,
-                                                             const int *__restrict__ dirty, int *__restrict__ long_list) {
-    VP_SKIP_IF_CLEAN(dirty);
+__device__ __forceinline__ void vp_scan_top_body(int nblk, int *__restrict__ blk_sum,
+                                                             const int *__restrict__ dirty, int *__restrict__ long_list, const int VBID, const int VGRID) {
     __shared__ int wave_tot[kBlock / 64];
     if (threadIdx.x == 0) long_list[0] = 0;      // re-armed for vp_long_list_kernel (runs after the scan)
     int carry = 0;
@@ -338,12 +357,17 @@ __global__ __launch_bounds__(kBlock) void vp_scan_top_kernel(int nblk, int *__re
     if (threadIdx.x == 0) blk_sum[nblk] = carry;
 }
 
-__global__ __launch_bounds__(kBlock) void vp_scan_add_kernel(long long V, int nblk,
+__global__ __launch_bounds__(kBlock) void vp_scan_top_kernel(int nblk, int *__restrict__ blk_sum,
+                                                             const int *__restrict__ dirty, int *__restrict__ long_list) {
+    VP_SKIP_IF_CLEAN(dirty);
+    vp_scan_top_body(nblk, blk_sum, dirty, long_list, (int)blockIdx.x, (int)gridDim.x);
+}
+
+__device__ __forceinline__ void vp_scan_add_body(long long V, int nblk,
                                                              const int *__restrict__ blk_sum,
                                                              int *__restrict__ seg_start,
-                                                             int *__restrict__ cursor, const int *__restrict__ dirty) {
-    VP_SKIP_IF_CLEAN(dirty);
-    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+                                                             int *__restrict__ cursor, const int *__restrict__ dirty, const int VBID, const int VGRID) {
+    const long long i = (long long)VBID * kBlock + threadIdx.x;
     if (i < V) {
         const int s = seg_start[i] + blk_sum[i / kScanElems];
         seg_start[i] = s;
@@ -353,13 +377,20 @@ __global__ __launch_bounds__(kBlock) void vp_scan_add_kernel(long long V, int nb
     }
 }
 
+__global__ __launch_bounds__(kBlock) void vp_scan_add_kernel(long long V, int nblk,
+                                                             const int *__restrict__ blk_sum,
+                                                             int *__restrict__ seg_start,
+                                                             int *__restrict__ cursor, const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    vp_scan_add_body(V, nblk, blk_sum, seg_start, cursor, dirty, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // voxels with more than kLongRun points -> long_list[1 ..], count in long_list[0] (order irrelevant: each entry is summed in
 // a fixed internal order by whichever workgroup picks it up)
-__global__ __launch_bounds__(kBlock) void vp_long_list_kernel(long long V, const int *__restrict__ seg_start,
+__device__ __forceinline__ void vp_long_list_body(long long V, const int *__restrict__ seg_start,
                                                               int *__restrict__ long_list, int cap,
-                                                              const int *__restrict__ dirty) {
-    VP_SKIP_IF_CLEAN(dirty);
-    const long long v = (long long)blockIdx.x * kBlock + threadIdx.x;
+                                                              const int *__restrict__ dirty, const int VBID, const int VGRID) {
+    const long long v = (long long)VBID * kBlock + threadIdx.x;
     if (v >= V) return;
     if (seg_start[v + 1] - seg_start[v] > kLongRun) {
         const int i = atomicAdd(long_list, 1);
@@ -367,14 +398,20 @@ __global__ __launch_bounds__(kBlock) void vp_long_list_kernel(long long V, const
     }
 }
 
-__global__ __launch_bounds__(kBlock) void vp_fill_kernel(long long total_pts, int N, int X, int Y, int Z,
+__global__ __launch_bounds__(kBlock) void vp_long_list_kernel(long long V, const int *__restrict__ seg_start,
+                                                              int *__restrict__ long_list, int cap,
+                                                              const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    vp_long_list_body(V, seg_start, long_list, cap, dirty, (int)blockIdx.x, (int)gridDim.x);
+}
+
+__device__ __forceinline__ void vp_fill_body(long long total_pts, int N, int X, int Y, int Z,
                                                          const int32_t *__restrict__ geom,
                                                          int *__restrict__ cursor,
                                                          int *__restrict__ order,
                                                          int *__restrict__ slot_voxel, const int *__restrict__ dirty,
-                                                         const int *__restrict__ seg_start) {
-    VP_SKIP_IF_CLEAN(dirty);
-    const long long pt = (long long)blockIdx.x * kBlock + threadIdx.x;
+                                                         const int *__restrict__ seg_start, const int VBID, const int VGRID) {
+    const long long pt = (long long)VBID * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int v = -1;
     if (pt < total_pts) {
@@ -396,15 +433,24 @@ __global__ __launch_bounds__(kBlock) void vp_fill_kernel(long long total_pts, in
     }
 }
 
+__global__ __launch_bounds__(kBlock) void vp_fill_kernel(long long total_pts, int N, int X, int Y, int Z,
+                                                         const int32_t *__restrict__ geom,
+                                                         int *__restrict__ cursor,
+                                                         int *__restrict__ order,
+                                                         int *__restrict__ slot_voxel, const int *__restrict__ dirty,
+                                                         const int *__restrict__ seg_start) {
+    VP_SKIP_IF_CLEAN(dirty);
+    vp_fill_body(total_pts, N, X, Y, Z, geom, cursor, order, slot_voxel, dirty, seg_start, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // ---- voxels by population class, stable in voxel order (perm), for the voxel-owner gather ------------------------------------
 // tbl[c * ncw + b] = number of class-c voxels among the 256 voxels of workgroup b
-__global__ __launch_bounds__(kBlock) void vp_cls_count_kernel(long long V, const int *__restrict__ seg_start, int ncw,
-                                                              int *__restrict__ tbl, const int *__restrict__ dirty) {
-    VP_SKIP_IF_CLEAN(dirty);
+__device__ __forceinline__ void vp_cls_count_body(long long V, const int *__restrict__ seg_start, int ncw,
+                                                              int *__restrict__ tbl, const int *__restrict__ dirty, const int VBID, const int VGRID) {
     __shared__ int h[kVoxClasses];
     if (threadIdx.x < kVoxClasses) h[threadIdx.x] = 0;
     __syncthreads();
-    const long long v = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long v = (long long)VBID * kBlock + threadIdx.x;
     const int c = v < V ? vp_class(seg_start[v + 1] - seg_start[v]) : -1;
 #pragma unroll
     for (int k = 0; k < kVoxClasses; ++k) {
@@ -412,15 +458,20 @@ __global__ __launch_bounds__(kBlock) void vp_cls_count_kernel(long long V, const
         if ((threadIdx.x & 63) == 0 && m != 0ull) atomicAdd(&h[k], __popcll(m));
     }
     __syncthreads();
-    if (threadIdx.x < kVoxClasses) tbl[threadIdx.x * ncw + blockIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < kVoxClasses) tbl[threadIdx.x * ncw + VBID] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBlock) void vp_cls_count_kernel(long long V, const int *__restrict__ seg_start, int ncw,
+                                                              int *__restrict__ tbl, const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    vp_cls_count_body(V, seg_start, ncw, tbl, dirty, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // one workgroup per class: exclusive scan of the class's row of the table (workgroups ascending), in place; tot[c] = its sum
-__global__ __launch_bounds__(kBlock) void vp_cls_scan_kernel(int ncw, int *__restrict__ tbl, int *__restrict__ tot,
-                                                             const int *__restrict__ dirty) {
-    VP_SKIP_IF_CLEAN(dirty);
+__device__ __forceinline__ void vp_cls_scan_body(int ncw, int *__restrict__ tbl, int *__restrict__ tot,
+                                                             const int *__restrict__ dirty, const int VBID, const int VGRID) {
     __shared__ int wave_tot[kBlock / 64];
-    const int c = blockIdx.x;
+    const int c = VBID;
     int *row = tbl + (size_t)c * ncw;
     int carry = 0;
     for (int b0 = 0; b0 < ncw; b0 += kBlock * kScanPerThread) {
@@ -443,13 +494,18 @@ __global__ __launch_bounds__(kBlock) void vp_cls_scan_kernel(int ncw, int *__res
     if (threadIdx.x == 0) tot[c] = carry;
 }
 
+__global__ __launch_bounds__(kBlock) void vp_cls_scan_kernel(int ncw, int *__restrict__ tbl, int *__restrict__ tot,
+                                                             const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    vp_cls_scan_body(ncw, tbl, tot, dirty, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // perm order: class kVoxClasses-1 first, class 0 (the empty voxels) last; inside a class the workgroups ascending and, inside a
 // workgroup, the voxels ascending (ranks by ballots).  cls[c] = position of class c's first record (written by workgroup 0).
-__global__ __launch_bounds__(kBlock) void vp_cls_scatter_kernel(long long V, const int *__restrict__ seg_start, int ncw,
+__device__ __forceinline__ void vp_cls_scatter_body(long long V, const int *__restrict__ seg_start, int ncw,
                                                                 const int *__restrict__ tbl, const int *__restrict__ tot,
                                                                 int *__restrict__ cls, int *__restrict__ perm,
-                                                                const int *__restrict__ dirty) {
-    VP_SKIP_IF_CLEAN(dirty);
+                                                                const int *__restrict__ dirty, const int VBID, const int VGRID) {
     __shared__ int wcnt[kBlock / 64][kVoxClasses];
     __shared__ int cbase[kVoxClasses];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -457,9 +513,9 @@ __global__ __launch_bounds__(kBlock) void vp_cls_scatter_kernel(long long V, con
         int bsum = 0;
         for (int k = kVoxClasses - 1; k > (int)threadIdx.x; --k) bsum += tot[k];
         cbase[threadIdx.x] = bsum;
-        if (blockIdx.x == 0) cls[threadIdx.x] = bsum;
+        if (VBID == 0) cls[threadIdx.x] = bsum;
     }
-    const long long v = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long v = (long long)VBID * kBlock + threadIdx.x;
     int s0 = 0, s1 = 0, c = -1;
     if (v < V) {
         s0 = seg_start[v];
@@ -475,10 +531,57 @@ __global__ __launch_bounds__(kBlock) void vp_cls_scatter_kernel(long long V, con
     }
     __syncthreads();
     if (c >= 0) {
-        int pos = cbase[c] + tbl[c * ncw + blockIdx.x] + rank;
+        int pos = cbase[c] + tbl[c * ncw + VBID] + rank;
         for (int w = 0; w < wid; ++w) pos += wcnt[w][c];
         reinterpret_cast<int4 *>(perm)[pos] = make_int4((int)v, s0, s1, 0);
     }
+}
+
+__global__ __launch_bounds__(kBlock) void vp_cls_scatter_kernel(long long V, const int *__restrict__ seg_start, int ncw,
+                                                                const int *__restrict__ tbl, const int *__restrict__ tot,
+                                                                int *__restrict__ cls, int *__restrict__ perm,
+                                                                const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    vp_cls_scatter_body(V, seg_start, ncw, tbl, tot, cls, perm, dirty, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ascending sort of order[s .. s + n), n <= 64 R, by one wave: the list lives in R registers per lane (element e = r * 64 + lane)
+template <int R>
+__device__ __forceinline__ void vp_sort_regs(int *__restrict__ order, int s, int n, int lane) {
+    int val[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) val[r] = (r * 64 + lane) < n ? order[s + r * 64 + lane] : 0x7fffffff;
+#pragma unroll
+    for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const int rj = j >> 6;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if ((r & rj) == 0) {
+                        const bool up = (((r * 64 + lane) & k) == 0);
+                        const int a = val[r], b = val[r | rj];
+                        const int mn = min(a, b), mx = max(a, b);
+                        val[r] = up ? mn : mx;
+                        val[r | rj] = up ? mx : mn;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int other = __shfl_xor(val[r], j, 64);
+                    const bool up = (((r * 64 + lane) & k) == 0);
+                    const bool lower = (lane & j) == 0;
+                    const int mn = min(val[r], other), mx = max(val[r], other);
+                    val[r] = (lower == up) ? mn : mx;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if ((r * 64 + lane) < n) order[s + r * 64 + lane] = val[r];
 }
 
 // Segments of lo+1 .. 64*R points: one wave per voxel, the list lives in R registers per lane
@@ -486,13 +589,12 @@ __global__ __launch_bounds__(kBlock) void vp_cls_scatter_kernel(long long V, con
 // network (distance < 64) or between registers of one lane (distance >= 64): no LDS, no barrier, and
 // every long voxel gets its own wave, so the per-voxel multiplicity skew costs no serialisation.
 template <int R>
-__global__ __launch_bounds__(kBlock) void vp_sort_wave_kernel(long long V, const int *__restrict__ seg_start,
+__device__ __forceinline__ void vp_sort_wave_body(long long V, const int *__restrict__ seg_start,
                                                               int *__restrict__ order, int lo,
-                                                              const int *__restrict__ dirty) {
-    VP_SKIP_IF_CLEAN(dirty);
+                                                              const int *__restrict__ dirty, const int VBID, const int VGRID) {
     const int lane = threadIdx.x & 63;
-    const long long wave0 = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const long long nwaves = (long long)gridDim.x * (kBlock / 64);
+    const long long wave0 = (long long)VBID * (kBlock / 64) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)VGRID * (kBlock / 64);
     // voxels are dealt to waves with a per-round rotation (97 is coprime to any power-of-two wave
     // count): long lists cluster in a few BEV columns and a plain stride would pile them on few waves
     for (long long it = 0; it * nwaves < V; ++it) {
@@ -501,51 +603,45 @@ __global__ __launch_bounds__(kBlock) void vp_sort_wave_kernel(long long V, const
         const int s = seg_start[v];
         const int n = seg_start[v + 1] - s;
         if (n <= lo || n > 64 * R) continue;   // wave-uniform
-        int val[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) val[r] = (r * 64 + lane) < n ? order[s + r * 64 + lane] : 0x7fffffff;
-#pragma unroll
-        for (int k = 2; k <= 64 * R; k <<= 1) {
-#pragma unroll
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                if (j >= 64) {
-                    const int rj = j >> 6;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if ((r & rj) == 0) {
-                            const bool up = (((r * 64 + lane) & k) == 0);
-                            const int a = val[r], b = val[r | rj];
-                            const int mn = min(a, b), mx = max(a, b);
-                            val[r] = up ? mn : mx;
-                            val[r | rj] = up ? mx : mn;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int other = __shfl_xor(val[r], j, 64);
-                        const bool up = (((r * 64 + lane) & k) == 0);
-                        const bool lower = (lane & j) == 0;
-                        const int mn = min(val[r], other), mx = max(val[r], other);
-                        val[r] = (lower == up) ? mn : mx;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if ((r * 64 + lane) < n) order[s + r * 64 + lane] = val[r];
+        vp_sort_regs<R>(order, s, n, lane);
     }
+}
+
+// The four length classes of vp_sort_wave_kernel in ONE walk over the voxels (the one-launch rebuild has few waves: a walk is
+// V / waves dependent seg_start loads, and four of them were most of its time)
+__device__ __forceinline__ void vp_sort_wave_all_body(long long V, const int *__restrict__ seg_start, int *__restrict__ order,
+                                                      const int VBID, const int VGRID) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)VBID * (kBlock / 64) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)VGRID * (kBlock / 64);
+    for (long long it = 0; it * nwaves < V; ++it) {
+        const long long v = it * nwaves + (wave0 + 97 * it) % nwaves;
+        if (v >= V) continue;
+        const int s = seg_start[v];
+        const int n = seg_start[v + 1] - s;          // wave-uniform
+        if (n <= 1 || n > 2048) continue;
+        if (n <= 64) vp_sort_regs<1>(order, s, n, lane);
+        else if (n <= 256) vp_sort_regs<4>(order, s, n, lane);
+        else if (n <= 1024) vp_sort_regs<16>(order, s, n, lane);
+        else vp_sort_regs<32>(order, s, n, lane);
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void vp_sort_wave_kernel(long long V, const int *__restrict__ seg_start,
+                                                              int *__restrict__ order, int lo,
+                                                              const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    vp_sort_wave_body<R>(V, seg_start, order, lo, dirty, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Ascending sort of every segment whose length is in (lo, hi]: normalised bitonic network (all
 // comparators ascending, virtual +inf padding => works for any length), data staged in LDS when it
 // fits, otherwise sorted in place in global memory by the one workgroup that owns the segment.
 template <int T, int LDS_CAP>
-__global__ __launch_bounds__(T) void vp_sort_segments_kernel(long long V, const int *__restrict__ seg_start,
+__device__ __forceinline__ void vp_sort_segments_body(long long V, const int *__restrict__ seg_start,
                                                              int *__restrict__ order, int lo, int hi,
-                                                             const int *__restrict__ dirty) {
-    VP_SKIP_IF_CLEAN(dirty);
+                                                             const int *__restrict__ dirty, const int VBID, const int VGRID) {
     __shared__ int buf[LDS_CAP];
     __shared__ int todo[T];
     __shared__ int ntodo;
@@ -553,21 +649,21 @@ __global__ __launch_bounds__(T) void vp_sort_segments_kernel(long long V, const 
     // The workgroup inspects T voxels at a time and queues the ones it has to sort.  Voxel ids are
     // dealt round-robin over the workgroups (v = slot * gridDim + block): long segments cluster in
     // neighbouring voxels (near the camera), a contiguous assignment would serialise them on one CU.
-    const long long G = gridDim.x;
+    const long long G = VGRID;
     for (long long sb = 0; sb * G < V; sb += T) {
         if (tid == 0) ntodo = 0;
         __syncthreads();
         {
             // rotate the column by 37 per row: a plain v = slot*G + block would hand one BEV column
             // (all rows of one x when G == X) to one workgroup, and the hot voxels sit in few columns
-            const long long v = (sb + tid) * G + (blockIdx.x + 37 * (sb + tid)) % G;
+            const long long v = (sb + tid) * G + (VBID + 37 * (sb + tid)) % G;
             const int n = v < V ? seg_start[v + 1] - seg_start[v] : 0;
             if (n > lo && n <= hi) todo[atomicAdd(&ntodo, 1)] = tid;   // queue order does not matter
         }
         __syncthreads();
         const int nq = ntodo;
         for (int qi = 0; qi < nq; ++qi) {
-            const long long v = (sb + todo[qi]) * G + (blockIdx.x + 37 * (sb + todo[qi])) % G;
+            const long long v = (sb + todo[qi]) * G + (VBID + 37 * (sb + todo[qi])) % G;
             const int s = seg_start[v];
             const int n = seg_start[v + 1] - s;
             int *data = order + s;
@@ -607,6 +703,123 @@ __global__ __launch_bounds__(T) void vp_sort_segments_kernel(long long V, const 
             __syncthreads();
         }
         __syncthreads();
+    }
+}
+
+template <int T, int LDS_CAP>
+__global__ __launch_bounds__(T) void vp_sort_segments_kernel(long long V, const int *__restrict__ seg_start,
+                                                             int *__restrict__ order, int lo, int hi,
+                                                             const int *__restrict__ dirty) {
+    VP_SKIP_IF_CLEAN(dirty);
+    vp_sort_segments_body<T, LDS_CAP>(V, seg_start, order, lo, hi, dirty, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole (re)build as ONE launch, for the level-1 entry (sgv3d_voxel_pooling_forward[_fresh]).
+//
+// The build above is ~16 launches that each leave at once while geom_xyz is the plan's: harmless from a stream (the host
+// enqueues them one call late, only after the device's note), but a stream CAPTURE has to record them in line -- 27 us of
+// empty launches in front of a 26 us gather (59.8 us per replay at cfg-2, profiles/r04_gather_probe.txt; ROCm 7.2 has no
+// conditional graph nodes, and a forked branch of the graph cost more than it hid: 75 us).  Here every phase is the body of
+// its kernel above, run by kOneGrid resident workgroups over that kernel's virtual grid, with device-wide barriers between
+// dependent phases:
+//
+//   zero | count | scan_local | scan_top | scan_add | long_list + cls_count + fill | cls_scan | cls_scatter + sorts | commit
+//
+// While the plan is current every workgroup leaves after one load: ONE empty launch.  The barrier is an arrival counter in the
+// plan header (zeroed by the prologue kernel that precedes this one on the stream); a workgroup waits with s_sleep and a
+// bounded number of polls -- a barrier that gives up (never observed; it would take the other workgroups not being scheduled
+// for ~1 s) raises PlanHeader::err, every later barrier returns at once, the commit is skipped and the plan stays dirty: the
+// entry's gated scatter serves the call and the next call tries again.  The grid is small enough (512 workgroups of 256
+// threads, 11 KB of LDS: two per CU) that several such launches are resident together.
+constexpr int kOneGrid = 512;
+constexpr int kOneSpinLimit = 1 << 22;       // polls of ~0.25 us
+
+struct PlanOneArgs {
+    long long total, V;
+    int N, X, Y, Z, nblk, ncw, long_cap;
+    const int32_t *geom;
+    int32_t *gcopy;
+    int *seg, *cur, *order, *slotvox, *blk, *long_list, *tbl, *tot, *cls, *perm;
+    PlanHeader *hdr;
+    int p[7];
+};
+
+__device__ __forceinline__ void vp_grid_barrier(PlanHeader *hdr, int &epoch) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ++epoch;
+        if (__hip_atomic_load(&hdr->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __threadfence();                                                      // release this workgroup's writes
+            __hip_atomic_fetch_add(&hdr->bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const int target = epoch * (int)gridDim.x;
+            int polls = 0;
+            while (__hip_atomic_load(&hdr->bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(32);            // (~0.9 us between polls: hundreds of workgroups poll ONE word)
+                if (++polls > kOneSpinLimit || __hip_atomic_load(&hdr->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    __hip_atomic_store(&hdr->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __threadfence();                                                      // acquire the others'
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ long long dcdiv(long long x, long long y) { return (x + y - 1) / y; }
+
+__global__ __launch_bounds__(kBlock) void vp_plan_build_one_kernel(const PlanOneArgs a) {
+    const int *dirty = &a.hdr->dirty;
+    if (*reinterpret_cast<const volatile int *>(dirty) == 0) return;
+    const int wg = blockIdx.x, G = gridDim.x;
+    int epoch = 0;
+    // a phase: the kernel's body over its virtual grid, this workgroup taking every G-th virtual block; __syncthreads between
+    // virtual blocks because the bodies reuse their LDS scratch
+#define VP_PHASE(NBLK, CALL)                                                    \
+    for (long long vb_ = wg; vb_ < (long long)(NBLK); vb_ += G) {               \
+        const int VB = (int)vb_;                                                \
+        CALL;                                                                   \
+        __syncthreads();                                                        \
+    }
+    // (bodies without LDS scratch: no barrier between virtual blocks)
+#define VP_PHASE_NOSYNC(NBLK, CALL)                                             \
+    for (long long vb_ = wg; vb_ < (long long)(NBLK); vb_ += G) {               \
+        const int VB = (int)vb_;                                                \
+        CALL;                                                                   \
+    }
+    const int pgrid = (int)dcdiv(a.total, kBlock);
+    VP_PHASE_NOSYNC(dcdiv(a.V + 1, kBlock), vp_zero_body(a.V + 1, a.cur, nullptr, VB, 0));
+    vp_grid_barrier(a.hdr, epoch);
+    VP_PHASE_NOSYNC(pgrid, vp_count_body(a.total, a.N, a.X, a.Y, a.Z, a.geom, nullptr, a.cur, nullptr, a.gcopy, VB, pgrid));
+    vp_grid_barrier(a.hdr, epoch);
+    VP_PHASE(a.nblk, vp_scan_local_body(a.V, a.cur, a.seg, a.blk, nullptr, VB, a.nblk));
+    vp_grid_barrier(a.hdr, epoch);
+    if (wg == 0) vp_scan_top_body(a.nblk, a.blk, nullptr, a.long_list, 0, 1);
+    vp_grid_barrier(a.hdr, epoch);
+    VP_PHASE_NOSYNC(dcdiv(a.V + 1, kBlock), vp_scan_add_body(a.V, a.nblk, a.blk, a.seg, a.cur, nullptr, VB, 0));
+    vp_grid_barrier(a.hdr, epoch);
+    VP_PHASE_NOSYNC(dcdiv(a.V, kBlock), vp_long_list_body(a.V, a.seg, a.long_list, a.long_cap, nullptr, VB, 0));
+    VP_PHASE(a.ncw, vp_cls_count_body(a.V, a.seg, a.ncw, a.tbl, nullptr, VB, a.ncw));
+    VP_PHASE_NOSYNC(pgrid, vp_fill_body(a.total, a.N, a.X, a.Y, a.Z, a.geom, a.cur, a.order, a.slotvox, nullptr, a.seg, VB, pgrid));
+    vp_grid_barrier(a.hdr, epoch);
+    VP_PHASE(kVoxClasses, vp_cls_scan_body(a.ncw, a.tbl, a.tot, nullptr, VB, kVoxClasses));
+    vp_grid_barrier(a.hdr, epoch);
+    VP_PHASE(a.ncw, vp_cls_scatter_body(a.V, a.seg, a.ncw, a.tbl, a.tot, a.cls, a.perm, nullptr, VB, a.ncw));
+    // the five sorts touch disjoint segments (by length class): one phase; each deals the voxels over the G workgroups itself
+    vp_sort_wave_all_body(a.V, a.seg, a.order, wg, G);
+    __syncthreads();
+    // (segments above 2048 points: LDS for up to 2048 ints here -- the stand-alone kernel stages 8192 -- longer ones are sorted in
+    //  place in global memory by their workgroup; 11 KB per workgroup instead of 35)
+    vp_sort_segments_body<kBlock, 2048>(a.V, a.seg, a.order, 2048, 0x7fffffff, nullptr, wg, G);
+    vp_grid_barrier(a.hdr, epoch);
+#undef VP_PHASE_NOSYNC
+#undef VP_PHASE
+    if (wg == 0 && threadIdx.x == 0 && __hip_atomic_load(&a.hdr->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        for (int i = 0; i < 7; ++i) a.hdr->params[i] = a.p[i];
+        a.hdr->builds += 1;
+        __threadfence();
+        a.hdr->dirty = 0;
     }
 }
 
@@ -2031,6 +2244,10 @@ __global__ __launch_bounds__(kBlock) void vp_level1_prologue_kernel(long long to
             }
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // re-arm the one-launch rebuild's barrier (it runs behind this kernel)
+        hdr->bar = 0;
+        hdr->err = 0;
+    }
     if (__ballot(diff) != 0ull && (threadIdx.x & 63) == 0) {             // (rare: one store per wave that saw a difference)
         __hip_atomic_store(&hdr->dirty, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // sticky note to the host: a later call enqueues the (device-gated) rebuild when it sees it
@@ -2218,22 +2435,40 @@ int level1_forward(int batch_size, int num_points, int num_channels, int num_vox
     else
         hipLaunchKernelGGL(vp_level1_prologue_kernel<false>, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, st, total, N, X, Y, Z,
                            geom_xyz, gcopy, pos_memo, hdr, flag_dev);
-    // (A stream capture records the gated build IN LINE: ~16 launches that leave at once while geom_xyz is the plan's, 27 us of a
-    //  59.8 us replay at cfg-2.  Recording them as a forked branch of the graph beside the gather -- built and measured in round 5
-    //  -- made a replay 75 us: the two cross-queue edges of a hipGraph cost more than the empty launches they hide.)
-    if (e->need_build || capturing) {
-        // gated build (its kernels return at once when the prologue found the plan up to date), then the gather on a plan
-        // that is right either way.  Also the form a stream capture records: valid for whatever geom_xyz a replay sees.
+    if (e->need_build && !capturing) {
+        // from a stream: the multi-launch build (the whole chip per phase: 114 us at cfg-2), gated on the device -- its kernels
+        // leave at once if the prologue found the plan current after all
         if (int rc = plan_build_impl(B, N, X, Y, Z, geom_xyz, nullptr, e->plan, e->plan_bytes, 1, true, st,
                                      "voxel_pooling_forward(level-1 plan)", /*compare_done=*/true)) return rc;
-        if (!capturing) {
-            e->need_build = false;
-            __atomic_store_n(e->host_flag, 0, __ATOMIC_RELAXED);
-        }
+        e->need_build = false;
+        __atomic_store_n(e->host_flag, 0, __ATOMIC_RELAXED);
         g_l1_stats[3]++;
-        g_l1_stats[1]++;
-        return launch_gather<false, false, false, !FRESH>(B, N, C, X, Y, e->plan, input_features, nullptr, nullptr, 1,
-                                                          output_features, nullptr, 0, st, 0, nullptr);
+    } else if (capturing) {
+        // What a stream capture records: the rebuild as ONE gated launch (vp_plan_build_one_kernel: leaves at once while
+        // geom_xyz is the plan's, lowers the dirty flag when it has rebuilt), then the gather and the scatter, both gated on
+        // that flag: right for whatever geom_xyz a replay sees.  (Rounds 3-4 recorded the ~16 gated launches of the build
+        // above: 27 us of empty launches per replay; a forked graph branch for them was slower still, 75 against 59.8 us.  The
+        // price: a replay whose geom_xyz did change rebuilds on a fraction of the chip, ~0.33 ms instead of 0.11.)
+        PlanOneArgs o;
+        o.total = total; o.V = L.V; o.N = N; o.X = X; o.Y = Y; o.Z = Z; o.nblk = L.nblk; o.ncw = L.ncw; o.long_cap = L.long_cap;
+        o.geom = geom_xyz;
+        o.gcopy = reinterpret_cast<int32_t *>(base + L.off_geom);
+        o.seg = reinterpret_cast<int *>(base + L.off_seg);
+        o.cur = reinterpret_cast<int *>(base + L.off_cur);
+        o.order = reinterpret_cast<int *>(base + L.off_order);
+        o.slotvox = reinterpret_cast<int *>(base + L.off_slotvox);
+        o.blk = reinterpret_cast<int *>(base + L.off_blk);
+        o.long_list = reinterpret_cast<int *>(base + L.off_long);
+        o.tbl = reinterpret_cast<int *>(base + L.off_bins);
+        o.cls = o.tbl + (size_t)kVoxClasses * L.ncw;
+        o.tot = o.cls + kVoxClasses;
+        o.perm = reinterpret_cast<int *>(base + L.off_perm);
+        o.hdr = hdr;
+        const int pm[7] = {kPlanMagic, B, N, X, Y, Z, 1};
+        for (int i = 0; i < 7; ++i) o.p[i] = pm[i];
+        static const int one_grid = [] { const char *v = getenv("SGV3D_VP_ONE_GRID"); const int g = v ? atoi(v) : 0; return g >= 32 && g <= 1024 ? g : kOneGrid; }();
+        hipLaunchKernelGGL(vp_plan_build_one_kernel, dim3(one_grid), dim3(kBlock), 0, st, o);
+        g_l1_stats[3]++;
     }
     g_l1_stats[1]++;
     // (FRESH: a gather that finds the plan stale zeroes the map on its way out -- the gated scatter below adds into zeros)

@@ -508,18 +508,35 @@ def test_level1_fresh_entry_overwrites_garbage_and_follows_geometry_changes(hip,
     hip.check(lib.sgv3d_voxel_pooling_cache_clear(), "clear")
 
 
-def test_level1_entry_inside_a_captured_graph(hip):
-    """A hipGraph that holds the level-1 call keeps working when geom_xyz is rewritten in place between replays."""
+@pytest.mark.parametrize("hot", [False, True])
+def test_level1_entry_inside_a_captured_graph(hip, hot):
+    """A hipGraph that holds the level-1 call keeps working when geom_xyz is rewritten in place between replays: the capture
+    records ONE gated rebuild launch (vp_plan_build_one_kernel: every phase of the plan build behind device-wide barriers), so a
+    replay with a changed geom_xyz rebuilds the plan and sums with the deterministic gather in that very replay -- the plan's
+    build counter moves, exact sums either way.  ``hot``: voxel populations in every class of the build's sorts, up to one voxel
+    with 5 000 points (in-register sorts of 64 .. 2 048, the workgroup sort beyond, in place in global memory past its LDS stage)."""
     hip.check(hip.load().sgv3d_voxel_pooling_cache_clear(), "clear")
     rng = np.random.default_rng(33)
-    B, N, C, X, Y, Z = 1, 9000, 80, 21, 17, 1
-    g0 = rng.integers(-1, 22, size=(B, N, 3)).astype(np.int32); g0[..., 2] = 0
-    g1 = rng.integers(-1, 22, size=(B, N, 3)).astype(np.int32); g1[..., 2] = 0
+    B, N, C, X, Y, Z = (1, 70000, 32, 40, 30, 1) if hot else (1, 9000, 80, 21, 17, 1)
+
+    def geometry(seed):
+        r = np.random.default_rng(seed)
+        g = r.integers(-1, max(X, Y) + 1, size=(B, N, 3)).astype(np.int32)
+        g[..., 2] = 0
+        if hot:                                            # populations 5000, 1500, 700, 300, 100 (+ the random background)
+            pos = 0
+            for k, n in enumerate((5000, 1500, 700, 300, 100)):
+                idx = r.permutation(N)[:n]
+                g[0, idx, 0], g[0, idx, 1] = 3 + 2 * k + seed % 2, 5 + k
+                pos += n
+        return g
+    g0, g1 = geometry(40), geometry(41)
     feats = rng.integers(-4, 5, size=(B, N, C)).astype(np.float32)
     g = torch.from_numpy(g0).to(DEV)
     f = torch.from_numpy(feats).to(DEV)
     out = torch.zeros(B, Y, X, C, device=DEV)
     s = torch.cuda.Stream()
+    s0 = _l1_stats(hip)
     with torch.cuda.stream(s):
         _level1(hip, g, f, out, None, X, Y, Z)                            # eager: creates the plan for this stream
         s.synchronize()
@@ -527,10 +544,11 @@ def test_level1_entry_inside_a_captured_graph(hip):
         with torch.cuda.graph(graph, stream=s):
             out.mul_(0.0)                                                 # (a kernel, not a memset node)
             _level1(hip, g, f, out, None, X, Y, Z)
-    for cur in (g0, g1, g1, g0):
+    for cur in (g0, g1, g1, g0, g0):
         g.copy_(torch.from_numpy(cur))
         graph.replay()
         torch.cuda.synchronize()
         ref, _ = VPO.forward(cur, feats, (X, Y, Z))
         assert np.array_equal(out.permute(0, 3, 1, 2).cpu().numpy(), ref)
+    assert _l1_stats(hip)[3] - s0[3] == 2                                 # the eager build + the one recorded into the graph
     hip.check(hip.load().sgv3d_voxel_pooling_cache_clear(), "clear")
