@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from .. import hip_ops
+from .. import host_ext as _host_ext
 from ..calibration import tensor_version
 from ..layers.backbones.bsm_lss_fpn import BSMLSSFPN
 from ..layers.backbones.lss_fpn import LSSFPN
@@ -85,7 +86,7 @@ class BEVHeight(nn.Module):
         pure host time for the ~860 tensors of the cfg-2 model: with one frame in flight (the reference harness's eval_step
         waits for every frame's boxes) the GPU idles through it.  So the walk only collects the ``_parameters`` / ``_buffers``
         dicts of the sub-modules; every forward sums the version counters and the addresses of what those dicts hold NOW
-        (~0.3 ms): an in-place write (optimiser step, ``load_state_dict``, ``copy_``) moves the first, a ``p.data = ...`` swap
+        (~0.3 ms in Python, ~0.03 ms through the compiled helper of sgv3d_amd/host_ext): an in-place write (optimiser step, ``load_state_dict``, ``copy_``) moves the first, a ``p.data = ...`` swap
         or a tensor object replaced inside a dict (a sub-module's own ``.to()`` / ``.half()``, ``_buffers[...] = ...``) the
         second.  Objects registered through ``nn.Module``'s own entry points -- ``m.weight = nn.Parameter(...)``,
         ``register_parameter`` / ``register_buffer``, a sub-module assigned, any ``load_state_dict(assign=True)`` from here, a
@@ -103,6 +104,10 @@ class BEVHeight(nn.Module):
             self._flat_age, self._flat_dirty = 0, False
             self._flat_reg = _REGISTRATIONS[0]
         self._flat_age += 1
+        fast = _host_ext.stamp()
+        if fast is not None:                         # the same three sums in C++ (sgv3d_amd/host_ext/stamp_ext.cpp): ~0.03 ms
+            n, ver, ptr = fast(walk[1])
+            return (self._flat_gen, n, ver, ptr)
         n = ver = ptr = 0
         for d in walk[1]:
             for t in d.values():

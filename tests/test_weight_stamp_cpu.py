@@ -91,3 +91,31 @@ def test_periodic_walk_catches_a_module_swapped_through_the_modules_dict():
     hn._modules['bn'] = copy.deepcopy(hn.bn)                # (no registration hook fires for a direct dict write)
     seen = [m._stamp() for _ in range(5)]
     assert seen[-1] != a and seen[-1][0] == a[0] + 1        # at the latest after _RESTAMP_EVERY forwards
+
+
+def test_compiled_stamp_helper_equals_the_python_loop():
+    """sgv3d_amd/host_ext/stamp_ext (host-only C++): the same (count, versions, addresses + ids) as the Python loop it replaces on
+    the hot path of the harness's one-frame-at-a-time eval_step; through every kind of change of the test above."""
+    import pytest
+    from sgv3d_amd import host_ext
+    fast = host_ext.stamp()
+    if fast is None:
+        pytest.skip("stamp_ext is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    m = _model()
+
+    def both():
+        a = m._stamp()
+        saved, host_ext._FN = host_ext._FN, None
+        try:
+            b = m._stamp()
+        finally:
+            host_ext._FN = saved
+        assert a == b
+        return a
+    s0 = both()
+    with torch.no_grad():
+        m.head.shared_conv.conv.weight.add_(1.0)
+    s1 = both()
+    m.backbone.height_net.bn._buffers['running_var'] = m.backbone.height_net.bn.running_var.clone()
+    s2 = both()
+    assert s0 != s1 != s2
