@@ -67,6 +67,17 @@ def static_copy(t):
         return t.clone()
 
 
+def capture_begin(graph, pool=None):
+    """``graph.capture_begin(pool=pool)`` outside inference mode.  The first live graph of a process makes torch allocate the
+    RNG generator's two graph-state tensors and EVERY later ``capture_begin`` fills them in place; allocated by a capture under
+    ``torch.inference_mode()`` (Lightning's validation loop) they are inference tensors, and the next capture under plain
+    ``torch.no_grad()`` -- a new input signature after ``trainer.validate()`` -- raises 'Inplace update to inference tensor outside
+    InferenceMode' from inside ``capture_begin``, which also leaves the generator marked as capturing (every later
+    ``torch.randn(device='cuda')`` of the process then fails).  Ordinary tensors can be filled from either mode."""
+    with torch.inference_mode(False):
+        graph.capture_begin(pool=pool) if pool is not None else graph.capture_begin()
+
+
 def _clone_aliased(obj, memo):
     """Deep copy of a nest of tensors that keeps their aliasing: tensors that share a storage become views of ONE copy of it
     (keyed by the storage, not by ``_base``: views made under ``torch.inference_mode()`` do not record their base)."""
@@ -149,10 +160,10 @@ class GraphedForward:
                     hip_ops._GRAPH_SPLIT_HOOK = None
                     self.graphs[-1].capture_end()
                     self.graphs.append(torch.cuda.CUDAGraph())
-                    self.graphs[-1].capture_begin(pool=pool)
+                    capture_begin(self.graphs[-1], pool)
                     fork_refresh()                         # a fork has to rejoin inside the graph it was recorded in: the last one
                 torch.cuda.synchronize(dev)
-                self.graphs[0].capture_begin(pool=pool)
+                capture_begin(self.graphs[0], pool)
                 try:
                     if split:
                         hip_ops._GRAPH_SPLIT_HOOK = cut
@@ -219,7 +230,8 @@ class FramePipeline:
                         with torch.cuda.stream(s), self._slot(i):
                             model(self.in_imgs[i], self.in_mats[i])      # builds the slot's geometry + plan, eagerly
                             torch.cuda.synchronize(imgs.device)
-                            with torch.cuda.graph(g, stream=s):
+                            # (outside inference mode, see capture_begin; the forward's tensors are then ordinary ones)
+                            with torch.inference_mode(False), torch.no_grad(), torch.cuda.graph(g, stream=s):
                                 self.outputs[i] = model(self.in_imgs[i], self.in_mats[i])
                         torch.cuda.current_stream(imgs.device).wait_stream(s)
                         self.graphs.append(g)

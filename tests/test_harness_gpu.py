@@ -285,6 +285,17 @@ def test_graph_captured_under_inference_mode_replays_under_no_grad(hip):
         assert len(model._graphs) == 1 and entry[1].replays == 2
     with torch.inference_mode():
         _assert_same(want, model(img, mats))
+    # a NEW signature captured under no_grad while the graph captured under inference mode is alive: torch fills the RNG generator's
+    # graph-state tensors in place at every capture_begin, and they were allocated by that first capture (pipeline.capture_begin)
+    import warnings
+    img_b2 = torch.cat([img, img2])
+    mats_b2 = S.make_mats(2, device='cuda', scale=bc['final_dim'][0] / 864)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model(img_b2, mats_b2)
+        model(img_b2, mats_b2)
+    assert len(model._graphs) == 2 and all(e[1] and e[1].replays >= 1 for e in model._graphs.values())
+    torch.randn(4, device='cuda')                            # (a failed capture_begin used to leave the generator "capturing")
     torch.cuda.synchronize()
 
 

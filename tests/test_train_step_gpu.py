@@ -218,15 +218,19 @@ def test_cfg5_share_training_step_through_one_rank_rccl():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "tools", "train_bench.py"), "--config", "cfg5", "--batch", "2", "--steps", "2",
-           "--warmup", "1"]
+           "--warmup", "1", "--dtype", "bf16"]          # the dtype BASELINE configs[4] names: mixed-precision products, f32 master weights
     base = {k: v for k, v in os.environ.items() if k not in ("SGV3D_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
     base["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     dist = _run_json(cmd, dict(base, SGV3D_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29535"), timeout=1200)
     assert dist["config"] == "cfg5" and dist["backend"] == "nccl" and dist["world_size"] == 1 and dist["collectives_active"] is True
+    assert dist["dtype"] == "bf16"
     assert dist["batch_per_gpu"] == 2 and dist["parameters"] > 90e6                      # ResNet-101 + MSCThead + BEV head
     assert dist["allreduces_launched_inside_backward"] == dist["allreduce_buckets"] >= 1
     assert dist["loss"] == dist["loss"] and 0.0 < dist["loss"] < 1e6                     # finite
-    print(f"cfg-5 share through 1-rank RCCL: {dist['ms_per_step']:.1f} ms / step at batch 2, "
+    f32 = _run_json(cmd[:-2], dict(base, SGV3D_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537"), timeout=1200)
+    assert f32["dtype"] == "f32" and abs(dist["loss"] - f32["loss"]) <= 3e-2 * abs(f32["loss"]), (dist["loss"], f32["loss"])
+    print(f"cfg-5 share through 1-rank RCCL, mixed precision: {dist['ms_per_step']:.1f} ms / step at batch 2 (f32 products: {f32['ms_per_step']:.1f} ms, "
+          f"loss {dist['loss']:.3f} / {f32['loss']:.3f}), "
           f"{dist['allreduce_bytes_per_step'] / 1e6:.0f} MB all-reduced in {dist['allreduce_buckets']} buckets, "
           f"peak memory {dist['peak_mem_gb']:.1f} GB, loss {dist['loss']:.3f}")
 
