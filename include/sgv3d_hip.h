@@ -754,6 +754,20 @@ int sgv3d_conv2d_backward_weight_batched(const sgv3d_conv_desc *desc /*host*/, c
 size_t sgv3d_conv2d_backward_weight_thin_workspace_bytes(const sgv3d_conv_desc *desc /*host*/);
 int sgv3d_conv2d_backward_weight_thin(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *dy, float *dw, void *workspace,
                                       size_t workspace_bytes, void *stream);
+/* The WHOLE backward of n such thin layers in one launch per gradient kind (csrc/conv_thin_grad.hip; the 36 final layers of the
+ * CenterHead branches, layers/heads/bev_height_head.py:75-110 through mmdet3d SeparateHead -- the reference asks cuDNN per layer and
+ * gradient).  desc: batch, in_h, in_w, cin (multiple of 4; x_ld == cin, x_coff == 0), out_h, out_w, pad, kh = kw = 3, stride = dil = 1;
+ * cout[i] in 1..4 (host); x_list[i] [batch, in_h, in_w, cin]; dy_list[i] CONTIGUOUS [batch, out_h, out_w, cout[i]]; w_list[i] OIHW
+ * [cout[i], cin, 3, 3].  Outputs, each list optional (NULL: that gradient is not computed): dx_list[i] [batch, in_h, in_w, cin]
+ * (16-byte aligned), dw_list[i] OIHW, db_list[i] [cout[i]] (= sum of dy over the pixels); single entries of dw_list / db_list may
+ * be NULL.  All lists are HOST arrays of device pointers.  Deterministic (fixed-order partial sums).  workspace (weight / bias
+ * gradients only): ..._workspace_bytes(desc, n, cout). */
+size_t sgv3d_conv3x3_thin_backward_batched_workspace_bytes(const sgv3d_conv_desc *desc /*host*/, int n, const int32_t *cout /*host*/);
+int sgv3d_conv3x3_thin_backward_batched(const sgv3d_conv_desc *desc /*host*/, int n, const int32_t *cout /*host*/,
+                                        const float *const *x_list /*host*/, const float *const *dy_list /*host*/,
+                                        const float *const *w_list /*host*/, float *const *dx_list /*host*/,
+                                        float *const *dw_list /*host*/, float *const *db_list /*host*/, void *workspace,
+                                        size_t workspace_bytes, void *stream);
 
 /* y[b, oy, ox, :] = x[b, oy/stride, ox/stride, :] where both divide evenly (and stay inside x), else 0.
  * NHWC f32, channels % 4 == 0, out >= (in - 1) * stride + 1.  The data gradient of a strided convolution is a

@@ -18,7 +18,7 @@ from . import _lib, grad_slots
 from .hip_ops import ConvDesc, PackedConv, prof, _st
 
 __all__ = ['conv2d_backward_weight', 'conv2d_backward_weight_bf16', 'conv2d_backward_weight_batched', 'conv2d_backward_data', 'zero_insert', 'conv2d', 'conv_transpose2d',
-           'multi_conv2d']
+           'multi_conv2d', 'thin_conv3x3_backward_batched', 'multi_thin_conv2d', 'thin_conv_eligible']
 
 
 def _out_hw(h, w, k, stride, pad, dil):
@@ -387,6 +387,97 @@ class _MultiConv2dNHWC(torch.autograd.Function):
         if any(ctx.needs_input_grad[1:]):
             dws = conv2d_backward_weight_batched(x, dys, 1, cin=cin, cout=cout, outs=[grad_slots.claim(w) for w in weights])
         return (dx, *dws)
+
+
+def thin_conv3x3_backward_batched(xs, dys, weights, pad=1, *, need_dx=True, need_dw=True, need_db=False, dw_outs=None, db_outs=None):
+    """The whole backward of n 3x3 / stride-1 convolutions with 1..4 output channels (sgv3d_conv3x3_thin_backward_batched): one launch
+    per gradient kind and output-channel count instead of three launches per layer.  ``xs[i]`` NHWC f32 [B, H, W, cin] (one shape for
+    all), ``dys[i]`` NHWC f32 [B, OH, OW, cout_i], ``weights[i]`` OIHW [cout_i, cin, 3, 3].  Returns (dxs | None, dws | None, dbs | None);
+    ``dw_outs`` / ``db_outs``: per-layer output buffers or None entries (gradient slots of the flat buckets)."""
+    n = len(xs)
+    assert n == len(dys) == len(weights) and 0 < n <= 48
+    B, H, W, cin = (int(v) for v in xs[0].shape)
+    _, OH, OW, _ = (int(v) for v in dys[0].shape)
+    dev = xs[0].device
+    assert (OH, OW) == _out_hw(H, W, (3, 3), 1, pad, 1)
+    couts = [int(w.shape[0]) for w in weights]
+    dys = [d.contiguous() for d in dys]
+    for x, d, w, c in zip(xs, dys, weights, couts):
+        assert x.shape == xs[0].shape and x.is_contiguous() and x.dtype == torch.float32 and x.is_cuda
+        assert tuple(d.shape) == (B, OH, OW, c) and d.dtype == torch.float32
+        assert tuple(w.shape) == (c, cin, 3, 3) and w.is_contiguous() and w.dtype == torch.float32
+    d = ConvDesc()
+    d.batch, d.in_h, d.in_w, d.cin, d.out_h, d.out_w, d.cout = B, H, W, cin, OH, OW, max(couts)
+    d.kh, d.kw, d.stride, d.pad, d.dil = 3, 3, 1, int(pad), 1
+    d.x_ld, d.x_coff, d.y_ld, d.y_coff = cin, 0, max(couts), 0
+    lib = _lib.load()
+    cc = (ctypes.c_int32 * n)(*couts)
+    arr = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    dxs = [torch.empty_like(x) for x in xs] if need_dx else None
+    dws = dbs = None
+    ws, nws = None, 0
+    if need_dw or need_db:
+        nws = lib.sgv3d_conv3x3_thin_backward_batched_workspace_bytes(ctypes.byref(d), n, cc)
+        ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
+        if need_dw:
+            dws = [_dw_buffer(None if dw_outs is None else dw_outs[i], (couts[i], cin, 3, 3), dev) for i in range(n)]
+        if need_db:
+            dbs = [_dw_buffer(None if db_outs is None else db_outs[i], (couts[i],), dev) for i in range(n)]
+    px = B * OH * OW
+    flops = sum(2.0 * px * c * cin * 9 for c in couts) * (int(bool(need_dx)) + int(bool(need_dw)))
+    with torch.cuda.device(dev), prof("conv_thin_backward_batched", flops):
+        rc = lib.sgv3d_conv3x3_thin_backward_batched(
+            ctypes.byref(d), n, cc, arr(xs), arr(dys), arr(weights), arr(dxs) if need_dx else None, arr(dws) if need_dw else None,
+            arr(dbs) if need_db else None, _lib.ptr(ws), nws, _st(xs[0]))
+    _lib.check(rc, "sgv3d_conv3x3_thin_backward_batched")
+    return dxs, dws, dbs
+
+
+def thin_conv_eligible(convs, xs):
+    """Whether ``multi_thin_conv2d`` takes these nn.Conv2d layers on these inputs."""
+    if not (1 < len(convs) <= 48 and len(convs) == len(xs)):
+        return False
+    cin = int(convs[0].weight.shape[1])
+    return all(c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1
+               and 1 <= int(c.weight.shape[0]) <= 4 and int(c.weight.shape[1]) == cin for c in convs) and cin % 4 == 0 and \
+        all(x.shape == xs[0].shape and int(x.shape[-1]) == cin and x.dtype == torch.float32 for x in xs)
+
+
+class _MultiThinConv2dNHWC(torch.autograd.Function):
+    """n independent 3x3 / stride-1 / pad-1 convolutions with 1..4 output channels each (the final layers of the CenterHead
+    branches): forward through the per-layer kernels, the 3 n gradient launches of the backward as one batched call."""
+    @staticmethod
+    def forward(ctx, n, *args):
+        xs, weights, biases = args[:n], args[n:2 * n], args[2 * n:3 * n]
+        ctx.n = n
+        ctx.save_for_backward(*xs, *weights)
+        ctx.has_bias = [b is not None for b in biases]
+        ctx.bias_refs = biases                      # (parameters: only their gradient slots are looked up in backward)
+        return tuple(PackedConv(w, stride=1, pad=1, shift=b, cin_pad=int(x.shape[-1]))(x) for x, w, b in zip(xs, weights, biases))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        xs, weights = saved[:n], saved[n:2 * n]
+        B, H, W, _ = (int(v) for v in xs[0].shape)
+        dys = [torch.zeros(B, H, W, int(w.shape[0]), dtype=torch.float32, device=xs[0].device) if d is None else d for d, w in zip(dys, weights)]
+        need_dx = any(ctx.needs_input_grad[1:1 + n])
+        need_dw = any(ctx.needs_input_grad[1 + n:1 + 2 * n])
+        need_db = any(h and g for h, g in zip(ctx.has_bias, ctx.needs_input_grad[1 + 2 * n:1 + 3 * n]))
+        dxs, dws, dbs = thin_conv3x3_backward_batched(
+            xs, dys, [w.detach() for w in weights], 1, need_dx=need_dx, need_dw=need_dw, need_db=need_db,
+            dw_outs=[grad_slots.claim(w) for w in weights] if need_dw else None,
+            db_outs=[grad_slots.claim(b) if h else None for b, h in zip(ctx.bias_refs, ctx.has_bias)] if need_db else None)
+        none = [None] * n
+        dbs = none if dbs is None else [g if h else None for g, h in zip(dbs, ctx.has_bias)]
+        return (None, *(dxs or none), *(dws or none), *dbs)
+
+
+def multi_thin_conv2d(xs, convs):
+    """[conv(x) for x, conv in zip(xs, convs)] for nn.Conv2d layers that satisfy ``thin_conv_eligible``; see _MultiThinConv2dNHWC."""
+    n = len(convs)
+    return _MultiThinConv2dNHWC.apply(n, *[x.contiguous() for x in xs], *[c.weight for c in convs], *[c.bias for c in convs])
 
 
 def multi_conv2d(x, weights):

@@ -1,0 +1,334 @@
+// Backward of n "thin" 3x3 convolutions in ONE launch per gradient kind (gfx950): stride 1, dilation 1, cin -> 1..4 output
+// channels -- the 36 final layers of the CenterHead branches (64 -> 1 / 2 / 3 at 256 x 256; reference:
+// layers/heads/bev_height_head.py:75-110 through mmdet3d SeparateHead, whose backward the reference leaves to cuDNN, one call
+// per layer and gradient).  Per layer the work is one pass over a 33 MB hidden map with a handful of FMAs per element: alone a
+// launch is a few microseconds of memory time behind ~15 us of latency (two units per wave, nothing to overlap with), and the
+// MFMA kernels run these shapes at 1-6 TFLOP/s (an MFMA tile would be 94-98 % padding).  Batched over the layers
+// (blockIdx.y / blockIdx.z = layer) every SIMD holds 4 waves of independent work:
+//
+//   thin_wgrad_kernel   dW[c][ci][r][s] = sum_p dY[p][c] X[p + (r, s) - pad][ci]  and  db[c] = sum_p dY[p][c]
+//                       a lane owns one input channel, a wave walks 32-pixel row segments: the 3 x 18 input values of its channel
+//                       in registers (coalesced 256-byte rows), the dY values of 16 pixels in ONE coalesced load, broadcast
+//                       with v_readlane, 9 x COUT (+ COUT for the bias) FMAs per pixel.  Waves meet in LDS in wave order, one
+//                       partial set per workgroup in the workspace, thin_reduce_kernel adds them in workgroup order
+//                       (deterministic) into OIHW / the bias gradient.
+//   thin_dgrad_kernel   dX[p][ci] = sum_{r,s,c} dY[p + pad - (r, s)][c] W[c][ci][r][s]
+//                       a lane owns 4 consecutive input channels of 4 consecutive pixels (16 lanes = one 256-byte pixel row of 64
+//                       channels), its 9 x COUT x 4 weights in registers for the whole launch, the 3 x 6 x COUT dY values of a
+//                       unit from L1 / L2 (dY of a layer is 0.5-1.5 MB), 16-byte stores.  No LDS, no barrier.
+//
+// Bound: HBM (X read once per layer for dW, dX written once per layer: 33.5 MB each at batch 2 of cfg-2).
+#include "common.hpp"
+
+using namespace sgv3d;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kMaxLayers = 48;
+constexpr int kSeg = 32;             // pixels per unit of the weight-gradient kernel
+constexpr int kDSeg = 16;            // pixels per unit of the data-gradient kernel (4 lanes-groups x 4 pixels)
+
+struct ThinBArgs {
+    const float *x[kMaxLayers];
+    const float *dy[kMaxLayers];
+    const float *w[kMaxLayers];
+    float *dx[kMaxLayers];
+    float *dw[kMaxLayers];
+    float *db[kMaxLayers];
+    unsigned char cout[kMaxLayers];
+    unsigned char group[kMaxLayers]; // the layers of the launch's output-channel count (the kernels are instantiated per count)
+    float *ws;
+    int n, batch, in_h, in_w, out_h, out_w, pad, cin;
+    int segs, units, wgs;            // weight gradient: 32-pixel segments per output row, units per layer, workgroups per layer
+    int dsegs, dunits;               // data gradient: 16-pixel segments per input row, units per layer
+    unsigned x_bytes;                // extent of one x / dx tensor
+    unsigned ypix;                   // batch * out_h * out_w (dy of layer i holds ypix * cout[i] floats)
+};
+
+constexpr unsigned kOob = 0x40000000u;     // byte offset beyond every buffer here (extents < 1 GiB are required), also after small immediates
+
+// ------------------------------------------------------------------------------------------------ weight + bias gradient
+template <int COUT>
+__device__ __forceinline__ void thin_wgrad_body(const ThinBArgs &a, const int layer, float (*red)[10 * COUT][64]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 4 + wave, waves = a.wgs * 4;
+    const int ci = blockIdx.y * 64 + lane;
+    const bool ci_ok = ci < a.cin;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x[layer], 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy[layer], 0, (int)(a.ypix * COUT * 4u), 0x00020000);
+    float acc[10][COUT];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[t][c] = 0.f;
+    const unsigned x_c = (unsigned)ci * 4u, xrow = (unsigned)a.cin * 4u;
+    for (int u = gw; u < a.units; u += waves) {
+        const int seg = u % a.segs, t0 = u / a.segs;
+        const int oy = t0 % a.out_h, img = t0 / a.out_h;
+        const int ox_begin = seg * kSeg, ox_end = min(ox_begin + kSeg, a.out_w);
+        const int iy0 = oy - a.pad;
+        unsigned rowoff[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = iy0 + r;
+            rowoff[r] = (ci_ok && (unsigned)iy < (unsigned)a.in_h) ? (unsigned)((img * a.in_h + iy) * a.in_w) * xrow + x_c : kOob;
+        }
+        auto load_x = [&](int r, int ix) -> float {
+            const unsigned off = (rowoff[r] != kOob && (unsigned)ix < (unsigned)a.in_w) ? rowoff[r] + (unsigned)ix * xrow : kOob;
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off, 0, 0));
+        };
+        float w[3][18];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            w[r][0] = load_x(r, ox_begin - a.pad);
+            w[r][1] = load_x(r, ox_begin - a.pad + 1);
+        }
+        const unsigned ybase = (unsigned)((img * a.out_h + oy) * a.out_w) * (unsigned)(COUT * 4);
+        for (int ox0 = ox_begin; ox0 < ox_end; ox0 += 16) {
+            // dY of 16 pixels: lane l holds element l of the row's flat (pixel, channel) array starting at pixel ox0
+            const int px = lane / COUT;
+            const bool yok = ox0 + px < ox_end && px < 16;     // pixels past the segment's end multiply dY = 0
+            const float dyv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                y_rsrc, yok ? ybase + (unsigned)(ox0 * COUT + lane) * 4u : kOob, 0, 0));
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[r][2 + j] = load_x(r, ox0 - a.pad + 2 + j);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) {
+                    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dyv), j * COUT + c));
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int s2 = 0; s2 < 3; ++s2) acc[r * 3 + s2][c] = __builtin_fmaf(d, w[r][j + s2], acc[r * 3 + s2][c]);
+                    acc[9][c] += d;                             // the bias gradient (the same sum in every lane)
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { w[r][0] = w[r][16]; w[r][1] = w[r][17]; }
+        }
+    }
+    // the four waves of the workgroup meet in LDS and are added in wave order; one partial set per workgroup
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) red[wave][t * COUT + c][lane] = acc[t][c];
+    __syncthreads();
+    float *ws = a.ws + ((size_t)layer * a.wgs + blockIdx.x) * (size_t)(10 * 4) * a.cin;
+    for (int e = threadIdx.x; e < 10 * COUT * 64; e += 256) {
+        const int l = e & 63, tc = e >> 6;
+        const int cc = blockIdx.y * 64 + l;
+        if (cc < a.cin) ws[(size_t)tc * a.cin + cc] = ((red[0][tc][l] + red[1][tc][l]) + red[2][tc][l]) + red[3][tc][l];
+    }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinBArgs a) {
+    __shared__ float red[4][10 * COUT][64];
+    thin_wgrad_body<COUT>(a, a.group[blockIdx.z], red);
+}
+
+// dw[c][ci][tap] / db[c] = sum over the layer's workgroups (in order) of ws[layer][workgroup][tap (9 = bias)][c][ci]
+__global__ __launch_bounds__(256) void thin_reduce_kernel(const ThinBArgs a) {
+    const int layer = blockIdx.y, cout = a.cout[layer];
+    const int total = 10 * cout * a.cin;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float *ws = a.ws + (size_t)layer * a.wgs * (size_t)(10 * 4) * a.cin + i;
+    const size_t stride = (size_t)(10 * 4) * a.cin;
+    float v = 0.f;
+    int p = 0;
+    for (; p + 8 <= a.wgs; p += 8) {                           // eight independent loads in flight, added in order
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = ws[(size_t)(p + j) * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += t[j];
+    }
+    for (; p < a.wgs; ++p) v += ws[(size_t)p * stride];
+    const int ci = i % a.cin, r = i / a.cin;
+    const int c = r % cout, tap = r / cout;
+    if (tap < 9) {
+        if (a.dw[layer]) a.dw[layer][((size_t)c * a.cin + ci) * 9 + tap] = v;
+    } else if (ci == 0 && a.db[layer]) {
+        a.db[layer][c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------- data gradient
+template <int COUT>
+__device__ __forceinline__ void thin_dgrad_body(const ThinBArgs &a, const int layer) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane & 15, g = lane >> 4;
+    const int ci = blockIdx.z * 64 + q * 4;
+    const bool q_ok = ci < a.cin;                              // (cin is a multiple of 4)
+    // this lane's weights W[c][ci .. ci + 3][r][s], kept for the whole launch
+    f32x2 wlo[9][COUT], whi[9][COUT];
+    {
+        const float *w = a.w[layer];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) {
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = q_ok ? w[((size_t)c * a.cin + ci + k) * 9 + t] : 0.f;
+                wlo[t][c] = f32x2{e[0], e[1]};
+                whi[t][c] = f32x2{e[2], e[3]};
+            }
+    }
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy[layer], 0, (int)(a.ypix * COUT * 4u), 0x00020000);
+    float *dx = a.dx[layer];
+    const int stride_u = gridDim.x * 4;
+    for (int u = blockIdx.x * 4 + wave; u < a.dunits; u += stride_u) {
+        const int xs = u % a.dsegs, t0 = u / a.dsegs;
+        const int iy = t0 % a.in_h, img = t0 / a.in_h;
+        const int px0 = xs * kDSeg + g * 4;
+        f32x2 lo[4], hi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lo[k] = f32x2{0.f, 0.f}; hi[k] = f32x2{0.f, 0.f}; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int oy = iy + a.pad - r;
+            const bool row_ok = (unsigned)oy < (unsigned)a.out_h;
+            const unsigned rowbase = (unsigned)((img * a.out_h + oy) * a.out_w);
+            float d[6][COUT];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int ox = px0 + a.pad - 2 + j;
+                const unsigned off = (row_ok && (unsigned)ox < (unsigned)a.out_w) ? (rowbase + (unsigned)ox) * (unsigned)(COUT * 4) : kOob;
+#pragma unroll
+                for (int c = 0; c < COUT; ++c)
+                    d[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y_rsrc, off + (unsigned)c * 4u, 0, 0));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int c = 0; c < COUT; ++c) {
+                        const float dv = d[k + 2 - s][c];
+                        const f32x2 d2 = f32x2{dv, dv};
+                        lo[k] = __builtin_elementwise_fma(d2, wlo[r * 3 + s][c], lo[k]);
+                        hi[k] = __builtin_elementwise_fma(d2, whi[r * 3 + s][c], hi[k]);
+                    }
+        }
+        if (q_ok) {
+            float *row = dx + ((size_t)(img * a.in_h + iy) * a.in_w) * a.cin + ci;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (px0 + k < a.in_w) *reinterpret_cast<f32x4 *>(row + (size_t)(px0 + k) * a.cin) = f32x4{lo[k][0], lo[k][1], hi[k][0], hi[k][1]};
+        }
+    }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void thin_dgrad_kernel(const ThinBArgs a) {
+    thin_dgrad_body<COUT>(a, a.group[blockIdx.y]);
+}
+
+int fill(const sgv3d_conv_desc *d, int n, const int32_t *cout, ThinBArgs &a) {
+    SGV3D_REQUIRE(d && cout, "conv3x3_thin_backward_batched: null descriptor / cout list");
+    SGV3D_REQUIRE(n >= 1 && n <= kMaxLayers, "conv3x3_thin_backward_batched: 1 .. %d layers", kMaxLayers);
+    SGV3D_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad >= 0 && d->pad <= 2,
+                  "conv3x3_thin_backward_batched: 3x3 / stride 1 / dilation 1 layers, pad 0 .. 2");
+    SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cin % 4 == 0 && d->x_ld == d->cin && d->x_coff == 0,
+                  "conv3x3_thin_backward_batched: contiguous NHWC inputs with a channel count that is a multiple of 4");
+    SGV3D_REQUIRE(d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2 && d->out_h > 0 && d->out_w > 0,
+                  "conv3x3_thin_backward_batched: output size does not belong to this input size");
+    const unsigned long long xb = (unsigned long long)d->batch * d->in_h * d->in_w * d->cin * 4ull;
+    const unsigned long long yp = (unsigned long long)d->batch * d->out_h * d->out_w;
+    SGV3D_REQUIRE(xb < kOob && yp * 16ull < kOob, "conv3x3_thin_backward_batched: tensors must be smaller than 1 GiB");
+    a = ThinBArgs{};
+    for (int i = 0; i < n; ++i) {
+        SGV3D_REQUIRE(cout[i] >= 1 && cout[i] <= 4, "conv3x3_thin_backward_batched: 1 .. 4 output channels per layer (layer %d has %d)", i, cout[i]);
+        a.cout[i] = (unsigned char)cout[i];
+    }
+    a.n = n; a.batch = d->batch; a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w; a.pad = d->pad; a.cin = d->cin;
+    a.segs = cdiv(d->out_w, kSeg);
+    a.units = d->batch * d->out_h * a.segs;
+    // about four waves per SIMD over the whole launch (1024 workgroups of 4 waves on 256 CUs), at least one unit per wave
+    const int chunks = cdiv(d->cin, 64);
+    int wgs = cdiv(1024, n * chunks);
+    wgs = wgs < 1 ? 1 : wgs;
+    wgs = wgs > cdiv(a.units, 4) ? cdiv(a.units, 4) : wgs;
+    a.wgs = wgs;
+    a.dsegs = cdiv(d->in_w, kDSeg);
+    a.dunits = d->batch * d->in_h * a.dsegs;
+    a.x_bytes = (unsigned)xb; a.ypix = (unsigned)yp;
+    return SGV3D_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sgv3d_conv3x3_thin_backward_batched_workspace_bytes(const sgv3d_conv_desc *d, int n, const int32_t *cout) {
+    ThinBArgs a;
+    if (fill(d, n, cout, a) != SGV3D_OK) return 0;
+    return (size_t)n * a.wgs * (10 * 4) * a.cin * sizeof(float);
+}
+
+extern "C" int sgv3d_conv3x3_thin_backward_batched(const sgv3d_conv_desc *d, int n, const int32_t *cout, const float *const *x_list,
+                                                   const float *const *dy_list, const float *const *w_list, float *const *dx_list,
+                                                   float *const *dw_list, float *const *db_list, void *workspace, size_t workspace_bytes,
+                                                   void *stream) {
+    ThinBArgs a;
+    if (int rc = fill(d, n, cout, a)) return rc;
+    SGV3D_REQUIRE(dy_list, "conv3x3_thin_backward_batched: null dy list");
+    const bool want_w = dw_list != nullptr || db_list != nullptr, want_x = dx_list != nullptr;
+    SGV3D_REQUIRE(!want_w || (x_list && workspace), "conv3x3_thin_backward_batched: weight / bias gradients need the inputs and the workspace");
+    SGV3D_REQUIRE(!want_x || w_list, "conv3x3_thin_backward_batched: data gradients need the weights");
+    const size_t need = (size_t)n * a.wgs * (10 * 4) * a.cin * sizeof(float);
+    SGV3D_REQUIRE(!want_w || workspace_bytes >= need, "conv3x3_thin_backward_batched: workspace too small (%zu < %zu)", workspace_bytes, need);
+    for (int i = 0; i < n; ++i) {
+        SGV3D_REQUIRE(dy_list[i] && (!want_w || x_list[i]) && (!want_x || (w_list[i] && dx_list[i])), "conv3x3_thin_backward_batched: null pointer (layer %d)", i);
+        SGV3D_REQUIRE(!want_x || (reinterpret_cast<uintptr_t>(dx_list[i]) & 15) == 0, "conv3x3_thin_backward_batched: dx must be 16-byte aligned (layer %d)", i);
+        a.dy[i] = dy_list[i];
+        a.x[i] = want_w ? x_list[i] : nullptr;
+        a.w[i] = want_x ? w_list[i] : nullptr;
+        a.dx[i] = want_x ? dx_list[i] : nullptr;
+        a.dw[i] = dw_list ? dw_list[i] : nullptr;
+        a.db[i] = db_list ? db_list[i] : nullptr;
+    }
+    a.ws = static_cast<float *>(workspace);
+    hipStream_t st = as_stream(stream);
+    const int chunks = cdiv(a.cin, 64);
+    int dwgs = cdiv(1024, n * chunks);
+    dwgs = dwgs < 1 ? 1 : dwgs;
+    dwgs = dwgs > cdiv(a.dunits, 4) ? cdiv(a.dunits, 4) : dwgs;
+    for (int c = 1; c <= 4; ++c) {                       // one launch per output-channel count present (CenterHead: 1, 2, 3)
+        int m = 0;
+        for (int i = 0; i < n; ++i)
+            if (a.cout[i] == c) a.group[m++] = (unsigned char)i;
+        if (m == 0) continue;
+        if (want_w) {
+            const dim3 grid(a.wgs, chunks, m);
+            switch (c) {
+                case 1: thin_wgrad_kernel<1><<<grid, 256, 0, st>>>(a); break;
+                case 2: thin_wgrad_kernel<2><<<grid, 256, 0, st>>>(a); break;
+                case 3: thin_wgrad_kernel<3><<<grid, 256, 0, st>>>(a); break;
+                default: thin_wgrad_kernel<4><<<grid, 256, 0, st>>>(a); break;
+            }
+            if (int rc = check_launch("thin_wgrad_kernel")) return rc;
+        }
+        if (want_x) {
+            const dim3 grid(dwgs, m, chunks);
+            switch (c) {
+                case 1: thin_dgrad_kernel<1><<<grid, 256, 0, st>>>(a); break;
+                case 2: thin_dgrad_kernel<2><<<grid, 256, 0, st>>>(a); break;
+                case 3: thin_dgrad_kernel<3><<<grid, 256, 0, st>>>(a); break;
+                default: thin_dgrad_kernel<4><<<grid, 256, 0, st>>>(a); break;
+            }
+            if (int rc = check_launch("thin_dgrad_kernel")) return rc;
+        }
+    }
+    if (want_w) {
+        thin_reduce_kernel<<<dim3(cdiv(10 * 4 * a.cin, 256), n), 256, 0, st>>>(a);
+        if (int rc = check_launch("thin_reduce_kernel")) return rc;
+    }
+    return SGV3D_OK;
+}

@@ -28,6 +28,8 @@ Layer semantics follow the eval-mode HIP path module by module (layers/blocks.py
 layers/heads/bev_height_head.py); the only differences are the ones training mode implies in the reference:
 BatchNorm uses and updates batch statistics, Dropout(0.5) in the ASPP is active.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -41,6 +43,8 @@ from .layers.backbones import bsm_lss_fpn, lss_fpn
 from .ops.voxel_pooling import voxel_pooling
 
 __all__ = ['bevheight_train_forward']
+
+THIN_BATCHED = os.environ.get("SGV3D_THIN_BATCHED", "1") != "0"      # 0: the CenterHead's final layers one by one (diagnostic)
 
 
 def _nchw(x):            # NHWC tensor -> NCHW view (channels-last strides)
@@ -265,19 +269,29 @@ def head_forward(head, bev):
                all(c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.bias is None and
                    c.weight.shape == firsts[0].weight.shape and c.weight.shape[0] % 4 == 0 for c in firsts))
     first_out = conv_grad.multi_conv2d(shared, [c.weight for c in firsts]) if batched else None
+    hidden, k = [], 0
+    for _, _, seq in seqs:
+        if batched:
+            y = bn(seq[0].bn, first_out[k], relu=True)
+            k += 1
+        else:
+            y = shared
+            for layer in seq[:-1]:
+                y = bn(layer.bn, conv(layer.conv, y), relu=True)
+        hidden.append(y)
+    # ... and the final layers (64 -> 1..3 channels) have their whole backward -- data, weight and bias gradients of all branches -- as
+    # one batched call (conv_grad.multi_thin_conv2d; three launches per layer otherwise, each a few microseconds of work)
+    finals = [seq[-1] for _, _, seq in seqs]
+    if THIN_BATCHED and conv_grad.thin_conv_eligible(finals, hidden):
+        outs = conv_grad.multi_thin_conv2d(hidden, finals)
+    else:
+        outs = [conv(f, y) for f, y in zip(finals, hidden)]
     ret, k = [], 0
     for th in head.task_heads:
         d = {}
         for name in th.heads:
-            seq = getattr(th, name)
-            if batched:
-                y = bn(seq[0].bn, first_out[k], relu=True)
-                k += 1
-            else:
-                y = shared
-                for layer in seq[:-1]:
-                    y = bn(layer.bn, conv(layer.conv, y), relu=True)
-            d[name] = _nchw(conv(seq[-1], y))                              # [B, c, H, W] like the reference
+            d[name] = _nchw(outs[k])                                       # [B, c, H, W] like the reference
+            k += 1
         ret.append([d])
     return tuple(ret)
 

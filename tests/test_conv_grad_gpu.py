@@ -284,3 +284,70 @@ def test_bias_gradient_and_chain():
     for got, want in zip(params, ref):
         wg = want.grad
         assert float((got.grad.cpu().double() - wg).abs().max()) <= 5e-5 * float(wg.abs().max())
+
+
+@pytest.mark.parametrize("shape", [
+    # B, cin, H, W, pad, couts
+    (2, 64, 20, 28, 1, (2, 1, 3, 2, 2, 1)),       # one CenterHead task: reg, height, dim, rot, vel, heatmap
+    (1, 64, 9, 75, 1, (4, 3, 3)),                 # rows of five 16-pixel / three 32-pixel segments with ragged ends, 4 channels
+    (3, 24, 7, 17, 0, (1, 2)),                    # cin below one 64-channel chunk, no padding
+    (1, 132, 6, 33, 2, (3, 4, 1, 2)),             # three channel chunks (the last one 4 channels), padding 2
+])
+def test_thin_backward_batched(shape):
+    """The whole backward of n thin 3x3 layers in one call (sgv3d_conv3x3_thin_backward_batched): data, weight and bias gradients
+    against float64 autograd, bitwise repeatable, exact on small integers; and each gradient kind on its own."""
+    B, cin, H, W, pad, couts = shape
+    g = torch.Generator().manual_seed(sum(shape[:5]) + len(couts))
+    n = len(couts)
+    oh, ow = H + 2 * pad - 2, W + 2 * pad - 2
+    xs = [torch.randn(B, H, W, cin, generator=g) for _ in range(n)]
+    dys = [torch.randn(B, oh, ow, c, generator=g) for c in couts]
+    ws = [torch.randn(c, cin, 3, 3, generator=g) / 8 for c in couts]
+    cu = lambda ts: [t.cuda() for t in ts]
+    dxs, dws, dbs = conv_grad.thin_conv3x3_backward_batched(cu(xs), cu(dys), cu(ws), pad, need_dx=True, need_dw=True, need_db=True)
+    for x, dy, w, dx, dw, db in zip(xs, dys, ws, dxs, dws, dbs):
+        _, dx_ref, dw_ref = _reference(x, w, dy, 1, pad, 1)
+        assert float((dx.cpu().double() - dx_ref).abs().max()) <= 2e-5 * float(dx_ref.abs().max())
+        assert float((dw.cpu().double() - dw_ref).abs().max()) <= 2e-5 * float(dw_ref.abs().max())
+        db_ref = dy.double().sum((0, 1, 2))
+        assert float((db.cpu().double() - db_ref).abs().max()) <= 2e-5 * max(1.0, float(db_ref.abs().max()))
+    again = conv_grad.thin_conv3x3_backward_batched(cu(xs), cu(dys), cu(ws), pad, need_dx=True, need_dw=True, need_db=True)
+    for a, b in zip(dxs + dws + dbs, again[0] + again[1] + again[2]):
+        assert torch.equal(a, b)
+    only_x = conv_grad.thin_conv3x3_backward_batched(cu(xs), cu(dys), cu(ws), pad, need_dx=True, need_dw=False, need_db=False)
+    assert only_x[1] is None and only_x[2] is None and all(torch.equal(a, b) for a, b in zip(only_x[0], dxs))
+    only_b = conv_grad.thin_conv3x3_backward_batched(cu(xs), cu(dys), cu(ws), pad, need_dx=False, need_dw=False, need_db=True)
+    assert only_b[0] is None and only_b[1] is None and all(torch.equal(a, b) for a, b in zip(only_b[2], dbs))
+    xi = [torch.randint(-3, 4, (B, H, W, cin), generator=g).float() for _ in range(n)]
+    dyi = [torch.randint(-2, 3, (B, oh, ow, c), generator=g).float() for c in couts]
+    wi = [torch.randint(-2, 3, (c, cin, 3, 3), generator=g).float() for c in couts]
+    dxs, dws, dbs = conv_grad.thin_conv3x3_backward_batched(cu(xi), cu(dyi), cu(wi), pad, need_dx=True, need_dw=True, need_db=True)
+    for x, dy, w, dx, dw, db in zip(xi, dyi, wi, dxs, dws, dbs):
+        _, dx_ref, dw_ref = _reference(x, w, dy, 1, pad, 1)
+        assert torch.equal(dx.cpu().double(), dx_ref) and torch.equal(dw.cpu().double(), dw_ref)
+        assert torch.equal(db.cpu().double(), dy.double().sum((0, 1, 2)))
+
+
+def test_multi_thin_conv2d_matches_the_per_layer_function():
+    """conv_grad.multi_thin_conv2d (what the CenterHead's final layers use in training): outputs bitwise the per-layer conv2d,
+    gradients of inputs / weights / biases against the per-layer autograd function (float32 summation order apart)."""
+    import torch.nn as nn
+    torch.manual_seed(5)
+    B, H, W, cin = 2, 24, 40, 64
+    couts = (2, 1, 3, 2)
+    convs = [nn.Conv2d(cin, c, 3, padding=1).cuda() for c in couts]
+    xs = [torch.randn(B, H, W, cin, device='cuda').requires_grad_(True) for _ in couts]
+    ups = [torch.randn(B, H, W, c, device='cuda') for c in couts]
+    assert conv_grad.thin_conv_eligible(convs, xs)
+    outs = conv_grad.multi_thin_conv2d(xs, convs)
+    sum((o * u).sum() for o, u in zip(outs, ups)).backward()
+    got = [(o.detach(), x.grad.clone(), c.weight.grad.clone(), c.bias.grad.clone()) for o, x, c in zip(outs, xs, convs)]
+    for x, c in zip(xs, convs):
+        x.grad = None; c.weight.grad = None; c.bias.grad = None
+    ref = [conv_grad.conv2d(x, c.weight, c.bias, 1, 1, 1) for x, c in zip(xs, convs)]
+    sum((o * u).sum() for o, u in zip(ref, ups)).backward()
+    for (o, dx, dw, db), r, x, c in zip(got, ref, xs, convs):
+        assert torch.equal(o, r.detach())
+        for a, b in ((dx, x.grad), (dw, c.weight.grad), (db, c.bias.grad)):
+            assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()), (a.shape, float((a - b).abs().max()), float(b.abs().max()))
+    assert not conv_grad.thin_conv_eligible(convs + [nn.Conv2d(cin, 8, 3, padding=1).cuda()], xs + [xs[0]])
