@@ -786,6 +786,12 @@ int sgv3d_weight_rot180_transpose(const float *w, int cout, int cin, int kh, int
 int sgv3d_adamw_step(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int step,
                      float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                      void *stream);
+/* ... with the step-dependent scalars read from DEVICE memory at kernel start: hyper = f32 [lr, lr / (1 - beta1^step),
+ * 1 / sqrt(1 - beta2^step)] -- for a launch recorded in a hipGraph (the recorded step follows the step counter and the learning-rate
+ * schedule of exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:298-305 through a 12-byte copy).  Bitwise
+ * sgv3d_adamw_step. */
+int sgv3d_adamw_step_dev(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *hyper,
+                         float beta1, float beta2, float eps, float weight_decay, float grad_scale, void *stream);
 
 /* Training-mode BatchNorm2d over NHWC f32 [pixels, channels] (channels % 4 == 0) fused with the residual add and the
  * ReLU that follow it in the reference's blocks: y = relu(gamma * (x - mean) / sqrt(var + eps) + beta + residual) with

@@ -316,7 +316,9 @@ def _dgrad_stride2(dy, weight, in_hw, pad):
                 outs.append(torch.zeros(B, max(n_y, 1), max(n_x, 1), (cin + 3) // 4 * 4, dtype=torch.float32, device=dy.device))
                 geo.append((max(n_y, 1), max(n_x, 1), 0, 0))
                 continue
-            sub = w[:, :, ty][:, :, :, tx].transpose(0, 1).contiguous()                  # [cin, cout, Ty, Tx]
+            # (taps are min, min + 2, ... in descending order: a strided slice and a flip -- indexing with the Python lists would build
+            # index tensors on the host and copy them over, which a stream capture cannot record)
+            sub = w[:, :, min(ty)::2, min(tx)::2].flip(2, 3).transpose(0, 1).contiguous()   # [cin, cout, Ty, Tx]
             # one symmetric padding that covers the low side of both axes and yields enough outputs on the high side
             need = lambda P, T, n_in, n_out: max(P, 0, n_out - n_in + T - 1 - P)
             pp = max(need(p_y, len(ty), hc, n_y), need(p_x, len(tx), wc, n_x))

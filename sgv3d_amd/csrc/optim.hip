@@ -15,6 +15,7 @@ struct AdamArgs {
     const float *g;
     long long n;
     float lr, beta1, beta2, eps, wd, grad_scale, step_size, inv_sqrt_bc2;
+    const float *hyper;      // device [lr, step_size, inv_sqrt_bc2] read at kernel start instead of the three host scalars (sgv3d_adamw_step_dev)
 };
 
 __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, const AdamArgs &a) {
@@ -26,7 +27,8 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
     p -= a.step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+    if (a.hyper) { a.lr = a.hyper[0]; a.step_size = a.hyper[1]; a.inv_sqrt_bc2 = a.hyper[2]; }
     const long long n4 = a.n / 4;
     float4 *p4 = reinterpret_cast<float4 *>(a.p), *m4 = reinterpret_cast<float4 *>(a.m), *v4 = reinterpret_cast<float4 *>(a.v);
     const float4 *g4 = reinterpret_cast<const float4 *>(a.g);
@@ -59,6 +61,25 @@ extern "C" int sgv3d_adamw_step(long long n, float *param, const float *grad, fl
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     a.step_size = (float)((double)lr / bc1);
     a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const long long blocks = (n / 4 + 255) / 256 + 1;
+    adamw_kernel<<<(int)(blocks < 4096 ? blocks : 4096), 256, 0, as_stream(stream)>>>(a);
+    return check_launch("adamw_kernel");
+}
+
+// The same update with the step-dependent scalars in DEVICE memory: hyper = [lr, lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)] (f32,
+// what sgv3d_adamw_step computes on the host from step and lr).  A launch recorded in a hipGraph (train_step.GraphedTrainStep) then
+// follows the step counter and the learning-rate schedule through a 12-byte copy per replay.  Bitwise sgv3d_adamw_step.
+extern "C" int sgv3d_adamw_step_dev(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                                    const float *hyper, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                    void *stream) {
+    SGV3D_REQUIRE(n >= 0, "adamw_step_dev: bad n");
+    if (n == 0) return SGV3D_OK;
+    SGV3D_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper, "adamw_step_dev: null pointer");
+    SGV3D_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                  "adamw_step_dev: buffers must be 16-byte aligned");
+    AdamArgs a{};
+    a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n; a.hyper = hyper;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.grad_scale = grad_scale;
     const long long blocks = (n / 4 + 255) / 256 + 1;
     adamw_kernel<<<(int)(blocks < 4096 ? blocks : 4096), 256, 0, as_stream(stream)>>>(a);
     return check_launch("adamw_kernel");

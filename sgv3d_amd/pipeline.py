@@ -67,15 +67,20 @@ def static_copy(t):
         return t.clone()
 
 
-def capture_begin(graph, pool=None):
+def capture_begin(graph, pool=None, error_mode=None):
     """``graph.capture_begin(pool=pool)`` outside inference mode.  The first live graph of a process makes torch allocate the
     RNG generator's two graph-state tensors and EVERY later ``capture_begin`` fills them in place; allocated by a capture under
     ``torch.inference_mode()`` (Lightning's validation loop) they are inference tensors, and the next capture under plain
     ``torch.no_grad()`` -- a new input signature after ``trainer.validate()`` -- raises 'Inplace update to inference tensor outside
     InferenceMode' from inside ``capture_begin``, which also leaves the generator marked as capturing (every later
-    ``torch.randn(device='cuda')`` of the process then fails).  Ordinary tensors can be filled from either mode."""
+    ``torch.randn(device='cuda')`` of the process then fails).  Ordinary tensors can be filled from either mode.
+    ``error_mode``: torch's ``capture_error_mode`` ("global" by default; "thread_local" lets OTHER threads -- the process group's
+    watchdog polling its events -- keep making calls a capture forbids)."""
+    kw = {} if pool is None else {"pool": pool}
+    if error_mode is not None:
+        kw["capture_error_mode"] = error_mode
     with torch.inference_mode(False):
-        graph.capture_begin(pool=pool) if pool is not None else graph.capture_begin()
+        graph.capture_begin(**kw)
 
 
 def _clone_aliased(obj, memo):

@@ -37,7 +37,7 @@ from . import _lib, grad_slots
 
 DIRECT_GRADS = os.environ.get("SGV3D_DIRECT_GRADS", "1") != "0"   # 0: every gradient goes through autograd's accumulate add
 
-__all__ = ['FlatParams', 'DataParallelAdamW', 'reference_lr', 'multistep_lr']
+__all__ = ['FlatParams', 'DataParallelAdamW', 'GraphedTrainStep', 'reference_lr', 'multistep_lr']
 
 
 def reference_lr(batch_size_per_device, gpus, basic_lr_per_img=2e-4 / 64):
@@ -114,6 +114,9 @@ class DataParallelAdamW:
         self.state = [(torch.zeros_like(p), torch.zeros_like(p)) for p, _, _ in self.flat.buckets]
         self.steps = 0
         self._pending = []
+        self._hyper = None            # device [lr, lr / bc1, 1 / sqrt(bc2)] of the step about to run (GraphedTrainStep)
+        self._hyper_host = None
+        self._in_graph = False        # inside GraphedTrainStep's capture: no collectives from the gradient hooks
         if self._collectives():
             self.broadcast_parameters()
 
@@ -200,6 +203,8 @@ class DataParallelAdamW:
                                       "changing which parameters train")
             self._hold.add(bi)
             return
+        if self._in_graph:
+            return
         self._left[bi] -= 1
         if self._left[bi] < 0:
             raise _lib.SGV3DError("overlap_with_backward: a second backward ran before step(); the bucket all-reduces of "
@@ -234,15 +239,37 @@ class DataParallelAdamW:
             self._unused = {id(p) for _, _, entries in self.flat.buckets for p, _, _ in entries} - self._fired
             self._learned = True
 
-    def step(self, lr=None):
+    def stage_hyper(self, lr=None):
+        """Advance the step counter and put the scalars of that step -- [lr, lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)], computed as
+        sgv3d_adamw_step computes them -- into the device buffer the recorded update reads (one 12-byte copy on the current stream).
+        ``step(recorded=True)`` launches the update against that buffer."""
+        import math
+        import struct
+        lr = self.lr if lr is None else float(lr)
+        self.steps += 1
+        f32 = lambda v: struct.unpack('f', struct.pack('f', v))[0]
+        b1, b2 = f32(self.betas[0]), f32(self.betas[1])           # (the C entry point receives the betas as floats)
+        bc1, bc2 = 1.0 - math.pow(b1, self.steps), 1.0 - math.pow(b2, self.steps)
+        dev = self.flat.buckets[0][0].device
+        if self._hyper is None:
+            self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+            self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        self._hyper_host[0], self._hyper_host[1], self._hyper_host[2] = f32(lr), f32(lr) / bc1, 1.0 / math.sqrt(bc2)
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
+
+    def step(self, lr=None, recorded=False):
         """One AdamW update of every bucket with the averaged gradients (call ``all_reduce_grads`` first when the
-        process group has more than one rank)."""
+        process group has more than one rank).  ``recorded``: the step-dependent scalars come from the device buffer that
+        ``stage_hyper`` filled (the launch can sit in a hipGraph); the step counter is then ``stage_hyper``'s to advance."""
         lr = self.lr if lr is None else float(lr)
         world = self._world()
-        if self._collectives() and not self._pending:
+        if self._collectives() and not self._pending and not self._in_graph:
             self.all_reduce_grads()
         self.flat.check_views()
-        self.steps += 1
+        if not recorded:
+            self.steps += 1
+        elif self._hyper is None:
+            raise _lib.SGV3DError("step(recorded=True) needs stage_hyper() first")
         lib = _lib.load()
         for i, ((p, g, _), (m, v)) in enumerate(zip(self.flat.buckets, self.state)):
             if self._pending:
@@ -250,9 +277,14 @@ class DataParallelAdamW:
             if not p.is_cuda:
                 raise _lib.SGV3DError("the fused AdamW update runs on the GPU (no CPU fallback)")
             with torch.cuda.device(p.device):
-                rc = lib.sgv3d_adamw_step(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), self.steps, lr,
-                                          self.betas[0], self.betas[1], self.eps, self.weight_decay, 1.0 / world,
-                                          _lib.stream_handle(p.device))
+                if recorded:
+                    rc = lib.sgv3d_adamw_step_dev(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), self._hyper.data_ptr(),
+                                                  self.betas[0], self.betas[1], self.eps, self.weight_decay, 1.0 / world,
+                                                  _lib.stream_handle(p.device))
+                else:
+                    rc = lib.sgv3d_adamw_step(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), self.steps, lr,
+                                              self.betas[0], self.betas[1], self.eps, self.weight_decay, 1.0 / world,
+                                              _lib.stream_handle(p.device))
             _lib.check(rc, "sgv3d_adamw_step")
         self._pending = []
         if hasattr(self, '_left') and self._fired:
@@ -261,3 +293,112 @@ class DataParallelAdamW:
             # unused-parameter set and re-arm here, so that the next backward is this step's successor, not a "second backward"
             self._learn_unused()
             self._arm()
+
+
+class GraphedTrainStep:
+    """One optimiser step -- ``opt.zero_grad()``, ``loss = forward_backward()``, the fused AdamW update -- recorded once as a
+    hipGraph and replayed per step.  The eager step of the R50 model is ~1500 launches from Python and the autograd engine; on a
+    host that needs 35 us per launch the GPU (45 ms of kernels at batch 2) waits for the launches, not the other way round.
+
+    ``forward_backward``: a callable without arguments that runs forward, loss and ``loss.backward()`` on STATIC tensors (the
+    caller refreshes them in place -- ``imgs.copy_(next_imgs)`` ... -- before each call; ground-truth boxes padded to a fixed
+    count with label -1, which ``BEVHeightHead.get_targets`` ignores) and returns the loss tensor.  Everything it launches must be
+    capturable: no ``.item()`` / ``.tolist()`` / host-side shape decisions on device data.  The per-layer kernel choices must
+    exist already (run a few eager steps first, as any warm-up does).
+
+    What the replay does not do: Python.  Hooks, ``p.grad`` re-binding, logging inside ``forward_backward`` run at capture time
+    only; the gradients live where the capture left them (views of the flat buckets), BatchNorm statistics, step counters and
+    the dropout stream advance on the device as in eager steps.
+
+    With a process group (data parallel): the recorded part ends after backward; the bucket all-reduces and the AdamW update are
+    launched eagerly after each replay (5 launches), so that no collective is part of a graph.  The loss's own all-reduce of its
+    averaging factors (``BEVHeightHead.loss``) has to be capturable by the backend (RCCL is; gloo is not) -- ``capture_error``
+    holds the exception if it was not, and the object then runs the eager step.
+
+    Construction runs ``warmup`` REAL eager steps on the capture stream first (allocator pools, lazily created state), then records;
+    the recorded step itself first runs at the first call.  ``graphed()`` returns the (static) loss tensor; ``graphed.result`` is the
+    same tensor."""
+
+    def __init__(self, forward_backward, opt, lr=None, warmup=1, strict=False):
+        self.fn, self.opt = forward_backward, opt
+        self.result = None
+        self.graph = None
+        self.capture_error = None
+        self.replays = 0
+        self.in_graph_update = not opt._collectives()
+        dev = opt.flat.buckets[0][0].device
+        from .pipeline import capture_begin, CAPTURE_ERRORS
+        # autograd keeps a parameter's AccumulateGrad node -- and the stream it was created on -- alive while a post-accumulate hook is
+        # registered on it (overlap_with_backward); a backward on the capture stream would then synchronise with that older stream,
+        # which a capture cannot record.  The hooks are not needed while the graph runs (no Python in a replay; the all-reduces are
+        # launched after it): removed here, re-installed if the capture fails.  (References of the CALLER to an earlier loss tensor keep
+        # the nodes alive the same way: drop them -- ``loss = float(loss)`` -- before constructing this object.)
+        had_hooks = bool(getattr(opt, '_hooks', None))
+        if had_hooks:
+            for h in opt._hooks:
+                h.remove()
+            opt._hooks = []
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, int(warmup))):      # on the capture stream: allocator pools, lazily created state
+                self._eager(lr)
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            steps_before = opt.steps
+            try:
+                opt._in_graph = True
+                if self.in_graph_update:
+                    opt.stage_hyper(lr)               # (outside the graph: a pinned-memory copy per step)
+                # with a process group its watchdog thread polls the events of earlier collectives while this thread records: legal
+                # only if the capture's error mode is per thread (kernels launched by the autograd engine's thread into the
+                # capturing stream are recorded in either mode)
+                capture_begin(g, error_mode=None if self.in_graph_update else "thread_local")
+                try:
+                    opt.zero_grad()
+                    self.result = self.fn()
+                    if self.in_graph_update:
+                        opt.step(lr, recorded=True)
+                finally:
+                    g.capture_end()
+                self.graph = g
+            except CAPTURE_ERRORS as e:
+                opt.steps = steps_before
+                self.capture_error = e
+                torch.cuda.synchronize(dev)
+                if strict:
+                    raise
+                import warnings
+                warnings.warn(f"GraphedTrainStep: hipGraph capture failed ({type(e).__name__}: {e}); running eager steps", RuntimeWarning,
+                              stacklevel=2)
+            finally:
+                opt._in_graph = False
+        torch.cuda.current_stream(dev).wait_stream(side)
+        if self.graph is None and had_hooks:
+            opt.overlap_with_backward()
+        if self.graph is not None:
+            # the capture launched nothing: the step it recorded has not run.  Undo the counter and run it as the first replay would.
+            opt.steps = steps_before
+        opt._pending = []
+        if hasattr(opt, '_left'):
+            opt._arm()
+
+    def _eager(self, lr):
+        self.opt.zero_grad()
+        self.result = self.fn()
+        self.opt.all_reduce_grads()
+        self.opt.step(lr)
+        return self.result
+
+    def __call__(self, lr=None):
+        if self.graph is None:
+            return self._eager(lr)
+        if self.in_graph_update:
+            self.opt.stage_hyper(lr)
+            self.graph.replay()
+        else:
+            self.graph.replay()
+            self.opt.all_reduce_grads()
+            self.opt.step(lr)
+        self.replays += 1
+        return self.result

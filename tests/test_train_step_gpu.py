@@ -58,6 +58,48 @@ def test_fused_adamw_same_gradients_match_to_rounding():
     assert err <= 6e-6, err          # |p| up to 4: a few ulps after 20 steps
 
 
+def test_adamw_with_device_scalars_is_bitwise_the_host_scalar_update():
+    """``step(recorded=True)`` after ``stage_hyper()`` (sgv3d_adamw_step_dev: lr and the two bias corrections read from device memory,
+    what a recorded hipGraph launch needs) against ``step()``: the same bits after every step, with a changing learning rate."""
+    g = torch.Generator(device='cuda').manual_seed(6)
+    p = torch.randn(70001, device='cuda', generator=g).requires_grad_(True)
+    q = p.detach().clone().requires_grad_(True)
+    a = DataParallelAdamW([p], lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7)
+    b = DataParallelAdamW([q], lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7)
+    for it in range(12):
+        grad = torch.randn(70001, device='cuda', generator=g) * (10.0 ** (it % 4 - 2))
+        lr = 2e-3 * (0.5 if it >= 6 else 1.0)
+        p.grad.copy_(grad)
+        q.grad.copy_(grad)
+        a.step(lr)
+        b.stage_hyper(lr)
+        b.step(lr, recorded=True)
+        assert a.steps == b.steps == it + 1
+        assert torch.equal(p.detach(), q.detach()), it
+        assert all(torch.equal(x, y) for sa, sb in zip(a.state, b.state) for x, y in zip(sa, sb))
+
+
+def test_graphed_train_step_follows_the_eager_steps():
+    """train_step.GraphedTrainStep: zero_grad + forward + targets + loss + backward + AdamW of the small model recorded as one hipGraph.
+    Same number of optimiser steps eagerly and through the graph (its constructor runs one real eager step, then every call is a
+    replay): the loss after the last step and the parameter checksum agree to the run-to-run noise of the eager step itself (the
+    deformable-convolution adjoint adds with float atomics), the step counter and the BatchNorm counters advance per replay."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("SGV3D_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(root, "tools", "train_bench.py"), "--config", "small", "--batch", "2", "--steps", "4"]
+    eager = _run_json(cmd + ["--warmup", "4"], base)                       # 4 + 4 steps
+    again = _run_json(cmd + ["--warmup", "4"], base)
+    graph = _run_json(cmd + ["--warmup", "2", "--graph"], base)            # 2 eager + 1 in the constructor + 1 + 4 replays
+    assert graph["graph"] is True and graph["graph_replays"] == 5 and graph["update_in_graph"] is True
+    assert eager["optimizer_steps"] == graph["optimizer_steps"] == 8
+    noise = abs(eager["loss"] - again["loss"])
+    assert abs(graph["loss"] - eager["loss"]) <= max(10 * noise, 2e-3 * abs(eager["loss"])), (graph["loss"], eager["loss"], again["loss"])
+    assert abs(graph["param_checksum"] - eager["param_checksum"]) <= 1e-5 * eager["param_checksum"]
+    print(f"small model, 8 steps: loss {eager['loss']:.5f} eager / {again['loss']:.5f} eager again / {graph['loss']:.5f} graphed")
+
+
 def test_training_slice_reduces_the_loss():
     """conv -> relu -> conv regression trained for a few steps entirely on the HIP kernels (forward, data and weight
     gradients, fused AdamW); an identical torch model with torch.optim.AdamW must follow the same trajectory."""
@@ -203,8 +245,14 @@ def test_cfg4_share_mixed_precision_step_through_one_rank_rccl():
     plain = _run_json(cmd, env)
     assert plain["dtype"] == "f32"
     assert mixed["loss"] == mixed["loss"] and abs(mixed["loss"] - plain["loss"]) <= 2e-2 * abs(plain["loss"]), (mixed["loss"], plain["loss"])
+    # ... and recorded as a hipGraph (train_step.GraphedTrainStep with a process group: forward, loss -- its all-reduce of the averaging
+    # factors included -- and backward are the graph, the bucket all-reduces and AdamW follow each replay): 3 + 1 eager steps, 3 replays
+    graphed = _run_json(cmd + ["--dtype", "bf16", "--graph", "--steps", "2", "--warmup", "3"], env)
+    assert graphed["graph"] is True and graphed["update_in_graph"] is False and graphed["graph_replays"] == 3 and graphed["optimizer_steps"] == 7
+    assert graphed["backend"] == "nccl" and graphed["collectives_active"] is True
+    assert graphed["loss"] == graphed["loss"] and abs(graphed["loss"]) < 1e6
     print(f"cfg-4 share, mixed precision: {mixed['ms_per_step']:.1f} ms / step against {plain['ms_per_step']:.1f} ms with f32 products "
-          f"(loss {mixed['loss']:.3f} / {plain['loss']:.3f})")
+          f"(loss {mixed['loss']:.3f} / {plain['loss']:.3f}); recorded as a hipGraph {graphed['ms_per_step']:.1f} ms / step")
 
 
 def test_cfg5_share_training_step_through_one_rank_rccl():

@@ -24,6 +24,8 @@ ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                 help="bf16 = mixed-precision step: every convolution product (forward, data gradient, weight gradient) on the bf16 matrix "
                      "cores with f32 accumulation; parameters, gradients, activations, BatchNorm, loss and AdamW stay f32")
 ap.add_argument("--no-overlap", action="store_true", help="all-reduce after backward instead of from grad hooks")
+ap.add_argument("--graph", action="store_true", help="the whole step (forward, targets, loss, backward, AdamW) as ONE hipGraph replay "
+                "(train_step.GraphedTrainStep); single process only: with a process group the gradient all-reduce stays outside the graph")
 ap.add_argument("--profile", action="store_true", help="per-kernel-family times of one step (HIP events, eager)")
 args = ap.parse_args()
 
@@ -62,8 +64,7 @@ if not args.no_overlap:
 nparam = sum(p.numel() for p in model.parameters())
 
 
-def step():
-    opt.zero_grad()
+def forward_backward():
     preds = model(imgs, mats)
     if BSM:                                     # exps/sgv3d/bsm_bev_height_lss_r101_864_1536_256x256.py:304-330
         preds, img_preds = preds
@@ -73,6 +74,12 @@ def step():
         loss = loss + semantic(img_preds, gt_semantic) * 500
     loss.backward()
     EARLY[0] = len(getattr(opt, '_early', {}))
+    return loss
+
+
+def step():
+    opt.zero_grad()
+    loss = forward_backward()
     opt.all_reduce_grads()
     opt.step()
     return loss
@@ -82,15 +89,25 @@ EARLY = [0]
 
 
 for _ in range(args.warmup):
-    loss = step()
+    loss = step().detach()              # (no reference to the autograd graph is kept: GraphedTrainStep)
 torch.cuda.synchronize()
-elapsed = group.timed(step, args.steps)
+run = step
+if args.graph:
+    from sgv3d_amd.train_step import GraphedTrainStep
+    graphed = GraphedTrainStep(forward_backward, opt, strict=True)
+    run = graphed
+    loss = run()
+    torch.cuda.synchronize()
+elapsed = group.timed(run, args.steps)
+if args.graph:
+    loss = graphed.result
 out = {"metric": "training samples/s (forward + loss + backward + all-reduce + AdamW)", "value": group.world * args.batch * args.steps / elapsed,
        "unit": "samples/s", "n_gpus": group.world, "steps": args.steps, "ms_per_step": 1e3 * elapsed / args.steps,
        "batch_per_gpu": args.batch, "global_batch": args.batch * group.world, "dtype": args.dtype,
        "world_size": group.dist.get_world_size() if group.dist is not None else 1, "backend": group.backend,
        "allreduce_bytes_per_step": 4 * sum(g.numel() for _, g, _ in opt.flat.buckets), "allreduce_buckets": len(opt.flat.buckets),
-       "allreduce_overlapped_with_backward": not args.no_overlap, "parameters": nparam, "loss": float(loss.detach()), "config": args.config,
+       "allreduce_overlapped_with_backward": not args.no_overlap, "parameters": nparam, "loss": float(loss.detach()), "config": args.config, "graph": bool(args.graph), "graph_replays": graphed.replays if args.graph else 0,
+       "update_in_graph": bool(graphed.in_graph_update) if args.graph else None, "optimizer_steps": opt.steps,
        "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2**30, "data": "synthetic",
        # (a 1-rank group with SGV3D_FORCE_DIST=1 still broadcasts / all-reduces through RCCL: the single-GPU stand-in for cfg-4)
        "collectives_active": bool(opt._collectives()), "allreduces_launched_inside_backward": EARLY[0],
