@@ -732,6 +732,18 @@ int sgv3d_conv2d_backward_weight(const sgv3d_conv_desc *desc /*host*/, const flo
 size_t sgv3d_conv2d_backward_weight_bf16_workspace_bytes(const sgv3d_conv_desc *desc /*host*/, int split);
 int sgv3d_conv2d_backward_weight_bf16(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *dy, float *dw, int split,
                                       void *workspace, size_t workspace_bytes, void *stream);
+/* ... with ALL NINE TAPS of a 3x3 / stride-1 layer (dilation 1 .. 20) in one workgroup (csrc/conv_wgrad3x3_bf16.hip): a workgroup owns a
+ * 64 x 64 (cout x cin) tile and walks down a 32-pixel-wide column of the map, one new dY row segment and ONE new input row per step
+ * (the other two stay in an LDS ring), operands kept in NHWC order in LDS and read with ds_read_b64_tr_b16 -- X and dY cross L2 -> LDS
+ * once per column instead of nine times.  Same tensors, tolerance and determinism as sgv3d_conv2d_backward_weight_bf16 (different
+ * summation order).  split: row chunks per column (0 = rule); workspace ALWAYS needed: ..._alltaps_workspace_bytes(desc, n, split) with
+ * n = 1, or the number of problems of the batched form (dy_list / dw_list: HOST arrays of device pointers, one x). */
+size_t sgv3d_conv2d_backward_weight_bf16_alltaps_workspace_bytes(const sgv3d_conv_desc *desc /*host*/, int n, int split);
+int sgv3d_conv2d_backward_weight_bf16_alltaps(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *dy, float *dw, int split,
+                                              void *workspace, size_t workspace_bytes, void *stream);
+int sgv3d_conv2d_backward_weight_bf16_alltaps_batched(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *const *dy_list /*host*/,
+                                                      float *const *dw_list /*host*/, int n, int split, void *workspace,
+                                                      size_t workspace_bytes, void *stream);
 /* ... and its batched form (n layers that read the same x, as sgv3d_conv2d_backward_weight_batched). */
 size_t sgv3d_conv2d_backward_weight_bf16_batched_workspace_bytes(const sgv3d_conv_desc *desc /*host*/, int n, int split);
 int sgv3d_conv2d_backward_weight_bf16_batched(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *const *dy_list /*host*/,

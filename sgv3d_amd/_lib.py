@@ -133,6 +133,9 @@ _PROTOS = {
     "sgv3d_conv2d_backward_weight_bf16": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 3 + [c_int, c_void_p, c_size_t, c_void_p]),
     "sgv3d_conv2d_backward_weight_bf16_batched_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc), c_int, c_int]),
     "sgv3d_conv2d_backward_weight_bf16_batched": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "sgv3d_conv2d_backward_weight_bf16_alltaps_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc), c_int, c_int]),
+    "sgv3d_conv2d_backward_weight_bf16_alltaps": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 3 + [c_int, c_void_p, c_size_t, c_void_p]),
+    "sgv3d_conv2d_backward_weight_bf16_alltaps_batched": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "sgv3d_conv2d_backward_weight_thin_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "sgv3d_conv2d_backward_weight_batched_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc), c_int, c_int]),
     "sgv3d_conv2d_backward_weight_batched": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, c_size_t, c_void_p]),

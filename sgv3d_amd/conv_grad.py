@@ -87,7 +87,9 @@ def _bf16_wgrad_ok(x, dy, cin, cout, x_coff, y_coff):
 def conv2d_backward_weight_bf16(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, cout=None, x_coff=0, y_coff=0, split=0, tile=0, out=None):
     """``conv2d_backward_weight`` with the products on the bf16 matrix cores (sgv3d_conv2d_backward_weight_bf16): f32 tensors in
     and out, operands rounded to bf16 while staging, f32 accumulation, fixed-order pixel-split reduce.  ``tile``: 0 = measured per
-    layer shape (first call) / the library's rule, 1 = 64 x 64, 4 = 128 x 128."""
+    layer shape (first call) / the library's rule, 1 = 64 x 64, 4 = 128 x 128 (one tap per workgroup, ``split`` = pixel ranges), 6 = the
+    all-taps kernel (3x3 / stride 1: a workgroup owns a 64 x 64 tile for all nine taps and walks down a column of the map;
+    ``split`` = row chunks per column, 0 = rule)."""
     from . import hip_ops
     kh, kw = (kernel, kernel) if isinstance(kernel, int) else kernel
     B, H, W, x_ld = (int(v) for v in x.shape)
@@ -108,6 +110,21 @@ def conv2d_backward_weight_bf16(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=No
     if not tile and not split:
         tile, split = _wgrad_choice(lib, d, x, dy, bf16=True)
         d.tile = int(tile)
+    if int(tile) == 6:              # all nine taps per workgroup (csrc/conv_wgrad3x3_bf16.hip); split = row chunks per column
+        d.tile = 0
+        nws = lib.sgv3d_conv2d_backward_weight_bf16_alltaps_workspace_bytes(ctypes.byref(d), 1, int(split))
+        if nws == 0:
+            raise _lib.SGV3DError("the all-taps bf16 weight-gradient kernel takes 3x3 / stride-1 layers (dilation <= 20) only")
+        ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+        dw = _dw_buffer(out, (cout, cin, kh, kw), x.device)
+        name = "conv_wgrad_bf16_alltaps"
+        if hip_ops.PROFILE_DETAIL:
+            name += f"|{B}x{H}x{W}x{cin}->{cout} k{kh} s{stride} d{dil} tile6 split{int(split)}"
+        with torch.cuda.device(x.device), prof(name, 2.0 * B * OH * OW * cout * cin * kh * kw):
+            rc = lib.sgv3d_conv2d_backward_weight_bf16_alltaps(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(split),
+                                                               ws.data_ptr(), nws, _st(x))
+        _lib.check(rc, "sgv3d_conv2d_backward_weight_bf16_alltaps")
+        return dw
     nws = lib.sgv3d_conv2d_backward_weight_bf16_workspace_bytes(ctypes.byref(d), int(split))
     ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
     dw = _dw_buffer(out, (cout, cin, kh, kw), x.device)
@@ -141,6 +158,16 @@ def conv2d_backward_weight_batched(x, dys, pad=1, *, cin=None, cout=None, split=
             and all(t.data_ptr() % 16 == 0 for t in dys)):
         # mixed-precision step: the same n gradients on the bf16 matrix cores, one launch (blockIdx.z = problem)
         d.tile = 0
+        if hip_ops.WGRAD_BF16_ALLTAPS:
+            nws = lib.sgv3d_conv2d_backward_weight_bf16_alltaps_workspace_bytes(ctypes.byref(d), n, 0)
+            ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
+            dws = [_dw_buffer(None if outs is None else outs[i], (cout, cin, 3, 3), x.device) for i in range(n)]
+            dyp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dys])
+            dwp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dws])
+            with torch.cuda.device(x.device), prof("conv_wgrad_bf16_alltaps", 2.0 * n * B * OH * OW * cout * cin * 9):
+                rc = lib.sgv3d_conv2d_backward_weight_bf16_alltaps_batched(ctypes.byref(d), x.data_ptr(), dyp, dwp, n, 0, ws.data_ptr(), nws, _st(x))
+            _lib.check(rc, "sgv3d_conv2d_backward_weight_bf16_alltaps_batched")
+            return dws
         tiles = -(-cout // 64) * -(-cin // 64) * 9 * n
         sp = max(1, min(-(-1024 // tiles), (B * OH * OW) // 256))
         nws = lib.sgv3d_conv2d_backward_weight_bf16_batched_workspace_bytes(ctypes.byref(d), n, int(sp))
@@ -209,16 +236,29 @@ def _wgrad_choice(lib, d, x, dy, bf16=False):
             sp = int(max(1, min(base * f, units)))
             if (5, sp) not in cands:
                 cands.append((5, sp))
+    if (bf16 and hip_ops.WGRAD_BF16_ALLTAPS and d.kh == 3 and d.kw == 3 and d.stride == 1 and d.dil <= 20):
+        # the all-taps bf16 kernel (tile 6): split = row chunks per column of the map; the rule (0) and fixed counts
+        for sp in (0, 1, 2, 4, 8):
+            cands.append((6, sp))
     dw = torch.empty(d.cout, d.cin, d.kh, d.kw, dtype=torch.float32, device=x.device)
     best, best_t = (0, 0), None
     with torch.cuda.device(x.device):
         for t, sp in cands:
             d.tile = t
-            nws = ws_bytes(ctypes.byref(d), sp)
-            if nws > (2 << 30):
-                continue
-            ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
-            run = lambda: launch(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), sp, ws.data_ptr(), nws, _st(x))
+            if t == 6:
+                d.tile = 0
+                nws = lib.sgv3d_conv2d_backward_weight_bf16_alltaps_workspace_bytes(ctypes.byref(d), 1, sp)
+                if nws == 0 or nws > (2 << 30):
+                    continue
+                ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+                run = lambda: lib.sgv3d_conv2d_backward_weight_bf16_alltaps(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), sp,
+                                                                            ws.data_ptr(), nws, _st(x))
+            else:
+                nws = ws_bytes(ctypes.byref(d), sp)
+                if nws > (2 << 30):
+                    continue
+                ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
+                run = lambda: launch(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), sp, ws.data_ptr(), nws, _st(x))
             if run() != 0:
                 continue
             nrep = max(3, hip_ops.TUNE_REPEATS + 1)

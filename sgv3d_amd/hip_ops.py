@@ -63,6 +63,9 @@ BF16_ACTIVATIONS = not _os.environ.get("SGV3D_NO_BF16_ACTIVATIONS")
 # bf16 compute mode in TRAINING (MFMA_BF16 with BF16_ACTIVATIONS off: f32 tensors, bf16 products): also the weight gradients
 # run on the bf16 matrix cores (conv_wgrad_bf16_kernel); 0: they stay on the f32 MFMA kernel
 TRAIN_BF16_WGRAD = _os.environ.get("SGV3D_TRAIN_BF16_WGRAD", "1") != "0"
+# ... and 3x3 / stride-1 layers may use the all-taps form (conv_wgrad3x3_bf16.hip: a workgroup owns a 64 x 64 tile for all nine taps;
+# the batched CenterHead launch always, single layers where the first-call measurement / the tune DB says so); 0: per-tap kernel only
+WGRAD_BF16_ALLTAPS = _os.environ.get("SGV3D_WGRAD_BF16_ALLTAPS", "1") != "0"
 # True (SGV3D_F32X3=1): the implicit-GEMM layers compute float32-accurate products on the bf16 matrix cores -- every
 # operand is split exactly into three bf16 terms and six partial products are accumulated in f32 (csrc/conv_igemm.hip,
 # SPLIT3): the error of a product is one f32 rounding, the MFMA time 192 instead of 512 cycles per 16 k.  Winograd

@@ -351,3 +351,66 @@ def test_multi_thin_conv2d_matches_the_per_layer_function():
         for a, b in ((dx, x.grad), (dw, c.weight.grad), (db, c.bias.grad)):
             assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()), (a.shape, float((a - b).abs().max()), float(b.abs().max()))
     assert not conv_grad.thin_conv_eligible(convs + [nn.Conv2d(cin, 8, 3, padding=1).cuda()], xs + [xs[0]])
+
+
+@pytest.mark.parametrize("shape", [
+    # B, cin, H, W, cout, pad, dil
+    (2, 64, 20, 28, 64, 1, 1),           # one tile, a ragged 32-pixel segment
+    (1, 128, 19, 70, 64, 1, 1),          # three segments (the last one 6 pixels), two input-channel tiles
+    (2, 96, 17, 33, 160, 1, 1),          # channel counts that are not multiples of 64 (partial tiles on both sides)
+    (1, 64, 23, 40, 64, 6, 6),           # ASPP dilation 6: six interleaved row phases, staged rows of 44 pixels
+    (1, 64, 21, 36, 128, 18, 18),        # dilation 18 = the map is smaller than the dilated kernel's reach in places
+    (1, 72, 12, 16, 68, 0, 1),           # no padding, 4-channel remainders
+    (2, 64, 9, 31, 64, 2, 1),            # padding 2 (output larger than the input)
+])
+def test_wgrad_bf16_alltaps(shape):
+    """sgv3d_conv2d_backward_weight_bf16_alltaps (tile 6: all nine taps of a 3x3 / stride-1 layer per workgroup, operands read from
+    NHWC-ordered LDS images with the transposing read): against the float64 gradient of the bf16-rounded operands, exact on small
+    integers, bitwise repeatable, every chunk count the same up to summation order, and channel windows of wider tensors."""
+    B, cin, H, W, cout, pad, dil = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    oh, ow = H + 2 * pad - 2 * dil, W + 2 * pad - 2 * dil
+    x = torch.randn(B, H, W, cin + 8, generator=g)
+    dy = torch.randn(B, oh, ow, cout + 4, generator=g)
+    rb = lambda t: t.bfloat16().float()
+    _, _, dw_ref = _reference(rb(x[..., 4:4 + cin]), torch.zeros(cout, cin, 3, 3), rb(dy[..., 4:4 + cout]), 1, pad, dil)
+    run = lambda split: conv_grad.conv2d_backward_weight_bf16(x.cuda(), dy.cuda(), 3, 1, pad, dil, cin=cin, cout=cout, x_coff=4, y_coff=4,
+                                                              tile=6, split=split)
+    dw = run(0)
+    scale = float(dw_ref.abs().max())
+    assert float((dw.cpu().double() - dw_ref).abs().max()) <= 2e-5 * scale
+    assert torch.equal(dw, run(0))
+    for split in (1, 2, 3):
+        assert float((run(split) - dw).abs().max()) <= 2e-5 * scale
+    per_tap = conv_grad.conv2d_backward_weight_bf16(x.cuda(), dy.cuda(), 3, 1, pad, dil, cin=cin, cout=cout, x_coff=4, y_coff=4, tile=1, split=2)
+    assert float((per_tap - dw).abs().max()) <= 2e-5 * scale
+    xi = torch.randint(-3, 4, (B, H, W, cin), generator=g).float()
+    dyi = torch.randint(-2, 3, (B, oh, ow, cout), generator=g).float()
+    _, _, want = _reference(xi, torch.zeros(cout, cin, 3, 3), dyi, 1, pad, dil)
+    assert torch.equal(conv_grad.conv2d_backward_weight_bf16(xi.cuda(), dyi.cuda(), 3, 1, pad, dil, tile=6).cpu().double(), want)
+
+
+def test_wgrad_bf16_alltaps_batched():
+    """The batched form (n gradients against one input, what the 36 first layers of the CenterHead branches use in the mixed-precision
+    step): each problem bitwise the single-problem launch with the same chunking rule applied to n = 1 ... here compared to 2e-5."""
+    from sgv3d_amd import hip_ops
+    g = torch.Generator().manual_seed(21)
+    B, H, W, cin, cout, n = 2, 21, 45, 64, 64, 5
+    x = torch.randn(B, H, W, cin, generator=g).cuda()
+    dys = [torch.randn(B, H, W, cout, generator=g).cuda() for _ in range(n)]
+    saved = (hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS, hip_ops.WGRAD_BF16_ALLTAPS)
+    try:
+        hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS, hip_ops.WGRAD_BF16_ALLTAPS = True, False, True
+        got = conv_grad.conv2d_backward_weight_batched(x, dys)
+        again = conv_grad.conv2d_backward_weight_batched(x, dys)
+        hip_ops.WGRAD_BF16_ALLTAPS = False
+        per_tap = conv_grad.conv2d_backward_weight_batched(x, dys)
+    finally:
+        hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS, hip_ops.WGRAD_BF16_ALLTAPS = saved
+    rb = lambda t: t.cpu().bfloat16().float()
+    for d, dw, dw2, dw3 in zip(dys, got, again, per_tap):
+        _, _, ref = _reference(rb(x), torch.zeros(cout, cin, 3, 3), rb(d), 1, 1, 1)
+        scale = float(ref.abs().max())
+        assert float((dw.cpu().double() - ref).abs().max()) <= 2e-5 * scale
+        assert torch.equal(dw, dw2)
+        assert float((dw - dw3).abs().max()) <= 2e-5 * scale

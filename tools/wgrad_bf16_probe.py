@@ -41,8 +41,28 @@ def main():
                 t = graph_us(fn, reps=5)
                 if best is None or t < best[0]:
                     best = (t, tile, split, float((got - ref).abs().max() / ref.abs().max()))
-        print(f"{name:26s} f32 {t32:8.1f} us = {flop / t32 / 1e6:6.1f} TF | bf16 best {best[0]:8.1f} us = {flop / best[0] / 1e6:7.1f} TF "
-              f"(tile {best[1]}, split {best[2]}; rel. diff to f32 {best[3]:.1e})", flush=True)
+        line = (f"{name:26s} f32 {t32:8.1f} us = {flop / t32 / 1e6:6.1f} TF | bf16 per tap {best[0]:8.1f} us = {flop / best[0] / 1e6:7.1f} TF "
+                f"(tile {best[1]}, split {best[2]}; rel. diff to f32 {best[3]:.1e})")
+        if k == 3 and s == 1:                                   # all nine taps per workgroup (tile 6; split = row chunks per column)
+            at = None
+            for split in (0, 1, 2, 4, 8):
+                fn = lambda: conv_grad.conv2d_backward_weight_bf16(x, dy, k, s, p, d, tile=6, split=split)
+                got = fn()
+                t = graph_us(fn, reps=5)
+                if at is None or t < at[0]:
+                    at = (t, split, float((got - ref).abs().max() / ref.abs().max()))
+            line += f" | all taps {at[0]:8.1f} us = {flop / at[0] / 1e6:7.1f} TF (chunks {at[1]}; {at[2]:.1e})"
+        print(line, flush=True)
+    # the 36 first layers of the CenterHead branches as one batched launch
+    from sgv3d_amd import hip_ops
+    hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS = True, False
+    x = torch.randn(B, 256, 256, 64, generator=g).to(dev)
+    dys = [torch.randn(B, 256, 256, 64, generator=g).to(dev) for _ in range(36)]
+    flop = 36 * 2.0 * B * 256 * 256 * 64 * 64 * 9
+    for flag in (False, True):
+        hip_ops.WGRAD_BF16_ALLTAPS = flag
+        t = graph_us(lambda: conv_grad.conv2d_backward_weight_batched(x, dys), reps=3)
+        print(f"36 x 64->64 3x3 @256x256 batched, {'all taps' if flag else 'per tap'}: {t:8.1f} us = {flop / t / 1e6:7.1f} TF", flush=True)
 
 
 if __name__ == "__main__":
