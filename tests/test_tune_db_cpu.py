@@ -22,7 +22,7 @@ def test_committed_tune_dbs_name_known_tiles():
             elif sig.startswith("wgrad|"):
                 assert t >= 0 and s >= 0, (f, sig, choice)               # weight-gradient (tile, pixel split); 0 = the kernel's own rule
                 if sig.endswith("xbf16"):
-                    assert t in (0, 1, 4), (f, sig, choice)              # the bf16 weight-gradient kernel has the 64x64 and 128x128 tiles
+                    assert t in (0, 1, 4, 6), (f, sig, choice)           # bf16 weight gradients: 64x64 / 128x128 per tap, 6 = all taps (3x3)
             elif sig.startswith("pair|"):
                 assert t in (0, 1), (f, sig, choice)                     # fused conv2 + conv3 launch or not
             else:
