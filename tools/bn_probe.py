@@ -6,23 +6,13 @@ the residual's gradient (32 B).  Prints microseconds and TB/s per call."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from sgv3d_amd.norm_grad import batch_norm_act
+from sgv3d_amd.norm_grad import batch_norm_act                # noqa: E402
 
 SHAPES = [(2, 432, 768, 64), (2, 216, 384, 64), (2, 216, 384, 256), (2, 108, 192, 128), (2, 108, 192, 512), (2, 54, 96, 256),
           (2, 54, 96, 1024), (2, 54, 96, 512), (2, 27, 48, 2048), (2, 256, 256, 64), (2, 128, 128, 160), (2, 64, 64, 320)]
 
 
-def timed(fn, reps=7):
-    fn(); fn()
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-    ev[0].record()
-    for i in range(reps):
-        fn()
-        ev[i + 1].record()
-    torch.cuda.synchronize()
-    return sorted(ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(reps))[reps // 2]
-
+from tools.vp_probe3 import graph_us                     # GPU time of a hipGraph of launches (not the host's launch cadence)
 
 for shape in SHAPES:
     n = 1
@@ -34,9 +24,13 @@ for shape in SHAPES:
     dy = torch.randn(*shape, device='cuda')
     row = f"{'x'.join(map(str, shape)):>18}"
     for name, r, fb, bb in (("relu", None, 12, 20), ("res+relu", res, 16, 32)):
-        with torch.no_grad():
-            t_f = timed(lambda: batch_norm_act(bn, x, r, relu=True))
-        y = batch_norm_act(bn, x, r, relu=True)
-        t_b = timed(lambda: torch.autograd.grad(y, [x] + ([r] if r is not None else []), dy, retain_graph=True))
+        def fwd():
+            with torch.no_grad():
+                batch_norm_act(bn, x, r, relu=True)
+        t_f = graph_us(fwd, reps=5)
+        def both():                # (forward + backward inside the capture: the autograd nodes must belong to the capturing stream)
+            y = batch_norm_act(bn, x, r, relu=True)
+            torch.autograd.grad(y, [x] + ([r] if r is not None else []), dy)
+        t_b = graph_us(both, reps=5) - t_f
         row += f" | {name}: fwd {t_f:6.1f} us {n * fb / t_f / 1e6:5.2f} TB/s, bwd {t_b:6.1f} us {n * bb / t_b / 1e6:5.2f} TB/s"
-    print(row)
+    print(row, flush=True)
