@@ -445,12 +445,19 @@ def main():
         torch.cuda.synchronize()
         gap_s = sorted(c0.elapsed_time(c1) for c0, c1 in cal)[len(cal) // 2] * 1e-3
         by_kernel, by_symbol = {}, {}
+        HBM_PEAK = 8.0e12
+        def executed_of(name, flops):
+            return flops / 4.0 if "wino4" in name else flops / 2.25 if "wino" in name else flops
         for name, flops, e0, e1, nbytes, extra in recs:
-            d = by_kernel.setdefault(name, [0.0, 0.0, 0, 0.0, {}])
+            d = by_kernel.setdefault(name, [0.0, 0.0, 0, 0.0, {}, 0.0, 0])
             d[0] += flops
             d[1] += max(e0.elapsed_time(e1) * 1e-3 - gap_s, 1e-7)
             d[2] += 1
             d[3] += nbytes
+            # the launch's floor under BOTH roofs: executed flops at the MFMA peak, algorithmic bytes at the HBM peak
+            t_mfma, t_hbm = executed_of(name, flops) / (peak * 1e12), nbytes / HBM_PEAK
+            d[5] += max(t_mfma, t_hbm)
+            d[6] += 1 if t_hbm > t_mfma else 0
             if extra:
                 d[4][extra["symbol"]] = d[4].get(extra["symbol"], 0) + 1
                 q = by_symbol.setdefault(extra["symbol"], [0.0, 0])
@@ -466,7 +473,7 @@ def main():
         # two transform kernels -- it is in conv_family.by_kernel, and its grouped GEMMs are in frac_from_rocprof's symbol)
         one_kernel = {k: v for k, v in conv.items() if k != "conv_wino4"} or conv
         top = max(one_kernel, key=lambda k: one_kernel[k][1])
-        fl, sec, n, nby, syms = conv[top]
+        fl, sec, n, nby, syms, floor_sec, hbm_bound_n = conv[top]
         fam_fl = sum(v[0] for v in conv.values())
         fam_ex = sum(executed(k, v[0]) for k, v in conv.items())
         fam_sec = sum(v[1] for v in conv.values())
@@ -496,17 +503,24 @@ def main():
             "executed": {"achieved": executed(top, fl) / sec / 1e12,
                          "frac": executed(top, fl) / sec / 1e12 / peak},
             "launches": n, "avg_launch_us": sec / n * 1e6, "flop_per_launch": fl / n,
+            # against BOTH roofs per launch (a 1x1 layer with 64 input channels is HBM-bound, not MFMA-bound): sum over the launches
+            # of max(executed flops / MFMA peak, algorithmic bytes / 8 TB/s) over the measured time
+            "two_roof": {"frac": floor_sec / sec, "floor_us_per_launch": floor_sec / n * 1e6, "hbm_bound_launches": hbm_bound_n,
+                         "hbm_peak_tb_s": 8.0},
             "conv_family": {"achieved": fam_fl / fam_sec / 1e12, "frac": fam_fl / fam_sec / 1e12 / peak,
                             "executed_achieved": fam_ex / fam_sec / 1e12,
                             "executed_frac": fam_ex / fam_sec / 1e12 / peak,
                             "gflop_per_frame": fam_fl / (args.steps * B) / 1e9,
                             "ms_per_step": fam_sec / args.steps * 1e3,
                             "share_of_instrumented_time": fam_sec / all_sec,
+                            "two_roof_frac": sum(v[5] for v in conv.values()) / fam_sec,
+                            "hbm_bound_launches_per_step": sum(v[6] for v in conv.values()) / args.steps,
                             "by_kernel": {k: {"ms_per_step": v[1] / args.steps * 1e3,
                                               "achieved": v[0] / v[1] / 1e12,
                                               "executed_achieved": executed(k, v[0]) / v[1] / 1e12,
                                               "launches_per_step": v[2] / args.steps,
                                               "algorithmic_bytes_per_launch": v[3] / v[2] if v[3] else None,
+                                              "two_roof_frac": v[5] / v[1],
                                               "symbol": (max(v[4], key=v[4].get) if v[4] else None)}
                                           for k, v in conv.items()}},
             "other_kernels_ms_per_step": {k: v[1] / args.steps * 1e3 for k, v in by_kernel.items()
