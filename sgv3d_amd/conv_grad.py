@@ -54,7 +54,7 @@ def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, c
         nws = lib.sgv3d_conv2d_backward_weight_thin_workspace_bytes(ctypes.byref(d))
         ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
         dw = _dw_buffer(out, (cout, cin, kh, kw), x.device)
-        with torch.cuda.device(x.device), prof("conv_wgrad_thin", 2.0 * B * OH * OW * cout * cin * kh * kw):
+        with torch.cuda.device(x.device), prof("conv_wgrad_thin", 2.0 * B * OH * OW * cout * cin * kh * kw, 4.0 * (B * H * W * cin + B * OH * OW * cout + cout * cin * kh * kw)):
             rc = lib.sgv3d_conv2d_backward_weight_thin(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nws, _st(x))
         _lib.check(rc, "sgv3d_conv2d_backward_weight_thin")
         return dw
@@ -71,7 +71,7 @@ def conv2d_backward_weight(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=None, c
     name = "conv_wgrad"
     if hip_ops.PROFILE_DETAIL:
         name += f"|{B}x{H}x{W}x{cin}->{cout} k{kh} s{stride} d{dil} tile{int(tile)} split{int(split)}"
-    with torch.cuda.device(x.device), prof(name, 2.0 * B * OH * OW * cout * cin * kh * kw):
+    with torch.cuda.device(x.device), prof(name, 2.0 * B * OH * OW * cout * cin * kh * kw, 4.0 * (B * H * W * cin + B * OH * OW * cout + cout * cin * kh * kw)):
         rc = lib.sgv3d_conv2d_backward_weight(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(split),
                                               ws.data_ptr(), nws, _st(x))
     _lib.check(rc, "sgv3d_conv2d_backward_weight")
@@ -120,7 +120,7 @@ def conv2d_backward_weight_bf16(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=No
         name = "conv_wgrad_bf16_alltaps"
         if hip_ops.PROFILE_DETAIL:
             name += f"|{B}x{H}x{W}x{cin}->{cout} k{kh} s{stride} d{dil} tile6 split{int(split)}"
-        with torch.cuda.device(x.device), prof(name, 2.0 * B * OH * OW * cout * cin * kh * kw):
+        with torch.cuda.device(x.device), prof(name, 2.0 * B * OH * OW * cout * cin * kh * kw, 4.0 * (B * H * W * cin + B * OH * OW * cout + cout * cin * kh * kw)):
             rc = lib.sgv3d_conv2d_backward_weight_bf16_alltaps(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(split),
                                                                ws.data_ptr(), nws, _st(x))
         _lib.check(rc, "sgv3d_conv2d_backward_weight_bf16_alltaps")
@@ -131,7 +131,7 @@ def conv2d_backward_weight_bf16(x, dy, kernel, stride=1, pad=0, dil=1, *, cin=No
     name = "conv_wgrad_bf16"
     if hip_ops.PROFILE_DETAIL:
         name += f"|{B}x{H}x{W}x{cin}->{cout} k{kh} s{stride} d{dil} tile{int(tile)} split{int(split)}"
-    with torch.cuda.device(x.device), prof(name, 2.0 * B * OH * OW * cout * cin * kh * kw):
+    with torch.cuda.device(x.device), prof(name, 2.0 * B * OH * OW * cout * cin * kh * kw, 4.0 * (B * H * W * cin + B * OH * OW * cout + cout * cin * kh * kw)):
         rc = lib.sgv3d_conv2d_backward_weight_bf16(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(split),
                                                    ws.data_ptr(), nws, _st(x))
     _lib.check(rc, "sgv3d_conv2d_backward_weight_bf16")
@@ -164,7 +164,7 @@ def conv2d_backward_weight_batched(x, dys, pad=1, *, cin=None, cout=None, split=
             dws = [_dw_buffer(None if outs is None else outs[i], (cout, cin, 3, 3), x.device) for i in range(n)]
             dyp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dys])
             dwp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dws])
-            with torch.cuda.device(x.device), prof("conv_wgrad_bf16_alltaps", 2.0 * n * B * OH * OW * cout * cin * 9):
+            with torch.cuda.device(x.device), prof("conv_wgrad_bf16_alltaps", 2.0 * n * B * OH * OW * cout * cin * 9, 4.0 * (B * H * W * cin + n * (B * OH * OW * cout + cout * cin * 9))):
                 rc = lib.sgv3d_conv2d_backward_weight_bf16_alltaps_batched(ctypes.byref(d), x.data_ptr(), dyp, dwp, n, 0, ws.data_ptr(), nws, _st(x))
             _lib.check(rc, "sgv3d_conv2d_backward_weight_bf16_alltaps_batched")
             return dws
@@ -175,7 +175,7 @@ def conv2d_backward_weight_batched(x, dys, pad=1, *, cin=None, cout=None, split=
         dws = [_dw_buffer(None if outs is None else outs[i], (cout, cin, 3, 3), x.device) for i in range(n)]
         dyp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dys])
         dwp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dws])
-        with torch.cuda.device(x.device), prof("conv_wgrad_bf16", 2.0 * n * B * OH * OW * cout * cin * 9):
+        with torch.cuda.device(x.device), prof("conv_wgrad_bf16", 2.0 * n * B * OH * OW * cout * cin * 9, 4.0 * (B * H * W * cin + n * (B * OH * OW * cout + cout * cin * 9))):
             rc = lib.sgv3d_conv2d_backward_weight_bf16_batched(ctypes.byref(d), x.data_ptr(), dyp, dwp, n, int(sp), ws.data_ptr(), nws, _st(x))
         _lib.check(rc, "sgv3d_conv2d_backward_weight_bf16_batched")
         return dws
@@ -189,7 +189,7 @@ def conv2d_backward_weight_batched(x, dys, pad=1, *, cin=None, cout=None, split=
     dws = [_dw_buffer(None if outs is None else outs[i], (cout, cin, 3, 3), x.device) for i in range(n)]
     dyp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dys])
     dwp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dws])
-    with torch.cuda.device(x.device), prof("conv_wgrad", 2.0 * n * B * OH * OW * cout * cin * 9):
+    with torch.cuda.device(x.device), prof("conv_wgrad", 2.0 * n * B * OH * OW * cout * cin * 9, 4.0 * (B * H * W * cin + n * (B * OH * OW * cout + cout * cin * 9))):
         rc = lib.sgv3d_conv2d_backward_weight_batched(ctypes.byref(d), x.data_ptr(), dyp, dwp, n, int(split), ws.data_ptr(), nws, _st(x))
     _lib.check(rc, "sgv3d_conv2d_backward_weight_batched")
     return dws
@@ -467,7 +467,7 @@ def thin_conv3x3_backward_batched(xs, dys, weights, pad=1, *, need_dx=True, need
             dbs = [_dw_buffer(None if db_outs is None else db_outs[i], (couts[i],), dev) for i in range(n)]
     px = B * OH * OW
     flops = sum(2.0 * px * c * cin * 9 for c in couts) * (int(bool(need_dx)) + int(bool(need_dw)))
-    with torch.cuda.device(dev), prof("conv_thin_backward_batched", flops):
+    with torch.cuda.device(dev), prof("conv_thin_backward_batched", flops, 4.0 * n * (B * H * W * cin * (int(bool(need_dx)) + int(bool(need_dw or need_db))) + px * max(couts))):
         rc = lib.sgv3d_conv3x3_thin_backward_batched(
             ctypes.byref(d), n, cc, arr(xs), arr(dys), arr(weights), arr(dxs) if need_dx else None, arr(dws) if need_dw else None,
             arr(dbs) if need_db else None, _lib.ptr(ws), nws, _st(xs[0]))

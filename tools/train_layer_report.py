@@ -39,6 +39,10 @@ torch.cuda.synchronize()
 recs = hip_ops.PROFILE
 hip_ops.PROFILE = None
 rows = [(r[0], r[1], r[2].elapsed_time(r[3]) * 1e3) for r in recs]
+PEAK = 2.5e15 if os.environ.get("DTYPE", "f32") == "bf16" else 157.3e12
+# floor of a launch under both roofs: algorithmic flops at the MFMA peak of the mode's dtype, algorithmic bytes at 8 TB/s (BatchNorm:
+# 12 / 20 B per element are not recorded here -> no floor)
+floors = [(r[0], r[2].elapsed_time(r[3]) * 1e3, max((r[1] or 0) / PEAK, (r[4] or 0) / 8e12) * 1e6, (r[4] or 0)) for r in recs]
 tot = sum(r[2] for r in rows)
 agg = {}
 for n, f, us in rows:
@@ -51,3 +55,7 @@ for k, (us, f, n) in sorted(agg.items(), key=lambda x: -x[1][0])[:14]:
 print("--- launches by time" + (" (" + os.environ["FILTER"] + ")" if os.environ.get("FILTER") else ""))
 for n, f, us in sorted((r for r in rows if r[0].startswith(os.environ.get("FILTER", ""))), key=lambda r: -r[2])[:int(os.environ.get("TOP", "40"))]:
     print(f"{us:8.1f} us {(f or 0) / us / 1e6:6.1f} TF  {n}")
+
+print("--- launches by time above their two-roof floor (flops at the MFMA peak / bytes at 8 TB/s; launches that record bytes)")
+for n, us, fl, nb in sorted((f for f in floors if f[3] > 0), key=lambda f: -(f[1] - f[2]))[:int(os.environ.get("TOP", "40"))]:
+    print(f"{us:8.1f} us  floor {fl:7.1f} us  {nb / us / 1e6:5.2f} TB/s  {n}")
