@@ -197,7 +197,11 @@ def run_other_configs(args, budget_s=120.0):
                     "value": rec["value"], "unit": "frames/s", "ms_per_step": rec["ms_per_step"], "steps": rec["steps"],
                     "frames_in_flight": rec["config"]["frames_in_flight"],
                     "conv_family_frac": (rf.get("conv_family") or {}).get("frac"), "dominant_kernel": rf.get("kernel"),
-                    "dominant_kernel_frac": rf.get("frac"), "roofline_hbm_frac": rh.get("frac"),
+                    # against BOTH roofs per launch (the large 1x1 layers of these configs are HBM-bound in bf16)
+                    "conv_family_two_roof_frac": (rf.get("conv_family") or {}).get("two_roof_frac"),
+                    "conv_family_hbm_bound_launches_per_step": (rf.get("conv_family") or {}).get("hbm_bound_launches_per_step"),
+                    "dominant_kernel_frac": rf.get("frac"), "dominant_kernel_two_roof_frac": (rf.get("two_roof") or {}).get("frac"),
+                    "roofline_hbm_frac": rh.get("frac"),
                     "parity": {k: par.get(k) for k in ("max_abs_err", "max_abs_ref", "rel_err", "tolerance",
                                                        "voxel_indices_equal", "ok")},
                     "exit_code": r.returncode, "wall_s": time.perf_counter() - t0})

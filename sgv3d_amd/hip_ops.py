@@ -572,8 +572,11 @@ class PackedConv:
             if occ:
                 name += "_occ5"
         # algorithmic bytes: input map (the channels this layer reads), weights, output (+ residual), each once
-        nbytes = 4.0 * (B * H * W * self.cin_real + self.cout_real * self.cin_real * self.kh * self.kw * (self.ks * self.ks if self.transposed else 1)
-                        + gemm_m * real_n * (2 if residual is not None else 1))
+        # (element sizes as the tensors are stored: bf16 activations in HBM count 2 bytes)
+        nbytes = (float(x.element_size()) * B * H * W * self.cin_real
+                  + (2.0 if MFMA_BF16 else 4.0) * self.cout_real * self.cin_real * self.kh * self.kw * (self.ks * self.ks if self.transposed else 1)
+                  + float(out.element_size()) * gemm_m * real_n
+                  + (float(residual.element_size()) * gemm_m * real_n if residual is not None else 0.0))
         if PROFILE_DETAIL:
             name += (f"|{B}x{H}x{W}x{self.cin}->{self.cout} k{self.kh if not self.transposed else -self.ks} "
                      f"s{self.stride} d{self.dil} splitk{sk}" + (" mfirst" if 20 < t < 30 or t == 45 else "") + (" occ5" if t in OCC5_TILES else ""))

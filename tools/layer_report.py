@@ -41,5 +41,16 @@ for i, name, flops, us in rows:
     tf = flops / us / 1e6 if flops else 0
     print(f"{i:3d} {us:8.1f} {tf:6.1f} {tf / (2500.0 if hip_ops.MFMA_BF16 else 157.3) * 100:5.1f}  {name}")
 print("total us", tot)
+# launches ranked by time above their two-roof floor: algorithmic flops at the mode's MFMA peak, algorithmic bytes at 8 TB/s (the byte
+# count of a record assumes f32 tensors; with bf16 activations in HBM the true floor is up to 2x lower)
+PEAK = 2.5e15 if hip_ops.MFMA_BF16 else 157.3e12
+ex = []
+for i, name, flops, us in rows:
+    nb = recs[i][4] or 0
+    fl = max((flops or 0) / PEAK, nb / 8e12) * 1e6
+    ex.append((us - fl, us, fl, nb, name))
+print("--- by time above the two-roof floor")
+for d, us, fl, nb, name in sorted(ex, reverse=True)[:int(os.environ.get("TOP", "30"))]:
+    print(f"{us:8.1f} us  floor {fl:7.1f} us  {nb / us / 1e6 if us else 0:5.2f} TB/s  {name}")
 json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "layers.json"), "w"))
 hip_ops.save_tune_db()          # no-op unless SGV3D_TUNE_CACHE is set (tools/layer_traffic.py replays the same choices under rocprofv3)
