@@ -66,6 +66,8 @@ TRAIN_BF16_WGRAD = _os.environ.get("SGV3D_TRAIN_BF16_WGRAD", "1") != "0"
 # ... and 3x3 / stride-1 layers may use the all-taps form (conv_wgrad3x3_bf16.hip: a workgroup owns a 64 x 64 tile for all nine taps;
 # the batched CenterHead launch always, single layers where the first-call measurement / the tune DB says so); 0: per-tap kernel only
 WGRAD_BF16_ALLTAPS = _os.environ.get("SGV3D_WGRAD_BF16_ALLTAPS", "1") != "0"
+# 1x1 layers with unpadded channel counts read the OIHW weight tensor itself as their packed weights (diagnostic: 0 packs a copy)
+ALIAS_1X1_WEIGHTS = _os.environ.get("SGV3D_ALIAS_1X1_WEIGHTS", "1") != "0"
 # True (SGV3D_F32X3=1): the implicit-GEMM layers compute float32-accurate products on the bf16 matrix cores -- every
 # operand is split exactly into three bf16 terms and six partial products are accumulated in f32 (csrc/conv_igemm.hip,
 # SPLIT3): the error of a product is one f32 rounding, the MFMA time 192 instead of 512 cycles per 16 k.  Winograd
@@ -338,6 +340,13 @@ class PackedConv:
             src = self._keep
             odim = 1 if self.transposed else 0
             cout, cin = int(src.shape[odim]), int(src.shape[1 - odim])
+            if (ALIAS_1X1_WEIGHTS and not self.transposed and self.kh == 1 and self.kw == 1 and cout == self.cout_pad and cin == self.k_pad
+                    and self.cin == cin and src.is_contiguous() and src.data_ptr() % 16 == 0):
+                # a 1x1 layer whose channel counts need no padding: OIHW [cout, cin, 1, 1] IS the packed layout [cout_pad, k_pad] (one tap:
+                # both k orders are the identity) -- no pack launch (a training step repacks every layer's weights, forward and data
+                # gradient, at ~5 us per launch)
+                self._w = src.view(self.cout_pad, self.k_pad)
+                return self._w
             self._w = torch.empty(self.cout_pad, self.k_pad, dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
                 rc = _lib.load().sgv3d_conv_pack_weight(src.data_ptr(), cout, cin, int(src.shape[2]), int(src.shape[3]), self.cin,

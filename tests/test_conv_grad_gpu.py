@@ -214,8 +214,8 @@ def test_wgrad_bf16_batched_matches_single_launches():
     B, H, W, cin, cout, n = 2, 21, 45, 64, 64, 5
     x = torch.randn(B, H, W, cin, generator=g)
     dys = [torch.randn(B, H, W, cout, generator=g) for _ in range(n)]
-    saved = hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS
-    hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS = True, False
+    saved = hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS, hip_ops.WGRAD_BF16_ALLTAPS
+    hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS, hip_ops.WGRAD_BF16_ALLTAPS = True, False, False     # the per-tap form (all taps: its own test below)
     try:
         hip_ops.PROFILE = []
         got = conv_grad.conv2d_backward_weight_batched(x.cuda(), [d.cuda() for d in dys])
@@ -224,7 +224,7 @@ def test_wgrad_bf16_batched_matches_single_launches():
         again = conv_grad.conv2d_backward_weight_batched(x.cuda(), [d.cuda() for d in dys])
     finally:
         hip_ops.PROFILE = None
-        hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS = saved
+        hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS, hip_ops.WGRAD_BF16_ALLTAPS = saved
     assert all(torch.equal(a, b) for a, b in zip(got, again))
     for d, dw in zip(dys, got):
         _, _, dw_ref = _reference(x.bfloat16().float(), torch.zeros(cout, cin, 3, 3), d.bfloat16().float(), 1, 1, 1)
