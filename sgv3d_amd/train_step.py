@@ -341,7 +341,7 @@ class GraphedTrainStep:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(max(1, int(warmup))):      # on the capture stream: allocator pools, lazily created state
+            for _ in range(max(0, int(warmup))):      # on the capture stream: allocator pools, lazily created state
                 self._eager(lr)
             side.synchronize()
             g = torch.cuda.CUDAGraph()

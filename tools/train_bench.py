@@ -24,6 +24,8 @@ ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                 help="bf16 = mixed-precision step: every convolution product (forward, data gradient, weight gradient) on the bf16 matrix "
                      "cores with f32 accumulation; parameters, gradients, activations, BatchNorm, loss and AdamW stay f32")
 ap.add_argument("--no-overlap", action="store_true", help="all-reduce after backward instead of from grad hooks")
+ap.add_argument("--no-dropout", action="store_true", help="Dropout(p=0) instead of the training default 0.5 (comparisons that must not depend on the random stream)")
+ap.add_argument("--trace-loss", action="store_true", help="record the loss of every timed step (a host read per step: not for timing)")
 ap.add_argument("--graph", action="store_true", help="the whole step (forward, targets, loss, backward, AdamW) as ONE hipGraph replay "
                 "(train_step.GraphedTrainStep); single process only: with a process group the gradient all-reduce stays outside the graph")
 ap.add_argument("--profile", action="store_true", help="per-kernel-family times of one step (HIP events, eager)")
@@ -46,11 +48,11 @@ torch.manual_seed(0)
 model = BEVHeight(bconf, hconf, is_train_height=BSM).to(dev).train()
 for m in model.modules():
     if isinstance(m, torch.nn.Dropout):
-        m.p = 0.5
+        m.p = 0.0 if args.no_dropout else 0.5
 if args.config == "small":
     model.head.train_cfg = dict(model.head.train_cfg, grid_size=[256, 256, 1], point_cloud_range=[0, -12.8, -5, 25.6, 12.8, 3])
 imgs = synthetic.make_images(args.batch, final=bconf['final_dim'], device=dev, seed=group.rank)
-mats = synthetic.make_mats(args.batch, device=dev)
+mats = synthetic.make_mats(args.batch, device=dev, scale=bconf['final_dim'][0] / 864)      # (calibration of the image size in use)
 boxes, labels = synthetic.make_gt(args.batch, seed=group.rank, n_range=(10, 40), stress=False)
 boxes, labels = [b.to(dev) for b in boxes], [l.to(dev) for l in labels]
 if BSM:
@@ -88,25 +90,40 @@ def step():
 EARLY = [0]
 
 
+loss = None
 for _ in range(args.warmup):
     loss = step().detach()              # (no reference to the autograd graph is kept: GraphedTrainStep)
 torch.cuda.synchronize()
-run = step
+LAST = [loss]
+
+
+def run():                                  # (the reported loss is the LAST timed step's, eagerly and graphed)
+    LAST[0] = step().detach()
+    return LAST[0]
+
+
 if args.graph:
     from sgv3d_amd.train_step import GraphedTrainStep
     graphed = GraphedTrainStep(forward_backward, opt, strict=True)
     run = graphed
     loss = run()
     torch.cuda.synchronize()
+TRACE = []
+if args.trace_loss:
+    _run = run
+
+    def run():
+        v = _run()
+        TRACE.append(float(v.detach()))
+        return v
 elapsed = group.timed(run, args.steps)
-if args.graph:
-    loss = graphed.result
+loss = graphed.result if args.graph else LAST[0]
 out = {"metric": "training samples/s (forward + loss + backward + all-reduce + AdamW)", "value": group.world * args.batch * args.steps / elapsed,
        "unit": "samples/s", "n_gpus": group.world, "steps": args.steps, "ms_per_step": 1e3 * elapsed / args.steps,
        "batch_per_gpu": args.batch, "global_batch": args.batch * group.world, "dtype": args.dtype,
        "world_size": group.dist.get_world_size() if group.dist is not None else 1, "backend": group.backend,
        "allreduce_bytes_per_step": 4 * sum(g.numel() for _, g, _ in opt.flat.buckets), "allreduce_buckets": len(opt.flat.buckets),
-       "allreduce_overlapped_with_backward": not args.no_overlap, "parameters": nparam, "loss": float(loss.detach()), "config": args.config, "graph": bool(args.graph), "graph_replays": graphed.replays if args.graph else 0,
+       "allreduce_overlapped_with_backward": not args.no_overlap, "parameters": nparam, "loss": float(loss.detach()), "config": args.config, "loss_trace": TRACE or None, "graph": bool(args.graph), "graph_replays": graphed.replays if args.graph else 0,
        "update_in_graph": bool(graphed.in_graph_update) if args.graph else None, "optimizer_steps": opt.steps,
        "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2**30, "data": "synthetic",
        # (a 1-rank group with SGV3D_FORCE_DIST=1 still broadcasts / all-reduces through RCCL: the single-GPU stand-in for cfg-4)
