@@ -7,14 +7,14 @@
 // (blockIdx.y / blockIdx.z = layer) every SIMD holds 4 waves of independent work:
 //
 //   thin_wgrad_kernel   dW[c][ci][r][s] = sum_p dY[p][c] X[p + (r, s) - pad][ci]  and  db[c] = sum_p dY[p][c]
-//                       a lane owns one input channel, a wave walks 32-pixel row segments: the 3 x 18 input values of its channel
-//                       in registers (coalesced 256-byte rows), the dY values of 16 pixels in ONE coalesced load, broadcast
+//                       a lane owns one input channel, a wave walks units of 3 output rows x 32 pixels: the 5 x 18 input values of its
+//                       channel in registers (coalesced 256-byte rows), the dY values of 8 pixels of a row in ONE coalesced load, broadcast
 //                       with v_readlane, 9 x COUT (+ COUT for the bias) FMAs per pixel.  Waves meet in LDS in wave order, one
 //                       partial set per workgroup in the workspace, thin_reduce_kernel adds them in workgroup order
 //                       (deterministic) into OIHW / the bias gradient.
 //   thin_dgrad_kernel   dX[p][ci] = sum_{r,s,c} dY[p + pad - (r, s)][c] W[c][ci][r][s]
 //                       a lane owns 4 consecutive input channels of 4 consecutive pixels (16 lanes = one 256-byte pixel row of 64
-//                       channels), its 9 x COUT x 4 weights in registers for the whole launch, the 3 x 6 x COUT dY values of a
+//                       channels) of 2 rows, its 9 x COUT x 4 weights in registers for the whole launch, the 4 x 6 x COUT dY values of a
 //                       unit from L1 / L2 (dY of a layer is 0.5-1.5 MB), 16-byte stores.  No LDS, no barrier.
 //
 // Bound: HBM (X read once per layer for dW, dX written once per layer: 33.5 MB each at batch 2 of cfg-2).
@@ -29,7 +29,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kMaxLayers = 48;
 constexpr int kSeg = 32;             // pixels per unit of the weight-gradient kernel
-constexpr int kDSeg = 16;            // pixels per unit of the data-gradient kernel (4 lanes-groups x 4 pixels)
+constexpr int kRB = 3;               // output rows per unit of the weight-gradient kernel (kRB + 2 input rows in registers)
+constexpr int kCh = 8;               // ... walked kCh pixels at a time
+constexpr int kDSeg = 16;            // pixels per row of a unit of the data-gradient kernel (4 lanes-groups x 4 pixels)
 
 struct ThinBArgs {
     const float *x[kMaxLayers];
@@ -42,8 +44,8 @@ struct ThinBArgs {
     unsigned char group[kMaxLayers]; // the layers of the launch's output-channel count (the kernels are instantiated per count)
     float *ws;
     int n, batch, in_h, in_w, out_h, out_w, pad, cin;
-    int segs, units, wgs;            // weight gradient: 32-pixel segments per output row, units per layer, workgroups per layer
-    int dsegs, dunits;               // data gradient: 16-pixel segments per input row, units per layer
+    int segs, bands, units, wgs;     // weight gradient: 32-pixel segments per output row, bands of kRB rows, units per layer, workgroups per layer
+    int dsegs, dunits;               // data gradient: 16-pixel segments per input row, rows x segments per layer (a unit is 1 or 2 rows)
     unsigned x_bytes;                // extent of one x / dx tensor
     unsigned ypix;                   // batch * out_h * out_w (dy of layer i holds ypix * cout[i] floats)
 };
@@ -66,13 +68,16 @@ __device__ __forceinline__ void thin_wgrad_body(const ThinBArgs &a, const int la
         for (int c = 0; c < COUT; ++c) acc[t][c] = 0.f;
     const unsigned x_c = (unsigned)ci * 4u, xrow = (unsigned)a.cin * 4u;
     for (int u = gw; u < a.units; u += waves) {
+        // a unit = kRB consecutive output rows of one 32-pixel segment: their kRB + 2 input rows are loaded once (a row alone would
+        // pull its three input rows, i.e. every input element three times through L2)
         const int seg = u % a.segs, t0 = u / a.segs;
-        const int oy = t0 % a.out_h, img = t0 / a.out_h;
+        const int band = t0 % a.bands, img = t0 / a.bands;
+        const int oy0 = band * kRB;
         const int ox_begin = seg * kSeg, ox_end = min(ox_begin + kSeg, a.out_w);
-        const int iy0 = oy - a.pad;
-        unsigned rowoff[3];
+        const int iy0 = oy0 - a.pad;
+        unsigned rowoff[kRB + 2];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < kRB + 2; ++r) {
             const int iy = iy0 + r;
             rowoff[r] = (ci_ok && (unsigned)iy < (unsigned)a.in_h) ? (unsigned)((img * a.in_h + iy) * a.in_w) * xrow + x_c : kOob;
         }
@@ -80,37 +85,44 @@ __device__ __forceinline__ void thin_wgrad_body(const ThinBArgs &a, const int la
             const unsigned off = (rowoff[r] != kOob && (unsigned)ix < (unsigned)a.in_w) ? rowoff[r] + (unsigned)ix * xrow : kOob;
             return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off, 0, 0));
         };
-        float w[3][18];
+        float w[kRB + 2][kCh + 2];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < kRB + 2; ++r) {
             w[r][0] = load_x(r, ox_begin - a.pad);
             w[r][1] = load_x(r, ox_begin - a.pad + 1);
         }
-        const unsigned ybase = (unsigned)((img * a.out_h + oy) * a.out_w) * (unsigned)(COUT * 4);
-        for (int ox0 = ox_begin; ox0 < ox_end; ox0 += 16) {
-            // dY of 16 pixels: lane l holds element l of the row's flat (pixel, channel) array starting at pixel ox0
+        for (int ox0 = ox_begin; ox0 < ox_end; ox0 += kCh) {
+            // dY of kCh pixels of each row: lane l holds element l of the row's flat (pixel, channel) array starting at pixel ox0
             const int px = lane / COUT;
-            const bool yok = ox0 + px < ox_end && px < 16;     // pixels past the segment's end multiply dY = 0
-            const float dyv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                y_rsrc, yok ? ybase + (unsigned)(ox0 * COUT + lane) * 4u : kOob, 0, 0));
+            const bool yok = ox0 + px < ox_end && px < kCh;    // pixels past the segment's end multiply dY = 0
+            float dyv[kRB];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) w[r][2 + j] = load_x(r, ox0 - a.pad + 2 + j);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-#pragma unroll
-                for (int c = 0; c < COUT; ++c) {
-                    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dyv), j * COUT + c));
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int s2 = 0; s2 < 3; ++s2) acc[r * 3 + s2][c] = __builtin_fmaf(d, w[r][j + s2], acc[r * 3 + s2][c]);
-                    acc[9][c] += d;                             // the bias gradient (the same sum in every lane)
-                }
+            for (int o = 0; o < kRB; ++o) {
+                const int oy = oy0 + o;
+                const unsigned ybase = (unsigned)((img * a.out_h + oy) * a.out_w) * (unsigned)(COUT * 4);
+                dyv[o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    y_rsrc, (yok && oy < a.out_h) ? ybase + (unsigned)(ox0 * COUT + lane) * 4u : kOob, 0, 0));
             }
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { w[r][0] = w[r][16]; w[r][1] = w[r][17]; }
+            for (int r = 0; r < kRB + 2; ++r)
+#pragma unroll
+                for (int j = 0; j < kCh; ++j) w[r][2 + j] = load_x(r, ox0 - a.pad + 2 + j);
+#pragma unroll
+            for (int o = 0; o < kRB; ++o)
+#pragma unroll
+                for (int j = 0; j < kCh; ++j) {
+#pragma unroll
+                    for (int c = 0; c < COUT; ++c) {
+                        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dyv[o]), j * COUT + c));
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int s2 = 0; s2 < 3; ++s2) acc[r * 3 + s2][c] = __builtin_fmaf(d, w[o + r][j + s2], acc[r * 3 + s2][c]);
+                        acc[9][c] += d;                         // the bias gradient (the same sum in every lane)
+                    }
+                }
+#pragma unroll
+            for (int r = 0; r < kRB + 2; ++r) { w[r][0] = w[r][kCh]; w[r][1] = w[r][kCh + 1]; }
         }
     }
     // the four waves of the workgroup meet in LDS and are added in wave order; one partial set per workgroup
@@ -185,44 +197,54 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinBArgs &a, const int la
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy[layer], 0, (int)(a.ypix * COUT * 4u), 0x00020000);
     float *dx = a.dx[layer];
     const int stride_u = gridDim.x * 4;
-    for (int u = blockIdx.x * 4 + wave; u < a.dunits; u += stride_u) {
+    constexpr int kDR = COUT <= 3 ? 2 : 1;                     // rows per unit (4 output channels: the second row's window would spill)
+    const int dbands = (a.in_h + kDR - 1) / kDR, dunits = a.batch * dbands * a.dsegs;
+    for (int u = blockIdx.x * 4 + wave; u < dunits; u += stride_u) {
+        // a unit = kDR consecutive rows of one 16-pixel segment: their kDR + 2 rows of dY are fetched once
         const int xs = u % a.dsegs, t0 = u / a.dsegs;
-        const int iy = t0 % a.in_h, img = t0 / a.in_h;
+        const int band = t0 % dbands, img = t0 / dbands;
+        const int iy0 = band * kDR;
         const int px0 = xs * kDSeg + g * 4;
-        f32x2 lo[4], hi[4];
+        float d[kDR + 2][6][COUT];                             // dY rows iy0 + pad - 2 + q, columns px0 + pad - 2 + j
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { lo[k] = f32x2{0.f, 0.f}; hi[k] = f32x2{0.f, 0.f}; }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int oy = iy + a.pad - r;
+        for (int qq = 0; qq < kDR + 2; ++qq) {
+            const int oy = iy0 + a.pad - 2 + qq;
             const bool row_ok = (unsigned)oy < (unsigned)a.out_h;
             const unsigned rowbase = (unsigned)((img * a.out_h + oy) * a.out_w);
-            float d[6][COUT];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int ox = px0 + a.pad - 2 + j;
                 const unsigned off = (row_ok && (unsigned)ox < (unsigned)a.out_w) ? (rowbase + (unsigned)ox) * (unsigned)(COUT * 4) : kOob;
 #pragma unroll
                 for (int c = 0; c < COUT; ++c)
-                    d[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y_rsrc, off + (unsigned)c * 4u, 0, 0));
+                    d[qq][j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y_rsrc, off + (unsigned)c * 4u, 0, 0));
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int s = 0; s < 3; ++s)
-#pragma unroll
-                    for (int c = 0; c < COUT; ++c) {
-                        const float dv = d[k + 2 - s][c];
-                        const f32x2 d2 = f32x2{dv, dv};
-                        lo[k] = __builtin_elementwise_fma(d2, wlo[r * 3 + s][c], lo[k]);
-                        hi[k] = __builtin_elementwise_fma(d2, whi[r * 3 + s][c], hi[k]);
-                    }
         }
-        if (q_ok) {
-            float *row = dx + ((size_t)(img * a.in_h + iy) * a.in_w) * a.cin + ci;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (px0 + k < a.in_w) *reinterpret_cast<f32x4 *>(row + (size_t)(px0 + k) * a.cin) = f32x4{lo[k][0], lo[k][1], hi[k][0], hi[k][1]};
+        for (int o = 0; o < kDR; ++o) {
+            f32x2 lo[4], hi[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { lo[k] = f32x2{0.f, 0.f}; hi[k] = f32x2{0.f, 0.f}; }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)                        // output row iy0 + o, tap row r: dY row iy0 + o + pad - r = window row o + 2 - r
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+                        for (int c = 0; c < COUT; ++c) {
+                            const float dv = d[o + 2 - r][k + 2 - s2][c];
+                            const f32x2 d2 = f32x2{dv, dv};
+                            lo[k] = __builtin_elementwise_fma(d2, wlo[r * 3 + s2][c], lo[k]);
+                            hi[k] = __builtin_elementwise_fma(d2, whi[r * 3 + s2][c], hi[k]);
+                        }
+            const int iy = iy0 + o;
+            if (q_ok && iy < a.in_h) {
+                float *row = dx + ((size_t)(img * a.in_h + iy) * a.in_w) * a.cin + ci;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (px0 + k < a.in_w) *reinterpret_cast<f32x4 *>(row + (size_t)(px0 + k) * a.cin) = f32x4{lo[k][0], lo[k][1], hi[k][0], hi[k][1]};
+            }
         }
     }
 }
@@ -251,7 +273,8 @@ int fill(const sgv3d_conv_desc *d, int n, const int32_t *cout, ThinBArgs &a) {
     }
     a.n = n; a.batch = d->batch; a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w; a.pad = d->pad; a.cin = d->cin;
     a.segs = cdiv(d->out_w, kSeg);
-    a.units = d->batch * d->out_h * a.segs;
+    a.bands = cdiv(d->out_h, kRB);
+    a.units = d->batch * a.bands * a.segs;
     // about four waves per SIMD over the whole launch (1024 workgroups of 4 waves on 256 CUs), at least one unit per wave
     const int chunks = cdiv(d->cin, 64);
     int wgs = cdiv(1024, n * chunks);
