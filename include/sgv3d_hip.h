@@ -774,6 +774,12 @@ int sgv3d_conv2d_backward_weight_thin(const sgv3d_conv_desc *desc /*host*/, cons
  * (16-byte aligned), dw_list[i] OIHW, db_list[i] [cout[i]] (= sum of dy over the pixels); single entries of dw_list / db_list may
  * be NULL.  All lists are HOST arrays of device pointers.  Deterministic (fixed-order partial sums).  workspace (weight / bias
  * gradients only): ..._workspace_bytes(desc, n, cout). */
+/* ... and their forward (cin <= 64): y_list[i] = conv3x3(x_list[i], w_list[i]) + bias_list[i] in f32 arithmetic whatever the mode,
+ * y_list[i] CONTIGUOUS [batch, out_h, out_w, cout[i]]; bias_list or entries of it may be NULL.  The MFMA kernels pad these layers to 64
+ * output columns (64 us per 33 MB layer at cfg-2 batch 2); here a layer is one pass over its input at HBM speed. */
+int sgv3d_conv3x3_thin_forward_batched(const sgv3d_conv_desc *desc /*host*/, int n, const int32_t *cout /*host*/,
+                                       const float *const *x_list /*host*/, const float *const *w_list /*host*/,
+                                       const float *const *bias_list /*host*/, float *const *y_list /*host*/, void *stream);
 size_t sgv3d_conv3x3_thin_backward_batched_workspace_bytes(const sgv3d_conv_desc *desc /*host*/, int n, const int32_t *cout /*host*/);
 int sgv3d_conv3x3_thin_backward_batched(const sgv3d_conv_desc *desc /*host*/, int n, const int32_t *cout /*host*/,
                                         const float *const *x_list /*host*/, const float *const *dy_list /*host*/,

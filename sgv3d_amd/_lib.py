@@ -140,6 +140,7 @@ _PROTOS = {
     "sgv3d_conv2d_backward_weight_batched_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc), c_int, c_int]),
     "sgv3d_conv2d_backward_weight_batched": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "sgv3d_conv2d_backward_weight_thin": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "sgv3d_conv3x3_thin_forward_batched": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(ctypes.c_int32)] + [ctypes.POINTER(c_void_p)] * 4 + [c_void_p]),
     "sgv3d_conv3x3_thin_backward_batched_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(ctypes.c_int32)]),
     "sgv3d_conv3x3_thin_backward_batched": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(ctypes.c_int32)] + [ctypes.POINTER(c_void_p)] * 6 + [c_void_p, c_size_t, c_void_p]),
     "sgv3d_weight_rot180_transpose": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),

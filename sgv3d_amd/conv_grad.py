@@ -18,7 +18,7 @@ from . import _lib, grad_slots
 from .hip_ops import ConvDesc, PackedConv, prof, _st
 
 __all__ = ['conv2d_backward_weight', 'conv2d_backward_weight_bf16', 'conv2d_backward_weight_batched', 'conv2d_backward_data', 'zero_insert', 'conv2d', 'conv_transpose2d',
-           'multi_conv2d', 'thin_conv3x3_backward_batched', 'multi_thin_conv2d', 'thin_conv_eligible']
+           'multi_conv2d', 'thin_conv3x3_forward_batched', 'thin_conv3x3_backward_batched', 'multi_thin_conv2d', 'thin_conv_eligible']
 
 
 def _out_hw(h, w, k, stride, pad, dil):
@@ -475,6 +475,34 @@ def thin_conv3x3_backward_batched(xs, dys, weights, pad=1, *, need_dx=True, need
     return dxs, dws, dbs
 
 
+def thin_conv3x3_forward_batched(xs, weights, biases=None, pad=1):
+    """[conv3x3(x, w, stride 1) + b] of n layers with 1..4 output channels and at most 64 input channels in one launch per
+    output-channel count (sgv3d_conv3x3_thin_forward_batched, f32 arithmetic): NHWC f32 ``xs[i]`` [B, H, W, cin] -> [B, OH, OW, cout_i]."""
+    n = len(xs)
+    assert n == len(weights) and 0 < n <= 48
+    B, H, W, cin = (int(v) for v in xs[0].shape)
+    OH, OW = _out_hw(H, W, (3, 3), 1, pad, 1)
+    dev = xs[0].device
+    couts = [int(w.shape[0]) for w in weights]
+    for x, w, c in zip(xs, weights, couts):
+        assert x.shape == xs[0].shape and x.is_contiguous() and x.dtype == torch.float32 and x.is_cuda
+        assert tuple(w.shape) == (c, cin, 3, 3) and w.is_contiguous() and w.dtype == torch.float32
+    d = ConvDesc()
+    d.batch, d.in_h, d.in_w, d.cin, d.out_h, d.out_w, d.cout = B, H, W, cin, OH, OW, max(couts)
+    d.kh, d.kw, d.stride, d.pad, d.dil = 3, 3, 1, int(pad), 1
+    d.x_ld, d.x_coff, d.y_ld, d.y_coff = cin, 0, max(couts), 0
+    ys = [torch.empty(B, OH, OW, c, dtype=torch.float32, device=dev) for c in couts]
+    cc = (ctypes.c_int32 * n)(*couts)
+    arr = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    bl = None if biases is None else [None if b is None else b.detach().float().contiguous() for b in biases]
+    with torch.cuda.device(dev), prof("conv_thin_forward_batched", sum(2.0 * B * OH * OW * c * cin * 9 for c in couts),
+                                      4.0 * n * (B * H * W * cin + B * OH * OW * max(couts))):
+        rc = _lib.load().sgv3d_conv3x3_thin_forward_batched(ctypes.byref(d), n, cc, arr(xs), arr(weights), None if bl is None else arr(bl), arr(ys),
+                                                            _st(xs[0]))
+    _lib.check(rc, "sgv3d_conv3x3_thin_forward_batched")
+    return ys
+
+
 def thin_conv_eligible(convs, xs):
     """Whether ``multi_thin_conv2d`` takes these nn.Conv2d layers on these inputs."""
     if not (1 < len(convs) <= 48 and len(convs) == len(xs)):
@@ -495,6 +523,9 @@ class _MultiThinConv2dNHWC(torch.autograd.Function):
         ctx.save_for_backward(*xs, *weights)
         ctx.has_bias = [b is not None for b in biases]
         ctx.bias_refs = biases                      # (parameters: only their gradient slots are looked up in backward)
+        if int(xs[0].shape[-1]) <= 64 and all(x.dtype == torch.float32 and x.is_contiguous() for x in xs):
+            # one launch per output-channel count instead of one MFMA launch per layer padded to 64 output columns
+            return tuple(thin_conv3x3_forward_batched(list(xs), [w.detach() for w in weights], list(biases), 1))
         return tuple(PackedConv(w, stride=1, pad=1, shift=b, cin_pad=int(x.shape[-1]))(x) for x, w, b in zip(xs, weights, biases))
 
     @staticmethod

@@ -17,7 +17,9 @@
 //                       channels) of 2 rows, its 9 x COUT x 4 weights in registers for the whole launch, the 4 x 6 x COUT dY values of a
 //                       unit from L1 / L2 (dY of a layer is 0.5-1.5 MB), 16-byte stores.  No LDS, no barrier.
 //
-// Bound: HBM (X read once per layer for dW, dX written once per layer: 33.5 MB each at batch 2 of cfg-2).
+//   thin_fwd_kernel     the forward of the same layers (cin <= 64), f32 FMAs + a 16-lane DPP reduction per pixel: see below.
+//
+// Bound: HBM (X read once per layer for dW / the forward, dX written once per layer: 33.5 MB each at batch 2 of cfg-2).
 #include "common.hpp"
 
 using namespace sgv3d;
@@ -254,6 +256,101 @@ __global__ __launch_bounds__(256) void thin_dgrad_kernel(const ThinBArgs a) {
     thin_dgrad_body<COUT>(a, a.group[blockIdx.y]);
 }
 
+// ------------------------------------------------------------------------------------------------------------- forward
+// y[p][c] = bias[c] + sum_{r,s,ci} X[p + (r, s) - pad][ci] W[c][ci][r][s] for cin <= 64: a lane owns 4 consecutive input channels of
+// 4 consecutive pixels (16 lanes = the 64 channels of a pixel), its 9 x COUT x 4 weights in registers for the whole launch, the
+// 3 x 6 window of float4 input values of a unit loaded once (coalesced 256-byte pixel rows), 9 x 4 x COUT FMAs per pixel and lane,
+// then the 16 lanes of a pixel are added with four row-shift DPP steps.  f32 arithmetic in every mode.  The MFMA kernels pad
+// these layers to 64 output columns and run them at 0.5 TB/s (64 us per 33 MB layer); here a layer is one pass at HBM speed.
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float v) {          // value of lane (l - N) of the 16-lane row, 0 outside the row
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+template <int COUT>
+__device__ __forceinline__ void thin_fwd_body(const ThinBArgs &a, const int layer) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane & 15, g = lane >> 4;
+    const int ci = q * 4;
+    const bool q_ok = ci < a.cin;
+    f32x4 wv[9][COUT];
+    {
+        const float *w = a.w[layer];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < COUT; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wv[t][c][k] = q_ok ? w[((size_t)c * a.cin + ci + k) * 9 + t] : 0.f;
+    }
+    float bias[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) bias[c] = a.db[layer] ? a.db[layer][c] : 0.f;        // (forward: db carries the bias vector, dx the output)
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x[layer], 0, (int)a.x_bytes, 0x00020000);
+    float *y = a.dx[layer];
+    const unsigned xrow = (unsigned)a.cin * 4u;
+    const int osegs = (a.out_w + kDSeg - 1) / kDSeg, ounits = a.batch * a.out_h * osegs;
+    const int stride_u = gridDim.x * 4;
+    for (int u = blockIdx.x * 4 + wave; u < ounits; u += stride_u) {
+        const int xs = u % osegs, t0 = u / osegs;
+        const int oy = t0 % a.out_h, img = t0 / a.out_h;
+        const int px0 = xs * kDSeg + g * 4;
+        float acc[4][COUT];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) acc[k][c] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oy - a.pad + r;
+            const bool row_ok = q_ok && (unsigned)iy < (unsigned)a.in_h;
+            const unsigned rowbase = (unsigned)((img * a.in_h + iy) * a.in_w);
+            f32x4 xv[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int ix = px0 - a.pad + j;
+                const unsigned off = (row_ok && (unsigned)ix < (unsigned)a.in_w) ? (rowbase + (unsigned)ix) * xrow + (unsigned)ci * 4u : kOob;
+                xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+                    for (int c = 0; c < COUT; ++c) {
+                        const f32x4 xx = xv[k + s2], ww = wv[r * 3 + s2][c];
+                        acc[k][c] = __builtin_fmaf(xx[0], ww[0], __builtin_fmaf(xx[1], ww[1], __builtin_fmaf(xx[2], ww[2], __builtin_fmaf(xx[3], ww[3], acc[k][c]))));
+                    }
+        }
+        // the 16 lanes of a pixel: lane 15 of the row ends up with the sum (fixed order)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) {
+                float v = acc[k][c];
+                v += row_dpp<0x118>(v);          // row_shr:8
+                v += row_dpp<0x114>(v);          // row_shr:4
+                v += row_dpp<0x112>(v);          // row_shr:2
+                v += row_dpp<0x111>(v);          // row_shr:1
+                acc[k][c] = v;
+            }
+        if (q == 15) {
+            float *row = y + ((size_t)(img * a.out_h + oy) * a.out_w) * COUT;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (px0 + k < a.out_w) {
+#pragma unroll
+                    for (int c = 0; c < COUT; ++c) row[(size_t)(px0 + k) * COUT + c] = acc[k][c] + bias[c];
+                }
+        }
+    }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void thin_fwd_kernel(const ThinBArgs a) {
+    thin_fwd_body<COUT>(a, a.group[blockIdx.y]);
+}
+
 int fill(const sgv3d_conv_desc *d, int n, const int32_t *cout, ThinBArgs &a) {
     SGV3D_REQUIRE(d && cout, "conv3x3_thin_backward_batched: null descriptor / cout list");
     SGV3D_REQUIRE(n >= 1 && n <= kMaxLayers, "conv3x3_thin_backward_batched: 1 .. %d layers", kMaxLayers);
@@ -352,6 +449,45 @@ extern "C" int sgv3d_conv3x3_thin_backward_batched(const sgv3d_conv_desc *d, int
     if (want_w) {
         thin_reduce_kernel<<<dim3(cdiv(10 * 4 * a.cin, 256), n), 256, 0, st>>>(a);
         if (int rc = check_launch("thin_reduce_kernel")) return rc;
+    }
+    return SGV3D_OK;
+}
+
+// Forward of the same n layers (cin <= 64): y_list[i] = conv3x3(x_list[i], w_list[i]) + bias_list[i], y CONTIGUOUS [batch, out_h, out_w, cout[i]]
+// f32; bias_list or single entries of it may be NULL.  One launch per output-channel count present.
+extern "C" int sgv3d_conv3x3_thin_forward_batched(const sgv3d_conv_desc *d, int n, const int32_t *cout, const float *const *x_list,
+                                                  const float *const *w_list, const float *const *bias_list, float *const *y_list,
+                                                  void *stream) {
+    ThinBArgs a;
+    if (int rc = fill(d, n, cout, a)) return rc;
+    SGV3D_REQUIRE(a.cin <= 64, "conv3x3_thin_forward_batched: at most 64 input channels (got %d)", a.cin);
+    SGV3D_REQUIRE(x_list && w_list && y_list, "conv3x3_thin_forward_batched: null list");
+    for (int i = 0; i < n; ++i) {
+        SGV3D_REQUIRE(x_list[i] && w_list[i] && y_list[i], "conv3x3_thin_forward_batched: null pointer (layer %d)", i);
+        SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(x_list[i]) & 15) == 0, "conv3x3_thin_forward_batched: x must be 16-byte aligned (layer %d)", i);
+        a.x[i] = x_list[i];
+        a.w[i] = w_list[i];
+        a.dx[i] = y_list[i];                       // (the argument block's dx / db slots carry the output and the bias in the forward)
+        a.db[i] = bias_list ? const_cast<float *>(bias_list[i]) : nullptr;
+    }
+    hipStream_t st = as_stream(stream);
+    const int units = a.batch * a.out_h * cdiv(a.out_w, kDSeg);
+    int wgs = cdiv(1024, n);
+    wgs = wgs < 1 ? 1 : wgs;
+    wgs = wgs > cdiv(units, 4) ? cdiv(units, 4) : wgs;
+    for (int c = 1; c <= 4; ++c) {
+        int m = 0;
+        for (int i = 0; i < n; ++i)
+            if (a.cout[i] == c) a.group[m++] = (unsigned char)i;
+        if (m == 0) continue;
+        const dim3 grid(wgs, m);
+        switch (c) {
+            case 1: thin_fwd_kernel<1><<<grid, 256, 0, st>>>(a); break;
+            case 2: thin_fwd_kernel<2><<<grid, 256, 0, st>>>(a); break;
+            case 3: thin_fwd_kernel<3><<<grid, 256, 0, st>>>(a); break;
+            default: thin_fwd_kernel<4><<<grid, 256, 0, st>>>(a); break;
+        }
+        if (int rc = check_launch("thin_fwd_kernel")) return rc;
     }
     return SGV3D_OK;
 }
