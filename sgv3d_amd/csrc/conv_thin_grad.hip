@@ -374,7 +374,14 @@ int fill(const sgv3d_conv_desc *d, int n, const int32_t *cout, ThinBArgs &a) {
     a.units = d->batch * a.bands * a.segs;
     // about four waves per SIMD over the whole launch (1024 workgroups of 4 waves on 256 CUs), at least one unit per wave
     const int chunks = cdiv(d->cin, 64);
-    int wgs = cdiv(1024, n * chunks);
+    // one launch per output-channel count: ~4 workgroups per CU for the SMALLEST of those launches (one count for all layers: the
+    // partial sums of every layer have the same workspace stride)
+    int cnt[5] = {0, 0, 0, 0, 0}, mmin = n;
+    for (int i = 0; i < n; ++i) ++cnt[a.cout[i]];
+    for (int c = 1; c <= 4; ++c)
+        if (cnt[c] > 0 && cnt[c] < mmin) mmin = cnt[c];
+    int wgs = cdiv(1024, mmin * chunks);
+    wgs = wgs > 256 ? 256 : wgs;
     wgs = wgs < 1 ? 1 : wgs;
     wgs = wgs > cdiv(a.units, 4) ? cdiv(a.units, 4) : wgs;
     a.wgs = wgs;
@@ -417,9 +424,6 @@ extern "C" int sgv3d_conv3x3_thin_backward_batched(const sgv3d_conv_desc *d, int
     a.ws = static_cast<float *>(workspace);
     hipStream_t st = as_stream(stream);
     const int chunks = cdiv(a.cin, 64);
-    int dwgs = cdiv(1024, n * chunks);
-    dwgs = dwgs < 1 ? 1 : dwgs;
-    dwgs = dwgs > cdiv(a.dunits, 4) ? cdiv(a.dunits, 4) : dwgs;
     for (int c = 1; c <= 4; ++c) {                       // one launch per output-channel count present (CenterHead: 1, 2, 3)
         int m = 0;
         for (int i = 0; i < n; ++i)
@@ -436,7 +440,9 @@ extern "C" int sgv3d_conv3x3_thin_backward_batched(const sgv3d_conv_desc *d, int
             if (int rc = check_launch("thin_wgrad_kernel")) return rc;
         }
         if (want_x) {
-            const dim3 grid(dwgs, m, chunks);
+            int gw = cdiv(1024, m * chunks);                // per launch, as above
+            gw = gw > cdiv(a.dunits, 4) ? cdiv(a.dunits, 4) : gw;
+            const dim3 grid(gw < 1 ? 1 : gw, m, chunks);
             switch (c) {
                 case 1: thin_dgrad_kernel<1><<<grid, 256, 0, st>>>(a); break;
                 case 2: thin_dgrad_kernel<2><<<grid, 256, 0, st>>>(a); break;
@@ -472,14 +478,13 @@ extern "C" int sgv3d_conv3x3_thin_forward_batched(const sgv3d_conv_desc *d, int 
     }
     hipStream_t st = as_stream(stream);
     const int units = a.batch * a.out_h * cdiv(a.out_w, kDSeg);
-    int wgs = cdiv(1024, n);
-    wgs = wgs < 1 ? 1 : wgs;
-    wgs = wgs > cdiv(units, 4) ? cdiv(units, 4) : wgs;
     for (int c = 1; c <= 4; ++c) {
         int m = 0;
         for (int i = 0; i < n; ++i)
             if (a.cout[i] == c) a.group[m++] = (unsigned char)i;
         if (m == 0) continue;
+        int wgs = cdiv(1024, m);                           // ~4 workgroups per CU over THIS launch (the layers of one channel count)
+        wgs = wgs > cdiv(units, 4) ? cdiv(units, 4) : wgs;
         const dim3 grid(wgs, m);
         switch (c) {
             case 1: thin_fwd_kernel<1><<<grid, 256, 0, st>>>(a); break;
