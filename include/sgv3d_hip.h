@@ -768,7 +768,8 @@ int sgv3d_conv2d_backward_weight_thin(const sgv3d_conv_desc *desc /*host*/, cons
                                       size_t workspace_bytes, void *stream);
 /* The WHOLE backward of n such thin layers in one launch per gradient kind (csrc/conv_thin_grad.hip; the 36 final layers of the
  * CenterHead branches, layers/heads/bev_height_head.py:75-110 through mmdet3d SeparateHead -- the reference asks cuDNN per layer and
- * gradient).  desc: batch, in_h, in_w, cin (multiple of 4; x_ld == cin, x_coff == 0), out_h, out_w, pad, kh = kw = 3, stride = dil = 1;
+ * gradient).  desc: batch, in_h, in_w, cin (multiple of 4), x_ld >= cin (pixel stride of the x / dx tensors: a layer may read / write a channel slice
+ * of a wider map, passed as the pointer to its first channel; x_coff == 0), out_h, out_w, pad, kh = kw = 3, stride = dil = 1;
  * cout[i] in 1..4 (host); x_list[i] [batch, in_h, in_w, cin]; dy_list[i] CONTIGUOUS [batch, out_h, out_w, cout[i]]; w_list[i] OIHW
  * [cout[i], cin, 3, 3].  Outputs, each list optional (NULL: that gradient is not computed): dx_list[i] [batch, in_h, in_w, cin]
  * (16-byte aligned), dw_list[i] OIHW, db_list[i] [cout[i]] (= sum of dy over the pixels); single entries of dw_list / db_list may

@@ -18,7 +18,7 @@ from . import _lib, grad_slots
 from .hip_ops import ConvDesc, PackedConv, prof, _st
 
 __all__ = ['conv2d_backward_weight', 'conv2d_backward_weight_bf16', 'conv2d_backward_weight_batched', 'conv2d_backward_data', 'zero_insert', 'conv2d', 'conv_transpose2d',
-           'multi_conv2d', 'thin_conv3x3_forward_batched', 'thin_conv3x3_backward_batched', 'multi_thin_conv2d', 'thin_conv_eligible']
+           'multi_conv2d', 'thin_conv3x3_forward_batched', 'thin_conv3x3_backward_batched', 'multi_thin_conv2d', 'sliced_thin_conv2d', 'cat_params', 'thin_conv_eligible']
 
 
 def _out_hw(h, w, k, stride, pad, dil):
@@ -431,11 +431,13 @@ class _MultiConv2dNHWC(torch.autograd.Function):
         return (dx, *dws)
 
 
-def thin_conv3x3_backward_batched(xs, dys, weights, pad=1, *, need_dx=True, need_dw=True, need_db=False, dw_outs=None, db_outs=None):
+def thin_conv3x3_backward_batched(xs, dys, weights, pad=1, *, need_dx=True, need_dw=True, need_db=False, dw_outs=None, db_outs=None, dx_like=None):
     """The whole backward of n 3x3 / stride-1 convolutions with 1..4 output channels (sgv3d_conv3x3_thin_backward_batched): one launch
     per gradient kind and output-channel count instead of three launches per layer.  ``xs[i]`` NHWC f32 [B, H, W, cin] (one shape for
     all), ``dys[i]`` NHWC f32 [B, OH, OW, cout_i], ``weights[i]`` OIHW [cout_i, cin, 3, 3].  Returns (dxs | None, dws | None, dbs | None);
-    ``dw_outs`` / ``db_outs``: per-layer output buffers or None entries (gradient slots of the flat buckets)."""
+    ``dw_outs`` / ``db_outs``: per-layer output buffers or None entries (gradient slots of the flat buckets).  The ``xs`` may be the n
+    equal channel slices of one contiguous map (``x_ld`` = its channel count); ``dx_like`` is then an empty map of that shape whose slices
+    receive the data gradients."""
     n = len(xs)
     assert n == len(dys) == len(weights) and 0 < n <= 48
     B, H, W, cin = (int(v) for v in xs[0].shape)
@@ -444,18 +446,25 @@ def thin_conv3x3_backward_batched(xs, dys, weights, pad=1, *, need_dx=True, need
     assert (OH, OW) == _out_hw(H, W, (3, 3), 1, pad, 1)
     couts = [int(w.shape[0]) for w in weights]
     dys = [d.contiguous() for d in dys]
+    x_ld = _slice_ld(xs)
     for x, d, w, c in zip(xs, dys, weights, couts):
-        assert x.shape == xs[0].shape and x.is_contiguous() and x.dtype == torch.float32 and x.is_cuda
         assert tuple(d.shape) == (B, OH, OW, c) and d.dtype == torch.float32
         assert tuple(w.shape) == (c, cin, 3, 3) and w.is_contiguous() and w.dtype == torch.float32
     d = ConvDesc()
     d.batch, d.in_h, d.in_w, d.cin, d.out_h, d.out_w, d.cout = B, H, W, cin, OH, OW, max(couts)
     d.kh, d.kw, d.stride, d.pad, d.dil = 3, 3, 1, int(pad), 1
-    d.x_ld, d.x_coff, d.y_ld, d.y_coff = cin, 0, max(couts), 0
+    d.x_ld, d.x_coff, d.y_ld, d.y_coff = x_ld, 0, max(couts), 0
     lib = _lib.load()
     cc = (ctypes.c_int32 * n)(*couts)
     arr = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
-    dxs = [torch.empty_like(x) for x in xs] if need_dx else None
+    dxs = None
+    if need_dx:
+        if dx_like is not None:                    # channel slices of ONE map shaped like the one the inputs are slices of
+            assert x_ld > cin and tuple(dx_like.shape) == (B, H, W, x_ld) and dx_like.is_contiguous() and x_ld == n * cin
+            dxs = [dx_like[..., i * cin:(i + 1) * cin] for i in range(n)]
+        else:
+            assert x_ld == cin, "channel-slice inputs: pass dx_like (the map to write the data gradients' slices into)"
+            dxs = [torch.empty_like(x) for x in xs]
     dws = dbs = None
     ws, nws = None, 0
     if need_dw or need_db:
@@ -475,6 +484,19 @@ def thin_conv3x3_backward_batched(xs, dys, weights, pad=1, *, need_dx=True, need
     return dxs, dws, dbs
 
 
+def _slice_ld(xs):
+    """Pixel stride (floats) of the NHWC f32 tensors ``xs``: contiguous tensors (stride = channel count) or equal channel slices of a
+    contiguous map; all of one shape and one stride, 16-byte aligned."""
+    B, H, W, cin = (int(v) for v in xs[0].shape)
+    ld = int(xs[0].stride(2))
+    for x in xs:
+        assert x.shape == xs[0].shape and x.dtype == torch.float32 and x.is_cuda and x.data_ptr() % 16 == 0
+        assert x.stride(3) == 1 and int(x.stride(2)) == ld and int(x.stride(1)) == W * ld and int(x.stride(0)) == H * W * ld, \
+            "NHWC tensors or channel slices of one NHWC map"
+    assert ld >= cin and ld % 4 == 0
+    return ld
+
+
 def thin_conv3x3_forward_batched(xs, weights, biases=None, pad=1):
     """[conv3x3(x, w, stride 1) + b] of n layers with 1..4 output channels and at most 64 input channels in one launch per
     output-channel count (sgv3d_conv3x3_thin_forward_batched, f32 arithmetic): NHWC f32 ``xs[i]`` [B, H, W, cin] -> [B, OH, OW, cout_i]."""
@@ -484,13 +506,13 @@ def thin_conv3x3_forward_batched(xs, weights, biases=None, pad=1):
     OH, OW = _out_hw(H, W, (3, 3), 1, pad, 1)
     dev = xs[0].device
     couts = [int(w.shape[0]) for w in weights]
-    for x, w, c in zip(xs, weights, couts):
-        assert x.shape == xs[0].shape and x.is_contiguous() and x.dtype == torch.float32 and x.is_cuda
+    x_ld = _slice_ld(xs)
+    for w, c in zip(weights, couts):
         assert tuple(w.shape) == (c, cin, 3, 3) and w.is_contiguous() and w.dtype == torch.float32
     d = ConvDesc()
     d.batch, d.in_h, d.in_w, d.cin, d.out_h, d.out_w, d.cout = B, H, W, cin, OH, OW, max(couts)
     d.kh, d.kw, d.stride, d.pad, d.dil = 3, 3, 1, int(pad), 1
-    d.x_ld, d.x_coff, d.y_ld, d.y_coff = cin, 0, max(couts), 0
+    d.x_ld, d.x_coff, d.y_ld, d.y_coff = x_ld, 0, max(couts), 0
     ys = [torch.empty(B, OH, OW, c, dtype=torch.float32, device=dev) for c in couts]
     cc = (ctypes.c_int32 * n)(*couts)
     arr = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
@@ -545,6 +567,72 @@ class _MultiThinConv2dNHWC(torch.autograd.Function):
         none = [None] * n
         dbs = none if dbs is None else [g if h else None for g, h in zip(dbs, ctx.has_bias)]
         return (None, *(dxs or none), *(dws or none), *dbs)
+
+
+class _SlicedThinConv2dNHWC(torch.autograd.Function):
+    """The n thin layers of _MultiThinConv2dNHWC reading the n equal channel slices of ONE map [B, H, W, n * cin] (the hidden maps of
+    the CenterHead branches kept as one tensor): the data gradients are written into the slices of one map of the same shape."""
+    @staticmethod
+    def forward(ctx, big, n, *args):
+        weights, biases = args[:n], args[n:2 * n]
+        cin = int(big.shape[-1]) // n
+        ctx.n, ctx.cin = n, cin
+        ctx.save_for_backward(big, *weights)
+        ctx.has_bias = [b is not None for b in biases]
+        ctx.bias_refs = biases
+        xs = [big[..., i * cin:(i + 1) * cin] for i in range(n)]
+        return tuple(thin_conv3x3_forward_batched(xs, [w.detach() for w in weights], list(biases), 1))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n, cin = ctx.n, ctx.cin
+        big, *weights = ctx.saved_tensors
+        B, H, W, _ = (int(v) for v in big.shape)
+        dys = [torch.zeros(B, H, W, int(w.shape[0]), dtype=torch.float32, device=big.device) if d is None else d for d, w in zip(dys, weights)]
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = any(ctx.needs_input_grad[2:2 + n])
+        need_db = any(h and g for h, g in zip(ctx.has_bias, ctx.needs_input_grad[2 + n:2 + 2 * n]))
+        dbig = torch.empty_like(big) if need_dx else None
+        xs = [big[..., i * cin:(i + 1) * cin] for i in range(n)]
+        _, dws, dbs = thin_conv3x3_backward_batched(
+            xs, dys, [w.detach() for w in weights], 1, need_dx=need_dx, need_dw=need_dw, need_db=need_db, dx_like=dbig,
+            dw_outs=[grad_slots.claim(w) for w in weights] if need_dw else None,
+            db_outs=[grad_slots.claim(b) if h else None for b, h in zip(ctx.bias_refs, ctx.has_bias)] if need_db else None)
+        none = [None] * n
+        dbs = none if dbs is None else [g if h else None for g, h in zip(dbs, ctx.has_bias)]
+        return (dbig, None, *(dws or none), *dbs)
+
+
+def sliced_thin_conv2d(big, convs):
+    """[conv(big[..., i * cin:(i + 1) * cin]) for i, conv in enumerate(convs)] for thin 3x3 layers (``thin_conv_eligible`` on the
+    slices); see _SlicedThinConv2dNHWC."""
+    n = len(convs)
+    return _SlicedThinConv2dNHWC.apply(big.contiguous(), n, *[c.weight for c in convs], *[c.bias for c in convs])
+
+
+class _CatParams(torch.autograd.Function):
+    """torch.cat(params, 0) whose backward hands every parameter its slice of the gradient through ONE multi-tensor copy, into the
+    parameters' gradient slots of the flat buckets where they are free (autograd's own cat backward is a narrow + accumulate per
+    parameter: 36 launches for the CenterHead's first-layer weights)."""
+    @staticmethod
+    def forward(ctx, *params):
+        ctx.refs = params
+        ctx.sizes = [int(p.shape[0]) for p in params]
+        return torch.cat([p.detach() for p in params], 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        srcs = list(g.contiguous().split(ctx.sizes, 0))
+        dsts = []
+        for p, s_ in zip(ctx.refs, srcs):
+            slot = grad_slots.claim(p)
+            dsts.append(slot if slot is not None else torch.empty_like(s_))
+        torch._foreach_copy_(dsts, srcs)
+        return tuple(d if need else None for d, need in zip(dsts, ctx.needs_input_grad))
+
+
+def cat_params(params):
+    return _CatParams.apply(*params)
 
 
 def multi_thin_conv2d(xs, convs):

@@ -46,6 +46,7 @@ struct ThinBArgs {
     unsigned char group[kMaxLayers]; // the layers of the launch's output-channel count (the kernels are instantiated per count)
     float *ws;
     int n, batch, in_h, in_w, out_h, out_w, pad, cin;
+    int x_ld;                        // floats per pixel of the x / dx tensors (>= cin: the layers may read / write channel slices of wider maps)
     int segs, bands, units, wgs;     // weight gradient: 32-pixel segments per output row, bands of kRB rows, units per layer, workgroups per layer
     int dsegs, dunits;               // data gradient: 16-pixel segments per input row, rows x segments per layer (a unit is 1 or 2 rows)
     unsigned x_bytes;                // extent of one x / dx tensor
@@ -68,7 +69,7 @@ __device__ __forceinline__ void thin_wgrad_body(const ThinBArgs &a, const int la
     for (int t = 0; t < 10; ++t)
 #pragma unroll
         for (int c = 0; c < COUT; ++c) acc[t][c] = 0.f;
-    const unsigned x_c = (unsigned)ci * 4u, xrow = (unsigned)a.cin * 4u;
+    const unsigned x_c = (unsigned)ci * 4u, xrow = (unsigned)a.x_ld * 4u;
     for (int u = gw; u < a.units; u += waves) {
         // a unit = kRB consecutive output rows of one 32-pixel segment: their kRB + 2 input rows are loaded once (a row alone would
         // pull its three input rows, i.e. every input element three times through L2)
@@ -242,10 +243,10 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinBArgs &a, const int la
                         }
             const int iy = iy0 + o;
             if (q_ok && iy < a.in_h) {
-                float *row = dx + ((size_t)(img * a.in_h + iy) * a.in_w) * a.cin + ci;
+                float *row = dx + ((size_t)(img * a.in_h + iy) * a.in_w) * a.x_ld + ci;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (px0 + k < a.in_w) *reinterpret_cast<f32x4 *>(row + (size_t)(px0 + k) * a.cin) = f32x4{lo[k][0], lo[k][1], hi[k][0], hi[k][1]};
+                    if (px0 + k < a.in_w) *reinterpret_cast<f32x4 *>(row + (size_t)(px0 + k) * a.x_ld) = f32x4{lo[k][0], lo[k][1], hi[k][0], hi[k][1]};
             }
         }
     }
@@ -288,7 +289,7 @@ __device__ __forceinline__ void thin_fwd_body(const ThinBArgs &a, const int laye
     for (int c = 0; c < COUT; ++c) bias[c] = a.db[layer] ? a.db[layer][c] : 0.f;        // (forward: db carries the bias vector, dx the output)
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x[layer], 0, (int)a.x_bytes, 0x00020000);
     float *y = a.dx[layer];
-    const unsigned xrow = (unsigned)a.cin * 4u;
+    const unsigned xrow = (unsigned)a.x_ld * 4u;
     const int osegs = (a.out_w + kDSeg - 1) / kDSeg, ounits = a.batch * a.out_h * osegs;
     const int stride_u = gridDim.x * 4;
     for (int u = blockIdx.x * 4 + wave; u < ounits; u += stride_u) {
@@ -356,11 +357,12 @@ int fill(const sgv3d_conv_desc *d, int n, const int32_t *cout, ThinBArgs &a) {
     SGV3D_REQUIRE(n >= 1 && n <= kMaxLayers, "conv3x3_thin_backward_batched: 1 .. %d layers", kMaxLayers);
     SGV3D_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad >= 0 && d->pad <= 2,
                   "conv3x3_thin_backward_batched: 3x3 / stride 1 / dilation 1 layers, pad 0 .. 2");
-    SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cin % 4 == 0 && d->x_ld == d->cin && d->x_coff == 0,
-                  "conv3x3_thin_backward_batched: contiguous NHWC inputs with a channel count that is a multiple of 4");
+    SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cin % 4 == 0 && d->x_ld >= d->cin && d->x_ld % 4 == 0 && d->x_coff == 0,
+                  "conv3x3_thin_backward_batched: NHWC inputs with channel count and pixel stride multiples of 4 (x_ld >= cin: a channel slice "
+                  "of a wider map is passed as the pointer to its first channel)");
     SGV3D_REQUIRE(d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2 && d->out_h > 0 && d->out_w > 0,
                   "conv3x3_thin_backward_batched: output size does not belong to this input size");
-    const unsigned long long xb = (unsigned long long)d->batch * d->in_h * d->in_w * d->cin * 4ull;
+    const unsigned long long xb = ((unsigned long long)d->batch * d->in_h * d->in_w - 1) * d->x_ld * 4ull + d->cin * 4ull;      // extent from the slice's first channel
     const unsigned long long yp = (unsigned long long)d->batch * d->out_h * d->out_w;
     SGV3D_REQUIRE(xb < kOob && yp * 16ull < kOob, "conv3x3_thin_backward_batched: tensors must be smaller than 1 GiB");
     a = ThinBArgs{};
@@ -368,7 +370,7 @@ int fill(const sgv3d_conv_desc *d, int n, const int32_t *cout, ThinBArgs &a) {
         SGV3D_REQUIRE(cout[i] >= 1 && cout[i] <= 4, "conv3x3_thin_backward_batched: 1 .. 4 output channels per layer (layer %d has %d)", i, cout[i]);
         a.cout[i] = (unsigned char)cout[i];
     }
-    a.n = n; a.batch = d->batch; a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w; a.pad = d->pad; a.cin = d->cin;
+    a.n = n; a.batch = d->batch; a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w; a.pad = d->pad; a.cin = d->cin; a.x_ld = d->x_ld;
     a.segs = cdiv(d->out_w, kSeg);
     a.bands = cdiv(d->out_h, kRB);
     a.units = d->batch * a.bands * a.segs;

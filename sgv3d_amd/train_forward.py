@@ -44,6 +44,7 @@ from .ops.voxel_pooling import voxel_pooling
 
 __all__ = ['bevheight_train_forward']
 
+HEAD_CONCAT = os.environ.get("SGV3D_HEAD_CONCAT", "1") != "0"        # 0: the CenterHead branches as n separate maps (diagnostic)
 THIN_BATCHED = os.environ.get("SGV3D_THIN_BATCHED", "1") != "0"      # 0: the CenterHead's final layers one by one (diagnostic)
 
 
@@ -268,6 +269,27 @@ def head_forward(head, bev):
     batched = (len(firsts) == len(seqs) and 1 < len(firsts) <= 48 and shared.shape[-1] % 4 == 0 and
                all(c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.bias is None and
                    c.weight.shape == firsts[0].weight.shape and c.weight.shape[0] % 4 == 0 for c in firsts))
+    finals = [seq[-1] for _, _, seq in seqs]
+    bns = [seq[0].bn for _, _, seq in seqs] if batched else []
+    if (batched and HEAD_CONCAT and all(isinstance(b, nn.BatchNorm2d) and b.training and b.track_running_stats and b.affine and b.momentum is not None
+                                        and b.eps == bns[0].eps and b.momentum == bns[0].momentum for b in bns)
+            and conv_grad.thin_conv_eligible(finals, [shared.new_empty((1, 1, 1, int(firsts[0].weight.shape[0])))] * len(finals))
+            and int(firsts[0].weight.shape[0]) <= 64):
+        # the n branches as ONE wide map: a single convolution with the n first-layer weights concatenated (one forward, one data-gradient
+        # and one weight-gradient launch instead of n each, and no running sum through n residual epilogues), BatchNorm over the n * 64
+        # channels in one launch sequence (it is per channel), the final layers on the map's channel slices (conv_grad.sliced_thin_conv2d)
+        from .norm_grad import batch_norm_act_multi
+        big = conv_grad.conv2d(shared, conv_grad.cat_params([c.weight for c in firsts]), None, 1, 1, 1)
+        hid = batch_norm_act_multi(bns, big, relu=True)
+        outs = conv_grad.sliced_thin_conv2d(hid, finals)
+        ret, k = [], 0
+        for th in head.task_heads:
+            d = {}
+            for name in th.heads:
+                d[name] = _nchw(outs[k])
+                k += 1
+            ret.append([d])
+        return tuple(ret)
     first_out = conv_grad.multi_conv2d(shared, [c.weight for c in firsts]) if batched else None
     hidden, k = [], 0
     for _, _, seq in seqs:
@@ -281,7 +303,6 @@ def head_forward(head, bev):
         hidden.append(y)
     # ... and the final layers (64 -> 1..3 channels) have their whole backward -- data, weight and bias gradients of all branches -- as
     # one batched call (conv_grad.multi_thin_conv2d; three launches per layer otherwise, each a few microseconds of work)
-    finals = [seq[-1] for _, _, seq in seqs]
     if THIN_BATCHED and conv_grad.thin_conv_eligible(finals, hidden):
         outs = conv_grad.multi_thin_conv2d(hidden, finals)
     else:
