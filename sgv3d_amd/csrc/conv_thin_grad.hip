@@ -53,7 +53,7 @@ struct ThinBArgs {
     unsigned ypix;                   // batch * out_h * out_w (dy of layer i holds ypix * cout[i] floats)
 };
 
-constexpr unsigned kOob = 0x40000000u;     // byte offset beyond every buffer here (extents < 1 GiB are required), also after small immediates
+constexpr unsigned kOob = 0xc0000000u;     // byte offset beyond every buffer here (extents < 3 GiB are required), also after small immediates
 
 // ------------------------------------------------------------------------------------------------ weight + bias gradient
 template <int COUT>
@@ -364,7 +364,7 @@ int fill(const sgv3d_conv_desc *d, int n, const int32_t *cout, ThinBArgs &a) {
                   "conv3x3_thin_backward_batched: output size does not belong to this input size");
     const unsigned long long xb = ((unsigned long long)d->batch * d->in_h * d->in_w - 1) * d->x_ld * 4ull + d->cin * 4ull;      // extent from the slice's first channel
     const unsigned long long yp = (unsigned long long)d->batch * d->out_h * d->out_w;
-    SGV3D_REQUIRE(xb < kOob && yp * 16ull < kOob, "conv3x3_thin_backward_batched: tensors must be smaller than 1 GiB");
+    SGV3D_REQUIRE(xb < kOob && yp * 16ull < kOob, "conv3x3_thin_backward_batched: tensors (a slice: the extent from its first channel) must be smaller than 3 GiB");
     a = ThinBArgs{};
     for (int i = 0; i < n; ++i) {
         SGV3D_REQUIRE(cout[i] >= 1 && cout[i] <= 4, "conv3x3_thin_backward_batched: 1 .. 4 output channels per layer (layer %d has %d)", i, cout[i]);

@@ -274,7 +274,8 @@ def head_forward(head, bev):
     if (batched and HEAD_CONCAT and all(isinstance(b, nn.BatchNorm2d) and b.training and b.track_running_stats and b.affine and b.momentum is not None
                                         and b.eps == bns[0].eps and b.momentum == bns[0].momentum for b in bns)
             and conv_grad.thin_conv_eligible(finals, [shared.new_empty((1, 1, 1, int(firsts[0].weight.shape[0])))] * len(finals))
-            and int(firsts[0].weight.shape[0]) <= 64):
+            and int(firsts[0].weight.shape[0]) <= 64
+            and shared.shape[0] * shared.shape[1] * shared.shape[2] * len(firsts) * int(firsts[0].weight.shape[0]) * 4 < (3 << 30)):      # (the thin kernels address < 3 GiB)
         # the n branches as ONE wide map: a single convolution with the n first-layer weights concatenated (one forward, one data-gradient
         # and one weight-gradient launch instead of n each, and no running sum through n residual epilogues), BatchNorm over the n * 64
         # channels in one launch sequence (it is per channel), the final layers on the map's channel slices (conv_grad.sliced_thin_conv2d)
