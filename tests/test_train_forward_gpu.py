@@ -48,7 +48,7 @@ def _oracle_loss(preds, targets, code_weights):
     return total
 
 
-def _compare_with_oracle(spread_regressions=False):
+def _compare_with_oracle(spread_regressions=False, yardstick=None, frustum=True):
     """One training-mode forward / backward of the small model on the GPU and in float64 through the oracle: (worst relative
     prediction error over the maps, relative loss error, [(relative L2 gradient error, name, |want|)] sorted descending).
     ``spread_regressions``: the final layers of the regression branches get N(0, 1) biases, so that the L1 loss's residuals are
@@ -65,7 +65,10 @@ def _compare_with_oracle(spread_regressions=False):
     head_cfg = dict(model.head.train_cfg, grid_size=[256, 256, 1], point_cloud_range=[0, -12.8, -5, 25.6, 12.8, 3])
     model.head.train_cfg = head_cfg
     imgs = synthetic.make_images(B, final=bconf['final_dim'], device='cuda', seed=3)
-    mats = synthetic.make_mats(B, device='cuda')
+    # frustum: the calibration of the reduced image size, so that the lifted points land in the BEV grid and the image path carries
+    # gradients; False: the full-size calibration -- the frustum misses the reduced grid, the BEV map is empty and only the head, the BEV
+    # trunk and the loss are compared (the mixed-precision per-tensor test, see there)
+    mats = synthetic.make_mats(B, device='cuda', scale=bconf['final_dim'][0] / 864 if frustum else 1.0)
     boxes, labels = _gt(B)
     preds = model(imgs, mats)
     targets = model.get_targets([b.cuda() for b in boxes], [l.cuda() for l in labels])
@@ -98,17 +101,42 @@ def _compare_with_oracle(spread_regressions=False):
         rel = float((got - want).norm() / (want.norm() + 1e-12))
         worst.append((rel, n, float(want.norm())))
     worst.sort(reverse=True)
+    if frustum:
+        assert sum(1 for w in worst if 'img_backbone' in w[1] and w[2] > 1e-6) > 20, "the image backbone must receive gradients (frustum inside the grid)"
+    if yardstick is not None:
+        # the SAME forward / backward through the oracle in float32 (torch on the CPU): what plain f32 arithmetic makes of this
+        # untrained batch-2 network, whose backward amplifies rounding by orders of magnitude
+        sd32 = {k: (v.detach().cpu().float() if v.dtype.is_floating_point else v.detach().cpu()) for k, v in model.state_dict().items()}
+        for n in names:
+            sd32[n].requires_grad_(True)
+        p32 = O.bevheight_train_forward(sd32, bconf, hconf, imgs.cpu(), {k: v.cpu() for k, v in mats.items()})
+        t32 = tuple([x.cpu() for x in part] for part in targets)
+        _oracle_loss(p32, t32, head_cfg['code_weights']).backward()
+        for n in names:
+            if sd[n].grad is not None and sd32[n].grad is not None:
+                yardstick.append((float((sd32[n].grad.double() - sd[n].grad).norm() / (sd[n].grad.norm() + 1e-12)), n, float(sd[n].grad.norm())))
+        yardstick.sort(reverse=True)
     return pred_err, loss_err, worst
 
 
 def test_training_forward_backward_matches_oracle():
-    pred_err, loss_err, worst = _compare_with_oracle()
+    """Predictions, loss and the gradient of every parameter against the float64 oracle, with the frustum inside the BEV grid (the
+    image path carries gradients).  The backward of this untrained batch-2 network is ill-conditioned: the oracle itself evaluated in
+    float32 (torch on the CPU) lands at a median relative L2 error of 1.5e-2 per tensor, 6e-2 at the 90th percentile, 0.12 worst.  The
+    HIP path has to be at least as close to float64 as that (it is ~4x closer: double-precision BatchNorm sums), and inside absolute
+    bars."""
+    yard = []
+    pred_err, loss_err, worst = _compare_with_oracle(yardstick=yard)
     assert pred_err <= 2e-3 and loss_err <= 1e-3, (pred_err, loss_err)
-    print('largest relative gradient errors:', [(f'{r:.1e}', n) for r, n, _ in worst[:5]])
-    bad = [w for w in worst if w[0] > 5e-3 and w[2] > 1e-7]
-    assert not bad, bad[:10]
-    assert sorted(w[0] for w in worst)[len(worst) // 2] < 3e-4          # typical tensor: fp32 rounding only
-    assert len(worst) > 150
+    live = [w for w in worst if w[2] > 1e-7]
+    ylive = [w for w in yard if w[2] > 1e-7]
+    stat = lambda rows: (sorted(r[0] for r in rows)[len(rows) // 2], sorted(r[0] for r in rows)[int(len(rows) * 0.9)], max(r[0] for r in rows))
+    (m, p90, mx), (ym, yp90, ymx) = stat(live), stat(ylive)
+    print(f'gradient tensors, relative L2 error to float64: HIP median {m:.1e} / p90 {p90:.1e} / worst {mx:.1e}; '
+          f'torch float32 {ym:.1e} / {yp90:.1e} / {ymx:.1e}; worst HIP tensors', [(f'{r:.1e}', n) for r, n, _ in live[:3]])
+    assert m <= ym and p90 <= yp90 and mx <= ymx, ((m, p90, mx), (ym, yp90, ymx))
+    assert m <= 1e-2 and p90 <= 3e-2 and mx <= 6e-2
+    assert len(live) > 150
 
 
 # Mixed-precision step (tools/train_bench.py --dtype bf16; BASELINE configs[4] names bf16, the reference trains with
@@ -133,7 +161,10 @@ def test_training_forward_backward_bf16_mode():
     hip_ops.MFMA_BF16, hip_ops.BF16_ACTIVATIONS = True, False
     try:
         hip_ops.PROFILE = []
-        pred_err, loss_err, worst = _compare_with_oracle(spread_regressions=True)
+        # (frustum=False: with the lifted points inside the grid the UNTRAINED height net's softmax over 90 bins turns the 2^-9 roundings of
+        #  its logits into a 27 % relative difference of the BEV map between f32 and bf16 products -- measured -- which no per-tensor bar
+        #  can hold; the whole path in mixed precision is held by the trajectory test below.  Here: head, BEV trunk, loss.)
+        pred_err, loss_err, worst = _compare_with_oracle(spread_regressions=True, frustum=False)
         kernels = {r[0].split('|')[0] for r in hip_ops.PROFILE}
     finally:
         hip_ops.PROFILE = None
@@ -164,7 +195,7 @@ def _six_steps(bf16):
         model = model.cuda().train()
         model.head.train_cfg = dict(model.head.train_cfg, grid_size=[256, 256, 1], point_cloud_range=[0, -12.8, -5, 25.6, 12.8, 3])
         imgs = synthetic.make_images(B, final=bconf['final_dim'], device='cuda', seed=4)
-        mats = synthetic.make_mats(B, device='cuda')
+        mats = synthetic.make_mats(B, device='cuda', scale=bconf['final_dim'][0] / 864)     # (frustum inside the grid)
         boxes, labels = _gt(B)
         targets = model.get_targets([b.cuda() for b in boxes], [l.cuda() for l in labels])
         opt = DataParallelAdamW(model.parameters(), lr=2e-4)
@@ -181,13 +212,14 @@ def _six_steps(bf16):
 
 
 def test_bf16_training_steps_track_the_f32_steps():
-    """What the mixed-precision mode is for: the same six AdamW steps on the same data with f32 and with bf16 products.  The
-    loss falls in both and the two trajectories stay within 2 % of each other at every step (f32 master weights, f32 AdamW)."""
+    """What the mixed-precision mode is for: the same six AdamW steps on the same data (frustum inside the grid: image backbone, height
+    net, lift, voxel pooling, BEV trunk, head all train) with f32 and with bf16 products.  The loss falls in both (115.8 -> 48.1 and
+    115.5 -> 47.2) and the two trajectories stay within 8 % of each other at every step (measured 3.5-4.9 %; f32 master weights, f32 AdamW)."""
     f32, bf16 = _six_steps(False), _six_steps(True)
     print("loss per step, f32 products :", [f"{v:.3f}" for v in f32])
     print("loss per step, bf16 products:", [f"{v:.3f}" for v in bf16])
     assert all(np.isfinite(bf16)) and bf16[-1] < bf16[0] and f32[-1] < f32[0]
-    assert max(abs(a - b) / abs(a) for a, b in zip(f32, bf16)) <= 2e-2, (f32, bf16)
+    assert max(abs(a - b) / abs(a) for a, b in zip(f32, bf16)) <= 8e-2, (f32, bf16)
 
 
 def test_training_steps_lower_the_loss_and_eval_sees_the_new_weights():
@@ -216,3 +248,43 @@ def test_training_steps_lower_the_loss_and_eval_sees_the_new_weights():
     with torch.no_grad():
         after = model(imgs, mats)[0][0]['heatmap']
     assert float((after - before).abs().max()) > 1e-4           # the packed inference weights were rebuilt
+
+
+def test_centerhead_branches_as_one_wide_map_match_the_per_branch_form():
+    """train_forward.HEAD_CONCAT: the 36 branches as ONE 64 -> 2304 convolution + one BatchNorm launch sequence + final layers on the
+    channel slices, against the per-branch form (36 maps): predictions, loss, every parameter gradient and the BatchNorm running
+    statistics agree to float32 summation order."""
+    from sgv3d_amd import train_forward
+    B = 2
+    res = {}
+    for flag in (True, False):
+        saved = train_forward.HEAD_CONCAT
+        train_forward.HEAD_CONCAT = flag
+        try:
+            model, bconf, hconf = _model(seed=2)
+            model = model.cuda().train()
+            model.head.train_cfg = dict(model.head.train_cfg, grid_size=[256, 256, 1], point_cloud_range=[0, -12.8, -5, 25.6, 12.8, 3])
+            imgs = synthetic.make_images(B, final=bconf['final_dim'], device='cuda', seed=4)
+            mats = synthetic.make_mats(B, device='cuda', scale=bconf['final_dim'][0] / 864)
+            boxes, labels = _gt(B)
+            targets = model.get_targets([b.cuda() for b in boxes], [l.cuda() for l in labels])
+            preds = model(imgs, mats)
+            loss = model.loss(targets, preds)
+            loss.backward()
+            res[flag] = (float(loss.detach()), [p[0][k].detach().clone() for p in preds for k in sorted(p[0])],
+                         {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
+                         {n: b.detach().clone() for n, b in model.named_buffers() if 'task_heads' in n and 'running_' in n})
+        finally:
+            train_forward.HEAD_CONCAT = saved
+    (la, pa, ga, ba), (lb, pb, gb, bb) = res[True], res[False]
+    assert abs(la - lb) <= 1e-5 * abs(lb), (la, lb)
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+    assert ga.keys() == gb.keys() and len(ba) == len(bb) > 0
+    # (a conv bias in front of a BatchNorm has a zero gradient -- pure rounding noise: compared on the absolute scale of the gradients)
+    gscale = max(float(v.abs().max()) for v in gb.values())
+    worst = max((float((ga[n] - gb[n]).abs().max()) / max(float(gb[n].abs().max()), 1e-3 * gscale), n) for n in gb)
+    assert worst[0] <= 2e-3, worst
+    for n in bb:
+        assert float((ba[n] - bb[n]).abs().max()) <= 1e-5 * max(1.0, float(bb[n].abs().max())), n
+    print(f"one wide map against 36 maps: loss {la:.6f} / {lb:.6f}; worst gradient tensor {worst[0]:.1e} ({worst[1]})")
