@@ -228,7 +228,7 @@ def test_training_steps_lower_the_loss_and_eval_sees_the_new_weights():
     model = model.cuda().train()
     model.head.train_cfg = dict(model.head.train_cfg, grid_size=[256, 256, 1], point_cloud_range=[0, -12.8, -5, 25.6, 12.8, 3])
     imgs = synthetic.make_images(B, final=bconf['final_dim'], device='cuda', seed=4)
-    mats = synthetic.make_mats(B, device='cuda')
+    mats = synthetic.make_mats(B, device='cuda', scale=bconf['final_dim'][0] / 864)
     boxes, labels = _gt(B)
     targets = model.get_targets([b.cuda() for b in boxes], [l.cuda() for l in labels])
     model.eval()
