@@ -253,7 +253,7 @@ def test_training_steps_lower_the_loss_and_eval_sees_the_new_weights():
 def test_centerhead_branches_as_one_wide_map_match_the_per_branch_form():
     """train_forward.HEAD_CONCAT: the 36 branches as ONE 64 -> 2304 convolution + one BatchNorm launch sequence + final layers on the
     channel slices, against the per-branch form (36 maps): predictions, loss, every parameter gradient and the BatchNorm running
-    statistics agree to float32 summation order."""
+    statistics agree to float32 summation order (gradients: to the run-to-run noise of this backward)."""
     from sgv3d_amd import train_forward
     B = 2
     res = {}
@@ -284,7 +284,9 @@ def test_centerhead_branches_as_one_wide_map_match_the_per_branch_form():
     # (a conv bias in front of a BatchNorm has a zero gradient -- pure rounding noise: compared on the absolute scale of the gradients)
     gscale = max(float(v.abs().max()) for v in gb.values())
     worst = max((float((ga[n] - gb[n]).abs().max()) / max(float(gb[n].abs().max()), 1e-3 * gscale), n) for n in gb)
-    assert worst[0] <= 2e-3, worst
+    # (two runs of ONE form differ by up to ~1e-2 in single tensors on this ill-conditioned backward: the deformable-convolution adjoint
+    #  adds with float atomics and the batch-statistics BatchNorms amplify it -- see the float32-yardstick test above)
+    assert worst[0] <= 3e-2, worst
     for n in bb:
         assert float((ba[n] - bb[n]).abs().max()) <= 1e-5 * max(1.0, float(bb[n].abs().max())), n
     print(f"one wide map against 36 maps: loss {la:.6f} / {lb:.6f}; worst gradient tensor {worst[0]:.1e} ({worst[1]})")
