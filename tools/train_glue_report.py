@@ -34,6 +34,44 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
+
+# Python-level sources of copies: .contiguous() on a non-contiguous tensor, clone, copy_, pad, cat, sum (C++-internal ones -- autograd's own
+# accumulations and view gradients -- do not pass here)
+import traceback
+SITES = collections.Counter()
+root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def site():
+    for fr in reversed(traceback.extract_stack(limit=12)[:-2]):
+        if "sgv3d_amd/" in fr.filename and "train_glue_report" not in fr.filename:
+            return f"{fr.filename.replace(root_dir + '/', '')}:{fr.lineno}"
+    return "?"
+
+
+def wrap(owner, name, cond=lambda *a, **k: True):
+    orig = getattr(owner, name)
+
+    def f(*a, **k):
+        if cond(*a, **k):
+            SITES[(f"{getattr(owner, '__name__', owner)}.{name}", site())] += 1
+        return orig(*a, **k)
+    setattr(owner, name, f)
+
+
+wrap(torch.Tensor, "contiguous", lambda self, *a, **k: self.is_cuda and not self.is_contiguous())
+wrap(torch.Tensor, "clone", lambda self, *a, **k: self.is_cuda)
+wrap(torch.Tensor, "copy_", lambda self, *a, **k: self.is_cuda)
+wrap(torch.Tensor, "sum", lambda self, *a, **k: self.is_cuda)
+wrap(torch.Tensor, "__setitem__", lambda self, *a, **k: self.is_cuda)
+wrap(torch.nn.functional, "pad")
+wrap(torch, "cat")
+wrap(torch, "zeros")
+step()
+torch.cuda.synchronize()
+print("--- Python-level copy / reduction sources in one step")
+for (op, where), n in SITES.most_common(40):
+    print(f"  n={n:4d}  {op:28s} {where}")
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
