@@ -800,17 +800,32 @@ int sgv3d_weight_rot180_transpose(const float *w, int cout, int cin, int kh, int
 
 /* One fused AdamW step (torch.optim.AdamW semantics, amsgrad off) over a flat fp32 bucket of n parameters:
  * the optimiser of the reference's configure_optimizers (exps/...:298-305).  grad is multiplied by grad_scale
- * first (1 / world size after a sum all-reduce).  step >= 1 is the step count after this update.  All four
- * buffers 16-byte aligned. */
+ * first (1 / world size after a sum all-reduce) and, with clip_coef != NULL, by the DEVICE scalar clip_coef[0]
+ * (sgv3d_clip_coef: Lightning's gradient_clip_val, exps/...:405).  step >= 1 is the step count after this update.
+ * All four buffers 16-byte aligned. */
 int sgv3d_adamw_step(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int step,
                      float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
-                     void *stream);
+                     const float *clip_coef, void *stream);
 /* ... with the step-dependent scalars read from DEVICE memory at kernel start: hyper = f32 [lr, lr / (1 - beta1^step),
  * 1 / sqrt(1 - beta2^step)] -- for a launch recorded in a hipGraph (the recorded step follows the step counter and the learning-rate
- * schedule of exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:298-305 through a 12-byte copy).  Bitwise
- * sgv3d_adamw_step. */
+ * schedule of exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:298-305 through one sgv3d_adamw_set_hyper launch per
+ * replay).  Bitwise sgv3d_adamw_step. */
 int sgv3d_adamw_step_dev(long long n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *hyper,
-                         float beta1, float beta2, float eps, float weight_decay, float grad_scale, void *stream);
+                         float beta1, float beta2, float eps, float weight_decay, float grad_scale, const float *clip_coef,
+                         void *stream);
+/* hyper[0..2] for sgv3d_adamw_step_dev, computed on the host as sgv3d_adamw_step does and passed as kernel arguments (copied at
+ * launch: the caller may stage the next step while this one's update is still queued; no host buffer is shared with the device). */
+int sgv3d_adamw_set_hyper(float *hyper, int step, float lr, float beta1, float beta2, void *stream);
+
+/* Global-norm gradient clipping -- Lightning's ``gradient_clip_val=5`` of the reference's Trainer
+ * (exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:405; exps/sgv3d/bsm_bev_height_lss_r101_864_1536_256x256.py:529),
+ * i.e. torch.nn.utils.clip_grad_norm_(parameters, max_norm, norm_type=2) on the averaged gradients.
+ * sgv3d_grad_sumsq: sgv3d_grad_sumsq_partials() doubles per flat bucket (fixed slices, fixed order: bitwise repeatable);
+ * sgv3d_clip_coef over the ``count`` partials of ALL buckets: out[0] = min(1, max_norm / (norm + 1e-6)), out[1] = norm, with
+ * norm = sqrt(sum) * grad_scale.  Both only enqueue (capturable); the AdamW entries read out[0] on the device. */
+int sgv3d_grad_sumsq_partials(void);
+int sgv3d_grad_sumsq(long long n, const float *grad, double *partials, void *stream);
+int sgv3d_clip_coef(const double *partials, int count, float grad_scale, float max_norm, float *out, void *stream);
 
 /* Training-mode BatchNorm2d over NHWC f32 [pixels, channels] (channels % 4 == 0) fused with the residual add and the
  * ReLU that follow it in the reference's blocks: y = relu(gamma * (x - mean) / sqrt(var + eps) + beta + residual) with

@@ -29,11 +29,23 @@ RESNET_BLOCKS = {18: ('basic', (2, 2, 2, 2)), 34: ('basic', (3, 4, 6, 3)), 50: (
 
 
 BN_TRAINING = False     # True: batch statistics (the training-mode checker, bevheight_train_forward); running stats untouched
+BN_FROZEN = ()          # name prefixes of BatchNorm layers that keep their running statistics in training mode (frozen_stages)
+
+
+def frozen_prefixes(prefix, cfg):
+    """mmdet 2.19.0 ``ResNet._freeze_stages`` as name prefixes: with ``frozen_stages >= 0`` the stem (conv1, bn1) is constant and
+    bn1 stays in eval mode; stages 1..frozen_stages likewise (exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:48:
+    ``frozen_stages=0``).  Parameters under these prefixes receive no gradient in the reference's training step."""
+    k = cfg.get('frozen_stages', -1)
+    if k < 0:
+        return ()
+    return tuple([f'{prefix}.conv1.', f'{prefix}.bn1.'] + [f'{prefix}.layer{i}.' for i in range(1, k + 1)])
 
 
 def bn(sd, p, x, eps=1e-5):
+    training = BN_TRAINING and not (p + '.').startswith(BN_FROZEN) if BN_FROZEN else BN_TRAINING
     return F.batch_norm(x, sd[p + '.running_mean'], sd[p + '.running_var'], sd[p + '.weight'], sd[p + '.bias'],
-                        BN_TRAINING, 0.0, eps)
+                        training, 0.0, eps)
 
 
 def conv(sd, p, x, stride=1, padding=0, dilation=1):
@@ -349,9 +361,11 @@ def bevheight_train_forward(sd, backbone_conf, head_conf, imgs, mats, is_train_h
     graph over ``sd``: the checker of sgv3d_amd/train_forward.py, for LSSFPN and the BSM variant.  With
     ``is_train_height`` returns ``(preds, height_pred)`` (:72-77): (semantic0, semantic1) logits of BSMLSSFPN
     (bsm_lss_fpn.py:557-558) / (assist, assist) of LSSFPN (lss_fpn.py:459,493-494).  Dropout is not restated (the tests
-    set p = 0)."""
-    global BN_TRAINING
+    set p = 0).  ``frozen_stages`` of the image backbone's config is honoured (``frozen_prefixes``): those BatchNorm layers use
+    their running statistics, and the caller leaves ``requires_grad`` off for the parameters under those prefixes."""
+    global BN_TRAINING, BN_FROZEN
     BN_TRAINING = True
+    BN_FROZEN = frozen_prefixes('backbone.img_backbone', backbone_conf['img_backbone_conf'])
     try:
         B, S, N, Cin, H, W = imgs.shape
         dt = next(iter(sd.values())).dtype
@@ -383,6 +397,7 @@ def bevheight_train_forward(sd, backbone_conf, head_conf, imgs, mats, is_train_h
         return (preds, aux) if is_train_height else preds
     finally:
         BN_TRAINING = False
+        BN_FROZEN = ()
 
 
 def bevheight_forward(sd, backbone_conf, head_conf, imgs, mats, keep=None):

@@ -152,8 +152,12 @@ _PROTOS = {
                                       [c_void_p] * 4 + [c_size_t, c_void_p]),
     "sgv3d_batchnorm_relu_train_backward_from_x": (c_int, [c_ll, c_int] + [c_void_p] * 9 + [c_void_p, c_size_t, c_void_p]),
     "sgv3d_batchnorm_train_backward": (c_int, [c_ll, c_int] + [c_void_p] * 6 + [c_int] + [c_void_p] * 5 + [c_size_t, c_void_p]),
-    "sgv3d_adamw_step": (c_int, [c_ll] + [c_void_p] * 4 + [c_int] + [ctypes.c_float] * 6 + [c_void_p]),
-    "sgv3d_adamw_step_dev": (c_int, [c_ll] + [c_void_p] * 5 + [ctypes.c_float] * 5 + [c_void_p]),
+    "sgv3d_adamw_step": (c_int, [c_ll] + [c_void_p] * 4 + [c_int] + [ctypes.c_float] * 6 + [c_void_p] * 2),
+    "sgv3d_adamw_step_dev": (c_int, [c_ll] + [c_void_p] * 5 + [ctypes.c_float] * 5 + [c_void_p] * 2),
+    "sgv3d_adamw_set_hyper": (c_int, [c_void_p, c_int] + [ctypes.c_float] * 3 + [c_void_p]),
+    "sgv3d_grad_sumsq_partials": (c_int, []),
+    "sgv3d_grad_sumsq": (c_int, [c_ll, c_void_p, c_void_p, c_void_p]),
+    "sgv3d_clip_coef": (c_int, [c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p]),
     "sgv3d_centerhead_loss_workspace_bytes": (c_size_t, [c_int]),
     "sgv3d_centerhead_loss_stats": (c_int, [c_int] * 5 + [c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sgv3d_centerhead_loss": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_ll, c_void_p, c_ll] + [c_void_p] * 4 +

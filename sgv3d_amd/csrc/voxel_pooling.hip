@@ -727,13 +727,19 @@ __global__ __launch_bounds__(T) void vp_sort_segments_kernel(long long V, const 
 //   zero | count | scan_local | scan_top | scan_add | long_list + cls_count + fill | cls_scan | cls_scatter + sorts | commit
 //
 // While the plan is current every workgroup leaves after one load: ONE empty launch.  The barrier is an arrival counter in the
-// plan header (zeroed by the prologue kernel that precedes this one on the stream); a workgroup waits with s_sleep and a
-// bounded number of polls -- a barrier that gives up (never observed; it would take the other workgroups not being scheduled
-// for ~1 s) raises PlanHeader::err, every later barrier returns at once, the commit is skipped and the plan stays dirty: the
-// entry's gated scatter serves the call and the next call tries again.  The grid is small enough (512 workgroups of 256
-// threads, 11 KB of LDS: two per CU) that several such launches are resident together.
+// plan header (zeroed by the prologue kernel that precedes this one on the stream).  Progress by construction, on a plain
+// (non-cooperative) launch that a stream capture can record:
+//   * the grid is at most what the chip can hold of THIS kernel at once (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs,
+//     capped at kOneGrid = 512 workgroups of 256 threads and 11 KB of LDS; vp_one_grid()), so every workgroup becomes resident
+//     as soon as the finite kernels of other streams have drained from the compute units it needs -- nothing it waits for waits
+//     for it;
+//   * a waiting workgroup sleeps between polls and gives up after kOneSpinTicks of the 100 MHz wall clock (20 ms: five frames
+//     of the cfg-2 model); giving up raises PlanHeader::err;
+//   * every barrier reports the error word to its whole workgroup, and a workgroup that sees it set RETURNS: no later phase
+//     runs on counts, cursors or segment bounds that an absent workgroup did not finish (they index the order / slot arrays).
+//     The commit is skipped, the plan stays dirty, the entry's gated scatter serves the call and the next call tries again.
 constexpr int kOneGrid = 512;
-constexpr int kOneSpinLimit = 1 << 22;       // polls of ~0.25 us
+constexpr long long kOneSpinTicks = 2000000;  // wall_clock64() runs at 100 MHz: 20 ms
 
 struct PlanOneArgs {
     long long total, V;
@@ -745,26 +751,33 @@ struct PlanOneArgs {
     int p[7];
 };
 
-__device__ __forceinline__ void vp_grid_barrier(PlanHeader *hdr, int &epoch) {
+// -> true (to every thread of the workgroup) when the build has failed: the caller returns.
+__device__ __forceinline__ bool vp_grid_barrier(PlanHeader *hdr, int &epoch) {
+    __shared__ int failed;
     __syncthreads();
     if (threadIdx.x == 0) {
         ++epoch;
-        if (__hip_atomic_load(&hdr->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        int err = __hip_atomic_load(&hdr->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (err == 0) {
             __threadfence();                                                      // release this workgroup's writes
             __hip_atomic_fetch_add(&hdr->bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             const int target = epoch * (int)gridDim.x;
-            int polls = 0;
+            const long long t0 = wall_clock64();
             while (__hip_atomic_load(&hdr->bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(32);            // (~0.9 us between polls: hundreds of workgroups poll ONE word)
-                if (++polls > kOneSpinLimit || __hip_atomic_load(&hdr->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __builtin_amdgcn_s_sleep(32);            // (~1 us between polls: hundreds of workgroups poll ONE word)
+                err = __hip_atomic_load(&hdr->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (err == 0 && wall_clock64() - t0 > kOneSpinTicks) {
                     __hip_atomic_store(&hdr->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+                    err = 1;
                 }
+                if (err != 0) break;
             }
             __threadfence();                                                      // acquire the others'
         }
+        failed = err;
     }
     __syncthreads();
+    return failed != 0;
 }
 
 __device__ __forceinline__ long long dcdiv(long long x, long long y) { return (x + y - 1) / y; }
@@ -790,21 +803,21 @@ __global__ __launch_bounds__(kBlock) void vp_plan_build_one_kernel(const PlanOne
     }
     const int pgrid = (int)dcdiv(a.total, kBlock);
     VP_PHASE_NOSYNC(dcdiv(a.V + 1, kBlock), vp_zero_body(a.V + 1, a.cur, nullptr, VB, 0));
-    vp_grid_barrier(a.hdr, epoch);
+    if (vp_grid_barrier(a.hdr, epoch)) return;
     VP_PHASE_NOSYNC(pgrid, vp_count_body(a.total, a.N, a.X, a.Y, a.Z, a.geom, nullptr, a.cur, nullptr, a.gcopy, VB, pgrid));
-    vp_grid_barrier(a.hdr, epoch);
+    if (vp_grid_barrier(a.hdr, epoch)) return;
     VP_PHASE(a.nblk, vp_scan_local_body(a.V, a.cur, a.seg, a.blk, nullptr, VB, a.nblk));
-    vp_grid_barrier(a.hdr, epoch);
+    if (vp_grid_barrier(a.hdr, epoch)) return;
     if (wg == 0) vp_scan_top_body(a.nblk, a.blk, nullptr, a.long_list, 0, 1);
-    vp_grid_barrier(a.hdr, epoch);
+    if (vp_grid_barrier(a.hdr, epoch)) return;
     VP_PHASE_NOSYNC(dcdiv(a.V + 1, kBlock), vp_scan_add_body(a.V, a.nblk, a.blk, a.seg, a.cur, nullptr, VB, 0));
-    vp_grid_barrier(a.hdr, epoch);
+    if (vp_grid_barrier(a.hdr, epoch)) return;
     VP_PHASE_NOSYNC(dcdiv(a.V, kBlock), vp_long_list_body(a.V, a.seg, a.long_list, a.long_cap, nullptr, VB, 0));
     VP_PHASE(a.ncw, vp_cls_count_body(a.V, a.seg, a.ncw, a.tbl, nullptr, VB, a.ncw));
     VP_PHASE_NOSYNC(pgrid, vp_fill_body(a.total, a.N, a.X, a.Y, a.Z, a.geom, a.cur, a.order, a.slotvox, nullptr, a.seg, VB, pgrid));
-    vp_grid_barrier(a.hdr, epoch);
+    if (vp_grid_barrier(a.hdr, epoch)) return;
     VP_PHASE(kVoxClasses, vp_cls_scan_body(a.ncw, a.tbl, a.tot, nullptr, VB, kVoxClasses));
-    vp_grid_barrier(a.hdr, epoch);
+    if (vp_grid_barrier(a.hdr, epoch)) return;
     VP_PHASE(a.ncw, vp_cls_scatter_body(a.V, a.seg, a.ncw, a.tbl, a.tot, a.cls, a.perm, nullptr, VB, a.ncw));
     // the five sorts touch disjoint segments (by length class): one phase; each deals the voxels over the G workgroups itself
     vp_sort_wave_all_body(a.V, a.seg, a.order, wg, G);
@@ -812,7 +825,7 @@ __global__ __launch_bounds__(kBlock) void vp_plan_build_one_kernel(const PlanOne
     // (segments above 2048 points: LDS for up to 2048 ints here -- the stand-alone kernel stages 8192 -- longer ones are sorted in
     //  place in global memory by their workgroup; 11 KB per workgroup instead of 35)
     vp_sort_segments_body<kBlock, 2048>(a.V, a.seg, a.order, 2048, 0x7fffffff, nullptr, wg, G);
-    vp_grid_barrier(a.hdr, epoch);
+    if (vp_grid_barrier(a.hdr, epoch)) return;
 #undef VP_PHASE_NOSYNC
 #undef VP_PHASE
     if (wg == 0 && threadIdx.x == 0 && __hip_atomic_load(&a.hdr->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
@@ -822,6 +835,25 @@ __global__ __launch_bounds__(kBlock) void vp_plan_build_one_kernel(const PlanOne
         a.hdr->dirty = 0;
     }
 }
+
+// Grid of vp_plan_build_one_kernel: never more workgroups than the device holds of this kernel at once (see above); SGV3D_VP_ONE_GRID
+// may lower it further (diagnostics).
+static int vp_one_grid() {
+    static const int grid = [] {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vp_plan_build_one_kernel, kBlock, 0) != hipSuccess || cus <= 0 || per_cu <= 0)
+            return 64;                                   // (a grid any gfx9 part holds)
+        long long fit = (long long)cus * per_cu;
+        int g = (int)(fit < kOneGrid ? fit : kOneGrid);
+        const char *v = getenv("SGV3D_VP_ONE_GRID");
+        const int want = v ? atoi(v) : 0;
+        if (want >= 32 && want < g) g = want;
+        return g;
+    }();
+    return grid;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // 2b/3. gather + register reduce.  One wave owns kVoxPerWave consecutive output rows; its 64 lanes
@@ -2466,8 +2498,7 @@ int level1_forward(int batch_size, int num_points, int num_channels, int num_vox
         o.hdr = hdr;
         const int pm[7] = {kPlanMagic, B, N, X, Y, Z, 1};
         for (int i = 0; i < 7; ++i) o.p[i] = pm[i];
-        static const int one_grid = [] { const char *v = getenv("SGV3D_VP_ONE_GRID"); const int g = v ? atoi(v) : 0; return g >= 32 && g <= 1024 ? g : kOneGrid; }();
-        hipLaunchKernelGGL(vp_plan_build_one_kernel, dim3(one_grid), dim3(kBlock), 0, st, o);
+        hipLaunchKernelGGL(vp_plan_build_one_kernel, dim3(vp_one_grid()), dim3(kBlock), 0, st, o);
         g_l1_stats[3]++;
     }
     g_l1_stats[1]++;

@@ -113,15 +113,18 @@ def load_default_tune_dbs():
     """tune/gfx950_*.json at the repository root: the (algorithm, tile, split-K) choices measured on an MI355X for the
     BASELINE configurations, committed so that a run neither spends its first forward on candidate timing nor moves by
     near-tie picks from run to run.  A layer signature that is not in there is measured as before (autotune is the
-    fallback).  SGV3D_NO_TUNE_DB=1 ignores the committed files; SGV3D_TUNE_CACHE=<file> is loaded on top and is the file
-    save_tune_db() writes."""
+    fallback).  SGV3D_NO_TUNE_DB=1 ignores the committed files, SGV3D_TUNE_SKIP=<name>[,<name>] only the named ones;
+    SGV3D_TUNE_CACHE=<file> is loaded on top and is the file save_tune_db() writes."""
     import glob
     import os
     if os.environ.get("SGV3D_NO_TUNE_DB"):
         return 0
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tune")
+    skip = {x for x in os.environ.get("SGV3D_TUNE_SKIP", "").split(",") if x}      # file names to leave out (re-measuring one DB)
     n = 0
     for f in sorted(glob.glob(os.path.join(root, "gfx950_*.json"))):
+        if os.path.basename(f) in skip:
+            continue
         with open(f) as fh:
             sigs = list(__import__("json").load(fh))
         n += load_tune_db(f) and 1

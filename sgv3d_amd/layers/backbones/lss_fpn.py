@@ -420,11 +420,11 @@ class LSSFPN(HipModule):
         cc = cache.entry(sweep_index)
         s2e = mats_dict['sensor2ego_mats']
         D, fH, fW, _ = (int(v) for v in self.frustum.shape)
-        # (the height net's packed weights are part of what the cached gates were computed from: a weight refresh makes
-        #  a new state dict, hence another tag)
-        hn_state = self.height_net.hip_state(s2e.device) if CACHE_CAMERA_GATES else None
+        # (the height net's packed weights are part of what the cached gates were computed from: a weight refresh compiles a
+        #  new state, whose generation number -- never reused, unlike the id() of the state dict -- makes another tag)
+        hn_gen = self.height_net.hip_generation(s2e.device) if CACHE_CAMERA_GATES else None
         tag = (int(sweep_index), tuple(s2e.shape), str(s2e.device), self.frustum.data_ptr(), self.frustum._version,
-               self._voxel_num_host, id(hn_state))
+               self._voxel_num_host, hn_gen)
         if cc.geom is not None and cc.matches(srcs, tag):
             cache.hits += 1
             cc.join_capture(s2e.device)            # (graph capture with the refresh on a forked branch)

@@ -32,14 +32,26 @@ def _kaiming_(m):
 class HipModule(nn.Module):
     """nn.Module whose packed HIP state (repacked weights, folded BN) is built lazily per device."""
 
+    _GENERATION = 0          # process-wide count of hip_compile runs: a compiled state's identity that is never reused
+
     def __init__(self):
         super().__init__()
         self._hip = None
+        self._hip_gen = 0
 
     def hip_state(self, device):
         if self._hip is None or self._hip[0] != device:
             self._hip = (device, self.hip_compile(device))
+            HipModule._GENERATION += 1
+            self._hip_gen = HipModule._GENERATION
         return self._hip[1]
+
+    def hip_generation(self, device):
+        """Identity of the packed state on ``device`` (compiling it if needed): a monotonically increasing number, unlike ``id()`` of
+        the state object, whose address CPython hands to the next allocation after ``refresh()`` dropped it -- anything cached beside
+        the packed weights (the height net's camera gates) is keyed on this."""
+        self.hip_state(device)
+        return self._hip_gen
 
     def hip_invalidate(self):
         self._hip = None
@@ -198,10 +210,44 @@ class ResNet(HipModule):
             self.add_module(name, nn.Sequential(*layers))
             self.res_layers.append(name)
         self.feat_dim = inplanes
+        self._freeze_stages()
 
     @property
     def norm1(self):
         return self.bn1
+
+    def _freeze_stages(self):
+        """mmdet 2.19.0 ``ResNet._freeze_stages`` (the configs of the reference set ``frozen_stages=0`` on the image backbone,
+        exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:48, exps/sgv3d/bsm_bev_height_lss_r101_864_1536_256x256.py:57):
+        with ``frozen_stages >= 0`` the stem's BatchNorm stays in eval mode and ``conv1`` / ``bn1`` stop training; stages
+        ``1 .. frozen_stages`` likewise.  Called from the constructor and re-applied by every ``train()``, as upstream."""
+        if self.frozen_stages >= 0:
+            self.bn1.eval()
+            for m in (self.conv1, self.bn1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f'layer{i}')
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def train(self, mode=True):
+        """mmdet ``ResNet.train``: the frozen stages are re-frozen, and with ``norm_eval`` every BatchNorm keeps its running
+        statistics while the rest of the network trains."""
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+        return self
+
+    def frozen_stem(self):
+        """True when conv1 + bn1 are constants of the training step (``frozen_stages >= 0``): the training forward then runs the stem
+        as the inference path does -- one convolution with the folded BatchNorm and ReLU in its epilogue, no statistics pass, no
+        weight gradient."""
+        return self.frozen_stages >= 0 and not self.bn1.training and not any(p.requires_grad for m in (self.conv1, self.bn1) for p in m.parameters())
 
     def init_weights(self):
         """Kaiming / constant init (mmdet's fallback when no checkpoint is given; the reference asks

@@ -26,7 +26,8 @@ throughout (an NCHW view with channels-last strides is handed to the torch opera
 
 Layer semantics follow the eval-mode HIP path module by module (layers/blocks.py, layers/backbones/lss_fpn.py,
 layers/heads/bev_height_head.py); the only differences are the ones training mode implies in the reference:
-BatchNorm uses and updates batch statistics, Dropout(0.5) in the ASPP is active.
+BatchNorm uses and updates batch statistics -- except in the stages ``frozen_stages`` freezes (the image backbone's stem in every
+shipped config), which keep their running statistics and receive no gradient --, Dropout(0.5) in the ASPP is active.
 """
 import os
 
@@ -88,8 +89,21 @@ def block(b, x):
     return bottleneck(b, x) if isinstance(b, blocks.Bottleneck) else basic_block(b, x)
 
 
+def _frozen_stem(r, x):
+    """conv1 + bn1 + ReLU of a ResNet whose stem is frozen (mmdet ``frozen_stages >= 0``: the reference's image backbone,
+    exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:48): constants of the step, so the inference form runs -- one
+    convolution with the running statistics folded into its epilogue, no statistics pass, no graph node, no weight gradient.  The
+    packed stem is rebuilt when one of its five tensors was written or replaced (``load_state_dict``)."""
+    ts = (r.conv1.weight, r.bn1.weight, r.bn1.bias, r.bn1.running_mean, r.bn1.running_var)
+    tag = tuple((t.data_ptr(), t._version) for t in ts) + (hip_ops.switch_state(),)
+    if getattr(r, '_frozen_stem_tag', None) != tag:
+        r._hip, r._frozen_stem_tag = None, tag
+    with torch.no_grad():
+        return r.hip_stem(x)
+
+
 def resnet(r, x, use_maxpool=True):
-    x = bn(r.bn1, conv(r.conv1, x), relu=True)
+    x = _frozen_stem(r, x) if r.frozen_stem() else bn(r.bn1, conv(r.conv1, x), relu=True)
     if use_maxpool:
         x = misc_grad.maxpool3x3s2(x)
     outs = []

@@ -6,12 +6,18 @@ The reference wraps the model in Lightning's DDP (exps/base_cli.py:57-58 ``accel
 
 * ``FlatParams`` re-homes every parameter and its gradient as views of a few large flat fp32 buffers (buckets) in
   reverse registration order -- the order backward produces gradients in -- so a bucket is ONE contiguous RCCL
-  all-reduce and ONE fused AdamW launch.  Buckets default to 256 MiB: xGMI is point-to-point (7 links, ~153 GB/s each),
-  a ring all-reduce is bound by one link, and the 288 GB of HBM make large buckets free; the ~0.4 GB of BEVHeight-R50
-  gradients are two collectives per step.
+  all-reduce and ONE fused AdamW launch.  Buckets default to 48 MiB (``DEFAULT_BUCKET_BYTES``): xGMI is point-to-point
+  (7 links, ~153 GB/s each), a ring all-reduce is bound by one link -- 48 MiB is ~0.6 ms of wire time, far above the
+  collective's launch latency --, and the ~0.3 GB of BEVHeight-R50 gradients become 7 collectives of which the first leaves
+  when the CenterHead's and the BEV trunk's gradients are done, with ~85 % of backward still to run under it (256 MiB
+  buckets, the earlier default, held the first collective back until backward was almost over).
 * ``all_reduce_grads`` launches the sum all-reduces asynchronously on torch's RCCL stream (``async_op=True``) as soon
   as it is called per bucket; the 1 / world factor is folded into the AdamW kernel (no averaging pass over HBM).
 * ``step`` waits for each bucket's collective and runs ``sgv3d_adamw_step`` on it.
+* ``max_grad_norm`` (Lightning's ``gradient_clip_val=5`` of the reference's Trainer, exps/...:405): the global L2 norm of the
+  averaged gradient over all buckets -- one ``sgv3d_grad_sumsq`` per bucket, one ``sgv3d_clip_coef`` -- and the coefficient
+  ``min(1, max_norm / (norm + 1e-6))`` of ``torch.nn.utils.clip_grad_norm_`` read by the AdamW kernel from device memory:
+  no pass that rewrites the gradients, no host round trip, capturable.
 
 * at construction with more than one rank the flat parameter buckets are broadcast from rank 0 (what Lightning's DDP
   does when it wraps the model), so replicas start identical whatever each rank's seed was; ``check_replicas`` compares
@@ -37,7 +43,11 @@ from . import _lib, grad_slots
 
 DIRECT_GRADS = os.environ.get("SGV3D_DIRECT_GRADS", "1") != "0"   # 0: every gradient goes through autograd's accumulate add
 
-__all__ = ['FlatParams', 'DataParallelAdamW', 'GraphedTrainStep', 'reference_lr', 'multistep_lr']
+DEFAULT_BUCKET_BYTES = int(os.environ.get("SGV3D_BUCKET_MIB", "48")) << 20
+REFERENCE_GRADIENT_CLIP_VAL = 5.0     # exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:405, exps/sgv3d/...r101...:529
+
+__all__ = ['FlatParams', 'DataParallelAdamW', 'GraphedTrainStep', 'reference_lr', 'multistep_lr', 'DEFAULT_BUCKET_BYTES',
+           'REFERENCE_GRADIENT_CLIP_VAL']
 
 
 def reference_lr(batch_size_per_device, gpus, basic_lr_per_img=2e-4 / 64):
@@ -51,8 +61,9 @@ def multistep_lr(base_lr, epoch, milestones=(19, 23), gamma=0.1):
 
 
 class FlatParams:
-    def __init__(self, params, bucket_bytes=256 << 20):
-        params = [p for p in params if p.requires_grad]
+    def __init__(self, params, bucket_bytes=None):
+        bucket_bytes = DEFAULT_BUCKET_BYTES if bucket_bytes is None else int(bucket_bytes)
+        params = [p for p in params if p.requires_grad]     # (frozen_stages: the image backbone's stem is not in any bucket)
         assert params, "no trainable parameters"
         assert all(p.dtype == torch.float32 for p in params), "fp32 parameters only"
         self.params = params
@@ -107,16 +118,20 @@ class FlatParams:
 class DataParallelAdamW:
     """AdamW over ``FlatParams`` with the gradient all-reduce of the data-parallel step."""
 
-    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7, bucket_bytes=256 << 20, group=None):
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7, bucket_bytes=None, group=None,
+                 max_grad_norm=None):
         self.flat = params if isinstance(params, FlatParams) else FlatParams(params, bucket_bytes)
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
         self.group = group
+        self.max_grad_norm = None if not max_grad_norm else float(max_grad_norm)     # None / 0: no clipping (Lightning's default)
+        self._clip = None             # device [coefficient, total norm] of the step that ran last
+        self._partials = None
         self.state = [(torch.zeros_like(p), torch.zeros_like(p)) for p, _, _ in self.flat.buckets]
         self.steps = 0
         self._pending = []
         self._hyper = None            # device [lr, lr / bc1, 1 / sqrt(bc2)] of the step about to run (GraphedTrainStep)
-        self._hyper_host = None
         self._in_graph = False        # inside GraphedTrainStep's capture: no collectives from the gradient hooks
+        self.first_early_event = None # a torch.cuda.Event recorded on the backward stream when bucket 0's all-reduce is launched
         if self._collectives():
             self.broadcast_parameters()
 
@@ -215,6 +230,8 @@ class DataParallelAdamW:
             while (self._next_early < len(self._left) and self._left[self._next_early] == 0
                    and self._next_early not in self._hold):
                 i = self._next_early
+                if i == 0 and self.first_early_event is not None:
+                    self.first_early_event.record()           # (diagnostic: where in backward the first collective leaves)
                 self._early[i] = dist.all_reduce(self.flat.buckets[i][1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self._next_early += 1
 
@@ -241,21 +258,45 @@ class DataParallelAdamW:
 
     def stage_hyper(self, lr=None):
         """Advance the step counter and put the scalars of that step -- [lr, lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)], computed as
-        sgv3d_adamw_step computes them -- into the device buffer the recorded update reads (one 12-byte copy on the current stream).
+        sgv3d_adamw_step computes them -- into the device buffer the recorded update reads: one ``sgv3d_adamw_set_hyper`` launch on the
+        current stream whose KERNEL ARGUMENTS carry the three numbers (copied at launch), so staging step t + 1 while the replay of
+        step t is still queued cannot disturb step t (a pinned staging buffer rewritten by the host could).
         ``step(recorded=True)`` launches the update against that buffer."""
-        import math
-        import struct
         lr = self.lr if lr is None else float(lr)
         self.steps += 1
-        f32 = lambda v: struct.unpack('f', struct.pack('f', v))[0]
-        b1, b2 = f32(self.betas[0]), f32(self.betas[1])           # (the C entry point receives the betas as floats)
-        bc1, bc2 = 1.0 - math.pow(b1, self.steps), 1.0 - math.pow(b2, self.steps)
         dev = self.flat.buckets[0][0].device
         if self._hyper is None:
             self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
-            self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
-        self._hyper_host[0], self._hyper_host[1], self._hyper_host[2] = f32(lr), f32(lr) / bc1, 1.0 / math.sqrt(bc2)
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        with torch.cuda.device(dev):
+            rc = _lib.load().sgv3d_adamw_set_hyper(self._hyper.data_ptr(), self.steps, lr, self.betas[0], self.betas[1],
+                                                   _lib.stream_handle(dev))
+        _lib.check(rc, "sgv3d_adamw_set_hyper")
+
+    def grad_norm(self):
+        """Total L2 norm of the averaged gradient of the last step (before clipping; one device -> host read).  None without
+        ``max_grad_norm``."""
+        return None if self._clip is None else float(self._clip[1])
+
+    def clip_coefficient(self):
+        return None if self._clip is None else float(self._clip[0])
+
+    def _clip_coef(self, world):
+        """Enqueue the global-norm coefficient of the gradients now in the buckets -> device pointer for the AdamW launches."""
+        lib = _lib.load()
+        dev = self.flat.buckets[0][0].device
+        if not self.flat.buckets[0][0].is_cuda:
+            raise _lib.SGV3DError("gradient clipping runs on the GPU (no CPU fallback)")
+        per = lib.sgv3d_grad_sumsq_partials()
+        if self._clip is None:
+            self._clip = torch.zeros(2, dtype=torch.float32, device=dev)
+            self._partials = torch.zeros(per * len(self.flat.buckets), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.stream_handle(dev)
+            for i, (_, g, _) in enumerate(self.flat.buckets):
+                _lib.check(lib.sgv3d_grad_sumsq(g.numel(), g.data_ptr(), self._partials.data_ptr() + i * per * 8, st), "sgv3d_grad_sumsq")
+            _lib.check(lib.sgv3d_clip_coef(self._partials.data_ptr(), per * len(self.flat.buckets), 1.0 / world, self.max_grad_norm,
+                                           self._clip.data_ptr(), st), "sgv3d_clip_coef")
+        return self._clip.data_ptr()
 
     def step(self, lr=None, recorded=False):
         """One AdamW update of every bucket with the averaged gradients (call ``all_reduce_grads`` first when the
@@ -271,6 +312,13 @@ class DataParallelAdamW:
         elif self._hyper is None:
             raise _lib.SGV3DError("step(recorded=True) needs stage_hyper() first")
         lib = _lib.load()
+        clip = None
+        if self.max_grad_norm is not None:
+            # the norm is over ALL buckets: every collective has to be in before the first update
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+            clip = self._clip_coef(world)
         for i, ((p, g, _), (m, v)) in enumerate(zip(self.flat.buckets, self.state)):
             if self._pending:
                 self._pending[i].wait()
@@ -279,11 +327,11 @@ class DataParallelAdamW:
             with torch.cuda.device(p.device):
                 if recorded:
                     rc = lib.sgv3d_adamw_step_dev(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), self._hyper.data_ptr(),
-                                                  self.betas[0], self.betas[1], self.eps, self.weight_decay, 1.0 / world,
+                                                  self.betas[0], self.betas[1], self.eps, self.weight_decay, 1.0 / world, clip,
                                                   _lib.stream_handle(p.device))
                 else:
                     rc = lib.sgv3d_adamw_step(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), self.steps, lr,
-                                              self.betas[0], self.betas[1], self.eps, self.weight_decay, 1.0 / world,
+                                              self.betas[0], self.betas[1], self.eps, self.weight_decay, 1.0 / world, clip,
                                               _lib.stream_handle(p.device))
             _lib.check(rc, "sgv3d_adamw_step")
         self._pending = []
@@ -349,7 +397,7 @@ class GraphedTrainStep:
             try:
                 opt._in_graph = True
                 if self.in_graph_update:
-                    opt.stage_hyper(lr)               # (outside the graph: a pinned-memory copy per step)
+                    opt.stage_hyper(lr)               # (outside the graph: one launch per step whose arguments carry the scalars)
                 # with a process group its watchdog thread polls the events of earlier collectives while this thread records: legal
                 # only if the capture's error mode is per thread (kernels launched by the autograd engine's thread into the
                 # capturing stream are recorded in either mode)

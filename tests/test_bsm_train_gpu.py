@@ -119,7 +119,7 @@ def _model(conf, is_train_height, seed=0):
 
 def _double_sd(model):
     sd = {k: (v.detach().cpu().double() if v.dtype.is_floating_point else v.detach().cpu()) for k, v in model.state_dict().items()}
-    names = [n for n, _ in model.named_parameters()]
+    names = [n for n, p in model.named_parameters() if p.requires_grad]      # (frozen_stages: the stem is constant, in product and oracle)
     for n in names:
         sd[n].requires_grad_(True)
     return sd, names

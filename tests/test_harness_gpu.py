@@ -351,6 +351,33 @@ def test_camera_gates_are_cached_per_calibration_and_equal_the_per_frame_ones(hi
     torch.cuda.synchronize()
 
 
+def test_cached_camera_gates_follow_a_weight_refresh_on_a_static_camera(hip):
+    """A static-camera stream (the same calibration tensors every frame) across weight changes: ``refresh()`` drops the packed state
+    the cached gates were computed from, and the calibration entry is keyed on the state's generation number -- the ``id()`` of the
+    freed state dict, the earlier key, is handed out again by CPython more often than not, and the old weights' gates were then
+    reused silently.  After every in-place change of the gate MLP's weights the cached gates equal freshly computed ones."""
+    from sgv3d_amd import synthetic as S
+    model, bc, _ = _model(seed=9)
+    scale = bc['final_dim'][0] / 864
+    img = S.make_images(1, bc['final_dim'], device='cuda', seed=6)
+    mats = S.make_mats(1, device='cuda', scale=scale)
+    model.graph_forward = False
+    bb = model.backbone
+    gens = []
+    with torch.no_grad():
+        model(img, mats)
+        for it in range(6):
+            bb.height_net.context_mlp.fc1.weight.mul_(1.5)            # (version bump -> stamp -> refresh on the next forward)
+            bb.height_net.height_mlp.fc2.bias.add_(0.3)
+            model(img, mats)
+            gens.append(bb.height_net._hip_gen)
+            fresh = bb.height_net.camera_gates(mats, img.device)
+            for a, b in zip(bb.calib_cache.entry(0).gates, fresh):
+                assert torch.equal(a, b), it
+    assert gens == sorted(set(gens)) and len(gens) == 6                # a new, larger generation per refresh
+    torch.cuda.synchronize()
+
+
 def test_aspp_pooled_branch_folded_into_the_bias_matches_the_concat_form(hip):
     """Batch 1, f32: ASPP's pooled branch is one vector per image, so its share of conv1 is a per-image bias (2048 instead of 2560
     input channels, no broadcast launch).  Against the five-branch concat form: same function, f32 rounding apart."""

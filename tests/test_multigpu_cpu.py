@@ -71,8 +71,16 @@ TRAIN_WORKER = textwrap.dedent("""
     torch.manual_seed(7 * rank)                              # DIFFERENT initial weights per rank ...
     net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 5, 1))
     mine = [p.detach().clone() for p in net.parameters()]
-    opt = DataParallelAdamW(net.parameters(), lr=1e-3, bucket_bytes=1024)     # tiny buckets: several collectives
+    # a frozen stem beside the trainable net (frozen_stages=0 of the reference's image backbone): in no bucket, on either rank
+    stem = torch.nn.Conv2d(3, 3, 1)
+    for p in stem.parameters():
+        p.requires_grad = False
+    stem_before = [p.detach().clone() for p in stem.parameters()]
+    opt = DataParallelAdamW(list(stem.parameters()) + list(net.parameters()), lr=1e-3, bucket_bytes=1024, max_grad_norm=5.0)     # tiny buckets: several collectives
     assert len(opt.flat.buckets) >= 2
+    bucketed = {id(p) for _, _, entries in opt.flat.buckets for p, _, _ in entries}
+    assert not any(id(p) in bucketed for p in stem.parameters()) and all(id(p) in bucketed for p in net.parameters())
+    assert all(torch.equal(a, b) for a, b in zip(stem_before, stem.parameters()))     # (not broadcast either: constants of the checkpoint)
     both = [None, None]
     dist.all_gather_object(both, [p.tolist() for p in mine])
     for i, p in enumerate(net.parameters()):                  # ... and the constructor broadcast rank 0's (what DDP does)

@@ -77,7 +77,7 @@ def _compare_with_oracle(spread_regressions=False, yardstick=None, frustum=True)
     grads = {n: p.grad.detach().cpu().double() for n, p in model.named_parameters() if p.grad is not None}
 
     sd = {k: (v.detach().cpu().double() if v.dtype.is_floating_point else v.detach().cpu()) for k, v in model.state_dict().items()}
-    names = [n for n, _ in model.named_parameters()]
+    names = [n for n, p in model.named_parameters() if p.requires_grad]      # (frozen_stages: the stem is constant, in product and oracle)
     for n in names:
         sd[n].requires_grad_(True)
     rpreds = O.bevheight_train_forward(sd, bconf, hconf, imgs.cpu(), {k: v.cpu() for k, v in mats.items()})

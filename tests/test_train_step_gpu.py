@@ -79,6 +79,253 @@ def test_adamw_with_device_scalars_is_bitwise_the_host_scalar_update():
         assert all(torch.equal(x, y) for sa, sb in zip(a.state, b.state) for x, y in zip(sa, sb))
 
 
+def test_clipped_update_is_clip_grad_norm_then_adamw():
+    """``max_grad_norm`` (Lightning's gradient_clip_val=5, exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:405) against
+    ``torch.nn.utils.clip_grad_norm_`` + ``torch.optim.AdamW`` on the same gradients: several buckets (the norm is global), steps whose
+    norm is above the bound (clipped) and below it (coefficient exactly 1), host-scalar and device-scalar update entries."""
+    g = torch.Generator(device='cuda').manual_seed(7)
+    shapes = [(257, 33), (4096,), (64, 3, 7, 7), (1000003,), (5,)]
+    for recorded in (False, True):
+        ps = [torch.randn(*sh, device='cuda', generator=g).requires_grad_(True) for sh in shapes]
+        qs = [p.detach().clone().requires_grad_(True) for p in ps]
+        opt = DataParallelAdamW(ps, lr=2e-3, betas=(0.9, 0.99), weight_decay=0.01, bucket_bytes=1 << 20, max_grad_norm=5.0)
+        assert len(opt.flat.buckets) >= 3
+        ropt = torch.optim.AdamW(qs, lr=2e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+        for it in range(10):
+            scale = [1.0, 1e-4, 30.0, 3e-3][it % 4]                 # norms ~1e3, ~0.1, ~3e4, ~3: clipped / not / clipped / not
+            for p, q in zip(ps, qs):
+                grad = torch.randn(p.shape, device='cuda', generator=g) * scale
+                p.grad.copy_(grad)
+                q.grad = grad.clone()
+            want_norm = float(torch.nn.utils.clip_grad_norm_(qs, 5.0))
+            ropt.step()
+            if recorded:
+                opt.stage_hyper()
+            opt.step(recorded=recorded)
+            assert abs(opt.grad_norm() - want_norm) <= 2e-6 * want_norm, (it, opt.grad_norm(), want_norm)
+            coef = opt.clip_coefficient()
+            assert (coef == 1.0) if want_norm < 5.0 else abs(coef - 5.0 / (want_norm + 1e-6)) <= 1e-6 * coef, (it, coef, want_norm)
+        for p, q in zip(ps, qs):
+            err = float((p.detach() - q.detach()).abs().max())
+            assert err <= 1e-5, (recorded, tuple(p.shape), err)       # |p| up to ~5, ten steps of lr 2e-3
+
+
+def test_clipping_changes_the_update_and_off_is_bitwise_the_old_path():
+    """max_grad_norm=None launches nothing new (bitwise the unclipped update); with a bound below the norm the step shrinks."""
+    g = torch.Generator(device='cuda').manual_seed(8)
+    base = torch.randn(50000, device='cuda', generator=g)
+    grad = torch.randn(50000, device='cuda', generator=g) * 10
+    outs = []
+    for mg in (None, 0, 1e9, 1.0):
+        p = base.clone().requires_grad_(True)
+        opt = DataParallelAdamW([p], lr=1e-2, weight_decay=0.0, eps=1e-3, max_grad_norm=mg)
+        p.grad.copy_(grad)
+        opt.step()
+        outs.append(p.detach().clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])         # coefficient exactly 1
+    assert not torch.equal(outs[0], outs[3])
+
+
+def test_frozen_stem_gets_no_gradient_and_keeps_its_statistics():
+    """``frozen_stages=0`` (exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:48; mmdet 2.19.0 ResNet._freeze_stages):
+    after a training step of the small model the image backbone's conv1 / bn1 have no gradient, are in no optimiser bucket, did not
+    move, bn1's running statistics and batch counter are untouched -- while the first trainable layer got a gradient and its
+    BatchNorm's statistics moved.  ``train()`` re-freezes after ``eval()``; ``frozen_stages=-1`` trains the stem."""
+    from sgv3d_amd import synthetic
+    from sgv3d_amd.models.bev_height import BEVHeight
+    dev = torch.device("cuda", 0)
+    bconf, hconf = synthetic.small_conf()
+    assert bconf['img_backbone_conf']['frozen_stages'] == 0
+    for frozen in (0, -1):
+        torch.manual_seed(0)
+        bc = dict(bconf, img_backbone_conf=dict(bconf['img_backbone_conf'], frozen_stages=frozen))
+        model = BEVHeight(bc, hconf).to(dev)
+        synthetic.randomize_norm_stats_(model, seed=1)
+        model.eval().train()                                             # (train() has to re-apply the freeze)
+        r = model.backbone.img_backbone
+        model.head.train_cfg = dict(model.head.train_cfg, grid_size=[256, 256, 1], point_cloud_range=[0, -12.8, -5, 25.6, 12.8, 3])
+        assert r.bn1.training == (frozen < 0) and r.conv1.weight.requires_grad == (frozen < 0) and r.bn1.weight.requires_grad == (frozen < 0)
+        assert r.layer1[0].bn1.training and r.layer1[0].conv1.weight.requires_grad
+        imgs = synthetic.make_images(2, final=bc['final_dim'], device=dev, seed=0)
+        mats = synthetic.make_mats(2, device=dev, scale=bc['final_dim'][0] / 864)
+        boxes, labels = synthetic.make_gt(2, seed=0, n_range=(10, 40), stress=False)
+        opt = DataParallelAdamW(model.parameters(), lr=2e-4, max_grad_norm=5.0)
+        in_buckets = {id(p) for _, _, entries in opt.flat.buckets for p, _, _ in entries}
+        before = {k: v.detach().clone() for k, v in r.state_dict().items() if k.startswith(('conv1.', 'bn1.', 'layer1.0.bn1.', 'layer1.0.conv1.'))}
+        opt.zero_grad()
+        loss = model.loss(model.get_targets([b.to(dev) for b in boxes], [l.to(dev) for l in labels]), model(imgs, mats))
+        loss.backward()
+        g1 = r.layer1[0].conv1.weight.grad
+        assert g1 is not None and float(g1.abs().max()) > 0
+        if frozen >= 0:
+            assert r.conv1.weight.grad is None and r.bn1.weight.grad is None and r.bn1.bias.grad is None
+            assert id(r.conv1.weight) not in in_buckets and id(r.bn1.weight) not in in_buckets
+        else:
+            assert r.conv1.weight.grad is not None and float(r.conv1.weight.grad.abs().max()) > 0
+        opt.step()
+        torch.cuda.synchronize()
+        after = r.state_dict()
+        for k, v in before.items():
+            same = torch.equal(v, after[k])
+            if k.startswith(('conv1.', 'bn1.')):
+                assert same == (frozen >= 0), (frozen, k)
+            else:
+                assert not same, (frozen, k)                            # (weights, statistics and the counter of layer1.0 all move)
+        assert opt.grad_norm() > 0
+
+
+def test_graph_replays_back_to_back_follow_the_eager_steps():
+    """Several replays of the recorded step with NO synchronisation in between (tools/train_bench.py --graph times them like that)
+    against the same number of eager steps from the same state, early in training where the bias corrections change quickly: the
+    per-step scalars travel as kernel arguments of ``sgv3d_adamw_set_hyper``, so staging step t + k cannot leak into step t (a reused
+    pinned staging buffer could).  Clipping (max_grad_norm=5) is part of the recorded step."""
+    from sgv3d_amd.train_step import GraphedTrainStep
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1)
+    w1 = (torch.randn(32, 8, 3, 3) * 0.2).cuda().requires_grad_(True)
+    w2 = (torch.randn(4, 32, 1, 1) * 0.2).cuda().requires_grad_(True)
+    x = torch.randn(2, 16, 20, 8, device=dev)
+    target = torch.randn(2, 16, 20, 4, device=dev) * 30
+    opt = DataParallelAdamW([w1, w2], lr=1e-2, weight_decay=0.0, max_grad_norm=5.0)
+
+    def forward_backward():
+        y = conv_grad.conv2d(torch.relu(conv_grad.conv2d(x, w1, None, 1, 1, 1)), w2)
+        loss = (y - target).square().mean()
+        loss.backward()
+        return loss
+
+    def eager():
+        opt.zero_grad()
+        forward_backward()
+        opt.step()
+
+    eager()                                                               # (per-layer kernel choices)
+    snap = [p.clone() for p, _, _ in opt.flat.buckets], [(m.clone(), v.clone()) for m, v in opt.state]
+
+    def restore():
+        for (p, _, _), q in zip(opt.flat.buckets, snap[0]):
+            p.copy_(q)
+        for (m, v), (m0, v0) in zip(opt.state, snap[1]):
+            m.copy_(m0); v.copy_(v0)
+        opt.steps = 0                                                     # the first steps: 1 - 0.9^t moves by a factor 1.9 from t=1 to 2
+
+    restore()
+    for _ in range(8):
+        eager()
+    torch.cuda.synchronize()
+    want = torch.cat([p for p, _, _ in opt.flat.buckets]).clone()
+    restore()
+    graphed = GraphedTrainStep(forward_backward, opt, warmup=0, strict=True)
+    assert graphed.graph is not None and graphed.in_graph_update
+    restore()
+    for _ in range(8):
+        graphed()                                                         # no sync, no .item()
+    torch.cuda.synchronize()
+    got = torch.cat([p for p, _, _ in opt.flat.buckets])
+    assert opt.steps == 8
+    assert opt.clip_coefficient() < 1.0                                   # the clip was active
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-7, float((got - want).abs().max())
+
+
+_DP_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+rank = int(os.environ["RANK"])
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("gloo", rank=rank, world_size=2)
+try:
+    probe = torch.ones(4, device=dev)
+    dist.all_reduce(probe)
+    assert float(probe[0]) == 2.0
+except Exception as e:                                   # a gloo build without device-tensor support
+    if rank == 0:
+        print(json.dumps({"skip": f"gloo cannot all-reduce device tensors here: {type(e).__name__}: {e}"}))
+    sys.exit(0)
+from sgv3d_amd import synthetic
+from sgv3d_amd.models.bev_height import BEVHeight
+from sgv3d_amd.train_step import DataParallelAdamW
+bconf, hconf = synthetic.small_conf(depth=18)
+torch.manual_seed(3 + rank)                                # different initial weights per rank: the constructor broadcasts rank 0's
+model = BEVHeight(bconf, hconf).to(dev).train()
+for m in model.modules():
+    if isinstance(m, torch.nn.Dropout):
+        m.p = 0.0
+model.head.train_cfg = dict(model.head.train_cfg, grid_size=[256, 256, 1], point_cloud_range=[0, -12.8, -5, 25.6, 12.8, 3])
+stem = model.backbone.img_backbone
+# the frozen stem is not broadcast (in the reference it comes from the checkpoint every rank loads): make it equal by hand
+for t in list(stem.conv1.parameters()) + list(stem.bn1.parameters()) + list(stem.bn1.buffers()):
+    dist.broadcast(t.data, src=0)
+stem_before = [t.detach().clone() for t in list(stem.conv1.parameters()) + list(stem.bn1.parameters()) + list(stem.bn1.buffers())]
+opt = DataParallelAdamW(model.parameters(), lr=2e-3, max_grad_norm=5.0, bucket_bytes=4 << 20)
+assert len(opt.flat.buckets) >= 4 and opt._collectives()
+opt.check_replicas()
+imgs = synthetic.make_images(2, final=bconf['final_dim'], device=dev, seed=10 + rank)     # different data per rank
+mats = synthetic.make_mats(2, device=dev, scale=bconf['final_dim'][0] / 864)
+boxes, labels = synthetic.make_gt(2, seed=20 + rank, n_range=(10, 40), stress=False)
+boxes, labels = [b.to(dev) for b in boxes], [l.to(dev) for l in labels]
+opt.zero_grad()
+loss = model.loss(model.get_targets(boxes, labels), model(imgs, mats))
+loss.backward()
+assert stem.conv1.weight.grad is None and stem.bn1.weight.grad is None
+local = torch.cat([g for _, g, _ in opt.flat.buckets]).clone()
+before = torch.cat([p for p, _, _ in opt.flat.buckets]).clone()
+both = [torch.empty_like(local) for _ in range(2)]
+dist.all_gather(both, local)
+avg = (both[0] + both[1]) / 2
+want_norm = float(avg.double().norm())
+opt.all_reduce_grads()
+opt.step()
+torch.cuda.synchronize()
+summed = torch.cat([g for _, g, _ in opt.flat.buckets])
+assert torch.allclose(summed, both[0] + both[1], rtol=1e-6, atol=1e-7)
+assert abs(opt.grad_norm() - want_norm) <= 1e-5 * want_norm, (opt.grad_norm(), want_norm)
+coef = min(1.0, 5.0 / (want_norm + 1e-6))
+assert coef < 1.0, want_norm                              # an untrained detector: the clip is active
+# the first AdamW step from zero moments moves every parameter by lr * g / (|g| + eps) -- sign-like --, so check the update with
+# torch's own AdamW on the clipped average
+q = before.clone().requires_grad_(True)
+q.grad = avg * coef
+ropt = torch.optim.AdamW([q], lr=2e-3, weight_decay=1e-7)
+ropt.step()
+after = torch.cat([p for p, _, _ in opt.flat.buckets])
+err = float((after - q.detach()).abs().max())
+opt.check_replicas()                                       # both ranks applied the same update
+assert all(torch.equal(a, b) for a, b in zip(stem_before, list(stem.conv1.parameters()) + list(stem.bn1.parameters()) + list(stem.bn1.buffers())))
+dist.destroy_process_group()
+if rank == 0:
+    print(json.dumps({"ok": True, "grad_norm": want_norm, "coef": coef, "update_err": err, "buckets": len(opt.flat.buckets)}))
+"""
+
+
+def test_two_rank_clipped_frozen_stem_step(tmp_path):
+    """The data-parallel step of BASELINE configs[3] with the reference's two training semantics -- ``frozen_stages=0`` and
+    ``gradient_clip_val=5`` -- on TWO ranks sharing this box's one MI355X (gloo carries the device tensors; RCCL refuses two ranks on
+    one device): the buckets hold the sum of both ranks' gradients, the norm is the averaged gradient's, the clipped update is
+    torch.optim.AdamW's on ``avg * min(1, 5 / (norm + 1e-6))``, both ranks end with identical parameters, and the frozen stem has no
+    gradient, sits in no bucket and does not move."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER % root)
+    env = {k: v for k, v in os.environ.items() if k not in ("SGV3D_FORCE_DIST",)}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-3000:]
+    rec = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    if "skip" in rec:
+        pytest.skip(rec["skip"])
+    assert rec["ok"] and rec["update_err"] <= 2e-6, rec
+    print(rec)
+
+
 def test_graphed_train_step_is_the_eager_step():
     """train_step.GraphedTrainStep -- zero_grad + forward + targets + loss + backward + AdamW of the small model recorded as one hipGraph --
     against the eager step FROM THE SAME STATE (parameters, AdamW moments, step counter restored in between): the same loss bit for
@@ -99,7 +346,7 @@ def test_graphed_train_step_is_the_eager_step():
     mats = synthetic.make_mats(2, device=dev, scale=bconf['final_dim'][0] / 864)
     boxes, labels = synthetic.make_gt(2, seed=0, n_range=(10, 40), stress=False)
     boxes, labels = [b.to(dev) for b in boxes], [l.to(dev) for l in labels]
-    opt = DataParallelAdamW(model.parameters(), lr=2e-4)
+    opt = DataParallelAdamW(model.parameters(), lr=2e-4, max_grad_norm=5.0)      # (the reference's gradient_clip_val: part of the recorded step)
 
     def forward_backward():
         loss = model.loss(model.get_targets(boxes, labels), model(imgs, mats))

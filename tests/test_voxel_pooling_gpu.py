@@ -552,3 +552,61 @@ def test_level1_entry_inside_a_captured_graph(hip, hot):
         assert np.array_equal(out.permute(0, 3, 1, 2).cpu().numpy(), ref)
     assert _l1_stats(hip)[3] - s0[3] == 2                                 # the eager build + the one recorded into the graph
     hip.check(hip.load().sgv3d_voxel_pooling_cache_clear(), "clear")
+
+
+def test_level1_graph_rebuilds_on_two_streams_under_a_saturating_load(hip):
+    """Two captured level-1 calls (two streams, two plans) replayed CONCURRENTLY with changed geometry while a third stream keeps every
+    compute unit busy with large GEMMs: the one-launch rebuild's grid barrier must not depend on co-residency it was not given.  Its
+    grid is sized from the kernel's occupancy, workgroups become resident as the finite load kernels drain, and a barrier that gives
+    up after 20 ms leaves through the gated scatter -- so whichever way a replay goes, the sums are exact and the call returns."""
+    import time
+    lib = hip.load()
+    hip.check(lib.sgv3d_voxel_pooling_cache_clear(), "clear")
+    B, N, C, X, Y, Z = 1, 120000, 80, 64, 48, 1
+    rng = np.random.default_rng(77)
+    feats = rng.integers(-4, 5, size=(B, N, C)).astype(np.float32)
+
+    def geometry(seed):
+        r = np.random.default_rng(seed)
+        g = r.integers(-2, max(X, Y) + 2, size=(B, N, 3)).astype(np.int32)
+        g[..., 2] = 0
+        return g
+    geoms = [geometry(100 + i) for i in range(4)]
+    refs = [VPO.forward(g, feats, (X, Y, Z))[0] for g in geoms]
+    f = torch.from_numpy(feats).to(DEV)
+    lanes = []
+    for lane in range(2):
+        s = torch.cuda.Stream()
+        g = torch.from_numpy(geoms[lane]).to(DEV)
+        out = torch.zeros(B, Y, X, C, device=DEV)
+        with torch.cuda.stream(s):
+            _level1(hip, g, f, out, None, X, Y, Z)                        # eager: this stream's plan
+            s.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                out.mul_(0.0)
+                _level1(hip, g, f, out, None, X, Y, Z)
+        lanes.append((s, g, out, graph))
+    load_stream = torch.cuda.Stream()
+    a = torch.randn(6144, 6144, device=DEV)
+    b = torch.randn(6144, 6144, device=DEV)
+    c = torch.empty_like(a)
+    torch.cuda.synchronize()
+    builds0 = _l1_stats(hip)[3]
+    t0 = time.perf_counter()
+    for rnd in range(6):
+        with torch.cuda.stream(load_stream):
+            for _ in range(6):
+                torch.matmul(a, b, out=c)                                  # ~3 ms each at the f32 peak: the chip is full throughout
+        picks = [(rnd + lane) % 4 for lane in range(2)]
+        for (s, g, out, graph), k in zip(lanes, picks):
+            with torch.cuda.stream(s):
+                g.copy_(torch.from_numpy(geoms[k]).to(DEV), non_blocking=True)      # changed geometry in every replay
+                graph.replay()
+        torch.cuda.synchronize()
+        for (s, g, out, graph), k in zip(lanes, picks):
+            assert np.array_equal(out.permute(0, 3, 1, 2).cpu().numpy(), refs[k]), (rnd, k)
+    wall = time.perf_counter() - t0
+    assert wall < 20.0, wall                                               # (a hung barrier used to poll for seconds per phase)
+    assert _l1_stats(hip)[3] == builds0                                    # replays record no new builds on the host side
+    hip.check(lib.sgv3d_voxel_pooling_cache_clear(), "clear")

@@ -12,7 +12,7 @@ synthetic.randomize_norm_stats_(model, seed=seed)
 BT = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 imgs = synthetic.make_images(BT, final=bconf['final_dim'], seed=11)
 mats = synthetic.make_mats(BT, scale=float(sys.argv[3]))
-names = [n for n, _ in model.named_parameters()]
+names = [n for n, p in model.named_parameters() if p.requires_grad]
 from test_train_forward_gpu import _gt, _oracle_loss
 head_cfg = dict(model.head.train_cfg, grid_size=[256, 256, 1], point_cloud_range=[0, -12.8, -5, 25.6, 12.8, 3])
 boxes, labels = _gt(BT)

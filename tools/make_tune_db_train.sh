@@ -8,7 +8,9 @@ mkdir -p $OUT
 export SGV3D_TUNE_ROUNDS=8 SGV3D_TUNE_REPEATS=4
 cd $R
 rm -f $OUT/gfx950_cfg2_train.json
-mkdir -p $OUT/hide && mv tune/gfx950_cfg2_train.json $OUT/hide/ 2>/dev/null      # measure the training signatures afresh, keep the inference DBs
+# measure the training signatures afresh, keep the inference DBs: the committed training DB is SKIPPED by the loader (never moved
+# out of the tree: a killed run used to leave the working copy without it)
+export SGV3D_TUNE_SKIP=gfx950_cfg2_train.json
 SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2_train.json python3 tools/train_bench.py --batch 2 --steps 3 > $OUT/train_b2.json 2> $OUT/train_b2.err
 echo "train b2 rc=$?"
 SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2_train.json python3 tools/train_bench.py --batch 4 --steps 3 > $OUT/train_b4.json 2> $OUT/train_b4.err
@@ -18,7 +20,7 @@ SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2_train.json python3 tools/train_bench.py --batc
 echo "train b2 bf16 rc=$?"
 SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2_train.json python3 tools/train_bench.py --batch 4 --steps 3 --dtype bf16 > $OUT/train_b4_bf16.json 2> $OUT/train_b4_bf16.err
 echo "train b4 bf16 rc=$?"
-mv $OUT/hide/gfx950_cfg2_train.json tune/ 2>/dev/null
+unset SGV3D_TUNE_SKIP
 python3 - <<PY
 import json, glob
 t = json.load(open("$OUT/gfx950_cfg2_train.json"))

@@ -2,7 +2,7 @@
 """Training step of BASELINE config 4's per-GPU share on synthetic data: forward (train mode) + targets + loss +
 backward + gradient all-reduce + fused AdamW.  `python tools/train_bench.py [--batch 4] [--steps 5] [--config cfg2|cfg5]`
 or, BASELINE config 4 (global batch 32 = 4 per GPU over 8 MI355X, 304 MB of fp32 gradients all-reduced over RCCL/xGMI in
-two flat buckets launched from inside backward):
+flat 48 MiB buckets launched from inside backward, clipped to a global gradient norm of 5 as the reference's Trainer does):
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
         tools/train_bench.py --config cfg4 --steps 10  Prints one JSON line (samples/s over all ranks); this is
 NOT the headline metric of bench.py (inference frames/s), it tracks SURVEY §8(f) rank 2."""
@@ -28,6 +28,9 @@ ap.add_argument("--no-dropout", action="store_true", help="Dropout(p=0) instead 
 ap.add_argument("--trace-loss", action="store_true", help="record the loss of every timed step (a host read per step: not for timing)")
 ap.add_argument("--graph", action="store_true", help="the whole step (forward, targets, loss, backward, AdamW) as ONE hipGraph replay "
                 "(train_step.GraphedTrainStep); single process only: with a process group the gradient all-reduce stays outside the graph")
+ap.add_argument("--clip", type=float, default=5.0, help="global gradient-norm bound (Lightning's gradient_clip_val of the reference's Trainer, "
+                "exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:405); 0 = off")
+ap.add_argument("--bucket-mib", type=int, default=None, help="flat gradient bucket size (default train_step.DEFAULT_BUCKET_BYTES = 48 MiB)")
 ap.add_argument("--profile", action="store_true", help="per-kernel-family times of one step (HIP events, eager)")
 args = ap.parse_args()
 
@@ -60,7 +63,8 @@ if BSM:
     semantic = SemanticSupervision(8)
     gt_semantic = torch.randint(0, 7, (args.batch, 1) + tuple(bconf['final_dim']), dtype=torch.uint8,
                                 generator=torch.Generator().manual_seed(group.rank)).to(dev)
-opt = DataParallelAdamW(model.parameters(), lr=reference_lr(args.batch, group.world))   # broadcasts rank 0's parameters
+opt = DataParallelAdamW(model.parameters(), lr=reference_lr(args.batch, group.world), max_grad_norm=args.clip or None,
+                        bucket_bytes=None if args.bucket_mib is None else args.bucket_mib << 20)   # broadcasts rank 0's parameters
 if not args.no_overlap:
     opt.overlap_with_backward()
 nparam = sum(p.numel() for p in model.parameters())
@@ -74,7 +78,11 @@ def forward_backward():
     loss = model.loss(targets, preds)
     if BSM:
         loss = loss + semantic(img_preds, gt_semantic) * 500
+    if BW_EVENTS:
+        BW_EVENTS[0].record()
     loss.backward()
+    if BW_EVENTS:
+        BW_EVENTS[1].record()
     EARLY[0] = len(getattr(opt, '_early', {}))
     return loss
 
@@ -88,6 +96,7 @@ def step():
 
 
 EARLY = [0]
+BW_EVENTS = []
 
 
 loss = None
@@ -118,6 +127,21 @@ if args.trace_loss:
         return v
 elapsed = group.timed(run, args.steps)
 loss = graphed.result if args.graph else LAST[0]
+grad_norm, clip_coef = opt.grad_norm(), opt.clip_coefficient()
+FIRST = None
+if opt._collectives() and not args.no_overlap and getattr(opt, '_hooks', None):
+    # one more eager step with three events: start of backward, launch of bucket 0's all-reduce, end of backward
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    opt.first_early_event = ev[1]
+    BW_EVENTS[:] = [ev[0], ev[2]]
+    try:
+        step()
+    finally:
+        BW_EVENTS[:] = []
+        opt.first_early_event = None
+    torch.cuda.synchronize()
+    if EARLY[0] > 0:
+        FIRST = ev[0].elapsed_time(ev[1]) / max(ev[0].elapsed_time(ev[2]), 1e-6)
 out = {"metric": "training samples/s (forward + loss + backward + all-reduce + AdamW)", "value": group.world * args.batch * args.steps / elapsed,
        "unit": "samples/s", "n_gpus": group.world, "steps": args.steps, "ms_per_step": 1e3 * elapsed / args.steps,
        "batch_per_gpu": args.batch, "global_batch": args.batch * group.world, "dtype": args.dtype,
@@ -128,6 +152,9 @@ out = {"metric": "training samples/s (forward + loss + backward + all-reduce + A
        "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2**30, "data": "synthetic",
        # (a 1-rank group with SGV3D_FORCE_DIST=1 still broadcasts / all-reduces through RCCL: the single-GPU stand-in for cfg-4)
        "collectives_active": bool(opt._collectives()), "allreduces_launched_inside_backward": EARLY[0],
+       "first_allreduce_launch_at_fraction_of_backward": FIRST, "bucket_mib": max(g.numel() for _, g, _ in opt.flat.buckets) * 4 / 2**20,
+       "gradient_clip_val": args.clip or None, "grad_norm_last_step": grad_norm, "clip_coefficient_last_step": clip_coef,
+       "frozen_parameters": sorted(n for n, p in model.named_parameters() if not p.requires_grad),
        "param_checksum": float(sum(p.double().abs().sum() for p, _, _ in opt.flat.buckets))}
 if args.profile:
     # the profiled step holds collectives (loss-factor and gradient all-reduces): every rank runs it, rank 0 reports
