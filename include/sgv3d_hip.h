@@ -262,6 +262,10 @@ typedef struct sgv3d_conv_desc {
 /* sgv3d_conv2d_winograd4_forward only: the grouped GEMM on v_mfma_f32_16x16x4_f32 with 48 x 64 workgroup tiles -- rows per
  * position padded to a multiple of 48 (a 54x96 map: 336 tiles exactly, against 384 / 352 for the 64- / 32-row tiles) */
 #define SGV3D_TILE_48x64 10
+/* F(4x4) position GEMM with f32-accurate products from three bf16 terms per operand (csrc/gemm_x3_grouped.hip): desc.tile =
+ * SGV3D_TILE_X3 | variant, variant = {0: 48, 1: 64, 2: 96, 3: 112, 4: 128} rows per workgroup x 128 columns, + 5: x 160 columns;
+ * the weights are those of sgv3d_conv_winograd4_pack_weight_x3 and desc.cout_pad their rows per block */
+#define SGV3D_TILE_X3 64
 /* ... | SGV3D_TILE_MFIRST: the workgroups walk the output-channel tiles of one m-tile back to back (input rows fetched once
  * from HBM) instead of the m-tiles of one channel tile (weight tile shared); same results */
 #define SGV3D_TILE_MFIRST 16
@@ -287,6 +291,11 @@ typedef struct sgv3d_conv_desc {
  * (sgv3d_conv2d_winograd4_workspace_bytes, 16-B aligned).  fp32 error ~1e-5 of the output scale. */
 int sgv3d_conv_winograd4_pack_weight(const float *w_src /*[cout, cin, 3, 3]*/, int cout, int cin, int k_pad, int cout_pad,
                                      float *u_packed /*36 x cout_pad x k_pad*/, void *stream);
+/* ... as three bf16 planes per element, layout [36][cout_pad][cin_pad / 32][3][32] (cin_pad % 32 == 0, cout_pad % 32 == 0), for
+ * desc.tile = SGV3D_TILE_X3 | variant of sgv3d_conv2d_winograd4_forward: every f32 weight of (G g G^T) split exactly into
+ * hi + mid + lo bf16 terms.  Same reference layers (layers/backbones/lss_fpn.py:161-250, layers/heads/bev_height_head.py:97-108). */
+int sgv3d_conv_winograd4_pack_weight_x3(const float *w_src, int cout, int cin, int cin_pad, int cout_pad, void *u3_packed,
+                                        void *stream);
 size_t sgv3d_conv2d_winograd4_workspace_bytes(const sgv3d_conv_desc *desc /*host*/);
 int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *u_packed,
                                    const float *scale, const float *bias, const float *residual, float *y,

@@ -78,5 +78,10 @@ int conv_gemm_grouped(const float *x, const float *w, float *y, int rows, int gr
 // the same product on v_mfma_f32_16x16x4_f32 with 48 x 64 workgroup tiles (gemm16_grouped.hip): rows % 48 == 0, K % 32 == 0
 int conv_gemm_grouped16(const float *x, const float *w, float *y, int rows, int groups, int K, int N, int k_pad, int cout_pad,
                         hipStream_t st);
+// f32x3 position GEMM of the F(4x4) path on bf16 planes (gemm_x3_grouped.hip); variant = m-tile index {48, 64, 96, 112, 128 rows}
+// + 5 for the five-wave (160-column) form
+int conv_gemm_grouped_x3(const void *x, const void *w, float *y, int rows, int K, int N, int cout_pad, int variant, hipStream_t st,
+                         size_t w_block_stride);
+int gemm_x3_tile_rows(int variant);
 
 }  // namespace sgv3d

@@ -214,13 +214,120 @@ __global__ __launch_bounds__(256) void wino4_pack_weight_kernel(const float *__r
     }
 }
 
+// ---- f32x3 forms (gemm_x3_grouped.hip): the operands of the position GEMMs as three bf16 planes ---------------------------
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// x = hi + mid + lo exactly (8 + 8 + 8 significand bits; the remainders x - hi and x - hi - mid are exact in f32)
+__device__ __forceinline__ void split3(const f4 &x, bf16x4 &hi, bf16x4 &mid, bf16x4 &lo) {
+    const f32x4v v = {x.x, x.y, x.z, x.w};
+    hi = __builtin_convertvector(v, bf16x4);
+    const f32x4v r1 = v - __builtin_convertvector(hi, f32x4v);
+    mid = __builtin_convertvector(r1, bf16x4);
+    const f32x4v r2 = r1 - __builtin_convertvector(mid, f32x4v);
+    lo = __builtin_convertvector(r2, bf16x4);
+}
+
+// as wino4_input_kernel, writing V3 [36][rows][cin/32][3][32] bf16: one thread = one tile x 4 input channels -> three 8-byte
+// stores per position (the 8 threads of a 32-channel record fill its three 64-byte planes)
+__global__ __launch_bounds__(256) void wino4_input_x3_kernel(const Wino4Args a) {
+    const int cq = a.cin >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long ntile = (long long)a.batch * a.ty * a.tx * a.dil * a.dil;
+    if (i >= ntile * cq) return;
+    const int t = (int)(i / cq), c = (int)(i - (long long)t * cq) * 4;
+    int b, py, px, iy, ix;
+    wino4_tile(a, t, b, py, px, iy, ix);
+    const int y0 = py + (4 * iy - 1) * a.dil, x0 = px + (4 * ix - 1) * a.dil;
+    const float *xb = a.x + (size_t)b * a.h * a.w * a.x_ld + a.x_coff + c;
+    f4 d[6][6];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+        const int yy = y0 + rr * a.dil;
+        const bool rok = (unsigned)yy < (unsigned)a.h;
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {
+            const int xx = x0 + cc * a.dil;
+            d[rr][cc] = (rok && (unsigned)xx < (unsigned)a.w) ? ld4(xb + ((size_t)yy * a.w + xx) * a.x_ld) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) wino4_bt(d[0][cc], d[1][cc], d[2][cc], d[3][cc], d[4][cc], d[5][cc]);     // B^T d
+    // record (row t, k-chunk c / 32) of position p: bf16 index ((p * rows + t) * (cin / 32) + c / 32) * 96 + plane * 32 + c % 32
+    __bf16 *vb = reinterpret_cast<__bf16 *>(a.v) + ((size_t)t * (a.cin >> 5) + (c >> 5)) * 96 + (c & 31);
+    const size_t plane = (size_t)a.rows * (a.cin >> 5) * 96;
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+        wino4_bt(d[rr][0], d[rr][1], d[rr][2], d[rr][3], d[rr][4], d[rr][5]);                                 // (B^T d) B
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {
+            bf16x4 hi, mid, lo;
+            split3(d[rr][cc], hi, mid, lo);
+            __bf16 *o = vb + (size_t)(rr * 6 + cc) * plane;
+            *reinterpret_cast<bf16x4 *>(o) = hi;
+            *reinterpret_cast<bf16x4 *>(o + 32) = mid;
+            *reinterpret_cast<bf16x4 *>(o + 64) = lo;
+        }
+    }
+}
+
+// U3[p][co][ci / 32][plane][ci % 32] = the three bf16 terms of (G g G^T)[i][j], p = 6 i + j; zero rows / columns in the padding.
+// One thread per (co, ci); the arithmetic of wino4_pack_weight_kernel, then the split.
+__global__ __launch_bounds__(256) void wino4_pack_weight_x3_kernel(const float *__restrict__ w, int cout, int cin, int k_pad,
+                                                                   int cout_pad, __bf16 *__restrict__ u) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)cout_pad * k_pad) return;
+    const int co = (int)(i / k_pad), ci = (int)(i - (long long)co * k_pad);
+    float g[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (co < cout && ci < cin) {
+        const float *p = w + ((size_t)co * cin + ci) * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = p[a * 3 + b];
+    }
+    float t[6][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const float s02 = g[0][b] + g[2][b];
+        t[0][b] = 0.25f * g[0][b];
+        t[1][b] = (-1.f / 6.f) * (s02 + g[1][b]);
+        t[2][b] = (-1.f / 6.f) * (s02 - g[1][b]);
+        t[3][b] = (1.f / 24.f) * g[0][b] + (1.f / 12.f) * g[1][b] + (1.f / 6.f) * g[2][b];
+        t[4][b] = (1.f / 24.f) * g[0][b] - (1.f / 12.f) * g[1][b] + (1.f / 6.f) * g[2][b];
+        t[5][b] = g[2][b];
+    }
+    const size_t block = (size_t)cout_pad * k_pad * 3;
+    __bf16 *ub = u + ((size_t)co * (k_pad >> 5) + (ci >> 5)) * 96 + (ci & 31);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const float s02 = t[r][0] + t[r][2];
+        const float o[6] = {0.25f * t[r][0], (-1.f / 6.f) * (s02 + t[r][1]), (-1.f / 6.f) * (s02 - t[r][1]),
+                            (1.f / 24.f) * t[r][0] + (1.f / 12.f) * t[r][1] + (1.f / 6.f) * t[r][2],
+                            (1.f / 24.f) * t[r][0] - (1.f / 12.f) * t[r][1] + (1.f / 6.f) * t[r][2], t[r][2]};
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const float v = o[c];
+            const __bf16 hi = (__bf16)v;
+            const float r1 = v - (float)hi;
+            const __bf16 mid = (__bf16)r1;
+            const __bf16 lo = (__bf16)(r1 - (float)mid);
+            __bf16 *q = ub + (size_t)(r * 6 + c) * block;
+            q[0] = hi;
+            q[32] = mid;
+            q[64] = lo;
+        }
+    }
+}
+
 // tiles of one sub-grid (the largest one: phase 0), of all phases and images, and the padded row count per position
 void wino4_geom(const sgv3d_conv_desc *d, int &ty, int &tx, long long &tiles, int &rows) {
     const int dil = d->dil;
     ty = cdiv(cdiv(d->out_h, dil), 4);
     tx = cdiv(cdiv(d->out_w, dil), 4);
     tiles = (long long)d->batch * dil * dil * ty * tx;
-    const int g = (d->tile & ~SGV3D_TILE_OCC5) == SGV3D_TILE_32x128 ? 32 : d->tile == SGV3D_TILE_48x64 ? 48 : 64;   // the GEMM's m-tile height
+    const int g = (d->tile & SGV3D_TILE_X3) ? gemm_x3_tile_rows(d->tile & 15)
+                  : (d->tile & ~SGV3D_TILE_OCC5) == SGV3D_TILE_32x128 ? 32 : d->tile == SGV3D_TILE_48x64 ? 48 : 64;   // the GEMM's m-tile height
     rows = (int)((tiles + g - 1) / g * g);
 }
 
@@ -248,12 +355,26 @@ extern "C" int sgv3d_conv_winograd4_pack_weight(const float *w_src, int cout, in
     return check_launch("wino4_pack_weight_kernel");
 }
 
+// ... as three bf16 planes per element for the f32x3 position GEMM (desc.tile = SGV3D_TILE_X3 | variant): u3_packed is
+// 36 x cout_pad x cin_pad x 3 bf16 (cin_pad % 32 == 0, cout_pad = cout rounded up to 32), layout [p][co][ci / 32][plane][ci % 32]
+extern "C" int sgv3d_conv_winograd4_pack_weight_x3(const float *w_src, int cout, int cin, int cin_pad, int cout_pad, void *u3_packed,
+                                                   void *stream) {
+    SGV3D_REQUIRE(w_src && u3_packed && cout > 0 && cin > 0 && cin_pad >= cin && cin_pad % 32 == 0 && cout_pad >= cout && cout_pad % 32 == 0,
+                  "conv_winograd4_pack_weight_x3: bad arguments (cout=%d cin=%d cin_pad=%d cout_pad=%d)", cout, cin, cin_pad, cout_pad);
+    const long long total = (long long)cout_pad * cin_pad;
+    hipLaunchKernelGGL(wino4_pack_weight_x3_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w_src, cout, cin, cin_pad,
+                       cout_pad, static_cast<__bf16 *>(u3_packed));
+    return check_launch("wino4_pack_weight_x3_kernel");
+}
+
 // bytes of V + M
 extern "C" size_t sgv3d_conv2d_winograd4_workspace_bytes(const sgv3d_conv_desc *d) {
     if (!d || d->batch <= 0 || d->out_h <= 0 || d->out_w <= 0 || d->cin <= 0 || d->cout <= 0 || d->dil <= 0) return 0;
     int ty, tx, rows;
     long long tiles;
     wino4_geom(d, ty, tx, tiles, rows);
+    if (d->tile & SGV3D_TILE_X3)         // V as three bf16 planes (6 bytes per element), M f32
+        return 36 * (size_t)rows * (6 * (size_t)d->cin + sizeof(float) * (size_t)wino4_chunk(d, rows));
     return sizeof(float) * 36 * (size_t)rows * ((size_t)d->cin + (size_t)wino4_chunk(d, rows));
 }
 
@@ -292,11 +413,30 @@ extern "C" int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *d, const fl
     wino4_geom(d, a.ty, a.tx, tiles, a.rows);
     a.dil = d->dil;
     SGV3D_REQUIRE(tiles < 0x7fffffffLL / 64, "conv2d_winograd4_forward: too many tiles");
+    const bool x3 = (d->tile & SGV3D_TILE_X3) != 0;
     a.v = static_cast<float *>(workspace);
-    a.m = a.v + (size_t)36 * a.rows * d->cin;
+    a.m = x3 ? reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + (size_t)36 * a.rows * d->cin * 6)
+             : a.v + (size_t)36 * a.rows * d->cin;
     hipStream_t st = as_stream(stream);
     a.gw = planes ? d->deconv_ks : 0;
     a.c0 = 0; a.cn = d->cout;
+    if (x3) {
+        // f32x3: u_packed is the three-plane bf16 form (sgv3d_conv_winograd4_pack_weight_x3), desc.cout_pad its rows per block
+        SGV3D_REQUIRE(d->cin % 32 == 0 && d->cout_pad % 32 == 0 && d->cout_pad >= d->cout,
+                      "conv2d_winograd4_forward: SGV3D_TILE_X3 needs cin %% 32 == 0 and cout_pad (a multiple of 32) of the x3 weights");
+        SGV3D_REQUIRE((d->tile & 15) < 10, "conv2d_winograd4_forward: unknown SGV3D_TILE_X3 variant %d", d->tile & 15);
+        hipLaunchKernelGGL(wino4_input_x3_kernel, dim3(cdiv(tiles * (d->cin / 4), 256)), dim3(256), 0, st, a);
+        const int chunk3 = wino4_chunk(d, a.rows);
+        for (int c0 = 0; c0 < d->cout; c0 += chunk3) {
+            a.c0 = c0;
+            a.cn = d->cout - c0 < chunk3 ? d->cout - c0 : chunk3;
+            // block p of the chunk's weights: cout_pad rows of cin * 6 bytes after block p - 1, shifted by c0 rows
+            if (int rc = conv_gemm_grouped_x3(a.v, static_cast<const unsigned char *>(static_cast<const void *>(u_packed)) + (size_t)c0 * d->cin * 6,
+                                              a.m, a.rows, d->cin, a.cn, d->cout_pad - c0, d->tile & 15, st, (size_t)d->cout_pad * d->cin * 6)) return rc;
+            hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(tiles * (a.cn / 4), 256)), dim3(256), 0, st, a);
+        }
+        return check_launch("conv2d_winograd4_forward(x3)");
+    }
     hipLaunchKernelGGL(wino4_input_kernel, dim3(cdiv(tiles * (d->cin / 4), 256)), dim3(256), 0, st, a);
     int tile = (d->tile == SGV3D_TILE_64x128 || d->tile == SGV3D_TILE_32x128 || d->tile == SGV3D_TILE_48x64) ? d->tile
                : (d->tile & SGV3D_TILE_OCC5) ? (SGV3D_TILE_64x64 | SGV3D_TILE_OCC5) : SGV3D_TILE_64x64;

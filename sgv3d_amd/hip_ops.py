@@ -153,6 +153,8 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: 
               38: "dw_bf16", 39: "dw_bf16",                                                # ... 64 pixels x 128 channels (39: two chunks ahead)
               40: "wino4_resident",    # F(4x4,3x3) with the transformed input resident in LDS (sgv3d_conv3x3_f4res_forward)
               47: "wino4",
+              50: "wino4_x3", 51: "wino4_x3", 52: "wino4_x3", 53: "wino4_x3", 54: "wino4_x3",    # F(4x4) with the f32x3 position GEMM
+              55: "wino4_x3", 56: "wino4_x3", 57: "wino4_x3", 58: "wino4_x3", 59: "wino4_x3",    # (csrc/gemm_x3_grouped.hip), by tile shape
               44: "64x64", 45: "64x64",    # the 64x64 tile at five workgroups per CU (SGV3D_TILE_OCC5); 45: walked m-tile first
               46: "wino4"}                 # F(4x4,3x3) in three launches with the five-per-CU 64x64 GEMM tile
 MFIRST = _os.environ.get("SGV3D_MFIRST", "1") != "0"
@@ -165,8 +167,16 @@ TILE_WINO4_WIDE = 10
 TILE_WINO4_NARROW = 15   # ... with the 32x128 GEMM tile: rows per position padded to 32 instead of 64 (336 tiles -> 352, 84 -> 96)
 TILE_WINO4_OCC = 46      # ... with the five-workgroups-per-CU form of the 64x64 GEMM tile (SGV3D_TILE_64x64 | SGV3D_TILE_OCC5)
 TILE_WINO4_G48 = 47      # ... with the grouped GEMM on v_mfma_f32_16x16x4_f32, 48 x 64 tiles (SGV3D_TILE_48x64): rows padded to 48 (336 -> 336)
-WINO4_TILES = (TILE_WINO4, TILE_WINO4_WIDE, TILE_WINO4_NARROW, TILE_WINO4_OCC, TILE_WINO4_G48)
+# ... with the position GEMM on the bf16 matrix cores, f32-accurate ("f32x3": every operand split exactly into three bf16 terms by its
+# PRODUCER -- the weight packer, the input transform --, six partial products accumulated in f32; csrc/gemm_x3_grouped.hip).  Host ids
+# 50 + v: v % 5 = m-tile of {48, 64, 96, 112, 128} rows, v >= 5: 160 instead of 128 columns per workgroup.
+WINO4_X3_TILES = tuple(range(50, 60))
+X3_TILE_ROWS = {50 + v: (48, 64, 96, 112, 128)[v % 5] for v in range(10)}
+X3_TILE_COLS = {50 + v: 160 if v >= 5 else 128 for v in range(10)}
+WINO4_TILES = (TILE_WINO4, TILE_WINO4_WIDE, TILE_WINO4_NARROW, TILE_WINO4_OCC, TILE_WINO4_G48) + WINO4_X3_TILES
 WINO4_G48 = _os.environ.get("SGV3D_WINO4_G48", "1") != "0"     # 0: never a candidate
+# 0: the f32x3 position GEMM is never a candidate -- every product of the f32 path on the f32 MFMA (bench.py's native_f32_value)
+WINO4_X3 = _os.environ.get("SGV3D_WINO4_X3", "1") != "0"
 # F(4x4,3x3) in ONE launch with V = B^T d B of a 16x16 block resident in LDS (csrc/head_wino4.hip: conv_f4res_kernel): 3x3 /
 # stride 1 / pad 1 layers with 64 input channels (ResNet layer 1) or 64 output channels (the CenterHead's shared layer), f32
 TILE_F4RES = 40
@@ -432,6 +442,21 @@ class PackedConv:
             self.w_wino4, self.wino4_geom = packed, (k_pad, cout_pad)
         return self.w_wino4
 
+    def _wino4_x3_weights(self):
+        """U[p] of F(4x4,3x3) as three bf16 planes per element ([36][cout_pad][cin / 32][3][32], cout_pad = cout rounded up to 32) for
+        the f32x3 position GEMM, made on first use by one kernel (sgv3d_conv_winograd4_pack_weight_x3)."""
+        if getattr(self, 'w_wino4_x3', None) is None:
+            lib = _lib.load()
+            w = self._keep                                           # [cout, cin_real, 3, 3] f32 on the device
+            cout_pad = (self.cout + 31) // 32 * 32
+            packed = torch.empty(36, cout_pad, self.cin // 32, 3, 32, dtype=torch.bfloat16, device=w.device)
+            with torch.cuda.device(w.device):
+                rc = lib.sgv3d_conv_winograd4_pack_weight_x3(w.data_ptr(), self.cout, int(w.shape[1]), self.cin, cout_pad,
+                                                             packed.data_ptr(), _st(w))
+            _lib.check(rc, "sgv3d_conv_winograd4_pack_weight_x3")
+            self.w_wino4_x3, self.wino4_x3_cout_pad = packed, cout_pad
+        return self.w_wino4_x3
+
     def _dw_weights(self):
         """Fragment-ordered bf16 weights of the direct-weight kernel (sgv3d_conv_dw_bf16_pack_weight), made on first use.
         Transposed convolution (kernel == stride): a 1x1 layer with ks * ks * cout outputs ordered (dy, dx, co)."""
@@ -606,14 +631,19 @@ class PackedConv:
                 # the grouped GEMM of the three-launch F(4x4) path: 36 positions x rows (tiles padded to the GEMM's m-tile)
                 dil = max(1, self.dil)
                 tiles = B * dil * dil * -(-(-(-oh // dil)) // 4) * -(-(-(-ow // dil)) // 4)
-                g = 32 if t == TILE_WINO4_NARROW else 48 if t == TILE_WINO4_G48 else 64
+                g = X3_TILE_ROWS[t] if t in WINO4_X3_TILES else 32 if t == TILE_WINO4_NARROW else 48 if t == TILE_WINO4_G48 else 64
                 rows = -(-tiles // g) * g
-                extra = {"symbol": {TILE_WINO4: "conv_igemm_kernel<1, 1, true, false, true, false, false>",
-                                    TILE_WINO4_WIDE: "conv_igemm_kernel<1, 2, true, false, true, false, false>",
-                                    TILE_WINO4_NARROW: "conv_igemm_kernel<1, 1, true, false, true, true, false>",
-                                    TILE_WINO4_OCC: "conv_igemm_kernel<1, 1, true, false, true, false, true>",
-                                    TILE_WINO4_G48: "gemm16_grouped_kernel<3>"}[t],
-                         "mfma_flops": 2.0 * 36 * rows * self.cin * self.cout}
+                if t in WINO4_X3_TILES:
+                    # six bf16 partial products per f32 product: the kernel's roofline is the bf16 MFMA peak over these flops
+                    extra = {"symbol": f"gemm_x3_grouped_kernel<{g // 16}, {X3_TILE_COLS[t] // 32}>",
+                             "mfma_flops": 2.0 * 36 * rows * self.cin * self.cout, "bf16_mfma_flops": 6 * 2.0 * 36 * rows * self.cin * self.cout}
+                else:
+                    extra = {"symbol": {TILE_WINO4: "conv_igemm_kernel<1, 1, true, false, true, false, false>",
+                                        TILE_WINO4_WIDE: "conv_igemm_kernel<1, 2, true, false, true, false, false>",
+                                        TILE_WINO4_NARROW: "conv_igemm_kernel<1, 1, true, false, true, true, false>",
+                                        TILE_WINO4_OCC: "conv_igemm_kernel<1, 1, true, false, true, false, true>",
+                                        TILE_WINO4_G48: "gemm16_grouped_kernel<3>"}[t],
+                             "mfma_flops": 2.0 * 36 * rows * self.cin * self.cout}
         with torch.cuda.device(x.device), prof(name, flops, nbytes, extra):
             rc = self._launch(lib, d, x, residual, gate, out, io)
         _lib.check(rc, "sgv3d_conv2d_forward")
@@ -680,11 +710,16 @@ class PackedConv:
             if not self.wino4_ok(d, gate) or d.split_k > 1:
                 raise _lib.SGV3DError("F(4x4) Winograd covers f32 3x3 / stride 1 / pad 1 layers with cin % 32 == 0, cout % 4 == 0, "
                                       "NHWC output, no gate, no split-K")
-            u = self._wino4_weights()
             host_tile, kp, cp = d.tile, d.k_pad, d.cout_pad
-            d.tile = {TILE_WINO4: 4, TILE_WINO4_WIDE: 3, TILE_WINO4_NARROW: 9, TILE_WINO4_OCC: 4 | 32,
-                      TILE_WINO4_G48: 10}[host_tile]      # SGV3D_TILE_64x64 / 64x128 / 32x128 / 64x64 | OCC5 / 48x64
-            d.k_pad, d.cout_pad = self.wino4_geom
+            if host_tile in WINO4_X3_TILES:
+                u = self._wino4_x3_weights()
+                d.tile = 64 | (host_tile - 50)                     # SGV3D_TILE_X3 | variant
+                d.k_pad, d.cout_pad = self.cin, self.wino4_x3_cout_pad
+            else:
+                u = self._wino4_weights()
+                d.tile = {TILE_WINO4: 4, TILE_WINO4_WIDE: 3, TILE_WINO4_NARROW: 9, TILE_WINO4_OCC: 4 | 32,
+                          TILE_WINO4_G48: 10}[host_tile]      # SGV3D_TILE_64x64 / 64x128 / 32x128 / 64x64 | OCC5 / 48x64
+                d.k_pad, d.cout_pad = self.wino4_geom
             try:
                 nws4 = lib.sgv3d_conv2d_winograd4_workspace_bytes(ctypes.byref(d))
                 ws4 = torch.empty(nws4, dtype=torch.uint8, device=x.device)
@@ -773,6 +808,8 @@ class PackedConv:
         if self.wino4_ok(d, gate):            # (also the dilated 3x3 layers, which the F(2x2) kernels do not cover)
             tiles += ((TILE_WINO4, TILE_WINO4_WIDE) + ((TILE_WINO4_NARROW,) if self.cin >= 128 else ()) + ((TILE_WINO4_OCC,) if OCC5 else ())
                       + ((TILE_WINO4_G48,) if WINO4_G48 and self.k_order == 1 else ()))
+            if WINO4_X3 and not MFMA_F32X3:
+                tiles += self._x3_tiles(d)
         if self.f4res_ok(d, gate, io):
             tiles += (TILE_F4RES,)
         if self._patch_eligible(d, gate):
@@ -822,6 +859,18 @@ class PackedConv:
                 splits = [1] + [s for s in (2, 3, 4, 6, 8) if nk // s >= 4 and wgs < 2048 and wgs * s <= 6144]
             cands.append((t, tuple(splits)))
         return cands
+
+    def _x3_tiles(self, d):
+        """The shapes of the f32x3 position GEMM worth timing for this layer: m-tiles that waste at most 10 % of the rows as padding
+        (the smallest waste always), 160 columns only where they cover cout with fewer idle columns than 128 do."""
+        dil = max(1, int(d.dil))
+        tiles = d.batch * dil * dil * -(-(-(-d.out_h // dil)) // 4) * -(-(-(-d.out_w // dil)) // 4)
+        waste = {r: (-(-tiles // r) * r - tiles) / tiles for r in (48, 64, 96, 112, 128)}
+        best = min(waste.values())
+        ms = [i for i, r in enumerate((48, 64, 96, 112, 128)) if waste[r] <= max(best, 0.10) and (r <= 64 or tiles >= r)]
+        idle = lambda c: -(-self.cout // c) * c - self.cout
+        ws = [0] + ([5] if idle(160) < idle(128) else [])
+        return tuple(50 + w + m for w in ws for m in ms)
 
     def _db_choice(self, sig, d, x, gate, gemm_m, gemm_n, nkt, fixed_tile, fixed_split, io=0):
         """The tune-DB entry of ``sig`` if it is one of the candidates this layer would be measured with right now, else None
@@ -940,7 +989,7 @@ def switch_state():
     g = globals()
     return tuple(g.get(k) for k in ("AUTOTUNE", "SPLIT_K", "WINOGRAD", "FUSED_HEAD", "HEAD_PATH", "MFMA_BF16", "BF16_ACTIVATIONS",
                                     "MFMA_F32X3", "MFIRST", "WINO4", "WINO_HALF", "PATCH_BF16", "DW_BF16", "DW_DEEP", "DW_NARROW",
-                                    "DW_SPLIT_K", "DW_DEEP_MAX_WGS", "PAIR_BF16", "TUNE_STREAMS", "PARALLEL_BRANCHES", "F4RES", "OCC5", "WINO4_G48", "DCN_FUSED"))
+                                    "DW_SPLIT_K", "DW_DEEP_MAX_WGS", "PAIR_BF16", "TUNE_STREAMS", "PARALLEL_BRANCHES", "F4RES", "OCC5", "WINO4_G48", "DCN_FUSED", "WINO4_X3"))
 
 
 def conv_pair_eligible(a, b, x, residual=None):

@@ -125,8 +125,16 @@ def _double_sd(model):
     return sd, names
 
 
-def _compare_grads(model, sd, names, min_tensors, bar=5e-2):
+def _compare_grads(model, sd, names, min_tensors, bar=5e-2, yard=None):
+    """``yard``: {name: gradient} of the SAME oracle evaluated in float32 by torch on the CPU.  Where plain f32 arithmetic itself is
+    further than ``bar`` from the float64 gradients on this ill-conditioned batch-2 problem, the bar is what f32 achieves: the HIP
+    path has to be at least as close to float64 as that (its worst tensor against the f32 oracle's worst tensor)."""
     grads = {n: p.grad.detach().cpu().double() for n, p in model.named_parameters() if p.grad is not None}
+    if yard is not None:
+        ys = [float((yard[n].double() - sd[n].grad).norm() / (sd[n].grad.norm() + 1e-12)) for n in names
+              if sd[n].grad is not None and yard.get(n) is not None and float(sd[n].grad.norm()) > 1e-7]
+        print(f'float32 oracle against float64: worst {max(ys):.1e}, median {sorted(ys)[len(ys) // 2]:.1e}')
+        bar = max(bar, max(ys))
     worst = []
     for n in names:
         want = sd[n].grad
@@ -182,8 +190,17 @@ def test_bsm_training_forward_backward_matches_oracle():
             got, want = preds[t][0][k].detach().cpu().double(), rpreds[t][0][k].detach()
             assert float((got - want).abs().max()) <= 2e-3 * max(1.0, float(want.abs().max())), (t, k)
     assert abs(float(sem_loss) - float(rsem)) <= 1e-3 * abs(float(rsem))
-    _compare_grads(model, sd, names, 400)
-    assert float(model.backbone.img_backbone.conv1.weight.grad.abs().max()) > 0
+    # the yardstick: the same forward / backward through the oracle in float32
+    sd32 = {k: (v.detach().cpu().float() if v.dtype.is_floating_point else v.detach().cpu()) for k, v in model.state_dict().items()}
+    for n in names:
+        sd32[n].requires_grad_(True)
+    p32, i32 = O.bevheight_train_forward(sd32, bconf, hconf, imgs.cpu(), {k: v.cpu() for k, v in mats.items()}, True)
+    t32 = tuple([x.cpu() for x in part] for part in targets)
+    (_oracle_loss(p32, t32, head_cfg['code_weights']) + R.semantic_loss(i32, gt_sem, 8) * 500).backward()
+    _compare_grads(model, sd, names, 400, yard={n: sd32[n].grad for n in names})
+    # frozen_stages=0 (exps/sgv3d/bsm_bev_height_lss_r101_864_1536_256x256.py:57): the stem is constant, the first stage trains
+    assert model.backbone.img_backbone.conv1.weight.grad is None
+    assert float(model.backbone.img_backbone.layer1[0].conv1.weight.grad.abs().max()) > 0
 
 
 def test_lss_is_train_height_returns_the_assist_features():

@@ -313,7 +313,7 @@ WINO4_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", WINO4_SHAPES)
-@pytest.mark.parametrize("tile", [9, 10, 15, 46, 47])  # hip_ops.TILE_WINO4 (64x64 GEMM tile), _WIDE (64x128), _NARROW (32x128), _OCC (64x64, five per CU), _G48 (16x16x4 MFMA, 48x64)
+@pytest.mark.parametrize("tile", [9, 10, 15, 46, 47] + list(range(50, 60)))  # hip_ops.TILE_WINO4 (64x64 GEMM tile), _WIDE (64x128), _NARROW (32x128), _OCC (64x64, five per CU), _G48 (16x16x4 MFMA, 48x64); 50-59: the f32x3 position GEMM (bf16 matrix cores, 48 / 64 / 96 / 112 / 128 rows x 128 / 160 columns)
 def test_winograd_f4x4_matches_conv2d(shape, tile):
     """csrc/conv_wino4.hip: input transform -> grouped GEMM over the 36 positions -> output transform, with folded BN,
     residual, ReLU and a concat offset, against a float64 convolution.  fp32 bound: 1e-4 of the output scale (measured ~1e-5:
@@ -355,8 +355,9 @@ def test_winograd_f4x4_rejects_what_it_does_not_cover():
         conv(x.cuda(), tile=9, split_k=2)                            # no split-K
 
 
+@pytest.mark.parametrize("tile", [9, 51, 53])
 @pytest.mark.parametrize("dil,H,W", [(6, 54, 96), (12, 54, 96), (18, 54, 96), (2, 19, 23), (3, 20, 20)])
-def test_winograd_f4x4_dilated(dil, H, W):
+def test_winograd_f4x4_dilated(dil, H, W, tile):
     """Dilated 3x3 (pad == dilation: the ASPP branches): dil x dil independent sub-grid convolutions through the same three
     launches, tiles of 4x4 outputs spaced `dil` apart; sub-grids of different sizes (54 = 4 * 12 + 6), ragged tiles."""
     from sgv3d_amd.hip_ops import PackedConv
@@ -368,7 +369,7 @@ def test_winograd_f4x4_dilated(dil, H, W):
     conv = PackedConv(w.cuda(), pad=dil, dil=dil, scale=scale.cuda(), shift=shift.cuda(), relu=True)
     assert conv.wino4_ok() and conv.w_wino is None
     out = torch.full((1, H, W, cout + 64), -3.0, device="cuda")
-    conv(x.cuda(), out, y_coff=32, tile=9, split_k=1)
+    conv(x.cuda(), out, y_coff=32, tile=tile, split_k=1)
     ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=dil, dilation=dil).permute(0, 2, 3, 1)
     ref = (ref * scale.double() + shift.double()).clamp_min(0)
     err = (out[..., 32:cout + 32].cpu().double() - ref).abs().max().item()
@@ -379,7 +380,7 @@ def test_winograd_f4x4_dilated(dil, H, W):
     assert (direct - out[..., 32:cout + 32]).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("tile", [9, 10])
+@pytest.mark.parametrize("tile", [9, 10, 52, 58])
 def test_winograd_f4x4_group_planes_in_channel_chunks(tile):
     """The CenterHead first layers as one convolution (64 -> 36 x 64) with the hidden maps as [branch][B][H][W][64] planes:
     F(4x4) runs the GEMM + output transform in chunks of output channels (M of a pass stays below ~160 MB), the input
@@ -399,3 +400,46 @@ def test_winograd_f4x4_group_planes_in_channel_chunks(tile):
     assert err < 1e-4 * max(1.0, ref.abs().max().item()), err
     direct = conv(x.cuda(), group_planes=64, tile=4, split_k=1)
     assert (direct - hidden).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(1, 512, 54, 96, 512), (1, 160, 64, 64, 160), (2, 128, 17, 33, 160)])
+def test_winograd_f4x4_x3_products_are_f32_products(shape):
+    """The f32x3 position GEMM (csrc/gemm_x3_grouped.hip: every operand split exactly into three bf16 terms by its producer, six
+    partial products accumulated in f32) against the f32-MFMA position GEMM of the same layer, both against float64: the x3 form is
+    as close to float64 as the native one (bar: within 1.5x of its error; measured 0.6-0.9x -- the dropped terms are below one f32
+    rounding of a product), on mixed-magnitude data (activations over four decades) where a bf16-only product would be off by 1e-2."""
+    from sgv3d_amd.hip_ops import PackedConv
+    B, cin, H, W, cout = shape
+    x, w = _mk(B, cin, H, W, cout, seed=14)
+    g = torch.Generator().manual_seed(15)
+    x = x * torch.pow(10.0, torch.randint(-2, 3, (1, 1, 1, cin), generator=g).float())       # per-channel magnitudes 1e-2 .. 1e2
+    conv = PackedConv(w.cuda(), pad=1)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    native = float((conv(x.cuda(), tile=47, split_k=1).cpu().double() - ref).abs().max()) / scale
+    worst = 0.0
+    for tile in [t for t in range(50, 60)]:
+        y = conv(x.cuda(), tile=tile, split_k=1)
+        worst = max(worst, float((y.cpu().double() - ref).abs().max()) / scale)
+    print(f"{shape}: f32 MFMA {native:.2e}, f32x3 worst of ten tile shapes {worst:.2e} of the output scale")
+    assert worst <= 1.5 * native and worst < 1e-4, (worst, native)
+
+
+def test_winograd_f4x4_x3_keeps_every_partial_product():
+    """Inputs in {-1, 0, 1} and weights that are multiples of 576 = 24^2 (G's denominators 4, 6, 24, squared): V is integer, U is
+    integer up to the rounding of 1 / 6 in the packer, every partial sum of a position GEMM stays below 2^24 -- both GEMMs are then
+    accurate to ~1e-7 of the output scale, and a dropped or doubled partial product (a missing lo term is 2^-16 = 1.5e-5 of a
+    product), a swapped plane or a wrong k chunk stands far out of the 2e-6 bar, on every tile shape."""
+    from sgv3d_amd.hip_ops import PackedConv
+    g = torch.Generator().manual_seed(21)
+    B, cin, H, W, cout = 1, 128, 24, 40, 160
+    x = torch.randint(-1, 2, (B, H, W, cin), generator=g).float()
+    w = torch.randint(-1, 2, (cout, cin, 3, 3), generator=g).float() * 576.0
+    conv = PackedConv(w.cuda(), pad=1)
+    want = conv(x.cuda(), tile=47, split_k=1).cpu().double()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    assert float((want - ref).abs().max()) <= 2e-6 * scale
+    for tile in range(50, 60):
+        y = conv(x.cuda(), tile=tile, split_k=1).cpu().double()
+        assert float((y - ref).abs().max()) <= 2e-6 * scale and float((y - want).abs().max()) <= 2e-6 * scale, tile
