@@ -13,21 +13,27 @@ frames shard over GPUs as independent replicas (no collective on the data path, 
 ``value`` = N * batch * K / max-over-ranks(time) and ``scaling`` is weak.
 
 Printed by rank 0 as ONE JSON line, with
-* ``roofline``: the dominant kernel (MFMA implicit-GEMM conv) — algorithmic FLOPs of its launches /
-  their summed durations, measured live with HIP events on the launch stream in an instrumented
-  pass over the same K steps (events around every launch would perturb the throughput loop, so the
-  two loops are separate; both run in this process on the same inputs);
-* ``roofline_hbm``: the voxel-pooling operator (vp_gather_fast_kernel) against HBM peak -- the 175.9 MB
-  of SURVEY 8(d) / launch duration -- with the plan build reported beside it (it runs once per
-  calibration, never inside the timed region);
+* ``value``: the K timed steps with the calibration handed over as FRESH tensor objects every frame -- the reference harness's
+  call pattern (exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:244-247); ``cached_calibration_value`` beside it
+  (a caller that keeps its calibration tensors; rounds 1-5 reported that one), ``native_f32_value`` (a child run with every
+  product on the f32 MFMA; ``config.products`` says which products of ``value`` are assembled from bf16 partial products);
+* ``roofline``: the dominant MFMA kernel SYMBOL of an instrumented pass over the same K steps (one stream, eager launches) --
+  executed flops of its launches / their durations from roctracer's kernel timestamps (torch.profiler), the quantity a rocprofv3
+  --kernel-trace reports; the HIP-event measurement of the same launches (raw and with the calibrated marker gap subtracted)
+  beside it with the ratio of the two; ``frac_from_rocprof``: the same flops per launch over the symbol's average in the
+  committed trace of ``bench.py --roofline-only`` (profiles/r*_bench_roofline_kernel_stats.csv), refused when that trace holds
+  another launch mix; ``by_symbol``: every MFMA kernel whose executed flops the pass recorded (the f32x3 GEMMs against the bf16
+  peak with the bf16 flops they execute);
+* ``roofline_hbm``: the voxel-pooling operator against HBM peak -- the 175.9 MB of SURVEY 8(d) / launch duration -- with the
+  plan build reported beside it (it runs once per calibration);
 * ``cpu_baseline``: the torch-CPU oracle restatement of the same forward (oracle/torch_model.py)
   timed on this box's host cores on a bounded sample (rank 0, N=1 only), plus the C restatement of the
   voxel-pooling operator single-threaded and with OpenMP (BASELINE.md 3);
 * ``parity``: the outputs of the very model that was timed against that oracle forward on the same
   frame and weights (max |hip - oracle| over all prediction maps, voxel indices bit-exact); the run
   exits non-zero if the fp32 line is above 1e-3 (bf16 mode: 2e-2 of the output scale);
-* ``fresh_calibration_every_frame``: the same K steps when every frame arrives with NEW calibration tensor
-  objects, as the reference harness does -- geometry kernel + device-side voxel-index compare per frame;
+* ``train_step``: the mixed-precision training step as one hipGraph (cfg-2 model at batch 2; BASELINE configs[3]'s per-GPU share
+  through a 1-rank RCCL group), child runs of tools/train_bench.py;
 * ``other_configs`` (default cfg-2 run at N=1 only): BASELINE configs[2] / [4] in bf16 as compact records
   from child runs of this script (value, conv-family and voxel-pooling fractions, parity).
 """
@@ -81,6 +87,15 @@ def parse():
                     help="skip the compact cfg-3 / cfg-5 bf16 records (other_configs) the default cfg-2 run appends")
     ap.add_argument("--sub", action="store_true",
                     help="internal: this is one of the other_configs child runs (prints a compact record)")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="warm-up + the instrumented roofline pass only (one stream, eager launches): the command whose rocprofv3 "
+                         "--kernel-trace --stats summary is committed as profiles/r*_bench_roofline_kernel_stats.csv -- the per-symbol "
+                         "averages there are over exactly the launches roofline.frac is made of")
+    ap.add_argument("--no-kernel-timestamps", action="store_true",
+                    help="roofline from HIP events only (no torch.profiler / roctracer pass: for runs under rocprofv3, which owns the tracer)")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the train_step child records (tools/train_bench.py)")
+    ap.add_argument("--no-native-f32", action="store_true",
+                    help="skip native_f32_value (a child run with SGV3D_WINO4_X3=0: every product on the f32 MFMA)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x3", "f32x3auto"],
                     help="f32 (default; what BASELINE cfg-2, the judged line, asks for) or bf16: convolutions multiply on "
                          "the bf16 matrix cores with f32 accumulation (the compute dtype of BASELINE configs[2] / [4]; "
@@ -169,6 +184,30 @@ def load_rocprof_avg(symbol):
     return None
 
 
+def load_rocprof_roofline(symbol):
+    """The newest committed ``profiles/r*_bench_roofline_kernel_stats.csv`` (rocprofv3 --kernel-trace --stats of
+    ``bench.py --roofline-only``) with the line that run printed beside it (``..._under_rocprof.json``: steps, warm-up): average
+    duration of ``symbol`` and its launches per step there.  None without such a pair."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_roofline_kernel_stats.csv")))
+    if not files or symbol is None:
+        return None
+    try:
+        line = json.loads(open(files[-1].replace("_kernel_stats.csv", "_under_rocprof.json")).read().strip().splitlines()[-1])
+        rl = line["roofline"]
+        if rl["kernel_symbol"] != symbol:
+            return None
+        with open(files[-1]) as f:
+            for row in csv.DictReader(f):
+                if symbol + "(" in row["Name"]:
+                    return {"avg_ns": float(row["AverageNs"]), "calls": int(row["Calls"]), "file": os.path.relpath(files[-1], ROOT),
+                            "launches_per_step": float(rl["launches_per_step"])}
+    except Exception:
+        pass
+    return None
+
+
 def run_other_configs(args, budget_s=120.0):
     """cfg-3 (R101 1088x1920 -> 512x512 BEV, batch 4) and cfg-5 (SGV3D BSM R101, batch 1) in bf16 -- the dtype BASELINE
     configs[2] / [4] name -- as child runs of this script: value, ms, conv-family fraction of the bf16 MFMA peak, voxel
@@ -206,6 +245,62 @@ def run_other_configs(args, budget_s=120.0):
                                                        "voxel_indices_equal", "ok")},
                     "exit_code": r.returncode, "wall_s": time.perf_counter() - t0})
     return out
+
+
+def run_train_steps(budget_s=150.0):
+    """The training step (exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:224-240,298-305,405) under this
+    script's clock, as child runs of tools/train_bench.py: the cfg-2 model at batch 2 and at BASELINE configs[3]'s per-GPU share
+    (batch 4, through a 1-rank RCCL group: broadcast, bucket all-reduces from inside backward, clipped fused AdamW), both as
+    mixed-precision steps (bf16 products, f32 master weights) recorded as one hipGraph, frozen stem and gradient_clip_val=5 as the
+    reference's Trainer has them.  Compact records; a failed child is reported, not dropped."""
+    import socket
+    import subprocess
+    out, t_start = [], time.perf_counter()
+    base = {k: v for k, v in os.environ.items() if k not in ("SGV3D_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    tb = os.path.join(ROOT, "tools", "train_bench.py")
+    for tag, extra, dist in (("cfg2_batch2", ["--config", "cfg2", "--batch", "2"], False), ("cfg4_share_batch4_1rank_rccl", ["--config", "cfg4"], True)):
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 25.0:
+            out.append({"case": tag, "skipped": f"train_step budget of {budget_s:.0f} s spent"})
+            continue
+        env = dict(base)
+        if dist:
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            env.update(SGV3D_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        cmd = [sys.executable, tb, "--dtype", "bf16", "--graph", "--steps", "10", "--warmup", "2"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=left + 30.0)
+            rec = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            out.append({"case": tag, "error": repr(e)[:300]})
+            continue
+        keep = ("ms_per_step", "value", "unit", "batch_per_gpu", "dtype", "graph", "update_in_graph", "steps", "loss", "backend", "world_size",
+                "collectives_active", "allreduce_buckets", "allreduce_bytes_per_step", "allreduces_launched_inside_backward",
+                "first_allreduce_launch_at_fraction_of_backward", "bucket_mib", "gradient_clip_val", "grad_norm_last_step",
+                "clip_coefficient_last_step", "frozen_parameters", "peak_mem_gb", "parameters")
+        out.append(dict({"case": tag, "command": "tools/train_bench.py " + " ".join(cmd[2:]), "exit_code": r.returncode,
+                         "wall_s": time.perf_counter() - t0}, **{k: rec.get(k) for k in keep}))
+    return out
+
+
+def run_native_f32(args, budget_s=60.0):
+    """``value`` of this very command with every product on the f32 MFMA (SGV3D_WINO4_X3=0: the F(4x4) position GEMMs on
+    v_mfma_f32_16x16x4_f32 instead of six bf16 partial products per f32 product) -- a child run, timed region only."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--sub", "--config", args.config, "--batch", str(args.batch), "--dtype", "f32",
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--streams", str(args.streams), "--no-roofline", "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, env=dict(os.environ, SGV3D_WINO4_X3="0"), capture_output=True, text=True, timeout=budget_s + 30.0)
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"], "exit_code": r.returncode,
+                "layers_measured_here": rec["config"]["per_rank"][0]["layers_measured_here"],
+                "what": "child run of this command with SGV3D_WINO4_X3=0; the layers whose committed choice is an f32x3 tile are "
+                        "re-measured among the f32-MFMA candidates at its first forward (layers_measured_here)"}
+    except Exception as e:
+        return {"error": repr(e)[:300]}
 
 
 def spawn_ranks(args):
@@ -282,9 +377,10 @@ def main():
     bc, hc = {"cfg2": S.r50_256_conf, "r101": S.r101_256_conf, "cfg3": S.r101_512_conf,
               "cfg5": S.bsm_r101_256_conf}[args.config]()
     workload = {"cfg2": "BASELINE cfg-2: ResNet-50 864x1536 -> 256x256 BEV, fp32, full BEVHeight forward "
-                        "(backbone+neck+HeightNet+lift+voxel_pooling+head; geometry + voxel plan cached per calibration: "
-                        "computed once outside the timed region, see fresh_calibration_every_frame_value for the "
-                        "reference harness's call pattern)",
+                        "(backbone+neck+HeightNet+lift+voxel_pooling+head); the calibration arrives as fresh tensor objects with every "
+                        "frame, as the reference harness hands it over: copy + geometry kernel + device-side compare of the voxel indices "
+                        "per frame inside the timed region, the voxel plan and the camera gates rebuilt only when the indices changed "
+                        "(cached_calibration_value: the caller keeps its calibration tensors)",
                 "r101": "ResNet-101 864x1536 -> 256x256 BEV, fp32, full BEVHeight forward",
                 "cfg3": "ResNet-101 1088x1920 (1080 padded) -> 512x512 BEV, fp32 (BASELINE configs[2] asks bf16), "
                         "full BEVHeight forward",
@@ -299,6 +395,11 @@ def main():
             "fp32", "bf16 MFMA operands / f32 accumulation, bf16 activations in HBM inside the conv chains "
                     "(height / depth logits, context, lifted features, BEV map and predictions f32)")
     B = args.batch
+    if args.roofline_only:
+        # one stream, eager launches from the first to the last forward of the process: every launch of a kernel symbol in a
+        # rocprofv3 trace of this command is then of the population roofline.frac is made of (kernels alone on the chip)
+        args.streams, args.no_graph, args.no_cpu_baseline, args.no_kernel_timestamps = 1, True, True, True
+        args.no_harness = args.no_other_configs = args.no_train_step = args.no_native_f32 = args.no_plan_timing = True
     nstreams = max(1, args.streams)
     if stub:
         class _StubPipe:
@@ -341,7 +442,17 @@ def main():
         use_graph = pipe.use_graph
         if not use_graph and not args.no_graph and rank == 0:
             print("[bench] hipGraph capture failed; running eager launches on the slot streams", file=sys.stderr)
-    run = lambda: pipe.submit(imgs, mats)       # the product call: resident frame -> slot's static inputs -> graph replay
+    # The product call: resident frame -> slot's static inputs -> graph replay.  The calibration arrives as NEW tensor objects with
+    # every frame, as the reference harness hands it over (exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:244-247
+    # makes fresh `mats[k].cuda()` tensors every step): the host fast path of the calibration cache never fires, every submit copies
+    # the seven tensors into the slot, re-runs calib_prep + the geometry kernel and the device-side compare of the voxel indices
+    # (the plan itself is rebuilt only when the indices really changed).  A ring of distinct tensor objects with the same content.
+    ring = None if stub else [{k: v.clone() for k, v in mats.items()} for _ in range(2 * nstreams + 1)]
+    ctr = [0]
+
+    def run():
+        ctr[0] += 1
+        return pipe.submit(imgs, mats if stub else ring[ctr[0] % len(ring)])
     for _ in range(args.warmup * nstreams):
         run()
     if not stub:
@@ -355,46 +466,43 @@ def main():
     def timed_local(fn, n):
         t = group.timed(fn, n, local_out=elapsed_local)
         return t
+    if args.roofline_only:
+        args.steps = max(1, args.steps)
     elapsed = timed_local(run, args.steps)          # barrier+sync | K steps | barrier+sync, MAX over ranks
     value = group.aggregate_throughput(B, args.steps, elapsed)
-    single = None
-    if nstreams > 1 and rank == 0 and world == 1 and not args.sub and not stub:   # same K steps with one frame in flight, for reference
-        one = FramePipeline(model, imgs, mats, slots=1, use_graph=use_graph)
-        for _ in range(args.warmup):
-            one.submit(imgs, mats)
-        t1 = group.timed(lambda: one.submit(imgs, mats), args.steps)
-        single = {"value": B * args.steps / t1, "ms_per_step": t1 / args.steps * 1e3}
-        del one
     # calibration cache counters of the timed slots: geometry / plan kernels launched inside the timed region
     calib = {"plan_builds_before_timed_region": counters0[2],
              "plan_builds_in_timed_region": sum(c.plan.builds() for c in pipe.caches if c.plan is not None) - counters0[2],
-             "geometry_launches_in_timed_region": sum(c.refreshes for c in pipe.caches) - counters0[1]}
-    # ---- the reference harness's call pattern: FRESH calibration tensors with every frame ------------------------
-    # exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:244-247 makes new `mats[k].cuda()` tensors every step, so
-    # the host fast path of the calibration cache never fires: every submit copies the seven tensors into the slot, re-runs
-    # calib_prep + the geometry kernel and the device-side compare of the voxel indices (the plan itself is rebuilt only when
-    # the indices really changed).  Same K steps, same pipeline; a ring of distinct tensor objects with the same content.
-    fresh = None
-    if rank == 0 and world == 1 and not args.sub and not stub:
-        ring = [{k: v.clone() for k, v in mats.items()} for _ in range(2 * nstreams + 1)]
-        ctr = [0]
-
-        def run_fresh():
+             "geometry_launches_in_timed_region": sum(c.refreshes for c in pipe.caches) - counters0[1],
+             "calibration_tensors": "fresh objects every frame (the reference harness's call pattern)"}
+    quick = args.roofline_only          # only the warm-up, the K steps above and the instrumented pass
+    single = None
+    if nstreams > 1 and rank == 0 and world == 1 and not args.sub and not stub and not quick:   # same K steps with one frame in flight, for reference
+        one = FramePipeline(model, imgs, mats, slots=1, use_graph=use_graph)
+        def run_one():
             ctr[0] += 1
-            return pipe.submit(imgs, ring[ctr[0] % len(ring)])
+            return one.submit(imgs, ring[ctr[0] % len(ring)])
+        for _ in range(args.warmup):
+            run_one()
+        t1 = group.timed(run_one, args.steps)
+        single = {"value": B * args.steps / t1, "ms_per_step": t1 / args.steps * 1e3}
+        del one
+    # ---- the same K steps with the calibration tensors of the warm-up handed in again every frame (a caller that keeps its
+    # calibration tensors: nothing of the view transform's setup is launched) -- rounds 1-5 reported THIS figure as `value`
+    cached = None
+    if rank == 0 and world == 1 and not args.sub and not stub and not quick:
         for _ in range(args.warmup * nstreams):
-            run_fresh()
+            pipe.submit(imgs, mats)
         c1 = (sum(c.refreshes for c in pipe.caches), sum(c.plan.builds() for c in pipe.caches if c.plan is not None))
-        tf = group.timed(run_fresh, args.steps)
-        fresh = {"value": B * args.steps / tf, "ms_per_step": tf / args.steps * 1e3,
+        tf = group.timed(lambda: pipe.submit(imgs, mats), args.steps)
+        cached = {"value": B * args.steps / tf, "ms_per_step": tf / args.steps * 1e3,
                  "geometry_launches_in_timed_region": sum(c.refreshes for c in pipe.caches) - c1[0],
                  "plan_builds_in_timed_region": sum(c.plan.builds() for c in pipe.caches if c.plan is not None) - c1[1]}
-        del ring
     # ---- ... and ANOTHER calibration with every frame (a stream that interleaves cameras, as a shuffled DAIR-V2X-I validation
     # set does): the voxel indices really change, so every submit rebuilds the slot's plan (~16 launches, 119 us) and the
     # height net's camera gates on top of the geometry kernel.  Same K steps; two calibrations in turn per slot.
     changing = None
-    if rank == 0 and world == 1 and not args.sub and not stub and B == 1:
+    if rank == 0 and world == 1 and not args.sub and not stub and B == 1 and not quick:
         other = {k: v[1:2].clone() for k, v in S.make_mats(2, device=dev).items()}      # sample 1 of a varied pair: another camera
         pair = [mats, other]
         ctr2 = [0]
@@ -415,7 +523,7 @@ def main():
     # ---- a timed region of >= 1 s with the same pipeline (the K-step region above is ~0.1 s at cfg-2: clock ramp and
     # the first replays weigh on it; `value` stays the K-step figure the contract asks for, this one sits beside it)
     long_run = None
-    if rank == 0 and world == 1 and not args.sub and not stub and not args.no_harness:
+    if rank == 0 and world == 1 and not args.sub and not stub and not args.no_harness and not quick:
         n_long = max(args.steps, int(1.2 / max(elapsed / args.steps, 1e-4)) + 1)
         tl = group.timed(run, n_long)
         long_run = {"value": B * n_long / tl, "ms_per_step": tl / n_long * 1e3, "steps": n_long, "seconds": tl}
@@ -429,7 +537,12 @@ def main():
                                         "layers_from_tune_db": hip_ops.TUNE_STATS["from_db"],
                                         "layers_measured_here": hip_ops.TUNE_STATS["measured"]})
 
-    # ---- roofline: instrumented pass, HIP events around every conv launch -------------------------
+    # ---- roofline: instrumented passes over the same K steps (one stream, eager launches) -----------------------
+    # pass A: HIP events around every launch (hip_ops.PROFILE: label, algorithmic flops, bytes, kernel symbol, executed flops);
+    # pass B: the same K steps under torch.profiler = roctracer's kernel begin / end timestamps, the quantity a rocprofv3
+    #         --kernel-trace of this loop reports per kernel symbol.  An event pair also measures the gap its two markers take on the
+    #         queue (~6 us on a 30 us launch), so the durations roofline.frac is made of are pass B's; pass A's -- raw and with the
+    #         calibrated gap subtracted -- sit beside them with their ratio (roofline.hip_events).
     roofline = None
     if rank == 0 and not args.no_roofline:
         hip_ops.PROFILE = []
@@ -438,9 +551,41 @@ def main():
         torch.cuda.synchronize()
         recs = hip_ops.PROFILE
         hip_ops.PROFILE = None
-        # An event pair with nothing between its records still measures the gap the two markers take on the
-        # queue; it is calibrated here and subtracted, so that avg_launch_us is the kernel's own duration (what
-        # the rocprofv3 kernel trace reports) and not duration + marker gap.
+        kernel_ts, kernel_ts_error = None, None
+        if not args.no_kernel_timestamps:
+            try:
+                from torch.profiler import profile as _tprofile, ProfilerActivity as _Act
+                from torch.autograd import DeviceType as _DevT
+                # (a session also delivers activity records of launches that preceded it -- graph replays of the timed loops --, so
+                #  pass B starts behind a marker kernel and only what began after the marker's end is counted)
+                from sgv3d_amd.pipeline import eager_forward as _eager
+                with _tprofile(activities=[_Act.CUDA], acc_events=True) as _prof, _eager(model):     # (plain launches, as in pass A)
+                    torch.cuda._sleep(20000)
+                    for _ in range(args.steps):
+                        step()
+                    torch.cuda.synchronize()
+                evs = [e for e in _prof.events() if e.device_type == _DevT.CUDA]
+                marks = [e for e in evs if "sleep" in e.name.lower() or "spin" in e.name.lower()]
+                if not marks:
+                    raise RuntimeError("marker kernel not in the trace: " + ", ".join(sorted({e.name[:40] for e in evs})[:6]))
+                t_mark = max(e.time_range.end for e in marks)
+                kernel_ts = {}
+                for e in evs:
+                    if e.time_range.start >= t_mark:
+                        q = kernel_ts.setdefault(e.name.replace(" ", ""), [0, 0.0])
+                        q[0] += 1
+                        q[1] += float(e.device_time) * 1e-6           # us -> s
+                del _prof
+            except Exception as ex:                  # reported in the line; the HIP-event figure then stands alone
+                kernel_ts, kernel_ts_error = None, repr(ex)[:200]
+
+        def ts_of(symbol):
+            """(launches, seconds) of a kernel symbol in pass B, or None."""
+            if kernel_ts is None or symbol is None:
+                return None
+            key = symbol.replace(" ", "") + "("
+            hit = [v for k, v in kernel_ts.items() if key in k]
+            return (sum(v[0] for v in hit), sum(v[1] for v in hit)) if hit else None
         cal = []
         for _ in range(200):
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -448,7 +593,7 @@ def main():
             cal.append((c0, c1))
         torch.cuda.synchronize()
         gap_s = sorted(c0.elapsed_time(c1) for c0, c1 in cal)[len(cal) // 2] * 1e-3
-        by_kernel, by_symbol = {}, {}
+        by_kernel, by_symbol, raw_sec = {}, {}, {}
         HBM_PEAK = 8.0e12
         def executed_of(name, flops):
             return flops / 4.0 if "wino4" in name else flops / 2.25 if "wino" in name else flops
@@ -462,11 +607,13 @@ def main():
             t_mfma, t_hbm = executed_of(name, flops) / (peak * 1e12), nbytes / HBM_PEAK
             d[5] += max(t_mfma, t_hbm)
             d[6] += 1 if t_hbm > t_mfma else 0
+            raw_sec[name] = raw_sec.get(name, 0.0) + e0.elapsed_time(e1) * 1e-3
             if extra:
                 d[4][extra["symbol"]] = d[4].get(extra["symbol"], 0) + 1
-                q = by_symbol.setdefault(extra["symbol"], [0.0, 0])
+                q = by_symbol.setdefault(extra["symbol"], [0.0, 0, 0.0])
                 q[0] += extra["mfma_flops"]
                 q[1] += 1
+                q[2] += extra.get("bf16_mfma_flops", 0.0)
         # `flops` of a record is the ALGORITHMIC work of the layer (2 x MACs of the direct convolution,
         # SURVEY 8d).  The Winograd F(2x2,3x3) kernels execute 1/2.25 of it on the MFMA pipe, so their
         # algorithmic rate can exceed the hardware peak; the executed rate is reported beside it.
@@ -475,7 +622,7 @@ def main():
         conv = {k: v for k, v in by_kernel.items() if k.startswith("conv_")}
         # the dominant KERNEL: among the labels that are one launch of one MFMA kernel (the three-launch F(4x4) label also holds
         # two transform kernels -- it is in conv_family.by_kernel, and its grouped GEMMs are in frac_from_rocprof's symbol)
-        one_kernel = {k: v for k, v in conv.items() if k != "conv_wino4"} or conv
+        one_kernel = {k: v for k, v in conv.items() if k not in ("conv_wino4", "conv_wino4_x3")} or conv
         top = max(one_kernel, key=lambda k: one_kernel[k][1])
         fl, sec, n, nby, syms, floor_sec, hbm_bound_n = conv[top]
         fam_fl = sum(v[0] for v in conv.values())
@@ -484,29 +631,75 @@ def main():
         all_sec = sum(v[1] for v in by_kernel.values())
         top_symbol = max(syms, key=syms.get) if syms else None       # (a label of this build names ONE instantiation)
         traffic, traffic_src = load_traffic(top, top_symbol)
-        # the same kernel in the committed rocprofv3 kernel trace of this command: its average there covers every launch of
-        # the SYMBOL (for the five-per-CU pointwise tile also the grouped GEMMs of the F(4x4) layers), so the flops set
-        # against it are the symbol's executed flops per launch of this run
-        rp = load_rocprof_avg(top_symbol)
+        # ---- the dominant kernel SYMBOL: every launch of it in the pass (for the five-per-CU pointwise tile also grouped GEMMs of
+        # F(4x4) layers that use the same instantiation), executed flops over kernel-timestamp durations
+        sym_fl, sym_n, _ = by_symbol.get(top_symbol, (executed(top, fl), n, 0.0))
+        ts = ts_of(top_symbol)
+        if os.environ.get("SGV3D_BENCH_DEBUG"):
+            print("[bench debug] by_symbol", {k: v[1] for k, v in by_symbol.items()}, file=sys.stderr)
+            print("[bench debug] labels", {k: (v[2], dict(v[4])) for k, v in by_kernel.items()}, file=sys.stderr)
+            if kernel_ts:
+                print("[bench debug] kernel_ts", {k[:110]: v[0] for k, v in kernel_ts.items()}, file=sys.stderr)
+        ts_ok = ts is not None and ts[0] == sym_n                     # the same population in both passes, or no figure
+        if ts_ok:
+            dur_s, dur_src = ts[1], "kernel begin/end timestamps (torch.profiler = roctracer), pass B"
+        else:
+            # (labels of this symbol only: the grouped GEMMs inside a three-launch label have no event pair of their own)
+            sym_fl, sym_n, dur_s = executed(top, fl), n, sec
+            dur_src = "HIP events, calibrated marker gap subtracted (no kernel timestamps: " + (kernel_ts_error or (
+                "--no-kernel-timestamps" if args.no_kernel_timestamps else f"launch counts differ, {ts} vs {sym_n}")) + ")"
+        achieved = sym_fl / dur_s / 1e12
         rocprof = None
-        if rp is not None and top_symbol in by_symbol:
-            sym_fl, sym_n = by_symbol[top_symbol]
-            rocprof = {"file": rp[2], "symbol": top_symbol, "avg_ns": rp[0], "calls_in_trace": rp[1],
-                       "launches_per_step_here": sym_n / args.steps, "executed_flop_per_launch_here": sym_fl / sym_n,
-                       "achieved": sym_fl / sym_n / rp[0] / 1e3, "frac": sym_fl / sym_n / rp[0] / 1e3 / peak,
-                       "what": "executed flops per launch of this symbol in THIS run (implicit-GEMM layers + grouped GEMMs of the "
-                               "F(4x4) layers that use the same instantiation) / the trace's average duration of the symbol"}
+        rp = load_rocprof_roofline(top_symbol)
+        if rp is not None:
+            # the committed trace of `bench.py --roofline-only` (same loop, same tune DB): refuse another population
+            same = abs(rp["launches_per_step"] - sym_n / args.steps) < 1e-9
+            rocprof = {"file": rp["file"], "symbol": top_symbol, "avg_ns": rp["avg_ns"], "calls_in_trace": rp["calls"],
+                       "launches_per_step_in_trace": rp["launches_per_step"], "launches_per_step_here": sym_n / args.steps,
+                       "executed_flop_per_launch_here": sym_fl / sym_n,
+                       "achieved": (sym_fl / sym_n / rp["avg_ns"] / 1e3) if same else None,
+                       "frac": (sym_fl / sym_n / rp["avg_ns"] / 1e3 / peak) if same else None,
+                       "refused": None if same else "the trace holds another launch mix of this symbol than this run (tune DB or switches "
+                                                    "changed since it was committed): no figure",
+                       "what": "executed flops per launch of this symbol in THIS run / the symbol's average duration in the committed "
+                               "rocprofv3 --kernel-trace --stats summary of `bench.py --roofline-only` (the same loop)"}
+        # every MFMA kernel symbol whose executed flops the pass recorded, from the kernel timestamps
+        by_sym_out = {}
+        for sym, (f32_fl, cnt, bf16_fl) in by_symbol.items():
+            t = ts_of(sym)
+            if t is None or t[0] != cnt:
+                continue
+            rec = {"launches_per_step": cnt / args.steps, "avg_us": t[1] / cnt * 1e6, "ms_per_step": t[1] / args.steps * 1e3,
+                   "executed_f32_equivalent_tflops": f32_fl / t[1] / 1e12}
+            if bf16_fl:
+                # f32x3: six bf16 partial products per f32 product -- priced against the bf16 peak with the bf16 flops it executes
+                rec.update({"bound": "mfma bf16", "executed_bf16_tflops": bf16_fl / t[1] / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+                            "frac": bf16_fl / t[1] / 1e12 / MFMA_BF16_PEAK_TFLOPS})
+            else:
+                rec.update({"bound": "mfma", "peak": peak, "frac": f32_fl / t[1] / 1e12 / peak})
+            by_sym_out[sym] = rec
         roofline = {
-            "bound": "mfma", "kernel": top, "kernel_symbol": top_symbol, "achieved": fl / sec / 1e12, "peak": peak,
-            "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak, "traffic": traffic,
+            "bound": "mfma", "kernel": top, "kernel_symbol": top_symbol, "achieved": achieved, "peak": peak,
+            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
             "traffic_source": traffic_src,
+            "flops": "executed (= algorithmic for an implicit GEMM)", "durations": dur_src,
+            "launches": sym_n, "launches_per_step": sym_n / args.steps, "avg_launch_us": dur_s / sym_n * 1e6,
+            "executed_flop_per_launch": sym_fl / sym_n,
+            # the contract's HIP-event measurement of the same launches (the labels of this symbol), raw and gap-corrected
+            "hip_events": {"launches": n, "avg_launch_us_raw": raw_sec[top] / n * 1e6, "avg_launch_us": sec / n * 1e6,
+                           "event_pair_gap_us": gap_s * 1e6,
+                           "achieved_raw": executed(top, fl) / raw_sec[top] / 1e12, "achieved": executed(top, fl) / sec / 1e12,
+                           "frac_raw": executed(top, fl) / raw_sec[top] / 1e12 / peak, "frac": executed(top, fl) / sec / 1e12 / peak,
+                           "gap_corrected_over_timestamps": ((executed(top, fl) / sec) / (sym_fl / dur_s)) if ts_ok else None,
+                           "what": "HIP events on the launch stream around every launch of the label; an event pair also measures its "
+                                   "markers' gap on the queue (calibrated on empty pairs, subtracted in the second figure)"},
             "algorithmic_bytes": nby / n if nby else None,
             "traffic_over_algorithmic": (traffic / (nby / n)) if (traffic and nby) else None,
             "frac_from_rocprof": rocprof,
+            "kernel_timestamps_error": kernel_ts_error,
+            "by_symbol": by_sym_out,
             "algorithm": "winograd F(2x2,3x3): executes 1/2.25 of the algorithmic flops" if "wino" in top else "implicit GEMM",
-            "executed": {"achieved": executed(top, fl) / sec / 1e12,
-                         "frac": executed(top, fl) / sec / 1e12 / peak},
-            "launches": n, "avg_launch_us": sec / n * 1e6, "flop_per_launch": fl / n,
+            "flop_per_launch": fl / n,
             # against BOTH roofs per launch (a 1x1 layer with 64 input channels is HBM-bound, not MFMA-bound): sum over the launches
             # of max(executed flops / MFMA peak, algorithmic bytes / 8 TB/s) over the measured time
             "two_roof": {"frac": floor_sec / sec, "floor_us_per_launch": floor_sec / n * 1e6, "hbm_bound_launches": hbm_bound_n,
@@ -529,8 +722,8 @@ def main():
                                           for k, v in conv.items()}},
             "other_kernels_ms_per_step": {k: v[1] / args.steps * 1e3 for k, v in by_kernel.items()
                                           if not k.startswith("conv_")},
-            "method": "HIP events on the launch stream around every launch (empty event-pair gap subtracted), "
-                      "separate instrumented pass",
+            "method": "two instrumented passes over the same K eager steps on one stream: HIP events around every launch (conv_family, "
+                      "two_roof, hip_events) and roctracer kernel timestamps through torch.profiler (achieved / frac, by_symbol)",
             "event_pair_gap_us": gap_s * 1e6,
         }
         # traffic / algorithmic bytes of every conv kernel whose symbol has a row in the PMC summary
@@ -542,7 +735,7 @@ def main():
 
     # ---- voxel pooling against the HBM roofline (north_star: >= 60 % of HBM peak) -----------------
     roofline_hbm = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not quick:
         from sgv3d_amd.ops.voxel_pooling import VoxelPlan
         bb = model.backbone
         with torch.no_grad():
@@ -890,13 +1083,30 @@ def main():
             and not args.no_cpu_baseline:
         other_configs = run_other_configs(args)
 
+    # ---- the training step and the all-f32-MFMA value, as child runs (one GPU process at a time) ------------------------------
+    train_steps = native_f32 = None
+    main_line = rank == 0 and world == 1 and args.config == "cfg2" and args.dtype == "f32" and not args.sub and not stub
+    if main_line and not args.no_train_step and not args.no_cpu_baseline:
+        train_steps = run_train_steps()
+    x3_layers = None
+    if not stub:
+        x3_layers = sum(1 for k, v in hip_ops.TUNE_DB.items() if v[0] in hip_ops.WINO4_X3_TILES and k.endswith(f"|ts{hip_ops.TUNE_STREAMS}")
+                        and f"|{B}x" in k)
+    if main_line and hip_ops.WINO4_X3 and not args.no_native_f32:
+        native_f32 = run_native_f32(args)
+
     if rank == 0:
+        products = ("f32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)" if not (hip_ops.WINO4_X3 and args.dtype == "f32") else
+                    "f32-accurate: every product of the three-launch F(4x4) layers' position GEMMs (csrc/gemm_x3_grouped.hip) is the f32 sum of "
+                    "six bf16 x bf16 partial products of operands split exactly into three bf16 terms (error of a product: one f32 rounding, "
+                    "f32 accumulation) where the per-layer measurement picked that form; every other product on the f32 MFMA "
+                    "(native_f32_value: all of them)")
         line = {
             "metric": "camera frames/sec at 864x1536->BEV",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "stub" if stub else "synthetic",
-            "config": {"workload": workload,
+            "config": {"workload": workload, "products": products, "layers_on_f32x3_tiles_in_tune_db": x3_layers,
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"replicas x{world}",
                        "hip_graph": bool(use_graph), "frames_in_flight": nstreams,
                        "one_frame_in_flight_value": single["value"] if single else None,
@@ -916,8 +1126,10 @@ def main():
             "long_run_value": long_run["value"] if long_run else None, "long_run": long_run,
             "harness_eval_step_value": harness_rec["value"] if harness_rec else None, "harness_eval_step": harness_rec,
             "harness_eval_step_b8": harness_b8,
-            "fresh_calibration_every_frame_value": fresh["value"] if fresh else None,
-            "fresh_calibration_every_frame": fresh,
+            "native_f32_value": native_f32["value"] if native_f32 and "value" in native_f32 else None, "native_f32": native_f32,
+            "train_step": train_steps,
+            "cached_calibration_value": cached["value"] if cached else None,
+            "cached_calibration": cached,
             "changing_calibration_every_frame_value": changing["value"] if changing else None,
             "changing_calibration_every_frame": changing,
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline, "parity": parity,
