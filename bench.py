@@ -287,17 +287,20 @@ def run_train_steps(budget_s=150.0):
 
 
 def run_native_f32(args, budget_s=60.0):
-    """``value`` of this very command with every product on the f32 MFMA (SGV3D_WINO4_X3=0: the F(4x4) position GEMMs on
-    v_mfma_f32_16x16x4_f32 instead of six bf16 partial products per f32 product) -- a child run, timed region only."""
+    """``value`` of this very command with every product on the f32 MFMA (SGV3D_WINO4_X3=0 SGV3D_PW_X3=0: the F(4x4) position GEMMs
+    and the 1x1 layers on v_mfma_f32_* instead of six bf16 partial products per f32 product) -- a child run, timed region only."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--sub", "--config", args.config, "--batch", str(args.batch), "--dtype", "f32",
            "--steps", str(args.steps), "--warmup", str(args.warmup), "--streams", str(args.streams), "--no-roofline", "--no-cpu-baseline"]
     try:
-        r = subprocess.run(cmd, env=dict(os.environ, SGV3D_WINO4_X3="0"), capture_output=True, text=True, timeout=budget_s + 30.0)
+        # (no SGV3D_TUNE_CACHE in the child: it re-measures the f32x3 layers among the f32 candidates and must not write that back)
+        env = {k: v for k, v in os.environ.items() if k != "SGV3D_TUNE_CACHE"}
+        env.update(SGV3D_WINO4_X3="0", SGV3D_PW_X3="0")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=budget_s + 30.0)
         rec = json.loads(r.stdout.strip().splitlines()[-1])
         return {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"], "exit_code": r.returncode,
                 "layers_measured_here": rec["config"]["per_rank"][0]["layers_measured_here"],
-                "what": "child run of this command with SGV3D_WINO4_X3=0; the layers whose committed choice is an f32x3 tile are "
+                "what": "child run of this command with SGV3D_WINO4_X3=0 SGV3D_PW_X3=0; the layers whose committed choice is an f32x3 tile are "
                         "re-measured among the f32-MFMA candidates at its first forward (layers_measured_here)"}
     except Exception as e:
         return {"error": repr(e)[:300]}
@@ -425,10 +428,7 @@ def main():
 
     if not stub:
         # ---- warm-up: packs weights, tunes tiles, fills the caching allocator ---------------------
-        # (the per-layer candidates are timed as the pipeline will run them: args.streams concurrent copies -- FramePipeline
-        # does the same when it sees the first forward; here that forward happens before the pipeline exists)
-        if "SGV3D_TUNE_STREAMS" not in os.environ and args.streams > 1:
-            hip_ops.TUNE_STREAMS = max(hip_ops.TUNE_STREAMS, args.streams)
+        # (the per-layer candidates are timed as isolated launches, hip_ops.TUNE_STREAMS = 1: the committed tune DB's "|ts1" entries)
         from sgv3d_amd.pipeline import eager_forward
         with eager_forward(model):      # (plain launches: BEVHeight's own per-signature graph is what harness_eval_step measures)
             for _ in range(max(1, args.warmup)):
@@ -1090,17 +1090,17 @@ def main():
         train_steps = run_train_steps()
     x3_layers = None
     if not stub:
-        x3_layers = sum(1 for k, v in hip_ops.TUNE_DB.items() if v[0] in hip_ops.WINO4_X3_TILES and k.endswith(f"|ts{hip_ops.TUNE_STREAMS}")
+        x3_layers = sum(1 for k, v in hip_ops.TUNE_DB.items() if v[0] in hip_ops.WINO4_X3_TILES + hip_ops.PW_X3_TILES and k.endswith(f"|ts{hip_ops.TUNE_STREAMS}")
                         and f"|{B}x" in k)
-    if main_line and hip_ops.WINO4_X3 and not args.no_native_f32:
+    if main_line and (hip_ops.WINO4_X3 or hip_ops.PW_X3) and not args.no_native_f32:
         native_f32 = run_native_f32(args)
 
     if rank == 0:
-        products = ("f32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)" if not (hip_ops.WINO4_X3 and args.dtype == "f32") else
-                    "f32-accurate: every product of the three-launch F(4x4) layers' position GEMMs (csrc/gemm_x3_grouped.hip) is the f32 sum of "
-                    "six bf16 x bf16 partial products of operands split exactly into three bf16 terms (error of a product: one f32 rounding, "
-                    "f32 accumulation) where the per-layer measurement picked that form; every other product on the f32 MFMA "
-                    "(native_f32_value: all of them)")
+        products = ("f32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)" if not ((hip_ops.WINO4_X3 or hip_ops.PW_X3) and args.dtype == "f32") else
+                    "f32-accurate: every product of the three-launch F(4x4) layers' position GEMMs (csrc/gemm_x3_grouped.hip) and of the 1x1 "
+                    "layers (csrc/conv_pw_x3.hip) is the f32 sum of six bf16 x bf16 partial products of operands split exactly into three "
+                    "bf16 terms (error of a product: one f32 rounding, f32 accumulation) where the per-layer measurement picked that form; "
+                    "every other product on the f32 MFMA (native_f32_value: all of them)")
         line = {
             "metric": "camera frames/sec at 864x1536->BEV",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -1,0 +1,288 @@
+// Pointwise (1x1, stride 1) convolution with float32-accurate products on the bf16 matrix cores ("f32x3") -- the ResNet
+// bottlenecks' 1x1 layers, HeightNet's and the necks' 1x1 layers, which the reference runs through cuDNN (mmdet ResNet built at
+// layers/backbones/lss_fpn.py:296-297; lss_fpn.py:175-205; layers/heads/bev_height_head.py:75-78).  These layers hold most of the
+// frame's multiply-adds: on the f32 MFMA (conv_igemm_kernel, five workgroups per CU) they run at ~0.55 of its peak, and six
+// v_mfma_f32_16x16x32_bf16 do the work of eight v_mfma_f32_16x16x4_f32 in 96 cycles instead of 256.
+//
+//   y[m][co] = act( scale[co] * sum_ci x[m][ci] * w[co][ci] + shift[co] (+ residual[m][co]) )        m = pixel (NHWC row)
+//
+// Arithmetic: as gemm_x3_grouped.hip -- x = hi + mid + lo exactly (three bf16 terms), the six partial products of weight >=
+// 2^-16 accumulated in f32, the three dropped ones below one f32 rounding of the product.  The WEIGHTS are split once, by the
+// packer (sgv3d_conv_pack_weight_x3: [cout_pad / 16][cin / 32][3][512] bf16, the fragment-ordered layout of the F(4x4) position GEMM's weights).  The
+// ACTIVATIONS stay f32 in HBM (the tensors between the layers do not change) and are split on their way into LDS: a thread
+// loads 4 consecutive channels of a pixel (16 bytes), forms the three bf16 quads (~24 vector instructions, issued in the
+// shadow of the 16-cycle MFMAs of the other waves) and stores three 8-byte pieces.
+//
+// Kernel: the core of gemm_x3_grouped_kernel.  Workgroup = WN waves, tile (16 MA) pixels x (32 WN) channels x 32 k; wave w owns
+// channels [32 w, 32 w + 32) and all pixels; C^T = W . X^T so that a lane ends up with 4 consecutive output channels of one
+// pixel (the epilogue is one 16-byte load of scale / shift / residual and one 16-byte store per accumulator tile).  The weights go
+// from global memory straight into the wave's registers (fragment order, nobody else reads a wave's channels); the pixels go
+// through LDS: one image per plane, rows of 64 bytes, 16-byte chunk c of row r at c ^ (-(r >> 2) & 3) (conflict-free fragment
+// reads, see gemm_x3_grouped.hip); one register stage, two LDS buffers, one barrier per k-step.
+//
+// Bound: MFMA bf16 (2.5 PFLOP/s) with 6 x 2 x M x cin x cout executed bf16 flop; HBM for the layers with few input channels.
+#include "conv_common.hpp"
+
+using namespace sgv3d;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct PwX3Args {
+    const float *x, *scale, *bias, *res;
+    const void *w;         // U3 [cout_pad][K/32][3][32] bf16
+    float *y;
+    int M, K, N;           // pixels, input channels (K % 32 == 0), output channels (N % 4 == 0)
+    int x_ld, x_coff, y_ld, y_coff, res_ld, relu;
+    int cout_pad, tiles_m, tiles_n, mfirst;
+    unsigned x_bytes, w_bytes;
+};
+
+template <int MA, int WN>
+__global__ __launch_bounds__(64 * WN, 2) void conv_pw_x3_kernel(const PwX3Args a) {
+    constexpr int NT = 64 * WN, BM = 16 * MA, BN = 32 * WN;
+    constexpr int PLANE = BM * 64 + 64;
+    constexpr int BUF = 3 * PLANE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+
+    // XCD-aware tile walk (bijective for any tile count); default: the workgroups of one XCD walk the m-tiles of one channel
+    // tile (weight panel shared); mfirst: the channel tiles of one m-tile (pixel rows fetched once)
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    int tn, tm;
+    if (a.mfirst) {
+        tm = (int)((unsigned)logical / (unsigned)a.tiles_n);
+        tn = logical - tm * a.tiles_n;
+    } else {
+        tn = (int)((unsigned)logical / (unsigned)a.tiles_m);
+        tm = logical - tn * a.tiles_m;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kb = a.K >> 5;
+
+    const int tid = threadIdx.x;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, (int)a.w_bytes, 0x00020000);
+
+    // ---- pixels (f32, split here): global -> registers -> three bf16 planes in LDS.  A pass covers NT / 8 rows; lane
+    // (tid >> 3, tid & 7) = 4 channels of one row
+    constexpr int RPA = NT / 8, PA = (BM + RPA - 1) / RPA;
+    static_assert(RPA % 16 == 0, "a pass is a multiple of 16 rows");
+    const int arow = tid >> 3, ach = tid & 7;
+    unsigned xg[PA];
+    bool a_on[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int r = arow + RPA * i;
+        a_on[i] = (arow & ~7) + RPA * i < BM;                                   // wave-uniform: a wave covers 8 rows
+        xg[i] = (a_on[i] && m0 + r < a.M) ? (unsigned)((((long long)(m0 + r)) * a.x_ld + a.x_coff + ach * 4) * 4) : 0xffffffffu;
+    }
+    // LDS: row r, 8-byte piece ach of its 64 bytes: 16-byte chunk (ach >> 1) swizzled, half (ach & 1)
+    const unsigned xl = (unsigned)(arow * 64 + ((((ach >> 1) ^ ((-(arow >> 2)) & 3)) << 4) | ((ach & 1) << 3)));
+
+    // ---- weights (U3, fragment order): global -> registers, no LDS (a wave owns its 32 channels)
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l16 = lane & 15, g = lane >> 4;
+    unsigned wgo[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int cb = (n0 >> 4) + 2 * wave + nb;
+        wgo[nb] = (cb * 16 < a.cout_pad) ? (unsigned)(((long long)cb * kb) * 3072 + lane * 16) : 0xffffffffu;
+    }
+    const unsigned sw = (unsigned)((g ^ ((-(l16 >> 2)) & 3)) << 4);
+    const unsigned x_frag = (unsigned)(l16 * 64) + sw;
+
+    f32x4 acc[MA][2];
+#pragma unroll
+    for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[ma][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 rx[PA];
+    bf16x8 fw[2][2][3];
+    const int nkt = kb;
+
+#define PWX3_LOAD_X(KT)                                                                                   \
+    do {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < PA; ++i)                                                    \
+            rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xg[i], (KT) * 128, 0)); \
+    } while (0)
+#define PWX3_STORE_X(B)                                                                                   \
+    do {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < PA; ++i)                                                    \
+            if (a_on[i]) {                                                                                \
+                const bf16x4 hi = __builtin_convertvector(rx[i], bf16x4);                                 \
+                const f32x4 r1 = rx[i] - __builtin_convertvector(hi, f32x4);                              \
+                const bf16x4 mid = __builtin_convertvector(r1, bf16x4);                                   \
+                const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);                                \
+                const bf16x4 lo = __builtin_convertvector(r2, bf16x4);                                    \
+                unsigned char *d = smem + (B) * BUF + xl + i * RPA * 64;                                  \
+                *reinterpret_cast<bf16x4 *>(d) = hi;                                                      \
+                *reinterpret_cast<bf16x4 *>(d + PLANE) = mid;                                             \
+                *reinterpret_cast<bf16x4 *>(d + 2 * PLANE) = lo;                                          \
+            }                                                                                             \
+    } while (0)
+#define PWX3_LOAD_W(KT, ST)                                                                               \
+    do {                                                                                                  \
+        _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                                  \
+            _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                 \
+                fw[ST][nb][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wgo[nb], (KT) * 3072 + s * 1024, 0)); \
+    } while (0)
+#define PWX3_FRAG(OFF) (*reinterpret_cast<const bf16x8 *>(smem + (OFF)))
+#define PWX3_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
+#define PWX3_SB() __builtin_amdgcn_sched_barrier(0)
+    // one k-step (as gemm_x3_grouped.hip): weights of the next k-step requested at the top; the pixels of the next k-step (in
+    // registers since the previous phase) are split and stored to the other LDS buffer behind all but the last block's MFMAs, the
+    // pixels of the k-step after that are requested right behind that store; one barrier per k-step
+#define PWX3_PHASE(KT, B, ST)                                                                             \
+    do {                                                                                                  \
+        if ((KT) + 1 < nkt) PWX3_LOAD_W((KT) + 1, (ST) ^ 1);                                              \
+        bf16x8 fx[2][3];                                                                                  \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s) fx[0][s] = PWX3_FRAG((B) * BUF + x_frag + s * PLANE); \
+        _Pragma("unroll") for (int ma = 0; ma < MA; ++ma) {                                               \
+            if (ma + 1 < MA) {                                                                            \
+                _Pragma("unroll") for (int s = 0; s < 3; ++s)                                             \
+                    fx[(ma + 1) & 1][s] = PWX3_FRAG((B) * BUF + x_frag + (ma + 1) * 16 * 64 + s * PLANE); \
+            }                                                                                             \
+            if (ma == (MA > 2 ? MA - 2 : MA - 1) && (KT) + 1 < nkt) {                                     \
+                PWX3_STORE_X((B) ^ 1);                                                                    \
+                if ((KT) + 2 < nkt) PWX3_LOAD_X((KT) + 2);                                                \
+            }                                                                                             \
+            PWX3_SB();                                                                                    \
+            const bf16x8 *v = fx[ma & 1];                                                                 \
+            _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                            \
+                PWX3_MFMA(fw[ST][nb][2], v[0], acc[ma][nb]);                                              \
+                PWX3_MFMA(fw[ST][nb][0], v[2], acc[ma][nb]);                                              \
+                PWX3_MFMA(fw[ST][nb][1], v[1], acc[ma][nb]);                                              \
+                PWX3_MFMA(fw[ST][nb][1], v[0], acc[ma][nb]);                                              \
+                PWX3_MFMA(fw[ST][nb][0], v[1], acc[ma][nb]);                                              \
+                PWX3_MFMA(fw[ST][nb][0], v[0], acc[ma][nb]);                                              \
+            }                                                                                             \
+            PWX3_SB();                                                                                    \
+        }                                                                                                 \
+        if ((KT) + 1 < nkt) __syncthreads();                                                              \
+    } while (0)
+
+    PWX3_LOAD_X(0);
+    PWX3_LOAD_W(0, 0);
+    PWX3_STORE_X(0);
+    if (nkt > 1) PWX3_LOAD_X(1);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+        PWX3_PHASE(kt, 0, 0);
+        PWX3_PHASE(kt + 1, 1, 1);
+    }
+    if (kt < nkt) PWX3_PHASE(kt, 0, 0);
+#undef PWX3_LOAD_X
+#undef PWX3_STORE_X
+#undef PWX3_LOAD_W
+#undef PWX3_FRAG
+#undef PWX3_MFMA
+#undef PWX3_SB
+#undef PWX3_PHASE
+
+    // epilogue: accumulator tile (ma, nb) of this lane = pixel m0 + 16 ma + l16, channels n0 + 32 wave + 16 nb + 4 g + (0..3)
+    const float floor_ = a.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int col = n0 + 32 * wave + 16 * nb + 4 * g;
+        if (col >= a.N) continue;
+        const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sh = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ma = 0; ma < MA; ++ma) {
+            const int row = m0 + 16 * ma + l16;
+            if (row >= a.M) continue;
+            f32x4 v = acc[ma][nb] * sc + sh;
+            if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + (size_t)row * a.res_ld + col);
+            v = f32x4{fmaxf(v[0], floor_), fmaxf(v[1], floor_), fmaxf(v[2], floor_), fmaxf(v[3], floor_)};
+            *reinterpret_cast<f32x4 *>(a.y + (size_t)row * a.y_ld + a.y_coff + col) = v;
+        }
+    }
+}
+
+// w [cout][cin] f32 (a 1x1 convolution's OIHW weights) -> U3 [cout_pad / 16][cin_pad / 32][3][512] bf16, zero rows / columns in the padding
+__global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float *__restrict__ w, int cout, int cin, int cin_pad, int cout_pad,
+                                                             __bf16 *__restrict__ u) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)cout_pad * cin_pad) return;
+    const int co = (int)(i / cin_pad), ci = (int)(i - (long long)co * cin_pad);
+    const float v = (co < cout && ci < cin) ? w[(size_t)co * cin + ci] : 0.f;
+    const __bf16 hi = (__bf16)v;
+    const float r1 = v - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    const __bf16 lo = (__bf16)(r1 - (float)mid);
+    // fragment order: block of 16 output channels x k-step x plane = 512 elements, (channel c, k) at ((k / 8) * 16 + c) * 8 + k % 8
+    __bf16 *q = u + (((size_t)(co >> 4) * (cin_pad >> 5) + (ci >> 5)) * 3) * 512 + ((((ci & 31) >> 3) * 16 + (co & 15)) * 8 + (ci & 7));
+    q[0] = hi;
+    q[512] = mid;
+    q[1024] = lo;
+}
+
+template <int MA, int WN>
+int launch_pw(const PwX3Args &a, hipStream_t st) {
+    hipLaunchKernelGGL((conv_pw_x3_kernel<MA, WN>), dim3(a.tiles_m * a.tiles_n), dim3(64 * WN), 0, st, a);
+    return check_launch("conv_pw_x3_kernel");
+}
+
+}  // namespace
+
+// variant: m-tile {0: 32, 1: 64, 2: 128} pixels, + 4: 64 instead of 128 channels per workgroup
+extern "C" int sgv3d_conv_pack_weight_x3(const float *w_src, int cout, int cin, int cin_pad, int cout_pad, void *u3_packed, void *stream) {
+    SGV3D_REQUIRE(w_src && u3_packed && cout > 0 && cin > 0 && cin_pad >= cin && cin_pad % 32 == 0 && cout_pad >= cout && cout_pad % 32 == 0,
+                  "conv_pack_weight_x3: bad arguments (cout=%d cin=%d cin_pad=%d cout_pad=%d)", cout, cin, cin_pad, cout_pad);
+    const long long total = (long long)cout_pad * cin_pad;
+    hipLaunchKernelGGL(pack_weight_x3_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w_src, cout, cin, cin_pad, cout_pad,
+                       static_cast<__bf16 *>(u3_packed));
+    return check_launch("pack_weight_x3_kernel");
+}
+
+extern "C" int sgv3d_conv1x1_x3_forward(const sgv3d_conv_desc *d, const float *x, const void *u3_packed, const float *scale,
+                                        const float *bias, const float *residual, float *y, void *stream) {
+    SGV3D_REQUIRE(d && x && u3_packed && y, "conv1x1_x3_forward: null pointer");
+    SGV3D_REQUIRE(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->mode == SGV3D_CONV_NORMAL && d->out_h == d->in_h &&
+                      d->out_w == d->in_w && d->split_k <= 1,
+                  "conv1x1_x3_forward: 1x1 / stride 1 / no padding, NHWC output, no split-K");
+    SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->cin % 32 == 0 && d->cout % 4 == 0,
+                  "conv1x1_x3_forward: cin %% 32 == 0, cout %% 4 == 0 (cin=%d cout=%d)", d->cin, d->cout);
+    SGV3D_REQUIRE((d->x_ld & 3) == 0 && (d->x_coff & 3) == 0 && (d->y_ld & 3) == 0 && (d->y_coff & 3) == 0 && (residual == nullptr || (d->res_ld & 3) == 0),
+                  "conv1x1_x3_forward: leading dimensions and channel offsets must be multiples of 4");
+    SGV3D_REQUIRE(d->x_ld >= d->x_coff + d->cin && d->y_ld >= d->y_coff + d->cout && (residual == nullptr || d->res_ld >= d->cout),
+                  "conv1x1_x3_forward: leading dimension too small");
+    SGV3D_REQUIRE(d->cout_pad >= d->cout && d->cout_pad % 32 == 0, "conv1x1_x3_forward: desc.cout_pad = rows of the x3 weights (a multiple of 32)");
+    SGV3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
+                    reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(u3_packed)) & 15) == 0,
+                  "conv1x1_x3_forward: pointers must be 16-B aligned");
+    const long long M = (long long)d->batch * d->in_h * d->in_w;
+    const long long xb = M * d->x_ld * 4, wb = (long long)d->cout_pad * d->cin * 6;
+    SGV3D_REQUIRE(M < 0x7fffffffLL && xb < 0xf0000000LL && wb < 0xf0000000LL, "conv1x1_x3_forward: operands larger than 3.75 GiB");
+    const int variant = d->tile & 7;
+    SGV3D_REQUIRE((d->tile & SGV3D_TILE_X3) && (variant & 3) < 3, "conv1x1_x3_forward: desc.tile = SGV3D_TILE_X3 | variant, variant in {0,1,2,4,5,6}");
+    PwX3Args a;
+    a.x = x; a.w = u3_packed; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
+    a.M = (int)M; a.K = d->cin; a.N = d->cout;
+    a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff; a.res_ld = d->res_ld; a.relu = d->relu;
+    a.cout_pad = d->cout_pad;
+    a.mfirst = (d->tile & SGV3D_TILE_MFIRST) ? 1 : 0;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+    const int bm = 32 << (variant & 3), bn = (variant & 4) ? 64 : 128;
+    a.tiles_m = (int)cdiv(M, bm);
+    a.tiles_n = cdiv(d->cout, bn);
+    hipStream_t st = as_stream(stream);
+    switch (variant) {
+        case 0: return launch_pw<2, 4>(a, st);
+        case 1: return launch_pw<4, 4>(a, st);
+        case 2: return launch_pw<8, 4>(a, st);
+        case 4: return launch_pw<2, 2>(a, st);
+        case 5: return launch_pw<4, 2>(a, st);
+        default: return launch_pw<8, 2>(a, st);
+    }
+}

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void wino4_input_x3_kernel(const Wino4Args a) 
     }
 }
 
-// U3[p][co][ci / 32][plane][ci % 32] = the three bf16 terms of (G g G^T)[i][j], p = 6 i + j; zero rows / columns in the padding.
+// U3[p][co / 16][ci / 32][plane][fragment order] = the three bf16 terms of (G g G^T)[i][j], p = 6 i + j; zero rows / columns in the padding.
 // One thread per (co, ci); the arithmetic of wino4_pack_weight_kernel, then the split.
 __global__ __launch_bounds__(256) void wino4_pack_weight_x3_kernel(const float *__restrict__ w, int cout, int cin, int k_pad,
                                                                    int cout_pad, __bf16 *__restrict__ u) {
@@ -298,7 +298,9 @@ __global__ __launch_bounds__(256) void wino4_pack_weight_x3_kernel(const float *
         t[5][b] = g[2][b];
     }
     const size_t block = (size_t)cout_pad * k_pad * 3;
-    __bf16 *ub = u + ((size_t)co * (k_pad >> 5) + (ci >> 5)) * 96 + (ci & 31);
+    // fragment order (gemm_x3_grouped.hip): block of 16 output channels x k-step x plane = 512 elements, (channel c, k) at
+    // ((k / 8) * 16 + c) * 8 + k % 8
+    __bf16 *ub = u + (((size_t)(co >> 4) * (k_pad >> 5) + (ci >> 5)) * 3) * 512 + ((((ci & 31) >> 3) * 16 + (co & 15)) * 8 + (ci & 7));
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
         const float s02 = t[r][0] + t[r][2];
@@ -314,8 +316,8 @@ __global__ __launch_bounds__(256) void wino4_pack_weight_x3_kernel(const float *
             const __bf16 lo = (__bf16)(r1 - (float)mid);
             __bf16 *q = ub + (size_t)(r * 6 + c) * block;
             q[0] = hi;
-            q[32] = mid;
-            q[64] = lo;
+            q[512] = mid;
+            q[1024] = lo;
         }
     }
 }

@@ -17,7 +17,9 @@
 // Layouts (bf16, "plane-interleaved k-chunks"): a row of an operand is K / 32 records of 192 bytes, record = [hi | mid | lo] x 32
 // consecutive k.  One k-step of a row is one contiguous 192-byte read.
 //   V3  [36][rows][K/32][3][32]      written by wino4_input_x3_kernel        rows = tiles padded to the m-tile (16 MA)
-//   U3  [36][cout_pad][K/32][3][32]  written by wino4_pack_weight_x3_kernel  cout_pad = cout rounded up to 32
+//   U3  [36][cout_pad/16][K/32][3][512]  written by wino4_pack_weight_x3_kernel, FRAGMENT order: block of 16 output channels x
+//       k-step x plane = 1024 contiguous bytes, element (channel c, k) at ((k / 8) * 16 + c) * 8 + k % 8 -- the 64 lanes of a
+//       wave load one MFMA operand with one buffer_load_dwordx4 each, contiguously; cout_pad = cout rounded up to 32
 //   M   [36][rows][N] f32            read by wino4_output_kernel (unchanged)
 //
 // Kernel.  Workgroup = WN waves; tile (16 MA) rows x (32 WN) columns x 32 k; wave w owns columns [32 w, 32 w + 32) and all rows:
@@ -60,9 +62,10 @@ struct GX3Args {
 
 template <int MA, int WN>
 __global__ __launch_bounds__(64 * WN, 2) void gemm_x3_grouped_kernel(const GX3Args a) {
-    constexpr int NT = 64 * WN, BM = 16 * MA, BN = 32 * WN, ROWS = BM + BN;
-    constexpr int PLANE = ROWS * 64 + 64;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * PLANE];
+    constexpr int NT = 64 * WN, BM = 16 * MA, BN = 32 * WN;
+    constexpr int PLANE = BM * 64 + 64;            // one plane of the row tile; + 64: see the header
+    constexpr int BUF = 3 * PLANE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
 
     // XCD-aware tile mapping (bijective for any tile count)
     const int per_pos = a.tiles_m * a.tiles_n;
@@ -76,38 +79,38 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_x3_grouped_kernel(const GX3Ar
     const int tn = (int)((unsigned)rem / (unsigned)a.tiles_m);
     const int tm = rem - tn * a.tiles_m;
     const int m0 = p * a.rows + tm * BM, n0 = tn * BN;
-    const int kb = a.K >> 5;                                   // 192-byte records per row
+    const int kb = a.K >> 5;                                   // k-steps
 
     const int tid = threadIdx.x;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.x), 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char *>(static_cast<const unsigned char *>(a.w)) + (size_t)p * a.w_stride, 0, (int)a.w_bytes, 0x00020000);
 
-    // Staging: a pass moves one PLANE of 64 rows -- lane (tid >> 2, tid & 3) the 16-byte chunk tid & 3 of row (tid >> 2) + 64 pass
-    // (WN = 5: 80 rows per pass).  Every address is one per-thread base plus wave-uniform terms: the global offset of pass / plane /
-    // k-step goes into the load's scalar offset, the LDS offset into the store's immediate (the swizzle key (row >> 2) & 3 does not
-    // depend on the pass: the rows of a pass are a multiple of 16 apart) -- two address registers instead of four per chunk.
-    constexpr int RP = NT / 4;                         // rows per pass
-    constexpr int PA = (BM + RP - 1) / RP, PB = BN / RP;
-    static_assert(BN % RP == 0 && RP % 16 == 0, "whole passes over the weight rows");
+    // ---- rows (V3): global -> registers -> LDS.  A pass moves one PLANE of NT / 4 rows: lane (tid >> 2, tid & 3) the 16-byte chunk
+    // tid & 3 of row (tid >> 2) + RP pass.  One per-thread base; pass / plane / k-step go into the load's scalar offset and the
+    // store's immediate (the swizzle key (row >> 2) & 3 does not depend on the pass: RP % 16 == 0).
+    constexpr int RP = NT / 4, PA = (BM + RP - 1) / RP;
+    static_assert(RP % 16 == 0, "a pass is a multiple of 16 rows");
     const int srow = tid >> 2, sch = tid & 3;
-    const unsigned row_b = (unsigned)kb * 192u;                                   // bytes per operand row
+    const unsigned row_b = (unsigned)kb * 192u;                                   // bytes per row
     const unsigned xg = (unsigned)((long long)(m0 + srow) * kb * 192 + sch * 16);
-    const unsigned wg = (unsigned)((long long)(n0 + srow) * kb * 192 + sch * 16);
     const unsigned sl = (unsigned)(srow * 64 + ((sch ^ ((-(srow >> 2)) & 3)) << 4));
-    // rows past the tile (the last A pass) / past the weight block: the load's offset is out of range -> zeros, never stored / zeros stored
     bool a_on[PA];
-    unsigned w_lim[PB];
 #pragma unroll
     for (int i = 0; i < PA; ++i) a_on[i] = (srow & ~15) + RP * i < BM;           // wave-uniform: a wave covers 16 rows
-#pragma unroll
-    for (int i = 0; i < PB; ++i) w_lim[i] = (n0 + srow + RP * i) < a.cout_pad ? wg : 0xffffffffu;
 
+    // ---- weights (U3, fragment order): global -> registers, no LDS -- a wave owns its 32 columns, nobody else reads them.
+    // Block cb = 16 output channels; (cb, k-step, plane) = 1024 contiguous bytes, lane l at 16 l.
     const int wave = tid >> 6, lane = tid & 63;
     const int l16 = lane & 15, g = lane >> 4;
+    unsigned wgo[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int cb = (n0 >> 4) + 2 * wave + nb;
+        wgo[nb] = (cb * 16 < a.cout_pad) ? (unsigned)(((long long)cb * kb) * 3072 + lane * 16) : 0xffffffffu;
+    }
     const unsigned sw = (unsigned)((g ^ ((-(l16 >> 2)) & 3)) << 4);
-    const unsigned x_frag = (unsigned)(l16 * 64) + sw;                               // + 16 ma rows, + plane
-    const unsigned w_frag = (unsigned)((BM + 32 * wave + l16) * 64) + sw;            // + 16 nb rows, + plane
+    const unsigned x_frag = (unsigned)(l16 * 64) + sw;                               // + 16 ma rows, + plane, + buffer
 
     f32x4 acc[MA][2];
 #pragma unroll
@@ -115,78 +118,83 @@ __global__ __launch_bounds__(64 * WN, 2) void gemm_x3_grouped_kernel(const GX3Ar
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) acc[ma][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    i32x4 rx[3][PA], rw[3][PB];
+    i32x4 rx[3][PA];
+    bf16x8 fw[2][2][3];                             // [stage][nb][plane]
     const int nkt = kb;
 
-#define GX3_LOAD(KT)                                                                                      \
+#define GX3_LOAD_X(KT)                                                                                    \
     do {                                                                                                  \
-        _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                   \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                     \
             _Pragma("unroll") for (int i = 0; i < PA; ++i)                                                \
                 rx[s][i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(                \
                     x_rsrc, a_on[i] ? xg : 0xffffffffu, (int)(row_b * (unsigned)(RP * i)) + (KT) * 192 + s * 64, 0)); \
-            _Pragma("unroll") for (int i = 0; i < PB; ++i)                                                \
-                rw[s][i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(                \
-                    w_rsrc, w_lim[i], (int)(row_b * (unsigned)(RP * i)) + (KT) * 192 + s * 64, 0));       \
-        }                                                                                                 \
     } while (0)
-#define GX3_STORE()                                                                                       \
+#define GX3_STORE_X(B)                                                                                    \
     do {                                                                                                  \
-        _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                   \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                     \
             _Pragma("unroll") for (int i = 0; i < PA; ++i)                                                \
-                if (a_on[i]) *reinterpret_cast<i32x4 *>(smem + sl + s * PLANE + i * RP * 64) = rx[s][i];  \
-            _Pragma("unroll") for (int i = 0; i < PB; ++i)                                                \
-                *reinterpret_cast<i32x4 *>(smem + sl + s * PLANE + (BM + i * RP) * 64) = rw[s][i];        \
-        }                                                                                                 \
+                if (a_on[i]) *reinterpret_cast<i32x4 *>(smem + (B) * BUF + sl + s * PLANE + i * RP * 64) = rx[s][i]; \
+    } while (0)
+#define GX3_LOAD_W(KT, ST)                                                                                \
+    do {                                                                                                  \
+        _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                                  \
+            _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                 \
+                fw[ST][nb][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wgo[nb], (KT) * 3072 + s * 1024, 0)); \
     } while (0)
 #define GX3_FRAG(OFF) (*reinterpret_cast<const bf16x8 *>(smem + (OFF)))
 #define GX3_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
 #define GX3_SB() __builtin_amdgcn_sched_barrier(0)
+    // One k-step: MFMAs from LDS buffer B and weight stage ST.  The weights of the next k-step are requested at the top; the rows of
+    // the next k-step (in registers since the previous phase) go to the other LDS buffer behind all but the last block's MFMAs, the
+    // rows of the k-step after that are requested right behind that store; one barrier per k-step.
+#define GX3_PHASE(KT, B, ST)                                                                              \
+    do {                                                                                                  \
+        if ((KT) + 1 < nkt) GX3_LOAD_W((KT) + 1, (ST) ^ 1);                                               \
+        bf16x8 fx[2][3];                                                                                  \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s) fx[0][s] = GX3_FRAG((B) * BUF + x_frag + s * PLANE); \
+        _Pragma("unroll") for (int ma = 0; ma < MA; ++ma) {                                               \
+            if (ma + 1 < MA) {                                                                            \
+                _Pragma("unroll") for (int s = 0; s < 3; ++s)                                             \
+                    fx[(ma + 1) & 1][s] = GX3_FRAG((B) * BUF + x_frag + (ma + 1) * 16 * 64 + s * PLANE);  \
+            }                                                                                             \
+            if (ma == (MA > 2 ? MA - 2 : MA - 1) && (KT) + 1 < nkt) {                                     \
+                GX3_STORE_X((B) ^ 1);                                                                     \
+                if ((KT) + 2 < nkt) GX3_LOAD_X((KT) + 2);                                                 \
+            }                                                                                             \
+            GX3_SB();                                                                                     \
+            const bf16x8 *v = fx[ma & 1];                                                                 \
+            _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                            \
+                /* small terms first: (u lo, v hi), (u hi, v lo), (mid, mid), (u mid, v hi), (u hi, v mid), (hi, hi) */ \
+                GX3_MFMA(fw[ST][nb][2], v[0], acc[ma][nb]);                                               \
+                GX3_MFMA(fw[ST][nb][0], v[2], acc[ma][nb]);                                               \
+                GX3_MFMA(fw[ST][nb][1], v[1], acc[ma][nb]);                                               \
+                GX3_MFMA(fw[ST][nb][1], v[0], acc[ma][nb]);                                               \
+                GX3_MFMA(fw[ST][nb][0], v[1], acc[ma][nb]);                                               \
+                GX3_MFMA(fw[ST][nb][0], v[0], acc[ma][nb]);                                               \
+            }                                                                                             \
+            GX3_SB();                                                                                     \
+        }                                                                                                 \
+        if ((KT) + 1 < nkt) __syncthreads();                                                              \
+    } while (0)
 
-    GX3_LOAD(0);
-    GX3_STORE();
+    GX3_LOAD_X(0);
+    GX3_LOAD_W(0, 0);
+    GX3_STORE_X(0);
+    if (nkt > 1) GX3_LOAD_X(1);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) GX3_LOAD(kt + 1);
-        bf16x8 fw[2][3];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int s = 0; s < 3; ++s) fw[nb][s] = GX3_FRAG(w_frag + nb * 16 * 64 + s * PLANE);
-        bf16x8 fx[2][3];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) fx[0][s] = GX3_FRAG(x_frag + s * PLANE);
-#pragma unroll
-        for (int ma = 0; ma < MA; ++ma) {
-            // the row fragments of block ma + 1 are requested before the 12 MFMAs of block ma (192 cycles cover the LDS latency)
-            if (ma + 1 < MA) {
-#pragma unroll
-                for (int s = 0; s < 3; ++s) fx[(ma + 1) & 1][s] = GX3_FRAG(x_frag + (ma + 1) * 16 * 64 + s * PLANE);
-            }
-            GX3_SB();
-            const bf16x8 *v = fx[ma & 1];
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                // small terms first: (u lo, v hi), (u hi, v lo), (mid, mid), (u mid, v hi), (u hi, v mid), (hi, hi)
-                GX3_MFMA(fw[nb][2], v[0], acc[ma][nb]);
-                GX3_MFMA(fw[nb][0], v[2], acc[ma][nb]);
-                GX3_MFMA(fw[nb][1], v[1], acc[ma][nb]);
-                GX3_MFMA(fw[nb][1], v[0], acc[ma][nb]);
-                GX3_MFMA(fw[nb][0], v[1], acc[ma][nb]);
-                GX3_MFMA(fw[nb][0], v[0], acc[ma][nb]);
-            }
-            GX3_SB();
-        }
-        if (kt + 1 < nkt) {
-            __syncthreads();                 // every wave has read this k-step's fragments
-            GX3_STORE();
-            __syncthreads();
-        }
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+        GX3_PHASE(kt, 0, 0);
+        GX3_PHASE(kt + 1, 1, 1);
     }
-#undef GX3_LOAD
-#undef GX3_STORE
+    if (kt < nkt) GX3_PHASE(kt, 0, 0);
+#undef GX3_LOAD_X
+#undef GX3_STORE_X
+#undef GX3_LOAD_W
 #undef GX3_FRAG
 #undef GX3_MFMA
 #undef GX3_SB
+#undef GX3_PHASE
 
     // accumulator tile (ma, nb): row (Winograd tile) m0 + 16 ma + l16, columns n0 + 32 wave + 16 nb + 4 g + (0..3)
 #pragma unroll

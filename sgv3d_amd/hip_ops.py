@@ -34,6 +34,7 @@ import os as _os
 # choice that fills idle CUs in isolation only adds work when the CUs are busy anyway).  N > 1 launches the candidate on
 # N streams at once and compares the time for all of them to finish.
 TUNE_STREAMS = max(1, int(_os.environ.get("SGV3D_TUNE_STREAMS", "1")))
+TUNE_VERBOSE = bool(_os.environ.get("SGV3D_TUNE_VERBOSE"))      # print every candidate's time as the first-call measurement goes
 # launches per stream and repetitions of a candidate's timing under load (SGV3D_TUNE_ROUNDS / SGV3D_TUNE_REPEATS; the committed
 # tune DBs are measured with 8 x 4 -- tools/make_tune_db.sh -- so that near-ties are not decided by noise)
 TUNE_ROUNDS = max(1, int(_os.environ.get("SGV3D_TUNE_ROUNDS", "3")))
@@ -155,6 +156,8 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: 
               47: "wino4",
               50: "wino4_x3", 51: "wino4_x3", 52: "wino4_x3", 53: "wino4_x3", 54: "wino4_x3",    # F(4x4) with the f32x3 position GEMM
               55: "wino4_x3", 56: "wino4_x3", 57: "wino4_x3", 58: "wino4_x3", 59: "wino4_x3",    # (csrc/gemm_x3_grouped.hip), by tile shape
+              60: "pw_x3", 61: "pw_x3", 62: "pw_x3", 64: "pw_x3", 65: "pw_x3", 66: "pw_x3",      # pointwise f32x3 (csrc/conv_pw_x3.hip)
+              70: "pw_x3", 71: "pw_x3", 72: "pw_x3", 74: "pw_x3", 75: "pw_x3", 76: "pw_x3",      # ... walked m-tile first
               44: "64x64", 45: "64x64",    # the 64x64 tile at five workgroups per CU (SGV3D_TILE_OCC5); 45: walked m-tile first
               46: "wino4"}                 # F(4x4,3x3) in three launches with the five-per-CU 64x64 GEMM tile
 MFIRST = _os.environ.get("SGV3D_MFIRST", "1") != "0"
@@ -177,6 +180,12 @@ WINO4_TILES = (TILE_WINO4, TILE_WINO4_WIDE, TILE_WINO4_NARROW, TILE_WINO4_OCC, T
 WINO4_G48 = _os.environ.get("SGV3D_WINO4_G48", "1") != "0"     # 0: never a candidate
 # 0: the f32x3 position GEMM is never a candidate -- every product of the f32 path on the f32 MFMA (bench.py's native_f32_value)
 WINO4_X3 = _os.environ.get("SGV3D_WINO4_X3", "1") != "0"
+# Pointwise (1x1 / stride 1) layers with f32-accurate products on the bf16 matrix cores (csrc/conv_pw_x3.hip: weights split into three
+# bf16 terms by the packer, activations on their way into LDS).  Host ids 60 + v / 70 + v (m-tile first): v & 3 = {0: 32, 1: 64, 2: 128}
+# pixels per workgroup, v & 4: 64 instead of 128 channels.  0: never a candidate.
+PW_X3 = _os.environ.get("SGV3D_PW_X3", "1") != "0"
+PW_X3_TILES = (60, 61, 62, 64, 65, 66, 70, 71, 72, 74, 75, 76)
+PW_X3_DIMS = {t: (32 << ((t % 10) & 3), 64 if (t % 10) & 4 else 128) for t in PW_X3_TILES}
 # F(4x4,3x3) in ONE launch with V = B^T d B of a 16x16 block resident in LDS (csrc/head_wino4.hip: conv_f4res_kernel): 3x3 /
 # stride 1 / pad 1 layers with 64 input channels (ResNet layer 1) or 64 output channels (the CenterHead's shared layer), f32
 TILE_F4RES = 40
@@ -442,6 +451,29 @@ class PackedConv:
             self.w_wino4, self.wino4_geom = packed, (k_pad, cout_pad)
         return self.w_wino4
 
+    def pw_x3_ok(self, d=None, gate=None, io=0):
+        """The pointwise f32x3 kernel covers this layer (and launch): 1x1 / stride 1 / no padding, f32 tensors, NHWC output, no gate."""
+        ok = (PW_X3 and not MFMA_BF16 and not MFMA_F32X3 and not self.transposed and self.kh == 1 and self.kw == 1 and self.stride == 1
+              and self.pad == 0 and gate is None and io == 0 and self.cin % 32 == 0 and self.cout % 4 == 0 and self.cin >= 64)
+        if ok and d is not None:
+            ok = (d.mode == CONV_NORMAL and d.x_ld % 4 == 0 and d.x_coff % 4 == 0 and d.y_ld % 4 == 0 and d.y_coff % 4 == 0
+                  and d.res_ld % 4 == 0)
+        return ok
+
+    def _pw_x3_weights(self):
+        """The 1x1 weights as three bf16 planes per element ([cout_pad][cin / 32][3][32], cout_pad = cout rounded up to 32), made on
+        first use (sgv3d_conv_pack_weight_x3)."""
+        if getattr(self, 'w_pw_x3', None) is None:
+            lib = _lib.load()
+            w = self._keep                                           # [cout, cin_real, 1, 1] f32 on the device
+            cout_pad = (self.cout + 31) // 32 * 32
+            packed = torch.empty(cout_pad, self.cin // 32, 3, 32, dtype=torch.bfloat16, device=w.device)
+            with torch.cuda.device(w.device):
+                rc = lib.sgv3d_conv_pack_weight_x3(w.data_ptr(), self.cout, int(w.shape[1]), self.cin, cout_pad, packed.data_ptr(), _st(w))
+            _lib.check(rc, "sgv3d_conv_pack_weight_x3")
+            self.w_pw_x3, self.pw_x3_cout_pad = packed, cout_pad
+        return self.w_pw_x3
+
     def _wino4_x3_weights(self):
         """U[p] of F(4x4,3x3) as three bf16 planes per element ([36][cout_pad][cin / 32][3][32], cout_pad = cout rounded up to 32) for
         the f32x3 position GEMM, made on first use by one kernel (sgv3d_conv_winograd4_pack_weight_x3)."""
@@ -594,9 +626,9 @@ class PackedConv:
         real_n = self.cout_real * (self.ks * self.ks if self.transposed else 1)
         flops = 2.0 * gemm_m * real_n * (self.cin_real * self.kh * self.kw)
         x3 = 10 < t < 20 or (MFMA_F32X3 is True and t < TILE_WINO)
-        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF, TILE_F4RES) + WINO4_TILES + DW_TILES else
+        name = ("conv_" if t in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF, TILE_F4RES) + WINO4_TILES + DW_TILES + PW_X3_TILES else
                 ("conv_igemm_bf16_" if MFMA_BF16 else "conv_igemm_f32x3_" if x3 else "conv_igemm_")) + TILE_NAMES[t]
-        plain = t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF, TILE_F4RES) + WINO4_TILES + DW_TILES
+        plain = t not in (TILE_WINO, TILE_WINO_RES, TILE_PATCH, TILE_WINO_HALF, TILE_F4RES) + WINO4_TILES + DW_TILES + PW_X3_TILES
         if plain and self.k_order == 0:
             name += "_tapmajor"        # the <.., false> instantiation (cin % 32 != 0: stems), a different kernel symbol
         elif plain and not MFMA_BF16 and not x3:
@@ -627,6 +659,10 @@ class PackedConv:
                 extra = {"symbol": f"conv_igemm_kernel<{wtm}, {wtn}, {b(self.k_order != 0)}, false, {b(name.endswith(('_pw', '_pw_occ5')))}, "
                                    f"false, {b(t in OCC5_TILES)}>",
                          "mfma_flops": 2.0 * gemm_m * self.cout * self.cin * self.kh * self.kw * (self.ks * self.ks if self.transposed else 1)}
+            elif t in PW_X3_TILES:
+                bm, bn = PW_X3_DIMS[t]
+                extra = {"symbol": f"conv_pw_x3_kernel<{bm // 16}, {bn // 32}>", "mfma_flops": 2.0 * gemm_m * self.cout * self.cin,
+                         "bf16_mfma_flops": 6 * 2.0 * gemm_m * self.cout * self.cin}
             elif t in WINO4_TILES:
                 # the grouped GEMM of the three-launch F(4x4) path: 36 positions x rows (tiles padded to the GEMM's m-tile)
                 dil = max(1, self.dil)
@@ -706,6 +742,19 @@ class PackedConv:
                                       "(cout % 64 == 0) or 64 output channels (cin % 64 == 0), NHWC output, no gate, no split-K")
             return lib.sgv3d_conv3x3_f4res_forward(ctypes.byref(d), x.data_ptr(), self._f4res_weights().data_ptr(), _lib.ptr(self.scale),
                                                    _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(), _st(x))
+        if d.tile in PW_X3_TILES:
+            if not self.pw_x3_ok(d, gate, io) or d.split_k > 1 or x.dtype != torch.float32:
+                raise _lib.SGV3DError("the pointwise f32x3 kernel covers f32 1x1 / stride 1 layers with cin % 32 == 0 (>= 64), cout % 4 == 0, "
+                                      "NHWC output, no gate, no split-K")
+            u = self._pw_x3_weights()
+            host_tile, cp = d.tile, d.cout_pad
+            d.tile = 64 | (host_tile % 10) | (16 if host_tile >= 70 else 0)      # SGV3D_TILE_X3 | variant [| SGV3D_TILE_MFIRST]
+            d.cout_pad = self.pw_x3_cout_pad
+            try:
+                return lib.sgv3d_conv1x1_x3_forward(ctypes.byref(d), x.data_ptr(), u.data_ptr(), _lib.ptr(self.scale), _lib.ptr(self.shift),
+                                                    _lib.ptr(residual), out.data_ptr(), _st(x))
+            finally:
+                d.tile, d.cout_pad = host_tile, cp
         if d.tile in WINO4_TILES:
             if not self.wino4_ok(d, gate) or d.split_k > 1:
                 raise _lib.SGV3DError("F(4x4) Winograd covers f32 3x3 / stride 1 / pad 1 layers with cin % 32 == 0, cout % 4 == 0, "
@@ -812,6 +861,13 @@ class PackedConv:
                 tiles += self._x3_tiles(d)
         if self.f4res_ok(d, gate, io):
             tiles += (TILE_F4RES,)
+        if self.pw_x3_ok(d, gate, io):
+            # shapes that leave the chip neither empty nor padded: at least ~128 workgroups, m-tiles no larger than the map needs
+            for t in PW_X3_TILES:
+                bm, bn = PW_X3_DIMS[t]
+                wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
+                if wgs >= 96 and (bn == 128 or gemm_n <= 64 or wgs < 1024) and (t < 70 or (MFIRST and gemm_n > bn)):
+                    tiles += (t,)
         if self._patch_eligible(d, gate):
             tiles += (TILE_PATCH,)
         if self._dw_eligible(d, gate, io):
@@ -844,7 +900,7 @@ class PackedConv:
                 nk = -(-(self.kh * self.kw * (self.cin // 32)) // 2)      # chunks of 64 k; >= 4 per split
                 bm, bn = {31: (64, 256), 32: (128, 128), 33: (256, 64), 34: (128, 256), 35: (256, 128), 36: (64, 256), 37: (128, 128), 38: (64, 128), 39: (64, 128)}[t]
                 wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
-            if t in (TILE_WINO_RES, TILE_F4RES) or t in WINO4_TILES or t in DW_DEEP_TILES or (t in DW_TILES and (d.mode != CONV_NORMAL or not DW_SPLIT_K)):
+            if t in (TILE_WINO_RES, TILE_F4RES) or t in WINO4_TILES or t in PW_X3_TILES or t in DW_DEEP_TILES or (t in DW_TILES and (d.mode != CONV_NORMAL or not DW_SPLIT_K)):
                 splits = (1,)
             elif t in DW_TILES:
                 splits = (fixed_split,) if fixed_split else \
@@ -916,6 +972,8 @@ class PackedConv:
                             evs[r + 1].record()
                         evs[-1].synchronize()
                         dt = min(evs[r].elapsed_time(evs[r + 1]) for r in range(nrep))
+                    if TUNE_VERBOSE:
+                        print(f"[tune] {self.cout}x{self.cin}k{self.kh} {d.batch}x{d.in_h}x{d.in_w}: tile {t} split {sk}: {dt * 1e3:.1f} us", flush=True)
                     if best_t is None or dt < best_t:
                         best, best_t = (t, sk), dt
         return best
@@ -989,7 +1047,7 @@ def switch_state():
     g = globals()
     return tuple(g.get(k) for k in ("AUTOTUNE", "SPLIT_K", "WINOGRAD", "FUSED_HEAD", "HEAD_PATH", "MFMA_BF16", "BF16_ACTIVATIONS",
                                     "MFMA_F32X3", "MFIRST", "WINO4", "WINO_HALF", "PATCH_BF16", "DW_BF16", "DW_DEEP", "DW_NARROW",
-                                    "DW_SPLIT_K", "DW_DEEP_MAX_WGS", "PAIR_BF16", "TUNE_STREAMS", "PARALLEL_BRANCHES", "F4RES", "OCC5", "WINO4_G48", "DCN_FUSED", "WINO4_X3"))
+                                    "DW_SPLIT_K", "DW_DEEP_MAX_WGS", "PAIR_BF16", "TUNE_STREAMS", "PARALLEL_BRANCHES", "F4RES", "OCC5", "WINO4_G48", "DCN_FUSED", "WINO4_X3", "PW_X3"))
 
 
 def conv_pair_eligible(a, b, x, residual=None):

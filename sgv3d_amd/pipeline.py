@@ -217,13 +217,11 @@ class FramePipeline:
         self.done = [torch.cuda.Event() for _ in range(self.slots)]
         self._next = 0
         self._own_cache = model.backbone.calib_cache
-        # The first forward times the per-layer candidates (tile, split-K, Winograd variant).  With several frames in flight a
-        # launch shares the chip with the other slots' kernels, and what wins alone is not what wins then (a Winograd kernel
-        # that owns a whole CU against one that leaves room for a second workgroup): the candidates are timed as `slots`
-        # concurrent copies unless SGV3D_TUNE_STREAMS says otherwise.
-        from . import hip_ops
-        if "SGV3D_TUNE_STREAMS" not in os.environ and self.slots > 1:
-            hip_ops.TUNE_STREAMS = max(hip_ops.TUNE_STREAMS, self.slots)
+        # The first forward times the per-layer candidates (tile, split-K, Winograd variant) as ISOLATED launches (hip_ops.TUNE_STREAMS
+        # = 1 unless SGV3D_TUNE_STREAMS says otherwise).  Rounds 3-5 timed them as `slots` concurrent copies; round 6 measured that the
+        # chip-filling launches of concurrent frames run one after the other on the device (a kernel trace of three frames in flight:
+        # the frame costs the sum of its kernels' isolated durations, the overlap hides the gaps between them) -- the isolated
+        # duration is what a frame pays, and the choices made on it are 1-2 % faster with three frames in flight as well.
         with torch.no_grad(), eager_forward(model):
             model(imgs, mats)                      # packs weights / tunes tiles outside any capture
             torch.cuda.synchronize(imgs.device)

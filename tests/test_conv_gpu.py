@@ -541,3 +541,68 @@ def test_five_per_cu_tile_is_bitwise_the_64x64_tile(hip, shape, split):
     # plain epilogue (no BN / residual / ReLU): the raw-store path
     plain = PackedConv(w, stride=stride, pad=pad)
     assert torch.equal(plain(x, tile=44, split_k=split), plain(x, tile=4, split_k=split))
+
+
+# ------------------------------------------------------------------------------------------------ pointwise f32x3 (csrc/conv_pw_x3.hip)
+PW_X3_SHAPES = [
+    # (B, cin, H, W, cout)
+    (1, 64, 40, 48, 256),       # ResNet layer 1 expand (HBM-bound shape)
+    (1, 256, 27, 31, 64),       # ragged M (837 pixels: partial last m-tile at every tile height)
+    (2, 128, 9, 13, 512),       # batch 2
+    (1, 1024, 11, 17, 256),     # long K
+    (1, 512, 20, 12, 100),      # cout not a multiple of 32 (rows of the packed weights padded to 128), N tail inside a wave
+    (1, 96, 7, 5, 36),          # cin = 3 k-steps, tiny cout
+]
+
+
+@pytest.mark.parametrize("shape", PW_X3_SHAPES)
+@pytest.mark.parametrize("tile", [60, 61, 62, 64, 65, 66, 70, 71, 72, 74, 75, 76])
+def test_pointwise_x3_matches_float64_like_the_f32_kernel(hip, shape, tile):
+    """conv_pw_x3_kernel through PackedConv(tile=...): a 1x1 convolution with folded BN, residual, ReLU, an input channel window and a
+    concat offset, against a float64 product -- and against the f32-MFMA implicit GEMM on the same call: the f32x3 form (weights split
+    into three bf16 terms by the packer, activations on their way into LDS, six partial products in f32) is as close to float64 as the
+    native kernel (bar: 1.5x its error, and 2e-6 of the output scale), on activations whose channels span four decades."""
+    from sgv3d_amd.hip_ops import PackedConv
+    B, cin, H, W, cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + tile)
+    x = torch.randn(B, H, W, cin + 16, generator=g) * torch.pow(10.0, torch.randint(-2, 3, (1, 1, 1, cin + 16), generator=g).float())
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    res = torch.randn(B, H, W, cout, generator=g)
+    conv = PackedConv(w.to(DEV), scale=scale.to(DEV), shift=shift.to(DEV), relu=True)
+    assert conv.pw_x3_ok()
+    want = x[..., 8:8 + cin].double().reshape(-1, cin) @ w.double().reshape(cout, cin).t() * scale.double() + shift.double()
+    want = torch.relu(want + res.double().reshape(-1, cout)).reshape(B, H, W, cout)
+    s = float(want.abs().max())
+    out = torch.full((B, H, W, cout + 12), -3.0, device=DEV)
+    conv(x.to(DEV), out, x_coff=8, y_coff=4, residual=res.to(DEV), tile=tile, split_k=1)
+    err = float((out[..., 4:4 + cout].cpu().double() - want).abs().max()) / s
+    native = conv(x.to(DEV), x_coff=8, residual=res.to(DEV), tile=4, split_k=1)
+    e_native = float((native.cpu().double() - want).abs().max()) / s
+    assert err <= max(1.5 * e_native, 2e-7) and err < 2e-6, (err, e_native)
+    assert float(out[..., :4].max()) == -3.0 and float(out[..., 4 + cout:].max()) == -3.0          # neighbours untouched
+    again = torch.full_like(out, -3.0)
+    conv(x.to(DEV), again, x_coff=8, y_coff=4, residual=res.to(DEV), tile=tile, split_k=1)
+    assert torch.equal(out, again)                                                                  # deterministic
+
+
+def test_pointwise_x3_keeps_every_partial_product_and_covers_only_what_it_should(hip):
+    """Integer data (exact in f32 on both paths, exact under the three-term split): every tile shape returns the f32 kernel's bits --
+    a dropped partial product or a swapped plane shows up as a whole number.  And the launch refuses what the kernel does not cover."""
+    from sgv3d_amd._lib import SGV3DError
+    from sgv3d_amd.hip_ops import PackedConv, PW_X3_TILES
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-200, 201, (1, 19, 23, 160), generator=g).float()
+    w = torch.randint(-300, 301, (96, 160, 1, 1), generator=g).float()
+    conv = PackedConv(w.to(DEV))
+    want = conv(x.to(DEV), tile=4, split_k=1)
+    ref = (x.double().reshape(-1, 160) @ w.double().reshape(96, 160).t()).reshape(1, 19, 23, 96)
+    assert torch.equal(want.cpu().double(), ref)                          # |sum| < 2^24: exact
+    for tile in PW_X3_TILES:
+        assert torch.equal(conv(x.to(DEV), tile=tile, split_k=1), want), tile
+    with pytest.raises(SGV3DError):
+        conv(x.to(DEV), tile=61, split_k=2)                               # no split-K
+    w3 = torch.randn(64, 64, 3, 3)
+    with pytest.raises(SGV3DError):
+        PackedConv(w3.to(DEV), pad=1)(torch.randn(1, 8, 8, 64, device=DEV), tile=61, split_k=1)     # not a 1x1 layer
+    assert not PackedConv(torch.randn(64, 48, 1, 1).to(DEV)).pw_x3_ok()  # cin % 32 != 0

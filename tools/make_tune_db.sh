@@ -10,7 +10,7 @@ export SGV3D_NO_TUNE_DB=1          # measure everything afresh
 export SGV3D_TUNE_ROUNDS=8 SGV3D_TUNE_REPEATS=4     # careful timing: near-ties are not to be decided by noise
 cd $R
 # cfg-2 fp32: three frames in flight ("|ts3" signatures) and, in the same run, one frame in flight ("|ts1")
-SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2.json python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs > $OUT/cfg2.json 2> $OUT/cfg2.err
+SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2.json python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs --no-native-f32 --no-train-step > $OUT/cfg2.json 2> $OUT/cfg2.err
 echo "cfg2 rc=$?"
 # cfg-3 / cfg-5 in bf16 at the batch sizes other_configs runs (and batch 4 for cfg-5)
 SGV3D_TUNE_CACHE=$OUT/gfx950_cfg3_bf16.json python3 bench.py --sub --config cfg3 --batch 4 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/cfg3.json 2> $OUT/cfg3.err

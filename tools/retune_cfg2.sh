@@ -7,7 +7,7 @@ mkdir -p $OUT
 export SGV3D_NO_TUNE_DB=1 SGV3D_TUNE_ROUNDS=8 SGV3D_TUNE_REPEATS=4
 cd $R
 rm -f $OUT/gfx950_cfg2.json
-SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2.json python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs > $OUT/cfg2.json 2> $OUT/cfg2.err
+SGV3D_TUNE_CACHE=$OUT/gfx950_cfg2.json python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs --no-native-f32 --no-train-step > $OUT/cfg2.json 2> $OUT/cfg2.err
 echo "cfg2 rc=$?"
 python3 - <<PY
 import json, collections
