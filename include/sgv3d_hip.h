@@ -297,16 +297,21 @@ int sgv3d_conv_winograd4_pack_weight(const float *w_src /*[cout, cin, 3, 3]*/, i
 int sgv3d_conv_winograd4_pack_weight_x3(const float *w_src, int cout, int cin, int cin_pad, int cout_pad, void *u3_packed,
                                         void *stream);
 
-/* Pointwise (1x1 / stride 1 / pad 0) convolution with f32-accurate products from three bf16 terms per operand
- * (csrc/conv_pw_x3.hip): the 1x1 layers of the mmdet ResNet bottlenecks, of HeightNet and of the necks
- * (layers/backbones/lss_fpn.py:175-205,296-297; layers/heads/bev_height_head.py:75-78).  Weights: sgv3d_conv_pack_weight_x3 splits
- * w [cout, cin] f32 once into [cout_pad][cin_pad / 32][3][32] bf16 (cin_pad % 32 == 0, cout_pad % 32 == 0); activations stay f32
- * tensors and are split on their way into LDS.  desc as for sgv3d_conv2d_forward (NORMAL mode, no gate, no split-K; folded BN /
- * bias, residual, ReLU, concat offsets), desc.cout_pad = rows of the x3 weights, desc.tile = SGV3D_TILE_X3 | variant
- * [| SGV3D_TILE_MFIRST]: variant & 3 = {0: 32, 1: 64, 2: 128} pixels per workgroup, variant & 4: 64 instead of 128 channels. */
-int sgv3d_conv_pack_weight_x3(const float *w_src, int cout, int cin, int cin_pad, int cout_pad, void *u3_packed, void *stream);
-int sgv3d_conv1x1_x3_forward(const sgv3d_conv_desc *desc, const float *x, const void *u3_packed, const float *scale,
-                             const float *bias, const float *residual, float *y, void *stream);
+/* Convolution as an implicit GEMM with f32-accurate products from three bf16 terms per operand (csrc/conv_pw_x3.hip): the 1x1 layers
+ * of the mmdet ResNet bottlenecks, of HeightNet and of the necks, and the strided 3x3 / 1x1 / patchify layers between the stages
+ * (layers/backbones/lss_fpn.py:175-205,296-297; layers/heads/bev_height_head.py:75-78) -- any kernel with at most 32 taps, any
+ * stride / padding / dilation, cin % 32 == 0.  Weights: sgv3d_conv_pack_weight_x3 splits w [cout, cin, kh, kw] f32 once into
+ * [cout_pad / 16][kh * kw * cin_pad / 32][3][512] bf16 (fragment order, k = ((ci / 32) * taps + tap) * 32 + ci % 32; cin_pad % 32 ==
+ * 0, cout_pad % 32 == 0); activations stay f32 tensors and are split on their way into LDS.  desc as for sgv3d_conv2d_forward
+ * (NORMAL mode, no gate; folded BN / bias, residual, ReLU, channel window and concat offsets; desc.split_k > 1 with a workspace of
+ * sgv3d_conv2d_workspace_bytes(desc): partial sums, fixed-order reduce), desc.cout_pad = rows of
+ * the x3 weights, desc.tile = SGV3D_TILE_X3 | variant [| SGV3D_TILE_MFIRST]: variant & 3 = {0: 32, 1: 64, 2: 128} output pixels
+ * per workgroup, variant & 4: 64 instead of 128 channels. */
+int sgv3d_conv_pack_weight_x3(const float *w_src, int cout, int cin, int kh, int kw, int cin_pad, int cout_pad, void *u3_packed,
+                              void *stream);
+int sgv3d_conv2d_x3_forward(const sgv3d_conv_desc *desc, const float *x, const void *u3_packed, const float *scale,
+                            const float *bias, const float *residual, float *y, void *workspace, size_t workspace_bytes,
+                            void *stream);
 size_t sgv3d_conv2d_winograd4_workspace_bytes(const sgv3d_conv_desc *desc /*host*/);
 int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *desc /*host*/, const float *x, const float *u_packed,
                                    const float *scale, const float *bias, const float *residual, float *y,

@@ -97,8 +97,8 @@ _PROTOS = {
     "sgv3d_conv2d_winograd_forward": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "sgv3d_conv_winograd4_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sgv3d_conv_winograd4_pack_weight_x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "sgv3d_conv_pack_weight_x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "sgv3d_conv1x1_x3_forward": (c_int, [c_void_p] * 8),
+    "sgv3d_conv_pack_weight_x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "sgv3d_conv2d_x3_forward": (c_int, [c_void_p] * 8 + [c_size_t, c_void_p]),
     "sgv3d_conv2d_winograd4_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "sgv3d_conv2d_winograd4_forward": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 7 + [c_size_t, c_void_p]),
     "sgv3d_maxpool3x3s2": (c_int, [c_int] * 4 + [c_void_p] * 3),

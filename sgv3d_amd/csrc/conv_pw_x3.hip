@@ -34,15 +34,22 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct PwX3Args {
     const float *x, *scale, *bias, *res;
-    const void *w;         // U3 [cout_pad][K/32][3][32] bf16
+    const void *w;         // U3 in fragment order, k = ((ci / 32) * taps + tap) * 32 + ci % 32
     float *y;
-    int M, K, N;           // pixels, input channels (K % 32 == 0), output channels (N % 4 == 0)
+    int M, K, N;           // output pixels, kh * kw * cin (cin % 32 == 0), output channels (N % 4 == 0)
     int x_ld, x_coff, y_ld, y_coff, res_ld, relu;
     int cout_pad, tiles_m, tiles_n, mfirst;
     unsigned x_bytes, w_bytes;
+    // TAPS form (a strided / multi-tap convolution as an implicit GEMM): geometry of the gather
+    int in_h, in_w, out_h, out_w, kh, kw, stride, pad, dil;
+    int split_k;           // > 1: blockIdx.y owns a slice of the k-steps and stores raw partial sums to ws [split_k][M][N]
+    float *ws;
 };
 
-template <int MA, int WN>
+// TAPS = false: pointwise (1x1 / stride 1): the input pixel is the output pixel.  TAPS = true: kh x kw taps (<= 32), any stride /
+// padding / dilation: k-step kt covers 32 channels of ONE tap (kt = chunk * taps + tap, the packed weights' k order); which taps of
+// a row's pixel fall inside the image is a bit mask made once, a k-step costs one bit test and one add per 16-byte chunk.
+template <int MA, int WN, bool TAPS>
 __global__ __launch_bounds__(64 * WN, 2) void conv_pw_x3_kernel(const PwX3Args a) {
     constexpr int NT = 64 * WN, BM = 16 * MA, BN = 32 * WN;
     constexpr int PLANE = BM * 64 + 64;
@@ -77,13 +84,36 @@ __global__ __launch_bounds__(64 * WN, 2) void conv_pw_x3_kernel(const PwX3Args a
     static_assert(RPA % 16 == 0, "a pass is a multiple of 16 rows");
     const int arow = tid >> 3, ach = tid & 7;
     unsigned xg[PA];
+    [[maybe_unused]] unsigned xmask[PA];
     bool a_on[PA];
+    const int taps = TAPS ? a.kh * a.kw : 1;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         const int r = arow + RPA * i;
         a_on[i] = (arow & ~7) + RPA * i < BM;                                   // wave-uniform: a wave covers 8 rows
-        xg[i] = (a_on[i] && m0 + r < a.M) ? (unsigned)((((long long)(m0 + r)) * a.x_ld + a.x_coff + ach * 4) * 4) : 0xffffffffu;
+        const bool live = a_on[i] && m0 + r < a.M;
+        if constexpr (!TAPS) {
+            xg[i] = live ? (unsigned)((((long long)(m0 + r)) * a.x_ld + a.x_coff + ach * 4) * 4) : 0xffffffffu;
+        } else {
+            const int m = live ? m0 + r : 0;
+            const int t = (int)((unsigned)m / (unsigned)a.out_w);
+            const int ow = m - t * a.out_w;
+            const int n = (int)((unsigned)t / (unsigned)a.out_h);
+            const int oh = t - n * a.out_h;
+            const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
+            // (the top-left tap may lie outside the image: the offset is formed in 64 bits and used only under its tap's mask bit)
+            xg[i] = (unsigned)((((long long)(n * a.in_h + ih0) * a.in_w + iw0) * a.x_ld + a.x_coff + ach * 4) * 4);
+            unsigned mk = 0;
+            int tt = 0;
+            for (int th = 0; th < a.kh; ++th) {
+                const bool row_in = live && (unsigned)(ih0 + th * a.dil) < (unsigned)a.in_h;
+                for (int tw = 0; tw < a.kw; ++tw, ++tt) mk |= (row_in && (unsigned)(iw0 + tw * a.dil) < (unsigned)a.in_w) ? (1u << tt) : 0u;
+            }
+            xmask[i] = mk;
+        }
     }
+    // TAPS: the walk over (channel chunk, tap) of the loads, wave-uniform
+    [[maybe_unused]] int ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_c0 = 0;
     // LDS: row r, 8-byte piece ach of its 64 bytes: 16-byte chunk (ach >> 1) swizzled, half (ach & 1)
     const unsigned xl = (unsigned)(arow * 64 + ((((ach >> 1) ^ ((-(arow >> 2)) & 3)) << 4) | ((ach & 1) << 3)));
 
@@ -107,12 +137,38 @@ __global__ __launch_bounds__(64 * WN, 2) void conv_pw_x3_kernel(const PwX3Args a
 
     f32x4 rx[PA];
     bf16x8 fw[2][2][3];
-    const int nkt = kb;
+    // split-K: this workgroup's k-steps are [kt0, kt0 + nkt)
+    int kt0 = 0, nkt = kb;
+    if (a.split_k > 1) {
+        kt0 = (int)((unsigned)kb * blockIdx.y / (unsigned)a.split_k);
+        nkt = (int)((unsigned)kb * (blockIdx.y + 1) / (unsigned)a.split_k) - kt0;
+        if constexpr (TAPS) {
+            const int chunk = kt0 / taps;
+            ld_tap = kt0 - chunk * taps;
+            ld_c0 = chunk * 32;
+            ld_kh = ld_tap / a.kw;
+            ld_kw = ld_tap - ld_kh * a.kw;
+        }
+    }
 
+    // (TAPS: called with consecutive KT = 0, 1, 2, ...: the tap walk advances by one per call)
 #define PWX3_LOAD_X(KT)                                                                                   \
     do {                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < PA; ++i)                                                    \
-            rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xg[i], (KT) * 128, 0)); \
+        if constexpr (!TAPS) {                                                                            \
+            _Pragma("unroll") for (int i = 0; i < PA; ++i)                                                \
+                rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xg[i], (kt0 + (KT)) * 128, 0)); \
+        } else {                                                                                          \
+            const unsigned koff_ = (unsigned)((((ld_kh * a.in_w + ld_kw) * a.dil) * a.x_ld + ld_c0) * 4);  \
+            const unsigned bit_ = 1u << ld_tap;                                                           \
+            _Pragma("unroll") for (int i = 0; i < PA; ++i)                                                \
+                rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                   \
+                    x_rsrc, (xmask[i] & bit_) ? xg[i] + koff_ : 0xffffffffu, 0, 0));                      \
+            ++ld_tap;                                                                                     \
+            if (++ld_kw == a.kw) {                                                                        \
+                ld_kw = 0;                                                                                \
+                if (++ld_kh == a.kh) { ld_kh = 0; ld_tap = 0; ld_c0 += 32; }                              \
+            }                                                                                             \
+        }                                                                                                 \
     } while (0)
 #define PWX3_STORE_X(B)                                                                                   \
     do {                                                                                                  \
@@ -133,7 +189,7 @@ __global__ __launch_bounds__(64 * WN, 2) void conv_pw_x3_kernel(const PwX3Args a
     do {                                                                                                  \
         _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                                  \
             _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                 \
-                fw[ST][nb][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wgo[nb], (KT) * 3072 + s * 1024, 0)); \
+                fw[ST][nb][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wgo[nb], (kt0 + (KT)) * 3072 + s * 1024, 0)); \
     } while (0)
 #define PWX3_FRAG(OFF) (*reinterpret_cast<const bf16x8 *>(smem + (OFF)))
 #define PWX3_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
@@ -190,6 +246,20 @@ __global__ __launch_bounds__(64 * WN, 2) void conv_pw_x3_kernel(const PwX3Args a
 #undef PWX3_PHASE
 
     // epilogue: accumulator tile (ma, nb) of this lane = pixel m0 + 16 ma + l16, channels n0 + 32 wave + 16 nb + 4 g + (0..3)
+    if (a.split_k > 1) {                 // raw partial sums; conv_splitk_reduce4_kernel adds them in fixed order and runs the epilogue
+        float *wsb = a.ws + (size_t)blockIdx.y * a.M * a.N;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = n0 + 32 * wave + 16 * nb + 4 * g;
+            if (col >= a.N) continue;
+#pragma unroll
+            for (int ma = 0; ma < MA; ++ma) {
+                const int row = m0 + 16 * ma + l16;
+                if (row < a.M) *reinterpret_cast<f32x4 *>(wsb + (size_t)row * a.N + col) = acc[ma][nb];
+            }
+        }
+        return;
+    }
     const float floor_ = a.relu ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -209,80 +279,114 @@ __global__ __launch_bounds__(64 * WN, 2) void conv_pw_x3_kernel(const PwX3Args a
     }
 }
 
-// w [cout][cin] f32 (a 1x1 convolution's OIHW weights) -> U3 [cout_pad / 16][cin_pad / 32][3][512] bf16, zero rows / columns in the padding
+// w [cout][cin][kh][kw] f32 (OIHW) -> U3 [cout_pad / 16][K / 32][3][512] bf16 with k = ((ci / 32) * taps + tap) * 32 + ci % 32
+// (K = taps * cin_pad), zero rows / columns in the padding
 __global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float *__restrict__ w, int cout, int cin, int cin_pad, int cout_pad,
-                                                             __bf16 *__restrict__ u) {
+                                                             int taps, __bf16 *__restrict__ u) {
+    const long long kp = (long long)taps * cin_pad;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)cout_pad * cin_pad) return;
-    const int co = (int)(i / cin_pad), ci = (int)(i - (long long)co * cin_pad);
-    const float v = (co < cout && ci < cin) ? w[(size_t)co * cin + ci] : 0.f;
+    if (i >= (long long)cout_pad * kp) return;
+    const int co = (int)(i / kp), k = (int)(i - (long long)co * kp);
+    const int chunk = k / (32 * taps), rem = k - chunk * 32 * taps;
+    const int tap = rem >> 5, ci = chunk * 32 + (rem & 31);
+    const float v = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * taps + tap] : 0.f;
     const __bf16 hi = (__bf16)v;
     const float r1 = v - (float)hi;
     const __bf16 mid = (__bf16)r1;
     const __bf16 lo = (__bf16)(r1 - (float)mid);
     // fragment order: block of 16 output channels x k-step x plane = 512 elements, (channel c, k) at ((k / 8) * 16 + c) * 8 + k % 8
-    __bf16 *q = u + (((size_t)(co >> 4) * (cin_pad >> 5) + (ci >> 5)) * 3) * 512 + ((((ci & 31) >> 3) * 16 + (co & 15)) * 8 + (ci & 7));
+    __bf16 *q = u + (((size_t)(co >> 4) * (kp >> 5) + (k >> 5)) * 3) * 512 + ((((k & 31) >> 3) * 16 + (co & 15)) * 8 + (k & 7));
     q[0] = hi;
     q[512] = mid;
     q[1024] = lo;
 }
 
 template <int MA, int WN>
-int launch_pw(const PwX3Args &a, hipStream_t st) {
-    hipLaunchKernelGGL((conv_pw_x3_kernel<MA, WN>), dim3(a.tiles_m * a.tiles_n), dim3(64 * WN), 0, st, a);
+int launch_pw(const PwX3Args &a, bool taps, hipStream_t st) {
+    const dim3 grid(a.tiles_m * a.tiles_n, a.split_k > 1 ? a.split_k : 1);
+    if (taps) hipLaunchKernelGGL((conv_pw_x3_kernel<MA, WN, true>), grid, dim3(64 * WN), 0, st, a);
+    else hipLaunchKernelGGL((conv_pw_x3_kernel<MA, WN, false>), grid, dim3(64 * WN), 0, st, a);
     return check_launch("conv_pw_x3_kernel");
 }
 
 }  // namespace
 
 // variant: m-tile {0: 32, 1: 64, 2: 128} pixels, + 4: 64 instead of 128 channels per workgroup
-extern "C" int sgv3d_conv_pack_weight_x3(const float *w_src, int cout, int cin, int cin_pad, int cout_pad, void *u3_packed, void *stream) {
-    SGV3D_REQUIRE(w_src && u3_packed && cout > 0 && cin > 0 && cin_pad >= cin && cin_pad % 32 == 0 && cout_pad >= cout && cout_pad % 32 == 0,
-                  "conv_pack_weight_x3: bad arguments (cout=%d cin=%d cin_pad=%d cout_pad=%d)", cout, cin, cin_pad, cout_pad);
-    const long long total = (long long)cout_pad * cin_pad;
+extern "C" int sgv3d_conv_pack_weight_x3(const float *w_src, int cout, int cin, int kh, int kw, int cin_pad, int cout_pad, void *u3_packed,
+                                         void *stream) {
+    SGV3D_REQUIRE(w_src && u3_packed && cout > 0 && cin > 0 && kh > 0 && kw > 0 && kh * kw <= 32 && cin_pad >= cin && cin_pad % 32 == 0 &&
+                      cout_pad >= cout && cout_pad % 32 == 0,
+                  "conv_pack_weight_x3: bad arguments (cout=%d cin=%d k=%dx%d cin_pad=%d cout_pad=%d)", cout, cin, kh, kw, cin_pad, cout_pad);
+    const long long total = (long long)cout_pad * cin_pad * kh * kw;
     hipLaunchKernelGGL(pack_weight_x3_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w_src, cout, cin, cin_pad, cout_pad,
-                       static_cast<__bf16 *>(u3_packed));
+                       kh * kw, static_cast<__bf16 *>(u3_packed));
     return check_launch("pack_weight_x3_kernel");
 }
 
-extern "C" int sgv3d_conv1x1_x3_forward(const sgv3d_conv_desc *d, const float *x, const void *u3_packed, const float *scale,
-                                        const float *bias, const float *residual, float *y, void *stream) {
-    SGV3D_REQUIRE(d && x && u3_packed && y, "conv1x1_x3_forward: null pointer");
-    SGV3D_REQUIRE(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->mode == SGV3D_CONV_NORMAL && d->out_h == d->in_h &&
-                      d->out_w == d->in_w && d->split_k <= 1,
-                  "conv1x1_x3_forward: 1x1 / stride 1 / no padding, NHWC output, no split-K");
+extern "C" int sgv3d_conv2d_x3_forward(const sgv3d_conv_desc *d, const float *x, const void *u3_packed, const float *scale,
+                                       const float *bias, const float *residual, float *y, void *workspace, size_t workspace_bytes,
+                                       void *stream) {
+    SGV3D_REQUIRE(d && x && u3_packed && y, "conv2d_x3_forward: null pointer");
+    SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL && d->kh > 0 && d->kw > 0 && d->kh * d->kw <= 32 && d->stride > 0 && d->dil > 0 && d->pad >= 0,
+                  "conv2d_x3_forward: NHWC output, at most 32 taps");
     SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->cin % 32 == 0 && d->cout % 4 == 0,
-                  "conv1x1_x3_forward: cin %% 32 == 0, cout %% 4 == 0 (cin=%d cout=%d)", d->cin, d->cout);
+                  "conv2d_x3_forward: cin %% 32 == 0, cout %% 4 == 0 (cin=%d cout=%d)", d->cin, d->cout);
+    SGV3D_REQUIRE(d->out_h == (d->in_h + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1 &&
+                      d->out_w == (d->in_w + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1,
+                  "conv2d_x3_forward: output size does not match the geometry");
     SGV3D_REQUIRE((d->x_ld & 3) == 0 && (d->x_coff & 3) == 0 && (d->y_ld & 3) == 0 && (d->y_coff & 3) == 0 && (residual == nullptr || (d->res_ld & 3) == 0),
-                  "conv1x1_x3_forward: leading dimensions and channel offsets must be multiples of 4");
+                  "conv2d_x3_forward: leading dimensions and channel offsets must be multiples of 4");
     SGV3D_REQUIRE(d->x_ld >= d->x_coff + d->cin && d->y_ld >= d->y_coff + d->cout && (residual == nullptr || d->res_ld >= d->cout),
-                  "conv1x1_x3_forward: leading dimension too small");
-    SGV3D_REQUIRE(d->cout_pad >= d->cout && d->cout_pad % 32 == 0, "conv1x1_x3_forward: desc.cout_pad = rows of the x3 weights (a multiple of 32)");
+                  "conv2d_x3_forward: leading dimension too small");
+    SGV3D_REQUIRE(d->cout_pad >= d->cout && d->cout_pad % 32 == 0, "conv2d_x3_forward: desc.cout_pad = rows of the x3 weights (a multiple of 32)");
     SGV3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
                     reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(u3_packed)) & 15) == 0,
-                  "conv1x1_x3_forward: pointers must be 16-B aligned");
-    const long long M = (long long)d->batch * d->in_h * d->in_w;
-    const long long xb = M * d->x_ld * 4, wb = (long long)d->cout_pad * d->cin * 6;
-    SGV3D_REQUIRE(M < 0x7fffffffLL && xb < 0xf0000000LL && wb < 0xf0000000LL, "conv1x1_x3_forward: operands larger than 3.75 GiB");
+                  "conv2d_x3_forward: pointers must be 16-B aligned");
+    const long long M = (long long)d->batch * d->out_h * d->out_w;
+    const long long K = (long long)d->kh * d->kw * d->cin;
+    const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * 4, wb = (long long)d->cout_pad * K * 6;
+    SGV3D_REQUIRE(M < 0x7fffffffLL && xb < 0xf0000000LL && wb < 0xf0000000LL, "conv2d_x3_forward: operands larger than 3.75 GiB");
     const int variant = d->tile & 7;
-    SGV3D_REQUIRE((d->tile & SGV3D_TILE_X3) && (variant & 3) < 3, "conv1x1_x3_forward: desc.tile = SGV3D_TILE_X3 | variant, variant in {0,1,2,4,5,6}");
+    SGV3D_REQUIRE((d->tile & SGV3D_TILE_X3) && (variant & 3) < 3, "conv2d_x3_forward: desc.tile = SGV3D_TILE_X3 | variant, variant in {0,1,2,4,5,6}");
+    const bool taps = !(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0);
     PwX3Args a;
     a.x = x; a.w = u3_packed; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
-    a.M = (int)M; a.K = d->cin; a.N = d->cout;
+    a.M = (int)M; a.K = (int)K; a.N = d->cout;
     a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff; a.res_ld = d->res_ld; a.relu = d->relu;
     a.cout_pad = d->cout_pad;
     a.mfirst = (d->tile & SGV3D_TILE_MFIRST) ? 1 : 0;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+    a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w;
+    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
     const int bm = 32 << (variant & 3), bn = (variant & 4) ? 64 : 128;
     a.tiles_m = (int)cdiv(M, bm);
     a.tiles_n = cdiv(d->cout, bn);
     hipStream_t st = as_stream(stream);
-    switch (variant) {
-        case 0: return launch_pw<2, 4>(a, st);
-        case 1: return launch_pw<4, 4>(a, st);
-        case 2: return launch_pw<8, 4>(a, st);
-        case 4: return launch_pw<2, 2>(a, st);
-        case 5: return launch_pw<4, 2>(a, st);
-        default: return launch_pw<8, 2>(a, st);
+    a.split_k = d->split_k > 1 ? d->split_k : 1;
+    a.ws = nullptr;
+    if (a.split_k > 1) {
+        SGV3D_REQUIRE(a.split_k <= K / 32, "conv2d_x3_forward: split_k %d exceeds the %lld k-steps", a.split_k, K / 32);
+        const size_t need = (size_t)a.split_k * (size_t)M * d->cout * sizeof(float);
+        if (!workspace || workspace_bytes < need)
+            return fail(SGV3D_ENOSPACE, "conv2d_x3_forward: split-K workspace has %zu bytes, needs %zu", workspace_bytes, need);
+        SGV3D_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "conv2d_x3_forward: workspace must be 16-B aligned");
+        a.ws = static_cast<float *>(workspace);
     }
+    int rc;
+    switch (variant) {
+        case 0: rc = launch_pw<2, 4>(a, taps, st); break;
+        case 1: rc = launch_pw<4, 4>(a, taps, st); break;
+        case 2: rc = launch_pw<8, 4>(a, taps, st); break;
+        case 4: rc = launch_pw<2, 2>(a, taps, st); break;
+        case 5: rc = launch_pw<4, 2>(a, taps, st); break;
+        default: rc = launch_pw<8, 2>(a, taps, st); break;
+    }
+    if (rc != SGV3D_OK || a.split_k <= 1) return rc;
+    // second stage: fixed-order sum of the partials + folded BN / bias, residual, ReLU (conv_igemm.hip)
+    ConvArgs r{};
+    r.M = a.M; r.N = a.N; r.ws = a.ws; r.split_k = a.split_k;
+    r.scale = scale; r.bias = bias; r.res = residual; r.res_ld = d->res_ld; r.relu = d->relu;
+    r.y = y; r.y_ld = d->y_ld; r.y_coff = d->y_coff; r.mode = SGV3D_CONV_NORMAL; r.cout = d->cout;
+    r.m_h = d->out_h; r.m_w = d->out_w; r.out_h = d->out_h; r.out_w = d->out_w;
+    return launch_splitk_reduce(r, st);
 }

@@ -180,7 +180,8 @@ WINO4_TILES = (TILE_WINO4, TILE_WINO4_WIDE, TILE_WINO4_NARROW, TILE_WINO4_OCC, T
 WINO4_G48 = _os.environ.get("SGV3D_WINO4_G48", "1") != "0"     # 0: never a candidate
 # 0: the f32x3 position GEMM is never a candidate -- every product of the f32 path on the f32 MFMA (bench.py's native_f32_value)
 WINO4_X3 = _os.environ.get("SGV3D_WINO4_X3", "1") != "0"
-# Pointwise (1x1 / stride 1) layers with f32-accurate products on the bf16 matrix cores (csrc/conv_pw_x3.hip: weights split into three
+# Implicit-GEMM layers (1x1, strided 3x3 / 1x1, patchify: at most 32 taps, cin % 32 == 0) with f32-accurate products on the bf16 matrix
+# cores (csrc/conv_pw_x3.hip: weights split into three
 # bf16 terms by the packer, activations on their way into LDS).  Host ids 60 + v / 70 + v (m-tile first): v & 3 = {0: 32, 1: 64, 2: 128}
 # pixels per workgroup, v & 4: 64 instead of 128 channels.  0: never a candidate.
 PW_X3 = _os.environ.get("SGV3D_PW_X3", "1") != "0"
@@ -452,24 +453,27 @@ class PackedConv:
         return self.w_wino4
 
     def pw_x3_ok(self, d=None, gate=None, io=0):
-        """The pointwise f32x3 kernel covers this layer (and launch): 1x1 / stride 1 / no padding, f32 tensors, NHWC output, no gate."""
-        ok = (PW_X3 and not MFMA_BF16 and not MFMA_F32X3 and not self.transposed and self.kh == 1 and self.kw == 1 and self.stride == 1
-              and self.pad == 0 and gate is None and io == 0 and self.cin % 32 == 0 and self.cout % 4 == 0 and self.cin >= 64)
+        """The implicit-GEMM f32x3 kernel (csrc/conv_pw_x3.hip) covers this layer (and launch): a convolution with at most 32 taps and
+        cin % 32 == 0 -- the 1x1 layers, the strided 3x3 / 1x1 layers between the stages, the patchify layers of the necks --, f32
+        tensors, NHWC output, no gate."""
+        ok = (PW_X3 and not MFMA_BF16 and not MFMA_F32X3 and not self.transposed and self.kh * self.kw <= 32 and gate is None and io == 0
+              and self.k_order == 1 and self.cin % 32 == 0 and self.cout % 4 == 0 and self.cin >= 64)
         if ok and d is not None:
             ok = (d.mode == CONV_NORMAL and d.x_ld % 4 == 0 and d.x_coff % 4 == 0 and d.y_ld % 4 == 0 and d.y_coff % 4 == 0
                   and d.res_ld % 4 == 0)
         return ok
 
     def _pw_x3_weights(self):
-        """The 1x1 weights as three bf16 planes per element ([cout_pad][cin / 32][3][32], cout_pad = cout rounded up to 32), made on
-        first use (sgv3d_conv_pack_weight_x3)."""
+        """The weights as three bf16 planes per element in fragment order ([cout_pad / 16][kh kw cin / 32][3][512], cout_pad = cout
+        rounded up to 32), made on first use (sgv3d_conv_pack_weight_x3)."""
         if getattr(self, 'w_pw_x3', None) is None:
             lib = _lib.load()
-            w = self._keep                                           # [cout, cin_real, 1, 1] f32 on the device
+            w = self._keep                                           # [cout, cin_real, kh, kw] f32 on the device
             cout_pad = (self.cout + 31) // 32 * 32
-            packed = torch.empty(cout_pad, self.cin // 32, 3, 32, dtype=torch.bfloat16, device=w.device)
+            packed = torch.empty(cout_pad // 16, self.kh * self.kw * self.cin // 32, 3, 512, dtype=torch.bfloat16, device=w.device)
             with torch.cuda.device(w.device):
-                rc = lib.sgv3d_conv_pack_weight_x3(w.data_ptr(), self.cout, int(w.shape[1]), self.cin, cout_pad, packed.data_ptr(), _st(w))
+                rc = lib.sgv3d_conv_pack_weight_x3(w.data_ptr(), self.cout, int(w.shape[1]), self.kh, self.kw, self.cin, cout_pad,
+                                                   packed.data_ptr(), _st(w))
             _lib.check(rc, "sgv3d_conv_pack_weight_x3")
             self.w_pw_x3, self.pw_x3_cout_pad = packed, cout_pad
         return self.w_pw_x3
@@ -661,8 +665,10 @@ class PackedConv:
                          "mfma_flops": 2.0 * gemm_m * self.cout * self.cin * self.kh * self.kw * (self.ks * self.ks if self.transposed else 1)}
             elif t in PW_X3_TILES:
                 bm, bn = PW_X3_DIMS[t]
-                extra = {"symbol": f"conv_pw_x3_kernel<{bm // 16}, {bn // 32}>", "mfma_flops": 2.0 * gemm_m * self.cout * self.cin,
-                         "bf16_mfma_flops": 6 * 2.0 * gemm_m * self.cout * self.cin}
+                pw1 = self.kh == 1 and self.kw == 1 and self.stride == 1 and self.pad == 0
+                kk = self.cin * self.kh * self.kw
+                extra = {"symbol": f"conv_pw_x3_kernel<{bm // 16}, {bn // 32}, {'false' if pw1 else 'true'}>",
+                         "mfma_flops": 2.0 * gemm_m * self.cout * kk, "bf16_mfma_flops": 6 * 2.0 * gemm_m * self.cout * kk}
             elif t in WINO4_TILES:
                 # the grouped GEMM of the three-launch F(4x4) path: 36 positions x rows (tiles padded to the GEMM's m-tile)
                 dil = max(1, self.dil)
@@ -743,16 +749,16 @@ class PackedConv:
             return lib.sgv3d_conv3x3_f4res_forward(ctypes.byref(d), x.data_ptr(), self._f4res_weights().data_ptr(), _lib.ptr(self.scale),
                                                    _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(), _st(x))
         if d.tile in PW_X3_TILES:
-            if not self.pw_x3_ok(d, gate, io) or d.split_k > 1 or x.dtype != torch.float32:
-                raise _lib.SGV3DError("the pointwise f32x3 kernel covers f32 1x1 / stride 1 layers with cin % 32 == 0 (>= 64), cout % 4 == 0, "
-                                      "NHWC output, no gate, no split-K")
+            if not self.pw_x3_ok(d, gate, io) or x.dtype != torch.float32:
+                raise _lib.SGV3DError("the implicit-GEMM f32x3 kernel covers f32 layers with at most 32 taps, cin % 32 == 0 (>= 64), cout % 4 == 0, "
+                                      "NHWC output, no gate")
             u = self._pw_x3_weights()
             host_tile, cp = d.tile, d.cout_pad
             d.tile = 64 | (host_tile % 10) | (16 if host_tile >= 70 else 0)      # SGV3D_TILE_X3 | variant [| SGV3D_TILE_MFIRST]
             d.cout_pad = self.pw_x3_cout_pad
             try:
-                return lib.sgv3d_conv1x1_x3_forward(ctypes.byref(d), x.data_ptr(), u.data_ptr(), _lib.ptr(self.scale), _lib.ptr(self.shift),
-                                                    _lib.ptr(residual), out.data_ptr(), _st(x))
+                return lib.sgv3d_conv2d_x3_forward(ctypes.byref(d), x.data_ptr(), u.data_ptr(), _lib.ptr(self.scale), _lib.ptr(self.shift),
+                                                   _lib.ptr(residual), out.data_ptr(), _lib.ptr(ws), nws, _st(x))
             finally:
                 d.tile, d.cout_pad = host_tile, cp
         if d.tile in WINO4_TILES:
@@ -866,7 +872,7 @@ class PackedConv:
             for t in PW_X3_TILES:
                 bm, bn = PW_X3_DIMS[t]
                 wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
-                if wgs >= 96 and (bn == 128 or gemm_n <= 64 or wgs < 1024) and (t < 70 or (MFIRST and gemm_n > bn)):
+                if (wgs >= 96 or (SPLIT_K and nkt >= 16)) and (bn == 128 or gemm_n <= 64 or wgs < 1024) and (t < 70 or (MFIRST and gemm_n > bn)):
                     tiles += (t,)
         if self._patch_eligible(d, gate):
             tiles += (TILE_PATCH,)
@@ -885,6 +891,7 @@ class PackedConv:
         dims = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 64), 6: (256, 64),
                 11: (128, 128), 12: (128, 64), 13: (64, 128), 14: (64, 64),
                 21: (128, 128), 22: (128, 64), 23: (64, 128), 24: (64, 64), 44: (64, 64), 45: (64, 64)}
+        dims.update(PW_X3_DIMS)
         cands = []
         for t in tiles:
             bm, bn = dims.get(t, (512, 64))
@@ -900,7 +907,7 @@ class PackedConv:
                 nk = -(-(self.kh * self.kw * (self.cin // 32)) // 2)      # chunks of 64 k; >= 4 per split
                 bm, bn = {31: (64, 256), 32: (128, 128), 33: (256, 64), 34: (128, 256), 35: (256, 128), 36: (64, 256), 37: (128, 128), 38: (64, 128), 39: (64, 128)}[t]
                 wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
-            if t in (TILE_WINO_RES, TILE_F4RES) or t in WINO4_TILES or t in PW_X3_TILES or t in DW_DEEP_TILES or (t in DW_TILES and (d.mode != CONV_NORMAL or not DW_SPLIT_K)):
+            if t in (TILE_WINO_RES, TILE_F4RES) or t in WINO4_TILES or t in DW_DEEP_TILES or (t in DW_TILES and (d.mode != CONV_NORMAL or not DW_SPLIT_K)):
                 splits = (1,)
             elif t in DW_TILES:
                 splits = (fixed_split,) if fixed_split else \

@@ -586,6 +586,36 @@ def test_pointwise_x3_matches_float64_like_the_f32_kernel(hip, shape, tile):
     assert torch.equal(out, again)                                                                  # deterministic
 
 
+@pytest.mark.parametrize("case", [(1, 128, 30, 44, 128, 3, 2, 1, 1), (2, 64, 17, 19, 96, 3, 1, 1, 1), (1, 256, 16, 24, 512, 1, 2, 0, 1),
+                                  (1, 256, 24, 32, 128, 4, 4, 0, 1), (1, 64, 21, 13, 64, 3, 1, 2, 2), (1, 96, 12, 20, 36, 5, 1, 2, 1),
+                                  (1, 512, 9, 11, 128, 2, 2, 0, 1), (3, 32 * 3, 5, 7, 40, 1, 2, 0, 1)])
+@pytest.mark.parametrize("tile,split", [(60, 1), (61, 1), (62, 1), (65, 1), (71, 1), (76, 1), (60, 2), (64, 3)])
+def test_implicit_gemm_x3_strided_and_multi_tap(hip, case, tile, split):
+    """The same kernel as an implicit GEMM over taps (TAPS = true): strided 3x3 / 1x1, patchify (k == stride), dilated and 5x5
+    layers with ragged maps and padding on every side, with BN / residual / ReLU and split-K, against a float64 convolution and the
+    f32-MFMA kernel (as accurate as it: within 2x its error -- the two kernels add the K products in different orders --, < 3e-6 of
+    the output scale)."""
+    from sgv3d_amd.hip_ops import PackedConv
+    B, cin, H, W, cout, k, stride, pad, dil = case
+    x, w = _conv_case(*case, seed=sum(case))
+    g = torch.Generator().manual_seed(sum(case) + tile)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    conv = PackedConv(w.to(DEV), stride=stride, pad=pad, dil=dil, scale=scale.to(DEV), shift=shift.to(DEV), relu=True)
+    assert conv.pw_x3_ok()
+    OH, OW = conv.out_hw(H, W)
+    res = torch.randn(B, OH, OW, cout, generator=g)
+    if split > 1 and conv.k_pad // 32 < split:
+        pytest.skip("not enough k-steps")
+    want = F.conv2d(x.double(), w.double(), None, stride, pad, dil).permute(0, 2, 3, 1) * scale.double() + shift.double()
+    want = torch.relu(want + res.double())
+    s = float(want.abs().max())
+    y = conv(nhwc(x).to(DEV), residual=res.to(DEV), tile=tile, split_k=split)
+    native = conv(nhwc(x).to(DEV), residual=res.to(DEV), tile=4, split_k=1)
+    err = float((y.cpu().double() - want).abs().max()) / s
+    e_native = float((native.cpu().double() - want).abs().max()) / s
+    assert err <= max(2.0 * e_native, 3e-7) and err < 3e-6, (err, e_native)
+
+
 def test_pointwise_x3_keeps_every_partial_product_and_covers_only_what_it_should(hip):
     """Integer data (exact in f32 on both paths, exact under the three-term split): every tile shape returns the f32 kernel's bits --
     a dropped partial product or a swapped plane shows up as a whole number.  And the launch refuses what the kernel does not cover."""
@@ -600,9 +630,9 @@ def test_pointwise_x3_keeps_every_partial_product_and_covers_only_what_it_should
     assert torch.equal(want.cpu().double(), ref)                          # |sum| < 2^24: exact
     for tile in PW_X3_TILES:
         assert torch.equal(conv(x.to(DEV), tile=tile, split_k=1), want), tile
+    for split in (2, 5):                                                  # split-K: partial sums + fixed-order reduce, still exact here
+        assert torch.equal(conv(x.to(DEV), tile=61, split_k=split), want), split
+    w7 = torch.randn(64, 64, 7, 7)
     with pytest.raises(SGV3DError):
-        conv(x.to(DEV), tile=61, split_k=2)                               # no split-K
-    w3 = torch.randn(64, 64, 3, 3)
-    with pytest.raises(SGV3DError):
-        PackedConv(w3.to(DEV), pad=1)(torch.randn(1, 8, 8, 64, device=DEV), tile=61, split_k=1)     # not a 1x1 layer
+        PackedConv(w7.to(DEV), pad=3)(torch.randn(1, 8, 8, 64, device=DEV), tile=61, split_k=1)     # more than 32 taps
     assert not PackedConv(torch.randn(64, 48, 1, 1).to(DEV)).pw_x3_ok()  # cin % 32 != 0

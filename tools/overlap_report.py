@@ -43,5 +43,5 @@ for k in set(alone) | set(shared):
     tot[k] = alone[k] + shared[k]
 print(f"{'kernel':70s} {'total ms':>9s} {'alone %':>8s} {'avg us':>8s}")
 cnt = collections.Counter(r[2] for r in rows)
-for k, v in tot.most_common(16):
+for k, v in tot.most_common(int(sys.argv[3]) if len(sys.argv) > 3 else 16):
     print(f"{k[:70]:70s} {v / 1e6:9.2f} {100 * alone[k] / v:8.1f} {v / cnt[k] / 1e3:8.1f}")

@@ -23,22 +23,30 @@ def main():
               ("512->2048 @27x48 +res", 512, 2048, 27, 48, True), ("2048->512 @27x48", 2048, 512, 27, 48, False),
               ("2048->512 @54x96", 2048, 512, 54, 96, False), ("512->512 @54x96", 512, 512, 54, 96, False),
               ("1024->512 @54x96", 1024, 512, 54, 96, False), ("512->256 @108x192", 512, 256, 108, 192, False))
-    for name, cin, cout, H, W, with_res in shapes:
+    import torch.nn.functional as F
+    shapes = tuple(s + (1, 1, 0) for s in shapes) + (
+        ("128->128 k3s2 @216x384", 128, 128, 216, 384, False, 3, 2, 1), ("256->256 k3s2 @108x192", 256, 256, 108, 192, False, 3, 2, 1),
+        ("512->512 k3s2 @54x96", 512, 512, 54, 96, False, 3, 2, 1), ("256->512 k1s2 @216x384", 256, 512, 216, 384, False, 1, 2, 0),
+        ("512->1024 k1s2 @108x192", 512, 1024, 108, 192, False, 1, 2, 0), ("1024->2048 k1s2 @54x96", 1024, 2048, 54, 96, False, 1, 2, 0),
+        ("160->320 k3s2 @128x128", 160, 320, 128, 128, False, 3, 2, 1), ("320->640 k3s2 @64x64", 320, 640, 64, 64, False, 3, 2, 1),
+        ("256->128 k4s4 @216x384", 256, 128, 216, 384, False, 4, 4, 0), ("512->128 k2s2 @108x192", 512, 128, 108, 192, False, 2, 2, 0))
+    for name, cin, cout, H, W, with_res, k, st, pd in shapes:
         if only and only not in name:
             continue
         x = torch.randn(1, H, W, cin, generator=g).to(dev)
-        w = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).to(dev)
+        w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)
         sc, sh = (torch.rand(cout, generator=g) + 0.5).to(dev), (torch.randn(cout, generator=g) * 0.2).to(dev)
-        res = torch.randn(1, H, W, cout, generator=g).to(dev) if with_res else None
-        conv = PackedConv(w, scale=sc, shift=sh, relu=True)
-        out = torch.empty(1, H, W, cout, device=dev)
-        want = x.double().reshape(-1, cin) @ w.double().reshape(cout, cin).t() * sc.double() + sh.double()
+        conv = PackedConv(w, stride=st, pad=pd, scale=sc, shift=sh, relu=True)
+        OH, OW = conv.out_hw(H, W)
+        res = torch.randn(1, OH, OW, cout, generator=g).to(dev) if with_res else None
+        out = torch.empty(1, OH, OW, cout, device=dev)
+        want = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), None, st, pd).permute(0, 2, 3, 1) * sc.double() + sh.double()
         if with_res:
-            want = want + res.double().reshape(-1, cout)
-        want = torch.relu(want).reshape(1, H, W, cout)
+            want = want + res.double()
+        want = torch.relu(want)
         scale = float(want.abs().max())
         row = []
-        for t, sk in ((44, 1), (45, 1), (44, 3)) + tuple((t, 1) for t in hip_ops.PW_X3_TILES):
+        for t, sk in ((44, 1), (45, 1), (44, 2), (44, 3), (44, 6)) + tuple((t, sk) for t in hip_ops.PW_X3_TILES for sk in (1, 2, 3, 4, 6)):
             try:
                 fn = lambda: conv(x, out=out, residual=res, tile=t, split_k=sk)
                 fn()
@@ -50,7 +58,7 @@ def main():
         f32 = min(r for r in row if r[1] < 60)
         x3 = sorted(r for r in row if r[1] >= 60)
         print(f"{name:24s} f32 best {f32[0]:6.1f} us (tile {f32[1]} sk{f32[2]}, e={f32[3]:.1e}) | x3: " +
-              " ".join(f"{t}:{us:.1f}" for us, t, _, _ in x3[:5]) + f" | worst x3 err {max(r[3] for r in x3):.1e}", flush=True)
+              " ".join(f"{t}/sk{k}:{us:.1f}" for us, t, k, _ in x3[:5]) + f" | worst x3 err {max(r[3] for r in x3):.1e}", flush=True)
 
 
 if __name__ == "__main__":
