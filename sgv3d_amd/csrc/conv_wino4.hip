@@ -68,6 +68,11 @@ __device__ __forceinline__ void wino4_at(const f4 &m0, const f4 &m1, const f4 &m
     y3 = add4(fma4(8.f, s, q), m5);
 }
 
+// Threads per workgroup of the transform kernels (single-wave workgroups -- 672 instead of 168 for a 512-channel 54x96 layer --
+// measured the same in round 6: the transforms are bound by the latency of their 36 dependent-free loads and 36-108 stores per
+// thread, not by how the waves spread over the CUs).
+constexpr int kTB = 256;
+
 struct Wino4Args {
     const float *x, *scale, *bias, *res;
     float *v, *m, *y;
@@ -94,9 +99,9 @@ __device__ __forceinline__ void wino4_tile(const Wino4Args &a, int t, int &b, in
 }
 
 // one thread: one tile x 4 input channels.  Consecutive threads = consecutive channel quads: 16-byte accesses, contiguous.
-__global__ __launch_bounds__(256) void wino4_input_kernel(const Wino4Args a) {
+__global__ __launch_bounds__(kTB) void wino4_input_kernel(const Wino4Args a) {
     const int cq = a.cin >> 2;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i = (long long)blockIdx.x * kTB + threadIdx.x;
     const long long ntile = (long long)a.batch * a.ty * a.tx * a.dil * a.dil;
     if (i >= ntile * cq) return;
     const int t = (int)(i / cq), c = (int)(i - (long long)t * cq) * 4;
@@ -128,9 +133,9 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const Wino4Args a) {
 }
 
 // one thread: one tile x 4 output channels
-__global__ __launch_bounds__(256) void wino4_output_kernel(const Wino4Args a) {
+__global__ __launch_bounds__(kTB) void wino4_output_kernel(const Wino4Args a) {
     const int cq = a.cn >> 2;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i = (long long)blockIdx.x * kTB + threadIdx.x;
     const long long ntile = (long long)a.batch * a.ty * a.tx * a.dil * a.dil;
     if (i >= ntile * cq) return;
     const int t = (int)(i / cq), cl = (int)(i - (long long)t * cq) * 4;     // cl: column inside the chunk
@@ -230,9 +235,9 @@ __device__ __forceinline__ void split3(const f4 &x, bf16x4 &hi, bf16x4 &mid, bf1
 
 // as wino4_input_kernel, writing V3 [36][rows][cin/32][3][32] bf16: one thread = one tile x 4 input channels -> three 8-byte
 // stores per position (the 8 threads of a 32-channel record fill its three 64-byte planes)
-__global__ __launch_bounds__(256) void wino4_input_x3_kernel(const Wino4Args a) {
+__global__ __launch_bounds__(kTB) void wino4_input_x3_kernel(const Wino4Args a) {
     const int cq = a.cin >> 2;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i = (long long)blockIdx.x * kTB + threadIdx.x;
     const long long ntile = (long long)a.batch * a.ty * a.tx * a.dil * a.dil;
     if (i >= ntile * cq) return;
     const int t = (int)(i / cq), c = (int)(i - (long long)t * cq) * 4;
@@ -427,7 +432,7 @@ extern "C" int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *d, const fl
         SGV3D_REQUIRE(d->cin % 32 == 0 && d->cout_pad % 32 == 0 && d->cout_pad >= d->cout,
                       "conv2d_winograd4_forward: SGV3D_TILE_X3 needs cin %% 32 == 0 and cout_pad (a multiple of 32) of the x3 weights");
         SGV3D_REQUIRE((d->tile & 15) < 10, "conv2d_winograd4_forward: unknown SGV3D_TILE_X3 variant %d", d->tile & 15);
-        hipLaunchKernelGGL(wino4_input_x3_kernel, dim3(cdiv(tiles * (d->cin / 4), 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(wino4_input_x3_kernel, dim3(cdiv(tiles * (d->cin / 4), kTB)), dim3(kTB), 0, st, a);
         const int chunk3 = wino4_chunk(d, a.rows);
         for (int c0 = 0; c0 < d->cout; c0 += chunk3) {
             a.c0 = c0;
@@ -435,11 +440,11 @@ extern "C" int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *d, const fl
             // block p of the chunk's weights: cout_pad rows of cin * 6 bytes after block p - 1, shifted by c0 rows
             if (int rc = conv_gemm_grouped_x3(a.v, static_cast<const unsigned char *>(static_cast<const void *>(u_packed)) + (size_t)c0 * d->cin * 6,
                                               a.m, a.rows, d->cin, a.cn, d->cout_pad - c0, d->tile & 15, st, (size_t)d->cout_pad * d->cin * 6)) return rc;
-            hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(tiles * (a.cn / 4), 256)), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(tiles * (a.cn / 4), kTB)), dim3(kTB), 0, st, a);
         }
         return check_launch("conv2d_winograd4_forward(x3)");
     }
-    hipLaunchKernelGGL(wino4_input_kernel, dim3(cdiv(tiles * (d->cin / 4), 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wino4_input_kernel, dim3(cdiv(tiles * (d->cin / 4), kTB)), dim3(kTB), 0, st, a);
     int tile = (d->tile == SGV3D_TILE_64x128 || d->tile == SGV3D_TILE_32x128 || d->tile == SGV3D_TILE_48x64) ? d->tile
                : (d->tile & SGV3D_TILE_OCC5) ? (SGV3D_TILE_64x64 | SGV3D_TILE_OCC5) : SGV3D_TILE_64x64;
     if (tile == SGV3D_TILE_32x128 && (d->k_order != 1 || d->cin < 128)) tile = SGV3D_TILE_64x64;    // (what the narrow tile covers)
@@ -456,7 +461,7 @@ extern "C" int sgv3d_conv2d_winograd4_forward(const sgv3d_conv_desc *d, const fl
                                              d->cout_pad, st)) return rc;
         } else if (int rc = conv_gemm_grouped(a.v, u_packed + (size_t)c0 * d->k_pad, a.m, a.rows, 36, d->cin, a.cn, d->k_pad,
                                               d->cout_pad, d->k_order, tile, st)) return rc;
-        hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(tiles * (a.cn / 4), 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(tiles * (a.cn / 4), kTB)), dim3(kTB), 0, st, a);
     }
     return check_launch("conv2d_winograd4_forward");
 }
