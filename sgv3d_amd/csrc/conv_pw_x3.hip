@@ -42,6 +42,7 @@ struct PwX3Args {
     unsigned x_bytes, w_bytes;
     // TAPS form (a strided / multi-tap convolution as an implicit GEMM): geometry of the gather
     int in_h, in_w, out_h, out_w, kh, kw, stride, pad, dil;
+    int cin4;              // MODE 2: cin / 4
     int split_k;           // > 1: blockIdx.y owns a slice of the k-steps and stores raw partial sums to ws [split_k][M][N]
     float *ws;
 };
@@ -49,8 +50,12 @@ struct PwX3Args {
 // TAPS = false: pointwise (1x1 / stride 1): the input pixel is the output pixel.  TAPS = true: kh x kw taps (<= 32), any stride /
 // padding / dilation: k-step kt covers 32 channels of ONE tap (kt = chunk * taps + tap, the packed weights' k order); which taps of
 // a row's pixel fall inside the image is a bit mask made once, a k-step costs one bit test and one add per 16-byte chunk.
-template <int MA, int WN, bool TAPS>
+// MODE 2 (tap-major, the weights' k order 0: k = tap * cin + ci, cin % 4 == 0, <= 64 taps): the stems -- 7x7 / stride 2 on the 4-channel
+// image and on the 80-channel BEV map.  A 16-byte chunk is 4 channels of ONE tap; the thread that owns chunk `ach` of a row walks
+// its own (tap, channel) pair from k-step to k-step (q = 8 kt + ach, tap = q / (cin / 4)); validity is a 64-bit mask per row.
+template <int MA, int WN, int MODE>
 __global__ __launch_bounds__(64 * WN, 2) void conv_pw_x3_kernel(const PwX3Args a) {
+    constexpr bool TAPS = MODE == 1, TM = MODE == 2;
     constexpr int NT = 64 * WN, BM = 16 * MA, BN = 32 * WN;
     constexpr int PLANE = BM * 64 + 64;
     constexpr int BUF = 3 * PLANE;
@@ -85,15 +90,31 @@ __global__ __launch_bounds__(64 * WN, 2) void conv_pw_x3_kernel(const PwX3Args a
     const int arow = tid >> 3, ach = tid & 7;
     unsigned xg[PA];
     [[maybe_unused]] unsigned xmask[PA];
+    [[maybe_unused]] unsigned long long xmask64[PA];
     bool a_on[PA];
-    const int taps = TAPS ? a.kh * a.kw : 1;
+    const int taps = (TAPS || TM) ? a.kh * a.kw : 1;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         const int r = arow + RPA * i;
         a_on[i] = (arow & ~7) + RPA * i < BM;                                   // wave-uniform: a wave covers 8 rows
         const bool live = a_on[i] && m0 + r < a.M;
-        if constexpr (!TAPS) {
+        if constexpr (!TAPS && !TM) {
             xg[i] = live ? (unsigned)((((long long)(m0 + r)) * a.x_ld + a.x_coff + ach * 4) * 4) : 0xffffffffu;
+        } else if constexpr (TM) {
+            const int m = live ? m0 + r : 0;
+            const int t = (int)((unsigned)m / (unsigned)a.out_w);
+            const int ow = m - t * a.out_w;
+            const int n = (int)((unsigned)t / (unsigned)a.out_h);
+            const int oh = t - n * a.out_h;
+            const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
+            xg[i] = (unsigned)((((long long)(n * a.in_h + ih0) * a.in_w + iw0) * a.x_ld + a.x_coff) * 4);
+            unsigned long long mk = 0;
+            int tt = 0;
+            for (int th = 0; th < a.kh; ++th) {
+                const bool row_in = live && (unsigned)(ih0 + th * a.dil) < (unsigned)a.in_h;
+                for (int tw = 0; tw < a.kw; ++tw, ++tt) mk |= (row_in && (unsigned)(iw0 + tw * a.dil) < (unsigned)a.in_w) ? (1ull << tt) : 0ull;
+            }
+            xmask64[i] = mk;
         } else {
             const int m = live ? m0 + r : 0;
             const int t = (int)((unsigned)m / (unsigned)a.out_w);
@@ -114,6 +135,9 @@ __global__ __launch_bounds__(64 * WN, 2) void conv_pw_x3_kernel(const PwX3Args a
     }
     // TAPS: the walk over (channel chunk, tap) of the loads, wave-uniform
     [[maybe_unused]] int ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_c0 = 0;
+    // MODE 2: this thread's own walk -- chunk q = 8 kt + ach of the k axis is channels [4 tm_c4, 4 tm_c4 + 4) of tap tm_tap = (tm_kh, tm_kw)
+    [[maybe_unused]] const int cq = a.cin4;
+    [[maybe_unused]] int tm_tap = 0, tm_kh = 0, tm_kw = 0, tm_c4 = 0;
     // LDS: row r, 8-byte piece ach of its 64 bytes: 16-byte chunk (ach >> 1) swizzled, half (ach & 1)
     const unsigned xl = (unsigned)(arow * 64 + ((((ach >> 1) ^ ((-(arow >> 2)) & 3)) << 4) | ((ach & 1) << 3)));
 
@@ -150,13 +174,32 @@ __global__ __launch_bounds__(64 * WN, 2) void conv_pw_x3_kernel(const PwX3Args a
             ld_kw = ld_tap - ld_kh * a.kw;
         }
     }
+    if constexpr (TM) {
+        const int q = kt0 * 8 + ach;
+        tm_tap = q / cq;
+        tm_c4 = q - tm_tap * cq;
+        tm_kh = tm_tap / a.kw;
+        tm_kw = tm_tap - tm_kh * a.kw;
+    }
 
     // (TAPS: called with consecutive KT = 0, 1, 2, ...: the tap walk advances by one per call)
 #define PWX3_LOAD_X(KT)                                                                                   \
     do {                                                                                                  \
-        if constexpr (!TAPS) {                                                                            \
+        if constexpr (!TAPS && !TM) {                                                                     \
             _Pragma("unroll") for (int i = 0; i < PA; ++i)                                                \
                 rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xg[i], (kt0 + (KT)) * 128, 0)); \
+        } else if constexpr (TM) {                                                                        \
+            const unsigned koff_ = (unsigned)((((tm_kh * a.in_w + tm_kw) * a.dil) * a.x_ld + tm_c4 * 4) * 4); \
+            const unsigned long long bit_ = tm_tap < taps ? 1ull << tm_tap : 0ull;     /* (the zero padding of K) */ \
+            _Pragma("unroll") for (int i = 0; i < PA; ++i)                                                \
+                rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                   \
+                    x_rsrc, (xmask64[i] & bit_) ? xg[i] + koff_ : 0xffffffffu, 0, 0));                    \
+            tm_c4 += 8;                                                                                   \
+            while (tm_c4 >= cq) {                                                                         \
+                tm_c4 -= cq;                                                                              \
+                ++tm_tap;                                                                                 \
+                if (++tm_kw == a.kw) { tm_kw = 0; ++tm_kh; }                                              \
+            }                                                                                             \
         } else {                                                                                          \
             const unsigned koff_ = (unsigned)((((ld_kh * a.in_w + ld_kw) * a.dil) * a.x_ld + ld_c0) * 4);  \
             const unsigned bit_ = 1u << ld_tap;                                                           \
@@ -281,15 +324,23 @@ __global__ __launch_bounds__(64 * WN, 2) void conv_pw_x3_kernel(const PwX3Args a
 
 // w [cout][cin][kh][kw] f32 (OIHW) -> U3 [cout_pad / 16][K / 32][3][512] bf16 with k = ((ci / 32) * taps + tap) * 32 + ci % 32
 // (K = taps * cin_pad), zero rows / columns in the padding
+// (k_order 0: k = tap * cin_pad + ci, K padded to a multiple of 32 with zeros: the stems)
 __global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float *__restrict__ w, int cout, int cin, int cin_pad, int cout_pad,
-                                                             int taps, __bf16 *__restrict__ u) {
-    const long long kp = (long long)taps * cin_pad;
+                                                             int taps, int k_order, __bf16 *__restrict__ u) {
+    const long long kp = k_order ? (long long)taps * cin_pad : ((long long)taps * cin_pad + 31) / 32 * 32;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)cout_pad * kp) return;
     const int co = (int)(i / kp), k = (int)(i - (long long)co * kp);
-    const int chunk = k / (32 * taps), rem = k - chunk * 32 * taps;
-    const int tap = rem >> 5, ci = chunk * 32 + (rem & 31);
-    const float v = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * taps + tap] : 0.f;
+    int tap, ci;
+    if (k_order) {
+        const int chunk = k / (32 * taps), rem = k - chunk * 32 * taps;
+        tap = rem >> 5;
+        ci = chunk * 32 + (rem & 31);
+    } else {
+        tap = k / cin_pad;
+        ci = k - tap * cin_pad;
+    }
+    const float v = (co < cout && ci < cin && tap < taps) ? w[((size_t)co * cin + ci) * taps + tap] : 0.f;
     const __bf16 hi = (__bf16)v;
     const float r1 = v - (float)hi;
     const __bf16 mid = (__bf16)r1;
@@ -302,10 +353,11 @@ __global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float *__rest
 }
 
 template <int MA, int WN>
-int launch_pw(const PwX3Args &a, bool taps, hipStream_t st) {
+int launch_pw(const PwX3Args &a, int mode, hipStream_t st) {
     const dim3 grid(a.tiles_m * a.tiles_n, a.split_k > 1 ? a.split_k : 1);
-    if (taps) hipLaunchKernelGGL((conv_pw_x3_kernel<MA, WN, true>), grid, dim3(64 * WN), 0, st, a);
-    else hipLaunchKernelGGL((conv_pw_x3_kernel<MA, WN, false>), grid, dim3(64 * WN), 0, st, a);
+    if (mode == 2) hipLaunchKernelGGL((conv_pw_x3_kernel<MA, WN, 2>), grid, dim3(64 * WN), 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((conv_pw_x3_kernel<MA, WN, 1>), grid, dim3(64 * WN), 0, st, a);
+    else hipLaunchKernelGGL((conv_pw_x3_kernel<MA, WN, 0>), grid, dim3(64 * WN), 0, st, a);
     return check_launch("conv_pw_x3_kernel");
 }
 
@@ -314,12 +366,16 @@ int launch_pw(const PwX3Args &a, bool taps, hipStream_t st) {
 // variant: m-tile {0: 32, 1: 64, 2: 128} pixels, + 4: 64 instead of 128 channels per workgroup
 extern "C" int sgv3d_conv_pack_weight_x3(const float *w_src, int cout, int cin, int kh, int kw, int cin_pad, int cout_pad, void *u3_packed,
                                          void *stream) {
-    SGV3D_REQUIRE(w_src && u3_packed && cout > 0 && cin > 0 && kh > 0 && kw > 0 && kh * kw <= 32 && cin_pad >= cin && cin_pad % 32 == 0 &&
-                      cout_pad >= cout && cout_pad % 32 == 0,
+    // cin_pad % 32 == 0: channel-chunk-major k (k order 1, <= 32 taps); otherwise tap-major k (k order 0: cin_pad % 4 == 0, <= 64 taps,
+    // K = taps * cin_pad rounded up to 32)
+    const int k_order = cin_pad % 32 == 0 ? 1 : 0;
+    SGV3D_REQUIRE(w_src && u3_packed && cout > 0 && cin > 0 && kh > 0 && kw > 0 && kh * kw <= (k_order ? 32 : 64) && cin_pad >= cin &&
+                      cin_pad % 4 == 0 && cout_pad >= cout && cout_pad % 32 == 0,
                   "conv_pack_weight_x3: bad arguments (cout=%d cin=%d k=%dx%d cin_pad=%d cout_pad=%d)", cout, cin, kh, kw, cin_pad, cout_pad);
-    const long long total = (long long)cout_pad * cin_pad * kh * kw;
+    const long long kp = k_order ? (long long)cin_pad * kh * kw : ((long long)cin_pad * kh * kw + 31) / 32 * 32;
+    const long long total = (long long)cout_pad * kp;
     hipLaunchKernelGGL(pack_weight_x3_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w_src, cout, cin, cin_pad, cout_pad,
-                       kh * kw, static_cast<__bf16 *>(u3_packed));
+                       kh * kw, k_order, static_cast<__bf16 *>(u3_packed));
     return check_launch("pack_weight_x3_kernel");
 }
 
@@ -327,10 +383,12 @@ extern "C" int sgv3d_conv2d_x3_forward(const sgv3d_conv_desc *d, const float *x,
                                        const float *bias, const float *residual, float *y, void *workspace, size_t workspace_bytes,
                                        void *stream) {
     SGV3D_REQUIRE(d && x && u3_packed && y, "conv2d_x3_forward: null pointer");
-    SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL && d->kh > 0 && d->kw > 0 && d->kh * d->kw <= 32 && d->stride > 0 && d->dil > 0 && d->pad >= 0,
-                  "conv2d_x3_forward: NHWC output, at most 32 taps");
-    SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->cin % 32 == 0 && d->cout % 4 == 0,
-                  "conv2d_x3_forward: cin %% 32 == 0, cout %% 4 == 0 (cin=%d cout=%d)", d->cin, d->cout);
+    const bool tapmajor = d->cin % 32 != 0;              // the weights' k order 0
+    SGV3D_REQUIRE(d->mode == SGV3D_CONV_NORMAL && d->kh > 0 && d->kw > 0 && d->kh * d->kw <= (tapmajor ? 64 : 32) && d->stride > 0 &&
+                      d->dil > 0 && d->pad >= 0,
+                  "conv2d_x3_forward: NHWC output, at most 32 taps (64 with tap-major weights)");
+    SGV3D_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->cin > 0 && d->cout > 0 && d->cin % 4 == 0 && d->cout % 4 == 0,
+                  "conv2d_x3_forward: cin %% 4 == 0, cout %% 4 == 0 (cin=%d cout=%d)", d->cin, d->cout);
     SGV3D_REQUIRE(d->out_h == (d->in_h + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1 &&
                       d->out_w == (d->in_w + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1,
                   "conv2d_x3_forward: output size does not match the geometry");
@@ -343,12 +401,12 @@ extern "C" int sgv3d_conv2d_x3_forward(const sgv3d_conv_desc *d, const float *x,
                     reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(u3_packed)) & 15) == 0,
                   "conv2d_x3_forward: pointers must be 16-B aligned");
     const long long M = (long long)d->batch * d->out_h * d->out_w;
-    const long long K = (long long)d->kh * d->kw * d->cin;
+    const long long K = tapmajor ? ((long long)d->kh * d->kw * d->cin + 31) / 32 * 32 : (long long)d->kh * d->kw * d->cin;
     const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * 4, wb = (long long)d->cout_pad * K * 6;
     SGV3D_REQUIRE(M < 0x7fffffffLL && xb < 0xf0000000LL && wb < 0xf0000000LL, "conv2d_x3_forward: operands larger than 3.75 GiB");
     const int variant = d->tile & 7;
     SGV3D_REQUIRE((d->tile & SGV3D_TILE_X3) && (variant & 3) < 3, "conv2d_x3_forward: desc.tile = SGV3D_TILE_X3 | variant, variant in {0,1,2,4,5,6}");
-    const bool taps = !(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0);
+    const int taps = tapmajor ? 2 : (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0) ? 0 : 1;      // kernel MODE
     PwX3Args a;
     a.x = x; a.w = u3_packed; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
     a.M = (int)M; a.K = (int)K; a.N = d->cout;
@@ -358,6 +416,7 @@ extern "C" int sgv3d_conv2d_x3_forward(const sgv3d_conv_desc *d, const float *x,
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+    a.cin4 = d->cin / 4;
     const int bm = 32 << (variant & 3), bn = (variant & 4) ? 64 : 128;
     a.tiles_m = (int)cdiv(M, bm);
     a.tiles_n = cdiv(d->cout, bn);

@@ -454,10 +454,13 @@ class PackedConv:
 
     def pw_x3_ok(self, d=None, gate=None, io=0):
         """The implicit-GEMM f32x3 kernel (csrc/conv_pw_x3.hip) covers this layer (and launch): a convolution with at most 32 taps and
-        cin % 32 == 0 -- the 1x1 layers, the strided 3x3 / 1x1 layers between the stages, the patchify layers of the necks --, f32
-        tensors, NHWC output, no gate."""
-        ok = (PW_X3 and not MFMA_BF16 and not MFMA_F32X3 and not self.transposed and self.kh * self.kw <= 32 and gate is None and io == 0
-              and self.k_order == 1 and self.cin % 32 == 0 and self.cout % 4 == 0 and self.cin >= 64)
+        cin % 32 == 0 -- the 1x1 layers, the strided 3x3 / 1x1 layers between the stages, the patchify layers of the necks -- or, with
+        tap-major weights, at most 64 taps and cin % 4 == 0 (the 7x7 stems); f32 tensors, NHWC output, no gate."""
+        taps = self.kh * self.kw
+        shape_ok = ((self.k_order == 1 and self.cin % 32 == 0 and self.cin >= 64 and taps <= 32) or        # channel-chunk-major k
+                    (self.k_order == 0 and self.cin % 4 == 0 and taps <= 64 and taps * self.cin >= 128))   # tap-major k: the 7x7 stems
+        ok = (PW_X3 and not MFMA_BF16 and not MFMA_F32X3 and not self.transposed and gate is None and io == 0 and shape_ok
+              and self.cout % 4 == 0)
         if ok and d is not None:
             ok = (d.mode == CONV_NORMAL and d.x_ld % 4 == 0 and d.x_coff % 4 == 0 and d.y_ld % 4 == 0 and d.y_coff % 4 == 0
                   and d.res_ld % 4 == 0)
@@ -470,7 +473,8 @@ class PackedConv:
             lib = _lib.load()
             w = self._keep                                           # [cout, cin_real, kh, kw] f32 on the device
             cout_pad = (self.cout + 31) // 32 * 32
-            packed = torch.empty(cout_pad // 16, self.kh * self.kw * self.cin // 32, 3, 512, dtype=torch.bfloat16, device=w.device)
+            k_pad = (self.kh * self.kw * self.cin + 31) // 32 * 32
+            packed = torch.empty(cout_pad // 16, k_pad // 32, 3, 512, dtype=torch.bfloat16, device=w.device)
             with torch.cuda.device(w.device):
                 rc = lib.sgv3d_conv_pack_weight_x3(w.data_ptr(), self.cout, int(w.shape[1]), self.kh, self.kw, self.cin, cout_pad,
                                                    packed.data_ptr(), _st(w))
@@ -666,8 +670,8 @@ class PackedConv:
             elif t in PW_X3_TILES:
                 bm, bn = PW_X3_DIMS[t]
                 pw1 = self.kh == 1 and self.kw == 1 and self.stride == 1 and self.pad == 0
-                kk = self.cin * self.kh * self.kw
-                extra = {"symbol": f"conv_pw_x3_kernel<{bm // 16}, {bn // 32}, {'false' if pw1 else 'true'}>",
+                kk = (self.cin * self.kh * self.kw + 31) // 32 * 32
+                extra = {"symbol": f"conv_pw_x3_kernel<{bm // 16}, {bn // 32}, {2 if self.k_order == 0 else 0 if pw1 else 1}>",
                          "mfma_flops": 2.0 * gemm_m * self.cout * kk, "bf16_mfma_flops": 6 * 2.0 * gemm_m * self.cout * kk}
             elif t in WINO4_TILES:
                 # the grouped GEMM of the three-launch F(4x4) path: 36 positions x rows (tiles padded to the GEMM's m-tile)

@@ -588,7 +588,9 @@ def test_pointwise_x3_matches_float64_like_the_f32_kernel(hip, shape, tile):
 
 @pytest.mark.parametrize("case", [(1, 128, 30, 44, 128, 3, 2, 1, 1), (2, 64, 17, 19, 96, 3, 1, 1, 1), (1, 256, 16, 24, 512, 1, 2, 0, 1),
                                   (1, 256, 24, 32, 128, 4, 4, 0, 1), (1, 64, 21, 13, 64, 3, 1, 2, 2), (1, 96, 12, 20, 36, 5, 1, 2, 1),
-                                  (1, 512, 9, 11, 128, 2, 2, 0, 1), (3, 32 * 3, 5, 7, 40, 1, 2, 0, 1)])
+                                  (1, 512, 9, 11, 128, 2, 2, 0, 1), (3, 32 * 3, 5, 7, 40, 1, 2, 0, 1),
+                                  # tap-major weights (cin % 32 != 0, up to 64 taps): the 7x7 stems, and a 3x3 on 20 channels
+                                  (1, 80, 32, 32, 160, 7, 2, 3, 1), (2, 4, 40, 56, 64, 7, 2, 3, 1), (1, 20, 13, 17, 48, 3, 1, 1, 1)])
 @pytest.mark.parametrize("tile,split", [(60, 1), (61, 1), (62, 1), (65, 1), (71, 1), (76, 1), (60, 2), (64, 3)])
 def test_implicit_gemm_x3_strided_and_multi_tap(hip, case, tile, split):
     """The same kernel as an implicit GEMM over taps (TAPS = true): strided 3x3 / 1x1, patchify (k == stride), dilated and 5x5

@@ -29,7 +29,8 @@ def main():
         ("512->512 k3s2 @54x96", 512, 512, 54, 96, False, 3, 2, 1), ("256->512 k1s2 @216x384", 256, 512, 216, 384, False, 1, 2, 0),
         ("512->1024 k1s2 @108x192", 512, 1024, 108, 192, False, 1, 2, 0), ("1024->2048 k1s2 @54x96", 1024, 2048, 54, 96, False, 1, 2, 0),
         ("160->320 k3s2 @128x128", 160, 320, 128, 128, False, 3, 2, 1), ("320->640 k3s2 @64x64", 320, 640, 64, 64, False, 3, 2, 1),
-        ("256->128 k4s4 @216x384", 256, 128, 216, 384, False, 4, 4, 0), ("512->128 k2s2 @108x192", 512, 128, 108, 192, False, 2, 2, 0))
+        ("256->128 k4s4 @216x384", 256, 128, 216, 384, False, 4, 4, 0), ("512->128 k2s2 @108x192", 512, 128, 108, 192, False, 2, 2, 0),
+        ("4->64 k7s2 @864x1536", 4, 64, 864, 1536, False, 7, 2, 3), ("80->160 k7s2 @256x256", 80, 160, 256, 256, False, 7, 2, 3))
     for name, cin, cout, H, W, with_res, k, st, pd in shapes:
         if only and only not in name:
             continue
@@ -46,7 +47,7 @@ def main():
         want = torch.relu(want)
         scale = float(want.abs().max())
         row = []
-        for t, sk in ((44, 1), (45, 1), (44, 2), (44, 3), (44, 6)) + tuple((t, sk) for t in hip_ops.PW_X3_TILES for sk in (1, 2, 3, 4, 6)):
+        for t, sk in ((44, 1), (45, 1), (44, 2), (44, 3), (44, 6), (4, 1), (4, 2), (24, 1), (1, 1), (2, 1)) + tuple((t, sk) for t in hip_ops.PW_X3_TILES for sk in (1, 2, 3, 4, 6)):
             try:
                 fn = lambda: conv(x, out=out, residual=res, tile=t, split_k=sk)
                 fn()
