@@ -1243,7 +1243,7 @@ __global__ void pack_weight_kernel(const float *__restrict__ src, int cout, int 
 }
 
 // SGV3D_SWAP_EPI=1 selects the swapped-operand kernel where it applies (results are bitwise the same either way).  It is NOT the
-// default: measured on the cfg-2 bottleneck layers (tools/swap_epi_probe.py, us per launch alone / with three launches in
+// default: measured on the cfg-2 bottleneck layers (a round-4 probe, retired in round 6; us per launch alone / with three launches in
 // flight) it ties or loses -- 64->256 @216x384 + residual 48.3 -> 55.1 alone, 128->512 @108x192 41.2 / 32.5 -> 43.2 / 34.7,
 // 256->1024 @54x96 37.7 / 28.7 -> 38.8 / 29.0, 512->2048 @27x48 37.8 / 28.4 -> 35.1 / 27.4: a dword store instruction of the
 // unswapped layout writes two full 128-byte row segments, a dwordx4 one of the swapped layout 32 bytes to each of 32 rows, and
@@ -1309,7 +1309,7 @@ int launch_t(const ConvArgs &a, hipStream_t st) {
                         (a.mode & kConvModeMask) != SGV3D_CONV_DECONV && a.cin >= 128 && pointwise_kernel_enabled();
         // (cin >= 128: with two k-tiles -- the 64 -> 256 expanders at 216x384, HBM-bound -- the generic kernel's longer
         //  prologue spreads the residual and output traffic better: 47.8 vs 53.5 us alone, 42.6 vs 43.7 with three in flight;
-        //  everywhere else the specialisation wins 3-6 %: tools/swap_epi_probe.py)
+        //  everywhere else the specialisation wins 3-6 %: the same probe)
         if (pw) {
             static PerDeviceSize lds_set_pw;
             if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&conv_igemm_kernel<WTM, WTN, true, false, true>), lds, lds_set_pw))

@@ -169,6 +169,19 @@ def do_eval(gt_annos, dt_annos, current_classes, min_overlaps, eval_types=('bbox
 _CLASS_TO_NAME = {0: 'Car', 1: 'Pedestrian', 2: 'Cyclist', 3: 'Bus', 4: 'Person_sitting'}
 
 
+class _Metric:
+    """One line kind of the report: its label in the text, its key in the result dictionary (None: text only), the AP array
+    [class, difficulty, strict | loose] and the number of digits it is printed with."""
+    __slots__ = ('label', 'key', 'values', 'digits')
+
+    def __init__(self, label, key, values, digits):
+        self.label, self.key, self.values, self.digits = label, key, values, digits
+
+
+def _row(head, triple, digits):
+    return head + ', '.join(f'{float(v):.{digits}f}' for v in triple)
+
+
 def kitti_eval(gt_annos, dt_annos, current_classes, eval_types=('bbox', 'bev', '3d'), metric="R40"):
     """-> (result text, dict of 'KITTI/<class>_<3D|BEV|2D>_<difficulty>_<strict|loose>' and 'KITTI/Overall_*' values)."""
     eval_types = list(eval_types)
@@ -191,50 +204,26 @@ def kitti_eval(gt_annos, dt_annos, current_classes, eval_types=('bbox', 'bev', '
     if compute_aos and 'aos' not in eval_types:
         eval_types.append('aos')
     mAPbbox, mAPbev, mAP3d, mAPaos = do_eval(gt_annos, dt_annos, current_classes, min_overlaps, eval_types, metric=metric)
-    result = ''
-    ret_dict = {}
-    difficulty = ['easy', 'moderate', 'hard']
+    # The report is the wire format the AP text is compared on (evaluators/kitti_utils/eval.py:722-781): one table says which
+    # metrics exist, in which order, under which label and dictionary key, with how many digits
+    table = [m for m in (_Metric('bbox', '2D', mAPbbox, 4), _Metric('bev ', 'BEV', mAPbev, 4), _Metric('3d  ', '3D', mAP3d, 4),
+                         _Metric('aos ', None, mAPaos if compute_aos else None, 2)) if m.values is not None]
+    difficulty = ('easy', 'moderate', 'hard')
+    lines, ret_dict = [], {}
     for j, curcls in enumerate(current_classes):
         name = _CLASS_TO_NAME[curcls]
-        for i in range(min_overlaps.shape[0]):
-            result += '{} AP@{:.2f}, {:.2f}, {:.2f}:\n'.format(name, *min_overlaps[i, :, j])
-            if mAPbbox is not None:
-                result += 'bbox AP:{:.4f}, {:.4f}, {:.4f}\n'.format(*mAPbbox[j, :, i])
-            if mAPbev is not None:
-                result += 'bev  AP:{:.4f}, {:.4f}, {:.4f}\n'.format(*mAPbev[j, :, i])
-            if mAP3d is not None:
-                result += '3d   AP:{:.4f}, {:.4f}, {:.4f}\n'.format(*mAP3d[j, :, i])
-            if compute_aos:
-                result += 'aos  AP:{:.2f}, {:.2f}, {:.2f}\n'.format(*mAPaos[j, :, i])
-            for idx in range(3):
-                postfix = f'{difficulty[idx]}_strict' if i == 0 else f'{difficulty[idx]}_loose'
-                prefix = f'KITTI/{name}'
-                if mAP3d is not None:
-                    ret_dict[f'{prefix}_3D_{postfix}'] = mAP3d[j, idx, i]
-                if mAPbev is not None:
-                    ret_dict[f'{prefix}_BEV_{postfix}'] = mAPbev[j, idx, i]
-                if mAPbbox is not None:
-                    ret_dict[f'{prefix}_2D_{postfix}'] = mAPbbox[j, idx, i]
+        for i, kind in enumerate(('strict', 'loose')[:min_overlaps.shape[0]]):
+            lines.append(_row(f'{name} AP@', min_overlaps[i, :, j], 2) + ':')
+            lines += [_row(f'{m.label} AP:', m.values[j, :, i], m.digits) for m in table]
+            # (dictionary order of the reference: per difficulty 3D, BEV, 2D)
+            for idx, diff in enumerate(difficulty):
+                for m in sorted((m for m in table if m.key), key=lambda m: ('3D', 'BEV', '2D').index(m.key)):
+                    ret_dict[f'KITTI/{name}_{m.key}_{diff}_{kind}'] = m.values[j, idx, i]
     if len(current_classes) > 1:                                          # :756-779
-        result += '\nOverall AP@{}, {}, {}:\n'.format(*difficulty)
-        if mAPbbox is not None:
-            mAPbbox = mAPbbox.mean(axis=0)
-            result += 'bbox AP:{:.4f}, {:.4f}, {:.4f}\n'.format(*mAPbbox[:, 0])
-        if mAPbev is not None:
-            mAPbev = mAPbev.mean(axis=0)
-            result += 'bev  AP:{:.4f}, {:.4f}, {:.4f}\n'.format(*mAPbev[:, 0])
-        if mAP3d is not None:
-            mAP3d = mAP3d.mean(axis=0)
-            result += '3d   AP:{:.4f}, {:.4f}, {:.4f}\n'.format(*mAP3d[:, 0])
-        if compute_aos:
-            mAPaos = mAPaos.mean(axis=0)
-            result += 'aos  AP:{:.2f}, {:.2f}, {:.2f}\n'.format(*mAPaos[:, 0])
-        for idx in range(3):
-            postfix = f'{difficulty[idx]}'
-            if mAP3d is not None:
-                ret_dict[f'KITTI/Overall_3D_{postfix}'] = mAP3d[idx, 0]
-            if mAPbev is not None:
-                ret_dict[f'KITTI/Overall_BEV_{postfix}'] = mAPbev[idx, 0]
-            if mAPbbox is not None:
-                ret_dict[f'KITTI/Overall_2D_{postfix}'] = mAPbbox[idx, 0]
-    return result, ret_dict
+        lines.append('\nOverall AP@' + ', '.join(difficulty) + ':')
+        means = [_Metric(m.label, m.key, m.values.mean(axis=0), m.digits) for m in table]
+        lines += [_row(f'{m.label} AP:', m.values[:, 0], m.digits) for m in means]
+        for idx, diff in enumerate(difficulty):
+            for m in sorted((m for m in means if m.key), key=lambda m: ('3D', 'BEV', '2D').index(m.key)):
+                ret_dict[f'KITTI/Overall_{m.key}_{diff}'] = m.values[idx, 0]
+    return ''.join(line + '\n' for line in lines), ret_dict

@@ -26,18 +26,41 @@ from ..layers.heads.bev_height_head import BEVHeightHead
 
 __all__ = ['BEVHeight']
 
-# Bumped whenever ANY nn.Module in the process registers a parameter, a buffer or a sub-module (torch's global registration
-# hooks; they also fire for attribute assignment and for load_state_dict(assign=True)): BEVHeight._stamp redoes its walk.
+# Bumped whenever a module that belongs to a LIVE BEVHeight tree registers a parameter, a buffer or a sub-module (torch's global
+# registration hooks; they also fire for attribute assignment and for load_state_dict(assign=True)): BEVHeight._stamp redoes its walk.
+# The hooks are process-wide by torch's design, so they are installed with the first BEVHeight instance, removed with the last, and
+# ignore every module that is not in such a tree (`_TRACKED`: ids of the modules of the live instances' last walks; a module that
+# is attached to a tree later announces itself through the registration on its -- tracked -- parent).
 _REGISTRATIONS = [0]
+_TRACKED = set()
+_LIVE = weakref.WeakSet()
+_HOOKS = []
 
 
 def _count_registration(module, name, value):
-    _REGISTRATIONS[0] += 1
+    if id(module) in _TRACKED:
+        _REGISTRATIONS[0] += 1
 
 
-nn.modules.module.register_module_parameter_registration_hook(_count_registration)
-nn.modules.module.register_module_buffer_registration_hook(_count_registration)
-nn.modules.module.register_module_module_registration_hook(_count_registration)
+def _install_hooks():
+    if not _HOOKS:
+        _HOOKS.extend([nn.modules.module.register_module_parameter_registration_hook(_count_registration),
+                       nn.modules.module.register_module_buffer_registration_hook(_count_registration),
+                       nn.modules.module.register_module_module_registration_hook(_count_registration)])
+
+
+def _instance_gone():
+    """A BEVHeight instance was collected: with no instance left the hooks go; otherwise the tracked set is rebuilt by the
+    survivors' next walks."""
+    _TRACKED.clear()
+    alive = list(_LIVE)                   # (iteration skips the dying instance: its weak references are cleared already)
+    if not alive:
+        for h in _HOOKS:
+            h.remove()
+        _HOOKS.clear()
+    else:
+        for m in alive:
+            m._flat_dirty = True
 
 
 class BEVHeight(nn.Module):
@@ -69,6 +92,9 @@ class BEVHeight(nn.Module):
             with open(checkpoint, "rb") as f:
                 state_dict = torch.load(f, map_location='cpu')
             self.backbone.load_state_dict(self.get_backbone(state_dict))
+        _LIVE.add(self)
+        _install_hooks()
+        weakref.finalize(self, _instance_gone)
 
     @staticmethod
     def get_backbone(state_dict):
@@ -90,8 +116,9 @@ class BEVHeight(nn.Module):
         or a tensor object replaced inside a dict (a sub-module's own ``.to()`` / ``.half()``, ``_buffers[...] = ...``) the
         second.  Objects registered through ``nn.Module``'s own entry points -- ``m.weight = nn.Parameter(...)``,
         ``register_parameter`` / ``register_buffer``, a sub-module assigned, any ``load_state_dict(assign=True)`` from here, a
-        sub-module or a parent (Lightning) -- bump a process-wide registration counter (torch's global registration hooks,
-        ``_REGISTRATIONS``) and the walk is redone on the NEXT forward: no window of stale weights.  ``_apply`` / ``load_state_dict``
+        sub-module or a parent (Lightning) -- on a module of this tree bump a registration counter (torch's global registration
+        hooks, installed while a BEVHeight instance lives and deaf to every other module; ``_REGISTRATIONS``) and the walk is redone
+        on the NEXT forward: no window of stale weights.  ``_apply`` / ``load_state_dict``
         / ``train()`` of this module drop the walk themselves.  What no hook sees -- a sub-module swapped by writing into a
         ``_modules`` dict directly -- is caught by the full walk every ``_RESTAMP_EVERY`` forwards."""
         walk = self._flat
@@ -101,6 +128,7 @@ class BEVHeight(nn.Module):
             if walk is None or len(mods) != len(walk[0]) or any(a is not b for a, b in zip(mods, walk[0])):
                 self._flat_gen += 1                 # another module tree: never equal to an earlier stamp
             self._flat = walk = (mods, dicts)
+            _TRACKED.update(id(m) for m in mods)          # (the registration hooks listen to these modules only)
             self._flat_age, self._flat_dirty = 0, False
             self._flat_reg = _REGISTRATIONS[0]
         self._flat_age += 1

@@ -119,3 +119,31 @@ def test_compiled_stamp_helper_equals_the_python_loop():
     m.backbone.height_net.bn._buffers['running_var'] = m.backbone.height_net.bn.running_var.clone()
     s2 = both()
     assert s0 != s1 != s2
+
+
+def test_registration_hooks_listen_to_bevheight_trees_only():
+    """The registration hooks are torch-global: they exist only while a BEVHeight instance lives, and constructing or editing an
+    unrelated nn.Module does not move the counter (rounds 4-5 installed them at import and counted every registration of the
+    process)."""
+    import gc
+    from sgv3d_amd.models import bev_height as BH
+    gc.collect()
+    m = _model()
+    m._stamp()                                              # (the walk announces this tree's modules to the hooks)
+    assert len(BH._HOOKS) == 3
+    n0 = BH._REGISTRATIONS[0]
+    other = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8))      # ~10 registrations, none of them ours
+    other[0].weight = torch.nn.Parameter(torch.zeros(8, 3, 3, 3))
+    other.register_buffer("extra", torch.zeros(1))
+    assert BH._REGISTRATIONS[0] == n0
+    m.head.shared_conv.conv.weight = torch.nn.Parameter(m.head.shared_conv.conv.weight.data.clone())
+    assert BH._REGISTRATIONS[0] == n0 + 1                   # ours: counted
+    m.backbone.add_module("probe", other)                   # an unrelated module attached to the tree: the parent announces it
+    assert BH._REGISTRATIONS[0] == n0 + 2
+    a = m._stamp()                                          # (the walk now tracks the attached modules too)
+    other[1].register_buffer("late", torch.zeros(2))
+    assert BH._REGISTRATIONS[0] == n0 + 3 and m._stamp() != a
+    del m, other, a
+    gc.collect()
+    if not list(BH._LIVE):                                  # (other tests' models may still be alive in this process)
+        assert BH._HOOKS == [] and not BH._TRACKED
