@@ -363,7 +363,7 @@ int launch_pw(const PwX3Args &a, int mode, hipStream_t st) {
 
 }  // namespace
 
-// variant: m-tile {0: 32, 1: 64, 2: 128} pixels, + 4: 64 instead of 128 channels per workgroup
+// variant: m-tile {0: 32, 1: 64, 2: 128} pixels, + 4: 64 / + 8: 256 instead of 128 channels per workgroup (2 / 8 waves)
 extern "C" int sgv3d_conv_pack_weight_x3(const float *w_src, int cout, int cin, int kh, int kw, int cin_pad, int cout_pad, void *u3_packed,
                                          void *stream) {
     // cin_pad % 32 == 0: channel-chunk-major k (k order 1, <= 32 taps); otherwise tap-major k (k order 0: cin_pad % 4 == 0, <= 64 taps,
@@ -404,8 +404,9 @@ extern "C" int sgv3d_conv2d_x3_forward(const sgv3d_conv_desc *d, const float *x,
     const long long K = tapmajor ? ((long long)d->kh * d->kw * d->cin + 31) / 32 * 32 : (long long)d->kh * d->kw * d->cin;
     const long long xb = (long long)d->batch * d->in_h * d->in_w * d->x_ld * 4, wb = (long long)d->cout_pad * K * 6;
     SGV3D_REQUIRE(M < 0x7fffffffLL && xb < 0xf0000000LL && wb < 0xf0000000LL, "conv2d_x3_forward: operands larger than 3.75 GiB");
-    const int variant = d->tile & 7;
-    SGV3D_REQUIRE((d->tile & SGV3D_TILE_X3) && (variant & 3) < 3, "conv2d_x3_forward: desc.tile = SGV3D_TILE_X3 | variant, variant in {0,1,2,4,5,6}");
+    const int variant = d->tile & 15;
+    SGV3D_REQUIRE((d->tile & SGV3D_TILE_X3) && (variant & 3) < 3 && (variant & 12) != 12,
+                  "conv2d_x3_forward: desc.tile = SGV3D_TILE_X3 | variant, variant in {0,1,2, 4,5,6, 8,9,10}");
     const int taps = tapmajor ? 2 : (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0) ? 0 : 1;      // kernel MODE
     PwX3Args a;
     a.x = x; a.w = u3_packed; a.scale = scale; a.bias = bias; a.res = residual; a.y = y;
@@ -417,7 +418,7 @@ extern "C" int sgv3d_conv2d_x3_forward(const sgv3d_conv_desc *d, const float *x,
     a.in_h = d->in_h; a.in_w = d->in_w; a.out_h = d->out_h; a.out_w = d->out_w;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
     a.cin4 = d->cin / 4;
-    const int bm = 32 << (variant & 3), bn = (variant & 4) ? 64 : 128;
+    const int bm = 32 << (variant & 3), bn = (variant & 8) ? 256 : (variant & 4) ? 64 : 128;
     a.tiles_m = (int)cdiv(M, bm);
     a.tiles_n = cdiv(d->cout, bn);
     hipStream_t st = as_stream(stream);
@@ -438,7 +439,10 @@ extern "C" int sgv3d_conv2d_x3_forward(const sgv3d_conv_desc *d, const float *x,
         case 2: rc = launch_pw<8, 4>(a, taps, st); break;
         case 4: rc = launch_pw<2, 2>(a, taps, st); break;
         case 5: rc = launch_pw<4, 2>(a, taps, st); break;
-        default: rc = launch_pw<8, 2>(a, taps, st); break;
+        case 6: rc = launch_pw<8, 2>(a, taps, st); break;
+        case 8: rc = launch_pw<2, 8>(a, taps, st); break;
+        case 9: rc = launch_pw<4, 8>(a, taps, st); break;
+        default: rc = launch_pw<8, 8>(a, taps, st); break;
     }
     if (rc != SGV3D_OK || a.split_k <= 1) return rc;
     // second stage: fixed-order sum of the partials + folded BN / bias, residual, ReLU (conv_igemm.hip)

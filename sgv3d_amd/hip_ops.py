@@ -158,6 +158,7 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x128", 4: "64x64", 5: "wino", 6: 
               55: "wino4_x3", 56: "wino4_x3", 57: "wino4_x3", 58: "wino4_x3", 59: "wino4_x3",    # (csrc/gemm_x3_grouped.hip), by tile shape
               60: "pw_x3", 61: "pw_x3", 62: "pw_x3", 64: "pw_x3", 65: "pw_x3", 66: "pw_x3",      # pointwise f32x3 (csrc/conv_pw_x3.hip)
               70: "pw_x3", 71: "pw_x3", 72: "pw_x3", 74: "pw_x3", 75: "pw_x3", 76: "pw_x3",      # ... walked m-tile first
+              80: "pw_x3", 81: "pw_x3", 82: "pw_x3", 90: "pw_x3", 91: "pw_x3", 92: "pw_x3",      # ... 256 channels per workgroup
               44: "64x64", 45: "64x64",    # the 64x64 tile at five workgroups per CU (SGV3D_TILE_OCC5); 45: walked m-tile first
               46: "wino4"}                 # F(4x4,3x3) in three launches with the five-per-CU 64x64 GEMM tile
 MFIRST = _os.environ.get("SGV3D_MFIRST", "1") != "0"
@@ -185,8 +186,8 @@ WINO4_X3 = _os.environ.get("SGV3D_WINO4_X3", "1") != "0"
 # bf16 terms by the packer, activations on their way into LDS).  Host ids 60 + v / 70 + v (m-tile first): v & 3 = {0: 32, 1: 64, 2: 128}
 # pixels per workgroup, v & 4: 64 instead of 128 channels.  0: never a candidate.
 PW_X3 = _os.environ.get("SGV3D_PW_X3", "1") != "0"
-PW_X3_TILES = (60, 61, 62, 64, 65, 66, 70, 71, 72, 74, 75, 76)
-PW_X3_DIMS = {t: (32 << ((t % 10) & 3), 64 if (t % 10) & 4 else 128) for t in PW_X3_TILES}
+PW_X3_TILES = (60, 61, 62, 64, 65, 66, 70, 71, 72, 74, 75, 76, 80, 81, 82, 90, 91, 92)    # 8x / 9x: 256 channels per workgroup (8 waves)
+PW_X3_DIMS = {t: (32 << ((t % 10) & 3), 256 if t >= 80 else 64 if (t % 10) & 4 else 128) for t in PW_X3_TILES}
 # F(4x4,3x3) in ONE launch with V = B^T d B of a 16x16 block resident in LDS (csrc/head_wino4.hip: conv_f4res_kernel): 3x3 /
 # stride 1 / pad 1 layers with 64 input channels (ResNet layer 1) or 64 output channels (the CenterHead's shared layer), f32
 TILE_F4RES = 40
@@ -758,7 +759,8 @@ class PackedConv:
                                       "NHWC output, no gate")
             u = self._pw_x3_weights()
             host_tile, cp = d.tile, d.cout_pad
-            d.tile = 64 | (host_tile % 10) | (16 if host_tile >= 70 else 0)      # SGV3D_TILE_X3 | variant [| SGV3D_TILE_MFIRST]
+            # SGV3D_TILE_X3 | variant [| SGV3D_TILE_MFIRST]: 6x / 7x: variant = t % 10; 8x / 9x: 8 + t % 10 (256-channel tiles)
+            d.tile = 64 | ((host_tile % 10) + (8 if host_tile >= 80 else 0)) | (16 if host_tile // 10 in (7, 9) else 0)
             d.cout_pad = self.pw_x3_cout_pad
             try:
                 return lib.sgv3d_conv2d_x3_forward(ctypes.byref(d), x.data_ptr(), u.data_ptr(), _lib.ptr(self.scale), _lib.ptr(self.shift),
@@ -876,7 +878,10 @@ class PackedConv:
             for t in PW_X3_TILES:
                 bm, bn = PW_X3_DIMS[t]
                 wgs = -(-gemm_m // bm) * -(-gemm_n // bn)
-                if (wgs >= 96 or (SPLIT_K and nkt >= 16)) and (bn == 128 or gemm_n <= 64 or wgs < 1024) and (t < 70 or (MFIRST and gemm_n > bn)):
+                mfirst = t // 10 in (7, 9)
+                if bn == 256 and gemm_n < 256:
+                    continue
+                if (wgs >= 96 or (SPLIT_K and nkt >= 16)) and (bn >= 128 or gemm_n <= 64 or wgs < 1024) and (not mfirst or (MFIRST and gemm_n > bn)):
                     tiles += (t,)
         if self._patch_eligible(d, gate):
             tiles += (TILE_PATCH,)
