@@ -22,8 +22,8 @@ for it in range(N):
     stride = rng.choice([1, 1, 1, 2])
     dil = rng.choice([1, 1, 1, 2, 3]) if k == 3 else 1
     pad = rng.choice([0, (k // 2) * dil, (k // 2) * dil])
-    cin = rng.choice([4, 8, 16, 32, 40, 64, 96, 128, 160])
-    cout = rng.choice([1, 3, 8, 20, 64, 70, 128, 200])
+    cin = rng.choice([4, 8, 16, 32, 40, 64, 96, 128, 160, 256])
+    cout = rng.choice([1, 3, 8, 20, 64, 70, 128, 200, 288])
     B = rng.choice([1, 1, 2, 3])
     H, W = rng.randint(7, 48), rng.randint(7, 70)
     if (H + 2 * pad - dil * (k - 1) - 1) < 0 or (W + 2 * pad - dil * (k - 1) - 1) < 0:
@@ -58,9 +58,15 @@ for it in range(N):
         cands += [(TILE_WINO, 1), (TILE_WINO, 2), (TILE_WINO, 3), (TILE_WINO_HALF, 1), (TILE_WINO_HALF, 2), (TILE_WINO_HALF, 3)]
         if cin <= 96:
             cands.append((TILE_WINO_RES, 1))
+    # round 6: the f32x3 kernels -- implicit GEMM (tiles 60-92 x split-K, csrc/conv_pw_x3.hip) and the F(4x4) position GEMM (50-59)
+    if MODE == "f32" and not use_gate and cout % 4 == 0:
+        if conv.pw_x3_ok():
+            cands += [(t, s) for t in hip_ops.PW_X3_TILES for s in (1, 2, 3) if t < 80 or cout >= 256]
+        if conv.wino4_ok():
+            cands += [(t, 1) for t in hip_ops.WINO4_X3_TILES]
     scale_ref = max(1.0, ref.abs().max().item())
     for t, s in cands:
-        nk = conv.k_pad // 32 if (t < TILE_WINO or t > 20) else cin // 8      # (Winograd variants: k-steps of 8 channels)
+        nk = (cin * k * k + 31) // 32 if t in hip_ops.PW_X3_TILES else conv.k_pad // 32 if (t < TILE_WINO or t > 20) else cin // 8      # (Winograd variants: k-steps of 8 channels)
         if s > nk:
             continue
         out = torch.full((B, OH, OW, cout + y_extra), -7.0, device="cuda")
