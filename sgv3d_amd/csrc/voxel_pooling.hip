@@ -2346,12 +2346,13 @@ bool level1_enabled() {
 }
 
 void level1_free(Level1Entry &e) {
+    // (best effort on a teardown path: the return codes have nobody to go to)
     int cur = 0;
-    hipGetDevice(&cur);
-    hipSetDevice(e.dev);
-    if (e.plan) hipFree(e.plan);
-    if (e.host_flag) hipHostFree(e.host_flag);
-    hipSetDevice(cur);
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(e.dev);
+    if (e.plan) (void)hipFree(e.plan);
+    if (e.host_flag) (void)hipHostFree(e.host_flag);
+    (void)hipSetDevice(cur);
 }
 
 int launch_atomic(int B, int N, int C, int X, int Y, int Z, const int32_t *geom, const float *feats, float *out,
@@ -2406,7 +2407,7 @@ int level1_forward(int batch_size, int num_points, int num_channels, int num_vox
     if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
     const bool capturing = cap != hipStreamCaptureStatusNone;
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     Level1Entry *e = nullptr;
     for (auto &c : g_l1)
         if (c.dev == dev && c.st == st && c.B == B && c.N == N && c.X == X && c.Y == Y && c.Z == Z) e = &c;
@@ -2549,7 +2550,7 @@ extern "C" int sgv3d_voxel_pooling_select_kernel(int which) {
 
 extern "C" int sgv3d_voxel_pooling_cache_clear(void) {
     std::lock_guard<std::mutex> lock(g_l1_mutex);
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     std::vector<Level1Entry> kept;
     for (auto &e : g_l1) {
         if (e.pinned) kept.push_back(e);        // a captured graph holds its pointers (see Level1Entry::pinned)

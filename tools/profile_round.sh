@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 # the small summaries tools/summarize_profiles.py makes of it go to gpurun_out/profiles_<tag>/ and from there, by hand, to profiles/
 OUT=/tmp/sgv3d_profiles_$TAG
 KEEP=$R/gpurun_out/profiles_$TAG
-PARTS=${PARTS:-ab}      # a = bench line, kernel traces, PMC passes (steps 1-3b); b = voxel pooling, harness, gather probe (4-6); the
+PARTS=${PARTS:-abc}     # a = bench line, kernel traces, PMC passes (steps 1-3b); b = voxel pooling, harness, gather probe (4-6); c = bf16 configs (7); the
                         # summaries are made at the end of every call from whatever raw files are there (gpurun calls are <= 20 min)
 if [[ $PARTS == *a* ]]; then rm -rf $OUT; fi
 mkdir -p $OUT $KEEP
@@ -25,6 +25,11 @@ echo "[profile_round] $(date +%H:%M:%S) 2. kernel trace + stats of the same comm
 #    per-kernel durations are those of the kernels alone (with 3 frames in flight concurrent kernels stretch each
 #    other) and compare directly with roofline.avg_launch_us of the bench line, which is measured the same way.
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-plan-timing --no-other-configs --no-harness --streams 1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err
+# 2r. the ROOFLINE population alone: bench.py --roofline-only = warm-up + the instrumented pass, one stream, eager launches from the
+#     first to the last forward -- the per-symbol averages of this trace are over exactly the launches roofline.frac is made of
+#     (bench.py pairs its own flops per launch with this file: roofline.frac_from_rocprof)
+echo "[profile_round] $(date +%H:%M:%S) 2r. bench.py --roofline-only under the kernel trace" | tee -a $KEEP/progress.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench_roofline -- python3 $R/bench.py --roofline-only --steps 20 --warmup 3 > $OUT/${TAG}_bench_roofline_under_rocprof.json 2> $OUT/rocprof_roofline.err
 # 2b. the HEADLINE command itself (three frames in flight) under the kernel trace: concurrent kernels stretch each other,
 echo "[profile_round] $(date +%H:%M:%S) 2b. the HEADLINE command itself (three frames in flight) u" | tee -a $KEEP/progress.log
 #     so these per-kernel durations are "under load" figures, not comparable with roofline.avg_launch_us
@@ -43,6 +48,16 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o ${TAG}_
 # 3b. MFMA utilisation counters (own pass; SQ counters fit one pass)
 echo "[profile_round] $(date +%H:%M:%S) 3b. MFMA utilisation counters (own pass; SQ counters fit o" | tee -a $KEEP/progress.log
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -o ${TAG}_pmc_mfma -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs --no-harness --streams 1 > /dev/null 2> $OUT/pmc_mfma.err
+fi
+if [[ $PARTS == *c* ]]; then
+# 7. the bf16 configurations: one frame in flight under the kernel trace (cfg-3 batch 4, cfg-5 batch 1), and their per-layer tables
+echo "[profile_round] $(date +%H:%M:%S) 7. bf16 cfg-3 / cfg-5 kernel traces and layer tables" | tee -a $KEEP/progress.log
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench_cfg3_bf16 -- python3 $R/bench.py --sub --config cfg3 --batch 4 --dtype bf16 --steps 12 --warmup 3 --streams 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_cfg3_bf16_under_rocprof.json 2> $OUT/cfg3.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench_cfg5_bf16 -- python3 $R/bench.py --sub --config cfg5 --batch 1 --dtype bf16 --steps 30 --warmup 3 --streams 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_cfg5_bf16_under_rocprof.json 2> $OUT/cfg5.err
+CONFIG=cfg3 DTYPE=bf16 BATCH=4 python3 $R/tools/layer_report.py > $OUT/${TAG}_layers_cfg3_bf16_b4.txt 2> $OUT/layers_cfg3.err
+CONFIG=cfg5 DTYPE=bf16 BATCH=1 python3 $R/tools/layer_report.py > $OUT/${TAG}_layers_cfg5_bf16_b1.txt 2> $OUT/layers_cfg5.err
 fi
 if [[ $PARTS == *b* ]]; then
 # 4. voxel pooling micro-benchmark (the HBM-bound headline kernel) + its trace and traffic

@@ -38,7 +38,9 @@ for f in (f"{tag}_bench.json", f"{tag}_bench_kernel_stats.csv", f"{tag}_vp_kerne
           f"{tag}_wino4_kernel_stats.csv", f"{tag}_bench_cfg3_bf16_b4.json", f"{tag}_bench_cfg5_bf16.json",
           f"{tag}_bench_cfg5_bf16_b4.json", f"{tag}_bench_cfg3_fp32_b4.json", f"{tag}_bench_cfg5.json",
           f"{tag}_bench_cfg3_bf16_kernel_stats.csv", f"{tag}_harness_phases.txt", f"{tag}_harness_kernel_stats.csv",
-          f"{tag}_gather_probe.txt"):
+          f"{tag}_gather_probe.txt", f"{tag}_bench_roofline_kernel_stats.csv", f"{tag}_bench_roofline_under_rocprof.json",
+          f"{tag}_bench_cfg5_bf16_kernel_stats.csv", f"{tag}_bench_cfg3_bf16_under_rocprof.json", f"{tag}_bench_cfg5_bf16_under_rocprof.json",
+          f"{tag}_layers_cfg3_bf16_b4.txt", f"{tag}_layers_cfg5_bf16_b1.txt"):
     p = os.path.join(src, f)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f))
@@ -69,7 +71,7 @@ if os.path.exists(mfma_csv):
     seen = collections.defaultdict(set)
     for r in csv.DictReader(open(mfma_csv)):
         k = short(r["Kernel_Name"])
-        if not k.startswith(("conv_", "head_wino4_kernel", "head_bf16", "gemm16_grouped", "dcn3x3")):      # the MFMA kernels
+        if not k.startswith(("conv_", "head_wino4_kernel", "head_bf16", "gemm16_grouped", "gemm_x3_grouped", "dcn3x3")):      # the MFMA kernels
             continue
         per[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Dispatch_Id"] not in seen[k]:
