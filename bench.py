@@ -202,7 +202,8 @@ def load_rocprof_roofline(symbol):
             for row in csv.DictReader(f):
                 if symbol + "(" in row["Name"]:
                     return {"avg_ns": float(row["AverageNs"]), "calls": int(row["Calls"]), "file": os.path.relpath(files[-1], ROOT),
-                            "launches_per_step": float(rl["launches_per_step"])}
+                            "launches_per_step": float(rl["launches_per_step_with_event_pair"]),
+                            "flop_per_launch": float(rl["executed_flop_per_launch_all_launches"])}
     except Exception:
         pass
     return None
@@ -552,7 +553,12 @@ def main():
         recs = hip_ops.PROFILE
         hip_ops.PROFILE = None
         kernel_ts, kernel_ts_error = None, None
-        if not args.no_kernel_timestamps:
+        # (under rocprofv3 a second tracer in the process -- torch.profiler -- delivers durations of ~1 us for 25-us kernels: the
+        #  profiler's preloaded tool owns the queue's timestamps.  The trace itself is then the timestamp source.)
+        under_rocprof = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+        if under_rocprof and not args.no_kernel_timestamps:
+            kernel_ts_error = "running under rocprofv3: its own trace holds the kernel timestamps"
+        if not args.no_kernel_timestamps and not under_rocprof:
             try:
                 from torch.profiler import profile as _tprofile, ProfilerActivity as _Act
                 from torch.autograd import DeviceType as _DevT
@@ -593,72 +599,98 @@ def main():
             cal.append((c0, c1))
         torch.cuda.synchronize()
         gap_s = sorted(c0.elapsed_time(c1) for c0, c1 in cal)[len(cal) // 2] * 1e-3
-        by_kernel, by_symbol, raw_sec = {}, {}, {}
+        by_kernel, by_symbol, raw_sec, sym_ev = {}, {}, {}, {}
         HBM_PEAK = 8.0e12
+        # the three-launch F(4x4) labels hold two transform kernels beside the grouped GEMMs: no event pair of a kernel's own there
+        THREE_LAUNCH = ("conv_wino4", "conv_wino4_x3")
         def executed_of(name, flops):
             return flops / 4.0 if "wino4" in name else flops / 2.25 if "wino" in name else flops
         for name, flops, e0, e1, nbytes, extra in recs:
             d = by_kernel.setdefault(name, [0.0, 0.0, 0, 0.0, {}, 0.0, 0])
+            raw_s = e0.elapsed_time(e1) * 1e-3
+            cor_s = max(raw_s - gap_s, 1e-7)
             d[0] += flops
-            d[1] += max(e0.elapsed_time(e1) * 1e-3 - gap_s, 1e-7)
+            d[1] += cor_s
             d[2] += 1
             d[3] += nbytes
-            # the launch's floor under BOTH roofs: executed flops at the MFMA peak, algorithmic bytes at the HBM peak
-            t_mfma, t_hbm = executed_of(name, flops) / (peak * 1e12), nbytes / HBM_PEAK
+            # the launch's floor under BOTH roofs: executed flops at the MFMA peak of the products it runs (an f32x3 kernel: its six
+            # bf16 partial products per f32 product at the bf16 peak), algorithmic bytes at the HBM peak
+            bf16_fl = extra.get("bf16_mfma_flops", 0.0) if extra else 0.0
+            t_mfma = bf16_fl / (MFMA_BF16_PEAK_TFLOPS * 1e12) if bf16_fl else executed_of(name, flops) / (peak * 1e12)
+            t_hbm = nbytes / HBM_PEAK
             d[5] += max(t_mfma, t_hbm)
             d[6] += 1 if t_hbm > t_mfma else 0
-            raw_sec[name] = raw_sec.get(name, 0.0) + e0.elapsed_time(e1) * 1e-3
+            raw_sec[name] = raw_sec.get(name, 0.0) + raw_s
             if extra:
                 d[4][extra["symbol"]] = d[4].get(extra["symbol"], 0) + 1
                 q = by_symbol.setdefault(extra["symbol"], [0.0, 0, 0.0])
                 q[0] += extra["mfma_flops"]
                 q[1] += 1
-                q[2] += extra.get("bf16_mfma_flops", 0.0)
+                q[2] += bf16_fl
+                if name.startswith("conv_") and name not in THREE_LAUNCH:
+                    # one event pair = one launch of this symbol: the per-SYMBOL HIP-event record (a label such as conv_pw_x3 covers
+                    # several instantiations, so labels are not the unit here)
+                    v = sym_ev.setdefault(extra["symbol"], {"f32": 0.0, "bf16": 0.0, "n": 0, "raw": 0.0, "cor": 0.0, "bytes": 0.0,
+                                                            "alg": 0.0, "floor": 0.0, "hbm_bound": 0, "labels": {}})
+                    v["f32"] += extra["mfma_flops"]; v["bf16"] += bf16_fl; v["n"] += 1; v["raw"] += raw_s; v["cor"] += cor_s
+                    v["bytes"] += nbytes; v["alg"] += flops; v["floor"] += max(t_mfma, t_hbm); v["hbm_bound"] += 1 if t_hbm > t_mfma else 0
+                    v["labels"][name] = v["labels"].get(name, 0) + 1
         # `flops` of a record is the ALGORITHMIC work of the layer (2 x MACs of the direct convolution,
         # SURVEY 8d).  The Winograd F(2x2,3x3) kernels execute 1/2.25 of it on the MFMA pipe, so their
         # algorithmic rate can exceed the hardware peak; the executed rate is reported beside it.
         def executed(name, flops):
-            return flops / 4.0 if "wino4" in name else flops / 2.25 if "wino" in name else flops
+            return executed_of(name, flops)
         conv = {k: v for k, v in by_kernel.items() if k.startswith("conv_")}
-        # the dominant KERNEL: among the labels that are one launch of one MFMA kernel (the three-launch F(4x4) label also holds
-        # two transform kernels -- it is in conv_family.by_kernel, and its grouped GEMMs are in frac_from_rocprof's symbol)
-        one_kernel = {k: v for k, v in conv.items() if k not in ("conv_wino4", "conv_wino4_x3")} or conv
-        top = max(one_kernel, key=lambda k: one_kernel[k][1])
-        fl, sec, n, nby, syms, floor_sec, hbm_bound_n = conv[top]
         fam_fl = sum(v[0] for v in conv.values())
         fam_ex = sum(executed(k, v[0]) for k, v in conv.items())
         fam_sec = sum(v[1] for v in conv.values())
         all_sec = sum(v[1] for v in by_kernel.values())
-        top_symbol = max(syms, key=syms.get) if syms else None       # (a label of this build names ONE instantiation)
+        # ---- the dominant KERNEL = the kernel SYMBOL with the largest summed (gap-corrected) HIP-event time among the launches that
+        # have an event pair of their own (the grouped GEMMs inside a three-launch F(4x4) label are in `by_symbol`, from the kernel
+        # timestamps).  An f32x3 kernel runs bf16 MFMAs: its achieved rate is the bf16 flops it EXECUTES (six partial products per f32
+        # product) and its peak the dense bf16 peak -- never the f32-equivalent rate over the f32 peak.
+        top_symbol = max(sym_ev, key=lambda k: sym_ev[k]["cor"])
+        ev = sym_ev[top_symbol]
+        top = max(ev["labels"], key=ev["labels"].get)
+        is_x3 = ev["bf16"] > 0.0
+        k_peak = MFMA_BF16_PEAK_TFLOPS if is_x3 else peak
+        ev_fl = ev["bf16"] if is_x3 else ev["f32"]                     # executed flops of the event-pair launches, in the kernel's products
+        fl, sec, n, nby, floor_sec, hbm_bound_n = ev["alg"], ev["cor"], ev["n"], ev["bytes"], ev["floor"], ev["hbm_bound"]
         traffic, traffic_src = load_traffic(top, top_symbol)
-        # ---- the dominant kernel SYMBOL: every launch of it in the pass (for the five-per-CU pointwise tile also grouped GEMMs of
-        # F(4x4) layers that use the same instantiation), executed flops over kernel-timestamp durations
-        sym_fl, sym_n, _ = by_symbol.get(top_symbol, (executed(top, fl), n, 0.0))
+        # every launch of the symbol in the pass (for the five-per-CU pointwise tile also grouped GEMMs of F(4x4) layers that use the
+        # same instantiation): executed flops over kernel-timestamp durations when pass B saw the same launches
+        all_f32, all_n, all_bf16 = by_symbol[top_symbol]
         ts = ts_of(top_symbol)
         if os.environ.get("SGV3D_BENCH_DEBUG"):
             print("[bench debug] by_symbol", {k: v[1] for k, v in by_symbol.items()}, file=sys.stderr)
             print("[bench debug] labels", {k: (v[2], dict(v[4])) for k, v in by_kernel.items()}, file=sys.stderr)
             if kernel_ts:
                 print("[bench debug] kernel_ts", {k[:110]: v[0] for k, v in kernel_ts.items()}, file=sys.stderr)
-        ts_ok = ts is not None and ts[0] == sym_n                     # the same population in both passes, or no figure
+        ts_ok = ts is not None and ts[0] == all_n                     # the same population in both passes, or no figure
+        if ts_ok and not (0.6 < (ts[1] / ts[0]) / (ev["raw"] / n) < 1.2):
+            # kernel timestamps that disagree grossly with the event pairs around the same launches are a broken trace, not a fast kernel
+            kernel_ts = None                                          # (by_symbol stays empty too)
+            ts_ok, kernel_ts_error = False, f"timestamps implausible: {ts[1] / ts[0] * 1e6:.2f} us against {ev['raw'] / n * 1e6:.2f} us between events"
         if ts_ok:
-            dur_s, dur_src = ts[1], "kernel begin/end timestamps (torch.profiler = roctracer), pass B"
+            sym_fl, sym_n, dur_s = (all_bf16 if is_x3 else all_f32), all_n, ts[1]
+            dur_src = "kernel begin/end timestamps (torch.profiler = roctracer), pass B"
         else:
-            # (labels of this symbol only: the grouped GEMMs inside a three-launch label have no event pair of their own)
-            sym_fl, sym_n, dur_s = executed(top, fl), n, sec
+            sym_fl, sym_n, dur_s = ev_fl, n, sec
             dur_src = "HIP events, calibrated marker gap subtracted (no kernel timestamps: " + (kernel_ts_error or (
-                "--no-kernel-timestamps" if args.no_kernel_timestamps else f"launch counts differ, {ts} vs {sym_n}")) + ")"
+                "--no-kernel-timestamps" if args.no_kernel_timestamps else f"launch counts differ, {ts} vs {all_n}")) + ")"
         achieved = sym_fl / dur_s / 1e12
         rocprof = None
         rp = load_rocprof_roofline(top_symbol)
         if rp is not None:
-            # the committed trace of `bench.py --roofline-only` (same loop, same tune DB): refuse another population
-            same = abs(rp["launches_per_step"] - sym_n / args.steps) < 1e-9
+            # the committed trace of `bench.py --roofline-only` (same loop, same tune DB): refuse another population -- the launches
+            # per step WITH an event pair are what both runs print, and the executed flops per launch of the symbol must agree
+            fpl = (all_bf16 if is_x3 else all_f32) / all_n
+            same = abs(rp["launches_per_step"] - n / args.steps) < 1e-9 and abs(rp["flop_per_launch"] / fpl - 1.0) < 1e-6
             rocprof = {"file": rp["file"], "symbol": top_symbol, "avg_ns": rp["avg_ns"], "calls_in_trace": rp["calls"],
-                       "launches_per_step_in_trace": rp["launches_per_step"], "launches_per_step_here": sym_n / args.steps,
-                       "executed_flop_per_launch_here": sym_fl / sym_n,
-                       "achieved": (sym_fl / sym_n / rp["avg_ns"] / 1e3) if same else None,
-                       "frac": (sym_fl / sym_n / rp["avg_ns"] / 1e3 / peak) if same else None,
+                       "launches_per_step_in_trace": rp["launches_per_step"], "launches_per_step_here": n / args.steps,
+                       "executed_flop_per_launch_in_trace": rp["flop_per_launch"], "executed_flop_per_launch_here": fpl,
+                       "achieved": (fpl / rp["avg_ns"] / 1e3) if same else None,
+                       "frac": (fpl / rp["avg_ns"] / 1e3 / k_peak) if same else None,
                        "refused": None if same else "the trace holds another launch mix of this symbol than this run (tune DB or switches "
                                                     "changed since it was committed): no figure",
                        "what": "executed flops per launch of this symbol in THIS run / the symbol's average duration in the committed "
@@ -679,20 +711,28 @@ def main():
                 rec.update({"bound": "mfma", "peak": peak, "frac": f32_fl / t[1] / 1e12 / peak})
             by_sym_out[sym] = rec
         roofline = {
-            "bound": "mfma", "kernel": top, "kernel_symbol": top_symbol, "achieved": achieved, "peak": peak,
-            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+            "bound": "mfma bf16 (f32x3: three bf16 planes per f32 operand, six partial products)" if is_x3 else "mfma",
+            "kernel": top, "kernel_symbol": top_symbol, "achieved": achieved, "peak": k_peak,
+            "unit": "TFLOP/s", "frac": achieved / k_peak, "traffic": traffic,
             "traffic_source": traffic_src,
-            "flops": "executed (= algorithmic for an implicit GEMM)", "durations": dur_src,
+            "flops": ("executed bf16 MFMA flops (6 x the f32 products of the implicit GEMM, padded tiles included)" if is_x3
+                      else "executed (= algorithmic for an implicit GEMM)"), "durations": dur_src,
             "launches": sym_n, "launches_per_step": sym_n / args.steps, "avg_launch_us": dur_s / sym_n * 1e6,
             "executed_flop_per_launch": sym_fl / sym_n,
-            # the contract's HIP-event measurement of the same launches (the labels of this symbol), raw and gap-corrected
-            "hip_events": {"launches": n, "avg_launch_us_raw": raw_sec[top] / n * 1e6, "avg_launch_us": sec / n * 1e6,
+            "executed_flop_per_launch_all_launches": (all_bf16 if is_x3 else all_f32) / all_n,
+            "launches_per_step_with_event_pair": n / args.steps,
+            "f32_equivalent": ({"achieved": all_f32 / all_n * sym_n / dur_s / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                                "what": "the f32 products the kernel stands for, per second, beside the native f32 MFMA peak -- not "
+                                        "a roofline fraction: the kernel runs on the bf16 pipe"} if is_x3 else None),
+            # the contract's HIP-event measurement: the event pairs around the launches of THIS symbol, raw and gap-corrected
+            "hip_events": {"launches": n, "avg_launch_us_raw": ev["raw"] / n * 1e6, "avg_launch_us": sec / n * 1e6,
                            "event_pair_gap_us": gap_s * 1e6,
-                           "achieved_raw": executed(top, fl) / raw_sec[top] / 1e12, "achieved": executed(top, fl) / sec / 1e12,
-                           "frac_raw": executed(top, fl) / raw_sec[top] / 1e12 / peak, "frac": executed(top, fl) / sec / 1e12 / peak,
-                           "gap_corrected_over_timestamps": ((executed(top, fl) / sec) / (sym_fl / dur_s)) if ts_ok else None,
-                           "what": "HIP events on the launch stream around every launch of the label; an event pair also measures its "
-                                   "markers' gap on the queue (calibrated on empty pairs, subtracted in the second figure)"},
+                           "achieved_raw": ev_fl / ev["raw"] / 1e12, "achieved": ev_fl / sec / 1e12,
+                           "frac_raw": ev_fl / ev["raw"] / 1e12 / k_peak, "frac": ev_fl / sec / 1e12 / k_peak,
+                           "gap_corrected_over_timestamps": ((ev_fl / sec) / (sym_fl / dur_s)) if ts_ok else None,
+                           "what": "HIP events on the launch stream around every launch of the symbol that is a label of its own; an "
+                                   "event pair also measures its markers' gap on the queue (calibrated on empty pairs, subtracted in "
+                                   "the second figure)"},
             "algorithmic_bytes": nby / n if nby else None,
             "traffic_over_algorithmic": (traffic / (nby / n)) if (traffic and nby) else None,
             "frac_from_rocprof": rocprof,
@@ -707,6 +747,10 @@ def main():
             "conv_family": {"achieved": fam_fl / fam_sec / 1e12, "frac": fam_fl / fam_sec / 1e12 / peak,
                             "executed_achieved": fam_ex / fam_sec / 1e12,
                             "executed_frac": fam_ex / fam_sec / 1e12 / peak,
+                            "executed_frac_note": ("f32-equivalent products over the native f32 MFMA peak; layers on f32x3 tiles run on "
+                                                   "the bf16 pipe (by_symbol prices them against the bf16 peak), so this is the "
+                                                   "family's rate in f32 terms, not a fraction of the pipe they occupy"
+                                                   if any(v[2] for v in by_symbol.values()) else None),
                             "gflop_per_frame": fam_fl / (args.steps * B) / 1e9,
                             "ms_per_step": fam_sec / args.steps * 1e3,
                             "share_of_instrumented_time": fam_sec / all_sec,
@@ -718,7 +762,9 @@ def main():
                                               "launches_per_step": v[2] / args.steps,
                                               "algorithmic_bytes_per_launch": v[3] / v[2] if v[3] else None,
                                               "two_roof_frac": v[5] / v[1],
-                                              "symbol": (max(v[4], key=v[4].get) if v[4] else None)}
+                                              # (a label that covers several instantiations names no single symbol)
+                                              "symbol": (next(iter(v[4])) if len(v[4]) == 1 else None),
+                                              "symbols": ({q: c / args.steps for q, c in v[4].items()} if len(v[4]) > 1 else None)}
                                           for k, v in conv.items()}},
             "other_kernels_ms_per_step": {k: v[1] / args.steps * 1e3 for k, v in by_kernel.items()
                                           if not k.startswith("conv_")},

@@ -27,14 +27,17 @@
 // with 4 consecutive output channels of one row: one 16-byte store per accumulator tile.  Per k-step a wave reads 6 weight
 // fragments once and 3 row fragments per row block (ds_read_b128 each) for 12 MA MFMAs: (3 MA + 6) / (12 MA) reads per MFMA --
 // 0.32 at MA = 7, a third of what saturates the LDS array beside 16-cycle MFMAs.
-//   LDS      one image per plane, rows of 64 bytes (32 k), the 16-byte chunk c of row r stored at c ^ (-(r >> 2) & 3): the four
-//            16-lane groups of a ds_read_b128 (rows {0-3, 12-15} at one chunk with rows {4-11} at the next, and so on) each fall
-//            on 64 distinct banks; a plane starts 64 bytes past a multiple of 128 so that the 8-lane groups of a staging store
-//            that straddle two planes or two rows use both halves of the banks.  (16 MA + 32 WN) x 192 B: 46 KB at MA 7, WN 4.
-//   pipeline one register stage, ONE LDS buffer, two barriers per k-step; three workgroups per CU (162 registers at MA 7) cover
-//            each other's barriers.  The row fragments of block ma + 1 are requested before the 12 MFMAs of block ma.
-//   traffic  a k-step loads (16 MA + 32 WN) x 192 B for 12 MA x WN x 8192 MACs: 10 MACs per byte at MA 7, WN 4 -- 1.5 x the bytes
-//            of the f32 kernel for 2.7 x its MFMA rate, so the L2 -> LDS stream is the second bound (~17 TB/s chip-wide).
+//   weights  never touch LDS: a wave's 6 fragments of a k-step (2 column blocks x 3 planes, 1 KB each) come from L2 straight into
+//            registers with one buffer_load_dwordx4 per lane and fragment, requested one k-step ahead.
+//   LDS      the ROW tile only, two buffers of three planes; rows of 64 bytes (32 k), the 16-byte chunk c of row r stored at
+//            c ^ (-(r >> 2) & 3): the four 16-lane groups of a ds_read_b128 (rows {0-3, 12-15} at one chunk with rows {4-11} at the
+//            next, and so on) each fall on 64 distinct banks; a plane is BM x 64 + 64 bytes so that the 8-lane groups of a staging
+//            store that straddle two planes or two rows use both halves of the banks.  2 x 3 x (16 MA x 64 + 64) B: 43 KB at MA 7.
+//   pipeline the rows of k-step k + 1 are in registers while k-step k computes, stored into the OTHER buffer behind its MFMAs: ONE
+//            barrier per k-step.  Two workgroups per CU (launch bound), sched_barriers keep the request / MFMA / store order.
+//            (Prefetch distance 2, three workgroups per CU, 64-thread workgroups: measured, no gain -- DESIGN 3.9.)
+//   traffic  a k-step loads 16 MA x 192 B of rows per workgroup and 32 WN x 192 B of weights (registers) for 12 MA x WN x 8192 MACs:
+//            10 MACs per byte at MA 7, WN 4 -- 1.5 x the bytes of the f32 kernel for 2.7 x its MFMA rate.
 //   mapping  XCD-aware: the workgroups of one XCD walk consecutive tiles (m fastest, then n, then position): the tiles that share
 //            a weight panel or a row panel run on the same L2.
 //

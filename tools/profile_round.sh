@@ -17,14 +17,12 @@ if [[ $PARTS == *a* ]]; then
 export TMPDIR=/tmp
 cd /tmp
 # (tile / split-K choices come from the committed tune DB, tune/gfx950_*.json: every run below makes the same ones)
-# 1. the bench line itself (with the CPU baseline)
-echo "[profile_round] $(date +%H:%M:%S) 1. the bench line itself (with the CPU baseline)" | tee -a $KEEP/progress.log
-python3 $R/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+# (1. the bench line itself runs LAST, below: it pairs its flops per launch with this round's roofline trace and PMC summary)
 # 2. kernel trace + stats of the same command (no CPU baseline: it is host work).  One frame in flight, so that the
 echo "[profile_round] $(date +%H:%M:%S) 2. kernel trace + stats of the same command (no CPU baseli" | tee -a $KEEP/progress.log
 #    per-kernel durations are those of the kernels alone (with 3 frames in flight concurrent kernels stretch each
 #    other) and compare directly with roofline.avg_launch_us of the bench line, which is measured the same way.
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-plan-timing --no-other-configs --no-harness --streams 1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-plan-timing --no-other-configs --no-harness --no-train-step --no-native-f32 --streams 1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err
 # 2r. the ROOFLINE population alone: bench.py --roofline-only = warm-up + the instrumented pass, one stream, eager launches from the
 #     first to the last forward -- the per-symbol averages of this trace are over exactly the launches roofline.frac is made of
 #     (bench.py pairs its own flops per launch with this file: roofline.frac_from_rocprof)
@@ -78,4 +76,12 @@ fi
 ls -la $OUT | head -60
 python3 $R/tools/summarize_profiles.py $OUT $TAG $KEEP > $KEEP/summarize.log 2>&1
 cp $OUT/*.err $KEEP/ 2>/dev/null
+if [[ $PARTS == *a* ]]; then
+# 1. the bench line itself (with the CPU baseline), after this round's roofline trace + the line printed under it and the PMC summary
+#    have been put where bench.py reads them (profiles/ of this checkout): roofline.frac_from_rocprof and roofline.traffic then come
+#    from the SAME tree's traces
+cp $KEEP/${TAG}_bench_roofline_kernel_stats.csv $KEEP/${TAG}_bench_roofline_under_rocprof.json $KEEP/${TAG}_hbm_traffic.json $R/profiles/
+echo "[profile_round] $(date +%H:%M:%S) 1. the bench line itself (with the CPU baseline)" | tee -a $KEEP/progress.log
+python3 $R/bench.py --steps 20 --warmup 3 > $KEEP/${TAG}_bench.json 2> $KEEP/bench.err
+fi
 ls -la $KEEP
