@@ -859,11 +859,7 @@ int sgv3d_clip_coef(const double *partials, int count, float grad_scale, float m
  * f32 [channels] are kept for the backward.  Backward: dy is the gradient w.r.t. y; dx w.r.t. x, dresidual (NULL = not
  * wanted) w.r.t. the residual, dgamma / dbeta w.r.t. the affine parameters; y (the forward output) supplies the ReLU
  * mask.  Statistics and gradient sums are accumulated in float64 in a fixed order (deterministic).
- * Each pass over the map is one launch: the last workgroup to finish the statistics (gradient sums) pass adds the per-block
- * partials in a fixed order and finalizes -- no separate finalize launch.
- * workspace: sgv3d_batchnorm_workspace_bytes(channels) bytes, 16-byte aligned like every tensor here, ZERO-FILLED ONCE before its
- * first use (its first 16 KB are arrival counters that every call leaves at zero again) and owned by ONE stream: calls on a stream
- * are ordered and may share a workspace sized for the largest channel count, calls on different streams need their own. */
+ * workspace: sgv3d_batchnorm_workspace_bytes(channels) bytes, 16-byte aligned like every tensor here. */
 size_t sgv3d_batchnorm_workspace_bytes(int channels);
 int sgv3d_batchnorm_train_forward(long long pixels, int channels, const float *x, const float *residual,
                                   const float *gamma, const float *beta, float *running_mean, float *running_var,

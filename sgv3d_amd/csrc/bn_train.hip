@@ -4,21 +4,13 @@
 // with batch statistics + separate add and ReLU kernels.  All four kernels are HBM-bound streams:
 //
 //   forward   bn_stats_kernel    per-channel sum and sum of squares over the B*H*W pixels (float64 accumulators: no
-//                                cancellation in E[x^2] - mean^2), per-block partials; the LAST block to finish sums them and
-//                                finalizes: mean, biased variance, 1/sqrt(var + eps), folded scale / shift, running statistics
+//                                cancellation in E[x^2] - mean^2), per-block partials
+//             bn_finalize_kernel mean, biased variance, 1/sqrt(var + eps), folded scale / shift, running statistics
 //                                (momentum, unbiased variance) -- what nn.BatchNorm2d updates in training mode
 //             bn_apply_kernel    y = relu(x * scale + shift + residual)              (reads x [+ residual], writes y)
-//   backward  bn_bwd_reduce_kernel   dz = dy * (y > 0);  dbeta = sum dz;  dgamma = sum dz * xhat   (float64 partials, summed by
-//                                    the last block to finish)
+//   backward  bn_bwd_reduce_kernel   dz = dy * (y > 0);  dbeta = sum dz;  dgamma = sum dz * xhat   (float64 partials)
+//             bn_bwd_finalize_kernel sums the partials
 //             bn_bwd_apply_kernel    dx = gamma * invstd * (dz - dbeta / M - xhat * dgamma / M);  d_residual = dz
-//
-// "The last block to finish" (round 6; rounds 1-5 launched a finalize kernel between the two passes: 182 launches of ~5 us per
-// training step).  Two levels, both in FIXED order whatever block happens to be last: the ranges of a channel group form groups of
-// kGroup consecutive ranges; the last block of a group (arrival counter) adds the group's partials in range order into a level-2
-// partial, the last group of the channel group adds the level-2 partials in group order and finalizes its 64 channels -- a tail of
-// two short dependent reads (<= 32 rows each) instead of one block reading up to 1024 rows.  Counters live at the front of the
-// workspace, start at zero and are reset by the block that consumes them: the workspace must be zero-filled ONCE before its first
-// use and belongs to one stream (calls on one stream are ordered; two streams need two workspaces).
 //
 // Thread layout: 16 lanes x float4 cover 64 channels of a pixel (256 contiguous bytes), 16 pixel rows per block pass;
 // a block owns a (64-channel, pixel-range) slab, blockIdx.x = channel group, blockIdx.y = pixel range.
@@ -36,74 +28,13 @@ struct BnArgs {
     const float *gamma, *beta;
     float *running_mean, *running_var, *mean, *invstd, *scale, *shift, *dgamma, *dbeta;
     double *partial;                       // [ranges][C][2]
-    double *partial2;                      // [channel group][group][64][2]: level-2 partials
-    unsigned *counter1, *counter2;         // arrivals per (channel group, group) / per channel group; zero between calls
-    int ngroups;                           // groups of kGroup ranges per channel group
     long long pixels;
     int channels, ranges, pix_per_range, relu;   // relu 2 (backward): the mask is bn(x) > 0 recomputed from x (no residual in the forward)
     float momentum, eps;
 };
 
-constexpr int kGroup = 32;       // ranges per level-1 group
-
-__device__ __forceinline__ double load_agent(const double *p) {          // (written by another block, possibly on another XCD)
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Every thread of the block calls this after its global writes.  True in all threads of the block that arrives LAST (of n) at
-// `counter`, which is left at zero for the next call.
-__device__ __forceinline__ bool last_arrival(unsigned *counter, unsigned n, unsigned *flag) {
-    __threadfence();                       // release this thread's partials to the device
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = old == n - 1;
-        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = last ? 1u : 0u;
-    }
-    __syncthreads();
-    const bool last = *flag != 0u;
-    if (last) __threadfence();             // acquire the other blocks' partials
-    return last;
-}
-
-// Called by every thread of a block of grid (channel groups, ranges) after the block's row of `partial` is written.  Returns true
-// in the ONE block per channel group that holds the complete sums: thread t < 128 then has in `out` the sum over all ranges of
-// (channel cg + t / 2, component t % 2), added in a fixed order.
-__device__ __forceinline__ bool reduce_in_last_block(const BnArgs &a, double (*lds2)[128], unsigned *flag, double &out) {
-    const int cg = blockIdx.x * 64, grp = blockIdx.y / kGroup;
-    const int g0 = grp * kGroup, gn = a.ranges - g0 < kGroup ? a.ranges - g0 : kGroup;
-    if (!last_arrival(a.counter1 + blockIdx.x * a.ngroups + grp, (unsigned)gn, flag)) return false;
-    // level 1: the group's rows in range order, two halves of the rows in flight
-    const int t = threadIdx.x & 127, half = threadIdx.x >> 7;
-    const int c = t >> 1, k = t & 1;
-    double s = 0;
-    if (cg + c < a.channels)
-        for (int r = half * (kGroup / 2); r < (half + 1) * (kGroup / 2) && r < gn; ++r)
-            s += load_agent(a.partial + ((size_t)(g0 + r) * a.channels + cg + c) * 2 + k);
-    lds2[half][t] = s;
-    __syncthreads();
-    double *p2 = a.partial2 + ((size_t)blockIdx.x * a.ngroups + grp) * 128;
-    if (half == 0) p2[t] = lds2[0][t] + lds2[1][t];
-    if (!last_arrival(a.counter2 + blockIdx.x, (unsigned)a.ngroups, flag)) return false;
-    // level 2: the channel group's level-2 rows in group order
-    s = 0;
-    const double *q2 = a.partial2 + (size_t)blockIdx.x * a.ngroups * 128;
-    const int per = (a.ngroups + 1) / 2;
-    for (int g = half * per; g < (half + 1) * per && g < a.ngroups; ++g) s += load_agent(q2 + (size_t)g * 128 + t);
-    __syncthreads();                       // (lds2 of level 1 has been read)
-    lds2[half][t] = s;
-    __syncthreads();
-    out = lds2[0][t] + lds2[1][t];
-    return true;
-}
-
-__device__ __forceinline__ void finalize_channel(const BnArgs &a, int c, double s, double q);
-
 __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs a) {
     __shared__ double lds[16][64][2];
-    __shared__ double lds2[2][128];
-    __shared__ unsigned flag;
     const int cg = blockIdx.x * 64, c4 = (threadIdx.x & 15) * 4, prow = threadIdx.x >> 4;
     const long long p0 = (long long)blockIdx.y * a.pix_per_range;
     const long long p1 = p0 + a.pix_per_range < a.pixels ? p0 + a.pix_per_range : a.pixels;
@@ -137,16 +68,45 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnArgs a) {
         for (int r = 0; r < 16; ++r) t += lds[r][c][k];
         if (cg + c < a.channels) a.partial[((size_t)blockIdx.y * a.channels + cg + c) * 2 + k] = t;
     }
-    double tot;
-    if (!reduce_in_last_block(a, lds2, &flag, tot)) return;
-    // thread 2 c has the sum, thread 2 c + 1 the sum of squares of channel cg + c
-    __syncthreads();
-    if (threadIdx.x < 128) lds2[0][threadIdx.x] = tot;
-    __syncthreads();
-    if (threadIdx.x < 64 && cg + threadIdx.x < a.channels) finalize_channel(a, cg + threadIdx.x, lds2[0][2 * threadIdx.x], lds2[0][2 * threadIdx.x + 1]);
 }
 
-__device__ __forceinline__ void finalize_channel(const BnArgs &a, int c, double s, double q) {
+// Sum of the per-range partials of channel c: kFinCh channels per block, 256 / kFinCh threads per channel over the range axis (a
+// 1024-range layer: 16 independent loads per thread, issued together), the slice sums added in slice order (fixed order);
+// s0 / s1 valid in the threads with slice 0.
+constexpr int kFinCh = 4, kFinSlices = 256 / kFinCh;
+
+__device__ __forceinline__ void sum_partials(const BnArgs &a, int c, int slice, double (*lds)[kFinCh][2], double &s0, double &s1) {
+    double s = 0, q = 0;
+    if (c < a.channels) {
+        int r = slice;
+        for (; r + 3 * kFinSlices < a.ranges; r += 4 * kFinSlices) {
+            double2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const double2 *>(a.partial + ((size_t)(r + u * kFinSlices) * a.channels + c) * 2);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += v[u].x; q += v[u].y; }
+        }
+        for (; r < a.ranges; r += kFinSlices) {
+            const double2 v = *reinterpret_cast<const double2 *>(a.partial + ((size_t)r * a.channels + c) * 2);
+            s += v.x;
+            q += v.y;
+        }
+    }
+    const int cl = threadIdx.x % kFinCh;
+    lds[slice][cl][0] = s;
+    lds[slice][cl][1] = q;
+    __syncthreads();
+    s0 = s1 = 0;
+    if (slice == 0)
+        for (int i = 0; i < kFinSlices; ++i) { s0 += lds[i][cl][0]; s1 += lds[i][cl][1]; }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const BnArgs a) {
+    __shared__ double lds[kFinSlices][kFinCh][2];
+    const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, slice = threadIdx.x / kFinCh;
+    double s, q;
+    sum_partials(a, c, slice, lds, s, q);
+    if (slice != 0 || c >= a.channels) return;
     const double m = (double)a.pixels;
     const double mean = s / m;
     double var = q / m - mean * mean;
@@ -188,7 +148,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs a) {
     }
 }
 
-// scale / shift of channels c .. c + 3 exactly as finalize_channel folded them (same roundings)
+// scale / shift of channels c .. c + 3 exactly as bn_finalize_kernel folded them (same roundings)
 __device__ __forceinline__ void fold_affine(const BnArgs &a, int c, const float4 mean, const float4 istd, float4 &sc, float4 &sh) {
     float4 g = make_float4(1.f, 1.f, 1.f, 1.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.gamma) g = *reinterpret_cast<const float4 *>(a.gamma + c);
@@ -199,8 +159,6 @@ __device__ __forceinline__ void fold_affine(const BnArgs &a, int c, const float4
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnArgs a) {
     __shared__ double lds[16][64][2];
-    __shared__ double lds2[2][128];
-    __shared__ unsigned flag;
     const int cg = blockIdx.x * 64, c4 = (threadIdx.x & 15) * 4, prow = threadIdx.x >> 4;
     const long long p0 = (long long)blockIdx.y * a.pix_per_range;
     const long long p1 = p0 + a.pix_per_range < a.pixels ? p0 + a.pix_per_range : a.pixels;
@@ -246,14 +204,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnArgs a) {
         for (int r = 0; r < 16; ++r) t += lds[r][c][k];
         if (cg + c < a.channels) a.partial[((size_t)blockIdx.y * a.channels + cg + c) * 2 + k] = t;
     }
-    double tot;
-    if (!reduce_in_last_block(a, lds2, &flag, tot)) return;
-    if (threadIdx.x < 128 && cg + (threadIdx.x >> 1) < a.channels) {
-        if (threadIdx.x & 1) a.dgamma[cg + (threadIdx.x >> 1)] = (float)tot;
-        else a.dbeta[cg + (threadIdx.x >> 1)] = (float)tot;
-    }
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnArgs a) {
+    __shared__ double lds[kFinSlices][kFinCh][2];
+    const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, slice = threadIdx.x / kFinCh;
+    double sb, sg;
+    sum_partials(a, c, slice, lds, sb, sg);
+    if (slice != 0 || c >= a.channels) return;
+    a.dbeta[c] = (float)sb;
+    a.dgamma[c] = (float)sg;
+}
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a) {
     const int c4n = a.channels / 4;
@@ -304,7 +265,6 @@ int plan(long long pixels, int channels, BnArgs &a) {
     ranges = ranges > cap ? (int)cap : ranges;
     a.pix_per_range = (int)((pixels + ranges - 1) / ranges);
     a.ranges = (int)((pixels + a.pix_per_range - 1) / a.pix_per_range);
-    a.ngroups = cdiv(a.ranges, kGroup);
     return SGV3D_OK;
 }
 
@@ -321,28 +281,12 @@ int stream_blocks(long long total, int c4n) {
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// workspace: [counters, fixed size][partials][level-2 partials][scale, shift] -- the counters sit at the SAME offset for every
-// channel count, so one zero-filled workspace serves all layers of a stream
-constexpr size_t kCounterBytes = 16384;                                  // counter1: <= 32 + kMaxBlocks groups, counter2: <= kMaxBlocks
-constexpr int kMaxGroups = kMaxBlocks / kGroup + kMaxBlocks;            // sum over channel groups of ceil(ranges / kGroup)
 size_t partial_bytes(int) { return (size_t)kMaxBlocks * 64 * 2 * sizeof(double); }
-size_t partial2_bytes() { return (size_t)kMaxGroups * 128 * sizeof(double); }
-static_assert((kMaxGroups + kMaxBlocks) * sizeof(unsigned) <= kCounterBytes, "counter area");
-
-void carve(BnArgs &a, void *workspace, int channels) {
-    char *w = static_cast<char *>(workspace);
-    a.counter1 = reinterpret_cast<unsigned *>(w);
-    a.counter2 = a.counter1 + kMaxGroups;
-    a.partial = reinterpret_cast<double *>(w + kCounterBytes);
-    a.partial2 = reinterpret_cast<double *>(w + kCounterBytes + partial_bytes(channels));
-    a.scale = reinterpret_cast<float *>(w + kCounterBytes + partial_bytes(channels) + partial2_bytes());
-    a.shift = a.scale + channels;
-}
 
 }  // namespace
 
 extern "C" size_t sgv3d_batchnorm_workspace_bytes(int channels) {
-    return channels > 0 ? kCounterBytes + partial_bytes(channels) + partial2_bytes() + 2 * (size_t)channels * sizeof(float) : 0;
+    return channels > 0 ? partial_bytes(channels) + 2 * (size_t)channels * sizeof(float) : 0;
 }
 
 extern "C" int sgv3d_batchnorm_train_forward(long long pixels, int channels, const float *x, const float *residual,
@@ -358,10 +302,14 @@ extern "C" int sgv3d_batchnorm_train_forward(long long pixels, int channels, con
                   "batchnorm_train_forward: buffers must be 16-byte aligned");
     a.x = x; a.res = residual; a.y = y; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean;
     a.running_var = running_var; a.mean = save_mean; a.invstd = save_invstd; a.momentum = momentum; a.eps = eps; a.relu = relu;
-    carve(a, workspace, channels);
+    a.partial = static_cast<double *>(workspace);
+    a.scale = reinterpret_cast<float *>(static_cast<char *>(workspace) + partial_bytes(channels));
+    a.shift = a.scale + channels;
     hipStream_t s = as_stream(stream);
     bn_stats_kernel<<<dim3(cdiv(channels, 64), a.ranges), 256, 0, s>>>(a);
     if (int rc = check_launch("bn_stats_kernel")) return rc;
+    bn_finalize_kernel<<<cdiv(channels, kFinCh), 256, 0, s>>>(a);
+    if (int rc = check_launch("bn_finalize_kernel")) return rc;
     bn_apply_kernel<<<stream_blocks(pixels * (channels / 4), channels / 4), 256, 0, s>>>(a);
     return check_launch("bn_apply_kernel");
 }
@@ -405,10 +353,12 @@ int bn_backward(long long pixels, int channels, const float *x, const float *y, 
                   "batchnorm_train_backward: buffers must be 16-byte aligned");
     a.x = x; a.y_in = y; a.dy = dy; a.gamma = gamma; a.mean = const_cast<float *>(save_mean);
     a.invstd = const_cast<float *>(save_invstd); a.relu = relu; a.dx = dx; a.dres = dresidual; a.dgamma = dgamma; a.dbeta = dbeta;
-    carve(a, workspace, channels);
+    a.partial = static_cast<double *>(workspace);
     hipStream_t s = as_stream(stream);
     bn_bwd_reduce_kernel<<<dim3(cdiv(channels, 64), a.ranges), 256, 0, s>>>(a);
     if (int rc = check_launch("bn_bwd_reduce_kernel")) return rc;
+    bn_bwd_finalize_kernel<<<cdiv(channels, kFinCh), 256, 0, s>>>(a);
+    if (int rc = check_launch("bn_bwd_finalize_kernel")) return rc;
     bn_bwd_apply_kernel<<<stream_blocks(pixels * (channels / 4), channels / 4), 256, 0, s>>>(a);
     return check_launch("bn_bwd_apply_kernel");
 }

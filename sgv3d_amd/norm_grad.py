@@ -14,22 +14,9 @@ __all__ = ['batch_norm_act', 'batch_norm_act_multi', 'deferred_counters']
 MASK_FROM_X = os.environ.get("SGV3D_BN_MASK_FROM_X", "1") != "0"   # 0: the backward of relu(bn(x)) always reads the forward output
 
 
-_WORKSPACES = {}
-
-
 def _ws(channels, device):
-    """The BatchNorm workspace of the current stream of ``device``: zero-filled once, kept (csrc/bn_train.hip: the arrival counters at
-    its front start at zero and are reset by the block that consumes them; calls on one stream are ordered, so they share it)."""
     n = _lib.load().sgv3d_batchnorm_workspace_bytes(int(channels))
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, torch.cuda.current_stream(device).cuda_stream)
-    ws = _WORKSPACES.get(key)
-    if ws is None or ws.numel() < n:
-        if ws is not None:
-            # (the old one may still be in use by launches in flight on this stream: the allocator keeps its memory until they are done)
-            ws.record_stream(torch.cuda.current_stream(device))
-        ws = _WORKSPACES[key] = torch.zeros(max(n, 4 << 20), dtype=torch.uint8, device=device)
-    return ws, ws.numel()
+    return torch.empty(n, dtype=torch.uint8, device=device), n
 
 
 class _BatchNormAct(torch.autograd.Function):
