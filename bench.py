@@ -649,6 +649,15 @@ def main():
         # have an event pair of their own (the grouped GEMMs inside a three-launch F(4x4) label are in `by_symbol`, from the kernel
         # timestamps).  An f32x3 kernel runs bf16 MFMAs: its achieved rate is the bf16 flops it EXECUTES (six partial products per f32
         # product) and its peak the dense bf16 peak -- never the f32-equivalent rate over the f32 peak.
+        if not sym_ev:
+            # no launch of this configuration records its kernel symbol (the bf16 kernels of --dtype bf16: one instantiation per
+            # label): the dominant LABEL stands for its kernel, flops = executed flops of the label
+            one_kernel = {k: v for k, v in conv.items() if k not in THREE_LAUNCH} or conv
+            lab = max(one_kernel, key=lambda k: one_kernel[k][1])
+            v = conv[lab]
+            sym_ev[None] = {"f32": executed(lab, v[0]), "bf16": 0.0, "n": v[2], "raw": raw_sec[lab], "cor": v[1], "bytes": v[3],
+                            "alg": v[0], "floor": v[5], "hbm_bound": v[6], "labels": {lab: v[2]}}
+            by_symbol[None] = [executed(lab, v[0]), v[2], 0.0]
         top_symbol = max(sym_ev, key=lambda k: sym_ev[k]["cor"])
         ev = sym_ev[top_symbol]
         top = max(ev["labels"], key=ev["labels"].get)
