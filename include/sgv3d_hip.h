@@ -823,6 +823,18 @@ int sgv3d_zero_insert(int batch, int in_h, int in_w, int channels, int stride, i
  * stride-1 convolution that computes a data gradient (one launch for torch's flip + transpose + contiguous). */
 int sgv3d_weight_rot180_transpose(const float *w, int cout, int cin, int kh, int kw, float *out, void *stream);
 
+/* Every packed weight form of a model refreshed in ONE launch (training: the weights change once per step, the packed forms the
+ * kernels read -- implicit-GEMM rows, the rotated / transposed rows of the data gradients, bf16 fragment orders -- are permutations
+ * of the parameters with zero padding).  jobs: DEVICE array of n_jobs records of sgv3d_gather_pack_job_bytes() bytes
+ *   { const float *src; void *dst; const int32 *idx; int64 n; int32 first_block; int32 bf16; }
+ * dst[i] = idx[i] < 0 ? 0 : src[idx[i]] for i < n, rounded to bf16 (nearest even, the pack kernels' rounding) when bf16 != 0;
+ * dst and idx 16-byte aligned.  Job k owns the blocks [first_block_k, first_block_{k+1}) with ceil(n / elements_per_block) blocks,
+ * first_block ascending from 0; total_blocks = their sum.  The reference repacks nothing (cuDNN reads OIHW); this replaces the
+ * per-layer sgv3d_conv_pack_weight / sgv3d_weight_rot180_transpose / ..._bf16_pack_weight launches of a training step. */
+int sgv3d_gather_pack_job_bytes(void);
+int sgv3d_gather_pack_elements_per_block(void);
+int sgv3d_gather_pack(const void *jobs, int n_jobs, int total_blocks, void *stream);
+
 /* One fused AdamW step (torch.optim.AdamW semantics, amsgrad off) over a flat fp32 bucket of n parameters:
  * the optimiser of the reference's configure_optimizers (exps/...:298-305).  grad is multiplied by grad_scale
  * first (1 / world size after a sum all-reduce) and, with clip_coef != NULL, by the DEVICE scalar clip_coef[0]

@@ -147,6 +147,9 @@ _PROTOS = {
     "sgv3d_conv3x3_thin_backward_batched_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(ctypes.c_int32)]),
     "sgv3d_conv3x3_thin_backward_batched": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(ctypes.c_int32)] + [ctypes.POINTER(c_void_p)] * 6 + [c_void_p, c_size_t, c_void_p]),
     "sgv3d_weight_rot180_transpose": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
+    "sgv3d_gather_pack_job_bytes": (c_int, []),
+    "sgv3d_gather_pack_elements_per_block": (c_int, []),
+    "sgv3d_gather_pack": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "sgv3d_zero_insert": (c_int, [c_int] * 7 + [c_void_p] * 3),
     "sgv3d_interleave_phases2": (c_int, [c_int] * 4 + [ctypes.POINTER(c_void_p)] + [ctypes.POINTER(ctypes.c_int32)] * 4 +
                                  [c_void_p, c_void_p]),

@@ -14,7 +14,7 @@ import ctypes
 
 import torch
 
-from . import _lib, grad_slots
+from . import _lib, grad_slots, pack_cache
 from .hip_ops import ConvDesc, PackedConv, prof, _st
 
 __all__ = ['conv2d_backward_weight', 'conv2d_backward_weight_bf16', 'conv2d_backward_weight_batched', 'conv2d_backward_data', 'zero_insert', 'conv2d', 'conv_transpose2d',
@@ -290,6 +290,13 @@ def zero_insert(x, stride, out_hw):
     return y
 
 
+def _packed_call(weight, key, make, x, **kw):
+    """``make(weight)(x, **kw)`` -- through the layer's kept PackedConv while the optimiser's pack-cache window is open
+    (sgv3d_amd/pack_cache.py: packed forms refreshed by one launch per step), packed from the current weights otherwise."""
+    e = pack_cache.entry_for(weight, key, make)
+    return e.call(x, **kw) if e is not None else make(weight.detach())(x, **kw)
+
+
 def _rot180_transpose(w):
     """``w.flip(2, 3).transpose(0, 1).contiguous()`` of an OIHW f32 weight tensor in one launch."""
     w = w.contiguous()
@@ -313,11 +320,14 @@ def conv2d_backward_data(dy, weight, in_hw, stride=1, pad=0, dil=1, add_to=None)
     if kh == stride and stride > 1 and pad == 0 and dil == 1:
         # kernel == stride ("patchify" convolutions of the necks): every input pixel belongs to exactly one output pixel,
         # so the data gradient is the transposed convolution with the same weight tensor read as [in = cout, out = cin, k, k]
-        dx = PackedConv(weight.detach(), stride=stride, transposed=True, cin_pad=int(dy.shape[-1]))(dy)
+        cp = int(dy.shape[-1])
+        dx = _packed_call(weight, ('dgrad_patch', stride, cp), lambda w: PackedConv(w, stride=stride, transposed=True, cin_pad=cp), dy)
         ph, pw = H - int(dx.shape[1]), W - int(dx.shape[2])
         return dx if ph == 0 and pw == 0 else torch.nn.functional.pad(dx, (0, 0, 0, pw, 0, ph))   # rows the conv never read
-    wt = _rot180_transpose(weight.detach())                               # [cin, cout, kh, kw], rotated by 180 degrees
-    conv = PackedConv(wt, stride=1, pad=dil * (kh - 1) - pad, dil=dil, cin_pad=int(dy.shape[-1]), pad_out=True)
+    cp, rpad = int(dy.shape[-1]), dil * (kh - 1) - pad
+    # the stride-1 convolution with the weights rotated by 180 degrees and in / out swapped ([cin, cout, kh, kw])
+    make = lambda w: PackedConv(_rot180_transpose(w), stride=1, pad=rpad, dil=dil, cin_pad=cp, pad_out=True)
+    conv = lambda x, **kw: _packed_call(weight, ('dgrad', rpad, dil, cp), make, x, **kw)
     if stride == 1:
         return conv(dy, residual=add_to)
     assert add_to is None, "add_to: stride-1 layers only"
@@ -346,7 +356,6 @@ def _dgrad_stride2(dy, weight, in_hw, pad):
     cout, cin, kh, kw = (int(v) for v in weight.shape)
     H, W = in_hw
     B, hc, wc, _ = (int(v) for v in dy.shape)
-    w = weight.detach()
     outs, geo = [], []
     for py in range(2):
         ty, p_y, n_y = _phase_1d(kh, pad, py, hc, H)
@@ -358,11 +367,14 @@ def _dgrad_stride2(dy, weight, in_hw, pad):
                 continue
             # (taps are min, min + 2, ... in descending order: a strided slice and a flip -- indexing with the Python lists would build
             # index tensors on the host and copy them over, which a stream capture cannot record)
-            sub = w[:, :, min(ty)::2, min(tx)::2].flip(2, 3).transpose(0, 1).contiguous()   # [cin, cout, Ty, Tx]
             # one symmetric padding that covers the low side of both axes and yields enough outputs on the high side
             need = lambda P, T, n_in, n_out: max(P, 0, n_out - n_in + T - 1 - P)
             pp = max(need(p_y, len(ty), hc, n_y), need(p_x, len(tx), wc, n_x))
-            o = PackedConv(sub, stride=1, pad=pp, cin_pad=int(dy.shape[-1]), pad_out=True)(dy)
+            cp, ay, ax = int(dy.shape[-1]), min(ty), min(tx)
+            # sub-kernel [cin, cout, Ty, Tx] of the phase
+            make = lambda v, ay=ay, ax=ax, pp=pp: PackedConv(v[:, :, ay::2, ax::2].flip(2, 3).transpose(0, 1).contiguous(), stride=1, pad=pp,
+                                                             cin_pad=cp, pad_out=True)
+            o = _packed_call(weight, ('dgrad_s2', py, px, pad, pp, cp), make, dy)
             outs.append(o)
             geo.append((int(o.shape[1]), int(o.shape[2]), pp - p_y, pp - p_x))
     C = int(outs[0].shape[-1])
@@ -383,10 +395,11 @@ def _pad4(x):
 class _Conv2dNHWC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil):
-        conv = PackedConv(weight, stride=stride, pad=pad, dil=dil, shift=bias, cin_pad=int(x.shape[-1]))
+        cp = int(x.shape[-1])
         ctx.save_for_backward(x, weight)
         ctx.geom = (stride, pad, dil, bias is not None)
-        return conv(x)
+        return _packed_call(weight, ('fwd', stride, pad, dil, cp, None if bias is None else bias.data_ptr()),
+                            lambda w: PackedConv(w, stride=stride, pad=pad, dil=dil, shift=bias, cin_pad=cp), x)
 
     @staticmethod
     def backward(ctx, dy):
@@ -661,7 +674,8 @@ class _ConvTranspose2dNHWC(torch.autograd.Function):
         assert int(weight.shape[2]) == int(weight.shape[3]) == stride
         ctx.save_for_backward(x, weight)
         ctx.stride = stride
-        return PackedConv(weight, stride=stride, transposed=True, cin_pad=int(x.shape[-1]))(x)
+        cp = int(x.shape[-1])
+        return _packed_call(weight, ('deconv', stride, cp), lambda w: PackedConv(w, stride=stride, transposed=True, cin_pad=cp), x)
 
     @staticmethod
     def backward(ctx, dy):
@@ -674,7 +688,8 @@ class _ConvTranspose2dNHWC(torch.autograd.Function):
             # dX[i, j, ci] = sum_{dy, dx, co} dY[i k + dy, j k + dx, co] W[ci, co, dy, dx]: a stride-k convolution of dY
             # whose OIHW weight is W as stored
             dyp = dy if int(dy.shape[-1]) % 4 == 0 else torch.nn.functional.pad(dy, (0, 4 - int(dy.shape[-1]) % 4))
-            dx = PackedConv(weight, stride=k, cin_pad=int(dyp.shape[-1]), pad_out=True)(dyp)
+            cp = int(dyp.shape[-1])
+            dx = _packed_call(weight, ('deconv_dgrad', k, cp), lambda w: PackedConv(w, stride=k, cin_pad=cp, pad_out=True), dyp)
             if int(dx.shape[-1]) != int(x.shape[-1]):
                 dx = torch.nn.functional.pad(dx, (0, int(x.shape[-1]) - int(dx.shape[-1])))
         if ctx.needs_input_grad[1]:

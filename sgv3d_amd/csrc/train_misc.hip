@@ -179,7 +179,71 @@ __global__ __launch_bounds__(kT) void weight_rot180_transpose_kernel(const float
     out[i] = w[((size_t)co * cin + ci) * taps + (taps - 1 - t)];
 }
 
+// ------------------------------------------------------------------------------------------------ packed weights, all layers
+// One launch refreshes every packed weight form of a model after an optimiser step: every packed form the training step reads
+// (implicit-GEMM rows, rotated / transposed data-gradient rows, bf16 fragment orders) is a PERMUTATION of a parameter tensor with
+// zero padding, so a job is (parameter, packed buffer, index map); the maps are made once by running the layer's own pack kernels on
+// an index-valued weight tensor (sgv3d_amd/pack_cache.py).  Replaces ~270 pack / rotate / flip launches of 5-10 us per step.
+struct GatherJob {
+    const float *src;        // the parameter (flat)
+    void *dst;               // packed buffer: f32 or bf16
+    const int *idx;          // [n]: element of src, or -1 = 0
+    long long n;
+    int first_block;         // blocks [first_block, next job's first_block) work on this job
+    int bf16;                // dst dtype
+};
+constexpr int kGatherPerBlock = kT * 8;
+
+__global__ __launch_bounds__(kT) void gather_pack_kernel(const GatherJob *__restrict__ jobs, int n_jobs) {
+    // the job of this block: the last one whose first_block <= blockIdx.x
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const GatherJob j = jobs[lo];
+    const long long base = (long long)((int)blockIdx.x - j.first_block) * kGatherPerBlock;
+    // two 16-byte index loads per thread, issued before the gathers
+    const long long i0 = base + (long long)threadIdx.x * 4, i1 = i0 + kT * 4;
+    int4 a = make_int4(-1, -1, -1, -1), b = a;
+    const bool full0 = i0 + 4 <= j.n, full1 = i1 + 4 <= j.n;
+    if (full0) a = *reinterpret_cast<const int4 *>(j.idx + i0);
+    else if (i0 < j.n) { a.x = j.idx[i0]; if (i0 + 1 < j.n) a.y = j.idx[i0 + 1]; if (i0 + 2 < j.n) a.z = j.idx[i0 + 2]; }
+    if (full1) b = *reinterpret_cast<const int4 *>(j.idx + i1);
+    else if (i1 < j.n) { b.x = j.idx[i1]; if (i1 + 1 < j.n) b.y = j.idx[i1 + 1]; if (i1 + 2 < j.n) b.z = j.idx[i1 + 2]; }
+    auto get = [&](int k) { return k >= 0 ? j.src[k] : 0.f; };
+    const float v[8] = {get(a.x), get(a.y), get(a.z), get(a.w), get(b.x), get(b.y), get(b.z), get(b.w)};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const long long i = h ? i1 : i0;
+        if (i >= j.n) continue;
+        const bool full = i + 4 <= j.n;
+        if (j.bf16) {
+            __bf16 *d = static_cast<__bf16 *>(j.dst) + i;
+            if (full) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<bf16x4 *>(d) = bf16x4{(__bf16)v[4 * h], (__bf16)v[4 * h + 1], (__bf16)v[4 * h + 2], (__bf16)v[4 * h + 3]};
+            } else {
+                for (int u = 0; u < 4 && i + u < j.n; ++u) d[u] = (__bf16)v[4 * h + u];
+            }
+        } else {
+            float *d = static_cast<float *>(j.dst) + i;
+            if (full) *reinterpret_cast<float4 *>(d) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+            else for (int u = 0; u < 4 && i + u < j.n; ++u) d[u] = v[4 * h + u];
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int sgv3d_gather_pack_job_bytes(void) { return (int)sizeof(GatherJob); }
+extern "C" int sgv3d_gather_pack_elements_per_block(void) { return kGatherPerBlock; }
+
+extern "C" int sgv3d_gather_pack(const void *jobs, int n_jobs, int total_blocks, void *stream) {
+    SGV3D_REQUIRE(jobs && n_jobs > 0 && total_blocks > 0, "gather_pack: bad argument");
+    hipLaunchKernelGGL(gather_pack_kernel, dim3(total_blocks), dim3(kT), 0, as_stream(stream), static_cast<const GatherJob *>(jobs), n_jobs);
+    return check_launch("gather_pack_kernel");
+}
 
 extern "C" int sgv3d_weight_rot180_transpose(const float *w, int cout, int cin, int kh, int kw, float *out, void *stream) {
     SGV3D_REQUIRE(w && out && cout > 0 && cin > 0 && kh > 0 && kw > 0 && (long long)cout * cin * kh * kw < 0x7fffffffLL,

@@ -8,7 +8,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, pack_cache
 from ._lib import ConvDesc, CONV_NORMAL, CONV_DECONV, CONV_NCHW_OUT, CONV_GROUP_PLANES  # noqa: F401
 
 
@@ -345,6 +345,7 @@ class PackedConv:
         # first use: a training step packs the current weights of every layer twice (forward, data gradient) and only
         # needs the form its kernel choice reads.
         self._w = self._w_wino = None
+        self._entry = None          # pack_cache._Entry when this object is kept across training steps (sgv3d_amd/pack_cache.py)
         self.device = device
         # Winograd F(2x2,3x3) covers the layer
         self.wino_ok = bool(WINOGRAD and not transposed and kh == 3 and kw == 3 and self.stride == 1 and self.dil == 1
@@ -370,6 +371,10 @@ class PackedConv:
                 # both k orders are the identity) -- no pack launch (a training step repacks every layer's weights, forward and data
                 # gradient, at ~5 us per launch)
                 self._w = src.view(self.cout_pad, self.k_pad)
+                if self._entry is not None and src.data_ptr() != self._entry.param.data_ptr():
+                    # kept across steps and NOT a view of the parameter itself (the rotated copy of a data gradient): refreshed like a
+                    # packed form, in place
+                    self._entry.register('w', self._w, lambda pc: pc.w)
                 return self._w
             self._w = torch.empty(self.cout_pad, self.k_pad, dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
@@ -377,11 +382,15 @@ class PackedConv:
                                                        1 if self.transposed else 0, self.k_order, self._w.data_ptr(),
                                                        self.k_pad, self.cout_pad, _st(src))
             _lib.check(rc, "sgv3d_conv_pack_weight")
+            if self._entry is not None:
+                self._entry.register('w', self._w, lambda pc: pc.w)
         return self._w
 
     @property
     def w_wino(self):
         """Winograd F(2x2,3x3) weights (sgv3d_conv_winograd_pack_weight), None when the layer is not covered."""
+        if self._entry is not None:
+            raise pack_cache.NotAPermutation('w_wino')     # a transformed form: this layer packs per call (pack_cache._Entry.call)
         if self._w_wino is None and self.wino_ok:
             lib = _lib.load()
             src = self._keep
@@ -400,6 +409,8 @@ class PackedConv:
             with torch.cuda.device(self.device):
                 rc = _lib.load().sgv3d_conv_weight_to_bf16(self.w.data_ptr(), self.k_pad, self.cout_pad, self.w_bf16.data_ptr(), _st(self.w))
             _lib.check(rc, "sgv3d_conv_weight_to_bf16")
+            if self._entry is not None:
+                self._entry.register('w_bf16', self.w_bf16, lambda pc: pc._bf16_weights())
         return self.w_bf16
 
     def wino4_ok(self, d=None, gate=None):
@@ -427,6 +438,8 @@ class PackedConv:
 
     def _f4res_weights(self):
         """U = G g G^T in the fragment order conv_f4res_kernel streams (sgv3d_conv3x3_f4res_pack_weight), made on first use."""
+        if self._entry is not None:
+            raise pack_cache.NotAPermutation('w_f4res')     # a transformed form: this layer packs per call (pack_cache._Entry.call)
         if getattr(self, 'w_f4res', None) is None:
             lib = _lib.load()
             w = self._keep                                           # [cout, cin_real, 3, 3] f32 on the device
@@ -441,6 +454,8 @@ class PackedConv:
     def _wino4_weights(self):
         """U[p] = (G g G^T)[i][j] for the 36 positions of F(4x4,3x3), each a packed 1x1 weight block of the implicit-GEMM
         kernel (36 x cout_pad x k_pad floats), made on first use by one kernel (sgv3d_conv_winograd4_pack_weight)."""
+        if self._entry is not None:
+            raise pack_cache.NotAPermutation('w_wino4')     # a transformed form: this layer packs per call (pack_cache._Entry.call)
         if getattr(self, 'w_wino4', None) is None:
             lib = _lib.load()
             w = self._keep                                           # [cout, cin_real, 3, 3] f32 on the device
@@ -470,6 +485,8 @@ class PackedConv:
     def _pw_x3_weights(self):
         """The weights as three bf16 planes per element in fragment order ([cout_pad / 16][kh kw cin / 32][3][512], cout_pad = cout
         rounded up to 32), made on first use (sgv3d_conv_pack_weight_x3)."""
+        if self._entry is not None:
+            raise pack_cache.NotAPermutation('w_pw_x3')     # a transformed form: this layer packs per call (pack_cache._Entry.call)
         if getattr(self, 'w_pw_x3', None) is None:
             lib = _lib.load()
             w = self._keep                                           # [cout, cin_real, kh, kw] f32 on the device
@@ -486,6 +503,8 @@ class PackedConv:
     def _wino4_x3_weights(self):
         """U[p] of F(4x4,3x3) as three bf16 planes per element ([36][cout_pad][cin / 32][3][32], cout_pad = cout rounded up to 32) for
         the f32x3 position GEMM, made on first use by one kernel (sgv3d_conv_winograd4_pack_weight_x3)."""
+        if self._entry is not None:
+            raise pack_cache.NotAPermutation('w_wino4_x3')     # a transformed form: this layer packs per call (pack_cache._Entry.call)
         if getattr(self, 'w_wino4_x3', None) is None:
             lib = _lib.load()
             w = self._keep                                           # [cout, cin_real, 3, 3] f32 on the device
@@ -514,6 +533,8 @@ class PackedConv:
                                                         self.w_dw.data_ptr(), _st(w))
             _lib.check(rc, "sgv3d_conv_dw_bf16_pack_weight")
             self._keep_dw = w
+            if self._entry is not None:
+                self._entry.register('w_dw', self.w_dw, lambda pc: pc._dw_weights())
         return self.w_dw
 
     def _dw_eligible(self, d, gate=None, io=0):
@@ -530,6 +551,8 @@ class PackedConv:
             with torch.cuda.device(w.device):
                 rc = lib.sgv3d_conv3x3_patch_bf16_pack_weight(w.data_ptr(), self.cout, self.cin, self.w_patch.data_ptr(), _st(w))
             _lib.check(rc, "sgv3d_conv3x3_patch_bf16_pack_weight")
+            if self._entry is not None:
+                self._entry.register('w_patch', self.w_patch, lambda pc: pc._patch_weights())
         return self.w_patch
 
     def out_hw(self, h, w):

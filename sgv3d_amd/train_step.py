@@ -39,7 +39,7 @@ import os
 
 import torch
 
-from . import _lib, grad_slots
+from . import _lib, grad_slots, pack_cache
 
 DIRECT_GRADS = os.environ.get("SGV3D_DIRECT_GRADS", "1") != "0"   # 0: every gradient goes through autograd's accumulate add
 
@@ -132,6 +132,7 @@ class DataParallelAdamW:
         self._hyper = None            # device [lr, lr / bc1, 1 / sqrt(bc2)] of the step about to run (GraphedTrainStep)
         self._in_graph = False        # inside GraphedTrainStep's capture: no collectives from the gradient hooks
         self.first_early_event = None # a torch.cuda.Event recorded on the backward stream when bucket 0's all-reduce is launched
+        self.packs = None             # pack_cache.PackCache of these parameters (made by the first zero_grad)
         if self._collectives():
             self.broadcast_parameters()
 
@@ -174,6 +175,13 @@ class DataParallelAdamW:
         self.flat.zero_grad()
         if hasattr(self, '_left') and not self._pending:
             self._arm()
+        # the step's window of kept packed weights opens here: every registered packed form is rewritten from the parameters as they
+        # are now (one launch), and stays valid until step() changes them (sgv3d_amd/pack_cache.py)
+        if pack_cache.ENABLED and self.flat.buckets[0][0].is_cuda:
+            if self.packs is None:
+                self.packs = pack_cache.PackCache(self.flat.params)
+            pack_cache.ACTIVE = self.packs
+            self.packs.refresh(self.flat.buckets[0][0].device)
 
     def overlap_with_backward(self):
         """Launch a bucket's all-reduce from inside backward, as soon as the last of its parameters has accumulated its
@@ -304,6 +312,8 @@ class DataParallelAdamW:
         ``stage_hyper`` filled (the launch can sit in a hipGraph); the step counter is then ``stage_hyper``'s to advance."""
         lr = self.lr if lr is None else float(lr)
         world = self._world()
+        if self.packs is not None:
+            self.packs.close()          # the weights change below: packed forms are stale until the next zero_grad refreshes them
         if self._collectives() and not self._pending and not self._in_graph:
             self.all_reduce_grads()
         self.flat.check_views()

@@ -155,6 +155,10 @@ out = {"metric": "training samples/s (forward + loss + backward + all-reduce + A
        "first_allreduce_launch_at_fraction_of_backward": FIRST, "bucket_mib": max(g.numel() for _, g, _ in opt.flat.buckets) * 4 / 2**20,
        "gradient_clip_val": args.clip or None, "grad_norm_last_step": grad_norm, "clip_coefficient_last_step": clip_coef,
        "frozen_parameters": sorted(n for n, p in model.named_parameters() if not p.requires_grad),
+       # packed weight forms kept across steps and refreshed by one gather launch per step (sgv3d_amd/pack_cache.py; SGV3D_PACK_CACHE=0: off)
+       "pack_cache": (None if getattr(opt, "packs", None) is None else
+                      {"forms": len(opt.packs.jobs()), "elements": sum(j.dst.numel() for j in opt.packs.jobs()),
+                       "layers_packing_per_call": sum(not e.tracked for e in opt.packs.entries.values())}),
        "param_checksum": float(sum(p.double().abs().sum() for p, _, _ in opt.flat.buckets))}
 if args.profile:
     # the profiled step holds collectives (loss-factor and gradient all-reduces): every rank runs it, rank 0 reports
