@@ -74,7 +74,7 @@ def test_refreshed_forms_are_bitwise_the_pack_kernels_output(mode):
         jobs = [(e, n, j) for e in cache.entries.values() if e.tracked for n, j in e.jobs.items()]
         assert len(jobs) >= (20 if mode == "bf16" else 8), len(jobs)      # (f32: the 3x3 layers read Winograd forms and pack per call)
         kinds = {n for _, n, _ in jobs}
-        assert 'w' in kinds and (mode != "bf16" or 'w_patch' in kinds), kinds
+        assert 'w' in kinds, kinds            # (which bf16 forms appear depends on the per-layer choices: test_every_permutation_form...)
         for e, name, j in jobs:
             want = j.getter(e.make(e.param.detach()))     # the layer's own pack path on the current weights
             want = want.view(torch.bfloat16) if want.dtype == torch.uint8 else want
@@ -180,3 +180,46 @@ def test_outside_the_window_every_layer_packs_from_the_current_weights(mixed_pre
         for k in a:
             assert torch.equal(a[k], b[k]), k
             assert torch.equal(c[k], b[k]), k
+
+
+@pytest.mark.parametrize("shape,kw", [
+    ((64, 64, 3, 3), dict(pad=1)),                    # 3x3: implicit-GEMM rows, bf16 patch fragments, direct-weight fragments
+    ((96, 160, 1, 1), dict()),                        # 1x1 with padded output rows
+    ((128, 32, 2, 2), dict(stride=2, transposed=True)),
+])
+def test_every_permutation_form_is_refreshed_bitwise(shape, kw):
+    """Every packed form the cache keeps (implicit-GEMM rows, their bf16 copy, the bf16 fragment orders of the patch and the
+    direct-weight kernels), made through a cache entry, then the parameter changed behind torch's back and ONE gather launch: bitwise
+    what the pack kernels write for the new weights -- also through a rotated / transposed source (the data-gradient form)."""
+    from sgv3d_amd.hip_ops import PackedConv
+    from sgv3d_amd.conv_grad import _rot180_transpose
+    g = torch.Generator().manual_seed(sum(shape))
+    w = torch.nn.Parameter(torch.randn(shape, generator=g).to(DEV))
+    cache = pack_cache.PackCache([w])
+    cache.open = True
+    transposed = kw.get('transposed', False)
+    cin = shape[0] if transposed else shape[1]
+    makes = {"plain": lambda v: PackedConv(v, cin_pad=cin, **kw)}
+    if not transposed:
+        makes["rotated"] = lambda v: PackedConv(_rot180_transpose(v), cin_pad=shape[0], pad_out=True, **kw)
+    getters = {"w": lambda pc: pc.w, "w_bf16": lambda pc: pc._bf16_weights(), "w_dw": lambda pc: pc._dw_weights()}
+    if shape[2] == 3 and not transposed:
+        getters["w_patch"] = lambda pc: pc._patch_weights()
+    entries = {}
+    for name, make in makes.items():
+        e = entries[name] = cache.lookup(w, name, make)
+        pc = e.conv()
+        for get in getters.values():
+            if name == "rotated" and get is getters.get("w_patch") and not pc.patch_ok:
+                continue
+            get(pc)
+    assert sum(len(e.jobs) for e in entries.values()) >= len(getters)
+    with torch.no_grad():
+        w.data.mul_(-0.37).add_(0.01)                    # (through .data: no version bump, like the fused AdamW)
+    cache.refresh(DEV)
+    for name, e in entries.items():
+        fresh = e.make(w.detach())
+        for fname, job in e.jobs.items():
+            want = getters[fname](fresh)
+            assert torch.equal(job.dst.view(torch.uint8), want.reshape(-1).view(torch.uint8)), (name, fname)
+        assert e.pc is not None and all(getattr(e.pc, a, None) is not None for a in ("_w",))
