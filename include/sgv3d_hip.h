@@ -197,6 +197,21 @@ int sgv3d_geometry_voxel_index(int num_cams, int cams_per_batch, int num_depth, 
                                const float *voxel_size /*host*/, int32_t *geom_xyz, float *geom_f,
                                void *stream);
 
+/* The reference recomputes the geometry for every batch (lss_fpn.py:478-488) from calibration tensors its data loader creates anew
+ * per batch -- for a roadside camera the same numbers every time.  sgv3d_calib_changed decides ON THE DEVICE whether the n (<= 8)
+ * calibration tensors (device pointers, byte counts: multiples of 4) differ from `copy` (sum of nbytes bytes, zero-filled before the
+ * first call), the values at the last change: changed[0] = 1 and copy := the tensors if they differ or force != 0, else changed[0] = 0.
+ * The *_gated entry points take that flag as `run` (device pointer, NULL = always run): with run[0] == 0 the launch returns at once
+ * and its outputs keep what the last run wrote -- no host synchronisation anywhere. */
+int sgv3d_calib_changed(int n, const void *const *tensors /*host array of device pointers*/, const int32_t *nbytes /*host*/,
+                        void *copy, int force, int32_t *changed, void *stream);
+int sgv3d_calib_prep_gated(int num_cams, const float *sensor2ego, const float *sensor2virtual, const float *intrin,
+                           const float *ida, float *prep, const int32_t *run, void *stream);
+int sgv3d_geometry_voxel_index_gated(int num_cams, int cams_per_batch, int num_depth, int feat_h, int feat_w,
+                                     const float *frustum, const float *prep, const float *ref_h, const float *bda,
+                                     const float *voxel_coord /*host*/, const float *voxel_size /*host*/, int32_t *geom_xyz,
+                                     float *geom_f, const int32_t *run, void *stream);
+
 /* ================================================================================================
  * Lift (softmax over height bins  (x)  context)
  * ================================================================================================ */
@@ -413,6 +428,9 @@ int sgv3d_global_avgpool(int batch, int pixels, int channels, int x_ld, const fl
  * act: 0 none, 1 relu, 2 sigmoid. */
 int sgv3d_dense(int batch, int k, int n, const float *x, const float *w, const float *scale,
                 const float *bias, int act, float *y, void *stream);
+/* ... skipped when run[0] == 0 (device flag of sgv3d_calib_changed; NULL = always run): y keeps its previous contents. */
+int sgv3d_dense_gated(int batch, int k, int n, const float *x, const float *w, const float *scale,
+                      const float *bias, int act, float *y, const int32_t *run, void *stream);
 
 /* y[b, p, coff + c] = v[b, c] for every pixel p (F.interpolate of a 1x1 map, lss_fpn.py:101-104). */
 int sgv3d_broadcast_channels(int batch, int pixels, int channels, int y_ld, int y_coff,

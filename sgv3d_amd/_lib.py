@@ -47,6 +47,10 @@ _PROTOS = {
     "sgv3d_lift_splat_planned": (c_int, [c_int] * 6 + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "sgv3d_voxel_pooling_backward": (c_int, [c_int] * 3 + [c_void_p, c_void_p, c_ll, c_ll, c_ll, c_ll, c_void_p, c_void_p]),
     "sgv3d_calib_prep": (c_int, [c_int] + [c_void_p] * 6),
+    "sgv3d_calib_prep_gated": (c_int, [c_int] + [c_void_p] * 7),
+    "sgv3d_calib_changed": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_void_p, c_int, c_void_p, c_void_p]),
+    "sgv3d_geometry_voxel_index_gated": (c_int, [c_int] * 5 + [c_void_p] * 4 + [ctypes.POINTER(ctypes.c_float)] * 2 + [c_void_p] * 4),
+    "sgv3d_dense_gated": (c_int, [c_int] * 3 + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p]),
     "sgv3d_geometry_voxel_index": (c_int, [c_int] * 5 + [c_void_p] * 4 + [ctypes.POINTER(ctypes.c_float)] * 2 + [c_void_p] * 3),
     "sgv3d_lift": (c_int, [c_int] * 4 + [c_void_p] * 4),
     "sgv3d_lift_bf16": (c_int, [c_int] * 4 + [c_void_p] * 4),

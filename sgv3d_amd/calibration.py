@@ -10,10 +10,11 @@ plan build altogether:
   versions, as last time (static input buffers of a hipGraph replay, a benchmark loop, a harness that
   keeps its ``mats`` on the device) -> nothing is launched.  The cache holds references to those tensors,
   so their addresses cannot be recycled for other data while it trusts them;
-* **device path** (new tensor objects, e.g. the reference harness's ``mats[k].cuda()`` per step): the
-  geometry kernel rewrites ``geom`` in place and the cached plan build compares it with the copy the plan
-  was built for ON THE DEVICE (no host sync) and rebuilds only on a difference
-  (``VoxelPlan(cached=True)``, csrc/voxel_pooling.hip).
+* **device path** (new tensor objects, e.g. the reference harness's ``mats[k].cuda()`` per step): one small kernel
+  compares the tensors' numbers with those of the last change ON THE DEVICE (``sgv3d_calib_changed``, round 6); the
+  geometry kernels and the gate MLPs take its flag and return at once when nothing changed, otherwise the geometry
+  kernel rewrites ``geom`` in place and the cached plan build compares it with the copy the plan was built for -- also
+  on the device, no host sync -- and rebuilds only on a difference (``VoxelPlan(cached=True)``, csrc/voxel_pooling.hip).
 
 Writes through raw pointers (other libraries' kernels) do not bump tensor versions; the calibration tensors
 are only ever written by torch ops here (``copy_``), which do.
@@ -46,7 +47,7 @@ class CalibrationCache:
     that rewrite the calibration tensors out of band (raw pointers, ``.data``): tensor versions do not see such writes."""
 
     class Entry:
-        __slots__ = ("_src", "_tag", "geom", "plan", "gates", "event", "stream", "join_stream")
+        __slots__ = ("_src", "_tag", "geom", "plan", "gates", "event", "stream", "join_stream", "content", "changed", "gate_tmp")
 
         def __init__(self):
             self._src = None          # [(tensor, version)] the cached geometry was computed from
@@ -58,6 +59,9 @@ class CalibrationCache:
             self.event = None         # recorded behind the last (re)build
             self.stream = None        # cuda_stream handle of that build
             self.join_stream = None   # stream capture only: the side stream the refresh was recorded on (see join_capture)
+            self.content = None       # device copy of the calibration tensors' bytes at the last change (sgv3d_calib_changed)
+            self.changed = None       # int32 device flag of the refresh in flight: 0 = same numbers as `content`, kernels skip
+            self.gate_tmp = None      # the gate MLPs' intermediate vectors (persistent: the gated launches write in place)
 
         def matches(self, tensors, tag):
             if self._src is None or self._tag != tag or len(tensors) != len(self._src):
@@ -128,7 +132,8 @@ class CalibrationCache:
         self._entries[0].remember(tensors, tag)
 
     def invalidate(self):
-        """Forget what the cached geometry was computed from (every sweep): the next forward re-runs the geometry kernel
-        and the device-side plan check.  Needed after writing calibration tensors through raw pointers / ``.data``."""
+        """Forget what the cached geometry was computed from (every sweep): the next forward goes through the device path (the
+        calibration tensors' numbers compared with the last ones on the device, geometry kernel and plan check when they
+        differ).  Needed after writing calibration tensors through raw pointers / ``.data``."""
         for e in self._entries.values():
             e._src = None

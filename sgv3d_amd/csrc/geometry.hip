@@ -74,9 +74,12 @@ __device__ void mm4(const float *__restrict__ A, const float *__restrict__ B, fl
         }
 }
 
+// run: nullable DEVICE flag; 0 = the calibration is the one `prep` / the index tensor were computed from (sgv3d_calib_changed):
+// the launch returns at once and leaves its outputs as they are
 __global__ void calib_prep_kernel(int num_cams, const float *__restrict__ s2e, const float *__restrict__ s2v,
                                   const float *__restrict__ intrin, const float *__restrict__ ida,
-                                  float *__restrict__ prep) {
+                                  float *__restrict__ prep, const int *__restrict__ run) {
+    if (run && *run == 0) return;
     const int cam = blockIdx.x * blockDim.x + threadIdx.x;
     if (cam >= num_cams) return;
     float tmp[16];
@@ -122,7 +125,8 @@ __global__ __launch_bounds__(256) void geometry_kernel(int pts_per_cam, int cams
                                                        const float *__restrict__ ref_h,
                                                        const float *__restrict__ bda, GeomConst gc,
                                                        int32_t *__restrict__ geom_xyz,
-                                                       float *__restrict__ geom_f) {
+                                                       float *__restrict__ geom_f, const int *__restrict__ run) {
+    if (run && *run == 0) return;
     __shared__ float M[64];  // ida_inv | combine_virtual | combine_ego | bda
     const int cam = blockIdx.y;
     if (threadIdx.x < 48) M[threadIdx.x] = prep[(size_t)cam * 48 + threadIdx.x];
@@ -170,20 +174,87 @@ __global__ __launch_bounds__(256) void geometry_kernel(int pts_per_cam, int cams
 
 }  // namespace
 
-extern "C" int sgv3d_calib_prep(int num_cams, const float *sensor2ego, const float *sensor2virtual,
-                                const float *intrin, const float *ida, float *prep, void *stream) {
+extern "C" int sgv3d_calib_prep_gated(int num_cams, const float *sensor2ego, const float *sensor2virtual,
+                                      const float *intrin, const float *ida, float *prep, const int32_t *run, void *stream) {
     SGV3D_REQUIRE(num_cams > 0, "calib_prep: num_cams=%d", num_cams);
     SGV3D_REQUIRE(sensor2ego && sensor2virtual && intrin && ida && prep, "calib_prep: null pointer");
     hipLaunchKernelGGL(calib_prep_kernel, dim3(cdiv(num_cams, 64)), dim3(64), 0, as_stream(stream), num_cams,
-                       sensor2ego, sensor2virtual, intrin, ida, prep);
+                       sensor2ego, sensor2virtual, intrin, ida, prep, run);
     return check_launch("calib_prep_kernel");
 }
+
+extern "C" int sgv3d_calib_prep(int num_cams, const float *sensor2ego, const float *sensor2virtual,
+                                const float *intrin, const float *ida, float *prep, void *stream) {
+    return sgv3d_calib_prep_gated(num_cams, sensor2ego, sensor2virtual, intrin, ida, prep, nullptr, stream);
+}
+
+// ---- "is this the calibration the cached state was computed from?" decided on the device --------------------------------
+namespace {
+struct CalibSrc {
+    const unsigned *p[8];
+    int words[8];
+    int n;
+};
+// One workgroup: compares the calibration tensors word for word with the copy taken at the last change; on a difference (or
+// force) stores the new values as the copy.  changed[0] = 1 / 0.
+__global__ __launch_bounds__(256) void calib_changed_kernel(CalibSrc s, unsigned *__restrict__ copy, int force, int *__restrict__ changed) {
+    __shared__ int diff;
+    if (threadIdx.x == 0) diff = force ? 1 : 0;
+    __syncthreads();
+    int off = 0, mine = 0;
+    for (int t = 0; t < s.n; ++t) {
+        for (int i = threadIdx.x; i < s.words[t]; i += 256) mine |= s.p[t][i] != copy[off + i];
+        off += s.words[t];
+    }
+    if (mine) atomicOr(&diff, 1);
+    __syncthreads();
+    const int d = diff;
+    if (d) {
+        off = 0;
+        for (int t = 0; t < s.n; ++t) {
+            for (int i = threadIdx.x; i < s.words[t]; i += 256) copy[off + i] = s.p[t][i];
+            off += s.words[t];
+        }
+    }
+    if (threadIdx.x == 0) changed[0] = d;
+}
+}  // namespace
+
+extern "C" int sgv3d_calib_changed(int n, const void *const *tensors, const int32_t *nbytes, void *copy, int force,
+                                   int32_t *changed, void *stream) {
+    SGV3D_REQUIRE(n > 0 && n <= 8 && tensors && nbytes && copy && changed, "calib_changed: 1..8 tensors, non-null pointers");
+    CalibSrc s;
+    s.n = n;
+    for (int i = 0; i < n; ++i) {
+        SGV3D_REQUIRE(tensors[i] && nbytes[i] > 0 && nbytes[i] % 4 == 0 && (reinterpret_cast<uintptr_t>(tensors[i]) & 3) == 0,
+                      "calib_changed: tensor %d must be non-null, 4-byte aligned, a multiple of 4 bytes", i);
+        s.p[i] = static_cast<const unsigned *>(tensors[i]);
+        s.words[i] = nbytes[i] / 4;
+    }
+    hipLaunchKernelGGL(calib_changed_kernel, dim3(1), dim3(256), 0, as_stream(stream), s, static_cast<unsigned *>(copy), force, changed);
+    return check_launch("calib_changed_kernel");
+}
+
+extern "C" int sgv3d_geometry_voxel_index_gated(int num_cams, int cams_per_batch, int num_depth, int feat_h,
+                                                int feat_w, const float *frustum, const float *prep,
+                                                const float *ref_h, const float *bda, const float *voxel_coord,
+                                                const float *voxel_size, int32_t *geom_xyz, float *geom_f,
+                                                const int32_t *run, void *stream);
 
 extern "C" int sgv3d_geometry_voxel_index(int num_cams, int cams_per_batch, int num_depth, int feat_h,
                                           int feat_w, const float *frustum, const float *prep,
                                           const float *ref_h, const float *bda, const float *voxel_coord,
                                           const float *voxel_size, int32_t *geom_xyz, float *geom_f,
                                           void *stream) {
+    return sgv3d_geometry_voxel_index_gated(num_cams, cams_per_batch, num_depth, feat_h, feat_w, frustum, prep, ref_h, bda,
+                                            voxel_coord, voxel_size, geom_xyz, geom_f, nullptr, stream);
+}
+
+extern "C" int sgv3d_geometry_voxel_index_gated(int num_cams, int cams_per_batch, int num_depth, int feat_h,
+                                                int feat_w, const float *frustum, const float *prep,
+                                                const float *ref_h, const float *bda, const float *voxel_coord,
+                                                const float *voxel_size, int32_t *geom_xyz, float *geom_f,
+                                                const int32_t *run, void *stream) {
     SGV3D_REQUIRE(num_cams > 0 && cams_per_batch > 0 && num_depth > 0 && feat_h > 0 && feat_w > 0,
                   "geometry_voxel_index: non-positive size");
     SGV3D_REQUIRE(frustum && prep && ref_h && voxel_coord && voxel_size && geom_xyz,
@@ -201,6 +272,6 @@ extern "C" int sgv3d_geometry_voxel_index(int num_cams, int cams_per_batch, int 
     }
     dim3 grid(cdiv(pts, 256), num_cams);
     hipLaunchKernelGGL(geometry_kernel, grid, dim3(256), 0, as_stream(stream), (int)pts, cams_per_batch,
-                       reinterpret_cast<const float4 *>(frustum), prep, ref_h, bda, gc, geom_xyz, geom_f);
+                       reinterpret_cast<const float4 *>(frustum), prep, ref_h, bda, gc, geom_xyz, geom_f, run);
     return check_launch("geometry_kernel");
 }

@@ -142,7 +142,9 @@ __global__ __launch_bounds__(kBlock) void global_avgpool_final_kernel(int B, int
 // (Mlp fc1/fc2, SELayer conv_reduce/conv_expand on [B,C,1,1], ASPP pooled 1x1; lss_fpn.py:122-159,81-86)
 __global__ __launch_bounds__(kBlock) void dense_kernel(int B, int K, int N, const float *__restrict__ x,
                                                        const float *__restrict__ w, const float *__restrict__ scale,
-                                                       const float *__restrict__ bias, int act, float *__restrict__ y) {
+                                                       const float *__restrict__ bias, int act, float *__restrict__ y,
+                                                       const int *__restrict__ run) {
+    if (run && *run == 0) return;                 // (sgv3d_dense_gated: y keeps what an earlier launch wrote)
     const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (wave >= B * N) return;
@@ -516,13 +518,18 @@ extern "C" int sgv3d_global_avgpool(int batch, int pixels, int channels, int x_l
     return check_launch("global_avgpool_kernel");
 }
 
-extern "C" int sgv3d_dense(int batch, int k, int n, const float *x, const float *w, const float *scale,
-                           const float *bias, int act, float *y, void *stream) {
+extern "C" int sgv3d_dense_gated(int batch, int k, int n, const float *x, const float *w, const float *scale,
+                                 const float *bias, int act, float *y, const int32_t *run, void *stream) {
     SGV3D_REQUIRE(batch > 0 && k > 0 && n > 0 && act >= 0 && act <= 2, "dense: bad shape/act");
     SGV3D_REQUIRE(x && w && y, "dense: null pointer");
     hipLaunchKernelGGL(dense_kernel, dim3(cdiv((long long)batch * n, kBlock / 64)), dim3(kBlock), 0, as_stream(stream),
-                       batch, k, n, x, w, scale, bias, act, y);
+                       batch, k, n, x, w, scale, bias, act, y, run);
     return check_launch("dense_kernel");
+}
+
+extern "C" int sgv3d_dense(int batch, int k, int n, const float *x, const float *w, const float *scale,
+                           const float *bias, int act, float *y, void *stream) {
+    return sgv3d_dense_gated(batch, k, n, x, w, scale, bias, act, y, nullptr, stream);
 }
 
 extern "C" int sgv3d_broadcast_channels(int batch, int pixels, int channels, int y_ld, int y_coff, const float *v,

@@ -1036,6 +1036,34 @@ _BRANCH_POOL = {}
 _BRANCH_TOP = {}
 
 
+_OWNED_STREAMS = {}       # device index -> cuda_stream handles handed out by distinct_stream() and still meant to be distinct
+
+
+def distinct_stream(device, avoid=()):
+    """A ``torch.cuda.Stream`` whose underlying HIP stream is none of ``avoid`` (streams), not the current stream and none that
+    this function handed out before on the device.  ``torch.cuda.Stream()`` draws round-robin from a pool of 32 per device: the
+    33rd object IS the first one's stream again, and a fork of a stream capture onto the capturing stream itself (or onto another
+    branch of the same capture) is not the graph the code meant -- after enough pipelines / graphed forwards in one process that
+    happened (a crash inside hipStreamEndCapture in the GPU suite, round 6)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    taken = _OWNED_STREAMS.setdefault(key, set())
+    banned = {st.cuda_stream for st in avoid if st is not None} | {torch.cuda.current_stream(dev).cuda_stream} | taken
+    for _ in range(64):
+        st = torch.cuda.Stream(device=dev)
+        if st.cuda_stream not in banned:
+            if len(taken) < 24:                     # (beyond that the pool cannot keep everything distinct: best effort)
+                taken.add(st.cuda_stream)
+            return st
+    return torch.cuda.Stream(device=dev)
+
+
+def release_stream(st):
+    """Give a stream of ``distinct_stream`` back (its owner is gone)."""
+    for taken in _OWNED_STREAMS.values():
+        taken.discard(st.cuda_stream)
+
+
 def run_parallel(device, thunks):
     """``[t() for t in thunks]``; inside a stream capture the thunks are forked branches of the graph (the first one stays on
     the capturing stream).  A call from inside a forked branch runs its thunks in sequence."""
@@ -1052,7 +1080,7 @@ def run_parallel(device, thunks):
         return [t() for t in thunks]
     need = top + len(thunks) - 1
     while len(pool) < need:
-        pool.append(torch.cuda.Stream(device=dev))
+        pool.append(distinct_stream(dev, pool))
     mine = pool[top:need]
     _BRANCH_TOP[key] = need
     cur = torch.cuda.current_stream(dev)
@@ -1227,16 +1255,23 @@ def global_avgpool(x, out=None):
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
 
-def dense(x, w, scale=None, bias=None, act=ACT_NONE, out=None):
-    """x [B,K], w [N,K] -> act(scale*(x @ w.T) + bias) [B,N]."""
+def dense(x, w, scale=None, bias=None, act=ACT_NONE, out=None, run=None):
+    """x [B,K], w [N,K] -> act(scale*(x @ w.T) + bias) [B,N].  ``run``: int32 device flag; 0 skips the launch's work and leaves
+    ``out`` (then required) as it is (sgv3d_dense_gated)."""
     B, K = (int(s) for s in x.shape)
     N = int(w.shape[0])
     assert int(w.shape[1]) == K and x.is_contiguous() and w.is_contiguous()
+    assert run is None or out is not None
     if out is None:
         out = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    assert tuple(out.shape) == (B, N) and out.dtype == torch.float32 and out.is_contiguous()
     with torch.cuda.device(x.device), prof("dense"):
-        rc = _lib.load().sgv3d_dense(B, K, N, x.data_ptr(), w.data_ptr(), _lib.ptr(scale), _lib.ptr(bias),
-                                    int(act), out.data_ptr(), _st(x))
+        if run is not None:
+            rc = _lib.load().sgv3d_dense_gated(B, K, N, x.data_ptr(), w.data_ptr(), _lib.ptr(scale), _lib.ptr(bias),
+                                              int(act), out.data_ptr(), run.data_ptr(), _st(x))
+        else:
+            rc = _lib.load().sgv3d_dense(B, K, N, x.data_ptr(), w.data_ptr(), _lib.ptr(scale), _lib.ptr(bias),
+                                        int(act), out.data_ptr(), _st(x))
     _lib.check(rc, "sgv3d_dense")
     return out
 

@@ -163,18 +163,28 @@ class MSCThead(HipModule):
             ]
         return s
 
-    def camera_gates(self, mats_dict, device):
+    def camera_gates(self, mats_dict, device, out=None, tmp=None, run=None):
         """The SE gate vectors of the two scales (:262-299): a function of the calibration and the weights alone, kept per
-        calibration by ``LSSFPN.calibration`` (layers/backbones/lss_fpn.py here)."""
+        calibration by ``LSSFPN.calibration`` (layers/backbones/lss_fpn.py here).  ``out`` / ``tmp`` / ``run``: in place into the
+        persistent vectors, skipped on the device when the flag says the calibration is the last one's (HeightNet.camera_gates)."""
         s = self.hip_state(device)
         v = HeightNet.mlp_input(mats_dict)                                   # :262-292
-        out = []
+        res = []
         for i in (0, 1):
+            layers = s[f'gate{i}']
             h = v
-            for w, b, act in s[f'gate{i}']:
-                h = hip_ops.dense(h, w, None, b, act)
-            out.append(h)
-        return out
+            if tmp is None:
+                for w, b, act in layers:
+                    h = hip_ops.dense(h, w, None, b, act)
+            else:
+                bufs = tmp.get(i)
+                if bufs is None or bufs[0].shape[0] != v.shape[0]:
+                    bufs = tmp[i] = [torch.zeros(v.shape[0], int(w.shape[0]), dtype=torch.float32, device=v.device) for w, _, _ in layers[:-1]]
+                last = out[i] if out is not None else torch.zeros(v.shape[0], int(layers[-1][0].shape[0]), dtype=torch.float32, device=v.device)
+                for (w, b, act), dst in zip(layers, bufs + [last]):
+                    h = hip_ops.dense(h, w, None, b, act, out=dst, run=run)
+            res.append(h)
+        return res
 
     def hip_forward(self, feats, mats_dict, out_ld, gates=None):
         """feats = [stride-16 map, stride-8 map] NHWC.  Returns (height_context, semantic1, semantic0):

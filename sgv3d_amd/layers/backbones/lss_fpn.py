@@ -32,6 +32,9 @@ import os as _os
 # 0: the height net's camera-aware SE gates (27 calibration numbers -> MLP -> sigmoid; no pixel enters) are recomputed on every
 # forward, as the reference does (lss_fpn.py:208-246); default: kept per calibration beside the voxel indices and the plan
 CACHE_CAMERA_GATES = _os.environ.get("SGV3D_CACHE_CAMERA_GATES", "1") != "0"
+# new calibration tensor objects with the numbers of the last frame (the reference harness: fresh tensors per batch, static camera):
+# decided by one compare launch on the device, the geometry kernels and gate MLPs skip themselves (0: always recompute)
+GATED_CALIBRATION = _os.environ.get("SGV3D_GATED_CALIBRATION", "1") != "0"
 # 0: ASPP's pooled branch is broadcast into the concat buffer and multiplied by conv1 like the other four (lss_fpn.py:101-108);
 # default (batch 1, f32): folded into conv1's per-image bias
 FOLD_ASPP_POOL = _os.environ.get("SGV3D_FOLD_ASPP_POOL", "1") != "0"
@@ -269,11 +272,13 @@ class HeightNet(HipModule):
         )
         return mlp_input.reshape(-1, mlp_input.shape[-1]).float().contiguous()
 
-    def camera_gates(self, mats_dict, device):
+    def camera_gates(self, mats_dict, device, out=None, tmp=None, run=None):
         """The two SE gate vectors [B*N, mid] (context, height) of lss_fpn.py:208-246: BatchNorm1d(27) -> Mlp -> SELayer's
         reduce / expand / sigmoid on the 27 calibration numbers per camera.  A function of the calibration (and the weights)
         alone -- no pixel enters -- so ``LSSFPN.calibration`` keeps them per calibration like the voxel indices; eight
-        one-workgroup launches plus the torch indexing of ``mlp_input`` that a static camera pays once, not per frame."""
+        one-workgroup launches plus the torch indexing of ``mlp_input`` that a static camera pays once, not per frame.
+        ``out`` (the two persistent gate vectors) / ``tmp`` (dict for the intermediate vectors, filled here) / ``run`` (int32
+        device flag of ``sgv3d_calib_changed``): every launch writes in place and is skipped on the device when the flag is 0."""
         s = self.hip_state(device)
         v = self.mlp_input(mats_dict)                                                   # [B*N, 27]
         # BatchNorm1d(27) in eval mode is a per-feature affine: folded once into fc1
@@ -285,12 +290,22 @@ class HeightNet(HipModule):
                 s[key] = ((fc1_w * s['bn_scale'][None, :]).contiguous(),
                           (fc1_b + fc1_w @ s['bn_shift']).contiguous())
 
-        def gate(name):                                   # four one-workgroup launches each
-            h = hip_ops.dense(v, s[name + '_fc1_folded'][0], None, s[name + '_fc1_folded'][1], hip_ops.ACT_RELU)
-            for w, b, act in s[name + '_gate'][1:]:
-                h = hip_ops.dense(h, w, None, b, act)
-            return h                                                                    # sigmoid gate [B*N, mid]
-        return [gate('context'), gate('height')]
+        def gate(i, name):                                # four one-workgroup launches each
+            layers = [(s[name + '_fc1_folded'][0], s[name + '_fc1_folded'][1], hip_ops.ACT_RELU)] + list(s[name + '_gate'][1:])
+            if tmp is None:
+                h = v
+                for w, b, act in layers:
+                    h = hip_ops.dense(h, w, None, b, act)
+                return h                                                                # sigmoid gate [B*N, mid]
+            bufs = tmp.get(name)
+            if bufs is None or bufs[0].shape[0] != v.shape[0]:
+                bufs = tmp[name] = [torch.zeros(v.shape[0], int(w.shape[0]), dtype=torch.float32, device=v.device) for w, _, _ in layers[:-1]]
+            last = out[i] if out is not None else torch.zeros(v.shape[0], int(layers[-1][0].shape[0]), dtype=torch.float32, device=v.device)
+            h = v
+            for (w, b, act), dst in zip(layers, bufs + [last]):
+                h = hip_ops.dense(h, w, None, b, act, out=dst, run=run)
+            return h
+        return [gate(0, 'context'), gate(1, 'height')]
 
     def hip_forward(self, x, mats_dict, gates=None):
         """x NHWC [B*N,fH,fW,in] -> NHWC [B*N,fH,fW,D+C] = cat(height logits, context)  (:250).  ``gates``: the result of
@@ -380,10 +395,11 @@ class LSSFPN(HipModule):
 
     # -------------------------------------------------------------------------------- geometry
     def get_geometry_voxel_index(self, sensor2ego_mat, sensor2virtual_mat, intrin_mat, ida_mat,
-                                 reference_heights, bda_mat, want_float=False, out=None):
+                                 reference_heights, bda_mat, want_float=False, out=None, run=None):
         """get_geometry (lss_fpn.py:372-401) fused with the quantise of :487-488.
         Inputs [B, num_cams, 4, 4] / [B, num_cams] / [B, 4, 4] on the device.
-        Returns int32 [B, num_cams, D, fH, fW, 3] (written into ``out`` when given; and the float points when asked)."""
+        Returns int32 [B, num_cams, D, fH, fW, 3] (written into ``out`` when given; and the float points when asked).
+        ``run`` (with ``out``): int32 device flag; 0 = ``out`` already holds this calibration's indices, both kernels return at once."""
         lib = _lib.load()
         B, num_cams = int(sensor2ego_mat.shape[0]), int(sensor2ego_mat.shape[1])
         n = B * num_cams
@@ -402,12 +418,36 @@ class LSSFPN(HipModule):
         vs = (ctypes.c_float * 3)(*self._voxel_size_host)
         with torch.cuda.device(dev), hip_ops.prof("geometry"):
             st = _lib.stream_handle(dev)
-            _lib.check(lib.sgv3d_calib_prep(n, s2e.data_ptr(), s2v.data_ptr(), K.data_ptr(), ida.data_ptr(),
-                                            prep.data_ptr(), st), "sgv3d_calib_prep")
-            _lib.check(lib.sgv3d_geometry_voxel_index(n, num_cams, D, fH, fW, frustum.data_ptr(), prep.data_ptr(),
-                                                      refh.data_ptr(), _lib.ptr(bda), vc, vs, geom.data_ptr(),
-                                                      _lib.ptr(geom_f), st), "sgv3d_geometry_voxel_index")
+            assert run is None or (out is not None and not want_float)
+            _lib.check(lib.sgv3d_calib_prep_gated(n, s2e.data_ptr(), s2v.data_ptr(), K.data_ptr(), ida.data_ptr(),
+                                                  prep.data_ptr(), _lib.ptr(run), st), "sgv3d_calib_prep")
+            _lib.check(lib.sgv3d_geometry_voxel_index_gated(n, num_cams, D, fH, fW, frustum.data_ptr(), prep.data_ptr(),
+                                                            refh.data_ptr(), _lib.ptr(bda), vc, vs, geom.data_ptr(),
+                                                            _lib.ptr(geom_f), _lib.ptr(run), st), "sgv3d_geometry_voxel_index")
         return (geom, geom_f) if want_float else geom
+
+    def _calibration_changed(self, cc, srcs, force):
+        """int32 device flag: 1 when the calibration tensors' numbers differ from those of the last change kept in ``cc.content`` (or
+        ``force``), which then takes the new ones; 0 otherwise (``sgv3d_calib_changed``: one workgroup, no host sync).  None when the
+        tensors cannot be compared that way (not contiguous, odd sizes) or the gating is switched off."""
+        ts = [t for t in srcs if t is not None]
+        if not GATED_CALIBRATION or not all(t.is_cuda and t.is_contiguous() and (t.numel() * t.element_size()) % 4 == 0 and t.numel() > 0
+                                            and t.data_ptr() % 4 == 0 for t in ts) or len(ts) > 8:
+            cc.content = None
+            return None
+        dev = ts[0].device
+        nbytes = [t.numel() * t.element_size() for t in ts]
+        if cc.content is None or cc.content.numel() != sum(nbytes) or cc.content.device != dev:
+            cc.content = torch.zeros(sum(nbytes), dtype=torch.uint8, device=dev)
+            cc.changed = torch.ones(1, dtype=torch.int32, device=dev)
+            force = True
+        ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        sizes = (ctypes.c_int * len(ts))(*nbytes)
+        with torch.cuda.device(dev):
+            rc = _lib.load().sgv3d_calib_changed(len(ts), ptrs, sizes, cc.content.data_ptr(), 1 if force else 0, cc.changed.data_ptr(),
+                                                 _lib.stream_handle(dev))
+        _lib.check(rc, "sgv3d_calib_changed")
+        return cc.changed
 
     def calibration(self, mats_dict, sweep_index=0):
         """(geom_xyz int32 [B, num_cams, D, fH, fW, 3], VoxelPlan) for the calibration in ``mats_dict``, through
@@ -435,13 +475,19 @@ class LSSFPN(HipModule):
         reuse = cc.geom is not None and tuple(cc.geom.shape) == shape and cc.geom.device == s2e.device
         if reuse:
             cc.order_after_build(s2e.device)       # the buffers are rewritten in place: after their last builder
+        # new tensor objects -- the reference harness creates the calibration tensors anew for every batch -- with, for a static
+        # camera, the numbers of the last frame: decided on the device (one small launch); the kernels below take the flag and
+        # return at once when nothing changed (geom, plan and gates are persistent buffers that then keep their contents)
+        run = self._calibration_changed(cc, srcs, force=not (reuse and cc._tag == tag and cc.plan is not None))
+        if not reuse:
+            run = None                             # (fresh buffers: nothing to keep)
         geom = self.get_geometry_voxel_index(
             mats_dict['sensor2ego_mats'][:, sweep_index, ...],
             mats_dict['sensor2virtual_mats'][:, sweep_index, ...],
             mats_dict['intrin_mats'][:, sweep_index, ...],
             mats_dict['ida_mats'][:, sweep_index, ...],
             mats_dict['reference_heights'][:, sweep_index, ...],
-            mats_dict.get('bda_mat', None), out=cc.geom if reuse else None)
+            mats_dict.get('bda_mat', None), out=cc.geom if reuse else None, run=run)
         flat = geom.view(B, -1, 3)
         if reuse and cc.plan is not None:
             cc.plan.rebuild(flat)
@@ -451,12 +497,15 @@ class LSSFPN(HipModule):
         if int(sweep_index) == 0 and CACHE_CAMERA_GATES:
             # the camera-aware SE gates use the key frame's calibration whatever the sweep (lss_fpn.py:208-240 index 0:1);
             # persistent buffers rewritten in place: a captured graph that reads them sees the refreshed values
-            fresh = self.height_net.camera_gates(mats_dict, s2e.device)
-            if cc.gates is not None and len(cc.gates) == len(fresh) and all(a.shape == b.shape and a.device == b.device
-                                                                              for a, b in zip(cc.gates, fresh)):
-                torch._foreach_copy_(cc.gates, fresh)
-            else:
-                cc.gates = fresh
+            n_rows = int(s2e.shape[0]) * int(s2e.shape[2])
+            keep = cc.gates is not None and all(g.shape[0] == n_rows and g.device == s2e.device for g in cc.gates)
+            if not keep:
+                cc.gates, cc.gate_tmp = None, {}           # (first calibration of this shape: new persistent vectors, made below)
+            if cc.gate_tmp is None:
+                cc.gate_tmp = {}
+            # every launch writes in place into the persistent vectors (a captured graph that reads them sees the refreshed
+            # values) and skips itself when the flag says the calibration is the last one's
+            cc.gates = self.height_net.camera_gates(mats_dict, s2e.device, out=cc.gates, tmp=cc.gate_tmp, run=run if keep else None)
         cc.remember(srcs, tag)
         cc.mark_built(s2e.device)
         cache.refreshes += 1

@@ -39,6 +39,8 @@ from .calibration import CalibrationCache, tensor_version
 # refuses to run under capture as SGV3DError); anything else is a bug and propagates
 from ._lib import SGV3DError  # noqa: E402
 CAPTURE_ERRORS = (RuntimeError, SGV3DError)
+# GraphedForward: the calibration refresh as a forked branch of the graph (under the image backbone) instead of in line
+FORK_REFRESH = os.environ.get("SGV3D_GRAPH_FORK_REFRESH", "0") == "1"
 
 
 class eager_forward:
@@ -106,10 +108,12 @@ class GraphedForward:
     exps/bevheight/dair-v2x/bev_height_lss_r50_864_1536_256x256.py:242-258 -- gets graph speed without knowing this class).
 
     What the graph holds, besides the forward itself:
-    * the **calibration refresh** (calib_prep + geometry kernel + the device-gated plan rebuild, ~25 mostly empty launches) as
-      a forked branch that runs UNDER the image backbone and is joined right in front of the lift-splat gather: the harness
-      hands fresh calibration tensors with every frame, and the refresh used to be 25 launches the GPU waited for before the
-      forward could start.  The plan is rebuilt only when the voxel indices really changed (decided on the device);
+    * the **calibration refresh** (the device-side "same numbers as last frame?" check, then calib_prep + geometry kernel + the
+      device-gated plan rebuild + the camera gates, all of which return at once for a static camera): the harness hands fresh
+      calibration tensors with every frame.  In line in front of the forward since round 6 (``SGV3D_GRAPH_FORK_REFRESH=1``: as a
+      forked branch under the image backbone, joined right in front of the lift-splat gather -- rounds 4-5; graphs with parallel
+      branches turned out to crash ROCm 7.2's hipGraphLaunch in long-lived processes).  The plan is rebuilt only when the voxel
+      indices really changed (decided on the device);
     * the **box decode** of the forward's own output (``BEVHeightHead.decode_device``: top-K, box assembly, circle NMS, task
       merge), right behind the head: ``BEVHeight.get_bboxes`` on the very maps this call returned finds them decoded and only
       reads the detection counts back.
@@ -130,8 +134,11 @@ class GraphedForward:
         self.cache = CalibrationCache()
         self.replays = 0
         self.decoded = None
-        side = torch.cuda.Stream(device=dev)
-        branch = torch.cuda.Stream(device=dev)
+        # (streams that are neither each other, nor the caller's, nor a branch stream of hip_ops.run_parallel: torch hands its 32
+        # pool streams out round-robin)
+        side = hip_ops.distinct_stream(dev)
+        branch = hip_ops.distinct_stream(dev, (side,))
+        self._streams = (side, branch)
         cur = torch.cuda.current_stream(dev)
         side.wait_stream(cur)
         own = model.backbone.calib_cache
@@ -152,8 +159,18 @@ class GraphedForward:
                 pool = torch.cuda.graph_pool_handle()
                 split = os.environ.get("SGV3D_GRAPH_SPLIT", "1") != "0"
 
-                def fork_refresh():                        # the refresh is recorded on its own branch ...
-                    branch.wait_stream(side)
+                def fork_refresh():
+                    if not FORK_REFRESH:
+                        # in line, in front of the forward.  With the device-side "same numbers as last frame?" check
+                        # (calibration.py, round 6) the refresh of a static camera is ~15 launches that return at once (~50 us),
+                        # and the graph stays a LINEAR chain: hipGraphLaunch of graphs with parallel branches crashed inside
+                        # hip::Graph::UpdateStreams (ROCm 7.2) after a few dozen such graphs had been created in one process --
+                        # order-dependent, seen in the GPU suite in round 6.
+                        self.cache.invalidate()
+                        for sweep in sweeps:
+                            model.backbone.calibration(self.in_mats, sweep)
+                        return
+                    branch.wait_stream(side)               # SGV3D_GRAPH_FORK_REFRESH=1: the refresh recorded on its own branch ...
                     with torch.cuda.stream(branch):
                         self.cache.invalidate()
                         for sweep in sweeps:
@@ -178,7 +195,8 @@ class GraphedForward:
                     if hip_ops._GRAPH_SPLIT_HOOK is not None:      # (a backbone without the cut point)
                         hip_ops._GRAPH_SPLIT_HOOK = None
                         fork_refresh()
-                    side.wait_stream(branch)               # (a join of its own if the forward never asked for the plan)
+                    if FORK_REFRESH:
+                        side.wait_stream(branch)           # (a join of its own if the forward never asked for the plan)
                     self.decoded = model.head.decode_device(self.outputs)
                 finally:
                     hip_ops._GRAPH_SPLIT_HOOK = None
@@ -188,6 +206,10 @@ class GraphedForward:
                 self.cache.entry(sweep).join_stream = None
             model.backbone.calib_cache = own
         cur.wait_stream(side)
+
+    def __del__(self):
+        for st in getattr(self, '_streams', ()):
+            hip_ops.release_stream(st)
 
     def __call__(self, model, imgs, mats):
         with torch.no_grad():
@@ -207,7 +229,9 @@ class FramePipeline:
         self.capture_error = None                  # the exception that made the pipeline fall back to eager launches
         self.device = imgs.device
         self.slots = max(1, int(slots))
-        self.streams = [torch.cuda.Stream(device=imgs.device) for _ in range(self.slots)]
+        self.streams = []
+        for _ in range(self.slots):                # pairwise distinct HIP streams (hip_ops.distinct_stream)
+            self.streams.append(hip_ops.distinct_stream(imgs.device, self.streams))
         self.in_imgs = [static_copy(imgs) for _ in range(self.slots)]
         self.in_mats = [{k: static_copy(v) for k, v in mats.items()} for _ in range(self.slots)]
         self.caches = [CalibrationCache() for _ in range(self.slots)]
@@ -251,6 +275,10 @@ class FramePipeline:
                     warnings.warn(f"FramePipeline: hipGraph capture failed ({type(e).__name__}: {e}); running eager launches on "
                                   f"the slot streams instead (pass strict=True to raise)", RuntimeWarning, stacklevel=2)
         self.use_graph = bool(self.graphs)
+
+    def __del__(self):
+        for st in getattr(self, 'streams', ()):
+            hip_ops.release_stream(st)
 
     class _Slot:
         def __init__(self, pipe, i):
@@ -298,14 +326,19 @@ class FramePipeline:
             if imgs.is_cuda:
                 imgs.record_stream(s)
             if not self._same_mats(i, mats):
-                for k, v in mats.items():
-                    self.in_mats[i][k].copy_(v, non_blocking=True)
+                keys = list(mats)
+                torch._foreach_copy_([self.in_mats[i][k] for k in keys], [mats[k] for k in keys], non_blocking=True)   # one launch
+                for v in mats.values():
                     if v.is_cuda:
                         v.record_stream(s)
                 self._last_mats[i] = {k: (v, tensor_version(v)) for k, v in mats.items()}
                 if self.graphs:
                     # the captured graph holds no geometry / plan kernels: bring the slot's plan buffer up to date
-                    # here (a no-op on the device when the new calibration yields the same voxel indices)
+                    # here (a no-op on the device when the new calibration yields the same voxel indices).
+                    # (Round 6 measured the alternatives: the refresh recorded into a second graph per slot, inline -- the same frame
+                    # rate as these eager launches; as a forked branch under the image backbone (the layout of GraphedForward) -- 10 %
+                    # SLOWER with three frames in flight, cached calibration included: the extra streams alone cost it, and more
+                    # hardware queues (GPU_MAX_HW_QUEUES 8 / 16) made it worse, 2 queues likewise.)
                     with self._slot(i):
                         self.model.backbone.calibration(self.in_mats[i], 0)
         return self.replay(i)
