@@ -3,6 +3,7 @@
 #   bash tools/profile_round.sh r01
 # Outputs land in gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/.
 set -u
+# (PARTS=a and PARTS=b on different boxes: profiles/<tag>_hbm_traffic.json is the two calls' sections put together by hand)
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 # raw rocprofv3 output (kernel traces, counter collections: > 64 MiB, more than gpurun copies back) stays on the box under /tmp;
