@@ -336,7 +336,7 @@ class FramePipeline:
                     # the captured graph holds no geometry / plan kernels: bring the slot's plan buffer up to date
                     # here (a no-op on the device when the new calibration yields the same voxel indices).
                     # (Round 6 measured the alternatives: the refresh recorded into a second graph per slot, inline -- the same frame
-                    # rate as these eager launches; as a forked branch under the image backbone (the layout of GraphedForward) -- 10 %
+                    # rate as these eager launches; as a forked branch under the image backbone (GraphedForward's layout of rounds 4-5) -- 10 %
                     # SLOWER with three frames in flight, cached calibration included: the extra streams alone cost it, and more
                     # hardware queues (GPU_MAX_HW_QUEUES 8 / 16) made it worse, 2 queues likewise.)
                     with self._slot(i):
